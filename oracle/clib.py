@@ -1,0 +1,128 @@
+"""ctypes binding of oracle/_build/liboracle.so (TEST INFRASTRUCTURE ONLY).
+
+The shared object is built by `make -C oracle` (also called from
+__graft_entry__.build()).  If it is missing it is built on first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, "csrc", f) for f in ("oracle.c", "gmg.c")]
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_set_threads.argtypes = [C.c_int]
+        _lib.orc_spmv.argtypes = [C.c_int64, _i64p, _i64p, _f64p, _f64p, _f64p]
+        _lib.orc_spmv32.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
+        sig = [C.c_int64, _i64p, _i64p, _f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+               C.c_double, C.c_int, C.c_int, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]
+        _lib.orc_cg.argtypes = sig
+        _lib.orc_cg.restype = C.c_int
+        _lib.orc_bcgs.argtypes = sig
+        _lib.orc_bcgs.restype = C.c_int
+        _lib.orc_spgemm_symbolic.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, _i64p, _i64p, _i64p]
+        _lib.orc_spgemm_symbolic.restype = C.c_int64
+        _lib.orc_spgemm_numeric.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, _f64p, _i64p, _i64p, _f64p, _i64p,
+                                            _i64p, _f64p]
+        _lib.orc_axpy_pattern_count.argtypes = [C.c_int64, _i64p, _i64p, _i64p, _i64p, _i64p]
+        _lib.orc_axpy_pattern_count.restype = C.c_int64
+        _lib.orc_axpy_pattern_fill.argtypes = [C.c_int64, C.c_double, _i64p, _i64p, _f64p, _i64p, _i64p, _f64p, _i64p,
+                                               _i64p, _f64p]
+    return _lib
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(int(n))
+
+
+def spmv(m, x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty(m.n_rows)
+    lib().orc_spmv(m.n_rows, m.rowptr, m.col, m.val, x, y)
+    return y
+
+
+def spmv32(n, rowptr32, col32, val, x, y) -> None:
+    lib().orc_spmv32(n, rowptr32, col32, val, x, y)
+
+
+def spgemm(a, b):
+    from .operators import CSR
+    L = lib()
+    crp = np.zeros(a.n_rows + 1, dtype=np.int64)
+    nnz = L.orc_spgemm_symbolic(a.n_rows, b.n_cols, a.rowptr, a.col, b.rowptr, b.col, crp)
+    ccol = np.zeros(max(nnz, 1), dtype=np.int64)
+    cval = np.zeros(max(nnz, 1))
+    L.orc_spgemm_numeric(a.n_rows, b.n_cols, a.rowptr, a.col, a.val, b.rowptr, b.col, b.val, crp, ccol, cval)
+    return CSR(a.n_rows, b.n_cols, crp, ccol[:nnz], cval[:nnz])
+
+
+def axpy_pattern(y, a: float, x):
+    from .operators import CSR
+    L = lib()
+    zrp = np.zeros(y.n_rows + 1, dtype=np.int64)
+    nnz = L.orc_axpy_pattern_count(y.n_rows, y.rowptr, y.col, x.rowptr, x.col, zrp)
+    zcol = np.zeros(max(nnz, 1), dtype=np.int64)
+    zval = np.zeros(max(nnz, 1))
+    L.orc_axpy_pattern_fill(y.n_rows, a, y.rowptr, y.col, y.val, x.rowptr, x.col, x.val, zrp, zcol, zval)
+    return CSR(y.n_rows, y.n_cols, zrp, zcol[:nnz], zval[:nnz])
+
+
+PC = {"none": 0, "jacobi": 1}
+NORM = {"preconditioned": 0, "unpreconditioned": 1}
+
+
+def _krylov(fn, m, b, x0=None, pc="none", nullspace=0, norm="preconditioned", rtol=1e-5, atol=1e-50, dtol=1e4,
+            maxit=10000):
+    n = m.n_rows
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    dinv = None
+    if pc == "jacobi":
+        dinv = np.ascontiguousarray(1.0 / m.diagonal())
+    hist = np.full(maxit + 2, np.nan)
+    its = C.c_int(0)
+    rn = C.c_double(0)
+    reason = fn(n, m.rowptr, m.col, m.val, dinv.ctypes.data if dinv is not None else None, PC[pc], int(nullspace),
+                NORM[norm], rtol, atol, dtol, int(maxit), int(x0 is not None), b, x, C.byref(its), C.byref(rn),
+                hist.ctypes.data)
+    return {"x": x, "iters": its.value, "rnorm": rn.value, "reason": int(reason),
+            "history": hist[: its.value + 1].copy()}
+
+
+def cg(m, b, **kw):
+    """KSPCG restatement -- see oracle/csrc/oracle.c:orc_cg."""
+    return _krylov(lib().orc_cg, m, b, **kw)
+
+
+def bcgs(m, b, **kw):
+    """KSPBCGS restatement -- see oracle/csrc/oracle.c:orc_bcgs."""
+    return _krylov(lib().orc_bcgs, m, b, **kw)

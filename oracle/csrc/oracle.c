@@ -1,0 +1,439 @@
+/*
+ * oracle.c -- CPU restatement (plain C) of the Krylov arithmetic on PetIBM's
+ * linear-solve path.  TEST INFRASTRUCTURE ONLY: built into
+ * oracle/_build/liboracle.so and used by tests/, __graft_entry__.smoke() and
+ * the cpu_baseline leg of bench.py as the checker / CPU baseline.  Nothing in
+ * the product (petibm_amd/) links or loads it.
+ *
+ * What it restates, and from where:
+ *   - The reference itself only configures a KSP and calls KSPSolve
+ *     (src/linsolver/linsolverksp.cpp:62-66,92) or AmgXSolver::solve
+ *     (src/linsolver/linsolveramgx.cpp:96).  The arithmetic lives in PETSc
+ *     3.16.x (pinned by CMakeLists.txt:78-84) and AmgX 2.2.0 via AmgXWrapper
+ *     1.6.1 (CMakeLists.txt:124-144) -- third-party, NOT vendored, absent
+ *     from this image.  Their published algorithms are restated here:
+ *       KSPCG   (PETSc src/ksp/ksp/impls/cg/cg.c, KSPSolve_CG): Hestenes-
+ *               Stiefel PCG; beta = z'r, dpi = p'w, a = beta/dpi, x += a p,
+ *               r -= a w, z = B r, b = beta/betaold, p = z + b p; default
+ *               norm type PRECONDITIONED (||z||_2); indefiniteness is flagged
+ *               on a SIGN CHANGE of dpi / beta, not on negativity, which is
+ *               why PetIBM's negative semi-definite DBNG works with CG.
+ *       KSPBCGS (PETSc src/ksp/ksp/impls/bcgs/bcgs.c, KSPSolve_BCGS):
+ *               right-hand-side-preconditioned BiCGStab in PETSc's form.
+ *       PCJACOBI: z = r / diag(A).
+ *       KSPConvergedDefault: converged when rnorm <= max(rtol*rnorm0, atol);
+ *               diverged when rnorm >= dtol*rnorm0 (dtol = 1e4).
+ *       MatNullSpace(constant): KSP_PCApply removes the mean from z
+ *               (KSP_RemoveNullSpace, petsc/private/kspimpl.h).
+ *       AmgX PCG / PBICGSTAB with convergence=ABSOLUTE|RELATIVE_INI, norm=L2:
+ *               the same recurrences monitored on the true-residual 2-norm.
+ *   - SpMV summation order is the one the HIP kernel reproduces exactly:
+ *       y_i = ((0 + a_i0*x_c0) + a_i1*x_c1) + ...   products rounded, then
+ *       added in CSR order, no FMA contraction (-ffp-contract=off).
+ *   - SpGEMM follows PETSc's SeqAIJ MatMatMultNumeric order (row of A in
+ *     column order, sparse accumulator), used for BN*G and D*BNG
+ *     (applications/navierstokes/navierstokes.cpp:349-356).
+ *
+ * Parity status: "parity unpinned" for solves -- the reference ships no test,
+ * golden vector or fixture for any LinSolver.  The recurrences
+ * are cross-checked against scipy in tests/test_oracle_krylov.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef int64_t i64;
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------ SpMV */
+/* y = A x ; canonical summation order (see header).  32-bit column/offset
+ * variant is what the cpu_baseline times (same bytes as the device CSR). */
+void orc_spmv(i64 n, const i64 *rowptr, const i64 *col, const double *val,
+              const double *x, double *y)
+{
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (i64 p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            double t = val[p] * x[col[p]];
+            s = s + t;
+        }
+        y[i] = s;
+    }
+}
+
+void orc_spmv32(i64 n, const int32_t *rowptr, const int32_t *col,
+                const double *val, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            double t = val[p] * x[col[p]];
+            s = s + t;
+        }
+        y[i] = s;
+    }
+}
+
+/* ------------------------------------------------------------- BLAS-1 */
+static double dot(i64 n, const double *a, const double *b)
+{
+    double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (i64 i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+static void axpy(i64 n, double a, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) y[i] = y[i] + a * x[i];
+}
+static void aypx(i64 n, double a, const double *x, double *y) /* y = x + a y */
+{
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) y[i] = x[i] + a * y[i];
+}
+static void copy(i64 n, const double *x, double *y) { memcpy(y, x, (size_t)n * sizeof(double)); }
+static void remove_mean(i64 n, double *z)
+{
+    double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (i64 i = 0; i < n; ++i) s += z[i];
+    s /= (double)n;
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) z[i] -= s;
+}
+
+/* --------------------------------------------------------------- config */
+enum { PC_NONE = 0, PC_JACOBI = 1 };
+enum { NORM_PRECONDITIONED = 0, NORM_UNPRECONDITIONED = 1 };
+/* reasons: PETSc numbering */
+enum {
+    CONVERGED_RTOL = 2,
+    CONVERGED_ATOL = 3,
+    CONVERGED_ITS_ZERO_BETA = 4, /* beta == 0: happy breakdown */
+    DIVERGED_ITS = -3,
+    DIVERGED_DTOL = -4,
+    DIVERGED_BREAKDOWN = -5,
+    DIVERGED_INDEFINITE_PC = -8,
+    DIVERGED_NANORINF = -9,
+    DIVERGED_INDEFINITE_MAT = -10
+};
+
+typedef struct {
+    i64 n;
+    const i64 *rowptr;
+    const i64 *col;
+    const double *val;
+    const double *dinv; /* 1/diag for Jacobi, NULL otherwise */
+    int pc;
+    int nullspace; /* 1: remove the mean after every PC apply (MatNullSpace const) */
+} sys_t;
+
+static void matmult(const sys_t *s, const double *x, double *y) { orc_spmv(s->n, s->rowptr, s->col, s->val, x, y); }
+
+static void pcapply(const sys_t *s, const double *r, double *z)
+{
+    i64 n = s->n;
+    if (s->pc == PC_JACOBI) {
+        const double *d = s->dinv;
+#pragma omp parallel for schedule(static)
+        for (i64 i = 0; i < n; ++i) z[i] = r[i] * d[i];
+    } else {
+        copy(n, r, z);
+    }
+    if (s->nullspace == 1) remove_mean(n, z);
+}
+
+static int converged_default(double rnorm, double ttol, double rnorm0, double atol, double dtol, int *reason)
+{
+    if (rnorm != rnorm) { *reason = DIVERGED_NANORINF; return 1; }
+    if (rnorm <= ttol) { *reason = (rnorm < atol) ? CONVERGED_ATOL : CONVERGED_RTOL; return 1; }
+    if (rnorm >= dtol * rnorm0) { *reason = DIVERGED_DTOL; return 1; }
+    return 0;
+}
+
+/*
+ * KSPSolve_CG restatement.  x is in/out; guess_nonzero=0 means x is zeroed
+ * first (KSP default, linsolverksp.cpp relies on it).  history[0..its] receives
+ * the monitored norm per iteration (history may be NULL).
+ * returns reason; *its_out = iteration count as KSPGetIterationNumber.
+ */
+int orc_cg(i64 n, const i64 *rowptr, const i64 *col, const double *val, const double *dinv, int pc,
+           int nullspace, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
+           const double *b, double *x, int *its_out, double *rnorm_out, double *history)
+{
+    sys_t S = {n, rowptr, col, val, dinv, pc, nullspace};
+    double *R = malloc((size_t)n * 8), *Z = malloc((size_t)n * 8), *P = malloc((size_t)n * 8),
+           *W = malloc((size_t)n * 8);
+    double beta = 0, betaold = 1, dpi = 0, dpiold = 0, dp = 0, a, bb, ttol, rnorm0;
+    int reason = 0, i = 0;
+
+    if (!guess_nonzero) {
+        memset(x, 0, (size_t)n * 8);
+        copy(n, b, R);
+    } else {
+        matmult(&S, x, R);
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) R[q] = b[q] - R[q];
+    }
+    if (normtype == NORM_PRECONDITIONED) {
+        pcapply(&S, R, Z);
+        dp = sqrt(dot(n, Z, Z));
+    } else {
+        dp = sqrt(dot(n, R, R));
+    }
+    rnorm0 = dp;
+    ttol = fmax(rtol * rnorm0, atol);
+    if (history) history[0] = dp;
+    *its_out = 0;
+    if (converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) goto done;
+    if (normtype != NORM_PRECONDITIONED) pcapply(&S, R, Z);
+    beta = dot(n, Z, R);
+
+    do {
+        *its_out = i + 1;
+        if (beta == 0.0) { reason = CONVERGED_ATOL; break; }
+        if (i > 0 && ((beta > 0) != (betaold > 0))) { reason = DIVERGED_INDEFINITE_PC; break; }
+        if (i == 0) {
+            copy(n, Z, P);
+        } else {
+            bb = beta / betaold;
+            aypx(n, bb, Z, P); /* p = z + b p */
+        }
+        dpiold = dpi;
+        matmult(&S, P, W);
+        dpi = dot(n, P, W);
+        betaold = beta;
+        if (dpi == 0.0 || (i > 0 && ((dpi > 0) != (dpiold > 0)))) { reason = DIVERGED_INDEFINITE_MAT; break; }
+        a = beta / dpi;
+        axpy(n, a, P, x);
+        axpy(n, -a, W, R);
+        if (normtype == NORM_PRECONDITIONED) {
+            pcapply(&S, R, Z);
+            dp = sqrt(dot(n, Z, Z));
+        } else {
+            dp = sqrt(dot(n, R, R));
+        }
+        if (history) history[i + 1] = dp;
+        if (converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) break;
+        if (normtype != NORM_PRECONDITIONED) pcapply(&S, R, Z);
+        beta = dot(n, Z, R);
+        i++;
+    } while (i < maxit);
+    if (!reason && i >= maxit) reason = DIVERGED_ITS;
+done:
+    *rnorm_out = dp;
+    free(R); free(Z); free(P); free(W);
+    return reason;
+}
+
+/*
+ * KSPSolve_BCGS restatement (PETSc's left-preconditioned BiCGStab; the
+ * recurrences run on the PRECONDITIONED residual r = B(b - A x)):
+ *   R = B(b - A x); RP = R; rho=alpha=omega=1; P = V = 0
+ *   loop: rho = <R,RP>; beta = (rho/rhoold)(alpha/omegaold);
+ *         P = R + beta (P - omegaold V);  V = B A P;  d1 = <V,RP>;
+ *         alpha = rho/d1;  S = R - alpha V;  T = B A S;
+ *         omega = <S,T>/<T,T>;  X += alpha P + omega S;  R = S - omega T;
+ *         dp = ||R||
+ * With normtype UNPRECONDITIONED (AmgX PBICGSTAB monitors the true residual)
+ * the same recurrences are run in right-preconditioned form: R is the true
+ * residual, V = A B P, T = A B S, X += alpha B P + omega B S.
+ */
+int orc_bcgs(i64 n, const i64 *rowptr, const i64 *col, const double *val, const double *dinv, int pc,
+             int nullspace, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
+             const double *b, double *x, int *its_out, double *rnorm_out, double *history)
+{
+    sys_t Sy = {n, rowptr, col, val, dinv, pc, nullspace};
+    size_t nb = (size_t)n * 8;
+    double *R = malloc(nb), *RP = malloc(nb), *V = calloc((size_t)n, 8), *T = malloc(nb), *S = malloc(nb),
+           *P = calloc((size_t)n, 8), *T2 = malloc(nb), *PH = malloc(nb), *SH = malloc(nb);
+    double rho, rhoold = 1, alpha = 1, omega = 1, omegaold = 1, beta, d1, d2, dp, ttol, rnorm0;
+    int reason = 0, i = 0;
+    int left = (normtype == NORM_PRECONDITIONED);
+
+    if (!guess_nonzero) {
+        memset(x, 0, nb);
+        copy(n, b, T2);
+    } else {
+        matmult(&Sy, x, T2);
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) T2[q] = b[q] - T2[q];
+    }
+    if (left) pcapply(&Sy, T2, R); else copy(n, T2, R);
+    dp = sqrt(dot(n, R, R));
+    rnorm0 = dp;
+    ttol = fmax(rtol * rnorm0, atol);
+    if (history) history[0] = dp;
+    *its_out = 0;
+    if (converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) goto done;
+    copy(n, R, RP);
+
+    do {
+        rho = dot(n, R, RP);
+        if (rho == 0.0) { reason = DIVERGED_BREAKDOWN; break; }
+        beta = (rho / rhoold) * (alpha / omegaold);
+        /* P = R + beta (P - omegaold V)  (VecAXPBYPCZ(P,1,-omegaold*beta,beta,R,V)) */
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) P[q] = R[q] - (omegaold * beta) * V[q] + beta * P[q];
+        if (left) { matmult(&Sy, P, T2); pcapply(&Sy, T2, V); }
+        else { pcapply(&Sy, P, PH); matmult(&Sy, PH, V); }
+        d1 = dot(n, V, RP);
+        if (d1 == 0.0) { reason = DIVERGED_BREAKDOWN; break; }
+        alpha = rho / d1;
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) S[q] = R[q] - alpha * V[q];
+        if (left) { matmult(&Sy, S, T2); pcapply(&Sy, T2, T); }
+        else { pcapply(&Sy, S, SH); matmult(&Sy, SH, T); }
+        d1 = dot(n, S, T);
+        d2 = dot(n, T, T);
+        if (d2 == 0.0) {
+            /* t = 0: s is the (preconditioned) residual; PETSc accepts x += alpha p */
+            double ss = dot(n, S, S);
+            if (ss != 0.0) { reason = DIVERGED_BREAKDOWN; break; }
+            axpy(n, alpha, left ? P : PH, x);
+            *its_out = i + 1;
+            dp = 0.0;
+            if (history) history[i + 1] = dp;
+            reason = CONVERGED_ATOL;
+            break;
+        }
+        omega = d1 / d2;
+        if (left) {
+#pragma omp parallel for schedule(static)
+            for (i64 q = 0; q < n; ++q) x[q] = x[q] + alpha * P[q] + omega * S[q];
+        } else {
+#pragma omp parallel for schedule(static)
+            for (i64 q = 0; q < n; ++q) x[q] = x[q] + alpha * PH[q] + omega * SH[q];
+        }
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) R[q] = S[q] - omega * T[q];
+        dp = sqrt(dot(n, R, R));
+        rhoold = rho;
+        omegaold = omega;
+        *its_out = i + 1;
+        if (history) history[i + 1] = dp;
+        if (converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) break;
+        if (rho == 0.0) { reason = DIVERGED_BREAKDOWN; break; }
+        i++;
+    } while (i < maxit);
+    if (!reason && i >= maxit) reason = DIVERGED_ITS;
+done:
+    *rnorm_out = dp;
+    free(R); free(RP); free(V); free(T); free(S); free(P); free(T2); free(PH); free(SH);
+    return reason;
+}
+
+/* ---------------------------------------------------------------- SpGEMM */
+/* symbolic: returns nnz of C = A*B and fills crowptr (size a_rows+1). */
+i64 orc_spgemm_symbolic(i64 a_rows, i64 b_cols, const i64 *arp, const i64 *acol, const i64 *brp, const i64 *bcol,
+                        i64 *crp)
+{
+    i64 *mark = malloc((size_t)b_cols * sizeof(i64));
+    for (i64 j = 0; j < b_cols; ++j) mark[j] = -1;
+    crp[0] = 0;
+    for (i64 i = 0; i < a_rows; ++i) {
+        i64 cnt = 0;
+        for (i64 p = arp[i]; p < arp[i + 1]; ++p) {
+            i64 k = acol[p];
+            for (i64 q = brp[k]; q < brp[k + 1]; ++q) {
+                i64 j = bcol[q];
+                if (mark[j] != i) { mark[j] = i; cnt++; }
+            }
+        }
+        crp[i + 1] = crp[i] + cnt;
+    }
+    free(mark);
+    return crp[a_rows];
+}
+
+static int cmp_i64(const void *a, const void *b)
+{
+    i64 x = *(const i64 *)a, y = *(const i64 *)b;
+    return (x > y) - (x < y);
+}
+
+void orc_spgemm_numeric(i64 a_rows, i64 b_cols, const i64 *arp, const i64 *acol, const double *aval, const i64 *brp,
+                        const i64 *bcol, const double *bval, const i64 *crp, i64 *ccol, double *cval)
+{
+    i64 *mark = malloc((size_t)b_cols * sizeof(i64));
+    double *acc = calloc((size_t)b_cols, sizeof(double));
+    for (i64 j = 0; j < b_cols; ++j) mark[j] = -1;
+    for (i64 i = 0; i < a_rows; ++i) {
+        i64 base = crp[i], cnt = 0;
+        for (i64 p = arp[i]; p < arp[i + 1]; ++p) {
+            i64 k = acol[p];
+            double av = aval[p];
+            for (i64 q = brp[k]; q < brp[k + 1]; ++q) {
+                i64 j = bcol[q];
+                double t = av * bval[q];
+                if (mark[j] != i) {
+                    mark[j] = i;
+                    ccol[base + cnt++] = j;
+                    acc[j] = t;
+                } else {
+                    acc[j] = acc[j] + t;
+                }
+            }
+        }
+        qsort(ccol + base, (size_t)cnt, sizeof(i64), cmp_i64);
+        for (i64 c = 0; c < cnt; ++c) cval[base + c] = acc[ccol[base + c]];
+    }
+    free(mark);
+    free(acc);
+}
+
+/* Y = Y + a*X with the union pattern (MatAXPY DIFFERENT_NONZERO_PATTERN);
+ * two-pass: count then fill; both inputs have sorted columns. */
+i64 orc_axpy_pattern_count(i64 n, const i64 *yrp, const i64 *ycol, const i64 *xrp, const i64 *xcol, i64 *zrp)
+{
+    zrp[0] = 0;
+    for (i64 i = 0; i < n; ++i) {
+        i64 p = yrp[i], q = xrp[i], c = 0;
+        while (p < yrp[i + 1] || q < xrp[i + 1]) {
+            if (q >= xrp[i + 1] || (p < yrp[i + 1] && ycol[p] < xcol[q])) p++;
+            else if (p >= yrp[i + 1] || xcol[q] < ycol[p]) q++;
+            else { p++; q++; }
+            c++;
+        }
+        zrp[i + 1] = zrp[i] + c;
+    }
+    return zrp[n];
+}
+
+void orc_axpy_pattern_fill(i64 n, double a, const i64 *yrp, const i64 *ycol, const double *yval, const i64 *xrp,
+                           const i64 *xcol, const double *xval, const i64 *zrp, i64 *zcol, double *zval)
+{
+    for (i64 i = 0; i < n; ++i) {
+        i64 p = yrp[i], q = xrp[i], o = zrp[i];
+        while (p < yrp[i + 1] || q < xrp[i + 1]) {
+            if (q >= xrp[i + 1] || (p < yrp[i + 1] && ycol[p] < xcol[q])) { zcol[o] = ycol[p]; zval[o] = yval[p]; p++; }
+            else if (p >= yrp[i + 1] || xcol[q] < ycol[p]) { zcol[o] = xcol[q]; zval[o] = a * xval[q]; q++; }
+            else { zcol[o] = ycol[p]; zval[o] = yval[p] + a * xval[q]; p++; q++; }
+            o++;
+        }
+    }
+}
