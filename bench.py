@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- Poisson DOF/s + CG iterations/s on the 512^3 lid-driven-cavity
+pressure system (BASELINE.json metric), one rank per GPU.
+
+A "step" is one `pSolver->solve(dP, rhs2)` (applications/navierstokes/
+navierstokes.cpp:566-580) on the 512^3 DBNG operator to a relative residual of
+1e-10 (north-star tolerance), zero initial guess, inputs already resident in
+HBM.  N > 1: the same 512^3 problem split into DMDA-style z-slabs (strong
+scaling), RCCL halo planes + scalar all-reduce.
+
+    python bench.py --gpus N --steps K --warmup W
+
+prints ONE JSON line on rank 0 (contract in the task statement) with the extra
+objects `roofline` (CSR SpMV, algorithmic bytes / HIP-event launch duration)
+and `cpu_baseline` (the oracle = CPU restatement of the reference path, timed
+on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def solver_config(pc: str, tol: float, max_iters: int) -> str:
+    prec = {"gmg": "AMG", "jacobi": "BLOCK_JACOBI", "none": "NOSOLVER"}[pc]
+    return (f"config_version=2\nsolver(solv)=PCG\nsolv:max_iters={max_iters}\nsolv:monitor_residual=1\n"
+            f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
+            f"solv:preconditioner(prec)={prec}\nprec:relaxation_factor=1.0\n"
+            "prec:cycle=V\nprec:presweeps=1\nprec:postsweeps=1\nprec:smoother(smooth)=BLOCK_JACOBI\n"
+            "smooth:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n")
+
+
+def slab(nplanes: int, nranks: int, rank: int):
+    b = 0
+    for r in range(rank):
+        b += nplanes // nranks + (1 if (nplanes % nranks) > r else 0)
+    return b, b + nplanes // nranks + (1 if (nplanes % nranks) > rank else 0)
+
+
+def manufactured_solution(n: int, k0: int, k1: int) -> np.ndarray:
+    """x* = cos(pi x) cos(pi y) cos(pi z) at pressure-cell centres of the unit
+    cube; zero mean by symmetry; slab [k0, k1)."""
+    h = 1.0 / n
+    c = np.cos(np.pi * (np.arange(n) + 0.5) * h)
+    cz = c[k0:k1]
+    return (cz[:, None, None] * c[None, :, None] * c[None, None, :]).reshape(-1)
+
+
+def cpu_baseline(pc: str, tol: float, budget_s: float = 20.0):
+    """The oracle (CPU restatement of the KSP path, all host cores) on a bounded
+    sample: the same solver on a smaller cavity, sized for ~10-30 s."""
+    from oracle import clib, mesh as omesh, operators as oops
+    cores = clib.num_threads()
+    n = 96
+    m = omesh.create_mesh(omesh.uniform_config((n, n, n)))
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, 5e-4, 0.5e-3)
+    xs = manufactured_solution(n, 0, n)
+    b = clib.spmv(A, xs)
+    t0 = time.perf_counter()
+    r = clib.cg(A, b, pc="jacobi" if pc != "none" else "none", nullspace=1, norm="unpreconditioned", rtol=tol,
+                atol=0.0, dtol=1e300, maxit=100000)
+    t = time.perf_counter() - t0
+    return {"value": m.pN / t, "unit": "DOF/s", "cores": cores, "kind": "port",
+            "sample": f"Jacobi-PCG (KSPCG recurrences, oracle/csrc/oracle.c) on a {n}^3 cavity Poisson system, "
+                      f"rtol {tol:g}: {r['iters']} iterations in {t:.2f} s = {r['iters'] / t:.1f} it/s",
+            "iters": r["iters"], "seconds": t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=512, help="cells per direction (BASELINE: 512)")
+    ap.add_argument("--pc", default="jacobi", choices=["gmg", "jacobi", "none"])
+    ap.add_argument("--tol", type=float, default=1e-10)
+    ap.add_argument("--max-iters", type=int, default=20000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    uid = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    if world > 1:
+        import ctypes
+        buf = ctypes.create_string_buffer(capi.UID_BYTES)
+        if rank == 0:
+            capi.check(capi.load().pib_comm_unique_id(buf))
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
+        dist.broadcast(t, src=0)
+        uid = bytes(t.cpu().numpy().tobytes())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = args.n
+    dt = 5e-4 if n == 512 else 1e-3  # cfg3 (512^3) dt=5e-4, cfg2 (256^3) dt=1e-3
+    s = LinSolverHIP("poisson", config_text=solver_config(args.pc, args.tol, args.max_iters), rank=rank,
+                     nranks=world, uid=uid, device=local)
+    w = np.full(n, 1.0 / n)
+    t_setup = time.perf_counter()
+    s.assemblePoisson((n, n, n), [w, w, w], dt, capi.NULLSPACE_CONSTANT)
+    s.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    k0, k1 = slab(n, world, rank)
+    xs = manufactured_solution(n, k0, k1)
+    xs_d, b_d, x_d = s.deviceVec(), s.deviceVec(), s.deviceVec()
+    xs_d.upload(xs)
+    s.matMult(xs_d, b_d)  # b = DBNG x*  (compatible with the constant null space)
+    del xs
+
+    pN = n ** 3
+    for _ in range(args.warmup):
+        s.solve(x_d, b_d)
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        s.solve(x_d, b_d)
+        iters += s.getIters()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # residual contract, recomputed on the device with the CSR operator
+    r_d = s.deviceVec()
+    s.matMult(x_d, r_d)
+    bl = b_d.download()
+    rl = bl - r_d.download()
+    num = torch.tensor([float(rl @ rl), float(bl @ bl)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(num)
+    true_rel = float(torch.sqrt(num[0] / num[1]).item())
+
+    # roofline of the dominant kernel: CSR SpMV, HIP events on the solver's stream
+    ms_spmv = s.timeKernel(0, args.kernel_reps)
+    nnz_l, n_l = s.nnz, s.n_local
+    alg_bytes = 12.0 * nnz_l + 4.0 * (n_l + 1) + 16.0 * n_l  # SURVEY.md 8d B_spmv_csr
+    achieved = alg_bytes / (ms_spmv * 1e-3) / 1e9
+    counters = s.counters()
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Poisson DOF/s (one pressure solve to rel. residual 1e-10), 512^3 cavity",
+            "value": pN * args.steps / elapsed, "unit": "DOF/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n}^3 lid-driven cavity pressure Poisson (DBNG, 7-point, fp64 CSR int32), "
+                                   f"PCG+{args.pc}, zero guess, rtol {args.tol:g}, manufactured cosine RHS",
+                       "grid": [n, n, n], "dt": dt, "parallelism": f"zslab{world}", "pc": args.pc},
+            "cg_iters_per_s": iters / elapsed, "iters_per_solve": iters / args.steps,
+            "true_rel_residual": true_rel, "setup_s": t_setup,
+            "spmv_gdof_per_s": n_l / (ms_spmv * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<int32> (fp64 CSR SpMV, local slab)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes},
+            "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "host_polls": int(counters[4])},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.pc, args.tol)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    s.destroy()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/*
+ * petibm_amd.h -- C ABI of the MI355X-native linear-solve backend for PetIBM.
+ *
+ * This is the drop-in boundary: a PETSc-free, torch-free
+ * shared library (libpetibm_amd.so, hand-written HIP for gfx950 + RCCL) whose
+ * entry points are exactly what PetIBM's linear-solver plugin would bind.
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the PetIBM source tree).
+ *
+ * Conventions mirrored from the reference:
+ *   - every function returns an int error code, 0 = success, propagated by the
+ *     caller with CHKERRQ (all reference methods return PetscErrorCode);
+ *     the non-zero values are PETSc's own PETSC_ERR_* integers so a PETSc
+ *     caller can hand them straight to CHKERRQ;
+ *   - non-convergence of a "CPU"/KSP-flavoured solver is an ERROR
+ *     (PETSC_ERR_CONV_FAILED, src/linsolver/linsolverksp.cpp:96-104); an
+ *     AmgX-flavoured solver does not check (src/linsolver/linsolveramgx.cpp:90-99);
+ *     both are selectable with the config key `error_if_not_converged`;
+ *   - the caller owns matrices and vectors; the solver copies the matrix at
+ *     set time and may be given a new one any number of times
+ *     (applications/rigidkinematics/rigidkinematics.cpp:135);
+ *   - all calls are collective over the ranks given at pib_create, one rank
+ *     per GPU (the reference is collective over PETSC_COMM_WORLD,
+ *     src/linsolver/linsolverksp.cpp:62, src/linsolver/linsolveramgx.cpp:69);
+ *   - single-threaded per rank.
+ */
+#ifndef PETIBM_AMD_H
+#define PETIBM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: the PETSc integers the reference's CHKERRQ propagates ---- */
+#define PIB_SUCCESS 0
+#define PIB_ERR_MEM 55             /* PETSC_ERR_MEM */
+#define PIB_ERR_SUP 56             /* PETSC_ERR_SUP: createbn.cpp:27 uses 56 for order < 1 */
+#define PIB_ERR_ORDER 58           /* PETSC_ERR_ORDER: solve before setMatrix */
+#define PIB_ERR_ARG_SIZ 60         /* PETSC_ERR_ARG_SIZ */
+#define PIB_ERR_ARG_WRONG 62       /* PETSC_ERR_ARG_WRONG: src/linsolver/linsolver.cpp:85-88 */
+#define PIB_ERR_ARG_OUTOFRANGE 63  /* PETSC_ERR_ARG_OUTOFRANGE */
+#define PIB_ERR_FILE_OPEN 65       /* PETSC_ERR_FILE_OPEN */
+#define PIB_ERR_LIB 76             /* PETSC_ERR_LIB: a HIP / RCCL call failed */
+#define PIB_ERR_CONV_FAILED 82     /* PETSC_ERR_CONV_FAILED: linsolverksp.cpp:100 */
+#define PIB_ERR_ARG_NULL 85        /* PETSC_ERR_ARG_NULL */
+
+/* ---- convergence reasons (PETSc KSPConvergedReason numbering) ---- */
+#define PIB_CONVERGED_RTOL 2
+#define PIB_CONVERGED_ATOL 3
+#define PIB_CONVERGED_ITS 4
+#define PIB_DIVERGED_ITS (-3)
+#define PIB_DIVERGED_DTOL (-4)
+#define PIB_DIVERGED_BREAKDOWN (-5)
+#define PIB_DIVERGED_INDEFINITE_PC (-8)
+#define PIB_DIVERGED_NANORINF (-9)
+#define PIB_DIVERGED_INDEFINITE_MAT (-10)
+
+/* ---- null-space convention of the Poisson system
+ *      (applications/navierstokes/navierstokes.cpp:395-429) ---- */
+#define PIB_NULLSPACE_NONE 0
+#define PIB_NULLSPACE_CONSTANT 1 /* "PETSc KSP": MatSetNullSpace(constant) (:404-412) */
+#define PIB_NULLSPACE_PINNED 2   /* "NVIDIA AmgX": MatZeroRowsColumns(row 0, diag 1) (:414-420) */
+
+typedef struct pib_solver pib_solver;
+
+/* Message of the last error raised on this thread (never NULL). */
+const char *pib_last_error(void);
+
+/* Library version (major*10000 + minor*100 + patch). */
+int pib_version(void);
+
+/* ---- multi-GPU bootstrap ------------------------------------------------
+ * One rank per GPU.  Rank 0 calls pib_comm_unique_id(), the host program
+ * broadcasts the 128 bytes (MPI_Bcast in PetIBM, torch.distributed in
+ * bench.py) and every rank passes them to pib_create.  Replaces the
+ * communicator argument of AmgXSolver::initialize(PETSC_COMM_WORLD, ...)
+ * (src/linsolver/linsolveramgx.cpp:69). */
+#define PIB_UID_BYTES 128
+int pib_comm_unique_id(void *uid_out /* PIB_UID_BYTES */);
+
+/* ---- life cycle ---------------------------------------------------------
+ * pib_create replaces LinSolverAmgX::LinSolverAmgX + init
+ * (src/linsolver/linsolveramgx.cpp:20-75; AmgXSolver::initialize(comm,"dDDI",cfg))
+ * and LinSolverKSP::init (src/linsolver/linsolverksp.cpp:48-69).
+ *   name      solver name ("velocity", "poisson", "forces"): also the option
+ *             prefix `-<name>_` of a PETSc-style options file
+ *   cfg_path  solver configuration file, or NULL / "None" for defaults.  Two
+ *             syntaxes are auto-detected: the AmgX key=value subset used by
+ *             every reference example (the *.info files under examples/<case>_GPU/config) and
+ *             the PETSc options subset (the <name>_solver.info files under examples/<case>/config)
+ *   device    HIP device ordinal (-1: rank % device count)
+ */
+int pib_create(pib_solver **s, const char *name, const char *cfg_path, int rank, int nranks,
+               const void *uid_or_null, int device);
+/* Same, configuration given as text (tests; no temp files). */
+int pib_create_from_string(pib_solver **s, const char *name, const char *cfg_text, int rank, int nranks,
+                           const void *uid_or_null, int device);
+/* LinSolverBase::destroy / AmgXSolver::finalize (linsolveramgx.cpp:37,47). */
+int pib_destroy(pib_solver *s);
+
+/* LinSolverBase::getType (include/petibm/linsolver.h:97): "NVIDIA AmgX" for a
+ * solver created from an AmgX-style config or `type: GPU`, "PETSc KSP" for a
+ * PETSc-options config -- unchanged applications select the null-space
+ * convention from this string (navierstokes.cpp:402-426). */
+int pib_get_type(pib_solver *s, char *buf, int buflen);
+
+/* ---- setMatrix ------------------------------------------------------------
+ * LinSolverBase::setMatrix(const Mat&) / AmgXSolver::setA(A)
+ * (src/linsolver/linsolveramgx.cpp:84, src/linsolver/linsolverksp.cpp:78-79).
+ * Local rows [row0, row0+n_local) of an assembled AIJ matrix, GLOBAL column
+ * indices, host pointers (what MatMPIAIJGetLocalMat/MatGetRowIJ give).
+ * The matrix is copied to HBM; the arrays may be freed on return. */
+int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_global, const int64_t *rowptr,
+                const int64_t *col_global, const double *val);
+/* PetscInt is 32-bit by default (AmgX mode dDDI): same with int32 indices. */
+int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t n_global, const int32_t *rowptr,
+                    const int32_t *col_global, const double *val);
+
+/* Optional structure hint that enables the matrix-free stencil twin and the
+ * geometric-multigrid preconditioner: the matrix set by pib_set_csr is the
+ * (5/7-point) operator
+ *     (A x)_ijk = sum_d  cx_d[s] * w_d(perp) * (x_{s+1} - x_s) - (same at s-1)
+ * of a tensor-product grid in natural ordering i + nx*(j + ny*k), i.e. the
+ * DBNG of applications/navierstokes/navierstokes.cpp:349-356 for BN order 1:
+ *   n[d]   global cell counts (n[2] = 1 in 2D)
+ *   w[d]   cell widths dL[3][d][0..n[d])             (createdivergence.cpp:140-151)
+ *   g[d]   dt / dL[d][d][s], s in [0, n[d]-1)          (creategradient.cpp:70-86, createbn.cpp:49)
+ * The hint is verified against the CSR on the device; a mismatch is an error. */
+int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
+                      const double *wz, const double *gx, const double *gy, const double *gz, int nullspace);
+
+/* Assemble the Poisson operator DBNG = D * (dt*I) * G directly in HBM from the
+ * mesh widths (the product of createDivergence(normalize=FALSE),
+ * createBnHead(N=1) and createGradient(normalize=FALSE) --
+ * navierstokes.cpp:326-356 -- evaluated in the same floating-point order),
+ * for this rank's z-slab [k0,k1) (y-slab in 2D), set it as the solver's matrix
+ * and register the grid hint.  pinned != 0 applies MatZeroRowsColumns(row 0,
+ * diag = 1) (navierstokes.cpp:414-420).  w[d] has n[d] entries, dt scalar. */
+int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
+                         const double *wz, double dt, int nullspace);
+
+/* ---- solve ------------------------------------------------------------------
+ * LinSolverBase::solve(Vec &x, Vec &b) / AmgXSolver::solve(x, b)
+ * (src/linsolver/linsolveramgx.cpp:96, src/linsolver/linsolverksp.cpp:92).
+ * x, b: this rank's n_local entries; each pointer may be host or device
+ * memory (detected).  b is read-only.  x is in/out: an AmgX-flavoured solver
+ * uses it as the initial guess, a KSP-flavoured one zeroes it first unless
+ * `ksp_initial_guess_nonzero` is set.
+ * Returns PIB_ERR_CONV_FAILED when error_if_not_converged is on and the
+ * iteration diverged or hit max_iters. */
+int pib_solve(pib_solver *s, double *x_inout, const double *b);
+
+/* LinSolverBase::getIters (linsolveramgx.cpp:108, linsolverksp.cpp:116). */
+int pib_get_iters(pib_solver *s, int *iters);
+/* LinSolverBase::getResidual: final residual norm of the last solve
+ * (linsolveramgx.cpp:120-123 -> AmgXSolver::getResidual(iters, res);
+ *  linsolverksp.cpp:128 -> KSPGetResidualNorm). */
+int pib_get_residual(pib_solver *s, double *res);
+/* AmgXSolver::getResidual(iter, res): entry `iter` of the stored history. */
+int pib_get_residual_at(pib_solver *s, int iter, double *res);
+/* KSPGetConvergedReason (linsolverksp.cpp:94). */
+int pib_get_reason(pib_solver *s, int *reason);
+
+/* ---- MatMult on the solver's matrix (K1; also what the applications call in
+ * RHS assembly, navierstokes.cpp:442,490,549,592).  host or device pointers. */
+int pib_mat_mult(pib_solver *s, const double *x, double *y);
+
+/* ---- device-side helpers for callers that keep vectors in HBM (bench.py) ---- */
+int pib_device_alloc(pib_solver *s, int64_t nbytes, void **ptr);
+int pib_device_free(pib_solver *s, void *ptr);
+int pib_memcpy_h2d(pib_solver *s, void *dst, const void *src, int64_t nbytes);
+int pib_memcpy_d2h(pib_solver *s, void *dst, const void *src, int64_t nbytes);
+int pib_synchronize(pib_solver *s);
+/* Download the solver's local CSR (tests: device assembly vs oracle).
+ * Pass NULL arrays to query sizes only. */
+int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, int64_t *col_global, double *val);
+
+/* ---- instrumentation (bench.py roofline leg) --------------------------------
+ * Time `reps` launches of kernel `which` on the solver's stream with HIP events
+ * (events recorded on that stream); *ms_avg = average launch duration.
+ * which: 0 = CSR SpMV (K1), 1 = fused CG vector update, 2 = dot,
+ *        3 = matrix-free stencil apply (K2), 4 = GMG V-cycle. */
+int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_avg);
+/* Counters of the last solve: [0]=spmv launches, [1]=pc applies, [2]=reductions,
+ * [3]=halo exchanges, [4]=host syncs. */
+int pib_get_counters(pib_solver *s, int64_t counters[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PETIBM_AMD_H */

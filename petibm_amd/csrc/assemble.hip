@@ -1,0 +1,251 @@
+// assemble.hip -- matrix ingestion and on-device operator assembly.
+//
+//  * upload_csr: LinSolverBase::setMatrix / AmgXSolver::setA
+//    (src/linsolver/linsolveramgx.cpp:84): local rows, global columns ->
+//    HBM-resident CSR with int32 ghost-shifted local columns.
+//  * assemble_poisson: DBNG = D * (dt I) * G built directly in HBM from the
+//    1-D mesh width arrays, reproducing -- in the same floating-point order --
+//    what createDivergence(normalize=FALSE) (src/operators/createdivergence.cpp:
+//    135-223), createBnHead(N=1) (src/operators/createbn.cpp:49,53),
+//    createGradient(normalize=FALSE) (src/operators/creategradient.cpp:64-128)
+//    and the two MatMatMult calls of applications/navierstokes/navierstokes.cpp:
+//    349-356 produce, so that the 512^3 operator (9.4e8 non-zeros, 11.8 GB)
+//    never crosses PCIe.  Row offsets come from a closed-form prefix count, so
+//    assembly is a single streaming kernel (no scan).
+#include <algorithm>
+#include <limits>
+
+#include "pib_internal.hpp"
+
+namespace pib {
+
+void DeviceCsr::release()
+{
+    if (rowptr) (void)hipFree(rowptr);
+    if (col) (void)hipFree(col);
+    if (val) (void)hipFree(val);
+    if (dinv) (void)hipFree(dinv);
+    rowptr = nullptr;
+    col = nullptr;
+    val = nullptr;
+    dinv = nullptr;
+    n = nnz = 0;
+}
+
+// DMDA default ownership along one axis (cartesianmesh.cpp:492-538 via
+// DMDACreate3d with l* = nullptr): rank r of P owns N/P + ((N % P) > r) planes.
+void slab_range(int64_t nplanes, int nranks, int rank, int64_t *b, int64_t *e)
+{
+    int64_t beg = 0;
+    for (int r = 0; r < rank; ++r) beg += nplanes / nranks + ((nplanes % nranks) > r ? 1 : 0);
+    *b = beg;
+    *e = beg + nplanes / nranks + ((nplanes % nranks) > rank ? 1 : 0);
+}
+
+int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rowptr,
+               const int64_t *col, const int32_t *rowptr32, const int32_t *col32, const double *val)
+{
+    if (n_local < 0 || row0 < 0 || n_global < n_local) return fail(PIB_ERR_ARG_OUTOFRANGE, "set_csr: bad sizes");
+    if ((rowptr == nullptr && rowptr32 == nullptr) || (col == nullptr && col32 == nullptr && n_local > 0) ||
+        (val == nullptr && n_local > 0))
+        return fail(PIB_ERR_ARG_NULL, "set_csr: null array");
+    auto RP = [&](int64_t i) -> int64_t { return rowptr ? rowptr[i] : (int64_t)rowptr32[i]; };
+    auto CL = [&](int64_t p) -> int64_t { return col ? col[p] : (int64_t)col32[p]; };
+    const int64_t base = RP(0);
+    const int64_t nnz = RP(n_local) - base;
+    if (nnz < 0) return fail(PIB_ERR_ARG_OUTOFRANGE, "set_csr: negative nnz");
+    int64_t cmin = std::numeric_limits<int64_t>::max(), cmax = -1;
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t c = CL(base + p);
+        if (c < 0 || c >= n_global) return fail(PIB_ERR_ARG_OUTOFRANGE, "set_csr: column %lld out of range", (long long)c);
+        cmin = std::min(cmin, c);
+        cmax = std::max(cmax, c);
+    }
+    DeviceCsr &A = s->A;
+    A.release();
+    A.n = n_local;
+    A.nnz = nnz;
+    A.row0 = row0;
+    A.n_global = n_global;
+    A.ghost_lo = (nnz > 0 && cmin < row0) ? row0 - cmin : 0;
+    A.ghost_hi = (nnz > 0 && cmax > row0 + n_local - 1) ? cmax - (row0 + n_local - 1) : 0;
+    if (A.ghost_lo + A.n + A.ghost_hi >= (int64_t)std::numeric_limits<int32_t>::max())
+        return fail(PIB_ERR_SUP, "set_csr: local column range does not fit 32-bit indices");
+    A.rp64 = nnz >= (int64_t)std::numeric_limits<int32_t>::max();
+    const int64_t shift = row0 - A.ghost_lo;
+    std::vector<int32_t> c32((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t p = 0; p < nnz; ++p) c32[(size_t)p] = (int32_t)(CL(base + p) - shift);
+    PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+    PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
+    PIB_HIP(hipMemcpy(A.col, c32.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    PIB_HIP(hipMemcpy(A.val, val + base, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    if (A.rp64) {
+        std::vector<int64_t> rp((size_t)n_local + 1);
+        for (int64_t i = 0; i <= n_local; ++i) rp[(size_t)i] = RP(i) - base;
+        PIB_HIP(hipMalloc(&A.rowptr, sizeof(int64_t) * ((size_t)n_local + 1)));
+        PIB_HIP(hipMemcpy(A.rowptr, rp.data(), sizeof(int64_t) * ((size_t)n_local + 1), hipMemcpyHostToDevice));
+    } else {
+        std::vector<int32_t> rp((size_t)n_local + 1);
+        for (int64_t i = 0; i <= n_local; ++i) rp[(size_t)i] = (int32_t)(RP(i) - base);
+        PIB_HIP(hipMalloc(&A.rowptr, sizeof(int32_t) * ((size_t)n_local + 1)));
+        PIB_HIP(hipMemcpy(A.rowptr, rp.data(), sizeof(int32_t) * ((size_t)n_local + 1), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------
+// closed-form number of non-zeros in rows [0, g) of the natural-order
+// (2*dim+1)-point operator with no-neighbour walls.
+__host__ __device__ inline int64_t nnz_before(int64_t g, int dim, int64_t nx, int64_t ny, int64_t nz)
+{
+    const int64_t pl = nx * ny;
+    int64_t c = g;                               // diagonals
+    c += g - (g + nx - 1) / nx;                  // has i-1  (cells with i == 0: ceil(g/nx))
+    c += g - g / nx;                             // has i+1  (cells with i == nx-1: floor(g/nx))
+    const int64_t kq = g / pl, rem = g % pl;
+    c += g - (kq * nx + (rem < nx ? rem : nx));  // has j-1
+    const int64_t top = rem - (ny - 1) * nx;
+    c += g - (kq * nx + (top > 0 ? top : 0));    // has j+1
+    if (dim == 3) {
+        c += g - (g < pl ? g : pl);              // has k-1
+        const int64_t last = g - (nz - 1) * pl;
+        c += g - (last > 0 ? last : 0);          // has k+1
+    }
+    return c;
+}
+
+template <typename RP>
+__global__ __launch_bounds__(256) void k_assemble_poisson(int dim, int64_t nx, int64_t ny, int64_t nz, int64_t row0,
+                                                          int64_t n_local, int64_t ghost_lo, int64_t nnz0,
+                                                          const double *__restrict__ wx, const double *__restrict__ wy,
+                                                          const double *__restrict__ wz, const double *__restrict__ gx,
+                                                          const double *__restrict__ gy, const double *__restrict__ gz,
+                                                          int pinned, RP *__restrict__ rowptr,
+                                                          int32_t *__restrict__ col, double *__restrict__ val)
+{
+    const int64_t pl = nx * ny;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n_local; r += (int64_t)gridDim.x * 256) {
+        const int64_t g = row0 + r;
+        int64_t p = nnz_before(g, dim, nx, ny, nz) - nnz0;
+        rowptr[r] = (RP)p;
+        if (r == n_local) break;
+        const int64_t i = g % nx, j = (g / nx) % ny, k = g / pl;
+        const double ax = wy[j] * wz[k];  // dL[0][1][j]*dL[0][2][k]  (createdivergence.cpp:140-143)
+        const double ay = wx[i] * wz[k];  // dL[1][0][i]*dL[1][2][k]
+        const double az = wx[i] * wy[j];  // dL[2][0][i]*dL[2][1][j]
+        // face terms D_cf * (dt*G_fc'), in the column order of D's row:
+        // u(i-1), u(i), v(j-1), v(j), w(k-1), w(k)
+        const bool hxm = i > 0, hxp = i < nx - 1, hym = j > 0, hyp = j < ny - 1;
+        const bool hzm = (dim == 3) && k > 0, hzp = (dim == 3) && k < nz - 1;
+        const double oxm = hxm ? ax * gx[i - 1] : 0.0, oxp = hxp ? ax * gx[i] : 0.0;
+        const double oym = hym ? ay * gy[j - 1] : 0.0, oyp = hyp ? ay * gy[j] : 0.0;
+        const double ozm = hzm ? az * gz[k - 1] : 0.0, ozp = hzp ? az * gz[k] : 0.0;
+        // diagonal: first contribution assigned, the rest added (sparse accumulator)
+        double d = 0.0;
+        bool first = true;
+#define PIB_ACC(has, t)                      \
+    if (has) {                               \
+        if (first) { d = -(t); first = false; } \
+        else d = d + (-(t));                 \
+    }
+        PIB_ACC(hxm, oxm) PIB_ACC(hxp, oxp) PIB_ACC(hym, oym) PIB_ACC(hyp, oyp) PIB_ACC(hzm, ozm) PIB_ACC(hzp, ozp)
+#undef PIB_ACC
+        const int64_t lc = r + ghost_lo;  // local column of the diagonal
+        const bool row_pinned = pinned && g == 0;
+#define PIB_PUT(has, c, v, zero_col)                                   \
+    if (has) {                                                         \
+        col[p] = (int32_t)(c);                                         \
+        val[p] = (row_pinned || (pinned && (zero_col))) ? 0.0 : (v);   \
+        ++p;                                                           \
+    }
+        PIB_PUT(hzm, lc - pl, ozm, g - pl == 0)
+        PIB_PUT(hym, lc - nx, oym, g - nx == 0)
+        PIB_PUT(hxm, lc - 1, oxm, g - 1 == 0)
+        col[p] = (int32_t)lc;
+        val[p] = row_pinned ? 1.0 : d;
+        ++p;
+        PIB_PUT(hxp, lc + 1, oxp, false)
+        PIB_PUT(hyp, lc + nx, oyp, false)
+        PIB_PUT(hzp, lc + pl, ozp, false)
+#undef PIB_PUT
+    }
+}
+
+static int upload_vec(const std::vector<double> &h, double **d)
+{
+    PIB_HIP(hipMalloc(d, sizeof(double) * std::max<size_t>(h.size(), 1)));
+    if (!h.empty()) PIB_HIP(hipMemcpy(*d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace)
+{
+    if (dim != 2 && dim != 3) return fail(PIB_ERR_ARG_OUTOFRANGE, "assemble_poisson: dim must be 2 or 3");
+    const int64_t nx = n[0], ny = n[1], nz = (dim == 3) ? n[2] : 1;
+    if (nx < 2 || ny < 2 || (dim == 3 && nz < 2)) return fail(PIB_ERR_ARG_SIZ, "assemble_poisson: need >= 2 cells per direction");
+    if (w[0] == nullptr || w[1] == nullptr || (dim == 3 && w[2] == nullptr)) return fail(PIB_ERR_ARG_NULL, "assemble_poisson: null widths");
+    // host: 1-D arrays.  g_d[s] = dt * (1 / (0.5*(w[s+1] + w[s])))
+    //   velocity-cell width: cartesianmesh.cpp:246-258 (adjacent_difference with 0.5*(x+y))
+    //   G value 1/dL:        creategradient.cpp:70-86 ; BN = dt*I: createbn.cpp:49
+    std::vector<double> hw[3], hg[3];
+    for (int d = 0; d < 3; ++d) {
+        const int64_t nd = (d < dim) ? n[d] : 1;
+        hw[d].resize((size_t)nd);
+        for (int64_t q = 0; q < nd; ++q) hw[d][(size_t)q] = (d < dim) ? w[d][q] : 1.0;
+        hg[d].resize((size_t)std::max<int64_t>(nd - 1, 0));
+        for (int64_t q = 0; q + 1 < nd; ++q) {
+            const double dl = 0.5 * (hw[d][(size_t)q + 1] + hw[d][(size_t)q]);
+            const double v = 1.0 / dl;
+            hg[d][(size_t)q] = dt * v;
+        }
+    }
+    const int P = s->comm.nranks, r = s->comm.rank;
+    const int64_t nlast = (dim == 3) ? nz : ny;
+    const int64_t plane = (dim == 3) ? nx * ny : nx;
+    int64_t k0, k1;
+    slab_range(nlast, P, r, &k0, &k1);
+    if (k1 - k0 < 1) return fail(PIB_ERR_SUP, "assemble_poisson: a rank owns no plane (%lld planes on %d ranks)", (long long)nlast, P);
+
+    DeviceCsr &A = s->A;
+    A.release();
+    A.n = (k1 - k0) * plane;
+    A.row0 = k0 * plane;
+    A.n_global = nx * ny * nz;
+    A.ghost_lo = (r > 0) ? plane : 0;
+    A.ghost_hi = (r < P - 1) ? plane : 0;
+    const int64_t nnz0 = nnz_before(A.row0, dim, nx, ny, nz);
+    A.nnz = nnz_before(A.row0 + A.n, dim, nx, ny, nz) - nnz0;
+    A.rp64 = A.nnz >= (int64_t)std::numeric_limits<int32_t>::max();
+    if (A.ghost_lo + A.n + A.ghost_hi >= (int64_t)std::numeric_limits<int32_t>::max())
+        return fail(PIB_ERR_SUP, "assemble_poisson: local slab too large for 32-bit column indices");
+    PIB_HIP(hipMalloc(&A.rowptr, (A.rp64 ? 8 : 4) * ((size_t)A.n + 1)));
+    PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)A.nnz));
+    PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)A.nnz));
+    double *dw[3] = {nullptr, nullptr, nullptr}, *dg[3] = {nullptr, nullptr, nullptr};
+    for (int d = 0; d < 3; ++d) {
+        PIB_CHK(upload_vec(hw[d], &dw[d]));
+        PIB_CHK(upload_vec(hg[d], &dg[d]));
+    }
+    const int pinned = (nullspace == PIB_NULLSPACE_PINNED) ? 1 : 0;
+    const int nb = (int)std::min<int64_t>(8192, (A.n + 1 + 255) / 256);
+    if (A.rp64)
+        hipLaunchKernelGGL(k_assemble_poisson<int64_t>, dim3(nb), dim3(256), 0, s->stream, dim, nx, ny, nz, A.row0, A.n,
+                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, (int64_t *)A.rowptr, A.col,
+                           A.val);
+    else
+        hipLaunchKernelGGL(k_assemble_poisson<int32_t>, dim3(nb), dim3(256), 0, s->stream, dim, nx, ny, nz, A.row0, A.n,
+                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, (int32_t *)A.rowptr, A.col,
+                           A.val);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    // hand the 1-D arrays to the structured (stencil / multigrid) path
+    const double *cw[3] = {hw[0].data(), hw[1].data(), hw[2].data()};
+    const double *cg[3] = {hg[0].data(), hg[1].data(), hg[2].data()};
+    for (int d = 0; d < 3; ++d) {
+        (void)hipFree(dw[d]);
+        (void)hipFree(dg[d]);
+    }
+    return grid_register(s, dim, n, cw, cg, nullspace);
+}
+
+}  // namespace pib

@@ -1,0 +1,348 @@
+// capi.cpp -- the extern "C" surface declared in include/petibm_amd.h.
+#include <cstring>
+#include <new>
+
+#include "pib_internal.hpp"
+
+using namespace pib;
+
+static int make_solver(pib_solver **out, const char *name, const Config &cfg, const char *cfg_path, int rank,
+                       int nranks, const void *uid, int device)
+{
+    if (out == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_create: null output handle");
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_create: bad rank %d / %d", rank, nranks);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(PIB_ERR_LIB, "pib_create: no HIP device available (%s) -- this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0) device = rank % ndev;
+    if (device >= ndev) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_create: device %d of %d", device, ndev);
+    PIB_HIP(hipSetDevice(device));
+    pib_solver *s = new (std::nothrow) pib_solver();
+    if (s == nullptr) return fail(PIB_ERR_MEM, "pib_create: out of memory");
+    s->name = name ? name : "";
+    s->cfg_path = cfg_path ? cfg_path : "None";
+    s->cfg = cfg;
+    s->type_string = (cfg.flavor == Flavor::AMGX) ? "NVIDIA AmgX" : "PETSc KSP";
+    s->device = device;
+    PIB_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    PIB_HIP(hipStreamCreateWithFlags(&s->stream_comm, hipStreamNonBlocking));
+    PIB_HIP(hipEventCreate(&s->ev_a));
+    PIB_HIP(hipEventCreate(&s->ev_b));
+    PIB_HIP(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
+    PIB_HIP(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+    PIB_HIP(hipMalloc(&s->d_s, sizeof(Scalars)));
+    PIB_HIP(hipMemset(s->d_s, 0, sizeof(Scalars)));
+    PIB_HIP(hipHostMalloc(&s->h_s, sizeof(Scalars)));
+    std::memset(s->h_s, 0, sizeof(Scalars));
+    PIB_HIP(hipMalloc(&s->d_part, sizeof(double) * PIB_NRED * PIB_MAXPART));
+    PIB_HIP(hipMemset(s->d_part, 0, sizeof(double) * PIB_NRED * PIB_MAXPART));
+    int err = comm_init(s, rank, nranks, uid);
+    if (err) {
+        pib_destroy(s);
+        return err;
+    }
+    *out = s;
+    return 0;
+}
+
+extern "C" {
+
+int pib_version(void) { return 100; }
+
+int pib_create(pib_solver **s, const char *name, const char *cfg_path, int rank, int nranks, const void *uid_or_null,
+               int device)
+{
+    Config cfg;
+    PIB_CHK(parse_config_file(cfg_path, name ? name : "", cfg));
+    return make_solver(s, name, cfg, cfg_path, rank, nranks, uid_or_null, device);
+}
+
+int pib_create_from_string(pib_solver **s, const char *name, const char *cfg_text, int rank, int nranks,
+                           const void *uid_or_null, int device)
+{
+    Config cfg;
+    PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", cfg));
+    return make_solver(s, name, cfg, "<string>", rank, nranks, uid_or_null, device);
+}
+
+int pib_destroy(pib_solver *s)
+{
+    if (s == nullptr) return 0;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    gmg_release(s);
+    s->A.release();
+    if (s->graph) (void)hipGraphExecDestroy(s->graph);
+    if (s->work_base) (void)hipFree(s->work_base);
+    if (s->x_dev) (void)hipFree(s->x_dev);
+    if (s->b_dev) (void)hipFree(s->b_dev);
+    if (s->d_s) (void)hipFree(s->d_s);
+    if (s->h_s) (void)hipHostFree(s->h_s);
+    if (s->d_part) (void)hipFree(s->d_part);
+    if (s->d_hist) (void)hipFree(s->d_hist);
+    if (s->comm.comm) (void)ncclCommDestroy(s->comm.comm);
+    if (s->ev_a) (void)hipEventDestroy(s->ev_a);
+    if (s->ev_b) (void)hipEventDestroy(s->ev_b);
+    if (s->ev_halo) (void)hipEventDestroy(s->ev_halo);
+    if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->stream_comm) (void)hipStreamDestroy(s->stream_comm);
+    delete s;
+    return 0;
+}
+
+int pib_get_type(pib_solver *s, char *buf, int buflen)
+{
+    if (s == nullptr || buf == nullptr || buflen < 1) return fail(PIB_ERR_ARG_NULL, "pib_get_type: null argument");
+    std::strncpy(buf, s->type_string.c_str(), (size_t)buflen - 1);
+    buf[buflen - 1] = '\0';
+    return 0;
+}
+
+static int after_set_matrix(pib_solver *s)
+{
+    PIB_CHK(comm_setup_halo(s));
+    int missing = 0;
+    PIB_CHK(extract_dinv(s, &missing));
+    if (missing > 0 && s->cfg.pc == Precond::JACOBI)
+        return fail(PIB_ERR_ARG_WRONG, "solver %s: %d rows have no (or a zero) diagonal entry: Jacobi preconditioning impossible",
+                    s->name.c_str(), missing);
+    // KSPReset semantics (linsolverksp.cpp:78): everything derived from the old matrix goes
+    if (s->graph) {
+        (void)hipGraphExecDestroy(s->graph);
+        s->graph = nullptr;
+    }
+    s->has_matrix = true;
+    return 0;
+}
+
+int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_global, const int64_t *rowptr,
+                const int64_t *col_global, const double *val)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr: null solver");
+    PIB_HIP(hipSetDevice(s->device));
+    s->has_matrix = false;
+    s->has_grid = false;
+    gmg_release(s);
+    PIB_CHK(upload_csr(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val));
+    return after_set_matrix(s);
+}
+
+int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t n_global, const int32_t *rowptr,
+                    const int32_t *col_global, const double *val)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr_i32: null solver");
+    PIB_HIP(hipSetDevice(s->device));
+    s->has_matrix = false;
+    s->has_grid = false;
+    gmg_release(s);
+    PIB_CHK(upload_csr(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val));
+    return after_set_matrix(s);
+}
+
+int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
+                      const double *gx, const double *gy, const double *gz, int nullspace)
+{
+    if (s == nullptr || n == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_grid_hint: null argument");
+    if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_set_grid_hint: set the matrix first");
+    PIB_HIP(hipSetDevice(s->device));
+    const double one = 1.0;
+    const double *w[3] = {wx, wy, (dim == 3) ? wz : &one};
+    const double *g[3] = {gx, gy, (dim == 3) ? gz : nullptr};
+    return grid_register(s, dim, n, w, g, nullspace);
+}
+
+int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
+                         const double *wz, double dt, int nullspace)
+{
+    if (s == nullptr || n == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_assemble_poisson: null argument");
+    PIB_HIP(hipSetDevice(s->device));
+    s->has_matrix = false;
+    s->has_grid = false;
+    gmg_release(s);
+    const double *w[3] = {wx, wy, wz};
+    PIB_CHK(assemble_poisson(s, dim, n, w, dt, nullspace));
+    return after_set_matrix(s);
+}
+
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory: clear the sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+static int ensure_stage(pib_solver *s)
+{
+    if (s->stage_n >= s->A.n && s->x_dev) return 0;
+    if (s->x_dev) (void)hipFree(s->x_dev);
+    if (s->b_dev) (void)hipFree(s->b_dev);
+    s->x_dev = s->b_dev = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)(s->A.n > 0 ? s->A.n : 1);
+    PIB_HIP(hipMalloc(&s->x_dev, bytes));
+    PIB_HIP(hipMalloc(&s->b_dev, bytes));
+    s->stage_n = s->A.n;
+    return 0;
+}
+
+int pib_solve(pib_solver *s, double *x, const double *b)
+{
+    if (s == nullptr || x == nullptr || b == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_solve: null argument");
+    if (!s->has_matrix) return fail(PIB_ERR_ORDER, "solver %s: pib_solve called before a matrix was set", s->name.c_str());
+    PIB_HIP(hipSetDevice(s->device));
+    const bool xd = is_device_ptr(x), bd = is_device_ptr(b);
+    double *xdev = x;
+    const double *bdev = b;
+    const size_t bytes = sizeof(double) * (size_t)s->A.n;
+    if (!xd || !bd) PIB_CHK(ensure_stage(s));
+    if (!xd) {
+        xdev = s->x_dev;
+        if (s->cfg.initial_guess_nonzero) PIB_HIP(hipMemcpyAsync(xdev, x, bytes, hipMemcpyHostToDevice, s->stream));
+    }
+    if (!bd) {
+        PIB_HIP(hipMemcpyAsync(s->b_dev, b, bytes, hipMemcpyHostToDevice, s->stream));
+        bdev = s->b_dev;
+    }
+    int err;
+    if (s->cfg.method == Method::CG)
+        err = solve_cg(s, xdev, bdev);
+    else if (s->cfg.method == Method::BICGSTAB)
+        err = solve_bicgstab(s, xdev, bdev);
+    else
+        err = fail(PIB_ERR_SUP, "solver %s: unsupported Krylov method", s->name.c_str());
+    if (err) return err;
+    if (!xd) {
+        PIB_HIP(hipMemcpyAsync(x, xdev, bytes, hipMemcpyDeviceToHost, s->stream));
+        PIB_HIP(hipStreamSynchronize(s->stream));
+    }
+    if (s->reason < 0 && s->cfg.error_if_not_converged)
+        return fail(PIB_ERR_CONV_FAILED, "PetIBM exited due to solver %s diverged with reason %d (iterations %d, residual %g).",
+                    s->name.c_str(), s->reason, s->iters, s->residual);
+    return 0;
+}
+
+int pib_get_iters(pib_solver *s, int *iters)
+{
+    if (s == nullptr || iters == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_iters: null argument");
+    *iters = s->iters;
+    return 0;
+}
+
+int pib_get_residual(pib_solver *s, double *res)
+{
+    if (s == nullptr || res == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_residual: null argument");
+    *res = s->residual;
+    return 0;
+}
+
+int pib_get_residual_at(pib_solver *s, int iter, double *res)
+{
+    if (s == nullptr || res == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_residual_at: null argument");
+    if (iter < 0 || (size_t)iter >= s->history.size())
+        return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_get_residual_at: iteration %d outside the stored history [0,%zu)", iter,
+                    s->history.size());
+    *res = s->history[(size_t)iter];
+    return 0;
+}
+
+int pib_get_reason(pib_solver *s, int *reason)
+{
+    if (s == nullptr || reason == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_reason: null argument");
+    *reason = s->reason;
+    return 0;
+}
+
+int pib_mat_mult(pib_solver *s, const double *x, double *y)
+{
+    if (s == nullptr || x == nullptr || y == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_mat_mult: null argument");
+    if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_mat_mult called before a matrix was set");
+    PIB_HIP(hipSetDevice(s->device));
+    PIB_CHK(ensure_work(s, 4));
+    const size_t bytes = sizeof(double) * (size_t)s->A.n;
+    double *P = s->vec(2), *W = s->vec(3);
+    PIB_HIP(hipMemcpyAsync(P, x, bytes, hipMemcpyDefault, s->stream));
+    if (s->comm.nranks > 1) PIB_CHK(halo_exchange(s, P, s->stream));
+    PIB_CHK(spmv_rows(s, P, W, 0, s->A.n, nullptr, false, s->stream));
+    PIB_HIP(hipMemcpyAsync(y, W, bytes, hipMemcpyDefault, s->stream));
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int pib_device_alloc(pib_solver *s, int64_t nbytes, void **ptr)
+{
+    if (s == nullptr || ptr == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_device_alloc: null argument");
+    PIB_HIP(hipSetDevice(s->device));
+    PIB_HIP(hipMalloc(ptr, (size_t)(nbytes > 0 ? nbytes : 1)));
+    return 0;
+}
+int pib_device_free(pib_solver *s, void *ptr)
+{
+    if (s != nullptr) PIB_HIP(hipSetDevice(s->device));
+    if (ptr) PIB_HIP(hipFree(ptr));
+    return 0;
+}
+int pib_memcpy_h2d(pib_solver *s, void *dst, const void *src, int64_t nbytes)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "null solver");
+    PIB_HIP(hipSetDevice(s->device));
+    PIB_HIP(hipMemcpy(dst, src, (size_t)nbytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int pib_memcpy_d2h(pib_solver *s, void *dst, const void *src, int64_t nbytes)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "null solver");
+    PIB_HIP(hipSetDevice(s->device));
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    PIB_HIP(hipMemcpy(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int pib_synchronize(pib_solver *s)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "null solver");
+    PIB_HIP(hipSetDevice(s->device));
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, int64_t *col_global, double *val)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "null solver");
+    if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_get_csr: no matrix");
+    PIB_HIP(hipSetDevice(s->device));
+    const DeviceCsr &A = s->A;
+    if (n_local) *n_local = A.n;
+    if (nnz) *nnz = A.nnz;
+    if (rowptr) {
+        if (A.rp64) {
+            PIB_HIP(hipMemcpy(rowptr, A.rowptr, sizeof(int64_t) * ((size_t)A.n + 1), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<int32_t> t((size_t)A.n + 1);
+            PIB_HIP(hipMemcpy(t.data(), A.rowptr, sizeof(int32_t) * ((size_t)A.n + 1), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < t.size(); ++i) rowptr[i] = t[i];
+        }
+    }
+    if (col_global) {
+        std::vector<int32_t> t((size_t)A.nnz);
+        PIB_HIP(hipMemcpy(t.data(), A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+        const int64_t shift = A.row0 - A.ghost_lo;
+        for (size_t i = 0; i < t.size(); ++i) col_global[i] = (int64_t)t[i] + shift;
+    }
+    if (val) PIB_HIP(hipMemcpy(val, A.val, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pib_get_counters(pib_solver *s, int64_t counters[8])
+{
+    if (s == nullptr || counters == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
+    for (int k = 0; k < 8; ++k) counters[k] = s->counters[k];
+    return 0;
+}
+
+}  // extern "C"

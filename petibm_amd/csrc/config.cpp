@@ -1,0 +1,339 @@
+// config.cpp -- solver configuration files.
+//
+// Two syntaxes, auto-detected, both restricted to the subset every reference
+// example uses:
+//   * AmgX "legacy" key=value files read by AmgXSolver::initialize
+//     (src/linsolver/linsolveramgx.cpp:62-72), e.g.
+//     examples/navierstokes/liddrivencavity2dRe1000_GPU/config/poisson_solver.info
+//         solver(solv)=PCG ; solv:max_iters=1000 ; solv:preconditioner(prec)=AMG ;
+//         prec:smoother(smooth)=BLOCK_JACOBI ; smooth:relaxation_factor=0.9
+//     A key looked up in a scope falls back to the "default" scope, then to
+//     the AmgX built-in default.
+//   * PETSc options files inserted by LinSolverKSP::init with prefix -<name>_
+//     (src/linsolver/linsolverksp.cpp:56-66), e.g.
+//     examples/navierstokes/liddrivencavity2dRe100/config/poisson_solver.info
+//         -poisson_ksp_type cg ; -poisson_ksp_atol 1.0E-06 ; -poisson_pc_type gamg
+// AMG-type preconditioners (AmgX AMG, PCGAMG, hypre) map onto this library's
+// geometric multigrid (needs pib_set_grid_hint / pib_assemble_poisson).
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "pib_internal.hpp"
+
+namespace pib {
+
+static thread_local char g_err[1024] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+const char *last_error() { return g_err; }
+
+static std::string trim(const std::string &s)
+{
+    size_t a = 0, b = s.size();
+    while (a < b && std::isspace((unsigned char)s[a])) ++a;
+    while (b > a && std::isspace((unsigned char)s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+static std::string upper(std::string s)
+{
+    for (auto &c : s) c = (char)std::toupper((unsigned char)c);
+    return s;
+}
+static std::string lower(std::string s)
+{
+    for (auto &c : s) c = (char)std::tolower((unsigned char)c);
+    return s;
+}
+static bool truthy(const std::string &v)
+{
+    std::string u = upper(trim(v));
+    return !(u == "0" || u == "FALSE" || u == "NO" || u == "OFF" || u.empty());
+}
+
+// ---------------------------------------------------------------- AmgX syntax
+struct AmgxDoc {
+    std::map<std::string, std::map<std::string, std::string>> scopes;  // scope -> key -> value
+    std::map<std::string, std::string> child;                          // "scope:key" -> new scope name
+    bool has(const std::string &scope, const std::string &key) const
+    {
+        auto it = scopes.find(scope);
+        if (it != scopes.end() && it->second.count(key)) return true;
+        auto d = scopes.find("default");
+        return d != scopes.end() && d->second.count(key);
+    }
+    std::string get(const std::string &scope, const std::string &key, const std::string &dflt) const
+    {
+        auto it = scopes.find(scope);
+        if (it != scopes.end()) {
+            auto k = it->second.find(key);
+            if (k != it->second.end()) return k->second;
+        }
+        auto d = scopes.find("default");
+        if (d != scopes.end()) {
+            auto k = d->second.find(key);
+            if (k != d->second.end()) return k->second;
+        }
+        return dflt;
+    }
+    std::string child_scope(const std::string &scope, const std::string &key) const
+    {
+        auto it = child.find(scope + ":" + key);
+        return it == child.end() ? std::string("default") : it->second;
+    }
+};
+
+static int parse_amgx(const std::string &text, AmgxDoc &doc)
+{
+    std::string norm = text;
+    std::replace(norm.begin(), norm.end(), ',', '\n');
+    std::replace(norm.begin(), norm.end(), ';', '\n');
+    std::istringstream in(norm);
+    std::string line;
+    while (std::getline(in, line)) {
+        size_t h = line.find('#');
+        if (h != std::string::npos) line = line.substr(0, h);
+        line = trim(line);
+        if (line.empty()) continue;
+        size_t eq = line.find('=');
+        if (eq == std::string::npos) return fail(PIB_ERR_ARG_WRONG, "config: cannot parse line \"%s\"", line.c_str());
+        std::string lhs = trim(line.substr(0, eq)), rhs = trim(line.substr(eq + 1));
+        std::string scope = "default", key = lhs, newscope;
+        size_t colon = lhs.find(':');
+        if (colon != std::string::npos) {
+            scope = trim(lhs.substr(0, colon));
+            key = trim(lhs.substr(colon + 1));
+        }
+        size_t lp = key.find('(');
+        if (lp != std::string::npos) {
+            size_t rp = key.find(')', lp);
+            if (rp == std::string::npos) return fail(PIB_ERR_ARG_WRONG, "config: unbalanced '(' in \"%s\"", line.c_str());
+            newscope = trim(key.substr(lp + 1, rp - lp - 1));
+            key = trim(key.substr(0, lp));
+            doc.child[scope + ":" + key] = newscope;
+        }
+        doc.scopes[scope][key] = rhs;
+    }
+    return 0;
+}
+
+static int apply_amgx(const AmgxDoc &d, Config &c)
+{
+    c.flavor = Flavor::AMGX;
+    c.norm = NormType::UNPRECONDITIONED;  // norm=L2 of the true residual
+    c.initial_guess_nonzero = true;
+    c.dtol = 0.0;                         // AmgX has no divergence tolerance
+    // AmgX never reports non-convergence to PetIBM (linsolveramgx.cpp:90-99);
+    // this library defaults to an error unless the key says otherwise.
+    c.error_if_not_converged = true;
+
+    std::string top = "default";
+    std::string solver = upper(d.get("default", "solver", "PCG"));
+    std::string ss = d.child_scope("default", "solver");
+    if (solver == "PCG" || solver == "CG" || solver == "PCGF")
+        c.method = Method::CG;
+    else if (solver == "PBICGSTAB" || solver == "BICGSTAB")
+        c.method = Method::BICGSTAB;
+    else
+        return fail(PIB_ERR_SUP, "config: solver=%s is not supported (PCG, PBICGSTAB)", solver.c_str());
+    (void)top;
+
+    c.max_iters = std::atoi(d.get(ss, "max_iters", "100").c_str());
+    double tol = std::atof(d.get(ss, "tolerance", "1e-12").c_str());
+    std::string conv = upper(d.get(ss, "convergence", "ABSOLUTE"));
+    if (conv == "ABSOLUTE") {
+        c.atol = tol;
+        c.rtol = 0.0;
+    } else if (conv == "RELATIVE_INI" || conv == "RELATIVE_INI_CORE") {
+        c.atol = 0.0;
+        c.rtol = tol;
+    } else {
+        return fail(PIB_ERR_SUP, "config: convergence=%s is not supported (ABSOLUTE, RELATIVE_INI[_CORE])", conv.c_str());
+    }
+    std::string nrm = upper(d.get(ss, "norm", "L2"));
+    if (nrm != "L2") return fail(PIB_ERR_SUP, "config: norm=%s is not supported (L2)", nrm.c_str());
+    c.monitor_residual = truthy(d.get(ss, "monitor_residual", "0"));
+    c.store_res_history = truthy(d.get(ss, "store_res_history", "0"));
+    if (d.has(ss, "error_if_not_converged")) c.error_if_not_converged = truthy(d.get(ss, "error_if_not_converged", "1"));
+
+    std::string pc = upper(d.get(ss, "preconditioner", "NOSOLVER"));
+    std::string ps = d.child_scope(ss, "preconditioner");
+    if (pc == "NOSOLVER" || pc == "NONE") {
+        c.pc = Precond::NONE;
+    } else if (pc == "BLOCK_JACOBI" || pc == "JACOBI" || pc == "JACOBI_L1") {
+        c.pc = Precond::JACOBI;
+        c.jacobi_relaxation = std::atof(d.get(ps, "relaxation_factor", "0.9").c_str());
+    } else if (pc == "AMG" || pc == "GMG") {
+        c.pc = Precond::GMG;
+        std::string cyc = upper(d.get(ps, "cycle", "V"));
+        if (cyc != "V") return fail(PIB_ERR_SUP, "config: cycle=%s is not supported (V)", cyc.c_str());
+        c.presweeps = std::atoi(d.get(ps, "presweeps", "1").c_str());
+        c.postsweeps = std::atoi(d.get(ps, "postsweeps", "1").c_str());
+        c.max_levels = std::atoi(d.get(ps, "max_levels", "100").c_str());
+        c.min_coarse_rows = std::atoi(d.get(ps, "min_coarse_rows", "2").c_str());
+        c.dense_lu_num_rows = std::atoi(d.get(ps, "dense_lu_num_rows", "128").c_str());
+        c.coarsest_sweeps = std::max(1, std::atoi(d.get(ps, "coarsest_sweeps", "2").c_str())) * 16;
+        std::string sm = upper(d.get(ps, "smoother", "BLOCK_JACOBI"));
+        std::string sms = d.child_scope(ps, "smoother");
+        if (sm == "BLOCK_JACOBI" || sm == "JACOBI" || sm == "JACOBI_L1" || sm == "MULTICOLOR_DILU" ||
+            sm == "MULTICOLOR_GS")
+            c.smoother = Smoother::JACOBI;
+        else if (sm == "CHEBYSHEV" || sm == "CHEBYSHEV_POLY")
+            c.smoother = Smoother::CHEBYSHEV;
+        else
+            return fail(PIB_ERR_SUP, "config: smoother=%s is not supported", sm.c_str());
+        c.smoother_relaxation = std::atof(d.get(sms, "relaxation_factor", "0.9").c_str());
+        c.cheby_degree = std::atoi(d.get(sms, "chebyshev_polynomial_order", "2").c_str());
+    } else {
+        return fail(PIB_ERR_SUP, "config: preconditioner=%s is not supported (NOSOLVER, BLOCK_JACOBI, AMG)", pc.c_str());
+    }
+    // library-specific keys (default scope)
+    c.check_every = std::atoi(d.get("default", "pib_check_every", "0").c_str());
+    c.use_graph = std::atoi(d.get("default", "pib_use_graph", "1").c_str());
+    c.spmv_variant = std::atoi(d.get("default", "pib_spmv_variant", "0").c_str());
+    c.overlap_halo = std::atoi(d.get("default", "pib_overlap_halo", "1").c_str());
+    if (d.has("default", "pib_initial_guess_nonzero"))
+        c.initial_guess_nonzero = truthy(d.get("default", "pib_initial_guess_nonzero", "1"));
+    if (d.has("default", "pib_norm")) {
+        std::string v = upper(d.get("default", "pib_norm", ""));
+        c.norm = (v == "PRECONDITIONED") ? NormType::PRECONDITIONED : NormType::UNPRECONDITIONED;
+    }
+    if (c.max_iters < 0) return fail(PIB_ERR_ARG_OUTOFRANGE, "config: max_iters < 0");
+    return 0;
+}
+
+// --------------------------------------------------------------- PETSc syntax
+static int apply_petsc(const std::string &text, const std::string &name, Config &c)
+{
+    c.flavor = Flavor::KSP;
+    c.method = Method::CG;  // KSPSetType(ksp, KSPCG): linsolverksp.cpp:64
+    c.pc = Precond::JACOBI; // PETSc's own default (ILU) is not provided; see INTEGRATION.md
+    c.norm = NormType::PRECONDITIONED;
+    c.max_iters = 10000;
+    c.rtol = 1e-5;
+    c.atol = 1e-50;
+    c.dtol = 1e4;
+    c.monitor_residual = true;
+    c.store_res_history = true;
+    c.error_if_not_converged = true;  // linsolverksp.cpp:96-104
+    c.initial_guess_nonzero = false;
+    c.jacobi_relaxation = 1.0;
+
+    std::map<std::string, std::string> opt;
+    std::istringstream in(text);
+    std::string line;
+    while (std::getline(in, line)) {
+        size_t h = line.find('#');
+        if (h != std::string::npos) line = line.substr(0, h);
+        std::istringstream ls(line);
+        std::string tok, pending;
+        while (ls >> tok) {
+            if (tok.size() > 1 && tok[0] == '-' && !std::isdigit((unsigned char)tok[1]) && tok[1] != '.') {
+                if (!pending.empty()) opt[pending] = "true";
+                pending = tok.substr(1);
+            } else if (!pending.empty()) {
+                opt[pending] = tok;
+                pending.clear();
+            }
+        }
+        if (!pending.empty()) opt[pending] = "true";
+    }
+    const std::string pre = name + "_";
+    auto get = [&](const std::string &k, std::string &v) {
+        auto it = opt.find(pre + k);
+        if (it == opt.end()) return false;
+        v = it->second;
+        return true;
+    };
+    std::string v;
+    if (get("ksp_type", v)) {
+        v = lower(v);
+        if (v == "cg") c.method = Method::CG;
+        else if (v == "bcgs" || v == "bicg" || v == "bcgsl") c.method = Method::BICGSTAB;
+        else return fail(PIB_ERR_SUP, "config: -%sksp_type %s is not supported (cg, bcgs)", pre.c_str(), v.c_str());
+    }
+    if (get("ksp_atol", v)) c.atol = std::atof(v.c_str());
+    if (get("ksp_rtol", v)) c.rtol = std::atof(v.c_str());
+    if (get("ksp_divtol", v)) c.dtol = std::atof(v.c_str());
+    if (get("ksp_max_it", v)) c.max_iters = std::atoi(v.c_str());
+    if (get("ksp_initial_guess_nonzero", v)) c.initial_guess_nonzero = truthy(v);
+    if (get("ksp_norm_type", v)) {
+        v = lower(v);
+        if (v == "preconditioned") c.norm = NormType::PRECONDITIONED;
+        else if (v == "unpreconditioned") c.norm = NormType::UNPRECONDITIONED;
+        else return fail(PIB_ERR_SUP, "config: -%sksp_norm_type %s is not supported", pre.c_str(), v.c_str());
+    }
+    if (get("pc_type", v)) {
+        v = lower(v);
+        if (v == "none") c.pc = Precond::NONE;
+        else if (v == "jacobi") c.pc = Precond::JACOBI;
+        else if (v == "gamg" || v == "hypre" || v == "mg" || v == "ml") {
+            c.pc = Precond::GMG;
+            c.smoother = Smoother::CHEBYSHEV;  // PCGAMG's default level smoother is Chebyshev/Jacobi
+            c.presweeps = c.postsweeps = 1;
+            c.cheby_degree = 2;
+        } else
+            return fail(PIB_ERR_SUP, "config: -%spc_type %s is not supported (none, jacobi, gamg, hypre)", pre.c_str(),
+                        v.c_str());
+    }
+    if (get("pib_check_every", v)) c.check_every = std::atoi(v.c_str());
+    if (get("pib_use_graph", v)) c.use_graph = std::atoi(v.c_str());
+    if (get("pib_spmv_variant", v)) c.spmv_variant = std::atoi(v.c_str());
+    if (get("pib_overlap_halo", v)) c.overlap_halo = std::atoi(v.c_str());
+    if (get("pib_presweeps", v)) c.presweeps = std::atoi(v.c_str());
+    if (get("pib_postsweeps", v)) c.postsweeps = std::atoi(v.c_str());
+    if (get("pib_cheby_degree", v)) c.cheby_degree = std::atoi(v.c_str());
+    if (get("pib_smoother", v)) c.smoother = (upper(v) == "JACOBI") ? Smoother::JACOBI : Smoother::CHEBYSHEV;
+    return 0;
+}
+
+int parse_config_text(const std::string &text, const std::string &name, Config &cfg)
+{
+    cfg = Config();
+    cfg.raw = text;
+    // PETSc options files have lines that start with '-'
+    bool petsc = false;
+    {
+        std::istringstream in(text);
+        std::string line;
+        while (std::getline(in, line)) {
+            std::string t = trim(line);
+            if (t.empty() || t[0] == '#') continue;
+            petsc = (t[0] == '-');
+            break;
+        }
+    }
+    if (petsc) return apply_petsc(text, name, cfg);
+    AmgxDoc doc;
+    PIB_CHK(parse_amgx(text, doc));
+    return apply_amgx(doc, cfg);
+}
+
+int parse_config_file(const char *path, const std::string &name, Config &cfg)
+{
+    if (path == nullptr || std::strcmp(path, "None") == 0 || path[0] == '\0') {
+        // LinSolverAmgX::init writes an empty temporary file (linsolveramgx.cpp:62-72):
+        // every key takes its AmgX default.
+        return parse_config_text("", name, cfg);
+    }
+    std::ifstream f(path);
+    if (!f) return fail(PIB_ERR_FILE_OPEN, "cannot open solver configuration file \"%s\"", path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return parse_config_text(ss.str(), name, cfg);
+}
+
+}  // namespace pib
+
+extern "C" const char *pib_last_error(void) { return pib::last_error(); }

@@ -1,0 +1,236 @@
+// kernels_spmv.hip -- K1: fp64 CSR SpMV for gfx950 (MI355X), plus diagonal
+// extraction and halo-row classification.
+//
+// Replaces the MatMult that PETSc / AmgX run inside KSPSolve / AmgXSolver::solve
+// (src/linsolver/linsolverksp.cpp:92, src/linsolver/linsolveramgx.cpp:96) and
+// the applications' own MatMult calls (applications/navierstokes/navierstokes.cpp:
+// 442,490,549,592).
+//
+// Design (HBM-bound, 0.13 flop/B; MFMA unused -- no dense contraction):
+//   * "CSR-stream": a 256-thread workgroup owns 256 consecutive rows.  The
+//     val/col arrays of those rows are one contiguous span, read with fully
+//     coalesced wave-wide loads (lane i reads entry p0+i); each lane multiplies
+//     its entries by the gathered x[col] and parks the products in LDS
+//     (16 KiB tile).  Then thread t adds up row t's products from LDS in CSR
+//     order.  HBM sees val/col/rowptr exactly once, perfectly coalesced.
+//   * x is gathered through L1/L2: for the 5/7-point operator in natural
+//     ordering a workgroup touches five short contiguous x windows
+//     (r0-nx*ny, r0-nx, r0-1..r0+R+1, r0+nx, r0+nx*ny); x is read from HBM
+//     once per SpMV and the re-reads hit the XCD's L2 / the 256 MiB MALL.
+//   * XCD-aware chunk order: workgroup b runs on XCD b%8 (observed dispatch
+//     rule, speed only); XCD x walks the contiguous chunk range
+//     [x*cpx,(x+1)*cpx) so the +-nx neighbours of a chunk are in the SAME
+//     XCD's 4 MiB L2 when the adjacent chunk needs them.
+//   * persistent grid (2048 workgroups = 8 per CU) with a chunk loop: a fixed,
+//     small number of partial sums when the p.Ap dot product is fused in.
+//   * summation order per row is sequential in CSR order with rounded
+//     products (no FMA contraction: the library is built -ffp-contract=off),
+//     which the oracle reproduces -> bit-exact parity.
+#include "pib_internal.hpp"
+
+namespace pib {
+
+constexpr int SPMV_BLOCK = 256;
+constexpr int SPMV_ROWS = 256;
+constexpr int SPMV_NPT = 8;
+constexpr int SPMV_TILE = SPMV_BLOCK * SPMV_NPT;  // 2048 products = 16 KiB
+constexpr int SPMV_GRID = 2048;                   // 256 CUs x 8 workgroups
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum over a 256-thread block; result valid in thread 0
+__device__ __forceinline__ double block_sum_256(double v, double *sh /* >= 4 */)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;
+}
+
+template <typename RP, bool DOT>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_stream(const Scalars *__restrict__ S, int64_t r_begin,
+                                                            int64_t r_end, const RP *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ col,
+                                                            const double *__restrict__ val,
+                                                            const double *__restrict__ xg,  // ghosted base
+                                                            int64_t ghost_lo, double *__restrict__ y,
+                                                            double *__restrict__ part)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ double prod[SPMV_TILE];
+    __shared__ RP srow[SPMV_ROWS + 1];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t nchunks = (r_end - r_begin + SPMV_ROWS - 1) / SPMV_ROWS;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int64_t cpx = (nchunks + 7) >> 3;
+    const int64_t c_lo = (int64_t)xcd * cpx;
+    const int64_t c_hi = (c_lo + cpx < nchunks) ? c_lo + cpx : nchunks;
+    double dacc = 0.0;
+
+    for (int64_t c = c_lo + j; c < c_hi; c += bpx) {
+        const int64_t r0 = r_begin + c * SPMV_ROWS;
+        const int nr = (int)((r_end - r0 < SPMV_ROWS) ? (r_end - r0) : SPMV_ROWS);
+        for (int t = tid; t <= nr; t += SPMV_BLOCK) srow[t] = rowptr[r0 + t];
+        __syncthreads();
+        const RP p0 = srow[0], p1 = srow[nr];
+        RP rs = 0, re = 0;
+        if (tid < nr) {
+            rs = srow[tid];
+            re = srow[tid + 1];
+        }
+        double sum = 0.0;
+        for (RP t0 = p0; t0 < p1; t0 += SPMV_TILE) {
+            const int cnt = (int)((p1 - t0 < (RP)SPMV_TILE) ? (p1 - t0) : (RP)SPMV_TILE);
+            int32_t cc[SPMV_NPT];
+            double vv[SPMV_NPT];
+#pragma unroll
+            for (int u = 0; u < SPMV_NPT; ++u) {
+                const int i = tid + u * SPMV_BLOCK;
+                cc[u] = (i < cnt) ? col[t0 + i] : 0;
+                vv[u] = (i < cnt) ? val[t0 + i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < SPMV_NPT; ++u) {
+                const int i = tid + u * SPMV_BLOCK;
+                if (i < cnt) prod[i] = vv[u] * xg[cc[u]];
+            }
+            __syncthreads();
+            if (tid < nr) {
+                const RP lo = (rs > t0) ? rs : t0;
+                const RP hi = (re < t0 + cnt) ? re : (t0 + cnt);
+                for (RP p = lo; p < hi; ++p) sum = sum + prod[(int)(p - t0)];
+            }
+            __syncthreads();
+        }
+        if (p1 == p0) __syncthreads();  // srow is rewritten by the next chunk
+        if (tid < nr) {
+            y[r0 + tid] = sum;
+            if (DOT) dacc += xg[ghost_lo + r0 + tid] * sum;
+        }
+    }
+    if (DOT) {
+        const double s = block_sum_256(dacc, red);
+        if (tid == 0) part[blockIdx.x] = s;
+    }
+}
+
+// Row-per-thread fallback (variant 2): simplest possible CSR kernel, kept as
+// the A/B baseline for the profile and as the checker of the stream kernel.
+template <typename RP, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_scalar(const Scalars *__restrict__ S, int64_t r_begin, int64_t r_end,
+                                                     const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                     const double *__restrict__ val, const double *__restrict__ xg,
+                                                     int64_t ghost_lo, double *__restrict__ y,
+                                                     double *__restrict__ part)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ double red[4];
+    double dacc = 0.0;
+    for (int64_t r = r_begin + (int64_t)blockIdx.x * 256 + threadIdx.x; r < r_end; r += (int64_t)gridDim.x * 256) {
+        double sum = 0.0;
+        const RP pe = rowptr[r + 1];
+        for (RP p = rowptr[r]; p < pe; ++p) sum = sum + val[p] * xg[col[p]];
+        y[r] = sum;
+        if (DOT) dacc += xg[ghost_lo + r] * sum;
+    }
+    if (DOT) {
+        const double s = block_sum_256(dacc, red);
+        if (threadIdx.x == 0) part[blockIdx.x] = s;
+    }
+}
+
+int spmv_launch_blocks() { return SPMV_GRID; }
+
+// y[r_begin:r_end) = (A x)[r_begin:r_end).  x_owned points at the owned part
+// of a ghost-padded vector.  If dot_part != nullptr, SPMV_GRID partial sums of
+// x.y over the row range are written there.
+int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, int64_t r_end, double *dot_part,
+              bool guarded, hipStream_t st)
+{
+    const DeviceCsr &A = s->A;
+    if (r_end <= r_begin) {
+        if (dot_part) PIB_HIP(hipMemsetAsync(dot_part, 0, SPMV_GRID * sizeof(double), st));
+        return 0;
+    }
+    const double *xg = x_owned - A.ghost_lo;
+    const Scalars *S = guarded ? s->d_s : nullptr;
+    const int variant = s->cfg.spmv_variant;
+#define PIB_LAUNCH(KERNEL, RP)                                                                                   \
+    do {                                                                                                         \
+        if (dot_part)                                                                                            \
+            hipLaunchKernelGGL((KERNEL<RP, true>), dim3(SPMV_GRID), dim3(256), 0, st, S, r_begin, r_end,        \
+                               (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, dot_part);                 \
+        else                                                                                                     \
+            hipLaunchKernelGGL((KERNEL<RP, false>), dim3(SPMV_GRID), dim3(256), 0, st, S, r_begin, r_end,       \
+                               (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, (double *)nullptr);        \
+    } while (0)
+    if (variant == 2) {
+        if (A.rp64) PIB_LAUNCH(k_spmv_scalar, int64_t); else PIB_LAUNCH(k_spmv_scalar, int32_t);
+    } else {
+        if (A.rp64) PIB_LAUNCH(k_spmv_stream, int64_t); else PIB_LAUNCH(k_spmv_stream, int32_t);
+    }
+#undef PIB_LAUNCH
+    PIB_HIP(hipGetLastError());
+    s->counters[0]++;
+    return 0;
+}
+
+// ---------------------------------------------------------------- 1/diag
+template <typename RP>
+__global__ void k_extract_dinv(int64_t n, int64_t ghost_lo, const RP *__restrict__ rowptr,
+                               const int32_t *__restrict__ col, const double *__restrict__ val,
+                               double *__restrict__ dinv, int *__restrict__ missing)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double d = 0.0;
+    bool found = false;
+    for (RP p = rowptr[r]; p < rowptr[r + 1]; ++p)
+        if ((int64_t)col[p] == r + ghost_lo) {
+            d = d + val[p];
+            found = true;
+        }
+    if (!found || d == 0.0) {
+        atomicAdd(missing, 1);
+        dinv[r] = 0.0;
+    } else {
+        dinv[r] = 1.0 / d;
+    }
+}
+
+int extract_dinv(pib_solver *s, int *n_missing)
+{
+    DeviceCsr &A = s->A;
+    if (A.dinv == nullptr) PIB_HIP(hipMalloc(&A.dinv, (size_t)(A.n > 0 ? A.n : 1) * sizeof(double)));
+    int *d_missing = nullptr;
+    PIB_HIP(hipMalloc(&d_missing, sizeof(int)));
+    PIB_HIP(hipMemsetAsync(d_missing, 0, sizeof(int), s->stream));
+    if (A.n > 0) {
+        const int nb = (int)((A.n + 255) / 256);
+        if (A.rp64)
+            hipLaunchKernelGGL(k_extract_dinv<int64_t>, dim3(nb), dim3(256), 0, s->stream, A.n, A.ghost_lo,
+                               (const int64_t *)A.rowptr, A.col, A.val, A.dinv, d_missing);
+        else
+            hipLaunchKernelGGL(k_extract_dinv<int32_t>, dim3(nb), dim3(256), 0, s->stream, A.n, A.ghost_lo,
+                               (const int32_t *)A.rowptr, A.col, A.val, A.dinv, d_missing);
+        PIB_HIP(hipGetLastError());
+    }
+    int h = 0;
+    PIB_HIP(hipMemcpyAsync(&h, d_missing, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    PIB_HIP(hipFree(d_missing));
+    *n_missing = h;
+    return 0;
+}
+
+}  // namespace pib

@@ -1,0 +1,200 @@
+// pib_internal.hpp -- internal types of libpetibm_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/petibm_amd.h"
+
+namespace pib {
+
+int fail(int code, const char *fmt, ...);  // records the message, returns code
+const char *last_error();
+
+#define PIB_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return pib::fail(PIB_ERR_LIB, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call,            \
+                             hipGetErrorString(e_));                                                    \
+    } while (0)
+#define PIB_NCCL(call)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t e_ = (call);                                                                       \
+        if (e_ != ncclSuccess)                                                                          \
+            return pib::fail(PIB_ERR_LIB, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call,            \
+                             ncclGetErrorString(e_));                                                   \
+    } while (0)
+#define PIB_CHK(call)                   \
+    do {                                \
+        int e_ = (call);                \
+        if (e_ != 0) return e_;         \
+    } while (0)
+
+// ------------------------------------------------------------------ config
+enum class Flavor { AMGX, KSP };
+enum class Method { CG, BICGSTAB, PREONLY };
+enum class Precond { NONE, JACOBI, GMG };
+enum class Smoother { JACOBI, CHEBYSHEV };
+enum class NormType { PRECONDITIONED, UNPRECONDITIONED };
+
+struct Config {
+    Flavor flavor = Flavor::AMGX;
+    Method method = Method::CG;
+    Precond pc = Precond::NONE;
+    NormType norm = NormType::UNPRECONDITIONED;
+    int max_iters = 100;       // AmgX default; KSP default 10000
+    double rtol = 0.0;         // relative to the initial monitored norm
+    double atol = 1e-12;       // absolute
+    double dtol = 1e4;         // KSP divergence tolerance (AmgX: disabled)
+    bool monitor_residual = true;
+    bool store_res_history = true;
+    bool error_if_not_converged = true;
+    bool initial_guess_nonzero = true;  // AmgX: x is the guess; KSP: false
+    double jacobi_relaxation = 1.0;     // AmgX BLOCK_JACOBI relaxation_factor (as PC)
+    // geometric multigrid (stands in for AmgX AMG / PCGAMG)
+    int presweeps = 1, postsweeps = 1;
+    Smoother smoother = Smoother::JACOBI;
+    double smoother_relaxation = 0.9;
+    int cheby_degree = 2;
+    int max_levels = 100;
+    int min_coarse_rows = 2;
+    int dense_lu_num_rows = 128;  // coarsest level size at which coarsening stops
+    int coarsest_sweeps = 32;
+    // execution
+    int check_every = 0;     // iterations enqueued between host convergence polls (0 = auto)
+    int use_graph = 1;       // capture the iteration body in a hipGraph (single GPU)
+    int spmv_variant = 0;    // 0 = auto
+    int overlap_halo = 1;
+    std::string raw;
+};
+
+int parse_config_text(const std::string &text, const std::string &name, Config &cfg);
+int parse_config_file(const char *path, const std::string &name, Config &cfg);
+
+// ------------------------------------------------------------- device scalars
+// One block of scalars in HBM drives the Krylov recurrences: no host round
+// trip inside an iteration.  Every iteration kernel starts with `if (S->done)
+// return;` so over-enqueued iterations are no-ops.
+constexpr int PIB_NRED = 8;       // reduction slots
+constexpr int PIB_MAXPART = 4096; // partial sums per slot (>= max blocks of a reduction)
+struct Scalars {
+    double red[PIB_NRED];  // finalized (and all-reduced) sums
+    double beta, betaold, dpi, dpiold, dp, a, b;
+    double rho, rhoold, alpha, omega, omegaold;  // BiCGStab
+    double rnorm0, ttol, atol, rtol, dtol;
+    double mean;  // null-space projection
+    int its;      // completed iterations
+    int reason;   // 0 while running
+    int done;     // != 0: all further kernels are no-ops
+    int maxit;
+    int normtype;  // 0 preconditioned 1 unpreconditioned
+    int pad;
+};
+
+// ------------------------------------------------------------------ matrix
+struct DeviceCsr {
+    int64_t n = 0;        // local rows
+    int64_t nnz = 0;
+    int64_t row0 = 0;     // global index of local row 0
+    int64_t n_global = 0;
+    int64_t ghost_lo = 0, ghost_hi = 0;  // halo widths: local col index = global col - (row0 - ghost_lo)
+    bool rp64 = false;
+    void *rowptr = nullptr;   // int32 or int64 [n+1], values relative to this rank's first nnz
+    int32_t *col = nullptr;   // local (ghost-shifted) column index
+    double *val = nullptr;
+    double *dinv = nullptr;   // 1/diag
+    int64_t first_boundary_lo = 0;  // rows [0, n_lo) touch the low halo
+    int64_t n_lo = 0, n_hi = 0;     // rows touching the low / high halo (contiguous at both ends)
+    int64_t send_prev = 0, send_next = 0;  // entries the neighbours need from this rank
+    void release();
+};
+
+// grid hint / structured operator of one multigrid level (device arrays)
+struct GridLevel {
+    int dim = 0;
+    int64_t n[3] = {1, 1, 1};   // global cells
+    int64_t k0 = 0, k1 = 1;     // owned slab along the last axis
+    // face coefficient factors: off-diagonal toward +d of cell s is
+    //   c_d[s] * (product of the two perpendicular width arrays)
+    double *w[3] = {nullptr, nullptr, nullptr};  // [n[d]]
+    double *g[3] = {nullptr, nullptr, nullptr};  // [n[d]-1] (g[d][s] couples s and s+1), already * dt
+    double *dinv = nullptr;                      // 1/diag per local cell (with pinned handling)
+    double *x = nullptr, *b = nullptr, *r = nullptr;  // level vectors (ghost-padded along the slab axis)
+    int64_t nloc = 0, plane = 0;
+};
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+}  // namespace pib
+
+struct pib_solver {
+    std::string name, cfg_path, type_string;
+    pib::Config cfg;
+    pib::Comm comm;
+    int device = 0;
+    hipStream_t stream = nullptr, stream_comm = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr, ev_ready = nullptr;
+    pib::DeviceCsr A;
+    bool has_matrix = false;
+    // grid hint
+    bool has_grid = false;
+    int nullspace = PIB_NULLSPACE_NONE;
+    std::vector<pib::GridLevel> levels;
+    // work vectors: each ghost-padded [ghost_lo + n + ghost_hi]
+    double *work = nullptr, *work_base = nullptr;
+    int64_t work_stride = 0;
+    int n_work = 0;
+    double *x_dev = nullptr, *b_dev = nullptr;  // staging for host-pointer callers
+    int64_t stage_n = 0;
+    pib::Scalars *d_s = nullptr, *h_s = nullptr;
+    double *d_part = nullptr;  // [PIB_NRED][PIB_MAXPART]
+    double *d_hist = nullptr;
+    int hist_cap = 0;
+    hipGraphExec_t graph = nullptr;
+    int graph_iters = 0;
+    // results of the last solve
+    int iters = 0, reason = 0;
+    double residual = 0.0;
+    std::vector<double> history;
+    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double *vec(int i) const { return work + (int64_t)i * work_stride + A.ghost_lo; }
+};
+
+namespace pib {
+// kernels_spmv.hip
+int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, int64_t r_end, double *dot_part,
+              bool guarded, hipStream_t st);
+int spmv_launch_blocks();
+int extract_dinv(pib_solver *s, int *n_missing);
+// halo.cpp
+int comm_init(pib_solver *s, int rank, int nranks, const void *uid);
+int comm_setup_halo(pib_solver *s);
+int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st);
+int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, int64_t hi, int64_t send_prev,
+                         int64_t send_next, hipStream_t st);
+int allreduce_slots(pib_solver *s, int first, int count, hipStream_t st);
+// krylov.hip
+int solve_cg(pib_solver *s, double *x, const double *b);
+int solve_bicgstab(pib_solver *s, double *x, const double *b);
+int ensure_work(pib_solver *s, int nvec);
+// assemble.hip
+int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);
+int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rowptr,
+               const int64_t *col, const int32_t *rowptr32, const int32_t *col32, const double *val);
+void slab_range(int64_t nplanes, int nranks, int rank, int64_t *b, int64_t *e);
+// gmg.hip
+int gmg_setup(pib_solver *s);
+int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t st);
+void gmg_release(pib_solver *s);
+int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double *const g[3],
+                  int nullspace);
+}  // namespace pib
