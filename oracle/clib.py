@@ -126,3 +126,67 @@ def cg(m, b, **kw):
 def bcgs(m, b, **kw):
     """KSPBCGS restatement -- see oracle/csrc/oracle.c:orc_bcgs."""
     return _krylov(lib().orc_bcgs, m, b, **kw)
+
+
+# ------------------------------------------------------------------ GMG oracle
+class GMG:
+    """CPU restatement of the build's geometric V-cycle (oracle/csrc/gmg.c)."""
+
+    def __init__(self, n, widths, dt, nullspace=1, pre=1, post=1, omega=0.9, coarsest_sweeps=32, max_levels=100):
+        L = lib()
+        L.orc_gmg_create.restype = C.c_void_p
+        L.orc_gmg_create.argtypes = [C.c_int, _i64p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
+                                     C.c_int, C.c_double, C.c_int, C.c_int]
+        L.orc_gmg_destroy.argtypes = [C.c_void_p]
+        L.orc_gmg_apply.argtypes = [C.c_void_p, _f64p, _f64p]
+        L.orc_gmg_apply_operator.argtypes = [C.c_void_p, C.c_int, _f64p, _f64p]
+        L.orc_gmg_num_levels.argtypes = [C.c_void_p]
+        L.orc_gmg_level_size.argtypes = [C.c_void_p, C.c_int, _i64p]
+        L.orc_pcg_gmg.restype = C.c_int
+        L.orc_pcg_gmg.argtypes = [C.c_void_p, C.c_int64, _i64p, _i64p, _f64p, C.c_int, C.c_double, C.c_double, C.c_int,
+                                  C.c_int, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]
+        self.dim = len(n)
+        self.n = np.array(list(n), dtype=np.int64)
+        self._w = [np.ascontiguousarray(w, dtype=np.float64) for w in widths]
+        p = [w.ctypes.data for w in self._w] + [None] * (3 - self.dim)
+        self._h = L.orc_gmg_create(self.dim, self.n, p[0], p[1], p[2], float(dt), int(nullspace), int(pre), int(post),
+                                   float(omega), int(coarsest_sweeps), int(max_levels))
+        self.N = int(np.prod(self.n))
+        self.nullspace = nullspace
+
+    def num_levels(self):
+        return int(lib().orc_gmg_num_levels(self._h))
+
+    def level_size(self, lev):
+        out = np.zeros(3, dtype=np.int64)
+        lib().orc_gmg_level_size(self._h, lev, out)
+        return out
+
+    def apply(self, r):
+        z = np.empty(self.N)
+        lib().orc_gmg_apply(self._h, np.ascontiguousarray(r, dtype=np.float64), z)
+        return z
+
+    def apply_operator(self, x, lev=0):
+        n = int(np.prod(self.level_size(lev)))
+        y = np.empty(n)
+        lib().orc_gmg_apply_operator(self._h, lev, np.ascontiguousarray(x, dtype=np.float64), y)
+        return y
+
+    def pcg(self, m, b, x0=None, norm="unpreconditioned", rtol=1e-10, atol=0.0, maxit=1000):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros(m.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
+        hist = np.full(maxit + 2, np.nan)
+        its, rn = C.c_int(0), C.c_double(0)
+        reason = lib().orc_pcg_gmg(self._h, m.n_rows, m.rowptr, m.col, m.val, NORM[norm], rtol, atol, int(maxit),
+                                   int(x0 is not None), b, x, C.byref(its), C.byref(rn), hist.ctypes.data)
+        return {"x": x, "iters": its.value, "rnorm": rn.value, "reason": int(reason),
+                "history": hist[: its.value + 1].copy()}
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_gmg_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -245,7 +245,7 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
         (void)hipFree(dw[d]);
         (void)hipFree(dg[d]);
     }
-    return grid_register(s, dim, n, cw, cg, nullspace);
+    return grid_register(s, dim, n, cw, cg, nullspace, dt);
 }
 
 }  // namespace pib

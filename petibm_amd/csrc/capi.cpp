@@ -152,7 +152,7 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
     const double one = 1.0;
     const double *w[3] = {wx, wy, (dim == 3) ? wz : &one};
     const double *g[3] = {gx, gy, (dim == 3) ? gz : nullptr};
-    return grid_register(s, dim, n, w, g, nullspace);
+    return grid_register(s, dim, n, w, g, nullspace, -1.0);
 }
 
 int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,

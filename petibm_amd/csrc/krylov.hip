@@ -154,20 +154,22 @@ static int finalize(pib_solver *s, int slot0, int nslots, int count, hipStream_t
 }
 
 // ------------------------------------------------------------------ ops
-// reduction slot map (CG): 0 z.r  1 z.z  2 r.r  3 sum z  4 sum r  5 p.w
+// reduction slot map (CG): 0 z.r  1 z.z  2 sum z  3 z[0] (pinned GMG)  4 r.r  5 sum r  6 p.w
+constexpr int SLOT_PW = 6;
 enum { PCM_NONE = 0, PCM_JACOBI = 1, PCM_EXTERNAL = 2 };
 
-// r = b - w (guess) or r = b ; z = M^-1 r ; partials 0..4
+// r = b - w (guess) or r = b ; z = M^-1 r ; partials 0..5
 template <int PCM>
 struct OpInit {
-    static constexpr int NRED = 5;
+    static constexpr int NRED = 6;
     const double *b, *w, *dinv;
     double *r, *z;
     double omega;
     int guess;
+    int pin0;  // this rank owns the pinned row 0: its residual is exactly 0 (x[0] = b[0] was set)
     __device__ void prepare(const Scalars *) {}
     template <int W>
-    __device__ void apply(int64_t i, double (&acc)[5]) const
+    __device__ void apply(int64_t i, double (&acc)[6]) const
     {
         Pack<W> vb = ld<W>(b, i), vr, vz;
         if (guess) {
@@ -177,6 +179,7 @@ struct OpInit {
         } else {
             vr = vb;
         }
+        if (pin0 && i == 0) vr.v[0] = 0.0;
         if (PCM == PCM_JACOBI) {
             Pack<W> vd = ld<W>(dinv, i);
 #pragma unroll
@@ -190,9 +193,9 @@ struct OpInit {
         for (int k = 0; k < W; ++k) {
             acc[0] += vz.v[k] * vr.v[k];
             acc[1] += vz.v[k] * vz.v[k];
-            acc[2] += vr.v[k] * vr.v[k];
-            acc[3] += vz.v[k];
-            acc[4] += vr.v[k];
+            acc[2] += vz.v[k];
+            acc[4] += vr.v[k] * vr.v[k];
+            acc[5] += vr.v[k];
         }
     }
 };
@@ -200,14 +203,14 @@ struct OpInit {
 // x += a p ; r -= a w ; z = M^-1 r ; partials 0..4
 template <int PCM>
 struct OpUpdateXR {
-    static constexpr int NRED = 5;
+    static constexpr int NRED = 6;
     const double *p, *w, *dinv;
     double *x, *r, *z;
     double omega;
     double a;
     __device__ void prepare(const Scalars *S) { a = S->a; }
     template <int W>
-    __device__ void apply(int64_t i, double (&acc)[5]) const
+    __device__ void apply(int64_t i, double (&acc)[6]) const
     {
         Pack<W> vp = ld<W>(p, i), vw = ld<W>(w, i), vx = ld<W>(x, i), vr = ld<W>(r, i), vz;
 #pragma unroll
@@ -229,26 +232,27 @@ struct OpUpdateXR {
         for (int k = 0; k < W; ++k) {
             acc[0] += vz.v[k] * vr.v[k];
             acc[1] += vz.v[k] * vz.v[k];
-            acc[2] += vr.v[k] * vr.v[k];
-            acc[3] += vz.v[k];
-            acc[4] += vr.v[k];
+            acc[2] += vz.v[k];
+            acc[4] += vr.v[k] * vr.v[k];
+            acc[5] += vr.v[k];
         }
     }
 };
 
-// partials 0 z.r, 1 z.z, (2 untouched), 3 sum z -- after an external PC apply
+// partials 0 z.r, 1 z.z, 2 sum z -- after an external PC apply
 struct OpDotZR {
-    static constexpr int NRED = 2;
+    static constexpr int NRED = 3;
     const double *z, *r;
     __device__ void prepare(const Scalars *) {}
     template <int W>
-    __device__ void apply(int64_t i, double (&acc)[2]) const
+    __device__ void apply(int64_t i, double (&acc)[3]) const
     {
         Pack<W> vz = ld<W>(z, i), vr = ld<W>(r, i);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             acc[0] += vz.v[k] * vr.v[k];
             acc[1] += vz.v[k] * vz.v[k];
+            acc[2] += vz.v[k];
         }
     }
 };
@@ -324,18 +328,34 @@ __device__ __forceinline__ void converged_default(Scalars *S, double dp)
     }
 }
 
-// flags: bit0 lazy mean (null space, PC none/Jacobi)
-__global__ void k_cg_s_init(Scalars *S, double *hist, double n_global, int lazy_mean, int monitor)
+// lazy: 0 no shift; 1 z <- z - mean(z) (constant null space); 2 z <- z - z[0] (pinned pressure + multigrid).
+// The shift m is applied lazily: p = (z - m) + b p in OpUpdateP, and the dot products are corrected here:
+//   (z-m).r = z.r - m sum(r) ;  |z-m|^2 = z.z - 2 m sum(z) + n m^2
+__device__ __forceinline__ void lazy_shift(Scalars *S, double n_global, int lazy, double &zr, double &zz)
 {
-    double zr = S->red[0], zz = S->red[1], rr = S->red[2];
-    double mean = 0.0;
-    if (lazy_mean) {
-        mean = S->red[3] / n_global;
-        zr = zr - mean * S->red[4];
-        zz = zz - n_global * mean * mean;
+    double m = 0.0;
+    if (lazy == 1) m = S->red[2] / n_global;
+    if (lazy == 2) m = S->red[3];
+    if (lazy) {
+        zr = zr - m * S->red[5];
+        zz = (zz - 2.0 * m * S->red[2]) + n_global * m * m;
         if (zz < 0.0) zz = 0.0;
     }
-    S->mean = mean;
+    S->mean = m;
+}
+
+__global__ void k_fetch_z0(Scalars *S, const double *z, int owner)
+{
+    if (S->done) return;
+    S->red[3] = owner ? z[0] : 0.0;
+}
+
+__global__ void k_pin_x0(double *x, const double *b) { x[0] = b[0]; }
+
+__global__ void k_cg_s_init(Scalars *S, double *hist, double n_global, int lazy_mean, int monitor)
+{
+    double zr = S->red[0], zz = S->red[1], rr = S->red[4];
+    lazy_shift(S, n_global, lazy_mean, zr, zz);
     const double dp = (S->normtype == 0) ? sqrt(zz) : sqrt(rr);
     S->dp = dp;
     S->rnorm0 = dp;
@@ -366,7 +386,7 @@ __global__ void k_cg_s1(Scalars *S)
 {
     if (S->done) return;
     S->dpiold = S->dpi;
-    const double dpi = S->red[5];
+    const double dpi = S->red[6];
     S->dpi = dpi;
     if (dpi == 0.0 || dpi != dpi || (S->its > 0 && ((dpi > 0.0) != (S->dpiold > 0.0)))) {
         S->reason = (dpi != dpi) ? PIB_DIVERGED_NANORINF : PIB_DIVERGED_INDEFINITE_MAT;
@@ -383,14 +403,8 @@ __global__ void k_cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean
                         int conv_is_its)
 {
     if (S->done) return;
-    double zr = S->red[0], zz = S->red[1], rr = S->red[2];
-    if (lazy_mean) {
-        const double mean = S->red[3] / n_global;
-        S->mean = mean;
-        zr = zr - mean * S->red[4];
-        zz = zz - n_global * mean * mean;
-        if (zz < 0.0) zz = 0.0;
-    }
+    double zr = S->red[0], zz = S->red[1], rr = S->red[4];
+    if (do_beta) lazy_shift(S, n_global, lazy_mean, zr, zz);
     if (do_norm) {
         const double dp = (S->normtype == 0) ? sqrt(zz) : sqrt(rr);
         S->dp = dp;
@@ -498,6 +512,21 @@ static int fetch_results(pib_solver *s)
 }
 
 // ------------------------------------------------------------------ CG
+// Apply the multigrid preconditioner z = M^-1 r and finalize z.r, z.z, sum z (+ z[0] when pinned).
+static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guarded, hipStream_t q)
+{
+    int nb = 0;
+    s->gmg_guarded = guarded;
+    PIB_CHK(gmg_apply(s, R, Z, q));
+    s->counters[1]++;
+    OpDotZR dz{Z, R};
+    PIB_CHK(launch_vec(s, s->A.n, dz, true, 0, &nb, guarded, q));
+    hipLaunchKernelGGL(k_finalize, dim3(3), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);
+    hipLaunchKernelGGL(k_fetch_z0, dim3(1), dim3(1), 0, q, s->d_s, Z, (s->A.row0 == 0) ? 1 : 0);
+    PIB_HIP(hipGetLastError());
+    return allreduce_slots(s, 0, 4, q);
+}
+
 // x, b: device pointers, n_local entries.
 int solve_cg(pib_solver *s, double *x, const double *b)
 {
@@ -509,13 +538,17 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     const Precond pc = s->cfg.pc;
     const bool guess = s->cfg.initial_guess_nonzero;
     const double ng = (double)A.n_global;
-    const int lazy_mean = (s->nullspace == PIB_NULLSPACE_CONSTANT && pc != Precond::GMG) ? 1 : 0;
+    const bool gmg = (pc == Precond::GMG);
+    int lazy = 0;
+    if (s->nullspace == PIB_NULLSPACE_CONSTANT) lazy = 1;
+    if (s->nullspace == PIB_NULLSPACE_PINNED && gmg) lazy = 2;
     const int monitor = s->cfg.monitor_residual ? 1 : 0;
     const int conv_is_its = monitor ? 0 : 1;
+    const bool unprec = (s->cfg.norm == NormType::UNPRECONDITIONED);
     const bool v2 = aligned16(x) && aligned16(b);
     if (pc == Precond::NONE) Z = R;  // z aliases r
     if (pc == Precond::JACOBI && A.dinv == nullptr) return fail(PIB_ERR_ORDER, "Jacobi preconditioner without a diagonal");
-    if (pc == Precond::GMG && !s->has_grid)
+    if (gmg && !s->has_grid)
         return fail(PIB_ERR_ORDER,
                     "solver %s: a multigrid (AMG/GMG) preconditioner needs the grid structure: call "
                     "pib_set_grid_hint or pib_assemble_poisson before pib_solve", s->name.c_str());
@@ -523,35 +556,29 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     for (int k = 0; k < 8; ++k) s->counters[k] = 0;
     PIB_CHK(init_scalars(s));
     int nb = 0;
+    const int pin0 = (lazy == 2 && A.row0 == 0) ? 1 : 0;
 
     // ---- initial residual, z, norms
+    if (!guess) {
+        OpFill z0{x, 0.0};
+        PIB_CHK(launch_vec(s, n, z0, v2, 0, nullptr, false, q));
+    }
+    if (pin0) hipLaunchKernelGGL(k_pin_x0, dim3(1), dim3(1), 0, q, x, b);  // identity row 0: x[0] = b[0], r[0] = 0
     if (guess) {
         OpCopy cp{x, P};
         PIB_CHK(launch_vec(s, n, cp, v2, 0, nullptr, false, q));
         PIB_CHK(matmult(s, P, W, nullptr, false, q));
-    } else {
-        OpFill z0{x, 0.0};
-        PIB_CHK(launch_vec(s, n, z0, v2, 0, nullptr, false, q));
     }
     if (pc == Precond::JACOBI) {
-        OpInit<PCM_JACOBI> op{b, W, A.dinv, R, Z, omega, guess ? 1 : 0};
+        OpInit<PCM_JACOBI> op{b, W, A.dinv, R, Z, omega, guess ? 1 : 0, pin0};
         PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
     } else {
-        OpInit<PCM_NONE> op{b, W, nullptr, R, Z, 1.0, guess ? 1 : 0};
+        OpInit<PCM_NONE> op{b, W, nullptr, R, Z, 1.0, guess ? 1 : 0, pin0};
         PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
     }
-    if (pc == Precond::GMG) {
-        hipLaunchKernelGGL(k_finalize, dim3(5), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);  // r.r, sum r (done==0)
-        PIB_CHK(allreduce_slots(s, 0, 5, q));
-        PIB_CHK(gmg_apply(s, R, Z, q));
-        s->counters[1]++;
-        OpDotZR dz{Z, R};
-        PIB_CHK(launch_vec(s, n, dz, true, 0, &nb, false, q));
-        PIB_CHK(finalize(s, 0, 2, nb, q));
-    } else {
-        PIB_CHK(finalize(s, 0, 5, nb, q));
-    }
-    hipLaunchKernelGGL(k_cg_s_init, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy_mean, monitor);
+    PIB_CHK(finalize(s, 0, 6, nb, q));
+    if (gmg) PIB_CHK(gmg_pc_and_dots(s, R, Z, false, q));
+    hipLaunchKernelGGL(k_cg_s_init, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, monitor);
     PIB_HIP(hipGetLastError());
 
     // ---- iterations
@@ -559,15 +586,15 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     const int spmv_blocks = spmv_launch_blocks();
     int enq = 0;
     const int maxit = s->cfg.max_iters;
-    double *part5 = s->d_part + (int64_t)5 * PIB_MAXPART;
+    double *part_pw = s->d_part + (int64_t)SLOT_PW * PIB_MAXPART;
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(batch, maxit - enq);
         for (int it = 0; it < todo; ++it) {
             OpUpdateP up{Z, P, 0.0, 0.0, 0};
             PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
-            PIB_CHK(matmult(s, P, W, part5, true, q));
-            PIB_CHK(finalize(s, 5, 1, spmv_blocks, q));
+            PIB_CHK(matmult(s, P, W, part_pw, true, q));
+            PIB_CHK(finalize(s, SLOT_PW, 1, spmv_blocks, q));
             hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s);
             if (pc == Precond::JACOBI) {
                 OpUpdateXR<PCM_JACOBI> op{P, W, A.dinv, x, R, Z, omega, 0.0};
@@ -576,23 +603,15 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 OpUpdateXR<PCM_NONE> op{P, W, nullptr, x, R, Z, 1.0, 0.0};
                 PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, true, q));
             }
-            if (pc == Precond::GMG) {
-                PIB_CHK(finalize(s, 0, 5, nb, q));
-                const bool unprec = (s->cfg.norm == NormType::UNPRECONDITIONED);
-                if (unprec) {
+            PIB_CHK(finalize(s, 0, 6, nb, q));
+            if (gmg) {
+                if (unprec)
                     hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, 0, 1, 0, conv_is_its);
-                }
-                PIB_CHK(gmg_apply(s, R, Z, q));
-                s->counters[1]++;
-                OpDotZR dz{Z, R};
-                PIB_CHK(launch_vec(s, n, dz, true, 0, &nb, true, q));
-                PIB_CHK(finalize(s, 0, 2, nb, q));
-                hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, 0, unprec ? 0 : 1, 1,
+                PIB_CHK(gmg_pc_and_dots(s, R, Z, true, q));
+                hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, unprec ? 0 : 1, 1,
                                    conv_is_its);
             } else {
-                PIB_CHK(finalize(s, 0, 5, nb, q));
-                hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy_mean, 1, 1,
-                                   conv_is_its);
+                hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, 1, 1, conv_is_its);
             }
             PIB_HIP(hipGetLastError());
         }
@@ -604,10 +623,372 @@ int solve_cg(pib_solver *s, double *x, const double *b)
 
 }  // namespace pib
 
-// ------------------------------------------------------------ BiCGStab (stub until K10 lands)
+// ------------------------------------------------------------------ BiCGStab (K10)
+// PETSc's KSPBCGS recurrences (oracle/csrc/oracle.c:orc_bcgs):
+//   KSP flavour : left preconditioning, recurrences on the preconditioned residual
+//   AmgX flavour: PBICGSTAB, right preconditioning, true-residual L2 norm
+// used for the velocity system A = I/dt - c nu L (navierstokes.cpp:342-344), which is
+// non-symmetric on stretched meshes (createlaplacian.cpp row scaling).
+// reduction slots: 0 |r|^2  1 r.rp  2 v.rp  3 s.t  4 t.t
 namespace pib {
-int solve_bicgstab_impl(pib_solver *s, double *x, const double *b);
+
+template <int PCM>
+struct OpBInit {  // r = M^-1 (b - w) (left) or b - w (right); rp = r; p = v = 0
+    static constexpr int NRED = 1;
+    const double *b, *w, *dinv;
+    double *r, *rp, *p, *v;
+    double omega_pc;
+    int guess, left;
+    __device__ void prepare(const Scalars *) {}
+    template <int W>
+    __device__ void apply(int64_t i, double (&acc)[1]) const
+    {
+        Pack<W> vb = ld<W>(b, i), vr, zero;
+        if (guess) {
+            Pack<W> vw = ld<W>(w, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vr.v[k] = vb.v[k] - vw.v[k];
+        } else {
+            vr = vb;
+        }
+        if (PCM == PCM_JACOBI && left) {
+            Pack<W> vd = ld<W>(dinv, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vr.v[k] = omega_pc * (vd.v[k] * vr.v[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            zero.v[k] = 0.0;
+            acc[0] += vr.v[k] * vr.v[k];
+        }
+        st<W>(r, i, vr);
+        st<W>(rp, i, vr);
+        st<W>(p, i, zero);
+        st<W>(v, i, zero);
+    }
+};
+
+template <int PCM>
+struct OpBUpdateP {  // p = r - (omegaold*beta) v + beta p ; right: ph = M^-1 p
+    static constexpr int NRED = 0;
+    const double *r, *v, *dinv;
+    double *p, *ph;
+    double omega_pc;
+    int left;
+    double beta, ob;
+    __device__ void prepare(const Scalars *S)
+    {
+        beta = S->b;
+        ob = S->omegaold * S->b;
+    }
+    template <int W>
+    __device__ void apply(int64_t i, double (&)[1]) const
+    {
+        Pack<W> vr = ld<W>(r, i), vv = ld<W>(v, i), vp = ld<W>(p, i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) vp.v[k] = (vr.v[k] - ob * vv.v[k]) + beta * vp.v[k];
+        st<W>(p, i, vp);
+        if (!left && PCM == PCM_JACOBI) {
+            Pack<W> vd = ld<W>(dinv, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vp.v[k] = omega_pc * (vd.v[k] * vp.v[k]);
+            st<W>(ph, i, vp);
+        }
+    }
+};
+
+template <int PCM>
+struct OpBPcDot {  // left: out = M^-1 in ; partial slot = out . other
+    static constexpr int NRED = 1;
+    const double *in, *dinv, *other;
+    double *out;
+    double omega_pc;
+    __device__ void prepare(const Scalars *) {}
+    template <int W>
+    __device__ void apply(int64_t i, double (&acc)[1]) const
+    {
+        Pack<W> vi = ld<W>(in, i), vo = ld<W>(other, i);
+        if (PCM == PCM_JACOBI) {
+            Pack<W> vd = ld<W>(dinv, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vi.v[k] = omega_pc * (vd.v[k] * vi.v[k]);
+            st<W>(out, i, vi);
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc[0] += vi.v[k] * vo.v[k];
+    }
+};
+
+template <int PCM>
+struct OpBUpdateS {  // s = r - alpha v ; right: sh = M^-1 s
+    static constexpr int NRED = 0;
+    const double *r, *v, *dinv;
+    double *sv, *sh;
+    double omega_pc;
+    int left;
+    double alpha;
+    __device__ void prepare(const Scalars *S) { alpha = S->alpha; }
+    template <int W>
+    __device__ void apply(int64_t i, double (&)[1]) const
+    {
+        Pack<W> vr = ld<W>(r, i), vv = ld<W>(v, i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) vr.v[k] = vr.v[k] - alpha * vv.v[k];
+        st<W>(sv, i, vr);
+        if (!left && PCM == PCM_JACOBI) {
+            Pack<W> vd = ld<W>(dinv, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vr.v[k] = omega_pc * (vd.v[k] * vr.v[k]);
+            st<W>(sh, i, vr);
+        }
+    }
+};
+
+template <int PCM>
+struct OpBPcDot2 {  // left: t = M^-1 in ; partials s.t (slot 3) t.t (slot 4)
+    static constexpr int NRED = 2;
+    const double *in, *dinv, *sv;
+    double *t;
+    double omega_pc;
+    int left;
+    __device__ void prepare(const Scalars *) {}
+    template <int W>
+    __device__ void apply(int64_t i, double (&acc)[2]) const
+    {
+        Pack<W> vi = ld<W>(in, i), vs = ld<W>(sv, i);
+        if (left && PCM == PCM_JACOBI) {
+            Pack<W> vd = ld<W>(dinv, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vi.v[k] = omega_pc * (vd.v[k] * vi.v[k]);
+            st<W>(t, i, vi);
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            acc[0] += vs.v[k] * vi.v[k];
+            acc[1] += vi.v[k] * vi.v[k];
+        }
+    }
+};
+
+struct OpBUpdateX {  // x += alpha ph + omega sh ; r = s - omega t ; partials |r|^2 (0), r.rp (1)
+    static constexpr int NRED = 2;
+    const double *ph, *sh, *sv, *t, *rp;
+    double *x, *r;
+    double alpha, omega;
+    int only_alpha;  // t == 0 exit of PETSc: x += alpha p, nothing else
+    __device__ void prepare(const Scalars *S)
+    {
+        alpha = S->alpha;
+        omega = S->omega;
+    }
+    template <int W>
+    __device__ void apply(int64_t i, double (&acc)[2]) const
+    {
+        Pack<W> vp = ld<W>(ph, i), vsh = ld<W>(sh, i), vs = ld<W>(sv, i), vt = ld<W>(t, i), vx = ld<W>(x, i),
+                vrp = ld<W>(rp, i), vr;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            vx.v[k] = (vx.v[k] + alpha * vp.v[k]) + omega * vsh.v[k];
+            vr.v[k] = vs.v[k] - omega * vt.v[k];
+            acc[0] += vr.v[k] * vr.v[k];
+            acc[1] += vr.v[k] * vrp.v[k];
+        }
+        st<W>(x, i, vx);
+        st<W>(r, i, vr);
+    }
+};
+
+__global__ void k_b_s_init(Scalars *S, double *hist, int monitor)
+{
+    const double dp = sqrt(S->red[0]);
+    S->dp = dp;
+    S->rnorm0 = dp;
+    S->ttol = monitor ? fmax(S->rtol * dp, S->atol) : -1.0;
+    S->its = 0;
+    S->reason = 0;
+    S->done = 0;
+    hist[0] = dp;
+    converged_default(S, dp);
+    S->rho = S->red[0];  // rp = r  ->  <r,rp> = |r|^2
+    S->rhoold = 1.0;
+    S->alpha = 1.0;
+    S->omega = 1.0;
+    S->omegaold = 1.0;
+    if (!S->done && S->maxit <= 0) {
+        S->reason = PIB_DIVERGED_ITS;
+        S->done = 1;
+    }
+    if (!S->done && S->rho == 0.0) {
+        S->reason = PIB_DIVERGED_BREAKDOWN;
+        S->done = 1;
+    }
+    S->b = (S->rho / S->rhoold) * (S->alpha / S->omegaold);  // beta of the first iteration
 }
+
+__global__ void k_b_s_alpha(Scalars *S)
+{
+    if (S->done) return;
+    const double d1 = S->red[2];
+    if (d1 == 0.0 || d1 != d1) {
+        S->reason = (d1 != d1) ? PIB_DIVERGED_NANORINF : PIB_DIVERGED_BREAKDOWN;
+        S->done = 1;
+        return;
+    }
+    S->alpha = S->rho / d1;
+}
+
+__global__ void k_b_s_omega(Scalars *S)
+{
+    if (S->done) return;
+    const double d1 = S->red[3], d2 = S->red[4];
+    if (d2 == 0.0) {
+        // t = 0: PETSc accepts x += alpha p when s = 0 too; s.s is not available separately here, but
+        // t = K s = 0 with a non-singular operator means s = 0.
+        S->omega = 0.0;
+        return;
+    }
+    S->omega = d1 / d2;
+}
+
+__global__ void k_b_s_end(Scalars *S, double *hist, int conv_is_its)
+{
+    if (S->done) return;
+    const double dp = sqrt(S->red[0]);
+    S->dp = dp;
+    S->rhoold = S->rho;
+    S->omegaold = S->omega;
+    S->its += 1;
+    hist[S->its] = dp;
+    converged_default(S, dp);
+    if (!S->done && S->its >= S->maxit) {
+        S->reason = conv_is_its ? PIB_CONVERGED_ITS : PIB_DIVERGED_ITS;
+        S->done = 1;
+    }
+    if (S->done) return;
+    if (S->rhoold == 0.0 || S->omega == 0.0) {
+        S->reason = PIB_DIVERGED_BREAKDOWN;
+        S->done = 1;
+        return;
+    }
+    S->rho = S->red[1];
+    if (S->rho == 0.0) {
+        S->reason = PIB_DIVERGED_BREAKDOWN;
+        S->done = 1;
+        return;
+    }
+    S->b = (S->rho / S->rhoold) * (S->alpha / S->omegaold);
+}
+
+int solve_bicgstab(pib_solver *s, double *x, const double *b)
+{
+    const DeviceCsr &A = s->A;
+    const int64_t n = A.n;
+    hipStream_t q = s->stream;
+    const Precond pc = s->cfg.pc;
+    if (pc == Precond::GMG)
+        return fail(PIB_ERR_SUP, "solver %s: BiCGStab with a multigrid preconditioner is not supported (use Jacobi)",
+                    s->name.c_str());
+    if (pc == Precond::JACOBI && A.dinv == nullptr) return fail(PIB_ERR_ORDER, "Jacobi preconditioner without a diagonal");
+    PIB_CHK(ensure_work(s, 9));
+    double *R = s->vec(0), *RP = s->vec(1), *P = s->vec(2), *V = s->vec(3), *S = s->vec(4), *T = s->vec(5),
+           *T2 = s->vec(6), *PH = s->vec(7), *SH = s->vec(8);
+    const bool left = (s->cfg.norm == NormType::PRECONDITIONED);
+    const bool jac = (pc == Precond::JACOBI);
+    const bool guess = s->cfg.initial_guess_nonzero;
+    const double opc = jac ? s->cfg.jacobi_relaxation : 1.0;
+    const int monitor = s->cfg.monitor_residual ? 1 : 0;
+    const int conv_is_its = monitor ? 0 : 1;
+    const bool v2 = aligned16(x) && aligned16(b);
+    if (!jac || left) {  // no separate preconditioned copies needed
+        PH = P;
+        SH = S;
+    }
+    for (int k = 0; k < 8; ++k) s->counters[k] = 0;
+    PIB_CHK(init_scalars(s));
+    int nb = 0;
+    if (guess) {
+        OpCopy cp{x, PH == P ? PH : P};
+        // use T2 as the ghost-padded SpMV input so P stays free
+        OpCopy cp2{x, T2};
+        (void)cp;
+        PIB_CHK(launch_vec(s, n, cp2, v2, 0, nullptr, false, q));
+        PIB_CHK(matmult(s, T2, T, nullptr, false, q));
+    } else {
+        OpFill z0{x, 0.0};
+        PIB_CHK(launch_vec(s, n, z0, v2, 0, nullptr, false, q));
+    }
+    if (jac) {
+        OpBInit<PCM_JACOBI> op{b, T, A.dinv, R, RP, P, V, opc, guess ? 1 : 0, left ? 1 : 0};
+        PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
+    } else {
+        OpBInit<PCM_NONE> op{b, T, nullptr, R, RP, P, V, 1.0, guess ? 1 : 0, left ? 1 : 0};
+        PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
+    }
+    PIB_CHK(finalize(s, 0, 1, nb, q));
+    hipLaunchKernelGGL(k_b_s_init, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, monitor);
+    PIB_HIP(hipGetLastError());
+
+    const int batch = auto_batch(s);
+    const int maxit = s->cfg.max_iters;
+    int enq = 0;
+    PIB_CHK(poll(s));
+    while (!s->h_s->done && enq < maxit) {
+        const int todo = std::min(batch, maxit - enq);
+        for (int it = 0; it < todo; ++it) {
+            // p = r - omegaold*beta*v + beta*p  (+ ph = M^-1 p)
+            if (jac) {
+                OpBUpdateP<PCM_JACOBI> op{R, V, A.dinv, P, PH, opc, left ? 1 : 0, 0.0, 0.0};
+                PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
+            } else {
+                OpBUpdateP<PCM_NONE> op{R, V, nullptr, P, PH, 1.0, left ? 1 : 0, 0.0, 0.0};
+                PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
+            }
+            // v = K p ; d1 = v.rp
+            if (left && jac) {
+                PIB_CHK(matmult(s, P, T2, nullptr, true, q));
+                OpBPcDot<PCM_JACOBI> op{T2, A.dinv, RP, V, opc};
+                PIB_CHK(launch_vec(s, n, op, true, 2, &nb, true, q));
+            } else {
+                PIB_CHK(matmult(s, PH, V, nullptr, true, q));
+                OpBPcDot<PCM_NONE> op{V, nullptr, RP, V, 1.0};
+                PIB_CHK(launch_vec(s, n, op, true, 2, &nb, true, q));
+            }
+            PIB_CHK(finalize(s, 2, 1, nb, q));
+            hipLaunchKernelGGL(k_b_s_alpha, dim3(1), dim3(1), 0, q, s->d_s);
+            // s = r - alpha v (+ sh = M^-1 s)
+            if (jac) {
+                OpBUpdateS<PCM_JACOBI> op{R, V, A.dinv, S, SH, opc, left ? 1 : 0, 0.0};
+                PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
+            } else {
+                OpBUpdateS<PCM_NONE> op{R, V, nullptr, S, SH, 1.0, left ? 1 : 0, 0.0};
+                PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
+            }
+            // t = K s ; s.t, t.t
+            if (left && jac) {
+                PIB_CHK(matmult(s, S, T2, nullptr, true, q));
+                OpBPcDot2<PCM_JACOBI> op{T2, A.dinv, S, T, opc, 1};
+                PIB_CHK(launch_vec(s, n, op, true, 3, &nb, true, q));
+            } else {
+                PIB_CHK(matmult(s, SH, T, nullptr, true, q));
+                OpBPcDot2<PCM_NONE> op{T, nullptr, S, T, 1.0, 0};
+                PIB_CHK(launch_vec(s, n, op, true, 3, &nb, true, q));
+            }
+            PIB_CHK(finalize(s, 3, 2, nb, q));
+            hipLaunchKernelGGL(k_b_s_omega, dim3(1), dim3(1), 0, q, s->d_s);
+            // x += alpha ph + omega sh ; r = s - omega t ; |r|^2, r.rp
+            OpBUpdateX op{PH, SH, S, T, RP, x, R, 0.0, 0.0, 0};
+            PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, true, q));
+            PIB_CHK(finalize(s, 0, 2, nb, q));
+            hipLaunchKernelGGL(k_b_s_end, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, conv_is_its);
+            PIB_HIP(hipGetLastError());
+        }
+        enq += todo;
+        PIB_CHK(poll(s));
+    }
+    return fetch_results(s);
+}
+
+}  // namespace pib
 
 // ------------------------------------------------------------ instrumentation
 extern "C" int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_avg)

