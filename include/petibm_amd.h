@@ -97,6 +97,10 @@ int pib_create(pib_solver **s, const char *name, const char *cfg_path, int rank,
 /* Same, configuration given as text (tests; no temp files). */
 int pib_create_from_string(pib_solver **s, const char *name, const char *cfg_text, int rank, int nranks,
                            const void *uid_or_null, int device);
+/* Parse a configuration exactly as pib_create would and write a one-line
+ * normalised description ("flavor=amgx method=cg pc=gmg ...") into buf.  Pure
+ * host code (no GPU needed): lets a caller validate a *_solver.info file. */
+int pib_config_describe(const char *name, const char *cfg_text, char *buf, int buflen);
 /* LinSolverBase::destroy / AmgXSolver::finalize (linsolveramgx.cpp:37,47). */
 int pib_destroy(pib_solver *s);
 
@@ -140,6 +144,11 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
  * diag = 1) (navierstokes.cpp:414-420).  w[d] has n[d] entries, dt scalar. */
 int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                          const double *wz, double dt, int nullspace);
+
+/* The z-slab (y-slab in 2D) of planes [*begin, *end) that rank `rank` of `nranks`
+ * owns: the DMDA default split m = N/P + ((N % P) > rank) the reference gets from
+ * DMDACreate3d (src/mesh/cartesianmesh.cpp:492-538).  Pure host code. */
+int pib_slab_range(int64_t nplanes, int nranks, int rank, int64_t *begin, int64_t *end);
 
 /* ---- solve ------------------------------------------------------------------
  * LinSolverBase::solve(Vec &x, Vec &b) / AmgXSolver::solve(x, b)

@@ -41,6 +41,8 @@ _PROTOS = {
     "pib_comm_unique_id": (C.c_int, [_vp]),
     "pib_create": (C.c_int, [C.POINTER(_vp), C.c_char_p, C.c_char_p, C.c_int, C.c_int, _vp, C.c_int]),
     "pib_create_from_string": (C.c_int, [C.POINTER(_vp), C.c_char_p, C.c_char_p, C.c_int, C.c_int, _vp, C.c_int]),
+    "pib_config_describe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
+    "pib_slab_range": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "pib_destroy": (C.c_int, [_vp]),
     "pib_get_type": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "pib_set_csr": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
@@ -95,3 +97,15 @@ def _ptr(a):
     if isinstance(a, np.ndarray):
         return a.ctypes.data
     return int(a)  # raw device pointer
+
+
+def config_describe(name: str, text: str) -> dict:
+    """pib_config_describe as a dict (host-only; works without a GPU)."""
+    buf = C.create_string_buffer(2048)
+    check(load().pib_config_describe(name.encode(), text.encode(), buf, 2048))
+    out = {}
+    import shlex
+    for tok in shlex.split(buf.value.decode()):
+        k, _, v = tok.partition("=")
+        out[k] = v
+    return out

@@ -68,6 +68,34 @@ int pib_create_from_string(pib_solver **s, const char *name, const char *cfg_tex
     return make_solver(s, name, cfg, "<string>", rank, nranks, uid_or_null, device);
 }
 
+int pib_slab_range(int64_t nplanes, int nranks, int rank, int64_t *begin, int64_t *end)
+{
+    if (begin == nullptr || end == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_slab_range: null output");
+    if (nranks < 1 || rank < 0 || rank >= nranks || nplanes < 0) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_slab_range: bad arguments");
+    slab_range(nplanes, nranks, rank, begin, end);
+    return 0;
+}
+
+int pib_config_describe(const char *name, const char *cfg_text, char *buf, int buflen)
+{
+    if (buf == nullptr || buflen < 1) return fail(PIB_ERR_ARG_NULL, "pib_config_describe: null buffer");
+    Config c;
+    PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", c));
+    const char *method = c.method == Method::CG ? "cg" : (c.method == Method::BICGSTAB ? "bicgstab" : "preonly");
+    const char *pc = c.pc == Precond::NONE ? "none" : (c.pc == Precond::JACOBI ? "jacobi" : "gmg");
+    std::snprintf(buf, (size_t)buflen,
+                  "flavor=%s type=\"%s\" method=%s pc=%s norm=%s max_iters=%d rtol=%.17g atol=%.17g dtol=%.17g "
+                  "monitor=%d guess_nonzero=%d error_if_not_converged=%d jacobi_relaxation=%.17g presweeps=%d "
+                  "postsweeps=%d smoother=%s smoother_relaxation=%.17g coarsest_sweeps=%d max_levels=%d",
+                  c.flavor == Flavor::AMGX ? "amgx" : "ksp", c.flavor == Flavor::AMGX ? "NVIDIA AmgX" : "PETSc KSP",
+                  method, pc, c.norm == NormType::PRECONDITIONED ? "preconditioned" : "unpreconditioned", c.max_iters,
+                  c.rtol, c.atol, c.dtol, c.monitor_residual ? 1 : 0, c.initial_guess_nonzero ? 1 : 0,
+                  c.error_if_not_converged ? 1 : 0, c.jacobi_relaxation, c.presweeps, c.postsweeps,
+                  c.smoother == Smoother::JACOBI ? "jacobi" : "chebyshev", c.smoother_relaxation, c.coarsest_sweeps,
+                  c.max_levels);
+    return 0;
+}
+
 int pib_destroy(pib_solver *s)
 {
     if (s == nullptr) return 0;

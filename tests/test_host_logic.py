@@ -1,0 +1,191 @@
+"""CPU tests of the host logic and of the C-ABI surface (no GPU, no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# The keys of the AmgX-style files the reference ships for its GPU examples
+# (examples/navierstokes/liddrivencavity2dRe1000_GPU/config/poisson_solver.info) -- own text, same keys.
+AMGX_POISSON = """
+config_version=2
+communicator=MPI
+determinism_flag=1
+solver(solv)=PCG
+solv:max_iters=1000
+solv:monitor_residual=1
+solv:convergence=ABSOLUTE
+solv:tolerance=1.0E-06
+solv:norm=L2
+solv:store_res_history=1
+solv:preconditioner(prec)=AMG
+prec:algorithm=CLASSICAL
+prec:max_iters=1
+prec:cycle=V
+prec:presweeps=1
+prec:postsweeps=1
+prec:max_levels=100
+prec:min_coarse_rows=2
+prec:coarse_solver(c_solver)=DENSE_LU_SOLVER
+prec:dense_lu_num_rows=128
+prec:coarsest_sweeps=1
+prec:smoother(smooth)=BLOCK_JACOBI
+smooth:relaxation_factor=0.9
+"""
+AMGX_VELOCITY = """
+config_version=2
+solver(solv)=PBICGSTAB
+solv:max_iters=1000
+solv:monitor_residual=1
+solv:convergence=ABSOLUTE
+solv:tolerance=1.0E-14
+solv:norm=L2
+solv:store_res_history=1
+solv:preconditioner(prec)=BLOCK_JACOBI
+prec:relaxation_factor=0.9
+prec:max_iters=1
+"""
+PETSC_BOTH = """
+# Poisson solver: prefix `-poisson_`
+-poisson_ksp_type cg
+-poisson_ksp_atol 1.0E-06
+-poisson_ksp_rtol 0.0
+-poisson_ksp_max_it 1000
+-poisson_pc_type gamg
+-poisson_pc_gamg_type agg
+-poisson_pc_gamg_agg_nsmooths 1
+# velocity solver: prefix `-velocity_`
+-velocity_ksp_type bcgs
+-velocity_ksp_atol 1.0E-06
+-velocity_ksp_rtol 0.0
+-velocity_ksp_max_it 1000
+-velocity_pc_type jacobi
+-velocity_pc_jacobi_type diagonal
+"""
+
+
+@pytest.fixture(scope="module")
+def capi(built_library):
+    from petibm_amd import capi
+    capi.load()
+    return capi
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    """Every function include/petibm_amd.h declares is exported by the built library and bound in capi.py."""
+    header = open(os.path.join(ROOT, "include", "petibm_amd.h")).read()
+    declared = set(re.findall(r"\b(pib_[a-z0-9_]+)\s*\(", header))
+    from petibm_amd import capi
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", built_library], text=True)
+    exported = {ln.split()[-1] for ln in syms.splitlines() if ln.strip()}
+    assert declared <= exported, declared - exported
+    assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
+    # C ABI: no torch / C++ types leak into the exported names
+    assert all(not s.startswith("_Z") for s in declared)
+    # the header is plain C
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "petibm_amd.h")])
+
+
+def test_library_loads_and_has_no_cpu_fallback(capi):
+    lib = capi.load()
+    assert lib.pib_version() >= 100
+    import torch
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p()
+        code = lib.pib_create_from_string(ctypes.byref(h), b"poisson", b"", 0, 1, None, -1)
+        assert code == capi.ERR_LIB and b"no CPU fallback" in lib.pib_last_error()
+
+
+def test_amgx_config_subset(capi):
+    d = capi.config_describe("poisson", AMGX_POISSON)
+    assert d["flavor"] == "amgx" and d["type"] == "NVIDIA AmgX"
+    assert d["method"] == "cg" and d["pc"] == "gmg" and d["norm"] == "unpreconditioned"
+    assert int(d["max_iters"]) == 1000 and float(d["atol"]) == 1e-6 and float(d["rtol"]) == 0.0
+    assert d["smoother"] == "jacobi" and float(d["smoother_relaxation"]) == 0.9
+    assert (int(d["presweeps"]), int(d["postsweeps"])) == (1, 1) and int(d["guess_nonzero"]) == 1
+    v = capi.config_describe("velocity", AMGX_VELOCITY)
+    assert v["method"] == "bicgstab" and v["pc"] == "jacobi" and float(v["jacobi_relaxation"]) == 0.9
+    assert float(v["atol"]) == 1e-14
+    # an empty file = AmgX defaults (linsolveramgx.cpp:62-72 writes an empty temporary file)
+    e = capi.config_describe("forces", "")
+    assert e["method"] == "cg" and e["pc"] == "none" and int(e["max_iters"]) == 100 and int(e["monitor"]) == 0
+    r = capi.config_describe("poisson", AMGX_POISSON.replace("ABSOLUTE", "RELATIVE_INI_CORE"))
+    assert float(r["rtol"]) == 1e-6 and float(r["atol"]) == 0.0
+    # keys without a scope fall back to the default scope
+    f = capi.config_describe("p", "solver=PCG\nmax_iters=7\ntolerance=1e-3\nmonitor_residual=1\n")
+    assert int(f["max_iters"]) == 7 and float(f["atol"]) == 1e-3
+
+
+def test_petsc_options_subset(capi):
+    p = capi.config_describe("poisson", PETSC_BOTH)
+    assert p["flavor"] == "ksp" and p["type"] == "PETSc KSP"
+    assert p["method"] == "cg" and p["pc"] == "gmg" and p["norm"] == "preconditioned"
+    assert float(p["atol"]) == 1e-6 and float(p["rtol"]) == 0.0 and int(p["max_iters"]) == 1000
+    assert int(p["guess_nonzero"]) == 0 and int(p["error_if_not_converged"]) == 1 and float(p["dtol"]) == 1e4
+    v = capi.config_describe("velocity", PETSC_BOTH)
+    assert v["method"] == "bicgstab" and v["pc"] == "jacobi"
+    # another solver's prefix does not leak: KSP defaults (rtol 1e-5, atol 1e-50, 10000 its, CG)
+    f = capi.config_describe("forces", PETSC_BOTH)
+    assert f["method"] == "cg" and float(f["rtol"]) == 1e-5 and int(f["max_iters"]) == 10000
+
+
+@pytest.mark.parametrize("text,code", [
+    ("solver(s)=FGMRES\n", 56), ("solver(s)=PCG\ns:preconditioner(p)=MULTICOLOR_DILU\n", 56),
+    ("solver(s)=PCG\ns:convergence=RELATIVE_MAX\n", 56), ("solver(s)=PCG\ns:norm=L1\n", 56),
+    ("this is not a config\n", 62), ("-poisson_ksp_type gmres\n", 56), ("-poisson_pc_type lu\n", 56),
+])
+def test_unsupported_config_is_an_error(capi, text, code):
+    with pytest.raises(capi.PibError) as ei:
+        capi.config_describe("poisson", text)
+    assert ei.value.code == code
+
+
+def test_missing_config_file_and_null_arguments(capi):
+    lib = capi.load()
+    h = ctypes.c_void_p()
+    assert lib.pib_create(ctypes.byref(h), b"poisson", b"/nonexistent/solver.info", 0, 1, None, -1) == capi.ERR_FILE_OPEN
+    assert lib.pib_create(None, b"poisson", None, 0, 1, None, -1) in (capi.ERR_ARG_NULL, capi.ERR_LIB)
+    assert lib.pib_get_iters(None, None) == capi.ERR_ARG_NULL
+    assert lib.pib_solve(None, None, None) == capi.ERR_ARG_NULL
+    assert lib.pib_destroy(None) == 0
+
+
+def test_createlinsolver_factory_dispatch(capi, tmp_path):
+    """src/linsolver/linsolver.cpp:57-91: default type CPU, relative config path joined to `directory`,
+    unknown type -> PETSC_ERR_ARG_WRONG (62)."""
+    from petibm_amd import linsolver
+    node = {"directory": str(tmp_path), "parameters": {"poissonSolver": {"type": "GPU", "config": "config/p.info"}}}
+    with pytest.raises(capi.PibError) as ei:
+        linsolver.createLinSolver("poisson", node)  # file does not exist -> the joined path is reported
+    assert ei.value.code == capi.ERR_FILE_OPEN and str(tmp_path / "config" / "p.info") in ei.value.message
+    with pytest.raises(capi.PibError) as ei:
+        linsolver.createLinSolver("velocity", {"parameters": {}})  # default type: CPU, not provided here
+    assert ei.value.code == capi.ERR_ARG_WRONG
+    with pytest.raises(capi.PibError) as ei:
+        linsolver.createLinSolver("poisson", {"parameters": {"poissonSolver": {"type": "TPU"}}})
+    assert ei.value.code == capi.ERR_ARG_WRONG and "Unrecognized value" in ei.value.message
+
+
+def test_slab_range_matches_python_partition_and_dmda_rule(capi):
+    from petibm_amd import partition
+    from oracle import mesh as omesh
+    lib = capi.load()
+    for n, P in ((512, 8), (512, 4), (256, 8), (10, 4), (7, 3), (450, 8), (5, 5)):
+        got = []
+        for r in range(P):
+            b, e = ctypes.c_int64(), ctypes.c_int64()
+            assert lib.pib_slab_range(n, P, r, ctypes.byref(b), ctypes.byref(e)) == 0
+            got.append((b.value, e.value))
+            assert partition.slab_range(n, P, r) == (b.value, e.value)
+        assert got == omesh.slab_ranges(n, P)
+        assert got[0][0] == 0 and got[-1][1] == n and all(got[i][1] == got[i + 1][0] for i in range(P - 1))
+    plans = partition.all_plans((512, 512, 512), 8)
+    assert all(p.n_local == 64 * 512 * 512 for p in plans)
+    assert plans[0].ghost_lo == 0 and plans[0].ghost_hi == 512 * 512 and plans[7].ghost_hi == 0
+    # what a rank sends is what its neighbour receives
+    for a, b in zip(plans[:-1], plans[1:]):
+        assert a.send_next == b.ghost_lo and b.send_prev == a.ghost_hi

@@ -1,0 +1,119 @@
+"""The oracle's Krylov restatements (KSPCG / KSPBCGS recurrences, GMG-PCG) cross-checked against
+scipy.sparse.linalg -- an independent implementation of the published algorithms."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import clib, mesh as omesh, operators as oops
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_test_vectors.json")))
+
+
+@pytest.fixture(scope="module")
+def systems():
+    m = omesh.create_mesh(G["cartesianmesh2d_dirichlet"]["config"])
+    D, Gm, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, Gm, L, 0.01, 0.005)
+    Av = oops.create_velocity_operator(L, 0.01, 0.005)
+    return m, A, Av
+
+
+def test_spmv_order_and_value(systems):
+    m, A, _ = systems
+    x = np.random.default_rng(1).uniform(-1, 1, A.n_cols)
+    y = clib.spmv(A, x)
+    # canonical order: rounded products added sequentially in CSR order
+    for r in (0, 17, 131):
+        s = 0.0
+        for p in range(A.rowptr[r], A.rowptr[r + 1]):
+            s = s + A.val[p] * x[A.col[p]]
+        assert y[r] == s
+    assert np.allclose(y, A.to_dense() @ x, rtol=1e-13, atol=1e-18)
+
+
+def test_cg_matches_scipy_iterates(systems):
+    spla = pytest.importorskip("scipy.sparse.linalg")
+    m, A, _ = systems
+    P = oops.pin_row0(A)
+    rng = np.random.default_rng(2)
+    b = rng.uniform(-1, 1, A.n_rows)
+    b[0] = 0.0
+    # negative definite (+1 at the decoupled pinned row): PETSc's CG flags sign CHANGES only; scipy needs SPD
+    Ps = P.to_scipy().tolil()
+    Ps = -Ps
+    Ps[0, 0] = 1.0
+    Ps = Ps.tocsr()
+    its = []
+    x_sp, info = spla.cg(Ps, -b, rtol=1e-12, atol=0.0, maxiter=2000, callback=lambda xk: its.append(1))
+    assert info == 0
+    r = clib.cg(P, b, pc="none", norm="unpreconditioned", rtol=1e-12, atol=0.0, dtol=1e300, maxit=2000)
+    assert r["reason"] > 0
+    assert abs(r["iters"] - len(its)) <= 2
+    assert np.linalg.norm(r["x"] - x_sp) <= 1e-8 * np.linalg.norm(x_sp)
+    # monotone-ish history, first entry = ||b||
+    assert np.isclose(r["history"][0], np.linalg.norm(b))
+
+
+def test_cg_constant_nullspace_and_jacobi(systems):
+    m, A, _ = systems
+    xs = np.random.default_rng(3).uniform(-1, 1, A.n_rows)
+    xs -= xs.mean()
+    b = clib.spmv(A, xs)
+    for pc in ("none", "jacobi"):
+        for norm in ("preconditioned", "unpreconditioned"):
+            r = clib.cg(A, b, pc=pc, nullspace=1, norm=norm, rtol=1e-12, atol=0.0, dtol=1e300, maxit=3000)
+            assert r["reason"] > 0
+            e = r["x"] - r["x"].mean() - xs
+            assert np.linalg.norm(e) <= 1e-8 * np.linalg.norm(xs)
+    # KSPConvergedDefault: atol wins when larger; reason ATOL vs RTOL
+    r = clib.cg(A, b, pc="jacobi", nullspace=1, rtol=0.0, atol=1e-6, maxit=3000)
+    assert r["reason"] == 3 and r["rnorm"] < 1e-6
+    # max_it -> DIVERGED_ITS (-3)
+    r = clib.cg(A, b, pc="none", nullspace=1, rtol=1e-14, atol=0.0, maxit=3)
+    assert r["reason"] == -3 and r["iters"] == 3
+
+
+def test_bcgs_matches_scipy_solution(systems):
+    spla = pytest.importorskip("scipy.sparse.linalg")
+    m, _, Av = systems
+    us = np.random.default_rng(4).uniform(-1, 1, Av.n_rows)
+    b = clib.spmv(Av, us)
+    assert np.abs(Av.to_dense() - Av.to_dense().T).max() > 0  # non-symmetric on the stretched mesh
+    x_sp, info = spla.bicgstab(Av.to_scipy(), b, rtol=1e-13, atol=0.0, maxiter=500)
+    assert info == 0
+    for norm in ("preconditioned", "unpreconditioned"):
+        r = clib.bcgs(Av, b, pc="jacobi", norm=norm, rtol=0.0, atol=1e-12, dtol=1e300, maxit=500)
+        assert r["reason"] > 0 and r["iters"] < 20
+        assert np.linalg.norm(r["x"] - us) <= 1e-10 * np.linalg.norm(us)
+        assert np.linalg.norm(r["x"] - x_sp) <= 1e-9 * np.linalg.norm(us)
+
+
+@pytest.mark.parametrize("n", [(32, 32, 32), (20, 17, 9), (48, 40)])
+def test_gmg_oracle_properties(n):
+    """The build's V-cycle: the level-0 stencil twin equals the CSR operator, the preconditioner is
+    symmetric (<Mr,s> = <r,Ms> on zero-mean vectors), and PCG iteration counts are mesh-independent."""
+    m = omesh.create_mesh(omesh.uniform_config(n))
+    D, Gm, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    dt = 1e-3
+    _, A = oops.create_poisson_operator(D, Gm, L, dt, 0.5e-3)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    g = clib.GMG(n, w, dt, nullspace=1)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, m.pN)
+    ax = clib.spmv(A, x)
+    assert np.abs(g.apply_operator(x) - ax).max() <= 1e-13 * np.abs(ax).max()
+    r1 = rng.uniform(-1, 1, m.pN)
+    r2 = rng.uniform(-1, 1, m.pN)
+    r1 -= r1.mean()
+    r2 -= r2.mean()
+    z1, z2 = g.apply(r1), g.apply(r2)
+    z1 -= z1.mean()
+    z2 -= z2.mean()
+    assert abs(z1 @ r2 - r1 @ z2) <= 1e-10 * abs(z1 @ r2)
+    xs = x - x.mean()
+    b = clib.spmv(A, xs)
+    res = g.pcg(A, b, rtol=1e-10)
+    assert res["reason"] > 0 and res["iters"] <= 25
+    assert np.linalg.norm(b - clib.spmv(A, res["x"])) <= 1.2e-10 * np.linalg.norm(b)
