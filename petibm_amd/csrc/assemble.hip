@@ -75,8 +75,11 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
     const int64_t shift = row0 - A.ghost_lo;
     std::vector<int32_t> c32((size_t)std::max<int64_t>(nnz, 1));
     for (int64_t p = 0; p < nnz; ++p) c32[(size_t)p] = (int32_t)(CL(base + p) - shift);
-    PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
-    PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
+    // +4 entries of padding: the SpMV reads val/col in aligned pairs
+    PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMemset(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMemset(A.val, 0, sizeof(double) * (size_t)(nnz + 4)));
     PIB_HIP(hipMemcpy(A.col, c32.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     PIB_HIP(hipMemcpy(A.val, val + base, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     if (A.rp64) {
@@ -219,8 +222,10 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
     if (A.ghost_lo + A.n + A.ghost_hi >= (int64_t)std::numeric_limits<int32_t>::max())
         return fail(PIB_ERR_SUP, "assemble_poisson: local slab too large for 32-bit column indices");
     PIB_HIP(hipMalloc(&A.rowptr, (A.rp64 ? 8 : 4) * ((size_t)A.n + 1)));
-    PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)A.nnz));
-    PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)A.nnz));
+    PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(A.nnz + 4)));  // +4: the SpMV reads aligned pairs
+    PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(A.nnz + 4)));
+    PIB_HIP(hipMemsetAsync(A.col + A.nnz, 0, sizeof(int32_t) * 4, s->stream));
+    PIB_HIP(hipMemsetAsync(A.val + A.nnz, 0, sizeof(double) * 4, s->stream));
     double *dw[3] = {nullptr, nullptr, nullptr}, *dg[3] = {nullptr, nullptr, nullptr};
     for (int d = 0; d < 3; ++d) {
         PIB_CHK(upload_vec(hw[d], &dw[d]));

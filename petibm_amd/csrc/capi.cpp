@@ -110,6 +110,7 @@ int pib_destroy(pib_solver *s)
     if (s->d_s) (void)hipFree(s->d_s);
     if (s->h_s) (void)hipHostFree(s->h_s);
     if (s->d_part) (void)hipFree(s->d_part);
+    if (s->d_spmv_part) (void)hipFree(s->d_spmv_part);
     if (s->d_hist) (void)hipFree(s->d_hist);
     if (s->comm.comm) (void)ncclCommDestroy(s->comm.comm);
     if (s->ev_a) (void)hipEventDestroy(s->ev_a);

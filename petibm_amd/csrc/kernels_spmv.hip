@@ -7,22 +7,23 @@
 // 442,490,549,592).
 //
 // Design (HBM-bound, 0.13 flop/B; MFMA unused -- no dense contraction):
-//   * "CSR-stream": a 256-thread workgroup owns 256 consecutive rows.  The
-//     val/col arrays of those rows are one contiguous span, read with fully
-//     coalesced wave-wide loads (lane i reads entry p0+i); each lane multiplies
-//     its entries by the gathered x[col] and parks the products in LDS
-//     (16 KiB tile).  Then thread t adds up row t's products from LDS in CSR
-//     order.  HBM sees val/col/rowptr exactly once, perfectly coalesced.
-//   * x is gathered through L1/L2: for the 5/7-point operator in natural
-//     ordering a workgroup touches five short contiguous x windows
-//     (r0-nx*ny, r0-nx, r0-1..r0+R+1, r0+nx, r0+nx*ny); x is read from HBM
-//     once per SpMV and the re-reads hit the XCD's L2 / the 256 MiB MALL.
-//   * XCD-aware chunk order: workgroup b runs on XCD b%8 (observed dispatch
-//     rule, speed only); XCD x walks the contiguous chunk range
-//     [x*cpx,(x+1)*cpx) so the +-nx neighbours of a chunk are in the SAME
-//     XCD's 4 MiB L2 when the adjacent chunk needs them.
-//   * persistent grid (2048 workgroups = 8 per CU) with a chunk loop: a fixed,
-//     small number of partial sums when the p.Ap dot product is fused in.
+//   * default kernel k_spmv_lds ("LDS transpose"): a 256-thread workgroup owns
+//     256 consecutive rows.  Phase 1 copies the rows' contiguous val/col span
+//     into LDS with 16 B/8 B-per-lane fully coalesced loads (HBM sees
+//     val/col/rowptr exactly once).  Phase 2: thread t owns row t, reads its
+//     (val, col) pairs back from LDS (stride-7 accesses: bank-conflict free) and
+//     gathers x with the ROW-PER-LANE mapping, so one gather instruction reads
+//     ~64 consecutive x values (4-5 cache lines) instead of 9 rows x 7
+//     diagonals (10+ lines): the vector-L1 tag rate, not HBM, was what capped
+//     the entry-per-lane kernel (k_spmv_stream, kept as variant 1) at 50 %.
+//   * one chunk per workgroup, workgroups dispatched in sequence order: the
+//     chip sweeps a moving window of addresses (measured: persistent
+//     grid-stride loops stream 10-15 % slower on MI355X).
+//   * chunk order: with a 3-D grid hint the chunk sequence is "plane-
+//     interleaved tiles" (tile of tj grid lines, all z planes of the tile
+//     before the next tile): the +-nx*ny neighbours of a chunk are the chunks
+//     just before / after it in the sequence, so x is fetched from HBM ~once
+//     (rocprof FETCH_SIZE: 13.8 GB vs 15.4 GB in natural order at 512^3).
 //   * summation order per row is sequential in CSR order with rounded
 //     products (no FMA contraction: the library is built -ffp-contract=off),
 //     which the oracle reproduces -> bit-exact parity.
@@ -124,6 +125,114 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_stream(const Scalars *__res
     }
 }
 
+
+// ----------------------------------------------------------------------------
+// chunk order (see header): sequence position -> chunk id
+struct ChunkOrder {
+    int tiled;        // 0: natural
+    int64_t cpp;      // chunks per plane
+    int64_t cpt;      // chunks per tile
+    int64_t nplanes;
+};
+__device__ __forceinline__ int64_t chunk_of(const ChunkOrder &o, int64_t seq)
+{
+    if (!o.tiled) return seq;
+    const int64_t per_tile = o.cpt * o.nplanes;
+    const int64_t tile = seq / per_tile, rem = seq % per_tile;
+    const int64_t k = rem / o.cpt, w = rem % o.cpt;
+    return k * o.cpp + tile * o.cpt + w;
+}
+
+constexpr int LDS_ROWS = 256;
+constexpr int LDS_TILE = 2048;
+
+template <typename RP, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S, int64_t r_begin, int64_t r_end,
+                                                  const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                  const double *__restrict__ val, const double *__restrict__ xg,
+                                                  int64_t ghost_lo, double *__restrict__ y, double *__restrict__ part,
+                                                  ChunkOrder ord)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ __attribute__((aligned(16))) double vals[LDS_TILE + 2];
+    __shared__ __attribute__((aligned(16))) int32_t cols[LDS_TILE + 2];
+    __shared__ RP srow[LDS_ROWS + 1];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t nchunks = (r_end - r_begin + LDS_ROWS - 1) / LDS_ROWS;
+    // workgroup b runs on XCD b%8 (observed; speed only): XCD x walks the contiguous
+    // sequence range [x*cpx, (x+1)*cpx) in dispatch order
+    const int64_t cpx = (nchunks + 7) >> 3;
+    const int64_t sq = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    double dacc = 0.0;
+    if ((int64_t)(blockIdx.x >> 3) < cpx && sq < nchunks) {
+        const int64_t c = chunk_of(ord, sq);
+        const int64_t r0 = r_begin + c * LDS_ROWS;
+        const int nr = (int)((r_end - r0 < LDS_ROWS) ? (r_end - r0) : LDS_ROWS);
+        for (int t = tid; t <= nr; t += 256) srow[t] = rowptr[r0 + t];
+        __syncthreads();
+        const RP p0 = srow[0], p1 = srow[nr];
+        RP rs = 0, re = 0;
+        if (tid < nr) {
+            rs = srow[tid];
+            re = srow[tid + 1];
+        }
+        double sum = 0.0;
+        const RP a0 = p0 & ~(RP)1;  // val/col are 16-byte aligned at even entries
+        for (RP t0 = a0; t0 < p1; t0 += LDS_TILE) {
+#pragma unroll
+            for (int u = 0; u < LDS_TILE / 512; ++u) {
+                const RP q = t0 + 2 * (tid + u * 256);
+                if (q < p1) {
+                    *reinterpret_cast<double2 *>(&vals[(int)(q - t0)]) = *reinterpret_cast<const double2 *>(val + q);
+                    *reinterpret_cast<int2 *>(&cols[(int)(q - t0)]) = *reinterpret_cast<const int2 *>(col + q);
+                }
+            }
+            __syncthreads();
+            const RP lo = (rs > t0) ? rs : t0;
+            const RP hi = (re < t0 + LDS_TILE) ? re : (t0 + LDS_TILE);
+            for (RP p = lo; p < hi; p += 8) {
+                double vv[8], xx[8];
+                int32_t cc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = p + u < hi;
+                    cc[u] = ok ? cols[(int)(p - t0) + u] : 0;
+                    vv[u] = ok ? vals[(int)(p - t0) + u] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xx[u] = (p + u < hi) ? xg[cc[u]] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (p + u < hi) sum = sum + vv[u] * xx[u];
+            }
+            __syncthreads();
+        }
+        if (tid < nr) {
+            y[r0 + tid] = sum;
+            if (DOT) dacc = xg[ghost_lo + r0 + tid] * sum;
+        }
+    }
+    if (DOT) {
+        const double s = block_sum_256(dacc, red);
+        if (tid == 0) part[blockIdx.x] = s;
+    }
+}
+
+// stage 1 of the p.Ap reduction: `nin` per-workgroup partials -> <= 1024 partial sums (fixed order)
+__global__ __launch_bounds__(256) void k_reduce_partials(const Scalars *__restrict__ S, const double *__restrict__ in,
+                                                         int64_t nin, double *__restrict__ out)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ double red[4];
+    const int64_t per = (nin + gridDim.x - 1) / gridDim.x;
+    const int64_t b = (int64_t)blockIdx.x * per, e = (b + per < nin) ? b + per : nin;
+    double v = 0.0;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) v += in[i];
+    const double s = block_sum_256(v, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
 // Row-per-thread fallback (variant 2): simplest possible CSR kernel, kept as
 // the A/B baseline for the profile and as the checker of the stream kernel.
 template <typename RP, bool DOT>
@@ -151,9 +260,31 @@ __global__ __launch_bounds__(256) void k_spmv_scalar(const Scalars *__restrict__
 
 int spmv_launch_blocks() { return SPMV_GRID; }
 
-// y[r_begin:r_end) = (A x)[r_begin:r_end).  x_owned points at the owned part
-// of a ghost-padded vector.  If dot_part != nullptr, SPMV_GRID partial sums of
-// x.y over the row range are written there.
+// chunk order for rows [r_begin, r_end) given the registered grid (3-D only; the rows must start on a plane)
+static ChunkOrder make_order(const pib_solver *s, int64_t r_begin, int64_t r_end)
+{
+    ChunkOrder o{0, 0, 0, 0};
+    if (!s->has_grid || s->levels.empty() || s->cfg.spmv_variant == 3) return o;
+    const GridLevel &g = s->levels[0];
+    const int64_t nx = g.n[0], ny = g.n[1], plane = nx * ny;
+    if (ny < 2 || plane % LDS_ROWS != 0 || r_begin % plane != 0 || (r_end - r_begin) % plane != 0) return o;
+    const int64_t nplanes = (r_end - r_begin) / plane;
+    if (nplanes < 3) return o;
+    for (int64_t tj : {64, 32, 16, 8, 4, 2, 1}) {
+        if (ny % tj == 0 && (tj * nx) % LDS_ROWS == 0) {
+            o.tiled = 1;
+            o.cpp = plane / LDS_ROWS;
+            o.cpt = tj * nx / LDS_ROWS;
+            o.nplanes = nplanes;
+            break;
+        }
+    }
+    return o;
+}
+
+// y[r_begin:r_end) = (A x)[r_begin:r_end).  x_owned points at the owned part of a ghost-padded vector.
+// If dot_part != nullptr, x.y over the row range is reduced into `*n_part` partial sums written there
+// (fixed order: deterministic).
 int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, int64_t r_end, double *dot_part,
               bool guarded, hipStream_t st)
 {
@@ -165,6 +296,40 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
     const double *xg = x_owned - A.ghost_lo;
     const Scalars *S = guarded ? s->d_s : nullptr;
     const int variant = s->cfg.spmv_variant;
+    if (variant == 0 || variant == 3) {
+        const int64_t nchunks = (r_end - r_begin + LDS_ROWS - 1) / LDS_ROWS;
+        const int64_t grid = ((nchunks + 7) / 8) * 8;
+        const ChunkOrder ord = make_order(s, r_begin, r_end);
+        double *big = nullptr;
+        if (dot_part) {
+            if (s->spmv_part_cap < grid) {
+                if (s->d_spmv_part) PIB_HIP(hipFree(s->d_spmv_part));
+                s->d_spmv_part = nullptr;
+                PIB_HIP(hipMalloc(&s->d_spmv_part, sizeof(double) * (size_t)grid));
+                s->spmv_part_cap = grid;
+            }
+            big = s->d_spmv_part;
+        }
+#define PIB_LAUNCH_LDS(RP)                                                                                        \
+    do {                                                                                                          \
+        if (dot_part)                                                                                             \
+            hipLaunchKernelGGL((k_spmv_lds<RP, true>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, \
+                               (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, big, ord);                  \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_spmv_lds<RP, false>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin,      \
+                               r_end, (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord); \
+    } while (0)
+        if (A.rp64) PIB_LAUNCH_LDS(int64_t); else PIB_LAUNCH_LDS(int32_t);
+#undef PIB_LAUNCH_LDS
+        PIB_HIP(hipGetLastError());
+        if (dot_part) {
+            // SPMV_GRID partial sums out, like the persistent kernels
+            hipLaunchKernelGGL(k_reduce_partials, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
+            PIB_HIP(hipGetLastError());
+        }
+        s->counters[0]++;
+        return 0;
+    }
 #define PIB_LAUNCH(KERNEL, RP)                                                                                   \
     do {                                                                                                         \
         if (dot_part)                                                                                            \

@@ -69,7 +69,7 @@ struct Config {
     // execution
     int check_every = 0;     // iterations enqueued between host convergence polls (0 = auto)
     int use_graph = 1;       // capture the iteration body in a hipGraph (single GPU)
-    int spmv_variant = 0;    // 0 = auto
+    int spmv_variant = 0;    // 0 LDS-transpose + tiled chunk order (default), 3 same in natural order, 1 entry-per-lane stream, 2 row-per-thread
     int overlap_halo = 1;
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;
@@ -162,6 +162,8 @@ struct pib_solver {
     int64_t stage_n = 0;
     pib::Scalars *d_s = nullptr, *h_s = nullptr;
     double *d_part = nullptr;  // [PIB_NRED][PIB_MAXPART]
+    double *d_spmv_part = nullptr;  // one p.Ap partial per SpMV workgroup
+    int64_t spmv_part_cap = 0;
     double *d_hist = nullptr;
     int hist_cap = 0;
     hipGraphExec_t graph = nullptr;
