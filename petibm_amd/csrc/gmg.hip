@@ -29,12 +29,12 @@
 namespace pib {
 
 struct LevelDev {
-    int64_t nx, ny, nzg;  // global cells
-    int64_t k0, nk;       // owned planes [k0, k0+nk)
+    int nx, ny, nzg;  // global cells (each < 2^31; the local cell count fits int32 like the CSR columns)
+    int k0, nk;       // owned planes [k0, k0+nk)
     const double *wx, *wy, *wz, *gx, *gy, *gz;
 };
 
-__device__ __forceinline__ void face_coefs(const LevelDev &L, int64_t i, int64_t j, int64_t k, double c[6])
+__device__ __forceinline__ void face_coefs(const LevelDev &L, int i, int j, int k, double c[6])
 {
     const double wxi = L.wx[i], wyj = L.wy[j], wzk = L.wz[k];
     const double ax = wyj * wzk, ay = wxi * wzk, az = wxi * wyj;
@@ -47,12 +47,12 @@ __device__ __forceinline__ void face_coefs(const LevelDev &L, int64_t i, int64_t
 }
 
 // (A x) at local cell p (x points at the first OWNED plane; halo planes sit at -plane and +nk*plane)
-__device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__restrict__ x, int64_t p, int64_t i,
-                                             int64_t j, int64_t k, double *diag)
+__device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__restrict__ x, int64_t p, int i, int j,
+                                             int k, double *diag)
 {
     double c[6];
     face_coefs(L, i, j, k, c);
-    const int64_t sy = L.nx, sz = L.nx * L.ny;
+    const int64_t sy = L.nx, sz = (int64_t)L.nx * L.ny;
     const double xc = x[p];
     double s = 0.0;
     if (i > 0) s += c[0] * (x[p - 1] - xc);
@@ -65,13 +65,18 @@ __device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__
     return s;
 }
 
-#define PIB_CELL_LOOP(L)                                                                                      \
-    const int64_t plane_ = (L).nx * (L).ny, nloc_ = plane_ * (L).nk;                                          \
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nloc_; p += (int64_t)gridDim.x * blockDim.x)
-#define PIB_CELL_IJK(L)                                  \
-    const int64_t i = p % (L).nx;                        \
-    const int64_t j = (p / (L).nx) % (L).ny;             \
-    const int64_t k = (L).k0 + p / plane_;
+// Launch geometry of every level kernel: grid (ceil(plane/256) capped, nk); blockIdx.y is the local plane, so
+// k is workgroup-uniform (its coefficients come through the scalar path) and only ONE 32-bit division per
+// cell is left (j = q / nx).  64-bit div/mod per cell made the first version of these kernels ALU-bound.
+#define PIB_PLANE_LOOP(L)                                                                  \
+    const unsigned plane_ = (unsigned)(L).nx * (unsigned)(L).ny;                           \
+    const int kk_ = blockIdx.y;                                                            \
+    const int k = (L).k0 + kk_;                                                            \
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < plane_; q += gridDim.x * 256u)
+#define PIB_PLANE_IJ(L)                                  \
+    const int j = (int)(q / (unsigned)(L).nx);           \
+    const int i = (int)(q - (unsigned)j * (unsigned)(L).nx); \
+    const int64_t p = (int64_t)kk_ * plane_ + q;
 
 // mode 0: y = A x                       (stencil twin K2)
 // mode 1: xo = omega * b / diag          (Jacobi from a zero guess)
@@ -84,9 +89,9 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
                                                double *__restrict__ xo, const double *__restrict__ pin_sum)
 {
     if (S != nullptr && S->done) return;
-    PIB_CELL_LOOP(L)
+    PIB_PLANE_LOOP(L)
     {
-        PIB_CELL_IJK(L)
+        PIB_PLANE_IJ(L)
         double d;
         if (MODE == 0) {
             xo[p] = apply_cell(L, xi, p, i, j, k, &d);
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
 // 1-D transfer stencil of fine cell s: parent s/2 (3/4) and the coarse cell on
 // the child's side (1/4), folded onto the parent at a wall; identity if the
 // direction is not coarsened.
-__device__ __forceinline__ void tr1d(int64_t s, int64_t nc, bool coarsened, int64_t I[2], double wt[2])
+__device__ __forceinline__ void tr1d(int s, int nc, bool coarsened, int I[2], double wt[2])
 {
     if (!coarsened) {
         I[0] = I[1] = s;
@@ -120,8 +125,8 @@ __device__ __forceinline__ void tr1d(int64_t s, int64_t nc, bool coarsened, int6
         wt[1] = 0.0;
         return;
     }
-    const int64_t P = s >> 1;
-    const int64_t O = (s & 1) ? P + 1 : P - 1;
+    const int P = s >> 1;
+    const int O = (s & 1) ? P + 1 : P - 1;
     I[0] = P;
     if (O < 0 || O >= nc) {
         I[1] = P;
@@ -134,6 +139,34 @@ __device__ __forceinline__ void tr1d(int64_t s, int64_t nc, bool coarsened, int6
     }
 }
 
+// transposed form: the (up to 4) fine cells that feed coarse cell I and their weights
+// (fine cell s feeds I with 3/4 [1 when its other target is beyond a wall] if s/2 == I, with 1/4 otherwise).
+__device__ __forceinline__ int rs1d(int I, int nf, int nc, bool coarsened, int s[4], double wt[4])
+{
+    if (!coarsened) {
+        s[0] = I;
+        wt[0] = 1.0;
+        return 1;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int o = -1; o <= 2; ++o) {
+        const int f = 2 * I + o;
+        if (f < 0 || f >= nf) continue;
+        const int P = f >> 1;
+        const int O = (f & 1) ? P + 1 : P - 1;
+        double w;
+        if (P == I)
+            w = (O < 0 || O >= nc) ? 1.0 : 0.75;
+        else
+            w = 0.25;  // then O == I by construction
+        s[cnt] = f;
+        wt[cnt] = w;
+        ++cnt;
+    }
+    return cnt;
+}
+
 // xf += P xc.   xc points at the coarse level's first owned plane (coarse k0c);
 // coarse halo planes must be valid when the level is distributed.
 __global__ __launch_bounds__(256) void k_prolong_add(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
@@ -141,11 +174,11 @@ __global__ __launch_bounds__(256) void k_prolong_add(const Scalars *__restrict__
 {
     if (S != nullptr && S->done) return;
     const bool cx = C.nx != F.nx, cy = C.ny != F.ny, cz = C.nzg != F.nzg;
-    const int64_t cplane = C.nx * C.ny;
-    PIB_CELL_LOOP(F)
+    const int64_t cplane = (int64_t)C.nx * C.ny;
+    PIB_PLANE_LOOP(F)
     {
-        PIB_CELL_IJK(F)
-        int64_t I[2], J[2], K[2];
+        PIB_PLANE_IJ(F)
+        int I[2], J[2], K[2];
         double wi[2], wj[2], wk[2];
         tr1d(i, C.nx, cx, I, wi);
         tr1d(j, C.ny, cy, J, wj);
@@ -158,52 +191,40 @@ __global__ __launch_bounds__(256) void k_prolong_add(const Scalars *__restrict__
 #pragma unroll
                 for (int a2 = 0; a2 < 2; ++a2) {
                     const double wgt = (wk[c2] * wj[b2]) * wi[a2];
-                    if (wgt != 0.0) s += wgt * xc[I[a2] + C.nx * J[b2] + cplane * (K[c2] - C.k0)];
+                    if (wgt != 0.0) s += wgt * xc[I[a2] + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0)];
                 }
         xf[p] += s;
     }
 }
 
 // bc = P^T rf, gather form over the owned coarse cells; fine halo planes valid.
+// The summation visits fine cells in ascending (k, j, i) order with weights ((wz*wy)*wx): same as the oracle.
 __global__ __launch_bounds__(256) void k_restrict(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
                                                   const double *__restrict__ rf, double *__restrict__ bc)
 {
     if (S != nullptr && S->done) return;
     const bool cx = C.nx != F.nx, cy = C.ny != F.ny, cz = C.nzg != F.nzg;
-    const int64_t fplane = F.nx * F.ny;
-    PIB_CELL_LOOP(C)
+    const int64_t fplane = (int64_t)F.nx * F.ny;
+    PIB_PLANE_LOOP(C)
     {
-        const int64_t I = p % C.nx, J = (p / C.nx) % C.ny, K = C.k0 + p / plane_;
+        const int J = (int)(q / (unsigned)C.nx);
+        const int I = (int)(q - (unsigned)J * (unsigned)C.nx);
+        const int K = k;
+        int si[4], sj[4], sk[4];
+        double wi[4], wj[4], wk[4];
+        const int ni = rs1d(I, F.nx, C.nx, cx, si, wi);
+        const int nj = rs1d(J, F.ny, C.ny, cy, sj, wj);
+        const int nk = rs1d(K, F.nzg, C.nzg, cz, sk, wk);
         double s = 0.0;
-        const int64_t k0 = cz ? 2 * K - 1 : K, k1 = cz ? 2 * K + 2 : K;
-        const int64_t j0 = cy ? 2 * J - 1 : J, j1 = cy ? 2 * J + 2 : J;
-        const int64_t i0 = cx ? 2 * I - 1 : I, i1 = cx ? 2 * I + 2 : I;
-        for (int64_t k = k0; k <= k1; ++k) {
-            if (k < 0 || k >= F.nzg) continue;
-            int64_t KK[2];
-            double wk[2];
-            tr1d(k, C.nzg, cz, KK, wk);
-            const double wz = (KK[0] == K ? wk[0] : 0.0) + ((KK[1] == K && wk[1] != 0.0) ? wk[1] : 0.0);
-            if (wz == 0.0) continue;
-            for (int64_t j = j0; j <= j1; ++j) {
-                if (j < 0 || j >= F.ny) continue;
-                int64_t JJ[2];
-                double wj[2];
-                tr1d(j, C.ny, cy, JJ, wj);
-                const double wy = (JJ[0] == J ? wj[0] : 0.0) + ((JJ[1] == J && wj[1] != 0.0) ? wj[1] : 0.0);
-                if (wy == 0.0) continue;
-                for (int64_t i = i0; i <= i1; ++i) {
-                    if (i < 0 || i >= F.nx) continue;
-                    int64_t II[2];
-                    double wi[2];
-                    tr1d(i, C.nx, cx, II, wi);
-                    const double wx = (II[0] == I ? wi[0] : 0.0) + ((II[1] == I && wi[1] != 0.0) ? wi[1] : 0.0);
-                    if (wx == 0.0) continue;
-                    s += ((wz * wy) * wx) * rf[i + F.nx * j + fplane * (k - F.k0)];
-                }
+        for (int c = 0; c < nk; ++c) {
+            const double *pk = rf + fplane * (sk[c] - F.k0);
+            for (int b2 = 0; b2 < nj; ++b2) {
+                const double wzy = wk[c] * wj[b2];
+                const double *pj = pk + (int64_t)F.nx * sj[b2];
+                for (int a = 0; a < ni; ++a) s += (wzy * wi[a]) * pj[si[a]];
             }
         }
-        bc[p] = s;
+        bc[(int64_t)kk_ * plane_ + q] = s;
     }
 }
 
@@ -214,11 +235,11 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
                                                   double *__restrict__ xb, double *__restrict__ xout)
 {
     if (S != nullptr && S->done) return;
-    const int64_t plane = L.nx * L.ny, n = plane * L.nk;
+    const int plane = L.nx * L.ny, n = plane * L.nk;
     double *cur = xa, *nxt = xb;
     for (int sw = 0; sw < sweeps; ++sw) {
-        for (int64_t p = threadIdx.x; p < n; p += blockDim.x) {
-            const int64_t i = p % L.nx, j = (p / L.nx) % L.ny, k = L.k0 + p / plane;
+        for (int p = threadIdx.x; p < n; p += blockDim.x) {
+            const int i = p % L.nx, j = (p / L.nx) % L.ny, k = L.k0 + p / plane;
             double d;
             if (sw == 0) {
                 double c[6];
@@ -237,7 +258,7 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
         nxt = t;
     }
     if (cur != xout) {
-        for (int64_t p = threadIdx.x; p < n; p += blockDim.x) xout[p] = cur[p];
+        for (int p = threadIdx.x; p < n; p += blockDim.x) xout[p] = cur[p];
     }
 }
 
@@ -245,11 +266,11 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
 static LevelDev dev_of(const GridLevel &g)
 {
     LevelDev L;
-    L.nx = g.n[0];
-    L.ny = g.n[1];
-    L.nzg = g.n[2];
-    L.k0 = g.k0;
-    L.nk = g.k1 - g.k0;
+    L.nx = (int)g.n[0];
+    L.ny = (int)g.n[1];
+    L.nzg = (int)g.n[2];
+    L.k0 = (int)g.k0;
+    L.nk = (int)(g.k1 - g.k0);
     L.wx = g.w[0];
     L.wy = g.w[1];
     L.wz = g.w[2];
@@ -260,6 +281,12 @@ static LevelDev dev_of(const GridLevel &g)
 }
 
 static int grid_blocks(int64_t n) { return (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n + 255) / 256)); }
+// (x, y) = (workgroups per plane, owned planes)
+static dim3 level_grid(const GridLevel &g)
+{
+    const int64_t plane = g.n[0] * g.n[1];
+    return dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (plane + 255) / 256)), (unsigned)std::max<int64_t>(1, g.k1 - g.k0));
+}
 
 static int up(const std::vector<double> &h, double **d)
 {
@@ -526,7 +553,7 @@ template <int MODE>
 static int launch_level(pib_solver *s, const GridLevel &g, double omega, const double *b, const double *xi, double *xo,
                         const double *pin_sum, bool guarded, hipStream_t q)
 {
-    hipLaunchKernelGGL(k_level<MODE>, dim3(grid_blocks(g.nloc)), dim3(256), 0, q, guarded ? s->d_s : nullptr, dev_of(g),
+    hipLaunchKernelGGL(k_level<MODE>, level_grid(g), dim3(256), 0, q, guarded ? s->d_s : nullptr, dev_of(g),
                        omega, b, xi, xo, pin_sum);
     PIB_HIP(hipGetLastError());
     return 0;
@@ -597,7 +624,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             own.k1 = (g.k1 == g.n[2]) ? cg.n[2] : g.k1 / 2;
             own.nloc = (own.k1 - own.k0) * cg.plane;
             double *scratch = cg.r + cg.plane;
-            hipLaunchKernelGGL(k_restrict, dim3(grid_blocks(own.nloc)), dim3(256), 0, q, S, dev_of(g), dev_of(own), rr, scratch);
+            hipLaunchKernelGGL(k_restrict, level_grid(own), dim3(256), 0, q, S, dev_of(g), dev_of(own), rr, scratch);
             PIB_HIP(hipGetLastError());
             s->gather_planes_total = cg.n[2];
             s->gather_plane_size = cg.plane;
@@ -605,7 +632,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // split is even; grid_register guarantees it.
             PIB_CHK(gather_level(s, own, scratch, own.nloc, cg.b + cg.plane, q));
         } else {
-            hipLaunchKernelGGL(k_restrict, dim3(grid_blocks(cg.nloc)), dim3(256), 0, q, S, dev_of(g), dev_of(cg), rr,
+            hipLaunchKernelGGL(k_restrict, level_grid(cg), dim3(256), 0, q, S, dev_of(g), dev_of(cg), rr,
                                cg.b + cg.plane);
             PIB_HIP(hipGetLastError());
         }
@@ -623,7 +650,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         double *a = cur[(size_t)l], *c = s->gmg_spare[(size_t)l];
         double *xc = cur[(size_t)l + 1];
         PIB_CHK(halo_level(s, cg, xc, q));
-        hipLaunchKernelGGL(k_prolong_add, dim3(grid_blocks(g.nloc)), dim3(256), 0, q, S, dev_of(g), dev_of(cg), xc, a);
+        hipLaunchKernelGGL(k_prolong_add, level_grid(g), dim3(256), 0, q, S, dev_of(g), dev_of(cg), xc, a);
         PIB_HIP(hipGetLastError());
         for (int sw = 0; sw < post; ++sw) {
             PIB_CHK(halo_level(s, g, a, q));
