@@ -56,25 +56,60 @@ def manufactured_solution(n: int, k0: int, k1: int) -> np.ndarray:
     return (cz[:, None, None] * c[None, :, None] * c[None, None, :]).reshape(-1)
 
 
-def cpu_baseline(pc: str, tol: float, budget_s: float = 20.0):
-    """The oracle (CPU restatement of the KSP path, all host cores) on a bounded
-    sample: the same solver on a smaller cavity, sized for ~10-30 s."""
-    from oracle import clib, mesh as omesh, operators as oops
+def cpu_baseline(n_gpu: int, tol: float, dt: float, budget_s: float = 45.0):
+    """The oracle (CPU restatement of the same path: int32 CSR SpMV + KSPCG recurrences + the same V-cycle,
+    oracle/csrc/*.c, OpenMP over all host cores) timed on this box.  It runs the SAME workload as the GPU when
+    a calibration solve at n/2 says it fits the time budget and the host has the memory; otherwise the
+    bounded sample is the largest power-of-two cavity that does."""
+    from oracle import clib
     cores = clib.num_threads()
-    n = 96
-    m = omesh.create_mesh(omesh.uniform_config((n, n, n)))
-    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
-    _, A = oops.create_poisson_operator(D, G, L, 5e-4, 0.5e-3)
-    xs = manufactured_solution(n, 0, n)
-    b = clib.spmv(A, xs)
-    t0 = time.perf_counter()
-    r = clib.cg(A, b, pc="jacobi" if pc != "none" else "none", nullspace=1, norm="unpreconditioned", rtol=tol,
-                atol=0.0, dtol=1e300, maxit=100000)
-    t = time.perf_counter() - t0
-    return {"value": m.pN / t, "unit": "DOF/s", "cores": cores, "kind": "port",
-            "sample": f"Jacobi-PCG (KSPCG recurrences, oracle/csrc/oracle.c) on a {n}^3 cavity Poisson system, "
-                      f"rtol {tol:g}: {r['iters']} iterations in {t:.2f} s = {r['iters'] / t:.1f} it/s",
-            "iters": r["iters"], "seconds": t}
+
+    def run(n):
+        w = np.full(n, 1.0 / n)
+        t0 = time.perf_counter()
+        rp, cl, vl = clib.assemble_poisson32((n, n, n), [w, w, w], dt)
+        g = clib.GMG((n, n, n), [w, w, w], dt, nullspace=1, pre=1, post=1, omega=0.9, coarsest_sweeps=32)
+        xs = manufactured_solution(n, 0, n)
+        b = np.empty(n ** 3)
+        clib.spmv32(n ** 3, rp, cl, vl, xs, b)
+        t_setup = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        r = clib.pcg_gmg32(g, rp, cl, vl, b, rtol=tol, maxit=200)
+        return time.perf_counter() - t0, r, t_setup
+
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 0
+    n = min(128, n_gpu)
+    t, r, ts = run(n)
+    while 2 * n <= n_gpu:
+        need = 40.0 * (2 * n) ** 3 * 8  # ~40 doubles per cell: CSR + vectors + levels
+        if 8.5 * (t + ts) > budget_s or need > 0.6 * avail:
+            break
+        n *= 2
+        t, r, ts = run(n)
+    same = "the same workload" if n == n_gpu else f"a bounded sample of it ({n}^3 instead of {n_gpu}^3)"
+    return {"value": n ** 3 / t, "unit": "DOF/s", "cores": cores, "kind": "port",
+            "sample": f"{same}: GMG-PCG (oracle/csrc: KSPCG recurrences + the build's V(1,1) cycle, int32 CSR) on the "
+                      f"{n}^3 cavity Poisson system, rtol {tol:g}: {r['iters']} iterations in {t:.2f} s "
+                      f"(+ {ts:.1f} s CPU assembly, not counted)",
+            "iters": r["iters"], "seconds": t, "grid": n}
+
+
+def measured_traffic(n: int, world: int):
+    """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/r01_spmv_pmc.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same command; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no pass matches this configuration."""
+    path = os.path.join(ROOT, "profiles", "spmv_pmc.json")
+    try:
+        for e in json.load(open(path)):
+            if e.get("n") == n and e.get("gpus") == world:
+                return e.get("traffic_bytes")
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -83,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=512, help="cells per direction (BASELINE: 512)")
-    ap.add_argument("--pc", default="jacobi", choices=["gmg", "jacobi", "none"])
+    ap.add_argument("--pc", default="gmg", choices=["gmg", "jacobi", "none"])
     ap.add_argument("--tol", type=float, default=1e-10)
     ap.add_argument("--max-iters", type=int, default=20000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -181,14 +216,14 @@ def main():
             "cg_iters_per_s": iters / elapsed, "iters_per_solve": iters / args.steps,
             "true_rel_residual": true_rel, "setup_s": t_setup,
             "spmv_gdof_per_s": n_l / (ms_spmv * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<int32> (fp64 CSR SpMV, local slab)",
+            "roofline": {"bound": "hbm", "kernel": "pib::k_spmv_lds<int32> (fp64 CSR SpMV K1, local slab)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world),
                          "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes},
             "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "host_polls": int(counters[4])},
         }
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.pc, args.tol)
+            out["cpu_baseline"] = cpu_baseline(n, args.tol, dt)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -190,3 +190,36 @@ class GMG:
                 self._h = None
         except Exception:
             pass
+
+
+def assemble_poisson32(n, widths, dt):
+    """DBNG as int32 CSR straight from the cell widths (oracle/csrc/gmg.c:orc_assemble_poisson32)."""
+    L = lib()
+    dim = len(n)
+    nx, ny = int(n[0]), int(n[1])
+    nz = int(n[2]) if dim == 3 else 1
+    L.orc_poisson_nnz.restype = C.c_int64
+    L.orc_poisson_nnz.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64]
+    nnz = int(L.orc_poisson_nnz(dim, nx, ny, nz))
+    N = nx * ny * nz
+    rp = np.empty(N + 1, dtype=np.int32)
+    cl = np.empty(nnz, dtype=np.int32)
+    vl = np.empty(nnz)
+    w = [np.ascontiguousarray(a, dtype=np.float64) for a in widths]
+    L.orc_assemble_poisson32.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, _f64p, _f64p, C.c_void_p, C.c_double,
+                                         _i32p, _i32p, _f64p]
+    L.orc_assemble_poisson32(dim, nx, ny, nz, w[0], w[1], w[2].ctypes.data if dim == 3 else None, float(dt), rp, cl, vl)
+    return rp, cl, vl
+
+
+def pcg_gmg32(gmg: "GMG", rp, cl, vl, b, rtol=1e-10, maxit=200):
+    L = lib()
+    L.orc_pcg_gmg32.restype = C.c_int
+    L.orc_pcg_gmg32.argtypes = [C.c_void_p, C.c_int64, _i32p, _i32p, _f64p, C.c_double, C.c_int, _f64p, _f64p,
+                                C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    n = len(rp) - 1
+    x = np.empty(n)
+    its, rn = C.c_int(0), C.c_double(0)
+    reason = L.orc_pcg_gmg32(gmg._h, n, rp, cl, vl, float(rtol), int(maxit), np.ascontiguousarray(b), x, C.byref(its),
+                             C.byref(rn))
+    return {"x": x, "iters": its.value, "rnorm": rn.value, "reason": int(reason)}

@@ -54,6 +54,9 @@ typedef struct {
     int nullspace; /* 0 none 1 constant 2 pinned */
 } gmg_t;
 
+static double vec_sum(i64 n, const double *a);
+static void shift_vec(i64 n, double *a, double m);
+
 static inline i64 idx(const level_t *l, i64 i, i64 j, i64 k) { return i + l->n[0] * (j + l->n[1] * k); }
 
 /* diagonal of the level operator at (i,j,k): -(sum of face coefficients) */
@@ -315,11 +318,7 @@ void orc_gmg_apply(void *h, const double *r, double *z)
     gmg_t *G = h;
     level_t *l = &G->L[0];
     memcpy(l->b, r, sizeof(double) * (size_t)l->N);
-    if (G->nullspace == 2) {
-        double s = 0.0;
-        for (i64 p = 0; p < l->N; ++p) s += r[p];
-        l->b[0] = r[0] - s;
-    }
+    if (G->nullspace == 2) l->b[0] = r[0] - vec_sum(l->N, r);
     vcycle(G, 0);
     memcpy(z, l->x, sizeof(double) * (size_t)l->N);
 }
@@ -328,6 +327,19 @@ void orc_gmg_apply(void *h, const double *r, double *z)
  * the V-cycle; normtype 0: ||z|| (after projection), 1: ||r||.
  * nullspace 1: z <- z - mean(z); 2: z <- z - z[0], z[0] = r[0].            */
 void orc_spmv(i64 n, const i64 *rowptr, const i64 *col, const double *val, const double *x, double *y);
+
+static double vec_sum(i64 n, const double *a)
+{
+    double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (i64 i = 0; i < n; ++i) s += a[i];
+    return s;
+}
+static void shift_vec(i64 n, double *a, double m)
+{
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) a[i] -= m;
+}
 
 static double ddot(i64 n, const double *a, const double *b)
 {
@@ -348,19 +360,16 @@ int orc_pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double 
     if (!guess_nonzero) { memset(x, 0, (size_t)n * 8); memcpy(R, b, (size_t)n * 8); }
     else {
         orc_spmv(n, rowptr, col, val, x, R);
+#pragma omp parallel for schedule(static)
         for (i64 q = 0; q < n; ++q) R[q] = b[q] - R[q];
     }
 #define PCAPPLY()                                                        \
     do {                                                                 \
         orc_gmg_apply(G, R, Z);                                          \
         if (G->nullspace == 1) {                                         \
-            double m = 0.0;                                              \
-            for (i64 q = 0; q < n; ++q) m += Z[q];                       \
-            m /= (double)n;                                              \
-            for (i64 q = 0; q < n; ++q) Z[q] -= m;                       \
+            shift_vec(n, Z, vec_sum(n, Z) / (double)n);                  \
         } else if (G->nullspace == 2) {                                  \
-            const double z0 = Z[0];                                      \
-            for (i64 q = 0; q < n; ++q) Z[q] -= z0;                      \
+            shift_vec(n, Z, Z[0]);                                       \
             Z[0] = R[0];                                                 \
         }                                                                \
     } while (0)
@@ -377,13 +386,18 @@ int orc_pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double 
         if (beta == 0.0) { reason = 3; break; }
         if (i > 0 && ((beta > 0) != (betaold > 0))) { reason = -8; break; }
         if (i == 0) memcpy(P, Z, (size_t)n * 8);
-        else { const double bb = beta / betaold; for (i64 q = 0; q < n; ++q) P[q] = Z[q] + bb * P[q]; }
+        else {
+            const double bb = beta / betaold;
+#pragma omp parallel for schedule(static)
+            for (i64 q = 0; q < n; ++q) P[q] = Z[q] + bb * P[q];
+        }
         dpiold = dpi;
         orc_spmv(n, rowptr, col, val, P, W);
         dpi = ddot(n, P, W);
         betaold = beta;
         if (dpi == 0.0 || (i > 0 && ((dpi > 0) != (dpiold > 0)))) { reason = -10; break; }
         a = beta / dpi;
+#pragma omp parallel for schedule(static)
         for (i64 q = 0; q < n; ++q) { x[q] = x[q] + a * P[q]; R[q] = R[q] - a * W[q]; }
         if (normtype == 1) {
             dp = sqrt(ddot(n, R, R));
@@ -400,6 +414,127 @@ int orc_pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double 
         i++;
     } while (i < maxit);
     if (!reason && i >= maxit) reason = -3;
+done:
+    *rnorm_out = dp;
+    free(R); free(Z); free(P); free(W);
+    return reason;
+}
+
+
+/* ---- DBNG = D (dt I) G assembled directly from the cell widths, entry for entry the same arithmetic as
+ * oracle/operators.py:create_poisson_operator (createdivergence.cpp:140-151, creategradient.cpp:70-86,
+ * createbn.cpp:49, navierstokes.cpp:349-356); used for full-size CPU baselines where the numpy COO route
+ * would need hundreds of GB.  2-D grids: nz = 1.  int32 output (the device CSR's index width). */
+static i64 nnz_before(i64 g, int dim, i64 nx, i64 ny, i64 nz)
+{
+    const i64 pl = nx * ny;
+    i64 c = g;
+    c += g - (g + nx - 1) / nx;
+    c += g - g / nx;
+    const i64 kq = g / pl, rem = g % pl;
+    c += g - (kq * nx + (rem < nx ? rem : nx));
+    const i64 top = rem - (ny - 1) * nx;
+    c += g - (kq * nx + (top > 0 ? top : 0));
+    if (dim == 3) {
+        c += g - (g < pl ? g : pl);
+        const i64 last = g - (nz - 1) * pl;
+        c += g - (last > 0 ? last : 0);
+    }
+    return c;
+}
+
+i64 orc_poisson_nnz(int dim, i64 nx, i64 ny, i64 nz) { return nnz_before(nx * ny * nz, dim, nx, ny, nz); }
+
+void orc_assemble_poisson32(int dim, i64 nx, i64 ny, i64 nz, const double *wx, const double *wy, const double *wz,
+                            double dt, int32_t *rowptr, int32_t *col, double *val)
+{
+    const i64 n = nx * ny * nz, pl = nx * ny;
+    const double one = 1.0;
+    if (dim == 2) wz = &one;
+    double *g[3];
+    const double *w[3] = {wx, wy, wz};
+    const i64 nn[3] = {nx, ny, nz};
+    for (int d = 0; d < 3; ++d) {
+        g[d] = malloc(sizeof(double) * (size_t)(nn[d] > 1 ? nn[d] - 1 : 1));
+        for (i64 s = 0; s + 1 < nn[d]; ++s) {
+            const double dl = 0.5 * (w[d][s + 1] + w[d][s]);
+            const double v = 1.0 / dl;
+            g[d][s] = dt * v;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (i64 r = 0; r <= n; ++r) {
+        i64 p = nnz_before(r, dim, nx, ny, nz);
+        rowptr[r] = (int32_t)p;
+        if (r == n) continue;
+        const i64 i = r % nx, j = (r / nx) % ny, k = r / pl;
+        const double ax = wy[j] * wz[k], ay = wx[i] * wz[k], az = wx[i] * wy[j];
+        const int hxm = i > 0, hxp = i < nx - 1, hym = j > 0, hyp = j < ny - 1;
+        const int hzm = (dim == 3) && k > 0, hzp = (dim == 3) && k < nz - 1;
+        const double oxm = hxm ? ax * g[0][i - 1] : 0.0, oxp = hxp ? ax * g[0][i] : 0.0;
+        const double oym = hym ? ay * g[1][j - 1] : 0.0, oyp = hyp ? ay * g[1][j] : 0.0;
+        const double ozm = hzm ? az * g[2][k - 1] : 0.0, ozp = hzp ? az * g[2][k] : 0.0;
+        double d = 0.0;
+        int first = 1;
+        const double t[6] = {oxm, oxp, oym, oyp, ozm, ozp};
+        const int has[6] = {hxm, hxp, hym, hyp, hzm, hzp};
+        for (int q = 0; q < 6; ++q)
+            if (has[q]) {
+                if (first) { d = -t[q]; first = 0; }
+                else d = d + (-t[q]);
+            }
+        if (hzm) { col[p] = (int32_t)(r - pl); val[p] = ozm; ++p; }
+        if (hym) { col[p] = (int32_t)(r - nx); val[p] = oym; ++p; }
+        if (hxm) { col[p] = (int32_t)(r - 1); val[p] = oxm; ++p; }
+        col[p] = (int32_t)r; val[p] = d; ++p;
+        if (hxp) { col[p] = (int32_t)(r + 1); val[p] = oxp; ++p; }
+        if (hyp) { col[p] = (int32_t)(r + nx); val[p] = oyp; ++p; }
+        if (hzp) { col[p] = (int32_t)(r + pl); val[p] = ozp; ++p; }
+    }
+    for (int d = 0; d < 3; ++d) free(g[d]);
+}
+
+/* the same PCG+V-cycle on the int32 CSR (what the cpu_baseline leg of bench.py times) */
+void orc_spmv32(i64 n, const int32_t *rowptr, const int32_t *col, const double *val, const double *x, double *y);
+
+int orc_pcg_gmg32(void *h, i64 n, const int32_t *rowptr, const int32_t *col, const double *val, double rtol, int maxit,
+                  const double *b, double *x, int *its_out, double *rnorm_out)
+{
+    gmg_t *G = h;
+    double *R = malloc((size_t)n * 8), *Z = malloc((size_t)n * 8), *P = malloc((size_t)n * 8), *W = malloc((size_t)n * 8);
+    double beta, betaold = 1.0, dpi, dp, a, ttol;
+    int reason = 0, i = 0;
+#pragma omp parallel for schedule(static)
+    for (i64 q = 0; q < n; ++q) { x[q] = 0.0; R[q] = b[q]; }
+    orc_gmg_apply(G, R, Z);
+    if (G->nullspace == 1) shift_vec(n, Z, vec_sum(n, Z) / (double)n);
+    dp = sqrt(ddot(n, R, R));
+    ttol = rtol * dp;
+    *its_out = 0;
+    beta = ddot(n, Z, R);
+    if (dp <= ttol) { reason = 2; goto done; }
+    do {
+        *its_out = i + 1;
+        if (i == 0) memcpy(P, Z, (size_t)n * 8);
+        else {
+            const double bb = beta / betaold;
+#pragma omp parallel for schedule(static)
+            for (i64 q = 0; q < n; ++q) P[q] = Z[q] + bb * P[q];
+        }
+        orc_spmv32(n, rowptr, col, val, P, W);
+        dpi = ddot(n, P, W);
+        betaold = beta;
+        a = beta / dpi;
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) { x[q] = x[q] + a * P[q]; R[q] = R[q] - a * W[q]; }
+        dp = sqrt(ddot(n, R, R));
+        if (dp <= ttol) { reason = 2; break; }
+        orc_gmg_apply(G, R, Z);
+        if (G->nullspace == 1) shift_vec(n, Z, vec_sum(n, Z) / (double)n);
+        beta = ddot(n, Z, R);
+        i++;
+    } while (i < maxit);
+    if (!reason) reason = -3;
 done:
     *rnorm_out = dp;
     free(R); free(Z); free(P); free(W);

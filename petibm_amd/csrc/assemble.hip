@@ -243,14 +243,18 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
                            A.val);
     PIB_HIP(hipGetLastError());
     PIB_HIP(hipStreamSynchronize(s->stream));
-    // hand the 1-D arrays to the structured (stencil / multigrid) path
-    const double *cw[3] = {hw[0].data(), hw[1].data(), hw[2].data()};
-    const double *cg[3] = {hg[0].data(), hg[1].data(), hg[2].data()};
     for (int d = 0; d < 3; ++d) {
         (void)hipFree(dw[d]);
         (void)hipFree(dg[d]);
     }
-    return grid_register(s, dim, n, cw, cg, nullspace, dt);
+    // the caller registers the structure (grid_register) AFTER the halo plan exists: the hint
+    // verification exchanges ghost planes.
+    for (int d = 0; d < 3; ++d) {
+        s->asm_w[d] = hw[d];
+        s->asm_g[d] = hg[d];
+    }
+    s->asm_dt = dt;
+    return 0;
 }
 
 }  // namespace pib

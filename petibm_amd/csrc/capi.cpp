@@ -194,7 +194,10 @@ int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const doubl
     gmg_release(s);
     const double *w[3] = {wx, wy, wz};
     PIB_CHK(assemble_poisson(s, dim, n, w, dt, nullspace));
-    return after_set_matrix(s);
+    PIB_CHK(after_set_matrix(s));  // halo plan first: registering the grid verifies it with a halo exchange
+    const double *cw[3] = {s->asm_w[0].data(), s->asm_w[1].data(), s->asm_w[2].data()};
+    const double *cg[3] = {s->asm_g[0].data(), s->asm_g[1].data(), s->asm_g[2].data()};
+    return grid_register(s, dim, n, cw, cg, nullspace, s->asm_dt);
 }
 
 static bool is_device_ptr(const void *p)

@@ -153,6 +153,8 @@ struct pib_solver {
     std::vector<pib::GridLevel> levels;
     std::vector<double *> gmg_spare = std::vector<double *>(64, nullptr);
     bool gmg_guarded = true;
+    std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
+    double asm_dt = 0.0;
     int64_t gather_planes_total = 0, gather_plane_size = 0;
     // work vectors: each ghost-padded [ghost_lo + n + ghost_hi]
     double *work = nullptr, *work_base = nullptr;

@@ -453,3 +453,20 @@ def test_full_size_properties_256(lin):
     assert np.linalg.norm(b - y.download()) <= 1.5e-10 * np.linalg.norm(b)
     assert s.getIters() < 40
     s.destroy()
+
+
+def test_cpp_host_mirror_demo_runs():
+    """include/petibm_amd/linsolver.hpp (the C++ mirror of petibm::linsolver) over the C ABI, from a plain
+    g++ program: createLinSolver -> setMatrix -> setGridHint -> solve -> getIters/getResidual."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "cpp", "poisson_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++14", "-I", os.path.join(root, "include"),
+                               os.path.join(root, "examples", "cpp", "poisson_demo.cpp"), "-L",
+                               os.path.join(root, "petibm_amd", "lib"), "-lpetibm_amd",
+                               "-Wl,-rpath,$ORIGIN/../../petibm_amd/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Type: NVIDIA AmgX" in out.stdout and "recomputed ||b-Ax||/||b||" in out.stdout
