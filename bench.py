@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=512, help="cells per direction (BASELINE: 512)")
+    ap.add_argument("--grid", dest="n", type=int, default=512, help="cells per direction (BASELINE: 512)")
     ap.add_argument("--pc", default="gmg", choices=["gmg", "jacobi", "none"])
     ap.add_argument("--tol", type=float, default=1e-10)
     ap.add_argument("--max-iters", type=int, default=20000)
@@ -131,12 +131,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # PIB_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0, torch side on gloo -- lets the N>1 code path be
+    # exercised on a 1-GPU box when RCCL accepts several ranks per device.
+    share = os.environ.get("PIB_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     uid = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     from petibm_amd import capi
     from petibm_amd.linsolver import LinSolverHIP
     if world > 1:
@@ -144,7 +152,9 @@ def main():
         buf = ctypes.create_string_buffer(capi.UID_BYTES)
         if rank == 0:
             capi.check(capi.load().pib_comm_unique_id(buf))
-        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+        if not share:
+            t = t.cuda()
         dist.broadcast(t, src=0)
         uid = bytes(t.cpu().numpy().tobytes())
 
@@ -181,7 +191,8 @@ def main():
         iters += s.getIters()
     barrier()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if (world > 1 and share) else "cuda"
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
@@ -191,7 +202,7 @@ def main():
     s.matMult(x_d, r_d)
     bl = b_d.download()
     rl = bl - r_d.download()
-    num = torch.tensor([float(rl @ rl), float(bl @ bl)], dtype=torch.float64, device="cuda")
+    num = torch.tensor([float(rl @ rl), float(bl @ bl)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(num)
     true_rel = float(torch.sqrt(num[0] / num[1]).item())

@@ -80,6 +80,12 @@ int pib_version(void);
 #define PIB_UID_BYTES 128
 int pib_comm_unique_id(void *uid_out /* PIB_UID_BYTES */);
 
+/* TEST transport: `nranks` ranks = host threads of ONE process sharing ONE GPU (RCCL refuses several
+ * ranks per device).  Fills a PIB_UID_BYTES id to pass to pib_create from every thread.  Used by the
+ * parity tests to run the multi-rank algorithm on a single-GPU box; never by an application. */
+int pib_comm_loopback_create(int nranks, void *uid_out /* PIB_UID_BYTES */);
+int pib_comm_loopback_destroy(const void *uid);
+
 /* ---- life cycle ---------------------------------------------------------
  * pib_create replaces LinSolverAmgX::LinSolverAmgX + init
  * (src/linsolver/linsolveramgx.cpp:20-75; AmgXSolver::initialize(comm,"dDDI",cfg))

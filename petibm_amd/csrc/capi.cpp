@@ -112,7 +112,7 @@ int pib_destroy(pib_solver *s)
     if (s->d_part) (void)hipFree(s->d_part);
     if (s->d_spmv_part) (void)hipFree(s->d_spmv_part);
     if (s->d_hist) (void)hipFree(s->d_hist);
-    if (s->comm.comm) (void)ncclCommDestroy(s->comm.comm);
+    comm_release(s);
     if (s->ev_a) (void)hipEventDestroy(s->ev_a);
     if (s->ev_b) (void)hipEventDestroy(s->ev_b);
     if (s->ev_halo) (void)hipEventDestroy(s->ev_halo);

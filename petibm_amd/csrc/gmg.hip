@@ -532,6 +532,7 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
 {
     gmg_release(s);
     s->nullspace = nullspace;
+    s->gmg_error.clear();
     if (dim != 2 && dim != 3) return fail(PIB_ERR_ARG_OUTOFRANGE, "grid hint: dim must be 2 or 3");
     const int P = s->comm.nranks, rank = s->comm.rank;
     // internal layout (nx, ny, nz) with 2-D -> (nx, 1, ny)
@@ -569,6 +570,12 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
     std::vector<GridLevel> &lv = s->levels;
     const int max_levels = std::max(1, s->cfg.max_levels);
     bool replicated = (P == 1);
+    s->gmg_own.clear();
+    {
+        std::vector<std::pair<int64_t, int64_t>> o0((size_t)P);
+        for (int r = 0; r < P; ++r) slab_range(nn[2], P, r, &o0[(size_t)r].first, &o0[(size_t)r].second);
+        s->gmg_own.push_back(o0);
+    }
     for (int l = 0;; ++l) {
         GridLevel G;
         G.dim = dim;
@@ -600,24 +607,50 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
         // next level
         int64_t nc[3];
         for (int d = 0; d < 3; ++d) nc[d] = (nn[d] > 2) ? (nn[d] + 1) / 2 : nn[d];
-        if (!replicated) {
-            // stay distributed only while every slab boundary is even, every rank keeps >= 2 coarse
-            // planes and the level is big enough to amortise the halo latency
-            bool ok = (nc[2] != nn[2]);
-            int64_t b = 0;
-            for (int r = 0; r < P && ok; ++r) {
-                int64_t e;
-                slab_range(nn[2], P, r, &b, &e);
-                if ((b & 1) || ((e & 1) && e != nn[2]) || (e - b) < 4) ok = false;
+        {
+            // ownership of the coarse planes = owner of fine plane 2K (recorded also for the level at which the
+            // hierarchy switches to replicated: it defines who restricts what before the all-gather)
+            const auto &of = s->gmg_own.back();
+            std::vector<std::pair<int64_t, int64_t>> oc((size_t)P);
+            for (int r = 0; r < P; ++r) {
+                const int64_t b = of[(size_t)r].first, e = of[(size_t)r].second;
+                if (nc[2] != nn[2]) oc[(size_t)r] = {(b + 1) / 2, (e == nn[2]) ? nc[2] : (e + 1) / 2};
+                else oc[(size_t)r] = {b, e};
             }
-            if (nc[0] * nc[1] * nc[2] <= (int64_t)s->cfg.agglomerate_below) ok = false;
-            if (ok) {
-                // coarse ownership follows fine plane 2K
-                k0 = k0 / 2;
-                k1 = (k1 == nn[2]) ? nc[2] : k1 / 2;
-            } else {
-                replicated = true;
+            if (!replicated) {
+                // stay distributed only while every slab boundary is even, every rank keeps >= 2 coarse
+                // planes and the level is big enough to amortise the halo latency
+                bool ok = (nc[2] != nn[2]);
+                for (int r = 0; r < P && ok; ++r) {
+                    const int64_t b = of[(size_t)r].first, e = of[(size_t)r].second;
+                    if ((b & 1) || ((e & 1) && e != nn[2]) || (e - b) < 4) ok = false;
+                    // a distributed level must itself have even boundaries, or nothing could be restricted
+                    // (or gathered) from it with a one-plane halo
+                    const int64_t cb = oc[(size_t)r].first, ce = oc[(size_t)r].second;
+                    if ((cb & 1) || ((ce & 1) && ce != nc[2])) ok = false;
+                }
+                if (nc[0] * nc[1] * nc[2] <= (int64_t)s->cfg.agglomerate_below) ok = false;
+                if (ok) {
+                    k0 = oc[(size_t)rank].first;
+                    k1 = oc[(size_t)rank].second;
+                } else {
+                    // the restriction into the first replicated level needs fine planes 2K-1 .. 2K+2 of the owned
+                    // coarse planes: legal with one halo plane only if the fine boundaries are even
+                    for (int r = 0; r < P; ++r) {
+                        const int64_t b = of[(size_t)r].first, e = of[(size_t)r].second;
+                        if (nc[2] != nn[2] && ((b & 1) || ((e & 1) && e != nn[2]))) {
+                            char msg[256];
+                            std::snprintf(msg, sizeof msg,
+                                          "multigrid on %d ranks needs even z-slab boundaries on the finest level "
+                                          "(rank %d owns planes [%lld,%lld))", P, r, (long long)b, (long long)e);
+                            s->gmg_error = msg;  // the structure stays usable for the stencil twin / chunk order
+                        }
+                    }
+                    if (!s->gmg_error.empty()) break;
+                    replicated = true;
+                }
             }
+            s->gmg_own.push_back(oc);
         }
         for (int d = 0; d < 3; ++d) {
             if (nc[d] != nn[d]) {
@@ -645,38 +678,20 @@ static int halo_level(pib_solver *s, const GridLevel &g, double *x_owned, hipStr
     return halo_exchange_planes(s, x_owned, g.nloc, r > 0 ? pl : 0, r < P - 1 ? pl : 0, r > 0 ? pl : 0, r < P - 1 ? pl : 0, q);
 }
 
-// all-gather the owned part of a distributed coarse rhs into a replicated level vector
-static int gather_level(pib_solver *s, const GridLevel &src_owned_layout, const double *owned, int64_t n_owned,
+// all-gather the owned coarse planes of level `lc` (ownership = the finer level's slabs halved) into the
+// replicated level vector
+static int gather_level(pib_solver *s, int lc, int64_t coarse_plane, const double *owned, int64_t n_owned,
                         double *full_owned_base, hipStream_t q)
 {
-    (void)src_owned_layout;
     const int P = s->comm.nranks;
-    // equal counts per rank are guaranteed by the even-slab rule when n % P == 0; otherwise use broadcasts
     std::vector<int64_t> cnt((size_t)P), off((size_t)P);
-    bool equal = true;
-    int64_t total_planes = s->gather_planes_total;
-    int64_t o = 0;
     for (int r = 0; r < P; ++r) {
-        int64_t b, e;
-        slab_range(total_planes, P, r, &b, &e);
-        cnt[(size_t)r] = (e - b) * s->gather_plane_size;
-        off[(size_t)r] = o;
-        o += cnt[(size_t)r];
-        if (cnt[(size_t)r] != cnt[0]) equal = false;
+        const auto &o = s->gmg_own[(size_t)lc][(size_t)r];
+        cnt[(size_t)r] = (o.second - o.first) * coarse_plane;
+        off[(size_t)r] = o.first * coarse_plane;
     }
     if (cnt[(size_t)s->comm.rank] != n_owned) return fail(PIB_ERR_LIB, "gmg gather: inconsistent slab sizes");
-    if (equal) {
-        PIB_NCCL(ncclAllGather(owned, full_owned_base, (size_t)n_owned, ncclDouble, s->comm.comm, q));
-    } else {
-        PIB_NCCL(ncclGroupStart());
-        for (int r = 0; r < P; ++r) {
-            const double *src = (r == s->comm.rank) ? owned : full_owned_base + off[(size_t)r];
-            PIB_NCCL(ncclBroadcast(src, full_owned_base + off[(size_t)r], (size_t)cnt[(size_t)r], ncclDouble, r, s->comm.comm, q));
-        }
-        PIB_NCCL(ncclGroupEnd());
-    }
-    s->counters[3]++;
-    return 0;
+    return comm_allgatherv(s, owned, full_owned_base, cnt, off, q);
 }
 
 template <int MODE>
@@ -705,6 +720,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
 {
     if (!s->has_grid || s->levels.empty())
         return fail(PIB_ERR_ORDER, "solver %s: multigrid preconditioner without grid structure", s->name.c_str());
+    if (!s->gmg_error.empty()) return fail(PIB_ERR_SUP, "solver %s: %s", s->name.c_str(), s->gmg_error.c_str());
     const bool guarded = s->gmg_guarded;
     const Scalars *S = guarded ? s->d_s : nullptr;
     const double omega = s->cfg.smoother_relaxation;
@@ -760,17 +776,13 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         if (cg.replicated && !g.replicated && s->comm.nranks > 1) {
             // restrict the owned coarse planes into a scratch (cg.r), then all-gather into cg.b
             GridLevel own = cg;
-            own.k0 = g.k0 / 2;
-            own.k1 = (g.k1 == g.n[2]) ? cg.n[2] : g.k1 / 2;
+            own.k0 = s->gmg_own[(size_t)l + 1][(size_t)s->comm.rank].first;
+            own.k1 = s->gmg_own[(size_t)l + 1][(size_t)s->comm.rank].second;
             own.nloc = (own.k1 - own.k0) * cg.plane;
             double *scratch = cg.r + cg.plane;
             hipLaunchKernelGGL(k_restrict, level_grid(own), dim3(256), 0, q, S, dev_of(g), dev_of(own), rr, scratch);
             PIB_HIP(hipGetLastError());
-            s->gather_planes_total = cg.n[2];
-            s->gather_plane_size = cg.plane;
-            // ownership of coarse planes = fine slab halved, which equals slab_range(cg.n[2]) only when the fine
-            // split is even; grid_register guarantees it.
-            PIB_CHK(gather_level(s, own, scratch, own.nloc, cg.b + cg.plane, q));
+            PIB_CHK(gather_level(s, l + 1, cg.plane, scratch, own.nloc, cg.b + cg.plane, q));
         } else {
             hipLaunchKernelGGL(k_restrict, level_grid(cg), dim3(256), 0, q, S, dev_of(g), dev_of(cg), rr,
                                cg.b + cg.plane);

@@ -139,11 +139,7 @@ static int launch_vec(pib_solver *s, int64_t n, const Op &op, bool vec2, int slo
 
 int allreduce_slots(pib_solver *s, int first, int count, hipStream_t stq)
 {
-    if (s->comm.nranks > 1) {
-        PIB_NCCL(ncclAllReduce(&s->d_s->red[first], &s->d_s->red[first], count, ncclDouble, ncclSum, s->comm.comm, stq));
-        s->counters[2]++;
-    }
-    return 0;
+    return comm_allreduce_sum(s, &s->d_s->red[first], count, stq);
 }
 
 static int finalize(pib_solver *s, int slot0, int nslots, int count, hipStream_t stq)

@@ -131,8 +131,10 @@ struct GridLevel {
     int64_t nloc = 0, plane = 0;
 };
 
+struct LoopbackGroup;  // halo.hip: test-only transport (ranks = threads of one process on one GPU)
 struct Comm {
     ncclComm_t comm = nullptr;
+    LoopbackGroup *loop = nullptr;
     int rank = 0, nranks = 1;
 };
 
@@ -153,9 +155,11 @@ struct pib_solver {
     std::vector<pib::GridLevel> levels;
     std::vector<double *> gmg_spare = std::vector<double *>(64, nullptr);
     bool gmg_guarded = true;
+    std::string gmg_error;  // why the hierarchy could not be built (reported when a multigrid solve is asked for)
     std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
     double asm_dt = 0.0;
-    int64_t gather_planes_total = 0, gather_plane_size = 0;
+    // multi-GPU multigrid: plane ownership [b,e) of every rank on every level (level-0 slabs halved level by level)
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> gmg_own;
     // work vectors: each ghost-padded [ghost_lo + n + ghost_hi]
     double *work = nullptr, *work_base = nullptr;
     int64_t work_stride = 0;
@@ -191,6 +195,10 @@ int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st);
 int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, int64_t hi, int64_t send_prev,
                          int64_t send_next, hipStream_t st);
 int allreduce_slots(pib_solver *s, int first, int count, hipStream_t st);
+int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st);
+int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const std::vector<int64_t> &counts,
+                    const std::vector<int64_t> &offs, hipStream_t st);
+void comm_release(pib_solver *s);
 // krylov.hip
 int solve_cg(pib_solver *s, double *x, const double *b);
 int solve_bicgstab(pib_solver *s, double *x, const double *b);
