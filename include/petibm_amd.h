@@ -151,6 +151,17 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
 int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                          const double *wz, double dt, int nullspace);
 
+/* Assemble the velocity operator A = I/dt - c*nu*L directly in HBM and set it as the solver's matrix:
+ * createLaplacian (src/operators/createlaplacian.cpp:108-263, incl. the ghost-point a0 fold :232-243) on the
+ * packed (u,v[,w]) ordering, then MatScale(-c*nu) + MatShift(1/dt) (navierstokes.cpp:342-344), evaluated in
+ * the reference's floating-point order.  w[d]: pressure-cell widths; lo/hi: domain start / end per direction
+ * (mesh->min / mesh->max); a0[6*f + loc]: ghost coefficient of field f at boundary loc (xMinus,xPlus,yMinus,
+ * yPlus,zMinus,zPlus): Dirichlet/convective 0 when loc's normal is f else -1, Neumann 1
+ * (src/boundary/singleboundary{dirichlet,neumann,convective}.cpp).  Non-periodic meshes, single rank. */
+int pib_assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
+                          const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
+                          double coeff_nu);
+
 /* The z-slab (y-slab in 2D) of planes [*begin, *end) that rank `rank` of `nranks`
  * owns: the DMDA default split m = N/P + ((N % P) > rank) the reference gets from
  * DMDACreate3d (src/mesh/cartesianmesh.cpp:492-538).  Pure host code. */

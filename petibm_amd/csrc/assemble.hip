@@ -258,3 +258,193 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
 }
 
 }  // namespace pib
+
+// ============================================================================
+// Velocity operator A = I/dt - c nu L assembled directly in HBM (K9, a-8, a-9).
+//
+//   L: petibm::operators::createLaplacian (src/operators/createlaplacian.cpp:108-263) on the packed
+//      (u,v[,w]) ordering of one rank (src/mesh/cartesianmesh.cpp:741-779): per velocity point and direction
+//      1/(dLNeg*dLSelf), 1/(dLPos*dLSelf) with dLSelf = dL[f][dir][self] and dLNeg/dLPos = coordinate
+//      differences including the ghost coordinates (:134-148); diagonal = -accumulate(values, 0.0) in stencil
+//      order x-,x+,y-,y+,z-,z+ (:151); ghost columns dropped; then L[row,row] += coeff*a0 per ghost (:232-243).
+//   A: MatDuplicate(L); MatScale(A, -c nu); MatShift(A, 1/dt)   (applications/navierstokes/navierstokes.cpp:342-344)
+//   mesh arithmetic: CartesianMesh::createVelocityMesh (src/mesh/cartesianmesh.cpp:213-355), non-periodic.
+// Same floating-point evaluation order as the oracle (oracle/operators.py): bit-identical entries.
+// Single rank only (the packed ordering interleaves the fields per rank: its halo is not a contiguous plane).
+namespace pib {
+
+struct FieldDev {
+    int64_t n[3];        // points of this field
+    int64_t row_off;     // first packed row of the field's block
+    int64_t nnz_off;     // first nnz of the field's block
+    const double *dl[3];     // dL[f][d], index s+1 (ghost at 0)
+    const double *co[3];     // coord[f][d], index s+1
+    double a0[6];            // ghost coefficient per boundary location (0 where periodic / unused)
+};
+
+template <typename RP>
+__global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, double scale, double shift,
+                                                           RP *__restrict__ rowptr, int32_t *__restrict__ col,
+                                                           double *__restrict__ val, int last_field)
+{
+    const int64_t nx = F.n[0], ny = F.n[1], nz = F.n[2], pl = nx * ny, nf = pl * nz;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= nf; r += (int64_t)gridDim.x * 256) {
+        int64_t p = F.nnz_off + nnz_before(r, dim, nx, ny, nz);
+        if (r < nf || last_field) rowptr[F.row_off + r] = (RP)p;
+        if (r == nf) break;
+        const int64_t ijk[3] = {r % nx, (r / nx) % ny, r / pl};
+        double v[6] = {0, 0, 0, 0, 0, 0};
+        bool interior[6] = {false, false, false, false, false, false};
+        double acc = 0.0;
+        for (int d = 0; d < dim; ++d) {
+            const int64_t sidx = ijk[d];
+            const double dLSelf = F.dl[d][sidx + 1];
+            const double dLNeg = F.co[d][sidx + 1] - F.co[d][sidx];
+            const double dLPos = F.co[d][sidx + 2] - F.co[d][sidx + 1];
+            v[2 * d] = 1.0 / (dLNeg * dLSelf);
+            v[2 * d + 1] = 1.0 / (dLPos * dLSelf);
+            interior[2 * d] = sidx > 0;
+            interior[2 * d + 1] = sidx < F.n[d] - 1;
+            acc = acc + v[2 * d];
+            acc = acc + v[2 * d + 1];
+        }
+        double diag = -acc;
+        for (int q = 0; q < 2 * dim; ++q)
+            if (!interior[q]) {
+                const double t = v[q] * F.a0[q];
+                if (t != 0.0) diag = diag + t;  // MAT_IGNORE_ZERO_ENTRIES: a zero fold is not added
+            }
+        const int64_t lc = F.row_off + r;
+        const int64_t st[3] = {1, nx, pl};
+        // columns ascending: z-, y-, x-, diag, x+, y+, z+
+        for (int d = dim - 1; d >= 0; --d)
+            if (interior[2 * d]) {
+                col[p] = (int32_t)(lc - st[d]);
+                val[p] = v[2 * d] * scale;
+                ++p;
+            }
+        col[p] = (int32_t)lc;
+        val[p] = diag * scale + shift;
+        ++p;
+        for (int d = 0; d < dim; ++d)
+            if (interior[2 * d + 1]) {
+                col[p] = (int32_t)(lc + st[d]);
+                val[p] = v[2 * d + 1] * scale;
+                ++p;
+            }
+    }
+}
+
+int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
+                      const double mx[3], const double a0[18], double dt, double coeff_nu)
+{
+    if (dim != 2 && dim != 3) return fail(PIB_ERR_ARG_OUTOFRANGE, "assemble_velocity: dim must be 2 or 3");
+    if (s->comm.nranks > 1) return fail(PIB_ERR_SUP, "assemble_velocity: single rank only (packed ordering)");
+    for (int d = 0; d < dim; ++d)
+        if (n[d] < 2 || w[d] == nullptr) return fail(PIB_ERR_ARG_SIZ, "assemble_velocity: need >= 2 cells per direction");
+    // ---- host mesh arithmetic (cartesianmesh.cpp:136-355, non-periodic)
+    std::vector<double> c3[3], c4[3];
+    for (int d = 0; d < dim; ++d) {
+        const int64_t nd = n[d];
+        c3[d].resize((size_t)nd);
+        c4[d].resize((size_t)nd + 1);
+        double run = 0.0;
+        c4[d][0] = 0.0 + mn[d];
+        for (int64_t q = 0; q < nd; ++q) {
+            run = (q == 0) ? w[d][0] : run + w[d][q];  // std::partial_sum
+            c3[d][(size_t)q] = (run + mn[d]) - 0.5 * w[d][q];
+            c4[d][(size_t)q + 1] = run + mn[d];
+        }
+    }
+    std::vector<double> hdl[3][3], hco[3][3];
+    int64_t fn[3][3];
+    for (int f = 0; f < dim; ++f)
+        for (int d = 0; d < 3; ++d) {
+            if (d >= dim) {
+                fn[f][d] = 1;
+                continue;
+            }
+            const int64_t n3 = n[d];
+            if (d == f) {
+                const int64_t nf = n3 - 1;
+                fn[f][d] = nf;
+                hco[f][d] = c4[d];  // n3+1 = nf+2 entries: vertices, ghosts = the walls
+                hdl[f][d].assign((size_t)nf + 2, 0.0);
+                hdl[f][d][0] = w[d][0];
+                for (int64_t q = 1; q < n3; ++q) hdl[f][d][(size_t)q] = 0.5 * (w[d][q] + w[d][q - 1]);
+                hdl[f][d][(size_t)nf + 1] = w[d][n3 - 1];
+            } else {
+                fn[f][d] = n3;
+                hco[f][d].assign((size_t)n3 + 2, 0.0);
+                hdl[f][d].assign((size_t)n3 + 2, 0.0);
+                for (int64_t q = 0; q < n3; ++q) {
+                    hco[f][d][(size_t)q + 1] = c3[d][(size_t)q];
+                    hdl[f][d][(size_t)q + 1] = w[d][q];
+                }
+                hco[f][d][0] = mn[d] - w[d][0] / 2.0;
+                hco[f][d][(size_t)n3 + 1] = mx[d] + w[d][n3 - 1] / 2.0;
+                hdl[f][d][0] = w[d][0];
+                hdl[f][d][(size_t)n3 + 1] = w[d][n3 - 1];
+            }
+        }
+    // ---- sizes
+    int64_t rows = 0, nnz = 0, row_off[3] = {0, 0, 0}, nnz_off[3] = {0, 0, 0};
+    for (int f = 0; f < dim; ++f) {
+        row_off[f] = rows;
+        nnz_off[f] = nnz;
+        const int64_t nf = fn[f][0] * fn[f][1] * fn[f][2];
+        rows += nf;
+        nnz += nnz_before(nf, dim, fn[f][0], fn[f][1], fn[f][2]);
+    }
+    DeviceCsr &A = s->A;
+    A.release();
+    A.n = rows;
+    A.row0 = 0;
+    A.n_global = rows;
+    A.ghost_lo = A.ghost_hi = 0;
+    A.nnz = nnz;
+    A.rp64 = nnz >= (int64_t)std::numeric_limits<int32_t>::max();
+    if (rows >= (int64_t)std::numeric_limits<int32_t>::max())
+        return fail(PIB_ERR_SUP, "assemble_velocity: more than 2^31 rows on one GPU");
+    PIB_HIP(hipMalloc(&A.rowptr, (A.rp64 ? 8 : 4) * ((size_t)rows + 1)));
+    PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMemsetAsync(A.col + nnz, 0, sizeof(int32_t) * 4, s->stream));
+    PIB_HIP(hipMemsetAsync(A.val + nnz, 0, sizeof(double) * 4, s->stream));
+    const double scale = -coeff_nu, shift = 1.0 / dt;
+    std::vector<double *> tofree;
+    for (int f = 0; f < dim; ++f) {
+        FieldDev F;
+        for (int d = 0; d < 3; ++d) {
+            F.n[d] = fn[f][d];
+            F.dl[d] = F.co[d] = nullptr;
+            if (d < dim) {
+                double *p1 = nullptr, *p2 = nullptr;
+                PIB_CHK(upload_vec(hdl[f][d], &p1));
+                PIB_CHK(upload_vec(hco[f][d], &p2));
+                F.dl[d] = p1;
+                F.co[d] = p2;
+                tofree.push_back(p1);
+                tofree.push_back(p2);
+            }
+        }
+        F.row_off = row_off[f];
+        F.nnz_off = nnz_off[f];
+        for (int q = 0; q < 6; ++q) F.a0[q] = a0[6 * f + q];
+        const int64_t nf = fn[f][0] * fn[f][1] * fn[f][2];
+        const int nb = (int)std::min<int64_t>(8192, (nf + 1 + 255) / 256);
+        const int last = (f == dim - 1) ? 1 : 0;
+        if (A.rp64)
+            hipLaunchKernelGGL(k_assemble_velocity<int64_t>, dim3(nb), dim3(256), 0, s->stream, dim, F, scale, shift,
+                               (int64_t *)A.rowptr, A.col, A.val, last);
+        else
+            hipLaunchKernelGGL(k_assemble_velocity<int32_t>, dim3(nb), dim3(256), 0, s->stream, dim, F, scale, shift,
+                               (int32_t *)A.rowptr, A.col, A.val, last);
+        PIB_HIP(hipGetLastError());
+    }
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    for (double *p : tofree) (void)hipFree(p);
+    return 0;
+}
+
+}  // namespace pib

@@ -200,6 +200,21 @@ int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const doubl
     return grid_register(s, dim, n, cw, cg, nullspace, s->asm_dt);
 }
 
+int pib_assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
+                          const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
+                          double coeff_nu)
+{
+    if (s == nullptr || n == nullptr || lo == nullptr || hi == nullptr || a0 == nullptr)
+        return fail(PIB_ERR_ARG_NULL, "pib_assemble_velocity: null argument");
+    PIB_HIP(hipSetDevice(s->device));
+    s->has_matrix = false;
+    s->has_grid = false;
+    gmg_release(s);
+    const double *w[3] = {wx, wy, wz};
+    PIB_CHK(assemble_velocity(s, dim, n, w, lo, hi, a0, dt, coeff_nu));
+    return after_set_matrix(s);
+}
+
 static bool is_device_ptr(const void *p)
 {
     hipPointerAttribute_t a;

@@ -205,6 +205,8 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b);
 int ensure_work(pib_solver *s, int nvec);
 // assemble.hip
 int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);
+int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
+                      const double mx[3], const double a0[18], double dt, double coeff_nu);
 int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rowptr,
                const int64_t *col, const int32_t *rowptr32, const int32_t *col32, const double *val);
 void slab_range(int64_t nplanes, int nranks, int rank, int64_t *b, int64_t *e);

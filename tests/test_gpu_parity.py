@@ -470,3 +470,50 @@ def test_cpp_host_mirror_demo_runs():
     out = subprocess.run([exe], capture_output=True, text=True, cwd=root, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Type: NVIDIA AmgX" in out.stdout and "recomputed ||b-Ax||/||b||" in out.stdout
+
+
+# ------------------------------------------------ velocity operator assembled on the device (K9, a-8, a-9)
+def _a0_table(mesh):
+    a0 = np.zeros((3, 6))
+    for f in range(mesh.dim):
+        for loc in range(2 * mesh.dim):
+            t = mesh.bc_types.get((f, loc), "NOBC")
+            if t not in ("NOBC", "PERIODIC"):
+                a0[f, loc] = oops.bc_a0(t, f, loc)
+    return a0
+
+
+def _outflow_3d():
+    cfg = stretched_3d((10, 9, 8))
+    bcs = cfg["flow"]["boundaryConditions"]
+    bcs[1]["u"] = ["CONVECTIVE", 1.0]
+    bcs[1]["v"] = ["CONVECTIVE", 1.0]
+    bcs[1]["w"] = ["CONVECTIVE", 1.0]
+    bcs[5]["u"] = ["NEUMANN", 0.0]
+    bcs[5]["v"] = ["NEUMANN", 0.0]
+    bcs[5]["w"] = ["NEUMANN", 0.0]
+    return cfg
+
+
+@pytest.mark.parametrize("case", ["2d_stretched", "3d_stretched", "3d_outflow"])
+def test_device_velocity_operator_bit_exact_and_bicgstab(lin, case):
+    cfg = {"2d_stretched": STRETCHED_2D, "3d_stretched": stretched_3d(), "3d_outflow": _outflow_3d()}[case]
+    m = omesh.create_mesh(cfg)
+    L = oops.create_laplacian(m)
+    dt, cnu = 0.004, 0.5 * 0.01
+    A = oops.create_velocity_operator(L, dt, cnu)
+    s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12,
+                                                          conv="ABSOLUTE", maxit=500))
+    n = [int(v) for v in m.n[3][: m.dim]]
+    s.assembleVelocity(n, [m.dL[3][d].true for d in range(m.dim)], m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
+    rp, cl, vl = s.getCSR()
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(cl, A.col)
+    assert np.array_equal(vl, A.val)  # same floating-point order as createLaplacian + MatScale + MatShift
+    us = np.random.default_rng(2).uniform(-1, 1, A.n_rows)
+    b = clib.spmv(A, us)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    ref = clib.bcgs(A, b, pc="jacobi", norm="unpreconditioned", rtol=0.0, atol=1e-12, dtol=1e300, maxit=500)
+    assert iters_close(s.getIters(), ref["iters"]) and s.getIters() < 30
+    assert np.linalg.norm(x - us) <= 1e-10 * np.linalg.norm(us)
+    s.destroy()
