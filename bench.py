@@ -31,13 +31,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
-def solver_config(pc: str, tol: float, max_iters: int) -> str:
+def solver_config(pc: str, tol: float, max_iters: int, omega: float = 0.9, pre: int = 1, post: int = 1) -> str:
     prec = {"gmg": "AMG", "jacobi": "BLOCK_JACOBI", "none": "NOSOLVER"}[pc]
     return (f"config_version=2\nsolver(solv)=PCG\nsolv:max_iters={max_iters}\nsolv:monitor_residual=1\n"
             f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
             f"solv:preconditioner(prec)={prec}\nprec:relaxation_factor=1.0\n"
-            "prec:cycle=V\nprec:presweeps=1\nprec:postsweeps=1\nprec:smoother(smooth)=BLOCK_JACOBI\n"
-            "smooth:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n")
+            f"prec:cycle=V\nprec:presweeps={pre}\nprec:postsweeps={post}\nprec:smoother(smooth)=BLOCK_JACOBI\n"
+            f"smooth:relaxation_factor={omega}\npib_initial_guess_nonzero=0\n")
 
 
 def slab(nplanes: int, nranks: int, rank: int):
@@ -112,6 +112,62 @@ def measured_traffic(n: int, world: int):
     return None
 
 
+def velocity_bench(args):
+    """Secondary line (not the BASELINE metric): the velocity solve of the same cavity,
+    A = I/dt - c nu L (navierstokes.cpp:342-344) with PBICGSTAB + BLOCK_JACOBI to an absolute residual of 1e-10
+    (examples/navierstokes/taylorgreenvortex3dRe1600_GPU/config/velocity_solver.info), single GPU.  At 512^3 the
+    operator has 2.8e9 non-zeros: the 64-bit row-offset kernels."""
+    import torch
+    assert torch.cuda.is_available()
+    from petibm_amd.linsolver import LinSolverHIP
+    n = args.n
+    dt, nu = (5e-4, 1e-3) if n == 512 else (1e-3, 1e-3)
+    cfg = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
+           "solv:convergence=ABSOLUTE\nsolv:tolerance=1e-10\nsolv:norm=L2\nsolv:store_res_history=1\n"
+           "solv:preconditioner(prec)=BLOCK_JACOBI\nprec:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n")
+    s = LinSolverHIP("velocity", config_text=cfg)
+    w = np.full(n, 1.0 / n)
+    a0 = np.array([[0.0 if (loc // 2) == f else -1.0 for loc in range(6)] for f in range(3)])  # all-Dirichlet cavity
+    t0 = time.perf_counter()
+    s.assembleVelocity((n, n, n), [w, w, w], (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), a0, dt, 0.5 * nu)
+    s.synchronize()
+    t_setup = time.perf_counter() - t0
+    UN = s.n_local
+    us_d, b_d, x_d = s.deviceVec(), s.deviceVec(), s.deviceVec()
+    rng = np.random.default_rng(20260928)
+    chunk = 1 << 24
+    from petibm_amd import capi
+    for off in range(0, UN, chunk):  # u* uniform in [-1,1), uploaded in pieces
+        m = min(chunk, UN - off)
+        a = rng.uniform(-1.0, 1.0, m)
+        capi.check(capi.load().pib_memcpy_h2d(s._h, us_d.ptr + 8 * off, a.ctypes.data, 8 * m))
+    s.matMult(us_d, b_d)
+    for _ in range(args.warmup):
+        s.solve(x_d, b_d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(args.steps):
+        s.solve(x_d, b_d)
+        its += s.getIters()
+    s.synchronize()
+    el = time.perf_counter() - t0
+    ms_spmv = s.timeKernel(0, args.kernel_reps)
+    rp_bytes = 8 if s.nnz >= 2 ** 31 - 1 else 4
+    alg = 12.0 * s.nnz + rp_bytes * (UN + 1) + 16.0 * UN
+    print(json.dumps({
+        "metric": "velocity-system DOF/s (BiCGStab+Jacobi to |r| <= 1e-10), secondary line", "value": UN * args.steps / el,
+        "unit": "DOF/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+        "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n}^3 cavity velocity system A = I/dt - c nu L, {UN} rows, {s.nnz} nnz, "
+                               f"{8 * rp_bytes}-bit row offsets"},
+        "iters_per_solve": its / args.steps, "final_residual": s.getResidual(), "setup_s": t_setup,
+        "roofline": {"bound": "hbm", "kernel": f"pib::k_spmv_lds<int{8 * rp_bytes}>", "achieved": alg / ms_spmv / 1e6,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ms_spmv / 1e6 / HBM_PEAK_GBS,
+                     "ms_per_launch": ms_spmv, "algorithmic_bytes": alg}}), flush=True)
+    s.destroy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,7 +179,14 @@ def main():
     ap.add_argument("--max-iters", type=int, default=20000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--omega", type=float, default=0.9, help="Jacobi smoother relaxation factor of the V-cycle")
+    ap.add_argument("--presweeps", type=int, default=1)
+    ap.add_argument("--postsweeps", type=int, default=1)
+    ap.add_argument("--system", default="poisson", choices=["poisson", "velocity"],
+                    help="poisson (the BASELINE metric) or the velocity system A = I/dt - c nu L with BiCGStab+Jacobi")
     args = ap.parse_args()
+    if args.system == "velocity":
+        return velocity_bench(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -166,7 +229,8 @@ def main():
 
     n = args.n
     dt = 5e-4 if n == 512 else 1e-3  # cfg3 (512^3) dt=5e-4, cfg2 (256^3) dt=1e-3
-    s = LinSolverHIP("poisson", config_text=solver_config(args.pc, args.tol, args.max_iters), rank=rank,
+    s = LinSolverHIP("poisson", config_text=solver_config(args.pc, args.tol, args.max_iters, args.omega, args.presweeps,
+                                                           args.postsweeps), rank=rank,
                      nranks=world, uid=uid, device=local)
     w = np.full(n, 1.0 / n)
     t_setup = time.perf_counter()
