@@ -31,8 +31,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
-def solver_config(pc: str, tol: float, max_iters: int, omega: float = 0.9, pre: int = 1, post: int = 1) -> str:
+def solver_config(pc: str, tol: float, max_iters: int, omega: float = 0.9, pre: int = 1, post: int = 1,
+                  smoother: str = "jacobi") -> str:
     prec = {"gmg": "AMG", "jacobi": "BLOCK_JACOBI", "none": "NOSOLVER"}[pc]
+    if smoother == "chebyshev":
+        return (f"config_version=2\nsolver(solv)=PCG\nsolv:max_iters={max_iters}\nsolv:monitor_residual=1\n"
+                f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
+                f"solv:preconditioner(prec)={prec}\nprec:relaxation_factor=1.0\n"
+                f"prec:cycle=V\nprec:presweeps={pre}\nprec:postsweeps={post}\nprec:smoother(smooth)=CHEBYSHEV_POLY\n"
+                "smooth:chebyshev_polynomial_order=2\nsmooth:cheby_max_lambda=2.0\nsmooth:cheby_min_lambda=0.5\n"
+                "pib_initial_guess_nonzero=0\n")
     return (f"config_version=2\nsolver(solv)=PCG\nsolv:max_iters={max_iters}\nsolv:monitor_residual=1\n"
             f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
             f"solv:preconditioner(prec)={prec}\nprec:relaxation_factor=1.0\n"
@@ -62,6 +70,7 @@ def cpu_baseline(n_gpu: int, tol: float, dt: float, budget_s: float = 45.0):
     a calibration solve at n/2 says it fits the time budget and the host has the memory; otherwise the
     bounded sample is the largest power-of-two cavity that does."""
     from oracle import clib
+    clib.set_threads(os.cpu_count() or 1)  # all host cores (the oracle defaults to 8 for the tiny test systems)
     cores = clib.num_threads()
 
     def run(n):
@@ -180,6 +189,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--omega", type=float, default=0.9, help="Jacobi smoother relaxation factor of the V-cycle")
+    ap.add_argument("--smoother", default="jacobi", choices=["jacobi", "chebyshev"])
     ap.add_argument("--presweeps", type=int, default=1)
     ap.add_argument("--postsweeps", type=int, default=1)
     ap.add_argument("--system", default="poisson", choices=["poisson", "velocity"],
@@ -230,7 +240,7 @@ def main():
     n = args.n
     dt = 5e-4 if n == 512 else 1e-3  # cfg3 (512^3) dt=5e-4, cfg2 (256^3) dt=1e-3
     s = LinSolverHIP("poisson", config_text=solver_config(args.pc, args.tol, args.max_iters, args.omega, args.presweeps,
-                                                           args.postsweeps), rank=rank,
+                                                           args.postsweeps, args.smoother), rank=rank,
                      nranks=world, uid=uid, device=local)
     w = np.full(n, 1.0 / n)
     t_setup = time.perf_counter()

@@ -52,6 +52,9 @@ def lib():
         _lib.orc_axpy_pattern_count.restype = C.c_int64
         _lib.orc_axpy_pattern_fill.argtypes = [C.c_int64, C.c_double, _i64p, _i64p, _f64p, _i64p, _i64p, _f64p, _i64p,
                                                _i64p, _f64p]
+        # the parity tests run tiny systems: a 128-thread OpenMP team on 132-cell grids spends minutes in
+        # fork/join.  Default to <= 8 threads; the cpu_baseline leg of bench.py asks for all cores explicitly.
+        _lib.orc_set_threads(max(1, min(8, os.cpu_count() or 1)))
     return _lib
 
 
@@ -153,6 +156,12 @@ class GMG:
                                    float(omega), int(coarsest_sweeps), int(max_levels))
         self.N = int(np.prod(self.n))
         self.nullspace = nullspace
+        L.orc_gmg_set_chebyshev.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+
+    def set_chebyshev(self, lmax=2.0, ratio=4.0, on=True):
+        """Chebyshev-Jacobi smoothing: pre/post given at construction are then the number of recurrence steps."""
+        lib().orc_gmg_set_chebyshev(self._h, 1 if on else 0, float(lmax), float(ratio))
+        return self
 
     def num_levels(self):
         return int(lib().orc_gmg_num_levels(self._h))

@@ -52,6 +52,9 @@ typedef struct {
     int pre, post, coarsest_sweeps;
     double omega;
     int nullspace; /* 0 none 1 constant 2 pinned */
+    int smoother;  /* 0 damped Jacobi, 1 Chebyshev-Jacobi (pre/post = polynomial degree) */
+    double cheb_lmax, cheb_ratio; /* eigenvalue window [lmax/ratio, lmax] of D^-1 A */
+    double *d[MAXLEV];
 } gmg_t;
 
 static double vec_sum(i64 n, const double *a);
@@ -130,6 +133,7 @@ void *orc_gmg_create(int dim, const i64 *n_in, const double *wx, const double *w
         make_g(l, dt);
         l->x = calloc((size_t)l->N, 8); l->x2 = calloc((size_t)l->N, 8);
         l->b = calloc((size_t)l->N, 8); l->r = calloc((size_t)l->N, 8);
+        G->d[nl - 1] = calloc((size_t)l->N, 8);
         if (nl >= max_levels) break;
         if (l->n[0] <= 2 && l->n[1] <= 2 && l->n[2] <= 2) break;
         level_t *c = &G->L[nl];
@@ -150,7 +154,7 @@ void *orc_gmg_create(int dim, const i64 *n_in, const double *wx, const double *w
 void orc_gmg_destroy(void *h)
 {
     gmg_t *G = h;
-    for (int i = 0; i < G->nlev; ++i) lvl_free(&G->L[i]);
+    for (int i = 0; i < G->nlev; ++i) { lvl_free(&G->L[i]); free(G->d[i]); }
     free(G);
 }
 
@@ -281,6 +285,47 @@ static void restrict_t(const level_t *f, const level_t *c, const double *rf, dou
             }
 }
 
+/* Chebyshev-Jacobi: `deg` steps of the three-term recurrence on D^-1 A over [lmax/ratio, lmax];
+ * x in/out (zero_guess: x starts at 0), d = work vector, tmp = ping-pong buffer for x */
+static double *cheby(gmg_t *G, level_t *l, int lev, int deg, const double *b, double *x, double *x2, int zero_guess)
+{
+    const double lmax = G->cheb_lmax, lmin = lmax / G->cheb_ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    double *d = G->d[lev], *cur = x, *nxt = x2;
+    for (int s = 0; s < deg; ++s) {
+        const double c_d = (s == 0) ? 0.0 : 0.0; (void)c_d;
+        double rho_new = (s == 0) ? rho : 1.0 / (2.0 * sigma - rho);
+        const double a_d = (s == 0) ? 0.0 : rho_new * rho;
+        const double a_z = (s == 0) ? 1.0 / theta : 2.0 * rho_new / delta;
+        const int zg = zero_guess && s == 0;
+#pragma omp parallel for schedule(static)
+        for (i64 k = 0; k < l->n[2]; ++k)
+            for (i64 j = 0; j < l->n[1]; ++j)
+                for (i64 i = 0; i < l->n[0]; ++i) {
+                    const i64 p = idx(l, i, j, k);
+                    double dg, z;
+                    if (zg) {
+                        double c[6];
+                        face_coefs(l, i, j, k, c);
+                        dg = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
+                        z = b[p] / dg;
+                        d[p] = a_z * z;
+                        nxt[p] = d[p];
+                    } else {
+                        const double ax = apply_cell(l, cur, i, j, k, &dg);
+                        z = (b[p] - ax) / dg;
+                        const double dn = a_d * d[p] + a_z * z;
+                        d[p] = dn;
+                        nxt[p] = cur[p] + dn;
+                    }
+                }
+        if (s > 0) rho = rho_new;
+        double *t = cur; cur = nxt; nxt = t;
+    }
+    return cur;
+}
+
 static void vcycle(gmg_t *G, int lev)
 {
     level_t *l = &G->L[lev];
@@ -296,15 +341,23 @@ static void vcycle(gmg_t *G, int lev)
         return;
     }
     double *a = l->x, *b2 = l->x2;
+    if (G->smoother == 1) {
+        a = cheby(G, l, lev, G->pre, l->b, l->x2, l->x, 1);  /* first step writes into l->x */
+        b2 = (a == l->x) ? l->x2 : l->x;
+    } else {
     smooth(l, G->omega, l->b, NULL, a, 1);
     for (int s = 1; s < G->pre; ++s) {
         smooth(l, G->omega, l->b, a, b2, 0);
         double *t = a; a = b2; b2 = t;
     }
+    }
     residual(l, l->b, a, l->r);
     restrict_t(l, &G->L[lev + 1], l->r, G->L[lev + 1].b);
     vcycle(G, lev + 1);
     prolong_add(l, &G->L[lev + 1], G->L[lev + 1].x, a);
+    if (G->smoother == 1) {
+        a = cheby(G, l, lev, G->post, l->b, a, b2, 0);
+    } else
     for (int s = 0; s < G->post; ++s) {
         smooth(l, G->omega, l->b, a, b2, 0);
         double *t = a; a = b2; b2 = t;
@@ -539,4 +592,12 @@ done:
     *rnorm_out = dp;
     free(R); free(Z); free(P); free(W);
     return reason;
+}
+
+void orc_gmg_set_chebyshev(void *h, int on, double lmax, double ratio)
+{
+    gmg_t *G = h;
+    G->smoother = on;
+    G->cheb_lmax = lmax;
+    G->cheb_ratio = ratio;
 }

@@ -195,6 +195,12 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
             return fail(PIB_ERR_SUP, "config: smoother=%s is not supported", sm.c_str());
         c.smoother_relaxation = std::atof(d.get(sms, "relaxation_factor", "0.9").c_str());
         c.cheby_degree = std::atoi(d.get(sms, "chebyshev_polynomial_order", "2").c_str());
+        c.cheby_lmax = std::atof(d.get(sms, "cheby_max_lambda", "2.0").c_str());
+        {
+            const double lmin = std::atof(d.get(sms, "cheby_min_lambda", "0.5").c_str());
+            if (!(lmin > 0.0) || !(c.cheby_lmax > lmin)) return fail(PIB_ERR_ARG_OUTOFRANGE, "config: need 0 < cheby_min_lambda < cheby_max_lambda");
+            c.cheby_ratio = c.cheby_lmax / lmin;
+        }
     } else {
         return fail(PIB_ERR_SUP, "config: preconditioner=%s is not supported (NOSOLVER, BLOCK_JACOBI, AMG)", pc.c_str());
     }

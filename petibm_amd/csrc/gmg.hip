@@ -88,10 +88,13 @@ __device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__
 // read as one 16/32-byte access each, index arithmetic and the j/k coefficients are amortised over C cells.
 // One cell per lane ran at 1.9 TB/s (24 B/cell) on the 512^3 level, four cells per lane at 3.7 TB/s
 // (tools/gmg_lab.hip); the arithmetic per cell is unchanged, so results are bit-identical.
+// mode 5: Chebyshev-Jacobi step   d = a_d d + a_z (b - A xi)/diag ; xo = xi + d      (omega carries a_z)
+// mode 6: first Chebyshev step from a zero guess:  d = a_z b/diag ; xo = d
 template <int MODE, int C>
 __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                const double *__restrict__ b, const double *__restrict__ xi,
-                                               double *__restrict__ xo, const double *__restrict__ pin_sum)
+                                               double *__restrict__ xo, const double *__restrict__ pin_sum,
+                                               double *__restrict__ dvec, double a_d)
 {
     if (S != nullptr && S->done) return;
     typedef double vt __attribute__((ext_vector_type(C), aligned(C == 1 ? 8 : 16)));
@@ -111,7 +114,9 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
         const double ax = wyj * wzk;
         vt xc, bv, ym, yp, zm, zp, out;
         double xl = 0.0, xr = 0.0;
-        if (MODE != 1) {
+        vt dv;
+        if (MODE == 5 && a_d != 0.0) dv = *reinterpret_cast<const vt *>(dvec + p);
+        if (MODE != 1 && MODE != 6) {
             xc = *reinterpret_cast<const vt *>(xi + p);
             ym = yp = zm = zp = xc;
             if (i0 > 0) xl = xi[p - 1];
@@ -139,6 +144,11 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
                 out[c] = omega * (bv[c] / d);
                 continue;
             }
+            if (MODE == 6) {
+                out[c] = omega * (bv[c] / d);
+                dv[c] = out[c];
+                continue;
+            }
             const double left = (c == 0) ? xl : xc[c > 0 ? c - 1 : 0];
             const double right = (c == C - 1) ? xr : xc[c < C - 1 ? c + 1 : 0];
             const double xcc = xc[c];
@@ -153,9 +163,15 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
                 out[c] = s;
             else if (MODE == 2)
                 out[c] = xcc + omega * ((bv[c] - s) / d);
-            else
+            else if (MODE == 5) {
+                const double z = (bv[c] - s) / d;
+                const double dn = (a_d != 0.0) ? a_d * dv[c] + omega * z : omega * z;
+                dv[c] = dn;
+                out[c] = xcc + dn;
+            } else
                 out[c] = bv[c] - s;
         }
+        if (MODE == 5 || MODE == 6) *reinterpret_cast<vt *>(dvec + p) = dv;
         *reinterpret_cast<vt *>(xo + p) = out;
     }
 }
@@ -436,6 +452,7 @@ void gmg_release(pib_solver *s)
         if (L.b) (void)hipFree(L.b);
         if (L.r) (void)hipFree(L.r);
         if (L.x2) (void)hipFree(L.x2);
+        if (L.d) (void)hipFree(L.d);
     }
     s->levels.clear();
     s->has_grid = false;
@@ -451,6 +468,8 @@ static int alloc_level_vectors(GridLevel &g, bool need_b)
     PIB_HIP(hipMemset(g.x, 0, sz));
     PIB_HIP(hipMemset(g.x2, 0, sz));
     PIB_HIP(hipMemset(g.r, 0, sz));
+    PIB_HIP(hipMalloc(&g.d, sz));
+    PIB_HIP(hipMemset(g.d, 0, sz));
     if (need_b) {
         PIB_HIP(hipMalloc(&g.b, sz));
         PIB_HIP(hipMemset(g.b, 0, sz));
@@ -462,7 +481,7 @@ static int alloc_level_vectors(GridLevel &g, bool need_b)
 
 template <int MODE>
 static int launch_level(pib_solver *s, const GridLevel &g, double omega, const double *b, const double *xi, double *xo,
-                        const double *pin_sum, bool guarded, hipStream_t q);
+                        const double *pin_sum, bool guarded, hipStream_t q, double *dvec = nullptr, double a_d = 0.0);
 
 // ---- hint verification: stencil twin vs CSR SpMV on a fixed pseudo-random vector
 // skip0: the pinned convention (row/column 0 of the CSR replaced by the identity) is the one place where
@@ -696,20 +715,20 @@ static int gather_level(pib_solver *s, int lc, int64_t coarse_plane, const doubl
 
 template <int MODE>
 static int launch_level(pib_solver *s, const GridLevel &g, double omega, const double *b, const double *xi, double *xo,
-                        const double *pin_sum, bool guarded, hipStream_t q)
+                        const double *pin_sum, bool guarded, hipStream_t q, double *dvec, double a_d)
 {
     const Scalars *S = guarded ? s->d_s : nullptr;
     const int64_t nx = g.n[0], ny = g.n[1];
     const unsigned nk = (unsigned)std::max<int64_t>(1, g.k1 - g.k0);
     auto aligned = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    const bool vec_ok = aligned(b) && aligned(xi) && aligned(xo);
+    const bool vec_ok = aligned(b) && aligned(xi) && aligned(xo) && aligned(dvec);
     auto gx = [&](int c) { return dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (nx / c * ny + 255) / 256)), nk); };
     if (vec_ok && nx % 4 == 0)
-        hipLaunchKernelGGL((k_level<MODE, 4>), gx(4), dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum);
+        hipLaunchKernelGGL((k_level<MODE, 4>), gx(4), dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, dvec, a_d);
     else if (vec_ok && nx % 2 == 0)
-        hipLaunchKernelGGL((k_level<MODE, 2>), gx(2), dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum);
+        hipLaunchKernelGGL((k_level<MODE, 2>), gx(2), dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, dvec, a_d);
     else
-        hipLaunchKernelGGL((k_level<MODE, 1>), gx(1), dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum);
+        hipLaunchKernelGGL((k_level<MODE, 1>), gx(1), dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, dvec, a_d);
     PIB_HIP(hipGetLastError());
     return 0;
 }
@@ -724,10 +743,47 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     const bool guarded = s->gmg_guarded;
     const Scalars *S = guarded ? s->d_s : nullptr;
     const double omega = s->cfg.smoother_relaxation;
-    const int pre = std::max(1, s->cfg.presweeps), post = std::max(0, s->cfg.postsweeps);
+    const bool cheb0 = (s->cfg.smoother == Smoother::CHEBYSHEV);
+    const int deg = cheb0 ? std::max(1, s->cfg.cheby_degree) : 1;  // one Chebyshev "sweep" = a degree-`deg` polynomial
+    const int pre = std::max(1, s->cfg.presweeps) * deg, post = std::max(0, s->cfg.postsweeps) * deg;
     const int nl = (int)s->levels.size();
     const double *pin = (s->nullspace == PIB_NULLSPACE_PINNED) ? &s->d_s->red[5] : nullptr;
     std::vector<double *> cur((size_t)nl, nullptr);  // current iterate buffer per level (owned pointer)
+    const bool cheb = (s->cfg.smoother == Smoother::CHEBYSHEV);
+    const double lmax = s->cfg.cheby_lmax, lmin = lmax / s->cfg.cheby_ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    // `nsteps` smoothing steps on level g: iterate in `a` (result left in `a` after the swaps), spare buffer `c`.
+    // Jacobi: x <- x + omega D^-1 (b - A x).  Chebyshev-Jacobi: three-term recurrence over [lmin, lmax] of D^-1 A,
+    // restarted for every segment (oracle/csrc/gmg.c:cheby).
+    auto smooth_seq = [&](GridLevel &g, const double *b, const double *pin_l, double *&a, double *&c, int nsteps,
+                          bool from_zero) -> int {
+        double rho = 1.0 / sigma;
+        double *dvec = g.d + g.plane;
+        for (int sw = 0; sw < nsteps; ++sw) {
+            if (from_zero && sw == 0) {
+                if (cheb)
+                    PIB_CHK(launch_level<6>(s, g, 1.0 / theta, b, nullptr, a, pin_l, guarded, q, dvec, 0.0));
+                else
+                    PIB_CHK(launch_level<1>(s, g, omega, b, nullptr, a, pin_l, guarded, q));
+                continue;
+            }
+            PIB_CHK(halo_level(s, g, a, q));
+            if (cheb) {
+                double a_d = 0.0, a_z = 1.0 / theta;
+                if (sw > 0) {
+                    const double rho_new = 1.0 / (2.0 * sigma - rho);
+                    a_d = rho_new * rho;
+                    a_z = 2.0 * rho_new / delta;
+                    rho = rho_new;
+                }
+                PIB_CHK(launch_level<5>(s, g, a_z, b, a, c, pin_l, guarded, q, dvec, a_d));
+            } else {
+                PIB_CHK(launch_level<2>(s, g, omega, b, a, c, pin_l, guarded, q));
+            }
+            std::swap(a, c);
+        }
+        return 0;
+    };
 
     // ---- downward leg
     for (int l = 0; l < nl; ++l) {
@@ -762,12 +818,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // final buffer after `swaps` swaps starting from a: a if even else c
             if (swaps % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
         }
-        PIB_CHK(launch_level<1>(s, g, omega, b, nullptr, a, pin_l, guarded, q));
-        for (int sw = 1; sw < pre; ++sw) {
-            PIB_CHK(halo_level(s, g, a, q));
-            PIB_CHK(launch_level<2>(s, g, omega, b, a, c, pin_l, guarded, q));
-            std::swap(a, c);
-        }
+        PIB_CHK(smooth_seq(g, b, pin_l, a, c, pre, true));
         PIB_CHK(halo_level(s, g, a, q));
         double *rr = g.r + pl;
         PIB_CHK(launch_level<3>(s, g, omega, b, a, rr, pin_l, guarded, q));
@@ -810,11 +861,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             hipLaunchKernelGGL(k_prolong_add, level_grid(g), dim3(256), 0, q, S, dev_of(g), dev_of(cg), xc, a);
         }
         PIB_HIP(hipGetLastError());
-        for (int sw = 0; sw < post; ++sw) {
-            PIB_CHK(halo_level(s, g, a, q));
-            PIB_CHK(launch_level<2>(s, g, omega, b, a, c, pin_l, guarded, q));
-            std::swap(a, c);
-        }
+        PIB_CHK(smooth_seq(g, b, pin_l, a, c, post, false));
         cur[(size_t)l] = a;
         if (l == 0 && a != z) return fail(PIB_ERR_LIB, "gmg: internal buffer parity error");
     }

@@ -62,6 +62,8 @@ struct Config {
     Smoother smoother = Smoother::JACOBI;
     double smoother_relaxation = 0.9;
     int cheby_degree = 2;
+    double cheby_lmax = 2.0;   // eigenvalue window [lmax/ratio, lmax] of D^-1 A (Gershgorin: <= 2 for the FV Poisson operator)
+    double cheby_ratio = 4.0;
     int max_levels = 100;
     int min_coarse_rows = 2;
     int dense_lu_num_rows = 128;  // coarsest level size at which coarsening stops
@@ -127,6 +129,7 @@ struct GridLevel {
     double *g[3] = {nullptr, nullptr, nullptr};  // [n[d]-1] (g[d][s] couples s and s+1), already * dt
     double *dinv = nullptr;                      // 1/diag per local cell (with pinned handling)
     double *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;  // level vectors (one halo plane each side)
+    double *d = nullptr;  // Chebyshev direction vector
     bool replicated = false;  // multi-GPU: every rank holds the whole level
     int64_t nloc = 0, plane = 0;
 };
