@@ -203,6 +203,29 @@ int pib_synchronize(pib_solver *s);
  * Pass NULL arrays to query sizes only. */
 int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, int64_t *col_global, double *val);
 
+/* ---- device-resident time step --------------------------------------------------
+ * One NavierStokesSolver::advance (applications/navierstokes/navierstokes.cpp:240-266) with all vectors in HBM:
+ * assembleRHSVelocity (:432-521), solveVelocity (:524-537), assembleRHSPoisson (:540-563), solvePoisson
+ * (:566-580), applyDivergenceFreeVelocity (:583-598), updatePressure (:601-615).  G, D, L, BNG and the
+ * convective term N(u) (src/operators/createconvection.cpp) are applied matrix-free in the summation order of
+ * the reference's assembled matrices; AB2 convection + Crank-Nicolson diffusion, BN order 1.
+ *   bc_type[6*f+loc]: 0 DIRICHLET, 1 NEUMANN; bc_value[6*f+loc] (flow.boundaryConditions of the YAML file);
+ *   velocity_cfg / poisson_cfg: solver configuration TEXT (same syntaxes as pib_create).  The Poisson
+ *   solver's flavour selects the null-space convention exactly like NavierStokesSolver::setNullSpace
+ *   (:395-429): "NVIDIA AmgX" -> pinned row 0 and rhs2[0] = 0, "PETSc KSP" -> constant null space.
+ * Single GPU, time-independent ghost equations (Dirichlet / Neumann). */
+typedef struct pib_ns pib_ns;
+int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
+                  const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
+                  double nu, const char *velocity_cfg, const char *poisson_cfg, int device);
+int pib_ns_sizes(pib_ns *ns, int64_t *UN, int64_t *pN);
+int pib_ns_set_state(pib_ns *ns, const double *U_packed_or_null, const double *p_or_null);        /* host arrays */
+int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs2);               /* any may be NULL */
+int pib_ns_advance(pib_ns *ns, int nsteps);
+/* the columns of iterations-<start>.txt (navierstokes.cpp:766-794) for the last step */
+int pib_ns_get_solver_info(pib_ns *ns, int *v_iters, double *v_res, int *p_iters, double *p_res);
+int pib_ns_destroy(pib_ns *ns);
+
 /* ---- instrumentation (bench.py roofline leg) --------------------------------
  * Time `reps` launches of kernel `which` on the solver's stream with HIP events
  * (events recorded on that stream); *ms_avg = average launch duration.

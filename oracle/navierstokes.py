@@ -1,0 +1,249 @@
+"""Oracle restatement of one NavierStokesSolver time step (Perot fractional step).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows applications/navierstokes/navierstokes.cpp:
+  :240-266  advance()              rhs1 -> velocity solve -> rhs2 -> Poisson solve -> project -> p += dP
+                                    -> bc->updateGhostValues
+  :432-521  assembleRHSVelocity()   rhs1 = -G p + u/dt + sum c_i conv_i + sum d_i diff_i + c nu Lbc
+  :540-563  assembleRHSPoisson()    rhs2 = D u* + Dbc (rhs2[0] = 0 when the pressure is pinned)
+  :583-615  applyDivergenceFreeVelocity / updatePressure
+and src/operators/createconvection.cpp:40-339 (matrix-free convective term N(u) with ghost values),
+src/operators/createlaplacian.cpp:45-78 / createdivergence.cpp:45-78 (BC correction shells: sum coeff*a1),
+src/boundary/singleboundary{dirichlet,neumann}.cpp (ghost = a0*target + a1),
+include/petibm/timeintegration.h:107-166 (AB2 {1.5,-0.5}; CN implicit 0.5, explicit {0.5}).
+
+Restricted to time-independent ghost equations (Dirichlet, Neumann): a0/a1 constant.
+Every vector operation is done in the reference's order (VecScale / VecAXPY sequence) so that the device
+engine can be compared bit-for-bit on the explicit parts.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import clib, operators as oops
+from .mesh import CartesianMesh
+
+
+def bc_a1(mesh: CartesianMesh, f: int, loc: int) -> float:
+    """a1 of ghost = a0*target + a1 (constant BCs).
+    Dirichlet: value if the boundary normal is the field's direction else 2*value
+    (singleboundarydirichlet.cpp:35-44); Neumann: normal*dL*value (singleboundaryneumann.cpp:27-28) with
+    dL = distance ghost-target (misc.cpp:187-190)."""
+    t = mesh.bc_types.get((f, loc), "NOBC")
+    v = mesh.bc_values.get((f, loc), 0.0)
+    axis = loc // 2
+    if t == "DIRICHLET":
+        return v if axis == f else 2.0 * v
+    if t == "NEUMANN":
+        n = int(mesh.n[f][axis])
+        c = mesh.coord[f][axis]
+        d = (c[n] - c[n - 1]) if loc % 2 == 1 else (c[0] - c[-1])
+        normal = 1.0 if loc % 2 == 1 else -1.0
+        return normal * d * v
+    raise ValueError(f"time-dependent or periodic BC {t} not restated here")
+
+
+def _field_arrays(mesh: CartesianMesh, U: np.ndarray):
+    out, off = [], 0
+    for f in range(mesh.dim):
+        n0, n1, n2 = (int(v) for v in mesh.n[f])
+        sz = n0 * n1 * n2
+        out.append(U[off:off + sz].reshape(n2, n1, n0))
+        off += sz
+    return out
+
+
+def ghost_padded(mesh: CartesianMesh, U: np.ndarray):
+    """Local arrays with one ghost layer per direction (what DMCompositeScatter + copyValues2LocalVecs give
+    createconvection.cpp:213-220); ghost = a0*target + a1."""
+    res = []
+    for f, a in enumerate(_field_arrays(mesh, U)):
+        n2, n1, n0 = a.shape
+        g = np.zeros((n2 + 2, n1 + 2, n0 + 2))
+        g[1:-1, 1:-1, 1:-1] = a
+        for loc in range(2 * mesh.dim):
+            a0 = oops.bc_a0(mesh.bc_types[(f, loc)], f, loc)
+            a1 = bc_a1(mesh, f, loc)
+            axis = loc // 2
+            ax = 2 - axis  # numpy axis of (k, j, i)
+            sl_g = [slice(1, -1)] * 3
+            sl_t = [slice(1, -1)] * 3
+            if loc % 2 == 0:
+                sl_g[ax], sl_t[ax] = 0, 1
+            else:
+                sl_g[ax], sl_t[ax] = g.shape[ax] - 1, g.shape[ax] - 2
+            g[tuple(sl_g)] = a0 * g[tuple(sl_t)] + a1
+        res.append(g)
+    return res
+
+
+def convection(mesh: CartesianMesh, U: np.ndarray) -> np.ndarray:
+    """N(u): createconvection.cpp:40-195 kernels, vectorised; same expression order."""
+    q = ghost_padded(mesh, U)
+    dim = mesh.dim
+    out = []
+
+    def sh(a, di=0, dj=0, dk=0, n=None):
+        """a[k+dk, j+dj, i+di] for interior (i,j,k) of a field with shape n (k,j,i), on the padded array"""
+        n2, n1, n0 = n
+        return a[1 + dk:1 + dk + n2, 1 + dj:1 + dj + n1, 1 + di:1 + di + n0]
+
+    for f in range(dim):
+        n0, n1, n2 = (int(v) for v in mesh.n[f])
+        n = (n2, n1, n0)
+        s = q[f]
+        self_ = sh(s, n=n)
+        dLx = mesh.dL[f][0][np.arange(n0)][None, None, :]
+        dLy = mesh.dL[f][1][np.arange(n1)][None, :, None]
+        dLz = mesh.dL[f][2][np.arange(n2)][:, None, None] if dim == 3 else None
+        # same-component face averages
+        W = (self_ + sh(s, di=-1, n=n)) / 2.0
+        E = (self_ + sh(s, di=1, n=n)) / 2.0
+        S = (self_ + sh(s, dj=-1, n=n)) / 2.0
+        N = (self_ + sh(s, dj=1, n=n)) / 2.0
+        if dim == 3:
+            B = (self_ + sh(s, dk=-1, n=n)) / 2.0
+            F = (self_ + sh(s, dk=1, n=n)) / 2.0
+        u, v = q[0], q[1]
+        w = q[2] if dim == 3 else None
+        if f == 0:
+            vS = (sh(v, dj=-1, n=n) + sh(v, di=1, dj=-1, n=n)) / 2.0
+            vN = (sh(v, n=n) + sh(v, di=1, n=n)) / 2.0
+            r = (E * E - W * W) / dLx + (vN * N - vS * S) / dLy
+            if dim == 3:
+                wB = (sh(w, dk=-1, n=n) + sh(w, di=1, dk=-1, n=n)) / 2.0
+                wF = (sh(w, n=n) + sh(w, di=1, n=n)) / 2.0
+                r = r + (wF * F - wB * B) / dLz
+        elif f == 1:
+            uW = (sh(u, di=-1, n=n) + sh(u, di=-1, dj=1, n=n)) / 2.0
+            uE = (sh(u, n=n) + sh(u, dj=1, n=n)) / 2.0
+            r = (uE * E - uW * W) / dLx + (N * N - S * S) / dLy
+            if dim == 3:
+                wB = (sh(w, dk=-1, n=n) + sh(w, dj=1, dk=-1, n=n)) / 2.0
+                wF = (sh(w, n=n) + sh(w, dj=1, n=n)) / 2.0
+                r = r + (wF * F - wB * B) / dLz
+        else:
+            uW = (sh(u, di=-1, n=n) + sh(u, di=-1, dk=1, n=n)) / 2.0
+            uE = (sh(u, n=n) + sh(u, dk=1, n=n)) / 2.0
+            vS = (sh(v, dj=-1, n=n) + sh(v, dj=-1, dk=1, n=n)) / 2.0
+            vN = (sh(v, n=n) + sh(v, dk=1, n=n)) / 2.0
+            r = (uE * E - uW * W) / dLx + (vN * N - vS * S) / dLy + (F * F - B * B) / dLz
+        out.append(r.reshape(-1))
+    return np.concatenate(out)
+
+
+def laplacian_correction(mesh: CartesianMesh) -> np.ndarray:
+    """LCorrectionMult (createlaplacian.cpp:45-78): y[row] += coeff*a1 for every ghost, in (field, loc) order."""
+    y = np.zeros(mesh.UN)
+    off = 0
+    for f in range(mesh.dim):
+        n0, n1, n2 = (int(v) for v in mesh.n[f])
+        k, j, i = np.meshgrid(np.arange(n2), np.arange(n1), np.arange(n0), indexing="ij")
+        ijk = (i.ravel(), j.ravel(), k.ravel())
+        rows = np.arange(n0 * n1 * n2) + off
+        for loc in range(2 * mesh.dim):
+            d = loc // 2
+            s = ijk[d]
+            on = (s == 0) if loc % 2 == 0 else (s == mesh.n[f][d] - 1)
+            dLSelf = mesh.dL[f][d][s[on]]
+            if loc % 2 == 0:
+                dist = mesh.coord[f][d][s[on]] - mesh.coord[f][d][s[on] - 1]
+            else:
+                dist = mesh.coord[f][d][s[on] + 1] - mesh.coord[f][d][s[on]]
+            coeff = 1.0 / (dist * dLSelf)
+            y[rows[on]] = y[rows[on]] + coeff * bc_a1(mesh, f, loc)
+        off += n0 * n1 * n2
+    return y
+
+
+def divergence_correction(mesh: CartesianMesh, normalize: bool = False) -> np.ndarray:
+    """DCorrectionMult (createdivergence.cpp:45-78): y[cell] += (+-area)*a1 for the normal-velocity ghost faces."""
+    y = np.zeros(mesh.pN)
+    n0, n1, n2 = (int(v) for v in mesh.n[3])
+    k, j, i = np.meshgrid(np.arange(n2), np.arange(n1), np.arange(n0), indexing="ij")
+    i, j, k = i.ravel(), j.ravel(), k.ravel()
+    ijk = (i, j, k)
+    for f in range(mesh.dim):
+        if f == 0:
+            area = mesh.dL[0][1][j] * mesh.dL[0][2][k]
+        elif f == 1:
+            area = mesh.dL[1][0][i] * mesh.dL[1][2][k]
+        else:
+            area = mesh.dL[2][0][i] * mesh.dL[2][1][j]
+        for loc in (2 * f, 2 * f + 1):
+            on = (ijk[f] == 0) if loc % 2 == 0 else (ijk[f] == mesh.n[3][f] - 1)
+            coeff = (-area[on]) if loc % 2 == 0 else area[on]
+            y[on] = y[on] + coeff * bc_a1(mesh, f, loc)
+    return y
+
+
+class NavierStokes:
+    """State + one-step advance, AB2 convection + CN diffusion, BN order 1."""
+
+    def __init__(self, mesh: CartesianMesh, dt: float, nu: float, pinned: bool = False, vtol=1e-14, ptol=1e-13):
+        self.mesh, self.dt, self.nu, self.pinned = mesh, dt, nu, pinned
+        self.conv_c = [1.5, -0.5]
+        self.diff_c = [0.5]
+        self.cimpl = 0.5
+        self.D = oops.create_divergence(mesh)
+        self.G = oops.create_gradient(mesh)
+        self.L = oops.create_laplacian(mesh)
+        self.A = oops.create_velocity_operator(self.L, dt, self.cimpl * nu)
+        self.BNG, DBNG = oops.create_poisson_operator(self.D, self.G, self.L, dt, self.cimpl * nu)
+        self.DBNG = oops.pin_row0(DBNG) if pinned else DBNG
+        self.lc = laplacian_correction(mesh)
+        self.dbc = divergence_correction(mesh)
+        self.U = np.zeros(mesh.UN)
+        self.p = np.zeros(mesh.pN)
+        self.conv = [np.zeros(mesh.UN), np.zeros(mesh.UN)]
+        self.vtol, self.ptol = vtol, ptol
+        self.info = {}
+        w = [mesh.dL[3][d].true for d in range(mesh.dim)]
+        self.gmg = clib.GMG([int(v) for v in mesh.n[3][:mesh.dim]], w, dt, nullspace=2 if pinned else 1)
+
+    def rhs_velocity(self):
+        dt, nu = self.dt, self.nu
+        rhs1 = clib.spmv(self.G, self.p)
+        rhs1 = -1.0 * rhs1
+        rhs1 = rhs1 + (1.0 / dt) * self.U
+        self.conv[1], self.conv[0] = self.conv[0], self.conv[1]  # VecSwap chain for 2 terms
+        self.conv[0] = -1.0 * convection(self.mesh, self.U)
+        for c, v in zip(self.conv_c, self.conv):
+            rhs1 = rhs1 + c * v
+        diff0 = clib.spmv(self.L, self.U)
+        diff0 = diff0 + self.lc
+        diff0 = nu * diff0
+        rhs1 = rhs1 + self.diff_c[0] * diff0
+        bc1 = nu * self.lc
+        rhs1 = rhs1 + self.cimpl * bc1
+        return rhs1
+
+    def rhs_poisson(self):
+        rhs2 = clib.spmv(self.D, self.U)
+        rhs2 = rhs2 + self.dbc
+        if self.pinned:
+            rhs2[0] = 0.0
+        return rhs2
+
+    def advance(self, velocity_rhs_only=False):
+        rhs1 = self.rhs_velocity()
+        self.last_rhs1 = rhs1
+        if velocity_rhs_only:
+            return
+        r = clib.bcgs(self.A, rhs1, x0=self.U, pc="jacobi", norm="unpreconditioned", rtol=0.0, atol=self.vtol,
+                      dtol=1e300, maxit=2000)
+        assert r["reason"] > 0
+        self.U = r["x"]
+        self.info["vIters"] = r["iters"]
+        rhs2 = self.rhs_poisson()
+        self.last_rhs2 = rhs2
+        rp = self.gmg.pcg(self.DBNG, rhs2, rtol=0.0, atol=self.ptol, maxit=500)
+        assert rp["reason"] > 0, rp
+        dP = rp["x"]
+        if not self.pinned:
+            dP = dP - dP.mean()
+        self.info["pIters"] = rp["iters"]
+        rhs1 = clib.spmv(self.BNG, dP)
+        self.U = self.U + (-1.0) * rhs1
+        self.p = self.p + 1.0 * dP

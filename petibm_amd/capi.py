@@ -64,6 +64,15 @@ _PROTOS = {
     "pib_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, _i64]),
     "pib_synchronize": (C.c_int, [_vp]),
     "pib_get_csr": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp, _vp]),
+    "pib_ns_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double,
+                                C.c_char_p, C.c_char_p, C.c_int]),
+    "pib_ns_sizes": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "pib_ns_set_state": (C.c_int, [_vp, _vp, _vp]),
+    "pib_ns_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pib_ns_advance": (C.c_int, [_vp, C.c_int]),
+    "pib_ns_get_solver_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_double)]),
+    "pib_ns_destroy": (C.c_int, [_vp]),
     "pib_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pib_get_counters": (C.c_int, [_vp, _vp]),
 }

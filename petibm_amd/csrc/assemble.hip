@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(int dim, int64_t nx, i
     }
 }
 
-static int upload_vec(const std::vector<double> &h, double **d)
+int upload_vec(const std::vector<double> &h, double **d)
 {
     PIB_HIP(hipMalloc(d, sizeof(double) * std::max<size_t>(h.size(), 1)));
     if (!h.empty()) PIB_HIP(hipMemcpy(*d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
@@ -282,6 +282,57 @@ struct FieldDev {
     double a0[6];            // ghost coefficient per boundary location (0 where periodic / unused)
 };
 
+
+// Coordinates and widths (with one ghost entry each side, index s+1) of the velocity fields:
+// CartesianMesh::createPressureMesh / createVertexMesh / createVelocityMesh (src/mesh/cartesianmesh.cpp:136-355),
+// non-periodic.  Same evaluation order as oracle/mesh.py.
+void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3], const double mn[3], const double mx[3],
+                          std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3])
+{
+    std::vector<double> c3[3], c4[3];
+    for (int d = 0; d < dim; ++d) {
+        const int64_t nd = n[d];
+        c3[d].resize((size_t)nd);
+        c4[d].resize((size_t)nd + 1);
+        double run = 0.0;
+        c4[d][0] = 0.0 + mn[d];
+        for (int64_t q = 0; q < nd; ++q) {
+            run = (q == 0) ? w[d][0] : run + w[d][q];  // std::partial_sum
+            c3[d][(size_t)q] = (run + mn[d]) - 0.5 * w[d][q];
+            c4[d][(size_t)q + 1] = run + mn[d];
+        }
+    }
+    for (int f = 0; f < 3; ++f)
+        for (int d = 0; d < 3; ++d) {
+            fn[f][d] = 1;
+            hdl[f][d].clear();
+            hco[f][d].clear();
+            if (f >= dim || d >= dim) continue;
+            const int64_t n3 = n[d];
+            if (d == f) {
+                const int64_t nf = n3 - 1;
+                fn[f][d] = nf;
+                hco[f][d] = c4[d];  // n3+1 = nf+2 entries: vertices, ghosts = the walls
+                hdl[f][d].assign((size_t)nf + 2, 0.0);
+                hdl[f][d][0] = w[d][0];
+                for (int64_t q = 1; q < n3; ++q) hdl[f][d][(size_t)q] = 0.5 * (w[d][q] + w[d][q - 1]);
+                hdl[f][d][(size_t)nf + 1] = w[d][n3 - 1];
+            } else {
+                fn[f][d] = n3;
+                hco[f][d].assign((size_t)n3 + 2, 0.0);
+                hdl[f][d].assign((size_t)n3 + 2, 0.0);
+                for (int64_t q = 0; q < n3; ++q) {
+                    hco[f][d][(size_t)q + 1] = c3[d][(size_t)q];
+                    hdl[f][d][(size_t)q + 1] = w[d][q];
+                }
+                hco[f][d][0] = mn[d] - w[d][0] / 2.0;
+                hco[f][d][(size_t)n3 + 1] = mx[d] + w[d][n3 - 1] / 2.0;
+                hdl[f][d][0] = w[d][0];
+                hdl[f][d][(size_t)n3 + 1] = w[d][n3 - 1];
+            }
+        }
+}
+
 template <typename RP>
 __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, double scale, double shift,
                                                            RP *__restrict__ rowptr, int32_t *__restrict__ col,
@@ -343,50 +394,9 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
     for (int d = 0; d < dim; ++d)
         if (n[d] < 2 || w[d] == nullptr) return fail(PIB_ERR_ARG_SIZ, "assemble_velocity: need >= 2 cells per direction");
     // ---- host mesh arithmetic (cartesianmesh.cpp:136-355, non-periodic)
-    std::vector<double> c3[3], c4[3];
-    for (int d = 0; d < dim; ++d) {
-        const int64_t nd = n[d];
-        c3[d].resize((size_t)nd);
-        c4[d].resize((size_t)nd + 1);
-        double run = 0.0;
-        c4[d][0] = 0.0 + mn[d];
-        for (int64_t q = 0; q < nd; ++q) {
-            run = (q == 0) ? w[d][0] : run + w[d][q];  // std::partial_sum
-            c3[d][(size_t)q] = (run + mn[d]) - 0.5 * w[d][q];
-            c4[d][(size_t)q + 1] = run + mn[d];
-        }
-    }
     std::vector<double> hdl[3][3], hco[3][3];
     int64_t fn[3][3];
-    for (int f = 0; f < dim; ++f)
-        for (int d = 0; d < 3; ++d) {
-            if (d >= dim) {
-                fn[f][d] = 1;
-                continue;
-            }
-            const int64_t n3 = n[d];
-            if (d == f) {
-                const int64_t nf = n3 - 1;
-                fn[f][d] = nf;
-                hco[f][d] = c4[d];  // n3+1 = nf+2 entries: vertices, ghosts = the walls
-                hdl[f][d].assign((size_t)nf + 2, 0.0);
-                hdl[f][d][0] = w[d][0];
-                for (int64_t q = 1; q < n3; ++q) hdl[f][d][(size_t)q] = 0.5 * (w[d][q] + w[d][q - 1]);
-                hdl[f][d][(size_t)nf + 1] = w[d][n3 - 1];
-            } else {
-                fn[f][d] = n3;
-                hco[f][d].assign((size_t)n3 + 2, 0.0);
-                hdl[f][d].assign((size_t)n3 + 2, 0.0);
-                for (int64_t q = 0; q < n3; ++q) {
-                    hco[f][d][(size_t)q + 1] = c3[d][(size_t)q];
-                    hdl[f][d][(size_t)q + 1] = w[d][q];
-                }
-                hco[f][d][0] = mn[d] - w[d][0] / 2.0;
-                hco[f][d][(size_t)n3 + 1] = mx[d] + w[d][n3 - 1] / 2.0;
-                hdl[f][d][0] = w[d][0];
-                hdl[f][d][(size_t)n3 + 1] = w[d][n3 - 1];
-            }
-        }
+    velocity_mesh_arrays(dim, n, w, mn, mx, hdl, hco, fn);
     // ---- sizes
     int64_t rows = 0, nnz = 0, row_off[3] = {0, 0, 0}, nnz_off[3] = {0, 0, 0};
     for (int f = 0; f < dim; ++f) {

@@ -1,0 +1,134 @@
+"""Device-resident time step against the oracle restatement of NavierStokesSolver::advance
+and against the physics data the reference ships (Ghia et al. 1982, examples/data)."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mesh as omesh, navierstokes as ons
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_test_vectors.json")))
+
+
+def cavity(n, nu=0.01, dt=0.01, lid=1.0, stretched=False):
+    cfg = omesh.uniform_config(n, lid=lid)
+    if stretched:
+        for d, ax in enumerate(cfg["mesh"]):
+            h = n[d] // 2
+            ax["subDomains"] = [{"end": 0.5, "cells": h, "stretchRatio": 1.0 / (1.05 + 0.02 * d)},
+                                {"end": 1.0, "cells": n[d] - h, "stretchRatio": 1.05 + 0.02 * d}]
+    cfg["flow"]["nu"] = nu
+    cfg["parameters"] = {"dt": dt, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    return cfg
+
+
+def moving_walls_3d():
+    cfg = cavity((10, 9, 8), nu=0.02, dt=0.005, stretched=True)
+    bcs = cfg["flow"]["boundaryConditions"]
+    bcs[0]["v"] = ["DIRICHLET", 0.3]       # xMinus: tangential motion
+    bcs[2]["w"] = ["DIRICHLET", -0.2]      # yMinus
+    bcs[4]["u"] = ["DIRICHLET", 0.25]      # zMinus
+    bcs[0]["u"] = ["DIRICHLET", 0.1]       # inflow through xMinus ...
+    bcs[1]["u"] = ["DIRICHLET", 0.1]       # ... leaves through xPlus (same area: compatible with the Neumann Poisson problem)
+    bcs[1]["v"] = ["NEUMANN", 0.0]         # zero-gradient tangential components at the outlet
+    bcs[1]["w"] = ["NEUMANN", 0.05]
+    return cfg
+
+
+AMGX_P = ("config_version=2\nsolver(solv)=PCG\nsolv:max_iters=500\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+          "solv:tolerance=1e-13\nsolv:norm=L2\nsolv:store_res_history=1\nsolv:preconditioner(prec)=AMG\nprec:cycle=V\n"
+          "prec:presweeps=1\nprec:postsweeps=1\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
+          "smooth:relaxation_factor=0.9\n")
+KSP_P = ("-poisson_ksp_type cg\n-poisson_ksp_atol 1.0E-13\n-poisson_ksp_rtol 0.0\n-poisson_ksp_max_it 500\n"
+         "-poisson_ksp_norm_type unpreconditioned\n-poisson_pc_type gamg\n-poisson_pib_smoother JACOBI\n")
+VEL = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+       "solv:tolerance=1e-14\nsolv:norm=L2\nsolv:store_res_history=1\nsolv:preconditioner(prec)=BLOCK_JACOBI\n"
+       "prec:relaxation_factor=1.0\n")
+
+
+@pytest.mark.parametrize("case,pinned", [("2d_stretched", False), ("2d_stretched", True), ("3d_moving_walls", False),
+                                         ("3d_uniform", True)])
+def test_time_step_matches_oracle(case, pinned):
+    from petibm_amd.navierstokes import NavierStokesSolver
+    cfg = {"2d_stretched": cavity((14, 12), stretched=True), "3d_moving_walls": moving_walls_3d(),
+           "3d_uniform": cavity((8, 8, 8), nu=0.05, dt=0.01)}[case]
+    m = omesh.create_mesh(cfg)
+    dt, nu = cfg["parameters"]["dt"], cfg["flow"]["nu"]
+    ref = ons.NavierStokes(m, dt, nu, pinned=pinned, vtol=1e-14, ptol=1e-13)
+    rng = np.random.default_rng(9)
+    U0 = 0.1 * rng.uniform(-1, 1, m.UN)
+    p0 = 0.1 * rng.uniform(-1, 1, m.pN)
+    if pinned:
+        p0[0] = 0.0
+    ref.U, ref.p = U0.copy(), p0.copy()
+    s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=AMGX_P if pinned else KSP_P)
+    assert (s.UN, s.pN) == (m.UN, m.pN)
+    s.setState(U0, p0)
+    for step in range(3):
+        ref.advance()
+        s.advance()
+        U, p, r1, r2 = s.getState(rhs=True)
+        if step == 0:
+            # explicit part, first step: same operations in the same order -> identical bits
+            assert np.array_equal(r1, ref.last_rhs1)
+        scale = np.abs(ref.last_rhs1).max()
+        assert np.abs(r1 - ref.last_rhs1).max() <= 1e-9 * scale
+        assert np.abs(r2 - ref.last_rhs2).max() <= 1e-9 * max(np.abs(ref.last_rhs2).max(), 1e-30) + 1e-14
+        assert np.abs(U - ref.U).max() <= 1e-9 * np.abs(ref.U).max()
+        dp = (p - p.mean()) - (ref.p - ref.p.mean())
+        assert np.abs(dp).max() <= 1e-8 * max(np.abs(ref.p - ref.p.mean()).max(), 1e-30)
+    ite, vi, vr, pi, pr = s.linSolversInfo()
+    assert ite == 3 and 0 < vi < 50 and 0 < pi < 60 and vr <= 1e-14 and pr <= 1e-13
+    # discrete continuity after the projection: D u + Dbc = 0
+    from oracle import clib
+    div = clib.spmv(ref.D, U) + ref.dbc
+    assert np.abs(div).max() <= 1e-10 * np.abs(ref.D.val).max()
+    s.destroy()
+
+
+def test_unsupported_boundary_conditions_are_errors():
+    from petibm_amd.capi import PibError, ERR_SUP
+    from petibm_amd.navierstokes import NavierStokesSolver
+    cfg = cavity((8, 8))
+    cfg["flow"]["boundaryConditions"][1]["u"] = ["NEUMANN", 0.0]   # normal component: changes D and DBNG
+    with pytest.raises(PibError) as ei:
+        NavierStokesSolver(cfg)
+    assert ei.value.code == ERR_SUP
+    cfg = cavity((8, 8))
+    cfg["flow"]["boundaryConditions"][1]["u"] = ["CONVECTIVE", 1.0]  # time-dependent ghost equation
+    with pytest.raises(PibError) as ei:
+        NavierStokesSolver(cfg)
+    assert ei.value.code == ERR_SUP
+
+
+def test_lid_driven_cavity_re100_matches_ghia():
+    """The reference's own validation case (examples/navierstokes/liddrivencavity2dRe100: 32x32, nu = 0.01,
+    dt = 0.01, 1000 steps, README compares the centre-line velocities with Ghia et al. 1982), run on the GPU."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    n = 32
+    cfg = cavity((n, n), nu=0.01, dt=0.01)
+    s = NavierStokesSolver(cfg)
+    s.advance(1000)
+    U, p = s.getState()
+    u = U[: (n - 1) * n].reshape(n, n - 1)
+    v = U[(n - 1) * n:].reshape(n - 1, n)
+    yc = (np.arange(n) + 0.5) / n
+    g = G["ghia_1982_re100_u_centerline"]
+    ui = np.interp(g["y"][1:-1], yc, u[:, n // 2 - 1])       # u along the vertical centre line x = 0.5
+    vi = np.interp(g["x"][1:-1], yc, v[n // 2 - 1, :])       # v along the horizontal centre line y = 0.5
+    assert np.abs(ui - np.array(g["u"][1:-1])).max() < 0.006
+    assert np.abs(vi - np.array(g["v"][1:-1])).max() < 0.008
+    # and against the oracle stepping the same 40 steps from rest
+    m = omesh.create_mesh(cfg)
+    ref = ons.NavierStokes(m, 0.01, 0.01, pinned=False, vtol=1e-13, ptol=1e-12)
+    t = NavierStokesSolver(cfg)
+    for _ in range(40):
+        ref.advance()
+    t.advance(40)
+    Ut, _ = t.getState()
+    assert np.abs(Ut - ref.U).max() <= 1e-8
+    s.destroy()
+    t.destroy()
