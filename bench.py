@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--omega", type=float, default=0.9, help="Jacobi smoother relaxation factor of the V-cycle")
     ap.add_argument("--smoother", default="jacobi", choices=["jacobi", "chebyshev"])
+    ap.add_argument("--extra-config", default="", help="extra solver-config lines (\\n separated), e.g. pib_coarse_tail=0")
     ap.add_argument("--presweeps", type=int, default=1)
     ap.add_argument("--postsweeps", type=int, default=1)
     ap.add_argument("--system", default="poisson", choices=["poisson", "velocity"],
@@ -240,7 +241,8 @@ def main():
     n = args.n
     dt = 5e-4 if n == 512 else 1e-3  # cfg3 (512^3) dt=5e-4, cfg2 (256^3) dt=1e-3
     s = LinSolverHIP("poisson", config_text=solver_config(args.pc, args.tol, args.max_iters, args.omega, args.presweeps,
-                                                           args.postsweeps, args.smoother), rank=rank,
+                                                           args.postsweeps, args.smoother) + args.extra_config.replace("\\n", "\n") + "\n",
+                     rank=rank,
                      nranks=world, uid=uid, device=local)
     w = np.full(n, 1.0 / n)
     t_setup = time.perf_counter()

@@ -408,6 +408,145 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
     }
 }
 
+
+// ---- coarse tail: every level with <= TAIL_MAX_CELLS cells (replicated / single rank) in ONE workgroup ----
+// The levels below ~32^3 are launch-latency bound: five 4.4-us launches per level and V-cycle (rocprof: 40 of
+// the 53 kernels of a 512^3 iteration are such launches).  One 1024-thread workgroup walks the whole remaining
+// V-cycle (pre-smooth, residual, restriction, ..., coarsest sweeps, ..., prolongation, post-smooth) with block
+// barriers between the phases; the per-cell arithmetic is the same as in k_level / k_restrict / k_prolong_add,
+// so results are bit-identical to the per-level launches.  Damped Jacobi only.
+constexpr int TAIL_MAX_CELLS = 32768;
+constexpr int TAIL_MAX_LEVELS = 12;
+struct TailLevel {
+    LevelDev L;
+    double *xa, *xb, *b, *r;
+};
+struct TailArgs {
+    int nlev;
+    TailLevel lv[TAIL_MAX_LEVELS];
+    double omega;
+    int pre, post, sweeps;
+};
+
+__device__ __forceinline__ void tail_smooth(const LevelDev &L, double omega, const double *b, const double *xi, double *xo,
+                                            bool zero_guess)
+{
+    const int plane = L.nx * L.ny, n = plane * L.nk;
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+        const int i = p % L.nx, j = (p / L.nx) % L.ny, k = L.k0 + p / plane;
+        double d;
+        if (zero_guess) {
+            double c[6];
+            face_coefs(L, i, j, k, c);
+            d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
+            xo[p] = omega * (b[p] / d);
+        } else {
+            const double ax = apply_cell(L, xi, p, i, j, k, &d);
+            xo[p] = xi[p] + omega * ((b[p] - ax) / d);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict__ S, TailArgs T)
+{
+    if (S != nullptr && S->done) return;
+    double *cur[TAIL_MAX_LEVELS], *spare[TAIL_MAX_LEVELS];
+    const int nl = T.nlev;
+    // ---- downward leg
+    for (int l = 0; l < nl - 1; ++l) {
+        const TailLevel &V = T.lv[l];
+        const LevelDev &F = V.L;
+        const LevelDev &C = T.lv[l + 1].L;
+        double *a = V.xa, *c = V.xb;
+        tail_smooth(F, T.omega, V.b, nullptr, a, true);
+        for (int sw = 1; sw < T.pre; ++sw) {
+            tail_smooth(F, T.omega, V.b, a, c, false);
+            double *t = a; a = c; c = t;
+        }
+        const int fplane = F.nx * F.ny, nf = fplane * F.nk;
+        for (int p = threadIdx.x; p < nf; p += blockDim.x) {
+            const int i = p % F.nx, j = (p / F.nx) % F.ny, k = F.k0 + p / fplane;
+            double d;
+            V.r[p] = V.b[p] - apply_cell(F, a, p, i, j, k, &d);
+        }
+        __threadfence_block();
+        __syncthreads();
+        const bool cx = C.nx != F.nx, cy = C.ny != F.ny, cz = C.nzg != F.nzg;
+        const int cplane = C.nx * C.ny, nc = cplane * C.nk;
+        double *bc = T.lv[l + 1].b;
+        for (int q = threadIdx.x; q < nc; q += blockDim.x) {
+            const int I = q % C.nx, J = (q / C.nx) % C.ny, K = C.k0 + q / cplane;
+            double wi[4], wj[4], wk[4];
+            int si[4], sj[4], sk[4];
+            rs1d4(I, F.nx, C.nx, cx, wi, si);
+            rs1d4(J, F.ny, C.ny, cy, wj, sj);
+            rs1d4(K, F.nzg, C.nzg, cz, wk, sk);
+            double sum = 0.0;
+            for (int c2 = 0; c2 < 4; ++c2) {
+                if (wk[c2] == 0.0) continue;
+                const double *pk = V.r + (int64_t)fplane * (sk[c2] - F.k0);
+                for (int b2 = 0; b2 < 4; ++b2) {
+                    const double wzy = wk[c2] * wj[b2];
+                    const double *pj = pk + (int64_t)F.nx * sj[b2];
+                    for (int a2 = 0; a2 < 4; ++a2) sum += (wzy * wi[a2]) * pj[si[a2]];
+                }
+            }
+            bc[q] = sum;
+        }
+        __threadfence_block();
+        __syncthreads();
+        cur[l] = a;
+        spare[l] = c;
+    }
+    // ---- coarsest level: Jacobi sweeps from zero
+    {
+        const TailLevel &V = T.lv[nl - 1];
+        double *a = V.xa, *c = V.xb;
+        tail_smooth(V.L, T.omega, V.b, nullptr, a, true);
+        for (int sw = 1; sw < T.sweeps; ++sw) {
+            tail_smooth(V.L, T.omega, V.b, a, c, false);
+            double *t = a; a = c; c = t;
+        }
+        cur[nl - 1] = a;
+    }
+    // ---- upward leg
+    for (int l = nl - 2; l >= 0; --l) {
+        const TailLevel &V = T.lv[l];
+        const LevelDev &F = V.L;
+        const LevelDev &C = T.lv[l + 1].L;
+        double *a = cur[l], *c = spare[l];
+        const double *xc = cur[l + 1];
+        const bool cx = C.nx != F.nx, cy = C.ny != F.ny, cz = C.nzg != F.nzg;
+        const int fplane = F.nx * F.ny, nf = fplane * F.nk;
+        const int64_t cplane = (int64_t)C.nx * C.ny;
+        for (int p = threadIdx.x; p < nf; p += blockDim.x) {
+            const int i = p % F.nx, j = (p / F.nx) % F.ny, k = F.k0 + p / fplane;
+            int I[2], J[2], K[2];
+            double wi[2], wj[2], wk[2];
+            tr1d(i, C.nx, cx, I, wi);
+            tr1d(j, C.ny, cy, J, wj);
+            tr1d(k, C.nzg, cz, K, wk);
+            double sum = 0.0;
+            for (int c2 = 0; c2 < 2; ++c2)
+                for (int b2 = 0; b2 < 2; ++b2)
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const double wgt = (wk[c2] * wj[b2]) * wi[a2];
+                        if (wgt != 0.0) sum += wgt * xc[I[a2] + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0)];
+                    }
+            a[p] += sum;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int sw = 0; sw < T.post; ++sw) {
+            tail_smooth(F, T.omega, V.b, a, c, false);
+            double *t = a; a = c; c = t;
+        }
+        cur[l] = a;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static LevelDev dev_of(const GridLevel &g)
 {
@@ -785,10 +924,41 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         return 0;
     };
 
+    // first level handled by the single-workgroup coarse tail (never level 0; Jacobi only; no communication)
+    int tail0 = nl;
+    if (!cheb && s->cfg.coarse_tail) {
+        for (int l = nl - 1; l >= 1; --l) {
+            const GridLevel &g = s->levels[(size_t)l];
+            const bool local = (s->comm.nranks == 1) || g.replicated;
+            if (local && g.nloc <= std::min<int64_t>(TAIL_MAX_CELLS, s->cfg.coarse_tail) && nl - l < TAIL_MAX_LEVELS) tail0 = l; else break;
+        }
+        if (nl - tail0 < 2) tail0 = nl;  // a single level is what k_coarsest already does
+    }
     // ---- downward leg
     for (int l = 0; l < nl; ++l) {
         GridLevel &g = s->levels[(size_t)l];
         const int64_t pl = g.plane;
+        if (l == tail0) {
+            TailArgs T;
+            T.nlev = nl - tail0;
+            T.omega = omega;
+            T.pre = pre;
+            T.post = post;
+            T.sweeps = s->cfg.coarsest_sweeps;
+            for (int q = 0; q < T.nlev; ++q) {
+                GridLevel &t = s->levels[(size_t)(tail0 + q)];
+                T.lv[q].L = dev_of(t);
+                T.lv[q].xa = t.x + t.plane;
+                T.lv[q].xb = t.x2 + t.plane;
+                T.lv[q].b = t.b + t.plane;
+                T.lv[q].r = t.r + t.plane;
+            }
+            hipLaunchKernelGGL(k_coarse_tail, dim3(1), dim3(1024), 0, q, S, T);
+            PIB_HIP(hipGetLastError());
+            const int swaps = (pre - 1) + post;
+            cur[(size_t)l] = (swaps % 2 == 0) ? (g.x + pl) : (g.x2 + pl);
+            break;
+        }
         const double *b = (l == 0) ? r : g.b + pl;
         const double *pin_l = (l == 0) ? pin : nullptr;
         double *xa = g.x + pl, *xb = g.x2 + pl;
@@ -844,7 +1014,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         s->gmg_spare[(size_t)l] = c;
     }
     // ---- upward leg
-    for (int l = nl - 2; l >= 0; --l) {
+    for (int l = std::min(nl - 2, tail0 - 1); l >= 0; --l) {
         GridLevel &g = s->levels[(size_t)l];
         GridLevel &cg = s->levels[(size_t)l + 1];
         const int64_t pl = g.plane;

@@ -73,6 +73,9 @@ struct Config {
     int use_graph = 1;       // capture the iteration body in a hipGraph (single GPU)
     int spmv_variant = 0;    // 0 LDS-transpose + tiled chunk order (default), 3 same in natural order, 1 entry-per-lane stream, 2 row-per-thread
     int overlap_halo = 1;
+    int coarse_tail = 0;     // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel.
+                             // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
+                             // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;
 };

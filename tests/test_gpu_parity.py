@@ -402,6 +402,27 @@ def test_gmg_chebyshev_smoother_matches_oracle(lin, case):
     j.destroy()
 
 
+def test_gmg_coarse_tail_kernel_is_bit_identical(lin):
+    """pib_coarse_tail > 0 runs the small levels in one single-workgroup kernel: same arithmetic, same bits."""
+    from petibm_amd import capi
+    cfg = stretched_3d((24, 20, 16))
+    dt = 0.01
+    m, A, _ = poisson_system(cfg, dt=dt)
+    xs, b = rhs_for(A)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    out = []
+    for tail in (0, 512, 4096):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(extra=f"pib_coarse_tail={tail}\n"))
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        out.append((x, s.getIters()))
+        s.destroy()
+    assert out[0][1] == out[1][1] == out[2][1]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
+
+
 def test_gmg_pcg_pinned_pressure_matches_oracle(lin):
     from petibm_amd import capi
     cfg = stretched_3d((20, 16, 12))
