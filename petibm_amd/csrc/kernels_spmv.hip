@@ -27,6 +27,8 @@
 //   * summation order per row is sequential in CSR order with rounded
 //     products (no FMA contraction: the library is built -ffp-contract=off),
 //     which the oracle reproduces -> bit-exact parity.
+#include <algorithm>
+
 #include "pib_internal.hpp"
 
 namespace pib {
@@ -144,9 +146,10 @@ __device__ __forceinline__ int64_t chunk_of(const ChunkOrder &o, int64_t seq)
 }
 
 constexpr int LDS_ROWS = 256;
-constexpr int LDS_TILE = 2048;
 
-template <typename RP, bool DOT>
+// CAP = LDS capacity in entries (even).  1282: 5-point rows, 1794: 7-point rows (7 workgroups per CU instead of
+// 6), 2050: anything else (rows longer than a tile are walked tile by tile).
+template <typename RP, bool DOT, int CAP>
 __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S, int64_t r_begin, int64_t r_end,
                                                   const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                   const double *__restrict__ val, const double *__restrict__ xg,
@@ -154,9 +157,8 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S,
                                                   ChunkOrder ord)
 {
     if (S != nullptr && S->done) return;
-    __shared__ __attribute__((aligned(16))) double vals[LDS_TILE + 2];
-    __shared__ __attribute__((aligned(16))) int32_t cols[LDS_TILE + 2];
-    __shared__ RP srow[LDS_ROWS + 1];
+    __shared__ __attribute__((aligned(16))) double vals[CAP];
+    __shared__ __attribute__((aligned(16))) int32_t cols[CAP];
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int64_t nchunks = (r_end - r_begin + LDS_ROWS - 1) / LDS_ROWS;
@@ -169,28 +171,30 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S,
         const int64_t c = chunk_of(ord, sq);
         const int64_t r0 = r_begin + c * LDS_ROWS;
         const int nr = (int)((r_end - r0 < LDS_ROWS) ? (r_end - r0) : LDS_ROWS);
-        for (int t = tid; t <= nr; t += 256) srow[t] = rowptr[r0 + t];
-        __syncthreads();
-        const RP p0 = srow[0], p1 = srow[nr];
+        // the span [p0, p1) of the chunk from two workgroup-uniform (scalar) loads: phase 1 starts at once; the
+        // per-row offsets go straight to registers and are first needed in phase 2
+        const RP p0 = rowptr[r0], p1 = rowptr[r0 + nr];
         RP rs = 0, re = 0;
         if (tid < nr) {
-            rs = srow[tid];
-            re = srow[tid + 1];
+            rs = rowptr[r0 + tid];
+            re = rowptr[r0 + tid + 1];
         }
-        double sum = 0.0;
+        double sum = 0.0, xd = 0.0;
+        bool have_diag = false;
+        const int32_t dcol = (int32_t)(ghost_lo + r0 + tid);
         const RP a0 = p0 & ~(RP)1;  // val/col are 16-byte aligned at even entries
-        for (RP t0 = a0; t0 < p1; t0 += LDS_TILE) {
+        for (RP t0 = a0; t0 < p1; t0 += CAP) {
 #pragma unroll
-            for (int u = 0; u < LDS_TILE / 512; ++u) {
+            for (int u = 0; u < (CAP + 511) / 512; ++u) {
                 const RP q = t0 + 2 * (tid + u * 256);
-                if (q < p1) {
+                if (q < p1 && q - t0 < CAP) {
                     *reinterpret_cast<double2 *>(&vals[(int)(q - t0)]) = *reinterpret_cast<const double2 *>(val + q);
                     *reinterpret_cast<int2 *>(&cols[(int)(q - t0)]) = *reinterpret_cast<const int2 *>(col + q);
                 }
             }
             __syncthreads();
             const RP lo = (rs > t0) ? rs : t0;
-            const RP hi = (re < t0 + LDS_TILE) ? re : (t0 + LDS_TILE);
+            const RP hi = (re < t0 + CAP) ? re : (t0 + CAP);
             for (RP p = lo; p < hi; p += 8) {
                 double vv[8], xx[8];
                 int32_t cc[8];
@@ -204,19 +208,42 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S,
                 for (int u = 0; u < 8; ++u) xx[u] = (p + u < hi) ? xg[cc[u]] : 0.0;
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (p + u < hi) sum = sum + vv[u] * xx[u];
+                    if (p + u < hi) {
+                        sum = sum + vv[u] * xx[u];
+                        if (DOT && cc[u] == dcol) {
+                            xd = xx[u];  // x of this row: already gathered with the diagonal entry
+                            have_diag = true;
+                        }
+                    }
             }
-            __syncthreads();
+            if (t0 + CAP < p1) __syncthreads();
         }
         if (tid < nr) {
             y[r0 + tid] = sum;
-            if (DOT) dacc = xg[ghost_lo + r0 + tid] * sum;
+            if (DOT) {
+                if (!have_diag) xd = xg[dcol];
+                dacc = xd * sum;
+            }
         }
     }
     if (DOT) {
         const double s = block_sum_256(dacc, red);
         if (tid == 0) part[blockIdx.x] = s;
     }
+}
+
+// largest number of entries in a 256-row chunk (chooses the LDS capacity)
+template <typename RP>
+__global__ void k_max_chunk_nnz(int64_t n, const RP *__restrict__ rowptr, unsigned long long *__restrict__ out)
+{
+    const int64_t nchunks = (n + LDS_ROWS - 1) / LDS_ROWS;
+    unsigned long long m = 0;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r0 = c * LDS_ROWS, r1 = (r0 + LDS_ROWS < n) ? r0 + LDS_ROWS : n;
+        const unsigned long long v = (unsigned long long)(rowptr[r1] - rowptr[r0]);
+        m = v > m ? v : m;
+    }
+    atomicMax(out, m);
 }
 
 // stage 1 of the p.Ap reduction: `nin` per-workgroup partials -> <= 1024 partial sums (fixed order)
@@ -310,16 +337,24 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
             }
             big = s->d_spmv_part;
         }
-#define PIB_LAUNCH_LDS(RP)                                                                                        \
+#define PIB_LAUNCH_LDS(RP, CAP)                                                                                   \
     do {                                                                                                          \
         if (dot_part)                                                                                             \
-            hipLaunchKernelGGL((k_spmv_lds<RP, true>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, \
-                               (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, big, ord);                  \
+            hipLaunchKernelGGL((k_spmv_lds<RP, true, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin,  \
+                               r_end, (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, big, ord);           \
         else                                                                                                      \
-            hipLaunchKernelGGL((k_spmv_lds<RP, false>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin,      \
+            hipLaunchKernelGGL((k_spmv_lds<RP, false, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, \
                                r_end, (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord); \
     } while (0)
-        if (A.rp64) PIB_LAUNCH_LDS(int64_t); else PIB_LAUNCH_LDS(int32_t);
+        // +1: the span is widened to an even start
+        const int64_t need = A.max_chunk_nnz + 1;
+        if (need <= 1282) {
+            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 1282); else PIB_LAUNCH_LDS(int32_t, 1282);
+        } else if (need <= 1794) {
+            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 1794); else PIB_LAUNCH_LDS(int32_t, 1794);
+        } else {
+            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 2050); else PIB_LAUNCH_LDS(int32_t, 2050);
+        }
 #undef PIB_LAUNCH_LDS
         PIB_HIP(hipGetLastError());
         if (dot_part) {
@@ -392,8 +427,23 @@ int extract_dinv(pib_solver *s, int *n_missing)
     }
     int h = 0;
     PIB_HIP(hipMemcpyAsync(&h, d_missing, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    // largest 256-row chunk (LDS capacity of the SpMV)
+    unsigned long long *d_max = nullptr, h_max = 0;
+    PIB_HIP(hipMalloc(&d_max, sizeof(unsigned long long)));
+    PIB_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned long long), s->stream));
+    if (A.n > 0) {
+        const int nb = (int)std::min<int64_t>(1024, ((A.n + LDS_ROWS - 1) / LDS_ROWS + 255) / 256);
+        if (A.rp64)
+            hipLaunchKernelGGL(k_max_chunk_nnz<int64_t>, dim3(nb), dim3(256), 0, s->stream, A.n, (const int64_t *)A.rowptr, d_max);
+        else
+            hipLaunchKernelGGL(k_max_chunk_nnz<int32_t>, dim3(nb), dim3(256), 0, s->stream, A.n, (const int32_t *)A.rowptr, d_max);
+        PIB_HIP(hipGetLastError());
+    }
+    PIB_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, s->stream));
     PIB_HIP(hipStreamSynchronize(s->stream));
     PIB_HIP(hipFree(d_missing));
+    PIB_HIP(hipFree(d_max));
+    A.max_chunk_nnz = (int64_t)h_max;
     *n_missing = h;
     return 0;
 }

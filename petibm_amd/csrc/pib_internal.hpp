@@ -118,6 +118,7 @@ struct DeviceCsr {
     int64_t first_boundary_lo = 0;  // rows [0, n_lo) touch the low halo
     int64_t n_lo = 0, n_hi = 0;     // rows touching the low / high halo (contiguous at both ends)
     int64_t send_prev = 0, send_next = 0;  // entries the neighbours need from this rank
+    int64_t max_chunk_nnz = 1 << 30;       // largest 256-row chunk (selects the SpMV's LDS capacity)
     void release();
 };
 

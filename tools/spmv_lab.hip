@@ -357,6 +357,84 @@ __global__ __launch_bounds__(256) void k_spmv_t(int64_t n, const int32_t *__rest
     }
 }
 
+
+// ---- variant T2: as T (non-persistent), but (i) p0/p1 come from two uniform loads so phase 1 starts at once,
+// per-row offsets go straight to registers (no srow in LDS, one barrier less); (ii) LDS sized TILE=1792+pad for
+// 7-entry rows (7 instead of 6 workgroups per CU); (iii) optional fused x.y dot reusing the gathered diagonal.
+template <int TILE, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_t2(int64_t n, const int32_t *__restrict__ rowptr,
+                                                 const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                 const double *__restrict__ x, double *__restrict__ y, Order o,
+                                                 double *__restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) double vals[TILE + 2];
+    __shared__ __attribute__((aligned(16))) int32_t cols[TILE + 2];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t nchunks = (n + 255) / 256;
+    const int64_t cpx = (nchunks + 7) >> 3;
+    const int64_t sq = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    double dacc = 0.0;
+    if ((int64_t)(blockIdx.x >> 3) < cpx && sq < nchunks) {
+        const int64_t c = chunk_of(o, sq, nchunks);
+        const int64_t r0 = c * 256;
+        const int nr = (int)((n - r0 < 256) ? (n - r0) : 256);
+        const int32_t p0 = rowptr[r0], p1 = rowptr[r0 + nr];  // uniform: scalar loads
+        int32_t rs = 0, re = 0;
+        if (tid < nr) {
+            rs = rowptr[r0 + tid];
+            re = rowptr[r0 + tid + 1];
+        }
+        double sum = 0.0;
+        const int32_t a0 = p0 & ~1;
+        for (int32_t t0 = a0; t0 < p1; t0 += TILE) {
+#pragma unroll
+            for (int u = 0; u < (TILE + 511) / 512; ++u) {
+                const int32_t q = t0 + 2 * (tid + u * 256);
+                if (q < p1 && q - t0 < TILE) {
+                    *reinterpret_cast<double2 *>(&vals[q - t0]) = *reinterpret_cast<const double2 *>(val + q);
+                    *reinterpret_cast<int2 *>(&cols[q - t0]) = *reinterpret_cast<const int2 *>(col + q);
+                }
+            }
+            __syncthreads();
+            const int32_t lo = (rs > t0) ? rs : t0;
+            const int32_t hi = (re < t0 + TILE) ? re : (t0 + TILE);
+            for (int32_t p = lo; p < hi; p += 8) {
+                double vv[8], xx[8];
+                int32_t cc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = p + u < hi;
+                    cc[u] = ok ? cols[p + u - t0] : 0;
+                    vv[u] = ok ? vals[p + u - t0] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xx[u] = (p + u < hi) ? x[cc[u]] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (p + u < hi) {
+                        sum = sum + vv[u] * xx[u];
+                        if (DOT && cc[u] == (int32_t)(r0 + tid)) dacc = xx[u];
+                    }
+            }
+            if (t0 + TILE < p1) __syncthreads();
+        }
+        if (tid < nr) {
+            y[r0 + tid] = sum;
+            if (DOT) dacc = dacc * sum;
+        }
+    }
+    if (DOT) {
+        // wave sums -> LDS -> one value per workgroup
+        double v = dacc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
 // streaming floor: read val/col/rowptr, write y, no gather (x[0] only)
 __global__ __launch_bounds__(256) void k_stream_floor(int64_t n, int64_t nnz, const int32_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ col, const double *__restrict__ val,
@@ -472,6 +550,22 @@ int main(int argc, char **argv)
         RUNT(nm, true, 2048, til);
         snprintf(nm, sizeof nm, "T  lds-transpose non-persist tiles tj=%d", tj);
         RUNT(nm, false, NPG, til);
+    }
+    {
+        double *part;
+        CK(hipMalloc(&part, 8 * (size_t)(NPG + 8)));
+        const int64_t cpp = nx * ny / 256, cpt = (int64_t)64 * nx / 256;
+        Order til{1, cpp, cpt, nz};
+        bench("T2 tile2048 nodot tiles tj=64", [&] {
+            hipLaunchKernelGGL((k_spmv_t2<2048, false>), dim3(NPG), dim3(256), 0, 0, n, rowptr, col, val, x, y, til, part); }, true);
+        bench("T2 tile1792 nodot tiles tj=64", [&] {
+            hipLaunchKernelGGL((k_spmv_t2<1792, false>), dim3(NPG), dim3(256), 0, 0, n, rowptr, col, val, x, y, til, part); }, true);
+        bench("T2 tile1792 DOT   tiles tj=64", [&] {
+            hipLaunchKernelGGL((k_spmv_t2<1792, true>), dim3(NPG), dim3(256), 0, 0, n, rowptr, col, val, x, y, til, part); }, true);
+        bench("T2 tile2048 DOT   tiles tj=64", [&] {
+            hipLaunchKernelGGL((k_spmv_t2<2048, true>), dim3(NPG), dim3(256), 0, 0, n, rowptr, col, val, x, y, til, part); }, true);
+        bench("T  (product kernel shape) tiles tj=64", [&] {
+            hipLaunchKernelGGL((k_spmv_t<256, 8, false>), dim3(NPG), dim3(256), 0, 0, n, rowptr, col, val, x, y, til); }, true);
     }
     for (int tj : {16, 64, 128}) {
         const int64_t cpp = nx * ny / 256, cpt = (int64_t)tj * nx / 256;
