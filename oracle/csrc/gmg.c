@@ -20,9 +20,14 @@
  *       (A x)_c = sum_faces coef_f (x_nb - x_c),  coef = area_perp * g_d[s],
  *       g_d[s] = dt / (0.5 (w_d[s] + w_d[s+1]))      (the DBNG of
  *       applications/navierstokes/navierstokes.cpp:349-356 for BN order 1);
- *     coarse widths W_I = w_2I + w_2I+1 (last cell alone when n is odd);
- *   - transfer: cell-centred tri-linear prolongation with weights 3/4, 1/4
- *     (constant extrapolation at walls), restriction = its transpose;
+ *   - selective coarsening per direction: walking the cells of a direction, two neighbours are merged only if
+ *     their combined width is <= 1.5 * hmin * 2^(level+1) (hmin = smallest fine cell); cells that are already
+ *     larger stay alone, so the stretched far field catches up with the refined region and the level grids
+ *     become more and more uniform (on a uniform mesh this is plain pairing); coarse width = sum of children;
+ *   - transfer: cell-centred (tri-)linear prolongation with width-based weights: a child at distance b/2 from
+ *     its parent's centre (b = its sibling's width) takes t = b / (W_parent + W_neighbour) from the neighbouring
+ *     coarse cell on its side and 1 - t from its parent (3/4, 1/4 on a uniform mesh, exactly); a lone child and
+ *     a child at a wall take the parent's value; restriction = transpose;
  *   - smoother: damped Jacobi, omega = relaxation_factor; pre-smoothing starts
  *     from a zero guess; V(nu1, nu2);
  *   - coarsest level (<= 2 cells per direction): `coarsest_sweeps` Jacobi sweeps;
@@ -44,6 +49,10 @@ typedef struct {
     double *w[3]; /* widths, n[d] */
     double *g[3]; /* face factors incl. dt, n[d]-1 */
     double *x, *x2, *b, *r;
+    /* transfer tables towards the next coarser level, per direction (NULL on the coarsest level) */
+    int32_t *par[3], *oth[3]; /* [n[d]] parent / other coarse index of fine cell s (oth == par: none) */
+    double *wpar[3], *woth[3]; /* [n[d]] their weights */
+    int32_t *fst[3];           /* [nc[d]+1] first child of coarse cell I */
 } level_t;
 
 typedef struct {
@@ -52,6 +61,8 @@ typedef struct {
     int pre, post, coarsest_sweeps;
     double omega;
     int nullspace; /* 0 none 1 constant 2 pinned */
+    double hmin;      /* smallest fine cell width over the coarsenable directions */
+    int target_shift; /* extra doublings of the merge target (levels on which nothing merged are skipped) */
     int smoother;  /* 0 damped Jacobi, 1 Chebyshev-Jacobi (pre/post = polynomial degree) */
     double cheb_lmax, cheb_ratio; /* eigenvalue window [lmax/ratio, lmax] of D^-1 A */
     double *d[MAXLEV];
@@ -94,7 +105,7 @@ static inline double apply_cell(const level_t *l, const double *x, i64 i, i64 j,
 
 static void lvl_free(level_t *l)
 {
-    for (int d = 0; d < 3; ++d) { free(l->w[d]); free(l->g[d]); }
+    for (int d = 0; d < 3; ++d) { free(l->w[d]); free(l->g[d]); free(l->par[d]); free(l->oth[d]); free(l->wpar[d]); free(l->woth[d]); free(l->fst[d]); }
     free(l->x); free(l->x2); free(l->b); free(l->r);
 }
 
@@ -127,6 +138,11 @@ void *orc_gmg_create(int dim, const i64 *n_in, const double *wx, const double *w
     }
     int nl = 1;
     if (max_levels > MAXLEV) max_levels = MAXLEV;
+    G->hmin = 0.0;
+    for (int d = 0; d < 3; ++d)
+        if (l->n[d] > 1)
+            for (i64 q = 0; q < l->n[d]; ++q)
+                if (G->hmin == 0.0 || l->w[d][q] < G->hmin) G->hmin = l->w[d][q];
     for (;;) {
         l = &G->L[nl - 1];
         l->N = l->n[0] * l->n[1] * l->n[2];
@@ -137,14 +153,58 @@ void *orc_gmg_create(int dim, const i64 *n_in, const double *wx, const double *w
         if (nl >= max_levels) break;
         if (l->n[0] <= 2 && l->n[1] <= 2 && l->n[2] <= 2) break;
         level_t *c = &G->L[nl];
-        for (int d = 0; d < 3; ++d) {
-            c->n[d] = (l->n[d] > 2) ? (l->n[d] + 1) / 2 : l->n[d];
-            c->w[d] = malloc(sizeof(double) * (size_t)c->n[d]);
-            if (c->n[d] == l->n[d]) memcpy(c->w[d], l->w[d], sizeof(double) * (size_t)l->n[d]);
-            else
-                for (i64 I = 0; I < c->n[d]; ++I)
-                    c->w[d][I] = (2 * I + 1 < l->n[d]) ? l->w[d][2 * I] + l->w[d][2 * I + 1] : l->w[d][2 * I];
+        /* selective coarsening: raise the target until at least one direction merges something */
+        int merged_any = 0;
+        for (int tries = 0; tries < 64 && !merged_any; ++tries, ++G->target_shift) {
+            const double target = 1.5 * G->hmin * ldexp(1.0, nl + G->target_shift);
+            for (int d = 0; d < 3; ++d) {
+                const i64 n = l->n[d];
+                free(l->par[d]); free(l->oth[d]); free(l->wpar[d]); free(l->woth[d]); free(l->fst[d]); free(c->w[d]);
+                l->par[d] = malloc(sizeof(int32_t) * (size_t)n);
+                l->oth[d] = malloc(sizeof(int32_t) * (size_t)n);
+                l->wpar[d] = malloc(sizeof(double) * (size_t)n);
+                l->woth[d] = malloc(sizeof(double) * (size_t)n);
+                l->fst[d] = malloc(sizeof(int32_t) * (size_t)(n + 1));
+                c->w[d] = malloc(sizeof(double) * (size_t)n);
+                i64 I = 0;
+                for (i64 s = 0; s < n; ++I) {
+                    l->fst[d][I] = (int32_t)s;
+                    if (n > 2 && s + 1 < n && l->w[d][s] + l->w[d][s + 1] <= target) {
+                        l->par[d][s] = l->par[d][s + 1] = (int32_t)I;
+                        c->w[d][I] = l->w[d][s] + l->w[d][s + 1];
+                        s += 2;
+                        merged_any = 1;
+                    } else {
+                        l->par[d][s] = (int32_t)I;
+                        c->w[d][I] = l->w[d][s];
+                        s += 1;
+                    }
+                }
+                l->fst[d][I] = (int32_t)n;
+                c->n[d] = I;
+                /* width-based linear interpolation weights */
+                for (i64 s = 0; s < n; ++s) {
+                    const i64 P = l->par[d][s];
+                    const i64 f0 = l->fst[d][P], f1 = l->fst[d][P + 1];
+                    i64 O = P;
+                    double t = 0.0;
+                    if (f1 - f0 == 2) {
+                        const int left = (s == f0);
+                        O = left ? P - 1 : P + 1;
+                        if (O < 0 || O >= I) O = P;
+                        else {
+                            const double sib = left ? l->w[d][s + 1] : l->w[d][s - 1];
+                            t = sib / (c->w[d][P] + c->w[d][O]);
+                        }
+                    }
+                    l->oth[d][s] = (int32_t)O;
+                    l->wpar[d][s] = 1.0 - t;
+                    l->woth[d][s] = t;
+                }
+            }
         }
+        if (!merged_any) break;
+        G->target_shift--; /* the loop's ++ after the successful try */
         nl++;
     }
     G->nlev = nl;
@@ -207,33 +267,17 @@ static void residual(const level_t *l, const double *b, const double *x, double 
             }
 }
 
-/* 1-D transfer stencil of fine cell s (in a direction that was coarsened):
- * parent I = s/2 with weight 3/4, other coarse cell (I-1 for the left child,
- * I+1 for the right child) with weight 1/4, folded onto the parent at a wall. */
-static inline void tr1d(i64 s, i64 nf, i64 nc, int coarsened, i64 I[2], double wt[2])
-{
-    if (!coarsened) { I[0] = s; I[1] = s; wt[0] = 1.0; wt[1] = 0.0; (void)nf; return; }
-    const i64 P = s / 2;
-    const i64 O = (s & 1) ? P + 1 : P - 1;
-    I[0] = P;
-    if (O < 0 || O >= nc) { I[1] = P; wt[0] = 1.0; wt[1] = 0.0; }
-    else { I[1] = O; wt[0] = 0.75; wt[1] = 0.25; }
-}
-
-/* xf += P xc */
+/* xf += P xc (table driven) */
 static void prolong_add(const level_t *f, const level_t *c, const double *xc, double *xf)
 {
-    int co[3];
-    for (int d = 0; d < 3; ++d) co[d] = c->n[d] != f->n[d];
 #pragma omp parallel for schedule(static)
     for (i64 k = 0; k < f->n[2]; ++k)
         for (i64 j = 0; j < f->n[1]; ++j)
             for (i64 i = 0; i < f->n[0]; ++i) {
-                i64 I[2], J[2], K[2];
-                double wi[2], wj[2], wk[2];
-                tr1d(i, f->n[0], c->n[0], co[0], I, wi);
-                tr1d(j, f->n[1], c->n[1], co[1], J, wj);
-                tr1d(k, f->n[2], c->n[2], co[2], K, wk);
+                const i64 I[2] = {f->par[0][i], f->oth[0][i]}, J[2] = {f->par[1][j], f->oth[1][j]},
+                          K[2] = {f->par[2][k], f->oth[2][k]};
+                const double wi[2] = {f->wpar[0][i], f->woth[0][i]}, wj[2] = {f->wpar[1][j], f->woth[1][j]},
+                             wk[2] = {f->wpar[2][k], f->woth[2][k]};
                 double s = 0.0;
                 for (int c2 = 0; c2 < 2; ++c2)
                     for (int b2 = 0; b2 < 2; ++b2)
@@ -245,37 +289,37 @@ static void prolong_add(const level_t *f, const level_t *c, const double *xc, do
             }
 }
 
-/* bc = P^T rf : gather form over coarse cells (what the HIP kernel does) */
+/* weight with which fine cell s feeds coarse cell I in one direction */
+static inline double rw(const level_t *f, int d, i64 s, i64 I)
+{
+    double w = 0.0;
+    if (f->par[d][s] == I) w = f->wpar[d][s];
+    else if (f->oth[d][s] == I) w = f->woth[d][s];
+    return w;
+}
+
+/* bc = P^T rf : gather form over coarse cells (what the HIP kernel does): fine cells fst[I]-1 .. fst[I+1] */
 static void restrict_t(const level_t *f, const level_t *c, const double *rf, double *bc)
 {
-    int co[3];
-    for (int d = 0; d < 3; ++d) co[d] = c->n[d] != f->n[d];
 #pragma omp parallel for schedule(static)
     for (i64 K = 0; K < c->n[2]; ++K)
         for (i64 J = 0; J < c->n[1]; ++J)
             for (i64 I = 0; I < c->n[0]; ++I) {
-                /* candidate fine cells per direction: 2I-1 .. 2I+2 (or just I) */
                 double s = 0.0;
-                const i64 k0 = co[2] ? 2 * K - 1 : K, k1 = co[2] ? 2 * K + 2 : K;
-                const i64 j0 = co[1] ? 2 * J - 1 : J, j1 = co[1] ? 2 * J + 2 : J;
-                const i64 i0 = co[0] ? 2 * I - 1 : I, i1 = co[0] ? 2 * I + 2 : I;
+                const i64 k0 = f->fst[2][K] - 1, k1 = f->fst[2][K + 1];
+                const i64 j0 = f->fst[1][J] - 1, j1 = f->fst[1][J + 1];
+                const i64 i0 = f->fst[0][I] - 1, i1 = f->fst[0][I + 1];
                 for (i64 k = k0; k <= k1; ++k) {
                     if (k < 0 || k >= f->n[2]) continue;
-                    i64 KK[2]; double wk[2];
-                    tr1d(k, f->n[2], c->n[2], co[2], KK, wk);
-                    const double wz = (KK[0] == K ? wk[0] : 0.0) + ((KK[1] == K && wk[1] != 0.0) ? wk[1] : 0.0);
+                    const double wz = rw(f, 2, k, K);
                     if (wz == 0.0) continue;
                     for (i64 j = j0; j <= j1; ++j) {
                         if (j < 0 || j >= f->n[1]) continue;
-                        i64 JJ[2]; double wj[2];
-                        tr1d(j, f->n[1], c->n[1], co[1], JJ, wj);
-                        const double wy = (JJ[0] == J ? wj[0] : 0.0) + ((JJ[1] == J && wj[1] != 0.0) ? wj[1] : 0.0);
+                        const double wy = rw(f, 1, j, J);
                         if (wy == 0.0) continue;
                         for (i64 i = i0; i <= i1; ++i) {
                             if (i < 0 || i >= f->n[0]) continue;
-                            i64 II[2]; double wi[2];
-                            tr1d(i, f->n[0], c->n[0], co[0], II, wi);
-                            const double wx = (II[0] == I ? wi[0] : 0.0) + ((II[1] == I && wi[1] != 0.0) ? wi[1] : 0.0);
+                            const double wx = rw(f, 0, i, I);
                             if (wx == 0.0) continue;
                             s += ((wz * wy) * wx) * rf[idx(f, i, j, k)];
                         }

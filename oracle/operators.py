@@ -37,6 +37,12 @@ class CSR:
     def nnz(self) -> int:
         return int(self.rowptr[-1])
 
+    @staticmethod
+    def from_csr32(rowptr, col, val) -> "CSR":
+        """square CSR from the int32 arrays of clib.assemble_poisson32"""
+        n = len(rowptr) - 1
+        return CSR(n, n, np.asarray(rowptr, dtype=np.int64), np.asarray(col, dtype=np.int64), np.asarray(val))
+
     def copy(self) -> "CSR":
         return CSR(self.n_rows, self.n_cols, self.rowptr.copy(), self.col.copy(), self.val.copy())
 

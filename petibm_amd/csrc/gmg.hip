@@ -12,10 +12,15 @@
 //     the slab (decomposition) axis is always the last one;
 //   * level operator = rediscretised FV operator from three 1-D width arrays
 //     (16-24 B/row of HBM traffic instead of the CSR's 104 B/row);
-//   * tri-linear cell-centred prolongation (3/4, 1/4), restriction = P^T,
+//   * selective coarsening per direction (neighbours merge only while their
+//     combined width is <= 1.5 hmin 2^(level+1): the stretched far field of a
+//     PetIBM mesh waits for the refined region; plain pairing when uniform);
+//   * tri-linear cell-centred prolongation with width-based weights from 1-D
+//     tables (3/4, 1/4 on a uniform mesh), restriction = P^T,
 //     damped-Jacobi V(nu1,nu2), pre-smoothing from a zero guess;
 //   * multi-GPU: levels are z-slab distributed (one halo plane, RCCL
-//     send/recv) while slabs stay even and the level is large; below that the
+//     send/recv; aggregates never straddle a slab boundary) while every rank
+//     keeps >= 2 planes and the level is large; below that the
 //     level's right-hand side is all-gathered and the remaining levels are
 //     solved redundantly on every GPU (no further communication);
 //   * null space: CONSTANT leaves z un-projected (the Krylov kernels subtract
@@ -28,10 +33,23 @@
 
 namespace pib {
 
+// 1-D transfer table of one direction towards the next coarser level (see grid_register)
+struct Tr1 {
+    const int *par, *oth, *fst;  // parent / other coarse cell of fine cell s; first child of coarse cell I
+    const double *wpar, *woth;   // their interpolation weights
+};
+// x direction, packed per COARSE cell I for the row kernels (one lane <-> one coarse cell and its children)
+struct TrX {
+    const int2 *fc;     // first child, number of children (1 or 2)
+    const double4 *pw;  // prolongation: child0 <- (I, I-1) weights, child1 <- (I, I+1) weights (zeros: none)
+    const double4 *rw;  // restriction: weights with which fine cells f0-1, f0, f0+1 (0 if lone), f0+cnt feed I
+};
 struct LevelDev {
     int nx, ny, nzg;  // global cells (each < 2^31; the local cell count fits int32 like the CSR columns)
     int k0, nk;       // owned planes [k0, k0+nk)
     const double *wx, *wy, *wz, *gx, *gy, *gz;
+    Tr1 t[3];         // x, y, z tables (null on the coarsest level)
+    TrX tx;
 };
 
 __device__ __forceinline__ void face_coefs(const LevelDev &L, int i, int j, int k, double c[6])
@@ -176,202 +194,155 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
     }
 }
 
-// 1-D transfer stencil of fine cell s: parent s/2 (3/4) and the coarse cell on
-// the child's side (1/4), folded onto the parent at a wall; identity if the
-// direction is not coarsened.
-__device__ __forceinline__ void tr1d(int s, int nc, bool coarsened, int I[2], double wt[2])
+// 1-D transfer stencil of fine cell s: its parent aggregate (weight 1 - t) and the coarse cell on the child's
+// side (weight t = sibling width / (W_parent + W_neighbour); 3/4, 1/4 on a uniform mesh); a lone child, a child
+// at a wall and a direction that is not coarsened have oth == par with weights (1, 0).
+__device__ __forceinline__ void tr1d(const Tr1 &t, int s, int I[2], double wt[2])
 {
-    if (!coarsened) {
-        I[0] = I[1] = s;
-        wt[0] = 1.0;
-        wt[1] = 0.0;
-        return;
-    }
-    const int P = s >> 1;
-    const int O = (s & 1) ? P + 1 : P - 1;
-    I[0] = P;
-    if (O < 0 || O >= nc) {
-        I[1] = P;
-        wt[0] = 1.0;
-        wt[1] = 0.0;
-    } else {
-        I[1] = O;
-        wt[0] = 0.75;
-        wt[1] = 0.25;
-    }
+    I[0] = t.par[s];
+    I[1] = t.oth[s];
+    wt[0] = t.wpar[s];
+    wt[1] = t.woth[s];
 }
 
-// transposed form: the (up to 4) fine cells that feed coarse cell I and their weights
-// (fine cell s feeds I with 3/4 [1 when its other target is beyond a wall] if s/2 == I, with 1/4 otherwise).
-__device__ __forceinline__ int rs1d(int I, int nf, int nc, bool coarsened, int s[4], double wt[4])
+// ---- transfer kernels, row form -------------------------------------------------------------------------
+// One wave <-> one grid row (fixed j, k: the y / z stencils are wave-uniform, i.e. scalar loads), one lane <-> one
+// COARSE cell I of that row and its one or two fine children.  The x neighbours I-1 / I+1 come from the
+// neighbouring lanes (__shfl), only the two wave-edge lanes load them: a coarse value is loaded once per row
+// instead of three times (prolongation) and a fine value once instead of twice (restriction) -- these kernels
+// are bound by the vector-memory issue rate, not by HBM (rocprof r01: 1.2 ms / 0.83 ms per 512^3 launch with
+// per-lane table gathers, 0.47 / 0.25 ms of HBM time).  Row groups are dealt to the XCDs in contiguous ranges
+// (workgroup b runs on XCD b % 8), so a coarse row is fetched by one L2 only.
+// Summation order = the oracle's: z, then y, then x ascending, weights ((wz*wy)*wx); zero weights add exactly 0.
+__device__ __forceinline__ bool row_of_wave(int ngroups, int per_xcd, int nrows, int *row)
 {
-    if (!coarsened) {
-        s[0] = I;
-        wt[0] = 1.0;
-        return 1;
-    }
-    int cnt = 0;
-#pragma unroll
-    for (int o = -1; o <= 2; ++o) {
-        const int f = 2 * I + o;
-        if (f < 0 || f >= nf) continue;
-        const int P = f >> 1;
-        const int O = (f & 1) ? P + 1 : P - 1;
-        double w;
-        if (P == I)
-            w = (O < 0 || O >= nc) ? 1.0 : 0.75;
-        else
-            w = 0.25;  // then O == I by construction
-        s[cnt] = f;
-        wt[cnt] = w;
-        ++cnt;
-    }
-    return cnt;
+    const int b = blockIdx.x;
+    const int rg = (b & 7) * per_xcd + (b >> 3);
+    *row = __builtin_amdgcn_readfirstlane(rg * 4 + (int)threadIdx.y);
+    return rg < ngroups && *row < nrows;
 }
 
-// xf += P xc.   xc points at the coarse level's first owned plane (coarse k0c);
-// coarse halo planes must be valid when the level is distributed.
-__global__ __launch_bounds__(256) void k_prolong_add(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
-                                                     const double *__restrict__ xc, double *__restrict__ xf)
+// xf += P xc.   xc points at the coarse level's first owned plane (coarse k0c); coarse halo planes must be valid
+// when the level is distributed.
+__global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
+                                                      const double *__restrict__ xc, double *__restrict__ xf,
+                                                      int ngroups, int per_xcd, int vec_ok)
 {
     if (S != nullptr && S->done) return;
-    const bool cx = C.nx != F.nx, cy = C.ny != F.ny, cz = C.nzg != F.nzg;
-    const int64_t cplane = (int64_t)C.nx * C.ny;
-    PIB_PLANE_LOOP(F)
-    {
-        PIB_PLANE_IJ(F)
-        int I[2], J[2], K[2];
-        double wi[2], wj[2], wk[2];
-        tr1d(i, C.nx, cx, I, wi);
-        tr1d(j, C.ny, cy, J, wj);
-        tr1d(k, C.nzg, cz, K, wk);
-        double s = 0.0;
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-                for (int a2 = 0; a2 < 2; ++a2) {
-                    const double wgt = (wk[c2] * wj[b2]) * wi[a2];
-                    if (wgt != 0.0) s += wgt * xc[I[a2] + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0)];
-                }
-        xf[p] += s;
-    }
-}
-
-// Pair form of the prolongation for a coarsened, even-sized x direction: lane <-> coarse cell I, i.e. the two
-// fine children 2I, 2I+1 (one 16-byte read-modify-write); 12 coarse reads serve both children.  Same
-// per-child summation order as k_prolong_add (c2, b2, then parent before neighbour): bit-identical.
-__global__ __launch_bounds__(256) void k_prolong_add2(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
-                                                      const double *__restrict__ xc, double *__restrict__ xf)
-{
-    if (S != nullptr && S->done) return;
-    const bool cy = C.ny != F.ny, cz = C.nzg != F.nzg;
+    int row;
+    if (!row_of_wave(ngroups, per_xcd, F.ny * F.nk, &row)) return;
+    const int kk = row / F.ny, j = row - kk * F.ny, k = F.k0 + kk;
+    int J[2], K[2];
+    double wj[2], wk[2];
+    tr1d(F.t[1], j, J, wj);
+    tr1d(F.t[2], k, K, wk);
+    const int lane = threadIdx.x;
+    const int Iraw = blockIdx.y * 64 + lane;
+    const bool valid = Iraw < C.nx;
+    const int I = valid ? Iraw : C.nx - 1;
+    const int2 fc = F.tx.fc[I];
+    const double4 pw = F.tx.pw[I];
+    const bool edgeL = (lane == 0 && I > 0), edgeR = (lane == 63 && I + 1 < C.nx);
     const int64_t cplane = (int64_t)C.nx * C.ny, fplane = (int64_t)F.nx * F.ny;
-    const unsigned nxc = (unsigned)F.nx / 2;
-    const unsigned planec = nxc * (unsigned)F.ny;
-    const int kk = blockIdx.y;
-    const int k = F.k0 + kk;
-    int K[2];
-    double wk[2];
-    tr1d(k, C.nzg, cz, K, wk);
-    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < planec; q += gridDim.x * 256u) {
-        const int j = (int)(q / nxc);
-        const int I = (int)(q - (unsigned)j * nxc);
-        int J[2];
-        double wj[2];
-        tr1d(j, C.ny, cy, J, wj);
-        const bool hasL = I > 0, hasR = I + 1 < C.nx;
-        const double wp_l = hasL ? 0.75 : 1.0, wo_l = hasL ? 0.25 : 0.0;  // left child 2I: parent I, other I-1
-        const double wp_r = hasR ? 0.75 : 1.0, wo_r = hasR ? 0.25 : 0.0;  // right child 2I+1: parent I, other I+1
-        double sl = 0.0, sr = 0.0;
+    double sl = 0.0, sr = 0.0;
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
+    for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
-                const double wkj = wk[c2] * wj[b2];
-                if (wkj == 0.0) continue;
-                const double *row = xc + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0);
-                const double vP = row[I];
-                const double vL = hasL ? row[I - 1] : 0.0, vR = hasR ? row[I + 1] : 0.0;
-                sl += (wkj * wp_l) * vP;
-                if (hasL) sl += (wkj * wo_l) * vL;
-                sr += (wkj * wp_r) * vP;
-                if (hasR) sr += (wkj * wo_r) * vR;
-            }
-        double2 *dst = reinterpret_cast<double2 *>(xf + (int64_t)kk * fplane + (int64_t)j * F.nx + 2 * I);
-        double2 v = *dst;
-        v.x += sl;
-        v.y += sr;
-        *dst = v;
-    }
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const double wkj = wk[c2] * wj[b2];
+            if (wkj == 0.0) continue;  // wave-uniform
+            const double *rowp = xc + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0);
+            const double vP = rowp[I];
+            double vL = __shfl_up(vP, 1, 64), vR = __shfl_down(vP, 1, 64);
+            if (edgeL) vL = rowp[I - 1];
+            if (edgeR) vR = rowp[I + 1];
+            sl += (wkj * pw.x) * vP;
+            sl += (wkj * pw.y) * vL;
+            sr += (wkj * pw.z) * vP;
+            sr += (wkj * pw.w) * vR;
+        }
+    if (!valid) return;
+    double *dst = xf + (int64_t)kk * fplane + (int64_t)j * F.nx + fc.x;
+    if (fc.y == 2) {
+        if (vec_ok && !(fc.x & 1)) {
+            double2 v = *reinterpret_cast<double2 *>(dst);
+            v.x += sl;
+            v.y += sr;
+            *reinterpret_cast<double2 *>(dst) = v;
+        } else {
+            dst[0] += sl;
+            dst[1] += sr;
+        }
+    } else
+        dst[0] += sl;
 }
 
-// 1-D restriction stencil of coarse cell I in fixed 4-slot form: slot o <-> fine cell f0 + o with weight
-// w[o] (0 where there is no such fine cell); f0 = 2I-1 when the direction is coarsened, else I-1 (only
-// slot 1 is live).  Indices are clamped so the loads are always legal; a zero weight adds exactly 0.
-__device__ __forceinline__ int rs1d4(int I, int nf, int nc, bool coarsened, double w[4], int f[4])
+// 1-D restriction stencil of coarse cell I in fixed 4-slot form: slot o <-> fine cell fst[I] - 1 + o (the left
+// neighbour, the one or two children, the right neighbour) with the weight that cell gives to I (0 where there
+// is no such fine cell or it does not feed I).  Indices are clamped so the loads are always legal; a zero
+// weight adds exactly 0.
+__device__ __forceinline__ void rs1d4(const Tr1 &t, int I, int nf, double w[4], int f[4])
 {
-    const int f0 = coarsened ? 2 * I - 1 : I - 1;
+    const int f0 = t.fst[I] - 1;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         const int ff = f0 + o;
         double wt = 0.0;
         if (ff >= 0 && ff < nf) {
-            if (!coarsened) {
-                wt = (o == 1) ? 1.0 : 0.0;
-            } else {
-                const int P = ff >> 1;
-                const int O = (ff & 1) ? P + 1 : P - 1;
-                if (P == I)
-                    wt = (O < 0 || O >= nc) ? 1.0 : 0.75;
-                else if (O == I)
-                    wt = 0.25;
-            }
+            if (t.par[ff] == I)
+                wt = t.wpar[ff];
+            else if (t.oth[ff] == I)
+                wt = t.woth[ff];
         }
         w[o] = wt;
         f[o] = ff < 0 ? 0 : (ff >= nf ? nf - 1 : ff);
     }
-    return f0;
 }
 
-// bc = P^T rf, gather form over the owned coarse cells; fine halo planes valid.
-// The summation visits the (up to 64) fine cells in ascending (k, j, i) order with weights ((wz*wy)*wx):
-// the oracle's order; terms with zero weight add exactly 0.
-__global__ __launch_bounds__(256) void k_restrict(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
-                                                  const double *__restrict__ rf, double *__restrict__ bc)
+// bc = P^T rf over the owned coarse rows; fine halo planes valid.
+__global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
+                                                       const double *__restrict__ rf, double *__restrict__ bc,
+                                                       int ngroups, int per_xcd)
 {
     if (S != nullptr && S->done) return;
-    const bool cx = C.nx != F.nx, cy = C.ny != F.ny, cz = C.nzg != F.nzg;
+    int row;
+    if (!row_of_wave(ngroups, per_xcd, C.ny * C.nk, &row)) return;
+    const int KK = row / C.ny, J = row - KK * C.ny, K = C.k0 + KK;
+    double wk[4], wj[4];
+    int sk[4], sj[4];
+    rs1d4(F.t[2], K, F.nzg, wk, sk);
+    rs1d4(F.t[1], J, F.ny, wj, sj);
+    const int lane = threadIdx.x;
+    const int Iraw = blockIdx.y * 64 + lane;
+    const bool valid = Iraw < C.nx;
+    const int I = valid ? Iraw : C.nx - 1;
+    const int2 fc = F.tx.fc[I];
+    const double4 rw = F.tx.rw[I];
+    const bool pair = (fc.y == 2);
+    const int f0 = fc.x, f1 = pair ? f0 + 1 : f0;
+    const bool edgeL = (lane == 0 && I > 0), edgeR = (lane == 63 && I + 1 < C.nx);
     const int64_t fplane = (int64_t)F.nx * F.ny;
-    const unsigned plane_ = (unsigned)C.nx * (unsigned)C.ny;
-    const int kk_ = blockIdx.y;
-    const int K = C.k0 + kk_;
-    double wk[4];
-    int sk[4];
-    rs1d4(K, F.nzg, C.nzg, cz, wk, sk);
-    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < plane_; q += gridDim.x * 256u) {
-        const int J = (int)(q / (unsigned)C.nx);
-        const int I = (int)(q - (unsigned)J * (unsigned)C.nx);
-        double wi[4], wj[4];
-        int si[4], sj[4];
-        rs1d4(I, F.nx, C.nx, cx, wi, si);
-        rs1d4(J, F.ny, C.ny, cy, wj, sj);
-        double s = 0.0;
+    double s = 0.0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (wk[c] == 0.0) continue;  // workgroup-uniform
-            const double *pk = rf + fplane * (sk[c] - F.k0);
+    for (int c = 0; c < 4; ++c) {
+        if (wk[c] == 0.0) continue;  // wave-uniform
+        const double *pk = rf + fplane * (sk[c] - F.k0);
 #pragma unroll
-            for (int b2 = 0; b2 < 4; ++b2) {
-                const double wzy = wk[c] * wj[b2];
-                const double *pj = pk + (int64_t)F.nx * sj[b2];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) s += (wzy * wi[a]) * pj[si[a]];
-            }
+        for (int b2 = 0; b2 < 4; ++b2) {
+            if (wj[b2] == 0.0) continue;  // wave-uniform
+            const double wzy = wk[c] * wj[b2];
+            const double *pj = pk + (int64_t)F.nx * sj[b2];
+            const double c0 = pj[f0], c1 = pj[f1];
+            double vl = __shfl_up(c1, 1, 64), vr = __shfl_down(c0, 1, 64);
+            if (edgeL) vl = pj[f0 - 1];
+            if (edgeR) vr = pj[f1 + 1];
+            s += (wzy * rw.x) * vl;
+            s += (wzy * rw.y) * c0;
+            s += (wzy * rw.z) * c1;
+            s += (wzy * rw.w) * vr;
         }
-        bc[(int64_t)kk_ * plane_ + q] = s;
     }
+    if (valid) bc[(int64_t)KK * C.nx * C.ny + (int64_t)J * C.nx + I] = s;
 }
 
 // coarsest level in ONE workgroup: `sweeps` damped-Jacobi sweeps from zero,
@@ -473,16 +444,15 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
         }
         __threadfence_block();
         __syncthreads();
-        const bool cx = C.nx != F.nx, cy = C.ny != F.ny, cz = C.nzg != F.nzg;
         const int cplane = C.nx * C.ny, nc = cplane * C.nk;
         double *bc = T.lv[l + 1].b;
         for (int q = threadIdx.x; q < nc; q += blockDim.x) {
             const int I = q % C.nx, J = (q / C.nx) % C.ny, K = C.k0 + q / cplane;
             double wi[4], wj[4], wk[4];
             int si[4], sj[4], sk[4];
-            rs1d4(I, F.nx, C.nx, cx, wi, si);
-            rs1d4(J, F.ny, C.ny, cy, wj, sj);
-            rs1d4(K, F.nzg, C.nzg, cz, wk, sk);
+            rs1d4(F.t[0], I, F.nx, wi, si);
+            rs1d4(F.t[1], J, F.ny, wj, sj);
+            rs1d4(F.t[2], K, F.nzg, wk, sk);
             double sum = 0.0;
             for (int c2 = 0; c2 < 4; ++c2) {
                 if (wk[c2] == 0.0) continue;
@@ -518,16 +488,15 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
         const LevelDev &C = T.lv[l + 1].L;
         double *a = cur[l], *c = spare[l];
         const double *xc = cur[l + 1];
-        const bool cx = C.nx != F.nx, cy = C.ny != F.ny, cz = C.nzg != F.nzg;
         const int fplane = F.nx * F.ny, nf = fplane * F.nk;
         const int64_t cplane = (int64_t)C.nx * C.ny;
         for (int p = threadIdx.x; p < nf; p += blockDim.x) {
             const int i = p % F.nx, j = (p / F.nx) % F.ny, k = F.k0 + p / fplane;
             int I[2], J[2], K[2];
             double wi[2], wj[2], wk[2];
-            tr1d(i, C.nx, cx, I, wi);
-            tr1d(j, C.ny, cy, J, wj);
-            tr1d(k, C.nzg, cz, K, wk);
+            tr1d(F.t[0], i, I, wi);
+            tr1d(F.t[1], j, J, wj);
+            tr1d(F.t[2], k, K, wk);
             double sum = 0.0;
             for (int c2 = 0; c2 < 2; ++c2)
                 for (int b2 = 0; b2 < 2; ++b2)
@@ -562,6 +531,8 @@ static LevelDev dev_of(const GridLevel &g)
     L.gx = g.g[0];
     L.gy = g.g[1];
     L.gz = g.g[2];
+    for (int d = 0; d < 3; ++d) L.t[d] = Tr1{g.t_par[d], g.t_oth[d], g.t_fst[d], g.t_wpar[d], g.t_woth[d]};
+    L.tx = TrX{g.tx_fc, g.tx_pw, g.tx_rw};
     return L;
 }
 
@@ -573,10 +544,11 @@ static dim3 level_grid(const GridLevel &g)
     return dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (plane + 255) / 256)), (unsigned)std::max<int64_t>(1, g.k1 - g.k0));
 }
 
-static int up(const std::vector<double> &h, double **d)
+template <class T>
+static int up(const std::vector<T> &h, T **d)
 {
-    PIB_HIP(hipMalloc(d, sizeof(double) * std::max<size_t>(h.size(), 1)));
-    if (!h.empty()) PIB_HIP(hipMemcpy(*d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    PIB_HIP(hipMalloc(d, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    if (!h.empty()) PIB_HIP(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -586,7 +558,15 @@ void gmg_release(pib_solver *s)
         for (int d = 0; d < 3; ++d) {
             if (L.w[d]) (void)hipFree(L.w[d]);
             if (L.g[d]) (void)hipFree(L.g[d]);
+            if (L.t_par[d]) (void)hipFree(L.t_par[d]);
+            if (L.t_oth[d]) (void)hipFree(L.t_oth[d]);
+            if (L.t_fst[d]) (void)hipFree(L.t_fst[d]);
+            if (L.t_wpar[d]) (void)hipFree(L.t_wpar[d]);
+            if (L.t_woth[d]) (void)hipFree(L.t_woth[d]);
         }
+        if (L.tx_fc) (void)hipFree(L.tx_fc);
+        if (L.tx_pw) (void)hipFree(L.tx_pw);
+        if (L.tx_rw) (void)hipFree(L.tx_rw);
         if (L.x) (void)hipFree(L.x);
         if (L.b) (void)hipFree(L.b);
         if (L.r) (void)hipFree(L.r);
@@ -621,6 +601,36 @@ static int alloc_level_vectors(GridLevel &g, bool need_b)
 template <int MODE>
 static int launch_level(pib_solver *s, const GridLevel &g, double omega, const double *b, const double *xi, double *xo,
                         const double *pin_sum, bool guarded, hipStream_t q, double *dvec = nullptr, double a_d = 0.0);
+
+// row-kernel geometry: 4 rows per workgroup (one per wave), row groups dealt to the 8 XCDs in contiguous ranges
+struct RowGrid {
+    int ngroups, per_xcd;
+    dim3 grid;
+};
+static RowGrid row_grid(int64_t nrows, int64_t ncx)
+{
+    RowGrid r;
+    r.ngroups = (int)((nrows + 3) / 4);
+    r.per_xcd = (r.ngroups + 7) / 8;
+    r.grid = dim3((unsigned)(8 * r.per_xcd), (unsigned)((ncx + 63) / 64));
+    return r;
+}
+static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *xc, double *xf, const Scalars *S, hipStream_t q)
+{
+    const RowGrid r = row_grid(f.n[1] * (f.k1 - f.k0), c.n[0]);
+    const int vec_ok = (f.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(xf) & 15u) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_prolong_rows, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), xc, xf, r.ngroups, r.per_xcd, vec_ok);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+// `c` carries the coarse planes to produce in k0 / k1 (the owned ones, which may be a part of a replicated level)
+static int launch_restrict(const GridLevel &f, const GridLevel &c, const double *rf, double *bc, const Scalars *S, hipStream_t q)
+{
+    const RowGrid r = row_grid(c.n[1] * (c.k1 - c.k0), c.n[0]);
+    hipLaunchKernelGGL(k_restrict_rows, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), rf, bc, r.ngroups, r.per_xcd);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
 
 // ---- hint verification: stencil twin vs CSR SpMV on a fixed pseudo-random vector
 // skip0: the pinned convention (row/column 0 of the CSR replaced by the identity) is the one place where
@@ -734,6 +744,17 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
         for (int r = 0; r < P; ++r) slab_range(nn[2], P, r, &o0[(size_t)r].first, &o0[(size_t)r].second);
         s->gmg_own.push_back(o0);
     }
+    // Selective coarsening (oracle/csrc/gmg.c:orc_gmg_create): walking the cells of a direction, two neighbours
+    // merge only if their combined width is <= 1.5 * hmin * 2^(level+1); cells that are already larger stay
+    // alone, so the stretched far field of a PetIBM mesh catches up with the refined region and the level grids
+    // become uniform (plain pairing on a uniform mesh).  On a distributed level the z aggregates never straddle
+    // a slab boundary, so every coarse plane has one owner and one halo plane serves both transfers.
+    double hmin = 0.0;
+    for (int d = 0; d < 3; ++d)
+        if (nn[d] > 1)
+            for (double v : hw[d])
+                if (hmin == 0.0 || v < hmin) hmin = v;
+    int target_shift = 0;
     for (int l = 0;; ++l) {
         GridLevel G;
         G.dim = dim;
@@ -759,69 +780,127 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
             PIB_CHK(up(hg[d], &G.g[d]));
         }
         PIB_CHK(alloc_level_vectors(G, l > 0));
-        lv.push_back(G);
-        if (l + 1 >= max_levels) break;
-        if (nn[0] <= 2 && nn[1] <= 2 && nn[2] <= 2) break;
-        // next level
-        int64_t nc[3];
-        for (int d = 0; d < 3; ++d) nc[d] = (nn[d] > 2) ? (nn[d] + 1) / 2 : nn[d];
+        const bool last = (l + 1 >= max_levels) || (nn[0] <= 2 && nn[1] <= 2 && nn[2] <= 2);
+        // next level: aggregates and transfer tables
+        std::vector<int32_t> par[3], oth[3], fst[3];
+        std::vector<double> wpar[3], woth[3], cw[3];
+        int64_t nc[3] = {nn[0], nn[1], nn[2]};
+        bool merged_any = false;
+        const auto &of = s->gmg_own.back();
+        for (int tries = 0; !last && tries < 64 && !merged_any; ++tries, ++target_shift) {
+            const double target = 1.5 * hmin * std::ldexp(1.0, l + 1 + target_shift);
+            for (int d = 0; d < 3; ++d) {
+                const int64_t n = nn[d];
+                par[d].assign((size_t)n, 0);
+                oth[d].assign((size_t)n, 0);
+                wpar[d].assign((size_t)n, 1.0);
+                woth[d].assign((size_t)n, 0.0);
+                fst[d].clear();
+                cw[d].clear();
+                std::vector<char> slab_start((size_t)n + 1, 0);
+                if (d == 2 && !replicated)
+                    for (int r = 0; r < P; ++r) slab_start[(size_t)of[(size_t)r].first] = 1;
+                int64_t I = 0;
+                for (int64_t q = 0; q < n; ++I) {
+                    fst[d].push_back((int32_t)q);
+                    if (n > 2 && q + 1 < n && !slab_start[(size_t)q + 1] && hw[d][(size_t)q] + hw[d][(size_t)q + 1] <= target) {
+                        par[d][(size_t)q] = par[d][(size_t)q + 1] = (int32_t)I;
+                        cw[d].push_back(hw[d][(size_t)q] + hw[d][(size_t)q + 1]);
+                        q += 2;
+                        merged_any = true;
+                    } else {
+                        par[d][(size_t)q] = (int32_t)I;
+                        cw[d].push_back(hw[d][(size_t)q]);
+                        q += 1;
+                    }
+                }
+                fst[d].push_back((int32_t)n);
+                nc[d] = I;
+                for (int64_t q = 0; q < n; ++q) {
+                    const int64_t Pq = par[d][(size_t)q];
+                    const int64_t f0 = fst[d][(size_t)Pq], f1 = fst[d][(size_t)Pq + 1];
+                    int64_t O = Pq;
+                    double t = 0.0;
+                    if (f1 - f0 == 2) {
+                        const bool left = (q == f0);
+                        O = left ? Pq - 1 : Pq + 1;
+                        if (O < 0 || O >= I)
+                            O = Pq;
+                        else {
+                            const double sib = left ? hw[d][(size_t)q + 1] : hw[d][(size_t)q - 1];
+                            t = sib / (cw[d][(size_t)Pq] + cw[d][(size_t)O]);
+                        }
+                    }
+                    oth[d][(size_t)q] = (int32_t)O;
+                    wpar[d][(size_t)q] = 1.0 - t;
+                    woth[d][(size_t)q] = t;
+                }
+            }
+        }
+        if (last || !merged_any) {
+            lv.push_back(G);
+            break;
+        }
+        target_shift--;  // the loop's ++ after the successful try
+        for (int d = 0; d < 3; ++d) {
+            PIB_CHK(up(par[d], &G.t_par[d]));
+            PIB_CHK(up(oth[d], &G.t_oth[d]));
+            PIB_CHK(up(fst[d], &G.t_fst[d]));
+            PIB_CHK(up(wpar[d], &G.t_wpar[d]));
+            PIB_CHK(up(woth[d], &G.t_woth[d]));
+        }
         {
-            // ownership of the coarse planes = owner of fine plane 2K (recorded also for the level at which the
+            // x tables packed per coarse cell for the row kernels
+            std::vector<int2> fc((size_t)nc[0]);
+            std::vector<double4> pw((size_t)nc[0]), rw((size_t)nc[0]);
+            for (int64_t I = 0; I < nc[0]; ++I) {
+                const int f0 = fst[0][(size_t)I], cnt = fst[0][(size_t)I + 1] - f0;
+                const int fl = f0 - 1, fr = f0 + cnt;
+                fc[(size_t)I] = make_int2(f0, cnt);
+                pw[(size_t)I] = make_double4(wpar[0][(size_t)f0], woth[0][(size_t)f0], cnt == 2 ? wpar[0][(size_t)f0 + 1] : 0.0,
+                                             cnt == 2 ? woth[0][(size_t)f0 + 1] : 0.0);
+                const double wl = (fl >= 0 && par[0][(size_t)fl] != I && oth[0][(size_t)fl] == I) ? woth[0][(size_t)fl] : 0.0;
+                const double wr = (fr < nn[0] && par[0][(size_t)fr] != I && oth[0][(size_t)fr] == I) ? woth[0][(size_t)fr] : 0.0;
+                rw[(size_t)I] = make_double4(wl, wpar[0][(size_t)f0], cnt == 2 ? wpar[0][(size_t)f0 + 1] : 0.0, wr);
+            }
+            PIB_CHK(up(fc, &G.tx_fc));
+            PIB_CHK(up(pw, &G.tx_pw));
+            PIB_CHK(up(rw, &G.tx_rw));
+        }
+        lv.push_back(G);
+        {
+            // ownership of the coarse planes = owner of their children (recorded also for the level at which the
             // hierarchy switches to replicated: it defines who restricts what before the all-gather)
-            const auto &of = s->gmg_own.back();
             std::vector<std::pair<int64_t, int64_t>> oc((size_t)P);
             for (int r = 0; r < P; ++r) {
                 const int64_t b = of[(size_t)r].first, e = of[(size_t)r].second;
-                if (nc[2] != nn[2]) oc[(size_t)r] = {(b + 1) / 2, (e == nn[2]) ? nc[2] : (e + 1) / 2};
-                else oc[(size_t)r] = {b, e};
+                if (replicated || e <= b)
+                    oc[(size_t)r] = {0, nc[2]};
+                else
+                    oc[(size_t)r] = {par[2][(size_t)b], (int64_t)par[2][(size_t)e - 1] + 1};
             }
             if (!replicated) {
-                // stay distributed only while every slab boundary is even, every rank keeps >= 2 coarse
-                // planes and the level is big enough to amortise the halo latency
-                bool ok = (nc[2] != nn[2]);
-                for (int r = 0; r < P && ok; ++r) {
-                    const int64_t b = of[(size_t)r].first, e = of[(size_t)r].second;
-                    if ((b & 1) || ((e & 1) && e != nn[2]) || (e - b) < 4) ok = false;
-                    // a distributed level must itself have even boundaries, or nothing could be restricted
-                    // (or gathered) from it with a one-plane halo
-                    const int64_t cb = oc[(size_t)r].first, ce = oc[(size_t)r].second;
-                    if ((cb & 1) || ((ce & 1) && ce != nc[2])) ok = false;
-                }
+                // stay distributed only while every rank keeps >= 2 coarse planes and the level is big enough
+                // to amortise the halo latency
+                bool ok = true;
+                for (int r = 0; r < P && ok; ++r)
+                    if (oc[(size_t)r].second - oc[(size_t)r].first < 2) ok = false;
                 if (nc[0] * nc[1] * nc[2] <= (int64_t)s->cfg.agglomerate_below) ok = false;
                 if (ok) {
                     k0 = oc[(size_t)rank].first;
                     k1 = oc[(size_t)rank].second;
                 } else {
-                    // the restriction into the first replicated level needs fine planes 2K-1 .. 2K+2 of the owned
-                    // coarse planes: legal with one halo plane only if the fine boundaries are even
-                    for (int r = 0; r < P; ++r) {
-                        const int64_t b = of[(size_t)r].first, e = of[(size_t)r].second;
-                        if (nc[2] != nn[2] && ((b & 1) || ((e & 1) && e != nn[2]))) {
-                            char msg[256];
-                            std::snprintf(msg, sizeof msg,
-                                          "multigrid on %d ranks needs even z-slab boundaries on the finest level "
-                                          "(rank %d owns planes [%lld,%lld))", P, r, (long long)b, (long long)e);
-                            s->gmg_error = msg;  // the structure stays usable for the stencil twin / chunk order
-                        }
-                    }
-                    if (!s->gmg_error.empty()) break;
                     replicated = true;
                 }
             }
             s->gmg_own.push_back(oc);
         }
         for (int d = 0; d < 3; ++d) {
-            if (nc[d] != nn[d]) {
-                std::vector<double> cw((size_t)nc[d]);
-                for (int64_t I = 0; I < nc[d]; ++I)
-                    cw[(size_t)I] = (2 * I + 1 < nn[d]) ? hw[d][(size_t)(2 * I)] + hw[d][(size_t)(2 * I + 1)] : hw[d][(size_t)(2 * I)];
-                hw[d].swap(cw);
-            }
+            hw[d].swap(cw[d]);
             nn[d] = nc[d];
         }
     }
-    // distributed slabs of level l>0 must tile the same way on every rank: slab_range of the FINE level halved.
-    // (ranks compute the same k0/k1 sequence from slab_range, so neighbours agree.)
+    // every rank derives the same aggregates and ownership from the same width arrays, so neighbours agree.
     s->has_grid = true;
 
     // verify the hint against the CSR: stencil twin vs CSR SpMV on a fixed vector
@@ -1001,13 +1080,10 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             own.k1 = s->gmg_own[(size_t)l + 1][(size_t)s->comm.rank].second;
             own.nloc = (own.k1 - own.k0) * cg.plane;
             double *scratch = cg.r + cg.plane;
-            hipLaunchKernelGGL(k_restrict, level_grid(own), dim3(256), 0, q, S, dev_of(g), dev_of(own), rr, scratch);
-            PIB_HIP(hipGetLastError());
+            PIB_CHK(launch_restrict(g, own, rr, scratch, S, q));
             PIB_CHK(gather_level(s, l + 1, cg.plane, scratch, own.nloc, cg.b + cg.plane, q));
         } else {
-            hipLaunchKernelGGL(k_restrict, level_grid(cg), dim3(256), 0, q, S, dev_of(g), dev_of(cg), rr,
-                               cg.b + cg.plane);
-            PIB_HIP(hipGetLastError());
+            PIB_CHK(launch_restrict(g, cg, rr, cg.b + cg.plane, S, q));
         }
         cur[(size_t)l] = a;
         // remember the spare buffer in g.scratch for the upward leg
@@ -1023,14 +1099,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         double *a = cur[(size_t)l], *c = s->gmg_spare[(size_t)l];
         double *xc = cur[(size_t)l + 1];
         PIB_CHK(halo_level(s, cg, xc, q));
-        if (cg.n[0] != g.n[0] && g.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(a) & 15u) == 0) {
-            const dim3 gr((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (g.n[0] / 2 * g.n[1] + 255) / 256)),
-                          (unsigned)std::max<int64_t>(1, g.k1 - g.k0));
-            hipLaunchKernelGGL(k_prolong_add2, gr, dim3(256), 0, q, S, dev_of(g), dev_of(cg), xc, a);
-        } else {
-            hipLaunchKernelGGL(k_prolong_add, level_grid(g), dim3(256), 0, q, S, dev_of(g), dev_of(cg), xc, a);
-        }
-        PIB_HIP(hipGetLastError());
+        PIB_CHK(launch_prolong(g, cg, xc, a, S, q));
         PIB_CHK(smooth_seq(g, b, pin_l, a, c, post, false));
         cur[(size_t)l] = a;
         if (l == 0 && a != z) return fail(PIB_ERR_LIB, "gmg: internal buffer parity error");

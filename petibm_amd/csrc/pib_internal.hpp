@@ -134,6 +134,14 @@ struct GridLevel {
     double *dinv = nullptr;                      // 1/diag per local cell (with pinned handling)
     double *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;  // level vectors (one halo plane each side)
     double *d = nullptr;  // Chebyshev direction vector
+    // transfer tables towards the next coarser level, per direction (null on the coarsest level): parent /
+    // other coarse index and their weights per fine cell [n[d]], first child per coarse cell [nc[d]+1]
+    int32_t *t_par[3] = {nullptr, nullptr, nullptr}, *t_oth[3] = {nullptr, nullptr, nullptr},
+            *t_fst[3] = {nullptr, nullptr, nullptr};
+    double *t_wpar[3] = {nullptr, nullptr, nullptr}, *t_woth[3] = {nullptr, nullptr, nullptr};
+    // x direction packed per coarse cell (gmg.hip: TrX)
+    int2 *tx_fc = nullptr;
+    double4 *tx_pw = nullptr, *tx_rw = nullptr;
     bool replicated = false;  // multi-GPU: every rank holds the whole level
     int64_t nloc = 0, plane = 0;
 };

@@ -107,9 +107,63 @@ def test_multirank_poisson_solve_matches_single_rank(P, n, pc, extra):
     assert abs(res[0][2] - s1.getIters()) <= max(1, int(0.03 * s1.getIters()))
     h1 = s1.getResidualHistory()
     ke = min(len(h1), len(res[0][3]), 6)
-    assert np.allclose(res[0][3][:ke], h1[:ke], rtol=1e-9)
+    # same hierarchy when the slab boundaries coincide with the single-rank aggregates; where they do not (the
+    # 2-D case: 24 -> 12 -> 6 -> 3 rows per rank) a distributed level pairs differently and the histories only agree
+    # to the accuracy of the preconditioner
+    assert np.allclose(res[0][3][:ke], h1[:ke], rtol=1e-9 if len(n) == 3 else 1e-4)
     e = (x - x.mean()) - (x1 - x1.mean())
     assert np.linalg.norm(e) <= 1e-8 * np.linalg.norm(x1)
+    s1.destroy()
+
+
+@pytest.mark.parametrize("P,n,extra", [
+    (3, (20, 18, 23), "pib_agglomerate_below=10\n"),   # odd slabs: aggregates stop at the slab boundaries
+    (2, (24, 20, 17), ""),
+    (3, (36, 50), "pib_agglomerate_below=10\n"),
+])
+def test_multirank_gmg_on_stretched_mesh_with_ragged_slabs(P, n, extra):
+    """Slab boundaries that no pairing would respect (odd plane counts, stretched widths): the z aggregates of
+    a distributed level stop at the slab boundaries, so the hierarchy differs slightly from the single-rank one
+    but stays a symmetric V-cycle of the same quality: same residual contract, iteration count within 3."""
+    from petibm_amd import capi, partition
+    from petibm_amd.linsolver import LinSolverHIP
+    dt = 0.01
+    dim = len(n)
+    r = (1.1, 0.9, 1.07)
+    cfg = omesh.uniform_config(n)
+    cfg["mesh"] = [{"direction": "xyz"[d], "start": -1.0,
+                    "subDomains": [{"end": 0.0, "cells": n[d] // 2, "stretchRatio": 1.0 / r[d]},
+                                   {"end": 2.0 + d, "cells": n[d] - n[d] // 2, "stretchRatio": r[d]}]}
+                   for d in range(dim)]
+    m = omesh.create_mesh(cfg)
+    w = [m.dL[3][d].true for d in range(dim)]
+    A = oops.CSR.from_csr32(*clib.assemble_poisson32(list(n), w, dt))
+    xs = np.random.default_rng(8).uniform(-1, 1, A.n_rows)
+    xs -= xs.mean()
+    b = clib.spmv(A, xs)
+    plans = partition.all_plans(n, P)
+
+    def rank_fn(rk, uid):
+        pl = plans[rk]
+        s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=extra), rank=rk, nranks=P, uid=uid, device=0)
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(pl.n_local)
+        s.solve(x, np.ascontiguousarray(b[pl.row0:pl.row0 + pl.n_local]))
+        its, reason = s.getIters(), s.getReason()
+        s.destroy()
+        return x, its, reason
+
+    res = _run_ranks(P, rank_fn)
+    x = np.concatenate([q[0] for q in res])
+    assert all(q[2] > 0 for q in res) and len({q[1] for q in res}) == 1
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    s1 = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=extra))
+    s1.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+    x1 = np.zeros(A.n_rows)
+    s1.solve(x1, b)
+    assert abs(res[0][1] - s1.getIters()) <= 3 and s1.getIters() <= 24
+    e = (x - x.mean()) - (x1 - x1.mean())
+    assert np.linalg.norm(e) <= 1e-7 * np.linalg.norm(x1)
     s1.destroy()
 
 
