@@ -13,7 +13,8 @@ src/operators/createlaplacian.cpp:45-78 / createdivergence.cpp:45-78 (BC correct
 src/boundary/singleboundary{dirichlet,neumann}.cpp (ghost = a0*target + a1),
 include/petibm/timeintegration.h:107-166 (AB2 {1.5,-0.5}; CN implicit 0.5, explicit {0.5}).
 
-Restricted to time-independent ghost equations (Dirichlet, Neumann): a0/a1 constant.
+Ghost points carry per-point state (a0, a1, value) as in the reference: Dirichlet / Neumann equations are
+constant, the convective outlet (singleboundaryconvective.cpp) updates a1 every step.
 Every vector operation is done in the reference's order (VecScale / VecAXPY sequence) so that the device
 engine can be compared bit-for-bit on the explicit parts.
 """
@@ -25,23 +26,75 @@ from . import clib, operators as oops
 from .mesh import CartesianMesh
 
 
-def bc_a1(mesh: CartesianMesh, f: int, loc: int) -> float:
-    """a1 of ghost = a0*target + a1 (constant BCs).
-    Dirichlet: value if the boundary normal is the field's direction else 2*value
-    (singleboundarydirichlet.cpp:35-44); Neumann: normal*dL*value (singleboundaryneumann.cpp:27-28) with
-    dL = distance ghost-target (misc.cpp:187-190)."""
-    t = mesh.bc_types.get((f, loc), "NOBC")
-    v = mesh.bc_values.get((f, loc), 0.0)
-    axis = loc // 2
-    if t == "DIRICHLET":
-        return v if axis == f else 2.0 * v
-    if t == "NEUMANN":
-        n = int(mesh.n[f][axis])
-        c = mesh.coord[f][axis]
-        d = (c[n] - c[n - 1]) if loc % 2 == 1 else (c[0] - c[-1])
-        normal = 1.0 if loc % 2 == 1 else -1.0
-        return normal * d * v
-    raise ValueError(f"time-dependent or periodic BC {t} not restated here")
+def _face_slices(shape, loc):
+    """numpy index tuples (ghost layer, target layer) of boundary `loc` on a (k, j, i) array; the target layer of an
+    un-padded field array is `_target_slice`."""
+    ax = 2 - loc // 2
+    sl = [slice(None)] * 3
+    sl[ax] = 0 if loc % 2 == 0 else shape[ax] - 1
+    return tuple(sl)
+
+
+class GhostPoints:
+    """The ghost points of one (field, boundary): the reference's GhostPointInfo list (include/petibm/type.h,
+    misc.cpp:150-196) as arrays over the face, indexed (b, a) with the perpendicular axes in natural order.
+    ghost = a0 * target + a1; `value` is the ghost value seen by the convective operator
+    (singleboundarybase.cpp:146-182)."""
+
+    def __init__(self, mesh: CartesianMesh, f: int, loc: int):
+        self.f, self.loc = f, loc
+        self.type = mesh.bc_types.get((f, loc), "NOBC")
+        self.bc_value = mesh.bc_values.get((f, loc), 0.0)
+        self.axis = loc // 2
+        self.normal = 1.0 if loc % 2 == 1 else -1.0
+        n = int(mesh.n[f][self.axis])
+        c = mesh.coord[f][self.axis]
+        self.dL = (c[n] - c[n - 1]) if loc % 2 == 1 else (c[0] - c[-1])  # misc.cpp:187-190
+        self.same = self.axis == f
+        self.a0 = oops.bc_a0(self.type, f, loc)
+        n0, n1, n2 = (int(v) for v in mesh.n[f])
+        shape = [n2, n1, n0]
+        del shape[2 - self.axis]
+        self.a1 = np.zeros(shape)
+        self.value = np.zeros(shape)
+
+    def target(self, field_array: np.ndarray) -> np.ndarray:
+        return field_array[_face_slices(field_array.shape, self.loc)]
+
+    def _convective(self, target, dt):
+        # singleboundaryconvective.cpp:12-38
+        if self.same:
+            return self.value - self.normal * dt * self.bc_value * (self.value - target) / self.dL
+        return self.value + target - 2.0 * self.normal * dt * self.bc_value * (self.value - target) / self.dL
+
+    def set_ics(self, field_array):
+        """setGhostICsKernel: singleboundarydirichlet.cpp:22-46, singleboundaryneumann.cpp:22-33,
+        singleboundaryconvective.cpp:69-85"""
+        t = self.target(field_array)
+        if self.type == "DIRICHLET":
+            self.a1[...] = self.bc_value if self.same else 2.0 * self.bc_value
+            self.value = self.a0 * t + self.a1
+        elif self.type == "NEUMANN":
+            self.a1[...] = self.normal * self.dL * self.bc_value
+            self.value = self.a0 * t + self.a1
+        elif self.type == "CONVECTIVE":
+            self.value = t.copy()
+            self.a1 = self._convective(t, 0.0)
+        else:
+            raise ValueError(f"BC type {self.type} not restated here")
+
+    def update_eqs(self, field_array, dt):
+        """updateEqsKernel: a no-op for the time-independent types, the convective equation otherwise"""
+        if self.type == "CONVECTIVE":
+            self.a1 = self._convective(self.target(field_array), dt)
+
+    def update_values(self, field_array):
+        """singleboundarybase.cpp:146-164"""
+        self.value = self.a0 * self.target(field_array) + self.a1
+
+
+def make_ghosts(mesh: CartesianMesh):
+    return {(f, loc): GhostPoints(mesh, f, loc) for f in range(mesh.dim) for loc in range(2 * mesh.dim)}
 
 
 def _field_arrays(mesh: CartesianMesh, U: np.ndarray):
@@ -54,33 +107,44 @@ def _field_arrays(mesh: CartesianMesh, U: np.ndarray):
     return out
 
 
-def ghost_padded(mesh: CartesianMesh, U: np.ndarray):
+def set_ghost_ics(mesh, ghosts, U):
+    fa = _field_arrays(mesh, U)
+    for (f, loc), g in ghosts.items():
+        g.set_ics(fa[f])
+
+
+def update_eqs(mesh, ghosts, U, dt):
+    fa = _field_arrays(mesh, U)
+    for (f, loc), g in ghosts.items():
+        g.update_eqs(fa[f], dt)
+
+
+def update_ghost_values(mesh, ghosts, U):
+    fa = _field_arrays(mesh, U)
+    for (f, loc), g in ghosts.items():
+        g.update_values(fa[f])
+
+
+def ghost_padded(mesh: CartesianMesh, U: np.ndarray, ghosts):
     """Local arrays with one ghost layer per direction (what DMCompositeScatter + copyValues2LocalVecs give
-    createconvection.cpp:213-220); ghost = a0*target + a1."""
+    createconvection.cpp:213-220): the stored ghost values."""
     res = []
     for f, a in enumerate(_field_arrays(mesh, U)):
         n2, n1, n0 = a.shape
         g = np.zeros((n2 + 2, n1 + 2, n0 + 2))
         g[1:-1, 1:-1, 1:-1] = a
         for loc in range(2 * mesh.dim):
-            a0 = oops.bc_a0(mesh.bc_types[(f, loc)], f, loc)
-            a1 = bc_a1(mesh, f, loc)
-            axis = loc // 2
-            ax = 2 - axis  # numpy axis of (k, j, i)
+            ax = 2 - loc // 2  # numpy axis of (k, j, i)
             sl_g = [slice(1, -1)] * 3
-            sl_t = [slice(1, -1)] * 3
-            if loc % 2 == 0:
-                sl_g[ax], sl_t[ax] = 0, 1
-            else:
-                sl_g[ax], sl_t[ax] = g.shape[ax] - 1, g.shape[ax] - 2
-            g[tuple(sl_g)] = a0 * g[tuple(sl_t)] + a1
+            sl_g[ax] = 0 if loc % 2 == 0 else g.shape[ax] - 1
+            g[tuple(sl_g)] = ghosts[(f, loc)].value
         res.append(g)
     return res
 
 
-def convection(mesh: CartesianMesh, U: np.ndarray) -> np.ndarray:
+def convection(mesh: CartesianMesh, U: np.ndarray, ghosts) -> np.ndarray:
     """N(u): createconvection.cpp:40-195 kernels, vectorised; same expression order."""
-    q = ghost_padded(mesh, U)
+    q = ghost_padded(mesh, U, ghosts)
     dim = mesh.dim
     out = []
 
@@ -133,7 +197,14 @@ def convection(mesh: CartesianMesh, U: np.ndarray) -> np.ndarray:
     return np.concatenate(out)
 
 
-def laplacian_correction(mesh: CartesianMesh) -> np.ndarray:
+def _face_take(g: GhostPoints, ijk, on):
+    """a1 of the ghost point facing each selected boundary-adjacent point (flattened (k, j, i) order)"""
+    idx = [ijk[2][on], ijk[1][on], ijk[0][on]]
+    del idx[2 - g.axis]
+    return g.a1[tuple(idx)]
+
+
+def laplacian_correction(mesh: CartesianMesh, ghosts) -> np.ndarray:
     """LCorrectionMult (createlaplacian.cpp:45-78): y[row] += coeff*a1 for every ghost, in (field, loc) order."""
     y = np.zeros(mesh.UN)
     off = 0
@@ -152,12 +223,12 @@ def laplacian_correction(mesh: CartesianMesh) -> np.ndarray:
             else:
                 dist = mesh.coord[f][d][s[on] + 1] - mesh.coord[f][d][s[on]]
             coeff = 1.0 / (dist * dLSelf)
-            y[rows[on]] = y[rows[on]] + coeff * bc_a1(mesh, f, loc)
+            y[rows[on]] = y[rows[on]] + coeff * _face_take(ghosts[(f, loc)], ijk, on)
         off += n0 * n1 * n2
     return y
 
 
-def divergence_correction(mesh: CartesianMesh, normalize: bool = False) -> np.ndarray:
+def divergence_correction(mesh: CartesianMesh, ghosts, normalize: bool = False) -> np.ndarray:
     """DCorrectionMult (createdivergence.cpp:45-78): y[cell] += (+-area)*a1 for the normal-velocity ghost faces."""
     y = np.zeros(mesh.pN)
     n0, n1, n2 = (int(v) for v in mesh.n[3])
@@ -174,7 +245,7 @@ def divergence_correction(mesh: CartesianMesh, normalize: bool = False) -> np.nd
         for loc in (2 * f, 2 * f + 1):
             on = (ijk[f] == 0) if loc % 2 == 0 else (ijk[f] == mesh.n[3][f] - 1)
             coeff = (-area[on]) if loc % 2 == 0 else area[on]
-            y[on] = y[on] + coeff * bc_a1(mesh, f, loc)
+            y[on] = y[on] + coeff * _face_take(ghosts[(f, loc)], ijk, on)
     return y
 
 
@@ -192,15 +263,22 @@ class NavierStokes:
         self.A = oops.create_velocity_operator(self.L, dt, self.cimpl * nu)
         self.BNG, DBNG = oops.create_poisson_operator(self.D, self.G, self.L, dt, self.cimpl * nu)
         self.DBNG = oops.pin_row0(DBNG) if pinned else DBNG
-        self.lc = laplacian_correction(mesh)
-        self.dbc = divergence_correction(mesh)
+        self.ghosts = make_ghosts(mesh)
         self.U = np.zeros(mesh.UN)
         self.p = np.zeros(mesh.pN)
+        set_ghost_ics(mesh, self.ghosts, self.U)
         self.conv = [np.zeros(mesh.UN), np.zeros(mesh.UN)]
         self.vtol, self.ptol = vtol, ptol
         self.info = {}
         w = [mesh.dL[3][d].true for d in range(mesh.dim)]
         self.gmg = clib.GMG([int(v) for v in mesh.n[3][:mesh.dim]], w, dt, nullspace=2 if pinned else 1)
+
+    def set_state(self, U, p=None):
+        """initial data + bc->setGhostICs(solution) (navierstokes.cpp:139-142)"""
+        self.U = np.array(U, dtype=np.float64)
+        if p is not None:
+            self.p = np.array(p, dtype=np.float64)
+        set_ghost_ics(self.mesh, self.ghosts, self.U)
 
     def rhs_velocity(self):
         dt, nu = self.dt, self.nu
@@ -208,20 +286,21 @@ class NavierStokes:
         rhs1 = -1.0 * rhs1
         rhs1 = rhs1 + (1.0 / dt) * self.U
         self.conv[1], self.conv[0] = self.conv[0], self.conv[1]  # VecSwap chain for 2 terms
-        self.conv[0] = -1.0 * convection(self.mesh, self.U)
+        self.conv[0] = -1.0 * convection(self.mesh, self.U, self.ghosts)
         for c, v in zip(self.conv_c, self.conv):
             rhs1 = rhs1 + c * v
         diff0 = clib.spmv(self.L, self.U)
-        diff0 = diff0 + self.lc
+        diff0 = diff0 + laplacian_correction(self.mesh, self.ghosts)  # ghost equations of the previous step
         diff0 = nu * diff0
         rhs1 = rhs1 + self.diff_c[0] * diff0
-        bc1 = nu * self.lc
+        update_eqs(self.mesh, self.ghosts, self.U, dt)  # navierstokes.cpp:508
+        bc1 = nu * laplacian_correction(self.mesh, self.ghosts)
         rhs1 = rhs1 + self.cimpl * bc1
         return rhs1
 
     def rhs_poisson(self):
         rhs2 = clib.spmv(self.D, self.U)
-        rhs2 = rhs2 + self.dbc
+        rhs2 = rhs2 + divergence_correction(self.mesh, self.ghosts)
         if self.pinned:
             rhs2[0] = 0.0
         return rhs2
@@ -247,3 +326,4 @@ class NavierStokes:
         rhs1 = clib.spmv(self.BNG, dP)
         self.U = self.U + (-1.0) * rhs1
         self.p = self.p + 1.0 * dP
+        update_ghost_values(self.mesh, self.ghosts, self.U)  # navierstokes.cpp:263

@@ -11,10 +11,12 @@
 // G, D, L, BNG are applied matrix-free from the 1-D mesh arrays, entry for entry and in the same summation
 // order as the assembled AIJ matrices of the reference (creategradient.cpp:64-128, createdivergence.cpp:135-223,
 // createlaplacian.cpp:108-263); N(u) is src/operators/createconvection.cpp:40-195 with ghost values computed on
-// the fly (ghost = a0*target + a1: singleboundarydirichlet.cpp:35-44, singleboundaryneumann.cpp:27-28); the BC
-// correction shells (createlaplacian.cpp:45-78, createdivergence.cpp:45-78) are the constant vectors
-// sum coeff*a1.  AB2 convection {1.5,-0.5} + Crank-Nicolson diffusion (timeintegration.h:107-166), BN order 1.
-// Time-independent ghost equations only (Dirichlet, Neumann); single GPU.
+// the stored ghost values; the BC correction shells (createlaplacian.cpp:45-78, createdivergence.cpp:45-78) are
+// sum coeff*a1 over the ghost points of a row.  Ghost points carry the reference's per-point state (a0, a1, value:
+// type.h GhostPointInfo) in face arrays: Dirichlet / Neumann equations are constant
+// (singleboundarydirichlet.cpp:22-46, singleboundaryneumann.cpp:22-33), the convective outlet re-derives a1
+// every step (singleboundaryconvective.cpp:12-38).
+// AB2 convection {1.5,-0.5} + Crank-Nicolson diffusion (timeintegration.h:107-166), BN order 1.  Single GPU.
 // The oracle (oracle/navierstokes.py) performs the same VecScale/VecAXPY sequence; the explicit parts agree
 // bit for bit, the solves to solver tolerance.
 #include <cstring>
@@ -28,7 +30,14 @@ struct NsField {
     int64_t off;            // first entry of the field's block in the packed vector
     const double *dl[3];    // dL[f][d], index s+1
     const double *co[3];    // coord[f][d], index s+1
-    double a0[6], a1[6];    // ghost = a0*target + a1 per boundary location
+    // ghost points per boundary location: ghost = a0*target + a1 (a0 is uniform over a face); face arrays are
+    // indexed a + na*b over the two perpendicular axes in natural order (misc.cpp:154-196)
+    double a0[6];
+    int type[6];            // 0 DIRICHLET, 1 NEUMANN, 2 CONVECTIVE
+    double bcv[6];          // the BC value (Dirichlet value, Neumann gradient, convective speed)
+    double gdl[6];          // distance ghost - target
+    int64_t goff[6];        // offset of the face in the ghost arrays
+    int64_t gcnt[6];        // points of the face
 };
 struct NsDev {
     int dim;
@@ -36,14 +45,25 @@ struct NsDev {
     int64_t pn[3];          // pressure cells
     const double *pw[3];    // pressure-cell widths
     int64_t UN, pN;
+    int64_t nghost;
+    double *a1, *a1n, *gv;  // [nghost] current / next ghost equations' a1, ghost values
 };
+
+// index of the ghost point of boundary `loc` facing (i,j,k) within its face
+__device__ __forceinline__ int64_t face_index(const NsField &F, int loc, int64_t i, int64_t j, int64_t k)
+{
+    const int axis = loc >> 1;
+    if (axis == 0) return F.goff[loc] + j + F.n[1] * k;
+    if (axis == 1) return F.goff[loc] + i + F.n[0] * k;
+    return F.goff[loc] + i + F.n[0] * j;
+}
 
 __device__ __forceinline__ int64_t fidx(const NsField &F, int64_t i, int64_t j, int64_t k)
 {
     return F.off + i + F.n[0] * (j + F.n[1] * k);
 }
 
-// velocity value at (i,j,k) of field f; an index one step outside is the ghost point a0*target + a1
+// velocity value at (i,j,k) of field f; an index one step outside is the stored ghost value
 __device__ __forceinline__ double vel(const NsDev &D, const double *__restrict__ U, int f, int64_t i, int64_t j, int64_t k)
 {
     const NsField &F = D.f[f];
@@ -53,8 +73,7 @@ __device__ __forceinline__ double vel(const NsDev &D, const double *__restrict__
     if (D.dim == 3) {
         if (k < 0) { loc = 4; k = 0; } else if (k >= F.n[2]) { loc = 5; k = F.n[2] - 1; }
     }
-    const double t = U[fidx(F, i, j, k)];
-    return loc < 0 ? t : F.a0[loc] * t + F.a1[loc];
+    return loc < 0 ? U[fidx(F, i, j, k)] : D.gv[face_index(F, loc, i, j, k)];
 }
 
 // -N(u) of createconvection.cpp at one velocity point (the caller scales by -1)
@@ -101,9 +120,10 @@ __device__ __forceinline__ double convection_at(const NsDev &D, const double *__
     return r;
 }
 
-// (L u)_row in the CSR order of createLaplacian (z-, y-, x-, diag, x+, y+, z+) and the BC correction lc = sum coeff*a1
+// (L u)_row in the CSR order of createLaplacian (z-, y-, x-, diag, x+, y+, z+) and the BC correction
+// sum coeff*a1 with the current (lc) and the updated (lcn) ghost equations
 __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__restrict__ U, int f, int64_t i, int64_t j,
-                                             int64_t k, double *lu, double *lc)
+                                             int64_t k, double *lu, double *lc, double *lcn)
 {
     const NsField &F = D.f[f];
     const int64_t ijk[3] = {i, j, k};
@@ -122,12 +142,14 @@ __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__res
         acc = acc + v[2 * d];
         acc = acc + v[2 * d + 1];
     }
-    double diag = -acc, corr = 0.0;
+    double diag = -acc, corr = 0.0, corrn = 0.0;
     for (int q = 0; q < 2 * D.dim; ++q)
         if (!interior[q]) {
             const double t = v[q] * F.a0[q];
             if (t != 0.0) diag = diag + t;
-            corr = corr + v[q] * F.a1[q];
+            const int64_t g = face_index(F, q, i, j, k);
+            corr = corr + v[q] * D.a1[g];
+            corrn = corrn + v[q] * D.a1n[g];
         }
     const int64_t st[3] = {1, F.n[0], F.n[0] * F.n[1]};
     const int64_t p = fidx(F, i, j, k);
@@ -139,6 +161,7 @@ __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__res
         if (interior[2 * d + 1]) s = s + v[2 * d + 1] * U[p + st[d]];
     *lu = s;
     *lc = corr;
+    *lcn = corrn;
 }
 
 // rhs1 and the new convective term (navierstokes.cpp:432-521), one velocity point per lane
@@ -167,12 +190,14 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         conv0[g] = cn;
         r = r + c0 * cn;
         r = r + c1 * conv1[g];
-        double lu, lc;
-        laplacian_at(D, U, f, i, j, k, &lu, &lc);
+        // explicit diffusion with the ghost equations of the previous step, implicit correction with the updated
+        // ones (bc->updateEqs sits between the two, navierstokes.cpp:492-514)
+        double lu, lc, lcn;
+        laplacian_at(D, U, f, i, j, k, &lu, &lc, &lcn);
         double df = lu + lc;
         df = nu * df;
         r = r + d0 * df;
-        const double b1 = nu * lc;
+        const double b1 = nu * lcn;
         r = r + cimpl * b1;
         rhs1[g] = r;
     }
@@ -201,7 +226,7 @@ __global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int pinned, con
             if (!has_m) {  // ghost - face folds onto the + face (its target): D[row,target] += coeff*a0
                 const double t = (-area[f]) * F.a0[2 * f];
                 if (t != 0.0) vp = vp + t;
-                corr = corr + (-area[f]) * F.a1[2 * f];
+                corr = corr + (-area[f]) * D.a1[face_index(F, 2 * f, fi[0], fi[1], fi[2])];
             }
             if (!has_p) {
                 const double t = area[f] * F.a0[2 * f + 1];
@@ -209,11 +234,72 @@ __global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int pinned, con
             }
             if (has_m) s = s + vm * U[has_p ? base - st : base];
             if (has_p) s = s + vp * U[base];
-            if (!has_p) corr = corr + area[f] * F.a1[2 * f + 1];
+            if (!has_p) corr = corr + area[f] * D.a1[face_index(F, 2 * f + 1, fi[0], fi[1], fi[2])];
         }
         double r = s + corr;
         if (pinned && c == 0) r = 0.0;
         rhs2[c] = r;
+    }
+}
+
+// Ghost-point state, one ghost point per lane.  MODE 0: setGhostICs (navierstokes.cpp:142), 1: updateEqs into
+// a1n (navierstokes.cpp:508), 2: updateGhostValues (navierstokes.cpp:263).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ns_ghosts(NsDev D, double dt, const double *__restrict__ U)
+{
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < D.nghost; g += (int64_t)gridDim.x * 256) {
+        int f = 0, loc = 0;
+        for (int ff = 0; ff < D.dim; ++ff)
+            for (int q = 0; q < 2 * D.dim; ++q)
+                if (g >= D.f[ff].goff[q] && g < D.f[ff].goff[q] + D.f[ff].gcnt[q]) {
+                    f = ff;
+                    loc = q;
+                }
+        const NsField &F = D.f[f];
+        const int axis = loc >> 1;
+        const int64_t r = g - F.goff[loc];
+        int64_t ijk[3];
+        const int64_t na = (axis == 0) ? F.n[1] : F.n[0];
+        const int64_t a = r % na, b = r / na;
+        if (axis == 0) { ijk[1] = a; ijk[2] = b; } else if (axis == 1) { ijk[0] = a; ijk[2] = b; } else { ijk[0] = a; ijk[1] = b; }
+        ijk[axis] = (loc & 1) ? F.n[axis] - 1 : 0;
+        const double target = U[fidx(F, ijk[0], ijk[1], ijk[2])];
+        const bool same = (axis == f);
+        const double normal = (loc & 1) ? 1.0 : -1.0;
+        const double value = F.bcv[loc];
+        if (MODE == 2) {
+            D.gv[g] = F.a0[loc] * target + D.a1[g];
+            continue;
+        }
+        if (F.type[loc] == 2) {  // singleboundaryconvective.cpp:12-38
+            double pv = D.gv[g];
+            double tdt = dt;
+            if (MODE == 0) {
+                pv = target;  // t = 0: the ghost takes the target's value, dt = 0 in the kernel (:69-85)
+                tdt = 0.0;
+                D.gv[g] = pv;
+            }
+            double a1;
+            if (same)
+                a1 = pv - normal * tdt * value * (pv - target) / F.gdl[loc];
+            else
+                a1 = pv + target - 2.0 * normal * tdt * value * (pv - target) / F.gdl[loc];
+            if (MODE == 0) D.a1[g] = a1;
+            D.a1n[g] = a1;
+        } else {
+            if (MODE == 0) {
+                double a1;
+                if (F.type[loc] == 0)
+                    a1 = same ? value : 2.0 * value;  // singleboundarydirichlet.cpp:35-44
+                else
+                    a1 = normal * F.gdl[loc] * value;  // singleboundaryneumann.cpp:27-28
+                D.a1[g] = a1;
+                D.a1n[g] = a1;
+                D.gv[g] = F.a0[loc] * target + a1;
+            } else {
+                D.a1n[g] = D.a1[g];
+            }
+        }
     }
 }
 
@@ -258,6 +344,8 @@ struct pib_ns {
     int64_t steps = 0;
 };
 
+static int ghost_blocks(const pib::NsDev &D) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (D.nghost + 255) / 256)); }
+
 extern "C" {
 
 int pib_ns_destroy(pib_ns *ns)
@@ -300,30 +388,33 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     PIB_HIP(hipSetDevice(ns->device));
     PIB_HIP(hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking));
     // ghost-equation tables: ghost = a0*target + a1
-    double a0[18], a1[18];
+    double a0[18], gdl[18];
+    int btype[18];
     for (int f = 0; f < 3; ++f)
         for (int loc = 0; loc < 6; ++loc) {
-            a0[6 * f + loc] = a1[6 * f + loc] = 0.0;
+            a0[6 * f + loc] = gdl[6 * f + loc] = 0.0;
+            btype[6 * f + loc] = 0;
             if (f >= dim || loc >= 2 * dim) continue;
             const int t = bc_type[6 * f + loc];
-            const double v = bc_value[6 * f + loc];
             const int axis = loc / 2;
-            if (t == 0) {  // DIRICHLET (singleboundarydirichlet.cpp:35-44)
+            btype[6 * f + loc] = t;
+            {   // distance ghost - target (misc.cpp:187-190)
+                const std::vector<double> &c = hco[f][axis];
+                const int64_t nf = fn[f][axis];
+                gdl[6 * f + loc] = (loc % 2 == 1) ? c[(size_t)nf + 1] - c[(size_t)nf] : c[1] - c[0];
+            }
+            if (t == 0 || t == 2) {  // DIRICHLET (singleboundarydirichlet.cpp:35-44), CONVECTIVE (singleboundaryconvective.cpp:20-36)
                 a0[6 * f + loc] = (axis == f) ? 0.0 : -1.0;
-                a1[6 * f + loc] = (axis == f) ? v : 2.0 * v;
             } else if (t == 1 && axis == f) {
                 // a Neumann condition on the NORMAL component folds a0 = 1 into D (createdivergence.cpp:231-242) and
                 // hence into DBNG; pib_assemble_poisson builds the a0 = 0 operator only
                 return bail(fail(PIB_ERR_SUP, "pib_ns_create: NEUMANN on the normal velocity component (field %d, boundary %d) "
                                               "is not supported by the on-device Poisson assembly", f, loc));
-            } else if (t == 1) {  // NEUMANN (singleboundaryneumann.cpp:27-28; dL = ghost-target distance, misc.cpp:187-190)
-                const std::vector<double> &c = hco[f][axis];
-                const int64_t nf = fn[f][axis];
-                const double d = (loc % 2 == 1) ? c[(size_t)nf + 1] - c[(size_t)nf] : c[1] - c[0];
+            } else if (t == 1) {  // NEUMANN (singleboundaryneumann.cpp:27-28)
                 a0[6 * f + loc] = 1.0;
-                a1[6 * f + loc] = ((loc % 2 == 1) ? 1.0 : -1.0) * d * v;
             } else {
-                return bail(fail(PIB_ERR_SUP, "pib_ns_create: boundary type %d is not supported (0 DIRICHLET, 1 NEUMANN)", t));
+                return bail(fail(PIB_ERR_SUP, "pib_ns_create: boundary type %d is not supported (0 DIRICHLET, 1 NEUMANN, "
+                                              "2 CONVECTIVE)", t));
             }
         }
     // matrices: A = I/dt - c nu L (CN: c = 1/2), DBNG; null-space convention from the Poisson solver's flavour
@@ -356,10 +447,21 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
         if (f < dim) off += fn[f][0] * fn[f][1] * fn[f][2];
         for (int q = 0; q < 6; ++q) {
             F.a0[q] = a0[6 * f + q];
-            F.a1[q] = a1[6 * f + q];
+            F.type[q] = btype[6 * f + q];
+            F.bcv[q] = bc_value[6 * f + q];
+            F.gdl[q] = gdl[6 * f + q];
+            F.goff[q] = F.gcnt[q] = 0;
         }
     }
     D.UN = off;
+    D.nghost = 0;
+    for (int f = 0; f < dim; ++f)
+        for (int q = 0; q < 2 * dim; ++q) {
+            NsField &F = D.f[f];
+            F.goff[q] = D.nghost;
+            F.gcnt[q] = fn[f][0] * fn[f][1] * fn[f][2] / fn[f][q / 2];
+            D.nghost += F.gcnt[q];
+        }
     D.pN = 1;
     for (int d = 0; d < 3; ++d) {
         D.pn[d] = (d < dim) ? n[d] : 1;
@@ -381,8 +483,13 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     };
     if ((err = alloc(&ns->U, D.UN)) || (err = alloc(&ns->rhs1, D.UN)) || (err = alloc(&ns->conv[0], D.UN)) ||
         (err = alloc(&ns->conv[1], D.UN)) || (err = alloc(&ns->p, D.pN)) || (err = alloc(&ns->dP, D.pN)) ||
-        (err = alloc(&ns->rhs2, D.pN)))
+        (err = alloc(&ns->rhs2, D.pN)) || (err = alloc(&D.a1, D.nghost)) || (err = alloc(&D.a1n, D.nghost)) ||
+        (err = alloc(&D.gv, D.nghost)))
         return bail(err);
+    // bc->setGhostICs(solution) for the zero initial state (navierstokes.cpp:142)
+    hipLaunchKernelGGL(k_ns_ghosts<0>, dim3(ghost_blocks(D)), dim3(256), 0, ns->stream, D, 0.0, ns->U);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipStreamSynchronize(ns->stream));
     *out = ns;
     return 0;
 }
@@ -400,7 +507,13 @@ int pib_ns_set_state(pib_ns *ns, const double *U, const double *p)
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
-    if (U) PIB_HIP(hipMemcpy(ns->U, U, sizeof(double) * (size_t)ns->D.UN, hipMemcpyHostToDevice));
+    if (U) {
+        PIB_HIP(hipMemcpy(ns->U, U, sizeof(double) * (size_t)ns->D.UN, hipMemcpyHostToDevice));
+        // initial data are followed by bc->setGhostICs(solution) (navierstokes.cpp:139-142, restart :743)
+        hipLaunchKernelGGL(k_ns_ghosts<0>, dim3(ghost_blocks(ns->D)), dim3(256), 0, ns->stream, ns->D, 0.0, ns->U);
+        PIB_HIP(hipGetLastError());
+        PIB_HIP(hipStreamSynchronize(ns->stream));
+    }
     if (p) PIB_HIP(hipMemcpy(ns->p, p, sizeof(double) * (size_t)ns->D.pN, hipMemcpyHostToDevice));
     return 0;
 }
@@ -423,15 +536,19 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
-    const NsDev &D = ns->D;
+    NsDev &D = ns->D;
+    const int gg = ghost_blocks(D);
     const int gu = (int)std::min<int64_t>(4096, (D.UN + 255) / 256), gp = (int)std::min<int64_t>(4096, (D.pN + 255) / 256);
     const int gt = gu > gp ? gu : gp;
     for (int it = 0; it < nsteps; ++it) {
         // VecSwap chain of the convective terms (navierstokes.cpp:452-458)
         std::swap(ns->conv[0], ns->conv[1]);
+        // bc->updateEqs(solution, dt) (:508) into a1n; the right-hand side needs both generations
+        hipLaunchKernelGGL(k_ns_ghosts<1>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);
         hipLaunchKernelGGL(k_ns_rhs_velocity, dim3(gu), dim3(256), 0, ns->stream, D, ns->dt, ns->nu, 1.5, -0.5, 0.5, 0.5, ns->U,
                            ns->p, ns->conv[1], ns->conv[0], ns->rhs1);
         PIB_HIP(hipGetLastError());
+        std::swap(D.a1, D.a1n);
         PIB_HIP(hipStreamSynchronize(ns->stream));
         PIB_CHK(pib_solve(ns->vsol, ns->U, ns->rhs1));  // vSolver->solve(UGlobal, rhs1)  (:532)
         hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns->pinned, ns->U, ns->rhs2);
@@ -439,6 +556,7 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         PIB_HIP(hipStreamSynchronize(ns->stream));
         PIB_CHK(pib_solve(ns->psol, ns->dP, ns->rhs2));  // pSolver->solve(dP, rhs2)      (:575)
         hipLaunchKernelGGL(k_ns_project, dim3(gt), dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
+        hipLaunchKernelGGL(k_ns_ghosts<2>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);  // bc->updateGhostValues (:263)
         PIB_HIP(hipGetLastError());
         ns->steps++;
     }

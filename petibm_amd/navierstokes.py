@@ -14,7 +14,7 @@ from . import capi
 
 _DIR = {"x": 0, "y": 1, "z": 2}
 _LOC = {"xMinus": 0, "xPlus": 1, "yMinus": 2, "yPlus": 3, "zMinus": 4, "zPlus": 5}
-_BCT = {"DIRICHLET": 0, "NEUMANN": 1}
+_BCT = {"DIRICHLET": 0, "NEUMANN": 1, "CONVECTIVE": 2}
 
 DEFAULT_VELOCITY_CFG = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
                         "solv:convergence=ABSOLUTE\nsolv:tolerance=1e-12\nsolv:norm=L2\nsolv:store_res_history=1\n"
