@@ -42,9 +42,12 @@ extern "C" {
 #define PIB_ERR_ARG_WRONG 62       /* PETSC_ERR_ARG_WRONG: src/linsolver/linsolver.cpp:85-88 */
 #define PIB_ERR_ARG_OUTOFRANGE 63  /* PETSC_ERR_ARG_OUTOFRANGE */
 #define PIB_ERR_FILE_OPEN 65       /* PETSC_ERR_FILE_OPEN */
+#define PIB_ERR_MAT_LU_ZRPVT 71    /* PETSC_ERR_MAT_LU_ZRPVT: zero pivot in the direct solver */
 #define PIB_ERR_LIB 76             /* PETSC_ERR_LIB: a HIP / RCCL call failed */
 #define PIB_ERR_CONV_FAILED 82     /* PETSC_ERR_CONV_FAILED: linsolverksp.cpp:100 */
 #define PIB_ERR_ARG_NULL 85        /* PETSC_ERR_ARG_NULL */
+#define PIB_ERR_ARG_UNKNOWN_TYPE 86 /* PETSC_ERR_ARG_UNKNOWN_TYPE: src/misc/delta.cpp:58-60 */
+#define PIB_ERR_MAX_VALUE 99       /* PETSC_ERR_MAX_VALUE: body outside the domain, singlebodypoints.cpp:99-104 */
 
 /* ---- convergence reasons (PETSc KSPConvergedReason numbering) ---- */
 #define PIB_CONVERGED_RTOL 2
@@ -209,11 +212,12 @@ int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, 
  * (:566-580), applyDivergenceFreeVelocity (:583-598), updatePressure (:601-615).  G, D, L, BNG and the
  * convective term N(u) (src/operators/createconvection.cpp) are applied matrix-free in the summation order of
  * the reference's assembled matrices; AB2 convection + Crank-Nicolson diffusion, BN order 1.
- *   bc_type[6*f+loc]: 0 DIRICHLET, 1 NEUMANN; bc_value[6*f+loc] (flow.boundaryConditions of the YAML file);
+ *   bc_type[6*f+loc]: 0 DIRICHLET, 1 NEUMANN, 2 CONVECTIVE; bc_value[6*f+loc] (flow.boundaryConditions of the YAML
+ *   file; ghost points keep the reference's per-point state: src/boundary/singleboundary*.cpp);
  *   velocity_cfg / poisson_cfg: solver configuration TEXT (same syntaxes as pib_create).  The Poisson
  *   solver's flavour selects the null-space convention exactly like NavierStokesSolver::setNullSpace
  *   (:395-429): "NVIDIA AmgX" -> pinned row 0 and rhs2[0] = 0, "PETSc KSP" -> constant null space.
- * Single GPU, time-independent ghost equations (Dirichlet / Neumann). */
+ * Single GPU. */
 typedef struct pib_ns pib_ns;
 int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                   const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
@@ -225,6 +229,30 @@ int pib_ns_advance(pib_ns *ns, int nsteps);
 /* the columns of iterations-<start>.txt (navierstokes.cpp:766-794) for the last step */
 int pib_ns_get_solver_info(pib_ns *ns, int *v_iters, double *v_res, int *p_iters, double *p_res);
 int pib_ns_destroy(pib_ns *ns);
+
+/* ---- immersed bodies: DecoupledIBPMSolver (applications/decoupledibpm/decoupledibpm.cpp) ----------------------
+ * pib_ns_set_bodies turns the engine into the decoupled IBPM: it assembles on the device Delta
+ * (src/operators/createdelta.cpp:34-208, kernels src/misc/delta.cpp:17-43: "ROMA_ET_AL_1999" | "PESKIN_2002"),
+ * E = Delta R MHat, H = Delta^T, BNH = dt H and EBNH = E BNH (decoupledibpm.cpp:141-216), creates the forces solver
+ * from `forces_cfg` (the text of forces_solver.info; the examples use -forces_ksp_type preonly -forces_pc_type lu)
+ * and hands it EBNH; pib_ns_advance then runs DecoupledIBPMSolver::advance (:105-131).
+ *   npts[b]: Lagrangian points of body b; coords: all points, body after body, dim values per point (the body
+ *   files of the reference, src/io/io.cpp:23-118); force unknown of (point q, direction d) = q*dim + d over the
+ *   concatenated points (src/body/bodypack.cpp:261-283 on one rank).
+ * Errors: unknown kernel -> PIB_ERR_ARG_UNKNOWN_TYPE, a point outside the domain -> PIB_ERR_MAX_VALUE. */
+int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double *coords, const char *delta_kernel,
+                      const char *forces_cfg);
+int pib_ns_num_forces(pib_ns *ns, int64_t *nf, int *nbodies);
+/* Lagrangian forces f [nf] and/or the bodies' forces [nbodies*dim] = minus the sum over the body's points
+ * (src/body/singlebodypoints.cpp:228-259; one line of forces-<start>.txt, decoupledibpm.cpp:437-465) */
+int pib_ns_get_forces(pib_ns *ns, double *f, double *body_forces);
+int pib_ns_set_forces(pib_ns *ns, const double *f);   /* restart (decoupledibpm.cpp:372-375) */
+/* iterations / residual of the forces solver in the last step (third column pair of iterations-<start>.txt) */
+int pib_ns_get_forces_solver_info(pib_ns *ns, int *f_iters, double *f_res);
+/* Inspection of the operators (host arrays, 32-bit CSR).  which: 0 Delta, 1 E, 2 H (only the velocity points under
+ * the kernels' support are stored: row_ids[n_rows] names them), 3 EBNH.  Null arrays: sizes only. */
+int pib_ns_get_ib_operator(pib_ns *ns, int which, int64_t *n_rows, int64_t *nnz, int32_t *rowptr, int32_t *col,
+                           double *val, int32_t *row_ids);
 
 /* ---- instrumentation (bench.py roofline leg) --------------------------------
  * Time `reps` launches of kernel `which` on the solver's stream with HIP events

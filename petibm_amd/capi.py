@@ -30,6 +30,7 @@ class PibError(RuntimeError):
 # error / reason constants mirrored from the header
 ERR_SUP, ERR_ORDER, ERR_ARG_WRONG, ERR_ARG_OUTOFRANGE = 56, 58, 62, 63
 ERR_FILE_OPEN, ERR_LIB, ERR_CONV_FAILED, ERR_ARG_NULL = 65, 76, 82, 85
+ERR_FILE_READ, ERR_MAT_LU_ZRPVT, ERR_ARG_UNKNOWN_TYPE, ERR_MAX_VALUE = 66, 71, 86, 99
 NULLSPACE_NONE, NULLSPACE_CONSTANT, NULLSPACE_PINNED = 0, 1, 2
 UID_BYTES = 128
 
@@ -73,6 +74,12 @@ _PROTOS = {
     "pib_ns_get_solver_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                          C.POINTER(C.c_double)]),
     "pib_ns_destroy": (C.c_int, [_vp]),
+    "pib_ns_set_bodies": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_char_p, C.c_char_p]),
+    "pib_ns_num_forces": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int)]),
+    "pib_ns_get_forces": (C.c_int, [_vp, _vp, _vp]),
+    "pib_ns_set_forces": (C.c_int, [_vp, _vp]),
+    "pib_ns_get_forces_solver_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "pib_ns_get_ib_operator": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "pib_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pib_get_counters": (C.c_int, [_vp, _vp]),
 }

@@ -96,6 +96,31 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
     return 0;
 }
 
+int adopt_device_csr(pib_solver *s, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col, const double *val)
+{
+    PIB_HIP(hipSetDevice(s->device));
+    s->has_matrix = false;
+    s->has_grid = false;
+    gmg_release(s);
+    DeviceCsr &A = s->A;
+    A.release();
+    A.n = n;
+    A.nnz = nnz;
+    A.row0 = 0;
+    A.n_global = n;
+    A.ghost_lo = A.ghost_hi = 0;
+    A.rp64 = false;
+    PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMemset(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMemset(A.val, 0, sizeof(double) * (size_t)(nnz + 4)));
+    PIB_HIP(hipMalloc(&A.rowptr, sizeof(int32_t) * ((size_t)n + 1)));
+    PIB_HIP(hipMemcpy(A.col, col, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice));
+    PIB_HIP(hipMemcpy(A.val, val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice));
+    PIB_HIP(hipMemcpy(A.rowptr, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToDevice));
+    return after_set_matrix(s);
+}
+
 // ------------------------------------------------------------------------
 // closed-form number of non-zeros in rows [0, g) of the natural-order
 // (2*dim+1)-point operator with no-neighbour walls.

@@ -82,7 +82,7 @@ int pib_config_describe(const char *name, const char *cfg_text, char *buf, int b
     Config c;
     PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", c));
     const char *method = c.method == Method::CG ? "cg" : (c.method == Method::BICGSTAB ? "bicgstab" : "preonly");
-    const char *pc = c.pc == Precond::NONE ? "none" : (c.pc == Precond::JACOBI ? "jacobi" : "gmg");
+    const char *pc = c.pc == Precond::NONE ? "none" : (c.pc == Precond::JACOBI ? "jacobi" : (c.pc == Precond::LU ? "lu" : "gmg"));
     std::snprintf(buf, (size_t)buflen,
                   "flavor=%s type=\"%s\" method=%s pc=%s norm=%s max_iters=%d rtol=%.17g atol=%.17g dtol=%.17g "
                   "monitor=%d guess_nonzero=%d error_if_not_converged=%d jacobi_relaxation=%.17g presweeps=%d "
@@ -103,6 +103,7 @@ int pib_destroy(pib_solver *s)
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     gmg_release(s);
+    dense_release(s);
     s->A.release();
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
     if (s->work_base) (void)hipFree(s->work_base);
@@ -132,7 +133,9 @@ int pib_get_type(pib_solver *s, char *buf, int buflen)
     return 0;
 }
 
-static int after_set_matrix(pib_solver *s)
+extern "C++" {
+namespace pib {
+int after_set_matrix(pib_solver *s)
 {
     PIB_CHK(comm_setup_halo(s));
     int missing = 0;
@@ -145,9 +148,12 @@ static int after_set_matrix(pib_solver *s)
         (void)hipGraphExecDestroy(s->graph);
         s->graph = nullptr;
     }
+    if (s->cfg.pc == Precond::LU) PIB_CHK(dense_setup(s));  // PCSetUp of a direct solve = the factorisation
     s->has_matrix = true;
     return 0;
 }
+}  // namespace pib
+}  // extern "C++"
 
 int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_global, const int64_t *rowptr,
                 const int64_t *col_global, const double *val)
@@ -263,6 +269,8 @@ int pib_solve(pib_solver *s, double *x, const double *b)
         err = solve_cg(s, xdev, bdev);
     else if (s->cfg.method == Method::BICGSTAB)
         err = solve_bicgstab(s, xdev, bdev);
+    else if (s->cfg.method == Method::PREONLY && s->cfg.pc == Precond::LU)
+        err = solve_direct(s, xdev, bdev);
     else
         err = fail(PIB_ERR_SUP, "solver %s: unsupported Krylov method", s->name.c_str());
     if (err) return err;

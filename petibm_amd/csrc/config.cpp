@@ -145,8 +145,12 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
         c.method = Method::CG;
     else if (solver == "PBICGSTAB" || solver == "BICGSTAB")
         c.method = Method::BICGSTAB;
-    else
-        return fail(PIB_ERR_SUP, "config: solver=%s is not supported (PCG, PBICGSTAB)", solver.c_str());
+    else if (solver == "DENSE_LU_SOLVER") {
+        c.method = Method::PREONLY;
+        c.pc = Precond::LU;
+        return 0;
+    } else
+        return fail(PIB_ERR_SUP, "config: solver=%s is not supported (PCG, PBICGSTAB, DENSE_LU_SOLVER)", solver.c_str());
     (void)top;
 
     c.max_iters = std::atoi(d.get(ss, "max_iters", "100").c_str());
@@ -269,7 +273,8 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
         v = lower(v);
         if (v == "cg") c.method = Method::CG;
         else if (v == "bcgs" || v == "bicg" || v == "bcgsl") c.method = Method::BICGSTAB;
-        else return fail(PIB_ERR_SUP, "config: -%sksp_type %s is not supported (cg, bcgs)", pre.c_str(), v.c_str());
+        else if (v == "preonly") c.method = Method::PREONLY;
+        else return fail(PIB_ERR_SUP, "config: -%sksp_type %s is not supported (cg, bcgs, preonly)", pre.c_str(), v.c_str());
     }
     if (get("ksp_atol", v)) c.atol = std::atof(v.c_str());
     if (get("ksp_rtol", v)) c.rtol = std::atof(v.c_str());
@@ -291,10 +296,15 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
             c.smoother = Smoother::CHEBYSHEV;  // PCGAMG's default level smoother is Chebyshev/Jacobi
             c.presweeps = c.postsweeps = 1;
             c.cheby_degree = 2;
+        } else if (v == "lu" || v == "cholesky") {
+            c.pc = Precond::LU;  // -pc_factor_mat_solver_type (superlu_dist, mumps ...) selects PETSc's back end only
         } else
-            return fail(PIB_ERR_SUP, "config: -%spc_type %s is not supported (none, jacobi, gamg, hypre)", pre.c_str(),
+            return fail(PIB_ERR_SUP, "config: -%spc_type %s is not supported (none, jacobi, gamg, hypre, lu)", pre.c_str(),
                         v.c_str());
     }
+    if ((c.method == Method::PREONLY) != (c.pc == Precond::LU))
+        return fail(PIB_ERR_SUP, "config: -%sksp_type preonly and -%spc_type lu go together (direct solve)", pre.c_str(),
+                    pre.c_str());
     if (get("pib_check_every", v)) c.check_every = std::atoi(v.c_str());
     if (get("pib_use_graph", v)) c.use_graph = std::atoi(v.c_str());
     if (get("pib_spmv_variant", v)) c.spmv_variant = std::atoi(v.c_str());

@@ -1,0 +1,540 @@
+// ibm.hip -- SURVEY.md 8f-3: immersed-boundary operators and the force system of the decoupled IBPM, on the device.
+//
+//   createDelta  (src/operators/createdelta.cpp:34-208)   Delta[row(point, dof), velocity point of component dof]
+//                = prod_d kernel(X_d - x_d, h_d) over the +-window cells around the point's background cell
+//                (src/body/singlebodypoints.cpp:90-113); zero entries are not stored (MAT_IGNORE_ZERO_ENTRIES)
+//   kernels      (src/misc/delta.cpp:17-43)                Roma et al. 1999 (window 2), Peskin 2002 (window 3)
+//   E = Delta R MHat, H = Delta^T, BNH = BN H (BN = dt I), EBNH = E BNH
+//                (applications/decoupledibpm/decoupledibpm.cpp:141-216, creatediagmatrix.cpp:88-171)
+//   per step     rhs1 += H f ; rhsf = -E u ; EBNH df = rhsf ; u += BNH df ; f += df   (decoupledibpm.cpp:105-131,232-313)
+//
+// Layouts: Delta / E share one CSR over the Lagrangian rows (columns ascend: the reference's k, j, i loops); H is
+// the same entries sorted by (velocity point, row) with a compressed row index -- only the few thousand velocity
+// points under the kernels' support are stored, so spreading touches nothing else of the 10^5..10^8-entry field;
+// EBNH is a CSR built by intersecting the sorted column lists of row pairs whose background cells are within two
+// windows (same summation order as a row-wise sparse product).  Every sum runs in a fixed order: results are
+// bit-identical to the oracle (oracle/ibm.py), which follows PETSc's MatMult / MatMultAdd / MatMatMult order.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ns_internal.hpp"
+
+namespace pib {
+
+constexpr int IB_MAXW = 7;  // 2*window + 1, Peskin
+
+struct IbDev {
+    int dim, window, kernel;  // kernel: 0 Roma et al. 1999, 1 Peskin 2002
+    int64_t npts, nf;         // Lagrangian points of all bodies, force unknowns = npts * dim
+    const double *X;          // [npts*dim] coordinates
+    const int *ijk;           // [npts*dim] background (pressure) cell
+    const double *h;          // [npts*dim] kernel widths (uniform within a body: createdelta.cpp:69-76)
+};
+
+struct IbState {
+    IbDev I;
+    int nbodies = 0;
+    std::vector<int64_t> npts;
+    pib_solver *fsol = nullptr;
+    // Delta / E
+    int32_t *rowptr = nullptr, *col = nullptr;
+    double *val = nullptr, *eval = nullptr;
+    int64_t nnz = 0;
+    // H = Delta^T, compressed rows
+    int32_t *hcols = nullptr, *hptr = nullptr, *hrow = nullptr;
+    double *hval = nullptr;
+    int64_t hrows = 0;
+    // EBNH
+    int32_t *c_rowptr = nullptr, *c_col = nullptr;
+    double *c_val = nullptr;
+    int64_t c_nnz = 0;
+    double *f = nullptr, *df = nullptr, *rhsf = nullptr;
+    std::vector<void *> owned;
+};
+
+void ib_release(IbState *ib)
+{
+    if (ib == nullptr) return;
+    if (ib->fsol) pib_destroy(ib->fsol);
+    for (void *p : ib->owned) (void)hipFree(p);
+    delete ib;
+}
+
+__device__ __forceinline__ double delta_kernel(int kernel, double r, double dr)
+{
+    const double x = fabs(r) / dr;
+    if (kernel == 0) {  // delta.cpp:17-28
+        if (x > 1.5) return 0.0;
+        if (x > 0.5 && x <= 1.5) return (5 - 3 * x - sqrt(-3 * (1 - x) * (1 - x) + 1)) / (6 * dr);
+        return (1 + sqrt(-3 * x * x + 1)) / (3 * dr);
+    }
+    // delta.cpp:31-40
+    if (x >= 0.0 && x <= 1.0) return (3 - 2 * x + sqrt(1 + 4 * x - 4 * x * x)) / (8 * dr);
+    if (x >= 1.0 && x <= 2.0) return (5 - 2 * x - sqrt(-7 + 12 * x - 4 * x * x)) / (8 * dr);
+    return 0.0;
+}
+
+// One Lagrangian row per lane.  FILL = false: count the stored entries; true: write col / val / eval at rowptr[r].
+template <bool FILL>
+__global__ __launch_bounds__(128) void k_ib_delta(NsDev D, IbDev I, int32_t *__restrict__ count,
+                                                  const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                                                  double *__restrict__ val, double *__restrict__ eval)
+{
+    const int64_t r = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (r >= I.nf) return;
+    const int64_t pt = r / I.dim;
+    const int dof = (int)(r - pt * I.dim);
+    const NsField &F = D.f[dof];
+    int ids[3][IB_MAXW], cnt[3] = {0, 1, 1};
+    double phi[3][IB_MAXW];
+    ids[1][0] = ids[2][0] = 0;
+    for (int d = 0; d < I.dim; ++d) {
+        const int c0 = I.ijk[pt * I.dim + d];
+        const double x = I.X[pt * I.dim + d], h = I.h[pt * I.dim + d];
+        int c = 0;
+        for (int s = c0 - I.window; s <= c0 + I.window; ++s)
+            if (s >= 0 && s < F.n[d]) {
+                ids[d][c] = s;
+                phi[d][c] = delta_kernel(I.kernel, x - F.co[d][s + 1], h);
+                ++c;
+            }
+        cnt[d] = c;
+    }
+    int64_t q = FILL ? rowptr[r] : 0;
+    int n = 0;
+    for (int kk = 0; kk < cnt[2]; ++kk)
+        for (int jj = 0; jj < cnt[1]; ++jj)
+            for (int ii = 0; ii < cnt[0]; ++ii) {
+                double v = 1.0;  // delta.cpp:65-72
+                v *= phi[0][ii];
+                v *= phi[1][jj];
+                if (I.dim == 3) v *= phi[2][kk];
+                if (v == 0.0) continue;
+                ++n;
+                if (FILL) {
+                    const int64_t i = ids[0][ii], j = ids[1][jj], k = ids[2][kk];
+                    const int64_t ijk[3] = {i, j, k};
+                    // R (face area) and MHat (width along the component): creatediagmatrix.cpp:88-171
+                    const int a = (dof == 0) ? 1 : 0, b = (dof == 2) ? 1 : 2;
+                    const double la = F.dl[a][ijk[a] + 1], lb = (b < I.dim) ? F.dl[b][ijk[b] + 1] : 1.0;
+                    const double R = la * lb, M = F.dl[dof][ijk[dof] + 1];
+                    col[q] = (int32_t)fidx(F, i, j, k);
+                    val[q] = v;
+                    double e = v * R;  // MatDiagonalScale(E, nullptr, RDiag), then MHatDiag (decoupledibpm.cpp:172-173)
+                    e = e * M;
+                    eval[q] = e;
+                    ++q;
+                }
+            }
+    if (!FILL) count[r] = n;
+}
+
+__global__ __launch_bounds__(256) void k_ib_keys(int64_t nf, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                 uint64_t *__restrict__ keys, int32_t *__restrict__ idx)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nf; r += (int64_t)gridDim.x * 256)
+        for (int32_t q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+            keys[q] = (uint64_t)col[q] * (uint64_t)nf + (uint64_t)r;
+            idx[q] = q;
+        }
+}
+
+// sorted entries -> H arrays and segment heads
+__global__ __launch_bounds__(256) void k_ib_hfill(int64_t nnz, int64_t nf, const uint64_t *__restrict__ keys,
+                                                  const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                                  int32_t *__restrict__ hrow, double *__restrict__ hval, int32_t *__restrict__ head)
+{
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * 256) {
+        const uint64_t c = keys[q] / (uint64_t)nf;
+        hrow[q] = (int32_t)(keys[q] - c * (uint64_t)nf);
+        hval[q] = val[idx[q]];
+        head[q] = (q == 0 || keys[q - 1] / (uint64_t)nf != c) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ib_hrows(int64_t nnz, int64_t nf, const uint64_t *__restrict__ keys,
+                                                  const int32_t *__restrict__ head, const int32_t *__restrict__ pos,
+                                                  int32_t *__restrict__ hcols, int32_t *__restrict__ hptr)
+{
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * 256)
+        if (head[q]) {
+            hcols[pos[q] - 1] = (int32_t)(keys[q] / (uint64_t)nf);
+            hptr[pos[q] - 1] = (int32_t)q;
+        }
+}
+
+// EBNH row r1 = (p1, dof): one wave; lanes sweep the points p2 in ascending order, pairs whose background cells are
+// within 2*window in every direction are intersected.  FILL = false: count the structurally non-empty pairs.
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_ib_ebnh(IbDev I, double dt, const int32_t *__restrict__ rowptr,
+                                                const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                const double *__restrict__ eval, int32_t *__restrict__ count,
+                                                const int32_t *__restrict__ c_rowptr, int32_t *__restrict__ c_col,
+                                                double *__restrict__ c_val)
+{
+    const int64_t r1 = blockIdx.x;
+    const int64_t p1 = r1 / I.dim;
+    const int dof = (int)(r1 - p1 * I.dim);
+    const int lane = threadIdx.x;
+    const int32_t a0 = rowptr[r1], a1 = rowptr[r1 + 1];
+    int64_t out = FILL ? c_rowptr[r1] : 0;
+    int total = 0;
+    for (int64_t base = 0; base < I.npts; base += 64) {
+        const int64_t p2 = base + lane;
+        bool hit = false;
+        double sum = 0.0;
+        if (p2 < I.npts) {
+            bool near = true;
+            for (int d = 0; d < I.dim; ++d) {
+                const int dd = I.ijk[p1 * I.dim + d] - I.ijk[p2 * I.dim + d];
+                near = near && (dd <= 2 * I.window) && (dd >= -2 * I.window);
+            }
+            if (near) {
+                const int64_t r2 = p2 * I.dim + dof;
+                int32_t a = a0, b = rowptr[r2];
+                const int32_t b1 = rowptr[r2 + 1];
+                while (a < a1 && b < b1) {
+                    const int32_t ca = col[a], cb = col[b];
+                    if (ca == cb) {
+                        hit = true;
+                        if (FILL) {
+                            const double bnh = 0.0 + dt * val[b];  // BNH = BN H, BN = dt I (one-term row product)
+                            sum = sum + eval[a] * bnh;
+                        }
+                        ++a;
+                        ++b;
+                    } else if (ca < cb)
+                        ++a;
+                    else
+                        ++b;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (FILL && hit) {
+            const int64_t o = out + __popcll(m & ((1ull << lane) - 1ull));
+            c_col[o] = (int32_t)(p2 * I.dim + dof);
+            c_val[o] = sum;
+        }
+        const int c = __popcll(m);
+        out += c;
+        total += c;
+    }
+    if (!FILL && lane == 0) count[r1] = total;
+}
+
+// y[row] = y[row] + sum_q (scale * hval[q]) * x[hrow[q]] over the stored rows of H (MatMultAdd: the row sum starts
+// from y[row]; scale = 1: H, scale = dt: BNH whose stored value is the product dt * val)
+__global__ __launch_bounds__(256) void k_ib_spread(int64_t hrows, double scale, const int32_t *__restrict__ hcols,
+                                                   const int32_t *__restrict__ hptr, const int32_t *__restrict__ hrow,
+                                                   const double *__restrict__ hval, const double *__restrict__ x,
+                                                   double *__restrict__ y)
+{
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < hrows; m += (int64_t)gridDim.x * 256) {
+        const int32_t c = hcols[m];
+        double s = y[c];
+        for (int32_t q = hptr[m]; q < hptr[m + 1]; ++q) {
+            const double a = 0.0 + scale * hval[q];
+            s = s + a * x[hrow[q]];
+        }
+        y[c] = s;
+    }
+}
+
+// rhsf = -(E u)
+__global__ __launch_bounds__(256) void k_ib_interp(int64_t nf, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const double *__restrict__ eval, const double *__restrict__ U,
+                                                   double *__restrict__ rhsf)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nf; r += (int64_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int32_t q = rowptr[r]; q < rowptr[r + 1]; ++q) s = s + eval[q] * U[col[q]];
+        rhsf[r] = -1.0 * s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ib_axpy(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = y[i] + a * x[i];
+}
+
+static int blocks_for(int64_t n) { return (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n + 255) / 256)); }
+
+template <class T>
+static int dev_alloc(IbState *ib, T **p, int64_t count)
+{
+    PIB_HIP(hipMalloc(p, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
+    PIB_HIP(hipMemset(*p, 0, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
+    ib->owned.push_back(*p);
+    return 0;
+}
+
+// exclusive prefix sum of per-row counts on the host (a few thousand rows, set-up only)
+static int scan_counts(const int32_t *d_count, int64_t n, int32_t *d_rowptr, int64_t *total, hipStream_t q)
+{
+    std::vector<int32_t> c((size_t)n), rp((size_t)n + 1, 0);
+    PIB_HIP(hipMemcpyAsync(c.data(), d_count, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, q));
+    PIB_HIP(hipStreamSynchronize(q));
+    int64_t run = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        rp[(size_t)i] = (int32_t)run;
+        run += c[(size_t)i];
+    }
+    if (run >= (int64_t)std::numeric_limits<int32_t>::max()) return fail(PIB_ERR_SUP, "immersed-boundary operator too large for 32-bit offsets");
+    rp[(size_t)n] = (int32_t)run;
+    PIB_HIP(hipMemcpyAsync(d_rowptr, rp.data(), sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, q));
+    PIB_HIP(hipStreamSynchronize(q));
+    *total = run;
+    return 0;
+}
+
+int ib_spread_forces(pib_ns *ns)
+{
+    IbState *ib = ns->ib;
+    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, ns->stream, ib->hrows, 1.0, ib->hcols, ib->hptr,
+                       ib->hrow, ib->hval, ib->f, ns->rhs1);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+
+int ib_solve_forces(pib_ns *ns)
+{
+    IbState *ib = ns->ib;
+    const int64_t nf = ib->I.nf;
+    hipLaunchKernelGGL(k_ib_interp, dim3(blocks_for(nf)), dim3(256), 0, ns->stream, nf, ib->rowptr, ib->col, ib->eval, ns->U, ib->rhsf);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipStreamSynchronize(ns->stream));
+    PIB_CHK(pib_solve(ib->fsol, ib->df, ib->rhsf));  // fSolver->solve(df, rhsf)  (decoupledibpm.cpp:267)
+    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, ns->stream, ib->hrows, ns->dt, ib->hcols, ib->hptr,
+                       ib->hrow, ib->hval, ib->df, ns->U);  // MatMultAdd(BNH, df, U, U)  (:283-284)
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+
+int ib_update_forces(pib_ns *ns)
+{
+    IbState *ib = ns->ib;
+    hipLaunchKernelGGL(k_ib_axpy, dim3(blocks_for(ib->I.nf)), dim3(256), 0, ns->stream, ib->I.nf, 1.0, ib->df, ib->f);  // :301
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pib
+
+extern "C" {
+
+int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double *coords, const char *delta_kernel,
+                      const char *forces_cfg)
+{
+    using namespace pib;
+    if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
+    if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
+    PIB_HIP(hipSetDevice(ns->device));
+    ib_release(ns->ib);
+    ns->ib = nullptr;
+    const int dim = ns->D.dim;
+    int kernel, window;
+    const std::string kn = delta_kernel ? delta_kernel : "ROMA_ET_AL_1999";  // decoupledibpm.cpp:162
+    if (kn == "ROMA_ET_AL_1999") { kernel = 0; window = 2; }
+    else if (kn == "PESKIN_2002") { kernel = 1; window = 3; }
+    else return fail(PIB_ERR_ARG_UNKNOWN_TYPE, "No support for delta kernel `%s`.", kn.c_str());  // delta.cpp:58-60
+    IbState *ib = new IbState();
+    auto bail = [&](int e) {
+        ib_release(ib);
+        return e;
+    };
+    int err = 0;
+    ib->nbodies = nbodies;
+    int64_t total = 0;
+    for (int b = 0; b < nbodies; ++b) {
+        if (npts[b] < 1) return bail(fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: body %d has no points", b));
+        ib->npts.push_back(npts[b]);
+        total += npts[b];
+    }
+    // background cells (singlebodypoints.cpp:90-113) and kernel widths (createdelta.cpp:69-76) on the host
+    std::vector<int> ijk((size_t)(total * dim));
+    std::vector<double> h((size_t)(total * dim));
+    int64_t p0 = 0;
+    for (int b = 0; b < nbodies; ++b) {
+        for (int64_t q = p0; q < p0 + npts[b]; ++q)
+            for (int d = 0; d < dim; ++d) {
+                const double x = coords[q * dim + d];
+                if (ns->lo[d] >= x || ns->hi[d] <= x)
+                    return bail(fail(PIB_ERR_MAX_VALUE, "body coordinate %g is outside domain [%g, %g] !", x, ns->lo[d], ns->hi[d]));
+                const std::vector<double> &v = ns->h_vtx[d];
+                ijk[(size_t)(q * dim + d)] = (int)(std::upper_bound(v.begin(), v.end(), x) - v.begin()) - 1;
+            }
+        for (int64_t q = p0; q < p0 + npts[b]; ++q)
+            for (int d = 0; d < dim; ++d) h[(size_t)(q * dim + d)] = ns->h_dlu[d][(size_t)ijk[(size_t)(p0 * dim + d)] + 1];
+        p0 += npts[b];
+    }
+    IbDev &I = ib->I;
+    I.dim = dim;
+    I.window = window;
+    I.kernel = kernel;
+    I.npts = total;
+    I.nf = total * dim;
+    double *dX = nullptr, *dh = nullptr;
+    int *dijk = nullptr;
+    if ((err = dev_alloc(ib, &dX, total * dim)) || (err = dev_alloc(ib, &dh, total * dim)) || (err = dev_alloc(ib, &dijk, total * dim)))
+        return bail(err);
+    PIB_HIP(hipMemcpy(dX, coords, sizeof(double) * (size_t)(total * dim), hipMemcpyHostToDevice));
+    PIB_HIP(hipMemcpy(dh, h.data(), sizeof(double) * (size_t)(total * dim), hipMemcpyHostToDevice));
+    PIB_HIP(hipMemcpy(dijk, ijk.data(), sizeof(int) * (size_t)(total * dim), hipMemcpyHostToDevice));
+    I.X = dX;
+    I.h = dh;
+    I.ijk = dijk;
+    hipStream_t q = ns->stream;
+    const int64_t nf = I.nf;
+    // ---- Delta / E
+    int32_t *count = nullptr;
+    if ((err = dev_alloc(ib, &count, nf)) || (err = dev_alloc(ib, &ib->rowptr, nf + 1))) return bail(err);
+    const unsigned gb = (unsigned)((nf + 127) / 128);
+    hipLaunchKernelGGL(k_ib_delta<false>, dim3(gb), dim3(128), 0, q, ns->D, I, count, (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (double *)nullptr, (double *)nullptr);
+    PIB_HIP(hipGetLastError());
+    if ((err = scan_counts(count, nf, ib->rowptr, &ib->nnz, q))) return bail(err);
+    if ((err = dev_alloc(ib, &ib->col, ib->nnz)) || (err = dev_alloc(ib, &ib->val, ib->nnz)) || (err = dev_alloc(ib, &ib->eval, ib->nnz)))
+        return bail(err);
+    hipLaunchKernelGGL(k_ib_delta<true>, dim3(gb), dim3(128), 0, q, ns->D, I, count, ib->rowptr, ib->col, ib->val, ib->eval);
+    PIB_HIP(hipGetLastError());
+    // ---- H = Delta^T: sort the entries by (velocity point, row)
+    {
+        const int64_t nnz = ib->nnz;
+        uint64_t *k_in = nullptr, *k_out = nullptr;
+        int32_t *i_in = nullptr, *i_out = nullptr, *head = nullptr, *pos = nullptr;
+        if ((err = dev_alloc(ib, &k_in, nnz)) || (err = dev_alloc(ib, &k_out, nnz)) || (err = dev_alloc(ib, &i_in, nnz)) ||
+            (err = dev_alloc(ib, &i_out, nnz)) || (err = dev_alloc(ib, &head, nnz)) || (err = dev_alloc(ib, &pos, nnz)) ||
+            (err = dev_alloc(ib, &ib->hrow, nnz)) || (err = dev_alloc(ib, &ib->hval, nnz)))
+            return bail(err);
+        hipLaunchKernelGGL(k_ib_keys, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, k_in, i_in);
+        PIB_HIP(hipGetLastError());
+        size_t tmp_bytes = 0;
+        void *tmp = nullptr;
+        PIB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)nnz, 0, 64, q));
+        PIB_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+        ib->owned.push_back(tmp);
+        PIB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)nnz, 0, 64, q));
+        hipLaunchKernelGGL(k_ib_hfill, dim3(blocks_for(nnz)), dim3(256), 0, q, nnz, nf, k_out, i_out, ib->val, ib->hrow, ib->hval, head);
+        PIB_HIP(hipGetLastError());
+        size_t tmp2_bytes = 0;
+        void *tmp2 = nullptr;
+        PIB_HIP(rocprim::inclusive_scan(nullptr, tmp2_bytes, head, pos, (size_t)nnz, rocprim::plus<int32_t>(), q));
+        PIB_HIP(hipMalloc(&tmp2, std::max<size_t>(tmp2_bytes, 16)));
+        ib->owned.push_back(tmp2);
+        PIB_HIP(rocprim::inclusive_scan(tmp2, tmp2_bytes, head, pos, (size_t)nnz, rocprim::plus<int32_t>(), q));
+        int32_t m = 0;
+        if (nnz > 0) PIB_HIP(hipMemcpyAsync(&m, pos + (nnz - 1), sizeof(int32_t), hipMemcpyDeviceToHost, q));
+        PIB_HIP(hipStreamSynchronize(q));
+        ib->hrows = m;
+        if ((err = dev_alloc(ib, &ib->hcols, m)) || (err = dev_alloc(ib, &ib->hptr, (int64_t)m + 1))) return bail(err);
+        hipLaunchKernelGGL(k_ib_hrows, dim3(blocks_for(nnz)), dim3(256), 0, q, nnz, nf, k_out, head, pos, ib->hcols, ib->hptr);
+        PIB_HIP(hipGetLastError());
+        const int32_t last = (int32_t)nnz;
+        PIB_HIP(hipMemcpyAsync(ib->hptr + m, &last, sizeof(int32_t), hipMemcpyHostToDevice, q));
+        PIB_HIP(hipStreamSynchronize(q));
+    }
+    // ---- EBNH = E (BN H)
+    if ((err = dev_alloc(ib, &ib->c_rowptr, nf + 1))) return bail(err);
+    hipLaunchKernelGGL(k_ib_ebnh<false>, dim3((unsigned)nf), dim3(64), 0, q, I, ns->dt, ib->rowptr, ib->col, ib->val, ib->eval, count,
+                       (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
+    PIB_HIP(hipGetLastError());
+    if ((err = scan_counts(count, nf, ib->c_rowptr, &ib->c_nnz, q))) return bail(err);
+    if ((err = dev_alloc(ib, &ib->c_col, ib->c_nnz)) || (err = dev_alloc(ib, &ib->c_val, ib->c_nnz))) return bail(err);
+    hipLaunchKernelGGL(k_ib_ebnh<true>, dim3((unsigned)nf), dim3(64), 0, q, I, ns->dt, ib->rowptr, ib->col, ib->val, ib->eval, count,
+                       ib->c_rowptr, ib->c_col, ib->c_val);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipStreamSynchronize(q));
+    // ---- forces solver (decoupledibpm.cpp:75-80: createLinSolver("forces", ...), setMatrix(EBNH))
+    if ((err = pib_create_from_string(&ib->fsol, "forces", forces_cfg ? forces_cfg : "", 0, 1, nullptr, ns->device))) return bail(err);
+    if ((err = adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val))) return bail(err);
+    if ((err = dev_alloc(ib, &ib->f, nf)) || (err = dev_alloc(ib, &ib->df, nf)) || (err = dev_alloc(ib, &ib->rhsf, nf))) return bail(err);
+    ns->ib = ib;
+    return 0;
+}
+
+int pib_ns_num_forces(pib_ns *ns, int64_t *nf, int *nbodies)
+{
+    if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
+    if (nf) *nf = ns->ib ? ns->ib->I.nf : 0;
+    if (nbodies) *nbodies = ns->ib ? ns->ib->nbodies : 0;
+    return 0;
+}
+
+/* Lagrangian forces f [nf] and the bodies' forces [nbodies*dim] = minus the sum of the Lagrangian forces of each
+ * body (singlebodypoints.cpp:228-259; one line of forces-<start>.txt, decoupledibpm.cpp:437-465) */
+int pib_ns_get_forces(pib_ns *ns, double *f, double *body_forces)
+{
+    using namespace pib;
+    if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
+    if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_get_forces: the flow has no immersed bodies");
+    PIB_HIP(hipSetDevice(ns->device));
+    PIB_HIP(hipStreamSynchronize(ns->stream));
+    IbState *ib = ns->ib;
+    std::vector<double> h((size_t)ib->I.nf);
+    PIB_HIP(hipMemcpy(h.data(), ib->f, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    if (f) std::memcpy(f, h.data(), sizeof(double) * h.size());
+    if (body_forces) {
+        const int dim = ib->I.dim;
+        int64_t p0 = 0;
+        for (int b = 0; b < ib->nbodies; ++b) {
+            for (int d = 0; d < dim; ++d) body_forces[b * dim + d] = 0.0;
+            for (int64_t q = p0; q < p0 + ib->npts[(size_t)b]; ++q)
+                for (int d = 0; d < dim; ++d) body_forces[b * dim + d] -= h[(size_t)(q * dim + d)];
+            p0 += ib->npts[(size_t)b];
+        }
+    }
+    return 0;
+}
+
+int pib_ns_get_forces_solver_info(pib_ns *ns, int *f_iters, double *f_res)
+{
+    if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
+    if (ns->ib == nullptr) return pib::fail(PIB_ERR_ORDER, "pib_ns_get_forces_solver_info: the flow has no immersed bodies");
+    if (f_iters) pib_get_iters(ns->ib->fsol, f_iters);
+    if (f_res) pib_get_residual(ns->ib->fsol, f_res);
+    return 0;
+}
+
+int pib_ns_set_forces(pib_ns *ns, const double *f)
+{
+    using namespace pib;
+    if (ns == nullptr || f == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_forces: null argument");
+    if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_set_forces: the flow has no immersed bodies");
+    PIB_HIP(hipSetDevice(ns->device));
+    PIB_HIP(hipMemcpy(ns->ib->f, f, sizeof(double) * (size_t)ns->ib->I.nf, hipMemcpyHostToDevice));
+    return 0;
+}
+
+/* Parity / inspection access to the operators.  which: 0 Delta, 1 E, 2 H (compressed rows, row_ids = the velocity
+ * points stored), 3 EBNH.  Call with null arrays to get the sizes. */
+int pib_ns_get_ib_operator(pib_ns *ns, int which, int64_t *n_rows, int64_t *nnz, int32_t *rowptr, int32_t *col, double *val,
+                           int32_t *row_ids)
+{
+    using namespace pib;
+    if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
+    if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_get_ib_operator: the flow has no immersed bodies");
+    PIB_HIP(hipSetDevice(ns->device));
+    IbState *ib = ns->ib;
+    int64_t nr, nz;
+    const int32_t *rp, *cl;
+    const double *vl;
+    switch (which) {
+        case 0: nr = ib->I.nf; nz = ib->nnz; rp = ib->rowptr; cl = ib->col; vl = ib->val; break;
+        case 1: nr = ib->I.nf; nz = ib->nnz; rp = ib->rowptr; cl = ib->col; vl = ib->eval; break;
+        case 2: nr = ib->hrows; nz = ib->nnz; rp = ib->hptr; cl = ib->hrow; vl = ib->hval; break;
+        case 3: nr = ib->I.nf; nz = ib->c_nnz; rp = ib->c_rowptr; cl = ib->c_col; vl = ib->c_val; break;
+        default: return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_get_ib_operator: which = %d", which);
+    }
+    if (n_rows) *n_rows = nr;
+    if (nnz) *nnz = nz;
+    if (rowptr) PIB_HIP(hipMemcpy(rowptr, rp, sizeof(int32_t) * (size_t)(nr + 1), hipMemcpyDeviceToHost));
+    if (col) PIB_HIP(hipMemcpy(col, cl, sizeof(int32_t) * (size_t)nz, hipMemcpyDeviceToHost));
+    if (val) PIB_HIP(hipMemcpy(val, vl, sizeof(double) * (size_t)nz, hipMemcpyDeviceToHost));
+    if (row_ids && which == 2) PIB_HIP(hipMemcpy(row_ids, ib->hcols, sizeof(int32_t) * (size_t)nr, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -21,47 +21,9 @@
 // bit for bit, the solves to solver tolerance.
 #include <cstring>
 
-#include "pib_internal.hpp"
+#include "ns_internal.hpp"
 
 namespace pib {
-
-struct NsField {
-    int64_t n[3];
-    int64_t off;            // first entry of the field's block in the packed vector
-    const double *dl[3];    // dL[f][d], index s+1
-    const double *co[3];    // coord[f][d], index s+1
-    // ghost points per boundary location: ghost = a0*target + a1 (a0 is uniform over a face); face arrays are
-    // indexed a + na*b over the two perpendicular axes in natural order (misc.cpp:154-196)
-    double a0[6];
-    int type[6];            // 0 DIRICHLET, 1 NEUMANN, 2 CONVECTIVE
-    double bcv[6];          // the BC value (Dirichlet value, Neumann gradient, convective speed)
-    double gdl[6];          // distance ghost - target
-    int64_t goff[6];        // offset of the face in the ghost arrays
-    int64_t gcnt[6];        // points of the face
-};
-struct NsDev {
-    int dim;
-    NsField f[3];
-    int64_t pn[3];          // pressure cells
-    const double *pw[3];    // pressure-cell widths
-    int64_t UN, pN;
-    int64_t nghost;
-    double *a1, *a1n, *gv;  // [nghost] current / next ghost equations' a1, ghost values
-};
-
-// index of the ghost point of boundary `loc` facing (i,j,k) within its face
-__device__ __forceinline__ int64_t face_index(const NsField &F, int loc, int64_t i, int64_t j, int64_t k)
-{
-    const int axis = loc >> 1;
-    if (axis == 0) return F.goff[loc] + j + F.n[1] * k;
-    if (axis == 1) return F.goff[loc] + i + F.n[0] * k;
-    return F.goff[loc] + i + F.n[0] * j;
-}
-
-__device__ __forceinline__ int64_t fidx(const NsField &F, int64_t i, int64_t j, int64_t k)
-{
-    return F.off + i + F.n[0] * (j + F.n[1] * k);
-}
 
 // velocity value at (i,j,k) of field f; an index one step outside is the stored ghost value
 __device__ __forceinline__ double vel(const NsDev &D, const double *__restrict__ U, int f, int64_t i, int64_t j, int64_t k)
@@ -330,20 +292,6 @@ __global__ __launch_bounds__(256) void k_ns_project(NsDev D, double dt, const do
 
 }  // namespace pib
 
-struct pib_ns {
-    pib::NsDev D;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    pib_solver *vsol = nullptr, *psol = nullptr;
-    double dt = 0, nu = 0;
-    double *U = nullptr, *p = nullptr, *dP = nullptr, *rhs1 = nullptr, *rhs2 = nullptr, *conv[2] = {nullptr, nullptr};
-    std::vector<double *> owned;
-    int pinned = 0;
-    int v_iters = 0, p_iters = 0;
-    double v_res = 0, p_res = 0;
-    int64_t steps = 0;
-};
-
 static int ghost_blocks(const pib::NsDev &D) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (D.nghost + 255) / 256)); }
 
 extern "C" {
@@ -352,6 +300,8 @@ int pib_ns_destroy(pib_ns *ns)
 {
     if (ns == nullptr) return 0;
     (void)hipSetDevice(ns->device);
+    pib::ib_release(ns->ib);
+    ns->ib = nullptr;
     if (ns->vsol) pib_destroy(ns->vsol);
     if (ns->psol) pib_destroy(ns->psol);
     for (double *q : ns->owned) (void)hipFree(q);
@@ -376,6 +326,12 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     pib_ns *ns = new pib_ns();
     ns->dt = dt;
     ns->nu = nu;
+    for (int d = 0; d < dim; ++d) {
+        ns->h_vtx[d] = hco[d][d];  // coord[component d][direction d] = the vertices (cartesianmesh.cpp:246)
+        ns->h_dlu[d] = hdl[0][d];
+        ns->lo[d] = lo[d];
+        ns->hi[d] = hi[d];
+    }
     int err = 0;
     auto bail = [&](int e) {
         pib_ns_destroy(ns);
@@ -549,13 +505,16 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
                            ns->p, ns->conv[1], ns->conv[0], ns->rhs1);
         PIB_HIP(hipGetLastError());
         std::swap(D.a1, D.a1n);
+        if (ns->ib) PIB_CHK(ib_spread_forces(ns));  // rhs1 += H f  (decoupledibpm.cpp:243)
         PIB_HIP(hipStreamSynchronize(ns->stream));
         PIB_CHK(pib_solve(ns->vsol, ns->U, ns->rhs1));  // vSolver->solve(UGlobal, rhs1)  (:532)
+        if (ns->ib) PIB_CHK(ib_solve_forces(ns));   // assembleRHSForces, solveForces, applyNoSlip (decoupledibpm.cpp:116-118)
         hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns->pinned, ns->U, ns->rhs2);
         PIB_HIP(hipGetLastError());
         PIB_HIP(hipStreamSynchronize(ns->stream));
         PIB_CHK(pib_solve(ns->psol, ns->dP, ns->rhs2));  // pSolver->solve(dP, rhs2)      (:575)
         hipLaunchKernelGGL(k_ns_project, dim3(gt), dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
+        if (ns->ib) PIB_CHK(ib_update_forces(ns));  // f += df  (decoupledibpm.cpp:125)
         hipLaunchKernelGGL(k_ns_ghosts<2>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);  // bc->updateGhostValues (:263)
         PIB_HIP(hipGetLastError());
         ns->steps++;

@@ -1,0 +1,77 @@
+// ns_internal.hpp -- device-side mesh / ghost-point description and the engine state shared by the time-step
+// kernels (navierstokes.hip) and the immersed-boundary operators (ibm.hip).
+#pragma once
+#include "pib_internal.hpp"
+
+struct pib_ns;
+
+namespace pib {
+
+struct NsField {
+    int64_t n[3];
+    int64_t off;            // first entry of the field's block in the packed vector
+    const double *dl[3];    // dL[f][d], index s+1
+    const double *co[3];    // coord[f][d], index s+1
+    // ghost points per boundary location: ghost = a0*target + a1 (a0 is uniform over a face); face arrays are
+    // indexed a + na*b over the two perpendicular axes in natural order (misc.cpp:154-196)
+    double a0[6];
+    int type[6];            // 0 DIRICHLET, 1 NEUMANN, 2 CONVECTIVE
+    double bcv[6];          // the BC value (Dirichlet value, Neumann gradient, convective speed)
+    double gdl[6];          // distance ghost - target
+    int64_t goff[6];        // offset of the face in the ghost arrays
+    int64_t gcnt[6];        // points of the face
+};
+struct NsDev {
+    int dim;
+    NsField f[3];
+    int64_t pn[3];          // pressure cells
+    const double *pw[3];    // pressure-cell widths
+    int64_t UN, pN;
+    int64_t nghost;
+    double *a1, *a1n, *gv;  // [nghost] current / next ghost equations' a1, ghost values
+};
+
+// index of the ghost point of boundary `loc` facing (i,j,k) within its face
+__device__ __forceinline__ int64_t face_index(const NsField &F, int loc, int64_t i, int64_t j, int64_t k)
+{
+    const int axis = loc >> 1;
+    if (axis == 0) return F.goff[loc] + j + F.n[1] * k;
+    if (axis == 1) return F.goff[loc] + i + F.n[0] * k;
+    return F.goff[loc] + i + F.n[0] * j;
+}
+
+__device__ __forceinline__ int64_t fidx(const NsField &F, int64_t i, int64_t j, int64_t k)
+{
+    return F.off + i + F.n[0] * (j + F.n[1] * k);
+}
+
+struct IbState;
+void ib_release(IbState *ib);
+// the extra stages of DecoupledIBPMSolver::advance (decoupledibpm.cpp:105-131)
+int ib_spread_forces(pib_ns *ns);   // rhs1 += H f
+int ib_solve_forces(pib_ns *ns);    // rhsf = -E u ; EBNH df = rhsf ; u += BNH df
+int ib_update_forces(pib_ns *ns);   // f += df
+
+}  // namespace pib
+
+struct pib_ns {
+    pib::NsDev D;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    pib_solver *vsol = nullptr, *psol = nullptr;
+    double dt = 0, nu = 0;
+    double *U = nullptr, *p = nullptr, *dP = nullptr, *rhs1 = nullptr, *rhs2 = nullptr, *conv[2] = {nullptr, nullptr};
+    std::vector<double *> owned;
+    int pinned = 0;
+    int v_iters = 0, p_iters = 0;
+    double v_res = 0, p_res = 0;
+    int64_t steps = 0;
+    // immersed bodies (ibm.hip); null when the flow has none
+    pib::IbState *ib = nullptr;
+    std::vector<double> h_vtx[3];  // vertex coordinates (coord[4][d]) and u-widths (dL[0][d], ghosted) on the host:
+    std::vector<double> h_dlu[3];  // background-cell search and kernel widths of the bodies
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int f_iters = 0;
+    double f_res = 0;
+};
+

@@ -39,7 +39,7 @@ const char *last_error();
 // ------------------------------------------------------------------ config
 enum class Flavor { AMGX, KSP };
 enum class Method { CG, BICGSTAB, PREONLY };
-enum class Precond { NONE, JACOBI, GMG };
+enum class Precond { NONE, JACOBI, GMG, LU };
 enum class Smoother { JACOBI, CHEBYSHEV };
 enum class NormType { PRECONDITIONED, UNPRECONDITIONED };
 
@@ -189,6 +189,8 @@ struct pib_solver {
     int hist_cap = 0;
     hipGraphExec_t graph = nullptr;
     int graph_iters = 0;
+    double *dense_inv = nullptr;  // dense.hip: explicit inverse of the direct solver [dense_n x dense_n]
+    int64_t dense_n = 0;
     // results of the last solve
     int iters = 0, reason = 0;
     double residual = 0.0;
@@ -218,6 +220,13 @@ void comm_release(pib_solver *s);
 int solve_cg(pib_solver *s, double *x, const double *b);
 int solve_bicgstab(pib_solver *s, double *x, const double *b);
 int ensure_work(pib_solver *s, int nvec);
+// assemble.hip: take a copy of a CSR that already lives in HBM (single rank, 32-bit offsets) as the solver's matrix
+int adopt_device_csr(pib_solver *s, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col, const double *val);
+int after_set_matrix(pib_solver *s);
+// dense.hip
+int dense_setup(pib_solver *s);
+void dense_release(pib_solver *s);
+int solve_direct(pib_solver *s, double *x, const double *b);
 // assemble.hip
 int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);
 int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],

@@ -87,6 +87,31 @@ class NavierStokesSolver:
         self.UN, self.pN = un.value, pn.value
         self.ite = 0
         self.t = 0.0
+        # flow.initialVelocity (src/solution/solutionsimple.cpp:122-226 setInitialConditions, called from
+        # NavierStokesSolver::init): one entry per component, a number or an expression in x, y, z, t, nu
+        # (the reference parses them with SymEngine) evaluated at the component's points at t = 0
+        ic = config["flow"].get("initialVelocity")
+        if ic is not None:
+            U0 = self._initial_velocity(ic, lo)
+            if np.any(U0 != 0.0):
+                self.setState(U0, None)
+
+    def _initial_velocity(self, ic, lo):
+        import math
+        names = {k: getattr(np, k) for k in ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "abs")}
+        names.update(pi=math.pi, e=math.e, t=0.0, nu=self.nu)
+        parts = []
+        for f in range(self.dim):
+            axes = []
+            for d in range(self.dim):
+                vtx = lo[d] + np.concatenate([[0.0], np.cumsum(self.widths[d])])
+                axes.append(vtx[1:-1] if d == f else 0.5 * (vtx[1:] + vtx[:-1]))
+            grids = np.meshgrid(*axes[::-1], indexing="ij")[::-1]  # arrays indexed (k, j, i)
+            env = dict(names, x=grids[0], y=grids[1], z=grids[2] if self.dim == 3 else 0.0)
+            v = ic[f]
+            val = float(v) if not isinstance(v, str) else eval(v.replace("^", "**"), {"__builtins__": {}}, env)  # noqa: S307
+            parts.append(np.broadcast_to(np.asarray(val, dtype=np.float64), grids[0].shape).reshape(-1))
+        return np.concatenate(parts)
 
     def setState(self, U=None, p=None):
         U = None if U is None else np.ascontiguousarray(U, dtype=np.float64)
@@ -124,3 +149,82 @@ class NavierStokesSolver:
             self.destroy()
         except Exception:
             pass
+
+
+DEFAULT_FORCES_CFG = "-forces_ksp_type preonly\n-forces_pc_type lu\n-forces_pc_factor_mat_solver_type superlu_dist\n"
+
+
+def read_lagrangian_points(path: str) -> np.ndarray:
+    """Body file of the reference (src/io/io.cpp:23-118): the number of points, then one coordinate set per line."""
+    with open(path) as fh:
+        first = fh.readline().split()
+        if len(first) != 1:
+            raise capi.PibError(66, f"The first line in file {path} contains more than one integer. Please check the format.")
+        n = int(first[0])
+        pts = [[float(v) for v in line.split()] for line in fh if line.strip()]
+    if len(pts) != n:
+        raise capi.PibError(66, f"The number of coordinate sets in {path} does not match the header ({len(pts)} vs {n}).")
+    return np.array(pts, dtype=np.float64)
+
+
+class DecoupledIBPMSolver(NavierStokesSolver):
+    """Mirror of `DecoupledIBPMSolver` (applications/decoupledibpm/decoupledibpm.h): the flow solver plus immersed
+    bodies given as Lagrangian points (`bodies:` of the YAML file: `type: points`, `file:` relative to the simulation
+    directory, src/body/bodypack.cpp; or arrays), the delta kernel `parameters.delta` and a forces solver."""
+
+    def __init__(self, config: dict, bodies=None, velocity_cfg: str = DEFAULT_VELOCITY_CFG,
+                 poisson_cfg: str = DEFAULT_POISSON_CFG, forces_cfg: str = DEFAULT_FORCES_CFG, device: int = -1,
+                 directory: str = "."):
+        super().__init__(config, velocity_cfg=velocity_cfg, poisson_cfg=poisson_cfg, device=device)
+        import os
+        if bodies is None:
+            bodies = []
+            for node in config.get("bodies", []):
+                if node.get("type", "points") != "points":
+                    raise capi.PibError(capi.ERR_SUP, f"body type {node.get('type')} is not supported (points)")
+                f = node["file"]
+                bodies.append(read_lagrangian_points(f if os.path.isabs(f) else os.path.join(directory, f)))
+        self.bodies = [np.ascontiguousarray(b, dtype=np.float64) for b in bodies]
+        for b in self.bodies:
+            if b.ndim != 2 or b.shape[1] != self.dim:
+                raise capi.PibError(66, "The dimension of Lagrangian points are different than that of the background mesh!")
+        npts = np.array([b.shape[0] for b in self.bodies], dtype=np.int64)
+        coords = np.ascontiguousarray(np.concatenate(self.bodies, axis=0))
+        kernel = str(config.get("parameters", {}).get("delta", "ROMA_ET_AL_1999"))
+        capi.check(capi.load().pib_ns_set_bodies(self._h, len(self.bodies), npts.ctypes.data, coords.ctypes.data,
+                                                 kernel.encode(), forces_cfg.encode()))
+        nf, nb = C.c_int64(), C.c_int()
+        capi.check(capi.load().pib_ns_num_forces(self._h, C.byref(nf), C.byref(nb)))
+        self.nf, self.nBodies = nf.value, nb.value
+
+    def getForces(self):
+        """(Lagrangian forces f, per-body forces): the second is one line of forces-<start>.txt (decoupledibpm.cpp:437-465)"""
+        f = np.empty(self.nf)
+        avg = np.empty(self.nBodies * self.dim)
+        capi.check(capi.load().pib_ns_get_forces(self._h, f.ctypes.data, avg.ctypes.data))
+        return f, avg.reshape(self.nBodies, self.dim)
+
+    def setForces(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        capi.check(capi.load().pib_ns_set_forces(self._h, f.ctypes.data))
+
+    def linSolversInfo(self):
+        """ite, vIters, vRes, pIters, pRes, fIters, fRes (decoupledibpm.cpp:399-434)"""
+        base = super().linSolversInfo()
+        fi, fr = C.c_int(), C.c_double()
+        capi.check(capi.load().pib_ns_get_forces_solver_info(self._h, C.byref(fi), C.byref(fr)))
+        return base + (fi.value, fr.value)
+
+    def getOperator(self, which: str):
+        """'delta' | 'E' | 'H' | 'EBNH' as (n_rows, rowptr, col, val[, row_ids]) host arrays (inspection / parity)"""
+        w = {"delta": 0, "E": 1, "H": 2, "EBNH": 3}[which]
+        nr, nz = C.c_int64(), C.c_int64()
+        lib = capi.load()
+        capi.check(lib.pib_ns_get_ib_operator(self._h, w, C.byref(nr), C.byref(nz), None, None, None, None))
+        rp = np.empty(nr.value + 1, dtype=np.int32)
+        cl = np.empty(nz.value, dtype=np.int32)
+        vl = np.empty(nz.value)
+        ids = np.empty(nr.value, dtype=np.int32) if w == 2 else None
+        capi.check(lib.pib_ns_get_ib_operator(self._h, w, C.byref(nr), C.byref(nz), rp.ctypes.data, cl.ctypes.data,
+                                              vl.ctypes.data, None if ids is None else ids.ctypes.data))
+        return (nr.value, rp, cl, vl) if ids is None else (nr.value, rp, cl, vl, ids)

@@ -1,0 +1,179 @@
+"""Immersed-boundary operators, the direct forces solve and the decoupled-IBPM time step on the GPU
+against the oracle (oracle/ibm.py) and against the validation data the reference ships (Koumoutsakos & Leonard 1995)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import clib, ibm, mesh as omesh, operators as oops
+from test_oracle_ibm import body_mesh, circle
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_test_vectors.json")))
+
+VEL = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+       "solv:tolerance=1e-14\nsolv:norm=L2\nsolv:store_res_history=1\nsolv:preconditioner(prec)=BLOCK_JACOBI\n"
+       "prec:relaxation_factor=1.0\n")
+AMGX_P = ("config_version=2\nsolver(solv)=PCG\nsolv:max_iters=500\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+          "solv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\nsolv:preconditioner(prec)=AMG\nprec:cycle=V\n"
+          "prec:presweeps=1\nprec:postsweeps=1\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
+          "smooth:relaxation_factor=0.9\n")
+FORCES = "-forces_ksp_type preonly\n-forces_pc_type lu\n-forces_pc_factor_mat_solver_type superlu_dist\n"
+
+
+def flow_config(mesh_cfg, nu=0.025, dt=0.01, kernel=None):
+    cfg = dict(mesh_cfg)
+    dim = len(cfg["mesh"])
+    for bc in cfg["flow"]["boundaryConditions"]:
+        for c in ["u", "v", "w"][:dim]:
+            free = 1.0 if c == "u" else 0.0
+            bc[c] = ["CONVECTIVE", 1.0] if bc["location"] == "xPlus" else ["DIRICHLET", free]
+    cfg["flow"]["nu"] = nu
+    cfg["flow"]["initialVelocity"] = [1.0, 0.0, 0.0][:dim]
+    cfg["parameters"] = {"dt": dt, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    if kernel:
+        cfg["parameters"]["delta"] = kernel
+    return cfg
+
+
+def sphere_points(n=60, r=0.4):
+    k = np.arange(n) + 0.5
+    phi, th = np.arccos(1 - 2 * k / n), np.pi * (1 + 5 ** 0.5) * k
+    return np.stack([r * np.cos(th) * np.sin(phi), r * np.sin(th) * np.sin(phi), r * np.cos(phi)], axis=1)
+
+
+def as_csr(n_rows, n_cols, rp, cl, vl):
+    return oops.CSR(n_rows, n_cols, rp.astype(np.int64), cl.astype(np.int64), vl)
+
+
+@pytest.mark.parametrize("case", ["2d_roma", "2d_peskin_two_bodies", "3d_roma", "2d_clipped"])
+def test_ib_operators_are_bit_identical_to_the_oracle(case):
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    if case == "3d_roma":
+        cfg = flow_config(body_mesh(cells=(5, 10, 5), ratio=1.3, span=2.0, core=0.6, dim=3), dt=0.02)
+        bodies = [sphere_points()]
+    elif case == "2d_clipped":
+        cfg = flow_config(omesh.uniform_config((16, 12)), dt=0.02)
+        bodies = [circle(9, r=0.12, c=(0.3, 0.5)), np.array([[0.02, 0.03], [0.97, 0.95], [0.5, 0.01]])]
+    else:
+        cfg = flow_config(body_mesh(), dt=0.01, kernel="PESKIN_2002" if "peskin" in case else None)
+        bodies = [circle(40)] if case == "2d_roma" else [circle(25, r=0.3, c=(-0.3, 0.1)), circle(31, r=0.25, c=(0.4, -0.2))]
+    m = omesh.create_mesh(cfg)
+    ref = ibm.create_ib_operators(m, bodies, cfg["parameters"]["dt"], cfg["parameters"].get("delta", "ROMA_ET_AL_1999"))
+    s = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=AMGX_P.format(tol=1e-12), forces_cfg=FORCES)
+    assert s.nf == ref["E"].n_rows
+    for name in ("delta", "E", "EBNH"):
+        nr, rp, cl, vl = s.getOperator(name)
+        r = ref[name]
+        assert nr == r.n_rows and np.array_equal(rp, r.rowptr) and np.array_equal(cl, r.col), name
+        assert np.array_equal(vl, r.val), name
+    nr, rp, cl, vl, ids = s.getOperator("H")
+    H = ref["H"]
+    live = np.flatnonzero(np.diff(H.rowptr))
+    assert np.array_equal(ids, live) and np.array_equal(rp, H.rowptr[np.append(live, H.n_rows)])
+    assert np.array_equal(cl, H.col) and np.array_equal(vl, H.val)
+    s.destroy()
+
+
+def test_direct_forces_solve_matches_lapack(lin=None):
+    """-forces_ksp_type preonly -forces_pc_type lu: the explicit inverse built on the device reproduces a dense LU solve"""
+    from petibm_amd.linsolver import LinSolverHIP
+    m = omesh.create_mesh(body_mesh())
+    A = ibm.create_ib_operators(m, [circle(60), circle(30, r=0.2)], 0.01)["EBNH"]
+    b = np.random.default_rng(2).uniform(-1, 1, A.n_rows)
+    want = np.linalg.solve(A.to_dense(), b)
+    for text in (FORCES, "config_version=2\nsolver(s)=DENSE_LU_SOLVER\n"):
+        s = LinSolverHIP("forces", config_text=text)
+        s.setMatrix(A)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        assert np.linalg.norm(x - want) <= 1e-11 * np.linalg.norm(want)
+        # backward error (the two overlapping bodies make this system ill-conditioned: |x| ~ 1e4 |b|)
+        assert np.linalg.norm(b - clib.spmv(A, x)) <= 1e-13 * np.linalg.norm(A.val) * np.linalg.norm(x)
+        assert s.getIters() == 1 and s.getReason() > 0
+        s.destroy()
+    # a singular matrix is a zero-pivot error (PETSC_ERR_MAT_LU_ZRPVT), not a wrong answer
+    from petibm_amd import capi
+    Z = A.copy()
+    Z.val = Z.val * 0.0
+    s = LinSolverHIP("forces", config_text=FORCES)
+    with pytest.raises(capi.PibError) as ei:
+        s.setMatrix(Z)
+    assert ei.value.code == capi.ERR_MAT_LU_ZRPVT
+    s.destroy()
+
+
+@pytest.mark.parametrize("case", ["2d", "3d"])
+def test_decoupled_ibpm_step_matches_oracle(case):
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    if case == "2d":
+        cfg = flow_config(body_mesh(cells=(8, 16, 8), ratio=1.25, span=3.0, core=0.8), dt=0.01)
+        bodies = [circle(32)]
+    else:
+        cfg = flow_config(body_mesh(cells=(4, 8, 4), ratio=1.4, span=2.0, core=0.6, dim=3), nu=0.05, dt=0.02)
+        bodies = [sphere_points(40, r=0.35)]
+    m = omesh.create_mesh(cfg)
+    dt, nu = cfg["parameters"]["dt"], cfg["flow"]["nu"]
+    ref = ibm.DecoupledIBPM(m, dt, nu, bodies, pinned=True, vtol=1e-14, ptol=1e-13)
+    U0 = np.zeros(m.UN)
+    U0[: int(np.prod(m.n[0]))] = 1.0
+    U0 += 0.02 * np.random.default_rng(3).uniform(-1, 1, m.UN)
+    ref.set_state(U0, np.zeros(m.pN))
+    s = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=AMGX_P.format(tol=1e-13), forces_cfg=FORCES)
+    s.setState(U0, np.zeros(m.pN))
+    for step in range(3):
+        ref.advance()
+        s.advance()
+        U, p, r1, r2 = s.getState(rhs=True)
+        f, avg = s.getForces()
+        if step == 0:
+            assert np.array_equal(r1, ref.last_rhs1)  # f = 0: the spread adds exact zeros
+        assert np.abs(r1 - ref.last_rhs1).max() <= 1e-9 * np.abs(ref.last_rhs1).max()
+        assert np.abs(U - ref.U).max() <= 1e-9 * np.abs(ref.U).max()
+        assert np.abs(f - ref.f).max() <= 1e-8 * np.abs(ref.f).max()
+        assert np.allclose(avg, ref.body_forces(), rtol=1e-8, atol=1e-12)
+    # no-slip: the interpolated velocity vanishes on the body after applyNoSlip (up to the projection's correction)
+    info = s.linSolversInfo()
+    assert len(info) == 7 and info[5] == 1
+    s.destroy()
+
+
+def test_errors_of_the_body_input():
+    from petibm_amd import capi
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    cfg = flow_config(body_mesh())
+    with pytest.raises(capi.PibError) as ei:
+        DecoupledIBPMSolver(cfg, bodies=[np.array([[5.0, 0.0]])])   # singlebodypoints.cpp:99-104
+    assert ei.value.code == capi.ERR_MAX_VALUE
+    bad = flow_config(body_mesh(), kernel="COSINE")
+    with pytest.raises(capi.PibError) as ei:
+        DecoupledIBPMSolver(bad, bodies=[circle(10)])               # delta.cpp:58-60
+    assert ei.value.code == capi.ERR_ARG_UNKNOWN_TYPE
+
+
+def test_cylinder_re40_drag_matches_koumoutsakos_leonard():
+    """The reference's validation case, verbatim: examples/decoupledibpm/cylinder2dRe40_GPU (186^2 stretched mesh on
+    [-15,15]^2, 126 Lagrangian points, dt = 0.01, nu = 0.025, convective outlet, AmgX-flavoured Poisson solve at 1e-6,
+    direct forces solve), 500 of its 2000 steps; plotDragCoefficient.py compares cd = 2 fx with Koumoutsakos & Leonard."""
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    sub = [{"end": -0.6, "cells": 69, "stretchRatio": 0.952380952}, {"end": 0.6, "cells": 48, "stretchRatio": 1.0},
+           {"end": 15.0, "cells": 69, "stretchRatio": 1.05}]
+    base = omesh.uniform_config((186, 186))
+    base["mesh"] = [{"direction": d, "start": -15.0, "subDomains": sub} for d in "xy"]
+    cfg = flow_config(base, nu=0.025, dt=0.01)
+    vel = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n"
+           "-velocity_pc_type jacobi\n-velocity_pc_jacobi_type diagonal\n")
+    s = DecoupledIBPMSolver(cfg, bodies=[circle(126)], velocity_cfg=vel, poisson_cfg=AMGX_P.format(tol="1.0E-06"),
+                            forces_cfg=FORCES)
+    kl = G["koumoutsakos_leonard_1995_cylinder_re40"]
+    t_ref, cd_ref = 0.5 * np.array(kl["t_radius_units"]), np.array(kl["cd"])
+    for it in (200, 300, 400, 500):
+        s.advance(it - s.ite)
+        _, avg = s.getForces()
+        cd = 2.0 * avg[0][0]
+        assert abs(cd - np.interp(it * 0.01, t_ref, cd_ref)) < 0.05 * cd, (it, cd)
+        assert abs(avg[0][1]) < 1e-4
+    ite, vi, vr, pi, pr, fi, fr = s.linSolversInfo()
+    assert ite == 500 and vi < 30 and pi < 30 and fi == 1
+    s.destroy()

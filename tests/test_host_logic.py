@@ -131,12 +131,20 @@ def test_petsc_options_subset(capi):
     # another solver's prefix does not leak: KSP defaults (rtol 1e-5, atol 1e-50, 10000 its, CG)
     f = capi.config_describe("forces", PETSC_BOTH)
     assert f["method"] == "cg" and float(f["rtol"]) == 1e-5 and int(f["max_iters"]) == 10000
+    # every forces_solver.info of the reference's decoupled-IBPM examples: a direct solve
+    # (examples/decoupledibpm/cylinder2dRe40_GPU/config/forces_solver.info)
+    d = capi.config_describe("forces", "# forces solver: prefix `-forces_`\n-forces_ksp_type preonly\n-forces_pc_type lu\n"
+                                       "-forces_pc_factor_mat_solver_type superlu_dist\n")
+    assert d["method"] == "preonly" and d["pc"] == "lu"
+    a = capi.config_describe("forces", "config_version=2\nsolver(s)=DENSE_LU_SOLVER\n")
+    assert a["method"] == "preonly" and a["pc"] == "lu" and a["flavor"] == "amgx"
 
 
 @pytest.mark.parametrize("text,code", [
     ("solver(s)=FGMRES\n", 56), ("solver(s)=PCG\ns:preconditioner(p)=MULTICOLOR_DILU\n", 56),
     ("solver(s)=PCG\ns:convergence=RELATIVE_MAX\n", 56), ("solver(s)=PCG\ns:norm=L1\n", 56),
     ("this is not a config\n", 62), ("-poisson_ksp_type gmres\n", 56), ("-poisson_pc_type lu\n", 56),
+    ("-poisson_ksp_type preonly\n-poisson_pc_type jacobi\n", 56), ("-poisson_pc_type ilu\n", 56),
 ])
 def test_unsupported_config_is_an_error(capi, text, code):
     with pytest.raises(capi.PibError) as ei:
