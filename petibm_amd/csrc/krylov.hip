@@ -466,6 +466,21 @@ static int auto_batch(const pib_solver *s)
     int b = (int)std::ceil(0.5e-3 / t_iter);
     return std::max(1, std::min(b, 64));
 }
+// Iterations enqueued before the first / between later host polls.  Over-enqueued iterations are no-ops but still cost
+// a launch slot each (~1.6 us; rocprof on the 186^2 cylinder case: 33 iterations enqueued for 5 needed = 2.7 ms of a
+// 6.4 ms time step), so inside a time loop the first batch is the iteration count of the previous solve and the later
+// ones are short.
+static int first_batch(const pib_solver *s)
+{
+    if (s->cfg.check_every > 0) return s->cfg.check_every;
+    if (s->hint_iters > 0) return std::min(s->hint_iters, 256);
+    return std::min(auto_batch(s), 8);
+}
+static int next_batch(const pib_solver *s)
+{
+    if (s->cfg.check_every > 0) return s->cfg.check_every;
+    return std::max(1, std::min(auto_batch(s), 4));
+}
 
 int halo_exchange(pib_solver *s, double *x_owned, hipStream_t stq);
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t stq);
@@ -500,6 +515,7 @@ static int fetch_results(pib_solver *s)
 {
     PIB_CHK(poll(s));
     s->iters = s->h_s->its;
+    s->hint_iters = s->iters;
     s->reason = s->h_s->reason;
     s->residual = s->h_s->dp;
     s->history.assign((size_t)s->iters + 1, 0.0);
@@ -578,14 +594,14 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     PIB_HIP(hipGetLastError());
 
     // ---- iterations
-    const int batch = auto_batch(s);
+    const int batch0 = first_batch(s), batch1 = next_batch(s);
     const int spmv_blocks = spmv_launch_blocks();
     int enq = 0;
     const int maxit = s->cfg.max_iters;
     double *part_pw = s->d_part + (int64_t)SLOT_PW * PIB_MAXPART;
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
-        const int todo = std::min(batch, maxit - enq);
+        const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         for (int it = 0; it < todo; ++it) {
             OpUpdateP up{Z, P, 0.0, 0.0, 0};
             PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
@@ -924,12 +940,12 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     hipLaunchKernelGGL(k_b_s_init, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, monitor);
     PIB_HIP(hipGetLastError());
 
-    const int batch = auto_batch(s);
+    const int batch0 = first_batch(s), batch1 = next_batch(s);
     const int maxit = s->cfg.max_iters;
     int enq = 0;
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
-        const int todo = std::min(batch, maxit - enq);
+        const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         for (int it = 0; it < todo; ++it) {
             // p = r - omegaold*beta*v + beta*p  (+ ph = M^-1 p)
             if (jac) {

@@ -193,6 +193,7 @@ struct pib_solver {
     int64_t dense_n = 0;
     // results of the last solve
     int iters = 0, reason = 0;
+    int hint_iters = 0;  // iterations of the previous solve (first enqueue batch of the next one)
     double residual = 0.0;
     std::vector<double> history;
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
