@@ -177,3 +177,35 @@ def test_cylinder_re40_drag_matches_koumoutsakos_leonard():
     ite, vi, vr, pi, pr, fi, fr = s.linSolversInfo()
     assert ite == 500 and vi < 30 and pi < 30 and fi == 1
     s.destroy()
+
+
+def test_cylinder_re550_baseline_config4_drag():
+    """BASELINE config 4, the reference's examples/decoupledibpm/cylinder2dRe550_GPU verbatim: 450^2 stretched mesh
+    (ratios 0.980392156 / 1 / 1.02), 315 Lagrangian points, nu = 1/550, dt = 0.0025, 1200 steps, convective outlet.
+    Its plotDragCoefficient.py compares cd = 2 fx with Koumoutsakos & Leonard (1995) on 0 <= t <= 3.
+    The decoupled scheme enforces no-slip and continuity one after the other, so after an impulsive start the
+    projection restores most of the slip until the accumulated force has stopped the fluid inside the closed body:
+    a damped start-up oscillation of the force (oracle and device alike) that has died out by t = 1.75; from there
+    on the curve is the vortex-method one."""
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    sub = [{"end": -0.54, "cells": 171, "stretchRatio": 0.980392156}, {"end": 0.54, "cells": 108, "stretchRatio": 1.0},
+           {"end": 15.0, "cells": 171, "stretchRatio": 1.02}]
+    base = omesh.uniform_config((450, 450))
+    base["mesh"] = [{"direction": d, "start": -15.0, "subDomains": sub} for d in "xy"]
+    cfg = flow_config(base, nu=0.00181818181818, dt=0.0025)
+    vel = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n"
+           "-velocity_pc_type jacobi\n-velocity_pc_jacobi_type diagonal\n")
+    s = DecoupledIBPMSolver(cfg, bodies=[circle(315)], velocity_cfg=vel, poisson_cfg=AMGX_P.format(tol="1.0E-06"),
+                            forces_cfg=FORCES)
+    assert s.pN == 202500 and s.nf == 630
+    kl = G["koumoutsakos_leonard_1995_cylinder_re550"]
+    t_ref, cd_ref = 0.5 * np.array(kl["t_radius_units"]), np.array(kl["cd"])
+    worst_p = 0
+    for it in (700, 800, 900, 1000, 1100, 1200):
+        s.advance(it - s.ite)
+        _, avg = s.getForces()
+        cd = 2.0 * avg[0][0]
+        assert abs(cd - np.interp(it * 0.0025, t_ref, cd_ref)) < 0.04 * cd, (it, cd)
+        worst_p = max(worst_p, s.linSolversInfo()[3])
+    assert worst_p <= 12  # the multigrid keeps its uniform-mesh rate on this mesh (cell widths span a factor 29)
+    s.destroy()

@@ -554,6 +554,41 @@ def test_full_size_properties_256(lin):
     s.destroy()
 
 
+def test_full_size_stretched_mesh_config5(lin):
+    """BASELINE config 5's mesh class at full size: 384 x 256 x 256 cells, three sub-domains per axis (uniform block
+    around the body, geometric stretching outwards: the layout of examples/decoupledibpm/flatplate3dRe100AoA30_GPU),
+    25.2 M pressure unknowns.  Size-independent checks: zero row sums, and the multigrid-PCG solve meets the
+    residual contract (recomputed with the CSR operator) at the uniform-mesh iteration count."""
+    from petibm_amd import capi
+
+    n = [384, 256, 256]
+    w = []
+    for nd, span in zip(n, (12.0, 8.0, 8.0)):
+        a = (nd - nd // 3) // 2
+        sub = [{"end": -1.0, "cells": a, "stretchRatio": 1.0 / 1.02}, {"end": 1.0, "cells": nd - 2 * a, "stretchRatio": 1.0},
+               {"end": span, "cells": a, "stretchRatio": 1.02}]
+        w.append(omesh.parse_subdomains(sub, -span)[2])
+    assert [len(a) for a in w] == n and max(a.max() for a in w) / min(a.min() for a in w) > 10
+    s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(tol=1e-10) + "pib_initial_guess_nonzero=0\n")
+    s.assemblePoisson(n, w, 2e-3, capi.NULLSPACE_CONSTANT)
+    N = int(np.prod(n))
+    one, y = s.deviceVec(), s.deviceVec()
+    one.upload(np.ones(N))
+    s.matMult(one, y)
+    assert np.abs(y.download()).max() <= 1e-12
+    u = np.random.default_rng(20260928).uniform(-1, 1, N)
+    ud = s.deviceVec().upload(u)
+    s.matMult(ud, y)
+    b = y.download()
+    b -= b.mean()
+    bd, xd = s.deviceVec().upload(b), s.deviceVec()
+    s.solve(xd, bd)
+    s.matMult(xd, y)
+    assert np.linalg.norm(b - y.download()) <= 1.5e-10 * np.linalg.norm(b)
+    assert s.getIters() <= 22
+    s.destroy()
+
+
 def test_cpp_host_mirror_demo_runs():
     """include/petibm_amd/linsolver.hpp (the C++ mirror of petibm::linsolver) over the C ABI, from a plain
     g++ program: createLinSolver -> setMatrix -> setGridHint -> solve -> getIters/getResidual."""
