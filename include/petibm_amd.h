@@ -242,6 +242,11 @@ int pib_ns_destroy(pib_ns *ns);
  * Errors: unknown kernel -> PIB_ERR_ARG_UNKNOWN_TYPE, a point outside the domain -> PIB_ERR_MAX_VALUE. */
 int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double *coords, const char *delta_kernel,
                       const char *forces_cfg);
+/* RigidKinematicsSolver::moveBodies (applications/rigidkinematics/rigidkinematics.cpp:118-140): new coordinates of all
+ * points (layout of pib_ns_set_bodies) and, if not NULL, their prescribed velocities UB [nf]: the operators are
+ * re-assembled on the device, the forces solver receives the new EBNH and the forces right-hand side becomes
+ * UB - E u (:147-160).  Call before pib_ns_advance(ns, 1) of the step that ends at the new position. */
+int pib_ns_move_bodies(pib_ns *ns, const double *coords, const double *body_velocity);
 int pib_ns_num_forces(pib_ns *ns, int64_t *nf, int *nbodies);
 /* Lagrangian forces f [nf] and/or the bodies' forces [nbodies*dim] = minus the sum over the body's points
  * (src/body/singlebodypoints.cpp:228-259; one line of forces-<start>.txt, decoupledibpm.cpp:437-465) */

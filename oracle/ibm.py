@@ -177,6 +177,17 @@ class DecoupledIBPM(ons.NavierStokes):
         self.nf = self.ops["E"].n_rows
         self.f = np.zeros(self.nf)
         self.EBNH_dense = self.ops["EBNH"].to_dense()
+        self.kernel_name = kernel_name
+        self.UB = None
+
+    def move_bodies(self, bodies, velocities=None):
+        """RigidKinematicsSolver::moveBodies (applications/rigidkinematics/rigidkinematics.cpp:118-140): new
+        coordinates, prescribed point velocities UB, operators rebuilt, fSolver->setMatrix(EBNH)"""
+        self.bodies = [np.asarray(b, dtype=np.float64) for b in bodies]
+        self.ops = create_ib_operators(self.mesh, self.bodies, self.dt, self.kernel_name)
+        self.EBNH_dense = self.ops["EBNH"].to_dense()
+        if velocities is not None:
+            self.UB = np.concatenate([np.asarray(v, dtype=np.float64) for v in velocities], axis=0).reshape(-1)
 
     def advance(self):
         rhs1 = self.rhs_velocity()
@@ -189,6 +200,8 @@ class DecoupledIBPM(ons.NavierStokes):
         self.info["vIters"] = r["iters"]
         rhsf = clib.spmv(self.ops["E"], self.U)
         rhsf = -1.0 * rhsf
+        if self.UB is not None:
+            rhsf = self.UB + 1.0 * rhsf  # VecAYPX(rhsf, 1.0, UB)  (rigidkinematics.cpp:157)
         self.last_rhsf = rhsf
         df = np.linalg.solve(self.EBNH_dense, rhsf)  # -forces_ksp_type preonly -forces_pc_type lu
         self.U = mult_add(self.ops["BNH"], df, self.U)  # MatMultAdd(BNH, df, U, U)

@@ -75,6 +75,7 @@ _PROTOS = {
                                          C.POINTER(C.c_double)]),
     "pib_ns_destroy": (C.c_int, [_vp]),
     "pib_ns_set_bodies": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_char_p, C.c_char_p]),
+    "pib_ns_move_bodies": (C.c_int, [_vp, _vp, _vp]),
     "pib_ns_num_forces": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int)]),
     "pib_ns_get_forces": (C.c_int, [_vp, _vp, _vp]),
     "pib_ns_set_forces": (C.c_int, [_vp, _vp]),

@@ -51,7 +51,11 @@ struct IbState {
     double *c_val = nullptr;
     int64_t c_nnz = 0;
     double *f = nullptr, *df = nullptr, *rhsf = nullptr;
-    std::vector<void *> owned;
+    double *ub = nullptr;     // prescribed velocity of the Lagrangian points (RigidKinematicsSolver: rhsf = UB - E u)
+    bool moving = false;
+    double dt = 0.0;
+    std::vector<void *> owned;      // operators of the current body position (released by every re-assembly)
+    std::vector<void *> persistent; // forces and friends: live as long as the bodies
 };
 
 void ib_release(IbState *ib)
@@ -59,6 +63,7 @@ void ib_release(IbState *ib)
     if (ib == nullptr) return;
     if (ib->fsol) pib_destroy(ib->fsol);
     for (void *p : ib->owned) (void)hipFree(p);
+    for (void *p : ib->persistent) (void)hipFree(p);
     delete ib;
 }
 
@@ -243,15 +248,17 @@ __global__ __launch_bounds__(256) void k_ib_spread(int64_t hrows, double scale, 
     }
 }
 
-// rhsf = -(E u)
+// rhsf = -(E u)  (decoupledibpm.cpp:251-252);  with ub: rhsf = UB + 1.0 * rhsf  (rigidkinematics.cpp:155-157, VecAYPX)
 __global__ __launch_bounds__(256) void k_ib_interp(int64_t nf, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const double *__restrict__ eval, const double *__restrict__ U,
-                                                   double *__restrict__ rhsf)
+                                                   const double *__restrict__ ub, double *__restrict__ rhsf)
 {
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nf; r += (int64_t)gridDim.x * 256) {
         double s = 0.0;
         for (int32_t q = rowptr[r]; q < rowptr[r + 1]; ++q) s = s + eval[q] * U[col[q]];
-        rhsf[r] = -1.0 * s;
+        double v = -1.0 * s;
+        if (ub != nullptr) v = ub[r] + 1.0 * v;
+        rhsf[r] = v;
     }
 }
 
@@ -303,7 +310,8 @@ int ib_solve_forces(pib_ns *ns)
 {
     IbState *ib = ns->ib;
     const int64_t nf = ib->I.nf;
-    hipLaunchKernelGGL(k_ib_interp, dim3(blocks_for(nf)), dim3(256), 0, ns->stream, nf, ib->rowptr, ib->col, ib->eval, ns->U, ib->rhsf);
+    hipLaunchKernelGGL(k_ib_interp, dim3(blocks_for(nf)), dim3(256), 0, ns->stream, nf, ib->rowptr, ib->col, ib->eval, ns->U,
+                       ib->moving ? ib->ub : (const double *)nullptr, ib->rhsf);
     PIB_HIP(hipGetLastError());
     PIB_HIP(hipStreamSynchronize(ns->stream));
     PIB_CHK(pib_solve(ib->fsol, ib->df, ib->rhsf));  // fSolver->solve(df, rhsf)  (decoupledibpm.cpp:267)
@@ -324,6 +332,109 @@ int ib_update_forces(pib_ns *ns)
 }  // namespace pib
 
 extern "C" {
+
+// (re-)assemble Delta, E, H, EBNH for the point coordinates `coords` and hand EBNH to the forces solver
+static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
+{
+    using namespace pib;
+    for (void *p : ib->owned) (void)hipFree(p);
+    ib->owned.clear();
+    const int dim = ns->D.dim;
+    const int64_t total = ib->I.npts;
+    int err = 0;
+    // background cells (singlebodypoints.cpp:90-113) and kernel widths (createdelta.cpp:69-76) on the host
+    std::vector<int> ijk((size_t)(total * dim));
+    std::vector<double> h((size_t)(total * dim));
+    int64_t p0 = 0;
+    for (int b = 0; b < ib->nbodies; ++b) {
+        const int64_t nb = ib->npts[(size_t)b];
+        for (int64_t q = p0; q < p0 + nb; ++q)
+            for (int d = 0; d < dim; ++d) {
+                const double x = coords[q * dim + d];
+                if (ns->lo[d] >= x || ns->hi[d] <= x)
+                    return fail(PIB_ERR_MAX_VALUE, "body coordinate %g is outside domain [%g, %g] !", x, ns->lo[d], ns->hi[d]);
+                const std::vector<double> &v = ns->h_vtx[d];
+                ijk[(size_t)(q * dim + d)] = (int)(std::upper_bound(v.begin(), v.end(), x) - v.begin()) - 1;
+            }
+        for (int64_t q = p0; q < p0 + nb; ++q)
+            for (int d = 0; d < dim; ++d) h[(size_t)(q * dim + d)] = ns->h_dlu[d][(size_t)ijk[(size_t)(p0 * dim + d)] + 1];
+        p0 += nb;
+    }
+    IbDev &I = ib->I;
+    double *dX = nullptr, *dh = nullptr;
+    int *dijk = nullptr;
+    if ((err = dev_alloc(ib, &dX, total * dim)) || (err = dev_alloc(ib, &dh, total * dim)) || (err = dev_alloc(ib, &dijk, total * dim)))
+        return err;
+    PIB_HIP(hipMemcpy(dX, coords, sizeof(double) * (size_t)(total * dim), hipMemcpyHostToDevice));
+    PIB_HIP(hipMemcpy(dh, h.data(), sizeof(double) * (size_t)(total * dim), hipMemcpyHostToDevice));
+    PIB_HIP(hipMemcpy(dijk, ijk.data(), sizeof(int) * (size_t)(total * dim), hipMemcpyHostToDevice));
+    I.X = dX;
+    I.h = dh;
+    I.ijk = dijk;
+    hipStream_t q = ns->stream;
+    const int64_t nf = I.nf;
+    // ---- Delta / E
+    int32_t *count = nullptr;
+    if ((err = dev_alloc(ib, &count, nf)) || (err = dev_alloc(ib, &ib->rowptr, nf + 1))) return err;
+    const unsigned gb = (unsigned)((nf + 127) / 128);
+    hipLaunchKernelGGL(k_ib_delta<false>, dim3(gb), dim3(128), 0, q, ns->D, I, count, (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (double *)nullptr, (double *)nullptr);
+    PIB_HIP(hipGetLastError());
+    if ((err = scan_counts(count, nf, ib->rowptr, &ib->nnz, q))) return err;
+    if ((err = dev_alloc(ib, &ib->col, ib->nnz)) || (err = dev_alloc(ib, &ib->val, ib->nnz)) || (err = dev_alloc(ib, &ib->eval, ib->nnz)))
+        return err;
+    hipLaunchKernelGGL(k_ib_delta<true>, dim3(gb), dim3(128), 0, q, ns->D, I, count, ib->rowptr, ib->col, ib->val, ib->eval);
+    PIB_HIP(hipGetLastError());
+    // ---- H = Delta^T: sort the entries by (velocity point, row)
+    {
+        const int64_t nnz = ib->nnz;
+        uint64_t *k_in = nullptr, *k_out = nullptr;
+        int32_t *i_in = nullptr, *i_out = nullptr, *head = nullptr, *pos = nullptr;
+        if ((err = dev_alloc(ib, &k_in, nnz)) || (err = dev_alloc(ib, &k_out, nnz)) || (err = dev_alloc(ib, &i_in, nnz)) ||
+            (err = dev_alloc(ib, &i_out, nnz)) || (err = dev_alloc(ib, &head, nnz)) || (err = dev_alloc(ib, &pos, nnz)) ||
+            (err = dev_alloc(ib, &ib->hrow, nnz)) || (err = dev_alloc(ib, &ib->hval, nnz)))
+            return err;
+        hipLaunchKernelGGL(k_ib_keys, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, k_in, i_in);
+        PIB_HIP(hipGetLastError());
+        size_t tmp_bytes = 0;
+        void *tmp = nullptr;
+        PIB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)nnz, 0, 64, q));
+        PIB_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+        ib->owned.push_back(tmp);
+        PIB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)nnz, 0, 64, q));
+        hipLaunchKernelGGL(k_ib_hfill, dim3(blocks_for(nnz)), dim3(256), 0, q, nnz, nf, k_out, i_out, ib->val, ib->hrow, ib->hval, head);
+        PIB_HIP(hipGetLastError());
+        size_t tmp2_bytes = 0;
+        void *tmp2 = nullptr;
+        PIB_HIP(rocprim::inclusive_scan(nullptr, tmp2_bytes, head, pos, (size_t)nnz, rocprim::plus<int32_t>(), q));
+        PIB_HIP(hipMalloc(&tmp2, std::max<size_t>(tmp2_bytes, 16)));
+        ib->owned.push_back(tmp2);
+        PIB_HIP(rocprim::inclusive_scan(tmp2, tmp2_bytes, head, pos, (size_t)nnz, rocprim::plus<int32_t>(), q));
+        int32_t m = 0;
+        if (nnz > 0) PIB_HIP(hipMemcpyAsync(&m, pos + (nnz - 1), sizeof(int32_t), hipMemcpyDeviceToHost, q));
+        PIB_HIP(hipStreamSynchronize(q));
+        ib->hrows = m;
+        if ((err = dev_alloc(ib, &ib->hcols, m)) || (err = dev_alloc(ib, &ib->hptr, (int64_t)m + 1))) return err;
+        hipLaunchKernelGGL(k_ib_hrows, dim3(blocks_for(nnz)), dim3(256), 0, q, nnz, nf, k_out, head, pos, ib->hcols, ib->hptr);
+        PIB_HIP(hipGetLastError());
+        const int32_t last = (int32_t)nnz;
+        PIB_HIP(hipMemcpyAsync(ib->hptr + m, &last, sizeof(int32_t), hipMemcpyHostToDevice, q));
+        PIB_HIP(hipStreamSynchronize(q));
+    }
+    // ---- EBNH = E (BN H)
+    if ((err = dev_alloc(ib, &ib->c_rowptr, nf + 1))) return err;
+    hipLaunchKernelGGL(k_ib_ebnh<false>, dim3((unsigned)nf), dim3(64), 0, q, I, ns->dt, ib->rowptr, ib->col, ib->val, ib->eval, count,
+                       (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
+    PIB_HIP(hipGetLastError());
+    if ((err = scan_counts(count, nf, ib->c_rowptr, &ib->c_nnz, q))) return err;
+    if ((err = dev_alloc(ib, &ib->c_col, ib->c_nnz)) || (err = dev_alloc(ib, &ib->c_val, ib->c_nnz))) return err;
+    hipLaunchKernelGGL(k_ib_ebnh<true>, dim3((unsigned)nf), dim3(64), 0, q, I, ns->dt, ib->rowptr, ib->col, ib->val, ib->eval, count,
+                       ib->c_rowptr, ib->c_col, ib->c_val);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipStreamSynchronize(q));
+    // fSolver->setMatrix(EBNH)  (decoupledibpm.cpp:80, rigidkinematics.cpp:139)
+    return adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val);
+}
 
 int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double *coords, const char *delta_kernel,
                       const char *forces_cfg)
@@ -353,105 +464,42 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
         ib->npts.push_back(npts[b]);
         total += npts[b];
     }
-    // background cells (singlebodypoints.cpp:90-113) and kernel widths (createdelta.cpp:69-76) on the host
-    std::vector<int> ijk((size_t)(total * dim));
-    std::vector<double> h((size_t)(total * dim));
-    int64_t p0 = 0;
-    for (int b = 0; b < nbodies; ++b) {
-        for (int64_t q = p0; q < p0 + npts[b]; ++q)
-            for (int d = 0; d < dim; ++d) {
-                const double x = coords[q * dim + d];
-                if (ns->lo[d] >= x || ns->hi[d] <= x)
-                    return bail(fail(PIB_ERR_MAX_VALUE, "body coordinate %g is outside domain [%g, %g] !", x, ns->lo[d], ns->hi[d]));
-                const std::vector<double> &v = ns->h_vtx[d];
-                ijk[(size_t)(q * dim + d)] = (int)(std::upper_bound(v.begin(), v.end(), x) - v.begin()) - 1;
-            }
-        for (int64_t q = p0; q < p0 + npts[b]; ++q)
-            for (int d = 0; d < dim; ++d) h[(size_t)(q * dim + d)] = ns->h_dlu[d][(size_t)ijk[(size_t)(p0 * dim + d)] + 1];
-        p0 += npts[b];
-    }
     IbDev &I = ib->I;
     I.dim = dim;
     I.window = window;
     I.kernel = kernel;
     I.npts = total;
     I.nf = total * dim;
-    double *dX = nullptr, *dh = nullptr;
-    int *dijk = nullptr;
-    if ((err = dev_alloc(ib, &dX, total * dim)) || (err = dev_alloc(ib, &dh, total * dim)) || (err = dev_alloc(ib, &dijk, total * dim)))
-        return bail(err);
-    PIB_HIP(hipMemcpy(dX, coords, sizeof(double) * (size_t)(total * dim), hipMemcpyHostToDevice));
-    PIB_HIP(hipMemcpy(dh, h.data(), sizeof(double) * (size_t)(total * dim), hipMemcpyHostToDevice));
-    PIB_HIP(hipMemcpy(dijk, ijk.data(), sizeof(int) * (size_t)(total * dim), hipMemcpyHostToDevice));
-    I.X = dX;
-    I.h = dh;
-    I.ijk = dijk;
-    hipStream_t q = ns->stream;
-    const int64_t nf = I.nf;
-    // ---- Delta / E
-    int32_t *count = nullptr;
-    if ((err = dev_alloc(ib, &count, nf)) || (err = dev_alloc(ib, &ib->rowptr, nf + 1))) return bail(err);
-    const unsigned gb = (unsigned)((nf + 127) / 128);
-    hipLaunchKernelGGL(k_ib_delta<false>, dim3(gb), dim3(128), 0, q, ns->D, I, count, (const int32_t *)nullptr, (int32_t *)nullptr,
-                       (double *)nullptr, (double *)nullptr);
-    PIB_HIP(hipGetLastError());
-    if ((err = scan_counts(count, nf, ib->rowptr, &ib->nnz, q))) return bail(err);
-    if ((err = dev_alloc(ib, &ib->col, ib->nnz)) || (err = dev_alloc(ib, &ib->val, ib->nnz)) || (err = dev_alloc(ib, &ib->eval, ib->nnz)))
-        return bail(err);
-    hipLaunchKernelGGL(k_ib_delta<true>, dim3(gb), dim3(128), 0, q, ns->D, I, count, ib->rowptr, ib->col, ib->val, ib->eval);
-    PIB_HIP(hipGetLastError());
-    // ---- H = Delta^T: sort the entries by (velocity point, row)
-    {
-        const int64_t nnz = ib->nnz;
-        uint64_t *k_in = nullptr, *k_out = nullptr;
-        int32_t *i_in = nullptr, *i_out = nullptr, *head = nullptr, *pos = nullptr;
-        if ((err = dev_alloc(ib, &k_in, nnz)) || (err = dev_alloc(ib, &k_out, nnz)) || (err = dev_alloc(ib, &i_in, nnz)) ||
-            (err = dev_alloc(ib, &i_out, nnz)) || (err = dev_alloc(ib, &head, nnz)) || (err = dev_alloc(ib, &pos, nnz)) ||
-            (err = dev_alloc(ib, &ib->hrow, nnz)) || (err = dev_alloc(ib, &ib->hval, nnz)))
-            return bail(err);
-        hipLaunchKernelGGL(k_ib_keys, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, k_in, i_in);
-        PIB_HIP(hipGetLastError());
-        size_t tmp_bytes = 0;
-        void *tmp = nullptr;
-        PIB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)nnz, 0, 64, q));
-        PIB_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-        ib->owned.push_back(tmp);
-        PIB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)nnz, 0, 64, q));
-        hipLaunchKernelGGL(k_ib_hfill, dim3(blocks_for(nnz)), dim3(256), 0, q, nnz, nf, k_out, i_out, ib->val, ib->hrow, ib->hval, head);
-        PIB_HIP(hipGetLastError());
-        size_t tmp2_bytes = 0;
-        void *tmp2 = nullptr;
-        PIB_HIP(rocprim::inclusive_scan(nullptr, tmp2_bytes, head, pos, (size_t)nnz, rocprim::plus<int32_t>(), q));
-        PIB_HIP(hipMalloc(&tmp2, std::max<size_t>(tmp2_bytes, 16)));
-        ib->owned.push_back(tmp2);
-        PIB_HIP(rocprim::inclusive_scan(tmp2, tmp2_bytes, head, pos, (size_t)nnz, rocprim::plus<int32_t>(), q));
-        int32_t m = 0;
-        if (nnz > 0) PIB_HIP(hipMemcpyAsync(&m, pos + (nnz - 1), sizeof(int32_t), hipMemcpyDeviceToHost, q));
-        PIB_HIP(hipStreamSynchronize(q));
-        ib->hrows = m;
-        if ((err = dev_alloc(ib, &ib->hcols, m)) || (err = dev_alloc(ib, &ib->hptr, (int64_t)m + 1))) return bail(err);
-        hipLaunchKernelGGL(k_ib_hrows, dim3(blocks_for(nnz)), dim3(256), 0, q, nnz, nf, k_out, head, pos, ib->hcols, ib->hptr);
-        PIB_HIP(hipGetLastError());
-        const int32_t last = (int32_t)nnz;
-        PIB_HIP(hipMemcpyAsync(ib->hptr + m, &last, sizeof(int32_t), hipMemcpyHostToDevice, q));
-        PIB_HIP(hipStreamSynchronize(q));
-    }
-    // ---- EBNH = E (BN H)
-    if ((err = dev_alloc(ib, &ib->c_rowptr, nf + 1))) return bail(err);
-    hipLaunchKernelGGL(k_ib_ebnh<false>, dim3((unsigned)nf), dim3(64), 0, q, I, ns->dt, ib->rowptr, ib->col, ib->val, ib->eval, count,
-                       (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
-    PIB_HIP(hipGetLastError());
-    if ((err = scan_counts(count, nf, ib->c_rowptr, &ib->c_nnz, q))) return bail(err);
-    if ((err = dev_alloc(ib, &ib->c_col, ib->c_nnz)) || (err = dev_alloc(ib, &ib->c_val, ib->c_nnz))) return bail(err);
-    hipLaunchKernelGGL(k_ib_ebnh<true>, dim3((unsigned)nf), dim3(64), 0, q, I, ns->dt, ib->rowptr, ib->col, ib->val, ib->eval, count,
-                       ib->c_rowptr, ib->c_col, ib->c_val);
-    PIB_HIP(hipGetLastError());
-    PIB_HIP(hipStreamSynchronize(q));
-    // ---- forces solver (decoupledibpm.cpp:75-80: createLinSolver("forces", ...), setMatrix(EBNH))
+    // forces solver (decoupledibpm.cpp:75-80: createLinSolver("forces", ...)) and the force vectors
     if ((err = pib_create_from_string(&ib->fsol, "forces", forces_cfg ? forces_cfg : "", 0, 1, nullptr, ns->device))) return bail(err);
-    if ((err = adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val))) return bail(err);
-    if ((err = dev_alloc(ib, &ib->f, nf)) || (err = dev_alloc(ib, &ib->df, nf)) || (err = dev_alloc(ib, &ib->rhsf, nf))) return bail(err);
+    auto palloc = [&](double **p) -> int {
+        PIB_HIP(hipMalloc(p, sizeof(double) * (size_t)I.nf));
+        PIB_HIP(hipMemset(*p, 0, sizeof(double) * (size_t)I.nf));
+        ib->persistent.push_back(*p);
+        return 0;
+    };
+    if ((err = palloc(&ib->f)) || (err = palloc(&ib->df)) || (err = palloc(&ib->rhsf)) || (err = palloc(&ib->ub))) return bail(err);
+    if ((err = ib_assemble(ns, ib, coords))) return bail(err);
     ns->ib = ib;
+    return 0;
+}
+
+/* RigidKinematicsSolver::moveBodies (applications/rigidkinematics/rigidkinematics.cpp:118-140): new coordinates of
+ * every Lagrangian point and their prescribed velocities UB [nf]; the operators are re-assembled, the forces solver
+ * gets the new EBNH, and the forces right-hand side becomes UB - E u (:147-160).  The accumulated forces stay. */
+int pib_ns_move_bodies(pib_ns *ns, const double *coords, const double *ub)
+{
+    using namespace pib;
+    if (ns == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_move_bodies: null argument");
+    if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_move_bodies: the flow has no immersed bodies");
+    PIB_HIP(hipSetDevice(ns->device));
+    PIB_HIP(hipStreamSynchronize(ns->stream));
+    IbState *ib = ns->ib;
+    PIB_CHK(ib_assemble(ns, ib, coords));
+    if (ub != nullptr) {
+        PIB_HIP(hipMemcpy(ib->ub, ub, sizeof(double) * (size_t)ib->I.nf, hipMemcpyHostToDevice));
+        ib->moving = true;
+    }
     return 0;
 }
 

@@ -197,6 +197,17 @@ class DecoupledIBPMSolver(NavierStokesSolver):
         capi.check(capi.load().pib_ns_num_forces(self._h, C.byref(nf), C.byref(nb)))
         self.nf, self.nBodies = nf.value, nb.value
 
+    def moveBodies(self, bodies, velocities=None):
+        """RigidKinematicsSolver::moveBodies (applications/rigidkinematics/rigidkinematics.cpp:118-140): new point
+        coordinates per body and their prescribed velocities (same shapes); call before the `advance()` of the step."""
+        self.bodies = [np.ascontiguousarray(b, dtype=np.float64) for b in bodies]
+        coords = np.ascontiguousarray(np.concatenate(self.bodies, axis=0))
+        ub = None if velocities is None else np.ascontiguousarray(
+            np.concatenate([np.asarray(v, dtype=np.float64) for v in velocities], axis=0)).reshape(-1)
+        if coords.shape[0] * self.dim != self.nf or (ub is not None and ub.size != self.nf):
+            raise capi.PibError(capi.ERR_ARG_WRONG, "moveBodies: the number of Lagrangian points must not change")
+        capi.check(capi.load().pib_ns_move_bodies(self._h, coords.ctypes.data, None if ub is None else ub.ctypes.data))
+
     def getForces(self):
         """(Lagrangian forces f, per-body forces): the second is one line of forces-<start>.txt (decoupledibpm.cpp:437-465)"""
         f = np.empty(self.nf)

@@ -139,6 +139,50 @@ def test_decoupled_ibpm_step_matches_oracle(case):
     s.destroy()
 
 
+def test_moving_body_matches_oracle():
+    """RigidKinematicsSolver (applications/rigidkinematics): a cylinder oscillating in a closed box of fluid at rest.
+    Every step moves the points, re-assembles Delta / E / H / EBNH on the device, re-factorises the force system and
+    uses rhsf = UB - E u."""
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    cfg = body_mesh(cells=(6, 20, 6), ratio=1.3, span=2.0, core=1.0)
+    cfg["flow"]["nu"] = 0.02
+    cfg["parameters"] = {"dt": 0.01, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    m = omesh.create_mesh(cfg)
+    base = circle(36, r=0.3)
+    amp, om, dt = 0.25, 2.0 * np.pi, 0.01
+
+    def pose(t):
+        x = base + np.array([amp * np.sin(om * t), 0.0])
+        v = np.tile([amp * om * np.cos(om * t), 0.0], (base.shape[0], 1))
+        return x, v
+
+    ref = ibm.DecoupledIBPM(m, dt, 0.02, [base], pinned=False, vtol=1e-14, ptol=1e-13)
+    ref.set_state(np.zeros(m.UN), np.zeros(m.pN))
+    kspp = ("-poisson_ksp_type cg\n-poisson_ksp_atol 1.0E-13\n-poisson_ksp_rtol 0.0\n-poisson_ksp_max_it 500\n"
+            "-poisson_ksp_norm_type unpreconditioned\n-poisson_pc_type gamg\n-poisson_pib_smoother JACOBI\n")
+    s = DecoupledIBPMSolver(cfg, bodies=[base], velocity_cfg=VEL, poisson_cfg=kspp, forces_cfg=FORCES)
+    for step in range(1, 6):
+        x, v = pose(step * dt)  # moveBodies(t + dt) precedes the step (rigidkinematics.cpp:75-79)
+        ref.move_bodies([x], [v])
+        s.moveBodies([x], [v])
+        nr, rp, cl, vl = s.getOperator("EBNH")
+        r = ref.ops["EBNH"]
+        assert np.array_equal(rp, r.rowptr) and np.array_equal(cl, r.col) and np.array_equal(vl, r.val)
+        ref.advance()
+        s.advance()
+        U, p = s.getState()
+        f, avg = s.getForces()
+        assert np.abs(U - ref.U).max() <= 1e-8 * np.abs(ref.U).max()
+        assert np.abs(f - ref.f).max() <= 1e-7 * np.abs(ref.f).max()
+    # the fluid follows the body: the interpolated velocity at the points is close to the prescribed one
+    eu = clib.spmv(ref.ops["E"], U)
+    ub = pose(5 * dt)[1].reshape(-1)
+    assert np.linalg.norm(eu - ub) < 0.5 * np.linalg.norm(ub)
+    with pytest.raises(Exception):
+        s.moveBodies([base[:10]])
+    s.destroy()
+
+
 def test_errors_of_the_body_input():
     from petibm_amd import capi
     from petibm_amd.navierstokes import DecoupledIBPMSolver
