@@ -907,9 +907,44 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
     return gmg_verify(s);
 }
 
+// Halo/compute overlap (cfg.overlap_halo): a kernel that PRODUCES a vector whose halo the next kernel needs runs
+// its two boundary planes first; their exchange goes to the communication stream and overlaps the interior planes
+// of the same producer; the consumer-side halo_level() call that follows finds the halo fresh and does nothing.
+static int halo_level_async(pib_solver *s, const GridLevel &g, double *x_owned, hipStream_t q)
+{
+    const int r = s->comm.rank, P = s->comm.nranks;
+    const int64_t pl = g.plane;
+    PIB_HIP(hipEventRecord(s->ev_ready, q));
+    PIB_HIP(hipStreamWaitEvent(s->stream_comm, s->ev_ready, 0));
+    PIB_CHK(halo_exchange_planes(s, x_owned, g.nloc, r > 0 ? pl : 0, r < P - 1 ? pl : 0, r > 0 ? pl : 0, r < P - 1 ? pl : 0,
+                                 s->stream_comm));
+    PIB_HIP(hipEventRecord(s->ev_halo, s->stream_comm));
+    return 0;
+}
+
+// launch(kb, kc) runs the producer on the owned planes [kb, kb + kc) of level g
+template <class F>
+static int produce_and_exchange(pib_solver *s, const GridLevel &g, double *vec, hipStream_t q, F launch)
+{
+    const int64_t nk = g.k1 - g.k0;
+    if (s->comm.nranks <= 1 || g.replicated || !s->cfg.overlap_halo || nk < 4) return launch((int64_t)0, nk);
+    PIB_CHK(launch((int64_t)0, (int64_t)1));
+    PIB_CHK(launch(nk - 1, (int64_t)1));
+    PIB_CHK(halo_level_async(s, g, vec, q));
+    PIB_CHK(launch((int64_t)1, nk - 2));
+    PIB_HIP(hipStreamWaitEvent(q, s->ev_halo, 0));
+    s->halo_fresh = vec;
+    return 0;
+}
+
 static int halo_level(pib_solver *s, const GridLevel &g, double *x_owned, hipStream_t q)
 {
     if (s->comm.nranks <= 1 || g.replicated) return 0;
+    if (s->halo_fresh == x_owned) {  // exchanged by its producer (produce_and_exchange)
+        s->halo_fresh = nullptr;
+        return 0;
+    }
+    s->halo_fresh = nullptr;
     const int r = s->comm.rank, P = s->comm.nranks;
     const int64_t pl = g.plane;
     return halo_exchange_planes(s, x_owned, g.nloc, r > 0 ? pl : 0, r < P - 1 ? pl : 0, r > 0 ? pl : 0, r < P - 1 ? pl : 0, q);
@@ -951,6 +986,20 @@ static int launch_level(pib_solver *s, const GridLevel &g, double omega, const d
     return 0;
 }
 
+// the same on the owned planes [kb, kb + kc) only
+template <int MODE>
+static int launch_level_planes(pib_solver *s, const GridLevel &g, int64_t kb, int64_t kc, double omega, const double *b,
+                               const double *xi, double *xo, const double *pin_sum, bool guarded, hipStream_t q,
+                               double *dvec = nullptr, double a_d = 0.0)
+{
+    if (kc <= 0) return 0;
+    GridLevel sub = g;
+    sub.k0 = g.k0 + kb;
+    sub.k1 = sub.k0 + kc;
+    const int64_t o = kb * g.plane;
+    return launch_level<MODE>(s, sub, omega, b ? b + o : b, xi ? xi + o : xi, xo + o, pin_sum, guarded, q, dvec ? dvec + o : dvec, a_d);
+}
+
 // One V-cycle: z = M^-1 r.   r, z: ghost-padded work vectors of the Krylov solver
 // (their ghost planes double as the level-0 halo planes).
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
@@ -960,6 +1009,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     if (!s->gmg_error.empty()) return fail(PIB_ERR_SUP, "solver %s: %s", s->name.c_str(), s->gmg_error.c_str());
     const bool guarded = s->gmg_guarded;
     const Scalars *S = guarded ? s->d_s : nullptr;
+    s->halo_fresh = nullptr;
     const double omega = s->cfg.smoother_relaxation;
     const bool cheb0 = (s->cfg.smoother == Smoother::CHEBYSHEV);
     const int deg = cheb0 ? std::max(1, s->cfg.cheby_degree) : 1;  // one Chebyshev "sweep" = a degree-`deg` polynomial
@@ -974,15 +1024,19 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     // Jacobi: x <- x + omega D^-1 (b - A x).  Chebyshev-Jacobi: three-term recurrence over [lmin, lmax] of D^-1 A,
     // restarted for every segment (oracle/csrc/gmg.c:cheby).
     auto smooth_seq = [&](GridLevel &g, const double *b, const double *pin_l, double *&a, double *&c, int nsteps,
-                          bool from_zero) -> int {
+                          bool from_zero, bool halo_after_last) -> int {
         double rho = 1.0 / sigma;
         double *dvec = g.d + g.plane;
         for (int sw = 0; sw < nsteps; ++sw) {
+            // every step but the last of the up-leg feeds a kernel that needs its halo
+            const bool feeds = (sw + 1 < nsteps) || halo_after_last;
             if (from_zero && sw == 0) {
-                if (cheb)
-                    PIB_CHK(launch_level<6>(s, g, 1.0 / theta, b, nullptr, a, pin_l, guarded, q, dvec, 0.0));
-                else
-                    PIB_CHK(launch_level<1>(s, g, omega, b, nullptr, a, pin_l, guarded, q));
+                double *out = a;
+                auto run = [&](int64_t kb, int64_t kc) -> int {
+                    if (cheb) return launch_level_planes<6>(s, g, kb, kc, 1.0 / theta, b, nullptr, out, pin_l, guarded, q, dvec, 0.0);
+                    return launch_level_planes<1>(s, g, kb, kc, omega, b, nullptr, out, pin_l, guarded, q);
+                };
+                if (feeds) PIB_CHK(produce_and_exchange(s, g, out, q, run)); else PIB_CHK(run(0, g.k1 - g.k0));
                 continue;
             }
             PIB_CHK(halo_level(s, g, a, q));
@@ -994,9 +1048,19 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                     a_z = 2.0 * rho_new / delta;
                     rho = rho_new;
                 }
-                PIB_CHK(launch_level<5>(s, g, a_z, b, a, c, pin_l, guarded, q, dvec, a_d));
+                const double *in = a;
+                double *out = c;
+                auto run = [&](int64_t kb, int64_t kc) -> int {
+                    return launch_level_planes<5>(s, g, kb, kc, a_z, b, in, out, pin_l, guarded, q, dvec, a_d);
+                };
+                if (feeds) PIB_CHK(produce_and_exchange(s, g, out, q, run)); else PIB_CHK(run(0, g.k1 - g.k0));
             } else {
-                PIB_CHK(launch_level<2>(s, g, omega, b, a, c, pin_l, guarded, q));
+                const double *in = a;
+                double *out = c;
+                auto run = [&](int64_t kb, int64_t kc) -> int {
+                    return launch_level_planes<2>(s, g, kb, kc, omega, b, in, out, pin_l, guarded, q);
+                };
+                if (feeds) PIB_CHK(produce_and_exchange(s, g, out, q, run)); else PIB_CHK(run(0, g.k1 - g.k0));
             }
             std::swap(a, c);
         }
@@ -1067,10 +1131,16 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // final buffer after `swaps` swaps starting from a: a if even else c
             if (swaps % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
         }
-        PIB_CHK(smooth_seq(g, b, pin_l, a, c, pre, true));
+        PIB_CHK(smooth_seq(g, b, pin_l, a, c, pre, true, true));
         PIB_CHK(halo_level(s, g, a, q));
         double *rr = g.r + pl;
-        PIB_CHK(launch_level<3>(s, g, omega, b, a, rr, pin_l, guarded, q));
+        {
+            const double *in = a;
+            auto run = [&](int64_t kb, int64_t kc) -> int {
+                return launch_level_planes<3>(s, g, kb, kc, omega, b, in, rr, pin_l, guarded, q);
+            };
+            PIB_CHK(produce_and_exchange(s, g, rr, q, run));
+        }
         PIB_CHK(halo_level(s, g, rr, q));
         GridLevel &cg = s->levels[(size_t)l + 1];
         if (cg.replicated && !g.replicated && s->comm.nranks > 1) {
@@ -1099,8 +1169,19 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         double *a = cur[(size_t)l], *c = s->gmg_spare[(size_t)l];
         double *xc = cur[(size_t)l + 1];
         PIB_CHK(halo_level(s, cg, xc, q));
-        PIB_CHK(launch_prolong(g, cg, xc, a, S, q));
-        PIB_CHK(smooth_seq(g, b, pin_l, a, c, post, false));
+        {
+            double *out = a;
+            auto run = [&](int64_t kb, int64_t kc) -> int {
+                if (kc <= 0) return 0;
+                GridLevel sub = g;
+                sub.k0 = g.k0 + kb;
+                sub.k1 = sub.k0 + kc;
+                return launch_prolong(sub, cg, xc, out + kb * g.plane, S, q);
+            };
+            // the prolongated iterate feeds the post-smoothing (or, without one, the level above)
+            if (post > 0 || l > 0) PIB_CHK(produce_and_exchange(s, g, out, q, run)); else PIB_CHK(run(0, g.k1 - g.k0));
+        }
+        PIB_CHK(smooth_seq(g, b, pin_l, a, c, post, false, l > 0));
         cur[(size_t)l] = a;
         if (l == 0 && a != z) return fail(PIB_ERR_LIB, "gmg: internal buffer parity error");
     }

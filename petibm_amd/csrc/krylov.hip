@@ -72,8 +72,10 @@ __device__ __forceinline__ void st(double *p, int64_t i, const Pack<W> &r)
 
 // Generic fused vector kernel.  Op::NRED partial sums go to
 // part[(k)*PIB_MAXPART + blockIdx.x].
+// [e_begin, e_end): element range (multiples of W; the odd tail element belongs to the range that ends at n)
 template <int W, class Op>
-__global__ __launch_bounds__(256) void k_vec(const Scalars *__restrict__ S, int64_t n, Op op, double *__restrict__ part)
+__global__ __launch_bounds__(256) void k_vec(const Scalars *__restrict__ S, int64_t n, Op op, double *__restrict__ part,
+                                             int64_t e_begin, int64_t e_end)
 {
     if (S != nullptr && S->done) return;
     constexpr int NR = Op::NRED > 0 ? Op::NRED : 1;
@@ -81,11 +83,11 @@ __global__ __launch_bounds__(256) void k_vec(const Scalars *__restrict__ S, int6
 #pragma unroll
     for (int k = 0; k < NR; ++k) acc[k] = 0.0;
     op.prepare(S);
-    const int64_t ng = n / W;
+    const int64_t ng = (e_end == n) ? n / W : e_end / W;
     const int64_t stride = (int64_t)gridDim.x * 256;
 #pragma unroll 2
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ng; i += stride) op.template apply<W>(i, acc);
-    if (W == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) op.template apply<1>(n - 1, acc);
+    for (int64_t i = e_begin / W + (int64_t)blockIdx.x * 256 + threadIdx.x; i < ng; i += stride) op.template apply<W>(i, acc);
+    if (W == 2 && (n & 1) && e_end == n && blockIdx.x == 0 && threadIdx.x == 0) op.template apply<1>(n - 1, acc);
     if (Op::NRED > 0) {
         __shared__ double sh[NR][4];
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -122,16 +124,18 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 template <class Op>
 static int launch_vec(pib_solver *s, int64_t n, const Op &op, bool vec2, int slot0, int *nblocks_out, bool guarded,
-                      hipStream_t stq)
+                      hipStream_t stq, int64_t e_begin = 0, int64_t e_end = -1)
 {
-    int64_t ng = vec2 ? n / 2 : n;
+    if (e_end < 0) e_end = n;
+    if (e_end <= e_begin) return 0;
+    int64_t ng = vec2 ? (e_end - e_begin + 1) / 2 : (e_end - e_begin);
     int nb = (int)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (ng + 255) / 256));
     double *part = s->d_part + (int64_t)slot0 * PIB_MAXPART;
     const Scalars *S = guarded ? s->d_s : nullptr;
     if (vec2)
-        hipLaunchKernelGGL((k_vec<2, Op>), dim3(nb), dim3(256), 0, stq, S, n, op, part);
+        hipLaunchKernelGGL((k_vec<2, Op>), dim3(nb), dim3(256), 0, stq, S, n, op, part, e_begin, e_end);
     else
-        hipLaunchKernelGGL((k_vec<1, Op>), dim3(nb), dim3(256), 0, stq, S, n, op, part);
+        hipLaunchKernelGGL((k_vec<1, Op>), dim3(nb), dim3(256), 0, stq, S, n, op, part, e_begin, e_end);
     PIB_HIP(hipGetLastError());
     if (nblocks_out) *nblocks_out = nb;
     return 0;
@@ -488,8 +492,31 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t stq);
 // w = A p including the halo update of p (p is ghost-padded), optional fused p.w partials
 static int matmult(pib_solver *s, double *p_owned, double *w, double *dot_part, bool guarded, hipStream_t stq)
 {
-    if (s->comm.nranks > 1) PIB_CHK(halo_exchange(s, p_owned, stq));
+    if (s->comm.nranks > 1 && s->halo_fresh != p_owned) PIB_CHK(halo_exchange(s, p_owned, stq));
+    s->halo_fresh = nullptr;
     return spmv_rows(s, p_owned, w, 0, s->A.n, dot_part, guarded, stq);
+}
+
+// p = z + beta p with the halo exchange of p overlapped (cfg.overlap_halo): the entries the neighbours need are
+// updated first, their exchange runs on the communication stream while the rest of p is updated; the SpMV that
+// follows finds the halo fresh.
+template <class Op>
+static int update_p_and_exchange(pib_solver *s, int64_t n, const Op &up, double *P, hipStream_t q)
+{
+    const DeviceCsr &A = s->A;
+    const bool split = s->comm.nranks > 1 && s->cfg.overlap_halo && (A.send_prev % 2 == 0) && (A.send_next % 2 == 0) &&
+                       (n % 2 == 0) && A.send_prev + A.send_next < n;
+    if (!split) return launch_vec(s, n, up, true, 0, nullptr, true, q);
+    PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q, 0, A.send_prev));
+    PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q, n - A.send_next, n));
+    PIB_HIP(hipEventRecord(s->ev_ready, q));
+    PIB_HIP(hipStreamWaitEvent(s->stream_comm, s->ev_ready, 0));
+    PIB_CHK(halo_exchange(s, P, s->stream_comm));
+    PIB_HIP(hipEventRecord(s->ev_halo, s->stream_comm));
+    PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q, A.send_prev, n - A.send_next));
+    PIB_HIP(hipStreamWaitEvent(q, s->ev_halo, 0));
+    s->halo_fresh = P;
+    return 0;
 }
 
 static int init_scalars(pib_solver *s)
@@ -604,7 +631,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         for (int it = 0; it < todo; ++it) {
             OpUpdateP up{Z, P, 0.0, 0.0, 0};
-            PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
+            PIB_CHK(update_p_and_exchange(s, n, up, P, q));
             PIB_CHK(matmult(s, P, W, part_pw, true, q));
             PIB_CHK(finalize(s, SLOT_PW, 1, spmv_blocks, q));
             hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s);

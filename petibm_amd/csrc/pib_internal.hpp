@@ -194,6 +194,7 @@ struct pib_solver {
     // results of the last solve
     int iters = 0, reason = 0;
     int hint_iters = 0;  // iterations of the previous solve (first enqueue batch of the next one)
+    const double *halo_fresh = nullptr;  // vector whose halo planes were exchanged by its producer (overlap path)
     double residual = 0.0;
     std::vector<double> history;
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};

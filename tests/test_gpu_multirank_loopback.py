@@ -167,6 +167,34 @@ def test_multirank_gmg_on_stretched_mesh_with_ragged_slabs(P, n, extra):
     s1.destroy()
 
 
+def test_halo_overlap_does_not_change_a_single_bit():
+    """pib_overlap_halo: boundary planes first, exchange on the communication stream during the interior part of the
+    producing kernel (V-cycle smoothers, residual, prolongation, p = z + beta p).  Same kernels, same values: the
+    residual history and the solution are identical with and without it."""
+    from petibm_amd import capi, partition
+    from petibm_amd.linsolver import LinSolverHIP
+    P, n, dt = 3, (16, 16, 24), 0.01
+    m, A, xs, b = _system(n, dt)
+    w = [m.dL[3][d].true for d in range(3)]
+    plans = partition.all_plans(n, P)
+    out = {}
+    for flag in (0, 1):
+        def rank_fn(r, uid, flag=flag):
+            pl = plans[r]
+            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=f"pib_agglomerate_below=10\npib_overlap_halo={flag}\n"),
+                             rank=r, nranks=P, uid=uid, device=0)
+            s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+            x = np.zeros(pl.n_local)
+            s.solve(x, np.ascontiguousarray(b[pl.row0:pl.row0 + pl.n_local]))
+            h = s.getResidualHistory()
+            s.destroy()
+            return x, h
+        res = _run_ranks(P, rank_fn)
+        out[flag] = (np.concatenate([q[0] for q in res]), res[0][1])
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    assert np.linalg.norm(b - clib.spmv(A, out[1][0])) <= 1.5e-10 * np.linalg.norm(b)
+
+
 def test_multirank_setcsr_route_and_pinned_gmg():
     """The PetIBM route (setMatrix with local rows / global columns + grid hint) on 2 ranks, pinned pressure."""
     from petibm_amd import capi, partition
