@@ -489,6 +489,59 @@ static int next_batch(const pib_solver *s)
 int halo_exchange(pib_solver *s, double *x_owned, hipStream_t stq);
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t stq);
 
+// Enqueue `todo` repetitions of one Krylov iteration (`body` launches its 15..70 kernels on q).  Small systems are
+// launch-bound (rocprof, 186^2 cylinder case: ~2 us kernels, the host cannot feed them faster than ~2.4 us apiece), so
+// on a single GPU the body is captured ONCE per (matrix, vectors) into a hipGraph and replayed: one host call per
+// iteration.  The first iteration of a solve always runs directly (lazy allocations happen there, never in a capture).
+constexpr int64_t GRAPH_MAX_ROWS = 1 << 22;
+static uint64_t graph_key(int method, const void *x, const void *b)
+{
+    return (uint64_t)reinterpret_cast<uintptr_t>(x) * 0x9E3779B97F4A7C15ull ^ (uint64_t)reinterpret_cast<uintptr_t>(b) ^
+           ((uint64_t)method << 60);
+}
+template <class Body>
+static int run_iterations(pib_solver *s, int todo, int first_index, uint64_t key, hipStream_t q, Body body)
+{
+    const bool use = s->cfg.use_graph && s->comm.nranks == 1 && s->A.n <= GRAPH_MAX_ROWS;
+    for (int it = 0; it < todo; ++it) {
+        if (!use || first_index + it == 0) {
+            PIB_CHK(body());
+            continue;
+        }
+        if (s->graph == nullptr || s->graph_key != key) {
+            if (s->graph) (void)hipGraphExecDestroy(s->graph);
+            s->graph = nullptr;
+            int64_t before[8];
+            for (int k = 0; k < 8; ++k) before[k] = s->counters[k];
+            PIB_HIP(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
+            const int err = body();
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(q, &g);
+            for (int k = 0; k < 8; ++k) {
+                s->graph_counts[k] = s->counters[k] - before[k];
+                s->counters[k] = before[k];
+            }
+            if (err || e != hipSuccess || g == nullptr) {
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                if (err) return err;
+                return fail(PIB_ERR_LIB, "solver %s: hipGraph capture of the iteration body failed (%s)", s->name.c_str(),
+                            hipGetErrorString(e));
+            }
+            const hipError_t ei = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ei != hipSuccess) {
+                s->graph = nullptr;
+                return fail(PIB_ERR_LIB, "solver %s: hipGraphInstantiate failed (%s)", s->name.c_str(), hipGetErrorString(ei));
+            }
+            s->graph_key = key;
+        }
+        PIB_HIP(hipGraphLaunch(s->graph, q));
+        for (int k = 0; k < 8; ++k) s->counters[k] += s->graph_counts[k];
+    }
+    return 0;
+}
+
 // w = A p including the halo update of p (p is ghost-padded), optional fused p.w partials
 static int matmult(pib_solver *s, double *p_owned, double *w, double *dot_part, bool guarded, hipStream_t stq)
 {
@@ -629,7 +682,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
-        for (int it = 0; it < todo; ++it) {
+        auto body = [&]() -> int {
             OpUpdateP up{Z, P, 0.0, 0.0, 0};
             PIB_CHK(update_p_and_exchange(s, n, up, P, q));
             PIB_CHK(matmult(s, P, W, part_pw, true, q));
@@ -653,7 +706,9 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, 1, 1, conv_is_its);
             }
             PIB_HIP(hipGetLastError());
-        }
+            return 0;
+        };
+        PIB_CHK(run_iterations(s, todo, enq, graph_key(1, x, b), q, body));
         enq += todo;
         PIB_CHK(poll(s));
     }
@@ -973,7 +1028,7 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
-        for (int it = 0; it < todo; ++it) {
+        auto body = [&]() -> int {
             // p = r - omegaold*beta*v + beta*p  (+ ph = M^-1 p)
             if (jac) {
                 OpBUpdateP<PCM_JACOBI> op{R, V, A.dinv, P, PH, opc, left ? 1 : 0, 0.0, 0.0};
@@ -1020,7 +1075,9 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
             PIB_CHK(finalize(s, 0, 2, nb, q));
             hipLaunchKernelGGL(k_b_s_end, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, conv_is_its);
             PIB_HIP(hipGetLastError());
-        }
+            return 0;
+        };
+        PIB_CHK(run_iterations(s, todo, enq, graph_key(2, x, b), q, body));
         enq += todo;
         PIB_CHK(poll(s));
     }

@@ -187,8 +187,9 @@ struct pib_solver {
     int64_t spmv_part_cap = 0;
     double *d_hist = nullptr;
     int hist_cap = 0;
-    hipGraphExec_t graph = nullptr;
-    int graph_iters = 0;
+    hipGraphExec_t graph = nullptr;   // one Krylov iteration (krylov.hip: run_iterations)
+    uint64_t graph_key = 0;           // the (method, x, b) it was captured for
+    int64_t graph_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // instrumentation counters one replay stands for
     double *dense_inv = nullptr;  // dense.hip: explicit inverse of the direct solver [dense_n x dense_n]
     int64_t dense_n = 0;
     // results of the last solve
