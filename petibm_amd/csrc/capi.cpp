@@ -113,6 +113,7 @@ int pib_destroy(pib_solver *s)
     if (s->h_s) (void)hipHostFree(s->h_s);
     if (s->d_part) (void)hipFree(s->d_part);
     if (s->d_spmv_part) (void)hipFree(s->d_spmv_part);
+    if (s->d_gmg_part) (void)hipFree(s->d_gmg_part);
     if (s->d_hist) (void)hipFree(s->d_hist);
     comm_release(s);
     if (s->ev_a) (void)hipEventDestroy(s->ev_a);

@@ -609,11 +609,15 @@ static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guard
 {
     int nb = 0;
     s->gmg_guarded = guarded;
+    s->gmg_want_dots = (s->cfg.fuse_dots != 0);
     PIB_CHK(gmg_apply(s, R, Z, q));
+    s->gmg_want_dots = false;
     s->counters[1]++;
-    OpDotZR dz{Z, R};
-    PIB_CHK(launch_vec(s, s->A.n, dz, true, 0, &nb, guarded, q));
-    hipLaunchKernelGGL(k_finalize, dim3(3), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);
+    if (!s->gmg_dots_done) {  // else: z.r, z.z, sum z came out of the V-cycle's last smoothing kernel
+        OpDotZR dz{Z, R};
+        PIB_CHK(launch_vec(s, s->A.n, dz, true, 0, &nb, guarded, q));
+        hipLaunchKernelGGL(k_finalize, dim3(3), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);
+    }
     hipLaunchKernelGGL(k_fetch_z0, dim3(1), dim3(1), 0, q, s->d_s, Z, (s->A.row0 == 0) ? 1 : 0);
     PIB_HIP(hipGetLastError());
     return allreduce_slots(s, 0, 4, q);

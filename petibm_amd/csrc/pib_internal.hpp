@@ -76,6 +76,7 @@ struct Config {
     int coarse_tail = 0;     // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel.
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
+    int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;
 };
@@ -185,6 +186,9 @@ struct pib_solver {
     double *d_part = nullptr;  // [PIB_NRED][PIB_MAXPART]
     double *d_spmv_part = nullptr;  // one p.Ap partial per SpMV workgroup
     int64_t spmv_part_cap = 0;
+    double *d_gmg_part = nullptr;   // z.r, z.z, sum z partials of the V-cycle's last smoothing kernel (gmg.hip mode 8)
+    int64_t gmg_part_cap = 0;
+    bool gmg_want_dots = false, gmg_dots_done = false;
     double *d_hist = nullptr;
     int hist_cap = 0;
     hipGraphExec_t graph = nullptr;   // one Krylov iteration (krylov.hip: run_iterations)
