@@ -128,7 +128,11 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
     const int k = L.k0 + kk;
     const double wzk = L.wz[k];
     const double gzm = (k > 0) ? L.gz[k - 1] : 0.0, gzp = (k < L.nzg - 1) ? L.gz[k] : 0.0;
-    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < planec; q += gridDim.x * 256u) {
+    // Workgroup b runs on XCD b % 8.  With the plain order the two grid lines of a workgroup have their +-y neighbours
+    // in the workgroups of OTHER XCDs, so every L2 fetched x twice (PMC: 3.22 GB read per 512^3 sweep for 2.15 GB
+    // of b and x).  Dealing each XCD a contiguous band of the plane leaves 8 band edges per plane instead.
+    const unsigned bx = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (unsigned q = bx * 256u + threadIdx.x; q < planec; q += gridDim.x * 256u) {
         const int j = (int)(q / nxc);
         const int i0 = (int)(q - (unsigned)j * nxc) * C;
         const int64_t p = (int64_t)kk * plane + (int64_t)j * L.nx + i0;
@@ -346,7 +350,7 @@ __device__ __forceinline__ void rs1d4(const Tr1 &t, int I, int nf, double w[4], 
 // bc = P^T rf over the owned coarse rows; fine halo planes valid.
 __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
                                                        const double *__restrict__ rf, double *__restrict__ bc,
-                                                       int ngroups, int per_xcd)
+                                                       int ngroups, int per_xcd, int vec_ok)
 {
     if (S != nullptr && S->done) return;
     int row;
@@ -367,22 +371,41 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
     const bool edgeL = (lane == 0 && I > 0), edgeR = (lane == 63 && I + 1 < C.nx);
     const int64_t fplane = (int64_t)F.nx * F.ny;
     double s = 0.0;
+    // all sixteen row loads are issued before the first use (no branch on the wave-uniform zero weights: a zero
+    // weight adds exactly 0 and its clamped row index is legal) -- 32 loads in flight per wave
+    double c0[4][4], c1[4][4];
+    // plain pairing along x (every lane's children are the aligned pair 2I, 2I+1): one 16-byte load per lane and row
+    // instead of two 8-byte loads with a stride of two
+    const bool vec = vec_ok && __all(pair && !(f0 & 1));
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (wk[c] == 0.0) continue;  // wave-uniform
         const double *pk = rf + fplane * (sk[c] - F.k0);
 #pragma unroll
         for (int b2 = 0; b2 < 4; ++b2) {
-            if (wj[b2] == 0.0) continue;  // wave-uniform
+            const double *pj = pk + (int64_t)F.nx * sj[b2];
+            if (vec) {
+                const double2 v = *reinterpret_cast<const double2 *>(pj + f0);
+                c0[c][b2] = v.x;
+                c1[c][b2] = v.y;
+            } else {
+                c0[c][b2] = pj[f0];
+                c1[c][b2] = pj[f1];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double *pk = rf + fplane * (sk[c] - F.k0);
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) {
             const double wzy = wk[c] * wj[b2];
             const double *pj = pk + (int64_t)F.nx * sj[b2];
-            const double c0 = pj[f0], c1 = pj[f1];
-            double vl = __shfl_up(c1, 1, 64), vr = __shfl_down(c0, 1, 64);
+            double vl = __shfl_up(c1[c][b2], 1, 64), vr = __shfl_down(c0[c][b2], 1, 64);
             if (edgeL) vl = pj[f0 - 1];
             if (edgeR) vr = pj[f1 + 1];
             s += (wzy * rw.x) * vl;
-            s += (wzy * rw.y) * c0;
-            s += (wzy * rw.z) * c1;
+            s += (wzy * rw.y) * c0[c][b2];
+            s += (wzy * rw.z) * c1[c][b2];
             s += (wzy * rw.w) * vr;
         }
     }
@@ -671,7 +694,8 @@ static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *
 static int launch_restrict(const GridLevel &f, const GridLevel &c, const double *rf, double *bc, const Scalars *S, hipStream_t q)
 {
     const RowGrid r = row_grid(c.n[1] * (c.k1 - c.k0), c.n[0]);
-    hipLaunchKernelGGL(k_restrict_rows, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), rf, bc, r.ngroups, r.per_xcd);
+    const int vec_ok = (f.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(rf) & 15u) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_restrict_rows, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), rf, bc, r.ngroups, r.per_xcd, vec_ok);
     PIB_HIP(hipGetLastError());
     return 0;
 }
