@@ -271,19 +271,19 @@ __device__ __forceinline__ bool row_of_wave(int ngroups, int per_xcd, int nrows,
 }
 
 // xf += P xc.   xc points at the coarse level's first owned plane (coarse k0c); coarse halo planes must be valid
-// when the level is distributed.
+// when the level is distributed.  One wave does RP consecutive fine rows and issues every load of all of them
+// (4 coarse rows + the old fine values each) before the first use: a single row per wave left ~3 dependent memory
+// round trips of latency per 1 KB written.
+template <int RP>
 __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
                                                       const double *__restrict__ xc, double *__restrict__ xf,
                                                       int ngroups, int per_xcd, int vec_ok)
 {
     if (S != nullptr && S->done) return;
-    int row;
-    if (!row_of_wave(ngroups, per_xcd, F.ny * F.nk, &row)) return;
-    const int kk = row / F.ny, j = row - kk * F.ny, k = F.k0 + kk;
-    int J[2], K[2];
-    double wj[2], wk[2];
-    tr1d(F.t[1], j, J, wj);
-    tr1d(F.t[2], k, K, wk);
+    int row0;
+    const int nrows = F.ny * F.nk;
+    if (!row_of_wave(ngroups, per_xcd, (nrows + RP - 1) / RP, &row0)) return;
+    row0 *= RP;
     const int lane = threadIdx.x;
     const int Iraw = blockIdx.y * 64 + lane;
     const bool valid = Iraw < C.nx;
@@ -292,37 +292,62 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
     const double4 pw = F.tx.pw[I];
     const bool edgeL = (lane == 0 && I > 0), edgeR = (lane == 63 && I + 1 < C.nx);
     const int64_t cplane = (int64_t)C.nx * C.ny, fplane = (int64_t)F.nx * F.ny;
-    double sl = 0.0, sr = 0.0;
+    const bool vec = vec_ok && __all(!valid || (fc.y == 2 && !(fc.x & 1)));
+    double vP[RP][4], eL[RP][4], eR[RP][4], w4[RP][4], d0[RP], d1[RP];
+    int64_t off[RP];
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
+    for (int r = 0; r < RP; ++r) {
+        const int row = min(row0 + r, nrows - 1);  // a clamped duplicate row is loaded but never stored
+        const int kk = row / F.ny, j = row - kk * F.ny, k = F.k0 + kk;
+        int J[2], K[2];
+        double wj[2], wk[2];
+        tr1d(F.t[1], j, J, wj);
+        tr1d(F.t[2], k, K, wk);
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) {
-            const double wkj = wk[c2] * wj[b2];
-            if (wkj == 0.0) continue;  // wave-uniform
-            const double *rowp = xc + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0);
-            const double vP = rowp[I];
-            double vL = __shfl_up(vP, 1, 64), vR = __shfl_down(vP, 1, 64);
-            if (edgeL) vL = rowp[I - 1];
-            if (edgeR) vR = rowp[I + 1];
-            sl += (wkj * pw.x) * vP;
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const double *rowp = xc + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0);
+                w4[r][c2 * 2 + b2] = wk[c2] * wj[b2];
+                vP[r][c2 * 2 + b2] = rowp[I];
+                eL[r][c2 * 2 + b2] = edgeL ? rowp[I - 1] : 0.0;
+                eR[r][c2 * 2 + b2] = edgeR ? rowp[I + 1] : 0.0;
+            }
+        off[r] = (int64_t)kk * fplane + (int64_t)j * F.nx + fc.x;
+        if (vec) {
+            const double2 v = *reinterpret_cast<const double2 *>(xf + off[r]);
+            d0[r] = v.x;
+            d1[r] = v.y;
+        } else {
+            d0[r] = xf[off[r]];
+            d1[r] = (fc.y == 2) ? xf[off[r] + 1] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        double sl = 0.0, sr = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double wkj = w4[r][q];
+            const double v = vP[r][q];
+            double vL = __shfl_up(v, 1, 64), vR = __shfl_down(v, 1, 64);
+            if (edgeL) vL = eL[r][q];
+            if (edgeR) vR = eR[r][q];
+            if (wkj == 0.0) continue;  // wave-uniform: the oracle skips zero weights too
+            sl += (wkj * pw.x) * v;
             sl += (wkj * pw.y) * vL;
-            sr += (wkj * pw.z) * vP;
+            sr += (wkj * pw.z) * v;
             sr += (wkj * pw.w) * vR;
         }
-    if (!valid) return;
-    double *dst = xf + (int64_t)kk * fplane + (int64_t)j * F.nx + fc.x;
-    if (fc.y == 2) {
-        if (vec_ok && !(fc.x & 1)) {
-            double2 v = *reinterpret_cast<double2 *>(dst);
-            v.x += sl;
-            v.y += sr;
-            *reinterpret_cast<double2 *>(dst) = v;
-        } else {
-            dst[0] += sl;
-            dst[1] += sr;
+        if (!valid || row0 + r >= nrows) continue;
+        double *dst = xf + off[r];
+        if (vec)
+            *reinterpret_cast<double2 *>(dst) = make_double2(d0[r] + sl, d1[r] + sr);
+        else {
+            dst[0] = d0[r] + sl;
+            if (fc.y == 2) dst[1] = d1[r] + sr;
         }
-    } else
-        dst[0] += sl;
+    }
 }
 
 // 1-D restriction stencil of coarse cell I in fixed 4-slot form: slot o <-> fine cell fst[I] - 1 + o (the left
@@ -684,9 +709,15 @@ static RowGrid row_grid(int64_t nrows, int64_t ncx)
 }
 static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *xc, double *xf, const Scalars *S, hipStream_t q)
 {
-    const RowGrid r = row_grid(f.n[1] * (f.k1 - f.k0), c.n[0]);
+    const int64_t nrows = f.n[1] * (f.k1 - f.k0);
     const int vec_ok = (f.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(xf) & 15u) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_prolong_rows, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), xc, xf, r.ngroups, r.per_xcd, vec_ok);
+    if (nrows >= 65536) {  // enough rows to keep the chip busy with four per wave
+        const RowGrid r = row_grid((nrows + 3) / 4, c.n[0]);
+        hipLaunchKernelGGL(k_prolong_rows<4>, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), xc, xf, r.ngroups, r.per_xcd, vec_ok);
+    } else {
+        const RowGrid r = row_grid(nrows, c.n[0]);
+        hipLaunchKernelGGL(k_prolong_rows<1>, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), xc, xf, r.ngroups, r.per_xcd, vec_ok);
+    }
     PIB_HIP(hipGetLastError());
     return 0;
 }
