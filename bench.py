@@ -66,11 +66,11 @@ def manufactured_solution(n: int, k0: int, k1: int) -> np.ndarray:
 
 def cpu_baseline(n_gpu: int, tol: float, dt: float, budget_s: float = 45.0):
     """The oracle (CPU restatement of the same path: int32 CSR SpMV + KSPCG recurrences + the same V-cycle,
-    oracle/csrc/*.c, OpenMP over all host cores) timed on this box.  It runs the SAME workload as the GPU when
+    oracle/csrc/*.c, OpenMP over every core the process may use: affinity and cgroup quota) timed on this box.  It runs the SAME workload as the GPU when
     a calibration solve at n/2 says it fits the time budget and the host has the memory; otherwise the
     bounded sample is the largest power-of-two cavity that does."""
     from oracle import clib
-    clib.set_threads(os.cpu_count() or 1)  # all host cores (the oracle defaults to 8 for the tiny test systems)
+    clib.set_threads(clib.usable_cores())  # every core this process may use (affinity and cgroup quota respected)
     cores = clib.num_threads()
 
     def run(n):

@@ -66,6 +66,28 @@ def set_threads(n: int) -> None:
     lib().orc_set_threads(int(n))
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (a container that sees
+    256 hardware threads but is limited to 16 CPUs runs a 256-thread OpenMP team a thousand times slower than a
+    16-thread one: every barrier spins on descheduled threads)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / p_)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def spmv(m, x: np.ndarray) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.empty(m.n_rows)

@@ -227,19 +227,32 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
     }
 }
 
-// sum `count` per-workgroup partials of slot k (k = blockIdx.x) into S->red[k], fixed order
-__global__ __launch_bounds__(256) void k_finalize_big(Scalars *__restrict__ S, const double *__restrict__ part, int stride, int count)
+// the per-workgroup partials of slot k = blockIdx.y (up to 5 * 10^5 of them) in two fixed-order stages: 64 workgroups
+// per slot sum a contiguous chunk each, one workgroup per slot sums the 64 results into S->red[k]
+constexpr int BIG_STAGE = 64;
+__global__ __launch_bounds__(256) void k_reduce_big(const Scalars *__restrict__ S, const double *__restrict__ part, int stride,
+                                                    int count, double *__restrict__ out /* [3][BIG_STAGE] */)
 {
     if (S->done) return;
-    const double *p = part + (int64_t)blockIdx.x * stride;
+    const double *p = part + (int64_t)blockIdx.y * stride;
+    const int chunk = (count + BIG_STAGE - 1) / BIG_STAGE;
+    const int lo = blockIdx.x * chunk, hi = min(lo + chunk, count);
     double v = 0.0;
-    for (int i = threadIdx.x; i < count; i += 256) v += p[i];
+    for (int i = lo + threadIdx.x; i < hi; i += 256) v += p[i];
     __shared__ double sh[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) S->red[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) out[blockIdx.y * BIG_STAGE + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(64) void k_finalize_big(Scalars *__restrict__ S, const double *__restrict__ in)
+{
+    if (S->done) return;
+    double v = in[blockIdx.x * BIG_STAGE + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (threadIdx.x == 0) S->red[blockIdx.x] = v;
 }
 
 // 1-D transfer stencil of fine cell s: its parent aggregate (weight 1 - t) and the coarse cell on the child's
@@ -1078,7 +1091,7 @@ static int launch_level(pib_solver *s, const GridLevel &g, double omega, const d
         if (s->gmg_part_cap < cap) {
             if (s->d_gmg_part) PIB_HIP(hipFree(s->d_gmg_part));
             s->d_gmg_part = nullptr;
-            PIB_HIP(hipMalloc(&s->d_gmg_part, sizeof(double) * 3 * (size_t)cap));
+            PIB_HIP(hipMalloc(&s->d_gmg_part, sizeof(double) * (3 * (size_t)cap + 3 * BIG_STAGE)));
             s->gmg_part_cap = cap;
         }
         part = s->d_gmg_part;
@@ -1103,7 +1116,9 @@ static int launch_level(pib_solver *s, const GridLevel &g, double omega, const d
     }
     PIB_HIP(hipGetLastError());
     if (MODE == 8) {
-        hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(256), 0, q, s->d_s, part, part_stride, (int)(grid.x * grid.y));
+        double *stage = part + 3 * (int64_t)part_stride;
+        hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)(grid.x * grid.y), stage);
+        hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
         PIB_HIP(hipGetLastError());
     }
     return 0;
