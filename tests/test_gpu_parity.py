@@ -297,6 +297,62 @@ def test_solve_before_setmatrix_and_device_vectors(lin):
     s.destroy()
 
 
+def test_degenerate_systems_and_inputs(lin):
+    """Edge cases around the boundary: a 1x1 system, a zero right-hand side, a zero diagonal under Jacobi, columns out of
+    range, a grid hint that does not describe the matrix, more iterations asked for than needed."""
+    from petibm_amd import capi
+    from petibm_amd.capi import PibError
+    one = oops.CSR(1, 1, np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int64), np.array([-2.5]))
+    for pc in ("NOSOLVER", "BLOCK_JACOBI"):
+        s = lin.LinSolverHIP("poisson", config_text=amgx_cfg(pc=pc, tol=1e-14))
+        s.setMatrix(one)
+        x = np.zeros(1)
+        s.solve(x, np.array([5.0]))
+        assert abs(x[0] + 2.0) <= 1e-14 and s.getIters() <= 1
+        s.destroy()
+    m, A, _ = poisson_system(STRETCHED_2D, pinned=True)
+    s = lin.LinSolverHIP("poisson", config_text=amgx_cfg(pc="BLOCK_JACOBI", tol=1e-12))
+    s.setMatrix(A)
+    x = np.zeros(A.n_rows)
+    s.solve(x, np.zeros(A.n_rows))  # b = 0: converged before the first iteration, x stays 0
+    assert s.getIters() == 0 and s.getReason() > 0 and not x.any()
+    # the same solver object takes a different matrix afterwards (KSPReset semantics, linsolverksp.cpp:78)
+    m3, A3, _ = poisson_system(stretched_3d((8, 7, 6)), pinned=True)
+    xs, b = rhs_for(A3, zero_mean=False)
+    b[0] = 0.0
+    s.setMatrix(A3)
+    x = np.zeros(A3.n_rows)
+    s.solve(x, b)
+    assert np.linalg.norm(b - clib.spmv(A3, x)) <= 1e-11 * max(np.linalg.norm(b), 1.0)
+    s.destroy()
+    # zero diagonal + Jacobi: refused at setMatrix, not a NaN later
+    Z = A.copy()
+    rows = np.repeat(np.arange(Z.n_rows), np.diff(Z.rowptr))
+    Z.val[(rows == Z.col) & (rows == 3)] = 0.0
+    s = lin.LinSolverHIP("poisson", config_text=amgx_cfg(pc="BLOCK_JACOBI"))
+    with pytest.raises(PibError) as ei:
+        s.setMatrix(Z)
+    assert ei.value.code == capi.ERR_ARG_WRONG
+    s.destroy()
+    # a column index beyond the matrix
+    B = A.copy()
+    B.col = B.col.copy()
+    B.col[5] = B.n_rows + 7
+    s = lin.LinSolverHIP("poisson", config_text=amgx_cfg(pc="NOSOLVER"))
+    with pytest.raises(PibError) as ei:
+        s.setMatrix(B)
+    assert ei.value.code == capi.ERR_ARG_OUTOFRANGE
+    # a grid hint that belongs to another mesh: stencil twin and CSR disagree -> PETSC_ERR_ARG_WRONG
+    s.setMatrix(A)
+    n = [int(v) for v in m.n[3][:2]]
+    w = [m.dL[3][d].true[::-1].copy() for d in range(2)]
+    g = [0.01 * (1.0 / (0.5 * (wd[1:] + wd[:-1]))) for wd in w]
+    with pytest.raises(PibError) as ei:
+        s.setGridHint(n, w, g, capi.NULLSPACE_PINNED)
+    assert ei.value.code == capi.ERR_ARG_WRONG
+    s.destroy()
+
+
 # ------------------------------------------------------------ BiCGStab (K10)
 @pytest.mark.parametrize("flavour", ["amgx", "ksp"])
 @pytest.mark.parametrize("case", ["2d_stretched", "3d_stretched"])
