@@ -7,7 +7,8 @@ Picks the flow solver the way the reference's two applications do (applications/
 applications/decoupledibpm/main.cpp): immersed bodies -> decoupled IBPM, none -> Navier-Stokes.  Writes
 output/iterations-<start>.txt (ite, iterations and residual per solver: navierstokes.cpp:766-794,
 decoupledibpm.cpp:399-434) and, with bodies, output/forces-<start>.txt (t, fx, fy[, fz] per body:
-decoupledibpm.cpp:437-465) -- the files the reference's plotting scripts read."""
+decoupledibpm.cpp:437-465), output/grid.h5 and the solution / restart files output/<step>.h5 (every nsave / nrestart
+steps; startStep > 0 restarts from output/<startStep>.h5) -- the files the reference's plotting scripts read."""
 import argparse
 import os
 import sys
@@ -48,8 +49,24 @@ def main():
         s = navierstokes.NavierStokesSolver(cfg, **kw)
     out = os.path.join(d, "output")
     os.makedirs(out, exist_ok=True)
-    it_file = open(os.path.join(out, f"iterations-{start}.txt"), "w")
-    f_file = open(os.path.join(out, f"forces-{start}.txt"), "w") if cfg.get("bodies") else None
+    nsave = int(par.get("nsave", 0))
+    nrestart = int(par.get("nrestart", 0))
+    try:
+        from petibm_amd import h5io
+        h5io.lib()
+        have_h5 = True
+    except ImportError as e:
+        print(f"HDF5 output disabled: {e}")
+        have_h5 = False
+    if have_h5:
+        s.writeGrid(os.path.join(out, "grid.h5"))                      # main.cpp: mesh->write(output/grid.h5)
+        if start > 0:
+            s.readRestartData(os.path.join(out, f"{start:07d}.h5"))    # ioInitialData (navierstokes.cpp:189-236)
+        else:
+            s.write(os.path.join(out, f"{start:07d}.h5"))
+    mode = "a" if start > 0 else "w"
+    it_file = open(os.path.join(out, f"iterations-{start}.txt"), mode)
+    f_file = open(os.path.join(out, f"forces-{start}.txt"), mode) if cfg.get("bodies") else None
     t0 = time.perf_counter()
     for _ in range(nt):
         s.advance()
@@ -58,6 +75,10 @@ def main():
         if f_file:
             _, avg = s.getForces()
             f_file.write(f"{s.t:10.8e}\t" + "\t".join(f"{v:10.8e}" for v in avg.reshape(-1)) + "\t\n")
+        if have_h5 and nsave > 0 and s.ite % nsave == 0:
+            s.write(os.path.join(out, f"{s.ite:07d}.h5"))
+        if have_h5 and nrestart > 0 and s.ite % nrestart == 0:
+            s.writeRestartData(os.path.join(out, f"{s.ite:07d}.h5"))
     wall = time.perf_counter() - t0
     print(f"{nt} steps in {wall:.2f} s ({1e3 * wall / max(nt, 1):.2f} ms/step); last step: {s.linSolversInfo()}")
     s.destroy()

@@ -226,6 +226,10 @@ int pib_ns_sizes(pib_ns *ns, int64_t *UN, int64_t *pN);
 int pib_ns_set_state(pib_ns *ns, const double *U_packed_or_null, const double *p_or_null);        /* host arrays */
 int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs2);               /* any may be NULL */
 int pib_ns_advance(pib_ns *ns, int nsteps);
+/* explicit terms kept between steps, for restart files (navierstokes.cpp:637-686,689-746: /convection/0,
+ * /convection/1, /diffusion/0); host arrays of UN entries, any may be NULL */
+int pib_ns_get_history(pib_ns *ns, double *conv0, double *conv1, double *diff0);
+int pib_ns_set_history(pib_ns *ns, const double *conv0, const double *conv1);
 /* the columns of iterations-<start>.txt (navierstokes.cpp:766-794) for the last step */
 int pib_ns_get_solver_info(pib_ns *ns, int *v_iters, double *v_res, int *p_iters, double *p_res);
 int pib_ns_destroy(pib_ns *ns);

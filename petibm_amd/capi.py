@@ -71,6 +71,8 @@ _PROTOS = {
     "pib_ns_set_state": (C.c_int, [_vp, _vp, _vp]),
     "pib_ns_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "pib_ns_advance": (C.c_int, [_vp, C.c_int]),
+    "pib_ns_get_history": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pib_ns_set_history": (C.c_int, [_vp, _vp, _vp]),
     "pib_ns_get_solver_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                          C.POINTER(C.c_double)]),
     "pib_ns_destroy": (C.c_int, [_vp]),

@@ -130,7 +130,8 @@ __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__res
 __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, double nu, double c0, double c1, double d0,
                                                          double cimpl, const double *__restrict__ U,
                                                          const double *__restrict__ p, const double *__restrict__ conv1,
-                                                         double *__restrict__ conv0, double *__restrict__ rhs1)
+                                                         double *__restrict__ conv0, double *__restrict__ rhs1,
+                                                         double *__restrict__ diff0)
 {
     for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < D.UN; g += (int64_t)gridDim.x * 256) {
         int f = 0;
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         laplacian_at(D, U, f, i, j, k, &lu, &lc, &lcn);
         double df = lu + lc;
         df = nu * df;
+        diff0[g] = df;
         r = r + d0 * df;
         const double b1 = nu * lcn;
         r = r + cimpl * b1;
@@ -438,7 +440,7 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
         return 0;
     };
     if ((err = alloc(&ns->U, D.UN)) || (err = alloc(&ns->rhs1, D.UN)) || (err = alloc(&ns->conv[0], D.UN)) ||
-        (err = alloc(&ns->conv[1], D.UN)) || (err = alloc(&ns->p, D.pN)) || (err = alloc(&ns->dP, D.pN)) ||
+        (err = alloc(&ns->conv[1], D.UN)) || (err = alloc(&ns->diff0, D.UN)) || (err = alloc(&ns->p, D.pN)) || (err = alloc(&ns->dP, D.pN)) ||
         (err = alloc(&ns->rhs2, D.pN)) || (err = alloc(&D.a1, D.nghost)) || (err = alloc(&D.a1n, D.nghost)) ||
         (err = alloc(&D.gv, D.nghost)))
         return bail(err);
@@ -487,6 +489,31 @@ int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs
     return 0;
 }
 
+/* the explicit terms a restart needs (navierstokes.cpp:637-686: /convection/0, /convection/1, /diffusion/0); any may be NULL */
+int pib_ns_get_history(pib_ns *ns, double *conv0, double *conv1, double *diff0)
+{
+    using namespace pib;
+    if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
+    PIB_HIP(hipSetDevice(ns->device));
+    PIB_HIP(hipStreamSynchronize(ns->stream));
+    const size_t bytes = sizeof(double) * (size_t)ns->D.UN;
+    if (conv0) PIB_HIP(hipMemcpy(conv0, ns->conv[0], bytes, hipMemcpyDeviceToHost));
+    if (conv1) PIB_HIP(hipMemcpy(conv1, ns->conv[1], bytes, hipMemcpyDeviceToHost));
+    if (diff0) PIB_HIP(hipMemcpy(diff0, ns->diff0, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pib_ns_set_history(pib_ns *ns, const double *conv0, const double *conv1)
+{
+    using namespace pib;
+    if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
+    PIB_HIP(hipSetDevice(ns->device));
+    const size_t bytes = sizeof(double) * (size_t)ns->D.UN;
+    if (conv0) PIB_HIP(hipMemcpy(ns->conv[0], conv0, bytes, hipMemcpyHostToDevice));
+    if (conv1) PIB_HIP(hipMemcpy(ns->conv[1], conv1, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int pib_ns_advance(pib_ns *ns, int nsteps)
 {
     using namespace pib;
@@ -502,7 +529,7 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         // bc->updateEqs(solution, dt) (:508) into a1n; the right-hand side needs both generations
         hipLaunchKernelGGL(k_ns_ghosts<1>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);
         hipLaunchKernelGGL(k_ns_rhs_velocity, dim3(gu), dim3(256), 0, ns->stream, D, ns->dt, ns->nu, 1.5, -0.5, 0.5, 0.5, ns->U,
-                           ns->p, ns->conv[1], ns->conv[0], ns->rhs1);
+                           ns->p, ns->conv[1], ns->conv[0], ns->rhs1, ns->diff0);
         PIB_HIP(hipGetLastError());
         std::swap(D.a1, D.a1n);
         if (ns->ib) PIB_CHK(ib_spread_forces(ns));  // rhs1 += H f  (decoupledibpm.cpp:243)

@@ -61,6 +61,7 @@ struct pib_ns {
     pib_solver *vsol = nullptr, *psol = nullptr;
     double dt = 0, nu = 0;
     double *U = nullptr, *p = nullptr, *dP = nullptr, *rhs1 = nullptr, *rhs2 = nullptr, *conv[2] = {nullptr, nullptr};
+    double *diff0 = nullptr;  // explicit diffusion term of the last step (restart files carry it: navierstokes.cpp:672-680)
     std::vector<double *> owned;
     int pinned = 0;
     int v_iters = 0, p_iters = 0;

@@ -56,6 +56,7 @@ class NavierStokesSolver:
             hi.append(e)
         self.n = [len(w) for w in ws]
         self.widths = ws
+        self._lo = list(lo)
         bc_t = np.zeros(18, dtype=np.int32)
         bc_v = np.zeros(18)
         for bc in config["flow"]["boundaryConditions"]:
@@ -132,6 +133,87 @@ class NavierStokesSolver:
                                                 None if r1 is None else r1.ctypes.data,
                                                 None if r2 is None else r2.ctypes.data))
         return (U, p, r1, r2) if rhs else (U, p)
+
+    # ---- files of the reference (HDF5 through petibm_amd.h5io; formats: see that module) -------------------------
+    def _field_shapes(self):
+        """(name, shape (nz,) ny, nx) of the velocity components, then the pressure"""
+        out = []
+        for f in range(self.dim):
+            nf = [self.n[d] - (1 if d == f else 0) for d in range(self.dim)]
+            out.append(("uvw"[f], tuple(nf[::-1])))
+        out.append(("p", tuple(self.n[::-1])))
+        return out
+
+    def writeGrid(self, path: str) -> None:
+        """CartesianMesh::write (src/mesh/cartesianmesh.cpp:798-823): groups u, v, w, p, vertex with the gridline
+        coordinates x, y, z of each field (single zeros for the directions / fields a 2-D run does not have)"""
+        from . import h5io
+        vtx = [self._lo[d] + np.concatenate([[0.0], np.cumsum(self.widths[d])]) for d in range(self.dim)]
+        ctr = [0.5 * (v[1:] + v[:-1]) for v in vtx]
+        with h5io.File(path, "w") as f:
+            for fi, name in enumerate(("u", "v", "w", "p", "vertex")):
+                for d, ax in enumerate("xyz"):
+                    if d >= self.dim or (fi == 2 and self.dim == 2):
+                        c = np.zeros(1)
+                    elif fi == 4:
+                        c = vtx[d]
+                    elif fi == 3 or fi != d:
+                        c = ctr[d]
+                    else:
+                        c = vtx[d][1:-1]
+                    f.write(f"{name}/{ax}", c)
+
+    def write(self, path: str) -> None:
+        """NavierStokesSolver::writeSolutionHDF5 (navierstokes.cpp:618-634): u, v[, w], p as (nz,) ny, nx arrays and
+        the time as attribute `time` of /p"""
+        from . import h5io
+        U, p = self.getState()
+        with h5io.File(path, "w") as f:
+            off = 0
+            for name, shape in self._field_shapes():
+                sz = int(np.prod(shape))
+                if name == "p":
+                    f.write(name, p.reshape(shape))
+                else:
+                    f.write(name, U[off:off + sz].reshape(shape))
+                    off += sz
+            f.write_attr("p", "time", self.t)
+
+    def _history(self):
+        c0, c1, d0 = np.empty(self.UN), np.empty(self.UN), np.empty(self.UN)
+        capi.check(capi.load().pib_ns_get_history(self._h, c0.ctypes.data, c1.ctypes.data, d0.ctypes.data))
+        return c0, c1, d0
+
+    def writeRestartData(self, path: str) -> None:
+        """NavierStokesSolver::writeRestartDataHDF5 (navierstokes.cpp:637-686): the solution file plus the explicit
+        terms /convection/0, /convection/1, /diffusion/0 (packed velocity ordering)"""
+        from . import h5io
+        import os
+        if not os.path.exists(path):
+            self.write(path)
+        c0, c1, d0 = self._history()
+        with h5io.File(path, "a") as f:
+            f.write("convection/0", c0)
+            f.write("convection/1", c1)
+            f.write("diffusion/0", d0)
+
+    def readRestartData(self, path: str) -> None:
+        """NavierStokesSolver::readRestartDataHDF5 (navierstokes.cpp:689-746): fields, time, explicit convective terms,
+        then bc->setGhostICs(solution)"""
+        from . import h5io
+        with h5io.File(path, "r") as f:
+            parts = []
+            for name, shape in self._field_shapes():
+                a = f.read(name)
+                if a.shape != shape:
+                    raise capi.PibError(capi.ERR_FILE_READ, f"{path}: dataset {name} has shape {a.shape}, the mesh needs {shape}")
+                parts.append(a.reshape(-1))
+            self.t = f.read_attr("p", "time")
+            c0, c1 = f.read("convection/0"), f.read("convection/1")
+        self.setState(np.concatenate(parts[:-1]), parts[-1])  # includes setGhostICs
+        c0, c1 = np.ascontiguousarray(c0), np.ascontiguousarray(c1)
+        capi.check(capi.load().pib_ns_set_history(self._h, c0.ctypes.data, c1.ctypes.data))
+        self.ite = int(round(self.t / self.dt))
 
     def linSolversInfo(self):
         """ite, vIters, vRes, pIters, pRes -- one line of iterations-<start>.txt (navierstokes.cpp:766-794)"""
@@ -225,6 +307,19 @@ class DecoupledIBPMSolver(NavierStokesSolver):
         fi, fr = C.c_int(), C.c_double()
         capi.check(capi.load().pib_ns_get_forces_solver_info(self._h, C.byref(fi), C.byref(fr)))
         return base + (fi.value, fr.value)
+
+    def writeRestartData(self, path: str) -> None:
+        """DecoupledIBPMSolver::writeRestartDataHDF5 (decoupledibpm.cpp:316-349): + the Lagrangian forces as /force"""
+        from . import h5io
+        super().writeRestartData(path)
+        with h5io.File(path, "a") as f:
+            f.write("force", self.getForces()[0])
+
+    def readRestartData(self, path: str) -> None:
+        from . import h5io
+        super().readRestartData(path)
+        with h5io.File(path, "r") as f:
+            self.setForces(f.read("force"))
 
     def getOperator(self, which: str):
         """'delta' | 'E' | 'H' | 'EBNH' as (n_rows, rowptr, col, val[, row_ids]) host arrays (inspection / parity)"""

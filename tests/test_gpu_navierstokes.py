@@ -151,3 +151,42 @@ def test_lid_driven_cavity_re100_matches_ghia():
     assert np.abs(Ut - ref.U).max() <= 1e-8
     s.destroy()
     t.destroy()
+
+
+def test_solution_grid_and_restart_files(tmp_path):
+    """The reference's on-disk formats (PetscViewerHDF5): grid.h5 (cartesianmesh.cpp:798-823), <step>.h5 with u, v, p and the
+    `time` attribute of /p (navierstokes.cpp:618-634), restart data /convection/<i>, /diffusion/0 (:637-746).  A run
+    restarted from its own file continues exactly like the uninterrupted one."""
+    h5io = pytest.importorskip("petibm_amd.h5io")
+    try:
+        h5io.lib()
+    except ImportError as e:
+        pytest.skip(str(e))
+    from petibm_amd.navierstokes import NavierStokesSolver
+    cfg = cavity((16, 12), nu=0.02, dt=0.01, stretched=True)
+    a = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=KSP_P)
+    a.advance(3)
+    rst = str(tmp_path / "0000003.h5")
+    a.write(rst)
+    a.writeRestartData(rst)
+    a.writeGrid(str(tmp_path / "grid.h5"))
+    a.advance(3)
+    Ua, pa = a.getState()
+    b = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=KSP_P)
+    b.readRestartData(rst)
+    assert b.ite == 3 and abs(b.t - 0.03) < 1e-15
+    b.advance(3)
+    Ub, pb = b.getState()
+    assert np.abs(Ub - Ua).max() <= 1e-13 and np.abs((pb - pb.mean()) - (pa - pa.mean())).max() <= 1e-11
+    with h5io.File(rst, "r") as f:
+        assert f.read("u").shape == (12, 15) and f.read("v").shape == (11, 16) and f.read("p").shape == (12, 16)
+        assert f.read_attr("p", "time") == pytest.approx(0.03) and f.read("diffusion/0").shape == (a.UN,)
+    with h5io.File(str(tmp_path / "grid.h5"), "r") as f:
+        m = omesh.create_mesh(cfg)
+        for fi, name in enumerate(("u", "v")):
+            for d, ax in enumerate("xy"):
+                want = np.array([m.coord[fi][d][i] for i in range(int(m.n[fi][d]))])  # n[f][d] entries from index 0
+                assert np.allclose(f.read(f"{name}/{ax}"), want, rtol=0, atol=1e-15)
+        assert np.allclose(f.read("p/x"), m.coord[3][0].true) and f.read("vertex/y").shape == (13,) and f.read("w/z").shape == (1,)
+    a.destroy()
+    b.destroy()
