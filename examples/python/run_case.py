@@ -80,6 +80,9 @@ def main():
         if have_h5 and nrestart > 0 and s.ite % nrestart == 0:
             s.writeRestartData(os.path.join(out, f"{s.ite:07d}.h5"))
     wall = time.perf_counter() - t0
+    it_file.close()
+    if f_file:
+        f_file.close()
     print(f"{nt} steps in {wall:.2f} s ({1e3 * wall / max(nt, 1):.2f} ms/step); last step: {s.linSolversInfo()}")
     s.destroy()
 
