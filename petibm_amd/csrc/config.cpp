@@ -185,8 +185,8 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
         c.presweeps = std::atoi(d.get(ps, "presweeps", "1").c_str());
         c.postsweeps = std::atoi(d.get(ps, "postsweeps", "1").c_str());
         c.max_levels = std::atoi(d.get(ps, "max_levels", "100").c_str());
-        c.min_coarse_rows = std::atoi(d.get(ps, "min_coarse_rows", "2").c_str());
-        c.dense_lu_num_rows = std::atoi(d.get(ps, "dense_lu_num_rows", "128").c_str());
+        // min_coarse_rows / dense_lu_num_rows / selector / interpolator ... steer AmgX's algebraic coarsening and have no
+        // counterpart in a geometric hierarchy (it always coarsens down to <= 2 cells per direction): accepted, unused
         c.coarsest_sweeps = std::max(1, std::atoi(d.get(ps, "coarsest_sweeps", "2").c_str())) * 16;
         std::string sm = upper(d.get(ps, "smoother", "BLOCK_JACOBI"));
         std::string sms = d.child_scope(ps, "smoother");

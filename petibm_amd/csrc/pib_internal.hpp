@@ -65,8 +65,6 @@ struct Config {
     double cheby_lmax = 2.0;   // eigenvalue window [lmax/ratio, lmax] of D^-1 A (Gershgorin: <= 2 for the FV Poisson operator)
     double cheby_ratio = 4.0;
     int max_levels = 100;
-    int min_coarse_rows = 2;
-    int dense_lu_num_rows = 128;  // coarsest level size at which coarsening stops
     int coarsest_sweeps = 32;
     // execution
     int check_every = 0;     // iterations enqueued between host convergence polls (0 = auto)
