@@ -253,3 +253,44 @@ def test_cylinder_re550_baseline_config4_drag():
         worst_p = max(worst_p, s.linSolversInfo()[3])
     assert worst_p <= 12  # the multigrid keeps its uniform-mesh rate on this mesh (cell widths span a factor 29)
     s.destroy()
+
+
+def test_flat_plate_3d_re100_aoa30_force_coefficients():
+    """The reference's 3-D validation case, verbatim: examples/decoupledibpm/flatplate3dRe100_GPU/AoA30 (127 x 56 x 84
+    stretched mesh, plate of aspect ratio 2 with 26 x 51 Lagrangian points, nu = 0.01, dt = 0.01, 2000 steps, convective
+    outlet, direct forces solve with 3978 unknowns).  Its plotForceCoefficients.py averages the forces over 15 <= t <= 20;
+    the reference's documentation shows C_D ~ 0.75, C_L ~ 0.72 for this angle next to Taira et al.'s measurements."""
+    import math
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    def sub(a, b, c, e1, e2, e3, r1, r3):
+        return [{"end": e1, "cells": a, "stretchRatio": r1}, {"end": e2, "cells": b, "stretchRatio": 1.0},
+                {"end": e3, "cells": c, "stretchRatio": r3}]
+    base = omesh.uniform_config((127, 56, 84))
+    base["mesh"] = [{"direction": "x", "start": -4.0, "subDomains": sub(43, 30, 54, -0.5, 0.7, 6.1, 0.970873786407767, 1.03)},
+                    {"direction": "y", "start": -5.0, "subDomains": sub(13, 30, 13, -0.6, 0.6, 5.0, 0.7692307692307692, 1.3)},
+                    {"direction": "z", "start": -5.0, "subDomains": sub(12, 60, 12, -1.2, 1.2, 5.0, 0.7692307692307692, 1.3)}]
+    cfg = flow_config(base, nu=0.01, dt=0.01)
+    for bc in cfg["flow"]["boundaryConditions"]:
+        if bc["location"] == "xPlus":
+            bc["v"], bc["w"] = ["CONVECTIVE", 0.0], ["CONVECTIVE", 0.0]
+    n = math.ceil(1.0 / 0.04)
+    sx = np.linspace(-0.5, 0.5, n + 1)
+    x, y = np.cos(np.radians(-30.0)) * sx, np.sin(np.radians(-30.0)) * sx
+    z = np.linspace(-1.0, 1.0, math.ceil(2.0 / 0.04) + 1)
+    body = np.concatenate([np.stack([x, y, np.full_like(x, zi)], axis=1) for zi in z])
+    vel = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
+           "solv:convergence=ABSOLUTE\nsolv:tolerance=1.0E-06\nsolv:norm=L2\nsolv:preconditioner(prec)=NOSOLVER\n")
+    s = DecoupledIBPMSolver(cfg, bodies=[body], velocity_cfg=vel, poisson_cfg=AMGX_P.format(tol="1.0E-06"), forces_cfg=FORCES)
+    assert s.pN == 127 * 56 * 84 and s.nf == 3 * 1326
+    s.advance(1500)
+    acc = np.zeros(3)
+    for _ in range(500):
+        s.advance()
+        acc += s.getForces()[1][0]
+    cd, cl, cz = acc / 500
+    g = G["taira_et_al_2007_flatplate_re100_ar2"]
+    ref = g["petibm_figure_at_30deg"]
+    assert abs(cd - ref["cd"]) <= ref["reading_error"] and abs(cl - ref["cl"]) <= ref["reading_error"]
+    assert abs(cd - np.interp(30.0, g["cd_aoa"], g["cd"])) < 0.2 * cd and abs(cl - np.interp(30.0, g["cl_aoa"], g["cl"])) < 0.08 * cl
+    assert abs(cz) < 1e-6  # symmetric in z: no side force
+    s.destroy()
