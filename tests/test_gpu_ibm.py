@@ -294,3 +294,24 @@ def test_flat_plate_3d_re100_aoa30_force_coefficients():
     assert abs(cd - np.interp(30.0, g["cd_aoa"], g["cd"])) < 0.2 * cd and abs(cl - np.interp(30.0, g["cl_aoa"], g["cl"])) < 0.08 * cl
     assert abs(cz) < 1e-6  # symmetric in z: no side force
     s.destroy()
+
+
+def test_cpp_flow_solver_mirror_runs_the_cylinder():
+    """include/petibm_amd/flowsolver.hpp (C++ mirror of NavierStokesSolver / DecoupledIBPMSolver / RigidKinematicsSolver)
+    over the C ABI from a plain g++ program, no Python in the process: the reference's cylinder2dRe40 parameters, 300 steps."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "cpp", "cylinder_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++14", "-I", os.path.join(root, "include"),
+                               os.path.join(root, "examples", "cpp", "cylinder_demo.cpp"), "-L",
+                               os.path.join(root, "petibm_amd", "lib"), "-lpetibm_amd",
+                               "-Wl,-rpath,$ORIGIN/../../petibm_amd/lib", "-o", exe])
+    out = subprocess.run([exe, "300"], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "UN = 68820, pN = 34596, force unknowns = 252" in out.stdout
+    cd = float(re.search(r"cd = ([-0-9.eE+]+)", out.stdout).group(1))
+    kl = G["koumoutsakos_leonard_1995_cylinder_re40"]
+    want = np.interp(3.0, 0.5 * np.array(kl["t_radius_units"]), np.array(kl["cd"]))
+    assert abs(cd - want) < 0.05 * cd
