@@ -30,6 +30,11 @@ void DeviceCsr::release()
     val = nullptr;
     dinv = nullptr;
     n = nnz = 0;
+    seg_send_prev.clear();
+    seg_send_next.clear();
+    seg_recv_lo.clear();
+    seg_recv_hi.clear();
+    segmented = false;
 }
 
 // DMDA default ownership along one axis (cartesianmesh.cpp:492-538 via
@@ -299,9 +304,12 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
 namespace pib {
 
 struct FieldDev {
-    int64_t n[3];        // points of this field
-    int64_t row_off;     // first packed row of the field's block
+    int64_t n[3];        // points of this field (global)
+    int64_t row_off;     // first packed LOCAL row of the field's block
     int64_t nnz_off;     // first nnz of the field's block
+    // slab of this rank along the last axis: planes [kb, ke) of the field; the neighbours' planes kb-1 / ke live in the
+    // ghost pads at ghost_lo_off / ghost_hi_off (local column indices: [ghost_lo | owned | ghost_hi])
+    int64_t kb, ke, col_base, ghost_lo_off, ghost_hi_off;
     const double *dl[3];     // dL[f][d], index s+1 (ghost at 0)
     const double *co[3];     // coord[f][d], index s+1
     double a0[6];            // ghost coefficient per boundary location (0 where periodic / unused)
@@ -363,12 +371,17 @@ __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, 
                                                            RP *__restrict__ rowptr, int32_t *__restrict__ col,
                                                            double *__restrict__ val, int last_field)
 {
-    const int64_t nx = F.n[0], ny = F.n[1], nz = F.n[2], pl = nx * ny, nf = pl * nz;
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= nf; r += (int64_t)gridDim.x * 256) {
-        int64_t p = F.nnz_off + nnz_before(r, dim, nx, ny, nz);
-        if (r < nf || last_field) rowptr[F.row_off + r] = (RP)p;
-        if (r == nf) break;
-        const int64_t ijk[3] = {r % nx, (r / nx) % ny, r / pl};
+    // the slab axis is the last one: z in 3-D, y in 2-D (planes of a 2-D field are its grid lines)
+    const int64_t nx = F.n[0], ny = F.n[1], nz = F.n[2];
+    const int64_t pl = (dim == 3) ? nx * ny : nx;  // entries per plane of the slab axis
+    const int64_t g0 = pl * F.kb, nf = pl * (F.ke - F.kb);
+    const int64_t base_nnz = nnz_before(g0, dim, nx, ny, nz);
+    for (int64_t lr = (int64_t)blockIdx.x * 256 + threadIdx.x; lr <= nf; lr += (int64_t)gridDim.x * 256) {
+        const int64_t r = g0 + lr;  // row in the field's global natural order
+        int64_t p = F.nnz_off + (nnz_before(r, dim, nx, ny, nz) - base_nnz);
+        if (lr < nf || last_field) rowptr[F.row_off + lr] = (RP)p;
+        if (lr == nf) break;
+        const int64_t ijk[3] = {r % nx, (r / nx) % ny, r / (nx * ny)};
         double v[6] = {0, 0, 0, 0, 0, 0};
         bool interior[6] = {false, false, false, false, false, false};
         double acc = 0.0;
@@ -390,12 +403,15 @@ __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, 
                 const double t = v[q] * F.a0[q];
                 if (t != 0.0) diag = diag + t;  // MAT_IGNORE_ZERO_ENTRIES: a zero fold is not added
             }
-        const int64_t lc = F.row_off + r;
-        const int64_t st[3] = {1, nx, pl};
-        // columns ascending: z-, y-, x-, diag, x+, y+, z+
+        const int64_t lc = F.col_base + F.row_off + lr;  // local column of this row's own entry
+        const int64_t st[3] = {1, nx, nx * ny};
+        const int sd = dim - 1;
+        const int64_t ks = ijk[sd], inplane = lr % pl;
+        // columns ascending: z-, y-, x-, diag, x+, y+, z+ (a neighbour rank's plane sits in a ghost pad: the low pad
+        // precedes and the high pad follows every owned column, so the order is kept)
         for (int d = dim - 1; d >= 0; --d)
             if (interior[2 * d]) {
-                col[p] = (int32_t)(lc - st[d]);
+                col[p] = (d == sd && ks - 1 < F.kb) ? (int32_t)(F.ghost_lo_off + inplane) : (int32_t)(lc - st[d]);
                 val[p] = v[2 * d] * scale;
                 ++p;
             }
@@ -404,7 +420,7 @@ __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, 
         ++p;
         for (int d = 0; d < dim; ++d)
             if (interior[2 * d + 1]) {
-                col[p] = (int32_t)(lc + st[d]);
+                col[p] = (d == sd && ks + 1 >= F.ke) ? (int32_t)(F.ghost_hi_off + inplane) : (int32_t)(lc + st[d]);
                 val[p] = v[2 * d + 1] * scale;
                 ++p;
             }
@@ -415,32 +431,76 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
                       const double mx[3], const double a0[18], double dt, double coeff_nu)
 {
     if (dim != 2 && dim != 3) return fail(PIB_ERR_ARG_OUTOFRANGE, "assemble_velocity: dim must be 2 or 3");
-    if (s->comm.nranks > 1) return fail(PIB_ERR_SUP, "assemble_velocity: single rank only (packed ordering)");
     for (int d = 0; d < dim; ++d)
         if (n[d] < 2 || w[d] == nullptr) return fail(PIB_ERR_ARG_SIZ, "assemble_velocity: need >= 2 cells per direction");
     // ---- host mesh arithmetic (cartesianmesh.cpp:136-355, non-periodic)
     std::vector<double> hdl[3][3], hco[3][3];
     int64_t fn[3][3];
     velocity_mesh_arrays(dim, n, w, mn, mx, hdl, hco, fn);
-    // ---- sizes
-    int64_t rows = 0, nnz = 0, row_off[3] = {0, 0, 0}, nnz_off[3] = {0, 0, 0};
+    // ---- sizes.  Decomposition: slabs along the last axis with the pressure grid's ownership (the velocity DMDAs
+    // reuse the pressure process grid, cartesianmesh.cpp:516-535): rank r owns the planes of its pressure cells; the
+    // component along the slab axis has one plane fewer, taken from the last rank.  Each rank's vector is the packed
+    // [u-slab | v-slab | w-slab] of the reference's DMComposite (cartesianmesh.cpp:740-779).
+    const int P = s->comm.nranks, rank = s->comm.rank, sd = dim - 1;
+    int64_t pk0, pk1;
+    slab_range(n[sd], P, rank, &pk0, &pk1);
+    int64_t rows = 0, nnz = 0, row_off[3] = {0, 0, 0}, nnz_off[3] = {0, 0, 0}, kb[3] = {0, 0, 0}, ke[3] = {0, 0, 0},
+            pl[3] = {0, 0, 0}, glo[3] = {0, 0, 0}, ghi[3] = {0, 0, 0};
+    int64_t ghost_lo = 0, ghost_hi = 0;
     for (int f = 0; f < dim; ++f) {
+        kb[f] = pk0;
+        ke[f] = std::min(pk1, fn[f][sd]);
+        if (P > 1 && ke[f] - kb[f] < 1)
+            return fail(PIB_ERR_SUP, "assemble_velocity: rank %d owns no plane of velocity component %d (need >= 2 pressure planes "
+                                     "per rank)", rank, f);
+        pl[f] = (dim == 3) ? fn[f][0] * fn[f][1] : fn[f][0];
         row_off[f] = rows;
         nnz_off[f] = nnz;
-        const int64_t nf = fn[f][0] * fn[f][1] * fn[f][2];
-        rows += nf;
-        nnz += nnz_before(nf, dim, fn[f][0], fn[f][1], fn[f][2]);
+        rows += pl[f] * (ke[f] - kb[f]);
+        nnz += nnz_before(pl[f] * ke[f], dim, fn[f][0], fn[f][1], fn[f][2]) -
+               nnz_before(pl[f] * kb[f], dim, fn[f][0], fn[f][1], fn[f][2]);
+        if (rank > 0) {
+            glo[f] = ghost_lo;
+            ghost_lo += pl[f];
+        }
+        if (rank < P - 1) {
+            ghi[f] = ghost_hi;
+            ghost_hi += pl[f];
+        }
+    }
+    int64_t n_global = 0, row0 = 0;
+    for (int q = 0; q < P; ++q) {
+        int64_t b, e, nq = 0;
+        slab_range(n[sd], P, q, &b, &e);
+        for (int f = 0; f < dim; ++f) nq += pl[f] * (std::min(e, fn[f][sd]) - b);
+        if (q < rank) row0 += nq;
+        n_global += nq;
     }
     DeviceCsr &A = s->A;
     A.release();
     A.n = rows;
-    A.row0 = 0;
-    A.n_global = rows;
-    A.ghost_lo = A.ghost_hi = 0;
+    A.row0 = row0;
+    A.n_global = n_global;
+    A.ghost_lo = ghost_lo;
+    A.ghost_hi = ghost_hi;
     A.nnz = nnz;
     A.rp64 = nnz >= (int64_t)std::numeric_limits<int32_t>::max();
-    if (rows >= (int64_t)std::numeric_limits<int32_t>::max())
-        return fail(PIB_ERR_SUP, "assemble_velocity: more than 2^31 rows on one GPU");
+    if (ghost_lo + rows + ghost_hi >= (int64_t)std::numeric_limits<int32_t>::max())
+        return fail(PIB_ERR_SUP, "assemble_velocity: more than 2^31 local columns on one GPU");
+    if (P > 1) {
+        // one plane of every component to each neighbour, received back to back into the ghost pads
+        A.segmented = true;
+        for (int f = 0; f < dim; ++f) {
+            if (rank > 0) {
+                A.seg_send_prev.push_back({row_off[f], pl[f]});
+                A.seg_recv_lo.push_back(pl[f]);
+            }
+            if (rank < P - 1) {
+                A.seg_send_next.push_back({row_off[f] + pl[f] * (ke[f] - kb[f] - 1), pl[f]});
+                A.seg_recv_hi.push_back(pl[f]);
+            }
+        }
+    }
     PIB_HIP(hipMalloc(&A.rowptr, (A.rp64 ? 8 : 4) * ((size_t)rows + 1)));
     PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
     PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));
@@ -465,8 +525,13 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
         }
         F.row_off = row_off[f];
         F.nnz_off = nnz_off[f];
+        F.kb = kb[f];
+        F.ke = ke[f];
+        F.col_base = ghost_lo;
+        F.ghost_lo_off = glo[f];
+        F.ghost_hi_off = ghost_lo + rows + ghi[f];
         for (int q = 0; q < 6; ++q) F.a0[q] = a0[6 * f + q];
-        const int64_t nf = fn[f][0] * fn[f][1] * fn[f][2];
+        const int64_t nf = pl[f] * (ke[f] - kb[f]);
         const int nb = (int)std::min<int64_t>(8192, (nf + 1 + 255) / 256);
         const int last = (f == dim - 1) ? 1 : 0;
         if (A.rp64)

@@ -34,6 +34,7 @@ struct LoopbackGroup {
     // per-rank published state
     std::vector<const double *> ptr;
     std::vector<int64_t> count;
+    std::vector<const std::vector<std::pair<int64_t, int64_t>> *> segs_prev, segs_next;  // segmented plans of the ranks
     std::vector<hipEvent_t> ev_ready, ev_done;
     std::vector<int64_t> host_vals;  // [nranks][4]
     double *staging = nullptr;       // device, [nranks][PIB_NRED]
@@ -126,6 +127,7 @@ int comm_setup_halo(pib_solver *s)
             return fail(PIB_ERR_ARG_OUTOFRANGE, "single-rank matrix has columns outside [0, n)");
         return 0;
     }
+    if (A.segmented) return 0;  // the assembly that chose the segmented plan has set every list
     const int P = s->comm.nranks, r = s->comm.rank;
     const int64_t mine[4] = {A.n, A.ghost_lo, A.ghost_hi, A.row0};
     std::vector<int64_t> all;
@@ -198,9 +200,73 @@ int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_
     return 0;
 }
 
+// segmented plan (DeviceCsr::seg_*): several {offset, count} pieces of the owned vector per neighbour, received back to
+// back into the ghost pads
+static int halo_exchange_segments(pib_solver *s, double *x_owned, hipStream_t st)
+{
+    const DeviceCsr &A = s->A;
+    const int P = s->comm.nranks, r = s->comm.rank;
+    s->counters[3]++;
+    if (s->comm.loop) {
+        LoopbackGroup *g = s->comm.loop;
+        g->ptr[(size_t)r] = x_owned;
+        g->segs_prev[(size_t)r] = &A.seg_send_prev;
+        g->segs_next[(size_t)r] = &A.seg_send_next;
+        PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
+        g->barrier();
+        if (r > 0 && !A.seg_recv_lo.empty()) {
+            PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)(r - 1)], 0));
+            double *dst = x_owned - A.ghost_lo;
+            for (const auto &sg : *g->segs_next[(size_t)(r - 1)]) {  // what r-1 sends to its next rank = my low ghosts
+                PIB_HIP(hipMemcpyAsync(dst, g->ptr[(size_t)(r - 1)] + sg.first, sizeof(double) * (size_t)sg.second,
+                                       hipMemcpyDeviceToDevice, st));
+                dst += sg.second;
+            }
+        }
+        if (r < P - 1 && !A.seg_recv_hi.empty()) {
+            PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)(r + 1)], 0));
+            double *dst = x_owned + A.n;
+            for (const auto &sg : *g->segs_prev[(size_t)(r + 1)]) {
+                PIB_HIP(hipMemcpyAsync(dst, g->ptr[(size_t)(r + 1)] + sg.first, sizeof(double) * (size_t)sg.second,
+                                       hipMemcpyDeviceToDevice, st));
+                dst += sg.second;
+            }
+        }
+        PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
+        g->barrier();
+        if (r > 0) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)(r - 1)], 0));
+        if (r < P - 1) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)(r + 1)], 0));
+        g->barrier();
+        return 0;
+    }
+    PIB_NCCL(ncclGroupStart());
+    if (r > 0) {
+        for (const auto &sg : A.seg_send_prev)
+            PIB_NCCL(ncclSend(x_owned + sg.first, (size_t)sg.second, ncclDouble, r - 1, s->comm.comm, st));
+        double *dst = x_owned - A.ghost_lo;
+        for (int64_t c : A.seg_recv_lo) {
+            PIB_NCCL(ncclRecv(dst, (size_t)c, ncclDouble, r - 1, s->comm.comm, st));
+            dst += c;
+        }
+    }
+    if (r < P - 1) {
+        for (const auto &sg : A.seg_send_next)
+            PIB_NCCL(ncclSend(x_owned + sg.first, (size_t)sg.second, ncclDouble, r + 1, s->comm.comm, st));
+        double *dst = x_owned + A.n;
+        for (int64_t c : A.seg_recv_hi) {
+            PIB_NCCL(ncclRecv(dst, (size_t)c, ncclDouble, r + 1, s->comm.comm, st));
+            dst += c;
+        }
+    }
+    PIB_NCCL(ncclGroupEnd());
+    return 0;
+}
+
 int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st)
 {
     const DeviceCsr &A = s->A;
+    if (s->comm.nranks <= 1) return 0;
+    if (A.segmented) return halo_exchange_segments(s, x_owned, st);
     return halo_exchange_planes(s, x_owned, A.n, A.ghost_lo, A.ghost_hi, A.send_prev, A.send_next, st);
 }
 
@@ -287,6 +353,8 @@ extern "C" int pib_comm_loopback_create(int nranks, void *uid_out)
     LoopbackGroup *g = new LoopbackGroup();
     g->nranks = nranks;
     g->ptr.assign((size_t)nranks, nullptr);
+    g->segs_prev.assign((size_t)nranks, nullptr);
+    g->segs_next.assign((size_t)nranks, nullptr);
     g->count.assign((size_t)nranks, 0);
     g->host_vals.assign(4 * (size_t)nranks, 0);
     g->ev_ready.resize((size_t)nranks);

@@ -118,6 +118,13 @@ struct DeviceCsr {
     int64_t n_lo = 0, n_hi = 0;     // rows touching the low / high halo (contiguous at both ends)
     int64_t send_prev = 0, send_next = 0;  // entries the neighbours need from this rank
     int64_t max_chunk_nnz = 1 << 30;       // largest 256-row chunk (selects the SpMV's LDS capacity)
+    // Segmented halo plan (packed velocity ordering: a rank's vector is [u-slab | v-slab | w-slab], so what a neighbour
+    // needs is one plane out of each block): {offset in the owned vector, count} per message to the previous / next
+    // rank; the ghost pads receive the neighbours' segments back to back in the same order.  Empty: the contiguous
+    // plan (send_prev / send_next entries from the two ends).
+    std::vector<std::pair<int64_t, int64_t>> seg_send_prev, seg_send_next;
+    std::vector<int64_t> seg_recv_lo, seg_recv_hi;  // counts of the segments received into the low / high ghost pad
+    bool segmented = false;
     void release();
 };
 
