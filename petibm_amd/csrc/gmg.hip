@@ -132,9 +132,14 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
     // in the workgroups of OTHER XCDs, so every L2 fetched x twice (PMC: 3.22 GB read per 512^3 sweep for 2.15 GB
     // of b and x).  Dealing each XCD a contiguous band of the plane leaves 8 band edges per plane instead.
     const unsigned bx = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // rocprof SQ counters: these kernels stall on vector-memory ISSUE (SQ_WAIT_INST_ANY 0.6 of the wave cycles, 26 VMEM
+    // reads per wave), not on data.  When a wave stays inside one grid line (nxc a multiple of 64) j is wave-uniform:
+    // its coefficients then come through the scalar path; the x coefficients of the lane's C cells are one vector load.
+    const bool j_uniform = (nxc & 63u) == 0u;
     for (unsigned q = bx * 256u + threadIdx.x; q < planec; q += gridDim.x * 256u) {
-        const int j = (int)(q / nxc);
+        int j = (int)(q / nxc);
         const int i0 = (int)(q - (unsigned)j * nxc) * C;
+        if (j_uniform) j = __builtin_amdgcn_readfirstlane(j);
         const int64_t p = (int64_t)kk * plane + (int64_t)j * L.nx + i0;
         const double wyj = L.wy[j];
         const double gym = (j > 0) ? L.gy[j - 1] : 0.0, gyp = (j < L.ny - 1) ? L.gy[j] : 0.0;
@@ -160,11 +165,13 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             if (pin_sum != nullptr && p == 0 && L.k0 == 0) bv[0] = bv[0] - *pin_sum;
         }
         double gxm = (i0 > 0) ? L.gx[i0 - 1] : 0.0;
+        const vt wxv = *reinterpret_cast<const vt *>(L.wx + i0);
+        const vt gxv = *reinterpret_cast<const vt *>(L.gx + i0);  // gx is padded: entry nx-1 exists and is never used
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int i = i0 + c;
-            const double wxi = L.wx[i];
-            const double gxp = (i < L.nx - 1) ? L.gx[i] : 0.0;
+            const double wxi = wxv[c];
+            const double gxp = (i < L.nx - 1) ? gxv[c] : 0.0;
             const double ay = wxi * wzk, az = wxi * wyj;
             const double c0 = ax * gxm, c1 = ax * gxp, c2 = ay * gym, c3 = ay * gyp, c4 = az * gzm, c5 = az * gzp;
             gxm = gxp;
@@ -649,10 +656,12 @@ static dim3 level_grid(const GridLevel &g)
     return dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (plane + 255) / 256)), (unsigned)std::max<int64_t>(1, g.k1 - g.k0));
 }
 
+// (+8 zero entries of padding: the level kernels read the 1-D arrays in aligned vectors of up to 4)
 template <class T>
 static int up(const std::vector<T> &h, T **d)
 {
-    PIB_HIP(hipMalloc(d, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    PIB_HIP(hipMalloc(d, sizeof(T) * (h.size() + 8)));
+    PIB_HIP(hipMemset(*d, 0, sizeof(T) * (h.size() + 8)));
     if (!h.empty()) PIB_HIP(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     return 0;
 }
