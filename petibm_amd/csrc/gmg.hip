@@ -276,12 +276,16 @@ __device__ __forceinline__ void tr1d(const Tr1 &t, int s, int I[2], double wt[2]
 // ---- transfer kernels, row form -------------------------------------------------------------------------
 // One wave <-> one grid row (fixed j, k: the y / z stencils are wave-uniform, i.e. scalar loads), one lane <-> one
 // COARSE cell I of that row and its one or two fine children.  The x neighbours I-1 / I+1 come from the
-// neighbouring lanes (__shfl), only the two wave-edge lanes load them: a coarse value is loaded once per row
+// neighbouring lanes (__shfl).  Prolongation: consecutive waves overlap by two lanes (62 producing lanes, lanes 0 and
+// 63 only feed their neighbours -- single-lane edge loads were most of its vector-memory instructions: 737 -> 566 us);
+// restriction: aligned 64-lane chunks whose two edge lanes load their outer neighbour (the overlap measured slower
+// there: 740 -> 854 us).  A coarse value is loaded once per row
 // instead of three times (prolongation) and a fine value once instead of twice (restriction) -- these kernels
 // are bound by the vector-memory issue rate, not by HBM (rocprof r01: 1.2 ms / 0.83 ms per 512^3 launch with
 // per-lane table gathers, 0.47 / 0.25 ms of HBM time).  Row groups are dealt to the XCDs in contiguous ranges
 // (workgroup b runs on XCD b % 8), so a coarse row is fetched by one L2 only.
 // Summation order = the oracle's: z, then y, then x ascending, weights ((wz*wy)*wx); zero weights add exactly 0.
+constexpr int ROW_LANES = 62;  // producing lanes per wave; lanes 0 and 63 are the overlap with the neighbouring waves
 __device__ __forceinline__ bool row_of_wave(int ngroups, int per_xcd, int nrows, int *row)
 {
     const int b = blockIdx.x;
@@ -305,15 +309,14 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
     if (!row_of_wave(ngroups, per_xcd, (nrows + RP - 1) / RP, &row0)) return;
     row0 *= RP;
     const int lane = threadIdx.x;
-    const int Iraw = blockIdx.y * 64 + lane;
-    const bool valid = Iraw < C.nx;
-    const int I = valid ? Iraw : C.nx - 1;
+    const int Iraw = blockIdx.y * ROW_LANES + lane - 1;
+    const bool valid = lane >= 1 && lane <= ROW_LANES && Iraw < C.nx;
+    const int I = min(max(Iraw, 0), C.nx - 1);
     const int2 fc = F.tx.fc[I];
     const double4 pw = F.tx.pw[I];
-    const bool edgeL = (lane == 0 && I > 0), edgeR = (lane == 63 && I + 1 < C.nx);
     const int64_t cplane = (int64_t)C.nx * C.ny, fplane = (int64_t)F.nx * F.ny;
     const bool vec = vec_ok && __all(!valid || (fc.y == 2 && !(fc.x & 1)));
-    double vP[RP][4], eL[RP][4], eR[RP][4], w4[RP][4], d0[RP], d1[RP];
+    double vP[RP][4], w4[RP][4], d0[RP], d1[RP];
     int64_t off[RP];
 #pragma unroll
     for (int r = 0; r < RP; ++r) {
@@ -330,17 +333,18 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
                 const double *rowp = xc + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0);
                 w4[r][c2 * 2 + b2] = wk[c2] * wj[b2];
                 vP[r][c2 * 2 + b2] = rowp[I];
-                eL[r][c2 * 2 + b2] = edgeL ? rowp[I - 1] : 0.0;
-                eR[r][c2 * 2 + b2] = edgeR ? rowp[I + 1] : 0.0;
             }
         off[r] = (int64_t)kk * fplane + (int64_t)j * F.nx + fc.x;
-        if (vec) {
-            const double2 v = *reinterpret_cast<const double2 *>(xf + off[r]);
-            d0[r] = v.x;
-            d1[r] = v.y;
-        } else {
-            d0[r] = xf[off[r]];
-            d1[r] = (fc.y == 2) ? xf[off[r] + 1] : 0.0;
+        d0[r] = d1[r] = 0.0;
+        if (valid) {
+            if (vec) {
+                const double2 v = *reinterpret_cast<const double2 *>(xf + off[r]);
+                d0[r] = v.x;
+                d1[r] = v.y;
+            } else {
+                d0[r] = xf[off[r]];
+                if (fc.y == 2) d1[r] = xf[off[r] + 1];
+            }
         }
     }
 #pragma unroll
@@ -350,9 +354,7 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
         for (int q = 0; q < 4; ++q) {
             const double wkj = w4[r][q];
             const double v = vP[r][q];
-            double vL = __shfl_up(v, 1, 64), vR = __shfl_down(v, 1, 64);
-            if (edgeL) vL = eL[r][q];
-            if (edgeR) vR = eR[r][q];
+            const double vL = __shfl_up(v, 1, 64), vR = __shfl_down(v, 1, 64);
             if (wkj == 0.0) continue;  // wave-uniform: the oracle skips zero weights too
             sl += (wkj * pw.x) * v;
             sl += (wkj * pw.y) * vL;
@@ -721,12 +723,12 @@ struct RowGrid {
     int ngroups, per_xcd;
     dim3 grid;
 };
-static RowGrid row_grid(int64_t nrows, int64_t ncx)
+static RowGrid row_grid(int64_t nrows, int64_t ncx, int lanes = ROW_LANES)
 {
     RowGrid r;
     r.ngroups = (int)((nrows + 3) / 4);
     r.per_xcd = (r.ngroups + 7) / 8;
-    r.grid = dim3((unsigned)(8 * r.per_xcd), (unsigned)((ncx + 63) / 64));
+    r.grid = dim3((unsigned)(8 * r.per_xcd), (unsigned)((ncx + lanes - 1) / lanes));
     return r;
 }
 static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *xc, double *xf, const Scalars *S, hipStream_t q)
@@ -746,7 +748,7 @@ static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *
 // `c` carries the coarse planes to produce in k0 / k1 (the owned ones, which may be a part of a replicated level)
 static int launch_restrict(const GridLevel &f, const GridLevel &c, const double *rf, double *bc, const Scalars *S, hipStream_t q)
 {
-    const RowGrid r = row_grid(c.n[1] * (c.k1 - c.k0), c.n[0]);
+    const RowGrid r = row_grid(c.n[1] * (c.k1 - c.k0), c.n[0], 64);  // aligned 64-lane chunks + edge loads (62 overlapping lanes measured slower here)
     const int vec_ok = (f.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(rf) & 15u) == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_restrict_rows, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), rf, bc, r.ngroups, r.per_xcd, vec_ok);
     PIB_HIP(hipGetLastError());
