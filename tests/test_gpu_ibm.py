@@ -315,3 +315,36 @@ def test_cpp_flow_solver_mirror_runs_the_cylinder():
     kl = G["koumoutsakos_leonard_1995_cylinder_re40"]
     want = np.interp(3.0, 0.5 * np.array(kl["t_radius_units"]), np.array(kl["cd"]))
     assert abs(cd - want) < 0.05 * cd
+
+
+def test_cylinder_re100_vortex_shedding_matches_the_reference_readme():
+    """examples/decoupledibpm/cylinder2dRe100_GPU verbatim (562 x 447 stretched mesh, 158 points, dt = 0.01, 20000 steps).
+    Its README reports, for the reference's own run, <Cl> = 0.0022 with min -0.3473 and max 0.3474 over 100 <= t <= 200
+    (and <Cd> = 1.3422 over the same window, which contains part of the growth of the instability; here the shedding,
+    triggered by rounding alone, saturates around t = 160, so the limit-cycle amplitude is the comparable number)."""
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    def axis(lo, a, b, c, e3):
+        return {"start": lo, "subDomains": [{"end": -0.75, "cells": a, "stretchRatio": 0.991332611050921},
+                                            {"end": 0.75, "cells": b, "stretchRatio": 1.0},
+                                            {"end": e3, "cells": c, "stretchRatio": 1.008743169398907}]}
+    base = omesh.uniform_config((562, 447))
+    base["mesh"] = [dict(axis(-10.0, 186, 75, 301, 30.0), direction="x"), dict(axis(-10.0, 186, 75, 186, 10.0), direction="y")]
+    cfg = flow_config(base, nu=0.01, dt=0.01)
+    vel = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n"
+           "-velocity_pc_type jacobi\n-velocity_pc_jacobi_type diagonal\n")
+    s = DecoupledIBPMSolver(cfg, bodies=[circle(158)], velocity_cfg=vel, poisson_cfg=AMGX_P.format(tol="1.0E-06"), forces_cfg=FORCES)
+    assert s.pN == 562 * 447
+    s.advance(17000)
+    cl, cd = [], []
+    for _ in range(3000):
+        s.advance()
+        f = s.getForces()[1][0]
+        cd.append(2.0 * f[0])
+        cl.append(2.0 * f[1])
+    cl, cd = np.array(cl), np.array(cd)
+    assert abs(cl.max() - 0.3474) < 0.004 and abs(cl.min() + 0.3473) < 0.004   # the reference's reported extrema
+    assert 1.33 < cd.mean() < 1.42
+    up = np.flatnonzero((cl[:-1] < 0) & (cl[1:] >= 0))
+    st = 1.0 / (np.diff(up).mean() * 0.01)   # shedding frequency * D / U
+    assert 0.16 < st < 0.175
+    s.destroy()
