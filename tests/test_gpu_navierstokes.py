@@ -190,3 +190,29 @@ def test_solution_grid_and_restart_files(tmp_path):
         assert np.allclose(f.read("p/x"), m.coord[3][0].true) and f.read("vertex/y").shape == (13,) and f.read("w/z").shape == (1,)
     a.destroy()
     b.destroy()
+
+
+def test_lid_driven_cavity_re1000_matches_ghia():
+    """examples/navierstokes/liddrivencavity2dRe1000 verbatim: 128 x 128, nu = 0.001, dt = 0.004, 10000 steps (t = 40);
+    its plotCenterlineVelocities.py compares with Ghia et al. (1982) at Re = 1000."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    n = 128
+    cfg = cavity((n, n), nu=0.001, dt=0.004)
+    vel = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n"
+           "-velocity_pc_type jacobi\n")
+    poi = ("-poisson_ksp_type cg\n-poisson_ksp_atol 1.0E-06\n-poisson_ksp_rtol 0.0\n-poisson_ksp_max_it 1000\n"
+           "-poisson_pc_type gamg\n")
+    s = NavierStokesSolver(cfg, velocity_cfg=vel, poisson_cfg=poi)
+    s.advance(10000)
+    U, p = s.getState()
+    u = U[: (n - 1) * n].reshape(n, n - 1)
+    v = U[(n - 1) * n:].reshape(n - 1, n)
+    yc = (np.arange(n) + 0.5) / n
+    g = G["ghia_1982_re1000_centerlines"]
+    ui = np.interp(g["y"][1:-1], yc, u[:, n // 2 - 1])
+    vi = np.interp(g["x"][1:-1], yc, v[n // 2 - 1, :])
+    assert np.abs(ui - np.array(g["u"][1:-1])).max() < 0.02
+    assert np.abs(vi - np.array(g["v"][1:-1])).max() < 0.02
+    ite, vi_, vr, pi_, pr = s.linSolversInfo()
+    assert ite == 10000 and vi_ < 20 and pi_ < 20
+    s.destroy()
