@@ -6,7 +6,8 @@
 // with a few hundred to a few thousand unknowns and is solved once per time step, so the set-up cost is paid once
 // (static bodies) and the solve must be a single short launch: setMatrix forms the explicit inverse in HBM by
 // Gauss-Jordan elimination (no pivoting: SPD / diagonally dominant matrices; a vanishing pivot is an error), one
-// pair of launches per column, each a rank-1 update streamed at HBM rate (n^3 * 16 B in total: 0.13 s at n = 4000);
+// launch per column (workgroup i owns row i), all of them captured once per matrix order into a hipGraph -- a moving
+// body re-factorises every time step; each launch is a rank-1 update streamed at HBM rate (n^3 * 16 B in total);
 // solve is one dense mat-vec, one wave per row, fixed summation order.
 #include <cmath>
 
@@ -29,37 +30,35 @@ __global__ __launch_bounds__(256) void k_dense_identity(int64_t n, double *__res
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) I[r * n + r] = 1.0;
 }
 
-// step k, part 1: scaled pivot row of [M | Inv] into rowM / rowI, elimination factors (column k of M) into fac
-__global__ __launch_bounds__(256) void k_gj_pivot(int64_t n, int64_t k, double *__restrict__ M, double *__restrict__ Inv,
-                                                  double *__restrict__ rowM, double *__restrict__ rowI,
-                                                  double *__restrict__ fac, int *__restrict__ bad)
-{
-    const double p = M[k * n + k];
-    if (!(fabs(p) > 1e-300)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *bad = (int)k + 1;
-        return;
-    }
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) {
-        rowM[c] = M[k * n + c] / p;
-        rowI[c] = Inv[k * n + c] / p;
-        fac[c] = (c == k) ? 0.0 : M[c * n + k];
-    }
-}
-
-// step k, part 2: rows i != k:  M[i, k:] -= f_i rowM[k:],  Inv[i, :k+1] -= f_i rowI[:k+1]; row k := the scaled row.
-// (columns < k of M are already unit vectors, columns > k of Inv still are.)
-__global__ __launch_bounds__(256) void k_gj_update(int64_t n, int64_t k, double *__restrict__ M, double *__restrict__ Inv,
-                                                   const double *__restrict__ rowM, const double *__restrict__ rowI,
-                                                   const double *__restrict__ fac, const int *__restrict__ bad)
+// Gauss-Jordan step k, ONE launch: workgroup i owns row i of [M | Inv] (nobody else writes it), reads the pivot row k
+// (which no workgroup modifies in step k) and its own factor f_i = M[i,k] / M[k,k] before touching anything:
+//   row_i -= f_i * row_k   (i != k);   columns < k of M are already zero outside the diagonal, columns > k of Inv still are.
+// The pivots stay unscaled until k_gj_scale divides every row by its diagonal entry.
+__global__ __launch_bounds__(256) void k_gj_step(int64_t n, int64_t k, double *__restrict__ M, double *__restrict__ Inv,
+                                                 int *__restrict__ bad)
 {
     if (*bad) return;
-    const int64_t i = blockIdx.y;
-    const double f = fac[i];
-    const bool piv = (i == k);
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) {
-        if (c >= k) M[i * n + c] = piv ? rowM[c] : M[i * n + c] - f * rowM[c];
-        if (c <= k) Inv[i * n + c] = piv ? rowI[c] : Inv[i * n + c] - f * rowI[c];
+    const int64_t i = blockIdx.x;
+    const double p = M[k * n + k];
+    if (!(fabs(p) > 1e-300)) {
+        if (i == 0 && threadIdx.x == 0) *bad = (int)k + 1;
+        return;
     }
+    if (i == k) return;
+    const double f = M[i * n + k] / p;
+    __syncthreads();  // every thread has its factor before the row (including M[i,k]) changes
+    if (f == 0.0) return;
+    for (int64_t c = k + threadIdx.x; c < n; c += 256) M[i * n + c] = M[i * n + c] - f * M[k * n + c];
+    for (int64_t c = threadIdx.x; c <= k; c += 256) Inv[i * n + c] = Inv[i * n + c] - f * Inv[k * n + c];
+}
+
+__global__ __launch_bounds__(256) void k_gj_scale(int64_t n, const double *__restrict__ M, double *__restrict__ Inv,
+                                                  const int *__restrict__ bad)
+{
+    if (*bad) return;
+    const int64_t i = blockIdx.x;
+    const double d = M[i * n + i];
+    for (int64_t c = threadIdx.x; c < n; c += 256) Inv[i * n + c] = Inv[i * n + c] / d;
 }
 
 // y = Inv b, one wave per row
@@ -78,56 +77,74 @@ __global__ __launch_bounds__(256) void k_dense_apply(int64_t n, const double *__
 
 void dense_release(pib_solver *s)
 {
+    if (s->dense_graph) (void)hipGraphExecDestroy(s->dense_graph);
     if (s->dense_inv) (void)hipFree(s->dense_inv);
-    s->dense_inv = nullptr;
+    if (s->dense_work) (void)hipFree(s->dense_work);
+    if (s->dense_bad) (void)hipFree(s->dense_bad);
+    s->dense_graph = nullptr;
+    s->dense_inv = s->dense_work = nullptr;
+    s->dense_bad = nullptr;
     s->dense_n = 0;
 }
 
 int dense_setup(pib_solver *s)
 {
-    dense_release(s);
     if (s->comm.nranks > 1) return fail(PIB_ERR_SUP, "solver %s: the direct solver is single-rank", s->name.c_str());
     const DeviceCsr &A = s->A;
     const int64_t n = A.n;
     if (n > DENSE_MAX_ROWS)
         return fail(PIB_ERR_SUP, "solver %s: direct solve asked for %lld rows (limit %lld); use a Krylov method", s->name.c_str(),
                     (long long)n, (long long)DENSE_MAX_ROWS);
-    if (n == 0) return 0;
+    if (n == 0) {
+        dense_release(s);
+        return 0;
+    }
     hipStream_t q = s->stream;
-    double *M = nullptr, *rows = nullptr;
-    int *bad = nullptr;
     const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
-    PIB_HIP(hipMalloc(&s->dense_inv, bytes));
-    PIB_HIP(hipMalloc(&M, bytes));
-    PIB_HIP(hipMalloc(&rows, sizeof(double) * 3 * (size_t)n));
-    PIB_HIP(hipMalloc(&bad, sizeof(int)));
+    // buffers (and the captured elimination graph) are kept while the size stays the same: a moving body re-factorises
+    // a matrix of the same order every time step (rigidkinematics.cpp:135-139)
+    if (s->dense_n != n || s->dense_inv == nullptr) {
+        dense_release(s);
+        PIB_HIP(hipMalloc(&s->dense_inv, bytes));
+        PIB_HIP(hipMalloc(&s->dense_work, bytes));
+        PIB_HIP(hipMalloc(&s->dense_bad, sizeof(int)));
+        s->dense_n = n;
+    }
+    double *M = s->dense_work;
     PIB_HIP(hipMemsetAsync(M, 0, bytes, q));
     PIB_HIP(hipMemsetAsync(s->dense_inv, 0, bytes, q));
-    PIB_HIP(hipMemsetAsync(bad, 0, sizeof(int), q));
+    PIB_HIP(hipMemsetAsync(s->dense_bad, 0, sizeof(int), q));
     const int gb = (int)std::min<int64_t>(4096, n);
     if (A.rp64)
         hipLaunchKernelGGL(k_dense_fill<int64_t>, dim3(gb), dim3(256), 0, q, n, (const int64_t *)A.rowptr, A.col, A.val, M);
     else
         hipLaunchKernelGGL(k_dense_fill<int32_t>, dim3(gb), dim3(256), 0, q, n, (const int32_t *)A.rowptr, A.col, A.val, M);
-    const int g1 = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(k_dense_identity, dim3(g1), dim3(256), 0, q, n, s->dense_inv);
-    double *rowM = rows, *rowI = rows + n, *fac = rows + 2 * n;
-    for (int64_t k = 0; k < n; ++k) {
-        hipLaunchKernelGGL(k_gj_pivot, dim3(g1), dim3(256), 0, q, n, k, M, s->dense_inv, rowM, rowI, fac, bad);
-        hipLaunchKernelGGL(k_gj_update, dim3(g1, (unsigned)n), dim3(256), 0, q, n, k, M, s->dense_inv, rowM, rowI, fac, bad);
-    }
+    hipLaunchKernelGGL(k_dense_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, n, s->dense_inv);
     PIB_HIP(hipGetLastError());
+    // the n elimination launches as one hipGraph (their arguments are fixed for a given order n and buffers)
+    if (s->dense_graph == nullptr) {
+        hipGraph_t g = nullptr;
+        PIB_HIP(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
+        for (int64_t k = 0; k < n; ++k)
+            hipLaunchKernelGGL(k_gj_step, dim3((unsigned)n), dim3(256), 0, q, n, k, M, s->dense_inv, s->dense_bad);
+        hipLaunchKernelGGL(k_gj_scale, dim3((unsigned)n), dim3(256), 0, q, n, M, s->dense_inv, s->dense_bad);
+        const hipError_t e = hipStreamEndCapture(q, &g);
+        if (e != hipSuccess || g == nullptr) return fail(PIB_ERR_LIB, "solver %s: capturing the factorisation failed (%s)", s->name.c_str(), hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&s->dense_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) {
+            s->dense_graph = nullptr;
+            return fail(PIB_ERR_LIB, "solver %s: hipGraphInstantiate failed (%s)", s->name.c_str(), hipGetErrorString(ei));
+        }
+    }
+    PIB_HIP(hipGraphLaunch(s->dense_graph, q));
     int hbad = 0;
-    PIB_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, q));
+    PIB_HIP(hipMemcpyAsync(&hbad, s->dense_bad, sizeof(int), hipMemcpyDeviceToHost, q));
     PIB_HIP(hipStreamSynchronize(q));
-    PIB_HIP(hipFree(M));
-    PIB_HIP(hipFree(rows));
-    PIB_HIP(hipFree(bad));
     if (hbad) {
         dense_release(s);
         return fail(PIB_ERR_MAT_LU_ZRPVT, "solver %s: zero pivot in row %d of the direct factorisation", s->name.c_str(), hbad - 1);
     }
-    s->dense_n = n;
     return 0;
 }
 

@@ -200,6 +200,9 @@ struct pib_solver {
     uint64_t graph_key = 0;           // the (method, x, b) it was captured for
     int64_t graph_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // instrumentation counters one replay stands for
     double *dense_inv = nullptr;  // dense.hip: explicit inverse of the direct solver [dense_n x dense_n]
+    double *dense_work = nullptr; // the matrix being eliminated
+    int *dense_bad = nullptr;     // zero-pivot flag
+    hipGraphExec_t dense_graph = nullptr;  // the dense_n elimination launches
     int64_t dense_n = 0;
     // results of the last solve
     int iters = 0, reason = 0;
