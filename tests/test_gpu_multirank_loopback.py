@@ -18,11 +18,11 @@ from oracle import clib, mesh as omesh, operators as oops
 pytestmark = pytest.mark.gpu
 
 
-def _cfg(pc, tol=1e-10, extra=""):
+def _cfg(pc, tol=1e-10, extra="", sweeps=1):
     return (f"config_version=2\nsolver(solv)=PCG\nsolv:max_iters=2000\nsolv:monitor_residual=1\n"
             f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
-            f"solv:preconditioner(prec)={pc}\nprec:relaxation_factor=1.0\nprec:cycle=V\nprec:presweeps=1\n"
-            f"prec:postsweeps=1\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
+            f"solv:preconditioner(prec)={pc}\nprec:relaxation_factor=1.0\nprec:cycle=V\nprec:presweeps={sweeps}\n"
+            f"prec:postsweeps={sweeps}\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
             f"smooth:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n{extra}")
 
 
@@ -70,8 +70,12 @@ def _system(n, dt=0.01):
     (4, (32, 32, 32), "AMG", "pib_agglomerate_below=100\n"),
     (4, (32, 16, 64), "AMG", ""),
     (2, (32, 48), "AMG", "pib_agglomerate_below=10\n"),             # 2-D: slabs along y
+    (4, (32, 32, 32), "AMG", "pib_agglomerate_below=100\nV22"),      # the bench's V(2,2) cycle on distributed levels
+    (3, (16, 16, 36), "AMG", "V22"),
 ])
 def test_multirank_poisson_solve_matches_single_rank(P, n, pc, extra):
+    sweeps = 2 if extra.endswith("V22") else 1
+    extra = extra[:-3] if sweeps == 2 else extra
     from petibm_amd import capi, partition
     from petibm_amd.linsolver import LinSolverHIP
     dt = 0.01
@@ -81,7 +85,7 @@ def test_multirank_poisson_solve_matches_single_rank(P, n, pc, extra):
 
     def rank_fn(r, uid):
         pl = plans[r]
-        s = LinSolverHIP("poisson", config_text=_cfg(pc, extra=extra), rank=r, nranks=P, uid=uid, device=0)
+        s = LinSolverHIP("poisson", config_text=_cfg(pc, extra=extra, sweeps=sweeps), rank=r, nranks=P, uid=uid, device=0)
         s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
         assert s.n_local == pl.n_local
         # SpMV across the slab boundary: bit-identical to the oracle
@@ -100,7 +104,7 @@ def test_multirank_poisson_solve_matches_single_rank(P, n, pc, extra):
     assert len({r[2] for r in res}) == 1  # every rank stops at the same iteration
     assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
     # single-rank solve of the same system with the same configuration
-    s1 = LinSolverHIP("poisson", config_text=_cfg(pc, extra=extra))
+    s1 = LinSolverHIP("poisson", config_text=_cfg(pc, extra=extra, sweeps=sweeps))
     s1.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
     x1 = np.zeros(A.n_rows)
     s1.solve(x1, b)
