@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
 // The levels below ~32^3 are launch-latency bound: five 4.4-us launches per level and V-cycle (rocprof: 40 of
 // the 53 kernels of a 512^3 iteration are such launches).  One 1024-thread workgroup walks the whole remaining
 // V-cycle (pre-smooth, residual, restriction, ..., coarsest sweeps, ..., prolongation, post-smooth) with block
-// barriers between the phases; the per-cell arithmetic is the same as in k_level / k_restrict / k_prolong_add,
+// barriers between the phases; the per-cell arithmetic is the same as in k_level / k_restrict_rows / k_prolong_rows,
 // so results are bit-identical to the per-level launches.  Damped Jacobi only.
 constexpr int TAIL_MAX_CELLS = 32768;
 constexpr int TAIL_MAX_LEVELS = 12;
@@ -1073,7 +1073,7 @@ static int halo_level(pib_solver *s, const GridLevel &g, double *x_owned, hipStr
     return halo_exchange_planes(s, x_owned, g.nloc, r > 0 ? pl : 0, r < P - 1 ? pl : 0, r > 0 ? pl : 0, r < P - 1 ? pl : 0, q);
 }
 
-// all-gather the owned coarse planes of level `lc` (ownership = the finer level's slabs halved) into the
+// all-gather the owned coarse planes of level `lc` (ownership = the parents of the finer level's slab planes) into the
 // replicated level vector
 static int gather_level(pib_solver *s, int lc, int64_t coarse_plane, const double *owned, int64_t n_owned,
                         double *full_owned_base, hipStream_t q)

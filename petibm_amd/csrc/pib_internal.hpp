@@ -179,7 +179,7 @@ struct pib_solver {
     std::string gmg_error;  // why the hierarchy could not be built (reported when a multigrid solve is asked for)
     std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
     double asm_dt = 0.0;
-    // multi-GPU multigrid: plane ownership [b,e) of every rank on every level (level-0 slabs halved level by level)
+    // multi-GPU multigrid: plane ownership [b,e) of every rank on every level (the aggregates of the finer level's slab planes: gmg.hip grid_register)
     std::vector<std::vector<std::pair<int64_t, int64_t>>> gmg_own;
     // work vectors: each ghost-padded [ghost_lo + n + ghost_hi]
     double *work = nullptr, *work_base = nullptr;
@@ -220,7 +220,7 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
               bool guarded, hipStream_t st);
 int spmv_launch_blocks();
 int extract_dinv(pib_solver *s, int *n_missing);
-// halo.cpp
+// halo.hip
 int comm_init(pib_solver *s, int rank, int nranks, const void *uid);
 int comm_setup_halo(pib_solver *s);
 int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st);
