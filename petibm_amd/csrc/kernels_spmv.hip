@@ -147,8 +147,10 @@ __device__ __forceinline__ int64_t chunk_of(const ChunkOrder &o, int64_t seq)
 
 constexpr int LDS_ROWS = 256;
 
-// CAP = LDS capacity in entries (even).  1282: 5-point rows, 1794: 7-point rows (7 workgroups per CU instead of
-// 6), 2050: anything else (rows longer than a tile are walked tile by tile).
+// CAP = LDS capacity in entries (a multiple of 4).  1284: 5-point rows, 1796: 7-point rows (7 workgroups per CU instead
+// of 6), 2052: anything else (rows longer than a tile are walked tile by tile).
+// Phase 1 is LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS at wave base + lane * 16, no staging
+// registers, no ds_write pass): two values or four column indices per lane and instruction.
 template <typename RP, bool DOT, int CAP>
 __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S, int64_t r_begin, int64_t r_end,
                                                   const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -182,16 +184,23 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S,
         double sum = 0.0, xd = 0.0;
         bool have_diag = false;
         const int32_t dcol = (int32_t)(ghost_lo + r0 + tid);
-        const RP a0 = p0 & ~(RP)1;  // val/col are 16-byte aligned at even entries
+        const RP a0 = p0 & ~(RP)3;  // val is 16-byte aligned at even entries, col at multiples of four
         for (RP t0 = a0; t0 < p1; t0 += CAP) {
 #pragma unroll
             for (int u = 0; u < (CAP + 511) / 512; ++u) {
                 const RP q = t0 + 2 * (tid + u * 256);
-                if (q < p1 && q - t0 < CAP) {
-                    *reinterpret_cast<double2 *>(&vals[(int)(q - t0)]) = *reinterpret_cast<const double2 *>(val + q);
-                    *reinterpret_cast<int2 *>(&cols[(int)(q - t0)]) = *reinterpret_cast<const int2 *>(col + q);
-                }
+                if (q < p1 && q - t0 < CAP)
+                    __builtin_amdgcn_global_load_lds((const void *)(val + q), (__attribute__((address_space(3))) void *)&vals[(int)(q - t0)],
+                                                     16, 0, 0);
             }
+#pragma unroll
+            for (int u = 0; u < (CAP + 1023) / 1024; ++u) {
+                const RP q = t0 + 4 * (tid + u * 256);
+                if (q < p1 && q - t0 < CAP)
+                    __builtin_amdgcn_global_load_lds((const void *)(col + q), (__attribute__((address_space(3))) void *)&cols[(int)(q - t0)],
+                                                     16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const RP lo = (rs > t0) ? rs : t0;
             const RP hi = (re < t0 + CAP) ? re : (t0 + CAP);
@@ -346,14 +355,14 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
             hipLaunchKernelGGL((k_spmv_lds<RP, false, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, \
                                r_end, (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord); \
     } while (0)
-        // +1: the span is widened to an even start
-        const int64_t need = A.max_chunk_nnz + 1;
-        if (need <= 1282) {
-            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 1282); else PIB_LAUNCH_LDS(int32_t, 1282);
-        } else if (need <= 1794) {
-            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 1794); else PIB_LAUNCH_LDS(int32_t, 1794);
+        // +3: the span is widened to a start that is a multiple of four
+        const int64_t need = A.max_chunk_nnz + 3;
+        if (need <= 1284) {
+            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 1284); else PIB_LAUNCH_LDS(int32_t, 1284);
+        } else if (need <= 1796) {
+            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 1796); else PIB_LAUNCH_LDS(int32_t, 1796);
         } else {
-            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 2050); else PIB_LAUNCH_LDS(int32_t, 2050);
+            if (A.rp64) PIB_LAUNCH_LDS(int64_t, 2052); else PIB_LAUNCH_LDS(int32_t, 2052);
         }
 #undef PIB_LAUNCH_LDS
         PIB_HIP(hipGetLastError());
