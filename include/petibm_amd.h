@@ -144,6 +144,14 @@ int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t
 int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                       const double *wz, const double *gx, const double *gy, const double *gz, int nullspace);
 
+/* Periodic directions of the mesh (flow.boundaryConditions type PERIODIC at both ends of a direction for every
+ * component: src/misc/misc.cpp checkPeriodicBC, cartesianmesh.cpp:595-681 wraps the neighbour indices).  Call BEFORE
+ * pib_assemble_poisson / pib_assemble_velocity / pib_set_grid_hint: the assembled operators then carry the wrapped
+ * columns (component d has n[d] points along a periodic d instead of n[d]-1, cartesianmesh.cpp:259-266) and the grid
+ * hint takes one more face factor per periodic direction, g[d][n[d]-1] = dt / (0.5*(w[0] + w[n[d]-1])).  A periodic
+ * direction needs >= 3 cells; a periodic SLAB axis on several ranks is not supported (PIB_ERR_SUP). */
+int pib_set_periodic(pib_solver *s, const int periodic[3]);
+
 /* Assemble the Poisson operator DBNG = D * (dt*I) * G directly in HBM from the
  * mesh widths (the product of createDivergence(normalize=FALSE),
  * createBnHead(N=1) and createGradient(normalize=FALSE) --

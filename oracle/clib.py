@@ -157,11 +157,12 @@ def bcgs(m, b, **kw):
 class GMG:
     """CPU restatement of the build's geometric V-cycle (oracle/csrc/gmg.c)."""
 
-    def __init__(self, n, widths, dt, nullspace=1, pre=1, post=1, omega=0.9, coarsest_sweeps=32, max_levels=100):
+    def __init__(self, n, widths, dt, nullspace=1, pre=1, post=1, omega=0.9, coarsest_sweeps=32, max_levels=100,
+                 periodic=(False, False, False)):
         L = lib()
-        L.orc_gmg_create.restype = C.c_void_p
-        L.orc_gmg_create.argtypes = [C.c_int, _i64p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
-                                     C.c_int, C.c_double, C.c_int, C.c_int]
+        L.orc_gmg_create_periodic.restype = C.c_void_p
+        L.orc_gmg_create_periodic.argtypes = [C.c_int, _i64p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                              C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.orc_gmg_destroy.argtypes = [C.c_void_p]
         L.orc_gmg_apply.argtypes = [C.c_void_p, _f64p, _f64p]
         L.orc_gmg_apply_operator.argtypes = [C.c_void_p, C.c_int, _f64p, _f64p]
@@ -174,8 +175,9 @@ class GMG:
         self.n = np.array(list(n), dtype=np.int64)
         self._w = [np.ascontiguousarray(w, dtype=np.float64) for w in widths]
         p = [w.ctypes.data for w in self._w] + [None] * (3 - self.dim)
-        self._h = L.orc_gmg_create(self.dim, self.n, p[0], p[1], p[2], float(dt), int(nullspace), int(pre), int(post),
-                                   float(omega), int(coarsest_sweeps), int(max_levels))
+        per = (C.c_int * 3)(*[int(bool(periodic[d])) if d < len(periodic) else 0 for d in range(3)])
+        self._h = L.orc_gmg_create_periodic(self.dim, self.n, p[0], p[1], p[2], float(dt), int(nullspace), int(pre),
+                                            int(post), float(omega), int(coarsest_sweeps), int(max_levels), per)
         self.N = int(np.prod(self.n))
         self.nullspace = nullspace
         L.orc_gmg_set_chebyshev.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]

@@ -47,7 +47,8 @@ typedef struct {
     i64 n[3];
     i64 N;
     double *w[3]; /* widths, n[d] */
-    double *g[3]; /* face factors incl. dt, n[d]-1 */
+    double *g[3]; /* face factors incl. dt, n[d]-1 (+ the wrap face n[d]-1 <-> 0 at index n[d]-1 when periodic) */
+    int per[3];   /* periodic direction: the level operator wraps (transfers treat the seam like a wall) */
     double *x, *x2, *b, *r;
     /* transfer tables towards the next coarser level, per direction (NULL on the coarsest level) */
     int32_t *par[3], *oth[3]; /* [n[d]] parent / other coarse index of fine cell s (oth == par: none) */
@@ -77,12 +78,12 @@ static inline i64 idx(const level_t *l, i64 i, i64 j, i64 k) { return i + l->n[0
 static inline void face_coefs(const level_t *l, i64 i, i64 j, i64 k, double c[6])
 {
     const double ax = l->w[1][j] * l->w[2][k], ay = l->w[0][i] * l->w[2][k], az = l->w[0][i] * l->w[1][j];
-    c[0] = (i > 0) ? ax * l->g[0][i - 1] : 0.0;
-    c[1] = (i < l->n[0] - 1) ? ax * l->g[0][i] : 0.0;
-    c[2] = (j > 0) ? ay * l->g[1][j - 1] : 0.0;
-    c[3] = (j < l->n[1] - 1) ? ay * l->g[1][j] : 0.0;
-    c[4] = (k > 0) ? az * l->g[2][k - 1] : 0.0;
-    c[5] = (k < l->n[2] - 1) ? az * l->g[2][k] : 0.0;
+    c[0] = (i > 0) ? ax * l->g[0][i - 1] : (l->per[0] ? ax * l->g[0][l->n[0] - 1] : 0.0);
+    c[1] = (i < l->n[0] - 1 || l->per[0]) ? ax * l->g[0][i] : 0.0;
+    c[2] = (j > 0) ? ay * l->g[1][j - 1] : (l->per[1] ? ay * l->g[1][l->n[1] - 1] : 0.0);
+    c[3] = (j < l->n[1] - 1 || l->per[1]) ? ay * l->g[1][j] : 0.0;
+    c[4] = (k > 0) ? az * l->g[2][k - 1] : (l->per[2] ? az * l->g[2][l->n[2] - 1] : 0.0);
+    c[5] = (k < l->n[2] - 1 || l->per[2]) ? az * l->g[2][k] : 0.0;
 }
 
 /* y = A x at one cell, and the diagonal */
@@ -94,11 +95,17 @@ static inline double apply_cell(const level_t *l, const double *x, i64 i, i64 j,
     const double xc = x[p];
     double s = 0.0;
     if (i > 0) s += c[0] * (x[p - sx] - xc);
+    else if (l->per[0]) s += c[0] * (x[p + (l->n[0] - 1) * sx] - xc);
     if (i < l->n[0] - 1) s += c[1] * (x[p + sx] - xc);
+    else if (l->per[0]) s += c[1] * (x[p - (l->n[0] - 1) * sx] - xc);
     if (j > 0) s += c[2] * (x[p - sy] - xc);
+    else if (l->per[1]) s += c[2] * (x[p + (l->n[1] - 1) * sy] - xc);
     if (j < l->n[1] - 1) s += c[3] * (x[p + sy] - xc);
+    else if (l->per[1]) s += c[3] * (x[p - (l->n[1] - 1) * sy] - xc);
     if (k > 0) s += c[4] * (x[p - sz] - xc);
+    else if (l->per[2]) s += c[4] * (x[p + (l->n[2] - 1) * sz] - xc);
     if (k < l->n[2] - 1) s += c[5] * (x[p + sz] - xc);
+    else if (l->per[2]) s += c[5] * (x[p - (l->n[2] - 1) * sz] - xc);
     *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
     return s;
 }
@@ -113,17 +120,36 @@ static void make_g(level_t *l, double dt)
 {
     for (int d = 0; d < 3; ++d) {
         i64 n = l->n[d];
-        l->g[d] = malloc(sizeof(double) * (size_t)(n > 1 ? n - 1 : 1));
+        l->g[d] = malloc(sizeof(double) * (size_t)(n > 1 ? n : 1));
         for (i64 s = 0; s + 1 < n; ++s) {
             const double dl = 0.5 * (l->w[d][s + 1] + l->w[d][s]);
             const double v = 1.0 / dl;
             l->g[d][s] = dt * v;
         }
+        if (l->per[d] && n > 1) { /* wrap face: dL[d][d] of the periodic velocity mesh, 0.5*(w[0] + w[n-1]) (cartesianmesh.cpp:259-266) */
+            const double dl = 0.5 * (l->w[d][0] + l->w[d][n - 1]);
+            const double v = 1.0 / dl;
+            l->g[d][n - 1] = dt * v;
+        }
     }
 }
 
+void *orc_gmg_create_periodic(int dim, const i64 *n_in, const double *wx, const double *wy, const double *wz, double dt,
+                              int nullspace, int pre, int post, double omega, int coarsest_sweeps, int max_levels,
+                              const int *periodic);
 void *orc_gmg_create(int dim, const i64 *n_in, const double *wx, const double *wy, const double *wz, double dt,
                      int nullspace, int pre, int post, double omega, int coarsest_sweeps, int max_levels)
+{
+    const int none[3] = {0, 0, 0};
+    return orc_gmg_create_periodic(dim, n_in, wx, wy, wz, dt, nullspace, pre, post, omega, coarsest_sweeps, max_levels, none);
+}
+
+/* periodic[d] (problem directions x, y[, z]): the level operators get the wrap face n-1 <-> 0, rediscretised on every
+ * level like the interior faces (a direction coarsened down to ONE cell has no face left); coarsening and the transfer
+ * tables are unchanged, i.e. the interpolation treats the seam like a wall. */
+void *orc_gmg_create_periodic(int dim, const i64 *n_in, const double *wx, const double *wy, const double *wz, double dt,
+                              int nullspace, int pre, int post, double omega, int coarsest_sweeps, int max_levels,
+                              const int *periodic)
 {
     gmg_t *G = calloc(1, sizeof(gmg_t));
     G->pre = pre; G->post = post; G->omega = omega; G->coarsest_sweeps = coarsest_sweeps; G->nullspace = nullspace;
@@ -132,6 +158,10 @@ void *orc_gmg_create(int dim, const i64 *n_in, const double *wx, const double *w
     const double *ws[3];
     if (dim == 3) { l->n[0] = n_in[0]; l->n[1] = n_in[1]; l->n[2] = n_in[2]; ws[0] = wx; ws[1] = wy; ws[2] = wz; }
     else { l->n[0] = n_in[0]; l->n[1] = 1; l->n[2] = n_in[1]; ws[0] = wx; ws[1] = &one; ws[2] = wy; }
+    int per[3];
+    if (dim == 3) { per[0] = periodic[0]; per[1] = periodic[1]; per[2] = periodic[2]; }
+    else { per[0] = periodic[0]; per[1] = 0; per[2] = periodic[1]; }
+    for (int d = 0; d < 3; ++d) l->per[d] = per[d] && l->n[d] > 1;
     for (int d = 0; d < 3; ++d) {
         l->w[d] = malloc(sizeof(double) * (size_t)l->n[d]);
         memcpy(l->w[d], ws[d], sizeof(double) * (size_t)l->n[d]);
@@ -205,6 +235,7 @@ void *orc_gmg_create(int dim, const i64 *n_in, const double *wx, const double *w
         }
         if (!merged_any) break;
         G->target_shift--; /* the loop's ++ after the successful try */
+        for (int d = 0; d < 3; ++d) c->per[d] = per[d] && c->n[d] > 1;
         nl++;
     }
     G->nlev = nl;

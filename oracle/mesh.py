@@ -305,3 +305,21 @@ def uniform_config(n: Sequence[int], lo=0.0, hi=1.0, lid: float = 1.0) -> dict:
             bc["u"] = ["DIRICHLET", lid]
         bcs.append(bc)
     return {"mesh": mesh, "flow": {"boundaryConditions": bcs}}
+
+
+def periodic_config(n: Sequence[int], periodic: Sequence[bool], lo=0.0, hi=1.0, ratios=None) -> dict:
+    """Config dict with PERIODIC boundaries in the flagged directions (both ends, every component --
+    examples/navierstokes/taylorgreenvortex2dRe100/config.yaml:1-18) and no-slip Dirichlet walls elsewhere."""
+    dim = len(n)
+    names = "xyz"
+    mesh = [{"direction": names[d], "start": lo,
+             "subDomains": [{"end": hi, "cells": int(n[d]), "stretchRatio": float(ratios[d]) if ratios else 1.0}]}
+            for d in range(dim)]
+    locs = ["xMinus", "xPlus", "yMinus", "yPlus", "zMinus", "zPlus"][: 2 * dim]
+    bcs = []
+    for q, loc in enumerate(locs):
+        bc = {"location": loc}
+        for c in "uvw"[:dim]:
+            bc[c] = ["PERIODIC", 0.0] if periodic[q // 2] else ["DIRICHLET", 0.0]
+        bcs.append(bc)
+    return {"mesh": mesh, "flow": {"boundaryConditions": bcs}}

@@ -128,79 +128,122 @@ int adopt_device_csr(pib_solver *s, int64_t n, int64_t nnz, const int32_t *rowpt
 
 // ------------------------------------------------------------------------
 // closed-form number of non-zeros in rows [0, g) of the natural-order
-// (2*dim+1)-point operator with no-neighbour walls.
-__host__ __device__ inline int64_t nnz_before(int64_t g, int dim, int64_t nx, int64_t ny, int64_t nz)
+// (2*dim+1)-point operator with no-neighbour walls; per: bit d set = direction d periodic (every cell has both
+// neighbours in that direction: the columns wrap, cartesianmesh.cpp:595-681)
+__host__ __device__ inline int64_t nnz_before(int64_t g, int dim, int64_t nx, int64_t ny, int64_t nz, int per)
 {
     const int64_t pl = nx * ny;
     int64_t c = g;                               // diagonals
-    c += g - (g + nx - 1) / nx;                  // has i-1  (cells with i == 0: ceil(g/nx))
-    c += g - g / nx;                             // has i+1  (cells with i == nx-1: floor(g/nx))
+    if (per & 1)
+        c += 2 * g;
+    else {
+        c += g - (g + nx - 1) / nx;              // has i-1  (cells with i == 0: ceil(g/nx))
+        c += g - g / nx;                         // has i+1  (cells with i == nx-1: floor(g/nx))
+    }
     const int64_t kq = g / pl, rem = g % pl;
-    c += g - (kq * nx + (rem < nx ? rem : nx));  // has j-1
-    const int64_t top = rem - (ny - 1) * nx;
-    c += g - (kq * nx + (top > 0 ? top : 0));    // has j+1
+    if (per & 2)
+        c += 2 * g;
+    else {
+        c += g - (kq * nx + (rem < nx ? rem : nx));  // has j-1
+        const int64_t top = rem - (ny - 1) * nx;
+        c += g - (kq * nx + (top > 0 ? top : 0));    // has j+1
+    }
     if (dim == 3) {
-        c += g - (g < pl ? g : pl);              // has k-1
-        const int64_t last = g - (nz - 1) * pl;
-        c += g - (last > 0 ? last : 0);          // has k+1
+        if (per & 4)
+            c += 2 * g;
+        else {
+            c += g - (g < pl ? g : pl);              // has k-1
+            const int64_t last = g - (nz - 1) * pl;
+            c += g - (last > 0 ? last : 0);          // has k+1
+        }
     }
     return c;
 }
 
+// One row = up to 7 entries.  Values are the face terms D_cf * (dt * G_fc'); the diagonal is what the sparse accumulator
+// of MatMatMult leaves: the face terms in the column order of D's row (first one assigned, the rest added).  D's
+// columns are the packed velocity indices u(i-1), u(i), v(j-1), v(j), w(k-1), w(k); on a periodic direction the minus
+// face of cell 0 is velocity point n-1, which sorts AFTER the plus face (point 0).  The row's entries are stored by
+// ascending column (a wrapped neighbour changes its place).
 template <typename RP>
 __global__ __launch_bounds__(256) void k_assemble_poisson(int dim, int64_t nx, int64_t ny, int64_t nz, int64_t row0,
                                                           int64_t n_local, int64_t ghost_lo, int64_t nnz0,
                                                           const double *__restrict__ wx, const double *__restrict__ wy,
                                                           const double *__restrict__ wz, const double *__restrict__ gx,
                                                           const double *__restrict__ gy, const double *__restrict__ gz,
-                                                          int pinned, RP *__restrict__ rowptr,
+                                                          int pinned, int per, RP *__restrict__ rowptr,
                                                           int32_t *__restrict__ col, double *__restrict__ val)
 {
     const int64_t pl = nx * ny;
+    const bool px = per & 1, py = per & 2, pz = per & 4;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n_local; r += (int64_t)gridDim.x * 256) {
         const int64_t g = row0 + r;
-        int64_t p = nnz_before(g, dim, nx, ny, nz) - nnz0;
+        int64_t p = nnz_before(g, dim, nx, ny, nz, per) - nnz0;
         rowptr[r] = (RP)p;
         if (r == n_local) break;
         const int64_t i = g % nx, j = (g / nx) % ny, k = g / pl;
         const double ax = wy[j] * wz[k];  // dL[0][1][j]*dL[0][2][k]  (createdivergence.cpp:140-143)
         const double ay = wx[i] * wz[k];  // dL[1][0][i]*dL[1][2][k]
         const double az = wx[i] * wy[j];  // dL[2][0][i]*dL[2][1][j]
-        // face terms D_cf * (dt*G_fc'), in the column order of D's row:
-        // u(i-1), u(i), v(j-1), v(j), w(k-1), w(k)
-        const bool hxm = i > 0, hxp = i < nx - 1, hym = j > 0, hyp = j < ny - 1;
-        const bool hzm = (dim == 3) && k > 0, hzp = (dim == 3) && k < nz - 1;
-        const double oxm = hxm ? ax * gx[i - 1] : 0.0, oxp = hxp ? ax * gx[i] : 0.0;
-        const double oym = hym ? ay * gy[j - 1] : 0.0, oyp = hyp ? ay * gy[j] : 0.0;
-        const double ozm = hzm ? az * gz[k - 1] : 0.0, ozp = hzp ? az * gz[k] : 0.0;
+        // minus / plus face of each direction: present?, value, column offset (wrapped on a periodic direction)
+        bool has[6];
+        double o[6];
+        int64_t off[6];
+        has[0] = i > 0 || px;
+        has[1] = i < nx - 1 || px;
+        has[2] = j > 0 || py;
+        has[3] = j < ny - 1 || py;
+        has[4] = (dim == 3) && (k > 0 || pz);
+        has[5] = (dim == 3) && (k < nz - 1 || pz);
+        o[0] = has[0] ? ax * gx[i > 0 ? i - 1 : nx - 1] : 0.0;
+        o[1] = has[1] ? ax * gx[i] : 0.0;
+        o[2] = has[2] ? ay * gy[j > 0 ? j - 1 : ny - 1] : 0.0;
+        o[3] = has[3] ? ay * gy[j] : 0.0;
+        o[4] = has[4] ? az * gz[k > 0 ? k - 1 : nz - 1] : 0.0;
+        o[5] = has[5] ? az * gz[k] : 0.0;
+        off[0] = i > 0 ? -1 : nx - 1;
+        off[1] = i < nx - 1 ? 1 : -(nx - 1);
+        off[2] = j > 0 ? -nx : (ny - 1) * nx;
+        off[3] = j < ny - 1 ? nx : -(ny - 1) * nx;
+        off[4] = k > 0 ? -pl : (nz - 1) * pl;
+        off[5] = k < nz - 1 ? pl : -(nz - 1) * pl;
         // diagonal: first contribution assigned, the rest added (sparse accumulator)
         double d = 0.0;
         bool first = true;
-#define PIB_ACC(has, t)                      \
-    if (has) {                               \
-        if (first) { d = -(t); first = false; } \
-        else d = d + (-(t));                 \
+#define PIB_ACC(q)                                 \
+    if (has[q]) {                                  \
+        if (first) { d = -(o[q]); first = false; } \
+        else d = d + (-(o[q]));                    \
     }
-        PIB_ACC(hxm, oxm) PIB_ACC(hxp, oxp) PIB_ACC(hym, oym) PIB_ACC(hyp, oyp) PIB_ACC(hzm, ozm) PIB_ACC(hzp, ozp)
+        if (i == 0 && px) { PIB_ACC(1) PIB_ACC(0) } else { PIB_ACC(0) PIB_ACC(1) }
+        if (j == 0 && py) { PIB_ACC(3) PIB_ACC(2) } else { PIB_ACC(2) PIB_ACC(3) }
+        if (k == 0 && pz) { PIB_ACC(5) PIB_ACC(4) } else { PIB_ACC(4) PIB_ACC(5) }
 #undef PIB_ACC
         const int64_t lc = r + ghost_lo;  // local column of the diagonal
         const bool row_pinned = pinned && g == 0;
-#define PIB_PUT(has, c, v, zero_col)                                   \
-    if (has) {                                                         \
-        col[p] = (int32_t)(c);                                         \
-        val[p] = (row_pinned || (pinned && (zero_col))) ? 0.0 : (v);   \
-        ++p;                                                           \
-    }
-        PIB_PUT(hzm, lc - pl, ozm, g - pl == 0)
-        PIB_PUT(hym, lc - nx, oym, g - nx == 0)
-        PIB_PUT(hxm, lc - 1, oxm, g - 1 == 0)
-        col[p] = (int32_t)lc;
-        val[p] = row_pinned ? 1.0 : d;
-        ++p;
-        PIB_PUT(hxp, lc + 1, oxp, false)
-        PIB_PUT(hyp, lc + nx, oyp, false)
-        PIB_PUT(hzp, lc + pl, ozp, false)
-#undef PIB_PUT
+        // entries by ascending column offset: insertion sort of (offset, value) with the diagonal at offset 0
+        int64_t eo[7];
+        double ev[7];
+        int ne = 1;
+        eo[0] = 0;
+        ev[0] = row_pinned ? 1.0 : d;
+        for (int q = 0; q < 6; ++q) {
+            if (!has[q]) continue;
+            const double v = (row_pinned || (pinned && g + off[q] == 0)) ? 0.0 : o[q];
+            int t = ne++;
+            while (t > 0 && eo[t - 1] > off[q]) {
+                eo[t] = eo[t - 1];
+                ev[t] = ev[t - 1];
+                --t;
+            }
+            eo[t] = off[q];
+            ev[t] = v;
+        }
+        for (int t = 0; t < ne; ++t) {
+            col[p] = (int32_t)(lc + eo[t]);
+            val[p] = ev[t];
+            ++p;
+        }
     }
 }
 
@@ -221,18 +264,29 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
     //   velocity-cell width: cartesianmesh.cpp:246-258 (adjacent_difference with 0.5*(x+y))
     //   G value 1/dL:        creategradient.cpp:70-86 ; BN = dt*I: createbn.cpp:49
     std::vector<double> hw[3], hg[3];
+    int per = 0;
     for (int d = 0; d < 3; ++d) {
         const int64_t nd = (d < dim) ? n[d] : 1;
         hw[d].resize((size_t)nd);
         for (int64_t q = 0; q < nd; ++q) hw[d][(size_t)q] = (d < dim) ? w[d][q] : 1.0;
-        hg[d].resize((size_t)std::max<int64_t>(nd - 1, 0));
+        const bool wrap = d < dim && s->periodic[d] != 0;
+        if (wrap) per |= 1 << d;
+        if (wrap && nd < 3) return fail(PIB_ERR_SUP, "assemble_poisson: a periodic direction needs >= 3 cells");
+        hg[d].resize((size_t)std::max<int64_t>(nd - 1, 0) + (wrap ? 1 : 0));
         for (int64_t q = 0; q + 1 < nd; ++q) {
             const double dl = 0.5 * (hw[d][(size_t)q + 1] + hw[d][(size_t)q]);
             const double v = 1.0 / dl;
             hg[d][(size_t)q] = dt * v;
         }
+        if (wrap) {  // dL[d][d] of velocity point n-1 on a periodic axis: 0.5*(w[0] + w[n-1])  (cartesianmesh.cpp:259-266)
+            const double dl = 0.5 * (hw[d][0] + hw[d][(size_t)nd - 1]);
+            const double v = 1.0 / dl;
+            hg[d][(size_t)nd - 1] = dt * v;
+        }
     }
     const int P = s->comm.nranks, r = s->comm.rank;
+    if (P > 1 && (per & (1 << (dim - 1))))
+        return fail(PIB_ERR_SUP, "assemble_poisson: a periodic slab axis on several ranks is not supported");
     const int64_t nlast = (dim == 3) ? nz : ny;
     const int64_t plane = (dim == 3) ? nx * ny : nx;
     int64_t k0, k1;
@@ -246,8 +300,8 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
     A.n_global = nx * ny * nz;
     A.ghost_lo = (r > 0) ? plane : 0;
     A.ghost_hi = (r < P - 1) ? plane : 0;
-    const int64_t nnz0 = nnz_before(A.row0, dim, nx, ny, nz);
-    A.nnz = nnz_before(A.row0 + A.n, dim, nx, ny, nz) - nnz0;
+    const int64_t nnz0 = nnz_before(A.row0, dim, nx, ny, nz, per);
+    A.nnz = nnz_before(A.row0 + A.n, dim, nx, ny, nz, per) - nnz0;
     A.rp64 = A.nnz >= (int64_t)std::numeric_limits<int32_t>::max();
     if (A.ghost_lo + A.n + A.ghost_hi >= (int64_t)std::numeric_limits<int32_t>::max())
         return fail(PIB_ERR_SUP, "assemble_poisson: local slab too large for 32-bit column indices");
@@ -265,11 +319,11 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
     const int nb = (int)std::min<int64_t>(8192, (A.n + 1 + 255) / 256);
     if (A.rp64)
         hipLaunchKernelGGL(k_assemble_poisson<int64_t>, dim3(nb), dim3(256), 0, s->stream, dim, nx, ny, nz, A.row0, A.n,
-                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, (int64_t *)A.rowptr, A.col,
+                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, per, (int64_t *)A.rowptr, A.col,
                            A.val);
     else
         hipLaunchKernelGGL(k_assemble_poisson<int32_t>, dim3(nb), dim3(256), 0, s->stream, dim, nx, ny, nz, A.row0, A.n,
-                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, (int32_t *)A.rowptr, A.col,
+                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, per, (int32_t *)A.rowptr, A.col,
                            A.val);
     PIB_HIP(hipGetLastError());
     PIB_HIP(hipStreamSynchronize(s->stream));
@@ -375,10 +429,10 @@ __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, 
     const int64_t nx = F.n[0], ny = F.n[1], nz = F.n[2];
     const int64_t pl = (dim == 3) ? nx * ny : nx;  // entries per plane of the slab axis
     const int64_t g0 = pl * F.kb, nf = pl * (F.ke - F.kb);
-    const int64_t base_nnz = nnz_before(g0, dim, nx, ny, nz);
+    const int64_t base_nnz = nnz_before(g0, dim, nx, ny, nz, 0);
     for (int64_t lr = (int64_t)blockIdx.x * 256 + threadIdx.x; lr <= nf; lr += (int64_t)gridDim.x * 256) {
         const int64_t r = g0 + lr;  // row in the field's global natural order
-        int64_t p = F.nnz_off + (nnz_before(r, dim, nx, ny, nz) - base_nnz);
+        int64_t p = F.nnz_off + (nnz_before(r, dim, nx, ny, nz, 0) - base_nnz);
         if (lr < nf || last_field) rowptr[F.row_off + lr] = (RP)p;
         if (lr == nf) break;
         const int64_t ijk[3] = {r % nx, (r / nx) % ny, r / (nx * ny)};
@@ -457,8 +511,8 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
         row_off[f] = rows;
         nnz_off[f] = nnz;
         rows += pl[f] * (ke[f] - kb[f]);
-        nnz += nnz_before(pl[f] * ke[f], dim, fn[f][0], fn[f][1], fn[f][2]) -
-               nnz_before(pl[f] * kb[f], dim, fn[f][0], fn[f][1], fn[f][2]);
+        nnz += nnz_before(pl[f] * ke[f], dim, fn[f][0], fn[f][1], fn[f][2], 0) -
+               nnz_before(pl[f] * kb[f], dim, fn[f][0], fn[f][1], fn[f][2], 0);
         if (rank > 0) {
             glo[f] = ghost_lo;
             ghost_lo += pl[f];

@@ -192,6 +192,13 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
     return grid_register(s, dim, n, w, g, nullspace, -1.0);
 }
 
+int pib_set_periodic(pib_solver *s, const int periodic[3])
+{
+    if (s == nullptr || periodic == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_periodic: null argument");
+    for (int d = 0; d < 3; ++d) s->periodic[d] = periodic[d] ? 1 : 0;
+    return 0;
+}
+
 int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                          const double *wz, double dt, int nullspace)
 {

@@ -47,6 +47,7 @@ struct TrX {
 struct LevelDev {
     int nx, ny, nzg;  // global cells (each < 2^31; the local cell count fits int32 like the CSR columns)
     int k0, nk;       // owned planes [k0, k0+nk)
+    int per;          // bit 0/1/2: x/y/z periodic (the operator wraps: g[n-1] couples cell n-1 and cell 0)
     const double *wx, *wy, *wz, *gx, *gy, *gz;
     Tr1 t[3];         // x, y, z tables (null on the coarsest level)
     TrX tx;
@@ -56,12 +57,13 @@ __device__ __forceinline__ void face_coefs(const LevelDev &L, int i, int j, int 
 {
     const double wxi = L.wx[i], wyj = L.wy[j], wzk = L.wz[k];
     const double ax = wyj * wzk, ay = wxi * wzk, az = wxi * wyj;
-    c[0] = (i > 0) ? ax * L.gx[i - 1] : 0.0;
-    c[1] = (i < L.nx - 1) ? ax * L.gx[i] : 0.0;
-    c[2] = (j > 0) ? ay * L.gy[j - 1] : 0.0;
-    c[3] = (j < L.ny - 1) ? ay * L.gy[j] : 0.0;
-    c[4] = (k > 0) ? az * L.gz[k - 1] : 0.0;
-    c[5] = (k < L.nzg - 1) ? az * L.gz[k] : 0.0;
+    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
+    c[0] = (i > 0) ? ax * L.gx[i - 1] : (px ? ax * L.gx[L.nx - 1] : 0.0);
+    c[1] = (i < L.nx - 1 || px) ? ax * L.gx[i] : 0.0;
+    c[2] = (j > 0) ? ay * L.gy[j - 1] : (py ? ay * L.gy[L.ny - 1] : 0.0);
+    c[3] = (j < L.ny - 1 || py) ? ay * L.gy[j] : 0.0;
+    c[4] = (k > 0) ? az * L.gz[k - 1] : (pz ? az * L.gz[L.nzg - 1] : 0.0);
+    c[5] = (k < L.nzg - 1 || pz) ? az * L.gz[k] : 0.0;
 }
 
 // (A x) at local cell p (x points at the first OWNED plane; halo planes sit at -plane and +nk*plane)
@@ -73,12 +75,19 @@ __device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__
     const int64_t sy = L.nx, sz = (int64_t)L.nx * L.ny;
     const double xc = x[p];
     double s = 0.0;
+    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;  // a periodic z level is never distributed
     if (i > 0) s += c[0] * (x[p - 1] - xc);
+    else if (px) s += c[0] * (x[p + (L.nx - 1)] - xc);
     if (i < L.nx - 1) s += c[1] * (x[p + 1] - xc);
+    else if (px) s += c[1] * (x[p - (L.nx - 1)] - xc);
     if (j > 0) s += c[2] * (x[p - sy] - xc);
+    else if (py) s += c[2] * (x[p + (L.ny - 1) * sy] - xc);
     if (j < L.ny - 1) s += c[3] * (x[p + sy] - xc);
+    else if (py) s += c[3] * (x[p - (L.ny - 1) * sy] - xc);
     if (k > 0) s += c[4] * (x[p - sz] - xc);
+    else if (pz) s += c[4] * (x[p + (L.nzg - 1) * sz] - xc);
     if (k < L.nzg - 1) s += c[5] * (x[p + sz] - xc);
+    else if (pz) s += c[5] * (x[p - (L.nzg - 1) * sz] - xc);
     *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
     return s;
 }
@@ -127,7 +136,8 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
     const int kk = blockIdx.y;
     const int k = L.k0 + kk;
     const double wzk = L.wz[k];
-    const double gzm = (k > 0) ? L.gz[k - 1] : 0.0, gzp = (k < L.nzg - 1) ? L.gz[k] : 0.0;
+    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
+    const double gzm = (k > 0) ? L.gz[k - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (k < L.nzg - 1 || pz) ? L.gz[k] : 0.0;
     // Workgroup b runs on XCD b % 8.  With the plain order the two grid lines of a workgroup have their +-y neighbours
     // in the workgroups of OTHER XCDs, so every L2 fetched x twice (PMC: 3.22 GB read per 512^3 sweep for 2.15 GB
     // of b and x).  Dealing each XCD a contiguous band of the plane leaves 8 band edges per plane instead.
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
         if (j_uniform) j = __builtin_amdgcn_readfirstlane(j);
         const int64_t p = (int64_t)kk * plane + (int64_t)j * L.nx + i0;
         const double wyj = L.wy[j];
-        const double gym = (j > 0) ? L.gy[j - 1] : 0.0, gyp = (j < L.ny - 1) ? L.gy[j] : 0.0;
+        const double gym = (j > 0) ? L.gy[j - 1] : (py ? L.gy[L.ny - 1] : 0.0), gyp = (j < L.ny - 1 || py) ? L.gy[j] : 0.0;
         const double ax = wyj * wzk;
         vt xc, bv, ym, yp, zm, zp, out;
         double xl = 0.0, xr = 0.0;
@@ -152,11 +162,17 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             xc = *reinterpret_cast<const vt *>(xi + p);
             ym = yp = zm = zp = xc;
             if (i0 > 0) xl = xi[p - 1];
+            else if (px) xl = xi[p + (L.nx - 1)];
             if (i0 + C < L.nx) xr = xi[p + C];
+            else if (px) xr = xi[p + C - L.nx];
             if (j > 0) ym = *reinterpret_cast<const vt *>(xi + p - L.nx);
+            else if (py) ym = *reinterpret_cast<const vt *>(xi + p + (int64_t)(L.ny - 1) * L.nx);
             if (j < L.ny - 1) yp = *reinterpret_cast<const vt *>(xi + p + L.nx);
+            else if (py) yp = *reinterpret_cast<const vt *>(xi + p - (int64_t)(L.ny - 1) * L.nx);
             if (k > 0) zm = *reinterpret_cast<const vt *>(xi + p - plane);
+            else if (pz) zm = *reinterpret_cast<const vt *>(xi + p + (int64_t)(L.nzg - 1) * plane);
             if (k < L.nzg - 1) zp = *reinterpret_cast<const vt *>(xi + p + plane);
+            else if (pz) zp = *reinterpret_cast<const vt *>(xi + p - (int64_t)(L.nzg - 1) * plane);
         }
         vt braw;
         if (MODE != 0) {
@@ -164,14 +180,14 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             if (MODE == 8) braw = bv;
             if (pin_sum != nullptr && p == 0 && L.k0 == 0) bv[0] = bv[0] - *pin_sum;
         }
-        double gxm = (i0 > 0) ? L.gx[i0 - 1] : 0.0;
+        double gxm = (i0 > 0) ? L.gx[i0 - 1] : (px ? L.gx[L.nx - 1] : 0.0);
         const vt wxv = *reinterpret_cast<const vt *>(L.wx + i0);
-        const vt gxv = *reinterpret_cast<const vt *>(L.gx + i0);  // gx is padded: entry nx-1 exists and is never used
+        const vt gxv = *reinterpret_cast<const vt *>(L.gx + i0);  // gx is padded: entry nx-1 exists (the wrap face when periodic)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int i = i0 + c;
             const double wxi = wxv[c];
-            const double gxp = (i < L.nx - 1) ? gxv[c] : 0.0;
+            const double gxp = (i < L.nx - 1 || px) ? gxv[c] : 0.0;
             const double ay = wxi * wzk, az = wxi * wyj;
             const double c0 = ax * gxm, c1 = ax * gxp, c2 = ay * gym, c3 = ay * gyp, c4 = az * gzm, c5 = az * gzp;
             gxm = gxp;
@@ -189,12 +205,12 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             const double right = (c == C - 1) ? xr : xc[c < C - 1 ? c + 1 : 0];
             const double xcc = xc[c];
             double s = 0.0;
-            if (i > 0) s += c0 * (left - xcc);
-            if (i < L.nx - 1) s += c1 * (right - xcc);
-            if (j > 0) s += c2 * (ym[c] - xcc);
-            if (j < L.ny - 1) s += c3 * (yp[c] - xcc);
-            if (k > 0) s += c4 * (zm[c] - xcc);
-            if (k < L.nzg - 1) s += c5 * (zp[c] - xcc);
+            if (i > 0 || px) s += c0 * (left - xcc);
+            if (i < L.nx - 1 || px) s += c1 * (right - xcc);
+            if (j > 0 || py) s += c2 * (ym[c] - xcc);
+            if (j < L.ny - 1 || py) s += c3 * (yp[c] - xcc);
+            if (k > 0 || pz) s += c4 * (zm[c] - xcc);
+            if (k < L.nzg - 1 || pz) s += c5 * (zp[c] - xcc);
             if (MODE == 0)
                 out[c] = s;
             else if (MODE == 2 || MODE == 8) {
@@ -639,6 +655,7 @@ static LevelDev dev_of(const GridLevel &g)
     L.nzg = (int)g.n[2];
     L.k0 = (int)g.k0;
     L.nk = (int)(g.k1 - g.k0);
+    L.per = g.per;
     L.wx = g.w[0];
     L.wy = g.w[1];
     L.wz = g.w[2];
@@ -829,6 +846,7 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
     // internal layout (nx, ny, nz) with 2-D -> (nx, 1, ny)
     int64_t nn[3];
     std::vector<double> hw[3], hg[3];
+    bool pern[3] = {false, false, false};
     const int map[3] = {0, (dim == 3) ? 1 : -1, (dim == 3) ? 2 : 1};
     for (int d = 0; d < 3; ++d) {
         if (map[d] < 0) {
@@ -839,9 +857,13 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
             nn[d] = n[map[d]];
             if (w[map[d]] == nullptr || (nn[d] > 1 && g[map[d]] == nullptr)) return fail(PIB_ERR_ARG_NULL, "grid hint: null array");
             hw[d].assign(w[map[d]], w[map[d]] + nn[d]);
-            hg[d].assign(g[map[d]], g[map[d]] + (nn[d] - 1));
+            // a periodic direction has one face more: g[n-1] couples cell n-1 and cell 0
+            pern[d] = s->periodic[map[d]] != 0 && nn[d] > 1;
+            hg[d].assign(g[map[d]], g[map[d]] + (nn[d] - 1) + (pern[d] ? 1 : 0));
         }
     }
+    if (pern[2] && P > 1)
+        return fail(PIB_ERR_SUP, "grid hint: a periodic slab axis on several ranks is not supported");
     if (nn[0] * nn[1] * nn[2] != s->A.n_global)
         return fail(PIB_ERR_ARG_SIZ, "grid hint: %lld x %lld x %lld cells but the matrix has %lld rows", (long long)nn[0],
                     (long long)nn[1], (long long)nn[2], (long long)s->A.n_global);
@@ -892,12 +914,19 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
         G.replicated = replicated && P > 1;
         for (int d = 0; d < 3; ++d) {
             PIB_CHK(up(hw[d], &G.w[d]));
+            const bool wrap = pern[d] && nn[d] > 1;  // a direction coarsened down to one cell has no face left
+            if (wrap) G.per |= 1 << d;
             if (l > 0) {
-                hg[d].assign((size_t)std::max<int64_t>(nn[d] - 1, 0), 0.0);
+                hg[d].assign((size_t)std::max<int64_t>(nn[d] - 1, 0) + (wrap ? 1 : 0), 0.0);
                 for (int64_t q = 0; q + 1 < nn[d]; ++q) {
                     const double dl = 0.5 * (hw[d][(size_t)q + 1] + hw[d][(size_t)q]);
                     const double v = 1.0 / dl;
                     hg[d][(size_t)q] = dt * v;
+                }
+                if (wrap) {
+                    const double dl = 0.5 * (hw[d][0] + hw[d][(size_t)nn[d] - 1]);
+                    const double v = 1.0 / dl;
+                    hg[d][(size_t)nn[d] - 1] = dt * v;
                 }
             }
             PIB_CHK(up(hg[d], &G.g[d]));

@@ -150,6 +150,7 @@ struct GridLevel {
     double4 *tx_pw = nullptr, *tx_rw = nullptr;
     bool replicated = false;  // multi-GPU: every rank holds the whole level
     int64_t nloc = 0, plane = 0;
+    int per = 0;  // bit d: direction d (internal order) is periodic and has > 1 cell: the level operator wraps
 };
 
 struct LoopbackGroup;  // halo.hip: test-only transport (ranks = threads of one process on one GPU)
@@ -177,6 +178,7 @@ struct pib_solver {
     std::vector<double *> gmg_spare = std::vector<double *>(64, nullptr);
     bool gmg_guarded = true;
     std::string gmg_error;  // why the hierarchy could not be built (reported when a multigrid solve is asked for)
+    int periodic[3] = {0, 0, 0};             // pib_set_periodic: problem directions x, y[, z]
     std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
     double asm_dt = 0.0;
     // multi-GPU multigrid: plane ownership [b,e) of every rank on every level (the aggregates of the finer level's slab planes: gmg.hip grid_register)

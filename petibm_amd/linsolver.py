@@ -172,6 +172,11 @@ class LinSolverBase:
         p = [a.ctypes.data if a is not None else None for a in ws + gs]
         capi.check(capi.load().pib_set_grid_hint(self._h, dim, n3.ctypes.data, *p, int(nullspace)))
 
+    def setPeriodic(self, periodic) -> None:
+        """periodic directions of the mesh (pib_set_periodic); call before the assembly / the grid hint"""
+        per = (C.c_int * 3)(*[int(bool(periodic[d])) if d < len(periodic) else 0 for d in range(3)])
+        capi.check(capi.load().pib_set_periodic(self._h, per))
+
     def assemblePoisson(self, n, widths, dt: float, nullspace: int) -> None:
         """DBNG assembled in HBM from the pressure-cell widths (pib_assemble_poisson)."""
         dim = len(n)
