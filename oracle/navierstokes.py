@@ -94,7 +94,10 @@ class GhostPoints:
 
 
 def make_ghosts(mesh: CartesianMesh):
-    return {(f, loc): GhostPoints(mesh, f, loc) for f in range(mesh.dim) for loc in range(2 * mesh.dim)}
+    """a periodic boundary has no ghost points (singleboundaryperiodic.cpp: every kernel is a no-op; the neighbour
+    indices wrap instead, cartesianmesh.cpp:595-681)"""
+    return {(f, loc): GhostPoints(mesh, f, loc) for f in range(mesh.dim) for loc in range(2 * mesh.dim)
+            if not mesh.periodic[f][loc // 2]}
 
 
 def _field_arrays(mesh: CartesianMesh, U: np.ndarray):
@@ -130,10 +133,16 @@ def ghost_padded(mesh: CartesianMesh, U: np.ndarray, ghosts):
     createconvection.cpp:213-220): the stored ghost values."""
     res = []
     for f, a in enumerate(_field_arrays(mesh, U)):
-        n2, n1, n0 = a.shape
-        g = np.zeros((n2 + 2, n1 + 2, n0 + 2))
-        g[1:-1, 1:-1, 1:-1] = a
+        # periodic axes first: DMGlobalToLocal on the BOX-stencil DMDA wraps them, corners between two periodic axes
+        # included (cartesianmesh.cpp:507-517); then a zero layer on the wall axes whose interior span receives the
+        # stored ghost values.  A corner between a wall ghost and a periodic wrap is written by neither
+        # (copyValues2LocalVecs only knows the ghosts facing owned points): it keeps the local vector's initial zero.
+        per = [bool(mesh.periodic[f][2 - ax]) if (2 - ax) < mesh.dim else False for ax in range(3)]
+        g = np.pad(a, [(1, 1) if per[ax] else (0, 0) for ax in range(3)], mode="wrap")
+        g = np.pad(g, [(0, 0) if per[ax] else (1, 1) for ax in range(3)], mode="constant")
         for loc in range(2 * mesh.dim):
+            if (f, loc) not in ghosts:
+                continue
             ax = 2 - loc // 2  # numpy axis of (k, j, i)
             sl_g = [slice(1, -1)] * 3
             sl_g[ax] = 0 if loc % 2 == 0 else g.shape[ax] - 1
@@ -214,6 +223,8 @@ def laplacian_correction(mesh: CartesianMesh, ghosts) -> np.ndarray:
         ijk = (i.ravel(), j.ravel(), k.ravel())
         rows = np.arange(n0 * n1 * n2) + off
         for loc in range(2 * mesh.dim):
+            if (f, loc) not in ghosts:
+                continue
             d = loc // 2
             s = ijk[d]
             on = (s == 0) if loc % 2 == 0 else (s == mesh.n[f][d] - 1)
@@ -243,6 +254,8 @@ def divergence_correction(mesh: CartesianMesh, ghosts, normalize: bool = False) 
         else:
             area = mesh.dL[2][0][i] * mesh.dL[2][1][j]
         for loc in (2 * f, 2 * f + 1):
+            if (f, loc) not in ghosts:
+                continue
             on = (ijk[f] == 0) if loc % 2 == 0 else (ijk[f] == mesh.n[3][f] - 1)
             coeff = (-area[on]) if loc % 2 == 0 else area[on]
             y[on] = y[on] + coeff * _face_take(ghosts[(f, loc)], ijk, on)
@@ -271,7 +284,8 @@ class NavierStokes:
         self.vtol, self.ptol = vtol, ptol
         self.info = {}
         w = [mesh.dL[3][d].true for d in range(mesh.dim)]
-        self.gmg = clib.GMG([int(v) for v in mesh.n[3][:mesh.dim]], w, dt, nullspace=2 if pinned else 1)
+        self.gmg = clib.GMG([int(v) for v in mesh.n[3][:mesh.dim]], w, dt, nullspace=2 if pinned else 1,
+                            periodic=[bool(mesh.periodic[0][d]) for d in range(mesh.dim)])
 
     def set_state(self, U, p=None):
         """initial data + bc->setGhostICs(solution) (navierstokes.cpp:139-142)"""

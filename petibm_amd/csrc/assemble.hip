@@ -367,14 +367,16 @@ struct FieldDev {
     const double *dl[3];     // dL[f][d], index s+1 (ghost at 0)
     const double *co[3];     // coord[f][d], index s+1
     double a0[6];            // ghost coefficient per boundary location (0 where periodic / unused)
+    int per;                 // bit d: direction d periodic (neighbour indices wrap, no ghost fold)
 };
 
 
 // Coordinates and widths (with one ghost entry each side, index s+1) of the velocity fields:
 // CartesianMesh::createPressureMesh / createVertexMesh / createVelocityMesh (src/mesh/cartesianmesh.cpp:136-355),
-// non-periodic.  Same evaluation order as oracle/mesh.py.
+// including the periodic variants (:259-266 one more point of component d along a periodic d, :300-318 ghost entries
+// taken from the other end).  Same evaluation order as oracle/mesh.py.
 void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3], const double mn[3], const double mx[3],
-                          std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3])
+                          const int per[3], std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3])
 {
     std::vector<double> c3[3], c4[3];
     for (int d = 0; d < dim; ++d) {
@@ -396,14 +398,21 @@ void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3],
             hco[f][d].clear();
             if (f >= dim || d >= dim) continue;
             const int64_t n3 = n[d];
+            const bool wrap = per != nullptr && per[d] != 0;
             if (d == f) {
-                const int64_t nf = n3 - 1;
+                const int64_t nf = wrap ? n3 : n3 - 1;
                 fn[f][d] = nf;
-                hco[f][d] = c4[d];  // n3+1 = nf+2 entries: vertices, ghosts = the walls
-                hdl[f][d].assign((size_t)nf + 2, 0.0);
+                hco[f][d] = c4[d];  // n3+1 entries: vertices, ghosts = the walls
+                hdl[f][d].assign((size_t)n3 + 1, 0.0);
                 hdl[f][d][0] = w[d][0];
                 for (int64_t q = 1; q < n3; ++q) hdl[f][d][(size_t)q] = 0.5 * (w[d][q] + w[d][q - 1]);
-                hdl[f][d][(size_t)nf + 1] = w[d][n3 - 1];
+                if (wrap) {
+                    hdl[f][d][(size_t)n3] = 0.5 * (w[d][0] + w[d][n3 - 1]);
+                    hdl[f][d][0] = hdl[f][d][(size_t)n3];
+                    hdl[f][d].push_back(hdl[f][d][1]);
+                    hco[f][d].push_back(mx[d] + w[d][0]);
+                } else
+                    hdl[f][d][(size_t)n3] = w[d][n3 - 1];
             } else {
                 fn[f][d] = n3;
                 hco[f][d].assign((size_t)n3 + 2, 0.0);
@@ -412,10 +421,17 @@ void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3],
                     hco[f][d][(size_t)q + 1] = c3[d][(size_t)q];
                     hdl[f][d][(size_t)q + 1] = w[d][q];
                 }
-                hco[f][d][0] = mn[d] - w[d][0] / 2.0;
-                hco[f][d][(size_t)n3 + 1] = mx[d] + w[d][n3 - 1] / 2.0;
-                hdl[f][d][0] = w[d][0];
-                hdl[f][d][(size_t)n3 + 1] = w[d][n3 - 1];
+                if (wrap) {
+                    hco[f][d][0] = mn[d] - w[d][n3 - 1] / 2.0;
+                    hco[f][d][(size_t)n3 + 1] = mx[d] + w[d][0] / 2.0;
+                    hdl[f][d][0] = w[d][n3 - 1];
+                    hdl[f][d][(size_t)n3 + 1] = w[d][0];
+                } else {
+                    hco[f][d][0] = mn[d] - w[d][0] / 2.0;
+                    hco[f][d][(size_t)n3 + 1] = mx[d] + w[d][n3 - 1] / 2.0;
+                    hdl[f][d][0] = w[d][0];
+                    hdl[f][d][(size_t)n3 + 1] = w[d][n3 - 1];
+                }
             }
         }
 }
@@ -429,10 +445,10 @@ __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, 
     const int64_t nx = F.n[0], ny = F.n[1], nz = F.n[2];
     const int64_t pl = (dim == 3) ? nx * ny : nx;  // entries per plane of the slab axis
     const int64_t g0 = pl * F.kb, nf = pl * (F.ke - F.kb);
-    const int64_t base_nnz = nnz_before(g0, dim, nx, ny, nz, 0);
+    const int64_t base_nnz = nnz_before(g0, dim, nx, ny, nz, F.per);
     for (int64_t lr = (int64_t)blockIdx.x * 256 + threadIdx.x; lr <= nf; lr += (int64_t)gridDim.x * 256) {
         const int64_t r = g0 + lr;  // row in the field's global natural order
-        int64_t p = F.nnz_off + (nnz_before(r, dim, nx, ny, nz, 0) - base_nnz);
+        int64_t p = F.nnz_off + (nnz_before(r, dim, nx, ny, nz, F.per) - base_nnz);
         if (lr < nf || last_field) rowptr[F.row_off + lr] = (RP)p;
         if (lr == nf) break;
         const int64_t ijk[3] = {r % nx, (r / nx) % ny, r / (nx * ny)};
@@ -446,8 +462,9 @@ __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, 
             const double dLPos = F.co[d][sidx + 2] - F.co[d][sidx + 1];
             v[2 * d] = 1.0 / (dLNeg * dLSelf);
             v[2 * d + 1] = 1.0 / (dLPos * dLSelf);
-            interior[2 * d] = sidx > 0;
-            interior[2 * d + 1] = sidx < F.n[d] - 1;
+            const bool wrap = (F.per >> d) & 1;
+            interior[2 * d] = sidx > 0 || wrap;
+            interior[2 * d + 1] = sidx < F.n[d] - 1 || wrap;
             acc = acc + v[2 * d];
             acc = acc + v[2 * d + 1];
         }
@@ -462,22 +479,38 @@ __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, 
         const int sd = dim - 1;
         const int64_t ks = ijk[sd], inplane = lr % pl;
         // columns ascending: z-, y-, x-, diag, x+, y+, z+ (a neighbour rank's plane sits in a ghost pad: the low pad
-        // precedes and the high pad follows every owned column, so the order is kept)
-        for (int d = dim - 1; d >= 0; --d)
-            if (interior[2 * d]) {
-                col[p] = (d == sd && ks - 1 < F.kb) ? (int32_t)(F.ghost_lo_off + inplane) : (int32_t)(lc - st[d]);
-                val[p] = v[2 * d] * scale;
-                ++p;
+        // precedes and the high pad follows every owned column, so the order is kept); a neighbour across a periodic
+        // seam has the wrapped column and takes its sorted place
+        int64_t ec[7];
+        double ev[7];
+        int ne = 1;
+        ec[0] = lc;
+        ev[0] = diag * scale + shift;
+        for (int q = 0; q < 2 * dim; ++q) {
+            if (!interior[q]) continue;
+            const int d = q >> 1;
+            int64_t c;
+            if (!(q & 1)) {
+                if (ijk[d] == 0) c = lc + (F.n[d] - 1) * st[d];
+                else c = (d == sd && ks - 1 < F.kb) ? F.ghost_lo_off + inplane : lc - st[d];
+            } else {
+                if (ijk[d] == F.n[d] - 1) c = lc - (F.n[d] - 1) * st[d];
+                else c = (d == sd && ks + 1 >= F.ke) ? F.ghost_hi_off + inplane : lc + st[d];
             }
-        col[p] = (int32_t)lc;
-        val[p] = diag * scale + shift;
-        ++p;
-        for (int d = 0; d < dim; ++d)
-            if (interior[2 * d + 1]) {
-                col[p] = (d == sd && ks + 1 >= F.ke) ? (int32_t)(F.ghost_hi_off + inplane) : (int32_t)(lc + st[d]);
-                val[p] = v[2 * d + 1] * scale;
-                ++p;
+            int t = ne++;
+            while (t > 0 && ec[t - 1] > c) {
+                ec[t] = ec[t - 1];
+                ev[t] = ev[t - 1];
+                --t;
             }
+            ec[t] = c;
+            ev[t] = v[q] * scale;
+        }
+        for (int t = 0; t < ne; ++t) {
+            col[p] = (int32_t)ec[t];
+            val[p] = ev[t];
+            ++p;
+        }
     }
 }
 
@@ -490,12 +523,19 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
     // ---- host mesh arithmetic (cartesianmesh.cpp:136-355, non-periodic)
     std::vector<double> hdl[3][3], hco[3][3];
     int64_t fn[3][3];
-    velocity_mesh_arrays(dim, n, w, mn, mx, hdl, hco, fn);
+    int per = 0;
+    for (int d = 0; d < dim; ++d)
+        if (s->periodic[d]) {
+            if (n[d] < 3) return fail(PIB_ERR_SUP, "assemble_velocity: a periodic direction needs >= 3 cells");
+            per |= 1 << d;
+        }
+    velocity_mesh_arrays(dim, n, w, mn, mx, s->periodic, hdl, hco, fn);
     // ---- sizes.  Decomposition: slabs along the last axis with the pressure grid's ownership (the velocity DMDAs
     // reuse the pressure process grid, cartesianmesh.cpp:516-535): rank r owns the planes of its pressure cells; the
     // component along the slab axis has one plane fewer, taken from the last rank.  Each rank's vector is the packed
     // [u-slab | v-slab | w-slab] of the reference's DMComposite (cartesianmesh.cpp:740-779).
     const int P = s->comm.nranks, rank = s->comm.rank, sd = dim - 1;
+    if (P > 1 && (per & (1 << sd))) return fail(PIB_ERR_SUP, "assemble_velocity: a periodic slab axis on several ranks is not supported");
     int64_t pk0, pk1;
     slab_range(n[sd], P, rank, &pk0, &pk1);
     int64_t rows = 0, nnz = 0, row_off[3] = {0, 0, 0}, nnz_off[3] = {0, 0, 0}, kb[3] = {0, 0, 0}, ke[3] = {0, 0, 0},
@@ -511,8 +551,8 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
         row_off[f] = rows;
         nnz_off[f] = nnz;
         rows += pl[f] * (ke[f] - kb[f]);
-        nnz += nnz_before(pl[f] * ke[f], dim, fn[f][0], fn[f][1], fn[f][2], 0) -
-               nnz_before(pl[f] * kb[f], dim, fn[f][0], fn[f][1], fn[f][2], 0);
+        nnz += nnz_before(pl[f] * ke[f], dim, fn[f][0], fn[f][1], fn[f][2], per) -
+               nnz_before(pl[f] * kb[f], dim, fn[f][0], fn[f][1], fn[f][2], per);
         if (rank > 0) {
             glo[f] = ghost_lo;
             ghost_lo += pl[f];
@@ -585,6 +625,7 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
         F.ghost_lo_off = glo[f];
         F.ghost_hi_off = ghost_lo + rows + ghi[f];
         for (int q = 0; q < 6; ++q) F.a0[q] = a0[6 * f + q];
+        F.per = per;
         const int64_t nf = pl[f] * (ke[f] - kb[f]);
         const int nb = (int)std::min<int64_t>(8192, (nf + 1 + 255) / 256);
         const int last = (f == dim - 1) ? 1 : 0;

@@ -25,17 +25,25 @@
 
 namespace pib {
 
-// velocity value at (i,j,k) of field f; an index one step outside is the stored ghost value
+// velocity value at (i,j,k) of field f; an index one step outside is the stored ghost value at a wall and the point
+// at the other end on a periodic direction (DMGlobalToLocal of the BOX-stencil DMDA, cartesianmesh.cpp:507-517).
+// A corner that is a wall ghost in one direction AND a periodic wrap in another is written by neither the scatter nor
+// copyValues2LocalVecs in the reference: its local vectors keep their initial zero there, and so does this.
 __device__ __forceinline__ double vel(const NsDev &D, const double *__restrict__ U, int f, int64_t i, int64_t j, int64_t k)
 {
     const NsField &F = D.f[f];
     int loc = -1;
-    if (i < 0) { loc = 0; i = 0; } else if (i >= F.n[0]) { loc = 1; i = F.n[0] - 1; }
-    if (j < 0) { loc = 2; j = 0; } else if (j >= F.n[1]) { loc = 3; j = F.n[1] - 1; }
+    bool wrapped = false;
+    if (i < 0) { if (D.per & 1) { i = F.n[0] - 1; wrapped = true; } else { loc = 0; i = 0; } }
+    else if (i >= F.n[0]) { if (D.per & 1) { i = 0; wrapped = true; } else { loc = 1; i = F.n[0] - 1; } }
+    if (j < 0) { if (D.per & 2) { j = F.n[1] - 1; wrapped = true; } else { loc = 2; j = 0; } }
+    else if (j >= F.n[1]) { if (D.per & 2) { j = 0; wrapped = true; } else { loc = 3; j = F.n[1] - 1; } }
     if (D.dim == 3) {
-        if (k < 0) { loc = 4; k = 0; } else if (k >= F.n[2]) { loc = 5; k = F.n[2] - 1; }
+        if (k < 0) { if (D.per & 4) { k = F.n[2] - 1; wrapped = true; } else { loc = 4; k = 0; } }
+        else if (k >= F.n[2]) { if (D.per & 4) { k = 0; wrapped = true; } else { loc = 5; k = F.n[2] - 1; } }
     }
-    return loc < 0 ? U[fidx(F, i, j, k)] : D.gv[face_index(F, loc, i, j, k)];
+    if (loc < 0) return U[fidx(F, i, j, k)];
+    return wrapped ? 0.0 : D.gv[face_index(F, loc, i, j, k)];
 }
 
 // -N(u) of createconvection.cpp at one velocity point (the caller scales by -1)
@@ -91,6 +99,7 @@ __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__res
     const int64_t ijk[3] = {i, j, k};
     double v[6] = {0, 0, 0, 0, 0, 0};
     bool interior[6] = {false, false, false, false, false, false};
+    bool anywrap = false;
     double acc = 0.0;
     for (int d = 0; d < D.dim; ++d) {
         const int64_t s = ijk[d];
@@ -99,8 +108,10 @@ __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__res
         const double dLPos = F.co[d][s + 2] - F.co[d][s + 1];
         v[2 * d] = 1.0 / (dLNeg * dLSelf);
         v[2 * d + 1] = 1.0 / (dLPos * dLSelf);
-        interior[2 * d] = s > 0;
-        interior[2 * d + 1] = s < F.n[d] - 1;
+        const bool wrap = (D.per >> d) & 1;
+        interior[2 * d] = s > 0 || wrap;
+        interior[2 * d + 1] = s < F.n[d] - 1 || wrap;
+        anywrap = anywrap || (wrap && (s == 0 || s == F.n[d] - 1));
         acc = acc + v[2 * d];
         acc = acc + v[2 * d + 1];
     }
@@ -116,11 +127,36 @@ __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__res
     const int64_t st[3] = {1, F.n[0], F.n[0] * F.n[1]};
     const int64_t p = fidx(F, i, j, k);
     double s = 0.0;
-    for (int d = D.dim - 1; d >= 0; --d)
-        if (interior[2 * d]) s = s + v[2 * d] * U[p - st[d]];
-    s = s + diag * U[p];
-    for (int d = 0; d < D.dim; ++d)
-        if (interior[2 * d + 1]) s = s + v[2 * d + 1] * U[p + st[d]];
+    if (!anywrap) {
+        for (int d = D.dim - 1; d >= 0; --d)
+            if (interior[2 * d]) s = s + v[2 * d] * U[p - st[d]];
+        s = s + diag * U[p];
+        for (int d = 0; d < D.dim; ++d)
+            if (interior[2 * d + 1]) s = s + v[2 * d + 1] * U[p + st[d]];
+    } else {
+        // a neighbour across the periodic seam has the wrapped column: the row is summed by ascending column
+        int64_t ec[7];
+        double ev[7];
+        int ne = 1;
+        ec[0] = p;
+        ev[0] = diag;
+        for (int q = 0; q < 2 * D.dim; ++q) {
+            if (!interior[q]) continue;
+            const int d = q >> 1;
+            int64_t c;
+            if (!(q & 1)) c = (ijk[d] == 0) ? p + (F.n[d] - 1) * st[d] : p - st[d];
+            else c = (ijk[d] == F.n[d] - 1) ? p - (F.n[d] - 1) * st[d] : p + st[d];
+            int t = ne++;
+            while (t > 0 && ec[t - 1] > c) {
+                ec[t] = ec[t - 1];
+                ev[t] = ev[t - 1];
+                --t;
+            }
+            ec[t] = c;
+            ev[t] = v[q];
+        }
+        for (int t = 0; t < ne; ++t) s = s + ev[t] * U[ec[t]];
+    }
     *lu = s;
     *lc = corr;
     *lcn = corrn;
@@ -145,8 +181,14 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         const double gv = 1.0 / F.dl[f][ijk[f] + 1];
         const int64_t pst[3] = {1, D.pn[0], D.pn[0] * D.pn[1]};
         const int64_t pc = i + D.pn[0] * (j + D.pn[1] * k);
-        double r = 0.0 + (-gv) * p[pc];
-        r = r + gv * p[pc + pst[f]];
+        double r;
+        if (ijk[f] < D.pn[f] - 1) {
+            r = 0.0 + (-gv) * p[pc];
+            r = r + gv * p[pc + pst[f]];
+        } else {  // last point of a periodic direction: the + neighbour is cell 0, the smaller column of G's row
+            r = 0.0 + gv * p[pc - (D.pn[f] - 1) * pst[f]];
+            r = r + (-gv) * p[pc];
+        }
         r = -1.0 * r;
         r = r + (1.0 / dt) * U[g];
         const double cn = -1.0 * convection_at(D, U, f, i, j, k);
@@ -183,6 +225,20 @@ __global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int pinned, con
             const int64_t s_ = ijk[f];
             // velocity point with the cell's own index = the + face; index s-1 = the - face
             int64_t fi[3] = {i, j, k};
+            if ((D.per >> f) & 1) {
+                // periodic: both faces are velocity points, + face = index s, - face = index s-1 (point n-1 for cell 0,
+                // which then sorts after the + face in D's row)
+                const int64_t base = fidx(F, i, j, k);
+                const int64_t im = (s_ > 0) ? base - st : base + (F.n[f] - 1) * st;
+                if (s_ > 0) {
+                    s = s + (-area[f]) * U[im];
+                    s = s + area[f] * U[base];
+                } else {
+                    s = s + area[f] * U[base];
+                    s = s + (-area[f]) * U[im];
+                }
+                continue;
+            }
             const bool has_m = s_ > 0, has_p = s_ < F.n[f];
             fi[f] = has_p ? s_ : s_ - 1;
             const int64_t base = fidx(F, fi[0], fi[1], fi[2]);
@@ -284,8 +340,14 @@ __global__ __launch_bounds__(256) void k_ns_project(NsDev D, double dt, const do
             const double gv = 1.0 / F.dl[f][ijk[f] + 1];
             const int64_t pst[3] = {1, D.pn[0], D.pn[0] * D.pn[1]};
             const int64_t pc = i + D.pn[0] * (j + D.pn[1] * k);
-            double r = 0.0 + (dt * (-gv)) * dP[pc];
-            r = r + (dt * gv) * dP[pc + pst[f]];
+            double r;
+            if (ijk[f] < D.pn[f] - 1) {
+                r = 0.0 + (dt * (-gv)) * dP[pc];
+                r = r + (dt * gv) * dP[pc + pst[f]];
+            } else {  // periodic seam: column order of BNG's row
+                r = 0.0 + (dt * gv) * dP[pc - (D.pn[f] - 1) * pst[f]];
+                r = r + (dt * (-gv)) * dP[pc];
+            }
             U[g] = U[g] + (-1.0) * r;
         }
         if (g < D.pN) p[g] = p[g] + 1.0 * dP[g];
@@ -324,8 +386,20 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     const double *w[3] = {wx, wy, wz};
     std::vector<double> hdl[3][3], hco[3][3];
     int64_t fn[3][3];
-    velocity_mesh_arrays(dim, n, w, lo, hi, hdl, hco, fn);
+    // periodic directions: PERIODIC at both ends for every component (misc.cpp:17-85 checkPeriodicBC)
+    int periodic[3] = {0, 0, 0};
+    for (int d = 0; d < dim; ++d) {
+        int cnt = 0;
+        for (int f = 0; f < dim; ++f)
+            for (int e = 0; e < 2; ++e) cnt += (bc_type[6 * f + 2 * d + e] == 3) ? 1 : 0;
+        if (cnt != 0 && cnt != 2 * dim)
+            return fail(PIB_ERR_ARG_WRONG, "pib_ns_create: direction %d is periodic for some components / ends only "
+                                           "(a periodic boundary needs PERIODIC at both ends for every velocity component)", d);
+        periodic[d] = cnt ? 1 : 0;
+    }
+    velocity_mesh_arrays(dim, n, w, lo, hi, periodic, hdl, hco, fn);
     pib_ns *ns = new pib_ns();
+    for (int d = 0; d < 3; ++d) ns->periodic[d] = periodic[d];
     ns->dt = dt;
     ns->nu = nu;
     for (int d = 0; d < dim; ++d) {
@@ -361,7 +435,9 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
                 const int64_t nf = fn[f][axis];
                 gdl[6 * f + loc] = (loc % 2 == 1) ? c[(size_t)nf + 1] - c[(size_t)nf] : c[1] - c[0];
             }
-            if (t == 0 || t == 2) {  // DIRICHLET (singleboundarydirichlet.cpp:35-44), CONVECTIVE (singleboundaryconvective.cpp:20-36)
+            if (t == 3) {  // PERIODIC: no ghost point, no fold (singleboundaryperiodic.cpp)
+                gdl[6 * f + loc] = 0.0;
+            } else if (t == 0 || t == 2) {  // DIRICHLET (singleboundarydirichlet.cpp:35-44), CONVECTIVE (singleboundaryconvective.cpp:20-36)
                 a0[6 * f + loc] = (axis == f) ? 0.0 : -1.0;
             } else if (t == 1 && axis == f) {
                 // a Neumann condition on the NORMAL component folds a0 = 1 into D (createdivergence.cpp:231-242) and
@@ -372,11 +448,12 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
                 a0[6 * f + loc] = 1.0;
             } else {
                 return bail(fail(PIB_ERR_SUP, "pib_ns_create: boundary type %d is not supported (0 DIRICHLET, 1 NEUMANN, "
-                                              "2 CONVECTIVE)", t));
+                                              "2 CONVECTIVE, 3 PERIODIC)", t));
             }
         }
     // matrices: A = I/dt - c nu L (CN: c = 1/2), DBNG; null-space convention from the Poisson solver's flavour
     // (navierstokes.cpp:395-429)
+    if ((err = pib_set_periodic(ns->vsol, periodic)) || (err = pib_set_periodic(ns->psol, periodic))) return bail(err);
     if ((err = pib_assemble_velocity(ns->vsol, dim, n, wx, wy, wz, lo, hi, a0, dt, 0.5 * nu))) return bail(err);
     char tbuf[64];
     pib_get_type(ns->psol, tbuf, sizeof tbuf);
@@ -386,6 +463,7 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     // device mesh arrays
     NsDev &D = ns->D;
     D.dim = dim;
+    D.per = (periodic[0] ? 1 : 0) | (periodic[1] ? 2 : 0) | (periodic[2] ? 4 : 0);
     int64_t off = 0;
     for (int f = 0; f < 3; ++f) {
         NsField &F = D.f[f];
@@ -417,7 +495,7 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
         for (int q = 0; q < 2 * dim; ++q) {
             NsField &F = D.f[f];
             F.goff[q] = D.nghost;
-            F.gcnt[q] = fn[f][0] * fn[f][1] * fn[f][2] / fn[f][q / 2];
+            F.gcnt[q] = periodic[q / 2] ? 0 : fn[f][0] * fn[f][1] * fn[f][2] / fn[f][q / 2];
             D.nghost += F.gcnt[q];
         }
     D.pN = 1;

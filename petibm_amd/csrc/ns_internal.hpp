@@ -15,7 +15,7 @@ struct NsField {
     // ghost points per boundary location: ghost = a0*target + a1 (a0 is uniform over a face); face arrays are
     // indexed a + na*b over the two perpendicular axes in natural order (misc.cpp:154-196)
     double a0[6];
-    int type[6];            // 0 DIRICHLET, 1 NEUMANN, 2 CONVECTIVE
+    int type[6];            // 0 DIRICHLET, 1 NEUMANN, 2 CONVECTIVE, 3 PERIODIC (no ghost points: indices wrap)
     double bcv[6];          // the BC value (Dirichlet value, Neumann gradient, convective speed)
     double gdl[6];          // distance ghost - target
     int64_t goff[6];        // offset of the face in the ghost arrays
@@ -23,6 +23,7 @@ struct NsField {
 };
 struct NsDev {
     int dim;
+    int per;                // bit d: direction d periodic (every component: misc.cpp checkPeriodicBC)
     NsField f[3];
     int64_t pn[3];          // pressure cells
     const double *pw[3];    // pressure-cell widths
@@ -74,5 +75,6 @@ struct pib_ns {
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     int f_iters = 0;
     double f_res = 0;
+    int periodic[3] = {0, 0, 0};
 };
 

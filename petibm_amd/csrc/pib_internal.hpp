@@ -252,7 +252,7 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
                const int64_t *col, const int32_t *rowptr32, const int32_t *col32, const double *val);
 void slab_range(int64_t nplanes, int nranks, int rank, int64_t *b, int64_t *e);
 void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3], const double mn[3], const double mx[3],
-                          std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3]);
+                          const int per[3], std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3]);
 int upload_vec(const std::vector<double> &h, double **d);
 // gmg.hip
 int gmg_verify(pib_solver *s);

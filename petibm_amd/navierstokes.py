@@ -14,7 +14,7 @@ from . import capi
 
 _DIR = {"x": 0, "y": 1, "z": 2}
 _LOC = {"xMinus": 0, "xPlus": 1, "yMinus": 2, "yPlus": 3, "zMinus": 4, "zPlus": 5}
-_BCT = {"DIRICHLET": 0, "NEUMANN": 1, "CONVECTIVE": 2}
+_BCT = {"DIRICHLET": 0, "NEUMANN": 1, "CONVECTIVE": 2, "PERIODIC": 3}
 
 DEFAULT_VELOCITY_CFG = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
                         "solv:convergence=ABSOLUTE\nsolv:tolerance=1e-12\nsolv:norm=L2\nsolv:store_res_history=1\n"
@@ -68,6 +68,10 @@ class NavierStokesSolver:
                         raise capi.PibError(capi.ERR_SUP, f"boundary type {t} is not supported by the device time step")
                     bc_t[6 * f + loc] = _BCT[t]
                     bc_v[6 * f + loc] = float(bc[name][1])
+        # a direction is periodic when every component is PERIODIC at both of its ends (misc.cpp checkPeriodicBC; the
+        # engine reports a partial specification as an error): component d then has n[d] points along d
+        self.periodic = [all(bc_t[6 * f + 2 * d + e] == 3 for f in range(self.dim) for e in range(2))
+                         for d in range(self.dim)]
         par = config["parameters"]
         self.dt = float(par["dt"])
         self.nu = float(config["flow"]["nu"])
@@ -92,24 +96,31 @@ class NavierStokesSolver:
         # NavierStokesSolver::init): one entry per component, a number or an expression in x, y, z, t, nu
         # (the reference parses them with SymEngine) evaluated at the component's points at t = 0
         ic = config["flow"].get("initialVelocity")
+        ip = config["flow"].get("initialPressure")  # optional, default 0 (parser.cpp:433-440)
         if ic is not None:
             U0 = self._initial_velocity(ic, lo)
-            if np.any(U0 != 0.0):
-                self.setState(U0, None)
+            p0 = self._initial_velocity([ip], lo, pressure=True) if ip is not None else None
+            if np.any(U0 != 0.0) or (p0 is not None and np.any(p0 != 0.0)):
+                self.setState(U0, p0)
 
-    def _initial_velocity(self, ic, lo):
+    def _points(self, f, d, lo=None):
+        """coordinates of field f (0..2 velocity components, 3 pressure) along direction d (cartesianmesh.cpp:136-355)"""
+        lo = self._lo if lo is None else lo
+        vtx = lo[d] + np.concatenate([[0.0], np.cumsum(self.widths[d])])
+        if f == d:
+            return vtx[1:] if self.periodic[d] else vtx[1:-1]
+        return 0.5 * (vtx[1:] + vtx[:-1])
+
+    def _initial_velocity(self, ic, lo, pressure=False):
         import math
         names = {k: getattr(np, k) for k in ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "abs")}
         names.update(pi=math.pi, e=math.e, t=0.0, nu=self.nu)
         parts = []
-        for f in range(self.dim):
-            axes = []
-            for d in range(self.dim):
-                vtx = lo[d] + np.concatenate([[0.0], np.cumsum(self.widths[d])])
-                axes.append(vtx[1:-1] if d == f else 0.5 * (vtx[1:] + vtx[:-1]))
+        for f in ([3] if pressure else range(self.dim)):
+            axes = [self._points(f, d, lo) for d in range(self.dim)]
             grids = np.meshgrid(*axes[::-1], indexing="ij")[::-1]  # arrays indexed (k, j, i)
             env = dict(names, x=grids[0], y=grids[1], z=grids[2] if self.dim == 3 else 0.0)
-            v = ic[f]
+            v = ic[0 if pressure else f]
             val = float(v) if not isinstance(v, str) else eval(v.replace("^", "**"), {"__builtins__": {}}, env)  # noqa: S307
             parts.append(np.broadcast_to(np.asarray(val, dtype=np.float64), grids[0].shape).reshape(-1))
         return np.concatenate(parts)
@@ -139,7 +150,7 @@ class NavierStokesSolver:
         """(name, shape (nz,) ny, nx) of the velocity components, then the pressure"""
         out = []
         for f in range(self.dim):
-            nf = [self.n[d] - (1 if d == f else 0) for d in range(self.dim)]
+            nf = [self.n[d] - (1 if (d == f and not self.periodic[d]) else 0) for d in range(self.dim)]
             out.append(("uvw"[f], tuple(nf[::-1])))
         out.append(("p", tuple(self.n[::-1])))
         return out
@@ -160,7 +171,7 @@ class NavierStokesSolver:
                     elif fi == 3 or fi != d:
                         c = ctr[d]
                     else:
-                        c = vtx[d][1:-1]
+                        c = vtx[d][1:] if self.periodic[d] else vtx[d][1:-1]
                     f.write(f"{name}/{ax}", c)
 
     def write(self, path: str) -> None:

@@ -109,7 +109,7 @@ def test_time_step_matches_oracle(case, pinned):
 
 
 def test_unsupported_boundary_conditions_are_errors():
-    from petibm_amd.capi import PibError, ERR_SUP
+    from petibm_amd.capi import PibError, ERR_SUP, ERR_ARG_WRONG
     from petibm_amd.navierstokes import NavierStokesSolver
     cfg = cavity((8, 8))
     cfg["flow"]["boundaryConditions"][1]["u"] = ["NEUMANN", 0.0]   # normal component: changes D and DBNG
@@ -117,10 +117,10 @@ def test_unsupported_boundary_conditions_are_errors():
         NavierStokesSolver(cfg)
     assert ei.value.code == ERR_SUP
     cfg = cavity((8, 8))
-    cfg["flow"]["boundaryConditions"][1]["u"] = ["PERIODIC", 0.0]  # wrap-around columns: not in the device time step
+    cfg["flow"]["boundaryConditions"][1]["u"] = ["PERIODIC", 0.0]  # one end / one component only (misc.cpp:32-82)
     with pytest.raises(PibError) as ei:
         NavierStokesSolver(cfg)
-    assert ei.value.code == ERR_SUP
+    assert ei.value.code == ERR_ARG_WRONG
 
 
 def test_lid_driven_cavity_re100_matches_ghia():

@@ -79,3 +79,117 @@ def test_periodic_gmg_pcg_matches_oracle(lin, case, n, per):
     ke = min(len(h), len(ref["history"]), 8)
     assert np.allclose(h[:ke], ref["history"][:ke], rtol=1e-8)
     s.destroy()
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_periodic_velocity_operator_bit_exact_and_bicgstab(lin, case):
+    from test_gpu_parity import _a0_table
+    m, per, _, L = system(case)
+    dt, cnu = 0.004, 0.5 * 0.01
+    A = oops.create_velocity_operator(L, dt, cnu)
+    s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12,
+                                                          conv="ABSOLUTE", maxit=500))
+    s.setPeriodic(per)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    s.assembleVelocity(n, [m.dL[3][d].true for d in range(m.dim)], m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
+    rp, cl, vl = s.getCSR()
+    assert len(rp) - 1 == m.UN
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(cl, A.col)
+    assert np.array_equal(vl, A.val)
+    us = np.random.default_rng(2).uniform(-1, 1, A.n_rows)
+    b = clib.spmv(A, us)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    assert s.getIters() < 30
+    assert np.linalg.norm(x - us) <= 1e-10 * np.linalg.norm(us)
+    s.destroy()
+
+
+VEL = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+       "solv:tolerance=1e-14\nsolv:norm=L2\nsolv:store_res_history=1\nsolv:preconditioner(prec)=BLOCK_JACOBI\n"
+       "prec:relaxation_factor=1.0\n")
+KSP_P = ("-poisson_ksp_type cg\n-poisson_ksp_atol 1.0E-13\n-poisson_ksp_rtol 0.0\n-poisson_ksp_max_it 500\n"
+         "-poisson_ksp_norm_type unpreconditioned\n-poisson_pc_type gamg\n-poisson_pib_smoother JACOBI\n")
+AMGX_P = ("config_version=2\nsolver(solv)=PCG\nsolv:max_iters=500\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+          "solv:tolerance=1e-13\nsolv:norm=L2\nsolv:store_res_history=1\nsolv:preconditioner(prec)=AMG\nprec:cycle=V\n"
+          "prec:presweeps=1\nprec:postsweeps=1\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
+          "smooth:relaxation_factor=0.9\n")
+
+
+def flow_config(n, per, nu=0.02, dt=0.005, ratios=None, lid=0.0):
+    cfg = omesh.periodic_config(n, per, lo=-0.5, hi=1.5, ratios=ratios)
+    cfg["flow"]["nu"] = nu
+    cfg["parameters"] = {"dt": dt, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    if lid:
+        for bc in cfg["flow"]["boundaryConditions"]:
+            if bc["location"] == "yPlus" and bc["u"][0] == "DIRICHLET":
+                bc["u"] = ["DIRICHLET", lid]
+    return cfg
+
+
+@pytest.mark.parametrize("case,pinned", [("2d_all", False), ("2d_all", True), ("2d_x_channel", False), ("2d_y_stretched", True),
+                                         ("3d_all", False), ("3d_xz_channel", True)])
+def test_periodic_time_step_matches_oracle(case, pinned):
+    """NavierStokesSolver::advance on periodic meshes (the Taylor-Green examples are periodic in every direction,
+    examples/decoupledibpm/multicylinders2dRe100_GPU in y only): random state, three steps, against the oracle."""
+    from oracle import navierstokes as ons
+    from petibm_amd.navierstokes import NavierStokesSolver
+    cfg = {"2d_all": flow_config((12, 10), (True, True)),
+           "2d_x_channel": flow_config((12, 10), (True, False), lid=0.5),
+           "2d_y_stretched": flow_config((11, 9), (False, True), ratios=(1.08, 1.0)),
+           "3d_all": flow_config((8, 7, 6), (True, True, True)),
+           "3d_xz_channel": flow_config((8, 7, 6), (True, False, True), ratios=(1.0, 0.93, 1.0), lid=0.4)}[case]
+    m = omesh.create_mesh(cfg)
+    dt, nu = cfg["parameters"]["dt"], cfg["flow"]["nu"]
+    ref = ons.NavierStokes(m, dt, nu, pinned=pinned, vtol=1e-14, ptol=1e-13)
+    rng = np.random.default_rng(11)
+    U0 = 0.1 * rng.uniform(-1, 1, m.UN)
+    p0 = 0.1 * rng.uniform(-1, 1, m.pN)
+    if pinned:
+        p0[0] = 0.0
+    ref.set_state(U0, p0)
+    s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=AMGX_P if pinned else KSP_P)
+    assert (s.UN, s.pN) == (m.UN, m.pN)
+    s.setState(U0, p0)
+    for step in range(3):
+        ref.advance()
+        s.advance()
+        U, p, r1, r2 = s.getState(rhs=True)
+        if step == 0:
+            assert np.array_equal(r1, ref.last_rhs1)  # explicit part: same operations in the same order
+        scale = np.abs(ref.last_rhs1).max()
+        assert np.abs(r1 - ref.last_rhs1).max() <= 1e-9 * scale
+        assert np.abs(r2 - ref.last_rhs2).max() <= 1e-9 * max(np.abs(ref.last_rhs2).max(), 1e-30) + 1e-14
+        assert np.abs(U - ref.U).max() <= 1e-9 * np.abs(ref.U).max()
+        dp = (p - p.mean()) - (ref.p - ref.p.mean())
+        assert np.abs(dp).max() <= 1e-8 * max(np.abs(ref.p - ref.p.mean()).max(), 1e-30)
+    div = clib.spmv(ref.D, U) + ons.divergence_correction(m, ref.ghosts)
+    if pinned:
+        div[0] = 0.0
+    assert np.abs(div).max() <= 1e-10 * np.abs(ref.D.val).max()
+    s.destroy()
+
+
+def test_taylor_green_vortex_2d_against_the_analytical_solution():
+    """examples/navierstokes/taylorgreenvortex2dRe100 (config.yaml verbatim but 64^2 cells and 200 steps): the
+    velocity decays like exp(-2 nu t); second-order in space."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    errs = []
+    for n in (32, 64):
+        cfg = omesh.periodic_config((n, n), (True, True), lo=-np.pi, hi=np.pi)
+        cfg["flow"].update(nu=0.01, initialVelocity=["cos(x) * sin(y)", "- sin(x) * cos(y)"],
+                           initialPressure="- (cos(2*x) + cos(2*y)) / 4")
+        cfg["parameters"] = {"dt": 0.01, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+        s = NavierStokesSolver(cfg)
+        s.advance(200)
+        U, p = s.getState()
+        t = 2.0
+        h = 2 * np.pi / n
+        xu = -np.pi + h * (1 + np.arange(n))       # u points: the vertices 1..n (one more than with walls)
+        xc = -np.pi + h * (0.5 + np.arange(n))
+        ue = (np.cos(xu)[None, :] * np.sin(xc)[:, None]) * np.exp(-2 * 0.01 * t)
+        ve = (-np.sin(xc)[None, :] * np.cos(xu)[:, None]) * np.exp(-2 * 0.01 * t)
+        e = np.concatenate([(U[: n * n].reshape(n, n) - ue).ravel(), (U[n * n:].reshape(n, n) - ve).ravel()])
+        errs.append(np.abs(e).max())
+        s.destroy()
+    assert errs[0] < 6e-3 and errs[1] < errs[0] / 3.0, errs

@@ -34,3 +34,33 @@ def test_gmg_level_operator_is_dbng(n, per):
     assert res["reason"] > 0 and res["iters"] <= 25, res
     r = b - DBNG.to_scipy() @ res["x"]
     assert np.linalg.norm(r) <= 1.01e-10 * np.linalg.norm(b)
+
+
+def tgv2d_fields(m, t, nu):
+    """Taylor-Green vortex of examples/navierstokes/taylorgreenvortex2dRe100/config.yaml at the velocity points"""
+    out = []
+    for f in range(2):
+        x = np.array([m.coord[f][0][i] for i in range(int(m.n[f][0]))])[None, :]
+        y = np.array([m.coord[f][1][j] for j in range(int(m.n[f][1]))])[:, None]
+        v = np.cos(x) * np.sin(y) if f == 0 else -np.sin(x) * np.cos(y)
+        out.append((v * np.exp(-2.0 * nu * t)).ravel())
+    return np.concatenate(out)
+
+
+def test_taylor_green_vortex_2d_decays_like_the_analytical_solution():
+    from oracle import navierstokes as ons
+    errs = []
+    for n in (16, 32):
+        cfg = omesh.periodic_config((n, n), (True, True), lo=-np.pi, hi=np.pi)
+        m = omesh.create_mesh(cfg)
+        nu, dt, nt = 0.1, 0.02 * 16 / n, 5 * n // 16
+        ns = ons.NavierStokes(m, dt, nu)
+        ns.set_state(tgv2d_fields(m, 0.0, nu))
+        for _ in range(nt):
+            ns.advance()
+        assert np.abs(ns.last_rhs2).max() < 1.0  # sanity
+        div = clib.spmv(ns.D, ns.U)
+        assert np.abs(div).max() < 1e-10
+        e = ns.U - tgv2d_fields(m, nt * dt, nu)
+        errs.append(np.abs(e).max())
+    assert errs[0] < 5e-3 and errs[1] < errs[0] / 2.5, errs  # between first and second order at these sizes
