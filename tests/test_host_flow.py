@@ -30,6 +30,7 @@ def test_python_mirror_initial_velocity_expressions():
         def __init__(self):  # no device
             self.dim, self.nu = 2, 0.1
             self.widths = [np.full(4, 0.25), np.full(3, 1.0 / 3.0)]
+            self.periodic = [False, False]
 
     s = Bare()
     U = s._initial_velocity(["sin(x)*cos(y)", 2.0], [0.0, 0.0])
@@ -40,6 +41,12 @@ def test_python_mirror_initial_velocity_expressions():
     assert np.allclose(V[:3], xu ** 2) and np.allclose(V[9:], np.pi)
     with pytest.raises(Exception):
         s._initial_velocity(["__import__('os').system('true')", 0.0], [0.0, 0.0])  # no builtins in the evaluator
+    # periodic x: one more u point per line, at the + boundary (cartesianmesh.cpp:249-266); pressure expression
+    s.periodic = [True, False]
+    W = s._initial_velocity(["x", 0.0], [0.0, 0.0])
+    assert W.shape == (4 * 3 + 4 * 2,) and np.allclose(W[:4], [0.25, 0.5, 0.75, 1.0])
+    P = s._initial_velocity(["x + y"], [0.0, 0.0], pressure=True)
+    assert P.shape == (12,) and np.isclose(P[0], 0.125 + 1.0 / 6.0)
 
 
 def test_body_files(tmp_path):
