@@ -32,7 +32,7 @@ struct MeshAxis {
     double start;
     std::vector<SubDomain> subDomains;
 };
-enum BCType { DIRICHLET = 0, NEUMANN = 1, CONVECTIVE = 2 };  // src/misc/type.cpp str2bt (PERIODIC: not provided)
+enum BCType { DIRICHLET = 0, NEUMANN = 1, CONVECTIVE = 2, PERIODIC = 3 };  // src/misc/type.cpp str2bt
 enum BCLoc { XMINUS = 0, XPLUS, YMINUS, YPLUS, ZMINUS, ZPLUS };
 struct BoundaryCondition {
     BCType type = DIRICHLET;
@@ -145,8 +145,8 @@ public:
             std::vector<double> U((size_t)UN, 0.0);
             int64_t off = 0;
             for (int f = 0; f < dim; ++f) {
-                int64_t nf = 1;
-                for (int d = 0; d < dim; ++d) nf *= n[d] - (d == f ? 1 : 0);
+                int64_t nf = 1;  // component f has one point fewer along f unless f is periodic (cartesianmesh.cpp:249-266)
+                for (int d = 0; d < dim; ++d) nf *= n[d] - ((d == f && cfg.bc[f][2 * d].type != PERIODIC) ? 1 : 0);
                 for (int64_t q = 0; q < nf; ++q) U[(size_t)(off + q)] = cfg.initialVelocity[(size_t)f];
                 off += nf;
             }

@@ -95,6 +95,9 @@ def create_delta(mesh: CartesianMesh, bodies, kernel_name: str = "ROMA_ET_AL_199
                 for d in range(dim):
                     s_list, p_list = [], []
                     for s in range(int(midx[pt][d]) - window, int(midx[pt][d]) + window + 1):
+                        # a window point outside the field contributes nothing, also on a periodic direction: the
+                        # reference wraps the index but evaluates the kernel a domain length away (createdelta.cpp:
+                        # 188-203: coord[s] -+ L), which is zero and not stored
                         if 0 <= s < nn[d]:
                             s_list.append(s)
                             p_list.append(kernel(body[pt][d] - mesh.coord[dof][d][s], widths[d]))

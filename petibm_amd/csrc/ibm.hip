@@ -82,6 +82,9 @@ __device__ __forceinline__ double delta_kernel(int kernel, double r, double dr)
 }
 
 // One Lagrangian row per lane.  FILL = false: count the stored entries; true: write col / val / eval at rowptr[r].
+// Window points outside [0, n) are skipped, also on a periodic direction: getEulerianNeighbors (createdelta.cpp:171-208)
+// does wrap their index there, but pairs it with the coordinate coord[s] -+ L, a whole domain length away from the
+// Lagrangian point, where the kernels vanish -- and zero entries are not stored (MAT_IGNORE_ZERO_ENTRIES, :61-62).
 template <bool FILL>
 __global__ __launch_bounds__(128) void k_ib_delta(NsDev D, IbDev I, int32_t *__restrict__ count,
                                                   const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
@@ -442,8 +445,6 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     using namespace pib;
     if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
-    if (ns->periodic[0] || ns->periodic[1] || ns->periodic[2])
-        return fail(PIB_ERR_SUP, "pib_ns_set_bodies: immersed bodies on a periodic mesh are not supported");
     PIB_HIP(hipSetDevice(ns->device));
     ib_release(ns->ib);
     ns->ib = nullptr;

@@ -193,3 +193,43 @@ def test_taylor_green_vortex_2d_against_the_analytical_solution():
         errs.append(np.abs(e).max())
         s.destroy()
     assert errs[0] < 6e-3 and errs[1] < errs[0] / 3.0, errs
+
+
+def test_decoupled_ibpm_on_a_y_periodic_mesh_matches_oracle():
+    """The boundary set of examples/decoupledibpm/multicylinders2dRe100_GPU (inflow / convective outlet in x, periodic
+    in y) with two cylinders, one of them with its kernel support clipped by the periodic seam."""
+    from oracle import ibm
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    from test_gpu_ibm import FORCES
+    from test_oracle_ibm import circle
+    cfg = omesh.periodic_config((40, 30), (False, True), lo=-2.0, hi=2.0)
+    cfg["mesh"][1]["start"] = -1.5
+    cfg["mesh"][1]["subDomains"][0]["end"] = 1.5
+    for bc in cfg["flow"]["boundaryConditions"]:
+        if bc["location"] in ("xMinus", "xPlus"):
+            for c, free in (("u", 1.0), ("v", 0.0)):
+                bc[c] = ["CONVECTIVE", 1.0] if bc["location"] == "xPlus" else ["DIRICHLET", free]
+    cfg["flow"]["nu"] = 0.025
+    cfg["parameters"] = {"dt": 0.01, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    bodies = [circle(24, r=0.3) + np.array([-0.6, 0.1]), circle(20, r=0.25) + np.array([0.5, 1.17])]
+    m = omesh.create_mesh(cfg)
+    assert m.n[1][1] == 30 and m.n[0][1] == 30  # periodic y: v has one more line of points
+    ref = ibm.DecoupledIBPM(m, 0.01, 0.025, bodies, pinned=True, vtol=1e-14, ptol=1e-13)
+    U0 = np.zeros(m.UN)
+    U0[: int(np.prod(m.n[0]))] = 1.0
+    U0 += 0.02 * np.random.default_rng(3).uniform(-1, 1, m.UN)
+    ref.set_state(U0, np.zeros(m.pN))
+    s = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=AMGX_P, forces_cfg=FORCES)
+    s.setState(U0, np.zeros(m.pN))
+    for step in range(3):
+        ref.advance()
+        s.advance()
+        U, p, r1, r2 = s.getState(rhs=True)
+        f, avg = s.getForces()
+        if step == 0:
+            assert np.array_equal(r1, ref.last_rhs1)
+        assert np.abs(r1 - ref.last_rhs1).max() <= 1e-9 * np.abs(ref.last_rhs1).max()
+        assert np.abs(U - ref.U).max() <= 1e-9 * np.abs(ref.U).max()
+        assert np.abs(f - ref.f).max() <= 1e-8 * np.abs(ref.f).max()
+        assert np.allclose(avg, ref.body_forces(), rtol=1e-8, atol=1e-12)
+    s.destroy()
