@@ -233,3 +233,42 @@ def test_decoupled_ibpm_on_a_y_periodic_mesh_matches_oracle():
         assert np.abs(f - ref.f).max() <= 1e-8 * np.abs(ref.f).max()
         assert np.allclose(avg, ref.body_forces(), rtol=1e-8, atol=1e-12)
     s.destroy()
+
+
+def test_two_cylinders_periodic_in_y_match_the_reference_readme():
+    """examples/decoupledibpm/multicylinders2dRe100_GPU verbatim (562 x 500 cells, periodic in y, two cylinders of 158
+    points, dt = 0.01, 20000 steps): the README's force coefficients averaged over 125 <= t <= 200."""
+    import json
+    import os
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    from test_gpu_ibm import FORCES
+    from test_oracle_ibm import circle
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_test_vectors.json")))["multicylinders2dRe100_readme"]
+    cfg = omesh.periodic_config((562, 500), (False, True))
+    cfg["mesh"] = [{"direction": "x", "start": -10.0, "subDomains": [
+        {"end": -0.75, "cells": 186, "stretchRatio": 0.991332611050921}, {"end": 0.75, "cells": 75, "stretchRatio": 1.0},
+        {"end": 30.0, "cells": 301, "stretchRatio": 1.008743169398907}]},
+        {"direction": "y", "start": -5.0, "subDomains": [{"end": 5.0, "cells": 500, "stretchRatio": 1.0}]}]
+    for bc in cfg["flow"]["boundaryConditions"]:
+        if bc["location"] == "xMinus":
+            bc["u"], bc["v"] = ["DIRICHLET", 1.0], ["DIRICHLET", 0.0]
+        elif bc["location"] == "xPlus":
+            bc["u"], bc["v"] = ["CONVECTIVE", 1.0], ["CONVECTIVE", 1.0]
+    cfg["flow"].update(nu=0.01, initialVelocity=[1.0, 0.0])
+    cfg["parameters"] = {"dt": 0.01, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    vel = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n"
+           "-velocity_pc_type jacobi\n-velocity_pc_jacobi_type diagonal\n")
+    bodies = [circle(158) + np.array([0.0, -2.5]), circle(158) + np.array([0.0, 2.5])]
+    s = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=vel, poisson_cfg=AMGX_P.replace("1e-13", "1.0E-06"),
+                            forces_cfg=FORCES)
+    s.advance(12500)
+    F = []
+    for _ in range(7500):
+        s.advance()
+        F.append(2.0 * s.getForces()[1])
+    F = np.array(F)  # (steps, body, xy)
+    for b, key in enumerate(("body1", "body2")):
+        assert abs(F[:, b, 0].mean() - g[key]["cd"]) < 0.004          # 1.7596 / 1.7598 here, 1.7603 / 1.7604 there
+        assert abs(F[:, b, 1].max() - g[key]["cl_max"]) < 0.003 and abs(F[:, b, 1].min() - g[key]["cl_min"]) < 0.003
+        assert abs(F[:, b, 1].mean()) < 0.005
+    s.destroy()
