@@ -158,6 +158,8 @@ public:
     {
         return pib_set_grid_hint(h_, dim, n, wx, wy, wz, gx, gy, gz, nullspace);
     }
+    /** periodic directions of the mesh (mesh->periodic[0][d]); before setGridHint / the on-device assembly */
+    ErrorCode setPeriodic(const int periodic[3]) { return pib_set_periodic(h_, periodic); }
     pib_solver *handle() { return h_; }
 
 protected:

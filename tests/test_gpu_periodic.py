@@ -272,3 +272,31 @@ def test_two_cylinders_periodic_in_y_match_the_reference_readme():
         assert abs(F[:, b, 1].max() - g[key]["cl_max"]) < 0.003 and abs(F[:, b, 1].min() - g[key]["cl_min"]) < 0.003
         assert abs(F[:, b, 1].mean()) < 0.005
     s.destroy()
+
+
+@pytest.mark.parametrize("n,per", [((24, 20), (True, True)), ((12, 10, 14), (False, True, True))])
+def test_periodic_setmatrix_and_grid_hint_route(lin, n, per):
+    """The PetIBM route on a periodic mesh: the application's DBNG (the oracle's) through setMatrix, then the hint with
+    the wrap face factor g[d][n-1] = dt / dL[d][d][n-1] (mesh->dL of the periodic velocity mesh); a hint without
+    pib_set_periodic does not describe that matrix and is rejected."""
+    from petibm_amd import capi
+    from petibm_amd.capi import PibError, ERR_ARG_WRONG
+    dt = 0.01
+    m = omesh.create_mesh(omesh.periodic_config(n, per))
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    xs, b = rhs_for(A)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    g = [np.array([dt * (1.0 / m.dL[d][d][s]) for s in range(int(m.n[d][d]))]) for d in range(m.dim)]
+    s = lin.LinSolverHIP("poisson", config_text=gmg_cfg())
+    s.setMatrix(A)
+    with pytest.raises(PibError) as ei:
+        s.setGridHint(list(n), w, [gd[: n[d] - 1] for d, gd in enumerate(g)], capi.NULLSPACE_CONSTANT)
+    assert ei.value.code == ERR_ARG_WRONG
+    s.setPeriodic(per)
+    s.setGridHint(list(n), w, g, capi.NULLSPACE_CONSTANT)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    assert s.getIters() <= 22
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    s.destroy()
