@@ -162,6 +162,19 @@ int pib_set_periodic(pib_solver *s, const int periodic[3]);
 int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                          const double *wz, double dt, int nullspace);
 
+/* The Poisson operator for `parameters.BN` > 1: DBNG = D * BN * G with
+ *   BN = sum_{k=1..order} dt^k (coeff_nu)^(k-1) L^(k-1)      createBnHead, src/operators/createbn.cpp:19-95
+ * built in HBM by the reference's own chain -- assembled G (creategradient.cpp:64-128), D (createdivergence.cpp:135-223)
+ * and L (createlaplacian.cpp:108-263), MatMatMult / MatAXPY(DIFFERENT_NONZERO_PATTERN) in PETSc's summation order
+ * (navierstokes.cpp:349-356) -- so the matrix is bit-identical to what the application would hand to setMatrix.
+ * lo / hi / a0 as in pib_assemble_velocity; coeff_nu = implicit diffusion coefficient * nu (0.5 nu for Crank-Nicolson).
+ * order 1 is pib_assemble_poisson.  The 13 / 25-point operator is solved with the CSR SpMV; an AMG entry in the solver
+ * file is served by the multigrid of the 7-point order-1 operator (same mesh) as preconditioner.  Single rank;
+ * order < 1 -> PIB_ERR_SUP like createBnHead; honours pib_set_periodic. */
+int pib_assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
+                            const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
+                            double coeff_nu, int bn_order, int nullspace);
+
 /* Assemble the velocity operator A = I/dt - c*nu*L directly in HBM and set it as the solver's matrix:
  * createLaplacian (src/operators/createlaplacian.cpp:108-263, incl. the ghost-point a0 fold :232-243) on the
  * packed (u,v[,w]) ordering, then MatScale(-c*nu) + MatShift(1/dt) (navierstokes.cpp:342-344), evaluated in

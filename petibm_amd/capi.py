@@ -53,6 +53,8 @@ _PROTOS = {
     "pib_set_grid_hint": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "pib_set_periodic": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "pib_assemble_poisson": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_double, C.c_int]),
+    "pib_assemble_poisson_bn": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
+                                          C.c_int]),
     "pib_assemble_velocity": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double]),
     "pib_solve": (C.c_int, [_vp, _vp, _vp]),
     "pib_get_iters": (C.c_int, [_vp, C.POINTER(C.c_int)]),

@@ -1,0 +1,458 @@
+// bn.hip -- the Poisson operator for BN order N > 1, built in HBM the way the reference builds
+// it: assembled G, D and L, then the chain of sparse products of
+//   createBnHead  (src/operators/createbn.cpp:19-95)    BN   = sum_{k=1..N} dt^k (c nu)^(k-1) L^(k-1)
+//   navierstokes.cpp:349-356                             BNG  = BN * G ,  DBNG = D * BNG
+// with the numerics of PETSc's SeqAIJ MatMatMult (row by row, A's row in column order, every product accumulated into
+// a sparse accumulator in encounter order, result columns sorted) and MatAXPY(DIFFERENT_NONZERO_PATTERN).  The oracle
+// (oracle/operators.py create_bn_head / create_poisson_operator over oracle/csrc/oracle.c) performs the same
+// operations in the same order: the matrices are bit-identical.
+//
+// Set-up only (one thread per row, the accumulator in scratch memory); the product matrices are 13 / 25-point and
+// wider, so the solve runs the CSR SpMV with the multigrid of the 7-point N = 1 operator as preconditioner (the two
+// operators differ by dt c nu L + ..., a small relative perturbation at the time steps PetIBM runs).  Single rank.
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <rocprim/rocprim.hpp>
+
+#include "pib_internal.hpp"
+
+namespace pib {
+
+struct Csr32 {
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    int32_t *rowptr = nullptr, *col = nullptr;
+    double *val = nullptr;
+    void release()
+    {
+        if (rowptr) (void)hipFree(rowptr);
+        if (col) (void)hipFree(col);
+        if (val) (void)hipFree(val);
+        rowptr = col = nullptr;
+        val = nullptr;
+        nrows = ncols = nnz = 0;
+    }
+};
+
+constexpr int SPGEMM_MAX_ROW = 192;  // widest product row: N = 3 in 3-D stays below 130
+
+static unsigned row_blocks(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + 127) / 128); }
+
+// counts -> exclusive offsets (rowptr[n] = total)
+static int offsets_from_counts(int32_t *d_rowptr /* counts in [0, n), slot n unused */, int64_t n, int64_t *total, hipStream_t q)
+{
+    PIB_HIP(hipMemsetAsync(d_rowptr + n, 0, sizeof(int32_t), q));
+    size_t bytes = 0;
+    void *tmp = nullptr;
+    PIB_HIP(rocprim::exclusive_scan(nullptr, bytes, d_rowptr, d_rowptr, 0, (size_t)n + 1, rocprim::plus<int32_t>(), q));
+    PIB_HIP(hipMalloc(&tmp, std::max<size_t>(bytes, 16)));
+    PIB_HIP(rocprim::exclusive_scan(tmp, bytes, d_rowptr, d_rowptr, 0, (size_t)n + 1, rocprim::plus<int32_t>(), q));
+    int32_t last = 0;
+    PIB_HIP(hipMemcpyAsync(&last, d_rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, q));
+    PIB_HIP(hipStreamSynchronize(q));
+    (void)hipFree(tmp);
+    *total = last;
+    return 0;
+}
+
+// C = A * B, one row per lane.  FILL = false: crp[i] = number of entries of row i; true: write them at crp[i].
+template <bool FILL>
+__global__ __launch_bounds__(128) void k_spgemm(int64_t nrows, const int32_t *__restrict__ arp, const int32_t *__restrict__ acol,
+                                                const double *__restrict__ aval, const int32_t *__restrict__ brp,
+                                                const int32_t *__restrict__ bcol, const double *__restrict__ bval,
+                                                int32_t *__restrict__ crp, int32_t *__restrict__ ccol, double *__restrict__ cval,
+                                                int *__restrict__ overflow)
+{
+    const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= nrows) return;
+    int32_t cols[SPGEMM_MAX_ROW];
+    double acc[SPGEMM_MAX_ROW];
+    int n = 0;
+    for (int32_t p = arp[i]; p < arp[i + 1]; ++p) {
+        const int32_t k = acol[p];
+        const double av = aval[p];
+        for (int32_t q = brp[k]; q < brp[k + 1]; ++q) {
+            const int32_t j = bcol[q];
+            // position of j in the sorted accumulator
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cols[mid] < j) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo < n && cols[lo] == j) {
+                if (FILL) {
+                    const double t = av * bval[q];
+                    acc[lo] = acc[lo] + t;
+                }
+                continue;
+            }
+            if (n == SPGEMM_MAX_ROW) {
+                *overflow = 1;
+                continue;
+            }
+            for (int t = n; t > lo; --t) {
+                cols[t] = cols[t - 1];
+                if (FILL) acc[t] = acc[t - 1];
+            }
+            cols[lo] = j;
+            if (FILL) acc[lo] = av * bval[q];
+            ++n;
+        }
+    }
+    if (!FILL) {
+        crp[i] = n;
+        return;
+    }
+    const int32_t base = crp[i];
+    for (int t = 0; t < n; ++t) {
+        ccol[base + t] = cols[t];
+        cval[base + t] = acc[t];
+    }
+}
+
+static int spgemm(const Csr32 &A, const Csr32 &B, Csr32 *C, hipStream_t q)
+{
+    C->release();
+    C->nrows = A.nrows;
+    C->ncols = B.ncols;
+    int *d_over = nullptr;
+    PIB_HIP(hipMalloc(&d_over, sizeof(int)));
+    PIB_HIP(hipMemsetAsync(d_over, 0, sizeof(int), q));
+    PIB_HIP(hipMalloc(&C->rowptr, sizeof(int32_t) * ((size_t)A.nrows + 1)));
+    hipLaunchKernelGGL(k_spgemm<false>, dim3(row_blocks(A.nrows)), dim3(128), 0, q, A.nrows, A.rowptr, A.col, A.val, B.rowptr, B.col,
+                       B.val, C->rowptr, (int32_t *)nullptr, (double *)nullptr, d_over);
+    PIB_HIP(hipGetLastError());
+    int over = 0;
+    PIB_HIP(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, q));
+    PIB_HIP(hipStreamSynchronize(q));
+    (void)hipFree(d_over);
+    if (over) return fail(PIB_ERR_SUP, "sparse product: a row has more than %d entries (BN order too high)", SPGEMM_MAX_ROW);
+    PIB_CHK(offsets_from_counts(C->rowptr, A.nrows, &C->nnz, q));
+    PIB_HIP(hipMalloc(&C->col, sizeof(int32_t) * (size_t)std::max<int64_t>(C->nnz, 1)));
+    PIB_HIP(hipMalloc(&C->val, sizeof(double) * (size_t)std::max<int64_t>(C->nnz, 1)));
+    hipLaunchKernelGGL(k_spgemm<true>, dim3(row_blocks(A.nrows)), dim3(128), 0, q, A.nrows, A.rowptr, A.col, A.val, B.rowptr, B.col,
+                       B.val, C->rowptr, C->col, C->val, (int *)nullptr);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipStreamSynchronize(q));
+    return 0;
+}
+
+// Z = Y + a X on the union pattern (both inputs sorted)
+template <bool FILL>
+__global__ __launch_bounds__(128) void k_axpy_pattern(int64_t nrows, double a, const int32_t *__restrict__ yrp,
+                                                      const int32_t *__restrict__ ycol, const double *__restrict__ yval,
+                                                      const int32_t *__restrict__ xrp, const int32_t *__restrict__ xcol,
+                                                      const double *__restrict__ xval, int32_t *__restrict__ zrp,
+                                                      int32_t *__restrict__ zcol, double *__restrict__ zval)
+{
+    const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= nrows) return;
+    int32_t p = yrp[i], q = xrp[i];
+    const int32_t pe = yrp[i + 1], qe = xrp[i + 1];
+    int32_t o = FILL ? zrp[i] : 0;
+    while (p < pe || q < qe) {
+        if (q >= qe || (p < pe && ycol[p] < xcol[q])) {
+            if (FILL) { zcol[o] = ycol[p]; zval[o] = yval[p]; }
+            ++p;
+        } else if (p >= pe || xcol[q] < ycol[p]) {
+            if (FILL) { zcol[o] = xcol[q]; zval[o] = a * xval[q]; }
+            ++q;
+        } else {
+            if (FILL) { zcol[o] = ycol[p]; zval[o] = yval[p] + a * xval[q]; }
+            ++p;
+            ++q;
+        }
+        ++o;
+    }
+    if (!FILL) zrp[i] = o;
+}
+
+static int axpy_pattern(const Csr32 &Y, double a, const Csr32 &X, Csr32 *Z, hipStream_t q)
+{
+    Z->release();
+    Z->nrows = Y.nrows;
+    Z->ncols = Y.ncols;
+    PIB_HIP(hipMalloc(&Z->rowptr, sizeof(int32_t) * ((size_t)Y.nrows + 1)));
+    hipLaunchKernelGGL(k_axpy_pattern<false>, dim3(row_blocks(Y.nrows)), dim3(128), 0, q, Y.nrows, a, Y.rowptr, Y.col, Y.val, X.rowptr,
+                       X.col, X.val, Z->rowptr, (int32_t *)nullptr, (double *)nullptr);
+    PIB_HIP(hipGetLastError());
+    PIB_CHK(offsets_from_counts(Z->rowptr, Y.nrows, &Z->nnz, q));
+    PIB_HIP(hipMalloc(&Z->col, sizeof(int32_t) * (size_t)std::max<int64_t>(Z->nnz, 1)));
+    PIB_HIP(hipMalloc(&Z->val, sizeof(double) * (size_t)std::max<int64_t>(Z->nnz, 1)));
+    hipLaunchKernelGGL(k_axpy_pattern<true>, dim3(row_blocks(Y.nrows)), dim3(128), 0, q, Y.nrows, a, Y.rowptr, Y.col, Y.val, X.rowptr,
+                       X.col, X.val, Z->rowptr, Z->col, Z->val);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipStreamSynchronize(q));
+    return 0;
+}
+
+// ---- G and D as matrices ---------------------------------------------------------------------------------
+struct GdMesh {
+    int dim, per;
+    int64_t fn[3][3], foff[3];   // points and first packed row of every velocity component
+    int64_t pn[3];
+    const double *dlff[3];       // dL[f][f], index s+1
+    const double *pw[3];         // pressure-cell widths
+};
+
+// createGradient (creategradient.cpp:64-128, normalize = FALSE): row of velocity point (f; i,j,k) = {-1/dL at its cell,
+// +1/dL at the next cell along f}, dL = dL[f][f][idx]; the next cell of the last point of a periodic direction is cell 0
+// (the smaller column).
+__global__ __launch_bounds__(256) void k_bn_gradient(GdMesh M, int64_t UN, int32_t *__restrict__ rp, int32_t *__restrict__ col,
+                                                     double *__restrict__ val)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= UN; r += (int64_t)gridDim.x * 256) {
+        rp[r] = (int32_t)(2 * r);
+        if (r == UN) break;
+        int f = 0;
+        if (M.dim > 1 && r >= M.foff[1]) f = 1;
+        if (M.dim > 2 && r >= M.foff[2]) f = 2;
+        const int64_t q = r - M.foff[f];
+        const int64_t ijk[3] = {q % M.fn[f][0], (q / M.fn[f][0]) % M.fn[f][1], q / (M.fn[f][0] * M.fn[f][1])};
+        const double gv = 1.0 / M.dlff[f][ijk[f] + 1];
+        const int64_t pst[3] = {1, M.pn[0], M.pn[0] * M.pn[1]};
+        const int64_t pc = ijk[0] + M.pn[0] * (ijk[1] + M.pn[1] * ijk[2]);
+        if (ijk[f] < M.pn[f] - 1) {
+            col[2 * r] = (int32_t)pc;
+            val[2 * r] = -gv;
+            col[2 * r + 1] = (int32_t)(pc + pst[f]);
+            val[2 * r + 1] = gv;
+        } else {
+            col[2 * r] = (int32_t)(pc - (M.pn[f] - 1) * pst[f]);
+            val[2 * r] = gv;
+            col[2 * r + 1] = (int32_t)pc;
+            val[2 * r + 1] = -gv;
+        }
+    }
+}
+
+// createDivergence (createdivergence.cpp:135-223, normalize = FALSE): row of a pressure cell = -area at the minus face,
+// +area at the plus face of every direction, columns = packed velocity indices in ascending order.  Ghost faces have no
+// column (a0 = 0 for the normal component with Dirichlet / convective boundaries, :231-242).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bn_divergence(GdMesh M, int64_t pN, int32_t *__restrict__ rp, int32_t *__restrict__ col,
+                                                       double *__restrict__ val)
+{
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < pN; c += (int64_t)gridDim.x * 256) {
+        const int64_t ijk[3] = {c % M.pn[0], (c / M.pn[0]) % M.pn[1], c / (M.pn[0] * M.pn[1])};
+        const double wx = M.pw[0][ijk[0]], wy = M.pw[1][ijk[1]], wz = (M.dim == 3) ? M.pw[2][ijk[2]] : 1.0;
+        const double area[3] = {wy * wz, wx * wz, wx * wy};
+        int32_t o = FILL ? rp[c] : 0;
+        for (int f = 0; f < M.dim; ++f) {
+            const int64_t st[3] = {1, M.fn[f][0], M.fn[f][0] * M.fn[f][1]};
+            const int64_t s = ijk[f];
+            const bool wrap = (M.per >> f) & 1;
+            const int64_t base = M.foff[f] + ijk[0] + M.fn[f][0] * (ijk[1] + M.fn[f][1] * ijk[2]);  // the + face (index s)
+            const bool has_m = s > 0 || wrap, has_p = s < M.fn[f][f];
+            const int64_t cm = (s > 0) ? base - st[f] : base + (M.fn[f][f] - 1) * st[f];
+            if (has_m && s > 0) {
+                if (FILL) { col[o] = (int32_t)cm; val[o] = -area[f]; }
+                ++o;
+            }
+            if (has_p) {
+                if (FILL) { col[o] = (int32_t)base; val[o] = area[f]; }
+                ++o;
+            }
+            if (has_m && s == 0) {  // wrapped minus face: velocity point n-1 sorts after the plus face
+                if (FILL) { col[o] = (int32_t)cm; val[o] = -area[f]; }
+                ++o;
+            }
+        }
+        if (!FILL) rp[c] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_identity(int64_t n, double v, int32_t *__restrict__ rp, int32_t *__restrict__ col,
+                                                     double *__restrict__ val)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n; r += (int64_t)gridDim.x * 256) {
+        rp[r] = (int32_t)r;
+        if (r < n) {
+            col[r] = (int32_t)r;
+            val[r] = v;
+        }
+    }
+}
+
+// MatZeroRowsColumns(DBNG, row 0, diag = 1) keeping the pattern (navierstokes.cpp:414-420)
+__global__ __launch_bounds__(256) void k_bn_pin(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                double *__restrict__ val)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256)
+        for (int32_t p = rp[r]; p < rp[r + 1]; ++p)
+            if (r == 0 || col[p] == 0) val[p] = (r == 0 && col[p] == 0) ? 1.0 : 0.0;
+}
+
+static int dup(const Csr32 &A, Csr32 *B, hipStream_t q)
+{
+    B->release();
+    B->nrows = A.nrows;
+    B->ncols = A.ncols;
+    B->nnz = A.nnz;
+    PIB_HIP(hipMalloc(&B->rowptr, sizeof(int32_t) * ((size_t)A.nrows + 1)));
+    PIB_HIP(hipMalloc(&B->col, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nnz, 1)));
+    PIB_HIP(hipMalloc(&B->val, sizeof(double) * (size_t)std::max<int64_t>(A.nnz, 1)));
+    PIB_HIP(hipMemcpyAsync(B->rowptr, A.rowptr, sizeof(int32_t) * ((size_t)A.nrows + 1), hipMemcpyDeviceToDevice, q));
+    PIB_HIP(hipMemcpyAsync(B->col, A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToDevice, q));
+    PIB_HIP(hipMemcpyAsync(B->val, A.val, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToDevice, q));
+    PIB_HIP(hipStreamSynchronize(q));
+    return 0;
+}
+
+// Builds BNG (UN x pN) and DBNG (pN x pN) for BN order `order` >= 2 on the solver's device.  `s` is used as the
+// workspace of the Laplacian assembly (its matrix is replaced).
+static int build_bn_chain(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
+                          const double mx[3], const double a0[18], double dt, double coeff_nu, int order, Csr32 *BNG, Csr32 *DBNG)
+{
+    hipStream_t q = s->stream;
+    for (int f = 0; f < dim; ++f)
+        if (a0[6 * f + 2 * f] != 0.0 || a0[6 * f + 2 * f + 1] != 0.0)
+            return fail(PIB_ERR_SUP, "BN order > 1: a ghost fold on the normal velocity component (Neumann) changes D; not supported");
+    // L = createLaplacian: the velocity assembly with MatScale(1), MatShift(0)
+    PIB_CHK(assemble_velocity(s, dim, n, w, mn, mx, a0, std::numeric_limits<double>::infinity(), -1.0));
+    if (s->A.rp64) return fail(PIB_ERR_SUP, "BN order > 1: the Laplacian needs 64-bit offsets (too large for the product chain)");
+    Csr32 L;
+    L.nrows = L.ncols = s->A.n;
+    L.nnz = s->A.nnz;
+    L.rowptr = (int32_t *)s->A.rowptr;
+    L.col = s->A.col;
+    L.val = s->A.val;
+    s->A.rowptr = nullptr;  // ownership moved
+    s->A.col = nullptr;
+    s->A.val = nullptr;
+    s->A.release();
+    // mesh arrays for G and D
+    std::vector<double> hdl[3][3], hco[3][3];
+    GdMesh M;
+    std::memset(&M, 0, sizeof M);
+    M.dim = dim;
+    velocity_mesh_arrays(dim, n, w, mn, mx, s->periodic, hdl, hco, M.fn);
+    std::vector<double *> tofree;
+    int64_t UN = 0, pN = 1;
+    for (int d = 0; d < 3; ++d) {
+        M.pn[d] = (d < dim) ? n[d] : 1;
+        pN *= M.pn[d];
+        M.foff[d] = UN;
+        if (d < dim) {
+            if (s->periodic[d]) M.per |= 1 << d;
+            UN += M.fn[d][0] * M.fn[d][1] * M.fn[d][2];
+            double *p1 = nullptr, *p2 = nullptr;
+            std::vector<double> hw(w[d], w[d] + n[d]);
+            PIB_CHK(upload_vec(hdl[d][d], &p1));
+            PIB_CHK(upload_vec(hw, &p2));
+            M.dlff[d] = p1;
+            M.pw[d] = p2;
+            tofree.push_back(p1);
+            tofree.push_back(p2);
+        }
+    }
+    if (UN != L.nrows) return fail(PIB_ERR_LIB, "BN chain: velocity sizes disagree");
+    Csr32 G, D, BN, right, tmp;
+    auto cleanup = [&]() {
+        L.release();
+        G.release();
+        D.release();
+        BN.release();
+        right.release();
+        tmp.release();
+        for (double *p : tofree) (void)hipFree(p);
+    };
+    int err = 0;
+    auto run = [&]() -> int {
+        G.nrows = UN;
+        G.ncols = pN;
+        G.nnz = 2 * UN;
+        PIB_HIP(hipMalloc(&G.rowptr, sizeof(int32_t) * ((size_t)UN + 1)));
+        PIB_HIP(hipMalloc(&G.col, sizeof(int32_t) * (size_t)G.nnz));
+        PIB_HIP(hipMalloc(&G.val, sizeof(double) * (size_t)G.nnz));
+        const unsigned gb = (unsigned)std::min<int64_t>(8192, (UN + 256) / 256);
+        hipLaunchKernelGGL(k_bn_gradient, dim3(gb), dim3(256), 0, q, M, UN, G.rowptr, G.col, G.val);
+        PIB_HIP(hipGetLastError());
+        D.nrows = pN;
+        D.ncols = UN;
+        PIB_HIP(hipMalloc(&D.rowptr, sizeof(int32_t) * ((size_t)pN + 1)));
+        const unsigned db = (unsigned)std::min<int64_t>(8192, (pN + 255) / 256);
+        hipLaunchKernelGGL(k_bn_divergence<false>, dim3(db), dim3(256), 0, q, M, pN, D.rowptr, (int32_t *)nullptr, (double *)nullptr);
+        PIB_HIP(hipGetLastError());
+        PIB_CHK(offsets_from_counts(D.rowptr, pN, &D.nnz, q));
+        PIB_HIP(hipMalloc(&D.col, sizeof(int32_t) * (size_t)D.nnz));
+        PIB_HIP(hipMalloc(&D.val, sizeof(double) * (size_t)D.nnz));
+        hipLaunchKernelGGL(k_bn_divergence<true>, dim3(db), dim3(256), 0, q, M, pN, D.rowptr, D.col, D.val);
+        PIB_HIP(hipGetLastError());
+        // BN = dt I + sum_{term >= 2} dt^term (c nu)^(term-1) L^(term-1)   (createbn.cpp:47-92)
+        BN.nrows = BN.ncols = BN.nnz = UN;
+        PIB_HIP(hipMalloc(&BN.rowptr, sizeof(int32_t) * ((size_t)UN + 1)));
+        PIB_HIP(hipMalloc(&BN.col, sizeof(int32_t) * (size_t)UN));
+        PIB_HIP(hipMalloc(&BN.val, sizeof(double) * (size_t)UN));
+        hipLaunchKernelGGL(k_bn_identity, dim3(gb), dim3(256), 0, q, UN, dt, BN.rowptr, BN.col, BN.val);
+        PIB_HIP(hipGetLastError());
+        for (int term = 2; term <= order; ++term) {
+            PIB_CHK(dup(L, &right, q));
+            for (int c = 2; c < term; ++c) {
+                PIB_CHK(spgemm(L, right, &tmp, q));
+                std::swap(right, tmp);
+            }
+            const double a = std::pow(dt, term) * std::pow(coeff_nu, term - 1);
+            PIB_CHK(axpy_pattern(BN, a, right, &tmp, q));
+            std::swap(BN, tmp);
+        }
+        PIB_CHK(spgemm(BN, G, BNG, q));
+        PIB_CHK(spgemm(D, *BNG, DBNG, q));
+        return 0;
+    };
+    err = run();
+    cleanup();
+    return err;
+}
+
+int assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
+                        const double mx[3], const double a0[18], double dt, double coeff_nu, int order, int nullspace,
+                        int32_t **bng_rowptr, int32_t **bng_col, double **bng_val, int64_t *bng_nnz)
+{
+    if (order < 1) return fail(PIB_ERR_SUP, "The order of Bn can not be smaller than 1.");  // createbn.cpp:27-29 (error 56)
+    if (s->comm.nranks > 1) return fail(PIB_ERR_SUP, "BN order > 1 is assembled on one rank only");
+    Csr32 BNG, DBNG;
+    int err = build_bn_chain(s, dim, n, w, mn, mx, a0, dt, coeff_nu, order, &BNG, &DBNG);
+    if (err) {
+        BNG.release();
+        DBNG.release();
+        return err;
+    }
+    hipStream_t q = s->stream;
+    if (nullspace == PIB_NULLSPACE_PINNED) {
+        hipLaunchKernelGGL(k_bn_pin, dim3((unsigned)std::min<int64_t>(8192, (DBNG.nrows + 255) / 256)), dim3(256), 0, q, DBNG.nrows,
+                           DBNG.rowptr, DBNG.col, DBNG.val);
+        PIB_HIP(hipGetLastError());
+        PIB_HIP(hipStreamSynchronize(q));
+    }
+    err = adopt_device_csr(s, DBNG.nrows, DBNG.nnz, DBNG.rowptr, DBNG.col, DBNG.val);
+    DBNG.release();
+    if (bng_rowptr) {
+        *bng_rowptr = BNG.rowptr;
+        *bng_col = BNG.col;
+        *bng_val = BNG.val;
+        *bng_nnz = BNG.nnz;
+    } else
+        BNG.release();
+    if (err) return err;
+    // the multigrid of the N = 1 operator as preconditioner: structure from the widths, not verified against the CSR
+    std::vector<double> hw[3], hg[3];
+    for (int d = 0; d < 3; ++d) {
+        const int64_t nd = (d < dim) ? n[d] : 1;
+        hw[d].resize((size_t)nd);
+        for (int64_t i = 0; i < nd; ++i) hw[d][(size_t)i] = (d < dim) ? w[d][i] : 1.0;
+        const bool wrap = d < dim && s->periodic[d] != 0;
+        hg[d].resize((size_t)std::max<int64_t>(nd - 1, 0) + (wrap ? 1 : 0));
+        for (int64_t i = 0; i + 1 < nd; ++i) hg[d][(size_t)i] = dt * (1.0 / (0.5 * (hw[d][(size_t)i + 1] + hw[d][(size_t)i])));
+        if (wrap) hg[d][(size_t)nd - 1] = dt * (1.0 / (0.5 * (hw[d][0] + hw[d][(size_t)nd - 1])));
+    }
+    const double *cw[3] = {hw[0].data(), hw[1].data(), hw[2].data()};
+    const double *cg[3] = {hg[0].data(), hg[1].data(), hg[2].data()};
+    s->hint_pc_only = true;
+    err = grid_register(s, dim, n, cw, cg, nullspace, dt);
+    s->hint_pc_only = false;
+    return err;
+}
+
+}  // namespace pib

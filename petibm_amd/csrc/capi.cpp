@@ -215,6 +215,21 @@ int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const doubl
     return grid_register(s, dim, n, cw, cg, nullspace, s->asm_dt);
 }
 
+int pib_assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
+                            const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
+                            double coeff_nu, int bn_order, int nullspace)
+{
+    if (s == nullptr || n == nullptr || lo == nullptr || hi == nullptr || a0 == nullptr)
+        return fail(PIB_ERR_ARG_NULL, "pib_assemble_poisson_bn: null argument");
+    if (bn_order == 1) return pib_assemble_poisson(s, dim, n, wx, wy, wz, dt, nullspace);
+    PIB_HIP(hipSetDevice(s->device));
+    s->has_matrix = false;
+    s->has_grid = false;
+    gmg_release(s);
+    const double *w[3] = {wx, wy, wz};
+    return assemble_poisson_bn(s, dim, n, w, lo, hi, a0, dt, coeff_nu, bn_order, nullspace, nullptr, nullptr, nullptr, nullptr);
+}
+
 int pib_assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                           const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
                           double coeff_nu)

@@ -1055,7 +1055,9 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
     // every rank derives the same aggregates and ownership from the same width arrays, so neighbours agree.
     s->has_grid = true;
 
-    // verify the hint against the CSR: stencil twin vs CSR SpMV on a fixed vector
+    // verify the hint against the CSR: stencil twin vs CSR SpMV on a fixed vector (not when the structure only describes
+    // the preconditioner's operator: BN order > 1, bn.hip)
+    if (s->hint_pc_only) return 0;
     return gmg_verify(s);
 }
 

@@ -179,6 +179,7 @@ struct pib_solver {
     bool gmg_guarded = true;
     std::string gmg_error;  // why the hierarchy could not be built (reported when a multigrid solve is asked for)
     int periodic[3] = {0, 0, 0};             // pib_set_periodic: problem directions x, y[, z]
+    bool hint_pc_only = false;               // the grid structure describes the preconditioner's operator only (BN order > 1)
     std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
     double asm_dt = 0.0;
     // multi-GPU multigrid: plane ownership [b,e) of every rank on every level (the aggregates of the finer level's slab planes: gmg.hip grid_register)
@@ -246,6 +247,11 @@ void dense_release(pib_solver *s);
 int solve_direct(pib_solver *s, double *x, const double *b);
 // assemble.hip
 int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);
+// bn.hip: D * BN(order) * G through the reference's chain of sparse products; optionally hands out BNG (device arrays
+// owned by the caller)
+int assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
+                        const double mx[3], const double a0[18], double dt, double coeff_nu, int order, int nullspace,
+                        int32_t **bng_rowptr, int32_t **bng_col, double **bng_val, int64_t *bng_nnz);
 int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
                       const double mx[3], const double a0[18], double dt, double coeff_nu);
 int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rowptr,

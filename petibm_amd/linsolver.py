@@ -207,6 +207,24 @@ class LinSolverBase:
         capi.check(capi.load().pib_get_csr(self._h, C.byref(nl), C.byref(nnz), None, None, None))
         self.n_local, self.nnz = nl.value, nnz.value
 
+    def assemblePoissonBN(self, n, widths, lo, hi, a0, dt: float, coeff_nu: float, bn_order: int, nullspace: int) -> None:
+        """DBNG = D * BN(bn_order) * G assembled in HBM through the reference's chain of sparse products
+        (pib_assemble_poisson_bn); arguments as assembleVelocity."""
+        dim = len(n)
+        n3 = np.array(list(n) + [1] * (3 - dim), dtype=np.int64)
+        ws = [np.ascontiguousarray(a, dtype=np.float64) for a in widths]
+        while len(ws) < 3:
+            ws.append(None)
+        p = [a.ctypes.data if a is not None else None for a in ws]
+        lo3 = np.array(list(lo) + [0.0] * (3 - len(lo)), dtype=np.float64)
+        hi3 = np.array(list(hi) + [1.0] * (3 - len(hi)), dtype=np.float64)
+        a = np.ascontiguousarray(np.asarray(a0, dtype=np.float64).reshape(18))
+        capi.check(capi.load().pib_assemble_poisson_bn(self._h, dim, n3.ctypes.data, *p, lo3.ctypes.data, hi3.ctypes.data,
+                                                       a.ctypes.data, float(dt), float(coeff_nu), int(bn_order), int(nullspace)))
+        nl, nnz = C.c_int64(), C.c_int64()
+        capi.check(capi.load().pib_get_csr(self._h, C.byref(nl), C.byref(nnz), None, None, None))
+        self.n_local, self.nnz = nl.value, nnz.value
+
     def getCSR(self):
         nl, nnz = C.c_int64(), C.c_int64()
         lib = capi.load()

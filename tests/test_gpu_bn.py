@@ -1,0 +1,82 @@
+"""BN order N > 1 (parameters.BN of the reference): the Poisson operator D * BN * G assembled in
+HBM through the reference's chain of sparse products (createBnHead, src/operators/createbn.cpp:19-95;
+navierstokes.cpp:349-356) against the oracle's restatement of the same chain -- bit-exact -- and its solve."""
+import numpy as np
+import pytest
+
+from oracle import clib, mesh as omesh, operators as oops
+from test_gpu_parity import STRETCHED_2D, _a0_table, amgx_cfg, gmg_cfg, iters_close, rhs_for, stretched_3d
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lin():
+    from petibm_amd import linsolver
+    return linsolver
+
+
+def make(case):
+    cfg = {"2d_stretched": STRETCHED_2D, "3d_stretched": stretched_3d((8, 7, 6)),
+           "2d_periodic_y": omesh.periodic_config((10, 9), (False, True), ratios=(1.07, 1.0)),
+           "3d_periodic": omesh.periodic_config((6, 5, 7), (True, True, True))}[case]
+    m = omesh.create_mesh(cfg)
+    per = [bool(m.periodic[0][d]) for d in range(m.dim)]
+    return m, per
+
+
+@pytest.mark.parametrize("case", ["2d_stretched", "3d_stretched", "2d_periodic_y", "3d_periodic"])
+@pytest.mark.parametrize("order,pinned", [(2, False), (3, True)])
+def test_bn_poisson_operator_bit_exact(lin, case, order, pinned):
+    from petibm_amd import capi
+    m, per = make(case)
+    dt, cnu = 0.0125, 0.5 * 0.02
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, cnu, bn_order=order)
+    if pinned:
+        A = oops.pin_row0(A)
+    s = lin.LinSolverHIP("poisson", config_text=amgx_cfg())
+    s.setPeriodic(per)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    s.assemblePoissonBN(n, [m.dL[3][d].true for d in range(m.dim)], m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu,
+                        order, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+    rp, cl, vl = s.getCSR()
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(cl, A.col)
+    assert np.array_equal(vl, A.val)
+    width = np.diff(rp).max()
+    assert width > 2 * m.dim + 1  # wider than the 5/7-point stencil
+    s.destroy()
+
+
+@pytest.mark.parametrize("case,order", [("2d", 2), ("3d", 2), ("3d", 3)])
+def test_bn_poisson_solve_with_the_order1_multigrid(lin, case, order):
+    from petibm_amd import capi
+    cfg = omesh.uniform_config((48, 40)) if case == "2d" else stretched_3d((20, 18, 14))
+    m = omesh.create_mesh(cfg)
+    dt, cnu = 0.01, 0.5 * 0.01
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, cnu, bn_order=order)
+    xs, b = rhs_for(A)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    s = lin.LinSolverHIP("poisson", config_text=gmg_cfg())
+    s.assemblePoissonBN(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu, order, capi.NULLSPACE_CONSTANT)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    g = clib.GMG(n, w, dt, nullspace=1, pre=1, post=1, omega=0.9, coarsest_sweeps=32)
+    ref = g.pcg(A, b, rtol=1e-10, maxit=200)
+    assert ref["reason"] > 0 and s.getReason() > 0
+    assert iters_close(s.getIters(), ref["iters"]) and s.getIters() <= 40
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    s.destroy()
+
+
+def test_bn_order_below_one_is_the_reference_error(lin):
+    from petibm_amd import capi
+    m, per = make("2d_stretched")
+    s = lin.LinSolverHIP("poisson", config_text=amgx_cfg())
+    with pytest.raises(capi.PibError) as ei:
+        s.assemblePoissonBN([int(v) for v in m.n[3][:2]], [m.dL[3][d].true for d in range(2)], m.min[:2], m.max[:2],
+                            _a0_table(m), 0.01, 0.005, 0, capi.NULLSPACE_CONSTANT)
+    assert ei.value.code == capi.ERR_SUP  # createbn.cpp:27-29: error 56
+    s.destroy()
