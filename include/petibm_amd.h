@@ -243,6 +243,10 @@ typedef struct pib_ns pib_ns;
 int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                   const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
                   double nu, const char *velocity_cfg, const char *poisson_cfg, int device);
+/* parameters.BN of config.yaml (default 1): order of BN in the Poisson operator D*BN*G and in the projection
+ * u = u* - BN G dP (navierstokes.cpp:349-356,583-598).  Call after pib_ns_create, before the first step.  N > 1 builds
+ * the operator through pib_assemble_poisson_bn's product chain; not combined with immersed bodies (PIB_ERR_SUP). */
+int pib_ns_set_bn_order(pib_ns *ns, int order);
 int pib_ns_sizes(pib_ns *ns, int64_t *UN, int64_t *pN);
 int pib_ns_set_state(pib_ns *ns, const double *U_packed_or_null, const double *p_or_null);        /* host arrays */
 int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs2);               /* any may be NULL */

@@ -47,6 +47,7 @@ struct FlowConfig {
     double dt = 0.0;
     std::string velocitySolver, poissonSolver, forcesSolver;  // the TEXT of the solver .info files
     std::string delta = "ROMA_ET_AL_1999";      // parameters.delta (decoupledibpm.cpp:162)
+    int BN = 1;                                 // parameters.BN: order of the approximate inverse (navierstokes.cpp:348)
 };
 
 /** \brief parseSubDomains + stretchGrid (src/parser/parser.cpp:298-356, include/petibm/misc.h:148-163). */
@@ -136,6 +137,10 @@ public:
         ErrorCode ierr = pib_ns_create(&ns, dim, n, w[0].data(), w[1].data(), dim == 3 ? w[2].data() : nullptr, lo, hi, bt, bv,
                                        cfg.dt, cfg.nu, cfg.velocitySolver.c_str(), cfg.poissonSolver.c_str(), device);
         if (ierr) return ierr;
+        if (cfg.BN != 1) {
+            ierr = pib_ns_set_bn_order(ns, cfg.BN);
+            if (ierr) return ierr;
+        }
         ierr = pib_ns_sizes(ns, &UN, &pN);
         if (ierr) return ierr;
         // flow.initialVelocity: a constant per component (solutionsimple.cpp:122-226 with constant expressions)

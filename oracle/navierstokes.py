@@ -265,7 +265,8 @@ def divergence_correction(mesh: CartesianMesh, ghosts, normalize: bool = False) 
 class NavierStokes:
     """State + one-step advance, AB2 convection + CN diffusion, BN order 1."""
 
-    def __init__(self, mesh: CartesianMesh, dt: float, nu: float, pinned: bool = False, vtol=1e-14, ptol=1e-13):
+    def __init__(self, mesh: CartesianMesh, dt: float, nu: float, pinned: bool = False, vtol=1e-14, ptol=1e-13,
+                 bn_order: int = 1):
         self.mesh, self.dt, self.nu, self.pinned = mesh, dt, nu, pinned
         self.conv_c = [1.5, -0.5]
         self.diff_c = [0.5]
@@ -274,7 +275,7 @@ class NavierStokes:
         self.G = oops.create_gradient(mesh)
         self.L = oops.create_laplacian(mesh)
         self.A = oops.create_velocity_operator(self.L, dt, self.cimpl * nu)
-        self.BNG, DBNG = oops.create_poisson_operator(self.D, self.G, self.L, dt, self.cimpl * nu)
+        self.BNG, DBNG = oops.create_poisson_operator(self.D, self.G, self.L, dt, self.cimpl * nu, bn_order)
         self.DBNG = oops.pin_row0(DBNG) if pinned else DBNG
         self.ghosts = make_ghosts(mesh)
         self.U = np.zeros(mesh.UN)

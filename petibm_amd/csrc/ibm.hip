@@ -445,6 +445,7 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     using namespace pib;
     if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
+    if (ns->bn_order > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bodies: BN order > 1 with immersed bodies is not supported");
     PIB_HIP(hipSetDevice(ns->device));
     ib_release(ns->ib);
     ns->ib = nullptr;

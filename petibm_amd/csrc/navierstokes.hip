@@ -354,6 +354,22 @@ __global__ __launch_bounds__(256) void k_ns_project(NsDev D, double dt, const do
     }
 }
 
+// u = u - BNG dP with the assembled BNG (BN order > 1: bn.hip), row sums in column order ; p = p + dP
+__global__ __launch_bounds__(256) void k_ns_project_csr(int64_t UN, int64_t pN, const int32_t *__restrict__ rp,
+                                                        const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                        const double *__restrict__ dP, double *__restrict__ U, double *__restrict__ p)
+{
+    const int64_t total = UN > pN ? UN : pN;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        if (g < UN) {
+            double r = 0.0;
+            for (int32_t q = rp[g]; q < rp[g + 1]; ++q) r = r + val[q] * dP[col[q]];
+            U[g] = U[g] + (-1.0) * r;
+        }
+        if (g < pN) p[g] = p[g] + 1.0 * dP[g];
+    }
+}
+
 }  // namespace pib
 
 static int ghost_blocks(const pib::NsDev &D) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (D.nghost + 255) / 256)); }
@@ -369,6 +385,9 @@ int pib_ns_destroy(pib_ns *ns)
     if (ns->vsol) pib_destroy(ns->vsol);
     if (ns->psol) pib_destroy(ns->psol);
     for (double *q : ns->owned) (void)hipFree(q);
+    if (ns->bng_rowptr) (void)hipFree(ns->bng_rowptr);
+    if (ns->bng_col) (void)hipFree(ns->bng_col);
+    if (ns->bng_val) (void)hipFree(ns->bng_val);
     if (ns->stream) (void)hipStreamDestroy(ns->stream);
     delete ns;
     return 0;
@@ -460,6 +479,11 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     ns->pinned = (std::strcmp(tbuf, "NVIDIA AmgX") == 0) ? 1 : 0;
     if ((err = pib_assemble_poisson(ns->psol, dim, n, wx, wy, wz, dt, ns->pinned ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT)))
         return bail(err);
+    for (int d = 0; d < dim; ++d) {
+        ns->h_n[d] = n[d];
+        ns->h_w[d].assign(w[d], w[d] + n[d]);
+    }
+    std::memcpy(ns->h_a0, a0, sizeof a0);
     // device mesh arrays
     NsDev &D = ns->D;
     D.dim = dim;
@@ -527,6 +551,38 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     PIB_HIP(hipGetLastError());
     PIB_HIP(hipStreamSynchronize(ns->stream));
     *out = ns;
+    return 0;
+}
+
+/* parameters.BN (navierstokes.cpp:349-356): order N of the approximate inverse BN.  N > 1 re-assembles the Poisson
+ * operator through the product chain D * BN * G (bn.hip) and keeps the assembled BNG for the projection. */
+int pib_ns_set_bn_order(pib_ns *ns, int order)
+{
+    using namespace pib;
+    if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
+    if (order < 1) return fail(PIB_ERR_SUP, "The order of Bn can not be smaller than 1.");
+    if (ns->ib && order > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bn_order: BN order > 1 with immersed bodies is not supported");
+    if (order == ns->bn_order) return 0;
+    PIB_HIP(hipSetDevice(ns->device));
+    if (ns->bng_rowptr) (void)hipFree(ns->bng_rowptr);
+    if (ns->bng_col) (void)hipFree(ns->bng_col);
+    if (ns->bng_val) (void)hipFree(ns->bng_val);
+    ns->bng_rowptr = ns->bng_col = nullptr;
+    ns->bng_val = nullptr;
+    ns->bng_nnz = 0;
+    const int dim = ns->D.dim;
+    const double *w[3] = {ns->h_w[0].data(), ns->h_w[1].data(), dim == 3 ? ns->h_w[2].data() : nullptr};
+    const int nullspace = ns->pinned ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT;
+    if (order == 1) {
+        PIB_CHK(pib_assemble_poisson(ns->psol, dim, ns->h_n, w[0], w[1], w[2], ns->dt, nullspace));
+    } else {
+        ns->psol->has_matrix = false;
+        ns->psol->has_grid = false;
+        gmg_release(ns->psol);
+        PIB_CHK(assemble_poisson_bn(ns->psol, dim, ns->h_n, w, ns->lo, ns->hi, ns->h_a0, ns->dt, 0.5 * ns->nu, order, nullspace,
+                                    &ns->bng_rowptr, &ns->bng_col, &ns->bng_val, &ns->bng_nnz));
+    }
+    ns->bn_order = order;
     return 0;
 }
 
@@ -618,7 +674,11 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         PIB_HIP(hipGetLastError());
         PIB_HIP(hipStreamSynchronize(ns->stream));
         PIB_CHK(pib_solve(ns->psol, ns->dP, ns->rhs2));  // pSolver->solve(dP, rhs2)      (:575)
-        hipLaunchKernelGGL(k_ns_project, dim3(gt), dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
+        if (ns->bn_order > 1)
+            hipLaunchKernelGGL(k_ns_project_csr, dim3(gt), dim3(256), 0, ns->stream, D.UN, D.pN, ns->bng_rowptr, ns->bng_col,
+                               ns->bng_val, ns->dP, ns->U, ns->p);
+        else
+            hipLaunchKernelGGL(k_ns_project, dim3(gt), dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
         if (ns->ib) PIB_CHK(ib_update_forces(ns));  // f += df  (decoupledibpm.cpp:125)
         hipLaunchKernelGGL(k_ns_ghosts<2>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);  // bc->updateGhostValues (:263)
         PIB_HIP(hipGetLastError());

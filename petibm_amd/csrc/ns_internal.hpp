@@ -76,5 +76,13 @@ struct pib_ns {
     int f_iters = 0;
     double f_res = 0;
     int periodic[3] = {0, 0, 0};
+    // parameters.BN > 1 (pib_ns_set_bn_order): the projection multiplies by the assembled BNG
+    int bn_order = 1;
+    int32_t *bng_rowptr = nullptr, *bng_col = nullptr;
+    double *bng_val = nullptr;
+    int64_t bng_nnz = 0;
+    int64_t h_n[3] = {1, 1, 1};
+    std::vector<double> h_w[3];
+    double h_a0[18] = {0};
 };
 

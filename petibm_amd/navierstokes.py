@@ -87,6 +87,9 @@ class NavierStokesSolver:
         capi.check(capi.load().pib_ns_create(C.byref(self._h), self.dim, n3.ctypes.data, wp[0], wp[1], wp[2],
                                              lo3.ctypes.data, hi3.ctypes.data, bc_t.ctypes.data, bc_v.ctypes.data,
                                              self.dt, self.nu, velocity_cfg.encode(), poisson_cfg.encode(), device))
+        self.bn_order = int(par.get("BN", 1))  # parameters.BN (parser: default 1)
+        if self.bn_order != 1:
+            capi.check(capi.load().pib_ns_set_bn_order(self._h, self.bn_order))
         un, pn = C.c_int64(), C.c_int64()
         capi.check(capi.load().pib_ns_sizes(self._h, C.byref(un), C.byref(pn)))
         self.UN, self.pN = un.value, pn.value

@@ -80,3 +80,36 @@ def test_bn_order_below_one_is_the_reference_error(lin):
                             _a0_table(m), 0.01, 0.005, 0, capi.NULLSPACE_CONSTANT)
     assert ei.value.code == capi.ERR_SUP  # createbn.cpp:27-29: error 56
     s.destroy()
+
+
+@pytest.mark.parametrize("case,order", [("2d_cavity", 2), ("3d_periodic_xz", 2), ("2d_cavity", 3)])
+def test_time_step_with_bn_order_matches_oracle(case, order):
+    """parameters.BN > 1 in the flow solver: the Poisson operator D*BN*G and the projection u = u* - BN G dP
+    (navierstokes.cpp:349-356,583-598)."""
+    from oracle import navierstokes as ons
+    from petibm_amd.navierstokes import NavierStokesSolver
+    from test_gpu_periodic import VEL, KSP_P
+    if case == "2d_cavity":
+        cfg = omesh.uniform_config((14, 12), lid=1.0)
+    else:
+        cfg = omesh.periodic_config((8, 7, 6), (True, False, True))
+    cfg["flow"]["nu"] = 0.02
+    cfg["parameters"] = {"dt": 0.005, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON", "BN": order}
+    m = omesh.create_mesh(cfg)
+    ref = ons.NavierStokes(m, 0.005, 0.02, vtol=1e-14, ptol=1e-13, bn_order=order)
+    rng = np.random.default_rng(5)
+    U0, p0 = 0.1 * rng.uniform(-1, 1, m.UN), 0.1 * rng.uniform(-1, 1, m.pN)
+    ref.set_state(U0, p0)
+    s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=KSP_P)
+    assert s.bn_order == order
+    s.setState(U0, p0)
+    for step in range(3):
+        ref.advance()
+        s.advance()
+        U, p, r1, r2 = s.getState(rhs=True)
+        assert np.abs(r1 - ref.last_rhs1).max() <= 1e-9 * np.abs(ref.last_rhs1).max()
+        assert np.abs(r2 - ref.last_rhs2).max() <= 1e-9 * np.abs(ref.last_rhs2).max() + 1e-14
+        assert np.abs(U - ref.U).max() <= 1e-9 * np.abs(ref.U).max()
+        dp = (p - p.mean()) - (ref.p - ref.p.mean())
+        assert np.abs(dp).max() <= 1e-8 * np.abs(ref.p - ref.p.mean()).max()
+    s.destroy()
