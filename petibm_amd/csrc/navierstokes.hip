@@ -162,43 +162,190 @@ __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__res
     *lcn = corrn;
 }
 
-// rhs1 and the new convective term (navierstokes.cpp:432-521), one velocity point per lane
+// rhs1 and the new convective term (navierstokes.cpp:432-521) at one velocity point, general form (ghost values, ghost
+// equations, periodic wraps)
+__device__ __forceinline__ void rhs_velocity_point(const NsDev &D, double dt, double nu, double c0, double c1, double d0,
+                                                   double cimpl, const double *__restrict__ U, const double *__restrict__ p,
+                                                   const double *__restrict__ conv1, double *__restrict__ conv0,
+                                                   double *__restrict__ rhs1, double *__restrict__ diff0, int f, int64_t i,
+                                                   int64_t j, int64_t k)
+{
+    const NsField &F = D.f[f];
+    const int64_t g = fidx(F, i, j, k);
+    // G p: row {-1/dL at the cell, +1/dL at the + neighbour}, dL = dL[f][f][idx]
+    const int64_t ijk[3] = {i, j, k};
+    const double gv = 1.0 / F.dl[f][ijk[f] + 1];
+    const int64_t pst[3] = {1, D.pn[0], D.pn[0] * D.pn[1]};
+    const int64_t pc = i + D.pn[0] * (j + D.pn[1] * k);
+    double r;
+    if (ijk[f] < D.pn[f] - 1) {
+        r = 0.0 + (-gv) * p[pc];
+        r = r + gv * p[pc + pst[f]];
+    } else {  // last point of a periodic direction: the + neighbour is cell 0, the smaller column of G's row
+        r = 0.0 + gv * p[pc - (D.pn[f] - 1) * pst[f]];
+        r = r + (-gv) * p[pc];
+    }
+    r = -1.0 * r;
+    r = r + (1.0 / dt) * U[g];
+    const double cn = -1.0 * convection_at(D, U, f, i, j, k);
+    conv0[g] = cn;
+    r = r + c0 * cn;
+    r = r + c1 * conv1[g];
+    // explicit diffusion with the ghost equations of the previous step, implicit correction with the updated
+    // ones (bc->updateEqs sits between the two, navierstokes.cpp:492-514)
+    double lu, lc, lcn;
+    laplacian_at(D, U, f, i, j, k, &lu, &lc, &lcn);
+    double df = lu + lc;
+    df = nu * df;
+    diff0[g] = df;
+    r = r + d0 * df;
+    const double b1 = nu * lcn;
+    r = r + cimpl * b1;
+    rhs1[g] = r;
+}
+
+// The outermost layer of a component (any index 0 or n-1: ghost values, ghost equations or periodic wraps in the
+// stencil), one point per lane in a dense enumeration -- x faces, then y faces without the x faces, then z faces without
+// both; `all` != 0: every point (a component with fewer than three points in some direction has no interior).
+__global__ __launch_bounds__(256) void k_ns_rhs_velocity_shell(NsDev D, int f, int all, double dt, double nu, double c0, double c1,
+                                                               double d0, double cimpl, const double *__restrict__ U,
+                                                               const double *__restrict__ p, const double *__restrict__ conv1,
+                                                               double *__restrict__ conv0, double *__restrict__ rhs1,
+                                                               double *__restrict__ diff0)
+{
+    const NsField &F = D.f[f];
+    const int64_t nx = F.n[0], ny = F.n[1], nz = F.n[2];
+    const bool three = D.dim == 3;
+    const int64_t cx = 2 * ny * nz, cy = 2 * (nx - 2) * nz, cz = three ? 2 * (nx - 2) * (ny - 2) : 0;
+    const int64_t total = all ? nx * ny * nz : cx + cy + cz;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        int64_t i, j, k;
+        if (all) {
+            i = t % nx;
+            j = (t / nx) % ny;
+            k = t / (nx * ny);
+        } else if (t < cx) {
+            i = (t & 1) ? nx - 1 : 0;
+            j = (t >> 1) % ny;
+            k = (t >> 1) / ny;
+        } else if (t < cx + cy) {
+            const int64_t q = t - cx;
+            j = (q & 1) ? ny - 1 : 0;
+            i = 1 + (q >> 1) % (nx - 2);
+            k = (q >> 1) / (nx - 2);
+        } else {
+            const int64_t q = t - cx - cy;
+            k = (q & 1) ? nz - 1 : 0;
+            i = 1 + (q >> 1) % (nx - 2);
+            j = 1 + (q >> 1) / (nx - 2);
+        }
+        rhs_velocity_point(D, dt, nu, c0, c1, d0, cimpl, U, p, conv1, conv0, rhs1, diff0, f, i, j, k);
+    }
+}
+
+// The interior of component F (every index in [1, n-2]: no ghost value, no ghost equation, no periodic wrap in the
+// stencil): grid (x chunks, j-1, k-1), so j and k are workgroup-uniform (their mesh coefficients come through the scalar
+// path, no per-point division) and a lane walks i; branch-free, direct loads, the operations of rhs_velocity_point in
+// the same order (bit-identical results; the boundary terms are exact zeros here).  The generic one-lane-per-point form
+// spent 4.8 ms per step on the 256^3 Taylor-Green case (5.0e7 points: 64-bit div/mod, twenty branchy vel() calls and
+// scratch-resident index arrays per point); mixing the two forms in one kernel left half of the waves paying for both.
+template <int DIM, int F>
 __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, double nu, double c0, double c1, double d0,
                                                          double cimpl, const double *__restrict__ U,
                                                          const double *__restrict__ p, const double *__restrict__ conv1,
                                                          double *__restrict__ conv0, double *__restrict__ rhs1,
                                                          double *__restrict__ diff0)
 {
-    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < D.UN; g += (int64_t)gridDim.x * 256) {
-        int f = 0;
-        if (D.dim > 1 && g >= D.f[1].off) f = 1;
-        if (D.dim > 2 && g >= D.f[2].off) f = 2;
-        const NsField &F = D.f[f];
-        const int64_t q = g - F.off;
-        const int64_t i = q % F.n[0], j = (q / F.n[0]) % F.n[1], k = q / (F.n[0] * F.n[1]);
-        // G p: row {-1/dL at the cell, +1/dL at the + neighbour}, dL = dL[f][f][idx]
-        const int64_t ijk[3] = {i, j, k};
-        const double gv = 1.0 / F.dl[f][ijk[f] + 1];
-        const int64_t pst[3] = {1, D.pn[0], D.pn[0] * D.pn[1]};
-        const int64_t pc = i + D.pn[0] * (j + D.pn[1] * k);
-        double r;
-        if (ijk[f] < D.pn[f] - 1) {
-            r = 0.0 + (-gv) * p[pc];
-            r = r + gv * p[pc + pst[f]];
-        } else {  // last point of a periodic direction: the + neighbour is cell 0, the smaller column of G's row
-            r = 0.0 + gv * p[pc - (D.pn[f] - 1) * pst[f]];
-            r = r + (-gv) * p[pc];
-        }
+    const NsField &Fd = D.f[F];
+    const int nx = (int)Fd.n[0];
+    const int j = blockIdx.y + 1, k = (DIM == 3) ? blockIdx.z + 1 : 0;
+    // bases of every component at (0, j, k) and their strides
+    int64_t b[DIM], sy[DIM], sz[DIM];
+#pragma unroll
+    for (int ff = 0; ff < DIM; ++ff) {
+        sy[ff] = D.f[ff].n[0];
+        sz[ff] = sy[ff] * D.f[ff].n[1];
+        b[ff] = D.f[ff].off + sy[ff] * j + sz[ff] * k;
+    }
+    const int64_t pbase = D.pn[0] * (j + D.pn[1] * (int64_t)k);
+    const int64_t pstF = (F == 0) ? 1 : (F == 1 ? D.pn[0] : D.pn[0] * D.pn[1]);
+    const double dLy = Fd.dl[1][j + 1];
+    const double dLz = (DIM == 3) ? Fd.dl[2][k + 1] : 1.0;
+    // Laplacian coefficients of the y and z directions (createlaplacian.cpp:134-148), from the tables
+    const double yNeg = Fd.lneg[1][j], yPos = Fd.lpos[1][j];
+    const double zNeg = (DIM == 3) ? Fd.lneg[2][k] : 0.0, zPos = (DIM == 3) ? Fd.lpos[2][k] : 0.0;
+    const double gvyz = (F == 1) ? Fd.ginv[j] : ((F == 2) ? Fd.ginv[k] : 0.0);
+#define PIB_V(ff, di, dj, dk) U[b[ff] + i + (di) + (dj) * sy[ff] + (dk) * sz[ff]]
+    for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i < nx - 1; i += gridDim.x * 256) {
+        const int64_t g = b[F] + i;
+        const double dLx = Fd.dl[0][i + 1];
+        // ---- G p
+        const double gv = (F == 0) ? Fd.ginv[i] : gvyz;
+        const int64_t pc = pbase + i;
+        double r = 0.0 + (-gv) * p[pc];
+        r = r + gv * p[pc + pstF];
         r = -1.0 * r;
-        r = r + (1.0 / dt) * U[g];
-        const double cn = -1.0 * convection_at(D, U, f, i, j, k);
+        const double self = U[g];
+        r = r + (1.0 / dt) * self;
+        // ---- N(u)  (createconvection.cpp:40-195)
+        const double W = (self + PIB_V(F, -1, 0, 0)) / 2.0, E = (self + PIB_V(F, 1, 0, 0)) / 2.0;
+        const double S = (self + PIB_V(F, 0, -1, 0)) / 2.0, N = (self + PIB_V(F, 0, 1, 0)) / 2.0;
+        double B = 0.0, Fw = 0.0;
+        if (DIM == 3) {
+            B = (self + PIB_V(F, 0, 0, -1)) / 2.0;
+            Fw = (self + PIB_V(F, 0, 0, 1)) / 2.0;
+        }
+        double cv;
+        if (F == 0) {
+            const double vS = (PIB_V(1, 0, -1, 0) + PIB_V(1, 1, -1, 0)) / 2.0;
+            const double vN = (PIB_V(1, 0, 0, 0) + PIB_V(1, 1, 0, 0)) / 2.0;
+            cv = (E * E - W * W) / dLx + (vN * N - vS * S) / dLy;
+            if (DIM == 3) {
+                const double wB = (PIB_V(DIM - 1, 0, 0, -1) + PIB_V(DIM - 1, 1, 0, -1)) / 2.0;
+                const double wF = (PIB_V(DIM - 1, 0, 0, 0) + PIB_V(DIM - 1, 1, 0, 0)) / 2.0;
+                cv = cv + (wF * Fw - wB * B) / dLz;
+            }
+        } else if (F == 1) {
+            const double uW = (PIB_V(0, -1, 0, 0) + PIB_V(0, -1, 1, 0)) / 2.0;
+            const double uE = (PIB_V(0, 0, 0, 0) + PIB_V(0, 0, 1, 0)) / 2.0;
+            cv = (uE * E - uW * W) / dLx + (N * N - S * S) / dLy;
+            if (DIM == 3) {
+                const double wB = (PIB_V(DIM - 1, 0, 0, -1) + PIB_V(DIM - 1, 0, 1, -1)) / 2.0;
+                const double wF = (PIB_V(DIM - 1, 0, 0, 0) + PIB_V(DIM - 1, 0, 1, 0)) / 2.0;
+                cv = cv + (wF * Fw - wB * B) / dLz;
+            }
+        } else {
+            const double uW = (PIB_V(0, -1, 0, 0) + PIB_V(0, -1, 0, 1)) / 2.0;
+            const double uE = (PIB_V(0, 0, 0, 0) + PIB_V(0, 0, 0, 1)) / 2.0;
+            const double vS = (PIB_V(1, 0, -1, 0) + PIB_V(1, 0, -1, 1)) / 2.0;
+            const double vN = (PIB_V(1, 0, 0, 0) + PIB_V(1, 0, 0, 1)) / 2.0;
+            cv = (uE * E - uW * W) / dLx + (vN * N - vS * S) / dLy + (Fw * Fw - B * B) / dLz;
+        }
+        const double cn = -1.0 * cv;
         conv0[g] = cn;
         r = r + c0 * cn;
         r = r + c1 * conv1[g];
-        // explicit diffusion with the ghost equations of the previous step, implicit correction with the updated
-        // ones (bc->updateEqs sits between the two, navierstokes.cpp:492-514)
-        double lu, lc, lcn;
-        laplacian_at(D, U, f, i, j, k, &lu, &lc, &lcn);
+        // ---- L u in the row's column order z-, y-, x-, diag, x+, y+, z+ ; no ghost point: the corrections are zero
+        const double xNeg = Fd.lneg[0][i], xPos = Fd.lpos[0][i];
+        double acc = 0.0;
+        acc = acc + xNeg;
+        acc = acc + xPos;
+        acc = acc + yNeg;
+        acc = acc + yPos;
+        if (DIM == 3) {
+            acc = acc + zNeg;
+            acc = acc + zPos;
+        }
+        const double diag = -acc;
+        double lu = 0.0;
+        if (DIM == 3) lu = lu + zNeg * PIB_V(F, 0, 0, -1);
+        lu = lu + yNeg * PIB_V(F, 0, -1, 0);
+        lu = lu + xNeg * PIB_V(F, -1, 0, 0);
+        lu = lu + diag * self;
+        lu = lu + xPos * PIB_V(F, 1, 0, 0);
+        lu = lu + yPos * PIB_V(F, 0, 1, 0);
+        if (DIM == 3) lu = lu + zPos * PIB_V(F, 0, 0, 1);
+        const double lc = 0.0, lcn = 0.0;
         double df = lu + lc;
         df = nu * df;
         diff0[g] = df;
@@ -207,6 +354,7 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         r = r + cimpl * b1;
         rhs1[g] = r;
     }
+#undef PIB_V
 }
 
 // rhs2 = D u + Dbc (navierstokes.cpp:540-563); D row in packed-column order u(i-1), u(i), v(j-1), v(j), w(k-1), w(k)
@@ -494,6 +642,8 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
         for (int d = 0; d < 3; ++d) {
             F.n[d] = fn[f][d];
             F.dl[d] = F.co[d] = nullptr;
+            F.lneg[d] = F.lpos[d] = nullptr;
+            if (d == 0) F.ginv = nullptr;
             if (f < dim && d < dim) {
                 double *p1 = nullptr, *p2 = nullptr;
                 if ((err = upload_vec(hdl[f][d], &p1)) || (err = upload_vec(hco[f][d], &p2))) return bail(err);
@@ -501,6 +651,30 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
                 ns->owned.push_back(p2);
                 F.dl[d] = p1;
                 F.co[d] = p2;
+                // quotient tables: the expressions of laplacian_at / the gradient row, evaluated once (IEEE division
+                // and multiplication round identically on the host)
+                const int64_t nfd = fn[f][d];
+                std::vector<double> tn((size_t)nfd), tp((size_t)nfd), tg((size_t)nfd);
+                for (int64_t q = 0; q < nfd; ++q) {
+                    const double dLSelf = hdl[f][d][(size_t)q + 1];
+                    const double dLNeg = hco[f][d][(size_t)q + 1] - hco[f][d][(size_t)q];
+                    const double dLPos = hco[f][d][(size_t)q + 2] - hco[f][d][(size_t)q + 1];
+                    tn[(size_t)q] = 1.0 / (dLNeg * dLSelf);
+                    tp[(size_t)q] = 1.0 / (dLPos * dLSelf);
+                    tg[(size_t)q] = 1.0 / dLSelf;
+                }
+                double *p3 = nullptr, *p4 = nullptr;
+                if ((err = upload_vec(tn, &p3)) || (err = upload_vec(tp, &p4))) return bail(err);
+                ns->owned.push_back(p3);
+                ns->owned.push_back(p4);
+                F.lneg[d] = p3;
+                F.lpos[d] = p4;
+                if (d == f) {
+                    double *p5 = nullptr;
+                    if ((err = upload_vec(tg, &p5))) return bail(err);
+                    ns->owned.push_back(p5);
+                    F.ginv = p5;
+                }
             }
         }
         F.off = off;
@@ -662,8 +836,32 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         std::swap(ns->conv[0], ns->conv[1]);
         // bc->updateEqs(solution, dt) (:508) into a1n; the right-hand side needs both generations
         hipLaunchKernelGGL(k_ns_ghosts<1>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);
-        hipLaunchKernelGGL(k_ns_rhs_velocity, dim3(gu), dim3(256), 0, ns->stream, D, ns->dt, ns->nu, 1.5, -0.5, 0.5, 0.5, ns->U,
-                           ns->p, ns->conv[1], ns->conv[0], ns->rhs1, ns->diff0);
+#define PIB_RHS(DIM_, F_)                                                                                                   \
+    {                                                                                                                       \
+        const NsField &Fq = D.f[F_];                                                                                        \
+        const bool inner = Fq.n[0] >= 3 && Fq.n[1] >= 3 && (DIM_ == 2 || Fq.n[2] >= 3);                                     \
+        if (inner)                                                                                                          \
+            hipLaunchKernelGGL((k_ns_rhs_velocity<DIM_, F_>),                                                               \
+                               dim3((unsigned)((Fq.n[0] - 2 + 255) / 256), (unsigned)(Fq.n[1] - 2),                           \
+                                    (unsigned)(DIM_ == 3 ? Fq.n[2] - 2 : 1)),                                                 \
+                               dim3(256), 0, ns->stream, D, ns->dt, ns->nu, 1.5, -0.5, 0.5, 0.5, ns->U, ns->p, ns->conv[1],  \
+                               ns->conv[0], ns->rhs1, ns->diff0);                                                           \
+        const int64_t shell = inner ? 2 * (Fq.n[1] * Fq.n[2] + (Fq.n[0] - 2) * Fq.n[2] +                                    \
+                                           (DIM_ == 3 ? (Fq.n[0] - 2) * (Fq.n[1] - 2) : 0))                                 \
+                                    : Fq.n[0] * Fq.n[1] * Fq.n[2];                                                          \
+        hipLaunchKernelGGL(k_ns_rhs_velocity_shell, dim3((unsigned)std::min<int64_t>(4096, (shell + 255) / 256)), dim3(256), 0, \
+                           ns->stream, D, F_, inner ? 0 : 1, ns->dt, ns->nu, 1.5, -0.5, 0.5, 0.5, ns->U, ns->p, ns->conv[1],   \
+                           ns->conv[0], ns->rhs1, ns->diff0);                                                               \
+    }
+        if (D.dim == 2) {
+            PIB_RHS(2, 0)
+            PIB_RHS(2, 1)
+        } else {
+            PIB_RHS(3, 0)
+            PIB_RHS(3, 1)
+            PIB_RHS(3, 2)
+        }
+#undef PIB_RHS
         PIB_HIP(hipGetLastError());
         std::swap(D.a1, D.a1n);
         if (ns->ib) PIB_CHK(ib_spread_forces(ns));  // rhs1 += H f  (decoupledibpm.cpp:243)

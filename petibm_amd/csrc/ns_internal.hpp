@@ -12,6 +12,10 @@ struct NsField {
     int64_t off;            // first entry of the field's block in the packed vector
     const double *dl[3];    // dL[f][d], index s+1
     const double *co[3];    // coord[f][d], index s+1
+    // per-direction tables of the point-wise quotients (same expressions as the kernels evaluate, hoisted: an fp64
+    // division costs ~40 instructions): Laplacian coefficients 1/((co[s]-co[s-1])*dl[s]), 1/((co[s+1]-co[s])*dl[s])
+    // (createlaplacian.cpp:134-148) and, along the component's own direction, the gradient entry 1/dl[s]; index s
+    const double *lneg[3], *lpos[3], *ginv;
     // ghost points per boundary location: ghost = a0*target + a1 (a0 is uniform over a face); face arrays are
     // indexed a + na*b over the two perpendicular axes in natural order (misc.cpp:154-196)
     double a0[6];
