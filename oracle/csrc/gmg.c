@@ -48,7 +48,9 @@ typedef struct {
     i64 N;
     double *w[3]; /* widths, n[d] */
     double *g[3]; /* face factors incl. dt, n[d]-1 (+ the wrap face n[d]-1 <-> 0 at index n[d]-1 when periodic) */
-    int per[3];   /* periodic direction: the level operator wraps (transfers treat the seam like a wall) */
+    int per[3];   /* periodic direction: the level operator wraps */
+    int tper[3];  /* ... and so do the transfers TOWARDS THE NEXT COARSER level (needs >= 4 cells: the four fine cells a
+                     coarse cell gathers from must be distinct) */
     double *x, *x2, *b, *r;
     /* transfer tables towards the next coarser level, per direction (NULL on the coarsest level) */
     int32_t *par[3], *oth[3]; /* [n[d]] parent / other coarse index of fine cell s (oth == par: none) */
@@ -145,8 +147,9 @@ void *orc_gmg_create(int dim, const i64 *n_in, const double *wx, const double *w
 }
 
 /* periodic[d] (problem directions x, y[, z]): the level operators get the wrap face n-1 <-> 0, rediscretised on every
- * level like the interior faces (a direction coarsened down to ONE cell has no face left); coarsening and the transfer
- * tables are unchanged, i.e. the interpolation treats the seam like a wall. */
+ * level like the interior faces (a direction coarsened down to ONE cell has no face left); the aggregates are unchanged
+ * (pairs never straddle the seam) and the interpolation / restriction reach across the seam while the level has >= 4
+ * cells in that direction. */
 void *orc_gmg_create_periodic(int dim, const i64 *n_in, const double *wx, const double *wy, const double *wz, double dt,
                               int nullspace, int pre, int post, double omega, int coarsest_sweeps, int max_levels,
                               const int *periodic)
@@ -189,6 +192,7 @@ void *orc_gmg_create_periodic(int dim, const i64 *n_in, const double *wx, const 
             const double target = 1.5 * G->hmin * ldexp(1.0, nl + G->target_shift);
             for (int d = 0; d < 3; ++d) {
                 const i64 n = l->n[d];
+                l->tper[d] = l->per[d] && n >= 4;
                 free(l->par[d]); free(l->oth[d]); free(l->wpar[d]); free(l->woth[d]); free(l->fst[d]); free(c->w[d]);
                 l->par[d] = malloc(sizeof(int32_t) * (size_t)n);
                 l->oth[d] = malloc(sizeof(int32_t) * (size_t)n);
@@ -221,6 +225,7 @@ void *orc_gmg_create_periodic(int dim, const i64 *n_in, const double *wx, const 
                     if (f1 - f0 == 2) {
                         const int left = (s == f0);
                         O = left ? P - 1 : P + 1;
+                        if (l->tper[d]) O = (O + I) % I; /* across the periodic seam */
                         if (O < 0 || O >= I) O = P;
                         else {
                             const double sib = left ? l->w[d][s + 1] : l->w[d][s - 1];
@@ -340,15 +345,21 @@ static void restrict_t(const level_t *f, const level_t *c, const double *rf, dou
                 const i64 k0 = f->fst[2][K] - 1, k1 = f->fst[2][K + 1];
                 const i64 j0 = f->fst[1][J] - 1, j1 = f->fst[1][J + 1];
                 const i64 i0 = f->fst[0][I] - 1, i1 = f->fst[0][I + 1];
-                for (i64 k = k0; k <= k1; ++k) {
+                for (i64 kr = k0; kr <= k1; ++kr) {
+                    i64 k = kr;
+                    if (f->tper[2]) k = (kr + f->n[2]) % f->n[2];
                     if (k < 0 || k >= f->n[2]) continue;
                     const double wz = rw(f, 2, k, K);
                     if (wz == 0.0) continue;
-                    for (i64 j = j0; j <= j1; ++j) {
+                    for (i64 jr = j0; jr <= j1; ++jr) {
+                        i64 j = jr;
+                        if (f->tper[1]) j = (jr + f->n[1]) % f->n[1];
                         if (j < 0 || j >= f->n[1]) continue;
                         const double wy = rw(f, 1, j, J);
                         if (wy == 0.0) continue;
-                        for (i64 i = i0; i <= i1; ++i) {
+                        for (i64 ir = i0; ir <= i1; ++ir) {
+                            i64 i = ir;
+                            if (f->tper[0]) i = (ir + f->n[0]) % f->n[0];
                             if (i < 0 || i >= f->n[0]) continue;
                             const double wx = rw(f, 0, i, I);
                             if (wx == 0.0) continue;

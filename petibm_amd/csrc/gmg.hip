@@ -48,6 +48,7 @@ struct LevelDev {
     int nx, ny, nzg;  // global cells (each < 2^31; the local cell count fits int32 like the CSR columns)
     int k0, nk;       // owned planes [k0, k0+nk)
     int per;          // bit 0/1/2: x/y/z periodic (the operator wraps: g[n-1] couples cell n-1 and cell 0)
+    int tper;         // ... and the transfers towards the next coarser level reach across the seam
     const double *wx, *wy, *wz, *gx, *gy, *gz;
     Tr1 t[3];         // x, y, z tables (null on the coarsest level)
     TrX tx;
@@ -328,6 +329,8 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
     const int Iraw = blockIdx.y * ROW_LANES + lane - 1;
     const bool valid = lane >= 1 && lane <= ROW_LANES && Iraw < C.nx;
     const int I = min(max(Iraw, 0), C.nx - 1);
+    // the coarse cell whose value this lane holds: across the periodic seam for the two lanes next to the row's ends
+    const int Iload = (F.tper & 1) ? (Iraw < 0 ? C.nx - 1 : (Iraw >= C.nx ? min(Iraw - C.nx, C.nx - 1) : Iraw)) : I;
     const int2 fc = F.tx.fc[I];
     const double4 pw = F.tx.pw[I];
     const int64_t cplane = (int64_t)C.nx * C.ny, fplane = (int64_t)F.nx * F.ny;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
             for (int b2 = 0; b2 < 2; ++b2) {
                 const double *rowp = xc + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0);
                 w4[r][c2 * 2 + b2] = wk[c2] * wj[b2];
-                vP[r][c2 * 2 + b2] = rowp[I];
+                vP[r][c2 * 2 + b2] = rowp[Iload];
             }
         off[r] = (int64_t)kk * fplane + (int64_t)j * F.nx + fc.x;
         d0[r] = d1[r] = 0.0;
@@ -392,12 +395,13 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
 // neighbour, the one or two children, the right neighbour) with the weight that cell gives to I (0 where there
 // is no such fine cell or it does not feed I).  Indices are clamped so the loads are always legal; a zero
 // weight adds exactly 0.
-__device__ __forceinline__ void rs1d4(const Tr1 &t, int I, int nf, double w[4], int f[4])
+__device__ __forceinline__ void rs1d4(const Tr1 &t, int I, int nf, bool wrap, double w[4], int f[4])
 {
     const int f0 = t.fst[I] - 1;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-        const int ff = f0 + o;
+        int ff = f0 + o;
+        if (wrap) ff = ff < 0 ? ff + nf : (ff >= nf ? ff - nf : ff);  // across the periodic seam
         double wt = 0.0;
         if (ff >= 0 && ff < nf) {
             if (t.par[ff] == I)
@@ -421,8 +425,8 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
     const int KK = row / C.ny, J = row - KK * C.ny, K = C.k0 + KK;
     double wk[4], wj[4];
     int sk[4], sj[4];
-    rs1d4(F.t[2], K, F.nzg, wk, sk);
-    rs1d4(F.t[1], J, F.ny, wj, sj);
+    rs1d4(F.t[2], K, F.nzg, F.tper & 4, wk, sk);
+    rs1d4(F.t[1], J, F.ny, F.tper & 2, wj, sj);
     const int lane = threadIdx.x;
     const int Iraw = blockIdx.y * 64 + lane;
     const bool valid = Iraw < C.nx;
@@ -431,7 +435,9 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
     const double4 rw = F.tx.rw[I];
     const bool pair = (fc.y == 2);
     const int f0 = fc.x, f1 = pair ? f0 + 1 : f0;
-    const bool edgeL = (lane == 0 && I > 0), edgeR = (lane == 63 && I + 1 < C.nx);
+    const bool wrapx = F.tper & 1;
+    const bool edgeL = (lane == 0 && (I > 0 || wrapx)), edgeR = (lane == 63 && I + 1 < C.nx) || (wrapx && Iraw == C.nx - 1);
+    const int fL = (f0 > 0) ? f0 - 1 : F.nx - 1, fR = (f1 + 1 < F.nx) ? f1 + 1 : 0;  // wrapped only when wrapx (else unused)
     const int64_t fplane = (int64_t)F.nx * F.ny;
     double s = 0.0;
     // all sixteen row loads are issued before the first use (no branch on the wave-uniform zero weights: a zero
@@ -464,8 +470,8 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
             const double wzy = wk[c] * wj[b2];
             const double *pj = pk + (int64_t)F.nx * sj[b2];
             double vl = __shfl_up(c1[c][b2], 1, 64), vr = __shfl_down(c0[c][b2], 1, 64);
-            if (edgeL) vl = pj[f0 - 1];
-            if (edgeR) vr = pj[f1 + 1];
+            if (edgeL) vl = pj[fL];
+            if (edgeR) vr = pj[fR];
             s += (wzy * rw.x) * vl;
             s += (wzy * rw.y) * c0[c][b2];
             s += (wzy * rw.z) * c1[c][b2];
@@ -580,9 +586,9 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
             const int I = q % C.nx, J = (q / C.nx) % C.ny, K = C.k0 + q / cplane;
             double wi[4], wj[4], wk[4];
             int si[4], sj[4], sk[4];
-            rs1d4(F.t[0], I, F.nx, wi, si);
-            rs1d4(F.t[1], J, F.ny, wj, sj);
-            rs1d4(F.t[2], K, F.nzg, wk, sk);
+            rs1d4(F.t[0], I, F.nx, F.tper & 1, wi, si);
+            rs1d4(F.t[1], J, F.ny, F.tper & 2, wj, sj);
+            rs1d4(F.t[2], K, F.nzg, F.tper & 4, wk, sk);
             double sum = 0.0;
             for (int c2 = 0; c2 < 4; ++c2) {
                 if (wk[c2] == 0.0) continue;
@@ -656,6 +662,7 @@ static LevelDev dev_of(const GridLevel &g)
     L.k0 = (int)g.k0;
     L.nk = (int)(g.k1 - g.k0);
     L.per = g.per;
+    L.tper = g.tper;
     L.wx = g.w[0];
     L.wy = g.w[1];
     L.wz = g.w[2];
@@ -937,12 +944,14 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
         std::vector<int32_t> par[3], oth[3], fst[3];
         std::vector<double> wpar[3], woth[3], cw[3];
         int64_t nc[3] = {nn[0], nn[1], nn[2]};
+        bool twrap[3] = {false, false, false};
         bool merged_any = false;
         const auto &of = s->gmg_own.back();
         for (int tries = 0; !last && tries < 64 && !merged_any; ++tries, ++target_shift) {
             const double target = 1.5 * hmin * std::ldexp(1.0, l + 1 + target_shift);
             for (int d = 0; d < 3; ++d) {
                 const int64_t n = nn[d];
+                twrap[d] = pern[d] && n >= 4;  // the four fine cells a coarse cell gathers from must be distinct
                 par[d].assign((size_t)n, 0);
                 oth[d].assign((size_t)n, 0);
                 wpar[d].assign((size_t)n, 1.0);
@@ -976,6 +985,7 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
                     if (f1 - f0 == 2) {
                         const bool left = (q == f0);
                         O = left ? Pq - 1 : Pq + 1;
+                        if (twrap[d]) O = (O + I) % I;  // across the periodic seam
                         if (O < 0 || O >= I)
                             O = Pq;
                         else {
@@ -994,6 +1004,8 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
             break;
         }
         target_shift--;  // the loop's ++ after the successful try
+        for (int d = 0; d < 3; ++d)
+            if (twrap[d]) G.tper |= 1 << d;
         for (int d = 0; d < 3; ++d) {
             PIB_CHK(up(par[d], &G.t_par[d]));
             PIB_CHK(up(oth[d], &G.t_oth[d]));
@@ -1007,7 +1019,11 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
             std::vector<double4> pw((size_t)nc[0]), rw((size_t)nc[0]);
             for (int64_t I = 0; I < nc[0]; ++I) {
                 const int f0 = fst[0][(size_t)I], cnt = fst[0][(size_t)I + 1] - f0;
-                const int fl = f0 - 1, fr = f0 + cnt;
+                int fl = f0 - 1, fr = f0 + cnt;
+                if (twrap[0]) {
+                    if (fl < 0) fl = (int)nn[0] - 1;
+                    if (fr >= nn[0]) fr = 0;
+                }
                 fc[(size_t)I] = make_int2(f0, cnt);
                 pw[(size_t)I] = make_double4(wpar[0][(size_t)f0], woth[0][(size_t)f0], cnt == 2 ? wpar[0][(size_t)f0 + 1] : 0.0,
                                              cnt == 2 ? woth[0][(size_t)f0 + 1] : 0.0);

@@ -151,6 +151,7 @@ struct GridLevel {
     bool replicated = false;  // multi-GPU: every rank holds the whole level
     int64_t nloc = 0, plane = 0;
     int per = 0;  // bit d: direction d (internal order) is periodic and has > 1 cell: the level operator wraps
+    int tper = 0; // bit d: ... and so do the transfers towards the next coarser level (>= 4 cells)
 };
 
 struct LoopbackGroup;  // halo.hip: test-only transport (ranks = threads of one process on one GPU)
