@@ -149,7 +149,8 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
  * pib_assemble_poisson / pib_assemble_velocity / pib_set_grid_hint: the assembled operators then carry the wrapped
  * columns (component d has n[d] points along a periodic d instead of n[d]-1, cartesianmesh.cpp:259-266) and the grid
  * hint takes one more face factor per periodic direction, g[d][n[d]-1] = dt / (0.5*(w[0] + w[n[d]-1])).  A periodic
- * direction needs >= 3 cells; a periodic SLAB axis on several ranks is not supported (PIB_ERR_SUP). */
+ * direction needs >= 3 cells.  A periodic SLAB axis on several ranks (rank 0 <-> rank P-1 become neighbours: ring halo)
+ * is provided for pib_assemble_poisson; the pib_set_csr route and pib_assemble_velocity return PIB_ERR_SUP there. */
 int pib_set_periodic(pib_solver *s, const int periodic[3]);
 
 /* Assemble the Poisson operator DBNG = D * (dt*I) * G directly in HBM from the

@@ -68,6 +68,7 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
     }
     DeviceCsr &A = s->A;
     A.release();
+    s->comm.ring = false;
     A.n = n_local;
     A.nnz = nnz;
     A.row0 = row0;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(int dim, int64_t nx, i
                                                           const double *__restrict__ wx, const double *__restrict__ wy,
                                                           const double *__restrict__ wz, const double *__restrict__ gx,
                                                           const double *__restrict__ gy, const double *__restrict__ gz,
-                                                          int pinned, int per, RP *__restrict__ rowptr,
+                                                          int pinned, int per, int ring, RP *__restrict__ rowptr,
                                                           int32_t *__restrict__ col, double *__restrict__ val)
 {
     const int64_t pl = nx * ny;
@@ -203,10 +204,11 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(int dim, int64_t nx, i
         o[5] = has[5] ? az * gz[k] : 0.0;
         off[0] = i > 0 ? -1 : nx - 1;
         off[1] = i < nx - 1 ? 1 : -(nx - 1);
-        off[2] = j > 0 ? -nx : (ny - 1) * nx;
-        off[3] = j < ny - 1 ? nx : -(ny - 1) * nx;
-        off[4] = k > 0 ? -pl : (nz - 1) * pl;
-        off[5] = k < nz - 1 ? pl : -(nz - 1) * pl;
+        // ring: the slab axis (y in 2-D, z in 3-D) wraps through the ghost pads, i.e. the plain neighbour offsets
+        off[2] = (j > 0 || (ring && dim == 2)) ? -nx : (ny - 1) * nx;
+        off[3] = (j < ny - 1 || (ring && dim == 2)) ? nx : -(ny - 1) * nx;
+        off[4] = (k > 0 || ring) ? -pl : (nz - 1) * pl;
+        off[5] = (k < nz - 1 || ring) ? pl : -(nz - 1) * pl;
         // diagonal: first contribution assigned, the rest added (sparse accumulator)
         double d = 0.0;
         bool first = true;
@@ -229,7 +231,10 @@ __global__ __launch_bounds__(256) void k_assemble_poisson(int dim, int64_t nx, i
         ev[0] = row_pinned ? 1.0 : d;
         for (int q = 0; q < 6; ++q) {
             if (!has[q]) continue;
-            const double v = (row_pinned || (pinned && g + off[q] == 0)) ? 0.0 : o[q];
+            int64_t gc = g + off[q];  // global column (ring: the ghost pads stand for the planes at the other end)
+            if (gc < 0) gc += pl * nz;
+            else if (gc >= pl * nz) gc -= pl * nz;
+            const double v = (row_pinned || (pinned && gc == 0)) ? 0.0 : o[q];
             int t = ne++;
             while (t > 0 && eo[t - 1] > off[q]) {
                 eo[t] = eo[t - 1];
@@ -285,8 +290,10 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
         }
     }
     const int P = s->comm.nranks, r = s->comm.rank;
-    if (P > 1 && (per & (1 << (dim - 1))))
-        return fail(PIB_ERR_SUP, "assemble_poisson: a periodic slab axis on several ranks is not supported");
+    // periodic slab axis on several ranks: rank 0 and rank P-1 are neighbours, every rank has both ghost planes and the
+    // wrapped columns of the outer planes point into them
+    const bool ring = P > 1 && (per & (1 << (dim - 1)));
+    s->comm.ring = ring;
     const int64_t nlast = (dim == 3) ? nz : ny;
     const int64_t plane = (dim == 3) ? nx * ny : nx;
     int64_t k0, k1;
@@ -298,8 +305,8 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
     A.n = (k1 - k0) * plane;
     A.row0 = k0 * plane;
     A.n_global = nx * ny * nz;
-    A.ghost_lo = (r > 0) ? plane : 0;
-    A.ghost_hi = (r < P - 1) ? plane : 0;
+    A.ghost_lo = (r > 0 || ring) ? plane : 0;
+    A.ghost_hi = (r < P - 1 || ring) ? plane : 0;
     const int64_t nnz0 = nnz_before(A.row0, dim, nx, ny, nz, per);
     A.nnz = nnz_before(A.row0 + A.n, dim, nx, ny, nz, per) - nnz0;
     A.rp64 = A.nnz >= (int64_t)std::numeric_limits<int32_t>::max();
@@ -319,11 +326,11 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
     const int nb = (int)std::min<int64_t>(8192, (A.n + 1 + 255) / 256);
     if (A.rp64)
         hipLaunchKernelGGL(k_assemble_poisson<int64_t>, dim3(nb), dim3(256), 0, s->stream, dim, nx, ny, nz, A.row0, A.n,
-                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, per, (int64_t *)A.rowptr, A.col,
+                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, per, ring ? 1 : 0, (int64_t *)A.rowptr, A.col,
                            A.val);
     else
         hipLaunchKernelGGL(k_assemble_poisson<int32_t>, dim3(nb), dim3(256), 0, s->stream, dim, nx, ny, nz, A.row0, A.n,
-                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, per, (int32_t *)A.rowptr, A.col,
+                           A.ghost_lo, nnz0, dw[0], dw[1], dw[2], dg[0], dg[1], dg[2], pinned, per, ring ? 1 : 0, (int32_t *)A.rowptr, A.col,
                            A.val);
     PIB_HIP(hipGetLastError());
     PIB_HIP(hipStreamSynchronize(s->stream));
@@ -572,6 +579,7 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
     }
     DeviceCsr &A = s->A;
     A.release();
+    s->comm.ring = false;
     A.n = rows;
     A.row0 = row0;
     A.n_global = n_global;

@@ -49,6 +49,7 @@ struct LevelDev {
     int k0, nk;       // owned planes [k0, k0+nk)
     int per;          // bit 0/1/2: x/y/z periodic (the operator wraps: g[n-1] couples cell n-1 and cell 0)
     int tper;         // ... and the transfers towards the next coarser level reach across the seam
+    int zring;        // distributed level of a periodic slab axis: the z wrap goes through the halo planes (+-plane)
     const double *wx, *wy, *wz, *gx, *gy, *gz;
     Tr1 t[3];         // x, y, z tables (null on the coarsest level)
     TrX tx;
@@ -76,7 +77,7 @@ __device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__
     const int64_t sy = L.nx, sz = (int64_t)L.nx * L.ny;
     const double xc = x[p];
     double s = 0.0;
-    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;  // a periodic z level is never distributed
+    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
     if (i > 0) s += c[0] * (x[p - 1] - xc);
     else if (px) s += c[0] * (x[p + (L.nx - 1)] - xc);
     if (i < L.nx - 1) s += c[1] * (x[p + 1] - xc);
@@ -86,9 +87,9 @@ __device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__
     if (j < L.ny - 1) s += c[3] * (x[p + sy] - xc);
     else if (py) s += c[3] * (x[p - (L.ny - 1) * sy] - xc);
     if (k > 0) s += c[4] * (x[p - sz] - xc);
-    else if (pz) s += c[4] * (x[p + (L.nzg - 1) * sz] - xc);
+    else if (pz) s += c[4] * (x[L.zring ? p - sz : p + (L.nzg - 1) * sz] - xc);
     if (k < L.nzg - 1) s += c[5] * (x[p + sz] - xc);
-    else if (pz) s += c[5] * (x[p - (L.nzg - 1) * sz] - xc);
+    else if (pz) s += c[5] * (x[L.zring ? p + sz : p - (L.nzg - 1) * sz] - xc);
     *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
     return s;
 }
@@ -171,9 +172,9 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             if (j < L.ny - 1) yp = *reinterpret_cast<const vt *>(xi + p + L.nx);
             else if (py) yp = *reinterpret_cast<const vt *>(xi + p - (int64_t)(L.ny - 1) * L.nx);
             if (k > 0) zm = *reinterpret_cast<const vt *>(xi + p - plane);
-            else if (pz) zm = *reinterpret_cast<const vt *>(xi + p + (int64_t)(L.nzg - 1) * plane);
+            else if (pz) zm = *reinterpret_cast<const vt *>(xi + p + (L.zring ? -plane : (int64_t)(L.nzg - 1) * plane));
             if (k < L.nzg - 1) zp = *reinterpret_cast<const vt *>(xi + p + plane);
-            else if (pz) zp = *reinterpret_cast<const vt *>(xi + p - (int64_t)(L.nzg - 1) * plane);
+            else if (pz) zp = *reinterpret_cast<const vt *>(xi + p + (L.zring ? plane : -(int64_t)(L.nzg - 1) * plane));
         }
         vt braw;
         if (MODE != 0) {
@@ -663,6 +664,7 @@ static LevelDev dev_of(const GridLevel &g)
     L.nk = (int)(g.k1 - g.k0);
     L.per = g.per;
     L.tper = g.tper;
+    L.zring = g.zring ? 1 : 0;
     L.wx = g.w[0];
     L.wy = g.w[1];
     L.wz = g.w[2];
@@ -869,8 +871,8 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
             hg[d].assign(g[map[d]], g[map[d]] + (nn[d] - 1) + (pern[d] ? 1 : 0));
         }
     }
-    if (pern[2] && P > 1)
-        return fail(PIB_ERR_SUP, "grid hint: a periodic slab axis on several ranks is not supported");
+    if (pern[2] && P > 1 && !s->comm.ring)
+        return fail(PIB_ERR_SUP, "grid hint: a periodic slab axis on several ranks needs the on-device assembly (pib_assemble_poisson)");
     if (nn[0] * nn[1] * nn[2] != s->A.n_global)
         return fail(PIB_ERR_ARG_SIZ, "grid hint: %lld x %lld x %lld cells but the matrix has %lld rows", (long long)nn[0],
                     (long long)nn[1], (long long)nn[2], (long long)s->A.n_global);
@@ -923,6 +925,7 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
             PIB_CHK(up(hw[d], &G.w[d]));
             const bool wrap = pern[d] && nn[d] > 1;  // a direction coarsened down to one cell has no face left
             if (wrap) G.per |= 1 << d;
+            if (wrap && d == 2 && !replicated && P > 1) G.zring = true;
             if (l > 0) {
                 hg[d].assign((size_t)std::max<int64_t>(nn[d] - 1, 0) + (wrap ? 1 : 0), 0.0);
                 for (int64_t q = 0; q + 1 < nn[d]; ++q) {
@@ -951,7 +954,9 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
             const double target = 1.5 * hmin * std::ldexp(1.0, l + 1 + target_shift);
             for (int d = 0; d < 3; ++d) {
                 const int64_t n = nn[d];
-                twrap[d] = pern[d] && n >= 4;  // the four fine cells a coarse cell gathers from must be distinct
+                // the four fine cells a coarse cell gathers from must be distinct; across ranks the seam of the slab
+                // axis stays a wall for the transfers (the halo planes serve the level operator only)
+                twrap[d] = pern[d] && n >= 4 && !(d == 2 && !replicated && P > 1);
                 par[d].assign((size_t)n, 0);
                 oth[d].assign((size_t)n, 0);
                 wpar[d].assign((size_t)n, 1.0);
@@ -1086,8 +1091,9 @@ static int halo_level_async(pib_solver *s, const GridLevel &g, double *x_owned, 
     const int64_t pl = g.plane;
     PIB_HIP(hipEventRecord(s->ev_ready, q));
     PIB_HIP(hipStreamWaitEvent(s->stream_comm, s->ev_ready, 0));
-    PIB_CHK(halo_exchange_planes(s, x_owned, g.nloc, r > 0 ? pl : 0, r < P - 1 ? pl : 0, r > 0 ? pl : 0, r < P - 1 ? pl : 0,
-                                 s->stream_comm));
+    const bool ring = s->comm.ring;
+    PIB_CHK(halo_exchange_planes(s, x_owned, g.nloc, (r > 0 || ring) ? pl : 0, (r < P - 1 || ring) ? pl : 0, (r > 0 || ring) ? pl : 0,
+                                 (r < P - 1 || ring) ? pl : 0, s->stream_comm));
     PIB_HIP(hipEventRecord(s->ev_halo, s->stream_comm));
     return 0;
 }
@@ -1117,7 +1123,9 @@ static int halo_level(pib_solver *s, const GridLevel &g, double *x_owned, hipStr
     s->halo_fresh = nullptr;
     const int r = s->comm.rank, P = s->comm.nranks;
     const int64_t pl = g.plane;
-    return halo_exchange_planes(s, x_owned, g.nloc, r > 0 ? pl : 0, r < P - 1 ? pl : 0, r > 0 ? pl : 0, r < P - 1 ? pl : 0, q);
+    const bool ring = s->comm.ring;
+    return halo_exchange_planes(s, x_owned, g.nloc, (r > 0 || ring) ? pl : 0, (r < P - 1 || ring) ? pl : 0, (r > 0 || ring) ? pl : 0,
+                                (r < P - 1 || ring) ? pl : 0, q);
 }
 
 // all-gather the owned coarse planes of level `lc` (ownership = the parents of the finer level's slab planes) into the

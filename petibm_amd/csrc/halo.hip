@@ -133,6 +133,14 @@ int comm_setup_halo(pib_solver *s)
     std::vector<int64_t> all;
     PIB_CHK(allgather_host4(s, mine, all));
     int err = 0;
+    if (s->comm.ring) {  // periodic slab axis: every rank has both neighbours
+        const size_t pv = (size_t)((r + P - 1) % P), nx = (size_t)((r + 1) % P);
+        if (A.ghost_lo > all[4 * pv] || A.ghost_hi > all[4 * nx]) return fail(PIB_ERR_SUP, "halo of rank %d reaches beyond its neighbour", r);
+        A.send_prev = all[4 * pv + 2];
+        A.send_next = all[4 * nx + 1];
+        if (A.send_prev > A.n || A.send_next > A.n) return fail(PIB_ERR_SUP, "a neighbour's halo is wider than this rank's slab");
+        return 0;
+    }
     if (r > 0) {
         if (A.ghost_lo > all[4 * (size_t)(r - 1)])
             err = fail(PIB_ERR_SUP, "halo of rank %d reaches beyond its neighbour (needs %lld entries, neighbour owns %lld)", r,
@@ -160,19 +168,21 @@ static int lb_halo(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, 
     g->count[(size_t)r] = n_owned;
     PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
     g->barrier();
-    if (r > 0 && lo > 0) {
-        PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)(r - 1)], 0));
-        const double *src = g->ptr[(size_t)(r - 1)] + g->count[(size_t)(r - 1)] - lo;
+    const bool ring = s->comm.ring;
+    const size_t pv = (size_t)((r + P - 1) % P), nx = (size_t)((r + 1) % P);
+    if ((r > 0 || ring) && lo > 0) {
+        PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[pv], 0));
+        const double *src = g->ptr[pv] + g->count[pv] - lo;
         PIB_HIP(hipMemcpyAsync(x_owned - lo, src, sizeof(double) * (size_t)lo, hipMemcpyDeviceToDevice, st));
     }
-    if (r < P - 1 && hi > 0) {
-        PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)(r + 1)], 0));
-        PIB_HIP(hipMemcpyAsync(x_owned + n_owned, g->ptr[(size_t)(r + 1)], sizeof(double) * (size_t)hi, hipMemcpyDeviceToDevice, st));
+    if ((r < P - 1 || ring) && hi > 0) {
+        PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[nx], 0));
+        PIB_HIP(hipMemcpyAsync(x_owned + n_owned, g->ptr[nx], sizeof(double) * (size_t)hi, hipMemcpyDeviceToDevice, st));
     }
     PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
     g->barrier();
-    if (r > 0) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)(r - 1)], 0));
-    if (r < P - 1) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)(r + 1)], 0));
+    if (r > 0 || ring) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[pv], 0));
+    if (r < P - 1 || ring) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[nx], 0));
     g->barrier();
     return 0;
 }
@@ -186,6 +196,19 @@ int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_
     if (P <= 1) return 0;
     s->counters[3]++;
     if (s->comm.loop) return lb_halo(s, x_owned, n_owned, lo, hi, st);
+    if (s->comm.ring) {
+        // periodic slab axis: rank 0's low ghost plane comes from rank P-1 and vice versa.  With P == 2 both messages
+        // of a rank go to the same peer and are matched in issue order: bottom plane first, then top plane, so the
+        // first message received is the peer's bottom plane (this rank's HIGH ghosts), the second its top plane.
+        const int pv = (r + P - 1) % P, nx = (r + 1) % P;
+        PIB_NCCL(ncclGroupStart());
+        if (send_prev > 0) PIB_NCCL(ncclSend(x_owned, (size_t)send_prev, ncclDouble, pv, s->comm.comm, st));
+        if (hi > 0) PIB_NCCL(ncclRecv(x_owned + n_owned, (size_t)hi, ncclDouble, nx, s->comm.comm, st));
+        if (send_next > 0) PIB_NCCL(ncclSend(x_owned + n_owned - send_next, (size_t)send_next, ncclDouble, nx, s->comm.comm, st));
+        if (lo > 0) PIB_NCCL(ncclRecv(x_owned - lo, (size_t)lo, ncclDouble, pv, s->comm.comm, st));
+        PIB_NCCL(ncclGroupEnd());
+        return 0;
+    }
     PIB_NCCL(ncclGroupStart());
     if (r > 0) {
         if (send_prev > 0) PIB_NCCL(ncclSend(x_owned, (size_t)send_prev, ncclDouble, r - 1, s->comm.comm, st));

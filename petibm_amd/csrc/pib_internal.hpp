@@ -152,6 +152,7 @@ struct GridLevel {
     int64_t nloc = 0, plane = 0;
     int per = 0;  // bit d: direction d (internal order) is periodic and has > 1 cell: the level operator wraps
     int tper = 0; // bit d: ... and so do the transfers towards the next coarser level (>= 4 cells)
+    bool zring = false;  // distributed level on a periodic slab axis: the z wrap goes through the halo planes
 };
 
 struct LoopbackGroup;  // halo.hip: test-only transport (ranks = threads of one process on one GPU)
@@ -159,6 +160,7 @@ struct Comm {
     ncclComm_t comm = nullptr;
     LoopbackGroup *loop = nullptr;
     int rank = 0, nranks = 1;
+    bool ring = false;  // the slab axis is periodic: rank 0 and rank P-1 are neighbours (their outer ghost planes wrap)
 };
 
 }  // namespace pib
