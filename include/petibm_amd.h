@@ -233,7 +233,8 @@ int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, 
  * assembleRHSVelocity (:432-521), solveVelocity (:524-537), assembleRHSPoisson (:540-563), solvePoisson
  * (:566-580), applyDivergenceFreeVelocity (:583-598), updatePressure (:601-615).  G, D, L, BNG and the
  * convective term N(u) (src/operators/createconvection.cpp) are applied matrix-free in the summation order of
- * the reference's assembled matrices; AB2 convection + Crank-Nicolson diffusion, BN order 1.
+ * the reference's assembled matrices; AB2 convection + Crank-Nicolson diffusion and BN order 1 unless
+ * pib_ns_set_time_integration / pib_ns_set_bn_order say otherwise.
  *   bc_type[6*f+loc]: 0 DIRICHLET, 1 NEUMANN, 2 CONVECTIVE; bc_value[6*f+loc] (flow.boundaryConditions of the YAML
  *   file; ghost points keep the reference's per-point state: src/boundary/singleboundary*.cpp);
  *   velocity_cfg / poisson_cfg: solver configuration TEXT (same syntaxes as pib_create).  The Poisson
@@ -248,6 +249,15 @@ int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, co
  * u = u* - BN G dP (navierstokes.cpp:349-356,583-598).  Call after pib_ns_create, before the first step.  N > 1 builds
  * the operator through pib_assemble_poisson_bn's product chain; not combined with immersed bodies (PIB_ERR_SUP). */
 int pib_ns_set_bn_order(pib_ns *ns, int order);
+/* parameters.convection / parameters.diffusion of config.yaml (createTimeIntegration, src/timeintegration/
+ * timeintegration.cpp:41-80): "EULER_EXPLICIT" | "EULER_IMPLICIT" | "ADAMS_BASHFORTH_2" | "CRANK_NICOLSON" for either
+ * term (include/petibm/timeintegration.h:107-166 for the coefficients); default ADAMS_BASHFORTH_2 + CRANK_NICOLSON.
+ * Call after pib_ns_create, before pib_ns_set_bodies and the first step; the velocity operator is re-assembled when
+ * the implicit coefficient changes.  Unknown name -> PIB_ERR_ARG_OUTOFRANGE like the reference. */
+int pib_ns_set_time_integration(pib_ns *ns, const char *convection, const char *diffusion);
+/* One explicit term kept between steps, for restart files with any scheme (/convection/<index>, /diffusion/<index>):
+ * kind 0 convection, 1 diffusion; set != 0 uploads `host`, 0 downloads into it (UN entries). */
+int pib_ns_history_term(pib_ns *ns, int kind, int index, int set, double *host);
 int pib_ns_sizes(pib_ns *ns, int64_t *UN, int64_t *pN);
 int pib_ns_set_state(pib_ns *ns, const double *U_packed_or_null, const double *p_or_null);        /* host arrays */
 int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs2);               /* any may be NULL */

@@ -48,6 +48,7 @@ struct FlowConfig {
     std::string velocitySolver, poissonSolver, forcesSolver;  // the TEXT of the solver .info files
     std::string delta = "ROMA_ET_AL_1999";      // parameters.delta (decoupledibpm.cpp:162)
     int BN = 1;                                 // parameters.BN: order of the approximate inverse (navierstokes.cpp:348)
+    std::string convection = "ADAMS_BASHFORTH_2", diffusion = "CRANK_NICOLSON";  // parameters.convection / diffusion
 };
 
 /** \brief parseSubDomains + stretchGrid (src/parser/parser.cpp:298-356, include/petibm/misc.h:148-163). */
@@ -137,6 +138,10 @@ public:
         ErrorCode ierr = pib_ns_create(&ns, dim, n, w[0].data(), w[1].data(), dim == 3 ? w[2].data() : nullptr, lo, hi, bt, bv,
                                        cfg.dt, cfg.nu, cfg.velocitySolver.c_str(), cfg.poissonSolver.c_str(), device);
         if (ierr) return ierr;
+        if (cfg.convection != "ADAMS_BASHFORTH_2" || cfg.diffusion != "CRANK_NICOLSON") {
+            ierr = pib_ns_set_time_integration(ns, cfg.convection.c_str(), cfg.diffusion.c_str());
+            if (ierr) return ierr;
+        }
         if (cfg.BN != 1) {
             ierr = pib_ns_set_bn_order(ns, cfg.BN);
             if (ierr) return ierr;

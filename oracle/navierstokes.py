@@ -266,11 +266,13 @@ class NavierStokes:
     """State + one-step advance, AB2 convection + CN diffusion, BN order 1."""
 
     def __init__(self, mesh: CartesianMesh, dt: float, nu: float, pinned: bool = False, vtol=1e-14, ptol=1e-13,
-                 bn_order: int = 1):
+                 bn_order: int = 1, convection: str = "ADAMS_BASHFORTH_2", diffusion: str = "CRANK_NICOLSON"):
         self.mesh, self.dt, self.nu, self.pinned = mesh, dt, nu, pinned
-        self.conv_c = [1.5, -0.5]
-        self.diff_c = [0.5]
-        self.cimpl = 0.5
+        # include/petibm/timeintegration.h:107-166: (implicit coefficient, explicit coefficients)
+        schemes = {"EULER_EXPLICIT": (0.0, [1.0]), "EULER_IMPLICIT": (1.0, []), "ADAMS_BASHFORTH_2": (0.0, [1.5, -0.5]),
+                   "CRANK_NICOLSON": (0.5, [0.5])}
+        self.conv_c = list(schemes[convection][1])
+        self.cimpl, self.diff_c = schemes[diffusion][0], list(schemes[diffusion][1])
         self.D = oops.create_divergence(mesh)
         self.G = oops.create_gradient(mesh)
         self.L = oops.create_laplacian(mesh)
@@ -281,7 +283,8 @@ class NavierStokes:
         self.U = np.zeros(mesh.UN)
         self.p = np.zeros(mesh.pN)
         set_ghost_ics(mesh, self.ghosts, self.U)
-        self.conv = [np.zeros(mesh.UN), np.zeros(mesh.UN)]
+        self.conv = [np.zeros(mesh.UN) for _ in self.conv_c]
+        self.diff = [np.zeros(mesh.UN) for _ in self.diff_c]
         self.vtol, self.ptol = vtol, ptol
         self.info = {}
         w = [mesh.dL[3][d].true for d in range(mesh.dim)]
@@ -300,14 +303,20 @@ class NavierStokes:
         rhs1 = clib.spmv(self.G, self.p)
         rhs1 = -1.0 * rhs1
         rhs1 = rhs1 + (1.0 / dt) * self.U
-        self.conv[1], self.conv[0] = self.conv[0], self.conv[1]  # VecSwap chain for 2 terms
-        self.conv[0] = -1.0 * convection(self.mesh, self.U, self.ghosts)
+        for i in range(len(self.conv) - 1, 0, -1):  # VecSwap chain (navierstokes.cpp:452-458)
+            self.conv[i], self.conv[i - 1] = self.conv[i - 1], self.conv[i]
+        if self.conv:
+            self.conv[0] = -1.0 * convection(self.mesh, self.U, self.ghosts)
         for c, v in zip(self.conv_c, self.conv):
             rhs1 = rhs1 + c * v
-        diff0 = clib.spmv(self.L, self.U)
-        diff0 = diff0 + laplacian_correction(self.mesh, self.ghosts)  # ghost equations of the previous step
-        diff0 = nu * diff0
-        rhs1 = rhs1 + self.diff_c[0] * diff0
+        for i in range(len(self.diff) - 1, 0, -1):
+            self.diff[i], self.diff[i - 1] = self.diff[i - 1], self.diff[i]
+        if self.diff:
+            diff0 = clib.spmv(self.L, self.U)
+            diff0 = diff0 + laplacian_correction(self.mesh, self.ghosts)  # ghost equations of the previous step
+            self.diff[0] = nu * diff0
+        for c, v in zip(self.diff_c, self.diff):
+            rhs1 = rhs1 + c * v
         update_eqs(self.mesh, self.ghosts, self.U, dt)  # navierstokes.cpp:508
         bc1 = nu * laplacian_correction(self.mesh, self.ghosts)
         rhs1 = rhs1 + self.cimpl * bc1

@@ -164,11 +164,11 @@ __device__ __forceinline__ void laplacian_at(const NsDev &D, const double *__res
 
 // rhs1 and the new convective term (navierstokes.cpp:432-521) at one velocity point, general form (ghost values, ghost
 // equations, periodic wraps)
-__device__ __forceinline__ void rhs_velocity_point(const NsDev &D, double dt, double nu, double c0, double c1, double d0,
-                                                   double cimpl, const double *__restrict__ U, const double *__restrict__ p,
+__device__ __forceinline__ void rhs_velocity_point(const NsDev &D, double dt, double nu, const NsTime &T,
+                                                   const double *__restrict__ U, const double *__restrict__ p,
                                                    const double *__restrict__ conv1, double *__restrict__ conv0,
-                                                   double *__restrict__ rhs1, double *__restrict__ diff0, int f, int64_t i,
-                                                   int64_t j, int64_t k)
+                                                   double *__restrict__ rhs1, double *__restrict__ diff0,
+                                                   const double *__restrict__ diff1, int f, int64_t i, int64_t j, int64_t k)
 {
     const NsField &F = D.f[f];
     const int64_t g = fidx(F, i, j, k);
@@ -187,31 +187,36 @@ __device__ __forceinline__ void rhs_velocity_point(const NsDev &D, double dt, do
     }
     r = -1.0 * r;
     r = r + (1.0 / dt) * U[g];
-    const double cn = -1.0 * convection_at(D, U, f, i, j, k);
-    conv0[g] = cn;
-    r = r + c0 * cn;
-    r = r + c1 * conv1[g];
+    if (T.nconv > 0) {
+        const double cn = -1.0 * convection_at(D, U, f, i, j, k);
+        conv0[g] = cn;
+        r = r + T.cc[0] * cn;
+        if (T.nconv > 1) r = r + T.cc[1] * conv1[g];
+    }
     // explicit diffusion with the ghost equations of the previous step, implicit correction with the updated
     // ones (bc->updateEqs sits between the two, navierstokes.cpp:492-514)
     double lu, lc, lcn;
     laplacian_at(D, U, f, i, j, k, &lu, &lc, &lcn);
-    double df = lu + lc;
-    df = nu * df;
-    diff0[g] = df;
-    r = r + d0 * df;
+    if (T.ndiff > 0) {
+        double df = lu + lc;
+        df = nu * df;
+        diff0[g] = df;
+        r = r + T.dc[0] * df;
+        if (T.ndiff > 1) r = r + T.dc[1] * diff1[g];
+    }
     const double b1 = nu * lcn;
-    r = r + cimpl * b1;
+    r = r + T.cimpl * b1;
     rhs1[g] = r;
 }
 
 // The outermost layer of a component (any index 0 or n-1: ghost values, ghost equations or periodic wraps in the
 // stencil), one point per lane in a dense enumeration -- x faces, then y faces without the x faces, then z faces without
 // both; `all` != 0: every point (a component with fewer than three points in some direction has no interior).
-__global__ __launch_bounds__(256) void k_ns_rhs_velocity_shell(NsDev D, int f, int all, double dt, double nu, double c0, double c1,
-                                                               double d0, double cimpl, const double *__restrict__ U,
+__global__ __launch_bounds__(256) void k_ns_rhs_velocity_shell(NsDev D, int f, int all, double dt, double nu, NsTime T,
+                                                               const double *__restrict__ U,
                                                                const double *__restrict__ p, const double *__restrict__ conv1,
                                                                double *__restrict__ conv0, double *__restrict__ rhs1,
-                                                               double *__restrict__ diff0)
+                                                               double *__restrict__ diff0, const double *__restrict__ diff1)
 {
     const NsField &F = D.f[f];
     const int64_t nx = F.n[0], ny = F.n[1], nz = F.n[2];
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity_shell(NsDev D, int f, i
             i = 1 + (q >> 1) % (nx - 2);
             j = 1 + (q >> 1) / (nx - 2);
         }
-        rhs_velocity_point(D, dt, nu, c0, c1, d0, cimpl, U, p, conv1, conv0, rhs1, diff0, f, i, j, k);
+        rhs_velocity_point(D, dt, nu, T, U, p, conv1, conv0, rhs1, diff0, diff1, f, i, j, k);
     }
 }
 
@@ -250,11 +255,11 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity_shell(NsDev D, int f, i
 // spent 4.8 ms per step on the 256^3 Taylor-Green case (5.0e7 points: 64-bit div/mod, twenty branchy vel() calls and
 // scratch-resident index arrays per point); mixing the two forms in one kernel left half of the waves paying for both.
 template <int DIM, int F>
-__global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, double nu, double c0, double c1, double d0,
-                                                         double cimpl, const double *__restrict__ U,
+__global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, double nu, NsTime T,
+                                                         const double *__restrict__ U,
                                                          const double *__restrict__ p, const double *__restrict__ conv1,
                                                          double *__restrict__ conv0, double *__restrict__ rhs1,
-                                                         double *__restrict__ diff0)
+                                                         double *__restrict__ diff0, const double *__restrict__ diff1)
 {
     const NsField &Fd = D.f[F];
     const int nx = (int)Fd.n[0];
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         const double self = U[g];
         r = r + (1.0 / dt) * self;
         // ---- N(u)  (createconvection.cpp:40-195)
+        if (T.nconv > 0) {
         const double W = (self + PIB_V(F, -1, 0, 0)) / 2.0, E = (self + PIB_V(F, 1, 0, 0)) / 2.0;
         const double S = (self + PIB_V(F, 0, -1, 0)) / 2.0, N = (self + PIB_V(F, 0, 1, 0)) / 2.0;
         double B = 0.0, Fw = 0.0;
@@ -323,8 +329,9 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         }
         const double cn = -1.0 * cv;
         conv0[g] = cn;
-        r = r + c0 * cn;
-        r = r + c1 * conv1[g];
+        r = r + T.cc[0] * cn;
+        if (T.nconv > 1) r = r + T.cc[1] * conv1[g];
+        }
         // ---- L u in the row's column order z-, y-, x-, diag, x+, y+, z+ ; no ghost point: the corrections are zero
         const double xNeg = Fd.lneg[0][i], xPos = Fd.lpos[0][i];
         double acc = 0.0;
@@ -346,12 +353,15 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         lu = lu + yPos * PIB_V(F, 0, 1, 0);
         if (DIM == 3) lu = lu + zPos * PIB_V(F, 0, 0, 1);
         const double lc = 0.0, lcn = 0.0;
-        double df = lu + lc;
-        df = nu * df;
-        diff0[g] = df;
-        r = r + d0 * df;
+        if (T.ndiff > 0) {
+            double df = lu + lc;
+            df = nu * df;
+            diff0[g] = df;
+            r = r + T.dc[0] * df;
+            if (T.ndiff > 1) r = r + T.dc[1] * diff1[g];
+        }
         const double b1 = nu * lcn;
-        r = r + cimpl * b1;
+        r = r + T.cimpl * b1;
         rhs1[g] = r;
     }
 #undef PIB_V
@@ -716,7 +726,7 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
         return 0;
     };
     if ((err = alloc(&ns->U, D.UN)) || (err = alloc(&ns->rhs1, D.UN)) || (err = alloc(&ns->conv[0], D.UN)) ||
-        (err = alloc(&ns->conv[1], D.UN)) || (err = alloc(&ns->diff0, D.UN)) || (err = alloc(&ns->p, D.pN)) || (err = alloc(&ns->dP, D.pN)) ||
+        (err = alloc(&ns->conv[1], D.UN)) || (err = alloc(&ns->diff0, D.UN)) || (err = alloc(&ns->diff1, D.UN)) || (err = alloc(&ns->p, D.pN)) || (err = alloc(&ns->dP, D.pN)) ||
         (err = alloc(&ns->rhs2, D.pN)) || (err = alloc(&D.a1, D.nghost)) || (err = alloc(&D.a1n, D.nghost)) ||
         (err = alloc(&D.gv, D.nghost)))
         return bail(err);
@@ -753,10 +763,67 @@ int pib_ns_set_bn_order(pib_ns *ns, int order)
         ns->psol->has_matrix = false;
         ns->psol->has_grid = false;
         gmg_release(ns->psol);
-        PIB_CHK(assemble_poisson_bn(ns->psol, dim, ns->h_n, w, ns->lo, ns->hi, ns->h_a0, ns->dt, 0.5 * ns->nu, order, nullspace,
+        PIB_CHK(assemble_poisson_bn(ns->psol, dim, ns->h_n, w, ns->lo, ns->hi, ns->h_a0, ns->dt, ns->T.cimpl * ns->nu, order, nullspace,
                                     &ns->bng_rowptr, &ns->bng_col, &ns->bng_val, &ns->bng_nnz));
     }
     ns->bn_order = order;
+    return 0;
+}
+
+/* parameters.convection / parameters.diffusion (src/timeintegration/timeintegration.cpp:41-80): EULER_EXPLICIT,
+ * EULER_IMPLICIT, ADAMS_BASHFORTH_2, CRANK_NICOLSON for either term; the convective term uses the scheme's explicit
+ * coefficients, the diffusive one its implicit coefficient (the velocity operator A = I/dt - c nu L is re-assembled)
+ * and its explicit coefficients (navierstokes.cpp:342-344,448-514). */
+static int scheme_coeffs(const char *name, int *nexp, double ce[2], double *cimpl)
+{
+    const std::string sname = name ? name : "";
+    ce[0] = ce[1] = 0.0;
+    if (sname == "EULER_EXPLICIT") { *cimpl = 0.0; *nexp = 1; ce[0] = 1.0; }
+    else if (sname == "EULER_IMPLICIT") { *cimpl = 1.0; *nexp = 0; }
+    else if (sname == "ADAMS_BASHFORTH_2") { *cimpl = 0.0; *nexp = 2; ce[0] = 1.5; ce[1] = -0.5; }
+    else if (sname == "CRANK_NICOLSON") { *cimpl = 0.5; *nexp = 1; ce[0] = 0.5; }
+    else return pib::fail(PIB_ERR_ARG_OUTOFRANGE, "The time integration scheme \"%s\" does not exist.", sname.c_str());
+    return 0;
+}
+
+int pib_ns_set_time_integration(pib_ns *ns, const char *convection, const char *diffusion)
+{
+    using namespace pib;
+    if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
+    NsTime T = ns->T;
+    double unused = 0.0;
+    PIB_CHK(scheme_coeffs(convection, &T.nconv, T.cc, &unused));
+    PIB_CHK(scheme_coeffs(diffusion, &T.ndiff, T.dc, &T.cimpl));
+    const bool reassemble = T.cimpl != ns->T.cimpl;
+    ns->T = T;
+    if (!reassemble) return 0;
+    PIB_HIP(hipSetDevice(ns->device));
+    const int dim = ns->D.dim;
+    PIB_CHK(pib_assemble_velocity(ns->vsol, dim, ns->h_n, ns->h_w[0].data(), ns->h_w[1].data(), dim == 3 ? ns->h_w[2].data() : nullptr,
+                                  ns->lo, ns->hi, ns->h_a0, ns->dt, T.cimpl * ns->nu));
+    if (ns->bn_order > 1) {  // BN depends on the implicit coefficient
+        const int order = ns->bn_order;
+        ns->bn_order = 0;
+        PIB_CHK(pib_ns_set_bn_order(ns, order));
+    }
+    if (ns->ib) return fail(PIB_ERR_ORDER, "pib_ns_set_time_integration: call before pib_ns_set_bodies");
+    return 0;
+}
+
+/* One explicit term kept between steps (restart files: /convection/<index>, /diffusion/<index>,
+ * navierstokes.cpp:637-686,689-746).  kind 0: convection, 1: diffusion; host array of UN entries. */
+int pib_ns_history_term(pib_ns *ns, int kind, int index, int set, double *host)
+{
+    using namespace pib;
+    if (ns == nullptr || host == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_history_term: null argument");
+    const int count = (kind == 0) ? ns->T.nconv : ns->T.ndiff;
+    if ((kind != 0 && kind != 1) || index < 0 || index >= count)
+        return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_history_term: the scheme keeps %d term(s) of kind %d", count, kind);
+    PIB_HIP(hipSetDevice(ns->device));
+    double *dev = (kind == 0) ? ns->conv[index] : (index == 0 ? ns->diff0 : ns->diff1);
+    const size_t bytes = sizeof(double) * (size_t)ns->D.UN;
+    if (set) PIB_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    else PIB_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -833,7 +900,8 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
     const int gt = gu > gp ? gu : gp;
     for (int it = 0; it < nsteps; ++it) {
         // VecSwap chain of the convective terms (navierstokes.cpp:452-458)
-        std::swap(ns->conv[0], ns->conv[1]);
+        if (ns->T.nconv > 1) std::swap(ns->conv[0], ns->conv[1]);
+        if (ns->T.ndiff > 1) std::swap(ns->diff0, ns->diff1);
         // bc->updateEqs(solution, dt) (:508) into a1n; the right-hand side needs both generations
         hipLaunchKernelGGL(k_ns_ghosts<1>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);
 #define PIB_RHS(DIM_, F_)                                                                                                   \
@@ -844,14 +912,14 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
             hipLaunchKernelGGL((k_ns_rhs_velocity<DIM_, F_>),                                                               \
                                dim3((unsigned)((Fq.n[0] - 2 + 255) / 256), (unsigned)(Fq.n[1] - 2),                           \
                                     (unsigned)(DIM_ == 3 ? Fq.n[2] - 2 : 1)),                                                 \
-                               dim3(256), 0, ns->stream, D, ns->dt, ns->nu, 1.5, -0.5, 0.5, 0.5, ns->U, ns->p, ns->conv[1],  \
-                               ns->conv[0], ns->rhs1, ns->diff0);                                                           \
+                               dim3(256), 0, ns->stream, D, ns->dt, ns->nu, ns->T, ns->U, ns->p, ns->conv[1],               \
+                               ns->conv[0], ns->rhs1, ns->diff0, ns->diff1);                                                \
         const int64_t shell = inner ? 2 * (Fq.n[1] * Fq.n[2] + (Fq.n[0] - 2) * Fq.n[2] +                                    \
                                            (DIM_ == 3 ? (Fq.n[0] - 2) * (Fq.n[1] - 2) : 0))                                 \
                                     : Fq.n[0] * Fq.n[1] * Fq.n[2];                                                          \
         hipLaunchKernelGGL(k_ns_rhs_velocity_shell, dim3((unsigned)std::min<int64_t>(4096, (shell + 255) / 256)), dim3(256), 0, \
-                           ns->stream, D, F_, inner ? 0 : 1, ns->dt, ns->nu, 1.5, -0.5, 0.5, 0.5, ns->U, ns->p, ns->conv[1],   \
-                           ns->conv[0], ns->rhs1, ns->diff0);                                                               \
+                           ns->stream, D, F_, inner ? 0 : 1, ns->dt, ns->nu, ns->T, ns->U, ns->p, ns->conv[1],                \
+                           ns->conv[0], ns->rhs1, ns->diff0, ns->diff1);                                                    \
     }
         if (D.dim == 2) {
             PIB_RHS(2, 0)

@@ -25,6 +25,13 @@ struct NsField {
     int64_t goff[6];        // offset of the face in the ghost arrays
     int64_t gcnt[6];        // points of the face
 };
+// time-integration coefficients (include/petibm/timeintegration.h:107-166): the explicit coefficients of the convective
+// scheme and the implicit / explicit coefficients of the diffusive one
+struct NsTime {
+    int nconv, ndiff;       // explicit terms kept: EULER_EXPLICIT 1, EULER_IMPLICIT 0, ADAMS_BASHFORTH_2 2, CRANK_NICOLSON 1
+    double cc[2], dc[2];
+    double cimpl;           // implicit coefficient of the diffusive scheme (A = I/dt - cimpl nu L)
+};
 struct NsDev {
     int dim;
     int per;                // bit d: direction d periodic (every component: misc.cpp checkPeriodicBC)
@@ -67,6 +74,8 @@ struct pib_ns {
     double dt = 0, nu = 0;
     double *U = nullptr, *p = nullptr, *dP = nullptr, *rhs1 = nullptr, *rhs2 = nullptr, *conv[2] = {nullptr, nullptr};
     double *diff0 = nullptr;  // explicit diffusion term of the last step (restart files carry it: navierstokes.cpp:672-680)
+    double *diff1 = nullptr;  // the one before (a two-term diffusive scheme only)
+    pib::NsTime T = {2, 1, {1.5, -0.5}, {0.5, 0.0}, 0.5};  // ADAMS_BASHFORTH_2 + CRANK_NICOLSON
     std::vector<double *> owned;
     int pinned = 0;
     int v_iters = 0, p_iters = 0;

@@ -75,9 +75,10 @@ class NavierStokesSolver:
         par = config["parameters"]
         self.dt = float(par["dt"])
         self.nu = float(config["flow"]["nu"])
-        for key, want in (("convection", "ADAMS_BASHFORTH_2"), ("diffusion", "CRANK_NICOLSON")):
-            if par.get(key, want) != want:
-                raise capi.PibError(capi.ERR_SUP, f"{key}: only {want} is provided")
+        # parameters.convection / diffusion (createTimeIntegration: both keys are required by the reference; the mirror
+        # defaults to the pair every example but the convergence study uses)
+        self.convection = str(par.get("convection", "ADAMS_BASHFORTH_2"))
+        self.diffusion = str(par.get("diffusion", "CRANK_NICOLSON"))
         n3 = np.array(self.n + [1] * (3 - self.dim), dtype=np.int64)
         lo3 = np.array(lo + [0.0] * (3 - self.dim))
         hi3 = np.array(hi + [1.0] * (3 - self.dim))
@@ -87,6 +88,10 @@ class NavierStokesSolver:
         capi.check(capi.load().pib_ns_create(C.byref(self._h), self.dim, n3.ctypes.data, wp[0], wp[1], wp[2],
                                              lo3.ctypes.data, hi3.ctypes.data, bc_t.ctypes.data, bc_v.ctypes.data,
                                              self.dt, self.nu, velocity_cfg.encode(), poisson_cfg.encode(), device))
+        if (self.convection, self.diffusion) != ("ADAMS_BASHFORTH_2", "CRANK_NICOLSON"):
+            capi.check(capi.load().pib_ns_set_time_integration(self._h, self.convection.encode(), self.diffusion.encode()))
+        kept = {"EULER_EXPLICIT": 1, "EULER_IMPLICIT": 0, "ADAMS_BASHFORTH_2": 2, "CRANK_NICOLSON": 1}
+        self._nconv, self._ndiff = kept[self.convection], kept[self.diffusion]
         self.bn_order = int(par.get("BN", 1))  # parameters.BN (parser: default 1)
         if self.bn_order != 1:
             capi.check(capi.load().pib_ns_set_bn_order(self._h, self.bn_order))
@@ -198,6 +203,11 @@ class NavierStokesSolver:
         capi.check(capi.load().pib_ns_get_history(self._h, c0.ctypes.data, c1.ctypes.data, d0.ctypes.data))
         return c0, c1, d0
 
+    def _history_term(self, kind: int, index: int, value=None):
+        a = np.empty(self.UN) if value is None else np.ascontiguousarray(value, dtype=np.float64)
+        capi.check(capi.load().pib_ns_history_term(self._h, kind, index, 0 if value is None else 1, a.ctypes.data))
+        return a
+
     def writeRestartData(self, path: str) -> None:
         """NavierStokesSolver::writeRestartDataHDF5 (navierstokes.cpp:637-686): the solution file plus the explicit
         terms /convection/0, /convection/1, /diffusion/0 (packed velocity ordering)"""
@@ -205,11 +215,11 @@ class NavierStokesSolver:
         import os
         if not os.path.exists(path):
             self.write(path)
-        c0, c1, d0 = self._history()
-        with h5io.File(path, "a") as f:
-            f.write("convection/0", c0)
-            f.write("convection/1", c1)
-            f.write("diffusion/0", d0)
+        with h5io.File(path, "a") as f:  # one dataset per explicit term the schemes keep
+            for i in range(self._nconv):
+                f.write(f"convection/{i}", self._history_term(0, i))
+            for i in range(self._ndiff):
+                f.write(f"diffusion/{i}", self._history_term(1, i))
 
     def readRestartData(self, path: str) -> None:
         """NavierStokesSolver::readRestartDataHDF5 (navierstokes.cpp:689-746): fields, time, explicit convective terms,
@@ -223,10 +233,13 @@ class NavierStokesSolver:
                     raise capi.PibError(capi.ERR_FILE_READ, f"{path}: dataset {name} has shape {a.shape}, the mesh needs {shape}")
                 parts.append(a.reshape(-1))
             self.t = f.read_attr("p", "time")
-            c0, c1 = f.read("convection/0"), f.read("convection/1")
+            conv = [f.read(f"convection/{i}") for i in range(self._nconv)]
+            diff = [f.read(f"diffusion/{i}") for i in range(self._ndiff)]
         self.setState(np.concatenate(parts[:-1]), parts[-1])  # includes setGhostICs
-        c0, c1 = np.ascontiguousarray(c0), np.ascontiguousarray(c1)
-        capi.check(capi.load().pib_ns_set_history(self._h, c0.ctypes.data, c1.ctypes.data))
+        for i, a in enumerate(conv):
+            self._history_term(0, i, a)
+        for i, a in enumerate(diff):
+            self._history_term(1, i, a)
         self.ite = int(round(self.t / self.dt))
 
     def linSolversInfo(self):
