@@ -216,3 +216,30 @@ def test_lid_driven_cavity_re1000_matches_ghia():
     ite, vi_, vr, pi_, pr = s.linSolversInfo()
     assert ite == 10000 and vi_ < 20 and pi_ < 20
     s.destroy()
+
+
+def test_lid_driven_cavity_re3200_matches_ghia():
+    """examples/navierstokes/liddrivencavity2dRe3200 verbatim: 192 x 192, nu = 1/3200, dt = 0.002, 25000 steps (t = 50);
+    centre-line velocities against Ghia et al. (1982) as in its plotCenterlineVelocities.py.  (Re = 5000, 60000 steps:
+    tools/cavity_ghia.py 5000, 65 s, within 0.027.)"""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    n = 192
+    cfg = cavity((n, n), nu=0.0003125, dt=0.002)
+    vel = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n"
+           "-velocity_pc_type jacobi\n")
+    poi = ("-poisson_ksp_type cg\n-poisson_ksp_atol 1.0E-06\n-poisson_ksp_rtol 0.0\n-poisson_ksp_max_it 1000\n"
+           "-poisson_pc_type gamg\n")
+    s = NavierStokesSolver(cfg, velocity_cfg=vel, poisson_cfg=poi)
+    s.advance(25000)
+    U, p = s.getState()
+    u = U[: (n - 1) * n].reshape(n, n - 1)
+    v = U[(n - 1) * n:].reshape(n - 1, n)
+    yc = (np.arange(n) + 0.5) / n
+    g = G["ghia_1982_re3200_centerlines"]
+    keep = np.array([abs(y - 0.4531) > 1e-6 for y in g["y"][1:-1]])  # the table's misprint (-0.86636 for -0.08664)
+    ui = np.interp(g["y"][1:-1], yc, u[:, n // 2 - 1])
+    vi = np.interp(g["x"][1:-1], yc, v[n // 2 - 1, :])
+    assert np.abs(ui - np.array(g["u"][1:-1]))[keep].max() < 0.04   # t = 50 is not quite steady at this Reynolds number
+    assert abs(ui[~keep][0] + 0.08664) < 0.02
+    assert np.abs(vi - np.array(g["v"][1:-1])).max() < 0.04
+    s.destroy()
