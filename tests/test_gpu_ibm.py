@@ -348,3 +348,27 @@ def test_cylinder_re100_vortex_shedding_matches_the_reference_readme():
     st = 1.0 / (np.diff(up).mean() * 0.01)   # shedding frequency * D / U
     assert 0.16 < st < 0.175
     s.destroy()
+
+
+def test_cylinder_re3000_drag_matches_koumoutsakos_leonard():
+    """examples/decoupledibpm/cylinder2dRe3000_GPU verbatim: 986^2 stretched mesh (ratios 0.9900990099 / 1 / 1.01), 786
+    Lagrangian points (a 1572 x 1572 force system, direct), nu = 1/3000, dt = 0.001, 3000 steps; cd = 2 fx against
+    Koumoutsakos & Leonard (1995).  As at Re = 550 the impulsive start rings in the decoupled scheme (here until t = 2)."""
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    sub = [{"end": -0.52, "cells": 363, "stretchRatio": 0.9900990099}, {"end": 0.52, "cells": 260, "stretchRatio": 1.0},
+           {"end": 15.0, "cells": 363, "stretchRatio": 1.01}]
+    base = omesh.uniform_config((986, 986))
+    base["mesh"] = [{"direction": d, "start": -15.0, "subDomains": sub} for d in "xy"]
+    cfg = flow_config(base, nu=0.00033333333333, dt=0.001)
+    vel = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n"
+           "-velocity_pc_type jacobi\n")
+    s = DecoupledIBPMSolver(cfg, bodies=[circle(786)], velocity_cfg=vel, poisson_cfg=AMGX_P.format(tol="1.0E-06"),
+                            forces_cfg=FORCES)
+    assert s.pN == 972196 and s.nf == 1572
+    kl = G["koumoutsakos_leonard_1995_cylinder_re3000"]
+    t_ref, cd_ref = 0.5 * np.array(kl["t_radius_units"]), np.array(kl["cd"])
+    for it in (2000, 2250, 2500, 2750, 3000):
+        s.advance(it - s.ite)
+        cd = 2.0 * s.getForces()[1][0][0]
+        assert abs(cd - np.interp(it * 0.001, t_ref, cd_ref)) < 0.07 * cd, (it, cd)
+    s.destroy()
