@@ -252,6 +252,103 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
     }
 }
 
+// ---- the first two pre-smoothing steps from a zero guess in ONE kernel:
+//   x1 = omega b / d            (mode 1)
+//   x2 = x1 + omega (b - A x1) / d   (mode 2)
+// as two streaming kernels these are 5 vector passes over HBM (b, x1 | x1, b, x2); here a workgroup owns a 128 x 8 tile
+// of the plane and marches through FZ planes with the x1 planes (tile + one halo cell in x and y) in a ring of four LDS
+// slots: b is read once (1.27 x with the halo), x2 written once.  Every k-independent mesh coefficient of the thread's
+// cells is loaded before the march (the 1-D arrays alone cost ~55 vector-memory instructions per thread and plane
+// otherwise).  Same expressions in the same order as modes 1 and 2: bit-identical (tools/fuse_lab.hip: 1.34 -> 0.78 ms
+// per 512^3 pair).  Levels that are whole on this rank, not periodic, 3-D, nx % 128 == 0, ny % 8 == 0.
+constexpr int FX = 128, FY = 8, FZ = 64, FSX = FX + 2, FSY = FY + 2;
+struct FCell {
+    double wx, wy, gxm, gxp, gym, gyp;
+};
+__device__ __forceinline__ FCell fcell(const LevelDev &L, int i, int j)
+{
+    FCell c;
+    c.wx = L.wx[i];
+    c.wy = L.wy[j];
+    c.gxm = (i > 0) ? L.gx[i - 1] : 0.0;
+    c.gxp = (i < L.nx - 1) ? L.gx[i] : 0.0;
+    c.gym = (j > 0) ? L.gy[j - 1] : 0.0;
+    c.gyp = (j < L.ny - 1) ? L.gy[j] : 0.0;
+    return c;
+}
+__device__ __forceinline__ double fdiag(const FCell &q, double wzk, double gzm, double gzp)
+{
+    const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
+    const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
+    return -(((((c0 + c1) + c2) + c3) + c4) + c5);
+}
+__global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ S, LevelDev L, double omega,
+                                                    const double *__restrict__ b, double *__restrict__ xo,
+                                                    const double *__restrict__ pin_sum)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ double x1[4][FSY][FSX];
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, k0 = blockIdx.z * FZ;
+    const int64_t plane = (int64_t)L.nx * L.ny;
+    const int j = j0 + ty, ic = i0 + 4 * tx;  // this thread's 4 cells: (ic .. ic+3, j)
+    // halo duty: every thread one cell of the two y-halo rows, 16 threads one cell of the two x-halo columns
+    const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
+    const int hx_col = (tid & 1) ? FX : -1, hx_y = (tid >> 1) & 7;
+    const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
+    const bool hy_ok = hyj >= 0 && hyj < L.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < L.nx;
+    const int64_t off_c = (int64_t)j * L.nx + ic, off_hy = (int64_t)hyj * L.nx + hyi, off_hx = (int64_t)hxj * L.nx + hxi;
+    FCell q4[4], qhy = {}, qhx = {};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = fcell(L, ic + c, j);
+    if (hy_ok) qhy = fcell(L, hyi, hyj);
+    if (hx_ok) qhx = fcell(L, hxi, hxj);
+    v4 bprev = {0, 0, 0, 0}, bcur = {0, 0, 0, 0};
+    for (int kk = k0 - 1; kk <= k0 + FZ; ++kk) {
+        const int slot = (kk + 4) & 3;
+        bprev = bcur;
+        if (kk >= 0 && kk < L.nzg) {
+            const double *pb = b + (int64_t)kk * plane;
+            v4 bv = *reinterpret_cast<const v4 *>(pb + off_c);
+            if (pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;  // PINNED: effective b at cell 0
+            const double hyv = hy_ok ? pb[off_hy] : 0.0, hxv = hx_ok ? pb[off_hx] : 0.0;
+            const double wzk = L.wz[kk];
+            const double gzm = (kk > 0) ? L.gz[kk - 1] : 0.0, gzp = (kk < L.nzg - 1) ? L.gz[kk] : 0.0;
+            bcur = bv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x1[slot][ty + 1][4 * tx + 1 + c] = omega * (bv[c] / fdiag(q4[c], wzk, gzm, gzp));
+            x1[slot][hy_row + 1][hy_x + 1] = hy_ok ? omega * (hyv / fdiag(qhy, wzk, gzm, gzp)) : 0.0;
+            if (tid < 16) x1[slot][hx_y + 1][hx_col + 1] = hx_ok ? omega * (hxv / fdiag(qhx, wzk, gzm, gzp)) : 0.0;
+        }
+        __syncthreads();
+        const int kc = kk - 1;  // the plane whose x1 neighbours are complete now
+        if (kc < k0 || kc >= L.nzg) continue;
+        const int sc = (kc + 4) & 3, sm = (kc + 3) & 3, sp = (kc + 5) & 3;
+        const double wzk = L.wz[kc];
+        const double gzm = (kc > 0) ? L.gz[kc - 1] : 0.0, gzp = (kc < L.nzg - 1) ? L.gz[kc] : 0.0;
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ic + c, lx = 4 * tx + 1 + c;
+            const FCell &q = q4[c];
+            const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
+            const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
+            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
+            const double xcc = x1[sc][ty + 1][lx];
+            double sum = 0.0;
+            if (i > 0) sum += c0 * (x1[sc][ty + 1][lx - 1] - xcc);
+            if (i < L.nx - 1) sum += c1 * (x1[sc][ty + 1][lx + 1] - xcc);
+            if (j > 0) sum += c2 * (x1[sc][ty][lx] - xcc);
+            if (j < L.ny - 1) sum += c3 * (x1[sc][ty + 2][lx] - xcc);
+            if (kc > 0) sum += c4 * (x1[sm][ty + 1][lx] - xcc);
+            if (kc < L.nzg - 1) sum += c5 * (x1[sp][ty + 1][lx] - xcc);
+            out[c] = xcc + omega * ((bprev[c] - sum) / d);
+        }
+        *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = out;
+    }
+}
+
 // the per-workgroup partials of slot k = blockIdx.y (up to 5 * 10^5 of them) in two fixed-order stages: 64 workgroups
 // per slot sum a contiguous chunk each, one workgroup per slot sums the 64 results into S->red[k]
 constexpr int BIG_STAGE = 64;
@@ -1204,6 +1301,15 @@ static int launch_level_planes(pib_solver *s, const GridLevel &g, int64_t kb, in
     return launch_level<MODE>(s, sub, omega, b ? b + o : b, xi ? xi + o : xi, xo + o, pin_sum, guarded, q, dvec ? dvec + o : dvec, a_d);
 }
 
+// the fused first two pre-smoothing steps (k_presmooth2) apply to this level
+static bool presmooth2_ok(const pib_solver *s, const GridLevel &g)
+{
+    if (!s->cfg.fuse_presmooth) return false;
+    const bool whole = (s->comm.nranks == 1) || g.replicated;
+    return whole && g.per == 0 && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && g.k0 == 0 &&
+           g.k1 == g.n[2];
+}
+
 // One V-cycle: z = M^-1 r.   r, z: ghost-padded work vectors of the Krylov solver
 // (their ghost planes double as the level-0 halo planes).
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
@@ -1235,6 +1341,16 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         for (int sw = 0; sw < nsteps; ++sw) {
             // every step but the last of the up-leg feeds a kernel that needs its halo
             const bool feeds = (sw + 1 < nsteps) || halo_after_last;
+            if (from_zero && sw == 0 && nsteps >= 2 && !cheb && presmooth2_ok(s, g) &&
+                (reinterpret_cast<uintptr_t>(b) & 31u) == 0 && (reinterpret_cast<uintptr_t>(c) & 31u) == 0) {
+                // steps 0 and 1 in one kernel; the result lands where step 1 would have put it
+                hipLaunchKernelGGL(k_presmooth2, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
+                                   dim3(256), 0, q, S, dev_of(g), omega, b, c, pin_l);
+                PIB_HIP(hipGetLastError());
+                std::swap(a, c);
+                sw = 1;
+                continue;
+            }
             if (from_zero && sw == 0) {
                 double *out = a;
                 auto run = [&](int64_t kb, int64_t kc) -> int {

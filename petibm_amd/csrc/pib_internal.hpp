@@ -74,6 +74,7 @@ struct Config {
     int coarse_tail = 0;     // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel.
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
+    int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;
