@@ -209,6 +209,121 @@ __global__ __launch_bounds__(256) void k_fused(L l, double omega, const double *
     }
 }
 
+// ---- two general Jacobi steps fused: x1 = S(x0) on tile + 1, x2 = S(x1) on the tile; x0 planes (tile + 2) in a ring of 3
+// LDS slots, x1 planes (tile + 1) in a ring of 4
+template <int KZ>
+__global__ __launch_bounds__(256) void k_fused_pair(L l, double omega, const double *__restrict__ b, const double *__restrict__ x0,
+                                                    double *__restrict__ xo)
+{
+    constexpr int HX = TX + 4, HY = TY + 4;
+    __shared__ double s0[3][HY][HX];
+    __shared__ double s1[4][SY][SX];
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const int i0 = blockIdx.x * TX, j0 = blockIdx.y * TY, k0 = blockIdx.z * KZ;
+    const int64_t plane = (int64_t)l.nx * l.ny;
+    const int j = j0 + ty, ic = i0 + 4 * tx;
+    const int hy_row = (tid < 128) ? -1 : TY, hy_x = tid & 127;
+    const int hx_col = (tid & 1) ? TX : -1, hx_y = (tid >> 1) & 7;
+    const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
+    const bool hy_ok = hyj >= 0 && hyj < l.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < l.nx;
+    const int64_t off_c = (int64_t)j * l.nx + ic, off_hy = (int64_t)hyj * l.nx + hyi, off_hx = (int64_t)hxj * l.nx + hxi;
+    Cell1 q4[4], qhy = {}, qhx = {};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = cell1(l, ic + c, j);
+    if (hy_ok) qhy = cell1(l, hyi, hyj);
+    if (hx_ok) qhx = cell1(l, hxi, hxj);
+    v4 b1 = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};  // b of planes kk-1 and kk-2 at the thread's cells
+    // one Jacobi step at a cell of plane kq from the x0 ring; (lx, ly) = position in the tile + 2 frame
+    auto step_a = [&](const Cell1 &q, int i, int jj, int kq, int lx, int ly, double bq) -> double {
+        const double wzk = l.wz[kq];
+        const double gzm = (kq > 0) ? l.gz[kq - 1] : 0.0, gzp = (kq < l.nz - 1) ? l.gz[kq] : 0.0;
+        const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
+        const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
+        const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
+        const int sc = (kq + 3) % 3, sm = (kq + 2) % 3, sp = (kq + 4) % 3;
+        const double xcc = s0[sc][ly][lx];
+        double s = 0.0;
+        if (i > 0) s += c0 * (s0[sc][ly][lx - 1] - xcc);
+        if (i < l.nx - 1) s += c1 * (s0[sc][ly][lx + 1] - xcc);
+        if (jj > 0) s += c2 * (s0[sc][ly - 1][lx] - xcc);
+        if (jj < l.ny - 1) s += c3 * (s0[sc][ly + 1][lx] - xcc);
+        if (kq > 0) s += c4 * (s0[sm][ly][lx] - xcc);
+        if (kq < l.nz - 1) s += c5 * (s0[sp][ly][lx] - xcc);
+        return xcc + omega * ((bq - s) / d);
+    };
+    for (int kk = k0 - 2; kk <= k0 + KZ + 1; ++kk) {
+        // (a) x0 plane kk -> ring (tile + 2; zeros outside the domain)
+        {
+            const int slot = (kk + 3) % 3;
+            const bool in = kk >= 0 && kk < l.nz;
+            const double *px = x0 + (int64_t)kk * plane;
+            v4 v = {0, 0, 0, 0};
+            if (in) v = *reinterpret_cast<const v4 *>(px + off_c);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s0[slot][ty + 2][4 * tx + 2 + c] = v[c];
+            for (int h = tid; h < 4 * HX + 4 * TY; h += 256) {
+                int ly, lx;
+                if (h < 4 * HX) {
+                    const int r = h / HX;
+                    ly = (r < 2) ? r : TY + r;  // rows 0, 1, TY+2, TY+3
+                    lx = h - r * HX;
+                } else {
+                    const int q = h - 4 * HX, r = q >> 2, cidx = q & 3;
+                    ly = r + 2;
+                    lx = (cidx < 2) ? cidx : TX + cidx;  // columns 0, 1, TX+2, TX+3
+                }
+                const int gi = i0 + lx - 2, gj = j0 + ly - 2;
+                double val = 0.0;
+                if (in && gi >= 0 && gi < l.nx && gj >= 0 && gj < l.ny) val = px[(int64_t)gj * l.nx + gi];
+                s0[slot][ly][lx] = val;
+            }
+        }
+        __syncthreads();
+        // (b) x1 of plane kk-1 on tile + 1
+        const int ka = kk - 1;
+        if (ka >= 0 && ka < l.nz && ka >= k0 - 1 && ka <= k0 + KZ) {
+            const double *pb = b + (int64_t)ka * plane;
+            const v4 bv = *reinterpret_cast<const v4 *>(pb + off_c);
+            b2 = b1;
+            b1 = bv;
+            const int slot = (ka + 4) & 3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s1[slot][ty + 1][4 * tx + 1 + c] = step_a(q4[c], ic + c, j, ka, 4 * tx + 2 + c, ty + 2, bv[c]);
+            s1[slot][hy_row + 1][hy_x + 1] = hy_ok ? step_a(qhy, hyi, hyj, ka, hy_x + 2, hy_row + 2, pb[off_hy]) : 0.0;
+            if (tid < 16) s1[slot][hx_y + 1][hx_col + 1] = hx_ok ? step_a(qhx, hxi, hxj, ka, hx_col + 2, hx_y + 2, pb[off_hx]) : 0.0;
+        } else {
+            b2 = b1;
+        }
+        __syncthreads();
+        // (c) x2 of plane kk-2 on the tile
+        const int kc = kk - 2;
+        if (kc < k0 || kc >= l.nz || kc >= k0 + KZ) continue;
+        const int sc = (kc + 4) & 3, sm = (kc + 3) & 3, sp = (kc + 5) & 3;
+        const double wzk = l.wz[kc];
+        const double gzm = (kc > 0) ? l.gz[kc - 1] : 0.0, gzp = (kc < l.nz - 1) ? l.gz[kc] : 0.0;
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ic + c, lx = 4 * tx + 1 + c;
+            const Cell1 &q = q4[c];
+            const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
+            const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
+            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
+            const double xcc = s1[sc][ty + 1][lx];
+            double s = 0.0;
+            if (i > 0) s += c0 * (s1[sc][ty + 1][lx - 1] - xcc);
+            if (i < l.nx - 1) s += c1 * (s1[sc][ty + 1][lx + 1] - xcc);
+            if (j > 0) s += c2 * (s1[sc][ty][lx] - xcc);
+            if (j < l.ny - 1) s += c3 * (s1[sc][ty + 2][lx] - xcc);
+            if (kc > 0) s += c4 * (s1[sm][ty + 1][lx] - xcc);
+            if (kc < l.nz - 1) s += c5 * (s1[sp][ty + 1][lx] - xcc);
+            out[c] = xcc + omega * ((b2[c] - s) / d);
+        }
+        *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = out;
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 512;
@@ -258,6 +373,21 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((k_fused<64, 1, 1>), dim3(n / TX, n / TY, n / 64), dim3(256), 0, 0, l, 0.9, b, y); });
     timeit("fused, z-marching, KZ 128, strided, prefetch", [&] {
         hipLaunchKernelGGL((k_fused<128, 1, 1>), dim3(n / TX, n / TY, n / 128), dim3(256), 0, 0, l, 0.9, b, y); });
+    {
+        // general pair: x0 = the fused result above (any field), reference = two mode-2 steps
+        double *x0 = y, *t1 = x1, *r2 = yref, *o2 = nullptr;
+        CK(hipMalloc(&o2, 8 * N));
+        CK(hipMemcpy(x0, b, 8 * N, hipMemcpyDeviceToDevice));
+        timeit("two general steps, two kernels", [&] {
+            hipLaunchKernelGGL(k_m2<4>, dim3((plane / 4 + 255) / 256, n), dim3(256), 0, 0, l, 0.9, b, x0, t1);
+            hipLaunchKernelGGL(k_m2<4>, dim3((plane / 4 + 255) / 256, n), dim3(256), 0, 0, l, 0.9, b, t1, r2);
+        });
+        timeit("two general steps fused, KZ 64", [&] {
+            hipLaunchKernelGGL((k_fused_pair<64>), dim3(n / TX, n / TY, n / 64), dim3(256), 0, 0, l, 0.9, b, x0, o2); });
+        timeit("two general steps fused, KZ 128", [&] {
+            hipLaunchKernelGGL((k_fused_pair<128>), dim3(n / TX, n / TY, n / 128), dim3(256), 0, 0, l, 0.9, b, x0, o2); });
+        CK(hipMemcpy(y, o2, 8 * N, hipMemcpyDeviceToDevice));
+    }
     std::vector<double> h0(N > (1 << 24) ? (1 << 24) : N), h1(h0.size());
     int64_t bad = 0;
     for (int64_t off : {int64_t(0), N / 2 - (int64_t)h0.size() / 2, N - (int64_t)h0.size()}) {
