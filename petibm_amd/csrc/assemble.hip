@@ -69,6 +69,7 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
     DeviceCsr &A = s->A;
     A.release();
     s->comm.ring = false;
+    vel_stencil_release(s);
     A.n = n_local;
     A.nnz = nnz;
     A.row0 = row0;
@@ -110,6 +111,7 @@ int adopt_device_csr(pib_solver *s, int64_t n, int64_t nnz, const int32_t *rowpt
     gmg_release(s);
     DeviceCsr &A = s->A;
     A.release();
+    vel_stencil_release(s);
     A.n = n;
     A.nnz = nnz;
     A.row0 = 0;
@@ -302,6 +304,7 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
 
     DeviceCsr &A = s->A;
     A.release();
+    vel_stencil_release(s);
     A.n = (k1 - k0) * plane;
     A.row0 = k0 * plane;
     A.n_global = nx * ny * nz;
@@ -580,6 +583,7 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
     DeviceCsr &A = s->A;
     A.release();
     s->comm.ring = false;
+    vel_stencil_release(s);
     A.n = rows;
     A.row0 = row0;
     A.n_global = n_global;
@@ -647,6 +651,39 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
     }
     PIB_HIP(hipStreamSynchronize(s->stream));
     for (double *p : tofree) (void)hipFree(p);
+    if (P == 1) {
+        // the operator's structure for the matrix-free product (velstencil.hip): the quotients the assembly kernel
+        // evaluates per entry, once per field, direction and index (IEEE division rounds identically on the host)
+        VelStencil &V = s->vel;
+        V.dim = dim;
+        V.per = per;
+        V.scale = scale;
+        V.shift = shift;
+        for (int f = 0; f < dim; ++f) {
+            V.off[f] = row_off[f];
+            for (int q = 0; q < 6; ++q) V.a0[f][q] = a0[6 * f + q];
+            for (int d = 0; d < 3; ++d) V.n[f][d] = fn[f][d];
+            for (int d = 0; d < dim; ++d) {
+                const int64_t nfd = fn[f][d];
+                std::vector<double> tn((size_t)nfd), tp((size_t)nfd);
+                for (int64_t q = 0; q < nfd; ++q) {
+                    const double dLSelf = hdl[f][d][(size_t)q + 1];
+                    const double dLNeg = hco[f][d][(size_t)q + 1] - hco[f][d][(size_t)q];
+                    const double dLPos = hco[f][d][(size_t)q + 2] - hco[f][d][(size_t)q + 1];
+                    tn[(size_t)q] = 1.0 / (dLNeg * dLSelf);
+                    tp[(size_t)q] = 1.0 / (dLPos * dLSelf);
+                }
+                double *p1 = nullptr, *p2 = nullptr;
+                PIB_CHK(upload_vec(tn, &p1));
+                PIB_CHK(upload_vec(tp, &p2));
+                V.owned.push_back(p1);
+                V.owned.push_back(p2);
+                V.lneg[f][d] = p1;
+                V.lpos[f][d] = p2;
+            }
+        }
+        V.valid = true;
+    }
     return 0;
 }
 

@@ -104,6 +104,7 @@ int pib_destroy(pib_solver *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     gmg_release(s);
     dense_release(s);
+    vel_stencil_release(s);
     s->A.release();
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
     if (s->work_base) (void)hipFree(s->work_base);

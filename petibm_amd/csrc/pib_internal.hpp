@@ -74,6 +74,7 @@ struct Config {
     int coarse_tail = 0;     // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel.
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
+    int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
@@ -164,6 +165,18 @@ struct Comm {
     bool ring = false;  // the slab axis is periodic: rank 0 and rank P-1 are neighbours (their outer ghost planes wrap)
 };
 
+// the velocity operator's structure (velstencil.hip): per field and direction the Laplacian quotients, the ghost folds,
+// MatScale / MatShift of A = I/dt - c nu L; valid after a single-rank pib_assemble_velocity
+struct VelStencil {
+    bool valid = false;
+    int dim = 0, per = 0;
+    int64_t n[3][3] = {{1, 1, 1}, {1, 1, 1}, {1, 1, 1}}, off[3] = {0, 0, 0};
+    const double *lneg[3][3] = {{nullptr}}, *lpos[3][3] = {{nullptr}};
+    double a0[3][6] = {{0}};
+    double scale = 0.0, shift = 0.0;
+    std::vector<double *> owned;
+};
+
 }  // namespace pib
 
 struct pib_solver {
@@ -183,6 +196,7 @@ struct pib_solver {
     bool gmg_guarded = true;
     std::string gmg_error;  // why the hierarchy could not be built (reported when a multigrid solve is asked for)
     int periodic[3] = {0, 0, 0};             // pib_set_periodic: problem directions x, y[, z]
+    pib::VelStencil vel;                     // matrix-free twin of the velocity operator (velstencil.hip)
     bool hint_pc_only = false;               // the grid structure describes the preconditioner's operator only (BN order > 1)
     std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
     double asm_dt = 0.0;
@@ -250,6 +264,8 @@ int dense_setup(pib_solver *s);
 void dense_release(pib_solver *s);
 int solve_direct(pib_solver *s, double *x, const double *b);
 // assemble.hip
+void vel_stencil_release(pib_solver *s);
+int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q);
 int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);
 // bn.hip: D * BN(order) * G through the reference's chain of sparse products; optionally hands out BNG (device arrays
 // owned by the caller)

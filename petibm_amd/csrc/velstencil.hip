@@ -1,0 +1,204 @@
+// velstencil.hip -- the velocity operator A = I/dt - c nu L applied matrix-free: what the CSR SpMV of the
+// matrix assembled by pib_assemble_velocity computes, row for row, from the 1-D mesh tables -- 56 B/row of HBM traffic
+// (x with its six neighbours mostly from cache, y) instead of 104 B/row of values, columns and offsets.
+//
+// Same numbers as the assembled matrix: an entry is (1 / (dLNeg * dLSelf)) * scale (createlaplacian.cpp:134-148 and
+// MatScale, navierstokes.cpp:342-344), the diagonal ((-sum) [+ ghost folds]) * scale + shift (:151, :232-243, MatShift),
+// and a row is summed by ascending column from 0.0 like the CSR kernels do -- the results are bit-identical to the SpMV
+// (tests/test_gpu_navierstokes.py).  Interior points (no ghost, no periodic wrap in the stencil) take a branch-free path
+// with j and k workgroup-uniform; the outermost layer goes through the general form, one point per lane in a dense
+// enumeration.  Single rank (the device time step is single-GPU); the Krylov solvers use it for their products when the
+// matrix came from pib_assemble_velocity and `pib_matrix_free_velocity` is on (default).
+#include "pib_internal.hpp"
+
+namespace pib {
+
+struct VelDev {
+    int dim, per;
+    int64_t n[3][3], off[3];
+    const double *lneg[3][3], *lpos[3][3];  // [field][direction], index s
+    double a0[3][6];
+    double scale, shift;
+};
+
+// general form of one row (ghost folds, periodic wraps)
+__device__ __forceinline__ double vel_row(const VelDev &V, const double *__restrict__ x, int f, int64_t i, int64_t j, int64_t k)
+{
+    const int64_t ijk[3] = {i, j, k};
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    bool interior[6] = {false, false, false, false, false, false};
+    bool anywrap = false;
+    double acc = 0.0;
+    for (int d = 0; d < V.dim; ++d) {
+        const int64_t s = ijk[d];
+        v[2 * d] = V.lneg[f][d][s];
+        v[2 * d + 1] = V.lpos[f][d][s];
+        const bool wrap = (V.per >> d) & 1;
+        interior[2 * d] = s > 0 || wrap;
+        interior[2 * d + 1] = s < V.n[f][d] - 1 || wrap;
+        anywrap = anywrap || (wrap && (s == 0 || s == V.n[f][d] - 1));
+        acc = acc + v[2 * d];
+        acc = acc + v[2 * d + 1];
+    }
+    double diag = -acc;
+    for (int q = 0; q < 2 * V.dim; ++q)
+        if (!interior[q]) {
+            const double t = v[q] * V.a0[f][q];
+            if (t != 0.0) diag = diag + t;
+        }
+    const double dval = diag * V.scale + V.shift;
+    const int64_t st[3] = {1, V.n[f][0], V.n[f][0] * V.n[f][1]};
+    const int64_t p = V.off[f] + i + V.n[f][0] * (j + V.n[f][1] * k);
+    double s = 0.0;
+    if (!anywrap) {
+        for (int d = V.dim - 1; d >= 0; --d)
+            if (interior[2 * d]) s = s + (v[2 * d] * V.scale) * x[p - st[d]];
+        s = s + dval * x[p];
+        for (int d = 0; d < V.dim; ++d)
+            if (interior[2 * d + 1]) s = s + (v[2 * d + 1] * V.scale) * x[p + st[d]];
+        return s;
+    }
+    int64_t ec[7];
+    double ev[7];
+    int ne = 1;
+    ec[0] = p;
+    ev[0] = dval;
+    for (int q = 0; q < 2 * V.dim; ++q) {
+        if (!interior[q]) continue;
+        const int d = q >> 1;
+        int64_t c;
+        if (!(q & 1)) c = (ijk[d] == 0) ? p + (V.n[f][d] - 1) * st[d] : p - st[d];
+        else c = (ijk[d] == V.n[f][d] - 1) ? p - (V.n[f][d] - 1) * st[d] : p + st[d];
+        int t = ne++;
+        while (t > 0 && ec[t - 1] > c) {
+            ec[t] = ec[t - 1];
+            ev[t] = ev[t - 1];
+            --t;
+        }
+        ec[t] = c;
+        ev[t] = v[q] * V.scale;
+    }
+    for (int t = 0; t < ne; ++t) s = s + ev[t] * x[ec[t]];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_vel_shell(const Scalars *__restrict__ S, VelDev V, int f, int all,
+                                                   const double *__restrict__ x, double *__restrict__ y)
+{
+    if (S != nullptr && S->done) return;
+    const int64_t nx = V.n[f][0], ny = V.n[f][1], nz = V.n[f][2];
+    const bool three = V.dim == 3;
+    const int64_t cx = 2 * ny * nz, cy = 2 * (nx - 2) * nz, cz = three ? 2 * (nx - 2) * (ny - 2) : 0;
+    const int64_t total = all ? nx * ny * nz : cx + cy + cz;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        int64_t i, j, k;
+        if (all) {
+            i = t % nx;
+            j = (t / nx) % ny;
+            k = t / (nx * ny);
+        } else if (t < cx) {
+            i = (t & 1) ? nx - 1 : 0;
+            j = (t >> 1) % ny;
+            k = (t >> 1) / ny;
+        } else if (t < cx + cy) {
+            const int64_t q = t - cx;
+            j = (q & 1) ? ny - 1 : 0;
+            i = 1 + (q >> 1) % (nx - 2);
+            k = (q >> 1) / (nx - 2);
+        } else {
+            const int64_t q = t - cx - cy;
+            k = (q & 1) ? nz - 1 : 0;
+            i = 1 + (q >> 1) % (nx - 2);
+            j = 1 + (q >> 1) / (nx - 2);
+        }
+        y[V.off[f] + i + nx * (j + ny * k)] = vel_row(V, x, f, i, j, k);
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_vel_interior(const Scalars *__restrict__ S, VelDev V, int f, const double *__restrict__ x,
+                                                      double *__restrict__ y)
+{
+    if (S != nullptr && S->done) return;
+    const int nx = (int)V.n[f][0];
+    const int j = blockIdx.y + 1, k = (DIM == 3) ? blockIdx.z + 1 : 0;
+    const int64_t sy = V.n[f][0], sz = sy * V.n[f][1];
+    const int64_t base = V.off[f] + sy * j + sz * k;
+    const double yneg = V.lneg[f][1][j], ypos = V.lpos[f][1][j];
+    const double zneg = (DIM == 3) ? V.lneg[f][2][k] : 0.0, zpos = (DIM == 3) ? V.lpos[f][2][k] : 0.0;
+    const double *__restrict__ xn = V.lneg[f][0], *__restrict__ xp = V.lpos[f][0];
+    for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i < nx - 1; i += gridDim.x * 256) {
+        const int64_t p = base + i;
+        const double xneg = xn[i], xpos = xp[i];
+        double acc = 0.0;
+        acc = acc + xneg;
+        acc = acc + xpos;
+        acc = acc + yneg;
+        acc = acc + ypos;
+        if (DIM == 3) {
+            acc = acc + zneg;
+            acc = acc + zpos;
+        }
+        const double diag = -acc;
+        const double dval = diag * V.scale + V.shift;
+        double s = 0.0;
+        if (DIM == 3) s = s + (zneg * V.scale) * x[p - sz];
+        s = s + (yneg * V.scale) * x[p - sy];
+        s = s + (xneg * V.scale) * x[p - 1];
+        s = s + dval * x[p];
+        s = s + (xpos * V.scale) * x[p + 1];
+        s = s + (ypos * V.scale) * x[p + sy];
+        if (DIM == 3) s = s + (zpos * V.scale) * x[p + sz];
+        y[p] = s;
+    }
+}
+
+static VelDev vel_dev(const VelStencil &h)
+{
+    VelDev V;
+    V.dim = h.dim;
+    V.per = h.per;
+    V.scale = h.scale;
+    V.shift = h.shift;
+    for (int f = 0; f < 3; ++f) {
+        V.off[f] = h.off[f];
+        for (int d = 0; d < 3; ++d) {
+            V.n[f][d] = h.n[f][d];
+            V.lneg[f][d] = h.lneg[f][d];
+            V.lpos[f][d] = h.lpos[f][d];
+        }
+        for (int q = 0; q < 6; ++q) V.a0[f][q] = h.a0[f][q];
+    }
+    return V;
+}
+
+void vel_stencil_release(pib_solver *s)
+{
+    for (double *p : s->vel.owned) (void)hipFree(p);
+    s->vel = VelStencil();
+}
+
+// y = A x on the whole (single-rank) vector
+int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q)
+{
+    const VelStencil &h = s->vel;
+    const VelDev V = vel_dev(h);
+    const Scalars *S = guarded ? s->d_s : nullptr;
+    for (int f = 0; f < h.dim; ++f) {
+        const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
+        const bool inner = nx >= 3 && ny >= 3 && (h.dim == 2 || nz >= 3);
+        if (inner) {
+            const dim3 grid((unsigned)((nx - 2 + 255) / 256), (unsigned)(ny - 2), (unsigned)(h.dim == 3 ? nz - 2 : 1));
+            if (h.dim == 3) hipLaunchKernelGGL(k_vel_interior<3>, grid, dim3(256), 0, q, S, V, f, x, y);
+            else hipLaunchKernelGGL(k_vel_interior<2>, grid, dim3(256), 0, q, S, V, f, x, y);
+        }
+        const int64_t shell = inner ? 2 * (ny * nz + (nx - 2) * nz + (h.dim == 3 ? (nx - 2) * (ny - 2) : 0)) : nx * ny * nz;
+        hipLaunchKernelGGL(k_vel_shell, dim3((unsigned)std::min<int64_t>(4096, (shell + 255) / 256)), dim3(256), 0, q, S, V, f,
+                           inner ? 0 : 1, x, y);
+    }
+    PIB_HIP(hipGetLastError());
+    s->counters[0]++;
+    return 0;
+}
+
+}  // namespace pib
