@@ -790,6 +790,7 @@ int pib_ns_set_time_integration(pib_ns *ns, const char *convection, const char *
 {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
+    if (ns->ib) return fail(PIB_ERR_ORDER, "pib_ns_set_time_integration: call before pib_ns_set_bodies");
     NsTime T = ns->T;
     double unused = 0.0;
     PIB_CHK(scheme_coeffs(convection, &T.nconv, T.cc, &unused));
@@ -806,7 +807,6 @@ int pib_ns_set_time_integration(pib_ns *ns, const char *convection, const char *
         ns->bn_order = 0;
         PIB_CHK(pib_ns_set_bn_order(ns, order));
     }
-    if (ns->ib) return fail(PIB_ERR_ORDER, "pib_ns_set_time_integration: call before pib_ns_set_bodies");
     return 0;
 }
 

@@ -103,3 +103,31 @@ def test_convergence_study_of_the_reference():
         e3 = np.linalg.norm(sol[540][k] - sol[180][k])
         first, last = np.log(e1 / e2) / np.log(3.0), np.log(e2 / e3) / np.log(3.0)
         assert 1.0 < last < 2.6, (name, first, last)
+
+
+def test_decoupled_ibpm_with_euler_schemes_matches_oracle():
+    from oracle import ibm
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    from test_gpu_ibm import AMGX_P, FORCES, flow_config
+    from test_oracle_ibm import body_mesh, circle
+    cfg = flow_config(body_mesh(cells=(8, 16, 8), ratio=1.25, span=3.0, core=0.8), dt=0.01)
+    cfg["parameters"].update(convection="EULER_EXPLICIT", diffusion="EULER_IMPLICIT")
+    bodies = [circle(32)]
+    m = omesh.create_mesh(cfg)
+    ref = ibm.DecoupledIBPM(m, 0.01, cfg["flow"]["nu"], bodies, pinned=True, vtol=1e-14, ptol=1e-13,
+                            convection="EULER_EXPLICIT", diffusion="EULER_IMPLICIT")
+    U0 = np.zeros(m.UN)
+    U0[: int(np.prod(m.n[0]))] = 1.0
+    U0 += 0.02 * np.random.default_rng(3).uniform(-1, 1, m.UN)
+    ref.set_state(U0, np.zeros(m.pN))
+    s = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=AMGX_P.format(tol=1e-13), forces_cfg=FORCES)
+    s.setState(U0, np.zeros(m.pN))
+    for step in range(3):
+        ref.advance()
+        s.advance()
+        U, p, r1, r2 = s.getState(rhs=True)
+        f, avg = s.getForces()
+        assert np.abs(r1 - ref.last_rhs1).max() <= 1e-9 * np.abs(ref.last_rhs1).max()
+        assert np.abs(U - ref.U).max() <= 1e-9 * np.abs(ref.U).max()
+        assert np.abs(f - ref.f).max() <= 1e-8 * np.abs(ref.f).max()
+    s.destroy()
