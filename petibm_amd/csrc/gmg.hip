@@ -1513,6 +1513,50 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
 }
 
 // y = A x with the matrix-free stencil (K2); x ghost-padded (halo exchanged here)
+// ---- the Krylov product w = A p from the stencil twin (the device time step's Poisson solves on large grids:
+// `pib_matrix_free_poisson`): 16 B/row for the product + 16 B/row for the p.w partials instead of the CSR's 104 B/row.
+// Same operator to rounding (the twin sums face differences, the CSR row sums products: verified to 1e-10 at registration).
+// PINNED: row 0 of the matrix is the identity; its column is zero, which the twin reproduces as long as p[0] = 0 -- the
+// Krylov vectors keep that entry at zero.
+__global__ __launch_bounds__(64) void k_twin_row0(const Scalars *__restrict__ S, const double *__restrict__ x, double *__restrict__ y)
+{
+    if (S != nullptr && S->done) return;
+    if (threadIdx.x == 0) y[0] = x[0];
+}
+__global__ __launch_bounds__(256) void k_twin_dot(const Scalars *__restrict__ S, int64_t n, const double *__restrict__ x,
+                                                  const double *__restrict__ y, double *__restrict__ part)
+{
+    if (S != nullptr && S->done) return;
+    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(lo + chunk, n);
+    double v = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) v += x[i] * y[i];
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+bool stencil_matmult_ok(const pib_solver *s)
+{
+    return s->cfg.matrix_free_poisson == 1 && s->has_grid && !s->hint_pc_only && !s->levels.empty() && s->comm.nranks == 1 &&
+           s->A.n >= ((int64_t)1 << 20);
+}
+
+int stencil_matmult(pib_solver *s, const double *x, double *y, double *dot_part, bool guarded, hipStream_t q)
+{
+    const GridLevel &g = s->levels[0];
+    PIB_CHK(launch_level<0>(s, g, 0.0, nullptr, x, y, nullptr, guarded, q));
+    const Scalars *S = guarded ? s->d_s : nullptr;
+    if (s->nullspace == PIB_NULLSPACE_PINNED) hipLaunchKernelGGL(k_twin_row0, dim3(1), dim3(64), 0, q, S, x, y);
+    if (dot_part) hipLaunchKernelGGL(k_twin_dot, dim3((unsigned)spmv_launch_blocks()), dim3(256), 0, q, S, s->A.n, x, y, dot_part);
+    PIB_HIP(hipGetLastError());
+    s->counters[0]++;
+    return 0;
+}
+
 int stencil_apply(pib_solver *s, double *x_owned, double *y, hipStream_t q)
 {
     if (!s->has_grid) return fail(PIB_ERR_ORDER, "stencil apply without grid structure");

@@ -593,6 +593,7 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     // the two linear solvers (same device)
     if ((err = pib_create_from_string(&ns->vsol, "velocity", velocity_cfg, 0, 1, nullptr, device))) return bail(err);
     if ((err = pib_create_from_string(&ns->psol, "poisson", poisson_cfg, 0, 1, nullptr, device))) return bail(err);
+    if (ns->psol->cfg.matrix_free_poisson < 0) ns->psol->cfg.matrix_free_poisson = 1;  // auto: on inside the time step
     ns->device = ns->vsol->device;
     PIB_HIP(hipSetDevice(ns->device));
     PIB_HIP(hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking));

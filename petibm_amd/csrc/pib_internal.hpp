@@ -74,6 +74,7 @@ struct Config {
     int coarse_tail = 0;     // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel.
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
+    int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
     int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
@@ -283,6 +284,9 @@ int upload_vec(const std::vector<double> &h, double **d);
 // gmg.hip
 int gmg_verify(pib_solver *s);
 int stencil_apply(pib_solver *s, double *x_owned, double *y, hipStream_t st);
+bool stencil_matmult_ok(const pib_solver *s);
+int stencil_matmult(pib_solver *s, const double *x, double *y, double *dot_part, bool guarded, hipStream_t q);
+int spmv_launch_blocks();
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t st);
 void gmg_release(pib_solver *s);
 int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double *const g[3],

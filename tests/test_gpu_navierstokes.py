@@ -243,3 +243,26 @@ def test_lid_driven_cavity_re3200_matches_ghia():
     assert abs(ui[~keep][0] + 0.08664) < 0.02
     assert np.abs(vi - np.array(g["v"][1:-1])).max() < 0.04
     s.destroy()
+
+
+@pytest.mark.parametrize("flavour", ["amgx_pinned", "ksp_constant"])
+def test_matrix_free_poisson_products_in_the_time_step(flavour):
+    """On grids of >= 2^20 cells the time step's Poisson solves take their Krylov products from the stencil twin
+    (gmg.hip stencil_matmult; `pib_matrix_free_poisson`): the same operator to rounding, so the steps agree with the CSR
+    products to solver tolerance -- also with the pinned pressure, whose identity row the twin patches."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    n = 1024
+    cfg = cavity((n, n), nu=0.01, dt=0.0005)
+    cfg["flow"]["initialVelocity"] = ["0.3*sin(3*x)*cos(2*y)", "-0.2*cos(2*x)*sin(3*y)"]
+    poi = AMGX_P if flavour == "amgx_pinned" else KSP_P
+    out = []
+    for mf in (1, 0):
+        extra = f"pib_matrix_free_poisson={mf}\n" if flavour == "amgx_pinned" else f"-poisson_pib_matrix_free_poisson {mf}\n"
+        s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=poi + extra)
+        s.advance(3)
+        U, p = s.getState()
+        out.append((U, p - p.mean(), s.linSolversInfo()))
+        s.destroy()
+    assert abs(out[0][2][3] - out[1][2][3]) <= 1 and out[0][2][3] > 0
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-10 * np.abs(out[1][0]).max()
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-8 * np.abs(out[1][1]).max()
