@@ -274,22 +274,34 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
+    # Everything below is reporting around the timed value: a failure in it must not lose the line (and must not leave
+    # the other ranks waiting in a collective), so local work is guarded and the collectives are unconditional.
+    notes = []
     # residual contract, recomputed on the device with the CSR operator
-    r_d = s.deviceVec()
-    s.matMult(x_d, r_d)
-    bl = b_d.download()
-    rl = bl - r_d.download()
-    num = torch.tensor([float(rl @ rl), float(bl @ bl)], dtype=torch.float64, device=red_dev)
+    try:
+        r_d = s.deviceVec()
+        s.matMult(x_d, r_d)
+        bl = b_d.download()
+        rl = bl - r_d.download()
+        local = [float(rl @ rl), float(bl @ bl)]
+    except Exception as e:  # noqa: BLE001
+        local = [float("nan"), 1.0]
+        notes.append(f"residual check failed: {e}")
+    num = torch.tensor(local, dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(num)
     true_rel = float(torch.sqrt(num[0] / num[1]).item())
 
     # roofline of the dominant kernel: CSR SpMV, HIP events on the solver's stream
-    ms_spmv = s.timeKernel(0, args.kernel_reps)
     nnz_l, n_l = s.nnz, s.n_local
     alg_bytes = 12.0 * nnz_l + 4.0 * (n_l + 1) + 16.0 * n_l  # SURVEY.md 8d B_spmv_csr
+    try:
+        ms_spmv = s.timeKernel(0, args.kernel_reps)
+        counters = s.counters()
+    except Exception as e:  # noqa: BLE001
+        ms_spmv, counters = float("nan"), [0] * 8
+        notes.append(f"kernel timing failed: {e}")
     achieved = alg_bytes / (ms_spmv * 1e-3) / 1e9
-    counters = s.counters()
 
     out = None
     if rank == 0:
@@ -311,10 +323,21 @@ def main():
                          "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes},
             "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "host_polls": int(counters[4])},
         }
+        def finite(o):  # NaN is not JSON
+            if isinstance(o, dict):
+                return {k: finite(v) for k, v in o.items()}
+            if isinstance(o, float) and not np.isfinite(o):
+                return None
+            return o
+        out = finite(out)
+        out["cpu_baseline"] = None
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n, args.tol, dt, args.presweeps, args.postsweeps, args.omega)
-        else:
-            out["cpu_baseline"] = None
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, args.tol, dt, args.presweeps, args.postsweeps, args.omega)
+            except Exception as e:  # noqa: BLE001
+                notes.append(f"cpu baseline failed: {e}")
+        if notes:
+            out["notes"] = notes
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
