@@ -282,6 +282,13 @@ int pib_ns_destroy(pib_ns *ns);
  * Errors: unknown kernel -> PIB_ERR_ARG_UNKNOWN_TYPE, a point outside the domain -> PIB_ERR_MAX_VALUE. */
 int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double *coords, const char *delta_kernel,
                       const char *forces_cfg);
+/* IBPMSolver (applications/ibpm/ibpm.cpp): the coupled immersed-boundary projection method -- pressure and Lagrangian
+ * forces are ONE unknown of the modified Poisson system D_c BN G_c with G_c = [G, -H], D_c = [D; E] (:110-194), so
+ * no-slip and continuity hold together at the end of a step.  The engine eliminates the small forces block exactly
+ * (EBNH^-1 from the direct forces solver) and runs the Poisson solver on the Schur complement; the step then is
+ * IBPMSolver's: u = u* - BN G_c [dP; df], p += dP, f += df.  Call after pib_ns_set_bodies (forces solver: preonly + lu);
+ * coupled = 0 goes back to the decoupled scheme. */
+int pib_ns_set_coupled(pib_ns *ns, int coupled);
 /* RigidKinematicsSolver::moveBodies (applications/rigidkinematics/rigidkinematics.cpp:118-140): new coordinates of all
  * points (layout of pib_ns_set_bodies) and, if not NULL, their prescribed velocities UB [nf]: the operators are
  * re-assembled on the device, the forces solver receives the new EBNH and the forces right-hand side becomes

@@ -230,3 +230,45 @@ class DecoupledIBPM(ons.NavierStokes):
             out.append(-self.f[off:off + n].reshape(-1, self.mesh.dim).sum(axis=0))
             off += n
         return np.array(out)
+
+
+class CoupledIBPM(DecoupledIBPM):
+    """IBPMSolver (applications/ibpm/ibpm.cpp): pressure and Lagrangian forces are one unknown of the modified Poisson
+    system D_c BN G_c with G_c = [G, -H], D_c = [D; E] (:110-194); pinned pressure = MatZeroRowsColumns(row 0) of the
+    stacked matrix (:264-268).  The restatement assembles the stacked matrix densely and solves it directly (small
+    meshes only) -- whatever route a solver takes, this is the solution it has to reach."""
+
+    def __init__(self, mesh, dt, nu, bodies, **kw):
+        kw["pinned"] = True
+        super().__init__(mesh, dt, nu, bodies, **kw)
+        pN, nf = mesh.pN, self.nf
+        D, BNG = self.D.to_dense(), self.BNG.to_dense()
+        E, BNH = self.ops["E"].to_dense(), self.ops["BNH"].to_dense()
+        M = np.zeros((pN + nf, pN + nf))
+        M[:pN, :pN] = D @ BNG
+        M[:pN, pN:] = -(D @ BNH)
+        M[pN:, :pN] = E @ BNG
+        M[pN:, pN:] = -(E @ BNH)
+        M[0, :] = 0.0
+        M[:, 0] = 0.0
+        M[0, 0] = 1.0
+        self.M = M
+
+    def advance(self):
+        rhs1 = self.rhs_velocity()
+        rhs1 = mult_add(self.ops["H"], self.f, rhs1)  # -G_c [p; f] = -G p + H f
+        self.last_rhs1 = rhs1
+        r = clib.bcgs(self.A, rhs1, x0=self.U, pc="jacobi", norm="unpreconditioned", rtol=0.0, atol=self.vtol,
+                      dtol=1e300, maxit=2000)
+        assert r["reason"] > 0
+        self.U = r["x"]
+        r1 = self.rhs_poisson()  # D u* + bc, zero at the pinned row
+        r2 = clib.spmv(self.ops["E"], self.U)
+        x = np.linalg.solve(self.M, np.concatenate([r1, r2]))
+        dP, df = x[: self.mesh.pN], x[self.mesh.pN:]
+        self.U = self.U - clib.spmv(self.BNG, dP)
+        self.U = mult_add(self.ops["BNH"], df, self.U)
+        self.p = self.p + dP
+        self.f = self.f + df
+        ons.update_ghost_values(self.mesh, self.ghosts, self.U)
+

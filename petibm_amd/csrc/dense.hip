@@ -75,6 +75,17 @@ __global__ __launch_bounds__(256) void k_dense_apply(int64_t n, const double *__
     if (lane == 0) y[r] = s;
 }
 
+// y = Inv b with the explicit inverse of a solver set up for a direct solve, on the caller's stream and without a host
+// synchronisation (the coupled immersed-boundary operator applies EBNH^-1 inside every Krylov product)
+int dense_apply_raw(const pib_solver *s, const double *b, double *y, hipStream_t q)
+{
+    const int64_t n = s->dense_n;
+    if (s->dense_inv == nullptr || n <= 0) return fail(PIB_ERR_ORDER, "solver %s: no explicit inverse", s->name.c_str());
+    hipLaunchKernelGGL(k_dense_apply, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, q, n, s->dense_inv, b, y);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+
 void dense_release(pib_solver *s)
 {
     if (s->dense_graph) (void)hipGraphExecDestroy(s->dense_graph);

@@ -1539,6 +1539,14 @@ __global__ __launch_bounds__(256) void k_twin_dot(const Scalars *__restrict__ S,
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// x.y as spmv_launch_blocks() fixed-order partial sums (what the SpMV's fused dot delivers)
+int dot_partials(pib_solver *s, const double *x, const double *y, double *part, bool guarded, hipStream_t q)
+{
+    hipLaunchKernelGGL(k_twin_dot, dim3((unsigned)spmv_launch_blocks()), dim3(256), 0, q, guarded ? s->d_s : nullptr, s->A.n, x, y, part);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+
 bool stencil_matmult_ok(const pib_solver *s)
 {
     return s->cfg.matrix_free_poisson == 1 && s->has_grid && !s->hint_pc_only && !s->levels.empty() && s->comm.nranks == 1 &&

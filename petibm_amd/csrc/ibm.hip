@@ -54,6 +54,10 @@ struct IbState {
     double *ub = nullptr;     // prescribed velocity of the Lagrangian points (RigidKinematicsSolver: rhsf = UB - E u)
     bool moving = false;
     double dt = 0.0;
+    // coupled IBPM (applications/ibpm): work vectors of the Schur-complement operator
+    bool coupled = false;
+    double *t_un = nullptr, *t_un2 = nullptr;  // [UN]
+    double *g_nf = nullptr, *y_nf = nullptr, *r2 = nullptr;  // [nf]
     std::vector<void *> owned;      // operators of the current body position (released by every re-assembly)
     std::vector<void *> persistent; // forces and friends: live as long as the bodies
 };
@@ -324,6 +328,88 @@ int ib_solve_forces(pib_ns *ns)
     return 0;
 }
 
+// out[r] = (E u)[r]
+__global__ __launch_bounds__(256) void k_ib_eu(int64_t nf, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                               const double *__restrict__ eval, const double *__restrict__ U, double *__restrict__ out)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nf; r += (int64_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int32_t q = rowptr[r]; q < rowptr[r + 1]; ++q) s = s + eval[q] * U[col[q]];
+        out[r] = s;
+    }
+}
+// y = a - b ; y = -x ; u = u - t
+__global__ __launch_bounds__(256) void k_ib_sub(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] - b[i];
+}
+__global__ __launch_bounds__(256) void k_ib_neg(int64_t n, const double *__restrict__ x, double *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = -x[i];
+}
+
+// ---- coupled IBPM (applications/ibpm/ibpm.cpp) ---------------------------------------------------------------------
+// The reference stacks pressure and Lagrangian forces into one unknown, G_c = [G, -H], D_c = [D; E] (:110-183), and
+// hands D_c BN G_c = [[A11, A12], [A21, A22]] to ONE linear solver (:185-194):
+//     A11 = D BN G (the Poisson operator), A12 = -D BNH, A21 = E BNG, A22 = -E BNH = -EBNH.
+// Here the small block is eliminated exactly -- EBNH^-1 is the explicit inverse the direct forces solver holds -- and
+// the pressure solver iterates on the Schur complement
+//     S phi = A11 phi - D BNH EBNH^-1 E BNG phi  =  r1 - D BNH EBNH^-1 r2 ,      df = -EBNH^-1 (r2 - E BNG phi),
+// negative semi-definite like A11 (S = -k G^T BN^(1/2) (I - Pi) BN^(1/2) G with Pi the projector onto the spread
+// forces), so the same PCG with the same multigrid applies; the term is added to every Krylov product by
+// pib_solver::post_matmult.  The pinned pressure zeroes row and column 0 of the stacked matrix (:264-268): row 0 of the
+// term is skipped, column 0 multiplies the Krylov vectors' zero entry.
+static int ib_schur_term(pib_solver *ps, const double *p, double *w, bool guarded, hipStream_t q, void *ctx)
+{
+    (void)guarded;  // after convergence these kernels only touch work vectors and a dead w
+    pib_ns *ns = (pib_ns *)ctx;
+    IbState *ib = ns->ib;
+    const int64_t nf = ib->I.nf, UN = ns->D.UN;
+    (void)ps;
+    PIB_CHK(ns_bng_apply(ns, p, ib->t_un, q));                                                      // t1 = BNG p
+    hipLaunchKernelGGL(k_ib_eu, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, ib->eval, ib->t_un, ib->g_nf);  // E t1
+    PIB_CHK(dense_apply_raw(ib->fsol, ib->g_nf, ib->y_nf, q));                                       // y = EBNH^-1 g
+    PIB_HIP(hipMemsetAsync(ib->t_un2, 0, sizeof(double) * (size_t)UN, q));
+    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ns->dt, ib->hcols, ib->hptr, ib->hrow,
+                       ib->hval, ib->y_nf, ib->t_un2);                                               // t2 = BNH y
+    PIB_HIP(hipGetLastError());
+    return ns_div_sub(ns, ib->t_un2, w, q);                                                          // w -= D t2
+}
+
+bool ib_is_coupled(const pib_ns *ns) { return ns->ib != nullptr && ns->ib->coupled; }
+
+int ib_coupled_solve_and_project(pib_ns *ns)
+{
+    IbState *ib = ns->ib;
+    const int64_t nf = ib->I.nf, UN = ns->D.UN, pN = ns->D.pN;
+    hipStream_t q = ns->stream;
+    // r2 = E u* ; r1 (= ns->rhs2, already D u* + bc, zero at a pinned row 0) -= D BNH EBNH^-1 r2
+    hipLaunchKernelGGL(k_ib_eu, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, ib->eval, ns->U, ib->r2);
+    PIB_CHK(dense_apply_raw(ib->fsol, ib->r2, ib->y_nf, q));
+    PIB_HIP(hipMemsetAsync(ib->t_un2, 0, sizeof(double) * (size_t)UN, q));
+    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ns->dt, ib->hcols, ib->hptr, ib->hrow,
+                       ib->hval, ib->y_nf, ib->t_un2);
+    PIB_HIP(hipGetLastError());
+    PIB_CHK(ns_div_sub(ns, ib->t_un2, ns->rhs2, q));
+    PIB_HIP(hipStreamSynchronize(q));
+    // S dP = r1'
+    PIB_CHK(pib_solve(ns->psol, ns->dP, ns->rhs2));
+    // df = -EBNH^-1 (r2 - E BNG dP)
+    PIB_CHK(ns_bng_apply(ns, ns->dP, ib->t_un, q));
+    hipLaunchKernelGGL(k_ib_eu, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, ib->eval, ib->t_un, ib->g_nf);
+    hipLaunchKernelGGL(k_ib_sub, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->r2, ib->g_nf, ib->rhsf);
+    PIB_CHK(dense_apply_raw(ib->fsol, ib->rhsf, ib->y_nf, q));
+    hipLaunchKernelGGL(k_ib_neg, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->y_nf, ib->df);
+    // u = u* - BNG dP + BNH df ; p += dP ; f += df
+    hipLaunchKernelGGL(k_ib_axpy, dim3(blocks_for(UN)), dim3(256), 0, q, UN, -1.0, ib->t_un, ns->U);
+    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ns->dt, ib->hcols, ib->hptr, ib->hrow,
+                       ib->hval, ib->df, ns->U);
+    hipLaunchKernelGGL(k_ib_axpy, dim3(blocks_for(pN)), dim3(256), 0, q, pN, 1.0, ns->dP, ns->p);
+    hipLaunchKernelGGL(k_ib_axpy, dim3(blocks_for(nf)), dim3(256), 0, q, nf, 1.0, ib->df, ib->f);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+
 int ib_update_forces(pib_ns *ns)
 {
     IbState *ib = ns->ib;
@@ -485,6 +571,53 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     if ((err = palloc(&ib->f)) || (err = palloc(&ib->df)) || (err = palloc(&ib->rhsf)) || (err = palloc(&ib->ub))) return bail(err);
     if ((err = ib_assemble(ns, ib, coords))) return bail(err);
     ns->ib = ib;
+    return 0;
+}
+
+/* IBPMSolver (applications/ibpm): pressure and Lagrangian forces solved as one unknown.  Needs bodies and a direct
+ * forces solver (its explicit inverse of EBNH is part of the operator). */
+int pib_ns_set_coupled(pib_ns *ns, int coupled)
+{
+    using namespace pib;
+    if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
+    if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_set_coupled: the flow has no immersed bodies");
+    IbState *ib = ns->ib;
+    PIB_HIP(hipSetDevice(ns->device));
+    if (!coupled) {
+        ib->coupled = false;
+        ns->psol->post_matmult = nullptr;
+        ns->psol->post_ctx = nullptr;
+        if (ns->psol->graph) {
+            (void)hipGraphExecDestroy(ns->psol->graph);
+            ns->psol->graph = nullptr;
+        }
+        ns->psol->graph_key = 0;
+        return 0;
+    }
+    if (ib->moving) return fail(PIB_ERR_SUP, "pib_ns_set_coupled: prescribed body motion belongs to the decoupled solver");
+    if (ib->fsol->dense_inv == nullptr)
+        return fail(PIB_ERR_SUP, "pib_ns_set_coupled: the forces solver must be the direct one (-forces_ksp_type preonly -forces_pc_type lu)");
+    if (ib->t_un == nullptr) {
+        auto palloc = [&](double **p, int64_t n) -> int {
+            PIB_HIP(hipMalloc(p, sizeof(double) * (size_t)n));
+            PIB_HIP(hipMemset(*p, 0, sizeof(double) * (size_t)n));
+            ib->persistent.push_back(*p);
+            return 0;
+        };
+        PIB_CHK(palloc(&ib->t_un, ns->D.UN));
+        PIB_CHK(palloc(&ib->t_un2, ns->D.UN));
+        PIB_CHK(palloc(&ib->g_nf, ib->I.nf));
+        PIB_CHK(palloc(&ib->y_nf, ib->I.nf));
+        PIB_CHK(palloc(&ib->r2, ib->I.nf));
+    }
+    ib->coupled = true;
+    ns->psol->post_matmult = ib_schur_term;
+    ns->psol->post_ctx = ns;
+    if (ns->psol->graph) {  // an iteration captured without the term must not be replayed
+        (void)hipGraphExecDestroy(ns->psol->graph);
+        ns->psol->graph = nullptr;
+    }
+    ns->psol->graph_key = 0;
     return 0;
 }
 

@@ -550,6 +550,14 @@ static int matmult(pib_solver *s, double *p_owned, double *w, double *dot_part, 
     // the velocity operator from its mesh tables (same bits as the CSR product, 56 instead of 104 B/row)
     if (s->vel.valid && s->cfg.matrix_free_velocity && dot_part == nullptr && s->comm.nranks == 1)
         return vel_stencil_apply(s, p_owned, w, guarded, stq);
+    if (s->post_matmult != nullptr) {
+        // operator = matrix + a term applied by the hook: the fused p.w of the SpMV would miss it
+        if (stencil_matmult_ok(s)) PIB_CHK(stencil_matmult(s, p_owned, w, nullptr, guarded, stq));
+        else PIB_CHK(spmv_rows(s, p_owned, w, 0, s->A.n, nullptr, guarded, stq));
+        PIB_CHK(s->post_matmult(s, p_owned, w, guarded, stq, s->post_ctx));
+        if (dot_part) PIB_CHK(dot_partials(s, p_owned, w, dot_part, guarded, stq));
+        return 0;
+    }
     if (stencil_matmult_ok(s)) return stencil_matmult(s, p_owned, w, dot_part, guarded, stq);
     return spmv_rows(s, p_owned, w, 0, s->A.n, dot_part, guarded, stq);
 }

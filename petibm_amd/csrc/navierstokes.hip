@@ -512,6 +512,66 @@ __global__ __launch_bounds__(256) void k_ns_project(NsDev D, double dt, const do
     }
 }
 
+// out = BNG phi (BNG = dt G): the row of k_ns_project, stored instead of subtracted
+__global__ __launch_bounds__(256) void k_ns_bng(NsDev D, double dt, const double *__restrict__ phi, double *__restrict__ out)
+{
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < D.UN; g += (int64_t)gridDim.x * 256) {
+        int f = 0;
+        if (D.dim > 1 && g >= D.f[1].off) f = 1;
+        if (D.dim > 2 && g >= D.f[2].off) f = 2;
+        const NsField &F = D.f[f];
+        const int64_t q = g - F.off;
+        const int64_t i = q % F.n[0], j = (q / F.n[0]) % F.n[1], k = q / (F.n[0] * F.n[1]);
+        const int64_t ijk[3] = {i, j, k};
+        const double gv = 1.0 / F.dl[f][ijk[f] + 1];
+        const int64_t pst[3] = {1, D.pn[0], D.pn[0] * D.pn[1]};
+        const int64_t pc = i + D.pn[0] * (j + D.pn[1] * k);
+        double r;
+        if (ijk[f] < D.pn[f] - 1) {
+            r = 0.0 + (dt * (-gv)) * phi[pc];
+            r = r + (dt * gv) * phi[pc + pst[f]];
+        } else {
+            r = 0.0 + (dt * gv) * phi[pc - (D.pn[f] - 1) * pst[f]];
+            r = r + (dt * (-gv)) * phi[pc];
+        }
+        out[g] = r;
+    }
+}
+
+// w = w - D t over the pressure cells (D without the boundary correction: the rows of k_ns_rhs_poisson); the identity
+// row of a pinned pressure is left alone
+__global__ __launch_bounds__(256) void k_ns_div_sub(NsDev D, int pinned, const double *__restrict__ t, double *__restrict__ w)
+{
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < D.pN; c += (int64_t)gridDim.x * 256) {
+        if (pinned && c == 0) continue;
+        const int64_t i = c % D.pn[0], j = (c / D.pn[0]) % D.pn[1], k = c / (D.pn[0] * D.pn[1]);
+        const int64_t ijk[3] = {i, j, k};
+        const double wx = D.pw[0][i], wy = D.pw[1][j], wz = (D.dim == 3) ? D.pw[2][k] : 1.0;
+        const double area[3] = {wy * wz, wx * wz, wx * wy};
+        double s = 0.0;
+        for (int f = 0; f < D.dim; ++f) {
+            const NsField &F = D.f[f];
+            const int64_t st = (f == 0) ? 1 : (f == 1 ? F.n[0] : F.n[0] * F.n[1]);
+            const int64_t s_ = ijk[f];
+            const bool per = (D.per >> f) & 1;
+            const bool has_m = s_ > 0 || per, has_p = s_ < F.n[f];
+            int64_t fi[3] = {i, j, k};
+            fi[f] = has_p ? s_ : s_ - 1;
+            const int64_t base = fidx(F, fi[0], fi[1], fi[2]);
+            if (per) {
+                const int64_t im = (s_ > 0) ? base - st : base + (F.n[f] - 1) * st;
+                s = s + (-area[f]) * t[im];
+                s = s + area[f] * t[base];
+                continue;
+            }
+            // ghost faces carry a0 = 0 for the normal component (Dirichlet / convective): no column
+            if (has_m) s = s + (-area[f]) * t[has_p ? base - st : base];
+            if (has_p) s = s + area[f] * t[base];
+        }
+        w[c] = w[c] - s;
+    }
+}
+
 // u = u - BNG dP with the assembled BNG (BN order > 1: bn.hip), row sums in column order ; p = p + dP
 __global__ __launch_bounds__(256) void k_ns_project_csr(int64_t UN, int64_t pN, const int32_t *__restrict__ rp,
                                                         const int32_t *__restrict__ col, const double *__restrict__ val,
@@ -528,6 +588,23 @@ __global__ __launch_bounds__(256) void k_ns_project_csr(int64_t UN, int64_t pN, 
     }
 }
 
+}  // namespace pib
+
+namespace pib {
+int ns_bng_apply(pib_ns *ns, const double *phi, double *out, hipStream_t q)
+{
+    const NsDev &D = ns->D;
+    hipLaunchKernelGGL(k_ns_bng, dim3((unsigned)std::min<int64_t>(4096, (D.UN + 255) / 256)), dim3(256), 0, q, D, ns->dt, phi, out);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+int ns_div_sub(pib_ns *ns, const double *t, double *w, hipStream_t q)
+{
+    const NsDev &D = ns->D;
+    hipLaunchKernelGGL(k_ns_div_sub, dim3((unsigned)std::min<int64_t>(4096, (D.pN + 255) / 256)), dim3(256), 0, q, D, ns->pinned, t, w);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
 }  // namespace pib
 
 static int ghost_blocks(const pib::NsDev &D) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (D.nghost + 255) / 256)); }
@@ -936,9 +1013,19 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         if (ns->ib) PIB_CHK(ib_spread_forces(ns));  // rhs1 += H f  (decoupledibpm.cpp:243)
         PIB_HIP(hipStreamSynchronize(ns->stream));
         PIB_CHK(pib_solve(ns->vsol, ns->U, ns->rhs1));  // vSolver->solve(UGlobal, rhs1)  (:532)
-        if (ns->ib) PIB_CHK(ib_solve_forces(ns));   // assembleRHSForces, solveForces, applyNoSlip (decoupledibpm.cpp:116-118)
+        const bool coupled = ib_is_coupled(ns);
+        if (ns->ib && !coupled) PIB_CHK(ib_solve_forces(ns));   // assembleRHSForces, solveForces, applyNoSlip (decoupledibpm.cpp:116-118)
         hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns->pinned, ns->U, ns->rhs2);
         PIB_HIP(hipGetLastError());
+        if (coupled) {
+            // IBPMSolver (applications/ibpm): pressure and forces are one unknown; solved here through the Schur
+            // complement on the pressure, then u = u* - BN [G, -H] [dP; df], p += dP, f += df
+            PIB_CHK(ib_coupled_solve_and_project(ns));
+            hipLaunchKernelGGL(k_ns_ghosts<2>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);
+            PIB_HIP(hipGetLastError());
+            ns->steps++;
+            continue;
+        }
         PIB_HIP(hipStreamSynchronize(ns->stream));
         PIB_CHK(pib_solve(ns->psol, ns->dP, ns->rhs2));  // pSolver->solve(dP, rhs2)      (:575)
         if (ns->bn_order > 1)

@@ -59,6 +59,12 @@ __device__ __forceinline__ int64_t fidx(const NsField &F, int64_t i, int64_t j, 
 
 struct IbState;
 void ib_release(IbState *ib);
+// coupled IBPM (applications/ibpm): the pressure / forces solve and the projection of one step (ibm.hip)
+bool ib_is_coupled(const pib_ns *ns);
+int ib_coupled_solve_and_project(pib_ns *ns);
+// out = BNG phi = dt G phi on the whole velocity vector ; w -= D t (row 0 untouched when the pressure is pinned)
+int ns_bng_apply(pib_ns *ns, const double *phi, double *out, hipStream_t q);
+int ns_div_sub(pib_ns *ns, const double *t, double *w, hipStream_t q);
 // the extra stages of DecoupledIBPMSolver::advance (decoupledibpm.cpp:105-131)
 int ib_spread_forces(pib_ns *ns);   // rhs1 += H f
 int ib_solve_forces(pib_ns *ns);    // rhsf = -E u ; EBNH df = rhsf ; u += BNH df

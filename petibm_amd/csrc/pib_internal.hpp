@@ -198,6 +198,10 @@ struct pib_solver {
     std::string gmg_error;  // why the hierarchy could not be built (reported when a multigrid solve is asked for)
     int periodic[3] = {0, 0, 0};             // pib_set_periodic: problem directions x, y[, z]
     pib::VelStencil vel;                     // matrix-free twin of the velocity operator (velstencil.hip)
+    // w <- w + (low-rank term) after every Krylov product: the coupled immersed-boundary operator (ibm.hip) turns the
+    // Poisson solve into the solve of its Schur complement
+    int (*post_matmult)(pib_solver *s, const double *p, double *w, bool guarded, hipStream_t q, void *ctx) = nullptr;
+    void *post_ctx = nullptr;
     bool hint_pc_only = false;               // the grid structure describes the preconditioner's operator only (BN order > 1)
     std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
     double asm_dt = 0.0;
@@ -284,6 +288,8 @@ int upload_vec(const std::vector<double> &h, double **d);
 // gmg.hip
 int gmg_verify(pib_solver *s);
 int stencil_apply(pib_solver *s, double *x_owned, double *y, hipStream_t st);
+int dense_apply_raw(const pib_solver *s, const double *b, double *y, hipStream_t q);
+int dot_partials(pib_solver *s, const double *x, const double *y, double *part, bool guarded, hipStream_t q);
 bool stencil_matmult_ok(const pib_solver *s);
 int stencil_matmult(pib_solver *s, const double *x, double *y, double *dot_part, bool guarded, hipStream_t q);
 int spmv_launch_blocks();

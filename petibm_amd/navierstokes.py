@@ -361,3 +361,13 @@ class DecoupledIBPMSolver(NavierStokesSolver):
         capi.check(lib.pib_ns_get_ib_operator(self._h, w, C.byref(nr), C.byref(nz), rp.ctypes.data, cl.ctypes.data,
                                               vl.ctypes.data, None if ids is None else ids.ctypes.data))
         return (nr.value, rp, cl, vl) if ids is None else (nr.value, rp, cl, vl, ids)
+
+
+class IBPMSolver(DecoupledIBPMSolver):
+    """Mirror of IBPMSolver (applications/ibpm/ibpm.h:30-111): the coupled immersed-boundary projection method -- same
+    construction as the decoupled solver, pressure and forces solved as one unknown (pib_ns_set_coupled)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        capi.check(capi.load().pib_ns_set_coupled(self._h, 1))
+
