@@ -248,6 +248,19 @@ protected:
     std::vector<double> coords;
 };
 
+/** \brief Mirror of IBPMSolver (applications/ibpm/ibpm.h:30-111): the coupled immersed-boundary projection method --
+ *  pressure and Lagrangian forces solved as one unknown; same construction as the decoupled solver. */
+class IBPMSolver : public DecoupledIBPMSolver
+{
+public:
+    ErrorCode init(const FlowConfig &cfg, const std::vector<std::vector<double>> &bodies, int device = -1) override
+    {
+        ErrorCode ierr = DecoupledIBPMSolver::init(cfg, bodies, device);
+        if (ierr) return ierr;
+        return pib_ns_set_coupled(ns, 1);
+    }
+};
+
 /** \brief Mirror of RigidKinematicsSolver (applications/rigidkinematics/rigidkinematics.cpp:68-160): the user supplies
  *  the kinematics by overriding setCoordinatesBodies / setVelocityBodies exactly as in the reference's API example
  *  (examples/api_examples/oscillatingcylinder2dRe100_GPU/oscillatingcylinder.cpp). */
