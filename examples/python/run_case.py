@@ -3,8 +3,9 @@
 
     python examples/python/run_case.py examples/cases/cylinder2dRe40 [--nt N]
 
-Picks the flow solver the way the reference's two applications do (applications/navierstokes/main.cpp,
-applications/decoupledibpm/main.cpp): immersed bodies -> decoupled IBPM, none -> Navier-Stokes.  Writes
+Picks the flow solver the way the reference's applications do (applications/navierstokes/main.cpp,
+applications/decoupledibpm/main.cpp): immersed bodies -> decoupled IBPM, none -> Navier-Stokes; --app ibpm selects the
+coupled IBPM of applications/ibpm.  Writes
 output/iterations-<start>.txt (ite, iterations and residual per solver: navierstokes.cpp:766-794,
 decoupledibpm.cpp:399-434) and, with bodies, output/forces-<start>.txt (t, fx, fy[, fz] per body:
 decoupledibpm.cpp:437-465), output/grid.h5 and the solution / restart files output/<step>.h5 (every nsave / nrestart
@@ -34,6 +35,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("directory")
     ap.add_argument("--nt", type=int, default=None, help="number of time steps (default: parameters.nt)")
+    ap.add_argument("--app", default="auto", choices=["auto", "navierstokes", "decoupledibpm", "ibpm"],
+                    help="which of the reference's applications to mirror (auto: decoupledibpm when the case has bodies)")
     a = ap.parse_args()
     d = os.path.abspath(a.directory)
     cfg = yaml.safe_load(open(os.path.join(d, "config.yaml")))
@@ -42,9 +45,11 @@ def main():
     start = int(par.get("startStep", 0))
     texts = {k: solver_text(cfg, k, d) for k in ("velocitySolver", "poissonSolver", "forcesSolver")}
     kw = {"velocity_cfg": texts["velocitySolver"], "poisson_cfg": texts["poissonSolver"]}
+    if a.app == "navierstokes":
+        cfg = dict(cfg, bodies=None)
     if cfg.get("bodies"):
-        s = navierstokes.DecoupledIBPMSolver(cfg, forces_cfg=texts["forcesSolver"] or navierstokes.DEFAULT_FORCES_CFG,
-                                             directory=d, **kw)
+        cls = navierstokes.IBPMSolver if a.app == "ibpm" else navierstokes.DecoupledIBPMSolver  # applications/ibpm: coupled
+        s = cls(cfg, forces_cfg=texts["forcesSolver"] or navierstokes.DEFAULT_FORCES_CFG, directory=d, **kw)
     else:
         s = navierstokes.NavierStokesSolver(cfg, **kw)
     out = os.path.join(d, "output")
