@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
 // cells is loaded before the march (the 1-D arrays alone cost ~55 vector-memory instructions per thread and plane
 // otherwise).  Same expressions in the same order as modes 1 and 2: bit-identical (tools/fuse_lab.hip: 1.34 -> 0.78 ms
 // per 512^3 pair).  Levels that are whole on this rank, not periodic, 3-D, nx % 128 == 0, ny % 8 == 0.
-constexpr int FX = 128, FY = 8, FZ = 64, FSX = FX + 2, FSY = FY + 2;
+constexpr int FX = 128, FY = 8, FSX = FX + 2, FSY = FY + 2;
 struct FCell {
     double wx, wy, gxm, gxp, gym, gyp;
 };
@@ -284,7 +284,7 @@ __device__ __forceinline__ double fdiag(const FCell &q, double wzk, double gzm, 
 }
 __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                     const double *__restrict__ b, double *__restrict__ xo,
-                                                    const double *__restrict__ pin_sum)
+                                                    const double *__restrict__ pin_sum, int FZ)
 {
     if (S != nullptr && S->done) return;
     __shared__ double x1[4][FSY][FSX];
@@ -346,6 +346,103 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
             out[c] = xcc + omega * ((bprev[c] - sum) / d);
         }
         *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = out;
+    }
+}
+
+// ---- one Jacobi step / residual, 2.5-D blocked (modes 2, 3, 8 of k_level on the levels k_presmooth2 serves): a workgroup
+// owns a 128 x 8 tile and marches through FZ planes; a thread keeps its cells' z neighbours in registers (the plane it
+// loads ahead becomes the centre, then the lower neighbour) and only the CURRENT plane (tile + one halo cell in x and y)
+// sits in LDS, double-buffered -- two vector loads, about one scalar load and one store per thread and plane instead of
+// six vector and two scalar loads: 0.76 instead of 0.88 ms per 512^3 sweep (tools/fuse_lab.hip), same expressions in the
+// same order (modes 2 and 3 bit-identical; mode 8's sums are grouped by tile instead of by line segment, i.e. equal to
+// rounding).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
+                                                     const double *__restrict__ b, const double *__restrict__ xi,
+                                                     double *__restrict__ xo, const double *__restrict__ pin_sum,
+                                                     double *__restrict__ part, int part_stride, int FZ)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ double sp[2][FSY][FSX];
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, k0 = blockIdx.z * FZ;
+    const int64_t plane = (int64_t)L.nx * L.ny;
+    const int j = j0 + ty, ic = i0 + 4 * tx;
+    const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
+    const int hx_col = (tid & 1) ? FX : -1, hx_y = (tid >> 1) & 7;
+    const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
+    const bool hy_ok = hyj >= 0 && hyj < L.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < L.nx;
+    const int64_t off_c = (int64_t)j * L.nx + ic, off_hy = (int64_t)hyj * L.nx + hyi, off_hx = (int64_t)hxj * L.nx + hxi;
+    FCell q4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = fcell(L, ic + c, j);
+    const int kend = (k0 + FZ < L.nzg) ? k0 + FZ : L.nzg;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0};
+    if (k0 > 0) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(k0 - 1) * plane + off_c);
+    xc = *reinterpret_cast<const v4 *>(xi + (int64_t)k0 * plane + off_c);
+    for (int kk = k0; kk < kend; ++kk) {
+        const int slot = kk & 1;
+        const double *px = xi + (int64_t)kk * plane;
+        if (kk + 1 < L.nzg) zp = *reinterpret_cast<const v4 *>(px + plane + off_c);
+        v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)kk * plane + off_c);
+        const v4 braw = bv;
+        if (pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
+        sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? px[off_hy] : 0.0;
+        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? px[off_hx] : 0.0;
+        __syncthreads();
+        const double wzk = L.wz[kk];
+        const double gzm = (kk > 0) ? L.gz[kk - 1] : 0.0, gzp = (kk < L.nzg - 1) ? L.gz[kk] : 0.0;
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ic + c, lx = 4 * tx + 1 + c;
+            const FCell &q = q4[c];
+            const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
+            const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
+            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
+            const double xcc = xc[c];
+            double sum = 0.0;
+            if (i > 0) sum += c0 * (sp[slot][ty + 1][lx - 1] - xcc);
+            if (i < L.nx - 1) sum += c1 * (sp[slot][ty + 1][lx + 1] - xcc);
+            if (j > 0) sum += c2 * (sp[slot][ty][lx] - xcc);
+            if (j < L.ny - 1) sum += c3 * (sp[slot][ty + 2][lx] - xcc);
+            if (kk > 0) sum += c4 * (zm[c] - xcc);
+            if (kk < L.nzg - 1) sum += c5 * (zp[c] - xcc);
+            if (MODE == 3)
+                out[c] = bv[c] - sum;
+            else {
+                out[c] = xcc + omega * ((bv[c] - sum) / d);
+                if (MODE == 8) {
+                    acc0 += out[c] * braw[c];
+                    acc1 += out[c] * out[c];
+                    acc2 += out[c];
+                }
+            }
+        }
+        *reinterpret_cast<v4 *>(xo + (int64_t)kk * plane + off_c) = out;
+        zm = xc;
+        xc = zp;
+    }
+    if (MODE == 8) {
+        __shared__ double sh[3][4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        double v[3] = {acc0, acc1, acc2};
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[k2] += __shfl_down(v[k2], o, 64);
+            if (lane == 0) sh[k2][w] = v[k2];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int k2 = threadIdx.x;
+            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            part[(int64_t)k2 * part_stride + blk] = (sh[k2][0] + sh[k2][1]) + (sh[k2][2] + sh[k2][3]);
+        }
     }
 }
 
@@ -1227,6 +1324,17 @@ static int halo_level(pib_solver *s, const GridLevel &g, double *x_owned, hipStr
 
 // all-gather the owned coarse planes of level `lc` (ownership = the parents of the finer level's slab planes) into the
 // replicated level vector
+// levels the LDS-tiled kernels (k_presmooth2, k_level_march) serve: whole on this rank, not periodic, 3-D, tile-divisible
+static bool march_ok(const pib_solver *s, const GridLevel &g)
+{
+    const bool whole = (s->comm.nranks == 1) || g.replicated;
+    // a march needs enough tiles x plane chunks to fill the chip: levels of at least 2^24 cells
+    return whole && g.per == 0 && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && g.k0 == 0 &&
+           g.k1 == g.n[2] && g.nloc >= (int64_t)s->cfg.march_min_cells;
+}
+// planes per workgroup: 64 on a 512^3 level (2048 workgroups), 16 on a 256^3 one (1024)
+static int march_planes(const GridLevel &g) { return g.nloc >= ((int64_t)1 << 26) ? 64 : 16; }
+
 static int gather_level(pib_solver *s, int lc, int64_t coarse_plane, const double *owned, int64_t n_owned,
                         double *full_owned_base, hipStream_t q)
 {
@@ -1263,6 +1371,21 @@ static int launch_level(pib_solver *s, const GridLevel &g, double omega, const d
     const Scalars *S = guarded ? s->d_s : nullptr;
     const int64_t nx = g.n[0], ny = g.n[1];
     const unsigned nk = (unsigned)std::max<int64_t>(1, g.k1 - g.k0);
+    if ((MODE == 2 || MODE == 3 || MODE == 8) && s->cfg.march_levels && march_ok(s, g) &&
+        ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(xi) | reinterpret_cast<uintptr_t>(xo)) & 31u) == 0) {
+        constexpr int M = (MODE == 3) ? 3 : (MODE == 8 ? 8 : 2);
+        const int FZ = march_planes(g);
+        const dim3 mg((unsigned)(nx / FX), (unsigned)(ny / FY), (unsigned)((g.n[2] + FZ - 1) / FZ));
+        hipLaunchKernelGGL((k_level_march<M>), mg, dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, part, part_stride, FZ);
+        PIB_HIP(hipGetLastError());
+        if (MODE == 8) {
+            double *stage = part + 3 * (int64_t)part_stride;
+            hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)(mg.x * mg.y * mg.z), stage);
+            hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
+            PIB_HIP(hipGetLastError());
+        }
+        return 0;
+    }
     auto aligned = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const bool vec_ok = aligned(b) && aligned(xi) && aligned(xo) && aligned(dvec);
     auto gx = [&](int c) { return dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (nx / c * ny + 255) / 256)), nk); };
@@ -1304,10 +1427,7 @@ static int launch_level_planes(pib_solver *s, const GridLevel &g, int64_t kb, in
 // the fused first two pre-smoothing steps (k_presmooth2) apply to this level
 static bool presmooth2_ok(const pib_solver *s, const GridLevel &g)
 {
-    if (!s->cfg.fuse_presmooth) return false;
-    const bool whole = (s->comm.nranks == 1) || g.replicated;
-    return whole && g.per == 0 && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && g.k0 == 0 &&
-           g.k1 == g.n[2];
+    return s->cfg.fuse_presmooth && march_ok(s, g);
 }
 
 // One V-cycle: z = M^-1 r.   r, z: ghost-padded work vectors of the Krylov solver
@@ -1344,8 +1464,9 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             if (from_zero && sw == 0 && nsteps >= 2 && !cheb && presmooth2_ok(s, g) &&
                 (reinterpret_cast<uintptr_t>(b) & 31u) == 0 && (reinterpret_cast<uintptr_t>(c) & 31u) == 0) {
                 // steps 0 and 1 in one kernel; the result lands where step 1 would have put it
+                const int FZ = march_planes(g);
                 hipLaunchKernelGGL(k_presmooth2, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
-                                   dim3(256), 0, q, S, dev_of(g), omega, b, c, pin_l);
+                                   dim3(256), 0, q, S, dev_of(g), omega, b, c, pin_l, FZ);
                 PIB_HIP(hipGetLastError());
                 std::swap(a, c);
                 sw = 1;

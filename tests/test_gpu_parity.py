@@ -723,7 +723,7 @@ def test_fused_presmoothing_pair_is_bit_identical(lin, n, pinned):
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
     for fuse in (1, 0):
-        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_fuse_presmooth={fuse}\n"))
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_fuse_presmooth={fuse}\n"))
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)
         s.solve(x, b)
@@ -735,3 +735,29 @@ def test_fused_presmoothing_pair_is_bit_identical(lin, n, pinned):
     assert iters_close(out[0][2], ref["iters"])
     ke = min(len(out[0][1]), len(ref["history"]), 6)
     assert np.allclose(out[0][1][:ke], ref["history"][:ke], rtol=1e-8)
+
+
+@pytest.mark.parametrize("n,pinned", [((128, 16, 12), False), ((128, 24, 70), True)])
+def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
+    """gmg.hip k_level_march (2.5-D blocked Jacobi step / residual on levels with nx % 128 == 0, ny % 8 == 0): the
+    same arithmetic as k_level modes 2 and 3; mode 8 groups its sums by tile, so the PCG scalars agree to rounding."""
+    from petibm_amd import capi
+    cfg = stretched_3d(n, r=(1.01, 0.97, 1.04))
+    dt = 0.01
+    m, A, _ = poisson_system(cfg, dt=dt, pinned=pinned)
+    xs, b = rhs_for(A, zero_mean=not pinned)
+    if pinned:
+        b[0] = 0.0
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    out = []
+    for march in (1, 0):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_march_levels={march}\n"))
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        out.append((x, s.getResidualHistory(), s.getIters()))
+        s.destroy()
+    assert out[0][2] == out[1][2]
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-9)
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * np.abs(out[1][0]).max()
+    assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)

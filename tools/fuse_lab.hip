@@ -324,6 +324,79 @@ __global__ __launch_bounds__(256) void k_fused_pair(L l, double omega, const dou
     }
 }
 
+// ---- ONE general Jacobi step, 2.5-D blocked: a workgroup owns a TX x TY tile and marches through KZ planes; a thread keeps
+// its cells' z neighbours in registers (the plane it loads ahead becomes the centre, then the lower neighbour) and only the
+// CURRENT plane (tile + one halo cell in x and y) sits in LDS, double-buffered: 2 vector loads + ~1 scalar + 1 store per
+// thread and plane instead of 6 vector + 2 scalar loads.
+template <int KZ, int XCD>
+__global__ __launch_bounds__(256) void k_sweep_march(L l, double omega, const double *__restrict__ b, const double *__restrict__ xi,
+                                                     double *__restrict__ xo)
+{
+    __shared__ double sp[2][SY][SX];
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (XCD) {
+        // workgroup b runs on XCD b % 8: give every XCD a contiguous range of tiles (y fastest, then x, then z chunks) so
+        // that the y-halo rows of a tile are fetched by the L2 that also serves its neighbours
+        const unsigned nb = gridDim.x, per = nb >> 3;
+        const unsigned t = (nb & 7u) ? blockIdx.x : (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        const unsigned ntx = l.nx / TX, nty = l.ny / TY;
+        by = t % nty;
+        bx = (t / nty) % ntx;
+        bz = t / (nty * ntx);
+    }
+    const int i0 = bx * TX, j0 = by * TY, k0 = bz * KZ;
+    const int64_t plane = (int64_t)l.nx * l.ny;
+    const int j = j0 + ty, ic = i0 + 4 * tx;
+    const int hy_row = (tid < 128) ? -1 : TY, hy_x = tid & 127;
+    const int hx_col = (tid & 1) ? TX : -1, hx_y = (tid >> 1) & 7;
+    const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
+    const bool hy_ok = hyj >= 0 && hyj < l.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < l.nx;
+    const int64_t off_c = (int64_t)j * l.nx + ic, off_hy = (int64_t)hyj * l.nx + hyi, off_hx = (int64_t)hxj * l.nx + hxi;
+    Cell1 q4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = cell1(l, ic + c, j);
+    const int kend = (k0 + KZ < l.nz) ? k0 + KZ : l.nz;
+    v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0};
+    if (k0 > 0) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(k0 - 1) * plane + off_c);
+    xc = *reinterpret_cast<const v4 *>(xi + (int64_t)k0 * plane + off_c);
+    for (int kk = k0; kk < kend; ++kk) {
+        const int slot = kk & 1;
+        const double *px = xi + (int64_t)kk * plane;
+        if (kk + 1 < l.nz) zp = *reinterpret_cast<const v4 *>(px + plane + off_c);
+        const v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)kk * plane + off_c);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
+        sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? px[off_hy] : 0.0;
+        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? px[off_hx] : 0.0;
+        __syncthreads();
+        const double wzk = l.wz[kk];
+        const double gzm = (kk > 0) ? l.gz[kk - 1] : 0.0, gzp = (kk < l.nz - 1) ? l.gz[kk] : 0.0;
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ic + c, lx = 4 * tx + 1 + c;
+            const Cell1 &q = q4[c];
+            const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
+            const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
+            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
+            const double xcc = xc[c];
+            double s = 0.0;
+            if (i > 0) s += c0 * (sp[slot][ty + 1][lx - 1] - xcc);
+            if (i < l.nx - 1) s += c1 * (sp[slot][ty + 1][lx + 1] - xcc);
+            if (j > 0) s += c2 * (sp[slot][ty][lx] - xcc);
+            if (j < l.ny - 1) s += c3 * (sp[slot][ty + 2][lx] - xcc);
+            if (kk > 0) s += c4 * (zm[c] - xcc);
+            if (kk < l.nz - 1) s += c5 * (zp[c] - xcc);
+            out[c] = xcc + omega * ((bv[c] - s) / d);
+        }
+        *reinterpret_cast<v4 *>(xo + (int64_t)kk * plane + off_c) = out;
+        zm = xc;
+        xc = zp;
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 512;
@@ -379,6 +452,35 @@ int main(int argc, char **argv)
         CK(hipMalloc(&o2, 8 * N));
         CK(hipMemcpy(x0, b, 8 * N, hipMemcpyDeviceToDevice));
         timeit("two general steps, two kernels", [&] {
+            hipLaunchKernelGGL(k_m2<4>, dim3((plane / 4 + 255) / 256, n), dim3(256), 0, 0, l, 0.9, b, x0, t1);
+            hipLaunchKernelGGL(k_m2<4>, dim3((plane / 4 + 255) / 256, n), dim3(256), 0, 0, l, 0.9, b, t1, r2);
+        });
+        timeit("ONE general step, streaming kernel (product's mode 2)", [&] {
+            hipLaunchKernelGGL(k_m2<4>, dim3((plane / 4 + 255) / 256, n), dim3(256), 0, 0, l, 0.9, b, x0, t1); });
+        CK(hipMemcpy(r2, t1, 8 * N, hipMemcpyDeviceToDevice));
+        for (int rep = 0; rep < 1; ++rep) {
+            timeit("ONE general step, 2.5-D blocked, KZ 32", [&] {
+                hipLaunchKernelGGL((k_sweep_march<32, 0>), dim3(n / TX, n / TY, n / 32), dim3(256), 0, 0, l, 0.9, b, x0, o2); });
+            timeit("ONE general step, 2.5-D blocked, KZ 64", [&] {
+                hipLaunchKernelGGL((k_sweep_march<64, 0>), dim3(n / TX, n / TY, n / 64), dim3(256), 0, 0, l, 0.9, b, x0, o2); });
+            timeit("ONE general step, 2.5-D blocked, KZ 32, XCD ranges", [&] {
+                hipLaunchKernelGGL((k_sweep_march<32, 1>), dim3((n / TX) * (n / TY) * (n / 32)), dim3(256), 0, 0, l, 0.9, b, x0, o2); });
+            timeit("ONE general step, 2.5-D blocked, KZ 64, XCD ranges", [&] {
+                hipLaunchKernelGGL((k_sweep_march<64, 1>), dim3((n / TX) * (n / TY) * (n / 64)), dim3(256), 0, 0, l, 0.9, b, x0, o2); });
+            timeit("ONE general step, 2.5-D blocked, KZ 16, XCD ranges", [&] {
+                hipLaunchKernelGGL((k_sweep_march<16, 1>), dim3((n / TX) * (n / TY) * (n / 16)), dim3(256), 0, 0, l, 0.9, b, x0, o2); });
+        }
+        {
+            std::vector<double> a0(1 << 22), a1(1 << 22);
+            int64_t bad1 = 0;
+            for (int64_t off : {int64_t(0), N / 2 - (int64_t)a0.size() / 2, N - (int64_t)a0.size()}) {
+                CK(hipMemcpy(a0.data(), r2 + off, 8 * a0.size(), hipMemcpyDeviceToHost));
+                CK(hipMemcpy(a1.data(), o2 + off, 8 * a0.size(), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < a0.size(); ++i) bad1 += (a0[i] != a1[i]);
+            }
+            printf("  2.5-D step vs streaming step: mismatching values %lld\n", (long long)bad1);
+        }
+        timeit("two general steps, two kernels (again)", [&] {
             hipLaunchKernelGGL(k_m2<4>, dim3((plane / 4 + 255) / 256, n), dim3(256), 0, 0, l, 0.9, b, x0, t1);
             hipLaunchKernelGGL(k_m2<4>, dim3((plane / 4 + 255) / 256, n), dim3(256), 0, 0, l, 0.9, b, t1, r2);
         });
