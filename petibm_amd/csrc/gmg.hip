@@ -366,7 +366,9 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
     __shared__ double sp[2][FSY][FSX];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, k0 = blockIdx.z * FZ;
+    // owned planes [L.k0, L.k0 + L.nk) of the level (a z-slab or a part of one); the vectors point at the first of them,
+    // the planes below / above hold the neighbours' values (halo planes) where they exist
+    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, l0 = blockIdx.z * FZ;
     const int64_t plane = (int64_t)L.nx * L.ny;
     const int j = j0 + ty, ic = i0 + 4 * tx;
     const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
@@ -377,16 +379,17 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
     FCell q4[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) q4[c] = fcell(L, ic + c, j);
-    const int kend = (k0 + FZ < L.nzg) ? k0 + FZ : L.nzg;
+    const int lend = (l0 + FZ < L.nk) ? l0 + FZ : L.nk;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0};
-    if (k0 > 0) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(k0 - 1) * plane + off_c);
-    xc = *reinterpret_cast<const v4 *>(xi + (int64_t)k0 * plane + off_c);
-    for (int kk = k0; kk < kend; ++kk) {
-        const int slot = kk & 1;
-        const double *px = xi + (int64_t)kk * plane;
+    if (L.k0 + l0 > 0) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(l0 - 1) * plane + off_c);
+    xc = *reinterpret_cast<const v4 *>(xi + (int64_t)l0 * plane + off_c);
+    for (int lk = l0; lk < lend; ++lk) {
+        const int kk = L.k0 + lk;  // global plane
+        const int slot = lk & 1;
+        const double *px = xi + (int64_t)lk * plane;
         if (kk + 1 < L.nzg) zp = *reinterpret_cast<const v4 *>(px + plane + off_c);
-        v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)kk * plane + off_c);
+        v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)lk * plane + off_c);
         const v4 braw = bv;
         if (pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
 #pragma unroll
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
                 }
             }
         }
-        *reinterpret_cast<v4 *>(xo + (int64_t)kk * plane + off_c) = out;
+        *reinterpret_cast<v4 *>(xo + (int64_t)lk * plane + off_c) = out;
         zm = xc;
         xc = zp;
     }
@@ -1332,8 +1335,16 @@ static bool march_ok(const pib_solver *s, const GridLevel &g)
     return whole && g.per == 0 && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && g.k0 == 0 &&
            g.k1 == g.n[2] && g.nloc >= (int64_t)s->cfg.march_min_cells;
 }
-// planes per workgroup: 64 on a 512^3 level (2048 workgroups), 16 on a 256^3 one (1024)
-static int march_planes(const GridLevel &g) { return g.nloc >= ((int64_t)1 << 26) ? 64 : 16; }
+// k_level_march also serves a slab (or a run of its planes: the interior part of produce_and_exchange): at least 8
+// planes and enough cells in the range
+static bool march_planes_ok(const pib_solver *s, const GridLevel &g)
+{
+    const int64_t nk = g.k1 - g.k0;
+    return g.per == 0 && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && nk >= 8 &&
+           nk * g.plane >= (int64_t)s->cfg.march_min_cells;
+}
+// planes per workgroup: 64 on a 512^3 range (2048 workgroups), 16 on a 256^3 one (1024)
+static int march_planes(const GridLevel &g) { return (g.k1 - g.k0) * g.plane >= ((int64_t)1 << 26) ? 64 : 16; }
 
 static int gather_level(pib_solver *s, int lc, int64_t coarse_plane, const double *owned, int64_t n_owned,
                         double *full_owned_base, hipStream_t q)
@@ -1371,11 +1382,11 @@ static int launch_level(pib_solver *s, const GridLevel &g, double omega, const d
     const Scalars *S = guarded ? s->d_s : nullptr;
     const int64_t nx = g.n[0], ny = g.n[1];
     const unsigned nk = (unsigned)std::max<int64_t>(1, g.k1 - g.k0);
-    if ((MODE == 2 || MODE == 3 || MODE == 8) && s->cfg.march_levels && march_ok(s, g) &&
+    if ((MODE == 2 || MODE == 3 || MODE == 8) && s->cfg.march_levels && march_planes_ok(s, g) &&
         ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(xi) | reinterpret_cast<uintptr_t>(xo)) & 31u) == 0) {
         constexpr int M = (MODE == 3) ? 3 : (MODE == 8 ? 8 : 2);
         const int FZ = march_planes(g);
-        const dim3 mg((unsigned)(nx / FX), (unsigned)(ny / FY), (unsigned)((g.n[2] + FZ - 1) / FZ));
+        const dim3 mg((unsigned)(nx / FX), (unsigned)(ny / FY), (unsigned)((nk + FZ - 1) / FZ));
         hipLaunchKernelGGL((k_level_march<M>), mg, dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, part, part_stride, FZ);
         PIB_HIP(hipGetLastError());
         if (MODE == 8) {

@@ -72,6 +72,9 @@ def _system(n, dt=0.01):
     (2, (32, 48), "AMG", "pib_agglomerate_below=10\n"),             # 2-D: slabs along y
     (4, (32, 32, 32), "AMG", "pib_agglomerate_below=100\nV22"),      # the bench's V(2,2) cycle on distributed levels
     (3, (16, 16, 36), "AMG", "V22"),
+    # the 2.5-D blocked level kernel (gmg.hip k_level_march) on slabs and on the interior run of the overlapped producers
+    (2, (128, 16, 40), "AMG", "pib_march_min_cells=0\nV22"),
+    (3, (128, 8, 48), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\nV22"),
 ])
 def test_multirank_poisson_solve_matches_single_rank(P, n, pc, extra):
     sweeps = 2 if extra.endswith("V22") else 1
