@@ -35,6 +35,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("directory")
     ap.add_argument("--nt", type=int, default=None, help="number of time steps (default: parameters.nt)")
+    ap.add_argument("--vorticity", action="store_true",
+                    help="append the vorticity fields of petibm-vorticity to every saved solution file (and their gridlines to grid.h5)")
     ap.add_argument("--app", default="auto", choices=["auto", "navierstokes", "decoupledibpm", "ibpm"],
                     help="which of the reference's applications to mirror (auto: decoupledibpm when the case has bodies)")
     a = ap.parse_args()
@@ -82,6 +84,8 @@ def main():
             f_file.write(f"{s.t:10.8e}\t" + "\t".join(f"{v:10.8e}" for v in avg.reshape(-1)) + "\t\n")
         if have_h5 and nsave > 0 and s.ite % nsave == 0:
             s.write(os.path.join(out, f"{s.ite:07d}.h5"))
+            if a.vorticity:
+                s.writeVorticity(os.path.join(out, f"{s.ite:07d}.h5"), os.path.join(out, "grid.h5"))
         if have_h5 and nrestart > 0 and s.ite % nrestart == 0:
             s.writeRestartData(os.path.join(out, f"{s.ite:07d}.h5"))
     wall = time.perf_counter() - t0

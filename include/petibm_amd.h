@@ -258,6 +258,10 @@ int pib_ns_set_time_integration(pib_ns *ns, const char *convection, const char *
 /* One explicit term kept between steps, for restart files with any scheme (/convection/<index>, /diffusion/<index>):
  * kind 0 convection, 1 diffusion; set != 0 uploads `host`, 0 downloads into it (UN entries). */
 int pib_ns_history_term(pib_ns *ns, int kind, int index, int set, double *host);
+/* The vorticity of the reference's post-processing utility petibm-vorticity (applications/vorticity/main.cpp:185-372,
+ * fields and their point sets :384-470), from the current velocity and ghost values: comp 0 wx, 1 wy, 2 wz (2-D: wz at
+ * the vertices).  n_out[3] receives the point counts; out == NULL only queries them. */
+int pib_ns_get_vorticity(pib_ns *ns, int comp, int64_t n_out[3], double *out);
 int pib_ns_sizes(pib_ns *ns, int64_t *UN, int64_t *pN);
 int pib_ns_set_state(pib_ns *ns, const double *U_packed_or_null, const double *p_or_null);        /* host arrays */
 int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs2);               /* any may be NULL */

@@ -351,3 +351,37 @@ class NavierStokes:
         self.U = self.U + (-1.0) * rhs1
         self.p = self.p + 1.0 * dP
         update_ghost_values(self.mesh, self.ghosts, self.U)  # navierstokes.cpp:263
+
+
+def vorticity(mesh: CartesianMesh, U: np.ndarray, ghosts) -> dict:
+    """petibm-vorticity (applications/vorticity/main.cpp:185-372; fields and point sets :384-470), restated index for
+    index on the ghost-padded local arrays: a local index -1 is the ghost layer, corners between two ghost layers keep
+    the local vectors' initial zero.  Returns {name: array (nz, ny, nx)}."""
+    q = ghost_padded(mesh, U, ghosts)  # [f][k+1, j+1, i+1]
+    n3 = [int(v) for v in mesh.n[3]]
+    n4 = [n3[d] + 1 if d < mesh.dim else 1 for d in range(3)]
+
+    def at(f, i, j, k):
+        return q[f][k + 1, j + 1, i + 1]
+
+    def co(f, d, s):
+        return np.array([mesh.coord[f][d][int(t)] for t in np.ravel(s)]).reshape(np.shape(s))
+
+    out = {}
+    if mesh.dim == 2:
+        j, i = np.meshgrid(np.arange(n4[1]), np.arange(n4[0]), indexing="ij")
+        k = np.zeros_like(i)
+        wz = (at(1, i, j - 1, k) - at(1, i - 1, j - 1, k)) / (co(1, 0, i) - co(1, 0, i - 1)) - \
+             (at(0, i - 1, j, k) - at(0, i - 1, j - 1, k)) / (co(0, 1, j) - co(0, 1, j - 1))
+        out["wz"] = wz
+        return out
+    k, j, i = np.meshgrid(np.arange(n4[2]), np.arange(n4[1]), np.arange(n3[0]), indexing="ij")
+    out["wx"] = (at(2, i - 1, j, k - 1) - at(2, i - 1, j - 1, k - 1)) / (co(2, 1, j) - co(2, 1, j - 1)) - \
+                (at(1, i - 1, j - 1, k) - at(1, i - 1, j - 1, k - 1)) / (co(1, 2, k) - co(1, 2, k - 1))
+    k, j, i = np.meshgrid(np.arange(n4[2]), np.arange(n3[1]), np.arange(n4[0]), indexing="ij")
+    out["wy"] = (at(0, i - 1, j - 1, k) - at(0, i - 1, j - 1, k - 1)) / (co(0, 2, k) - co(0, 2, k - 1)) - \
+                (at(2, i, j - 1, k - 1) - at(2, i - 1, j - 1, k - 1)) / (co(2, 0, i) - co(2, 0, i - 1))
+    k, j, i = np.meshgrid(np.arange(n3[2]), np.arange(n4[1]), np.arange(n4[0]), indexing="ij")
+    out["wz"] = (at(1, i, j - 1, k) - at(1, i - 1, j - 1, k)) / (co(1, 0, i) - co(1, 0, i - 1)) - \
+                (at(0, i - 1, j, k) - at(0, i - 1, j - 1, k)) / (co(0, 1, j) - co(0, 1, j - 1))
+    return out

@@ -71,6 +71,7 @@ _PROTOS = {
     "pib_ns_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double,
                                 C.c_char_p, C.c_char_p, C.c_int]),
     "pib_ns_set_bn_order": (C.c_int, [_vp, C.c_int]),
+    "pib_ns_get_vorticity": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "pib_ns_set_coupled": (C.c_int, [_vp, C.c_int]),
     "pib_ns_set_time_integration": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),
     "pib_ns_history_term": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),

@@ -32,18 +32,18 @@ namespace pib {
 __device__ __forceinline__ double vel(const NsDev &D, const double *__restrict__ U, int f, int64_t i, int64_t j, int64_t k)
 {
     const NsField &F = D.f[f];
-    int loc = -1;
+    int loc = -1, nghost = 0;  // a corner between two wall ghosts is written by nobody either (the vorticity utility reads some)
     bool wrapped = false;
-    if (i < 0) { if (D.per & 1) { i = F.n[0] - 1; wrapped = true; } else { loc = 0; i = 0; } }
-    else if (i >= F.n[0]) { if (D.per & 1) { i = 0; wrapped = true; } else { loc = 1; i = F.n[0] - 1; } }
-    if (j < 0) { if (D.per & 2) { j = F.n[1] - 1; wrapped = true; } else { loc = 2; j = 0; } }
-    else if (j >= F.n[1]) { if (D.per & 2) { j = 0; wrapped = true; } else { loc = 3; j = F.n[1] - 1; } }
+    if (i < 0) { if (D.per & 1) { i = F.n[0] - 1; wrapped = true; } else { loc = 0; i = 0; ++nghost; } }
+    else if (i >= F.n[0]) { if (D.per & 1) { i = 0; wrapped = true; } else { loc = 1; i = F.n[0] - 1; ++nghost; } }
+    if (j < 0) { if (D.per & 2) { j = F.n[1] - 1; wrapped = true; } else { loc = 2; j = 0; ++nghost; } }
+    else if (j >= F.n[1]) { if (D.per & 2) { j = 0; wrapped = true; } else { loc = 3; j = F.n[1] - 1; ++nghost; } }
     if (D.dim == 3) {
-        if (k < 0) { if (D.per & 4) { k = F.n[2] - 1; wrapped = true; } else { loc = 4; k = 0; } }
-        else if (k >= F.n[2]) { if (D.per & 4) { k = 0; wrapped = true; } else { loc = 5; k = F.n[2] - 1; } }
+        if (k < 0) { if (D.per & 4) { k = F.n[2] - 1; wrapped = true; } else { loc = 4; k = 0; ++nghost; } }
+        else if (k >= F.n[2]) { if (D.per & 4) { k = 0; wrapped = true; } else { loc = 5; k = F.n[2] - 1; ++nghost; } }
     }
     if (loc < 0) return U[fidx(F, i, j, k)];
-    return wrapped ? 0.0 : D.gv[face_index(F, loc, i, j, k)];
+    return (wrapped || nghost > 1) ? 0.0 : D.gv[face_index(F, loc, i, j, k)];
 }
 
 // -N(u) of createconvection.cpp at one velocity point (the caller scales by -1)
@@ -512,6 +512,36 @@ __global__ __launch_bounds__(256) void k_ns_project(NsDev D, double dt, const do
     }
 }
 
+// Vorticity as the reference's post-processing utility defines it (applications/vorticity/main.cpp:185-372), from the
+// velocity and the stored ghost values.  2-D: wz at the vertices.  3-D: wx on (x centres, y vertices, z vertices), wy on
+// (x vertices, y centres, z vertices), wz on (x vertices, y vertices, z centres) -- with the utility's index convention,
+// which reads the two face-centred components one point lower along the vorticity component's own centred direction
+// (w[k-1][j][i-1] for wx at centre i, :300-306; likewise j-1 for wy, :322-332).
+//   comp 0 wx, 1 wy, 2 wz;  n[3]: points of the vorticity field;  coord[f][d][s] is F.co[d][s+1]
+__global__ __launch_bounds__(256) void k_ns_vorticity(NsDev D, int comp, int64_t n0, int64_t n1, int64_t n2,
+                                                      const double *__restrict__ U, double *__restrict__ out)
+{
+    const int64_t total = n0 * n1 * n2;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t % n0, j = (t / n0) % n1, k = t / (n0 * n1);
+        double w;
+        if (D.dim == 2) {
+            w = (vel(D, U, 1, i, j - 1, 0) - vel(D, U, 1, i - 1, j - 1, 0)) / (D.f[1].co[0][i + 1] - D.f[1].co[0][i]) -
+                (vel(D, U, 0, i - 1, j, 0) - vel(D, U, 0, i - 1, j - 1, 0)) / (D.f[0].co[1][j + 1] - D.f[0].co[1][j]);
+        } else if (comp == 0) {
+            w = (vel(D, U, 2, i - 1, j, k - 1) - vel(D, U, 2, i - 1, j - 1, k - 1)) / (D.f[2].co[1][j + 1] - D.f[2].co[1][j]) -
+                (vel(D, U, 1, i - 1, j - 1, k) - vel(D, U, 1, i - 1, j - 1, k - 1)) / (D.f[1].co[2][k + 1] - D.f[1].co[2][k]);
+        } else if (comp == 1) {
+            w = (vel(D, U, 0, i - 1, j - 1, k) - vel(D, U, 0, i - 1, j - 1, k - 1)) / (D.f[0].co[2][k + 1] - D.f[0].co[2][k]) -
+                (vel(D, U, 2, i, j - 1, k - 1) - vel(D, U, 2, i - 1, j - 1, k - 1)) / (D.f[2].co[0][i + 1] - D.f[2].co[0][i]);
+        } else {
+            w = (vel(D, U, 1, i, j - 1, k) - vel(D, U, 1, i - 1, j - 1, k)) / (D.f[1].co[0][i + 1] - D.f[1].co[0][i]) -
+                (vel(D, U, 0, i - 1, j, k) - vel(D, U, 0, i - 1, j - 1, k)) / (D.f[0].co[1][j + 1] - D.f[0].co[1][j]);
+        }
+        out[t] = w;
+    }
+}
+
 // out = BNG phi (BNG = dt G): the row of k_ns_project, stored instead of subtracted
 __global__ __launch_bounds__(256) void k_ns_bng(NsDev D, double dt, const double *__restrict__ phi, double *__restrict__ out)
 {
@@ -902,6 +932,30 @@ int pib_ns_history_term(pib_ns *ns, int kind, int index, int set, double *host)
     const size_t bytes = sizeof(double) * (size_t)ns->D.UN;
     if (set) PIB_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
     else PIB_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* The vorticity field of the reference's petibm-vorticity utility (applications/vorticity/main.cpp) from the current
+ * velocity and ghost values.  comp: 0 wx, 1 wy, 2 wz (2-D: only 2).  n_out[3] receives the field's point counts
+ * (:384-470: vertices along the two directions the component is not centred on); out may be NULL to query them. */
+int pib_ns_get_vorticity(pib_ns *ns, int comp, int64_t n_out[3], double *out)
+{
+    using namespace pib;
+    if (ns == nullptr || n_out == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_get_vorticity: null argument");
+    const NsDev &D = ns->D;
+    if (comp < 0 || comp > 2 || (D.dim == 2 && comp != 2)) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_get_vorticity: component %d", comp);
+    for (int d = 0; d < 3; ++d) n_out[d] = (d < D.dim) ? ((d == comp) ? D.pn[d] : D.pn[d] + 1) : 1;
+    if (out == nullptr) return 0;
+    PIB_HIP(hipSetDevice(ns->device));
+    const int64_t total = n_out[0] * n_out[1] * n_out[2];
+    double *d_out = nullptr;
+    PIB_HIP(hipMalloc(&d_out, sizeof(double) * (size_t)total));
+    hipLaunchKernelGGL(k_ns_vorticity, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, ns->stream, D, comp,
+                       n_out[0], n_out[1], n_out[2], ns->U, d_out);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipStreamSynchronize(ns->stream));
+    PIB_HIP(hipMemcpy(out, d_out, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost));
+    PIB_HIP(hipFree(d_out));
     return 0;
 }
 

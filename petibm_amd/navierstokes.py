@@ -198,6 +198,37 @@ class NavierStokesSolver:
                     off += sz
             f.write_attr("p", "time", self.t)
 
+    def vorticity(self):
+        """{name: array (nz, ny, nx)} of the reference's petibm-vorticity utility (applications/vorticity/main.cpp): wz at the
+        vertices in 2-D; wx, wy, wz in 3-D"""
+        out = {}
+        for comp in ([2] if self.dim == 2 else [0, 1, 2]):
+            n3 = np.zeros(3, dtype=np.int64)
+            capi.check(capi.load().pib_ns_get_vorticity(self._h, comp, n3.ctypes.data, None))
+            a = np.empty(int(np.prod(n3)))
+            capi.check(capi.load().pib_ns_get_vorticity(self._h, comp, n3.ctypes.data, a.ctypes.data))
+            shape = tuple(int(v) for v in n3[: self.dim][::-1])
+            out["w" + "xyz"[comp]] = a.reshape(shape)
+        return out
+
+    def writeVorticity(self, path: str, grid_path: str = None) -> None:
+        """append the vorticity datasets to a solution file and (optionally) their gridlines to grid.h5, like
+        petibm-vorticity (main.cpp:98-107,160-163)"""
+        from . import h5io
+        w = self.vorticity()
+        with h5io.File(path, "a") as f:
+            for name, a in w.items():
+                f.write(name, a)
+        if grid_path is not None:
+            vtx = [self._lo[d] + np.concatenate([[0.0], np.cumsum(self.widths[d])]) for d in range(self.dim)]
+            ctr = [0.5 * (v[1:] + v[:-1]) for v in vtx]
+            with h5io.File(grid_path, "a") as f:
+                for name in w:
+                    comp = "xyz".index(name[1])
+                    for d, ax in enumerate("xyz"):
+                        c = np.zeros(1) if d >= self.dim else (ctr[d] if d == comp else vtx[d])
+                        f.write(f"{name}/{ax}", c)
+
     def _history(self):
         c0, c1, d0 = np.empty(self.UN), np.empty(self.UN), np.empty(self.UN)
         capi.check(capi.load().pib_ns_get_history(self._h, c0.ctypes.data, c1.ctypes.data, d0.ctypes.data))

@@ -266,3 +266,51 @@ def test_matrix_free_poisson_products_in_the_time_step(flavour):
     assert abs(out[0][2][3] - out[1][2][3]) <= 1 and out[0][2][3] > 0
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-10 * np.abs(out[1][0]).max()
     assert np.abs(out[0][1] - out[1][1]).max() <= 1e-8 * np.abs(out[1][1]).max()
+
+
+@pytest.mark.parametrize("case", ["2d", "3d", "2d_periodic_y"])
+def test_vorticity_utility_matches_the_restatement(case, tmp_path):
+    """petibm-vorticity (applications/vorticity/main.cpp) on the device, against the oracle's index-for-index
+    restatement; and the datasets it appends to the solution / grid files."""
+    from petibm_amd import h5io
+    from petibm_amd.navierstokes import NavierStokesSolver
+    if case == "2d":
+        cfg = cavity((14, 12), stretched=True)
+    elif case == "3d":
+        cfg = moving_walls_3d()
+    else:
+        cfg = omesh.periodic_config((12, 10), (False, True), lo=-1.0, hi=1.0)
+        cfg["flow"]["nu"] = 0.01
+        cfg["parameters"] = {"dt": 0.01}
+    m = omesh.create_mesh(cfg)
+    U0 = 0.3 * np.random.default_rng(1).uniform(-1, 1, m.UN)
+    s = NavierStokesSolver(cfg)
+    s.setState(U0, None)
+    ghosts = ons.make_ghosts(m)
+    ons.set_ghost_ics(m, ghosts, U0)
+    ref = ons.vorticity(m, U0, ghosts)
+    w = s.vorticity()
+    assert set(w) == set(ref)
+    for name in ref:
+        assert w[name].shape == ref[name].shape
+        assert np.array_equal(w[name], ref[name]), name
+    f = str(tmp_path / "0000000.h5")
+    g = str(tmp_path / "grid.h5")
+    s.write(f)
+    s.writeGrid(g)
+    s.writeVorticity(f, g)
+    with h5io.File(f) as h:
+        assert np.array_equal(h.read("wz"), w["wz"])
+    with h5io.File(g) as h:
+        assert len(h.read("wz/x")) == m.n[3][0] + 1
+    s.destroy()
+
+
+def test_vorticity_of_a_rigid_rotation_is_twice_the_rate():
+    from petibm_amd.navierstokes import NavierStokesSolver
+    cfg = cavity((16, 16))
+    cfg["flow"]["initialVelocity"] = ["-(y - 0.5)", "x - 0.5"]
+    s = NavierStokesSolver(cfg)
+    wz = s.vorticity()["wz"]
+    assert np.allclose(wz[2:-2, 2:-2], 2.0, atol=1e-12)
+    s.destroy()
