@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--nt", type=int, default=None, help="number of time steps (default: parameters.nt)")
     ap.add_argument("--vorticity", action="store_true",
                     help="append the vorticity fields of petibm-vorticity to every saved solution file (and their gridlines to grid.h5)")
+    ap.add_argument("--xdmf", action="store_true", help="write the .xmf descriptions of petibm-createxdmf next to the HDF5 files")
     ap.add_argument("--app", default="auto", choices=["auto", "navierstokes", "decoupledibpm", "ibpm"],
                     help="which of the reference's applications to mirror (auto: decoupledibpm when the case has bodies)")
     a = ap.parse_args()
@@ -89,6 +90,9 @@ def main():
         if have_h5 and nrestart > 0 and s.ite % nrestart == 0:
             s.writeRestartData(os.path.join(out, f"{s.ite:07d}.h5"))
     wall = time.perf_counter() - t0
+    if a.xdmf and have_h5 and nsave > 0:
+        from petibm_amd import xdmf
+        xdmf.write_all(out, s.dim, s.n, s.periodic, range(start, start + nt + 1, nsave), vorticity=a.vorticity)
     it_file.close()
     if f_file:
         f_file.close()

@@ -99,3 +99,20 @@ int main(int argc, char **argv) {
     got = np.array([float(v) for v in lines[1:1 + int(n)]])
     assert int(n) == 450 and float(end) == 15.0 and np.array_equal(got, want)
     assert lines[1 + int(n)] == "body 0 3 -0.125 8" and lines[2 + int(n)] == "missing 65"
+
+
+def test_xdmf_descriptions(tmp_path):
+    """petibm_amd/xdmf.py: one well-formed .xmf per field, a temporal collection over the saved steps, the point counts
+    of the staggered fields (createxdmf/main.cpp)"""
+    import xml.dom.minidom
+    from petibm_amd import xdmf
+    paths = xdmf.write_all(str(tmp_path), 2, (32, 24), (False, True), [0, 100, 200])
+    assert sorted(os.path.basename(p) for p in paths) == ["p.xmf", "u.xmf", "v.xmf", "wz.xmf"]
+    for p in paths:
+        text = open(p).read()
+        xml.dom.minidom.parseString(text)  # entities are internal: a standard parser accepts the file
+        assert text.count("<Time Value=") == 3 and "0000200.h5" in text
+    u, v = open(paths[0]).read(), open(paths[1]).read()
+    assert '<!ENTITY Nx "31">' in u and '<!ENTITY Ny "24">' in u
+    assert '<!ENTITY Nx "32">' in v and '<!ENTITY Ny "24">' in v   # periodic y: one more line of v points
+    assert "Format='XML'" in u  # the dummy z axis of a 2-D run
