@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
 //   x1 = omega b / d            (mode 1)
 //   x2 = x1 + omega (b - A x1) / d   (mode 2)
 // as two streaming kernels these are 5 vector passes over HBM (b, x1 | x1, b, x2); here a workgroup owns a 128 x 8 tile
-// of the plane and marches through FZ planes with the x1 planes (tile + one halo cell in x and y) in a ring of four LDS
-// slots: b is read once (1.27 x with the halo), x2 written once.  Every k-independent mesh coefficient of the thread's
+// of the plane and marches through FZ planes with the x1 planes (tile + one halo cell in x and y) in a ring of three LDS
+// slots (the thread's own x1 values of three consecutive planes stay in registers): b is read once (1.27 x with the halo), x2 written once.  Every k-independent mesh coefficient of the thread's
 // cells is loaded before the march (the 1-D arrays alone cost ~55 vector-memory instructions per thread and plane
 // otherwise).  Same expressions in the same order as modes 1 and 2: bit-identical (tools/fuse_lab.hip: 1.34 -> 0.78 ms
 // per 512^3 pair).  Levels that are whole on this rank, not periodic, 3-D, nx % 128 == 0, ny % 8 == 0.
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
                                                     const double *__restrict__ pin_sum, int FZ)
 {
     if (S != nullptr && S->done) return;
-    __shared__ double x1[4][FSY][FSX];
+    __shared__ double x1[3][FSY][FSX];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, k0 = blockIdx.z * FZ;
@@ -304,10 +304,15 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
     for (int c = 0; c < 4; ++c) q4[c] = fcell(L, ic + c, j);
     if (hy_ok) qhy = fcell(L, hyi, hyj);
     if (hx_ok) qhx = fcell(L, hxi, hxj);
+    // x1 of the thread's own cells on the planes kk-2, kk-1, kk stays in registers (the z neighbours of step 2); LDS holds
+    // the planes for the x / y neighbours only: plane kk is written while plane kk-1 is read, three slots, one barrier
     v4 bprev = {0, 0, 0, 0}, bcur = {0, 0, 0, 0};
+    v4 x1m = {0, 0, 0, 0}, x1c = {0, 0, 0, 0}, x1p = {0, 0, 0, 0};
     for (int kk = k0 - 1; kk <= k0 + FZ; ++kk) {
-        const int slot = (kk + 4) & 3;
+        const int slot = (kk + 3) % 3;
         bprev = bcur;
+        x1m = x1c;
+        x1c = x1p;
         if (kk >= 0 && kk < L.nzg) {
             const double *pb = b + (int64_t)kk * plane;
             v4 bv = *reinterpret_cast<const v4 *>(pb + off_c);
@@ -317,14 +322,17 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
             const double gzm = (kk > 0) ? L.gz[kk - 1] : 0.0, gzp = (kk < L.nzg - 1) ? L.gz[kk] : 0.0;
             bcur = bv;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) x1[slot][ty + 1][4 * tx + 1 + c] = omega * (bv[c] / fdiag(q4[c], wzk, gzm, gzp));
+            for (int c = 0; c < 4; ++c) {
+                x1p[c] = omega * (bv[c] / fdiag(q4[c], wzk, gzm, gzp));
+                x1[slot][ty + 1][4 * tx + 1 + c] = x1p[c];
+            }
             x1[slot][hy_row + 1][hy_x + 1] = hy_ok ? omega * (hyv / fdiag(qhy, wzk, gzm, gzp)) : 0.0;
             if (tid < 16) x1[slot][hx_y + 1][hx_col + 1] = hx_ok ? omega * (hxv / fdiag(qhx, wzk, gzm, gzp)) : 0.0;
         }
         __syncthreads();
         const int kc = kk - 1;  // the plane whose x1 neighbours are complete now
         if (kc < k0 || kc >= L.nzg) continue;
-        const int sc = (kc + 4) & 3, sm = (kc + 3) & 3, sp = (kc + 5) & 3;
+        const int sc = (kc + 3) % 3;
         const double wzk = L.wz[kc];
         const double gzm = (kc > 0) ? L.gz[kc - 1] : 0.0, gzp = (kc < L.nzg - 1) ? L.gz[kc] : 0.0;
         v4 out;
@@ -335,14 +343,14 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
             const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
             const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
             const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
-            const double xcc = x1[sc][ty + 1][lx];
+            const double xcc = x1c[c];
             double sum = 0.0;
             if (i > 0) sum += c0 * (x1[sc][ty + 1][lx - 1] - xcc);
             if (i < L.nx - 1) sum += c1 * (x1[sc][ty + 1][lx + 1] - xcc);
             if (j > 0) sum += c2 * (x1[sc][ty][lx] - xcc);
             if (j < L.ny - 1) sum += c3 * (x1[sc][ty + 2][lx] - xcc);
-            if (kc > 0) sum += c4 * (x1[sm][ty + 1][lx] - xcc);
-            if (kc < L.nzg - 1) sum += c5 * (x1[sp][ty + 1][lx] - xcc);
+            if (kc > 0) sum += c4 * (x1m[c] - xcc);
+            if (kc < L.nzg - 1) sum += c5 * (x1p[c] - xcc);
             out[c] = xcc + omega * ((bprev[c] - sum) / d);
         }
         *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = out;
