@@ -75,3 +75,28 @@ def test_coupled_cylinder_re550_follows_koumoutsakos_leonard_from_the_start():
         worst = max(worst, abs(cd - ref) / ref)
         assert abs(cd - ref) < 0.08 * ref, (it, cd, ref)
     s.destroy()
+
+
+def test_errors_of_the_newer_engine_entries():
+    """order / support errors of pib_ns_set_coupled, pib_ns_set_bn_order, pib_ns_set_time_integration, pib_ns_get_vorticity"""
+    import ctypes as C
+    from petibm_amd import capi
+    from petibm_amd.navierstokes import DecoupledIBPMSolver, NavierStokesSolver
+    lib = capi.load()
+    cfg = flow_config(body_mesh(cells=(6, 12, 6), ratio=1.3, span=2.5, core=0.7), dt=0.01)
+    s = NavierStokesSolver(cfg)
+    assert lib.pib_ns_set_coupled(s._h, 1) == capi.ERR_ORDER                      # no bodies
+    n3 = (C.c_int64 * 3)()
+    assert lib.pib_ns_get_vorticity(s._h, 0, n3, None) == capi.ERR_ARG_OUTOFRANGE  # wx in a 2-D run
+    assert lib.pib_ns_get_vorticity(s._h, 2, n3, None) == 0 and list(n3) == [25, 25, 1]
+    assert lib.pib_ns_set_bn_order(s._h, 0) == capi.ERR_SUP                        # createbn.cpp:27-29
+    assert lib.pib_ns_set_time_integration(s._h, b"ADAMS_BASHFORTH_3", b"CRANK_NICOLSON") == capi.ERR_ARG_OUTOFRANGE
+    s.destroy()
+    it = ("config_version=2\nsolver(solv)=PCG\nsolv:max_iters=100\nsolv:convergence=ABSOLUTE\nsolv:tolerance=1e-10\n"
+          "solv:norm=L2\nsolv:preconditioner(prec)=BLOCK_JACOBI\n")
+    d = DecoupledIBPMSolver(cfg, bodies=[circle(24, r=0.4)], forces_cfg=it)       # an iterative forces solver ...
+    assert lib.pib_ns_set_coupled(d._h, 1) == capi.ERR_SUP                         # ... has no explicit inverse to eliminate with
+    assert lib.pib_ns_set_bn_order(d._h, 2) == capi.ERR_SUP                        # BN > 1 with bodies
+    assert lib.pib_ns_set_time_integration(d._h, b"EULER_EXPLICIT", b"EULER_IMPLICIT") == capi.ERR_ORDER
+    d.advance(2)                                                                   # the decoupled scheme still runs
+    d.destroy()
