@@ -216,7 +216,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.fuse_dots = std::atoi(d.get("default", "pib_fuse_dots", "1").c_str());
     c.fuse_presmooth = std::atoi(d.get("default", "pib_fuse_presmooth", "1").c_str());
     c.march_levels = std::atoi(d.get("default", "pib_march_levels", "1").c_str());
-    c.march_min_cells = std::atoi(d.get("default", "pib_march_min_cells", "16777216").c_str());
+    c.march_min_cells = std::atoi(d.get("default", "pib_march_min_cells", "12582912").c_str());
     c.matrix_free_velocity = std::atoi(d.get("default", "pib_matrix_free_velocity", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
