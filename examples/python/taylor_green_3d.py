@@ -35,12 +35,15 @@ def main():
     ap.add_argument("--cells", type=int, default=None)
     ap.add_argument("--nt", type=int, default=None)
     ap.add_argument("--every", type=int, default=100)
+    ap.add_argument("--dt", type=float, default=None, help="time step (the case's 0.01 is the 256^3 one: CFL 0.4; halve it at 512^3)")
     a = ap.parse_args()
     d = os.path.join(ROOT, "examples", "cases", "taylorgreenvortex3dRe1600")
     cfg = yaml.safe_load(open(os.path.join(d, "config.yaml")))
     if a.cells:
         for ax in cfg["mesh"]:
             ax["subDomains"][0]["cells"] = a.cells
+    if a.dt:
+        cfg["parameters"]["dt"] = a.dt
     nt = a.nt if a.nt is not None else int(cfg["parameters"]["nt"])
     texts = {k: open(os.path.join(d, cfg["parameters"][k]["config"])).read() for k in ("velocitySolver", "poissonSolver")}
     ref = {round(r[0], 6): r[1] for r in json.load(open(os.path.join(ROOT, "tests", "golden", "reference_test_vectors.json")))[
