@@ -306,7 +306,7 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "Poisson DOF/s (one pressure solve to rel. residual 1e-10), 512^3 cavity",
+            "metric": f"Poisson DOF/s (one pressure solve to rel. residual 1e-10), {n}^3 cavity",
             "value": pN * args.steps / elapsed, "unit": "DOF/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
