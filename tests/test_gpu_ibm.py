@@ -372,3 +372,19 @@ def test_cylinder_re3000_drag_matches_koumoutsakos_leonard():
         cd = 2.0 * s.getForces()[1][0][0]
         assert abs(cd - np.interp(it * 0.001, t_ref, cd_ref)) < 0.07 * cd, (it, cd)
     s.destroy()
+
+
+@pytest.mark.parametrize("dim,npts", [(2, 4), (3, 8)])
+def test_average_forces_known_answer_of_the_reference(dim, npts):
+    """tests/body/singlebody_test.cpp:202-226 (calculateAvgForces2D / 3D): a body of 4 (8) points with a Lagrangian force
+    vector of ones has the averaged force -nPts in every direction (the minus sign of singlebodypoints.cpp:228-259)."""
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    cfg = flow_config(body_mesh(cells=(4, 8, 4), ratio=1.3, span=2.0, core=0.6, dim=dim), dt=0.01)
+    rng = np.random.default_rng(0)
+    body = 0.3 * rng.uniform(-1, 1, (npts, dim))
+    s = DecoupledIBPMSolver(cfg, bodies=[body], forces_cfg=FORCES)
+    s.setForces(np.ones(npts * dim))
+    f, avg = s.getForces()
+    assert np.array_equal(f, np.ones(npts * dim))
+    assert np.array_equal(avg, np.full((1, dim), -float(npts)))
+    s.destroy()
