@@ -220,7 +220,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.matrix_free_velocity = std::atoi(d.get("default", "pib_matrix_free_velocity", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
-    c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "0").c_str());
+    c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "-1").c_str());
     if (d.has("default", "pib_initial_guess_nonzero"))
         c.initial_guess_nonzero = truthy(d.get("default", "pib_initial_guess_nonzero", "1"));
     if (d.has("default", "pib_norm")) {

@@ -1533,11 +1533,15 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
 
     // first level handled by the single-workgroup coarse tail (never level 0; Jacobi only; no communication)
     int tail0 = nl;
-    if (!cheb && s->cfg.coarse_tail) {
+    // the small levels of a small problem are launch-bound (a 2-D flow case spends its V-cycle in ~5 us kernels): one
+    // workgroup walks them; on a large grid the same kernel costs more than it saves
+    const int tail_cells = (s->cfg.coarse_tail >= 0) ? s->cfg.coarse_tail
+                                                      : ((s->levels[0].n[0] * s->levels[0].n[1] * s->levels[0].n[2] < ((int64_t)1 << 22)) ? 1024 : 0);
+    if (!cheb && tail_cells) {
         for (int l = nl - 1; l >= 1; --l) {
             const GridLevel &g = s->levels[(size_t)l];
             const bool local = (s->comm.nranks == 1) || g.replicated;
-            if (local && g.nloc <= std::min<int64_t>(TAIL_MAX_CELLS, s->cfg.coarse_tail) && nl - l < TAIL_MAX_LEVELS) tail0 = l; else break;
+            if (local && g.nloc <= std::min<int64_t>(TAIL_MAX_CELLS, tail_cells) && nl - l < TAIL_MAX_LEVELS) tail0 = l; else break;
         }
         if (nl - tail0 < 2) tail0 = nl;  // a single level is what k_coarsest already does
     }
