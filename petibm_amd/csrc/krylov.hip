@@ -382,9 +382,8 @@ __global__ void k_cg_s_init(Scalars *S, double *hist, double n_global, int lazy_
     }
 }
 
-__global__ void k_cg_s1(Scalars *S)
+__device__ __forceinline__ void cg_s1(Scalars *S)
 {
-    if (S->done) return;
     S->dpiold = S->dpi;
     const double dpi = S->red[6];
     S->dpi = dpi;
@@ -396,6 +395,11 @@ __global__ void k_cg_s1(Scalars *S)
     }
     S->a = S->beta / dpi;
     S->betaold = S->beta;
+}
+__global__ void k_cg_s1(Scalars *S)
+{
+    if (S->done) return;
+    cg_s1(S);
 }
 
 // do_norm: evaluate the monitored norm + convergence; do_beta: new beta, b.
@@ -636,6 +640,9 @@ static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guard
 }
 
 // x, b: device pointers, n_local entries.
+template <int POST>
+static int finalize_post(pib_solver *s, int slot0, int nslots, int count, double *hist, int conv_is_its, hipStream_t q);
+
 int solve_cg(pib_solver *s, double *x, const double *b)
 {
     const DeviceCsr &A = s->A;
@@ -702,8 +709,12 @@ int solve_cg(pib_solver *s, double *x, const double *b)
             OpUpdateP up{Z, P, 0.0, 0.0, 0};
             PIB_CHK(update_p_and_exchange(s, n, up, P, q));
             PIB_CHK(matmult(s, P, W, part_pw, true, q));
-            PIB_CHK(finalize(s, SLOT_PW, 1, spmv_blocks, q));
-            hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s);
+            if (s->comm.nranks == 1)
+                PIB_CHK(finalize_post<4>(s, SLOT_PW, 1, spmv_blocks, nullptr, 0, q));
+            else {
+                PIB_CHK(finalize(s, SLOT_PW, 1, spmv_blocks, q));
+                hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s);
+            }
             if (pc == Precond::JACOBI) {
                 OpUpdateXR<PCM_JACOBI> op{P, W, A.dinv, x, R, Z, omega, 0.0};
                 PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, true, q));
@@ -935,9 +946,8 @@ __global__ void k_b_s_init(Scalars *S, double *hist, int monitor)
     S->b = (S->rho / S->rhoold) * (S->alpha / S->omegaold);  // beta of the first iteration
 }
 
-__global__ void k_b_s_alpha(Scalars *S)
+__device__ __forceinline__ void b_s_alpha(Scalars *S)
 {
-    if (S->done) return;
     const double d1 = S->red[2];
     if (d1 == 0.0 || d1 != d1) {
         S->reason = (d1 != d1) ? PIB_DIVERGED_NANORINF : PIB_DIVERGED_BREAKDOWN;
@@ -946,10 +956,14 @@ __global__ void k_b_s_alpha(Scalars *S)
     }
     S->alpha = S->rho / d1;
 }
-
-__global__ void k_b_s_omega(Scalars *S)
+__global__ void k_b_s_alpha(Scalars *S)
 {
     if (S->done) return;
+    b_s_alpha(S);
+}
+
+__device__ __forceinline__ void b_s_omega(Scalars *S)
+{
     const double d1 = S->red[3], d2 = S->red[4];
     if (d2 == 0.0) {
         // t = 0: PETSc accepts x += alpha p when s = 0 too; s.s is not available separately here, but
@@ -959,10 +973,14 @@ __global__ void k_b_s_omega(Scalars *S)
     }
     S->omega = d1 / d2;
 }
-
-__global__ void k_b_s_end(Scalars *S, double *hist, int conv_is_its)
+__global__ void k_b_s_omega(Scalars *S)
 {
     if (S->done) return;
+    b_s_omega(S);
+}
+
+__device__ __forceinline__ void b_s_end(Scalars *S, double *hist, int conv_is_its)
+{
     const double dp = sqrt(S->red[0]);
     S->dp = dp;
     S->rhoold = S->rho;
@@ -987,6 +1005,46 @@ __global__ void k_b_s_end(Scalars *S, double *hist, int conv_is_its)
         return;
     }
     S->b = (S->rho / S->rhoold) * (S->alpha / S->omegaold);
+}
+__global__ void k_b_s_end(Scalars *S, double *hist, int conv_is_its)
+{
+    if (S->done) return;
+    b_s_end(S, hist, conv_is_its);
+}
+
+// The reduction of k_finalize (same order, slot after slot) followed by the scalar step that consumes it, in one launch:
+// on one rank nothing sits between the two (no all-reduce), and a small problem's Krylov iteration is a chain of ~5 us
+// launches.  POST: 1 BiCGStab alpha, 2 omega, 3 end of iteration, 4 CG alpha.
+template <int POST>
+__global__ __launch_bounds__(256) void k_finalize_post(Scalars *__restrict__ S, const double *__restrict__ part, int slot0, int nslots,
+                                                       int count, double *hist, int conv_is_its)
+{
+    if (S->done) return;
+    __shared__ double sh[4];
+    for (int q = 0; q < nslots; ++q) {
+        const int slot = slot0 + q;
+        const double *p = part + (int64_t)slot * PIB_MAXPART;
+        double v = 0.0;
+        for (int i = threadIdx.x; i < count; i += 256) v += p[i];
+        v = wsum(v);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) S->red[slot] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (POST == 1) b_s_alpha(S);
+        if (POST == 2) b_s_omega(S);
+        if (POST == 3) b_s_end(S, hist, conv_is_its);
+        if (POST == 4) cg_s1(S);
+    }
+}
+template <int POST>
+static int finalize_post(pib_solver *s, int slot0, int nslots, int count, double *hist, int conv_is_its, hipStream_t q)
+{
+    hipLaunchKernelGGL((k_finalize_post<POST>), dim3(1), dim3(256), 0, q, s->d_s, s->d_part, slot0, nslots, count, hist, conv_is_its);
+    PIB_HIP(hipGetLastError());
+    return 0;
 }
 
 int solve_bicgstab(pib_solver *s, double *x, const double *b)
@@ -1040,6 +1098,7 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
 
     const int batch0 = first_batch(s), batch1 = next_batch(s);
     const int maxit = s->cfg.max_iters;
+    const bool one_rank = s->comm.nranks == 1;
     int enq = 0;
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
@@ -1063,8 +1122,12 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
                 OpBPcDot<PCM_NONE> op{V, nullptr, RP, V, 1.0};
                 PIB_CHK(launch_vec(s, n, op, true, 2, &nb, true, q));
             }
-            PIB_CHK(finalize(s, 2, 1, nb, q));
-            hipLaunchKernelGGL(k_b_s_alpha, dim3(1), dim3(1), 0, q, s->d_s);
+            if (one_rank)
+                PIB_CHK(finalize_post<1>(s, 2, 1, nb, nullptr, 0, q));
+            else {
+                PIB_CHK(finalize(s, 2, 1, nb, q));
+                hipLaunchKernelGGL(k_b_s_alpha, dim3(1), dim3(1), 0, q, s->d_s);
+            }
             // s = r - alpha v (+ sh = M^-1 s)
             if (jac) {
                 OpBUpdateS<PCM_JACOBI> op{R, V, A.dinv, S, SH, opc, left ? 1 : 0, 0.0};
@@ -1083,13 +1146,21 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
                 OpBPcDot2<PCM_NONE> op{T, nullptr, S, T, 1.0, 0};
                 PIB_CHK(launch_vec(s, n, op, true, 3, &nb, true, q));
             }
-            PIB_CHK(finalize(s, 3, 2, nb, q));
-            hipLaunchKernelGGL(k_b_s_omega, dim3(1), dim3(1), 0, q, s->d_s);
+            if (one_rank)
+                PIB_CHK(finalize_post<2>(s, 3, 2, nb, nullptr, 0, q));
+            else {
+                PIB_CHK(finalize(s, 3, 2, nb, q));
+                hipLaunchKernelGGL(k_b_s_omega, dim3(1), dim3(1), 0, q, s->d_s);
+            }
             // x += alpha ph + omega sh ; r = s - omega t ; |r|^2, r.rp
             OpBUpdateX op{PH, SH, S, T, RP, x, R, 0.0, 0.0, 0};
             PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, true, q));
-            PIB_CHK(finalize(s, 0, 2, nb, q));
-            hipLaunchKernelGGL(k_b_s_end, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, conv_is_its);
+            if (one_rank)
+                PIB_CHK(finalize_post<3>(s, 0, 2, nb, s->d_hist, conv_is_its, q));
+            else {
+                PIB_CHK(finalize(s, 0, 2, nb, q));
+                hipLaunchKernelGGL(k_b_s_end, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, conv_is_its);
+            }
             PIB_HIP(hipGetLastError());
             return 0;
         };
