@@ -687,6 +687,128 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
     if (valid) bc[(int64_t)KK * C.nx * C.ny + (int64_t)J * C.nx + I] = s;
 }
 
+// ---- restriction, z-marching form (fully paired 3-D levels: every coarse cell has the children 2I, 2I+1 in all three
+// directions).  The row kernel above is bound by the vector-memory issue rate (sixteen row loads per coarse cell, every
+// fine row fetched by four waves): 0.68 ms per 512^3 launch against 0.15 ms of HBM time.  Here a workgroup owns 64 x 8
+// coarse columns and walks up through the fine planes; a plane's 128 x 16 tile (+ the halo the 4-point stencils reach)
+// goes through LDS once, double-buffered, and feeds the two coarse planes it belongs to (slots 0/1 of the upper, 2/3 of
+// the lower one).  A coarse value is still the sum over z slot, y slot, x slot in that order with the same weight
+// products, i.e. the bits of k_restrict_rows (out-of-range slots carry the weight 0 there and are skipped here).
+constexpr int RX = 128, RY = 16, RSX = RX + 8, RSY = RY + 2, RV4 = (RSX / 4) * RSY;
+__device__ __forceinline__ double rz_weight(const Tr1 &t, int kf, int K)
+{
+    return t.par[kf] == K ? t.wpar[kf] : (t.oth[kf] == K ? t.woth[kf] : 0.0);
+}
+__global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
+                                                        const double *__restrict__ rf, double *__restrict__ bc, int CZ)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ double sp[2][RSY][RSX];
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, tw = tid >> 6;
+    const int i0 = blockIdx.x * RX, j0 = blockIdx.y * RY;
+    const int I = blockIdx.x * (RX / 2) + lane, J = blockIdx.y * (RY / 2) + 2 * tw;  // coarse cells (I, J) and (I, J + 1)
+    const int KA = C.k0 + blockIdx.z * CZ, KB = min(KA + CZ, C.k0 + C.nk);          // coarse planes [KA, KB) (global)
+    const double4 rw = F.tx.rw[I];
+    double wj[2][4];
+    {
+        int sj[4];
+        rs1d4(F.t[1], J, F.ny, false, wj[0], sj);
+        rs1d4(F.t[1], J + 1, F.ny, false, wj[1], sj);
+    }
+    const int64_t fplane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
+    // this thread's share of a plane's tile: up to three aligned 4-cell pieces (zero outside the domain)
+    int64_t goff[3];
+    int loff[3];
+    bool ok[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int idx = tid + 256 * e, row = idx / (RSX / 4), cx = idx - row * (RSX / 4);
+        const int gi = i0 - 4 + 4 * cx, gj = j0 - 1 + row;
+        ok[e] = idx < RV4 && gi >= 0 && gi < F.nx && gj >= 0 && gj < F.ny;
+        goff[e] = (int64_t)gj * F.nx + gi;
+        loff[e] = idx < RV4 ? row * RSX + 4 * cx : -1;
+    }
+    const int kf0 = 2 * KA - 1, kf1 = 2 * (KB - 1) + 2;  // fine planes that feed [KA, KB) (global, both ends inclusive)
+    const v4 zero = {0, 0, 0, 0};
+    v4 pre[3] = {zero, zero, zero};
+    auto fetch = [&](int kf) {
+        const double *pf = rf + (int64_t)(kf - F.k0) * fplane;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) pre[e] = ok[e] ? *reinterpret_cast<const v4 *>(pf + goff[e]) : zero;
+    };
+    if (kf0 >= 0) fetch(kf0);
+    double lo[2] = {0.0, 0.0}, hi[2] = {0.0, 0.0};
+    for (int kf = kf0; kf <= kf1; ++kf) {
+        const bool inz = kf >= 0 && kf < F.nzg;
+        const int slot = kf & 1;
+        if (inz) {
+            double *dst = &sp[slot][0][0];
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (loff[e] >= 0) *reinterpret_cast<v4 *>(dst + loff[e]) = pre[e];
+        }
+        __syncthreads();
+        if (kf + 1 <= kf1 && kf + 1 < F.nzg) fetch(kf + 1);
+        const bool odd = kf & 1;
+        const int Khi = odd ? (kf + 1) / 2 : kf / 2, Klo = Khi - 1;  // kf is slot 0 / 1 of Khi and slot 2 / 3 of Klo
+        if (inz) {
+            const bool dohi = Khi >= KA && Khi < KB, dolo = Klo >= KA && Klo < KB;
+            const double wkhi = dohi ? rz_weight(F.t[2], kf, Khi) : 0.0, wklo = dolo ? rz_weight(F.t[2], kf, Klo) : 0.0;
+            // the six fine rows of the two coarse rows
+            double vl[6], c0[6], c1[6], vr[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double *rowp = &sp[slot][4 * tw + r][2 * lane + 4];
+                const double2 cc = *reinterpret_cast<const double2 *>(rowp);
+                vl[r] = rowp[-1];
+                c0[r] = cc.x;
+                c1[r] = cc.y;
+                vr[r] = rowp[2];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (dolo) {
+                    double s = lo[a];
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) {
+                        const double wzy = wklo * wj[a][b2];
+                        const int r = 2 * a + b2;
+                        s += (wzy * rw.x) * vl[r];
+                        s += (wzy * rw.y) * c0[r];
+                        s += (wzy * rw.z) * c1[r];
+                        s += (wzy * rw.w) * vr[r];
+                    }
+                    lo[a] = s;
+                }
+                if (dohi) {
+                    double s = hi[a];
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) {
+                        const double wzy = wkhi * wj[a][b2];
+                        const int r = 2 * a + b2;
+                        s += (wzy * rw.x) * vl[r];
+                        s += (wzy * rw.y) * c0[r];
+                        s += (wzy * rw.z) * c1[r];
+                        s += (wzy * rw.w) * vr[r];
+                    }
+                    hi[a] = s;
+                }
+            }
+        }
+        if (!odd) {  // slot 3 of Klo is behind us: store it, the upper plane moves down
+            if (Klo >= KA && Klo < KB) {
+                double *dst = bc + (int64_t)(Klo - C.k0) * cplane + (int64_t)J * C.nx + I;
+                dst[0] = lo[0];
+                dst[C.nx] = lo[1];
+            }
+            lo[0] = hi[0];
+            lo[1] = hi[1];
+            hi[0] = hi[1] = 0.0;
+        }
+    }
+}
+
 // coarsest level in ONE workgroup: `sweeps` damped-Jacobi sweeps from zero,
 // ping-pong between xa / xb (global, L2-resident), block barrier between sweeps.
 __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S, LevelDev L, double omega, int sweeps,
@@ -977,8 +1099,19 @@ static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *
     return 0;
 }
 // `c` carries the coarse planes to produce in k0 / k1 (the owned ones, which may be a part of a replicated level)
-static int launch_restrict(const GridLevel &f, const GridLevel &c, const double *rf, double *bc, const Scalars *S, hipStream_t q)
+static int launch_restrict(const pib_solver *s, const GridLevel &f, const GridLevel &c, const double *rf, double *bc, const Scalars *S,
+                           hipStream_t q)
 {
+    const int64_t nkc = c.k1 - c.k0;
+    if (s->cfg.march_restrict && f.plain_pair && f.per == 0 && f.tper == 0 && f.n[0] % RX == 0 && f.n[1] % RY == 0 && nkc >= 4 &&
+        nkc * c.plane * 8 >= (int64_t)s->cfg.march_min_cells) {
+        // coarse planes per workgroup: 32 on a 512^3 fine level (1024 workgroups), 8 below
+        const int CZ = nkc * c.plane >= ((int64_t)1 << 23) ? 32 : 8;
+        hipLaunchKernelGGL(k_restrict_march, dim3((unsigned)(f.n[0] / RX), (unsigned)(f.n[1] / RY), (unsigned)((nkc + CZ - 1) / CZ)),
+                           dim3(256), 0, q, S, dev_of(f), dev_of(c), rf, bc, CZ);
+        PIB_HIP(hipGetLastError());
+        return 0;
+    }
     const RowGrid r = row_grid(c.n[1] * (c.k1 - c.k0), c.n[0], 64);  // aligned 64-lane chunks + edge loads (62 overlapping lanes measured slower here)
     const int vec_ok = (f.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(rf) & 15u) == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_restrict_rows, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), rf, bc, r.ngroups, r.per_xcd, vec_ok);
@@ -1216,6 +1349,7 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
         target_shift--;  // the loop's ++ after the successful try
         for (int d = 0; d < 3; ++d)
             if (twrap[d]) G.tper |= 1 << d;
+        G.plain_pair = nc[0] * 2 == nn[0] && nc[1] * 2 == nn[1] && nc[2] * 2 == nn[2];
         for (int d = 0; d < 3; ++d) {
             PIB_CHK(up(par[d], &G.t_par[d]));
             PIB_CHK(up(oth[d], &G.t_oth[d]));
@@ -1618,10 +1752,10 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             own.k1 = s->gmg_own[(size_t)l + 1][(size_t)s->comm.rank].second;
             own.nloc = (own.k1 - own.k0) * cg.plane;
             double *scratch = cg.r + cg.plane;
-            PIB_CHK(launch_restrict(g, own, rr, scratch, S, q));
+            PIB_CHK(launch_restrict(s, g, own, rr, scratch, S, q));
             PIB_CHK(gather_level(s, l + 1, cg.plane, scratch, own.nloc, cg.b + cg.plane, q));
         } else {
-            PIB_CHK(launch_restrict(g, cg, rr, cg.b + cg.plane, S, q));
+            PIB_CHK(launch_restrict(s, g, cg, rr, cg.b + cg.plane, S, q));
         }
         cur[(size_t)l] = a;
         // remember the spare buffer in g.scratch for the upward leg

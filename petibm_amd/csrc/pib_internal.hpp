@@ -78,6 +78,7 @@ struct Config {
     int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR
     int march_min_cells = 12 << 20;  // smallest level / plane run the LDS-tiled marching kernels take: a 256^3 level, the 62 interior planes of a 512 x 512 x 64 slab (tests lower it to reach them on small grids)
     int march_levels = 1;    // multigrid: Jacobi steps / residuals of the large levels by the 2.5-D blocked kernel (gmg.hip k_level_march)
+    int march_restrict = 1;  // multigrid: restriction of a fully paired 3-D level by the z-marching LDS kernel (gmg.hip k_restrict_march)
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
@@ -157,6 +158,7 @@ struct GridLevel {
     int64_t nloc = 0, plane = 0;
     int per = 0;  // bit d: direction d (internal order) is periodic and has > 1 cell: the level operator wraps
     int tper = 0; // bit d: ... and so do the transfers towards the next coarser level (>= 4 cells)
+    bool plain_pair = false;  // every aggregate towards the next coarser level is a pair of cells (n = 2 nc) in all three directions
     bool zring = false;  // distributed level on a periodic slab axis: the z wrap goes through the halo planes
 };
 

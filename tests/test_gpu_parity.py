@@ -761,3 +761,35 @@ def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
     assert np.allclose(out[0][1], out[1][1], rtol=1e-9)
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * np.abs(out[1][0]).max()
     assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("n,pinned", [((128, 32, 24), False), ((256, 16, 40), True)])
+def test_marching_restriction_is_bit_identical(lin, n, pinned):
+    """gmg.hip k_restrict_march (fully paired 3-D levels with nx % 128 == 0, ny % 16 == 0: a fine plane goes through LDS
+    once and feeds its two coarse planes) against the row kernel k_restrict_rows: the same sums in the same order, so
+    the whole solve is bit-identical; mildly stretched widths keep every aggregate a pair and the weights non-trivial."""
+    from petibm_amd import capi
+    names, r = "xyz", (1.002, 1.01, 0.99)
+    cfg = omesh.uniform_config(n)
+    cfg["mesh"] = [{"direction": names[d], "start": 0.0,
+                    "subDomains": [{"end": 0.05 * n[d], "cells": n[d], "stretchRatio": r[d]}]} for d in range(3)]
+    dt = 0.01
+    m, A, _ = poisson_system(cfg, dt=dt, pinned=pinned)
+    xs, b = rhs_for(A, zero_mean=not pinned)
+    if pinned:
+        b[0] = 0.0
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    out = []
+    for march in (1, 0):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_march_restrict={march}\n"))
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        out.append((x, s.getResidualHistory(), s.getIters()))
+        s.destroy()
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    g = clib.GMG(list(n), w, dt, nullspace=2 if pinned else 1, pre=2, post=2, omega=0.9, coarsest_sweeps=32)
+    ref = g.pcg(A, b, rtol=1e-10, maxit=200)
+    assert iters_close(out[0][2], ref["iters"])
+    ke = min(len(out[0][1]), len(ref["history"]), 6)
+    assert np.allclose(out[0][1][:ke], ref["history"][:ke], rtol=1e-8)
