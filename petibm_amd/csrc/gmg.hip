@@ -597,6 +597,177 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
     }
 }
 
+// ---- prolongation + the first post-smoothing step in one march (fully paired levels that k_level_march serves).  The
+// corrected iterate x + P e exists only on chip: a workgroup keeps the coarse planes a fine plane interpolates from in a
+// three-slot LDS ring (66 x 6 values each), corrects its 128 x 8 tile of the plane ahead (and that plane's x / y halo
+// cells) and relaxes the current plane exactly as k_level_march<2> does -- the iterate is read once and written once
+// instead of twice each.  Per-cell sums in the order of k_prolong_rows (z slot, y slot; own coarse cell, then the x
+// neighbour) followed by k_level's expression: bit-identical to the two kernels it replaces.
+constexpr int PCX = FX / 2 + 2, PCY = FY / 2 + 2;
+struct PHalo {
+    int r0, r1, lx, lxo;
+    double wj0, wj1, wa, wb;
+};
+__device__ __forceinline__ PHalo phalo(const LevelDev &F, int i, int j, int I0, int J0)
+{
+    PHalo h;
+    int J[2];
+    double wj[2];
+    tr1d(F.t[1], j, J, wj);
+    h.r0 = J[0] - J0 + 1;
+    h.r1 = J[1] - J0 + 1;
+    h.wj0 = wj[0];
+    h.wj1 = wj[1];
+    const int I = i >> 1;
+    const double4 pw = F.tx.pw[I];
+    const bool right = i & 1;
+    h.lx = I - I0 + 1;
+    h.lxo = right ? h.lx + 1 : h.lx - 1;
+    h.wa = right ? pw.z : pw.x;
+    h.wb = right ? pw.w : pw.y;
+    return h;
+}
+__global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
+                                                        const double *__restrict__ b, const double *__restrict__ xc,
+                                                        const double *__restrict__ xi, double *__restrict__ xo,
+                                                        const double *__restrict__ pin_sum, int FZ)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ __attribute__((aligned(16))) double sp[2][FSY][FSX];
+    __shared__ __attribute__((aligned(16))) double cs[3][PCY][PCX];
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, l0 = blockIdx.z * FZ;
+    const int I0 = i0 >> 1, J0 = j0 >> 1;
+    const int64_t plane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
+    const int j = j0 + ty, ic = i0 + 4 * tx;
+    const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
+    const int hx_col = (tid & 1) ? FX : -1, hx_y = (tid >> 1) & 7;
+    const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
+    const bool hy_ok = hyj >= 0 && hyj < F.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < F.nx;
+    const int64_t off_c = (int64_t)j * F.nx + ic, off_hy = (int64_t)hyj * F.nx + hyi, off_hx = (int64_t)hxj * F.nx + hxi;
+    FCell q4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = fcell(F, ic + c, j);
+    // interpolation data of the own cells (coarse columns I0 + 2 tx, + 1) and of the halo cells
+    const double4 pwA = F.tx.pw[I0 + 2 * tx], pwB = F.tx.pw[I0 + 2 * tx + 1];
+    int rr[2];
+    double wjv[2];
+    {
+        int J[2];
+        tr1d(F.t[1], j, J, wjv);
+        rr[0] = J[0] - J0 + 1;
+        rr[1] = J[1] - J0 + 1;
+    }
+    PHalo hy = {}, hx = {};
+    if (hy_ok) hy = phalo(F, hyi, hyj, I0, J0);
+    if (hx_ok) hx = phalo(F, hxi, hxj, I0, J0);
+    // coarse plane K (tile + one cell around it, zero outside the domain) into its ring slot
+    auto stage = [&](int K) {
+        const double *pc = xc + (int64_t)K * cplane;
+        double *dst = &cs[K % 3][0][0];
+        for (int e = tid; e < PCX * PCY; e += 256) {
+            const int row = e / PCX, cx = e - row * PCX;
+            const int I = I0 - 1 + cx, J = J0 - 1 + row;
+            dst[e] = (I >= 0 && I < C.nx && J >= 0 && J < C.ny) ? pc[(int64_t)J * C.nx + I] : 0.0;
+        }
+    };
+    // x + P e on plane k: the own cells (returned) and, with `halo`, the tile's halo cells -> LDS slot
+    auto correct = [&](int k, bool halo) -> v4 {
+        int K[2];
+        double wk[2];
+        tr1d(F.t[2], k, K, wk);
+        const double *px = xi + (int64_t)k * plane;
+        const v4 old = *reinterpret_cast<const v4 *>(px + off_c);
+        const double ohy = (halo && hy_ok) ? px[off_hy] : 0.0, ohx = (halo && hx_ok) ? px[off_hx] : 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, sy = 0.0, sx = 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const double(*cp)[PCX] = cs[K[c2] % 3];
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const double w = wk[c2] * wjv[b2];
+                const double *row = &cp[rr[b2]][2 * tx];
+                const double2 v01 = *reinterpret_cast<const double2 *>(row), v23 = *reinterpret_cast<const double2 *>(row + 2);
+                s0 += (w * pwA.x) * v01.y;
+                s0 += (w * pwA.y) * v01.x;
+                s1 += (w * pwA.z) * v01.y;
+                s1 += (w * pwA.w) * v23.x;
+                s2 += (w * pwB.x) * v23.x;
+                s2 += (w * pwB.y) * v01.y;
+                s3 += (w * pwB.z) * v23.x;
+                s3 += (w * pwB.w) * v23.y;
+                if (halo) {
+                    const double wy = wk[c2] * (b2 ? hy.wj1 : hy.wj0);
+                    const double *rowy = cp[b2 ? hy.r1 : hy.r0];
+                    sy += (wy * hy.wa) * rowy[hy.lx];
+                    sy += (wy * hy.wb) * rowy[hy.lxo];
+                    if (tid < 16) {
+                        const double wx = wk[c2] * (b2 ? hx.wj1 : hx.wj0);
+                        const double *rowx = cp[b2 ? hx.r1 : hx.r0];
+                        sx += (wx * hx.wa) * rowx[hx.lx];
+                        sx += (wx * hx.wb) * rowx[hx.lxo];
+                    }
+                }
+            }
+        }
+        v4 out;
+        out[0] = old[0] + s0;
+        out[1] = old[1] + s1;
+        out[2] = old[2] + s2;
+        out[3] = old[3] + s3;
+        if (halo) {
+            const int slot = k & 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = out[c];
+            sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? ohy + sy : 0.0;
+            if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? ohx + sx : 0.0;
+        }
+        return out;
+    };
+    const int lend = (l0 + FZ < F.nzg) ? l0 + FZ : F.nzg;
+    // prologue: the coarse planes under l0 - 1 and l0 (l0 is even: K0 - 1 and K0), then those two corrected planes
+    const int K0 = l0 >> 1;
+    if (K0 > 0) stage(K0 - 1);
+    stage(K0);
+    __syncthreads();
+    v4 zm = {0, 0, 0, 0}, xcur, zp = {0, 0, 0, 0};
+    if (l0 > 0) zm = correct(l0 - 1, false);
+    xcur = correct(l0, true);
+    for (int lk = l0; lk < lend; ++lk) {
+        const int slot = lk & 1;
+        const int kn = lk + 1;
+        if ((kn & 1) && kn < F.nzg && (kn + 1) / 2 < C.nzg) stage((kn + 1) / 2);  // an odd plane reaches up to the next coarse plane
+        __syncthreads();
+        if (kn < F.nzg) zp = correct(kn, kn < lend);
+        v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)lk * plane + off_c);
+        if (pin_sum != nullptr && lk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
+        const double wzk = F.wz[lk];
+        const double gzm = (lk > 0) ? F.gz[lk - 1] : 0.0, gzp = (lk < F.nzg - 1) ? F.gz[lk] : 0.0;
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ic + c, lx = 4 * tx + 1 + c;
+            const FCell &q = q4[c];
+            const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
+            const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
+            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
+            const double xcc = xcur[c];
+            double sum = 0.0;
+            if (i > 0) sum += c0 * (sp[slot][ty + 1][lx - 1] - xcc);
+            if (i < F.nx - 1) sum += c1 * (sp[slot][ty + 1][lx + 1] - xcc);
+            if (j > 0) sum += c2 * (sp[slot][ty][lx] - xcc);
+            if (j < F.ny - 1) sum += c3 * (sp[slot][ty + 2][lx] - xcc);
+            if (lk > 0) sum += c4 * (zm[c] - xcc);
+            if (lk < F.nzg - 1) sum += c5 * (zp[c] - xcc);
+            out[c] = xcc + omega * ((bv[c] - sum) / d);
+        }
+        *reinterpret_cast<v4 *>(xo + (int64_t)lk * plane + off_c) = out;
+        zm = xcur;
+        xcur = zp;
+    }
+}
+
 // 1-D restriction stencil of coarse cell I in fixed 4-slot form: slot o <-> fine cell fst[I] - 1 + o (the left
 // neighbour, the one or two children, the right neighbour) with the weight that cell gives to I (0 where there
 // is no such fine cell or it does not feed I).  Indices are clamped so the loads are always legal; a zero
@@ -703,7 +874,7 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
                                                         const double *__restrict__ rf, double *__restrict__ bc, int CZ)
 {
     if (S != nullptr && S->done) return;
-    __shared__ double sp[2][RSY][RSX];
+    __shared__ __attribute__((aligned(32))) double sp[2][RSY][RSX];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, tw = tid >> 6;
     const int i0 = blockIdx.x * RX, j0 = blockIdx.y * RY;
@@ -1771,6 +1942,20 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         double *a = cur[(size_t)l], *c = s->gmg_spare[(size_t)l];
         double *xc = cur[(size_t)l + 1];
         PIB_CHK(halo_level(s, cg, xc, q));
+        // prolongation + first post-smoothing step in one march (the corrected iterate never goes to HBM)
+        const bool dots_l = l == 0 && s->gmg_want_dots && !cheb;
+        if (s->cfg.fuse_prolong && !cheb && post >= 1 && !(post == 1 && dots_l) && march_ok(s, g) && g.plain_pair && g.tper == 0 &&
+            ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(b)) & 31u) == 0) {
+            const int FZ = march_planes(g);
+            hipLaunchKernelGGL(k_prolong_smooth, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
+                               dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, pin_l, FZ);
+            PIB_HIP(hipGetLastError());
+            std::swap(a, c);
+            PIB_CHK(smooth_seq(g, b, pin_l, a, c, post - 1, false, l > 0, dots_l));
+            cur[(size_t)l] = a;
+            if (l == 0 && a != z) return fail(PIB_ERR_LIB, "gmg: internal buffer parity error");
+            continue;
+        }
         {
             double *out = a;
             auto run = [&](int64_t kb, int64_t kc) -> int {

@@ -78,6 +78,7 @@ struct Config {
     int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR
     int march_min_cells = 12 << 20;  // smallest level / plane run the LDS-tiled marching kernels take: a 256^3 level, the 62 interior planes of a 512 x 512 x 64 slab (tests lower it to reach them on small grids)
     int march_levels = 1;    // multigrid: Jacobi steps / residuals of the large levels by the 2.5-D blocked kernel (gmg.hip k_level_march)
+    int fuse_prolong = 1;  // multigrid: prolongation + first post-smoothing step of a fully paired large level in one kernel (gmg.hip k_prolong_smooth)
     int march_restrict = 1;  // multigrid: restriction of a fully paired 3-D level by the z-marching LDS kernel (gmg.hip k_restrict_march)
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass

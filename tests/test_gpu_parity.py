@@ -763,11 +763,14 @@ def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
     assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("n,pinned", [((128, 32, 24), False), ((256, 16, 40), True)])
-def test_marching_restriction_is_bit_identical(lin, n, pinned):
+@pytest.mark.parametrize("key", ["pib_march_restrict", "pib_fuse_prolong"])
+@pytest.mark.parametrize("n,pinned", [((128, 32, 24), False), ((256, 16, 40), True), ((128, 16, 34), False)])
+def test_marching_transfers_are_bit_identical(lin, n, pinned, key):
     """gmg.hip k_restrict_march (fully paired 3-D levels with nx % 128 == 0, ny % 16 == 0: a fine plane goes through LDS
-    once and feeds its two coarse planes) against the row kernel k_restrict_rows: the same sums in the same order, so
-    the whole solve is bit-identical; mildly stretched widths keep every aggregate a pair and the weights non-trivial."""
+    once and feeds its two coarse planes) against the row kernel k_restrict_rows, and k_prolong_smooth (prolongation +
+    first post-smoothing step in one march, the corrected iterate only on chip) against k_prolong_rows + k_level_march:
+    the same sums in the same order, so the whole solve is bit-identical; mildly stretched widths keep every aggregate
+    a pair and the weights non-trivial."""
     from petibm_amd import capi
     names, r = "xyz", (1.002, 1.01, 0.99)
     cfg = omesh.uniform_config(n)
@@ -781,7 +784,7 @@ def test_marching_restriction_is_bit_identical(lin, n, pinned):
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
     for march in (1, 0):
-        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_march_restrict={march}\n"))
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)
         s.solve(x, b)
