@@ -672,14 +672,24 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
             dst[e] = (I >= 0 && I < C.nx && J >= 0 && J < C.ny) ? pc[(int64_t)J * C.nx + I] : 0.0;
         }
     };
+    // the old iterate on plane k (own cells, halo cells): loaded one plane ahead of its use, across the barrier
+    struct Old {
+        v4 c;
+        double hy, hx;
+    };
+    auto fetch = [&](int k, bool halo) -> Old {
+        Old o;
+        const double *px = xi + (int64_t)k * plane;
+        o.c = *reinterpret_cast<const v4 *>(px + off_c);
+        o.hy = (halo && hy_ok) ? px[off_hy] : 0.0;
+        o.hx = (halo && hx_ok) ? px[off_hx] : 0.0;
+        return o;
+    };
     // x + P e on plane k: the own cells (returned) and, with `halo`, the tile's halo cells -> LDS slot
-    auto correct = [&](int k, bool halo) -> v4 {
+    auto correct = [&](int k, bool halo, const Old &o) -> v4 {
         int K[2];
         double wk[2];
         tr1d(F.t[2], k, K, wk);
-        const double *px = xi + (int64_t)k * plane;
-        const v4 old = *reinterpret_cast<const v4 *>(px + off_c);
-        const double ohy = (halo && hy_ok) ? px[off_hy] : 0.0, ohx = (halo && hx_ok) ? px[off_hx] : 0.0;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, sy = 0.0, sx = 0.0;
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
@@ -712,16 +722,16 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
             }
         }
         v4 out;
-        out[0] = old[0] + s0;
-        out[1] = old[1] + s1;
-        out[2] = old[2] + s2;
-        out[3] = old[3] + s3;
+        out[0] = o.c[0] + s0;
+        out[1] = o.c[1] + s1;
+        out[2] = o.c[2] + s2;
+        out[3] = o.c[3] + s3;
         if (halo) {
             const int slot = k & 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = out[c];
-            sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? ohy + sy : 0.0;
-            if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? ohx + sx : 0.0;
+            sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? o.hy + sy : 0.0;
+            if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? o.hx + sx : 0.0;
         }
         return out;
     };
@@ -730,17 +740,25 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
     const int K0 = l0 >> 1;
     if (K0 > 0) stage(K0 - 1);
     stage(K0);
-    __syncthreads();
     v4 zm = {0, 0, 0, 0}, xcur, zp = {0, 0, 0, 0};
-    if (l0 > 0) zm = correct(l0 - 1, false);
-    xcur = correct(l0, true);
+    Old om = {}, o0 = fetch(l0, true), on = {};
+    if (l0 > 0) om = fetch(l0 - 1, false);
+    if (l0 + 1 < F.nzg) on = fetch(l0 + 1, l0 + 1 < lend);
+    v4 bc = *reinterpret_cast<const v4 *>(b + (int64_t)l0 * plane + off_c), bn = {0, 0, 0, 0};
+    __syncthreads();
+    if (l0 > 0) zm = correct(l0 - 1, false, om);
+    xcur = correct(l0, true, o0);
     for (int lk = l0; lk < lend; ++lk) {
         const int slot = lk & 1;
         const int kn = lk + 1;
+        // loads for the next step go out before the barrier: the old iterate two planes ahead, b one plane ahead
+        Old o2 = {};
+        if (kn + 1 < F.nzg && kn < lend) o2 = fetch(kn + 1, kn + 1 < lend);
+        if (kn < lend) bn = *reinterpret_cast<const v4 *>(b + (int64_t)kn * plane + off_c);
         if ((kn & 1) && kn < F.nzg && (kn + 1) / 2 < C.nzg) stage((kn + 1) / 2);  // an odd plane reaches up to the next coarse plane
         __syncthreads();
-        if (kn < F.nzg) zp = correct(kn, kn < lend);
-        v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)lk * plane + off_c);
+        if (kn < F.nzg) zp = correct(kn, kn < lend, on);
+        v4 bv = bc;
         if (pin_sum != nullptr && lk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
         const double wzk = F.wz[lk];
         const double gzm = (lk > 0) ? F.gz[lk - 1] : 0.0, gzp = (lk < F.nzg - 1) ? F.gz[lk] : 0.0;
@@ -765,6 +783,8 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
         *reinterpret_cast<v4 *>(xo + (int64_t)lk * plane + off_c) = out;
         zm = xcur;
         xcur = zp;
+        on = o2;
+        bc = bn;
     }
 }
 
