@@ -270,10 +270,11 @@ __device__ __forceinline__ FCell fcell(const LevelDev &L, int i, int j)
     FCell c;
     c.wx = L.wx[i];
     c.wy = L.wy[j];
-    c.gxm = (i > 0) ? L.gx[i - 1] : 0.0;
-    c.gxp = (i < L.nx - 1) ? L.gx[i] : 0.0;
-    c.gym = (j > 0) ? L.gy[j - 1] : 0.0;
-    c.gyp = (j < L.ny - 1) ? L.gy[j] : 0.0;
+    const bool px = L.per & 1, py = L.per & 2;  // the wrap face g[n - 1] couples cell n - 1 and cell 0 (face_coefs)
+    c.gxm = (i > 0) ? L.gx[i - 1] : (px ? L.gx[L.nx - 1] : 0.0);
+    c.gxp = (i < L.nx - 1 || px) ? L.gx[i] : 0.0;
+    c.gym = (j > 0) ? L.gy[j - 1] : (py ? L.gy[L.ny - 1] : 0.0);
+    c.gyp = (j < L.ny - 1 || py) ? L.gy[j] : 0.0;
     return c;
 }
 __device__ __forceinline__ double fdiag(const FCell &q, double wzk, double gzm, double gzp)
@@ -296,7 +297,12 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
     // halo duty: every thread one cell of the two y-halo rows, 16 threads one cell of the two x-halo columns
     const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
     const int hx_col = (tid & 1) ? FX : -1, hx_y = (tid >> 1) & 7;
-    const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
+    // periodic directions (whole levels only): the halo cells are the ones across the seam, plane -1 is plane nz - 1
+    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
+    int hyj = j0 + hy_row, hxi = i0 + hx_col;
+    const int hyi = i0 + hy_x, hxj = j0 + hx_y;
+    if (py) hyj = hyj < 0 ? L.ny - 1 : (hyj >= L.ny ? 0 : hyj);
+    if (px) hxi = hxi < 0 ? L.nx - 1 : (hxi >= L.nx ? 0 : hxi);
     const bool hy_ok = hyj >= 0 && hyj < L.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < L.nx;
     const int64_t off_c = (int64_t)j * L.nx + ic, off_hy = (int64_t)hyj * L.nx + hyi, off_hx = (int64_t)hxj * L.nx + hxi;
     FCell q4[4], qhy = {}, qhx = {};
@@ -313,13 +319,14 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
         bprev = bcur;
         x1m = x1c;
         x1c = x1p;
-        if (kk >= 0 && kk < L.nzg) {
-            const double *pb = b + (int64_t)kk * plane;
+        const int kw = pz ? (kk < 0 ? L.nzg - 1 : (kk >= L.nzg ? 0 : kk)) : kk;
+        if (kw >= 0 && kw < L.nzg) {
+            const double *pb = b + (int64_t)kw * plane;
             v4 bv = *reinterpret_cast<const v4 *>(pb + off_c);
-            if (pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;  // PINNED: effective b at cell 0
+            if (pin_sum != nullptr && kw == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;  // PINNED: effective b at cell 0
             const double hyv = hy_ok ? pb[off_hy] : 0.0, hxv = hx_ok ? pb[off_hx] : 0.0;
-            const double wzk = L.wz[kk];
-            const double gzm = (kk > 0) ? L.gz[kk - 1] : 0.0, gzp = (kk < L.nzg - 1) ? L.gz[kk] : 0.0;
+            const double wzk = L.wz[kw];
+            const double gzm = (kw > 0) ? L.gz[kw - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (kw < L.nzg - 1 || pz) ? L.gz[kw] : 0.0;
             bcur = bv;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
         if (kc < k0 || kc >= L.nzg) continue;
         const int sc = (kc + 3) % 3;
         const double wzk = L.wz[kc];
-        const double gzm = (kc > 0) ? L.gz[kc - 1] : 0.0, gzp = (kc < L.nzg - 1) ? L.gz[kc] : 0.0;
+        const double gzm = (kc > 0) ? L.gz[kc - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (kc < L.nzg - 1 || pz) ? L.gz[kc] : 0.0;
         v4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -345,12 +352,12 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
             const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
             const double xcc = x1c[c];
             double sum = 0.0;
-            if (i > 0) sum += c0 * (x1[sc][ty + 1][lx - 1] - xcc);
-            if (i < L.nx - 1) sum += c1 * (x1[sc][ty + 1][lx + 1] - xcc);
-            if (j > 0) sum += c2 * (x1[sc][ty][lx] - xcc);
-            if (j < L.ny - 1) sum += c3 * (x1[sc][ty + 2][lx] - xcc);
-            if (kc > 0) sum += c4 * (x1m[c] - xcc);
-            if (kc < L.nzg - 1) sum += c5 * (x1p[c] - xcc);
+            if (i > 0 || px) sum += c0 * (x1[sc][ty + 1][lx - 1] - xcc);
+            if (i < L.nx - 1 || px) sum += c1 * (x1[sc][ty + 1][lx + 1] - xcc);
+            if (j > 0 || py) sum += c2 * (x1[sc][ty][lx] - xcc);
+            if (j < L.ny - 1 || py) sum += c3 * (x1[sc][ty + 2][lx] - xcc);
+            if (kc > 0 || pz) sum += c4 * (x1m[c] - xcc);
+            if (kc < L.nzg - 1 || pz) sum += c5 * (x1p[c] - xcc);
             out[c] = xcc + omega * ((bprev[c] - sum) / d);
         }
         *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = out;
@@ -381,7 +388,13 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
     const int j = j0 + ty, ic = i0 + 4 * tx;
     const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
     const int hx_col = (tid & 1) ? FX : -1, hx_y = (tid >> 1) & 7;
-    const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
+    // periodic directions: the halo cells are the ones across the seam; a periodic z needs the whole level here
+    // (plane -1 is plane nz - 1), slabs are served with per == 0 only
+    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
+    int hyj = j0 + hy_row, hxi = i0 + hx_col;
+    const int hyi = i0 + hy_x, hxj = j0 + hx_y;
+    if (py) hyj = hyj < 0 ? L.ny - 1 : (hyj >= L.ny ? 0 : hyj);
+    if (px) hxi = hxi < 0 ? L.nx - 1 : (hxi >= L.nx ? 0 : hxi);
     const bool hy_ok = hyj >= 0 && hyj < L.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < L.nx;
     const int64_t off_c = (int64_t)j * L.nx + ic, off_hy = (int64_t)hyj * L.nx + hyi, off_hx = (int64_t)hxj * L.nx + hxi;
     FCell q4[4];
@@ -391,12 +404,14 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0};
     if (L.k0 + l0 > 0) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(l0 - 1) * plane + off_c);
+    else if (pz) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(L.nzg - 1) * plane + off_c);
     xc = *reinterpret_cast<const v4 *>(xi + (int64_t)l0 * plane + off_c);
     for (int lk = l0; lk < lend; ++lk) {
         const int kk = L.k0 + lk;  // global plane
         const int slot = lk & 1;
         const double *px = xi + (int64_t)lk * plane;
         if (kk + 1 < L.nzg) zp = *reinterpret_cast<const v4 *>(px + plane + off_c);
+        else if (pz) zp = *reinterpret_cast<const v4 *>(xi + off_c);
         v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)lk * plane + off_c);
         const v4 braw = bv;
         if (pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
         if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? px[off_hx] : 0.0;
         __syncthreads();
         const double wzk = L.wz[kk];
-        const double gzm = (kk > 0) ? L.gz[kk - 1] : 0.0, gzp = (kk < L.nzg - 1) ? L.gz[kk] : 0.0;
+        const double gzm = (kk > 0) ? L.gz[kk - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (kk < L.nzg - 1 || pz) ? L.gz[kk] : 0.0;
         v4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -417,12 +432,12 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
             const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
             const double xcc = xc[c];
             double sum = 0.0;
-            if (i > 0) sum += c0 * (sp[slot][ty + 1][lx - 1] - xcc);
-            if (i < L.nx - 1) sum += c1 * (sp[slot][ty + 1][lx + 1] - xcc);
-            if (j > 0) sum += c2 * (sp[slot][ty][lx] - xcc);
-            if (j < L.ny - 1) sum += c3 * (sp[slot][ty + 2][lx] - xcc);
-            if (kk > 0) sum += c4 * (zm[c] - xcc);
-            if (kk < L.nzg - 1) sum += c5 * (zp[c] - xcc);
+            if (i > 0 || px) sum += c0 * (sp[slot][ty + 1][lx - 1] - xcc);
+            if (i < L.nx - 1 || px) sum += c1 * (sp[slot][ty + 1][lx + 1] - xcc);
+            if (j > 0 || py) sum += c2 * (sp[slot][ty][lx] - xcc);
+            if (j < L.ny - 1 || py) sum += c3 * (sp[slot][ty + 2][lx] - xcc);
+            if (kk > 0 || pz) sum += c4 * (zm[c] - xcc);
+            if (kk < L.nzg - 1 || pz) sum += c5 * (zp[c] - xcc);
             if (MODE == 3)
                 out[c] = bv[c] - sum;
             else {
@@ -1660,12 +1675,13 @@ static int halo_level(pib_solver *s, const GridLevel &g, double *x_owned, hipStr
 
 // all-gather the owned coarse planes of level `lc` (ownership = the parents of the finer level's slab planes) into the
 // replicated level vector
-// levels the LDS-tiled kernels (k_presmooth2, k_level_march) serve: whole on this rank, not periodic, 3-D, tile-divisible
+// levels the LDS-tiled kernels (k_presmooth2, k_level_march) serve: whole on this rank, 3-D, tile-divisible (periodic or not;
+// the fused transfers k_prolong_smooth / k_restrict_march additionally want per == 0)
 static bool march_ok(const pib_solver *s, const GridLevel &g)
 {
     const bool whole = (s->comm.nranks == 1) || g.replicated;
     // a march needs enough tiles x plane chunks to fill the chip: levels of at least 2^24 cells
-    return whole && g.per == 0 && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && g.k0 == 0 &&
+    return whole && !g.zring && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && g.k0 == 0 &&
            g.k1 == g.n[2] && g.nloc >= (int64_t)s->cfg.march_min_cells;
 }
 // k_level_march also serves a slab (or a run of its planes: the interior part of produce_and_exchange): at least 8
@@ -1673,7 +1689,9 @@ static bool march_ok(const pib_solver *s, const GridLevel &g)
 static bool march_planes_ok(const pib_solver *s, const GridLevel &g)
 {
     const int64_t nk = g.k1 - g.k0;
-    return g.per == 0 && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && nk >= 8 &&
+    // a periodic z is served on the whole level only (plane -1 = plane nz - 1 of the same vector)
+    const bool z_ok = !(g.per & 4) || (!g.zring && g.k0 == 0 && g.k1 == g.n[2]);
+    return z_ok && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && nk >= 8 &&
            nk * g.plane >= (int64_t)s->cfg.march_min_cells;
 }
 // planes per workgroup: 64 on a 512^3 range (2048 workgroups), 16 on a 256^3 one (1024)
@@ -1964,7 +1982,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         PIB_CHK(halo_level(s, cg, xc, q));
         // prolongation + first post-smoothing step in one march (the corrected iterate never goes to HBM)
         const bool dots_l = l == 0 && s->gmg_want_dots && !cheb;
-        if (s->cfg.fuse_prolong && !cheb && post >= 1 && !(post == 1 && dots_l) && march_ok(s, g) && g.plain_pair && g.tper == 0 &&
+        if (s->cfg.fuse_prolong && !cheb && post >= 1 && !(post == 1 && dots_l) && march_ok(s, g) && g.plain_pair && g.per == 0 && g.tper == 0 &&
             ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(b)) & 31u) == 0) {
             const int FZ = march_planes(g);
             hipLaunchKernelGGL(k_prolong_smooth, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),

@@ -385,3 +385,39 @@ def test_matrix_free_velocity_operator_is_the_csr_product(lin, case):
         s.destroy()
     assert out[0][1] == out[1][1] and out[0][1] >= 2
     assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("n,per", [((128, 16, 24), (True, True, True)), ((128, 8, 40), (True, False, True)),
+                                   ((256, 16, 18), (False, True, False))])
+def test_blocked_smoothers_on_periodic_levels(lin, n, per):
+    """gmg.hip k_presmooth2 / k_level_march on periodic levels (the tile's halo cells are the ones across the seam,
+    plane -1 is plane nz - 1): the fused pre-smoothing pair is bit-identical to the streaming kernels, the blocked level
+    kernel equal to rounding (mode 8 groups its sums by tile), and both follow the oracle's periodic V-cycle."""
+    from petibm_amd import capi
+    dt = 0.01
+    cfg = omesh.periodic_config(n, per)
+    m = omesh.create_mesh(cfg)
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    xs, b = rhs_for(A)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    out = {}
+    for name, extra in (("march", "pib_march_min_cells=0\n"), ("nofuse", "pib_march_min_cells=0\npib_fuse_presmooth=0\n"),
+                        ("stream", "pib_march_min_cells=0\npib_march_levels=0\npib_fuse_presmooth=0\n")):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=extra))
+        s.setPeriodic(per)
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        out[name] = (x, s.getResidualHistory(), s.getIters())
+        s.destroy()
+    assert out["march"][2] == out["nofuse"][2] and np.array_equal(out["march"][1], out["nofuse"][1])
+    assert np.array_equal(out["march"][0], out["nofuse"][0])
+    assert out["march"][2] == out["stream"][2] and np.allclose(out["march"][1], out["stream"][1], rtol=1e-9)
+    assert np.abs(out["march"][0] - out["stream"][0]).max() <= 1e-11 * np.abs(out["stream"][0]).max()
+    g = clib.GMG(n, w, dt, nullspace=1, pre=2, post=2, omega=0.9, coarsest_sweeps=32, periodic=per)
+    ref = g.pcg(A, b, rtol=1e-10, maxit=200)
+    assert iters_close(out["march"][2], ref["iters"])
+    ke = min(len(out["march"][1]), len(ref["history"]), 6)
+    assert np.allclose(out["march"][1][:ke], ref["history"][:ke], rtol=1e-8)
+    assert np.linalg.norm(b - clib.spmv(A, out["march"][0])) <= 1.5e-10 * np.linalg.norm(b)
