@@ -172,6 +172,73 @@ static VelDev vel_dev(const VelStencil &h)
     return V;
 }
 
+// The same rows, four cells per lane (grid lines of a multiple of four points that start on a 32-byte boundary: every
+// periodic direction, every component across its own direction with an even count): the centre and the +-y / +-z
+// neighbours are one 32-byte access each, the x coefficients one vector load per table -- eleven vector-memory
+// instructions for four rows instead of thirty-six (the one-cell form is bound by their issue rate: 2.1 TB/s).  The
+// arithmetic per row is unchanged: bit-identical.  A wave owns one grid line; the cells i = 0 and nx - 1 of the first
+// and last group belong to the shell kernel and are not stored.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_vel_interior4(const Scalars *__restrict__ S, VelDev V, int f, const double *__restrict__ x,
+                                                       double *__restrict__ y)
+{
+    if (S != nullptr && S->done) return;
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int nx = (int)V.n[f][0], ny = (int)V.n[f][1];
+    const int j = blockIdx.y * 4 + threadIdx.y + 1, k = (DIM == 3) ? blockIdx.z + 1 : 0;
+    if (j >= ny - 1) return;
+    const int64_t sy = V.n[f][0], sz = sy * V.n[f][1];
+    const int64_t base = V.off[f] + sy * j + sz * k;
+    const double yneg = V.lneg[f][1][j], ypos = V.lpos[f][1][j];
+    const double zneg = (DIM == 3) ? V.lneg[f][2][k] : 0.0, zpos = (DIM == 3) ? V.lpos[f][2][k] : 0.0;
+    const double *__restrict__ xn = V.lneg[f][0], *__restrict__ xp = V.lpos[f][0];
+    for (int i0 = 4 * (blockIdx.x * 64 + threadIdx.x); i0 < nx; i0 += gridDim.x * 256) {
+        const int64_t p = base + i0;
+        const v4 xc = *reinterpret_cast<const v4 *>(x + p);
+        const v4 ym = *reinterpret_cast<const v4 *>(x + p - sy), yp = *reinterpret_cast<const v4 *>(x + p + sy);
+        v4 zm = {0, 0, 0, 0}, zp = {0, 0, 0, 0};
+        if (DIM == 3) {
+            zm = *reinterpret_cast<const v4 *>(x + p - sz);
+            zp = *reinterpret_cast<const v4 *>(x + p + sz);
+        }
+        const double xl = x[p - 1], xr = x[p + 4];
+        const v4 vn = *reinterpret_cast<const v4 *>(xn + i0), vp = *reinterpret_cast<const v4 *>(xp + i0);
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double xneg = vn[c], xpos = vp[c];
+            double acc = 0.0;
+            acc = acc + xneg;
+            acc = acc + xpos;
+            acc = acc + yneg;
+            acc = acc + ypos;
+            if (DIM == 3) {
+                acc = acc + zneg;
+                acc = acc + zpos;
+            }
+            const double diag = -acc;
+            const double dval = diag * V.scale + V.shift;
+            const double left = (c == 0) ? xl : xc[c - 1], right = (c == 3) ? xr : xc[c + 1];
+            double s = 0.0;
+            if (DIM == 3) s = s + (zneg * V.scale) * zm[c];
+            s = s + (yneg * V.scale) * ym[c];
+            s = s + (xneg * V.scale) * left;
+            s = s + dval * xc[c];
+            s = s + (xpos * V.scale) * right;
+            s = s + (ypos * V.scale) * yp[c];
+            if (DIM == 3) s = s + (zpos * V.scale) * zp[c];
+            out[c] = s;
+        }
+        if (i0 > 0 && i0 + 4 < nx)
+            *reinterpret_cast<v4 *>(y + p) = out;
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (i0 + c >= 1 && i0 + c <= nx - 2) y[p + c] = out[c];
+        }
+    }
+}
+
 void vel_stencil_release(pib_solver *s)
 {
     for (double *p : s->vel.owned) (void)hipFree(p);
@@ -188,9 +255,17 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
         const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
         const bool inner = nx >= 3 && ny >= 3 && (h.dim == 2 || nz >= 3);
         if (inner) {
-            const dim3 grid((unsigned)((nx - 2 + 255) / 256), (unsigned)(ny - 2), (unsigned)(h.dim == 3 ? nz - 2 : 1));
-            if (h.dim == 3) hipLaunchKernelGGL(k_vel_interior<3>, grid, dim3(256), 0, q, S, V, f, x, y);
-            else hipLaunchKernelGGL(k_vel_interior<2>, grid, dim3(256), 0, q, S, V, f, x, y);
+            const bool vec4 = nx % 4 == 0 && h.off[f] % 4 == 0 &&
+                              ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31u) == 0;
+            if (vec4) {
+                const dim3 grid((unsigned)((nx / 4 + 63) / 64), (unsigned)((ny - 2 + 3) / 4), (unsigned)(h.dim == 3 ? nz - 2 : 1));
+                if (h.dim == 3) hipLaunchKernelGGL(k_vel_interior4<3>, grid, dim3(64, 4), 0, q, S, V, f, x, y);
+                else hipLaunchKernelGGL(k_vel_interior4<2>, grid, dim3(64, 4), 0, q, S, V, f, x, y);
+            } else {
+                const dim3 grid((unsigned)((nx - 2 + 255) / 256), (unsigned)(ny - 2), (unsigned)(h.dim == 3 ? nz - 2 : 1));
+                if (h.dim == 3) hipLaunchKernelGGL(k_vel_interior<3>, grid, dim3(256), 0, q, S, V, f, x, y);
+                else hipLaunchKernelGGL(k_vel_interior<2>, grid, dim3(256), 0, q, S, V, f, x, y);
+            }
         }
         const int64_t shell = inner ? 2 * (ny * nz + (nx - 2) * nz + (h.dim == 3 ? (nx - 2) * (ny - 2) : 0)) : nx * ny * nz;
         hipLaunchKernelGGL(k_vel_shell, dim3((unsigned)std::min<int64_t>(4096, (shell + 255) / 256)), dim3(256), 0, q, S, V, f,
