@@ -283,9 +283,12 @@ __device__ __forceinline__ double fdiag(const FCell &q, double wzk, double gzm, 
     const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
     return -(((((c0 + c1) + c2) + c3) + c4) + c5);
 }
+// RES = 1 (a V(1,.) cycle: ONE pre-smoothing step): the second stage is the residual r = b - A x1 instead of the second
+// Jacobi step; x1 goes to xo, r to ro -- b read once, two vectors written, instead of mode 1 + mode 3 (2 + 3 passes).
+template <int RES>
 __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                     const double *__restrict__ b, double *__restrict__ xo,
-                                                    const double *__restrict__ pin_sum, int FZ)
+                                                    const double *__restrict__ pin_sum, int FZ, double *__restrict__ ro)
 {
     if (S != nullptr && S->done) return;
     __shared__ double x1[3][FSY][FSX];
@@ -358,9 +361,13 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
             if (j < L.ny - 1 || py) sum += c3 * (x1[sc][ty + 2][lx] - xcc);
             if (kc > 0 || pz) sum += c4 * (x1m[c] - xcc);
             if (kc < L.nzg - 1 || pz) sum += c5 * (x1p[c] - xcc);
-            out[c] = xcc + omega * ((bprev[c] - sum) / d);
+            out[c] = RES ? bprev[c] - sum : xcc + omega * ((bprev[c] - sum) / d);
         }
-        *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = out;
+        if (RES) {
+            *reinterpret_cast<v4 *>(ro + (int64_t)kc * plane + off_c) = out;
+            *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = x1c;
+        } else
+            *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = out;
     }
 }
 
@@ -1827,8 +1834,8 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 (reinterpret_cast<uintptr_t>(b) & 31u) == 0 && (reinterpret_cast<uintptr_t>(c) & 31u) == 0) {
                 // steps 0 and 1 in one kernel; the result lands where step 1 would have put it
                 const int FZ = march_planes(g);
-                hipLaunchKernelGGL(k_presmooth2, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
-                                   dim3(256), 0, q, S, dev_of(g), omega, b, c, pin_l, FZ);
+                hipLaunchKernelGGL(k_presmooth2<0>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
+                                   dim3(256), 0, q, S, dev_of(g), omega, b, c, pin_l, FZ, nullptr);
                 PIB_HIP(hipGetLastError());
                 std::swap(a, c);
                 sw = 1;
@@ -1942,10 +1949,20 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // final buffer after `swaps` swaps starting from a: a if even else c
             if (swaps % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
         }
-        PIB_CHK(smooth_seq(g, b, pin_l, a, c, pre, true, true));
-        PIB_CHK(halo_level(s, g, a, q));
         double *rr = g.r + pl;
-        {
+        const bool fused_res = pre == 1 && !cheb && presmooth2_ok(s, g) &&
+                               ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(rr)) & 31u) == 0;
+        if (fused_res) {
+            // one pre-smoothing step from zero and the residual of its result in one march
+            const int FZ = march_planes(g);
+            hipLaunchKernelGGL(k_presmooth2<1>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
+                               dim3(256), 0, q, S, dev_of(g), omega, b, a, pin_l, FZ, rr);
+            PIB_HIP(hipGetLastError());
+        } else {
+            PIB_CHK(smooth_seq(g, b, pin_l, a, c, pre, true, true));
+            PIB_CHK(halo_level(s, g, a, q));
+        }
+        if (!fused_res) {
             const double *in = a;
             auto run = [&](int64_t kb, int64_t kc) -> int {
                 return launch_level_planes<3>(s, g, kb, kc, omega, b, in, rr, pin_l, guarded, q);

@@ -709,10 +709,13 @@ def test_device_velocity_operator_bit_exact_and_bicgstab(lin, case):
     s.destroy()
 
 
+@pytest.mark.parametrize("sweeps", [2, 1])
 @pytest.mark.parametrize("n,pinned", [((128, 16, 12), False), ((128, 24, 10), True), ((256, 8, 70), False)])
-def test_fused_presmoothing_pair_is_bit_identical(lin, n, pinned):
+def test_fused_presmoothing_pair_is_bit_identical(lin, n, pinned, sweeps):
     """gmg.hip k_presmooth2: the first two pre-smoothing steps from a zero guess in one LDS-tiled kernel (levels with
-    nx % 128 == 0, ny % 8 == 0) against the two streaming kernels -- same iterates, bit for bit -- and the oracle."""
+    nx % 128 == 0, ny % 8 == 0) against the two streaming kernels -- same iterates, bit for bit -- and the oracle.
+    sweeps = 1 (the V(1,1) cycle of the reference's AmgX configurations): the one pre-smoothing step and the residual
+    of its result in that kernel (k_presmooth2<1>) against mode 1 + the residual kernel."""
     from petibm_amd import capi
     cfg = stretched_3d(n, r=(1.01, 0.97, 1.04))
     dt = 0.01
@@ -723,14 +726,14 @@ def test_fused_presmoothing_pair_is_bit_identical(lin, n, pinned):
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
     for fuse in (1, 0):
-        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_fuse_presmooth={fuse}\n"))
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra=f"pib_march_min_cells=0\npib_fuse_presmooth={fuse}\n"))
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)
         s.solve(x, b)
         out.append((x, s.getResidualHistory(), s.getIters()))
         s.destroy()
     assert out[0][2] == out[1][2] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
-    g = clib.GMG(list(n), w, dt, nullspace=2 if pinned else 1, pre=2, post=2, omega=0.9, coarsest_sweeps=32)
+    g = clib.GMG(list(n), w, dt, nullspace=2 if pinned else 1, pre=sweeps, post=sweeps, omega=0.9, coarsest_sweeps=32)
     ref = g.pcg(A, b, rtol=1e-10, maxit=200)
     assert iters_close(out[0][2], ref["iters"])
     ke = min(len(out[0][1]), len(ref["history"]), 6)
