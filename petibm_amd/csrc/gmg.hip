@@ -649,10 +649,13 @@ __device__ __forceinline__ PHalo phalo(const LevelDev &F, int i, int j, int I0, 
     h.wb = right ? pw.w : pw.y;
     return h;
 }
+// DOTS (the only post-smoothing step of level 0 writes z = M^-1 r): the partial sums of k_level_march<8>, same grouping.
+template <int DOTS>
 __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
                                                         const double *__restrict__ b, const double *__restrict__ xc,
                                                         const double *__restrict__ xi, double *__restrict__ xo,
-                                                        const double *__restrict__ pin_sum, int FZ)
+                                                        const double *__restrict__ pin_sum, int FZ, double *__restrict__ part,
+                                                        int part_stride)
 {
     if (S != nullptr && S->done) return;
     __shared__ __attribute__((aligned(16))) double sp[2][FSY][FSX];
@@ -758,6 +761,7 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
         return out;
     };
     const int lend = (l0 + FZ < F.nzg) ? l0 + FZ : F.nzg;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     // prologue: the coarse planes under l0 - 1 and l0 (l0 is even: K0 - 1 and K0), then those two corrected planes
     const int K0 = l0 >> 1;
     if (K0 > 0) stage(K0 - 1);
@@ -781,6 +785,7 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
         __syncthreads();
         if (kn < F.nzg) zp = correct(kn, kn < lend, on);
         v4 bv = bc;
+        const v4 braw = bc;
         if (pin_sum != nullptr && lk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
         const double wzk = F.wz[lk];
         const double gzm = (lk > 0) ? F.gz[lk - 1] : 0.0, gzp = (lk < F.nzg - 1) ? F.gz[lk] : 0.0;
@@ -801,12 +806,34 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
             if (lk > 0) sum += c4 * (zm[c] - xcc);
             if (lk < F.nzg - 1) sum += c5 * (zp[c] - xcc);
             out[c] = xcc + omega * ((bv[c] - sum) / d);
+            if (DOTS) {
+                acc0 += out[c] * braw[c];
+                acc1 += out[c] * out[c];
+                acc2 += out[c];
+            }
         }
         *reinterpret_cast<v4 *>(xo + (int64_t)lk * plane + off_c) = out;
         zm = xcur;
         xcur = zp;
         on = o2;
         bc = bn;
+    }
+    if (DOTS) {
+        __shared__ double sh[3][4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        double v[3] = {acc0, acc1, acc2};
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[k2] += __shfl_down(v[k2], o, 64);
+            if (lane == 0) sh[k2][w] = v[k2];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int k2 = threadIdx.x;
+            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            part[(int64_t)k2 * part_stride + blk] = (sh[k2][0] + sh[k2][1]) + (sh[k2][2] + sh[k2][3]);
+        }
     }
 }
 
@@ -1999,11 +2026,29 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         PIB_CHK(halo_level(s, cg, xc, q));
         // prolongation + first post-smoothing step in one march (the corrected iterate never goes to HBM)
         const bool dots_l = l == 0 && s->gmg_want_dots && !cheb;
-        if (s->cfg.fuse_prolong && !cheb && post >= 1 && !(post == 1 && dots_l) && march_ok(s, g) && g.plain_pair && g.per == 0 && g.tper == 0 &&
+        if (s->cfg.fuse_prolong && !cheb && post >= 1 && march_ok(s, g) && g.plain_pair && g.per == 0 && g.tper == 0 &&
             ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(b)) & 31u) == 0) {
             const int FZ = march_planes(g);
-            hipLaunchKernelGGL(k_prolong_smooth, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
-                               dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, pin_l, FZ);
+            const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ));
+            if (post == 1 && dots_l) {
+                // the only post-smoothing step also delivers z.r, z.z, sum z (what launch_level<8> does)
+                const int64_t need = (int64_t)mg.x * mg.y * mg.z;
+                if (need > s->gmg_part_cap) {
+                    if (s->d_gmg_part) (void)hipFree(s->d_gmg_part);
+                    s->d_gmg_part = nullptr;
+                    PIB_HIP(hipMalloc(&s->d_gmg_part, sizeof(double) * (size_t)(3 * need + 3 * BIG_STAGE)));
+                    s->gmg_part_cap = need;
+                }
+                double *part = s->d_gmg_part;
+                const int part_stride = (int)s->gmg_part_cap;
+                hipLaunchKernelGGL(k_prolong_smooth<1>, mg, dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, pin_l, FZ, part,
+                                   part_stride);
+                double *stage = part + 3 * (int64_t)part_stride;
+                hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)need, stage);
+                hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
+                s->gmg_dots_done = true;
+            } else
+                hipLaunchKernelGGL(k_prolong_smooth<0>, mg, dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, pin_l, FZ, nullptr, 0);
             PIB_HIP(hipGetLastError());
             std::swap(a, c);
             PIB_CHK(smooth_seq(g, b, pin_l, a, c, post - 1, false, l > 0, dots_l));

@@ -766,14 +766,15 @@ def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
     assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("key", ["pib_march_restrict", "pib_fuse_prolong"])
+@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
 @pytest.mark.parametrize("n,pinned", [((128, 32, 24), False), ((256, 16, 40), True), ((128, 16, 34), False)])
-def test_marching_transfers_are_bit_identical(lin, n, pinned, key):
+def test_marching_transfers_are_bit_identical(lin, n, pinned, key, sweeps):
     """gmg.hip k_restrict_march (fully paired 3-D levels with nx % 128 == 0, ny % 16 == 0: a fine plane goes through LDS
     once and feeds its two coarse planes) against the row kernel k_restrict_rows, and k_prolong_smooth (prolongation +
     first post-smoothing step in one march, the corrected iterate only on chip) against k_prolong_rows + k_level_march:
     the same sums in the same order, so the whole solve is bit-identical; mildly stretched widths keep every aggregate
-    a pair and the weights non-trivial."""
+    a pair and the weights non-trivial.  sweeps = 1: the one post-smoothing step of level 0 also delivers the
+    Krylov sums (k_prolong_smooth<1>, grouped like k_level_march<8>)."""
     from petibm_amd import capi
     names, r = "xyz", (1.002, 1.01, 0.99)
     cfg = omesh.uniform_config(n)
@@ -787,14 +788,14 @@ def test_marching_transfers_are_bit_identical(lin, n, pinned, key):
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
     for march in (1, 0):
-        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)
         s.solve(x, b)
         out.append((x, s.getResidualHistory(), s.getIters()))
         s.destroy()
     assert out[0][2] == out[1][2] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
-    g = clib.GMG(list(n), w, dt, nullspace=2 if pinned else 1, pre=2, post=2, omega=0.9, coarsest_sweeps=32)
+    g = clib.GMG(list(n), w, dt, nullspace=2 if pinned else 1, pre=sweeps, post=sweeps, omega=0.9, coarsest_sweeps=32)
     ref = g.pcg(A, b, rtol=1e-10, maxit=200)
     assert iters_close(out[0][2], ref["iters"])
     ke = min(len(out[0][1]), len(ref["history"]), 6)
