@@ -177,6 +177,40 @@ def velocity_bench(args):
     s.destroy()
 
 
+def refuse(args, why: str) -> int:
+    """A run that cannot start still prints ONE JSON line (value null + the reason) instead of a bare traceback."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"metric": f"Poisson DOF/s (one pressure solve to rel. residual 1e-10), {args.n}^3 cavity",
+                          "value": None, "unit": "DOF/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "f64", "data": "synthetic", "config": {"workload": f"{args.n}^3 cavity pressure Poisson"},
+                          "notes": [why]}), flush=True)
+    return 2
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one per GPU, RCCL over xGMI) through
+    `python -m torch.distributed.run` on 127.0.0.1 with a free port, and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    try:
+        import torch
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:  # noqa: BLE001
+        ndev = 0
+    if ndev < args.gpus and os.environ.get("PIB_BENCH_SHARE_GPU", "0") != "1":
+        return refuse(args, f"--gpus {args.gpus} but only {ndev} GPU(s) visible on this node (one rank per GPU)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,12 +234,19 @@ def main():
     if args.system == "velocity":
         return velocity_bench(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if world != args.gpus:
+        return refuse(args, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        return refuse(args, "no GPU visible: bench.py has no CPU path")
+    share_probe = os.environ.get("PIB_BENCH_SHARE_GPU", "0") == "1"
+    if not share_probe and torch.cuda.device_count() < (world if world > 1 else 1):
+        return refuse(args, f"{world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU)")
     # PIB_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0, torch side on gloo -- lets the N>1 code path be
     # exercised on a 1-GPU box when RCCL accepts several ranks per device.
     share = os.environ.get("PIB_BENCH_SHARE_GPU", "0") == "1"
@@ -346,4 +387,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -11,11 +11,13 @@
 //     rows + global columns; contiguous double arrays).  Used by the examples
 //     and tests of this repository, which must build where PETSc is absent.
 //   * -DPIB_WITH_PETSC: the class takes PETSc `Mat` / `Vec` exactly like the
-//     reference (`setMatrix(const Mat&)`, `solve(Vec&, Vec&)`), pulling the
-//     local CSR with MatMPIAIJGetLocalMat + MatGetRowIJ and the arrays with
-//     VecGetArray.  This is the class PetIBM's factory instantiates for
-//     `type: GPU`.  It cannot be compiled in this image
-//     (no PETSc); it is kept deliberately small.
+//     reference (`setMatrix(const Mat&)`, `solve(Vec&, Vec&)`); the local
+//     CSR comes from MatGetRowIJ on the matrix itself (MATSEQAIJ, np = 1) or
+//     on MatMPIAIJGetLocalMat's result (MATMPIAIJ), the arrays from
+//     VecGetArray (petsc_adapter.hpp).  This is the class PetIBM's factory
+//     instantiates for `type: GPU`.  No PETSc exists in this
+//     image: the branch is syntax-checked against a declarations-only stub
+//     (tests/stubs/petsc, tests/test_boundary_headers.py), nothing more.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -26,13 +28,19 @@
 #include "../petibm_amd.h"
 
 #ifdef PIB_WITH_PETSC
-#include <petscmat.h>
-#include <petscvec.h>
+#include "petsc_adapter.hpp"
 #endif
 
 namespace petibm_amd
 {
 typedef int ErrorCode;  // PetscErrorCode-compatible: 0 success, PETSC_ERR_* otherwise
+#ifdef PIB_WITH_PETSC
+typedef PetscInt Int;    // getIters(PetscInt &), getResidual(PetscReal &): include/petibm/linsolver.h:122,131
+typedef PetscReal Real;
+#else
+typedef int Int;
+typedef double Real;
+#endif
 
 #ifndef PIB_WITH_PETSC
 // minimal stand-ins for the two PETSc types on the boundary
@@ -77,8 +85,8 @@ public:
     virtual ErrorCode setMatrix(const Mat &A) = 0;
     virtual ErrorCode solve(Vec &x, Vec &b) = 0;
 #endif
-    virtual ErrorCode getIters(int &iters) = 0;
-    virtual ErrorCode getResidual(double &res) = 0;
+    virtual ErrorCode getIters(Int &iters) = 0;
+    virtual ErrorCode getResidual(Real &res) = 0;
 
 protected:
     std::string name, config, type;
@@ -99,6 +107,9 @@ public:
     }
     ~LinSolverHIP() override
     {
+#ifdef PIB_WITH_PETSC
+        if (petsc::finalized()) return;  // no-op after PetscFinalize, like ~LinSolverAmgX (linsolveramgx.cpp:28-38)
+#endif
         if (h_) pib_destroy(h_);
     }
     ErrorCode constructionError() const { return err_; }
@@ -109,40 +120,9 @@ public:
         return LinSolverBase::destroy();
     }
 #ifdef PIB_WITH_PETSC
-    ErrorCode setMatrix(const ::Mat &A) override
-    {
-        // local rows, global columns of the assembled (MPI)AIJ matrix -- what AmgXSolver::setA extracts
-        ::Mat lA;
-        PetscErrorCode ierr;
-        PetscInt n, rstart, rend, N;
-        const PetscInt *ia, *ja;
-        PetscScalar *va;
-        PetscBool done;
-        ierr = MatGetOwnershipRange(A, &rstart, &rend); CHKERRQ(ierr);
-        ierr = MatGetSize(A, &N, nullptr); CHKERRQ(ierr);
-        ierr = MatMPIAIJGetLocalMat(A, MAT_INITIAL_MATRIX, &lA); CHKERRQ(ierr);  // columns are global
-        ierr = MatGetRowIJ(lA, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done); CHKERRQ(ierr);
-        ierr = MatSeqAIJGetArray(lA, &va); CHKERRQ(ierr);
-        int e = (sizeof(PetscInt) == 4)
-                    ? pib_set_csr_i32(h_, (int32_t)n, (int32_t)rstart, (int32_t)N, (const int32_t *)ia, (const int32_t *)ja, va)
-                    : pib_set_csr(h_, n, rstart, N, (const int64_t *)ia, (const int64_t *)ja, va);
-        ierr = MatSeqAIJRestoreArray(lA, &va); CHKERRQ(ierr);
-        ierr = MatRestoreRowIJ(lA, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done); CHKERRQ(ierr);
-        ierr = MatDestroy(&lA); CHKERRQ(ierr);
-        return e;
-    }
-    ErrorCode solve(::Vec &x, ::Vec &b) override
-    {
-        PetscErrorCode ierr;
-        PetscScalar *xa;
-        const PetscScalar *ba;
-        ierr = VecGetArray(x, &xa); CHKERRQ(ierr);
-        ierr = VecGetArrayRead(b, &ba); CHKERRQ(ierr);
-        int e = pib_solve(h_, xa, ba);
-        ierr = VecRestoreArrayRead(b, &ba); CHKERRQ(ierr);
-        ierr = VecRestoreArray(x, &xa); CHKERRQ(ierr);
-        return e;
-    }
+    // SeqAIJ (np = 1) or MPIAIJ: local rows, global columns -- what AmgXSolver::setA extracts (petsc_adapter.hpp)
+    ErrorCode setMatrix(const ::Mat &A) override { return petsc::setMatrix(h_, A); }
+    ErrorCode solve(::Vec &x, ::Vec &b) override { return petsc::solve(h_, x, b); }
 #else
     ErrorCode setMatrix(const Mat &A) override
     {
@@ -150,8 +130,20 @@ public:
     }
     ErrorCode solve(Vec &x, Vec &b) override { return pib_solve(h_, x.data(), b.data()); }
 #endif
-    ErrorCode getIters(int &iters) override { return pib_get_iters(h_, &iters); }
-    ErrorCode getResidual(double &res) override { return pib_get_residual(h_, &res); }
+    ErrorCode getIters(Int &iters) override
+    {
+        int it = 0;
+        const int e = pib_get_iters(h_, &it);
+        iters = (Int)it;
+        return e;
+    }
+    ErrorCode getResidual(Real &res) override
+    {
+        double r = 0.0;
+        const int e = pib_get_residual(h_, &r);
+        res = (Real)r;
+        return e;
+    }
     /** mesh structure of the Poisson operator (enables the stencil twin + multigrid) */
     ErrorCode setGridHint(int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                           const double *gx, const double *gy, const double *gz, int nullspace)
