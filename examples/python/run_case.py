@@ -47,7 +47,8 @@ def main():
     nt = a.nt if a.nt is not None else int(par["nt"])
     start = int(par.get("startStep", 0))
     texts = {k: solver_text(cfg, k, d) for k in ("velocitySolver", "poissonSolver", "forcesSolver")}
-    kw = {"velocity_cfg": texts["velocitySolver"], "poisson_cfg": texts["poissonSolver"]}
+    # an absent parameters.<name>Solver node means "the defaults" (linsolver.cpp:67: type CPU, config None)
+    kw = {k: v for k, v in (("velocity_cfg", texts["velocitySolver"]), ("poisson_cfg", texts["poissonSolver"])) if v is not None}
     if a.app == "navierstokes":
         cfg = dict(cfg, bodies=None)
     if cfg.get("bodies"):

@@ -144,6 +144,16 @@ int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t
 int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                       const double *wz, const double *gx, const double *gy, const double *gz, int nullspace);
 
+/* The grid structure the solver holds (from pib_set_grid_hint, an on-device assembly, or recovered from the matrix):
+ * *has = 0 none; dim, n[3] (problem order), nullspace as registered; *detected != 0 when pib_set_csr recovered it from
+ * the CSR itself.  With a multigrid (AMG) preconditioner pib_set_csr[_i32] inspects the matrix: the 5/7-point DBNG of a
+ * non-periodic tensor-product mesh in natural ordering on z-slabs (y-slabs in 2-D) factorises into 1-D arrays
+ * (csrc/structure.cpp), the recovered operator is verified against the CSR on the device, and an application that only
+ * ever calls setMatrix -- AmgXSolver::setA, src/linsolver/linsolveramgx.cpp:84 -- gets the geometric multigrid without
+ * registering anything.  Any other matrix is left without structure (`pib_detect_structure=0` switches the search off).
+ * Any output pointer may be NULL. */
+int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int *nullspace, int *detected);
+
 /* Periodic directions of the mesh (flow.boundaryConditions type PERIODIC at both ends of a direction for every
  * component: src/misc/misc.cpp checkPeriodicBC, cartesianmesh.cpp:595-681 wraps the neighbour indices).  Call BEFORE
  * pib_assemble_poisson / pib_assemble_velocity / pib_set_grid_hint: the assembled operators then carry the wrapped
@@ -182,7 +192,9 @@ int pib_assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const do
  * the reference's floating-point order.  w[d]: pressure-cell widths; lo/hi: domain start / end per direction
  * (mesh->min / mesh->max); a0[6*f + loc]: ghost coefficient of field f at boundary loc (xMinus,xPlus,yMinus,
  * yPlus,zMinus,zPlus): Dirichlet/convective 0 when loc's normal is f else -1, Neumann 1
- * (src/boundary/singleboundary{dirichlet,neumann,convective}.cpp).  Non-periodic meshes, single rank. */
+ * (src/boundary/singleboundary{dirichlet,neumann,convective}.cpp).  Honours pib_set_periodic.  On several ranks every
+ * rank assembles the rows of its slab of the packed [u | v | w] ordering with a segmented halo plan; a
+ * periodic slab axis on several ranks is PIB_ERR_SUP. */
 int pib_assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                           const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
                           double coeff_nu);

@@ -166,7 +166,11 @@ int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_g
     s->has_grid = false;
     gmg_release(s);
     PIB_CHK(upload_csr(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val));
-    return after_set_matrix(s);
+    PIB_CHK(after_set_matrix(s));
+    s->structure_detected = false;
+    if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
+        PIB_CHK(detect_grid_structure(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val));
+    return 0;
 }
 
 int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t n_global, const int32_t *rowptr,
@@ -178,7 +182,11 @@ int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t
     s->has_grid = false;
     gmg_release(s);
     PIB_CHK(upload_csr(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val));
-    return after_set_matrix(s);
+    PIB_CHK(after_set_matrix(s));
+    s->structure_detected = false;
+    if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
+        PIB_CHK(detect_grid_structure(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val));
+    return 0;
 }
 
 int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
@@ -190,7 +198,27 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
     const double one = 1.0;
     const double *w[3] = {wx, wy, (dim == 3) ? wz : &one};
     const double *g[3] = {gx, gy, (dim == 3) ? gz : nullptr};
+    s->structure_detected = false;
     return grid_register(s, dim, n, w, g, nullspace, -1.0);
+}
+
+int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int *nullspace, int *detected)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_grid_structure: null solver");
+    const bool have = s->has_grid && !s->levels.empty();
+    if (has) *has = have ? 1 : 0;
+    if (detected) *detected = (have && s->structure_detected) ? 1 : 0;
+    if (nullspace) *nullspace = have ? s->nullspace : PIB_NULLSPACE_NONE;
+    if (have) {
+        const GridLevel &g = s->levels[0];
+        if (dim) *dim = g.dim;
+        if (n) {  // internal layout of a 2-D grid is (nx, 1, ny)
+            n[0] = g.n[0];
+            n[1] = (g.dim == 3) ? g.n[1] : g.n[2];
+            n[2] = (g.dim == 3) ? g.n[2] : 1;
+        }
+    }
+    return 0;
 }
 
 int pib_set_periodic(pib_solver *s, const int periodic[3])

@@ -34,13 +34,31 @@ __global__ __launch_bounds__(256) void k_dense_identity(int64_t n, double *__res
 // (which no workgroup modifies in step k) and its own factor f_i = M[i,k] / M[k,k] before touching anything:
 //   row_i -= f_i * row_k   (i != k);   columns < k of M are already zero outside the diagonal, columns > k of Inv still are.
 // The pivots stay unscaled until k_gj_scale divides every row by its diagonal entry.
+// The elimination does not pivot (EBNH is symmetric positive definite for distinct Lagrangian points: E BN H with
+// H = E^T up to the diagonal scalings), so a pivot that has collapsed RELATIVE to the matrix -- coincident or duplicated
+// points, bodies closer than the kernel support -- is reported as PETSC_ERR_MAT_LU_ZRPVT like the LU of the reference
+// would, instead of producing a garbage inverse: |pivot| <= 1e-13 * max |diagonal of the original matrix|.
+__global__ __launch_bounds__(256) void k_dense_maxdiag(int64_t n, const double *__restrict__ M, double *__restrict__ out)
+{
+    double v = 0.0;
+    for (int64_t r = threadIdx.x; r < n; r += 256) v = fmax(v, fabs(M[r * n + r]));
+    __shared__ double sh[256];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
 __global__ __launch_bounds__(256) void k_gj_step(int64_t n, int64_t k, double *__restrict__ M, double *__restrict__ Inv,
-                                                 int *__restrict__ bad)
+                                                 int *__restrict__ bad, const double *__restrict__ maxdiag)
 {
     if (*bad) return;
     const int64_t i = blockIdx.x;
     const double p = M[k * n + k];
-    if (!(fabs(p) > 1e-300)) {
+    if (!(fabs(p) > 1e-300) || !(fabs(p) > 1e-13 * *maxdiag)) {
         if (i == 0 && threadIdx.x == 0) *bad = (int)k + 1;
         return;
     }
@@ -118,7 +136,7 @@ int dense_setup(pib_solver *s)
         dense_release(s);
         PIB_HIP(hipMalloc(&s->dense_inv, bytes));
         PIB_HIP(hipMalloc(&s->dense_work, bytes));
-        PIB_HIP(hipMalloc(&s->dense_bad, sizeof(int)));
+        PIB_HIP(hipMalloc(&s->dense_bad, sizeof(int) + sizeof(double) * 2));  // flag + (8-byte aligned) max |diagonal|
         s->dense_n = n;
     }
     double *M = s->dense_work;
@@ -131,13 +149,15 @@ int dense_setup(pib_solver *s)
     else
         hipLaunchKernelGGL(k_dense_fill<int32_t>, dim3(gb), dim3(256), 0, q, n, (const int32_t *)A.rowptr, A.col, A.val, M);
     hipLaunchKernelGGL(k_dense_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, n, s->dense_inv);
+    double *maxdiag = reinterpret_cast<double *>(s->dense_bad) + 1;
+    hipLaunchKernelGGL(k_dense_maxdiag, dim3(1), dim3(256), 0, q, n, M, maxdiag);
     PIB_HIP(hipGetLastError());
     // the n elimination launches as one hipGraph (their arguments are fixed for a given order n and buffers)
     if (s->dense_graph == nullptr) {
         hipGraph_t g = nullptr;
         PIB_HIP(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
         for (int64_t k = 0; k < n; ++k)
-            hipLaunchKernelGGL(k_gj_step, dim3((unsigned)n), dim3(256), 0, q, n, k, M, s->dense_inv, s->dense_bad);
+            hipLaunchKernelGGL(k_gj_step, dim3((unsigned)n), dim3(256), 0, q, n, k, M, s->dense_inv, s->dense_bad, maxdiag);
         hipLaunchKernelGGL(k_gj_scale, dim3((unsigned)n), dim3(256), 0, q, n, M, s->dense_inv, s->dense_bad);
         const hipError_t e = hipStreamEndCapture(q, &g);
         if (e != hipSuccess || g == nullptr) return fail(PIB_ERR_LIB, "solver %s: capturing the factorisation failed (%s)", s->name.c_str(), hipGetErrorString(e));
@@ -154,7 +174,7 @@ int dense_setup(pib_solver *s)
     PIB_HIP(hipStreamSynchronize(q));
     if (hbad) {
         dense_release(s);
-        return fail(PIB_ERR_MAT_LU_ZRPVT, "solver %s: zero pivot in row %d of the direct factorisation", s->name.c_str(), hbad - 1);
+        return fail(PIB_ERR_MAT_LU_ZRPVT, "solver %s: zero (or relatively vanishing) pivot in row %d of the direct factorisation", s->name.c_str(), hbad - 1);
     }
     return 0;
 }

@@ -1406,6 +1406,7 @@ int gmg_verify(pib_solver *s)
     PIB_HIP(hipMalloc(&d_out, 2 * sizeof(double)));
     PIB_HIP(hipMemsetAsync(d_out, 0, 2 * sizeof(double), q));
     hipLaunchKernelGGL(k_diff_sums, dim3(grid_blocks(n)), dim3(256), 0, q, n, s->A.row0, skip0, Y2, Y1, d_out);
+    PIB_CHK(comm_allreduce_sum(s, d_out, 2, q));  // the same verdict on every rank
     double h[2] = {0, 0};
     PIB_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, q));
     PIB_HIP(hipStreamSynchronize(q));

@@ -116,6 +116,29 @@ static int allgather_host4(pib_solver *s, const int64_t mine[4], std::vector<int
     return 0;
 }
 
+// host-side all-gather of `mine.size()` doubles per rank (same count everywhere; setup only)
+int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vector<double> &all)
+{
+    const int P = s->comm.nranks, r = s->comm.rank;
+    const size_t L = mine.size();
+    if (P <= 1) {
+        all = mine;
+        return 0;
+    }
+    all.assign(L * (size_t)P, 0.0);
+    double *d_all = nullptr;
+    PIB_HIP(hipMalloc(&d_all, sizeof(double) * L * (size_t)P));
+    PIB_HIP(hipMemcpyAsync(d_all + L * (size_t)r, mine.data(), sizeof(double) * L, hipMemcpyHostToDevice, s->stream));
+    std::vector<int64_t> cnt((size_t)P, (int64_t)L), off((size_t)P);
+    for (int q = 0; q < P; ++q) off[(size_t)q] = (int64_t)(L * (size_t)q);
+    PIB_CHK(comm_allgatherv(s, d_all + L * (size_t)r, d_all, cnt, off, s->stream));
+    PIB_HIP(hipMemcpyAsync(all.data(), d_all, sizeof(double) * L * (size_t)P, hipMemcpyDeviceToHost, s->stream));
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    if (s->comm.loop) s->comm.loop->barrier();  // nobody frees while a peer still reads
+    PIB_HIP(hipFree(d_all));
+    return 0;
+}
+
 // After the matrix is known: tell the neighbours how many entries this rank
 // needs from them (all-gather of {n_local, ghost_lo, ghost_hi, row0}).
 int comm_setup_halo(pib_solver *s)

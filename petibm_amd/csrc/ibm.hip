@@ -533,6 +533,17 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
     if (ns->bn_order > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bodies: BN order > 1 with immersed bodies is not supported");
     PIB_HIP(hipSetDevice(ns->device));
+    if (ns->ib != nullptr && ns->psol != nullptr) {
+        // the coupled scheme's Schur hook points into the state that goes away: back to the plain Poisson operator
+        // (and no replay of an iteration captured with the hook); the caller asks for pib_ns_set_coupled again
+        ns->psol->post_matmult = nullptr;
+        ns->psol->post_ctx = nullptr;
+        if (ns->psol->graph) {
+            (void)hipGraphExecDestroy(ns->psol->graph);
+            ns->psol->graph = nullptr;
+        }
+        ns->psol->graph_key = 0;
+    }
     ib_release(ns->ib);
     ns->ib = nullptr;
     const int dim = ns->D.dim;

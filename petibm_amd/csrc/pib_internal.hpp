@@ -82,6 +82,7 @@ struct Config {
     int march_restrict = 1;  // multigrid: restriction of a fully paired 3-D level by the z-marching LDS kernel (gmg.hip k_restrict_march)
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
+    int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;
 };
@@ -207,6 +208,7 @@ struct pib_solver {
     // Poisson solve into the solve of its Schur complement
     int (*post_matmult)(pib_solver *s, const double *p, double *w, bool guarded, hipStream_t q, void *ctx) = nullptr;
     void *post_ctx = nullptr;
+    bool structure_detected = false;         // the grid structure was recovered from the CSR itself (structure.cpp)
     bool hint_pc_only = false;               // the grid structure describes the preconditioner's operator only (BN order > 1)
     std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
     double asm_dt = 0.0;
@@ -259,6 +261,7 @@ int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_
                          int64_t send_next, hipStream_t st);
 int allreduce_slots(pib_solver *s, int first, int count, hipStream_t st);
 int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st);
+int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vector<double> &all);
 int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const std::vector<int64_t> &counts,
                     const std::vector<int64_t> &offs, hipStream_t st);
 void comm_release(pib_solver *s);
@@ -290,6 +293,9 @@ void slab_range(int64_t nplanes, int nranks, int rank, int64_t *b, int64_t *e);
 void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3], const double mn[3], const double mx[3],
                           const int per[3], std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3]);
 int upload_vec(const std::vector<double> &h, double **d);
+// structure.cpp
+int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
+                          const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val);
 // gmg.hip
 int gmg_verify(pib_solver *s);
 int stencil_apply(pib_solver *s, double *x_owned, double *y, hipStream_t st);

@@ -1,0 +1,240 @@
+// structure.cpp -- recover the mesh structure of a Poisson matrix handed over as a plain CSR.
+//
+// The reference's `type: GPU` path gives the solver nothing but the assembled matrix: LinSolverAmgX::setMatrix ->
+// AmgXSolver::setA(A) (src/linsolver/linsolveramgx.cpp:84).  AmgX builds its algebraic hierarchy from those entries;
+// this backend's multigrid is geometric and wants the 1-D width arrays of the mesh.  For PetIBM's Poisson operator they
+// can be read back from the entries: DBNG = D (dt I) G (applications/navierstokes/navierstokes.cpp:349-356) in natural
+// ordering has, toward +x of cell (i,j,k), the entry
+//        dt dy_j dz_k / (0.5 (dx_i + dx_{i+1}))  =  gx_i wy_j wz_k          (createdivergence.cpp:140-151,
+//                                                                           creategradient.cpp:70-86, createbn.cpp:49)
+// i.e. a product of three 1-D factors, and likewise toward +y and +z.  Lines of entries through one base cell give the
+// factors up to one scale per direction; the three conditions g_d[0] * 0.5 (w_d[0] + w_d[1]) = dt (the same dt in every
+// direction) fix the scales up to ONE common length unit, which the operator -- on every multigrid level, because the
+// coarse operators are rediscretised from the widths -- does not depend on.
+//
+// The recovered arrays go through grid_register, which verifies the matrix-free twin against the CSR on the device
+// (1e-10 relative): a matrix that is not such an operator (velocity system, BN order > 1, periodic wrap, arbitrary CSR)
+// simply stays without grid structure.  Several ranks: z-slabs (y-slabs in 2-D); the in-plane lines come from the rank
+// that owns slab plane 1, the lines along the slab axis from every rank's planes, all-gathered as RAW matrix entries so
+// that every rank does the same arithmetic on the same numbers (the level hierarchy must come out identical everywhere).
+#include <algorithm>
+#include <cmath>
+#include <set>
+
+#include "pib_internal.hpp"
+
+namespace pib {
+
+namespace {
+struct HostCsr {
+    int64_t n_local, row0, n_global;
+    const int64_t *rp64, *cl64;
+    const int32_t *rp32, *cl32;
+    const double *val;
+    int64_t RP(int64_t i) const { return rp64 ? rp64[i] : (int64_t)rp32[i]; }
+    int64_t CL(int64_t p) const { return cl64 ? cl64[p] : (int64_t)cl32[p]; }
+    // entry (global row, global column) of a LOCAL row; false if the row is not local or the entry is not stored
+    bool entry(int64_t row, int64_t col, double *v) const
+    {
+        const int64_t l = row - row0;
+        if (l < 0 || l >= n_local) return false;
+        for (int64_t p = RP(l); p < RP(l + 1); ++p)
+            if (CL(p) == col) {
+                *v = val[p];
+                return true;
+            }
+        return false;
+    }
+};
+}  // namespace
+
+int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vector<double> &all);
+
+// returns 0 always unless a collective / HIP call fails; success shows in s->has_grid
+int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
+                          const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val)
+{
+    const HostCsr A{n_local, row0, n_global, rp64, cl64, rp32, cl32, val};
+    const int P = s->comm.nranks, rank = s->comm.rank;
+    // every rank walks through the same collectives whatever it finds locally: `ok` only gates the local work
+    bool ok = !(s->periodic[0] || s->periodic[1] || s->periodic[2]) && n_local > 0;
+    // ---- the distinct |column - row| of the first rows: {1, nx[, nx ny]}
+    int64_t off[3] = {0, 0, 0};
+    int dim = 0;
+    if (ok) {
+        std::set<int64_t> offs;
+        for (int64_t l = 0; l < std::min<int64_t>(n_local, 8); ++l)
+            for (int64_t p = A.RP(l); p < A.RP(l + 1); ++p) {
+                const int64_t d = std::llabs(A.CL(p) - (row0 + l));
+                if (d > 0) offs.insert(d);
+            }
+        if (offs.size() == 2 || offs.size() == 3) {
+            dim = (int)offs.size();
+            int q = 0;
+            for (int64_t d : offs) off[q++] = d;
+        } else
+            ok = false;
+    }
+    int64_t n[3] = {1, 1, 1};
+    if (ok) {
+        ok = off[0] == 1 && off[1] >= 3;
+        if (ok && dim == 3) ok = off[2] % off[1] == 0 && n_global % off[2] == 0;
+        if (ok && dim == 2) ok = n_global % off[1] == 0;
+    }
+    if (ok) {
+        n[0] = off[1];
+        n[1] = (dim == 3) ? off[2] / off[1] : n_global / off[1];
+        n[2] = (dim == 3) ? n_global / off[2] : 1;
+        for (int d = 0; d < dim; ++d) ok = ok && n[d] >= 3;
+    }
+    const int sd = dim - 1;                               // slab axis
+    const int64_t st[3] = {1, n[0], n[0] * n[1]};         // strides
+    const int64_t pl = ok ? st[sd] : 1;                   // cells per slab plane
+    int64_t k0 = 0, k1 = 0;
+    if (ok) {
+        slab_range(n[sd], P, rank, &k0, &k1);
+        ok = k0 * pl == row0 && (k1 - k0) * pl == n_local;  // rows = the DMDA z-slab (y-slab) of this rank
+    }
+    // ---- raw lines of entries.  Buffer layout per rank (fixed length so one all-gather serves):
+    //   [0] status: -1 an expected entry is missing, 1 fine, 2 fine and row 0 is the identity (rank 0)
+    //   in-plane lines (owner of slab plane 1): X[0..mx) A[0..mx) Y[0..mx) B[0..mx)      mx = max in-plane extent
+    //   slab-axis lines (own planes):           Cs[0..mp) Zs[0..mp)                       mp = max planes per rank
+    // first the locally detected sizes (every rank must have found the same grid), then the lines themselves
+    {
+        std::vector<double> head = {ok ? 1.0 : 0.0, (double)dim, (double)n[0], (double)n[1], (double)n[2], 0.0};
+        std::vector<double> heads;
+        PIB_CHK(comm_allgather_host(s, head, heads));
+        bool all_ok = true;
+        for (int r = 0; r < P; ++r) {
+            const double *h = &heads[6 * (size_t)r];
+            all_ok = all_ok && h[0] == 1.0 && h[1] == heads[1] && h[2] == heads[2] && h[3] == heads[3] && h[4] == heads[4];
+        }
+        if (!all_ok) return 0;  // every rank sees the same heads: all leave together
+    }
+    const int64_t mx_all = std::max(n[0], dim == 3 ? n[1] : (int64_t)0);  // longest in-plane line
+    const int64_t mp_all = (n[sd] + P - 1) / P;                           // most planes on one rank
+    const size_t L = 1 + 4 * (size_t)mx_all + 2 * (size_t)mp_all;
+    std::vector<double> mine(L, 0.0), all;
+    mine[0] = 1.0;
+    double *X = &mine[1], *Ax = X + mx_all, *Y = Ax + mx_all, *B = Y + mx_all, *Cs = B + mx_all, *Zs = Cs + mp_all;
+    bool found = true;
+    auto take = [&](int64_t row, int64_t col, double *dst) {
+        double v = 0.0;
+        if (!A.entry(row, col, &v)) found = false;
+        *dst = v;
+    };
+    if (k0 <= 1 && 1 < k1) {  // owner of slab plane 1: the in-plane lines through base index 1
+        if (dim == 3) {
+            const int64_t b = 1 * st[2];
+            for (int64_t i = 0; i < n[0]; ++i) {
+                const int64_t c = b + 1 * st[1] + i;
+                if (i + 1 < n[0]) take(c, c + 1, &X[i]);   // gx_i wy_1 wz_1
+                take(c, c + st[1], &Ax[i]);                 // wx_i gy_1 wz_1
+            }
+            for (int64_t j = 0; j < n[1]; ++j) {
+                const int64_t c = b + j * st[1] + 1;
+                if (j + 1 < n[1]) take(c, c + st[1], &Y[j]);  // wx_1 gy_j wz_1
+                take(c, c + 1, &B[j]);                        // gx_1 wy_j wz_1
+            }
+        } else {
+            for (int64_t i = 0; i < n[0]; ++i) {
+                const int64_t c = 1 * st[1] + i;
+                if (i + 1 < n[0]) take(c, c + 1, &X[i]);   // gx_i wy_1
+                take(c, c + st[1], &Ax[i]);                 // wx_i gy_1
+            }
+        }
+    }
+    for (int64_t k = k0; k < k1; ++k) {  // the lines along the slab axis through the in-plane base cell (1[,1])
+        const int64_t c = k * st[sd] + (dim == 3 ? st[1] + 1 : 1);
+        take(c, c + 1, &Cs[k - k0]);                          // gx_1 wy_1 wz_k     (2-D: gx_1 wy_k)
+        if (k + 1 < n[sd]) take(c, c + st[sd], &Zs[k - k0]);  // wx_1 wy_1 gz_k     (2-D: wx_1 gy_k)
+    }
+    if (rank == 0) {  // pinned pressure: row 0 is the identity (MatZeroRowsColumns, navierstokes.cpp:416-418)
+        bool pinned = true;
+        for (int64_t p = A.RP(0); p < A.RP(1); ++p) pinned = pinned && (A.CL(p) == 0 ? val[p] == 1.0 : val[p] == 0.0);
+        if (pinned) mine[0] = 2.0;
+    }
+    if (!found) mine[0] = -1.0;
+    PIB_CHK(comm_allgather_host(s, mine, all));
+    for (int r = 0; r < P; ++r)
+        if (all[L * (size_t)r] < 0.0) return 0;  // some expected entry is not stored: not this kind of matrix
+    const int nullspace = (all[0] == 2.0) ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT;
+    // ---- assemble the global lines (identical on every rank)
+    int owner1 = 0;
+    for (int r = 0; r < P; ++r) {
+        int64_t b, e;
+        slab_range(n[sd], P, r, &b, &e);
+        if (b <= 1 && 1 < e) owner1 = r;
+    }
+    const double *o1 = &all[L * (size_t)owner1 + 1];
+    std::vector<double> gX(o1, o1 + mx_all), gA(o1 + mx_all, o1 + 2 * mx_all), gY(o1 + 2 * mx_all, o1 + 3 * mx_all),
+        gB(o1 + 3 * mx_all, o1 + 4 * mx_all), gCs((size_t)n[sd], 0.0), gZs((size_t)n[sd], 0.0);
+    for (int r = 0; r < P; ++r) {
+        int64_t b, e;
+        slab_range(n[sd], P, r, &b, &e);
+        const double *src = &all[L * (size_t)r + 1 + 4 * (size_t)mx_all];
+        for (int64_t k = b; k < e; ++k) {
+            gCs[(size_t)k] = src[k - b];
+            gZs[(size_t)k] = src[mp_all + (k - b)];
+        }
+    }
+    // ---- scales: wx_1 = 1; the same dt from face 0 of every direction
+    std::vector<double> w[3], g[3];
+    double dt = 0.0;
+    auto positive = [](const std::vector<double> &v, int64_t cnt) {
+        for (int64_t q = 0; q < cnt; ++q)
+            if (!(v[(size_t)q] > 0.0) || !std::isfinite(v[(size_t)q])) return false;
+        return true;
+    };
+    if (dim == 3) {
+        if (!positive(gX, n[0] - 1) || !positive(gA, n[0]) || !positive(gY, n[1] - 1) || !positive(gB, n[1]) ||
+            !positive(gCs, n[2]) || !positive(gZs, n[2] - 1))
+            return 0;
+        const double xh = gX[0] * (0.5 * (gA[0] / gA[1] + 1.0)), yh = gY[0] * (0.5 * (gB[0] / gB[1] + 1.0)),
+                     zh = gZs[0] * (0.5 * (gCs[0] / gCs[1] + 1.0));
+        const double beta = std::sqrt(xh / yh), gamma = std::sqrt(xh / zh);
+        dt = xh / (beta * gamma);
+        w[0].resize((size_t)n[0]);
+        w[1].resize((size_t)n[1]);
+        w[2].resize((size_t)n[2]);
+        g[0].resize((size_t)n[0] - 1);
+        g[1].resize((size_t)n[1] - 1);
+        g[2].resize((size_t)n[2] - 1);
+        for (int64_t i = 0; i < n[0]; ++i) w[0][(size_t)i] = gA[(size_t)i] / gA[1];
+        for (int64_t j = 0; j < n[1]; ++j) w[1][(size_t)j] = beta * (gB[(size_t)j] / gB[1]);
+        for (int64_t k = 0; k < n[2]; ++k) w[2][(size_t)k] = gamma * (gCs[(size_t)k] / gCs[1]);
+        for (int64_t i = 0; i + 1 < n[0]; ++i) g[0][(size_t)i] = gX[(size_t)i] / (beta * gamma);
+        for (int64_t j = 0; j + 1 < n[1]; ++j) g[1][(size_t)j] = gY[(size_t)j] / gamma;
+        for (int64_t k = 0; k + 1 < n[2]; ++k) g[2][(size_t)k] = gZs[(size_t)k] / beta;
+    } else {
+        if (!positive(gX, n[0] - 1) || !positive(gA, n[0]) || !positive(gCs, n[1]) || !positive(gZs, n[1] - 1)) return 0;
+        const double xh = gX[0] * (0.5 * (gA[0] / gA[1] + 1.0)), zh = gZs[0] * (0.5 * (gCs[0] / gCs[1] + 1.0));
+        const double beta = std::sqrt(xh / zh);
+        dt = xh / beta;
+        w[0].resize((size_t)n[0]);
+        w[1].resize((size_t)n[1]);
+        g[0].resize((size_t)n[0] - 1);
+        g[1].resize((size_t)n[1] - 1);
+        for (int64_t i = 0; i < n[0]; ++i) w[0][(size_t)i] = gA[(size_t)i] / gA[1];
+        for (int64_t k = 0; k < n[1]; ++k) w[1][(size_t)k] = beta * (gCs[(size_t)k] / gCs[1]);
+        for (int64_t i = 0; i + 1 < n[0]; ++i) g[0][(size_t)i] = gX[(size_t)i] / beta;
+        for (int64_t k = 0; k + 1 < n[1]; ++k) g[1][(size_t)k] = gZs[(size_t)k];
+    }
+    if (!(dt > 0.0) || !std::isfinite(dt)) return 0;
+    const double *cw[3] = {w[0].data(), w[1].data(), dim == 3 ? w[2].data() : nullptr};
+    const double *cg[3] = {g[0].data(), g[1].data(), dim == 3 ? g[2].data() : nullptr};
+    const double one = 1.0;
+    if (dim == 2) cw[2] = &one;
+    // registration verifies the recovered operator against the CSR on the device; a mismatch leaves the solver without
+    // grid structure (the outcome is the same on every rank: the check is a global sum)
+    const int e = grid_register(s, dim, n, cw, cg, nullspace, dt);
+    if (e != 0) {
+        s->gmg_error.clear();
+        s->has_grid = false;
+    } else {
+        s->structure_detected = true;
+    }
+    return 0;
+}
+
+}  // namespace pib

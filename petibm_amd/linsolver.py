@@ -172,6 +172,17 @@ class LinSolverBase:
         p = [a.ctypes.data if a is not None else None for a in ws + gs]
         capi.check(capi.load().pib_set_grid_hint(self._h, dim, n3.ctypes.data, *p, int(nullspace)))
 
+    def gridStructure(self):
+        """pib_get_grid_structure: None, or dict(dim, n, nullspace, detected)"""
+        has, dim, ns, det = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        n3 = np.zeros(3, dtype=np.int64)
+        capi.check(capi.load().pib_get_grid_structure(self._h, C.byref(has), C.byref(dim), n3.ctypes.data, C.byref(ns),
+                                                      C.byref(det)))
+        if not has.value:
+            return None
+        return {"dim": dim.value, "n": tuple(int(v) for v in n3[:dim.value]), "nullspace": ns.value,
+                "detected": bool(det.value)}
+
     def setPeriodic(self, periodic) -> None:
         """periodic directions of the mesh (pib_set_periodic); call before the assembly / the grid hint"""
         per = (C.c_int * 3)(*[int(bool(periodic[d])) if d < len(periodic) else 0 for d in range(3)])

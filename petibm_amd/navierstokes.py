@@ -16,6 +16,35 @@ _DIR = {"x": 0, "y": 1, "z": 2}
 _LOC = {"xMinus": 0, "xPlus": 1, "yMinus": 2, "yPlus": 3, "zMinus": 4, "zPlus": 5}
 _BCT = {"DIRICHLET": 0, "NEUMANN": 1, "CONVECTIVE": 2, "PERIODIC": 3}
 
+def _eval_expression(text: str, env: dict):
+    """flow.initialVelocity / initialPressure expressions (the reference parses them with SymEngine,
+    src/parser/parser.cpp): arithmetic on x, y, z, t, nu, pi, e and the elementary functions in `env`.  The text is
+    parsed with `ast` and only those node types are evaluated -- a case directory from somebody else must not be able
+    to run code."""
+    import ast
+    import operator
+    ops = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv,
+           ast.Pow: operator.pow, ast.USub: operator.neg, ast.UAdd: operator.pos}
+
+    def ev(node):
+        if isinstance(node, ast.Expression):
+            return ev(node.body)
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)) and not isinstance(node.value, bool):
+            return node.value
+        if isinstance(node, ast.Name) and node.id in env and not callable(env[node.id]):
+            return env[node.id]
+        if isinstance(node, ast.BinOp) and type(node.op) in ops:
+            return ops[type(node.op)](ev(node.left), ev(node.right))
+        if isinstance(node, ast.UnaryOp) and type(node.op) in ops:
+            return ops[type(node.op)](ev(node.operand))
+        if (isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and callable(env.get(node.func.id))
+                and not node.keywords):
+            return env[node.func.id](*[ev(a) for a in node.args])
+        raise ValueError(f"unsupported element in expression {text!r}: {ast.dump(node)[:60]}")
+
+    return ev(ast.parse(text.replace("^", "**"), mode="eval"))
+
+
 DEFAULT_VELOCITY_CFG = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
                         "solv:convergence=ABSOLUTE\nsolv:tolerance=1e-12\nsolv:norm=L2\nsolv:store_res_history=1\n"
                         "solv:preconditioner(prec)=BLOCK_JACOBI\nprec:relaxation_factor=1.0\n")
@@ -129,7 +158,7 @@ class NavierStokesSolver:
             grids = np.meshgrid(*axes[::-1], indexing="ij")[::-1]  # arrays indexed (k, j, i)
             env = dict(names, x=grids[0], y=grids[1], z=grids[2] if self.dim == 3 else 0.0)
             v = ic[0 if pressure else f]
-            val = float(v) if not isinstance(v, str) else eval(v.replace("^", "**"), {"__builtins__": {}}, env)  # noqa: S307
+            val = float(v) if not isinstance(v, str) else _eval_expression(v, env)
             parts.append(np.broadcast_to(np.asarray(val, dtype=np.float64), grids[0].shape).reshape(-1))
         return np.concatenate(parts)
 
@@ -329,6 +358,8 @@ class DecoupledIBPMSolver(NavierStokesSolver):
             if b.ndim != 2 or b.shape[1] != self.dim:
                 raise capi.PibError(66, "The dimension of Lagrangian points are different than that of the background mesh!")
         npts = np.array([b.shape[0] for b in self.bodies], dtype=np.int64)
+        if not self.bodies:
+            raise capi.PibError(capi.ERR_ARG_OUTOFRANGE, "DecoupledIBPMSolver: the case has no bodies (use NavierStokesSolver)")
         coords = np.ascontiguousarray(np.concatenate(self.bodies, axis=0))
         kernel = str(config.get("parameters", {}).get("delta", "ROMA_ET_AL_1999"))
         capi.check(capi.load().pib_ns_set_bodies(self._h, len(self.bodies), npts.ctypes.data, coords.ctypes.data,

@@ -1,0 +1,144 @@
+"""setMatrix is all an unchanged PetIBM gives a `type: GPU` solver (LinSolverAmgX::setMatrix -> AmgXSolver::setA,
+src/linsolver/linsolveramgx.cpp:84): with an AMG entry in the solver file the backend recovers the mesh structure of the
+Poisson operator from the CSR itself (csrc/structure.cpp) and runs its geometric multigrid.
+
+Bars: the recovered structure solves exactly like the registered one (same iteration count, residual contract recomputed
+by the oracle); anything that is not such an operator is left without structure -- no error at setMatrix, the reference's
+ordering error (PETSC_ERR_ORDER) at solve.
+"""
+import numpy as np
+import pytest
+
+from oracle import clib, mesh as omesh, operators as oops
+from test_gpu_parity import STRETCHED_2D, stretched_3d, poisson_system, rhs_for, amgx_cfg
+from test_gpu_multirank_loopback import _run_ranks, _cfg
+
+pytestmark = pytest.mark.gpu
+
+AMG = "prec:cycle=V\nprec:presweeps=1\nprec:postsweeps=1\nprec:smoother(smooth)=BLOCK_JACOBI\nsmooth:relaxation_factor=0.9\n"
+
+
+def _hint(m, dt, dim):
+    w = [m.dL[3][d].true for d in range(dim)]
+    g = [dt * (1.0 / (0.5 * (wd[1:] + wd[:-1]))) for wd in w]
+    return [int(v) for v in m.n[3][:dim]], w, g
+
+
+@pytest.mark.parametrize("case", ["2d", "3d", "3d_uniform"])
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("idx", ["i64", "i32"])
+def test_structure_recovered_from_the_matrix_solves_like_the_registered_one(case, pinned, idx):
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    cfg = {"2d": STRETCHED_2D, "3d": stretched_3d((20, 18, 14)), "3d_uniform": omesh.uniform_config((16, 12, 20))}[case]
+    dim = 2 if case == "2d" else 3
+    dt = 0.01
+    m, A, _ = poisson_system(cfg, dt=dt, pinned=pinned)
+    xs, b = rhs_for(A, zero_mean=not pinned)
+    if pinned:
+        b[0] = 0.0
+    if idx == "i32":
+        A = oops.CSR(A.n_rows, A.n_cols, A.rowptr.astype(np.int32), A.col.astype(np.int32), A.val)
+    text = amgx_cfg(pc="AMG", tol=1e-10, extra=AMG + "pib_initial_guess_nonzero=0\n")
+    s = LinSolverHIP("poisson", config_text=text)
+    s.setMatrix(A)
+    st = s.gridStructure()
+    n, w, g = _hint(m, dt, dim)
+    assert st is not None and st["detected"] and st["dim"] == dim and list(st["n"]) == n
+    assert st["nullspace"] == (capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    it_detected = s.getIters()
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    if pinned:
+        assert x[0] == 0.0
+    # the same solve with the structure registered by the application (pib_set_grid_hint)
+    t = LinSolverHIP("poisson", config_text=text + "pib_detect_structure=0\n")
+    t.setMatrix(A)
+    assert t.gridStructure() is None
+    t.setGridHint(n, w, g, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+    assert not t.gridStructure()["detected"]
+    y = np.zeros(A.n_rows)
+    t.solve(y, b)
+    assert t.getIters() == it_detected
+    assert np.linalg.norm((x - x.mean()) - (y - y.mean())) <= 1e-8 * np.linalg.norm(y - y.mean())
+    s.destroy()
+    t.destroy()
+
+
+def test_matrices_that_are_not_the_poisson_operator_stay_without_structure():
+    from petibm_amd import capi
+    from petibm_amd.capi import PibError
+    from petibm_amd.linsolver import LinSolverHIP
+    text = amgx_cfg(pc="AMG", tol=1e-10, extra=AMG)
+    m, A, L = poisson_system(stretched_3d((10, 9, 8)))
+    # (i) one entry (and its diagonal) off: factorises almost, the device check against the CSR refuses it
+    B = A.copy()
+    B.val = B.val.copy()
+    rows = np.repeat(np.arange(B.n_rows), np.diff(B.rowptr))
+    hit = np.nonzero((rows == 400) & (B.col == 401))[0][0]
+    B.val[hit] *= 1.001
+    s = LinSolverHIP("poisson", config_text=text)
+    s.setMatrix(B)
+    assert s.gridStructure() is None
+    with pytest.raises(PibError) as ei:
+        s.solve(np.zeros(B.n_rows), np.ones(B.n_rows))
+    assert ei.value.code == capi.ERR_ORDER
+    # (ii) the velocity operator (packed u,v,w ordering, row-scaled Laplacian): a different pattern altogether
+    V = oops.create_velocity_operator(L, 0.01, 0.5 * 0.01) if hasattr(oops, "create_velocity_operator") else None
+    if V is not None:
+        s.setMatrix(V)
+        assert s.gridStructure() is None
+    # (iii) with a Jacobi preconditioner nothing is searched for
+    t = LinSolverHIP("poisson", config_text=amgx_cfg(pc="BLOCK_JACOBI"))
+    t.setMatrix(A)
+    assert t.gridStructure() is None
+    # (iv) the good matrix right after a bad one on the same solver object
+    s.setMatrix(A)
+    assert s.gridStructure() is not None and s.gridStructure()["detected"]
+    s.destroy()
+    t.destroy()
+
+
+@pytest.mark.parametrize("P,n,pinned", [(2, (16, 12, 16), True), (3, (12, 10, 18), False), (2, (24, 20), True),
+                                        (4, (16, 16, 4), False)])
+def test_structure_recovered_on_slabs(P, n, pinned):
+    """every rank hands over its rows only (MatMPIAIJGetLocalMat layout); the lines of entries are gathered"""
+    from petibm_amd import capi, partition
+    from petibm_amd.linsolver import LinSolverHIP
+    dim, dt = len(n), 0.02
+    cfg = omesh.uniform_config(n)
+    m = omesh.create_mesh(cfg)
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.5e-2)
+    if pinned:
+        A = oops.pin_row0(A)
+    xs = np.random.default_rng(3).uniform(-1, 1, m.pN)
+    if pinned:
+        xs[0] = 0.0
+    else:
+        xs -= xs.mean()
+    b = clib.spmv(A, xs)
+    plans = partition.all_plans(n, P)
+
+    def rank_fn(r, uid):
+        pl = plans[r]
+        s = LinSolverHIP("poisson", config_text=_cfg("AMG", tol=1e-11), rank=r, nranks=P, uid=uid, device=0)
+        r0, r1 = pl.row0, pl.row0 + pl.n_local
+        p0, p1 = A.rowptr[r0], A.rowptr[r1]
+        local = oops.CSR(pl.n_local, A.n_cols, A.rowptr[r0:r1 + 1] - p0, A.col[p0:p1], A.val[p0:p1])
+        s.setMatrix(local, row0=r0, n_global=A.n_rows)
+        st = s.gridStructure()
+        x = np.zeros(pl.n_local)
+        s.solve(x, np.ascontiguousarray(b[r0:r1]))
+        its = s.getIters()
+        s.destroy()
+        return x, its, st
+
+    res = _run_ranks(P, rank_fn)
+    for r in res:
+        assert r[2] is not None and r[2]["detected"] and list(r[2]["n"]) == list(n)
+        assert r[2]["nullspace"] == (capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+    x = np.concatenate([r[0] for r in res])
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-11 * np.linalg.norm(b)
+    assert len({r[1] for r in res}) == 1 and res[0][1] < 40
