@@ -252,11 +252,25 @@ int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, 
  *   velocity_cfg / poisson_cfg: solver configuration TEXT (same syntaxes as pib_create).  The Poisson
  *   solver's flavour selects the null-space convention exactly like NavierStokesSolver::setNullSpace
  *   (:395-429): "NVIDIA AmgX" -> pinned row 0 and rhs2[0] = 0, "PETSc KSP" -> constant null space.
- * Single GPU. */
+ * One GPU; pib_ns_create_slab is the same engine on z-slabs. */
 typedef struct pib_ns pib_ns;
 int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                   const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
                   double nu, const char *velocity_cfg, const char *poisson_cfg, int device);
+/* The same engine on this rank's z-slab (y-slab in 2-D) of the mesh: NavierStokesSolver on the DMDA decomposition of
+ * src/mesh/cartesianmesh.cpp:492-538 with nProc = (1, 1, P) (BASELINE configs 3 and 5 are stated on 8
+ * GPUs).  Arguments as pib_ns_create -- the GLOBAL mesh and boundary conditions -- plus rank / nranks / uid as
+ * pib_create.  Collective.  A rank keeps its planes of every field plus one plane of each neighbour; the two solvers
+ * share one communicator; per step: one exchange of u* after the velocity solve, one of dP after the Poisson solve, one
+ * of the projected velocity.  pib_ns_sizes / pib_ns_set_state / pib_ns_get_state / the history terms then speak of this
+ * rank's part of the distributed vectors: the packed [u-slab | v-slab | w-slab] of the reference's DMComposite
+ * (cartesianmesh.cpp:740-779; the component along the slab axis has one plane fewer, on the last rank) and the owned
+ * pressure cells.  Every rank needs >= 2 planes.  Not on slabs: immersed bodies, BN order > 1, a periodic slab axis,
+ * the vorticity utility (PIB_ERR_SUP). */
+int pib_ns_create_slab(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
+                       const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
+                       double nu, const char *velocity_cfg, const char *poisson_cfg, int rank, int nranks,
+                       const void *uid_or_null, int device);
 /* parameters.BN of config.yaml (default 1): order of BN in the Poisson operator D*BN*G and in the projection
  * u = u* - BN G dP (navierstokes.cpp:349-356,583-598).  Call after pib_ns_create, before the first step.  N > 1 builds
  * the operator through pib_assemble_poisson_bn's product chain; not combined with immersed bodies (PIB_ERR_SUP). */

@@ -72,6 +72,8 @@ _PROTOS = {
     "pib_get_csr": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp, _vp]),
     "pib_ns_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double,
                                 C.c_char_p, C.c_char_p, C.c_int]),
+    "pib_ns_create_slab": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double,
+                                     C.c_char_p, C.c_char_p, C.c_int, C.c_int, _vp, C.c_int]),
     "pib_ns_set_bn_order": (C.c_int, [_vp, C.c_int]),
     "pib_ns_get_vorticity": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "pib_ns_set_coupled": (C.c_int, [_vp, C.c_int]),

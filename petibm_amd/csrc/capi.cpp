@@ -48,6 +48,19 @@ static int make_solver(pib_solver **out, const char *name, const Config &cfg, co
     return 0;
 }
 
+namespace pib {
+int create_sharing_comm(pib_solver **out, const char *name, const char *cfg_text, pib_solver *other)
+{
+    Config cfg;
+    PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", cfg));
+    PIB_CHK(make_solver(out, name, cfg, "<string>", 0, 1, nullptr, other->device));
+    (*out)->comm = other->comm;
+    (*out)->comm.borrowed = true;
+    (*out)->comm.ring = false;
+    return 0;
+}
+}  // namespace pib
+
 extern "C" {
 
 int pib_version(void) { return 100; }

@@ -127,10 +127,11 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
                                                const double *__restrict__ b, const double *__restrict__ xi,
                                                double *__restrict__ xo, const double *__restrict__ pin_sum,
                                                double *__restrict__ dvec, double a_d, double *__restrict__ part,
-                                               int part_stride)
+                                               int part_stride, int dlo, int dhi)
 {
     if (S != nullptr && S->done) return;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const bool dots = MODE == 8 && (int)blockIdx.y >= dlo && (int)blockIdx.y < dhi;  // the sums cover the OWNED planes only
     typedef double vt __attribute__((ext_vector_type(C), aligned(C == 1 ? 8 : 16)));
     const unsigned nxc = (unsigned)L.nx / C;  // lane groups per grid line
     const unsigned planec = nxc * (unsigned)L.ny;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
                 out[c] = s;
             else if (MODE == 2 || MODE == 8) {
                 out[c] = xcc + omega * ((bv[c] - s) / d);
-                if (MODE == 8) {
+                if (MODE == 8 && dots) {
                     acc0 += out[c] * braw[c];
                     acc1 += out[c] * out[c];
                     acc2 += out[c];
@@ -294,8 +295,14 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
     __shared__ double x1[3][FSY][FSX];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, k0 = blockIdx.z * FZ;
+    // processed planes: [L.k0, L.k0 + L.nk) (global); b / xo / ro point at the first of them.  A whole level, or a run of
+    // planes of a z-slab whose right-hand side is valid one plane beyond the run on every side that has a neighbour.
+    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, k0 = L.k0 + blockIdx.z * FZ;
+    const int kend = min(k0 + FZ, L.k0 + L.nk);
     const int64_t plane = (int64_t)L.nx * L.ny;
+    b -= (int64_t)L.k0 * plane;  // index by global plane below
+    xo -= (int64_t)L.k0 * plane;
+    if (RES) ro -= (int64_t)L.k0 * plane;
     const int j = j0 + ty, ic = i0 + 4 * tx;  // this thread's 4 cells: (ic .. ic+3, j)
     // halo duty: every thread one cell of the two y-halo rows, 16 threads one cell of the two x-halo columns
     const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
     // the planes for the x / y neighbours only: plane kk is written while plane kk-1 is read, three slots, one barrier
     v4 bprev = {0, 0, 0, 0}, bcur = {0, 0, 0, 0};
     v4 x1m = {0, 0, 0, 0}, x1c = {0, 0, 0, 0}, x1p = {0, 0, 0, 0};
-    for (int kk = k0 - 1; kk <= k0 + FZ; ++kk) {
+    for (int kk = k0 - 1; kk <= kend; ++kk) {
         const int slot = (kk + 3) % 3;
         bprev = bcur;
         x1m = x1c;
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
         }
         __syncthreads();
         const int kc = kk - 1;  // the plane whose x1 neighbours are complete now
-        if (kc < k0 || kc >= L.nzg) continue;
+        if (kc < k0 || kc >= kend) continue;
         const int sc = (kc + 3) % 3;
         const double wzk = L.wz[kc];
         const double gzm = (kc > 0) ? L.gz[kc - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (kc < L.nzg - 1 || pz) ? L.gz[kc] : 0.0;
@@ -382,7 +389,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                      const double *__restrict__ b, const double *__restrict__ xi,
                                                      double *__restrict__ xo, const double *__restrict__ pin_sum,
-                                                     double *__restrict__ part, int part_stride, int FZ)
+                                                     double *__restrict__ part, int part_stride, int FZ, int dlo, int dhi)
 {
     if (S != nullptr && S->done) return;
     __shared__ double sp[2][FSY][FSX];
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
                 out[c] = bv[c] - sum;
             else {
                 out[c] = xcc + omega * ((bv[c] - sum) / d);
-                if (MODE == 8) {
+                if (MODE == 8 && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
                     acc0 += out[c] * braw[c];
                     acc1 += out[c] * out[c];
                     acc2 += out[c];
@@ -655,16 +662,25 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
                                                         const double *__restrict__ b, const double *__restrict__ xc,
                                                         const double *__restrict__ xi, double *__restrict__ xo,
                                                         const double *__restrict__ pin_sum, int FZ, double *__restrict__ part,
-                                                        int part_stride)
+                                                        int part_stride, int dlo, int dhi)
 {
     if (S != nullptr && S->done) return;
     __shared__ __attribute__((aligned(16))) double sp[2][FSY][FSX];
     __shared__ __attribute__((aligned(16))) double cs[3][PCY][PCX];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, l0 = blockIdx.z * FZ;
+    // relaxed planes: [F.k0, F.k0 + F.nk) (global) -- a whole level or a run of planes of a z-slab; b / xi / xo point at
+    // the first of them, xc at coarse plane C.k0.  The planes one below / above the run are corrected too (they are the
+    // z neighbours of the relaxation): the old iterate and the coarse planes they interpolate from must be valid there.
+    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, l0 = F.k0 + blockIdx.z * FZ;
     const int I0 = i0 >> 1, J0 = j0 >> 1;
     const int64_t plane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
+    b -= (int64_t)F.k0 * plane;  // index by global plane below
+    xi -= (int64_t)F.k0 * plane;
+    xo -= (int64_t)F.k0 * plane;
+    xc -= (int64_t)C.k0 * cplane;
+    dlo += F.k0;
+    dhi += F.k0;
     const int j = j0 + ty, ic = i0 + 4 * tx;
     const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
     const int hx_col = (tid & 1) ? FX : -1, hx_y = (tid >> 1) & 7;
@@ -760,12 +776,11 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
         }
         return out;
     };
-    const int lend = (l0 + FZ < F.nzg) ? l0 + FZ : F.nzg;
+    const int lend = min(l0 + FZ, F.k0 + F.nk);
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    // prologue: the coarse planes under l0 - 1 and l0 (l0 is even: K0 - 1 and K0), then those two corrected planes
-    const int K0 = l0 >> 1;
-    if (K0 > 0) stage(K0 - 1);
-    stage(K0);
+    // prologue: the coarse planes under l0 - 1 and l0 (K0 - 1 and K0 for an even l0 = 2 K0, K0 - 1 .. K0 + 1 for an odd
+    // l0 = 2 K0 + 1: three distinct ring slots), then those two corrected planes
+    for (int K = max((l0 - 2) >> 1, 0); K <= min((l0 + 1) >> 1, C.nzg - 1); ++K) stage(K);
     v4 zm = {0, 0, 0, 0}, xcur, zp = {0, 0, 0, 0};
     Old om = {}, o0 = fetch(l0, true), on = {};
     if (l0 > 0) om = fetch(l0 - 1, false);
@@ -806,7 +821,7 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
             if (lk > 0) sum += c4 * (zm[c] - xcc);
             if (lk < F.nzg - 1) sum += c5 * (zp[c] - xcc);
             out[c] = xcc + omega * ((bv[c] - sum) / d);
-            if (DOTS) {
+            if (DOTS && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
                 acc0 += out[c] * braw[c];
                 acc1 += out[c] * out[c];
                 acc2 += out[c];
@@ -1221,6 +1236,10 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
 }
 
 // ------------------------------------------------------------------ host side
+// halo memory / deepest exchange of a distributed level (see "halos of a distributed level" below)
+constexpr int HALO_PAD_PLANES = 6;   // memory per side (the fused kernels read one plane beyond the run they process)
+constexpr int HALO_MAX_DEPTH = 4;    // deepest exchange: V(2,2) needs 4 planes of the residual on level 0, 3 below
+
 static LevelDev dev_of(const GridLevel &g)
 {
     LevelDev L;
@@ -1286,10 +1305,12 @@ void gmg_release(pib_solver *s)
     s->has_grid = false;
 }
 
-static int alloc_level_vectors(GridLevel &g, bool need_b)
+// halo_planes of memory below and above the owned planes (HALO_PAD_PLANES on a distributed level, 1 otherwise)
+static int alloc_level_vectors(GridLevel &g, bool need_b, int halo_planes)
 {
     const int64_t plane = g.n[0] * g.n[1];
-    const size_t sz = sizeof(double) * (size_t)((g.k1 - g.k0 + 2) * plane);
+    g.pad = (int64_t)halo_planes * plane;
+    const size_t sz = sizeof(double) * (size_t)((g.k1 - g.k0 + 2 * halo_planes) * plane);
     PIB_HIP(hipMalloc(&g.x, sz));
     PIB_HIP(hipMalloc(&g.x2, sz));
     PIB_HIP(hipMalloc(&g.r, sz));
@@ -1520,7 +1541,7 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
             }
             PIB_CHK(up(hg[d], &G.g[d]));
         }
-        PIB_CHK(alloc_level_vectors(G, l > 0));
+        PIB_CHK(alloc_level_vectors(G, l > 0, (P > 1 && !replicated) ? HALO_PAD_PLANES : 1));
         const bool last = (l + 1 >= max_levels) || (nn[0] <= 2 && nn[1] <= 2 && nn[2] <= 2);
         // next level: aggregates and transfer tables
         std::vector<int32_t> par[3], oth[3], fst[3];
@@ -1591,6 +1612,8 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
         for (int d = 0; d < 3; ++d)
             if (twrap[d]) G.tper |= 1 << d;
         G.plain_pair = nc[0] * 2 == nn[0] && nc[1] * 2 == nn[1] && nc[2] * 2 == nn[2];
+        G.hz_par = par[2];
+        G.hz_oth = oth[2];
         for (int d = 0; d < 3; ++d) {
             PIB_CHK(up(par[d], &G.t_par[d]));
             PIB_CHK(up(oth[d], &G.t_oth[d]));
@@ -1655,6 +1678,8 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
     }
     // every rank derives the same aggregates and ownership from the same width arrays, so neighbours agree.
     s->has_grid = true;
+    // the Krylov work vectors double as level-0 vectors: the same halo memory around their owned part
+    s->work_pad = (P > 1) ? HALO_PAD_PLANES * plane0 : 0;
 
     // verify the hint against the CSR: stencil twin vs CSR SpMV on a fixed vector (not when the structure only describes
     // the preconditioner's operator: BN order > 1, bn.hip)
@@ -1662,76 +1687,26 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
     return gmg_verify(s);
 }
 
-// Halo/compute overlap (cfg.overlap_halo): a kernel that PRODUCES a vector whose halo the next kernel needs runs
-// its two boundary planes first; their exchange goes to the communication stream and overlaps the interior planes
-// of the same producer; the consumer-side halo_level() call that follows finds the halo fresh and does nothing.
-static int halo_level_async(pib_solver *s, const GridLevel &g, double *x_owned, hipStream_t q)
+// ---- halos of a distributed level ------------------------------------------------------------------------------
+// A z-slab keeps up to HALO_PAD_PLANES planes of memory below and above its owned planes.  An exchange fills the first
+// `depth` of them with the neighbours' owned planes (contiguous: no pack kernel); every stencil kernel that follows may
+// then run on the owned planes PLUS the ghost planes whose inputs are still valid -- each application of the 7-point
+// stencil costs one plane of validity per side.  The ghost values a rank computes are the bits its neighbour computes
+// for the same cells (same kernels, same expressions), so a cycle on P slabs is the cycle on one rank; what it saves
+// is messages: one exchange of the right-hand side per level on the way down (deep enough for the smoothing steps, the
+// residual and the restriction's reach), one of the coarse correction per level on the way up, instead of one per kernel.
+
+static int exchange_planes(pib_solver *s, const GridLevel &g, double *x_owned, int depth, hipStream_t q)
 {
     const int r = s->comm.rank, P = s->comm.nranks;
-    const int64_t pl = g.plane;
-    PIB_HIP(hipEventRecord(s->ev_ready, q));
-    PIB_HIP(hipStreamWaitEvent(s->stream_comm, s->ev_ready, 0));
     const bool ring = s->comm.ring;
-    PIB_CHK(halo_exchange_planes(s, x_owned, g.nloc, (r > 0 || ring) ? pl : 0, (r < P - 1 || ring) ? pl : 0, (r > 0 || ring) ? pl : 0,
-                                 (r < P - 1 || ring) ? pl : 0, s->stream_comm));
-    PIB_HIP(hipEventRecord(s->ev_halo, s->stream_comm));
-    return 0;
-}
-
-// launch(kb, kc) runs the producer on the owned planes [kb, kb + kc) of level g
-template <class F>
-static int produce_and_exchange(pib_solver *s, const GridLevel &g, double *vec, hipStream_t q, F launch)
-{
-    const int64_t nk = g.k1 - g.k0;
-    if (s->comm.nranks <= 1 || g.replicated || !s->cfg.overlap_halo || nk < 4) return launch((int64_t)0, nk);
-    PIB_CHK(launch((int64_t)0, (int64_t)1));
-    PIB_CHK(launch(nk - 1, (int64_t)1));
-    PIB_CHK(halo_level_async(s, g, vec, q));
-    PIB_CHK(launch((int64_t)1, nk - 2));
-    PIB_HIP(hipStreamWaitEvent(q, s->ev_halo, 0));
-    s->halo_fresh = vec;
-    return 0;
-}
-
-static int halo_level(pib_solver *s, const GridLevel &g, double *x_owned, hipStream_t q)
-{
-    if (s->comm.nranks <= 1 || g.replicated) return 0;
-    if (s->halo_fresh == x_owned) {  // exchanged by its producer (produce_and_exchange)
-        s->halo_fresh = nullptr;
-        return 0;
-    }
-    s->halo_fresh = nullptr;
-    const int r = s->comm.rank, P = s->comm.nranks;
-    const int64_t pl = g.plane;
-    const bool ring = s->comm.ring;
-    return halo_exchange_planes(s, x_owned, g.nloc, (r > 0 || ring) ? pl : 0, (r < P - 1 || ring) ? pl : 0, (r > 0 || ring) ? pl : 0,
-                                (r < P - 1 || ring) ? pl : 0, q);
+    const int64_t cnt = (int64_t)depth * g.plane;
+    const int64_t lo = (r > 0 || ring) ? cnt : 0, hi = (r < P - 1 || ring) ? cnt : 0;
+    return halo_exchange_planes(s, x_owned, g.nloc, lo, hi, lo, hi, q);
 }
 
 // all-gather the owned coarse planes of level `lc` (ownership = the parents of the finer level's slab planes) into the
 // replicated level vector
-// levels the LDS-tiled kernels (k_presmooth2, k_level_march) serve: whole on this rank, 3-D, tile-divisible (periodic or not;
-// the fused transfers k_prolong_smooth / k_restrict_march additionally want per == 0)
-static bool march_ok(const pib_solver *s, const GridLevel &g)
-{
-    const bool whole = (s->comm.nranks == 1) || g.replicated;
-    // a march needs enough tiles x plane chunks to fill the chip: levels of at least 2^24 cells
-    return whole && !g.zring && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && g.k0 == 0 &&
-           g.k1 == g.n[2] && g.nloc >= (int64_t)s->cfg.march_min_cells;
-}
-// k_level_march also serves a slab (or a run of its planes: the interior part of produce_and_exchange): at least 8
-// planes and enough cells in the range
-static bool march_planes_ok(const pib_solver *s, const GridLevel &g)
-{
-    const int64_t nk = g.k1 - g.k0;
-    // a periodic z is served on the whole level only (plane -1 = plane nz - 1 of the same vector)
-    const bool z_ok = !(g.per & 4) || (!g.zring && g.k0 == 0 && g.k1 == g.n[2]);
-    return z_ok && g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0 && nk >= 8 &&
-           nk * g.plane >= (int64_t)s->cfg.march_min_cells;
-}
-// planes per workgroup: 64 on a 512^3 range (2048 workgroups), 16 on a 256^3 one (1024)
-static int march_planes(const GridLevel &g) { return (g.k1 - g.k0) * g.plane >= ((int64_t)1 << 26) ? 64 : 16; }
-
 static int gather_level(pib_solver *s, int lc, int64_t coarse_plane, const double *owned, int64_t n_owned,
                         double *full_owned_base, hipStream_t q)
 {
@@ -1746,68 +1721,26 @@ static int gather_level(pib_solver *s, int lc, int64_t coarse_plane, const doubl
     return comm_allgatherv(s, owned, full_owned_base, cnt, off, q);
 }
 
-template <int MODE>
-static int launch_level(pib_solver *s, const GridLevel &g, double omega, const double *b, const double *xi, double *xo,
-                        const double *pin_sum, bool guarded, hipStream_t q, double *dvec, double a_d)
+// runs of planes the LDS-tiled kernels serve (k_presmooth2, k_level_march, k_prolong_smooth): 3-D, tile-divisible, enough
+// cells in the run to fill the chip; a periodic z only on the whole level (plane -1 = plane nz - 1 of the same vector)
+static bool tiles_ok(const GridLevel &g) { return g.n[1] > 1 && g.n[2] > 1 && g.n[0] % FX == 0 && g.n[1] % FY == 0; }
+static bool run_whole(const GridLevel &g, int64_t kb, int64_t kc) { return g.k0 + kb == 0 && kc == g.n[2]; }
+static bool march_run_ok(const pib_solver *s, const GridLevel &g, int64_t kb, int64_t kc)
 {
-    double *part = nullptr;
-    int part_stride = 0;
-    if (MODE == 8) {
-        // per-workgroup partials of the fused sums: 3 x (workgroups per plane x planes)
-        const int64_t per_plane = std::min<int64_t>(1024, std::max<int64_t>(1, (g.n[0] * g.n[1] + 255) / 256));
-        const int64_t cap = per_plane * std::max<int64_t>(1, g.k1 - g.k0);
-        if (s->gmg_part_cap < cap) {
-            if (s->d_gmg_part) PIB_HIP(hipFree(s->d_gmg_part));
-            s->d_gmg_part = nullptr;
-            PIB_HIP(hipMalloc(&s->d_gmg_part, sizeof(double) * (3 * (size_t)cap + 3 * BIG_STAGE)));
-            s->gmg_part_cap = cap;
-        }
-        part = s->d_gmg_part;
-        part_stride = (int)s->gmg_part_cap;
-    }
-    const Scalars *S = guarded ? s->d_s : nullptr;
-    const int64_t nx = g.n[0], ny = g.n[1];
-    const unsigned nk = (unsigned)std::max<int64_t>(1, g.k1 - g.k0);
-    if ((MODE == 2 || MODE == 3 || MODE == 8) && s->cfg.march_levels && march_planes_ok(s, g) &&
-        ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(xi) | reinterpret_cast<uintptr_t>(xo)) & 31u) == 0) {
-        constexpr int M = (MODE == 3) ? 3 : (MODE == 8 ? 8 : 2);
-        const int FZ = march_planes(g);
-        const dim3 mg((unsigned)(nx / FX), (unsigned)(ny / FY), (unsigned)((nk + FZ - 1) / FZ));
-        hipLaunchKernelGGL((k_level_march<M>), mg, dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, part, part_stride, FZ);
-        PIB_HIP(hipGetLastError());
-        if (MODE == 8) {
-            double *stage = part + 3 * (int64_t)part_stride;
-            hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)(mg.x * mg.y * mg.z), stage);
-            hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
-            PIB_HIP(hipGetLastError());
-        }
-        return 0;
-    }
-    auto aligned = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    const bool vec_ok = aligned(b) && aligned(xi) && aligned(xo) && aligned(dvec);
-    auto gx = [&](int c) { return dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (nx / c * ny + 255) / 256)), nk); };
-    dim3 grid;
-    if (vec_ok && nx % 4 == 0) {
-        grid = gx(4);
-        hipLaunchKernelGGL((k_level<MODE, 4>), grid, dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, dvec, a_d, part, part_stride);
-    } else if (vec_ok && nx % 2 == 0) {
-        grid = gx(2);
-        hipLaunchKernelGGL((k_level<MODE, 2>), grid, dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, dvec, a_d, part, part_stride);
-    } else {
-        grid = gx(1);
-        hipLaunchKernelGGL((k_level<MODE, 1>), grid, dim3(256), 0, q, S, dev_of(g), omega, b, xi, xo, pin_sum, dvec, a_d, part, part_stride);
-    }
-    PIB_HIP(hipGetLastError());
-    if (MODE == 8) {
-        double *stage = part + 3 * (int64_t)part_stride;
-        hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)(grid.x * grid.y), stage);
-        hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
-        PIB_HIP(hipGetLastError());
-    }
-    return 0;
+    const bool z_ok = !(g.per & 4) || (!g.zring && run_whole(g, kb, kc));
+    return z_ok && tiles_ok(g) && kc >= 8 && kc * g.plane >= (int64_t)s->cfg.march_min_cells;
 }
+// the fused kernels (two pre-smoothing steps; prolongation + first post-smoothing step)
+static bool fused_run_ok(const pib_solver *s, const GridLevel &g, int64_t kb, int64_t kc)
+{
+    const bool z_ok = !(g.per & 4) || (!g.zring && run_whole(g, kb, kc));
+    return z_ok && tiles_ok(g) && kc >= 2 && kc * g.plane >= (int64_t)s->cfg.march_min_cells;
+}
+// planes per workgroup: 64 on a 512^3 run (2048 workgroups), 16 on a 256^3 one (1024)
+static int march_planes(const GridLevel &g, int64_t kc) { return kc * g.plane >= ((int64_t)1 << 26) ? 64 : 16; }
 
-// the same on the owned planes [kb, kb + kc) only
+// MODE on the planes [kb, kb + kc) relative to the first owned plane (kb < 0 / kb + kc > nk: ghost planes); the vectors
+// point at the first OWNED plane.  dots: mode 8 sums over the owned planes only.
 template <int MODE>
 static int launch_level_planes(pib_solver *s, const GridLevel &g, int64_t kb, int64_t kc, double omega, const double *b,
                                const double *xi, double *xo, const double *pin_sum, bool guarded, hipStream_t q,
@@ -1818,13 +1751,86 @@ static int launch_level_planes(pib_solver *s, const GridLevel &g, int64_t kb, in
     sub.k0 = g.k0 + kb;
     sub.k1 = sub.k0 + kc;
     const int64_t o = kb * g.plane;
-    return launch_level<MODE>(s, sub, omega, b ? b + o : b, xi ? xi + o : xi, xo + o, pin_sum, guarded, q, dvec ? dvec + o : dvec, a_d);
+    b = b ? b + o : b;
+    xi = xi ? xi + o : xi;
+    xo += o;
+    dvec = dvec ? dvec + o : dvec;
+    // owned planes inside the run (local indices of the run)
+    const int dlo = (int)std::max<int64_t>(0, -kb), dhi = (int)std::min<int64_t>(kc, (g.k1 - g.k0) - kb);
+    double *part = nullptr;
+    int part_stride = 0;
+    const int64_t nx = g.n[0], ny = g.n[1];
+    const unsigned nk = (unsigned)kc;
+    const bool march = (MODE == 2 || MODE == 3 || MODE == 8) && s->cfg.march_levels && march_run_ok(s, g, kb, kc) &&
+                       ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(xi) | reinterpret_cast<uintptr_t>(xo)) & 31u) == 0;
+    const int FZ = march_planes(g, kc);
+    const dim3 mg((unsigned)(nx / FX), (unsigned)(ny / FY), (unsigned)((nk + FZ - 1) / FZ));
+    auto aligned = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec_ok = aligned(b) && aligned(xi) && aligned(xo) && aligned(dvec);
+    const int C = (vec_ok && nx % 4 == 0) ? 4 : ((vec_ok && nx % 2 == 0) ? 2 : 1);
+    const dim3 sg((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (nx / C * ny + 255) / 256)), nk);
+    if (MODE == 8) {
+        // per-workgroup partials of the fused sums
+        const int64_t cap = march ? (int64_t)mg.x * mg.y * mg.z : (int64_t)sg.x * sg.y;
+        if (s->gmg_part_cap < cap) {
+            if (s->d_gmg_part) PIB_HIP(hipFree(s->d_gmg_part));
+            s->d_gmg_part = nullptr;
+            PIB_HIP(hipMalloc(&s->d_gmg_part, sizeof(double) * (3 * (size_t)cap + 3 * BIG_STAGE)));
+            s->gmg_part_cap = cap;
+        }
+        part = s->d_gmg_part;
+        part_stride = (int)s->gmg_part_cap;
+    }
+    const Scalars *S = guarded ? s->d_s : nullptr;
+    int nparts = 0;
+    if (march) {
+        constexpr int M = (MODE == 3) ? 3 : (MODE == 8 ? 8 : 2);
+        hipLaunchKernelGGL((k_level_march<M>), mg, dim3(256), 0, q, S, dev_of(sub), omega, b, xi, xo, pin_sum, part, part_stride, FZ, dlo, dhi);
+        nparts = (int)(mg.x * mg.y * mg.z);
+    } else {
+        if (C == 4)
+            hipLaunchKernelGGL((k_level<MODE, 4>), sg, dim3(256), 0, q, S, dev_of(sub), omega, b, xi, xo, pin_sum, dvec, a_d, part, part_stride, dlo, dhi);
+        else if (C == 2)
+            hipLaunchKernelGGL((k_level<MODE, 2>), sg, dim3(256), 0, q, S, dev_of(sub), omega, b, xi, xo, pin_sum, dvec, a_d, part, part_stride, dlo, dhi);
+        else
+            hipLaunchKernelGGL((k_level<MODE, 1>), sg, dim3(256), 0, q, S, dev_of(sub), omega, b, xi, xo, pin_sum, dvec, a_d, part, part_stride, dlo, dhi);
+        nparts = (int)(sg.x * sg.y);
+    }
+    PIB_HIP(hipGetLastError());
+    if (MODE == 8) {
+        double *stage = part + 3 * (int64_t)part_stride;
+        hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, nparts, stage);
+        hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
+        PIB_HIP(hipGetLastError());
+    }
+    return 0;
 }
 
-// the fused first two pre-smoothing steps (k_presmooth2) apply to this level
-static bool presmooth2_ok(const pib_solver *s, const GridLevel &g)
+// the whole owned part of the level
+template <int MODE>
+static int launch_level(pib_solver *s, const GridLevel &g, double omega, const double *b, const double *xi, double *xo,
+                        const double *pin_sum, bool guarded, hipStream_t q, double *dvec, double a_d)
 {
-    return s->cfg.fuse_presmooth && march_ok(s, g);
+    return launch_level_planes<MODE>(s, g, 0, g.k1 - g.k0, omega, b, xi, xo, pin_sum, guarded, q, dvec, a_d);
+}
+
+// coarse ghost planes (beyond a rank's owned coarse planes) that the interpolation of its boundary planes and of `e` fine
+// ghost planes per side reads -- the maximum over ALL ranks, so that every rank asks for the same exchange depth
+static int coarse_need(const pib_solver *s, int l, int e)
+{
+    const GridLevel &f = s->levels[(size_t)l];
+    int need = 0;
+    for (int r = 0; r < s->comm.nranks; ++r) {
+        const auto &of = s->gmg_own[(size_t)l][(size_t)r];
+        const auto &oc = s->gmg_own[(size_t)l + 1][(size_t)r];
+        if (of.second <= of.first) continue;
+        for (int g2 = 0; g2 <= e; ++g2) {
+            const int64_t up = of.second - 1 + g2, dn = of.first - g2;
+            if (up < f.n[2]) need = std::max<int>(need, (int)(std::max(f.hz_par[(size_t)up], f.hz_oth[(size_t)up]) - (oc.second - 1)));
+            if (dn >= 0) need = std::max<int>(need, (int)(oc.first - std::min(f.hz_par[(size_t)dn], f.hz_oth[(size_t)dn])));
+        }
+    }
+    return std::max(need, 0);
 }
 
 // One V-cycle: z = M^-1 r.   r, z: ghost-padded work vectors of the Krylov solver
@@ -1838,47 +1844,129 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     const Scalars *S = guarded ? s->d_s : nullptr;
     s->halo_fresh = nullptr;
     s->gmg_dots_done = false;
+    s->z_halo_depth = 0;
     const double omega = s->cfg.smoother_relaxation;
-    const bool cheb0 = (s->cfg.smoother == Smoother::CHEBYSHEV);
-    const int deg = cheb0 ? std::max(1, s->cfg.cheby_degree) : 1;  // one Chebyshev "sweep" = a degree-`deg` polynomial
+    const bool cheb = (s->cfg.smoother == Smoother::CHEBYSHEV);
+    const int deg = cheb ? std::max(1, s->cfg.cheby_degree) : 1;  // one Chebyshev "sweep" = a degree-`deg` polynomial
     const int pre = std::max(1, s->cfg.presweeps) * deg, post = std::max(0, s->cfg.postsweeps) * deg;
     const int nl = (int)s->levels.size();
+    const int P = s->comm.nranks, rank = s->comm.rank;
     const double *pin = (s->nullspace == PIB_NULLSPACE_PINNED) ? &s->d_s->red[5] : nullptr;
     std::vector<double *> cur((size_t)nl, nullptr);  // current iterate buffer per level (owned pointer)
-    const bool cheb = (s->cfg.smoother == Smoother::CHEBYSHEV);
     const double lmax = s->cfg.cheby_lmax, lmin = lmax / s->cfg.cheby_ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
-    // `nsteps` smoothing steps on level g: iterate in `a` (result left in `a` after the swaps), spare buffer `c`.
+
+    // ---- per-level halo facts and the validity (in ghost planes per side) of every vector this cycle touches
+    struct LI {
+        bool dist, lo, hi;
+        int maxd;    // deepest exchange
+        int cdepth;  // ghost planes a kernel may compute on (0 on a periodic slab axis: the ghost planes of the outer ranks
+                     // are the planes at the other end of the axis, the kernels index the mesh arrays by plane number)
+        int64_t nk;
+    };
+    std::vector<LI> li((size_t)nl);
+    for (int l = 0; l < nl; ++l) {
+        const GridLevel &g = s->levels[(size_t)l];
+        LI &I = li[(size_t)l];
+        I.dist = P > 1 && !g.replicated;
+        I.lo = I.dist && (rank > 0 || s->comm.ring);
+        I.hi = I.dist && (rank < P - 1 || s->comm.ring);
+        I.nk = g.k1 - g.k0;
+        I.maxd = I.cdepth = 0;
+        if (I.dist) {
+            int m = (s->cfg.deep_halo && !g.zring) ? HALO_MAX_DEPTH : 1;
+            for (int q2 = 0; q2 < P; ++q2)  // an exchange takes planes the NEIGHBOUR owns
+                m = (int)std::min<int64_t>(m, s->gmg_own[(size_t)l][(size_t)q2].second - s->gmg_own[(size_t)l][(size_t)q2].first);
+            I.maxd = std::max(1, m);
+            I.cdepth = g.zring ? 0 : I.maxd;
+        }
+    }
+    std::vector<std::pair<const double *, int>> vd;
+    auto valid = [&](const double *v) -> int {
+        for (auto &e : vd)
+            if (e.first == v) return e.second;
+        return 0;
+    };
+    auto set_valid = [&](const double *v, int d) {
+        for (auto &e : vd)
+            if (e.first == v) {
+                e.second = d;
+                return;
+            }
+        vd.push_back({v, d});
+    };
+    // make `vec` of level l valid on d ghost planes per side
+    auto need = [&](int l, const double *vec, int d) -> int {
+        const LI &I = li[(size_t)l];
+        if (!I.dist || d <= 0 || valid(vec) >= d) return 0;
+        if (d > I.maxd) return fail(PIB_ERR_LIB, "gmg: halo depth %d not available on level %d", d, l);
+        PIB_CHK(exchange_planes(s, s->levels[(size_t)l], const_cast<double *>(vec), d, q));
+        set_valid(vec, d);
+        return 0;
+    };
+    // planes [a, a + c) relative to the first owned plane for a run that reaches d ghost planes into the neighbours
+    auto run = [&](int l, int d, int64_t &a, int64_t &c) {
+        const LI &I = li[(size_t)l];
+        a = I.lo ? -d : 0;
+        c = I.nk + (I.hi ? d : 0) - a;
+    };
+    // Depth a stencil kernel produces: what is desired, no more than its right-hand side is valid, one plane less than its
+    // input; an input without any valid ghost plane is exchanged first.  The rule depends on nothing rank-specific and
+    // the fused kernels below record exactly what the steps they replace would: every rank issues the same exchanges.
+    auto stencil_depth = [&](int l, int desired, const double *in, const double *b, int *out) -> int {
+        const LI &I = li[(size_t)l];
+        *out = 0;
+        if (!I.dist) return 0;
+        int o = std::max(0, std::min(std::min(desired, I.maxd - 1), valid(b)));
+        if (valid(in) >= 1) o = std::min(o, valid(in) - 1);
+        else PIB_CHK(need(l, in, o + 1));
+        *out = o;
+        return 0;
+    };
+
+    // `nsteps` smoothing steps on level l: iterate in `a` (result left in `a` after the swaps), spare buffer `c`.
     // Jacobi: x <- x + omega D^-1 (b - A x).  Chebyshev-Jacobi: three-term recurrence over [lmin, lmax] of D^-1 A,
-    // restarted for every segment (oracle/csrc/gmg.c:cheby).
-    auto smooth_seq = [&](GridLevel &g, const double *b, const double *pin_l, double *&a, double *&c, int nsteps,
-                          bool from_zero, bool halo_after_last, bool dots_in_last = false) -> int {
+    // restarted for every segment (oracle/csrc/gmg.c:cheby).  The last step's result is valid on d_final ghost planes,
+    // the one before on d_final + 1, ... (as far as the inputs allow; a missing plane is exchanged).
+    auto smooth_seq = [&](int l, const double *b, const double *pin_l, double *&a, double *&c, int nsteps, bool from_zero,
+                          int d_final, bool dots_in_last = false) -> int {
+        GridLevel &g = s->levels[(size_t)l];
+        const LI &I = li[(size_t)l];
         double rho = 1.0 / sigma;
-        double *dvec = g.d + g.plane;
+        double *dvec = g.d + g.pad;
         for (int sw = 0; sw < nsteps; ++sw) {
-            // every step but the last of the up-leg feeds a kernel that needs its halo
-            const bool feeds = (sw + 1 < nsteps) || halo_after_last;
-            if (from_zero && sw == 0 && nsteps >= 2 && !cheb && presmooth2_ok(s, g) &&
-                (reinterpret_cast<uintptr_t>(b) & 31u) == 0 && (reinterpret_cast<uintptr_t>(c) & 31u) == 0) {
+            const int desired = d_final + (nsteps - 1 - sw);
+            int64_t ka, kc;
+            if (from_zero && sw == 0 && nsteps >= 2 && !cheb && s->cfg.fuse_presmooth) {
                 // steps 0 and 1 in one kernel; the result lands where step 1 would have put it
-                const int FZ = march_planes(g);
-                hipLaunchKernelGGL(k_presmooth2<0>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
-                                   dim3(256), 0, q, S, dev_of(g), omega, b, c, pin_l, FZ, nullptr);
-                PIB_HIP(hipGetLastError());
-                std::swap(a, c);
-                sw = 1;
-                continue;
+                int o = I.dist ? std::min(std::min(desired - 1, I.maxd - 1), valid(b) - 1) : 0;
+                run(l, std::max(o, 0), ka, kc);
+                if (o >= 0 && fused_run_ok(s, g, ka, kc) &&
+                    ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 31u) == 0) {
+                    GridLevel sub = g;
+                    sub.k0 = g.k0 + ka;
+                    sub.k1 = sub.k0 + kc;
+                    const int FZ = march_planes(g, kc);
+                    hipLaunchKernelGGL(k_presmooth2<0>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((kc + FZ - 1) / FZ)),
+                                       dim3(256), 0, q, S, dev_of(sub), omega, b + ka * g.plane, c + ka * g.plane, pin_l, FZ, nullptr);
+                    PIB_HIP(hipGetLastError());
+                    set_valid(c, o);
+                    std::swap(a, c);
+                    sw = 1;
+                    continue;
+                }
             }
             if (from_zero && sw == 0) {
-                double *out = a;
-                auto run = [&](int64_t kb, int64_t kc) -> int {
-                    if (cheb) return launch_level_planes<6>(s, g, kb, kc, 1.0 / theta, b, nullptr, out, pin_l, guarded, q, dvec, 0.0);
-                    return launch_level_planes<1>(s, g, kb, kc, omega, b, nullptr, out, pin_l, guarded, q);
-                };
-                if (feeds) PIB_CHK(produce_and_exchange(s, g, out, q, run)); else PIB_CHK(run(0, g.k1 - g.k0));
+                const int o = I.dist ? std::max(0, std::min(std::min(desired, I.cdepth), valid(b))) : 0;  // pointwise: as deep as b
+                run(l, o, ka, kc);
+                if (cheb) PIB_CHK(launch_level_planes<6>(s, g, ka, kc, 1.0 / theta, b, nullptr, a, pin_l, guarded, q, dvec, 0.0));
+                else PIB_CHK(launch_level_planes<1>(s, g, ka, kc, omega, b, nullptr, a, pin_l, guarded, q));
+                set_valid(a, o);
                 continue;
             }
-            PIB_CHK(halo_level(s, g, a, q));
+            int o;
+            PIB_CHK(stencil_depth(l, desired, a, b, &o));
+            run(l, o, ka, kc);
             if (cheb) {
                 double a_d = 0.0, a_z = 1.0 / theta;
                 if (sw > 0) {
@@ -1887,23 +1975,16 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                     a_z = 2.0 * rho_new / delta;
                     rho = rho_new;
                 }
-                const double *in = a;
-                double *out = c;
-                auto run = [&](int64_t kb, int64_t kc) -> int {
-                    return launch_level_planes<5>(s, g, kb, kc, a_z, b, in, out, pin_l, guarded, q, dvec, a_d);
-                };
-                if (feeds) PIB_CHK(produce_and_exchange(s, g, out, q, run)); else PIB_CHK(run(0, g.k1 - g.k0));
+                PIB_CHK(launch_level_planes<5>(s, g, ka, kc, a_z, b, a, c, pin_l, guarded, q, dvec, a_d));
             } else {
-                const double *in = a;
-                double *out = c;
-                const bool dots = dots_in_last && sw + 1 == nsteps && !feeds;
-                auto run = [&](int64_t kb, int64_t kc) -> int {
-                    if (dots) return launch_level_planes<8>(s, g, kb, kc, omega, b, in, out, pin_l, guarded, q);
-                    return launch_level_planes<2>(s, g, kb, kc, omega, b, in, out, pin_l, guarded, q);
-                };
-                if (dots) s->gmg_dots_done = true;
-                if (feeds) PIB_CHK(produce_and_exchange(s, g, out, q, run)); else PIB_CHK(run(0, g.k1 - g.k0));
+                const bool dots = dots_in_last && sw + 1 == nsteps;
+                if (dots) {
+                    PIB_CHK(launch_level_planes<8>(s, g, ka, kc, omega, b, a, c, pin_l, guarded, q));
+                    s->gmg_dots_done = true;
+                } else
+                    PIB_CHK(launch_level_planes<2>(s, g, ka, kc, omega, b, a, c, pin_l, guarded, q));
             }
+            set_valid(c, o);
             std::swap(a, c);
         }
         return 0;
@@ -1923,9 +2004,19 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         }
         if (nl - tail0 < 2) tail0 = nl;  // a single level is what k_coarsest already does
     }
+    // depth of the level's right-hand side on the way down: the pre-smoothing steps, the residual and the restriction's
+    // reach of one plane; level 0 also carries the post-smoothing steps and one plane of the result z, so that neither
+    // the corrected iterate nor p = z + beta p (the next Krylov product's input) needs an exchange of its own
+    auto final_depth = [&](int l) -> int { return (l == 0 && li[0].dist && li[0].maxd > 1) ? 1 : 0; };
+    auto down_depth = [&](int l) -> int {
+        const LI &I = li[(size_t)l];
+        if (!I.dist) return 0;
+        return std::min(I.cdepth, std::max(pre + 1, pre + post - 1 + final_depth(l)));
+    };
     // ---- downward leg
     for (int l = 0; l < nl; ++l) {
         GridLevel &g = s->levels[(size_t)l];
+        const LI &I = li[(size_t)l];
         const int64_t pl = g.plane;
         if (l == tail0) {
             TailArgs T;
@@ -1934,39 +2025,41 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             T.pre = pre;
             T.post = post;
             T.sweeps = s->cfg.coarsest_sweeps;
-            for (int q = 0; q < T.nlev; ++q) {
-                GridLevel &t = s->levels[(size_t)(tail0 + q)];
-                T.lv[q].L = dev_of(t);
-                T.lv[q].xa = t.x + t.plane;
-                T.lv[q].xb = t.x2 + t.plane;
-                T.lv[q].b = t.b + t.plane;
-                T.lv[q].r = t.r + t.plane;
+            for (int q2 = 0; q2 < T.nlev; ++q2) {
+                GridLevel &t = s->levels[(size_t)(tail0 + q2)];
+                T.lv[q2].L = dev_of(t);
+                T.lv[q2].xa = t.x + t.pad;
+                T.lv[q2].xb = t.x2 + t.pad;
+                T.lv[q2].b = t.b + t.pad;
+                T.lv[q2].r = t.r + t.pad;
             }
             hipLaunchKernelGGL(k_coarse_tail, dim3(1), dim3(1024), 0, q, S, T);
             PIB_HIP(hipGetLastError());
             const int swaps = (pre - 1) + post;
-            cur[(size_t)l] = (swaps % 2 == 0) ? (g.x + pl) : (g.x2 + pl);
+            cur[(size_t)l] = (swaps % 2 == 0) ? (g.x + g.pad) : (g.x2 + g.pad);
             break;
         }
-        const double *b = (l == 0) ? r : g.b + pl;
+        const double *b = (l == 0) ? r : g.b + g.pad;
         const double *pin_l = (l == 0) ? pin : nullptr;
-        double *xa = g.x + pl, *xb = g.x2 + pl;
+        double *xa = g.x + g.pad, *xb = g.x2 + g.pad;
         if (l == nl - 1) {
             double *out = (l == 0) ? z : xa;
-            if (g.nloc <= 4096) {
+            if (g.nloc <= 4096 && !I.dist) {
                 hipLaunchKernelGGL(k_coarsest, dim3(1), dim3(256), 0, q, S, dev_of(g), omega, s->cfg.coarsest_sweeps, b, xa, xb,
                                    out);
                 PIB_HIP(hipGetLastError());
             } else {
-                PIB_CHK(launch_level<1>(s, g, omega, b, nullptr, xa, pin_l, guarded, q));
+                PIB_CHK(launch_level<1>(s, g, omega, b, nullptr, xa, pin_l, guarded, q, nullptr, 0.0));
                 double *a = xa, *c = xb;
                 for (int sw = 1; sw < s->cfg.coarsest_sweeps; ++sw) {
-                    PIB_CHK(halo_level(s, g, a, q));
-                    PIB_CHK(launch_level<2>(s, g, omega, b, a, c, pin_l, guarded, q));
+                    set_valid(a, 0);
+                    PIB_CHK(need(l, a, 1));
+                    PIB_CHK(launch_level<2>(s, g, omega, b, a, c, pin_l, guarded, q, nullptr, 0.0));
                     std::swap(a, c);
                 }
                 if (a != out) PIB_HIP(hipMemcpyAsync(out, a, sizeof(double) * (size_t)g.nloc, hipMemcpyDeviceToDevice, q));
             }
+            set_valid(out, 0);
             cur[(size_t)l] = out;
             break;
         }
@@ -1977,27 +2070,49 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // final buffer after `swaps` swaps starting from a: a if even else c
             if (swaps % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
         }
-        double *rr = g.r + pl;
-        const bool fused_res = pre == 1 && !cheb && presmooth2_ok(s, g) &&
-                               ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(rr)) & 31u) == 0;
-        if (fused_res) {
-            // one pre-smoothing step from zero and the residual of its result in one march
-            const int FZ = march_planes(g);
-            hipLaunchKernelGGL(k_presmooth2<1>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ)),
-                               dim3(256), 0, q, S, dev_of(g), omega, b, a, pin_l, FZ, rr);
-            PIB_HIP(hipGetLastError());
+        double *rr = g.r + g.pad;
+        // the right-hand side on as many ghost planes as the way down (and, on level 0, the way up) consumes
+        const int Dd = down_depth(l);
+        set_valid(b, 0);
+        PIB_CHK(need(l, b, Dd));
+        if (pre == 1 && !cheb) {
+            // one pre-smoothing step from zero and the residual of its result: x1 kept and r valid on o ghost planes
+            const int o = I.dist ? std::max(0, std::min(std::min(Dd - 1, I.maxd - 1), valid(b) - 1)) : 0;
+            int64_t ka, kc;
+            run(l, o, ka, kc);
+            if (s->cfg.fuse_presmooth && fused_run_ok(s, g, ka, kc) && (!I.dist || valid(b) >= o + 1) &&
+                ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(rr)) & 31u) == 0) {
+                GridLevel sub = g;  // both in one march (b read once)
+                sub.k0 = g.k0 + ka;
+                sub.k1 = sub.k0 + kc;
+                const int FZ = march_planes(g, kc);
+                hipLaunchKernelGGL(k_presmooth2<1>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((kc + FZ - 1) / FZ)),
+                                   dim3(256), 0, q, S, dev_of(sub), omega, b + ka * pl, a + ka * pl, pin_l, FZ, rr + ka * pl);
+                PIB_HIP(hipGetLastError());
+            } else {
+                // x1 one plane deeper than it is kept (pointwise: as deep as b), then its residual
+                const int dx = I.dist ? std::min(std::min(o + 1, valid(b)), I.cdepth) : 0;
+                int64_t xa2, xc2;
+                run(l, dx, xa2, xc2);
+                PIB_CHK(launch_level_planes<1>(s, g, xa2, xc2, omega, b, nullptr, a, pin_l, guarded, q));
+                set_valid(a, dx);
+                if (I.dist && dx < o + 1) PIB_CHK(need(l, a, o + 1));
+                PIB_CHK(launch_level_planes<3>(s, g, ka, kc, omega, b, a, rr, pin_l, guarded, q));
+            }
+            set_valid(a, o);
+            set_valid(rr, o);
         } else {
-            PIB_CHK(smooth_seq(g, b, pin_l, a, c, pre, true, true));
-            PIB_CHK(halo_level(s, g, a, q));
+            // the pre-smoothed iterate is kept as deep as the way up wants it (the corrected iterate starts from it)
+            const int want_x = I.dist ? std::max(2, post + final_depth(l)) : 0;
+            PIB_CHK(smooth_seq(l, b, pin_l, a, c, pre, true, want_x));
+            int o;
+            PIB_CHK(stencil_depth(l, 1, a, b, &o));
+            int64_t ka, kc;
+            run(l, o, ka, kc);
+            PIB_CHK(launch_level_planes<3>(s, g, ka, kc, omega, b, a, rr, pin_l, guarded, q));
+            set_valid(rr, o);
         }
-        if (!fused_res) {
-            const double *in = a;
-            auto run = [&](int64_t kb, int64_t kc) -> int {
-                return launch_level_planes<3>(s, g, kb, kc, omega, b, in, rr, pin_l, guarded, q);
-            };
-            PIB_CHK(produce_and_exchange(s, g, rr, q, run));
-        }
-        PIB_CHK(halo_level(s, g, rr, q));
+        PIB_CHK(need(l, rr, 1));  // the restriction reaches one fine plane beyond the slab
         GridLevel &cg = s->levels[(size_t)l + 1];
         if (cg.replicated && !g.replicated && s->comm.nranks > 1) {
             // restrict the owned coarse planes into a scratch (cg.r), then all-gather into cg.b
@@ -2005,11 +2120,11 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             own.k0 = s->gmg_own[(size_t)l + 1][(size_t)s->comm.rank].first;
             own.k1 = s->gmg_own[(size_t)l + 1][(size_t)s->comm.rank].second;
             own.nloc = (own.k1 - own.k0) * cg.plane;
-            double *scratch = cg.r + cg.plane;
+            double *scratch = cg.r + cg.pad;
             PIB_CHK(launch_restrict(s, g, own, rr, scratch, S, q));
-            PIB_CHK(gather_level(s, l + 1, cg.plane, scratch, own.nloc, cg.b + cg.plane, q));
+            PIB_CHK(gather_level(s, l + 1, cg.plane, scratch, own.nloc, cg.b + cg.pad, q));
         } else {
-            PIB_CHK(launch_restrict(s, g, cg, rr, cg.b + cg.plane, S, q));
+            PIB_CHK(launch_restrict(s, g, cg, rr, cg.b + cg.pad, S, q));
         }
         cur[(size_t)l] = a;
         // remember the spare buffer in g.scratch for the upward leg
@@ -2019,60 +2134,78 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     for (int l = std::min(nl - 2, tail0 - 1); l >= 0; --l) {
         GridLevel &g = s->levels[(size_t)l];
         GridLevel &cg = s->levels[(size_t)l + 1];
+        const LI &I = li[(size_t)l];
         const int64_t pl = g.plane;
-        const double *b = (l == 0) ? r : g.b + pl;
+        const double *b = (l == 0) ? r : g.b + g.pad;
         const double *pin_l = (l == 0) ? pin : nullptr;
         double *a = cur[(size_t)l], *c = s->gmg_spare[(size_t)l];
         double *xc = cur[(size_t)l + 1];
-        PIB_CHK(halo_level(s, cg, xc, q));
-        // prolongation + first post-smoothing step in one march (the corrected iterate never goes to HBM)
+        const int fin = final_depth(l);
+        // the corrected iterate x + P e on e ghost planes: as deep as the post-smoothing consumes, no deeper than the
+        // pre-smoothed iterate is valid and than the coarse correction can be had
+        int e = 0;
+        if (I.dist) {
+            e = std::min(std::min(fin + post, I.maxd), valid(a));
+            if (li[(size_t)l + 1].dist)
+                while (e > 0 && coarse_need(s, l, e) > li[(size_t)l + 1].maxd) --e;
+            if (li[(size_t)l + 1].dist) PIB_CHK(need(l + 1, xc, coarse_need(s, l, e)));
+        }
         const bool dots_l = l == 0 && s->gmg_want_dots && !cheb;
-        if (s->cfg.fuse_prolong && !cheb && post >= 1 && march_ok(s, g) && g.plain_pair && g.per == 0 && g.tper == 0 &&
-            ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(b)) & 31u) == 0) {
-            const int FZ = march_planes(g);
-            const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((g.n[2] + FZ - 1) / FZ));
-            if (post == 1 && dots_l) {
-                // the only post-smoothing step also delivers z.r, z.z, sum z (what launch_level<8> does)
-                const int64_t need = (int64_t)mg.x * mg.y * mg.z;
-                if (need > s->gmg_part_cap) {
-                    if (s->d_gmg_part) (void)hipFree(s->d_gmg_part);
-                    s->d_gmg_part = nullptr;
-                    PIB_HIP(hipMalloc(&s->d_gmg_part, sizeof(double) * (size_t)(3 * need + 3 * BIG_STAGE)));
-                    s->gmg_part_cap = need;
-                }
-                double *part = s->d_gmg_part;
-                const int part_stride = (int)s->gmg_part_cap;
-                hipLaunchKernelGGL(k_prolong_smooth<1>, mg, dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, pin_l, FZ, part,
-                                   part_stride);
-                double *stage = part + 3 * (int64_t)part_stride;
-                hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)need, stage);
-                hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
-                s->gmg_dots_done = true;
-            } else
-                hipLaunchKernelGGL(k_prolong_smooth<0>, mg, dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, pin_l, FZ, nullptr, 0);
-            PIB_HIP(hipGetLastError());
-            std::swap(a, c);
-            PIB_CHK(smooth_seq(g, b, pin_l, a, c, post - 1, false, l > 0, dots_l));
-            cur[(size_t)l] = a;
-            if (l == 0 && a != z) return fail(PIB_ERR_LIB, "gmg: internal buffer parity error");
-            continue;
-        }
-        {
-            double *out = a;
-            auto run = [&](int64_t kb, int64_t kc) -> int {
-                if (kc <= 0) return 0;
+        // prolongation + first post-smoothing step in one march (the corrected iterate never goes to HBM)
+        bool fused = false;
+        if (s->cfg.fuse_prolong && !cheb && post >= 1 && g.plain_pair && g.per == 0 && g.tper == 0 && (!I.dist || e >= 1)) {
+            const int o = I.dist ? std::min(std::min(e - 1, fin + post - 1), valid(b)) : 0;
+            int64_t ka, kc;
+            run(l, o, ka, kc);
+            if (fused_run_ok(s, g, ka, kc) &&
+                ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(b)) & 31u) == 0) {
                 GridLevel sub = g;
-                sub.k0 = g.k0 + kb;
+                sub.k0 = g.k0 + ka;
                 sub.k1 = sub.k0 + kc;
-                return launch_prolong(sub, cg, xc, out + kb * g.plane, S, q);
-            };
-            // the prolongated iterate feeds the post-smoothing (or, without one, the level above)
-            if (post > 0 || l > 0) PIB_CHK(produce_and_exchange(s, g, out, q, run)); else PIB_CHK(run(0, g.k1 - g.k0));
+                const int FZ = march_planes(g, kc);
+                const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((kc + FZ - 1) / FZ));
+                const int dlo = (int)std::max<int64_t>(0, -ka), dhi = (int)std::min<int64_t>(kc, I.nk - ka);
+                if (post == 1 && dots_l) {
+                    // the only post-smoothing step also delivers z.r, z.z, sum z (what mode 8 does)
+                    const int64_t needp = (int64_t)mg.x * mg.y * mg.z;
+                    if (needp > s->gmg_part_cap) {
+                        if (s->d_gmg_part) (void)hipFree(s->d_gmg_part);
+                        s->d_gmg_part = nullptr;
+                        PIB_HIP(hipMalloc(&s->d_gmg_part, sizeof(double) * (size_t)(3 * needp + 3 * BIG_STAGE)));
+                        s->gmg_part_cap = needp;
+                    }
+                    double *part = s->d_gmg_part;
+                    const int part_stride = (int)s->gmg_part_cap;
+                    hipLaunchKernelGGL(k_prolong_smooth<1>, mg, dim3(256), 0, q, S, dev_of(sub), dev_of(cg), omega, b + ka * pl, xc,
+                                       a + ka * pl, c + ka * pl, pin_l, FZ, part, part_stride, dlo, dhi);
+                    double *stage = part + 3 * (int64_t)part_stride;
+                    hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)needp, stage);
+                    hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
+                    s->gmg_dots_done = true;
+                } else
+                    hipLaunchKernelGGL(k_prolong_smooth<0>, mg, dim3(256), 0, q, S, dev_of(sub), dev_of(cg), omega, b + ka * pl, xc,
+                                       a + ka * pl, c + ka * pl, pin_l, FZ, nullptr, 0, dlo, dhi);
+                PIB_HIP(hipGetLastError());
+                set_valid(c, o);
+                std::swap(a, c);
+                PIB_CHK(smooth_seq(l, b, pin_l, a, c, post - 1, false, fin, dots_l));
+                fused = true;
+            }
         }
-        PIB_CHK(smooth_seq(g, b, pin_l, a, c, post, false, l > 0, l == 0 && s->gmg_want_dots && !cheb));
+        if (!fused) {
+            int64_t ka, kc;
+            run(l, e, ka, kc);
+            GridLevel sub = g;
+            sub.k0 = g.k0 + ka;
+            sub.k1 = sub.k0 + kc;
+            PIB_CHK(launch_prolong(sub, cg, xc, a + ka * pl, S, q));
+            set_valid(a, e);
+            PIB_CHK(smooth_seq(l, b, pin_l, a, c, post, false, fin, dots_l));
+        }
         cur[(size_t)l] = a;
         if (l == 0 && a != z) return fail(PIB_ERR_LIB, "gmg: internal buffer parity error");
     }
+    s->z_halo_depth = li[0].dist ? valid(z) : 0;
     return 0;
 }
 
@@ -2133,8 +2266,8 @@ int stencil_apply(pib_solver *s, double *x_owned, double *y, hipStream_t q)
 {
     if (!s->has_grid) return fail(PIB_ERR_ORDER, "stencil apply without grid structure");
     const GridLevel &g = s->levels[0];
-    PIB_CHK(halo_level(s, g, x_owned, q));
-    return launch_level<0>(s, g, 0.0, nullptr, x_owned, y, nullptr, false, q);
+    if (s->comm.nranks > 1 && !g.replicated) PIB_CHK(exchange_planes(s, g, x_owned, 1, q));
+    return launch_level<0>(s, g, 0.0, nullptr, x_owned, y, nullptr, false, q, nullptr, 0.0);
 }
 
 }  // namespace pib

@@ -88,7 +88,7 @@ int comm_init(pib_solver *s, int rank, int nranks, const void *uid)
 
 void comm_release(pib_solver *s)
 {
-    if (s->comm.comm) (void)ncclCommDestroy(s->comm.comm);
+    if (s->comm.comm && !s->comm.borrowed) (void)ncclCommDestroy(s->comm.comm);
     s->comm.comm = nullptr;
     s->comm.loop = nullptr;  // the group is owned by whoever created it
 }

@@ -442,16 +442,19 @@ __global__ void k_cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean
 int ensure_work(pib_solver *s, int nvec)
 {
     const DeviceCsr &A = s->A;
-    int64_t stride = A.ghost_lo + A.n + A.ghost_hi + 4;
-    stride = (stride + 1) & ~int64_t(1);
-    if (s->work != nullptr && s->n_work >= nvec && s->work_stride == stride) return 0;
+    // [halo below | owned | halo above]: the CSR's ghost columns, or the deeper halo of the multigrid's slabs
+    int64_t lo = std::max(A.ghost_lo, s->work_pad), hi = std::max(A.ghost_hi, s->work_pad);
+    lo = (lo + 3) & ~int64_t(3);  // owned part 32-byte aligned
+    int64_t stride = lo + A.n + hi + 4;
+    stride = (stride + 3) & ~int64_t(3);
+    if (s->work != nullptr && s->n_work >= nvec && s->work_stride == stride && s->work_lo == lo) return 0;
     if (s->work_base) PIB_HIP(hipFree(s->work_base));
     s->work_base = nullptr;
     s->work = nullptr;
-    PIB_HIP(hipMalloc(&s->work_base, (size_t)(stride * nvec + 2) * sizeof(double)));
-    PIB_HIP(hipMemsetAsync(s->work_base, 0, (size_t)(stride * nvec + 2) * sizeof(double), s->stream));
-    // owned part (work + ghost_lo) 16-byte aligned
-    s->work = s->work_base + (A.ghost_lo & 1);
+    PIB_HIP(hipMalloc(&s->work_base, (size_t)(stride * nvec + 4) * sizeof(double)));
+    PIB_HIP(hipMemsetAsync(s->work_base, 0, (size_t)(stride * nvec + 4) * sizeof(double), s->stream));
+    s->work = s->work_base;  // hipMalloc is 256-byte aligned; lo and stride are multiples of 4 doubles
+    s->work_lo = lo;
     s->work_stride = stride;
     s->n_work = nvec;
     return 0;
@@ -706,8 +709,17 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         auto body = [&]() -> int {
-            OpUpdateP up{Z, P, 0.0, 0.0, 0};
-            PIB_CHK(update_p_and_exchange(s, n, up, P, q));
+            const int64_t zv = gmg ? (int64_t)s->z_halo_depth * s->levels[0].plane : 0;
+            if (s->comm.nranks > 1 && zv > 0 && zv >= A.ghost_lo && zv >= A.ghost_hi) {
+                // the V-cycle left z valid on the ghost planes the matrix reaches: p = z + beta p there too (the ghost
+                // values of p follow the same recurrence as their owners'), and the product needs no exchange
+                OpUpdateP up{Z - A.ghost_lo, P - A.ghost_lo, 0.0, 0.0, 0};
+                PIB_CHK(launch_vec(s, n + A.ghost_lo + A.ghost_hi, up, (A.ghost_lo & 1) == 0, 0, nullptr, true, q));
+                s->halo_fresh = P;
+            } else {
+                OpUpdateP up{Z, P, 0.0, 0.0, 0};
+                PIB_CHK(update_p_and_exchange(s, n, up, P, q));
+            }
             PIB_CHK(matmult(s, P, W, part_pw, true, q));
             if (s->comm.nranks == 1)
                 PIB_CHK(finalize_post<4>(s, SLOT_PW, 1, spmv_blocks, nullptr, 0, q));

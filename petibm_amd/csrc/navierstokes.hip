@@ -658,16 +658,34 @@ int pib_ns_destroy(pib_ns *ns)
     return 0;
 }
 
-int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
-                  const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
-                  double nu, const char *velocity_cfg, const char *poisson_cfg, int device)
+}  // extern "C"
+
+// The engine on one rank's z-slab (y-slab in 2-D) of the mesh -- SURVEY.md 8e, NavierStokesSolver on the DMDA
+// decomposition (src/mesh/cartesianmesh.cpp:492-538).  A rank keeps, of every field, its owned planes plus one plane of
+// each neighbour (and one more, unused, plane above: the component along the slab axis lives on the faces BETWEEN the
+// planes), all in the packed [u | v | w] layout: to the kernels this EXTENDED slab is simply a smaller mesh whose 1-D
+// arrays along the slab axis are slices of the global ones -- the "ghost" entries at a cut are the neighbour's real
+// coordinates -- so every kernel of the single-rank engine runs unchanged and computes, on the owned planes, the bits
+// the single rank computes (their stencils reach one plane; what the kernels write on the neighbours' planes from the
+// dummy boundary condition at a cut is overwritten by the next halo exchange).  The two linear solvers work on the
+// GLOBAL systems (this rank's rows: pib_assemble_velocity / pib_assemble_poisson on slabs) and share one communicator.
+static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], const double *wx, const double *wy,
+                          const double *wz, const double lo[3], const double hi[3], const int bc_type_in[18],
+                          const double bc_value_in[18], double dt, double nu, const char *velocity_cfg,
+                          const char *poisson_cfg, int device, int rank, int nranks, const void *uid)
 {
     using namespace pib;
-    if (out == nullptr || n == nullptr || lo == nullptr || hi == nullptr || bc_type == nullptr || bc_value == nullptr)
+    if (out == nullptr || n_global == nullptr || lo == nullptr || hi == nullptr || bc_type_in == nullptr || bc_value_in == nullptr)
         return fail(PIB_ERR_ARG_NULL, "pib_ns_create: null argument");
     *out = nullptr;
     if (dim != 2 && dim != 3) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_create: dim must be 2 or 3");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_create: bad rank %d / %d", rank, nranks);
     const double *w[3] = {wx, wy, wz};
+    const int64_t *n = n_global;
+    int bc_type[18];
+    double bc_value[18];
+    std::memcpy(bc_type, bc_type_in, sizeof bc_type);
+    std::memcpy(bc_value, bc_value_in, sizeof bc_value);
     std::vector<double> hdl[3][3], hco[3][3];
     int64_t fn[3][3];
     // periodic directions: PERIODIC at both ends for every component (misc.cpp:17-85 checkPeriodicBC)
@@ -682,7 +700,41 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
         periodic[d] = cnt ? 1 : 0;
     }
     velocity_mesh_arrays(dim, n, w, lo, hi, periodic, hdl, hco, fn);
+    // ---- this rank's extended slab: cells [e0, e1) of the slab axis = owned [pk0, pk1) + one plane below + two above
+    const int sd = dim - 1;
+    int64_t pk0 = 0, pk1 = n[sd], e0 = 0, e1 = n[sd];
+    int64_t fn_global[3] = {1, 1, 1};
+    for (int f = 0; f < dim; ++f) fn_global[f] = fn[f][sd];
+    std::vector<double> w_slab;
+    int64_t n_local[3] = {n[0], n[1], n[2]};
+    if (nranks > 1) {
+        if (periodic[sd]) return fail(PIB_ERR_SUP, "pib_ns_create_slab: a periodic slab axis on several ranks is not provided");
+        slab_range(n[sd], nranks, rank, &pk0, &pk1);
+        if (pk1 - pk0 < 2) return fail(PIB_ERR_SUP, "pib_ns_create_slab: rank %d owns %lld plane(s); every rank needs >= 2", rank, (long long)(pk1 - pk0));
+        e0 = std::max<int64_t>(pk0 - 1, 0);
+        e1 = std::min<int64_t>(pk1 + 2, n[sd]);
+        for (int f = 0; f < dim; ++f) {
+            const int64_t cnt = (f == sd) ? (e1 - e0 - 1) : (e1 - e0);  // faces between the local planes / the local planes
+            std::vector<double> &a = hdl[f][sd], &c = hco[f][sd];
+            a = std::vector<double>(a.begin() + e0, a.begin() + e0 + cnt + 2);  // entry s + 1 <-> point s, one entry beyond each end
+            c = std::vector<double>(c.begin() + e0, c.begin() + e0 + cnt + 2);
+            fn[f][sd] = cnt;
+        }
+        w_slab.assign(w[sd] + e0, w[sd] + e1);
+        w[sd] = w_slab.data();
+        n_local[sd] = e1 - e0;
+        // a cut is a dummy wall (the values the kernels derive from it land on the neighbours' planes only)
+        for (int f = 0; f < dim; ++f) {
+            if (e0 > 0) { bc_type[6 * f + 2 * sd] = 0; bc_value[6 * f + 2 * sd] = 0.0; }
+            if (e1 < n[sd]) { bc_type[6 * f + 2 * sd + 1] = 0; bc_value[6 * f + 2 * sd + 1] = 0.0; }
+        }
+    }
     pib_ns *ns = new pib_ns();
+    ns->nranks = nranks;
+    ns->rank = rank;
+    ns->slab_pk0 = pk0;
+    ns->slab_pk1 = pk1;
+    ns->slab_e0 = e0;
     for (int d = 0; d < 3; ++d) ns->periodic[d] = periodic[d];
     ns->dt = dt;
     ns->nu = nu;
@@ -698,8 +750,9 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
         return e;
     };
     // the two linear solvers (same device)
-    if ((err = pib_create_from_string(&ns->vsol, "velocity", velocity_cfg, 0, 1, nullptr, device))) return bail(err);
-    if ((err = pib_create_from_string(&ns->psol, "poisson", poisson_cfg, 0, 1, nullptr, device))) return bail(err);
+    if ((err = pib_create_from_string(&ns->vsol, "velocity", velocity_cfg, rank, nranks, uid, device))) return bail(err);
+    // one communicator (an RCCL id makes one): the Poisson solver borrows the velocity solver's
+    if ((err = create_sharing_comm(&ns->psol, "poisson", poisson_cfg, ns->vsol))) return bail(err);
     if (ns->psol->cfg.matrix_free_poisson < 0) ns->psol->cfg.matrix_free_poisson = 1;  // auto: on inside the time step
     ns->device = ns->vsol->device;
     PIB_HIP(hipSetDevice(ns->device));
@@ -739,17 +792,28 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
     // matrices: A = I/dt - c nu L (CN: c = 1/2), DBNG; null-space convention from the Poisson solver's flavour
     // (navierstokes.cpp:395-429)
     if ((err = pib_set_periodic(ns->vsol, periodic)) || (err = pib_set_periodic(ns->psol, periodic))) return bail(err);
-    if ((err = pib_assemble_velocity(ns->vsol, dim, n, wx, wy, wz, lo, hi, a0, dt, 0.5 * nu))) return bail(err);
+    // the global systems (this rank's rows); a0 of the TRUE boundaries (the dummy walls at the cuts are Dirichlet too, so
+    // the table built above already has the true values wherever a true boundary exists)
+    double a0_global[18];
+    std::memcpy(a0_global, a0, sizeof a0);
+    for (int f = 0; f < dim && nranks > 1; ++f)
+        for (int e = 0; e < 2; ++e) {
+            const int t = bc_type_in[6 * f + 2 * sd + e];
+            a0_global[6 * f + 2 * sd + e] = (t == 1) ? 1.0 : ((sd == f) ? 0.0 : -1.0);
+        }
+    if ((err = pib_assemble_velocity(ns->vsol, dim, n, wx, wy, wz, lo, hi, a0_global, dt, 0.5 * nu))) return bail(err);
     char tbuf[64];
     pib_get_type(ns->psol, tbuf, sizeof tbuf);
     ns->pinned = (std::strcmp(tbuf, "NVIDIA AmgX") == 0) ? 1 : 0;
     if ((err = pib_assemble_poisson(ns->psol, dim, n, wx, wy, wz, dt, ns->pinned ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT)))
         return bail(err);
+    const double *wg[3] = {wx, wy, wz};
     for (int d = 0; d < dim; ++d) {
         ns->h_n[d] = n[d];
-        ns->h_w[d].assign(w[d], w[d] + n[d]);
+        ns->h_w[d].assign(wg[d], wg[d] + n[d]);
     }
-    std::memcpy(ns->h_a0, a0, sizeof a0);
+    std::memcpy(ns->h_a0, a0_global, sizeof a0_global);
+    n = n_local;  // from here on: the (extended) slab as the kernels' mesh
     // device mesh arrays
     NsDev &D = ns->D;
     D.dim = dim;
@@ -838,12 +902,88 @@ int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, c
         (err = alloc(&ns->rhs2, D.pN)) || (err = alloc(&D.a1, D.nghost)) || (err = alloc(&D.a1n, D.nghost)) ||
         (err = alloc(&D.gv, D.nghost)))
         return bail(err);
+    // slab bookkeeping: the owned planes of every field inside the extended slab, and the packed [u | v | w] vector of
+    // the owned points the velocity solver works on (what DMCompositeGetAccess hands out on a rank)
+    ns->UN_owned = 0;
+    for (int f = 0; f < 3; ++f) {
+        ns->fld_plane[f] = ns->fld_own_lo[f] = ns->fld_own_cnt[f] = ns->fld_pk_off[f] = 0;
+        if (f >= dim) continue;
+        ns->fld_plane[f] = (dim == 3) ? fn[f][0] * fn[f][1] : fn[f][0];
+        ns->fld_own_lo[f] = pk0 - e0;
+        ns->fld_own_cnt[f] = std::min(pk1, fn_global[f]) - pk0;
+        ns->fld_pk_off[f] = ns->UN_owned;
+        ns->UN_owned += ns->fld_plane[f] * ns->fld_own_cnt[f];
+    }
+    ns->p_plane = (dim == 3) ? n[0] * n[1] : n[0];
+    ns->pN_owned = ns->p_plane * (pk1 - pk0);
+    if (nranks > 1) {
+        if (ns->UN_owned != ns->vsol->A.n || ns->pN_owned != ns->psol->A.n)
+            return bail(fail(PIB_ERR_LIB, "pib_ns_create_slab: slab sizes disagree with the assembled systems"));
+        if ((err = alloc(&ns->Upk, ns->UN_owned)) || (err = alloc(&ns->rhs1pk, ns->UN_owned))) return bail(err);
+    }
     // bc->setGhostICs(solution) for the zero initial state (navierstokes.cpp:142)
     hipLaunchKernelGGL(k_ns_ghosts<0>, dim3(ghost_blocks(D)), dim3(256), 0, ns->stream, D, 0.0, ns->U);
     PIB_HIP(hipGetLastError());
     PIB_HIP(hipStreamSynchronize(ns->stream));
     *out = ns;
     return 0;
+}
+
+// ---- slab helpers (no-ops on one rank)
+namespace pib {
+// owned points of the extended-slab vector `ext` <-> the packed vector `pk` (three contiguous pieces)
+static int ns_pack(pib_ns *ns, const double *ext, double *pk)
+{
+    for (int f = 0; f < ns->D.dim; ++f)
+        PIB_HIP(hipMemcpyAsync(pk + ns->fld_pk_off[f], ext + ns->D.f[f].off + ns->fld_own_lo[f] * ns->fld_plane[f],
+                               sizeof(double) * (size_t)(ns->fld_own_cnt[f] * ns->fld_plane[f]), hipMemcpyDeviceToDevice, ns->stream));
+    return 0;
+}
+static int ns_unpack(pib_ns *ns, const double *pk, double *ext)
+{
+    for (int f = 0; f < ns->D.dim; ++f)
+        PIB_HIP(hipMemcpyAsync(ext + ns->D.f[f].off + ns->fld_own_lo[f] * ns->fld_plane[f], pk + ns->fld_pk_off[f],
+                               sizeof(double) * (size_t)(ns->fld_own_cnt[f] * ns->fld_plane[f]), hipMemcpyDeviceToDevice, ns->stream));
+    return 0;
+}
+// one plane of every velocity component from each neighbour (C1: the VecScatter of DMGlobalToLocal, navierstokes.cpp:246)
+static int ns_halo_velocity(pib_ns *ns, double *ext)
+{
+    if (ns->nranks <= 1) return 0;
+    const int r = ns->rank, P = ns->nranks;
+    for (int f = 0; f < ns->D.dim; ++f) {
+        const int64_t pl = ns->fld_plane[f];
+        PIB_CHK(halo_exchange_planes(ns->vsol, ext + ns->D.f[f].off + ns->fld_own_lo[f] * pl, ns->fld_own_cnt[f] * pl, r > 0 ? pl : 0,
+                                     r < P - 1 ? pl : 0, r > 0 ? pl : 0, r < P - 1 ? pl : 0, ns->stream));
+    }
+    return 0;
+}
+static int ns_halo_cells(pib_ns *ns, double *ext)
+{
+    if (ns->nranks <= 1) return 0;
+    const int r = ns->rank, P = ns->nranks;
+    const int64_t pl = ns->p_plane;
+    return halo_exchange_planes(ns->vsol, ext + (ns->slab_pk0 - ns->slab_e0) * pl, ns->pN_owned, r > 0 ? pl : 0, r < P - 1 ? pl : 0,
+                                r > 0 ? pl : 0, r < P - 1 ? pl : 0, ns->stream);
+}
+}  // namespace pib
+
+extern "C" {
+
+int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
+                  const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
+                  double nu, const char *velocity_cfg, const char *poisson_cfg, int device)
+{
+    return ns_create_impl(out, dim, n, wx, wy, wz, lo, hi, bc_type, bc_value, dt, nu, velocity_cfg, poisson_cfg, device, 0, 1, nullptr);
+}
+
+int pib_ns_create_slab(pib_ns **out, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
+                       const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
+                       double nu, const char *velocity_cfg, const char *poisson_cfg, int rank, int nranks,
+                       const void *uid_or_null, int device)
+{
+    return ns_create_impl(out, dim, n, wx, wy, wz, lo, hi, bc_type, bc_value, dt, nu, velocity_cfg, poisson_cfg, device, rank, nranks,
+                          uid_or_null);
 }
 
 /* parameters.BN (navierstokes.cpp:349-356): order N of the approximate inverse BN.  N > 1 re-assembles the Poisson
@@ -855,6 +995,7 @@ int pib_ns_set_bn_order(pib_ns *ns, int order)
     if (order < 1) return fail(PIB_ERR_SUP, "The order of Bn can not be smaller than 1.");
     if (ns->ib && order > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bn_order: BN order > 1 with immersed bodies is not supported");
     if (order == ns->bn_order) return 0;
+    if (ns->nranks > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bn_order: BN order > 1 on several ranks is not provided");
     PIB_HIP(hipSetDevice(ns->device));
     if (ns->bng_rowptr) (void)hipFree(ns->bng_rowptr);
     if (ns->bng_col) (void)hipFree(ns->bng_col);
@@ -929,6 +1070,19 @@ int pib_ns_history_term(pib_ns *ns, int kind, int index, int set, double *host)
         return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_history_term: the scheme keeps %d term(s) of kind %d", count, kind);
     PIB_HIP(hipSetDevice(ns->device));
     double *dev = (kind == 0) ? ns->conv[index] : (index == 0 ? ns->diff0 : ns->diff1);
+    if (ns->nranks > 1) {  // the packed owned points (only those are ever read back by the right-hand side)
+        const size_t ub = sizeof(double) * (size_t)ns->UN_owned;
+        if (set) {
+            PIB_HIP(hipMemcpy(ns->rhs1pk, host, ub, hipMemcpyHostToDevice));
+            PIB_CHK(ns_unpack(ns, ns->rhs1pk, dev));
+            PIB_HIP(hipStreamSynchronize(ns->stream));
+        } else {
+            PIB_CHK(ns_pack(ns, dev, ns->rhs1pk));
+            PIB_HIP(hipStreamSynchronize(ns->stream));
+            PIB_HIP(hipMemcpy(host, ns->rhs1pk, ub, hipMemcpyDeviceToHost));
+        }
+        return 0;
+    }
     const size_t bytes = sizeof(double) * (size_t)ns->D.UN;
     if (set) PIB_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
     else PIB_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
@@ -944,6 +1098,7 @@ int pib_ns_get_vorticity(pib_ns *ns, int comp, int64_t n_out[3], double *out)
     if (ns == nullptr || n_out == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_get_vorticity: null argument");
     const NsDev &D = ns->D;
     if (comp < 0 || comp > 2 || (D.dim == 2 && comp != 2)) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_get_vorticity: component %d", comp);
+    if (ns->nranks > 1) return fail(PIB_ERR_SUP, "pib_ns_get_vorticity: post-processing runs on one rank");
     for (int d = 0; d < 3; ++d) n_out[d] = (d < D.dim) ? ((d == comp) ? D.pn[d] : D.pn[d] + 1) : 1;
     if (out == nullptr) return 0;
     PIB_HIP(hipSetDevice(ns->device));
@@ -962,8 +1117,9 @@ int pib_ns_get_vorticity(pib_ns *ns, int comp, int64_t n_out[3], double *out)
 int pib_ns_sizes(pib_ns *ns, int64_t *UN, int64_t *pN)
 {
     if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
-    if (UN) *UN = ns->D.UN;
-    if (pN) *pN = ns->D.pN;
+    // on a slab: this rank's part of the distributed vectors (packed owned [u | v | w]; owned pressure cells)
+    if (UN) *UN = (ns->nranks > 1) ? ns->UN_owned : ns->D.UN;
+    if (pN) *pN = (ns->nranks > 1) ? ns->pN_owned : ns->D.pN;
     return 0;
 }
 
@@ -972,14 +1128,27 @@ int pib_ns_set_state(pib_ns *ns, const double *U, const double *p)
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
+    const bool slab = ns->nranks > 1;
     if (U) {
-        PIB_HIP(hipMemcpy(ns->U, U, sizeof(double) * (size_t)ns->D.UN, hipMemcpyHostToDevice));
+        if (slab) {
+            PIB_HIP(hipMemcpy(ns->Upk, U, sizeof(double) * (size_t)ns->UN_owned, hipMemcpyHostToDevice));
+            PIB_CHK(ns_unpack(ns, ns->Upk, ns->U));
+            PIB_CHK(ns_halo_velocity(ns, ns->U));
+        } else
+            PIB_HIP(hipMemcpy(ns->U, U, sizeof(double) * (size_t)ns->D.UN, hipMemcpyHostToDevice));
         // initial data are followed by bc->setGhostICs(solution) (navierstokes.cpp:139-142, restart :743)
         hipLaunchKernelGGL(k_ns_ghosts<0>, dim3(ghost_blocks(ns->D)), dim3(256), 0, ns->stream, ns->D, 0.0, ns->U);
         PIB_HIP(hipGetLastError());
         PIB_HIP(hipStreamSynchronize(ns->stream));
     }
-    if (p) PIB_HIP(hipMemcpy(ns->p, p, sizeof(double) * (size_t)ns->D.pN, hipMemcpyHostToDevice));
+    if (p) {
+        if (slab) {
+            PIB_HIP(hipMemcpy(ns->p + (ns->slab_pk0 - ns->slab_e0) * ns->p_plane, p, sizeof(double) * (size_t)ns->pN_owned, hipMemcpyHostToDevice));
+            PIB_CHK(ns_halo_cells(ns, ns->p));
+            PIB_HIP(hipStreamSynchronize(ns->stream));
+        } else
+            PIB_HIP(hipMemcpy(ns->p, p, sizeof(double) * (size_t)ns->D.pN, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -989,6 +1158,23 @@ int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
     PIB_HIP(hipStreamSynchronize(ns->stream));
+    if (ns->nranks > 1) {  // this rank's owned points
+        const int64_t own = (ns->slab_pk0 - ns->slab_e0) * ns->p_plane;
+        const size_t ub = sizeof(double) * (size_t)ns->UN_owned, pb = sizeof(double) * (size_t)ns->pN_owned;
+        if (U) {
+            PIB_CHK(ns_pack(ns, ns->U, ns->Upk));
+            PIB_HIP(hipStreamSynchronize(ns->stream));
+            PIB_HIP(hipMemcpy(U, ns->Upk, ub, hipMemcpyDeviceToHost));
+        }
+        if (rhs1) {
+            PIB_CHK(ns_pack(ns, ns->rhs1, ns->rhs1pk));
+            PIB_HIP(hipStreamSynchronize(ns->stream));
+            PIB_HIP(hipMemcpy(rhs1, ns->rhs1pk, ub, hipMemcpyDeviceToHost));
+        }
+        if (p) PIB_HIP(hipMemcpy(p, ns->p + own, pb, hipMemcpyDeviceToHost));
+        if (rhs2) PIB_HIP(hipMemcpy(rhs2, ns->rhs2 + own, pb, hipMemcpyDeviceToHost));
+        return 0;
+    }
     if (U) PIB_HIP(hipMemcpy(U, ns->U, sizeof(double) * (size_t)ns->D.UN, hipMemcpyDeviceToHost));
     if (p) PIB_HIP(hipMemcpy(p, ns->p, sizeof(double) * (size_t)ns->D.pN, hipMemcpyDeviceToHost));
     if (rhs1) PIB_HIP(hipMemcpy(rhs1, ns->rhs1, sizeof(double) * (size_t)ns->D.UN, hipMemcpyDeviceToHost));
@@ -1003,6 +1189,12 @@ int pib_ns_get_history(pib_ns *ns, double *conv0, double *conv1, double *diff0)
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
     PIB_HIP(hipStreamSynchronize(ns->stream));
+    if (ns->nranks > 1) {
+        if (conv0 && ns->T.nconv > 0) PIB_CHK(pib_ns_history_term(ns, 0, 0, 0, conv0));
+        if (conv1 && ns->T.nconv > 1) PIB_CHK(pib_ns_history_term(ns, 0, 1, 0, conv1));
+        if (diff0 && ns->T.ndiff > 0) PIB_CHK(pib_ns_history_term(ns, 1, 0, 0, diff0));
+        return 0;
+    }
     const size_t bytes = sizeof(double) * (size_t)ns->D.UN;
     if (conv0) PIB_HIP(hipMemcpy(conv0, ns->conv[0], bytes, hipMemcpyDeviceToHost));
     if (conv1) PIB_HIP(hipMemcpy(conv1, ns->conv[1], bytes, hipMemcpyDeviceToHost));
@@ -1015,6 +1207,11 @@ int pib_ns_set_history(pib_ns *ns, const double *conv0, const double *conv1)
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
+    if (ns->nranks > 1) {
+        if (conv0 && ns->T.nconv > 0) PIB_CHK(pib_ns_history_term(ns, 0, 0, 1, const_cast<double *>(conv0)));
+        if (conv1 && ns->T.nconv > 1) PIB_CHK(pib_ns_history_term(ns, 0, 1, 1, const_cast<double *>(conv1)));
+        return 0;
+    }
     const size_t bytes = sizeof(double) * (size_t)ns->D.UN;
     if (conv0) PIB_HIP(hipMemcpy(ns->conv[0], conv0, bytes, hipMemcpyHostToDevice));
     if (conv1) PIB_HIP(hipMemcpy(ns->conv[1], conv1, bytes, hipMemcpyHostToDevice));
@@ -1065,8 +1262,18 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         PIB_HIP(hipGetLastError());
         std::swap(D.a1, D.a1n);
         if (ns->ib) PIB_CHK(ib_spread_forces(ns));  // rhs1 += H f  (decoupledibpm.cpp:243)
+        if (ns->nranks > 1) {
+            // the solver's vectors are the packed owned points; afterwards the neighbours' planes of u* (DMGlobalToLocal)
+            PIB_CHK(ns_pack(ns, ns->rhs1, ns->rhs1pk));
+            PIB_CHK(ns_pack(ns, ns->U, ns->Upk));
+            PIB_HIP(hipStreamSynchronize(ns->stream));
+            PIB_CHK(pib_solve(ns->vsol, ns->Upk, ns->rhs1pk));
+            PIB_CHK(ns_unpack(ns, ns->Upk, ns->U));
+            PIB_CHK(ns_halo_velocity(ns, ns->U));
+        } else {
         PIB_HIP(hipStreamSynchronize(ns->stream));
         PIB_CHK(pib_solve(ns->vsol, ns->U, ns->rhs1));  // vSolver->solve(UGlobal, rhs1)  (:532)
+        }
         const bool coupled = ib_is_coupled(ns);
         if (ns->ib && !coupled) PIB_CHK(ib_solve_forces(ns));   // assembleRHSForces, solveForces, applyNoSlip (decoupledibpm.cpp:116-118)
         hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns->pinned, ns->U, ns->rhs2);
@@ -1081,13 +1288,18 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
             continue;
         }
         PIB_HIP(hipStreamSynchronize(ns->stream));
-        PIB_CHK(pib_solve(ns->psol, ns->dP, ns->rhs2));  // pSolver->solve(dP, rhs2)      (:575)
+        {
+            const int64_t own = (ns->slab_pk0 - ns->slab_e0) * ns->p_plane;  // the owned cells are contiguous in the extended slab
+            PIB_CHK(pib_solve(ns->psol, ns->dP + own, ns->rhs2 + own));  // pSolver->solve(dP, rhs2)      (:575)
+            PIB_CHK(ns_halo_cells(ns, ns->dP));  // G dP at the faces towards the neighbours
+        }
         if (ns->bn_order > 1)
             hipLaunchKernelGGL(k_ns_project_csr, dim3(gt), dim3(256), 0, ns->stream, D.UN, D.pN, ns->bng_rowptr, ns->bng_col,
                                ns->bng_val, ns->dP, ns->U, ns->p);
         else
             hipLaunchKernelGGL(k_ns_project, dim3(gt), dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
         if (ns->ib) PIB_CHK(ib_update_forces(ns));  // f += df  (decoupledibpm.cpp:125)
+        PIB_CHK(ns_halo_velocity(ns, ns->U));       // the projected velocity on the neighbours' planes
         hipLaunchKernelGGL(k_ns_ghosts<2>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);  // bc->updateGhostValues (:263)
         PIB_HIP(hipGetLastError());
         ns->steps++;

@@ -100,6 +100,12 @@ struct pib_ns {
     int32_t *bng_rowptr = nullptr, *bng_col = nullptr;
     double *bng_val = nullptr;
     int64_t bng_nnz = 0;
+    // z-slab (y-slab) decomposition: the engine's mesh is this rank's EXTENDED slab (navierstokes.hip: ns_create_impl)
+    int rank = 0, nranks = 1;
+    int64_t slab_pk0 = 0, slab_pk1 = 0, slab_e0 = 0;          // owned pressure planes [pk0, pk1), first plane of the extended slab
+    int64_t fld_plane[3] = {0, 0, 0}, fld_own_lo[3] = {0, 0, 0}, fld_own_cnt[3] = {0, 0, 0}, fld_pk_off[3] = {0, 0, 0};
+    int64_t UN_owned = 0, pN_owned = 0, p_plane = 0;
+    double *Upk = nullptr, *rhs1pk = nullptr;                  // packed owned [u | v | w] (the velocity solver's vectors)
     int64_t h_n[3] = {1, 1, 1};
     std::vector<double> h_w[3];
     double h_a0[18] = {0};

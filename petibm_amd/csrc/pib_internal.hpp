@@ -83,6 +83,7 @@ struct Config {
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
+    int deep_halo = 1;       // multi-GPU multigrid: exchange several ghost planes at once and recompute the ghost cells (gmg.hip); 0: one plane per stencil kernel
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;
 };
@@ -158,6 +159,8 @@ struct GridLevel {
     double4 *tx_pw = nullptr, *tx_rw = nullptr;
     bool replicated = false;  // multi-GPU: every rank holds the whole level
     int64_t nloc = 0, plane = 0;
+    int64_t pad = 0;          // entries of halo memory before the first owned plane of every level vector
+    std::vector<int32_t> hz_par, hz_oth;  // host copy of the z transfer table (halo-depth planning, gmg.hip)
     int per = 0;  // bit d: direction d (internal order) is periodic and has > 1 cell: the level operator wraps
     int tper = 0; // bit d: ... and so do the transfers towards the next coarser level (>= 4 cells)
     bool plain_pair = false;  // every aggregate towards the next coarser level is a pair of cells (n = 2 nc) in all three directions
@@ -169,6 +172,7 @@ struct Comm {
     ncclComm_t comm = nullptr;
     LoopbackGroup *loop = nullptr;
     int rank = 0, nranks = 1;
+    bool borrowed = false;  // the communicator belongs to another solver of the same engine (one RCCL id makes one communicator)
     bool ring = false;  // the slab axis is periodic: rank 0 and rank P-1 are neighbours (their outer ghost planes wrap)
 };
 
@@ -240,11 +244,14 @@ struct pib_solver {
     // results of the last solve
     int iters = 0, reason = 0;
     int hint_iters = 0;  // iterations of the previous solve (first enqueue batch of the next one)
+    int64_t work_pad = 0;     // entries of halo memory the Krylov work vectors keep below / above their owned part (>= the CSR's ghost columns)
+    int z_halo_depth = 0;     // ghost planes on which the last V-cycle's result is valid (multi-GPU)
     const double *halo_fresh = nullptr;  // vector whose halo planes were exchanged by its producer (overlap path)
     double residual = 0.0;
     std::vector<double> history;
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double *vec(int i) const { return work + (int64_t)i * work_stride + A.ghost_lo; }
+    int64_t work_lo = 0;      // entries before the owned part of a work vector
+    double *vec(int i) const { return work + (int64_t)i * work_stride + work_lo; }
 };
 
 namespace pib {
@@ -265,6 +272,8 @@ int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vec
 int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const std::vector<int64_t> &counts,
                     const std::vector<int64_t> &offs, hipStream_t st);
 void comm_release(pib_solver *s);
+// a solver on `other`'s device, rank and communicator (the second solver of a flow engine)
+int create_sharing_comm(pib_solver **out, const char *name, const char *cfg_text, pib_solver *other);
 // krylov.hip
 int solve_cg(pib_solver *s, double *x, const double *b);
 int solve_bicgstab(pib_solver *s, double *x, const double *b);

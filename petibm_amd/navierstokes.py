@@ -74,7 +74,11 @@ def _widths(axis: dict):
 
 class NavierStokesSolver:
     def __init__(self, config: dict, velocity_cfg: str = DEFAULT_VELOCITY_CFG, poisson_cfg: str = DEFAULT_POISSON_CFG,
-                 device: int = -1):
+                 device: int = -1, rank: int = 0, nranks: int = 1, uid: bytes = None):
+        """rank / nranks / uid (as LinSolverHIP): the engine on this rank's z-slab (y-slab in 2-D) of the mesh, one rank
+        per GPU (pib_ns_create_slab).  UN / pN, setState / getState then speak of this rank's part of the distributed
+        vectors; `ownedVelocity` / `ownedPressure` cut it out of a global array."""
+        self.rank, self.nranks = int(rank), int(nranks)
         axes = sorted(config["mesh"], key=lambda a: _DIR[a["direction"]])
         self.dim = len(axes)
         ws, lo, hi = [], [], []
@@ -114,9 +118,16 @@ class NavierStokesSolver:
         wp = [w.ctypes.data for w in ws] + [None] * (3 - self.dim)
         self._h = C.c_void_p()
         self._keep = (n3, lo3, hi3, bc_t, bc_v)
-        capi.check(capi.load().pib_ns_create(C.byref(self._h), self.dim, n3.ctypes.data, wp[0], wp[1], wp[2],
-                                             lo3.ctypes.data, hi3.ctypes.data, bc_t.ctypes.data, bc_v.ctypes.data,
-                                             self.dt, self.nu, velocity_cfg.encode(), poisson_cfg.encode(), device))
+        if self.nranks > 1:
+            uidbuf = C.create_string_buffer(uid, capi.UID_BYTES)
+            capi.check(capi.load().pib_ns_create_slab(C.byref(self._h), self.dim, n3.ctypes.data, wp[0], wp[1], wp[2],
+                                                      lo3.ctypes.data, hi3.ctypes.data, bc_t.ctypes.data, bc_v.ctypes.data,
+                                                      self.dt, self.nu, velocity_cfg.encode(), poisson_cfg.encode(),
+                                                      self.rank, self.nranks, uidbuf, device))
+        else:
+            capi.check(capi.load().pib_ns_create(C.byref(self._h), self.dim, n3.ctypes.data, wp[0], wp[1], wp[2],
+                                                 lo3.ctypes.data, hi3.ctypes.data, bc_t.ctypes.data, bc_v.ctypes.data,
+                                                 self.dt, self.nu, velocity_cfg.encode(), poisson_cfg.encode(), device))
         if (self.convection, self.diffusion) != ("ADAMS_BASHFORTH_2", "CRANK_NICOLSON"):
             capi.check(capi.load().pib_ns_set_time_integration(self._h, self.convection.encode(), self.diffusion.encode()))
         kept = {"EULER_EXPLICIT": 1, "EULER_IMPLICIT": 0, "ADAMS_BASHFORTH_2": 2, "CRANK_NICOLSON": 1}
@@ -137,8 +148,40 @@ class NavierStokesSolver:
         if ic is not None:
             U0 = self._initial_velocity(ic, lo)
             p0 = self._initial_velocity([ip], lo, pressure=True) if ip is not None else None
-            if np.any(U0 != 0.0) or (p0 is not None and np.any(p0 != 0.0)):
-                self.setState(U0, p0)
+            if np.any(U0 != 0.0) or (p0 is not None and np.any(p0 != 0.0)) or self.nranks > 1:  # collective on slabs
+                self.setState(self.ownedVelocity(U0), None if p0 is None else self.ownedPressure(p0))
+
+    def _slab(self):
+        """owned planes [k0, k1) of the slab axis: the DMDA split (pib_slab_range)"""
+        b, e = C.c_int64(), C.c_int64()
+        capi.check(capi.load().pib_slab_range(self.n[-1], self.nranks, self.rank, C.byref(b), C.byref(e)))
+        return b.value, e.value
+
+    def _field_shape(self, f):
+        """points of velocity component f as (slab axis, ..., x)"""
+        n = [self.n[d] - (0 if (d != f or self.periodic[d]) else 1) for d in range(self.dim)]
+        return tuple(n[::-1])
+
+    def ownedVelocity(self, U):
+        """this rank's packed [u-slab | v-slab | w-slab] of a GLOBAL packed velocity array (cartesianmesh.cpp:740-779)"""
+        if self.nranks == 1:
+            return U
+        k0, k1 = self._slab()
+        parts, off = [], 0
+        for f in range(self.dim):
+            shp = self._field_shape(f)
+            cnt = int(np.prod(shp))
+            blk = np.asarray(U[off:off + cnt]).reshape(shp)
+            parts.append(blk[k0:min(k1, shp[0])].reshape(-1))
+            off += cnt
+        return np.ascontiguousarray(np.concatenate(parts))
+
+    def ownedPressure(self, p):
+        if self.nranks == 1:
+            return p
+        k0, k1 = self._slab()
+        pl = int(np.prod(self.n[:-1]))
+        return np.ascontiguousarray(np.asarray(p)[k0 * pl:k1 * pl])
 
     def _points(self, f, d, lo=None):
         """coordinates of field f (0..2 velocity components, 3 pressure) along direction d (cartesianmesh.cpp:136-355)"""

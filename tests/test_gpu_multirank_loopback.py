@@ -75,6 +75,13 @@ def _system(n, dt=0.01):
     # the 2.5-D blocked level kernel (gmg.hip k_level_march) on slabs and on the interior run of the overlapped producers
     (2, (128, 16, 40), "AMG", "pib_march_min_cells=0\nV22"),
     (3, (128, 8, 48), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\nV22"),
+    # one ghost plane per stencil kernel (pib_deep_halo=0: an exchange before every kernel) instead of the deep halos
+    (4, (32, 32, 32), "AMG", "pib_agglomerate_below=100\npib_deep_halo=0\nV22"),
+    (3, (128, 8, 48), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\npib_deep_halo=0\nV22"),
+    # the fused LDS-tiled kernels (two pre-smoothing steps, prolongation + post-smoothing) on slabs with ghost planes
+    (2, (128, 16, 64), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\nV22"),
+    (4, (128, 16, 64), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\nV22"),
+    (2, (128, 16, 64), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\n"),     # V(1,1): step + residual fused
 ])
 def test_multirank_poisson_solve_matches_single_rank(P, n, pc, extra):
     sweeps = 2 if extra.endswith("V22") else 1
@@ -304,3 +311,46 @@ def test_multirank_setcsr_route_and_pinned_gmg():
     assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-11 * np.linalg.norm(b)
     assert np.linalg.norm(x - xs) <= 1e-7 * np.linalg.norm(xs)
     assert res[0][1] == res[1][1] and res[0][1] < 40
+
+
+
+def test_config3_512_cubed_on_8_slabs():
+    """BASELINE config 3 -- the 512^3 cavity pressure system on 8 z-slabs of 64 planes, the exact rank layout of
+    `bench.py --gpus 8` (multigrid-PCG, V(2,2), rtol 1e-10) -- through the loopback transport on the one test GPU: every
+    kernel, halo plan and collective call site of the 8-GPU run except RCCL itself (the ranks time-share the device, so
+    the time means nothing).  Bars: the single-rank iteration count (11) on every rank, the residual contract recomputed
+    with the CSR operator, and the communication budget of DESIGN.md 5: at most 6 plane exchanges (all-gather included)
+    and 3 reductions per iteration."""
+    import bench
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    P, n = 8, 512
+    w = np.full(n, 1.0 / n)
+    cfg = bench.solver_config("gmg", 1e-10, 200, 0.9, 2, 2, "jacobi") + "\n"
+
+    def rank_fn(r, uid):
+        s = LinSolverHIP("poisson", config_text=cfg, rank=r, nranks=P, uid=uid, device=0)
+        s.assemblePoisson((n, n, n), [w, w, w], 5e-4, capi.NULLSPACE_CONSTANT)
+        k0, k1 = bench.slab(n, P, r)
+        xs_d, b_d, x_d, r_d = s.deviceVec(), s.deviceVec(), s.deviceVec(), s.deviceVec()
+        xs_d.upload(bench.manufactured_solution(n, k0, k1))
+        s.matMult(xs_d, b_d)
+        s.solve(x_d, b_d)
+        cnt = s.counters().copy()
+        s.matMult(x_d, r_d)
+        bl = b_d.download()
+        rl = bl - r_d.download()
+        out = (s.getIters(), float(rl @ rl), float(bl @ bl), cnt)
+        s.destroy()
+        return out
+
+    res = _run_ranks(P, rank_fn)
+    assert {r[0] for r in res} == {11}
+    rel = np.sqrt(sum(r[1] for r in res) / sum(r[2] for r in res))
+    assert rel <= 1.5e-10
+    its = res[0][0]
+    for r in res:
+        pc_applies, reductions, exchanges = int(r[3][1]), int(r[3][2]), int(r[3][3])
+        assert pc_applies == its + 1
+        assert exchanges <= 6 * pc_applies + 2, f"{exchanges} exchanges for {pc_applies} V-cycles"
+        assert reductions <= 3 * its + 3

@@ -34,10 +34,23 @@ def main():
             e["tot"] += d
             e["min"] = min(e["min"], d)
             e["max"] = max(e["max"], d)
+    # counters: the mean over all dispatches of a kernel and -- the multigrid launches one kernel on every level -- the
+    # values of its LONGEST dispatch (the fine level), matched through the dispatch id
+    dur = {}
+    for f in traces:
+        for r in csv.DictReader(open(f)):
+            dur[r.get("Dispatch_Id", "")] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    top = {}
     for f in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            d = dur.get(r.get("Dispatch_Id", ""), 0.0)
+            t = top.setdefault(r["Kernel_Name"], {"us": -1.0, "id": None, "c": {}})
+            if d > t["us"]:
+                t.update(us=d, id=r.get("Dispatch_Id"), c={})
+            if r.get("Dispatch_Id") == t["id"]:
+                t["c"][r["Counter_Name"]] = float(r["Counter_Value"])
     counters = sorted({c for k in pmc.values() for c in k})
     total = sum(e["tot"] for e in agg.values())
     lines = []
@@ -47,7 +60,7 @@ def main():
         lines.append(f"command: `{a.cmd}`\n")
     lines.append(f"total kernel time {total / 1e3:.2f} ms over {sum(e['n'] for e in agg.values())} dispatches\n")
     hdr = ["kernel", "calls", "total_ms", "share_%", "avg_us", "min_us", "max_us", "vgpr", "lds_B", "wg"] + \
-          [f"mean_{c}" for c in counters]
+          [f"mean_{c}" for c in counters] + ([f"longest_{c}" for c in counters] if counters else [])
     lines.append("| " + " | ".join(hdr) + " |")
     lines.append("|" + "---|" * len(hdr))
     for name, e in sorted(agg.items(), key=lambda kv: -kv[1]["tot"]):
@@ -57,6 +70,9 @@ def main():
         for c in counters:
             v = pmc.get(name, {}).get(c)
             row.append(f"{sum(v) / len(v):.4g}" if v else "")
+        for c in counters:
+            v = top.get(name, {}).get("c", {}).get(c)
+            row.append(f"{v:.4g}" if v is not None else "")
         lines.append("| " + " | ".join(row) + " |")
     text = "\n".join(lines) + "\n"
     if a.out:
