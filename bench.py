@@ -121,15 +121,14 @@ def measured_traffic(n: int, world: int):
     return None
 
 
-def velocity_bench(args):
-    """Secondary line (not the BASELINE metric): the velocity solve of the same cavity,
-    A = I/dt - c nu L (navierstokes.cpp:342-344) with PBICGSTAB + BLOCK_JACOBI to an absolute residual of 1e-10
-    (examples/navierstokes/taylorgreenvortex3dRe1600_GPU/config/velocity_solver.info), single GPU.  At 512^3 the
-    operator has 2.8e9 non-zeros: the 64-bit row-offset kernels."""
-    import torch
-    assert torch.cuda.is_available()
+def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int) -> dict:
+    """The velocity solve of the same cavity, A = I/dt - c nu L (navierstokes.cpp:342-344) with PBICGSTAB + BLOCK_JACOBI to
+    an absolute residual of 1e-10 (examples/navierstokes/taylorgreenvortex3dRe1600_GPU/config/velocity_solver.info),
+    single GPU.  The Krylov products run matrix-free from the mesh tables (velstencil.hip: 56 B/row -- x read once, y
+    written once, the quotient tables are 1-D -- instead of the CSR's 104); the roofline entry is THAT kernel group, the
+    CSR SpMV of the same operator is reported next to it.  At 512^3 the CSR has 2.8e9 non-zeros (64-bit row offsets)."""
+    from petibm_amd import capi
     from petibm_amd.linsolver import LinSolverHIP
-    n = args.n
     dt, nu = (5e-4, 1e-3) if n == 512 else (1e-3, 1e-3)
     cfg = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
            "solv:convergence=ABSOLUTE\nsolv:tolerance=1e-10\nsolv:norm=L2\nsolv:store_res_history=1\n"
@@ -142,39 +141,127 @@ def velocity_bench(args):
     s.synchronize()
     t_setup = time.perf_counter() - t0
     UN = s.n_local
-    us_d, b_d, x_d = s.deviceVec(), s.deviceVec(), s.deviceVec()
+    us_d, b_d, x_d, r_d = s.deviceVec(), s.deviceVec(), s.deviceVec(), s.deviceVec()
     rng = np.random.default_rng(20260928)
     chunk = 1 << 24
-    from petibm_amd import capi
     for off in range(0, UN, chunk):  # u* uniform in [-1,1), uploaded in pieces
         m = min(chunk, UN - off)
         a = rng.uniform(-1.0, 1.0, m)
         capi.check(capi.load().pib_memcpy_h2d(s._h, us_d.ptr + 8 * off, a.ctypes.data, 8 * m))
     s.matMult(us_d, b_d)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         s.solve(x_d, b_d)
-    torch.cuda.synchronize()
+    s.synchronize()
     t0 = time.perf_counter()
     its = 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         s.solve(x_d, b_d)
         its += s.getIters()
     s.synchronize()
     el = time.perf_counter() - t0
-    ms_spmv = s.timeKernel(0, args.kernel_reps)
+    # residual contract with the CSR operator: |b - A x|_2 <= 1e-10 (absolute, as configured)
+    s.matMult(x_d, r_d)
+    res = 0.0
+    for off in range(0, UN, chunk):
+        m = min(chunk, UN - off)
+        rb, bb = np.empty(m), np.empty(m)
+        capi.check(capi.load().pib_memcpy_d2h(s._h, rb.ctypes.data, r_d.ptr + 8 * off, 8 * m))
+        capi.check(capi.load().pib_memcpy_d2h(s._h, bb.ctypes.data, b_d.ptr + 8 * off, 8 * m))
+        res += float(np.sum((bb - rb) ** 2))
+    ms_free = s.timeKernel(5, kernel_reps)
+    ms_spmv = s.timeKernel(0, max(2, kernel_reps // 4))
     rp_bytes = 8 if s.nnz >= 2 ** 31 - 1 else 4
-    alg = 12.0 * s.nnz + rp_bytes * (UN + 1) + 16.0 * UN
-    print(json.dumps({
-        "metric": "velocity-system DOF/s (BiCGStab+Jacobi to |r| <= 1e-10), secondary line", "value": UN * args.steps / el,
-        "unit": "DOF/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-        "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+    alg_csr = 12.0 * s.nnz + rp_bytes * (UN + 1) + 16.0 * UN
+    alg_free = 16.0 * UN  # x read once, y written once; tables are 1-D (reported apart from the CSR figure)
+    out = {
+        "metric": "velocity-system DOF/s (BiCGStab+Jacobi to |r| <= 1e-10)", "value": UN * steps / el,
+        "unit": "DOF/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps, "dtype": "f64",
         "config": {"workload": f"{n}^3 cavity velocity system A = I/dt - c nu L, {UN} rows, {s.nnz} nnz, "
-                               f"{8 * rp_bytes}-bit row offsets"},
-        "iters_per_solve": its / args.steps, "final_residual": s.getResidual(), "setup_s": t_setup,
-        "roofline": {"bound": "hbm", "kernel": f"pib::k_spmv_lds<int{8 * rp_bytes}>", "achieved": alg / ms_spmv / 1e6,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / ms_spmv / 1e6 / HBM_PEAK_GBS,
-                     "ms_per_launch": ms_spmv, "algorithmic_bytes": alg}}), flush=True)
+                               f"{8 * rp_bytes}-bit row offsets, random u*"},
+        "iters_per_solve": its / steps, "final_residual": s.getResidual(), "true_abs_residual": float(np.sqrt(res)),
+        "setup_s": t_setup,
+        "roofline": {"bound": "hbm", "kernel": "pib::k_vel_interior4<3> + k_vel_shell x 3 components (the products BiCGStab runs)",
+                     "achieved": alg_free / ms_free / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_free / ms_free / 1e6 / HBM_PEAK_GBS, "ms_per_launch": ms_free, "algorithmic_bytes": alg_free,
+                     "traffic": None},
+        "csr_spmv": {"kernel": f"pib::k_spmv_lds<int{8 * rp_bytes}>", "achieved": alg_csr / ms_spmv / 1e6, "unit": "GB/s",
+                     "frac": alg_csr / ms_spmv / 1e6 / HBM_PEAK_GBS, "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_csr}}
     s.destroy()
+    return out
+
+
+def velocity_bench(args):
+    import torch
+    assert torch.cuda.is_available()
+    out = velocity_case(args.n, args.steps, args.warmup, args.kernel_reps)
+    out.update({"n_gpus": 1, "higher_is_better": True, "data": "synthetic"})
+    print(json.dumps(out), flush=True)
+
+
+def random_rhs_solution(n: int, k0: int, k1: int) -> np.ndarray:
+    """x* uniform in [-1, 1), PCG64 seed 20260928, projected to zero mean; slab [k0, k1)"""
+    rng = np.random.default_rng(20260928)
+    x = rng.uniform(-1.0, 1.0, n ** 3)
+    x -= x.mean()
+    return x[k0 * n * n:k1 * n * n]
+
+
+# Algorithmic HBM bytes per row of one multigrid-PCG iteration as this build runs it (DESIGN.md 3), fp64 / int32:
+#   CSR SpMV 104 (12 nnz/n + 4 + 16) ; p = z + beta p 24 ; x += a p, r -= a w + sums 48 ;
+#   V(2,2) cycle on the fine level: two pre-smoothing steps from zero 16 (b read, x written), residual 24, restriction
+#   8 + 1, prolongation + first post-smoothing step 24 + 1, second post-smoothing step (+ the Krylov sums) 24 = 98,
+#   times 8/7 for the coarser levels = 112.            Sum: 288 B per row and iteration.
+def solve_bytes_per_row_iter(pre: int, post: int, nnz_per_row: float) -> float:
+    spmv = 12.0 * nnz_per_row + 4.0 + 16.0
+    down = (16.0 if pre >= 2 else 8.0 + 8.0) + 24.0 * max(pre - 2, 0) + 24.0 + 9.0
+    up = (25.0 if post >= 1 else 17.0) + 24.0 * max(post - 1, 0)
+    return spmv + 24.0 + 48.0 + (down + up) * 8.0 / 7.0
+
+
+def poisson_case(n: int, dt: float, cfg_text: str, rhs: str, steps: int, warmup: int, kernel_reps: int, which_kernel: int = 0):
+    """One single-GPU Poisson line: assemble, b = A x*, `steps` timed solves, residual contract with the CSR operator."""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    s = LinSolverHIP("poisson", config_text=cfg_text)
+    w = np.full(n, 1.0 / n)
+    s.assemblePoisson((n, n, n), [w, w, w], dt, capi.NULLSPACE_CONSTANT)
+    xs_d, b_d, x_d, r_d = s.deviceVec(), s.deviceVec(), s.deviceVec(), s.deviceVec()
+    xs_d.upload(manufactured_solution(n, 0, n) if rhs == "cosine" else random_rhs_solution(n, 0, n))
+    s.matMult(xs_d, b_d)
+    for _ in range(warmup):
+        s.solve(x_d, b_d)
+    s.synchronize()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(steps):
+        s.solve(x_d, b_d)
+        its += s.getIters()
+    s.synchronize()
+    el = time.perf_counter() - t0
+    s.matMult(x_d, r_d)
+    bl = b_d.download()
+    rl = bl - r_d.download()
+    rel = float(np.sqrt((rl @ rl) / (bl @ bl)))
+    ms_k = s.timeKernel(which_kernel, kernel_reps)
+    out = {"value": n ** 3 * steps / el, "unit": "DOF/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
+           "iters_per_solve": its / steps, "true_rel_residual": rel, "grid": [n, n, n], "dt": dt, "rhs": rhs}
+    nnz, nl = s.nnz, s.n_local
+    s.destroy()
+    return out, ms_k, nnz, nl
+
+
+def secondary_poisson(n, dt, cfg_text, rhs, which_kernel, args) -> dict:
+    out, ms_k, nnz, nl = poisson_case(n, dt, cfg_text, rhs, 2, 1, args.kernel_reps, which_kernel)
+    if which_kernel == 0:
+        alg = 12.0 * nnz + 4.0 * (nl + 1) + 16.0 * nl
+        kname = "pib::k_spmv_lds<int32> (CSR SpMV)"
+    else:
+        alg = 16.0 * nl + 8.0 * 3 * n  # SURVEY.md 8d B_stencil: x read once, y written once, the 1-D width arrays
+        kname = "pib::k_level<0,4> (matrix-free stencil twin, reported apart from the CSR figure)"
+    out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": alg / ms_k / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": alg / ms_k / 1e6 / HBM_PEAK_GBS, "ms_per_launch": ms_k, "algorithmic_bytes": alg, "traffic": None}
+    out["metric"] = "Poisson DOF/s (one pressure solve to rel. residual 1e-10)"
+    return out
 
 
 def refuse(args, why: str) -> int:
@@ -221,6 +308,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-10)
     ap.add_argument("--max-iters", type=int, default=20000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (random RHS, 256^3, stencil twin, velocity)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--omega", type=float, default=0.9, help="Jacobi smoother relaxation factor of the V-cycle")
     ap.add_argument("--smoother", default="jacobi", choices=["jacobi", "chebyshev"])
@@ -362,8 +450,19 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world),
                          "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes},
-            "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "host_polls": int(counters[4])},
+            "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "reductions": int(counters[2]),
+                         "halo_exchanges": int(counters[3]), "host_polls": int(counters[4]),
+                         "comm_ranks": int(counters[5])},  # ncclCommCount of the solver's communicator (1: none)
         }
+        if args.pc == "gmg" and world == 1:
+            # the whole solve against the roofline: algorithmic bytes of every kernel of an iteration (model in
+            # solve_bytes_per_row_iter; the initial residual + V-cycle count as one more iteration) / the measured time
+            bpr = solve_bytes_per_row_iter(args.presweeps, args.postsweeps, nnz_l / n_l)
+            per_solve = iters / args.steps + 1.0
+            gbs = bpr * n_l * per_solve / (elapsed / args.steps) / 1e9
+            out["roofline_solve"] = {"bound": "hbm", "bytes_per_row_per_iteration": bpr, "iterations_counted": per_solve,
+                                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                     "ms_per_iteration": 1e3 * elapsed / args.steps / per_solve}
         def finite(o):  # NaN is not JSON
             if isinstance(o, dict):
                 return {k: finite(v) for k, v in o.items()}
@@ -379,11 +478,27 @@ def main():
                 notes.append(f"cpu baseline failed: {e}")
         if notes:
             out["notes"] = notes
+    s.destroy()
+    if rank == 0 and world == 1 and not args.no_secondary and n == 512 and args.pc == "gmg":
+        # the other lines SURVEY.md 8d asks for, each with its own residual check; failures are notes, never the headline
+        base_cfg = solver_config(args.pc, args.tol, args.max_iters, args.omega, args.presweeps, args.postsweeps, args.smoother)
+        out["secondary"] = []
+        for name, fn in (("random_rhs_512", lambda: secondary_poisson(512, 5e-4, base_cfg, "random", 0, args)),
+                         ("config2_256_cubed", lambda: secondary_poisson(256, 1e-3, base_cfg, "cosine", 0, args)),
+                         ("stencil_twin_products_512", lambda: secondary_poisson(512, 5e-4, base_cfg + "pib_matrix_free_poisson=1\n",
+                                                                                 "cosine", 3, args)),
+                         ("velocity_256_cubed", lambda: velocity_case(256, 2, 1, args.kernel_reps))):
+            try:
+                entry = fn()
+                entry["name"] = name
+                out["secondary"].append(entry)
+            except Exception as exc:  # noqa: BLE001
+                out.setdefault("notes", []).append(f"secondary line {name} failed: {exc}")
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    s.destroy()
 
 
 if __name__ == "__main__":

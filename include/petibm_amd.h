@@ -340,10 +340,11 @@ int pib_ns_get_ib_operator(pib_ns *ns, int which, int64_t *n_rows, int64_t *nnz,
  * Time `reps` launches of kernel `which` on the solver's stream with HIP events
  * (events recorded on that stream); *ms_avg = average launch duration.
  * which: 0 = CSR SpMV (K1), 1 = fused CG vector update, 2 = dot,
- *        3 = matrix-free stencil apply (K2), 4 = GMG V-cycle. */
+ *        3 = matrix-free stencil product (K2), 4 = GMG V-cycle,
+ *        5 = matrix-free product of the velocity operator (the kernels BiCGStab runs after pib_assemble_velocity). */
 int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_avg);
 /* Counters of the last solve: [0]=spmv launches, [1]=pc applies, [2]=reductions,
- * [3]=halo exchanges, [4]=host syncs. */
+ * [3]=halo exchanges (all-gathers included), [4]=host syncs, [5]=ranks of the communicator (ncclCommCount). */
 int pib_get_counters(pib_solver *s, int64_t counters[8]);
 
 #ifdef __cplusplus

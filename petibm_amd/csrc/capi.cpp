@@ -463,6 +463,13 @@ int pib_get_counters(pib_solver *s, int64_t counters[8])
 {
     if (s == nullptr || counters == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
     for (int k = 0; k < 8; ++k) counters[k] = s->counters[k];
+    counters[5] = 1;  // ranks of the communicator as the transport reports them
+    if (s->comm.comm) {
+        int cnt = 0;
+        PIB_NCCL(ncclCommCount(s->comm.comm, &cnt));
+        counters[5] = cnt;
+    } else if (s->comm.nranks > 1)
+        counters[5] = s->comm.nranks;
     return 0;
 }
 

@@ -1214,7 +1214,15 @@ extern "C" int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_av
                     PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, false, q));
                     break;
                 }
+                case 3:  // the Krylov product of the stencil twin (K2, 16 B/row)
+                    if (!s->has_grid || s->levels.empty() || s->comm.nranks != 1) return fail(PIB_ERR_ORDER, "pib_time_kernel: no grid structure");
+                    PIB_CHK(stencil_matmult(s, P, W, nullptr, false, q));
+                    break;
                 case 4: PIB_CHK(gmg_apply(s, R, Z, q)); break;
+                case 5:  // the matrix-free product of the velocity operator (velstencil.hip, 56 B/row)
+                    if (!s->vel.valid) return fail(PIB_ERR_ORDER, "pib_time_kernel: no velocity-operator structure");
+                    PIB_CHK(vel_stencil_apply(s, P, W, false, q));
+                    break;
                 default: return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_time_kernel: unknown kernel %d", which);
             }
         }
