@@ -4,13 +4,13 @@
 import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
-from oracle import mesh as omesh   # mesh-config helper only
+from petibm_amd import cases
 from petibm_amd.navierstokes import NavierStokesSolver
 
 re = int(sys.argv[1]) if len(sys.argv) > 1 else 3200
 nu, nt = {3200: (0.0003125, 25000), 5000: (0.0002, 60000)}[re]
 n = 192
-cfg = omesh.uniform_config((n, n), lid=1.0)
+cfg = cases.cavity((n, n), lid=1.0)
 cfg["flow"]["nu"] = nu
 cfg["parameters"] = {"dt": 0.002, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
 vel = "-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n-velocity_pc_type jacobi\n"

@@ -1,14 +1,14 @@
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
-from oracle import mesh as omesh
+from petibm_amd import cases
 from petibm_amd.navierstokes import NavierStokesSolver
 vel = "-velocity_ksp_type bcgs\n-velocity_ksp_rtol 1.0E-08\n-velocity_ksp_atol 0.0\n-velocity_ksp_max_it 10000\n-velocity_pc_type jacobi\n"
 poi = "-poisson_ksp_type cg\n-poisson_ksp_rtol 1.0E-08\n-poisson_ksp_atol 0.0\n-poisson_ksp_max_it 20000\n-poisson_pc_type gamg\n"
 sol = {}
 t0 = time.perf_counter()
 for n in (20, 60, 180, 540):
-    cfg = omesh.uniform_config((n, n), lid=1.0)
+    cfg = cases.cavity((n, n), lid=1.0)
     cfg["flow"]["nu"] = 0.01
     cfg["parameters"] = {"dt": 5.0e-4, "convection": "EULER_EXPLICIT", "diffusion": "EULER_IMPLICIT"}
     s = NavierStokesSolver(cfg, velocity_cfg=vel, poisson_cfg=poi)

@@ -1,14 +1,14 @@
 import sys, json, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
-from oracle import mesh as omesh
+from petibm_amd import cases
 from petibm_amd.navierstokes import DecoupledIBPMSolver
 from test_gpu_ibm import flow_config, AMGX_P, FORCES
-from test_oracle_ibm import circle
+from petibm_amd.cases import circle
 G = json.load(open("tests/golden/reference_test_vectors.json"))
 sub = [{"end": -0.52, "cells": 363, "stretchRatio": 0.9900990099}, {"end": 0.52, "cells": 260, "stretchRatio": 1.0},
        {"end": 15.0, "cells": 363, "stretchRatio": 1.01}]
-base = omesh.uniform_config((986, 986))
+base = cases.cavity((986, 986))
 base["mesh"] = [{"direction": d, "start": -15.0, "subDomains": sub} for d in "xy"]
 cfg = flow_config(base, nu=0.00033333333333, dt=0.001)
 vel = "-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n-velocity_pc_type jacobi\n"

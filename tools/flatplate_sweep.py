@@ -5,7 +5,7 @@ import json, math, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from oracle import mesh as omesh  # mesh-config helper only
+from petibm_amd import cases
 from petibm_amd.navierstokes import DecoupledIBPMSolver
 from test_gpu_ibm import AMGX_P, FORCES, flow_config
 
@@ -22,7 +22,7 @@ vel = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:moni
 print(" AoA    C_D     C_L   | Taira et al.: C_D     C_L   | wall s")
 total = 0.0
 for aoa in range(0, 91, 10):
-    base = omesh.uniform_config((127, 56, 84))
+    base = cases.cavity((127, 56, 84))
     base["mesh"] = [{"direction": "x", "start": -4.0, "subDomains": sub(43, 30, 54, -0.5, 0.7, 6.1, 0.970873786407767, 1.03)},
                     {"direction": "y", "start": -5.0, "subDomains": sub(13, 30, 13, -0.6, 0.6, 5.0, 0.7692307692307692, 1.3)},
                     {"direction": "z", "start": -5.0, "subDomains": sub(12, 60, 12, -1.2, 1.2, 5.0, 0.7692307692307692, 1.3)}]

@@ -4,10 +4,10 @@ import json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from oracle import mesh as omesh  # mesh-config helper only
+from petibm_amd import cases
 from petibm_amd.navierstokes import IBPMSolver
 from test_gpu_ibm import AMGX_P, FORCES, flow_config
-from test_oracle_ibm import circle
+from petibm_amd.cases import circle
 
 re = int(sys.argv[1]) if len(sys.argv) > 1 else 550
 case = {40: dict(sub=[(-0.6, 69, 0.952380952), (0.6, 48, 1.0), (15.0, 69, 1.05)], nu=0.025, dt=0.01, nt=2000, npts=158, every=200),
@@ -15,7 +15,7 @@ case = {40: dict(sub=[(-0.6, 69, 0.952380952), (0.6, 48, 1.0), (15.0, 69, 1.05)]
         3000: dict(sub=[(-0.52, 363, 0.9900990099), (0.52, 260, 1.0), (15.0, 363, 1.01)], nu=0.00033333333333, dt=0.001, nt=3000, npts=786, every=250)}[re]
 sub = [{"end": e, "cells": c, "stretchRatio": r} for e, c, r in case["sub"]]
 n = sum(c for _, c, _ in case["sub"])
-base = omesh.uniform_config((n, n))
+base = cases.cavity((n, n))
 base["mesh"] = [{"direction": d, "start": -15.0, "subDomains": sub} for d in "xy"]
 cfg = flow_config(base, nu=case["nu"], dt=case["dt"])
 vel = "-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n-velocity_pc_type jacobi\n"

@@ -1,13 +1,13 @@
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch
-from oracle import mesh as omesh
+from petibm_amd import cases
 from petibm_amd.navierstokes import NavierStokesSolver, DecoupledIBPMSolver
-from test_oracle_ibm import circle, body_mesh
+from petibm_amd.cases import circle, body_block as body_mesh
 from test_gpu_ibm import flow_config, FORCES
 def free():
     torch.cuda.synchronize(); return torch.cuda.mem_get_info()[0]
-cfgp = omesh.periodic_config((64, 64, 64), (True, True, True)); cfgp["flow"]["nu"] = 0.01
+cfgp = cases.periodic_box((64, 64, 64), (True, True, True)); cfgp["flow"]["nu"] = 0.01
 cfgp["parameters"] = {"dt": 0.01, "BN": 2}
 cfgi = flow_config(body_mesh(cells=(8, 16, 8), ratio=1.25, span=3.0, core=0.8), dt=0.01)
 cfgi["parameters"].update(convection="EULER_EXPLICIT", diffusion="EULER_IMPLICIT")
