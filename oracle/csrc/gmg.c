@@ -17,7 +17,8 @@
  *   - grid (nx, ny, nz) in natural ordering, 2-D grids are stored as
  *     (nx, 1, ny) so the slab axis is always the last one;
  *   - level operator: rediscretised finite-volume 7-point operator
- *       (A x)_c = sum_faces coef_f (x_nb - x_c),  coef = area_perp * g_d[s],
+ *       (A x)_c = sum_faces coef_f (x_nb - x_c),  coef = area_perp * g_d[s]   (evaluated through the volume-scaled rows:
+ *       see face_coefs below),
  *       g_d[s] = dt / (0.5 (w_d[s] + w_d[s+1]))      (the DBNG of
  *       applications/navierstokes/navierstokes.cpp:349-356 for BN order 1);
  *   - selective coarsening per direction: walking the cells of a direction, two neighbours are merged only if
@@ -48,6 +49,7 @@ typedef struct {
     i64 N;
     double *w[3]; /* widths, n[d] */
     double *g[3]; /* face factors incl. dt, n[d]-1 (+ the wrap face n[d]-1 <-> 0 at index n[d]-1 when periodic) */
+    double *cm[3], *cp[3], *rw[3]; /* volume-scaled rows: g[s-1] / w[s], g[s] / w[s] (0 at a wall), 1 / w[s] */
     int per[3];   /* periodic direction: the level operator wraps */
     int tper[3];  /* ... and so do the transfers TOWARDS THE NEXT COARSER level (needs >= 4 cells: the four fine cells a
                      coarse cell gathers from must be distinct) */
@@ -76,19 +78,24 @@ static void shift_vec(i64 n, double *a, double m);
 
 static inline i64 idx(const level_t *l, i64 i, i64 j, i64 k) { return i + l->n[0] * (j + l->n[1] * k); }
 
-/* diagonal of the level operator at (i,j,k): -(sum of face coefficients) */
+/* The rows of the level operator DIVIDED BY THE CELL VOLUME: towards +d of cell s the coefficient (w_a w_b) g_d[s]
+ * becomes g_d[s] / w_d[s], a function of one index -- the tables cm / cp made by make_g (0 at a wall, the wrap face on a
+ * periodic direction).  Jacobi uses D^-1 (b - A x), which a row scaling leaves unchanged, so the smoothers work on the
+ * scaled row (t, d, b / volume); the residual and the operator multiply the volume back in.  Same expressions, same
+ * order as petibm_amd/csrc/gmg.hip ("level operator"). */
 static inline void face_coefs(const level_t *l, i64 i, i64 j, i64 k, double c[6])
 {
-    const double ax = l->w[1][j] * l->w[2][k], ay = l->w[0][i] * l->w[2][k], az = l->w[0][i] * l->w[1][j];
-    c[0] = (i > 0) ? ax * l->g[0][i - 1] : (l->per[0] ? ax * l->g[0][l->n[0] - 1] : 0.0);
-    c[1] = (i < l->n[0] - 1 || l->per[0]) ? ax * l->g[0][i] : 0.0;
-    c[2] = (j > 0) ? ay * l->g[1][j - 1] : (l->per[1] ? ay * l->g[1][l->n[1] - 1] : 0.0);
-    c[3] = (j < l->n[1] - 1 || l->per[1]) ? ay * l->g[1][j] : 0.0;
-    c[4] = (k > 0) ? az * l->g[2][k - 1] : (l->per[2] ? az * l->g[2][l->n[2] - 1] : 0.0);
-    c[5] = (k < l->n[2] - 1 || l->per[2]) ? az * l->g[2][k] : 0.0;
+    c[0] = l->cm[0][i];
+    c[1] = l->cp[0][i];
+    c[2] = l->cm[1][j];
+    c[3] = l->cp[1][j];
+    c[4] = l->cm[2][k];
+    c[5] = l->cp[2][k];
 }
+static inline double cell_rvol(const level_t *l, i64 i, i64 j, i64 k) { return (l->rw[0][i] * l->rw[1][j]) * l->rw[2][k]; }
+static inline double unscale(const level_t *l, i64 i, i64 j, i64 k, double t) { return (t * (l->w[0][i] * l->w[1][j])) * l->w[2][k]; }
 
-/* y = A x at one cell, and the diagonal */
+/* the scaled row sum t = sum_faces c (x_nb - x_c) at one cell, and the scaled diagonal */
 static inline double apply_cell(const level_t *l, const double *x, i64 i, i64 j, i64 k, double *diag)
 {
     double c[6];
@@ -114,7 +121,7 @@ static inline double apply_cell(const level_t *l, const double *x, i64 i, i64 j,
 
 static void lvl_free(level_t *l)
 {
-    for (int d = 0; d < 3; ++d) { free(l->w[d]); free(l->g[d]); free(l->par[d]); free(l->oth[d]); free(l->wpar[d]); free(l->woth[d]); free(l->fst[d]); }
+    for (int d = 0; d < 3; ++d) { free(l->w[d]); free(l->g[d]); free(l->cm[d]); free(l->cp[d]); free(l->rw[d]); free(l->par[d]); free(l->oth[d]); free(l->wpar[d]); free(l->woth[d]); free(l->fst[d]); }
     free(l->x); free(l->x2); free(l->b); free(l->r);
 }
 
@@ -132,6 +139,18 @@ static void make_g(level_t *l, double dt)
             const double dl = 0.5 * (l->w[d][0] + l->w[d][n - 1]);
             const double v = 1.0 / dl;
             l->g[d][n - 1] = dt * v;
+        }
+        l->cm[d] = calloc((size_t)(n > 1 ? n : 1), sizeof(double));
+        l->cp[d] = calloc((size_t)(n > 1 ? n : 1), sizeof(double));
+        l->rw[d] = malloc(sizeof(double) * (size_t)(n > 1 ? n : 1));
+        for (i64 s = 0; s < n; ++s) {
+            const double wq = l->w[d][s];
+            l->rw[d][s] = 1.0 / wq;
+            if (n > 1) {
+                if (s > 0) l->cm[d][s] = l->g[d][s - 1] / wq;
+                else if (l->per[d]) l->cm[d][s] = l->g[d][n - 1] / wq;
+                if (s < n - 1 || l->per[d]) l->cp[d][s] = l->g[d][s] / wq;
+            }
         }
     }
 }
@@ -266,7 +285,7 @@ void orc_gmg_apply_operator(void *h, int lev, const double *x, double *y)
         for (i64 j = 0; j < l->n[1]; ++j)
             for (i64 i = 0; i < l->n[0]; ++i) {
                 double d;
-                y[idx(l, i, j, k)] = apply_cell(l, x, i, j, k, &d);
+                y[idx(l, i, j, k)] = unscale(l, i, j, k, apply_cell(l, x, i, j, k, &d));
             }
 }
 
@@ -283,10 +302,10 @@ static void smooth(const level_t *l, double omega, const double *b, const double
                     double c[6];
                     face_coefs(l, i, j, k, c);
                     d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-                    xo[p] = omega * (b[p] / d);
+                    xo[p] = omega * ((b[p] * cell_rvol(l, i, j, k)) / d);
                 } else {
                     const double ax = apply_cell(l, xi, i, j, k, &d);
-                    xo[p] = xi[p] + omega * ((b[p] - ax) / d);
+                    xo[p] = xi[p] + omega * (((b[p] * cell_rvol(l, i, j, k)) - ax) / d);
                 }
             }
 }
@@ -299,7 +318,7 @@ static void residual(const level_t *l, const double *b, const double *x, double 
             for (i64 i = 0; i < l->n[0]; ++i) {
                 double d;
                 const i64 p = idx(l, i, j, k);
-                r[p] = b[p] - apply_cell(l, x, i, j, k, &d);
+                r[p] = b[p] - unscale(l, i, j, k, apply_cell(l, x, i, j, k, &d));
             }
 }
 
@@ -395,12 +414,12 @@ static double *cheby(gmg_t *G, level_t *l, int lev, int deg, const double *b, do
                         double c[6];
                         face_coefs(l, i, j, k, c);
                         dg = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-                        z = b[p] / dg;
+                        z = (b[p] * cell_rvol(l, i, j, k)) / dg;
                         d[p] = a_z * z;
                         nxt[p] = d[p];
                     } else {
                         const double ax = apply_cell(l, cur, i, j, k, &dg);
-                        z = (b[p] - ax) / dg;
+                        z = ((b[p] * cell_rvol(l, i, j, k)) - ax) / dg;
                         const double dn = a_d * d[p] + a_z * z;
                         d[p] = dn;
                         nxt[p] = cur[p] + dn;

@@ -85,8 +85,8 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
     // +4 entries of padding: the SpMV reads val/col in aligned pairs
     PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
     PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));
-    PIB_HIP(hipMemset(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4)));
-    PIB_HIP(hipMemset(A.val, 0, sizeof(double) * (size_t)(nnz + 4)));
+    PIB_MEMSET(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4));
+    PIB_MEMSET(A.val, 0, sizeof(double) * (size_t)(nnz + 4));
     PIB_HIP(hipMemcpy(A.col, c32.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
     PIB_HIP(hipMemcpy(A.val, val + base, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     if (A.rp64) {
@@ -120,12 +120,17 @@ int adopt_device_csr(pib_solver *s, int64_t n, int64_t nnz, const int32_t *rowpt
     A.rp64 = false;
     PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
     PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));
-    PIB_HIP(hipMemset(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4)));
-    PIB_HIP(hipMemset(A.val, 0, sizeof(double) * (size_t)(nnz + 4)));
+    PIB_MEMSET(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4));
+    PIB_MEMSET(A.val, 0, sizeof(double) * (size_t)(nnz + 4));
     PIB_HIP(hipMalloc(&A.rowptr, sizeof(int32_t) * ((size_t)n + 1)));
-    PIB_HIP(hipMemcpy(A.col, col, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice));
-    PIB_HIP(hipMemcpy(A.val, val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice));
-    PIB_HIP(hipMemcpy(A.rowptr, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToDevice));
+    // on the solver's own stream: a device-to-device hipMemcpy on the null stream may return before the copy has run,
+    // and the non-blocking streams do not wait for the null stream (the caller has synchronised the producer of the source)
+    PIB_HIP(hipMemsetAsync(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4), s->stream));
+    PIB_HIP(hipMemsetAsync(A.val, 0, sizeof(double) * (size_t)(nnz + 4), s->stream));
+    PIB_HIP(hipMemcpyAsync(A.col, col, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, s->stream));
+    PIB_HIP(hipMemcpyAsync(A.val, val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, s->stream));
+    PIB_HIP(hipMemcpyAsync(A.rowptr, rowptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToDevice, s->stream));
+    PIB_HIP(hipStreamSynchronize(s->stream));
     return after_set_matrix(s);
 }
 

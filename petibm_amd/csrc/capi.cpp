@@ -34,11 +34,11 @@ static int make_solver(pib_solver **out, const char *name, const Config &cfg, co
     PIB_HIP(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
     PIB_HIP(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
     PIB_HIP(hipMalloc(&s->d_s, sizeof(Scalars)));
-    PIB_HIP(hipMemset(s->d_s, 0, sizeof(Scalars)));
+    PIB_MEMSET(s->d_s, 0, sizeof(Scalars));
     PIB_HIP(hipHostMalloc(&s->h_s, sizeof(Scalars)));
     std::memset(s->h_s, 0, sizeof(Scalars));
     PIB_HIP(hipMalloc(&s->d_part, sizeof(double) * PIB_NRED * PIB_MAXPART));
-    PIB_HIP(hipMemset(s->d_part, 0, sizeof(double) * PIB_NRED * PIB_MAXPART));
+    PIB_MEMSET(s->d_part, 0, sizeof(double) * PIB_NRED * PIB_MAXPART);
     int err = comm_init(s, rank, nranks, uid);
     if (err) {
         pib_destroy(s);

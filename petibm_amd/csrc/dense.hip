@@ -118,7 +118,7 @@ void dense_release(pib_solver *s)
 
 int dense_setup(pib_solver *s)
 {
-    if (s->comm.nranks > 1) return fail(PIB_ERR_SUP, "solver %s: the direct solver is single-rank", s->name.c_str());
+    if (s->comm.nranks > 1) return fail(PIB_ERR_SUP, "solver %s: the direct solver is single-rank (replicated)", s->name.c_str());
     const DeviceCsr &A = s->A;
     const int64_t n = A.n;
     if (n > DENSE_MAX_ROWS)
@@ -148,11 +148,21 @@ int dense_setup(pib_solver *s)
         hipLaunchKernelGGL(k_dense_fill<int64_t>, dim3(gb), dim3(256), 0, q, n, (const int64_t *)A.rowptr, A.col, A.val, M);
     else
         hipLaunchKernelGGL(k_dense_fill<int32_t>, dim3(gb), dim3(256), 0, q, n, (const int32_t *)A.rowptr, A.col, A.val, M);
+    // every rank holds partial sums of the entries: the full matrix on all of them (the inverse is replicated)
+    if (s->reduce_via != nullptr) PIB_CHK(comm_allreduce_big(s->reduce_via, M, n * n, q));
     hipLaunchKernelGGL(k_dense_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, n, s->dense_inv);
     double *maxdiag = reinterpret_cast<double *>(s->dense_bad) + 1;
     hipLaunchKernelGGL(k_dense_maxdiag, dim3(1), dim3(256), 0, q, n, M, maxdiag);
     PIB_HIP(hipGetLastError());
-    // the n elimination launches as one hipGraph (their arguments are fixed for a given order n and buffers)
+    // the n elimination launches as one hipGraph (their arguments are fixed for a given order n and buffers).  Not under
+    // the test-only loopback transport: its ranks are threads of one process, and capturing / replaying graphs from
+    // several threads at once proved unreliable in the HIP runtime (sporadic garbage in the eliminated matrix)
+    if (s->reduce_via != nullptr && s->reduce_via->comm.loop != nullptr) {
+        for (int64_t k = 0; k < n; ++k)
+            hipLaunchKernelGGL(k_gj_step, dim3((unsigned)n), dim3(256), 0, q, n, k, M, s->dense_inv, s->dense_bad, maxdiag);
+        hipLaunchKernelGGL(k_gj_scale, dim3((unsigned)n), dim3(256), 0, q, n, M, s->dense_inv, s->dense_bad);
+        PIB_HIP(hipGetLastError());
+    } else {
     if (s->dense_graph == nullptr) {
         hipGraph_t g = nullptr;
         PIB_HIP(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
@@ -169,6 +179,7 @@ int dense_setup(pib_solver *s)
         }
     }
     PIB_HIP(hipGraphLaunch(s->dense_graph, q));
+    }
     int hbad = 0;
     PIB_HIP(hipMemcpyAsync(&hbad, s->dense_bad, sizeof(int), hipMemcpyDeviceToHost, q));
     PIB_HIP(hipStreamSynchronize(q));

@@ -51,24 +51,38 @@ struct LevelDev {
     int tper;         // ... and the transfers towards the next coarser level reach across the seam
     int zring;        // distributed level of a periodic slab axis: the z wrap goes through the halo planes (+-plane)
     const double *wx, *wy, *wz, *gx, *gy, *gz;
+    // volume-scaled rows (see "level operator" below): coefficient towards -d / +d of cell s, and 1 / width
+    const double *cmx, *cpx, *rwx, *cmy, *cpy, *rwy, *cmz, *cpz, *rwz;
     Tr1 t[3];         // x, y, z tables (null on the coarsest level)
     TrX tx;
 };
 
+// ---- level operator --------------------------------------------------------------------------------------------
+// Row (i,j,k) of the level's finite-volume operator has the face coefficient (w_a w_b) g_d[s] towards +d.  Divided by
+// the cell volume w_x w_y w_z it becomes g_d[s] / w_d[s]: a function of ONE index, tabulated per level as
+//     cm_d[s] (towards -d), cp_d[s] (towards +d)            -- zero at a wall, the wrap face on a periodic direction --
+// and the diagonal is -(sum of the six).  Jacobi only ever uses D^-1 (b - A x), which a row scaling leaves unchanged, so
+// every smoothing kernel works with the scaled row
+//     t = sum_faces c (x_nb - x_c),   d = -(((((cxm + cxp) + cym) + cyp) + czm) + czp),   bs = (b (1/wx 1/wy)) 1/wz,
+//     x' = x + omega (bs - t) / d
+// -- no per-cell coefficient products, no boundary branches (a missing neighbour is a zero coefficient times a value
+// that is 0 or the centre's own) -- and only the residual and the operator itself multiply the volume back in:
+//     r = b - (t (wx wy)) wz.
+// The expressions and their order are the same in every kernel below and in the oracle (oracle/csrc/gmg.c): fused and
+// unfused, tiled and streaming forms give the same bits.  tools/vcycle_lab.hip: 0.76 -> 0.61 ms per 512^3 Jacobi step.
 __device__ __forceinline__ void face_coefs(const LevelDev &L, int i, int j, int k, double c[6])
 {
-    const double wxi = L.wx[i], wyj = L.wy[j], wzk = L.wz[k];
-    const double ax = wyj * wzk, ay = wxi * wzk, az = wxi * wyj;
-    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
-    c[0] = (i > 0) ? ax * L.gx[i - 1] : (px ? ax * L.gx[L.nx - 1] : 0.0);
-    c[1] = (i < L.nx - 1 || px) ? ax * L.gx[i] : 0.0;
-    c[2] = (j > 0) ? ay * L.gy[j - 1] : (py ? ay * L.gy[L.ny - 1] : 0.0);
-    c[3] = (j < L.ny - 1 || py) ? ay * L.gy[j] : 0.0;
-    c[4] = (k > 0) ? az * L.gz[k - 1] : (pz ? az * L.gz[L.nzg - 1] : 0.0);
-    c[5] = (k < L.nzg - 1 || pz) ? az * L.gz[k] : 0.0;
+    c[0] = L.cmx[i];
+    c[1] = L.cpx[i];
+    c[2] = L.cmy[j];
+    c[3] = L.cpy[j];
+    c[4] = L.cmz[k];
+    c[5] = L.cpz[k];
 }
+__device__ __forceinline__ double cell_rvol(const LevelDev &L, int i, int j, int k) { return (L.rwx[i] * L.rwy[j]) * L.rwz[k]; }
+__device__ __forceinline__ double unscale(const LevelDev &L, int i, int j, int k, double t) { return (t * (L.wx[i] * L.wy[j])) * L.wz[k]; }
 
-// (A x) at local cell p (x points at the first OWNED plane; halo planes sit at -plane and +nk*plane)
+// the scaled row sum t at local cell p (x points at the first OWNED plane; halo planes sit at -plane and +nk*plane)
 __device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__restrict__ x, int64_t p, int i, int j,
                                              int k, double *diag)
 {
@@ -138,9 +152,8 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
     const int64_t plane = (int64_t)L.nx * L.ny;
     const int kk = blockIdx.y;
     const int k = L.k0 + kk;
-    const double wzk = L.wz[k];
+    const double wzk = L.wz[k], rwz = L.rwz[k], czm = L.cmz[k], czp = L.cpz[k];
     const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
-    const double gzm = (k > 0) ? L.gz[k - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (k < L.nzg - 1 || pz) ? L.gz[k] : 0.0;
     // Workgroup b runs on XCD b % 8.  With the plain order the two grid lines of a workgroup have their +-y neighbours
     // in the workgroups of OTHER XCDs, so every L2 fetched x twice (PMC: 3.22 GB read per 512^3 sweep for 2.15 GB
     // of b and x).  Dealing each XCD a contiguous band of the plane leaves 8 band edges per plane instead.
@@ -154,9 +167,7 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
         const int i0 = (int)(q - (unsigned)j * nxc) * C;
         if (j_uniform) j = __builtin_amdgcn_readfirstlane(j);
         const int64_t p = (int64_t)kk * plane + (int64_t)j * L.nx + i0;
-        const double wyj = L.wy[j];
-        const double gym = (j > 0) ? L.gy[j - 1] : (py ? L.gy[L.ny - 1] : 0.0), gyp = (j < L.ny - 1 || py) ? L.gy[j] : 0.0;
-        const double ax = wyj * wzk;
+        const double wyj = L.wy[j], rwy = L.rwy[j], cym = L.cmy[j], cyp = L.cpy[j];
         vt xc, bv, ym, yp, zm, zp, out;
         double xl = 0.0, xr = 0.0;
         vt dv;
@@ -183,41 +194,41 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             if (MODE == 8) braw = bv;
             if (pin_sum != nullptr && p == 0 && L.k0 == 0) bv[0] = bv[0] - *pin_sum;
         }
-        double gxm = (i0 > 0) ? L.gx[i0 - 1] : (px ? L.gx[L.nx - 1] : 0.0);
-        const vt wxv = *reinterpret_cast<const vt *>(L.wx + i0);
-        const vt gxv = *reinterpret_cast<const vt *>(L.gx + i0);  // gx is padded: entry nx-1 exists (the wrap face when periodic)
+        // the 1-D tables are padded: aligned vectors of C entries may be read at any i0
+        const vt cxmv = *reinterpret_cast<const vt *>(L.cmx + i0), cxpv = *reinterpret_cast<const vt *>(L.cpx + i0);
+        const vt rwxv = *reinterpret_cast<const vt *>(L.rwx + i0);
+        vt wxv;
+        if (MODE == 0 || MODE == 3) wxv = *reinterpret_cast<const vt *>(L.wx + i0);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const int i = i0 + c;
-            const double wxi = wxv[c];
-            const double gxp = (i < L.nx - 1 || px) ? gxv[c] : 0.0;
-            const double ay = wxi * wzk, az = wxi * wyj;
-            const double c0 = ax * gxm, c1 = ax * gxp, c2 = ay * gym, c3 = ay * gyp, c4 = az * gzm, c5 = az * gzp;
-            gxm = gxp;
-            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
+            const double cxm = cxmv[c], cxp = cxpv[c];
+            const double d = -(((((cxm + cxp) + cym) + cyp) + czm) + czp);
+            double bs = 0.0;
+            if (MODE != 0) bs = (bv[c] * (rwxv[c] * rwy)) * rwz;
             if (MODE == 1) {
-                out[c] = omega * (bv[c] / d);
+                out[c] = omega * (bs / d);
                 continue;
             }
             if (MODE == 6) {
-                out[c] = omega * (bv[c] / d);
+                out[c] = omega * (bs / d);
                 dv[c] = out[c];
                 continue;
             }
             const double left = (c == 0) ? xl : xc[c > 0 ? c - 1 : 0];
             const double right = (c == C - 1) ? xr : xc[c < C - 1 ? c + 1 : 0];
             const double xcc = xc[c];
+            // a missing neighbour: zero coefficient, and the value is 0 (xl, xr) or the centre's own (ym .. zp)
             double s = 0.0;
-            if (i > 0 || px) s += c0 * (left - xcc);
-            if (i < L.nx - 1 || px) s += c1 * (right - xcc);
-            if (j > 0 || py) s += c2 * (ym[c] - xcc);
-            if (j < L.ny - 1 || py) s += c3 * (yp[c] - xcc);
-            if (k > 0 || pz) s += c4 * (zm[c] - xcc);
-            if (k < L.nzg - 1 || pz) s += c5 * (zp[c] - xcc);
+            s += cxm * (left - xcc);
+            s += cxp * (right - xcc);
+            s += cym * (ym[c] - xcc);
+            s += cyp * (yp[c] - xcc);
+            s += czm * (zm[c] - xcc);
+            s += czp * (zp[c] - xcc);
             if (MODE == 0)
-                out[c] = s;
+                out[c] = (s * (wxv[c] * wyj)) * wzk;
             else if (MODE == 2 || MODE == 8) {
-                out[c] = xcc + omega * ((bv[c] - s) / d);
+                out[c] = xcc + omega * ((bs - s) / d);
                 if (MODE == 8 && dots) {
                     acc0 += out[c] * braw[c];
                     acc1 += out[c] * out[c];
@@ -225,12 +236,12 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
                 }
             }
             else if (MODE == 5) {
-                const double z = (bv[c] - s) / d;
+                const double z = (bs - s) / d;
                 const double dn = (a_d != 0.0) ? a_d * dv[c] + omega * z : omega * z;
                 dv[c] = dn;
                 out[c] = xcc + dn;
             } else
-                out[c] = bv[c] - s;
+                out[c] = bv[c] - (s * (wxv[c] * wyj)) * wzk;
         }
         if (MODE == 5 || MODE == 6) *reinterpret_cast<vt *>(dvec + p) = dv;
         *reinterpret_cast<vt *>(xo + p) = out;
@@ -263,27 +274,24 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
 // otherwise).  Same expressions in the same order as modes 1 and 2: bit-identical (tools/fuse_lab.hip: 1.34 -> 0.78 ms
 // per 512^3 pair).  Levels that are whole on this rank, not periodic, 3-D, nx % 128 == 0, ny % 8 == 0.
 constexpr int FX = 128, FY = 8, FSX = FX + 2, FSY = FY + 2;
+// what a thread keeps of a cell column (i, j) across the planes: the scaled in-plane coefficients, their part of the
+// diagonal sum, 1 / (wx wy) and wx wy
 struct FCell {
-    double wx, wy, gxm, gxp, gym, gyp;
+    double cxm, cxp, cym, cyp, s4, rxy, vxy;
 };
 __device__ __forceinline__ FCell fcell(const LevelDev &L, int i, int j)
 {
     FCell c;
-    c.wx = L.wx[i];
-    c.wy = L.wy[j];
-    const bool px = L.per & 1, py = L.per & 2;  // the wrap face g[n - 1] couples cell n - 1 and cell 0 (face_coefs)
-    c.gxm = (i > 0) ? L.gx[i - 1] : (px ? L.gx[L.nx - 1] : 0.0);
-    c.gxp = (i < L.nx - 1 || px) ? L.gx[i] : 0.0;
-    c.gym = (j > 0) ? L.gy[j - 1] : (py ? L.gy[L.ny - 1] : 0.0);
-    c.gyp = (j < L.ny - 1 || py) ? L.gy[j] : 0.0;
+    c.cxm = L.cmx[i];
+    c.cxp = L.cpx[i];
+    c.cym = L.cmy[j];
+    c.cyp = L.cpy[j];
+    c.s4 = ((c.cxm + c.cxp) + c.cym) + c.cyp;
+    c.rxy = L.rwx[i] * L.rwy[j];
+    c.vxy = L.wx[i] * L.wy[j];
     return c;
 }
-__device__ __forceinline__ double fdiag(const FCell &q, double wzk, double gzm, double gzp)
-{
-    const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
-    const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
-    return -(((((c0 + c1) + c2) + c3) + c4) + c5);
-}
+__device__ __forceinline__ double fdiag(const FCell &q, double czm, double czp) { return -((q.s4 + czm) + czp); }
 // RES = 1 (a V(1,.) cycle: ONE pre-smoothing step): the second stage is the residual r = b - A x1 instead of the second
 // Jacobi step; x1 goes to xo, r to ro -- b read once, two vectors written, instead of mode 1 + mode 3 (2 + 3 passes).
 template <int RES>
@@ -335,40 +343,36 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
             v4 bv = *reinterpret_cast<const v4 *>(pb + off_c);
             if (pin_sum != nullptr && kw == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;  // PINNED: effective b at cell 0
             const double hyv = hy_ok ? pb[off_hy] : 0.0, hxv = hx_ok ? pb[off_hx] : 0.0;
-            const double wzk = L.wz[kw];
-            const double gzm = (kw > 0) ? L.gz[kw - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (kw < L.nzg - 1 || pz) ? L.gz[kw] : 0.0;
+            const double rwz = L.rwz[kw], czm = L.cmz[kw], czp = L.cpz[kw];
             bcur = bv;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                x1p[c] = omega * (bv[c] / fdiag(q4[c], wzk, gzm, gzp));
+                x1p[c] = omega * (((bv[c] * q4[c].rxy) * rwz) / fdiag(q4[c], czm, czp));
                 x1[slot][ty + 1][4 * tx + 1 + c] = x1p[c];
             }
-            x1[slot][hy_row + 1][hy_x + 1] = hy_ok ? omega * (hyv / fdiag(qhy, wzk, gzm, gzp)) : 0.0;
-            if (tid < 16) x1[slot][hx_y + 1][hx_col + 1] = hx_ok ? omega * (hxv / fdiag(qhx, wzk, gzm, gzp)) : 0.0;
+            x1[slot][hy_row + 1][hy_x + 1] = hy_ok ? omega * (((hyv * qhy.rxy) * rwz) / fdiag(qhy, czm, czp)) : 0.0;
+            if (tid < 16) x1[slot][hx_y + 1][hx_col + 1] = hx_ok ? omega * (((hxv * qhx.rxy) * rwz) / fdiag(qhx, czm, czp)) : 0.0;
         }
         __syncthreads();
         const int kc = kk - 1;  // the plane whose x1 neighbours are complete now
         if (kc < k0 || kc >= kend) continue;
         const int sc = (kc + 3) % 3;
-        const double wzk = L.wz[kc];
-        const double gzm = (kc > 0) ? L.gz[kc - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (kc < L.nzg - 1 || pz) ? L.gz[kc] : 0.0;
+        const double wzk = L.wz[kc], rwz = L.rwz[kc], czm = L.cmz[kc], czp = L.cpz[kc];
         v4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int i = ic + c, lx = 4 * tx + 1 + c;
+            const int lx = 4 * tx + 1 + c;
             const FCell &q = q4[c];
-            const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
-            const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
-            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
             const double xcc = x1c[c];
+            // missing neighbours: zero coefficients; the LDS halo cells and x1m / x1p outside the domain hold 0
             double sum = 0.0;
-            if (i > 0 || px) sum += c0 * (x1[sc][ty + 1][lx - 1] - xcc);
-            if (i < L.nx - 1 || px) sum += c1 * (x1[sc][ty + 1][lx + 1] - xcc);
-            if (j > 0 || py) sum += c2 * (x1[sc][ty][lx] - xcc);
-            if (j < L.ny - 1 || py) sum += c3 * (x1[sc][ty + 2][lx] - xcc);
-            if (kc > 0 || pz) sum += c4 * (x1m[c] - xcc);
-            if (kc < L.nzg - 1 || pz) sum += c5 * (x1p[c] - xcc);
-            out[c] = RES ? bprev[c] - sum : xcc + omega * ((bprev[c] - sum) / d);
+            sum += q.cxm * (x1[sc][ty + 1][lx - 1] - xcc);
+            sum += q.cxp * (x1[sc][ty + 1][lx + 1] - xcc);
+            sum += q.cym * (x1[sc][ty][lx] - xcc);
+            sum += q.cyp * (x1[sc][ty + 2][lx] - xcc);
+            sum += czm * (x1m[c] - xcc);
+            sum += czp * (x1p[c] - xcc);
+            out[c] = RES ? bprev[c] - (sum * q.vxy) * wzk : xcc + omega * ((((bprev[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
         }
         if (RES) {
             *reinterpret_cast<v4 *>(ro + (int64_t)kc * plane + off_c) = out;
@@ -434,28 +438,24 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
         sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? px[off_hy] : 0.0;
         if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? px[off_hx] : 0.0;
         __syncthreads();
-        const double wzk = L.wz[kk];
-        const double gzm = (kk > 0) ? L.gz[kk - 1] : (pz ? L.gz[L.nzg - 1] : 0.0), gzp = (kk < L.nzg - 1 || pz) ? L.gz[kk] : 0.0;
+        const double wzk = L.wz[kk], rwz = L.rwz[kk], czm = L.cmz[kk], czp = L.cpz[kk];
         v4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int i = ic + c, lx = 4 * tx + 1 + c;
+            const int lx = 4 * tx + 1 + c;
             const FCell &q = q4[c];
-            const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
-            const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
-            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
             const double xcc = xc[c];
             double sum = 0.0;
-            if (i > 0 || px) sum += c0 * (sp[slot][ty + 1][lx - 1] - xcc);
-            if (i < L.nx - 1 || px) sum += c1 * (sp[slot][ty + 1][lx + 1] - xcc);
-            if (j > 0 || py) sum += c2 * (sp[slot][ty][lx] - xcc);
-            if (j < L.ny - 1 || py) sum += c3 * (sp[slot][ty + 2][lx] - xcc);
-            if (kk > 0 || pz) sum += c4 * (zm[c] - xcc);
-            if (kk < L.nzg - 1 || pz) sum += c5 * (zp[c] - xcc);
+            sum += q.cxm * (sp[slot][ty + 1][lx - 1] - xcc);
+            sum += q.cxp * (sp[slot][ty + 1][lx + 1] - xcc);
+            sum += q.cym * (sp[slot][ty][lx] - xcc);
+            sum += q.cyp * (sp[slot][ty + 2][lx] - xcc);
+            sum += czm * (zm[c] - xcc);
+            sum += czp * (zp[c] - xcc);
             if (MODE == 3)
-                out[c] = bv[c] - sum;
+                out[c] = bv[c] - (sum * q.vxy) * wzk;
             else {
-                out[c] = xcc + omega * ((bv[c] - sum) / d);
+                out[c] = xcc + omega * ((((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
                 if (MODE == 8 && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
                     acc0 += out[c] * braw[c];
                     acc1 += out[c] * out[c];
@@ -802,25 +802,21 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
         v4 bv = bc;
         const v4 braw = bc;
         if (pin_sum != nullptr && lk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
-        const double wzk = F.wz[lk];
-        const double gzm = (lk > 0) ? F.gz[lk - 1] : 0.0, gzp = (lk < F.nzg - 1) ? F.gz[lk] : 0.0;
+        const double rwz = F.rwz[lk], czm = F.cmz[lk], czp = F.cpz[lk];
         v4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int i = ic + c, lx = 4 * tx + 1 + c;
+            const int lx = 4 * tx + 1 + c;
             const FCell &q = q4[c];
-            const double ax = q.wy * wzk, ay = q.wx * wzk, az = q.wx * q.wy;
-            const double c0 = ax * q.gxm, c1 = ax * q.gxp, c2 = ay * q.gym, c3 = ay * q.gyp, c4 = az * gzm, c5 = az * gzp;
-            const double d = -(((((c0 + c1) + c2) + c3) + c4) + c5);
             const double xcc = xcur[c];
             double sum = 0.0;
-            if (i > 0) sum += c0 * (sp[slot][ty + 1][lx - 1] - xcc);
-            if (i < F.nx - 1) sum += c1 * (sp[slot][ty + 1][lx + 1] - xcc);
-            if (j > 0) sum += c2 * (sp[slot][ty][lx] - xcc);
-            if (j < F.ny - 1) sum += c3 * (sp[slot][ty + 2][lx] - xcc);
-            if (lk > 0) sum += c4 * (zm[c] - xcc);
-            if (lk < F.nzg - 1) sum += c5 * (zp[c] - xcc);
-            out[c] = xcc + omega * ((bv[c] - sum) / d);
+            sum += q.cxm * (sp[slot][ty + 1][lx - 1] - xcc);
+            sum += q.cxp * (sp[slot][ty + 1][lx + 1] - xcc);
+            sum += q.cym * (sp[slot][ty][lx] - xcc);
+            sum += q.cyp * (sp[slot][ty + 2][lx] - xcc);
+            sum += czm * (zm[c] - xcc);
+            sum += czp * (zp[c] - xcc);
+            out[c] = xcc + omega * ((((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
             if (DOTS && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
                 acc0 += out[c] * braw[c];
                 acc1 += out[c] * out[c];
@@ -1081,10 +1077,10 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
                 double c[6];
                 face_coefs(L, i, j, k, c);
                 d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-                nxt[p] = omega * (b[p] / d);
+                nxt[p] = omega * ((b[p] * cell_rvol(L, i, j, k)) / d);
             } else {
                 const double ax = apply_cell(L, cur, p, i, j, k, &d);
-                nxt[p] = cur[p] + omega * ((b[p] - ax) / d);
+                nxt[p] = cur[p] + omega * (((b[p] * cell_rvol(L, i, j, k)) - ax) / d);
             }
         }
         __threadfence_block();
@@ -1129,10 +1125,10 @@ __device__ __forceinline__ void tail_smooth(const LevelDev &L, double omega, con
             double c[6];
             face_coefs(L, i, j, k, c);
             d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-            xo[p] = omega * (b[p] / d);
+            xo[p] = omega * ((b[p] * cell_rvol(L, i, j, k)) / d);
         } else {
             const double ax = apply_cell(L, xi, p, i, j, k, &d);
-            xo[p] = xi[p] + omega * ((b[p] - ax) / d);
+            xo[p] = xi[p] + omega * (((b[p] * cell_rvol(L, i, j, k)) - ax) / d);
         }
     }
     __threadfence_block();
@@ -1159,7 +1155,7 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
         for (int p = threadIdx.x; p < nf; p += blockDim.x) {
             const int i = p % F.nx, j = (p / F.nx) % F.ny, k = F.k0 + p / fplane;
             double d;
-            V.r[p] = V.b[p] - apply_cell(F, a, p, i, j, k, &d);
+            V.r[p] = V.b[p] - unscale(F, i, j, k, apply_cell(F, a, p, i, j, k, &d));
         }
         __threadfence_block();
         __syncthreads();
@@ -1257,6 +1253,15 @@ static LevelDev dev_of(const GridLevel &g)
     L.gx = g.g[0];
     L.gy = g.g[1];
     L.gz = g.g[2];
+    L.cmx = g.cm[0];
+    L.cpx = g.cp[0];
+    L.rwx = g.rw[0];
+    L.cmy = g.cm[1];
+    L.cpy = g.cp[1];
+    L.rwy = g.rw[1];
+    L.cmz = g.cm[2];
+    L.cpz = g.cp[2];
+    L.rwz = g.rw[2];
     for (int d = 0; d < 3; ++d) L.t[d] = Tr1{g.t_par[d], g.t_oth[d], g.t_fst[d], g.t_wpar[d], g.t_woth[d]};
     L.tx = TrX{g.tx_fc, g.tx_pw, g.tx_rw};
     return L;
@@ -1275,7 +1280,7 @@ template <class T>
 static int up(const std::vector<T> &h, T **d)
 {
     PIB_HIP(hipMalloc(d, sizeof(T) * (h.size() + 8)));
-    PIB_HIP(hipMemset(*d, 0, sizeof(T) * (h.size() + 8)));
+    PIB_MEMSET(*d, 0, sizeof(T) * (h.size() + 8));
     if (!h.empty()) PIB_HIP(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     return 0;
 }
@@ -1286,6 +1291,9 @@ void gmg_release(pib_solver *s)
         for (int d = 0; d < 3; ++d) {
             if (L.w[d]) (void)hipFree(L.w[d]);
             if (L.g[d]) (void)hipFree(L.g[d]);
+            if (L.cm[d]) (void)hipFree(L.cm[d]);
+            if (L.cp[d]) (void)hipFree(L.cp[d]);
+            if (L.rw[d]) (void)hipFree(L.rw[d]);
             if (L.t_par[d]) (void)hipFree(L.t_par[d]);
             if (L.t_oth[d]) (void)hipFree(L.t_oth[d]);
             if (L.t_fst[d]) (void)hipFree(L.t_fst[d]);
@@ -1314,14 +1322,14 @@ static int alloc_level_vectors(GridLevel &g, bool need_b, int halo_planes)
     PIB_HIP(hipMalloc(&g.x, sz));
     PIB_HIP(hipMalloc(&g.x2, sz));
     PIB_HIP(hipMalloc(&g.r, sz));
-    PIB_HIP(hipMemset(g.x, 0, sz));
-    PIB_HIP(hipMemset(g.x2, 0, sz));
-    PIB_HIP(hipMemset(g.r, 0, sz));
+    PIB_MEMSET(g.x, 0, sz);
+    PIB_MEMSET(g.x2, 0, sz);
+    PIB_MEMSET(g.r, 0, sz);
     PIB_HIP(hipMalloc(&g.d, sz));
-    PIB_HIP(hipMemset(g.d, 0, sz));
+    PIB_MEMSET(g.d, 0, sz);
     if (need_b) {
         PIB_HIP(hipMalloc(&g.b, sz));
-        PIB_HIP(hipMemset(g.b, 0, sz));
+        PIB_MEMSET(g.b, 0, sz);
     }
     g.plane = plane;
     g.nloc = (g.k1 - g.k0) * plane;
@@ -1540,6 +1548,23 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
                 }
             }
             PIB_CHK(up(hg[d], &G.g[d]));
+            {
+                // rows divided by the cell volume: g / w per face, a function of the index along d only
+                const int64_t nd = nn[d];
+                std::vector<double> cm((size_t)nd, 0.0), cp((size_t)nd, 0.0), rw((size_t)nd, 1.0);
+                for (int64_t q = 0; q < nd; ++q) {
+                    const double wq = hw[d][(size_t)q];
+                    rw[(size_t)q] = 1.0 / wq;
+                    if (nd > 1) {
+                        if (q > 0) cm[(size_t)q] = hg[d][(size_t)q - 1] / wq;
+                        else if (wrap) cm[(size_t)q] = hg[d][(size_t)nd - 1] / wq;
+                        if (q < nd - 1 || wrap) cp[(size_t)q] = hg[d][(size_t)q] / wq;
+                    }
+                }
+                PIB_CHK(up(cm, &G.cm[d]));
+                PIB_CHK(up(cp, &G.cp[d]));
+                PIB_CHK(up(rw, &G.rw[d]));
+            }
         }
         PIB_CHK(alloc_level_vectors(G, l > 0, (P > 1 && !replicated) ? HALO_PAD_PLANES : 1));
         const bool last = (l + 1 >= max_levels) || (nn[0] <= 2 && nn[1] <= 2 && nn[2] <= 2);

@@ -16,6 +16,7 @@
 //     GPU, so this is how the multi-rank algorithm (halo plans, distributed / replicated multigrid levels,
 //     all-reduced recurrences) is exercised end to end through the C ABI.  Device-to-device copies ordered
 //     with HIP events + a host barrier per collective.
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -341,6 +342,43 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
     return 0;
 }
 
+__global__ void k_lb_add(double *__restrict__ acc, const double *__restrict__ x, int64_t n, int first)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc[i] = first ? x[i] : acc[i] + x[i];
+}
+
+// in-place sum over ranks of `count` doubles (any count): the dense force system of the immersed boundaries, whose
+// entries every rank sums over its own velocity points
+int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st)
+{
+    if (s->comm.nranks <= 1 || count <= 0) return 0;
+    if (s->comm.loop) {
+        LoopbackGroup *g = s->comm.loop;
+        const int P = s->comm.nranks, r = s->comm.rank;
+        double *tmp = nullptr;
+        PIB_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)count));
+        g->ptr[(size_t)r] = dev;
+        PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
+        g->barrier();
+        const int nb = (int)std::min<int64_t>(4096, (count + 255) / 256);
+        for (int q = 0; q < P; ++q) {  // rank order: the same bits on every rank
+            if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)q], 0));
+            hipLaunchKernelGGL(k_lb_add, dim3(nb), dim3(256), 0, st, tmp, g->ptr[(size_t)q], count, q == 0 ? 1 : 0);
+        }
+        PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
+        g->barrier();
+        for (int q = 0; q < P; ++q)
+            if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)q], 0));  // everybody has read my buffer
+        PIB_HIP(hipMemcpyAsync(dev, tmp, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
+        PIB_HIP(hipStreamSynchronize(st));
+        g->barrier();
+        PIB_HIP(hipFree(tmp));
+        return 0;
+    }
+    PIB_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, s->comm.comm, st));
+    return 0;
+}
+
 // every rank contributes counts[rank] doubles at `send`; `recv_base + offs[q]` receives rank q's part
 int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const std::vector<int64_t> &counts,
                     const std::vector<int64_t> &offs, hipStream_t st)
@@ -410,7 +448,7 @@ extern "C" int pib_comm_loopback_create(int nranks, void *uid_out)
         PIB_HIP(hipEventCreateWithFlags(&g->ev_done[(size_t)r], hipEventDisableTiming));
     }
     PIB_HIP(hipMalloc(&g->staging, sizeof(double) * PIB_NRED * (size_t)nranks));
-    PIB_HIP(hipMemset(g->staging, 0, sizeof(double) * PIB_NRED * (size_t)nranks));
+    PIB_MEMSET(g->staging, 0, sizeof(double) * PIB_NRED * (size_t)nranks);
     std::memset(uid_out, 0, PIB_UID_BYTES);
     std::memcpy(uid_out, LOOP_MAGIC, 8);
     std::memcpy((char *)uid_out + 8, &g, sizeof(g));

@@ -31,6 +31,11 @@ struct IbDev {
     const double *X;          // [npts*dim] coordinates
     const int *ijk;           // [npts*dim] background (pressure) cell
     const double *h;          // [npts*dim] kernel widths (uniform within a body: createdelta.cpp:69-76)
+    // z-slabs: the engine's mesh is the rank's extended slab; a row keeps the velocity points this rank OWNS only (planes
+    // [own_lo, own_hi) of component dof along direction sd), so that sums over velocity points -- E u, E BN H -- add up
+    // over the ranks without counting a point twice.  sd = -1: one rank, every point.
+    int sd;
+    int own_lo[3], own_hi[3];
 };
 
 struct IbState {
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(128) void k_ib_delta(NsDev D, IbDev I, int32_t *__r
         const double x = I.X[pt * I.dim + d], h = I.h[pt * I.dim + d];
         int c = 0;
         for (int s = c0 - I.window; s <= c0 + I.window; ++s)
-            if (s >= 0 && s < F.n[d]) {
+            if (s >= 0 && s < F.n[d] && (d != I.sd || (s >= I.own_lo[dof] && s < I.own_hi[dof]))) {
                 ids[d][c] = s;
                 phi[d][c] = delta_kernel(I.kernel, x - F.co[d][s + 1], h);
                 ++c;
@@ -280,7 +285,7 @@ template <class T>
 static int dev_alloc(IbState *ib, T **p, int64_t count)
 {
     PIB_HIP(hipMalloc(p, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
-    PIB_HIP(hipMemset(*p, 0, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
+    PIB_MEMSET(*p, 0, sizeof(T) * (size_t)std::max<int64_t>(count, 1));
     ib->owned.push_back(*p);
     return 0;
 }
@@ -304,6 +309,9 @@ static int scan_counts(const int32_t *d_count, int64_t n, int32_t *d_rowptr, int
     return 0;
 }
 
+__global__ void k_ib_eu(int64_t nf, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                        const double *__restrict__ eval, const double *__restrict__ U, double *__restrict__ out);
+
 int ib_spread_forces(pib_ns *ns)
 {
     IbState *ib = ns->ib;
@@ -313,10 +321,29 @@ int ib_spread_forces(pib_ns *ns)
     return 0;
 }
 
+// rhsf = -s (+ UB) from the interpolated velocity s = E u summed over the ranks
+__global__ __launch_bounds__(256) void k_ib_rhsf_finish(int64_t nf, const double *__restrict__ ub, double *__restrict__ rhsf)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nf; r += (int64_t)gridDim.x * 256) {
+        double v = -1.0 * rhsf[r];
+        if (ub != nullptr) v = ub[r] + 1.0 * v;
+        rhsf[r] = v;
+    }
+}
+
 int ib_solve_forces(pib_ns *ns)
 {
     IbState *ib = ns->ib;
     const int64_t nf = ib->I.nf;
+    if (ns->nranks > 1) {
+        // E u: this rank's velocity points, then the sum over the ranks (the same bits everywhere: the replicated
+        // force solves must not drift apart)
+        hipLaunchKernelGGL(k_ib_eu, dim3(blocks_for(nf)), dim3(256), 0, ns->stream, nf, ib->rowptr, ib->col, ib->eval, ns->U, ib->rhsf);
+        PIB_HIP(hipGetLastError());
+        PIB_CHK(comm_allreduce_big(ns->vsol, ib->rhsf, nf, ns->stream));
+        hipLaunchKernelGGL(k_ib_rhsf_finish, dim3(blocks_for(nf)), dim3(256), 0, ns->stream, nf,
+                           ib->moving ? ib->ub : (const double *)nullptr, ib->rhsf);
+    } else
     hipLaunchKernelGGL(k_ib_interp, dim3(blocks_for(nf)), dim3(256), 0, ns->stream, nf, ib->rowptr, ib->col, ib->eval, ns->U,
                        ib->moving ? ib->ub : (const double *)nullptr, ib->rhsf);
     PIB_HIP(hipGetLastError());
@@ -450,6 +477,21 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
         p0 += nb;
     }
     IbDev &I = ib->I;
+    I.sd = -1;
+    for (int f = 0; f < 3; ++f) {
+        I.own_lo[f] = 0;
+        I.own_hi[f] = 0x7fffffff;
+    }
+    if (ns->nranks > 1) {
+        // background cells were found on the GLOBAL mesh; the kernels index this rank's extended slab (a cell outside it
+        // simply has no window point here)
+        I.sd = dim - 1;
+        for (int64_t q = 0; q < total; ++q) ijk[(size_t)(q * dim + I.sd)] -= (int)ns->slab_e0;
+        for (int f = 0; f < dim; ++f) {
+            I.own_lo[f] = (int)ns->fld_own_lo[f];
+            I.own_hi[f] = (int)(ns->fld_own_lo[f] + ns->fld_own_cnt[f]);
+        }
+    }
     double *dX = nullptr, *dh = nullptr;
     int *dijk = nullptr;
     if ((err = dev_alloc(ib, &dX, total * dim)) || (err = dev_alloc(ib, &dh, total * dim)) || (err = dev_alloc(ib, &dijk, total * dim)))
@@ -521,7 +563,13 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
                        ib->c_rowptr, ib->c_col, ib->c_val);
     PIB_HIP(hipGetLastError());
     PIB_HIP(hipStreamSynchronize(q));
-    // fSolver->setMatrix(EBNH)  (decoupledibpm.cpp:80, rigidkinematics.cpp:139)
+    // fSolver->setMatrix(EBNH)  (decoupledibpm.cpp:80, rigidkinematics.cpp:139); on slabs every rank holds the part of
+    // each entry that runs over its own velocity points: the direct solver sums the dense matrix over the ranks
+    if (ns->nranks > 1) {
+        if (ib->fsol->cfg.pc != Precond::LU)
+            return fail(PIB_ERR_SUP, "immersed bodies on several ranks need the direct forces solver (-forces_ksp_type preonly -forces_pc_type lu)");
+        ib->fsol->reduce_via = ns->vsol;
+    }
     return adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val);
 }
 
@@ -532,7 +580,6 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
     if (ns->bn_order > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bodies: BN order > 1 with immersed bodies is not supported");
-    if (ns->nranks > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bodies: immersed bodies on several ranks are not provided yet");
     PIB_HIP(hipSetDevice(ns->device));
     if (ns->ib != nullptr && ns->psol != nullptr) {
         // the coupled scheme's Schur hook points into the state that goes away: back to the plain Poisson operator
@@ -576,7 +623,7 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     if ((err = pib_create_from_string(&ib->fsol, "forces", forces_cfg ? forces_cfg : "", 0, 1, nullptr, ns->device))) return bail(err);
     auto palloc = [&](double **p) -> int {
         PIB_HIP(hipMalloc(p, sizeof(double) * (size_t)I.nf));
-        PIB_HIP(hipMemset(*p, 0, sizeof(double) * (size_t)I.nf));
+        PIB_MEMSET(*p, 0, sizeof(double) * (size_t)I.nf);
         ib->persistent.push_back(*p);
         return 0;
     };
@@ -606,13 +653,14 @@ int pib_ns_set_coupled(pib_ns *ns, int coupled)
         ns->psol->graph_key = 0;
         return 0;
     }
+    if (ns->nranks > 1) return fail(PIB_ERR_SUP, "pib_ns_set_coupled: the coupled scheme runs on one rank");
     if (ib->moving) return fail(PIB_ERR_SUP, "pib_ns_set_coupled: prescribed body motion belongs to the decoupled solver");
     if (ib->fsol->dense_inv == nullptr)
         return fail(PIB_ERR_SUP, "pib_ns_set_coupled: the forces solver must be the direct one (-forces_ksp_type preonly -forces_pc_type lu)");
     if (ib->t_un == nullptr) {
         auto palloc = [&](double **p, int64_t n) -> int {
             PIB_HIP(hipMalloc(p, sizeof(double) * (size_t)n));
-            PIB_HIP(hipMemset(*p, 0, sizeof(double) * (size_t)n));
+            PIB_MEMSET(*p, 0, sizeof(double) * (size_t)n);
             ib->persistent.push_back(*p);
             return 0;
         };

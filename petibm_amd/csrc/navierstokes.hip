@@ -700,6 +700,11 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
         periodic[d] = cnt ? 1 : 0;
     }
     velocity_mesh_arrays(dim, n, w, lo, hi, periodic, hdl, hco, fn);
+    std::vector<double> vtx_global[3], dlu_global[3];  // before the slab axis is cut: the bodies' background cells are global
+    for (int d = 0; d < dim; ++d) {
+        vtx_global[d] = hco[d][d];
+        dlu_global[d] = hdl[0][d];
+    }
     // ---- this rank's extended slab: cells [e0, e1) of the slab axis = owned [pk0, pk1) + one plane below + two above
     const int sd = dim - 1;
     int64_t pk0 = 0, pk1 = n[sd], e0 = 0, e1 = n[sd];
@@ -739,8 +744,8 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     ns->dt = dt;
     ns->nu = nu;
     for (int d = 0; d < dim; ++d) {
-        ns->h_vtx[d] = hco[d][d];  // coord[component d][direction d] = the vertices (cartesianmesh.cpp:246)
-        ns->h_dlu[d] = hdl[0][d];
+        ns->h_vtx[d] = vtx_global[d];  // coord[component d][direction d] = the vertices (cartesianmesh.cpp:246)
+        ns->h_dlu[d] = dlu_global[d];
         ns->lo[d] = lo[d];
         ns->hi[d] = hi[d];
     }
@@ -893,7 +898,7 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     }
     auto alloc = [&](double **q, int64_t cnt) -> int {
         PIB_HIP(hipMalloc(q, sizeof(double) * (size_t)cnt));
-        PIB_HIP(hipMemset(*q, 0, sizeof(double) * (size_t)cnt));
+        PIB_MEMSET(*q, 0, sizeof(double) * (size_t)cnt);
         ns->owned.push_back(*q);
         return 0;
     };
@@ -1275,7 +1280,10 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         PIB_CHK(pib_solve(ns->vsol, ns->U, ns->rhs1));  // vSolver->solve(UGlobal, rhs1)  (:532)
         }
         const bool coupled = ib_is_coupled(ns);
-        if (ns->ib && !coupled) PIB_CHK(ib_solve_forces(ns));   // assembleRHSForces, solveForces, applyNoSlip (decoupledibpm.cpp:116-118)
+        if (ns->ib && !coupled) {
+            PIB_CHK(ib_solve_forces(ns));   // assembleRHSForces, solveForces, applyNoSlip (decoupledibpm.cpp:116-118)
+            PIB_CHK(ns_halo_velocity(ns, ns->U));  // u += BNH df changed owned points next to the neighbours' planes
+        }
         hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns->pinned, ns->U, ns->rhs2);
         PIB_HIP(hipGetLastError());
         if (coupled) {

@@ -23,6 +23,13 @@ const char *last_error();
             return pib::fail(PIB_ERR_LIB, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call,            \
                              hipGetErrorString(e_));                                                    \
     } while (0)
+// hipMemset of device memory may return before it has run, and the solver streams are non-blocking (they do not wait
+// for the null stream): a kernel launched next on such a stream could be overtaken by the memset.  Set-up paths only.
+#define PIB_MEMSET(ptr, value, bytes)                 \
+    do {                                              \
+        PIB_HIP(hipMemset((ptr), (value), (bytes)));  \
+        PIB_HIP(hipStreamSynchronize(nullptr));       \
+    } while (0)
 #define PIB_NCCL(call)                                                                                  \
     do {                                                                                                \
         ncclResult_t e_ = (call);                                                                       \
@@ -146,6 +153,9 @@ struct GridLevel {
     //   c_d[s] * (product of the two perpendicular width arrays)
     double *w[3] = {nullptr, nullptr, nullptr};  // [n[d]]
     double *g[3] = {nullptr, nullptr, nullptr};  // [n[d]-1] (g[d][s] couples s and s+1), already * dt
+    // the level operator's rows divided by the cell volume have 1-D coefficients (gmg.hip): towards -d / +d of cell s
+    // cm[d][s] = g[d][s-1] / w[d][s], cp[d][s] = g[d][s] / w[d][s] (0 at a wall, the wrap face when periodic); rw = 1 / w
+    double *cm[3] = {nullptr, nullptr, nullptr}, *cp[3] = {nullptr, nullptr, nullptr}, *rw[3] = {nullptr, nullptr, nullptr};
     double *dinv = nullptr;                      // 1/diag per local cell (with pinned handling)
     double *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;  // level vectors (one halo plane each side)
     double *d = nullptr;  // Chebyshev direction vector
@@ -236,6 +246,8 @@ struct pib_solver {
     hipGraphExec_t graph = nullptr;   // one Krylov iteration (krylov.hip: run_iterations)
     uint64_t graph_key = 0;           // the (method, x, b) it was captured for
     int64_t graph_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // instrumentation counters one replay stands for
+    pib_solver *reduce_via = nullptr;  // direct solve of a matrix whose entries every rank holds PARTIAL sums of (the force system of
+                                       // immersed bodies on slabs): the dense matrix is summed over this solver's communicator first
     double *dense_inv = nullptr;  // dense.hip: explicit inverse of the direct solver [dense_n x dense_n]
     double *dense_work = nullptr; // the matrix being eliminated
     int *dense_bad = nullptr;     // zero-pivot flag
@@ -268,6 +280,7 @@ int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_
                          int64_t send_next, hipStream_t st);
 int allreduce_slots(pib_solver *s, int first, int count, hipStream_t st);
 int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st);
+int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st);
 int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vector<double> &all);
 int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const std::vector<int64_t> &counts,
                     const std::vector<int64_t> &offs, hipStream_t st);

@@ -386,8 +386,9 @@ class DecoupledIBPMSolver(NavierStokesSolver):
 
     def __init__(self, config: dict, bodies=None, velocity_cfg: str = DEFAULT_VELOCITY_CFG,
                  poisson_cfg: str = DEFAULT_POISSON_CFG, forces_cfg: str = DEFAULT_FORCES_CFG, device: int = -1,
-                 directory: str = "."):
-        super().__init__(config, velocity_cfg=velocity_cfg, poisson_cfg=poisson_cfg, device=device)
+                 directory: str = ".", rank: int = 0, nranks: int = 1, uid: bytes = None):
+        super().__init__(config, velocity_cfg=velocity_cfg, poisson_cfg=poisson_cfg, device=device, rank=rank,
+                         nranks=nranks, uid=uid)
         import os
         if bodies is None:
             bodies = []

@@ -86,3 +86,74 @@ def test_slab_engine_limits_and_sizes():
     # u, v: 4 planes of 7*8 / 8*7 points each; w: 4 planes on rank 0, 3 on the last rank (7 faces in all)
     assert res[0][0] == (4 * 56 + 4 * 56 + 4 * 64, 4 * 64) and res[1][0] == (4 * 56 + 4 * 56 + 3 * 64, 4 * 64)
     assert all(c == capi.ERR_SUP for r in res for c in r[1])
+
+
+# ---- immersed bodies on slabs (DecoupledIBPMSolver / RigidKinematicsSolver on the DMDA decomposition) -----------------
+# Every rank assembles Delta / E / H on the velocity points it owns; the sums over velocity points -- E u and the force
+# system E BN H -- add up over the ranks (all-reduce), the small force system is factorised on every rank.  The order of
+# those sums differs from the single rank's, so the bar is the solver tolerance, not bits.
+FORCES = "-forces_ksp_type preonly\n-forces_pc_type lu\n-forces_pc_factor_mat_solver_type superlu_dist\n"
+
+
+def _ib_case(kind):
+    from petibm_amd import cases
+    from test_gpu_ibm import flow_config, sphere_points
+    if kind == "2d_cylinder":
+        # the body sits across the cut of two y-slabs and inside the middle one of three
+        return flow_config(cases.body_block(cells=(8, 16, 8), ratio=1.25, span=3.0, core=0.8)), [cases.circle(40, 0.5)], None
+    if kind == "3d_sphere":
+        return flow_config(cases.body_block(cells=(4, 10, 4), ratio=1.4, span=2.0, core=0.7, dim=3), nu=0.05), [sphere_points(50, 0.4)], None
+    # a cylinder oscillating in a closed box of fluid at rest (applications/rigidkinematics)
+    cfg = cases.body_block(cells=(6, 20, 6), ratio=1.3, span=2.0, core=1.0)
+    cfg["flow"]["nu"] = 0.02
+    cfg["parameters"] = {"dt": 0.01, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    base = cases.circle(36, 0.3)
+    amp, om = 0.25, 2.0 * np.pi
+
+    def pose(t):
+        return base + np.array([0.0, amp * np.sin(om * t)]), np.tile([0.0, amp * om * np.cos(om * t)], (base.shape[0], 1))
+
+    return cfg, [base], pose
+
+
+@pytest.mark.parametrize("kind,P", [("2d_cylinder", 2), ("2d_cylinder", 3), ("3d_sphere", 2), ("moving_cylinder", 2),
+                                    ("moving_cylinder", 3)])
+def test_immersed_bodies_on_slabs_reproduce_the_single_rank(kind, P):
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    cfg, bodies, pose = _ib_case(kind)
+    dt = cfg["parameters"]["dt"]
+    nsteps = 4
+
+    def run(s):
+        out = []
+        for step in range(1, nsteps + 1):
+            if pose is not None:
+                x, v = pose(step * dt)  # moveBodies(t + dt) precedes the step (rigidkinematics.cpp:75-79)
+                s.moveBodies([x], [v])
+            s.advance()
+            U, p = s.getState()
+            f, avg = s.getForces()
+            out.append((U, p, f.copy(), avg.copy()))
+        return out
+
+    one = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=KSP_P, forces_cfg=FORCES)
+    ref = run(one)
+
+    def rank_fn(r, uid):
+        s = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=KSP_P, forces_cfg=FORCES, device=0, rank=r,
+                                nranks=P, uid=uid)
+        got = run(s)
+        cut = [(s.ownedVelocity(U), s.ownedPressure(p)) for U, p, _, _ in ref]
+        s.destroy()
+        return got, cut
+
+    res = _run_ranks(P, rank_fn)
+    for got, cut in res:
+        for (U, p, f, avg), (cU, cp), (_, _, rf, ravg) in zip(got, cut, ref):
+            assert np.abs(U - cU).max() <= 1e-8 * max(1.0, np.abs(cU).max())
+            assert np.abs(f - rf).max() <= 1e-7 * np.abs(rf).max()
+            assert np.abs(avg - ravg).max() <= 1e-7 * np.abs(ravg).max()
+    # every rank holds the same forces, bit for bit (the replicated force solves must not drift apart)
+    for step in range(nsteps):
+        assert all(np.array_equal(res[0][0][step][2], r[0][step][2]) for r in res[1:])
+    one.destroy()
