@@ -92,7 +92,7 @@ static inline void face_coefs(const level_t *l, i64 i, i64 j, i64 k, double c[6]
     c[4] = l->cm[2][k];
     c[5] = l->cp[2][k];
 }
-static inline double cell_rvol(const level_t *l, i64 i, i64 j, i64 k) { return (l->rw[0][i] * l->rw[1][j]) * l->rw[2][k]; }
+static inline double scale_b(const level_t *l, i64 i, i64 j, i64 k, double b) { return (b * (l->rw[0][i] * l->rw[1][j])) * l->rw[2][k]; }
 static inline double unscale(const level_t *l, i64 i, i64 j, i64 k, double t) { return (t * (l->w[0][i] * l->w[1][j])) * l->w[2][k]; }
 
 /* the scaled row sum t = sum_faces c (x_nb - x_c) at one cell, and the scaled diagonal */
@@ -302,10 +302,10 @@ static void smooth(const level_t *l, double omega, const double *b, const double
                     double c[6];
                     face_coefs(l, i, j, k, c);
                     d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-                    xo[p] = omega * ((b[p] * cell_rvol(l, i, j, k)) / d);
+                    xo[p] = omega * (scale_b(l, i, j, k, b[p]) / d);
                 } else {
                     const double ax = apply_cell(l, xi, i, j, k, &d);
-                    xo[p] = xi[p] + omega * (((b[p] * cell_rvol(l, i, j, k)) - ax) / d);
+                    xo[p] = xi[p] + omega * ((scale_b(l, i, j, k, b[p]) - ax) / d);
                 }
             }
 }
@@ -414,12 +414,12 @@ static double *cheby(gmg_t *G, level_t *l, int lev, int deg, const double *b, do
                         double c[6];
                         face_coefs(l, i, j, k, c);
                         dg = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-                        z = (b[p] * cell_rvol(l, i, j, k)) / dg;
+                        z = scale_b(l, i, j, k, b[p]) / dg;
                         d[p] = a_z * z;
                         nxt[p] = d[p];
                     } else {
                         const double ax = apply_cell(l, cur, i, j, k, &dg);
-                        z = ((b[p] * cell_rvol(l, i, j, k)) - ax) / dg;
+                        z = (scale_b(l, i, j, k, b[p]) - ax) / dg;
                         const double dn = a_d * d[p] + a_z * z;
                         d[p] = dn;
                         nxt[p] = cur[p] + dn;

@@ -224,6 +224,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
     c.detect_structure = std::atoi(d.get("default", "pib_detect_structure", "1").c_str());
     c.deep_halo = std::atoi(d.get("default", "pib_deep_halo", "1").c_str());
+    c.overlap_min_bytes = std::atoi(d.get("default", "pib_overlap_min_bytes", "1048576").c_str());
     c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "-1").c_str());
     if (d.has("default", "pib_initial_guess_nonzero"))
         c.initial_guess_nonzero = truthy(d.get("default", "pib_initial_guess_nonzero", "1"));
@@ -330,6 +331,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_agglomerate_below", v)) c.agglomerate_below = std::atoi(v.c_str());
     if (get("pib_detect_structure", v)) c.detect_structure = std::atoi(v.c_str());
     if (get("pib_deep_halo", v)) c.deep_halo = std::atoi(v.c_str());
+    if (get("pib_overlap_min_bytes", v)) c.overlap_min_bytes = std::atoi(v.c_str());
     if (get("pib_coarse_tail", v)) c.coarse_tail = std::atoi(v.c_str());
     if (get("pib_presweeps", v)) c.presweeps = std::atoi(v.c_str());
     if (get("pib_postsweeps", v)) c.postsweeps = std::atoi(v.c_str());

@@ -79,7 +79,8 @@ __device__ __forceinline__ void face_coefs(const LevelDev &L, int i, int j, int 
     c[4] = L.cmz[k];
     c[5] = L.cpz[k];
 }
-__device__ __forceinline__ double cell_rvol(const LevelDev &L, int i, int j, int k) { return (L.rwx[i] * L.rwy[j]) * L.rwz[k]; }
+// b / volume in the association every kernel uses: (b (1/wx 1/wy)) 1/wz
+__device__ __forceinline__ double scale_b(const LevelDev &L, int i, int j, int k, double b) { return (b * (L.rwx[i] * L.rwy[j])) * L.rwz[k]; }
 __device__ __forceinline__ double unscale(const LevelDev &L, int i, int j, int k, double t) { return (t * (L.wx[i] * L.wy[j])) * L.wz[k]; }
 
 // the scaled row sum t at local cell p (x points at the first OWNED plane; halo planes sit at -plane and +nk*plane)
@@ -1077,10 +1078,10 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
                 double c[6];
                 face_coefs(L, i, j, k, c);
                 d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-                nxt[p] = omega * ((b[p] * cell_rvol(L, i, j, k)) / d);
+                nxt[p] = omega * (scale_b(L, i, j, k, b[p]) / d);
             } else {
                 const double ax = apply_cell(L, cur, p, i, j, k, &d);
-                nxt[p] = cur[p] + omega * (((b[p] * cell_rvol(L, i, j, k)) - ax) / d);
+                nxt[p] = cur[p] + omega * ((scale_b(L, i, j, k, b[p]) - ax) / d);
             }
         }
         __threadfence_block();
@@ -1125,10 +1126,10 @@ __device__ __forceinline__ void tail_smooth(const LevelDev &L, double omega, con
             double c[6];
             face_coefs(L, i, j, k, c);
             d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-            xo[p] = omega * ((b[p] * cell_rvol(L, i, j, k)) / d);
+            xo[p] = omega * (scale_b(L, i, j, k, b[p]) / d);
         } else {
             const double ax = apply_cell(L, xi, p, i, j, k, &d);
-            xo[p] = xi[p] + omega * (((b[p] * cell_rvol(L, i, j, k)) - ax) / d);
+            xo[p] = xi[p] + omega * ((scale_b(L, i, j, k, b[p]) - ax) / d);
         }
     }
     __threadfence_block();
@@ -1929,6 +1930,28 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         set_valid(vec, d);
         return 0;
     };
+    // The same exchange on the communication stream while the main stream goes on with work that needs owned planes
+    // only; wait_halo() joins.  Used for the exchange of a level's right-hand side when it is large (>= 1 MiB per
+    // neighbour: at 512^3 on 8 GPUs that is 8 MiB on level 0 and 1.5 MiB on level 1): the first kernel of the way down
+    // runs on the interior planes meanwhile and on the planes next to the neighbours afterwards.
+    bool halo_pending = false;
+    auto need_async = [&](int l, const double *vec, int d) -> int {
+        const LI &I = li[(size_t)l];
+        if (!I.dist || d <= 0 || valid(vec) >= d) return 0;
+        if (d > I.maxd) return fail(PIB_ERR_LIB, "gmg: halo depth %d not available on level %d", d, l);
+        PIB_HIP(hipEventRecord(s->ev_ready, q));
+        PIB_HIP(hipStreamWaitEvent(s->stream_comm, s->ev_ready, 0));
+        PIB_CHK(exchange_planes(s, s->levels[(size_t)l], const_cast<double *>(vec), d, s->stream_comm));
+        PIB_HIP(hipEventRecord(s->ev_halo, s->stream_comm));
+        set_valid(vec, d);
+        halo_pending = true;
+        return 0;
+    };
+    auto wait_halo = [&]() -> int {
+        if (halo_pending) PIB_HIP(hipStreamWaitEvent(q, s->ev_halo, 0));
+        halo_pending = false;
+        return 0;
+    };
     // planes [a, a + c) relative to the first owned plane for a run that reaches d ghost planes into the neighbours
     auto run = [&](int l, int d, int64_t &a, int64_t &c) {
         const LI &I = li[(size_t)l];
@@ -1968,12 +1991,24 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 run(l, std::max(o, 0), ka, kc);
                 if (o >= 0 && fused_run_ok(s, g, ka, kc) &&
                     ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 31u) == 0) {
-                    GridLevel sub = g;
-                    sub.k0 = g.k0 + ka;
-                    sub.k1 = sub.k0 + kc;
                     const int FZ = march_planes(g, kc);
-                    hipLaunchKernelGGL(k_presmooth2<0>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((kc + FZ - 1) / FZ)),
-                                       dim3(256), 0, q, S, dev_of(sub), omega, b + ka * g.plane, c + ka * g.plane, pin_l, FZ, nullptr);
+                    auto launch = [&](int64_t ra, int64_t rc) {
+                        if (rc <= 0) return;
+                        GridLevel sub = g;
+                        sub.k0 = g.k0 + ra;
+                        sub.k1 = sub.k0 + rc;
+                        hipLaunchKernelGGL(k_presmooth2<0>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((rc + FZ - 1) / FZ)),
+                                           dim3(256), 0, q, S, dev_of(sub), omega, b + ra * g.plane, c + ra * g.plane, pin_l, FZ, nullptr);
+                    };
+                    if (halo_pending) {
+                        // planes whose two steps read owned planes of b only, while the exchange is in flight
+                        const int64_t ia = I.lo ? 1 : 0, ie = I.nk - (I.hi ? 1 : 0);
+                        launch(ia, ie - ia);
+                        PIB_CHK(wait_halo());
+                        launch(ka, ia - ka);
+                        launch(ie, ka + kc - ie);
+                    } else
+                        launch(ka, kc);
                     PIB_HIP(hipGetLastError());
                     set_valid(c, o);
                     std::swap(a, c);
@@ -1981,6 +2016,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                     continue;
                 }
             }
+            PIB_CHK(wait_halo());
             if (from_zero && sw == 0) {
                 const int o = I.dist ? std::max(0, std::min(std::min(desired, I.cdepth), valid(b))) : 0;  // pointwise: as deep as b
                 run(l, o, ka, kc);
@@ -2099,8 +2135,12 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         // the right-hand side on as many ghost planes as the way down (and, on level 0, the way up) consumes
         const int Dd = down_depth(l);
         set_valid(b, 0);
-        PIB_CHK(need(l, b, Dd));
+        if (I.dist && s->cfg.overlap_halo && I.nk >= 4 && (int64_t)Dd * g.plane * 8 >= (int64_t)s->cfg.overlap_min_bytes)
+            PIB_CHK(need_async(l, b, Dd));
+        else
+            PIB_CHK(need(l, b, Dd));
         if (pre == 1 && !cheb) {
+            PIB_CHK(wait_halo());
             // one pre-smoothing step from zero and the residual of its result: x1 kept and r valid on o ghost planes
             const int o = I.dist ? std::max(0, std::min(std::min(Dd - 1, I.maxd - 1), valid(b) - 1)) : 0;
             int64_t ka, kc;

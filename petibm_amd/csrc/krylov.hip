@@ -200,25 +200,21 @@ struct OpInit {
     }
 };
 
-// x += a p ; r -= a w ; z = M^-1 r ; partials 0..4
+// r -= a w ; z = M^-1 r ; partials 0..4.  (x += a p rides on the next p-update, which reads p anyway: OpUpdateP.)
 template <int PCM>
 struct OpUpdateXR {
     static constexpr int NRED = 6;
-    const double *p, *w, *dinv;
-    double *x, *r, *z;
+    const double *w, *dinv;
+    double *r, *z;
     double omega;
     double a;
     __device__ void prepare(const Scalars *S) { a = S->a; }
     template <int W>
     __device__ void apply(int64_t i, double (&acc)[6]) const
     {
-        Pack<W> vp = ld<W>(p, i), vw = ld<W>(w, i), vx = ld<W>(x, i), vr = ld<W>(r, i), vz;
+        Pack<W> vw = ld<W>(w, i), vr = ld<W>(r, i), vz;
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-            vx.v[k] = vx.v[k] + a * vp.v[k];
-            vr.v[k] = vr.v[k] - a * vw.v[k];
-        }
-        st<W>(x, i, vx);
+        for (int k = 0; k < W; ++k) vr.v[k] = vr.v[k] - a * vw.v[k];
         st<W>(r, i, vr);
         if (PCM == PCM_JACOBI) {
             Pack<W> vd = ld<W>(dinv, i);
@@ -257,18 +253,23 @@ struct OpDotZR {
     }
 };
 
+// x += a p (the update the previous iteration owes, elements [xlo, xhi) of the index space: x has no ghost entries) ;
 // p = (z - mean) + b p      (first iteration: p = z - mean)
 struct OpUpdateP {
     static constexpr int NRED = 0;
     const double *z;
     double *p;
-    double bcoef, mean;
-    int first;
+    double *x;          // indexed like p; may be null (no x update)
+    int64_t xlo, xhi;   // both even
+    double bcoef, mean, a;
+    int first, pend;
     __device__ void prepare(const Scalars *S)
     {
         bcoef = S->b;
         mean = S->mean;
         first = (S->its == 0);
+        a = S->a;
+        pend = (x != nullptr && S->xa_it != S->xapplied);
     }
     template <int W>
     __device__ void apply(int64_t i, double (&)[1]) const
@@ -279,12 +280,28 @@ struct OpUpdateP {
             for (int k = 0; k < W; ++k) vp.v[k] = vz.v[k] - mean;
         } else {
             vp = ld<W>(p, i);
+            if (pend && i * W >= xlo && i * W < xhi) {
+                Pack<W> vx = ld<W>(x, i);
+#pragma unroll
+                for (int k = 0; k < W; ++k) vx.v[k] = vx.v[k] + a * vp.v[k];
+                st<W>(x, i, vx);
+            }
 #pragma unroll
             for (int k = 0; k < W; ++k) vp.v[k] = (vz.v[k] - mean) + bcoef * vp.v[k];
         }
         st<W>(p, i, vp);
     }
 };
+
+// the x update still owed when the iteration stops: x += a p
+__global__ __launch_bounds__(256) void k_flush_x(const Scalars *__restrict__ S, int64_t n, const double *__restrict__ p,
+                                                 double *__restrict__ x)
+{
+    if (S->xa_it == S->xapplied) return;
+    const double a = S->a;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = x[i] + a * p[i];
+}
+__global__ void k_flush_done(Scalars *S) { S->xapplied = S->xa_it; }
 
 struct OpCopy {
     static constexpr int NRED = 0;
@@ -384,6 +401,7 @@ __global__ void k_cg_s_init(Scalars *S, double *hist, double n_global, int lazy_
 
 __device__ __forceinline__ void cg_s1(Scalars *S)
 {
+    S->xapplied = S->xa_it;  // this iteration's p-update has applied what the previous one owed
     S->dpiold = S->dpi;
     const double dpi = S->red[6];
     S->dpi = dpi;
@@ -395,6 +413,7 @@ __device__ __forceinline__ void cg_s1(Scalars *S)
     }
     S->a = S->beta / dpi;
     S->betaold = S->beta;
+    S->xa_it += 1;  // x += a p is owed
 }
 __global__ void k_cg_s1(Scalars *S)
 {
@@ -573,19 +592,19 @@ static int matmult(pib_solver *s, double *p_owned, double *w, double *dot_part, 
 // updated first, their exchange runs on the communication stream while the rest of p is updated; the SpMV that
 // follows finds the halo fresh.
 template <class Op>
-static int update_p_and_exchange(pib_solver *s, int64_t n, const Op &up, double *P, hipStream_t q)
+static int update_p_and_exchange(pib_solver *s, int64_t n, const Op &up, double *P, hipStream_t q, bool vec2 = true)
 {
     const DeviceCsr &A = s->A;
     const bool split = s->comm.nranks > 1 && s->cfg.overlap_halo && (A.send_prev % 2 == 0) && (A.send_next % 2 == 0) &&
                        (n % 2 == 0) && A.send_prev + A.send_next < n;
-    if (!split) return launch_vec(s, n, up, true, 0, nullptr, true, q);
-    PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q, 0, A.send_prev));
-    PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q, n - A.send_next, n));
+    if (!split) return launch_vec(s, n, up, vec2, 0, nullptr, true, q);
+    PIB_CHK(launch_vec(s, n, up, vec2, 0, nullptr, true, q, 0, A.send_prev));
+    PIB_CHK(launch_vec(s, n, up, vec2, 0, nullptr, true, q, n - A.send_next, n));
     PIB_HIP(hipEventRecord(s->ev_ready, q));
     PIB_HIP(hipStreamWaitEvent(s->stream_comm, s->ev_ready, 0));
     PIB_CHK(halo_exchange(s, P, s->stream_comm));
     PIB_HIP(hipEventRecord(s->ev_halo, s->stream_comm));
-    PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q, A.send_prev, n - A.send_next));
+    PIB_CHK(launch_vec(s, n, up, vec2, 0, nullptr, true, q, A.send_prev, n - A.send_next));
     PIB_HIP(hipStreamWaitEvent(q, s->ev_halo, 0));
     s->halo_fresh = P;
     return 0;
@@ -664,6 +683,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     const int conv_is_its = monitor ? 0 : 1;
     const bool unprec = (s->cfg.norm == NormType::UNPRECONDITIONED);
     const bool v2 = aligned16(x) && aligned16(b);
+    const bool xal = aligned16(x);  // the p-update carries x += a p: paired accesses need x aligned like the work vectors
     if (pc == Precond::NONE) Z = R;  // z aliases r
     if (pc == Precond::JACOBI && A.dinv == nullptr) return fail(PIB_ERR_ORDER, "Jacobi preconditioner without a diagonal");
     if (gmg && !s->has_grid)
@@ -713,12 +733,13 @@ int solve_cg(pib_solver *s, double *x, const double *b)
             if (s->comm.nranks > 1 && zv > 0 && zv >= A.ghost_lo && zv >= A.ghost_hi) {
                 // the V-cycle left z valid on the ghost planes the matrix reaches: p = z + beta p there too (the ghost
                 // values of p follow the same recurrence as their owners'), and the product needs no exchange
-                OpUpdateP up{Z - A.ghost_lo, P - A.ghost_lo, 0.0, 0.0, 0};
-                PIB_CHK(launch_vec(s, n + A.ghost_lo + A.ghost_hi, up, (A.ghost_lo & 1) == 0, 0, nullptr, true, q));
+                const bool ev = (A.ghost_lo & 1) == 0 && (n & 1) == 0 && xal;
+                OpUpdateP up{Z - A.ghost_lo, P - A.ghost_lo, x - A.ghost_lo, A.ghost_lo, A.ghost_lo + n, 0.0, 0.0, 0.0, 0, 0};
+                PIB_CHK(launch_vec(s, n + A.ghost_lo + A.ghost_hi, up, ev, 0, nullptr, true, q));
                 s->halo_fresh = P;
             } else {
-                OpUpdateP up{Z, P, 0.0, 0.0, 0};
-                PIB_CHK(update_p_and_exchange(s, n, up, P, q));
+                OpUpdateP up{Z, P, x, 0, n, 0.0, 0.0, 0.0, 0, 0};
+                PIB_CHK(update_p_and_exchange(s, n, up, P, q, xal));
             }
             PIB_CHK(matmult(s, P, W, part_pw, true, q));
             if (s->comm.nranks == 1)
@@ -728,11 +749,11 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s);
             }
             if (pc == Precond::JACOBI) {
-                OpUpdateXR<PCM_JACOBI> op{P, W, A.dinv, x, R, Z, omega, 0.0};
-                PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, true, q));
+                OpUpdateXR<PCM_JACOBI> op{W, A.dinv, R, Z, omega, 0.0};
+                PIB_CHK(launch_vec(s, n, op, true, 0, &nb, true, q));
             } else {
-                OpUpdateXR<PCM_NONE> op{P, W, nullptr, x, R, Z, 1.0, 0.0};
-                PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, true, q));
+                OpUpdateXR<PCM_NONE> op{W, nullptr, R, Z, 1.0, 0.0};
+                PIB_CHK(launch_vec(s, n, op, true, 0, &nb, true, q));
             }
             PIB_CHK(finalize(s, 0, 6, nb, q));
             if (gmg) {
@@ -751,6 +772,11 @@ int solve_cg(pib_solver *s, double *x, const double *b)
         enq += todo;
         PIB_CHK(poll(s));
     }
+    // the x update the last iteration owes
+    hipLaunchKernelGGL(k_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
+                       s->d_s, n, P, x);
+    hipLaunchKernelGGL(k_flush_done, dim3(1), dim3(1), 0, q, s->d_s);
+    PIB_HIP(hipGetLastError());
     return fetch_results(s);
 }
 
@@ -1203,7 +1229,7 @@ extern "C" int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_av
             switch (which) {
                 case 0: PIB_CHK(spmv_rows(s, P, W, 0, n, nullptr, false, q)); break;
                 case 1: {
-                    OpUpdateXR<PCM_JACOBI> op{P, W, s->A.dinv, Z, R, Z, 1.0, 0.0};
+                    OpUpdateXR<PCM_JACOBI> op{W, s->A.dinv, R, Z, 1.0, 0.0};
                     // a = 0 from a zeroed Scalars copy is not guaranteed: use an unguarded launch with S = nullptr
                     // (prepare() needs S) -> use the guarded form; d_s->done must be 0.
                     PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));

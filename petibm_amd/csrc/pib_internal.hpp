@@ -78,6 +78,7 @@ struct Config {
     int use_graph = 1;       // capture the iteration body in a hipGraph (single GPU)
     int spmv_variant = 0;    // 0 LDS-transpose + tiled chunk order (default), 3 same in natural order, 1 entry-per-lane stream, 2 row-per-thread
     int overlap_halo = 1;
+    int overlap_min_bytes = 1 << 20;  // multigrid on slabs: a right-hand-side exchange of at least this size per neighbour runs on the communication stream behind the interior planes of its first consumer
     int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024 when the fine level has < 2^22 cells (the 2-D cases, launch-bound), off on large grids; 0: off.
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
@@ -115,6 +116,9 @@ struct Scalars {
     int done;     // != 0: all further kernels are no-ops
     int maxit;
     int normtype;  // 0 preconditioned 1 unpreconditioned
+    // CG: x += a p of iteration k is applied by the p-update of iteration k + 1 (one pass over p less); xa_it counts the
+    // updates owed, xapplied the ones the p-updates have made: they differ while one is pending (flushed after the loop)
+    int xa_it, xapplied;
     int pad;
 };
 

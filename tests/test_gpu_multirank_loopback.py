@@ -82,6 +82,9 @@ def _system(n, dt=0.01):
     (2, (128, 16, 64), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\nV22"),
     (4, (128, 16, 64), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\nV22"),
     (2, (128, 16, 64), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\n"),     # V(1,1): step + residual fused
+    # the right-hand-side exchange on the communication stream behind the interior planes of the fused pre-smoothing
+    (3, (128, 16, 96), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\npib_overlap_min_bytes=0\nV22"),
+    (4, (32, 32, 32), "AMG", "pib_agglomerate_below=100\npib_overlap_min_bytes=0\nV22"),
 ])
 def test_multirank_poisson_solve_matches_single_rank(P, n, pc, extra):
     sweeps = 2 if extra.endswith("V22") else 1
