@@ -153,6 +153,31 @@ def test_lid_driven_cavity_re100_matches_ghia():
     t.destroy()
 
 
+def test_baseline_config1_cavity_128_re100_matches_ghia():
+    """BASELINE config 1 as stated: the 2-D lid-driven cavity on 128 x 128 cells at Re = 100 (the reference's
+    liddrivencavity2dRe100 case -- nu = 0.01, dt = 0.01, CG + BiCGStab from its PETSc options files -- on the finer mesh),
+    2000 steps to t = 20; centre-line velocities against Ghia et al. (1982)."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    n = 128
+    cfg = cavity((n, n), nu=0.01, dt=0.01)
+    vel = ("-velocity_ksp_type bcgs\n-velocity_ksp_atol 1.0E-06\n-velocity_ksp_rtol 0.0\n-velocity_ksp_max_it 1000\n"
+           "-velocity_pc_type jacobi\n")
+    poi = ("-poisson_ksp_type cg\n-poisson_ksp_atol 1.0E-06\n-poisson_ksp_rtol 0.0\n-poisson_ksp_max_it 1000\n"
+           "-poisson_pc_type gamg\n")
+    s = NavierStokesSolver(cfg, velocity_cfg=vel, poisson_cfg=poi)
+    s.advance(2000)
+    U, p = s.getState()
+    u = U[: (n - 1) * n].reshape(n, n - 1)
+    v = U[(n - 1) * n:].reshape(n - 1, n)
+    yc = (np.arange(n) + 0.5) / n
+    g = G["ghia_1982_re100_u_centerline"]
+    ui = np.interp(g["y"][1:-1], yc, u[:, n // 2 - 1])
+    vi = np.interp(g["x"][1:-1], yc, v[n // 2 - 1, :])
+    assert np.abs(ui - np.array(g["u"][1:-1])).max() < 0.006
+    assert np.abs(vi - np.array(g["v"][1:-1])).max() < 0.01  # Ghia's tabulated v at Re = 100 is no better than this (32 x 32: 0.008)
+    s.destroy()
+
+
 def test_solution_grid_and_restart_files(tmp_path):
     """The reference's on-disk formats (PetscViewerHDF5): grid.h5 (cartesianmesh.cpp:798-823), <step>.h5 with u, v, p and the
     `time` attribute of /p (navierstokes.cpp:618-634), restart data /convection/<i>, /diffusion/0 (:637-746).  A run

@@ -103,6 +103,14 @@ def _ib_case(kind):
         return flow_config(cases.body_block(cells=(8, 16, 8), ratio=1.25, span=3.0, core=0.8)), [cases.circle(40, 0.5)], None
     if kind == "3d_sphere":
         return flow_config(cases.body_block(cells=(4, 10, 4), ratio=1.4, span=2.0, core=0.7, dim=3), nu=0.05), [sphere_points(50, 0.4)], None
+    if kind == "moving_sphere_3d":
+        cfg = flow_config(cases.body_block(cells=(4, 12, 4), ratio=1.4, span=2.0, core=0.8, dim=3), nu=0.05)
+        base3 = sphere_points(40, 0.3)
+
+        def pose3(t):
+            return base3 + np.array([0.0, 0.0, 0.2 * np.sin(2.0 * np.pi * t)]), np.tile([0.0, 0.0, 0.4 * np.pi * np.cos(2.0 * np.pi * t)], (40, 1))
+
+        return cfg, [base3], pose3
     # a cylinder oscillating in a closed box of fluid at rest (applications/rigidkinematics)
     cfg = cases.body_block(cells=(6, 20, 6), ratio=1.3, span=2.0, core=1.0)
     cfg["flow"]["nu"] = 0.02
@@ -117,7 +125,7 @@ def _ib_case(kind):
 
 
 @pytest.mark.parametrize("kind,P", [("2d_cylinder", 2), ("2d_cylinder", 3), ("3d_sphere", 2), ("moving_cylinder", 2),
-                                    ("moving_cylinder", 3)])
+                                    ("moving_cylinder", 3), ("moving_sphere_3d", 2), ("moving_sphere_3d", 4)])
 def test_immersed_bodies_on_slabs_reproduce_the_single_rank(kind, P):
     from petibm_amd.navierstokes import DecoupledIBPMSolver
     cfg, bodies, pose = _ib_case(kind)
@@ -157,3 +165,64 @@ def test_immersed_bodies_on_slabs_reproduce_the_single_rank(kind, P):
     for step in range(nsteps):
         assert all(np.array_equal(res[0][0][step][2], r[0][step][2]) for r in res[1:])
     one.destroy()
+
+
+def _three_block_axis(name, core, cells_core, cells_out, ratio):
+    """stretched / uniform / stretched with continuous widths (the layout of flatplate3dRe100AoA30_GPU/config.yaml:30-68)"""
+    h = 2.0 * core / cells_core
+    out = h * ratio * (ratio ** cells_out - 1.0) / (ratio - 1.0)
+    return {"direction": name, "start": -core - out,
+            "subDomains": [{"end": -core, "cells": cells_out, "stretchRatio": 1.0 / ratio},
+                           {"end": core, "cells": cells_core, "stretchRatio": 1.0},
+                           {"end": core + out, "cells": cells_out, "stretchRatio": ratio}]}
+
+
+def test_config5_heaving_plate_384x256x256_on_8_slabs():
+    """BASELINE config 5 at its size: a 384 x 256 x 256 mesh of three sub-domains per axis, a rigid body with prescribed
+    motion (a heaving plate, RigidKinematicsSolver: operators re-assembled and the force system re-factorised every step),
+    on 8 z-slabs -- through the loopback transport on the one test GPU -- against the single-rank engine on the same mesh:
+    velocity to 1e-8, forces to 1e-7 after two steps; every rank holds the same forces bit for bit."""
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    from test_gpu_ibm import flow_config
+    from petibm_amd import cases
+    cfg = cases.cavity((384, 256, 256), lid=0.0)
+    cfg["mesh"] = [_three_block_axis("x", 1.5, 192, 96, 1.04), _three_block_axis("y", 1.0, 128, 64, 1.04),
+                   _three_block_axis("z", 1.0, 128, 64, 1.04)]
+    cfg = flow_config(cfg, nu=0.01, dt=0.004)
+    h = 3.0 / 192
+    xs, zs = np.meshgrid(-0.25 + h * np.arange(24), -0.19 + h * np.arange(24), indexing="ij")
+    plate = np.stack([xs.ravel(), np.zeros(xs.size), zs.ravel()], axis=1)
+    amp, om, dt = 0.1, 2.0 * np.pi, cfg["parameters"]["dt"]
+
+    def pose(t):
+        x = plate + np.array([0.0, amp * np.sin(om * t), 0.0])
+        return x, np.tile([0.0, amp * om * np.cos(om * t), 0.0], (plate.shape[0], 1))
+
+    def run(s, n=2):
+        for step in range(1, n + 1):
+            x, v = pose(step * dt)
+            s.moveBodies([x], [v])
+            s.advance()
+        U, p = s.getState()
+        f, avg = s.getForces()
+        return U, f.copy(), avg.copy()
+
+    one = DecoupledIBPMSolver(cfg, bodies=[plate], velocity_cfg=VEL, poisson_cfg=KSP_P, forces_cfg=FORCES)
+    U1, f1, a1 = run(one)
+    one.destroy()
+    P = 8
+
+    def rank_fn(r, uid):
+        s = DecoupledIBPMSolver(cfg, bodies=[plate], velocity_cfg=VEL, poisson_cfg=KSP_P, forces_cfg=FORCES, device=0, rank=r,
+                                nranks=P, uid=uid)
+        U, f, a = run(s)
+        cU = s.ownedVelocity(U1)
+        s.destroy()
+        return U, f, a, cU
+
+    res = _run_ranks(P, rank_fn)
+    for U, f, a, cU in res:
+        assert np.abs(U - cU).max() <= 1e-8 * max(1.0, np.abs(cU).max())
+        assert np.abs(f - f1).max() <= 1e-7 * np.abs(f1).max()
+        assert np.array_equal(f, res[0][1])
+    assert np.abs(res[0][2] - a1).max() <= 1e-7 * np.abs(a1).max()
