@@ -220,6 +220,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.march_levels = std::atoi(d.get("default", "pib_march_levels", "1").c_str());
     c.march_min_cells = std::atoi(d.get("default", "pib_march_min_cells", "12582912").c_str());
     c.matrix_free_velocity = std::atoi(d.get("default", "pib_matrix_free_velocity", "1").c_str());
+    c.march_velocity = std::atoi(d.get("default", "pib_march_velocity", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
     c.detect_structure = std::atoi(d.get("default", "pib_detect_structure", "1").c_str());
@@ -327,6 +328,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_march_levels", v)) c.march_levels = std::atoi(v.c_str());
     if (get("pib_march_min_cells", v)) c.march_min_cells = std::atoi(v.c_str());
     if (get("pib_matrix_free_velocity", v)) c.matrix_free_velocity = std::atoi(v.c_str());
+    if (get("pib_march_velocity", v)) c.march_velocity = std::atoi(v.c_str());
     if (get("pib_matrix_free_poisson", v)) c.matrix_free_poisson = std::atoi(v.c_str());
     if (get("pib_agglomerate_below", v)) c.agglomerate_below = std::atoi(v.c_str());
     if (get("pib_detect_structure", v)) c.detect_structure = std::atoi(v.c_str());

@@ -387,6 +387,33 @@ def test_matrix_free_velocity_operator_is_the_csr_product(lin, case):
     assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][0], out[1][0])
 
 
+@pytest.mark.parametrize("n,per", [((128, 16, 24), (True, True, True)), ((128, 12, 10), (False, False, False)),
+                                   ((256, 19, 9), (False, True, False)), ((128, 8, 40), (True, False, True))])
+def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
+    """velstencil.hip k_vel_march (the LDS-tiled z-marching form of the matrix-free velocity product, components whose
+    grid lines are a multiple of 128 points): BiCGStab takes the iterates of the CSR products, bit for bit -- periodic box
+    (every component), wall-bounded mesh (the components across their own direction; partial tiles in y), mixed."""
+    from test_gpu_parity import _a0_table
+    cfg = omesh.periodic_config(n, per)
+    m = omesh.create_mesh(cfg)
+    dt, cnu = 0.004, 0.5 * 0.01
+    b = np.random.default_rng(5).uniform(-1, 1, m.UN)
+    out = []
+    for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\n", "pib_matrix_free_velocity=1\npib_march_velocity=0\n",
+                  "pib_matrix_free_velocity=0\n"):
+        s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-13, conv="ABSOLUTE",
+                                                              maxit=500, extra=extra))
+        s.setPeriodic(per)
+        s.assembleVelocity(list(n), [m.dL[3][d].true for d in range(m.dim)], m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
+        x = np.zeros(m.UN)
+        s.solve(x, b)
+        out.append((x, s.getIters(), s.getResidualHistory()))
+        s.destroy()
+    assert out[0][1] == out[1][1] == out[2][1] and out[0][1] >= 2
+    for o in out[1:]:
+        assert np.array_equal(out[0][2], o[2]) and np.array_equal(out[0][0], o[0])
+
+
 @pytest.mark.parametrize("n,per", [((128, 16, 24), (True, True, True)), ((128, 8, 40), (True, False, True)),
                                    ((256, 16, 18), (False, True, False))])
 def test_blocked_smoothers_on_periodic_levels(lin, n, per):
