@@ -249,6 +249,10 @@ __global__ __launch_bounds__(256) void k_vel_interior4(const Scalars *__restrict
 // k_vel_interior: bit-identical.  Components whose grid lines are a multiple of 128 points on a 32-byte boundary (every
 // component of a periodic box, the components across their own direction of a wall-bounded one); 3-D.
 constexpr int VX = 128, VY = 8, VSX = VX + 2, VSY = VY + 2;
+// V4: a thread's four cells are consecutive (aligned 32-byte accesses; grid lines a multiple of 128 points on a 32-byte
+// boundary).  Otherwise they are 32 cells apart (lane-consecutive 8-byte accesses, any line length and alignment: the
+// 255-point lines of a wall-bounded component along its own direction; the last tile of a line is partial).
+template <bool V4>
 __global__ __launch_bounds__(256) void k_vel_march(const Scalars *__restrict__ S, VelDev V, int f, const double *__restrict__ x,
                                                    double *__restrict__ y, int MZ)
 {
@@ -260,33 +264,56 @@ __global__ __launch_bounds__(256) void k_vel_march(const Scalars *__restrict__ S
     const int i0 = blockIdx.x * VX, j0 = blockIdx.y * VY;
     const int k0 = 1 + blockIdx.z * MZ, kend = min(k0 + MZ, nz - 1);  // interior planes [1, nz - 1)
     const int64_t sy = nx, sz = (int64_t)nx * ny;
-    const int j = j0 + ty, ic = i0 + 4 * tx;
-    const int jc = min(j, ny - 1);  // a partial tile's rows beyond the component are clamped for the loads, never stored
+    const int j = j0 + ty;
+    const int jc = min(j, ny - 1);  // a partial tile's rows / cells beyond the component are clamped for the loads, never stored
+    int ci[4], lx[4];               // global index (clamped) and LDS column of the thread's cells
+    bool cin[4];                    // interior cell of the line
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int t = V4 ? 4 * tx + c : tx + 32 * c;
+        lx[c] = t + 1;
+        cin[c] = i0 + t >= 1 && i0 + t <= nx - 2;
+        ci[c] = min(i0 + t, nx - 1);
+    }
     const int hy_row = (tid < 128) ? -1 : VY, hy_x = tid & 127;
     const int hx_col = (tid & 1) ? VX : -1, hx_y = (tid >> 1) & 7;
     const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = min(j0 + hx_y, ny - 1), hxi = i0 + hx_col;
-    const bool hy_ok = hyj >= 0 && hyj < ny, hx_ok = tid < 16 && hxi >= 0 && hxi < nx;
+    const bool hy_ok = hyj >= 0 && hyj < ny && hyi < nx, hx_ok = tid < 16 && hxi >= 0 && hxi < nx;
     const int64_t base = V.off[f];
-    const int64_t off_c = base + (int64_t)jc * sy + ic, off_hy = base + (int64_t)hyj * sy + hyi, off_hx = base + (int64_t)hxj * sy + hxi;
+    const int64_t row = base + (int64_t)jc * sy, off_hy = base + (int64_t)hyj * sy + hyi, off_hx = base + (int64_t)hxj * sy + hxi;
     const bool jin = j >= 1 && j <= ny - 2;
     const double yneg = V.lneg[f][1][jc], ypos = V.lpos[f][1][jc];
-    const v4 vn = *reinterpret_cast<const v4 *>(V.lneg[f][0] + ic), vp = *reinterpret_cast<const v4 *>(V.lpos[f][0] + ic);
-    v4 zm = *reinterpret_cast<const v4 *>(x + off_c + (int64_t)(k0 - 1) * sz);
-    v4 xc = *reinterpret_cast<const v4 *>(x + off_c + (int64_t)k0 * sz), zp;
+    double vn[4], vp[4], zm[4], xc[4], zp[4];
+    auto load4 = [&](const double *pl, double (&o)[4]) {
+        if (V4) {
+            const v4 t = *reinterpret_cast<const v4 *>(pl + row + ci[0]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = t[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = pl[row + ci[c]];
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        vn[c] = V.lneg[f][0][ci[c]];
+        vp[c] = V.lpos[f][0][ci[c]];
+    }
+    load4(x + (int64_t)(k0 - 1) * sz, zm);
+    load4(x + (int64_t)k0 * sz, xc);
     for (int k = k0; k < kend; ++k) {
         const int slot = k & 1;
         const double *px = x + (int64_t)k * sz;
-        zp = *reinterpret_cast<const v4 *>(px + sz + off_c);
+        load4(px + sz, zp);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
+        for (int c = 0; c < 4; ++c) sp[slot][ty + 1][lx[c]] = xc[c];
         sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? px[off_hy] : 0.0;
         if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? px[off_hx] : 0.0;
         __syncthreads();
         const double zneg = V.lneg[f][2][k], zpos = V.lpos[f][2][k];
-        v4 out;
+        double out[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int lx = 4 * tx + 1 + c;
             const double xneg = vn[c], xpos = vp[c];
             double acc = 0.0;
             acc = acc + xneg;
@@ -299,26 +326,32 @@ __global__ __launch_bounds__(256) void k_vel_march(const Scalars *__restrict__ S
             const double dval = diag * V.scale + V.shift;
             double s2 = 0.0;
             s2 = s2 + (zneg * V.scale) * zm[c];
-            s2 = s2 + (yneg * V.scale) * sp[slot][ty][lx];
-            s2 = s2 + (xneg * V.scale) * sp[slot][ty + 1][lx - 1];
+            s2 = s2 + (yneg * V.scale) * sp[slot][ty][lx[c]];
+            s2 = s2 + (xneg * V.scale) * sp[slot][ty + 1][lx[c] - 1];
             s2 = s2 + dval * xc[c];
-            s2 = s2 + (xpos * V.scale) * sp[slot][ty + 1][lx + 1];
-            s2 = s2 + (ypos * V.scale) * sp[slot][ty + 2][lx];
+            s2 = s2 + (xpos * V.scale) * sp[slot][ty + 1][lx[c] + 1];
+            s2 = s2 + (ypos * V.scale) * sp[slot][ty + 2][lx[c]];
             s2 = s2 + (zpos * V.scale) * zp[c];
             out[c] = s2;
         }
         if (jin) {
-            double *py = y + (int64_t)k * sz + off_c;
-            if (ic > 0 && ic + 4 < nx)
-                *reinterpret_cast<v4 *>(py) = out;
-            else {
+            double *py = y + (int64_t)k * sz + row;
+            if (V4 && cin[0] && cin[3]) {
+                v4 t;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[c] = out[c];
+                *reinterpret_cast<v4 *>(py + ci[0]) = t;
+            } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (ic + c >= 1 && ic + c <= nx - 2) py[c] = out[c];
+                    if (cin[c]) py[ci[c]] = out[c];
             }
         }
-        zm = xc;
-        xc = zp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            zm[c] = xc[c];
+            xc[c] = zp[c];
+        }
     }
 }
 
@@ -340,10 +373,11 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
         if (inner) {
             const bool vec4 = nx % 4 == 0 && h.off[f] % 4 == 0 &&
                               ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31u) == 0;
-            if (vec4 && h.dim == 3 && nx % VX == 0 && s->cfg.march_velocity && nx * ny * nz >= std::min<int64_t>(s->cfg.march_min_cells, (int64_t)1 << 22)) {
+            if (h.dim == 3 && s->cfg.march_velocity && nx >= VX - 1 && nx * ny * nz >= std::min<int64_t>(s->cfg.march_min_cells, (int64_t)1 << 22)) {
                 const int MZ = 16;
-                hipLaunchKernelGGL(k_vel_march, dim3((unsigned)(nx / VX), (unsigned)((ny + VY - 1) / VY), (unsigned)((nz - 2 + MZ - 1) / MZ)),
-                                   dim3(256), 0, q, S, V, f, x, y, MZ);
+                const dim3 grid((unsigned)((nx + VX - 1) / VX), (unsigned)((ny + VY - 1) / VY), (unsigned)((nz - 2 + MZ - 1) / MZ));
+                if (vec4 && nx % VX == 0) hipLaunchKernelGGL(k_vel_march<true>, grid, dim3(256), 0, q, S, V, f, x, y, MZ);
+                else hipLaunchKernelGGL(k_vel_march<false>, grid, dim3(256), 0, q, S, V, f, x, y, MZ);
             } else if (vec4) {
                 const dim3 grid((unsigned)((nx / 4 + 63) / 64), (unsigned)((ny - 2 + 3) / 4), (unsigned)(h.dim == 3 ? nz - 2 : 1));
                 if (h.dim == 3) hipLaunchKernelGGL(k_vel_interior4<3>, grid, dim3(64, 4), 0, q, S, V, f, x, y);
