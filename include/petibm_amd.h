@@ -265,8 +265,10 @@ int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, co
  * of the projected velocity.  pib_ns_sizes / pib_ns_set_state / pib_ns_get_state / the history terms then speak of this
  * rank's part of the distributed vectors: the packed [u-slab | v-slab | w-slab] of the reference's DMComposite
  * (cartesianmesh.cpp:740-779; the component along the slab axis has one plane fewer, on the last rank) and the owned
- * pressure cells.  Every rank needs >= 2 planes.  Not on slabs: immersed bodies, BN order > 1, a periodic slab axis,
- * the vorticity utility (PIB_ERR_SUP). */
+ * pressure cells.  Every rank needs >= 2 planes.  Immersed bodies (pib_ns_set_bodies / pib_ns_move_bodies, collective,
+ * the same bodies on every rank; direct forces solver): every rank assembles the operators on the velocity points it
+ * owns, E u and the force system E BN H are summed over the ranks, the forces are replicated.  Not on slabs: BN order
+ * > 1, a periodic slab axis, the coupled IBPM, the vorticity utility (PIB_ERR_SUP). */
 int pib_ns_create_slab(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                        const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
                        double nu, const char *velocity_cfg, const char *poisson_cfg, int rank, int nranks,
