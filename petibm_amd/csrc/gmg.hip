@@ -247,6 +247,22 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
         if (MODE == 5 || MODE == 6) *reinterpret_cast<vt *>(dvec + p) = dv;
         *reinterpret_cast<vt *>(xo + p) = out;
     }
+    if (MODE == 0 && part != nullptr) {
+        // one partial per workgroup; the slots up to part_stride that no workgroup owns are zeroed (the consumer sums a
+        // fixed number of them)
+        __shared__ double sh0[4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc0 += __shfl_down(acc0, o, 64);
+        if (lane == 0) sh0[w] = acc0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int64_t nwg = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            part[blk] = (sh0[0] + sh0[1]) + (sh0[2] + sh0[3]);
+            for (int64_t e = blk + nwg; e < part_stride; e += nwg) part[e] = 0.0;
+        }
+    }
     if (MODE == 8) {
         __shared__ double sh[3][4];
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -431,9 +447,10 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
         const double *px = xi + (int64_t)lk * plane;
         if (kk + 1 < L.nzg) zp = *reinterpret_cast<const v4 *>(px + plane + off_c);
         else if (pz) zp = *reinterpret_cast<const v4 *>(xi + off_c);
-        v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)lk * plane + off_c);
+        v4 bv = {0, 0, 0, 0};
+        if (MODE != 0) bv = *reinterpret_cast<const v4 *>(b + (int64_t)lk * plane + off_c);
         const v4 braw = bv;
-        if (pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
+        if (MODE != 0 && pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
 #pragma unroll
         for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
         sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? px[off_hy] : 0.0;
@@ -453,7 +470,10 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
             sum += q.cyp * (sp[slot][ty + 2][lx] - xcc);
             sum += czm * (zm[c] - xcc);
             sum += czp * (zp[c] - xcc);
-            if (MODE == 3)
+            if (MODE == 0) {  // y = A x (the Krylov product of the stencil twin), x.y over the owned planes on request
+                out[c] = (sum * q.vxy) * wzk;
+                if (part != nullptr && lk >= dlo && lk < dhi) acc0 += out[c] * xcc;
+            } else if (MODE == 3)
                 out[c] = bv[c] - (sum * q.vxy) * wzk;
             else {
                 out[c] = xcc + omega * ((((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
@@ -467,6 +487,22 @@ __global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__
         *reinterpret_cast<v4 *>(xo + (int64_t)lk * plane + off_c) = out;
         zm = xc;
         xc = zp;
+    }
+    if (MODE == 0 && part != nullptr) {
+        // one partial per workgroup; the slots up to part_stride that no workgroup owns are zeroed (the consumer sums a
+        // fixed number of them)
+        __shared__ double sh0[4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc0 += __shfl_down(acc0, o, 64);
+        if (lane == 0) sh0[w] = acc0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int64_t nwg = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            part[blk] = (sh0[0] + sh0[1]) + (sh0[2] + sh0[3]);
+            for (int64_t e = blk + nwg; e < part_stride; e += nwg) part[e] = 0.0;
+        }
     }
     if (MODE == 8) {
         __shared__ double sh[3][4];
@@ -638,18 +674,25 @@ struct PHalo {
     int r0, r1, lx, lxo;
     double wj0, wj1, wa, wb;
 };
-__device__ __forceinline__ PHalo phalo(const LevelDev &F, int i, int j, int I0, int J0)
+// row of coarse row J in a tile that starts at coarse row J0 - 1: a row across the periodic seam sits at the tile's edge
+__device__ __forceinline__ int ptile_row(int J, int J0, int ncy)
+{
+    const int r = J - J0 + 1;
+    return r < 0 ? r + ncy : (r >= PCY ? r - ncy : r);
+}
+// i: the cell's position (-1 and nx are the cells across a periodic seam), iw / j: its indices in the tables
+__device__ __forceinline__ PHalo phalo(const LevelDev &F, int ncx, int ncy, int i, int iw, int j, int I0, int J0)
 {
     PHalo h;
     int J[2];
     double wj[2];
     tr1d(F.t[1], j, J, wj);
-    h.r0 = J[0] - J0 + 1;
-    h.r1 = J[1] - J0 + 1;
+    h.r0 = ptile_row(J[0], J0, ncy);
+    h.r1 = ptile_row(J[1], J0, ncy);
     h.wj0 = wj[0];
     h.wj1 = wj[1];
     const int I = i >> 1;
-    const double4 pw = F.tx.pw[I];
+    const double4 pw = F.tx.pw[iw >> 1];
     const bool right = i & 1;
     h.lx = I - I0 + 1;
     h.lxo = right ? h.lx + 1 : h.lx - 1;
@@ -685,9 +728,15 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
     const int j = j0 + ty, ic = i0 + 4 * tx;
     const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
     const int hx_col = (tid & 1) ? FX : -1, hx_y = (tid >> 1) & 7;
+    // periodic directions (operator and transfers alike: the caller checks per == tper): the cells beyond the domain are
+    // the ones across the seam; a periodic z has the whole level here, plane -1 is plane nz - 1 and coarse plane -1 is
+    // coarse plane nzc - 1 (planes are counted through the seam below, `zw` / `Kw` give their place in memory)
+    const bool px = F.per & 1, py = F.per & 2, pz = F.per & 4;
     const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
-    const bool hy_ok = hyj >= 0 && hyj < F.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < F.nx;
-    const int64_t off_c = (int64_t)j * F.nx + ic, off_hy = (int64_t)hyj * F.nx + hyi, off_hx = (int64_t)hxj * F.nx + hxi;
+    const int hyjw = py ? (hyj < 0 ? F.ny - 1 : (hyj >= F.ny ? 0 : hyj)) : hyj;
+    const int hxiw = px ? (hxi < 0 ? F.nx - 1 : (hxi >= F.nx ? 0 : hxi)) : hxi;
+    const bool hy_ok = hyjw >= 0 && hyjw < F.ny, hx_ok = tid < 16 && hxiw >= 0 && hxiw < F.nx;
+    const int64_t off_c = (int64_t)j * F.nx + ic, off_hy = (int64_t)hyjw * F.nx + hyi, off_hx = (int64_t)hxj * F.nx + hxiw;
     FCell q4[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) q4[c] = fcell(F, ic + c, j);
@@ -698,19 +747,23 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
     {
         int J[2];
         tr1d(F.t[1], j, J, wjv);
-        rr[0] = J[0] - J0 + 1;
-        rr[1] = J[1] - J0 + 1;
+        rr[0] = ptile_row(J[0], J0, C.ny);
+        rr[1] = ptile_row(J[1], J0, C.ny);
     }
     PHalo hy = {}, hx = {};
-    if (hy_ok) hy = phalo(F, hyi, hyj, I0, J0);
-    if (hx_ok) hx = phalo(F, hxi, hxj, I0, J0);
+    if (hy_ok) hy = phalo(F, C.nx, C.ny, hyi, hyi, hyjw, I0, J0);
+    if (hx_ok) hx = phalo(F, C.nx, C.ny, hxi, hxiw, hxj, I0, J0);
+    auto zw = [&](int k) { return pz ? (k < 0 ? k + F.nzg : (k >= F.nzg ? k - F.nzg : k)) : k; };
     // coarse plane K (tile + one cell around it, zero outside the domain) into its ring slot
     auto stage = [&](int K) {
-        const double *pc = xc + (int64_t)K * cplane;
-        double *dst = &cs[K % 3][0][0];
+        const int Kw = pz ? (K < 0 ? K + C.nzg : (K >= C.nzg ? K - C.nzg : K)) : K;
+        const double *pc = xc + (int64_t)Kw * cplane;
+        double *dst = &cs[(K + 3) % 3][0][0];
         for (int e = tid; e < PCX * PCY; e += 256) {
             const int row = e / PCX, cx = e - row * PCX;
-            const int I = I0 - 1 + cx, J = J0 - 1 + row;
+            int I = I0 - 1 + cx, J = J0 - 1 + row;
+            if (px) I = I < 0 ? I + C.nx : (I >= C.nx ? I - C.nx : I);
+            if (py) J = J < 0 ? J + C.ny : (J >= C.ny ? J - C.ny : J);
             dst[e] = (I >= 0 && I < C.nx && J >= 0 && J < C.ny) ? pc[(int64_t)J * C.nx + I] : 0.0;
         }
     };
@@ -721,21 +774,26 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
     };
     auto fetch = [&](int k, bool halo) -> Old {
         Old o;
-        const double *px = xi + (int64_t)k * plane;
-        o.c = *reinterpret_cast<const v4 *>(px + off_c);
-        o.hy = (halo && hy_ok) ? px[off_hy] : 0.0;
-        o.hx = (halo && hx_ok) ? px[off_hx] : 0.0;
+        const double *pl = xi + (int64_t)zw(k) * plane;
+        o.c = *reinterpret_cast<const v4 *>(pl + off_c);
+        o.hy = (halo && hy_ok) ? pl[off_hy] : 0.0;
+        o.hx = (halo && hx_ok) ? pl[off_hx] : 0.0;
         return o;
     };
     // x + P e on plane k: the own cells (returned) and, with `halo`, the tile's halo cells -> LDS slot
     auto correct = [&](int k, bool halo, const Old &o) -> v4 {
         int K[2];
         double wk[2];
-        tr1d(F.t[2], k, K, wk);
+        tr1d(F.t[2], zw(k), K, wk);
+        if (pz) {  // the tables hold the planes' places in memory: count them through the seam like k
+            const int Kc = k >> 1;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) K[c2] = K[c2] > Kc + 1 ? K[c2] - C.nzg : (K[c2] < Kc - 1 ? K[c2] + C.nzg : K[c2]);
+        }
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, sy = 0.0, sx = 0.0;
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
-            const double(*cp)[PCX] = cs[K[c2] % 3];
+            const double(*cp)[PCX] = cs[(K[c2] + 3) % 3];
 #pragma unroll
             for (int b2 = 0; b2 < 2; ++b2) {
                 const double w = wk[c2] * wjv[b2];
@@ -781,25 +839,25 @@ __global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restric
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     // prologue: the coarse planes under l0 - 1 and l0 (K0 - 1 and K0 for an even l0 = 2 K0, K0 - 1 .. K0 + 1 for an odd
     // l0 = 2 K0 + 1: three distinct ring slots), then those two corrected planes
-    for (int K = max((l0 - 2) >> 1, 0); K <= min((l0 + 1) >> 1, C.nzg - 1); ++K) stage(K);
+    for (int K = pz ? (l0 - 2) >> 1 : max((l0 - 2) >> 1, 0); K <= (pz ? (l0 + 1) >> 1 : min((l0 + 1) >> 1, C.nzg - 1)); ++K) stage(K);
     v4 zm = {0, 0, 0, 0}, xcur, zp = {0, 0, 0, 0};
     Old om = {}, o0 = fetch(l0, true), on = {};
-    if (l0 > 0) om = fetch(l0 - 1, false);
-    if (l0 + 1 < F.nzg) on = fetch(l0 + 1, l0 + 1 < lend);
+    if (l0 > 0 || pz) om = fetch(l0 - 1, false);
+    if (l0 + 1 < F.nzg || pz) on = fetch(l0 + 1, l0 + 1 < lend);
     v4 bc = *reinterpret_cast<const v4 *>(b + (int64_t)l0 * plane + off_c), bn = {0, 0, 0, 0};
     __syncthreads();
-    if (l0 > 0) zm = correct(l0 - 1, false, om);
+    if (l0 > 0 || pz) zm = correct(l0 - 1, false, om);
     xcur = correct(l0, true, o0);
     for (int lk = l0; lk < lend; ++lk) {
         const int slot = lk & 1;
         const int kn = lk + 1;
         // loads for the next step go out before the barrier: the old iterate two planes ahead, b one plane ahead
         Old o2 = {};
-        if (kn + 1 < F.nzg && kn < lend) o2 = fetch(kn + 1, kn + 1 < lend);
+        if ((kn + 1 < F.nzg || pz) && kn < lend) o2 = fetch(kn + 1, kn + 1 < lend);
         if (kn < lend) bn = *reinterpret_cast<const v4 *>(b + (int64_t)kn * plane + off_c);
-        if ((kn & 1) && kn < F.nzg && (kn + 1) / 2 < C.nzg) stage((kn + 1) / 2);  // an odd plane reaches up to the next coarse plane
+        if ((kn & 1) && kn < F.nzg && ((kn + 1) / 2 < C.nzg || pz)) stage((kn + 1) / 2);  // an odd plane reaches up to the next coarse plane
         __syncthreads();
-        if (kn < F.nzg) zp = correct(kn, kn < lend, on);
+        if (kn < F.nzg || pz) zp = correct(kn, kn < lend, on);
         v4 bv = bc;
         const v4 braw = bc;
         if (pin_sum != nullptr && lk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
@@ -962,11 +1020,14 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
     const int I = blockIdx.x * (RX / 2) + lane, J = blockIdx.y * (RY / 2) + 2 * tw;  // coarse cells (I, J) and (I, J + 1)
     const int KA = C.k0 + blockIdx.z * CZ, KB = min(KA + CZ, C.k0 + C.nk);          // coarse planes [KA, KB) (global)
     const double4 rw = F.tx.rw[I];
+    // transfers that reach across a periodic seam (F.tper): the tile's cells beyond the domain are the ones at the other
+    // end (whole aligned pieces: nx % 128 == 0), plane -1 is plane nz - 1 (the whole level is here then)
+    const bool wx = F.tper & 1, wy = F.tper & 2, wz = F.tper & 4;
     double wj[2][4];
     {
         int sj[4];
-        rs1d4(F.t[1], J, F.ny, false, wj[0], sj);
-        rs1d4(F.t[1], J + 1, F.ny, false, wj[1], sj);
+        rs1d4(F.t[1], J, F.ny, wy, wj[0], sj);
+        rs1d4(F.t[1], J + 1, F.ny, wy, wj[1], sj);
     }
     const int64_t fplane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
     // this thread's share of a plane's tile: up to three aligned 4-cell pieces (zero outside the domain)
@@ -976,7 +1037,9 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
         const int idx = tid + 256 * e, row = idx / (RSX / 4), cx = idx - row * (RSX / 4);
-        const int gi = i0 - 4 + 4 * cx, gj = j0 - 1 + row;
+        int gi = i0 - 4 + 4 * cx, gj = j0 - 1 + row;
+        if (wx) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
+        if (wy) gj = gj < 0 ? gj + F.ny : (gj >= F.ny ? gj - F.ny : gj);
         ok[e] = idx < RV4 && gi >= 0 && gi < F.nx && gj >= 0 && gj < F.ny;
         goff[e] = (int64_t)gj * F.nx + gi;
         loff[e] = idx < RV4 ? row * RSX + 4 * cx : -1;
@@ -985,14 +1048,16 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
     const v4 zero = {0, 0, 0, 0};
     v4 pre[3] = {zero, zero, zero};
     auto fetch = [&](int kf) {
+        if (wz) kf = kf < 0 ? kf + F.nzg : (kf >= F.nzg ? kf - F.nzg : kf);
         const double *pf = rf + (int64_t)(kf - F.k0) * fplane;
 #pragma unroll
         for (int e = 0; e < 3; ++e) pre[e] = ok[e] ? *reinterpret_cast<const v4 *>(pf + goff[e]) : zero;
     };
-    if (kf0 >= 0) fetch(kf0);
+    if (kf0 >= 0 || wz) fetch(kf0);
     double lo[2] = {0.0, 0.0}, hi[2] = {0.0, 0.0};
     for (int kf = kf0; kf <= kf1; ++kf) {
-        const bool inz = kf >= 0 && kf < F.nzg;
+        const bool inz = wz || (kf >= 0 && kf < F.nzg);
+        const int kfw = wz ? (kf < 0 ? kf + F.nzg : (kf >= F.nzg ? kf - F.nzg : kf)) : kf;  // the plane's index in the tables
         const int slot = kf & 1;
         if (inz) {
             double *dst = &sp[slot][0][0];
@@ -1001,12 +1066,12 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
                 if (loff[e] >= 0) *reinterpret_cast<v4 *>(dst + loff[e]) = pre[e];
         }
         __syncthreads();
-        if (kf + 1 <= kf1 && kf + 1 < F.nzg) fetch(kf + 1);
+        if (kf + 1 <= kf1 && (kf + 1 < F.nzg || wz)) fetch(kf + 1);
         const bool odd = kf & 1;
         const int Khi = odd ? (kf + 1) / 2 : kf / 2, Klo = Khi - 1;  // kf is slot 0 / 1 of Khi and slot 2 / 3 of Klo
         if (inz) {
             const bool dohi = Khi >= KA && Khi < KB, dolo = Klo >= KA && Klo < KB;
-            const double wkhi = dohi ? rz_weight(F.t[2], kf, Khi) : 0.0, wklo = dolo ? rz_weight(F.t[2], kf, Klo) : 0.0;
+            const double wkhi = dohi ? rz_weight(F.t[2], kfw, Khi) : 0.0, wklo = dolo ? rz_weight(F.t[2], kfw, Klo) : 0.0;
             // the six fine rows of the two coarse rows
             double vl[6], c0[6], c1[6], vr[6];
 #pragma unroll
@@ -1373,7 +1438,9 @@ static int launch_restrict(const pib_solver *s, const GridLevel &f, const GridLe
                            hipStream_t q)
 {
     const int64_t nkc = c.k1 - c.k0;
-    if (s->cfg.march_restrict && f.plain_pair && f.per == 0 && f.tper == 0 && f.n[0] % RX == 0 && f.n[1] % RY == 0 && nkc >= 4 &&
+    // transfers across a periodic z seam: the whole fine level is on this rank (the slab axis of a distributed level never wraps)
+    const bool z_ok = !(f.tper & 4) || (f.k0 == 0 && f.k1 == f.n[2]);
+    if (s->cfg.march_restrict && f.plain_pair && z_ok && f.n[0] % RX == 0 && f.n[1] % RY == 0 && nkc >= 4 &&
         nkc * c.plane * 8 >= (int64_t)s->cfg.march_min_cells) {
         // coarse planes per workgroup: 32 on a 512^3 fine level (1024 workgroups), 8 below
         const int CZ = nkc * c.plane >= ((int64_t)1 << 23) ? 32 : 8;
@@ -2218,7 +2285,9 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         const bool dots_l = l == 0 && s->gmg_want_dots && !cheb;
         // prolongation + first post-smoothing step in one march (the corrected iterate never goes to HBM)
         bool fused = false;
-        if (s->cfg.fuse_prolong && !cheb && post >= 1 && g.plain_pair && g.per == 0 && g.tper == 0 && (!I.dist || e >= 1)) {
+        // periodic levels: operator and transfers wrap alike, z with >= 8 planes (the ring of coarse planes counts through the seam)
+        const bool per_ok = g.per == g.tper && (!(g.per & 4) || g.n[2] >= 8);
+        if (s->cfg.fuse_prolong && !cheb && post >= 1 && g.plain_pair && per_ok && (!I.dist || e >= 1)) {
             const int o = I.dist ? std::min(std::min(e - 1, fin + post - 1), valid(b)) : 0;
             int64_t ka, kc;
             run(l, o, ka, kc);
@@ -2318,8 +2387,25 @@ bool stencil_matmult_ok(const pib_solver *s)
 int stencil_matmult(pib_solver *s, const double *x, double *y, double *dot_part, bool guarded, hipStream_t q)
 {
     const GridLevel &g = s->levels[0];
-    PIB_CHK(launch_level<0>(s, g, 0.0, nullptr, x, y, nullptr, guarded, q));
     const Scalars *S = guarded ? s->d_s : nullptr;
+    // the LDS-tiled march reads x once (the streaming kernel leans on the caches for the six neighbours) and leaves the
+    // x.y partials as it goes; x[0] = 0 under a pinned pressure, so the identity row patched below adds nothing to x.y
+    const int64_t nk = g.k1 - g.k0;
+    const int FZ = march_planes(g, nk);
+    const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((nk + FZ - 1) / FZ));
+    const bool march = s->cfg.march_levels && g.dim == 3 && march_run_ok(s, g, 0, nk) &&
+                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31u) == 0 &&
+                       (int64_t)mg.x * mg.y * mg.z <= spmv_launch_blocks();
+    if (march) {
+        hipLaunchKernelGGL((k_level_march<0>), mg, dim3(256), 0, q, S, dev_of(g), 0.0, (const double *)nullptr, x, y,
+                           (const double *)nullptr, dot_part, spmv_launch_blocks(), FZ, 0, (int)nk);
+        PIB_HIP(hipGetLastError());
+        if (s->nullspace == PIB_NULLSPACE_PINNED) hipLaunchKernelGGL(k_twin_row0, dim3(1), dim3(64), 0, q, S, x, y);
+        PIB_HIP(hipGetLastError());
+        s->counters[0]++;
+        return 0;
+    }
+    PIB_CHK(launch_level<0>(s, g, 0.0, nullptr, x, y, nullptr, guarded, q));
     if (s->nullspace == PIB_NULLSPACE_PINNED) hipLaunchKernelGGL(k_twin_row0, dim3(1), dim3(64), 0, q, S, x, y);
     if (dot_part) hipLaunchKernelGGL(k_twin_dot, dim3((unsigned)spmv_launch_blocks()), dim3(256), 0, q, S, s->A.n, x, y, dot_part);
     PIB_HIP(hipGetLastError());

@@ -414,6 +414,39 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
         assert np.array_equal(out[0][2], o[2]) and np.array_equal(out[0][0], o[0])
 
 
+@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
+@pytest.mark.parametrize("n,per,ratios", [((128, 32, 24), (True, True, True), None), ((256, 16, 40), (True, False, True), (1.0, 1.01, 1.0)),
+                                          ((128, 16, 34), (False, True, False), (1.002, 1.0, 0.99)),
+                                          ((128, 16, 8), (False, False, True), (1.002, 1.01, 1.0))])
+def test_marching_transfers_on_periodic_levels_are_bit_identical(lin, n, per, ratios, key, sweeps):
+    """gmg.hip k_restrict_march / k_prolong_smooth where the transfers reach across a periodic seam (the tile's cells
+    beyond the domain are the ones at the other end, plane -1 is plane nz - 1, coarse plane -1 is coarse plane nzc - 1):
+    the same sums in the same order as the row kernels, so the whole solve is bit-identical with them switched off; the
+    all-periodic case is the Taylor-Green box of examples/navierstokes/taylorgreenvortex3dRe1600_GPU."""
+    from petibm_amd import capi
+    dt = 0.01
+    cfg = omesh.periodic_config(n, per, ratios=ratios)
+    m = omesh.create_mesh(cfg)
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    xs, b = rhs_for(A)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    out = []
+    for march in (1, 0):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
+        s.setPeriodic(per)
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        out.append((x, s.getResidualHistory(), s.getIters()))
+        s.destroy()
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    g = clib.GMG(n, w, dt, nullspace=1, pre=sweeps, post=sweeps, omega=0.9, coarsest_sweeps=32, periodic=per)
+    ref = g.pcg(A, b, rtol=1e-10, maxit=200)
+    assert iters_close(out[0][2], ref["iters"])
+    assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
+
+
 @pytest.mark.parametrize("n,per", [((128, 16, 24), (True, True, True)), ((128, 8, 40), (True, False, True)),
                                    ((256, 16, 18), (False, True, False))])
 def test_blocked_smoothers_on_periodic_levels(lin, n, per):
