@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--nt", type=int, default=None)
     ap.add_argument("--every", type=int, default=100)
     ap.add_argument("--dt", type=float, default=None, help="time step (the case's 0.01 is the 256^3 one: CFL 0.4; halve it at 512^3)")
+    ap.add_argument("--poisson-extra", default="", help="lines appended to the Poisson solver's configuration (';' separated)")
+    ap.add_argument("--velocity-extra", default="", help="lines appended to the velocity solver's configuration (';' separated)")
     a = ap.parse_args()
     d = os.path.join(ROOT, "examples", "cases", "taylorgreenvortex3dRe1600")
     cfg = yaml.safe_load(open(os.path.join(d, "config.yaml")))
@@ -46,6 +48,8 @@ def main():
         cfg["parameters"]["dt"] = a.dt
     nt = a.nt if a.nt is not None else int(cfg["parameters"]["nt"])
     texts = {k: open(os.path.join(d, cfg["parameters"][k]["config"])).read() for k in ("velocitySolver", "poissonSolver")}
+    texts["poissonSolver"] += "".join(ln + "\n" for ln in a.poisson_extra.split(";") if ln)
+    texts["velocitySolver"] += "".join(ln + "\n" for ln in a.velocity_extra.split(";") if ln)
     ref = {round(r[0], 6): r[1] for r in json.load(open(os.path.join(ROOT, "tests", "golden", "reference_test_vectors.json")))[
         "taylor_green_vortex_3d_re1600_spectral_512"]["rows"]}
     t0 = time.perf_counter()

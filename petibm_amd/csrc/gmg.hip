@@ -2120,10 +2120,11 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
 
     // first level handled by the single-workgroup coarse tail (never level 0; Jacobi only; no communication)
     int tail0 = nl;
-    // the small levels of a small problem are launch-bound (a 2-D flow case spends its V-cycle in ~5 us kernels): one
-    // workgroup walks them; on a large grid the same kernel costs more than it saves
-    const int tail_cells = (s->cfg.coarse_tail >= 0) ? s->cfg.coarse_tail
-                                                      : ((s->levels[0].n[0] * s->levels[0].n[1] * s->levels[0].n[2] < ((int64_t)1 << 22)) ? 1024 : 0);
+    // the smallest levels are launch-bound (~5 us kernels, five to seven per level): one workgroup walks those of <= 1024
+    // cells.  A 2-D flow case spends most of its V-cycle there; on a 256^3 / 512^3 grid it is 0.2 ms of a time step / of
+    // a solve (17.4 -> 17.2 ms, 88.2 -> 88.1 ms), and taking larger levels into the one workgroup costs more than the
+    // launches it saves (4096: 90.3 ms, 32768: 20.4 ms per Taylor-Green step)
+    const int tail_cells = (s->cfg.coarse_tail >= 0) ? s->cfg.coarse_tail : 1024;
     if (!cheb && tail_cells) {
         for (int l = nl - 1; l >= 1; --l) {
             const GridLevel &g = s->levels[(size_t)l];

@@ -79,7 +79,7 @@ struct Config {
     int spmv_variant = 0;    // 0 LDS-transpose + tiled chunk order (default), 3 same in natural order, 1 entry-per-lane stream, 2 row-per-thread
     int overlap_halo = 1;
     int overlap_min_bytes = 1 << 20;  // multigrid on slabs: a right-hand-side exchange of at least this size per neighbour runs on the communication stream behind the interior planes of its first consumer
-    int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024 when the fine level has < 2^22 cells (the 2-D cases, launch-bound), off on large grids; 0: off.
+    int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024; 0: off.
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
