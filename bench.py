@@ -121,7 +121,7 @@ def measured_traffic(n: int, world: int):
     return None
 
 
-def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int) -> dict:
+def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str = "") -> dict:
     """The velocity solve of the same cavity, A = I/dt - c nu L (navierstokes.cpp:342-344) with PBICGSTAB + BLOCK_JACOBI to
     an absolute residual of 1e-10 (examples/navierstokes/taylorgreenvortex3dRe1600_GPU/config/velocity_solver.info),
     single GPU.  The Krylov products run matrix-free from the mesh tables (velstencil.hip: 56 B/row -- x read once, y
@@ -133,7 +133,7 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int) -> dict:
     cfg = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
            "solv:convergence=ABSOLUTE\nsolv:tolerance=1e-10\nsolv:norm=L2\nsolv:store_res_history=1\n"
            "solv:preconditioner(prec)=BLOCK_JACOBI\nprec:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n")
-    s = LinSolverHIP("velocity", config_text=cfg)
+    s = LinSolverHIP("velocity", config_text=cfg + extra.replace("\\n", "\n") + "\n")
     w = np.full(n, 1.0 / n)
     a0 = np.array([[0.0 if (loc // 2) == f else -1.0 for loc in range(6)] for f in range(3)])  # all-Dirichlet cavity
     t0 = time.perf_counter()
@@ -193,7 +193,7 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int) -> dict:
 def velocity_bench(args):
     import torch
     assert torch.cuda.is_available()
-    out = velocity_case(args.n, args.steps, args.warmup, args.kernel_reps)
+    out = velocity_case(args.n, args.steps, args.warmup, args.kernel_reps, args.extra_config)
     out.update({"n_gpus": 1, "higher_is_better": True, "data": "synthetic"})
     print(json.dumps(out), flush=True)
 

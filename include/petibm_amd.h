@@ -89,6 +89,13 @@ int pib_comm_unique_id(void *uid_out /* PIB_UID_BYTES */);
 int pib_comm_loopback_create(int nranks, void *uid_out /* PIB_UID_BYTES */);
 int pib_comm_loopback_destroy(const void *uid);
 
+/* TEST: the RCCL calls of the production transport (grouped ncclSend / ncclRecv incl. the periodic ring, in-place
+ * ncclAllReduce, ncclAllGather / grouped ncclBroadcast, an exchange on the communication stream ordered with events) in a
+ * ONE-rank RCCL world on `device`, on a vector of n_owned entries with `ghost` ghost entries at either end; *max_err_out
+ * is the largest deviation of what arrived from what must arrive (0), *comm_ranks_out ncclCommCount (1).  The multi-rank
+ * algorithm itself runs through the loopback transport; a one-GPU box can do no more with RCCL than this. */
+int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, double *max_err_out, int *comm_ranks_out);
+
 /* ---- life cycle ---------------------------------------------------------
  * pib_create replaces LinSolverAmgX::LinSolverAmgX + init
  * (src/linsolver/linsolveramgx.cpp:20-75; AmgXSolver::initialize(comm,"dDDI",cfg))

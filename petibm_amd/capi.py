@@ -42,6 +42,7 @@ _PROTOS = {
     "pib_comm_unique_id": (C.c_int, [_vp]),
     "pib_comm_loopback_create": (C.c_int, [C.c_int, _vp]),
     "pib_comm_loopback_destroy": (C.c_int, [_vp]),
+    "pib_comm_selftest": (C.c_int, [C.c_int, _i64, _i64, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pib_create": (C.c_int, [C.POINTER(_vp), C.c_char_p, C.c_char_p, C.c_int, C.c_int, _vp, C.c_int]),
     "pib_create_from_string": (C.c_int, [C.POINTER(_vp), C.c_char_p, C.c_char_p, C.c_int, C.c_int, _vp, C.c_int]),
     "pib_config_describe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),

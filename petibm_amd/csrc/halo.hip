@@ -17,6 +17,7 @@
 //     all-reduced recurrences) is exercised end to end through the C ABI.  Device-to-device copies ordered
 //     with HIP events + a host barrier per collective.
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -122,7 +123,7 @@ int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vec
 {
     const int P = s->comm.nranks, r = s->comm.rank;
     const size_t L = mine.size();
-    if (P <= 1) {
+    if (!s->comm.active()) {
         all = mine;
         return 0;
     }
@@ -217,7 +218,7 @@ int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_
                          int64_t send_next, hipStream_t st)
 {
     const int P = s->comm.nranks, r = s->comm.rank;
-    if (P <= 1) return 0;
+    if (!s->comm.active()) return 0;
     s->counters[3]++;
     if (s->comm.loop) return lb_halo(s, x_owned, n_owned, lo, hi, st);
     if (s->comm.ring) {
@@ -312,7 +313,7 @@ static int halo_exchange_segments(pib_solver *s, double *x_owned, hipStream_t st
 int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st)
 {
     const DeviceCsr &A = s->A;
-    if (s->comm.nranks <= 1) return 0;
+    if (!s->comm.active()) return 0;
     if (A.segmented) return halo_exchange_segments(s, x_owned, st);
     return halo_exchange_planes(s, x_owned, A.n, A.ghost_lo, A.ghost_hi, A.send_prev, A.send_next, st);
 }
@@ -320,7 +321,7 @@ int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st)
 // in-place sum over ranks of `count` (<= PIB_NRED) doubles in device memory
 int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
 {
-    if (s->comm.nranks <= 1) return 0;
+    if (!s->comm.active()) return 0;
     s->counters[2]++;
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
@@ -351,7 +352,7 @@ __global__ void k_lb_add(double *__restrict__ acc, const double *__restrict__ x,
 // entries every rank sums over its own velocity points
 int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st)
 {
-    if (s->comm.nranks <= 1 || count <= 0) return 0;
+    if (!s->comm.active() || count <= 0) return 0;
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
         const int P = s->comm.nranks, r = s->comm.rank;
@@ -384,7 +385,7 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
                     const std::vector<int64_t> &offs, hipStream_t st)
 {
     const int P = s->comm.nranks, r = s->comm.rank;
-    if (P <= 1) return 0;
+    if (!s->comm.active()) return 0;
     s->counters[3]++;
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
@@ -427,6 +428,129 @@ extern "C" int pib_comm_unique_id(void *uid_out)
     PIB_NCCL(ncclGetUniqueId(&id));
     std::memset(uid_out, 0, PIB_UID_BYTES);
     std::memcpy(uid_out, &id, sizeof(id));
+    return 0;
+}
+
+// ---- the RCCL entry points on hardware with ONE rank.  RCCL refuses several ranks per device and the test box has one
+// GPU, so the multi-rank ALGORITHM is tested through the loopback transport; this runs the other half -- the RCCL calls
+// themselves, exactly as the functions above issue them (grouped ncclSend / ncclRecv incl. the periodic ring whose two
+// neighbours are the rank itself, in-place ncclAllReduce of the recurrence scalars and of a large buffer, in-place
+// ncclAllGather, the grouped ncclBroadcast form of the all-gather-v, an exchange on the communication stream ordered
+// with events against the solver's stream) -- in a one-rank world and checks what arrives.
+__global__ void k_selftest_fill(double *x, int64_t n, double a, double b)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = a + b * (double)i;
+}
+extern "C" int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, double *max_err_out, int *comm_ranks_out)
+{
+    using namespace pib;
+    if (max_err_out == nullptr || n_owned < 2 * ghost || ghost < 1) return fail(PIB_ERR_ARG_WRONG, "pib_comm_selftest: bad arguments");
+    int ndev = 0;
+    PIB_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(PIB_ERR_LIB, "pib_comm_selftest: no GPU");
+    PIB_HIP(hipSetDevice(device < 0 ? 0 : device));
+    pib_solver S;
+    pib_solver *s = &S;
+    s->name = "selftest";
+    s->device = device < 0 ? 0 : device;
+    PIB_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    PIB_HIP(hipStreamCreateWithFlags(&s->stream_comm, hipStreamNonBlocking));
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    PIB_HIP(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+    PIB_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+    ncclUniqueId id;
+    PIB_NCCL(ncclGetUniqueId(&id));
+    s->comm.rank = 0;
+    s->comm.nranks = 1;
+    PIB_NCCL(ncclCommInitRank(&s->comm.comm, 1, id, 0));
+    int cnt = 0;
+    PIB_NCCL(ncclCommCount(s->comm.comm, &cnt));
+    if (comm_ranks_out) *comm_ranks_out = cnt;
+    const int64_t tot = n_owned + 2 * ghost;
+    double *d = nullptr, *d2 = nullptr;
+    PIB_HIP(hipMalloc(&d, sizeof(double) * (size_t)tot));
+    PIB_HIP(hipMalloc(&d2, sizeof(double) * (size_t)tot));
+    std::vector<double> h((size_t)tot);
+    double err = 0.0;
+    auto owned = [&](int64_t i) { return 1.0 + 0.5 * (double)i; };
+    auto refill = [&](hipStream_t q) {
+        PIB_HIP(hipMemsetAsync(d, 0xff, sizeof(double) * (size_t)tot, q));  // NaN pattern in the ghosts
+        hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, q, d + ghost, n_owned, 1.0, 0.5);
+        PIB_HIP(hipGetLastError());
+        return 0;
+    };
+    auto fetch = [&](hipStream_t q) {
+        PIB_HIP(hipMemcpyAsync(h.data(), d, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost, q));
+        PIB_HIP(hipStreamSynchronize(q));
+        return 0;
+    };
+    // 1. wall-bounded slab axis, one rank: no neighbour, an empty group; the ghosts stay untouched
+    s->comm.ring = false;
+    PIB_CHK(refill(s->stream));
+    PIB_CHK(halo_exchange_planes(s, d + ghost, n_owned, ghost, ghost, ghost, ghost, s->stream));
+    PIB_CHK(fetch(s->stream));
+    for (int64_t i = 0; i < n_owned; ++i) err = std::max(err, std::fabs(h[(size_t)(ghost + i)] - owned(i)));
+    if (h[0] == h[0] || h[(size_t)(tot - 1)] == h[(size_t)(tot - 1)]) err = std::max(err, 1.0);  // must still be NaN
+    // 2. periodic slab axis: both neighbours are this rank -- the low ghosts are its top entries, the high ghosts its
+    //    bottom entries (two messages to the same peer, matched in issue order)
+    s->comm.ring = true;
+    PIB_CHK(refill(s->stream));
+    PIB_CHK(halo_exchange_planes(s, d + ghost, n_owned, ghost, ghost, ghost, ghost, s->stream));
+    PIB_CHK(fetch(s->stream));
+    for (int64_t i = 0; i < ghost; ++i) {
+        err = std::max(err, std::fabs(h[(size_t)i] - owned(n_owned - ghost + i)));
+        err = std::max(err, std::fabs(h[(size_t)(ghost + n_owned + i)] - owned(i)));
+    }
+    // 3. the same exchange on the communication stream, ordered against the solver's stream with events (gmg.hip's
+    //    overlapped right-hand-side exchange)
+    PIB_CHK(refill(s->stream));
+    PIB_HIP(hipEventRecord(ev_a, s->stream));
+    PIB_HIP(hipStreamWaitEvent(s->stream_comm, ev_a, 0));
+    PIB_CHK(halo_exchange_planes(s, d + ghost, n_owned, ghost, ghost, ghost, ghost, s->stream_comm));
+    PIB_HIP(hipEventRecord(ev_b, s->stream_comm));
+    PIB_HIP(hipStreamWaitEvent(s->stream, ev_b, 0));
+    PIB_CHK(fetch(s->stream));
+    for (int64_t i = 0; i < ghost; ++i) {
+        err = std::max(err, std::fabs(h[(size_t)i] - owned(n_owned - ghost + i)));
+        err = std::max(err, std::fabs(h[(size_t)(ghost + n_owned + i)] - owned(i)));
+    }
+    s->comm.ring = false;
+    // 4. in-place all-reduce of the recurrence scalars and of a large buffer: one rank, the values stay
+    PIB_CHK(refill(s->stream));
+    PIB_CHK(comm_allreduce_sum(s, d + ghost, PIB_NRED, s->stream));
+    PIB_CHK(comm_allreduce_big(s, d + ghost, n_owned, s->stream));
+    PIB_CHK(fetch(s->stream));
+    for (int64_t i = 0; i < n_owned; ++i) err = std::max(err, std::fabs(h[(size_t)(ghost + i)] - owned(i)));
+    // 5. all-gather (in place: the send buffer is the rank's part of the receive buffer) and its grouped-broadcast form
+    {
+        std::vector<int64_t> counts(1, n_owned), offs(1, 0);
+        PIB_CHK(comm_allgatherv(s, d + ghost, d + ghost, counts, offs, s->stream));
+        offs[0] = ghost;  // not rank * count: the all-gather-v form
+        PIB_HIP(hipMemsetAsync(d2, 0, sizeof(double) * (size_t)tot, s->stream));
+        PIB_CHK(comm_allgatherv(s, d + ghost, d2, counts, offs, s->stream));
+        PIB_CHK(fetch(s->stream));
+        for (int64_t i = 0; i < n_owned; ++i) err = std::max(err, std::fabs(h[(size_t)(ghost + i)] - owned(i)));
+        PIB_HIP(hipMemcpyAsync(h.data(), d2, sizeof(double) * (size_t)tot, hipMemcpyDeviceToHost, s->stream));
+        PIB_HIP(hipStreamSynchronize(s->stream));
+        for (int64_t i = 0; i < n_owned; ++i) err = std::max(err, std::fabs(h[(size_t)(ghost + i)] - owned(i)));
+    }
+    // 6. the host-side all-gather of the set-up
+    {
+        std::vector<double> mine = {3.0, 4.0, 5.0}, all;
+        PIB_CHK(comm_allgather_host(s, mine, all));
+        if (all.size() != 3) err = std::max(err, 1.0);
+        else for (int k = 0; k < 3; ++k) err = std::max(err, std::fabs(all[(size_t)k] - mine[(size_t)k]));
+    }
+    *max_err_out = err;
+    PIB_HIP(hipFree(d));
+    PIB_HIP(hipFree(d2));
+    (void)ncclCommDestroy(s->comm.comm);
+    s->comm.comm = nullptr;
+    (void)hipEventDestroy(ev_a);
+    (void)hipEventDestroy(ev_b);
+    (void)hipStreamDestroy(s->stream);
+    (void)hipStreamDestroy(s->stream_comm);
+    s->stream = s->stream_comm = nullptr;
     return 0;
 }
 

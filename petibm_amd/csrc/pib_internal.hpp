@@ -84,6 +84,8 @@ struct Config {
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
     int march_velocity = 1;        // matrix-free velocity product: LDS-tiled z-marching form for tile-divisible components (velstencil.hip k_vel_march)
+    int velocity_march_planes = 16;  // planes a workgroup of k_vel_march walks through
+    int fuse_velocity_product = 1;  // 3-D: the three components' tiles and shells in one launch (velstencil.hip k_vel_product)
     int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR
     int march_min_cells = 12 << 20;  // smallest level / plane run the LDS-tiled marching kernels take: a 256^3 level, the 62 interior planes of a 512 x 512 x 64 slab (tests lower it to reach them on small grids)
     int march_levels = 1;    // multigrid: Jacobi steps / residuals of the large levels by the 2.5-D blocked kernel (gmg.hip k_level_march)
@@ -189,6 +191,8 @@ struct Comm {
     int rank = 0, nranks = 1;
     bool borrowed = false;  // the communicator belongs to another solver of the same engine (one RCCL id makes one communicator)
     bool ring = false;  // the slab axis is periodic: rank 0 and rank P-1 are neighbours (their outer ghost planes wrap)
+    // a transport is attached (always and only when nranks > 1, except in pib_comm_selftest's one-rank RCCL world)
+    bool active() const { return comm != nullptr || loop != nullptr; }
 };
 
 // the velocity operator's structure (velstencil.hip): per field and direction the Laplacian quotients, the ghost folds,

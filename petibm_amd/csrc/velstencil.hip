@@ -84,15 +84,15 @@ __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restr
     return s;
 }
 
-__global__ __launch_bounds__(256) void k_vel_shell(const Scalars *__restrict__ S, VelDev V, int f, int all,
-                                                   const double *__restrict__ x, double *__restrict__ y)
+// the outermost layer of component f (all = 1: every point), dealt to `nblk` workgroups of which this is number `blk`
+__device__ __forceinline__ void vel_shell_part(const VelDev &V, int f, int all, const double *__restrict__ x, double *__restrict__ y,
+                                               int64_t blk, int64_t nblk)
 {
-    if (S != nullptr && S->done) return;
     const int64_t nx = V.n[f][0], ny = V.n[f][1], nz = V.n[f][2];
     const bool three = V.dim == 3;
     const int64_t cx = 2 * ny * nz, cy = 2 * (nx - 2) * nz, cz = three ? 2 * (nx - 2) * (ny - 2) : 0;
     const int64_t total = all ? nx * ny * nz : cx + cy + cz;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    for (int64_t t = blk * 256 + threadIdx.x; t < total; t += nblk * 256) {
         int64_t i, j, k;
         if (all) {
             i = t % nx;
@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256) void k_vel_shell(const Scalars *__restrict__ S
         }
         y[V.off[f] + i + nx * (j + ny * k)] = vel_row(V, x, f, i, j, k);
     }
+}
+__global__ __launch_bounds__(256) void k_vel_shell(const Scalars *__restrict__ S, VelDev V, int f, int all,
+                                                   const double *__restrict__ x, double *__restrict__ y)
+{
+    if (S != nullptr && S->done) return;
+    vel_shell_part(V, f, all, x, y, blockIdx.x, gridDim.x);
 }
 
 template <int DIM>
@@ -253,16 +259,14 @@ constexpr int VX = 128, VY = 8, VSX = VX + 2, VSY = VY + 2;
 // boundary).  Otherwise they are 32 cells apart (lane-consecutive 8-byte accesses, any line length and alignment: the
 // 255-point lines of a wall-bounded component along its own direction; the last tile of a line is partial).
 template <bool V4>
-__global__ __launch_bounds__(256) void k_vel_march(const Scalars *__restrict__ S, VelDev V, int f, const double *__restrict__ x,
-                                                   double *__restrict__ y, int MZ)
+__device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const double *__restrict__ x, double *__restrict__ y, int MZ,
+                                               int bx, int by, int bz, double (&sp)[2][VSY][VSX])
 {
-    if (S != nullptr && S->done) return;
-    __shared__ double sp[2][VSY][VSX];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int nx = (int)V.n[f][0], ny = (int)V.n[f][1], nz = (int)V.n[f][2];
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-    const int i0 = blockIdx.x * VX, j0 = blockIdx.y * VY;
-    const int k0 = 1 + blockIdx.z * MZ, kend = min(k0 + MZ, nz - 1);  // interior planes [1, nz - 1)
+    const int i0 = bx * VX, j0 = by * VY;
+    const int k0 = 1 + bz * MZ, kend = min(k0 + MZ, nz - 1);  // interior planes [1, nz - 1)
     const int64_t sy = nx, sz = (int64_t)nx * ny;
     const int j = j0 + ty;
     const int jc = min(j, ny - 1);  // a partial tile's rows / cells beyond the component are clamped for the loads, never stored
@@ -355,6 +359,42 @@ __global__ __launch_bounds__(256) void k_vel_march(const Scalars *__restrict__ S
     }
 }
 
+template <bool V4>
+__global__ __launch_bounds__(256) void k_vel_march(const Scalars *__restrict__ S, VelDev V, int f, const double *__restrict__ x,
+                                                   double *__restrict__ y, int MZ)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ double sp[2][VSY][VSX];
+    vel_march_tile<V4>(V, f, x, y, MZ, blockIdx.x, blockIdx.y, blockIdx.z, sp);
+}
+
+// ---- the whole product in ONE launch (3-D, every component on the marching path): six back-to-back launches -- three
+// marches of ~70 us and three shells of ~30 us at 256^3 -- each ramp up and drain the chip on their own, and the shells
+// (one strided point per lane) are latency-bound.  Here the shell workgroups of all components come first in the grid and
+// the tiles follow, so the shells' loads are in flight while the tiles stream.  Same device functions, same bits.
+struct VelPlan {
+    int first[7];       // first workgroup of: shell of component 0, 1, 2, tiles of component 0, 1, 2, end
+    int gx[3], gy[3];   // tiles per plane of a component
+    int v4[3];
+};
+__global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__ S, VelDev V, VelPlan P, const double *__restrict__ x,
+                                                     double *__restrict__ y, int MZ)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ double sp[2][VSY][VSX];
+    const int b = blockIdx.x;
+    if (b < P.first[3]) {
+        const int f = (b >= P.first[1]) + (b >= P.first[2]);
+        vel_shell_part(V, f, 0, x, y, b - P.first[f], P.first[f + 1] - P.first[f]);
+        return;
+    }
+    const int f = (b >= P.first[4]) + (b >= P.first[5]);
+    const int lb = b - P.first[3 + f];
+    const int bx = lb % P.gx[f], by = (lb / P.gx[f]) % P.gy[f], bz = lb / (P.gx[f] * P.gy[f]);
+    if (P.v4[f]) vel_march_tile<true>(V, f, x, y, MZ, bx, by, bz, sp);
+    else vel_march_tile<false>(V, f, x, y, MZ, bx, by, bz, sp);
+}
+
 void vel_stencil_release(pib_solver *s)
 {
     for (double *p : s->vel.owned) (void)hipFree(p);
@@ -367,14 +407,42 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
     const VelStencil &h = s->vel;
     const VelDev V = vel_dev(h);
     const Scalars *S = guarded ? s->d_s : nullptr;
+    const int MZ = std::max(2, s->cfg.velocity_march_planes);
+    auto marches = [&](int f) {
+        const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
+        return h.dim == 3 && s->cfg.march_velocity && ny >= 3 && nz >= 3 && nx >= VX - 1 &&
+               nx * ny * nz >= std::min<int64_t>(s->cfg.march_min_cells, (int64_t)1 << 22);
+    };
+    if (h.dim == 3 && s->cfg.fuse_velocity_product && marches(0) && marches(1) && marches(2)) {
+        VelPlan P;
+        int nb = 0;
+        for (int f = 0; f < 3; ++f) {
+            const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
+            const int64_t shell = 2 * (ny * nz + (nx - 2) * nz + (nx - 2) * (ny - 2));
+            P.first[f] = nb;
+            nb += (int)std::min<int64_t>(4096, (shell + 255) / 256);
+        }
+        for (int f = 0; f < 3; ++f) {
+            const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
+            P.first[3 + f] = nb;
+            P.gx[f] = (int)((nx + VX - 1) / VX);
+            P.gy[f] = (int)((ny + VY - 1) / VY);
+            P.v4[f] = (nx % VX == 0 && h.off[f] % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31u) == 0) ? 1 : 0;
+            nb += P.gx[f] * P.gy[f] * (int)((nz - 2 + MZ - 1) / MZ);
+        }
+        P.first[6] = nb;
+        hipLaunchKernelGGL(k_vel_product, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
+        PIB_HIP(hipGetLastError());
+        s->counters[0]++;
+        return 0;
+    }
     for (int f = 0; f < h.dim; ++f) {
         const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
         const bool inner = nx >= 3 && ny >= 3 && (h.dim == 2 || nz >= 3);
         if (inner) {
             const bool vec4 = nx % 4 == 0 && h.off[f] % 4 == 0 &&
                               ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31u) == 0;
-            if (h.dim == 3 && s->cfg.march_velocity && nx >= VX - 1 && nx * ny * nz >= std::min<int64_t>(s->cfg.march_min_cells, (int64_t)1 << 22)) {
-                const int MZ = 16;
+            if (marches(f)) {
                 const dim3 grid((unsigned)((nx + VX - 1) / VX), (unsigned)((ny + VY - 1) / VY), (unsigned)((nz - 2 + MZ - 1) / MZ));
                 if (vec4 && nx % VX == 0) hipLaunchKernelGGL(k_vel_march<true>, grid, dim3(256), 0, q, S, V, f, x, y, MZ);
                 else hipLaunchKernelGGL(k_vel_march<false>, grid, dim3(256), 0, q, S, V, f, x, y, MZ);

@@ -399,8 +399,10 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
     dt, cnu = 0.004, 0.5 * 0.01
     b = np.random.default_rng(5).uniform(-1, 1, m.UN)
     out = []
-    for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\n", "pib_matrix_free_velocity=1\npib_march_velocity=0\n",
-                  "pib_matrix_free_velocity=0\n"):
+    # one launch for the three components' tiles and shells (k_vel_product), a launch each, the streaming kernels, the CSR
+    for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\n",
+                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_velocity_product=0\n",
+                  "pib_matrix_free_velocity=1\npib_march_velocity=0\n", "pib_matrix_free_velocity=0\n"):
         s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-13, conv="ABSOLUTE",
                                                               maxit=500, extra=extra))
         s.setPeriodic(per)
@@ -409,7 +411,7 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
         s.solve(x, b)
         out.append((x, s.getIters(), s.getResidualHistory()))
         s.destroy()
-    assert out[0][1] == out[1][1] == out[2][1] and out[0][1] >= 2
+    assert out[0][1] == out[1][1] == out[2][1] == out[3][1] and out[0][1] >= 2
     for o in out[1:]:
         assert np.array_equal(out[0][2], o[2]) and np.array_equal(out[0][0], o[0])
 
