@@ -223,6 +223,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.march_velocity = std::atoi(d.get("default", "pib_march_velocity", "1").c_str());
     c.fuse_velocity_product = std::atoi(d.get("default", "pib_fuse_velocity_product", "1").c_str());
     c.velocity_march_planes = std::atoi(d.get("default", "pib_velocity_march_planes", "16").c_str());
+    c.lean_bicgstab = std::atoi(d.get("default", "pib_lean_bicgstab", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
     c.detect_structure = std::atoi(d.get("default", "pib_detect_structure", "1").c_str());
@@ -333,6 +334,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_march_velocity", v)) c.march_velocity = std::atoi(v.c_str());
     if (get("pib_fuse_velocity_product", v)) c.fuse_velocity_product = std::atoi(v.c_str());
     if (get("pib_velocity_march_planes", v)) c.velocity_march_planes = std::atoi(v.c_str());
+    if (get("pib_lean_bicgstab", v)) c.lean_bicgstab = std::atoi(v.c_str());
     if (get("pib_matrix_free_poisson", v)) c.matrix_free_poisson = std::atoi(v.c_str());
     if (get("pib_agglomerate_below", v)) c.agglomerate_below = std::atoi(v.c_str());
     if (get("pib_detect_structure", v)) c.detect_structure = std::atoi(v.c_str());

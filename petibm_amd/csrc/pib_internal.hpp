@@ -84,6 +84,7 @@ struct Config {
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
     int march_velocity = 1;        // matrix-free velocity product: LDS-tiled z-marching form for tile-divisible components (velstencil.hip k_vel_march)
+    int lean_bicgstab = 1;  // BiCGStab on the matrix-free velocity operator without stored M^-1 p / M^-1 s and with the x update deferred (krylov.hip OpBFUpdateP)
     int velocity_march_planes = 16;  // planes a workgroup of k_vel_march walks through
     int fuse_velocity_product = 1;  // 3-D: the three components' tiles and shells in one launch (velstencil.hip k_vel_product)
     int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR
@@ -122,7 +123,10 @@ struct Scalars {
     // CG: x += a p of iteration k is applied by the p-update of iteration k + 1 (one pass over p less); xa_it counts the
     // updates owed, xapplied the ones the p-updates have made: they differ while one is pending (flushed after the loop)
     int xa_it, xapplied;
-    int pad;
+    // BiCGStab on the matrix-free velocity operator: x += xalpha M^-1 p + xomega M^-1 s of iteration k is applied by the
+    // p-update of iteration k + 1 (xpend: one is owed; flushed after the loop)
+    int xpend;
+    double xalpha, xomega;
 };
 
 // ------------------------------------------------------------------ matrix
@@ -309,7 +313,8 @@ void dense_release(pib_solver *s);
 int solve_direct(pib_solver *s, double *x, const double *b);
 // assemble.hip
 void vel_stencil_release(pib_solver *s);
-int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q);
+int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv = nullptr, double opc = 1.0);
+bool vel_stencil_fused_ok(const pib_solver *s);
 int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);
 // bn.hip: D * BN(order) * G through the reference's chain of sparse products; optionally hands out BNG (device arrays
 // owned by the caller)

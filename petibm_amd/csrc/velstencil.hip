@@ -21,7 +21,16 @@ struct VelDev {
     const double *lneg[3][3], *lpos[3][3];  // [field][direction], index s
     double a0[3][6];
     double scale, shift;
+    // y = A (opc * (dinv o x)) when dinv != nullptr: the right-preconditioned products of BiCGStab with the Jacobi sweep
+    // applied as the input is read (the same product opc * (dinv[i] * x[i]) a stored copy would hold: same bits)
+    const double *dinv;
+    double opc;
 };
+__device__ __forceinline__ double vel_in(const VelDev &V, const double *__restrict__ x, int64_t idx)
+{
+    const double v = x[idx];
+    return V.dinv != nullptr ? V.opc * (V.dinv[idx] * v) : v;
+}
 
 // general form of one row (ghost folds, periodic wraps)
 __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restrict__ x, int f, int64_t i, int64_t j, int64_t k)
@@ -54,10 +63,10 @@ __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restr
     double s = 0.0;
     if (!anywrap) {
         for (int d = V.dim - 1; d >= 0; --d)
-            if (interior[2 * d]) s = s + (v[2 * d] * V.scale) * x[p - st[d]];
-        s = s + dval * x[p];
+            if (interior[2 * d]) s = s + (v[2 * d] * V.scale) * vel_in(V, x, p - st[d]);
+        s = s + dval * vel_in(V, x, p);
         for (int d = 0; d < V.dim; ++d)
-            if (interior[2 * d + 1]) s = s + (v[2 * d + 1] * V.scale) * x[p + st[d]];
+            if (interior[2 * d + 1]) s = s + (v[2 * d + 1] * V.scale) * vel_in(V, x, p + st[d]);
         return s;
     }
     int64_t ec[7];
@@ -80,7 +89,7 @@ __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restr
         ec[t] = c;
         ev[t] = v[q] * V.scale;
     }
-    for (int t = 0; t < ne; ++t) s = s + ev[t] * x[ec[t]];
+    for (int t = 0; t < ne; ++t) s = s + ev[t] * vel_in(V, x, ec[t]);
     return s;
 }
 
@@ -168,6 +177,8 @@ static VelDev vel_dev(const VelStencil &h)
     V.per = h.per;
     V.scale = h.scale;
     V.shift = h.shift;
+    V.dinv = nullptr;
+    V.opc = 1.0;
     for (int f = 0; f < 3; ++f) {
         V.off[f] = h.off[f];
         for (int d = 0; d < 3; ++d) {
@@ -288,14 +299,26 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
     const bool jin = j >= 1 && j <= ny - 2;
     const double yneg = V.lneg[f][1][jc], ypos = V.lpos[f][1][jc];
     double vn[4], vp[4], zm[4], xc[4], zp[4];
-    auto load4 = [&](const double *pl, double (&o)[4]) {
+    const bool scaled = V.dinv != nullptr;
+    // pl: the plane of x, kp: its index (the plane of dinv)
+    auto load4 = [&](const double *pl, int kp, double (&o)[4]) {
         if (V4) {
             const v4 t = *reinterpret_cast<const v4 *>(pl + row + ci[0]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = t[c];
+            if (scaled) {
+                const v4 d = *reinterpret_cast<const v4 *>(V.dinv + (int64_t)kp * sz + row + ci[0]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = V.opc * (d[c] * o[c]);
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = pl[row + ci[c]];
+            if (scaled) {
+                const double *pd = V.dinv + (int64_t)kp * sz;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = V.opc * (pd[row + ci[c]] * o[c]);
+            }
         }
     };
 #pragma unroll
@@ -303,16 +326,22 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         vn[c] = V.lneg[f][0][ci[c]];
         vp[c] = V.lpos[f][0][ci[c]];
     }
-    load4(x + (int64_t)(k0 - 1) * sz, zm);
-    load4(x + (int64_t)k0 * sz, xc);
+    load4(x + (int64_t)(k0 - 1) * sz, k0 - 1, zm);
+    load4(x + (int64_t)k0 * sz, k0, xc);
     for (int k = k0; k < kend; ++k) {
         const int slot = k & 1;
         const double *px = x + (int64_t)k * sz;
-        load4(px + sz, zp);
+        load4(px + sz, k + 1, zp);
 #pragma unroll
         for (int c = 0; c < 4; ++c) sp[slot][ty + 1][lx[c]] = xc[c];
-        sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? px[off_hy] : 0.0;
-        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? px[off_hx] : 0.0;
+        double hyv = hy_ok ? px[off_hy] : 0.0, hxv = hx_ok ? px[off_hx] : 0.0;
+        if (scaled) {
+            const double *pd = V.dinv + (int64_t)k * sz;
+            if (hy_ok) hyv = V.opc * (pd[off_hy] * hyv);
+            if (hx_ok) hxv = V.opc * (pd[off_hx] * hxv);
+        }
+        sp[slot][hy_row + 1][hy_x + 1] = hyv;
+        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hxv;
         __syncthreads();
         const double zneg = V.lneg[f][2][k], zpos = V.lpos[f][2][k];
         double out[4];
@@ -402,10 +431,28 @@ void vel_stencil_release(pib_solver *s)
 }
 
 // y = A x on the whole (single-rank) vector
-int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q)
+// the one-launch product serves this operator (3-D, every component on the marching path): the form that can take its
+// input through the Jacobi sweep (vel_stencil_apply's dinv / opc)
+bool vel_stencil_fused_ok(const pib_solver *s)
 {
     const VelStencil &h = s->vel;
-    const VelDev V = vel_dev(h);
+    if (!h.valid || h.dim != 3 || !s->cfg.march_velocity || !s->cfg.fuse_velocity_product) return false;
+    for (int f = 0; f < 3; ++f) {
+        const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
+        if (!(ny >= 3 && nz >= 3 && nx >= VX - 1 && nx * ny * nz >= std::min<int64_t>(s->cfg.march_min_cells, (int64_t)1 << 22))) return false;
+    }
+    return true;
+}
+
+int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv, double opc)
+{
+    const VelStencil &h = s->vel;
+    VelDev V = vel_dev(h);
+    if (dinv != nullptr) {
+        if (!vel_stencil_fused_ok(s)) return fail(PIB_ERR_ORDER, "velocity product with the Jacobi sweep folded in: the one-launch form does not serve this operator");
+        V.dinv = dinv;
+        V.opc = opc;
+    }
     const Scalars *S = guarded ? s->d_s : nullptr;
     const int MZ = std::max(2, s->cfg.velocity_march_planes);
     auto marches = [&](int f) {

@@ -400,7 +400,9 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
     b = np.random.default_rng(5).uniform(-1, 1, m.UN)
     out = []
     # one launch for the three components' tiles and shells (k_vel_product), a launch each, the streaming kernels, the CSR
+    # (the first also runs BiCGStab without stored M^-1 p / M^-1 s and with the x update deferred: krylov.hip OpBFUpdateP)
     for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\n",
+                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_lean_bicgstab=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_velocity_product=0\n",
                   "pib_matrix_free_velocity=1\npib_march_velocity=0\n", "pib_matrix_free_velocity=0\n"):
         s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-13, conv="ABSOLUTE",
@@ -411,7 +413,7 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
         s.solve(x, b)
         out.append((x, s.getIters(), s.getResidualHistory()))
         s.destroy()
-    assert out[0][1] == out[1][1] == out[2][1] == out[3][1] and out[0][1] >= 2
+    assert out[0][1] == out[1][1] == out[2][1] == out[3][1] == out[4][1] and out[0][1] >= 2
     for o in out[1:]:
         assert np.array_equal(out[0][2], o[2]) and np.array_equal(out[0][0], o[0])
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ Cell1 cell1(const L &l, int i, int j)
 }
 
 // VAR 0: product expressions; 1: volume-scaled; 2: volume-scaled + hoisted reciprocal (uniform z)
-template <int VAR, int TY, int KZ>
+template <int VAR, int TY, int KZ, int PF = 0>
 __global__ __launch_bounds__(32 * TY) void k_step(L l, double omega, const double *__restrict__ b, const double *__restrict__ xi,
                                                   double *__restrict__ xo)
 {
@@ -93,14 +93,37 @@ __global__ __launch_bounds__(32 * TY) void k_step(L l, double omega, const doubl
         if (VAR == 2) rinv[c] = 1.0 / (-((q1[c].s4 + l.cmz[1]) + l.cpz[1]));  // interior planes of a uniform z direction
     }
     const int kend = (k0 + KZ < l.nz) ? k0 + KZ : l.nz;
-    v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0};
+    v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0}, zq = {0, 0, 0, 0}, bv = {0, 0, 0, 0}, bn = {0, 0, 0, 0};
+    // PF (TY == 8): plane two ahead, next plane's halo cells and right-hand side requested an iteration early
+    const int hy_row = (tid < 128) ? -1 : TY, hy_x = tid & 127, hyj = j0 + hy_row;
+    const bool hy_ok = hyj >= 0 && hyj < l.ny;
+    const int64_t off_hy = (int64_t)hyj * l.nx + i0 + hy_x;
+    double hyv = 0.0, hxv = 0.0, hyn = 0.0, hxn = 0.0;
     if (k0 > 0) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(k0 - 1) * plane + off_c);
     xc = *reinterpret_cast<const v4 *>(xi + (int64_t)k0 * plane + off_c);
+    if (PF) {
+        if (k0 + 1 < l.nz) zp = *reinterpret_cast<const v4 *>(xi + (int64_t)(k0 + 1) * plane + off_c);
+        hyv = hy_ok ? xi[(int64_t)k0 * plane + off_hy] : 0.0;
+        hxv = hx_ok ? xi[(int64_t)k0 * plane + off_hx] : 0.0;
+        bv = *reinterpret_cast<const v4 *>(b + (int64_t)k0 * plane + off_c);
+    }
     for (int kk = k0; kk < kend; ++kk) {
         const int slot = kk & 1;
         const double *px = xi + (int64_t)kk * plane;
+        if (PF) {
+            if (kk + 2 < l.nz && kk + 1 < kend) zq = *reinterpret_cast<const v4 *>(px + 2 * plane + off_c);
+            if (kk + 1 < kend) {
+                hyn = hy_ok ? px[plane + off_hy] : 0.0;
+                hxn = hx_ok ? px[plane + off_hx] : 0.0;
+                bn = *reinterpret_cast<const v4 *>(b + (int64_t)(kk + 1) * plane + off_c);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
+            sp[slot][hy_row + 1][hy_x + 1] = hyv;
+            if (hx_use) sp[slot][hx_y + 1][hx_col + 1] = hxv;
+        } else {
         if (kk + 1 < l.nz) zp = *reinterpret_cast<const v4 *>(px + plane + off_c);
-        const v4 bv = *reinterpret_cast<const v4 *>(b + (int64_t)kk * plane + off_c);
+        bv = *reinterpret_cast<const v4 *>(b + (int64_t)kk * plane + off_c);
 #pragma unroll
         for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
 #pragma unroll
@@ -109,6 +132,7 @@ __global__ __launch_bounds__(32 * TY) void k_step(L l, double omega, const doubl
             sp[slot][row + 1][hx + 1] = (gj >= 0 && gj < l.ny) ? px[(int64_t)gj * l.nx + i0 + hx] : 0.0;
         }
         if (hx_use) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? px[off_hx] : 0.0;
+        }
         __syncthreads();
         v4 out;
         if (VAR == 0) {
@@ -159,7 +183,100 @@ __global__ __launch_bounds__(32 * TY) void k_step(L l, double omega, const doubl
         *reinterpret_cast<v4 *>(xo + (int64_t)kk * plane + off_c) = out;
         zm = xc;
         xc = zp;
+        if (PF) {
+            zp = zq;
+            hyv = hyn;
+            hxv = hxn;
+            bv = bn;
+        }
     }
+}
+
+// M: y = A x (the stencil twin's product, 16 B per cell: one input stream).  PF: the plane two ahead and the next plane's
+// halo cells are requested an iteration early; NT: nontemporal stores
+template <int TY, int KZ, int PF, int NT>
+__global__ __launch_bounds__(32 * TY) void k_mv(L l, const double *__restrict__ xi, double *__restrict__ xo)
+{
+    constexpr int SX = TX + 2, SY = TY + 2;
+    __shared__ double sp[2][SY][SX];
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const int i0 = blockIdx.x * TX, j0 = blockIdx.y * TY, k0 = blockIdx.z * KZ;
+    const int64_t plane = (int64_t)l.nx * l.ny;
+    const int j = j0 + ty, ic = i0 + 4 * tx;
+    static_assert(TY == 8, "halo mapping below is for 256 threads");
+    const int hy_row = (tid < 128) ? -1 : TY, hy_x = tid & 127;
+    const int hx_col = (tid & 1) ? TX : -1, hx_y = (tid >> 1) & 7;
+    const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = j0 + hx_y, hxi = i0 + hx_col;
+    const bool hy_ok = hyj >= 0 && hyj < l.ny, hx_ok = tid < 16 && hxi >= 0 && hxi < l.nx;
+    const int64_t off_c = (int64_t)j * l.nx + ic, off_hy = (int64_t)hyj * l.nx + hyi, off_hx = (int64_t)hxj * l.nx + hxi;
+    Cell1 q1[4];
+    double vxy[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        q1[c] = cell1(l, ic + c, j);
+        vxy[c] = l.wx[ic + c] * l.wy[j];
+    }
+    const int kend = (k0 + KZ < l.nz) ? k0 + KZ : l.nz;
+    v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0}, zq = {0, 0, 0, 0};
+    double hyv = 0.0, hxv = 0.0, hyn = 0.0, hxn = 0.0;
+    if (k0 > 0) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(k0 - 1) * plane + off_c);
+    xc = *reinterpret_cast<const v4 *>(xi + (int64_t)k0 * plane + off_c);
+    if (PF) {
+        if (k0 + 1 < l.nz) zp = *reinterpret_cast<const v4 *>(xi + (int64_t)(k0 + 1) * plane + off_c);
+        hyv = hy_ok ? xi[(int64_t)k0 * plane + off_hy] : 0.0;
+        hxv = hx_ok ? xi[(int64_t)k0 * plane + off_hx] : 0.0;
+    }
+    for (int kk = k0; kk < kend; ++kk) {
+        const int slot = kk & 1;
+        const double *px = xi + (int64_t)kk * plane;
+        if (PF) {
+            if (kk + 2 < l.nz && kk + 1 < kend) zq = *reinterpret_cast<const v4 *>(px + 2 * plane + off_c);
+            if (kk + 1 < kend) {
+                hyn = hy_ok ? px[plane + off_hy] : 0.0;
+                hxn = hx_ok ? px[plane + off_hx] : 0.0;
+            }
+        } else {
+            if (kk + 1 < l.nz) zp = *reinterpret_cast<const v4 *>(px + plane + off_c);
+            hyv = hy_ok ? px[off_hy] : 0.0;
+            hxv = hx_ok ? px[off_hx] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
+        sp[slot][hy_row + 1][hy_x + 1] = hyv;
+        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hxv;
+        __syncthreads();
+        const double czm = l.cmz[kk], czp = l.cpz[kk], wzk = l.wz[kk];
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int lx = 4 * tx + 1 + c;
+            const Cell1 &q = q1[c];
+            const double xcc = xc[c];
+            double s = 0.0;
+            s += q.cxm * (sp[slot][ty + 1][lx - 1] - xcc);
+            s += q.cxp * (sp[slot][ty + 1][lx + 1] - xcc);
+            s += q.cym * (sp[slot][ty][lx] - xcc);
+            s += q.cyp * (sp[slot][ty + 2][lx] - xcc);
+            s += czm * (zm[c] - xcc);
+            s += czp * (zp[c] - xcc);
+            out[c] = (s * vxy[c]) * wzk;
+        }
+        if (NT) __builtin_nontemporal_store(out, reinterpret_cast<v4 *>(xo + (int64_t)kk * plane + off_c));
+        else *reinterpret_cast<v4 *>(xo + (int64_t)kk * plane + off_c) = out;
+        zm = xc;
+        xc = zp;
+        if (PF) {
+            zp = zq;
+            hyv = hyn;
+            hxv = hxn;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_copy1(const v4 *__restrict__ a, v4 *__restrict__ o)
+{
+    const int64_t base = (int64_t)blockIdx.x * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[base + u * 256 + threadIdx.x] = a[base + u * 256 + threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_stream(int64_t n4, const v4 *__restrict__ a, const v4 *__restrict__ b, v4 *__restrict__ o)
@@ -260,6 +377,19 @@ int main(int argc, char **argv)
     timeit("V3 volume-scaled rows, 128x16 tile (512 threads), KZ 64", [&] { hipLaunchKernelGGL((k_step<1, 16, 64>), dim3(n / TX, n / 16, n / 64), dim3(512), 0, 0, l, 0.9, b, x0, y1); });
     timeit("V3 volume-scaled rows, 128x16 tile (512 threads), KZ 32", [&] { hipLaunchKernelGGL((k_step<1, 16, 32>), dim3(n / TX, n / 16, n / 32), dim3(512), 0, 0, l, 0.9, b, x0, y1); });
     timeit("V0 product expressions, 128x16 tile (512 threads), KZ 64", [&] { hipLaunchKernelGGL((k_step<0, 16, 64>), dim3(n / TX, n / 16, n / 64), dim3(512), 0, 0, l, 0.9, b, x0, y0); });
+    timeit("V1 volume-scaled rows, 128x8 tile, KZ 64, prefetch", [&] { hipLaunchKernelGGL((k_step<1, 8, 64, 1>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, 0.9, b, x0, y1); });
+    timeit("V1 volume-scaled rows, 128x8 tile, KZ 32, prefetch", [&] { hipLaunchKernelGGL((k_step<1, 8, 32, 1>), dim3(n / TX, n / 8, n / 32), dim3(256), 0, 0, l, 0.9, b, x0, y1); });
+    timeit("V1 volume-scaled rows, 128x8 tile, KZ 16, prefetch", [&] { hipLaunchKernelGGL((k_step<1, 8, 16, 1>), dim3(n / TX, n / 8, n / 16), dim3(256), 0, 0, l, 0.9, b, x0, y1); });
+    timeit("V1 volume-scaled rows, 128x8 tile, KZ 16", [&] { hipLaunchKernelGGL((k_step<1, 8, 16, 0>), dim3(n / TX, n / 8, n / 16), dim3(256), 0, 0, l, 0.9, b, x0, y1); });
+    printf("one input stream (16 B/cell; the TB/s column counts 24: multiply by 2/3)\n");
+    timeit("C  copy, one chunk per workgroup", [&] { hipLaunchKernelGGL(k_copy1, dim3((unsigned)(N / 4 / 1024)), dim3(256), 0, 0, (const v4 *)x0, (v4 *)y0); });
+    timeit("M  y = A x, 128x8 tile, KZ 64", [&] { hipLaunchKernelGGL((k_mv<8, 64, 0, 0>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y1); });
+    timeit("M  y = A x, 128x8 tile, KZ 32", [&] { hipLaunchKernelGGL((k_mv<8, 32, 0, 0>), dim3(n / TX, n / 8, n / 32), dim3(256), 0, 0, l, x0, y1); });
+    timeit("M  y = A x, 128x8 tile, KZ 16", [&] { hipLaunchKernelGGL((k_mv<8, 16, 0, 0>), dim3(n / TX, n / 8, n / 16), dim3(256), 0, 0, l, x0, y1); });
+    timeit("M  y = A x, 128x8 tile, KZ 64, prefetch", [&] { hipLaunchKernelGGL((k_mv<8, 64, 1, 0>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y1); });
+    timeit("M  y = A x, 128x8 tile, KZ 32, prefetch", [&] { hipLaunchKernelGGL((k_mv<8, 32, 1, 0>), dim3(n / TX, n / 8, n / 32), dim3(256), 0, 0, l, x0, y1); });
+    timeit("M  y = A x, 128x8 tile, KZ 64, nontemporal stores", [&] { hipLaunchKernelGGL((k_mv<8, 64, 0, 1>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y1); });
+    timeit("M  y = A x, 128x8 tile, KZ 64, prefetch + nontemporal", [&] { hipLaunchKernelGGL((k_mv<8, 64, 1, 1>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y1); });
     timeit("V1 volume-scaled rows, 128x4 tile (128 threads), KZ 64", [&] { hipLaunchKernelGGL((k_step<1, 4, 64>), dim3(n / TX, n / 4, n / 64), dim3(128), 0, 0, l, 0.9, b, x0, y1); });
     return 0;
 }
