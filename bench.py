@@ -317,6 +317,9 @@ def main():
     # V(2,2) with damped Jacobi: 11 PCG iterations and 119 ms per 512^3 solve; V(1,1): 15 and 130 ms, V(3,3): 10 and 127 ms
     ap.add_argument("--presweeps", type=int, default=2)
     ap.add_argument("--postsweeps", type=int, default=2)
+    ap.add_argument("--transport", default=os.environ.get("PIB_TRANSPORT", "rccl"), choices=["rccl", "peer"],
+                    help="N > 1: RCCL (default) or the peer transport (HIP-IPC-mapped neighbours, one node; also what lets several "
+                         "ranks share one GPU with PIB_BENCH_SHARE_GPU=1)")
     ap.add_argument("--system", default="poisson", choices=["poisson", "velocity"],
                     help="poisson (the BASELINE metric) or the velocity system A = I/dt - c nu L with BiCGStab+Jacobi")
     args = ap.parse_args()
@@ -336,8 +339,8 @@ def main():
     share_probe = os.environ.get("PIB_BENCH_SHARE_GPU", "0") == "1"
     if not share_probe and torch.cuda.device_count() < (world if world > 1 else 1):
         return refuse(args, f"{world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU)")
-    # PIB_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0, torch side on gloo -- lets the N>1 code path be
-    # exercised on a 1-GPU box when RCCL accepts several ranks per device.
+    # PIB_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0, torch side on gloo -- the N > 1 code path on a 1-GPU
+    # box; RCCL refuses several ranks per device, the peer transport (--transport peer) takes them.
     share = os.environ.get("PIB_BENCH_SHARE_GPU", "0") == "1"
     if share:
         local = 0
@@ -356,7 +359,7 @@ def main():
         import ctypes
         buf = ctypes.create_string_buffer(capi.UID_BYTES)
         if rank == 0:
-            capi.check(capi.load().pib_comm_unique_id(buf))
+            capi.check((capi.load().pib_comm_peer_id if args.transport == "peer" else capi.load().pib_comm_unique_id)(buf))
         t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
         if not share:
             t = t.cuda()
@@ -443,7 +446,8 @@ def main():
             "config": {"workload": f"{n}^3 lid-driven cavity pressure Poisson (DBNG, 7-point, fp64 CSR int32), "
                                    f"PCG+{args.pc}" + (f" V({args.presweeps},{args.postsweeps})" if args.pc == "gmg" else "") +
                                    f", zero guess, rtol {args.tol:g}, manufactured cosine RHS",
-                       "grid": [n, n, n], "dt": dt, "parallelism": f"zslab{world}", "pc": args.pc},
+                       "grid": [n, n, n], "dt": dt, "parallelism": f"zslab{world}", "pc": args.pc,
+                       "transport": "none" if world == 1 else args.transport},
             "cg_iters_per_s": iters / elapsed, "iters_per_solve": iters / args.steps,
             "true_rel_residual": true_rel, "setup_s": t_setup,
             "spmv_gdof_per_s": n_l / (ms_spmv * 1e-3) / 1e9,

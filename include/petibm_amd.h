@@ -83,6 +83,13 @@ int pib_version(void);
 #define PIB_UID_BYTES 128
 int pib_comm_unique_id(void *uid_out /* PIB_UID_BYTES */);
 
+/* PEER transport (one node): one process per rank, the neighbours' vectors mapped through HIP IPC (peer memory over
+ * xGMI) and pulled with device-to-device copies ordered by interprocess events; the ranks meet in a POSIX shared-memory
+ * segment whose name this id carries.  Rank 0 calls pib_comm_peer_id, the id travels to the other ranks like the RCCL
+ * one, every rank passes it to pib_create.  Several ranks may share a GPU (RCCL refuses that), so this is also how the
+ * multi-process path is tested on a one-GPU box.  PIB_PEER_TIMEOUT_S (default 600) bounds every wait for another rank. */
+int pib_comm_peer_id(void *uid_out /* PIB_UID_BYTES */);
+
 /* TEST transport: `nranks` ranks = host threads of ONE process sharing ONE GPU (RCCL refuses several
  * ranks per device).  Fills a PIB_UID_BYTES id to pass to pib_create from every thread.  Used by the
  * parity tests to run the multi-rank algorithm on a single-GPU box; never by an application. */

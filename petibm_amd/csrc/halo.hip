@@ -9,52 +9,197 @@
 // pair per neighbour grouped in a single RCCL group (point-to-point over the
 // direct xGMI link between adjacent ranks; no ring involved).
 //
-// Two transports behind the same four operations:
-//   * RCCL (production): ncclSend/ncclRecv, ncclAllReduce, ncclAllGather on the solver's stream.
+// Three transports behind the same four operations:
+//   * RCCL (production, default): ncclSend/ncclRecv, ncclAllReduce, ncclAllGather on the solver's stream.
+//   * peer (production, one node; pib_comm_peer_id): one PROCESS per rank, the neighbours' vectors mapped through HIP IPC
+//     (hipIpcOpenMemHandle: peer memory over xGMI) and pulled with device-to-device copies, ordered by interprocess HIP
+//     events; the ranks meet in a POSIX shared-memory segment (handles, counts, a host barrier of atomics).  No RCCL kernel
+//     on the critical path -- and, unlike RCCL, it accepts several ranks on one GPU, so the multi-PROCESS path (id
+//     exchange, attach, exchanges, reductions) is tested end to end on the one-GPU box (tests/test_gpu_peer_transport.py).
 //   * loopback (test only): P ranks = P host threads of ONE process sharing ONE GPU
 //     (pib_comm_loopback_create).  RCCL refuses several ranks per device, and the test box has a single
 //     GPU, so this is how the multi-rank algorithm (halo plans, distributed / replicated multigrid levels,
 //     all-reduced recurrences) is exercised end to end through the C ABI.  Device-to-device copies ordered
 //     with HIP events + a host barrier per collective.
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 
 #include "pib_internal.hpp"
 
 namespace pib {
 
-// ------------------------------------------------------------------ loopback group
+// ------------------------------------------------------------------ loopback / peer group
+// What the ranks of the peer transport share (POSIX shared memory; plain data and lock-free atomics only)
+constexpr int PEER_MAX_RANKS = 64;
+struct alignas(64) PeerFlag {
+    std::atomic<uint64_t> v;
+};
+struct PeerShm {
+    std::atomic<uint32_t> state;  // 1: initialised by rank 0
+    int nranks;
+    std::atomic<int> attached;
+    std::atomic<uint32_t> bar_count, bar_gen;
+    std::atomic<int> failed;      // a rank gave up (timeout / error): everybody leaves the waits
+    std::atomic<int> open_lock;   // one rank at a time inside hipIpcOpenMemHandle
+    int64_t window_doubles;       // size of every rank's window (the same everywhere: rank 0's setting)
+    hipIpcMemHandle_t staging;    // rank 0's [nranks][PIB_NRED] buffer of the scalar all-reduce
+    hipIpcMemHandle_t window[PEER_MAX_RANKS];  // every rank's window: what it sends lies there for the others to fetch
+    // collective number `seq` (counted alike on every rank): ready[r] >= seq -- rank r's window holds its data for it;
+    // done[r] >= seq -- rank r has fetched what it needs from the others' windows.  Set by host functions in stream order.
+    PeerFlag ready[PEER_MAX_RANKS], done[PEER_MAX_RANKS];
+    int64_t host_vals[PEER_MAX_RANKS][4];
+};
+
 struct LoopbackGroup {
     int nranks = 0;
+    // loopback flavour: threads of one process
     std::mutex mu;
     std::condition_variable cv;
     int arrived = 0;
     uint64_t generation = 0;
-    // per-rank published state
+    // peer flavour: one process per rank
+    PeerShm *shm = nullptr;
+    int me = -1;
+    double timeout_s = 600.0;
+    uint64_t seq = 0;                 // collectives issued so far
+    double *staging_local = nullptr;  // rank 0 owns the staging buffer
+    // Windows.  A rank never maps another rank's vectors (mapping a 2 GB work-vector allocation in the middle of a run
+    // did not come back from hipIpcOpenMemHandle on the test box; tools/ipc_probe*.hip could not reproduce it in
+    // isolation): it copies what it sends into its own window -- one half for the previous rank, one for the next, the
+    // whole of it for the all-to-all collectives -- and the others fetch from there.  The windows are mapped once, at
+    // attach, when nothing else is going on.
+    double *win_local = nullptr;
+    std::vector<double *> win;        // every rank's window as this process sees it (win[me] = win_local)
+    int64_t win_doubles = 0;
+    // per-rank published state as this rank sees it
     std::vector<const double *> ptr;
     std::vector<int64_t> count;
     std::vector<const std::vector<std::pair<int64_t, int64_t>> *> segs_prev, segs_next;  // segmented plans of the ranks
     std::vector<hipEvent_t> ev_ready, ev_done;
     std::vector<int64_t> host_vals;  // [nranks][4]
     double *staging = nullptr;       // device, [nranks][PIB_NRED]
-    void barrier()
+
+    int barrier()
     {
-        std::unique_lock<std::mutex> lk(mu);
-        const uint64_t gen = generation;
-        if (++arrived == nranks) {
-            arrived = 0;
-            ++generation;
-            cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return generation != gen; });
+        if (shm == nullptr) {
+            std::unique_lock<std::mutex> lk(mu);
+            const uint64_t gen = generation;
+            if (++arrived == nranks) {
+                arrived = 0;
+                ++generation;
+                cv.notify_all();
+            } else {
+                cv.wait(lk, [&] { return generation != gen; });
+            }
+            return 0;
         }
+        const uint32_t gen = shm->bar_gen.load(std::memory_order_acquire);
+        if (shm->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)nranks) {
+            shm->bar_count.store(0, std::memory_order_relaxed);
+            shm->bar_gen.fetch_add(1, std::memory_order_release);
+            return shm->failed.load() ? fail(PIB_ERR_LIB, "peer transport: another rank failed") : 0;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t spins = 0; shm->bar_gen.load(std::memory_order_acquire) == gen; ++spins) {
+            if (shm->failed.load(std::memory_order_relaxed)) return fail(PIB_ERR_LIB, "peer transport: another rank failed");
+            if ((spins & 1023) == 1023) {
+                sched_yield();
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                    shm->failed.store(1);
+                    return fail(PIB_ERR_LIB, "peer transport: rank %d waited %.0f s for the other ranks (PIB_PEER_TIMEOUT_S)", me, timeout_s);
+                }
+            }
+        }
+        return 0;
+    }
+
+    // loopback flavour: make `p` (count entries, optionally the segment lists of a packed vector) visible to the other
+    // rank threads
+    int publish(int r, const double *p, int64_t cnt, const std::vector<std::pair<int64_t, int64_t>> *sp = nullptr,
+                const std::vector<std::pair<int64_t, int64_t>> *sn = nullptr)
+    {
+        ptr[(size_t)r] = p;
+        count[(size_t)r] = cnt;
+        segs_prev[(size_t)r] = sp;
+        segs_next[(size_t)r] = sn;
+        return 0;
+    }
+
+    bool trace = std::getenv("PIB_PEER_TRACE") != nullptr;
+    void note(const char *what, uint64_t k) const
+    {
+        if (trace) {
+            std::fprintf(stderr, "[peer %d] %s %llu\n", me, what, (unsigned long long)k);
+            std::fflush(stderr);
+        }
+    }
+    uint64_t begin() { return ++seq; }
+
+    // ---- peer flavour: ordering between the ranks.  HIP's interprocess events stop after 32 records on this runtime
+    // (tools/ipc_probe2.hip), so completion travels through the shared segment: a host function enqueued behind the
+    // producing work raises the rank's flag, the consumer's host waits for it before it enqueues the copies.  The GPU
+    // streams never wait for another rank; the host threads do, at every collective.
+    struct HostSet {
+        std::atomic<uint64_t> *flag;
+        uint64_t val;
+        bool trace;
+    };
+    static void host_set(void *p)
+    {
+        HostSet *h = static_cast<HostSet *>(p);
+        h->flag->store(h->val, std::memory_order_release);
+        if (h->trace) {
+            std::fprintf(stderr, "[peer] flag raised to %llu\n", (unsigned long long)h->val);
+            std::fflush(stderr);
+        }
+        delete h;
+    }
+    int raise(hipStream_t st, PeerFlag &f, uint64_t val)
+    {
+        HostSet *h = new HostSet{&f.v, val, trace};
+        const hipError_t e = hipLaunchHostFunc(st, host_set, h);
+        if (e != hipSuccess) {
+            delete h;
+            return fail(PIB_ERR_LIB, "peer transport: hipLaunchHostFunc: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    int await(const PeerFlag &f, uint64_t val, const char *what, int q)
+    {
+        note(what, val);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t spins = 0; f.v.load(std::memory_order_acquire) < val; ++spins) {
+            if (shm->failed.load(std::memory_order_relaxed)) return fail(PIB_ERR_LIB, "peer transport: another rank failed");
+            if ((spins & 255) == 255) {
+                sched_yield();
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                    shm->failed.store(1);
+                    return fail(PIB_ERR_LIB, "peer transport: rank %d waited %.0f s for rank %d (%s, collective %llu)", me, timeout_s, q,
+                                what, (unsigned long long)val);
+                }
+            }
+        }
+        return 0;
     }
 };
 
 static const char LOOP_MAGIC[8] = {'P', 'I', 'B', 'L', 'O', 'O', 'P', '1'};
+static const char PEER_MAGIC[8] = {'P', 'I', 'B', 'P', 'E', 'E', 'R', '1'};
 
 __global__ void k_lb_sum(double *dst, const double *staging, int nranks, int count)
 {
@@ -64,6 +209,130 @@ __global__ void k_lb_sum(double *dst, const double *staging, int nranks, int cou
         for (int r = 0; r < nranks; ++r) s += staging[r * PIB_NRED + i];
         dst[i] = s;
     }
+}
+
+// ---- peer transport: the ranks (processes) meet in the shared-memory segment named in the id
+static void peer_destroy(LoopbackGroup *g)
+{
+    if (g == nullptr) return;
+    for (int q = 0; q < (int)g->win.size(); ++q)
+        if (q != g->me && g->win[(size_t)q]) (void)hipIpcCloseMemHandle(g->win[(size_t)q]);
+    if (g->win_local) (void)hipFree(g->win_local);
+    if (g->staging_local) (void)hipFree(g->staging_local);
+    else if (g->staging) (void)hipIpcCloseMemHandle(g->staging);
+    if (g->shm) (void)munmap(g->shm, sizeof(PeerShm));
+    delete g;
+}
+static int peer_attach(pib_solver *s, int rank, int nranks, const char *name)
+{
+    if (nranks > PEER_MAX_RANKS) return fail(PIB_ERR_SUP, "peer transport: at most %d ranks", PEER_MAX_RANKS);
+    LoopbackGroup *g = new LoopbackGroup();
+    g->nranks = nranks;
+    g->me = rank;
+    if (const char *t = std::getenv("PIB_PEER_TIMEOUT_S")) g->timeout_s = std::max(1.0, std::atof(t));
+    g->ptr.assign((size_t)nranks, nullptr);
+    g->count.assign((size_t)nranks, 0);
+    g->segs_prev.assign((size_t)nranks, nullptr);
+    g->segs_next.assign((size_t)nranks, nullptr);
+    g->win.assign((size_t)nranks, nullptr);
+    g->host_vals.assign(4 * (size_t)nranks, 0);
+    g->ev_ready.assign((size_t)nranks, nullptr);
+    g->ev_done.assign((size_t)nranks, nullptr);
+    auto bail = [&](int err) {
+        if (g->shm) g->shm->failed.store(1);
+        peer_destroy(g);
+        return err;
+    };
+    // rank 0 creates the segment, the others wait for it
+    const auto t0 = std::chrono::steady_clock::now();
+    auto late = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > g->timeout_s; };
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)sizeof(PeerShm)) != 0) {
+            if (fd >= 0) (void)close(fd);
+            return bail(fail(PIB_ERR_LIB, "peer transport: cannot create the shared segment %s", name));
+        }
+    } else {
+        for (;;) {
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(PeerShm)) break;
+            if (fd >= 0) (void)close(fd);
+            fd = -1;
+            if (late()) return bail(fail(PIB_ERR_LIB, "peer transport: rank %d never saw rank 0's segment %s", rank, name));
+            usleep(1000);
+        }
+    }
+    void *m = mmap(nullptr, sizeof(PeerShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    (void)close(fd);
+    if (m == MAP_FAILED) return bail(fail(PIB_ERR_LIB, "peer transport: mmap of the shared segment failed"));
+    g->shm = static_cast<PeerShm *>(m);
+    if (rank == 0) {
+        std::memset(m, 0, sizeof(PeerShm));  // a fresh segment is zero-filled already; the atomics start at 0
+        g->shm->nranks = nranks;
+        g->shm->state.store(1, std::memory_order_release);
+    } else {
+        while (g->shm->state.load(std::memory_order_acquire) != 1) {
+            if (late()) return bail(fail(PIB_ERR_LIB, "peer transport: rank 0 never initialised the segment"));
+            usleep(100);
+        }
+        if (g->shm->nranks != nranks) return bail(fail(PIB_ERR_ARG_WRONG, "peer transport: the ranks disagree about nranks"));
+    }
+    g->shm->attached.fetch_add(1);
+    // this rank's window and (rank 0) the staging buffer of the scalar all-reduce
+    if (rank == 0) {
+        double mb = 128.0;
+        if (const char *t = std::getenv("PIB_PEER_WINDOW_MB")) mb = std::max(1.0, std::atof(t));
+        g->shm->window_doubles = ((int64_t)(mb * 1048576.0 / 8.0) / 64) * 64;
+    }
+    int err0 = g->barrier();
+    if (err0) return bail(err0);
+    g->win_doubles = g->shm->window_doubles;
+    hipError_t e = hipMalloc(&g->win_local, sizeof(double) * (size_t)g->win_doubles);
+    if (e == hipSuccess) e = hipMemset(g->win_local, 0, sizeof(double) * (size_t)g->win_doubles);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&g->shm->window[rank], g->win_local);
+    g->win[(size_t)rank] = g->win_local;
+    if (e == hipSuccess && rank == 0) {
+        e = hipMalloc(&g->staging_local, sizeof(double) * PIB_NRED * (size_t)nranks);
+        if (e == hipSuccess) e = hipMemset(g->staging_local, 0, sizeof(double) * PIB_NRED * (size_t)nranks);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&g->shm->staging, g->staging_local);
+        g->staging = g->staging_local;
+    }
+    if (e != hipSuccess) return bail(fail(PIB_ERR_LIB, "peer transport: staging buffer: %s", hipGetErrorString(e)));
+    int err = g->barrier();
+    if (err) return bail(err);
+    // map the others' windows and the staging buffer, one rank at a time
+    {
+        const auto t1 = std::chrono::steady_clock::now();
+        for (int expect = 0; !g->shm->open_lock.compare_exchange_weak(expect, 1, std::memory_order_acquire); expect = 0) {
+            sched_yield();
+            if (g->shm->failed.load() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() > g->timeout_s)
+                return bail(fail(PIB_ERR_LIB, "peer transport: rank %d waited %.0f s for its turn to map the windows", rank, g->timeout_s));
+        }
+        for (int q = 0; q < nranks && e == hipSuccess; ++q) {
+            if (q == rank) continue;
+            void *base = nullptr;
+            e = hipIpcOpenMemHandle(&base, g->shm->window[q], hipIpcMemLazyEnablePeerAccess);
+            g->win[(size_t)q] = static_cast<double *>(base);
+        }
+        if (e == hipSuccess && rank != 0) {
+            void *st_base = nullptr;
+            e = hipIpcOpenMemHandle(&st_base, g->shm->staging, hipIpcMemLazyEnablePeerAccess);
+            g->staging = static_cast<double *>(st_base);
+        }
+        g->shm->open_lock.store(0, std::memory_order_release);
+        if (e != hipSuccess) return bail(fail(PIB_ERR_LIB, "peer transport: mapping the windows: %s", hipGetErrorString(e)));
+    }
+    err = g->barrier();
+    if (err) return bail(err);
+    if (rank == 0) (void)shm_unlink(name);  // everybody holds a mapping: the name can go
+    s->comm.loop = g;
+    s->comm.peer = true;
+    return 0;
 }
 
 int comm_init(pib_solver *s, int rank, int nranks, const void *uid)
@@ -81,6 +350,7 @@ int comm_init(pib_solver *s, int rank, int nranks, const void *uid)
         s->comm.loop = g;
         return 0;
     }
+    if (std::memcmp(uid, PEER_MAGIC, 8) == 0) return peer_attach(s, rank, nranks, (const char *)uid + 8);
     ncclUniqueId id;
     static_assert(sizeof(ncclUniqueId) <= PIB_UID_BYTES, "unique id does not fit");
     std::memcpy(&id, uid, sizeof(id));
@@ -92,7 +362,8 @@ void comm_release(pib_solver *s)
 {
     if (s->comm.comm && !s->comm.borrowed) (void)ncclCommDestroy(s->comm.comm);
     s->comm.comm = nullptr;
-    s->comm.loop = nullptr;  // the group is owned by whoever created it
+    if (s->comm.loop && s->comm.peer && !s->comm.borrowed) peer_destroy(s->comm.loop);  // this solver attached it
+    s->comm.loop = nullptr;  // a loopback group is owned by whoever created it
 }
 
 // host-side all-gather of 4 int64 per rank (setup only)
@@ -102,10 +373,18 @@ static int allgather_host4(pib_solver *s, const int64_t mine[4], std::vector<int
     all.assign(4 * (size_t)P, 0);
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
+        if (g->shm) {
+            for (int k = 0; k < 4; ++k) g->shm->host_vals[r][k] = mine[k];
+            PIB_CHK(g->barrier());
+            for (int q = 0; q < P; ++q)
+                for (int k = 0; k < 4; ++k) all[4 * (size_t)q + k] = g->shm->host_vals[q][k];
+            PIB_CHK(g->barrier());
+            return 0;
+        }
         for (int k = 0; k < 4; ++k) g->host_vals[4 * (size_t)r + k] = mine[k];
-        g->barrier();
+        PIB_CHK(g->barrier());
         all = g->host_vals;
-        g->barrier();
+        PIB_CHK(g->barrier());
         return 0;
     }
     int64_t *d_all = nullptr;
@@ -136,7 +415,7 @@ int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vec
     PIB_CHK(comm_allgatherv(s, d_all + L * (size_t)r, d_all, cnt, off, s->stream));
     PIB_HIP(hipMemcpyAsync(all.data(), d_all, sizeof(double) * L * (size_t)P, hipMemcpyDeviceToHost, s->stream));
     PIB_HIP(hipStreamSynchronize(s->stream));
-    if (s->comm.loop) s->comm.loop->barrier();  // nobody frees while a peer still reads
+    if (s->comm.loop) PIB_CHK(s->comm.loop->barrier());  // nobody frees while a peer still reads
     PIB_HIP(hipFree(d_all));
     return 0;
 }
@@ -185,14 +464,58 @@ int comm_setup_halo(pib_solver *s)
 }
 
 // loopback: publish -> barrier -> pull from the neighbours -> barrier -> order later writes after their reads
+// peer: what the neighbours need goes into this rank's window (first half: for the previous rank, second half: for the
+// next one), `ready` is raised behind those copies, the ghosts are fetched from the neighbours' windows once theirs is up,
+// `done` is raised behind the fetches -- and the call returns when the neighbours have fetched (the window is free again)
+static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, bool has_pv, bool has_nx,
+                                const std::vector<std::pair<const double *, int64_t>> &to_prev,
+                                const std::vector<std::pair<const double *, int64_t>> &to_next, double *ghost_lo, int64_t lo,
+                                double *ghost_hi, int64_t hi, const char *what)
+{
+    LoopbackGroup *g = s->comm.loop;
+    const int r = s->comm.rank;
+    const int64_t half = g->win_doubles / 2;
+    int64_t np = 0, nn = 0;
+    for (const auto &m : to_prev) np += m.second;
+    for (const auto &m : to_next) nn += m.second;
+    if (np > half || nn > half || lo > half || hi > half)
+        return fail(PIB_ERR_SUP, "peer transport: a message of %lld entries does not fit half a window (%lld): raise PIB_PEER_WINDOW_MB",
+                    (long long)std::max(std::max(np, nn), std::max(lo, hi)), (long long)half);
+    const uint64_t seq = g->begin();
+    double *dst = g->win_local;
+    if (has_pv)
+        for (const auto &m : to_prev) {
+            if (m.second > 0) PIB_HIP(hipMemcpyAsync(dst, m.first, sizeof(double) * (size_t)m.second, hipMemcpyDeviceToDevice, st));
+            dst += m.second;
+        }
+    dst = g->win_local + half;
+    if (has_nx)
+        for (const auto &m : to_next) {
+            if (m.second > 0) PIB_HIP(hipMemcpyAsync(dst, m.first, sizeof(double) * (size_t)m.second, hipMemcpyDeviceToDevice, st));
+            dst += m.second;
+        }
+    PIB_CHK(g->raise(st, g->shm->ready[r], seq));
+    if (has_pv && lo > 0) {  // the previous rank's message for ITS next rank
+        PIB_CHK(g->await(g->shm->ready[pv], seq, what, pv));
+        PIB_HIP(hipMemcpyAsync(ghost_lo, g->win[(size_t)pv] + half, sizeof(double) * (size_t)lo, hipMemcpyDeviceToDevice, st));
+    }
+    if (has_nx && hi > 0) {
+        PIB_CHK(g->await(g->shm->ready[nx], seq, what, nx));
+        PIB_HIP(hipMemcpyAsync(ghost_hi, g->win[(size_t)nx], sizeof(double) * (size_t)hi, hipMemcpyDeviceToDevice, st));
+    }
+    PIB_CHK(g->raise(st, g->shm->done[r], seq));
+    if (has_pv) PIB_CHK(g->await(g->shm->done[pv], seq, "window fetched", pv));
+    if (has_nx && nx != pv) PIB_CHK(g->await(g->shm->done[nx], seq, "window fetched", nx));
+    return 0;
+}
+
 static int lb_halo(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, int64_t hi, hipStream_t st)
 {
     LoopbackGroup *g = s->comm.loop;
     const int P = s->comm.nranks, r = s->comm.rank;
-    g->ptr[(size_t)r] = x_owned;
-    g->count[(size_t)r] = n_owned;
+    PIB_CHK(g->publish(r, x_owned, n_owned));
     PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
-    g->barrier();
+    PIB_CHK(g->barrier());
     const bool ring = s->comm.ring;
     const size_t pv = (size_t)((r + P - 1) % P), nx = (size_t)((r + 1) % P);
     if ((r > 0 || ring) && lo > 0) {
@@ -205,10 +528,10 @@ static int lb_halo(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, 
         PIB_HIP(hipMemcpyAsync(x_owned + n_owned, g->ptr[nx], sizeof(double) * (size_t)hi, hipMemcpyDeviceToDevice, st));
     }
     PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
-    g->barrier();
+    PIB_CHK(g->barrier());
     if (r > 0 || ring) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[pv], 0));
     if (r < P - 1 || ring) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[nx], 0));
-    g->barrier();
+    PIB_CHK(g->barrier());
     return 0;
 }
 
@@ -220,6 +543,11 @@ int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_
     const int P = s->comm.nranks, r = s->comm.rank;
     if (!s->comm.active()) return 0;
     s->counters[3]++;
+    if (s->comm.loop && s->comm.loop->shm) {
+        const bool ring = s->comm.ring;
+        return peer_window_exchange(s, st, (r + P - 1) % P, (r + 1) % P, r > 0 || ring, r < P - 1 || ring, {{x_owned, send_prev}},
+                                    {{x_owned + n_owned - send_next, send_next}}, x_owned - lo, lo, x_owned + n_owned, hi, "halo planes");
+    }
     if (s->comm.loop) return lb_halo(s, x_owned, n_owned, lo, hi, st);
     if (s->comm.ring) {
         // periodic slab axis: rank 0's low ghost plane comes from rank P-1 and vice versa.  With P == 2 both messages
@@ -255,13 +583,21 @@ static int halo_exchange_segments(pib_solver *s, double *x_owned, hipStream_t st
     const DeviceCsr &A = s->A;
     const int P = s->comm.nranks, r = s->comm.rank;
     s->counters[3]++;
+    if (s->comm.loop && s->comm.loop->shm) {
+        std::vector<std::pair<const double *, int64_t>> to_prev, to_next;
+        for (const auto &sg : A.seg_send_prev) to_prev.emplace_back(x_owned + sg.first, sg.second);
+        for (const auto &sg : A.seg_send_next) to_next.emplace_back(x_owned + sg.first, sg.second);
+        int64_t lo = 0, hi = 0;
+        for (int64_t c : A.seg_recv_lo) lo += c;
+        for (int64_t c : A.seg_recv_hi) hi += c;
+        return peer_window_exchange(s, st, r - 1, r + 1, r > 0, r < P - 1, to_prev, to_next, x_owned - A.ghost_lo, lo, x_owned + A.n, hi,
+                                    "halo segments");
+    }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
-        g->ptr[(size_t)r] = x_owned;
-        g->segs_prev[(size_t)r] = &A.seg_send_prev;
-        g->segs_next[(size_t)r] = &A.seg_send_next;
+        PIB_CHK(g->publish(r, x_owned, A.n, &A.seg_send_prev, &A.seg_send_next));
         PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         if (r > 0 && !A.seg_recv_lo.empty()) {
             PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)(r - 1)], 0));
             double *dst = x_owned - A.ghost_lo;
@@ -281,10 +617,10 @@ static int halo_exchange_segments(pib_solver *s, double *x_owned, hipStream_t st
             }
         }
         PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         if (r > 0) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)(r - 1)], 0));
         if (r < P - 1) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)(r + 1)], 0));
-        g->barrier();
+        PIB_CHK(g->barrier());
         return 0;
     }
     PIB_NCCL(ncclGroupStart());
@@ -323,20 +659,36 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
 {
     if (!s->comm.active()) return 0;
     s->counters[2]++;
+    if (s->comm.loop && s->comm.loop->shm) {
+        // every rank copies its values into its row of rank 0's staging buffer, then sums the rows in rank order
+        LoopbackGroup *g = s->comm.loop;
+        const int P = s->comm.nranks, r = s->comm.rank;
+        const uint64_t seq = g->begin();
+        PIB_HIP(hipMemcpyAsync(g->staging + (size_t)r * PIB_NRED, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
+        PIB_CHK(g->raise(st, g->shm->ready[r], seq));
+        for (int q = 0; q < P; ++q)
+            if (q != r) PIB_CHK(g->await(g->shm->ready[q], seq, "all-reduce", q));
+        hipLaunchKernelGGL(k_lb_sum, dim3(1), dim3(64), 0, st, dev, g->staging, P, count);
+        PIB_HIP(hipGetLastError());
+        PIB_CHK(g->raise(st, g->shm->done[r], seq));
+        for (int q = 0; q < P; ++q)
+            if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "all-reduce read", q));  // the rows are free again
+        return 0;
+    }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
         const int P = s->comm.nranks, r = s->comm.rank;
         PIB_HIP(hipMemcpyAsync(g->staging + (size_t)r * PIB_NRED, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
         PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         for (int q = 0; q < P; ++q)
             if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)q], 0));
         hipLaunchKernelGGL(k_lb_sum, dim3(1), dim3(64), 0, st, dev, g->staging, P, count);
         PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         for (int q = 0; q < P; ++q)
             if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)q], 0));
-        g->barrier();
+        PIB_CHK(g->barrier());
         return 0;
     }
     PIB_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, s->comm.comm, st));
@@ -353,26 +705,48 @@ __global__ void k_lb_add(double *__restrict__ acc, const double *__restrict__ x,
 int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st)
 {
     if (!s->comm.active() || count <= 0) return 0;
+    if (s->comm.loop && s->comm.loop->shm) {
+        // a window's worth at a time: every rank lays its piece into its window, then sums all the windows' pieces in
+        // rank order (the same bits on every rank) straight into its own buffer
+        LoopbackGroup *g = s->comm.loop;
+        const int P = s->comm.nranks, r = s->comm.rank;
+        for (int64_t off = 0; off < count; off += g->win_doubles) {
+            const int64_t len = std::min<int64_t>(g->win_doubles, count - off);
+            const uint64_t seq = g->begin();
+            PIB_HIP(hipMemcpyAsync(g->win_local, dev + off, sizeof(double) * (size_t)len, hipMemcpyDeviceToDevice, st));
+            PIB_CHK(g->raise(st, g->shm->ready[r], seq));
+            const int nb = (int)std::min<int64_t>(4096, (len + 255) / 256);
+            for (int q = 0; q < P; ++q) {
+                if (q != r) PIB_CHK(g->await(g->shm->ready[q], seq, "all-reduce (large)", q));
+                hipLaunchKernelGGL(k_lb_add, dim3(nb), dim3(256), 0, st, dev + off, g->win[(size_t)q], len, q == 0 ? 1 : 0);
+            }
+            PIB_HIP(hipGetLastError());
+            PIB_CHK(g->raise(st, g->shm->done[r], seq));
+            for (int q = 0; q < P; ++q)
+                if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "window fetched", q));
+        }
+        return 0;
+    }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
         const int P = s->comm.nranks, r = s->comm.rank;
         double *tmp = nullptr;
         PIB_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)count));
-        g->ptr[(size_t)r] = dev;
+        PIB_CHK(g->publish(r, dev, count));
         PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         const int nb = (int)std::min<int64_t>(4096, (count + 255) / 256);
         for (int q = 0; q < P; ++q) {  // rank order: the same bits on every rank
             if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)q], 0));
             hipLaunchKernelGGL(k_lb_add, dim3(nb), dim3(256), 0, st, tmp, g->ptr[(size_t)q], count, q == 0 ? 1 : 0);
         }
         PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         for (int q = 0; q < P; ++q)
             if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)q], 0));  // everybody has read my buffer
         PIB_HIP(hipMemcpyAsync(dev, tmp, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
         PIB_HIP(hipStreamSynchronize(st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         PIB_HIP(hipFree(tmp));
         return 0;
     }
@@ -387,21 +761,43 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
     const int P = s->comm.nranks, r = s->comm.rank;
     if (!s->comm.active()) return 0;
     s->counters[3]++;
+    if (s->comm.loop && s->comm.loop->shm) {
+        LoopbackGroup *g = s->comm.loop;
+        int64_t longest = 0;
+        for (int q = 0; q < P; ++q) longest = std::max(longest, counts[(size_t)q]);
+        for (int64_t off = 0; off < longest; off += g->win_doubles) {  // a window's worth of every rank's part at a time
+            const uint64_t seq = g->begin();
+            const int64_t mine = std::max<int64_t>(0, std::min<int64_t>(g->win_doubles, counts[(size_t)r] - off));
+            if (mine > 0) PIB_HIP(hipMemcpyAsync(g->win_local, send + off, sizeof(double) * (size_t)mine, hipMemcpyDeviceToDevice, st));
+            PIB_CHK(g->raise(st, g->shm->ready[r], seq));
+            for (int q = 0; q < P; ++q) {
+                const int64_t len = std::max<int64_t>(0, std::min<int64_t>(g->win_doubles, counts[(size_t)q] - off));
+                if (q != r) PIB_CHK(g->await(g->shm->ready[q], seq, "all-gather", q));
+                if (len > 0)
+                    PIB_HIP(hipMemcpyAsync(recv_base + offs[(size_t)q] + off, g->win[(size_t)q], sizeof(double) * (size_t)len,
+                                           hipMemcpyDeviceToDevice, st));
+            }
+            PIB_CHK(g->raise(st, g->shm->done[r], seq));
+            for (int q = 0; q < P; ++q)
+                if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "window fetched", q));
+        }
+        return 0;
+    }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
-        g->ptr[(size_t)r] = send;
+        PIB_CHK(g->publish(r, send, counts[(size_t)r]));
         PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         for (int q = 0; q < P; ++q) {
             if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)q], 0));
             PIB_HIP(hipMemcpyAsync(recv_base + offs[(size_t)q], g->ptr[(size_t)q], sizeof(double) * (size_t)counts[(size_t)q],
                                    hipMemcpyDeviceToDevice, st));
         }
         PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
-        g->barrier();
+        PIB_CHK(g->barrier());
         for (int q = 0; q < P; ++q)
             if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)q], 0));
-        g->barrier();
+        PIB_CHK(g->barrier());
         return 0;
     }
     bool equal = true;
@@ -551,6 +947,20 @@ extern "C" int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, dou
     (void)hipStreamDestroy(s->stream);
     (void)hipStreamDestroy(s->stream_comm);
     s->stream = s->stream_comm = nullptr;
+    return 0;
+}
+
+// the id of a peer-transport world: a fresh shared-memory name; rank 0 makes it, every rank gets it (like the RCCL id)
+extern "C" int pib_comm_peer_id(void *uid_out)
+{
+    using namespace pib;
+    if (uid_out == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_comm_peer_id: null output");
+    static std::atomic<unsigned> serial{0};
+    const auto now = std::chrono::steady_clock::now().time_since_epoch().count();
+    std::memset(uid_out, 0, PIB_UID_BYTES);
+    std::memcpy(uid_out, PEER_MAGIC, 8);
+    std::snprintf((char *)uid_out + 8, PIB_UID_BYTES - 8, "/pib_peer_%d_%u_%llx", (int)getpid(), serial.fetch_add(1),
+                  (unsigned long long)now);
     return 0;
 }
 

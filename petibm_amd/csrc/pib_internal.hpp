@@ -194,6 +194,7 @@ struct Comm {
     LoopbackGroup *loop = nullptr;
     int rank = 0, nranks = 1;
     bool borrowed = false;  // the communicator belongs to another solver of the same engine (one RCCL id makes one communicator)
+    bool peer = false;      // `loop` is a peer-transport group (one process per rank, HIP IPC) that this solver attached
     bool ring = false;  // the slab axis is periodic: rank 0 and rank P-1 are neighbours (their outer ghost planes wrap)
     // a transport is attached (always and only when nranks > 1, except in pib_comm_selftest's one-rank RCCL world)
     bool active() const { return comm != nullptr || loop != nullptr; }

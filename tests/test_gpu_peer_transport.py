@@ -1,0 +1,151 @@
+"""The peer transport (csrc/halo.hip, pib_comm_peer_id): ONE PROCESS PER RANK, the neighbours' vectors mapped through HIP
+IPC and pulled with device-to-device copies ordered by interprocess events, the ranks meeting in a POSIX shared-memory
+segment.  RCCL refuses several ranks per device; this transport does not, so here the multi-PROCESS path of SURVEY.md 8e
+-- the id made by rank 0 and handed to every rank, the attach, z-slab assembly, halo plans incl. the periodic ring and the
+packed velocity ordering, all-reduced recurrences, distributed / replicated multigrid levels, the time step and immersed
+bodies on slabs, and bench.py's own N > 1 launch -- runs end to end on the one test GPU, P processes at a time
+(tests/peer_worker.py is one rank)."""
+import ctypes
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import clib, mesh as omesh, operators as oops
+from test_gpu_multirank_loopback import _cfg
+from test_gpu_parity import rhs_for
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+WORKER = os.path.join(ROOT, "tests", "peer_worker.py")
+
+
+def peer_id() -> bytes:
+    from petibm_amd import capi
+    uid = ctypes.create_string_buffer(capi.UID_BYTES)
+    capi.check(capi.load().pib_comm_peer_id(uid))
+    assert uid.raw[:8] == b"PIBPEER1"
+    return uid.raw
+
+
+def run_ranks(tmp_path, job, P, timeout=420):
+    """P worker processes on the one GPU; returns their result files"""
+    job = dict(job, P=P, uid=peer_id())
+    path = os.path.join(tmp_path, "job.pkl")
+    pickle.dump(job, open(path, "wb"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PIB_PEER_TIMEOUT_S="240")
+    procs = [subprocess.Popen([sys.executable, WORKER, path, str(r)], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(P)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=timeout)[0])
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(P)]
+
+
+@pytest.mark.parametrize("P,n,per,pc,extra,sweeps", [
+    (2, (16, 16, 16), None, "BLOCK_JACOBI", "", 1),
+    (3, (24, 20), None, "BLOCK_JACOBI", "", 1),                                        # 2-D: slabs along y
+    (2, (16, 16, 32), None, "AMG", "pib_agglomerate_below=10\n", 1),                    # several distributed levels
+    (4, (32, 32, 32), None, "AMG", "pib_agglomerate_below=100\n", 2),                   # the bench's V(2,2) cycle
+    (3, (128, 16, 96), None, "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\npib_overlap_min_bytes=0\n", 2),  # fused kernels, overlapped exchange
+    (2, (16, 16, 32), (True, True, True), "AMG", "", 1),                               # periodic slab axis: the ring, P = 2
+    (3, (16, 16, 36), (True, False, True), "AMG", "", 1),
+])
+def test_poisson_solve_across_processes_matches_single_rank(tmp_path, P, n, per, pc, extra, sweeps):
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    dt = 0.01
+    m = omesh.create_mesh(omesh.periodic_config(n, per) if per else omesh.uniform_config(n))
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    xs, b = rhs_for(A)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    cfg = _cfg(pc, extra=extra, sweeps=sweeps)
+    res = run_ranks(str(tmp_path), dict(kind="poisson", n=n, w=w, dt=dt, cfg=cfg, xs=xs, b=b, periodic=per), P)
+    y = np.concatenate([r["y"] for r in res])
+    x = np.concatenate([r["x"] for r in res])
+    if per and per[-1]:
+        assert np.abs(y - b).max() <= 4e-16 * np.abs(A.val).max() * np.abs(xs).max() * 8  # wrapped neighbour summed first
+    else:
+        assert np.array_equal(y, b)  # SpMV across the slab boundaries: bit-identical to the oracle
+    assert len({int(r["its"]) for r in res}) == 1
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    assert all(int(r["counters"][5]) == P for r in res)  # ranks the transport reports
+    s1 = LinSolverHIP("poisson", config_text=cfg)
+    if per:
+        s1.setPeriodic(per)
+    s1.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+    x1 = np.zeros(A.n_rows)
+    s1.solve(x1, b)
+    assert int(res[0]["its"]) <= s1.getIters() + (6 if per else 1)
+    e = (x - x.mean()) - (x1 - x1.mean())
+    assert np.linalg.norm(e) <= 1e-7 * np.linalg.norm(x1)
+    s1.destroy()
+
+
+@pytest.mark.parametrize("case,P,bodies", [("3d_cavity", 2, False), ("2d_convective_outlet", 3, False), ("3d_sphere", 2, True),
+                                           ("moving_cylinder", 3, True)])
+def test_time_step_across_processes_matches_single_rank(tmp_path, case, P, bodies):
+    """the device time step (and the decoupled IBPM step with its all-reduced force system) on slabs, one process per rank"""
+    import test_gpu_navierstokes_slabs as T
+    from petibm_amd.navierstokes import DecoupledIBPMSolver, NavierStokesSolver
+    steps = 3
+    job = dict(kind="navierstokes", case=case, bodies=bodies, steps=steps)
+    if bodies:
+        cfg, bods, pose = T._ib_case(case)
+        one = DecoupledIBPMSolver(cfg, bodies=bods, velocity_cfg=T.VEL, poisson_cfg=T.KSP_P, forces_cfg=T.FORCES)
+        dt = cfg["parameters"]["dt"]
+        for step in range(1, steps + 1):
+            if pose is not None:
+                x, v = pose(step * dt)
+                one.moveBodies([x], [v])
+            one.advance()
+        f1 = np.asarray(one.getForces()[0])
+    else:
+        make, pinned = T.CASES[case]
+        one = NavierStokesSolver(make(), velocity_cfg=T.VEL, poisson_cfg=T.AMGX_P if pinned else T.KSP_P)
+        rng = np.random.default_rng(11)
+        job["U0"] = 0.1 * rng.uniform(-1, 1, one.UN)
+        job["p0"] = 0.1 * rng.uniform(-1, 1, one.pN)
+        if "convective" in case:
+            job["U0"][: int(np.prod(one._field_shape(0)))] += 1.0
+        one.setState(job["U0"], job["p0"])
+        one.advance(steps)
+    job["U_ref"], job["p_ref"] = one.getState()
+    one.destroy()
+    res = run_ranks(str(tmp_path), job, P)
+    for r in res:
+        assert np.abs(r["U"] - r["U_ref"]).max() <= 1e-8 * max(1.0, np.abs(r["U_ref"]).max())
+        if bodies:
+            assert np.abs(r["forces"] - f1).max() <= 1e-7 * np.abs(f1).max()
+            assert np.array_equal(r["forces"], res[0]["forces"])  # replicated force solves: the same bits on every rank
+
+
+def test_bench_launches_its_own_ranks_over_the_peer_transport():
+    """`python bench.py --gpus 2 --transport peer` with no launcher around it spawns its two ranks (torch.distributed.run on
+    127.0.0.1), which share the one GPU here (PIB_BENCH_SHARE_GPU=1: torch side on gloo): the N > 1 bench path end to end
+    in separate processes -- one JSON line, n_gpus 2, the transport's rank count, the residual contract."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PIB_BENCH_SHARE_GPU="1", PIB_PEER_TIMEOUT_S="240")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "peer", "--grid", "128", "--steps", "2",
+           "--warmup", "1", "--no-cpu", "--no-secondary", "--kernel-reps", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["counters"]["comm_ranks"] == 2
+    assert d["config"]["parallelism"] == "zslab2" and d["config"]["transport"] == "peer"
+    assert d["true_rel_residual"] <= 1.5e-10 and d["counters"]["halo_exchanges"] > 0
