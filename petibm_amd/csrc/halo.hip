@@ -148,7 +148,27 @@ struct LoopbackGroup {
             std::fflush(stderr);
         }
     }
-    uint64_t begin() { return ++seq; }
+    // The collectives of a rank are issued one after the other by its host thread, but on whatever stream the caller works
+    // on (a solver's, the engine's, the communication stream).  They are chained on the GPU as well: a collective's copies
+    // start after the previous collective's fetches have finished, so `done` is never raised for collective k + 1 while
+    // a fetch of collective k is still reading a neighbour's window.
+    hipEvent_t chain = nullptr;
+    hipStream_t chain_stream = nullptr;
+    bool chained = false;
+    int begin(hipStream_t st, uint64_t *out)
+    {
+        if (chained && chain_stream != st) PIB_HIP(hipStreamWaitEvent(st, chain, 0));
+        *out = ++seq;
+        return 0;
+    }
+    int finish(hipStream_t st)
+    {
+        if (chain == nullptr) PIB_HIP(hipEventCreateWithFlags(&chain, hipEventDisableTiming));
+        PIB_HIP(hipEventRecord(chain, st));
+        chain_stream = st;
+        chained = true;
+        return 0;
+    }
 
     // ---- peer flavour: ordering between the ranks.  HIP's interprocess events stop after 32 records on this runtime
     // (tools/ipc_probe2.hip), so completion travels through the shared segment: a host function enqueued behind the
@@ -162,7 +182,9 @@ struct LoopbackGroup {
     static void host_set(void *p)
     {
         HostSet *h = static_cast<HostSet *>(p);
-        h->flag->store(h->val, std::memory_order_release);
+        // never backwards: collectives on different streams may run their host functions out of order
+        uint64_t cur = h->flag->load(std::memory_order_relaxed);
+        while (cur < h->val && !h->flag->compare_exchange_weak(cur, h->val, std::memory_order_release, std::memory_order_relaxed)) {}
         if (h->trace) {
             std::fprintf(stderr, "[peer] flag raised to %llu\n", (unsigned long long)h->val);
             std::fflush(stderr);
@@ -218,6 +240,7 @@ static void peer_destroy(LoopbackGroup *g)
     for (int q = 0; q < (int)g->win.size(); ++q)
         if (q != g->me && g->win[(size_t)q]) (void)hipIpcCloseMemHandle(g->win[(size_t)q]);
     if (g->win_local) (void)hipFree(g->win_local);
+    if (g->chain) (void)hipEventDestroy(g->chain);
     if (g->staging_local) (void)hipFree(g->staging_local);
     else if (g->staging) (void)hipIpcCloseMemHandle(g->staging);
     if (g->shm) (void)munmap(g->shm, sizeof(PeerShm));
@@ -481,7 +504,8 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
     if (np > half || nn > half || lo > half || hi > half)
         return fail(PIB_ERR_SUP, "peer transport: a message of %lld entries does not fit half a window (%lld): raise PIB_PEER_WINDOW_MB",
                     (long long)std::max(std::max(np, nn), std::max(lo, hi)), (long long)half);
-    const uint64_t seq = g->begin();
+    uint64_t seq = 0;
+    PIB_CHK(g->begin(st, &seq));
     double *dst = g->win_local;
     if (has_pv)
         for (const auto &m : to_prev) {
@@ -504,6 +528,7 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
         PIB_HIP(hipMemcpyAsync(ghost_hi, g->win[(size_t)nx], sizeof(double) * (size_t)hi, hipMemcpyDeviceToDevice, st));
     }
     PIB_CHK(g->raise(st, g->shm->done[r], seq));
+    PIB_CHK(g->finish(st));
     if (has_pv) PIB_CHK(g->await(g->shm->done[pv], seq, "window fetched", pv));
     if (has_nx && nx != pv) PIB_CHK(g->await(g->shm->done[nx], seq, "window fetched", nx));
     return 0;
@@ -663,7 +688,8 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
         // every rank copies its values into its row of rank 0's staging buffer, then sums the rows in rank order
         LoopbackGroup *g = s->comm.loop;
         const int P = s->comm.nranks, r = s->comm.rank;
-        const uint64_t seq = g->begin();
+        uint64_t seq = 0;
+        PIB_CHK(g->begin(st, &seq));
         PIB_HIP(hipMemcpyAsync(g->staging + (size_t)r * PIB_NRED, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, st));
         PIB_CHK(g->raise(st, g->shm->ready[r], seq));
         for (int q = 0; q < P; ++q)
@@ -671,6 +697,7 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
         hipLaunchKernelGGL(k_lb_sum, dim3(1), dim3(64), 0, st, dev, g->staging, P, count);
         PIB_HIP(hipGetLastError());
         PIB_CHK(g->raise(st, g->shm->done[r], seq));
+        PIB_CHK(g->finish(st));
         for (int q = 0; q < P; ++q)
             if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "all-reduce read", q));  // the rows are free again
         return 0;
@@ -712,7 +739,8 @@ int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st
         const int P = s->comm.nranks, r = s->comm.rank;
         for (int64_t off = 0; off < count; off += g->win_doubles) {
             const int64_t len = std::min<int64_t>(g->win_doubles, count - off);
-            const uint64_t seq = g->begin();
+            uint64_t seq = 0;
+            PIB_CHK(g->begin(st, &seq));
             PIB_HIP(hipMemcpyAsync(g->win_local, dev + off, sizeof(double) * (size_t)len, hipMemcpyDeviceToDevice, st));
             PIB_CHK(g->raise(st, g->shm->ready[r], seq));
             const int nb = (int)std::min<int64_t>(4096, (len + 255) / 256);
@@ -722,6 +750,7 @@ int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st
             }
             PIB_HIP(hipGetLastError());
             PIB_CHK(g->raise(st, g->shm->done[r], seq));
+            PIB_CHK(g->finish(st));
             for (int q = 0; q < P; ++q)
                 if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "window fetched", q));
         }
@@ -766,7 +795,8 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
         int64_t longest = 0;
         for (int q = 0; q < P; ++q) longest = std::max(longest, counts[(size_t)q]);
         for (int64_t off = 0; off < longest; off += g->win_doubles) {  // a window's worth of every rank's part at a time
-            const uint64_t seq = g->begin();
+            uint64_t seq = 0;
+            PIB_CHK(g->begin(st, &seq));
             const int64_t mine = std::max<int64_t>(0, std::min<int64_t>(g->win_doubles, counts[(size_t)r] - off));
             if (mine > 0) PIB_HIP(hipMemcpyAsync(g->win_local, send + off, sizeof(double) * (size_t)mine, hipMemcpyDeviceToDevice, st));
             PIB_CHK(g->raise(st, g->shm->ready[r], seq));
@@ -778,6 +808,7 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
                                            hipMemcpyDeviceToDevice, st));
             }
             PIB_CHK(g->raise(st, g->shm->done[r], seq));
+            PIB_CHK(g->finish(st));
             for (int q = 0; q < P; ++q)
                 if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "window fetched", q));
         }
