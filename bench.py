@@ -64,6 +64,18 @@ def manufactured_solution(n: int, k0: int, k1: int) -> np.ndarray:
     return (cz[:, None, None] * c[None, :, None] * c[None, None, :]).reshape(-1)
 
 
+def petsc_probe() -> str:
+    """a second CPU row from the reference's own library (KSPSolve on the same CSR) needs a PETSc install on
+    the host.  This looks for one (PETSC_DIR, the loader path) and says what it found; no PETSc has been seen on any box
+    this ran on, so the KSPSolve driver itself is not part of the repo."""
+    import ctypes.util
+    d = os.environ.get("PETSC_DIR")
+    lib = ctypes.util.find_library("petsc")
+    if d or lib:
+        return f"a PETSc install is visible (PETSC_DIR={d}, libpetsc={lib}) but no KSPSolve driver is built here: port row only"
+    return "not found on this host (PETSC_DIR unset, no libpetsc on the loader path): port row only"
+
+
 def cpu_baseline(n_gpu: int, tol: float, dt: float, pre: int = 2, post: int = 2, omega: float = 0.9, budget_s: float = 45.0):
     """The oracle (CPU restatement of the same path: int32 CSR SpMV + KSPCG recurrences + the same V-cycle,
     oracle/csrc/*.c, OpenMP over every core the process may use: affinity and cgroup quota) timed on this box.  It runs the SAME workload as the GPU when
@@ -100,7 +112,7 @@ def cpu_baseline(n_gpu: int, tol: float, dt: float, pre: int = 2, post: int = 2,
         n *= 2
         t, r, ts = run(n)
     same = "the same workload" if n == n_gpu else f"a bounded sample of it ({n}^3 instead of {n_gpu}^3)"
-    return {"value": n ** 3 / t, "unit": "DOF/s", "cores": cores, "kind": "port",
+    return {"value": n ** 3 / t, "unit": "DOF/s", "cores": cores, "kind": "port", "petsc": petsc_probe(),
             "sample": f"{same}: GMG-PCG (oracle/csrc: KSPCG recurrences + the build's V({pre},{post}) cycle, int32 CSR) on the "
                       f"{n}^3 cavity Poisson system, rtol {tol:g}: {r['iters']} iterations in {t:.2f} s "
                       f"(+ {ts:.1f} s CPU assembly, not counted)",
@@ -328,6 +340,16 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
+    try:
+        return poisson_bench(args)
+    except Exception as exc:  # noqa: BLE001 -- e.g. the communicator cannot be set up: still ONE JSON line with the reason
+        import traceback
+        traceback.print_exc()
+        refuse(args, f"{type(exc).__name__}: {exc}")
+        return 1
+
+
+def poisson_bench(args) -> int:
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
