@@ -291,6 +291,31 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
 // otherwise).  Same expressions in the same order as modes 1 and 2: bit-identical (tools/fuse_lab.hip: 1.34 -> 0.78 ms
 // per 512^3 pair).  Levels that are whole on this rank, not periodic, 3-D, nx % 128 == 0, ny % 8 == 0.
 constexpr int FX = 128, FY = 8, FSX = FX + 2, FSY = FY + 2;
+// Register budgets of the LDS-tiled kernels.  A 256-thread workgroup is four waves, one per SIMD, and the compiler sizes
+// its register use for whatever occupancy it happens to reach: k_level_march<8> took 144 VGPRs (three waves per SIMD),
+// k_presmooth2 142 (three), k_prolong_smooth 212 (two).  amdgpu_waves_per_eu(n) asks for n: the march fits 126 without
+// a spill (kept), the pre-smoothing pair 128 with five spilled dwords, the fused prolongation 168 with 43.  Measured on
+// the 512^3 solve (two runs each): none 89.7 / 88.1 ms, march at four waves 86.7 / 88.0, + pre-smoothing at four 87.4 /
+// 88.1, + prolongation at three 112.6 / 113.2 -- occupancy is not what holds these kernels back, spills are poison.
+// (The `vgpr` column of rocprofv3's kernel trace counts in units of two on gfx950 -- 72 there is 144 here; the numbers
+// above are the code object's .vgpr_count.)
+#ifndef PIB_WAVES_MARCH
+#define PIB_WAVES_MARCH 4
+#endif
+#ifndef PIB_WAVES_PRESMOOTH
+#define PIB_WAVES_PRESMOOTH 0
+#endif
+#ifndef PIB_WAVES_PROLONG
+#define PIB_WAVES_PROLONG 0
+#endif
+#define PIB_WAVES_ATTR_0
+#define PIB_WAVES_ATTR_2 __attribute__((amdgpu_waves_per_eu(2)))
+#define PIB_WAVES_ATTR_3 __attribute__((amdgpu_waves_per_eu(3)))
+#define PIB_WAVES_ATTR_4 __attribute__((amdgpu_waves_per_eu(4)))
+#define PIB_WAVES_ATTR_5 __attribute__((amdgpu_waves_per_eu(5)))
+#define PIB_WAVES_CAT(a, b) a##b
+#define PIB_WAVES_ATTR(n) PIB_WAVES_CAT(PIB_WAVES_ATTR_, n)
+
 // what a thread keeps of a cell column (i, j) across the planes: the scaled in-plane coefficients, their part of the
 // diagonal sum, 1 / (wx wy) and wx wy
 struct FCell {
@@ -312,7 +337,7 @@ __device__ __forceinline__ double fdiag(const FCell &q, double czm, double czp) 
 // RES = 1 (a V(1,.) cycle: ONE pre-smoothing step): the second stage is the residual r = b - A x1 instead of the second
 // Jacobi step; x1 goes to xo, r to ro -- b read once, two vectors written, instead of mode 1 + mode 3 (2 + 3 passes).
 template <int RES>
-__global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ S, LevelDev L, double omega,
+__global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_presmooth2(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                     const double *__restrict__ b, double *__restrict__ xo,
                                                     const double *__restrict__ pin_sum, int FZ, double *__restrict__ ro)
 {
@@ -407,7 +432,7 @@ __global__ __launch_bounds__(256) void k_presmooth2(const Scalars *__restrict__ 
 // same order (modes 2 and 3 bit-identical; mode 8's sums are grouped by tile instead of by line segment, i.e. equal to
 // rounding).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
+__global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_MARCH) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                      const double *__restrict__ b, const double *__restrict__ xi,
                                                      double *__restrict__ xo, const double *__restrict__ pin_sum,
                                                      double *__restrict__ part, int part_stride, int FZ, int dlo, int dhi)
@@ -702,7 +727,7 @@ __device__ __forceinline__ PHalo phalo(const LevelDev &F, int ncx, int ncy, int 
 }
 // DOTS (the only post-smoothing step of level 0 writes z = M^-1 r): the partial sums of k_level_march<8>, same grouping.
 template <int DOTS>
-__global__ __launch_bounds__(256) void k_prolong_smooth(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
+__global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolong_smooth(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
                                                         const double *__restrict__ b, const double *__restrict__ xc,
                                                         const double *__restrict__ xi, double *__restrict__ xo,
                                                         const double *__restrict__ pin_sum, int FZ, double *__restrict__ part,
