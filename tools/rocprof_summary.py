@@ -74,6 +74,8 @@ def main():
             v = top.get(name, {}).get("c", {}).get(c)
             row.append(f"{v:.4g}" if v is not None else "")
         lines.append("| " + " | ".join(row) + " |")
+    lines.append("\n`vgpr` is rocprofv3's VGPR_Count as printed; on gfx950 it is HALF the code object's `.vgpr_count` (72 here is 144 "
+                 "32-bit registers per lane: three waves per SIMD, not seven).")
     text = "\n".join(lines) + "\n"
     if a.out:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)

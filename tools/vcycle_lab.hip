@@ -67,10 +67,11 @@ __device__ __forceinline__ Cell1 cell1(const L &l, int i, int j)
 }
 
 // VAR 0: product expressions; 1: volume-scaled; 2: volume-scaled + hoisted reciprocal (uniform z)
-template <int VAR, int TY, int KZ, int PF = 0>
+template <int VAR, int TY, int KZ, int PF = 0, int DOTS = 0>
 __global__ __launch_bounds__(32 * TY) void k_step(L l, double omega, const double *__restrict__ b, const double *__restrict__ xi,
-                                                  double *__restrict__ xo)
+                                                  double *__restrict__ xo, double *__restrict__ part = nullptr)
 {
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     constexpr int SX = TX + 2, SY = TY + 2;
     __shared__ double sp[2][SY][SX];
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
@@ -178,6 +179,11 @@ __global__ __launch_bounds__(32 * TY) void k_step(L l, double omega, const doubl
                     const double d = -((q.s4 + czm) + czp);
                     out[c] = xcc + omega * ((bs - s) / d);
                 }
+                if (DOTS) {  // the sums k_level_march<8> leaves for CG: z.r, z.z, sum z
+                    acc0 += out[c] * bv[c];
+                    acc1 += out[c] * out[c];
+                    acc2 += out[c];
+                }
             }
         }
         *reinterpret_cast<v4 *>(xo + (int64_t)kk * plane + off_c) = out;
@@ -188,6 +194,24 @@ __global__ __launch_bounds__(32 * TY) void k_step(L l, double omega, const doubl
             hyv = hyn;
             hxv = hxn;
             bv = bn;
+        }
+    }
+    if (DOTS) {
+        __shared__ double sh[3][TY / 2];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        double v[3] = {acc0, acc1, acc2};
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[k2] += __shfl_down(v[k2], o, 64);
+            if (lane == 0) sh[k2][w] = v[k2];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < TY / 2; ++w2) t += sh[threadIdx.x][w2];
+            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            part[(int64_t)threadIdx.x * 4096 + blk] = t;
         }
     }
 }
@@ -381,6 +405,13 @@ int main(int argc, char **argv)
     timeit("V1 volume-scaled rows, 128x8 tile, KZ 32, prefetch", [&] { hipLaunchKernelGGL((k_step<1, 8, 32, 1>), dim3(n / TX, n / 8, n / 32), dim3(256), 0, 0, l, 0.9, b, x0, y1); });
     timeit("V1 volume-scaled rows, 128x8 tile, KZ 16, prefetch", [&] { hipLaunchKernelGGL((k_step<1, 8, 16, 1>), dim3(n / TX, n / 8, n / 16), dim3(256), 0, 0, l, 0.9, b, x0, y1); });
     timeit("V1 volume-scaled rows, 128x8 tile, KZ 16", [&] { hipLaunchKernelGGL((k_step<1, 8, 16, 0>), dim3(n / TX, n / 8, n / 16), dim3(256), 0, 0, l, 0.9, b, x0, y1); });
+    {
+        double *part;
+        CK(hipMalloc(&part, 8 * 3 * 4096));
+        timeit("V1 + the three CG sums, 128x8 tile, KZ 64", [&] { hipLaunchKernelGGL((k_step<1, 8, 64, 0, 1>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, 0.9, b, x0, y1, part); });
+        timeit("V1 + the three CG sums, 128x8 tile, KZ 64, prefetch", [&] { hipLaunchKernelGGL((k_step<1, 8, 64, 1, 1>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, 0.9, b, x0, y1, part); });
+        timeit("V1 volume-scaled rows, 128x8 tile, KZ 64 (again)", [&] { hipLaunchKernelGGL((k_step<1, 8, 64>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, 0.9, b, x0, y1); });
+    }
     printf("one input stream (16 B/cell; the TB/s column counts 24: multiply by 2/3)\n");
     timeit("C  copy, one chunk per workgroup", [&] { hipLaunchKernelGGL(k_copy1, dim3((unsigned)(N / 4 / 1024)), dim3(256), 0, 0, (const v4 *)x0, (v4 *)y0); });
     timeit("M  y = A x, 128x8 tile, KZ 64", [&] { hipLaunchKernelGGL((k_mv<8, 64, 0, 0>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y1); });
