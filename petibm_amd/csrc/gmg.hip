@@ -462,24 +462,39 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_MARCH) void k_level_m
     for (int c = 0; c < 4; ++c) q4[c] = fcell(L, ic + c, j);
     const int lend = (l0 + FZ < L.nk) ? l0 + FZ : L.nk;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0};
-    if (L.k0 + l0 > 0) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(l0 - 1) * plane + off_c);
-    else if (pz) zm = *reinterpret_cast<const v4 *>(xi + (int64_t)(L.nzg - 1) * plane + off_c);
+    // software pipeline: the own cells of the plane TWO ahead, and the halo cells and right-hand side of the NEXT plane,
+    // are requested an iteration before their first use (tools/vcycle_lab.hip: -4 % for the Jacobi step, -13 % for the
+    // one-input product at 512^3).  plane_of: a plane's place in memory (local index; across the periodic seam)
+    auto plane_of = [&](int lk) -> int64_t {
+        const int kk = L.k0 + lk;
+        if (pz) return kk < 0 ? L.nzg - 1 : (kk >= L.nzg ? 0 : lk);
+        return lk;
+    };
+    auto have = [&](int lk) { return pz || (L.k0 + lk >= 0 && L.k0 + lk < L.nzg); };
+    v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0}, zq = {0, 0, 0, 0}, bv = {0, 0, 0, 0}, bn = {0, 0, 0, 0};
+    double hyv, hxv, hyn = 0.0, hxn = 0.0;
+    if (have(l0 - 1)) zm = *reinterpret_cast<const v4 *>(xi + plane_of(l0 - 1) * plane + off_c);
     xc = *reinterpret_cast<const v4 *>(xi + (int64_t)l0 * plane + off_c);
+    if (have(l0 + 1)) zp = *reinterpret_cast<const v4 *>(xi + plane_of(l0 + 1) * plane + off_c);
+    hyv = hy_ok ? xi[(int64_t)l0 * plane + off_hy] : 0.0;
+    hxv = hx_ok ? xi[(int64_t)l0 * plane + off_hx] : 0.0;
+    if (MODE != 0) bv = *reinterpret_cast<const v4 *>(b + (int64_t)l0 * plane + off_c);
     for (int lk = l0; lk < lend; ++lk) {
         const int kk = L.k0 + lk;  // global plane
         const int slot = lk & 1;
-        const double *px = xi + (int64_t)lk * plane;
-        if (kk + 1 < L.nzg) zp = *reinterpret_cast<const v4 *>(px + plane + off_c);
-        else if (pz) zp = *reinterpret_cast<const v4 *>(xi + off_c);
-        v4 bv = {0, 0, 0, 0};
-        if (MODE != 0) bv = *reinterpret_cast<const v4 *>(b + (int64_t)lk * plane + off_c);
+        if (lk + 1 < lend) {
+            const double *pn = xi + (int64_t)(lk + 1) * plane;
+            if (have(lk + 2)) zq = *reinterpret_cast<const v4 *>(xi + plane_of(lk + 2) * plane + off_c);
+            hyn = hy_ok ? pn[off_hy] : 0.0;
+            hxn = hx_ok ? pn[off_hx] : 0.0;
+            if (MODE != 0) bn = *reinterpret_cast<const v4 *>(b + (int64_t)(lk + 1) * plane + off_c);
+        }
         const v4 braw = bv;
         if (MODE != 0 && pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
 #pragma unroll
         for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
-        sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? px[off_hy] : 0.0;
-        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? px[off_hx] : 0.0;
+        sp[slot][hy_row + 1][hy_x + 1] = hyv;
+        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hxv;
         __syncthreads();
         const double wzk = L.wz[kk], rwz = L.rwz[kk], czm = L.cmz[kk], czp = L.cpz[kk];
         v4 out;
@@ -512,6 +527,10 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_MARCH) void k_level_m
         *reinterpret_cast<v4 *>(xo + (int64_t)lk * plane + off_c) = out;
         zm = xc;
         xc = zp;
+        zp = zq;
+        hyv = hyn;
+        hxv = hxn;
+        bv = bn;
     }
     if (MODE == 0 && part != nullptr) {
         // one partial per workgroup; the slots up to part_stride that no workgroup owns are zeroed (the consumer sums a
