@@ -298,7 +298,9 @@ constexpr int FX = 128, FY = 8, FSX = FX + 2, FSY = FY + 2;
 // the 512^3 solve (two runs each): none 89.7 / 88.1 ms, march at four waves 86.7 / 88.0, + pre-smoothing at four 87.4 /
 // 88.1, + prolongation at three 112.6 / 113.2 -- occupancy is not what holds these kernels back, spills are poison.
 // (The `vgpr` column of rocprofv3's kernel trace counts in units of two on gfx950 -- 72 there is 144 here; the numbers
-// above are the code object's .vgpr_count.)
+// above are the code object's .vgpr_count.)  With the two-plane prefetch of k_level_march the step with the Krylov sums
+// (mode 8) no longer fits four waves without 17 spilled dwords -- 823 instead of 620 us per 512^3 launch inside the solve
+// (tools/ab_trace.sh) -- so it asks for three (162 VGPRs, no spill); the other modes keep four (128, three dwords).
 #ifndef PIB_WAVES_MARCH
 #define PIB_WAVES_MARCH 4
 #endif
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
 // same order (modes 2 and 3 bit-identical; mode 8's sums are grouped by tile instead of by line segment, i.e. equal to
 // rounding).
 template <int MODE>
-__global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_MARCH) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ? 3 : PIB_WAVES_MARCH))) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                      const double *__restrict__ b, const double *__restrict__ xi,
                                                      double *__restrict__ xo, const double *__restrict__ pin_sum,
                                                      double *__restrict__ part, int part_stride, int FZ, int dlo, int dhi)
