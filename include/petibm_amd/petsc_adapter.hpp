@@ -12,6 +12,8 @@
 // Needs <petscmat.h>; it has never been compiled against a real PETSc in this repository's image (none installed) --
 // tests/test_boundary_headers.py runs a SYNTAX check of it against a declarations-only stub (tests/stubs/petsc).
 #pragma once
+#include <cstdlib>
+#include <string>
 #include <petscmat.h>
 #include <petscvec.h>
 
@@ -33,7 +35,11 @@ inline PetscErrorCode broadcastUniqueId(MPI_Comm comm, PetscMPIInt *rank, PetscM
     ierr = MPI_Comm_size(comm, size); CHKERRQ(ierr);
     for (int i = 0; i < PIB_UID_BYTES; ++i) uid[i] = 0;
     if (*size > 1) {
-        if (*rank == 0) { ierr = pib_comm_unique_id(uid); CHKERRQ(ierr); }
+        // RCCL unless PIB_TRANSPORT=peer asks for the HIP-IPC window transport (one node; petibm_amd.h, pib_comm_peer_id)
+        if (*rank == 0) {
+            const char *t = std::getenv("PIB_TRANSPORT");
+            ierr = (t != nullptr && std::string(t) == "peer") ? pib_comm_peer_id(uid) : pib_comm_unique_id(uid); CHKERRQ(ierr);
+        }
         ierr = MPI_Bcast(uid, PIB_UID_BYTES, MPI_BYTE, 0, comm); CHKERRQ(ierr);
     }
     return 0;
