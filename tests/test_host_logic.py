@@ -100,6 +100,22 @@ def test_library_loads_and_has_no_cpu_fallback(capi):
         assert code == capi.ERR_LIB and b"no CPU fallback" in lib.pib_last_error()
 
 
+def test_peer_transport_ids_are_fresh_shared_memory_names(capi):
+    """pib_comm_peer_id needs no GPU: a magic + the name of the POSIX shared-memory segment the ranks will meet in, never the
+    same twice; a null output is an error like everywhere in the C ABI."""
+    lib = capi.load()
+    ids = []
+    for _ in range(3):
+        buf = ctypes.create_string_buffer(capi.UID_BYTES)
+        assert lib.pib_comm_peer_id(buf) == 0
+        assert buf.raw[:8] == b"PIBPEER1"
+        name = buf.raw[8:].split(b"\0", 1)[0]
+        assert name.startswith(b"/pib_peer_") and b"/" not in name[1:] and len(name) < 100
+        ids.append(name)
+    assert len(set(ids)) == 3
+    assert lib.pib_comm_peer_id(None) != 0 and b"null output" in lib.pib_last_error()
+
+
 def test_amgx_config_subset(capi):
     d = capi.config_describe("poisson", AMGX_POISSON)
     assert d["flavor"] == "amgx" and d["type"] == "NVIDIA AmgX"
