@@ -296,6 +296,118 @@ __global__ __launch_bounds__(32 * TY) void k_mv(L l, const double *__restrict__ 
         }
     }
 }
+// MD: y = A x with the planes brought in by LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight into LDS, no staging
+// registers) D planes ahead into a ring of D + 1 slots.  Every wave issues exactly three DMA instructions per plane (two
+// body rows; the third is a y-halo row, the x-halo cells as dwords, or a dummy), so s_waitcnt vmcnt(3 D) means "the oldest
+// plane has landed" (loads return in order; outstanding stores only make the wait longer).
+constexpr int DSX = TX + 4;  // row stride 132 doubles: the body starts at column 2 (16-byte aligned), halo cells at 1 and 130
+template <int KZ, int D>
+__global__ __launch_bounds__(256) void k_mv_dma(L l, const double *__restrict__ xi, double *__restrict__ xo)
+{
+    // ring of D + 2 slots: planes kk - 1 (other waves may still read it when this wave issues the next DMA) .. kk + D
+    constexpr int TY = 8, SY = TY + 2, R = D + 2;
+    __shared__ __attribute__((aligned(16))) double sp[R][SY][DSX];
+    __shared__ __attribute__((aligned(16))) double hx[R][32];  // x-halo cells of a plane: [0..7] left column, [8..15] right; 64 dwords per DMA
+    __shared__ __attribute__((aligned(16))) double dummy[32];
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31, wave = tid >> 6, lane = tid & 63;
+    const int i0 = blockIdx.x * TX, j0 = blockIdx.y * TY, k0 = blockIdx.z * KZ;
+    const int64_t plane = (int64_t)l.nx * l.ny;
+    const int j = j0 + ty, ic = i0 + 4 * tx;
+    const int64_t off_c = (int64_t)j * l.nx + ic;
+    const bool top_ok = j0 > 0, bot_ok = j0 + TY < l.ny, left_ok = i0 > 0, right_ok = i0 + TX < l.nx;
+    Cell1 q1[4];
+    double vxy[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        q1[c] = cell1(l, ic + c, j);
+        vxy[c] = l.wx[ic + c] * l.wy[j];
+    }
+    // rows beyond the domain hold zero in every slot, once and for all (the DMA never writes them)
+    for (int e = tid; e < R * SY * DSX; e += 256) (&sp[0][0][0])[e] = 0.0;
+    __syncthreads();
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    // exactly three DMA instructions per wave and plane
+    auto dma_plane = [&](int kk) {
+        const int slot = kk % R;
+        const double *px = xi + (int64_t)kk * plane;
+        __builtin_amdgcn_global_load_lds((const void *)(px + (int64_t)(j0 + wave) * l.nx + i0 + 2 * lane), (lds_ptr)&sp[slot][wave + 1][2 + 2 * lane], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void *)(px + (int64_t)(j0 + wave + 4) * l.nx + i0 + 2 * lane), (lds_ptr)&sp[slot][wave + 5][2 + 2 * lane], 16, 0, 0);
+        if (wave == 0 && top_ok)
+            __builtin_amdgcn_global_load_lds((const void *)(px + (int64_t)(j0 - 1) * l.nx + i0 + 2 * lane), (lds_ptr)&sp[slot][0][2 + 2 * lane], 16, 0, 0);
+        else if (wave == 1 && bot_ok)
+            __builtin_amdgcn_global_load_lds((const void *)(px + (int64_t)(j0 + TY) * l.nx + i0 + 2 * lane), (lds_ptr)&sp[slot][SY - 1][2 + 2 * lane], 16, 0, 0);
+        else if (wave == 2) {
+            // dword `lane` of hx[slot]: double lane / 2 = row (lane / 2) % 8 of the left (lane < 16) / right column; lanes beyond
+            // the 32 dwords and columns beyond the domain fetch something harmless (their values are never used)
+            const int dbl = (lane >> 1) & 15, row = dbl & 7, right = dbl >> 3;
+            const bool ok = lane < 32 && (right ? right_ok : left_ok);
+            const int gi = ok ? (right ? i0 + TX : i0 - 1) : i0;
+            const int *src = reinterpret_cast<const int *>(px + (int64_t)(j0 + row) * l.nx + gi) + (lane & 1);
+            __builtin_amdgcn_global_load_lds((const void *)src, (lds_ptr)(reinterpret_cast<int *>(&hx[slot][0]) + lane), 4, 0, 0);
+        } else
+            __builtin_amdgcn_global_load_lds((const void *)(reinterpret_cast<const int *>(px + off_c)), (lds_ptr)(reinterpret_cast<int *>(&dummy[0]) + lane), 4, 0, 0);
+    };
+    const int kend = (k0 + KZ < l.nz) ? k0 + KZ : l.nz;
+    const int kfirst = k0 > 0 ? k0 - 1 : k0, klast = kend < l.nz ? kend : kend - 1;  // planes this workgroup reads: [kfirst, klast]
+    int issued = kfirst;  // planes [kfirst, issued) are on their way or here
+    for (; issued <= klast && issued < k0 + D; ++issued) dma_plane(issued);
+    auto land = [&](int kk) {  // plane kk has landed for every wave: at most the planes issued after it are outstanding
+        const int behind = issued - 1 - kk;
+        if (behind >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (behind == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    auto own = [&](int kk) -> v4 {
+        const double *row = &sp[kk % R][ty + 1][2 + 4 * tx];
+        const double2 a = *reinterpret_cast<const double2 *>(row), b = *reinterpret_cast<const double2 *>(row + 2);
+        v4 r = {a.x, a.y, b.x, b.y};
+        return r;
+    };
+    v4 zm = {0, 0, 0, 0}, xc, zp = {0, 0, 0, 0};
+    if (k0 > 0) {
+        land(k0 - 1);
+        zm = own(k0 - 1);
+    }
+    land(k0);
+    xc = own(k0);
+    for (int kk = k0; kk < kend; ++kk) {
+        // slot (kk + D) % R held plane kk - 2: every wave has passed the barrier that followed its use
+        if (kk + D <= klast) {
+            dma_plane(kk + D);
+            issued = kk + D + 1;
+        }
+        if (kk + 1 < l.nz) {
+            land(kk + 1);
+            zp = own(kk + 1);
+        } else
+            __syncthreads();
+        const int slot = kk % R;
+        const double czm = l.cmz[kk], czp = l.cpz[kk], wzk = l.wz[kk];
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int lx = 4 * tx + 2 + c;
+            const Cell1 &q = q1[c];
+            const double xcc = xc[c];
+            const double left = (c == 0 && tx == 0) ? (left_ok ? hx[slot][ty] : 0.0) : sp[slot][ty + 1][lx - 1];
+            const double right = (c == 3 && tx == 31) ? (right_ok ? hx[slot][TY + ty] : 0.0) : sp[slot][ty + 1][lx + 1];
+            double s = 0.0;
+            s += q.cxm * (left - xcc);
+            s += q.cxp * (right - xcc);
+            s += q.cym * (sp[slot][ty][lx] - xcc);
+            s += q.cyp * (sp[slot][ty + 2][lx] - xcc);
+            s += czm * (zm[c] - xcc);
+            s += czp * (zp[c] - xcc);
+            out[c] = (s * vxy[c]) * wzk;
+        }
+        *reinterpret_cast<v4 *>(xo + (int64_t)kk * plane + off_c) = out;
+        zm = xc;
+        xc = zp;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy1(const v4 *__restrict__ a, v4 *__restrict__ o)
 {
     const int64_t base = (int64_t)blockIdx.x * 1024;
@@ -421,6 +533,23 @@ int main(int argc, char **argv)
     timeit("M  y = A x, 128x8 tile, KZ 32, prefetch", [&] { hipLaunchKernelGGL((k_mv<8, 32, 1, 0>), dim3(n / TX, n / 8, n / 32), dim3(256), 0, 0, l, x0, y1); });
     timeit("M  y = A x, 128x8 tile, KZ 64, nontemporal stores", [&] { hipLaunchKernelGGL((k_mv<8, 64, 0, 1>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y1); });
     timeit("M  y = A x, 128x8 tile, KZ 64, prefetch + nontemporal", [&] { hipLaunchKernelGGL((k_mv<8, 64, 1, 1>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y1); });
+    timeit("MD y = A x, LDS-DMA ring, 2 planes ahead, KZ 64", [&] { hipLaunchKernelGGL((k_mv_dma<64, 2>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y0); });
+    {
+        std::vector<double> a0(1 << 22), a1(1 << 22);
+        double worst = 0.0;
+        for (int64_t off : {int64_t(0), N / 2 - (int64_t)a0.size() / 2, N - (int64_t)a0.size()}) {
+            CK(hipMemcpy(a0.data(), y0 + off, 8 * a0.size(), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(a1.data(), y1 + off, 8 * a0.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < a0.size(); ++i) {
+                const double e = a0[i] - a1[i];
+                if ((e < 0 ? -e : e) > worst) worst = e < 0 ? -e : e;
+            }
+        }
+        printf("   MD vs M: largest difference %.3e\n", worst);
+    }
+    timeit("MD y = A x, LDS-DMA ring, 3 planes ahead, KZ 64", [&] { hipLaunchKernelGGL((k_mv_dma<64, 3>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y0); });
+    timeit("MD y = A x, LDS-DMA ring, 3 planes ahead, KZ 32", [&] { hipLaunchKernelGGL((k_mv_dma<32, 3>), dim3(n / TX, n / 8, n / 32), dim3(256), 0, 0, l, x0, y0); });
+    timeit("MD y = A x, LDS-DMA ring, 1 plane ahead, KZ 64", [&] { hipLaunchKernelGGL((k_mv_dma<64, 1>), dim3(n / TX, n / 8, n / 64), dim3(256), 0, 0, l, x0, y0); });
     timeit("V1 volume-scaled rows, 128x4 tile (128 threads), KZ 64", [&] { hipLaunchKernelGGL((k_step<1, 4, 64>), dim3(n / TX, n / 4, n / 64), dim3(128), 0, 0, l, 0.9, b, x0, y1); });
     return 0;
 }
