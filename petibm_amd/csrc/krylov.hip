@@ -992,7 +992,9 @@ struct OpBUpdateX {  // x += alpha ph + omega sh ; r = s - omega t ; partials |r
 // product): M^-1 p and M^-1 s are never stored -- the products apply the sweep as they read their input
 // (vel_stencil_apply's dinv / opc) -- and x += alpha M^-1 p + omega M^-1 s is applied by the NEXT iteration's p-update,
 // which reads p anyway.  216 -> 200 B/row/iteration (27 -> 25 vector passes).  Every value is computed by the expression
-// of the general path above: bit-identical iterates.
+// of the general path above: bit-identical iterates -- unless `pib_fuse_bicgstab_dots` (default off: no gain) lets the products sum
+// v.rp and s.t, t.t themselves (two passes less, 184 B/row/iteration): those sums are grouped by tile, so alpha and omega
+// agree with the general path's to rounding only.
 struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*beta) v + beta p
     static constexpr int NRED = 0;
     const double *r, *v, *dinv, *sv;
@@ -1255,6 +1257,7 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
                       s->post_matmult == nullptr && vel_stencil_fused_ok(s) && aligned16(x) &&
                       ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(V) |
                         reinterpret_cast<uintptr_t>(T)) & 31u) == 0;
+    const bool fused_dots = lean && s->cfg.fuse_bicgstab_dots;
     int enq = 0;
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
@@ -1262,15 +1265,25 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
         auto body_lean = [&]() -> int {
             OpBFUpdateP up{R, V, A.dinv, S, P, x, opc, 0.0, 0.0, 0.0, 0.0, 0};
             PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
-            PIB_CHK(vel_stencil_apply(s, P, V, true, q, A.dinv, opc));  // v = K M^-1 p
-            OpBPcDot<PCM_NONE> d1{V, nullptr, RP, V, 1.0};
-            PIB_CHK(launch_vec(s, n, d1, true, 2, &nb, true, q));
+            if (fused_dots) {  // v = K M^-1 p and v.rp by the same kernel
+                PIB_CHK(vel_stencil_apply(s, P, V, true, q, A.dinv, opc, 1, RP, 2));
+                nb = VEL_DOT_PARTIALS;
+            } else {
+                PIB_CHK(vel_stencil_apply(s, P, V, true, q, A.dinv, opc));  // v = K M^-1 p
+                OpBPcDot<PCM_NONE> d1{V, nullptr, RP, V, 1.0};
+                PIB_CHK(launch_vec(s, n, d1, true, 2, &nb, true, q));
+            }
             PIB_CHK(finalize_post<5>(s, 2, 1, nb, nullptr, 0, q));
             OpBUpdateS<PCM_NONE> us{R, V, nullptr, S, S, 1.0, 0, 0.0};  // s = r - alpha v
             PIB_CHK(launch_vec(s, n, us, true, 0, nullptr, true, q));
-            PIB_CHK(vel_stencil_apply(s, S, T, true, q, A.dinv, opc));  // t = K M^-1 s
-            OpBPcDot2<PCM_NONE> d2{T, nullptr, S, T, 1.0, 0};
-            PIB_CHK(launch_vec(s, n, d2, true, 3, &nb, true, q));
+            if (fused_dots) {  // t = K M^-1 s with s.t and t.t
+                PIB_CHK(vel_stencil_apply(s, S, T, true, q, A.dinv, opc, 2, nullptr, 3));
+                nb = VEL_DOT_PARTIALS;
+            } else {
+                PIB_CHK(vel_stencil_apply(s, S, T, true, q, A.dinv, opc));  // t = K M^-1 s
+                OpBPcDot2<PCM_NONE> d2{T, nullptr, S, T, 1.0, 0};
+                PIB_CHK(launch_vec(s, n, d2, true, 3, &nb, true, q));
+            }
             PIB_CHK(finalize_post<2>(s, 3, 2, nb, nullptr, 0, q));
             OpBFUpdateR ur{S, T, RP, R, 0.0};
             PIB_CHK(launch_vec(s, n, ur, true, 0, &nb, true, q));

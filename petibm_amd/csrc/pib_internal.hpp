@@ -84,6 +84,7 @@ struct Config {
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
     int march_velocity = 1;        // matrix-free velocity product: LDS-tiled z-marching form for tile-divisible components (velstencil.hip k_vel_march)
+    int fuse_bicgstab_dots = 0;  // ... and its two dot-only passes summed by the products themselves (sums grouped by tile: the iterates equal the CSR path's to rounding, no longer bit for bit).  Off: measured, no gain
     int lean_bicgstab = 1;  // BiCGStab on the matrix-free velocity operator without stored M^-1 p / M^-1 s and with the x update deferred (krylov.hip OpBFUpdateP)
     int velocity_march_planes = 16;  // planes a workgroup of k_vel_march walks through
     int fuse_velocity_product = 1;  // 3-D: the three components' tiles and shells in one launch (velstencil.hip k_vel_product)
@@ -252,6 +253,8 @@ struct pib_solver {
     double *d_part = nullptr;  // [PIB_NRED][PIB_MAXPART]
     double *d_spmv_part = nullptr;  // one p.Ap partial per SpMV workgroup
     int64_t spmv_part_cap = 0;
+    double *d_vel_part = nullptr;  // per-workgroup partials of the velocity product's fused sums [2][vel_part_cap]
+    int vel_part_cap = 0;
     double *d_gmg_part = nullptr;   // z.r, z.z, sum z partials of the V-cycle's last smoothing kernel (gmg.hip mode 8)
     int64_t gmg_part_cap = 0;
     bool gmg_want_dots = false, gmg_dots_done = false;
@@ -314,7 +317,9 @@ void dense_release(pib_solver *s);
 int solve_direct(pib_solver *s, double *x, const double *b);
 // assemble.hip
 void vel_stencil_release(pib_solver *s);
-int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv = nullptr, double opc = 1.0);
+int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv = nullptr, double opc = 1.0,
+                      int dot_mode = 0, const double *dot_other = nullptr, int dot_slot0 = 0);
+constexpr int VEL_DOT_PARTIALS = 64;  // partial sums per slot the fused sums of vel_stencil_apply leave in d_part
 bool vel_stencil_fused_ok(const pib_solver *s);
 int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);
 // bn.hip: D * BN(order) * G through the reference's chain of sparse products; optionally hands out BNG (device arrays

@@ -25,6 +25,12 @@ struct VelDev {
     // applied as the input is read (the same product opc * (dinv[i] * x[i]) a stored copy would hold: same bits)
     const double *dinv;
     double opc;
+    // fused Krylov sums (k_vel_product only): dot_mode 1: y . other ; 2: y . x (the RAW input) and y . y -- one partial per
+    // workgroup at dot_part[blk] (and dot_part[dot_stride + blk])
+    int dot_mode;
+    const double *dot_other;
+    double *dot_part;
+    int dot_stride;
 };
 __device__ __forceinline__ double vel_in(const VelDev &V, const double *__restrict__ x, int64_t idx)
 {
@@ -95,7 +101,7 @@ __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restr
 
 // the outermost layer of component f (all = 1: every point), dealt to `nblk` workgroups of which this is number `blk`
 __device__ __forceinline__ void vel_shell_part(const VelDev &V, int f, int all, const double *__restrict__ x, double *__restrict__ y,
-                                               int64_t blk, int64_t nblk)
+                                               int64_t blk, int64_t nblk, double *acc = nullptr)
 {
     const int64_t nx = V.n[f][0], ny = V.n[f][1], nz = V.n[f][2];
     const bool three = V.dim == 3;
@@ -122,7 +128,16 @@ __device__ __forceinline__ void vel_shell_part(const VelDev &V, int f, int all, 
             i = 1 + (q >> 1) % (nx - 2);
             j = 1 + (q >> 1) / (nx - 2);
         }
-        y[V.off[f] + i + nx * (j + ny * k)] = vel_row(V, x, f, i, j, k);
+        const int64_t p = V.off[f] + i + nx * (j + ny * k);
+        const double v = vel_row(V, x, f, i, j, k);
+        y[p] = v;
+        if (acc != nullptr) {
+            if (V.dot_mode == 1) acc[0] += v * V.dot_other[p];
+            else {
+                acc[0] += v * x[p];
+                acc[1] += v * v;
+            }
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_vel_shell(const Scalars *__restrict__ S, VelDev V, int f, int all,
@@ -179,6 +194,10 @@ static VelDev vel_dev(const VelStencil &h)
     V.shift = h.shift;
     V.dinv = nullptr;
     V.opc = 1.0;
+    V.dot_mode = 0;
+    V.dot_other = nullptr;
+    V.dot_part = nullptr;
+    V.dot_stride = 0;
     for (int f = 0; f < 3; ++f) {
         V.off[f] = h.off[f];
         for (int d = 0; d < 3; ++d) {
@@ -271,7 +290,7 @@ constexpr int VX = 128, VY = 8, VSX = VX + 2, VSY = VY + 2;
 // 255-point lines of a wall-bounded component along its own direction; the last tile of a line is partial).
 template <bool V4>
 __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const double *__restrict__ x, double *__restrict__ y, int MZ,
-                                               int bx, int by, int bz, double (&sp)[2][VSY][VSX])
+                                               int bx, int by, int bz, double (&sp)[2][VSY][VSX], double *acc = nullptr)
 {
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int nx = (int)V.n[f][0], ny = (int)V.n[f][1], nz = (int)V.n[f][2];
@@ -367,6 +386,17 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
             s2 = s2 + (zpos * V.scale) * zp[c];
             out[c] = s2;
         }
+        if (jin && acc != nullptr) {
+            // the stored rows only (the shell owns the others); the second factor straight from memory (an L2 hit for the
+            // raw input, which this workgroup loaded a plane ago)
+            const double *po = (V.dot_mode == 1 ? V.dot_other : x) + (int64_t)k * sz + row;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (cin[c]) {
+                    acc[0] += out[c] * po[ci[c]];
+                    if (V.dot_mode == 2) acc[1] += out[c] * out[c];
+                }
+        }
         if (jin) {
             double *py = y + (int64_t)k * sz + row;
             if (V4 && cin[0] && cin[3]) {
@@ -412,20 +442,59 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
     if (S != nullptr && S->done) return;
     __shared__ double sp[2][VSY][VSX];
     const int b = blockIdx.x;
+    double acc[2] = {0.0, 0.0};
+    double *pa = V.dot_mode ? acc : nullptr;
     if (b < P.first[3]) {
         const int f = (b >= P.first[1]) + (b >= P.first[2]);
-        vel_shell_part(V, f, 0, x, y, b - P.first[f], P.first[f + 1] - P.first[f]);
-        return;
+        vel_shell_part(V, f, 0, x, y, b - P.first[f], P.first[f + 1] - P.first[f], pa);
+    } else {
+        const int f = (b >= P.first[4]) + (b >= P.first[5]);
+        const int lb = b - P.first[3 + f];
+        const int bx = lb % P.gx[f], by = (lb / P.gx[f]) % P.gy[f], bz = lb / (P.gx[f] * P.gy[f]);
+        if (P.v4[f]) vel_march_tile<true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
+        else vel_march_tile<false>(V, f, x, y, MZ, bx, by, bz, sp, pa);
     }
-    const int f = (b >= P.first[4]) + (b >= P.first[5]);
-    const int lb = b - P.first[3 + f];
-    const int bx = lb % P.gx[f], by = (lb / P.gx[f]) % P.gy[f], bz = lb / (P.gx[f] * P.gy[f]);
-    if (P.v4[f]) vel_march_tile<true>(V, f, x, y, MZ, bx, by, bz, sp);
-    else vel_march_tile<false>(V, f, x, y, MZ, bx, by, bz, sp);
+    if (V.dot_mode) {  // one partial per workgroup and sum, fixed order
+        __shared__ double sh[2][4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            double v = acc[k2];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) sh[k2][w] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 && (threadIdx.x == 0 || V.dot_mode == 2))
+            V.dot_part[(int64_t)threadIdx.x * V.dot_stride + b] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+    }
+}
+
+// second stage of the fused sums: the per-workgroup partials of slot y -> 64 partial sums in the Krylov solver's partial
+// array (d_part[slot0 + y][0..63]), which its finalize kernels take from there
+constexpr int VEL_STAGE = 64;
+__global__ __launch_bounds__(256) void k_vel_reduce(const Scalars *__restrict__ S, const double *__restrict__ part, int stride, int count,
+                                                    double *__restrict__ out, int slot0)
+{
+    if (S != nullptr && S->done) return;
+    const double *p = part + (int64_t)blockIdx.y * stride;
+    const int chunk = (count + VEL_STAGE - 1) / VEL_STAGE;
+    const int lo = blockIdx.x * chunk, hi = min(lo + chunk, count);
+    double v = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) v += p[i];
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(int64_t)(slot0 + blockIdx.y) * PIB_MAXPART + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 void vel_stencil_release(pib_solver *s)
 {
+    if (s->d_vel_part) (void)hipFree(s->d_vel_part);
+    s->d_vel_part = nullptr;
+    s->vel_part_cap = 0;
     for (double *p : s->vel.owned) (void)hipFree(p);
     s->vel = VelStencil();
 }
@@ -444,14 +513,17 @@ bool vel_stencil_fused_ok(const pib_solver *s)
     return true;
 }
 
-int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv, double opc)
+int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv, double opc,
+                      int dot_mode, const double *dot_other, int dot_slot0)
 {
     const VelStencil &h = s->vel;
     VelDev V = vel_dev(h);
-    if (dinv != nullptr) {
-        if (!vel_stencil_fused_ok(s)) return fail(PIB_ERR_ORDER, "velocity product with the Jacobi sweep folded in: the one-launch form does not serve this operator");
+    if (dinv != nullptr || dot_mode != 0) {
+        if (!vel_stencil_fused_ok(s)) return fail(PIB_ERR_ORDER, "velocity product with the Jacobi sweep / the Krylov sums folded in: the one-launch form does not serve this operator");
         V.dinv = dinv;
         V.opc = opc;
+        V.dot_mode = dot_mode;
+        V.dot_other = dot_other;
     }
     const Scalars *S = guarded ? s->d_s : nullptr;
     const int MZ = std::max(2, s->cfg.velocity_march_planes);
@@ -478,7 +550,20 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
             nb += P.gx[f] * P.gy[f] * (int)((nz - 2 + MZ - 1) / MZ);
         }
         P.first[6] = nb;
+        if (dot_mode != 0) {
+            if (s->vel_part_cap < nb) {
+                if (s->d_vel_part) PIB_HIP(hipFree(s->d_vel_part));
+                s->d_vel_part = nullptr;
+                PIB_HIP(hipMalloc(&s->d_vel_part, sizeof(double) * 2 * (size_t)nb));
+                s->vel_part_cap = nb;
+            }
+            V.dot_part = s->d_vel_part;
+            V.dot_stride = s->vel_part_cap;
+        }
         hipLaunchKernelGGL(k_vel_product, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
+        if (dot_mode != 0)
+            hipLaunchKernelGGL(k_vel_reduce, dim3(VEL_STAGE, dot_mode == 2 ? 2 : 1), dim3(256), 0, q, S, s->d_vel_part, s->vel_part_cap, nb,
+                               s->d_part, dot_slot0);
         PIB_HIP(hipGetLastError());
         s->counters[0]++;
         return 0;

@@ -400,11 +400,13 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
     b = np.random.default_rng(5).uniform(-1, 1, m.UN)
     out = []
     # one launch for the three components' tiles and shells (k_vel_product), a launch each, the streaming kernels, the CSR
-    # (the first also runs BiCGStab without stored M^-1 p / M^-1 s and with the x update deferred: krylov.hip OpBFUpdateP)
+    # (the first also runs BiCGStab without stored M^-1 p / M^-1 s and with the x update deferred: krylov.hip OpBFUpdateP);
+    # the last lets the products also sum v.rp, s.t, t.t (grouped by tile: equal to rounding, not bit for bit)
     for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_lean_bicgstab=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_velocity_product=0\n",
-                  "pib_matrix_free_velocity=1\npib_march_velocity=0\n", "pib_matrix_free_velocity=0\n"):
+                  "pib_matrix_free_velocity=1\npib_march_velocity=0\n", "pib_matrix_free_velocity=0\n",
+                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_bicgstab_dots=1\n"):
         s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-13, conv="ABSOLUTE",
                                                               maxit=500, extra=extra))
         s.setPeriodic(per)
@@ -414,8 +416,13 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
         out.append((x, s.getIters(), s.getResidualHistory()))
         s.destroy()
     assert out[0][1] == out[1][1] == out[2][1] == out[3][1] == out[4][1] and out[0][1] >= 2
-    for o in out[1:]:
+    for o in out[1:5]:
         assert np.array_equal(out[0][2], o[2]) and np.array_equal(out[0][0], o[0])
+    fused = out[5]
+    assert abs(fused[1] - out[0][1]) <= 1
+    k = min(len(fused[2]), len(out[0][2])) - 1  # the last residuals sit at the round-off floor of the recurrence
+    assert np.allclose(fused[2][:k], out[0][2][:k], rtol=1e-6)
+    assert np.abs(fused[0] - out[0][0]).max() <= 1e-12 * max(1.0, np.abs(out[0][0]).max())
 
 
 @pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
