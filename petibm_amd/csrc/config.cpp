@@ -224,7 +224,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.fuse_velocity_product = std::atoi(d.get("default", "pib_fuse_velocity_product", "1").c_str());
     c.velocity_march_planes = std::atoi(d.get("default", "pib_velocity_march_planes", "16").c_str());
     c.lean_bicgstab = std::atoi(d.get("default", "pib_lean_bicgstab", "1").c_str());
-    c.fuse_bicgstab_dots = std::atoi(d.get("default", "pib_fuse_bicgstab_dots", "0").c_str());
+    c.fuse_bicgstab_dots = std::atoi(d.get("default", "pib_fuse_bicgstab_dots", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
     c.detect_structure = std::atoi(d.get("default", "pib_detect_structure", "1").c_str());

@@ -992,7 +992,7 @@ struct OpBUpdateX {  // x += alpha ph + omega sh ; r = s - omega t ; partials |r
 // product): M^-1 p and M^-1 s are never stored -- the products apply the sweep as they read their input
 // (vel_stencil_apply's dinv / opc) -- and x += alpha M^-1 p + omega M^-1 s is applied by the NEXT iteration's p-update,
 // which reads p anyway.  216 -> 200 B/row/iteration (27 -> 25 vector passes).  Every value is computed by the expression
-// of the general path above: bit-identical iterates -- unless `pib_fuse_bicgstab_dots` (default off: no gain) lets the products sum
+// of the general path above: bit-identical iterates -- unless `pib_fuse_bicgstab_dots` (default on) lets the products sum
 // v.rp and s.t, t.t themselves (two passes less, 184 B/row/iteration): those sums are grouped by tile, so alpha and omega
 // agree with the general path's to rounding only.
 struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*beta) v + beta p

@@ -436,6 +436,7 @@ struct VelPlan {
     int gx[3], gy[3];   // tiles per plane of a component
     int v4[3];
 };
+template <int DOT>  // DOT = 1: with the fused Krylov sums (V.dot_mode); a separate instantiation keeps the plain product's registers
 __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__ S, VelDev V, VelPlan P, const double *__restrict__ x,
                                                      double *__restrict__ y, int MZ)
 {
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
     __shared__ double sp[2][VSY][VSX];
     const int b = blockIdx.x;
     double acc[2] = {0.0, 0.0};
-    double *pa = V.dot_mode ? acc : nullptr;
+    double *pa = DOT ? acc : nullptr;
     if (b < P.first[3]) {
         const int f = (b >= P.first[1]) + (b >= P.first[2]);
         vel_shell_part(V, f, 0, x, y, b - P.first[f], P.first[f + 1] - P.first[f], pa);
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
         if (P.v4[f]) vel_march_tile<true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
         else vel_march_tile<false>(V, f, x, y, MZ, bx, by, bz, sp, pa);
     }
-    if (V.dot_mode) {  // one partial per workgroup and sum, fixed order
+    if (DOT) {  // one partial per workgroup and sum, fixed order
         __shared__ double sh[2][4];
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -560,7 +561,8 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
             V.dot_part = s->d_vel_part;
             V.dot_stride = s->vel_part_cap;
         }
-        hipLaunchKernelGGL(k_vel_product, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
+        if (dot_mode != 0) hipLaunchKernelGGL(k_vel_product<1>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
+        else hipLaunchKernelGGL(k_vel_product<0>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
         if (dot_mode != 0)
             hipLaunchKernelGGL(k_vel_reduce, dim3(VEL_STAGE, dot_mode == 2 ? 2 : 1), dim3(256), 0, q, S, s->d_vel_part, s->vel_part_cap, nb,
                                s->d_part, dot_slot0);

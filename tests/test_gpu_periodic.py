@@ -401,12 +401,12 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per):
     out = []
     # one launch for the three components' tiles and shells (k_vel_product), a launch each, the streaming kernels, the CSR
     # (the first also runs BiCGStab without stored M^-1 p / M^-1 s and with the x update deferred: krylov.hip OpBFUpdateP);
-    # the last lets the products also sum v.rp, s.t, t.t (grouped by tile: equal to rounding, not bit for bit)
-    for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\n",
+    # the last is the default, whose products also sum v.rp, s.t, t.t (grouped by tile: equal to rounding, not bit for bit)
+    for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_bicgstab_dots=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_lean_bicgstab=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_velocity_product=0\n",
                   "pib_matrix_free_velocity=1\npib_march_velocity=0\n", "pib_matrix_free_velocity=0\n",
-                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_bicgstab_dots=1\n"):
+                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\n"):
         s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-13, conv="ABSOLUTE",
                                                               maxit=500, extra=extra))
         s.setPeriodic(per)
