@@ -149,3 +149,20 @@ def test_bench_launches_its_own_ranks_over_the_peer_transport():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["counters"]["comm_ranks"] == 2
     assert d["config"]["parallelism"] == "zslab2" and d["config"]["transport"] == "peer"
     assert d["true_rel_residual"] <= 1.5e-10 and d["counters"]["halo_exchanges"] > 0
+
+
+def test_config3_512_cubed_on_8_processes():
+    """BASELINE config 3 -- the 512^3 cavity on 8 z-slabs of 64 planes, multigrid-PCG V(2,2), rtol 1e-10 -- with EIGHT PROCESSES
+    (bench.py's own launch, peer transport, all on the one GPU): the single-rank iteration count and the residual contract,
+    every rank through the same ~110 collectives of a solve.  (test_config3_512_cubed_on_8_slabs runs the same on 8 loopback
+    threads; timing means nothing here -- eight contexts time-slice one GPU.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PIB_BENCH_SHARE_GPU="1", PIB_PEER_TIMEOUT_S="300")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--transport", "peer", "--steps", "1", "--warmup", "0",
+           "--no-cpu", "--no-secondary", "--kernel-reps", "1"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "zslab8" and d["counters"]["comm_ranks"] == 8
+    assert d["iters_per_solve"] == 11 and d["true_rel_residual"] <= 1.5e-10
