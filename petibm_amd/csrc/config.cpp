@@ -224,6 +224,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.fuse_velocity_product = std::atoi(d.get("default", "pib_fuse_velocity_product", "1").c_str());
     c.velocity_march_planes = std::atoi(d.get("default", "pib_velocity_march_planes", "16").c_str());
     c.lean_bicgstab = std::atoi(d.get("default", "pib_lean_bicgstab", "1").c_str());
+    c.blocked_reductions = std::atoi(d.get("default", "pib_blocked_reductions", "1").c_str());
     c.fuse_bicgstab_dots = std::atoi(d.get("default", "pib_fuse_bicgstab_dots", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
@@ -336,6 +337,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_fuse_velocity_product", v)) c.fuse_velocity_product = std::atoi(v.c_str());
     if (get("pib_velocity_march_planes", v)) c.velocity_march_planes = std::atoi(v.c_str());
     if (get("pib_lean_bicgstab", v)) c.lean_bicgstab = std::atoi(v.c_str());
+    if (get("pib_blocked_reductions", v)) c.blocked_reductions = std::atoi(v.c_str());
     if (get("pib_fuse_bicgstab_dots", v)) c.fuse_bicgstab_dots = std::atoi(v.c_str());
     if (get("pib_matrix_free_poisson", v)) c.matrix_free_poisson = std::atoi(v.c_str());
     if (get("pib_agglomerate_below", v)) c.agglomerate_below = std::atoi(v.c_str());
