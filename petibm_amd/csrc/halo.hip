@@ -263,6 +263,7 @@ static int peer_attach(pib_solver *s, int rank, int nranks, const char *name)
     g->ev_done.assign((size_t)nranks, nullptr);
     auto bail = [&](int err) {
         if (g->shm) g->shm->failed.store(1);
+        if (rank == 0) (void)shm_unlink(name);  // nobody will: the name would outlive the run
         peer_destroy(g);
         return err;
     };
