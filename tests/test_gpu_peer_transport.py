@@ -166,3 +166,17 @@ def test_config3_512_cubed_on_8_processes():
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "zslab8" and d["counters"]["comm_ranks"] == 8
     assert d["iters_per_solve"] == 11 and d["true_rel_residual"] <= 1.5e-10
+
+
+def test_a_missing_rank_is_an_error_not_a_hang(monkeypatch):
+    """every wait for another rank is bounded (PIB_PEER_TIMEOUT_S): rank 0 of a two-rank world whose rank 1 never shows up gets
+    the error code and a message that names the wait, and the shared-memory name does not outlive the attempt"""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    monkeypatch.setenv("PIB_PEER_TIMEOUT_S", "2")
+    uid = peer_id()
+    name = uid[8:].split(b"\0", 1)[0].decode()
+    with pytest.raises(capi.PibError) as e:
+        LinSolverHIP("poisson", config_text=_cfg("BLOCK_JACOBI"), rank=0, nranks=2, uid=uid, device=0)
+    assert "peer transport" in str(e.value) and "waited" in str(e.value)
+    assert not os.path.exists("/dev/shm" + name)
