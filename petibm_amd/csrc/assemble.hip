@@ -383,6 +383,8 @@ struct FieldDev {
     const double *co[3];     // coord[f][d], index s+1
     double a0[6];            // ghost coefficient per boundary location (0 where periodic / unused)
     int per;                 // bit d: direction d periodic (neighbour indices wrap, no ghost fold)
+    int ring;                // the slab axis is periodic AND distributed: its wrap goes through the ghost pads (rank 0's
+                             // lower neighbour plane is the last rank's top plane)
 };
 
 
@@ -505,11 +507,12 @@ __global__ __launch_bounds__(256) void k_assemble_velocity(int dim, FieldDev F, 
             if (!interior[q]) continue;
             const int d = q >> 1;
             int64_t c;
+            const bool via_pads = d == sd && F.ring;
             if (!(q & 1)) {
-                if (ijk[d] == 0) c = lc + (F.n[d] - 1) * st[d];
+                if (ijk[d] == 0 && !via_pads) c = lc + (F.n[d] - 1) * st[d];
                 else c = (d == sd && ks - 1 < F.kb) ? F.ghost_lo_off + inplane : lc - st[d];
             } else {
-                if (ijk[d] == F.n[d] - 1) c = lc - (F.n[d] - 1) * st[d];
+                if (ijk[d] == F.n[d] - 1 && !via_pads) c = lc - (F.n[d] - 1) * st[d];
                 else c = (d == sd && ks + 1 >= F.ke) ? F.ghost_hi_off + inplane : lc + st[d];
             }
             int t = ne++;
@@ -550,7 +553,9 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
     // component along the slab axis has one plane fewer, taken from the last rank.  Each rank's vector is the packed
     // [u-slab | v-slab | w-slab] of the reference's DMComposite (cartesianmesh.cpp:740-779).
     const int P = s->comm.nranks, rank = s->comm.rank, sd = dim - 1;
-    if (P > 1 && (per & (1 << sd))) return fail(PIB_ERR_SUP, "assemble_velocity: a periodic slab axis on several ranks is not supported");
+    // a periodic slab axis on several ranks: rank 0 and rank P - 1 are neighbours, every rank has both ghost pads and the
+    // exchange is a ring (as in assemble_poisson)
+    const bool ring = P > 1 && (per & (1 << sd));
     int64_t pk0, pk1;
     slab_range(n[sd], P, rank, &pk0, &pk1);
     int64_t rows = 0, nnz = 0, row_off[3] = {0, 0, 0}, nnz_off[3] = {0, 0, 0}, kb[3] = {0, 0, 0}, ke[3] = {0, 0, 0},
@@ -568,11 +573,11 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
         rows += pl[f] * (ke[f] - kb[f]);
         nnz += nnz_before(pl[f] * ke[f], dim, fn[f][0], fn[f][1], fn[f][2], per) -
                nnz_before(pl[f] * kb[f], dim, fn[f][0], fn[f][1], fn[f][2], per);
-        if (rank > 0) {
+        if (rank > 0 || ring) {
             glo[f] = ghost_lo;
             ghost_lo += pl[f];
         }
-        if (rank < P - 1) {
+        if (rank < P - 1 || ring) {
             ghi[f] = ghost_hi;
             ghost_hi += pl[f];
         }
@@ -587,7 +592,7 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
     }
     DeviceCsr &A = s->A;
     A.release();
-    s->comm.ring = false;
+    s->comm.ring = ring;
     vel_stencil_release(s);
     A.n = rows;
     A.row0 = row0;
@@ -602,11 +607,11 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
         // one plane of every component to each neighbour, received back to back into the ghost pads
         A.segmented = true;
         for (int f = 0; f < dim; ++f) {
-            if (rank > 0) {
+            if (rank > 0 || ring) {
                 A.seg_send_prev.push_back({row_off[f], pl[f]});
                 A.seg_recv_lo.push_back(pl[f]);
             }
-            if (rank < P - 1) {
+            if (rank < P - 1 || ring) {
                 A.seg_send_next.push_back({row_off[f] + pl[f] * (ke[f] - kb[f] - 1), pl[f]});
                 A.seg_recv_hi.push_back(pl[f]);
             }
@@ -643,6 +648,7 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
         F.ghost_hi_off = ghost_lo + rows + ghi[f];
         for (int q = 0; q < 6; ++q) F.a0[q] = a0[6 * f + q];
         F.per = per;
+        F.ring = ring ? 1 : 0;
         const int64_t nf = pl[f] * (ke[f] - kb[f]);
         const int nb = (int)std::min<int64_t>(8192, (nf + 1 + 255) / 256);
         const int last = (f == dim - 1) ? 1 : 0;

@@ -616,37 +616,59 @@ static int halo_exchange_segments(pib_solver *s, double *x_owned, hipStream_t st
         int64_t lo = 0, hi = 0;
         for (int64_t c : A.seg_recv_lo) lo += c;
         for (int64_t c : A.seg_recv_hi) hi += c;
-        return peer_window_exchange(s, st, r - 1, r + 1, r > 0, r < P - 1, to_prev, to_next, x_owned - A.ghost_lo, lo, x_owned + A.n, hi,
-                                    "halo segments");
+        const bool ring = s->comm.ring;
+        return peer_window_exchange(s, st, (r + P - 1) % P, (r + 1) % P, r > 0 || ring, r < P - 1 || ring, to_prev, to_next,
+                                    x_owned - A.ghost_lo, lo, x_owned + A.n, hi, "halo segments");
     }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
         PIB_CHK(g->publish(r, x_owned, A.n, &A.seg_send_prev, &A.seg_send_next));
         PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
         PIB_CHK(g->barrier());
-        if (r > 0 && !A.seg_recv_lo.empty()) {
-            PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)(r - 1)], 0));
+        const bool ring = s->comm.ring;
+        const size_t pv = (size_t)((r + P - 1) % P), nx = (size_t)((r + 1) % P);
+        if ((r > 0 || ring) && !A.seg_recv_lo.empty()) {
+            PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[pv], 0));
             double *dst = x_owned - A.ghost_lo;
-            for (const auto &sg : *g->segs_next[(size_t)(r - 1)]) {  // what r-1 sends to its next rank = my low ghosts
-                PIB_HIP(hipMemcpyAsync(dst, g->ptr[(size_t)(r - 1)] + sg.first, sizeof(double) * (size_t)sg.second,
-                                       hipMemcpyDeviceToDevice, st));
+            for (const auto &sg : *g->segs_next[pv]) {  // what the previous rank sends to its next rank = my low ghosts
+                PIB_HIP(hipMemcpyAsync(dst, g->ptr[pv] + sg.first, sizeof(double) * (size_t)sg.second, hipMemcpyDeviceToDevice, st));
                 dst += sg.second;
             }
         }
-        if (r < P - 1 && !A.seg_recv_hi.empty()) {
-            PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)(r + 1)], 0));
+        if ((r < P - 1 || ring) && !A.seg_recv_hi.empty()) {
+            PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[nx], 0));
             double *dst = x_owned + A.n;
-            for (const auto &sg : *g->segs_prev[(size_t)(r + 1)]) {
-                PIB_HIP(hipMemcpyAsync(dst, g->ptr[(size_t)(r + 1)] + sg.first, sizeof(double) * (size_t)sg.second,
-                                       hipMemcpyDeviceToDevice, st));
+            for (const auto &sg : *g->segs_prev[nx]) {
+                PIB_HIP(hipMemcpyAsync(dst, g->ptr[nx] + sg.first, sizeof(double) * (size_t)sg.second, hipMemcpyDeviceToDevice, st));
                 dst += sg.second;
             }
         }
         PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
         PIB_CHK(g->barrier());
-        if (r > 0) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)(r - 1)], 0));
-        if (r < P - 1) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)(r + 1)], 0));
+        if (r > 0 || ring) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[pv], 0));
+        if (r < P - 1 || ring) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[nx], 0));
         PIB_CHK(g->barrier());
+        return 0;
+    }
+    if (s->comm.ring) {
+        // periodic slab axis: every rank has both neighbours.  With P == 2 all messages of a rank go to the one peer and are
+        // matched in issue order: the pieces for the previous rank first (the peer receives them as its HIGH ghosts), then the
+        // pieces for the next rank -- so the high ghosts are received first, the low ghosts second
+        const int pv = (r + P - 1) % P, nx = (r + 1) % P;
+        PIB_NCCL(ncclGroupStart());
+        for (const auto &sg : A.seg_send_prev) PIB_NCCL(ncclSend(x_owned + sg.first, (size_t)sg.second, ncclDouble, pv, s->comm.comm, st));
+        double *dst = x_owned + A.n;
+        for (int64_t c : A.seg_recv_hi) {
+            PIB_NCCL(ncclRecv(dst, (size_t)c, ncclDouble, nx, s->comm.comm, st));
+            dst += c;
+        }
+        for (const auto &sg : A.seg_send_next) PIB_NCCL(ncclSend(x_owned + sg.first, (size_t)sg.second, ncclDouble, nx, s->comm.comm, st));
+        dst = x_owned - A.ghost_lo;
+        for (int64_t c : A.seg_recv_lo) {
+            PIB_NCCL(ncclRecv(dst, (size_t)c, ncclDouble, pv, s->comm.comm, st));
+            dst += c;
+        }
+        PIB_NCCL(ncclGroupEnd());
         return 0;
     }
     PIB_NCCL(ncclGroupStart());

@@ -359,6 +359,57 @@ def test_periodic_slab_axis_across_ranks(P, n, per, pc, extra):
     s1.destroy()
 
 
+@pytest.mark.parametrize("P,n,per", [(2, (10, 9, 12), (True, True, True)), (3, (8, 6, 12), (False, False, True)),
+                                     (2, (12, 10), (True, True)), (4, (6, 5, 16), (True, False, True))])
+def test_velocity_system_on_a_periodic_slab_axis(P, n, per):
+    """a periodic slab axis (the Taylor-Green box on several GPUs) for the velocity operator A = I/dt - c nu L --
+    every rank has both ghost pads, the wrapped neighbours of rank 0's first and the last rank's last plane arrive through the
+    ring of the segmented halo plan (one plane of u, v and w each way).  Loopback ranks on one GPU against the oracle's operator
+    and the single-rank solve."""
+    from petibm_amd.linsolver import LinSolverHIP
+    from test_gpu_multirank_loopback import _run_ranks, _velocity_slab_indices
+    from test_gpu_parity import _a0_table
+    m = omesh.create_mesh(omesh.periodic_config(n, per))
+    dt, cnu = 0.004, 0.5 * 0.01
+    A = oops.create_velocity_operator(oops.create_laplacian(m), dt, cnu)
+    us = np.random.default_rng(12).uniform(-1, 1, A.n_rows)
+    b = clib.spmv(A, us)
+    nn = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    text = amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500)
+    own = [_velocity_slab_indices(m, P, r) for r in range(P)]
+    assert sorted(np.concatenate(own).tolist()) == list(range(A.n_rows))
+
+    def rank_fn(r, uid):
+        s = LinSolverHIP("velocity", config_text=text, rank=r, nranks=P, uid=uid, device=0)
+        s.setPeriodic(per)
+        s.assembleVelocity(nn, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
+        assert s.n_local == own[r].size
+        y = np.empty(own[r].size)
+        s.matMult(np.ascontiguousarray(us[own[r]]), y)
+        x = np.zeros(own[r].size)
+        s.solve(x, np.ascontiguousarray(b[own[r]]))
+        its = s.getIters()
+        s.destroy()
+        return y, x, its
+
+    res = _run_ranks(P, rank_fn)
+    y, x = np.empty(A.n_rows), np.empty(A.n_rows)
+    for r in range(P):
+        y[own[r]], x[own[r]] = res[r][0], res[r][1]
+    # the rows of the outer planes sum their wrapped neighbour first (ghost pad) instead of last: last-bit differences
+    assert np.abs(y - b).max() <= 8 * 4e-16 * np.abs(A.val).max() * np.abs(us).max()
+    assert len({q[2] for q in res}) == 1
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1e-11 * np.linalg.norm(b)
+    s1 = LinSolverHIP("velocity", config_text=text)
+    s1.setPeriodic(per)
+    s1.assembleVelocity(nn, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
+    x1 = np.zeros(A.n_rows)
+    s1.solve(x1, b)
+    assert abs(res[0][2] - s1.getIters()) <= 1 and np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
+    s1.destroy()
+
+
 @pytest.mark.parametrize("case", ["2d_stretched", "3d_stretched", "3d_outflow", "2d_xy", "2d_y", "3d_xz", "3d_all", "tiny"])
 def test_matrix_free_velocity_operator_is_the_csr_product(lin, case):
     """velstencil.hip: the Krylov products of the velocity solve from the mesh tables.  Same entries, same summation
