@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
 }
 
 // rhs2 = D u + Dbc (navierstokes.cpp:540-563); D row in packed-column order u(i-1), u(i), v(j-1), v(j), w(k-1), w(k)
-__global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int pinned, const double *__restrict__ U,
+__global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int64_t pin_cell, const double *__restrict__ U,
                                                         double *__restrict__ rhs2)
 {
     for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < D.pN; c += (int64_t)gridDim.x * 256) {
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int pinned, con
             if (!has_p) corr = corr + area[f] * D.a1[face_index(F, 2 * f + 1, fi[0], fi[1], fi[2])];
         }
         double r = s + corr;
-        if (pinned && c == 0) r = 0.0;
+        if (c == pin_cell) r = 0.0;  // the pinned pressure's row (global cell 0; -1: none on this rank)
         rhs2[c] = r;
     }
 }
@@ -570,10 +570,10 @@ __global__ __launch_bounds__(256) void k_ns_bng(NsDev D, double dt, const double
 
 // w = w - D t over the pressure cells (D without the boundary correction: the rows of k_ns_rhs_poisson); the identity
 // row of a pinned pressure is left alone
-__global__ __launch_bounds__(256) void k_ns_div_sub(NsDev D, int pinned, const double *__restrict__ t, double *__restrict__ w)
+__global__ __launch_bounds__(256) void k_ns_div_sub(NsDev D, int64_t pin_cell, const double *__restrict__ t, double *__restrict__ w)
 {
     for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < D.pN; c += (int64_t)gridDim.x * 256) {
-        if (pinned && c == 0) continue;
+        if (c == pin_cell) continue;
         const int64_t i = c % D.pn[0], j = (c / D.pn[0]) % D.pn[1], k = c / (D.pn[0] * D.pn[1]);
         const int64_t ijk[3] = {i, j, k};
         const double wx = D.pw[0][i], wy = D.pw[1][j], wz = (D.dim == 3) ? D.pw[2][k] : 1.0;
@@ -628,10 +628,16 @@ int ns_bng_apply(pib_ns *ns, const double *phi, double *out, hipStream_t q)
     PIB_HIP(hipGetLastError());
     return 0;
 }
+// the pinned pressure's cell (global cell 0) in this rank's (extended) slab, -1 where there is none
+static int64_t ns_pin_cell(const pib_ns *ns)
+{
+    if (!ns->pinned || ns->rank != 0) return -1;
+    return (ns->slab_pk0 - ns->slab_e0) * ns->p_plane;  // 0 unless the slab starts with a plane of the last rank (periodic slab axis)
+}
 int ns_div_sub(pib_ns *ns, const double *t, double *w, hipStream_t q)
 {
     const NsDev &D = ns->D;
-    hipLaunchKernelGGL(k_ns_div_sub, dim3((unsigned)std::min<int64_t>(4096, (D.pN + 255) / 256)), dim3(256), 0, q, D, ns->pinned, t, w);
+    hipLaunchKernelGGL(k_ns_div_sub, dim3((unsigned)std::min<int64_t>(4096, (D.pN + 255) / 256)), dim3(256), 0, q, D, ns_pin_cell(ns), t, w);
     PIB_HIP(hipGetLastError());
     return 0;
 }
@@ -712,27 +718,55 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     for (int f = 0; f < dim; ++f) fn_global[f] = fn[f][sd];
     std::vector<double> w_slab;
     int64_t n_local[3] = {n[0], n[1], n[2]};
+    // a periodic slab axis on several ranks (the Taylor-Green box on several GPUs): every rank's extended slab has a cut at
+    // both ends -- rank 0's lower neighbour plane is the last rank's top plane -- and the engine's kernels see a wall-bounded
+    // direction there; the wrap lives in the plane exchanges (a ring) and in the two linear systems
+    const bool ring = nranks > 1 && periodic[sd] != 0;
+    int periodic_local[3] = {periodic[0], periodic[1], periodic[2]};
     if (nranks > 1) {
-        if (periodic[sd]) return fail(PIB_ERR_SUP, "pib_ns_create_slab: a periodic slab axis on several ranks is not provided");
         slab_range(n[sd], nranks, rank, &pk0, &pk1);
         if (pk1 - pk0 < 2) return fail(PIB_ERR_SUP, "pib_ns_create_slab: rank %d owns %lld plane(s); every rank needs >= 2", rank, (long long)(pk1 - pk0));
-        e0 = std::max<int64_t>(pk0 - 1, 0);
-        e1 = std::min<int64_t>(pk1 + 2, n[sd]);
+        e0 = ring ? pk0 - 1 : std::max<int64_t>(pk0 - 1, 0);            // with a ring: cell -1 is cell n - 1, cells n, n + 1 are 0, 1
+        e1 = ring ? pk1 + 2 : std::min<int64_t>(pk1 + 2, n[sd]);
+        const double length = hi[sd] - lo[sd];
         for (int f = 0; f < dim; ++f) {
             const int64_t cnt = (f == sd) ? (e1 - e0 - 1) : (e1 - e0);  // faces between the local planes / the local planes
             std::vector<double> &a = hdl[f][sd], &c = hco[f][sd];
-            a = std::vector<double>(a.begin() + e0, a.begin() + e0 + cnt + 2);  // entry s + 1 <-> point s, one entry beyond each end
-            c = std::vector<double>(c.begin() + e0, c.begin() + e0 + cnt + 2);
+            // entry s + 1 <-> point s, one entry beyond each end
+            if (!ring) {
+                a = std::vector<double>(a.begin() + e0, a.begin() + e0 + cnt + 2);
+                c = std::vector<double>(c.begin() + e0, c.begin() + e0 + cnt + 2);
+            } else {
+                // the single-rank arrays hold the points -1 .. np (their two ghost entries are the wrapped neighbours): those
+                // entries are taken as they are (same bits as on one rank); a point further out -- only the dummy entries beyond
+                // the cuts -- is its periodic image, a domain length away
+                const int64_t np = fn[f][sd];
+                std::vector<double> a2, c2;
+                for (int64_t j = e0; j < e0 + cnt + 2; ++j) {
+                    if (j >= 0 && j <= np + 1) {
+                        a2.push_back(a[(size_t)j]);
+                        c2.push_back(c[(size_t)j]);
+                    } else {
+                        const int64_t pt = j - 1, img = ((pt % np) + np) % np, turns = (pt - img) / np;
+                        a2.push_back(a[(size_t)img + 1]);
+                        c2.push_back(c[(size_t)img + 1] + (double)turns * length);
+                    }
+                }
+                a = a2;
+                c = c2;
+            }
             fn[f][sd] = cnt;
         }
-        w_slab.assign(w[sd] + e0, w[sd] + e1);
+        w_slab.clear();
+        for (int64_t q = e0; q < e1; ++q) w_slab.push_back(w[sd][(size_t)(((q % n[sd]) + n[sd]) % n[sd])]);
         w[sd] = w_slab.data();
         n_local[sd] = e1 - e0;
         // a cut is a dummy wall (the values the kernels derive from it land on the neighbours' planes only)
         for (int f = 0; f < dim; ++f) {
-            if (e0 > 0) { bc_type[6 * f + 2 * sd] = 0; bc_value[6 * f + 2 * sd] = 0.0; }
-            if (e1 < n[sd]) { bc_type[6 * f + 2 * sd + 1] = 0; bc_value[6 * f + 2 * sd + 1] = 0.0; }
+            if (e0 > 0 || ring) { bc_type[6 * f + 2 * sd] = 0; bc_value[6 * f + 2 * sd] = 0.0; }
+            if (e1 < n[sd] || ring) { bc_type[6 * f + 2 * sd + 1] = 0; bc_value[6 * f + 2 * sd + 1] = 0.0; }
         }
+        if (ring) periodic_local[sd] = 0;
     }
     pib_ns *ns = new pib_ns();
     ns->nranks = nranks;
@@ -741,6 +775,7 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     ns->slab_pk1 = pk1;
     ns->slab_e0 = e0;
     for (int d = 0; d < 3; ++d) ns->periodic[d] = periodic[d];
+    ns->ring = ring;
     ns->dt = dt;
     ns->nu = nu;
     for (int d = 0; d < dim; ++d) {
@@ -822,7 +857,7 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     // device mesh arrays
     NsDev &D = ns->D;
     D.dim = dim;
-    D.per = (periodic[0] ? 1 : 0) | (periodic[1] ? 2 : 0) | (periodic[2] ? 4 : 0);
+    D.per = (periodic_local[0] ? 1 : 0) | (periodic_local[1] ? 2 : 0) | (periodic_local[2] ? 4 : 0);
     int64_t off = 0;
     for (int f = 0; f < 3; ++f) {
         NsField &F = D.f[f];
@@ -880,7 +915,7 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
         for (int q = 0; q < 2 * dim; ++q) {
             NsField &F = D.f[f];
             F.goff[q] = D.nghost;
-            F.gcnt[q] = periodic[q / 2] ? 0 : fn[f][0] * fn[f][1] * fn[f][2] / fn[f][q / 2];
+            F.gcnt[q] = periodic_local[q / 2] ? 0 : fn[f][0] * fn[f][1] * fn[f][2] / fn[f][q / 2];
             D.nghost += F.gcnt[q];
         }
     D.pN = 1;
@@ -958,8 +993,9 @@ static int ns_halo_velocity(pib_ns *ns, double *ext)
     const int r = ns->rank, P = ns->nranks;
     for (int f = 0; f < ns->D.dim; ++f) {
         const int64_t pl = ns->fld_plane[f];
-        PIB_CHK(halo_exchange_planes(ns->vsol, ext + ns->D.f[f].off + ns->fld_own_lo[f] * pl, ns->fld_own_cnt[f] * pl, r > 0 ? pl : 0,
-                                     r < P - 1 ? pl : 0, r > 0 ? pl : 0, r < P - 1 ? pl : 0, ns->stream));
+        const int64_t lo_n = (r > 0 || ns->ring) ? pl : 0, hi_n = (r < P - 1 || ns->ring) ? pl : 0;
+        PIB_CHK(halo_exchange_planes(ns->vsol, ext + ns->D.f[f].off + ns->fld_own_lo[f] * pl, ns->fld_own_cnt[f] * pl, lo_n, hi_n, lo_n,
+                                     hi_n, ns->stream));
     }
     return 0;
 }
@@ -968,8 +1004,8 @@ static int ns_halo_cells(pib_ns *ns, double *ext)
     if (ns->nranks <= 1) return 0;
     const int r = ns->rank, P = ns->nranks;
     const int64_t pl = ns->p_plane;
-    return halo_exchange_planes(ns->vsol, ext + (ns->slab_pk0 - ns->slab_e0) * pl, ns->pN_owned, r > 0 ? pl : 0, r < P - 1 ? pl : 0,
-                                r > 0 ? pl : 0, r < P - 1 ? pl : 0, ns->stream);
+    const int64_t lo_n = (r > 0 || ns->ring) ? pl : 0, hi_n = (r < P - 1 || ns->ring) ? pl : 0;
+    return halo_exchange_planes(ns->vsol, ext + (ns->slab_pk0 - ns->slab_e0) * pl, ns->pN_owned, lo_n, hi_n, lo_n, hi_n, ns->stream);
 }
 }  // namespace pib
 
@@ -1284,7 +1320,7 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
             PIB_CHK(ib_solve_forces(ns));   // assembleRHSForces, solveForces, applyNoSlip (decoupledibpm.cpp:116-118)
             PIB_CHK(ns_halo_velocity(ns, ns->U));  // u += BNH df changed owned points next to the neighbours' planes
         }
-        hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns->pinned, ns->U, ns->rhs2);
+        hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns_pin_cell(ns), ns->U, ns->rhs2);
         PIB_HIP(hipGetLastError());
         if (coupled) {
             // IBPMSolver (applications/ibpm): pressure and forces are one unknown; solved here through the Schur

@@ -95,6 +95,7 @@ struct pib_ns {
     int f_iters = 0;
     double f_res = 0;
     int periodic[3] = {0, 0, 0};
+    bool ring = false;  // several ranks and a periodic slab axis: both ends of the extended slab are cuts, the plane exchanges wrap
     // parameters.BN > 1 (pib_ns_set_bn_order): the projection multiplies by the assembled BNG
     int bn_order = 1;
     int32_t *bng_rowptr = nullptr, *bng_col = nullptr;
