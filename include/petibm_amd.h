@@ -96,7 +96,8 @@ int pib_comm_peer_id(void *uid_out /* PIB_UID_BYTES */);
 int pib_comm_loopback_create(int nranks, void *uid_out /* PIB_UID_BYTES */);
 int pib_comm_loopback_destroy(const void *uid);
 
-/* TEST: the RCCL calls of the production transport (grouped ncclSend / ncclRecv incl. the periodic ring, in-place
+/* TEST: the RCCL calls of the production transport (grouped ncclSend / ncclRecv incl. the periodic ring of plane and of
+ * segmented -- packed velocity -- exchanges, in-place
  * ncclAllReduce, ncclAllGather / grouped ncclBroadcast, an exchange on the communication stream ordered with events) in a
  * ONE-rank RCCL world on `device`, on a vector of n_owned entries with `ghost` ghost entries at either end; *max_err_out
  * is the largest deviation of what arrived from what must arrive (0), *comm_ranks_out ncclCommCount (1).  The multi-rank
@@ -207,8 +208,8 @@ int pib_assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const do
  * (mesh->min / mesh->max); a0[6*f + loc]: ghost coefficient of field f at boundary loc (xMinus,xPlus,yMinus,
  * yPlus,zMinus,zPlus): Dirichlet/convective 0 when loc's normal is f else -1, Neumann 1
  * (src/boundary/singleboundary{dirichlet,neumann,convective}.cpp).  Honours pib_set_periodic.  On several ranks every
- * rank assembles the rows of its slab of the packed [u | v | w] ordering with a segmented halo plan; a
- * periodic slab axis on several ranks is PIB_ERR_SUP. */
+ * rank assembles the rows of its slab of the packed [u | v | w] ordering with a segmented halo plan; with a
+ * periodic slab axis rank 0 and rank P - 1 are neighbours (every rank has both ghost pads, the exchange is a ring). */
 int pib_assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                           const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
                           double coeff_nu);
@@ -281,8 +282,10 @@ int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, co
  * (cartesianmesh.cpp:740-779; the component along the slab axis has one plane fewer, on the last rank) and the owned
  * pressure cells.  Every rank needs >= 2 planes.  Immersed bodies (pib_ns_set_bodies / pib_ns_move_bodies, collective,
  * the same bodies on every rank; direct forces solver): every rank assembles the operators on the velocity points it
- * owns, E u and the force system E BN H are summed over the ranks, the forces are replicated.  Not on slabs: BN order
- * > 1, a periodic slab axis, the coupled IBPM, the vorticity utility (PIB_ERR_SUP). */
+ * owns, E u and the force system E BN H are summed over the ranks, the forces are replicated.  A periodic slab axis (the
+ * Taylor-Green box on several GPUs) makes both ends of every rank's slab a cut and the plane exchanges a ring.  Not on
+ * slabs: BN order > 1, immersed bodies together with a periodic slab axis, the coupled IBPM, the vorticity utility
+ * (PIB_ERR_SUP). */
 int pib_ns_create_slab(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                        const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
                        double nu, const char *velocity_cfg, const char *poisson_cfg, int rank, int nranks,

@@ -964,6 +964,43 @@ extern "C" int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, dou
         err = std::max(err, std::fabs(h[(size_t)i] - owned(n_owned - ghost + i)));
         err = std::max(err, std::fabs(h[(size_t)(ghost + n_owned + i)] - owned(i)));
     }
+    // 3b. the segmented plan of the packed velocity ordering on the ring: two pieces to either neighbour (= this rank), the
+    //     pieces for the previous rank arrive as the high ghosts, the pieces for the next rank as the low ghosts
+    {
+        DeviceCsr &A = s->A;
+        const int64_t g2 = ghost / 2, g1 = ghost - g2;
+        A.n = n_owned;
+        A.ghost_lo = A.ghost_hi = ghost;
+        A.segmented = true;
+        A.seg_send_prev = {{0, g1}, {n_owned / 2, g2}};
+        A.seg_send_next = {{n_owned / 2 - g1, g1}, {n_owned - g2, g2}};
+        A.seg_recv_lo = {g1, g2};
+        A.seg_recv_hi = {g1, g2};
+        if (g2 == 0) {
+            A.seg_send_prev.pop_back();
+            A.seg_send_next.pop_back();
+            A.seg_recv_lo.pop_back();
+            A.seg_recv_hi.pop_back();
+        }
+        PIB_CHK(refill(s->stream));
+        PIB_CHK(halo_exchange(s, d + ghost, s->stream));
+        PIB_CHK(fetch(s->stream));
+        for (int64_t i = 0; i < g1; ++i) {
+            err = std::max(err, std::fabs(h[(size_t)i] - owned(n_owned / 2 - g1 + i)));                 // low ghosts: "next" pieces
+            err = std::max(err, std::fabs(h[(size_t)(ghost + n_owned + i)] - owned(i)));               // high ghosts: "prev" pieces
+        }
+        for (int64_t i = 0; i < g2; ++i) {
+            err = std::max(err, std::fabs(h[(size_t)(g1 + i)] - owned(n_owned - g2 + i)));
+            err = std::max(err, std::fabs(h[(size_t)(ghost + n_owned + g1 + i)] - owned(n_owned / 2 + i)));
+        }
+        A.segmented = false;
+        A.seg_send_prev.clear();
+        A.seg_send_next.clear();
+        A.seg_recv_lo.clear();
+        A.seg_recv_hi.clear();
+        A.n = 0;
+        A.ghost_lo = A.ghost_hi = 0;
+    }
     s->comm.ring = false;
     // 4. in-place all-reduce of the recurrence scalars and of a large buffer: one rank, the values stay
     PIB_CHK(refill(s->stream));

@@ -95,7 +95,8 @@ def test_poisson_solve_across_processes_matches_single_rank(tmp_path, P, n, per,
 
 
 @pytest.mark.parametrize("case,P,bodies", [("3d_cavity", 2, False), ("2d_convective_outlet", 3, False), ("3d_sphere", 2, True),
-                                           ("moving_cylinder", 3, True)])
+                                           ("moving_cylinder", 3, True), ("3d_periodic_box", 2, False),
+                                           ("3d_channel_periodic_z", 3, False)])
 def test_time_step_across_processes_matches_single_rank(tmp_path, case, P, bodies):
     """the device time step (and the decoupled IBPM step with its all-reduced force system) on slabs, one process per rank"""
     import test_gpu_navierstokes_slabs as T

@@ -17,7 +17,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 @pytest.mark.parametrize("n_owned,ghost", [(4096, 64), (3 * 512 * 512, 512 * 512), (10, 4)])
 def test_rccl_entry_points_in_a_one_rank_world(n_owned, ghost):
     """grouped ncclSend / ncclRecv (wall-bounded: an empty group; periodic ring: both neighbours are the rank itself, two
-    messages to one peer matched in issue order -- the P == 2 case of halo_exchange_planes), the same exchange on the
+    messages to one peer matched in issue order -- the P == 2 case of halo_exchange_planes -- and the same ring for the
+    segmented plan of the packed velocity ordering: several pieces each way), the same exchange on the
     communication stream between two events, ncclAllReduce in place (PIB_NRED scalars, a large buffer), ncclAllGather in
     place and the grouped-ncclBroadcast form: everything that arrives is what must arrive."""
     from petibm_amd import capi
