@@ -580,7 +580,6 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
     if (ns->bn_order > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bodies: BN order > 1 with immersed bodies is not supported");
-    if (ns->ring) return fail(PIB_ERR_SUP, "pib_ns_set_bodies: immersed bodies with a periodic slab axis on several ranks are not provided");
     PIB_HIP(hipSetDevice(ns->device));
     if (ns->ib != nullptr && ns->psol != nullptr) {
         // the coupled scheme's Schur hook points into the state that goes away: back to the plain Poisson operator

@@ -43,6 +43,12 @@ __device__ __forceinline__ double vel(const NsDev &D, const double *__restrict__
         else if (k >= F.n[2]) { if (D.per & 4) { k = 0; wrapped = true; } else { loc = 5; k = F.n[2] - 1; ++nghost; } }
     }
     if (loc < 0) return U[fidx(F, i, j, k)];
+    if (D.seam_axis >= 0 && (loc >> 1) != D.seam_axis) {
+        // on a rank next to the periodic seam of the slab axis the same corner (a wall ghost seen from a plane across the
+        // seam) has a ghost value here -- the cut is a wall to this engine -- but must read as on one rank
+        const int64_t q = D.seam_axis == 0 ? i : (D.seam_axis == 1 ? j : k);
+        if (q < D.seam_lo || q >= D.seam_hi) return 0.0;
+    }
     return (wrapped || nghost > 1) ? 0.0 : D.gv[face_index(F, loc, i, j, k)];
 }
 
@@ -722,6 +728,7 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     // both ends -- rank 0's lower neighbour plane is the last rank's top plane -- and the engine's kernels see a wall-bounded
     // direction there; the wrap lives in the plane exchanges (a ring) and in the two linear systems
     const bool ring = nranks > 1 && periodic[sd] != 0;
+    const int64_t n_global_sd = n[sd];
     int periodic_local[3] = {periodic[0], periodic[1], periodic[2]};
     if (nranks > 1) {
         slab_range(n[sd], nranks, rank, &pk0, &pk1);
@@ -858,6 +865,9 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     NsDev &D = ns->D;
     D.dim = dim;
     D.per = (periodic_local[0] ? 1 : 0) | (periodic_local[1] ? 2 : 0) | (periodic_local[2] ? 4 : 0);
+    D.seam_axis = ring ? sd : -1;
+    D.seam_lo = (ring && e0 < 0) ? -e0 : 0;
+    D.seam_hi = ring ? n_global_sd - e0 : 0;
     int64_t off = 0;
     for (int f = 0; f < 3; ++f) {
         NsField &F = D.f[f];

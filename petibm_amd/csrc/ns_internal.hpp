@@ -41,6 +41,10 @@ struct NsDev {
     int64_t UN, pN;
     int64_t nghost;
     double *a1, *a1n, *gv;  // [nghost] current / next ghost equations' a1, ghost values
+    // several ranks on a periodic slab axis: planes [0, seam_lo) and [seam_hi, ...) of the extended slab along seam_axis are
+    // images from across the seam (-1: none)
+    int seam_axis;
+    int64_t seam_lo, seam_hi;
 };
 
 // index of the ghost point of boundary `loc` facing (i,j,k) within its face

@@ -120,6 +120,16 @@ def _ib_case(kind):
     if kind == "2d_cylinder":
         # the body sits across the cut of two y-slabs and inside the middle one of three
         return flow_config(cases.body_block(cells=(8, 16, 8), ratio=1.25, span=3.0, core=0.8)), [cases.circle(40, 0.5)], None
+    if kind == "2d_cylinder_periodic_y":
+        # the cylinder array of examples/decoupledibpm/multicylinders2dRe100_GPU in small: free stream along x, periodic y --
+        # in 2-D the slab axis.  A window point beyond the periodic seam is a domain length away from the body and carries
+        # nothing (createdelta.cpp:171-208), on one rank and on slabs alike.
+        cfg = flow_config(cases.body_block(cells=(8, 16, 8), ratio=1.25, span=3.0, core=0.8))
+        for bc in cfg["flow"]["boundaryConditions"]:
+            if bc["location"] in ("yMinus", "yPlus"):
+                for c in "uv":
+                    bc[c] = ["PERIODIC", 0.0]
+        return cfg, [cases.circle(40, 0.5) + np.array([0.0, 2.3])], None   # its kernel windows reach beyond the seam of the last slab
     if kind == "3d_sphere":
         return flow_config(cases.body_block(cells=(4, 10, 4), ratio=1.4, span=2.0, core=0.7, dim=3), nu=0.05), [sphere_points(50, 0.4)], None
     if kind == "moving_sphere_3d":
@@ -144,7 +154,8 @@ def _ib_case(kind):
 
 
 @pytest.mark.parametrize("kind,P", [("2d_cylinder", 2), ("2d_cylinder", 3), ("3d_sphere", 2), ("moving_cylinder", 2),
-                                    ("moving_cylinder", 3), ("moving_sphere_3d", 2), ("moving_sphere_3d", 4)])
+                                    ("moving_cylinder", 3), ("moving_sphere_3d", 2), ("moving_sphere_3d", 4),
+                                    ("2d_cylinder_periodic_y", 2), ("2d_cylinder_periodic_y", 3)])
 def test_immersed_bodies_on_slabs_reproduce_the_single_rank(kind, P):
     from petibm_amd.navierstokes import DecoupledIBPMSolver
     cfg, bodies, pose = _ib_case(kind)
