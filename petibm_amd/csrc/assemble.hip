@@ -59,12 +59,26 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
     const int64_t base = RP(0);
     const int64_t nnz = RP(n_local) - base;
     if (nnz < 0) return fail(PIB_ERR_ARG_OUTOFRANGE, "set_csr: negative nnz");
-    int64_t cmin = std::numeric_limits<int64_t>::max(), cmax = -1;
+    // On several ranks a column may belong to a row across a periodic seam of the slab axis (rank 0's first plane couples
+    // to the last rank's last plane and back): such a column is taken a whole vector length away, next to this rank's rows
+    // -- the previous rank of rank 0 is rank P - 1 -- and the halo exchange becomes a ring (comm_setup_halo)
+    const bool may_wrap = s->comm.nranks > 1;
+    auto near = [&](int64_t c) -> int64_t {
+        if (!may_wrap) return c;
+        const int64_t lo = row0, hi = row0 + n_local - 1;
+        auto dist = [&](int64_t x) { return x < lo ? lo - x : (x > hi ? x - hi : 0); };
+        int64_t best = c;
+        if (dist(c - n_global) < dist(best)) best = c - n_global;
+        if (dist(c + n_global) < dist(best)) best = c + n_global;
+        return best;
+    };
+    int64_t cmin = std::numeric_limits<int64_t>::max(), cmax = std::numeric_limits<int64_t>::min();
     for (int64_t p = 0; p < nnz; ++p) {
         const int64_t c = CL(base + p);
         if (c < 0 || c >= n_global) return fail(PIB_ERR_ARG_OUTOFRANGE, "set_csr: column %lld out of range", (long long)c);
-        cmin = std::min(cmin, c);
-        cmax = std::max(cmax, c);
+        const int64_t cn = near(c);
+        cmin = std::min(cmin, cn);
+        cmax = std::max(cmax, cn);
     }
     DeviceCsr &A = s->A;
     A.release();
@@ -81,7 +95,7 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
     A.rp64 = nnz >= (int64_t)std::numeric_limits<int32_t>::max();
     const int64_t shift = row0 - A.ghost_lo;
     std::vector<int32_t> c32((size_t)std::max<int64_t>(nnz, 1));
-    for (int64_t p = 0; p < nnz; ++p) c32[(size_t)p] = (int32_t)(CL(base + p) - shift);
+    for (int64_t p = 0; p < nnz; ++p) c32[(size_t)p] = (int32_t)(near(CL(base + p)) - shift);
     // +4 entries of padding: the SpMV reads val/col in aligned pairs
     PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
     PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));

@@ -461,6 +461,9 @@ int comm_setup_halo(pib_solver *s)
     std::vector<int64_t> all;
     PIB_CHK(allgather_host4(s, mine, all));
     int err = 0;
+    // the setMatrix route: rank 0 reaching below its first row (or the last rank beyond its last) means the slab axis is
+    // periodic -- upload_csr has placed those columns next to the rank's rows
+    if (all[4 * 0 + 1] > 0 || all[4 * (size_t)(P - 1) + 2] > 0) s->comm.ring = true;
     if (s->comm.ring) {  // periodic slab axis: every rank has both neighbours
         const size_t pv = (size_t)((r + P - 1) % P), nx = (size_t)((r + 1) % P);
         if (A.ghost_lo > all[4 * pv] || A.ghost_hi > all[4 * nx]) return fail(PIB_ERR_SUP, "halo of rank %d reaches beyond its neighbour", r);

@@ -10,10 +10,11 @@
 // i.e. a product of three 1-D factors, and likewise toward +y and +z.  Lines of entries through one base cell give the
 // factors up to one scale per direction; the three conditions g_d[0] * 0.5 (w_d[0] + w_d[1]) = dt (the same dt in every
 // direction) fix the scales up to ONE common length unit, which the operator -- on every multigrid level, because the
-// coarse operators are rediscretised from the widths -- does not depend on.
+// coarse operators are rediscretised from the widths -- does not depend on.  A periodic direction shows as the wrapped
+// neighbour of its first cell (one more offset in the first rows) and contributes one more face, the one across the seam.
 //
 // The recovered arrays go through grid_register, which verifies the matrix-free twin against the CSR on the device
-// (1e-10 relative): a matrix that is not such an operator (velocity system, BN order > 1, periodic wrap, arbitrary CSR)
+// (1e-10 relative): a matrix that is not such an operator (velocity system, BN order > 1, arbitrary CSR)
 // simply stays without grid structure.  Several ranks: z-slabs (y-slabs in 2-D); the in-plane lines come from the rank
 // that owns slab plane 1, the lines along the slab axis from every rank's planes, all-gathered as RAW matrix entries so
 // that every rank does the same arithmetic on the same numbers (the level hierarchy must come out identical everywhere).
@@ -57,10 +58,12 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
     const HostCsr A{n_local, row0, n_global, rp64, cl64, rp32, cl32, val};
     const int P = s->comm.nranks, rank = s->comm.rank;
     // every rank walks through the same collectives whatever it finds locally: `ok` only gates the local work
-    bool ok = !(s->periodic[0] || s->periodic[1] || s->periodic[2]) && n_local > 0;
-    // ---- the distinct |column - row| of the first rows: {1, nx[, nx ny]}
-    int64_t off[3] = {0, 0, 0};
+    bool ok = n_local > 0;
+    // ---- the distinct |column - row| of the first rows: {1, nx[, nx ny]}, and for a periodic direction the wrapped
+    // neighbour of its first cell: nx - 1 (next to nx: the only two consecutive values), nx (ny - 1), nx ny (nz - 1)
     int dim = 0;
+    int64_t n[3] = {1, 1, 1};
+    bool per[3] = {false, false, false};
     if (ok) {
         std::set<int64_t> offs;
         for (int64_t l = 0; l < std::min<int64_t>(n_local, 8); ++l)
@@ -68,24 +71,53 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
                 const int64_t d = std::llabs(A.CL(p) - (row0 + l));
                 if (d > 0) offs.insert(d);
             }
-        if (offs.size() == 2 || offs.size() == 3) {
-            dim = (int)offs.size();
-            int q = 0;
-            for (int64_t d : offs) off[q++] = d;
-        } else
-            ok = false;
-    }
-    int64_t n[3] = {1, 1, 1};
-    if (ok) {
-        ok = off[0] == 1 && off[1] >= 3;
-        if (ok && dim == 3) ok = off[2] % off[1] == 0 && n_global % off[2] == 0;
-        if (ok && dim == 2) ok = n_global % off[1] == 0;
-    }
-    if (ok) {
-        n[0] = off[1];
-        n[1] = (dim == 3) ? off[2] / off[1] : n_global / off[1];
-        n[2] = (dim == 3) ? n_global / off[2] : 1;
+        const std::vector<int64_t> S(offs.begin(), offs.end());
+        ok = S.size() >= 2 && S.size() <= 6 && S[0] == 1;
+        size_t q = 2;
+        if (ok) {
+            if (S.size() > 2 && S[2] == S[1] + 1) {
+                per[0] = true;
+                n[0] = S[2];
+                q = 3;
+            } else
+                n[0] = S[1];
+            ok = n[0] >= 3 && n_global % n[0] == 0;
+        }
+        if (ok) {
+            const int64_t rows = n_global / n[0];  // ny, or ny nz
+            std::vector<int64_t> m;                // the larger offsets in grid lines: {ny - 1 (y periodic), ny (3-D), ny (nz - 1) (z periodic)}
+            for (size_t t = q; t < S.size() && ok; ++t) {
+                ok = S[t] % n[0] == 0;
+                m.push_back(S[t] / n[0]);
+            }
+            auto has = [&](int64_t v) { return std::find(m.begin(), m.end(), v) != m.end(); };
+            if (!ok) {
+            } else if (m.empty() || (m.size() == 1 && m[0] == rows - 1)) {
+                dim = 2;
+                n[1] = rows;
+                per[1] = !m.empty();
+            } else {
+                dim = 3;
+                ok = false;
+                for (int64_t y : m) {
+                    if (y < 3 || rows % y != 0 || rows / y < 3) continue;
+                    const int64_t z = rows / y;
+                    bool fits = true;
+                    for (int64_t v : m) fits = fits && (v == y || v == y - 1 || v == y * (z - 1));
+                    if (!fits) continue;
+                    n[1] = y;
+                    n[2] = z;
+                    per[1] = has(y - 1);
+                    per[2] = has(y * (z - 1));
+                    ok = true;
+                    break;
+                }
+            }
+        }
         for (int d = 0; d < dim; ++d) ok = ok && n[d] >= 3;
+        // directions the caller declared periodic (pib_set_periodic) must be the ones found
+        for (int d = 0; d < 3 && ok; ++d)
+            if (s->periodic[d] && !per[d] && !(d == dim - 1 && P > 1)) ok = false;
     }
     const int sd = dim - 1;                               // slab axis
     const int64_t st[3] = {1, n[0], n[0] * n[1]};         // strides
@@ -101,15 +133,21 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
     //   slab-axis lines (own planes):           Cs[0..mp) Zs[0..mp)                       mp = max planes per rank
     // first the locally detected sizes (every rank must have found the same grid), then the lines themselves
     {
-        std::vector<double> head = {ok ? 1.0 : 0.0, (double)dim, (double)n[0], (double)n[1], (double)n[2], 0.0};
+        // [5]: the in-plane periodic directions (every rank sees them); [6]: the wrap of the slab axis, which only the ranks
+        // at the seam see -- it holds if any rank found it
+        const double inplane = (per[0] ? 1.0 : 0.0) + ((dim == 3 && per[1]) ? 2.0 : 0.0);
+        std::vector<double> head = {ok ? 1.0 : 0.0, (double)dim, (double)n[0], (double)n[1], (double)n[2], inplane,
+                                    (ok && per[sd]) ? 1.0 : 0.0, 0.0};
         std::vector<double> heads;
         PIB_CHK(comm_allgather_host(s, head, heads));
-        bool all_ok = true;
+        bool all_ok = true, seam = false;
         for (int r = 0; r < P; ++r) {
-            const double *h = &heads[6 * (size_t)r];
-            all_ok = all_ok && h[0] == 1.0 && h[1] == heads[1] && h[2] == heads[2] && h[3] == heads[3] && h[4] == heads[4];
+            const double *h = &heads[8 * (size_t)r];
+            all_ok = all_ok && h[0] == 1.0 && h[1] == heads[1] && h[2] == heads[2] && h[3] == heads[3] && h[4] == heads[4] && h[5] == heads[5];
+            seam = seam || h[6] == 1.0;
         }
         if (!all_ok) return 0;  // every rank sees the same heads: all leave together
+        per[sd] = seam;
     }
     const int64_t mx_all = std::max(n[0], dim == 3 ? n[1] : (int64_t)0);  // longest in-plane line
     const int64_t mp_all = (n[sd] + P - 1) / P;                           // most planes on one rank
@@ -129,17 +167,20 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
             for (int64_t i = 0; i < n[0]; ++i) {
                 const int64_t c = b + 1 * st[1] + i;
                 if (i + 1 < n[0]) take(c, c + 1, &X[i]);   // gx_i wy_1 wz_1
+                else if (per[0]) take(c, c - (n[0] - 1), &X[i]);  // the face across the periodic seam
                 take(c, c + st[1], &Ax[i]);                 // wx_i gy_1 wz_1
             }
             for (int64_t j = 0; j < n[1]; ++j) {
                 const int64_t c = b + j * st[1] + 1;
                 if (j + 1 < n[1]) take(c, c + st[1], &Y[j]);  // wx_1 gy_j wz_1
+                else if (per[1]) take(c, c - (n[1] - 1) * st[1], &Y[j]);
                 take(c, c + 1, &B[j]);                        // gx_1 wy_j wz_1
             }
         } else {
             for (int64_t i = 0; i < n[0]; ++i) {
                 const int64_t c = 1 * st[1] + i;
                 if (i + 1 < n[0]) take(c, c + 1, &X[i]);   // gx_i wy_1
+                else if (per[0]) take(c, c - (n[0] - 1), &X[i]);
                 take(c, c + st[1], &Ax[i]);                 // wx_i gy_1
             }
         }
@@ -148,6 +189,7 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
         const int64_t c = k * st[sd] + (dim == 3 ? st[1] + 1 : 1);
         take(c, c + 1, &Cs[k - k0]);                          // gx_1 wy_1 wz_k     (2-D: gx_1 wy_k)
         if (k + 1 < n[sd]) take(c, c + st[sd], &Zs[k - k0]);  // wx_1 wy_1 gz_k     (2-D: wx_1 gy_k)
+        else if (per[sd]) take(c, c - (n[sd] - 1) * st[sd], &Zs[k - k0]);
     }
     if (rank == 0) {  // pinned pressure: row 0 is the identity (MatZeroRowsColumns, navierstokes.cpp:416-418)
         bool pinned = true;
@@ -181,14 +223,15 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
     // ---- scales: wx_1 = 1; the same dt from face 0 of every direction
     std::vector<double> w[3], g[3];
     double dt = 0.0;
+    const int64_t ng[3] = {per[0] ? n[0] : n[0] - 1, per[1] ? n[1] : n[1] - 1, per[2] ? n[2] : n[2] - 1};  // faces: one more across a seam
     auto positive = [](const std::vector<double> &v, int64_t cnt) {
         for (int64_t q = 0; q < cnt; ++q)
             if (!(v[(size_t)q] > 0.0) || !std::isfinite(v[(size_t)q])) return false;
         return true;
     };
     if (dim == 3) {
-        if (!positive(gX, n[0] - 1) || !positive(gA, n[0]) || !positive(gY, n[1] - 1) || !positive(gB, n[1]) ||
-            !positive(gCs, n[2]) || !positive(gZs, n[2] - 1))
+        if (!positive(gX, ng[0]) || !positive(gA, n[0]) || !positive(gY, ng[1]) || !positive(gB, n[1]) ||
+            !positive(gCs, n[2]) || !positive(gZs, ng[2]))
             return 0;
         const double xh = gX[0] * (0.5 * (gA[0] / gA[1] + 1.0)), yh = gY[0] * (0.5 * (gB[0] / gB[1] + 1.0)),
                      zh = gZs[0] * (0.5 * (gCs[0] / gCs[1] + 1.0));
@@ -197,28 +240,28 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
         w[0].resize((size_t)n[0]);
         w[1].resize((size_t)n[1]);
         w[2].resize((size_t)n[2]);
-        g[0].resize((size_t)n[0] - 1);
-        g[1].resize((size_t)n[1] - 1);
-        g[2].resize((size_t)n[2] - 1);
+        g[0].resize((size_t)ng[0]);
+        g[1].resize((size_t)ng[1]);
+        g[2].resize((size_t)ng[2]);
         for (int64_t i = 0; i < n[0]; ++i) w[0][(size_t)i] = gA[(size_t)i] / gA[1];
         for (int64_t j = 0; j < n[1]; ++j) w[1][(size_t)j] = beta * (gB[(size_t)j] / gB[1]);
         for (int64_t k = 0; k < n[2]; ++k) w[2][(size_t)k] = gamma * (gCs[(size_t)k] / gCs[1]);
-        for (int64_t i = 0; i + 1 < n[0]; ++i) g[0][(size_t)i] = gX[(size_t)i] / (beta * gamma);
-        for (int64_t j = 0; j + 1 < n[1]; ++j) g[1][(size_t)j] = gY[(size_t)j] / gamma;
-        for (int64_t k = 0; k + 1 < n[2]; ++k) g[2][(size_t)k] = gZs[(size_t)k] / beta;
+        for (int64_t i = 0; i < ng[0]; ++i) g[0][(size_t)i] = gX[(size_t)i] / (beta * gamma);
+        for (int64_t j = 0; j < ng[1]; ++j) g[1][(size_t)j] = gY[(size_t)j] / gamma;
+        for (int64_t k = 0; k < ng[2]; ++k) g[2][(size_t)k] = gZs[(size_t)k] / beta;
     } else {
-        if (!positive(gX, n[0] - 1) || !positive(gA, n[0]) || !positive(gCs, n[1]) || !positive(gZs, n[1] - 1)) return 0;
+        if (!positive(gX, ng[0]) || !positive(gA, n[0]) || !positive(gCs, n[1]) || !positive(gZs, ng[1])) return 0;
         const double xh = gX[0] * (0.5 * (gA[0] / gA[1] + 1.0)), zh = gZs[0] * (0.5 * (gCs[0] / gCs[1] + 1.0));
         const double beta = std::sqrt(xh / zh);
         dt = xh / beta;
         w[0].resize((size_t)n[0]);
         w[1].resize((size_t)n[1]);
-        g[0].resize((size_t)n[0] - 1);
-        g[1].resize((size_t)n[1] - 1);
+        g[0].resize((size_t)ng[0]);
+        g[1].resize((size_t)ng[1]);
         for (int64_t i = 0; i < n[0]; ++i) w[0][(size_t)i] = gA[(size_t)i] / gA[1];
         for (int64_t k = 0; k < n[1]; ++k) w[1][(size_t)k] = beta * (gCs[(size_t)k] / gCs[1]);
-        for (int64_t i = 0; i + 1 < n[0]; ++i) g[0][(size_t)i] = gX[(size_t)i] / beta;
-        for (int64_t k = 0; k + 1 < n[1]; ++k) g[1][(size_t)k] = gZs[(size_t)k];
+        for (int64_t i = 0; i < ng[0]; ++i) g[0][(size_t)i] = gX[(size_t)i] / beta;
+        for (int64_t k = 0; k < ng[1]; ++k) g[1][(size_t)k] = gZs[(size_t)k];
     }
     if (!(dt > 0.0) || !std::isfinite(dt)) return 0;
     const double *cw[3] = {w[0].data(), w[1].data(), dim == 3 ? w[2].data() : nullptr};
@@ -227,10 +270,13 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
     if (dim == 2) cw[2] = &one;
     // registration verifies the recovered operator against the CSR on the device; a mismatch leaves the solver without
     // grid structure (the outcome is the same on every rank: the check is a global sum)
+    int was[3] = {s->periodic[0], s->periodic[1], s->periodic[2]};
+    for (int d = 0; d < 3; ++d) s->periodic[d] = per[d] ? 1 : 0;  // what pib_set_periodic would have said
     const int e = grid_register(s, dim, n, cw, cg, nullspace, dt);
     if (e != 0) {
         s->gmg_error.clear();
         s->has_grid = false;
+        for (int d = 0; d < 3; ++d) s->periodic[d] = was[d];
     } else {
         s->structure_detected = true;
     }

@@ -410,6 +410,73 @@ def test_velocity_system_on_a_periodic_slab_axis(P, n, per):
     s1.destroy()
 
 
+@pytest.mark.parametrize("P,system_kind,pc", [(2, "poisson", "BLOCK_JACOBI"), (3, "poisson", "BLOCK_JACOBI"), (2, "poisson", "AMG"),
+                                              (2, "poisson", "AMG_DETECT"), (3, "poisson", "AMG_DETECT"),
+                                              (2, "velocity", "BLOCK_JACOBI"), (3, "velocity", "BLOCK_JACOBI")])
+def test_setmatrix_route_with_a_periodic_slab_axis(P, system_kind, pc):
+    """The PetIBM route (setMatrix: local rows, GLOBAL columns) on several ranks when the slab axis is periodic -- what an
+    unchanged PetIBM hands over for taylorgreenvortex3dRe1600_GPU on 4 GPUs: rank 0's first plane carries columns of the
+    last rank's last plane and back.  upload_csr takes such a column a vector length away, next to the rank's rows, and the
+    halo exchange becomes a ring; the Poisson system (natural ordering) and the velocity system in the distributed packed
+    ordering [u_r | v_r | w_r] per rank; with a grid hint + setPeriodic the geometric multigrid runs on it."""
+    import scipy.sparse as sp
+    from petibm_amd import capi, partition
+    from petibm_amd.linsolver import LinSolverHIP
+    from test_gpu_multirank_loopback import _cfg, _run_ranks, _velocity_slab_indices
+    n, per, dt = (8, 6, 12), (True, False, True), 0.01
+    m = omesh.create_mesh(omesh.periodic_config(n, per))
+    if system_kind == "poisson":
+        D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+        _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+        plans = partition.all_plans(n, P)
+        own = [np.arange(pl.row0, pl.row0 + pl.n_local) for pl in plans]
+        text = _cfg("AMG" if pc == "AMG_DETECT" else pc, tol=1e-10)
+    else:
+        A = oops.create_velocity_operator(oops.create_laplacian(m), 0.004, 0.5 * 0.01)
+        own = [_velocity_slab_indices(m, P, r) for r in range(P)]
+        text = amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500)
+    perm = np.concatenate(own)                      # distributed global index -> single-rank index
+    M = sp.csr_matrix((A.val, A.col, A.rowptr), shape=(A.n_rows, A.n_cols))[perm][:, perm].tocsr()
+    M.sort_indices()
+    xs = np.random.default_rng(8).uniform(-1, 1, A.n_rows)
+    if system_kind == "poisson":
+        xs -= xs.mean()
+    b = M @ xs
+    starts = np.concatenate([[0], np.cumsum([o.size for o in own])])
+    w = [m.dL[3][d].true for d in range(3)]
+
+    def rank_fn(r, uid):
+        s = LinSolverHIP(system_kind, config_text=text, rank=r, nranks=P, uid=uid, device=0)
+        r0, r1 = int(starts[r]), int(starts[r + 1])
+        p0, p1 = M.indptr[r0], M.indptr[r1]
+        local = oops.CSR(r1 - r0, A.n_cols, (M.indptr[r0:r1 + 1] - p0).astype(np.int64), M.indices[p0:p1].astype(np.int64), M.data[p0:p1])
+        if pc == "AMG":
+            s.setPeriodic(per)
+        s.setMatrix(local, row0=r0, n_global=A.n_rows)
+        if pc == "AMG":
+            g = [dt * (1.0 / (0.5 * (wd[1:] + wd[:-1]))) for wd in w]
+            g = [np.concatenate([gd, [dt / (0.5 * (wd[0] + wd[-1]))]]) if per[d] else gd for d, (gd, wd) in enumerate(zip(g, w))]
+            s.setGridHint(n, w, g, capi.NULLSPACE_CONSTANT)
+        y = np.empty(r1 - r0)
+        s.matMult(np.ascontiguousarray(xs[r0:r1]), y)
+        x = np.zeros(r1 - r0)
+        s.solve(x, np.ascontiguousarray(b[r0:r1]))
+        its = s.getIters()
+        gs = s.gridStructure()
+        s.destroy()
+        return y, x, its, gs
+
+    res = _run_ranks(P, rank_fn)
+    y = np.concatenate([q[0] for q in res])
+    x = np.concatenate([q[1] for q in res])
+    assert np.abs(y - b).max() <= 8 * 4e-16 * np.abs(A.val).max() * np.abs(xs).max() * 8
+    assert len({q[2] for q in res}) == 1
+    assert np.linalg.norm(b - M @ x) <= 2e-10 * np.linalg.norm(b)
+    if pc == "AMG_DETECT":  # nothing but setMatrix: the mesh, its periodic directions included, recovered from the entries
+        assert all(q[3] is not None and q[3]["detected"] and q[3]["n"] == n for q in res)
+        assert res[0][2] <= 30
+
+
 @pytest.mark.parametrize("case", ["2d_stretched", "3d_stretched", "3d_outflow", "2d_xy", "2d_y", "3d_xz", "3d_all", "tiny"])
 def test_matrix_free_velocity_operator_is_the_csr_product(lin, case):
     """velstencil.hip: the Krylov products of the velocity solve from the mesh tables.  Same entries, same summation

@@ -67,6 +67,45 @@ def test_structure_recovered_from_the_matrix_solves_like_the_registered_one(case
     t.destroy()
 
 
+@pytest.mark.parametrize("n,per", [((12, 10, 9), (True, True, True)), ((10, 8, 12), (False, False, True)), ((9, 12, 8), (True, False, False)),
+                                   ((8, 9, 10), (False, True, True)), ((14, 12), (True, True)), ((12, 10), (False, True)),
+                                   ((16, 9), (True, False))])
+def test_structure_of_periodic_meshes_recovered_from_the_matrix(n, per):
+    """The Taylor-Green cases of the reference are periodic boxes: a periodic direction shows in the matrix as the wrapped
+    neighbour of its first cell (one more |column - row| in the first rows) and contributes one more face factor, the one
+    across the seam.  Nothing but setMatrix: dimensions, sizes AND the periodic directions come out of the entries, and
+    the solve is the one of the registered structure (setPeriodic + grid hint)."""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    dt, dim = 0.01, len(n)
+    ratios = [1.0 if p else 1.0 + 0.01 * (d + 1) for d, p in enumerate(per)]
+    m = omesh.create_mesh(omesh.periodic_config(n, per, ratios=ratios))
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    xs, b = rhs_for(A)
+    text = amgx_cfg(pc="AMG", tol=1e-10, extra=AMG + "pib_initial_guess_nonzero=0\n")
+    s = LinSolverHIP("poisson", config_text=text)
+    s.setMatrix(A)
+    st = s.gridStructure()
+    assert st is not None and st["detected"] and st["dim"] == dim and tuple(st["n"]) == tuple(n)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    w = [m.dL[3][d].true for d in range(dim)]
+    g = [dt * (1.0 / (0.5 * (wd[1:] + wd[:-1]))) for wd in w]
+    g = [np.concatenate([gd, [dt / (0.5 * (wd[0] + wd[-1]))]]) if per[d] else gd for d, (gd, wd) in enumerate(zip(g, w))]
+    t = LinSolverHIP("poisson", config_text=text + "pib_detect_structure=0\n")
+    t.setPeriodic(per)
+    t.setMatrix(A)
+    t.setGridHint(list(n), w, g, capi.NULLSPACE_CONSTANT)
+    y = np.zeros(A.n_rows)
+    t.solve(y, b)
+    assert t.getIters() == s.getIters()
+    assert np.linalg.norm((x - x.mean()) - (y - y.mean())) <= 1e-8 * np.linalg.norm(y - y.mean())
+    s.destroy()
+    t.destroy()
+
+
 def test_matrices_that_are_not_the_poisson_operator_stay_without_structure():
     from petibm_amd import capi
     from petibm_amd.capi import PibError
