@@ -162,7 +162,8 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
 /* The grid structure the solver holds (from pib_set_grid_hint, an on-device assembly, or recovered from the matrix):
  * *has = 0 none; dim, n[3] (problem order), nullspace as registered; *detected != 0 when pib_set_csr recovered it from
  * the CSR itself.  With a multigrid (AMG) preconditioner pib_set_csr[_i32] inspects the matrix: the 5/7-point DBNG of a
- * non-periodic tensor-product mesh in natural ordering on z-slabs (y-slabs in 2-D) factorises into 1-D arrays
+ * tensor-product mesh (periodic directions included: they show as wrapped neighbours and are set as pib_set_periodic would)
+ * in natural ordering on z-slabs (y-slabs in 2-D) factorises into 1-D arrays
  * (csrc/structure.cpp), the recovered operator is verified against the CSR on the device, and an application that only
  * ever calls setMatrix -- AmgXSolver::setA, src/linsolver/linsolveramgx.cpp:84 -- gets the geometric multigrid without
  * registering anything.  Any other matrix is left without structure (`pib_detect_structure=0` switches the search off).
@@ -174,8 +175,9 @@ int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int 
  * pib_assemble_poisson / pib_assemble_velocity / pib_set_grid_hint: the assembled operators then carry the wrapped
  * columns (component d has n[d] points along a periodic d instead of n[d]-1, cartesianmesh.cpp:259-266) and the grid
  * hint takes one more face factor per periodic direction, g[d][n[d]-1] = dt / (0.5*(w[0] + w[n[d]-1])).  A periodic
- * direction needs >= 3 cells.  A periodic SLAB axis on several ranks (rank 0 <-> rank P-1 become neighbours: ring halo)
- * is provided for pib_assemble_poisson; the pib_set_csr route and pib_assemble_velocity return PIB_ERR_SUP there. */
+ * direction needs >= 3 cells.  A periodic SLAB axis on several ranks makes rank 0 and rank P-1 neighbours (ring halo):
+ * pib_assemble_poisson, pib_assemble_velocity, the pib_set_csr route (columns across the seam are recognised) and the
+ * time step on slabs all provide it. */
 int pib_set_periodic(pib_solver *s, const int periodic[3]);
 
 /* Assemble the Poisson operator DBNG = D * (dt*I) * G directly in HBM from the
