@@ -212,6 +212,9 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
     const double *w[3] = {wx, wy, (dim == 3) ? wz : &one};
     const double *g[3] = {gx, gy, (dim == 3) ? gz : nullptr};
     s->structure_detected = false;
+    // the hint's arrays are sized by what the CALLER declared periodic, whatever a structure recovered from the matrix
+    // had found before
+    for (int d = 0; d < 3; ++d) s->periodic[d] = s->periodic_user[d];
     return grid_register(s, dim, n, w, g, nullspace, -1.0);
 }
 
@@ -237,7 +240,7 @@ int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int 
 int pib_set_periodic(pib_solver *s, const int periodic[3])
 {
     if (s == nullptr || periodic == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_periodic: null argument");
-    for (int d = 0; d < 3; ++d) s->periodic[d] = periodic[d] ? 1 : 0;
+    for (int d = 0; d < 3; ++d) s->periodic[d] = s->periodic_user[d] = periodic[d] ? 1 : 0;
     return 0;
 }
 

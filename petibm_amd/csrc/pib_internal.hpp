@@ -232,7 +232,8 @@ struct pib_solver {
     std::vector<double *> gmg_spare = std::vector<double *>(64, nullptr);
     bool gmg_guarded = true;
     std::string gmg_error;  // why the hierarchy could not be built (reported when a multigrid solve is asked for)
-    int periodic[3] = {0, 0, 0};             // pib_set_periodic: problem directions x, y[, z]
+    int periodic[3] = {0, 0, 0};             // pib_set_periodic: problem directions x, y[, z] (in effect: the structure recovery may set them for the structure it registers)
+    int periodic_user[3] = {0, 0, 0};        // ... as the caller declared them: what an explicit pib_set_grid_hint describes
     pib::VelStencil vel;                     // matrix-free twin of the velocity operator (velstencil.hip)
     // w <- w + (low-rank term) after every Krylov product: the coupled immersed-boundary operator (ibm.hip) turns the
     // Poisson solve into the solve of its Schur complement

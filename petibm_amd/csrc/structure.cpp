@@ -117,7 +117,7 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
         for (int d = 0; d < dim; ++d) ok = ok && n[d] >= 3;
         // directions the caller declared periodic (pib_set_periodic) must be the ones found
         for (int d = 0; d < 3 && ok; ++d)
-            if (s->periodic[d] && !per[d] && !(d == dim - 1 && P > 1)) ok = false;
+            if (s->periodic_user[d] && !per[d] && !(d == dim - 1 && P > 1)) ok = false;
     }
     const int sd = dim - 1;                               // slab axis
     const int64_t st[3] = {1, n[0], n[0] * n[1]};         // strides
@@ -271,7 +271,7 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
     // registration verifies the recovered operator against the CSR on the device; a mismatch leaves the solver without
     // grid structure (the outcome is the same on every rank: the check is a global sum)
     int was[3] = {s->periodic[0], s->periodic[1], s->periodic[2]};
-    for (int d = 0; d < 3; ++d) s->periodic[d] = per[d] ? 1 : 0;  // what pib_set_periodic would have said
+    for (int d = 0; d < 3; ++d) s->periodic[d] = per[d] ? 1 : 0;  // what pib_set_periodic would have said (periodic_user stays)
     const int e = grid_register(s, dim, n, cw, cg, nullspace, dt);
     if (e != 0) {
         s->gmg_error.clear();
