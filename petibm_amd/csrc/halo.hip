@@ -155,11 +155,23 @@ struct LoopbackGroup {
     hipEvent_t chain = nullptr;
     hipStream_t chain_stream = nullptr;
     bool chained = false;
+    // ranks that still have to finish fetching what this rank laid out for the previous collective: waited for at the
+    // START of the next one (the window / the staging rows are rewritten only then; the host thread meanwhile goes on
+    // enqueuing the kernels between the two collectives)
+    std::vector<int> owed_by;
+    uint64_t owed_seq = 0;
     int begin(hipStream_t st, uint64_t *out)
     {
+        for (int q : owed_by) PIB_CHK(await(shm->done[q], owed_seq, "previous collective fetched", q));
+        owed_by.clear();
         if (chained && chain_stream != st) PIB_HIP(hipStreamWaitEvent(st, chain, 0));
         *out = ++seq;
         return 0;
+    }
+    void owe(uint64_t k, int q)
+    {
+        owed_seq = k;
+        owed_by.push_back(q);
     }
     int finish(hipStream_t st)
     {
@@ -237,6 +249,10 @@ __global__ void k_lb_sum(double *dst, const double *staging, int nranks, int cou
 static void peer_destroy(LoopbackGroup *g)
 {
     if (g == nullptr) return;
+    // the others may still be fetching what this rank laid out last: the window must outlive that
+    if (g->shm != nullptr && !g->shm->failed.load())
+        for (int q : g->owed_by) (void)g->await(g->shm->done[q], g->owed_seq, "last collective fetched", q);
+    g->owed_by.clear();
     for (int q = 0; q < (int)g->win.size(); ++q)
         if (q != g->me && g->win[(size_t)q]) (void)hipIpcCloseMemHandle(g->win[(size_t)q]);
     if (g->win_local) (void)hipFree(g->win_local);
@@ -493,7 +509,8 @@ int comm_setup_halo(pib_solver *s)
 // loopback: publish -> barrier -> pull from the neighbours -> barrier -> order later writes after their reads
 // peer: what the neighbours need goes into this rank's window (first half: for the previous rank, second half: for the
 // next one), `ready` is raised behind those copies, the ghosts are fetched from the neighbours' windows once theirs is up,
-// `done` is raised behind the fetches -- and the call returns when the neighbours have fetched (the window is free again)
+// `done` is raised behind the fetches; the next collective of this rank starts by waiting for the neighbours' `done`
+// (the window is free again then)
 static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, bool has_pv, bool has_nx,
                                 const std::vector<std::pair<const double *, int64_t>> &to_prev,
                                 const std::vector<std::pair<const double *, int64_t>> &to_next, double *ghost_lo, int64_t lo,
@@ -533,8 +550,8 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
     }
     PIB_CHK(g->raise(st, g->shm->done[r], seq));
     PIB_CHK(g->finish(st));
-    if (has_pv) PIB_CHK(g->await(g->shm->done[pv], seq, "window fetched", pv));
-    if (has_nx && nx != pv) PIB_CHK(g->await(g->shm->done[nx], seq, "window fetched", nx));
+    if (has_pv) g->owe(seq, pv);
+    if (has_nx && nx != pv) g->owe(seq, nx);
     return 0;
 }
 
@@ -725,7 +742,7 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
         PIB_CHK(g->raise(st, g->shm->done[r], seq));
         PIB_CHK(g->finish(st));
         for (int q = 0; q < P; ++q)
-            if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "all-reduce read", q));  // the rows are free again
+            if (q != r) g->owe(seq, q);  // the rows are free again once everybody has summed them
         return 0;
     }
     if (s->comm.loop) {
@@ -778,7 +795,7 @@ int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st
             PIB_CHK(g->raise(st, g->shm->done[r], seq));
             PIB_CHK(g->finish(st));
             for (int q = 0; q < P; ++q)
-                if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "window fetched", q));
+                if (q != r) g->owe(seq, q);
         }
         return 0;
     }
@@ -836,7 +853,7 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
             PIB_CHK(g->raise(st, g->shm->done[r], seq));
             PIB_CHK(g->finish(st));
             for (int q = 0; q < P; ++q)
-                if (q != r) PIB_CHK(g->await(g->shm->done[q], seq, "window fetched", q));
+                if (q != r) g->owe(seq, q);
         }
         return 0;
     }
