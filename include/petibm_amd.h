@@ -170,6 +170,15 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
  * Any output pointer may be NULL. */
 int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int *nullspace, int *detected);
 
+/* The structure of the velocity operator A = I/dt - c nu L the solver holds for its matrix-free products (16 B/row instead
+ * of the CSR's 104): *has = 0 none; dim, n[3] = pressure cells per direction, periodic[3]; *detected != 0 when
+ * pib_set_csr[_i32] recovered it from the matrix -- vSolver->setMatrix(A) of an unchanged PetIBM, navierstokes.cpp:345:
+ * in the packed [u | v | w] ordering one line of entries per field and direction is the coefficient table, a wall's ghost
+ * fold is read off a boundary point's diagonal (csrc/structure.cpp), and the recovered product is verified against the CSR
+ * SpMV on the device (1e-12) before it is used.  One rank; a preconditioner other than AMG; `pib_detect_structure=0` or
+ * `pib_matrix_free_velocity=0` switch it off.  Any output pointer may be NULL. */
+int pib_get_velocity_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int periodic[3], int *detected);
+
 /* Periodic directions of the mesh (flow.boundaryConditions type PERIODIC at both ends of a direction for every
  * component: src/misc/misc.cpp checkPeriodicBC, cartesianmesh.cpp:595-681 wraps the neighbour indices).  Call BEFORE
  * pib_assemble_poisson / pib_assemble_velocity / pib_set_grid_hint: the assembled operators then carry the wrapped

@@ -56,6 +56,7 @@ _PROTOS = {
     "pib_set_periodic": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "pib_get_grid_structure": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, C.POINTER(C.c_int),
                                          C.POINTER(C.c_int)]),
+    "pib_get_velocity_structure": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp, C.POINTER(C.c_int)]),
     "pib_assemble_poisson": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_double, C.c_int]),
     "pib_assemble_poisson_bn": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
                                           C.c_int]),

@@ -183,6 +183,9 @@ int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_g
     s->structure_detected = false;
     if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
         PIB_CHK(detect_grid_structure(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val));
+    s->vel_detected = false;
+    if (s->cfg.pc != Precond::GMG && s->cfg.detect_structure && s->cfg.matrix_free_velocity)
+        PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val));
     return 0;
 }
 
@@ -199,6 +202,9 @@ int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t
     s->structure_detected = false;
     if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
         PIB_CHK(detect_grid_structure(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val));
+    s->vel_detected = false;
+    if (s->cfg.pc != Precond::GMG && s->cfg.detect_structure && s->cfg.matrix_free_velocity)
+        PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val));
     return 0;
 }
 
@@ -233,6 +239,22 @@ int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int 
             n[1] = (g.dim == 3) ? g.n[1] : g.n[2];
             n[2] = (g.dim == 3) ? g.n[2] : 1;
         }
+    }
+    return 0;
+}
+
+int pib_get_velocity_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int periodic[3], int *detected)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_velocity_structure: null solver");
+    const VelStencil &V = s->vel;
+    if (has) *has = V.valid ? 1 : 0;
+    if (detected) *detected = (V.valid && s->vel_detected) ? 1 : 0;
+    if (dim) *dim = V.valid ? V.dim : 0;
+    for (int d = 0; d < 3; ++d) {
+        const bool p = V.valid && ((V.per >> d) & 1);
+        if (periodic) periodic[d] = p ? 1 : 0;
+        // pressure cells along d: component d has one point fewer than that unless d is periodic
+        if (n) n[d] = (V.valid && d < V.dim) ? V.n[d][d] + (p ? 0 : 1) : 1;
     }
     return 0;
 }

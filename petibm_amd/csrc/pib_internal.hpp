@@ -255,6 +255,7 @@ struct pib_solver {
     double *d_part = nullptr;  // [PIB_NRED][PIB_MAXPART]
     double *d_spmv_part = nullptr;  // one p.Ap partial per SpMV workgroup
     int64_t spmv_part_cap = 0;
+    bool vel_detected = false;     // s->vel was recovered from a matrix handed over through pib_set_csr (structure.cpp)
     double *d_vel_part = nullptr;  // per-workgroup partials of the velocity product's fused sums [2][vel_part_cap]
     int vel_part_cap = 0;
     double *d_gmg_part = nullptr;   // z.r, z.z, sum z partials of the V-cycle's last smoothing kernel (gmg.hip mode 8)
@@ -319,6 +320,7 @@ void dense_release(pib_solver *s);
 int solve_direct(pib_solver *s, double *x, const double *b);
 // assemble.hip
 void vel_stencil_release(pib_solver *s);
+int vel_stencil_verify(pib_solver *s);  // the matrix-free product against the CSR SpMV on a pseudo-random vector; invalidates s->vel on a mismatch
 int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv = nullptr, double opc = 1.0,
                       int dot_mode = 0, const double *dot_other = nullptr, int dot_slot0 = 0);
 constexpr int VEL_DOT_PARTIALS = 64;  // partial sums per slot the fused sums of vel_stencil_apply leave in d_part
@@ -338,6 +340,8 @@ void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3],
                           const int per[3], std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3]);
 int upload_vec(const std::vector<double> &h, double **d);
 // structure.cpp
+int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
+                              const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val);
 int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
                           const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val);
 // gmg.hip

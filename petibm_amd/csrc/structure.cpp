@@ -283,4 +283,186 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
     return 0;
 }
 
+// ---- the velocity operator A = I/dt - c nu L handed over as a plain CSR (an unchanged PetIBM: vSolver->setMatrix(A),
+// navierstokes.cpp:345): recover what the matrix-free product (velstencil.hip) needs, so that the drop-in route gets the
+// 16 B/row products instead of the CSR's 104.  In the packed [u | v | w] ordering the entry of a row towards -d / +d is a
+// function of the point's index along d only (createlaplacian.cpp:134-148: 1 / (dLNeg dLSelf), times MatScale), so one
+// line of entries per field and direction IS the table; the diagonal is shift - (sum of the six table values) where a
+// missing neighbour (a wall) contributes an effective value read off the diagonal of one boundary point (it carries the
+// ghost fold a0 with it, whatever the boundary type).  scale = 1, a0 = 0 in the recovered description; the product is
+// verified against the CSR SpMV on the device before it is used (1e-12), so anything that is not such an operator keeps
+// its CSR products.  One rank (the matrix-free product is a single-rank path).
+int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
+                              const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val)
+{
+    if (s->comm.nranks != 1 || n_local != n_global || row0 != 0 || n_local < 27) return 0;
+    const HostCsr A{n_local, row0, n_global, rp64, cl64, rp32, cl32, val};
+    // ---- field u: the offsets of its first rows
+    std::set<int64_t> offs;
+    for (int64_t l = 0; l < std::min<int64_t>(n_local, 8); ++l)
+        for (int64_t p = A.RP(l); p < A.RP(l + 1); ++p) {
+            const int64_t d = std::llabs(A.CL(p) - l);
+            if (d > 0) offs.insert(d);
+        }
+    const std::vector<int64_t> S(offs.begin(), offs.end());
+    if (S.size() < 2 || S.size() > 6 || S[0] != 1) return 0;
+    bool per[3] = {false, false, false};
+    int64_t nxu = 0;
+    size_t q = 2;
+    if (S.size() > 2 && S[2] == S[1] + 1) {
+        per[0] = true;
+        nxu = S[2];
+        q = 3;
+    } else
+        nxu = S[1];
+    if (nxu < 3) return 0;
+    std::vector<int64_t> m;
+    for (size_t t = q; t < S.size(); ++t) {
+        if (S[t] % nxu != 0) return 0;
+        m.push_back(S[t] / nxu);
+    }
+    auto has = [&](int64_t v) { return std::find(m.begin(), m.end(), v) != m.end(); };
+    int64_t n[3] = {per[0] ? nxu : nxu + 1, 1, 1};
+    int dim = 0;
+    // candidates for ny (u has ny points along y): 2-D when u's block is all there is besides v's
+    for (int pass = 0; pass < 2 && dim == 0; ++pass) {
+        if (pass == 0) {  // 2-D: offsets {ny - 1 (y periodic)} only; n_global = nxu ny + nx nyv
+            for (int py = 0; py < 2 && dim == 0; ++py) {
+                // n_global = nxu ny + nx (ny - (py ? 0 : 1))
+                const int64_t num = n_global + (py ? 0 : n[0]), den = nxu + n[0];
+                if (num % den != 0) continue;
+                const int64_t ny = num / den;
+                if (ny < 3) continue;
+                if (m.empty() ? py == 0 : (m.size() == 1 && m[0] == ny - 1 && py == 1)) {
+                    dim = 2;
+                    n[1] = ny;
+                    per[1] = py != 0;
+                }
+            }
+        } else {
+            for (int64_t y : m) {
+                if (y < 3) continue;
+                for (int py = 0; py < 2 && dim == 0; ++py)
+                    for (int pz = 0; pz < 2 && dim == 0; ++pz) {
+                        // n_global = nz [nxu y + nx (y - !py)] + nx y (nz - !pz)
+                        const int64_t a = nxu * y + n[0] * (y - (py ? 0 : 1)) + n[0] * y;
+                        const int64_t num = n_global + (pz ? 0 : n[0] * y);
+                        if (num % a != 0) continue;
+                        const int64_t z = num / a;
+                        if (z < 3) continue;
+                        bool fits = has(y);
+                        for (int64_t v : m) fits = fits && (v == y || (py && v == y - 1) || (pz && v == y * (z - 1)));
+                        fits = fits && (py == (has(y - 1) ? 1 : 0)) && (pz == (has(y * (z - 1)) ? 1 : 0));
+                        if (!fits) continue;
+                        dim = 3;
+                        n[1] = y;
+                        n[2] = z;
+                        per[1] = py != 0;
+                        per[2] = pz != 0;
+                    }
+            }
+        }
+    }
+    if (dim == 0) return 0;
+    // ---- field sizes and offsets
+    int64_t fn[3][3], off[3] = {0, 0, 0};
+    int64_t total = 0;
+    for (int f = 0; f < 3; ++f)
+        for (int d = 0; d < 3; ++d) fn[f][d] = 1;
+    for (int f = 0; f < dim; ++f) {
+        off[f] = total;
+        int64_t cnt = 1;
+        for (int d = 0; d < dim; ++d) {
+            fn[f][d] = n[d] - ((d == f && !per[d]) ? 1 : 0);
+            if (fn[f][d] < 3) return 0;
+            cnt *= fn[f][d];
+        }
+        total += cnt;
+    }
+    if (total != n_global) return 0;
+    // ---- shift and tables
+    VelStencil V;
+    V.dim = dim;
+    V.per = (per[0] ? 1 : 0) | (per[1] ? 2 : 0) | (per[2] ? 4 : 0);
+    V.scale = 1.0;
+    bool found = true;
+    auto get = [&](int64_t row, int64_t col) {
+        double v = 0.0;
+        if (!A.entry(row, col, &v)) found = false;
+        return v;
+    };
+    std::vector<double> tn[3][3], tp[3][3];
+    double shift = 0.0;
+    for (int f = 0; f < dim && found; ++f) {
+        const int64_t st[3] = {1, fn[f][0], fn[f][0] * fn[f][1]};
+        auto point = [&](int d, int64_t sidx) {  // index 1 in the other directions
+            int64_t p = off[f];
+            for (int e = 0; e < dim; ++e) p += st[e] * (e == d ? sidx : 1);
+            return p;
+        };
+        // neighbour column of point p (index sidx along d), or -1 at a wall
+        auto nbr = [&](int64_t p, int d, int64_t sidx, int side) -> int64_t {
+            const int64_t nd = fn[f][d];
+            if (side < 0) return sidx > 0 ? p - st[d] : (per[d] ? p + (nd - 1) * st[d] : -1);
+            return sidx < nd - 1 ? p + st[d] : (per[d] ? p - (nd - 1) * st[d] : -1);
+        };
+        if (f == 0) {
+            const int64_t b = point(0, 1);
+            double sum = 0.0;
+            for (int d = 0; d < dim; ++d) sum += get(b, nbr(b, d, 1, -1)) + get(b, nbr(b, d, 1, +1));
+            shift = get(b, b) + sum;  // diag = shift - (sum of the six table values)
+        }
+        for (int d = 0; d < dim && found; ++d) {
+            const int64_t nd = fn[f][d];
+            tn[f][d].assign((size_t)nd, 0.0);
+            tp[f][d].assign((size_t)nd, 0.0);
+            for (int64_t sidx = 0; sidx < nd; ++sidx) {
+                const int64_t p = point(d, sidx);
+                const int64_t cm = nbr(p, d, sidx, -1), cp = nbr(p, d, sidx, +1);
+                if (cm >= 0) tn[f][d][(size_t)sidx] = get(p, cm);
+                if (cp >= 0) tp[f][d][(size_t)sidx] = get(p, cp);
+            }
+            // walls: the effective value of the missing neighbour from the diagonal of the boundary point of this line
+            // (the other directions' neighbours of that point exist: it sits at index 1 there)
+            for (int side = -1; side <= 1 && !per[d]; side += 2) {
+                const int64_t sidx = side < 0 ? 0 : nd - 1, p = point(d, sidx);
+                double present = 0.0;
+                for (int e = 0; e < dim; ++e)
+                    for (int sd2 = -1; sd2 <= 1; sd2 += 2) {
+                        const int64_t c = nbr(p, e, e == d ? sidx : 1, sd2);
+                        if (c >= 0) present += get(p, c);
+                    }
+                const double eff = (shift - get(p, p)) - present;
+                (side < 0 ? tn : tp)[f][d][(size_t)sidx] = eff;
+            }
+        }
+    }
+    if (!found || !std::isfinite(shift)) return 0;
+    V.shift = shift;
+    for (int f = 0; f < dim; ++f) {
+        V.off[f] = off[f];
+        for (int d = 0; d < 3; ++d) V.n[f][d] = fn[f][d];
+        for (int qq = 0; qq < 6; ++qq) V.a0[f][qq] = 0.0;
+        for (int d = 0; d < dim; ++d) {
+            double *p1 = nullptr, *p2 = nullptr;
+            PIB_CHK(upload_vec(tn[f][d], &p1));
+            PIB_CHK(upload_vec(tp[f][d], &p2));
+            V.owned.push_back(p1);
+            V.owned.push_back(p2);
+            V.lneg[f][d] = p1;
+            V.lpos[f][d] = p2;
+        }
+    }
+    V.valid = true;
+    vel_stencil_release(s);
+    s->vel = V;
+    // ---- the recovered product against the CSR's, on the device
+    int err = vel_stencil_verify(s);
+    if (err != 0 || !s->vel.valid) {
+        vel_stencil_release(s);
+    } else
+        s->vel_detected = true;
+    return 0;
+}
+
 }  // namespace pib

@@ -10,6 +10,7 @@
 // enumeration.  Single rank (the device time step is single-GPU); the Krylov solvers use it for their products when the
 // matrix came from pib_assemble_velocity and `pib_matrix_free_velocity` is on (default).
 #include <algorithm>
+#include <cstring>
 
 #include "pib_internal.hpp"
 
@@ -489,6 +490,61 @@ __global__ __launch_bounds__(256) void k_vel_reduce(const Scalars *__restrict__ 
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) out[(int64_t)(slot0 + blockIdx.y) * PIB_MAXPART + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ---- verification of a recovered structure (structure.cpp): y = A x from the tables against the CSR SpMV
+__global__ __launch_bounds__(256) void k_vel_verify_fill(int64_t n, double *__restrict__ x)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 32;
+        x[i] = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+__global__ __launch_bounds__(256) void k_vel_verify_diff(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                         unsigned long long *__restrict__ out /* bits of max |a - b|, max |a| */)
+{
+    double d = 0.0, m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double e = fabs(a[i] - b[i]);
+        d = (e > d || e != e) ? (e != e ? 1e300 : e) : d;
+        m = fmax(m, fabs(a[i]));
+    }
+    // non-negative doubles order like their bit patterns
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(d));
+    atomicMax(&out[1], (unsigned long long)__double_as_longlong(m));
+}
+int vel_stencil_verify(pib_solver *s)
+{
+    const int64_t n = s->A.n;
+    double *buf = nullptr;
+    unsigned long long *out = nullptr;
+    PIB_HIP(hipMalloc(&buf, sizeof(double) * 3 * (size_t)n));
+    PIB_HIP(hipMalloc(&out, 2 * sizeof(unsigned long long)));
+    double *x = buf, *y1 = buf + n, *y2 = buf + 2 * n;
+    hipStream_t q = s->stream;
+    PIB_HIP(hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), q));
+    const unsigned nb = (unsigned)std::min<int64_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(k_vel_verify_fill, dim3(nb), dim3(256), 0, q, n, x);
+    int err = spmv_rows(s, x, y1, 0, n, nullptr, false, q);
+    if (!err) err = vel_stencil_apply(s, x, y2, false, q);
+    if (!err) {
+        hipLaunchKernelGGL(k_vel_verify_diff, dim3(nb), dim3(256), 0, q, n, y1, y2, out);
+        unsigned long long h[2] = {0, 0};
+        if (hipMemcpyAsync(h, out, sizeof h, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess)
+            err = fail(PIB_ERR_LIB, "velocity structure check: HIP error");
+        else {
+            double d, m;
+            std::memcpy(&d, &h[0], 8);
+            std::memcpy(&m, &h[1], 8);
+            if (!(d <= 1e-12 * m) || !(m > 0.0)) s->vel.valid = false;
+        }
+    }
+    (void)hipFree(buf);
+    (void)hipFree(out);
+    return err;
 }
 
 void vel_stencil_release(pib_solver *s)

@@ -183,6 +183,17 @@ class LinSolverBase:
         return {"dim": dim.value, "n": tuple(int(v) for v in n3[:dim.value]), "nullspace": ns.value,
                 "detected": bool(det.value)}
 
+    def velocityStructure(self):
+        """pib_get_velocity_structure: None, or dict(dim, n, periodic, detected)"""
+        has, dim, det = C.c_int(), C.c_int(), C.c_int()
+        n3 = np.zeros(3, dtype=np.int64)
+        per = (C.c_int * 3)()
+        capi.check(capi.load().pib_get_velocity_structure(self._h, C.byref(has), C.byref(dim), n3.ctypes.data, per, C.byref(det)))
+        if not has.value:
+            return None
+        return {"dim": dim.value, "n": tuple(int(v) for v in n3[:dim.value]), "periodic": tuple(bool(per[d]) for d in range(dim.value)),
+                "detected": bool(det.value)}
+
     def setPeriodic(self, periodic) -> None:
         """periodic directions of the mesh (pib_set_periodic); call before the assembly / the grid hint"""
         per = (C.c_int * 3)(*[int(bool(periodic[d])) if d < len(periodic) else 0 for d in range(3)])

@@ -106,6 +106,79 @@ def test_structure_of_periodic_meshes_recovered_from_the_matrix(n, per):
     t.destroy()
 
 
+@pytest.mark.parametrize("case", ["2d_stretched", "3d_stretched", "3d_outflow", "3d_all_periodic", "2d_periodic_y", "3d_periodic_xz",
+                                  "3d_big_march"])
+def test_velocity_structure_recovered_from_the_matrix(case):
+    """vSolver->setMatrix(A) is all an unchanged PetIBM gives the velocity solver (navierstokes.cpp:345).  With a Jacobi
+    preconditioner the backend recovers the operator's structure from the CSR -- field sizes and periodic directions from
+    the offsets of the first rows, the coefficient tables from one line of entries per field and direction, the walls' ghost
+    folds from boundary diagonals -- verifies the matrix-free product against the CSR SpMV on the device, and runs BiCGStab on
+    it: same iteration count as the CSR products, solutions equal to rounding (the diagonal is re-formed from the tables)."""
+    from petibm_amd.linsolver import LinSolverHIP
+    from test_gpu_parity import _outflow_3d
+    extra = ""
+    if case == "3d_all_periodic":
+        cfg, per = omesh.periodic_config((10, 8, 9), (True, True, True)), (True, True, True)
+    elif case == "2d_periodic_y":
+        cfg, per = omesh.periodic_config((14, 12), (False, True)), (False, True)
+    elif case == "3d_periodic_xz":
+        cfg, per = omesh.periodic_config((9, 10, 8), (True, False, True), ratios=(1.0, 1.02, 1.0)), (True, False, True)
+    elif case == "3d_big_march":  # the one-launch marching product (and the BiCGStab built on it) with recovered tables
+        cfg, per = omesh.periodic_config((128, 16, 24), (False, True, False), ratios=(1.002, 1.0, 1.01)), (False, True, False)
+        extra = "pib_march_min_cells=0\n"
+    else:
+        cfg = {"2d_stretched": STRETCHED_2D, "3d_stretched": stretched_3d((11, 9, 10)), "3d_outflow": _outflow_3d()}[case]
+        per = (False,) * len(cfg["mesh"])
+    m = omesh.create_mesh(cfg)
+    dt, cnu = 0.004, 0.5 * 0.01
+    A = oops.create_velocity_operator(oops.create_laplacian(m), dt, cnu)
+    b = np.random.default_rng(4).uniform(-1, 1, m.UN)
+    out = []
+    for mf in (1, 0):
+        s = LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500,
+                                                          extra=extra + f"pib_matrix_free_velocity={mf}\n"))
+        s.setMatrix(A)
+        st = s.velocityStructure()
+        if mf:
+            assert st is not None and st["detected"] and st["dim"] == m.dim
+            assert st["n"] == tuple(int(v) for v in m.n[3][: m.dim]) and st["periodic"] == tuple(per)
+        else:
+            assert st is None
+        y = np.empty(m.UN)
+        s.matMult(b, y)
+        x = np.zeros(m.UN)
+        s.solve(x, b)
+        out.append((x, s.getIters(), y))
+        s.destroy()
+    assert np.array_equal(out[0][2], out[1][2])  # pib_mat_mult stays the CSR product
+    assert out[0][1] == out[1][1] and out[0][1] >= 2
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * np.abs(out[1][0]).max()
+    assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1e-11 * np.linalg.norm(b)
+
+
+def test_a_matrix_that_only_looks_like_the_velocity_operator_keeps_its_csr_products():
+    from petibm_amd.linsolver import LinSolverHIP
+    m = omesh.create_mesh(stretched_3d((9, 8, 7)))
+    A = oops.create_velocity_operator(oops.create_laplacian(m), 0.004, 0.005)
+    B = A.copy()
+    B.val = B.val.copy()
+    rows = np.repeat(np.arange(B.n_rows), np.diff(B.rowptr))
+    hit = np.nonzero((rows == 300) & (B.col == 301))[0][0]
+    B.val[hit] *= 1.0 + 1e-6  # one entry off the tensor structure: the device check against the CSR refuses the tables
+    s = LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500))
+    s.setMatrix(B)
+    assert s.velocityStructure() is None
+    b = np.random.default_rng(5).uniform(-1, 1, m.UN)
+    x = np.zeros(m.UN)
+    s.solve(x, b)
+    assert np.linalg.norm(b - clib.spmv(B, x)) <= 1e-11 * np.linalg.norm(b)
+    # the Poisson matrix with a Jacobi preconditioner is not mistaken for it either
+    _, P, _ = poisson_system(stretched_3d((9, 8, 7)))
+    s.setMatrix(P)
+    assert s.velocityStructure() is None
+    s.destroy()
+
+
 def test_matrices_that_are_not_the_poisson_operator_stay_without_structure():
     from petibm_amd import capi
     from petibm_amd.capi import PibError
