@@ -175,7 +175,8 @@ int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int 
  * pib_set_csr[_i32] recovered it from the matrix -- vSolver->setMatrix(A) of an unchanged PetIBM, navierstokes.cpp:345:
  * in the packed [u | v | w] ordering one line of entries per field and direction is the coefficient table, a wall's ghost
  * fold is read off a boundary point's diagonal (csrc/structure.cpp), and the recovered product is verified against the CSR
- * SpMV on the device (1e-12) before it is used.  One rank; a preconditioner other than AMG; `pib_detect_structure=0` or
+ * SpMV on the device (1e-12) before it is used.  The recovery runs on one rank (pib_assemble_velocity holds the structure
+ * on slabs too: the neighbour rank's planes are read from the ghost pads); a preconditioner other than AMG; `pib_detect_structure=0` or
  * `pib_matrix_free_velocity=0` switch it off.  Any output pointer may be NULL. */
 int pib_get_velocity_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int periodic[3], int *detected);
 

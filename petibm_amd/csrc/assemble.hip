@@ -676,18 +676,25 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
     }
     PIB_HIP(hipStreamSynchronize(s->stream));
     for (double *p : tofree) (void)hipFree(p);
-    if (P == 1) {
+    {
         // the operator's structure for the matrix-free product (velstencil.hip): the quotients the assembly kernel
-        // evaluates per entry, once per field, direction and index (IEEE division rounds identically on the host)
+        // evaluates per entry, once per field, direction and index (IEEE division rounds identically on the host).  On
+        // several ranks: this rank's slab, the neighbours' planes in the ghost pads (the slab axis never wraps locally)
         VelStencil &V = s->vel;
         V.dim = dim;
-        V.per = per;
+        V.per = (P > 1) ? (per & ~(1 << sd)) : per;
         V.scale = scale;
         V.shift = shift;
+        V.slab_axis = (P > 1) ? sd : -1;
+        V.has_lo = P > 1 && (rank > 0 || ring);
+        V.has_hi = P > 1 && (rank < P - 1 || ring);
         for (int f = 0; f < dim; ++f) {
             V.off[f] = row_off[f];
+            V.pad_lo[f] = -ghost_lo + glo[f];
+            V.pad_hi[f] = rows + ghi[f];
             for (int q = 0; q < 6; ++q) V.a0[f][q] = a0[6 * f + q];
             for (int d = 0; d < 3; ++d) V.n[f][d] = fn[f][d];
+            if (P > 1) V.n[f][sd] = ke[f] - kb[f];
             for (int d = 0; d < dim; ++d) {
                 const int64_t nfd = fn[f][d];
                 std::vector<double> tn((size_t)nfd), tp((size_t)nfd);
@@ -703,8 +710,9 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
                 PIB_CHK(upload_vec(tp, &p2));
                 V.owned.push_back(p1);
                 V.owned.push_back(p2);
-                V.lneg[f][d] = p1;
-                V.lpos[f][d] = p2;
+                const int64_t first = (P > 1 && d == sd) ? kb[f] : 0;  // local index 0 <-> the slab's first plane
+                V.lneg[f][d] = p1 + first;
+                V.lpos[f][d] = p2 + first;
             }
         }
         V.valid = true;

@@ -615,7 +615,7 @@ static int matmult(pib_solver *s, double *p_owned, double *w, double *dot_part, 
     if (s->comm.nranks > 1 && s->halo_fresh != p_owned) PIB_CHK(halo_exchange(s, p_owned, stq));
     s->halo_fresh = nullptr;
     // the velocity operator from its mesh tables (same bits as the CSR product, 56 instead of 104 B/row)
-    if (s->vel.valid && s->cfg.matrix_free_velocity && dot_part == nullptr && s->comm.nranks == 1)
+    if (s->vel.valid && s->cfg.matrix_free_velocity && dot_part == nullptr && (s->comm.nranks == 1 || s->vel.slab_axis >= 0))
         return vel_stencil_apply(s, p_owned, w, guarded, stq);
     if (s->post_matmult != nullptr) {
         // operator = matrix + a term applied by the hook: the fused p.w of the SpMV would miss it

@@ -212,6 +212,12 @@ struct VelStencil {
     double a0[3][6] = {{0}};
     double scale = 0.0, shift = 0.0;
     std::vector<double *> owned;
+    // several ranks: this rank's slab of every field along the last axis (n[f][sd] = its planes, the tables along sd start at
+    // its first plane); the neighbours' planes sit in the ghost pads of the vector, at pad_lo[f] / pad_hi[f] relative to
+    // the first owned entry (0: no neighbour there -- a true boundary)
+    int slab_axis = -1;
+    int64_t pad_lo[3] = {0, 0, 0}, pad_hi[3] = {0, 0, 0};
+    bool has_lo = false, has_hi = false;
 };
 
 }  // namespace pib

@@ -32,6 +32,10 @@ struct VelDev {
     const double *dot_other;
     double *dot_part;
     int dot_stride;
+    // several ranks (see VelStencil): the slab axis, the ghost-pad places of the neighbours' planes, who has a neighbour
+    int slab_axis;
+    int64_t pad_lo[3], pad_hi[3];
+    int has_lo, has_hi;
 };
 __device__ __forceinline__ double vel_in(const VelDev &V, const double *__restrict__ x, int64_t idx)
 {
@@ -52,8 +56,10 @@ __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restr
         v[2 * d] = V.lneg[f][d][s];
         v[2 * d + 1] = V.lpos[f][d][s];
         const bool wrap = (V.per >> d) & 1;
-        interior[2 * d] = s > 0 || wrap;
-        interior[2 * d + 1] = s < V.n[f][d] - 1 || wrap;
+        // on a slab the first / last plane's neighbour along the slab axis exists where a neighbour rank does (its plane
+        // sits in a ghost pad); elsewhere that plane is a true boundary
+        interior[2 * d] = s > 0 || wrap || (d == V.slab_axis && V.has_lo);
+        interior[2 * d + 1] = s < V.n[f][d] - 1 || wrap || (d == V.slab_axis && V.has_hi);
         anywrap = anywrap || (wrap && (s == 0 || s == V.n[f][d] - 1));
         acc = acc + v[2 * d];
         acc = acc + v[2 * d + 1];
@@ -67,13 +73,19 @@ __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restr
     const double dval = diag * V.scale + V.shift;
     const int64_t st[3] = {1, V.n[f][0], V.n[f][0] * V.n[f][1]};
     const int64_t p = V.off[f] + i + V.n[f][0] * (j + V.n[f][1] * k);
+    // the neighbour's place in the vector: in the block, or -- across a slab end -- in a ghost pad (the low pad precedes and
+    // the high pad follows every owned entry: the ascending-column order of the CSR row is the natural order still)
+    const int sa = V.slab_axis;
+    const int64_t inplane = (sa < 0) ? 0 : (p - V.off[f]) % st[sa];
+    auto below = [&](int d) { return (d == sa && ijk[d] == 0) ? V.pad_lo[f] + inplane : p - st[d]; };
+    auto above = [&](int d) { return (d == sa && ijk[d] == V.n[f][d] - 1) ? V.pad_hi[f] + inplane : p + st[d]; };
     double s = 0.0;
     if (!anywrap) {
         for (int d = V.dim - 1; d >= 0; --d)
-            if (interior[2 * d]) s = s + (v[2 * d] * V.scale) * vel_in(V, x, p - st[d]);
+            if (interior[2 * d]) s = s + (v[2 * d] * V.scale) * vel_in(V, x, below(d));
         s = s + dval * vel_in(V, x, p);
         for (int d = 0; d < V.dim; ++d)
-            if (interior[2 * d + 1]) s = s + (v[2 * d + 1] * V.scale) * vel_in(V, x, p + st[d]);
+            if (interior[2 * d + 1]) s = s + (v[2 * d + 1] * V.scale) * vel_in(V, x, above(d));
         return s;
     }
     int64_t ec[7];
@@ -85,7 +97,8 @@ __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restr
         if (!interior[q]) continue;
         const int d = q >> 1;
         int64_t c;
-        if (!(q & 1)) c = (ijk[d] == 0) ? p + (V.n[f][d] - 1) * st[d] : p - st[d];
+        if (d == sa) c = (q & 1) ? above(d) : below(d);  // never wraps locally: the pads
+        else if (!(q & 1)) c = (ijk[d] == 0) ? p + (V.n[f][d] - 1) * st[d] : p - st[d];
         else c = (ijk[d] == V.n[f][d] - 1) ? p - (V.n[f][d] - 1) * st[d] : p + st[d];
         int t = ne++;
         while (t > 0 && ec[t - 1] > c) {
@@ -199,6 +212,13 @@ static VelDev vel_dev(const VelStencil &h)
     V.dot_other = nullptr;
     V.dot_part = nullptr;
     V.dot_stride = 0;
+    V.slab_axis = h.slab_axis;
+    V.has_lo = h.has_lo ? 1 : 0;
+    V.has_hi = h.has_hi ? 1 : 0;
+    for (int f = 0; f < 3; ++f) {
+        V.pad_lo[f] = h.pad_lo[f];
+        V.pad_hi[f] = h.pad_hi[f];
+    }
     for (int f = 0; f < 3; ++f) {
         V.off[f] = h.off[f];
         for (int d = 0; d < 3; ++d) {

@@ -229,14 +229,15 @@ def _velocity_slab_indices(m, P, r):
     return np.concatenate(idx)
 
 
-@pytest.mark.parametrize("P,case", [(2, "3d"), (3, "3d"), (2, "2d"), (4, "3d_outflow")])
+@pytest.mark.parametrize("P,case", [(2, "3d"), (3, "3d"), (2, "2d"), (4, "3d_outflow"), (2, "3d_march"), (3, "3d_march")])
 def test_multirank_velocity_system(P, case):
     """The velocity operator A = I/dt - c nu L on slabs: every rank assembles its rows of the packed
     ordering, the neighbours' boundary planes of u, v and w arrive through the segmented halo plan; SpMV across the
     slab boundaries is bit-identical to the oracle and BiCGStab + Jacobi reproduces the single-rank solve."""
     from petibm_amd.linsolver import LinSolverHIP
     from test_gpu_parity import STRETCHED_2D, _a0_table, _outflow_3d, amgx_cfg, stretched_3d
-    cfg = {"3d": stretched_3d((10, 9, 12)), "2d": STRETCHED_2D, "3d_outflow": _outflow_3d()}[case]
+    cfg = {"3d": stretched_3d((10, 9, 12)), "2d": STRETCHED_2D, "3d_outflow": _outflow_3d(),
+           "3d_march": stretched_3d((128, 10, 16))}[case]  # wide enough for the LDS-tiled one-launch product on every slab
     if case == "3d_outflow":
         cfg = _outflow_3d()
         cfg["mesh"][2]["subDomains"][0]["cells"] += 4  # 12 planes: three per rank
@@ -248,22 +249,29 @@ def test_multirank_velocity_system(P, case):
     n = [int(v) for v in m.n[3][: m.dim]]
     w = [m.dL[3][d].true for d in range(m.dim)]
     text = amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500)
+    if case == "3d_march":
+        text += "pib_march_min_cells=0\n"
     own = [_velocity_slab_indices(m, P, r) for r in range(P)]
     assert sorted(np.concatenate(own).tolist()) == list(range(A.n_rows))
 
-    def rank_fn(r, uid):
-        s = LinSolverHIP("velocity", config_text=text, rank=r, nranks=P, uid=uid, device=0)
+    def rank_fn(r, uid, extra=""):
+        s = LinSolverHIP("velocity", config_text=text + extra, rank=r, nranks=P, uid=uid, device=0)
         s.assembleVelocity(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
         assert s.n_local == own[r].size
         y = np.empty(own[r].size)
         s.matMult(np.ascontiguousarray(us[own[r]]), y)
         x = np.zeros(own[r].size)
         s.solve(x, np.ascontiguousarray(b[own[r]]))
-        its = s.getIters()
+        its, hist = s.getIters(), s.getResidualHistory()
         s.destroy()
-        return y, x, its
+        return y, x, its, hist
 
     res = _run_ranks(P, rank_fn)
+    # the Krylov products come from the mesh tables on slabs too (velstencil.hip: the neighbours' planes in the ghost pads);
+    # with the CSR products instead the iterates are the same, bit for bit
+    csr = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_matrix_free_velocity=0\n"))
+    for a, c in zip(res, csr):
+        assert a[2] == c[2] and np.array_equal(a[3], c[3]) and np.array_equal(a[1], c[1])
     y, x = np.empty(A.n_rows), np.empty(A.n_rows)
     for r in range(P):
         y[own[r]], x[own[r]] = res[r][0], res[r][1]
@@ -274,7 +282,8 @@ def test_multirank_velocity_system(P, case):
     s1.assembleVelocity(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
     x1 = np.zeros(A.n_rows)
     s1.solve(x1, b)
-    assert abs(res[0][2] - s1.getIters()) <= 1 and np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
+    # (BiCGStab's count moves by a few in ~90 with the order of its sums: the one-rank solve folds them into the product)
+    assert abs(res[0][2] - s1.getIters()) <= max(1, res[0][2] // 20) and np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
     s1.destroy()
 
 

@@ -360,7 +360,8 @@ def test_periodic_slab_axis_across_ranks(P, n, per, pc, extra):
 
 
 @pytest.mark.parametrize("P,n,per", [(2, (10, 9, 12), (True, True, True)), (3, (8, 6, 12), (False, False, True)),
-                                     (2, (12, 10), (True, True)), (4, (6, 5, 16), (True, False, True))])
+                                     (2, (12, 10), (True, True)), (4, (6, 5, 16), (True, False, True)),
+                                     (2, (128, 8, 16), (True, True, True)), (3, (128, 9, 12), (False, True, True))])  # one-launch march on the slabs
 def test_velocity_system_on_a_periodic_slab_axis(P, n, per):
     """a periodic slab axis (the Taylor-Green box on several GPUs) for the velocity operator A = I/dt - c nu L --
     every rank has both ghost pads, the wrapped neighbours of rank 0's first and the last rank's last plane arrive through the
@@ -377,11 +378,13 @@ def test_velocity_system_on_a_periodic_slab_axis(P, n, per):
     nn = [int(v) for v in m.n[3][: m.dim]]
     w = [m.dL[3][d].true for d in range(m.dim)]
     text = amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500)
+    if n[0] >= 128:
+        text += "pib_march_min_cells=0\n"
     own = [_velocity_slab_indices(m, P, r) for r in range(P)]
     assert sorted(np.concatenate(own).tolist()) == list(range(A.n_rows))
 
-    def rank_fn(r, uid):
-        s = LinSolverHIP("velocity", config_text=text, rank=r, nranks=P, uid=uid, device=0)
+    def rank_fn(r, uid, extra=""):
+        s = LinSolverHIP("velocity", config_text=text + extra, rank=r, nranks=P, uid=uid, device=0)
         s.setPeriodic(per)
         s.assembleVelocity(nn, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
         assert s.n_local == own[r].size
@@ -389,11 +392,14 @@ def test_velocity_system_on_a_periodic_slab_axis(P, n, per):
         s.matMult(np.ascontiguousarray(us[own[r]]), y)
         x = np.zeros(own[r].size)
         s.solve(x, np.ascontiguousarray(b[own[r]]))
-        its = s.getIters()
+        its, hist = s.getIters(), s.getResidualHistory()
         s.destroy()
-        return y, x, its
+        return y, x, its, hist
 
     res = _run_ranks(P, rank_fn)
+    csr = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_matrix_free_velocity=0\n"))  # matrix-free products on slabs = the CSR's
+    for a, c in zip(res, csr):
+        assert a[2] == c[2] and np.array_equal(a[3], c[3]) and np.array_equal(a[1], c[1])
     y, x = np.empty(A.n_rows), np.empty(A.n_rows)
     for r in range(P):
         y[own[r]], x[own[r]] = res[r][0], res[r][1]
