@@ -207,8 +207,10 @@ int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const doubl
  * (navierstokes.cpp:349-356) -- so the matrix is bit-identical to what the application would hand to setMatrix.
  * lo / hi / a0 as in pib_assemble_velocity; coeff_nu = implicit diffusion coefficient * nu (0.5 nu for Crank-Nicolson).
  * order 1 is pib_assemble_poisson.  The 13 / 25-point operator is solved with the CSR SpMV; an AMG entry in the solver
- * file is served by the multigrid of the 7-point order-1 operator (same mesh) as preconditioner.  Single rank;
- * order < 1 -> PIB_ERR_SUP like createBnHead; honours pib_set_periodic. */
+ * file is served by the multigrid of the 7-point order-1 operator (same mesh) as preconditioner.  On several ranks
+ * (n, the widths, lo / hi of the WHOLE mesh, as pib_assemble_poisson takes them) a rank runs the chain on a window of the
+ * mesh around its slab and keeps its rows -- the entries of the one-rank matrix, ghost columns `order` planes deep; a slab
+ * must hold at least `order` planes.  order < 1 -> PIB_ERR_SUP like createBnHead; honours pib_set_periodic. */
 int pib_assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                             const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
                             double coeff_nu, int bn_order, int nullspace);
@@ -296,7 +298,7 @@ int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, co
  * the same bodies on every rank; direct forces solver): every rank assembles the operators on the velocity points it
  * owns, E u and the force system E BN H are summed over the ranks, the forces are replicated.  A periodic slab axis (the
  * Taylor-Green box, the cylinder array of multicylinders2dRe100 on several GPUs) makes both ends of every rank's slab a
- * cut and the plane exchanges a ring.  Not on slabs: BN order > 1, the coupled IBPM, the vorticity utility (PIB_ERR_SUP). */
+ * cut and the plane exchanges a ring.  Not on slabs: BN order > 1 in the time step, the coupled IBPM, the vorticity utility (PIB_ERR_SUP). */
 int pib_ns_create_slab(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                        const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
                        double nu, const char *velocity_cfg, const char *poisson_cfg, int rank, int nranks,

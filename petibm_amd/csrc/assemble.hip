@@ -407,19 +407,36 @@ struct FieldDev {
 // including the periodic variants (:259-266 one more point of component d along a periodic d, :300-318 ghost entries
 // taken from the other end).  Same evaluation order as oracle/mesh.py.
 void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3], const double mn[3], const double mx[3],
-                          const int per[3], std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3])
+                          const int per[3], std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3],
+                          const MeshWindow *win)
 {
     std::vector<double> c3[3], c4[3];
     for (int d = 0; d < dim; ++d) {
-        const int64_t nd = n[d];
+        const bool windowed = win != nullptr && win->active && win->axis == d;
+        const int64_t nd = windowed ? win->n_global : n[d];
+        const double *wd = windowed ? win->w_global : w[d];
+        const double m0 = windowed ? win->lo : mn[d];
         c3[d].resize((size_t)nd);
         c4[d].resize((size_t)nd + 1);
         double run = 0.0;
-        c4[d][0] = 0.0 + mn[d];
+        c4[d][0] = 0.0 + m0;
         for (int64_t q = 0; q < nd; ++q) {
-            run = (q == 0) ? w[d][0] : run + w[d][q];  // std::partial_sum
-            c3[d][(size_t)q] = (run + mn[d]) - 0.5 * w[d][q];
-            c4[d][(size_t)q + 1] = run + mn[d];
+            run = (q == 0) ? wd[0] : run + wd[q];  // std::partial_sum
+            c3[d][(size_t)q] = (run + m0) - 0.5 * wd[q];
+            c4[d][(size_t)q + 1] = run + m0;
+        }
+        if (windowed) {  // the window's planes of the whole mesh's coordinates
+            std::vector<double> a((size_t)n[d]), b((size_t)n[d] + 1);
+            const double period = win->hi - win->lo;
+            auto turn = [&](int64_t k) { return (double)((k >= 0) ? k / nd : -((-k + nd - 1) / nd)); };
+            for (int64_t q = 0; q <= n[d]; ++q) {
+                const int64_t k = win->first + q, km = ((k % nd) + nd) % nd;
+                if (q < n[d]) a[(size_t)q] = (turn(k) == 0.0) ? c3[d][(size_t)km] : c3[d][(size_t)km] + turn(k) * period;
+                // (vertex nd of the whole mesh is its upper end, not vertex 0 a period on)
+                b[(size_t)q] = (k >= 0 && k <= nd) ? c4[d][(size_t)k] : c4[d][(size_t)km] + turn(k) * period;
+            }
+            c3[d].swap(a);
+            c4[d].swap(b);
         }
     }
     for (int f = 0; f < 3; ++f)
@@ -561,7 +578,7 @@ int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *
             if (n[d] < 3) return fail(PIB_ERR_SUP, "assemble_velocity: a periodic direction needs >= 3 cells");
             per |= 1 << d;
         }
-    velocity_mesh_arrays(dim, n, w, mn, mx, s->periodic, hdl, hco, fn);
+    velocity_mesh_arrays(dim, n, w, mn, mx, s->periodic, hdl, hco, fn, &s->mesh_window);
     // ---- sizes.  Decomposition: slabs along the last axis with the pressure grid's ownership (the velocity DMDAs
     // reuse the pressure process grid, cartesianmesh.cpp:516-535): rank r owns the planes of its pressure cells; the
     // component along the slab axis has one plane fewer, taken from the last rank.  Each rank's vector is the packed

@@ -9,7 +9,8 @@
 //
 // Set-up only (one thread per row, the accumulator in scratch memory); the product matrices are 13 / 25-point and
 // wider, so the solve runs the CSR SpMV with the multigrid of the 7-point N = 1 operator as preconditioner (the two
-// operators differ by dt c nu L + ..., a small relative perturbation at the time steps PetIBM runs).  Single rank.
+// operators differ by dt c nu L + ..., a small relative perturbation at the time steps PetIBM runs).  On slabs every rank
+// runs the chain on a window of the mesh around its planes (assemble_poisson_bn_slab).
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -276,12 +277,13 @@ __global__ __launch_bounds__(256) void k_bn_identity(int64_t n, double v, int32_
 }
 
 // MatZeroRowsColumns(DBNG, row 0, diag = 1) keeping the pattern (navierstokes.cpp:414-420)
+// (`pin` = where row 0 of the whole matrix sits in this numbering: 0 on one rank, its place in a rank's window on slabs)
 __global__ __launch_bounds__(256) void k_bn_pin(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
-                                                double *__restrict__ val)
+                                                double *__restrict__ val, int64_t pin)
 {
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256)
         for (int32_t p = rp[r]; p < rp[r + 1]; ++p)
-            if (r == 0 || col[p] == 0) val[p] = (r == 0 && col[p] == 0) ? 1.0 : 0.0;
+            if (r == pin || col[p] == pin) val[p] = (r == pin && col[p] == pin) ? 1.0 : 0.0;
 }
 
 static int dup(const Csr32 &A, Csr32 *B, hipStream_t q)
@@ -327,7 +329,7 @@ static int build_bn_chain(pib_solver *s, int dim, const int64_t n[3], const doub
     GdMesh M;
     std::memset(&M, 0, sizeof M);
     M.dim = dim;
-    velocity_mesh_arrays(dim, n, w, mn, mx, s->periodic, hdl, hco, M.fn);
+    velocity_mesh_arrays(dim, n, w, mn, mx, s->periodic, hdl, hco, M.fn, &s->mesh_window);
     std::vector<double *> tofree;
     int64_t UN = 0, pN = 1;
     for (int d = 0; d < 3; ++d) {
@@ -406,12 +408,113 @@ static int build_bn_chain(pib_solver *s, int dim, const int64_t n[3], const doub
     return err;
 }
 
+static int bn_register_preconditioner(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);
+
+// Several ranks (z-slabs; y in 2-D).  A row of D BN G reaches `order` planes along the slab axis, so a rank runs the
+// chain above on a WINDOW of the mesh -- its planes and order + 1 more on either side (across the seam of a periodic
+// slab axis), a one-rank problem in a scratch solver -- and keeps its own rows: the operators of the chain are made of the
+// cell widths and of the whole mesh's coordinates (MeshWindow), every product row is accumulated in the order of the
+// whole matrix's row (the window's numbering is monotone in the global one inside a row's reach), so the kept rows carry
+// the entries of the one-rank matrix bit for bit -- next to the seam of a periodic slab axis, where the wrapped
+// neighbours come first instead of last, to rounding; what the window's artificial ends spoil stays within `order` planes
+// of them.  The rows go through the setMatrix route (upload_csr: ghost columns `order` planes deep, ring across a seam).
+static int assemble_poisson_bn_slab(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
+                                    const double mx[3], const double a0[18], double dt, double coeff_nu, int order, int nullspace)
+{
+    const int P = s->comm.nranks, rank = s->comm.rank, sd = dim - 1;
+    const int64_t nz = n[sd], H = order + 1;
+    const bool wrap = s->periodic[sd] != 0;
+    // (the same verdict on every rank: nobody is left waiting in a collective)
+    if (nz / P < order) return fail(PIB_ERR_SUP, "BN order %d on %d ranks: slabs of %lld planes are thinner than the operator's reach", order, P, (long long)(nz / P));
+    if (wrap && (nz + P - 1) / P + 2 * H > nz) return fail(PIB_ERR_SUP, "BN order %d on %d ranks: the periodic slab axis (%lld planes) is too short for the windows", order, P, (long long)nz);
+    int64_t k0 = 0, k1 = 0;
+    slab_range(nz, P, rank, &k0, &k1);
+    int64_t K0 = k0 - H, K1 = k1 + H;
+    if (!wrap) {
+        K0 = std::max<int64_t>(K0, 0);
+        K1 = std::min<int64_t>(K1, nz);
+    }
+    auto plane_of = [&](int64_t kl) { return ((K0 + kl) % nz + nz) % nz; };
+    int64_t nwin[3] = {1, 1, 1}, pl = 1;
+    for (int d = 0; d < dim; ++d) nwin[d] = n[d];
+    nwin[sd] = K1 - K0;
+    for (int d = 0; d < sd; ++d) pl *= n[d];
+    std::vector<double> ww((size_t)(K1 - K0));
+    for (int64_t q = 0; q < K1 - K0; ++q) ww[(size_t)q] = w[sd][plane_of(q)];
+    const double *wwin[3] = {w[0], w[1], w[2]};
+    wwin[sd] = ww.data();
+    double mnw[3] = {mn[0], mn[1], mn[2]}, mxw[3] = {mx[0], mx[1], mx[2]}, a0w[18];
+    if (wrap || K1 < nz) {  // (an end of the whole mesh keeps its coordinate: the wall's ghost point is made of it)
+        mxw[sd] = mnw[sd];
+        for (double v : ww) mxw[sd] += v;
+    }
+    std::memcpy(a0w, a0, sizeof a0w);
+    for (int f = 0; f < 3; ++f) {
+        if (wrap || K0 > 0) a0w[6 * f + 2 * sd] = 0.0;      // an artificial end: its rows are not kept
+        if (wrap || K1 < nz) a0w[6 * f + 2 * sd + 1] = 0.0;
+    }
+    pib_solver *t = nullptr;
+    PIB_CHK(pib_create_from_string(&t, "velocity", "", 0, 1, nullptr, s->device));
+    for (int d = 0; d < 3; ++d) t->periodic[d] = (d == sd) ? 0 : s->periodic[d];
+    t->mesh_window.active = true;
+    t->mesh_window.axis = sd;
+    t->mesh_window.first = K0;
+    t->mesh_window.n_global = nz;
+    t->mesh_window.w_global = w[sd];
+    t->mesh_window.lo = mn[sd];
+    t->mesh_window.hi = mx[sd];
+    Csr32 BNG, DBNG;
+    std::vector<int32_t> hrp, hcl;
+    std::vector<double> hv;
+    const int64_t r0 = (k0 - K0) * pl, nloc = (k1 - k0) * pl;
+    auto run = [&]() -> int {
+        PIB_CHK(build_bn_chain(t, dim, nwin, wwin, mnw, mxw, a0w, dt, coeff_nu, order, &BNG, &DBNG));
+        hipStream_t q = t->stream;
+        if (nullspace == PIB_NULLSPACE_PINNED) {
+            int64_t pin = -1;  // row 0 of the whole matrix, if the window holds it
+            for (int64_t kl = 0; kl < K1 - K0; ++kl)
+                if (plane_of(kl) == 0) pin = kl * pl;
+            hipLaunchKernelGGL(k_bn_pin, dim3((unsigned)std::min<int64_t>(8192, (DBNG.nrows + 255) / 256)), dim3(256), 0, q, DBNG.nrows,
+                               DBNG.rowptr, DBNG.col, DBNG.val, pin);
+            PIB_HIP(hipGetLastError());
+        }
+        hrp.resize((size_t)nloc + 1);
+        PIB_HIP(hipMemcpyAsync(hrp.data(), DBNG.rowptr + r0, sizeof(int32_t) * ((size_t)nloc + 1), hipMemcpyDeviceToHost, q));
+        PIB_HIP(hipStreamSynchronize(q));
+        const int64_t p0 = hrp[0], nnz = hrp[(size_t)nloc] - p0;
+        hcl.resize((size_t)std::max<int64_t>(nnz, 1));
+        hv.resize((size_t)std::max<int64_t>(nnz, 1));
+        PIB_HIP(hipMemcpyAsync(hcl.data(), DBNG.col + p0, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, q));
+        PIB_HIP(hipMemcpyAsync(hv.data(), DBNG.val + p0, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, q));
+        PIB_HIP(hipStreamSynchronize(q));
+        return 0;
+    };
+    int err = run();
+    BNG.release();
+    DBNG.release();
+    (void)pib_destroy(t);
+    if (err) return err;
+    int64_t pN = pl * nz;
+    std::vector<int64_t> grp((size_t)nloc + 1), gcl(hcl.size());
+    for (int64_t i = 0; i <= nloc; ++i) grp[(size_t)i] = (int64_t)hrp[(size_t)i] - hrp[0];
+    for (int64_t p = 0; p < grp[(size_t)nloc]; ++p) {
+        const int64_t c = hcl[(size_t)p];
+        gcl[(size_t)p] = plane_of(c / pl) * pl + c % pl;
+    }
+    PIB_CHK(upload_csr(s, nloc, k0 * pl, pN, grp.data(), gcl.data(), nullptr, nullptr, hv.data()));
+    PIB_CHK(after_set_matrix(s));
+    return bn_register_preconditioner(s, dim, n, w, dt, nullspace);
+}
+
 int assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
                         const double mx[3], const double a0[18], double dt, double coeff_nu, int order, int nullspace,
                         int32_t **bng_rowptr, int32_t **bng_col, double **bng_val, int64_t *bng_nnz)
 {
     if (order < 1) return fail(PIB_ERR_SUP, "The order of Bn can not be smaller than 1.");  // createbn.cpp:27-29 (error 56)
-    if (s->comm.nranks > 1) return fail(PIB_ERR_SUP, "BN order > 1 is assembled on one rank only");
+    if (s->comm.nranks > 1) {
+        if (bng_rowptr) return fail(PIB_ERR_SUP, "BN order > 1: the projection's BNG is assembled on one rank only");
+        return assemble_poisson_bn_slab(s, dim, n, w, mn, mx, a0, dt, coeff_nu, order, nullspace);
+    }
     Csr32 BNG, DBNG;
     int err = build_bn_chain(s, dim, n, w, mn, mx, a0, dt, coeff_nu, order, &BNG, &DBNG);
     if (err) {
@@ -422,7 +525,7 @@ int assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double
     hipStream_t q = s->stream;
     if (nullspace == PIB_NULLSPACE_PINNED) {
         hipLaunchKernelGGL(k_bn_pin, dim3((unsigned)std::min<int64_t>(8192, (DBNG.nrows + 255) / 256)), dim3(256), 0, q, DBNG.nrows,
-                           DBNG.rowptr, DBNG.col, DBNG.val);
+                           DBNG.rowptr, DBNG.col, DBNG.val, (int64_t)0);
         PIB_HIP(hipGetLastError());
         PIB_HIP(hipStreamSynchronize(q));
     }
@@ -436,7 +539,13 @@ int assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double
     } else
         BNG.release();
     if (err) return err;
-    // the multigrid of the N = 1 operator as preconditioner: structure from the widths, not verified against the CSR
+    return bn_register_preconditioner(s, dim, n, w, dt, nullspace);
+}
+
+// the multigrid of the N = 1 operator as preconditioner: structure from the widths, not verified against the CSR
+static int bn_register_preconditioner(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace)
+{
+    int err = 0;
     std::vector<double> hw[3], hg[3];
     for (int d = 0; d < 3; ++d) {
         const int64_t nd = (d < dim) ? n[d] : 1;

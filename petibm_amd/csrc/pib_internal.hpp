@@ -222,6 +222,17 @@ struct VelStencil {
 
 }  // namespace pib
 
+// a window of the mesh along one axis (bn.hip on slabs): the coordinates are those of the whole mesh -- running sums from
+// its first cell, the Laplacian's coefficients are made of their differences -- at planes first .. first + n[axis] - 1
+// (taken modulo n_global across a periodic seam, shifted by the period)
+struct MeshWindow {
+    bool active = false;
+    int axis = 0;
+    int64_t first = 0, n_global = 0;
+    const double *w_global = nullptr;
+    double lo = 0.0, hi = 0.0;  // ends of the whole mesh along the axis
+};
+
 struct pib_solver {
     std::string name, cfg_path, type_string;
     pib::Config cfg;
@@ -246,6 +257,7 @@ struct pib_solver {
     int (*post_matmult)(pib_solver *s, const double *p, double *w, bool guarded, hipStream_t q, void *ctx) = nullptr;
     void *post_ctx = nullptr;
     bool structure_detected = false;         // the grid structure was recovered from the CSR itself (structure.cpp)
+    MeshWindow mesh_window;                  // scratch solver of a slab's BN chain: the mesh is a window of the whole one
     bool hint_pc_only = false;               // the grid structure describes the preconditioner's operator only (BN order > 1)
     std::vector<double> asm_w[3], asm_g[3];  // 1-D arrays of the last on-device assembly
     double asm_dt = 0.0;
@@ -343,7 +355,8 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
                const int64_t *col, const int32_t *rowptr32, const int32_t *col32, const double *val);
 void slab_range(int64_t nplanes, int nranks, int rank, int64_t *b, int64_t *e);
 void velocity_mesh_arrays(int dim, const int64_t n[3], const double *const w[3], const double mn[3], const double mx[3],
-                          const int per[3], std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3]);
+                          const int per[3], std::vector<double> hdl[3][3], std::vector<double> hco[3][3], int64_t fn[3][3],
+                          const MeshWindow *win = nullptr);
 int upload_vec(const std::vector<double> &h, double **d);
 // structure.cpp
 int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,

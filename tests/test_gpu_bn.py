@@ -113,3 +113,71 @@ def test_time_step_with_bn_order_matches_oracle(case, order):
         dp = (p - p.mean()) - (ref.p - ref.p.mean())
         assert np.abs(dp).max() <= 1e-8 * np.abs(ref.p - ref.p.mean()).max()
     s.destroy()
+
+
+@pytest.mark.parametrize("P,case,order,pinned", [(2, "3d", 2, False), (3, "3d", 3, True), (2, "2d", 2, True), (4, "2d", 3, False),
+                                                 (2, "3d_periodic", 2, False), (3, "3d_periodic", 2, True), (2, "2d_periodic_y", 3, False)])
+def test_bn_poisson_operator_on_slabs(lin, P, case, order, pinned):
+    """SURVEY.md 8e for BN order > 1: every rank runs the product chain on a window of the mesh around its planes and keeps
+    its rows (bn.hip: assemble_poisson_bn_slab); the ghost columns reach `order` planes into the neighbours, across the seam
+    of a periodic slab axis through the ring.  Rows against the oracle's one-rank chain -- bit for bit, to rounding next to a
+    periodic seam -- and the solve on the ranks against the one-rank solve."""
+    from petibm_amd import capi, partition
+    from test_gpu_multirank_loopback import _run_ranks
+    cfg = {"3d": stretched_3d((8, 7, 13)), "2d": omesh.uniform_config((14, 17)),
+           "3d_periodic": omesh.periodic_config((6, 5, 16), (True, False, True)),
+           "2d_periodic_y": omesh.periodic_config((10, 18), (False, True), ratios=(1.07, 1.0))}[case]
+    m = omesh.create_mesh(cfg)
+    per = [bool(m.periodic[0][d]) for d in range(m.dim)]
+    dt, cnu = 0.0125, 0.5 * 0.02
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, cnu, bn_order=order)
+    if pinned:
+        A = oops.pin_row0(A)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    null = capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT
+    pl = int(np.prod(n[:-1]))
+    xs, b = rhs_for(A)
+
+    def rank_fn(r, uid):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(), rank=r, nranks=P, uid=uid, device=0)
+        s.setPeriodic(per)
+        s.assemblePoissonBN(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu, order, null)
+        k0, k1 = partition.slab_range(n[-1], P, r)
+        assert s.n_local == (k1 - k0) * pl
+        csr = s.getCSR()
+        x = np.zeros(s.n_local)
+        s.solve(x, np.ascontiguousarray(b[k0 * pl: k1 * pl]))
+        out = csr, x, s.getIters(), s.getReason()
+        s.destroy()
+        return out
+
+    res = _run_ranks(P, rank_fn)
+    seam = per[-1]
+    x = np.concatenate([q[1] for q in res])
+    row = 0
+    for (rp, cl, vl), _, _, reason in res:
+        assert reason > 0
+        for i in range(rp.size - 1):
+            c, v = cl[rp[i]: rp[i + 1]] % A.n_rows, vl[rp[i]: rp[i + 1]]
+            o = np.argsort(c, kind="stable")
+            a0_, a1_ = A.rowptr[row], A.rowptr[row + 1]
+            assert np.array_equal(c[o], A.col[a0_:a1_])
+            if seam:
+                assert np.allclose(v[o], A.val[a0_:a1_], rtol=1e-13, atol=1e-13 * np.abs(A.val[a0_:a1_]).max())
+            else:
+                assert np.array_equal(v[o], A.val[a0_:a1_])
+            row += 1
+    assert row == A.n_rows
+    assert len({q[2] for q in res}) == 1
+    s1 = lin.LinSolverHIP("poisson", config_text=gmg_cfg())
+    s1.setPeriodic(per)
+    s1.assemblePoissonBN(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu, order, null)
+    x1 = np.zeros(A.n_rows)
+    s1.solve(x1, b)
+    assert abs(res[0][2] - s1.getIters()) <= 3
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 2e-10 * np.linalg.norm(b)
+    e = (x - x.mean()) - (x1 - x1.mean()) if not pinned else x - x1
+    assert np.linalg.norm(e) <= 1e-7 * np.linalg.norm(x1)
+    s1.destroy()
