@@ -1,0 +1,197 @@
+"""Seeded sweep over meshes and boundary sets the hand-written cases do not list ("edge cases the reference
+tests" -- one to three sub-domains per direction with their own stretching ratios, three to a dozen cells, walls / sliding
+walls / zero-gradient tangential components / a convective outlet / periodic directions in any combination, 2-D and 3-D):
+the assembled Poisson and velocity operators bit for bit against the oracle's restatement of createDivergence /
+createGradient / createLaplacian, and two time steps of NavierStokesSolver::advance against the oracle's."""
+import numpy as np
+import pytest
+
+from oracle import clib, mesh as omesh, navierstokes as ons, operators as oops
+from test_gpu_navierstokes import AMGX_P, KSP_P, VEL
+from test_gpu_parity import _a0_table, amgx_cfg
+
+pytestmark = pytest.mark.gpu
+NAMES = "xyz"
+
+
+def random_config(seed):
+    rng = np.random.default_rng(1000 + seed)
+    dim = 2 if seed % 3 else 3
+    comps = ["u", "v", "w"][:dim]
+    mesh, periodic = [], []
+    for d in range(dim):
+        nsub = int(rng.integers(1, 4))
+        cells = [int(rng.integers(1, 5)) for _ in range(nsub)]
+        while sum(cells) < 4:
+            cells[int(rng.integers(0, nsub))] += 1
+        start = float(rng.uniform(-1.0, 0.5))
+        end, subs = start, []
+        for c in cells:
+            end += float(rng.uniform(0.3, 1.2))
+            subs.append({"end": end, "cells": c, "stretchRatio": float(rng.choice([1.0, 1.0, 1.07, 0.9, 1.3, 0.75]))})
+        mesh.append({"direction": NAMES[d], "start": start, "subDomains": subs})
+        periodic.append(bool(rng.uniform() < 0.3))
+    stream = int(rng.integers(0, dim)) if rng.uniform() < 0.35 else -1
+    if stream >= 0:
+        periodic[stream] = False
+    bcs = []
+    for d in range(dim):
+        for side, loc in enumerate((NAMES[d] + "Minus", NAMES[d] + "Plus")):
+            bc = {"location": loc}
+            kind = "periodic" if periodic[d] else str(rng.choice(["wall", "sliding", "zero_gradient"]))
+            for f, c in enumerate(comps):
+                if kind == "periodic":
+                    bc[c] = ["PERIODIC", 0.0]
+                elif stream >= 0 and d == stream and side == 1:
+                    bc[c] = ["CONVECTIVE", 1.0]           # the outlet of the cylinder cases
+                elif stream >= 0:
+                    bc[c] = ["DIRICHLET", 1.0 if f == stream else 0.0]  # inflow and free stream
+                elif f == d:
+                    bc[c] = ["DIRICHLET", 0.0]            # no flow through a wall (a normal NEUMANN changes D: PIB_ERR_SUP)
+                elif kind == "sliding":
+                    bc[c] = ["DIRICHLET", float(rng.uniform(-0.5, 0.5))]
+                elif kind == "zero_gradient":
+                    bc[c] = ["NEUMANN", float(rng.uniform(-0.05, 0.05))]
+                else:
+                    bc[c] = ["DIRICHLET", 0.0]
+            bcs.append(bc)
+    cfg = {"mesh": mesh, "flow": {"nu": float(rng.choice([0.01, 0.05])), "boundaryConditions": bcs},
+           "parameters": {"dt": float(rng.choice([0.004, 0.01])), "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}}
+    return cfg, periodic, stream
+
+
+SEEDS = list(range(24))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_mesh_operators_bit_exact(seed):
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    cfg, per, _ = random_config(seed)
+    m = omesh.create_mesh(cfg)
+    dt, cnu = cfg["parameters"]["dt"], 0.5 * cfg["flow"]["nu"]
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, cnu, bn_order=1)
+    pinned = bool(seed % 2)
+    if pinned:
+        A = oops.pin_row0(A)
+    s = LinSolverHIP("poisson", config_text=amgx_cfg())
+    s.setPeriodic(per)
+    s.assemblePoisson(n, w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+    rp, cl, vl = s.getCSR()
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(cl, A.col) and np.array_equal(vl, A.val)
+    x = np.random.default_rng(seed).uniform(-1, 1, A.n_rows)
+    y = np.empty_like(x)
+    s.matMult(x, y)
+    assert np.array_equal(y, clib.spmv(A, x))
+    s.destroy()
+    V = oops.create_velocity_operator(L, dt, cnu)
+    s = LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500))
+    s.setPeriodic(per)
+    s.assembleVelocity(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
+    rp, cl, vl = s.getCSR()
+    assert np.array_equal(rp, V.rowptr) and np.array_equal(cl, V.col) and np.array_equal(vl, V.val)
+    us = np.random.default_rng(seed + 1).uniform(-1, 1, V.n_rows)
+    b = clib.spmv(V, us)
+    for free in (1, 0):  # the products of the solve from the mesh tables, then from the CSR: same iterates
+        t = LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500)
+                         + f"pib_matrix_free_velocity={free}\npib_lean_bicgstab=0\n")
+        t.setPeriodic(per)
+        t.assembleVelocity(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
+        xv = np.zeros(V.n_rows)
+        t.solve(xv, b)
+        if free:
+            x_free, it_free = xv, t.getIters()
+        else:
+            assert t.getIters() == it_free and np.array_equal(xv, x_free)
+        t.destroy()
+    assert np.linalg.norm(x_free - us) <= 1e-9 * np.linalg.norm(us)
+    s.destroy()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_mesh_time_steps_match_oracle(seed):
+    from petibm_amd.navierstokes import NavierStokesSolver
+    cfg, per, stream = random_config(seed)
+    m = omesh.create_mesh(cfg)
+    dt, nu = cfg["parameters"]["dt"], cfg["flow"]["nu"]
+    pinned = bool(seed % 2) or stream >= 0  # (an outlet's net flux makes rhs2 incompatible with the constant null space)
+    ref = ons.NavierStokes(m, dt, nu, pinned=pinned, vtol=1e-14, ptol=1e-13)
+    rng = np.random.default_rng(77 + seed)
+    U0, p0 = 0.1 * rng.uniform(-1, 1, m.UN), 0.1 * rng.uniform(-1, 1, m.pN)
+    if stream >= 0:
+        off = sum(int(np.prod(m.n[f])) for f in range(stream))
+        U0[off: off + int(np.prod(m.n[stream]))] += 1.0
+    if pinned:
+        p0[0] = 0.0
+    ref.set_state(U0, p0)
+    s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=AMGX_P if pinned else KSP_P)
+    assert (s.UN, s.pN) == (m.UN, m.pN)
+    s.setState(U0, p0)
+    for step in range(2):
+        ref.advance()
+        s.advance()
+        U, p, r1, r2 = s.getState(rhs=True)
+        scale = np.abs(ref.last_rhs1).max()
+        if step == 0 and not any(per):
+            assert np.array_equal(r1, ref.last_rhs1)
+        assert np.abs(r1 - ref.last_rhs1).max() <= 1e-9 * scale
+        assert np.abs(r2 - ref.last_rhs2).max() <= 1e-9 * max(np.abs(ref.last_rhs2).max(), 1e-30) + 1e-14
+        assert np.abs(U - ref.U).max() <= 1e-9 * np.abs(ref.U).max()
+        dp = (p - p.mean()) - (ref.p - ref.p.mean())
+        assert np.abs(dp).max() <= 1e-8 * max(np.abs(ref.p - ref.p.mean()).max(), 1e-30)
+    s.destroy()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_mesh_time_steps_on_slabs(seed):
+    """The same configurations on 2 or 3 slabs (loopback ranks on the one GPU) against the single-rank engine: rhs1 of the
+    first step bit for bit (to rounding with a periodic direction), the fields after two steps to the solver tolerance."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    from test_gpu_multirank_loopback import _run_ranks
+    cfg, per, stream = random_config(seed)
+    m = omesh.create_mesh(cfg)
+    P = 2 if int(m.n[3][m.dim - 1]) < 6 or seed % 2 else 3
+    pinned = bool(seed % 2) or stream >= 0
+    pcfg = AMGX_P if pinned else KSP_P
+    one = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=pcfg)
+    rng = np.random.default_rng(77 + seed)
+    U0, p0 = 0.1 * rng.uniform(-1, 1, m.UN), 0.1 * rng.uniform(-1, 1, m.pN)
+    if stream >= 0:
+        off = sum(int(np.prod(m.n[f])) for f in range(stream))
+        U0[off: off + int(np.prod(m.n[stream]))] += 1.0
+    if pinned:
+        p0[0] = 0.0
+    one.setState(U0, p0)
+    one.advance(1)
+    _, _, rhs1, rhs2 = one.getState(rhs=True)
+    one.advance(1)
+    U2, p2 = one.getState()
+
+    def rank_fn(r, uid):
+        s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=pcfg, device=0, rank=r, nranks=P, uid=uid)
+        s.setState(s.ownedVelocity(U0), s.ownedPressure(p0))
+        s.advance(1)
+        a = s.getState(rhs=True)
+        s.advance(1)
+        b = s.getState()
+        cut = [s.ownedVelocity(x) for x in (rhs1, U2)] + [s.ownedPressure(x) for x in (rhs2, p2)]
+        s.destroy()
+        return a, b, cut
+
+    res = _run_ranks(P, rank_fn)
+    for (_, _, r1, r2), (Ub, pb), (crhs1, cU2, crhs2, cp2) in res:
+        if any(per):
+            assert np.abs(r1 - crhs1).max() <= 1e-13 * np.abs(rhs1).max()
+        else:
+            assert np.array_equal(r1, crhs1)
+        assert np.allclose(r2, crhs2, rtol=0, atol=1e-11 * max(1.0, np.abs(rhs2).max()))
+        assert np.allclose(Ub, cU2, rtol=0, atol=1e-9 * max(1.0, np.abs(U2).max()))
+        if pinned:
+            assert np.allclose(pb, cp2, rtol=0, atol=1e-8 * max(1.0, np.abs(p2).max()))
+    if not pinned:
+        pg = np.concatenate([r[1][1] for r in res])
+        assert np.allclose(pg - pg.mean(), p2 - p2.mean(), rtol=0, atol=1e-8 * max(1.0, np.abs(p2).max()))
+    one.destroy()
