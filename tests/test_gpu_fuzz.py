@@ -195,3 +195,41 @@ def test_random_mesh_time_steps_on_slabs(seed):
         pg = np.concatenate([r[1][1] for r in res])
         assert np.allclose(pg - pg.mean(), p2 - p2.mean(), rtol=0, atol=1e-8 * max(1.0, np.abs(p2).max()))
     one.destroy()
+
+
+@pytest.mark.parametrize("seed", SEEDS[:16])
+def test_random_bodies_ib_operators_bit_identical(seed):
+    """Immersed-boundary operators (createDelta / E / H / E BN H, src/operators/createdelta.cpp:34-208) for random
+    Lagrangian points on the random meshes: anywhere in the box -- next to walls (clipped supports), across periodic
+    seams, in the stretched regions -- with either kernel."""
+    from oracle import ibm
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    from test_gpu_ibm import AMGX_P as IB_P
+    # (an iterative forces solver without a preconditioner: random points closer than a cell make E BN H singular -- a zero
+    # pivot for the direct solver -- and a point whose support holds no point of a component has a zero diagonal entry)
+    FORCES = "-forces_ksp_type cg\n-forces_pc_type none\n-forces_ksp_atol 1.0E-12\n-forces_ksp_rtol 0.0\n"
+    cfg, per, stream = random_config(seed)
+    rng = np.random.default_rng(500 + seed)
+    kernel = "PESKIN_2002" if seed % 2 else "ROMA_ET_AL_1999"
+    cfg["parameters"]["delta"] = kernel
+    m = omesh.create_mesh(cfg)
+    lo, hi = np.array(m.min[: m.dim]), np.array(m.max[: m.dim])
+    bodies = []
+    for _ in range(int(rng.integers(1, 3))):
+        npts = int(rng.integers(3, 20))
+        bodies.append(lo + (hi - lo) * rng.uniform(0.02, 0.98, (npts, m.dim)))
+    dt = cfg["parameters"]["dt"]
+    ref = ibm.create_ib_operators(m, bodies, dt, kernel)
+    s = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=IB_P.format(tol=1e-12), forces_cfg=FORCES)
+    assert s.nf == ref["E"].n_rows
+    for name in ("delta", "E", "EBNH"):
+        nr, rp, cl, vl = s.getOperator(name)
+        r = ref[name]
+        assert nr == r.n_rows and np.array_equal(rp, r.rowptr) and np.array_equal(cl, r.col), name
+        assert np.array_equal(vl, r.val), name
+    nr, rp, cl, vl, ids = s.getOperator("H")
+    H = ref["H"]
+    live = np.flatnonzero(np.diff(H.rowptr))
+    assert np.array_equal(ids, live) and np.array_equal(rp, H.rowptr[np.append(live, H.n_rows)])
+    assert np.array_equal(cl, H.col) and np.array_equal(vl, H.val)
+    s.destroy()
