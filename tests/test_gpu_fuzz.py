@@ -233,3 +233,56 @@ def test_random_bodies_ib_operators_bit_identical(seed):
     assert np.array_equal(ids, live) and np.array_equal(rp, H.rowptr[np.append(live, H.n_rows)])
     assert np.array_equal(cl, H.col) and np.array_equal(vl, H.val)
     s.destroy()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_mesh_drop_in_route_recovers_the_structure(seed):
+    """Nothing but setMatrix (an unchanged PetIBM: linsolveramgx.cpp:84, navierstokes.cpp:345, 357): the mesh structure of
+    the oracle's Poisson matrix -- sizes, periodic directions, null-space convention -- and of its velocity matrix come out
+    of the entries, or the matrix is left to the CSR kernels; either way the solves meet the residual contract."""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    cfg, per, _ = random_config(seed)
+    m = omesh.create_mesh(cfg)
+    dt, cnu = cfg["parameters"]["dt"], 0.5 * cfg["flow"]["nu"]
+    n = tuple(int(v) for v in m.n[3][: m.dim])
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, cnu, bn_order=1)
+    pinned = bool(seed % 2)
+    if pinned:
+        A = oops.pin_row0(A)
+    xs = np.random.default_rng(seed).uniform(-1, 1, A.n_rows)
+    if pinned:
+        xs[0] = 0.0
+    else:
+        xs -= xs.mean()
+    b = clib.spmv(A, xs)
+    amg = "prec:cycle=V\nprec:presweeps=1\nprec:postsweeps=1\nprec:smoother(smooth)=BLOCK_JACOBI\nsmooth:relaxation_factor=0.9\n"
+    s = LinSolverHIP("poisson", config_text=amgx_cfg(pc="AMG", tol=1e-10, extra=amg + "pib_initial_guess_nonzero=0\n"))
+    s.setMatrix(A)
+    st = s.gridStructure()
+    assert st is not None and st["detected"], "an operator assembled by createDivergence / createGradient must be recognised"
+    assert st["dim"] == m.dim and tuple(st["n"]) == n
+    assert st["nullspace"] == (capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    assert s.getReason() > 0 and s.getIters() <= 40
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    s.destroy()
+    V = oops.create_velocity_operator(L, dt, cnu)
+    bv = np.random.default_rng(seed + 3).uniform(-1, 1, V.n_rows)
+    out = []
+    for mf in (1, 0):
+        t = LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500,
+                                                          extra=f"pib_matrix_free_velocity={mf}\n"))
+        t.setMatrix(V)
+        sv = t.velocityStructure()
+        if mf and sv is not None:
+            assert sv["detected"] and sv["dim"] == m.dim and sv["n"] == n and sv["periodic"] == tuple(per)
+        xv = np.zeros(V.n_rows)
+        t.solve(xv, bv)
+        out.append((xv, t.getIters(), sv is not None))
+        t.destroy()
+    assert out[0][1] == out[1][1]
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * np.abs(out[1][0]).max()
+    assert np.linalg.norm(bv - clib.spmv(V, out[0][0])) <= 1e-11 * np.linalg.norm(bv)
