@@ -286,3 +286,51 @@ def test_random_mesh_drop_in_route_recovers_the_structure(seed):
     assert out[0][1] == out[1][1]
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * np.abs(out[1][0]).max()
     assert np.linalg.norm(bv - clib.spmv(V, out[0][0])) <= 1e-11 * np.linalg.norm(bv)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_mesh_drop_in_route_on_slabs(seed):
+    """The same on 2 or 3 ranks: every rank hands over its rows (MatMPIAIJGetLocalMat layout, global columns -- across the
+    seam of a periodic slab axis too); the structure is gathered from the ranks' lines of entries."""
+    from petibm_amd import capi, partition
+    from petibm_amd.linsolver import LinSolverHIP
+    from test_gpu_multirank_loopback import _cfg, _run_ranks
+    cfg, per, _ = random_config(seed)
+    m = omesh.create_mesh(cfg)
+    dt, cnu = cfg["parameters"]["dt"], 0.5 * cfg["flow"]["nu"]
+    n = tuple(int(v) for v in m.n[3][: m.dim])
+    P = 2 if n[-1] < 6 or seed % 2 else 3
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, cnu, bn_order=1)
+    pinned = bool(seed % 2)
+    if pinned:
+        A = oops.pin_row0(A)
+    xs = np.random.default_rng(seed).uniform(-1, 1, A.n_rows)
+    if pinned:
+        xs[0] = 0.0
+    else:
+        xs -= xs.mean()
+    b = clib.spmv(A, xs)
+    plans = partition.all_plans(n, P)
+
+    def rank_fn(r, uid):
+        pl = plans[r]
+        s = LinSolverHIP("poisson", config_text=_cfg("AMG", tol=1e-11), rank=r, nranks=P, uid=uid, device=0)
+        r0, r1 = pl.row0, pl.row0 + pl.n_local
+        p0, p1 = A.rowptr[r0], A.rowptr[r1]
+        local = oops.CSR(pl.n_local, A.n_cols, A.rowptr[r0:r1 + 1] - p0, A.col[p0:p1], A.val[p0:p1])
+        s.setMatrix(local, row0=r0, n_global=A.n_rows)
+        st = s.gridStructure()
+        x = np.zeros(pl.n_local)
+        s.solve(x, np.ascontiguousarray(b[r0:r1]))
+        out = x, s.getIters(), st, s.getReason()
+        s.destroy()
+        return out
+
+    res = _run_ranks(P, rank_fn)
+    for r in res:
+        assert r[3] > 0 and r[2] is not None and r[2]["detected"] and tuple(r[2]["n"]) == n
+        assert r[2]["nullspace"] == (capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+    x = np.concatenate([r[0] for r in res])
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-11 * np.linalg.norm(b)
+    assert len({r[1] for r in res}) == 1 and res[0][1] < 60
