@@ -34,7 +34,10 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
               bool guarded, hipStream_t st);
 int spmv_launch_blocks();
 
-constexpr int VGRID_MAX = 2048;
+#ifndef PIB_VGRID_MAX
+#define PIB_VGRID_MAX 2048
+#endif
+constexpr int VGRID_MAX = PIB_VGRID_MAX;
 
 __device__ __forceinline__ double wsum(double v)
 {
