@@ -185,6 +185,10 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str 
     rp_bytes = 8 if s.nnz >= 2 ** 31 - 1 else 4
     alg_csr = 12.0 * s.nnz + rp_bytes * (UN + 1) + 16.0 * UN
     alg_free = 16.0 * UN  # x read once, y written once; tables are 1-D (reported apart from the CSR figure)
+    # velstencil.hip vel_stencil_apply: components of >= 4 M points with lines of >= 127 take the one-launch marching form
+    vel_kernel = ("pib::k_vel_product<0> (LDS-tiled march of the three components + their boundary shells in one launch: the product BiCGStab runs)"
+                  if n ** 3 >= (1 << 22) and n >= 128 and "pib_fuse_velocity_product=0" not in extra and "pib_march_velocity=0" not in extra
+                  else "pib::k_vel_interior4<3> / k_vel_march + k_vel_shell x 3 components (the products BiCGStab runs)")
     out = {
         "metric": "velocity-system DOF/s (BiCGStab+Jacobi to |r| <= 1e-10)", "value": UN * steps / el,
         "unit": "DOF/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps, "dtype": "f64",
@@ -192,7 +196,7 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str 
                                f"{8 * rp_bytes}-bit row offsets, random u*"},
         "iters_per_solve": its / steps, "final_residual": s.getResidual(), "true_abs_residual": float(np.sqrt(res)),
         "setup_s": t_setup,
-        "roofline": {"bound": "hbm", "kernel": "pib::k_vel_interior4<3> + k_vel_shell x 3 components (the products BiCGStab runs)",
+        "roofline": {"bound": "hbm", "kernel": vel_kernel,
                      "achieved": alg_free / ms_free / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_free / ms_free / 1e6 / HBM_PEAK_GBS, "ms_per_launch": ms_free, "algorithmic_bytes": alg_free,
                      "traffic": None},
