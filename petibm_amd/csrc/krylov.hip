@@ -1009,9 +1009,13 @@ struct OpBUpdateX {  // x += alpha ph + omega sh ; r = s - omega t ; partials |r
 // v.rp and s.t, t.t themselves (two passes less, 184 B/row/iteration): those sums are grouped by tile, so alpha and omega
 // agree with the general path's to rounding only.
 struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*beta) v + beta p
+    // y != nullptr: the owed update goes into y += xalpha p + xomega s instead -- the sum of the search directions BEFORE the
+    // (stationary) Jacobi sweep, x = x0 + M^-1 y once at the end (k_b_flush_x) -- which takes the dinv and x streams out
+    // of this pass: 56 instead of 64 B/row.  x then differs from the general path's by rounding (the residual recurrence
+    // does not see x), so this rides with the fused sums (`pib_fuse_bicgstab_dots`), not with the bit-identical route.
     static constexpr int NRED = 0;
     const double *r, *v, *dinv, *sv;
-    double *p, *x;
+    double *p, *x, *y;
     double omega_pc;
     double beta, ob, xa, xo;
     int pend;
@@ -1027,7 +1031,12 @@ struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*b
     __device__ void apply(int64_t i, double (&)[1]) const
     {
         Pack<W> vr = ld<W>(r, i), vv = ld<W>(v, i), vp = ld<W>(p, i);
-        if (pend) {
+        if (pend && y != nullptr) {
+            Pack<W> vs = ld<W>(sv, i), vy = ld<W>(y, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vy.v[k] = (vy.v[k] + xa * vp.v[k]) + xo * vs.v[k];
+            st<W>(y, i, vy);
+        } else if (pend) {
             Pack<W> vd = ld<W>(dinv, i), vs = ld<W>(sv, i), vx = ld<W>(x, i);
 #pragma unroll
             for (int k = 0; k < W; ++k) {
@@ -1061,15 +1070,22 @@ struct OpBFUpdateR {  // r = s - omega t ; partials |r|^2 (0), r.rp (1)
     }
 };
 // the x update still owed when the iteration stops
+// (y != nullptr: x = x0 + M^-1 (y + what is owed), see OpBFUpdateP)
 __global__ __launch_bounds__(256) void k_b_flush_x(Scalars *__restrict__ S, int64_t n, const double *__restrict__ p,
                                                    const double *__restrict__ sv, const double *__restrict__ dinv, double omega_pc,
-                                                   double *__restrict__ x)
+                                                   double *__restrict__ x, const double *__restrict__ y)
 {
-    if (!S->xpend) return;
+    const int pend = S->xpend;
+    if (!pend && y == nullptr) return;
     const double xa = S->xalpha, xo = S->xomega;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double ph = omega_pc * (dinv[i] * p[i]), sh = omega_pc * (dinv[i] * sv[i]);
-        x[i] = (x[i] + xa * ph) + xo * sh;
+        if (y != nullptr) {
+            const double acc = pend ? (y[i] + xa * p[i]) + xo * sv[i] : y[i];
+            x[i] = x[i] + omega_pc * (dinv[i] * acc);
+        } else {
+            const double ph = omega_pc * (dinv[i] * p[i]), sh = omega_pc * (dinv[i] * sv[i]);
+            x[i] = (x[i] + xa * ph) + xo * sh;
+        }
     }
 }
 __global__ void k_b_flush_done(Scalars *S) { S->xpend = 0; }
@@ -1271,12 +1287,18 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
                       ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(V) |
                         reinterpret_cast<uintptr_t>(T)) & 31u) == 0;
     const bool fused_dots = lean && s->cfg.fuse_bicgstab_dots;
+    // ... and x accumulated before the Jacobi sweep (OpBFUpdateP::y) in the vector the general path keeps M^-1 p in
+    double *Y = (fused_dots && s->cfg.accumulate_unscaled_x && PH != P) ? PH : nullptr;
+    if (Y != nullptr) {
+        OpFill y0{Y, 0.0};
+        PIB_CHK(launch_vec(s, n, y0, v2, 0, nullptr, false, q));
+    }
     int enq = 0;
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         auto body_lean = [&]() -> int {
-            OpBFUpdateP up{R, V, A.dinv, S, P, x, opc, 0.0, 0.0, 0.0, 0.0, 0};
+            OpBFUpdateP up{R, V, A.dinv, S, P, x, Y, opc, 0.0, 0.0, 0.0, 0.0, 0};
             PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
             if (fused_dots) {  // v = K M^-1 p and v.rp by the same kernel
                 PIB_CHK(vel_stencil_apply(s, P, V, true, q, A.dinv, opc, 1, RP, 2));
@@ -1372,7 +1394,7 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     }
     if (lean) {  // the x update the last iteration owes
         hipLaunchKernelGGL(k_b_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
-                           s->d_s, n, P, S, A.dinv, opc, x);
+                           s->d_s, n, P, S, A.dinv, opc, x, (const double *)Y);
         hipLaunchKernelGGL(k_b_flush_done, dim3(1), dim3(1), 0, q, s->d_s);
         PIB_HIP(hipGetLastError());
     }
