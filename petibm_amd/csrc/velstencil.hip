@@ -366,12 +366,30 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         vn[c] = V.lneg[f][0][ci[c]];
         vp[c] = V.lpos[f][0][ci[c]];
     }
+    // the second factor of the fused sums (V.dot_other, or the raw input) for the thread's cells of plane kp: fetched a
+    // plane ahead with the input planes -- behind the barrier it would be a load consumed at once, a memory round trip
+    // on every plane's critical path
+    const double *pbase = (acc != nullptr) ? (V.dot_mode == 1 ? V.dot_other : x) : nullptr;
+    auto loadp = [&](int kp, double (&o)[4]) {
+        const double *pl = pbase + (int64_t)kp * sz;
+        if (V4) {
+            const v4 t = *reinterpret_cast<const v4 *>(pl + row + ci[0]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = t[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = pl[row + ci[c]];
+        }
+    };
+    double pc[4] = {0.0, 0.0, 0.0, 0.0}, pn[4] = {0.0, 0.0, 0.0, 0.0};
     load4(x + (int64_t)(k0 - 1) * sz, k0 - 1, zm);
     load4(x + (int64_t)k0 * sz, k0, xc);
+    if (acc != nullptr) loadp(k0, pc);
     for (int k = k0; k < kend; ++k) {
         const int slot = k & 1;
         const double *px = x + (int64_t)k * sz;
         load4(px + sz, k + 1, zp);
+        if (acc != nullptr && k + 1 < kend) loadp(k + 1, pn);
 #pragma unroll
         for (int c = 0; c < 4; ++c) sp[slot][ty + 1][lx[c]] = xc[c];
         double hyv = hy_ok ? px[off_hy] : 0.0, hxv = hx_ok ? px[off_hx] : 0.0;
@@ -407,14 +425,11 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
             s2 = s2 + (zpos * V.scale) * zp[c];
             out[c] = s2;
         }
-        if (jin && acc != nullptr) {
-            // the stored rows only (the shell owns the others); the second factor straight from memory (an L2 hit for the
-            // raw input, which this workgroup loaded a plane ago)
-            const double *po = (V.dot_mode == 1 ? V.dot_other : x) + (int64_t)k * sz + row;
+        if (jin && acc != nullptr) {  // the stored rows only (the shell owns the others)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (cin[c]) {
-                    acc[0] += out[c] * po[ci[c]];
+                    acc[0] += out[c] * pc[c];
                     if (V.dot_mode == 2) acc[1] += out[c] * out[c];
                 }
         }
@@ -435,6 +450,7 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         for (int c = 0; c < 4; ++c) {
             zm[c] = xc[c];
             xc[c] = zp[c];
+            pc[c] = pn[c];
         }
     }
 }
