@@ -1036,6 +1036,11 @@ struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*b
 #pragma unroll
             for (int k = 0; k < W; ++k) vy.v[k] = (vy.v[k] + xa * vp.v[k]) + xo * vs.v[k];
             st<W>(y, i, vy);
+        } else if (pend && dinv == nullptr) {  // no preconditioner (NOSOLVER): ph = p, sh = s
+            Pack<W> vs = ld<W>(sv, i), vx = ld<W>(x, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vx.v[k] = (vx.v[k] + xa * vp.v[k]) + xo * vs.v[k];
+            st<W>(x, i, vx);
         } else if (pend) {
             Pack<W> vd = ld<W>(dinv, i), vs = ld<W>(sv, i), vx = ld<W>(x, i);
 #pragma unroll
@@ -1081,7 +1086,9 @@ __global__ __launch_bounds__(256) void k_b_flush_x(Scalars *__restrict__ S, int6
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (y != nullptr) {
             const double acc = pend ? (y[i] + xa * p[i]) + xo * sv[i] : y[i];
-            x[i] = x[i] + omega_pc * (dinv[i] * acc);
+            x[i] = x[i] + (dinv != nullptr ? omega_pc * (dinv[i] * acc) : acc);
+        } else if (dinv == nullptr) {
+            x[i] = (x[i] + xa * p[i]) + xo * sv[i];
         } else {
             const double ph = omega_pc * (dinv[i] * p[i]), sh = omega_pc * (dinv[i] * sv[i]);
             x[i] = (x[i] + xa * ph) + xo * sh;
@@ -1282,13 +1289,16 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     const int maxit = s->cfg.max_iters;
     const bool one_rank = s->comm.nranks == 1;
     // the matrix-free velocity operator in its one-launch form: no stored M^-1 p / M^-1 s, deferred x update (OpBFUpdateP)
-    const bool lean = jac && !left && one_rank && s->cfg.lean_bicgstab && s->vel.valid && s->cfg.matrix_free_velocity &&
+    // (also without a preconditioner -- NOSOLVER, the velocity solver file of flatplate3dRe100_GPU and multicylinders2dRe100_GPU:
+    // the sweep drops out, dv == nullptr)
+    const double *dv = jac ? A.dinv : nullptr;
+    const bool lean = (jac || pc == Precond::NONE) && !left && one_rank && s->cfg.lean_bicgstab && s->vel.valid && s->cfg.matrix_free_velocity &&
                       s->post_matmult == nullptr && vel_stencil_fused_ok(s) && aligned16(x) &&
                       ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(V) |
                         reinterpret_cast<uintptr_t>(T)) & 31u) == 0;
     const bool fused_dots = lean && s->cfg.fuse_bicgstab_dots;
     // ... and x accumulated before the Jacobi sweep (OpBFUpdateP::y) in the vector the general path keeps M^-1 p in
-    double *Y = (fused_dots && s->cfg.accumulate_unscaled_x && PH != P) ? PH : nullptr;
+    double *Y = (fused_dots && s->cfg.accumulate_unscaled_x) ? s->vec(7) : nullptr;
     if (Y != nullptr) {
         OpFill y0{Y, 0.0};
         PIB_CHK(launch_vec(s, n, y0, v2, 0, nullptr, false, q));
@@ -1298,13 +1308,13 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         auto body_lean = [&]() -> int {
-            OpBFUpdateP up{R, V, A.dinv, S, P, x, Y, opc, 0.0, 0.0, 0.0, 0.0, 0};
+            OpBFUpdateP up{R, V, dv, S, P, x, Y, opc, 0.0, 0.0, 0.0, 0.0, 0};
             PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
             if (fused_dots) {  // v = K M^-1 p and v.rp by the same kernel
-                PIB_CHK(vel_stencil_apply(s, P, V, true, q, A.dinv, opc, 1, RP, 2));
+                PIB_CHK(vel_stencil_apply(s, P, V, true, q, dv, opc, 1, RP, 2));
                 nb = VEL_DOT_PARTIALS;
             } else {
-                PIB_CHK(vel_stencil_apply(s, P, V, true, q, A.dinv, opc));  // v = K M^-1 p
+                PIB_CHK(vel_stencil_apply(s, P, V, true, q, dv, opc));  // v = K M^-1 p
                 OpBPcDot<PCM_NONE> d1{V, nullptr, RP, V, 1.0};
                 PIB_CHK(launch_vec(s, n, d1, true, 2, &nb, true, q));
             }
@@ -1312,10 +1322,10 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
             OpBUpdateS<PCM_NONE> us{R, V, nullptr, S, S, 1.0, 0, 0.0};  // s = r - alpha v
             PIB_CHK(launch_vec(s, n, us, true, 0, nullptr, true, q));
             if (fused_dots) {  // t = K M^-1 s with s.t and t.t
-                PIB_CHK(vel_stencil_apply(s, S, T, true, q, A.dinv, opc, 2, nullptr, 3));
+                PIB_CHK(vel_stencil_apply(s, S, T, true, q, dv, opc, 2, nullptr, 3));
                 nb = VEL_DOT_PARTIALS;
             } else {
-                PIB_CHK(vel_stencil_apply(s, S, T, true, q, A.dinv, opc));  // t = K M^-1 s
+                PIB_CHK(vel_stencil_apply(s, S, T, true, q, dv, opc));  // t = K M^-1 s
                 OpBPcDot2<PCM_NONE> d2{T, nullptr, S, T, 1.0, 0};
                 PIB_CHK(launch_vec(s, n, d2, true, 3, &nb, true, q));
             }
@@ -1394,7 +1404,7 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     }
     if (lean) {  // the x update the last iteration owes
         hipLaunchKernelGGL(k_b_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
-                           s->d_s, n, P, S, A.dinv, opc, x, (const double *)Y);
+                           s->d_s, n, P, S, dv, opc, x, (const double *)Y);
         hipLaunchKernelGGL(k_b_flush_done, dim3(1), dim3(1), 0, q, s->d_s);
         PIB_HIP(hipGetLastError());
     }
