@@ -7,7 +7,8 @@
 // (static bodies) and the solve must be a single short launch: setMatrix forms the explicit inverse in HBM by
 // Gauss-Jordan elimination (no pivoting: SPD / diagonally dominant matrices; a vanishing pivot is an error), one
 // launch per column (workgroup i owns row i), all of them captured once per matrix order into a hipGraph -- a moving
-// body re-factorises every time step; each launch is a rank-1 update streamed at HBM rate (n^3 * 16 B in total);
+// body re-factorises every time step; each launch is a rank-1 update streamed at HBM rate (n^3 * 16 B in total).  From
+// 128 unknowns on the elimination runs 64 columns at a time with its products on the matrix cores (k_bgj_*, below).
 // solve is one dense mat-vec, one wave per row, fixed summation order.
 #include <cmath>
 
@@ -79,6 +80,156 @@ __global__ __launch_bounds__(256) void k_gj_scale(int64_t n, const double *__res
     for (int64_t c = threadIdx.x; c < n; c += 256) Inv[i * n + c] = Inv[i * n + c] / d;
 }
 
+// ---- blocked in-place Gauss-Jordan (orders >= 2 blocks): the same elimination 64 columns at a time, so that nearly all
+// of its 2 n^3 flops are 64 x 64 x 64 products out of LDS instead of n rank-1 updates streamed through the caches
+// (n = 3456, the force system of a 1152-point plate: 3456 launches and 27 ms per factorisation before, a moving body pays
+// that every time step).  W is the matrix padded with an identity to a multiple of 64 (leading dimension np); for the
+// pivot block K:   P = inv(W_KK)   W_KJ = P W_KJ   W_IJ -= W_IK W_KJ   W_IK = -W_IK P   W_KK = P      (I, J != K)
+// and after the last block W is the inverse.  No pivoting (see above); the scalar pivots inside a block are the ones the
+// unblocked elimination meets, with the same relative test.
+constexpr int GB = 64;
+
+// P = inv(W_KK), one workgroup: scalar in-place Gauss-Jordan on the 64 x 64 block, a 4 x 4 patch per thread in registers;
+// a step's pivot row and column go through LDS (two buffers in turn: one barrier per step)
+__global__ __launch_bounds__(256) void k_bgj_diag(int64_t np, int64_t kb, double *__restrict__ W, double *__restrict__ P,
+                                                  int *__restrict__ bad, const double *__restrict__ maxdiag)
+{
+    if (*bad) return;
+    __shared__ double rowp[2][4][GB], colp[2][4][GB];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    double *blk = W + (kb + 4 * ty) * np + kb + 4 * tx;
+    double a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[r][c] = blk[(int64_t)r * np + c];
+    const double tiny = 1e-13 * *maxdiag;
+    for (int p = 0; p < GB; ++p) {
+        const int buf = p & 1, pr = p >> 2, pq = p & 3;
+        // the threads holding the pivot row (column) publish their whole patch rows (columns): the readers pick line pq
+        // (a selection among the registers here would turn the patch into an indexed array, i.e. scratch memory)
+        if (ty == pr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rowp[buf][r][4 * tx + c] = a[r][c];
+        }
+        if (tx == pr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) colp[buf][c][4 * ty + r] = a[r][c];
+        }
+        __syncthreads();
+        const double piv = rowp[buf][pq][p];
+        if (!(fabs(piv) > 1e-300) || !(fabs(piv) > tiny)) {
+            if (tid == 0) *bad = (int)(kb + p) + 1;
+            return;  // uniform: every thread reads the same pivot
+        }
+        const double d = 1.0 / piv;
+        double rs[4], f[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rs[c] = rowp[buf][pq][4 * tx + c] * d;  // the scaled pivot row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[r] = colp[buf][pq][4 * ty + r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = 4 * ty + r, j = 4 * tx + c;
+                if (i == p) a[r][c] = (j == p) ? d : rs[c];
+                else a[r][c] = (j == p) ? -f[r] * d : __builtin_fma(-f[r], rs[c], a[r][c]);
+            }
+    }
+    double *Pp = P + (4 * ty) * GB + 4 * tx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            blk[(int64_t)r * np + c] = a[r][c];
+            Pp[r * GB + c] = a[r][c];
+        }
+}
+
+// The 64 x 64 x 64 block products on the matrix cores: v_mfma_f64_16x16x4_f64, wave w of the workgroup owns rows
+// 16 w .. 16 w + 15 of the tile and its four 16 x 16 column tiles.  Operand layout (cdna_hip_programming.md): lane l feeds
+// A[row = l & 15][k' = l >> 4] and B[k' = l >> 4][col = l & 15]; of its four results, number v is C[row = (l >> 4) + 4 v][col = l & 15].
+// Which k of the product a lane group feeds in which of the 16 instructions is free as long as A and B agree: group g takes
+// k = 16 g + step, so a lane's sixteen A operands are 128 contiguous bytes of its row -- they come straight from memory
+// into registers, only B goes through LDS (an odd leading dimension spreads a wave's operand reads over the banks), and the
+// C tile of the update is fetched ahead of the products.  37 KB of LDS and ~150 registers: three workgroups per CU.
+// MODE 0: W_KJ = P W_KJ (J = blockIdx.x, J != K) ; MODE 1: W_IK = -W_IK P (I = blockIdx.x, I != K) ;
+// MODE 2: W_IJ -= W_IK W_KJ (I = blockIdx.y, J = blockIdx.x, both != K)
+constexpr int GLB = GB + 1;
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bgj_block(int64_t np, int64_t kb, double *__restrict__ W, const double *__restrict__ P,
+                                                   const int *__restrict__ bad)
+{
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    if (*bad) return;
+    const int64_t K = kb / GB;
+    const int64_t J = (MODE == 1) ? K : (int64_t)blockIdx.x, I = (MODE == 0) ? K : (MODE == 1 ? (int64_t)blockIdx.x : (int64_t)blockIdx.y);
+    if ((MODE != 1 && J == K) || (MODE != 0 && I == K)) return;
+    __shared__ double Bs[GB][GLB];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, g = l >> 4;
+    const double *Ap = (MODE == 0) ? P : W + I * GB * np + kb;        // left factor and its leading dimension
+    const int64_t lda = (MODE == 0) ? GB : np;
+    const double *Bp = (MODE == 1) ? P : W + kb * np + J * GB;        // right factor
+    const int64_t ldb = (MODE == 1) ? GB : np;
+    double av[16];
+    const v2d *arow = reinterpret_cast<const v2d *>(Ap + (int64_t)(16 * w + lr) * lda + 16 * g);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const v2d t = arow[q];
+        av[2 * q] = t[0];
+        av[2 * q + 1] = t[1];
+    }
+    for (int e = tid; e < GB * GB / 2; e += 256) {
+        const int r = e / (GB / 2), c = 2 * (e % (GB / 2));
+        const v2d t = *reinterpret_cast<const v2d *>(Bp + (int64_t)r * ldb + c);
+        Bs[r][c] = t[0];
+        Bs[r][c + 1] = t[1];
+    }
+    double *Cp = W + (I * GB + 16 * w + g) * np + J * GB + lr;
+    v4d acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (MODE == 2) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[t][v] = -Cp[(int64_t)(4 * v) * np + 16 * t];  // acc = -(C - A B) = -C + A B
+        } else {
+            acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], Bs[16 * g + kk][16 * t + lr], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double *o = Cp + (int64_t)(4 * v) * np + 16 * t;
+            *o = (MODE == 0) ? acc[t][v] : -acc[t][v];
+        }
+}
+
+// W = [M 0 ; 0 I] (leading dimension np) and back
+__global__ __launch_bounds__(256) void k_bgj_pack(int64_t n, int64_t np, const double *__restrict__ M, double *__restrict__ W)
+{
+    const int64_t r = blockIdx.x;
+    for (int64_t c = threadIdx.x; c < np; c += 256) W[r * np + c] = (r < n && c < n) ? M[r * n + c] : (r == c ? 1.0 : 0.0);
+}
+__global__ __launch_bounds__(256) void k_bgj_unpack(int64_t n, int64_t np, const double *__restrict__ W, double *__restrict__ Inv,
+                                                    const int *__restrict__ bad)
+{
+    if (*bad) return;
+    const int64_t r = blockIdx.x;
+    for (int64_t c = threadIdx.x; c < n; c += 256) Inv[r * n + c] = W[r * np + c];
+}
+
 // y = Inv b, one wave per row
 __global__ __launch_bounds__(256) void k_dense_apply(int64_t n, const double *__restrict__ Inv, const double *__restrict__ b,
                                                      double *__restrict__ y)
@@ -110,6 +261,8 @@ void dense_release(pib_solver *s)
     if (s->dense_inv) (void)hipFree(s->dense_inv);
     if (s->dense_work) (void)hipFree(s->dense_work);
     if (s->dense_bad) (void)hipFree(s->dense_bad);
+    if (s->dense_pad) (void)hipFree(s->dense_pad);
+    s->dense_pad = nullptr;
     s->dense_graph = nullptr;
     s->dense_inv = s->dense_work = nullptr;
     s->dense_bad = nullptr;
@@ -130,6 +283,8 @@ int dense_setup(pib_solver *s)
     }
     hipStream_t q = s->stream;
     const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
+    const int64_t np = (n + GB - 1) / GB * GB;
+    const bool blocked = s->cfg.blocked_direct_solve && n >= 2 * GB;
     // buffers (and the captured elimination graph) are kept while the size stays the same: a moving body re-factorises
     // a matrix of the same order every time step (rigidkinematics.cpp:135-139)
     if (s->dense_n != n || s->dense_inv == nullptr) {
@@ -137,6 +292,7 @@ int dense_setup(pib_solver *s)
         PIB_HIP(hipMalloc(&s->dense_inv, bytes));
         PIB_HIP(hipMalloc(&s->dense_work, bytes));
         PIB_HIP(hipMalloc(&s->dense_bad, sizeof(int) + sizeof(double) * 2));  // flag + (8-byte aligned) max |diagonal|
+        if (blocked) PIB_HIP(hipMalloc(&s->dense_pad, sizeof(double) * ((size_t)np * (size_t)np + GB * GB)));
         s->dense_n = n;
     }
     double *M = s->dense_work;
@@ -157,18 +313,32 @@ int dense_setup(pib_solver *s)
     // the n elimination launches as one hipGraph (their arguments are fixed for a given order n and buffers).  Not under
     // the test-only loopback transport: its ranks are threads of one process, and capturing / replaying graphs from
     // several threads at once proved unreliable in the HIP runtime (sporadic garbage in the eliminated matrix)
-    if (s->reduce_via != nullptr && s->reduce_via->comm.loop != nullptr) {
+    auto eliminate = [&]() {
+        if (blocked) {
+            double *W = s->dense_pad, *P = s->dense_pad + (size_t)np * (size_t)np;
+            const unsigned nblk = (unsigned)(np / GB);
+            hipLaunchKernelGGL(k_bgj_pack, dim3((unsigned)np), dim3(256), 0, q, n, np, M, W);
+            for (int64_t kb = 0; kb < np; kb += GB) {
+                hipLaunchKernelGGL(k_bgj_diag, dim3(1), dim3(256), 0, q, np, kb, W, P, s->dense_bad, maxdiag);
+                hipLaunchKernelGGL(k_bgj_block<0>, dim3(nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad);
+                hipLaunchKernelGGL(k_bgj_block<2>, dim3(nblk, nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad);
+                hipLaunchKernelGGL(k_bgj_block<1>, dim3(nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad);
+            }
+            hipLaunchKernelGGL(k_bgj_unpack, dim3((unsigned)n), dim3(256), 0, q, n, np, W, s->dense_inv, s->dense_bad);
+            return;
+        }
         for (int64_t k = 0; k < n; ++k)
             hipLaunchKernelGGL(k_gj_step, dim3((unsigned)n), dim3(256), 0, q, n, k, M, s->dense_inv, s->dense_bad, maxdiag);
         hipLaunchKernelGGL(k_gj_scale, dim3((unsigned)n), dim3(256), 0, q, n, M, s->dense_inv, s->dense_bad);
+    };
+    if (s->reduce_via != nullptr && s->reduce_via->comm.loop != nullptr) {
+        eliminate();
         PIB_HIP(hipGetLastError());
     } else {
     if (s->dense_graph == nullptr) {
         hipGraph_t g = nullptr;
         PIB_HIP(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
-        for (int64_t k = 0; k < n; ++k)
-            hipLaunchKernelGGL(k_gj_step, dim3((unsigned)n), dim3(256), 0, q, n, k, M, s->dense_inv, s->dense_bad, maxdiag);
-        hipLaunchKernelGGL(k_gj_scale, dim3((unsigned)n), dim3(256), 0, q, n, M, s->dense_inv, s->dense_bad);
+        eliminate();
         const hipError_t e = hipStreamEndCapture(q, &g);
         if (e != hipSuccess || g == nullptr) return fail(PIB_ERR_LIB, "solver %s: capturing the factorisation failed (%s)", s->name.c_str(), hipGetErrorString(e));
         const hipError_t ei = hipGraphInstantiate(&s->dense_graph, g, nullptr, nullptr, 0);

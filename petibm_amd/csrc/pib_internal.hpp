@@ -85,6 +85,7 @@ struct Config {
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
     int march_velocity = 1;        // matrix-free velocity product: LDS-tiled z-marching form for tile-divisible components (velstencil.hip k_vel_march)
     int fuse_bicgstab_dots = 1;  // ... and its two dot-only passes summed by the products themselves (sums grouped by tile: the iterates equal the CSR path's to rounding, no longer bit for bit; 0 keeps the bit-identical route)
+    int blocked_direct_solve = 1;   // dense.hip: the explicit inverse of the direct solver by 64-column block elimination (0: one launch per column)
     int accumulate_unscaled_x = 1;  // ... and x summed before the Jacobi sweep, swept once at the end (krylov.hip OpBFUpdateP::y): 8 B/row/iteration less, x to rounding
     int blocked_reductions = 1;  // vector kernels with sums on >= 2^22 entries: a contiguous range per workgroup instead of a grid stride
     int lean_bicgstab = 1;  // BiCGStab on the matrix-free velocity operator without stored M^-1 p / M^-1 s and with the x update deferred (krylov.hip OpBFUpdateP)
@@ -290,6 +291,7 @@ struct pib_solver {
     double *dense_inv = nullptr;  // dense.hip: explicit inverse of the direct solver [dense_n x dense_n]
     double *dense_work = nullptr; // the matrix being eliminated
     int *dense_bad = nullptr;     // zero-pivot flag
+    double *dense_pad = nullptr;  // the matrix padded to a multiple of the block order, inverted in place by the blocked elimination (+ one block of scratch)
     hipGraphExec_t dense_graph = nullptr;  // the dense_n elimination launches
     int64_t dense_n = 0;
     // results of the last solve
