@@ -234,6 +234,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.deep_halo = std::atoi(d.get("default", "pib_deep_halo", "1").c_str());
     c.overlap_min_bytes = std::atoi(d.get("default", "pib_overlap_min_bytes", "1048576").c_str());
     c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "-1").c_str());
+    c.coarse_tail_lds = std::atoi(d.get("default", "pib_coarse_tail_lds", "0").c_str());
     if (d.has("default", "pib_initial_guess_nonzero"))
         c.initial_guess_nonzero = truthy(d.get("default", "pib_initial_guess_nonzero", "1"));
     if (d.has("default", "pib_norm")) {
@@ -349,6 +350,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_deep_halo", v)) c.deep_halo = std::atoi(v.c_str());
     if (get("pib_overlap_min_bytes", v)) c.overlap_min_bytes = std::atoi(v.c_str());
     if (get("pib_coarse_tail", v)) c.coarse_tail = std::atoi(v.c_str());
+    if (get("pib_coarse_tail_lds", v)) c.coarse_tail_lds = std::atoi(v.c_str());
     if (get("pib_presweeps", v)) c.presweeps = std::atoi(v.c_str());
     if (get("pib_postsweeps", v)) c.postsweeps = std::atoi(v.c_str());
     if (get("pib_cheby_degree", v)) c.cheby_degree = std::atoi(v.c_str());

@@ -28,6 +28,7 @@
 //     operator; both keep the preconditioner symmetric.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "pib_internal.hpp"
 
@@ -1219,13 +1220,21 @@ struct TailLevel {
     LevelDev L;
     double *xa, *xb, *b, *r;
 };
+constexpr int TAIL_POOL = 6144;  // doubles of LDS for the tail's vectors (48 KB)
+constexpr int TAIL_GUARD = 768;  // ... and of margin around them
 struct TailArgs {
     int nlev;
     TailLevel lv[TAIL_MAX_LEVELS];
     double omega;
     int pre, post, sweeps;
+    // the four vectors of every tail level in LDS when they fit (lds_off[l] >= 0: place of level l's group of four in the pool):
+    // a tail is ~25 phases of a few hundred cells with a barrier in between -- with the vectors in HBM every phase is a round
+    // trip through the L2 (65 us per V-cycle of the 450^2 cylinder mesh, a quarter of that case's time step)
+    int lds_off[TAIL_MAX_LEVELS];
+    double *out0;  // where the tail's first level leaves its result (global memory)
 };
 
+// (4 KB: more than a kernel's argument segment takes beside the hidden arguments -- the kernel reads it from HBM)
 __device__ __forceinline__ void tail_smooth(const LevelDev &L, double omega, const double *b, const double *xi, double *xo,
                                             bool zero_guess)
 {
@@ -1247,17 +1256,38 @@ __device__ __forceinline__ void tail_smooth(const LevelDev &L, double omega, con
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict__ S, TailArgs T)
+__global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict__ S, const TailArgs *__restrict__ Tp)
 {
     if (S != nullptr && S->done) return;
+    const TailArgs &T = *Tp;
+    // (a margin on either side: like their padded counterparts in HBM the vectors may be read a little outside -- a
+    // neighbour the row kernels load before they know its weight is zero -- and a flat access below the LDS aperture
+    // is a fault, not a zero)
+    __shared__ double pool_[TAIL_GUARD + TAIL_POOL + TAIL_GUARD];
+    double *const pool = pool_ + TAIL_GUARD;
     double *cur[TAIL_MAX_LEVELS], *spare[TAIL_MAX_LEVELS];
     const int nl = T.nlev;
+    const bool lds = T.lds_off[0] >= 0;
+    // level l's xa / xb / b / r: in the pool or in global memory
+    auto vec = [&](int l, int which) -> double * {
+        const TailLevel &V = T.lv[l];
+        if (lds) return pool + T.lds_off[l] + which * (V.L.nx * V.L.ny * V.L.nk);
+        return which == 0 ? V.xa : (which == 1 ? V.xb : (which == 2 ? V.b : V.r));
+    };
+    if (lds) {
+        for (int p = threadIdx.x; p < TAIL_GUARD + TAIL_POOL + TAIL_GUARD; p += blockDim.x) pool_[p] = 0.0;  // (finite: 0 * it = 0)
+        __syncthreads();
+        const int n0 = T.lv[0].L.nx * T.lv[0].L.ny * T.lv[0].L.nk;
+        double *b0 = vec(0, 2);
+        for (int p = threadIdx.x; p < n0; p += blockDim.x) b0[p] = T.lv[0].b[p];
+        __syncthreads();
+    }
     // ---- downward leg
     for (int l = 0; l < nl - 1; ++l) {
-        const TailLevel &V = T.lv[l];
-        const LevelDev &F = V.L;
+        const LevelDev &F = T.lv[l].L;
         const LevelDev &C = T.lv[l + 1].L;
-        double *a = V.xa, *c = V.xb;
+        struct { double *b, *r; } V = {vec(l, 2), vec(l, 3)};
+        double *a = vec(l, 0), *c = vec(l, 1);
         tail_smooth(F, T.omega, V.b, nullptr, a, true);
         for (int sw = 1; sw < T.pre; ++sw) {
             tail_smooth(F, T.omega, V.b, a, c, false);
@@ -1272,7 +1302,7 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
         __threadfence_block();
         __syncthreads();
         const int cplane = C.nx * C.ny, nc = cplane * C.nk;
-        double *bc = T.lv[l + 1].b;
+        double *bc = vec(l + 1, 2);
         for (int q = threadIdx.x; q < nc; q += blockDim.x) {
             const int I = q % C.nx, J = (q / C.nx) % C.ny, K = C.k0 + q / cplane;
             double wi[4], wj[4], wk[4];
@@ -1299,20 +1329,21 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
     }
     // ---- coarsest level: Jacobi sweeps from zero
     {
-        const TailLevel &V = T.lv[nl - 1];
-        double *a = V.xa, *c = V.xb;
-        tail_smooth(V.L, T.omega, V.b, nullptr, a, true);
+        const LevelDev &L = T.lv[nl - 1].L;
+        const double *bl = vec(nl - 1, 2);
+        double *a = vec(nl - 1, 0), *c = vec(nl - 1, 1);
+        tail_smooth(L, T.omega, bl, nullptr, a, true);
         for (int sw = 1; sw < T.sweeps; ++sw) {
-            tail_smooth(V.L, T.omega, V.b, a, c, false);
+            tail_smooth(L, T.omega, bl, a, c, false);
             double *t = a; a = c; c = t;
         }
         cur[nl - 1] = a;
     }
     // ---- upward leg
     for (int l = nl - 2; l >= 0; --l) {
-        const TailLevel &V = T.lv[l];
-        const LevelDev &F = V.L;
+        const LevelDev &F = T.lv[l].L;
         const LevelDev &C = T.lv[l + 1].L;
+        struct { const double *b; } V = {vec(l, 2)};
         double *a = cur[l], *c = spare[l];
         const double *xc = cur[l + 1];
         const int fplane = F.nx * F.ny, nf = fplane * F.nk;
@@ -1340,6 +1371,10 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
             double *t = a; a = c; c = t;
         }
         cur[l] = a;
+    }
+    if (lds) {
+        const int n0 = T.lv[0].L.nx * T.lv[0].L.ny * T.lv[0].L.nk;
+        for (int p = threadIdx.x; p < n0; p += blockDim.x) T.out0[p] = cur[0][p];
     }
 }
 
@@ -1399,6 +1434,9 @@ static int up(const std::vector<T> &h, T **d)
 
 void gmg_release(pib_solver *s)
 {
+    if (s->d_tail_args) (void)hipFree(s->d_tail_args);
+    s->d_tail_args = nullptr;
+    s->h_tail_args.clear();
     for (auto &L : s->levels) {
         for (int d = 0; d < 3; ++d) {
             if (L.w[d]) (void)hipFree(L.w[d]);
@@ -2195,6 +2233,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         const int64_t pl = g.plane;
         if (l == tail0) {
             TailArgs T;
+            std::memset(&T, 0, sizeof T);
             T.nlev = nl - tail0;
             T.omega = omega;
             T.pre = pre;
@@ -2208,10 +2247,27 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 T.lv[q2].b = t.b + t.pad;
                 T.lv[q2].r = t.r + t.pad;
             }
-            hipLaunchKernelGGL(k_coarse_tail, dim3(1), dim3(1024), 0, q, S, T);
-            PIB_HIP(hipGetLastError());
             const int swaps = (pre - 1) + post;
             cur[(size_t)l] = (swaps % 2 == 0) ? (g.x + g.pad) : (g.x2 + g.pad);
+            int64_t need = 0;
+            bool fits = s->cfg.coarse_tail_lds != 0;
+            for (int q2 = 0; q2 < T.nlev; ++q2) {
+                const GridLevel &t = s->levels[(size_t)(tail0 + q2)];
+                T.lds_off[q2] = (int)need;
+                need += 4 * t.nloc;
+                fits = fits && !t.zring && t.nloc == t.n[0] * t.n[1] * t.n[2];
+            }
+            if (!fits || need > TAIL_POOL)
+                for (int q2 = 0; q2 < TAIL_MAX_LEVELS; ++q2) T.lds_off[q2] = -1;
+            T.out0 = cur[(size_t)l];
+            // the argument block lives in HBM, rewritten only when it changes (levels, sweeps and buffers are fixed per set-up)
+            if (s->d_tail_args == nullptr) PIB_HIP(hipMalloc(&s->d_tail_args, sizeof(TailArgs)));
+            if (s->h_tail_args.size() != sizeof(TailArgs) || std::memcmp(s->h_tail_args.data(), &T, sizeof(TailArgs)) != 0) {
+                s->h_tail_args.assign(reinterpret_cast<const char *>(&T), reinterpret_cast<const char *>(&T) + sizeof(TailArgs));
+                PIB_HIP(hipMemcpyAsync(s->d_tail_args, s->h_tail_args.data(), sizeof(TailArgs), hipMemcpyHostToDevice, q));
+            }
+            hipLaunchKernelGGL(k_coarse_tail, dim3(1), dim3(1024), 0, q, S, static_cast<const TailArgs *>(s->d_tail_args));
+            PIB_HIP(hipGetLastError());
             break;
         }
         const double *b = (l == 0) ? r : g.b + g.pad;

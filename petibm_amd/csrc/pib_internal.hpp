@@ -80,6 +80,7 @@ struct Config {
     int overlap_halo = 1;
     int overlap_min_bytes = 1 << 20;  // multigrid on slabs: a right-hand-side exchange of at least this size per neighbour runs on the communication stream behind the interior planes of its first consumer
     int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024; 0: off.
+    int coarse_tail_lds = 0;  // ... with the tail levels' vectors in LDS when they fit (48 KB): 72 -> 63 us per tail, nothing per time step; off
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
@@ -291,6 +292,8 @@ struct pib_solver {
     double *dense_inv = nullptr;  // dense.hip: explicit inverse of the direct solver [dense_n x dense_n]
     double *dense_work = nullptr; // the matrix being eliminated
     int *dense_bad = nullptr;     // zero-pivot flag
+    void *d_tail_args = nullptr;        // gmg.hip: argument block of the single-workgroup coarse tail (+ its host copy)
+    std::vector<char> h_tail_args;
     double *dense_pad = nullptr;  // the matrix padded to a multiple of the block order, inverted in place by the blocked elimination (+ one block of scratch)
     hipGraphExec_t dense_graph = nullptr;  // the dense_n elimination launches
     int64_t dense_n = 0;
