@@ -24,6 +24,7 @@
 //     device scalars (one call for all sums of a step).
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstring>
 
 #include "pib_internal.hpp"
@@ -1292,7 +1293,10 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     // (also without a preconditioner -- NOSOLVER, the velocity solver file of flatplate3dRe100_GPU and multicylinders2dRe100_GPU:
     // the sweep drops out, dv == nullptr)
     const double *dv = jac ? A.dinv : nullptr;
-    const bool lean = (jac || pc == Precond::NONE) && !left && one_rank && s->cfg.lean_bicgstab && s->vel.valid && s->cfg.matrix_free_velocity &&
+    // On slabs the unpreconditioned case only (the sweep would need the neighbours' diagonal on the ghost planes): the
+    // products exchange their input's boundary planes first, the sums go through the all-reduce before their scalar step.
+    const bool lean = (jac || pc == Precond::NONE) && !left && (one_rank || (pc == Precond::NONE && s->vel.slab_axis >= 0)) &&
+                      s->cfg.lean_bicgstab && s->vel.valid && s->cfg.matrix_free_velocity &&
                       s->post_matmult == nullptr && vel_stencil_fused_ok(s) && aligned16(x) &&
                       ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(V) |
                         reinterpret_cast<uintptr_t>(T)) & 31u) == 0;
@@ -1307,9 +1311,18 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     PIB_CHK(poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
+        // reduce the partial sums of `nslots` slots and run scalar step POST: one launch on one rank, with the all-reduce
+        // in between on several (k_finalize_post with no slots left to reduce is the scalar step alone)
+        auto reduce_then = [&](auto post_tag, int slot0, int nslots, int count, double *hist, int cis) -> int {
+            constexpr int POST = decltype(post_tag)::value;
+            if (one_rank) return finalize_post<POST>(s, slot0, nslots, count, hist, cis, q);
+            PIB_CHK(finalize(s, slot0, nslots, count, q));
+            return finalize_post<POST>(s, slot0, 0, 0, hist, cis, q);
+        };
         auto body_lean = [&]() -> int {
             OpBFUpdateP up{R, V, dv, S, P, x, Y, opc, 0.0, 0.0, 0.0, 0.0, 0};
             PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
+            if (!one_rank) PIB_CHK(halo_exchange(s, P, q));
             if (fused_dots) {  // v = K M^-1 p and v.rp by the same kernel
                 PIB_CHK(vel_stencil_apply(s, P, V, true, q, dv, opc, 1, RP, 2));
                 nb = VEL_DOT_PARTIALS;
@@ -1318,9 +1331,10 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
                 OpBPcDot<PCM_NONE> d1{V, nullptr, RP, V, 1.0};
                 PIB_CHK(launch_vec(s, n, d1, true, 2, &nb, true, q));
             }
-            PIB_CHK(finalize_post<5>(s, 2, 1, nb, nullptr, 0, q));
+            PIB_CHK(reduce_then(std::integral_constant<int, 5>(), 2, 1, nb, nullptr, 0));
             OpBUpdateS<PCM_NONE> us{R, V, nullptr, S, S, 1.0, 0, 0.0};  // s = r - alpha v
             PIB_CHK(launch_vec(s, n, us, true, 0, nullptr, true, q));
+            if (!one_rank) PIB_CHK(halo_exchange(s, S, q));
             if (fused_dots) {  // t = K M^-1 s with s.t and t.t
                 PIB_CHK(vel_stencil_apply(s, S, T, true, q, dv, opc, 2, nullptr, 3));
                 nb = VEL_DOT_PARTIALS;
@@ -1329,10 +1343,10 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
                 OpBPcDot2<PCM_NONE> d2{T, nullptr, S, T, 1.0, 0};
                 PIB_CHK(launch_vec(s, n, d2, true, 3, &nb, true, q));
             }
-            PIB_CHK(finalize_post<2>(s, 3, 2, nb, nullptr, 0, q));
+            PIB_CHK(reduce_then(std::integral_constant<int, 2>(), 3, 2, nb, nullptr, 0));
             OpBFUpdateR ur{S, T, RP, R, 0.0};
             PIB_CHK(launch_vec(s, n, ur, true, 0, &nb, true, q));
-            PIB_CHK(finalize_post<6>(s, 0, 2, nb, s->d_hist, conv_is_its, q));
+            PIB_CHK(reduce_then(std::integral_constant<int, 6>(), 0, 2, nb, s->d_hist, conv_is_its));
             PIB_HIP(hipGetLastError());
             return 0;
         };

@@ -229,7 +229,8 @@ def _velocity_slab_indices(m, P, r):
     return np.concatenate(idx)
 
 
-@pytest.mark.parametrize("P,case", [(2, "3d"), (3, "3d"), (2, "2d"), (4, "3d_outflow"), (2, "3d_march"), (3, "3d_march")])
+@pytest.mark.parametrize("P,case", [(2, "3d"), (3, "3d"), (2, "2d"), (4, "3d_outflow"), (2, "3d_march"), (3, "3d_march"),
+                                    (2, "3d_march_nopc"), (3, "3d_march_nopc")])
 def test_multirank_velocity_system(P, case):
     """The velocity operator A = I/dt - c nu L on slabs: every rank assembles its rows of the packed
     ordering, the neighbours' boundary planes of u, v and w arrive through the segmented halo plan; SpMV across the
@@ -237,7 +238,10 @@ def test_multirank_velocity_system(P, case):
     from petibm_amd.linsolver import LinSolverHIP
     from test_gpu_parity import STRETCHED_2D, _a0_table, _outflow_3d, amgx_cfg, stretched_3d
     cfg = {"3d": stretched_3d((10, 9, 12)), "2d": STRETCHED_2D, "3d_outflow": _outflow_3d(),
-           "3d_march": stretched_3d((128, 10, 16))}[case]  # wide enough for the LDS-tiled one-launch product on every slab
+           "3d_march": stretched_3d((128, 10, 16)),  # wide enough for the LDS-tiled one-launch product on every slab
+           # ... without a preconditioner (the velocity solver file of flatplate3dRe100_GPU): on slabs too BiCGStab then runs
+           # on the products with the fused sums and the deferred x update (krylov.hip body_lean; iterates to rounding)
+           "3d_march_nopc": stretched_3d((128, 10, 16))}[case]
     if case == "3d_outflow":
         cfg = _outflow_3d()
         cfg["mesh"][2]["subDomains"][0]["cells"] += 4  # 12 planes: three per rank
@@ -248,8 +252,9 @@ def test_multirank_velocity_system(P, case):
     b = clib.spmv(A, us)
     n = [int(v) for v in m.n[3][: m.dim]]
     w = [m.dL[3][d].true for d in range(m.dim)]
-    text = amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500)
-    if case == "3d_march":
+    nopc = case.endswith("nopc")
+    text = amgx_cfg(solver="PBICGSTAB", pc="NOSOLVER" if nopc else "BLOCK_JACOBI", tol=1e-10 if nopc else 1e-12, conv="ABSOLUTE", maxit=500)
+    if case.startswith("3d_march"):
         text += "pib_march_min_cells=0\n"
     own = [_velocity_slab_indices(m, P, r) for r in range(P)]
     assert sorted(np.concatenate(own).tolist()) == list(range(A.n_rows))
@@ -271,19 +276,25 @@ def test_multirank_velocity_system(P, case):
     # with the CSR products instead the iterates are the same, bit for bit
     csr = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_matrix_free_velocity=0\n"))
     for a, c in zip(res, csr):
-        assert a[2] == c[2] and np.array_equal(a[3], c[3]) and np.array_equal(a[1], c[1])
+        if nopc:
+            # ~120 unpreconditioned iterations on this stretched mesh: the early history agrees to rounding, the count of
+            # BiCGStab's erratic tail moves by a few per cent with the order of the sums
+            assert abs(a[2] - c[2]) <= max(1, c[2] // 8) and np.allclose(a[3][:10], c[3][:10], rtol=1e-8)
+            assert np.abs(a[1] - c[1]).max() <= 1e-8 * max(1.0, np.abs(c[1]).max())
+        else:
+            assert a[2] == c[2] and np.array_equal(a[3], c[3]) and np.array_equal(a[1], c[1])
     y, x = np.empty(A.n_rows), np.empty(A.n_rows)
     for r in range(P):
         y[own[r]], x[own[r]] = res[r][0], res[r][1]
     assert np.array_equal(y, b)
     assert len({q[2] for q in res}) == 1
-    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1e-11 * np.linalg.norm(b)
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= (1e-9 if nopc else 1e-11) * np.linalg.norm(b)
     s1 = LinSolverHIP("velocity", config_text=text)
     s1.assembleVelocity(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
     x1 = np.zeros(A.n_rows)
     s1.solve(x1, b)
     # (BiCGStab's count moves by a few in ~90 with the order of its sums: the one-rank solve folds them into the product)
-    assert abs(res[0][2] - s1.getIters()) <= max(1, res[0][2] // 20) and np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
+    assert abs(res[0][2] - s1.getIters()) <= max(1, res[0][2] // (8 if nopc else 20)) and np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
     s1.destroy()
 
 
