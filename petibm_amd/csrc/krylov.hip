@@ -1292,10 +1292,11 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     // the matrix-free velocity operator in its one-launch form: no stored M^-1 p / M^-1 s, deferred x update (OpBFUpdateP)
     // (also without a preconditioner -- NOSOLVER, the velocity solver file of flatplate3dRe100_GPU and multicylinders2dRe100_GPU:
     // the sweep drops out, dv == nullptr)
-    const double *dv = jac ? A.dinv : nullptr;
-    // On slabs the unpreconditioned case only (the sweep would need the neighbours' diagonal on the ghost planes): the
-    // products exchange their input's boundary planes first, the sums go through the all-reduce before their scalar step.
-    const bool lean = (jac || pc == Precond::NONE) && !left && (one_rank || (pc == Precond::NONE && s->vel.slab_axis >= 0)) &&
+    const double *dv = jac ? A.dinv : nullptr;  // (on slabs: its ghost-padded copy, below)
+    // On slabs the products exchange their input's boundary planes first and the sums go through the all-reduce before their
+    // scalar step; the sweep needs the neighbours' diagonal on the ghost planes: a ghost-padded copy of 1 / a_ii, exchanged
+    // once per solve, in the vector the general path keeps M^-1 s in.
+    const bool lean = (jac || pc == Precond::NONE) && !left && (one_rank || s->vel.slab_axis >= 0) &&
                       s->cfg.lean_bicgstab && s->vel.valid && s->cfg.matrix_free_velocity &&
                       s->post_matmult == nullptr && vel_stencil_fused_ok(s) && aligned16(x) &&
                       ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(V) |
@@ -1303,6 +1304,12 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     const bool fused_dots = lean && s->cfg.fuse_bicgstab_dots;
     // ... and x accumulated before the Jacobi sweep (OpBFUpdateP::y) in the vector the general path keeps M^-1 p in
     double *Y = (fused_dots && s->cfg.accumulate_unscaled_x) ? s->vec(7) : nullptr;
+    if (lean && jac && !one_rank) {
+        double *D = s->vec(8);
+        PIB_HIP(hipMemcpyAsync(D, A.dinv, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, q));
+        PIB_CHK(halo_exchange(s, D, q));
+        dv = D;
+    }
     if (Y != nullptr) {
         OpFill y0{Y, 0.0};
         PIB_CHK(launch_vec(s, n, y0, v2, 0, nullptr, false, q));
