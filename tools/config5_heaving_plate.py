@@ -21,7 +21,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def axis(name, half, cells_core, cells_out, ratio):
-    core, out = half / 2.0, half
+    """uniform block [-half/2, half/2] of `cells_core` cells, stretched outwards by `ratio` over `cells_out` cells on either
+    side -- the outer blocks as long as it takes for their first cell to continue the core's width (the way the reference's
+    example meshes are laid out: examples/decoupledibpm/flatplate3dRe100_GPU/config.yaml)"""
+    core = half / 2.0
+    h = half / cells_core
+    out = h * ratio * (ratio ** cells_out - 1.0) / (ratio - 1.0)
     return {"direction": name, "start": -core - out,
             "subDomains": [{"end": -core, "cells": cells_out, "stretchRatio": 1.0 / ratio},
                            {"end": core, "cells": cells_core, "stretchRatio": 1.0},
