@@ -170,6 +170,12 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
  * Any output pointer may be NULL. */
 int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int *nullspace, int *detected);
 
+/* The hierarchy of the geometric multigrid this solver holds (diagnostics; what AmgX prints with print_grid_stats=1,
+ * examples/navierstokes/liddrivencavity2dRe1000_GPU/config/poisson_solver.info): *nlevels = number of levels (0: none),
+ * n3[3 l .. 3 l + 2] = cells per direction of level l for l < min(*nlevels, max_levels); n3 may be NULL.  The selective
+ * coarsening merges the finest cells of a stretched mesh first, so the sizes need not halve. */
+int pib_get_multigrid_levels(pib_solver *s, int *nlevels, int64_t *n3, int max_levels);
+
 /* The structure of the velocity operator A = I/dt - c nu L the solver holds for its matrix-free products (16 B/row instead
  * of the CSR's 104): *has = 0 none; dim, n[3] = pressure cells per direction, periodic[3]; *detected != 0 when
  * pib_set_csr[_i32] recovered it from the matrix -- vSolver->setMatrix(A) of an unchanged PetIBM, navierstokes.cpp:345:

@@ -54,6 +54,7 @@ _PROTOS = {
     "pib_set_csr_i32": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "pib_set_grid_hint": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "pib_set_periodic": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "pib_get_multigrid_levels": (C.c_int, [_vp, C.POINTER(C.c_int), _vp, C.c_int]),
     "pib_get_grid_structure": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, C.POINTER(C.c_int),
                                          C.POINTER(C.c_int)]),
     "pib_get_velocity_structure": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp, C.POINTER(C.c_int)]),

@@ -243,6 +243,19 @@ int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int 
     return 0;
 }
 
+int pib_get_multigrid_levels(pib_solver *s, int *nlevels, int64_t *n3, int max_levels)
+{
+    if (s == nullptr || nlevels == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_multigrid_levels: null argument");
+    *nlevels = (int)s->levels.size();
+    for (int l = 0; n3 != nullptr && l < *nlevels && l < max_levels; ++l) {
+        const GridLevel &g = s->levels[(size_t)l];  // internal layout of a 2-D grid is (nx, 1, ny)
+        n3[3 * l] = g.n[0];
+        n3[3 * l + 1] = (g.dim == 3) ? g.n[1] : g.n[2];
+        n3[3 * l + 2] = (g.dim == 3) ? g.n[2] : 1;
+    }
+    return 0;
+}
+
 int pib_get_velocity_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int periodic[3], int *detected)
 {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_velocity_structure: null solver");

@@ -172,6 +172,14 @@ class LinSolverBase:
         p = [a.ctypes.data if a is not None else None for a in ws + gs]
         capi.check(capi.load().pib_set_grid_hint(self._h, dim, n3.ctypes.data, *p, int(nullspace)))
 
+    def multigridLevels(self):
+        """pib_get_multigrid_levels: the cells per direction of every level of the geometric multigrid ([] if there is none)"""
+        nl = C.c_int()
+        capi.check(capi.load().pib_get_multigrid_levels(self._h, C.byref(nl), None, 0))
+        n3 = np.zeros(3 * max(nl.value, 1), dtype=np.int64)
+        capi.check(capi.load().pib_get_multigrid_levels(self._h, C.byref(nl), n3.ctypes.data, nl.value))
+        return [tuple(int(v) for v in n3[3 * l: 3 * l + 3]) for l in range(nl.value)]
+
     def gridStructure(self):
         """pib_get_grid_structure: None, or dict(dim, n, nullspace, detected)"""
         has, dim, ns, det = C.c_int(), C.c_int(), C.c_int(), C.c_int()

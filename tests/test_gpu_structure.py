@@ -255,3 +255,41 @@ def test_structure_recovered_on_slabs(P, n, pinned):
     x = np.concatenate([r[0] for r in res])
     assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-11 * np.linalg.norm(b)
     assert len({r[1] for r in res}) == 1 and res[0][1] < 40
+
+
+@pytest.mark.parametrize("case", ["uniform_3d", "stretched_3d", "stretched_2d", "periodic_3d"])
+def test_multigrid_hierarchy_is_the_oracles(case):
+    """pib_get_multigrid_levels (what AmgX's print_grid_stats shows): the selective coarsening of the device build produces
+    the level sizes of the oracle's restatement -- plain halving on a uniform mesh, the finest cells first on a stretched one."""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    per = None
+    if case == "uniform_3d":
+        cfg = omesh.uniform_config((32, 24, 40))  # unit cube: widths 1/32, 1/24, 1/40 -- the finer directions coarsen first
+    elif case == "stretched_3d":
+        cfg = stretched_3d((40, 36, 28))
+    elif case == "periodic_3d":
+        cfg, per = omesh.periodic_config((24, 20, 16), (True, False, True)), (True, False, True)
+    else:
+        cfg = STRETCHED_2D
+    m = omesh.create_mesh(cfg)
+    dim = m.dim
+    n = [int(v) for v in m.n[3][:dim]]
+    w = [m.dL[3][d].true for d in range(dim)]
+    s = LinSolverHIP("poisson", config_text=amgx_cfg(pc="AMG", tol=1e-10, extra=AMG))
+    if per:
+        s.setPeriodic(per)
+    s.assemblePoisson(n, w, 0.01, capi.NULLSPACE_CONSTANT)
+    got = s.multigridLevels()
+    g = clib.GMG(n, w, 0.01, nullspace=1, pre=1, post=1, omega=0.9, coarsest_sweeps=2, periodic=per or (False,) * dim)
+    want = [tuple(int(v) for v in g.level_size(l)) for l in range(g.num_levels())]
+    if dim == 2:  # the oracle keeps a 2-D grid as (nx, 1, ny)
+        want = [(t[0], t[2]) if len(t) == 3 else t for t in want]
+    assert got[0][:dim] == tuple(n) and len(got) >= 3
+    assert [t[:dim] for t in got] == [tuple(t[:dim]) for t in want], (got, want)
+    if case == "uniform_3d":
+        assert got[1] == (16, 24, 20) and got[2] == (8, 12, 10)
+    s.destroy()
+    t = LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI"))
+    assert t.multigridLevels() == []
+    t.destroy()

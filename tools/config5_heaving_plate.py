@@ -59,6 +59,13 @@ def main():
     t0 = time.perf_counter()
     s = DecoupledIBPMSolver(cfg, bodies=[plate], velocity_cfg=text["velocity"], poisson_cfg=text["poisson"], forces_cfg=text["forces"])
     print(f"{s.pN} cells, {s.UN} velocity unknowns, {3 * plate.shape[0]} force unknowns; set-up {time.perf_counter() - t0:.1f} s", flush=True)
+    try:  # the pressure solver's multigrid hierarchy (pib_get_multigrid_levels)
+        lv = s.poissonSolver.multigridLevels() if hasattr(s, "poissonSolver") else []
+        if lv:
+            print("multigrid levels:", " ".join("x".join(str(v) for v in t) for t in lv[:6]), "...",
+                  f"cells of all levels / fine = {sum(t[0] * t[1] * t[2] for t in lv) / s.pN:.2f}", flush=True)
+    except Exception:  # noqa: BLE001
+        pass
     tm = ta = 0.0
     for step in range(1, a.steps + 1):
         x, v = pose(step * dt)
