@@ -161,19 +161,28 @@ __global__ __launch_bounds__(256) void k_vel_shell(const Scalars *__restrict__ S
     vel_shell_part(V, f, all, x, y, blockIdx.x, gridDim.x);
 }
 
+// interior rows (j, k) of component f, cells 1 + bx * 256 + lane (+ stride)
+template <int DIM>
+__device__ __forceinline__ void vel_interior_part(const VelDev &V, int f, const double *__restrict__ x, double *__restrict__ y, int bx,
+                                                  int nbx, int j, int k);
 template <int DIM>
 __global__ __launch_bounds__(256) void k_vel_interior(const Scalars *__restrict__ S, VelDev V, int f, const double *__restrict__ x,
                                                       double *__restrict__ y)
 {
     if (S != nullptr && S->done) return;
+    vel_interior_part<DIM>(V, f, x, y, blockIdx.x, gridDim.x, blockIdx.y + 1, (DIM == 3) ? blockIdx.z + 1 : 0);
+}
+template <int DIM>
+__device__ __forceinline__ void vel_interior_part(const VelDev &V, int f, const double *__restrict__ x, double *__restrict__ y, int bx,
+                                                  int nbx, int j, int k)
+{
     const int nx = (int)V.n[f][0];
-    const int j = blockIdx.y + 1, k = (DIM == 3) ? blockIdx.z + 1 : 0;
     const int64_t sy = V.n[f][0], sz = sy * V.n[f][1];
     const int64_t base = V.off[f] + sy * j + sz * k;
     const double yneg = V.lneg[f][1][j], ypos = V.lpos[f][1][j];
     const double zneg = (DIM == 3) ? V.lneg[f][2][k] : 0.0, zpos = (DIM == 3) ? V.lpos[f][2][k] : 0.0;
     const double *__restrict__ xn = V.lneg[f][0], *__restrict__ xp = V.lpos[f][0];
-    for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i < nx - 1; i += gridDim.x * 256) {
+    for (int i = 1 + bx * 256 + threadIdx.x; i < nx - 1; i += nbx * 256) {
         const int64_t p = base + i;
         const double xneg = xn[i], xpos = xp[i];
         double acc = 0.0;
@@ -229,6 +238,32 @@ static VelDev vel_dev(const VelStencil &h)
         for (int q = 0; q < 6; ++q) V.a0[f][q] = h.a0[f][q];
     }
     return V;
+}
+
+// Small operators (the 2-D cases of the reference, a few 10^5 rows): the whole product in ONE launch of the streaming forms --
+// the shells of the components first, their interior rows behind -- instead of two launches per component; a time step of
+// those cases is a chain of ~5 us launches.  Same device functions, same bits.
+struct VelSmallPlan {
+    int first[7];   // first workgroup of: shell of component 0, 1, 2, interior of component 0, 1, 2, end
+    int all[3];     // the component has no interior: its shell part takes every row
+    int nbx[3];     // workgroups per interior grid line
+};
+template <int DIM>
+__global__ __launch_bounds__(256) void k_vel_product_small(const Scalars *__restrict__ S, VelDev V, VelSmallPlan P,
+                                                           const double *__restrict__ x, double *__restrict__ y)
+{
+    if (S != nullptr && S->done) return;
+    const int b = blockIdx.x;
+    if (b < P.first[3]) {
+        const int f = (b >= P.first[1]) + (b >= P.first[2]);
+        vel_shell_part(V, f, P.all[f], x, y, b - P.first[f], P.first[f + 1] - P.first[f]);
+        return;
+    }
+    const int f = (b >= P.first[4]) + (b >= P.first[5]);
+    const int lb = b - P.first[3 + f], nbx = P.nbx[f];
+    const int bx = lb % nbx, row = lb / nbx;
+    const int nyi = (int)V.n[f][1] - 2;
+    vel_interior_part<DIM>(V, f, x, y, bx, nbx, row % nyi + 1, (DIM == 3) ? row / nyi + 1 : 0);
 }
 
 // The same rows, four cells per lane (grid lines of a multiple of four points that start on a 32-byte boundary: every
@@ -658,6 +693,36 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
         if (dot_mode != 0)
             hipLaunchKernelGGL(k_vel_reduce, dim3(VEL_STAGE, dot_mode == 2 ? 2 : 1), dim3(256), 0, q, S, s->d_vel_part, s->vel_part_cap, nb,
                                s->d_part, dot_slot0);
+        PIB_HIP(hipGetLastError());
+        s->counters[0]++;
+        return 0;
+    }
+    if (s->cfg.fuse_velocity_product && h.off[h.dim - 1] + h.n[h.dim - 1][0] * h.n[h.dim - 1][1] * h.n[h.dim - 1][2] <= ((int64_t)1 << 21)) {
+        VelSmallPlan P;
+        int nb = 0;
+        int64_t rows[3] = {0, 0, 0};
+        for (int f = 0; f < 3; ++f) {
+            P.first[f] = nb;
+            P.all[f] = 0;
+            P.nbx[f] = 1;
+            if (f >= h.dim) continue;
+            const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
+            const bool inner = nx >= 3 && ny >= 3 && (h.dim == 2 || nz >= 3);
+            P.all[f] = inner ? 0 : 1;
+            const int64_t shell = inner ? 2 * (ny * nz + (nx - 2) * nz + (h.dim == 3 ? (nx - 2) * (ny - 2) : 0)) : nx * ny * nz;
+            nb += (int)std::min<int64_t>(4096, (shell + 255) / 256);
+            if (inner) {
+                P.nbx[f] = (int)((nx - 2 + 255) / 256);
+                rows[f] = (ny - 2) * (h.dim == 3 ? nz - 2 : 1);
+            }
+        }
+        for (int f = 0; f < 3; ++f) {
+            P.first[3 + f] = nb;
+            nb += (int)(rows[f] * P.nbx[f]);
+        }
+        P.first[6] = nb;
+        if (h.dim == 3) hipLaunchKernelGGL(k_vel_product_small<3>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y);
+        else hipLaunchKernelGGL(k_vel_product_small<2>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y);
         PIB_HIP(hipGetLastError());
         s->counters[0]++;
         return 0;
