@@ -213,3 +213,20 @@ def test_slab_range_matches_python_partition_and_dmda_rule(capi):
     # what a rank sends is what its neighbour receives
     for a, b in zip(plans[:-1], plans[1:]):
         assert a.send_next == b.ghost_lo and b.send_prev == a.ghost_hi
+
+
+def test_every_solver_file_key_of_the_backend_is_documented():
+    """INTEGRATION.md's key table lists every `pib_*` key csrc/config.cpp reads (and nothing it does not read)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = open(os.path.join(root, "petibm_amd", "csrc", "config.cpp")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    read = set(re.findall(r'get\("(pib_[a-z0-9_]+)"', cfg)) | set(re.findall(r'"default", "(pib_[a-z0-9_]+)"', cfg))
+    table = "\n".join(line for line in doc.splitlines() if line.startswith("| `pib_"))
+    listed = {k for k in re.findall(r"`(pib_[a-z0-9_]+)`", table) if not k.startswith(("pib_ns_", "pib_get_", "pib_set_", "pib_assemble",
+                                                                                      "pib_create", "pib_solve", "pib_comm", "pib_slab",
+                                                                                      "pib_mat_", "pib_destroy", "pib_time", "pib_memcpy",
+                                                                                      "pib_config", "pib_last", "pib_synchronize", "pib_version"))}
+    assert read - listed == set(), f"undocumented keys: {sorted(read - listed)}"
+    assert listed - read == set(), f"documented but not read: {sorted(listed - read)}"
