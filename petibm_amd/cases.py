@@ -57,3 +57,29 @@ def circle(npts: int, radius: float = 0.5, centre=(0.0, 0.0)) -> np.ndarray:
     """Lagrangian points of a cylinder section (the .body files of the reference's cylinder cases)"""
     a = 2.0 * np.pi * np.arange(npts) / npts
     return np.stack([centre[0] + radius * np.cos(a), centre[1] + radius * np.sin(a)], axis=1)
+
+
+# Solver files of the reference's immersed-boundary examples (examples/decoupledibpm/cylinder2dRe40_GPU/config/*.info): the Poisson
+# solver as an AmgX PCG + AMG V(1,1) text with the tolerance left open, the direct forces solve.
+AMGX_POISSON = ("config_version=2\nsolver(solv)=PCG\nsolv:max_iters=500\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+                "solv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\nsolv:preconditioner(prec)=AMG\nprec:cycle=V\n"
+                "prec:presweeps=1\nprec:postsweeps=1\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
+                "smooth:relaxation_factor=0.9\n")
+DIRECT_FORCES = "-forces_ksp_type preonly\n-forces_pc_type lu\n-forces_pc_factor_mat_solver_type superlu_dist\n"
+
+
+def uniform_stream(cfg: dict, nu: float = 0.025, dt: float = 0.01, kernel: str = None) -> dict:
+    """free stream u = 1 through the box of `cfg`: DIRICHLET inflow and sides, CONVECTIVE outlet on xPlus, AB2 + Crank-Nicolson
+    (the boundary set of the reference's cylinder and flat-plate cases)"""
+    cfg = dict(cfg)
+    dim = len(cfg["mesh"])
+    for bc in cfg["flow"]["boundaryConditions"]:
+        for c in "uvw"[:dim]:
+            free = 1.0 if c == "u" else 0.0
+            bc[c] = ["CONVECTIVE", 1.0] if bc["location"] == "xPlus" else ["DIRICHLET", free]
+    cfg["flow"]["nu"] = nu
+    cfg["flow"]["initialVelocity"] = [1.0, 0.0, 0.0][:dim]
+    cfg["parameters"] = {"dt": dt, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    if kernel:
+        cfg["parameters"]["delta"] = kernel
+    return cfg

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
 import numpy as np
 from petibm_amd import cases
 from petibm_amd.navierstokes import NavierStokesSolver

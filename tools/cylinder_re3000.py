@@ -1,9 +1,9 @@
 import sys, json, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
 import numpy as np
 from petibm_amd import cases
 from petibm_amd.navierstokes import DecoupledIBPMSolver
-from test_gpu_ibm import flow_config, AMGX_P, FORCES
+from petibm_amd.cases import uniform_stream as flow_config, AMGX_POISSON as AMGX_P, DIRECT_FORCES as FORCES
 from petibm_amd.cases import circle
 G = json.load(open("tests/golden/reference_test_vectors.json"))
 sub = [{"end": -0.52, "cells": 363, "stretchRatio": 0.9900990099}, {"end": 0.52, "cells": 260, "stretchRatio": 1.0},

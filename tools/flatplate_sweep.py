@@ -3,11 +3,11 @@ at 0, 10, ..., 90 degrees, 2000 steps each, force coefficients averaged over 15 
 reported by Taira et al. (2007) (tests/golden/reference_test_vectors.json).    python tools/flatplate_sweep.py"""
 import json, math, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np
 from petibm_amd import cases
 from petibm_amd.navierstokes import DecoupledIBPMSolver
-from test_gpu_ibm import AMGX_P, FORCES, flow_config
+from petibm_amd.cases import uniform_stream as flow_config, AMGX_POISSON as AMGX_P, DIRECT_FORCES as FORCES
 
 G = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_test_vectors.json")))["taira_et_al_2007_flatplate_re100_ar2"]
 

@@ -2,11 +2,11 @@
     python tools/ibpm_coupled_cylinder.py 40 | 550 | 3000"""
 import json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np
 from petibm_amd import cases
 from petibm_amd.navierstokes import IBPMSolver
-from test_gpu_ibm import AMGX_P, FORCES, flow_config
+from petibm_amd.cases import uniform_stream as flow_config, AMGX_POISSON as AMGX_P, DIRECT_FORCES as FORCES
 from petibm_amd.cases import circle
 
 re = int(sys.argv[1]) if len(sys.argv) > 1 else 550

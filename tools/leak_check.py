@@ -1,10 +1,25 @@
 import sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
 import numpy as np, torch
 from petibm_amd import cases
 from petibm_amd.navierstokes import NavierStokesSolver, DecoupledIBPMSolver
 from petibm_amd.cases import circle, body_block as body_mesh
-from test_gpu_ibm import flow_config, FORCES
+FORCES = "-forces_ksp_type preonly\n-forces_pc_type lu\n"
+
+
+def flow_config(cfg, nu=0.025, dt=0.01):
+    """uniform stream, convective outlet on xPlus (the boundary set of the reference's cylinder cases)"""
+    dim = len(cfg["mesh"])
+    for bc in cfg["flow"]["boundaryConditions"]:
+        for c in "uvw"[:dim]:
+            free_stream = 1.0 if c == "u" else 0.0
+            bc[c] = ["CONVECTIVE", 1.0] if bc["location"] == "xPlus" else ["DIRICHLET", free_stream]
+    cfg["flow"]["nu"] = nu
+    cfg["flow"]["initialVelocity"] = [1.0, 0.0, 0.0][:dim]
+    cfg["parameters"] = {"dt": dt, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
+    return cfg
+
+
 def free():
     torch.cuda.synchronize(); return torch.cuda.mem_get_info()[0]
 cfgp = cases.periodic_box((64, 64, 64), (True, True, True)); cfgp["flow"]["nu"] = 0.01
