@@ -224,15 +224,16 @@ def random_rhs_solution(n: int, k0: int, k1: int) -> np.ndarray:
 
 # Algorithmic HBM bytes per row of one multigrid-PCG iteration as this build runs it, fp64 / int32:
 #   CSR SpMV 104 (12 nnz/n + 4 + 16) ; x += a p (owed by the previous iteration) and p = z + beta p in one pass 40 ;
-#   r -= a w + sums 24 ;
+#   r -= a w + sums: inside the V-cycle's first march, which reads w beside r and writes the new r beside x: 16 (24 as a pass of
+#   its own before the end of round 2) ;
 #   V(2,2) cycle on the fine level: two pre-smoothing steps from zero 16 (b read, x written), residual 24, restriction
 #   8 + 1, prolongation + first post-smoothing step 24 + 1, second post-smoothing step (+ the Krylov sums) 24 = 98,
-#   times 8/7 for the coarser levels = 112.            Sum: 280 B per row and iteration.
+#   times 8/7 for the coarser levels = 112.            Sum: 272 B per row and iteration (280 with the separate pass).
 def solve_bytes_per_row_iter(pre: int, post: int, nnz_per_row: float) -> float:
     spmv = 12.0 * nnz_per_row + 4.0 + 16.0
     down = (16.0 if pre >= 2 else 8.0 + 8.0) + 24.0 * max(pre - 2, 0) + 24.0 + 9.0
     up = (25.0 if post >= 1 else 17.0) + 24.0 * max(post - 1, 0)
-    return spmv + 40.0 + 24.0 + (down + up) * 8.0 / 7.0
+    return spmv + 40.0 + 16.0 + (down + up) * 8.0 / 7.0
 
 
 def poisson_case(n: int, dt: float, cfg_text: str, rhs: str, steps: int, warmup: int, kernel_reps: int, which_kernel: int = 0):

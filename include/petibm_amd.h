@@ -382,7 +382,8 @@ int pib_ns_get_ib_operator(pib_ns *ns, int which, int64_t *n_rows, int64_t *nnz,
  *        5 = matrix-free product of the velocity operator (the kernels BiCGStab runs after pib_assemble_velocity). */
 int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_avg);
 /* Counters of the last solve: [0]=spmv launches, [1]=pc applies, [2]=reductions,
- * [3]=halo exchanges (all-gathers included), [4]=host syncs, [5]=ranks of the communicator (ncclCommCount). */
+ * [3]=halo exchanges (all-gathers included), [4]=host syncs, [5]=ranks of the communicator (ncclCommCount),
+ * [6]=PCG iterations whose residual update ran inside the V-cycle's first kernel (pib_fuse_residual_update). */
 int pib_get_counters(pib_solver *s, int64_t counters[8]);
 
 #ifdef __cplusplus

@@ -339,13 +339,22 @@ __device__ __forceinline__ FCell fcell(const LevelDev &L, int i, int j)
 __device__ __forceinline__ double fdiag(const FCell &q, double czm, double czp) { return -((q.s4 + czm) + czp); }
 // RES = 1 (a V(1,.) cycle: ONE pre-smoothing step): the second stage is the residual r = b - A x1 instead of the second
 // Jacobi step; x1 goes to xo, r to ro -- b read once, two vectors written, instead of mode 1 + mode 3 (2 + 3 passes).
-template <int RES>
+// UPD = 1 (level 0 of the preconditioner inside PCG, one rank): the right-hand side is the Krylov residual, and its update
+// r = r_old - alpha w is done HERE as the planes are read -- b is r_old, `uw` is w = A p, alpha is S->a -- instead of in a pass
+// of its own (24 B/row): every loaded cell (halo cells included) is updated on the fly, the tile's own cells of its own
+// planes are written to `unew` (a second buffer: a neighbouring tile still reads the old values of these cells) and their
+// r.r and sum r go to upart[0 / 1][workgroup] for the solver's finalize kernel.  Same expression as OpUpdateXR: same r.
+template <int RES, int UPD = 0>
 __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_presmooth2(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                     const double *__restrict__ b, double *__restrict__ xo,
-                                                    const double *__restrict__ pin_sum, int FZ, double *__restrict__ ro)
+                                                    const double *__restrict__ pin_sum, int FZ, double *__restrict__ ro,
+                                                    const double *__restrict__ uw = nullptr, double *__restrict__ unew = nullptr,
+                                                    double *__restrict__ upart = nullptr, int upart_stride = 0)
 {
     if (S != nullptr && S->done) return;
     __shared__ double x1[3][FSY][FSX];
+    const double ua = UPD ? S->a : 0.0;
+    double ur0 = 0.0, ur1 = 0.0;
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     // processed planes: [L.k0, L.k0 + L.nk) (global); b / xo / ro point at the first of them.  A whole level, or a run of
@@ -356,6 +365,10 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
     b -= (int64_t)L.k0 * plane;  // index by global plane below
     xo -= (int64_t)L.k0 * plane;
     if (RES) ro -= (int64_t)L.k0 * plane;
+    if (UPD) {
+        uw -= (int64_t)L.k0 * plane;
+        unew -= (int64_t)L.k0 * plane;
+    }
     const int j = j0 + ty, ic = i0 + 4 * tx;  // this thread's 4 cells: (ic .. ic+3, j)
     // halo duty: every thread one cell of the two y-halo rows, 16 threads one cell of the two x-halo columns
     const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
@@ -386,8 +399,24 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
         if (kw >= 0 && kw < L.nzg) {
             const double *pb = b + (int64_t)kw * plane;
             v4 bv = *reinterpret_cast<const v4 *>(pb + off_c);
+            double hyv = hy_ok ? pb[off_hy] : 0.0, hxv = hx_ok ? pb[off_hx] : 0.0;
+            if (UPD) {
+                const double *pw = uw + (int64_t)kw * plane;
+                const v4 wv = *reinterpret_cast<const v4 *>(pw + off_c);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bv[c] = bv[c] - ua * wv[c];
+                if (hy_ok) hyv = hyv - ua * pw[off_hy];
+                if (hx_ok) hxv = hxv - ua * pw[off_hx];
+                if (kk >= k0 && kk < kend) {  // this workgroup's own cells: the new residual and its sums
+                    *reinterpret_cast<v4 *>(unew + (int64_t)kw * plane + off_c) = bv;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ur0 += bv[c] * bv[c];
+                        ur1 += bv[c];
+                    }
+                }
+            }
             if (pin_sum != nullptr && kw == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;  // PINNED: effective b at cell 0
-            const double hyv = hy_ok ? pb[off_hy] : 0.0, hxv = hx_ok ? pb[off_hx] : 0.0;
             const double rwz = L.rwz[kw], czm = L.cmz[kw], czp = L.cpz[kw];
             bcur = bv;
 #pragma unroll
@@ -424,6 +453,24 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
             *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = x1c;
         } else
             *reinterpret_cast<v4 *>(xo + (int64_t)kc * plane + off_c) = out;
+    }
+    if (UPD) {
+        __shared__ double ush[2][4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ur0 += __shfl_down(ur0, o, 64);
+            ur1 += __shfl_down(ur1, o, 64);
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            ush[0][tid >> 6] = ur0;
+            ush[1][tid >> 6] = ur1;
+        }
+        __syncthreads();
+        if (tid < 2) {
+            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            upart[(int64_t)tid * upart_stride + blk] = (ush[tid][0] + ush[tid][1]) + (ush[tid][2] + ush[tid][3]);
+        }
     }
 }
 
@@ -2012,6 +2059,20 @@ static int coarse_need(const pib_solver *s, int l, int e)
 
 // One V-cycle: z = M^-1 r.   r, z: ghost-padded work vectors of the Krylov solver
 // (their ghost planes double as the level-0 halo planes).
+// PCG may leave its residual update to the level-0 pre-smoothing march (k_presmooth2<., 1>): one rank, the fused march serves
+// the whole fine level, Jacobi smoothing, no pinned unknown, and few enough workgroups for the solver's partial-sum slots
+bool gmg_fused_update_ok(const pib_solver *s)
+{
+    if (!s->has_grid || s->levels.empty() || !s->gmg_error.empty() || s->comm.nranks != 1) return false;
+    if (s->cfg.smoother == Smoother::CHEBYSHEV || !s->cfg.fuse_presmooth || s->nullspace == PIB_NULLSPACE_PINNED) return false;
+    if (s->levels.size() < 2) return false;
+    const GridLevel &g = s->levels[0];
+    const int64_t nk = g.k1 - g.k0;
+    if (g.k0 != 0 || nk != g.n[2] || !fused_run_ok(s, g, 0, nk)) return false;
+    const int FZ = march_planes(g, nk);
+    return (g.n[0] / FX) * (g.n[1] / FY) * ((nk + FZ - 1) / FZ) <= PIB_MAXPART;
+}
+
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
 {
     if (!s->has_grid || s->levels.empty())
@@ -2151,7 +2212,19 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                         hipLaunchKernelGGL(k_presmooth2<0>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((rc + FZ - 1) / FZ)),
                                            dim3(256), 0, q, S, dev_of(sub), omega, b + ra * g.plane, c + ra * g.plane, pin_l, FZ, nullptr);
                     };
-                    if (halo_pending) {
+                    if (l == 0 && s->gmg_upd.w != nullptr) {
+                        // PCG's residual update folded into this march (k_presmooth2<., 1>): b is the NEW residual's buffer
+                        if (I.dist || halo_pending || ka != 0 || kc != I.nk) return fail(PIB_ERR_LIB, "fused residual update: level 0 is not a whole single-rank level");
+                        const dim3 grid((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((kc + FZ - 1) / FZ));
+                        const int nblk = (int)(grid.x * grid.y * grid.z);
+                        if (nblk > PIB_MAXPART) return fail(PIB_ERR_LIB, "fused residual update: too many workgroups for the partial sums");
+                        hipLaunchKernelGGL((k_presmooth2<0, 1>), grid, dim3(256), 0, q, S, dev_of(g), omega, s->gmg_upd.r_old, c, pin_l, FZ,
+                                           (double *)nullptr, s->gmg_upd.w, const_cast<double *>(b), s->d_part + 4 * (int64_t)PIB_MAXPART,
+                                           (int)PIB_MAXPART);
+                        PIB_HIP(hipGetLastError());
+                        s->gmg_upd.used = true;
+                        PIB_CHK(s->gmg_upd.after(s, nblk, q));
+                    } else if (halo_pending) {
                         // planes whose two steps read owned planes of b only, while the exchange is in flight
                         const int64_t ia = I.lo ? 1 : 0, ie = I.nk - (I.hi ? 1 : 0);
                         launch(ia, ie - ia);
@@ -2321,9 +2394,21 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 sub.k0 = g.k0 + ka;
                 sub.k1 = sub.k0 + kc;
                 const int FZ = march_planes(g, kc);
+                if (l == 0 && s->gmg_upd.w != nullptr) {
+                    if (I.dist || ka != 0 || kc != I.nk) return fail(PIB_ERR_LIB, "fused residual update: level 0 is not a whole single-rank level");
+                    const dim3 grid((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((kc + FZ - 1) / FZ));
+                    const int nblk = (int)(grid.x * grid.y * grid.z);
+                    if (nblk > PIB_MAXPART) return fail(PIB_ERR_LIB, "fused residual update: too many workgroups for the partial sums");
+                    hipLaunchKernelGGL((k_presmooth2<1, 1>), grid, dim3(256), 0, q, S, dev_of(sub), omega, s->gmg_upd.r_old, a, pin_l, FZ, rr,
+                                       s->gmg_upd.w, const_cast<double *>(b), s->d_part + 4 * (int64_t)PIB_MAXPART, (int)PIB_MAXPART);
+                    PIB_HIP(hipGetLastError());
+                    s->gmg_upd.used = true;
+                    PIB_CHK(s->gmg_upd.after(s, nblk, q));
+                } else {
                 hipLaunchKernelGGL(k_presmooth2<1>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((kc + FZ - 1) / FZ)),
                                    dim3(256), 0, q, S, dev_of(sub), omega, b + ka * pl, a + ka * pl, pin_l, FZ, rr + ka * pl);
                 PIB_HIP(hipGetLastError());
+                }
             } else {
                 // x1 one plane deeper than it is kept (pointwise: as deep as b), then its residual
                 const int dx = I.dist ? std::min(std::min(o + 1, valid(b)), I.cdepth) : 0;

@@ -715,8 +715,9 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     const DeviceCsr &A = s->A;
     const int64_t n = A.n;
     hipStream_t q = s->stream;
-    PIB_CHK(ensure_work(s, 4));
+    PIB_CHK(ensure_work(s, 5));
     double *R = s->vec(0), *Z = s->vec(1), *P = s->vec(2), *W = s->vec(3);
+    double *R2 = s->vec(4);  // the other residual buffer of the fused update below
     const Precond pc = s->cfg.pc;
     const bool guess = s->cfg.initial_guess_nonzero;
     const double ng = (double)A.n_global;
@@ -765,6 +766,26 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     PIB_HIP(hipGetLastError());
 
     // ---- iterations
+    // Multigrid-preconditioned, one rank, systems too large for the captured graphs: r = r - alpha w is left to the V-cycle's
+    // first kernel, which reads the residual anyway (gmg.hip k_presmooth2<., 1>: 24 B/row and a launch less per iteration).
+    // That kernel recomputes halo cells, so the new residual goes to the OTHER of two buffers, iteration by iteration.
+    const bool fused_upd = gmg && s->cfg.fuse_residual_update && s->comm.nranks == 1 && lazy == 1 && n > GRAPH_MAX_ROWS &&
+                           gmg_fused_update_ok(s);
+    struct UpdCtx {
+        double *hist;
+        double ng;
+        int conv_is_its, unprec;
+    };
+    static thread_local UpdCtx upd_ctx;
+    upd_ctx = UpdCtx{s->d_hist, ng, conv_is_its, unprec ? 1 : 0};
+    auto after_update = +[](pib_solver *ps, int nblocks, hipStream_t st) -> int {
+        // r.r and sum r of the new residual from the march's partials (slots 4, 5), then the convergence step on |r|
+        hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, st, ps->d_s, ps->d_part, 4, nblocks);
+        if (upd_ctx.unprec)
+            hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, st, ps->d_s, upd_ctx.hist, upd_ctx.ng, 0, 1, 0, upd_ctx.conv_is_its);
+        PIB_HIP(hipGetLastError());
+        return 0;
+    };
     const int batch0 = first_batch(s), batch1 = next_batch(s);
     const int spmv_blocks = spmv_launch_blocks();
     int enq = 0;
@@ -792,6 +813,21 @@ int solve_cg(pib_solver *s, double *x, const double *b)
             else {
                 PIB_CHK(finalize(s, SLOT_PW, 1, spmv_blocks, q));
                 hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s);
+            }
+            if (fused_upd) {
+                s->gmg_upd.w = W;
+                s->gmg_upd.r_old = R;
+                s->gmg_upd.after = after_update;
+                s->gmg_upd.used = false;
+                const int err = gmg_pc_and_dots(s, R2, Z, true, q);
+                s->gmg_upd.w = nullptr;
+                if (err) return err;
+                if (!s->gmg_upd.used) return fail(PIB_ERR_LIB, "solver %s: the multigrid did not take the residual update", s->name.c_str());
+                std::swap(R, R2);
+                s->counters[6]++;
+                hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, unprec ? 0 : 1, 1, conv_is_its);
+                PIB_HIP(hipGetLastError());
+                return 0;
             }
             if (pc == Precond::JACOBI) {
                 OpUpdateXR<PCM_JACOBI> op{W, A.dinv, R, Z, omega, 0.0};

@@ -85,6 +85,7 @@ struct Config {
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
     int march_velocity = 1;        // matrix-free velocity product: LDS-tiled z-marching form for tile-divisible components (velstencil.hip k_vel_march)
+    int fuse_residual_update = 1;  // PCG + multigrid on one rank: r = r - alpha w by the V-cycle's first march instead of a pass of its own
     int fuse_bicgstab_dots = 1;  // ... and its two dot-only passes summed by the products themselves (sums grouped by tile: the iterates equal the CSR path's to rounding, no longer bit for bit; 0 keeps the bit-identical route)
     int blocked_direct_solve = 1;   // dense.hip: the explicit inverse of the direct solver by 64-column block elimination (0: one launch per column)
     int accumulate_unscaled_x = 1;  // ... and x summed before the Jacobi sweep, swept once at the end (krylov.hip OpBFUpdateP::y): 8 B/row/iteration less, x to rounding
@@ -282,6 +283,13 @@ struct pib_solver {
     double *d_gmg_part = nullptr;   // z.r, z.z, sum z partials of the V-cycle's last smoothing kernel (gmg.hip mode 8)
     int64_t gmg_part_cap = 0;
     bool gmg_want_dots = false, gmg_dots_done = false;
+    // PCG's residual update r = r_old - alpha w left to the preconditioner's first kernel (gmg.hip k_presmooth2<., 1>): set by
+    // the solver around gmg_apply; `after` finalizes r.r / sum r from the kernel's partials and runs the convergence step
+    struct GmgUpd {
+        const double *w = nullptr, *r_old = nullptr;
+        int (*after)(pib_solver *, int nblocks, hipStream_t) = nullptr;
+        bool used = false;
+    } gmg_upd;
     double *d_hist = nullptr;
     int hist_cap = 0;
     hipGraphExec_t graph = nullptr;   // one Krylov iteration (krylov.hip: run_iterations)
@@ -378,6 +386,7 @@ bool stencil_matmult_ok(const pib_solver *s);
 int stencil_matmult(pib_solver *s, const double *x, double *y, double *dot_part, bool guarded, hipStream_t q);
 int spmv_launch_blocks();
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t st);
+bool gmg_fused_update_ok(const pib_solver *s);
 void gmg_release(pib_solver *s);
 int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double *const g[3],
                   int nullspace, double dt /* <= 0: recover from g */);

@@ -800,3 +800,44 @@ def test_marching_transfers_are_bit_identical(lin, n, pinned, key, sweeps):
     assert iters_close(out[0][2], ref["iters"])
     ke = min(len(out[0][1]), len(ref["history"]), 6)
     assert np.allclose(out[0][1][:ke], ref["history"][:ke], rtol=1e-8)
+
+
+@pytest.mark.parametrize("flavour,sweeps", [("amgx", 2), ("amgx", 1), ("ksp", 2)])
+def test_residual_update_inside_the_vcycle_is_bit_identical(lin, flavour, sweeps):
+    """krylov.hip / gmg.hip k_presmooth2<., 1>: on systems beyond the captured-graph size (> 2^22 rows, one rank) PCG leaves
+    r = r - alpha w to the V-cycle's first march, which reads the residual anyway.  Same expression per cell: the iterates and
+    the solution are those of the separate pass bit for bit; only the printed norms (sums grouped by tile) move in the last
+    digits.  Both norm conventions (AmgX: |r| checked before the cycle; KSP: the preconditioned norm after it) and both
+    pre-smoothing forms (pair; step + residual)."""
+    from petibm_amd import capi
+    n = (256, 128, 136)
+    w = [np.full(n[0], 1.0 / n[0]) * (1.0 + 0.3 * np.sin(np.arange(n[0]) / 17.0)),
+         np.full(n[1], 1.0 / n[1]), np.full(n[2], 1.5 / n[2]) * (1.0 + 0.2 * np.cos(np.arange(n[2]) / 11.0))]
+    dt = 0.01
+    xs = np.random.default_rng(7).uniform(-1, 1, n[0] * n[1] * n[2])
+    xs -= xs.mean()
+    out = []
+    for fuse in (1, 0):
+        extra = f"pib_fuse_residual_update={fuse}\npib_march_min_cells=0\n"
+        if flavour == "amgx":
+            text = gmg_cfg(pre=sweeps, post=sweeps, extra=extra)
+        else:
+            text = ("-poisson_ksp_type cg\n-poisson_ksp_rtol 1.0E-10\n-poisson_ksp_atol 1.0E-50\n-poisson_ksp_max_it 200\n"
+                    "-poisson_pc_type gamg\n-poisson_pib_smoother JACOBI\n"
+                    f"-poisson_pib_presweeps {sweeps}\n-poisson_pib_postsweeps {sweeps}\n-poisson_pib_fuse_residual_update {fuse}\n"
+                    "-poisson_pib_march_min_cells 0\n")
+        s = lin.LinSolverHIP("poisson", config_text=text)
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+        b = np.empty_like(xs)
+        s.matMult(xs, b)
+        x = np.zeros_like(xs)
+        s.solve(x, b)
+        r = np.empty_like(xs)
+        s.matMult(x, r)
+        out.append((x, np.array(s.getResidualHistory()), s.getIters(), np.linalg.norm(b - r) / np.linalg.norm(b), int(s.counters()[6])))
+        s.destroy()
+    assert out[0][4] >= out[0][2] and out[1][4] == 0  # every (enqueued) iteration of the first run took the fused form, none of the second
+    assert out[0][2] == out[1][2] and 5 <= out[0][2] <= 40
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-12)
+    assert out[0][3] <= 2e-10
