@@ -515,7 +515,8 @@ def poisson_bench(args) -> int:
                          "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes},
             "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "reductions": int(counters[2]),
                          "halo_exchanges": int(counters[3]), "host_polls": int(counters[4]),
-                         "comm_ranks": int(counters[5])},  # ncclCommCount of the solver's communicator (1: none)
+                         "comm_ranks": int(counters[5]),  # ncclCommCount of the solver's communicator (1: none)
+                         "residual_updates_in_vcycle": int(counters[6])},  # iterations whose r -= a w ran inside the V-cycle's first march
         }
         if args.pc == "gmg" and world == 1:
             # the whole solve against the roofline: algorithmic bytes of every kernel of an iteration (model in
