@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "csrc")
 _LIBDIR = os.path.join(_HERE, "lib")
-SOURCES = ["config.cpp", "capi.cpp", "structure.cpp", "halo.hip", "kernels_spmv.hip", "krylov.hip", "assemble.hip", "gmg.hip", "dense.hip", "navierstokes.hip", "ibm.hip", "bn.hip", "velstencil.hip"]
+SOURCES = ["config.cpp", "capi.cpp", "structure.cpp", "partition.cpp", "redistribute.hip", "halo.hip", "kernels_spmv.hip", "krylov.hip", "assemble.hip", "gmg.hip", "dense.hip", "navierstokes.hip", "ibm.hip", "bn.hip", "velstencil.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wall", "-Wno-unused-function"]
 

@@ -35,6 +35,14 @@ void DeviceCsr::release()
     seg_recv_lo.clear();
     seg_recv_hi.clear();
     segmented = false;
+    if (send_idx) (void)hipFree(send_idx);
+    if (send_buf) (void)hipFree(send_buf);
+    send_idx = nullptr;
+    send_buf = nullptr;
+    general = false;
+    ghost_cols.clear();
+    ghost_off.clear();
+    xplan = ExchangePlan();
 }
 
 // DMDA default ownership along one axis (cartesianmesh.cpp:492-538 via

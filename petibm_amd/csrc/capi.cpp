@@ -115,6 +115,7 @@ int pib_destroy(pib_solver *s)
     if (s == nullptr) return 0;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    redist_release(s);
     gmg_release(s);
     dense_release(s);
     vel_stencil_release(s);
@@ -170,42 +171,55 @@ int after_set_matrix(pib_solver *s)
 }  // namespace pib
 }  // extern "C++"
 
-int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_global, const int64_t *rowptr,
-                const int64_t *col_global, const double *val)
+// LinSolverBase::setMatrix / AmgXSolver::setA (src/linsolver/linsolveramgx.cpp:84): this rank's rows, global columns, in
+// WHATEVER partition the application's DMDA produced (partition.cpp).  Collective on several ranks.
+static int set_csr_any(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_global, const int64_t *rp64,
+                       const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val)
 {
-    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr: null solver");
     PIB_HIP(hipSetDevice(s->device));
     s->has_matrix = false;
     s->has_grid = false;
     gmg_release(s);
-    PIB_CHK(upload_csr(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val));
-    PIB_CHK(after_set_matrix(s));
+    redist_release(s);
     s->structure_detected = false;
-    if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
-        PIB_CHK(detect_grid_structure(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val));
     s->vel_detected = false;
+    if (n_local < 0 || row0_global < 0 || n_global < n_local) return fail(PIB_ERR_ARG_OUTOFRANGE, "set_csr: bad sizes");
+    if ((rp64 == nullptr && rp32 == nullptr) || (cl64 == nullptr && cl32 == nullptr && n_local > 0) || (val == nullptr && n_local > 0))
+        return fail(PIB_ERR_ARG_NULL, "set_csr: null array");
+    std::vector<int64_t> ranges;
+    bool general = false;
+    PIB_CHK(classify_partition(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, ranges, &general));
+    if (general) {
+        PIB_CHK(upload_csr_general(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val, ranges));
+        PIB_CHK(after_set_matrix(s));
+        if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
+            PIB_CHK(redist_setup(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val, ranges));
+        if (s->cfg.pc == Precond::GMG && !s->redist.active)
+            s->gmg_error = "the rows came in a partition that is neither z-slabs in natural ordering nor DMDA boxes of PetIBM's Poisson "
+                           "operator: no mesh structure for the multigrid";
+        return 0;
+    }
+    PIB_CHK(upload_csr(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
+    PIB_CHK(after_set_matrix(s));
+    if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
+        PIB_CHK(detect_grid_structure(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
     if (s->cfg.pc != Precond::GMG && s->cfg.detect_structure && s->cfg.matrix_free_velocity)
-        PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val));
+        PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
     return 0;
+}
+
+int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_global, const int64_t *rowptr,
+                const int64_t *col_global, const double *val)
+{
+    if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr: null solver");
+    return set_csr_any(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val);
 }
 
 int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t n_global, const int32_t *rowptr,
                     const int32_t *col_global, const double *val)
 {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr_i32: null solver");
-    PIB_HIP(hipSetDevice(s->device));
-    s->has_matrix = false;
-    s->has_grid = false;
-    gmg_release(s);
-    PIB_CHK(upload_csr(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val));
-    PIB_CHK(after_set_matrix(s));
-    s->structure_detected = false;
-    if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
-        PIB_CHK(detect_grid_structure(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val));
-    s->vel_detected = false;
-    if (s->cfg.pc != Precond::GMG && s->cfg.detect_structure && s->cfg.matrix_free_velocity)
-        PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val));
-    return 0;
+    return set_csr_any(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val);
 }
 
 int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
@@ -227,6 +241,7 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
 int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int *nullspace, int *detected)
 {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_grid_structure: null solver");
+    if (s->redist.active) s = s->redist.inner;  // rows handed over in boxes: the structure lives in the slab solver
     const bool have = s->has_grid && !s->levels.empty();
     if (has) *has = have ? 1 : 0;
     if (detected) *detected = (have && s->structure_detected) ? 1 : 0;
@@ -246,6 +261,7 @@ int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int 
 int pib_get_multigrid_levels(pib_solver *s, int *nlevels, int64_t *n3, int max_levels)
 {
     if (s == nullptr || nlevels == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_multigrid_levels: null argument");
+    if (s->redist.active) s = s->redist.inner;
     *nlevels = (int)s->levels.size();
     for (int l = 0; n3 != nullptr && l < *nlevels && l < max_levels; ++l) {
         const GridLevel &g = s->levels[(size_t)l];  // internal layout of a 2-D grid is (nx, 1, ny)
@@ -368,7 +384,23 @@ int pib_solve(pib_solver *s, double *x, const double *b)
         bdev = s->b_dev;
     }
     int err;
-    if (s->cfg.method == Method::CG)
+    if (s->redist.active) {
+        // rows in DMDA boxes + multigrid: b (and the guess) go to the z-slabs of the inner solver, x comes back
+        Redist &R = s->redist;
+        pib_solver *in = R.inner;
+        PIB_CHK(redist_forward(s, bdev, R.b_nat, s->stream));
+        if (s->cfg.initial_guess_nonzero) PIB_CHK(redist_forward(s, xdev, R.x_nat, s->stream));
+        PIB_HIP(hipStreamSynchronize(s->stream));
+        in->cfg.error_if_not_converged = false;  // reported below, by this solver
+        err = pib_solve(in, R.x_nat, R.b_nat);
+        if (!err) err = hipStreamSynchronize(in->stream) == hipSuccess ? 0 : fail(PIB_ERR_LIB, "solver %s: the slab solver's stream failed", s->name.c_str());
+        if (!err) err = redist_backward(s, R.x_nat, xdev, s->stream);
+        s->iters = in->iters;
+        s->reason = in->reason;
+        s->residual = in->residual;
+        s->history = in->history;
+        for (int k = 0; k < 8; ++k) s->counters[k] = in->counters[k];
+    } else if (s->cfg.method == Method::CG)
         err = solve_cg(s, xdev, bdev);
     else if (s->cfg.method == Method::BICGSTAB)
         err = solve_bicgstab(s, xdev, bdev);
@@ -491,6 +523,13 @@ int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, 
         std::vector<int32_t> t((size_t)A.nnz);
         PIB_HIP(hipMemcpy(t.data(), A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
         const int64_t shift = A.row0 - A.ghost_lo;
+        if (A.general) {  // [low ghosts | owned | high ghosts]: the ghosts' global columns are kept on the host
+            for (size_t i = 0; i < t.size(); ++i) {
+                const int64_t c = t[i];
+                col_global[i] = c < A.ghost_lo ? A.ghost_cols[(size_t)c]
+                                               : (c < A.ghost_lo + A.n ? A.row0 + (c - A.ghost_lo) : A.ghost_cols[(size_t)(c - A.n)]);
+            }
+        } else
         for (size_t i = 0; i < t.size(); ++i) col_global[i] = (int64_t)t[i] + shift;
     }
     if (val) PIB_HIP(hipMemcpy(val, A.val, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToHost));

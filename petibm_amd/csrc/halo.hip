@@ -471,7 +471,7 @@ int comm_setup_halo(pib_solver *s)
             return fail(PIB_ERR_ARG_OUTOFRANGE, "single-rank matrix has columns outside [0, n)");
         return 0;
     }
-    if (A.segmented) return 0;  // the assembly that chose the segmented plan has set every list
+    if (A.segmented || A.general) return 0;  // the assembly / upload that chose such a plan has set every list
     const int P = s->comm.nranks, r = s->comm.rank;
     const int64_t mine[4] = {A.n, A.ghost_lo, A.ghost_hi, A.row0};
     std::vector<int64_t> all;
@@ -589,6 +589,7 @@ int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_
     const int P = s->comm.nranks, r = s->comm.rank;
     if (!s->comm.active()) return 0;
     s->counters[3]++;
+    s->counters[7] += 8 * (((r > 0 || s->comm.ring) ? send_prev : 0) + ((r < P - 1 || s->comm.ring) ? send_next : 0));  // bytes this rank sends
     if (s->comm.loop && s->comm.loop->shm) {
         const bool ring = s->comm.ring;
         return peer_window_exchange(s, st, (r + P - 1) % P, (r + 1) % P, r > 0 || ring, r < P - 1 || ring, {{x_owned, send_prev}},
@@ -629,6 +630,10 @@ static int halo_exchange_segments(pib_solver *s, double *x_owned, hipStream_t st
     const DeviceCsr &A = s->A;
     const int P = s->comm.nranks, r = s->comm.rank;
     s->counters[3]++;
+    if (r > 0 || s->comm.ring)
+        for (const auto &sg : A.seg_send_prev) s->counters[7] += 8 * sg.second;
+    if (r < P - 1 || s->comm.ring)
+        for (const auto &sg : A.seg_send_next) s->counters[7] += 8 * sg.second;
     if (s->comm.loop && s->comm.loop->shm) {
         std::vector<std::pair<const double *, int64_t>> to_prev, to_next;
         for (const auto &sg : A.seg_send_prev) to_prev.emplace_back(x_owned + sg.first, sg.second);
@@ -718,6 +723,7 @@ int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st)
 {
     const DeviceCsr &A = s->A;
     if (!s->comm.active()) return 0;
+    if (A.general) return halo_exchange_general(s, x_owned, st);
     if (A.segmented) return halo_exchange_segments(s, x_owned, st);
     return halo_exchange_planes(s, x_owned, A.n, A.ghost_lo, A.ghost_hi, A.send_prev, A.send_next, st);
 }
@@ -886,6 +892,73 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
         }
         PIB_NCCL(ncclGroupEnd());
     }
+    return 0;
+}
+
+// One message per ordered pair of ranks (ExchangePlan): a rank's messages lie back to back, in destination order, at
+// `stream`; what rank q sends to this rank lands at recv[q].  The general halo exchange of an arbitrary row partition
+// and the box <-> slab moves of redistribute.hip.  RCCL: one group of ncclSend / ncclRecv (point-to-point over xGMI,
+// every pair that has a message); loopback: the streams are published and pulled; peer: the streams go through the
+// windows a window's worth at a time -- every rank knows the whole table, so it knows which part of which message lies
+// where in a neighbour's window in every round.
+int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream, double *const *recv, hipStream_t st)
+{
+    const int P = pl.P, r = pl.me;
+    if (pl.from(r) > 0)
+        PIB_HIP(hipMemcpyAsync(recv[r], stream + pl.send_off[(size_t)r], sizeof(double) * (size_t)pl.from(r), hipMemcpyDeviceToDevice, st));
+    if (!s->comm.active()) return 0;
+    s->counters[3]++;
+    s->counters[7] += 8 * (pl.send_total - pl.to(r));
+    if (s->comm.loop && s->comm.loop->shm) {
+        LoopbackGroup *g = s->comm.loop;
+        const int64_t W = g->win_doubles;
+        const int64_t rounds = (pl.max_stream + W - 1) / W;
+        for (int64_t k = 0; k < rounds; ++k) {
+            const int64_t lo = k * W, hi = lo + W;
+            uint64_t seq = 0;
+            PIB_CHK(g->begin(st, &seq));
+            const int64_t mine = std::max<int64_t>(0, std::min(hi, pl.send_total) - lo);
+            if (mine > 0) PIB_HIP(hipMemcpyAsync(g->win_local, stream + lo, sizeof(double) * (size_t)mine, hipMemcpyDeviceToDevice, st));
+            PIB_CHK(g->raise(st, g->shm->ready[r], seq));
+            for (int q = 0; q < P; ++q) {
+                if (q == r) continue;
+                const int64_t a = std::max(lo, pl.src_off[(size_t)q]), b = std::min(hi, pl.src_off[(size_t)q] + pl.from(q));
+                if (b <= a) continue;
+                PIB_CHK(g->await(g->shm->ready[q], seq, "exchange", q));
+                PIB_HIP(hipMemcpyAsync(recv[q] + (a - pl.src_off[(size_t)q]), g->win[(size_t)q] + (a - lo), sizeof(double) * (size_t)(b - a),
+                                       hipMemcpyDeviceToDevice, st));
+            }
+            PIB_CHK(g->raise(st, g->shm->done[r], seq));
+            PIB_CHK(g->finish(st));
+            for (int q = 0; q < P; ++q)
+                if (q != r) g->owe(seq, q);
+        }
+        return 0;
+    }
+    if (s->comm.loop) {
+        LoopbackGroup *g = s->comm.loop;
+        PIB_CHK(g->publish(r, stream, pl.send_total));
+        PIB_HIP(hipEventRecord(g->ev_ready[(size_t)r], st));
+        PIB_CHK(g->barrier());
+        for (int q = 0; q < P; ++q) {
+            if (q == r || pl.from(q) == 0) continue;
+            PIB_HIP(hipStreamWaitEvent(st, g->ev_ready[(size_t)q], 0));
+            PIB_HIP(hipMemcpyAsync(recv[q], g->ptr[(size_t)q] + pl.src_off[(size_t)q], sizeof(double) * (size_t)pl.from(q), hipMemcpyDeviceToDevice, st));
+        }
+        PIB_HIP(hipEventRecord(g->ev_done[(size_t)r], st));
+        PIB_CHK(g->barrier());
+        for (int q = 0; q < P; ++q)
+            if (q != r && pl.to(q) > 0) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)q], 0));  // they have read my stream
+        PIB_CHK(g->barrier());
+        return 0;
+    }
+    PIB_NCCL(ncclGroupStart());
+    for (int q = 0; q < P; ++q) {
+        if (q == r) continue;
+        if (pl.to(q) > 0) PIB_NCCL(ncclSend(stream + pl.send_off[(size_t)q], (size_t)pl.to(q), ncclDouble, q, s->comm.comm, st));
+        if (pl.from(q) > 0) PIB_NCCL(ncclRecv(recv[q], (size_t)pl.from(q), ncclDouble, q, s->comm.comm, st));
+    }
+    PIB_NCCL(ncclGroupEnd());
     return 0;
 }
 

@@ -640,7 +640,8 @@ template <class Op>
 static int update_p_and_exchange(pib_solver *s, int64_t n, const Op &up, double *P, hipStream_t q, bool vec2 = true)
 {
     const DeviceCsr &A = s->A;
-    const bool split = s->comm.nranks > 1 && s->cfg.overlap_halo && (A.send_prev % 2 == 0) && (A.send_next % 2 == 0) &&
+    // (a general plan's send entries are scattered over the vector: no leading / trailing part to update first)
+    const bool split = s->comm.nranks > 1 && s->cfg.overlap_halo && !A.general && (A.send_prev % 2 == 0) && (A.send_next % 2 == 0) &&
                        (n % 2 == 0) && A.send_prev + A.send_next < n;
     if (!split) return launch_vec(s, n, up, vec2, 0, nullptr, true, q);
     PIB_CHK(launch_vec(s, n, up, vec2, 0, nullptr, true, q, 0, A.send_prev));

@@ -113,6 +113,7 @@ int parse_config_file(const char *path, const std::string &name, Config &cfg);
 // One block of scalars in HBM drives the Krylov recurrences: no host round
 // trip inside an iteration.  Every iteration kernel starts with `if (S->done)
 // return;` so over-enqueued iterations are no-ops.
+constexpr int PIB_MAX_RANKS = 64;  // ranks of one communicator (general halo plans, box <-> slab moves, the peer transport)
 constexpr int PIB_NRED = 8;       // reduction slots
 constexpr int PIB_MAXPART = 4096; // partial sums per slot (>= max blocks of a reduction)
 struct Scalars {
@@ -133,6 +134,39 @@ struct Scalars {
     // p-update of iteration k + 1 (xpend: one is owed; flushed after the loop)
     int xpend;
     double xalpha, xomega;
+};
+
+// ------------------------------------------------------------------ who sends how many doubles to whom
+// One message per ordered pair of ranks; every rank holds the whole table, so a receiver knows where its message lies
+// in the sender's stream (the sender's messages back to back in destination order) without asking.
+struct ExchangePlan {
+    int P = 0, me = 0;
+    std::vector<int64_t> cnt;       // [P * P]: cnt[s * P + d] doubles from s to d
+    std::vector<int64_t> send_off;  // [P + 1]: my message to d is stream[send_off[d] .. send_off[d + 1])
+    std::vector<int64_t> src_off;   // [P]: my message from s starts at this offset of s's stream
+    int64_t send_total = 0, recv_total = 0, max_stream = 0;
+    void finish(int nranks, int rank)
+    {
+        P = nranks;
+        me = rank;
+        send_off.assign((size_t)P + 1, 0);
+        src_off.assign((size_t)P, 0);
+        recv_total = max_stream = 0;
+        for (int d = 0; d < P; ++d) send_off[(size_t)d + 1] = send_off[(size_t)d] + cnt[(size_t)me * P + d];
+        send_total = send_off[(size_t)P];
+        for (int q = 0; q < P; ++q) {
+            int64_t o = 0, tot = 0;
+            for (int d = 0; d < P; ++d) {
+                if (d == me) o = tot;
+                tot += cnt[(size_t)q * P + d];
+            }
+            src_off[(size_t)q] = o;
+            recv_total += cnt[(size_t)q * P + me];
+            max_stream = tot > max_stream ? tot : max_stream;
+        }
+    }
+    int64_t to(int d) const { return cnt[(size_t)me * P + d]; }
+    int64_t from(int q) const { return cnt[(size_t)q * P + me]; }
 };
 
 // ------------------------------------------------------------------ matrix
@@ -158,6 +192,17 @@ struct DeviceCsr {
     std::vector<std::pair<int64_t, int64_t>> seg_send_prev, seg_send_next;
     std::vector<int64_t> seg_recv_lo, seg_recv_hi;  // counts of the segments received into the low / high ghost pad
     bool segmented = false;
+    // General plan (any row partition: the DMDA boxes PETSC_DECIDE gives an unchanged PetIBM from 4 ranks up, its
+    // per-rank-packed velocity ordering; partition.cpp): the ghost columns are the sorted distinct off-rank columns --
+    // those below row0 fill the low pad, the others the high pad --, every owner packs the entries its peers asked for
+    // (send_idx: local rows, grouped by destination rank) and one grouped exchange delivers them (what AmgX does behind
+    // AmgXSolver::setA, src/linsolver/linsolveramgx.cpp:84).
+    bool general = false;
+    ExchangePlan xplan;
+    int32_t *send_idx = nullptr;   // device [xplan.send_total]
+    double *send_buf = nullptr;    // device [xplan.send_total]
+    std::vector<int64_t> ghost_cols;   // host: global column of every ghost entry, ascending
+    std::vector<int64_t> ghost_off;    // [P + 1]: ghosts owned by rank q are ghost_cols[ghost_off[q] .. ghost_off[q + 1])
     void release();
 };
 
@@ -235,6 +280,24 @@ struct MeshWindow {
     int64_t first = 0, n_global = 0;
     const double *w_global = nullptr;
     double lo = 0.0, hi = 0.0;  // ends of the whole mesh along the axis
+};
+
+// Rows handed over in DMDA boxes (PETSc ordering) and a multigrid preconditioner asked for: the rows, and every solve's
+// b and x, are moved once / per solve to the z-slabs in natural ordering the geometric multigrid works on, inside an
+// inner solver that shares this one's communicator (partition.cpp, redistribute.hip).
+struct Redist {
+    bool active = false;
+    pib_solver *inner = nullptr;
+    int dim = 0;
+    int64_t n[3] = {1, 1, 1};       // cells, internal layout (a 2-D grid is (nx, 1, ny): the slab axis is always the last)
+    int grid[3] = {1, 1, 1};        // process grid (m, n, p) in the same layout
+    std::vector<int64_t> box;       // [P][6]: xs, ys, zs, xm, ym, zm of every rank
+    pib::ExchangePlan fwd, bwd;     // boxes -> slabs (b, the guess), slabs -> boxes (x)
+    int64_t k0 = 0, k1 = 0;         // this rank's slab
+    int32_t *d_split = nullptr;     // device: x / y / z box boundaries (m + 1, n + 1, p + 1 entries back to back)
+    int64_t *d_src = nullptr;       // device [P][2]: offset of rank q's chunk in the staging vector, first plane of the chunk
+    double *stage = nullptr, *b_nat = nullptr, *x_nat = nullptr;  // device [slab rows]
+    int64_t n_slab = 0;
 };
 
 struct pib_solver {
@@ -315,6 +378,7 @@ struct pib_solver {
     std::vector<double> history;
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t work_lo = 0;      // entries before the owned part of a work vector
+    Redist redist;            // general row partition + multigrid: the solve happens on z-slabs in the inner solver
     double *vec(int i) const { return work + (int64_t)i * work_stride + work_lo; }
 };
 
@@ -336,7 +400,22 @@ int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st
 int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vector<double> &all);
 int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const std::vector<int64_t> &counts,
                     const std::vector<int64_t> &offs, hipStream_t st);
+// every rank's messages lie back to back (destination order) at `stream`; the message from rank q lands at recv[q]
+int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream, double *const *recv, hipStream_t st);
 void comm_release(pib_solver *s);
+// partition.cpp: rows in any partition (DMDA boxes, the per-rank-packed velocity ordering)
+int classify_partition(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64, const int64_t *cl64,
+                       const int32_t *rp32, const int32_t *cl32, std::vector<int64_t> &ranges, bool *general);
+int upload_csr_general(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64, const int64_t *cl64,
+                       const int32_t *rp32, const int32_t *cl32, const double *val, const std::vector<int64_t> &ranges);
+int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64, const int64_t *cl64,
+                 const int32_t *rp32, const int32_t *cl32, const double *val, const std::vector<int64_t> &ranges);
+void redist_release(pib_solver *s);
+// redistribute.hip
+int halo_exchange_general(pib_solver *s, double *x_owned, hipStream_t st);
+int redist_tables(pib_solver *s);
+int redist_forward(pib_solver *s, const double *v_box, double *v_nat, hipStream_t st);
+int redist_backward(pib_solver *s, const double *v_nat, double *v_box, hipStream_t st);
 // a solver on `other`'s device, rank and communicator (the second solver of a flow engine)
 int create_sharing_comm(pib_solver **out, const char *name, const char *cfg_text, pib_solver *other);
 // krylov.hip

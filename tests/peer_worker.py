@@ -29,6 +29,26 @@ def poisson(job, r):
     return out
 
 
+def boxes(job, r):
+    """rows in DMDA boxes / the per-rank-packed velocity ordering (tests/test_gpu_dmda_boxes.py): setMatrix only"""
+    from oracle import operators as oops
+    from petibm_amd.linsolver import LinSolverHIP
+    P = job["P"]
+    s = LinSolverHIP(job["name"], config_text=job["cfg"], rank=r, nranks=P, uid=job["uid"], device=0)
+    rp, cl, vl = job["parts"][r]
+    r0, r1 = int(job["offsets"][r]), int(job["offsets"][r + 1])
+    s.setMatrix(oops.CSR(r1 - r0, job["n_global"], rp, cl, vl), row0=r0, n_global=job["n_global"])
+    st = s.gridStructure()
+    y = np.empty(r1 - r0)
+    s.matMult(np.ascontiguousarray(job["xs"][r0:r1]), y)
+    x = np.zeros(r1 - r0)
+    s.solve(x, np.ascontiguousarray(job["b"][r0:r1]))
+    out = dict(y=y, x=x, its=s.getIters(), reason=s.getReason(), counters=np.asarray(s.counters()),
+               detected=bool(st is not None and st["detected"]))
+    s.destroy()
+    return out
+
+
 def navierstokes(job, r):
     """cases of test_gpu_navierstokes_slabs.py (plain time step or immersed bodies) on this rank's slab; the single-rank
     fields of the job are cut to the owned points here (the solver knows its slab)"""
@@ -63,7 +83,7 @@ def navierstokes(job, r):
 def main():
     job = pickle.load(open(sys.argv[1], "rb"))
     r = int(sys.argv[2])
-    out = {"poisson": poisson, "navierstokes": navierstokes}[job["kind"]](job, r)
+    out = {"poisson": poisson, "navierstokes": navierstokes, "boxes": boxes}[job["kind"]](job, r)
     np.savez(os.path.join(os.path.dirname(sys.argv[1]), f"rank{r}.npz"), **out)
 
 
