@@ -15,8 +15,10 @@
 // the pinned-pressure convention as they do today (applications/navierstokes/navierstokes.cpp:414-420,553-558).
 // An `AMG` preconditioner entry is served by the geometric multigrid: the mesh structure it needs is RECOVERED FROM THE
 // MATRIX (pib_set_csr detects the 5/7-point DBNG of a tensor-product mesh and verifies the recovered operator against
-// the CSR on the device), so nothing beyond setA is asked of the application.  The process grid must be z-slabs
-// (-da_processors_x 1 -da_processors_y 1), the decomposition of SURVEY.md 8e.
+// the CSR on the device), so nothing beyond setA is asked of the application.  Several ranks: setA takes the rows in
+// whatever partition PetIBM's DMDAs produced -- PETSC_DECIDE cuts boxes from 4 ranks up (src/mesh/cartesianmesh.cpp:97,
+// 503-519; no command-line switch changes that: PetIBM never calls DMSetFromOptions) -- and the backend moves the
+// Poisson rows to natural z-slabs for its multigrid itself (csrc/partition.cpp, INTEGRATION.md "Several ranks").
 //
 // Needs PETSc + MPI headers: syntax-checked only in this repository (tests/stubs/petsc, tests/test_boundary_headers.py).
 #pragma once

@@ -388,6 +388,7 @@ int pib_solve(pib_solver *s, double *x, const double *b)
         // rows in DMDA boxes + multigrid: b (and the guess) go to the z-slabs of the inner solver, x comes back
         Redist &R = s->redist;
         pib_solver *in = R.inner;
+        for (int k = 0; k < 8; ++k) s->counters[k] = 0;  // the moves of b / x count as this solve's exchanges and bytes
         PIB_CHK(redist_forward(s, bdev, R.b_nat, s->stream));
         if (s->cfg.initial_guess_nonzero) PIB_CHK(redist_forward(s, xdev, R.x_nat, s->stream));
         PIB_HIP(hipStreamSynchronize(s->stream));
@@ -399,7 +400,7 @@ int pib_solve(pib_solver *s, double *x, const double *b)
         s->reason = in->reason;
         s->residual = in->residual;
         s->history = in->history;
-        for (int k = 0; k < 8; ++k) s->counters[k] = in->counters[k];
+        for (int k = 0; k < 8; ++k) s->counters[k] += in->counters[k];
     } else if (s->cfg.method == Method::CG)
         err = solve_cg(s, xdev, bdev);
     else if (s->cfg.method == Method::BICGSTAB)
