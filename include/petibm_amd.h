@@ -83,12 +83,20 @@ int pib_version(void);
 #define PIB_UID_BYTES 128
 int pib_comm_unique_id(void *uid_out /* PIB_UID_BYTES */);
 
-/* PEER transport (one node): one process per rank, the neighbours' vectors mapped through HIP IPC (peer memory over
- * xGMI) and pulled with device-to-device copies ordered by interprocess events; the ranks meet in a POSIX shared-memory
- * segment whose name this id carries.  Rank 0 calls pib_comm_peer_id, the id travels to the other ranks like the RCCL
- * one, every rank passes it to pib_create.  Several ranks may share a GPU (RCCL refuses that), so this is also how the
- * multi-process path is tested on a one-GPU box.  PIB_PEER_TIMEOUT_S (default 600) bounds every wait for another rank. */
+/* PEER transport (one node): one process per rank, every rank's windows mapped by all the others through HIP IPC (peer
+ * memory over xGMI); the ranks meet in a POSIX shared-memory segment whose name this id carries.  Rank 0 calls
+ * pib_comm_peer_id, the id travels to the other ranks like the RCCL one, every rank passes it to pib_create.  Two
+ * orderings of the collectives:
+ *   device-ordered (default): a rank STORES its boundary planes straight into the receiver's window, a release flag
+ *     follows in stream order, the receiver's kernel spins on it -- no host thread and no RCCL launch on the path of a
+ *     collective, and nothing per call that a captured iteration graph could not replay;
+ *   host-ordered (pib_comm_peer_id_ordered(uid, 0) or PIB_PEER_ORDER=host): device-to-device copies ordered by host
+ *     functions and host threads waiting on shared counters -- the first implementation, the reference the other is
+ *     compared with (same bits).
+ * Several ranks may share a GPU (RCCL refuses that), so this is also how the multi-process path is tested on a one-GPU
+ * box.  PIB_PEER_TIMEOUT_S (default 600; device-side spins: at most 60) bounds every wait for another rank. */
 int pib_comm_peer_id(void *uid_out /* PIB_UID_BYTES */);
+int pib_comm_peer_id_ordered(void *uid_out /* PIB_UID_BYTES */, int device_ordered);
 
 /* TEST transport: `nranks` ranks = host threads of ONE process sharing ONE GPU (RCCL refuses several
  * ranks per device).  Fills a PIB_UID_BYTES id to pass to pib_create from every thread.  Used by the

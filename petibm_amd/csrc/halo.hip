@@ -59,10 +59,52 @@ struct PeerShm {
     int64_t window_doubles;       // size of every rank's window (the same everywhere: rank 0's setting)
     hipIpcMemHandle_t staging;    // rank 0's [nranks][PIB_NRED] buffer of the scalar all-reduce
     hipIpcMemHandle_t window[PEER_MAX_RANKS];  // every rank's window: what it sends lies there for the others to fetch
+    hipIpcMemHandle_t dwindow[PEER_MAX_RANKS]; // device-ordered flavour: every rank's RECEIVE window (peers store into it)
     // collective number `seq` (counted alike on every rank): ready[r] >= seq -- rank r's window holds its data for it;
     // done[r] >= seq -- rank r has fetched what it needs from the others' windows.  Set by host functions in stream order.
     PeerFlag ready[PEER_MAX_RANKS], done[PEER_MAX_RANKS];
     int64_t host_vals[PEER_MAX_RANKS][4];
+};
+
+// ---- device-ordered flavour of the peer transport: no host thread and no RCCL launch on the path of a collective.
+// A rank STORES what it sends straight into the receiver's window (mapped through HIP IPC: peer memory over xGMI), a
+// release flag per ordered pair of ranks follows the data in stream order (system-scope fence, then the store), the
+// receiver's kernel spins on the flag, copies the data out of its own window and acknowledges; flags, acknowledgements
+// and the payload of the scalar all-reduce live in a block of the shared segment that every process registers with HIP
+// (host memory is fine-grained: a store from one GPU is visible to a polling load from another without a kernel
+// boundary).  Collective numbers are counted ON THE DEVICE (ctr[]), so the kernels carry no per-call constants and a
+// captured iteration graph replays them.  A window has two halves used in turn (collective k in half k & 1), laid out per
+// collective; before a sender stores into a half it waits until the RECEIVER has finished collective k - 2 altogether
+// (a progress counter per rank: other senders' data of that collective may lie where this one is about to write) -- which
+// has practically always happened: nobody runs more than two collectives ahead of a rank it sends to.
+struct PeerDevBlock {
+    uint64_t ready[PEER_MAX_RANKS * PEER_MAX_RANKS];  // ready[d * P + s]: s's data of collective # has landed in d's window
+    uint64_t done[PEER_MAX_RANKS];                    // done[d]: d has copied everything of collective # out of its window
+    uint64_t rflag[PEER_MAX_RANKS];                   // all-reduce #: rank's values are in vals
+    double vals[2 * PEER_MAX_RANKS * PIB_NRED];       // [parity][rank][slot]
+    int failed;                                       // a spin timed out
+};
+constexpr size_t PEER_DEV_OFF = (sizeof(PeerShm) + 4095) / 4096 * 4096;
+constexpr size_t PEER_DEV_BYTES = (sizeof(PeerDevBlock) + 4095) / 4096 * 4096;
+constexpr int DMSG = 16;
+struct DevMsgs {  // one launch: up to DMSG messages
+    int n;
+    int peer[DMSG];
+    const double *src[DMSG];  // put: local source
+    double *dst[DMSG];        // get: local destination
+    int64_t off[DMSG];        // place inside the current half of the RECEIVER's window
+    int64_t cnt[DMSG];
+};
+struct DevComm {
+    int me, P;
+    uint64_t *ready, *done, *rflag;
+    double *vals;
+    int *failed;
+    uint64_t *ctr;       // device: [0] collectives done, [1] all-reduces done, [2] / [3] arrival counters of put / get
+    double *const *wins; // device [P]: every rank's receive window as this process sees it
+    double *win_local;
+    int64_t half;        // doubles per half
+    uint64_t timeout_ticks;
 };
 
 struct LoopbackGroup {
@@ -86,6 +128,14 @@ struct LoopbackGroup {
     double *win_local = nullptr;
     std::vector<double *> win;        // every rank's window as this process sees it (win[me] = win_local)
     int64_t win_doubles = 0;
+    // device-ordered flavour
+    bool devord = false;
+    DevComm dc{};
+    double *dwin_local = nullptr;
+    std::vector<double *> dwin;
+    double **d_wins = nullptr;
+    uint64_t *d_ctr = nullptr;
+    PeerDevBlock *blk = nullptr;  // host view of the flag block (registered with HIP)
     // per-rank published state as this rank sees it
     std::vector<const double *> ptr;
     std::vector<int64_t> count;
@@ -245,6 +295,154 @@ __global__ void k_lb_sum(double *dst, const double *staging, int nranks, int cou
     }
 }
 
+// ---- device-ordered peer transport: kernels
+__device__ inline uint64_t ld_sys(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline void st_sys(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// spin until *p >= want; a timeout marks the job failed (every later wait returns at once: the host reports it)
+__device__ inline void spin_until(const uint64_t *p, uint64_t want, const DevComm &C)
+{
+    if (ld_sys(p) >= want) return;
+    const uint64_t t0 = wall_clock64();
+    for (uint32_t it = 0;; ++it) {
+        if (ld_sys(p) >= want) return;
+        if ((it & 63) == 63) {
+            if (__hip_atomic_load(C.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+            if (wall_clock64() - t0 > C.timeout_ticks) {
+                __hip_atomic_store(C.failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+__device__ inline void copy_part(double *__restrict__ dst, const double *__restrict__ src, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        const int64_t n2 = n >> 1;
+        const double2 *s2 = reinterpret_cast<const double2 *>(src);
+        double2 *d2 = reinterpret_cast<double2 *>(dst);
+        for (int64_t i = i0; i < n2; i += stride) d2[i] = s2[i];
+        if ((n & 1) && i0 == 0) dst[n - 1] = src[n - 1];
+    } else
+        for (int64_t i = i0; i < n; i += stride) dst[i] = src[i];
+}
+// store this rank's messages into the receivers' windows, then raise the pair flags; last & 1: the collective's last put
+// launch, last & 2: ... and this rank fetches nothing in this collective (it has then finished it)
+__global__ __launch_bounds__(256) void k_dput(DevMsgs M, DevComm C, int last)
+{
+    const uint64_t seq = *(volatile uint64_t *)&C.ctr[0] + 1;
+    const int h = (int)(seq & 1);
+    if ((int)threadIdx.x < M.n && seq > 2)  // the receiver is through with the collective that used this half before
+        spin_until(&C.done[M.peer[threadIdx.x]], seq - 2, C);
+    __syncthreads();
+    for (int m = 0; m < M.n; ++m) copy_part(C.wins[M.peer[m]] + (int64_t)h * C.half + M.off[m], M.src[m], M.cnt[m]);
+    __threadfence_system();  // the stores have reached the peers' memory before any flag goes up
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd((unsigned long long *)&C.ctr[2], 1ull) == (unsigned long long)gridDim.x - 1) {
+        C.ctr[2] = 0;
+        for (int m = 0; m < M.n; ++m) st_sys(&C.ready[(size_t)M.peer[m] * C.P + C.me], seq);
+        if (last & 1) C.ctr[0] = seq;
+        if (last & 2) st_sys(&C.done[C.me], seq);
+    }
+}
+// wait for the senders' flags, copy their messages out of this rank's window; the collective's last get launch reports
+// the rank's progress
+__global__ __launch_bounds__(256) void k_dget(DevMsgs M, DevComm C, int last)
+{
+    const uint64_t seq = *(volatile uint64_t *)&C.ctr[0];
+    const int h = (int)(seq & 1);
+    if ((int)threadIdx.x < M.n) spin_until(&C.ready[(size_t)C.me * C.P + M.peer[threadIdx.x]], seq, C);
+    __syncthreads();
+    __threadfence_system();  // acquire: nothing cached of the window from before the flags went up
+    for (int m = 0; m < M.n; ++m) copy_part(M.dst[m], C.win_local + (int64_t)h * C.half + M.off[m], M.cnt[m]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd((unsigned long long *)&C.ctr[3], 1ull) == (unsigned long long)gridDim.x - 1) {
+        C.ctr[3] = 0;
+        if (last) st_sys(&C.done[C.me], seq);
+    }
+}
+// in-place sum over ranks of count <= PIB_NRED doubles: the values travel through the flag block, every rank sums them
+// in rank order (the same bits everywhere, the order of k_lb_sum)
+__global__ __launch_bounds__(64) void k_dallreduce(double *dev, int count, DevComm C)
+{
+    const uint64_t seq = *(volatile uint64_t *)&C.ctr[1] + 1;
+    const int h = (int)(seq & 1), t = (int)threadIdx.x;
+    double *mine = C.vals + ((size_t)h * C.P + C.me) * PIB_NRED;
+    if (t < count) __hip_atomic_store(&mine[t], dev[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (t == 0) st_sys(&C.rflag[C.me], seq);
+    if (t < C.P) spin_until(&C.rflag[t], seq, C);
+    __threadfence_system();
+    __syncthreads();
+    if (t < count) {
+        double sum = 0.0;
+        for (int q = 0; q < C.P; ++q) sum += __hip_atomic_load(&C.vals[((size_t)h * C.P + q) * PIB_NRED + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dev[t] = sum;
+    }
+    if (t == 0) C.ctr[1] = seq;
+}
+
+struct PutMsg {
+    int peer;
+    const double *src;
+    int64_t off, cnt;
+};
+struct GetMsg {
+    int peer;
+    double *dst;
+    int64_t off, cnt;
+};
+// one device-ordered collective on stream st: this rank's stores, then its fetches (every rank issues one per collective,
+// with or without messages of its own: the collective number is counted by the put launch)
+static int dev_collective(pib_solver *s, hipStream_t st, const std::vector<PutMsg> &puts, const std::vector<GetMsg> &gets)
+{
+    LoopbackGroup *g = s->comm.loop;
+    if (g->blk->failed || g->shm->failed.load(std::memory_order_relaxed)) {
+        g->shm->failed.store(1);
+        return fail(PIB_ERR_LIB, "peer transport (device-ordered): a rank timed out waiting for a flag");
+    }
+    if (g->chained && g->chain_stream != st) PIB_HIP(hipStreamWaitEvent(st, g->chain, 0));
+    auto blocks = [](int64_t total) { return (int)std::max<int64_t>(1, std::min<int64_t>(128, (total + 4095) / 4096)); };
+    int ngets = 0;
+    for (const auto &m : gets) ngets += m.cnt > 0 ? 1 : 0;
+    size_t a = 0;
+    do {
+        DevMsgs M{};
+        int64_t total = 0;
+        for (; a < puts.size() && M.n < DMSG; ++a) {
+            if (puts[a].cnt <= 0) continue;
+            M.peer[M.n] = puts[a].peer;
+            M.src[M.n] = puts[a].src;
+            M.off[M.n] = puts[a].off;
+            M.cnt[M.n] = puts[a].cnt;
+            total += puts[a].cnt;
+            ++M.n;
+        }
+        hipLaunchKernelGGL(k_dput, dim3(blocks(total)), dim3(256), 0, st, M, g->dc, a >= puts.size() ? (ngets > 0 ? 1 : 3) : 0);
+    } while (a < puts.size());
+    a = 0;
+    int got = 0;
+    while (a < gets.size()) {
+        DevMsgs M{};
+        int64_t total = 0;
+        for (; a < gets.size() && M.n < DMSG; ++a) {
+            if (gets[a].cnt <= 0) continue;
+            M.peer[M.n] = gets[a].peer;
+            M.dst[M.n] = gets[a].dst;
+            M.off[M.n] = gets[a].off;
+            M.cnt[M.n] = gets[a].cnt;
+            total += gets[a].cnt;
+            ++M.n;
+        }
+        got += M.n;
+        if (M.n > 0) hipLaunchKernelGGL(k_dget, dim3(blocks(total)), dim3(256), 0, st, M, g->dc, got == ngets ? 1 : 0);
+    }
+    PIB_HIP(hipGetLastError());
+    return g->finish(st);
+}
+
 // ---- peer transport: the ranks (processes) meet in the shared-memory segment named in the id
 static void peer_destroy(LoopbackGroup *g)
 {
@@ -256,10 +454,21 @@ static void peer_destroy(LoopbackGroup *g)
     for (int q = 0; q < (int)g->win.size(); ++q)
         if (q != g->me && g->win[(size_t)q]) (void)hipIpcCloseMemHandle(g->win[(size_t)q]);
     if (g->win_local) (void)hipFree(g->win_local);
+    if (g->devord) {
+        // the peers may still be storing into / reading flags of this rank: leave together
+        (void)hipDeviceSynchronize();
+        if (g->shm != nullptr && !g->shm->failed.load()) (void)g->barrier();
+        for (int q = 0; q < (int)g->dwin.size(); ++q)
+            if (q != g->me && g->dwin[(size_t)q]) (void)hipIpcCloseMemHandle(g->dwin[(size_t)q]);
+        if (g->dwin_local) (void)hipFree(g->dwin_local);
+        if (g->d_wins) (void)hipFree(g->d_wins);
+        if (g->d_ctr) (void)hipFree(g->d_ctr);
+        if (g->blk) (void)hipHostUnregister(g->blk);
+    }
     if (g->chain) (void)hipEventDestroy(g->chain);
     if (g->staging_local) (void)hipFree(g->staging_local);
     else if (g->staging) (void)hipIpcCloseMemHandle(g->staging);
-    if (g->shm) (void)munmap(g->shm, sizeof(PeerShm));
+    if (g->shm) (void)munmap(g->shm, PEER_DEV_OFF + PEER_DEV_BYTES);
     delete g;
 }
 static int peer_attach(pib_solver *s, int rank, int nranks, const char *name)
@@ -290,7 +499,7 @@ static int peer_attach(pib_solver *s, int rank, int nranks, const char *name)
     if (rank == 0) {
         (void)shm_unlink(name);
         fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, (off_t)sizeof(PeerShm)) != 0) {
+        if (fd < 0 || ftruncate(fd, (off_t)(PEER_DEV_OFF + PEER_DEV_BYTES)) != 0) {
             if (fd >= 0) (void)close(fd);
             return bail(fail(PIB_ERR_LIB, "peer transport: cannot create the shared segment %s", name));
         }
@@ -298,19 +507,19 @@ static int peer_attach(pib_solver *s, int rank, int nranks, const char *name)
         for (;;) {
             fd = shm_open(name, O_RDWR, 0600);
             struct stat st;
-            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(PeerShm)) break;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= PEER_DEV_OFF + PEER_DEV_BYTES) break;
             if (fd >= 0) (void)close(fd);
             fd = -1;
             if (late()) return bail(fail(PIB_ERR_LIB, "peer transport: rank %d never saw rank 0's segment %s", rank, name));
             usleep(1000);
         }
     }
-    void *m = mmap(nullptr, sizeof(PeerShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    void *m = mmap(nullptr, PEER_DEV_OFF + PEER_DEV_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     (void)close(fd);
     if (m == MAP_FAILED) return bail(fail(PIB_ERR_LIB, "peer transport: mmap of the shared segment failed"));
     g->shm = static_cast<PeerShm *>(m);
     if (rank == 0) {
-        std::memset(m, 0, sizeof(PeerShm));  // a fresh segment is zero-filled already; the atomics start at 0
+        std::memset(m, 0, PEER_DEV_OFF + PEER_DEV_BYTES);  // a fresh segment is zero-filled already; the atomics start at 0
         g->shm->nranks = nranks;
         g->shm->state.store(1, std::memory_order_release);
     } else {
@@ -369,6 +578,61 @@ static int peer_attach(pib_solver *s, int rank, int nranks, const char *name)
     }
     err = g->barrier();
     if (err) return bail(err);
+    g->devord = std::strncmp(name, "/pib_peerD", 10) == 0;
+    if (g->devord) {
+        // a second window per rank, written by the peers; the flag block of the segment registered with HIP
+        g->dwin.assign((size_t)nranks, nullptr);
+        e = hipMalloc(&g->dwin_local, sizeof(double) * (size_t)g->win_doubles);
+        if (e == hipSuccess) e = hipMemset(g->dwin_local, 0, sizeof(double) * (size_t)g->win_doubles);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&g->shm->dwindow[rank], g->dwin_local);
+        g->dwin[(size_t)rank] = g->dwin_local;
+        if (e != hipSuccess) return bail(fail(PIB_ERR_LIB, "peer transport: receive window: %s", hipGetErrorString(e)));
+        err = g->barrier();
+        if (err) return bail(err);
+        for (int expect = 0; !g->shm->open_lock.compare_exchange_weak(expect, 1, std::memory_order_acquire); expect = 0) {
+            sched_yield();
+            if (g->shm->failed.load() || late()) return bail(fail(PIB_ERR_LIB, "peer transport: rank %d waited for its turn to map the receive windows", rank));
+        }
+        for (int q = 0; q < nranks && e == hipSuccess; ++q) {
+            if (q == rank) continue;
+            void *base = nullptr;
+            e = hipIpcOpenMemHandle(&base, g->shm->dwindow[q], hipIpcMemLazyEnablePeerAccess);
+            g->dwin[(size_t)q] = static_cast<double *>(base);
+        }
+        g->shm->open_lock.store(0, std::memory_order_release);
+        if (e != hipSuccess) return bail(fail(PIB_ERR_LIB, "peer transport: mapping the receive windows: %s", hipGetErrorString(e)));
+        g->blk = reinterpret_cast<PeerDevBlock *>(static_cast<char *>(m) + PEER_DEV_OFF);
+        void *dblk = nullptr;
+        e = hipHostRegister(g->blk, PEER_DEV_BYTES, hipHostRegisterMapped | hipHostRegisterPortable);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&dblk, g->blk, 0);
+        if (e == hipSuccess) e = hipMalloc(&g->d_wins, sizeof(double *) * (size_t)nranks);
+        if (e == hipSuccess) e = hipMemcpy(g->d_wins, g->dwin.data(), sizeof(double *) * (size_t)nranks, hipMemcpyHostToDevice);
+        const size_t nctr = 8;
+        if (e == hipSuccess) e = hipMalloc(&g->d_ctr, sizeof(uint64_t) * nctr);
+        if (e == hipSuccess) e = hipMemset(g->d_ctr, 0, sizeof(uint64_t) * nctr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            g->blk = nullptr;
+            return bail(fail(PIB_ERR_LIB, "peer transport: registering the flag block: %s", hipGetErrorString(e)));
+        }
+        PeerDevBlock *db = static_cast<PeerDevBlock *>(dblk);
+        DevComm &C = g->dc;
+        C.me = rank;
+        C.P = nranks;
+        C.ready = db->ready;
+        C.done = db->done;
+        C.rflag = db->rflag;
+        C.vals = db->vals;
+        C.failed = &db->failed;
+        C.ctr = g->d_ctr;
+        C.wins = g->d_wins;
+        C.win_local = g->dwin_local;
+        C.half = (g->win_doubles / 2 / 64) * 64;
+        C.timeout_ticks = (uint64_t)(std::min(g->timeout_s, 60.0) * 1.0e8);  // wall_clock64: 100 MHz
+        err = g->barrier();
+        if (err) return bail(err);
+    }
     if (rank == 0) (void)shm_unlink(name);  // everybody holds a mapping: the name can go
     s->comm.loop = g;
     s->comm.peer = true;
@@ -518,13 +782,33 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
 {
     LoopbackGroup *g = s->comm.loop;
     const int r = s->comm.rank;
-    const int64_t half = g->win_doubles / 2;
+    const int64_t half = g->devord ? g->dc.half / 2 : g->win_doubles / 2;
     int64_t np = 0, nn = 0;
     for (const auto &m : to_prev) np += m.second;
     for (const auto &m : to_next) nn += m.second;
     if (np > half || nn > half || lo > half || hi > half)
-        return fail(PIB_ERR_SUP, "peer transport: a message of %lld entries does not fit half a window (%lld): raise PIB_PEER_WINDOW_MB",
-                    (long long)std::max(std::max(np, nn), std::max(lo, hi)), (long long)half);
+        return fail(PIB_ERR_SUP, "peer transport: a message of %lld entries does not fit %s a window (%lld): raise PIB_PEER_WINDOW_MB",
+                    (long long)std::max(std::max(np, nn), std::max(lo, hi)), g->devord ? "a quarter of" : "half", (long long)half);
+    if (g->devord) {
+        // a rank's receive half: [what the previous rank sends | what the next rank sends]
+        std::vector<PutMsg> puts;
+        std::vector<GetMsg> gets;
+        int64_t o = half;  // this rank is the previous rank's NEXT
+        if (has_pv)
+            for (const auto &m : to_prev) {
+                puts.push_back({pv, m.first, o, m.second});
+                o += m.second;
+            }
+        o = 0;
+        if (has_nx)
+            for (const auto &m : to_next) {
+                puts.push_back({nx, m.first, o, m.second});
+                o += m.second;
+            }
+        if (has_pv && lo > 0) gets.push_back({pv, ghost_lo, 0, lo});
+        if (has_nx && hi > 0) gets.push_back({nx, ghost_hi, half, hi});
+        return dev_collective(s, st, puts, gets);
+    }
     uint64_t seq = 0;
     PIB_CHK(g->begin(st, &seq));
     double *dst = g->win_local;
@@ -733,6 +1017,17 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
 {
     if (!s->comm.active()) return 0;
     s->counters[2]++;
+    if (s->comm.loop && s->comm.loop->shm && s->comm.loop->devord) {
+        LoopbackGroup *g = s->comm.loop;
+        if (g->blk->failed || g->shm->failed.load(std::memory_order_relaxed)) {
+            g->shm->failed.store(1);
+            return fail(PIB_ERR_LIB, "peer transport (device-ordered): a rank timed out waiting for a flag");
+        }
+        if (g->chained && g->chain_stream != st) PIB_HIP(hipStreamWaitEvent(st, g->chain, 0));
+        hipLaunchKernelGGL(k_dallreduce, dim3(1), dim3(64), 0, st, dev, count, g->dc);
+        PIB_HIP(hipGetLastError());
+        return g->finish(st);
+    }
     if (s->comm.loop && s->comm.loop->shm) {
         // every rank copies its values into its row of rank 0's staging buffer, then sums the rows in rank order
         LoopbackGroup *g = s->comm.loop;
@@ -839,6 +1134,23 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
     const int P = s->comm.nranks, r = s->comm.rank;
     if (!s->comm.active()) return 0;
     s->counters[3]++;
+    if (s->comm.loop && s->comm.loop->shm && s->comm.loop->devord) {
+        LoopbackGroup *g = s->comm.loop;
+        std::vector<int64_t> place((size_t)P + 1, 0);  // every receive half: the ranks' parts back to back
+        for (int q = 0; q < P; ++q) place[(size_t)q + 1] = place[(size_t)q] + counts[(size_t)q];
+        if (place[(size_t)P] <= g->dc.half) {
+            std::vector<PutMsg> puts;
+            std::vector<GetMsg> gets;
+            for (int q = 0; q < P; ++q) {
+                if (q == r) continue;
+                puts.push_back({q, send, place[(size_t)r], counts[(size_t)r]});
+                gets.push_back({q, recv_base + offs[(size_t)q], place[(size_t)q], counts[(size_t)q]});
+            }
+            if (recv_base + offs[(size_t)r] != send && counts[(size_t)r] > 0)
+                PIB_HIP(hipMemcpyAsync(recv_base + offs[(size_t)r], send, sizeof(double) * (size_t)counts[(size_t)r], hipMemcpyDeviceToDevice, st));
+            return dev_collective(s, st, puts, gets);
+        }
+    }
     if (s->comm.loop && s->comm.loop->shm) {
         LoopbackGroup *g = s->comm.loop;
         int64_t longest = 0;
@@ -909,6 +1221,31 @@ int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream,
     if (!s->comm.active()) return 0;
     s->counters[3]++;
     s->counters[7] += 8 * (pl.send_total - pl.to(r));
+    if (s->comm.loop && s->comm.loop->shm && s->comm.loop->devord) {
+        LoopbackGroup *g = s->comm.loop;
+        int64_t most = 0;  // the fullest receive half (every rank holds the whole table: the same verdict everywhere)
+        for (int d = 0; d < P; ++d) {
+            int64_t t = 0;
+            for (int q = 0; q < P; ++q) t += pl.cnt[(size_t)q * P + d];
+            most = std::max(most, t);
+        }
+        if (most <= g->dc.half) {
+            std::vector<PutMsg> puts;
+            std::vector<GetMsg> gets;
+            for (int d = 0; d < P; ++d) {
+                if (d == r || pl.to(d) == 0) continue;
+                int64_t o = 0;
+                for (int q = 0; q < r; ++q) o += pl.cnt[(size_t)q * P + d];
+                puts.push_back({d, stream + pl.send_off[(size_t)d], o, pl.to(d)});
+            }
+            int64_t o = 0;
+            for (int q = 0; q < P; ++q) {
+                if (q != r && pl.from(q) > 0) gets.push_back({q, recv[q], o, pl.from(q)});
+                o += pl.from(q);
+            }
+            return dev_collective(s, st, puts, gets);
+        }
+    }
     if (s->comm.loop && s->comm.loop->shm) {
         LoopbackGroup *g = s->comm.loop;
         const int64_t W = g->win_doubles;
@@ -1135,7 +1472,7 @@ extern "C" int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, dou
 }
 
 // the id of a peer-transport world: a fresh shared-memory name; rank 0 makes it, every rank gets it (like the RCCL id)
-extern "C" int pib_comm_peer_id(void *uid_out)
+extern "C" int pib_comm_peer_id_ordered(void *uid_out, int device_ordered)
 {
     using namespace pib;
     if (uid_out == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_comm_peer_id: null output");
@@ -1143,9 +1480,16 @@ extern "C" int pib_comm_peer_id(void *uid_out)
     const auto now = std::chrono::steady_clock::now().time_since_epoch().count();
     std::memset(uid_out, 0, PIB_UID_BYTES);
     std::memcpy(uid_out, PEER_MAGIC, 8);
-    std::snprintf((char *)uid_out + 8, PIB_UID_BYTES - 8, "/pib_peer_%d_%u_%llx", (int)getpid(), serial.fetch_add(1),
-                  (unsigned long long)now);
+    std::snprintf((char *)uid_out + 8, PIB_UID_BYTES - 8, "/pib_peer%c_%d_%u_%llx", device_ordered ? 'D' : 'H', (int)getpid(),
+                  serial.fetch_add(1), (unsigned long long)now);
     return 0;
+}
+// the ordering of the collectives -- flags written and awaited by the GPUs in stream order (default), or by host threads
+// (PIB_PEER_ORDER=host: the first implementation, kept as the reference the device-ordered one is compared with)
+extern "C" int pib_comm_peer_id(void *uid_out)
+{
+    const char *o = std::getenv("PIB_PEER_ORDER");
+    return pib_comm_peer_id_ordered(uid_out, (o != nullptr && std::strcmp(o, "host") == 0) ? 0 : 1);
 }
 
 extern "C" int pib_comm_loopback_create(int nranks, void *uid_out)

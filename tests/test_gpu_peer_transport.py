@@ -24,17 +24,21 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 WORKER = os.path.join(ROOT, "tests", "peer_worker.py")
 
 
-def peer_id() -> bytes:
+def peer_id(order=None) -> bytes:
+    """order None: the default (device-ordered unless PIB_PEER_ORDER=host), "host" / "device": that ordering"""
     from petibm_amd import capi
     uid = ctypes.create_string_buffer(capi.UID_BYTES)
-    capi.check(capi.load().pib_comm_peer_id(uid))
+    if order is None:
+        capi.check(capi.load().pib_comm_peer_id(uid))
+    else:
+        capi.check(capi.load().pib_comm_peer_id_ordered(uid, 1 if order == "device" else 0))
     assert uid.raw[:8] == b"PIBPEER1"
     return uid.raw
 
 
-def run_ranks(tmp_path, job, P, timeout=420):
+def run_ranks(tmp_path, job, P, timeout=420, order=None):
     """P worker processes on the one GPU; returns their result files"""
-    job = dict(job, P=P, uid=peer_id())
+    job = dict(job, P=P, uid=peer_id(order))
     path = os.path.join(tmp_path, "job.pkl")
     pickle.dump(job, open(path, "wb"))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PIB_PEER_TIMEOUT_S="240")
@@ -92,6 +96,32 @@ def test_poisson_solve_across_processes_matches_single_rank(tmp_path, P, n, per,
     e = (x - x.mean()) - (x1 - x1.mean())
     assert np.linalg.norm(e) <= 1e-7 * np.linalg.norm(x1)
     s1.destroy()
+
+
+@pytest.mark.parametrize("P,n,pc,extra,sweeps", [
+    (4, (32, 32, 32), "AMG", "pib_agglomerate_below=100\n", 2),
+    (3, (128, 16, 96), "AMG", "pib_march_min_cells=0\npib_agglomerate_below=100\npib_overlap_min_bytes=0\n", 2),
+    (2, (24, 20), "BLOCK_JACOBI", "", 1),
+])
+def test_device_ordered_collectives_give_the_host_ordered_bits(tmp_path, P, n, pc, extra, sweeps):
+    """The two orderings of the peer transport move the same data and sum the scalars in the same (rank) order: products,
+    iterates, residual histories and solutions agree bit for bit."""
+    dt = 0.01
+    m = omesh.create_mesh(omesh.uniform_config(n))
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    xs, b = rhs_for(A)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    job = dict(kind="poisson", n=n, w=w, dt=dt, cfg=_cfg(pc, extra=extra, sweeps=sweeps), xs=xs, b=b, periodic=None)
+    out = {}
+    for order in ("host", "device"):
+        d = os.path.join(str(tmp_path), order)
+        os.makedirs(d)
+        out[order] = run_ranks(d, job, P, order=order)
+    for h, dv in zip(out["host"], out["device"]):
+        assert int(h["its"]) == int(dv["its"])
+        assert np.array_equal(h["y"], dv["y"]) and np.array_equal(h["x"], dv["x"]) and np.array_equal(h["hist"], dv["hist"])
+        assert np.array_equal(h["counters"][:6], dv["counters"][:6])
 
 
 @pytest.mark.parametrize("case,P,bodies", [("3d_cavity", 2, False), ("2d_convective_outlet", 3, False), ("3d_sphere", 2, True),
