@@ -97,6 +97,10 @@ int pib_comm_unique_id(void *uid_out /* PIB_UID_BYTES */);
  * box.  PIB_PEER_TIMEOUT_S (default 600; device-side spins: at most 60) bounds every wait for another rank. */
 int pib_comm_peer_id(void *uid_out /* PIB_UID_BYTES */);
 int pib_comm_peer_id_ordered(void *uid_out /* PIB_UID_BYTES */, int device_ordered);
+/* Wall time per plane exchange (`count` doubles each way) and per scalar all-reduce on the transport `s` has attached,
+ * `reps` back-to-back calls each; s == NULL: RCCL in a one-rank world (ring neighbours = the rank itself).  Collective.
+ * tools/comm_latency.py */
+int pib_comm_latency(pib_solver *s, int64_t count, int reps, double usec[2]);
 
 /* TEST transport: `nranks` ranks = host threads of ONE process sharing ONE GPU (RCCL refuses several
  * ranks per device).  Fills a PIB_UID_BYTES id to pass to pib_create from every thread.  Used by the

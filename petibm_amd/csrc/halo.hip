@@ -1471,6 +1471,62 @@ extern "C" int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, dou
     return 0;
 }
 
+// Latency of the two collectives of a Krylov iteration on whatever transport `s` has attached (s == NULL: RCCL in a
+// one-rank world whose ring neighbours are the rank itself, as in pib_comm_selftest): `reps` back-to-back plane exchanges
+// of `count` doubles each way, then `reps` all-reduces of PIB_NRED doubles; usec[0] / usec[1] = wall time per call
+// (enqueue + execution, one stream synchronisation at the end).  tools/comm_latency.py
+extern "C" int pib_comm_latency(pib_solver *s, int64_t count, int reps, double usec[2])
+{
+    using namespace pib;
+    if (usec == nullptr || count < 1 || reps < 1) return fail(PIB_ERR_ARG_WRONG, "pib_comm_latency: bad arguments");
+    pib_solver S;
+    bool own = false;
+    if (s == nullptr) {
+        own = true;
+        s = &S;
+        PIB_HIP(hipSetDevice(0));
+        PIB_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        ncclUniqueId id;
+        PIB_NCCL(ncclGetUniqueId(&id));
+        PIB_NCCL(ncclCommInitRank(&s->comm.comm, 1, id, 0));
+        s->comm.ring = true;
+    } else
+        PIB_HIP(hipSetDevice(s->device));
+    const int P = s->comm.nranks, r = s->comm.rank;
+    const bool ring = s->comm.ring;
+    const int64_t n = 4 * count;
+    double *d = nullptr;
+    PIB_HIP(hipMalloc(&d, sizeof(double) * (size_t)(n + 2 * count)));
+    PIB_MEMSET(d, 0, sizeof(double) * (size_t)(n + 2 * count));
+    const int64_t lo = (r > 0 || ring) ? count : 0, hi = (r < P - 1 || ring) ? count : 0;
+    auto run = [&](int which) -> int {
+        for (int w = 0; w < 2; ++w) {  // warm-up, then the timed pass
+            const int k = w == 0 ? std::min(reps, 10) : reps;
+            PIB_HIP(hipStreamSynchronize(s->stream));
+            if (s->comm.loop) PIB_CHK(s->comm.loop->barrier());
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < k; ++i) {
+                if (which == 0) PIB_CHK(halo_exchange_planes(s, d + count, n, lo, hi, lo, hi, s->stream));
+                else PIB_CHK(comm_allreduce_sum(s, d + count, PIB_NRED, s->stream));
+            }
+            PIB_HIP(hipStreamSynchronize(s->stream));
+            usec[which] = 1.0e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / k;
+        }
+        return 0;
+    };
+    PIB_CHK(run(0));
+    PIB_CHK(run(1));
+    if (s->comm.loop) PIB_CHK(s->comm.loop->barrier());
+    PIB_HIP(hipFree(d));
+    if (own) {
+        (void)ncclCommDestroy(s->comm.comm);
+        s->comm.comm = nullptr;
+        (void)hipStreamDestroy(s->stream);
+        s->stream = nullptr;
+    }
+    return 0;
+}
+
 // the id of a peer-transport world: a fresh shared-memory name; rank 0 makes it, every rank gets it (like the RCCL id)
 extern "C" int pib_comm_peer_id_ordered(void *uid_out, int device_ordered)
 {

@@ -564,7 +564,6 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t stq);
 // launch-bound (rocprof, 186^2 cylinder case: ~2 us kernels, the host cannot feed them faster than ~2.4 us apiece), so
 // on a single GPU the body is captured ONCE per (matrix, vectors) into a hipGraph and replayed: one host call per
 // iteration.  The first iteration of a solve always runs directly (lazy allocations happen there, never in a capture).
-constexpr int64_t GRAPH_MAX_ROWS = 1 << 22;
 static uint64_t graph_key(int method, const void *x, const void *b)
 {
     return (uint64_t)reinterpret_cast<uintptr_t>(x) * 0x9E3779B97F4A7C15ull ^ (uint64_t)reinterpret_cast<uintptr_t>(b) ^
@@ -573,7 +572,7 @@ static uint64_t graph_key(int method, const void *x, const void *b)
 template <class Body>
 static int run_iterations(pib_solver *s, int todo, int first_index, uint64_t key, hipStream_t q, Body body)
 {
-    const bool use = s->cfg.use_graph && s->comm.nranks == 1 && s->A.n <= GRAPH_MAX_ROWS;
+    const bool use = s->cfg.use_graph && s->comm.nranks == 1 && s->A.n <= s->cfg.graph_max_rows;
     for (int it = 0; it < todo; ++it) {
         if (!use || first_index + it == 0) {
             PIB_CHK(body());
@@ -770,7 +769,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     // Multigrid-preconditioned, one rank, systems too large for the captured graphs: r = r - alpha w is left to the V-cycle's
     // first kernel, which reads the residual anyway (gmg.hip k_presmooth2<., 1>: 24 B/row and a launch less per iteration).
     // That kernel recomputes halo cells, so the new residual goes to the OTHER of two buffers, iteration by iteration.
-    const bool fused_upd = gmg && s->cfg.fuse_residual_update && s->comm.nranks == 1 && lazy == 1 && n > GRAPH_MAX_ROWS &&
+    const bool fused_upd = gmg && s->cfg.fuse_residual_update && s->comm.nranks == 1 && lazy == 1 && n > s->cfg.graph_max_rows &&
                            gmg_fused_update_ok(s);
     struct UpdCtx {
         double *hist;

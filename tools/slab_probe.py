@@ -8,10 +8,11 @@ import bench
 from petibm_amd import capi
 from petibm_amd.linsolver import LinSolverHIP
 
+EXTRA = os.environ.get("PIB_PROBE_CFG", "").replace(";", "\n")  # e.g. PIB_PROBE_CFG="pib_graph_max_rows=100000000"
 for P in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     n = 512
     nz = n // P
-    s = LinSolverHIP("poisson", config_text=bench.solver_config("gmg", 1e-10, 200, 0.8, 2, 2, "jacobi") + "\n")
+    s = LinSolverHIP("poisson", config_text=bench.solver_config("gmg", 1e-10, 200, 0.8, 2, 2, "jacobi") + "\n" + EXTRA + "\n")
     w = np.full(n, 1.0 / n)
     s.assemblePoisson((n, n, nz), [w, w, w[:nz]], 5e-4, capi.NULLSPACE_CONSTANT)
     rng = np.random.default_rng(0)
