@@ -64,16 +64,84 @@ def manufactured_solution(n: int, k0: int, k1: int) -> np.ndarray:
     return (cz[:, None, None] * c[None, :, None] * c[None, None, :]).reshape(-1)
 
 
-def petsc_probe() -> str:
-    """a second CPU row from the reference's own library (KSPSolve on the same CSR) needs a PETSc install on
-    the host.  This looks for one (PETSC_DIR, the loader path) and says what it found; no PETSc has been seen on any box
-    this ran on, so the KSPSolve driver itself is not part of the repo."""
-    import ctypes.util
+def petsc_config():
+    """Where a PETSc installation is, if the host has one: (cflags, ldflags, description) from `pkg-config petsc` /
+    `pkg-config PETSc` or from PETSC_DIR[/PETSC_ARCH]; None when there is none (every box this has run on so far)."""
+    import shutil
+    import subprocess
+    if shutil.which("pkg-config"):
+        for name in ("petsc", "PETSc"):
+            try:
+                c = subprocess.run(["pkg-config", "--cflags", name], capture_output=True, text=True)
+                l = subprocess.run(["pkg-config", "--libs", name], capture_output=True, text=True)
+                if c.returncode == 0 and l.returncode == 0:
+                    return c.stdout.split(), l.stdout.split(), f"pkg-config {name}"
+            except OSError:
+                pass
     d = os.environ.get("PETSC_DIR")
-    lib = ctypes.util.find_library("petsc")
-    if d or lib:
-        return f"a PETSc install is visible (PETSC_DIR={d}, libpetsc={lib}) but no KSPSolve driver is built here: port row only"
-    return "not found on this host (PETSC_DIR unset, no libpetsc on the loader path): port row only"
+    if d and os.path.isdir(d):
+        arch = os.environ.get("PETSC_ARCH", "")
+        inc = [f"-I{os.path.join(d, 'include')}"] + ([f"-I{os.path.join(d, arch, 'include')}"] if arch else [])
+        libdir = os.path.join(d, arch, "lib") if arch else os.path.join(d, "lib")
+        if os.path.isdir(libdir):
+            return inc, [f"-L{libdir}", f"-Wl,-rpath,{libdir}", "-lpetsc"], f"PETSC_DIR={d} PETSC_ARCH={arch}"
+    return None
+
+
+def petsc_probe() -> str:
+    cfg = petsc_config()
+    if cfg is None:
+        return "not found on this host (no pkg-config petsc, PETSC_DIR unset): port row only"
+    return f"found ({cfg[2]}): the KSPSolve row (tools/petsc_ksp_driver.c) is built and run beside the port"
+
+
+def petsc_baseline(n: int, tol: float, dt: float, budget_s: float = 60.0):
+    """SURVEY.md 8d / BASELINE.md 4: the reference's own CPU path -- PETSc's KSPCG with -pc_type gamg
+    (src/linsolver/linsolverksp.cpp:48-107; the options of examples/navierstokes/liddrivencavity2dRe100/config/
+    poisson_solver.info) -- on the same int32 CSR and right-hand side the port row solved, ONLY when a PETSc installation
+    is found: tools/petsc_ksp_driver.c is compiled against it at run time (mpicc, else gcc).  Returns a cpu_baseline-shaped
+    dict of kind "petsc", or None when there is no PETSc (the line stays as it was)."""
+    import shutil
+    import subprocess
+    import tempfile
+    cfg = petsc_config()
+    if cfg is None:
+        return None
+    from oracle import clib
+    cc = shutil.which("mpicc") or shutil.which("gcc")
+    tmp = tempfile.mkdtemp(prefix="pib_petsc_")
+    exe = os.path.join(tmp, "petsc_ksp_driver")
+    build = subprocess.run([cc, "-O2", os.path.join(ROOT, "tools", "petsc_ksp_driver.c"), "-o", exe] + cfg[0] + cfg[1] + ["-lm"],
+                           capture_output=True, text=True)
+    if build.returncode != 0:
+        return {"kind": "petsc", "value": None, "note": f"PETSc found ({cfg[2]}) but the driver did not build: {build.stderr[-400:]}"}
+    w = np.full(n, 1.0 / n)
+    rp, cl, vl = clib.assemble_poisson32((n, n, n), [w, w, w], dt)
+    xs = manufactured_solution(n, 0, n)
+    b = np.empty(n ** 3)
+    clib.spmv32(n ** 3, rp, cl, vl, xs, b)
+    path = os.path.join(tmp, "system.bin")
+    with open(path, "wb") as f:
+        np.array([n ** 3, len(cl)], dtype=np.int64).tofile(f)
+        np.asarray(rp, dtype=np.int32).tofile(f)
+        np.asarray(cl, dtype=np.int32).tofile(f)
+        np.asarray(vl, dtype=np.float64).tofile(f)
+        b.tofile(f)
+    opts = ["-poisson_ksp_type", "cg", "-poisson_ksp_rtol", f"{tol:g}", "-poisson_ksp_atol", "1e-50", "-poisson_ksp_max_it", "20000",
+            "-poisson_pc_type", "gamg", "-poisson_pc_gamg_type", "agg", "-poisson_pc_gamg_agg_nsmooths", "1"]
+    try:
+        run = subprocess.run([exe, path] + opts, capture_output=True, text=True, timeout=budget_s * 4)
+        line = [ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1]
+        r = json.loads(line)
+    except Exception as e:  # noqa: BLE001
+        return {"kind": "petsc", "value": None, "note": f"PETSc driver failed: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": n ** 3 / r["seconds"], "unit": "DOF/s", "cores": 1, "kind": "petsc",
+            "sample": f"PETSc KSPCG + PCGAMG (agg, 1 smoothing step; the reference's poisson_solver.info) on the {n}^3 cavity Poisson "
+                      f"system, rtol {tol:g}, one process: {r['iters']} iterations in {r['seconds']:.2f} s (KSPSetUp not counted), "
+                      f"reason {r['reason']}, preconditioned residual {r['residual']:.3e}; {cfg[2]}",
+            "iters": r["iters"], "seconds": r["seconds"], "grid": n}
 
 
 def cpu_baseline(n_gpu: int, tol: float, dt: float, pre: int = 2, post: int = 2, omega: float = 0.9, budget_s: float = 45.0):
@@ -120,17 +188,19 @@ def cpu_baseline(n_gpu: int, tol: float, dt: float, pre: int = 2, post: int = 2,
 
 
 def measured_traffic(n: int, world: int):
-    """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/r01_spmv_pmc.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same command; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when no pass matches this configuration."""
+    """HBM bytes per SpMV launch from the COMMITTED rocprofv3 PMC passes (profiles/spmv_pmc.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc passes of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950) -- a number read from a file, not measured in this run: the second value says so.
+    (None, None) when no pass matches this configuration."""
     path = os.path.join(ROOT, "profiles", "spmv_pmc.json")
     try:
         for e in json.load(open(path)):
             if e.get("n") == n and e.get("gpus") == world:
-                return e.get("traffic_bytes")
+                return e.get("traffic_bytes"), (f"profiles/spmv_pmc.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round "
+                                                f"{e.get('round')}, {e.get('kernel')}; not collected in this run)")
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str = "") -> dict:
@@ -493,6 +563,11 @@ def poisson_bench(args) -> int:
         ms_spmv, counters = float("nan"), [0] * 8
         notes.append(f"kernel timing failed: {e}")
     achieved = alg_bytes / (ms_spmv * 1e-3) / 1e9
+    all_counters = [[int(c) for c in counters]]
+    if world > 1:
+        gathered = [torch.zeros(8, dtype=torch.int64, device=red_dev) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([int(c) for c in counters], dtype=torch.int64, device=red_dev))
+        all_counters = [[int(v) for v in g.cpu().tolist()] for g in gathered]
 
     out = None
     if rank == 0:
@@ -511,21 +586,27 @@ def poisson_bench(args) -> int:
             "spmv_gdof_per_s": n_l / (ms_spmv * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "kernel": "pib::k_spmv_lds<int32> (fp64 CSR SpMV K1, local slab)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world)[0],
+                         "traffic_source": measured_traffic(n, world)[1],
                          "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes},
             "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "reductions": int(counters[2]),
                          "halo_exchanges": int(counters[3]), "host_polls": int(counters[4]),
                          "comm_ranks": int(counters[5]),  # ncclCommCount of the solver's communicator (1: none)
-                         "residual_updates_in_vcycle": int(counters[6])},  # iterations whose r -= a w ran inside the V-cycle's first march
+                         "residual_updates_in_vcycle": int(counters[6]),  # iterations whose r -= a w ran inside the V-cycle's first march
+                         "halo_bytes_sent": int(counters[7])},  # by this rank in the last solve (exchanges + all-gathers)
         }
-        if args.pc == "gmg" and world == 1:
+        if world > 1:  # what every rank communicated in its last solve
+            out["per_rank"] = [{"rank": q, "halo_exchanges": int(all_counters[q][3]), "reductions": int(all_counters[q][2]),
+                                "halo_bytes_sent": int(all_counters[q][7]), "spmv": int(all_counters[q][0])} for q in range(world)]
+        if args.pc == "gmg":
             # the whole solve against the roofline: algorithmic bytes of every kernel of an iteration (model in
-            # solve_bytes_per_row_iter; the initial residual + V-cycle count as one more iteration) / the measured time
+            # solve_bytes_per_row_iter; the initial residual + V-cycle count as one more iteration) / the measured time.
+            # Several ranks: all rows against the ranks' combined peak (the slabs' redundant ghost planes are not counted).
             bpr = solve_bytes_per_row_iter(args.presweeps, args.postsweeps, nnz_l / n_l)
             per_solve = iters / args.steps + 1.0
-            gbs = bpr * n_l * per_solve / (elapsed / args.steps) / 1e9
+            gbs = bpr * pN * per_solve / (elapsed / args.steps) / 1e9
             out["roofline_solve"] = {"bound": "hbm", "bytes_per_row_per_iteration": bpr, "iterations_counted": per_solve,
-                                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                     "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
                                      "ms_per_iteration": 1e3 * elapsed / args.steps / per_solve}
         def finite(o):  # NaN is not JSON
             if isinstance(o, dict):
@@ -540,6 +621,12 @@ def poisson_bench(args) -> int:
                 out["cpu_baseline"] = cpu_baseline(n, args.tol, dt, args.presweeps, args.postsweeps, args.omega)
             except Exception as e:  # noqa: BLE001
                 notes.append(f"cpu baseline failed: {e}")
+            try:  # the reference's own library on the same sample, when the host has one (never in the build image)
+                pb = petsc_baseline(out["cpu_baseline"]["grid"] if out["cpu_baseline"] else 128, args.tol, dt)
+                if pb is not None:
+                    out["cpu_baseline_petsc"] = pb
+            except Exception as e:  # noqa: BLE001
+                notes.append(f"PETSc baseline failed: {e}")
         if notes:
             out["notes"] = notes
     s.destroy()

@@ -2375,6 +2375,21 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             if (swaps % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
         }
         double *rr = g.r + g.pad;
+        if (l == 0 && s->gmg_upd.w != nullptr) {
+            // PCG left r = r_old - alpha w to this cycle's first march: decided HERE, with the pointers the march would get, by the
+            // predicate of its two launch sites below; if it cannot take the update, the update runs as a pass of its own first
+            const int FZ0 = march_planes(g, I.nk);
+            auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
+            const bool site = s->cfg.fuse_residual_update == 1 && !I.dist && !cheb && s->cfg.fuse_presmooth && fused_run_ok(s, g, 0, I.nk) &&
+                              (g.n[0] / FX) * (g.n[1] / FY) * ((I.nk + FZ0 - 1) / FZ0) <= PIB_MAXPART && al32(b) &&
+                              (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
+            if (!site) {
+                if (s->gmg_upd.fallback == nullptr) return fail(PIB_ERR_LIB, "fused residual update: no fallback registered");
+                PIB_CHK(s->gmg_upd.fallback(s, const_cast<double *>(b), q));
+                s->gmg_upd.w = nullptr;
+                s->gmg_upd.used = true;
+            }
+        }
         // the right-hand side on as many ghost planes as the way down (and, on level 0, the way up) consumes
         const int Dd = down_depth(l);
         set_valid(b, 0);

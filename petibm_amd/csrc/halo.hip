@@ -282,6 +282,23 @@ struct LoopbackGroup {
     }
 };
 
+// A rank that leaves a peer collective with an error of its own (a HIP call, a window too small for ITS message) must not
+// leave the others spinning until their timeout: every error exit marks the job failed, which all the waits look at.
+struct PeerFailGuard {
+    LoopbackGroup *g;
+    bool ok = false;
+    explicit PeerFailGuard(LoopbackGroup *grp) : g(grp) {}
+    ~PeerFailGuard()
+    {
+        if (!ok && g != nullptr && g->shm != nullptr) g->shm->failed.store(1);
+    }
+    int done()
+    {
+        ok = true;
+        return 0;
+    }
+};
+
 static const char LOOP_MAGIC[8] = {'P', 'I', 'B', 'L', 'O', 'O', 'P', '1'};
 static const char PEER_MAGIC[8] = {'P', 'I', 'B', 'P', 'E', 'E', 'R', '1'};
 
@@ -781,6 +798,7 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
                                 double *ghost_hi, int64_t hi, const char *what)
 {
     LoopbackGroup *g = s->comm.loop;
+    PeerFailGuard guard(g);
     const int r = s->comm.rank;
     const int64_t half = g->devord ? g->dc.half / 2 : g->win_doubles / 2;
     int64_t np = 0, nn = 0;
@@ -807,7 +825,8 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
             }
         if (has_pv && lo > 0) gets.push_back({pv, ghost_lo, 0, lo});
         if (has_nx && hi > 0) gets.push_back({nx, ghost_hi, half, hi});
-        return dev_collective(s, st, puts, gets);
+        PIB_CHK(dev_collective(s, st, puts, gets));
+        return guard.done();
     }
     uint64_t seq = 0;
     PIB_CHK(g->begin(st, &seq));
@@ -836,7 +855,7 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
     PIB_CHK(g->finish(st));
     if (has_pv) g->owe(seq, pv);
     if (has_nx && nx != pv) g->owe(seq, nx);
-    return 0;
+    return guard.done();
 }
 
 static int lb_halo(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, int64_t hi, hipStream_t st)
@@ -1015,7 +1034,8 @@ int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st)
 // in-place sum over ranks of `count` (<= PIB_NRED) doubles in device memory
 int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
 {
-    if (!s->comm.active()) return 0;
+    PeerFailGuard guard((s->comm.loop && s->comm.loop->shm) ? s->comm.loop : nullptr);
+    if (!s->comm.active()) return guard.done();
     s->counters[2]++;
     if (s->comm.loop && s->comm.loop->shm && s->comm.loop->devord) {
         LoopbackGroup *g = s->comm.loop;
@@ -1026,7 +1046,8 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
         if (g->chained && g->chain_stream != st) PIB_HIP(hipStreamWaitEvent(st, g->chain, 0));
         hipLaunchKernelGGL(k_dallreduce, dim3(1), dim3(64), 0, st, dev, count, g->dc);
         PIB_HIP(hipGetLastError());
-        return g->finish(st);
+        PIB_CHK(g->finish(st));
+        return guard.done();
     }
     if (s->comm.loop && s->comm.loop->shm) {
         // every rank copies its values into its row of rank 0's staging buffer, then sums the rows in rank order
@@ -1044,7 +1065,7 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
         PIB_CHK(g->finish(st));
         for (int q = 0; q < P; ++q)
             if (q != r) g->owe(seq, q);  // the rows are free again once everybody has summed them
-        return 0;
+        return guard.done();
     }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
@@ -1060,10 +1081,10 @@ int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st)
         for (int q = 0; q < P; ++q)
             if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)q], 0));
         PIB_CHK(g->barrier());
-        return 0;
+        return guard.done();
     }
     PIB_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, s->comm.comm, st));
-    return 0;
+    return guard.done();
 }
 
 __global__ void k_lb_add(double *__restrict__ acc, const double *__restrict__ x, int64_t n, int first)
@@ -1075,7 +1096,8 @@ __global__ void k_lb_add(double *__restrict__ acc, const double *__restrict__ x,
 // entries every rank sums over its own velocity points
 int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st)
 {
-    if (!s->comm.active() || count <= 0) return 0;
+    PeerFailGuard guard((s->comm.loop && s->comm.loop->shm) ? s->comm.loop : nullptr);
+    if (!s->comm.active() || count <= 0) return guard.done();
     if (s->comm.loop && s->comm.loop->shm) {
         // a window's worth at a time: every rank lays its piece into its window, then sums all the windows' pieces in
         // rank order (the same bits on every rank) straight into its own buffer
@@ -1098,7 +1120,7 @@ int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st
             for (int q = 0; q < P; ++q)
                 if (q != r) g->owe(seq, q);
         }
-        return 0;
+        return guard.done();
     }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
@@ -1121,18 +1143,19 @@ int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st
         PIB_HIP(hipStreamSynchronize(st));
         PIB_CHK(g->barrier());
         PIB_HIP(hipFree(tmp));
-        return 0;
+        return guard.done();
     }
     PIB_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, s->comm.comm, st));
-    return 0;
+    return guard.done();
 }
 
 // every rank contributes counts[rank] doubles at `send`; `recv_base + offs[q]` receives rank q's part
 int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const std::vector<int64_t> &counts,
                     const std::vector<int64_t> &offs, hipStream_t st)
 {
+    PeerFailGuard guard((s->comm.loop && s->comm.loop->shm) ? s->comm.loop : nullptr);
     const int P = s->comm.nranks, r = s->comm.rank;
-    if (!s->comm.active()) return 0;
+    if (!s->comm.active()) return guard.done();
     s->counters[3]++;
     if (s->comm.loop && s->comm.loop->shm && s->comm.loop->devord) {
         LoopbackGroup *g = s->comm.loop;
@@ -1148,7 +1171,8 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
             }
             if (recv_base + offs[(size_t)r] != send && counts[(size_t)r] > 0)
                 PIB_HIP(hipMemcpyAsync(recv_base + offs[(size_t)r], send, sizeof(double) * (size_t)counts[(size_t)r], hipMemcpyDeviceToDevice, st));
-            return dev_collective(s, st, puts, gets);
+            PIB_CHK(dev_collective(s, st, puts, gets));
+            return guard.done();
         }
     }
     if (s->comm.loop && s->comm.loop->shm) {
@@ -1173,7 +1197,7 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
             for (int q = 0; q < P; ++q)
                 if (q != r) g->owe(seq, q);
         }
-        return 0;
+        return guard.done();
     }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
@@ -1190,7 +1214,7 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
         for (int q = 0; q < P; ++q)
             if (q != r) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)q], 0));
         PIB_CHK(g->barrier());
-        return 0;
+        return guard.done();
     }
     bool equal = true;
     for (int q = 0; q < P; ++q) equal = equal && counts[(size_t)q] == counts[0] && offs[(size_t)q] == (int64_t)q * counts[0];
@@ -1204,7 +1228,7 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
         }
         PIB_NCCL(ncclGroupEnd());
     }
-    return 0;
+    return guard.done();
 }
 
 // One message per ordered pair of ranks (ExchangePlan): a rank's messages lie back to back, in destination order, at
@@ -1215,10 +1239,11 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
 // where in a neighbour's window in every round.
 int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream, double *const *recv, hipStream_t st)
 {
+    PeerFailGuard guard((s->comm.loop && s->comm.loop->shm) ? s->comm.loop : nullptr);
     const int P = pl.P, r = pl.me;
     if (pl.from(r) > 0)
         PIB_HIP(hipMemcpyAsync(recv[r], stream + pl.send_off[(size_t)r], sizeof(double) * (size_t)pl.from(r), hipMemcpyDeviceToDevice, st));
-    if (!s->comm.active()) return 0;
+    if (!s->comm.active()) return guard.done();
     s->counters[3]++;
     s->counters[7] += 8 * (pl.send_total - pl.to(r));
     if (s->comm.loop && s->comm.loop->shm && s->comm.loop->devord) {
@@ -1243,7 +1268,8 @@ int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream,
                 if (q != r && pl.from(q) > 0) gets.push_back({q, recv[q], o, pl.from(q)});
                 o += pl.from(q);
             }
-            return dev_collective(s, st, puts, gets);
+            PIB_CHK(dev_collective(s, st, puts, gets));
+            return guard.done();
         }
     }
     if (s->comm.loop && s->comm.loop->shm) {
@@ -1270,7 +1296,7 @@ int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream,
             for (int q = 0; q < P; ++q)
                 if (q != r) g->owe(seq, q);
         }
-        return 0;
+        return guard.done();
     }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
@@ -1287,7 +1313,7 @@ int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream,
         for (int q = 0; q < P; ++q)
             if (q != r && pl.to(q) > 0) PIB_HIP(hipStreamWaitEvent(st, g->ev_done[(size_t)q], 0));  // they have read my stream
         PIB_CHK(g->barrier());
-        return 0;
+        return guard.done();
     }
     PIB_NCCL(ncclGroupStart());
     for (int q = 0; q < P; ++q) {
@@ -1296,7 +1322,7 @@ int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream,
         if (pl.from(q) > 0) PIB_NCCL(ncclRecv(recv[q], (size_t)pl.from(q), ncclDouble, q, s->comm.comm, st));
     }
     PIB_NCCL(ncclGroupEnd());
-    return 0;
+    return guard.done();
 }
 
 }  // namespace pib

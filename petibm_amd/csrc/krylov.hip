@@ -775,9 +775,24 @@ int solve_cg(pib_solver *s, double *x, const double *b)
         double *hist;
         double ng;
         int conv_is_its, unprec;
+        int64_t n;
+        double *z;
     };
     static thread_local UpdCtx upd_ctx;
-    upd_ctx = UpdCtx{s->d_hist, ng, conv_is_its, unprec ? 1 : 0};
+    upd_ctx = UpdCtx{s->d_hist, ng, conv_is_its, unprec ? 1 : 0, n, Z};
+    // the cycle's first march cannot take the update (gmg.hip decides with its own launch-site predicate): the separate pass
+    // of the general path, landing in the new residual's buffer
+    auto update_fallback = +[](pib_solver *ps, double *r_new, hipStream_t st) -> int {
+        int nblk = 0;
+        PIB_HIP(hipMemcpyAsync(r_new, ps->gmg_upd.r_old, sizeof(double) * (size_t)upd_ctx.n, hipMemcpyDeviceToDevice, st));
+        OpUpdateXR<PCM_NONE> op{ps->gmg_upd.w, nullptr, r_new, upd_ctx.z, 1.0, 0.0};
+        PIB_CHK(launch_vec(ps, upd_ctx.n, op, true, 0, &nblk, true, st));
+        PIB_CHK(finalize(ps, 0, 6, nblk, st));
+        if (upd_ctx.unprec)
+            hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, st, ps->d_s, upd_ctx.hist, upd_ctx.ng, 0, 1, 0, upd_ctx.conv_is_its);
+        PIB_HIP(hipGetLastError());
+        return 0;
+    };
     auto after_update = +[](pib_solver *ps, int nblocks, hipStream_t st) -> int {
         // r.r and sum r of the new residual from the march's partials (slots 4, 5), then the convergence step on |r|
         hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, st, ps->d_s, ps->d_part, 4, nblocks);
@@ -818,6 +833,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 s->gmg_upd.w = W;
                 s->gmg_upd.r_old = R;
                 s->gmg_upd.after = after_update;
+                s->gmg_upd.fallback = update_fallback;
                 s->gmg_upd.used = false;
                 const int err = gmg_pc_and_dots(s, R2, Z, true, q);
                 s->gmg_upd.w = nullptr;

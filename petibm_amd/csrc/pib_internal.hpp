@@ -352,6 +352,9 @@ struct pib_solver {
     struct GmgUpd {
         const double *w = nullptr, *r_old = nullptr;
         int (*after)(pib_solver *, int nblocks, hipStream_t) = nullptr;
+        // the march cannot take the update after all (alignment of the cycle's buffers, a level that is not tile-divisible):
+        // r_new = r_old - alpha w and its sums in a pass of their own, after which the cycle runs its plain form
+        int (*fallback)(pib_solver *, double *r_new, hipStream_t) = nullptr;
         bool used = false;
     } gmg_upd;
     double *d_hist = nullptr;

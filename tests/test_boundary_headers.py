@@ -33,6 +33,29 @@ def test_amgx_surface_rejects_a_wrong_argument_type():
     assert r.returncode != 0
 
 
+def test_petsc_ksp_driver_parses_against_the_stub_and_bench_builds_it_only_when_petsc_is_found(monkeypatch, tmp_path):
+    """tools/petsc_ksp_driver.c -- the optional genuine-PETSc CPU row of SURVEY.md 8d (KSPCG + GAMG on the bench's own CSR) --
+    is SYNTAX-checked against the declarations-only stub (no PETSc in the image: it has never been linked); bench.py builds
+    and runs it only when pkg-config / PETSC_DIR resolve, and leaves the line alone otherwise."""
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", "tests/stubs/petsc",
+                        "tools/petsc_ksp_driver.c"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.delenv("PETSC_DIR", raising=False)
+    if bench.petsc_config() is None:  # the build image: nothing found, nothing added
+        assert bench.petsc_baseline(16, 1e-10, 1e-3) is None and "port row only" in bench.petsc_probe()
+    # a PETSC_DIR that holds no usable library: found, build fails, reported as a note -- never an exception
+    fake = tmp_path / "petsc"
+    (fake / "include").mkdir(parents=True)
+    (fake / "lib").mkdir()
+    monkeypatch.setenv("PETSC_DIR", str(fake))
+    monkeypatch.setenv("PETSC_ARCH", "")
+    if bench.petsc_config() is not None and "PETSC_DIR" in bench.petsc_config()[2]:
+        out = bench.petsc_baseline(8, 1e-10, 1e-3)
+        assert out["kind"] == "petsc" and out["value"] is None and "did not build" in out["note"]
+
+
 def test_plain_mirror_still_builds_without_petsc():
     r = _syntax(["-I", "include", "-x", "c++", "-include", "petibm_amd/linsolver.hpp", "/dev/null"])
     assert r.returncode == 0, r.stderr

@@ -817,7 +817,7 @@ def test_residual_update_inside_the_vcycle_is_bit_identical(lin, flavour, sweeps
     xs = np.random.default_rng(7).uniform(-1, 1, n[0] * n[1] * n[2])
     xs -= xs.mean()
     out = []
-    for fuse in (1, 0):
+    for fuse in (1, 0, 2):  # 2: the solver asks for the fused form, the cycle's launch-site predicate refuses it (forced): fallback pass
         extra = f"pib_fuse_residual_update={fuse}\npib_march_min_cells=0\n"
         if flavour == "amgx":
             text = gmg_cfg(pre=sweeps, post=sweeps, extra=extra)
@@ -841,3 +841,5 @@ def test_residual_update_inside_the_vcycle_is_bit_identical(lin, flavour, sweeps
     assert np.array_equal(out[0][0], out[1][0])
     assert np.allclose(out[0][1], out[1][1], rtol=1e-12)
     assert out[0][3] <= 2e-10
+    # the fallback (a refusing launch site no longer fails the solve: the update runs as its own pass, into the other buffer)
+    assert out[2][2] == out[1][2] and np.array_equal(out[2][0], out[1][0]) and np.array_equal(out[2][1], out[1][1])

@@ -110,9 +110,11 @@ def test_peer_transport_ids_are_fresh_shared_memory_names(capi):
         assert lib.pib_comm_peer_id(buf) == 0
         assert buf.raw[:8] == b"PIBPEER1"
         name = buf.raw[8:].split(b"\0", 1)[0]
-        assert name.startswith(b"/pib_peer_") and b"/" not in name[1:] and len(name) < 100
+        assert name.startswith(b"/pib_peerD_") and b"/" not in name[1:] and len(name) < 100  # D: device-ordered collectives (the default)
         ids.append(name)
     assert len(set(ids)) == 3
+    buf = ctypes.create_string_buffer(capi.UID_BYTES)
+    assert lib.pib_comm_peer_id_ordered(buf, 0) == 0 and buf.raw[8:].startswith(b"/pib_peerH_")  # host-ordered, on request
     assert lib.pib_comm_peer_id(None) != 0 and b"null output" in lib.pib_last_error()
 
 

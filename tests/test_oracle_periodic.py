@@ -36,6 +36,35 @@ def test_gmg_level_operator_is_dbng(n, per):
     assert np.linalg.norm(r) <= 1.01e-10 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("n,per,ratios", [((14, 10), (False, False), (1.15, 0.9)), ((12, 10), (True, False), (1.1, 1.2)),
+                                          ((9, 8, 10), (False, True, False), (1.2, 1.05, 0.85)), ((8, 7, 9), (True, True, True), (1.1, 0.9, 1.3)),
+                                          ((10, 9, 8), (False, False, False), (0.8, 1.25, 1.1))])
+def test_gmg_scaled_rows_are_the_assembled_operator_on_stretched_meshes(n, per, ratios):
+    """oracle/csrc/gmg.c works, like gmg.hip, on the level operator's rows divided by the cell volume (1-D tables cm / cp / 1/w);
+    that formulation is checked HERE against an independent one -- the reference's assembled D (dt I) G
+    (createdivergence.cpp:135-223, creategradient.cpp:64-128) from oracle/operators.py -- on stretched, periodic and mixed
+    meshes: the level-0 operator the V-cycle smooths with is that matrix to rounding, so an error in the scaled tables (wall
+    or wrap handling) cannot hide on both sides of the GPU-vs-oracle multigrid parity tests."""
+    dim = len(n)
+    m = omesh.create_mesh(omesh.periodic_config(n, per, ratios=list(ratios)))
+    dt = 0.02
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, DBNG = oops.create_poisson_operator(D, G, L, dt, 0.5 * 0.01, 1)
+    w = [np.array([m.dL[3][d][i] for i in range(n[d])]) for d in range(dim)]
+    assert max(wd.max() / wd.min() for wd in w) > 1.5  # really stretched
+    g = clib.GMG(n, w, dt, nullspace=1, pre=2, post=2, omega=0.9, periodic=per)
+    A = DBNG.to_dense()
+    for seed in range(3):
+        x = np.random.default_rng(seed).standard_normal(m.pN)
+        y_ref = A @ x
+        assert np.abs(g.apply_operator(x) - y_ref).max() <= 2e-13 * np.abs(A).max() * np.abs(x).max() * (2 * dim + 1)
+    # unit vectors: entry by entry (column by column) for the first, a middle and the last cell
+    for c in (0, m.pN // 2, m.pN - 1):
+        e = np.zeros(m.pN)
+        e[c] = 1.0
+        assert np.abs(g.apply_operator(e) - A[:, c]).max() <= 1e-13 * np.abs(A).max()
+
+
 def tgv2d_fields(m, t, nu):
     """Taylor-Green vortex of examples/navierstokes/taylorgreenvortex2dRe100/config.yaml at the velocity points"""
     out = []
