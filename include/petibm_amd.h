@@ -323,7 +323,10 @@ int pib_ns_create_slab(pib_ns **ns, int dim, const int64_t n[3], const double *w
                        const void *uid_or_null, int device);
 /* parameters.BN of config.yaml (default 1): order of BN in the Poisson operator D*BN*G and in the projection
  * u = u* - BN G dP (navierstokes.cpp:349-356,583-598).  Call after pib_ns_create, before the first step.  N > 1 builds
- * the operator through pib_assemble_poisson_bn's product chain; not combined with immersed bodies (PIB_ERR_SUP). */
+ * the operator through pib_assemble_poisson_bn's product chain and keeps the assembled BN: immersed bodies set afterwards
+ * (pib_ns_set_bodies / pib_ns_move_bodies) build BNH = BN H and EBNH = E BNH from it through the same chain
+ * (applications/decoupledibpm/decoupledibpm.cpp:194-205) -- so call this BEFORE pib_ns_set_bodies (PIB_ERR_ORDER
+ * otherwise).  Not with the coupled IBPM (PIB_ERR_SUP). */
 int pib_ns_set_bn_order(pib_ns *ns, int order);
 /* parameters.convection / parameters.diffusion of config.yaml (createTimeIntegration, src/timeintegration/
  * timeintegration.cpp:41-80): "EULER_EXPLICIT" | "EULER_IMPLICIT" | "ADAMS_BASHFORTH_2" | "CRANK_NICOLSON" for either

@@ -145,7 +145,8 @@ def transpose(a: CSR) -> CSR:
     return CSR(a.n_cols, a.n_rows, rp, rows[order].astype(np.int64), a.val[order].copy())
 
 
-def create_ib_operators(mesh: CartesianMesh, bodies, dt: float, kernel_name: str = "ROMA_ET_AL_1999"):
+def create_ib_operators(mesh: CartesianMesh, bodies, dt: float, kernel_name: str = "ROMA_ET_AL_1999", BN: CSR = None):
+    """decoupledibpm.cpp:141-216; BN: createBnHead(L, dt, c nu, N) for parameters.BN = N > 1 (:194-197), dt I otherwise"""
     delta = create_delta(mesh, bodies, kernel_name)
     H = transpose(delta)
     R, M = diag_r_mhat(mesh)
@@ -153,7 +154,8 @@ def create_ib_operators(mesh: CartesianMesh, bodies, dt: float, kernel_name: str
     E.val = E.val * R[E.col]  # MatDiagonalScale(E, nullptr, RDiag)
     E.val = E.val * M[E.col]  # MatDiagonalScale(E, nullptr, MHatDiag)
     nu_ = H.n_rows
-    BN = CSR(nu_, nu_, np.arange(nu_ + 1, dtype=np.int64), np.arange(nu_, dtype=np.int64), np.full(nu_, dt))
+    if BN is None:
+        BN = CSR(nu_, nu_, np.arange(nu_ + 1, dtype=np.int64), np.arange(nu_, dtype=np.int64), np.full(nu_, dt))
     BNH = oops.matmatmult(BN, H)
     EBNH = oops.matmatmult(E, BNH)
     return {"delta": delta, "E": E, "H": H, "BNH": BNH, "EBNH": EBNH}
@@ -176,7 +178,9 @@ class DecoupledIBPM(ons.NavierStokes):
     def __init__(self, mesh: CartesianMesh, dt: float, nu: float, bodies, kernel_name="ROMA_ET_AL_1999", **kw):
         super().__init__(mesh, dt, nu, **kw)
         self.bodies = [np.asarray(b, dtype=np.float64) for b in bodies]
-        self.ops = create_ib_operators(mesh, self.bodies, dt, kernel_name)
+        bn_order = int(kw.get("bn_order", 1))
+        self.BN = oops.create_bn_head(self.L, dt, self.cimpl * nu, bn_order) if bn_order > 1 else None
+        self.ops = create_ib_operators(mesh, self.bodies, dt, kernel_name, self.BN)
         self.nf = self.ops["E"].n_rows
         self.f = np.zeros(self.nf)
         self.EBNH_dense = self.ops["EBNH"].to_dense()
@@ -187,7 +191,7 @@ class DecoupledIBPM(ons.NavierStokes):
         """RigidKinematicsSolver::moveBodies (applications/rigidkinematics/rigidkinematics.cpp:118-140): new
         coordinates, prescribed point velocities UB, operators rebuilt, fSolver->setMatrix(EBNH)"""
         self.bodies = [np.asarray(b, dtype=np.float64) for b in bodies]
-        self.ops = create_ib_operators(self.mesh, self.bodies, self.dt, self.kernel_name)
+        self.ops = create_ib_operators(self.mesh, self.bodies, self.dt, self.kernel_name, self.BN)
         self.EBNH_dense = self.ops["EBNH"].to_dense()
         if velocities is not None:
             self.UB = np.concatenate([np.asarray(v, dtype=np.float64) for v in velocities], axis=0).reshape(-1)

@@ -139,6 +139,37 @@ static int spgemm(const Csr32 &A, const Csr32 &B, Csr32 *C, hipStream_t q)
     return 0;
 }
 
+// C = A B for the immersed-boundary operators (BNH = BN H, EBNH = E BNH with BN order > 1: decoupledibpm.cpp:194-205), the
+// numerics of PETSc's SeqAIJ MatMatMult as above.  The caller owns the output arrays.
+int device_spgemm(int64_t a_rows, int64_t a_cols, int64_t b_cols, const int32_t *arp, const int32_t *acol, const double *aval, int64_t a_nnz,
+                  const int32_t *brp, const int32_t *bcol, const double *bval, int64_t b_nnz, int32_t **crp, int32_t **ccol, double **cval,
+                  int64_t *c_nnz, hipStream_t q)
+{
+    Csr32 A, B, C;
+    A.nrows = a_rows;
+    A.ncols = a_cols;
+    A.nnz = a_nnz;
+    A.rowptr = const_cast<int32_t *>(arp);
+    A.col = const_cast<int32_t *>(acol);
+    A.val = const_cast<double *>(aval);
+    B.nrows = a_cols;
+    B.ncols = b_cols;
+    B.nnz = b_nnz;
+    B.rowptr = const_cast<int32_t *>(brp);
+    B.col = const_cast<int32_t *>(bcol);
+    B.val = const_cast<double *>(bval);
+    const int err = spgemm(A, B, &C, q);
+    if (err) {
+        C.release();
+        return err;
+    }
+    *crp = C.rowptr;
+    *ccol = C.col;
+    *cval = C.val;
+    *c_nnz = C.nnz;
+    return 0;
+}
+
 // Z = Y + a X on the union pattern (both inputs sorted)
 template <bool FILL>
 __global__ __launch_bounds__(128) void k_axpy_pattern(int64_t nrows, double a, const int32_t *__restrict__ yrp,
@@ -305,7 +336,8 @@ static int dup(const Csr32 &A, Csr32 *B, hipStream_t q)
 // Builds BNG (UN x pN) and DBNG (pN x pN) for BN order `order` >= 2 on the solver's device.  `s` is used as the
 // workspace of the Laplacian assembly (its matrix is replaced).
 static int build_bn_chain(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
-                          const double mx[3], const double a0[18], double dt, double coeff_nu, int order, Csr32 *BNG, Csr32 *DBNG)
+                          const double mx[3], const double a0[18], double dt, double coeff_nu, int order, Csr32 *BNG, Csr32 *DBNG,
+                          Csr32 *BNkeep = nullptr)
 {
     hipStream_t q = s->stream;
     for (int f = 0; f < dim; ++f)
@@ -401,6 +433,7 @@ static int build_bn_chain(pib_solver *s, int dim, const int64_t n[3], const doub
         }
         PIB_CHK(spgemm(BN, G, BNG, q));
         PIB_CHK(spgemm(D, *BNG, DBNG, q));
+        if (BNkeep != nullptr) std::swap(*BNkeep, BN);  // the immersed-boundary operators need BN itself (BNH = BN H)
         return 0;
     };
     err = run();
@@ -508,19 +541,27 @@ static int assemble_poisson_bn_slab(pib_solver *s, int dim, const int64_t n[3], 
 
 int assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
                         const double mx[3], const double a0[18], double dt, double coeff_nu, int order, int nullspace,
-                        int32_t **bng_rowptr, int32_t **bng_col, double **bng_val, int64_t *bng_nnz)
+                        int32_t **bng_rowptr, int32_t **bng_col, double **bng_val, int64_t *bng_nnz, int32_t **bn_rowptr,
+                        int32_t **bn_col, double **bn_val, int64_t *bn_nnz)
 {
     if (order < 1) return fail(PIB_ERR_SUP, "The order of Bn can not be smaller than 1.");  // createbn.cpp:27-29 (error 56)
     if (s->comm.nranks > 1) {
         if (bng_rowptr) return fail(PIB_ERR_SUP, "BN order > 1: the projection's BNG is assembled on one rank only");
         return assemble_poisson_bn_slab(s, dim, n, w, mn, mx, a0, dt, coeff_nu, order, nullspace);
     }
-    Csr32 BNG, DBNG;
-    int err = build_bn_chain(s, dim, n, w, mn, mx, a0, dt, coeff_nu, order, &BNG, &DBNG);
+    Csr32 BNG, DBNG, BN;
+    int err = build_bn_chain(s, dim, n, w, mn, mx, a0, dt, coeff_nu, order, &BNG, &DBNG, bn_rowptr ? &BN : nullptr);
     if (err) {
         BNG.release();
         DBNG.release();
+        BN.release();
         return err;
+    }
+    if (bn_rowptr) {
+        *bn_rowptr = BN.rowptr;
+        *bn_col = BN.col;
+        *bn_val = BN.val;
+        *bn_nnz = BN.nnz;
     }
     hipStream_t q = s->stream;
     if (nullspace == PIB_NULLSPACE_PINNED) {

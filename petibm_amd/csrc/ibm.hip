@@ -55,6 +55,10 @@ struct IbState {
     int32_t *c_rowptr = nullptr, *c_col = nullptr;
     double *c_val = nullptr;
     int64_t c_nnz = 0;
+    // BN order > 1: BNH = BN H assembled (UN rows, most of them empty); order 1 applies dt * H from the compressed rows
+    int32_t *bnh_rowptr = nullptr, *bnh_col = nullptr;
+    double *bnh_val = nullptr;
+    int64_t bnh_nnz = 0;
     double *f = nullptr, *df = nullptr, *rhsf = nullptr;
     double *ub = nullptr;     // prescribed velocity of the Lagrangian points (RigidKinematicsSolver: rhsf = UB - E u)
     bool moving = false;
@@ -312,6 +316,38 @@ static int scan_counts(const int32_t *d_count, int64_t n, int32_t *d_rowptr, int
 __global__ void k_ib_eu(int64_t nf, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                         const double *__restrict__ eval, const double *__restrict__ U, double *__restrict__ out);
 
+// y = y + A x for an assembled CSR with many empty rows (BNH with BN order > 1): MatMultAdd, the row sum starts from y[row]
+__global__ __launch_bounds__(256) void k_ib_csr_mult_add(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                         const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const int32_t a = rp[r], b = rp[r + 1];
+        if (a == b) continue;
+        double s = y[r];
+        for (int32_t q = a; q < b; ++q) s = s + val[q] * x[col[q]];
+        y[r] = s;
+    }
+}
+// rowptr counts of H as a full CSR over the velocity points, from its compressed rows
+__global__ __launch_bounds__(256) void k_ib_hcounts(int64_t hrows, const int32_t *__restrict__ hcols, const int32_t *__restrict__ hptr,
+                                                    int32_t *__restrict__ count)
+{
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < hrows; m += (int64_t)gridDim.x * 256) count[hcols[m]] = hptr[m + 1] - hptr[m];
+}
+
+// y += BNH x  (MatMultAdd(BNH, x, y, y): decoupledibpm.cpp:283-284)
+static int ib_bnh_mult_add(pib_ns *ns, const double *x, double *y, hipStream_t q)
+{
+    IbState *ib = ns->ib;
+    if (ib->bnh_rowptr != nullptr)
+        hipLaunchKernelGGL(k_ib_csr_mult_add, dim3(blocks_for(ns->D.UN)), dim3(256), 0, q, ns->D.UN, ib->bnh_rowptr, ib->bnh_col, ib->bnh_val, x, y);
+    else
+        hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ns->dt, ib->hcols, ib->hptr, ib->hrow,
+                           ib->hval, x, y);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
+
 int ib_spread_forces(pib_ns *ns)
 {
     IbState *ib = ns->ib;
@@ -349,10 +385,7 @@ int ib_solve_forces(pib_ns *ns)
     PIB_HIP(hipGetLastError());
     PIB_HIP(hipStreamSynchronize(ns->stream));
     PIB_CHK(pib_solve(ib->fsol, ib->df, ib->rhsf));  // fSolver->solve(df, rhsf)  (decoupledibpm.cpp:267)
-    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, ns->stream, ib->hrows, ns->dt, ib->hcols, ib->hptr,
-                       ib->hrow, ib->hval, ib->df, ns->U);  // MatMultAdd(BNH, df, U, U)  (:283-284)
-    PIB_HIP(hipGetLastError());
-    return 0;
+    return ib_bnh_mult_add(ns, ib->df, ns->U, ns->stream);  // MatMultAdd(BNH, df, U, U)  (:283-284)
 }
 
 // out[r] = (E u)[r]
@@ -397,9 +430,7 @@ static int ib_schur_term(pib_solver *ps, const double *p, double *w, bool guarde
     hipLaunchKernelGGL(k_ib_eu, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, ib->eval, ib->t_un, ib->g_nf);  // E t1
     PIB_CHK(dense_apply_raw(ib->fsol, ib->g_nf, ib->y_nf, q));                                       // y = EBNH^-1 g
     PIB_HIP(hipMemsetAsync(ib->t_un2, 0, sizeof(double) * (size_t)UN, q));
-    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ns->dt, ib->hcols, ib->hptr, ib->hrow,
-                       ib->hval, ib->y_nf, ib->t_un2);                                               // t2 = BNH y
-    PIB_HIP(hipGetLastError());
+    PIB_CHK(ib_bnh_mult_add(ns, ib->y_nf, ib->t_un2, q));                                            // t2 = BNH y
     return ns_div_sub(ns, ib->t_un2, w, q);                                                          // w -= D t2
 }
 
@@ -414,9 +445,7 @@ int ib_coupled_solve_and_project(pib_ns *ns)
     hipLaunchKernelGGL(k_ib_eu, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, ib->eval, ns->U, ib->r2);
     PIB_CHK(dense_apply_raw(ib->fsol, ib->r2, ib->y_nf, q));
     PIB_HIP(hipMemsetAsync(ib->t_un2, 0, sizeof(double) * (size_t)UN, q));
-    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ns->dt, ib->hcols, ib->hptr, ib->hrow,
-                       ib->hval, ib->y_nf, ib->t_un2);
-    PIB_HIP(hipGetLastError());
+    PIB_CHK(ib_bnh_mult_add(ns, ib->y_nf, ib->t_un2, q));
     PIB_CHK(ns_div_sub(ns, ib->t_un2, ns->rhs2, q));
     PIB_HIP(hipStreamSynchronize(q));
     // S dP = r1'
@@ -429,8 +458,7 @@ int ib_coupled_solve_and_project(pib_ns *ns)
     hipLaunchKernelGGL(k_ib_neg, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->y_nf, ib->df);
     // u = u* - BNG dP + BNH df ; p += dP ; f += df
     hipLaunchKernelGGL(k_ib_axpy, dim3(blocks_for(UN)), dim3(256), 0, q, UN, -1.0, ib->t_un, ns->U);
-    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ns->dt, ib->hcols, ib->hptr, ib->hrow,
-                       ib->hval, ib->df, ns->U);
+    PIB_CHK(ib_bnh_mult_add(ns, ib->df, ns->U, q));
     hipLaunchKernelGGL(k_ib_axpy, dim3(blocks_for(pN)), dim3(256), 0, q, pN, 1.0, ns->dP, ns->p);
     hipLaunchKernelGGL(k_ib_axpy, dim3(blocks_for(nf)), dim3(256), 0, q, nf, 1.0, ib->df, ib->f);
     PIB_HIP(hipGetLastError());
@@ -552,6 +580,37 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
         PIB_HIP(hipMemcpyAsync(ib->hptr + m, &last, sizeof(int32_t), hipMemcpyHostToDevice, q));
         PIB_HIP(hipStreamSynchronize(q));
     }
+    ib->bnh_rowptr = ib->bnh_col = nullptr;
+    ib->bnh_val = nullptr;
+    ib->bnh_nnz = 0;
+    if (ns->bn_order > 1) {
+        // ---- BN order > 1: BNH = BN H and EBNH = E BNH through the reference's MatMatMult chain (decoupledibpm.cpp:194-205) with
+        // the assembled BN of pib_ns_set_bn_order (createBnHead, bn.hip); H as a full CSR over the velocity points
+        if (ns->nranks > 1) return fail(PIB_ERR_SUP, "immersed bodies with BN order > 1 on several ranks are not provided");
+        if (ns->bn_rowptr == nullptr) return fail(PIB_ERR_ORDER, "immersed bodies with BN order > 1: call pib_ns_set_bn_order first");
+        const int64_t UN = ns->D.UN;
+        int32_t *h_rp = nullptr;
+        if ((err = dev_alloc(ib, &h_rp, UN + 1))) return err;
+        PIB_HIP(hipMemsetAsync(h_rp, 0, sizeof(int32_t) * (size_t)(UN + 1), q));
+        hipLaunchKernelGGL(k_ib_hcounts, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ib->hcols, ib->hptr, h_rp);
+        PIB_HIP(hipGetLastError());
+        int64_t h_nnz = 0;
+        if ((err = scan_counts(h_rp, UN, h_rp, &h_nnz, q))) return err;
+        if (h_nnz != ib->nnz) return fail(PIB_ERR_LIB, "immersed bodies: H has %lld entries, Delta %lld", (long long)h_nnz, (long long)ib->nnz);
+        if ((err = device_spgemm(UN, UN, nf, ns->bn_rowptr, ns->bn_col, ns->bn_val, ns->bn_nnz, h_rp, ib->hrow, ib->hval, h_nnz,
+                                 &ib->bnh_rowptr, &ib->bnh_col, &ib->bnh_val, &ib->bnh_nnz, q)))
+            return err;
+        ib->owned.push_back(ib->bnh_rowptr);
+        ib->owned.push_back(ib->bnh_col);
+        ib->owned.push_back(ib->bnh_val);
+        if ((err = device_spgemm(nf, UN, nf, ib->rowptr, ib->col, ib->eval, ib->nnz, ib->bnh_rowptr, ib->bnh_col, ib->bnh_val, ib->bnh_nnz,
+                                 &ib->c_rowptr, &ib->c_col, &ib->c_val, &ib->c_nnz, q)))
+            return err;
+        ib->owned.push_back(ib->c_rowptr);
+        ib->owned.push_back(ib->c_col);
+        ib->owned.push_back(ib->c_val);
+        return adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val);
+    }
     // ---- EBNH = E (BN H)
     if ((err = dev_alloc(ib, &ib->c_rowptr, nf + 1))) return err;
     hipLaunchKernelGGL(k_ib_ebnh<false>, dim3((unsigned)nf), dim3(64), 0, q, I, ns->dt, ib->rowptr, ib->col, ib->val, ib->eval, count,
@@ -579,7 +638,6 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     using namespace pib;
     if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
-    if (ns->bn_order > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bodies: BN order > 1 with immersed bodies is not supported");
     PIB_HIP(hipSetDevice(ns->device));
     if (ns->ib != nullptr && ns->psol != nullptr) {
         // the coupled scheme's Schur hook points into the state that goes away: back to the plain Poisson operator
@@ -637,6 +695,8 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
  * forces solver (its explicit inverse of EBNH is part of the operator). */
 int pib_ns_set_coupled(pib_ns *ns, int coupled)
 {
+    if (ns != nullptr && coupled && ns->bn_order > 1)
+        return pib::fail(PIB_ERR_SUP, "pib_ns_set_coupled: the coupled IBPM with BN order > 1 is not provided (decoupled: yes)");
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_set_coupled: the flow has no immersed bodies");
@@ -771,6 +831,9 @@ int pib_ns_get_ib_operator(pib_ns *ns, int which, int64_t *n_rows, int64_t *nnz,
         case 1: nr = ib->I.nf; nz = ib->nnz; rp = ib->rowptr; cl = ib->col; vl = ib->eval; break;
         case 2: nr = ib->hrows; nz = ib->nnz; rp = ib->hptr; cl = ib->hrow; vl = ib->hval; break;
         case 3: nr = ib->I.nf; nz = ib->c_nnz; rp = ib->c_rowptr; cl = ib->c_col; vl = ib->c_val; break;
+        case 4:  // BNH, assembled for BN order > 1 only
+            if (ib->bnh_rowptr == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_get_ib_operator: BNH is assembled for BN order > 1 only");
+            nr = ns->D.UN; nz = ib->bnh_nnz; rp = ib->bnh_rowptr; cl = ib->bnh_col; vl = ib->bnh_val; break;
         default: return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_get_ib_operator: which = %d", which);
     }
     if (n_rows) *n_rows = nr;

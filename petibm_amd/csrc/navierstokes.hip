@@ -665,6 +665,9 @@ int pib_ns_destroy(pib_ns *ns)
     if (ns->bng_rowptr) (void)hipFree(ns->bng_rowptr);
     if (ns->bng_col) (void)hipFree(ns->bng_col);
     if (ns->bng_val) (void)hipFree(ns->bng_val);
+    if (ns->bn_rowptr) (void)hipFree(ns->bn_rowptr);
+    if (ns->bn_col) (void)hipFree(ns->bn_col);
+    if (ns->bn_val) (void)hipFree(ns->bn_val);
     if (ns->stream) (void)hipStreamDestroy(ns->stream);
     delete ns;
     return 0;
@@ -1044,16 +1047,19 @@ int pib_ns_set_bn_order(pib_ns *ns, int order)
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     if (order < 1) return fail(PIB_ERR_SUP, "The order of Bn can not be smaller than 1.");
-    if (ns->ib && order > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bn_order: BN order > 1 with immersed bodies is not supported");
     if (order == ns->bn_order) return 0;
+    if (ns->ib) return fail(PIB_ERR_ORDER, "pib_ns_set_bn_order: call it before pib_ns_set_bodies (BNH = BN H and E BN H are built from BN)");
     if (ns->nranks > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bn_order: BN order > 1 on several ranks is not provided");
     PIB_HIP(hipSetDevice(ns->device));
     if (ns->bng_rowptr) (void)hipFree(ns->bng_rowptr);
     if (ns->bng_col) (void)hipFree(ns->bng_col);
     if (ns->bng_val) (void)hipFree(ns->bng_val);
-    ns->bng_rowptr = ns->bng_col = nullptr;
-    ns->bng_val = nullptr;
-    ns->bng_nnz = 0;
+    if (ns->bn_rowptr) (void)hipFree(ns->bn_rowptr);
+    if (ns->bn_col) (void)hipFree(ns->bn_col);
+    if (ns->bn_val) (void)hipFree(ns->bn_val);
+    ns->bng_rowptr = ns->bng_col = ns->bn_rowptr = ns->bn_col = nullptr;
+    ns->bng_val = ns->bn_val = nullptr;
+    ns->bng_nnz = ns->bn_nnz = 0;
     const int dim = ns->D.dim;
     const double *w[3] = {ns->h_w[0].data(), ns->h_w[1].data(), dim == 3 ? ns->h_w[2].data() : nullptr};
     const int nullspace = ns->pinned ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT;
@@ -1064,7 +1070,8 @@ int pib_ns_set_bn_order(pib_ns *ns, int order)
         ns->psol->has_grid = false;
         gmg_release(ns->psol);
         PIB_CHK(assemble_poisson_bn(ns->psol, dim, ns->h_n, w, ns->lo, ns->hi, ns->h_a0, ns->dt, ns->T.cimpl * ns->nu, order, nullspace,
-                                    &ns->bng_rowptr, &ns->bng_col, &ns->bng_val, &ns->bng_nnz));
+                                    &ns->bng_rowptr, &ns->bng_col, &ns->bng_val, &ns->bng_nnz, &ns->bn_rowptr, &ns->bn_col, &ns->bn_val,
+                                    &ns->bn_nnz));
     }
     ns->bn_order = order;
     return 0;

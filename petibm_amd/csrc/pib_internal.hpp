@@ -445,7 +445,11 @@ int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *c
 // owned by the caller)
 int assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
                         const double mx[3], const double a0[18], double dt, double coeff_nu, int order, int nullspace,
-                        int32_t **bng_rowptr, int32_t **bng_col, double **bng_val, int64_t *bng_nnz);
+                        int32_t **bng_rowptr, int32_t **bng_col, double **bng_val, int64_t *bng_nnz, int32_t **bn_rowptr = nullptr,
+                        int32_t **bn_col = nullptr, double **bn_val = nullptr, int64_t *bn_nnz = nullptr);
+int device_spgemm(int64_t a_rows, int64_t a_cols, int64_t b_cols, const int32_t *arp, const int32_t *acol, const double *aval, int64_t a_nnz,
+                  const int32_t *brp, const int32_t *bcol, const double *bval, int64_t b_nnz, int32_t **crp, int32_t **ccol, double **cval,
+                  int64_t *c_nnz, hipStream_t q);
 int assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double mn[3],
                       const double mx[3], const double a0[18], double dt, double coeff_nu);
 int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rowptr,

@@ -455,8 +455,9 @@ class DecoupledIBPMSolver(NavierStokesSolver):
             self.setForces(f.read("force"))
 
     def getOperator(self, which: str):
-        """'delta' | 'E' | 'H' | 'EBNH' as (n_rows, rowptr, col, val[, row_ids]) host arrays (inspection / parity)"""
-        w = {"delta": 0, "E": 1, "H": 2, "EBNH": 3}[which]
+        """'delta' | 'E' | 'H' | 'EBNH' | 'BNH' (assembled for parameters.BN > 1 only) as (n_rows, rowptr, col, val[, row_ids])
+        host arrays (inspection / parity)"""
+        w = {"delta": 0, "E": 1, "H": 2, "EBNH": 3, "BNH": 4}[which]
         nr, nz = C.c_int64(), C.c_int64()
         lib = capi.load()
         capi.check(lib.pib_ns_get_ib_operator(self._h, w, C.byref(nr), C.byref(nz), None, None, None, None))
