@@ -638,6 +638,8 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     using namespace pib;
     if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
+    if (ns->bn_order > 1 && ns->nranks > 1)
+        return fail(PIB_ERR_SUP, "pib_ns_set_bodies: immersed bodies with BN order > 1 on several ranks are not provided (one rank: yes)");
     PIB_HIP(hipSetDevice(ns->device));
     if (ns->ib != nullptr && ns->psol != nullptr) {
         // the coupled scheme's Schur hook points into the state that goes away: back to the plain Poisson operator

@@ -1020,6 +1020,59 @@ static int ns_halo_cells(pib_ns *ns, double *ext)
     const int64_t lo_n = (r > 0 || ns->ring) ? pl : 0, hi_n = (r < P - 1 || ns->ring) ? pl : 0;
     return halo_exchange_planes(ns->vsol, ext + (ns->slab_pk0 - ns->slab_e0) * pl, ns->pN_owned, lo_n, hi_n, lo_n, hi_n, ns->stream);
 }
+__global__ __launch_bounds__(256) void k_ns_axpy(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = y[i] + a * x[i];
+}
+// u = u - BN G dP, p = p + dP on z-slabs with BN order N > 1 (navierstokes.cpp:583-615).  One rank multiplies by the
+// assembled BNG; a row of it reaches N planes along the slab axis, so here BN = sum_k dt^k (c nu)^(k-1) L^(k-1)
+// (createbn.cpp:47-92) is APPLIED term by term to t = dt G dP instead: L is the velocity solver's matrix-free operator with
+// MatScale(1), MatShift(0) -- its tables cover this rank's planes, the neighbours' planes come through the solver's own
+// halo exchange -- one exchange per extra term.  The same operator to rounding (the sums run in another order than the
+// assembled rows'): tests/test_gpu_bn.py compares 2 / 3 loopback ranks with the single rank at the solver tolerance.
+static int ns_project_bn_slab(pib_ns *ns)
+{
+    pib_solver *vs = ns->vsol;
+    if (!vs->vel.valid || vs->vel.slab_axis < 0)
+        return fail(PIB_ERR_SUP, "BN order > 1 on z-slabs needs the matrix-free velocity operator (pib_matrix_free_velocity=1)");
+    const NsDev &D = ns->D;
+    hipStream_t q = ns->stream;
+    const int64_t no = ns->UN_owned;
+    const unsigned gb = (unsigned)std::min<int64_t>(4096, (no + 255) / 256);
+    PIB_CHK(ensure_work(vs, 2));
+    if (ns->bn_tmp == nullptr) {
+        PIB_HIP(hipMalloc(&ns->bn_tmp, sizeof(double) * (size_t)D.UN));
+        ns->owned.push_back(ns->bn_tmp);
+    }
+    double *Y = vs->vec(0), *Z = vs->vec(1), *acc = ns->rhs1pk, *t = ns->bn_tmp;  // the velocity solve is over: its vectors are free
+    PIB_CHK(ns_bng_apply(ns, ns->dP, t, q));                                   // t = dt G dP on the extended slab
+    PIB_CHK(ns_pack(ns, t, Y));
+    PIB_HIP(hipMemcpyAsync(acc, Y, sizeof(double) * (size_t)no, hipMemcpyDeviceToDevice, q));  // term 1: dt I
+    const double scale0 = vs->vel.scale, shift0 = vs->vel.shift;
+    const double cnu = ns->T.cimpl * ns->nu;
+    int err = 0;
+    for (int term = 2; term <= ns->bn_order && !err; ++term) {
+        PIB_HIP(hipStreamSynchronize(q));  // the exchange below runs on the solver's stream
+        if ((err = halo_exchange(vs, Y, vs->stream))) break;
+        vs->vel.scale = 1.0;  // L itself
+        vs->vel.shift = 0.0;
+        err = vel_stencil_apply(vs, Y, Z, false, vs->stream);
+        vs->vel.scale = scale0;
+        vs->vel.shift = shift0;
+        if (err) break;
+        PIB_HIP(hipStreamSynchronize(vs->stream));
+        std::swap(Y, Z);
+        hipLaunchKernelGGL(k_ns_axpy, dim3(gb), dim3(256), 0, q, no, std::pow(ns->dt, term - 1) * std::pow(cnu, term - 1), Y, acc);
+        PIB_HIP(hipGetLastError());
+    }
+    if (err) return err;
+    PIB_HIP(hipMemsetAsync(t, 0, sizeof(double) * (size_t)D.UN, q));
+    PIB_CHK(ns_unpack(ns, acc, t));
+    hipLaunchKernelGGL(k_ns_axpy, dim3((unsigned)std::min<int64_t>(4096, (D.UN + 255) / 256)), dim3(256), 0, q, D.UN, -1.0, t, ns->U);
+    hipLaunchKernelGGL(k_ns_axpy, dim3((unsigned)std::min<int64_t>(4096, (D.pN + 255) / 256)), dim3(256), 0, q, D.pN, 1.0, ns->dP, ns->p);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
 }  // namespace pib
 
 extern "C" {
@@ -1049,7 +1102,6 @@ int pib_ns_set_bn_order(pib_ns *ns, int order)
     if (order < 1) return fail(PIB_ERR_SUP, "The order of Bn can not be smaller than 1.");
     if (order == ns->bn_order) return 0;
     if (ns->ib) return fail(PIB_ERR_ORDER, "pib_ns_set_bn_order: call it before pib_ns_set_bodies (BNH = BN H and E BN H are built from BN)");
-    if (ns->nranks > 1) return fail(PIB_ERR_SUP, "pib_ns_set_bn_order: BN order > 1 on several ranks is not provided");
     PIB_HIP(hipSetDevice(ns->device));
     if (ns->bng_rowptr) (void)hipFree(ns->bng_rowptr);
     if (ns->bng_col) (void)hipFree(ns->bng_col);
@@ -1069,6 +1121,10 @@ int pib_ns_set_bn_order(pib_ns *ns, int order)
         ns->psol->has_matrix = false;
         ns->psol->has_grid = false;
         gmg_release(ns->psol);
+        if (ns->nranks > 1)  // z-slabs: the operator from the window chain (bn.hip), the projection applies BN term by term
+            PIB_CHK(assemble_poisson_bn(ns->psol, dim, ns->h_n, w, ns->lo, ns->hi, ns->h_a0, ns->dt, ns->T.cimpl * ns->nu, order, nullspace,
+                                        nullptr, nullptr, nullptr, nullptr));
+        else
         PIB_CHK(assemble_poisson_bn(ns->psol, dim, ns->h_n, w, ns->lo, ns->hi, ns->h_a0, ns->dt, ns->T.cimpl * ns->nu, order, nullspace,
                                     &ns->bng_rowptr, &ns->bng_col, &ns->bng_val, &ns->bng_nnz, &ns->bn_rowptr, &ns->bn_col, &ns->bn_val,
                                     &ns->bn_nnz));
@@ -1354,7 +1410,9 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
             PIB_CHK(pib_solve(ns->psol, ns->dP + own, ns->rhs2 + own));  // pSolver->solve(dP, rhs2)      (:575)
             PIB_CHK(ns_halo_cells(ns, ns->dP));  // G dP at the faces towards the neighbours
         }
-        if (ns->bn_order > 1)
+        if (ns->bn_order > 1 && ns->nranks > 1)
+            PIB_CHK(ns_project_bn_slab(ns));
+        else if (ns->bn_order > 1)
             hipLaunchKernelGGL(k_ns_project_csr, dim3(gt), dim3(256), 0, ns->stream, D.UN, D.pN, ns->bng_rowptr, ns->bng_col,
                                ns->bng_val, ns->dP, ns->U, ns->p);
         else

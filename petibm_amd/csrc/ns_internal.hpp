@@ -109,6 +109,7 @@ struct pib_ns {
     int32_t *bn_rowptr = nullptr, *bn_col = nullptr;
     double *bn_val = nullptr;
     int64_t bn_nnz = 0;
+    double *bn_tmp = nullptr;  // z-slabs: t = dt G dP on the extended slab (the projection applies BN term by term)
     // z-slab (y-slab) decomposition: the engine's mesh is this rank's EXTENDED slab (navierstokes.hip: ns_create_impl)
     int rank = 0, nranks = 1;
     int64_t slab_pk0 = 0, slab_pk1 = 0, slab_e0 = 0;          // owned pressure planes [pk0, pk1), first plane of the extended slab

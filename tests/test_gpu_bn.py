@@ -234,3 +234,64 @@ def test_decoupled_ibpm_with_bn_order_above_one(case, order):
         assert np.abs(U - ref.U).max() <= 1e-8 * np.abs(ref.U).max()
         assert np.abs(f - ref.f).max() <= 1e-7 * np.abs(ref.f).max()
     s.destroy()
+
+
+@pytest.mark.parametrize("case,P,order", [("3d_cavity", 2, 2), ("3d_cavity", 3, 3), ("2d_cavity", 3, 2), ("3d_convective_outlet", 2, 2),
+                                          ("3d_channel_periodic_z", 2, 2)])
+def test_bn_order_above_one_in_the_time_step_on_slabs(case, P, order):
+    """parameters.BN = N > 1 in the slab engine (BASELINE configs 3 and 5 are 8-GPU runs of the time step): the Poisson
+    operator D BN G from the per-rank windows of the product chain, the projection u -= BN G dP by applying BN term by term
+    with the velocity solver's matrix-free L (a row of the assembled BNG reaches N planes beyond the slab; one exchange per
+    extra term instead).  2 / 3 loopback ranks against the single-rank engine (which multiplies by the assembled BNG): the
+    first right-hand side bit for bit, three steps to the solver tolerance."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    from test_gpu_multirank_loopback import _run_ranks
+    from test_gpu_navierstokes import AMGX_P, KSP_P, VEL
+    from test_gpu_navierstokes_slabs import CASES
+    make, pinned = CASES[case]
+    cfg = make()
+    cfg["parameters"]["BN"] = order
+    pcfg = AMGX_P if pinned else KSP_P
+    one = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=pcfg)
+    rng = np.random.default_rng(11)
+    U0 = 0.1 * rng.uniform(-1, 1, one.UN)
+    p0 = 0.1 * rng.uniform(-1, 1, one.pN)
+    if "convective" in case:
+        U0[: int(np.prod(one._field_shape(0)))] += 1.0
+    one.setState(U0, p0)
+    one.advance(1)
+    U1, p1, rhs1, rhs2 = one.getState(rhs=True)
+    one.advance(2)
+    U3, p3 = one.getState()
+
+    def rank_fn(r, uid):
+        s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=pcfg, device=0, rank=r, nranks=P, uid=uid)
+        s.setState(s.ownedVelocity(U0), s.ownedPressure(p0))
+        s.advance(1)
+        a = s.getState(rhs=True)
+        s.advance(2)
+        b = s.getState()
+        cut = [s.ownedVelocity(x) for x in (U1, rhs1, U3)] + [s.ownedPressure(x) for x in (p1, rhs2, p3)]
+        s.destroy()
+        return a, b, cut
+
+    res = _run_ranks(P, rank_fn)
+    for (Ua, pa, r1, r2), (Ub, pb), (cU1, crhs1, cU3, cp1, crhs2, cp3) in res:
+        if "periodic" in case:
+            assert np.abs(r1 - crhs1).max() <= 1e-13 * np.abs(crhs1).max()
+        else:
+            assert np.array_equal(r1, crhs1)
+        assert np.allclose(Ua, cU1, rtol=0, atol=1e-10) and np.allclose(Ub, cU3, rtol=0, atol=1e-9)
+        if pinned:
+            assert np.allclose(pa, cp1, rtol=0, atol=1e-8) and np.allclose(pb, cp3, rtol=0, atol=1e-8)
+    if not pinned:
+        pg = np.concatenate([r[1][1] for r in res])
+        assert np.allclose(pg - pg.mean(), p3 - p3.mean(), rtol=0, atol=1e-8)
+    # BN > 1 really changes the step (the same cases with BN = 1 end elsewhere)
+    cfg1 = make()
+    ref1 = NavierStokesSolver(cfg1, velocity_cfg=VEL, poisson_cfg=pcfg)
+    ref1.setState(U0, p0)
+    ref1.advance(3)
+    assert np.abs(ref1.getState()[0] - U3).max() > 1e-7
+    ref1.destroy()
+    one.destroy()

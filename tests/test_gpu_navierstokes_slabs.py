@@ -97,7 +97,7 @@ def test_slab_engine_limits_and_sizes():
         s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=KSP_P, device=0, rank=r, nranks=2, uid=uid)
         sizes = (s.UN, s.pN)
         lib = capi.load()
-        codes = (lib.pib_ns_set_bn_order(s._h, 2),)
+        codes = (lib.pib_ns_set_bn_order(s._h, 0),)  # "The order of Bn can not be smaller than 1." (createbn.cpp:27-29)
         s.destroy()
         return sizes, codes
 
