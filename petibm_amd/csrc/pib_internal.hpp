@@ -92,6 +92,7 @@ struct Config {
     int accumulate_unscaled_x = 1;  // ... and x summed before the Jacobi sweep, swept once at the end (krylov.hip OpBFUpdateP::y): 8 B/row/iteration less, x to rounding
     int blocked_reductions = 1;  // vector kernels with sums on >= 2^22 entries: a contiguous range per workgroup instead of a grid stride
     int lean_bicgstab = 1;  // BiCGStab on the matrix-free velocity operator without stored M^-1 p / M^-1 s and with the x update deferred (krylov.hip OpBFUpdateP)
+    int velocity_tile_edges = 1;  // one-launch velocity product, wall-bounded x and y: the tiles produce their x / y boundary cells, the shell is two planes
     int velocity_march_planes = 16;  // planes a workgroup of k_vel_march walks through
     int fuse_velocity_product = 1;  // 3-D: the three components' tiles and shells in one launch (velstencil.hip k_vel_product)
     int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR

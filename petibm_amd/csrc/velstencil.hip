@@ -120,10 +120,15 @@ __device__ __forceinline__ void vel_shell_part(const VelDev &V, int f, int all, 
     const int64_t nx = V.n[f][0], ny = V.n[f][1], nz = V.n[f][2];
     const bool three = V.dim == 3;
     const int64_t cx = 2 * ny * nz, cy = 2 * (nx - 2) * nz, cz = three ? 2 * (nx - 2) * (ny - 2) : 0;
-    const int64_t total = all ? nx * ny * nz : cx + cy + cz;
+    const int64_t total = all == 2 ? 2 * nx * ny : (all ? nx * ny * nz : cx + cy + cz);
     for (int64_t t = blk * 256 + threadIdx.x; t < total; t += nblk * 256) {
         int64_t i, j, k;
-        if (all) {
+        if (all == 2) {  // the first and the last plane, whole (contiguous): the tiles of the one-launch product own the x / y edges of the planes between
+            const int64_t q = t % (nx * ny);
+            i = q % nx;
+            j = q / nx;
+            k = t < nx * ny ? 0 : nz - 1;
+        } else if (all) {
             i = t % nx;
             j = (t / nx) % ny;
             k = t / (nx * ny);
@@ -340,11 +345,25 @@ __global__ __launch_bounds__(256) void k_vel_interior4(const Scalars *__restrict
 // of their seven reads (2.0 TB/s of algorithmic traffic at 256^3).  Same expressions in the same order as
 // k_vel_interior: bit-identical.  Components whose grid lines are a multiple of 128 points on a 32-byte boundary (every
 // component of a periodic box, the components across their own direction of a wall-bounded one); 3-D.
-constexpr int VX = 128, VY = 8, VSX = VX + 2, VSY = VY + 2;
+constexpr int VX = 128, VY = 8, VSX = VX + 4, VSY = VY + 2;
+// LDS column of cell t (-1 .. VX) of a tile row.  With four CONSECUTIVE cells per thread the plain layout t + 1 makes every
+// LDS access of a wave a stride of 32 bytes -- an 8-way bank conflict: SQ counters had the LDS pipe busy for the whole
+// kernel, 58 % of it conflicts (profiles/r03_velocity256_pmc_SQ.md).  Cells are therefore dealt to four groups of 33 columns
+// by t mod 4: the lanes of a wave (consecutive tx, the same c) then touch consecutive columns for the centre, the left and
+// the right neighbour alike.  Cells 32 apart per thread (the other form) are lane-consecutive in the plain layout already.
+template <bool V4>
+__device__ __forceinline__ int vcol(int t)
+{
+    return V4 ? (t & 3) * 33 + (t >> 2) + 1 : t + 1;
+}
 // V4: a thread's four cells are consecutive (aligned 32-byte accesses; grid lines a multiple of 128 points on a 32-byte
 // boundary).  Otherwise they are 32 cells apart (lane-consecutive 8-byte accesses, any line length and alignment: the
 // 255-point lines of a wall-bounded component along its own direction; the last tile of a line is partial).
-template <bool V4>
+// EDGES (wall-bounded x and y; the one-launch product): the tile also produces the rows of its cells on the component's x / y
+// boundaries -- the same sums with the missing neighbour left out and its ghost fold on the diagonal, in vel_row's order: the
+// bits the shell computes -- so that the shell workgroups only own the first and the last plane.  (The x faces of a shell are
+// one strided point per lane: 40 of the product's 240 us at 256^3.)
+template <bool V4, bool EDGES = false>
 __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const double *__restrict__ x, double *__restrict__ y, int MZ,
                                                int bx, int by, int bz, double (&sp)[2][VSY][VSX], double *acc = nullptr)
 {
@@ -356,22 +375,31 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
     const int64_t sy = nx, sz = (int64_t)nx * ny;
     const int j = j0 + ty;
     const int jc = min(j, ny - 1);  // a partial tile's rows / cells beyond the component are clamped for the loads, never stored
-    int ci[4], lx[4];               // global index (clamped) and LDS column of the thread's cells
+    int ci[4], lx[4], lxm[4], lxp[4];  // global index (clamped), LDS column of the thread's cells and of their x neighbours
     bool cin[4];                    // interior cell of the line
+    bool exm[4], exq[4], cok[4];    // EDGES: first / last cell of the line, a cell of the component at all
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int t = V4 ? 4 * tx + c : tx + 32 * c;
-        lx[c] = t + 1;
+        exm[c] = i0 + t == 0;
+        exq[c] = i0 + t == nx - 1;
+        cok[c] = i0 + t < nx;
+        lx[c] = vcol<V4>(t);
+        lxm[c] = vcol<V4>(t - 1);
+        lxp[c] = vcol<V4>(t + 1);
         cin[c] = i0 + t >= 1 && i0 + t <= nx - 2;
         ci[c] = min(i0 + t, nx - 1);
     }
     const int hy_row = (tid < 128) ? -1 : VY, hy_x = tid & 127;
     const int hx_col = (tid & 1) ? VX : -1, hx_y = (tid >> 1) & 7;
+    const int hy_lx = vcol<V4>(hy_x), hx_lx = vcol<V4>(hx_col);
     const int hyj = j0 + hy_row, hyi = i0 + hy_x, hxj = min(j0 + hx_y, ny - 1), hxi = i0 + hx_col;
     const bool hy_ok = hyj >= 0 && hyj < ny && hyi < nx, hx_ok = tid < 16 && hxi >= 0 && hxi < nx;
     const int64_t base = V.off[f];
     const int64_t row = base + (int64_t)jc * sy, off_hy = base + (int64_t)hyj * sy + hyi, off_hx = base + (int64_t)hxj * sy + hxi;
     const bool jin = j >= 1 && j <= ny - 2;
+    const bool eym = EDGES && j == 0, eyq = EDGES && j == ny - 1, jok = j < ny;
+    const double fxm = V.a0[f][0], fxq = V.a0[f][1], fym = V.a0[f][2], fyq = V.a0[f][3];
     const double yneg = V.lneg[f][1][jc], ypos = V.lpos[f][1][jc];
     double vn[4], vp[4], zm[4], xc[4], zp[4];
     const bool scaled = V.dinv != nullptr;
@@ -417,24 +445,38 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         }
     };
     double pc[4] = {0.0, 0.0, 0.0, 0.0}, pn[4] = {0.0, 0.0, 0.0, 0.0};
-    load4(x + (int64_t)(k0 - 1) * sz, k0 - 1, zm);
-    load4(x + (int64_t)k0 * sz, k0, xc);
-    if (acc != nullptr) loadp(k0, pc);
-    for (int k = k0; k < kend; ++k) {
-        const int slot = k & 1;
-        const double *px = x + (int64_t)k * sz;
-        load4(px + sz, k + 1, zp);
-        if (acc != nullptr && k + 1 < kend) loadp(k + 1, pn);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sp[slot][ty + 1][lx[c]] = xc[c];
-        double hyv = hy_ok ? px[off_hy] : 0.0, hxv = hx_ok ? px[off_hx] : 0.0;
+    // Every load of a step is consumed in the NEXT step: the plane two ahead (it becomes the upper neighbour), the halo cells
+    // and the fused sums' second factor of the plane one ahead.  Nothing a step issues is waited for in that step, so the
+    // loads stay in flight across the barrier (a load consumed in the step that issues it drains the in-order memory counter
+    // and with it every prefetch behind it: SQ counters had 77 % of the wave cycles waiting with < 3 memory instructions in
+    // flight per CU).
+    auto load_halo = [&](int kp, double &hyv, double &hxv) {
+        const double *pl = x + (int64_t)kp * sz;
+        hyv = hy_ok ? pl[off_hy] : 0.0;
+        hxv = hx_ok ? pl[off_hx] : 0.0;
         if (scaled) {
-            const double *pd = V.dinv + (int64_t)k * sz;
+            const double *pd = V.dinv + (int64_t)kp * sz;
             if (hy_ok) hyv = V.opc * (pd[off_hy] * hyv);
             if (hx_ok) hxv = V.opc * (pd[off_hx] * hxv);
         }
-        sp[slot][hy_row + 1][hy_x + 1] = hyv;
-        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hxv;
+    };
+    double zn[4] = {0.0, 0.0, 0.0, 0.0}, hyc, hxc, hyn = 0.0, hxn = 0.0;
+    load4(x + (int64_t)(k0 - 1) * sz, k0 - 1, zm);
+    load4(x + (int64_t)k0 * sz, k0, xc);
+    load_halo(k0, hyc, hxc);
+    load4(x + (int64_t)(k0 + 1) * sz, k0 + 1, zp);
+    if (acc != nullptr) loadp(k0, pc);
+    for (int k = k0; k < kend; ++k) {
+        const int slot = k & 1;
+        if (k + 1 < kend) {
+            load4(x + (int64_t)(k + 2) * sz, k + 2, zn);
+            load_halo(k + 1, hyn, hxn);
+            if (acc != nullptr) loadp(k + 1, pn);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sp[slot][ty + 1][lx[c]] = xc[c];
+        sp[slot][hy_row + 1][hy_lx] = hyc;
+        if (tid < 16) sp[slot][hx_y + 1][hx_lx] = hxc;
         __syncthreads();
         const double zneg = V.lneg[f][2][k], zpos = V.lpos[f][2][k];
         double out[4];
@@ -448,19 +490,34 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
             acc = acc + ypos;
             acc = acc + zneg;
             acc = acc + zpos;
-            const double diag = -acc;
+            double diag = -acc;
+            const bool em = EDGES && exm[c], eq = EDGES && exq[c];
+            if (EDGES) {  // a wall's ghost fold (vel_row: x-, x+, y-, y+; exact zeros are not added)
+                double t = xneg * fxm;
+                diag = (em && t != 0.0) ? diag + t : diag;
+                t = xpos * fxq;
+                diag = (eq && t != 0.0) ? diag + t : diag;
+                t = yneg * fym;
+                diag = (eym && t != 0.0) ? diag + t : diag;
+                t = ypos * fyq;
+                diag = (eyq && t != 0.0) ? diag + t : diag;
+            }
             const double dval = diag * V.scale + V.shift;
             double s2 = 0.0;
             s2 = s2 + (zneg * V.scale) * zm[c];
-            s2 = s2 + (yneg * V.scale) * sp[slot][ty][lx[c]];
-            s2 = s2 + (xneg * V.scale) * sp[slot][ty + 1][lx[c] - 1];
+            if (!eym) s2 = s2 + (yneg * V.scale) * sp[slot][ty][lx[c]];
+            if (!em) s2 = s2 + (xneg * V.scale) * sp[slot][ty + 1][lxm[c]];
             s2 = s2 + dval * xc[c];
-            s2 = s2 + (xpos * V.scale) * sp[slot][ty + 1][lx[c] + 1];
-            s2 = s2 + (ypos * V.scale) * sp[slot][ty + 2][lx[c]];
+            if (!eq) s2 = s2 + (xpos * V.scale) * sp[slot][ty + 1][lxp[c]];
+            if (!eyq) s2 = s2 + (ypos * V.scale) * sp[slot][ty + 2][lx[c]];
             s2 = s2 + (zpos * V.scale) * zp[c];
             out[c] = s2;
         }
-        if (jin && acc != nullptr) {  // the stored rows only (the shell owns the others)
+        if (EDGES) {  // every cell of the component in this tile is stored here
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cin[c] = cok[c];
+        }
+        if ((EDGES ? jok : jin) && acc != nullptr) {  // the stored rows only (the shell owns the others)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (cin[c]) {
@@ -468,7 +525,7 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
                     if (V.dot_mode == 2) acc[1] += out[c] * out[c];
                 }
         }
-        if (jin) {
+        if (EDGES ? jok : jin) {
             double *py = y + (int64_t)k * sz + row;
             if (V4 && cin[0] && cin[3]) {
                 v4 t;
@@ -485,8 +542,11 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         for (int c = 0; c < 4; ++c) {
             zm[c] = xc[c];
             xc[c] = zp[c];
+            zp[c] = zn[c];
             pc[c] = pn[c];
         }
+        hyc = hyn;
+        hxc = hxn;
     }
 }
 
@@ -504,6 +564,7 @@ __global__ __launch_bounds__(256) void k_vel_march(const Scalars *__restrict__ S
 // (one strided point per lane) are latency-bound.  Here the shell workgroups of all components come first in the grid and
 // the tiles follow, so the shells' loads are in flight while the tiles stream.  Same device functions, same bits.
 struct VelPlan {
+    int edges;          // wall-bounded x and y: the tiles produce their own boundary cells, the shell is the first and the last plane
     int first[7];       // first workgroup of: shell of component 0, 1, 2, tiles of component 0, 1, 2, end
     int gx[3], gy[3];   // tiles per plane of a component
     int v4[3];
@@ -519,13 +580,18 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
     double *pa = DOT ? acc : nullptr;
     if (b < P.first[3]) {
         const int f = (b >= P.first[1]) + (b >= P.first[2]);
-        vel_shell_part(V, f, 0, x, y, b - P.first[f], P.first[f + 1] - P.first[f], pa);
+        vel_shell_part(V, f, P.edges ? 2 : 0, x, y, b - P.first[f], P.first[f + 1] - P.first[f], pa);
     } else {
         const int f = (b >= P.first[4]) + (b >= P.first[5]);
         const int lb = b - P.first[3 + f];
         const int bx = lb % P.gx[f], by = (lb / P.gx[f]) % P.gy[f], bz = lb / (P.gx[f] * P.gy[f]);
-        if (P.v4[f]) vel_march_tile<true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
-        else vel_march_tile<false>(V, f, x, y, MZ, bx, by, bz, sp, pa);
+        if (P.edges) {
+            if (P.v4[f]) vel_march_tile<true, true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
+            else vel_march_tile<false, true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
+        } else {
+            if (P.v4[f]) vel_march_tile<true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
+            else vel_march_tile<false>(V, f, x, y, MZ, bx, by, bz, sp, pa);
+        }
     }
     if (DOT) {  // one partial per workgroup and sum, fixed order
         __shared__ double sh[2][4];
@@ -662,10 +728,11 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
     };
     if (h.dim == 3 && s->cfg.fuse_velocity_product && marches(0) && marches(1) && marches(2)) {
         VelPlan P;
+        P.edges = ((h.per & 3) == 0 && s->cfg.velocity_tile_edges) ? 1 : 0;
         int nb = 0;
         for (int f = 0; f < 3; ++f) {
             const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
-            const int64_t shell = 2 * (ny * nz + (nx - 2) * nz + (nx - 2) * (ny - 2));
+            const int64_t shell = P.edges ? 2 * nx * ny : 2 * (ny * nz + (nx - 2) * nz + (nx - 2) * (ny - 2));
             P.first[f] = nb;
             nb += (int)std::min<int64_t>(4096, (shell + 255) / 256);
         }
