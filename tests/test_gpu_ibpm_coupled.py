@@ -96,7 +96,7 @@ def test_errors_of_the_newer_engine_entries():
           "solv:norm=L2\nsolv:preconditioner(prec)=BLOCK_JACOBI\n")
     d = DecoupledIBPMSolver(cfg, bodies=[circle(24, r=0.4)], forces_cfg=it)       # an iterative forces solver ...
     assert lib.pib_ns_set_coupled(d._h, 1) == capi.ERR_SUP                         # ... has no explicit inverse to eliminate with
-    assert lib.pib_ns_set_bn_order(d._h, 2) == capi.ERR_SUP                        # BN > 1 with bodies
+    assert lib.pib_ns_set_bn_order(d._h, 2) == capi.ERR_ORDER                      # BN > 1 goes BEFORE the bodies (BNH = BN H is built from it)
     assert lib.pib_ns_set_time_integration(d._h, b"EULER_EXPLICIT", b"EULER_IMPLICIT") == capi.ERR_ORDER
     d.advance(2)                                                                   # the decoupled scheme still runs
     d.destroy()

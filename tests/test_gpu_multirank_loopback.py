@@ -298,8 +298,10 @@ def test_multirank_velocity_system(P, case):
     s1.assembleVelocity(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
     x1 = np.zeros(A.n_rows)
     s1.solve(x1, b)
-    # (BiCGStab's count moves by a few in ~90 with the order of its sums: the one-rank solve folds them into the product)
-    assert abs(res[0][2] - s1.getIters()) <= max(1, res[0][2] // (8 if nopc else 20)) and np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
+    # (BiCGStab's count moves with the order of its sums: the one-rank solve folds them into the product.  Without a
+    # preconditioner on this stretched mesh the tail is erratic -- tools/nopc_probe.py: 118 .. 138 iterations over 1 / 2 / 3
+    # ranks and the four forms of the product, the bit-exact CSR route alone 125 / 123 / 129 -- all to the same residual.)
+    assert abs(res[0][2] - s1.getIters()) <= max(1, res[0][2] // (5 if nopc else 20)) and np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
     s1.destroy()
 
 
