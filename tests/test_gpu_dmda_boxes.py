@@ -263,3 +263,54 @@ def test_dmda_boxes_across_processes(tmp_path, P, n, kind):
         assert all(bool(r["detected"]) for r in res)
         x, x1 = x - x.mean(), x1 - x1.mean()
     assert np.linalg.norm(x - x1) <= 1e-8 * np.linalg.norm(x1)
+
+
+def test_256_cubed_on_8_petsc_decide_boxes():
+    """BASELINE config 2's mesh on config 3's rank count, the way an unchanged PetIBM would hand it over: the 256^3 cavity
+    Poisson operator on the (2,2,2) boxes PETSC_DECIDE picks for 8 ranks, every rank's DMDA-ordered rows through
+    pib_set_csr_i32 only, the bench's solver file (multigrid-PCG V(2,2), rtol 1e-10), vectors resident in HBM.  Bars: the
+    structure is recovered on every rank, the single-rank iteration count (11), the residual contract recomputed with the box
+    CSR, and the per-solve budget: the slab solve's exchanges plus the three moves of b / x."""
+    import bench
+    from petibm_amd.linsolver import LinSolverHIP
+    P, n, dt = 8, 256, 1e-3
+    w = np.full(n, 1.0 / n)
+    A = oops.CSR.from_csr32(*clib.assemble_poisson32([n, n, n], [w, w, w], dt))
+
+    from types import SimpleNamespace
+    counts = np.array([[n - 1, n, n], [n, n - 1, n], [n, n, n - 1], [n, n, n], [n + 1] * 3])
+    L = dmda.dmda_layout(SimpleNamespace(dim=3, n=counts), P)
+    assert L.grid == (2, 2, 2)
+    lay = L.pressure
+    parts = [dmda.permuted_local_rows(A, lay.petsc_of_natural, lay.offsets, r)[0] for r in range(P)]
+    inv = np.empty(A.n_rows, dtype=np.int64)
+    inv[lay.petsc_of_natural] = np.arange(A.n_rows)
+    xs = bench.manufactured_solution(n, 0, n)
+    b_p = clib.spmv(A, xs)[inv]
+    cfg = bench.solver_config("gmg", 1e-10, 200, 0.9, 2, 2, "jacobi") + "\n"
+
+    def rank_fn(r, uid):
+        s = LinSolverHIP("poisson", config_text=cfg, rank=r, nranks=P, uid=uid, device=0)
+        r0, r1 = int(lay.offsets[r]), int(lay.offsets[r + 1])
+        loc = parts[r]
+        s.setMatrix(oops.CSR(loc.n_rows, loc.n_cols, loc.rowptr.astype(np.int32), loc.col.astype(np.int32), loc.val), row0=r0, n_global=A.n_rows)
+        st = s.gridStructure()
+        x_d, b_d, r_d = s.deviceVec(r1 - r0), s.deviceVec(r1 - r0), s.deviceVec(r1 - r0)
+        b_d.upload(np.ascontiguousarray(b_p[r0:r1]))
+        s.solve(x_d, b_d)
+        cnt = s.counters().copy()
+        s.matMult(x_d, r_d)
+        bl = b_d.download()
+        rl = bl - r_d.download()
+        out = s.getIters(), float(rl @ rl), float(bl @ bl), cnt, st
+        s.destroy()
+        return out
+
+    res = _run_ranks(P, rank_fn)
+    assert {q[0] for q in res} == {11}
+    assert np.sqrt(sum(q[1] for q in res) / sum(q[2] for q in res)) <= 1.5e-10
+    for q in res:
+        assert q[4] is not None and q[4]["detected"] and tuple(q[4]["n"]) == (n, n, n)
+        its, pc, exch = q[0], int(q[3][1]), int(q[3][3])
+        # (pc counts the enqueued V-cycles: a first solve over-enqueues a few guarded no-ops) the slab solve's exchanges + b in, x out
+        assert its + 1 <= pc <= its + 8 and exch <= 6 * pc + 2 + 2
