@@ -402,6 +402,9 @@ int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_avg);
  * [3]=halo exchanges (all-gathers included), [4]=host syncs, [5]=ranks of the communicator (ncclCommCount),
  * [6]=PCG iterations whose residual update ran inside the V-cycle's first kernel (pib_fuse_residual_update). */
 int pib_get_counters(pib_solver *s, int64_t counters[8]);
+/* Krylov iterations launched as replays of the captured iteration graph since the solver was created (launch-bound systems:
+ * pib_use_graph, pib_graph_max_rows; on several ranks with the device-ordered peer transport only). */
+int pib_get_graph_replays(pib_solver *s, int64_t *replays);
 
 #ifdef __cplusplus
 }

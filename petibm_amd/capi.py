@@ -42,6 +42,7 @@ _PROTOS = {
     "pib_comm_unique_id": (C.c_int, [_vp]),
     "pib_comm_peer_id": (C.c_int, [_vp]),
     "pib_comm_peer_id_ordered": (C.c_int, [_vp, C.c_int]),
+    "pib_get_graph_replays": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "pib_comm_latency": (C.c_int, [_vp, _i64, C.c_int, C.POINTER(C.c_double)]),
     "pib_comm_loopback_create": (C.c_int, [C.c_int, _vp]),
     "pib_comm_loopback_destroy": (C.c_int, [_vp]),

@@ -537,6 +537,13 @@ int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, 
     return 0;
 }
 
+int pib_get_graph_replays(pib_solver *s, int64_t *replays)
+{
+    if (s == nullptr || replays == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
+    *replays = s->graph_replays + (s->redist.active ? s->redist.inner->graph_replays : 0);
+    return 0;
+}
+
 int pib_get_counters(pib_solver *s, int64_t counters[8])
 {
     if (s == nullptr || counters == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");

@@ -210,8 +210,10 @@ struct LoopbackGroup {
     // enqueuing the kernels between the two collectives)
     std::vector<int> owed_by;
     uint64_t owed_seq = 0;
+    bool capturing = false;  // an iteration is being captured into a hipGraph: only the device-ordered collectives may run
     int begin(hipStream_t st, uint64_t *out)
     {
+        if (capturing) return fail(PIB_ERR_SUP, "peer transport: a host-ordered collective (a message larger than half a window?) inside a captured iteration");
         for (int q : owed_by) PIB_CHK(await(shm->done[q], owed_seq, "previous collective fetched", q));
         owed_by.clear();
         if (chained && chain_stream != st) PIB_HIP(hipStreamWaitEvent(st, chain, 0));
@@ -1552,6 +1554,25 @@ extern "C" int pib_comm_latency(pib_solver *s, int64_t count, int reps, double u
     }
     return 0;
 }
+
+namespace pib {
+// An iteration of a solver on several ranks can be captured into a hipGraph when its collectives are kernels and copies only
+// and carry nothing per call: the device-ordered peer transport (collective numbers are counted on the device).  RCCL's
+// calls capture in principle; they have never run on more than one rank here, so they are left out.
+bool comm_capturable(const pib_solver *s)
+{
+    return s->comm.nranks == 1 || (s->comm.loop != nullptr && s->comm.loop->shm != nullptr && s->comm.loop->devord);
+}
+// around the capture: the event that chains a rank's collectives across streams must not cross the capture's boundary
+// (an event recorded inside a capture cannot be waited for outside it and vice versa); all collectives of the iteration
+// body are issued on the capturing stream or on streams forked from and joined back to it
+void comm_capture_boundary(pib_solver *s, bool begin)
+{
+    if (s->comm.loop == nullptr || s->comm.loop->shm == nullptr) return;
+    s->comm.loop->capturing = begin;
+    s->comm.loop->chained = false;
+}
+}  // namespace pib
 
 // the id of a peer-transport world: a fresh shared-memory name; rank 0 makes it, every rank gets it (like the RCCL id)
 extern "C" int pib_comm_peer_id_ordered(void *uid_out, int device_ordered)

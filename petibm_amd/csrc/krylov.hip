@@ -572,7 +572,8 @@ static uint64_t graph_key(int method, const void *x, const void *b)
 template <class Body>
 static int run_iterations(pib_solver *s, int todo, int first_index, uint64_t key, hipStream_t q, Body body)
 {
-    const bool use = s->cfg.use_graph && s->comm.nranks == 1 && s->A.n <= s->cfg.graph_max_rows;
+    // (several ranks: when the transport's collectives can be captured -- the device-ordered peer transport, halo.hip)
+    const bool use = s->cfg.use_graph && comm_capturable(s) && s->A.n <= s->cfg.graph_max_rows;
     for (int it = 0; it < todo; ++it) {
         if (!use || first_index + it == 0) {
             PIB_CHK(body());
@@ -583,10 +584,15 @@ static int run_iterations(pib_solver *s, int todo, int first_index, uint64_t key
             s->graph = nullptr;
             int64_t before[8];
             for (int k = 0; k < 8; ++k) before[k] = s->counters[k];
+            if (s->comm.nranks > 1) {
+                PIB_HIP(hipStreamSynchronize(q));  // nothing of the collectives before is in flight on another stream
+                comm_capture_boundary(s, true);
+            }
             PIB_HIP(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
             const int err = body();
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(q, &g);
+            if (s->comm.nranks > 1) comm_capture_boundary(s, false);
             for (int k = 0; k < 8; ++k) {
                 s->graph_counts[k] = s->counters[k] - before[k];
                 s->counters[k] = before[k];
@@ -607,6 +613,7 @@ static int run_iterations(pib_solver *s, int todo, int first_index, uint64_t key
             s->graph_key = key;
         }
         PIB_HIP(hipGraphLaunch(s->graph, q));
+        s->graph_replays++;
         for (int k = 0; k < 8; ++k) s->counters[k] += s->graph_counts[k];
     }
     return 0;

@@ -362,6 +362,7 @@ struct pib_solver {
     int hist_cap = 0;
     hipGraphExec_t graph = nullptr;   // one Krylov iteration (krylov.hip: run_iterations)
     uint64_t graph_key = 0;           // the (method, x, b) it was captured for
+    int64_t graph_replays = 0;        // iterations launched as a graph replay since the solver was created
     int64_t graph_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // instrumentation counters one replay stands for
     pib_solver *reduce_via = nullptr;  // direct solve of a matrix whose entries every rank holds PARTIAL sums of (the force system of
                                        // immersed bodies on slabs): the dense matrix is summed over this solver's communicator first
@@ -408,6 +409,8 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
 // every rank's messages lie back to back (destination order) at `stream`; the message from rank q lands at recv[q]
 int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream, double *const *recv, hipStream_t st);
 void comm_release(pib_solver *s);
+bool comm_capturable(const pib_solver *s);
+void comm_capture_boundary(pib_solver *s, bool begin);
 // partition.cpp: rows in any partition (DMDA boxes, the per-rank-packed velocity ordering)
 int classify_partition(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64, const int64_t *cl64,
                        const int32_t *rp32, const int32_t *cl32, std::vector<int64_t> &ranges, bool *general);

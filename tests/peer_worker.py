@@ -24,7 +24,17 @@ def poisson(job, r):
     s.matMult(np.ascontiguousarray(job["xs"][pl.row0:pl.row0 + pl.n_local]), y)
     x = np.zeros(pl.n_local)
     s.solve(x, np.ascontiguousarray(job["b"][pl.row0:pl.row0 + pl.n_local]))
-    out = dict(y=y, x=x, its=s.getIters(), hist=np.asarray(s.getResidualHistory()), counters=np.asarray(s.counters()))
+    import ctypes
+    import time
+    rep = ctypes.c_int64(0)
+    capi.check(capi.load().pib_get_graph_replays(s._h, ctypes.byref(rep)))
+    t0 = time.perf_counter()
+    for _ in range(int(job.get("timed_solves", 0))):
+        x2 = np.zeros(pl.n_local)
+        s.solve(x2, np.ascontiguousarray(job["b"][pl.row0:pl.row0 + pl.n_local]))
+    dt = (time.perf_counter() - t0) / max(1, int(job.get("timed_solves", 0)))
+    out = dict(y=y, x=x, its=s.getIters(), hist=np.asarray(s.getResidualHistory()), counters=np.asarray(s.counters()),
+               graph_replays=rep.value, seconds_per_solve=dt)
     s.destroy()
     return out
 
