@@ -218,9 +218,13 @@ def test_box_halo_bytes_match_the_faces():
         assert int(cnt[7]) == 8 * faces * int(cnt[3]), (r, cnt)
 
 
-@pytest.mark.parametrize("P,n,kind", [(4, (16, 12, 12), "poisson"), (8, (16, 16, 16), "poisson"), (4, (10, 9, 8), "velocity"),
-                                      (8, (32, 24), "poisson")])
-def test_dmda_boxes_across_processes(tmp_path, P, n, kind):
+@pytest.mark.parametrize("P,n,kind,order,window_mb", [(4, (16, 12, 12), "poisson", None, None), (8, (16, 16, 16), "poisson", None, None),
+                                                      (4, (10, 9, 8), "velocity", None, None), (8, (32, 24), "poisson", None, None),
+                                                      # windows of 16384 doubles: the rows travel in several rounds (host-ordered
+                                                      # exchange: a window's worth of every rank's stream at a time), and the
+                                                      # device-ordered flavour falls back to that path for what does not fit a half
+                                                      (4, (24, 24, 24), "poisson", "host", "0.125"), (4, (24, 24, 24), "poisson", "device", "0.125")])
+def test_dmda_boxes_across_processes(tmp_path, monkeypatch, P, n, kind, order, window_mb):
     """The same through the peer transport: one PROCESS per rank (HIP-IPC windows), P = 4 and 8 on the one GPU -- the general
     exchange a window's worth at a time, the index lists and the rows travelling at set-up, b / x per solve."""
     from petibm_amd.linsolver import LinSolverHIP
@@ -247,7 +251,9 @@ def test_dmda_boxes_across_processes(tmp_path, P, n, kind):
     inv[new] = np.arange(A.n_rows)
     job = dict(kind="boxes", name=name, cfg=cfg, n_global=A.n_rows, offsets=offs, xs=xs[inv], b=b[inv],
                parts=[(p.rowptr, p.col, p.val) for p in parts])
-    res = run_ranks(str(tmp_path), job, P)
+    if window_mb:
+        monkeypatch.setenv("PIB_PEER_WINDOW_MB", window_mb)
+    res = run_ranks(str(tmp_path), job, P, order=order)
     assert np.array_equal(np.concatenate([r["y"] for r in res]), clib.spmv(Ap, xs[inv]))
     assert len({int(r["its"]) for r in res}) == 1 and all(int(r["reason"]) > 0 for r in res)
     assert all(int(r["counters"][5]) == P for r in res)
