@@ -227,6 +227,9 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
 {
     if (s == nullptr || n == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_grid_hint: null argument");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_set_grid_hint: set the matrix first");
+    if (s->A.general)
+        return fail(PIB_ERR_SUP, "pib_set_grid_hint: the hint describes the mesh in natural ordering and needs rows in z-slabs; these rows came "
+                                 "in another partition (DMDA boxes?) -- leave the hint out: pib_set_csr recovers the structure itself");
     PIB_HIP(hipSetDevice(s->device));
     const double one = 1.0;
     const double *w[3] = {wx, wy, (dim == 3) ? wz : &one};

@@ -95,6 +95,11 @@ def test_poisson_rows_in_dmda_boxes(P, n, grid, pinned, periodic, i32):
             loc = oops.CSR(loc.n_rows, loc.n_cols, loc.rowptr.astype(np.int32), loc.col.astype(np.int32), loc.val)
         s.setMatrix(loc, row0=r0, n_global=m.pN)
         st = s.gridStructure()
+        if r == 0:  # an explicit hint speaks of natural z-slabs: refused on boxes with a message that says what to do instead
+            wdt = [m.dL[3][d].true for d in range(m.dim)]
+            with pytest.raises(capi.PibError) as ei:
+                s.setGridHint(n, wdt, [dt / (0.5 * (q[1:] + q[:-1])) for q in wdt], capi.NULLSPACE_CONSTANT)
+            assert ei.value.code == capi.ERR_SUP and "leave the hint out" in str(ei.value)
         y = np.empty(r1 - r0)
         s.matMult(np.ascontiguousarray(xs_p[r0:r1]), y)
         rp, cl, vl = s.getCSR()
