@@ -197,6 +197,10 @@ static int set_csr_any(pib_solver *s, int64_t n_local, int64_t row0_global, int6
         if (s->cfg.pc == Precond::GMG && !s->redist.active)
             s->gmg_error = "the rows came in a partition that is neither z-slabs in natural ordering nor DMDA boxes of PetIBM's Poisson "
                            "operator: no mesh structure for the multigrid";
+        // the velocity system in slabs of the packed ordering (an unchanged PetIBM on two ranks, a (1,1,P) process grid): the
+        // matrix-free products as on one rank (structure.cpp); boxes keep their CSR products
+        if (s->cfg.pc != Precond::GMG && s->cfg.detect_structure && s->cfg.matrix_free_velocity)
+            PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
         return 0;
     }
     PIB_CHK(upload_csr(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));

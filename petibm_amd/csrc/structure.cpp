@@ -292,21 +292,12 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
 // ghost fold a0 with it, whatever the boundary type).  scale = 1, a0 = 0 in the recovered description; the product is
 // verified against the CSR SpMV on the device before it is used (1e-12), so anything that is not such an operator keeps
 // its CSR products.  One rank (the matrix-free product is a single-rank path).
-int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
-                              const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val)
+// sizes and periodic directions of the velocity system from the distinct |column - row| of u's first rows and the total
+// row count (`slab`: rows on several ranks -- only the in-range offsets were collected, the slab axis must not be periodic)
+static bool parse_velocity_sizes(const std::vector<int64_t> &S, int64_t n_global, bool slab, int *dim_out, int64_t n[3], bool per[3])
 {
-    if (s->comm.nranks != 1 || n_local != n_global || row0 != 0 || n_local < 27) return 0;
-    const HostCsr A{n_local, row0, n_global, rp64, cl64, rp32, cl32, val};
-    // ---- field u: the offsets of its first rows
-    std::set<int64_t> offs;
-    for (int64_t l = 0; l < std::min<int64_t>(n_local, 8); ++l)
-        for (int64_t p = A.RP(l); p < A.RP(l + 1); ++p) {
-            const int64_t d = std::llabs(A.CL(p) - l);
-            if (d > 0) offs.insert(d);
-        }
-    const std::vector<int64_t> S(offs.begin(), offs.end());
-    if (S.size() < 2 || S.size() > 6 || S[0] != 1) return 0;
-    bool per[3] = {false, false, false};
+    if (S.size() < 2 || S.size() > 6 || S[0] != 1) return false;
+    per[0] = per[1] = per[2] = false;
     int64_t nxu = 0;
     size_t q = 2;
     if (S.size() > 2 && S[2] == S[1] + 1) {
@@ -315,19 +306,21 @@ int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int6
         q = 3;
     } else
         nxu = S[1];
-    if (nxu < 3) return 0;
+    if (nxu < 3) return false;
     std::vector<int64_t> m;
     for (size_t t = q; t < S.size(); ++t) {
-        if (S[t] % nxu != 0) return 0;
+        if (S[t] % nxu != 0) return false;
         m.push_back(S[t] / nxu);
     }
     auto has = [&](int64_t v) { return std::find(m.begin(), m.end(), v) != m.end(); };
-    int64_t n[3] = {per[0] ? nxu : nxu + 1, 1, 1};
+    n[0] = per[0] ? nxu : nxu + 1;
+    n[1] = n[2] = 1;
     int dim = 0;
     // candidates for ny (u has ny points along y): 2-D when u's block is all there is besides v's
     for (int pass = 0; pass < 2 && dim == 0; ++pass) {
         if (pass == 0) {  // 2-D: offsets {ny - 1 (y periodic)} only; n_global = nxu ny + nx nyv
             for (int py = 0; py < 2 && dim == 0; ++py) {
+                if (slab && py) continue;  // 2-D slabs run along y
                 // n_global = nxu ny + nx (ny - (py ? 0 : 1))
                 const int64_t num = n_global + (py ? 0 : n[0]), den = nxu + n[0];
                 if (num % den != 0) continue;
@@ -344,6 +337,7 @@ int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int6
                 if (y < 3) continue;
                 for (int py = 0; py < 2 && dim == 0; ++py)
                     for (int pz = 0; pz < 2 && dim == 0; ++pz) {
+                        if (slab && pz) continue;
                         // n_global = nz [nxu y + nx (y - !py)] + nx y (nz - !pz)
                         const int64_t a = nxu * y + n[0] * (y - (py ? 0 : 1)) + n[0] * y;
                         const int64_t num = n_global + (pz ? 0 : n[0] * y);
@@ -363,7 +357,31 @@ int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int6
             }
         }
     }
-    if (dim == 0) return 0;
+    *dim_out = dim;
+    return dim != 0;
+}
+
+static int detect_velocity_structure_slabs(pib_solver *s, const HostCsr &A);
+
+int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
+                              const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val)
+{
+    const HostCsr A{n_local, row0, n_global, rp64, cl64, rp32, cl32, val};
+    if (s->comm.nranks > 1) return detect_velocity_structure_slabs(s, A);
+    if (n_local != n_global || row0 != 0 || n_local < 27) return 0;
+    // ---- field u: the offsets of its first rows
+    std::set<int64_t> offs;
+    for (int64_t l = 0; l < std::min<int64_t>(n_local, 8); ++l)
+        for (int64_t p = A.RP(l); p < A.RP(l + 1); ++p) {
+            const int64_t d = std::llabs(A.CL(p) - l);
+            if (d > 0) offs.insert(d);
+        }
+    bool per[3] = {false, false, false};
+    int64_t n[3] = {1, 1, 1};
+    int dim = 0;
+    if (!parse_velocity_sizes(std::vector<int64_t>(offs.begin(), offs.end()), n_global, false, &dim, n, per)) return 0;
+    const int64_t nxu = per[0] ? n[0] : n[0] - 1;
+    (void)nxu;
     // ---- field sizes and offsets
     int64_t fn[3][3], off[3] = {0, 0, 0};
     int64_t total = 0;
@@ -462,6 +480,302 @@ int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int6
         vel_stencil_release(s);
     } else
         s->vel_detected = true;
+    return 0;
+}
+
+// ---- the same on several ranks, rows in z-slabs (y-slabs in 2-D) of the DMComposite's packed ordering: every rank hands
+// over [u-slab | v-slab | w-slab] (an unchanged PetIBM on two ranks -- PETSC_DECIDE gives (1,1,2) on a cube --, or one
+// whose process grid was set to (1,1,P)).  Such rows come through the general halo plan (partition.cpp): the low ghost
+// pad holds the previous rank's last plane of u, v, w back to back, the high pad the next rank's first planes -- the layout
+// pib_assemble_velocity's segmented plan has, so the matrix-free product of velstencil.hip serves them as it serves the
+// rows assembled on the device.  Global sizes from u's first rows as on one rank; a field's planes on this rank from
+// walking its +z neighbours (the DMDA splits a component's planes on its own: nz - 1 planes of w over P ranks are not the
+// pressure split); the in-plane tables from rank 0's lines, the tables along the slab axis gathered from every rank's
+// planes; the walls' effective values from the diagonals as on one rank.  Every rank walks the same collectives; the
+// recovered product is compared with the CSR's on all ranks before it is used.  The slab axis must not be periodic.
+static int detect_velocity_structure_slabs(pib_solver *s, const HostCsr &A)
+{
+    const int P = s->comm.nranks, rank = s->comm.rank;
+    const int64_t n_local = A.n_local, row0 = A.row0;
+    bool ok = s->A.general && n_local >= 27;
+    int dim = 0;
+    int64_t n[3] = {1, 1, 1};
+    bool per[3] = {false, false, false};
+    auto in_range = [&](int64_t c) { return c >= row0 && c < row0 + n_local; };
+    auto has_col = [&](int64_t l, int64_t c) {
+        for (int64_t p = A.RP(l); p < A.RP(l + 1); ++p)
+            if (A.CL(p) == c) return true;
+        return false;
+    };
+    if (ok) {
+        std::set<int64_t> offs;
+        for (int64_t l = 0; l < std::min<int64_t>(n_local, 8); ++l)
+            for (int64_t p = A.RP(l); p < A.RP(l + 1); ++p) {
+                const int64_t c = A.CL(p);
+                if (in_range(c) && c != row0 + l) offs.insert(std::llabs(c - (row0 + l)));
+            }
+        ok = parse_velocity_sizes(std::vector<int64_t>(offs.begin(), offs.end()), A.n_global, true, &dim, n, per);
+    }
+    const int sd = ok ? dim - 1 : 0;
+    int64_t fn[3][3], pl[3] = {0, 0, 0}, cnt[3] = {0, 0, 0}, loff[4] = {0, 0, 0, 0};
+    for (int f = 0; f < 3; ++f)
+        for (int d = 0; d < 3; ++d) fn[f][d] = 1;
+    if (ok) {
+        for (int f = 0; f < dim && ok; ++f) {
+            for (int d = 0; d < dim; ++d) {
+                fn[f][d] = n[d] - ((d == f && !per[d]) ? 1 : 0);
+                ok = ok && fn[f][d] >= 3;
+            }
+            pl[f] = dim == 3 ? fn[f][0] * fn[f][1] : fn[f][0];
+        }
+        // planes of every field on this rank: walk the +slab-axis neighbour of the block's first point
+        for (int f = 0; f < dim && ok; ++f) {
+            int64_t l = loff[f];
+            ok = l < n_local;
+            cnt[f] = 1;
+            while (ok && l + pl[f] < n_local && has_col(l, row0 + l + pl[f])) {
+                l += pl[f];
+                ++cnt[f];
+            }
+            loff[f + 1] = loff[f] + pl[f] * cnt[f];
+        }
+        ok = ok && loff[dim] == n_local;
+    }
+    // ---- what every rank found
+    const size_t HL = 12;
+    std::vector<double> head = {ok ? 1.0 : 0.0, (double)dim, (double)n[0], (double)n[1], (double)n[2],
+                                (double)((per[0] ? 1 : 0) | (per[1] ? 2 : 0) | (per[2] ? 4 : 0)), (double)cnt[0], (double)cnt[1], (double)cnt[2],
+                                (double)row0, (double)n_local, 0.0},
+                        heads;
+    PIB_CHK(comm_allgather_host(s, head, heads));
+    auto H = [&](int q, int k) { return (int64_t)heads[HL * (size_t)q + (size_t)k]; };
+    for (int q = 0; q < P; ++q)
+        for (int k = 0; k < 6; ++k)
+            if (H(q, 0) != 1 || H(q, k) != H(0, k)) return 0;
+    dim = (int)H(0, 1);
+    // first plane of every field on every rank; the ranks' blocks must tile the fields and the row ranges
+    std::vector<int64_t> kb[3];
+    for (int f = 0; f < dim; ++f) {
+        kb[f].assign((size_t)P + 1, 0);
+        for (int q = 0; q < P; ++q) kb[f][(size_t)q + 1] = kb[f][(size_t)q] + H(q, 6 + f);
+        if (kb[f][(size_t)P] != fn[f][sd]) return 0;
+    }
+    {
+        int64_t expect = 0;
+        for (int q = 0; q < P; ++q) {
+            if (H(q, 9) != expect) return 0;
+            expect += H(q, 10);
+        }
+    }
+    // global column of point (i, j, k) of field f (k: index along the slab axis; 2-D: j is that index)
+    auto gcol = [&](int f, int64_t inplane, int64_t k) -> int64_t {
+        int q = (int)(std::upper_bound(kb[f].begin(), kb[f].end(), k) - kb[f].begin()) - 1;
+        if (q < 0 || q >= P) return -1;
+        int64_t o = H(q, 9);
+        for (int e = 0; e < f; ++e) o += pl[e] * H(q, 6 + e);
+        return o + (k - kb[f][(size_t)q]) * pl[f] + inplane;
+    };
+    bool found = true;
+    auto get = [&](int64_t row, int64_t col) {
+        double v = 0.0;
+        if (col < 0 || !A.entry(row, col, &v)) found = false;
+        return v;
+    };
+    // ---- this rank's lines.  Buffer: [status, shift, per field: in-plane tables (tn, tp per in-plane direction), slab-axis
+    // tables of the own planes (tn, tp, padded to the most planes a rank holds)]
+    int64_t maxcnt = 0, inlen = 0;
+    for (int f = 0; f < dim; ++f) {
+        for (int q = 0; q < P; ++q) maxcnt = std::max(maxcnt, H(q, 6 + f));
+        for (int d = 0; d < dim; ++d)
+            if (d != sd) inlen += 2 * fn[f][d];
+    }
+    const size_t L = 2 + (size_t)inlen + 2 * (size_t)dim * (size_t)maxcnt;
+    std::vector<double> mine(L, 0.0), all;
+    double shift = 0.0;
+    {
+        size_t w = 2;
+        // rank 0 finds the shift first (an interior point of u: plane 1)
+        if (rank == 0 && cnt[0] >= 2) {
+            const int64_t st0[3] = {1, fn[0][0], pl[0]};
+            int64_t inpl = 0;
+            for (int e = 0; e < sd; ++e) inpl += st0[e];
+            const int64_t b = gcol(0, inpl, 1);
+            double sum = 0.0;
+            for (int e = 0; e < sd; ++e) sum += get(b, b - st0[e]) + get(b, b + st0[e]);
+            sum += get(b, gcol(0, inpl, 0)) + get(b, gcol(0, inpl, 2));
+            shift = get(b, b) + sum;
+        }
+        mine[1] = shift;
+        for (int f = 0; f < dim; ++f) {
+            const int64_t st[3] = {1, fn[f][0], pl[f]};
+            const int64_t k_lo = kb[f][(size_t)rank], k_hi = k_lo + cnt[f];  // own planes
+            // a plane of this rank that is no global boundary plane (its slab-axis neighbours exist)
+            const int64_t kg = std::max<int64_t>(k_lo, 1);
+            const bool have_kg = kg < k_hi && kg <= fn[f][sd] - 2;
+            for (int d = 0; d < dim; ++d) {
+                if (d == sd) continue;
+                const int64_t nd = fn[f][d];
+                double *tn = &mine[w], *tp = tn + nd;
+                w += 2 * (size_t)nd;
+                if (!have_kg || rank != 0) continue;  // the in-plane tables are rank 0's (the same entries on every rank)
+                auto inplane_of = [&](int64_t sidx) {
+                    int64_t p = 0;
+                    for (int e = 0; e < sd; ++e) p += st[e] * (e == d ? sidx : 1);
+                    return p;
+                };
+                for (int64_t sidx = 0; sidx < nd; ++sidx) {
+                    const int64_t p = gcol(f, inplane_of(sidx), kg);
+                    const int64_t cm = sidx > 0 ? p - st[d] : (per[d] ? p + (nd - 1) * st[d] : -1);
+                    const int64_t cp = sidx < nd - 1 ? p + st[d] : (per[d] ? p - (nd - 1) * st[d] : -1);
+                    if (cm >= 0) tn[sidx] = get(p, cm);
+                    if (cp >= 0) tp[sidx] = get(p, cp);
+                }
+                for (int side = -1; side <= 1 && !per[d]; side += 2) {  // a wall's effective value from the boundary point's diagonal
+                    const int64_t sidx = side < 0 ? 0 : nd - 1, p = gcol(f, inplane_of(sidx), kg);
+                    double present = get(p, gcol(f, inplane_of(sidx), kg - 1)) + get(p, gcol(f, inplane_of(sidx), kg + 1));
+                    for (int e = 0; e < sd; ++e) {
+                        const int64_t se = e == d ? sidx : 1, ne = fn[f][e];
+                        if (se > 0 || per[e]) present += get(p, se > 0 ? p - st[e] : p + (ne - 1) * st[e]);
+                        if (se < ne - 1 || per[e]) present += get(p, se < ne - 1 ? p + st[e] : p - (ne - 1) * st[e]);
+                    }
+                    (side < 0 ? tn : tp)[sidx] = (shift - get(p, p)) - present;
+                }
+            }
+        }
+        // the slab-axis tables of the own planes (every rank): the line through the in-plane point (1[, 1])
+        for (int f = 0; f < dim; ++f) {
+            const int64_t st[3] = {1, fn[f][0], pl[f]};
+            int64_t inpl = 0;
+            for (int e = 0; e < sd; ++e) inpl += st[e];
+            double *tn = &mine[w], *tp = tn + maxcnt;
+            w += 2 * (size_t)maxcnt;
+            const int64_t k_lo = kb[f][(size_t)rank];
+            for (int64_t t = 0; t < cnt[f]; ++t) {
+                const int64_t k = k_lo + t, p = gcol(f, inpl, k);
+                if (k > 0) tn[t] = get(p, gcol(f, inpl, k - 1));
+                if (k < fn[f][sd] - 1) tp[t] = get(p, gcol(f, inpl, k + 1));
+            }
+        }
+        mine[0] = found ? 1.0 : -1.0;
+    }
+    PIB_CHK(comm_allgather_host(s, mine, all));
+    for (int q = 0; q < P; ++q)
+        if (all[L * (size_t)q] < 0.0) return 0;
+    shift = all[1];  // rank 0's
+    if (!std::isfinite(shift)) return 0;
+    // the walls of the slab axis: effective values from the boundary planes' diagonals, computed by their owners with the
+    // gathered shift and sent round in a second (small) gather
+    std::vector<double> ends(2 * (size_t)dim, 0.0), all_ends;
+    found = true;
+    for (int f = 0; f < dim; ++f) {
+        const int64_t st[3] = {1, fn[f][0], pl[f]};
+        int64_t inpl = 0;
+        for (int e = 0; e < sd; ++e) inpl += st[e];
+        const int64_t k_lo = kb[f][(size_t)rank], k_hi = k_lo + cnt[f];
+        for (int side = 0; side < 2; ++side) {
+            const int64_t k = side == 0 ? 0 : fn[f][sd] - 1;
+            if (k < k_lo || k >= k_hi) continue;
+            const int64_t p = gcol(f, inpl, k);
+            double present = side == 0 ? get(p, gcol(f, inpl, k + 1)) : get(p, gcol(f, inpl, k - 1));
+            for (int e = 0; e < sd; ++e) present += get(p, p - st[e]) + get(p, p + st[e]);
+            ends[2 * (size_t)f + (size_t)side] = (shift - get(p, p)) - present;
+        }
+    }
+    if (!found) ends[0] = std::nan("");
+    PIB_CHK(comm_allgather_host(s, ends, all_ends));
+    for (double v : all_ends)
+        if (std::isnan(v)) return 0;
+    // ---- assemble the global tables (identical on every rank) and build the slab description
+    VelStencil V;
+    V.dim = dim;
+    V.per = ((per[0] ? 1 : 0) | (per[1] ? 2 : 0) | (per[2] ? 4 : 0)) & ~(1 << sd);
+    V.scale = 1.0;
+    V.shift = shift;
+    V.slab_axis = sd;
+    V.has_lo = rank > 0;
+    V.has_hi = rank < P - 1;
+    const DeviceCsr &M = s->A;
+    int64_t glo = 0, ghi = 0;
+    {
+        size_t w0 = 2;
+        const double *r0 = &all[0];  // rank 0's buffer: the in-plane tables
+        std::vector<std::vector<double>> inpl_tabs;
+        for (int f = 0; f < dim; ++f)
+            for (int d = 0; d < dim; ++d) {
+                if (d == sd) continue;
+                const int64_t nd = fn[f][d];
+                inpl_tabs.emplace_back(r0 + w0, r0 + w0 + nd);
+                inpl_tabs.emplace_back(r0 + w0 + nd, r0 + w0 + 2 * nd);
+                w0 += 2 * (size_t)nd;
+            }
+        size_t it = 0;
+        for (int f = 0; f < dim; ++f) {
+            V.off[f] = loff[f];
+            for (int d = 0; d < 3; ++d) V.n[f][d] = fn[f][d];
+            V.n[f][sd] = cnt[f];
+            for (int qq = 0; qq < 6; ++qq) V.a0[f][qq] = 0.0;
+            V.pad_lo[f] = V.has_lo ? -M.ghost_lo + glo : 0;
+            V.pad_hi[f] = V.has_hi ? n_local + ghi : 0;
+            if (V.has_lo) glo += pl[f];
+            if (V.has_hi) ghi += pl[f];
+            for (int d = 0; d < dim; ++d) {
+                std::vector<double> tn, tp;
+                int64_t first = 0;
+                if (d != sd) {
+                    tn = inpl_tabs[it++];
+                    tp = inpl_tabs[it++];
+                } else {
+                    tn.assign((size_t)fn[f][sd], 0.0);
+                    tp.assign((size_t)fn[f][sd], 0.0);
+                    for (int q = 0; q < P; ++q) {
+                        const double *src = &all[L * (size_t)q + 2 + (size_t)inlen + 2 * (size_t)f * (size_t)maxcnt];
+                        for (int64_t t = 0; t < H(q, 6 + f); ++t) {
+                            tn[(size_t)(kb[f][(size_t)q] + t)] = src[t];
+                            tp[(size_t)(kb[f][(size_t)q] + t)] = src[maxcnt + t];
+                        }
+                    }
+                    for (int q = 0; q < P; ++q) {  // the two walls: whoever owns the plane has the value
+                        const double lo_v = all_ends[2 * (size_t)dim * (size_t)q + 2 * (size_t)f], hi_v = all_ends[2 * (size_t)dim * (size_t)q + 2 * (size_t)f + 1];
+                        if (kb[f][(size_t)q] == 0) tn[0] = lo_v;
+                        if (kb[f][(size_t)q + 1] == fn[f][sd]) tp[(size_t)fn[f][sd] - 1] = hi_v;
+                    }
+                    first = kb[f][(size_t)rank];
+                }
+                double *p1 = nullptr, *p2 = nullptr;
+                PIB_CHK(upload_vec(tn, &p1));
+                PIB_CHK(upload_vec(tp, &p2));
+                V.owned.push_back(p1);
+                V.owned.push_back(p2);
+                V.lneg[f][d] = p1 + first;
+                V.lpos[f][d] = p2 + first;
+            }
+        }
+    }
+    if ((V.has_lo && glo != M.ghost_lo) || (V.has_hi && ghi != M.ghost_hi) || (!V.has_lo && M.ghost_lo != 0) || (!V.has_hi && M.ghost_hi != 0)) {
+        for (double *p : V.owned) (void)hipFree(p);  // the ghost pads are not one plane of every field: not this layout
+        V.owned.clear();
+        V.valid = false;
+    } else
+        V.valid = true;
+    // every rank must agree before anything collective follows
+    std::vector<double> okv = {V.valid ? 1.0 : 0.0}, okall;
+    PIB_CHK(comm_allgather_host(s, okv, okall));
+    bool all_valid = true;
+    for (double v : okall) all_valid = all_valid && v == 1.0;
+    vel_stencil_release(s);
+    if (!all_valid) {
+        for (double *p : V.owned) (void)hipFree(p);
+        return 0;
+    }
+    s->vel = V;
+    // ---- the recovered product against the CSR's on every rank's rows (halo planes exchanged like a Krylov product's)
+    int err = vel_stencil_verify(s);
+    std::vector<double> vv = {(err == 0 && s->vel.valid) ? 1.0 : 0.0}, vall;
+    PIB_CHK(comm_allgather_host(s, vv, vall));
+    bool good = true;
+    for (double v : vall) good = good && v == 1.0;
+    if (!good) vel_stencil_release(s);
+    else s->vel_detected = true;
     return 0;
 }
 

@@ -658,13 +658,24 @@ int vel_stencil_verify(pib_solver *s)
     const int64_t n = s->A.n;
     double *buf = nullptr;
     unsigned long long *out = nullptr;
-    PIB_HIP(hipMalloc(&buf, sizeof(double) * 3 * (size_t)n));
-    PIB_HIP(hipMalloc(&out, 2 * sizeof(unsigned long long)));
-    double *x = buf, *y1 = buf + n, *y2 = buf + 2 * n;
     hipStream_t q = s->stream;
+    double *x, *y1, *y2;
+    if (s->comm.nranks > 1) {  // ghost-padded vectors, the neighbours' planes exchanged like a Krylov product's (collective)
+        PIB_CHK(ensure_work(s, 3));
+        x = s->vec(0);
+        y1 = s->vec(1);
+        y2 = s->vec(2);
+    } else {
+        PIB_HIP(hipMalloc(&buf, sizeof(double) * 3 * (size_t)n));
+        x = buf;
+        y1 = buf + n;
+        y2 = buf + 2 * n;
+    }
+    PIB_HIP(hipMalloc(&out, 2 * sizeof(unsigned long long)));
     PIB_HIP(hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), q));
     const unsigned nb = (unsigned)std::min<int64_t>(4096, (n + 255) / 256);
     hipLaunchKernelGGL(k_vel_verify_fill, dim3(nb), dim3(256), 0, q, n, x);
+    if (s->comm.nranks > 1) PIB_CHK(halo_exchange(s, x, q));
     int err = spmv_rows(s, x, y1, 0, n, nullptr, false, q);
     if (!err) err = vel_stencil_apply(s, x, y2, false, q);
     if (!err) {
@@ -679,7 +690,7 @@ int vel_stencil_verify(pib_solver *s)
             if (!(d <= 1e-12 * m) || !(m > 0.0)) s->vel.valid = false;
         }
     }
-    (void)hipFree(buf);
+    if (buf) (void)hipFree(buf);
     (void)hipFree(out);
     return err;
 }
