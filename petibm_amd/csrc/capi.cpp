@@ -199,8 +199,13 @@ static int set_csr_any(pib_solver *s, int64_t n_local, int64_t row0_global, int6
                            "operator: no mesh structure for the multigrid";
         // the velocity system in slabs of the packed ordering (an unchanged PetIBM on two ranks, a (1,1,P) process grid): the
         // matrix-free products as on one rank (structure.cpp); boxes keep their CSR products
-        if (s->cfg.pc != Precond::GMG && s->cfg.detect_structure && s->cfg.matrix_free_velocity)
+        if (s->cfg.pc != Precond::GMG && s->cfg.detect_structure && s->cfg.matrix_free_velocity) {
             PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
+            // ... and the velocity system in BOXES ([u box | v box | w box] per rank, PETSC_DECIDE from 4 ranks up): moved to
+            // packed slabs inside the backend, like the pressure rows for the multigrid (partition.cpp)
+            if (!s->vel.valid && s->cfg.redistribute_velocity)
+                PIB_CHK(redist_velocity_setup(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val, ranges));
+        }
         return 0;
     }
     PIB_CHK(upload_csr(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
@@ -282,6 +287,7 @@ int pib_get_multigrid_levels(pib_solver *s, int *nlevels, int64_t *n3, int max_l
 int pib_get_velocity_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int periodic[3], int *detected)
 {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_velocity_structure: null solver");
+    if (s->redist.active && s->redist.nf > 1) s = s->redist.inner;  // rows handed over in boxes: the structure lives in the slab solver
     const VelStencil &V = s->vel;
     if (has) *has = V.valid ? 1 : 0;
     if (detected) *detected = (V.valid && s->vel_detected) ? 1 : 0;

@@ -225,6 +225,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.fuse_velocity_product = std::atoi(d.get("default", "pib_fuse_velocity_product", "1").c_str());
     c.velocity_march_planes = std::atoi(d.get("default", "pib_velocity_march_planes", "16").c_str());
     c.velocity_tile_edges = std::atoi(d.get("default", "pib_velocity_tile_edges", "1").c_str());
+    c.redistribute_velocity = std::atoi(d.get("default", "pib_redistribute_velocity", "1").c_str());
     c.lean_bicgstab = std::atoi(d.get("default", "pib_lean_bicgstab", "1").c_str());
     c.blocked_reductions = std::atoi(d.get("default", "pib_blocked_reductions", "1").c_str());
     c.fuse_bicgstab_dots = std::atoi(d.get("default", "pib_fuse_bicgstab_dots", "1").c_str());
@@ -344,6 +345,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_fuse_velocity_product", v)) c.fuse_velocity_product = std::atoi(v.c_str());
     if (get("pib_velocity_march_planes", v)) c.velocity_march_planes = std::atoi(v.c_str());
     if (get("pib_velocity_tile_edges", v)) c.velocity_tile_edges = std::atoi(v.c_str());
+    if (get("pib_redistribute_velocity", v)) c.redistribute_velocity = std::atoi(v.c_str());
     if (get("pib_lean_bicgstab", v)) c.lean_bicgstab = std::atoi(v.c_str());
     if (get("pib_blocked_reductions", v)) c.blocked_reductions = std::atoi(v.c_str());
     if (get("pib_fuse_bicgstab_dots", v)) c.fuse_bicgstab_dots = std::atoi(v.c_str());

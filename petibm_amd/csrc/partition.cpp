@@ -218,9 +218,11 @@ void redist_release(pib_solver *s)
 {
     Redist &R = s->redist;
     if (R.inner) (void)pib_destroy(R.inner);
-    if (R.d_split) (void)hipFree(R.d_split);
-    if (R.d_src) (void)hipFree(R.d_src);
-    if (R.stage) (void)hipFree(R.stage);
+    for (int f = 0; f < 3; ++f) {
+        if (R.f[f].d_split) (void)hipFree(R.f[f].d_split);
+        if (R.f[f].d_src) (void)hipFree(R.f[f].d_src);
+        if (R.f[f].stage) (void)hipFree(R.f[f].stage);
+    }
     if (R.b_nat) (void)hipFree(R.b_nat);
     if (R.x_nat) (void)hipFree(R.x_nat);
     R = Redist();
@@ -343,7 +345,9 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
     }
     if (N[0] * N[1] * N[2] != n_global) return 0;
     Redist &R = s->redist;
-    R.box.assign(6 * (size_t)P, 0);
+    R.nf = 1;
+    RedistField &F = R.f[0];
+    F.box.assign(6 * (size_t)P, 0);
     {
         int64_t expect = 0;
         for (int q = 0; q < P; ++q) {
@@ -353,8 +357,8 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
                 if (H(q, 2 + d) != ext[d][(size_t)pc[d]]) return 0;
                 int64_t o = 0;
                 for (int c = 0; c < pc[d]; ++c) o += ext[d][(size_t)c];
-                R.box[6 * (size_t)q + d] = o;
-                R.box[6 * (size_t)q + 3 + d] = ext[d][(size_t)pc[d]];
+                F.box[6 * (size_t)q + d] = o;
+                F.box[6 * (size_t)q + 3 + d] = ext[d][(size_t)pc[d]];
                 cells *= ext[d][(size_t)pc[d]];
             }
             if (ranges[(size_t)q] != expect || ranges[(size_t)q + 1] - ranges[(size_t)q] != cells) return 0;
@@ -366,36 +370,36 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
         std::swap(N[1], N[2]);
         std::swap(g3[1], g3[2]);
         for (int q = 0; q < P; ++q) {
-            std::swap(R.box[6 * (size_t)q + 1], R.box[6 * (size_t)q + 2]);
-            std::swap(R.box[6 * (size_t)q + 4], R.box[6 * (size_t)q + 5]);
+            std::swap(F.box[6 * (size_t)q + 1], F.box[6 * (size_t)q + 2]);
+            std::swap(F.box[6 * (size_t)q + 4], F.box[6 * (size_t)q + 5]);
         }
     }
     R.dim = dim;
     for (int d = 0; d < 3; ++d) {
-        R.n[d] = N[d];
+        F.n[d] = N[d];
         R.grid[d] = g3[d];
     }
     const int64_t pl = N[0] * N[1];
-    slab_range(N[2], P, rank, &R.k0, &R.k1);
-    R.n_slab = (R.k1 - R.k0) * pl;
-    auto B = [&](int q, int k) { return R.box[6 * (size_t)q + (size_t)k]; };
+    slab_range(N[2], P, rank, &F.k0, &F.k1);
+    F.n_slab = (F.k1 - F.k0) * pl;
+    auto B = [&](int q, int k) { return F.box[6 * (size_t)q + (size_t)k]; };
     // rows (= vector entries) box s -> slab d
-    R.fwd.cnt.assign((size_t)P * P, 0);
-    R.bwd.cnt.assign((size_t)P * P, 0);
+    F.fwd.cnt.assign((size_t)P * P, 0);
+    F.bwd.cnt.assign((size_t)P * P, 0);
     for (int a = 0; a < P; ++a)
         for (int d = 0; d < P; ++d) {
             int64_t kb, ke;
             slab_range(N[2], P, d, &kb, &ke);
             const int64_t lo = std::max(kb, B(a, 2)), hi = std::min(ke, B(a, 2) + B(a, 5));
             const int64_t c = hi > lo ? (hi - lo) * B(a, 3) * B(a, 4) : 0;
-            R.fwd.cnt[(size_t)a * P + d] = c;
-            R.bwd.cnt[(size_t)d * P + a] = c;
+            F.fwd.cnt[(size_t)a * P + d] = c;
+            F.bwd.cnt[(size_t)d * P + a] = c;
         }
-    R.fwd.finish(P, rank);
-    R.bwd.finish(P, rank);
+    F.fwd.finish(P, rank);
+    F.bwd.finish(P, rank);
     // ---- the rows themselves: fixed-width records [length | W columns (natural numbering) | W values]
     const int64_t RW = 1 + 2 * W;
-    ExchangePlan rows = R.fwd;
+    ExchangePlan rows = F.fwd;
     for (auto &c : rows.cnt) c *= RW;
     rows.finish(P, rank);
     std::vector<double> rec((size_t)std::max<int64_t>(n_local * RW, 1), 0.0);
@@ -416,7 +420,7 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
     }
     (void)base;
     double *d_send = nullptr, *d_recv = nullptr;
-    const int64_t nrecv = R.n_slab * RW;
+    const int64_t nrecv = F.n_slab * RW;
     PIB_HIP(hipMalloc(&d_send, sizeof(double) * rec.size()));
     PIB_HIP(hipMalloc(&d_recv, sizeof(double) * (size_t)std::max<int64_t>(nrecv, 1)));
     PIB_HIP(hipMemcpyAsync(d_send, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, s->stream));
@@ -424,10 +428,10 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
     std::vector<double *> recv((size_t)P, nullptr);
     std::vector<int64_t> roff((size_t)P + 1, 0);
     for (int q = 0; q < P; ++q) {
-        roff[(size_t)q + 1] = roff[(size_t)q] + R.fwd.from(q);
+        roff[(size_t)q + 1] = roff[(size_t)q] + F.fwd.from(q);
         recv[(size_t)q] = d_recv + roff[(size_t)q] * RW;
     }
-    if (roff[(size_t)P] != R.n_slab) return fail(PIB_ERR_LIB, "set_csr: internal error (the boxes do not cover this rank's slab)");
+    if (roff[(size_t)P] != F.n_slab) return fail(PIB_ERR_LIB, "set_csr: internal error (the boxes do not cover this rank's slab)");
     PIB_CHK(comm_exchange_v(s, rows, d_send, recv.data(), s->stream));
     std::vector<double> got((size_t)std::max<int64_t>(nrecv, 1), 0.0);
     PIB_HIP(hipMemcpyAsync(got.data(), d_recv, sizeof(double) * got.size(), hipMemcpyDeviceToHost, s->stream));
@@ -437,19 +441,19 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
     rec.clear();
     rec.shrink_to_fit();
     // natural local row of record t of source q
-    std::vector<int64_t> rp((size_t)R.n_slab + 1, 0);
+    std::vector<int64_t> rp((size_t)F.n_slab + 1, 0);
     auto local_row = [&](int q, int64_t t) {
-        const int64_t x = B(q, 3), y = B(q, 4), kf = std::max(B(q, 2), R.k0);
+        const int64_t x = B(q, 3), y = B(q, 4), kf = std::max(B(q, 2), F.k0);
         const int64_t i = t % x, j = (t / x) % y, k = kf + t / (x * y);
-        return (B(q, 0) + i) + N[0] * ((B(q, 1) + j) + N[1] * (k - R.k0));
+        return (B(q, 0) + i) + N[0] * ((B(q, 1) + j) + N[1] * (k - F.k0));
     };
     for (int q = 0; q < P; ++q)
-        for (int64_t t = 0; t < R.fwd.from(q); ++t) rp[(size_t)local_row(q, t) + 1] = (int64_t)got[(size_t)((roff[(size_t)q] + t) * RW)];
-    for (int64_t l = 0; l < R.n_slab; ++l) rp[(size_t)l + 1] += rp[(size_t)l];
-    std::vector<int64_t> cl((size_t)std::max<int64_t>(rp[(size_t)R.n_slab], 1));
-    std::vector<double> vl((size_t)std::max<int64_t>(rp[(size_t)R.n_slab], 1));
+        for (int64_t t = 0; t < F.fwd.from(q); ++t) rp[(size_t)local_row(q, t) + 1] = (int64_t)got[(size_t)((roff[(size_t)q] + t) * RW)];
+    for (int64_t l = 0; l < F.n_slab; ++l) rp[(size_t)l + 1] += rp[(size_t)l];
+    std::vector<int64_t> cl((size_t)std::max<int64_t>(rp[(size_t)F.n_slab], 1));
+    std::vector<double> vl((size_t)std::max<int64_t>(rp[(size_t)F.n_slab], 1));
     for (int q = 0; q < P; ++q)
-        for (int64_t t = 0; t < R.fwd.from(q); ++t) {
+        for (int64_t t = 0; t < F.fwd.from(q); ++t) {
             const double *rr = &got[(size_t)((roff[(size_t)q] + t) * RW)];
             const int64_t l = local_row(q, t), len = (int64_t)rr[0];
             // by ascending natural column, as MatMPIAIJGetLocalMat would deliver the row on slabs
@@ -474,10 +478,308 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
     pib_solver *in = R.inner;
     in->cfg = s->cfg;
     for (int d = 0; d < 3; ++d) in->periodic[d] = in->periodic_user[d] = s->periodic_user[d];
-    PIB_CHK(upload_csr(in, R.n_slab, R.k0 * pl, n_global, rp.data(), cl.data(), nullptr, nullptr, vl.data()));
+    PIB_CHK(upload_csr(in, F.n_slab, F.k0 * pl, n_global, rp.data(), cl.data(), nullptr, nullptr, vl.data()));
     PIB_CHK(after_set_matrix(in));
-    PIB_CHK(detect_grid_structure(in, R.n_slab, R.k0 * pl, n_global, rp.data(), cl.data(), nullptr, nullptr, vl.data()));
+    PIB_CHK(detect_grid_structure(in, F.n_slab, F.k0 * pl, n_global, rp.data(), cl.data(), nullptr, nullptr, vl.data()));
     if (!in->has_grid) {  // not PetIBM's Poisson operator after all (the same verdict on every rank: the check is a global sum)
+        redist_release(s);
+        return 0;
+    }
+    PIB_CHK(redist_tables(s));
+    R.active = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ velocity boxes -> slabs
+// vSolver->setMatrix(A) of an unchanged PetIBM from 4 ranks up: every rank holds [u box | v box | w box], the boxes of the
+// three velocity DMDAs on the pressure grid's process grid (cartesianmesh.cpp:551-553, 741-779).  Rows and, per solve,
+// vectors are moved to the packed z-slabs [u slab | v slab | w slab] (each component's planes split over the ranks by the
+// DMDA's default rule), where the inner solver recovers the operator's structure from the entries
+// (structure.cpp: detect_velocity_structure_slabs) and runs the matrix-free products of velstencil.hip: 16 B/row and product
+// instead of the CSR's 104.  A field's box is read off by WALKING from its first point: +1 neighbours give xm, +xm
+// neighbours ym, +xm ym neighbours zm (a row's columns are points of its own component only, so the walk stops at the
+// box's end); the next field starts behind it.  The process grid comes from the owners across u's + faces as for the
+// pressure boxes.  Anything that does not fit leaves the solver on its general plan with CSR products.
+int redist_velocity_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64, const int64_t *cl64,
+                          const int32_t *rp32, const int32_t *cl32, const double *val, const std::vector<int64_t> &ranges)
+{
+    redist_release(s);
+    const int P = s->comm.nranks, rank = s->comm.rank;
+    const View A{n_local, row0, n_global, rp64, cl64, rp32, cl32};
+    auto has_col = [&](int64_t l, int64_t c) {
+        if (l < 0 || l >= n_local) return false;
+        for (int64_t p = A.RP(l); p < A.RP(l + 1); ++p)
+            if (A.CL(p) == c) return true;
+        return false;
+    };
+    // ---- this rank's boxes
+    bool ok = n_local >= 8;
+    int nf = 0;
+    int64_t bx[3][3] = {{1, 1, 1}, {1, 1, 1}, {1, 1, 1}}, boff[4] = {0, 0, 0, 0}, own[3] = {-1, -1, -1}, maxlen = 0;
+    for (int64_t l = 0; l < n_local; ++l) maxlen = std::max(maxlen, A.RP(l + 1) - A.RP(l));
+    while (ok && boff[nf] < n_local) {
+        if (nf == 3) {
+            ok = false;
+            break;
+        }
+        const int64_t l0 = boff[nf];
+        int64_t xm = 1, ym = 1, zm = 1;
+        while (l0 + xm < n_local && has_col(l0 + xm - 1, row0 + l0 + xm)) ++xm;
+        while (l0 + ym * xm < n_local && has_col(l0 + (ym - 1) * xm, row0 + l0 + ym * xm)) ++ym;
+        while (l0 + zm * xm * ym < n_local && has_col(l0 + (zm - 1) * xm * ym, row0 + l0 + zm * xm * ym)) ++zm;
+        bx[nf][0] = xm;
+        bx[nf][1] = ym;
+        bx[nf][2] = zm;
+        boff[nf + 1] = l0 + xm * ym * zm;
+        ok = xm >= 3 && ym >= 3 && boff[nf + 1] <= n_local;
+        ++nf;
+    }
+    ok = ok && (nf == 2 || nf == 3) && boff[nf] == n_local;
+    const int dim = nf;
+    for (int f = 0; f < nf && ok; ++f) ok = (dim == 2) ? bx[f][2] == 1 : bx[f][2] >= 3;
+    if (ok) {  // owners across u's + faces
+        const int64_t st[3] = {1, bx[0][0], bx[0][0] * bx[0][1]};
+        for (int d = 0; d < dim && ok; ++d) {
+            int64_t l = 0;
+            for (int e = 0; e < dim; ++e) l += st[e] * (e == d ? bx[0][e] - 1 : 1);
+            int found = 0;
+            for (int64_t p = A.RP(l); p < A.RP(l + 1); ++p) {
+                const int64_t c = A.CL(p);
+                if (c < 0 || c >= n_global) ok = false;
+                else if (!A.mine(c)) {
+                    own[d] = owner_of(ranges, c);
+                    ++found;
+                }
+            }
+            ok = ok && found <= 1;
+        }
+    }
+    std::vector<double> head = {ok ? 1.0 : 0.0, (double)dim, (double)own[0], (double)own[1], (double)own[2], (double)maxlen};
+    for (int f = 0; f < 3; ++f)
+        for (int d = 0; d < 3; ++d) head.push_back((double)bx[f][d]);
+    const size_t HL = head.size();
+    std::vector<double> heads;
+    PIB_CHK(comm_allgather_host(s, head, heads));
+    auto H = [&](int q, int k) { return (int64_t)heads[HL * (size_t)q + (size_t)k]; };
+    int64_t W = 0;
+    for (int q = 0; q < P; ++q) {
+        if (H(q, 0) != 1 || H(q, 1) != H(0, 1)) return 0;
+        W = std::max(W, H(q, 5));
+    }
+    int g3[3] = {1, 1, 1};
+    {
+        int cur = 0, stride = 1;
+        for (int d = 0; d < dim; ++d) {
+            cur = 0;
+            while (cur + stride < P && H(cur, 2 + d) == cur + stride) {
+                cur += stride;
+                ++g3[d];
+            }
+            stride *= g3[d];
+        }
+        if (g3[0] * g3[1] * g3[2] != P) return 0;
+    }
+    Redist &R = s->redist;
+    R.nf = nf;
+    R.dim = dim;
+    int64_t total = 0;
+    std::vector<int64_t> cells_of((size_t)P, 0);
+    for (int f = 0; f < nf; ++f) {
+        RedistField &F = R.f[f];
+        std::vector<int64_t> ext[3];
+        int64_t N[3] = {1, 1, 1};
+        for (int d = 0; d < 3; ++d) {
+            const int stride = d == 0 ? 1 : (d == 1 ? g3[0] : g3[0] * g3[1]);
+            for (int c = 0; c < g3[d]; ++c) ext[d].push_back(H(c * stride, 6 + 3 * f + d));
+            N[d] = 0;
+            for (int64_t e : ext[d]) N[d] += e;
+        }
+        F.box.assign(6 * (size_t)P, 0);
+        for (int q = 0; q < P; ++q) {
+            const int pc[3] = {q % g3[0], (q / g3[0]) % g3[1], q / (g3[0] * g3[1])};
+            int64_t cells = 1;
+            for (int d = 0; d < 3; ++d) {
+                if (H(q, 6 + 3 * f + d) != ext[d][(size_t)pc[d]]) {
+                    redist_release(s);
+                    return 0;
+                }
+                int64_t o = 0;
+                for (int c = 0; c < pc[d]; ++c) o += ext[d][(size_t)c];
+                F.box[6 * (size_t)q + d] = o;
+                F.box[6 * (size_t)q + 3 + d] = ext[d][(size_t)pc[d]];
+                cells *= ext[d][(size_t)pc[d]];
+            }
+            cells_of[(size_t)q] += cells;
+        }
+        for (int d = 0; d < 3; ++d) F.n[d] = N[d];
+        total += N[0] * N[1] * N[2];
+    }
+    bool fits = total == n_global;
+    for (int q = 0; q < P && fits; ++q) fits = ranges[(size_t)q + 1] - ranges[(size_t)q] == cells_of[(size_t)q];
+    if (!fits) {
+        redist_release(s);
+        return 0;
+    }
+    // internal layout: the slab axis last (2-D: (nx, ny) -> (nx, 1, ny), process grid (m, n) -> (m, 1, n))
+    if (dim == 2) {
+        std::swap(g3[1], g3[2]);
+        for (int f = 0; f < nf; ++f) {
+            RedistField &F = R.f[f];
+            std::swap(F.n[1], F.n[2]);
+            for (int q = 0; q < P; ++q) {
+                std::swap(F.box[6 * (size_t)q + 1], F.box[6 * (size_t)q + 2]);
+                std::swap(F.box[6 * (size_t)q + 4], F.box[6 * (size_t)q + 5]);
+            }
+        }
+    }
+    for (int d = 0; d < 3; ++d) R.grid[d] = g3[d];
+    // a field's block in every rank's box-ordered vector / slab-ordered vector; the slab split of every field: the DMDA's
+    // default rule on its own plane count
+    std::vector<int64_t> bofq[3], sofq[3], srow0((size_t)P + 1, 0);
+    for (int f = 0; f < nf; ++f) {
+        bofq[f].assign((size_t)P, 0);
+        sofq[f].assign((size_t)P, 0);
+    }
+    for (int q = 0; q < P; ++q) {
+        int64_t bo = 0, so = 0;
+        for (int f = 0; f < nf; ++f) {
+            const RedistField &F = R.f[f];
+            bofq[f][(size_t)q] = bo;
+            sofq[f][(size_t)q] = so;
+            bo += F.box[6 * (size_t)q + 3] * F.box[6 * (size_t)q + 4] * F.box[6 * (size_t)q + 5];
+            int64_t kb, ke;
+            slab_range(F.n[2], P, q, &kb, &ke);
+            so += (ke - kb) * F.n[0] * F.n[1];
+        }
+        srow0[(size_t)q + 1] = srow0[(size_t)q] + so;
+    }
+    R.n_slab = 0;
+    for (int f = 0; f < nf; ++f) {
+        RedistField &F = R.f[f];
+        slab_range(F.n[2], P, rank, &F.k0, &F.k1);
+        F.n_slab = (F.k1 - F.k0) * F.n[0] * F.n[1];
+        F.boff = bofq[f][(size_t)rank];
+        F.soff = sofq[f][(size_t)rank];
+        F.fwd.cnt.assign((size_t)P * P, 0);
+        F.bwd.cnt.assign((size_t)P * P, 0);
+        for (int a = 0; a < P; ++a)
+            for (int d = 0; d < P; ++d) {
+                int64_t kb, ke;
+                slab_range(F.n[2], P, d, &kb, &ke);
+                const int64_t zs = F.box[6 * (size_t)a + 2], zm = F.box[6 * (size_t)a + 5];
+                const int64_t lo = std::max(kb, zs), hi = std::min(ke, zs + zm);
+                const int64_t c = hi > lo ? (hi - lo) * F.box[6 * (size_t)a + 3] * F.box[6 * (size_t)a + 4] : 0;
+                F.fwd.cnt[(size_t)a * P + d] = c;
+                F.bwd.cnt[(size_t)d * P + a] = c;
+            }
+        F.fwd.finish(P, rank);
+        F.bwd.finish(P, rank);
+        R.n_slab += F.n_slab;
+    }
+    // the slab-packed global index of box-packed global column c
+    auto slab_index = [&](int64_t c) -> int64_t {
+        const int q = A.mine(c) ? rank : owner_of(ranges, c);
+        int64_t l = c - ranges[(size_t)q];
+        int f = nf - 1;
+        while (f > 0 && l < bofq[f][(size_t)q]) --f;
+        l -= bofq[f][(size_t)q];
+        const RedistField &F = R.f[f];
+        const int64_t x = F.box[6 * (size_t)q + 3], y = F.box[6 * (size_t)q + 4];
+        const int64_t I = F.box[6 * (size_t)q] + l % x, J = F.box[6 * (size_t)q + 1] + (l / x) % y, K = F.box[6 * (size_t)q + 2] + l / (x * y);
+        // owner of plane K of field f: the DMDA split is monotone, find it by its range
+        int d = (int)std::min<int64_t>(P - 1, K * P / std::max<int64_t>(F.n[2], 1));
+        for (;;) {
+            int64_t kb, ke;
+            slab_range(F.n[2], P, d, &kb, &ke);
+            if (K < kb) --d;
+            else if (K >= ke) ++d;
+            else return srow0[(size_t)d] + sofq[f][(size_t)d] + (K - kb) * F.n[0] * F.n[1] + J * F.n[0] + I;
+        }
+    };
+    // ---- the rows, field by field: fixed-width records [length | W columns (slab-packed numbering) | W values]
+    const int64_t RW = 1 + 2 * W;
+    std::vector<int64_t> rp((size_t)R.n_slab + 1, 0);
+    std::vector<std::vector<double>> got_f((size_t)nf);
+    std::vector<std::vector<int64_t>> roff_f((size_t)nf);
+    for (int f = 0; f < nf; ++f) {
+        RedistField &F = R.f[f];
+        ExchangePlan rows = F.fwd;
+        for (auto &c : rows.cnt) c *= RW;
+        rows.finish(P, rank);
+        const int64_t nb = F.box[6 * (size_t)rank + 3] * F.box[6 * (size_t)rank + 4] * F.box[6 * (size_t)rank + 5];
+        std::vector<double> rec((size_t)std::max<int64_t>(nb * RW, 1), 0.0);
+        for (int64_t t = 0; t < nb; ++t) {
+            const int64_t l = F.boff + t;
+            double *rr = &rec[(size_t)(t * RW)];
+            const int64_t a = A.RP(l), len = A.RP(l + 1) - a;
+            rr[0] = (double)len;
+            for (int64_t u = 0; u < len; ++u) {
+                rr[1 + u] = (double)slab_index(A.CL(a + u));
+                rr[1 + W + u] = val[a + u];
+            }
+        }
+        double *d_send = nullptr, *d_recv = nullptr;
+        const int64_t nrecv = F.n_slab * RW;
+        PIB_HIP(hipMalloc(&d_send, sizeof(double) * rec.size()));
+        PIB_HIP(hipMalloc(&d_recv, sizeof(double) * (size_t)std::max<int64_t>(nrecv, 1)));
+        PIB_HIP(hipMemcpyAsync(d_send, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, s->stream));
+        PIB_HIP(hipStreamSynchronize(s->stream));
+        std::vector<double *> recv((size_t)P, nullptr);
+        std::vector<int64_t> &roff = roff_f[(size_t)f];
+        roff.assign((size_t)P + 1, 0);
+        for (int q = 0; q < P; ++q) {
+            roff[(size_t)q + 1] = roff[(size_t)q] + F.fwd.from(q);
+            recv[(size_t)q] = d_recv + roff[(size_t)q] * RW;
+        }
+        if (roff[(size_t)P] != F.n_slab) return fail(PIB_ERR_LIB, "set_csr: internal error (the velocity boxes do not cover this rank's slab)");
+        PIB_CHK(comm_exchange_v(s, rows, d_send, recv.data(), s->stream));
+        got_f[(size_t)f].assign((size_t)std::max<int64_t>(nrecv, 1), 0.0);
+        PIB_HIP(hipMemcpyAsync(got_f[(size_t)f].data(), d_recv, sizeof(double) * got_f[(size_t)f].size(), hipMemcpyDeviceToHost, s->stream));
+        PIB_HIP(hipStreamSynchronize(s->stream));
+        PIB_HIP(hipFree(d_send));
+        PIB_HIP(hipFree(d_recv));
+    }
+    auto local_row = [&](int f, int q, int64_t t) {
+        const RedistField &F = R.f[f];
+        const int64_t x = F.box[6 * (size_t)q + 3], y = F.box[6 * (size_t)q + 4], kf = std::max(F.box[6 * (size_t)q + 2], F.k0);
+        const int64_t i = t % x, j = (t / x) % y, k = kf + t / (x * y);
+        return F.soff + (F.box[6 * (size_t)q] + i) + F.n[0] * ((F.box[6 * (size_t)q + 1] + j) + F.n[1] * (k - F.k0));
+    };
+    for (int f = 0; f < nf; ++f)
+        for (int q = 0; q < P; ++q)
+            for (int64_t t = 0; t < R.f[f].fwd.from(q); ++t)
+                rp[(size_t)local_row(f, q, t) + 1] = (int64_t)got_f[(size_t)f][(size_t)((roff_f[(size_t)f][(size_t)q] + t) * RW)];
+    for (int64_t l = 0; l < R.n_slab; ++l) rp[(size_t)l + 1] += rp[(size_t)l];
+    std::vector<int64_t> cl((size_t)std::max<int64_t>(rp[(size_t)R.n_slab], 1));
+    std::vector<double> vl((size_t)std::max<int64_t>(rp[(size_t)R.n_slab], 1));
+    for (int f = 0; f < nf; ++f)
+        for (int q = 0; q < P; ++q)
+            for (int64_t t = 0; t < R.f[f].fwd.from(q); ++t) {
+                const double *rr = &got_f[(size_t)f][(size_t)((roff_f[(size_t)f][(size_t)q] + t) * RW)];
+                const int64_t l = local_row(f, q, t), len = (int64_t)rr[0];
+                std::vector<std::pair<int64_t, double>> e((size_t)len);
+                for (int64_t u = 0; u < len; ++u) e[(size_t)u] = {(int64_t)rr[1 + u], rr[1 + W + u]};
+                std::sort(e.begin(), e.end(), [](const std::pair<int64_t, double> &a, const std::pair<int64_t, double> &b) { return a.first < b.first; });
+                for (int64_t u = 0; u < len; ++u) {
+                    cl[(size_t)(rp[(size_t)l] + u)] = e[(size_t)u].first;
+                    vl[(size_t)(rp[(size_t)l] + u)] = e[(size_t)u].second;
+                }
+            }
+    got_f.clear();
+    // ---- the inner solver on the packed slabs: general plan, structure recovered from the entries
+    PIB_CHK(create_sharing_comm(&R.inner, s->name.c_str(), s->cfg.raw.c_str(), s));
+    pib_solver *in = R.inner;
+    in->cfg = s->cfg;
+    const int64_t in_row0 = srow0[(size_t)rank];
+    std::vector<int64_t> in_ranges;
+    bool in_general = false;
+    PIB_CHK(classify_partition(in, R.n_slab, in_row0, n_global, rp.data(), cl.data(), nullptr, nullptr, in_ranges, &in_general));
+    if (in_general) {
+        PIB_CHK(upload_csr_general(in, R.n_slab, in_row0, n_global, rp.data(), cl.data(), nullptr, nullptr, vl.data(), in_ranges));
+        PIB_CHK(after_set_matrix(in));
+        PIB_CHK(detect_velocity_structure(in, R.n_slab, in_row0, n_global, rp.data(), cl.data(), nullptr, nullptr, vl.data()));
+    }
+    if (!in_general || !in->vel.valid) {  // not PetIBM's velocity operator after all (the same verdict on every rank)
         redist_release(s);
         return 0;
     }

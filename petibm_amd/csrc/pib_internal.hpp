@@ -102,6 +102,7 @@ struct Config {
     int march_restrict = 1;  // multigrid: restriction of a fully paired 3-D level by the z-marching LDS kernel (gmg.hip k_restrict_march)
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
+    int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
     int deep_halo = 1;       // multi-GPU multigrid: exchange several ghost planes at once and recompute the ghost cells (gmg.hip); 0: one plane per stencil kernel
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
@@ -287,19 +288,26 @@ struct MeshWindow {
 // Rows handed over in DMDA boxes (PETSc ordering) and a multigrid preconditioner asked for: the rows, and every solve's
 // b and x, are moved once / per solve to the z-slabs in natural ordering the geometric multigrid works on, inside an
 // inner solver that shares this one's communicator (partition.cpp, redistribute.hip).
+struct RedistField {
+    int64_t n[3] = {1, 1, 1};       // points of the field, internal layout (a 2-D grid is (nx, 1, ny): the slab axis is always the last)
+    std::vector<int64_t> box;       // [P][6]: xs, ys, zs, xm, ym, zm of every rank
+    pib::ExchangePlan fwd, bwd;     // boxes -> slabs (b, the guess), slabs -> boxes (x)
+    int64_t k0 = 0, k1 = 0;         // this rank's planes of the field
+    int32_t *d_split = nullptr;     // device: x / y / z box boundaries (m + 1, n + 1, p + 1 entries back to back)
+    int64_t *d_src = nullptr;       // device [P][2]: offset of rank q's chunk in the staging vector, first plane of the chunk
+    double *stage = nullptr;        // device [n_slab]
+    int64_t n_slab = 0;
+    int64_t boff = 0, soff = 0;     // the field's block in this rank's box-ordered / slab-ordered vector
+};
 struct Redist {
     bool active = false;
     pib_solver *inner = nullptr;
     int dim = 0;
-    int64_t n[3] = {1, 1, 1};       // cells, internal layout (a 2-D grid is (nx, 1, ny): the slab axis is always the last)
-    int grid[3] = {1, 1, 1};        // process grid (m, n, p) in the same layout
-    std::vector<int64_t> box;       // [P][6]: xs, ys, zs, xm, ym, zm of every rank
-    pib::ExchangePlan fwd, bwd;     // boxes -> slabs (b, the guess), slabs -> boxes (x)
-    int64_t k0 = 0, k1 = 0;         // this rank's slab
-    int32_t *d_split = nullptr;     // device: x / y / z box boundaries (m + 1, n + 1, p + 1 entries back to back)
-    int64_t *d_src = nullptr;       // device [P][2]: offset of rank q's chunk in the staging vector, first plane of the chunk
-    double *stage = nullptr, *b_nat = nullptr, *x_nat = nullptr;  // device [slab rows]
-    int64_t n_slab = 0;
+    int grid[3] = {1, 1, 1};        // process grid (m, n, p), internal layout
+    int nf = 0;                     // 1: the pressure system; dim: the velocity system (per rank [u box | v box | w box] <-> [u slab | v slab | w slab])
+    RedistField f[3];
+    double *b_nat = nullptr, *x_nat = nullptr;  // device [slab rows]
+    int64_t n_slab = 0;             // slab rows of all fields
 };
 
 struct pib_solver {
@@ -418,6 +426,8 @@ int upload_csr_general(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_g
                        const int32_t *rp32, const int32_t *cl32, const double *val, const std::vector<int64_t> &ranges);
 int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64, const int64_t *cl64,
                  const int32_t *rp32, const int32_t *cl32, const double *val, const std::vector<int64_t> &ranges);
+int redist_velocity_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64, const int64_t *cl64,
+                          const int32_t *rp32, const int32_t *cl32, const double *val, const std::vector<int64_t> &ranges);
 void redist_release(pib_solver *s);
 // redistribute.hip
 int halo_exchange_general(pib_solver *s, double *x_owned, hipStream_t st);

@@ -68,50 +68,60 @@ int redist_tables(pib_solver *s)
     Redist &R = s->redist;
     const int P = s->comm.nranks;
     if (P > PIB_MAX_RANKS) return fail(PIB_ERR_SUP, "box -> slab redistribution: at most %d ranks", PIB_MAX_RANKS);
-    std::vector<int32_t> split;
-    for (int d = 0; d < 3; ++d) {
-        const int stride = d == 0 ? 1 : (d == 1 ? R.grid[0] : R.grid[0] * R.grid[1]);
-        for (int c = 0; c < R.grid[d]; ++c) split.push_back((int32_t)R.box[6 * (size_t)(c * stride) + (size_t)d]);
-        split.push_back((int32_t)R.n[d]);
+    R.n_slab = 0;
+    for (int f = 0; f < R.nf; ++f) {
+        RedistField &F = R.f[f];
+        std::vector<int32_t> split;
+        for (int d = 0; d < 3; ++d) {
+            const int stride = d == 0 ? 1 : (d == 1 ? R.grid[0] : R.grid[0] * R.grid[1]);
+            for (int c = 0; c < R.grid[d]; ++c) split.push_back((int32_t)F.box[6 * (size_t)(c * stride) + (size_t)d]);
+            split.push_back((int32_t)F.n[d]);
+        }
+        std::vector<int64_t> src(2 * (size_t)P, 0);
+        int64_t off = 0;
+        for (int q = 0; q < P; ++q) {
+            src[2 * (size_t)q] = off;
+            src[2 * (size_t)q + 1] = std::max(F.box[6 * (size_t)q + 2], F.k0);
+            off += F.fwd.from(q);
+        }
+        PIB_HIP(hipMalloc(&F.d_split, sizeof(int32_t) * split.size()));
+        PIB_HIP(hipMalloc(&F.d_src, sizeof(int64_t) * src.size()));
+        PIB_HIP(hipMemcpy(F.d_split, split.data(), sizeof(int32_t) * split.size(), hipMemcpyHostToDevice));
+        PIB_HIP(hipMemcpy(F.d_src, src.data(), sizeof(int64_t) * src.size(), hipMemcpyHostToDevice));
+        const size_t fb = sizeof(double) * (size_t)std::max<int64_t>(F.n_slab, 1);
+        PIB_HIP(hipMalloc(&F.stage, fb));
+        PIB_MEMSET(F.stage, 0, fb);
+        R.n_slab += F.n_slab;
     }
-    std::vector<int64_t> src(2 * (size_t)P, 0);
-    int64_t off = 0;
-    for (int q = 0; q < P; ++q) {
-        src[2 * (size_t)q] = off;
-        src[2 * (size_t)q + 1] = std::max(R.box[6 * (size_t)q + 2], R.k0);
-        off += R.fwd.from(q);
-    }
-    PIB_HIP(hipMalloc(&R.d_split, sizeof(int32_t) * split.size()));
-    PIB_HIP(hipMalloc(&R.d_src, sizeof(int64_t) * src.size()));
-    PIB_HIP(hipMemcpy(R.d_split, split.data(), sizeof(int32_t) * split.size(), hipMemcpyHostToDevice));
-    PIB_HIP(hipMemcpy(R.d_src, src.data(), sizeof(int64_t) * src.size(), hipMemcpyHostToDevice));
     const size_t bytes = sizeof(double) * (size_t)std::max<int64_t>(R.n_slab, 1);
-    PIB_HIP(hipMalloc(&R.stage, bytes));
     PIB_HIP(hipMalloc(&R.b_nat, bytes));
     PIB_HIP(hipMalloc(&R.x_nat, bytes));
-    PIB_MEMSET(R.stage, 0, bytes);
     PIB_MEMSET(R.b_nat, 0, bytes);
     PIB_MEMSET(R.x_nat, 0, bytes);
     return 0;
 }
 
-// v_box: this rank's entries in box order -> v_nat: its slab in natural order
+// v_box: this rank's entries in box order ([u box | v box | w box] for the velocity system) -> v_nat: its slabs in natural
+// order ([u slab | v slab | w slab]); one exchange per field
 int redist_forward(pib_solver *s, const double *v_box, double *v_nat, hipStream_t st)
 {
     Redist &R = s->redist;
     const int P = s->comm.nranks;
-    double *recv[PIB_MAX_RANKS];
-    int64_t off = 0;
-    for (int q = 0; q < P; ++q) {
-        recv[q] = R.stage + off;
-        off += R.fwd.from(q);
-    }
-    PIB_CHK(comm_exchange_v(s, R.fwd, v_box, recv, st));
-    if (R.n_slab > 0) {
-        const int nb = (int)std::min<int64_t>(4096, (R.n_slab + 255) / 256);
-        hipLaunchKernelGGL(k_redist<true>, dim3(nb), dim3(256), 0, st, v_nat, R.stage, R.n_slab, R.n[0], R.n[1], R.k0, R.grid[0], R.grid[1],
-                           R.grid[2], R.d_split, R.d_src);
-        PIB_HIP(hipGetLastError());
+    for (int f = 0; f < R.nf; ++f) {
+        RedistField &F = R.f[f];
+        double *recv[PIB_MAX_RANKS];
+        int64_t off = 0;
+        for (int q = 0; q < P; ++q) {
+            recv[q] = F.stage + off;
+            off += F.fwd.from(q);
+        }
+        PIB_CHK(comm_exchange_v(s, F.fwd, v_box + F.boff, recv, st));
+        if (F.n_slab > 0) {
+            const int nb = (int)std::min<int64_t>(4096, (F.n_slab + 255) / 256);
+            hipLaunchKernelGGL(k_redist<true>, dim3(nb), dim3(256), 0, st, v_nat + F.soff, F.stage, F.n_slab, F.n[0], F.n[1], F.k0, R.grid[0], R.grid[1],
+                               R.grid[2], F.d_split, F.d_src);
+            PIB_HIP(hipGetLastError());
+        }
     }
     return 0;
 }
@@ -120,15 +130,19 @@ int redist_backward(pib_solver *s, const double *v_nat, double *v_box, hipStream
 {
     Redist &R = s->redist;
     const int P = s->comm.nranks;
-    if (R.n_slab > 0) {
-        const int nb = (int)std::min<int64_t>(4096, (R.n_slab + 255) / 256);
-        hipLaunchKernelGGL(k_redist<false>, dim3(nb), dim3(256), 0, st, const_cast<double *>(v_nat), R.stage, R.n_slab, R.n[0], R.n[1], R.k0,
-                           R.grid[0], R.grid[1], R.grid[2], R.d_split, R.d_src);
-        PIB_HIP(hipGetLastError());
+    for (int f = 0; f < R.nf; ++f) {
+        RedistField &F = R.f[f];
+        if (F.n_slab > 0) {
+            const int nb = (int)std::min<int64_t>(4096, (F.n_slab + 255) / 256);
+            hipLaunchKernelGGL(k_redist<false>, dim3(nb), dim3(256), 0, st, const_cast<double *>(v_nat) + F.soff, F.stage, F.n_slab, F.n[0], F.n[1], F.k0,
+                               R.grid[0], R.grid[1], R.grid[2], F.d_split, F.d_src);
+            PIB_HIP(hipGetLastError());
+        }
+        double *recv[PIB_MAX_RANKS];
+        for (int q = 0; q < P; ++q) recv[q] = v_box + F.boff + F.fwd.send_off[(size_t)q];
+        PIB_CHK(comm_exchange_v(s, F.bwd, F.stage, recv, st));
     }
-    double *recv[PIB_MAX_RANKS];
-    for (int q = 0; q < P; ++q) recv[q] = v_box + R.fwd.send_off[(size_t)q];
-    return comm_exchange_v(s, R.bwd, R.stage, recv, st);
+    return 0;
 }
 
 }  // namespace pib

@@ -291,7 +291,7 @@ int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
 // missing neighbour (a wall) contributes an effective value read off the diagonal of one boundary point (it carries the
 // ghost fold a0 with it, whatever the boundary type).  scale = 1, a0 = 0 in the recovered description; the product is
 // verified against the CSR SpMV on the device before it is used (1e-12), so anything that is not such an operator keeps
-// its CSR products.  One rank (the matrix-free product is a single-rank path).
+// its CSR products.  One rank here; rows in packed z-slabs on several ranks: detect_velocity_structure_slabs below.
 // sizes and periodic directions of the velocity system from the distinct |column - row| of u's first rows and the total
 // row count (`slab`: rows on several ranks -- only the in-range offsets were collected, the slab axis must not be periodic)
 static bool parse_velocity_sizes(const std::vector<int64_t> &S, int64_t n_global, bool slab, int *dim_out, int64_t n[3], bool per[3])

@@ -107,6 +107,47 @@ def main():
                   f"iterations {sorted(its)}   exchanges {ex}   sent {sent / 1e6:.2f} MB per solve ({sent / max(ex, 1) / 1e3:.1f} kB per exchange, "
                   f"{prod} products)", flush=True)
         print(f"  boxes: true relative residual {rel:.3e}; structure {box[0]['st']}", flush=True)
+    velocity_part(int(sys.argv[3]) if len(sys.argv) > 3 else 128, P)
+
+
+def velocity_part(n, P):
+    """vSolver->setMatrix(A): per rank [u box | v box | w box]; moved to packed z-slabs for the matrix-free products
+    (default) against CSR products with the general packed halo plan on the boxes (pib_redistribute_velocity=0)."""
+    from oracle import mesh as omesh
+    dt, cnu = 1e-3, 0.5e-3
+    t0 = time.perf_counter()
+    m = omesh.create_mesh(omesh.uniform_config((n, n, n)))
+    V = oops.create_velocity_operator(oops.create_laplacian(m), dt, cnu)
+    L = dmda.dmda_layout(m, P)
+    parts = [dmda.permuted_local_rows(V, L.packed_of_natural, L.packed_offsets, r)[0] for r in range(P)]
+    inv = np.empty(m.UN, dtype=np.int64)
+    inv[L.packed_of_natural] = np.arange(m.UN)
+    b_p = clib.spmv(V, np.random.default_rng(3).uniform(-1, 1, m.UN))[inv]
+    print(f"# velocity system {n}^3 ({m.UN} rows) on {P} ranks, process grid {L.grid}; host preparation {time.perf_counter() - t0:.1f} s", flush=True)
+    base = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+            "solv:tolerance=1e-10\nsolv:norm=L2\nsolv:preconditioner(prec)=BLOCK_JACOBI\nprec:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n")
+    for extra, label in (("", "boxes -> packed slabs, matrix-free"), ("pib_redistribute_velocity=0\n", "boxes, CSR products")):
+        def rank_fn(r, uid):
+            s = LinSolverHIP("velocity", config_text=base + extra, rank=r, nranks=P, uid=uid, device=0)
+            r0, r1 = int(L.packed_offsets[r]), int(L.packed_offsets[r + 1])
+            loc = parts[r]
+            t = time.perf_counter()
+            s.setMatrix(oops.CSR(loc.n_rows, loc.n_cols, loc.rowptr.astype(np.int32), loc.col.astype(np.int32), loc.val), row0=r0, n_global=m.UN)
+            t_set = time.perf_counter() - t
+            x_d, b_d = s.deviceVec(r1 - r0), s.deviceVec(r1 - r0)
+            b_d.upload(np.ascontiguousarray(b_p[r0:r1]))
+            s.solve(x_d, b_d)
+            s.synchronize()
+            t = time.perf_counter()
+            s.solve(x_d, b_d)
+            s.synchronize()
+            out = dict(t_set=t_set, t_solve=time.perf_counter() - t, its=s.getIters(), cnt=s.counters().copy(), sv=s.velocityStructure())
+            s.destroy()
+            return out
+        res = _run_ranks(P, rank_fn)
+        print(f"  {label:38s} setMatrix {max(q['t_set'] for q in res):6.2f} s   solve {1e3 * max(q['t_solve'] for q in res):8.1f} ms   iterations "
+              f"{sorted({q['its'] for q in res})}   sent {max(int(q['cnt'][7]) for q in res) / 1e6:.2f} MB per solve   structure "
+              f"{'recovered' if res[0]['sv'] else 'none'}", flush=True)
 
 
 if __name__ == "__main__":
