@@ -41,6 +41,14 @@ inline int owner_of(const std::vector<int64_t> &ranges, int64_t c)
 {
     return (int)(std::upper_bound(ranges.begin(), ranges.end(), c) - ranges.begin()) - 1;
 }
+// a scratch device buffer of the set-up paths: released on every exit, the error ones included
+struct DevScratch {
+    double *p = nullptr;
+    ~DevScratch()
+    {
+        if (p) (void)hipFree(p);
+    }
+};
 // sorted distinct off-rank columns
 std::vector<int64_t> ghost_columns(const View &A)
 {
@@ -183,9 +191,10 @@ int upload_csr_general(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_g
     ask.finish(P, r);
     A.xplan.finish(P, r);
     const int64_t ns = A.xplan.send_total, ng = (int64_t)g.size();
-    double *d_req = nullptr, *d_got = nullptr;
-    PIB_HIP(hipMalloc(&d_req, sizeof(double) * (size_t)std::max<int64_t>(ng, 1)));
-    PIB_HIP(hipMalloc(&d_got, sizeof(double) * (size_t)std::max<int64_t>(ns, 1)));
+    DevScratch req_buf, got_buf;
+    PIB_HIP(hipMalloc(&req_buf.p, sizeof(double) * (size_t)std::max<int64_t>(ng, 1)));
+    PIB_HIP(hipMalloc(&got_buf.p, sizeof(double) * (size_t)std::max<int64_t>(ns, 1)));
+    double *const d_req = req_buf.p, *const d_got = got_buf.p;
     {
         std::vector<double> gd((size_t)std::max<int64_t>(ng, 1), 0.0);
         for (int64_t i = 0; i < ng; ++i) gd[(size_t)i] = (double)g[(size_t)i];  // exact below 2^53
@@ -198,8 +207,6 @@ int upload_csr_general(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_g
     std::vector<double> got((size_t)std::max<int64_t>(ns, 1), 0.0);
     PIB_HIP(hipMemcpyAsync(got.data(), d_got, sizeof(double) * (size_t)std::max<int64_t>(ns, 1), hipMemcpyDeviceToHost, s->stream));
     PIB_HIP(hipStreamSynchronize(s->stream));
-    PIB_HIP(hipFree(d_req));
-    PIB_HIP(hipFree(d_got));
     std::vector<int32_t> idx((size_t)std::max<int64_t>(ns, 1), 0);
     for (int64_t i = 0; i < ns; ++i) {
         const int64_t l = (int64_t)got[(size_t)i] - row0;
@@ -419,10 +426,11 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
         }
     }
     (void)base;
-    double *d_send = nullptr, *d_recv = nullptr;
+    DevScratch send_buf, recv_buf;
     const int64_t nrecv = F.n_slab * RW;
-    PIB_HIP(hipMalloc(&d_send, sizeof(double) * rec.size()));
-    PIB_HIP(hipMalloc(&d_recv, sizeof(double) * (size_t)std::max<int64_t>(nrecv, 1)));
+    PIB_HIP(hipMalloc(&send_buf.p, sizeof(double) * rec.size()));
+    PIB_HIP(hipMalloc(&recv_buf.p, sizeof(double) * (size_t)std::max<int64_t>(nrecv, 1)));
+    double *const d_send = send_buf.p, *const d_recv = recv_buf.p;
     PIB_HIP(hipMemcpyAsync(d_send, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, s->stream));
     PIB_HIP(hipStreamSynchronize(s->stream));
     std::vector<double *> recv((size_t)P, nullptr);
@@ -436,8 +444,6 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
     std::vector<double> got((size_t)std::max<int64_t>(nrecv, 1), 0.0);
     PIB_HIP(hipMemcpyAsync(got.data(), d_recv, sizeof(double) * got.size(), hipMemcpyDeviceToHost, s->stream));
     PIB_HIP(hipStreamSynchronize(s->stream));
-    PIB_HIP(hipFree(d_send));
-    PIB_HIP(hipFree(d_recv));
     rec.clear();
     rec.shrink_to_fit();
     // natural local row of record t of source q
@@ -718,10 +724,11 @@ int redist_velocity_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
                 rr[1 + W + u] = val[a + u];
             }
         }
-        double *d_send = nullptr, *d_recv = nullptr;
+        DevScratch send_buf, recv_buf;
         const int64_t nrecv = F.n_slab * RW;
-        PIB_HIP(hipMalloc(&d_send, sizeof(double) * rec.size()));
-        PIB_HIP(hipMalloc(&d_recv, sizeof(double) * (size_t)std::max<int64_t>(nrecv, 1)));
+        PIB_HIP(hipMalloc(&send_buf.p, sizeof(double) * rec.size()));
+        PIB_HIP(hipMalloc(&recv_buf.p, sizeof(double) * (size_t)std::max<int64_t>(nrecv, 1)));
+        double *const d_send = send_buf.p, *const d_recv = recv_buf.p;
         PIB_HIP(hipMemcpyAsync(d_send, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, s->stream));
         PIB_HIP(hipStreamSynchronize(s->stream));
         std::vector<double *> recv((size_t)P, nullptr);
@@ -736,8 +743,6 @@ int redist_velocity_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t 
         got_f[(size_t)f].assign((size_t)std::max<int64_t>(nrecv, 1), 0.0);
         PIB_HIP(hipMemcpyAsync(got_f[(size_t)f].data(), d_recv, sizeof(double) * got_f[(size_t)f].size(), hipMemcpyDeviceToHost, s->stream));
         PIB_HIP(hipStreamSynchronize(s->stream));
-        PIB_HIP(hipFree(d_send));
-        PIB_HIP(hipFree(d_recv));
     }
     auto local_row = [&](int f, int q, int64_t t) {
         const RedistField &F = R.f[f];
