@@ -7,7 +7,7 @@ iteration count and true residual against the z-slab route's, and the halo bytes
 general plan against the slabs' planes (Jacobi-PCG, where the boxes iterate on their own partition).
 The ranks share one GPU: times are functional evidence and relative costs, not scaling.
 
-    python tools/box_route_probe.py [n=256] [P=8]
+    python tools/box_route_probe.py [n=256] [P=8] [n of the velocity part=128; 0: skip]
 """
 import os
 import sys
@@ -47,7 +47,7 @@ def main():
     b_p = b[inv]
     print(f"# {n}^3 on {P} ranks, process grid {L.grid} (PETSC_DECIDE), boxes {lay.boxes[0][3:]}; host preparation {time.perf_counter() - t0:.1f} s",
           flush=True)
-    for pc, label in (("gmg", "multigrid-PCG V(2,2)"), ("jacobi", "Jacobi-PCG")):
+    for pc, label in (("gmg", "multigrid-PCG V(2,2)"), ("jacobi", "Jacobi-PCG"))[: 1 if n >= 512 else 2]:  # (Jacobi-PCG: ~2 n iterations)
         cfg = bench.solver_config(pc, 1e-10 if pc == "gmg" else 1e-6, 3000, 0.9, 2, 2, "jacobi") + "\n"
 
         def box_rank(r, uid):
@@ -107,7 +107,9 @@ def main():
                   f"iterations {sorted(its)}   exchanges {ex}   sent {sent / 1e6:.2f} MB per solve ({sent / max(ex, 1) / 1e3:.1f} kB per exchange, "
                   f"{prod} products)", flush=True)
         print(f"  boxes: true relative residual {rel:.3e}; structure {box[0]['st']}", flush=True)
-    velocity_part(int(sys.argv[3]) if len(sys.argv) > 3 else 128, P)
+    nv = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    if nv > 0:
+        velocity_part(nv, P)
 
 
 def velocity_part(n, P):
