@@ -238,7 +238,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.deep_halo = std::atoi(d.get("default", "pib_deep_halo", "1").c_str());
     c.overlap_min_bytes = std::atoi(d.get("default", "pib_overlap_min_bytes", "1048576").c_str());
     c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "-1").c_str());
-    c.coarse_tail_lds = std::atoi(d.get("default", "pib_coarse_tail_lds", "0").c_str());
+    c.coarse_tail_lds = std::atoi(d.get("default", "pib_coarse_tail_lds", "1").c_str());
     if (d.has("default", "pib_initial_guess_nonzero"))
         c.initial_guess_nonzero = truthy(d.get("default", "pib_initial_guess_nonzero", "1"));
     if (d.has("default", "pib_norm")) {

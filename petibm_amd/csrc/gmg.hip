@@ -1261,168 +1261,385 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
 // V-cycle (pre-smooth, residual, restriction, ..., coarsest sweeps, ..., prolongation, post-smooth) with block
 // barriers between the phases; the per-cell arithmetic is the same as in k_level / k_restrict_rows / k_prolong_rows,
 // so results are bit-identical to the per-level launches.  Damped Jacobi only.
+//
+// What a phase costs decides whether the tail pays (tools/tail_probe.py with the kernel's phase stamps,
+// profiles/r03_coarse_tail_phases.txt).  With vectors and tables in HBM a phase is a chain of L2 round trips (83 us per V-cycle
+// on a 448^2 mesh: five levels); as first written for LDS it was no better -- table-by-table staging, per-level pointer
+// arrays in scratch memory, and every access through a pointer that may be LDS or HBM, i.e. a FLAT instruction at the latency
+// of a vector-cache hit.  Now: one coalesced copy of the packed tables, the level descriptors in LDS, the kernel compiled
+// twice so that the LDS instance addresses pool and tables with LDS instructions, a level of at most one cell per thread
+// keeps the cell's row in registers for its whole visit, a level of at most 64 cells is walked by one wave without block
+// barriers, and the visit / restriction / prolongation code exists once, in a loop over the V-cycle's legs (the kernel runs
+// once per V-cycle from a cold instruction cache): 46 us on that mesh.
 constexpr int TAIL_MAX_CELLS = 32768;
 constexpr int TAIL_MAX_LEVELS = 12;
 struct TailLevel {
     LevelDev L;
     double *xa, *xb, *b, *r;
 };
-constexpr int TAIL_POOL = 6144;  // doubles of LDS for the tail's vectors (48 KB)
-constexpr int TAIL_GUARD = 768;  // ... and of margin around them
+constexpr int TAIL_POOL = 16384;  // doubles of LDS for the tail's vectors (128 KB of the CU's 160)
+constexpr int TAIL_GUARD = 512;   // ... and of margin around them
+constexpr int TAIL_TAB = 2048;    // doubles of LDS for the 1-D tables of the tail's levels
 struct TailArgs {
     int nlev;
     TailLevel lv[TAIL_MAX_LEVELS];
     double omega;
     int pre, post, sweeps;
-    // the four vectors of every tail level in LDS when they fit (lds_off[l] >= 0: place of level l's group of four in the pool):
-    // a tail is ~25 phases of a few hundred cells with a barrier in between -- with the vectors in HBM every phase is a round
-    // trip through the L2 (65 us per V-cycle of the 450^2 cylinder mesh, a quarter of that case's time step)
+    // LDS instance: place of level l's three vectors (iterate, spare, right-hand side; the residual takes the spare) in the pool
     int lds_off[TAIL_MAX_LEVELS];
+    // ... and the levels' 1-D coefficient and transfer tables, which the set-up packs into ONE block of HBM in the layout they
+    // have in LDS (tab_src, tab_used doubles; tt[l]: where level l's tables start inside it)
+    int tab_used;
+    const double *tab_src;
+    struct Tabs { int w[3], rw[3], cm[3], cp[3], wpar[3], woth[3], par[3], oth[3], fst[3]; } tt[TAIL_MAX_LEVELS];
     double *out0;  // where the tail's first level leaves its result (global memory)
 };
-
 // (4 KB: more than a kernel's argument segment takes beside the hidden arguments -- the kernel reads it from HBM)
-__device__ __forceinline__ void tail_smooth(const LevelDev &L, double omega, const double *b, const double *xi, double *xo,
-                                            bool zero_guess)
-{
-    const int plane = L.nx * L.ny, n = plane * L.nk;
-    for (int p = threadIdx.x; p < n; p += blockDim.x) {
-        const int i = p % L.nx, j = (p / L.nx) % L.ny, k = L.k0 + p / plane;
-        double d;
-        if (zero_guess) {
-            double c[6];
-            face_coefs(L, i, j, k, c);
-            d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-            xo[p] = omega * (scale_b(L, i, j, k, b[p]) / d);
-        } else {
-            const double ax = apply_cell(L, xi, p, i, j, k, &d);
-            xo[p] = xi[p] + omega * ((scale_b(L, i, j, k, b[p]) - ax) / d);
-        }
+
+// Reads of the tail's 1-D tables.  LDS: the descriptors' table pointers were redirected into the kernel's LDS block, but a
+// pointer loaded from a descriptor is a generic one (a FLAT load); the reader turns it back into an index of the block,
+// which the compiler addresses with LDS instructions.
+template <bool LDS>
+struct TailTab {
+    const double *g;  // the block's generic address
+    double *s;        // the block
+    __device__ __forceinline__ double operator()(const double *p, int i) const
+    {
+        if constexpr (LDS) return s[(p - g) + i];
+        else return p[i];
     }
-    __threadfence_block();
-    __syncthreads();
+    __device__ __forceinline__ int operator()(const int *p, int i) const
+    {
+        if constexpr (LDS) return reinterpret_cast<const int *>(s)[(p - reinterpret_cast<const int *>(g)) + i];
+        else return p[i];
+    }
+};
+
+// rs1d4 for the tail's lanes (every lane its own coarse cell, nothing wave-uniform): the four slots' table entries are loaded
+// unconditionally at clamped indices and selected afterwards -- sixteen independent loads instead of twelve dependent
+// little chains; the same weights
+template <class RD>
+__device__ __forceinline__ void rs1d4_lane(const RD &rd, const Tr1 &t, int I, int nf, bool wrap, double w[4], int f[4])
+{
+    const int f0 = rd(t.fst, I) - 1;
+    bool in[4];
+    int par[4], oth[4];
+    double wp[4], wo[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        int ff = f0 + o;
+        if (wrap) ff = ff < 0 ? ff + nf : (ff >= nf ? ff - nf : ff);
+        in[o] = ff >= 0 && ff < nf;
+        f[o] = ff < 0 ? 0 : (ff >= nf ? nf - 1 : ff);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        par[o] = rd(t.par, f[o]);
+        oth[o] = rd(t.oth, f[o]);
+        wp[o] = rd(t.wpar, f[o]);
+        wo[o] = rd(t.woth, f[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) w[o] = in[o] ? (par[o] == I ? wp[o] : (oth[o] == I ? wo[o] : 0.0)) : 0.0;
 }
 
+// One cell's row of the level operator -- face coefficients, diagonal, volume factors, where its six neighbours sit -- and
+// its scaled right-hand side.  Same expressions in the same order as face_coefs / scale_b / unscale / apply_cell.
+struct TailCell {
+    double c[6], d, rxy, rz, wxy, wz, bs;
+    int off[6];
+    int has;  // bit q: neighbour q exists (or is reached across a periodic seam); bit 8: there is a cell at all
+};
+template <class RD>
+__device__ __forceinline__ void tail_cell(const RD &rd, const LevelDev &L, int p, int n, const double *b, TailCell &t)
+{
+    t.has = 0;
+    if (p >= n) return;
+    const int plane = L.nx * L.ny;
+    const int i = p % L.nx, j = (p / L.nx) % L.ny, k = L.k0 + p / plane;
+    t.c[0] = rd(L.cmx, i);
+    t.c[1] = rd(L.cpx, i);
+    t.c[2] = rd(L.cmy, j);
+    t.c[3] = rd(L.cpy, j);
+    t.c[4] = rd(L.cmz, k);
+    t.c[5] = rd(L.cpz, k);
+    t.d = -(((((t.c[0] + t.c[1]) + t.c[2]) + t.c[3]) + t.c[4]) + t.c[5]);
+    t.rxy = rd(L.rwx, i) * rd(L.rwy, j);
+    t.rz = rd(L.rwz, k);
+    t.wxy = rd(L.wx, i) * rd(L.wy, j);
+    t.wz = rd(L.wz, k);
+    t.bs = (b[p] * t.rxy) * t.rz;
+    const int sy = L.nx, sz = plane;
+    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
+    int has = 256;
+    t.off[0] = i > 0 ? -1 : L.nx - 1;
+    if (i > 0 || px) has |= 1;
+    t.off[1] = i < L.nx - 1 ? 1 : -(L.nx - 1);
+    if (i < L.nx - 1 || px) has |= 2;
+    t.off[2] = j > 0 ? -sy : (L.ny - 1) * sy;
+    if (j > 0 || py) has |= 4;
+    t.off[3] = j < L.ny - 1 ? sy : -(L.ny - 1) * sy;
+    if (j < L.ny - 1 || py) has |= 8;
+    t.off[4] = k > 0 ? -sz : (L.zring ? -sz : (L.nzg - 1) * sz);
+    if (k > 0 || pz) has |= 16;
+    t.off[5] = k < L.nzg - 1 ? sz : (L.zring ? sz : -(L.nzg - 1) * sz);
+    if (k < L.nzg - 1 || pz) has |= 32;
+    t.has = has;
+}
+__device__ __forceinline__ double tail_row(const TailCell &t, const double *x, int p)
+{
+    const double xc = x[p];
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        if ((t.has >> q) & 1) s += t.c[q] * (x[p + t.off[q]] - xc);
+    return s;
+}
+// one phase of one cell: the step from a zero guess, a damped-Jacobi step x -> out, or the residual of x
+__device__ __forceinline__ void tail_cell_phase(const TailCell &t, bool zero, bool res, double omega, const double *b, const double *x,
+                                                double *out, int p)
+{
+    if (!t.has) return;
+    if (zero) {
+        out[p] = omega * (t.bs / t.d);
+        return;
+    }
+    const double row = tail_row(t, x, p);
+    if (res) out[p] = b[p] - (row * t.wxy) * t.wz;
+    else out[p] = x[p] + omega * ((t.bs - row) / t.d);
+}
+
+// One visit of a level: `steps` smoothing steps (the first from a zero guess on the way down) and, on the way down, the
+// residual; every step swaps the level's two vectors a / c, the residual goes to r.  Returns where the iterate is.
+// KIND 0: at most 64 cells -- the first wave alone, a wavefront-scope fence between the steps (a wave's memory operations are
+// issued and performed in order), the row in registers; 1: at most one cell per thread, block barriers, the row in
+// registers; 2: several cells per thread, the rows rebuilt from the tables in every phase.
+template <int KIND, class RD>
+__device__ __forceinline__ double *tail_visit(const RD &rd, const LevelDev &F, int n, double omega, int steps, bool zero_first, bool resid,
+                                              const double *b, double *a, double *c, double *r)
+{
+    const int phases = steps + (resid ? 1 : 0);
+    const int p0 = threadIdx.x;
+    const bool mine = KIND != 0 || p0 < 64;
+    TailCell tc;
+    tc.has = 0;
+    if (KIND != 2 && mine) tail_cell(rd, F, p0, n, b, tc);
+    for (int k = 0; k < phases; ++k) {
+        const bool zero = zero_first && k == 0, res = k == steps;
+        double *out = zero ? a : (res ? r : c);
+        if (KIND == 2) {
+            for (int p = p0; p < n; p += blockDim.x) {
+                tail_cell(rd, F, p, n, b, tc);
+                tail_cell_phase(tc, zero, res, omega, b, a, out, p);
+            }
+        } else if (mine)
+            tail_cell_phase(tc, zero, res, omega, b, a, out, p0);
+        if (KIND == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (!zero && !res) {
+            double *t = a; a = c; c = t;
+        }
+    }
+    if (KIND == 0) {
+        __threadfence_block();
+        __syncthreads();
+    }
+    return a;
+}
+
+// LDS: the levels' vectors and tables live in LDS -- a compile-time fact, so that they are reached with LDS instructions
+template <bool LDS>
 __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict__ S, const TailArgs *__restrict__ Tp)
 {
     if (S != nullptr && S->done) return;
     const TailArgs &T = *Tp;
-    // (a margin on either side: like their padded counterparts in HBM the vectors may be read a little outside -- a
-    // neighbour the row kernels load before they know its weight is zero -- and a flat access below the LDS aperture
-    // is a fault, not a zero)
-    __shared__ double pool_[TAIL_GUARD + TAIL_POOL + TAIL_GUARD];
-    double *const pool = pool_ + TAIL_GUARD;
-    double *cur[TAIL_MAX_LEVELS], *spare[TAIL_MAX_LEVELS];
+#ifdef PIB_TAIL_STAMPS
+    __shared__ unsigned long long st_[256];
+    __shared__ int sg_[256];
+    int nst_ = 0;
+#define STAMP(tag) do { if (threadIdx.x == 0 && nst_ < 256) { st_[nst_] = wall_clock64(); sg_[nst_] = (tag); } ++nst_; } while (0)
+#else
+#define STAMP(tag) do { } while (0)
+#endif
+    STAMP(0);
+    // (a margin on either side of the pool: a neighbour of zero weight may be read before its weight is known; an access
+    // below the LDS aperture is a fault, not a zero)
+    __shared__ double pool_[LDS ? TAIL_GUARD + TAIL_POOL + TAIL_GUARD : 1];
+    __shared__ double tab_[LDS ? TAIL_TAB : 1];
+    __shared__ LevelDev Ls_[TAIL_MAX_LEVELS];
+    double *const pool = pool_ + (LDS ? TAIL_GUARD : 0);
     const int nl = T.nlev;
-    const bool lds = T.lds_off[0] >= 0;
-    // level l's xa / xb / b / r: in the pool or in global memory
-    auto vec = [&](int l, int which) -> double * {
-        const TailLevel &V = T.lv[l];
-        if (lds) return pool + T.lds_off[l] + which * (V.L.nx * V.L.ny * V.L.nk);
-        return which == 0 ? V.xa : (which == 1 ? V.xb : (which == 2 ? V.b : V.r));
-    };
-    if (lds) {
-        for (int p = threadIdx.x; p < TAIL_GUARD + TAIL_POOL + TAIL_GUARD; p += blockDim.x) pool_[p] = 0.0;  // (finite: 0 * it = 0)
-        __syncthreads();
-        const int n0 = T.lv[0].L.nx * T.lv[0].L.ny * T.lv[0].L.nk;
-        double *b0 = vec(0, 2);
-        for (int p = threadIdx.x; p < n0; p += blockDim.x) b0[p] = T.lv[0].b[p];
-        __syncthreads();
-    }
-    // ---- downward leg
-    for (int l = 0; l < nl - 1; ++l) {
-        const LevelDev &F = T.lv[l].L;
-        const LevelDev &C = T.lv[l + 1].L;
-        struct { double *b, *r; } V = {vec(l, 2), vec(l, 3)};
-        double *a = vec(l, 0), *c = vec(l, 1);
-        tail_smooth(F, T.omega, V.b, nullptr, a, true);
-        for (int sw = 1; sw < T.pre; ++sw) {
-            tail_smooth(F, T.omega, V.b, a, c, false);
-            double *t = a; a = c; c = t;
+    const TailTab<LDS> rd = {tab_, tab_};
+    // the levels' descriptors into LDS (word by word, all threads), the tables after them; then one thread per level redirects
+    // its descriptor's table pointers to the LDS copies
+    {
+        constexpr int words = (int)(sizeof(LevelDev) / sizeof(int));
+        static_assert(sizeof(LevelDev) % sizeof(int) == 0, "LevelDev is copied in 4-byte words");
+        for (int e = threadIdx.x; e < nl * words; e += blockDim.x) {
+            const int l = e / words, w = e - l * words;
+            reinterpret_cast<int *>(&Ls_[l])[w] = reinterpret_cast<const int *>(&T.lv[l].L)[w];
         }
-        const int fplane = F.nx * F.ny, nf = fplane * F.nk;
-        for (int p = threadIdx.x; p < nf; p += blockDim.x) {
-            const int i = p % F.nx, j = (p / F.nx) % F.ny, k = F.k0 + p / fplane;
-            double d;
-            V.r[p] = V.b[p] - unscale(F, i, j, k, apply_cell(F, a, p, i, j, k, &d));
+        if (LDS) {
+            for (int p = threadIdx.x; p < T.tab_used; p += blockDim.x) tab_[p] = T.tab_src[p];
+            // (the margins finite; inside the pool every entry is written before it is read)
+            for (int p = threadIdx.x; p < 2 * TAIL_GUARD; p += blockDim.x) pool_[p < TAIL_GUARD ? p : TAIL_POOL + p] = 0.0;
         }
-        __threadfence_block();
         __syncthreads();
-        const int cplane = C.nx * C.ny, nc = cplane * C.nk;
-        double *bc = vec(l + 1, 2);
-        for (int q = threadIdx.x; q < nc; q += blockDim.x) {
-            const int I = q % C.nx, J = (q / C.nx) % C.ny, K = C.k0 + q / cplane;
-            double wi[4], wj[4], wk[4];
-            int si[4], sj[4], sk[4];
-            rs1d4(F.t[0], I, F.nx, F.tper & 1, wi, si);
-            rs1d4(F.t[1], J, F.ny, F.tper & 2, wj, sj);
-            rs1d4(F.t[2], K, F.nzg, F.tper & 4, wk, sk);
-            double sum = 0.0;
-            for (int c2 = 0; c2 < 4; ++c2) {
-                if (wk[c2] == 0.0) continue;
-                const double *pk = V.r + (int64_t)fplane * (sk[c2] - F.k0);
-                for (int b2 = 0; b2 < 4; ++b2) {
-                    const double wzy = wk[c2] * wj[b2];
-                    const double *pj = pk + (int64_t)F.nx * sj[b2];
-                    for (int a2 = 0; a2 < 4; ++a2) sum += (wzy * wi[a2]) * pj[si[a2]];
+        if (LDS && (int)threadIdx.x < nl) {
+            LevelDev &L = Ls_[threadIdx.x];
+            const TailArgs::Tabs &o = T.tt[threadIdx.x];
+            auto dbl = [&](int off) -> const double * { return tab_ + off; };
+            auto i32 = [&](int off) -> const int * { return reinterpret_cast<const int *>(tab_ + off); };
+            L.wx = dbl(o.w[0]), L.wy = dbl(o.w[1]), L.wz = dbl(o.w[2]);
+            L.rwx = dbl(o.rw[0]), L.rwy = dbl(o.rw[1]), L.rwz = dbl(o.rw[2]);
+            L.cmx = dbl(o.cm[0]), L.cmy = dbl(o.cm[1]), L.cmz = dbl(o.cm[2]);
+            L.cpx = dbl(o.cp[0]), L.cpy = dbl(o.cp[1]), L.cpz = dbl(o.cp[2]);
+            if ((int)threadIdx.x + 1 < nl) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    L.t[d].wpar = dbl(o.wpar[d]);
+                    L.t[d].woth = dbl(o.woth[d]);
+                    L.t[d].par = i32(o.par[d]);
+                    L.t[d].oth = i32(o.oth[d]);
+                    L.t[d].fst = i32(o.fst[d]);
                 }
             }
-            bc[q] = sum;
         }
-        __threadfence_block();
+        if (LDS) {  // the first level's right-hand side
+            const int n0 = T.lv[0].L.nx * T.lv[0].L.ny * T.lv[0].L.nk;
+            double *b0 = pool + T.lds_off[0] + 2 * n0;
+            for (int p = threadIdx.x; p < n0; p += blockDim.x) b0[p] = T.lv[0].b[p];
+        }
         __syncthreads();
-        cur[l] = a;
-        spare[l] = c;
     }
-    // ---- coarsest level: Jacobi sweeps from zero
-    {
-        const LevelDev &L = T.lv[nl - 1].L;
-        const double *bl = vec(nl - 1, 2);
-        double *a = vec(nl - 1, 0), *c = vec(nl - 1, 1);
-        tail_smooth(L, T.omega, bl, nullptr, a, true);
-        for (int sw = 1; sw < T.sweeps; ++sw) {
-            tail_smooth(L, T.omega, bl, a, c, false);
-            double *t = a; a = c; c = t;
-        }
-        cur[nl - 1] = a;
-    }
-    // ---- upward leg
-    for (int l = nl - 2; l >= 0; --l) {
-        const LevelDev &F = T.lv[l].L;
-        const LevelDev &C = T.lv[l + 1].L;
-        struct { const double *b; } V = {vec(l, 2)};
-        double *a = cur[l], *c = spare[l];
-        const double *xc = cur[l + 1];
+    STAMP(1);
+    // level l's iterate / spare / right-hand side (which = 0, 1, 2) and where its residual goes: the spare in LDS
+    auto vec = [&](int l, int which) -> double * {
+        const TailLevel &V = T.lv[l];
+        if constexpr (LDS) return pool + T.lds_off[l] + which * (V.L.nx * V.L.ny * V.L.nk);
+        else return which == 0 ? V.xa : (which == 1 ? V.xb : V.b);
+    };
+    // a level's two vectors swap with every step but the one from a zero guess: which of them holds the iterate after the
+    // way down (no per-level pointer arrays: indexed by a runtime level they would live in scratch memory)
+    const int dsteps = T.pre > 1 ? T.pre : 1;
+    int l = 0;
+    bool down = true;
+    double *a = nullptr;  // the iterate of the level just visited
+    for (;;) {
+        const LevelDev &F = Ls_[l];
         const int fplane = F.nx * F.ny, nf = fplane * F.nk;
-        const int64_t cplane = (int64_t)C.nx * C.ny;
-        for (int p = threadIdx.x; p < nf; p += blockDim.x) {
-            const int i = p % F.nx, j = (p / F.nx) % F.ny, k = F.k0 + p / fplane;
-            int I[2], J[2], K[2];
-            double wi[2], wj[2], wk[2];
-            tr1d(F.t[0], i, I, wi);
-            tr1d(F.t[1], j, J, wj);
-            tr1d(F.t[2], k, K, wk);
-            double sum = 0.0;
-            for (int c2 = 0; c2 < 2; ++c2)
-                for (int b2 = 0; b2 < 2; ++b2)
-                    for (int a2 = 0; a2 < 2; ++a2) {
-                        const double wgt = (wk[c2] * wj[b2]) * wi[a2];
-                        if (wgt != 0.0) sum += wgt * xc[I[a2] + (int64_t)C.nx * J[b2] + cplane * (K[c2] - C.k0)];
+        const bool coarsest = l == nl - 1;
+        const int steps = down ? (coarsest ? (T.sweeps > 1 ? T.sweeps : 1) : dsteps) : T.post;
+        const bool resid = down && !coarsest;
+        double *b = vec(l, 2);
+        const int at = down ? 0 : ((dsteps - 1) & 1);
+        double *xa = vec(l, at), *xc = vec(l, 1 - at);
+        double *r = xc;
+        if (resid) {
+            // (the spare at the time of the residual: the vector the last step did NOT write)
+            r = LDS ? vec(l, 1 - ((dsteps - 1) & 1)) : T.lv[l].r;
+        }
+        if (nf <= 64) a = tail_visit<0>(rd, F, nf, T.omega, steps, down, resid, b, xa, xc, r);
+        else if (nf <= (int)blockDim.x) a = tail_visit<1>(rd, F, nf, T.omega, steps, down, resid, b, xa, xc, r);
+        else a = tail_visit<2>(rd, F, nf, T.omega, steps, down, resid, b, xa, xc, r);
+        STAMP((down ? 10 : 90) + l);
+        if (resid) {
+            // ---- restriction: right-hand side of level l + 1 = P^T r
+            const LevelDev &C = Ls_[l + 1];
+            const int cplane = C.nx * C.ny, nc = cplane * C.nk;
+            double *bc = vec(l + 1, 2);
+            for (int q = threadIdx.x; q < nc; q += blockDim.x) {
+                const int I = q % C.nx, J = (q / C.nx) % C.ny, K = C.k0 + q / cplane;
+                double wi[4], wj[4], wk[4];
+                int si[4], sj[4], sk[4];
+                rs1d4_lane(rd, F.t[0], I, F.nx, F.tper & 1, wi, si);
+                __builtin_amdgcn_sched_barrier(0);  // (one direction's sixteen loads at a time: all three at once spill)
+                rs1d4_lane(rd, F.t[1], J, F.ny, F.tper & 2, wj, sj);
+                __builtin_amdgcn_sched_barrier(0);
+                rs1d4_lane(rd, F.t[2], K, F.nzg, F.tper & 4, wk, sk);
+                __builtin_amdgcn_sched_barrier(0);
+                double sum = 0.0;
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    if (wk[c2] == 0.0) continue;
+                    const double *pk = r + fplane * (sk[c2] - F.k0);
+                    for (int b2 = 0; b2 < 4; ++b2) {
+                        const double wzy = wk[c2] * wj[b2];
+                        if (wzy == 0.0) continue;  // (a 2-D level: one row of the four; the terms left out are +-0)
+                        const double *pj = pk + F.nx * sj[b2];
+#pragma unroll
+                        for (int a2 = 0; a2 < 4; ++a2) sum += (wzy * wi[a2]) * pj[si[a2]];
                     }
-            a[p] += sum;
+                }
+                bc[q] = sum;
+            }
+            __threadfence_block();
+            __syncthreads();
+            STAMP(50 + l);
+            ++l;
+            continue;
         }
-        __threadfence_block();
-        __syncthreads();
-        for (int sw = 0; sw < T.post; ++sw) {
-            tail_smooth(F, T.omega, V.b, a, c, false);
-            double *t = a; a = c; c = t;
+        if (l == 0) break;
+        // ---- prolongation: the iterate of level l - 1 += P a
+        {
+            const LevelDev &C = F;
+            const LevelDev &G = Ls_[l - 1];
+            const int gplane = G.nx * G.ny, ng = gplane * G.nk;
+            const int cplane = C.nx * C.ny;
+            double *xf = vec(l - 1, (dsteps - 1) & 1);
+            for (int p = threadIdx.x; p < ng; p += blockDim.x) {
+                const int i = p % G.nx, j = (p / G.nx) % G.ny, k = G.k0 + p / gplane;
+                int I[2], J[2], K[2];
+                double wi[2], wj[2], wk[2];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const Tr1 &t = G.t[d];
+                    const int sd = d == 0 ? i : (d == 1 ? j : k);
+                    int *Id = d == 0 ? I : (d == 1 ? J : K);
+                    double *wd = d == 0 ? wi : (d == 1 ? wj : wk);
+                    Id[0] = rd(t.par, sd);
+                    Id[1] = rd(t.oth, sd);
+                    wd[0] = rd(t.wpar, sd);
+                    wd[1] = rd(t.woth, sd);
+                }
+                double sum = 0.0;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                        for (int a2 = 0; a2 < 2; ++a2) {
+                            const double wgt = (wk[c2] * wj[b2]) * wi[a2];
+                            if (wgt != 0.0) sum += wgt * a[I[a2] + C.nx * J[b2] + cplane * (K[c2] - C.k0)];
+                        }
+                xf[p] += sum;
+            }
+            __threadfence_block();
+            __syncthreads();
+            STAMP(70 + l - 1);
         }
-        cur[l] = a;
+        --l;
+        down = false;
     }
-    if (lds) {
+    if (LDS) {
         const int n0 = T.lv[0].L.nx * T.lv[0].L.ny * T.lv[0].L.nk;
-        for (int p = threadIdx.x; p < n0; p += blockDim.x) T.out0[p] = cur[0][p];
+        for (int p = threadIdx.x; p < n0; p += blockDim.x) T.out0[p] = a[p];
     }
+    STAMP(4);
+#ifdef PIB_TAIL_STAMPS
+    // tools: phase times of some launches (tag: 1 staged, 10+l way-down visit of level l -- the coarsest's sweeps for the last
+    // --, 50+l restriction, 70+l prolongation onto l, 90+l post-smoothing, 4 result written); 10 ns units
+    if (threadIdx.x == 0) {
+        static __device__ int launches_ = 0;
+        if (atomicAdd(&launches_, 1) % 40 == 20)
+            for (int q = 1; q < nst_ && q < 256; ++q) printf("tail-stamp %d %llu\n", sg_[q], st_[q] - st_[q - 1]);
+    }
+#endif
+#undef STAMP
 }
 
 // ------------------------------------------------------------------ host side
@@ -1483,6 +1700,8 @@ void gmg_release(pib_solver *s)
 {
     if (s->d_tail_args) (void)hipFree(s->d_tail_args);
     s->d_tail_args = nullptr;
+    if (s->d_tail_tab) (void)hipFree(s->d_tail_tab);
+    s->d_tail_tab = nullptr;
     s->h_tail_args.clear();
     for (auto &L : s->levels) {
         for (int d = 0; d < 3; ++d) {
@@ -2327,19 +2546,68 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             for (int q2 = 0; q2 < T.nlev; ++q2) {
                 const GridLevel &t = s->levels[(size_t)(tail0 + q2)];
                 T.lds_off[q2] = (int)need;
-                need += 4 * t.nloc;
+                need += 3 * t.nloc;  // iterate, spare (the residual's place on the way down), right-hand side
                 fits = fits && !t.zring && t.nloc == t.n[0] * t.n[1] * t.n[2];
             }
             if (!fits || need > TAIL_POOL)
                 for (int q2 = 0; q2 < TAIL_MAX_LEVELS; ++q2) T.lds_off[q2] = -1;
+            // the tables of the tail's levels, packed (see TailArgs): offsets first, the block itself when the arguments change
+            struct Piece { const void *src; int off, bytes; };
+            std::vector<Piece> pieces;
+            int used = 0;
+            bool tabs_ok = true;
+            auto put_d = [&](const double *src, int n) -> int {
+                if (src == nullptr) tabs_ok = false;
+                const int off = used;
+                pieces.push_back({src, off, 8 * n});
+                used += n;
+                return off;
+            };
+            auto put_i = [&](const int32_t *src, int n) -> int {
+                if (src == nullptr) tabs_ok = false;
+                const int off = used;
+                pieces.push_back({src, off, 4 * n});
+                used += (n + 1) / 2;
+                return off;
+            };
+            for (int q2 = 0; q2 < T.nlev; ++q2) {
+                const GridLevel &t = s->levels[(size_t)(tail0 + q2)];
+                TailArgs::Tabs &o = T.tt[q2];
+                for (int d = 0; d < 3; ++d) {
+                    const int n = (int)t.n[d];
+                    o.w[d] = put_d(t.w[d], n);
+                    o.rw[d] = put_d(t.rw[d], n);
+                    o.cm[d] = put_d(t.cm[d], n);
+                    o.cp[d] = put_d(t.cp[d], n);
+                    if (q2 + 1 < T.nlev) {
+                        const int nc = (int)s->levels[(size_t)(tail0 + q2 + 1)].n[d];
+                        o.wpar[d] = put_d(t.t_wpar[d], n);
+                        o.woth[d] = put_d(t.t_woth[d], n);
+                        o.par[d] = put_i(t.t_par[d], n);
+                        o.oth[d] = put_i(t.t_oth[d], n);
+                        o.fst[d] = put_i(t.t_fst[d], nc);
+                    }
+                }
+            }
+            // (vectors and tables go to LDS together or not at all: the kernel has one instance for either)
+            const bool tab_lds = T.lds_off[0] >= 0 && tabs_ok && used <= TAIL_TAB;
+            if (!tab_lds)
+                for (int q2 = 0; q2 < TAIL_MAX_LEVELS; ++q2) T.lds_off[q2] = -1;
+            T.tab_used = tab_lds ? used : 0;
+            if (s->d_tail_tab == nullptr) PIB_HIP(hipMalloc(&s->d_tail_tab, sizeof(double) * TAIL_TAB));
+            T.tab_src = static_cast<const double *>(s->d_tail_tab);
             T.out0 = cur[(size_t)l];
             // the argument block lives in HBM, rewritten only when it changes (levels, sweeps and buffers are fixed per set-up)
             if (s->d_tail_args == nullptr) PIB_HIP(hipMalloc(&s->d_tail_args, sizeof(TailArgs)));
             if (s->h_tail_args.size() != sizeof(TailArgs) || std::memcmp(s->h_tail_args.data(), &T, sizeof(TailArgs)) != 0) {
                 s->h_tail_args.assign(reinterpret_cast<const char *>(&T), reinterpret_cast<const char *>(&T) + sizeof(TailArgs));
                 PIB_HIP(hipMemcpyAsync(s->d_tail_args, s->h_tail_args.data(), sizeof(TailArgs), hipMemcpyHostToDevice, q));
+                if (tab_lds)
+                    for (const Piece &pc : pieces)
+                        PIB_HIP(hipMemcpyAsync(static_cast<double *>(s->d_tail_tab) + pc.off, pc.src, (size_t)pc.bytes, hipMemcpyDeviceToDevice, q));
             }
-            hipLaunchKernelGGL(k_coarse_tail, dim3(1), dim3(1024), 0, q, S, static_cast<const TailArgs *>(s->d_tail_args));
+            if (T.lds_off[0] >= 0) hipLaunchKernelGGL(k_coarse_tail<true>, dim3(1), dim3(1024), 0, q, S, static_cast<const TailArgs *>(s->d_tail_args));
+            else hipLaunchKernelGGL(k_coarse_tail<false>, dim3(1), dim3(1024), 0, q, S, static_cast<const TailArgs *>(s->d_tail_args));
             PIB_HIP(hipGetLastError());
             break;
         }

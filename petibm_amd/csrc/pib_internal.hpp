@@ -81,7 +81,7 @@ struct Config {
     int overlap_halo = 1;
     int overlap_min_bytes = 1 << 20;  // multigrid on slabs: a right-hand-side exchange of at least this size per neighbour runs on the communication stream behind the interior planes of its first consumer
     int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024; 0: off.
-    int coarse_tail_lds = 0;  // ... with the tail levels' vectors in LDS when they fit (48 KB): 72 -> 63 us per tail, nothing per time step; off
+    int coarse_tail_lds = 1;  // ... with the tail levels' vectors and 1-D tables in LDS when they fit (gmg.hip: 83 -> 44 us per tail of a 448^2 mesh); 0: HBM
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
@@ -379,6 +379,7 @@ struct pib_solver {
     int *dense_bad = nullptr;     // zero-pivot flag
     void *d_tail_args = nullptr;        // gmg.hip: argument block of the single-workgroup coarse tail (+ its host copy)
     std::vector<char> h_tail_args;
+    void *d_tail_tab = nullptr;         // ... and the 1-D tables of the tail's levels packed for its LDS copy
     double *dense_pad = nullptr;  // the matrix padded to a multiple of the block order, inverted in place by the blocked elimination (+ one block of scratch)
     hipGraphExec_t dense_graph = nullptr;  // the dense_n elimination launches
     int64_t dense_n = 0;

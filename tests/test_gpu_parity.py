@@ -523,6 +523,52 @@ def test_gmg_coarse_tail_kernel_is_bit_identical(lin):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
 
 
+@pytest.mark.parametrize("case", ["3d_stretched", "2d_stretched", "3d_periodic_xz", "2d_periodic", "v22"])
+def test_gmg_coarse_tail_forms_are_bit_identical(lin, case):
+    """The single-workgroup tail walks its levels with the vectors and the 1-D tables in HBM or staged in LDS
+    (pib_coarse_tail_lds), one cell per thread with the cell's row in registers or -- levels of more cells than threads
+    (pib_coarse_tail=4096) -- through the tables in every phase: per-level launches, and every form of the tail, give the
+    same bits."""
+    from petibm_amd import capi
+    per = None
+    pre = post = 1
+    if case == "3d_stretched":
+        cfg = stretched_3d((24, 20, 16))
+    elif case == "2d_stretched":
+        cfg = STRETCHED_2D
+    elif case == "3d_periodic_xz":
+        per = (True, False, True)
+        cfg = omesh.periodic_config((24, 20, 16), per)
+    elif case == "2d_periodic":
+        per = (True, True)
+        cfg = omesh.periodic_config((64, 48), per)
+    else:
+        cfg = omesh.uniform_config((32, 32, 32))
+        pre = post = 2
+    dt = 0.01
+    m = omesh.create_mesh(cfg)
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    xs, b = rhs_for(A)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    out = []
+    for tail, lds in ((0, 0), (1024, 0), (1024, 1), (4096, 0), (4096, 1), (64, 1)):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post, extra=f"pib_coarse_tail={tail}\npib_coarse_tail_lds={lds}\n"))
+        if per is not None:
+            s.setPeriodic(per)
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        assert s.getReason() > 0
+        out.append((x, s.getIters(), s.getResidualHistory().copy()))
+        s.destroy()
+    for x, its, h in out[1:]:
+        assert its == out[0][1]
+        assert np.array_equal(x, out[0][0])
+        assert np.array_equal(h, out[0][2])
+
+
 def test_gmg_pcg_pinned_pressure_matches_oracle(lin):
     from petibm_amd import capi
     cfg = stretched_3d((20, 16, 12))
