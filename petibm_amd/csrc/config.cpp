@@ -239,6 +239,9 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.overlap_min_bytes = std::atoi(d.get("default", "pib_overlap_min_bytes", "1048576").c_str());
     c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "-1").c_str());
     c.coarse_tail_lds = std::atoi(d.get("default", "pib_coarse_tail_lds", "1").c_str());
+    c.fuse_small_levels = std::atoi(d.get("default", "pib_fuse_small_levels", "1").c_str());
+    c.small_level_cells = std::atoi(d.get("default", "pib_small_level_cells", "300000").c_str());
+    c.small_level_cells_3d = std::atoi(d.get("default", "pib_small_level_cells_3d", "40000").c_str());
     if (d.has("default", "pib_initial_guess_nonzero"))
         c.initial_guess_nonzero = truthy(d.get("default", "pib_initial_guess_nonzero", "1"));
     if (d.has("default", "pib_norm")) {
@@ -359,6 +362,9 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_overlap_min_bytes", v)) c.overlap_min_bytes = std::atoi(v.c_str());
     if (get("pib_coarse_tail", v)) c.coarse_tail = std::atoi(v.c_str());
     if (get("pib_coarse_tail_lds", v)) c.coarse_tail_lds = std::atoi(v.c_str());
+    if (get("pib_fuse_small_levels", v)) c.fuse_small_levels = std::atoi(v.c_str());
+    if (get("pib_small_level_cells", v)) c.small_level_cells = std::atoi(v.c_str());
+    if (get("pib_small_level_cells_3d", v)) c.small_level_cells_3d = std::atoi(v.c_str());
     if (get("pib_presweeps", v)) c.presweeps = std::atoi(v.c_str());
     if (get("pib_postsweeps", v)) c.postsweeps = std::atoi(v.c_str());
     if (get("pib_cheby_degree", v)) c.cheby_degree = std::atoi(v.c_str());

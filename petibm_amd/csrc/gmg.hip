@@ -1642,6 +1642,352 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
 #undef STAMP
 }
 
+// ---- small levels: a level's whole way down, and its whole way up, in ONE launch each -------------------------------
+// Between the marching kernels of the large levels and the single-workgroup tail sit three or four levels (64^3 ... 16^3
+// under a 512^3 grid, 224^2 ... 56^2 under a 448^2 one) that are launch-bound: seven kernels per level and V-cycle (step
+// from zero, step, residual, restriction | prolongation, two steps).  Here a workgroup owns the children of a box of coarse
+// cells and evaluates everything it needs on that box plus a margin in LDS -- the first step on the box grown by pre + 1
+// cells, every further step and the residual one cell less, then the restriction for its own coarse cells (way down); the
+// corrected iterate on the box grown by post cells, every post-smoothing step one cell less (way up).  The margins are
+// recomputed by the neighbouring workgroups; no field crosses HBM between the phases.
+// What such a kernel costs is the number of DEPENDENT trips to memory, ~2 us each when the lines are cold (phase stamps,
+// profiles/r03_small_level_kernels.txt: a first version that fetched tables and right-hand side where it used them took 19
+// us per launch, a third of it the restriction's little pointer chases).  So: ONE round of loads -- the 1-D coefficient and
+// transfer tables of the region into LDS, the thread's right-hand-side values (and iterate values, way up) into registers,
+// a thread keeping the same region cells through all phases -- and after it LDS only (way up: plus the gather of the coarse
+// values).  Same per-cell expressions in the same order as k_level / the transfers: the same bits.
+// Levels whole on this rank, Jacobi, 1-2 pre- / post-smoothing steps, operator and transfers wrapping alike.
+constexpr int SM_MAXE = 40;    // largest extent of a workgroup's region per direction
+constexpr int SM_MAXR = 3456;  // ... and its cells (two LDS buffers of that many doubles)
+constexpr int SM_NT = 512;     // threads per workgroup
+constexpr int SM_NB = (SM_MAXR + SM_NT - 1) / SM_NT;  // region cells per thread
+constexpr int SM_MAXBC = 16;   // coarse cells per direction and workgroup
+struct SmTabs {
+    double cm[3][SM_MAXE], cp[3][SM_MAXE], rw[3][SM_MAXE], w[3][SM_MAXE];  // coefficients, by region coordinate
+    double wpar[3][SM_MAXE], woth[3][SM_MAXE];                            // transfers of the region's fine cells
+    int par[3][SM_MAXE], oth[3][SM_MAXE];
+    int fst[3][SM_MAXBC + 1];                                              // first child of the owned coarse cells
+};
+struct SmGeom {
+    int n[3];           // the level's cells
+    int per[3];         // periodic directions
+    int I0[3], I1[3];   // owned coarse cells [I0, I1)
+    int F0[3], F1[3];   // their children: the owned fine cells [F0, F1)
+    int lo[3], ext[3];  // the largest region, in unwrapped level coordinates (clipped to the domain where it does not wrap)
+};
+__device__ __forceinline__ int sm_wrap(int g, int n) { return g < 0 ? g + n : (g >= n ? g - n : g); }
+
+// geometry of workgroup `blk`: its box of bc[] coarse cells, their children, the region grown by `grow_lo` / `grow_hi`.
+// Aggregates that are all pairs (or all single cells) need no table for the children's range.
+__device__ __forceinline__ void sm_geometry(const LevelDev &F, const LevelDev &C, int blk, int bcx, int bcy, int bcz, int grow_lo, int grow_hi,
+                                            SmGeom &G)
+{
+    const int bc[3] = {bcx, bcy, bcz};
+    const int nc[3] = {C.nx, C.ny, C.nzg};
+    G.n[0] = F.nx, G.n[1] = F.ny, G.n[2] = F.nzg;
+    int nb[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nb[d] = (nc[d] + bc[d] - 1) / bc[d];
+    const int b3[3] = {blk % nb[0], (blk / nb[0]) % nb[1], blk / (nb[0] * nb[1])};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        G.per[d] = (F.per >> d) & 1;
+        G.I0[d] = b3[d] * bc[d];
+        G.I1[d] = min(G.I0[d] + bc[d], nc[d]);
+        if (G.n[d] == 2 * nc[d]) G.F0[d] = 2 * G.I0[d], G.F1[d] = 2 * G.I1[d];
+        else if (G.n[d] == nc[d]) G.F0[d] = G.I0[d], G.F1[d] = G.I1[d];
+        else {
+            G.F0[d] = F.t[d].fst[G.I0[d]];
+            G.F1[d] = G.I1[d] < nc[d] ? F.t[d].fst[G.I1[d]] : G.n[d];
+        }
+        int lo = G.F0[d] - grow_lo, hi = G.F1[d] + grow_hi;
+        if (!G.per[d]) lo = max(lo, 0), hi = min(hi, G.n[d]);
+        G.lo[d] = lo;
+        G.ext[d] = hi - lo;
+    }
+}
+// the one round of table loads
+__device__ __forceinline__ void sm_stage_tabs(const LevelDev &F, const LevelDev &C, const SmGeom &G, SmTabs &T)
+{
+    const double *cm[3] = {F.cmx, F.cmy, F.cmz}, *cp[3] = {F.cpx, F.cpy, F.cpz}, *rw[3] = {F.rwx, F.rwy, F.rwz}, *w[3] = {F.wx, F.wy, F.wz};
+    const int nc[3] = {C.nx, C.ny, C.nzg};
+    // (thread t: direction t / 64, entry t % 64 -- all of a table's loads in one wave's single pass; the direction as a
+    // compile-time constant of an unrolled loop: indexed by a runtime one the geometry would live in scratch memory)
+    const int dw = threadIdx.x >> 6, r = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (dw == d && r < G.ext[d]) {
+            const int s = sm_wrap(G.lo[d] + r, G.n[d]);
+            const Tr1 &tt = F.t[d];
+            const double a0 = cm[d][s], a1 = cp[d][s], a2 = rw[d][s], a3 = w[d][s], a4 = tt.wpar[s], a5 = tt.woth[s];
+            const int i0 = tt.par[s], i1 = tt.oth[s];
+            T.cm[d][r] = a0, T.cp[d][r] = a1, T.rw[d][r] = a2, T.w[d][r] = a3, T.wpar[d][r] = a4, T.woth[d][r] = a5;
+            T.par[d][r] = i0, T.oth[d][r] = i1;
+        }
+        if (dw == d + 3 && r <= G.I1[d] - G.I0[d] && G.I0[d] + r < nc[d]) T.fst[d][r] = F.t[d].fst[G.I0[d] + r];
+    }
+}
+// the thread's cells of the largest region (the same in every phase): coordinates packed as rx | ry << 8 | rz << 16, -1: none
+__device__ __forceinline__ void sm_cells(const SmGeom &G, int cell[SM_NB])
+{
+    const int cells = G.ext[0] * G.ext[1] * G.ext[2], e01 = G.ext[0] * G.ext[1];
+#pragma unroll
+    for (int u = 0; u < SM_NB; ++u) {
+        const int t = threadIdx.x + u * SM_NT;
+        if (t < cells) {
+            const int rz = t / e01, tr = t - rz * e01;
+            const int ry = tr / G.ext[0], rx = tr - ry * G.ext[0];
+            cell[u] = rx | (ry << 8) | (rz << 16);
+        } else
+            cell[u] = -1;
+    }
+}
+__device__ __forceinline__ int64_t sm_global(const LevelDev &F, const SmGeom &G, int c)
+{
+    const int i = sm_wrap(G.lo[0] + (c & 255), G.n[0]), j = sm_wrap(G.lo[1] + ((c >> 8) & 255), G.n[1]), k = sm_wrap(G.lo[2] + (c >> 16), G.n[2]);
+    return (int64_t)i + (int64_t)F.nx * (j + (int64_t)F.ny * (k - F.k0));
+}
+// One phase over the region's cells that lie `m` cells inside its unclipped faces (a clipped face is the domain's: no margin
+// there).  MODE 1: x = omega bs / d; 2: x' = x + omega (bs - t) / d; 3: r = b - (t wx wy) wz.  src / dst: LDS fields indexed
+// like the largest region; gdst (MODE 2 only): the owned cells' values go to global memory as well.
+template <int MODE>
+__device__ __forceinline__ void sm_phase(const LevelDev &F, const SmGeom &G, const SmTabs &T, const int cell[SM_NB], const double bq[SM_NB],
+                                         int grow_lo, int grow_hi, int m, double omega, const double *src, double *dst,
+                                         double *__restrict__ gdst)
+{
+    int a[3], e[3];  // the phase's box, relative to the region
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int lo = G.F0[d] - grow_lo + m, hi = G.F1[d] + grow_hi - m;
+        if (!G.per[d]) lo = max(lo, 0), hi = min(hi, G.n[d]);
+        a[d] = lo - G.lo[d];
+        e[d] = hi - lo;
+    }
+    const int sy = G.ext[0], sz = G.ext[0] * G.ext[1];
+    // Branch-free up to the store: the thread's cells are independent chains of LDS reads, ~20 dependent fp64 operations and a
+    // division -- as separate basic blocks (a `continue` per cell) they ran one after the other, 0.3 us each.  A cell outside
+    // the phase's box is evaluated all the same (at cell 0 if the thread has none: any finite or non-finite value will do)
+    // and not stored.
+    constexpr int GR = 3;  // cells evaluated together (all of them at once: 256 registers and a hundred spilled)
+#pragma unroll
+    for (int u0 = 0; u0 < SM_NB; u0 += GR) {
+    double v[GR];
+    int qv[GR];
+    bool st[GR];
+#pragma unroll
+    for (int uu = 0; uu < GR; ++uu) {
+        const int u = u0 + uu < SM_NB ? u0 + uu : SM_NB - 1;
+        const int c = cell[u] < 0 ? 0 : cell[u];
+        const int rx = c & 255, ry = (c >> 8) & 255, rz = c >> 16;
+        st[uu] = u0 + uu < SM_NB && cell[u] >= 0 && (unsigned)(rx - a[0]) < (unsigned)e[0] && (unsigned)(ry - a[1]) < (unsigned)e[1] &&
+                 (unsigned)(rz - a[2]) < (unsigned)e[2];
+        const int q = rx + sy * ry + sz * rz;
+        qv[uu] = q;
+        const double cxm = T.cm[0][rx], cxp = T.cp[0][rx], cym = T.cm[1][ry], cyp = T.cp[1][ry], czm = T.cm[2][rz], czp = T.cp[2][rz];
+        const double d = -(((((cxm + cxp) + cym) + cyp) + czm) + czp);
+        const double bv = bq[u];
+        const double bs = (bv * (T.rw[0][rx] * T.rw[1][ry])) * T.rw[2][rz];
+        if (MODE == 1) {
+            v[uu] = omega * (bs / d);
+        } else {
+            // a neighbour beyond the region: only at a clipped face, i.e. a wall -- zero coefficient, the centre's own value
+            const double xc = src[q];
+            double s = 0.0;
+            s += cxm * (src[rx > 0 ? q - 1 : q] - xc);
+            s += cxp * (src[rx < G.ext[0] - 1 ? q + 1 : q] - xc);
+            s += cym * (src[ry > 0 ? q - sy : q] - xc);
+            s += cyp * (src[ry < G.ext[1] - 1 ? q + sy : q] - xc);
+            s += czm * (src[rz > 0 ? q - sz : q] - xc);
+            s += czp * (src[rz < G.ext[2] - 1 ? q + sz : q] - xc);
+            if (MODE == 2) v[uu] = xc + omega * ((bs - s) / d);
+            else v[uu] = bv - (s * (T.w[0][rx] * T.w[1][ry])) * T.w[2][rz];
+        }
+    }
+#pragma unroll
+    for (int uu = 0; uu < GR; ++uu) {
+        if (!st[uu]) continue;
+        dst[qv[uu]] = v[uu];
+        if (MODE == 2 && gdst != nullptr) {
+            const int c = cell[u0 + uu < SM_NB ? u0 + uu : SM_NB - 1];
+            const int gx = G.lo[0] + (c & 255), gy = G.lo[1] + ((c >> 8) & 255), gz = G.lo[2] + (c >> 16);
+            if (gx >= G.F0[0] && gx < G.F1[0] && gy >= G.F0[1] && gy < G.F1[1] && gz >= G.F0[2] && gz < G.F1[2]) gdst[sm_global(F, G, c)] = v[uu];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// way down: b -> the pre-smoothed iterate x (owned cells) and the next level's right-hand side bc = P^T (b - A x)
+__global__ __launch_bounds__(SM_NT) void k_small_down(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega, int pre,
+                                                      const double *__restrict__ b, double *__restrict__ x, double *__restrict__ bc, int bcx,
+                                                      int bcy, int bcz)
+{
+    __shared__ double A_[SM_MAXR], B_[SM_MAXR];
+    __shared__ SmTabs T;
+#ifdef PIB_SMALL_STAMPS
+    unsigned long long st_[12]; int ns_ = 0;
+#define SST() do { st_[ns_++] = wall_clock64(); } while (0)
+#else
+#define SST() do { } while (0)
+#endif
+    SST();
+    const int done = (S != nullptr) ? S->done : 0;
+    // the residual on the owned children and one cell around them (two above: the fourth slot of the last coarse cell's
+    // restriction stencil), the iterate one cell beyond that, every earlier step one more
+    const int glo = 1 + pre, ghi = 2 + pre;
+    SmGeom G;
+    sm_geometry(F, C, blockIdx.x, bcx, bcy, bcz, glo, ghi, G);
+    if (done) return;
+    SST();
+    int cell[SM_NB];
+    double bq[SM_NB];
+    sm_cells(G, cell);
+#pragma unroll
+    for (int u = 0; u < SM_NB; ++u) bq[u] = cell[u] >= 0 ? b[sm_global(F, G, cell[u])] : 0.0;
+    sm_stage_tabs(F, C, G, T);
+    __syncthreads();
+    SST();
+    sm_phase<1>(F, G, T, cell, bq, glo, ghi, 0, omega, nullptr, A_, nullptr);
+    __syncthreads();
+    SST();
+    double *cur = A_, *oth = B_;
+    for (int sw = 1; sw < pre; ++sw) {
+        sm_phase<2>(F, G, T, cell, bq, glo, ghi, sw, omega, cur, oth, nullptr);
+        __syncthreads();
+        double *t = cur; cur = oth; oth = t;
+    }
+    SST();
+    sm_phase<3>(F, G, T, cell, bq, glo, ghi, pre, omega, cur, oth, nullptr);
+    // the owned cells of the iterate
+#pragma unroll
+    for (int u = 0; u < SM_NB; ++u) {
+        const int c = cell[u];
+        if (c < 0) continue;
+        const int gx = G.lo[0] + (c & 255), gy = G.lo[1] + ((c >> 8) & 255), gz = G.lo[2] + (c >> 16);
+        if (gx >= G.F0[0] && gx < G.F1[0] && gy >= G.F0[1] && gy < G.F1[1] && gz >= G.F0[2] && gz < G.F1[2])
+            x[sm_global(F, G, c)] = cur[(c & 255) + G.ext[0] * ((c >> 8) & 255) + G.ext[0] * G.ext[1] * (c >> 16)];
+    }
+    __syncthreads();
+    SST();
+    // restriction: one thread per owned coarse cell, the order of the sum as in k_restrict_rows / the tail
+    {
+        const double *r = oth;
+        const int e0 = G.I1[0] - G.I0[0], e1 = G.I1[1] - G.I0[1], e2 = G.I1[2] - G.I0[2];
+        const int sy = G.ext[0], sz = G.ext[0] * G.ext[1];
+        for (int t = threadIdx.x; t < e0 * e1 * e2; t += blockDim.x) {
+            const int tz = t / (e0 * e1), tr = t - tz * (e0 * e1);
+            const int ty = tr / e0, tx = tr - ty * e0;
+            const int Ic[3] = {G.I0[0] + tx, G.I0[1] + ty, G.I0[2] + tz};
+            const int Tc[3] = {tx, ty, tz};
+            double w[3][4];
+            int pos[3][4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int f0 = T.fst[d][Tc[d]] - 1;
+                const bool wrap = (F.tper >> d) & 1;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int fu = f0 + o;  // unwrapped: the region's coordinates
+                    const int ps = min(max(fu - G.lo[d], 0), G.ext[d] - 1);
+                    double wt = 0.0;
+                    if (wrap || (fu >= 0 && fu < G.n[d])) {
+                        if (T.par[d][ps] == Ic[d]) wt = T.wpar[d][ps];
+                        else if (T.oth[d][ps] == Ic[d]) wt = T.woth[d][ps];
+                    }
+                    w[d][o] = wt;
+                    pos[d][o] = ps;
+                }
+            }
+            // (no skipping of zero weights: a term of zero weight adds +-0 to a sum that is never -0, the residual is finite
+            // on the whole region -- and sixteen loads at a time are in flight instead of four behind a branch)
+            double sum = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                double rv[4][4];
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+                    for (int a2 = 0; a2 < 4; ++a2) rv[b2][a2] = r[sz * pos[2][c2] + sy * pos[1][b2] + pos[0][a2]];
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2) {
+                    const double wzy = w[2][c2] * w[1][b2];
+#pragma unroll
+                    for (int a2 = 0; a2 < 4; ++a2) sum += (wzy * w[0][a2]) * rv[b2][a2];
+                }
+            }
+            bc[(int64_t)Ic[0] + (int64_t)C.nx * (Ic[1] + (int64_t)C.ny * (Ic[2] - C.k0))] = sum;
+        }
+    }
+    SST();
+#ifdef PIB_SMALL_STAMPS
+    // tools: geometry | one round of loads | first step | further steps | residual + iterate out | restriction; 10 ns units
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {
+        static __device__ int launches_ = 0;
+        if (atomicAdd(&launches_, 1) % 60 == 30) {
+            printf("small-down n=%d,%d,%d blocks=%d blk=%d:", F.nx, F.ny, F.nzg, (int)gridDim.x, (int)blockIdx.x);
+            for (int q = 1; q < ns_; ++q) printf(" %llu", st_[q] - st_[q - 1]);
+            printf("\n");
+        }
+    }
+#endif
+#undef SST
+}
+
+// way up: out = `post` smoothing steps on x + P xc (owned cells)
+__global__ __launch_bounds__(SM_NT) void k_small_up(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega, int post,
+                                                    const double *__restrict__ b, const double *__restrict__ x, const double *__restrict__ xc,
+                                                    double *__restrict__ out, int bcx, int bcy, int bcz)
+{
+    __shared__ double A_[SM_MAXR], B_[SM_MAXR];
+    __shared__ SmTabs T;
+    const int done = (S != nullptr) ? S->done : 0;
+    SmGeom G;
+    sm_geometry(F, C, blockIdx.x, bcx, bcy, bcz, post, post, G);
+    if (done) return;
+    int cell[SM_NB];
+    double bq[SM_NB], xq[SM_NB];
+    sm_cells(G, cell);
+#pragma unroll
+    for (int u = 0; u < SM_NB; ++u) {
+        const int64_t p = cell[u] >= 0 ? sm_global(F, G, cell[u]) : 0;
+        bq[u] = cell[u] >= 0 ? b[p] : 0.0;
+        xq[u] = cell[u] >= 0 ? x[p] : 0.0;
+    }
+    sm_stage_tabs(F, C, G, T);
+    __syncthreads();
+    // the corrected iterate on the whole region
+    {
+        const int64_t cplane = (int64_t)C.nx * C.ny;
+#pragma unroll
+        for (int u = 0; u < SM_NB; ++u) {
+            const int c = cell[u];
+            if (c < 0) continue;
+            const int r3[3] = {c & 255, (c >> 8) & 255, c >> 16};
+            double sum = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const double wgt = ((c2 ? T.woth[2][r3[2]] : T.wpar[2][r3[2]]) * (b2 ? T.woth[1][r3[1]] : T.wpar[1][r3[1]])) *
+                                           (a2 ? T.woth[0][r3[0]] : T.wpar[0][r3[0]]);
+                        const int I = a2 ? T.oth[0][r3[0]] : T.par[0][r3[0]], J = b2 ? T.oth[1][r3[1]] : T.par[1][r3[1]],
+                                  K = c2 ? T.oth[2][r3[2]] : T.par[2][r3[2]];
+                        if (wgt != 0.0) sum += wgt * xc[I + (int64_t)C.nx * J + cplane * (K - C.k0)];
+                    }
+            A_[r3[0] + G.ext[0] * r3[1] + G.ext[0] * G.ext[1] * r3[2]] = xq[u] + sum;
+        }
+    }
+    __syncthreads();
+    double *cur = A_, *oth = B_;
+    for (int sw = 1; sw <= post; ++sw) {
+        sm_phase<2>(F, G, T, cell, bq, post, post, sw, omega, cur, oth, sw == post ? out : nullptr);
+        if (sw < post) __syncthreads();
+        double *t = cur; cur = oth; oth = t;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 // halo memory / deepest exchange of a distributed level (see "halos of a distributed level" below)
 constexpr int HALO_PAD_PLANES = 6;   // memory per side (the fused kernels read one plane beyond the run they process)
@@ -1784,6 +2130,41 @@ static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *
     return 0;
 }
 // `c` carries the coarse planes to produce in k0 / k1 (the owned ones, which may be a part of a replicated level)
+// the small-level kernels' box of coarse cells per workgroup (k_small_down: steps = pre, k_small_up: steps = post); false:
+// the level does not qualify
+static bool small_level_boxes(const pib_solver *s, const GridLevel &f, const GridLevel &c, int steps, bool down, int bc[3], unsigned *blocks)
+{
+    if (!s->cfg.fuse_small_levels || steps < 1 || steps > 2) return false;
+    if (f.nloc > (int64_t)s->cfg.small_level_cells || f.zring || c.zring) return false;
+    if (f.k0 != 0 || f.k1 != f.n[2] || c.k0 != 0 || c.k1 != c.n[2]) return false;  // both levels whole on this rank
+    if (f.per != f.tper) return false;
+    int nt = 0;
+    for (int d = 0; d < 3; ++d) nt += f.n[d] > 1 ? 1 : 0;
+    // a 3-D level pays 5-13 x in recomputed margins, all of it instruction issue on the workgroup's one CU
+    if (nt == 3 && f.nloc > (int64_t)s->cfg.small_level_cells_3d) return false;
+    // boxes of 4^3 coarse cells on a 3-D level; 8^2 on a 2-D one while that gives at most one workgroup per CU (the kernels
+    // hold one workgroup per CU: a second round of workgroups doubles the launch's time), else 16^2
+    for (int side = (nt == 3 ? 4 : 8);; side *= 2) {
+        int64_t cells = 1, nb = 1;
+        bool ok = true;
+        for (int d = 0; d < 3; ++d) {
+            if (f.t_fst[d] == nullptr || f.t_par[d] == nullptr) return false;
+            bc[d] = f.n[d] > 1 ? side : 1;
+            int e = 2 * bc[d] + (down ? 3 + 2 * steps : 2 * steps);  // aggregates of at most two cells
+            if (!((f.per >> d) & 1)) e = (int)std::min<int64_t>(e, f.n[d]);
+            if (e > SM_MAXE) ok = false;
+            cells *= e;
+            nb *= (c.n[d] + bc[d] - 1) / bc[d];
+        }
+        if (!ok || cells > SM_MAXR) return false;
+        if (nb <= 240 || nt == 3 || side >= SM_MAXBC) {
+            if (nb > 65535 * 16) return false;
+            *blocks = (unsigned)nb;
+            return true;
+        }
+    }
+}
+
 static int launch_restrict(const pib_solver *s, const GridLevel &f, const GridLevel &c, const double *rf, double *bc, const Scalars *S,
                            hipStream_t q)
 {
@@ -2658,6 +3039,23 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 s->gmg_upd.used = true;
             }
         }
+        // a small level that is whole on this rank: pre-smoothing, residual and restriction in one launch
+        {
+            GridLevel &cg1 = s->levels[(size_t)l + 1];
+            int bc3[3];
+            unsigned nblk = 0;
+            const bool local_pair = !I.dist && !li[(size_t)l + 1].dist && (s->comm.nranks == 1 || (g.replicated && cg1.replicated));
+            if (l >= 1 && !cheb && local_pair && small_level_boxes(s, g, cg1, pre, true, bc3, &nblk)) {
+                hipLaunchKernelGGL(k_small_down, dim3(nblk), dim3(SM_NT), 0, q, S, dev_of(g), dev_of(cg1), omega, pre, b, a, cg1.b + cg1.pad, bc3[0],
+                                   bc3[1], bc3[2]);
+                PIB_HIP(hipGetLastError());
+                set_valid(a, 0);
+                set_valid(cg1.b + cg1.pad, 0);
+                cur[(size_t)l] = a;
+                s->gmg_spare[(size_t)l] = c;
+                continue;
+            }
+        }
         // the right-hand side on as many ghost planes as the way down (and, on level 0, the way up) consumes
         const int Dd = down_depth(l);
         set_valid(b, 0);
@@ -2752,6 +3150,21 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             if (li[(size_t)l + 1].dist)
                 while (e > 0 && coarse_need(s, l, e) > li[(size_t)l + 1].maxd) --e;
             if (li[(size_t)l + 1].dist) PIB_CHK(need(l + 1, xc, coarse_need(s, l, e)));
+        }
+        {
+            // a small level whole on this rank: prolongation and the post-smoothing in one launch
+            int bc3[3];
+            unsigned nblk = 0;
+            const bool local_pair = !I.dist && !li[(size_t)l + 1].dist && (s->comm.nranks == 1 || (g.replicated && cg.replicated));
+            if (l >= 1 && !cheb && local_pair && small_level_boxes(s, g, cg, post, false, bc3, &nblk)) {
+                hipLaunchKernelGGL(k_small_up, dim3(nblk), dim3(SM_NT), 0, q, S, dev_of(g), dev_of(cg), omega, post, b, a, xc, c, bc3[0], bc3[1],
+                                   bc3[2]);
+                PIB_HIP(hipGetLastError());
+                set_valid(c, 0);
+                std::swap(a, c);
+                cur[(size_t)l] = a;
+                continue;
+            }
         }
         const bool dots_l = l == 0 && s->gmg_want_dots && !cheb;
         // prolongation + first post-smoothing step in one march (the corrected iterate never goes to HBM)

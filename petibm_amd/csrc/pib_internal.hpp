@@ -81,6 +81,9 @@ struct Config {
     int overlap_halo = 1;
     int overlap_min_bytes = 1 << 20;  // multigrid on slabs: a right-hand-side exchange of at least this size per neighbour runs on the communication stream behind the interior planes of its first consumer
     int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024; 0: off.
+    int fuse_small_levels = 1;  // gmg.hip: a small level's way down / way up in one launch each (k_small_down / k_small_up); 0: per-phase launches
+    int small_level_cells = 300000;  // ... levels of at most this many cells
+    int small_level_cells_3d = 40000;  // ... and of at most this many when the level is 3-D (the margins cost more there)
     int coarse_tail_lds = 1;  // ... with the tail levels' vectors and 1-D tables in LDS when they fit (gmg.hip: 83 -> 44 us per tail of a 448^2 mesh); 0: HBM
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.

@@ -569,6 +569,58 @@ def test_gmg_coarse_tail_forms_are_bit_identical(lin, case):
         assert np.array_equal(h, out[0][2])
 
 
+@pytest.mark.parametrize("case,pre,post", [("3d_stretched", 2, 2), ("3d_stretched", 1, 1), ("3d_odd", 2, 1), ("2d_stretched", 2, 2),
+                                           ("2d_uniform", 1, 2), ("3d_periodic_xz", 2, 2), ("2d_periodic", 2, 2), ("3d_periodic_all", 1, 1),
+                                           ("3d_64", 2, 2)])
+def test_gmg_small_level_kernels_are_bit_identical(lin, case, pre, post):
+    """k_small_down / k_small_up walk a small level's whole way down / up in one launch each, on boxes of coarse cells with
+    recomputed margins (pib_fuse_small_levels): the same bits as one launch per phase, with and without the single-workgroup
+    tail underneath."""
+    from petibm_amd import capi
+    per = None
+    if case == "3d_stretched":
+        cfg = stretched_3d((40, 36, 28))
+    elif case == "3d_odd":
+        cfg = omesh.uniform_config((37, 30, 21))
+    elif case == "2d_stretched":
+        cfg = STRETCHED_2D
+    elif case == "2d_uniform":
+        cfg = omesh.uniform_config((96, 80))
+    elif case == "3d_periodic_xz":
+        per = (True, False, True)
+        cfg = omesh.periodic_config((40, 24, 32), per)
+    elif case == "2d_periodic":
+        per = (True, True)
+        cfg = omesh.periodic_config((64, 48), per)
+    elif case == "3d_periodic_all":
+        per = (True, True, True)
+        cfg = omesh.periodic_config((32, 32, 32), per)
+    else:
+        cfg = omesh.uniform_config((64, 64, 64))
+    dt = 0.01
+    m = omesh.create_mesh(cfg)
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    xs, b = rhs_for(A)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    out = []
+    for fuse, tail in ((0, 0), (1, 0), (1, -1), (0, -1)):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post, extra=f"pib_fuse_small_levels={fuse}\npib_coarse_tail={tail}\n"))
+        if per is not None:
+            s.setPeriodic(per)
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        assert s.getReason() > 0
+        out.append((x, s.getIters(), s.getResidualHistory().copy()))
+        s.destroy()
+    for x, its, h in out[1:]:
+        assert its == out[0][1]
+        assert np.array_equal(h, out[0][2])
+        assert np.array_equal(x, out[0][0])
+
+
 def test_gmg_pcg_pinned_pressure_matches_oracle(lin):
     from petibm_amd import capi
     cfg = stretched_3d((20, 16, 12))
