@@ -2158,7 +2158,7 @@ static bool small_level_boxes(const pib_solver *s, const GridLevel &f, const Gri
         }
         if (!ok || cells > SM_MAXR) return false;
         if (nb <= 240 || nt == 3 || side >= SM_MAXBC) {
-            if (nb > 65535 * 16) return false;
+            if (nb > 256) return false;  // (more workgroups than CUs: the per-phase launches are faster)
             *blocks = (unsigned)nb;
             return true;
         }
@@ -3045,7 +3045,14 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             int bc3[3];
             unsigned nblk = 0;
             const bool local_pair = !I.dist && !li[(size_t)l + 1].dist && (s->comm.nranks == 1 || (g.replicated && cg1.replicated));
-            if (l >= 1 && !cheb && local_pair && small_level_boxes(s, g, cg1, pre, true, bc3, &nblk)) {
+            // (level 0 too -- a 2-D case's finest level is such a level -- unless its right-hand side needs the pinned row's
+            // correction or PCG's residual update folded in; the way up of level 0 keeps its launches: its last step delivers
+            // the Krylov sums in a fixed order of workgroups)
+            const bool level_ok = l >= 1 || (pin_l == nullptr && s->gmg_upd.w == nullptr);
+            if (level_ok && !cheb && local_pair && small_level_boxes(s, g, cg1, pre, true, bc3, &nblk)) {
+                if (l == 0) {  // no swaps on the way down: `post` swaps on the way up must end in z
+                    if (post % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
+                }
                 hipLaunchKernelGGL(k_small_down, dim3(nblk), dim3(SM_NT), 0, q, S, dev_of(g), dev_of(cg1), omega, pre, b, a, cg1.b + cg1.pad, bc3[0],
                                    bc3[1], bc3[2]);
                 PIB_HIP(hipGetLastError());
