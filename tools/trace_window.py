@@ -32,6 +32,22 @@ def main():
         a[1] += e - s
     print(f"# window {win / 1e6:.2f} ms, {len(sel)} launches, kernels busy {busy / 1e6:.2f} ms = {busy / win:.2f} of it"
           + (f"; per step: {win / 1e3 / steps:.1f} us wall, {len(sel) / steps:.1f} launches, {busy / 1e3 / steps:.1f} us of kernels" if steps else ""))
+    # idle time by the pair of kernels around it (gaps of more than 10 us)
+    gaps = {}
+    last_end = sel[0][1]
+    last_name = sel[0][2]
+    for s0, e0, n0 in sel[1:]:
+        g = s0 - last_end
+        if g > 10000:
+            a = gaps.setdefault((last_name[:60], n0[:60]), [0, 0])
+            a[0] += 1
+            a[1] += g
+        if e0 > last_end:
+            last_end, last_name = e0, n0
+    tot_gap = sum(v[1] for v in gaps.values())
+    print(f"# gaps > 10 us: {tot_gap / 1e6:.2f} ms in all" + (f" = {tot_gap / 1e3 / steps:.1f} us per step" if steps else ""))
+    for (a, b2), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"   {t / 1e6:8.2f} ms  {c:6d} x {t / c / 1e3:8.1f} us   after {a}  before {b2}")
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         per = f" {c / steps:6.1f}/step" if steps else ""
         print(f"{t / busy * 100:5.1f}%  {c:7d}{per}  avg {t / c / 1e3:7.2f} us  {n[:110]}")
