@@ -319,6 +319,27 @@ constexpr int FX = 128, FY = 8, FSX = FX + 2, FSY = FY + 2;
 #define PIB_WAVES_CAT(a, b) a##b
 #define PIB_WAVES_ATTR(n) PIB_WAVES_CAT(PIB_WAVES_ATTR_, n)
 
+// tile of this workgroup.  Workgroup b (in dispatch order: x fastest) runs on XCD b % 8; every XCD is dealt
+// a contiguous band of y-tiles (all x-tiles of it, z-chunk after z-chunk), so that the halo rows and columns two neighbouring
+// tiles both read are fetched by ONE L2 (profiles: k_presmooth2 reads 1.46 x its algorithmic bytes in the plain order)
+struct Tile3 {
+    int x, y, z;
+};
+template <bool BANDS = true>
+__device__ __forceinline__ Tile3 tile_of_block()
+{
+#ifndef PIB_NO_XCD_BANDS
+    const unsigned nbx = gridDim.x, nby = gridDim.y;
+    if (BANDS && (nby & 7u) == 0u) {
+        const unsigned id = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
+        const unsigned xcd = id & 7u, m = id >> 3, band = nby >> 3;
+        const unsigned r = m / nbx;
+        return {(int)(m - r * nbx), (int)(xcd * band + r % band), (int)(r / band)};
+    }
+#endif
+    return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+}
+
 // what a thread keeps of a cell column (i, j) across the planes: the scaled in-plane coefficients, their part of the
 // diagonal sum, 1 / (wx wy) and wx wy
 struct FCell {
@@ -359,7 +380,8 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     // processed planes: [L.k0, L.k0 + L.nk) (global); b / xo / ro point at the first of them.  A whole level, or a run of
     // planes of a z-slab whose right-hand side is valid one plane beyond the run on every side that has a neighbour.
-    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, k0 = L.k0 + blockIdx.z * FZ;
+    const Tile3 tb = tile_of_block();
+    const int i0 = tb.x * FX, j0 = tb.y * FY, k0 = L.k0 + tb.z * FZ;
     const int kend = min(k0 + FZ, L.k0 + L.nk);
     const int64_t plane = (int64_t)L.nx * L.ny;
     b -= (int64_t)L.k0 * plane;  // index by global plane below
@@ -468,7 +490,7 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
         }
         __syncthreads();
         if (tid < 2) {
-            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const int64_t blk = ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
             upart[(int64_t)tid * upart_stride + blk] = (ush[tid][0] + ush[tid][1]) + (ush[tid][2] + ush[tid][3]);
         }
     }
@@ -493,7 +515,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ?
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     // owned planes [L.k0, L.k0 + L.nk) of the level (a z-slab or a part of one); the vectors point at the first of them,
     // the planes below / above hold the neighbours' values (halo planes) where they exist
-    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, l0 = blockIdx.z * FZ;
+    const Tile3 tb = tile_of_block<MODE == 8>();
+    const int i0 = tb.x * FX, j0 = tb.y * FY, l0 = tb.z * FZ;
     const int64_t plane = (int64_t)L.nx * L.ny;
     const int j = j0 + ty, ic = i0 + 4 * tx;
     const int hy_row = (tid < 128) ? -1 : FY, hy_x = tid & 127;
@@ -593,7 +616,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ?
         __syncthreads();
         if (threadIdx.x == 0) {
             const int64_t nwg = (int64_t)gridDim.x * gridDim.y * gridDim.z;
-            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const int64_t blk = ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
             part[blk] = (sh0[0] + sh0[1]) + (sh0[2] + sh0[3]);
             for (int64_t e = blk + nwg; e < part_stride; e += nwg) part[e] = 0.0;
         }
@@ -611,7 +634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ?
         __syncthreads();
         if (threadIdx.x < 3) {
             const int k2 = threadIdx.x;
-            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const int64_t blk = ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
             part[(int64_t)k2 * part_stride + blk] = (sh[k2][0] + sh[k2][1]) + (sh[k2][2] + sh[k2][3]);
         }
     }
@@ -810,7 +833,8 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
     // relaxed planes: [F.k0, F.k0 + F.nk) (global) -- a whole level or a run of planes of a z-slab; b / xi / xo point at
     // the first of them, xc at coarse plane C.k0.  The planes one below / above the run are corrected too (they are the
     // z neighbours of the relaxation): the old iterate and the coarse planes they interpolate from must be valid there.
-    const int i0 = blockIdx.x * FX, j0 = blockIdx.y * FY, l0 = F.k0 + blockIdx.z * FZ;
+    const Tile3 tb = tile_of_block();
+    const int i0 = tb.x * FX, j0 = tb.y * FY, l0 = F.k0 + tb.z * FZ;
     const int I0 = i0 >> 1, J0 = j0 >> 1;
     const int64_t plane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
     b -= (int64_t)F.k0 * plane;  // index by global plane below
@@ -995,7 +1019,7 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
         __syncthreads();
         if (threadIdx.x < 3) {
             const int k2 = threadIdx.x;
-            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const int64_t blk = ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
             part[(int64_t)k2 * part_stride + blk] = (sh[k2][0] + sh[k2][1]) + (sh[k2][2] + sh[k2][3]);
         }
     }
@@ -1110,9 +1134,10 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
     __shared__ __attribute__((aligned(32))) double sp[2][RSY][RSX];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, tw = tid >> 6;
-    const int i0 = blockIdx.x * RX, j0 = blockIdx.y * RY;
-    const int I = blockIdx.x * (RX / 2) + lane, J = blockIdx.y * (RY / 2) + 2 * tw;  // coarse cells (I, J) and (I, J + 1)
-    const int KA = C.k0 + blockIdx.z * CZ, KB = min(KA + CZ, C.k0 + C.nk);          // coarse planes [KA, KB) (global)
+    const Tile3 tb = tile_of_block();
+    const int i0 = tb.x * RX, j0 = tb.y * RY;
+    const int I = tb.x * (RX / 2) + lane, J = tb.y * (RY / 2) + 2 * tw;  // coarse cells (I, J) and (I, J + 1)
+    const int KA = C.k0 + tb.z * CZ, KB = min(KA + CZ, C.k0 + C.nk);    // coarse planes [KA, KB) (global)
     const double4 rw = F.tx.rw[I];
     // transfers that reach across a periodic seam (F.tper): the tile's cells beyond the domain are the ones at the other
     // end (whole aligned pieces: nx % 128 == 0), plane -1 is plane nz - 1 (the whole level is here then)

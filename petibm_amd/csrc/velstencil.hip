@@ -576,6 +576,7 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
     if (S != nullptr && S->done) return;
     __shared__ double sp[2][VSY][VSX];
     const int b = blockIdx.x;
+    int tile_slot = b;
     double acc[2] = {0.0, 0.0};
     double *pa = DOT ? acc : nullptr;
     if (b < P.first[3]) {
@@ -584,7 +585,20 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
     } else {
         const int f = (b >= P.first[4]) + (b >= P.first[5]);
         const int lb = b - P.first[3 + f];
-        const int bx = lb % P.gx[f], by = (lb / P.gx[f]) % P.gy[f], bz = lb / (P.gx[f] * P.gy[f]);
+        int bx = lb % P.gx[f], by = (lb / P.gx[f]) % P.gy[f], bz = lb / (P.gx[f] * P.gy[f]);
+#ifndef PIB_NO_XCD_BANDS
+        // workgroups b, b + 8, ... share an XCD and its L2: each of the eight classes takes a contiguous band of y-tiles (all
+        // x-tiles of it, chunk of planes after chunk), so that the halo rows / columns neighbouring tiles both read are
+        // fetched from HBM once (gmg.hip: tile_of_block)
+        if ((P.gy[f] & 7) == 0) {
+            const int xcd = lb & 7, m = lb >> 3, band = P.gy[f] >> 3;
+            const int r = m / P.gx[f];
+            bx = m - r * P.gx[f];
+            by = xcd * band + r % band;
+            bz = r / band;
+        }
+#endif
+        tile_slot = P.first[3 + f] + bx + P.gx[f] * (by + P.gy[f] * bz);  // the sums stay with the tile: same order as ever
         if (P.edges) {
             if (P.v4[f]) vel_march_tile<true, true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
             else vel_march_tile<false, true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
@@ -605,7 +619,7 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
         }
         __syncthreads();
         if (threadIdx.x < 2 && (threadIdx.x == 0 || V.dot_mode == 2))
-            V.dot_part[(int64_t)threadIdx.x * V.dot_stride + b] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+            V.dot_part[(int64_t)threadIdx.x * V.dot_stride + tile_slot] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
     }
 }
 
