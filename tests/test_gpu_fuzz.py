@@ -335,3 +335,70 @@ def test_random_mesh_drop_in_route_on_slabs(seed):
     x = np.concatenate([r[0] for r in res])
     assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-11 * np.linalg.norm(b)
     assert len({r[1] for r in res}) == 1 and res[0][1] < 60
+
+
+def _multigrid_mesh(seed):
+    """Pressure grids for the multigrid's forms: 2-D and 3-D, one to three sub-domains per direction with their own
+    stretching, sizes that leave several levels (odd ones included), periodic directions at random."""
+    rng = np.random.default_rng(7000 + seed)
+    dim = 2 if seed % 2 else 3
+    lo_hi = (24, 90) if dim == 2 else (10, 40)
+    n, widths, per = [], [], []
+    for d in range(dim):
+        nsub = int(rng.integers(1, 4))
+        total = int(rng.integers(*lo_hi))
+        cuts = np.sort(rng.choice(np.arange(1, total), size=nsub - 1, replace=False)) if nsub > 1 else np.array([], dtype=int)
+        cells = np.diff(np.concatenate(([0], cuts, [total])))
+        w = []
+        for c in cells:
+            r = float(rng.choice([1.0, 1.0, 1.04, 0.95, 1.1]))
+            first = float(rng.uniform(0.5, 1.5))
+            w.extend(first * r ** np.arange(int(c)))
+        w = np.asarray(w) / np.sum(w)
+        p = bool(rng.uniform() < 0.3)
+        if p:
+            w = np.full(total, 1.0 / total)  # (a periodic direction: uniform, as the reference's periodic cases are)
+        n.append(total)
+        widths.append(w)
+        per.append(p)
+    return dim, n, widths, per
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("PIB_FUZZ_SEEDS", "16")))))
+def test_random_mesh_multigrid_forms_are_bit_identical(seed):
+    """The V-cycle's latency-bound bottom has several forms -- one launch per phase, the fused small-level kernels
+    (k_small_down / k_small_up), the single-workgroup tail in HBM or in LDS, one or several cells per thread: on random
+    meshes every form must give the bits of the per-phase launches, and the solve must reach its tolerance."""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    from test_gpu_parity import gmg_cfg
+    dim, n, w, per = _multigrid_mesh(seed)
+    rng = np.random.default_rng(seed)
+    pre, post = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    dt = 0.01
+    N = int(np.prod(n))
+    b = rng.uniform(-1, 1, N)
+    b -= b.mean()
+    out = []
+    res = None
+    forms = ((0, 0, 0), (1, 0, 0), (1, 1024, 0), (1, 1024, 1), (0, 1024, 1), (1, 4096, 1), (1, 200, 1))
+    for fuse, tail, lds in forms:
+        s = LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post, extra=f"pib_fuse_small_levels={fuse}\npib_coarse_tail={tail}\n"
+                                                                                 f"pib_coarse_tail_lds={lds}\n"))
+        if any(per):
+            s.setPeriodic(per)
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(N)
+        s.solve(x, b)
+        assert s.getReason() > 0, (seed, fuse, tail, lds)
+        out.append((x, s.getIters(), s.getResidualHistory().copy()))
+        if res is None:  # the true residual, with the assembled operator (the device's own CSR product)
+            Ax = np.zeros(N)
+            s.matMult(x, Ax)
+            res = np.linalg.norm(b - Ax) / np.linalg.norm(b)
+        s.destroy()
+    assert res <= 2e-10
+    for form, (x, its, h) in zip(forms[1:], out[1:]):
+        assert its == out[0][1], (seed, form)
+        assert np.array_equal(h, out[0][2]), (seed, form)
+        assert np.array_equal(x, out[0][0]), (seed, form)
