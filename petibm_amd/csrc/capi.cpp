@@ -130,6 +130,7 @@ int pib_destroy(pib_solver *s)
     if (s->d_spmv_part) (void)hipFree(s->d_spmv_part);
     if (s->d_gmg_part) (void)hipFree(s->d_gmg_part);
     if (s->d_hist) (void)hipFree(s->d_hist);
+    if (s->h_hist) (void)hipHostFree(s->h_hist);
     comm_release(s);
     if (s->ev_a) (void)hipEventDestroy(s->ev_a);
     if (s->ev_b) (void)hipEventDestroy(s->ev_b);

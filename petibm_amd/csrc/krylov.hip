@@ -677,19 +677,36 @@ static int init_scalars(pib_solver *s)
         if (s->d_hist) PIB_HIP(hipFree(s->d_hist));
         s->hist_cap = s->cfg.max_iters + 3;
         PIB_HIP(hipMalloc(&s->d_hist, (size_t)s->hist_cap * sizeof(double)));
+        if (s->h_hist) (void)hipHostFree(s->h_hist);
+        s->h_hist = nullptr;
+        PIB_HIP(hipHostMalloc(&s->h_hist, (size_t)s->hist_cap * sizeof(double)));
     }
     return 0;
 }
 
-static int fetch_results(pib_solver *s)
+// Host round trips of a solve.  Each is a stream synchronisation -- 15-30 us of wake-up latency during which the GPU idles
+// -- and a small system inside a time loop (the reference's 2-D cases: three solves of a few iterations per step) used to
+// make four of them per solve: the state after the set-up kernels, the state after the first batch of iterations, the final
+// state, the residual history.  Now two: the first poll is skipped when the previous solve of this solver iterated (the
+// batch is then the previous count, its iterations guarded by the device's `done` flag, so enqueuing them blind costs
+// nothing but empty launches in the rare case that the set-up already met the tolerance), and the final state comes with
+// the history in one synchronisation (`enq` bounds the entries).
+static int first_poll(pib_solver *s)
 {
+    if (s->cfg.check_every <= 0 && s->hint_iters >= 1 && s->cfg.max_iters >= 1) return 0;  // (h_s->done is 0: reset_scalars)
+    return poll(s);
+}
+static int fetch_results(pib_solver *s, int enq)
+{
+    const size_t entries = (size_t)std::min<int64_t>((int64_t)enq + 2, (int64_t)s->hist_cap);
+    PIB_HIP(hipMemcpyAsync(s->h_hist, s->d_hist, sizeof(double) * entries, hipMemcpyDeviceToHost, s->stream));
     PIB_CHK(poll(s));
     s->iters = s->h_s->its;
     s->hint_iters = s->iters;
     s->reason = s->h_s->reason;
     s->residual = s->h_s->dp;
-    s->history.assign((size_t)s->iters + 1, 0.0);
-    PIB_HIP(hipMemcpy(s->history.data(), s->d_hist, sizeof(double) * (size_t)(s->iters + 1), hipMemcpyDeviceToHost));
+    if ((size_t)s->iters + 1 > entries) return fail(PIB_ERR_LIB, "solver %s: %d iterations recorded, %d enqueued", s->name.c_str(), s->iters, enq);
+    s->history.assign(s->h_hist, s->h_hist + s->iters + 1);
     return 0;
 }
 
@@ -813,7 +830,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     int enq = 0;
     const int maxit = s->cfg.max_iters;
     double *part_pw = s->d_part + (int64_t)SLOT_PW * PIB_MAXPART;
-    PIB_CHK(poll(s));
+    PIB_CHK(first_poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         auto body = [&]() -> int {
@@ -881,7 +898,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                        s->d_s, n, P, x);
     hipLaunchKernelGGL(k_flush_done, dim3(1), dim3(1), 0, q, s->d_s);
     PIB_HIP(hipGetLastError());
-    return fetch_results(s);
+    return fetch_results(s, enq);
 }
 
 }  // namespace pib
@@ -1374,7 +1391,7 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
         PIB_CHK(launch_vec(s, n, y0, v2, 0, nullptr, false, q));
     }
     int enq = 0;
-    PIB_CHK(poll(s));
+    PIB_CHK(first_poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         // reduce the partial sums of `nslots` slots and run scalar step POST: one launch on one rank, with the all-reduce
@@ -1488,7 +1505,7 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
         hipLaunchKernelGGL(k_b_flush_done, dim3(1), dim3(1), 0, q, s->d_s);
         PIB_HIP(hipGetLastError());
     }
-    return fetch_results(s);
+    return fetch_results(s, enq);
 }
 
 }  // namespace pib

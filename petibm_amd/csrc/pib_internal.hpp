@@ -370,6 +370,7 @@ struct pib_solver {
         bool used = false;
     } gmg_upd;
     double *d_hist = nullptr;
+    double *h_hist = nullptr;  // its pinned host copy (fetched with the final scalars in one synchronisation)
     int hist_cap = 0;
     hipGraphExec_t graph = nullptr;   // one Krylov iteration (krylov.hip: run_iterations)
     uint64_t graph_key = 0;           // the (method, x, b) it was captured for
