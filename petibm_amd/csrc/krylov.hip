@@ -339,14 +339,20 @@ struct OpUpdateP {
 };
 
 // the x update still owed when the iteration stops: x += a p
+// (if_done: launched speculatively after the first batch of iterations -- acts only if the solve has stopped, see solve_cg)
 __global__ __launch_bounds__(256) void k_flush_x(const Scalars *__restrict__ S, int64_t n, const double *__restrict__ p,
-                                                 double *__restrict__ x)
+                                                 double *__restrict__ x, int if_done)
 {
+    if (if_done && !S->done) return;
     if (S->xa_it == S->xapplied) return;
     const double a = S->a;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = x[i] + a * p[i];
 }
-__global__ void k_flush_done(Scalars *S) { S->xapplied = S->xa_it; }
+__global__ void k_flush_done(Scalars *S, int if_done)
+{
+    if (if_done && !S->done) return;
+    S->xapplied = S->xa_it;
+}
 
 struct OpCopy {
     static constexpr int NRED = 0;
@@ -830,6 +836,12 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     int enq = 0;
     const int maxit = s->cfg.max_iters;
     double *part_pw = s->d_part + (int64_t)SLOT_PW * PIB_MAXPART;
+    // the x update the last iteration owes
+    auto flush = [&](int if_done) {
+        hipLaunchKernelGGL(k_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
+                           s->d_s, n, P, x, if_done);
+        hipLaunchKernelGGL(k_flush_done, dim3(1), dim3(1), 0, q, s->d_s, if_done);
+    };
     PIB_CHK(first_poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
@@ -890,14 +902,18 @@ int solve_cg(pib_solver *s, double *x, const double *b)
             return 0;
         };
         PIB_CHK(run_iterations(s, todo, enq, graph_key(1, x, b), q, body));
+        const bool first = enq == 0;
         enq += todo;
-        PIB_CHK(poll(s));
+        if (first) {
+            // the usual case inside a time loop: this batch was the whole solve.  The closing kernels go out behind it, acting
+            // only if the device has set `done`, and ONE synchronisation brings the final state and the history
+            flush(1);
+            PIB_CHK(fetch_results(s, enq));
+            if (s->h_s->done) return 0;
+        } else
+            PIB_CHK(poll(s));
     }
-    // the x update the last iteration owes
-    hipLaunchKernelGGL(k_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
-                       s->d_s, n, P, x);
-    hipLaunchKernelGGL(k_flush_done, dim3(1), dim3(1), 0, q, s->d_s);
-    PIB_HIP(hipGetLastError());
+    flush(0);
     return fetch_results(s, enq);
 }
 
@@ -1155,8 +1171,9 @@ struct OpBFUpdateR {  // r = s - omega t ; partials |r|^2 (0), r.rp (1)
 // (y != nullptr: x = x0 + M^-1 (y + what is owed), see OpBFUpdateP)
 __global__ __launch_bounds__(256) void k_b_flush_x(Scalars *__restrict__ S, int64_t n, const double *__restrict__ p,
                                                    const double *__restrict__ sv, const double *__restrict__ dinv, double omega_pc,
-                                                   double *__restrict__ x, const double *__restrict__ y)
+                                                   double *__restrict__ x, const double *__restrict__ y, int if_done)
 {
+    if (if_done && !S->done) return;
     const int pend = S->xpend;
     if (!pend && y == nullptr) return;
     const double xa = S->xalpha, xo = S->xomega;
@@ -1172,7 +1189,11 @@ __global__ __launch_bounds__(256) void k_b_flush_x(Scalars *__restrict__ S, int6
         }
     }
 }
-__global__ void k_b_flush_done(Scalars *S) { S->xpend = 0; }
+__global__ void k_b_flush_done(Scalars *S, int if_done)
+{
+    if (if_done && !S->done) return;
+    S->xpend = 0;
+}
 
 __global__ void k_b_s_init(Scalars *S, double *hist, int monitor)
 {
@@ -1391,6 +1412,13 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
         PIB_CHK(launch_vec(s, n, y0, v2, 0, nullptr, false, q));
     }
     int enq = 0;
+    // the x update the last iteration owes (lean recurrences only)
+    auto flush = [&](int if_done) {
+        if (!lean) return;
+        hipLaunchKernelGGL(k_b_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
+                           s->d_s, n, P, S, dv, opc, x, (const double *)Y, if_done);
+        hipLaunchKernelGGL(k_b_flush_done, dim3(1), dim3(1), 0, q, s->d_s, if_done);
+    };
     PIB_CHK(first_poll(s));
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
@@ -1496,15 +1524,16 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
             return 0;
         };
         PIB_CHK(run_iterations(s, todo, enq, graph_key(2, x, b), q, body));
+        const bool first = enq == 0;
         enq += todo;
-        PIB_CHK(poll(s));
+        if (first) {  // (as in solve_cg: closing kernels behind the first batch, one synchronisation if that was the solve)
+            flush(1);
+            PIB_CHK(fetch_results(s, enq));
+            if (s->h_s->done) return 0;
+        } else
+            PIB_CHK(poll(s));
     }
-    if (lean) {  // the x update the last iteration owes
-        hipLaunchKernelGGL(k_b_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
-                           s->d_s, n, P, S, dv, opc, x, (const double *)Y);
-        hipLaunchKernelGGL(k_b_flush_done, dim3(1), dim3(1), 0, q, s->d_s);
-        PIB_HIP(hipGetLastError());
-    }
+    flush(0);
     return fetch_results(s, enq);
 }
 
