@@ -383,7 +383,7 @@ int ib_solve_forces(pib_ns *ns)
     hipLaunchKernelGGL(k_ib_interp, dim3(blocks_for(nf)), dim3(256), 0, ns->stream, nf, ib->rowptr, ib->col, ib->eval, ns->U,
                        ib->moving ? ib->ub : (const double *)nullptr, ib->rhsf);
     PIB_HIP(hipGetLastError());
-    PIB_HIP(hipStreamSynchronize(ns->stream));
+    PIB_CHK(ns_before_solve(ns, ib->fsol));
     PIB_CHK(pib_solve(ib->fsol, ib->df, ib->rhsf));  // fSolver->solve(df, rhsf)  (decoupledibpm.cpp:267)
     return ib_bnh_mult_add(ns, ib->df, ns->U, ns->stream);  // MatMultAdd(BNH, df, U, U)  (:283-284)
 }

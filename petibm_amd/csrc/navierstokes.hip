@@ -651,6 +651,16 @@ int ns_div_sub(pib_ns *ns, const double *t, double *w, hipStream_t q)
 
 static int ghost_blocks(const pib::NsDev &D) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (D.nghost + 255) / 256)); }
 
+namespace pib {
+int ns_before_solve(pib_ns *ns, pib_solver *sol)
+{
+    PIB_HIP(hipEventRecord(ns->ev_dep, ns->stream));
+    PIB_HIP(hipStreamWaitEvent(sol->stream, ns->ev_dep, 0));
+    return 0;
+}
+
+}  // namespace pib
+
 extern "C" {
 
 int pib_ns_destroy(pib_ns *ns)
@@ -668,6 +678,7 @@ int pib_ns_destroy(pib_ns *ns)
     if (ns->bn_rowptr) (void)hipFree(ns->bn_rowptr);
     if (ns->bn_col) (void)hipFree(ns->bn_col);
     if (ns->bn_val) (void)hipFree(ns->bn_val);
+    if (ns->ev_dep) (void)hipEventDestroy(ns->ev_dep);
     if (ns->stream) (void)hipStreamDestroy(ns->stream);
     delete ns;
     return 0;
@@ -807,6 +818,7 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     ns->device = ns->vsol->device;
     PIB_HIP(hipSetDevice(ns->device));
     PIB_HIP(hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking));
+    PIB_HIP(hipEventCreateWithFlags(&ns->ev_dep, hipEventDisableTiming));
     // ghost-equation tables: ghost = a0*target + a1
     double a0[18], gdl[18];
     int btype[18];
@@ -1380,12 +1392,12 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
             // the solver's vectors are the packed owned points; afterwards the neighbours' planes of u* (DMGlobalToLocal)
             PIB_CHK(ns_pack(ns, ns->rhs1, ns->rhs1pk));
             PIB_CHK(ns_pack(ns, ns->U, ns->Upk));
-            PIB_HIP(hipStreamSynchronize(ns->stream));
+            PIB_CHK(ns_before_solve(ns, ns->vsol));
             PIB_CHK(pib_solve(ns->vsol, ns->Upk, ns->rhs1pk));
             PIB_CHK(ns_unpack(ns, ns->Upk, ns->U));
             PIB_CHK(ns_halo_velocity(ns, ns->U));
         } else {
-        PIB_HIP(hipStreamSynchronize(ns->stream));
+        PIB_CHK(ns_before_solve(ns, ns->vsol));
         PIB_CHK(pib_solve(ns->vsol, ns->U, ns->rhs1));  // vSolver->solve(UGlobal, rhs1)  (:532)
         }
         const bool coupled = ib_is_coupled(ns);
@@ -1404,7 +1416,7 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
             ns->steps++;
             continue;
         }
-        PIB_HIP(hipStreamSynchronize(ns->stream));
+        PIB_CHK(ns_before_solve(ns, ns->psol));
         {
             const int64_t own = (ns->slab_pk0 - ns->slab_e0) * ns->p_plane;  // the owned cells are contiguous in the extended slab
             PIB_CHK(pib_solve(ns->psol, ns->dP + own, ns->rhs2 + own));  // pSolver->solve(dP, rhs2)      (:575)

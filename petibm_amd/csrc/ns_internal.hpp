@@ -71,6 +71,9 @@ int ns_bng_apply(pib_ns *ns, const double *phi, double *out, hipStream_t q);
 int ns_div_sub(pib_ns *ns, const double *t, double *w, hipStream_t q);
 // the extra stages of DecoupledIBPMSolver::advance (decoupledibpm.cpp:105-131)
 int ib_spread_forces(pib_ns *ns);   // rhs1 += H f
+// what the engine's stream has enqueued so far must be done before `sol` starts: an event the solver's stream waits for --
+// not a host synchronisation (three per time step, each an idle gap of 15-20 us on the GPU)
+int ns_before_solve(pib_ns *ns, pib_solver *sol);
 int ib_solve_forces(pib_ns *ns);    // rhsf = -E u ; EBNH df = rhsf ; u += BNH df
 int ib_update_forces(pib_ns *ns);   // f += df
 
@@ -80,6 +83,7 @@ struct pib_ns {
     pib::NsDev D;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_dep = nullptr;  // what a solver's stream waits for before a solve (instead of a host synchronisation)
     pib_solver *vsol = nullptr, *psol = nullptr;
     double dt = 0, nu = 0;
     double *U = nullptr, *p = nullptr, *dP = nullptr, *rhs1 = nullptr, *rhs2 = nullptr, *conv[2] = {nullptr, nullptr};
@@ -120,4 +124,3 @@ struct pib_ns {
     std::vector<double> h_w[3];
     double h_a0[18] = {0};
 };
-
