@@ -699,7 +699,7 @@ static int init_scalars(pib_solver *s)
 // the history in one synchronisation (`enq` bounds the entries).
 static int first_poll(pib_solver *s)
 {
-    if (s->cfg.check_every <= 0 && s->hint_iters >= 1 && s->cfg.max_iters >= 1) return 0;  // (h_s->done is 0: reset_scalars)
+    if (s->cfg.check_every <= 0 && s->hint_iters >= 1 && s->cfg.max_iters >= 1) return 0;  // (h_s->done is 0: init_scalars)
     return poll(s);
 }
 static int fetch_results(pib_solver *s, int enq)
