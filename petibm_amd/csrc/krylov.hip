@@ -697,10 +697,9 @@ static int init_scalars(pib_solver *s)
 // batch is then the previous count, its iterations guarded by the device's `done` flag, so enqueuing them blind costs
 // nothing but empty launches in the rare case that the set-up already met the tolerance), and the final state comes with
 // the history in one synchronisation (`enq` bounds the entries).
-static int first_poll(pib_solver *s)
+static bool skip_first_poll(const pib_solver *s)
 {
-    if (s->cfg.check_every <= 0 && s->hint_iters >= 1 && s->cfg.max_iters >= 1) return 0;  // (h_s->done is 0: init_scalars)
-    return poll(s);
+    return s->cfg.check_every <= 0 && s->hint_iters >= 1 && s->cfg.max_iters >= 1;  // (h_s->done is 0: init_scalars)
 }
 static int fetch_results(pib_solver *s, int enq)
 {
@@ -842,7 +841,13 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                            s->d_s, n, P, x, if_done);
         hipLaunchKernelGGL(k_flush_done, dim3(1), dim3(1), 0, q, s->d_s, if_done);
     };
-    PIB_CHK(first_poll(s));
+    if (!skip_first_poll(s)) {
+        // the state after the set-up kernels; if they already met the tolerance (a time loop near its steady state) the closing
+        // kernels have gone out with the poll and this was the solve
+        flush(1);
+        PIB_CHK(fetch_results(s, 0));
+        if (s->h_s->done) return 0;
+    }
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         auto body = [&]() -> int {
@@ -1419,7 +1424,11 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
                            s->d_s, n, P, S, dv, opc, x, (const double *)Y, if_done);
         hipLaunchKernelGGL(k_b_flush_done, dim3(1), dim3(1), 0, q, s->d_s, if_done);
     };
-    PIB_CHK(first_poll(s));
+    if (!skip_first_poll(s)) {  // (as in solve_cg)
+        flush(1);
+        PIB_CHK(fetch_results(s, 0));
+        if (s->h_s->done) return 0;
+    }
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         // reduce the partial sums of `nslots` slots and run scalar step POST: one launch on one rank, with the all-reduce
