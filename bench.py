@@ -296,12 +296,13 @@ def random_rhs_solution(n: int, k0: int, k1: int) -> np.ndarray:
 #   CSR SpMV 104 (12 nnz/n + 4 + 16) ; x += a p (owed by the previous iteration) and p = z + beta p in one pass 40 ;
 #   r -= a w + sums: inside the V-cycle's first march, which reads w beside r and writes the new r beside x: 16 (24 as a pass of
 #   its own before the end of round 2) ;
-#   V(2,2) cycle on the fine level: two pre-smoothing steps from zero 16 (b read, x written), residual 24, restriction
-#   8 + 1, prolongation + first post-smoothing step 24 + 1, second post-smoothing step (+ the Krylov sums) 24 = 98,
-#   times 8/7 for the coarser levels = 112.            Sum: 272 B per row and iteration (280 with the separate pass).
-def solve_bytes_per_row_iter(pre: int, post: int, nnz_per_row: float) -> float:
+#   V(2,2) cycle on the fine level: two pre-smoothing steps from zero 16 (b read, x written), residual + restriction in one
+#   march 16 + 1 (b and x read, the coarse right-hand side written; 24 + 8 + 1 as two kernels, until late in round 3),
+#   prolongation + first post-smoothing step 24 + 1, second post-smoothing step (+ the Krylov sums) 24 = 82 (98),
+#   times 8/7 for the coarser levels = 94 (112).       Sum: 254 B per row and iteration (272 with the residual through HBM).
+def solve_bytes_per_row_iter(pre: int, post: int, nnz_per_row: float, fused_residual_restrict: bool = True) -> float:
     spmv = 12.0 * nnz_per_row + 4.0 + 16.0
-    down = (16.0 if pre >= 2 else 8.0 + 8.0) + 24.0 * max(pre - 2, 0) + 24.0 + 9.0
+    down = (16.0 if pre >= 2 else 8.0 + 8.0) + 24.0 * max(pre - 2, 0) + (17.0 if fused_residual_restrict and pre >= 2 else 24.0 + 9.0)
     up = (25.0 if post >= 1 else 17.0) + 24.0 * max(post - 1, 0)
     return spmv + 40.0 + 16.0 + (down + up) * 8.0 / 7.0
 
@@ -602,7 +603,8 @@ def poisson_bench(args) -> int:
             # the whole solve against the roofline: algorithmic bytes of every kernel of an iteration (model in
             # solve_bytes_per_row_iter; the initial residual + V-cycle count as one more iteration) / the measured time.
             # Several ranks: all rows against the ranks' combined peak (the slabs' redundant ghost planes are not counted).
-            bpr = solve_bytes_per_row_iter(args.presweeps, args.postsweeps, nnz_l / n_l)
+            bpr = solve_bytes_per_row_iter(args.presweeps, args.postsweeps, nnz_l / n_l,
+                                           "pib_fuse_residual_restrict=0" not in args.extra_config and world == 1)
             per_solve = iters / args.steps + 1.0
             gbs = bpr * pN * per_solve / (elapsed / args.steps) / 1e9
             out["roofline_solve"] = {"bound": "hbm", "bytes_per_row_per_iteration": bpr, "iterations_counted": per_solve,

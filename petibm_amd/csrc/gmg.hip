@@ -1245,6 +1245,210 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
     }
 }
 
+// ---- residual + restriction in one march (fully paired 3-D levels that are whole on this rank): bc = P^T (b - A x).
+// As two kernels the residual goes to HBM and comes back (k_level_march<3>: 24 B per fine cell, k_restrict_march: 9); here
+// a workgroup walks up through the fine planes of its 128 x 16 tile like k_restrict_march, but what it stages in LDS is the
+// ITERATE's plane (tile + two cells around it), from which every thread computes the residual of the cells it loaded --
+// their z neighbours are its own registers, the plane below / the plane / the plane above -- into the LDS tile the
+// restriction part reads: b and x are read once (~17 B per fine cell with the halos), nothing but the coarse right-hand
+// side is written.  The residual's expression and the restriction's order of summation are those of k_level_march<3> /
+// k_restrict_march: the same bits.
+constexpr int QSY = RSY + 2;                 // rows of the iterate's tile: the residual's rows and one more on either side
+constexpr int QV4 = (RSX / 4) * QSY;         // its aligned 4-cell pieces (680: up to three per thread)
+__global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
+                                                              const double *__restrict__ b, const double *__restrict__ x,
+                                                              double *__restrict__ bc, int CZ)
+{
+    if (S != nullptr && S->done) return;
+    __shared__ __attribute__((aligned(32))) double xs[QSY][RSX];   // the iterate on the current plane: cols i0-4 .. i0+131, rows j0-2 .. j0+17
+    __shared__ __attribute__((aligned(32))) double rs[RSY][RSX];   // its residual: rows j0-1 .. j0+16
+    __shared__ double tcx[3][RSX], tcy[3][QSY];                    // cm, cp, w of the tile's columns and rows
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, tw = tid >> 6;
+    const Tile3 tb = tile_of_block();
+    const int i0 = tb.x * RX, j0 = tb.y * RY;
+    const int I = tb.x * (RX / 2) + lane, J = tb.y * (RY / 2) + 2 * tw;  // coarse cells (I, J) and (I, J + 1)
+    const int KA = C.k0 + tb.z * CZ, KB = min(KA + CZ, C.k0 + C.nk);    // coarse planes [KA, KB)
+    const double4 rw = F.tx.rw[I];
+    const bool wx = F.tper & 1, wy = F.tper & 2, wz = F.tper & 4;       // (the caller checks per == tper)
+    double wj[2][4];
+    {
+        int sj[4];
+        rs1d4(F.t[1], J, F.ny, wy, wj[0], sj);
+        rs1d4(F.t[1], J + 1, F.ny, wy, wj[1], sj);
+    }
+    const int64_t fplane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
+    // the tile's 1-D coefficients (zero beyond the domain: such cells carry no residual)
+    for (int e = tid; e < RSX; e += 256) {
+        int gi = i0 - 4 + e;
+        if (wx) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
+        const bool in = gi >= 0 && gi < F.nx;
+        tcx[0][e] = in ? F.cmx[gi] : 0.0;
+        tcx[1][e] = in ? F.cpx[gi] : 0.0;
+        tcx[2][e] = in ? F.wx[gi] : 0.0;
+    }
+    if (tid < QSY) {
+        int gj = j0 - 2 + tid;
+        if (wy) gj = gj < 0 ? gj + F.ny : (gj >= F.ny ? gj - F.ny : gj);
+        const bool in = gj >= 0 && gj < F.ny;
+        tcy[0][tid] = in ? F.cmy[gj] : 0.0;
+        tcy[1][tid] = in ? F.cpy[gj] : 0.0;
+        tcy[2][tid] = in ? F.wy[gj] : 0.0;
+    }
+    // this thread's share of a plane: up to three aligned 4-cell pieces of the iterate's tile (zero outside the domain);
+    // a piece in the rows 1 .. RSY of that tile also carries the residual of its cells (and reads b there)
+    int64_t goff[3];
+    int prow[3], pcol[3];
+    bool ok[3], mine[3], res[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int idx = tid + 256 * e, row = idx / (RSX / 4), cx = idx - row * (RSX / 4);
+        int gi = i0 - 4 + 4 * cx, gj = j0 - 2 + row;
+        if (wx) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
+        if (wy) gj = gj < 0 ? gj + F.ny : (gj >= F.ny ? gj - F.ny : gj);
+        mine[e] = idx < QV4;
+        ok[e] = mine[e] && gi >= 0 && gi < F.nx && gj >= 0 && gj < F.ny;
+        res[e] = ok[e] && row >= 1 && row <= RSY;
+        goff[e] = (int64_t)gj * F.nx + gi;
+        prow[e] = row;
+        pcol[e] = 4 * cx;
+    }
+    const int kf0 = 2 * KA - 1, kf1 = 2 * (KB - 1) + 2;  // fine planes that feed [KA, KB) (both ends inclusive)
+    const v4 zero = {0, 0, 0, 0};
+    auto zwrap = [&](int kf) { return wz ? (kf < 0 ? kf + F.nzg : (kf >= F.nzg ? kf - F.nzg : kf)) : kf; };
+    auto inz = [&](int kf) { return wz || (kf >= 0 && kf < F.nzg); };
+    auto fetch_x = [&](int kf, v4 out[3]) {
+        const bool in = inz(kf);
+        const double *pf = x + (int64_t)(zwrap(kf) - F.k0) * fplane;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) out[e] = (in && ok[e]) ? *reinterpret_cast<const v4 *>(pf + goff[e]) : zero;
+    };
+    auto fetch_b = [&](int kf, v4 out[3]) {
+        const bool in = inz(kf);
+        const double *pf = b + (int64_t)(zwrap(kf) - F.k0) * fplane;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) out[e] = (in && res[e]) ? *reinterpret_cast<const v4 *>(pf + goff[e]) : zero;
+    };
+    auto put_x = [&](const v4 v[3]) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (mine[e]) *reinterpret_cast<v4 *>(&xs[prow[e]][pcol[e]]) = v[e];
+    };
+    // the iterate of the thread's pieces on the planes kf - 1, kf, kf + 1, the plane kf + 2 and the right-hand side of plane
+    // kf + 1 on their way
+    v4 xm[3], xc[3], xp[3], xn[3], bcur[3], bnext[3];
+    fetch_x(kf0 - 1, xm);
+    fetch_x(kf0, xc);
+    fetch_x(kf0 + 1, xp);
+    fetch_b(kf0, bcur);
+    __syncthreads();  // the coefficient tables
+    put_x(xc);
+    __syncthreads();
+    double lo[2] = {0.0, 0.0}, hi[2] = {0.0, 0.0};
+    for (int kf = kf0; kf <= kf1; ++kf) {
+        const bool in = inz(kf);
+        const int kfw = zwrap(kf);
+        if (kf + 1 <= kf1) {
+            fetch_x(kf + 2, xn);
+            fetch_b(kf + 1, bnext);
+        }
+        // ---- the residual of plane kf (xs holds the iterate of plane kf)
+        {
+            const double wzk = in ? F.wz[kfw] : 0.0, czm = in ? F.cmz[kfw] : 0.0, czp = in ? F.cpz[kfw] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                if (!mine[e] || prow[e] < 1 || prow[e] > RSY) continue;
+                v4 out = zero;
+                if (res[e] && in) {
+                    const int R = prow[e], X = pcol[e];
+                    const double cym = tcy[0][R], cyp = tcy[1][R], wyj = tcy[2][R];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double xcc = xc[e][c];
+                        const double left = (c == 0) ? (X > 0 ? xs[R][X - 1] : 0.0) : xc[e][c > 0 ? c - 1 : 0];
+                        const double right = (c == 3) ? (X + 4 < RSX ? xs[R][X + 4] : 0.0) : xc[e][c < 3 ? c + 1 : 0];
+                        double sum = 0.0;
+                        sum += tcx[0][X + c] * (left - xcc);
+                        sum += tcx[1][X + c] * (right - xcc);
+                        sum += cym * (xs[R - 1][X + c] - xcc);
+                        sum += cyp * (xs[R + 1][X + c] - xcc);
+                        sum += czm * (xm[e][c] - xcc);
+                        sum += czp * (xp[e][c] - xcc);
+                        out[c] = bcur[e][c] - (sum * (tcx[2][X + c] * wyj)) * wzk;
+                    }
+                }
+                *reinterpret_cast<v4 *>(&rs[prow[e] - 1][pcol[e]]) = out;
+            }
+        }
+        __syncthreads();
+        // ---- the iterate of the next plane takes the tile's place; the restriction's share of plane kf
+        put_x(xp);
+        const bool odd = kf & 1;
+        const int Khi = odd ? (kf + 1) / 2 : kf / 2, Klo = Khi - 1;  // kf is slot 0 / 1 of Khi and slot 2 / 3 of Klo
+        if (in) {
+            const bool dohi = Khi >= KA && Khi < KB, dolo = Klo >= KA && Klo < KB;
+            const double wkhi = dohi ? rz_weight(F.t[2], kfw, Khi) : 0.0, wklo = dolo ? rz_weight(F.t[2], kfw, Klo) : 0.0;
+            double vl[6], c0[6], c1[6], vr[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double *rowp = &rs[4 * tw + r][2 * lane + 4];
+                const double2 cc = *reinterpret_cast<const double2 *>(rowp);
+                vl[r] = rowp[-1];
+                c0[r] = cc.x;
+                c1[r] = cc.y;
+                vr[r] = rowp[2];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (dolo) {
+                    double s = lo[a];
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) {
+                        const double wzy = wklo * wj[a][b2];
+                        const int r = 2 * a + b2;
+                        s += (wzy * rw.x) * vl[r];
+                        s += (wzy * rw.y) * c0[r];
+                        s += (wzy * rw.z) * c1[r];
+                        s += (wzy * rw.w) * vr[r];
+                    }
+                    lo[a] = s;
+                }
+                if (dohi) {
+                    double s = hi[a];
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) {
+                        const double wzy = wkhi * wj[a][b2];
+                        const int r = 2 * a + b2;
+                        s += (wzy * rw.x) * vl[r];
+                        s += (wzy * rw.y) * c0[r];
+                        s += (wzy * rw.z) * c1[r];
+                        s += (wzy * rw.w) * vr[r];
+                    }
+                    hi[a] = s;
+                }
+            }
+        }
+        if (!odd) {  // slot 3 of Klo is behind us: store it, the upper plane moves down
+            if (Klo >= KA && Klo < KB) {
+                double *dst = bc + (int64_t)(Klo - C.k0) * cplane + (int64_t)J * C.nx + I;
+                dst[0] = lo[0];
+                dst[C.nx] = lo[1];
+            }
+            lo[0] = hi[0];
+            lo[1] = hi[1];
+            hi[0] = hi[1] = 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            xm[e] = xc[e];
+            xc[e] = xp[e];
+            xp[e] = xn[e];
+            bcur[e] = bnext[e];
+        }
+    }
+}
+
 // coarsest level in ONE workgroup: `sweeps` damped-Jacobi sweeps from zero,
 // ping-pong between xa / xb (global, L2-resident), block barrier between sweeps.
 __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S, LevelDev L, double omega, int sweeps,
@@ -3138,6 +3342,25 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // the pre-smoothed iterate is kept as deep as the way up wants it (the corrected iterate starts from it)
             const int want_x = I.dist ? std::max(2, post + final_depth(l)) : 0;
             PIB_CHK(smooth_seq(l, b, pin_l, a, c, pre, true, want_x));
+            // residual and restriction in one march where the marching restriction would run (k_resid_restrict_march): the
+            // residual never goes to HBM
+            {
+                const GridLevel &c1 = s->levels[(size_t)l + 1];
+                const int64_t nkc = c1.k1 - c1.k0;
+                const bool whole = !I.dist && !li[(size_t)l + 1].dist && (s->comm.nranks == 1 || (g.replicated && c1.replicated)) && g.k0 == 0 &&
+                                   g.k1 == g.n[2] && c1.k0 == 0 && c1.k1 == c1.n[2] && !g.zring;
+                if (s->cfg.fuse_residual_restrict && whole && pin_l == nullptr && s->cfg.march_restrict && g.plain_pair && g.per == g.tper &&
+                    g.n[0] % RX == 0 && g.n[1] % RY == 0 && nkc >= 4 && nkc * c1.plane * 8 >= (int64_t)s->cfg.march_min_cells) {
+                    const int CZ = nkc * c1.plane >= ((int64_t)1 << 23) ? 32 : 8;  // (as launch_restrict)
+                    hipLaunchKernelGGL(k_resid_restrict_march, dim3((unsigned)(g.n[0] / RX), (unsigned)(g.n[1] / RY), (unsigned)((nkc + CZ - 1) / CZ)),
+                                       dim3(256), 0, q, S, dev_of(g), dev_of(c1), b, a, c1.b + c1.pad, CZ);
+                    PIB_HIP(hipGetLastError());
+                    set_valid(c1.b + c1.pad, 0);
+                    cur[(size_t)l] = a;
+                    s->gmg_spare[(size_t)l] = c;
+                    continue;
+                }
+            }
             int o;
             PIB_CHK(stencil_depth(l, 1, a, b, &o));
             int64_t ka, kc;

@@ -864,12 +864,14 @@ def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
     assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
+@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
 @pytest.mark.parametrize("n,pinned", [((128, 32, 24), False), ((256, 16, 40), True), ((128, 16, 34), False)])
 def test_marching_transfers_are_bit_identical(lin, n, pinned, key, sweeps):
     """gmg.hip k_restrict_march (fully paired 3-D levels with nx % 128 == 0, ny % 16 == 0: a fine plane goes through LDS
     once and feeds its two coarse planes) against the row kernel k_restrict_rows, and k_prolong_smooth (prolongation +
-    first post-smoothing step in one march, the corrected iterate only on chip) against k_prolong_rows + k_level_march:
+    first post-smoothing step in one march, the corrected iterate only on chip) against k_prolong_rows + k_level_march,
+    k_resid_restrict_march (residual + restriction in one march, the residual only on chip) against k_level_march<3> +
+    k_restrict_march:
     the same sums in the same order, so the whole solve is bit-identical; mildly stretched widths keep every aggregate
     a pair and the weights non-trivial.  sweeps = 1: the one post-smoothing step of level 0 also delivers the
     Krylov sums (k_prolong_smooth<1>, grouped like k_level_march<8>)."""

@@ -555,7 +555,7 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per, pc):
     assert np.abs(fused[0] - out[0][0]).max() <= (1e-12 if pc != "NOSOLVER" else 1e-10) * max(1.0, np.abs(out[0][0]).max())
 
 
-@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
+@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
 @pytest.mark.parametrize("n,per,ratios", [((128, 32, 24), (True, True, True), None), ((256, 16, 40), (True, False, True), (1.0, 1.01, 1.0)),
                                           ((128, 16, 34), (False, True, False), (1.002, 1.0, 0.99)),
                                           ((128, 16, 8), (False, False, True), (1.002, 1.01, 1.0))])
