@@ -1025,6 +1025,271 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
     }
 }
 
+// ---- prolongation + BOTH post-smoothing steps in one march (V(.,2) on the levels k_prolong_smooth serves, whole on this
+// rank).  As two kernels (k_prolong_smooth, k_level_march<2 / 8>) the once-smoothed iterate goes to HBM and comes back and b
+// is read twice: 49 B per fine cell; here 25 (b, the old iterate and the coarse values read once, the result written once).
+// The scheme of k_resid_restrict_march, one stage deeper: a workgroup's region is its 128 x 8 tile and two cells around it, in
+// aligned 4-cell pieces -- every thread owns its tile piece (the cells k_level_march gives it: the Krylov sums keep their
+// grouping and their bits) and, 152 of the threads, one piece of the margin; a piece's z neighbours are the thread's
+// registers.  Per fine plane k: the corrected iterate x + P e of plane k + 2 on the whole region, the first step of plane
+// k + 1 on the region less its outer ring (in-plane neighbours from the LDS copy of the corrected plane), the second step of
+// plane k on the tile (neighbours from the LDS copy of the first step's plane).  Same expressions in the same order as the
+// two kernels: the same bits.
+constexpr int UY = FY + 4, UX = FX + 8, UPR = UX / 4;  // region rows, columns, pieces per row
+constexpr int UCX = FX / 2 + 8, UCY = FY / 2 + 4;       // the coarse planes' tile: columns I0 - 3 .. I0 + 68, rows J0 - 2 .. J0 + 5
+template <int DOTS>
+__global__ __launch_bounds__(256) void k_prolong_smooth2(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
+                                                         const double *__restrict__ b, const double *__restrict__ xc,
+                                                         const double *__restrict__ xi, double *__restrict__ xo, int FZ,
+                                                         double *__restrict__ part, int part_stride, int dlo, int dhi)
+{
+    if (S != nullptr && S->done) return;
+    // x + P e on the plane the first step works on, the first step's result on the plane the second works on: two copies each
+    // (one read, one written per iteration: a single barrier)
+    __shared__ __attribute__((aligned(32))) double XP[2][UY][UX];
+    __shared__ __attribute__((aligned(32))) double S1[2][UY][UX];
+    __shared__ __attribute__((aligned(16))) double cs[3][UCY][UCX];
+    __shared__ double tcx[3][UX], tcy[3][UY];                    // cm, cp, 1/w of the region's columns and rows
+    __shared__ double4 pwl[UCX];                                 // x interpolation weights of the coarse columns
+    __shared__ double tyw[2][UY];                                // y interpolation weights of the region's rows
+    __shared__ int tyr[2][UY];                                   // ... and the coarse tile's rows they apply to
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const Tile3 tb = tile_of_block();
+    const int i0 = tb.x * FX, j0 = tb.y * FY, l0 = tb.z * FZ, lend = min(l0 + FZ, F.nzg);
+    const int I0 = i0 >> 1, J0 = j0 >> 1;
+    const int64_t plane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
+    const bool px = F.per & 1, py = F.per & 2, pz = F.per & 4;  // (operator and transfers wrap alike: the caller checks)
+    // ---- tables of the region
+    for (int e = tid; e < UX; e += 256) {
+        int gi = i0 - 4 + e;
+        if (px) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
+        const bool in = gi >= 0 && gi < F.nx;
+        tcx[0][e] = in ? F.cmx[gi] : 0.0;
+        tcx[1][e] = in ? F.cpx[gi] : 0.0;
+        tcx[2][e] = in ? F.rwx[gi] : 0.0;
+    }
+    if (tid < UY) {
+        const int gu = j0 - 2 + tid;
+        int gj = gu;
+        if (py) gj = gj < 0 ? gj + F.ny : (gj >= F.ny ? gj - F.ny : gj);
+        const bool in = gj >= 0 && gj < F.ny;
+        tcy[0][tid] = in ? F.cmy[gj] : 0.0;
+        tcy[1][tid] = in ? F.cpy[gj] : 0.0;
+        tcy[2][tid] = in ? F.rwy[gj] : 0.0;
+        // the two coarse rows the row interpolates from: its parent and the coarse row on the child's side (pairs: the parent
+        // of fine row g is g >> 1), as rows of the coarse tile; weights from the level's table
+        const int par = gu >> 1, oth = (gu & 1) ? par + 1 : par - 1;
+        tyr[0][tid] = min(max(par - (J0 - 2), 0), UCY - 1);
+        tyr[1][tid] = min(max(oth - (J0 - 2), 0), UCY - 1);
+        tyw[0][tid] = in ? F.t[1].wpar[gj] : 0.0;
+        tyw[1][tid] = in ? F.t[1].woth[gj] : 0.0;
+    }
+    for (int e = tid; e < UCX; e += 256) {
+        int I = I0 - 3 + e;
+        if (px) I = I < 0 ? I + C.nx : (I >= C.nx ? I - C.nx : I);
+        pwl[e] = (I >= 0 && I < C.nx) ? F.tx.pw[I] : make_double4(0.0, 0.0, 0.0, 0.0);
+    }
+    // ---- the thread's pieces: 0 the tile piece, 1 a piece of the margin (threads 0 .. 151)
+    int prow[2], pcol[2];
+    int64_t goff[2];
+    bool ok[2], has[2], first[2];
+    prow[0] = 2 + ty;
+    pcol[0] = 4 + 4 * tx;
+    has[0] = true;
+    has[1] = tid < 4 * UPR + 2 * FY;
+    {
+        const int h = tid;
+        if (h < 4 * UPR) {
+            const int r4 = h / UPR;
+            prow[1] = r4 < 2 ? r4 : FY + r4;  // rows 0, 1, FY + 2, FY + 3
+            pcol[1] = 4 * (h - r4 * UPR);
+        } else {
+            const int q2 = h - 4 * UPR;
+            prow[1] = 2 + (q2 >> 1);
+            pcol[1] = (q2 & 1) ? UX - 4 : 0;
+        }
+        if (!has[1]) prow[1] = 0, pcol[1] = 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        int gi = i0 - 4 + pcol[e], gj = j0 - 2 + prow[e];
+        if (px) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
+        if (py) gj = gj < 0 ? gj + F.ny : (gj >= F.ny ? gj - F.ny : gj);
+        ok[e] = has[e] && gi >= 0 && gi < F.nx && gj >= 0 && gj < F.ny;
+        first[e] = ok[e] && prow[e] >= 1 && prow[e] <= FY + 2;  // carries the first step (the region less its outer rows)
+        goff[e] = (int64_t)gj * F.nx + gi;
+    }
+    const v4 zero = {0, 0, 0, 0};
+    auto zw = [&](int k) { return pz ? (k < 0 ? k + F.nzg : (k >= F.nzg ? k - F.nzg : k)) : k; };
+    auto inz = [&](int k) { return pz || (k >= 0 && k < F.nzg); };
+    // coarse plane K (its tile, zero outside the domain) into its ring slot
+    auto stage = [&](int K) {
+        const bool kin = pz || (K >= 0 && K < C.nzg);
+        const int Kw = pz ? (K < 0 ? K + C.nzg : (K >= C.nzg ? K - C.nzg : K)) : K;
+        const double *pc = xc + (int64_t)(kin ? Kw : 0) * cplane;
+        double *dst = &cs[((K % 3) + 3) % 3][0][0];
+        for (int e = tid; e < UCX * UCY; e += 256) {
+            const int row = e / UCX, cx = e - row * UCX;
+            int I = I0 - 3 + cx, J = J0 - 2 + row;
+            if (px) I = I < 0 ? I + C.nx : (I >= C.nx ? I - C.nx : I);
+            if (py) J = J < 0 ? J + C.ny : (J >= C.ny ? J - C.ny : J);
+            dst[e] = (kin && I >= 0 && I < C.nx && J >= 0 && J < C.ny) ? pc[(int64_t)J * C.nx + I] : 0.0;
+        }
+    };
+    auto fetch = [&](const double *v, int k, const bool *which, v4 out[2]) {
+        const bool in = inz(k);
+        const double *pl = v + (int64_t)zw(k) * plane;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) out[e] = (in && which[e]) ? *reinterpret_cast<const v4 *>(pl + goff[e]) : zero;
+    };
+    // x + P e of the thread's pieces on plane k (old: the old iterate there): own coarse cell, then the x neighbour, per
+    // z slot and y slot -- the order of k_prolong_rows / k_prolong_smooth
+    auto correct = [&](int k, const v4 old[2], v4 out[2]) {
+        const bool in = inz(k);
+        const int kw = zw(k);
+        const int Kp = k >> 1, Ko = (k & 1) ? Kp + 1 : Kp - 1;
+        const double wk[2] = {in ? F.t[2].wpar[kw] : 0.0, in ? F.t[2].woth[kw] : 0.0};
+        const int Ks[2] = {((Kp % 3) + 3) % 3, ((Ko % 3) + 3) % 3};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!(in && ok[e])) {
+                out[e] = zero;
+                continue;
+            }
+            const int R = prow[e], q0 = (pcol[e] >> 1) + 1;  // the piece's first coarse column in the tile (I0 - 3 + q0)
+            const double4 pwA = pwl[q0], pwB = pwl[q0 + 1];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const double w = wk[c2] * tyw[b2][R];
+                    const double *row = &cs[Ks[c2]][tyr[b2][R]][q0 - 1];
+                    const double v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+                    s0 += (w * pwA.x) * v1;
+                    s0 += (w * pwA.y) * v0;
+                    s1 += (w * pwA.z) * v1;
+                    s1 += (w * pwA.w) * v2;
+                    s2 += (w * pwB.x) * v2;
+                    s2 += (w * pwB.y) * v1;
+                    s3 += (w * pwB.z) * v2;
+                    s3 += (w * pwB.w) * v3;
+                }
+            }
+            out[e][0] = old[e][0] + s0;
+            out[e][1] = old[e][1] + s1;
+            out[e][2] = old[e][2] + s2;
+            out[e][3] = old[e][3] + s3;
+        }
+    };
+    // one damped-Jacobi step of piece e on a plane: centre values cc, z neighbours zm / zp, in-plane neighbours from `pl`
+    auto step = [&](int e, const double (*pl)[UX], const v4 &cc, const v4 &zm, const v4 &zp, const v4 &bv, double rwz, double czm,
+                    double czp) -> v4 {
+        const int R = prow[e], X = pcol[e];
+        const double cym = tcy[0][R], cyp = tcy[1][R], rwy = tcy[2][R];
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double xcc = cc[c];
+            const double left = (c == 0) ? (X > 0 ? pl[R][X - 1] : 0.0) : cc[c > 0 ? c - 1 : 0];
+            const double right = (c == 3) ? (X + 4 < UX ? pl[R][X + 4] : 0.0) : cc[c < 3 ? c + 1 : 0];
+            const double cxm = tcx[0][X + c], cxp = tcx[1][X + c];
+            double sum = 0.0;
+            sum += cxm * (left - xcc);
+            sum += cxp * (right - xcc);
+            sum += cym * (pl[R - 1][X + c] - xcc);
+            sum += cyp * (pl[R + 1][X + c] - xcc);
+            sum += czm * (zm[c] - xcc);
+            sum += czp * (zp[c] - xcc);
+            const double s4 = ((cxm + cxp) + cym) + cyp;
+            out[c] = xcc + omega * ((((bv[c] * (tcx[2][X + c] * rwy)) * rwz) - sum) / (-((s4 + czm) + czp)));
+        }
+        return out;
+    };
+    // ---- the march.  Iteration k: x + P e of plane k + 2, first step of plane k + 1, second step of plane k; four
+    // iterations ahead of the first owned plane fill the pipeline.
+    v4 xpm[2] = {zero, zero}, xpc[2] = {zero, zero}, xpn[2];       // x + P e on the planes k, k + 1 (k + 2: xpn)
+    v4 s1m[2] = {zero, zero}, s1c[2] = {zero, zero}, s1n[2];       // first step on the planes k - 1, k (k + 1: s1n)
+    v4 bcur[2] = {zero, zero}, bnext[2], anext[2], a2[2];
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    int staged = ((l0 - 2) >> 1) - 2;  // highest coarse plane in the ring
+    auto need_stage = [&](int k) {  // the coarse planes plane k interpolates from: k >> 1 and the one above (odd k) or below
+        const int hi = (k & 1) ? (k >> 1) + 1 : (k >> 1);
+        while (staged < hi) stage(++staged);
+    };
+    need_stage(l0 - 2);
+    fetch(xi, l0 - 2, ok, anext);
+    fetch(b, l0 - 3, first, bnext);
+    __syncthreads();
+    for (int k = l0 - 4; k < lend; ++k) {
+        const bool do1 = k + 1 >= l0 - 1 && k + 1 <= lend && inz(k + 1), do2 = k >= l0;
+        // loads of the next iteration go out first: the coarse plane the plane after next reaches (into the ring slot no plane
+        // of this iteration reads), the old iterate three planes ahead, b two
+        need_stage(k + 3);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) a2[e] = anext[e];
+        const v4 b1[2] = {bnext[0], bnext[1]};  // b of plane k + 1
+        if (k + 1 < lend) {
+            fetch(xi, k + 3, ok, anext);
+            fetch(b, k + 2, first, bnext);
+        }
+        correct(k + 2, a2, xpn);
+        const int cur = k & 1, nxt = cur ^ 1;
+        if (do1) {
+            const int kw = zw(k + 1);
+            const double rwz = F.rwz[kw], czm = F.cmz[kw], czp = F.cpz[kw];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) s1n[e] = first[e] ? step(e, XP[cur], xpc[e], xpm[e], xpn[e], b1[e], rwz, czm, czp) : zero;
+        } else {
+            s1n[0] = s1n[1] = zero;
+        }
+        if (do2) {
+            const double rwz = F.rwz[k], czm = F.cmz[k], czp = F.cpz[k];
+            const v4 out = step(0, S1[cur], s1c[0], s1m[0], s1n[0], bcur[0], rwz, czm, czp);
+            *reinterpret_cast<v4 *>(xo + (int64_t)k * plane + goff[0]) = out;
+            if (DOTS && k >= dlo && k < dhi) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc0 += out[c] * bcur[0][c];
+                    acc1 += out[c] * out[c];
+                    acc2 += out[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (has[e]) {
+                *reinterpret_cast<v4 *>(&XP[nxt][prow[e]][pcol[e]]) = xpn[e];
+                *reinterpret_cast<v4 *>(&S1[nxt][prow[e]][pcol[e]]) = s1n[e];
+            }
+            xpm[e] = xpc[e];
+            xpc[e] = xpn[e];
+            s1m[e] = s1c[e];
+            s1c[e] = s1n[e];
+            bcur[e] = b1[e];
+        }
+        __syncthreads();
+    }
+    if (DOTS) {
+        __shared__ double sh[3][4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        double v[3] = {acc0, acc1, acc2};
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[k2] += __shfl_down(v[k2], o, 64);
+            if (lane == 0) sh[k2][w] = v[k2];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int k2 = threadIdx.x;
+            const int64_t blk = ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
+            part[(int64_t)k2 * part_stride + blk] = (sh[k2][0] + sh[k2][1]) + (sh[k2][2] + sh[k2][3]);
+        }
+    }
+}
+
 // 1-D restriction stencil of coarse cell I in fixed 4-slot form: slot o <-> fine cell fst[I] - 1 + o (the left
 // neighbour, the one or two children, the right neighbour) with the weight that cell gives to I (0 where there
 // is no such fine cell or it does not feed I).  Indices are clamped so the loads are always legal; a zero
@@ -3128,6 +3393,26 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         if (!I.dist) return 0;
         return std::min(I.cdepth, std::max(pre + 1, pre + post - 1 + final_depth(l)));
     };
+    // prolongation and both post-smoothing steps of level l in one march (k_prolong_smooth2): V(., 2), a level and its coarser
+    // one whole on this rank, the conditions of k_prolong_smooth; decided here, before the way down, because the pair of steps
+    // is one swap of the level's buffers (level 0 must end in z)
+    auto post2_ok = [&](int l) -> bool {
+        if (!s->cfg.fuse_post_pair || post != 2 || cheb || !s->cfg.fuse_prolong || l + 1 >= nl || l >= tail0) return false;
+        const GridLevel &g = s->levels[(size_t)l];
+        const GridLevel &c1 = s->levels[(size_t)l + 1];
+        const LI &I = li[(size_t)l];
+        if (I.dist || li[(size_t)l + 1].dist || !(s->comm.nranks == 1 || (g.replicated && c1.replicated))) return false;
+        if (g.k0 != 0 || g.k1 != g.n[2] || c1.k0 != 0 || c1.k1 != c1.n[2] || g.zring) return false;
+        if (l == 0 && pin != nullptr) return false;
+        const bool per_ok = g.per == g.tper && (!(g.per & 4) || g.n[2] >= 8);
+        if (!g.plain_pair || !per_ok || !fused_run_ok(s, g, 0, I.nk)) return false;
+        // four iterations fill the kernel's pipeline and it is bound by instruction issue: it pays where a workgroup marches
+        // through 64 planes (levels of 2^26 cells and more: 1.58 ms against 0.94 + 0.58 at 512^3, but 0.23 against 0.12 + 0.07
+        // at 256^3); pib_fuse_post_pair=2 takes every level that qualifies (tests)
+        if (s->cfg.fuse_post_pair < 2 && I.nk * g.plane < ((int64_t)1 << 26)) return false;
+        auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
+        return al32(g.x + g.pad) && al32(g.x2 + g.pad) && al32(l == 0 ? (const void *)r : (const void *)(g.b + g.pad)) && (l != 0 || al32(z));
+    };
     // ---- downward leg
     for (int l = 0; l < nl; ++l) {
         GridLevel &g = s->levels[(size_t)l];
@@ -3248,7 +3533,8 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         // number of ping-pong swaps left on this level: (pre-1) + post; arrange that level 0 ends in z
         double *a = xa, *c = xb;
         if (l == 0) {
-            const int swaps = (pre - 1) + post;
+            // (both post-smoothing steps in one march, k_prolong_smooth2, are ONE swap)
+            const int swaps = (pre - 1) + (post2_ok(0) ? 1 : post);
             // final buffer after `swaps` swaps starting from a: a if even else c
             if (swaps % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
         }
@@ -3422,6 +3708,38 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             }
         }
         const bool dots_l = l == 0 && s->gmg_want_dots && !cheb;
+        if (post2_ok(l)) {
+            // prolongation + both post-smoothing steps in one march; on level 0 the second one delivers the Krylov sums
+            // planes per workgroup: four iterations fill the pipeline, so no fewer than 32 -- except where the Krylov sums are
+            // formed, which keep the grouping (and the bits) of k_level_march<8>
+            const int FZ = dots_l ? march_planes(g, I.nk) : std::max(march_planes(g, I.nk), 32);
+            const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((I.nk + FZ - 1) / FZ));
+            if (dots_l) {
+                const int64_t needp = (int64_t)mg.x * mg.y * mg.z;
+                if (needp > s->gmg_part_cap) {
+                    if (s->d_gmg_part) (void)hipFree(s->d_gmg_part);
+                    s->d_gmg_part = nullptr;
+                    PIB_HIP(hipMalloc(&s->d_gmg_part, sizeof(double) * (size_t)(3 * needp + 3 * BIG_STAGE)));
+                    s->gmg_part_cap = needp;
+                }
+                double *part = s->d_gmg_part;
+                const int part_stride = (int)s->gmg_part_cap;
+                hipLaunchKernelGGL(k_prolong_smooth2<1>, mg, dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, FZ, part, part_stride, 0,
+                                   (int)I.nk);
+                double *stage = part + 3 * (int64_t)part_stride;
+                hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)needp, stage);
+                hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
+                s->gmg_dots_done = true;
+            } else
+                hipLaunchKernelGGL(k_prolong_smooth2<0>, mg, dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, FZ, (double *)nullptr, 0, 0,
+                                   (int)I.nk);
+            PIB_HIP(hipGetLastError());
+            set_valid(c, 0);
+            std::swap(a, c);
+            cur[(size_t)l] = a;
+            if (l == 0 && a != z) return fail(PIB_ERR_LIB, "gmg: internal buffer parity error");
+            continue;
+        }
         // prolongation + first post-smoothing step in one march (the corrected iterate never goes to HBM)
         bool fused = false;
         // periodic levels: operator and transfers wrap alike, z with >= 8 planes (the ring of coarse planes counts through the seam)

@@ -864,14 +864,15 @@ def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
     assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
+@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
 @pytest.mark.parametrize("n,pinned", [((128, 32, 24), False), ((256, 16, 40), True), ((128, 16, 34), False)])
 def test_marching_transfers_are_bit_identical(lin, n, pinned, key, sweeps):
     """gmg.hip k_restrict_march (fully paired 3-D levels with nx % 128 == 0, ny % 16 == 0: a fine plane goes through LDS
     once and feeds its two coarse planes) against the row kernel k_restrict_rows, and k_prolong_smooth (prolongation +
     first post-smoothing step in one march, the corrected iterate only on chip) against k_prolong_rows + k_level_march,
     k_resid_restrict_march (residual + restriction in one march, the residual only on chip) against k_level_march<3> +
-    k_restrict_march:
+    k_restrict_march, k_prolong_smooth2 (prolongation + both post-smoothing steps in one march) against k_prolong_smooth +
+    k_level_march<2 / 8>:
     the same sums in the same order, so the whole solve is bit-identical; mildly stretched widths keep every aggregate
     a pair and the weights non-trivial.  sweeps = 1: the one post-smoothing step of level 0 also delivers the
     Krylov sums (k_prolong_smooth<1>, grouped like k_level_march<8>)."""
@@ -887,7 +888,7 @@ def test_marching_transfers_are_bit_identical(lin, n, pinned, key, sweeps):
         b[0] = 0.0
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
-    for march in (1, 0):
+    for march in ((2 if key == "pib_fuse_post_pair" else 1), 0):
         s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)

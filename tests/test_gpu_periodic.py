@@ -555,7 +555,7 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per, pc):
     assert np.abs(fused[0] - out[0][0]).max() <= (1e-12 if pc != "NOSOLVER" else 1e-10) * max(1.0, np.abs(out[0][0]).max())
 
 
-@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
+@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
 @pytest.mark.parametrize("n,per,ratios", [((128, 32, 24), (True, True, True), None), ((256, 16, 40), (True, False, True), (1.0, 1.01, 1.0)),
                                           ((128, 16, 34), (False, True, False), (1.002, 1.0, 0.99)),
                                           ((128, 16, 8), (False, False, True), (1.002, 1.01, 1.0))])
@@ -573,7 +573,7 @@ def test_marching_transfers_on_periodic_levels_are_bit_identical(lin, n, per, ra
     xs, b = rhs_for(A)
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
-    for march in (1, 0):
+    for march in ((2 if key == "pib_fuse_post_pair" else 1), 0):
         s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
         s.setPeriodic(per)
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
