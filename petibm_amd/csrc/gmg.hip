@@ -3633,8 +3633,14 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             {
                 const GridLevel &c1 = s->levels[(size_t)l + 1];
                 const int64_t nkc = c1.k1 - c1.k0;
-                const bool whole = !I.dist && !li[(size_t)l + 1].dist && (s->comm.nranks == 1 || (g.replicated && c1.replicated)) && g.k0 == 0 &&
-                                   g.k1 == g.n[2] && c1.k0 == 0 && c1.k1 == c1.n[2] && !g.zring;
+                bool whole = !I.dist && !li[(size_t)l + 1].dist && (s->comm.nranks == 1 || (g.replicated && c1.replicated)) && g.k0 == 0 &&
+                             g.k1 == g.n[2] && c1.k0 == 0 && c1.k1 == c1.n[2] && !g.zring;
+                // ... or both levels in z-slabs of the same ranks (an aggregate never straddles a cut): the march reads the iterate
+                // two planes and b one plane beyond the slab -- what the way down left valid there -- and the residual's own
+                // ghost plane needs no exchange any more
+                if (!whole && I.dist && li[(size_t)l + 1].dist && !g.zring && !(g.per & 4) && valid(a) >= 2 && valid(b) >= 1 &&
+                    std::min(I.maxd, I.cdepth) >= 2)
+                    whole = true;
                 if (s->cfg.fuse_residual_restrict && whole && pin_l == nullptr && s->cfg.march_restrict && g.plain_pair && g.per == g.tper &&
                     g.n[0] % RX == 0 && g.n[1] % RY == 0 && nkc >= 4 && nkc * c1.plane * 8 >= (int64_t)s->cfg.march_min_cells) {
                     const int CZ = nkc * c1.plane >= ((int64_t)1 << 23) ? 32 : 8;  // (as launch_restrict)
