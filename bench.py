@@ -607,7 +607,7 @@ def poisson_bench(args) -> int:
             # solve_bytes_per_row_iter; the initial residual + V-cycle count as one more iteration) / the measured time.
             # Several ranks: all rows against the ranks' combined peak (the slabs' redundant ghost planes are not counted).
             bpr = solve_bytes_per_row_iter(args.presweeps, args.postsweeps, nnz_l / n_l,
-                                           "pib_fuse_residual_restrict=0" not in args.extra_config and world == 1,
+                                           "pib_fuse_residual_restrict=0" not in args.extra_config,
                                            "pib_fuse_post_pair=0" not in args.extra_config and world == 1 and pN >= (1 << 26))
             per_solve = iters / args.steps + 1.0
             gbs = bpr * pN * per_solve / (elapsed / args.steps) / 1e9
