@@ -1035,10 +1035,15 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
 // k + 1 on the region less its outer ring (in-plane neighbours from the LDS copy of the corrected plane), the second step of
 // plane k on the tile (neighbours from the LDS copy of the first step's plane).  Same expressions in the same order as the
 // two kernels: the same bits.
-constexpr int UY = FY + 4, UX = FX + 8, UPR = UX / 4;  // region rows, columns, pieces per row
-constexpr int UCX = FX / 2 + 8, UCY = FY / 2 + 4;       // the coarse planes' tile: columns I0 - 3 .. I0 + 68, rows J0 - 2 .. J0 + 5
+// The tile is 128 x 16 -- two of k_level_march's tiles, 512 threads: the margins are 1.33 x / 1.2 x the tile's work instead of
+// 1.6 x / 1.33 x with eight rows, and the kernel is bound by instruction issue -- and each half of the workgroup forms the
+// Krylov sums of its own 128 x 8 tile.
+constexpr int UTY = 2 * FY, UNT = 32 * UTY;                 // tile rows, threads
+constexpr int UY = UTY + 4, UX = FX + 8, UPR = UX / 4;      // region rows, columns, pieces per row
+constexpr int UCX = FX / 2 + 8, UCY = UTY / 2 + 4;          // the coarse planes' tile: columns I0 - 3 .. I0 + 68, rows J0 - 2 .. J0 + UTY / 2 + 1
+constexpr int UMARGIN = 4 * UPR + 2 * UTY;                  // pieces of the margin
 template <int DOTS>
-__global__ __launch_bounds__(256) void k_prolong_smooth2(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
+__global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
                                                          const double *__restrict__ b, const double *__restrict__ xc,
                                                          const double *__restrict__ xi, double *__restrict__ xo, int FZ,
                                                          double *__restrict__ part, int part_stride, int dlo, int dhi)
@@ -1056,12 +1061,12 @@ __global__ __launch_bounds__(256) void k_prolong_smooth2(const Scalars *__restri
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     const Tile3 tb = tile_of_block();
-    const int i0 = tb.x * FX, j0 = tb.y * FY, l0 = tb.z * FZ, lend = min(l0 + FZ, F.nzg);
+    const int i0 = tb.x * FX, j0 = tb.y * UTY, l0 = tb.z * FZ, lend = min(l0 + FZ, F.nzg);
     const int I0 = i0 >> 1, J0 = j0 >> 1;
     const int64_t plane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
     const bool px = F.per & 1, py = F.per & 2, pz = F.per & 4;  // (operator and transfers wrap alike: the caller checks)
     // ---- tables of the region
-    for (int e = tid; e < UX; e += 256) {
+    for (int e = tid; e < UX; e += UNT) {
         int gi = i0 - 4 + e;
         if (px) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
         const bool in = gi >= 0 && gi < F.nx;
@@ -1085,24 +1090,24 @@ __global__ __launch_bounds__(256) void k_prolong_smooth2(const Scalars *__restri
         tyw[0][tid] = in ? F.t[1].wpar[gj] : 0.0;
         tyw[1][tid] = in ? F.t[1].woth[gj] : 0.0;
     }
-    for (int e = tid; e < UCX; e += 256) {
+    for (int e = tid; e < UCX; e += UNT) {
         int I = I0 - 3 + e;
         if (px) I = I < 0 ? I + C.nx : (I >= C.nx ? I - C.nx : I);
         pwl[e] = (I >= 0 && I < C.nx) ? F.tx.pw[I] : make_double4(0.0, 0.0, 0.0, 0.0);
     }
-    // ---- the thread's pieces: 0 the tile piece, 1 a piece of the margin (threads 0 .. 151)
+    // ---- the thread's pieces: 0 the tile piece, 1 a piece of the margin (threads 0 .. UMARGIN - 1)
     int prow[2], pcol[2];
     int64_t goff[2];
     bool ok[2], has[2], first[2];
     prow[0] = 2 + ty;
     pcol[0] = 4 + 4 * tx;
     has[0] = true;
-    has[1] = tid < 4 * UPR + 2 * FY;
+    has[1] = tid < UMARGIN;
     {
         const int h = tid;
         if (h < 4 * UPR) {
             const int r4 = h / UPR;
-            prow[1] = r4 < 2 ? r4 : FY + r4;  // rows 0, 1, FY + 2, FY + 3
+            prow[1] = r4 < 2 ? r4 : UTY + r4;  // rows 0, 1, UTY + 2, UTY + 3
             pcol[1] = 4 * (h - r4 * UPR);
         } else {
             const int q2 = h - 4 * UPR;
@@ -1117,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_prolong_smooth2(const Scalars *__restri
         if (px) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
         if (py) gj = gj < 0 ? gj + F.ny : (gj >= F.ny ? gj - F.ny : gj);
         ok[e] = has[e] && gi >= 0 && gi < F.nx && gj >= 0 && gj < F.ny;
-        first[e] = ok[e] && prow[e] >= 1 && prow[e] <= FY + 2;  // carries the first step (the region less its outer rows)
+        first[e] = ok[e] && prow[e] >= 1 && prow[e] <= UTY + 2;  // carries the first step (the region less its outer rows)
         goff[e] = (int64_t)gj * F.nx + gi;
     }
     const v4 zero = {0, 0, 0, 0};
@@ -1129,7 +1134,7 @@ __global__ __launch_bounds__(256) void k_prolong_smooth2(const Scalars *__restri
         const int Kw = pz ? (K < 0 ? K + C.nzg : (K >= C.nzg ? K - C.nzg : K)) : K;
         const double *pc = xc + (int64_t)(kin ? Kw : 0) * cplane;
         double *dst = &cs[((K % 3) + 3) % 3][0][0];
-        for (int e = tid; e < UCX * UCY; e += 256) {
+        for (int e = tid; e < UCX * UCY; e += UNT) {
             const int row = e / UCX, cx = e - row * UCX;
             int I = I0 - 3 + cx, J = J0 - 2 + row;
             if (px) I = I < 0 ? I + C.nx : (I >= C.nx ? I - C.nx : I);
@@ -1272,20 +1277,21 @@ __global__ __launch_bounds__(256) void k_prolong_smooth2(const Scalars *__restri
         __syncthreads();
     }
     if (DOTS) {
-        __shared__ double sh[3][4];
+        // one partial per 128 x 8 tile of k_level_march<8> (waves 0-3: the upper, 4-7: the lower one), summed as there
+        __shared__ double sh[2][3][4];
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         double v[3] = {acc0, acc1, acc2};
 #pragma unroll
         for (int k2 = 0; k2 < 3; ++k2) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v[k2] += __shfl_down(v[k2], o, 64);
-            if (lane == 0) sh[k2][w] = v[k2];
+            if (lane == 0) sh[w >> 2][k2][w & 3] = v[k2];
         }
         __syncthreads();
-        if (threadIdx.x < 3) {
-            const int k2 = threadIdx.x;
-            const int64_t blk = ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
-            part[(int64_t)k2 * part_stride + blk] = (sh[k2][0] + sh[k2][1]) + (sh[k2][2] + sh[k2][3]);
+        if (threadIdx.x < 6) {
+            const int half = threadIdx.x / 3, k2 = threadIdx.x - 3 * half;
+            const int64_t blk = ((int64_t)tb.z * (2 * gridDim.y) + 2 * tb.y + half) * gridDim.x + tb.x;
+            part[(int64_t)k2 * part_stride + blk] = (sh[half][k2][0] + sh[half][k2][1]) + (sh[half][k2][2] + sh[half][k2][3]);
         }
     }
 }
@@ -3405,7 +3411,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         if (g.k0 != 0 || g.k1 != g.n[2] || c1.k0 != 0 || c1.k1 != c1.n[2] || g.zring) return false;
         if (l == 0 && pin != nullptr) return false;
         const bool per_ok = g.per == g.tper && (!(g.per & 4) || g.n[2] >= 8);
-        if (!g.plain_pair || !per_ok || !fused_run_ok(s, g, 0, I.nk)) return false;
+        if (!g.plain_pair || !per_ok || !fused_run_ok(s, g, 0, I.nk) || g.n[1] % UTY != 0) return false;
         // four iterations fill the kernel's pipeline and it is bound by instruction issue: it pays where a workgroup marches
         // through 64 planes (levels of 2^26 cells and more: 1.58 ms against 0.94 + 0.58 at 512^3, but 0.23 against 0.12 + 0.07
         // at 256^3); pib_fuse_post_pair=2 takes every level that qualifies (tests)
@@ -3719,9 +3725,9 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // planes per workgroup: four iterations fill the pipeline, so no fewer than 32 -- except where the Krylov sums are
             // formed, which keep the grouping (and the bits) of k_level_march<8>
             const int FZ = dots_l ? march_planes(g, I.nk) : std::max(march_planes(g, I.nk), 32);
-            const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((I.nk + FZ - 1) / FZ));
+            const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / UTY), (unsigned)((I.nk + FZ - 1) / FZ));
             if (dots_l) {
-                const int64_t needp = (int64_t)mg.x * mg.y * mg.z;
+                const int64_t needp = 2 * (int64_t)mg.x * mg.y * mg.z;  // (a partial per 128 x 8 tile, as k_level_march<8>)
                 if (needp > s->gmg_part_cap) {
                     if (s->d_gmg_part) (void)hipFree(s->d_gmg_part);
                     s->d_gmg_part = nullptr;
@@ -3730,14 +3736,14 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 }
                 double *part = s->d_gmg_part;
                 const int part_stride = (int)s->gmg_part_cap;
-                hipLaunchKernelGGL(k_prolong_smooth2<1>, mg, dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, FZ, part, part_stride, 0,
+                hipLaunchKernelGGL(k_prolong_smooth2<1>, mg, dim3(UNT), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, FZ, part, part_stride, 0,
                                    (int)I.nk);
                 double *stage = part + 3 * (int64_t)part_stride;
                 hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)needp, stage);
                 hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
                 s->gmg_dots_done = true;
             } else
-                hipLaunchKernelGGL(k_prolong_smooth2<0>, mg, dim3(256), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, FZ, (double *)nullptr, 0, 0,
+                hipLaunchKernelGGL(k_prolong_smooth2<0>, mg, dim3(UNT), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, FZ, (double *)nullptr, 0, 0,
                                    (int)I.nk);
             PIB_HIP(hipGetLastError());
             set_valid(c, 0);
