@@ -298,16 +298,21 @@ def random_rhs_solution(n: int, k0: int, k1: int) -> np.ndarray:
 #   its own before the end of round 2) ;
 #   V(2,2) cycle on the fine level: two pre-smoothing steps from zero 16 (b read, x written), residual + restriction in one
 #   march 16 + 1 (b and x read, the coarse right-hand side written; 24 + 8 + 1 as two kernels, until late in round 3),
-#   prolongation + both post-smoothing steps (+ the Krylov sums) in one march 24 + 1 on the finest level (24 + 1 and 24 as two
-#   kernels on the coarser ones, and everywhere until late in round 3) -- 16 + 17 + 25 = 58 on the finest level (98), the
-#   coarser levels a seventh of 16 + 17 + 49.       Sum: 230 B per row and iteration (272 with both detours through HBM).
+#   prolongation + both post-smoothing steps (+ the Krylov sums) in one march 24 + 1 on the levels the marching kernels serve
+#   (24 + 1 and 24 as two kernels below them, and everywhere until late in round 3) -- 16 + 17 + 25 = 58 on the finest level
+#   (98), the coarser levels a seventh of that.       Sum: 227 B per row and iteration at 512^3 (272 with both detours through HBM).
 def solve_bytes_per_row_iter(pre: int, post: int, nnz_per_row: float, fused_residual_restrict: bool = True,
-                             fused_post_pair: bool = True) -> float:
+                             fused_post_pair: bool = True, n_rows: float = 134217728.0) -> float:
     spmv = 12.0 * nnz_per_row + 4.0 + 16.0
     down = (16.0 if pre >= 2 else 8.0 + 8.0) + 24.0 * max(pre - 2, 0) + (17.0 if fused_residual_restrict and pre >= 2 else 24.0 + 9.0)
     up = (25.0 if post >= 1 else 17.0) + 24.0 * max(post - 1, 0)
-    up0 = 25.0 if (fused_post_pair and post == 2) else up  # the finest level only
-    return spmv + 40.0 + 16.0 + down * 8.0 / 7.0 + up0 + up / 7.0
+    # the way up, level by level (cells / 8 each): fused on the levels the marching kernels serve (pib_march_min_cells)
+    up_all, cells, scale = 0.0, float(n_rows), 1.0
+    while cells >= 1.0:
+        up_all += (25.0 if (fused_post_pair and post == 2 and cells >= 12582912.0) else up) * scale
+        cells /= 8.0
+        scale /= 8.0
+    return spmv + 40.0 + 16.0 + down * 8.0 / 7.0 + up_all
 
 
 def poisson_case(n: int, dt: float, cfg_text: str, rhs: str, steps: int, warmup: int, kernel_reps: int, which_kernel: int = 0):
@@ -608,7 +613,7 @@ def poisson_bench(args) -> int:
             # Several ranks: all rows against the ranks' combined peak (the slabs' redundant ghost planes are not counted).
             bpr = solve_bytes_per_row_iter(args.presweeps, args.postsweeps, nnz_l / n_l,
                                            "pib_fuse_residual_restrict=0" not in args.extra_config,
-                                           "pib_fuse_post_pair=0" not in args.extra_config and world == 1 and pN >= (1 << 26))
+                                           "pib_fuse_post_pair=0" not in args.extra_config and world == 1, float(pN))
             per_solve = iters / args.steps + 1.0
             gbs = bpr * pN * per_solve / (elapsed / args.steps) / 1e9
             out["roofline_solve"] = {"bound": "hbm", "bytes_per_row_per_iteration": bpr, "iterations_counted": per_solve,

@@ -3412,10 +3412,6 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         if (l == 0 && pin != nullptr) return false;
         const bool per_ok = g.per == g.tper && (!(g.per & 4) || g.n[2] >= 8);
         if (!g.plain_pair || !per_ok || !fused_run_ok(s, g, 0, I.nk) || g.n[1] % UTY != 0) return false;
-        // four iterations fill the kernel's pipeline and it is bound by instruction issue: it pays where a workgroup marches
-        // through 64 planes (levels of 2^26 cells and more: 1.58 ms against 0.94 + 0.58 at 512^3, but 0.23 against 0.12 + 0.07
-        // at 256^3); pib_fuse_post_pair=2 takes every level that qualifies (tests)
-        if (s->cfg.fuse_post_pair < 2 && I.nk * g.plane < ((int64_t)1 << 26)) return false;
         auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
         return al32(g.x + g.pad) && al32(g.x2 + g.pad) && al32(l == 0 ? (const void *)r : (const void *)(g.b + g.pad)) && (l != 0 || al32(z));
     };
