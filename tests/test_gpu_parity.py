@@ -888,7 +888,7 @@ def test_marching_transfers_are_bit_identical(lin, n, pinned, key, sweeps):
         b[0] = 0.0
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
-    for march in ((2 if key == "pib_fuse_post_pair" else 1), 0):
+    for march in (1, 0):
         s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)

@@ -573,7 +573,7 @@ def test_marching_transfers_on_periodic_levels_are_bit_identical(lin, n, per, ra
     xs, b = rhs_for(A)
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
-    for march in ((2 if key == "pib_fuse_post_pair" else 1), 0):
+    for march in (1, 0):
         s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
         s.setPeriodic(per)
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
