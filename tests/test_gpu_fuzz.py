@@ -402,3 +402,43 @@ def test_random_mesh_multigrid_forms_are_bit_identical(seed):
         assert its == out[0][1], (seed, form)
         assert np.array_equal(h, out[0][2]), (seed, form)
         assert np.array_equal(x, out[0][0]), (seed, form)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("PIB_FUZZ_SEEDS", "12")))))
+def test_random_paired_levels_marching_kernels_are_bit_identical(seed):
+    """The LDS-tiled marching kernels of the large levels (pre-smoothing pair, residual + restriction in one march,
+    prolongation + post-smoothing in one march, the XCD bands) on random fully paired meshes -- mild stretching, walls and
+    periodic directions at random, V(1,1) ... V(2,2) -- against the streaming / row kernels: the same bits."""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    from test_gpu_parity import gmg_cfg
+    rng = np.random.default_rng(9000 + seed)
+    n = [(128, 32, 24), (128, 16, 40), (256, 16, 16), (128, 48, 32), (128, 32, 64)][int(rng.integers(0, 5))]
+    per = [bool(rng.uniform() < 0.35) for _ in range(3)]
+    ratios = [1.0 if per[d] else float(rng.choice([1.0, 1.002, 0.997, 1.006])) for d in range(3)]
+    pre, post = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    m = omesh.create_mesh(omesh.periodic_config(n, per, ratios=ratios))
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    dt = 0.01
+    N = int(np.prod(n))
+    b = rng.uniform(-1, 1, N)
+    b -= b.mean()
+    out = []
+    off = "pib_march_levels=0\npib_fuse_presmooth=0\npib_march_restrict=0\npib_fuse_prolong=0\n"
+    for extra in ("", "pib_fuse_post_pair=0\n", "pib_fuse_residual_restrict=0\n", off):
+        s = LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post, extra="pib_march_min_cells=0\n" + extra))
+        if any(per):
+            s.setPeriodic(per)
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(N)
+        s.solve(x, b)
+        assert s.getReason() > 0, (seed, extra)
+        out.append((x, s.getIters(), s.getResidualHistory().copy()))
+        s.destroy()
+    # the fused marches against the kernels they replace: bit for bit; against the streaming kernels (which group the Krylov
+    # sums differently): the same iteration count and the iterates to rounding
+    for x, its, h in out[1:3]:
+        assert its == out[0][1] and np.array_equal(h, out[0][2]) and np.array_equal(x, out[0][0]), seed
+    assert out[3][1] == out[0][1], seed
+    assert np.allclose(out[3][2], out[0][2], rtol=1e-9), seed
+    assert np.abs(out[3][0] - out[0][0]).max() <= 1e-10 * np.abs(out[0][0]).max(), seed
