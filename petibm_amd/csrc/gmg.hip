@@ -1061,9 +1061,17 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     const Tile3 tb = tile_of_block();
-    const int i0 = tb.x * FX, j0 = tb.y * UTY, l0 = tb.z * FZ, lend = min(l0 + FZ, F.nzg);
+    // relaxed planes: [F.k0, F.k0 + F.nk) (global) -- a whole level or a run of planes of a z-slab (its own planes and the
+    // ghost planes the caller wants the result on); b / xi / xo point at the first of them, xc at coarse plane C.k0.  The two
+    // planes below / above a workgroup's planes are corrected and the one next to them relaxed once as well: the old iterate
+    // and the coarse planes they interpolate from, and b one plane out, must be valid there.
+    const int i0 = tb.x * FX, j0 = tb.y * UTY, l0 = F.k0 + tb.z * FZ, lend = min(l0 + FZ, F.k0 + F.nk);
     const int I0 = i0 >> 1, J0 = j0 >> 1;
     const int64_t plane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
+    b -= (int64_t)F.k0 * plane;  // index by global plane below
+    xi -= (int64_t)F.k0 * plane;
+    xo -= (int64_t)F.k0 * plane;
+    xc -= (int64_t)C.k0 * cplane;
     const bool px = F.per & 1, py = F.per & 2, pz = F.per & 4;  // (operator and transfers wrap alike: the caller checks)
     // ---- tables of the region
     for (int e = tid; e < UX; e += UNT) {
@@ -3407,8 +3415,14 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         const GridLevel &g = s->levels[(size_t)l];
         const GridLevel &c1 = s->levels[(size_t)l + 1];
         const LI &I = li[(size_t)l];
-        if (I.dist || li[(size_t)l + 1].dist || !(s->comm.nranks == 1 || (g.replicated && c1.replicated))) return false;
-        if (g.k0 != 0 || g.k1 != g.n[2] || c1.k0 != 0 || c1.k1 != c1.n[2] || g.zring) return false;
+        const bool whole = !I.dist && !li[(size_t)l + 1].dist && (s->comm.nranks == 1 || (g.replicated && c1.replicated)) && g.k0 == 0 &&
+                           g.k1 == g.n[2] && c1.k0 == 0 && c1.k1 == c1.n[2];
+        // ... or both levels in z-slabs of the same ranks: the result on final_depth ghost planes needs the old iterate and the
+        // coarse values two planes deeper and b one (what the way down leaves valid; exchanged at the launch if not)
+        const int fin0 = (l == 0 && I.dist && I.maxd > 1) ? 1 : 0;  // (final_depth)
+        const bool slabs = I.dist && li[(size_t)l + 1].dist && !(g.per & 4) && std::min(I.maxd, I.cdepth) >= fin0 + 2 &&
+                           coarse_need(s, l, fin0 + 2) <= li[(size_t)l + 1].maxd;
+        if (!(whole || slabs) || g.zring) return false;
         if (l == 0 && pin != nullptr) return false;
         const bool per_ok = g.per == g.tper && (!(g.per & 4) || g.n[2] >= 8);
         if (!g.plain_pair || !per_ok || !fused_run_ok(s, g, 0, I.nk) || g.n[1] % UTY != 0) return false;
@@ -3720,8 +3734,22 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // prolongation + both post-smoothing steps in one march; on level 0 the second one delivers the Krylov sums
             // planes per workgroup: four iterations fill the pipeline, so no fewer than 32 -- except where the Krylov sums are
             // formed, which keep the grouping (and the bits) of k_level_march<8>
-            const int FZ = dots_l ? march_planes(g, I.nk) : std::max(march_planes(g, I.nk), 32);
-            const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / UTY), (unsigned)((I.nk + FZ - 1) / FZ));
+            int64_t ka = 0, kc = I.nk;
+            if (I.dist) {
+                // the run of planes the result is wanted on, and its inputs as deep as the two steps reach
+                const int cn = coarse_need(s, l, fin + 2);
+                if (li[(size_t)l + 1].dist) PIB_CHK(need(l + 1, xc, cn));
+                if (valid(a) < fin + 2) PIB_CHK(need(l, a, fin + 2));
+                if (valid(b) < fin + 1) PIB_CHK(need(l, b, fin + 1));
+                run(l, fin, ka, kc);
+            }
+            GridLevel sub = g;
+            sub.k0 = g.k0 + ka;
+            sub.k1 = sub.k0 + kc;
+            const int FZ = dots_l ? march_planes(g, kc) : std::max(march_planes(g, kc), 32);
+            const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / UTY), (unsigned)((kc + FZ - 1) / FZ));
+            const double *bq = b + ka * pl;
+            double *aq = a + ka * pl, *cq = c + ka * pl;
             if (dots_l) {
                 const int64_t needp = 2 * (int64_t)mg.x * mg.y * mg.z;  // (a partial per 128 x 8 tile, as k_level_march<8>)
                 if (needp > s->gmg_part_cap) {
@@ -3732,17 +3760,17 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 }
                 double *part = s->d_gmg_part;
                 const int part_stride = (int)s->gmg_part_cap;
-                hipLaunchKernelGGL(k_prolong_smooth2<1>, mg, dim3(UNT), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, FZ, part, part_stride, 0,
-                                   (int)I.nk);
+                hipLaunchKernelGGL(k_prolong_smooth2<1>, mg, dim3(UNT), 0, q, S, dev_of(sub), dev_of(cg), omega, bq, xc, aq, cq, FZ, part, part_stride,
+                                   (int)g.k0, (int)g.k1);
                 double *stage = part + 3 * (int64_t)part_stride;
                 hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)needp, stage);
                 hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
                 s->gmg_dots_done = true;
             } else
-                hipLaunchKernelGGL(k_prolong_smooth2<0>, mg, dim3(UNT), 0, q, S, dev_of(g), dev_of(cg), omega, b, xc, a, c, FZ, (double *)nullptr, 0, 0,
-                                   (int)I.nk);
+                hipLaunchKernelGGL(k_prolong_smooth2<0>, mg, dim3(UNT), 0, q, S, dev_of(sub), dev_of(cg), omega, bq, xc, aq, cq, FZ, (double *)nullptr, 0,
+                                   (int)g.k0, (int)g.k1);
             PIB_HIP(hipGetLastError());
-            set_valid(c, 0);
+            set_valid(c, I.dist ? fin : 0);
             std::swap(a, c);
             cur[(size_t)l] = a;
             if (l == 0 && a != z) return fail(PIB_ERR_LIB, "gmg: internal buffer parity error");
