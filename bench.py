@@ -613,7 +613,7 @@ def poisson_bench(args) -> int:
             # Several ranks: all rows against the ranks' combined peak (the slabs' redundant ghost planes are not counted).
             bpr = solve_bytes_per_row_iter(args.presweeps, args.postsweeps, nnz_l / n_l,
                                            "pib_fuse_residual_restrict=0" not in args.extra_config,
-                                           "pib_fuse_post_pair=0" not in args.extra_config and world == 1, float(pN))
+                                           "pib_fuse_post_pair=0" not in args.extra_config, float(pN))
             per_solve = iters / args.steps + 1.0
             gbs = bpr * pN * per_solve / (elapsed / args.steps) / 1e9
             out["roofline_solve"] = {"bound": "hbm", "bytes_per_row_per_iteration": bpr, "iterations_counted": per_solve,
