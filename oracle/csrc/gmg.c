@@ -76,6 +76,16 @@ typedef struct {
 static double vec_sum(i64 n, const double *a);
 static void shift_vec(i64 n, double *a, double m);
 
+/* Fused multiply-adds, spelled out (round 4): the library and this file are built -ffp-contract=off, so these four helpers are
+ * the only places where a product is not rounded before it is added -- fma() of <math.h> here (vfmadd under
+ * -march=x86-64-v3; the C library's correctly rounded software fma on a host without FMA3: the same bits), v_fma_f64 in
+ * petibm_amd/csrc/gmg.hip, the same calls in the same order: facc one face of the scaled row sum, jstep the damped-Jacobi
+ * update, resid the residual's last factor, tacc one term of an interpolation / restriction sum. */
+static inline double facc(double s, double c, double nb, double xc) { return fma(c, nb - xc, s); }
+static inline double jstep(double x, double omega, double q) { return fma(omega, q, x); }
+static inline double resid(double b, double t, double w) { return fma(-t, w, b); }
+static inline double tacc(double s, double w, double v) { return fma(w, v, s); }
+
 static inline i64 idx(const level_t *l, i64 i, i64 j, i64 k) { return i + l->n[0] * (j + l->n[1] * k); }
 
 /* The rows of the level operator DIVIDED BY THE CELL VOLUME: towards +d of cell s the coefficient (w_a w_b) g_d[s]
@@ -103,18 +113,18 @@ static inline double apply_cell(const level_t *l, const double *x, i64 i, i64 j,
     const i64 p = idx(l, i, j, k), sx = 1, sy = l->n[0], sz = l->n[0] * l->n[1];
     const double xc = x[p];
     double s = 0.0;
-    if (i > 0) s += c[0] * (x[p - sx] - xc);
-    else if (l->per[0]) s += c[0] * (x[p + (l->n[0] - 1) * sx] - xc);
-    if (i < l->n[0] - 1) s += c[1] * (x[p + sx] - xc);
-    else if (l->per[0]) s += c[1] * (x[p - (l->n[0] - 1) * sx] - xc);
-    if (j > 0) s += c[2] * (x[p - sy] - xc);
-    else if (l->per[1]) s += c[2] * (x[p + (l->n[1] - 1) * sy] - xc);
-    if (j < l->n[1] - 1) s += c[3] * (x[p + sy] - xc);
-    else if (l->per[1]) s += c[3] * (x[p - (l->n[1] - 1) * sy] - xc);
-    if (k > 0) s += c[4] * (x[p - sz] - xc);
-    else if (l->per[2]) s += c[4] * (x[p + (l->n[2] - 1) * sz] - xc);
-    if (k < l->n[2] - 1) s += c[5] * (x[p + sz] - xc);
-    else if (l->per[2]) s += c[5] * (x[p - (l->n[2] - 1) * sz] - xc);
+    if (i > 0) s = facc(s, c[0], x[p - sx], xc);
+    else if (l->per[0]) s = facc(s, c[0], x[p + (l->n[0] - 1) * sx], xc);
+    if (i < l->n[0] - 1) s = facc(s, c[1], x[p + sx], xc);
+    else if (l->per[0]) s = facc(s, c[1], x[p - (l->n[0] - 1) * sx], xc);
+    if (j > 0) s = facc(s, c[2], x[p - sy], xc);
+    else if (l->per[1]) s = facc(s, c[2], x[p + (l->n[1] - 1) * sy], xc);
+    if (j < l->n[1] - 1) s = facc(s, c[3], x[p + sy], xc);
+    else if (l->per[1]) s = facc(s, c[3], x[p - (l->n[1] - 1) * sy], xc);
+    if (k > 0) s = facc(s, c[4], x[p - sz], xc);
+    else if (l->per[2]) s = facc(s, c[4], x[p + (l->n[2] - 1) * sz], xc);
+    if (k < l->n[2] - 1) s = facc(s, c[5], x[p + sz], xc);
+    else if (l->per[2]) s = facc(s, c[5], x[p - (l->n[2] - 1) * sz], xc);
     *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
     return s;
 }
@@ -305,7 +315,7 @@ static void smooth(const level_t *l, double omega, const double *b, const double
                     xo[p] = omega * (scale_b(l, i, j, k, b[p]) / d);
                 } else {
                     const double ax = apply_cell(l, xi, i, j, k, &d);
-                    xo[p] = xi[p] + omega * ((scale_b(l, i, j, k, b[p]) - ax) / d);
+                    xo[p] = jstep(xi[p], omega, (scale_b(l, i, j, k, b[p]) - ax) / d);
                 }
             }
 }
@@ -318,7 +328,7 @@ static void residual(const level_t *l, const double *b, const double *x, double 
             for (i64 i = 0; i < l->n[0]; ++i) {
                 double d;
                 const i64 p = idx(l, i, j, k);
-                r[p] = b[p] - unscale(l, i, j, k, apply_cell(l, x, i, j, k, &d));
+                r[p] = resid(b[p], apply_cell(l, x, i, j, k, &d) * (l->w[0][i] * l->w[1][j]), l->w[2][k]);
             }
 }
 
@@ -338,7 +348,7 @@ static void prolong_add(const level_t *f, const level_t *c, const double *xc, do
                     for (int b2 = 0; b2 < 2; ++b2)
                         for (int a2 = 0; a2 < 2; ++a2) {
                             const double wgt = (wk[c2] * wj[b2]) * wi[a2];
-                            if (wgt != 0.0) s += wgt * xc[idx(c, I[a2], J[b2], K[c2])];
+                            if (wgt != 0.0) s = tacc(s, wgt, xc[idx(c, I[a2], J[b2], K[c2])]);
                         }
                 xf[idx(f, i, j, k)] += s;
             }
@@ -382,7 +392,7 @@ static void restrict_t(const level_t *f, const level_t *c, const double *rf, dou
                             if (i < 0 || i >= f->n[0]) continue;
                             const double wx = rw(f, 0, i, I);
                             if (wx == 0.0) continue;
-                            s += ((wz * wy) * wx) * rf[idx(f, i, j, k)];
+                            s = tacc(s, (wz * wy) * wx, rf[idx(f, i, j, k)]);
                         }
                     }
                 }

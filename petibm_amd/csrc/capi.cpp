@@ -410,6 +410,10 @@ int pib_solve(pib_solver *s, double *x, const double *b)
         err = pib_solve(in, R.x_nat, R.b_nat);
         if (!err) err = hipStreamSynchronize(in->stream) == hipSuccess ? 0 : fail(PIB_ERR_LIB, "solver %s: the slab solver's stream failed", s->name.c_str());
         if (!err) err = redist_backward(s, R.x_nat, xdev, s->stream);
+        // like solve_cg / solve_bicgstab (which return behind fetch_results' synchronisation), x is complete on return: the
+        // scatter and its exchange were only enqueued -- none of the transports synchronises by itself
+        if (hipStreamSynchronize(s->stream) != hipSuccess && !err)
+            err = fail(PIB_ERR_LIB, "solver %s: moving x back to the boxes failed", s->name.c_str());
         s->iters = in->iters;
         s->reason = in->reason;
         s->residual = in->residual;

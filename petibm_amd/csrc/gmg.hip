@@ -71,6 +71,19 @@ struct LevelDev {
 //     r = b - (t (wx wy)) wz.
 // The expressions and their order are the same in every kernel below and in the oracle (oracle/csrc/gmg.c): fused and
 // unfused, tiled and streaming forms give the same bits.  tools/vcycle_lab.hip: 0.76 -> 0.61 ms per 512^3 Jacobi step.
+//
+// Fused multiply-adds, spelled out (round 4).  The library is built -ffp-contract=off so that nothing contracts by accident;
+// these three helpers are the places where a product is NOT rounded before it is added -- v_fma_f64 here, fma() of <math.h>
+// (vfmadd under -march=x86-64-v3) in oracle/csrc/gmg.c, the same call in the same order on both sides, so the bits still
+// agree -- and a face term costs two fp64 instructions instead of three (the marching kernels are bound by VALU issue):
+//     facc : s + c (x_nb - x_c)        one face of the scaled row sum
+//     jstep: x + omega q               the damped-Jacobi update, q = (bs - t) / d
+//     resid: b - t w                   the residual's last factor (t = row sum times two widths, w the third)
+__device__ __forceinline__ double facc(double s, double c, double nb, double xc) { return fma(c, nb - xc, s); }
+__device__ __forceinline__ double jstep(double x, double omega, double q) { return fma(omega, q, x); }
+__device__ __forceinline__ double resid(double b, double t, double w) { return fma(-t, w, b); }
+//     tacc : s + w v                   one term of an interpolation / restriction sum (w = the product of the 1-D weights)
+__device__ __forceinline__ double tacc(double s, double w, double v) { return fma(w, v, s); }
 __device__ __forceinline__ void face_coefs(const LevelDev &L, int i, int j, int k, double c[6])
 {
     c[0] = L.cmx[i];
@@ -94,18 +107,18 @@ __device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__
     const double xc = x[p];
     double s = 0.0;
     const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
-    if (i > 0) s += c[0] * (x[p - 1] - xc);
-    else if (px) s += c[0] * (x[p + (L.nx - 1)] - xc);
-    if (i < L.nx - 1) s += c[1] * (x[p + 1] - xc);
-    else if (px) s += c[1] * (x[p - (L.nx - 1)] - xc);
-    if (j > 0) s += c[2] * (x[p - sy] - xc);
-    else if (py) s += c[2] * (x[p + (L.ny - 1) * sy] - xc);
-    if (j < L.ny - 1) s += c[3] * (x[p + sy] - xc);
-    else if (py) s += c[3] * (x[p - (L.ny - 1) * sy] - xc);
-    if (k > 0) s += c[4] * (x[p - sz] - xc);
-    else if (pz) s += c[4] * (x[L.zring ? p - sz : p + (L.nzg - 1) * sz] - xc);
-    if (k < L.nzg - 1) s += c[5] * (x[p + sz] - xc);
-    else if (pz) s += c[5] * (x[L.zring ? p + sz : p - (L.nzg - 1) * sz] - xc);
+    if (i > 0) s = facc(s, c[0], x[p - 1], xc);
+    else if (px) s = facc(s, c[0], x[p + (L.nx - 1)], xc);
+    if (i < L.nx - 1) s = facc(s, c[1], x[p + 1], xc);
+    else if (px) s = facc(s, c[1], x[p - (L.nx - 1)], xc);
+    if (j > 0) s = facc(s, c[2], x[p - sy], xc);
+    else if (py) s = facc(s, c[2], x[p + (L.ny - 1) * sy], xc);
+    if (j < L.ny - 1) s = facc(s, c[3], x[p + sy], xc);
+    else if (py) s = facc(s, c[3], x[p - (L.ny - 1) * sy], xc);
+    if (k > 0) s = facc(s, c[4], x[p - sz], xc);
+    else if (pz) s = facc(s, c[4], x[L.zring ? p - sz : p + (L.nzg - 1) * sz], xc);
+    if (k < L.nzg - 1) s = facc(s, c[5], x[p + sz], xc);
+    else if (pz) s = facc(s, c[5], x[L.zring ? p + sz : p - (L.nzg - 1) * sz], xc);
     *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
     return s;
 }
@@ -221,16 +234,16 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             const double xcc = xc[c];
             // a missing neighbour: zero coefficient, and the value is 0 (xl, xr) or the centre's own (ym .. zp)
             double s = 0.0;
-            s += cxm * (left - xcc);
-            s += cxp * (right - xcc);
-            s += cym * (ym[c] - xcc);
-            s += cyp * (yp[c] - xcc);
-            s += czm * (zm[c] - xcc);
-            s += czp * (zp[c] - xcc);
+            s = facc(s, cxm, left, xcc);
+            s = facc(s, cxp, right, xcc);
+            s = facc(s, cym, ym[c], xcc);
+            s = facc(s, cyp, yp[c], xcc);
+            s = facc(s, czm, zm[c], xcc);
+            s = facc(s, czp, zp[c], xcc);
             if (MODE == 0)
                 out[c] = (s * (wxv[c] * wyj)) * wzk;
             else if (MODE == 2 || MODE == 8) {
-                out[c] = xcc + omega * ((bs - s) / d);
+                out[c] = jstep(xcc, omega, (bs - s) / d);
                 if (MODE == 8 && dots) {
                     acc0 += out[c] * braw[c];
                     acc1 += out[c] * out[c];
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
                 dv[c] = dn;
                 out[c] = xcc + dn;
             } else
-                out[c] = bv[c] - (s * (wxv[c] * wyj)) * wzk;
+                out[c] = resid(bv[c], s * (wxv[c] * wyj), wzk);
         }
         if (MODE == 5 || MODE == 6) *reinterpret_cast<vt *>(dvec + p) = dv;
         *reinterpret_cast<vt *>(xo + p) = out;
@@ -462,13 +475,13 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
             const double xcc = x1c[c];
             // missing neighbours: zero coefficients; the LDS halo cells and x1m / x1p outside the domain hold 0
             double sum = 0.0;
-            sum += q.cxm * (x1[sc][ty + 1][lx - 1] - xcc);
-            sum += q.cxp * (x1[sc][ty + 1][lx + 1] - xcc);
-            sum += q.cym * (x1[sc][ty][lx] - xcc);
-            sum += q.cyp * (x1[sc][ty + 2][lx] - xcc);
-            sum += czm * (x1m[c] - xcc);
-            sum += czp * (x1p[c] - xcc);
-            out[c] = RES ? bprev[c] - (sum * q.vxy) * wzk : xcc + omega * ((((bprev[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
+            sum = facc(sum, q.cxm, x1[sc][ty + 1][lx - 1], xcc);
+            sum = facc(sum, q.cxp, x1[sc][ty + 1][lx + 1], xcc);
+            sum = facc(sum, q.cym, x1[sc][ty][lx], xcc);
+            sum = facc(sum, q.cyp, x1[sc][ty + 2][lx], xcc);
+            sum = facc(sum, czm, x1m[c], xcc);
+            sum = facc(sum, czp, x1p[c], xcc);
+            out[c] = RES ? resid(bprev[c], sum * q.vxy, wzk) : jstep(xcc, omega, (((bprev[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
         }
         if (RES) {
             *reinterpret_cast<v4 *>(ro + (int64_t)kc * plane + off_c) = out;
@@ -577,19 +590,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ?
             const FCell &q = q4[c];
             const double xcc = xc[c];
             double sum = 0.0;
-            sum += q.cxm * (sp[slot][ty + 1][lx - 1] - xcc);
-            sum += q.cxp * (sp[slot][ty + 1][lx + 1] - xcc);
-            sum += q.cym * (sp[slot][ty][lx] - xcc);
-            sum += q.cyp * (sp[slot][ty + 2][lx] - xcc);
-            sum += czm * (zm[c] - xcc);
-            sum += czp * (zp[c] - xcc);
+            sum = facc(sum, q.cxm, sp[slot][ty + 1][lx - 1], xcc);
+            sum = facc(sum, q.cxp, sp[slot][ty + 1][lx + 1], xcc);
+            sum = facc(sum, q.cym, sp[slot][ty][lx], xcc);
+            sum = facc(sum, q.cyp, sp[slot][ty + 2][lx], xcc);
+            sum = facc(sum, czm, zm[c], xcc);
+            sum = facc(sum, czp, zp[c], xcc);
             if (MODE == 0) {  // y = A x (the Krylov product of the stencil twin), x.y over the owned planes on request
                 out[c] = (sum * q.vxy) * wzk;
                 if (part != nullptr && lk >= dlo && lk < dhi) acc0 += out[c] * xcc;
             } else if (MODE == 3)
-                out[c] = bv[c] - (sum * q.vxy) * wzk;
+                out[c] = resid(bv[c], sum * q.vxy, wzk);
             else {
-                out[c] = xcc + omega * ((((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
+                out[c] = jstep(xcc, omega, (((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
                 if (MODE == 8 && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
                     acc0 += out[c] * braw[c];
                     acc1 += out[c] * out[c];
@@ -764,10 +777,10 @@ __global__ __launch_bounds__(256) void k_prolong_rows(const Scalars *__restrict_
             const double v = vP[r][q];
             const double vL = __shfl_up(v, 1, 64), vR = __shfl_down(v, 1, 64);
             if (wkj == 0.0) continue;  // wave-uniform: the oracle skips zero weights too
-            sl += (wkj * pw.x) * v;
-            sl += (wkj * pw.y) * vL;
-            sr += (wkj * pw.z) * v;
-            sr += (wkj * pw.w) * vR;
+            sl = tacc(sl, (wkj * pw.x), v);
+            sl = tacc(sl, (wkj * pw.y), vL);
+            sr = tacc(sr, (wkj * pw.z), v);
+            sr = tacc(sr, (wkj * pw.w), vR);
         }
         if (!valid || row0 + r >= nrows) continue;
         double *dst = xf + off[r];
@@ -917,24 +930,24 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
                 const double w = wk[c2] * wjv[b2];
                 const double *row = &cp[rr[b2]][2 * tx];
                 const double2 v01 = *reinterpret_cast<const double2 *>(row), v23 = *reinterpret_cast<const double2 *>(row + 2);
-                s0 += (w * pwA.x) * v01.y;
-                s0 += (w * pwA.y) * v01.x;
-                s1 += (w * pwA.z) * v01.y;
-                s1 += (w * pwA.w) * v23.x;
-                s2 += (w * pwB.x) * v23.x;
-                s2 += (w * pwB.y) * v01.y;
-                s3 += (w * pwB.z) * v23.x;
-                s3 += (w * pwB.w) * v23.y;
+                s0 = tacc(s0, (w * pwA.x), v01.y);
+                s0 = tacc(s0, (w * pwA.y), v01.x);
+                s1 = tacc(s1, (w * pwA.z), v01.y);
+                s1 = tacc(s1, (w * pwA.w), v23.x);
+                s2 = tacc(s2, (w * pwB.x), v23.x);
+                s2 = tacc(s2, (w * pwB.y), v01.y);
+                s3 = tacc(s3, (w * pwB.z), v23.x);
+                s3 = tacc(s3, (w * pwB.w), v23.y);
                 if (halo) {
                     const double wy = wk[c2] * (b2 ? hy.wj1 : hy.wj0);
                     const double *rowy = cp[b2 ? hy.r1 : hy.r0];
-                    sy += (wy * hy.wa) * rowy[hy.lx];
-                    sy += (wy * hy.wb) * rowy[hy.lxo];
+                    sy = tacc(sy, (wy * hy.wa), rowy[hy.lx]);
+                    sy = tacc(sy, (wy * hy.wb), rowy[hy.lxo]);
                     if (tid < 16) {
                         const double wx = wk[c2] * (b2 ? hx.wj1 : hx.wj0);
                         const double *rowx = cp[b2 ? hx.r1 : hx.r0];
-                        sx += (wx * hx.wa) * rowx[hx.lx];
-                        sx += (wx * hx.wb) * rowx[hx.lxo];
+                        sx = tacc(sx, (wx * hx.wa), rowx[hx.lx]);
+                        sx = tacc(sx, (wx * hx.wb), rowx[hx.lxo]);
                     }
                 }
             }
@@ -987,13 +1000,13 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
             const FCell &q = q4[c];
             const double xcc = xcur[c];
             double sum = 0.0;
-            sum += q.cxm * (sp[slot][ty + 1][lx - 1] - xcc);
-            sum += q.cxp * (sp[slot][ty + 1][lx + 1] - xcc);
-            sum += q.cym * (sp[slot][ty][lx] - xcc);
-            sum += q.cyp * (sp[slot][ty + 2][lx] - xcc);
-            sum += czm * (zm[c] - xcc);
-            sum += czp * (zp[c] - xcc);
-            out[c] = xcc + omega * ((((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
+            sum = facc(sum, q.cxm, sp[slot][ty + 1][lx - 1], xcc);
+            sum = facc(sum, q.cxp, sp[slot][ty + 1][lx + 1], xcc);
+            sum = facc(sum, q.cym, sp[slot][ty][lx], xcc);
+            sum = facc(sum, q.cyp, sp[slot][ty + 2][lx], xcc);
+            sum = facc(sum, czm, zm[c], xcc);
+            sum = facc(sum, czp, zp[c], xcc);
+            out[c] = jstep(xcc, omega, (((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
             if (DOTS && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
                 acc0 += out[c] * braw[c];
                 acc1 += out[c] * out[c];
@@ -1180,14 +1193,14 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
                     const double w = wk[c2] * tyw[b2][R];
                     const double *row = &cs[Ks[c2]][tyr[b2][R]][q0 - 1];
                     const double v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
-                    s0 += (w * pwA.x) * v1;
-                    s0 += (w * pwA.y) * v0;
-                    s1 += (w * pwA.z) * v1;
-                    s1 += (w * pwA.w) * v2;
-                    s2 += (w * pwB.x) * v2;
-                    s2 += (w * pwB.y) * v1;
-                    s3 += (w * pwB.z) * v2;
-                    s3 += (w * pwB.w) * v3;
+                    s0 = tacc(s0, (w * pwA.x), v1);
+                    s0 = tacc(s0, (w * pwA.y), v0);
+                    s1 = tacc(s1, (w * pwA.z), v1);
+                    s1 = tacc(s1, (w * pwA.w), v2);
+                    s2 = tacc(s2, (w * pwB.x), v2);
+                    s2 = tacc(s2, (w * pwB.y), v1);
+                    s3 = tacc(s3, (w * pwB.z), v2);
+                    s3 = tacc(s3, (w * pwB.w), v3);
                 }
             }
             out[e][0] = old[e][0] + s0;
@@ -1209,14 +1222,14 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
             const double right = (c == 3) ? (X + 4 < UX ? pl[R][X + 4] : 0.0) : cc[c < 3 ? c + 1 : 0];
             const double cxm = tcx[0][X + c], cxp = tcx[1][X + c];
             double sum = 0.0;
-            sum += cxm * (left - xcc);
-            sum += cxp * (right - xcc);
-            sum += cym * (pl[R - 1][X + c] - xcc);
-            sum += cyp * (pl[R + 1][X + c] - xcc);
-            sum += czm * (zm[c] - xcc);
-            sum += czp * (zp[c] - xcc);
+            sum = facc(sum, cxm, left, xcc);
+            sum = facc(sum, cxp, right, xcc);
+            sum = facc(sum, cym, pl[R - 1][X + c], xcc);
+            sum = facc(sum, cyp, pl[R + 1][X + c], xcc);
+            sum = facc(sum, czm, zm[c], xcc);
+            sum = facc(sum, czp, zp[c], xcc);
             const double s4 = ((cxm + cxp) + cym) + cyp;
-            out[c] = xcc + omega * ((((bv[c] * (tcx[2][X + c] * rwy)) * rwz) - sum) / (-((s4 + czm) + czp)));
+            out[c] = jstep(xcc, omega, (((bv[c] * (tcx[2][X + c] * rwy)) * rwz) - sum) / (-((s4 + czm) + czp)));
         }
         return out;
     };
@@ -1385,10 +1398,10 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
             double vl = __shfl_up(c1[c][b2], 1, 64), vr = __shfl_down(c0[c][b2], 1, 64);
             if (edgeL) vl = pj[fL];
             if (edgeR) vr = pj[fR];
-            s += (wzy * rw.x) * vl;
-            s += (wzy * rw.y) * c0[c][b2];
-            s += (wzy * rw.z) * c1[c][b2];
-            s += (wzy * rw.w) * vr;
+            s = tacc(s, (wzy * rw.x), vl);
+            s = tacc(s, (wzy * rw.y), c0[c][b2]);
+            s = tacc(s, (wzy * rw.z), c1[c][b2]);
+            s = tacc(s, (wzy * rw.w), vr);
         }
     }
     if (valid) bc[(int64_t)KK * C.nx * C.ny + (int64_t)J * C.nx + I] = s;
@@ -1489,10 +1502,10 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
                     for (int b2 = 0; b2 < 4; ++b2) {
                         const double wzy = wklo * wj[a][b2];
                         const int r = 2 * a + b2;
-                        s += (wzy * rw.x) * vl[r];
-                        s += (wzy * rw.y) * c0[r];
-                        s += (wzy * rw.z) * c1[r];
-                        s += (wzy * rw.w) * vr[r];
+                        s = tacc(s, (wzy * rw.x), vl[r]);
+                        s = tacc(s, (wzy * rw.y), c0[r]);
+                        s = tacc(s, (wzy * rw.z), c1[r]);
+                        s = tacc(s, (wzy * rw.w), vr[r]);
                     }
                     lo[a] = s;
                 }
@@ -1502,10 +1515,10 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
                     for (int b2 = 0; b2 < 4; ++b2) {
                         const double wzy = wkhi * wj[a][b2];
                         const int r = 2 * a + b2;
-                        s += (wzy * rw.x) * vl[r];
-                        s += (wzy * rw.y) * c0[r];
-                        s += (wzy * rw.z) * c1[r];
-                        s += (wzy * rw.w) * vr[r];
+                        s = tacc(s, (wzy * rw.x), vl[r]);
+                        s = tacc(s, (wzy * rw.y), c0[r]);
+                        s = tacc(s, (wzy * rw.z), c1[r]);
+                        s = tacc(s, (wzy * rw.w), vr[r]);
                     }
                     hi[a] = s;
                 }
@@ -1647,13 +1660,13 @@ __global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__r
                         const double left = (c == 0) ? (X > 0 ? xs[R][X - 1] : 0.0) : xc[e][c > 0 ? c - 1 : 0];
                         const double right = (c == 3) ? (X + 4 < RSX ? xs[R][X + 4] : 0.0) : xc[e][c < 3 ? c + 1 : 0];
                         double sum = 0.0;
-                        sum += tcx[0][X + c] * (left - xcc);
-                        sum += tcx[1][X + c] * (right - xcc);
-                        sum += cym * (xs[R - 1][X + c] - xcc);
-                        sum += cyp * (xs[R + 1][X + c] - xcc);
-                        sum += czm * (xm[e][c] - xcc);
-                        sum += czp * (xp[e][c] - xcc);
-                        out[c] = bcur[e][c] - (sum * (tcx[2][X + c] * wyj)) * wzk;
+                        sum = facc(sum, tcx[0][X + c], left, xcc);
+                        sum = facc(sum, tcx[1][X + c], right, xcc);
+                        sum = facc(sum, cym, xs[R - 1][X + c], xcc);
+                        sum = facc(sum, cyp, xs[R + 1][X + c], xcc);
+                        sum = facc(sum, czm, xm[e][c], xcc);
+                        sum = facc(sum, czp, xp[e][c], xcc);
+                        out[c] = resid(bcur[e][c], sum * (tcx[2][X + c] * wyj), wzk);
                     }
                 }
                 *reinterpret_cast<v4 *>(&rs[prow[e] - 1][pcol[e]]) = out;
@@ -1685,10 +1698,10 @@ __global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__r
                     for (int b2 = 0; b2 < 4; ++b2) {
                         const double wzy = wklo * wj[a][b2];
                         const int r = 2 * a + b2;
-                        s += (wzy * rw.x) * vl[r];
-                        s += (wzy * rw.y) * c0[r];
-                        s += (wzy * rw.z) * c1[r];
-                        s += (wzy * rw.w) * vr[r];
+                        s = tacc(s, (wzy * rw.x), vl[r]);
+                        s = tacc(s, (wzy * rw.y), c0[r]);
+                        s = tacc(s, (wzy * rw.z), c1[r]);
+                        s = tacc(s, (wzy * rw.w), vr[r]);
                     }
                     lo[a] = s;
                 }
@@ -1698,10 +1711,10 @@ __global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__r
                     for (int b2 = 0; b2 < 4; ++b2) {
                         const double wzy = wkhi * wj[a][b2];
                         const int r = 2 * a + b2;
-                        s += (wzy * rw.x) * vl[r];
-                        s += (wzy * rw.y) * c0[r];
-                        s += (wzy * rw.z) * c1[r];
-                        s += (wzy * rw.w) * vr[r];
+                        s = tacc(s, (wzy * rw.x), vl[r]);
+                        s = tacc(s, (wzy * rw.y), c0[r]);
+                        s = tacc(s, (wzy * rw.z), c1[r]);
+                        s = tacc(s, (wzy * rw.w), vr[r]);
                     }
                     hi[a] = s;
                 }
@@ -1748,7 +1761,7 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
                 nxt[p] = omega * (scale_b(L, i, j, k, b[p]) / d);
             } else {
                 const double ax = apply_cell(L, cur, p, i, j, k, &d);
-                nxt[p] = cur[p] + omega * ((scale_b(L, i, j, k, b[p]) - ax) / d);
+                nxt[p] = jstep(cur[p], omega, (scale_b(L, i, j, k, b[p]) - ax) / d);
             }
         }
         __threadfence_block();
@@ -1900,7 +1913,7 @@ __device__ __forceinline__ double tail_row(const TailCell &t, const double *x, i
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-        if ((t.has >> q) & 1) s += t.c[q] * (x[p + t.off[q]] - xc);
+        if ((t.has >> q) & 1) s = facc(s, t.c[q], x[p + t.off[q]], xc);
     return s;
 }
 // one phase of one cell: the step from a zero guess, a damped-Jacobi step x -> out, or the residual of x
@@ -1913,8 +1926,8 @@ __device__ __forceinline__ void tail_cell_phase(const TailCell &t, bool zero, bo
         return;
     }
     const double row = tail_row(t, x, p);
-    if (res) out[p] = b[p] - (row * t.wxy) * t.wz;
-    else out[p] = x[p] + omega * ((t.bs - row) / t.d);
+    if (res) out[p] = resid(b[p], row * t.wxy, t.wz);
+    else out[p] = jstep(x[p], omega, (t.bs - row) / t.d);
 }
 
 // One visit of a level: `steps` smoothing steps (the first from a zero guess on the way down) and, on the way down, the
@@ -2080,7 +2093,7 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
                         if (wzy == 0.0) continue;  // (a 2-D level: one row of the four; the terms left out are +-0)
                         const double *pj = pk + F.nx * sj[b2];
 #pragma unroll
-                        for (int a2 = 0; a2 < 4; ++a2) sum += (wzy * wi[a2]) * pj[si[a2]];
+                        for (int a2 = 0; a2 < 4; ++a2) sum = tacc(sum, (wzy * wi[a2]), pj[si[a2]]);
                     }
                 }
                 bc[q] = sum;
@@ -2122,7 +2135,7 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
 #pragma unroll
                         for (int a2 = 0; a2 < 2; ++a2) {
                             const double wgt = (wk[c2] * wj[b2]) * wi[a2];
-                            if (wgt != 0.0) sum += wgt * a[I[a2] + C.nx * J[b2] + cplane * (K[c2] - C.k0)];
+                            if (wgt != 0.0) sum = tacc(sum, wgt, a[I[a2] + C.nx * J[b2] + cplane * (K[c2] - C.k0)]);
                         }
                 xf[p] += sum;
             }
@@ -2301,14 +2314,14 @@ __device__ __forceinline__ void sm_phase(const LevelDev &F, const SmGeom &G, con
             // a neighbour beyond the region: only at a clipped face, i.e. a wall -- zero coefficient, the centre's own value
             const double xc = src[q];
             double s = 0.0;
-            s += cxm * (src[rx > 0 ? q - 1 : q] - xc);
-            s += cxp * (src[rx < G.ext[0] - 1 ? q + 1 : q] - xc);
-            s += cym * (src[ry > 0 ? q - sy : q] - xc);
-            s += cyp * (src[ry < G.ext[1] - 1 ? q + sy : q] - xc);
-            s += czm * (src[rz > 0 ? q - sz : q] - xc);
-            s += czp * (src[rz < G.ext[2] - 1 ? q + sz : q] - xc);
-            if (MODE == 2) v[uu] = xc + omega * ((bs - s) / d);
-            else v[uu] = bv - (s * (T.w[0][rx] * T.w[1][ry])) * T.w[2][rz];
+            s = facc(s, cxm, src[rx > 0 ? q - 1 : q], xc);
+            s = facc(s, cxp, src[rx < G.ext[0] - 1 ? q + 1 : q], xc);
+            s = facc(s, cym, src[ry > 0 ? q - sy : q], xc);
+            s = facc(s, cyp, src[ry < G.ext[1] - 1 ? q + sy : q], xc);
+            s = facc(s, czm, src[rz > 0 ? q - sz : q], xc);
+            s = facc(s, czp, src[rz < G.ext[2] - 1 ? q + sz : q], xc);
+            if (MODE == 2) v[uu] = jstep(xc, omega, (bs - s) / d);
+            else v[uu] = resid(bv, s * (T.w[0][rx] * T.w[1][ry]), T.w[2][rz]);
         }
     }
 #pragma unroll
@@ -2420,7 +2433,7 @@ __global__ __launch_bounds__(SM_NT) void k_small_down(const Scalars *__restrict_
                 for (int b2 = 0; b2 < 4; ++b2) {
                     const double wzy = w[2][c2] * w[1][b2];
 #pragma unroll
-                    for (int a2 = 0; a2 < 4; ++a2) sum += (wzy * w[0][a2]) * rv[b2][a2];
+                    for (int a2 = 0; a2 < 4; ++a2) sum = tacc(sum, (wzy * w[0][a2]), rv[b2][a2]);
                 }
             }
             bc[(int64_t)Ic[0] + (int64_t)C.nx * (Ic[1] + (int64_t)C.ny * (Ic[2] - C.k0))] = sum;
@@ -2482,7 +2495,7 @@ __global__ __launch_bounds__(SM_NT) void k_small_up(const Scalars *__restrict__ 
                                            (a2 ? T.woth[0][r3[0]] : T.wpar[0][r3[0]]);
                         const int I = a2 ? T.oth[0][r3[0]] : T.par[0][r3[0]], J = b2 ? T.oth[1][r3[1]] : T.par[1][r3[1]],
                                   K = c2 ? T.oth[2][r3[2]] : T.par[2][r3[2]];
-                        if (wgt != 0.0) sum += wgt * xc[I + (int64_t)C.nx * J + cplane * (K - C.k0)];
+                        if (wgt != 0.0) sum = tacc(sum, wgt, xc[I + (int64_t)C.nx * J + cplane * (K - C.k0)]);
                     }
             A_[r3[0] + G.ext[0] * r3[1] + G.ext[0] * G.ext[1] * r3[2]] = xq[u] + sum;
         }
@@ -3581,8 +3594,10 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // the Krylov sums in a fixed order of workgroups)
             const bool level_ok = l >= 1 || (pin_l == nullptr && s->gmg_upd.w == nullptr);
             if (level_ok && !cheb && local_pair && small_level_boxes(s, g, cg1, pre, true, bc3, &nblk)) {
-                if (l == 0) {  // no swaps on the way down: `post` swaps on the way up must end in z
-                    if (post % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
+                if (l == 0) {  // no swaps on the way down: the swaps of the way up must end in z (the fused pair of
+                               // post-smoothing steps, k_prolong_smooth2, is ONE swap -- the same count as above)
+                    const int up_swaps = post2_ok(0) ? 1 : post;
+                    if (up_swaps % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
                 }
                 hipLaunchKernelGGL(k_small_down, dim3(nblk), dim3(SM_NT), 0, q, S, dev_of(g), dev_of(cg1), omega, pre, b, a, cg1.b + cg1.pad, bc3[0],
                                    bc3[1], bc3[2]);

@@ -802,14 +802,19 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
     LoopbackGroup *g = s->comm.loop;
     PeerFailGuard guard(g);
     const int r = s->comm.rank;
-    const int64_t half = g->devord ? g->dc.half / 2 : g->win_doubles / 2;
     int64_t np = 0, nn = 0;
     for (const auto &m : to_prev) np += m.second;
     for (const auto &m : to_next) nn += m.second;
-    if (np > half || nn > half || lo > half || hi > half)
-        return fail(PIB_ERR_SUP, "peer transport: a message of %lld entries does not fit %s a window (%lld): raise PIB_PEER_WINDOW_MB",
-                    (long long)std::max(std::max(np, nn), std::max(lo, hi)), g->devord ? "a quarter of" : "half", (long long)half);
-    if (g->devord) {
+    const int64_t longest = std::max(std::max(np, nn), std::max(lo, hi));
+    // device-ordered: a message per neighbour in one receive half (a quarter window each).  Longer messages -- up to half a
+    // send window, the host-ordered limit -- take the host-ordered path below, as the general exchange and the all-gather do
+    // (inside a captured iteration that path refuses: begin()).
+    const bool devord = g->devord && longest <= g->dc.half / 2;
+    const int64_t half = devord ? g->dc.half / 2 : g->win_doubles / 2;
+    if (longest > half)
+        return fail(PIB_ERR_SUP, "peer transport: a message of %lld entries does not fit half a window (%lld): raise PIB_PEER_WINDOW_MB",
+                    (long long)longest, (long long)half);
+    if (devord) {
         // a rank's receive half: [what the previous rank sends | what the next rank sends]
         std::vector<PutMsg> puts;
         std::vector<GetMsg> gets;

@@ -594,7 +594,15 @@ static int run_iterations(pib_solver *s, int todo, int first_index, uint64_t key
                 PIB_HIP(hipStreamSynchronize(q));  // nothing of the collectives before is in flight on another stream
                 comm_capture_boundary(s, true);
             }
-            PIB_HIP(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
+            {
+                const hipError_t eb = hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal);
+                if (eb != hipSuccess) {
+                    // the communicator group is shared with the other solvers of the step: never leave it marked as capturing
+                    if (s->comm.nranks > 1) comm_capture_boundary(s, false);
+                    (void)hipGetLastError();
+                    return fail(PIB_ERR_LIB, "solver %s: hipStreamBeginCapture failed (%s)", s->name.c_str(), hipGetErrorString(eb));
+                }
+            }
             const int err = body();
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(q, &g);

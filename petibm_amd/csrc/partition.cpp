@@ -361,14 +361,20 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
             const int pc[3] = {q % g3[0], (q / g3[0]) % g3[1], q / (g3[0] * g3[1])};
             int64_t cells = 1;
             for (int d = 0; d < 3; ++d) {
-                if (H(q, 2 + d) != ext[d][(size_t)pc[d]]) return 0;
+                if (H(q, 2 + d) != ext[d][(size_t)pc[d]]) {
+                    redist_release(s);  // (R.nf / F.box are filled by now: leave no half-built state behind, like redist_velocity_setup)
+                    return 0;
+                }
                 int64_t o = 0;
                 for (int c = 0; c < pc[d]; ++c) o += ext[d][(size_t)c];
                 F.box[6 * (size_t)q + d] = o;
                 F.box[6 * (size_t)q + 3 + d] = ext[d][(size_t)pc[d]];
                 cells *= ext[d][(size_t)pc[d]];
             }
-            if (ranges[(size_t)q] != expect || ranges[(size_t)q + 1] - ranges[(size_t)q] != cells) return 0;
+            if (ranges[(size_t)q] != expect || ranges[(size_t)q + 1] - ranges[(size_t)q] != cells) {
+                redist_release(s);
+                return 0;
+            }
             expect += cells;
         }
     }
