@@ -42,6 +42,8 @@ def lib():
                C.c_double, C.c_int, C.c_int, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]
         _lib.orc_cg.argtypes = sig
         _lib.orc_cg.restype = C.c_int
+        _lib.orc_cg_single_reduction.argtypes = sig
+        _lib.orc_cg_single_reduction.restype = C.c_int
         _lib.orc_bcgs.argtypes = sig
         _lib.orc_bcgs.restype = C.c_int
         _lib.orc_spgemm_symbolic.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, _i64p, _i64p, _i64p]
@@ -143,9 +145,10 @@ def _krylov(fn, m, b, x0=None, pc="none", nullspace=0, norm="preconditioned", rt
             "history": hist[: its.value + 1].copy()}
 
 
-def cg(m, b, **kw):
-    """KSPCG restatement -- see oracle/csrc/oracle.c:orc_cg."""
-    return _krylov(lib().orc_cg, m, b, **kw)
+def cg(m, b, single_reduction=False, **kw):
+    """KSPCG restatement -- see oracle/csrc/oracle.c:orc_cg (single_reduction: orc_cg_single_reduction, the
+    KSPCGUseSingleReduction recurrences)."""
+    return _krylov(lib().orc_cg_single_reduction if single_reduction else lib().orc_cg, m, b, **kw)
 
 
 def bcgs(m, b, **kw):
@@ -171,6 +174,8 @@ class GMG:
         L.orc_pcg_gmg.restype = C.c_int
         L.orc_pcg_gmg.argtypes = [C.c_void_p, C.c_int64, _i64p, _i64p, _f64p, C.c_int, C.c_double, C.c_double, C.c_int,
                                   C.c_int, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]
+        L.orc_pcg_gmg_single_reduction.restype = C.c_int
+        L.orc_pcg_gmg_single_reduction.argtypes = L.orc_pcg_gmg.argtypes
         self.dim = len(n)
         self.n = np.array(list(n), dtype=np.int64)
         self._w = [np.ascontiguousarray(w, dtype=np.float64) for w in widths]
@@ -206,13 +211,14 @@ class GMG:
         lib().orc_gmg_apply_operator(self._h, lev, np.ascontiguousarray(x, dtype=np.float64), y)
         return y
 
-    def pcg(self, m, b, x0=None, norm="unpreconditioned", rtol=1e-10, atol=0.0, maxit=1000):
+    def pcg(self, m, b, x0=None, norm="unpreconditioned", rtol=1e-10, atol=0.0, maxit=1000, single_reduction=False):
         b = np.ascontiguousarray(b, dtype=np.float64)
         x = np.zeros(m.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
         hist = np.full(maxit + 2, np.nan)
         its, rn = C.c_int(0), C.c_double(0)
-        reason = lib().orc_pcg_gmg(self._h, m.n_rows, m.rowptr, m.col, m.val, NORM[norm], rtol, atol, int(maxit),
-                                   int(x0 is not None), b, x, C.byref(its), C.byref(rn), hist.ctypes.data)
+        fn = lib().orc_pcg_gmg_single_reduction if single_reduction else lib().orc_pcg_gmg
+        reason = fn(self._h, m.n_rows, m.rowptr, m.col, m.val, NORM[norm], rtol, atol, int(maxit),
+                    int(x0 is not None), b, x, C.byref(its), C.byref(rn), hist.ctypes.data)
         return {"x": x, "iters": its.value, "rnorm": rn.value, "reason": int(reason),
                 "history": hist[: its.value + 1].copy()}
 

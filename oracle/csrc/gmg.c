@@ -517,13 +517,16 @@ static double ddot(i64 n, const double *a, const double *b)
     return s;
 }
 
-int orc_pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double *val, int normtype, double rtol,
-                double atol, int maxit, int guess_nonzero, const double *b, double *x, int *its_out,
-                double *rnorm_out, double *history)
+/* single_reduction != 0: the recurrences of KSPCGUseSingleReduction (oracle.c:orc_cg_single_reduction): s = A z, delta = z's,
+ * w = s + b w and dpi = delta - beta^2 dpiold / betaold^2 from the second iteration on. */
+static int pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double *val, int normtype, double rtol,
+                   double atol, int maxit, int guess_nonzero, const double *b, double *x, int *its_out,
+                   double *rnorm_out, double *history, int single_reduction)
 {
     gmg_t *G = h;
     double *R = malloc((size_t)n * 8), *Z = malloc((size_t)n * 8), *P = malloc((size_t)n * 8), *W = malloc((size_t)n * 8);
-    double beta, betaold = 1.0, dpi = 0.0, dpiold, dp, a, ttol, rnorm0;
+    double *Sv = single_reduction ? malloc((size_t)n * 8) : NULL;
+    double beta, betaold = 1.0, dpi = 0.0, dpiold, dp, a, ttol, rnorm0, delta = 0.0;
     int reason = 0, i = 0;
     if (!guess_nonzero) { memset(x, 0, (size_t)n * 8); memcpy(R, b, (size_t)n * 8); }
     else {
@@ -548,6 +551,10 @@ int orc_pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double 
     if (history) history[0] = dp;
     *its_out = 0;
     if (dp <= ttol) { reason = 2; goto done; }
+    if (single_reduction) {
+        orc_spmv(n, rowptr, col, val, Z, Sv);
+        delta = ddot(n, Z, Sv);
+    }
     beta = ddot(n, Z, R);
     do {
         *its_out = i + 1;
@@ -560,8 +567,15 @@ int orc_pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double 
             for (i64 q = 0; q < n; ++q) P[q] = Z[q] + bb * P[q];
         }
         dpiold = dpi;
-        orc_spmv(n, rowptr, col, val, P, W);
-        dpi = ddot(n, P, W);
+        if (!single_reduction || i == 0) {
+            orc_spmv(n, rowptr, col, val, P, W);
+            dpi = ddot(n, P, W);
+        } else {
+            const double bb = beta / betaold;
+#pragma omp parallel for schedule(static)
+            for (i64 q = 0; q < n; ++q) W[q] = Sv[q] + bb * W[q];
+            dpi = delta - beta * beta * dpiold / (betaold * betaold);
+        }
         betaold = beta;
         if (dpi == 0.0 || (i > 0 && ((dpi > 0) != (dpiold > 0)))) { reason = -10; break; }
         a = beta / dpi;
@@ -578,14 +592,31 @@ int orc_pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double 
             if (history) history[i + 1] = dp;
             if (dp <= ttol) { reason = 2; break; }
         }
+        if (single_reduction) {
+            orc_spmv(n, rowptr, col, val, Z, Sv);
+            delta = ddot(n, Z, Sv);
+        }
         beta = ddot(n, Z, R);
         i++;
     } while (i < maxit);
     if (!reason && i >= maxit) reason = -3;
 done:
     *rnorm_out = dp;
-    free(R); free(Z); free(P); free(W);
+    free(R); free(Z); free(P); free(W); free(Sv);
     return reason;
+}
+
+int orc_pcg_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double *val, int normtype, double rtol,
+                double atol, int maxit, int guess_nonzero, const double *b, double *x, int *its_out,
+                double *rnorm_out, double *history)
+{
+    return pcg_gmg(h, n, rowptr, col, val, normtype, rtol, atol, maxit, guess_nonzero, b, x, its_out, rnorm_out, history, 0);
+}
+int orc_pcg_gmg_single_reduction(void *h, i64 n, const i64 *rowptr, const i64 *col, const double *val, int normtype, double rtol,
+                                 double atol, int maxit, int guess_nonzero, const double *b, double *x, int *its_out,
+                                 double *rnorm_out, double *history)
+{
+    return pcg_gmg(h, n, rowptr, col, val, normtype, rtol, atol, maxit, guess_nonzero, b, x, its_out, rnorm_out, history, 1);
 }
 
 

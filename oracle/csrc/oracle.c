@@ -251,6 +251,97 @@ done:
 }
 
 /*
+ * KSPSolve_CG with KSPCGUseSingleReduction / -<name>_ksp_cg_single_reduction (PETSc 3.16, src/ksp/ksp/impls/cg/cg.c: the
+ * `cg->singlereduction` branches of KSPSolve_CG; the reference configures its KSP from the options database at
+ * src/linsolver/linsolverksp.cpp:62-66, so the option is one line in a PetIBM solver file).  PETSc is absent from
+ * /root/reference: restated from its published algorithm (the inner products of an iteration merged into one VecMDot):
+ *   before the loop   z = B r;  s = A z;  delta = z's;  beta = z'r
+ *   iteration i       b = beta / betaold;  p = z + b p
+ *                     i == 0: w = A p, dpi = p'w          (PETSc multiplies once more on the first iteration; p = z there)
+ *                     i  > 0: w = s + b w,  dpi = delta - beta^2 dpiold / betaold^2
+ *                     a = beta / dpi;  x += a p;  r -= a w;  z = B r;  s = A z
+ *                     dp = |z| or |r|;  (delta, beta) = (z's, z'r) in ONE reduction
+ * The matrix is applied to z, never to p; w = A p follows by recurrence.  Same arguments and return values as orc_cg.
+ */
+int orc_cg_single_reduction(i64 n, const i64 *rowptr, const i64 *col, const double *val, const double *dinv, int pc,
+                            int nullspace, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
+                            const double *b, double *x, int *its_out, double *rnorm_out, double *history)
+{
+    sys_t S = {n, rowptr, col, val, dinv, pc, nullspace};
+    double *R = malloc((size_t)n * 8), *Z = malloc((size_t)n * 8), *P = malloc((size_t)n * 8),
+           *W = malloc((size_t)n * 8), *Sv = malloc((size_t)n * 8);
+    double beta = 0, betaold = 1, dpi = 0, dpiold = 0, dp = 0, delta = 0, a, bb, ttol, rnorm0;
+    int reason = 0, i = 0;
+
+    if (!guess_nonzero) {
+        memset(x, 0, (size_t)n * 8);
+        copy(n, b, R);
+    } else {
+        matmult(&S, x, R);
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) R[q] = b[q] - R[q];
+    }
+    if (normtype == NORM_PRECONDITIONED) {
+        pcapply(&S, R, Z);
+        dp = sqrt(dot(n, Z, Z));
+    } else {
+        dp = sqrt(dot(n, R, R));
+    }
+    rnorm0 = dp;
+    ttol = fmax(rtol * rnorm0, atol);
+    if (history) history[0] = dp;
+    *its_out = 0;
+    if (converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) goto done;
+    if (normtype != NORM_PRECONDITIONED) pcapply(&S, R, Z);
+    matmult(&S, Z, Sv);
+    delta = dot(n, Z, Sv);
+    beta = dot(n, Z, R);
+
+    do {
+        *its_out = i + 1;
+        if (beta == 0.0) { reason = CONVERGED_ATOL; break; }
+        if (i > 0 && ((beta > 0) != (betaold > 0))) { reason = DIVERGED_INDEFINITE_PC; break; }
+        dpiold = dpi;
+        if (i == 0) {
+            copy(n, Z, P);
+            matmult(&S, P, W);
+            dpi = dot(n, P, W);
+        } else {
+            bb = beta / betaold;
+            aypx(n, bb, Z, P);  /* p = z + b p */
+            aypx(n, bb, Sv, W); /* w = s + b w  ( = A p ) */
+            dpi = delta - beta * beta * dpiold / (betaold * betaold);
+        }
+        betaold = beta;
+        if (dpi == 0.0 || (i > 0 && ((dpi > 0) != (dpiold > 0)))) { reason = DIVERGED_INDEFINITE_MAT; break; }
+        a = beta / dpi;
+        axpy(n, a, P, x);
+        axpy(n, -a, W, R);
+        if (normtype == NORM_PRECONDITIONED) {
+            pcapply(&S, R, Z);
+            matmult(&S, Z, Sv);
+            dp = sqrt(dot(n, Z, Z));
+        } else {
+            dp = sqrt(dot(n, R, R));
+        }
+        if (history) history[i + 1] = dp;
+        if (converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) break;
+        if (normtype != NORM_PRECONDITIONED) {
+            pcapply(&S, R, Z);
+            matmult(&S, Z, Sv);
+        }
+        delta = dot(n, Z, Sv);
+        beta = dot(n, Z, R);
+        i++;
+    } while (i < maxit);
+    if (!reason && i >= maxit) reason = DIVERGED_ITS;
+done:
+    *rnorm_out = dp;
+    free(R); free(Z); free(P); free(W); free(Sv);
+    return reason;
+}
+
+/*
  * KSPSolve_BCGS restatement (PETSc's left-preconditioned BiCGStab; the
  * recurrences run on the PRECONDITIONED residual r = B(b - A x)):
  *   R = B(b - A x); RP = R; rho=alpha=omega=1; P = V = 0

@@ -338,6 +338,74 @@ struct OpUpdateP {
     }
 };
 
+// single-reduction CG: the whole vector part of an iteration in one pass --
+//   p = (z - mean) + b p ;  w = s + b w  (= A p) ;  x += a p ;  r -= a w ;  z = M^-1 r (Jacobi / none) ; partials 0, 1, 2, 4, 5
+// (the first iteration: p = z - mean, w = s).  PCM_EXTERNAL (multigrid): z is left alone, only r.r and sum r are summed.
+template <int PCM>
+struct OpSRUpdate {
+    static constexpr int NRED = 6;
+    const double *sv, *dinv;
+    double *z, *p, *w, *x, *r;
+    double omega;
+    double bcoef, a, mean;
+    int first;
+    __device__ void prepare(const Scalars *S)
+    {
+        bcoef = S->b;
+        a = S->a;
+        mean = S->mean;
+        first = (S->its == 0);
+    }
+    template <int W>
+    __device__ void apply(int64_t i, double (&acc)[6]) const
+    {
+        Pack<W> vz = ld<W>(z, i), vs = ld<W>(sv, i), vp, vw;
+        if (first) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                vp.v[k] = vz.v[k] - mean;
+                vw.v[k] = vs.v[k];
+            }
+        } else {
+            vp = ld<W>(p, i);
+            vw = ld<W>(w, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                vp.v[k] = (vz.v[k] - mean) + bcoef * vp.v[k];
+                vw.v[k] = vs.v[k] + bcoef * vw.v[k];
+            }
+        }
+        st<W>(p, i, vp);
+        st<W>(w, i, vw);
+        Pack<W> vx = ld<W>(x, i), vr = ld<W>(r, i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            vx.v[k] = vx.v[k] + a * vp.v[k];
+            vr.v[k] = vr.v[k] - a * vw.v[k];
+        }
+        st<W>(x, i, vx);
+        st<W>(r, i, vr);
+        if (PCM == PCM_JACOBI) {
+            Pack<W> vd = ld<W>(dinv, i);
+#pragma unroll
+            for (int k = 0; k < W; ++k) vz.v[k] = omega * (vd.v[k] * vr.v[k]);
+            st<W>(z, i, vz);
+        } else if (PCM == PCM_NONE) {
+            vz = vr;  // z aliases r
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            if (PCM != PCM_EXTERNAL) {
+                acc[0] += vz.v[k] * vr.v[k];
+                acc[1] += vz.v[k] * vz.v[k];
+                acc[2] += vz.v[k];
+            }
+            acc[4] += vr.v[k] * vr.v[k];
+            acc[5] += vr.v[k];
+        }
+    }
+};
+
 // the x update still owed when the iteration stops: x += a p
 // (if_done: launched speculatively after the first batch of iterations -- acts only if the solve has stopped, see solve_cg)
 __global__ __launch_bounds__(256) void k_flush_x(const Scalars *__restrict__ S, int64_t n, const double *__restrict__ p,
@@ -473,10 +541,9 @@ __global__ void k_cg_s1(Scalars *S)
 }
 
 // do_norm: evaluate the monitored norm + convergence; do_beta: new beta, b.
-__global__ void k_cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean, int do_norm, int do_beta,
-                        int conv_is_its)
+__device__ __forceinline__ void cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean, int do_norm, int do_beta,
+                                      int conv_is_its)
 {
-    if (S->done) return;
     double zr = S->red[0], zz = S->red[1], rr = S->red[4];
     if (do_beta) lazy_shift(S, n_global, lazy_mean, zr, zz);
     if (do_norm) {
@@ -506,6 +573,48 @@ __global__ void k_cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean
             S->b = zr / S->betaold;
         }
     }
+}
+__global__ void k_cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean, int do_norm, int do_beta,
+                        int conv_is_its)
+{
+    if (S->done) return;
+    cg_s2(S, hist, n_global, lazy_mean, do_norm, do_beta, conv_is_its);
+}
+
+// ---- single-reduction CG (KSPCGUseSingleReduction; oracle/csrc/oracle.c:orc_cg_single_reduction): the matrix is applied to z,
+// s = A z, and the top of an iteration needs no sum of its own --
+//     dpi = p'w = delta - beta^2 dpiold / betaold^2   (delta = z's; the first iteration: p = z, dpi = delta),   a = beta / dpi
+// -- so ALL sums of an iteration (z.r, z.z, sum z, z[0], r.r, sum r, z.s) go through ONE all-reduce, behind the product.
+// (z - m).s = z.s - m sum(s), and sum(s) = 1'A z = 0 for the symmetric operator with A 1 = 0 the lazy shift is used with: the
+// term is dropped.
+__device__ __forceinline__ void cg_sr_top(Scalars *S)
+{
+    S->dpiold = S->dpi;
+    const double delta = S->red[6], beta = S->beta, bo = S->betaold;
+    const double dpi = (S->its == 0) ? delta : delta - beta * beta * S->dpiold / (bo * bo);
+    S->dpi = dpi;
+    if (dpi == 0.0 || dpi != dpi || (S->its > 0 && ((dpi > 0.0) != (S->dpiold > 0.0)))) {
+        S->reason = (dpi != dpi) ? PIB_DIVERGED_NANORINF : PIB_DIVERGED_INDEFINITE_MAT;
+        S->its += 1;
+        S->done = 1;
+        return;
+    }
+    S->a = beta / dpi;
+    S->betaold = beta;
+}
+// after the set-up (k_cg_s_init has beta, b = 0) and the first product s = A z
+__global__ void k_cg_sr_first(Scalars *S)
+{
+    if (S->done) return;
+    cg_sr_top(S);
+}
+// end of an iteration (norm, convergence, the new beta and b) and the top of the next one (dpi, a)
+__global__ void k_cg_sr_step(Scalars *S, double *hist, double n_global, int lazy_mean, int conv_is_its)
+{
+    if (S->done) return;
+    cg_s2(S, hist, n_global, lazy_mean, 1, 1, conv_is_its);
+    if (S->done) return;
+    cg_sr_top(S);
 }
 
 // ------------------------------------------------------------------ helpers
@@ -725,7 +834,7 @@ static int fetch_results(pib_solver *s, int enq)
 
 // ------------------------------------------------------------------ CG
 // Apply the multigrid preconditioner z = M^-1 r and finalize z.r, z.z, sum z (+ z[0] when pinned).
-static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guarded, hipStream_t q)
+static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guarded, hipStream_t q, bool reduce = true)
 {
     int nb = 0;
     s->gmg_guarded = guarded;
@@ -740,6 +849,7 @@ static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guard
     }
     hipLaunchKernelGGL(k_fetch_z0, dim3(1), dim3(1), 0, q, s->d_s, Z, (s->A.row0 == 0) ? 1 : 0);
     PIB_HIP(hipGetLastError());
+    if (!reduce) return 0;  // (single-reduction CG: these sums travel with the product's)
     return allreduce_slots(s, 0, 4, q);
 }
 
@@ -927,6 +1037,127 @@ int solve_cg(pib_solver *s, double *x, const double *b)
             PIB_CHK(poll(s));
     }
     flush(0);
+    return fetch_results(s, enq);
+}
+
+// ------------------------------------------------------------------ CG, single reduction
+// `cg_single_reduction` (solver file: pib_cg_single_reduction=1; PETSc options: -<name>_ksp_cg_single_reduction, the reference's
+// KSP reads the options database at linsolverksp.cpp:62-66).  Per iteration: one vector pass (OpSRUpdate), the preconditioner,
+// s = A z with z.s fused, ONE all-reduce of seven sums, one scalar step -- against three all-reduces of the standard recurrence.
+// The price is w = s + b w: 16 B/row more vector traffic; it pays where the reductions' latency does (several ranks).
+// A z needs z on the matrix's ghost entries: the V-cycle on slabs leaves it valid there (no exchange at all), any other
+// preconditioner exchanges z; p never leaves the rank.  The monitored norm is tested behind the iteration's product, so the
+// iteration that meets the tolerance still pays its V-cycle and product (results, counts and history are unaffected).
+int solve_cg_sr(pib_solver *s, double *x, const double *b)
+{
+    const DeviceCsr &A = s->A;
+    const int64_t n = A.n;
+    hipStream_t q = s->stream;
+    PIB_CHK(ensure_work(s, 5));
+    double *R = s->vec(0), *Z = s->vec(1), *P = s->vec(2), *W = s->vec(3), *SV = s->vec(4);
+    const Precond pc = s->cfg.pc;
+    const bool guess = s->cfg.initial_guess_nonzero;
+    const double ng = (double)A.n_global;
+    const bool gmg = (pc == Precond::GMG);
+    int lazy = 0;
+    if (s->nullspace == PIB_NULLSPACE_CONSTANT) lazy = 1;
+    if (s->nullspace == PIB_NULLSPACE_PINNED && gmg)
+        return fail(PIB_ERR_SUP, "solver %s: single-reduction CG with the multigrid and a pinned pressure row is not supported "
+                                 "(the lazy shift by z[0] does not commute with the product): use the constant null space or the standard recurrence",
+                    s->name.c_str());
+    const int monitor = s->cfg.monitor_residual ? 1 : 0;
+    const int conv_is_its = monitor ? 0 : 1;
+    const bool v2 = aligned16(x) && aligned16(b);
+    const bool xal = aligned16(x);
+    if (pc == Precond::NONE) Z = R;  // z aliases r
+    if (pc == Precond::JACOBI && A.dinv == nullptr) return fail(PIB_ERR_ORDER, "Jacobi preconditioner without a diagonal");
+    if (gmg && !s->has_grid)
+        return fail(PIB_ERR_ORDER,
+                    "solver %s: a multigrid (AMG/GMG) preconditioner needs the grid structure: call "
+                    "pib_set_grid_hint or pib_assemble_poisson before pib_solve", s->name.c_str());
+    const double omega = (pc == Precond::JACOBI) ? s->cfg.jacobi_relaxation : 1.0;
+    for (int k = 0; k < 8; ++k) s->counters[k] = 0;
+    PIB_CHK(init_scalars(s));
+    int nb = 0;
+    const int spmv_blocks = spmv_launch_blocks();
+    double *part_zs = s->d_part + (int64_t)SLOT_PW * PIB_MAXPART;
+
+    // s = A z with the z.s partials (slot 6); the V-cycle on slabs leaves z valid on the matrix's ghost entries
+    auto product = [&](bool guarded) -> int {
+        const int64_t zv = gmg ? (int64_t)s->z_halo_depth * s->levels[0].plane : 0;
+        if (s->comm.nranks > 1 && zv > 0 && zv >= A.ghost_lo && zv >= A.ghost_hi) s->halo_fresh = Z;
+        PIB_CHK(matmult(s, Z, SV, part_zs, guarded, q));
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, q, s->d_s, s->d_part, SLOT_PW, spmv_blocks);
+        PIB_HIP(hipGetLastError());
+        return 0;
+    };
+
+    // ---- set-up: r, z, their sums (as solve_cg), then the first product and its sum
+    if (!guess) {
+        OpFill z0{x, 0.0};
+        PIB_CHK(launch_vec(s, n, z0, v2, 0, nullptr, false, q));
+    }
+    if (guess) {
+        OpCopy cp{x, P};
+        PIB_CHK(launch_vec(s, n, cp, v2, 0, nullptr, false, q));
+        PIB_CHK(matmult(s, P, W, nullptr, false, q));
+    }
+    if (pc == Precond::JACOBI) {
+        OpInit<PCM_JACOBI> op{b, W, A.dinv, R, Z, omega, guess ? 1 : 0, 0};
+        PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
+    } else {
+        OpInit<PCM_NONE> op{b, W, nullptr, R, Z, 1.0, guess ? 1 : 0, 0};
+        PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(6), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);
+    PIB_HIP(hipGetLastError());
+    if (gmg) PIB_CHK(gmg_pc_and_dots(s, R, Z, false, q, false));
+    PIB_CHK(product(false));
+    PIB_CHK(allreduce_slots(s, 0, 7, q));
+    hipLaunchKernelGGL(k_cg_s_init, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, monitor);
+    hipLaunchKernelGGL(k_cg_sr_first, dim3(1), dim3(1), 0, q, s->d_s);
+    PIB_HIP(hipGetLastError());
+
+    const int batch0 = first_batch(s), batch1 = next_batch(s);
+    int enq = 0;
+    const int maxit = s->cfg.max_iters;
+    if (!skip_first_poll(s)) {
+        PIB_CHK(fetch_results(s, 0));
+        if (s->h_s->done) return 0;
+    }
+    while (!s->h_s->done && enq < maxit) {
+        const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
+        auto body = [&]() -> int {
+            if (pc == Precond::JACOBI) {
+                OpSRUpdate<PCM_JACOBI> op{SV, A.dinv, Z, P, W, x, R, omega, 0.0, 0.0, 0.0, 0};
+                PIB_CHK(launch_vec(s, n, op, xal, 0, &nb, true, q));
+                hipLaunchKernelGGL(k_finalize, dim3(6), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);
+            } else if (pc == Precond::NONE) {
+                OpSRUpdate<PCM_NONE> op{SV, nullptr, Z, P, W, x, R, 1.0, 0.0, 0.0, 0.0, 0};
+                PIB_CHK(launch_vec(s, n, op, xal, 0, &nb, true, q));
+                hipLaunchKernelGGL(k_finalize, dim3(6), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);
+            } else {
+                OpSRUpdate<PCM_EXTERNAL> op{SV, nullptr, Z, P, W, x, R, 1.0, 0.0, 0.0, 0.0, 0};
+                PIB_CHK(launch_vec(s, n, op, xal, 0, &nb, true, q));
+                hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, q, s->d_s, s->d_part, 4, nb);  // r.r, sum r
+                PIB_CHK(gmg_pc_and_dots(s, R, Z, true, q, false));
+            }
+            PIB_HIP(hipGetLastError());
+            PIB_CHK(product(true));
+            PIB_CHK(allreduce_slots(s, 0, 7, q));
+            hipLaunchKernelGGL(k_cg_sr_step, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, conv_is_its);
+            PIB_HIP(hipGetLastError());
+            return 0;
+        };
+        PIB_CHK(run_iterations(s, todo, enq, graph_key(3, x, b), q, body));
+        const bool first = enq == 0;
+        enq += todo;
+        if (first) {
+            PIB_CHK(fetch_results(s, enq));
+            if (s->h_s->done) return 0;
+        } else
+            PIB_CHK(poll(s));
+    }
     return fetch_results(s, enq);
 }
 

@@ -156,6 +156,12 @@ def test_petsc_options_subset(capi):
     assert d["method"] == "preonly" and d["pc"] == "lu"
     a = capi.config_describe("forces", "config_version=2\nsolver(s)=DENSE_LU_SOLVER\n")
     assert a["method"] == "preonly" and a["pc"] == "lu" and a["flavor"] == "amgx"
+    # PETSc's single-reduction CG (KSPCGUseSingleReduction) by its own option name, per prefix; off by default; the AmgX-style key
+    assert int(p["cg_single_reduction"]) == 0
+    sr = capi.config_describe("poisson", PETSC_BOTH + "-poisson_ksp_cg_single_reduction\n")
+    assert int(sr["cg_single_reduction"]) == 1 and sr["method"] == "cg"
+    assert int(capi.config_describe("velocity", PETSC_BOTH + "-poisson_ksp_cg_single_reduction true\n")["cg_single_reduction"]) == 0
+    assert int(capi.config_describe("poisson", AMGX_POISSON + "pib_cg_single_reduction=1\n")["cg_single_reduction"]) == 1
 
 
 @pytest.mark.parametrize("text,code", [

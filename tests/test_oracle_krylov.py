@@ -117,3 +117,53 @@ def test_gmg_oracle_properties(n):
     res = g.pcg(A, b, rtol=1e-10)
     assert res["reason"] > 0 and res["iters"] <= 25
     assert np.linalg.norm(b - clib.spmv(A, res["x"])) <= 1.2e-10 * np.linalg.norm(b)
+
+
+def test_single_reduction_cg_is_the_same_iteration(systems):
+    """KSPCGUseSingleReduction (oracle.c:orc_cg_single_reduction) is an algebraic rearrangement of KSPCG -- the matrix applied
+    to z, w = A p and p'w by recurrence: in exact arithmetic the same iterates.  Checked against the standard restatement
+    (itself checked against scipy above): the first 15 residual norms to 1e-9 (over the hundreds of iterations of the
+    unpreconditioned solve the two rounding histories drift apart as any two CG runs do), counts within 10 %, the same
+    solution -- every preconditioner / norm / null-space combination; the multigrid PCG (11-14 iterations) throughout."""
+    m, A, _ = systems
+    xs = np.random.default_rng(31).uniform(-1, 1, A.n_rows)
+    xs -= xs.mean()
+    b = clib.spmv(A, xs)
+    for pc in ("none", "jacobi"):
+        for norm in ("preconditioned", "unpreconditioned"):
+            kw = dict(pc=pc, nullspace=1, norm=norm, rtol=1e-10, atol=0.0, dtol=1e300, maxit=3000)
+            r0, r1 = clib.cg(A, b, **kw), clib.cg(A, b, single_reduction=True, **kw)
+            assert r1["reason"] == r0["reason"] > 0 and abs(r1["iters"] - r0["iters"]) <= max(1, r0["iters"] // 10)
+            assert np.abs(r1["history"][:15] - r0["history"][:15]).max() <= 1e-9 * r0["history"][0]
+            e0, e1 = r0["x"] - r0["x"].mean() - xs, r1["x"] - r1["x"].mean() - xs
+            assert np.linalg.norm(e1) <= 1e-7 * np.linalg.norm(xs) and np.linalg.norm(e0) <= 1e-7 * np.linalg.norm(xs)
+            assert np.isclose(r1["history"][0], r0["history"][0], rtol=1e-14)  # (the set-up is the same code; OpenMP sums)
+    # a pinned (non-singular, negative definite) system without null space, nonzero guess
+    P = oops.pin_row0(A)
+    bp = b.copy()
+    bp[0] = 0.0
+    x0 = np.random.default_rng(32).uniform(-1, 1, A.n_rows)
+    x0[0] = 0.0  # (the decoupled +1 row stays out of the recurrences: r[0] = 0, as in the scipy test above)
+    kw = dict(pc="jacobi", norm="unpreconditioned", rtol=1e-11, atol=0.0, dtol=1e300, maxit=3000, x0=x0)
+    r0, r1 = clib.cg(P, bp, **kw), clib.cg(P, bp, single_reduction=True, **kw)
+    assert r1["reason"] > 0 and abs(r1["iters"] - r0["iters"]) <= max(1, r0["iters"] // 10)
+    assert np.abs(r1["history"][:15] - r0["history"][:15]).max() <= 1e-9 * r0["history"][0]
+    assert np.linalg.norm(r1["x"] - r0["x"]) <= 1e-7 * np.linalg.norm(r0["x"])
+    # max_it and the first iteration (where PETSc multiplies with p itself)
+    r = clib.cg(A, b, single_reduction=True, pc="none", nullspace=1, rtol=1e-14, atol=0.0, maxit=3)
+    assert r["reason"] == -3 and r["iters"] == 3
+    r0, r1 = (clib.cg(A, b, single_reduction=sr, pc="jacobi", nullspace=1, rtol=1e-14, atol=0.0, maxit=1) for sr in (False, True))
+    assert np.allclose(r0["x"], r1["x"], rtol=1e-12, atol=1e-14) and np.allclose(r0["history"], r1["history"], rtol=1e-13)
+    # multigrid PCG
+    mu = omesh.create_mesh(omesh.uniform_config((24, 20, 16)))
+    D, Gm, L = oops.create_divergence(mu), oops.create_gradient(mu), oops.create_laplacian(mu)
+    _, Au = oops.create_poisson_operator(D, Gm, L, 1e-3, 0.5e-3)
+    g = clib.GMG((24, 20, 16), [mu.dL[3][d].true for d in range(3)], 1e-3, nullspace=1, pre=2, post=2)
+    xu = np.random.default_rng(33).uniform(-1, 1, mu.pN)
+    xu -= xu.mean()
+    bu = clib.spmv(Au, xu)
+    for norm in ("preconditioned", "unpreconditioned"):
+        r0, r1 = g.pcg(Au, bu, norm=norm, rtol=1e-10), g.pcg(Au, bu, norm=norm, rtol=1e-10, single_reduction=True)
+        assert r1["reason"] > 0 and r1["iters"] == r0["iters"]
+        assert np.abs(r1["history"] - r0["history"]).max() <= 1e-8 * r0["history"][0]
+        assert np.linalg.norm(r1["x"] - r0["x"]) <= 1e-9 * np.linalg.norm(r0["x"])
