@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--xdmf", action="store_true", help="write the .xmf descriptions of petibm-createxdmf next to the HDF5 files")
     ap.add_argument("--app", default="auto", choices=["auto", "navierstokes", "decoupledibpm", "ibpm"],
                     help="which of the reference's applications to mirror (auto: decoupledibpm when the case has bodies)")
+    ap.add_argument("--log-view", action="store_true",
+                    help="time the stages of a step under the reference's PetscLogStage names (what `-log_view` prints per stage)")
     a = ap.parse_args()
     d = os.path.abspath(a.directory)
     cfg = yaml.safe_load(open(os.path.join(d, "config.yaml")))
@@ -76,6 +78,8 @@ def main():
     mode = "a" if start > 0 else "w"
     it_file = open(os.path.join(out, f"iterations-{start}.txt"), mode)
     f_file = open(os.path.join(out, f"forces-{start}.txt"), mode) if cfg.get("bodies") else None
+    if a.log_view:
+        s.enableStageTimers()
     t0 = time.perf_counter()
     for _ in range(nt):
         s.advance()
@@ -98,6 +102,13 @@ def main():
     if f_file:
         f_file.close()
     print(f"{nt} steps in {wall:.2f} s ({1e3 * wall / max(nt, 1):.2f} ms/step); last step: {s.linSolversInfo()}")
+    if a.log_view:
+        st = s.stageTimes()
+        steps = max(st.pop("steps"), 1)
+        total = sum(st.values())
+        print(f"stage                 ms/step   share   ({steps} steps, HIP events on the engine's stream)")
+        for name, ms in st.items():
+            print(f"  {name:<18s} {ms / steps:9.3f}  {100.0 * ms / max(total, 1e-30):5.1f} %")
     s.destroy()
 
 

@@ -351,6 +351,16 @@ int pib_ns_advance(pib_ns *ns, int nsteps);
  * /convection/1, /diffusion/0); host arrays of UN entries, any may be NULL */
 int pib_ns_get_history(pib_ns *ns, double *conv0, double *conv1, double *diff0);
 int pib_ns_set_history(pib_ns *ns, const double *conv0, const double *conv1);
+/* Stage timers under the reference's PetscLogStage names -- "rhsVelocity", "solveVelocity", "rhsPoisson", "solvePoisson",
+ * "update" (applications/navierstokes/navierstokes.cpp:186-199; pushed / popped at :436-530, :532, :540-572, :575, :583-615)
+ * and, with immersed bodies, "rhsForces" + "solveForces" as ONE entry "solveForces" (applications/decoupledibpm/
+ * decoupledibpm.cpp:93-97, 259-282).  pib_ns_stage_timers(ns, 1) switches them on and zeroes the sums (off by default: a step
+ * then records seven events on the engine's stream and waits for the last one); pib_ns_get_stage_times returns the
+ * milliseconds accumulated per stage in the order of pib_ns_stage_name(0..5) = rhsVelocity, solveVelocity, solveForces,
+ * rhsPoisson, solvePoisson, update, and the number of steps they cover.  What PETSc's -log_view prints per stage. */
+int pib_ns_stage_timers(pib_ns *ns, int enable);
+int pib_ns_get_stage_times(pib_ns *ns, double ms[6], int64_t *steps);
+const char *pib_ns_stage_name(int stage);
 /* the columns of iterations-<start>.txt (navierstokes.cpp:766-794) for the last step */
 int pib_ns_get_solver_info(pib_ns *ns, int *v_iters, double *v_res, int *p_iters, double *p_res);
 int pib_ns_destroy(pib_ns *ns);

@@ -94,6 +94,9 @@ _PROTOS = {
     "pib_ns_set_history": (C.c_int, [_vp, _vp, _vp]),
     "pib_ns_get_solver_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                          C.POINTER(C.c_double)]),
+    "pib_ns_stage_timers": (C.c_int, [_vp, C.c_int]),
+    "pib_ns_get_stage_times": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
+    "pib_ns_stage_name": (C.c_char_p, [C.c_int]),
     "pib_ns_destroy": (C.c_int, [_vp]),
     "pib_ns_set_bodies": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_char_p, C.c_char_p]),
     "pib_ns_move_bodies": (C.c_int, [_vp, _vp, _vp]),

@@ -669,6 +669,8 @@ int pib_ns_destroy(pib_ns *ns)
     (void)hipSetDevice(ns->device);
     pib::ib_release(ns->ib);
     ns->ib = nullptr;
+    for (int k = 0; k < 7; ++k)
+        if (ns->ev_stage[k]) (void)hipEventDestroy(ns->ev_stage[k]);
     if (ns->vsol) pib_destroy(ns->vsol);
     if (ns->psol) pib_destroy(ns->psol);
     for (double *q : ns->owned) (void)hipFree(q);
@@ -1353,7 +1355,26 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
     const int gg = ghost_blocks(D);
     const int gu = (int)std::min<int64_t>(4096, (D.UN + 255) / 256), gp = (int)std::min<int64_t>(4096, (D.pN + 255) / 256);
     const int gt = gu > gp ? gu : gp;
+    // stage boundaries (pib_ns_stage_timers): an event on the engine's stream; a solve runs on its solver's stream and returns
+    // behind its own host synchronisation, so the event recorded after it is stamped when it has finished
+    auto mark = [&](int k) -> int {
+        if (ns->stage_timing) PIB_HIP(hipEventRecord(ns->ev_stage[k], ns->stream));
+        return 0;
+    };
+    auto close_step = [&]() -> int {
+        if (!ns->stage_timing) return 0;
+        PIB_CHK(mark(6));  // end of update
+        PIB_HIP(hipEventSynchronize(ns->ev_stage[6]));
+        for (int k = 0; k < 6; ++k) {
+            float ms = 0.0f;
+            PIB_HIP(hipEventElapsedTime(&ms, ns->ev_stage[k], ns->ev_stage[k + 1]));
+            ns->stage_ms[k] += (double)ms;
+        }
+        ns->stage_steps++;
+        return 0;
+    };
     for (int it = 0; it < nsteps; ++it) {
+        PIB_CHK(mark(0));
         // VecSwap chain of the convective terms (navierstokes.cpp:452-458)
         if (ns->T.nconv > 1) std::swap(ns->conv[0], ns->conv[1]);
         if (ns->T.ndiff > 1) std::swap(ns->diff0, ns->diff1);
@@ -1388,6 +1409,7 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         PIB_HIP(hipGetLastError());
         std::swap(D.a1, D.a1n);
         if (ns->ib) PIB_CHK(ib_spread_forces(ns));  // rhs1 += H f  (decoupledibpm.cpp:243)
+        PIB_CHK(mark(1));  // end of rhsVelocity
         if (ns->nranks > 1) {
             // the solver's vectors are the packed owned points; afterwards the neighbours' planes of u* (DMGlobalToLocal)
             PIB_CHK(ns_pack(ns, ns->rhs1, ns->rhs1pk));
@@ -1400,20 +1422,25 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         PIB_CHK(ns_before_solve(ns, ns->vsol));
         PIB_CHK(pib_solve(ns->vsol, ns->U, ns->rhs1));  // vSolver->solve(UGlobal, rhs1)  (:532)
         }
+        PIB_CHK(mark(2));  // end of solveVelocity
         const bool coupled = ib_is_coupled(ns);
         if (ns->ib && !coupled) {
             PIB_CHK(ib_solve_forces(ns));   // assembleRHSForces, solveForces, applyNoSlip (decoupledibpm.cpp:116-118)
             PIB_CHK(ns_halo_velocity(ns, ns->U));  // u += BNH df changed owned points next to the neighbours' planes
         }
+        PIB_CHK(mark(3));  // end of rhsForces + solveForces (nothing between the two marks without bodies)
         hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns_pin_cell(ns), ns->U, ns->rhs2);
         PIB_HIP(hipGetLastError());
+        PIB_CHK(mark(4));  // end of rhsPoisson
         if (coupled) {
             // IBPMSolver (applications/ibpm): pressure and forces are one unknown; solved here through the Schur
             // complement on the pressure, then u = u* - BN [G, -H] [dP; df], p += dP, f += df
             PIB_CHK(ib_coupled_solve_and_project(ns));
+            PIB_CHK(mark(5));  // (the coupled pressure / forces solve and its projection count as solvePoisson)
             hipLaunchKernelGGL(k_ns_ghosts<2>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);
             PIB_HIP(hipGetLastError());
             ns->steps++;
+            PIB_CHK(close_step());
             continue;
         }
         PIB_CHK(ns_before_solve(ns, ns->psol));
@@ -1422,6 +1449,7 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
             PIB_CHK(pib_solve(ns->psol, ns->dP + own, ns->rhs2 + own));  // pSolver->solve(dP, rhs2)      (:575)
             PIB_CHK(ns_halo_cells(ns, ns->dP));  // G dP at the faces towards the neighbours
         }
+        PIB_CHK(mark(5));  // end of solvePoisson
         if (ns->bn_order > 1 && ns->nranks > 1)
             PIB_CHK(ns_project_bn_slab(ns));
         else if (ns->bn_order > 1)
@@ -1434,12 +1462,37 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
         hipLaunchKernelGGL(k_ns_ghosts<2>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);  // bc->updateGhostValues (:263)
         PIB_HIP(hipGetLastError());
         ns->steps++;
+        PIB_CHK(close_step());
     }
     PIB_HIP(hipStreamSynchronize(ns->stream));
     pib_get_iters(ns->vsol, &ns->v_iters);
     pib_get_residual(ns->vsol, &ns->v_res);
     pib_get_iters(ns->psol, &ns->p_iters);
     pib_get_residual(ns->psol, &ns->p_res);
+    return 0;
+}
+
+/* Stage timers under the reference's PetscLogStage names (navierstokes.cpp:186-199; decoupledibpm.cpp:93-97): HIP events on
+ * the engine's stream around the stages of NavierStokesSolver::advance / DecoupledIBPMSolver::advance. */
+static const char *const kStageNames[6] = {"rhsVelocity", "solveVelocity", "solveForces", "rhsPoisson", "solvePoisson", "update"};
+const char *pib_ns_stage_name(int stage) { return (stage >= 0 && stage < 6) ? kStageNames[stage] : ""; }
+int pib_ns_stage_timers(pib_ns *ns, int enable)
+{
+    if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
+    PIB_HIP(hipSetDevice(ns->device));
+    if (enable)
+        for (int k = 0; k < 7; ++k)
+            if (ns->ev_stage[k] == nullptr) PIB_HIP(hipEventCreate(&ns->ev_stage[k]));
+    ns->stage_timing = enable != 0;
+    for (int k = 0; k < 6; ++k) ns->stage_ms[k] = 0.0;
+    ns->stage_steps = 0;
+    return 0;
+}
+int pib_ns_get_stage_times(pib_ns *ns, double ms[6], int64_t *steps)
+{
+    if (ns == nullptr || ms == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "pib_ns_get_stage_times: null argument");
+    for (int k = 0; k < 6; ++k) ms[k] = ns->stage_ms[k];
+    if (steps) *steps = ns->stage_steps;
     return 0;
 }
 

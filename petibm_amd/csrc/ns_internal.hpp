@@ -115,6 +115,12 @@ struct pib_ns {
     int64_t bn_nnz = 0;
     double *bn_tmp = nullptr;  // z-slabs: t = dt G dP on the extended slab (the projection applies BN term by term)
     // z-slab (y-slab) decomposition: the engine's mesh is this rank's EXTENDED slab (navierstokes.hip: ns_create_impl)
+    // stage timers under the reference's PetscLogStage names (navierstokes.cpp:186-199, decoupledibpm.cpp:93-97): off by default;
+    // when on, events on the engine's stream bracket the stages of every step (pib_ns_stage_timers)
+    bool stage_timing = false;
+    hipEvent_t ev_stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double stage_ms[6] = {0, 0, 0, 0, 0, 0};
+    int64_t stage_steps = 0;
     int rank = 0, nranks = 1;
     int64_t slab_pk0 = 0, slab_pk1 = 0, slab_e0 = 0;          // owned pressure planes [pk0, pk1), first plane of the extended slab
     int64_t fld_plane[3] = {0, 0, 0}, fld_own_lo[3] = {0, 0, 0}, fld_own_cnt[3] = {0, 0, 0}, fld_pk_off[3] = {0, 0, 0};

@@ -216,6 +216,22 @@ class NavierStokesSolver:
         self.ite += nsteps
         self.t += nsteps * self.dt
 
+    # ---- the reference's PetscLogStage breakdown (navierstokes.cpp:186-199): rhsVelocity / solveVelocity / solveForces /
+    # rhsPoisson / solvePoisson / update
+    def enableStageTimers(self, on: bool = True) -> None:
+        capi.check(capi.load().pib_ns_stage_timers(self._h, 1 if on else 0))
+
+    def stageTimes(self) -> dict:
+        """milliseconds accumulated per stage since enableStageTimers(), and the steps they cover"""
+        import ctypes as C
+        ms = np.zeros(6)
+        steps = C.c_int64(0)
+        lib = capi.load()
+        capi.check(lib.pib_ns_get_stage_times(self._h, ms.ctypes.data, C.byref(steps)))
+        out = {lib.pib_ns_stage_name(k).decode(): float(ms[k]) for k in range(6)}
+        out["steps"] = int(steps.value)
+        return out
+
     def getState(self, rhs: bool = False):
         U, p = np.empty(self.UN), np.empty(self.pN)
         r1 = np.empty(self.UN) if rhs else None

@@ -369,3 +369,44 @@ def test_vorticity_of_a_rigid_rotation_is_twice_the_rate():
     wz = s.vorticity()["wz"]
     assert np.allclose(wz[2:-2, 2:-2], 2.0, atol=1e-12)
     s.destroy()
+
+
+def test_stage_timers_carry_the_reference_stage_names():
+    """the reference brackets a step with PetscLogStages "rhsVelocity", "solveVelocity", "rhsPoisson",
+    "solvePoisson", "update" (navierstokes.cpp:186-199; "rhsForces" / "solveForces" in decoupledibpm.cpp:93-97, one entry
+    here).  Off by default; on, the per-stage sums cover the steps taken, add up to (a little less than) the wall time
+    of those steps, and the two solves dominate a 3-D step as they do in the reference."""
+    import ctypes
+    import time
+    from petibm_amd import capi
+    from petibm_amd.navierstokes import NavierStokesSolver
+    lib = capi.load()
+    assert [lib.pib_ns_stage_name(k).decode() for k in range(7)] == ["rhsVelocity", "solveVelocity", "solveForces", "rhsPoisson",
+                                                                       "solvePoisson", "update", ""]
+    s = NavierStokesSolver(cavity((48, 48, 48), nu=0.01, dt=0.005))
+    s.advance(2)
+    st = s.stageTimes()
+    assert st["steps"] == 0 and all(st[k] == 0.0 for k in st if k != "steps")   # never switched on: nothing recorded
+    s.enableStageTimers()
+    t0 = time.perf_counter()
+    s.advance(3)
+    s.advance(2)
+    wall = 1e3 * (time.perf_counter() - t0)
+    st = s.stageTimes()
+    assert st.pop("steps") == 5
+    assert list(st) == ["rhsVelocity", "solveVelocity", "solveForces", "rhsPoisson", "solvePoisson", "update"]
+    assert all(v >= 0.0 for v in st.values()) and st["solveVelocity"] > 0 and st["solvePoisson"] > 0 and st["rhsVelocity"] > 0
+    total = sum(st.values())
+    assert 0.5 * wall <= total <= 1.02 * wall, (total, wall)
+    assert st["solveVelocity"] + st["solvePoisson"] >= 0.5 * total
+    assert st["solveForces"] <= 0.05 * total            # no bodies: nothing between the two marks
+    # the state is what the untimed engine computes
+    t = NavierStokesSolver(cavity((48, 48, 48), nu=0.01, dt=0.005))
+    t.advance(7)
+    assert np.array_equal(s.getState()[0], t.getState()[0])
+    s.enableStageTimers(False)
+    s.advance(1)
+    assert s.stageTimes()["steps"] == 0
+    assert lib.pib_ns_get_stage_times(None, None, None) != 0 and lib.pib_ns_stage_timers(None, 1) != 0
+    s.destroy()
+    t.destroy()

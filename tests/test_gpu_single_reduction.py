@@ -181,6 +181,8 @@ def test_single_reduction_on_slabs_one_allreduce_per_iteration(P, n, pc, extra, 
     its = res[0][1]
     for r, t in zip(res, std):
         reductions, exchanges = int(r[3][2]), int(r[3][3])
-        assert reductions == its + 1, (reductions, its)              # the set-up's and one per iteration
-        assert int(t[3][2]) >= 2 * t[1]                               # the standard recurrence on the same ranks
+        # the set-up's and one per ENQUEUED iteration (the host counts its calls: the last batch may reach a few iterations
+        # beyond the one that met the tolerance -- their kernels return at once on the device's `done`)
+        assert its + 1 <= reductions <= its + 1 + 8, (reductions, its)
+        assert int(t[3][2]) >= 2 * t[1] and 2 * reductions <= int(t[3][2]) + 10   # the standard recurrence on the same ranks: >= 2 per iteration
         assert exchanges <= int(t[3][3]) + 1, (exchanges, int(t[3][3]))  # never more exchanges than the standard recurrence
