@@ -45,7 +45,30 @@ def solver_config(pc: str, tol: float, max_iters: int, omega: float = 0.9, pre: 
             f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
             f"solv:preconditioner(prec)={prec}\nprec:relaxation_factor=1.0\n"
             f"prec:cycle=V\nprec:presweeps={pre}\nprec:postsweeps={post}\nprec:smoother(smooth)=BLOCK_JACOBI\n"
-            f"smooth:relaxation_factor={omega}\npib_initial_guess_nonzero=0\n")
+            f"smooth:relaxation_factor={omega}\npib_initial_guess_nonzero=0\npib_sweep_pairs=0\n")
+
+
+def reference_solver_file(tol: float, literal_sweeps: bool) -> str:
+    """The Poisson solver file an unchanged PetIBM hands a `type: GPU` solver, key for key the one of
+    examples/navierstokes/taylorgreenvortex3dRe1600_GPU/config/poisson_solver.info (and of every other *_GPU example: PCG,
+    classical AMG, presweeps = postsweeps = 1, BLOCK_JACOBI 0.9, DENSE_LU coarse solver) -- with the bench's convergence
+    criterion (relative 1e-10 instead of the file's absolute 1e-14) and the zero guess of the timed loop.  The AMG keys that
+    describe AmgX's own coarsening (selector, interpolator, strength ...) are read and ignored by the geometric stand-in.
+    literal_sweeps: pib_sweep_pairs=0, the file's sweep counts as they stand."""
+    keys = [("config_version", "2"), ("communicator", "MPI_DIRECT"), ("min_rows_latency_hiding", "-1"),
+            ("matrix_consolidation_lower_threshold", "0"), ("matrix_consolidation_upper_threshold", "1000"),
+            ("fine_level_consolidation", "0"), ("determinism_flag", "1"), ("solver(solv)", "PCG"), ("solv:max_iters", "1000"),
+            ("solv:monitor_residual", "1"), ("solv:convergence", "RELATIVE_INI"), ("solv:tolerance", f"{tol:.1E}"),
+            ("solv:norm", "L2"), ("solv:print_solve_stats", "0"), ("solv:store_res_history", "1"), ("solv:print_grid_stats", "0"),
+            ("solv:obtain_timings", "0"), ("solv:preconditioner(prec)", "AMG"), ("prec:algorithm", "CLASSICAL"),
+            ("prec:max_iters", "1"), ("prec:cycle", "V"), ("prec:presweeps", "1"), ("prec:postsweeps", "1"),
+            ("prec:max_levels", "100"), ("prec:min_coarse_rows", "2"), ("prec:interp_max_elements", "-1"),
+            ("prec:interp_truncation_factor", "1.1"), ("prec:interpolator", "D2"), ("prec:max_row_sum", "1.1"),
+            ("prec:selector", "PMIS"), ("prec:strength", "AHAT"), ("prec:strength_threshold", "0.25"),
+            ("prec:coarse_solver(c_solver)", "DENSE_LU_SOLVER"), ("prec:dense_lu_num_rows", "128"), ("prec:dense_lu_max_rows", "0"),
+            ("prec:coarsest_sweeps", "1"), ("prec:smoother(smooth)", "BLOCK_JACOBI"), ("smooth:relaxation_factor", "0.9")]
+    text = "\n".join(f"{k}={v}" for k, v in keys) + "\npib_initial_guess_nonzero=0\n"
+    return text + ("pib_sweep_pairs=0\n" if literal_sweeps else "")
 
 
 def slab(nplanes: int, nranks: int, rank: int):
@@ -649,6 +672,12 @@ def poisson_bench(args) -> int:
                          ("config2_256_cubed", lambda: secondary_poisson(256, 1e-3, base_cfg, "cosine", 0, args)),
                          ("stencil_twin_products_512", lambda: secondary_poisson(512, 5e-4, base_cfg + "pib_matrix_free_poisson=1\n",
                                                                                  "cosine", 3, args)),
+                         # the solver file an UNCHANGED PetIBM brings (V(1,1) in AmgX's terms): as the backend reads it by
+                         # default -- a sweep = a fused pair of damped-Jacobi steps -- and with the counts taken literally
+                         ("reference_solver_file_512", lambda: dict(secondary_poisson(512, 5e-4, reference_solver_file(args.tol, False), "cosine", 0, args),
+                                                                    cycle="V(1,1) of the file read as fused pairs: V(2,2) (pib_sweep_pairs=1, default)")),
+                         ("reference_solver_file_512_literal", lambda: dict(secondary_poisson(512, 5e-4, reference_solver_file(args.tol, True), "cosine", 0, args),
+                                                                            cycle="V(1,1) literally (pib_sweep_pairs=0)")),
                          ("velocity_256_cubed", lambda: velocity_case(256, 2, 1, args.kernel_reps)),
                          ("host_buffers_512", lambda: host_buffer_case(512, 5e-4, base_cfg))):
             try:

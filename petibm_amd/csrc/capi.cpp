@@ -100,13 +100,13 @@ int pib_config_describe(const char *name, const char *cfg_text, char *buf, int b
                   "flavor=%s type=\"%s\" method=%s pc=%s norm=%s max_iters=%d rtol=%.17g atol=%.17g dtol=%.17g "
                   "monitor=%d guess_nonzero=%d error_if_not_converged=%d jacobi_relaxation=%.17g presweeps=%d "
                   "postsweeps=%d smoother=%s smoother_relaxation=%.17g coarsest_sweeps=%d max_levels=%d "
-                  "cheby_degree=%d cheby_lmax=%.17g cheby_lmin=%.17g cg_single_reduction=%d",
+                  "cheby_degree=%d cheby_lmax=%.17g cheby_lmin=%.17g cg_single_reduction=%d sweep_pairs=%d",
                   c.flavor == Flavor::AMGX ? "amgx" : "ksp", c.flavor == Flavor::AMGX ? "NVIDIA AmgX" : "PETSc KSP",
                   method, pc, c.norm == NormType::PRECONDITIONED ? "preconditioned" : "unpreconditioned", c.max_iters,
                   c.rtol, c.atol, c.dtol, c.monitor_residual ? 1 : 0, c.initial_guess_nonzero ? 1 : 0,
                   c.error_if_not_converged ? 1 : 0, c.jacobi_relaxation, c.presweeps, c.postsweeps,
                   c.smoother == Smoother::JACOBI ? "jacobi" : "chebyshev", c.smoother_relaxation, c.coarsest_sweeps,
-                  c.max_levels, c.cheby_degree, c.cheby_lmax, c.cheby_lmax / c.cheby_ratio, c.cg_single_reduction);
+                  c.max_levels, c.cheby_degree, c.cheby_lmax, c.cheby_lmax / c.cheby_ratio, c.cg_single_reduction, c.sweep_pairs);
     return 0;
 }
 

@@ -3207,7 +3207,9 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     const double omega = s->cfg.smoother_relaxation;
     const bool cheb = (s->cfg.smoother == Smoother::CHEBYSHEV);
     const int deg = cheb ? std::max(1, s->cfg.cheby_degree) : 1;  // one Chebyshev "sweep" = a degree-`deg` polynomial
-    const int pre = std::max(1, s->cfg.presweeps) * deg, post = std::max(0, s->cfg.postsweeps) * deg;
+    // (damped Jacobi: a sweep of the solver file is a fused pair of steps unless pib_sweep_pairs=0 -- Config::sweep_pairs)
+    const int pairs = (!cheb && s->cfg.sweep_pairs) ? 2 : 1;
+    const int pre = std::max(1, s->cfg.presweeps) * deg * pairs, post = std::max(0, s->cfg.postsweeps) * deg * pairs;
     const int nl = (int)s->levels.size();
     const int P = s->comm.nranks, rank = s->comm.rank;
     const double *pin = (s->nullspace == PIB_NULLSPACE_PINNED) ? &s->d_s->red[5] : nullptr;

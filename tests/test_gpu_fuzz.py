@@ -257,7 +257,7 @@ def test_random_mesh_drop_in_route_recovers_the_structure(seed):
     else:
         xs -= xs.mean()
     b = clib.spmv(A, xs)
-    amg = "prec:cycle=V\nprec:presweeps=1\nprec:postsweeps=1\nprec:smoother(smooth)=BLOCK_JACOBI\nsmooth:relaxation_factor=0.9\n"
+    amg = "prec:cycle=V\nprec:presweeps=1\nprec:postsweeps=1\nprec:smoother(smooth)=BLOCK_JACOBI\nsmooth:relaxation_factor=0.9\npib_sweep_pairs=0\n"
     s = LinSolverHIP("poisson", config_text=amgx_cfg(pc="AMG", tol=1e-10, extra=amg + "pib_initial_guess_nonzero=0\n"))
     s.setMatrix(A)
     st = s.gridStructure()

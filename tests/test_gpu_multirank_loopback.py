@@ -23,7 +23,7 @@ def _cfg(pc, tol=1e-10, extra="", sweeps=1):
             f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
             f"solv:preconditioner(prec)={pc}\nprec:relaxation_factor=1.0\nprec:cycle=V\nprec:presweeps={sweeps}\n"
             f"prec:postsweeps={sweeps}\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
-            f"smooth:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n{extra}")
+            f"smooth:relaxation_factor=0.9\npib_initial_guess_nonzero=0\npib_sweep_pairs=0\n{extra}")
 
 
 def _run_ranks(P, fn):

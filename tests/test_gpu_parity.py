@@ -392,7 +392,7 @@ def gmg_cfg(tol=1e-10, pre=1, post=1, omega=0.9, extra=""):
             f"solv:convergence=RELATIVE_INI\nsolv:tolerance={tol}\nsolv:norm=L2\nsolv:store_res_history=1\n"
             f"solv:preconditioner(prec)=AMG\nprec:cycle=V\nprec:presweeps={pre}\nprec:postsweeps={post}\n"
             f"prec:max_levels=100\nprec:coarsest_sweeps=2\nprec:smoother(smooth)=BLOCK_JACOBI\n"
-            f"smooth:relaxation_factor={omega}\n{extra}")
+            f"smooth:relaxation_factor={omega}\npib_sweep_pairs=0\n{extra}")
 
 
 @pytest.mark.parametrize("case,pre,post", [("2d_stretched", 1, 1), ("3d_uniform", 1, 1), ("3d_stretched", 1, 1),
@@ -925,7 +925,7 @@ def test_residual_update_inside_the_vcycle_is_bit_identical(lin, flavour, sweeps
         else:
             text = ("-poisson_ksp_type cg\n-poisson_ksp_rtol 1.0E-10\n-poisson_ksp_atol 1.0E-50\n-poisson_ksp_max_it 200\n"
                     "-poisson_pc_type gamg\n-poisson_pib_smoother JACOBI\n"
-                    f"-poisson_pib_presweeps {sweeps}\n-poisson_pib_postsweeps {sweeps}\n-poisson_pib_fuse_residual_update {fuse}\n"
+                    f"-poisson_pib_presweeps {sweeps}\n-poisson_pib_postsweeps {sweeps}\n-poisson_pib_sweep_pairs 0\n-poisson_pib_fuse_residual_update {fuse}\n"
                     "-poisson_pib_march_min_cells 0\n")
         s = lin.LinSolverHIP("poisson", config_text=text)
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
@@ -944,3 +944,38 @@ def test_residual_update_inside_the_vcycle_is_bit_identical(lin, flavour, sweeps
     assert out[0][3] <= 2e-10
     # the fallback (a refusing launch site no longer fails the solve: the update runs as its own pass, into the other buffer)
     assert out[2][2] == out[1][2] and np.array_equal(out[2][0], out[1][0]) and np.array_equal(out[2][1], out[1][1])
+
+
+def test_one_sweep_of_the_solver_file_is_a_fused_pair_of_steps(lin):
+    """`pib_sweep_pairs` (default 1): the reference's files say presweeps = postsweeps = 1 (AmgX's classical AMG); the
+    geometric stand-in reads a sweep as one fused pair of damped-Jacobi steps.  The default with V(1,1) in the file is, bit
+    for bit, the literal V(2,2); `pib_sweep_pairs=0` is the literal V(1,1) -- the oracle's cycles either way.  Chebyshev
+    smoothing is not doubled."""
+    from petibm_amd import capi
+    dt = 0.01
+    m, A, _ = poisson_system(stretched_3d((24, 20, 16)), dt=dt)
+    xs, b = rhs_for(A)
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    file_v11 = gmg_cfg(pre=1, post=1).replace("pib_sweep_pairs=0\n", "")
+    assert "pib_sweep_pairs" not in file_v11
+
+    def run(text):
+        s = lin.LinSolverHIP("poisson", config_text=text)
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(A.n_rows)
+        s.solve(x, b)
+        out = (x, s.getIters(), s.getResidualHistory().copy())
+        s.destroy()
+        return out
+
+    default, v22, v11 = run(file_v11), run(gmg_cfg(pre=2, post=2)), run(gmg_cfg(pre=1, post=1))
+    assert default[1] == v22[1] and np.array_equal(default[2], v22[2]) and np.array_equal(default[0], v22[0])
+    assert v11[1] > v22[1]
+    for got, (pre, post) in ((v22, (2, 2)), (v11, (1, 1))):
+        ref = clib.GMG(n, w, dt, nullspace=1, pre=pre, post=post, omega=0.9, coarsest_sweeps=32).pcg(A, b, rtol=1e-10, maxit=200)
+        assert iters_close(got[1], ref["iters"])
+        assert np.allclose(got[2][:8], ref["history"][:8], rtol=1e-8)
+    cheb = file_v11.replace("BLOCK_JACOBI", "CHEBYSHEV_POLY")
+    c1, c0 = run(cheb), run(cheb + "pib_sweep_pairs=0\n")
+    assert c1[1] == c0[1] and np.array_equal(c1[2], c0[2])

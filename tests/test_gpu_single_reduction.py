@@ -100,7 +100,7 @@ def test_single_reduction_multigrid_pcg_matches_oracle(lin, case, pre, post, nor
         text = gmg_cfg(pre=pre, post=post, extra=SR)
     else:
         text = (f"-poisson_ksp_type cg\n-poisson_ksp_rtol 1.0E-10\n-poisson_ksp_atol 1.0E-50\n-poisson_pc_type gamg\n"
-                f"-poisson_ksp_cg_single_reduction true\n-poisson_pib_smoother jacobi\n-poisson_pib_presweeps {pre}\n-poisson_pib_postsweeps {post}\n")
+                f"-poisson_ksp_cg_single_reduction true\n-poisson_pib_smoother jacobi\n-poisson_pib_presweeps {pre}\n-poisson_pib_postsweeps {post}\n-poisson_pib_sweep_pairs 0\n")
     s = lin.LinSolverHIP("poisson", config_text=text)
     s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
     x = np.zeros(A.n_rows)
