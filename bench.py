@@ -226,6 +226,61 @@ def measured_traffic(n: int, world: int):
     return None, None
 
 
+def spmv_only(args) -> int:
+    """child of collect_traffic(): assemble the system and launch the CSR SpMV a few times -- what rocprofv3 --pmc counts"""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    n = args.n
+    s = LinSolverHIP("poisson", config_text=solver_config(args.pc, args.tol, args.max_iters, args.omega, args.presweeps, args.postsweeps))
+    w = np.full(n, 1.0 / n)
+    s.assemblePoisson((n, n, n), [w, w, w], 5e-4 if n == 512 else 1e-3, capi.NULLSPACE_CONSTANT)
+    s.timeKernel(0, 3)
+    s.destroy()
+    return 0
+
+
+def collect_traffic(n: int, mode: str):
+    """`roofline.traffic` measured in THIS run: the SpMV leg once more under `rocprofv3 --pmc FETCH_SIZE` and once under
+    `--pmc WRITE_SIZE` (separate passes with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; run from
+    /tmp with TMPDIR=/tmp), in a child process of this script (`--spmv-only`).  KiB per k_spmv_lds dispatch, averaged;
+    FETCH_SIZE doubled (gfx950 tallies 128-byte requests as 64).  (bytes, source) or (None, reason).
+    mode: "auto" (when rocprofv3 is on PATH and this is not already a profiled child), "on", "off"."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if mode == "off" or os.environ.get("PIB_BENCH_CHILD") == "1":
+        return None, "switched off"
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return None, "rocprofv3 not found"
+    env = dict(os.environ, TMPDIR="/tmp", PIB_BENCH_CHILD="1")
+    kib = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"pib_pmc_{counter}_", dir="/tmp")
+        try:
+            cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--",
+                   sys.executable, os.path.abspath(__file__), "--spmv-only", "--grid", str(n)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_spmv_lds" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"rocprofv3 --pmc {counter}: no k_spmv_lds dispatch in the output (rc {r.returncode})"
+            kib[counter] = sum(vals) / len(vals)
+        except Exception as e:  # noqa: BLE001
+            return None, f"rocprofv3 --pmc {counter} failed: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = 2.0 * 1024.0 * kib["FETCH_SIZE"] + 1024.0 * kib["WRITE_SIZE"]
+    return traffic, (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes over `bench.py --spmv-only "
+                     f"--grid {n}`), mean per k_spmv_lds dispatch: FETCH_SIZE {kib['FETCH_SIZE']:.4g} KiB x 2 (gfx950 correction) + "
+                     f"WRITE_SIZE {kib['WRITE_SIZE']:.4g} KiB")
+
+
 def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str = "") -> dict:
     """The velocity solve of the same cavity, A = I/dt - c nu L (navierstokes.cpp:342-344) with PBICGSTAB + BLOCK_JACOBI to
     an absolute residual of 1e-10 (examples/navierstokes/taylorgreenvortex3dRe1600_GPU/config/velocity_solver.info),
@@ -472,7 +527,15 @@ def main():
                          "ranks share one GPU with PIB_BENCH_SHARE_GPU=1)")
     ap.add_argument("--system", default="poisson", choices=["poisson", "velocity"],
                     help="poisson (the BASELINE metric) or the velocity system A = I/dt - c nu L with BiCGStab+Jacobi")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
+                    help="roofline.traffic from rocprofv3 --pmc passes of the SpMV leg made in THIS run (N = 1; auto: when rocprofv3 is on "
+                         "PATH); otherwise the committed passes of profiles/spmv_pmc.json, labelled as such")
+    ap.add_argument("--no-tune-recurrence", dest="tune_recurrence", action="store_false",
+                    help="N > 1: do not time the single-reduction CG recurrence against the standard one on untimed solves")
+    ap.add_argument("--spmv-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.spmv_only:
+        return spmv_only(args)
     if args.system == "velocity":
         return velocity_bench(args)
 
@@ -505,26 +568,38 @@ def poisson_bench(args) -> int:
     if share:
         local = 0
     torch.cuda.set_device(local)
-    uid = None
+    notes = []
+    # ---- the torch side of an N > 1 run (timing barrier, max over ranks, the id's broadcast): nccl (= RCCL) where it comes
+    # up -- proved by a first collective, the bootstrap is lazy --, gloo otherwise.  First contact with a multi-GPU node must
+    # not end in a traceback: every fallback taken is named in the line's `notes`.
+    cpu_side = share
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            try:
+                if os.environ.get("PIB_FORCE_RCCL_FAIL") == "1":
+                    raise RuntimeError("forced failure (PIB_FORCE_RCCL_FAIL=1)")
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all-reduce of ones over {world} ranks gave {probe.item()}")
+            except Exception as e:  # noqa: BLE001
+                notes.append(f"torch.distributed backend nccl (RCCL) failed on first contact ({type(e).__name__}: {e}): gloo carries the "
+                             "bench's own barrier / max-over-ranks instead")
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                dist.init_process_group(backend="gloo")
+                cpu_side = True
+    red_dev = "cpu" if (world > 1 and cpu_side) else "cuda"
     from petibm_amd import capi
     from petibm_amd.linsolver import LinSolverHIP
-    if world > 1:
-        import ctypes
-        buf = ctypes.create_string_buffer(capi.UID_BYTES)
-        if rank == 0:
-            capi.check((capi.load().pib_comm_peer_id if args.transport == "peer" else capi.load().pib_comm_unique_id)(buf))
-        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
-        if not share:
-            t = t.cuda()
-        dist.broadcast(t, src=0)
-        uid = bytes(t.cpu().numpy().tobytes())
 
     def barrier():
         torch.cuda.synchronize()
@@ -532,27 +607,103 @@ def poisson_bench(args) -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def agree(ok: bool) -> bool:
+        """every rank's verdict: a rank that failed must not leave the others inside a collective"""
+        if world == 1:
+            return ok
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(t)
+        return int(t.item()) == 0
+
+    def make_id(transport: str):
+        import ctypes
+        buf = ctypes.create_string_buffer(capi.UID_BYTES)
+        if rank == 0:
+            capi.check((capi.load().pib_comm_peer_id if transport == "peer" else capi.load().pib_comm_unique_id)(buf))
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+        if not cpu_side:
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
     n = args.n
     dt = 5e-4 if n == 512 else 1e-3  # SURVEY.md 8d: cfg3 (512^3) dt=5e-4, cfg2 (256^3) dt=1e-3
-    s = LinSolverHIP("poisson", config_text=solver_config(args.pc, args.tol, args.max_iters, args.omega, args.presweeps,
-                                                           args.postsweeps, args.smoother) + args.extra_config.replace("\\n", "\n") + "\n",
-                     rank=rank,
-                     nranks=world, uid=uid, device=local)
-    w = np.full(n, 1.0 / n)
-    t_setup = time.perf_counter()
-    s.assemblePoisson((n, n, n), [w, w, w], dt, capi.NULLSPACE_CONSTANT)
-    s.synchronize()
-    t_setup = time.perf_counter() - t_setup
-    k0, k1 = slab(n, world, rank)
-    xs = manufactured_solution(n, k0, k1)
-    xs_d, b_d, x_d = s.deviceVec(), s.deviceVec(), s.deviceVec()
-    xs_d.upload(xs)
-    s.matMult(xs_d, b_d)  # b = DBNG x*  (compatible with the constant null space)
-    del xs
-
     pN = n ** 3
-    for _ in range(args.warmup):
-        s.solve(x_d, b_d)
+    k0, k1 = slab(n, world, rank)
+    base_text = solver_config(args.pc, args.tol, args.max_iters, args.omega, args.presweeps, args.postsweeps,
+                              args.smoother) + args.extra_config.replace("\\n", "\n") + "\n"
+
+    def setup(transport: str, extra: str = ""):
+        """solver, system, vectors and the warm-up solves on one transport; (state, error)"""
+        st = {}
+        try:
+            uid = make_id(transport) if world > 1 else None
+            sv = LinSolverHIP("poisson", config_text=base_text + extra, rank=rank, nranks=world, uid=uid, device=local)
+            st["s"] = sv
+            w = np.full(n, 1.0 / n)
+            t_s = time.perf_counter()
+            sv.assemblePoisson((n, n, n), [w, w, w], dt, capi.NULLSPACE_CONSTANT)
+            sv.synchronize()
+            st["t_setup"] = time.perf_counter() - t_s
+            xs = manufactured_solution(n, k0, k1)
+            st["xs_d"], st["b_d"], st["x_d"] = sv.deviceVec(), sv.deviceVec(), sv.deviceVec()
+            st["xs_d"].upload(xs)
+            sv.matMult(st["xs_d"], st["b_d"])  # b = DBNG x*  (compatible with the constant null space)
+            del xs
+            for _ in range(args.warmup):
+                sv.solve(st["x_d"], st["b_d"])
+            sv.synchronize()
+            return st, None
+        except Exception as e:  # noqa: BLE001
+            return st, e
+
+    transport = args.transport if world > 1 else "none"
+    st, err = setup(transport)
+    if not agree(err is None):
+        if world > 1 and transport == "rccl":
+            # RCCL's bootstrap or its first collectives failed here or on another rank: the peer transport (HIP-IPC windows,
+            # device-ordered flags; csrc/halo.hip) needs nothing of RCCL.  The failed solver is left alone (destroying a
+            # communicator in an unknown state can hang).
+            notes.append(f"--transport rccl failed on first contact ({(type(err).__name__ + ': ' + str(err)) if err else 'on another rank'}): "
+                         "fell back to --transport peer")
+            transport = "peer"
+            st, err = setup(transport)
+            if not agree(err is None):
+                raise RuntimeError(f"both transports failed; peer: {err if err else 'on another rank'}")
+        else:
+            raise err if err is not None else RuntimeError("set-up failed on another rank")
+    s, xs_d, b_d, x_d, t_setup = st["s"], st["xs_d"], st["b_d"], st["x_d"], st["t_setup"]
+
+    # ---- several ranks: the CG recurrence is chosen at first contact.  The single-reduction recurrence (pib_cg_single_reduction,
+    # KSPCGUseSingleReduction) trades two all-reduces per iteration for 16 B/row of vector traffic; which wins depends on what an
+    # all-reduce costs between THESE GPUs, which nobody could measure before this run: both are timed on untimed solves and the
+    # faster one runs the timed region (--extra-config pib_cg_single_reduction=0/1 pins it).
+    recurrence = "single-reduction" if "pib_cg_single_reduction=1" in base_text else "standard"
+    if world > 1 and args.pc == "gmg" and "pib_cg_single_reduction" not in base_text and args.tune_recurrence:
+        def timed(state, reps=2):
+            barrier()
+            t_a = time.perf_counter()
+            for _ in range(reps):
+                state["s"].solve(state["x_d"], state["b_d"])
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / reps
+        t_std = timed(st)
+        st2, err2 = setup(transport, "pib_cg_single_reduction=1\n")
+        if agree(err2 is None):
+            t_sr = timed(st2)
+            notes.append(f"CG recurrence tuned at first contact: standard {1e3 * t_std:.2f} ms, single-reduction {1e3 * t_sr:.2f} ms per solve")
+            if t_sr < 0.98 * t_std:
+                st["s"].destroy()
+                st = st2
+                s, xs_d, b_d, x_d = st["s"], st["xs_d"], st["b_d"], st["x_d"]
+                recurrence = "single-reduction"
+            else:
+                st2["s"].destroy()
+        else:
+            notes.append(f"single-reduction CG could not be set up ({err2 if err2 else 'on another rank'}): standard recurrence")
+
     barrier()
     t0 = time.perf_counter()
     iters = 0
@@ -561,7 +712,6 @@ def poisson_bench(args) -> int:
         iters += s.getIters()
     barrier()
     t1 = time.perf_counter()
-    red_dev = "cpu" if (world > 1 and share) else "cuda"
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -569,7 +719,6 @@ def poisson_bench(args) -> int:
 
     # Everything below is reporting around the timed value: a failure in it must not lose the line (and must not leave
     # the other ranks waiting in a collective), so local work is guarded and the collectives are unconditional.
-    notes = []
     # residual contract, recomputed on the device with the CSR operator
     try:
         r_d = s.deviceVec()
@@ -603,6 +752,14 @@ def poisson_bench(args) -> int:
 
     out = None
     if rank == 0:
+        # HBM traffic of the SpMV: counted in this run where rocprofv3 exists (one GPU), else the committed passes
+        traffic = (None, None)
+        if world == 1:
+            traffic = collect_traffic(n, args.pmc)
+            if traffic[0] is None:
+                if args.pmc == "on":
+                    notes.append(f"--pmc on: {traffic[1]}")
+                traffic = measured_traffic(n, world)
         out = {
             "metric": f"Poisson DOF/s (one pressure solve to rel. residual 1e-10), {n}^3 cavity",
             "value": pN * args.steps / elapsed, "unit": "DOF/s", "n_gpus": world, "steps": args.steps,
@@ -612,14 +769,13 @@ def poisson_bench(args) -> int:
                                    f"PCG+{args.pc}" + (f" V({args.presweeps},{args.postsweeps})" if args.pc == "gmg" else "") +
                                    f", zero guess, rtol {args.tol:g}, manufactured cosine RHS",
                        "grid": [n, n, n], "dt": dt, "parallelism": f"zslab{world}", "pc": args.pc,
-                       "transport": "none" if world == 1 else args.transport},
+                       "transport": transport, "cg_recurrence": recurrence},
             "cg_iters_per_s": iters / elapsed, "iters_per_solve": iters / args.steps,
             "true_rel_residual": true_rel, "setup_s": t_setup,
             "spmv_gdof_per_s": n_l / (ms_spmv * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "kernel": "pib::k_spmv_lds<int32> (fp64 CSR SpMV K1, local slab)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, world)[0],
-                         "traffic_source": measured_traffic(n, world)[1],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0], "traffic_source": traffic[1],
                          "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes},
             "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "reductions": int(counters[2]),
                          "halo_exchanges": int(counters[3]), "host_polls": int(counters[4]),

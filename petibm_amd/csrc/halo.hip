@@ -677,6 +677,9 @@ int comm_init(pib_solver *s, int rank, int nranks, const void *uid)
     ncclUniqueId id;
     static_assert(sizeof(ncclUniqueId) <= PIB_UID_BYTES, "unique id does not fit");
     std::memcpy(&id, uid, sizeof(id));
+    // first-contact drill (tests, tools/first_contact.sh): behave as if RCCL's bootstrap had failed on this node
+    if (const char *f = std::getenv("PIB_FORCE_RCCL_FAIL"))
+        if (f[0] == '1') return fail(PIB_ERR_LIB, "ncclCommInitRank: forced failure (PIB_FORCE_RCCL_FAIL=1)");
     PIB_NCCL(ncclCommInitRank(&s->comm.comm, nranks, id, rank));
     return 0;
 }

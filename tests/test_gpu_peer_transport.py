@@ -208,6 +208,28 @@ def test_bench_launches_its_own_ranks_over_the_peer_transport():
     assert d["true_rel_residual"] <= 1.5e-10 and d["counters"]["halo_exchanges"] > 0
 
 
+def test_bench_falls_back_to_the_peer_transport_when_rccl_fails_on_first_contact():
+    """The first run on a multi-GPU node must end in a JSON line, not a traceback: with RCCL's bootstrap failing
+    (PIB_FORCE_RCCL_FAIL=1 makes ncclCommInitRank's call site return its error; the ranks share the one GPU here, torch side on
+    gloo) `bench.py --gpus 2` -- default transport rccl -- agrees on the failure across the ranks, switches to the peer
+    transport, says so in `notes` and `config.transport`, and still meets the residual contract; the CG recurrence tuned on
+    the untimed solves is named too, and every rank's counters are in the line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PIB_BENCH_SHARE_GPU="1", PIB_PEER_TIMEOUT_S="240", PIB_FORCE_RCCL_FAIL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PIB_TRANSPORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "2", "--warmup", "1", "--no-cpu",
+           "--no-secondary", "--kernel-reps", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["transport"] == "peer"
+    assert any("fell back to --transport peer" in nt and "PIB_FORCE_RCCL_FAIL" in nt for nt in d["notes"]), d["notes"]
+    assert any("CG recurrence tuned at first contact" in nt for nt in d["notes"]) and d["config"]["cg_recurrence"] in ("standard", "single-reduction")
+    assert d["true_rel_residual"] <= 1.5e-10 and len(d["per_rank"]) == 2 and all(r["halo_exchanges"] > 0 for r in d["per_rank"])
+
+
 def test_config3_512_cubed_on_8_processes():
     """BASELINE config 3 -- the 512^3 cavity on 8 z-slabs of 64 planes, multigrid-PCG V(2,2), rtol 1e-10 -- with EIGHT PROCESSES
     (bench.py's own launch, peer transport, all on the one GPU): the single-rank iteration count and the residual contract,
@@ -217,7 +239,7 @@ def test_config3_512_cubed_on_8_processes():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--transport", "peer", "--steps", "1", "--warmup", "0",
-           "--no-cpu", "--no-secondary", "--kernel-reps", "1"]
+           "--no-cpu", "--no-secondary", "--kernel-reps", "1", "--no-tune-recurrence"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])

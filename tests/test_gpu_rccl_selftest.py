@@ -51,3 +51,17 @@ def test_bench_under_the_drivers_launcher_with_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["counters"]["comm_ranks"] == 1
     assert d["true_rel_residual"] <= 1.5e-10
+
+
+def test_bench_under_the_drivers_launcher_at_256_cubed():
+    """the same launcher line on BASELINE config 2's grid (`--gpus 1 --grid 256`): the fused marches of the 256^3 level, the
+    roofline entry and the same-run PMC switch all come up under torch.distributed.run"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--grid", "256", "--steps", "2", "--warmup", "1",
+           "--no-cpu", "--no-secondary", "--kernel-reps", "2", "--pmc", "off"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["iters_per_solve"] == 11 and d["true_rel_residual"] <= 1.5e-10
+    assert d["config"]["grid"] == [256, 256, 256] and d["config"]["transport"] == "none" and d["roofline"]["frac"] > 0.3
