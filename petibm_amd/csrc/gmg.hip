@@ -3403,7 +3403,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     // the smallest levels are launch-bound (~5 us kernels, five to seven per level): one workgroup walks those of <= 1024
     // cells.  A 2-D flow case spends most of its V-cycle there; on a 256^3 / 512^3 grid it is 0.2 ms of a time step / of
     // a solve (17.4 -> 17.2 ms, 88.2 -> 88.1 ms), and taking larger levels into the one workgroup costs more than the
-    // launches it saves (4096: 90.3 ms, 32768: 20.4 ms per Taylor-Green step)
+    // launches it saves (4096: 90.3 ms, 32768: 20.4 ms per Taylor-Green step; docs/history/measured_and_rejected.md)
     const int tail_cells = (s->cfg.coarse_tail >= 0) ? s->cfg.coarse_tail : 1024;
     if (!cheb && tail_cells) {
         for (int l = nl - 1; l >= 1; --l) {
