@@ -240,6 +240,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
     c.detect_structure = std::atoi(d.get("default", "pib_detect_structure", "1").c_str());
     c.deep_halo = std::atoi(d.get("default", "pib_deep_halo", "1").c_str());
+    c.deep_up = std::atoi(d.get("default", "pib_deep_up", "1").c_str());
     c.overlap_min_bytes = std::atoi(d.get("default", "pib_overlap_min_bytes", "1048576").c_str());
     c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "-1").c_str());
     c.coarse_tail_lds = std::atoi(d.get("default", "pib_coarse_tail_lds", "1").c_str());
@@ -368,6 +369,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_agglomerate_below", v)) c.agglomerate_below = std::atoi(v.c_str());
     if (get("pib_detect_structure", v)) c.detect_structure = std::atoi(v.c_str());
     if (get("pib_deep_halo", v)) c.deep_halo = std::atoi(v.c_str());
+    if (get("pib_deep_up", v)) c.deep_up = std::atoi(v.c_str());
     if (get("pib_overlap_min_bytes", v)) c.overlap_min_bytes = std::atoi(v.c_str());
     if (get("pib_coarse_tail", v)) c.coarse_tail = std::atoi(v.c_str());
     if (get("pib_coarse_tail_lds", v)) c.coarse_tail_lds = std::atoi(v.c_str());

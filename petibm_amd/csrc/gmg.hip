@@ -2511,8 +2511,9 @@ __global__ __launch_bounds__(SM_NT) void k_small_up(const Scalars *__restrict__ 
 
 // ------------------------------------------------------------------ host side
 // halo memory / deepest exchange of a distributed level (see "halos of a distributed level" below)
-constexpr int HALO_PAD_PLANES = 6;   // memory per side (the fused kernels read one plane beyond the run they process)
-constexpr int HALO_MAX_DEPTH = 4;    // deepest exchange: V(2,2) needs 4 planes of the residual on level 0, 3 below
+constexpr int HALO_PAD_PLANES = 8;   // memory per side (the fused kernels read one plane beyond the run they process)
+constexpr int HALO_MAX_DEPTH = 6;    // deepest exchange: V(2,2) needs 4 planes of the residual on level 0; below it 3, or -- when the
+                                     // way up is to run without exchanges of its own (pib_deep_up) -- 5 on level 1 and 6 on level 2
 
 static LevelDev dev_of(const GridLevel &g)
 {
@@ -2638,6 +2639,20 @@ static RowGrid row_grid(int64_t nrows, int64_t ncx, int lanes = ROW_LANES)
 }
 static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *xc, double *xf, const Scalars *S, hipStream_t q)
 {
+    // the planes this launch touches, checked on the host tables (a plane outside the level, or a coarse plane outside the
+    // memory the coarse vector has, is a planner error -- reported, not a memory fault)
+    if (f.k1 > f.k0 && (f.k0 < 0 || f.k1 > f.n[2]))
+        return fail(PIB_ERR_LIB, "gmg: prolongation onto planes [%lld, %lld) of a level with %lld", (long long)f.k0, (long long)f.k1,
+                    (long long)f.n[2]);
+    if (!f.hz_par.empty() && c.plane > 0) {
+        const int64_t padc = c.pad / c.plane;
+        for (int64_t k = f.k0; k < f.k1; ++k) {
+            const int64_t lo = std::min(f.hz_par[(size_t)k], f.hz_oth[(size_t)k]), hi = std::max(f.hz_par[(size_t)k], f.hz_oth[(size_t)k]);
+            if (lo < c.k0 - padc || hi >= c.k1 + padc)
+                return fail(PIB_ERR_LIB, "gmg: fine plane %lld interpolates from coarse planes [%lld, %lld], the coarse slab [%lld, %lld) has %lld halo planes",
+                            (long long)k, (long long)lo, (long long)hi, (long long)c.k0, (long long)c.k1, (long long)padc);
+        }
+    }
     const int64_t nrows = f.n[1] * (f.k1 - f.k0);
     const int vec_ok = (f.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(xf) & 15u) == 0) ? 1 : 0;
     if (nrows >= 65536) {  // enough rows to keep the chip busy with four per wave
@@ -3416,7 +3431,20 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     // depth of the level's right-hand side on the way down: the pre-smoothing steps, the residual and the restriction's
     // reach of one plane; level 0 also carries the post-smoothing steps and one plane of the result z, so that neither
     // the corrected iterate nor p = z + beta p (the next Krylov product's input) needs an exchange of its own
-    auto final_depth = [&](int l) -> int { return (l == 0 && li[0].dist && li[0].maxd > 1) ? 1 : 0; };
+    // ... and a coarser distributed level delivers ITS final iterate on as many ghost planes as the prolongation onto the finer
+    // level reads (pib_deep_up, round 4): the exchange of the coarse correction on the way up -- a collective with nothing to
+    // hide behind -- goes, the right-hand side of that level is exchanged deeper on the way down instead (the same bytes: at
+    // 512^3 / 8 five planes of level 1 instead of 3 + 2, six of level 2 instead of 3 + 3) and a few more ghost planes of two
+    // latency-bound levels are relaxed redundantly.  Where the level's slabs are too thin for that depth the exchange stays.
+    std::vector<int> fin_l((size_t)nl, 0);
+    fin_l[0] = (li[0].dist && li[0].maxd > 1) ? 1 : 0;
+    if (s->cfg.deep_up && !cheb && post >= 1)
+        for (int l = 1; l < nl; ++l) {
+            if (!li[(size_t)l].dist || !li[(size_t)l - 1].dist) continue;
+            const int want = coarse_need(s, l - 1, fin_l[(size_t)l - 1] + post);
+            if (want > 0 && pre + post - 1 + want <= li[(size_t)l].cdepth) fin_l[(size_t)l] = want;
+        }
+    auto final_depth = [&](int l) -> int { return fin_l[(size_t)l]; };
     auto down_depth = [&](int l) -> int {
         const LI &I = li[(size_t)l];
         if (!I.dist) return 0;
@@ -3434,7 +3462,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                            g.k1 == g.n[2] && c1.k0 == 0 && c1.k1 == c1.n[2];
         // ... or both levels in z-slabs of the same ranks: the result on final_depth ghost planes needs the old iterate and the
         // coarse values two planes deeper and b one (what the way down leaves valid; exchanged at the launch if not)
-        const int fin0 = (l == 0 && I.dist && I.maxd > 1) ? 1 : 0;  // (final_depth)
+        const int fin0 = fin_l[(size_t)l];  // (final_depth)
         const bool slabs = I.dist && li[(size_t)l + 1].dist && !(g.per & 4) && std::min(I.maxd, I.cdepth) >= fin0 + 2 &&
                            coarse_need(s, l, fin0 + 2) <= li[(size_t)l + 1].maxd;
         if (!(whole || slabs) || g.zring) return false;
@@ -3726,7 +3754,9 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         // pre-smoothed iterate is valid and than the coarse correction can be had
         int e = 0;
         if (I.dist) {
-            e = std::min(std::min(fin + post, I.maxd), valid(a));
+            // (no deeper than a kernel may compute on: 0 on a periodic slab axis, whose outer ghost planes are the other end of the
+            // axis -- V(., 2) on such a level used to take the iterate's exchanged plane for a plane it could correct: plane -1)
+            e = std::min(std::min(fin + post, std::min(I.maxd, I.cdepth)), valid(a));
             if (li[(size_t)l + 1].dist)
                 while (e > 0 && coarse_need(s, l, e) > li[(size_t)l + 1].maxd) --e;
             if (li[(size_t)l + 1].dist) PIB_CHK(need(l + 1, xc, coarse_need(s, l, e)));

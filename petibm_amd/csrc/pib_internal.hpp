@@ -115,6 +115,7 @@ struct Config {
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
+    int deep_up = 1;         // ... and the coarse corrections of the way up need no exchange of their own: a distributed level's right-hand side is exchanged as deep as its final iterate is read by the finer level's prolongation (gmg.hip: fin_l[])
     int deep_halo = 1;       // multi-GPU multigrid: exchange several ghost planes at once and recompute the ghost cells (gmg.hip); 0: one plane per stencil kernel
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;

@@ -344,19 +344,24 @@ def test_multirank_setcsr_route_and_pinned_gmg():
 
 
 
-def test_config3_512_cubed_on_8_slabs():
+@pytest.mark.parametrize("recurrence", ["standard", "single_reduction"])
+def test_config3_512_cubed_on_8_slabs(recurrence):
     """BASELINE config 3 -- the 512^3 cavity pressure system on 8 z-slabs of 64 planes, the exact rank layout of
     `bench.py --gpus 8` (multigrid-PCG, V(2,2), rtol 1e-10) -- through the loopback transport on the one test GPU: every
     kernel, halo plan and collective call site of the 8-GPU run except RCCL itself (the ranks time-share the device, so
     the time means nothing).  Bars: the single-rank iteration count (11) on every rank, the residual contract recomputed
-    with the CSR operator, and the communication budget of DESIGN.md 5: at most 6 plane exchanges (all-gather included)
-    and 3 reductions per iteration."""
+    with the CSR operator, and the communication budget of DESIGN.md 5 (round 4): at most 4 plane exchanges per V-cycle
+    (the residual, the right-hand sides of levels 1 and 2, the all-gather at the replicated-level switch: none on the way
+    up, none for the Krylov product) and 3 reductions per iteration -- ONE with the single-reduction recurrence, i.e. at most
+    FIVE collectives per PCG iteration."""
     import bench
     from petibm_amd import capi
     from petibm_amd.linsolver import LinSolverHIP
     P, n = 8, 512
     w = np.full(n, 1.0 / n)
     cfg = bench.solver_config("gmg", 1e-10, 200, 0.9, 2, 2, "jacobi") + "\n"
+    if recurrence == "single_reduction":
+        cfg += "pib_cg_single_reduction=1\n"
 
     def rank_fn(r, uid):
         s = LinSolverHIP("poisson", config_text=cfg, rank=r, nranks=P, uid=uid, device=0)
@@ -381,6 +386,11 @@ def test_config3_512_cubed_on_8_slabs():
     its = res[0][0]
     for r in res:
         pc_applies, reductions, exchanges = int(r[3][1]), int(r[3][2]), int(r[3][3])
-        assert pc_applies == its + 1
-        assert exchanges <= 6 * pc_applies + 2, f"{exchanges} exchanges for {pc_applies} V-cycles"
-        assert reductions <= 3 * its + 3
+        # (the host counts what it enqueued: a batch may reach a few iterations beyond the one that met the tolerance)
+        assert its + 1 <= pc_applies <= its + 1 + 8
+        assert exchanges <= 4 * pc_applies + 2, f"{exchanges} exchanges for {pc_applies} V-cycles"
+        if recurrence == "single_reduction":
+            assert reductions <= pc_applies + 1, f"{reductions} reductions for {pc_applies} iterations"
+            assert exchanges + reductions <= 5 * pc_applies + 3
+        else:
+            assert reductions <= 3 * pc_applies + 3
