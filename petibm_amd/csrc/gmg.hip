@@ -383,8 +383,13 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
                                                     const double *__restrict__ b, double *__restrict__ xo,
                                                     const double *__restrict__ pin_sum, int FZ, double *__restrict__ ro,
                                                     const double *__restrict__ uw = nullptr, double *__restrict__ unew = nullptr,
-                                                    double *__restrict__ upart = nullptr, int upart_stride = 0)
+                                                    double *__restrict__ upart = nullptr, int upart_stride = 0, int wext = 0,
+                                                    int sum_lo = -(1 << 30), int sum_hi = 1 << 30, int blk_base = 0)
 {
+    // UPD on z-slabs (round 4): the run covers ghost planes too; the new residual is also written on the plane just below the
+    // run (wext bit 0, first z-chunk) / just above it (bit 1, last z-chunk) -- planes the march loads and updates anyway -- so
+    // that the neighbours' planes of r are kept by recurrence (w is exchanged, r never again); the sums cover the owned
+    // planes [sum_lo, sum_hi) only; the partials of the launches of one cycle sit side by side (blk_base).
     if (S != nullptr && S->done) return;
     __shared__ double x1[3][FSY][FSX];
     const double ua = UPD ? S->a : 0.0;
@@ -442,8 +447,10 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
                 for (int c = 0; c < 4; ++c) bv[c] = bv[c] - ua * wv[c];
                 if (hy_ok) hyv = hyv - ua * pw[off_hy];
                 if (hx_ok) hxv = hxv - ua * pw[off_hx];
-                if (kk >= k0 && kk < kend) {  // this workgroup's own cells: the new residual and its sums
-                    *reinterpret_cast<v4 *>(unew + (int64_t)kw * plane + off_c) = bv;
+                const bool own = kk >= k0 && kk < kend;
+                if (own || (kk == k0 - 1 && tb.z == 0 && (wext & 1)) || (kk == kend && kend == L.k0 + L.nk && (wext & 2)))
+                    *reinterpret_cast<v4 *>(unew + (int64_t)kw * plane + off_c) = bv;  // this workgroup's own cells: the new residual
+                if (own && kw >= sum_lo && kw < sum_hi) {                                // ... and its sums
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         ur0 += bv[c] * bv[c];
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
         }
         __syncthreads();
         if (tid < 2) {
-            const int64_t blk = ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
+            const int64_t blk = blk_base + ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
             upart[(int64_t)tid * upart_stride + blk] = (ush[tid][0] + ush[tid][1]) + (ush[tid][2] + ush[tid][3]);
         }
     }
@@ -3199,13 +3206,22 @@ static int coarse_need(const pib_solver *s, int l, int e)
 // the whole fine level, Jacobi smoothing, no pinned unknown, and few enough workgroups for the solver's partial-sum slots
 bool gmg_fused_update_ok(const pib_solver *s)
 {
-    if (!s->has_grid || s->levels.empty() || !s->gmg_error.empty() || s->comm.nranks != 1) return false;
+    if (!s->has_grid || s->levels.empty() || !s->gmg_error.empty()) return false;
     if (s->cfg.smoother == Smoother::CHEBYSHEV || !s->cfg.fuse_presmooth || s->nullspace == PIB_NULLSPACE_PINNED) return false;
     if (s->levels.size() < 2) return false;
     const GridLevel &g = s->levels[0];
     const int64_t nk = g.k1 - g.k0;
-    if (g.k0 != 0 || nk != g.n[2] || !fused_run_ok(s, g, 0, nk)) return false;
     const int FZ = march_planes(g, nk);
+    if (s->comm.nranks > 1) {
+        // z-slabs (round 4): level 0 distributed with deep halos, every rank's slab thick enough for them, the two-step march
+        // (the cycle decides again with its own predicate at the launch site and falls back to the separate pass if it must)
+        if (!s->cfg.fuse_residual_update_slabs || !s->cfg.deep_halo || g.replicated || g.zring || (g.per & 4)) return false;
+        if (std::max(1, s->cfg.presweeps) * (s->cfg.sweep_pairs ? 2 : 1) < 2) return false;
+        for (int q2 = 0; q2 < s->comm.nranks; ++q2)
+            if (s->gmg_own[0][(size_t)q2].second - s->gmg_own[0][(size_t)q2].first < 8) return false;
+        return fused_run_ok(s, g, 0, nk) && (g.n[0] / FX) * (g.n[1] / FY) * ((nk + FZ - 1) / FZ + 2) <= PIB_MAXPART;
+    }
+    if (g.k0 != 0 || nk != g.n[2] || !fused_run_ok(s, g, 0, nk)) return false;
     return (g.n[0] / FX) * (g.n[1] / FY) * ((nk + FZ - 1) / FZ) <= PIB_MAXPART;
 }
 
@@ -3350,7 +3366,39 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                         hipLaunchKernelGGL(k_presmooth2<0>, dim3((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((rc + FZ - 1) / FZ)),
                                            dim3(256), 0, q, S, dev_of(sub), omega, b + ra * g.plane, c + ra * g.plane, pin_l, FZ, nullptr);
                     };
-                    if (l == 0 && s->gmg_upd.w != nullptr) {
+                    if (l == 0 && s->gmg_upd.w != nullptr && I.dist) {
+                        // ... on z-slabs (round 4): w came through the exchange instead of the residual, whose ghost planes follow the
+                        // recurrence -- every launch updates the planes it loads, the run's planes and the one beyond it at either end
+                        // (the depth the next cycle reads r on) are written to the NEW residual's buffer, the sums cover the owned planes
+                        const double *ro = s->gmg_upd.r_old, *uw = s->gmg_upd.w;
+                        double *rn = const_cast<double *>(b);
+                        int nblk = 0;
+                        auto launch_upd = [&](int64_t ra, int64_t rc, int wext) {
+                            if (rc <= 0) return;
+                            GridLevel sub = g;
+                            sub.k0 = g.k0 + ra;
+                            sub.k1 = sub.k0 + rc;
+                            const dim3 grid((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((rc + FZ - 1) / FZ));
+                            hipLaunchKernelGGL((k_presmooth2<0, 1>), grid, dim3(256), 0, q, S, dev_of(sub), omega, ro + ra * g.plane, c + ra * g.plane, pin_l, FZ,
+                                               (double *)nullptr, uw + ra * g.plane, rn + ra * g.plane, s->d_part + 4 * (int64_t)PIB_MAXPART, (int)PIB_MAXPART,
+                                               wext, (int)g.k0, (int)g.k1, nblk);
+                            nblk += (int)(grid.x * grid.y * grid.z);
+                        };
+                        // the run reaches o ghost planes, the residual is read (and kept) one plane deeper
+                        const int wlo = (I.lo && o + 1 <= valid(uw)) ? 1 : 0, whi = (I.hi && o + 1 <= valid(uw)) ? 2 : 0;
+                        if (halo_pending) {
+                            const int64_t ia = I.lo ? 1 : 0, ie = I.nk - (I.hi ? 1 : 0);
+                            launch_upd(ia, ie - ia, 0);
+                            PIB_CHK(wait_halo());
+                            launch_upd(ka, ia - ka, wlo);
+                            launch_upd(ie, ka + kc - ie, whi);
+                        } else
+                            launch_upd(ka, kc, wlo | whi);
+                        PIB_HIP(hipGetLastError());
+                        if (nblk > PIB_MAXPART) return fail(PIB_ERR_LIB, "fused residual update: too many workgroups for the partial sums");
+                        s->gmg_upd.used = true;
+                        PIB_CHK(s->gmg_upd.after(s, nblk, q));
+                    } else if (l == 0 && s->gmg_upd.w != nullptr) {
                         // PCG's residual update folded into this march (k_presmooth2<., 1>): b is the NEW residual's buffer
                         if (I.dist || halo_pending || ka != 0 || kc != I.nk) return fail(PIB_ERR_LIB, "fused residual update: level 0 is not a whole single-rank level");
                         const dim3 grid((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((kc + FZ - 1) / FZ));
@@ -3603,9 +3651,13 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // predicate of its two launch sites below; if it cannot take the update, the update runs as a pass of its own first
             const int FZ0 = march_planes(g, I.nk);
             auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
-            const bool site = s->cfg.fuse_residual_update == 1 && !I.dist && !cheb && s->cfg.fuse_presmooth && fused_run_ok(s, g, 0, I.nk) &&
-                              (g.n[0] / FX) * (g.n[1] / FY) * ((I.nk + FZ0 - 1) / FZ0) <= PIB_MAXPART && al32(b) &&
-                              (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
+            bool site = s->cfg.fuse_residual_update == 1 && !cheb && s->cfg.fuse_presmooth && fused_run_ok(s, g, 0, I.nk) &&
+                        (g.n[0] / FX) * (g.n[1] / FY) * ((I.nk + FZ0 - 1) / FZ0 + 2) <= PIB_MAXPART && al32(b) &&
+                        (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
+            // z-slabs: the two-step march only, deep halos (the residual's depth is what w is exchanged to), aligned planes
+            if (I.dist)
+                site = site && pre >= 2 && !g.zring && down_depth(0) >= 2 && down_depth(0) <= I.maxd && al32(s->gmg_upd.w) && al32(s->gmg_upd.r_old) &&
+                       (g.plane % 4) == 0;
             if (!site) {
                 if (s->gmg_upd.fallback == nullptr) return fail(PIB_ERR_LIB, "fused residual update: no fallback registered");
                 PIB_CHK(s->gmg_upd.fallback(s, const_cast<double *>(b), q));
@@ -3642,10 +3694,15 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         // the right-hand side on as many ghost planes as the way down (and, on level 0, the way up) consumes
         const int Dd = down_depth(l);
         set_valid(b, 0);
+        // (PCG's residual update inside the first march, on slabs: w = A p is what travels; the new residual comes out of the
+        // march on the same planes, the neighbours' included)
+        const double *xv = (l == 0 && I.dist && s->gmg_upd.w != nullptr) ? s->gmg_upd.w : b;
+        set_valid(xv, 0);
         if (I.dist && s->cfg.overlap_halo && I.nk >= 4 && (int64_t)Dd * g.plane * 8 >= (int64_t)s->cfg.overlap_min_bytes)
-            PIB_CHK(need_async(l, b, Dd));
+            PIB_CHK(need_async(l, xv, Dd));
         else
-            PIB_CHK(need(l, b, Dd));
+            PIB_CHK(need(l, xv, Dd));
+        if (xv != b) set_valid(b, valid(xv));
         if (pre == 1 && !cheb) {
             PIB_CHK(wait_halo());
             // one pre-smoothing step from zero and the residual of its result: x1 kept and r valid on o ghost planes

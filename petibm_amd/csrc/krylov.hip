@@ -916,8 +916,8 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     // Multigrid-preconditioned, one rank, systems too large for the captured graphs: r = r - alpha w is left to the V-cycle's
     // first kernel, which reads the residual anyway (gmg.hip k_presmooth2<., 1>: 24 B/row and a launch less per iteration).
     // That kernel recomputes halo cells, so the new residual goes to the OTHER of two buffers, iteration by iteration.
-    const bool fused_upd = gmg && s->cfg.fuse_residual_update && s->comm.nranks == 1 && lazy == 1 && n > s->cfg.graph_max_rows &&
-                           gmg_fused_update_ok(s);
+    // (several ranks, round 4: on z-slabs with deep halos too -- w is exchanged instead of the residual, gmg.hip)
+    const bool fused_upd = gmg && s->cfg.fuse_residual_update && lazy == 1 && n > s->cfg.graph_max_rows && gmg_fused_update_ok(s);
     struct UpdCtx {
         double *hist;
         double ng;
@@ -943,6 +943,8 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     auto after_update = +[](pib_solver *ps, int nblocks, hipStream_t st) -> int {
         // r.r and sum r of the new residual from the march's partials (slots 4, 5), then the convergence step on |r|
         hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, st, ps->d_s, ps->d_part, 4, nblocks);
+        PIB_HIP(hipGetLastError());
+        PIB_CHK(allreduce_slots(ps, 4, 2, st));  // (several ranks; nothing on one)
         if (upd_ctx.unprec)
             hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, st, ps->d_s, upd_ctx.hist, upd_ctx.ng, 0, 1, 0, upd_ctx.conv_is_its);
         PIB_HIP(hipGetLastError());

@@ -95,6 +95,7 @@ struct Config {
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
     int march_velocity = 1;        // matrix-free velocity product: LDS-tiled z-marching form for tile-divisible components (velstencil.hip k_vel_march)
     int cg_single_reduction = 0;   // CG with PETSc's single-reduction recurrences (-<name>_ksp_cg_single_reduction; solver file: pib_cg_single_reduction=1): ONE all-reduce per iteration, 16 B/row more vector traffic (krylov.hip solve_cg_sr)
+    int fuse_residual_update_slabs = 1;  // ... on z-slabs too: w = A p is exchanged to the depth the residual was, the march keeps the residual's ghost planes by recurrence (gmg.hip k_presmooth2<., 1> with wext)
     int fuse_residual_update = 1;  // PCG + multigrid on one rank: r = r - alpha w by the V-cycle's first march instead of a pass of its own
     int fuse_bicgstab_dots = 1;  // ... and its two dot-only passes summed by the products themselves (sums grouped by tile: the iterates equal the CSR path's to rounding, no longer bit for bit; 0 keeps the bit-identical route)
     int blocked_direct_solve = 1;   // dense.hip: the explicit inverse of the direct solver by 64-column block elimination (0: one launch per column)

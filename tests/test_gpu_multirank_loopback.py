@@ -394,3 +394,58 @@ def test_config3_512_cubed_on_8_slabs(recurrence):
             assert exchanges + reductions <= 5 * pc_applies + 3
         else:
             assert reductions <= 3 * pc_applies + 3
+            assert int(r[3][6]) >= its  # r -= alpha w ran inside the V-cycle's first march on every rank (w travelled, not r)
+
+
+@pytest.mark.parametrize("P,n,extra", [
+    (2, (128, 16, 64), ""),
+    (3, (128, 16, 96), "pib_overlap_min_bytes=0\n"),     # w's exchange on the communication stream behind the interior planes
+    (4, (128, 32, 64), "pib_agglomerate_below=100\n"),
+    (2, (128, 16, 64), "pib_cg_single_reduction=0\npib_deep_up=0\n"),
+])
+def test_residual_update_inside_the_vcycle_on_slabs(P, n, extra):
+    """Round 4: PCG's r = r - alpha w inside the V-cycle's first march on z-slabs too (krylov.hip / gmg.hip k_presmooth2<., 1>
+    with `wext`): w = A p is exchanged to the depth the residual was, every launch updates the planes it loads, the neighbours'
+    planes of the new residual are written as well and follow the recurrence from then on.  Same expression per cell: the
+    iterates are those of the separate pass (pib_fuse_residual_update_slabs=0) bit for bit on every rank; the counters say the
+    fused form ran; the solve is the single rank's."""
+    from petibm_amd import capi, partition
+    from petibm_amd.linsolver import LinSolverHIP
+    dt = 0.01
+    m, A, xs, b = _system(n, dt)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    plans = partition.all_plans(n, P)
+    base = "pib_march_min_cells=0\npib_graph_max_rows=0\n" + extra
+
+    def run(fuse):
+        def rank_fn(r, uid):
+            pl = plans[r]
+            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=base + f"pib_fuse_residual_update_slabs={fuse}\n", sweeps=2), rank=r, nranks=P,
+                             uid=uid, device=0)
+            s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+            x = np.zeros(pl.n_local)
+            s.solve(x, np.ascontiguousarray(b[pl.row0:pl.row0 + pl.n_local]))
+            out = (x, s.getIters(), s.getResidualHistory().copy(), s.counters().copy())
+            # a second solve with the same solver: the residual's ghost planes start from the set-up's exchange again
+            x2 = np.zeros(pl.n_local)
+            s.solve(x2, np.ascontiguousarray(b[pl.row0:pl.row0 + pl.n_local]))
+            assert np.array_equal(x2, x)
+            s.destroy()
+            return out
+        return _run_ranks(P, rank_fn)
+
+    fused, plain = run(1), run(0)
+    for f, p_ in zip(fused, plain):
+        assert int(f[3][6]) >= f[1] > 0 and int(p_[3][6]) == 0   # every (enqueued) iteration took the fused form / none did
+        assert f[1] == p_[1] and np.array_equal(f[0], p_[0])
+        assert np.allclose(f[2], p_[2], rtol=1e-12)
+        assert int(f[3][3]) == int(p_[3][3])                      # the same number of exchanges: w travels instead of r
+    x = np.concatenate([f[0] for f in fused])
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    s1 = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=base, sweeps=2))
+    s1.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+    x1 = np.zeros(A.n_rows)
+    s1.solve(x1, b)
+    assert s1.getIters() == fused[0][1]
+    assert np.linalg.norm((x - x.mean()) - (x1 - x1.mean())) <= 1e-9 * np.linalg.norm(x1)
+    s1.destroy()
