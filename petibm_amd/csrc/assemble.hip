@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <limits>
 
+#include <mutex>
+
 #include "pib_internal.hpp"
 
 namespace pib {
@@ -81,12 +83,28 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
         return best;
     };
     int64_t cmin = std::numeric_limits<int64_t>::max(), cmax = std::numeric_limits<int64_t>::min();
-    for (int64_t p = 0; p < nnz; ++p) {
-        const int64_t c = CL(base + p);
-        if (c < 0 || c >= n_global) return fail(PIB_ERR_ARG_OUTOFRANGE, "set_csr: column %lld out of range", (long long)c);
-        const int64_t cn = near(c);
-        cmin = std::min(cmin, cn);
-        cmax = std::max(cmax, cn);
+    {
+        // (ranges of entries on a few host threads: the per-range minima / maxima and the first bad column are merged below)
+        std::mutex mu;
+        int64_t bad = -1;
+        par_ranges(nnz, [&](int64_t pb, int64_t pe) {
+            int64_t lo = std::numeric_limits<int64_t>::max(), hi = std::numeric_limits<int64_t>::min(), b = -1;
+            for (int64_t p = pb; p < pe; ++p) {
+                const int64_t c = CL(base + p);
+                if (c < 0 || c >= n_global) {
+                    b = c;
+                    break;
+                }
+                const int64_t cn = near(c);
+                lo = std::min(lo, cn);
+                hi = std::max(hi, cn);
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            cmin = std::min(cmin, lo);
+            cmax = std::max(cmax, hi);
+            if (b != -1 && bad == -1) bad = b;
+        });
+        if (bad != -1) return fail(PIB_ERR_ARG_OUTOFRANGE, "set_csr: column %lld out of range", (long long)bad);
     }
     DeviceCsr &A = s->A;
     A.release();
@@ -103,7 +121,9 @@ int upload_csr(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, c
     A.rp64 = nnz >= (int64_t)std::numeric_limits<int32_t>::max();
     const int64_t shift = row0 - A.ghost_lo;
     std::vector<int32_t> c32((size_t)std::max<int64_t>(nnz, 1));
-    for (int64_t p = 0; p < nnz; ++p) c32[(size_t)p] = (int32_t)(near(CL(base + p)) - shift);
+    par_ranges(nnz, [&](int64_t pb, int64_t pe) {
+        for (int64_t p = pb; p < pe; ++p) c32[(size_t)p] = (int32_t)(near(CL(base + p)) - shift);
+    });
     // +4 entries of padding: the SpMV reads val/col in aligned pairs
     PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
     PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));

@@ -189,12 +189,17 @@ static int set_csr_any(pib_solver *s, int64_t n_local, int64_t row0_global, int6
         return fail(PIB_ERR_ARG_NULL, "set_csr: null array");
     std::vector<int64_t> ranges;
     bool general = false;
+    SetupTrace tr("set_csr", s->comm.rank);
     PIB_CHK(classify_partition(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, ranges, &general));
+    tr.mark("classify_partition");
     if (general) {
         PIB_CHK(upload_csr_general(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val, ranges));
+        tr.mark("upload_csr_general");
         PIB_CHK(after_set_matrix(s));
+        tr.mark("after_set_matrix");
         if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
             PIB_CHK(redist_setup(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val, ranges));
+        tr.mark("redist_setup");
         if (s->cfg.pc == Precond::GMG && !s->redist.active)
             s->gmg_error = "the rows came in a partition that is neither z-slabs in natural ordering nor DMDA boxes of PetIBM's Poisson "
                            "operator: no mesh structure for the multigrid";
@@ -210,9 +215,12 @@ static int set_csr_any(pib_solver *s, int64_t n_local, int64_t row0_global, int6
         return 0;
     }
     PIB_CHK(upload_csr(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
+    tr.mark("upload_csr");
     PIB_CHK(after_set_matrix(s));
+    tr.mark("after_set_matrix");
     if (s->cfg.pc == Precond::GMG && s->cfg.detect_structure)
         PIB_CHK(detect_grid_structure(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
+    tr.mark("detect_grid_structure");
     if (s->cfg.pc != Precond::GMG && s->cfg.detect_structure && s->cfg.matrix_free_velocity)
         PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
     return 0;

@@ -148,15 +148,17 @@ int upload_csr_general(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_g
     A.rp64 = nnz >= (int64_t)INT32_MAX;
     // local columns: [low ghosts | owned | high ghosts]
     std::vector<int32_t> c32((size_t)std::max<int64_t>(nnz, 1));
-    for (int64_t p = 0; p < nnz; ++p) {
-        const int64_t c = V.CL(base + p);
-        if (V.mine(c))
-            c32[(size_t)p] = (int32_t)(A.ghost_lo + (c - row0));
-        else {
-            const int64_t idx = (int64_t)(std::lower_bound(g.begin(), g.end(), c) - g.begin());
-            c32[(size_t)p] = (int32_t)(idx + (c > row0 ? n_local : 0));
+    par_ranges(nnz, [&](int64_t pb, int64_t pe) {
+        for (int64_t p = pb; p < pe; ++p) {
+            const int64_t c = V.CL(base + p);
+            if (V.mine(c))
+                c32[(size_t)p] = (int32_t)(A.ghost_lo + (c - row0));
+            else {
+                const int64_t idx = (int64_t)(std::lower_bound(g.begin(), g.end(), c) - g.begin());
+                c32[(size_t)p] = (int32_t)(idx + (c > row0 ? n_local : 0));
+            }
         }
-    }
+    });
     PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
     PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));
     PIB_MEMSET(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4));
@@ -283,6 +285,7 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
     const int P = s->comm.nranks, rank = s->comm.rank;
     const View A{n_local, row0, n_global, rp64, cl64, rp32, cl32};
     const int64_t base = A.RP(0);
+    SetupTrace tr("redist_setup", rank);
     // ---- this rank's box: dims from the in-range offsets of its first rows, the owners across its + faces from the
     // off-range columns of the cells (xm - 1, 1, 1), (1, ym - 1, 1), (1, 1, zm - 1)
     bool ok = n_local > 0;
@@ -319,7 +322,9 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
                                 (double)own[2], (double)maxlen},
                         heads;
     const size_t HL = head.size();
+    tr.mark("own box read off the rows");
     PIB_CHK(comm_allgather_host(s, head, heads));
+    tr.mark("heads gathered");
     auto H = [&](int q, int k) { return (int64_t)heads[HL * (size_t)q + (size_t)k]; };
     int64_t W = 0;
     for (int q = 0; q < P; ++q) {
@@ -410,7 +415,47 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
         }
     F.fwd.finish(P, rank);
     F.bwd.finish(P, rank);
-    // ---- the rows themselves: fixed-width records [length | W columns (natural numbering) | W values]
+    // ---- the rows themselves, on the device (redistribute.hip: records, exchange, per-row sort, the slab's CSR); shapes that path
+    // does not take (rows wider than 16 entries, 64-bit sizes) and PIB_BOX_ROWS_ON_DEVICE=0 go through the host loops below
+    {
+        const char *e = std::getenv("PIB_BOX_ROWS_ON_DEVICE");
+        if (!(e && e[0] == '0')) {
+            tr.mark("plans");
+            PIB_CHK(create_sharing_comm(&R.inner, s->name.c_str(), s->cfg.raw.c_str(), s));
+            tr.mark("inner solver created");
+            pib_solver *in = R.inner;
+            in->cfg = s->cfg;
+            for (int d = 0; d < 3; ++d) in->periodic[d] = in->periodic_user[d] = s->periodic_user[d];
+            int32_t *h_rp = nullptr, *h_cl = nullptr;
+            double *h_vl = nullptr;
+            int64_t nnz_s = 0;
+            int err = redist_rows_on_device(s, in, F, N, n_local, row0, n_global, rp64, cl64, rp32, cl32, val, W, ranges, &h_rp, &h_cl, &h_vl, &nnz_s);
+            tr.mark("rows moved to the slab on the device");
+            if (err == 0) {
+                err = after_set_matrix(in);
+                tr.mark("inner after_set_matrix");
+                if (!err) err = detect_grid_structure(in, F.n_slab, F.k0 * pl, n_global, nullptr, nullptr, h_rp, h_cl, h_vl);
+                tr.mark("inner detect_grid_structure");
+            }
+            std::free(h_rp);
+            std::free(h_cl);
+            std::free(h_vl);
+            if (err == 0) {
+                if (!in->has_grid) {
+                    redist_release(s);
+                    return 0;
+                }
+                PIB_CHK(redist_tables(s));
+                tr.mark("redist_tables");
+                R.active = true;
+                return 0;
+            }
+            if (err != PIB_ERR_SUP) return err;
+            pib_destroy(R.inner);  // (not taken: the host path makes its own)
+            R.inner = nullptr;
+        }
+    }
+    // ---- the host path: fixed-width records [length | W columns (natural numbering) | W values]
     const int64_t RW = 1 + 2 * W;
     ExchangePlan rows = F.fwd;
     for (auto &c : rows.cnt) c *= RW;
@@ -422,16 +467,19 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
         const int64_t i = l % x, j = (l / x) % y, k = l / (x * y);
         return (B(q, 0) + i) + N[0] * ((B(q, 1) + j) + N[1] * (B(q, 2) + k));
     };
-    for (int64_t l = 0; l < n_local; ++l) {
-        double *rr = &rec[(size_t)(l * RW)];
-        const int64_t a = A.RP(l), len = A.RP(l + 1) - a;
-        rr[0] = (double)len;
-        for (int64_t t = 0; t < len; ++t) {
-            rr[1 + t] = (double)natural(A.CL(a + t));
-            rr[1 + W + t] = val[a + t];
+    par_ranges(n_local, [&](int64_t lb, int64_t le) {
+        for (int64_t l = lb; l < le; ++l) {
+            double *rr = &rec[(size_t)(l * RW)];
+            const int64_t a = A.RP(l), len = A.RP(l + 1) - a;
+            rr[0] = (double)len;
+            for (int64_t t = 0; t < len; ++t) {
+                rr[1 + t] = (double)natural(A.CL(a + t));
+                rr[1 + W + t] = val[a + t];
+            }
         }
-    }
+    });
     (void)base;
+    tr.mark("records built");
     DevScratch send_buf, recv_buf;
     const int64_t nrecv = F.n_slab * RW;
     PIB_HIP(hipMalloc(&send_buf.p, sizeof(double) * rec.size()));
@@ -446,12 +494,14 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
         recv[(size_t)q] = d_recv + roff[(size_t)q] * RW;
     }
     if (roff[(size_t)P] != F.n_slab) return fail(PIB_ERR_LIB, "set_csr: internal error (the boxes do not cover this rank's slab)");
+    tr.mark("records uploaded");
     PIB_CHK(comm_exchange_v(s, rows, d_send, recv.data(), s->stream));
     std::vector<double> got((size_t)std::max<int64_t>(nrecv, 1), 0.0);
     PIB_HIP(hipMemcpyAsync(got.data(), d_recv, sizeof(double) * got.size(), hipMemcpyDeviceToHost, s->stream));
     PIB_HIP(hipStreamSynchronize(s->stream));
     rec.clear();
     rec.shrink_to_fit();
+    tr.mark("records exchanged and fetched");
     // natural local row of record t of source q
     std::vector<int64_t> rp((size_t)F.n_slab + 1, 0);
     auto local_row = [&](int q, int64_t t) {
@@ -460,12 +510,15 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
         return (B(q, 0) + i) + N[0] * ((B(q, 1) + j) + N[1] * (k - F.k0));
     };
     for (int q = 0; q < P; ++q)
-        for (int64_t t = 0; t < F.fwd.from(q); ++t) rp[(size_t)local_row(q, t) + 1] = (int64_t)got[(size_t)((roff[(size_t)q] + t) * RW)];
+        par_ranges(F.fwd.from(q), [&](int64_t tb, int64_t te) {
+            for (int64_t t = tb; t < te; ++t) rp[(size_t)local_row(q, t) + 1] = (int64_t)got[(size_t)((roff[(size_t)q] + t) * RW)];
+        });
     for (int64_t l = 0; l < F.n_slab; ++l) rp[(size_t)l + 1] += rp[(size_t)l];
     std::vector<int64_t> cl((size_t)std::max<int64_t>(rp[(size_t)F.n_slab], 1));
     std::vector<double> vl((size_t)std::max<int64_t>(rp[(size_t)F.n_slab], 1));
     for (int q = 0; q < P; ++q)
-        for (int64_t t = 0; t < F.fwd.from(q); ++t) {
+        par_ranges(F.fwd.from(q), [&](int64_t tb, int64_t te) {
+        for (int64_t t = tb; t < te; ++t) {
             const double *rr = &got[(size_t)((roff[(size_t)q] + t) * RW)];
             const int64_t l = local_row(q, t), len = (int64_t)rr[0];
             // by ascending natural column, as MatMPIAIJGetLocalMat would deliver the row on slabs
@@ -483,16 +536,21 @@ int redist_setup(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global,
                 vl[(size_t)(rp[(size_t)l] + u)] = ep[u].second;
             }
         }
+        });
     got.clear();
     got.shrink_to_fit();
+    tr.mark("rows sorted into the slab's CSR");
     // ---- the inner solver: same configuration, same communicator, z-slabs in natural ordering
     PIB_CHK(create_sharing_comm(&R.inner, s->name.c_str(), s->cfg.raw.c_str(), s));
     pib_solver *in = R.inner;
     in->cfg = s->cfg;
     for (int d = 0; d < 3; ++d) in->periodic[d] = in->periodic_user[d] = s->periodic_user[d];
     PIB_CHK(upload_csr(in, F.n_slab, F.k0 * pl, n_global, rp.data(), cl.data(), nullptr, nullptr, vl.data()));
+    tr.mark("inner upload_csr");
     PIB_CHK(after_set_matrix(in));
+    tr.mark("inner after_set_matrix");
     PIB_CHK(detect_grid_structure(in, F.n_slab, F.k0 * pl, n_global, rp.data(), cl.data(), nullptr, nullptr, vl.data()));
+    tr.mark("inner detect_grid_structure");
     if (!in->has_grid) {  // not PetIBM's Poisson operator after all (the same verdict on every rank: the check is a global sum)
         redist_release(s);
         return 0;

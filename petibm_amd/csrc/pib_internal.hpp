@@ -5,8 +5,12 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/petibm_amd.h"
@@ -15,6 +19,49 @@ namespace pib {
 
 int fail(int code, const char *fmt, ...);  // records the message, returns code
 const char *last_error();
+
+// PIB_TRACE_SETUP=1: where the time of a set-up path goes (printed by rank 0 to stderr); tools/box_route_probe.py
+struct SetupTrace {
+    bool on;
+    const char *what;
+    std::chrono::steady_clock::time_point t;
+    SetupTrace(const char *w, int rank) : on(false), what(w), t(std::chrono::steady_clock::now())
+    {
+        const char *e = std::getenv("PIB_TRACE_SETUP");
+        on = e && e[0] == '1' && rank == 0;
+    }
+    void mark(const char *phase)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pib setup] %s: %s %.3f s\n", what, phase, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+
+// Host loops over the rows / entries of a matrix handed over through pib_set_csr (set-up only: the 16.8 M rows of a 512^3 / 8
+// box go through several of them): contiguous ranges on a few threads.  f(begin, end) must touch disjoint data per range.
+// PIB_HOST_THREADS overrides the count (default: the hardware's, at most 16; 1 below 2^18 items).
+template <class F>
+inline void par_ranges(int64_t n, F f)
+{
+    int T = 1;
+    if (n >= ((int64_t)1 << 18)) {
+        T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *e = std::getenv("PIB_HOST_THREADS")) T = std::max(1, std::atoi(e));
+    }
+    if (T <= 1) {
+        f((int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t chunk = (n + T - 1) / T;
+    for (int t = 0; t < T; ++t) {
+        const int64_t b = std::min<int64_t>(n, t * chunk), e = std::min<int64_t>(n, b + chunk);
+        if (e > b) th.emplace_back([=]() { f(b, e); });
+    }
+    for (auto &x : th) x.join();
+}
 
 #define PIB_HIP(call)                                                                                   \
     do {                                                                                                \
@@ -447,6 +494,9 @@ void redist_release(pib_solver *s);
 // redistribute.hip
 int halo_exchange_general(pib_solver *s, double *x_owned, hipStream_t st);
 int redist_tables(pib_solver *s);
+int redist_rows_on_device(pib_solver *s, pib_solver *in, const RedistField &F, const int64_t N[3], int64_t n_local, int64_t row0, int64_t n_global,
+                          const int64_t *rp64, const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val, int64_t W,
+                          const std::vector<int64_t> &ranges, int32_t **h_rp, int32_t **h_cl, double **h_vl, int64_t *nnz_out);
 int redist_forward(pib_solver *s, const double *v_box, double *v_nat, hipStream_t st);
 int redist_backward(pib_solver *s, const double *v_nat, double *v_box, hipStream_t st);
 // a solver on `other`'s device, rank and communicator (the second solver of a flow engine)

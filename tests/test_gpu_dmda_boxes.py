@@ -70,10 +70,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("host_rows", [False, True])
 @pytest.mark.parametrize("P,n,grid,pinned,periodic,i32", CASES)
-def test_poisson_rows_in_dmda_boxes(P, n, grid, pinned, periodic, i32):
+def test_poisson_rows_in_dmda_boxes(P, n, grid, pinned, periodic, i32, host_rows, monkeypatch):
+    """(host_rows: the set-up move of the rows through the host loops, PIB_BOX_ROWS_ON_DEVICE=0 -- the path rows wider than 16
+    entries take; default since round 4: records, per-row sort and the slab's CSR on the device, redistribute.hip)"""
     from petibm_amd import capi
     from petibm_amd.linsolver import LinSolverHIP
+    if host_rows:
+        monkeypatch.setenv("PIB_BOX_ROWS_ON_DEVICE", "0")
     dt = 0.01
     m, A, xs, b = _poisson(n, dt, pinned, periodic)
     L = dmda.dmda_layout(m, P, grid)
