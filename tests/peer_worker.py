@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 
 
 def poisson(job, r):
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     n, P = job["n"], job["P"]
     pl = partition.all_plans(n, P)[r]

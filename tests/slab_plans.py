@@ -1,4 +1,4 @@
-"""Host-side z-slab partition and halo plan (one rank per GPU).
+"""TEST SUPPORT (moved out of the product package in round 4): host-side z-slab partition and halo plan (one rank per GPU).
 
 The same rule the C library applies (pib_slab_range / assemble.hip:slab_range):
 PETSc's DMDA default split of N planes over P ranks, m_r = N/P + ((N % P) > r)

@@ -16,7 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import clib, mesh as omesh, operators as oops
-from petibm_amd import partition
+import slab_plans as partition
 
 
 def _free_port():

@@ -122,7 +122,8 @@ def test_bn_poisson_operator_on_slabs(lin, P, case, order, pinned):
     its rows (bn.hip: assemble_poisson_bn_slab); the ghost columns reach `order` planes into the neighbours, across the seam
     of a periodic slab axis through the ring.  Rows against the oracle's one-rank chain -- bit for bit, to rounding next to a
     periodic seam -- and the solve on the ranks against the one-rank solve."""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from test_gpu_multirank_loopback import _run_ranks
     cfg = {"3d": stretched_3d((8, 7, 13)), "2d": omesh.uniform_config((14, 17)),
            "3d_periodic": omesh.periodic_config((6, 5, 16), (True, False, True)),

@@ -293,7 +293,8 @@ def test_random_mesh_drop_in_route_on_slabs(seed):
     """The same on 2 or 3 ranks, rows cut into z-slabs of the natural ordering -- what a (1, 1, P) process grid gives
     MatMPIAIJGetLocalMat (global columns, across the seam of a periodic slab axis too); PETSC_DECIDE's boxes from 4 ranks
     up are tests/test_gpu_dmda_boxes.py.  The structure is gathered from the ranks' lines of entries."""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     from test_gpu_multirank_loopback import _cfg, _run_ranks
     cfg, per, _ = random_config(seed)

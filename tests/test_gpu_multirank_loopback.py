@@ -89,7 +89,8 @@ def _system(n, dt=0.01):
 def test_multirank_poisson_solve_matches_single_rank(P, n, pc, extra):
     sweeps = 2 if extra.endswith("V22") else 1
     extra = extra[:-3] if sweeps == 2 else extra
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     dt = 0.01
     m, A, xs, b = _system(n, dt)
@@ -142,7 +143,8 @@ def test_multirank_gmg_on_stretched_mesh_with_ragged_slabs(P, n, extra):
     """Slab boundaries that no pairing would respect (odd plane counts, stretched widths): the z aggregates of
     a distributed level stop at the slab boundaries, so the hierarchy differs slightly from the single-rank one
     but stays a symmetric V-cycle of the same quality: same residual contract, iteration count within 3."""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     dt = 0.01
     dim = len(n)
@@ -188,7 +190,8 @@ def test_halo_overlap_does_not_change_a_single_bit():
     """pib_overlap_halo: boundary planes first, exchange on the communication stream during the interior part of the
     producing kernel (V-cycle smoothers, residual, prolongation, p = z + beta p).  Same kernels, same values: the
     residual history and the solution are identical with and without it."""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     P, n, dt = 3, (16, 16, 24), 0.01
     m, A, xs, b = _system(n, dt)
@@ -216,7 +219,7 @@ def _velocity_slab_indices(m, P, r):
     """entries of the single-rank packed velocity vector owned by rank r, in that rank's packed order
     [u-slab | v-slab | w-slab] (cartesianmesh.cpp:516-535,740-779: the velocity DMDAs reuse the pressure slabs; the
     component along the slab axis has one plane fewer, on the last rank)"""
-    from petibm_amd import partition
+    import slab_plans as partition
     sd = m.dim - 1
     k0, k1 = partition.slab_range(int(m.n[3][sd]), P, r)
     idx, off = [], 0
@@ -307,7 +310,8 @@ def test_multirank_velocity_system(P, case):
 
 def test_multirank_setcsr_route_and_pinned_gmg():
     """The PetIBM route (setMatrix with local rows / global columns + grid hint) on 2 ranks, pinned pressure."""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     n, P, dt = (16, 12, 16), 2, 0.02
     m = omesh.create_mesh(omesh.uniform_config(n))
@@ -409,7 +413,8 @@ def test_residual_update_inside_the_vcycle_on_slabs(P, n, extra):
     planes of the new residual are written as well and follow the recurrence from then on.  Same expression per cell: the
     iterates are those of the separate pass (pib_fuse_residual_update_slabs=0) bit for bit on every rank; the counters say the
     fused form ran; the solve is the single rank's."""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     dt = 0.01
     m, A, xs, b = _system(n, dt)

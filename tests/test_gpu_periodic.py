@@ -320,7 +320,8 @@ def test_periodic_slab_axis_across_ranks(P, n, per, pc, extra):
     """a periodic slab axis wraps rank 0 <-> rank P-1 -- every rank has both ghost planes, the halo
     exchange is a ring, distributed multigrid levels take their z wrap from the halo planes.  Loopback ranks on one GPU
     (the ring's ncclSend / ncclRecv ordering for P = 2 is documented in csrc/halo.hip, not exercised here)."""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     from test_gpu_multirank_loopback import _cfg, _run_ranks
     dt = 0.01
@@ -436,7 +437,8 @@ def test_setmatrix_route_with_a_periodic_slab_axis(P, system_kind, pc):
     halo exchange becomes a ring; the Poisson system (natural ordering) and the velocity system in the distributed packed
     ordering [u_r | v_r | w_r] per rank; with a grid hint + setPeriodic the geometric multigrid runs on it."""
     import scipy.sparse as sp
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     from test_gpu_multirank_loopback import _cfg, _run_ranks, _velocity_slab_indices
     n, per, dt = (8, 6, 12), (True, False, True), 0.01

@@ -146,7 +146,8 @@ def test_single_reduction_on_slabs_one_allreduce_per_iteration(P, n, pc, extra, 
     """z-slabs over the loopback transport: the single rank's iteration count and solution, and the counters say what the
     variant is for -- one all-reduce per iteration (the standard recurrence: three with the multigrid, two without), no
     exchange for the Krylov product behind a V-cycle on deep halos (z comes out valid on the ghost plane the matrix reaches)."""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     from test_gpu_multirank_loopback import _cfg, _run_ranks, _system
     dt = 0.01

@@ -217,7 +217,8 @@ def test_matrices_that_are_not_the_poisson_operator_stay_without_structure():
                                         (4, (16, 16, 4), False)])
 def test_structure_recovered_on_slabs(P, n, pinned):
     """every rank hands over its rows only (MatMPIAIJGetLocalMat layout); the lines of entries are gathered"""
-    from petibm_amd import capi, partition
+    from petibm_amd import capi
+    import slab_plans as partition
     from petibm_amd.linsolver import LinSolverHIP
     dim, dt = len(n), 0.02
     cfg = omesh.uniform_config(n)

@@ -203,7 +203,7 @@ def test_createlinsolver_factory_dispatch(capi, tmp_path):
 
 
 def test_slab_range_matches_python_partition_and_dmda_rule(capi):
-    from petibm_amd import partition
+    import slab_plans as partition
     from oracle import mesh as omesh
     lib = capi.load()
     for n, P in ((512, 8), (512, 4), (256, 8), (10, 4), (7, 3), (450, 8), (5, 5)):

@@ -19,7 +19,8 @@ import numpy as np
 
 import bench
 from oracle import clib, dmda, operators as oops
-from petibm_amd import capi, partition
+from petibm_amd import capi
+import slab_plans as partition
 from petibm_amd.linsolver import LinSolverHIP
 from test_gpu_multirank_loopback import _run_ranks
 
