@@ -582,7 +582,8 @@ def poisson_bench(args) -> int:
             try:
                 if os.environ.get("PIB_FORCE_RCCL_FAIL") == "1":
                     raise RuntimeError("forced failure (PIB_FORCE_RCCL_FAIL=1)")
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+                import datetime
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=180))
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()

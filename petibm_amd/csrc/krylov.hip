@@ -27,6 +27,9 @@
 #include <type_traits>
 #include <cstring>
 
+#include <chrono>
+#include <thread>
+
 #include "pib_internal.hpp"
 
 namespace pib {
@@ -639,10 +642,39 @@ int ensure_work(pib_solver *s, int nvec)
     return 0;
 }
 
+// The host's wait for a batch of iterations.  On RCCL with several ranks it is BOUNDED (PIB_RCCL_TIMEOUT_S, default 180 s; 0: wait
+// for ever): a collective that never completes -- a rank that died, a link that never came up on first contact -- becomes
+// ncclCommAbort + an error the caller can act on (bench.py falls back to the peer transport) instead of a hung process.
 static int poll(pib_solver *s)
 {
     PIB_HIP(hipMemcpyAsync(s->h_s, s->d_s, sizeof(Scalars), hipMemcpyDeviceToHost, s->stream));
-    PIB_HIP(hipStreamSynchronize(s->stream));
+    static const double limit = [] {
+        const char *e = std::getenv("PIB_RCCL_TIMEOUT_S");
+        return e ? std::atof(e) : 180.0;
+    }();
+    if (s->comm.comm != nullptr && s->comm.nranks > 1 && limit > 0.0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int spins = 0;
+        for (;;) {
+            const hipError_t e = hipStreamQuery(s->stream);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) {
+                (void)hipGetLastError();
+                return fail(PIB_ERR_LIB, "solver %s: the stream failed while waiting for a batch of iterations (%s)", s->name.c_str(), hipGetErrorString(e));
+            }
+            (void)hipGetLastError();
+            if (++spins > 2000) {  // (the first ~2000 queries spin: a batch takes a millisecond or so; then 50 us naps)
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                    (void)ncclCommAbort(s->comm.comm);
+                    s->comm.comm = nullptr;
+                    return fail(PIB_ERR_LIB, "solver %s: an RCCL collective did not complete within %.0f s (PIB_RCCL_TIMEOUT_S): communicator aborted",
+                                s->name.c_str(), limit);
+                }
+            }
+        }
+    } else
+        PIB_HIP(hipStreamSynchronize(s->stream));
     s->counters[4]++;
     return 0;
 }
