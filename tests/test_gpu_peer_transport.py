@@ -208,14 +208,19 @@ def test_bench_launches_its_own_ranks_over_the_peer_transport():
     assert d["true_rel_residual"] <= 1.5e-10 and d["counters"]["halo_exchanges"] > 0
 
 
-def test_bench_falls_back_to_the_peer_transport_when_rccl_fails_on_first_contact():
+@pytest.mark.parametrize("how", ["forced", "genuine"])
+def test_bench_falls_back_to_the_peer_transport_when_rccl_fails_on_first_contact(how):
     """The first run on a multi-GPU node must end in a JSON line, not a traceback: with RCCL's bootstrap failing
     (PIB_FORCE_RCCL_FAIL=1 makes ncclCommInitRank's call site return its error; the ranks share the one GPU here, torch side on
     gloo) `bench.py --gpus 2` -- default transport rccl -- agrees on the failure across the ranks, switches to the peer
     transport, says so in `notes` and `config.transport`, and still meets the residual contract; the CG recurrence tuned on
     the untimed solves is named too, and every rank's counters are in the line."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PIB_BENCH_SHARE_GPU="1", PIB_PEER_TIMEOUT_S="240", PIB_FORCE_RCCL_FAIL="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PIB_TRANSPORT"):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PIB_BENCH_SHARE_GPU="1", PIB_PEER_TIMEOUT_S="240")
+    if how == "forced":
+        env["PIB_FORCE_RCCL_FAIL"] = "1"
+    # ("genuine": RCCL itself refuses two ranks on one device -- ncclCommInitRank returns `invalid usage` on every rank: a real
+    # first-contact failure of the library, handled by the same path)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PIB_TRANSPORT") + (("PIB_FORCE_RCCL_FAIL",) if how == "genuine" else ()):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "2", "--warmup", "1", "--no-cpu",
            "--no-secondary", "--kernel-reps", "2"]
@@ -225,7 +230,8 @@ def test_bench_falls_back_to_the_peer_transport_when_rccl_fails_on_first_contact
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["transport"] == "peer"
-    assert any("fell back to --transport peer" in nt and "PIB_FORCE_RCCL_FAIL" in nt for nt in d["notes"]), d["notes"]
+    assert any("fell back to --transport peer" in nt and ("PIB_FORCE_RCCL_FAIL" in nt if how == "forced" else "ncclCommInitRank" in nt)
+               for nt in d["notes"]), d["notes"]
     assert any("CG recurrence tuned at first contact" in nt for nt in d["notes"]) and d["config"]["cg_recurrence"] in ("standard", "single-reduction")
     assert d["true_rel_residual"] <= 1.5e-10 and len(d["per_rank"]) == 2 and all(r["halo_exchanges"] > 0 for r in d["per_rank"])
 
