@@ -2,10 +2,10 @@
 # First contact with a multi-GPU node (nothing with N > 1 has ever run on RCCL / xGMI: DESIGN.md 5).  Runs, in this order and
 # each under its own timeout so that one hang does not lose the rest:
 #   1. what a collective costs between two DIFFERENT GPUs: RCCL send/recv + all-reduce next to both peer-transport flavours
-#   2. bench.py --gpus 2 on RCCL, then on the peer transport   (256^3: seconds)
+#   2. bench.py --gpus 2 on RCCL, on the peer transport, and as the driver runs it (--transport auto: both timed, the faster kept)   (256^3: seconds)
 #   3. the forced-failure drill: RCCL's bootstrap "fails", bench.py must fall back to the peer transport and say so
 #   4. bench.py --gpus N (default 8) on RCCL and on the peer transport at the headline size, with the per-rank counters
-#   5. the scaling sweep 1 / 2 / 4 / N the driver makes
+#   5. the scaling sweep 1 / 2 / 4 / N the driver makes (default flags: transport and CG recurrence tuned on untimed solves)
 # usage: tools/first_contact.sh [N]      output: gpurun_out/first_contact/*.json|txt (copy what matters to profiles/)
 N=${1:-8}
 OUT=gpurun_out/first_contact
@@ -26,14 +26,15 @@ except Exception as e: print('')" 2>/dev/null)" | tee -a $OUT/summary.txt
 }
 run latency_two_gpus 600 python tools/comm_latency.py --two-gpus
 cat $OUT/latency_two_gpus.out >> $OUT/summary.txt
-run bench2_rccl_256 600 python bench.py --gpus 2 --grid 256 --steps 5 --warmup 2 --no-cpu --no-secondary
+run bench2_rccl_256 600 python bench.py --gpus 2 --grid 256 --steps 5 --warmup 2 --no-cpu --no-secondary --transport rccl
 run bench2_peer_256 600 python bench.py --gpus 2 --grid 256 --steps 5 --warmup 2 --no-cpu --no-secondary --transport peer
+run bench2_auto_256 600 python bench.py --gpus 2 --grid 256 --steps 5 --warmup 2 --no-cpu --no-secondary
 PIB_FORCE_RCCL_FAIL=1 run bench2_forced_rccl_failure 600 python bench.py --gpus 2 --grid 256 --steps 2 --warmup 1 --no-cpu --no-secondary
 if [ "$ndev" -ge "$N" ]; then
-  run bench${N}_rccl_512 900 python bench.py --gpus $N --steps 10 --warmup 3 --no-cpu --no-secondary
+  run bench${N}_rccl_512 900 python bench.py --gpus $N --steps 10 --warmup 3 --no-cpu --no-secondary --transport rccl
   run bench${N}_peer_512 900 python bench.py --gpus $N --steps 10 --warmup 3 --no-cpu --no-secondary --transport peer
-  run bench${N}_rccl_512_standard 900 python bench.py --gpus $N --steps 10 --warmup 3 --no-cpu --no-secondary --extra-config "pib_cg_single_reduction=0"
-  run bench${N}_rccl_512_single_reduction 900 python bench.py --gpus $N --steps 10 --warmup 3 --no-cpu --no-secondary --extra-config "pib_cg_single_reduction=1"
+  run bench${N}_rccl_512_standard 900 python bench.py --gpus $N --steps 10 --warmup 3 --no-cpu --no-secondary --transport rccl --extra-config "pib_cg_single_reduction=0"
+  run bench${N}_rccl_512_single_reduction 900 python bench.py --gpus $N --steps 10 --warmup 3 --no-cpu --no-secondary --transport rccl --extra-config "pib_cg_single_reduction=1"
 fi
 for g in 1 2 4 $N; do
   [ "$ndev" -ge "$g" ] && run scale_$g 900 python bench.py --gpus $g --steps 10 --warmup 3 --no-cpu --no-secondary --pmc off
