@@ -317,8 +317,9 @@ int pib_ns_create(pib_ns **ns, int dim, const int64_t n[3], const double *wx, co
  * owns, E u and the force system E BN H are summed over the ranks, the forces are replicated.  A periodic slab axis (the
  * Taylor-Green box, the cylinder array of multicylinders2dRe100 on several GPUs) makes both ends of every rank's slab a
  * cut and the plane exchanges a ring.  BN order > 1 (pib_ns_set_bn_order) works on slabs too: the operator from per-rank windows of the product chain, the
- * projection by applying BN term by term with the velocity solver's matrix-free L (one exchange per extra term).  Not on
- * slabs: immersed bodies together with BN order > 1, the coupled IBPM, the vorticity utility (PIB_ERR_SUP). */
+ * projection by applying BN term by term with the velocity solver's matrix-free L (one exchange per extra term).  Immersed
+ * bodies with BN order > 1 on slabs: E BN H is assembled densely, one column per force unknown through the same term-by-term
+ * BN, for the direct forces solver.  Not on slabs: the coupled IBPM, the vorticity utility (PIB_ERR_SUP). */
 int pib_ns_create_slab(pib_ns **ns, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                        const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
                        double nu, const char *velocity_cfg, const char *poisson_cfg, int rank, int nranks,

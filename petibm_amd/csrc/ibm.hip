@@ -59,6 +59,9 @@ struct IbState {
     int32_t *bnh_rowptr = nullptr, *bnh_col = nullptr;
     double *bnh_val = nullptr;
     int64_t bnh_nnz = 0;
+    // ... on z-slabs BN is applied term by term with the engine's halo exchanges (navierstokes.hip: ns_bn_series_slab): bn_t is the
+    // extended-slab work vector of y += BN H x, e_nf / col_nf the unit vector and the column of the dense EBNH assembly
+    double *bn_t = nullptr, *e_nf = nullptr, *col_nf = nullptr;
     double *f = nullptr, *df = nullptr, *rhsf = nullptr;
     double *ub = nullptr;     // prescribed velocity of the Lagrangian points (RigidKinematicsSolver: rhsf = UB - E u)
     bool moving = false;
@@ -336,9 +339,37 @@ __global__ __launch_bounds__(256) void k_ib_hcounts(int64_t hrows, const int32_t
 }
 
 // y += BNH x  (MatMultAdd(BNH, x, y, y): decoupledibpm.cpp:283-284)
+__global__ void k_ib_set1(double *x, int64_t j, double v) { x[j] = v; }
+// M[i][j] = col[i] for the dense EBNH held as a CSR with nf entries per row
+__global__ __launch_bounds__(256) void k_ib_put_column(int64_t nf, int64_t j, const double *__restrict__ col, double *__restrict__ val)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nf; i += (int64_t)gridDim.x * 256) val[i * nf + j] = col[i];
+}
+__global__ __launch_bounds__(256) void k_ib_dense_pattern(int64_t nf, int32_t *__restrict__ rp, int32_t *__restrict__ cl)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nf * nf; e += (int64_t)gridDim.x * 256) cl[e] = (int32_t)(e % nf);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= nf; i += (int64_t)gridDim.x * 256) rp[i] = (int32_t)(i * nf);
+}
+// z-slabs, BN order > 1 (round 4): t = BN H x on this rank's velocity points = the series applied to dt H x -- the spread over the
+// owned points, then (dt c nu L)^k term by term with the engine's halo exchanges, every rank in step (collective)
+static int ib_bnh_slab(pib_ns *ns, IbState *ib, const double *x, double *t)
+{
+    hipStream_t q = ns->stream;  // (ib: the state being assembled is not the engine's yet)
+    PIB_HIP(hipMemsetAsync(t, 0, sizeof(double) * (size_t)ns->D.UN, q));
+    hipLaunchKernelGGL(k_ib_spread, dim3(blocks_for(ib->hrows)), dim3(256), 0, q, ib->hrows, ns->dt, ib->hcols, ib->hptr, ib->hrow, ib->hval, x, t);
+    PIB_HIP(hipGetLastError());
+    return ns_bn_series_slab(ns, t);
+}
 static int ib_bnh_mult_add(pib_ns *ns, const double *x, double *y, hipStream_t q)
 {
     IbState *ib = ns->ib;
+    if (ns->nranks > 1 && ns->bn_order > 1) {
+        if (q != ns->stream) return fail(PIB_ERR_LIB, "immersed bodies, BN order > 1 on slabs: the BNH product runs on the engine's stream");
+        PIB_CHK(ib_bnh_slab(ns, ib, x, ib->bn_t));
+        hipLaunchKernelGGL(k_ib_axpy, dim3(blocks_for(ns->D.UN)), dim3(256), 0, q, ns->D.UN, 1.0, ib->bn_t, y);
+        PIB_HIP(hipGetLastError());
+        return 0;
+    }
     if (ib->bnh_rowptr != nullptr)
         hipLaunchKernelGGL(k_ib_csr_mult_add, dim3(blocks_for(ns->D.UN)), dim3(256), 0, q, ns->D.UN, ib->bnh_rowptr, ib->bnh_col, ib->bnh_val, x, y);
     else
@@ -586,7 +617,31 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
     if (ns->bn_order > 1) {
         // ---- BN order > 1: BNH = BN H and EBNH = E BNH through the reference's MatMatMult chain (decoupledibpm.cpp:194-205) with
         // the assembled BN of pib_ns_set_bn_order (createBnHead, bn.hip); H as a full CSR over the velocity points
-        if (ns->nranks > 1) return fail(PIB_ERR_SUP, "immersed bodies with BN order > 1 on several ranks are not provided");
+        if (ns->nranks > 1) {
+            // z-slabs (round 4): no assembled BN here -- EBNH = E (BN H) as a DENSE nf x nf matrix, column by column through the
+            // term-by-term BN of the slab engine (every rank in step; a column's entries are this rank's part of the sums over its
+            // own velocity points, the direct forces solver adds the ranks' matrices up).  nf (N - 1) stencil products and
+            // exchanges per assembly: meant for stationary bodies of moderate size (a moving body pays it every step).
+            if (ib->fsol->cfg.pc != Precond::LU)
+                return fail(PIB_ERR_SUP, "immersed bodies on several ranks need the direct forces solver (-forces_ksp_type preonly -forces_pc_type lu)");
+            if (nf * nf >= (int64_t)INT32_MAX) return fail(PIB_ERR_SUP, "immersed bodies with BN order > 1 on several ranks: %lld force unknowns are too many for the dense assembly", (long long)nf);
+            if ((err = dev_alloc(ib, &ib->c_rowptr, nf + 1)) || (err = dev_alloc(ib, &ib->c_col, nf * nf)) || (err = dev_alloc(ib, &ib->c_val, nf * nf))) return err;
+            ib->c_nnz = nf * nf;
+            hipLaunchKernelGGL(k_ib_dense_pattern, dim3(blocks_for(nf * nf)), dim3(256), 0, q, nf, ib->c_rowptr, ib->c_col);
+            PIB_HIP(hipGetLastError());
+            PIB_HIP(hipMemsetAsync(ib->e_nf, 0, sizeof(double) * (size_t)nf, q));
+            for (int64_t j = 0; j < nf; ++j) {
+                hipLaunchKernelGGL(k_ib_set1, dim3(1), dim3(1), 0, q, ib->e_nf, j, 1.0);
+                if ((err = ib_bnh_slab(ns, ib, ib->e_nf, ib->bn_t))) return err;
+                hipLaunchKernelGGL(k_ib_eu, dim3(blocks_for(nf)), dim3(256), 0, q, nf, ib->rowptr, ib->col, ib->eval, ib->bn_t, ib->col_nf);
+                hipLaunchKernelGGL(k_ib_put_column, dim3(blocks_for(nf)), dim3(256), 0, q, nf, j, ib->col_nf, ib->c_val);
+                hipLaunchKernelGGL(k_ib_set1, dim3(1), dim3(1), 0, q, ib->e_nf, j, 0.0);
+                PIB_HIP(hipGetLastError());
+            }
+            PIB_HIP(hipStreamSynchronize(q));
+            ib->fsol->reduce_via = ns->vsol;
+            return adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val);
+        }
         if (ns->bn_rowptr == nullptr) return fail(PIB_ERR_ORDER, "immersed bodies with BN order > 1: call pib_ns_set_bn_order first");
         const int64_t UN = ns->D.UN;
         int32_t *h_rp = nullptr;
@@ -638,8 +693,6 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     using namespace pib;
     if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
-    if (ns->bn_order > 1 && ns->nranks > 1)
-        return fail(PIB_ERR_SUP, "pib_ns_set_bodies: immersed bodies with BN order > 1 on several ranks are not provided (one rank: yes)");
     PIB_HIP(hipSetDevice(ns->device));
     if (ns->ib != nullptr && ns->psol != nullptr) {
         // the coupled scheme's Schur hook points into the state that goes away: back to the plain Poisson operator
@@ -688,6 +741,12 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
         return 0;
     };
     if ((err = palloc(&ib->f)) || (err = palloc(&ib->df)) || (err = palloc(&ib->rhsf)) || (err = palloc(&ib->ub))) return bail(err);
+    if (ns->nranks > 1 && ns->bn_order > 1) {  // BN term by term on the slabs (ib_bnh_slab)
+        if ((err = palloc(&ib->e_nf)) || (err = palloc(&ib->col_nf))) return bail(err);
+        PIB_HIP(hipMalloc(&ib->bn_t, sizeof(double) * (size_t)ns->D.UN));
+        PIB_MEMSET(ib->bn_t, 0, sizeof(double) * (size_t)ns->D.UN);
+        ib->persistent.push_back(ib->bn_t);
+    }
     if ((err = ib_assemble(ns, ib, coords))) return bail(err);
     ns->ib = ib;
     return 0;

@@ -1044,7 +1044,9 @@ __global__ __launch_bounds__(256) void k_ns_axpy(int64_t n, double a, const doub
 // MatScale(1), MatShift(0) -- its tables cover this rank's planes, the neighbours' planes come through the solver's own
 // halo exchange -- one exchange per extra term.  The same operator to rounding (the sums run in another order than the
 // assembled rows'): tests/test_gpu_bn.py compares 2 / 3 loopback ranks with the single rank at the solver tolerance.
-static int ns_project_bn_slab(pib_ns *ns)
+// t (extended slab; its owned points) <- sum_{k = 1 .. N} (dt c nu)^(k-1) L^(k-1) t : BN without its leading dt, term by term
+// (createBnHead's series, createbn.cpp:59-92).  Collective over the ranks; returns behind a synchronisation of both streams.
+int ns_bn_series_slab(pib_ns *ns, double *t)
 {
     pib_solver *vs = ns->vsol;
     if (!vs->vel.valid || vs->vel.slab_axis < 0)
@@ -1054,14 +1056,10 @@ static int ns_project_bn_slab(pib_ns *ns)
     const int64_t no = ns->UN_owned;
     const unsigned gb = (unsigned)std::min<int64_t>(4096, (no + 255) / 256);
     PIB_CHK(ensure_work(vs, 2));
-    if (ns->bn_tmp == nullptr) {
-        PIB_HIP(hipMalloc(&ns->bn_tmp, sizeof(double) * (size_t)D.UN));
-        ns->owned.push_back(ns->bn_tmp);
-    }
-    double *Y = vs->vec(0), *Z = vs->vec(1), *acc = ns->rhs1pk, *t = ns->bn_tmp;  // the velocity solve is over: its vectors are free
-    PIB_CHK(ns_bng_apply(ns, ns->dP, t, q));                                   // t = dt G dP on the extended slab
+    PIB_HIP(hipStreamSynchronize(vs->stream));  // (a first allocation clears the vectors on the SOLVER's stream: not behind the pack below)
+    double *Y = vs->vec(0), *Z = vs->vec(1), *acc = ns->rhs1pk;  // the velocity solve is over: its vectors are free
     PIB_CHK(ns_pack(ns, t, Y));
-    PIB_HIP(hipMemcpyAsync(acc, Y, sizeof(double) * (size_t)no, hipMemcpyDeviceToDevice, q));  // term 1: dt I
+    PIB_HIP(hipMemcpyAsync(acc, Y, sizeof(double) * (size_t)no, hipMemcpyDeviceToDevice, q));  // term 1: the identity
     const double scale0 = vs->vel.scale, shift0 = vs->vel.shift;
     const double cnu = ns->T.cimpl * ns->nu;
     int err = 0;
@@ -1082,6 +1080,20 @@ static int ns_project_bn_slab(pib_ns *ns)
     if (err) return err;
     PIB_HIP(hipMemsetAsync(t, 0, sizeof(double) * (size_t)D.UN, q));
     PIB_CHK(ns_unpack(ns, acc, t));
+    return 0;
+}
+
+static int ns_project_bn_slab(pib_ns *ns)
+{
+    const NsDev &D = ns->D;
+    hipStream_t q = ns->stream;
+    if (ns->bn_tmp == nullptr) {
+        PIB_HIP(hipMalloc(&ns->bn_tmp, sizeof(double) * (size_t)D.UN));
+        ns->owned.push_back(ns->bn_tmp);
+    }
+    double *t = ns->bn_tmp;
+    PIB_CHK(ns_bng_apply(ns, ns->dP, t, q));  // t = dt G dP on the extended slab
+    PIB_CHK(ns_bn_series_slab(ns, t));        // t = BN G dP
     hipLaunchKernelGGL(k_ns_axpy, dim3((unsigned)std::min<int64_t>(4096, (D.UN + 255) / 256)), dim3(256), 0, q, D.UN, -1.0, t, ns->U);
     hipLaunchKernelGGL(k_ns_axpy, dim3((unsigned)std::min<int64_t>(4096, (D.pN + 255) / 256)), dim3(256), 0, q, D.pN, 1.0, ns->dP, ns->p);
     PIB_HIP(hipGetLastError());

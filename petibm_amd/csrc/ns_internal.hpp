@@ -69,6 +69,8 @@ int ib_coupled_solve_and_project(pib_ns *ns);
 // out = BNG phi = dt G phi on the whole velocity vector ; w -= D t (row 0 untouched when the pressure is pinned)
 int ns_bng_apply(pib_ns *ns, const double *phi, double *out, hipStream_t q);
 int ns_div_sub(pib_ns *ns, const double *t, double *w, hipStream_t q);
+// z-slabs, BN order > 1: t (extended slab) <- sum_k (dt c nu)^(k-1) L^(k-1) t on the owned points (navierstokes.hip; collective)
+int ns_bn_series_slab(pib_ns *ns, double *t);
 // the extra stages of DecoupledIBPMSolver::advance (decoupledibpm.cpp:105-131)
 int ib_spread_forces(pib_ns *ns);   // rhs1 += H f
 // what the engine's stream has enqueued so far must be done before `sol` starts: an event the solver's stream waits for --

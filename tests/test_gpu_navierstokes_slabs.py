@@ -153,12 +153,17 @@ def _ib_case(kind):
     return cfg, [base], pose
 
 
-@pytest.mark.parametrize("kind,P", [("2d_cylinder", 2), ("2d_cylinder", 3), ("3d_sphere", 2), ("moving_cylinder", 2),
-                                    ("moving_cylinder", 3), ("moving_sphere_3d", 2), ("moving_sphere_3d", 4),
-                                    ("2d_cylinder_periodic_y", 2), ("2d_cylinder_periodic_y", 3)])
-def test_immersed_bodies_on_slabs_reproduce_the_single_rank(kind, P):
+@pytest.mark.parametrize("kind,P,bn", [("2d_cylinder", 2, 1), ("2d_cylinder", 3, 1), ("3d_sphere", 2, 1), ("moving_cylinder", 2, 1),
+                                       ("moving_cylinder", 3, 1), ("moving_sphere_3d", 2, 1), ("moving_sphere_3d", 4, 1),
+                                       ("2d_cylinder_periodic_y", 2, 1), ("2d_cylinder_periodic_y", 3, 1),
+                                       # parameters.BN > 1 WITH bodies on several ranks (round 4; decoupledibpm.cpp:194-205 builds BNH = BN H,
+                                       # EBNH = E BNH on any communicator): BN term by term through the engine's halo exchanges, EBNH dense
+                                       ("2d_cylinder", 2, 2), ("2d_cylinder", 3, 3), ("3d_sphere", 2, 2), ("moving_cylinder", 2, 2)])
+def test_immersed_bodies_on_slabs_reproduce_the_single_rank(kind, P, bn):
     from petibm_amd.navierstokes import DecoupledIBPMSolver
     cfg, bodies, pose = _ib_case(kind)
+    if bn > 1:
+        cfg["parameters"]["BN"] = bn
     dt = cfg["parameters"]["dt"]
     nsteps = 4
 
