@@ -75,6 +75,8 @@ def main():
         s.advance()
         s.getForces()
         t2 = time.perf_counter()
+        if step == 5:
+            s.enableStageTimers()  # the reference's PetscLogStage names (pib_ns_get_stage_times), HIP events on the engine's stream
         if step > 5:  # the first steps carry the start-up transient (and lazy allocations)
             tm += t1 - t0
             ta += t2 - t1
@@ -85,6 +87,9 @@ def main():
     n = a.steps - 5
     print(f"{n} steps: {1e3 * (tm + ta) / n:.1f} ms per step = {1e3 * tm / n:.1f} ms moving the body (operators + factorisation) "
           f"+ {1e3 * ta / n:.1f} ms advancing", flush=True)
+    st = s.stageTimes()
+    k = max(st.pop("steps"), 1)
+    print("stages of advance(), ms per step over", k, "steps:", "  ".join(f"{name} {ms / k:.2f}" for name, ms in st.items()), flush=True)
     s.destroy()
 
 
