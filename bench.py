@@ -281,17 +281,22 @@ def collect_traffic(n: int, mode: str):
                      f"WRITE_SIZE {kib['WRITE_SIZE']:.4g} KiB")
 
 
-def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str = "") -> dict:
+def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str = "", solver: str = "PBICGSTAB", tol: float = 1e-10) -> dict:
     """The velocity solve of the same cavity, A = I/dt - c nu L (navierstokes.cpp:342-344) with PBICGSTAB + BLOCK_JACOBI to
     an absolute residual of 1e-10 (examples/navierstokes/taylorgreenvortex3dRe1600_GPU/config/velocity_solver.info),
     single GPU.  The Krylov products run matrix-free from the mesh tables (velstencil.hip: 56 B/row -- x read once, y
     written once, the quotient tables are 1-D -- instead of the CSR's 104); the roofline entry is THAT kernel group, the
-    CSR SpMV of the same operator is reported next to it.  At 512^3 the CSR has 2.8e9 non-zeros (64-bit row offsets)."""
+    CSR SpMV of the same operator is reported next to it.  At 512^3 the CSR has 2.8e9 non-zeros (64-bit row offsets).
+    solver="CHEBYSHEV": the same system and tolerance through the Chebyshev iteration (`-velocity_ksp_type chebyshev` in PETSc's
+    terms, krylov.hip:solve_chebyshev: no inner products, Gershgorin bounds from the matrix) -- a solver-file choice, not what
+    the reference's example files say.  It tests the TRUE residual b - A x of every iterate, whose rounding floor at 256^3 is
+    ~1e-9 (eps |b_i| over 5e7 entries): its line runs to 1e-8, where BiCGStab's recurrence residual and true residual still
+    agree (at the 1e-10 of the first line they no longer do: true_abs_residual 1.3e-9)."""
     from petibm_amd import capi
     from petibm_amd.linsolver import LinSolverHIP
     dt, nu = (5e-4, 1e-3) if n == 512 else (1e-3, 1e-3)
-    cfg = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
-           "solv:convergence=ABSOLUTE\nsolv:tolerance=1e-10\nsolv:norm=L2\nsolv:store_res_history=1\n"
+    cfg = (f"config_version=2\nsolver(solv)={solver}\nsolv:max_iters=1000\nsolv:monitor_residual=1\n"
+           f"solv:convergence=ABSOLUTE\nsolv:tolerance={tol!r}\nsolv:norm=L2\nsolv:store_res_history=1\n"
            "solv:preconditioner(prec)=BLOCK_JACOBI\nprec:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n")
     s = LinSolverHIP("velocity", config_text=cfg + extra.replace("\\n", "\n") + "\n")
     w = np.full(n, 1.0 / n)
@@ -338,7 +343,7 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str 
                   if n ** 3 >= (1 << 22) and n >= 128 and "pib_fuse_velocity_product=0" not in extra and "pib_march_velocity=0" not in extra
                   else "pib::k_vel_interior4<3> / k_vel_march + k_vel_shell x 3 components (the products BiCGStab runs)")
     out = {
-        "metric": "velocity-system DOF/s (BiCGStab+Jacobi to |r| <= 1e-10)", "value": UN * steps / el,
+        "metric": f"velocity-system DOF/s ({'BiCGStab' if solver == 'PBICGSTAB' else 'Chebyshev'}+Jacobi to |r| <= {tol:g})", "value": UN * steps / el,
         "unit": "DOF/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps, "dtype": "f64",
         "config": {"workload": f"{n}^3 cavity velocity system A = I/dt - c nu L, {UN} rows, {s.nnz} nnz, "
                                f"{8 * rp_bytes}-bit row offsets, random u*"},
@@ -354,10 +359,18 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str 
     return out
 
 
+def velocity_chebyshev_pair(n: int, kernel_reps: int) -> dict:
+    """the Chebyshev line, with BiCGStab timed to the same (reachable) tolerance next to it"""
+    out = velocity_case(n, 3, 1, kernel_reps, solver="CHEBYSHEV", tol=1e-8)
+    ref = velocity_case(n, 3, 1, 2, solver="PBICGSTAB", tol=1e-8)
+    out["bicgstab_same_tolerance"] = {k: ref[k] for k in ("ms_per_step", "iters_per_solve", "true_abs_residual")}
+    return out
+
+
 def velocity_bench(args):
     import torch
     assert torch.cuda.is_available()
-    out = velocity_case(args.n, args.steps, args.warmup, args.kernel_reps, args.extra_config)
+    out = velocity_case(args.n, args.steps, args.warmup, args.kernel_reps, args.extra_config, args.velocity_solver, args.velocity_tol)
     out.update({"n_gpus": 1, "higher_is_better": True, "data": "synthetic"})
     print(json.dumps(out), flush=True)
 
@@ -526,6 +539,9 @@ def main():
                     help="N > 1: auto (default: RCCL and the peer windows are both timed on untimed solves, the faster one that meets "
                          "the residual contract runs), rccl (falls back to peer if it fails), or peer (HIP-IPC-mapped neighbours, one "
                          "node; also what lets several ranks share one GPU with PIB_BENCH_SHARE_GPU=1)")
+    ap.add_argument("--velocity-solver", default="PBICGSTAB", choices=["PBICGSTAB", "CHEBYSHEV"],
+                    help="--system velocity: the Krylov method of the solver file (the reference's examples: PBICGSTAB)")
+    ap.add_argument("--velocity-tol", type=float, default=1e-10, help="--system velocity: absolute tolerance of the solve")
     ap.add_argument("--system", default="poisson", choices=["poisson", "velocity"],
                     help="poisson (the BASELINE metric) or the velocity system A = I/dt - c nu L with BiCGStab+Jacobi")
     ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
@@ -885,6 +901,7 @@ def poisson_bench(args) -> int:
                          ("reference_solver_file_512_literal", lambda: dict(secondary_poisson(512, 5e-4, reference_solver_file(args.tol, True), "cosine", 0, args),
                                                                             cycle="V(1,1) literally (pib_sweep_pairs=0)")),
                          ("velocity_256_cubed", lambda: velocity_case(256, 2, 1, args.kernel_reps)),
+                         ("velocity_256_cubed_chebyshev", lambda: velocity_chebyshev_pair(256, args.kernel_reps)),
                          ("host_buffers_512", lambda: host_buffer_case(512, 5e-4, base_cfg))):
             try:
                 entry = fn()

@@ -46,6 +46,10 @@ def lib():
         _lib.orc_cg_single_reduction.restype = C.c_int
         _lib.orc_bcgs.argtypes = sig
         _lib.orc_bcgs.restype = C.c_int
+        _lib.orc_chebyshev.argtypes = sig + [C.c_double, C.c_double]
+        _lib.orc_chebyshev.restype = C.c_int
+        _lib.orc_gershgorin_jacobi.argtypes = [C.c_int64, _i64p, _i64p, _f64p]
+        _lib.orc_gershgorin_jacobi.restype = C.c_double
         _lib.orc_spgemm_symbolic.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, _i64p, _i64p, _i64p]
         _lib.orc_spgemm_symbolic.restype = C.c_int64
         _lib.orc_spgemm_numeric.argtypes = [C.c_int64, C.c_int64, _i64p, _i64p, _f64p, _i64p, _i64p, _f64p, _i64p,
@@ -154,6 +158,19 @@ def cg(m, b, single_reduction=False, **kw):
 def bcgs(m, b, **kw):
     """KSPBCGS restatement -- see oracle/csrc/oracle.c:orc_bcgs."""
     return _krylov(lib().orc_bcgs, m, b, **kw)
+
+
+def chebyshev(m, b, emin=None, emax=None, **kw):
+    """KSPCHEBYSHEV restatement -- see oracle/csrc/oracle.c:orc_chebyshev.  Without explicit bounds: the Gershgorin interval
+    [1 - rho, 1 + rho] of the Jacobi-preconditioned operator (orc_gershgorin_jacobi), the build's default."""
+    if emin is None or emax is None:
+        rho = gershgorin_jacobi(m)
+        emin, emax = 1.0 - rho, 1.0 + rho
+    return _krylov(lambda *a: lib().orc_chebyshev(*a, float(emin), float(emax)), m, b, **kw)
+
+
+def gershgorin_jacobi(m) -> float:
+    return float(lib().orc_gershgorin_jacobi(m.n_rows, m.rowptr, m.col, m.val))
 
 
 # ------------------------------------------------------------------ GMG oracle

@@ -438,6 +438,107 @@ done:
     return reason;
 }
 
+/*
+ * KSPSolve_Chebyshev restatement (PETSc 3.16 src/ksp/ksp/impls/cheby/cheby.c, restated from the published algorithm:
+ * PETSc is not in /root/reference, which reaches this solver through KSPSetFromOptions at
+ * src/linsolver/linsolverksp.cpp:62-66 with `-<name>_ksp_type chebyshev`: parity unpinned by the reference).
+ * [emin, emax] bound the spectrum of B A (B the preconditioner): `-ksp_chebyshev_eigenvalues emin,emax`.
+ *   scale = 2/(emax+emin); alpha = 1 - scale emin; mu = 1/alpha; omegaprod = 2/alpha; c[km1] = 1; c[k] = mu
+ *   r = b - A x (or b); [norm, test at 0]; p[km1] = x; p[k] = p[km1] + scale B r; its = 1
+ *   for i = 1 .. maxit-1: its++; r = b - A p[k]; z = B r; [norm of z (preconditioned) or r, test at i -> break]
+ *       c[kp1] = 2 mu c[k] - c[km1]; omega = omegaprod c[k] / c[kp1]
+ *       p[kp1] = (1 - omega) p[km1] + omega p[k] + omega scale z;   rotate
+ *   not converged: the residual of p[k] once more, its >= maxit -> test, else DIVERGED_ITS;  x = p[k]
+ * The iteration needs no inner products: the norms are the only reductions.
+ */
+int orc_chebyshev(i64 n, const i64 *rowptr, const i64 *col, const double *val, const double *dinv, int pc,
+                  int nullspace, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
+                  const double *b, double *x, int *its_out, double *rnorm_out, double *history, double emin, double emax)
+{
+    sys_t Sy = {n, rowptr, col, val, dinv, pc, nullspace};
+    size_t nb = (size_t)n * 8;
+    double *P[3] = {malloc(nb), malloc(nb), malloc(nb)}, *R = malloc(nb);
+    int km1 = 0, k = 1, kp1 = 2, reason = 0, i = 0, its = 0;
+    const double scale = 2.0 / (emax + emin), alpha = 1.0 - scale * emin, mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
+    double c[3], dp, ttol, rnorm0;
+    c[km1] = 1.0;
+    c[k] = mu;
+    if (!guess_nonzero) {
+        memset(x, 0, nb);
+        copy(n, b, R);
+    } else {
+        matmult(&Sy, x, R);
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) R[q] = b[q] - R[q];
+    }
+    copy(n, x, P[km1]);
+    pcapply(&Sy, R, P[k]);
+    dp = sqrt(normtype == NORM_PRECONDITIONED ? dot(n, P[k], P[k]) : dot(n, R, R));
+    rnorm0 = dp;
+    ttol = fmax(rtol * rnorm0, atol);
+    if (history) history[0] = dp;
+    if (converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) goto done;
+    if (maxit <= 0) { reason = DIVERGED_ITS; goto done; }
+#pragma omp parallel for schedule(static)
+    for (i64 q = 0; q < n; ++q) P[k][q] = P[km1][q] + scale * P[k][q];
+    its = 1;
+    for (i = 1; i < maxit; ++i) {
+        its++;
+        matmult(&Sy, P[k], R);
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) R[q] = b[q] - R[q];
+        pcapply(&Sy, R, P[kp1]);
+        dp = sqrt(normtype == NORM_PRECONDITIONED ? dot(n, P[kp1], P[kp1]) : dot(n, R, R));
+        if (history) history[i] = dp;
+        if (converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) break;
+        c[kp1] = 2.0 * mu * c[k] - c[km1];
+        {
+            const double omega = omegaprod * c[k] / c[kp1], a0 = 1.0 - omega, cz = omega * scale;
+            double *pn = P[kp1];
+            const double *pm = P[km1], *pk = P[k];
+#pragma omp parallel for schedule(static)
+            for (i64 q = 0; q < n; ++q) pn[q] = (a0 * pm[q] + omega * pk[q]) + cz * pn[q];
+        }
+        { int t = km1; km1 = k; k = kp1; kp1 = t; }
+        if (c[k] > 0x1p900) { c[k] *= 0x1p-900; c[km1] *= 0x1p-900; } /* only the ratio enters: exact rescaling (not in PETSc) */
+    }
+    if (!reason) {
+        matmult(&Sy, P[k], R);
+#pragma omp parallel for schedule(static)
+        for (i64 q = 0; q < n; ++q) R[q] = b[q] - R[q];
+        pcapply(&Sy, R, P[kp1]);
+        dp = sqrt(normtype == NORM_PRECONDITIONED ? dot(n, P[kp1], P[kp1]) : dot(n, R, R));
+        if (history) history[i] = dp;
+        if (!converged_default(dp, ttol, rnorm0, atol, dtol, &reason)) reason = DIVERGED_ITS;
+    }
+    copy(n, P[k], x);
+done:
+    *its_out = its;
+    *rnorm_out = dp;
+    if (history) history[its] = dp; /* (its counts the verifying product too: the entry getResidual(its) reads) */
+    free(P[0]); free(P[1]); free(P[2]); free(R);
+    return reason;
+}
+
+/* rho = max_i sum_{j != i} |a_ij| / |a_ii|: Gershgorin's circles put the spectrum of D^-1 A inside [1 - rho, 1 + rho] when it
+ * is real (the velocity operator I/dt - c nu L is a row scaling of a symmetric matrix: its Jacobi-preconditioned spectrum is) --
+ * what the build uses for `chebyshev` without explicit eigenvalues, where PETSc would estimate them with a few GMRES steps. */
+double orc_gershgorin_jacobi(i64 n, const i64 *rowptr, const i64 *col, const double *val)
+{
+    double rho = 0.0;
+#pragma omp parallel for reduction(max : rho) schedule(static)
+    for (i64 i = 0; i < n; ++i) {
+        double off = 0.0, d = 0.0;
+        for (i64 p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            if (col[p] == i) d += val[p];
+            else off += fabs(val[p]);
+        }
+        const double r = off / fabs(d);
+        if (r > rho) rho = r;
+    }
+    return rho;
+}
+
 /* ---------------------------------------------------------------- SpGEMM */
 /* symbolic: returns nnz of C = A*B and fills crowptr (size a_rows+1). */
 i64 orc_spgemm_symbolic(i64 a_rows, i64 b_cols, const i64 *arp, const i64 *acol, const i64 *brp, const i64 *bcol,

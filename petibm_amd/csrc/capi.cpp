@@ -94,7 +94,7 @@ int pib_config_describe(const char *name, const char *cfg_text, char *buf, int b
     if (buf == nullptr || buflen < 1) return fail(PIB_ERR_ARG_NULL, "pib_config_describe: null buffer");
     Config c;
     PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", c));
-    const char *method = c.method == Method::CG ? "cg" : (c.method == Method::BICGSTAB ? "bicgstab" : "preonly");
+    const char *method = c.method == Method::CG ? "cg" : (c.method == Method::BICGSTAB ? "bicgstab" : (c.method == Method::CHEBYSHEV ? "chebyshev" : "preonly"));
     const char *pc = c.pc == Precond::NONE ? "none" : (c.pc == Precond::JACOBI ? "jacobi" : (c.pc == Precond::LU ? "lu" : "gmg"));
     std::snprintf(buf, (size_t)buflen,
                   "flavor=%s type=\"%s\" method=%s pc=%s norm=%s max_iters=%d rtol=%.17g atol=%.17g dtol=%.17g "
@@ -161,6 +161,8 @@ int after_set_matrix(pib_solver *s)
         return fail(PIB_ERR_ARG_WRONG, "solver %s: %d rows have no (or a zero) diagonal entry: Jacobi preconditioning impossible",
                     s->name.c_str(), missing);
     // KSPReset semantics (linsolverksp.cpp:78): everything derived from the old matrix goes
+    s->gersh_lo = 0.0;
+    s->gersh_hi = -1.0;
     if (s->graph) {
         (void)hipGraphExecDestroy(s->graph);
         s->graph = nullptr;
@@ -431,6 +433,8 @@ int pib_solve(pib_solver *s, double *x, const double *b)
         err = s->cfg.cg_single_reduction ? solve_cg_sr(s, xdev, bdev) : solve_cg(s, xdev, bdev);
     else if (s->cfg.method == Method::BICGSTAB)
         err = solve_bicgstab(s, xdev, bdev);
+    else if (s->cfg.method == Method::CHEBYSHEV)
+        err = solve_chebyshev(s, xdev, bdev);
     else if (s->cfg.method == Method::PREONLY && s->cfg.pc == Precond::LU)
         err = solve_direct(s, xdev, bdev);
     else

@@ -145,12 +145,14 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
         c.method = Method::CG;
     else if (solver == "PBICGSTAB" || solver == "BICGSTAB")
         c.method = Method::BICGSTAB;
+    else if (solver == "CHEBYSHEV")
+        c.method = Method::CHEBYSHEV;
     else if (solver == "DENSE_LU_SOLVER") {
         c.method = Method::PREONLY;
         c.pc = Precond::LU;
         return 0;
     } else
-        return fail(PIB_ERR_SUP, "config: solver=%s is not supported (PCG, PBICGSTAB, DENSE_LU_SOLVER)", solver.c_str());
+        return fail(PIB_ERR_SUP, "config: solver=%s is not supported (PCG, PBICGSTAB, CHEBYSHEV, DENSE_LU_SOLVER)", solver.c_str());
     (void)top;
 
     c.max_iters = std::atoi(d.get(ss, "max_iters", "100").c_str());
@@ -171,6 +173,12 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.store_res_history = truthy(d.get(ss, "store_res_history", "0"));
     if (d.has(ss, "error_if_not_converged")) c.error_if_not_converged = truthy(d.get(ss, "error_if_not_converged", "1"));
 
+    if (c.method == Method::CHEBYSHEV && (d.has(ss, "cheby_min_lambda") || d.has(ss, "cheby_max_lambda"))) {
+        c.cheb_emin = std::atof(d.get(ss, "cheby_min_lambda", "0").c_str());
+        c.cheb_emax = std::atof(d.get(ss, "cheby_max_lambda", "0").c_str());
+        if (!(c.cheb_emin > 0.0) || !(c.cheb_emax > c.cheb_emin))
+            return fail(PIB_ERR_ARG_OUTOFRANGE, "config: solver=CHEBYSHEV needs 0 < cheby_min_lambda < cheby_max_lambda (or neither: Gershgorin bounds)");
+    }
     std::string pc = upper(d.get(ss, "preconditioner", "NOSOLVER"));
     std::string ps = d.child_scope(ss, "preconditioner");
     if (pc == "NOSOLVER" || pc == "NONE") {
@@ -235,6 +243,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.cg_single_reduction = std::atoi(d.get("default", "pib_cg_single_reduction", "0").c_str());
     c.fuse_residual_update_slabs = std::atoi(d.get("default", "pib_fuse_residual_update_slabs", "1").c_str());
     c.sweep_pairs = std::atoi(d.get("default", "pib_sweep_pairs", "1").c_str());
+    c.fuse_chebyshev_update = std::atoi(d.get("default", "pib_fuse_chebyshev_update", "1").c_str());
     c.blocked_direct_solve = std::atoi(d.get("default", "pib_blocked_direct_solve", "1").c_str());
     c.accumulate_unscaled_x = std::atoi(d.get("default", "pib_accumulate_unscaled_x", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
@@ -307,7 +316,15 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
         if (v == "cg") c.method = Method::CG;
         else if (v == "bcgs" || v == "bicg" || v == "bcgsl") c.method = Method::BICGSTAB;
         else if (v == "preonly") c.method = Method::PREONLY;
-        else return fail(PIB_ERR_SUP, "config: -%sksp_type %s is not supported (cg, bcgs, preonly)", pre.c_str(), v.c_str());
+        else if (v == "chebyshev") c.method = Method::CHEBYSHEV;
+        else return fail(PIB_ERR_SUP, "config: -%sksp_type %s is not supported (cg, bcgs, chebyshev, preonly)", pre.c_str(), v.c_str());
+    }
+    if (get("ksp_chebyshev_eigenvalues", v)) {  // emin,emax of the preconditioned operator (KSPChebyshevSetEigenvalues)
+        double lo = 0.0, hi = 0.0;
+        if (std::sscanf(v.c_str(), "%lf , %lf", &lo, &hi) != 2 || !(lo > 0.0) || !(hi > lo))
+            return fail(PIB_ERR_ARG_OUTOFRANGE, "config: -%sksp_chebyshev_eigenvalues wants emin,emax with 0 < emin < emax", pre.c_str());
+        c.cheb_emin = lo;
+        c.cheb_emax = hi;
     }
     if (get("ksp_atol", v)) c.atol = std::atof(v.c_str());
     if (get("ksp_rtol", v)) c.rtol = std::atof(v.c_str());
@@ -365,6 +382,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_cg_single_reduction", v)) c.cg_single_reduction = std::atoi(v.c_str());
     if (get("pib_fuse_residual_update_slabs", v)) c.fuse_residual_update_slabs = std::atoi(v.c_str());
     if (get("pib_sweep_pairs", v)) c.sweep_pairs = std::atoi(v.c_str());
+    if (get("pib_fuse_chebyshev_update", v)) c.fuse_chebyshev_update = std::atoi(v.c_str());
     if (get("pib_blocked_direct_solve", v)) c.blocked_direct_solve = std::atoi(v.c_str());
     if (get("pib_accumulate_unscaled_x", v)) c.accumulate_unscaled_x = std::atoi(v.c_str());
     if (get("pib_matrix_free_poisson", v)) c.matrix_free_poisson = std::atoi(v.c_str());

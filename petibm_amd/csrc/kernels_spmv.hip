@@ -29,6 +29,8 @@
 //     which the oracle reproduces -> bit-exact parity.
 #include <algorithm>
 
+#include <cstring>
+
 #include "pib_internal.hpp"
 
 namespace pib {
@@ -454,6 +456,94 @@ int extract_dinv(pib_solver *s, int *n_missing)
     PIB_HIP(hipFree(d_max));
     A.max_chunk_nnz = (int64_t)h_max;
     *n_missing = h;
+    return 0;
+}
+
+// ---------------------------------------------------------------- Gershgorin interval (the Chebyshev solver's default bounds)
+// Per row: d = a_ii, off = sum_{j != i} |a_ij|.  jacobi: the ratio off / |d| (the spectrum of D^-1 A lies in [1 - max, 1 + max]
+// when it is real); otherwise the interval [min (d - off), max (d + off)] of A itself.  Minimum and maximum go through 64-bit
+// atomics on an order-preserving key of the double (sign bit flipped for the non-negative ones, all bits for the negative).
+__host__ __device__ inline unsigned long long dkey(double v)
+{
+    unsigned long long u;
+    memcpy(&u, &v, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+inline double dkey_value(unsigned long long k)
+{
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v;
+    std::memcpy(&v, &u, 8);
+    return v;
+}
+template <typename RP>
+__global__ __launch_bounds__(256) void k_gershgorin(int64_t n, int64_t ghost_lo, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                    const double *__restrict__ val, int jacobi, unsigned long long *__restrict__ out)
+{
+    double lo = 1e300, hi = -1e300;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        double d = 0.0, off = 0.0;
+        for (RP p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+            if ((int64_t)col[p] == r + ghost_lo) d = d + val[p];
+            else off = off + fabs(val[p]);
+        }
+        if (jacobi) {
+            const double q = d != 0.0 ? off / fabs(d) : 1e300;
+            lo = fmin(lo, 1.0 - q);
+            hi = fmax(hi, 1.0 + q);
+        } else {
+            lo = fmin(lo, d - off);
+            hi = fmax(hi, d + off);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, o, 64));
+        hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], dkey(lo));
+        atomicMax(&out[1], dkey(hi));
+    }
+}
+
+int gershgorin_bounds(pib_solver *s, bool jacobi, double *lo, double *hi)
+{
+    if (s->gersh_hi >= s->gersh_lo && s->gersh_jacobi == (jacobi ? 1 : 0)) {
+        *lo = s->gersh_lo;
+        *hi = s->gersh_hi;
+        return 0;
+    }
+    DeviceCsr &A = s->A;
+    unsigned long long *d_out = nullptr, h[2] = {dkey(1e300), dkey(-1e300)};
+    PIB_HIP(hipMalloc(&d_out, 2 * sizeof(unsigned long long)));
+    PIB_HIP(hipMemcpyAsync(d_out, h, sizeof h, hipMemcpyHostToDevice, s->stream));
+    if (A.n > 0) {
+        const int nb = (int)std::min<int64_t>(4096, (A.n + 255) / 256);
+        if (A.rp64)
+            hipLaunchKernelGGL(k_gershgorin<int64_t>, dim3(nb), dim3(256), 0, s->stream, A.n, A.ghost_lo, (const int64_t *)A.rowptr, A.col, A.val,
+                               jacobi ? 1 : 0, d_out);
+        else
+            hipLaunchKernelGGL(k_gershgorin<int32_t>, dim3(nb), dim3(256), 0, s->stream, A.n, A.ghost_lo, (const int32_t *)A.rowptr, A.col, A.val,
+                               jacobi ? 1 : 0, d_out);
+    }
+    const hipError_t e = hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, s->stream);
+    const hipError_t e2 = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(PIB_ERR_LIB, "solver %s: the Gershgorin bounds' kernel failed", s->name.c_str());
+    double m0 = dkey_value(h[0]), m1 = dkey_value(h[1]);
+    // over the ranks (collective: every rank of a solver gets here in the same solve)
+    std::vector<double> mine = {m0, m1}, all;
+    PIB_CHK(comm_allgather_host(s, mine, all));
+    for (size_t q = 0; q + 1 < all.size(); q += 2) {
+        m0 = std::min(m0, all[q]);
+        m1 = std::max(m1, all[q + 1]);
+    }
+    *lo = m0;
+    *hi = m1;
+    s->gersh_lo = m0;
+    s->gersh_hi = m1;
+    s->gersh_jacobi = jacobi ? 1 : 0;
     return 0;
 }
 

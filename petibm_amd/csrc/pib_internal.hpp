@@ -92,7 +92,7 @@ inline void par_ranges(int64_t n, F f)
 
 // ------------------------------------------------------------------ config
 enum class Flavor { AMGX, KSP };
-enum class Method { CG, BICGSTAB, PREONLY };
+enum class Method { CG, BICGSTAB, PREONLY, CHEBYSHEV };
 enum class Precond { NONE, JACOBI, GMG, LU };
 enum class Smoother { JACOBI, CHEBYSHEV };
 enum class NormType { PRECONDITIONED, UNPRECONDITIONED };
@@ -118,8 +118,12 @@ struct Config {
     // V(2,2) -- two steps per pass of the LDS-tiled marches -- beats its V(1,1) by 24 % in time to solution at 512^3
     // (72.3 vs 89.8 ms, 11 vs 15 iterations: INTEGRATION.md).  0: the file's counts literally.  Chebyshev smoothing: never.
     int sweep_pairs = 1;
+    int fuse_chebyshev_update = 1;  // Method::CHEBYSHEV on the matrix-free velocity operator: the update inside the product's launch
     Smoother smoother = Smoother::JACOBI;
     double smoother_relaxation = 0.9;
+    // Method::CHEBYSHEV: bounds of the preconditioned operator's spectrum (-<name>_ksp_chebyshev_eigenvalues emin,emax;
+    // AmgX flavour: cheby_min_lambda / cheby_max_lambda of the solver's scope); both 0: the Gershgorin interval of the matrix
+    double cheb_emin = 0.0, cheb_emax = 0.0;
     int cheby_degree = 2;
     double cheby_lmax = 2.0;   // eigenvalue window [lmax/ratio, lmax] of D^-1 A (Gershgorin: <= 2 for the FV Poisson operator)
     double cheby_ratio = 4.0;
@@ -197,6 +201,10 @@ struct Scalars {
     // p-update of iteration k + 1 (xpend: one is owed; flushed after the loop)
     int xpend;
     double xalpha, xomega;
+    // Chebyshev iteration (solve_chebyshev): c[km1], c[k] of the recurrence, its constants, the coefficients of the NEXT update
+    // p[kp1] = a0 p[km1] + omega p[k] + cz z, and which of the two rotating vectors holds the current iterate
+    double c_km1, c_k, cheb_mu, cheb_omegaprod, cheb_scale, cheb_a0, cheb_cz;
+    int sol;
 };
 
 // ------------------------------------------------------------------ who sends how many doubles to whom
@@ -447,6 +455,11 @@ struct pib_solver {
     // results of the last solve
     int iters = 0, reason = 0;
     int hint_iters = 0;  // iterations of the previous solve (first enqueue batch of the next one)
+    const double *vel_epi_b = nullptr, *vel_epi_dinv = nullptr;  // vel_stencil_apply_cheb's arguments on their way into the launch
+    double *vel_epi_pm = nullptr;
+    double vel_epi_opc = 1.0;
+    double gersh_lo = 0.0, gersh_hi = -1.0;  // gershgorin_bounds' cache (hi < lo: not computed for this matrix)
+    int gersh_jacobi = -1;
     int64_t work_pad = 0;     // entries of halo memory the Krylov work vectors keep below / above their owned part (>= the CSR's ghost columns)
     int z_halo_depth = 0;     // ghost planes on which the last V-cycle's result is valid (multi-GPU)
     const double *halo_fresh = nullptr;  // vector whose halo planes were exchanged by its producer (overlap path)
@@ -505,6 +518,9 @@ int create_sharing_comm(pib_solver **out, const char *name, const char *cfg_text
 int solve_cg(pib_solver *s, double *x, const double *b);
 int solve_cg_sr(pib_solver *s, double *x, const double *b);  // KSPCGUseSingleReduction recurrences (cfg.cg_single_reduction)
 int solve_bicgstab(pib_solver *s, double *x, const double *b);
+int solve_chebyshev(pib_solver *s, double *x, const double *b);  // KSPCHEBYSHEV (oracle/csrc/oracle.c:orc_chebyshev)
+// Gershgorin interval [lo, hi] of the (Jacobi-)preconditioned matrix, the maximum over the ranks; cached per matrix
+int gershgorin_bounds(pib_solver *s, bool jacobi, double *lo, double *hi);
 int ensure_work(pib_solver *s, int nvec);
 // assemble.hip: take a copy of a CSR that already lives in HBM (single rank, 32-bit offsets) as the solver's matrix
 int adopt_device_csr(pib_solver *s, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col, const double *val);
@@ -518,6 +534,7 @@ void vel_stencil_release(pib_solver *s);
 int vel_stencil_verify(pib_solver *s);  // the matrix-free product against the CSR SpMV on a pseudo-random vector; invalidates s->vel on a mismatch
 int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv = nullptr, double opc = 1.0,
                       int dot_mode = 0, const double *dot_other = nullptr, int dot_slot0 = 0);
+int vel_stencil_apply_cheb(pib_solver *s, const double *x, double *pm, const double *b, const double *dinv, double opc, hipStream_t q, int slot0);
 constexpr int VEL_DOT_PARTIALS = 64;  // partial sums per slot the fused sums of vel_stencil_apply leave in d_part
 bool vel_stencil_fused_ok(const pib_solver *s);
 int assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], double dt, int nullspace);

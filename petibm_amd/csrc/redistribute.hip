@@ -309,7 +309,17 @@ int redist_rows_on_device(pib_solver *s, pib_solver *in, const RedistField &F, c
     const int P = s->comm.nranks, rank = s->comm.rank;
     constexpr int WMAX = 16;
     const int64_t base = rp64 ? rp64[0] : (int64_t)rp32[0], nnz_box = (rp64 ? rp64[n_local] : (int64_t)rp32[n_local]) - base;
-    if (W > WMAX || P > PIB_MAX_RANKS || n_global >= (int64_t)INT32_MAX || nnz_box >= (int64_t)INT32_MAX) return PIB_ERR_SUP;
+    // Whether this path takes the shape is decided TOGETHER: a rank that left for the host loops on its own would issue that
+    // path's exchange against the others' (sizes are per rank: boxes and slabs differ by a plane).  The slab's entries are
+    // bounded by its rows times the widest row, so nothing can turn out too large after the records have travelled.
+    {
+        const bool fits = W <= WMAX && P <= PIB_MAX_RANKS && n_global < (int64_t)INT32_MAX && nnz_box < (int64_t)INT32_MAX &&
+                          F.n_slab * W < (int64_t)INT32_MAX && s->A.val != nullptr && s->A.nnz == nnz_box;
+        std::vector<double> mine(1, fits ? 1.0 : 0.0), all;
+        PIB_CHK(comm_allgather_host(s, mine, all));
+        for (double v : all)
+            if (v == 0.0) return PIB_ERR_SUP;
+    }
     hipStream_t st = s->stream;
     SetupTrace tr("rows on device", rank);
     BoxGeom G;
@@ -342,7 +352,6 @@ int redist_rows_on_device(pib_solver *s, pib_solver *in, const RedistField &F, c
     PIB_HIP(hipMemcpyAsync(d_rp, rp64 ? (const void *)rp64 : (const void *)rp32, rpb * (size_t)(n_local + 1), hipMemcpyHostToDevice, st));
     PIB_HIP(hipMemcpyAsync(d_cl, cl64 ? (const void *)(cl64 + base) : (const void *)(cl32 + base), clb * (size_t)nnz_box, hipMemcpyHostToDevice, st));
     const double *d_val = s->A.val;  // (entry order = the caller's)
-    if (d_val == nullptr || s->A.nnz != nnz_box) return PIB_ERR_SUP;
     const unsigned nbl = (unsigned)std::min<int64_t>(8192, std::max<int64_t>(1, (n_local + 255) / 256));
 #define PIB_REC(RPT, CLT) \
     hipLaunchKernelGGL((k_box_records<RPT, CLT>), dim3(nbl), dim3(256), 0, st, G, n_local, reinterpret_cast<const RPT *>(d_rp), reinterpret_cast<const CLT *>(d_cl), d_val, (int)W, d_send)
@@ -387,7 +396,7 @@ int redist_rows_on_device(pib_solver *s, pib_solver *in, const RedistField &F, c
     PIB_HIP(hipMemcpyAsync(&nnz, d_rp64 + F.n_slab, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PIB_HIP(hipMemcpyAsync(mm, d_mm, sizeof mm, hipMemcpyDeviceToHost, st));
     PIB_HIP(hipStreamSynchronize(st));
-    if (nnz >= (int64_t)INT32_MAX) return PIB_ERR_SUP;
+    if (nnz >= (int64_t)INT32_MAX || nnz > F.n_slab * W) return fail(PIB_ERR_LIB, "set_csr: internal error (the slab's rows hold more entries than their widest row allows)");
     const int64_t cmin = (int64_t)(mm[0] - (1ULL << 62)), cmax = (int64_t)(mm[1] - (1ULL << 62));
     // ---- the slab's matrix, as upload_csr lays it out
     DeviceCsr &A = in->A;

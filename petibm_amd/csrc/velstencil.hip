@@ -32,6 +32,11 @@ struct VelDev {
     const double *dot_other;
     double *dot_part;
     int dot_stride;
+    // dot_mode 3: the Chebyshev iteration's update behind the product (krylov.hip: solve_chebyshev) -- with w = A x of a cell:
+    // r = ch_b - w ; z = ch_opc * (ch_dinv * r) (or r) ; ch_pm = (a0 ch_pm + omega x) + cz z instead of storing w; sums |r|^2, |z|^2
+    const double *ch_b, *ch_dinv;
+    double *ch_pm;
+    double ch_opc;
     // several ranks (see VelStencil): the slab axis, the ghost-pad places of the neighbours' planes, who has a neighbour
     int slab_axis;
     int64_t pad_lo[3], pad_hi[3];
@@ -113,9 +118,25 @@ __device__ __forceinline__ double vel_row(const VelDev &V, const double *__restr
     return s;
 }
 
+// the Chebyshev update of one cell (VelDev::ch_*; a0, omega, cz: the coefficients of this pass, from the device scalars)
+struct VelEpi {
+    const double *b, *dinv;
+    double *pm;
+    double opc, a0, om, cz;
+};
+__device__ __forceinline__ double vel_epilogue(const VelEpi &E, double w, double bv, double dv, double pmv, double xv, double *acc)
+{
+    const double r = bv - w;
+    const double z = E.dinv != nullptr ? E.opc * (dv * r) : r;
+    acc[0] += r * r;
+    acc[1] += z * z;
+    return (E.a0 * pmv + E.om * xv) + E.cz * z;
+}
+
 // the outermost layer of component f (all = 1: every point), dealt to `nblk` workgroups of which this is number `blk`
 __device__ __forceinline__ void vel_shell_part(const VelDev &V, int f, int all, const double *__restrict__ x, double *__restrict__ y,
-                                               int64_t blk, int64_t nblk, double *acc = nullptr)
+                                               int64_t blk, int64_t nblk, double *acc = nullptr, bool epi = false,
+                                               const VelEpi E = VelEpi())
 {
     const int64_t nx = V.n[f][0], ny = V.n[f][1], nz = V.n[f][2];
     const bool three = V.dim == 3;
@@ -149,6 +170,10 @@ __device__ __forceinline__ void vel_shell_part(const VelDev &V, int f, int all, 
         }
         const int64_t p = V.off[f] + i + nx * (j + ny * k);
         const double v = vel_row(V, x, f, i, j, k);
+        if (epi) {
+            E.pm[p] = vel_epilogue(E, v, E.b[p], E.dinv != nullptr ? E.dinv[p] : 1.0, E.pm[p], x[p], acc);
+            continue;
+        }
         y[p] = v;
         if (acc != nullptr) {
             if (V.dot_mode == 1) acc[0] += v * V.dot_other[p];
@@ -363,9 +388,10 @@ __device__ __forceinline__ int vcol(int t)
 // boundaries -- the same sums with the missing neighbour left out and its ghost fold on the diagonal, in vel_row's order: the
 // bits the shell computes -- so that the shell workgroups only own the first and the last plane.  (The x faces of a shell are
 // one strided point per lane: 40 of the product's 240 us at 256^3.)
-template <bool V4, bool EDGES = false>
+template <bool V4, bool EDGES = false, bool EPI = false>
 __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const double *__restrict__ x, double *__restrict__ y, int MZ,
-                                               int bx, int by, int bz, double (&sp)[2][VSY][VSX], double *acc = nullptr)
+                                               int bx, int by, int bz, double (&sp)[2][VSY][VSX], double *acc = nullptr,
+                                               const VelEpi E = VelEpi())
 {
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int nx = (int)V.n[f][0], ny = (int)V.n[f][1], nz = (int)V.n[f][2];
@@ -445,6 +471,26 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         }
     };
     double pc[4] = {0.0, 0.0, 0.0, 0.0}, pn[4] = {0.0, 0.0, 0.0, 0.0};
+    // EPI: b, 1 / a_ii and the vector the update overwrites, for the thread's cells of a plane -- fetched a plane ahead like the
+    // sums' second factor
+    double eb[4] = {0.0, 0.0, 0.0, 0.0}, ed[4] = {1.0, 1.0, 1.0, 1.0}, em[4] = {0.0, 0.0, 0.0, 0.0};
+    double nb4[4] = {0.0, 0.0, 0.0, 0.0}, nd4[4] = {1.0, 1.0, 1.0, 1.0}, nm4[4] = {0.0, 0.0, 0.0, 0.0};
+    auto loade1 = [&](const double *v, int kp, double (&o)[4]) {
+        const double *pl = v + (int64_t)kp * sz;
+        if (V4) {
+            const v4 t = *reinterpret_cast<const v4 *>(pl + row + ci[0]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = t[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = pl[row + ci[c]];
+        }
+    };
+    auto loade = [&](int kp, double (&ob)[4], double (&od)[4], double (&om)[4]) {
+        loade1(E.b, kp, ob);
+        if (E.dinv != nullptr) loade1(E.dinv, kp, od);
+        loade1(E.pm, kp, om);
+    };
     // Every load of a step is consumed in the NEXT step: the plane two ahead (it becomes the upper neighbour), the halo cells
     // and the fused sums' second factor of the plane one ahead.  Nothing a step issues is waited for in that step, so the
     // loads stay in flight across the barrier (a load consumed in the step that issues it drains the in-order memory counter
@@ -465,13 +511,15 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
     load4(x + (int64_t)k0 * sz, k0, xc);
     load_halo(k0, hyc, hxc);
     load4(x + (int64_t)(k0 + 1) * sz, k0 + 1, zp);
-    if (acc != nullptr) loadp(k0, pc);
+    if (!EPI && acc != nullptr) loadp(k0, pc);
+    if (EPI) loade(k0, eb, ed, em);
     for (int k = k0; k < kend; ++k) {
         const int slot = k & 1;
         if (k + 1 < kend) {
             load4(x + (int64_t)(k + 2) * sz, k + 2, zn);
             load_halo(k + 1, hyn, hxn);
-            if (acc != nullptr) loadp(k + 1, pn);
+            if (!EPI && acc != nullptr) loadp(k + 1, pn);
+            if (EPI) loade(k + 1, nb4, nd4, nm4);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) sp[slot][ty + 1][lx[c]] = xc[c];
@@ -517,7 +565,13 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
 #pragma unroll
             for (int c = 0; c < 4; ++c) cin[c] = cok[c];
         }
-        if ((EDGES ? jok : jin) && acc != nullptr) {  // the stored rows only (the shell owns the others)
+        if (EPI) {  // the update of the stored cells takes the product's place
+            if (EDGES ? jok : jin) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (cin[c]) out[c] = vel_epilogue(E, out[c], eb[c], ed[c], em[c], xc[c], acc);
+            }
+        } else if ((EDGES ? jok : jin) && acc != nullptr) {  // the stored rows only (the shell owns the others)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (cin[c]) {
@@ -526,7 +580,7 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
                 }
         }
         if (EDGES ? jok : jin) {
-            double *py = y + (int64_t)k * sz + row;
+            double *py = (EPI ? E.pm : y) + (int64_t)k * sz + row;
             if (V4 && cin[0] && cin[3]) {
                 v4 t;
 #pragma unroll
@@ -544,6 +598,11 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
             xc[c] = zp[c];
             zp[c] = zn[c];
             pc[c] = pn[c];
+            if (EPI) {
+                eb[c] = nb4[c];
+                ed[c] = nd4[c];
+                em[c] = nm4[c];
+            }
         }
         hyc = hyn;
         hxc = hxn;
@@ -569,7 +628,7 @@ struct VelPlan {
     int gx[3], gy[3];   // tiles per plane of a component
     int v4[3];
 };
-template <int DOT>  // DOT = 1: with the fused Krylov sums (V.dot_mode); a separate instantiation keeps the plain product's registers
+template <int DOT>  // DOT = 1: with the fused Krylov sums (V.dot_mode), 2: with the Chebyshev update (dot_mode 3); separate instantiations keep the plain product's registers
 __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__ S, VelDev V, VelPlan P, const double *__restrict__ x,
                                                      double *__restrict__ y, int MZ)
 {
@@ -579,9 +638,15 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
     int tile_slot = b;
     double acc[2] = {0.0, 0.0};
     double *pa = DOT ? acc : nullptr;
+    VelEpi epi = {V.ch_b, V.ch_dinv, V.ch_pm, V.ch_opc, 0.0, 0.0, 0.0};
+    if (DOT == 2) {  // (S is never null here: the coefficients of the pass live in the device scalars)
+        epi.a0 = S->cheb_a0;
+        epi.om = S->omega;
+        epi.cz = S->cheb_cz;
+    }
     if (b < P.first[3]) {
         const int f = (b >= P.first[1]) + (b >= P.first[2]);
-        vel_shell_part(V, f, P.edges ? 2 : 0, x, y, b - P.first[f], P.first[f + 1] - P.first[f], pa);
+        vel_shell_part(V, f, P.edges ? 2 : 0, x, y, b - P.first[f], P.first[f + 1] - P.first[f], pa, DOT == 2, epi);
     } else {
         const int f = (b >= P.first[4]) + (b >= P.first[5]);
         const int lb = b - P.first[3 + f];
@@ -600,11 +665,11 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
 #endif
         tile_slot = P.first[3 + f] + bx + P.gx[f] * (by + P.gy[f] * bz);  // the sums stay with the tile: same order as ever
         if (P.edges) {
-            if (P.v4[f]) vel_march_tile<true, true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
-            else vel_march_tile<false, true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
+            if (P.v4[f]) vel_march_tile<true, true, DOT == 2>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
+            else vel_march_tile<false, true, DOT == 2>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
         } else {
-            if (P.v4[f]) vel_march_tile<true>(V, f, x, y, MZ, bx, by, bz, sp, pa);
-            else vel_march_tile<false>(V, f, x, y, MZ, bx, by, bz, sp, pa);
+            if (P.v4[f]) vel_march_tile<true, false, DOT == 2>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
+            else vel_march_tile<false, false, DOT == 2>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
         }
     }
     if (DOT) {  // one partial per workgroup and sum, fixed order
@@ -618,7 +683,7 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
             if (lane == 0) sh[k2][w] = v;
         }
         __syncthreads();
-        if (threadIdx.x < 2 && (threadIdx.x == 0 || V.dot_mode == 2))
+        if (threadIdx.x < 2 && (threadIdx.x == 0 || V.dot_mode >= 2))
             V.dot_part[(int64_t)threadIdx.x * V.dot_stride + tile_slot] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
     }
 }
@@ -732,11 +797,34 @@ bool vel_stencil_fused_ok(const pib_solver *s)
     return true;
 }
 
+// One pass of the Chebyshev iteration in one launch: with w = A x, pm <- (a0 pm + omega x) + cz M^-1 (b - w) and the partial
+// sums of |b - w|^2, |M^-1 (b - w)|^2 in d_part[slot0], [slot0 + 1] (VEL_DOT_PARTIALS each); a0, omega, cz from the device scalars.
+int vel_stencil_apply_cheb(pib_solver *s, const double *x, double *pm, const double *b, const double *dinv, double opc, hipStream_t q, int slot0)
+{
+    if (!vel_stencil_fused_ok(s)) return fail(PIB_ERR_ORDER, "velocity product with the Chebyshev update folded in: the one-launch form does not serve this operator");
+    s->vel_epi_b = b;
+    s->vel_epi_dinv = dinv;
+    s->vel_epi_pm = pm;
+    s->vel_epi_opc = opc;
+    const int err = vel_stencil_apply(s, x, pm, true, q, nullptr, 1.0, 3, nullptr, slot0);
+    s->vel_epi_pm = nullptr;
+    return err;
+}
+
 int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, hipStream_t q, const double *dinv, double opc,
                       int dot_mode, const double *dot_other, int dot_slot0)
 {
     const VelStencil &h = s->vel;
     VelDev V = vel_dev(h);
+    V.ch_b = V.ch_dinv = nullptr;
+    V.ch_pm = nullptr;
+    V.ch_opc = 1.0;
+    if (dot_mode == 3) {
+        V.ch_b = s->vel_epi_b;
+        V.ch_dinv = s->vel_epi_dinv;
+        V.ch_pm = s->vel_epi_pm;
+        V.ch_opc = s->vel_epi_opc;
+    }
     if (dinv != nullptr || dot_mode != 0) {
         if (!vel_stencil_fused_ok(s)) return fail(PIB_ERR_ORDER, "velocity product with the Jacobi sweep / the Krylov sums folded in: the one-launch form does not serve this operator");
         V.dinv = dinv;
@@ -767,6 +855,7 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
             P.gx[f] = (int)((nx + VX - 1) / VX);
             P.gy[f] = (int)((ny + VY - 1) / VY);
             P.v4[f] = (nx % VX == 0 && h.off[f] % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31u) == 0) ? 1 : 0;
+            if (dot_mode == 3 && ((reinterpret_cast<uintptr_t>(V.ch_b) | reinterpret_cast<uintptr_t>(V.ch_dinv)) & 31u) != 0) P.v4[f] = 0;
             nb += P.gx[f] * P.gy[f] * (int)((nz - 2 + MZ - 1) / MZ);
         }
         P.first[6] = nb;
@@ -780,10 +869,11 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
             V.dot_part = s->d_vel_part;
             V.dot_stride = s->vel_part_cap;
         }
-        if (dot_mode != 0) hipLaunchKernelGGL(k_vel_product<1>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
+        if (dot_mode == 3) hipLaunchKernelGGL(k_vel_product<2>, dim3((unsigned)nb), dim3(256), 0, q, s->d_s, V, P, x, y, MZ);
+        else if (dot_mode != 0) hipLaunchKernelGGL(k_vel_product<1>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
         else hipLaunchKernelGGL(k_vel_product<0>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
         if (dot_mode != 0)
-            hipLaunchKernelGGL(k_vel_reduce, dim3(VEL_STAGE, dot_mode == 2 ? 2 : 1), dim3(256), 0, q, S, s->d_vel_part, s->vel_part_cap, nb,
+            hipLaunchKernelGGL(k_vel_reduce, dim3(VEL_STAGE, dot_mode >= 2 ? 2 : 1), dim3(256), 0, q, S, s->d_vel_part, s->vel_part_cap, nb,
                                s->d_part, dot_slot0);
         PIB_HIP(hipGetLastError());
         s->counters[0]++;

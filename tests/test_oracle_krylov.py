@@ -167,3 +167,52 @@ def test_single_reduction_cg_is_the_same_iteration(systems):
         assert r1["reason"] > 0 and r1["iters"] == r0["iters"]
         assert np.abs(r1["history"] - r0["history"]).max() <= 1e-8 * r0["history"][0]
         assert np.linalg.norm(r1["x"] - r0["x"]) <= 1e-9 * np.linalg.norm(r0["x"])
+
+
+def test_chebyshev_restatement_against_scipy_and_numpy(systems):
+    """orc_chebyshev (KSPSolve_Chebyshev restated: PETSc is not in /root/reference -- parity unpinned by the reference) on
+    the velocity operator: the solution is scipy's, the residual history is that of the textbook three-term recurrence
+    written with numpy, the Gershgorin bounds contain the spectrum, and the iteration count is KSP's (the verifying product
+    counts: its = steps + 1 on convergence, = max_it when the limit ends the loop)."""
+    spla = pytest.importorskip("scipy.sparse.linalg")
+    sp = pytest.importorskip("scipy.sparse")
+    m, _, Av = systems
+    rng = np.random.default_rng(5)
+    us = rng.uniform(-1, 1, Av.n_rows)
+    b = clib.spmv(Av, us)
+    S = sp.csr_matrix((Av.val, Av.col, Av.rowptr), shape=(Av.n_rows, Av.n_cols))
+    rho = clib.gershgorin_jacobi(Av)
+    d = S.diagonal()
+    ev = np.linalg.eigvals((sp.diags(1.0 / d) @ S).toarray())
+    assert 0.0 < rho < 1.0 and np.abs(ev.imag).max() < 1e-9 and ev.real.min() >= 1.0 - rho - 1e-12 and ev.real.max() <= 1.0 + rho + 1e-12
+    for norm in ("preconditioned", "unpreconditioned"):
+        r = clib.chebyshev(Av, b, pc="jacobi", norm=norm, rtol=1e-12, atol=0.0, maxit=500)
+        assert r["reason"] == 2 and np.linalg.norm(r["x"] - spla.spsolve(S.tocsc(), b)) <= 1e-10 * np.linalg.norm(us)
+        # the recurrence with numpy
+        emin, emax = 1.0 - rho, 1.0 + rho
+        scale = 2.0 / (emax + emin)
+        alpha = 1.0 - scale * emin
+        mu, omegaprod = 1.0 / alpha, 2.0 / alpha
+        c = [1.0, mu]
+        pm = np.zeros_like(b)
+        z = b / d
+        hist = [np.linalg.norm(z if norm == "preconditioned" else b)]
+        pk = pm + scale * z
+        for i in range(1, r["iters"]):
+            res = b - S @ pk
+            z = res / d
+            hist.append(np.linalg.norm(z if norm == "preconditioned" else res))
+            if i == r["iters"] - 1:
+                break
+            cn = 2.0 * mu * c[1] - c[0]
+            om = omegaprod * c[1] / cn
+            pm, pk = pk, (1.0 - om) * pm + om * pk + om * scale * z
+            c = [c[1], cn]
+        assert np.allclose(r["history"][: len(hist)], hist, rtol=1e-8, atol=1e-14 * hist[0])  # (the last entries sit at rounding level)
+        assert r["history"][-1] == r["history"][-2] == r["rnorm"] and hist[-1] <= 1e-12 * hist[0] < hist[-2]
+    lim = clib.chebyshev(Av, b, pc="jacobi", rtol=1e-12, atol=0.0, maxit=4)
+    assert lim["reason"] == -3 and lim["iters"] == 4 and len(lim["history"]) == 5
+    # no preconditioner, explicit bounds (-ksp_chebyshev_eigenvalues)
+    evA = np.linalg.eigvals(S.toarray()).real
+    r = clib.chebyshev(Av, b, emin=0.98 * evA.min(), emax=1.02 * evA.max(), pc="none", rtol=1e-12, atol=0.0, maxit=500)
+    assert r["reason"] == 2 and np.linalg.norm(r["x"] - us) <= 1e-10 * np.linalg.norm(us)

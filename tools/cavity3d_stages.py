@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("n", type=int, nargs="?", default=256)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--chebyshev", action="store_true", help="velocity_solver.info with solver=CHEBYSHEV instead of PBICGSTAB (krylov.hip: solve_chebyshev)")
     a = ap.parse_args()
     n = a.n
     cfg = cases.cavity((n, n, n), lid=1.0)
@@ -27,6 +28,9 @@ def main():
     cfg["parameters"] = {"dt": 0.001, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
     d = os.path.join(ROOT, "examples", "cases", "flatplate3dRe100AoA30", "config")  # the reference's 3-D GPU solver files
     vel, poi = (open(os.path.join(d, k + "_solver.info")).read() for k in ("velocity", "poisson"))
+    if a.chebyshev:
+        vel = vel.replace("solver(solv)=PBICGSTAB", "solver(solv)=CHEBYSHEV")
+        print("velocity solver: CHEBYSHEV", flush=True)
     t0 = time.perf_counter()
     s = NavierStokesSolver(cfg, velocity_cfg=vel, poisson_cfg=poi)
     print(f"{n}^3 cavity: {s.pN} cells, {s.UN} velocity unknowns; set-up {time.perf_counter() - t0:.1f} s", flush=True)

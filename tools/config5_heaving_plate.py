@@ -36,6 +36,7 @@ def axis(name, half, cells_core, cells_out, ratio):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--chebyshev", action="store_true", help="velocity_solver.info with solver=CHEBYSHEV instead of PBICGSTAB (krylov.hip: solve_chebyshev)")
     a = ap.parse_args()
     cfg = cases.cavity((384, 256, 256), lid=0.0)
     cfg["mesh"] = [axis("x", 1.5, 192, 96, 1.04), axis("y", 1.0, 128, 64, 1.04), axis("z", 1.0, 128, 64, 1.04)]
@@ -48,6 +49,9 @@ def main():
     cfg["parameters"] = {"dt": 0.004, "convection": "ADAMS_BASHFORTH_2", "diffusion": "CRANK_NICOLSON"}
     d = os.path.join(ROOT, "examples", "cases", "flatplate3dRe100AoA30", "config")
     text = {k: open(os.path.join(d, k + "_solver.info")).read() for k in ("velocity", "poisson", "forces")}
+    if a.chebyshev:
+        text["velocity"] = text["velocity"].replace("solver(solv)=PBICGSTAB", "solver(solv)=CHEBYSHEV")
+        print("velocity solver: CHEBYSHEV", flush=True)
     h = 3.0 / 192  # the uniform block's cell: 0.75 x 0.375 plate of 48 x 24 = 1152 points
     xs, zs = np.meshgrid(-0.375 + h * np.arange(48), -0.19 + h * np.arange(24), indexing="ij")
     plate = np.stack([xs.ravel(), np.zeros(xs.size), zs.ravel()], axis=1)
