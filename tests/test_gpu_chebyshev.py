@@ -220,3 +220,51 @@ def test_chebyshev_on_slabs(P):
             x[own[r]] = res[r][0]
             assert res[r][1] == its1 and np.allclose(res[r][2], h1, rtol=1e-10)
         assert np.array_equal(x, x1)
+
+
+CHEB_VEL = ("config_version=2\nsolver(solv)=CHEBYSHEV\nsolv:max_iters=1000\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
+            "solv:tolerance=1e-11\nsolv:norm=L2\nsolv:store_res_history=1\nsolv:preconditioner(prec)=BLOCK_JACOBI\n"
+            "prec:relaxation_factor=0.9\n")
+
+
+@pytest.mark.parametrize("case,P", [("3d_cavity", 1), ("3d_convective_outlet", 1), ("2d_cavity", 1), ("3d_periodic_box", 1),
+                                    ("3d_cavity", 2), ("3d_convective_outlet", 3), ("3d_periodic_box", 2), ("2d_periodic_y", 2)])
+def test_time_step_with_the_chebyshev_velocity_file(case, P):
+    """NavierStokesSolver::advance with `solver=CHEBYSHEV` in velocity_solver.info: three steps land where the BiCGStab file's
+    do (both solves to their tolerances), on one rank and on loopback slabs (one exchange + one all-reduce per pass)."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    from test_gpu_navierstokes import AMGX_P, KSP_P, VEL
+    from test_gpu_navierstokes_slabs import CASES
+    from test_gpu_multirank_loopback import _run_ranks
+    make, pinned = CASES[case]
+    cfg = make()
+    pcfg = AMGX_P if pinned else KSP_P
+    one = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=pcfg)
+    rng = np.random.default_rng(11)
+    U0 = 0.1 * rng.uniform(-1, 1, one.UN)
+    p0 = 0.1 * rng.uniform(-1, 1, one.pN)
+    if "convective" in case:
+        U0[: int(np.prod(one._field_shape(0)))] += 1.0
+    one.setState(U0, p0)
+    one.advance(3)
+    U3, p3 = one.getState()
+    its_b = one.linSolversInfo()[1]
+    one.destroy()
+
+    def rank_fn(r, uid):
+        kw = dict(device=0, rank=r, nranks=P, uid=uid) if P > 1 else {}
+        s = NavierStokesSolver(cfg, velocity_cfg=CHEB_VEL, poisson_cfg=pcfg, **kw)
+        s.setState(s.ownedVelocity(U0) if P > 1 else U0, s.ownedPressure(p0) if P > 1 else p0)
+        s.advance(3)
+        U, p = s.getState()
+        cut = (s.ownedVelocity(U3), s.ownedPressure(p3)) if P > 1 else (U3, p3)
+        its = s.linSolversInfo()[1]
+        s.destroy()
+        return U, p, cut, its
+
+    res = _run_ranks(P, rank_fn) if P > 1 else [rank_fn(0, None)]
+    for U, p, (cU, cp), its in res:
+        assert 2 <= its < 60 and its_b >= 1
+        assert np.allclose(U, cU, rtol=0, atol=1e-9)
+    pg, pr = np.concatenate([r[1] for r in res]), np.concatenate([r[2][1] for r in res])
+    assert np.allclose(pg - pg.mean(), pr - pr.mean(), rtol=0, atol=1e-7)
