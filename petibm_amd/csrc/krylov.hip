@@ -633,6 +633,10 @@ int ensure_work(pib_solver *s, int nvec)
     if (s->work_base) PIB_HIP(hipFree(s->work_base));
     s->work_base = nullptr;
     s->work = nullptr;
+    if (s->graph) {  // a captured iteration body holds the old vectors' addresses
+        (void)hipGraphExecDestroy(s->graph);
+        s->graph = nullptr;
+    }
     PIB_HIP(hipMalloc(&s->work_base, (size_t)(stride * nvec + 4) * sizeof(double)));
     PIB_HIP(hipMemsetAsync(s->work_base, 0, (size_t)(stride * nvec + 4) * sizeof(double), s->stream));
     s->work = s->work_base;  // hipMalloc is 256-byte aligned; lo and stride are multiples of 4 doubles
