@@ -79,10 +79,16 @@ static void shift_vec(i64 n, double *a, double m);
 /* Fused multiply-adds, spelled out (round 4): the library and this file are built -ffp-contract=off, so these four helpers are
  * the only places where a product is not rounded before it is added -- fma() of <math.h> here (vfmadd under
  * -march=x86-64-v3; the C library's correctly rounded software fma on a host without FMA3: the same bits), v_fma_f64 in
- * petibm_amd/csrc/gmg.hip, the same calls in the same order: facc one face of the scaled row sum, jstep the damped-Jacobi
- * update, resid the residual's last factor, tacc one term of an interpolation / restriction sum. */
+ * petibm_amd/csrc/gmg.hip, the same calls in the same order: facc one face of the scaled row sum, resid the
+ * residual's last factor, tacc one term of an interpolation / restriction sum (and nacc / jrelax below). */
 static inline double facc(double s, double c, double nb, double xc) { return fma(c, nb - xc, s); }
-static inline double jstep(double x, double omega, double q) { return fma(omega, q, x); }
+/* The damped-Jacobi step in its weighted-average form (gmg.hip, "weighted-average form"): with sum_faces c = -d,
+ *     x + omega (bs - sum c (x_nb - x)) / d  =  (1 - omega) x + (omega / d) (bs - sum c x_nb);
+ * jweight: wr = omega / d; nacc: one face, t - c x_nb, starting from t = bs in the order -x +x -y +y -z +z;
+ * jrelax: fma(wr, t, (1 - omega) x); a step from a zero guess is wr * bs.  The same calls in the same order as the kernels. */
+static inline double jweight(double omega, double d) { return omega / d; }
+static inline double nacc(double t, double c, double nb) { return fma(-c, nb, t); }
+static inline double jrelax(double x, double omc, double wr, double t) { return fma(wr, t, omc * x); }
 static inline double resid(double b, double t, double w) { return fma(-t, w, b); }
 static inline double tacc(double s, double w, double v) { return fma(w, v, s); }
 
@@ -127,6 +133,29 @@ static inline double apply_cell(const level_t *l, const double *x, i64 i, i64 j,
     else if (l->per[2]) s = facc(s, c[5], x[p - (l->n[2] - 1) * sz], xc);
     *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
     return s;
+}
+
+/* bs - sum_faces c x_nb at one cell (what jrelax takes), and the scaled diagonal */
+static inline double relax_cell(const level_t *l, const double *x, i64 i, i64 j, i64 k, double bs, double *diag)
+{
+    double c[6];
+    face_coefs(l, i, j, k, c);
+    const i64 p = idx(l, i, j, k), sx = 1, sy = l->n[0], sz = l->n[0] * l->n[1];
+    double t = bs;
+    if (i > 0) t = nacc(t, c[0], x[p - sx]);
+    else if (l->per[0]) t = nacc(t, c[0], x[p + (l->n[0] - 1) * sx]);
+    if (i < l->n[0] - 1) t = nacc(t, c[1], x[p + sx]);
+    else if (l->per[0]) t = nacc(t, c[1], x[p - (l->n[0] - 1) * sx]);
+    if (j > 0) t = nacc(t, c[2], x[p - sy]);
+    else if (l->per[1]) t = nacc(t, c[2], x[p + (l->n[1] - 1) * sy]);
+    if (j < l->n[1] - 1) t = nacc(t, c[3], x[p + sy]);
+    else if (l->per[1]) t = nacc(t, c[3], x[p - (l->n[1] - 1) * sy]);
+    if (k > 0) t = nacc(t, c[4], x[p - sz]);
+    else if (l->per[2]) t = nacc(t, c[4], x[p + (l->n[2] - 1) * sz]);
+    if (k < l->n[2] - 1) t = nacc(t, c[5], x[p + sz]);
+    else if (l->per[2]) t = nacc(t, c[5], x[p - (l->n[2] - 1) * sz]);
+    *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
+    return t;
 }
 
 static void lvl_free(level_t *l)
@@ -299,9 +328,10 @@ void orc_gmg_apply_operator(void *h, int lev, const double *x, double *y)
             }
 }
 
-/* xo = xi + omega * (b - A xi) / diag ; zero_guess: xo = omega * b / diag */
+/* xo = (1 - omega) xi + (omega / diag) (b - sum c x_nb) ; zero_guess: xo = (omega / diag) b */
 static void smooth(const level_t *l, double omega, const double *b, const double *xi, double *xo, int zero_guess)
 {
+    const double omc = 1.0 - omega;
 #pragma omp parallel for schedule(static)
     for (i64 k = 0; k < l->n[2]; ++k)
         for (i64 j = 0; j < l->n[1]; ++j)
@@ -312,10 +342,10 @@ static void smooth(const level_t *l, double omega, const double *b, const double
                     double c[6];
                     face_coefs(l, i, j, k, c);
                     d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-                    xo[p] = omega * (scale_b(l, i, j, k, b[p]) / d);
+                    xo[p] = jweight(omega, d) * scale_b(l, i, j, k, b[p]);
                 } else {
-                    const double ax = apply_cell(l, xi, i, j, k, &d);
-                    xo[p] = jstep(xi[p], omega, (scale_b(l, i, j, k, b[p]) - ax) / d);
+                    const double t = relax_cell(l, xi, i, j, k, scale_b(l, i, j, k, b[p]), &d);
+                    xo[p] = jrelax(xi[p], omc, jweight(omega, d), t);
                 }
             }
 }

@@ -77,13 +77,34 @@ struct LevelDev {
 // (vfmadd under -march=x86-64-v3) in oracle/csrc/gmg.c, the same call in the same order on both sides, so the bits still
 // agree -- and a face term costs two fp64 instructions instead of three (the marching kernels are bound by VALU issue):
 //     facc : s + c (x_nb - x_c)        one face of the scaled row sum
-//     jstep: x + omega q               the damped-Jacobi update, q = (bs - t) / d
 //     resid: b - t w                   the residual's last factor (t = row sum times two widths, w the third)
 __device__ __forceinline__ double facc(double s, double c, double nb, double xc) { return fma(c, nb - xc, s); }
-__device__ __forceinline__ double jstep(double x, double omega, double q) { return fma(omega, q, x); }
 __device__ __forceinline__ double resid(double b, double t, double w) { return fma(-t, w, b); }
 //     tacc : s + w v                   one term of an interpolation / restriction sum (w = the product of the 1-D weights)
 __device__ __forceinline__ double tacc(double s, double w, double v) { return fma(w, v, s); }
+// The damped-Jacobi step in its weighted-average form (round 4, second half).  With sum_faces c = -d,
+//     x + omega (bs - sum c (x_nb - x)) / d  =  (1 - omega) x + (omega / d) (bs - sum c x_nb)
+// -- the same step in exact arithmetic; in this form a face costs ONE fp64 instruction (six instead of twelve per cell), and
+// the only division, wr = omega / d, depends on the cell column's in-plane coefficients and on the PLANE's two z coefficients:
+// the marching kernels keep wr of their cells in registers and divide again only when a plane's (czm, czp) differ from the
+// previous plane's (a workgroup-uniform comparison; on a mesh with uniform spacing along z: at the two walls only).  The step
+// cost 33 fp64 instructions per cell in the difference form (10 of them the division), 11 here.  Every kernel below and
+// oracle/csrc/gmg.c use these three calls in this order:
+//     jweight: wr = omega / d                       (d = -(((((cxm + cxp) + cym) + cyp) + czm) + czp), one IEEE division)
+//     nacc   : t - c x_nb                           one face, starting from t = bs, in the order -x +x -y +y -z +z
+//     jrelax : (1 - omega) x + wr t                 as fma(wr, t, omc * x), omc = 1.0 - omega
+// and a step from a zero guess is wr * bs (what jrelax gives for x = 0 and zero neighbours).  The residual and the operator
+// itself keep the difference form (facc): they need d x_c, and cancellation there would cost them digits.
+__device__ __forceinline__ double jweight(double omega, double d) { return omega / d; }
+// a workgroup-uniform double the compiler loaded through the vector path (a table entry of the plane a march is on, read inside
+// a loop that also stores: no scalar load) moved to scalar registers
+__device__ __forceinline__ double uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double nacc(double t, double c, double nb) { return fma(-c, nb, t); }
+__device__ __forceinline__ double jrelax(double x, double omc, double wr, double t) { return fma(wr, t, omc * x); }
 __device__ __forceinline__ void face_coefs(const LevelDev &L, int i, int j, int k, double c[6])
 {
     c[0] = L.cmx[i];
@@ -121,6 +142,31 @@ __device__ __forceinline__ double apply_cell(const LevelDev &L, const double *__
     else if (pz) s = facc(s, c[5], x[L.zring ? p + sz : p - (L.nzg - 1) * sz], xc);
     *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
     return s;
+}
+
+// bs - sum_faces c x_nb at local cell p (what jrelax takes), and the scaled diagonal: apply_cell's walk in the weighted-average form
+__device__ __forceinline__ double relax_cell(const LevelDev &L, const double *__restrict__ x, int64_t p, int i, int j, int k, double bs,
+                                             double *diag)
+{
+    double c[6];
+    face_coefs(L, i, j, k, c);
+    const int64_t sy = L.nx, sz = (int64_t)L.nx * L.ny;
+    double t = bs;
+    const bool px = L.per & 1, py = L.per & 2, pz = L.per & 4;
+    if (i > 0) t = nacc(t, c[0], x[p - 1]);
+    else if (px) t = nacc(t, c[0], x[p + (L.nx - 1)]);
+    if (i < L.nx - 1) t = nacc(t, c[1], x[p + 1]);
+    else if (px) t = nacc(t, c[1], x[p - (L.nx - 1)]);
+    if (j > 0) t = nacc(t, c[2], x[p - sy]);
+    else if (py) t = nacc(t, c[2], x[p + (L.ny - 1) * sy]);
+    if (j < L.ny - 1) t = nacc(t, c[3], x[p + sy]);
+    else if (py) t = nacc(t, c[3], x[p - (L.ny - 1) * sy]);
+    if (k > 0) t = nacc(t, c[4], x[p - sz]);
+    else if (pz) t = nacc(t, c[4], x[L.zring ? p - sz : p + (L.nzg - 1) * sz]);
+    if (k < L.nzg - 1) t = nacc(t, c[5], x[p + sz]);
+    else if (pz) t = nacc(t, c[5], x[L.zring ? p + sz : p - (L.nzg - 1) * sz]);
+    *diag = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
+    return t;
 }
 
 // Launch geometry of every level kernel: grid (ceil(plane/256) capped, nk); blockIdx.y is the local plane, so
@@ -221,7 +267,7 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             double bs = 0.0;
             if (MODE != 0) bs = (bv[c] * (rwxv[c] * rwy)) * rwz;
             if (MODE == 1) {
-                out[c] = omega * (bs / d);
+                out[c] = jweight(omega, d) * bs;
                 continue;
             }
             if (MODE == 6) {
@@ -232,6 +278,22 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             const double left = (c == 0) ? xl : xc[c > 0 ? c - 1 : 0];
             const double right = (c == C - 1) ? xr : xc[c < C - 1 ? c + 1 : 0];
             const double xcc = xc[c];
+            if (MODE == 2 || MODE == 8) {
+                double t = bs;
+                t = nacc(t, cxm, left);
+                t = nacc(t, cxp, right);
+                t = nacc(t, cym, ym[c]);
+                t = nacc(t, cyp, yp[c]);
+                t = nacc(t, czm, zm[c]);
+                t = nacc(t, czp, zp[c]);
+                out[c] = jrelax(xcc, 1.0 - omega, jweight(omega, d), t);
+                if (MODE == 8 && dots) {
+                    acc0 += out[c] * braw[c];
+                    acc1 += out[c] * out[c];
+                    acc2 += out[c];
+                }
+                continue;
+            }
             // a missing neighbour: zero coefficient, and the value is 0 (xl, xr) or the centre's own (ym .. zp)
             double s = 0.0;
             s = facc(s, cxm, left, xcc);
@@ -242,14 +304,6 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
             s = facc(s, czp, zp[c], xcc);
             if (MODE == 0)
                 out[c] = (s * (wxv[c] * wyj)) * wzk;
-            else if (MODE == 2 || MODE == 8) {
-                out[c] = jstep(xcc, omega, (bs - s) / d);
-                if (MODE == 8 && dots) {
-                    acc0 += out[c] * braw[c];
-                    acc1 += out[c] * out[c];
-                    acc2 += out[c];
-                }
-            }
             else if (MODE == 5) {
                 const double z = (bs - s) / d;
                 const double dn = (a_d != 0.0) ? a_d * dv[c] + omega * z : omega * z;
@@ -430,11 +484,17 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
     // the planes for the x / y neighbours only: plane kk is written while plane kk-1 is read, three slots, one barrier
     v4 bprev = {0, 0, 0, 0}, bcur = {0, 0, 0, 0};
     v4 x1m = {0, 0, 0, 0}, x1c = {0, 0, 0, 0}, x1p = {0, 0, 0, 0};
+    // wr = omega / d of the thread's cells on the plane the first step works on (wn) and on the plane before it (wc: what
+    // the second step needs); divided again only when a plane's z coefficients differ from the previous plane's
+    const double omc = 1.0 - omega;
+    v4 wn = {0, 0, 0, 0}, wc = {0, 0, 0, 0};
+    double wn_hy = 0.0, wn_hx = 0.0, key_zm = __builtin_nan(""), key_zp = __builtin_nan("");
     for (int kk = k0 - 1; kk <= kend; ++kk) {
         const int slot = (kk + 3) % 3;
         bprev = bcur;
         x1m = x1c;
         x1c = x1p;
+        wc = wn;
         const int kw = pz ? (kk < 0 ? L.nzg - 1 : (kk >= L.nzg ? 0 : kk)) : kk;
         if (kw >= 0 && kw < L.nzg) {
             const double *pb = b + (int64_t)kw * plane;
@@ -461,13 +521,20 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
             if (pin_sum != nullptr && kw == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;  // PINNED: effective b at cell 0
             const double rwz = L.rwz[kw], czm = L.cmz[kw], czp = L.cpz[kw];
             bcur = bv;
+            if (czm != key_zm || czp != key_zp) {  // (workgroup-uniform)
+                key_zm = czm, key_zp = czp;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wn[c] = jweight(omega, fdiag(q4[c], czm, czp));
+                wn_hy = hy_ok ? jweight(omega, fdiag(qhy, czm, czp)) : 0.0;
+                wn_hx = hx_ok ? jweight(omega, fdiag(qhx, czm, czp)) : 0.0;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                x1p[c] = omega * (((bv[c] * q4[c].rxy) * rwz) / fdiag(q4[c], czm, czp));
+                x1p[c] = wn[c] * ((bv[c] * q4[c].rxy) * rwz);
                 x1[slot][ty + 1][4 * tx + 1 + c] = x1p[c];
             }
-            x1[slot][hy_row + 1][hy_x + 1] = hy_ok ? omega * (((hyv * qhy.rxy) * rwz) / fdiag(qhy, czm, czp)) : 0.0;
-            if (tid < 16) x1[slot][hx_y + 1][hx_col + 1] = hx_ok ? omega * (((hxv * qhx.rxy) * rwz) / fdiag(qhx, czm, czp)) : 0.0;
+            x1[slot][hy_row + 1][hy_x + 1] = hy_ok ? wn_hy * ((hyv * qhy.rxy) * rwz) : 0.0;
+            if (tid < 16) x1[slot][hx_y + 1][hx_col + 1] = hx_ok ? wn_hx * ((hxv * qhx.rxy) * rwz) : 0.0;
         }
         __syncthreads();
         const int kc = kk - 1;  // the plane whose x1 neighbours are complete now
@@ -481,14 +548,25 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
             const FCell &q = q4[c];
             const double xcc = x1c[c];
             // missing neighbours: zero coefficients; the LDS halo cells and x1m / x1p outside the domain hold 0
-            double sum = 0.0;
-            sum = facc(sum, q.cxm, x1[sc][ty + 1][lx - 1], xcc);
-            sum = facc(sum, q.cxp, x1[sc][ty + 1][lx + 1], xcc);
-            sum = facc(sum, q.cym, x1[sc][ty][lx], xcc);
-            sum = facc(sum, q.cyp, x1[sc][ty + 2][lx], xcc);
-            sum = facc(sum, czm, x1m[c], xcc);
-            sum = facc(sum, czp, x1p[c], xcc);
-            out[c] = RES ? resid(bprev[c], sum * q.vxy, wzk) : jstep(xcc, omega, (((bprev[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
+            if (RES) {
+                double sum = 0.0;
+                sum = facc(sum, q.cxm, x1[sc][ty + 1][lx - 1], xcc);
+                sum = facc(sum, q.cxp, x1[sc][ty + 1][lx + 1], xcc);
+                sum = facc(sum, q.cym, x1[sc][ty][lx], xcc);
+                sum = facc(sum, q.cyp, x1[sc][ty + 2][lx], xcc);
+                sum = facc(sum, czm, x1m[c], xcc);
+                sum = facc(sum, czp, x1p[c], xcc);
+                out[c] = resid(bprev[c], sum * q.vxy, wzk);
+            } else {
+                double t = (bprev[c] * q.rxy) * rwz;
+                t = nacc(t, q.cxm, x1[sc][ty + 1][lx - 1]);
+                t = nacc(t, q.cxp, x1[sc][ty + 1][lx + 1]);
+                t = nacc(t, q.cym, x1[sc][ty][lx]);
+                t = nacc(t, q.cyp, x1[sc][ty + 2][lx]);
+                t = nacc(t, czm, x1m[c]);
+                t = nacc(t, czp, x1p[c]);
+                out[c] = jrelax(xcc, omc, wc[c], t);
+            }
         }
         if (RES) {
             *reinterpret_cast<v4 *>(ro + (int64_t)kc * plane + off_c) = out;
@@ -524,7 +602,7 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
 // same order (modes 2 and 3 bit-identical; mode 8's sums are grouped by tile instead of by line segment, i.e. equal to
 // rounding).
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ? 3 : PIB_WAVES_MARCH))) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 8 || MODE == 2) ? 3 : PIB_WAVES_MARCH))) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                      const double *__restrict__ b, const double *__restrict__ xi,
                                                      double *__restrict__ xo, const double *__restrict__ pin_sum,
                                                      double *__restrict__ part, int part_stride, int FZ, int dlo, int dhi)
@@ -572,6 +650,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ?
     hyv = hy_ok ? xi[(int64_t)l0 * plane + off_hy] : 0.0;
     hxv = hx_ok ? xi[(int64_t)l0 * plane + off_hx] : 0.0;
     if (MODE != 0) bv = *reinterpret_cast<const v4 *>(b + (int64_t)l0 * plane + off_c);
+    // wr = omega / d of the thread's cells, divided again only when a plane's z coefficients differ from the previous plane's
+    const double omc = 1.0 - omega;
+    v4 wr = {0, 0, 0, 0};
+    double key_zm = __builtin_nan(""), key_zp = __builtin_nan("");
     for (int lk = l0; lk < lend; ++lk) {
         const int kk = L.k0 + lk;  // global plane
         const int slot = lk & 1;
@@ -591,11 +673,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ?
         __syncthreads();
         const double wzk = L.wz[kk], rwz = L.rwz[kk], czm = L.cmz[kk], czp = L.cpz[kk];
         v4 out;
+        if ((MODE == 2 || MODE == 8) && (czm != key_zm || czp != key_zp)) {  // (workgroup-uniform)
+            key_zm = czm, key_zp = czp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wr[c] = jweight(omega, fdiag(q4[c], czm, czp));
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int lx = 4 * tx + 1 + c;
             const FCell &q = q4[c];
             const double xcc = xc[c];
+            if (MODE == 2 || MODE == 8) {
+                double t = (bv[c] * q.rxy) * rwz;
+                t = nacc(t, q.cxm, sp[slot][ty + 1][lx - 1]);
+                t = nacc(t, q.cxp, sp[slot][ty + 1][lx + 1]);
+                t = nacc(t, q.cym, sp[slot][ty][lx]);
+                t = nacc(t, q.cyp, sp[slot][ty + 2][lx]);
+                t = nacc(t, czm, zm[c]);
+                t = nacc(t, czp, zp[c]);
+                out[c] = jrelax(xcc, omc, wr[c], t);
+                if (MODE == 8 && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
+                    acc0 += out[c] * braw[c];
+                    acc1 += out[c] * out[c];
+                    acc2 += out[c];
+                }
+                continue;
+            }
             double sum = 0.0;
             sum = facc(sum, q.cxm, sp[slot][ty + 1][lx - 1], xcc);
             sum = facc(sum, q.cxp, sp[slot][ty + 1][lx + 1], xcc);
@@ -606,16 +709,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 8 ?
             if (MODE == 0) {  // y = A x (the Krylov product of the stencil twin), x.y over the owned planes on request
                 out[c] = (sum * q.vxy) * wzk;
                 if (part != nullptr && lk >= dlo && lk < dhi) acc0 += out[c] * xcc;
-            } else if (MODE == 3)
+            } else
                 out[c] = resid(bv[c], sum * q.vxy, wzk);
-            else {
-                out[c] = jstep(xcc, omega, (((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
-                if (MODE == 8 && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
-                    acc0 += out[c] * braw[c];
-                    acc1 += out[c] * out[c];
-                    acc2 += out[c];
-                }
-            }
         }
         *reinterpret_cast<v4 *>(xo + (int64_t)lk * plane + off_c) = out;
         zm = xc;
@@ -986,6 +1081,10 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
     __syncthreads();
     if (l0 > 0 || pz) zm = correct(l0 - 1, false, om);
     xcur = correct(l0, true, o0);
+    // wr = omega / d of the thread's cells, divided again only when a plane's z coefficients differ from the previous plane's
+    const double omc = 1.0 - omega;
+    v4 wr = {0, 0, 0, 0};
+    double key_zm = __builtin_nan(""), key_zp = __builtin_nan("");
     for (int lk = l0; lk < lend; ++lk) {
         const int slot = lk & 1;
         const int kn = lk + 1;
@@ -1001,19 +1100,24 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
         if (pin_sum != nullptr && lk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
         const double rwz = F.rwz[lk], czm = F.cmz[lk], czp = F.cpz[lk];
         v4 out;
+        if (czm != key_zm || czp != key_zp) {  // (workgroup-uniform)
+            key_zm = czm, key_zp = czp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wr[c] = jweight(omega, fdiag(q4[c], czm, czp));
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int lx = 4 * tx + 1 + c;
             const FCell &q = q4[c];
             const double xcc = xcur[c];
-            double sum = 0.0;
-            sum = facc(sum, q.cxm, sp[slot][ty + 1][lx - 1], xcc);
-            sum = facc(sum, q.cxp, sp[slot][ty + 1][lx + 1], xcc);
-            sum = facc(sum, q.cym, sp[slot][ty][lx], xcc);
-            sum = facc(sum, q.cyp, sp[slot][ty + 2][lx], xcc);
-            sum = facc(sum, czm, zm[c], xcc);
-            sum = facc(sum, czp, zp[c], xcc);
-            out[c] = jstep(xcc, omega, (((bv[c] * q.rxy) * rwz) - sum) / fdiag(q, czm, czp));
+            double t = (bv[c] * q.rxy) * rwz;
+            t = nacc(t, q.cxm, sp[slot][ty + 1][lx - 1]);
+            t = nacc(t, q.cxp, sp[slot][ty + 1][lx + 1]);
+            t = nacc(t, q.cym, sp[slot][ty][lx]);
+            t = nacc(t, q.cyp, sp[slot][ty + 2][lx]);
+            t = nacc(t, czm, zm[c]);
+            t = nacc(t, czp, zp[c]);
+            out[c] = jrelax(xcc, omc, wr[c], t);
             if (DOTS && lk >= dlo && lk < dhi) {  // the sums cover the OWNED planes only
                 acc0 += out[c] * braw[c];
                 acc1 += out[c] * out[c];
@@ -1182,7 +1286,7 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         const bool in = inz(k);
         const int kw = zw(k);
         const int Kp = k >> 1, Ko = (k & 1) ? Kp + 1 : Kp - 1;
-        const double wk[2] = {in ? F.t[2].wpar[kw] : 0.0, in ? F.t[2].woth[kw] : 0.0};
+        const double wk[2] = {in ? uniform(F.t[2].wpar[kw]) : 0.0, in ? uniform(F.t[2].woth[kw]) : 0.0};
         const int Ks[2] = {((Kp % 3) + 3) % 3, ((Ko % 3) + 3) % 3};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -1217,8 +1321,22 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         }
     };
     // one damped-Jacobi step of piece e on a plane: centre values cc, z neighbours zm / zp, in-plane neighbours from `pl`
+    const double omc = 1.0 - omega;
+    // wr = omega / d of piece e's cells on a plane with the z coefficients czm, czp
+    auto weights = [&](int e, double czm, double czp) -> v4 {
+        const int R = prow[e], X = pcol[e];
+        const double cym = tcy[0][R], cyp = tcy[1][R];
+        v4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double cxm = tcx[0][X + c], cxp = tcx[1][X + c];
+            const double s4 = ((cxm + cxp) + cym) + cyp;
+            out[c] = jweight(omega, -((s4 + czm) + czp));
+        }
+        return out;
+    };
     auto step = [&](int e, const double (*pl)[UX], const v4 &cc, const v4 &zm, const v4 &zp, const v4 &bv, double rwz, double czm,
-                    double czp) -> v4 {
+                    double czp, const v4 &wr) -> v4 {
         const int R = prow[e], X = pcol[e];
         const double cym = tcy[0][R], cyp = tcy[1][R], rwy = tcy[2][R];
         v4 out;
@@ -1228,15 +1346,14 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
             const double left = (c == 0) ? (X > 0 ? pl[R][X - 1] : 0.0) : cc[c > 0 ? c - 1 : 0];
             const double right = (c == 3) ? (X + 4 < UX ? pl[R][X + 4] : 0.0) : cc[c < 3 ? c + 1 : 0];
             const double cxm = tcx[0][X + c], cxp = tcx[1][X + c];
-            double sum = 0.0;
-            sum = facc(sum, cxm, left, xcc);
-            sum = facc(sum, cxp, right, xcc);
-            sum = facc(sum, cym, pl[R - 1][X + c], xcc);
-            sum = facc(sum, cyp, pl[R + 1][X + c], xcc);
-            sum = facc(sum, czm, zm[c], xcc);
-            sum = facc(sum, czp, zp[c], xcc);
-            const double s4 = ((cxm + cxp) + cym) + cyp;
-            out[c] = jstep(xcc, omega, (((bv[c] * (tcx[2][X + c] * rwy)) * rwz) - sum) / (-((s4 + czm) + czp)));
+            double t = (bv[c] * (tcx[2][X + c] * rwy)) * rwz;
+            t = nacc(t, cxm, left);
+            t = nacc(t, cxp, right);
+            t = nacc(t, cym, pl[R - 1][X + c]);
+            t = nacc(t, cyp, pl[R + 1][X + c]);
+            t = nacc(t, czm, zm[c]);
+            t = nacc(t, czp, zp[c]);
+            out[c] = jrelax(xcc, omc, wr[c], t);
         }
         return out;
     };
@@ -1246,6 +1363,10 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     v4 s1m[2] = {zero, zero}, s1c[2] = {zero, zero}, s1n[2];       // first step on the planes k - 1, k (k + 1: s1n)
     v4 bcur[2] = {zero, zero}, bnext[2], anext[2], a2[2];
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    // wr of the pieces on the plane the first step works on (w1) and of the tile piece on the plane the second works on (w2):
+    // divided again only when a plane's z coefficients differ from those of the plane the weights were formed for
+    v4 w1[2] = {zero, zero}, w2 = zero;
+    double key1_zm = __builtin_nan(""), key1_zp = __builtin_nan(""), key2_zm = __builtin_nan(""), key2_zp = __builtin_nan("");
     int staged = ((l0 - 2) >> 1) - 2;  // highest coarse plane in the ring
     auto need_stage = [&](int k) {  // the coarse planes plane k interpolates from: k >> 1 and the one above (odd k) or below
         const int hi = (k & 1) ? (k >> 1) + 1 : (k >> 1);
@@ -1271,15 +1392,24 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         const int cur = k & 1, nxt = cur ^ 1;
         if (do1) {
             const int kw = zw(k + 1);
-            const double rwz = F.rwz[kw], czm = F.cmz[kw], czp = F.cpz[kw];
+            const double rwz = uniform(F.rwz[kw]), czm = uniform(F.cmz[kw]), czp = uniform(F.cpz[kw]);
+            if (czm != key1_zm || czp != key1_zp) {  // (workgroup-uniform)
+                key1_zm = czm, key1_zp = czp;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) s1n[e] = first[e] ? step(e, XP[cur], xpc[e], xpm[e], xpn[e], b1[e], rwz, czm, czp) : zero;
+                for (int e = 0; e < 2; ++e) w1[e] = first[e] ? weights(e, czm, czp) : zero;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) s1n[e] = first[e] ? step(e, XP[cur], xpc[e], xpm[e], xpn[e], b1[e], rwz, czm, czp, w1[e]) : zero;
         } else {
             s1n[0] = s1n[1] = zero;
         }
         if (do2) {
-            const double rwz = F.rwz[k], czm = F.cmz[k], czp = F.cpz[k];
-            const v4 out = step(0, S1[cur], s1c[0], s1m[0], s1n[0], bcur[0], rwz, czm, czp);
+            const double rwz = uniform(F.rwz[k]), czm = uniform(F.cmz[k]), czp = uniform(F.cpz[k]);
+            if (czm != key2_zm || czp != key2_zp) {
+                key2_zm = czm, key2_zp = czp;
+                w2 = weights(0, czm, czp);
+            }
+            const v4 out = step(0, S1[cur], s1c[0], s1m[0], s1n[0], bcur[0], rwz, czm, czp, w2);
             *reinterpret_cast<v4 *>(xo + (int64_t)k * plane + goff[0]) = out;
             if (DOTS && k >= dlo && k < dhi) {
 #pragma unroll
@@ -1765,10 +1895,10 @@ __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S,
                 double c[6];
                 face_coefs(L, i, j, k, c);
                 d = -(((((c[0] + c[1]) + c[2]) + c[3]) + c[4]) + c[5]);
-                nxt[p] = omega * (scale_b(L, i, j, k, b[p]) / d);
+                nxt[p] = jweight(omega, d) * scale_b(L, i, j, k, b[p]);
             } else {
-                const double ax = apply_cell(L, cur, p, i, j, k, &d);
-                nxt[p] = jstep(cur[p], omega, (scale_b(L, i, j, k, b[p]) - ax) / d);
+                const double t = relax_cell(L, cur, p, i, j, k, scale_b(L, i, j, k, b[p]), &d);
+                nxt[p] = jrelax(cur[p], 1.0 - omega, jweight(omega, d), t);
             }
         }
         __threadfence_block();
@@ -1929,12 +2059,18 @@ __device__ __forceinline__ void tail_cell_phase(const TailCell &t, bool zero, bo
 {
     if (!t.has) return;
     if (zero) {
-        out[p] = omega * (t.bs / t.d);
+        out[p] = jweight(omega, t.d) * t.bs;
         return;
     }
-    const double row = tail_row(t, x, p);
-    if (res) out[p] = resid(b[p], row * t.wxy, t.wz);
-    else out[p] = jstep(x[p], omega, (t.bs - row) / t.d);
+    if (res) {
+        out[p] = resid(b[p], tail_row(t, x, p) * t.wxy, t.wz);
+        return;
+    }
+    double s = t.bs;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        if ((t.has >> q) & 1) s = nacc(s, t.c[q], x[p + t.off[q]]);
+    out[p] = jrelax(x[p], 1.0 - omega, jweight(omega, t.d), s);
 }
 
 // One visit of a level: `steps` smoothing steps (the first from a zero guess on the way down) and, on the way down, the
@@ -2316,9 +2452,19 @@ __device__ __forceinline__ void sm_phase(const LevelDev &F, const SmGeom &G, con
         const double bv = bq[u];
         const double bs = (bv * (T.rw[0][rx] * T.rw[1][ry])) * T.rw[2][rz];
         if (MODE == 1) {
-            v[uu] = omega * (bs / d);
-        } else {
+            v[uu] = jweight(omega, d) * bs;
+        } else if (MODE == 2) {
             // a neighbour beyond the region: only at a clipped face, i.e. a wall -- zero coefficient, the centre's own value
+            const double xc = src[q];
+            double t = bs;
+            t = nacc(t, cxm, src[rx > 0 ? q - 1 : q]);
+            t = nacc(t, cxp, src[rx < G.ext[0] - 1 ? q + 1 : q]);
+            t = nacc(t, cym, src[ry > 0 ? q - sy : q]);
+            t = nacc(t, cyp, src[ry < G.ext[1] - 1 ? q + sy : q]);
+            t = nacc(t, czm, src[rz > 0 ? q - sz : q]);
+            t = nacc(t, czp, src[rz < G.ext[2] - 1 ? q + sz : q]);
+            v[uu] = jrelax(xc, 1.0 - omega, jweight(omega, d), t);
+        } else {
             const double xc = src[q];
             double s = 0.0;
             s = facc(s, cxm, src[rx > 0 ? q - 1 : q], xc);
@@ -2327,8 +2473,7 @@ __device__ __forceinline__ void sm_phase(const LevelDev &F, const SmGeom &G, con
             s = facc(s, cyp, src[ry < G.ext[1] - 1 ? q + sy : q], xc);
             s = facc(s, czm, src[rz > 0 ? q - sz : q], xc);
             s = facc(s, czp, src[rz < G.ext[2] - 1 ? q + sz : q], xc);
-            if (MODE == 2) v[uu] = jstep(xc, omega, (bs - s) / d);
-            else v[uu] = resid(bv, s * (T.w[0][rx] * T.w[1][ry]), T.w[2][rz]);
+            v[uu] = resid(bv, s * (T.w[0][rx] * T.w[1][ry]), T.w[2][rz]);
         }
     }
 #pragma unroll
@@ -3104,7 +3249,10 @@ static bool fused_run_ok(const pib_solver *s, const GridLevel &g, int64_t kb, in
     return z_ok && tiles_ok(g) && kc >= 2 && kc * g.plane >= (int64_t)s->cfg.march_min_cells;
 }
 // planes per workgroup: 64 on a 512^3 run (2048 workgroups), 16 on a 256^3 one (1024)
-static int march_planes(const GridLevel &g, int64_t kc) { return kc * g.plane >= ((int64_t)1 << 26) ? 64 : 16; }
+#ifndef PIB_MARCH_PLANES_BIG
+#define PIB_MARCH_PLANES_BIG 64
+#endif
+static int march_planes(const GridLevel &g, int64_t kc) { return kc * g.plane >= ((int64_t)1 << 26) ? PIB_MARCH_PLANES_BIG : 16; }
 
 // MODE on the planes [kb, kb + kc) relative to the first owned plane (kb < 0 / kb + kc > nk: ghost planes); the vectors
 // point at the first OWNED plane.  dots: mode 8 sums over the owned planes only.
