@@ -193,6 +193,10 @@ class GMG:
                                   C.c_int, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]
         L.orc_pcg_gmg_single_reduction.restype = C.c_int
         L.orc_pcg_gmg_single_reduction.argtypes = L.orc_pcg_gmg.argtypes
+        L.orc_bcgs_gmg.restype = C.c_int
+        L.orc_bcgs_gmg.argtypes = [C.c_void_p, C.c_int64, _i64p, _i64p, _f64p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                   C.c_double, C.c_int, C.c_int, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                   C.c_void_p]
         self.dim = len(n)
         self.n = np.array(list(n), dtype=np.int64)
         self._w = [np.ascontiguousarray(w, dtype=np.float64) for w in widths]
@@ -236,6 +240,20 @@ class GMG:
         fn = lib().orc_pcg_gmg_single_reduction if single_reduction else lib().orc_pcg_gmg
         reason = fn(self._h, m.n_rows, m.rowptr, m.col, m.val, NORM[norm], rtol, atol, int(maxit),
                     int(x0 is not None), b, x, C.byref(its), C.byref(rn), hist.ctypes.data)
+        return {"x": x, "iters": its.value, "rnorm": rn.value, "reason": int(reason),
+                "history": hist[: its.value + 1].copy()}
+
+    def bcgs(self, m, b, x0=None, norm="unpreconditioned", rtol=1e-10, atol=0.0, dtol=1e4, maxit=1000):
+        """KSPBCGS / PBICGSTAB preconditioned by the V-cycle (oracle/csrc/oracle.c:orc_bcgs_gmg): left-preconditioned with
+        norm="preconditioned" (the KSP flavour), right-preconditioned otherwise (the AmgX flavour); the mean is removed after
+        every application when the multigrid was created with nullspace=1."""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros(m.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
+        hist = np.full(maxit + 2, np.nan)
+        its, rn = C.c_int(0), C.c_double(0)
+        reason = lib().orc_bcgs_gmg(self._h, m.n_rows, m.rowptr, m.col, m.val, 1 if self.nullspace == 1 else 0, NORM[norm],
+                                    rtol, atol, dtol, int(maxit), int(x0 is not None), b, x, C.byref(its), C.byref(rn),
+                                    hist.ctypes.data)
         return {"x": x, "iters": its.value, "rnorm": rn.value, "reason": int(reason),
                 "history": hist[: its.value + 1].copy()}
 

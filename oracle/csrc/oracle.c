@@ -127,7 +127,8 @@ static void remove_mean(i64 n, double *z)
 }
 
 /* --------------------------------------------------------------- config */
-enum { PC_NONE = 0, PC_JACOBI = 1 };
+enum { PC_NONE = 0, PC_JACOBI = 1, PC_GMG = 2 };
+void orc_gmg_apply(void *h, const double *r, double *z); /* gmg.c: one V-cycle, z = M^-1 r, not projected */
 enum { NORM_PRECONDITIONED = 0, NORM_UNPRECONDITIONED = 1 };
 /* reasons: PETSc numbering */
 enum {
@@ -150,6 +151,7 @@ typedef struct {
     const double *dinv; /* 1/diag for Jacobi, NULL otherwise */
     int pc;
     int nullspace; /* 1: remove the mean after every PC apply (MatNullSpace const) */
+    void *gmg;     /* PC_GMG: the build's multigrid (gmg.c) */
 } sys_t;
 
 static void matmult(const sys_t *s, const double *x, double *y) { orc_spmv(s->n, s->rowptr, s->col, s->val, x, y); }
@@ -161,6 +163,8 @@ static void pcapply(const sys_t *s, const double *r, double *z)
         const double *d = s->dinv;
 #pragma omp parallel for schedule(static)
         for (i64 i = 0; i < n; ++i) z[i] = r[i] * d[i];
+    } else if (s->pc == PC_GMG) {
+        orc_gmg_apply(s->gmg, r, z);
     } else {
         copy(n, r, z);
     }
@@ -185,7 +189,7 @@ int orc_cg(i64 n, const i64 *rowptr, const i64 *col, const double *val, const do
            int nullspace, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
            const double *b, double *x, int *its_out, double *rnorm_out, double *history)
 {
-    sys_t S = {n, rowptr, col, val, dinv, pc, nullspace};
+    sys_t S = {n, rowptr, col, val, dinv, pc, nullspace, NULL};
     double *R = malloc((size_t)n * 8), *Z = malloc((size_t)n * 8), *P = malloc((size_t)n * 8),
            *W = malloc((size_t)n * 8);
     double beta = 0, betaold = 1, dpi = 0, dpiold = 0, dp = 0, a, bb, ttol, rnorm0;
@@ -267,7 +271,7 @@ int orc_cg_single_reduction(i64 n, const i64 *rowptr, const i64 *col, const doub
                             int nullspace, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
                             const double *b, double *x, int *its_out, double *rnorm_out, double *history)
 {
-    sys_t S = {n, rowptr, col, val, dinv, pc, nullspace};
+    sys_t S = {n, rowptr, col, val, dinv, pc, nullspace, NULL};
     double *R = malloc((size_t)n * 8), *Z = malloc((size_t)n * 8), *P = malloc((size_t)n * 8),
            *W = malloc((size_t)n * 8), *Sv = malloc((size_t)n * 8);
     double beta = 0, betaold = 1, dpi = 0, dpiold = 0, dp = 0, delta = 0, a, bb, ttol, rnorm0;
@@ -354,11 +358,30 @@ done:
  * the same recurrences are run in right-preconditioned form: R is the true
  * residual, V = A B P, T = A B S, X += alpha B P + omega B S.
  */
+static int bcgs_sys(sys_t Sy, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
+                    const double *b, double *x, int *its_out, double *rnorm_out, double *history);
 int orc_bcgs(i64 n, const i64 *rowptr, const i64 *col, const double *val, const double *dinv, int pc,
              int nullspace, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
              const double *b, double *x, int *its_out, double *rnorm_out, double *history)
 {
-    sys_t Sy = {n, rowptr, col, val, dinv, pc, nullspace};
+    sys_t Sy = {n, rowptr, col, val, dinv, pc, nullspace, NULL};
+    return bcgs_sys(Sy, normtype, rtol, atol, dtol, maxit, guess_nonzero, b, x, its_out, rnorm_out, history);
+}
+/* the same recurrences preconditioned by the build's V-cycle (handle of orc_gmg_create): what AmgX runs for
+ * solver=PBICGSTAB, preconditioner=AMG (any solver x preconditioner pair of a solver file: src/linsolver/linsolveramgx.cpp:62-72)
+ * and PETSc for -ksp_type bcgs -pc_type gamg; the mean is removed after every application on a singular system (nullspace 1),
+ * as KSP_PCApply + KSP_RemoveNullSpace do */
+int orc_bcgs_gmg(void *h, i64 n, const i64 *rowptr, const i64 *col, const double *val, int nullspace, int normtype,
+                 double rtol, double atol, double dtol, int maxit, int guess_nonzero, const double *b, double *x,
+                 int *its_out, double *rnorm_out, double *history)
+{
+    sys_t Sy = {n, rowptr, col, val, NULL, PC_GMG, nullspace, h};
+    return bcgs_sys(Sy, normtype, rtol, atol, dtol, maxit, guess_nonzero, b, x, its_out, rnorm_out, history);
+}
+static int bcgs_sys(sys_t Sy, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
+                    const double *b, double *x, int *its_out, double *rnorm_out, double *history)
+{
+    const i64 n = Sy.n;
     size_t nb = (size_t)n * 8;
     double *R = malloc(nb), *RP = malloc(nb), *V = calloc((size_t)n, 8), *T = malloc(nb), *S = malloc(nb),
            *P = calloc((size_t)n, 8), *T2 = malloc(nb), *PH = malloc(nb), *SH = malloc(nb);
@@ -455,7 +478,7 @@ int orc_chebyshev(i64 n, const i64 *rowptr, const i64 *col, const double *val, c
                   int nullspace, int normtype, double rtol, double atol, double dtol, int maxit, int guess_nonzero,
                   const double *b, double *x, int *its_out, double *rnorm_out, double *history, double emin, double emax)
 {
-    sys_t Sy = {n, rowptr, col, val, dinv, pc, nullspace};
+    sys_t Sy = {n, rowptr, col, val, dinv, pc, nullspace, NULL};
     size_t nb = (size_t)n * 8;
     double *P[3] = {malloc(nb), malloc(nb), malloc(nb)}, *R = malloc(nb);
     int km1 = 0, k = 1, kp1 = 2, reason = 0, i = 0, its = 0;

@@ -1376,6 +1376,37 @@ struct OpBUpdateX {  // x += alpha ph + omega sh ; r = s - omega t ; partials |r
     }
 };
 
+// the multigrid under BiCGStab: z = M^-1 r is one V-cycle, and on a singular system (constant null space) its mean is removed
+// after every application, as KSP_PCApply + KSP_RemoveNullSpace do (oracle: pcapply with PC_GMG)
+struct OpSumV {  // partial: sum v
+    static constexpr int NRED = 1;
+    const double *v;
+    __device__ void prepare(const Scalars *) {}
+    template <int W>
+    __device__ void apply(int64_t i, double (&acc)[1]) const
+    {
+        const Pack<W> vv = ld<W>(v, i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc[0] += vv.v[k];
+    }
+};
+struct OpShiftV {  // v -= red[slot] / n_global
+    static constexpr int NRED = 0;
+    double *v;
+    double inv_n;
+    int slot;
+    double m;
+    __device__ void prepare(const Scalars *S) { m = S->red[slot] * inv_n; }
+    template <int W>
+    __device__ void apply(int64_t i, double (&)[1]) const
+    {
+        Pack<W> vv = ld<W>(v, i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) vv.v[k] = vv.v[k] - m;
+        st<W>(v, i, vv);
+    }
+};
+
 // ---- the same recurrences on the matrix-free velocity operator (right preconditioning, Jacobi, one rank, the one-launch
 // product): M^-1 p and M^-1 s are never stored -- the products apply the sweep as they read their input
 // (vel_stencil_apply's dinv / opc) -- and x += alpha M^-1 p + omega M^-1 s is applied by the NEXT iteration's p-update,
@@ -1622,9 +1653,17 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     const int64_t n = A.n;
     hipStream_t q = s->stream;
     const Precond pc = s->cfg.pc;
-    if (pc == Precond::GMG)
-        return fail(PIB_ERR_SUP, "solver %s: BiCGStab with a multigrid preconditioner is not supported (use Jacobi)",
-                    s->name.c_str());
+    // BiCGStab with the multigrid (round 4): AmgX takes any solver x preconditioner pair of a solver file
+    // (/root/reference/src/linsolver/linsolveramgx.cpp:62-72), PETSc any -ksp_type / -pc_type; the V-cycle is applied where the
+    // general path applies the Jacobi sweep, as a call of its own (gmg_apply), followed by the projection on a singular system
+    const bool gmg = (pc == Precond::GMG);
+    if (gmg && !s->has_grid)
+        return fail(PIB_ERR_ORDER,
+                    "solver %s: a multigrid (AMG/GMG) preconditioner needs the grid structure: call "
+                    "pib_set_grid_hint or pib_assemble_poisson before pib_solve", s->name.c_str());
+    if (gmg && s->nullspace == PIB_NULLSPACE_PINNED)
+        return fail(PIB_ERR_SUP, "solver %s: BiCGStab with the multigrid and a pinned pressure row is not supported "
+                    "(CG takes the pair; or attach the constant null space)", s->name.c_str());
     if (pc == Precond::JACOBI && A.dinv == nullptr) return fail(PIB_ERR_ORDER, "Jacobi preconditioner without a diagonal");
     PIB_CHK(ensure_work(s, 9));
     double *R = s->vec(0), *RP = s->vec(1), *P = s->vec(2), *V = s->vec(3), *S = s->vec(4), *T = s->vec(5),
@@ -1636,13 +1675,29 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     const int monitor = s->cfg.monitor_residual ? 1 : 0;
     const int conv_is_its = monitor ? 0 : 1;
     const bool v2 = aligned16(x) && aligned16(b);
-    if (!jac || left) {  // no separate preconditioned copies needed
+    if ((!jac && !gmg) || left) {  // no separate preconditioned copies needed
         PH = P;
         SH = S;
     }
     for (int k = 0; k < 8; ++k) s->counters[k] = 0;
     PIB_CHK(init_scalars(s));
     int nb = 0;
+    const bool project = gmg && s->nullspace == PIB_NULLSPACE_CONSTANT;
+    auto apply_gmg = [&](const double *in, double *out, bool guarded) -> int {
+        s->gmg_guarded = guarded;
+        s->gmg_want_dots = false;
+        PIB_CHK(gmg_apply(s, in, out, q));
+        s->counters[1]++;
+        if (project) {
+            int nbs = 0;
+            OpSumV sv{out};
+            PIB_CHK(launch_vec(s, n, sv, true, 5, &nbs, guarded, q));
+            PIB_CHK(finalize(s, 5, 1, nbs, q));
+            OpShiftV sh{out, 1.0 / (double)A.n_global, 5, 0.0};
+            PIB_CHK(launch_vec(s, n, sh, true, 0, nullptr, true, q));  // (reads the sum from the scalars: always given them)
+        }
+        return 0;
+    };
     if (guess) {
         OpCopy cp{x, PH == P ? PH : P};
         // use T2 as the ghost-padded SpMV input so P stays free
@@ -1657,6 +1712,12 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     if (jac) {
         OpBInit<PCM_JACOBI> op{b, T, A.dinv, R, RP, P, V, opc, guess ? 1 : 0, left ? 1 : 0};
         PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
+    } else if (gmg && left) {  // r = M^-1 (b - w): the raw residual (in T2), the V-cycle, then the pass that sets rp, p, v and |r|^2
+        OpBInit<PCM_NONE> raw{b, T, nullptr, T2, RP, P, V, 1.0, guess ? 1 : 0, 0};
+        PIB_CHK(launch_vec(s, n, raw, v2, 0, &nb, false, q));
+        PIB_CHK(apply_gmg(T2, T, false));
+        OpBInit<PCM_NONE> op{T, T, nullptr, R, RP, P, V, 1.0, 0, 0};
+        PIB_CHK(launch_vec(s, n, op, true, 0, &nb, false, q));
     } else {
         OpBInit<PCM_NONE> op{b, T, nullptr, R, RP, P, V, 1.0, guess ? 1 : 0, left ? 1 : 0};
         PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
@@ -1756,9 +1817,15 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
             } else {
                 OpBUpdateP<PCM_NONE> op{R, V, nullptr, P, PH, 1.0, left ? 1 : 0, 0.0, 0.0};
                 PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
+                if (gmg && !left) PIB_CHK(apply_gmg(P, PH, true));  // ph = M^-1 p
             }
             // v = K p ; d1 = v.rp
-            if (left && jac) {
+            if (left && gmg) {  // v = M^-1 (K p)
+                PIB_CHK(matmult(s, P, T2, nullptr, true, q));
+                PIB_CHK(apply_gmg(T2, V, true));
+                OpBPcDot<PCM_NONE> op{V, nullptr, RP, V, 1.0};
+                PIB_CHK(launch_vec(s, n, op, true, 2, &nb, true, q));
+            } else if (left && jac) {
                 PIB_CHK(matmult(s, P, T2, nullptr, true, q));
                 OpBPcDot<PCM_JACOBI> op{T2, A.dinv, RP, V, opc};
                 PIB_CHK(launch_vec(s, n, op, true, 2, &nb, true, q));
@@ -1780,9 +1847,15 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
             } else {
                 OpBUpdateS<PCM_NONE> op{R, V, nullptr, S, SH, 1.0, left ? 1 : 0, 0.0};
                 PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
+                if (gmg && !left) PIB_CHK(apply_gmg(S, SH, true));  // sh = M^-1 s
             }
             // t = K s ; s.t, t.t
-            if (left && jac) {
+            if (left && gmg) {  // t = M^-1 (K s)
+                PIB_CHK(matmult(s, S, T2, nullptr, true, q));
+                PIB_CHK(apply_gmg(T2, T, true));
+                OpBPcDot2<PCM_NONE> op{T, nullptr, S, T, 1.0, 0};
+                PIB_CHK(launch_vec(s, n, op, true, 3, &nb, true, q));
+            } else if (left && jac) {
                 PIB_CHK(matmult(s, S, T2, nullptr, true, q));
                 OpBPcDot2<PCM_JACOBI> op{T2, A.dinv, S, T, opc, 1};
                 PIB_CHK(launch_vec(s, n, op, true, 3, &nb, true, q));
