@@ -350,6 +350,43 @@ __global__ __launch_bounds__(256) void k_ib_dense_pattern(int64_t nf, int32_t *_
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nf * nf; e += (int64_t)gridDim.x * 256) cl[e] = (int32_t)(e % nf);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= nf; i += (int64_t)gridDim.x * 256) rp[i] = (int32_t)(i * nf);
 }
+// z-slabs with a KRYLOV forces solver (round 4; any `forces_solver.info`, as decoupledibpm.cpp:75-80 hands whatever the file says to
+// createLinSolver): every rank holds the part of each entry of E BN H that runs over its own velocity points, in its own
+// sparsity pattern.  The parts are summed once, at assembly, into the dense nf x nf matrix -- the all-reduce the direct solver
+// makes before it factorises -- and every rank iterates on the same replicated matrix: no communication inside the forces
+// solve, the same bits on every rank (the right-hand side E u is all-reduced already).
+__global__ __launch_bounds__(256) void k_ib_csr_to_dense(int64_t nf, const int32_t *__restrict__ rp, const int32_t *__restrict__ cl,
+                                                         const double *__restrict__ val, double *__restrict__ dense)
+{
+    for (int64_t i = blockIdx.x; i < nf; i += gridDim.x)
+        for (int32_t e = rp[i] + (int32_t)threadIdx.x; e < rp[i + 1]; e += 256) dense[i * nf + cl[e]] = val[e];  // (a row's columns are distinct)
+}
+static int ib_adopt_summed(pib_ns *ns, IbState *ib, bool dense_already)
+{
+    hipStream_t q = ns->stream;
+    const int64_t nf = ib->I.nf;
+    int err = 0;
+    if (nf * nf >= (int64_t)INT32_MAX)
+        return fail(PIB_ERR_SUP, "immersed bodies on several ranks with a Krylov forces solver: %lld force unknowns are too many for the "
+                    "summed matrix (the direct solver, -forces_ksp_type preonly -forces_pc_type lu, has the same bound)", (long long)nf);
+    if (!dense_already) {
+        int32_t *rp = nullptr, *cl = nullptr;
+        double *dense = nullptr;
+        if ((err = dev_alloc(ib, &rp, nf + 1)) || (err = dev_alloc(ib, &cl, nf * nf)) || (err = dev_alloc(ib, &dense, nf * nf))) return err;
+        PIB_HIP(hipMemsetAsync(dense, 0, sizeof(double) * (size_t)(nf * nf), q));
+        hipLaunchKernelGGL(k_ib_csr_to_dense, dim3((unsigned)std::min<int64_t>(nf, 4096)), dim3(256), 0, q, nf, ib->c_rowptr, ib->c_col, ib->c_val, dense);
+        hipLaunchKernelGGL(k_ib_dense_pattern, dim3(blocks_for(nf * nf)), dim3(256), 0, q, nf, rp, cl);
+        PIB_HIP(hipGetLastError());
+        ib->c_rowptr = rp;
+        ib->c_col = cl;
+        ib->c_val = dense;
+        ib->c_nnz = nf * nf;
+    }
+    PIB_CHK(comm_allreduce_big(ns->vsol, ib->c_val, nf * nf, q));
+    PIB_HIP(hipStreamSynchronize(q));
+    return adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val);
+}
+
 // z-slabs, BN order > 1 (round 4): t = BN H x on this rank's velocity points = the series applied to dt H x -- the spread over the
 // owned points, then (dt c nu L)^k term by term with the engine's halo exchanges, every rank in step (collective)
 static int ib_bnh_slab(pib_ns *ns, IbState *ib, const double *x, double *t)
@@ -622,8 +659,6 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
             // term-by-term BN of the slab engine (every rank in step; a column's entries are this rank's part of the sums over its
             // own velocity points, the direct forces solver adds the ranks' matrices up).  nf (N - 1) stencil products and
             // exchanges per assembly: meant for stationary bodies of moderate size (a moving body pays it every step).
-            if (ib->fsol->cfg.pc != Precond::LU)
-                return fail(PIB_ERR_SUP, "immersed bodies on several ranks need the direct forces solver (-forces_ksp_type preonly -forces_pc_type lu)");
             if (nf * nf >= (int64_t)INT32_MAX) return fail(PIB_ERR_SUP, "immersed bodies with BN order > 1 on several ranks: %lld force unknowns are too many for the dense assembly", (long long)nf);
             if ((err = dev_alloc(ib, &ib->c_rowptr, nf + 1)) || (err = dev_alloc(ib, &ib->c_col, nf * nf)) || (err = dev_alloc(ib, &ib->c_val, nf * nf))) return err;
             ib->c_nnz = nf * nf;
@@ -639,6 +674,7 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
                 PIB_HIP(hipGetLastError());
             }
             PIB_HIP(hipStreamSynchronize(q));
+            if (ib->fsol->cfg.pc != Precond::LU) return ib_adopt_summed(ns, ib, true);
             ib->fsol->reduce_via = ns->vsol;
             return adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val);
         }
@@ -680,8 +716,7 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
     // fSolver->setMatrix(EBNH)  (decoupledibpm.cpp:80, rigidkinematics.cpp:139); on slabs every rank holds the part of
     // each entry that runs over its own velocity points: the direct solver sums the dense matrix over the ranks
     if (ns->nranks > 1) {
-        if (ib->fsol->cfg.pc != Precond::LU)
-            return fail(PIB_ERR_SUP, "immersed bodies on several ranks need the direct forces solver (-forces_ksp_type preonly -forces_pc_type lu)");
+        if (ib->fsol->cfg.pc != Precond::LU) return ib_adopt_summed(ns, ib, false);
         ib->fsol->reduce_via = ns->vsol;
     }
     return adopt_device_csr(ib->fsol, nf, ib->c_nnz, ib->c_rowptr, ib->c_col, ib->c_val);

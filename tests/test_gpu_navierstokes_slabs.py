@@ -202,6 +202,64 @@ def test_immersed_bodies_on_slabs_reproduce_the_single_rank(kind, P, bn):
     one.destroy()
 
 
+KRYLOV_FORCES = {"cg": "-forces_ksp_type cg\n-forces_pc_type jacobi\n-forces_ksp_rtol 1.0E-13\n-forces_ksp_atol 1.0E-50\n-forces_ksp_max_it 2000\n",
+                 "bcgs": "-forces_ksp_type bcgs\n-forces_pc_type none\n-forces_ksp_rtol 1.0E-13\n-forces_ksp_atol 1.0E-50\n-forces_ksp_max_it 2000\n",
+                 "amgx": ("config_version=2\nsolver(solv)=PCG\nsolv:max_iters=2000\nsolv:monitor_residual=1\nsolv:convergence=RELATIVE_INI\n"
+                          "solv:tolerance=1e-13\nsolv:norm=L2\nsolv:preconditioner(prec)=BLOCK_JACOBI\nprec:relaxation_factor=1.0\n")}
+
+
+@pytest.mark.parametrize("kind,P,bn,forces", [("2d_cylinder", 2, 1, "cg"), ("2d_cylinder", 3, 1, "bcgs"), ("3d_sphere", 2, 1, "amgx"),
+                                              ("moving_cylinder", 2, 1, "cg"), ("2d_cylinder", 2, 2, "cg")])
+def test_immersed_bodies_on_slabs_with_a_krylov_forces_solver(kind, P, bn, forces):
+    """decoupledibpm.cpp:75-80 hands whatever forces_solver.info says to createLinSolver, on any communicator.  On slabs the
+    ranks' parts of E BN H are summed once at assembly (csrc/ibm.hip: ib_adopt_summed) and every rank iterates on the same
+    replicated matrix: the single rank's forces to the solver tolerance, the same bits on every rank."""
+    from petibm_amd.navierstokes import DecoupledIBPMSolver
+    cfg, bodies, pose = _ib_case(kind)
+    if bn > 1:
+        cfg["parameters"]["BN"] = bn
+    dt = cfg["parameters"]["dt"]
+    nsteps = 3
+    fcfg = KRYLOV_FORCES[forces]
+
+    def run(s):
+        out = []
+        for step in range(1, nsteps + 1):
+            if pose is not None:
+                x, v = pose(step * dt)
+                s.moveBodies([x], [v])
+            s.advance()
+            U, p = s.getState()
+            f, avg = s.getForces()
+            out.append((U, p, f.copy(), avg.copy()))
+        return out
+
+    one = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=KSP_P, forces_cfg=fcfg)
+    ref = run(one)
+    direct = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=KSP_P, forces_cfg=FORCES)
+    refd = run(direct)
+    direct.destroy()
+
+    def rank_fn(r, uid):
+        s = DecoupledIBPMSolver(cfg, bodies=bodies, velocity_cfg=VEL, poisson_cfg=KSP_P, forces_cfg=fcfg, device=0, rank=r, nranks=P,
+                                uid=uid)
+        got = run(s)
+        cut = [(s.ownedVelocity(U), s.ownedPressure(p)) for U, p, _, _ in ref]
+        s.destroy()
+        return got, cut
+
+    res = _run_ranks(P, rank_fn)
+    for got, cut in res:
+        for (U, p, f, avg), (cU, cp), (_, _, rf, ravg), (_, _, df, _) in zip(got, cut, ref, refd):
+            assert np.abs(U - cU).max() <= 1e-8 * max(1.0, np.abs(cU).max())
+            assert np.abs(f - rf).max() <= 1e-7 * np.abs(rf).max()
+            assert np.abs(avg - ravg).max() <= 1e-7 * np.abs(ravg).max()
+            assert np.abs(f - df).max() <= 1e-6 * np.abs(df).max()   # ... and the direct solver's
+    for step in range(nsteps):
+        assert all(np.array_equal(res[0][0][step][2], r[0][step][2]) for r in res[1:])
+    one.destroy()
+
+
 def _three_block_axis(name, core, cells_core, cells_out, ratio):
     """stretched / uniform / stretched with continuous widths (the layout of flatplate3dRe100AoA30_GPU/config.yaml:30-68)"""
     h = 2.0 * core / cells_core
