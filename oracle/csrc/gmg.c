@@ -410,21 +410,26 @@ static void restrict_t(const level_t *f, const level_t *c, const double *rf, dou
                     if (k < 0 || k >= f->n[2]) continue;
                     const double wz = rw(f, 2, k, K);
                     if (wz == 0.0) continue;
+                    /* direction by direction (gmg.hip: rsum_x / restrict_plane): t = sum_x wx r, u = sum_y wy t, s = sum_z wz u */
+                    double u = 0.0;
                     for (i64 jr = j0; jr <= j1; ++jr) {
                         i64 j = jr;
                         if (f->tper[1]) j = (jr + f->n[1]) % f->n[1];
                         if (j < 0 || j >= f->n[1]) continue;
                         const double wy = rw(f, 1, j, J);
                         if (wy == 0.0) continue;
+                        double t = 0.0;
                         for (i64 ir = i0; ir <= i1; ++ir) {
                             i64 i = ir;
                             if (f->tper[0]) i = (ir + f->n[0]) % f->n[0];
                             if (i < 0 || i >= f->n[0]) continue;
                             const double wx = rw(f, 0, i, I);
                             if (wx == 0.0) continue;
-                            s = tacc(s, (wz * wy) * wx, rf[idx(f, i, j, k)]);
+                            t = tacc(t, wx, rf[idx(f, i, j, k)]);
                         }
+                        u = tacc(u, wy, t);
                     }
+                    s = tacc(s, wz, u);
                 }
                 bc[idx(c, I, J, K)] = s;
             }

@@ -1454,6 +1454,35 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     }
 }
 
+// The restriction is summed direction by direction (round 4, second half): x within a fine row, y over the rows of a plane, z over
+// the planes --
+//     t = ((wx0 r0 + wx1 r1) + wx2 r2) + wx3 r3 ;  u = sum_y wy t ;  s = sum_z wz u      (every + an fma: tacc)
+// -- 84 fused multiply-adds per coarse cell instead of 64 and 80 weight products, and in the marching kernels the row sums t are
+// shared by the two coarse planes and the two coarse rows a fine row feeds (the restriction was more than half of
+// k_resid_restrict_march's arithmetic).  Same order in every kernel and in oracle/csrc/gmg.c:restrict_t.
+__device__ __forceinline__ double rsum_x(const double4 &rw, double vl, double c0, double c1, double vr)
+{
+    return tacc(tacc(tacc(tacc(0.0, rw.x, vl), rw.y, c0), rw.z, c1), rw.w, vr);
+}
+// one fine plane's share of the coarse cells (I, J), (I, J + 1) of a marching kernel: the six fine rows' x sums, the two coarse rows'
+// y sums, then the plane's weight towards the lower (slots 2 / 3) and the upper (slots 0 / 1) coarse plane
+__device__ __forceinline__ void restrict_plane(const double4 &rw, const double (&wj)[2][4], const double (&vl)[6], const double (&c0)[6],
+                                               const double (&c1)[6], const double (&vr)[6], bool dolo, double wklo, bool dohi, double wkhi,
+                                               double (&lo)[2], double (&hi)[2])
+{
+    double t[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) t[r] = rsum_x(rw, vl[r], c0[r], c1[r], vr[r]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        double u = 0.0;
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) u = tacc(u, wj[a][b2], t[2 * a + b2]);
+        if (dolo) lo[a] = tacc(lo[a], wklo, u);
+        if (dohi) hi[a] = tacc(hi[a], wkhi, u);
+    }
+}
+
 // 1-D restriction stencil of coarse cell I in fixed 4-slot form: slot o <-> fine cell fst[I] - 1 + o (the left
 // neighbour, the one or two children, the right neighbour) with the weight that cell gives to I (0 where there
 // is no such fine cell or it does not feed I).  Indices are clamped so the loads are always legal; a zero
@@ -1528,18 +1557,16 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const double *pk = rf + fplane * (sk[c] - F.k0);
+        double u = 0.0;
 #pragma unroll
         for (int b2 = 0; b2 < 4; ++b2) {
-            const double wzy = wk[c] * wj[b2];
             const double *pj = pk + (int64_t)F.nx * sj[b2];
             double vl = __shfl_up(c1[c][b2], 1, 64), vr = __shfl_down(c0[c][b2], 1, 64);
             if (edgeL) vl = pj[fL];
             if (edgeR) vr = pj[fR];
-            s = tacc(s, (wzy * rw.x), vl);
-            s = tacc(s, (wzy * rw.y), c0[c][b2]);
-            s = tacc(s, (wzy * rw.z), c1[c][b2]);
-            s = tacc(s, (wzy * rw.w), vr);
+            u = tacc(u, wj[b2], rsum_x(rw, vl, c0[c][b2], c1[c][b2], vr));
         }
+        s = tacc(s, wk[c], u);
     }
     if (valid) bc[(int64_t)KK * C.nx * C.ny + (int64_t)J * C.nx + I] = s;
 }
@@ -1631,35 +1658,7 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
                 c1[r] = cc.y;
                 vr[r] = rowp[2];
             }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                if (dolo) {
-                    double s = lo[a];
-#pragma unroll
-                    for (int b2 = 0; b2 < 4; ++b2) {
-                        const double wzy = wklo * wj[a][b2];
-                        const int r = 2 * a + b2;
-                        s = tacc(s, (wzy * rw.x), vl[r]);
-                        s = tacc(s, (wzy * rw.y), c0[r]);
-                        s = tacc(s, (wzy * rw.z), c1[r]);
-                        s = tacc(s, (wzy * rw.w), vr[r]);
-                    }
-                    lo[a] = s;
-                }
-                if (dohi) {
-                    double s = hi[a];
-#pragma unroll
-                    for (int b2 = 0; b2 < 4; ++b2) {
-                        const double wzy = wkhi * wj[a][b2];
-                        const int r = 2 * a + b2;
-                        s = tacc(s, (wzy * rw.x), vl[r]);
-                        s = tacc(s, (wzy * rw.y), c0[r]);
-                        s = tacc(s, (wzy * rw.z), c1[r]);
-                        s = tacc(s, (wzy * rw.w), vr[r]);
-                    }
-                    hi[a] = s;
-                }
-            }
+            restrict_plane(rw, wj, vl, c0, c1, vr, dolo, wklo, dohi, wkhi, lo, hi);
         }
         if (!odd) {  // slot 3 of Klo is behind us: store it, the upper plane moves down
             if (Klo >= KA && Klo < KB) {
@@ -1827,35 +1826,7 @@ __global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__r
                 c1[r] = cc.y;
                 vr[r] = rowp[2];
             }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                if (dolo) {
-                    double s = lo[a];
-#pragma unroll
-                    for (int b2 = 0; b2 < 4; ++b2) {
-                        const double wzy = wklo * wj[a][b2];
-                        const int r = 2 * a + b2;
-                        s = tacc(s, (wzy * rw.x), vl[r]);
-                        s = tacc(s, (wzy * rw.y), c0[r]);
-                        s = tacc(s, (wzy * rw.z), c1[r]);
-                        s = tacc(s, (wzy * rw.w), vr[r]);
-                    }
-                    lo[a] = s;
-                }
-                if (dohi) {
-                    double s = hi[a];
-#pragma unroll
-                    for (int b2 = 0; b2 < 4; ++b2) {
-                        const double wzy = wkhi * wj[a][b2];
-                        const int r = 2 * a + b2;
-                        s = tacc(s, (wzy * rw.x), vl[r]);
-                        s = tacc(s, (wzy * rw.y), c0[r]);
-                        s = tacc(s, (wzy * rw.z), c1[r]);
-                        s = tacc(s, (wzy * rw.w), vr[r]);
-                    }
-                    hi[a] = s;
-                }
-            }
+            restrict_plane(rw, wj, vl, c0, c1, vr, dolo, wklo, dohi, wkhi, lo, hi);
         }
         if (!odd) {  // slot 3 of Klo is behind us: store it, the upper plane moves down
             if (Klo >= KA && Klo < KB) {
@@ -2231,13 +2202,16 @@ __global__ __launch_bounds__(1024) void k_coarse_tail(const Scalars *__restrict_
                 for (int c2 = 0; c2 < 4; ++c2) {
                     if (wk[c2] == 0.0) continue;
                     const double *pk = r + fplane * (sk[c2] - F.k0);
+                    double u = 0.0;
                     for (int b2 = 0; b2 < 4; ++b2) {
-                        const double wzy = wk[c2] * wj[b2];
-                        if (wzy == 0.0) continue;  // (a 2-D level: one row of the four; the terms left out are +-0)
+                        if (wj[b2] == 0.0) continue;  // (a 2-D level: one row of the four; the terms left out are +-0)
                         const double *pj = pk + F.nx * sj[b2];
+                        double t = 0.0;
 #pragma unroll
-                        for (int a2 = 0; a2 < 4; ++a2) sum = tacc(sum, (wzy * wi[a2]), pj[si[a2]]);
+                        for (int a2 = 0; a2 < 4; ++a2) t = tacc(t, wi[a2], pj[si[a2]]);
+                        u = tacc(u, wj[b2], t);
                     }
+                    sum = tacc(sum, wk[c2], u);
                 }
                 bc[q] = sum;
             }
@@ -2581,12 +2555,15 @@ __global__ __launch_bounds__(SM_NT) void k_small_down(const Scalars *__restrict_
                 for (int b2 = 0; b2 < 4; ++b2)
 #pragma unroll
                     for (int a2 = 0; a2 < 4; ++a2) rv[b2][a2] = r[sz * pos[2][c2] + sy * pos[1][b2] + pos[0][a2]];
+                double u = 0.0;
 #pragma unroll
                 for (int b2 = 0; b2 < 4; ++b2) {
-                    const double wzy = w[2][c2] * w[1][b2];
+                    double t = 0.0;
 #pragma unroll
-                    for (int a2 = 0; a2 < 4; ++a2) sum = tacc(sum, (wzy * w[0][a2]), rv[b2][a2]);
+                    for (int a2 = 0; a2 < 4; ++a2) t = tacc(t, w[0][a2], rv[b2][a2]);
+                    u = tacc(u, w[1][b2], t);
                 }
+                sum = tacc(sum, w[2][c2], u);
             }
             bc[(int64_t)Ic[0] + (int64_t)C.nx * (Ic[1] + (int64_t)C.ny * (Ic[2] - C.k0))] = sum;
         }

@@ -7,7 +7,7 @@ mkdir -p gpurun_out/$TAG
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 2400 python -m pytest tests -m gpu -x -q "$@" > gpurun_out/$TAG/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$TAG/pytest.log
+  timeout 2400 python -m pytest tests -m gpu -x -q -v -s "$@" > gpurun_out/$TAG/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$TAG/pytest.log
   tail -5 gpurun_out/$TAG/pytest.log
 fi
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
