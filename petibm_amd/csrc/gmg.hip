@@ -359,6 +359,29 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
 // otherwise).  Same expressions in the same order as modes 1 and 2: bit-identical (tools/fuse_lab.hip: 1.34 -> 0.78 ms
 // per 512^3 pair).  Levels that are whole on this rank, not periodic, 3-D, nx % 128 == 0, ny % 8 == 0.
 constexpr int FX = 128, FY = 8, FSX = FX + 2, FSY = FY + 2;
+// LDS rows of the marching kernels that hand 4-cell pieces to a lane (round 4, second half).  In the natural order a lane's
+// piece is 32 bytes and a ds_read_b128 / ds_write_b128 of half a piece across the lanes has a 32-byte stride: its 16-lane
+// groups use every other 16-byte slot of the 256-byte bank row -- a two-way conflict on every access (PMC: SQ_LDS_BANK_CONFLICT
+// half of SQ_LDS_IDX_ACTIVE in k_prolong_smooth2 and k_resid_restrict_march, the LDS busy half of their time).  Swizzled row:
+// the FIRST halves (cells 0, 1) of all pieces side by side, the SECOND halves (cells 2, 3) SWH doubles further on -- both
+// 16-byte strides; SWH = 40 slots = 8 (mod 16), so that an access whose lanes alternate between the halves (the restriction's
+// reads of the cells 2 l + 4, 2 l + 5) spreads over all sixteen slots too.  Cell X of a row sits at swz(X).
+constexpr int SWR = 160, SWH = 80;  // doubles per swizzled row (>= 2 SWH, rows 136 cells wide), offset of the second halves
+__device__ __forceinline__ int swz(int X) { return ((X >> 2) << 1) + (X & 1) + ((X >> 1) & 1) * SWH; }
+typedef double swv2 __attribute__((ext_vector_type(2)));
+typedef double swv4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void swz_put4(double *row, int X, const swv4 &v)  // X a multiple of 4
+{
+    const swv2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    *reinterpret_cast<swv2 *>(row + (X >> 1)) = a;
+    *reinterpret_cast<swv2 *>(row + (X >> 1) + SWH) = b;
+}
+__device__ __forceinline__ swv4 swz_get4(const double *row, int X)  // X a multiple of 4
+{
+    const swv2 a = *reinterpret_cast<const swv2 *>(row + (X >> 1)), b = *reinterpret_cast<const swv2 *>(row + (X >> 1) + SWH);
+    const swv4 v = {a[0], a[1], b[0], b[1]};
+    return v;
+}
 // Register budgets of the LDS-tiled kernels.  A 256-thread workgroup is four waves, one per SIMD, and the compiler sizes
 // its register use for whatever occupancy it happens to reach: k_level_march<8> took 144 VGPRs (three waves per SIMD),
 // k_presmooth2 142 (three), k_prolong_smooth 212 (two).  amdgpu_waves_per_eu(n) asks for n: the march fits 126 without
@@ -1175,11 +1198,14 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     if (S != nullptr && S->done) return;
     // x + P e on the plane the first step works on, the first step's result on the plane the second works on: two copies each
     // (one read, one written per iteration: a single barrier)
-    __shared__ __attribute__((aligned(32))) double XP[2][UY][UX];
-    __shared__ __attribute__((aligned(32))) double S1[2][UY][UX];
+    __shared__ __attribute__((aligned(32))) double XP[2][UY][SWR];  // (swizzled rows: cell X of a row at swz(X))
+    __shared__ __attribute__((aligned(32))) double S1[2][UY][SWR];
     __shared__ __attribute__((aligned(16))) double cs[3][UCY][UCX];
-    __shared__ double tcx[3][UX], tcy[3][UY];                    // cm, cp, 1/w of the region's columns and rows
-    __shared__ double4 pwl[UCX];                                 // x interpolation weights of the coarse columns
+    __shared__ __attribute__((aligned(16))) double tcx[3][SWR];  // cm, cp, 1/w of the region's columns (swizzled like the rows) ...
+    __shared__ double tcy[3][UY];                                // ... and of its rows
+    // x interpolation weights of a piece's two coarse columns (I0 - 3 + q0, q0 + 1 with q0 = 2 p + 1 for piece p of a row), as four
+    // 16-byte chunks per piece, chunk by chunk: a lane's reads have a 16-byte stride (a double4 per coarse column had 64: 4-way conflicts)
+    __shared__ __attribute__((aligned(16))) double pwc[4][UPR][2];
     __shared__ double tyw[2][UY];                                // y interpolation weights of the region's rows
     __shared__ int tyr[2][UY];                                   // ... and the coarse tile's rows they apply to
     typedef double v4 __attribute__((ext_vector_type(4)));
@@ -1202,9 +1228,9 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         int gi = i0 - 4 + e;
         if (px) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
         const bool in = gi >= 0 && gi < F.nx;
-        tcx[0][e] = in ? F.cmx[gi] : 0.0;
-        tcx[1][e] = in ? F.cpx[gi] : 0.0;
-        tcx[2][e] = in ? F.rwx[gi] : 0.0;
+        tcx[0][swz(e)] = in ? F.cmx[gi] : 0.0;
+        tcx[1][swz(e)] = in ? F.cpx[gi] : 0.0;
+        tcx[2][swz(e)] = in ? F.rwx[gi] : 0.0;
     }
     if (tid < UY) {
         const int gu = j0 - 2 + tid;
@@ -1222,10 +1248,15 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         tyw[0][tid] = in ? F.t[1].wpar[gj] : 0.0;
         tyw[1][tid] = in ? F.t[1].woth[gj] : 0.0;
     }
-    for (int e = tid; e < UCX; e += UNT) {
-        int I = I0 - 3 + e;
+    for (int e = tid; e < 2 * UPR; e += UNT) {
+        const int pp = e >> 1, q = 2 * pp + 1 + (e & 1);  // piece, coarse column of the tile
+        int I = I0 - 3 + q;
         if (px) I = I < 0 ? I + C.nx : (I >= C.nx ? I - C.nx : I);
-        pwl[e] = (I >= 0 && I < C.nx) ? F.tx.pw[I] : make_double4(0.0, 0.0, 0.0, 0.0);
+        const double4 w4 = (I >= 0 && I < C.nx) ? F.tx.pw[I] : make_double4(0.0, 0.0, 0.0, 0.0);
+        pwc[2 * (e & 1)][pp][0] = w4.x;
+        pwc[2 * (e & 1)][pp][1] = w4.y;
+        pwc[2 * (e & 1) + 1][pp][0] = w4.z;
+        pwc[2 * (e & 1) + 1][pp][1] = w4.w;
     }
     // ---- the thread's pieces: 0 the tile piece, 1 a piece of the margin (threads 0 .. UMARGIN - 1)
     int prow[2], pcol[2];
@@ -1295,7 +1326,10 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
                 continue;
             }
             const int R = prow[e], q0 = (pcol[e] >> 1) + 1;  // the piece's first coarse column in the tile (I0 - 3 + q0)
-            const double4 pwA = pwl[q0], pwB = pwl[q0 + 1];
+            const int pp = pcol[e] >> 2;
+            const swv2 wA0 = *reinterpret_cast<const swv2 *>(pwc[0][pp]), wA1 = *reinterpret_cast<const swv2 *>(pwc[1][pp]),
+                       wB0 = *reinterpret_cast<const swv2 *>(pwc[2][pp]), wB1 = *reinterpret_cast<const swv2 *>(pwc[3][pp]);
+            const double4 pwA = make_double4(wA0[0], wA0[1], wA1[0], wA1[1]), pwB = make_double4(wB0[0], wB0[1], wB1[0], wB1[1]);
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
@@ -1329,28 +1363,31 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         v4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const double cxm = tcx[0][X + c], cxp = tcx[1][X + c];
+            const double cxm = tcx[0][swz(X + c)], cxp = tcx[1][swz(X + c)];
             const double s4 = ((cxm + cxp) + cym) + cyp;
             out[c] = jweight(omega, -((s4 + czm) + czp));
         }
         return out;
     };
-    auto step = [&](int e, const double (*pl)[UX], const v4 &cc, const v4 &zm, const v4 &zp, const v4 &bv, double rwz, double czm,
+    auto step = [&](int e, const double (*pl)[SWR], const v4 &cc, const v4 &zm, const v4 &zp, const v4 &bv, double rwz, double czm,
                     double czp, const v4 &wr) -> v4 {
         const int R = prow[e], X = pcol[e];
         const double cym = tcy[0][R], cyp = tcy[1][R], rwy = tcy[2][R];
+        const v4 ylo = swz_get4(pl[R - 1], X), yhi = swz_get4(pl[R + 1], X);
+        const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X), rwx4 = swz_get4(tcx[2], X);
+        const double xleft = X > 0 ? pl[R][swz(X - 1)] : 0.0, xright = X + 4 < UX ? pl[R][swz(X + 4)] : 0.0;
         v4 out;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const double xcc = cc[c];
-            const double left = (c == 0) ? (X > 0 ? pl[R][X - 1] : 0.0) : cc[c > 0 ? c - 1 : 0];
-            const double right = (c == 3) ? (X + 4 < UX ? pl[R][X + 4] : 0.0) : cc[c < 3 ? c + 1 : 0];
-            const double cxm = tcx[0][X + c], cxp = tcx[1][X + c];
-            double t = (bv[c] * (tcx[2][X + c] * rwy)) * rwz;
+            const double left = (c == 0) ? xleft : cc[c > 0 ? c - 1 : 0];
+            const double right = (c == 3) ? xright : cc[c < 3 ? c + 1 : 0];
+            const double cxm = cxm4[c], cxp = cxp4[c];
+            double t = (bv[c] * (rwx4[c] * rwy)) * rwz;
             t = nacc(t, cxm, left);
             t = nacc(t, cxp, right);
-            t = nacc(t, cym, pl[R - 1][X + c]);
-            t = nacc(t, cyp, pl[R + 1][X + c]);
+            t = nacc(t, cym, ylo[c]);
+            t = nacc(t, cyp, yhi[c]);
             t = nacc(t, czm, zm[c]);
             t = nacc(t, czp, zp[c]);
             out[c] = jrelax(xcc, omc, wr[c], t);
@@ -1423,8 +1460,8 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (has[e]) {
-                *reinterpret_cast<v4 *>(&XP[nxt][prow[e]][pcol[e]]) = xpn[e];
-                *reinterpret_cast<v4 *>(&S1[nxt][prow[e]][pcol[e]]) = s1n[e];
+                swz_put4(XP[nxt][prow[e]], pcol[e], xpn[e]);
+                swz_put4(S1[nxt][prow[e]], pcol[e], s1n[e]);
             }
             xpm[e] = xpc[e];
             xpc[e] = xpn[e];
@@ -1579,6 +1616,7 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
 // the lower one).  A coarse value is still the sum over z slot, y slot, x slot in that order with the same weight
 // products, i.e. the bits of k_restrict_rows (out-of-range slots carry the weight 0 there and are skipped here).
 constexpr int RX = 128, RY = 16, RSX = RX + 8, RSY = RY + 2, RV4 = (RSX / 4) * RSY;
+
 __device__ __forceinline__ double rz_weight(const Tr1 &t, int kf, int K)
 {
     return t.par[kf] == K ? t.wpar[kf] : (t.oth[kf] == K ? t.woth[kf] : 0.0);
@@ -1589,7 +1627,7 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
     if (S != nullptr && S->done) return;
     __shared__ __attribute__((aligned(32))) double sp[2][RSY][RSX];
     typedef double v4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, lane = tid & 63, tw = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, tw = __builtin_amdgcn_readfirstlane(tid >> 6);  // (the wave's index: scalar, and so are J and the y weights)
     const Tile3 tb = tile_of_block();
     const int i0 = tb.x * RX, j0 = tb.y * RY;
     const int I = tb.x * (RX / 2) + lane, J = tb.y * (RY / 2) + 2 * tw;  // coarse cells (I, J) and (I, J + 1)
@@ -1683,16 +1721,17 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
 // k_restrict_march: the same bits.
 constexpr int QSY = RSY + 2;                 // rows of the iterate's tile: the residual's rows and one more on either side
 constexpr int QV4 = (RSX / 4) * QSY;         // its aligned 4-cell pieces (680: up to three per thread)
-__global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_resid_restrict_march(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
                                                               const double *__restrict__ b, const double *__restrict__ x,
                                                               double *__restrict__ bc, int CZ)
 {
     if (S != nullptr && S->done) return;
-    __shared__ __attribute__((aligned(32))) double xs[QSY][RSX];   // the iterate on the current plane: cols i0-4 .. i0+131, rows j0-2 .. j0+17
-    __shared__ __attribute__((aligned(32))) double rs[RSY][RSX];   // its residual: rows j0-1 .. j0+16
-    __shared__ double tcx[3][RSX], tcy[3][QSY];                    // cm, cp, w of the tile's columns and rows
+    __shared__ __attribute__((aligned(32))) double xs[QSY][SWR];   // the iterate on the current plane: cols i0-4 .. i0+131, rows j0-2 .. j0+17 (swizzled rows: swz)
+    __shared__ __attribute__((aligned(32))) double rs[RSY][SWR];   // its residual: rows j0-1 .. j0+16
+    __shared__ __attribute__((aligned(16))) double tcx[3][SWR];    // cm, cp, w of the tile's columns (swizzled like the rows) ...
+    __shared__ double tcy[3][QSY];                                 // ... and of its rows
     typedef double v4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, lane = tid & 63, tw = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, tw = __builtin_amdgcn_readfirstlane(tid >> 6);  // (the wave's index: scalar, and so are J and the y weights)
     const Tile3 tb = tile_of_block();
     const int i0 = tb.x * RX, j0 = tb.y * RY;
     const int I = tb.x * (RX / 2) + lane, J = tb.y * (RY / 2) + 2 * tw;  // coarse cells (I, J) and (I, J + 1)
@@ -1711,9 +1750,9 @@ __global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__r
         int gi = i0 - 4 + e;
         if (wx) gi = gi < 0 ? gi + F.nx : (gi >= F.nx ? gi - F.nx : gi);
         const bool in = gi >= 0 && gi < F.nx;
-        tcx[0][e] = in ? F.cmx[gi] : 0.0;
-        tcx[1][e] = in ? F.cpx[gi] : 0.0;
-        tcx[2][e] = in ? F.wx[gi] : 0.0;
+        tcx[0][swz(e)] = in ? F.cmx[gi] : 0.0;
+        tcx[1][swz(e)] = in ? F.cpx[gi] : 0.0;
+        tcx[2][swz(e)] = in ? F.wx[gi] : 0.0;
     }
     if (tid < QSY) {
         int gj = j0 - 2 + tid;
@@ -1760,7 +1799,7 @@ __global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__r
     auto put_x = [&](const v4 v[3]) {
 #pragma unroll
         for (int e = 0; e < 3; ++e)
-            if (mine[e]) *reinterpret_cast<v4 *>(&xs[prow[e]][pcol[e]]) = v[e];
+            if (mine[e]) swz_put4(xs[prow[e]], pcol[e], v[e]);
     };
     // the iterate of the thread's pieces on the planes kf - 1, kf, kf + 1, the plane kf + 2 and the right-hand side of plane
     // kf + 1 on their way
@@ -1790,22 +1829,25 @@ __global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__r
                 if (res[e] && in) {
                     const int R = prow[e], X = pcol[e];
                     const double cym = tcy[0][R], cyp = tcy[1][R], wyj = tcy[2][R];
+                    const v4 ylo = swz_get4(xs[R - 1], X), yhi = swz_get4(xs[R + 1], X);
+                    const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X), wx4 = swz_get4(tcx[2], X);
+                    const double xleft = X > 0 ? xs[R][swz(X - 1)] : 0.0, xright = X + 4 < RSX ? xs[R][swz(X + 4)] : 0.0;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const double xcc = xc[e][c];
-                        const double left = (c == 0) ? (X > 0 ? xs[R][X - 1] : 0.0) : xc[e][c > 0 ? c - 1 : 0];
-                        const double right = (c == 3) ? (X + 4 < RSX ? xs[R][X + 4] : 0.0) : xc[e][c < 3 ? c + 1 : 0];
+                        const double left = (c == 0) ? xleft : xc[e][c > 0 ? c - 1 : 0];
+                        const double right = (c == 3) ? xright : xc[e][c < 3 ? c + 1 : 0];
                         double sum = 0.0;
-                        sum = facc(sum, tcx[0][X + c], left, xcc);
-                        sum = facc(sum, tcx[1][X + c], right, xcc);
-                        sum = facc(sum, cym, xs[R - 1][X + c], xcc);
-                        sum = facc(sum, cyp, xs[R + 1][X + c], xcc);
+                        sum = facc(sum, cxm4[c], left, xcc);
+                        sum = facc(sum, cxp4[c], right, xcc);
+                        sum = facc(sum, cym, ylo[c], xcc);
+                        sum = facc(sum, cyp, yhi[c], xcc);
                         sum = facc(sum, czm, xm[e][c], xcc);
                         sum = facc(sum, czp, xp[e][c], xcc);
-                        out[c] = resid(bcur[e][c], sum * (tcx[2][X + c] * wyj), wzk);
+                        out[c] = resid(bcur[e][c], sum * (wx4[c] * wyj), wzk);
                     }
                 }
-                *reinterpret_cast<v4 *>(&rs[prow[e] - 1][pcol[e]]) = out;
+                swz_put4(rs[prow[e] - 1], pcol[e], out);
             }
         }
         __syncthreads();
@@ -1817,14 +1859,15 @@ __global__ __launch_bounds__(256) void k_resid_restrict_march(const Scalars *__r
             const bool dohi = Khi >= KA && Khi < KB, dolo = Klo >= KA && Klo < KB;
             const double wkhi = dohi ? rz_weight(F.t[2], kfw, Khi) : 0.0, wklo = dolo ? rz_weight(F.t[2], kfw, Klo) : 0.0;
             double vl[6], c0[6], c1[6], vr[6];
+            const int qc = swz(2 * lane + 4), ql = swz(2 * lane + 3), qr = swz(2 * lane + 6);  // the children, their left / right neighbours
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                const double *rowp = &rs[4 * tw + r][2 * lane + 4];
-                const double2 cc = *reinterpret_cast<const double2 *>(rowp);
-                vl[r] = rowp[-1];
+                const double *rowp = rs[4 * tw + r];
+                const double2 cc = *reinterpret_cast<const double2 *>(rowp + qc);
+                vl[r] = rowp[ql];
                 c0[r] = cc.x;
                 c1[r] = cc.y;
-                vr[r] = rowp[2];
+                vr[r] = rowp[qr];
             }
             restrict_plane(rw, wj, vl, c0, c1, vr, dolo, wklo, dohi, wkhi, lo, hi);
         }
