@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_level(const Scalars *__restrict__ S, Le
 // cells is loaded before the march (the 1-D arrays alone cost ~55 vector-memory instructions per thread and plane
 // otherwise).  Same expressions in the same order as modes 1 and 2: bit-identical (tools/fuse_lab.hip: 1.34 -> 0.78 ms
 // per 512^3 pair).  Levels that are whole on this rank, not periodic, 3-D, nx % 128 == 0, ny % 8 == 0.
-constexpr int FX = 128, FY = 8, FSX = FX + 2, FSY = FY + 2;
+constexpr int FX = 128, FY = 8, FSY = FY + 2;
 // LDS rows of the marching kernels that hand 4-cell pieces to a lane (round 4, second half).  In the natural order a lane's
 // piece is 32 bytes and a ds_read_b128 / ds_write_b128 of half a piece across the lanes has a 32-byte stride: its 16-lane
 // groups use every other 16-byte slot of the 256-byte bank row -- a two-way conflict on every access (PMC: SQ_LDS_BANK_CONFLICT
@@ -468,7 +468,10 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
     // that the neighbours' planes of r are kept by recurrence (w is exchanged, r never again); the sums cover the owned
     // planes [sum_lo, sum_hi) only; the partials of the launches of one cycle sit side by side (blk_base).
     if (S != nullptr && S->done) return;
-    __shared__ double x1[3][FSY][FSX];
+    // rows of the tile's plane in LDS: the cells i0 - 4 .. i0 + 131 in the swizzled order (swz: the thread's four cells at X = 4 + 4 tx as
+    // two aligned 16-byte halves with 16-byte lane strides; the x halo cells are X = 3 and X = 132) -- the natural order with one
+    // halo cell put a thread's cells at an odd offset: 8-byte accesses with a 32-byte stride, four-way bank conflicts
+    __shared__ __attribute__((aligned(32))) double x1[3][FSY][SWR];
     const double ua = UPD ? S->a : 0.0;
     double ur0 = 0.0, ur1 = 0.0;
     typedef double v4 __attribute__((ext_vector_type(4)));
@@ -552,12 +555,10 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
                 wn_hx = hx_ok ? jweight(omega, fdiag(qhx, czm, czp)) : 0.0;
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                x1p[c] = wn[c] * ((bv[c] * q4[c].rxy) * rwz);
-                x1[slot][ty + 1][4 * tx + 1 + c] = x1p[c];
-            }
-            x1[slot][hy_row + 1][hy_x + 1] = hy_ok ? wn_hy * ((hyv * qhy.rxy) * rwz) : 0.0;
-            if (tid < 16) x1[slot][hx_y + 1][hx_col + 1] = hx_ok ? wn_hx * ((hxv * qhx.rxy) * rwz) : 0.0;
+            for (int c = 0; c < 4; ++c) x1p[c] = wn[c] * ((bv[c] * q4[c].rxy) * rwz);
+            swz_put4(x1[slot][ty + 1], 4 + 4 * tx, x1p);
+            x1[slot][hy_row + 1][swz(4 + hy_x)] = hy_ok ? wn_hy * ((hyv * qhy.rxy) * rwz) : 0.0;
+            if (tid < 16) x1[slot][hx_y + 1][swz(4 + hx_col)] = hx_ok ? wn_hx * ((hxv * qhx.rxy) * rwz) : 0.0;
         }
         __syncthreads();
         const int kc = kk - 1;  // the plane whose x1 neighbours are complete now
@@ -565,27 +566,31 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
         const int sc = (kc + 3) % 3;
         const double wzk = L.wz[kc], rwz = L.rwz[kc], czm = L.cmz[kc], czp = L.cpz[kc];
         v4 out;
+        // in-plane neighbours: the rows above and below as the thread's aligned pieces, the cells left and right of its four
+        // (its own values from the registers: the same numbers the LDS holds)
+        const v4 ylo = swz_get4(x1[sc][ty], 4 + 4 * tx), yhi = swz_get4(x1[sc][ty + 2], 4 + 4 * tx);
+        const double xleft = x1[sc][ty + 1][swz(3 + 4 * tx)], xright = x1[sc][ty + 1][swz(8 + 4 * tx)];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int lx = 4 * tx + 1 + c;
             const FCell &q = q4[c];
             const double xcc = x1c[c];
+            const double left = (c == 0) ? xleft : x1c[c > 0 ? c - 1 : 0], right = (c == 3) ? xright : x1c[c < 3 ? c + 1 : 0];
             // missing neighbours: zero coefficients; the LDS halo cells and x1m / x1p outside the domain hold 0
             if (RES) {
                 double sum = 0.0;
-                sum = facc(sum, q.cxm, x1[sc][ty + 1][lx - 1], xcc);
-                sum = facc(sum, q.cxp, x1[sc][ty + 1][lx + 1], xcc);
-                sum = facc(sum, q.cym, x1[sc][ty][lx], xcc);
-                sum = facc(sum, q.cyp, x1[sc][ty + 2][lx], xcc);
+                sum = facc(sum, q.cxm, left, xcc);
+                sum = facc(sum, q.cxp, right, xcc);
+                sum = facc(sum, q.cym, ylo[c], xcc);
+                sum = facc(sum, q.cyp, yhi[c], xcc);
                 sum = facc(sum, czm, x1m[c], xcc);
                 sum = facc(sum, czp, x1p[c], xcc);
                 out[c] = resid(bprev[c], sum * q.vxy, wzk);
             } else {
                 double t = (bprev[c] * q.rxy) * rwz;
-                t = nacc(t, q.cxm, x1[sc][ty + 1][lx - 1]);
-                t = nacc(t, q.cxp, x1[sc][ty + 1][lx + 1]);
-                t = nacc(t, q.cym, x1[sc][ty][lx]);
-                t = nacc(t, q.cyp, x1[sc][ty + 2][lx]);
+                t = nacc(t, q.cxm, left);
+                t = nacc(t, q.cxp, right);
+                t = nacc(t, q.cym, ylo[c]);
+                t = nacc(t, q.cyp, yhi[c]);
                 t = nacc(t, czm, x1m[c]);
                 t = nacc(t, czp, x1p[c]);
                 out[c] = jrelax(xcc, omc, wc[c], t);
@@ -625,13 +630,13 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
 // same order (modes 2 and 3 bit-identical; mode 8's sums are grouped by tile instead of by line segment, i.e. equal to
 // rounding).
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 8 || MODE == 2) ? 3 : PIB_WAVES_MARCH))) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE != 0 ? 3 : PIB_WAVES_MARCH))) void k_level_march(const Scalars *__restrict__ S, LevelDev L, double omega,
                                                      const double *__restrict__ b, const double *__restrict__ xi,
                                                      double *__restrict__ xo, const double *__restrict__ pin_sum,
                                                      double *__restrict__ part, int part_stride, int FZ, int dlo, int dhi)
 {
     if (S != nullptr && S->done) return;
-    __shared__ double sp[2][FSY][FSX];
+    __shared__ __attribute__((aligned(32))) double sp[2][FSY][SWR];  // (swizzled rows, see k_presmooth2: cells i0 - 4 .. i0 + 131)
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     // owned planes [L.k0, L.k0 + L.nk) of the level (a z-slab or a part of one); the vectors point at the first of them,
@@ -689,10 +694,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 8 
         }
         const v4 braw = bv;
         if (MODE != 0 && pin_sum != nullptr && kk == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = xc[c];
-        sp[slot][hy_row + 1][hy_x + 1] = hyv;
-        if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hxv;
+        swz_put4(sp[slot][ty + 1], 4 + 4 * tx, xc);
+        sp[slot][hy_row + 1][swz(4 + hy_x)] = hyv;
+        if (tid < 16) sp[slot][hx_y + 1][swz(4 + hx_col)] = hxv;
         __syncthreads();
         const double wzk = L.wz[kk], rwz = L.rwz[kk], czm = L.cmz[kk], czp = L.cpz[kk];
         v4 out;
@@ -701,17 +705,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 8 
 #pragma unroll
             for (int c = 0; c < 4; ++c) wr[c] = jweight(omega, fdiag(q4[c], czm, czp));
         }
+        // in-plane neighbours: the rows above and below as aligned pieces, the cells left and right of the thread's four (its own
+        // values from the registers)
+        const v4 ylo = swz_get4(sp[slot][ty], 4 + 4 * tx), yhi = swz_get4(sp[slot][ty + 2], 4 + 4 * tx);
+        const double xleft = sp[slot][ty + 1][swz(3 + 4 * tx)], xright = sp[slot][ty + 1][swz(8 + 4 * tx)];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int lx = 4 * tx + 1 + c;
             const FCell &q = q4[c];
             const double xcc = xc[c];
+            const double nb_l = (c == 0) ? xleft : xc[c > 0 ? c - 1 : 0], nb_r = (c == 3) ? xright : xc[c < 3 ? c + 1 : 0];
             if (MODE == 2 || MODE == 8) {
                 double t = (bv[c] * q.rxy) * rwz;
-                t = nacc(t, q.cxm, sp[slot][ty + 1][lx - 1]);
-                t = nacc(t, q.cxp, sp[slot][ty + 1][lx + 1]);
-                t = nacc(t, q.cym, sp[slot][ty][lx]);
-                t = nacc(t, q.cyp, sp[slot][ty + 2][lx]);
+                t = nacc(t, q.cxm, nb_l);
+                t = nacc(t, q.cxp, nb_r);
+                t = nacc(t, q.cym, ylo[c]);
+                t = nacc(t, q.cyp, yhi[c]);
                 t = nacc(t, czm, zm[c]);
                 t = nacc(t, czp, zp[c]);
                 out[c] = jrelax(xcc, omc, wr[c], t);
@@ -723,10 +731,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE == 8 
                 continue;
             }
             double sum = 0.0;
-            sum = facc(sum, q.cxm, sp[slot][ty + 1][lx - 1], xcc);
-            sum = facc(sum, q.cxp, sp[slot][ty + 1][lx + 1], xcc);
-            sum = facc(sum, q.cym, sp[slot][ty][lx], xcc);
-            sum = facc(sum, q.cyp, sp[slot][ty + 2][lx], xcc);
+            sum = facc(sum, q.cxm, nb_l, xcc);
+            sum = facc(sum, q.cxp, nb_r, xcc);
+            sum = facc(sum, q.cym, ylo[c], xcc);
+            sum = facc(sum, q.cyp, yhi[c], xcc);
             sum = facc(sum, czm, zm[c], xcc);
             sum = facc(sum, czp, zp[c], xcc);
             if (MODE == 0) {  // y = A x (the Krylov product of the stencil twin), x.y over the owned planes on request
@@ -964,7 +972,7 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
                                                         int part_stride, int dlo, int dhi)
 {
     if (S != nullptr && S->done) return;
-    __shared__ __attribute__((aligned(16))) double sp[2][FSY][FSX];
+    __shared__ __attribute__((aligned(32))) double sp[2][FSY][SWR];  // (swizzled rows, see k_presmooth2: cells i0 - 4 .. i0 + 131)
     __shared__ __attribute__((aligned(16))) double cs[3][PCY][PCX];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
@@ -1084,10 +1092,9 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
         out[3] = o.c[3] + s3;
         if (halo) {
             const int slot = k & 1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) sp[slot][ty + 1][4 * tx + 1 + c] = out[c];
-            sp[slot][hy_row + 1][hy_x + 1] = hy_ok ? o.hy + sy : 0.0;
-            if (tid < 16) sp[slot][hx_y + 1][hx_col + 1] = hx_ok ? o.hx + sx : 0.0;
+            swz_put4(sp[slot][ty + 1], 4 + 4 * tx, out);
+            sp[slot][hy_row + 1][swz(4 + hy_x)] = hy_ok ? o.hy + sy : 0.0;
+            if (tid < 16) sp[slot][hx_y + 1][swz(4 + hx_col)] = hx_ok ? o.hx + sx : 0.0;
         }
         return out;
     };
@@ -1128,16 +1135,18 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PROLONG) void k_prolo
 #pragma unroll
             for (int c = 0; c < 4; ++c) wr[c] = jweight(omega, fdiag(q4[c], czm, czp));
         }
+        const v4 ylo = swz_get4(sp[slot][ty], 4 + 4 * tx), yhi = swz_get4(sp[slot][ty + 2], 4 + 4 * tx);
+        const double xleft = sp[slot][ty + 1][swz(3 + 4 * tx)], xright = sp[slot][ty + 1][swz(8 + 4 * tx)];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int lx = 4 * tx + 1 + c;
             const FCell &q = q4[c];
             const double xcc = xcur[c];
+            const double nb_l = (c == 0) ? xleft : xcur[c > 0 ? c - 1 : 0], nb_r = (c == 3) ? xright : xcur[c < 3 ? c + 1 : 0];
             double t = (bv[c] * q.rxy) * rwz;
-            t = nacc(t, q.cxm, sp[slot][ty + 1][lx - 1]);
-            t = nacc(t, q.cxp, sp[slot][ty + 1][lx + 1]);
-            t = nacc(t, q.cym, sp[slot][ty][lx]);
-            t = nacc(t, q.cyp, sp[slot][ty + 2][lx]);
+            t = nacc(t, q.cxm, nb_l);
+            t = nacc(t, q.cxp, nb_r);
+            t = nacc(t, q.cym, ylo[c]);
+            t = nacc(t, q.cyp, yhi[c]);
             t = nacc(t, czm, zm[c]);
             t = nacc(t, czp, zp[c]);
             out[c] = jrelax(xcc, omc, wr[c], t);
@@ -1625,7 +1634,7 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
                                                         const double *__restrict__ rf, double *__restrict__ bc, int CZ)
 {
     if (S != nullptr && S->done) return;
-    __shared__ __attribute__((aligned(32))) double sp[2][RSY][RSX];
+    __shared__ __attribute__((aligned(32))) double sp[2][RSY][SWR];  // (swizzled rows: swz)
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, tw = __builtin_amdgcn_readfirstlane(tid >> 6);  // (the wave's index: scalar, and so are J and the y weights)
     const Tile3 tb = tile_of_block();
@@ -1655,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
         if (wy) gj = gj < 0 ? gj + F.ny : (gj >= F.ny ? gj - F.ny : gj);
         ok[e] = idx < RV4 && gi >= 0 && gi < F.nx && gj >= 0 && gj < F.ny;
         goff[e] = (int64_t)gj * F.nx + gi;
-        loff[e] = idx < RV4 ? row * RSX + 4 * cx : -1;
+        loff[e] = idx < RV4 ? row * SWR + 2 * cx : -1;  // the piece's first half in its (swizzled) row
     }
     const int kf0 = 2 * KA - 1, kf1 = 2 * (KB - 1) + 2;  // fine planes that feed [KA, KB) (global, both ends inclusive)
     const v4 zero = {0, 0, 0, 0};
@@ -1676,7 +1685,7 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
             double *dst = &sp[slot][0][0];
 #pragma unroll
             for (int e = 0; e < 3; ++e)
-                if (loff[e] >= 0) *reinterpret_cast<v4 *>(dst + loff[e]) = pre[e];
+                if (loff[e] >= 0) swz_put4(dst + loff[e], 0, pre[e]);
         }
         __syncthreads();
         if (kf + 1 <= kf1 && (kf + 1 < F.nzg || wz)) fetch(kf + 1);
@@ -1687,14 +1696,15 @@ __global__ __launch_bounds__(256) void k_restrict_march(const Scalars *__restric
             const double wkhi = dohi ? rz_weight(F.t[2], kfw, Khi) : 0.0, wklo = dolo ? rz_weight(F.t[2], kfw, Klo) : 0.0;
             // the six fine rows of the two coarse rows
             double vl[6], c0[6], c1[6], vr[6];
+            const int qc = swz(2 * lane + 4), ql = swz(2 * lane + 3), qr = swz(2 * lane + 6);  // the children, their left / right neighbours
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                const double *rowp = &sp[slot][4 * tw + r][2 * lane + 4];
-                const double2 cc = *reinterpret_cast<const double2 *>(rowp);
-                vl[r] = rowp[-1];
+                const double *rowp = sp[slot][4 * tw + r];
+                const double2 cc = *reinterpret_cast<const double2 *>(rowp + qc);
+                vl[r] = rowp[ql];
                 c0[r] = cc.x;
                 c1[r] = cc.y;
-                vr[r] = rowp[2];
+                vr[r] = rowp[qr];
             }
             restrict_plane(rw, wj, vl, c0, c1, vr, dolo, wklo, dohi, wkhi, lo, hi);
         }
