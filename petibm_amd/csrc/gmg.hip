@@ -1217,6 +1217,12 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     __shared__ __attribute__((aligned(16))) double pwc[4][UPR][2];
     __shared__ double tyw[2][UY];                                // y interpolation weights of the region's rows
     __shared__ int tyr[2][UY];                                   // ... and the coarse tile's rows they apply to
+    // The per-plane entries of the z tables (interpolation weights, 1 / w, the two face coefficients) of the planes this
+    // workgroup touches, staged once: inside the march the compiler reads such a (workgroup-uniform) entry through the vector
+    // path -- the kernel stores to global memory, so no scalar load -- and waits for it on the spot: three memory round trips at
+    // the head of the three stages of EVERY plane.  From LDS it is a broadcast read.  Entry e <-> plane l0 - 4 + e.
+    constexpr int ZT = 144;  // >= planes per workgroup + 6
+    __shared__ double tz[5][ZT];
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
     const Tile3 tb = tile_of_block();
@@ -1232,6 +1238,18 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     xo -= (int64_t)F.k0 * plane;
     xc -= (int64_t)C.k0 * cplane;
     const bool px = F.per & 1, py = F.per & 2, pz = F.per & 4;  // (operator and transfers wrap alike: the caller checks)
+    for (int e = tid; e < ZT; e += UNT) {
+        const int kp = l0 - 4 + e;
+        const bool in = pz || (kp >= 0 && kp < F.nzg);
+        const int kw = pz ? (kp < 0 ? kp + F.nzg : (kp >= F.nzg ? kp - F.nzg : kp)) : kp;
+        const bool use = in && e < FZ + 6;
+        tz[0][e] = use ? F.t[2].wpar[kw] : 0.0;
+        tz[1][e] = use ? F.t[2].woth[kw] : 0.0;
+        tz[2][e] = use ? F.rwz[kw] : 0.0;
+        tz[3][e] = use ? F.cmz[kw] : 0.0;
+        tz[4][e] = use ? F.cpz[kw] : 0.0;
+    }
+    const int zt0 = l0 - 4;
     // ---- tables of the region
     for (int e = tid; e < UX; e += UNT) {
         int gi = i0 - 4 + e;
@@ -1314,6 +1332,29 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
             dst[e] = (kin && I >= 0 && I < C.nx && J >= 0 && J < C.ny) ? pc[(int64_t)J * C.nx + I] : 0.0;
         }
     };
+    // the same in two halves, for the march: the values are requested at the top of an iteration and go to the ring slot at its end
+    // (as one piece the loads were waited for on the spot -- a memory round trip at the head of every other plane)
+    auto stage_load = [&](int K, double cv[2]) {
+        const bool kin = pz || (K >= 0 && K < C.nzg);
+        const int Kw = pz ? (K < 0 ? K + C.nzg : (K >= C.nzg ? K - C.nzg : K)) : K;
+        const double *pc = xc + (int64_t)(kin ? Kw : 0) * cplane;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * UNT;
+            const int row = e / UCX, cx = e - row * UCX;
+            int I = I0 - 3 + cx, J = J0 - 2 + row;
+            if (px) I = I < 0 ? I + C.nx : (I >= C.nx ? I - C.nx : I);
+            if (py) J = J < 0 ? J + C.ny : (J >= C.ny ? J - C.ny : J);
+            cv[u] = (e < UCX * UCY && kin && I >= 0 && I < C.nx && J >= 0 && J < C.ny) ? pc[(int64_t)J * C.nx + I] : 0.0;
+        }
+    };
+    auto stage_store = [&](int K, const double cv[2]) {
+        double *dst = &cs[((K % 3) + 3) % 3][0][0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + u * UNT < UCX * UCY) dst[tid + u * UNT] = cv[u];
+    };
+    static_assert(UCX * UCY <= 2 * UNT, "two coarse values per thread");
     auto fetch = [&](const double *v, int k, const bool *which, v4 out[2]) {
         const bool in = inz(k);
         const double *pl = v + (int64_t)zw(k) * plane;
@@ -1324,9 +1365,8 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     // z slot and y slot -- the order of k_prolong_rows / k_prolong_smooth
     auto correct = [&](int k, const v4 old[2], v4 out[2]) {
         const bool in = inz(k);
-        const int kw = zw(k);
         const int Kp = k >> 1, Ko = (k & 1) ? Kp + 1 : Kp - 1;
-        const double wk[2] = {in ? uniform(F.t[2].wpar[kw]) : 0.0, in ? uniform(F.t[2].woth[kw]) : 0.0};
+        const double wk[2] = {uniform(tz[0][k - zt0]), uniform(tz[1][k - zt0])};  // (zero outside the domain)
         const int Ks[2] = {((Kp % 3) + 3) % 3, ((Ko % 3) + 3) % 3};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -1422,14 +1462,18 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     fetch(xi, l0 - 2, ok, anext);
     fetch(b, l0 - 3, first, bnext);
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending on entry either (see the wait inside the march)
     for (int k = l0 - 4; k < lend; ++k) {
         const bool do1 = k + 1 >= l0 - 1 && k + 1 <= lend && inz(k + 1), do2 = k >= l0;
         // loads of the next iteration go out first: the coarse plane the plane after next reaches (into the ring slot no plane
         // of this iteration reads), the old iterate three planes ahead, b two
-        need_stage(k + 3);
 #pragma unroll
         for (int e = 0; e < 2; ++e) a2[e] = anext[e];
         const v4 b1[2] = {bnext[0], bnext[1]};  // b of plane k + 1
+        const int want = ((k + 3) & 1) ? ((k + 3) >> 1) + 1 : ((k + 3) >> 1);  // (need_stage(k + 3): at most one plane per iteration)
+        const bool staging = staged < want;
+        double cv[2] = {0.0, 0.0};
+        if (staging) stage_load(++staged, cv);
         if (k + 1 < lend) {
             fetch(xi, k + 3, ok, anext);
             fetch(b, k + 2, first, bnext);
@@ -1437,8 +1481,7 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         correct(k + 2, a2, xpn);
         const int cur = k & 1, nxt = cur ^ 1;
         if (do1) {
-            const int kw = zw(k + 1);
-            const double rwz = uniform(F.rwz[kw]), czm = uniform(F.cmz[kw]), czp = uniform(F.cpz[kw]);
+            const double rwz = uniform(tz[2][k + 1 - zt0]), czm = uniform(tz[3][k + 1 - zt0]), czp = uniform(tz[4][k + 1 - zt0]);
             if (czm != key1_zm || czp != key1_zp) {  // (workgroup-uniform)
                 key1_zm = czm, key1_zp = czp;
 #pragma unroll
@@ -1449,8 +1492,14 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         } else {
             s1n[0] = s1n[1] = zero;
         }
+        // Loads and stores share one counter (vmcnt) and may complete out of order with each other: the wait for the planes
+        // requested at the top of this iteration, which the compiler would place at the top of the NEXT one, would also wait for
+        // the store below -- issued a few instructions earlier, a full write latency on every plane.  Waiting HERE (on every
+        // path: the builtin, which the compiler's own wait insertion takes into account), where those loads are long done, lets the
+        // store fly during the whole next iteration.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         if (do2) {
-            const double rwz = uniform(F.rwz[k]), czm = uniform(F.cmz[k]), czp = uniform(F.cpz[k]);
+            const double rwz = uniform(tz[2][k - zt0]), czm = uniform(tz[3][k - zt0]), czp = uniform(tz[4][k - zt0]);
             if (czm != key2_zm || czp != key2_zp) {
                 key2_zm = czm, key2_zp = czp;
                 w2 = weights(0, czm, czp);
@@ -1478,6 +1527,7 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
             s1c[e] = s1n[e];
             bcur[e] = b1[e];
         }
+        if (staging) stage_store(staged, cv);
         __syncthreads();
     }
     if (DOTS) {
@@ -1791,6 +1841,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         pcol[e] = 4 * cx;
     }
     const int kf0 = 2 * KA - 1, kf1 = 2 * (KB - 1) + 2;  // fine planes that feed [KA, KB) (both ends inclusive)
+    // the per-plane table entries of the planes this workgroup walks, staged once (k_prolong_smooth2 says why): w, the two face
+    // coefficients, the plane's restriction weights towards its upper and its lower coarse plane.  Entry e <-> fine plane kf0 + e.
+    constexpr int ZT = 80;  // >= 2 CZ + 2 planes (CZ <= 32)
+    __shared__ double tz[5][ZT];
+    for (int e = tid; e < ZT; e += 256) {
+        const int kf = kf0 + e;
+        const bool in = (wz || (kf >= 0 && kf < F.nzg)) && kf <= kf1;
+        const int kw = wz ? (kf < 0 ? kf + F.nzg : (kf >= F.nzg ? kf - F.nzg : kf)) : kf;
+        const int Kh = (kf & 1) ? (kf + 1) / 2 : kf / 2;
+        tz[0][e] = in ? F.wz[kw] : 0.0;
+        tz[1][e] = in ? F.cmz[kw] : 0.0;
+        tz[2][e] = in ? F.cpz[kw] : 0.0;
+        tz[3][e] = in ? rz_weight(F.t[2], kw, Kh) : 0.0;
+        tz[4][e] = in ? rz_weight(F.t[2], kw, Kh - 1) : 0.0;
+    }
     const v4 zero = {0, 0, 0, 0};
     auto zwrap = [&](int kf) { return wz ? (kf < 0 ? kf + F.nzg : (kf >= F.nzg ? kf - F.nzg : kf)) : kf; };
     auto inz = [&](int kf) { return wz || (kf >= 0 && kf < F.nzg); };
@@ -1822,16 +1887,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     put_x(xc);
     __syncthreads();
     double lo[2] = {0.0, 0.0}, hi[2] = {0.0, 0.0};
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending on entry either
     for (int kf = kf0; kf <= kf1; ++kf) {
         const bool in = inz(kf);
-        const int kfw = zwrap(kf);
         if (kf + 1 <= kf1) {
             fetch_x(kf + 2, xn);
             fetch_b(kf + 1, bnext);
         }
         // ---- the residual of plane kf (xs holds the iterate of plane kf)
         {
-            const double wzk = in ? F.wz[kfw] : 0.0, czm = in ? F.cmz[kfw] : 0.0, czp = in ? F.cpz[kfw] : 0.0;
+            const double wzk = tz[0][kf - kf0], czm = tz[1][kf - kf0], czp = tz[2][kf - kf0];
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
                 if (!mine[e] || prow[e] < 1 || prow[e] > RSY) continue;
@@ -1867,7 +1932,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int Khi = odd ? (kf + 1) / 2 : kf / 2, Klo = Khi - 1;  // kf is slot 0 / 1 of Khi and slot 2 / 3 of Klo
         if (in) {
             const bool dohi = Khi >= KA && Khi < KB, dolo = Klo >= KA && Klo < KB;
-            const double wkhi = dohi ? rz_weight(F.t[2], kfw, Khi) : 0.0, wklo = dolo ? rz_weight(F.t[2], kfw, Klo) : 0.0;
+            const double wkhi = dohi ? tz[3][kf - kf0] : 0.0, wklo = dolo ? tz[4][kf - kf0] : 0.0;
             double vl[6], c0[6], c1[6], vr[6];
             const int qc = swz(2 * lane + 4), ql = swz(2 * lane + 3), qr = swz(2 * lane + 6);  // the children, their left / right neighbours
 #pragma unroll
@@ -1881,6 +1946,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
             restrict_plane(rw, wj, vl, c0, c1, vr, dolo, wklo, dohi, wkhi, lo, hi);
         }
+        // (the planes requested at the top of this iteration are waited for HERE, on every path and through the builtin, so that the
+        // compiler does not place that wait behind the stores below, which would then be waited for too: see k_prolong_smooth2)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         if (!odd) {  // slot 3 of Klo is behind us: store it, the upper plane moves down
             if (Klo >= KA && Klo < KB) {
                 double *dst = bc + (int64_t)(Klo - C.k0) * cplane + (int64_t)J * C.nx + I;
