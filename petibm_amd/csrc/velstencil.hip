@@ -506,27 +506,55 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
             if (hx_ok) hxv = V.opc * (pd[off_hx] * hxv);
         }
     };
-    double zn[4] = {0.0, 0.0, 0.0, 0.0}, hyc, hxc, hyn = 0.0, hxn = 0.0;
+    // With the Jacobi sweep folded into the read (scaled: the input is M^-1 p, formed as the planes come in) the products
+    // opc (dinv x) used to stand right behind their loads, i.e. every load of a step was waited for on the spot after all (ISA:
+    // four to five s_waitcnt vmcnt(0) per plane).  The raw values are kept instead -- x and 1 / a_ii of the plane two ahead and of
+    // the next plane's halo cells -- and multiplied at the END of the step, a whole step after their loads went out (same
+    // expression, same bits).  The plane's two z coefficients, read behind the barrier as vector loads, travel a step ahead too.
+    auto raw4 = [&](const double *v, int kp, double (&o)[4]) {
+        const double *pl = v + (int64_t)kp * sz;
+        if (V4) {
+            const v4 t = *reinterpret_cast<const v4 *>(pl + row + ci[0]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = t[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = pl[row + ci[c]];
+        }
+    };
+    double zn[4] = {0.0, 0.0, 0.0, 0.0}, znd[4] = {1.0, 1.0, 1.0, 1.0}, hyc, hxc, hyn = 0.0, hxn = 0.0, hynd = 1.0, hxnd = 1.0;
     load4(x + (int64_t)(k0 - 1) * sz, k0 - 1, zm);
     load4(x + (int64_t)k0 * sz, k0, xc);
     load_halo(k0, hyc, hxc);
     load4(x + (int64_t)(k0 + 1) * sz, k0 + 1, zp);
     if (!EPI && acc != nullptr) loadp(k0, pc);
     if (EPI) loade(k0, eb, ed, em);
+    double zneg = V.lneg[f][2][k0], zpos = V.lpos[f][2][k0], znegn = 0.0, zposn = 0.0;
     for (int k = k0; k < kend; ++k) {
         const int slot = k & 1;
         if (k + 1 < kend) {
-            load4(x + (int64_t)(k + 2) * sz, k + 2, zn);
-            load_halo(k + 1, hyn, hxn);
+            raw4(x, k + 2, zn);
+            if (scaled) raw4(V.dinv, k + 2, znd);
+            {
+                const double *pl = x + (int64_t)(k + 1) * sz;
+                hyn = hy_ok ? pl[off_hy] : 0.0;
+                hxn = hx_ok ? pl[off_hx] : 0.0;
+                if (scaled) {
+                    const double *pd = V.dinv + (int64_t)(k + 1) * sz;
+                    hynd = hy_ok ? pd[off_hy] : 1.0;
+                    hxnd = hx_ok ? pd[off_hx] : 1.0;
+                }
+            }
             if (!EPI && acc != nullptr) loadp(k + 1, pn);
             if (EPI) loade(k + 1, nb4, nd4, nm4);
+            znegn = V.lneg[f][2][k + 1];
+            zposn = V.lpos[f][2][k + 1];
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) sp[slot][ty + 1][lx[c]] = xc[c];
         sp[slot][hy_row + 1][hy_lx] = hyc;
         if (tid < 16) sp[slot][hx_y + 1][hx_lx] = hxc;
         __syncthreads();
-        const double zneg = V.lneg[f][2][k], zpos = V.lpos[f][2][k];
         double out[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -592,6 +620,12 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
                     if (cin[c]) py[ci[c]] = out[c];
             }
         }
+        if (scaled && k + 1 < kend) {  // the sweep on what came in during this step (load4 / load_halo's expression)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zn[c] = V.opc * (znd[c] * zn[c]);
+            if (hy_ok) hyn = V.opc * (hynd * hyn);
+            if (hx_ok) hxn = V.opc * (hxnd * hxn);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             zm[c] = xc[c];
@@ -606,6 +640,8 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         }
         hyc = hyn;
         hxc = hxn;
+        zneg = znegn;
+        zpos = zposn;
     }
 }
 
