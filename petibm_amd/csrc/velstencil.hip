@@ -530,6 +530,7 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
     if (!EPI && acc != nullptr) loadp(k0, pc);
     if (EPI) loade(k0, eb, ed, em);
     double zneg = V.lneg[f][2][k0], zpos = V.lpos[f][2][k0], znegn = 0.0, zposn = 0.0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending on entry either
     for (int k = k0; k < kend; ++k) {
         const int slot = k & 1;
         if (k + 1 < kend) {
@@ -607,6 +608,17 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
                     if (V.dot_mode == 2) acc[1] += out[c] * out[c];
                 }
         }
+        // Everything this step requested is waited for HERE, ahead of the stores (and on every path, through the builtin, which the
+        // compiler's own wait insertion takes into account): loads and stores share one counter and may complete out of order
+        // with each other, so a wait behind the stores -- where the compiler would put it, at the first use of the loaded values
+        // -- waits for the stores too, a write latency on every plane.  Like this they are in flight during the whole next step.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if (scaled && k + 1 < kend) {  // the sweep on what came in during this step (load4 / load_halo's expression)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zn[c] = V.opc * (znd[c] * zn[c]);
+            if (hy_ok) hyn = V.opc * (hynd * hyn);
+            if (hx_ok) hxn = V.opc * (hxnd * hxn);
+        }
         if (EDGES ? jok : jin) {
             double *py = (EPI ? E.pm : y) + (int64_t)k * sz + row;
             if (V4 && cin[0] && cin[3]) {
@@ -619,12 +631,6 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
                 for (int c = 0; c < 4; ++c)
                     if (cin[c]) py[ci[c]] = out[c];
             }
-        }
-        if (scaled && k + 1 < kend) {  // the sweep on what came in during this step (load4 / load_halo's expression)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) zn[c] = V.opc * (znd[c] * zn[c]);
-            if (hy_ok) hyn = V.opc * (hynd * hyn);
-            if (hx_ok) hxn = V.opc * (hxnd * hxn);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
