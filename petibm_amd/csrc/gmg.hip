@@ -1667,6 +1667,115 @@ __global__ __launch_bounds__(256) void k_restrict_rows(const Scalars *__restrict
     if (valid) bc[(int64_t)KK * C.nx * C.ny + (int64_t)J * C.nx + I] = s;
 }
 
+// ---- restriction, z-marching form for ANY aggregation (selective coarsening on a stretched mesh: lone cells among the pairs).
+// The row kernel above loads sixteen fine rows per coarse cell -- every fine row by up to four waves (two coarse rows, two coarse
+// planes) -- and is bound by the vector-memory issue rate (0.38 ms for the 25 M-cell level of the config-5 plate: 0.55 TB/s; it was
+// 30 % of that case's V-cycle).  Here a wave owns ONE coarse row (64 coarse cells per lane group) and walks up through the fine
+// planes: a plane's four fine rows are loaded once and summed in x and y (rsum_x, then the row weights) into u, and u goes with
+// the plane's weight into the one or two coarse planes it feeds -- three running sums per lane, a coarse plane stored when the walk
+// has left it behind.  The order of the sums is the oracle's (z ascending outermost, then y, then x): the bits of k_restrict_rows.
+// Levels that are whole on this rank and have no periodic z seam; a fine plane's rows are requested a plane ahead.
+__global__ __launch_bounds__(256) void k_restrict_zmarch(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
+                                                         const double *__restrict__ rf, double *__restrict__ bc, int CZ, int vec_ok)
+{
+    if (S != nullptr && S->done) return;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int J = (int)blockIdx.x * 4 + w;
+    if (J >= C.ny) return;  // (no barrier in this kernel: a wave may leave)
+    const int KA = (int)blockIdx.z * CZ, KB = min(KA + CZ, C.nzg);
+    double wj[4];
+    int sj[4];
+    rs1d4(F.t[1], J, F.ny, F.tper & 2, wj, sj);
+    const int Iraw = (int)blockIdx.y * 64 + lane;
+    const bool valid = Iraw < C.nx;
+    const int I = valid ? Iraw : C.nx - 1;
+    const int2 fc = F.tx.fc[I];
+    const double4 rw = F.tx.rw[I];
+    const bool pair = (fc.y == 2);
+    const int f0 = fc.x, f1 = pair ? f0 + 1 : f0;
+    const bool wrapx = F.tper & 1;
+    const bool edgeL = (lane == 0 && (I > 0 || wrapx)), edgeR = (lane == 63 && I + 1 < C.nx) || (wrapx && Iraw == C.nx - 1);
+    const int fL = (f0 > 0) ? f0 - 1 : F.nx - 1, fR = (f1 + 1 < F.nx) ? f1 + 1 : 0;  // wrapped only when wrapx (else unused)
+    const int64_t fplane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
+    const bool vec = vec_ok && __all(pair && !(f0 & 1));
+    const Tr1 tz = F.t[2];
+    // fine planes that feed [KA, KB): from the lower neighbour of KA's first child to the first child of KB (its weight towards
+    // KB - 1), clipped to the level
+    const int k_lo = max(tz.fst[KA] - 1, 0), k_hi = min(KB < C.nzg ? tz.fst[KB] : F.nzg - 1, F.nzg - 1);
+    double c0[4], c1[4], el[4], er[4], n0[4], n1[4], nl[4], nr[4];
+    int Kp = 0, Ko = 0, Kpn = 0, Kon = 0;       // the plane's parent and other coarse plane, its weights towards them: they travel with
+    double wp = 0.0, wo = 0.0, wpn = 0.0, won = 0.0;  // the rows (read behind them they would be waited for at once, and the rows with them)
+    auto fetch = [&](int k, double (&a0)[4], double (&a1)[4], double (&al)[4], double (&ar)[4], int &kp, int &ko, double &vp, double &vo) {
+        kp = tz.par[k];
+        ko = tz.oth[k];
+        vp = tz.wpar[k];
+        vo = tz.woth[k];
+        const double *pk = rf + fplane * k;
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) {
+            const double *pj = pk + (int64_t)F.nx * sj[b2];
+            if (vec) {
+                const double2 v = *reinterpret_cast<const double2 *>(pj + f0);
+                a0[b2] = v.x;
+                a1[b2] = v.y;
+            } else {
+                a0[b2] = pj[f0];
+                a1[b2] = pj[f1];
+            }
+            al[b2] = edgeL ? pj[fL] : 0.0;
+            ar[b2] = edgeR ? pj[fR] : 0.0;
+        }
+    };
+    // three running sums: the coarse planes Kb, Kb + 1, Kb + 2
+    int Kb = KA - 1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    auto store = [&](int K, double v) {
+        if (valid && K >= KA && K < KB) bc[(int64_t)K * cplane + (int64_t)J * C.nx + I] = v;
+    };
+    if (k_lo <= k_hi) fetch(k_lo, c0, c1, el, er, Kp, Ko, wp, wo);
+    for (int k = k_lo; k <= k_hi; ++k) {
+        if (k + 1 <= k_hi) fetch(k + 1, n0, n1, nl, nr, Kpn, Kon, wpn, won);
+        double u = 0.0;
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) {
+            double vl = __shfl_up(c1[b2], 1, 64), vr = __shfl_down(c0[b2], 1, 64);
+            if (edgeL) vl = el[b2];
+            if (edgeR) vr = er[b2];
+            u = tacc(u, wj[b2], rsum_x(rw, vl, c0[b2], c1[b2], vr));
+        }
+        // the walk leaves plane Kb behind when this plane's parent is two above it (a plane touches its parent and one neighbour)
+        while (Kp > Kb + 1) {
+            store(Kb, a0);
+            a0 = a1;
+            a1 = a2;
+            a2 = 0.0;
+            ++Kb;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {  // the parent first or the other first: ascending coarse plane is not an order of a sum --
+            const int K = t ? Ko : Kp;  // each coarse plane gets this fine plane's ONE term
+            const double wt = t ? wo : wp;
+            if (K == Kb) a0 = tacc(a0, wt, u);
+            else if (K == Kb + 1) a1 = tacc(a1, wt, u);
+            else if (K == Kb + 2) a2 = tacc(a2, wt, u);
+        }
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) {
+            c0[b2] = n0[b2];
+            c1[b2] = n1[b2];
+            el[b2] = nl[b2];
+            er[b2] = nr[b2];
+        }
+        Kp = Kpn;
+        Ko = Kon;
+        wp = wpn;
+        wo = won;
+    }
+    store(Kb, a0);
+    store(Kb + 1, a1);
+    store(Kb + 2, a2);
+}
+
 // ---- restriction, z-marching form (fully paired 3-D levels: every coarse cell has the children 2I, 2I+1 in all three
 // directions).  The row kernel above is bound by the vector-memory issue rate (sixteen row loads per coarse cell, every
 // fine row fetched by four waves): 0.68 ms per 512^3 launch against 0.15 ms of HBM time.  Here a workgroup owns 64 x 8
@@ -2966,8 +3075,20 @@ static int launch_restrict(const pib_solver *s, const GridLevel &f, const GridLe
         PIB_HIP(hipGetLastError());
         return 0;
     }
-    const RowGrid r = row_grid(c.n[1] * (c.k1 - c.k0), c.n[0], 64);  // aligned 64-lane chunks + edge loads (62 overlapping lanes measured slower here)
     const int vec_ok = (f.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(rf) & 15u) == 0) ? 1 : 0;
+    // any aggregation, the level whole on this rank, no periodic z seam, 3-D, large enough to fill the chip with one wave per coarse
+    // row and z-chunk: the z-marching form
+    if (s->cfg.march_restrict && !(f.tper & 4) && f.k0 == 0 && f.k1 == f.n[2] && c.k0 == 0 && c.k1 == c.n[2] && f.n[1] > 1 && c.n[2] >= 4 &&
+        c.n[0] * c.n[1] * c.n[2] >= std::min<int64_t>((int64_t)1 << 17, s->cfg.march_min_cells)) {  // (the tests lower the bound)
+        // coarse planes per workgroup: so that there are about four workgroups per CU
+        const int64_t wg_plane = ((c.n[1] + 3) / 4) * ((c.n[0] + 63) / 64);
+        int CZ = (int)std::max<int64_t>(2, std::min<int64_t>(32, c.n[2] * wg_plane / 1024));
+        hipLaunchKernelGGL(k_restrict_zmarch, dim3((unsigned)((c.n[1] + 3) / 4), (unsigned)((c.n[0] + 63) / 64), (unsigned)((c.n[2] + CZ - 1) / CZ)),
+                           dim3(256), 0, q, S, dev_of(f), dev_of(c), rf, bc, CZ, vec_ok);
+        PIB_HIP(hipGetLastError());
+        return 0;
+    }
+    const RowGrid r = row_grid(c.n[1] * (c.k1 - c.k0), c.n[0], 64);  // aligned 64-lane chunks + edge loads (62 overlapping lanes measured slower here)
     hipLaunchKernelGGL(k_restrict_rows, r.grid, dim3(64, 4), 0, q, S, dev_of(f), dev_of(c), rf, bc, r.ngroups, r.per_xcd, vec_ok);
     PIB_HIP(hipGetLastError());
     return 0;

@@ -406,6 +406,47 @@ def test_random_mesh_multigrid_forms_are_bit_identical(seed):
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("PIB_FUZZ_SEEDS", "12")))))
+def test_random_mesh_general_restriction_march_is_bit_identical(seed):
+    """gmg.hip k_restrict_zmarch (restriction of ANY aggregation -- lone cells among the pairs of a stretched mesh -- as a z-march:
+    a wave per coarse row, a fine plane's rows loaded once) against k_restrict_rows on random 3-D meshes, stretched and periodic in
+    x / y at random: the same bits in the iterates and the residual histories."""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    from test_gpu_parity import gmg_cfg
+    rng = np.random.default_rng(1000 + seed)
+    n = [int(rng.integers(20, 70)), int(rng.integers(10, 40)), int(rng.integers(9, 40))]
+    w = []
+    for d in range(3):
+        r = float(rng.choice([1.0, 1.04, 1.1, 0.93]))
+        ww = r ** np.arange(n[d])
+        if rng.random() < 0.5:  # a refined block in the middle, stretched far field on both sides
+            m = n[d] // 3
+            ww = np.concatenate([1.08 ** np.arange(m, 0, -1), np.ones(n[d] - 2 * m), 1.08 ** np.arange(1, m + 1)])
+        w.append(ww / ww.sum())
+    per = [bool(rng.random() < 0.3), bool(rng.random() < 0.3), False]
+    pre, post = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    dt = 0.01
+    N = int(np.prod(n))
+    b = rng.uniform(-1, 1, N)
+    b -= b.mean()
+    out = []
+    for march in (0, 1):
+        s = LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post, extra=f"pib_march_min_cells=0\npib_march_restrict={march}\n"
+                                                                                 "pib_fuse_small_levels=0\npib_coarse_tail=0\n"))
+        if any(per):
+            s.setPeriodic(per)
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(N)
+        s.solve(x, b)
+        assert s.getReason() > 0, (seed, march)
+        out.append((x, s.getIters(), s.getResidualHistory().copy()))
+        s.destroy()
+    assert out[0][1] == out[1][1], seed
+    assert np.array_equal(out[0][2], out[1][2]), seed
+    assert np.array_equal(out[0][0], out[1][0]), seed
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("PIB_FUZZ_SEEDS", "12")))))
 def test_random_paired_levels_marching_kernels_are_bit_identical(seed):
     """The LDS-tiled marching kernels of the large levels (pre-smoothing pair, residual + restriction in one march,
     prolongation + post-smoothing in one march, the XCD bands) on random fully paired meshes -- mild stretching, walls and
