@@ -163,14 +163,18 @@ __global__ __launch_bounds__(256) void k_bgj_diag(int64_t np, int64_t kb, double
 constexpr int GLB = GB + 1;
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bgj_block(int64_t np, int64_t kb, double *__restrict__ W, const double *__restrict__ P,
-                                                   const int *__restrict__ bad)
+                                                   const int *__restrict__ bad, int64_t only = -1, int64_t skip = -1)
 {
     typedef double v4d __attribute__((ext_vector_type(4)));
     typedef double v2d __attribute__((ext_vector_type(2)));
     if (*bad) return;
     const int64_t K = kb / GB;
-    const int64_t J = (MODE == 1) ? K : (int64_t)blockIdx.x, I = (MODE == 0) ? K : (MODE == 1 ? (int64_t)blockIdx.x : (int64_t)blockIdx.y);
+    // MODE 2 with the look-ahead of dense_setup: `only` >= 0 -- the one block (only, only), a 1 x 1 grid; `skip` >= 0 -- every block
+    // but (skip, skip), which the look-ahead has updated (and inverted) already
+    const int64_t J = (MODE == 1) ? K : ((MODE == 2 && only >= 0) ? only : (int64_t)blockIdx.x),
+                  I = (MODE == 0) ? K : (MODE == 1 ? (int64_t)blockIdx.x : ((only >= 0) ? only : (int64_t)blockIdx.y));
     if ((MODE != 1 && J == K) || (MODE != 0 && I == K)) return;
+    if (MODE == 2 && I == skip && J == skip) return;
     __shared__ double Bs[GB][GLB];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, g = l >> 4;
     const double *Ap = (MODE == 0) ? P : W + I * GB * np + kb;        // left factor and its leading dimension
@@ -262,6 +266,13 @@ void dense_release(pib_solver *s)
     if (s->dense_work) (void)hipFree(s->dense_work);
     if (s->dense_bad) (void)hipFree(s->dense_bad);
     if (s->dense_pad) (void)hipFree(s->dense_pad);
+    if (s->dense_stream2) {
+        (void)hipStreamDestroy(s->dense_stream2);
+        for (int e = 0; e < 3; ++e)
+            if (s->dense_ev[e]) (void)hipEventDestroy(s->dense_ev[e]);
+        s->dense_stream2 = nullptr;
+        s->dense_ev[0] = s->dense_ev[1] = s->dense_ev[2] = nullptr;
+    }
     s->dense_pad = nullptr;
     s->dense_graph = nullptr;
     s->dense_inv = s->dense_work = nullptr;
@@ -292,8 +303,14 @@ int dense_setup(pib_solver *s)
         PIB_HIP(hipMalloc(&s->dense_inv, bytes));
         PIB_HIP(hipMalloc(&s->dense_work, bytes));
         PIB_HIP(hipMalloc(&s->dense_bad, sizeof(int) + sizeof(double) * 2));  // flag + (8-byte aligned) max |diagonal|
-        if (blocked) PIB_HIP(hipMalloc(&s->dense_pad, sizeof(double) * ((size_t)np * (size_t)np + GB * GB)));
+        if (blocked) PIB_HIP(hipMalloc(&s->dense_pad, sizeof(double) * ((size_t)np * (size_t)np + 2 * GB * GB)));
         s->dense_n = n;
+    }
+    if (blocked && s->dense_stream2 == nullptr) {
+        int prio_lo = 0, prio_hi = 0;  // (the look-ahead's one workgroup should not queue behind the trailing update's thousands)
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        PIB_HIP(hipStreamCreateWithPriority(&s->dense_stream2, hipStreamNonBlocking, prio_hi));
+        for (int e = 0; e < 3; ++e) PIB_HIP(hipEventCreateWithFlags(&s->dense_ev[e], hipEventDisableTiming));
     }
     double *M = s->dense_work;
     PIB_HIP(hipMemsetAsync(M, 0, bytes, q));
@@ -315,14 +332,32 @@ int dense_setup(pib_solver *s)
     // several threads at once proved unreliable in the HIP runtime (sporadic garbage in the eliminated matrix)
     auto eliminate = [&]() {
         if (blocked) {
-            double *W = s->dense_pad, *P = s->dense_pad + (size_t)np * (size_t)np;
+            // Look-ahead (round 4): the inversion of a 64 x 64 diagonal block is one workgroup walking 64 pivots (50 us) and stood
+            // between the trailing updates (47 us each on the matrix cores): 54 + 54 serial stages for the 3456 force unknowns of the
+            // config-5 plate, 6 ms per factorisation, every time step of a moving body.  The next diagonal block only needs ITS
+            // OWN update: it is updated alone and inverted on a second stream (into the other of two P buffers) while the trailing
+            // update of the whole matrix -- less that block -- runs on the first.  The same operations on every block: same bits.
+            double *W = s->dense_pad, *Pb[2] = {s->dense_pad + (size_t)np * (size_t)np, s->dense_pad + (size_t)np * (size_t)np + GB * GB};
             const unsigned nblk = (unsigned)(np / GB);
+            hipStream_t q2 = s->dense_stream2;
             hipLaunchKernelGGL(k_bgj_pack, dim3((unsigned)np), dim3(256), 0, q, n, np, M, W);
-            for (int64_t kb = 0; kb < np; kb += GB) {
-                hipLaunchKernelGGL(k_bgj_diag, dim3(1), dim3(256), 0, q, np, kb, W, P, s->dense_bad, maxdiag);
-                hipLaunchKernelGGL(k_bgj_block<0>, dim3(nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad);
-                hipLaunchKernelGGL(k_bgj_block<2>, dim3(nblk, nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad);
-                hipLaunchKernelGGL(k_bgj_block<1>, dim3(nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad);
+            hipLaunchKernelGGL(k_bgj_diag, dim3(1), dim3(256), 0, q, np, (int64_t)0, W, Pb[0], s->dense_bad, maxdiag);
+            for (int64_t kb = 0, K = 0; kb < np; kb += GB, ++K) {
+                double *P = Pb[K & 1];
+                const bool ahead = kb + GB < np;
+                hipLaunchKernelGGL(k_bgj_block<0>, dim3(nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad, (int64_t)-1, (int64_t)-1);
+                if (ahead) {
+                    (void)hipEventRecord(s->dense_ev[0], q);
+                    (void)hipStreamWaitEvent(q2, s->dense_ev[0], 0);
+                    hipLaunchKernelGGL(k_bgj_block<2>, dim3(1, 1), dim3(256), 0, q2, np, kb, W, P, s->dense_bad, K + 1, (int64_t)-1);
+                    (void)hipEventRecord(s->dense_ev[1], q2);  // column K of row block K + 1 has been read: block<1> may overwrite it
+                    hipLaunchKernelGGL(k_bgj_diag, dim3(1), dim3(256), 0, q2, np, kb + GB, W, Pb[(K + 1) & 1], s->dense_bad, maxdiag);
+                    (void)hipEventRecord(s->dense_ev[2], q2);
+                }
+                hipLaunchKernelGGL(k_bgj_block<2>, dim3(nblk, nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad, (int64_t)-1, ahead ? K + 1 : (int64_t)-1);
+                if (ahead) (void)hipStreamWaitEvent(q, s->dense_ev[1], 0);
+                hipLaunchKernelGGL(k_bgj_block<1>, dim3(nblk), dim3(256), 0, q, np, kb, W, P, s->dense_bad, (int64_t)-1, (int64_t)-1);
+                if (ahead) (void)hipStreamWaitEvent(q, s->dense_ev[2], 0);
             }
             hipLaunchKernelGGL(k_bgj_unpack, dim3((unsigned)n), dim3(256), 0, q, n, np, W, s->dense_inv, s->dense_bad);
             return;

@@ -72,13 +72,66 @@ struct IbState {
     double *g_nf = nullptr, *y_nf = nullptr, *r2 = nullptr;  // [nf]
     std::vector<void *> owned;      // operators of the current body position (released by every re-assembly)
     std::vector<void *> persistent; // forces and friends: live as long as the bodies
+    // A moving body re-assembles its operators every time step (rigidkinematics.cpp:75-79): some thirty device allocations of
+    // nearly the same sizes as the step before.  hipFree synchronises the device and hipMalloc costs a fraction of a millisecond:
+    // together they were most of the 7 ms a config-5-size plate spent "moving the body".  Blocks released by a re-assembly wait
+    // in `pool` (capacity, pointer) and the next one takes the smallest block that fits (at most twice the request).
+    std::vector<std::pair<size_t, void *>> pool;
+    std::vector<std::pair<void *, size_t>> owned_cap;  // capacity of the blocks in `owned` that came through ib_malloc
 };
+
+// a device block of at least `bytes`: from the pool when one fits, else a new one (rounded up so that next step's slightly larger
+// request still fits); tracked in ib->owned
+static int ib_malloc(IbState *ib, void **p, size_t bytes)
+{
+    bytes = std::max<size_t>(bytes, 16);
+    size_t best = (size_t)-1;
+    int at = -1;
+    for (int i = 0; i < (int)ib->pool.size(); ++i) {
+        const size_t cap = ib->pool[(size_t)i].first;
+        if (cap >= bytes && cap <= 2 * bytes + 65536 && cap < best) {
+            best = cap;
+            at = i;
+        }
+    }
+    size_t cap = 0;
+    if (at >= 0) {
+        *p = ib->pool[(size_t)at].second;
+        cap = ib->pool[(size_t)at].first;
+        ib->pool.erase(ib->pool.begin() + at);
+    } else {
+        cap = bytes + bytes / 8 + 256;  // head room for the next position of the body
+        PIB_HIP(hipMalloc(p, cap));
+    }
+    ib->owned.push_back(*p);
+    ib->owned_cap.emplace_back(*p, cap);
+    return 0;
+}
+// the blocks of the last assembly go back to the pool (those of unknown capacity -- handed over by other modules -- are freed)
+static void ib_recycle(IbState *ib)
+{
+    for (void *p : ib->owned) {
+        size_t cap = 0;
+        for (const auto &pc : ib->owned_cap)
+            if (pc.first == p) cap = pc.second;
+        if (cap > 0) ib->pool.emplace_back(cap, p);
+        else (void)hipFree(p);
+    }
+    ib->owned.clear();
+    ib->owned_cap.clear();
+    // blocks that found no taker for a while would pile up: keep the pool bounded
+    while (ib->pool.size() > 96) {
+        (void)hipFree(ib->pool.front().second);
+        ib->pool.erase(ib->pool.begin());
+    }
+}
 
 void ib_release(IbState *ib)
 {
     if (ib == nullptr) return;
     if (ib->fsol) pib_destroy(ib->fsol);
     for (void *p : ib->owned) (void)hipFree(p);
+    for (const auto &pc : ib->pool) (void)hipFree(pc.second);
     for (void *p : ib->persistent) (void)hipFree(p);
     delete ib;
 }
@@ -291,9 +344,10 @@ static int blocks_for(int64_t n) { return (int)std::min<int64_t>(4096, std::max<
 template <class T>
 static int dev_alloc(IbState *ib, T **p, int64_t count)
 {
-    PIB_HIP(hipMalloc(p, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
+    void *q = nullptr;
+    PIB_CHK(ib_malloc(ib, &q, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
+    *p = static_cast<T *>(q);
     PIB_MEMSET(*p, 0, sizeof(T) * (size_t)std::max<int64_t>(count, 1));
-    ib->owned.push_back(*p);
     return 0;
 }
 
@@ -549,8 +603,7 @@ extern "C" {
 static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
 {
     using namespace pib;
-    for (void *p : ib->owned) (void)hipFree(p);
-    ib->owned.clear();
+    ib_recycle(ib);
     const int dim = ns->D.dim;
     const int64_t total = ib->I.npts;
     int err = 0;
@@ -626,16 +679,14 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
         size_t tmp_bytes = 0;
         void *tmp = nullptr;
         PIB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)nnz, 0, 64, q));
-        PIB_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-        ib->owned.push_back(tmp);
+        PIB_CHK(ib_malloc(ib, &tmp, tmp_bytes));
         PIB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, i_in, i_out, (size_t)nnz, 0, 64, q));
         hipLaunchKernelGGL(k_ib_hfill, dim3(blocks_for(nnz)), dim3(256), 0, q, nnz, nf, k_out, i_out, ib->val, ib->hrow, ib->hval, head);
         PIB_HIP(hipGetLastError());
         size_t tmp2_bytes = 0;
         void *tmp2 = nullptr;
         PIB_HIP(rocprim::inclusive_scan(nullptr, tmp2_bytes, head, pos, (size_t)nnz, rocprim::plus<int32_t>(), q));
-        PIB_HIP(hipMalloc(&tmp2, std::max<size_t>(tmp2_bytes, 16)));
-        ib->owned.push_back(tmp2);
+        PIB_CHK(ib_malloc(ib, &tmp2, tmp2_bytes));
         PIB_HIP(rocprim::inclusive_scan(tmp2, tmp2_bytes, head, pos, (size_t)nnz, rocprim::plus<int32_t>(), q));
         int32_t m = 0;
         if (nnz > 0) PIB_HIP(hipMemcpyAsync(&m, pos + (nnz - 1), sizeof(int32_t), hipMemcpyDeviceToHost, q));

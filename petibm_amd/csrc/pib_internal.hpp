@@ -451,6 +451,8 @@ struct pib_solver {
     void *d_tail_tab = nullptr;         // ... and the 1-D tables of the tail's levels packed for its LDS copy
     double *dense_pad = nullptr;  // the matrix padded to a multiple of the block order, inverted in place by the blocked elimination (+ one block of scratch)
     hipGraphExec_t dense_graph = nullptr;  // the dense_n elimination launches
+    hipStream_t dense_stream2 = nullptr;   // blocked elimination: the look-ahead's stream (the next diagonal block) and its events
+    hipEvent_t dense_ev[3] = {nullptr, nullptr, nullptr};
     int64_t dense_n = 0;
     // results of the last solve
     int iters = 0, reason = 0;
