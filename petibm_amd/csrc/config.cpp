@@ -246,6 +246,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.fuse_chebyshev_update = std::atoi(d.get("default", "pib_fuse_chebyshev_update", "1").c_str());
     c.blocked_direct_solve = std::atoi(d.get("default", "pib_blocked_direct_solve", "1").c_str());
     c.accumulate_unscaled_x = std::atoi(d.get("default", "pib_accumulate_unscaled_x", "1").c_str());
+    c.bicgstab_merge_r = std::atoi(d.get("default", "pib_bicgstab_merge_r", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
     c.detect_structure = std::atoi(d.get("default", "pib_detect_structure", "1").c_str());
@@ -385,6 +386,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_fuse_chebyshev_update", v)) c.fuse_chebyshev_update = std::atoi(v.c_str());
     if (get("pib_blocked_direct_solve", v)) c.blocked_direct_solve = std::atoi(v.c_str());
     if (get("pib_accumulate_unscaled_x", v)) c.accumulate_unscaled_x = std::atoi(v.c_str());
+    if (get("pib_bicgstab_merge_r", v)) c.bicgstab_merge_r = std::atoi(v.c_str());
     if (get("pib_matrix_free_poisson", v)) c.matrix_free_poisson = std::atoi(v.c_str());
     if (get("pib_agglomerate_below", v)) c.agglomerate_below = std::atoi(v.c_str());
     if (get("pib_detect_structure", v)) c.detect_structure = std::atoi(v.c_str());

@@ -1419,12 +1419,17 @@ struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*b
     // (stationary) Jacobi sweep, x = x0 + M^-1 y once at the end (k_b_flush_x) -- which takes the dinv and x streams out
     // of this pass: 56 instead of 64 B/row.  x then differs from the general path's by rounding (the residual recurrence
     // does not see x), so this rides with the fused sums (`pib_fuse_bicgstab_dots`), not with the bit-identical route.
+    // t != nullptr (`pib_bicgstab_merge_r`, with y): the residual update the previous iteration owes, r = s - omega t, is formed
+    // HERE (s is read for y anyway) and stored for the next s = r - alpha v: OpBFUpdateR's pass (s, t, rp in, r out) is gone, its two
+    // sums come out of the second product's five (k_finalize_post<7>).  Same expression: r has the bits OpBFUpdateR would store.
     static constexpr int NRED = 0;
     const double *r, *v, *dinv, *sv;
     double *p, *x, *y;
     double omega_pc;
     double beta, ob, xa, xo;
     int pend;
+    const double *t = nullptr;
+    double *rw = nullptr;
     __device__ void prepare(const Scalars *S)
     {
         beta = S->b;
@@ -1436,9 +1441,16 @@ struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*b
     template <int W>
     __device__ void apply(int64_t i, double (&)[1]) const
     {
-        Pack<W> vr = ld<W>(r, i), vv = ld<W>(v, i), vp = ld<W>(p, i);
+        Pack<W> vr, vv = ld<W>(v, i), vp = ld<W>(p, i);
+        if (!(pend && t != nullptr)) vr = ld<W>(r, i);
         if (pend && y != nullptr) {
             Pack<W> vs = ld<W>(sv, i), vy = ld<W>(y, i);
+            if (t != nullptr) {
+                const Pack<W> vt = ld<W>(t, i);
+#pragma unroll
+                for (int k = 0; k < W; ++k) vr.v[k] = vs.v[k] - xo * vt.v[k];
+                st<W>(rw, i, vr);
+            }
 #pragma unroll
             for (int k = 0; k < W; ++k) vy.v[k] = (vy.v[k] + xa * vp.v[k]) + xo * vs.v[k];
             st<W>(y, i, vy);
@@ -1637,6 +1649,19 @@ __global__ __launch_bounds__(256) void k_finalize_post(Scalars *__restrict__ S, 
             S->xpend = 1;
             b_s_end(S, hist, conv_is_its);
         }
+        if (POST == 7) {  // omega and the end of the iteration at once: r = s - omega t is owed too (OpBFUpdateP::t), its sums
+            // follow from the second product's five -- red[3..7] = s.t, t.t, s.s, rp.s, rp.t:
+            // |r|^2 = s.s - omega (2 s.t - omega t.t), r.rp = rp.s - omega rp.t
+            b_s_omega(S);
+            const double om = S->omega;
+            const double r2 = S->red[5] - om * (2.0 * S->red[3] - om * S->red[4]);
+            S->red[0] = r2 > 0.0 ? r2 : (r2 != r2 ? r2 : 0.0);
+            S->red[1] = S->red[6] - om * S->red[7];
+            S->xalpha = S->alpha;
+            S->xomega = S->omega;
+            S->xpend = 1;
+            b_s_end(S, hist, conv_is_its);
+        }
     }
 }
 template <int POST>
@@ -1744,6 +1769,8 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     const bool fused_dots = lean && s->cfg.fuse_bicgstab_dots;
     // ... and x accumulated before the Jacobi sweep (OpBFUpdateP::y) in the vector the general path keeps M^-1 p in
     double *Y = (fused_dots && s->cfg.accumulate_unscaled_x) ? s->vec(7) : nullptr;
+    // ... and the residual update merged into the next p-update, |r|^2 and r.rp out of the second product's sums
+    const bool merge_r = Y != nullptr && s->cfg.bicgstab_merge_r;
     if (lean && jac && !one_rank) {
         double *D = s->vec(8);
         PIB_HIP(hipMemcpyAsync(D, A.dinv, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, q));
@@ -1779,6 +1806,10 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
         };
         auto body_lean = [&]() -> int {
             OpBFUpdateP up{R, V, dv, S, P, x, Y, opc, 0.0, 0.0, 0.0, 0.0, 0};
+            if (merge_r) {
+                up.t = T;
+                up.rw = R;
+            }
             PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
             if (!one_rank) PIB_CHK(halo_exchange(s, P, q));
             if (fused_dots) {  // v = K M^-1 p and v.rp by the same kernel
@@ -1793,6 +1824,12 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
             OpBUpdateS<PCM_NONE> us{R, V, nullptr, S, S, 1.0, 0, 0.0};  // s = r - alpha v
             PIB_CHK(launch_vec(s, n, us, true, 0, nullptr, true, q));
             if (!one_rank) PIB_CHK(halo_exchange(s, S, q));
+            if (merge_r) {  // t = K M^-1 s with s.t, t.t, s.s, rp.s, rp.t; omega and the end of the iteration in one scalar step
+                PIB_CHK(vel_stencil_apply(s, S, T, true, q, dv, opc, 4, RP, 3));
+                PIB_CHK(reduce_then(std::integral_constant<int, 7>(), 3, 5, VEL_DOT_PARTIALS, s->d_hist, conv_is_its));
+                PIB_HIP(hipGetLastError());
+                return 0;
+            }
             if (fused_dots) {  // t = K M^-1 s with s.t and t.t
                 PIB_CHK(vel_stencil_apply(s, S, T, true, q, dv, opc, 2, nullptr, 3));
                 nb = VEL_DOT_PARTIALS;

@@ -151,6 +151,7 @@ struct Config {
     int fuse_bicgstab_dots = 1;  // ... and its two dot-only passes summed by the products themselves (sums grouped by tile: the iterates equal the CSR path's to rounding, no longer bit for bit; 0 keeps the bit-identical route)
     int blocked_direct_solve = 1;   // dense.hip: the explicit inverse of the direct solver by 64-column block elimination (0: one launch per column)
     int accumulate_unscaled_x = 1;  // ... and x summed before the Jacobi sweep, swept once at the end (krylov.hip OpBFUpdateP::y): 8 B/row/iteration less, x to rounding
+    int bicgstab_merge_r = 1;  // ... and r = s - omega t formed by the next p-update, |r|^2 and r.rp from the second product's five sums (krylov.hip OpBFUpdateP::t): 16 B/row/iteration and one reduction less
     int blocked_reductions = 1;  // vector kernels with sums on >= 2^22 entries: a contiguous range per workgroup instead of a grid stride
     int lean_bicgstab = 1;  // BiCGStab on the matrix-free velocity operator without stored M^-1 p / M^-1 s and with the x update deferred (krylov.hip OpBFUpdateP)
     int velocity_tile_edges = 1;  // one-launch velocity product, wall-bounded x and y: the tiles produce their x / y boundary cells, the shell is two planes

@@ -27,7 +27,8 @@ struct VelDev {
     const double *dinv;
     double opc;
     // fused Krylov sums (k_vel_product only): dot_mode 1: y . other ; 2: y . x (the RAW input) and y . y -- one partial per
-    // workgroup at dot_part[blk] (and dot_part[dot_stride + blk])
+    // workgroup at dot_part[blk] (and dot_part[dot_stride + blk]); 4: those two, then x . x, other . x, other . y (BiCGStab with the
+    // residual update merged into the next p-update, krylov.hip: the sums |r|^2 and r . rp are formed from these five)
     int dot_mode;
     const double *dot_other;
     double *dot_part;
@@ -178,8 +179,15 @@ __device__ __forceinline__ void vel_shell_part(const VelDev &V, int f, int all, 
         if (acc != nullptr) {
             if (V.dot_mode == 1) acc[0] += v * V.dot_other[p];
             else {
-                acc[0] += v * x[p];
+                const double xv = x[p];
+                acc[0] += v * xv;
                 acc[1] += v * v;
+                if (V.dot_mode == 4) {
+                    const double ov = V.dot_other[p];
+                    acc[2] += xv * xv;
+                    acc[3] += ov * xv;
+                    acc[4] += ov * v;
+                }
             }
         }
     }
@@ -388,7 +396,7 @@ __device__ __forceinline__ int vcol(int t)
 // boundaries -- the same sums with the missing neighbour left out and its ghost fold on the diagonal, in vel_row's order: the
 // bits the shell computes -- so that the shell workgroups only own the first and the last plane.  (The x faces of a shell are
 // one strided point per lane: 40 of the product's 240 us at 256^3.)
-template <bool V4, bool EDGES = false, bool EPI = false>
+template <bool V4, bool EDGES = false, bool EPI = false, bool D5 = false>
 __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const double *__restrict__ x, double *__restrict__ y, int MZ,
                                                int bx, int by, int bz, double (&sp)[2][VSY][VSX], double *acc = nullptr,
                                                const VelEpi E = VelEpi())
@@ -471,6 +479,8 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         }
     };
     double pc[4] = {0.0, 0.0, 0.0, 0.0}, pn[4] = {0.0, 0.0, 0.0, 0.0};
+    double qc[4] = {0.0, 0.0, 0.0, 0.0}, qn[4] = {0.0, 0.0, 0.0, 0.0};  // D5 (dot_mode 4): V.dot_other beside the raw input
+    double la[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // the tile's sums, in registers (added to acc[] -- zero on entry -- at the end)
     // EPI: b, 1 / a_ii and the vector the update overwrites, for the thread's cells of a plane -- fetched a plane ahead like the
     // sums' second factor
     double eb[4] = {0.0, 0.0, 0.0, 0.0}, ed[4] = {1.0, 1.0, 1.0, 1.0}, em[4] = {0.0, 0.0, 0.0, 0.0};
@@ -528,6 +538,7 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
     load_halo(k0, hyc, hxc);
     load4(x + (int64_t)(k0 + 1) * sz, k0 + 1, zp);
     if (!EPI && acc != nullptr) loadp(k0, pc);
+    if (D5) loade1(V.dot_other, k0, qc);
     if (EPI) loade(k0, eb, ed, em);
     double zneg = V.lneg[f][2][k0], zpos = V.lpos[f][2][k0], znegn = 0.0, zposn = 0.0;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending on entry either
@@ -547,6 +558,7 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
                 }
             }
             if (!EPI && acc != nullptr) loadp(k + 1, pn);
+            if (D5) loade1(V.dot_other, k + 1, qn);
             if (EPI) loade(k + 1, nb4, nd4, nm4);
             znegn = V.lneg[f][2][k + 1];
             zposn = V.lpos[f][2][k + 1];
@@ -604,8 +616,13 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (cin[c]) {
-                    acc[0] += out[c] * pc[c];
-                    if (V.dot_mode == 2) acc[1] += out[c] * out[c];
+                    la[0] += out[c] * pc[c];
+                    if (D5 || V.dot_mode == 2) la[1] += out[c] * out[c];
+                    if (D5) {
+                        la[2] += pc[c] * pc[c];
+                        la[3] += qc[c] * pc[c];
+                        la[4] += qc[c] * out[c];
+                    }
                 }
         }
         // Everything this step requested is waited for HERE, ahead of the stores (and on every path, through the builtin, which the
@@ -638,6 +655,7 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
             xc[c] = zp[c];
             zp[c] = zn[c];
             pc[c] = pn[c];
+            if (D5) qc[c] = qn[c];
             if (EPI) {
                 eb[c] = nb4[c];
                 ed[c] = nd4[c];
@@ -648,6 +666,15 @@ __device__ __forceinline__ void vel_march_tile(const VelDev &V, int f, const dou
         hxc = hxn;
         zneg = znegn;
         zpos = zposn;
+    }
+    if (!EPI && acc != nullptr) {
+        acc[0] += la[0];
+        acc[1] += la[1];
+        if (D5) {
+            acc[2] += la[2];
+            acc[3] += la[3];
+            acc[4] += la[4];
+        }
     }
 }
 
@@ -670,7 +697,7 @@ struct VelPlan {
     int gx[3], gy[3];   // tiles per plane of a component
     int v4[3];
 };
-template <int DOT>  // DOT = 1: with the fused Krylov sums (V.dot_mode), 2: with the Chebyshev update (dot_mode 3); separate instantiations keep the plain product's registers
+template <int DOT>  // DOT = 1: with the fused Krylov sums (V.dot_mode 1, 2), 2: with the Chebyshev update (dot_mode 3), 3: the five sums of dot_mode 4; separate instantiations keep the plain product's registers
 __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__ S, VelDev V, VelPlan P, const double *__restrict__ x,
                                                      double *__restrict__ y, int MZ)
 {
@@ -678,7 +705,10 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
     __shared__ double sp[2][VSY][VSX];
     const int b = blockIdx.x;
     int tile_slot = b;
-    double acc[2] = {0.0, 0.0};
+    constexpr int NACC = (DOT == 3) ? 5 : 2;
+    double acc[NACC];
+#pragma unroll
+    for (int k2 = 0; k2 < NACC; ++k2) acc[k2] = 0.0;
     double *pa = DOT ? acc : nullptr;
     VelEpi epi = {V.ch_b, V.ch_dinv, V.ch_pm, V.ch_opc, 0.0, 0.0, 0.0};
     if (DOT == 2) {  // (S is never null here: the coefficients of the pass live in the device scalars)
@@ -707,25 +737,25 @@ __global__ __launch_bounds__(256) void k_vel_product(const Scalars *__restrict__
 #endif
         tile_slot = P.first[3 + f] + bx + P.gx[f] * (by + P.gy[f] * bz);  // the sums stay with the tile: same order as ever
         if (P.edges) {
-            if (P.v4[f]) vel_march_tile<true, true, DOT == 2>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
-            else vel_march_tile<false, true, DOT == 2>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
+            if (P.v4[f]) vel_march_tile<true, true, DOT == 2, DOT == 3>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
+            else vel_march_tile<false, true, DOT == 2, DOT == 3>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
         } else {
-            if (P.v4[f]) vel_march_tile<true, false, DOT == 2>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
-            else vel_march_tile<false, false, DOT == 2>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
+            if (P.v4[f]) vel_march_tile<true, false, DOT == 2, DOT == 3>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
+            else vel_march_tile<false, false, DOT == 2, DOT == 3>(V, f, x, y, MZ, bx, by, bz, sp, pa, epi);
         }
     }
     if (DOT) {  // one partial per workgroup and sum, fixed order
-        __shared__ double sh[2][4];
+        __shared__ double sh[NACC][4];
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
+        for (int k2 = 0; k2 < NACC; ++k2) {
             double v = acc[k2];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
             if (lane == 0) sh[k2][w] = v;
         }
         __syncthreads();
-        if (threadIdx.x < 2 && (threadIdx.x == 0 || V.dot_mode >= 2))
+        if (threadIdx.x < NACC && (threadIdx.x == 0 || V.dot_mode >= 2))
             V.dot_part[(int64_t)threadIdx.x * V.dot_stride + tile_slot] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
     }
 }
@@ -905,17 +935,18 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
             if (s->vel_part_cap < nb) {
                 if (s->d_vel_part) PIB_HIP(hipFree(s->d_vel_part));
                 s->d_vel_part = nullptr;
-                PIB_HIP(hipMalloc(&s->d_vel_part, sizeof(double) * 2 * (size_t)nb));
+                PIB_HIP(hipMalloc(&s->d_vel_part, sizeof(double) * 5 * (size_t)nb));
                 s->vel_part_cap = nb;
             }
             V.dot_part = s->d_vel_part;
             V.dot_stride = s->vel_part_cap;
         }
         if (dot_mode == 3) hipLaunchKernelGGL(k_vel_product<2>, dim3((unsigned)nb), dim3(256), 0, q, s->d_s, V, P, x, y, MZ);
+        else if (dot_mode == 4) hipLaunchKernelGGL(k_vel_product<3>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
         else if (dot_mode != 0) hipLaunchKernelGGL(k_vel_product<1>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
         else hipLaunchKernelGGL(k_vel_product<0>, dim3((unsigned)nb), dim3(256), 0, q, S, V, P, x, y, MZ);
         if (dot_mode != 0)
-            hipLaunchKernelGGL(k_vel_reduce, dim3(VEL_STAGE, dot_mode >= 2 ? 2 : 1), dim3(256), 0, q, S, s->d_vel_part, s->vel_part_cap, nb,
+            hipLaunchKernelGGL(k_vel_reduce, dim3(VEL_STAGE, dot_mode == 4 ? 5 : dot_mode >= 2 ? 2 : 1), dim3(256), 0, q, S, s->d_vel_part, s->vel_part_cap, nb,
                                s->d_part, dot_slot0);
         PIB_HIP(hipGetLastError());
         s->counters[0]++;

@@ -538,11 +538,12 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per, pc):
     out = []
     # one launch for the three components' tiles and shells (k_vel_product), a launch each, the streaming kernels, the CSR
     # (the first also runs BiCGStab without stored M^-1 p / M^-1 s and with the x update deferred: krylov.hip OpBFUpdateP);
-    # the last is the default, whose products also sum v.rp, s.t, t.t (grouped by tile: equal to rounding, not bit for bit)
+    # the last two are the fused routes, whose products also sum v.rp, s.t, t.t (grouped by tile: equal to rounding, not bit for bit)
     for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_bicgstab_dots=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_lean_bicgstab=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_velocity_product=0\n",
                   "pib_matrix_free_velocity=1\npib_march_velocity=0\n", "pib_matrix_free_velocity=0\n",
+                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_bicgstab_merge_r=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\n"):
         s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc=pc, tol=1e-13 if pc != "NOSOLVER" else 1e-10,
                                                               conv="ABSOLUTE", maxit=500, extra=extra))
@@ -555,11 +556,13 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per, pc):
     assert out[0][1] == out[1][1] == out[2][1] == out[3][1] == out[4][1] and out[0][1] >= 2
     for o in out[1:5]:
         assert np.array_equal(out[0][2], o[2]) and np.array_equal(out[0][0], o[0])
-    fused = out[5]
-    assert abs(fused[1] - out[0][1]) <= 1
-    k = min(len(fused[2]), len(out[0][2])) - 1  # the last residuals sit at the round-off floor of the recurrence
-    assert np.allclose(fused[2][:k], out[0][2][:k], rtol=1e-6)
-    assert np.abs(fused[0] - out[0][0]).max() <= (1e-12 if pc != "NOSOLVER" else 1e-10) * max(1.0, np.abs(out[0][0]).max())
+    # ... out[5] with r = s - omega t as a pass of its own, out[6] (the default) with that update merged into the next p-update and
+    # |r|^2, r.rp taken from the second product's five sums (krylov.hip OpBFUpdateP::t, k_finalize_post<7>)
+    for fused in out[5:]:
+        assert abs(fused[1] - out[0][1]) <= 1
+        k = min(len(fused[2]), len(out[0][2])) - 1  # the last residuals sit at the round-off floor of the recurrence
+        assert np.allclose(fused[2][:k], out[0][2][:k], rtol=1e-6)
+        assert np.abs(fused[0] - out[0][0]).max() <= (1e-12 if pc != "NOSOLVER" else 1e-10) * max(1.0, np.abs(out[0][0]).max())
 
 
 @pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
