@@ -28,7 +28,7 @@ class PibError(RuntimeError):
 
 
 # error / reason constants mirrored from the header
-ERR_SUP, ERR_ORDER, ERR_ARG_WRONG, ERR_ARG_OUTOFRANGE = 56, 58, 62, 63
+ERR_MEM, ERR_SUP, ERR_ORDER, ERR_ARG_WRONG, ERR_ARG_OUTOFRANGE = 55, 56, 58, 62, 63
 ERR_FILE_OPEN, ERR_LIB, ERR_CONV_FAILED, ERR_ARG_NULL = 65, 76, 82, 85
 ERR_FILE_READ, ERR_MAT_LU_ZRPVT, ERR_ARG_UNKNOWN_TYPE, ERR_MAX_VALUE = 66, 71, 86, 99
 NULLSPACE_NONE, NULLSPACE_CONSTANT, NULLSPACE_PINNED = 0, 1, 2

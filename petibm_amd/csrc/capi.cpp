@@ -2,6 +2,9 @@
 #include <cstring>
 #include <new>
 
+#include <new>
+#include <stdexcept>
+
 #include "pib_internal.hpp"
 
 using namespace pib;
@@ -67,31 +70,44 @@ int pib_version(void) { return 100; }
 
 int pib_create(pib_solver **s, const char *name, const char *cfg_path, int rank, int nranks, const void *uid_or_null,
                int device)
-{
+try {
+    install_crash_backtrace();
     Config cfg;
     PIB_CHK(parse_config_file(cfg_path, name ? name : "", cfg));
     return make_solver(s, name, cfg, cfg_path, rank, nranks, uid_or_null, device);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_create_from_string(pib_solver **s, const char *name, const char *cfg_text, int rank, int nranks,
                            const void *uid_or_null, int device)
-{
+try {
+    install_crash_backtrace();
     Config cfg;
     PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", cfg));
     return make_solver(s, name, cfg, "<string>", rank, nranks, uid_or_null, device);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_slab_range(int64_t nplanes, int nranks, int rank, int64_t *begin, int64_t *end)
-{
+try {
     if (begin == nullptr || end == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_slab_range: null output");
     if (nranks < 1 || rank < 0 || rank >= nranks || nplanes < 0) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_slab_range: bad arguments");
     slab_range(nplanes, nranks, rank, begin, end);
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_config_describe(const char *name, const char *cfg_text, char *buf, int buflen)
-{
+try {
     if (buf == nullptr || buflen < 1) return fail(PIB_ERR_ARG_NULL, "pib_config_describe: null buffer");
+    // (drill of the ABI's catch-all, tests/test_host_logic.py: an exception raised inside the library comes back as a code)
+    if (const char *e = std::getenv("PIB_TEST_THROW")) {
+        if (e[0] == 'm') throw std::bad_alloc();
+        throw std::runtime_error(e);
+    }
     Config c;
     PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", c));
     const char *method = c.method == Method::CG ? "cg" : (c.method == Method::BICGSTAB ? "bicgstab" : (c.method == Method::CHEBYSHEV ? "chebyshev" : "preonly"));
@@ -108,19 +124,23 @@ int pib_config_describe(const char *name, const char *cfg_text, char *buf, int b
                   c.smoother == Smoother::JACOBI ? "jacobi" : "chebyshev", c.smoother_relaxation, c.coarsest_sweeps,
                   c.max_levels, c.cheby_degree, c.cheby_lmax, c.cheby_lmax / c.cheby_ratio, c.cg_single_reduction, c.sweep_pairs);
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_destroy(pib_solver *s)
-{
+try {
     if (s == nullptr) return 0;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    // the captured iteration goes first: a graph exec is destroyed BEFORE the memory its kernel / copy / fill nodes point at
+    // is freed (krylov.hip: drop_iteration_graph has the story)
+    drop_iteration_graph(s);
     redist_release(s);
     gmg_release(s);
     dense_release(s);
     vel_stencil_release(s);
     s->A.release();
-    if (s->graph) (void)hipGraphExecDestroy(s->graph);
     if (s->work_base) (void)hipFree(s->work_base);
     if (s->x_dev) (void)hipFree(s->x_dev);
     if (s->b_dev) (void)hipFree(s->b_dev);
@@ -140,14 +160,18 @@ int pib_destroy(pib_solver *s)
     if (s->stream_comm) (void)hipStreamDestroy(s->stream_comm);
     delete s;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_type(pib_solver *s, char *buf, int buflen)
-{
+try {
     if (s == nullptr || buf == nullptr || buflen < 1) return fail(PIB_ERR_ARG_NULL, "pib_get_type: null argument");
     std::strncpy(buf, s->type_string.c_str(), (size_t)buflen - 1);
     buf[buflen - 1] = '\0';
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 extern "C++" {
@@ -163,10 +187,7 @@ int after_set_matrix(pib_solver *s)
     // KSPReset semantics (linsolverksp.cpp:78): everything derived from the old matrix goes
     s->gersh_lo = 0.0;
     s->gersh_hi = -1.0;
-    if (s->graph) {
-        (void)hipGraphExecDestroy(s->graph);
-        s->graph = nullptr;
-    }
+    drop_iteration_graph(s);
     if (s->cfg.pc == Precond::LU) PIB_CHK(dense_setup(s));  // PCSetUp of a direct solve = the factorisation
     s->has_matrix = true;
     return 0;
@@ -230,21 +251,25 @@ static int set_csr_any(pib_solver *s, int64_t n_local, int64_t row0_global, int6
 
 int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_global, const int64_t *rowptr,
                 const int64_t *col_global, const double *val)
-{
+try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr: null solver");
     return set_csr_any(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t n_global, const int32_t *rowptr,
                     const int32_t *col_global, const double *val)
-{
+try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr_i32: null solver");
     return set_csr_any(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                       const double *gx, const double *gy, const double *gz, int nullspace)
-{
+try {
     if (s == nullptr || n == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_grid_hint: null argument");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_set_grid_hint: set the matrix first");
     if (s->A.general)
@@ -259,10 +284,12 @@ int pib_set_grid_hint(pib_solver *s, int dim, const int64_t n[3], const double *
     // had found before
     for (int d = 0; d < 3; ++d) s->periodic[d] = s->periodic_user[d];
     return grid_register(s, dim, n, w, g, nullspace, -1.0);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int *nullspace, int *detected)
-{
+try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_grid_structure: null solver");
     if (s->redist.active) s = s->redist.inner;  // rows handed over in boxes: the structure lives in the slab solver
     const bool have = s->has_grid && !s->levels.empty();
@@ -279,10 +306,12 @@ int pib_get_grid_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int 
         }
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_multigrid_levels(pib_solver *s, int *nlevels, int64_t *n3, int max_levels)
-{
+try {
     if (s == nullptr || nlevels == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_multigrid_levels: null argument");
     if (s->redist.active) s = s->redist.inner;
     *nlevels = (int)s->levels.size();
@@ -293,10 +322,12 @@ int pib_get_multigrid_levels(pib_solver *s, int *nlevels, int64_t *n3, int max_l
         n3[3 * l + 2] = (g.dim == 3) ? g.n[2] : 1;
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_velocity_structure(pib_solver *s, int *has, int *dim, int64_t n[3], int periodic[3], int *detected)
-{
+try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_velocity_structure: null solver");
     if (s->redist.active && s->redist.nf > 1) s = s->redist.inner;  // rows handed over in boxes: the structure lives in the slab solver
     const VelStencil &V = s->vel;
@@ -310,18 +341,22 @@ int pib_get_velocity_structure(pib_solver *s, int *has, int *dim, int64_t n[3], 
         if (n) n[d] = (V.valid && d < V.dim) ? V.n[d][d] + (p ? 0 : 1) : 1;
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_set_periodic(pib_solver *s, const int periodic[3])
-{
+try {
     if (s == nullptr || periodic == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_periodic: null argument");
     for (int d = 0; d < 3; ++d) s->periodic[d] = s->periodic_user[d] = periodic[d] ? 1 : 0;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                          const double *wz, double dt, int nullspace)
-{
+try {
     if (s == nullptr || n == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_assemble_poisson: null argument");
     PIB_HIP(hipSetDevice(s->device));
     s->has_matrix = false;
@@ -333,12 +368,14 @@ int pib_assemble_poisson(pib_solver *s, int dim, const int64_t n[3], const doubl
     const double *cw[3] = {s->asm_w[0].data(), s->asm_w[1].data(), s->asm_w[2].data()};
     const double *cg[3] = {s->asm_g[0].data(), s->asm_g[1].data(), s->asm_g[2].data()};
     return grid_register(s, dim, n, cw, cg, nullspace, s->asm_dt);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                             const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
                             double coeff_nu, int bn_order, int nullspace)
-{
+try {
     if (s == nullptr || n == nullptr || lo == nullptr || hi == nullptr || a0 == nullptr)
         return fail(PIB_ERR_ARG_NULL, "pib_assemble_poisson_bn: null argument");
     if (bn_order == 1) return pib_assemble_poisson(s, dim, n, wx, wy, wz, dt, nullspace);
@@ -348,12 +385,14 @@ int pib_assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const do
     gmg_release(s);
     const double *w[3] = {wx, wy, wz};
     return assemble_poisson_bn(s, dim, n, w, lo, hi, a0, dt, coeff_nu, bn_order, nullspace, nullptr, nullptr, nullptr, nullptr);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const double *wx, const double *wy,
                           const double *wz, const double lo[3], const double hi[3], const double a0[18], double dt,
                           double coeff_nu)
-{
+try {
     if (s == nullptr || n == nullptr || lo == nullptr || hi == nullptr || a0 == nullptr)
         return fail(PIB_ERR_ARG_NULL, "pib_assemble_velocity: null argument");
     PIB_HIP(hipSetDevice(s->device));
@@ -363,6 +402,8 @@ int pib_assemble_velocity(pib_solver *s, int dim, const int64_t n[3], const doub
     const double *w[3] = {wx, wy, wz};
     PIB_CHK(assemble_velocity(s, dim, n, w, lo, hi, a0, dt, coeff_nu));
     return after_set_matrix(s);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 static bool is_device_ptr(const void *p)
@@ -390,7 +431,7 @@ static int ensure_stage(pib_solver *s)
 }
 
 int pib_solve(pib_solver *s, double *x, const double *b)
-{
+try {
     if (s == nullptr || x == nullptr || b == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_solve: null argument");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "solver %s: pib_solve called before a matrix was set", s->name.c_str());
     PIB_HIP(hipSetDevice(s->device));
@@ -448,41 +489,51 @@ int pib_solve(pib_solver *s, double *x, const double *b)
         return fail(PIB_ERR_CONV_FAILED, "PetIBM exited due to solver %s diverged with reason %d (iterations %d, residual %g).",
                     s->name.c_str(), s->reason, s->iters, s->residual);
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_iters(pib_solver *s, int *iters)
-{
+try {
     if (s == nullptr || iters == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_iters: null argument");
     *iters = s->iters;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_residual(pib_solver *s, double *res)
-{
+try {
     if (s == nullptr || res == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_residual: null argument");
     *res = s->residual;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_residual_at(pib_solver *s, int iter, double *res)
-{
+try {
     if (s == nullptr || res == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_residual_at: null argument");
     if (iter < 0 || (size_t)iter >= s->history.size())
         return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_get_residual_at: iteration %d outside the stored history [0,%zu)", iter,
                     s->history.size());
     *res = s->history[(size_t)iter];
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_reason(pib_solver *s, int *reason)
-{
+try {
     if (s == nullptr || reason == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_get_reason: null argument");
     *reason = s->reason;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_mat_mult(pib_solver *s, const double *x, double *y)
-{
+try {
     if (s == nullptr || x == nullptr || y == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_mat_mult: null argument");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_mat_mult called before a matrix was set");
     PIB_HIP(hipSetDevice(s->device));
@@ -495,46 +546,58 @@ int pib_mat_mult(pib_solver *s, const double *x, double *y)
     PIB_HIP(hipMemcpyAsync(y, W, bytes, hipMemcpyDefault, s->stream));
     PIB_HIP(hipStreamSynchronize(s->stream));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_device_alloc(pib_solver *s, int64_t nbytes, void **ptr)
-{
+try {
     if (s == nullptr || ptr == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_device_alloc: null argument");
     PIB_HIP(hipSetDevice(s->device));
     PIB_HIP(hipMalloc(ptr, (size_t)(nbytes > 0 ? nbytes : 1)));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 int pib_device_free(pib_solver *s, void *ptr)
-{
+try {
     if (s != nullptr) PIB_HIP(hipSetDevice(s->device));
     if (ptr) PIB_HIP(hipFree(ptr));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 int pib_memcpy_h2d(pib_solver *s, void *dst, const void *src, int64_t nbytes)
-{
+try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "null solver");
     PIB_HIP(hipSetDevice(s->device));
     PIB_HIP(hipMemcpy(dst, src, (size_t)nbytes, hipMemcpyHostToDevice));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 int pib_memcpy_d2h(pib_solver *s, void *dst, const void *src, int64_t nbytes)
-{
+try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "null solver");
     PIB_HIP(hipSetDevice(s->device));
     PIB_HIP(hipStreamSynchronize(s->stream));
     PIB_HIP(hipMemcpy(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 int pib_synchronize(pib_solver *s)
-{
+try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "null solver");
     PIB_HIP(hipSetDevice(s->device));
     PIB_HIP(hipStreamSynchronize(s->stream));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, int64_t *col_global, double *val)
-{
+try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "null solver");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_get_csr: no matrix");
     PIB_HIP(hipSetDevice(s->device));
@@ -565,17 +628,21 @@ int pib_get_csr(pib_solver *s, int64_t *n_local, int64_t *nnz, int64_t *rowptr, 
     }
     if (val) PIB_HIP(hipMemcpy(val, A.val, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToHost));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_graph_replays(pib_solver *s, int64_t *replays)
-{
+try {
     if (s == nullptr || replays == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
     *replays = s->graph_replays + (s->redist.active ? s->redist.inner->graph_replays : 0);
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_get_counters(pib_solver *s, int64_t counters[8])
-{
+try {
     if (s == nullptr || counters == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
     for (int k = 0; k < 8; ++k) counters[k] = s->counters[k];
     counters[5] = 1;  // ranks of the communicator as the transport reports them
@@ -586,6 +653,8 @@ int pib_get_counters(pib_solver *s, int64_t counters[8])
     } else if (s->comm.nranks > 1)
         counters[5] = s->comm.nranks;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 }  // extern "C"

@@ -21,7 +21,14 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
+#include <new>
 #include <sstream>
+#include <stdexcept>
+
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 #include "pib_internal.hpp"
 
@@ -38,6 +45,68 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 const char *last_error() { return g_err; }
+
+// PIB_CRASH_BACKTRACE=1 (tests/conftest.py sets it): on SIGSEGV / SIGABRT / SIGBUS the faulting thread's NATIVE frames go to stderr
+// before the handler that was installed before ours runs (Python's faulthandler prints the Python frames only -- which is how
+// the intermittent crash inside pib_destroy went unexplained for a round).  Diagnostics: backtrace() is not async-signal-safe
+// to the letter, the process is dying anyway.
+static struct sigaction g_prev_action[3];
+static const int g_crash_signals[3] = {SIGSEGV, SIGABRT, SIGBUS};
+static void crash_backtrace(int sig, siginfo_t *info, void *ctx)
+{
+    static const char head[] = "\n[petibm_amd] fatal signal: native frames of the faulting thread\n";
+    if (write(2, head, sizeof(head) - 1) < 0) {}
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    for (int k = 0; k < 3; ++k) {
+        if (g_crash_signals[k] != sig) continue;
+        const struct sigaction &prev = g_prev_action[k];
+        sigaction(sig, &prev, nullptr);
+        if ((prev.sa_flags & SA_SIGINFO) && prev.sa_sigaction != nullptr) {
+            prev.sa_sigaction(sig, info, ctx);
+            return;
+        }
+        if (prev.sa_handler != SIG_DFL && prev.sa_handler != SIG_IGN && prev.sa_handler != nullptr) {
+            prev.sa_handler(sig);
+            return;
+        }
+    }
+    raise(sig);  // (default action restored above)
+}
+void install_crash_backtrace()
+{
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const char *e = std::getenv("PIB_CRASH_BACKTRACE");
+        if (e == nullptr || std::atoi(e) == 0) return;
+        void *warm[4];
+        (void)backtrace(warm, 4);  // (loads the unwinder now, not inside the handler)
+        for (int k = 0; k < 3; ++k) {
+            struct sigaction sa;
+            std::memset(&sa, 0, sizeof sa);
+            sa.sa_sigaction = crash_backtrace;
+            sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+            sigemptyset(&sa.sa_mask);
+            sigaction(g_crash_signals[k], &sa, &g_prev_action[k]);
+        }
+    });
+}
+
+// The C ABI's catch-all (every extern "C" entry point is a function-try-block ending in this): an exception must not unwind into
+// a C / ctypes / cgo caller -- that is std::terminate, i.e. the host application aborted by its linear solver.
+int fail_exception(const char *where) noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(PIB_ERR_MEM, "%s: out of host memory (std::bad_alloc)", where);
+    } catch (const std::exception &e) {
+        return fail(PIB_ERR_LIB, "%s: C++ exception: %s", where, e.what());
+    } catch (...) {
+        return fail(PIB_ERR_LIB, "%s: unknown C++ exception", where);
+    }
+}
 
 static std::string trim(const std::string &s)
 {

@@ -261,7 +261,11 @@ int dense_apply_raw(const pib_solver *s, const double *b, double *y, hipStream_t
 
 void dense_release(pib_solver *s)
 {
-    if (s->dense_graph) (void)hipGraphExecDestroy(s->dense_graph);
+    drop_iteration_graph(s);
+    if (s->dense_graph) {  // (the factorisation's graph: before its buffers, its second stream and its events go)
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        (void)hipGraphExecDestroy(s->dense_graph);
+    }
     if (s->dense_inv) (void)hipFree(s->dense_inv);
     if (s->dense_work) (void)hipFree(s->dense_work);
     if (s->dense_bad) (void)hipFree(s->dense_bad);

@@ -2925,6 +2925,7 @@ static int up(const std::vector<T> &h, T **d)
 
 void gmg_release(pib_solver *s)
 {
+    drop_iteration_graph(s);  // (krylov.hip: the captured iteration goes before the memory it points at)
     if (s->d_tail_args) (void)hipFree(s->d_tail_args);
     s->d_tail_args = nullptr;
     if (s->d_tail_tab) (void)hipFree(s->d_tail_tab);

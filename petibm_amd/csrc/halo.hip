@@ -1338,13 +1338,15 @@ int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream,
 }  // namespace pib
 
 extern "C" int pib_comm_unique_id(void *uid_out)
-{
+try {
     if (uid_out == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "pib_comm_unique_id: null output");
     ncclUniqueId id;
     PIB_NCCL(ncclGetUniqueId(&id));
     std::memset(uid_out, 0, PIB_UID_BYTES);
     std::memcpy(uid_out, &id, sizeof(id));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 // ---- the RCCL entry points on hardware with ONE rank.  RCCL refuses several ranks per device and the test box has one
@@ -1358,7 +1360,7 @@ __global__ void k_selftest_fill(double *x, int64_t n, double a, double b)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = a + b * (double)i;
 }
 extern "C" int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, double *max_err_out, int *comm_ranks_out)
-{
+try {
     using namespace pib;
     if (max_err_out == nullptr || n_owned < 2 * ghost || ghost < 1) return fail(PIB_ERR_ARG_WRONG, "pib_comm_selftest: bad arguments");
     int ndev = 0;
@@ -1505,6 +1507,8 @@ extern "C" int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, dou
     (void)hipStreamDestroy(s->stream_comm);
     s->stream = s->stream_comm = nullptr;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 // Latency of the two collectives of a Krylov iteration on whatever transport `s` has attached (s == NULL: RCCL in a
@@ -1512,7 +1516,7 @@ extern "C" int pib_comm_selftest(int device, int64_t n_owned, int64_t ghost, dou
 // of `count` doubles each way, then `reps` all-reduces of PIB_NRED doubles; usec[0] / usec[1] = wall time per call
 // (enqueue + execution, one stream synchronisation at the end).  tools/comm_latency.py
 extern "C" int pib_comm_latency(pib_solver *s, int64_t count, int reps, double usec[2])
-{
+try {
     using namespace pib;
     if (usec == nullptr || count < 1 || reps < 1) return fail(PIB_ERR_ARG_WRONG, "pib_comm_latency: bad arguments");
     pib_solver S;
@@ -1561,6 +1565,8 @@ extern "C" int pib_comm_latency(pib_solver *s, int64_t count, int reps, double u
         s->stream = nullptr;
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 namespace pib {
@@ -1584,7 +1590,7 @@ void comm_capture_boundary(pib_solver *s, bool begin)
 
 // the id of a peer-transport world: a fresh shared-memory name; rank 0 makes it, every rank gets it (like the RCCL id)
 extern "C" int pib_comm_peer_id_ordered(void *uid_out, int device_ordered)
-{
+try {
     using namespace pib;
     if (uid_out == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_comm_peer_id: null output");
     static std::atomic<unsigned> serial{0};
@@ -1594,17 +1600,21 @@ extern "C" int pib_comm_peer_id_ordered(void *uid_out, int device_ordered)
     std::snprintf((char *)uid_out + 8, PIB_UID_BYTES - 8, "/pib_peer%c_%d_%u_%llx", device_ordered ? 'D' : 'H', (int)getpid(),
                   serial.fetch_add(1), (unsigned long long)now);
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 // the ordering of the collectives -- flags written and awaited by the GPUs in stream order (default), or by host threads
 // (PIB_PEER_ORDER=host: the first implementation, kept as the reference the device-ordered one is compared with)
 extern "C" int pib_comm_peer_id(void *uid_out)
-{
+try {
     const char *o = std::getenv("PIB_PEER_ORDER");
     return pib_comm_peer_id_ordered(uid_out, (o != nullptr && std::strcmp(o, "host") == 0) ? 0 : 1);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 extern "C" int pib_comm_loopback_create(int nranks, void *uid_out)
-{
+try {
     using namespace pib;
     if (uid_out == nullptr || nranks < 2) return fail(PIB_ERR_ARG_WRONG, "pib_comm_loopback_create: bad arguments");
     LoopbackGroup *g = new LoopbackGroup();
@@ -1626,10 +1636,12 @@ extern "C" int pib_comm_loopback_create(int nranks, void *uid_out)
     std::memcpy(uid_out, LOOP_MAGIC, 8);
     std::memcpy((char *)uid_out + 8, &g, sizeof(g));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 extern "C" int pib_comm_loopback_destroy(const void *uid)
-{
+try {
     using namespace pib;
     if (uid == nullptr || std::memcmp(uid, LOOP_MAGIC, 8) != 0) return fail(PIB_ERR_ARG_WRONG, "not a loopback id");
     LoopbackGroup *g = nullptr;
@@ -1641,4 +1653,6 @@ extern "C" int pib_comm_loopback_destroy(const void *uid)
         delete g;
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }

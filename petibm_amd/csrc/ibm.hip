@@ -775,7 +775,7 @@ static int ib_assemble(pib_ns *ns, pib::IbState *ib, const double *coords)
 
 int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double *coords, const char *delta_kernel,
                       const char *forces_cfg)
-{
+try {
     using namespace pib;
     if (ns == nullptr || npts == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_bodies: null argument");
     if (nbodies < 1) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_set_bodies: need at least one body");
@@ -785,10 +785,7 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
         // (and no replay of an iteration captured with the hook); the caller asks for pib_ns_set_coupled again
         ns->psol->post_matmult = nullptr;
         ns->psol->post_ctx = nullptr;
-        if (ns->psol->graph) {
-            (void)hipGraphExecDestroy(ns->psol->graph);
-            ns->psol->graph = nullptr;
-        }
+        drop_iteration_graph(ns->psol);
         ns->psol->graph_key = 0;
     }
     ib_release(ns->ib);
@@ -836,12 +833,14 @@ int pib_ns_set_bodies(pib_ns *ns, int nbodies, const int64_t *npts, const double
     if ((err = ib_assemble(ns, ib, coords))) return bail(err);
     ns->ib = ib;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* IBPMSolver (applications/ibpm): pressure and Lagrangian forces solved as one unknown.  Needs bodies and a direct
  * forces solver (its explicit inverse of EBNH is part of the operator). */
 int pib_ns_set_coupled(pib_ns *ns, int coupled)
-{
+try {
     if (ns != nullptr && coupled && ns->bn_order > 1)
         return pib::fail(PIB_ERR_SUP, "pib_ns_set_coupled: the coupled IBPM with BN order > 1 is not provided (decoupled: yes)");
     using namespace pib;
@@ -853,10 +852,7 @@ int pib_ns_set_coupled(pib_ns *ns, int coupled)
         ib->coupled = false;
         ns->psol->post_matmult = nullptr;
         ns->psol->post_ctx = nullptr;
-        if (ns->psol->graph) {
-            (void)hipGraphExecDestroy(ns->psol->graph);
-            ns->psol->graph = nullptr;
-        }
+        drop_iteration_graph(ns->psol);
         ns->psol->graph_key = 0;
         return 0;
     }
@@ -880,19 +876,18 @@ int pib_ns_set_coupled(pib_ns *ns, int coupled)
     ib->coupled = true;
     ns->psol->post_matmult = ib_schur_term;
     ns->psol->post_ctx = ns;
-    if (ns->psol->graph) {  // an iteration captured without the term must not be replayed
-        (void)hipGraphExecDestroy(ns->psol->graph);
-        ns->psol->graph = nullptr;
-    }
+    drop_iteration_graph(ns->psol);  // an iteration captured without the term must not be replayed
     ns->psol->graph_key = 0;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* RigidKinematicsSolver::moveBodies (applications/rigidkinematics/rigidkinematics.cpp:118-140): new coordinates of
  * every Lagrangian point and their prescribed velocities UB [nf]; the operators are re-assembled, the forces solver
  * gets the new EBNH, and the forces right-hand side becomes UB - E u (:147-160).  The accumulated forces stay. */
 int pib_ns_move_bodies(pib_ns *ns, const double *coords, const double *ub)
-{
+try {
     using namespace pib;
     if (ns == nullptr || coords == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_move_bodies: null argument");
     if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_move_bodies: the flow has no immersed bodies");
@@ -905,20 +900,24 @@ int pib_ns_move_bodies(pib_ns *ns, const double *coords, const double *ub)
         ib->moving = true;
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_num_forces(pib_ns *ns, int64_t *nf, int *nbodies)
-{
+try {
     if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
     if (nf) *nf = ns->ib ? ns->ib->I.nf : 0;
     if (nbodies) *nbodies = ns->ib ? ns->ib->nbodies : 0;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* Lagrangian forces f [nf] and the bodies' forces [nbodies*dim] = minus the sum of the Lagrangian forces of each
  * body (singlebodypoints.cpp:228-259; one line of forces-<start>.txt, decoupledibpm.cpp:437-465) */
 int pib_ns_get_forces(pib_ns *ns, double *f, double *body_forces)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_get_forces: the flow has no immersed bodies");
@@ -939,32 +938,38 @@ int pib_ns_get_forces(pib_ns *ns, double *f, double *body_forces)
         }
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_get_forces_solver_info(pib_ns *ns, int *f_iters, double *f_res)
-{
+try {
     if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
     if (ns->ib == nullptr) return pib::fail(PIB_ERR_ORDER, "pib_ns_get_forces_solver_info: the flow has no immersed bodies");
     if (f_iters) pib_get_iters(ns->ib->fsol, f_iters);
     if (f_res) pib_get_residual(ns->ib->fsol, f_res);
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_set_forces(pib_ns *ns, const double *f)
-{
+try {
     using namespace pib;
     if (ns == nullptr || f == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_set_forces: null argument");
     if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_set_forces: the flow has no immersed bodies");
     PIB_HIP(hipSetDevice(ns->device));
     PIB_HIP(hipMemcpy(ns->ib->f, f, sizeof(double) * (size_t)ns->ib->I.nf, hipMemcpyHostToDevice));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* Parity / inspection access to the operators.  which: 0 Delta, 1 E, 2 H (compressed rows, row_ids = the velocity
  * points stored), 3 EBNH.  Call with null arrays to get the sizes. */
 int pib_ns_get_ib_operator(pib_ns *ns, int which, int64_t *n_rows, int64_t *nnz, int32_t *rowptr, int32_t *col, double *val,
                            int32_t *row_ids)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     if (ns->ib == nullptr) return fail(PIB_ERR_ORDER, "pib_ns_get_ib_operator: the flow has no immersed bodies");
@@ -990,6 +995,8 @@ int pib_ns_get_ib_operator(pib_ns *ns, int which, int64_t *n_rows, int64_t *nnz,
     if (val) PIB_HIP(hipMemcpy(val, vl, sizeof(double) * (size_t)nz, hipMemcpyDeviceToHost));
     if (row_ids && which == 2) PIB_HIP(hipMemcpy(row_ids, ib->hcols, sizeof(int32_t) * (size_t)nr, hipMemcpyDeviceToHost));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 }  // extern "C"

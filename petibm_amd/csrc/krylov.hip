@@ -621,6 +621,21 @@ __global__ void k_cg_sr_step(Scalars *S, double *hist, double n_global, int lazy
 }
 
 // ------------------------------------------------------------------ helpers
+// The captured iteration body (hipGraphExec) is destroyed BEFORE any memory its kernel, copy and fill nodes point at is freed,
+// and before a stream it was launched on goes: every release path (pib_destroy, a new matrix, new work vectors, the multigrid's
+// and the redistribution's buffers, the immersed-boundary state behind the Schur hook) calls this first.  Until round 4's end
+// pib_destroy freed the level buffers first and the graph after them; now and then (2 of 16 cold-start runs of the parity /
+// fuzz subset, never in 2800 create-solve-destroy cycles of tools/destroy_stress.py) the process died INSIDE pib_destroy, in the
+// HIP runtime -- once with SIGSEGV, once with std::bad_variant_access ("std::get: wrong index for variant", a string only
+// libamdhip64.so contains) -- the signature of the runtime walking node state that refers to released memory objects.
+void drop_iteration_graph(pib_solver *s)
+{
+    if (s == nullptr || s->graph == nullptr) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);  // never under a launch still in flight
+    (void)hipGraphExecDestroy(s->graph);
+    s->graph = nullptr;
+}
+
 int ensure_work(pib_solver *s, int nvec)
 {
     const DeviceCsr &A = s->A;
@@ -630,13 +645,10 @@ int ensure_work(pib_solver *s, int nvec)
     int64_t stride = lo + A.n + hi + 4;
     stride = (stride + 3) & ~int64_t(3);
     if (s->work != nullptr && s->n_work >= nvec && s->work_stride == stride && s->work_lo == lo) return 0;
+    drop_iteration_graph(s);  // a captured iteration body holds the old vectors' addresses (and goes BEFORE they do)
     if (s->work_base) PIB_HIP(hipFree(s->work_base));
     s->work_base = nullptr;
     s->work = nullptr;
-    if (s->graph) {  // a captured iteration body holds the old vectors' addresses
-        (void)hipGraphExecDestroy(s->graph);
-        s->graph = nullptr;
-    }
     PIB_HIP(hipMalloc(&s->work_base, (size_t)(stride * nvec + 4) * sizeof(double)));
     PIB_HIP(hipMemsetAsync(s->work_base, 0, (size_t)(stride * nvec + 4) * sizeof(double), s->stream));
     s->work = s->work_base;  // hipMalloc is 256-byte aligned; lo and stride are multiples of 4 doubles
@@ -731,8 +743,7 @@ static int run_iterations(pib_solver *s, int todo, int first_index, uint64_t key
             continue;
         }
         if (s->graph == nullptr || s->graph_key != key) {
-            if (s->graph) (void)hipGraphExecDestroy(s->graph);
-            s->graph = nullptr;
+            drop_iteration_graph(s);  // (another key: synchronises first -- the old body may still be running)
             int64_t before[8];
             for (int k = 0; k < 8; ++k) before[k] = s->counters[k];
             if (s->comm.nranks > 1) {
@@ -2193,7 +2204,7 @@ int solve_chebyshev(pib_solver *s, double *x, const double *b)
 
 // ------------------------------------------------------------ instrumentation
 extern "C" int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_avg)
-{
+try {
     using namespace pib;
     if (s == nullptr || ms_avg == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_time_kernel: null argument");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_time_kernel: no matrix");
@@ -2246,4 +2257,6 @@ extern "C" int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_av
     PIB_HIP(hipEventElapsedTime(&ms, s->ev_a, s->ev_b));
     *ms_avg = (double)ms / reps;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }

@@ -685,9 +685,12 @@ int ns_before_solve(pib_ns *ns, pib_solver *sol)
 extern "C" {
 
 int pib_ns_destroy(pib_ns *ns)
-{
+try {
     if (ns == nullptr) return 0;
     (void)hipSetDevice(ns->device);
+    // (captured iterations first: the Poisson solver's may hold the Schur hook's pointers into the immersed-boundary state)
+    pib::drop_iteration_graph(ns->psol);
+    pib::drop_iteration_graph(ns->vsol);
     pib::ib_release(ns->ib);
     ns->ib = nullptr;
     for (int k = 0; k < 7; ++k)
@@ -705,6 +708,8 @@ int pib_ns_destroy(pib_ns *ns)
     if (ns->stream) (void)hipStreamDestroy(ns->stream);
     delete ns;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 }  // extern "C"
@@ -1127,23 +1132,27 @@ extern "C" {
 int pib_ns_create(pib_ns **out, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                   const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
                   double nu, const char *velocity_cfg, const char *poisson_cfg, int device)
-{
+try {
     return ns_create_impl(out, dim, n, wx, wy, wz, lo, hi, bc_type, bc_value, dt, nu, velocity_cfg, poisson_cfg, device, 0, 1, nullptr);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_create_slab(pib_ns **out, int dim, const int64_t n[3], const double *wx, const double *wy, const double *wz,
                        const double lo[3], const double hi[3], const int bc_type[18], const double bc_value[18], double dt,
                        double nu, const char *velocity_cfg, const char *poisson_cfg, int rank, int nranks,
                        const void *uid_or_null, int device)
-{
+try {
     return ns_create_impl(out, dim, n, wx, wy, wz, lo, hi, bc_type, bc_value, dt, nu, velocity_cfg, poisson_cfg, device, rank, nranks,
                           uid_or_null);
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* parameters.BN (navierstokes.cpp:349-356): order N of the approximate inverse BN.  N > 1 re-assembles the Poisson
  * operator through the product chain D * BN * G (bn.hip) and keeps the assembled BNG for the projection. */
 int pib_ns_set_bn_order(pib_ns *ns, int order)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     if (order < 1) return fail(PIB_ERR_SUP, "The order of Bn can not be smaller than 1.");
@@ -1178,6 +1187,8 @@ int pib_ns_set_bn_order(pib_ns *ns, int order)
     }
     ns->bn_order = order;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* parameters.convection / parameters.diffusion (src/timeintegration/timeintegration.cpp:41-80): EULER_EXPLICIT,
@@ -1197,7 +1208,7 @@ static int scheme_coeffs(const char *name, int *nexp, double ce[2], double *cimp
 }
 
 int pib_ns_set_time_integration(pib_ns *ns, const char *convection, const char *diffusion)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     if (ns->ib) return fail(PIB_ERR_ORDER, "pib_ns_set_time_integration: call before pib_ns_set_bodies");
@@ -1218,12 +1229,14 @@ int pib_ns_set_time_integration(pib_ns *ns, const char *convection, const char *
         PIB_CHK(pib_ns_set_bn_order(ns, order));
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* One explicit term kept between steps (restart files: /convection/<index>, /diffusion/<index>,
  * navierstokes.cpp:637-686,689-746).  kind 0: convection, 1: diffusion; host array of UN entries. */
 int pib_ns_history_term(pib_ns *ns, int kind, int index, int set, double *host)
-{
+try {
     using namespace pib;
     if (ns == nullptr || host == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_history_term: null argument");
     const int count = (kind == 0) ? ns->T.nconv : ns->T.ndiff;
@@ -1248,13 +1261,15 @@ int pib_ns_history_term(pib_ns *ns, int kind, int index, int set, double *host)
     if (set) PIB_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
     else PIB_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* The vorticity field of the reference's petibm-vorticity utility (applications/vorticity/main.cpp) from the current
  * velocity and ghost values.  comp: 0 wx, 1 wy, 2 wz (2-D: only 2).  n_out[3] receives the field's point counts
  * (:384-470: vertices along the two directions the component is not centred on); out may be NULL to query them. */
 int pib_ns_get_vorticity(pib_ns *ns, int comp, int64_t n_out[3], double *out)
-{
+try {
     using namespace pib;
     if (ns == nullptr || n_out == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_ns_get_vorticity: null argument");
     const NsDev &D = ns->D;
@@ -1273,19 +1288,23 @@ int pib_ns_get_vorticity(pib_ns *ns, int comp, int64_t n_out[3], double *out)
     PIB_HIP(hipMemcpy(out, d_out, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost));
     PIB_HIP(hipFree(d_out));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_sizes(pib_ns *ns, int64_t *UN, int64_t *pN)
-{
+try {
     if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
     // on a slab: this rank's part of the distributed vectors (packed owned [u | v | w]; owned pressure cells)
     if (UN) *UN = (ns->nranks > 1) ? ns->UN_owned : ns->D.UN;
     if (pN) *pN = (ns->nranks > 1) ? ns->pN_owned : ns->D.pN;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_set_state(pib_ns *ns, const double *U, const double *p)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
@@ -1311,10 +1330,12 @@ int pib_ns_set_state(pib_ns *ns, const double *U, const double *p)
             PIB_HIP(hipMemcpy(ns->p, p, sizeof(double) * (size_t)ns->D.pN, hipMemcpyHostToDevice));
     }
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs2)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
@@ -1341,11 +1362,13 @@ int pib_ns_get_state(pib_ns *ns, double *U, double *p, double *rhs1, double *rhs
     if (rhs1) PIB_HIP(hipMemcpy(rhs1, ns->rhs1, sizeof(double) * (size_t)ns->D.UN, hipMemcpyDeviceToHost));
     if (rhs2) PIB_HIP(hipMemcpy(rhs2, ns->rhs2, sizeof(double) * (size_t)ns->D.pN, hipMemcpyDeviceToHost));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* the explicit terms a restart needs (navierstokes.cpp:637-686: /convection/0, /convection/1, /diffusion/0); any may be NULL */
 int pib_ns_get_history(pib_ns *ns, double *conv0, double *conv1, double *diff0)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
@@ -1361,10 +1384,12 @@ int pib_ns_get_history(pib_ns *ns, double *conv0, double *conv1, double *diff0)
     if (conv1) PIB_HIP(hipMemcpy(conv1, ns->conv[1], bytes, hipMemcpyDeviceToHost));
     if (diff0) PIB_HIP(hipMemcpy(diff0, ns->diff0, bytes, hipMemcpyDeviceToHost));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_set_history(pib_ns *ns, const double *conv0, const double *conv1)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
@@ -1377,10 +1402,12 @@ int pib_ns_set_history(pib_ns *ns, const double *conv0, const double *conv1)
     if (conv0) PIB_HIP(hipMemcpy(ns->conv[0], conv0, bytes, hipMemcpyHostToDevice));
     if (conv1) PIB_HIP(hipMemcpy(ns->conv[1], conv1, bytes, hipMemcpyHostToDevice));
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 int pib_ns_advance(pib_ns *ns, int nsteps)
-{
+try {
     using namespace pib;
     if (ns == nullptr) return fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
@@ -1503,6 +1530,8 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
     pib_get_iters(ns->psol, &ns->p_iters);
     pib_get_residual(ns->psol, &ns->p_res);
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* Stage timers under the reference's PetscLogStage names (navierstokes.cpp:186-199; decoupledibpm.cpp:93-97): HIP events on
@@ -1510,7 +1539,7 @@ int pib_ns_advance(pib_ns *ns, int nsteps)
 static const char *const kStageNames[6] = {"rhsVelocity", "solveVelocity", "solveForces", "rhsPoisson", "solvePoisson", "update"};
 const char *pib_ns_stage_name(int stage) { return (stage >= 0 && stage < 6) ? kStageNames[stage] : ""; }
 int pib_ns_stage_timers(pib_ns *ns, int enable)
-{
+try {
     if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
     PIB_HIP(hipSetDevice(ns->device));
     if (enable)
@@ -1520,24 +1549,30 @@ int pib_ns_stage_timers(pib_ns *ns, int enable)
     for (int k = 0; k < 6; ++k) ns->stage_ms[k] = 0.0;
     ns->stage_steps = 0;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 int pib_ns_get_stage_times(pib_ns *ns, double ms[6], int64_t *steps)
-{
+try {
     if (ns == nullptr || ms == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "pib_ns_get_stage_times: null argument");
     for (int k = 0; k < 6; ++k) ms[k] = ns->stage_ms[k];
     if (steps) *steps = ns->stage_steps;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 /* the columns of iterations-<start>.txt (navierstokes.cpp:766-794): vIters, vRes, pIters, pRes of the last step */
 int pib_ns_get_solver_info(pib_ns *ns, int *v_iters, double *v_res, int *p_iters, double *p_res)
-{
+try {
     if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
     if (v_iters) *v_iters = ns->v_iters;
     if (v_res) *v_res = ns->v_res;
     if (p_iters) *p_iters = ns->p_iters;
     if (p_res) *p_res = ns->p_res;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
 }
 
 }  // extern "C"

@@ -225,6 +225,7 @@ int upload_csr_general(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_g
 // ------------------------------------------------------------------------------------------------ boxes -> slabs
 void redist_release(pib_solver *s)
 {
+    drop_iteration_graph(s);  // (krylov.hip: the captured iteration goes before the memory it points at)
     Redist &R = s->redist;
     if (R.inner) (void)pib_destroy(R.inner);
     for (int f = 0; f < 3; ++f) {

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -18,6 +19,8 @@
 namespace pib {
 
 int fail(int code, const char *fmt, ...);  // records the message, returns code
+int fail_exception(const char *where) noexcept;  // the C ABI's catch-all: the exception in flight as an error code + message (config.cpp)
+void install_crash_backtrace();  // PIB_CRASH_BACKTRACE=1: native frames on SIGSEGV / SIGABRT / SIGBUS, then the previous handler (config.cpp)
 const char *last_error();
 
 // PIB_TRACE_SETUP=1: where the time of a set-up path goes (printed by rank 0 to stderr); tools/box_route_probe.py
@@ -58,7 +61,12 @@ inline void par_ranges(int64_t n, F f)
     const int64_t chunk = (n + T - 1) / T;
     for (int t = 0; t < T; ++t) {
         const int64_t b = std::min<int64_t>(n, t * chunk), e = std::min<int64_t>(n, b + chunk);
-        if (e > b) th.emplace_back([=]() { f(b, e); });
+        if (e <= b) continue;
+        try {
+            th.emplace_back([=]() { f(b, e); });
+        } catch (const std::system_error &) {  // no more threads to be had (a pids limit): the range on this one
+            f(b, e);
+        }
     }
     for (auto &x : th) x.join();
 }
@@ -574,6 +582,7 @@ int stencil_matmult(pib_solver *s, const double *x, double *y, double *dot_part,
 int spmv_launch_blocks();
 int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t st);
 bool gmg_fused_update_ok(const pib_solver *s);
+void drop_iteration_graph(pib_solver *s);  // krylov.hip: the captured iteration goes before the memory it points at
 void gmg_release(pib_solver *s);
 int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *const w[3], const double *const g[3],
                   int nullspace, double dt /* <= 0: recover from g */);

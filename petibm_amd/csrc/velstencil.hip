@@ -848,6 +848,7 @@ int vel_stencil_verify(pib_solver *s)
 
 void vel_stencil_release(pib_solver *s)
 {
+    drop_iteration_graph(s);  // (krylov.hip: the captured iteration goes before the memory it points at)
     if (s->d_vel_part) (void)hipFree(s->d_vel_part);
     s->d_vel_part = nullptr;
     s->vel_part_cap = 0;

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# a crash inside the library or the HIP runtime under it prints its native frames before Python's faulthandler has its say
+# (csrc/config.cpp: install_crash_backtrace)
+os.environ.setdefault("PIB_CRASH_BACKTRACE", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -238,3 +238,20 @@ def test_every_solver_file_key_of_the_backend_is_documented():
                                                                                       "pib_config", "pib_last", "pib_synchronize", "pib_version"))}
     assert read - listed == set(), f"undocumented keys: {sorted(read - listed)}"
     assert listed - read == set(), f"documented but not read: {sorted(listed - read)}"
+
+
+def test_an_exception_inside_the_library_comes_back_as_an_error_code(capi, monkeypatch):
+    """Every extern "C" entry point is a function-try-block (csrc/config.cpp: fail_exception): a C++ exception must not unwind
+    into the C / ctypes / cgo caller (std::terminate: the host application aborted by its linear solver).  The reference's
+    own boundary behaves like this: PETSc functions return error codes (CHKERRQ, /root/reference/src/linsolver/linsolverksp.cpp:48-60)."""
+    from petibm_amd.capi import PibError
+    monkeypatch.setenv("PIB_TEST_THROW", "drill")
+    with pytest.raises(PibError) as e:
+        capi.config_describe("poisson", AMGX_POISSON)
+    assert e.value.code == capi.ERR_LIB and "C++ exception: drill" in str(e.value)
+    monkeypatch.setenv("PIB_TEST_THROW", "m")
+    with pytest.raises(PibError) as e:
+        capi.config_describe("poisson", AMGX_POISSON)
+    assert e.value.code == capi.ERR_MEM
+    monkeypatch.delenv("PIB_TEST_THROW")
+    assert capi.config_describe("poisson", AMGX_POISSON)["method"] == "cg"
