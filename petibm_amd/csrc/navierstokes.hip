@@ -281,11 +281,27 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
                                                          const double *__restrict__ U,
                                                          const double *__restrict__ p, const double *__restrict__ conv1,
                                                          double *__restrict__ conv0, double *__restrict__ rhs1,
-                                                         double *__restrict__ diff0, const double *__restrict__ diff1)
+                                                         double *__restrict__ diff0, const double *__restrict__ diff1, int gx,
+                                                         int band, int KZ)
 {
     const NsField &Fd = D.f[F];
     const int nx = (int)Fd.n[0];
-    const int j = blockIdx.y + 1, k = (DIM == 3) ? blockIdx.z + 1 : 0;
+    // band > 0 (3-D, 1-D grid of gx * 8 * band * (nz - 2) workgroups): workgroups L, L + 8, ... share an XCD and its L2, so each
+    // of the eight classes takes a contiguous band of rows and walks it plane after plane -- a row's y neighbours and the three
+    // planes of every component the stencils reach (band * nx * 8 B each) then stay in THAT L2 from one plane to the next.
+    // Dealt out row by row, every XCD touched every row: nine planes of 512 KB at 256^3 per 4 MB L2, refetched for every plane.
+    int bxi = blockIdx.x, j = blockIdx.y + 1, k = (DIM == 3) ? blockIdx.z + 1 : 0;
+    if (band > 0) {
+        const int L = blockIdx.x, c = L & 7;
+        int m = L >> 3;
+        bxi = m % gx;
+        m /= gx;
+        j = c * band + m % band + 1;
+        k = (m / band) * KZ + 1;
+        if (j > (int)Fd.n[1] - 2) return;
+    }
+    const int kend = (DIM == 3 && band > 0) ? min(k + KZ, (int)Fd.n[2] - 1) : k + 1;
+    for (; k < kend; ++k) {
     // bases of every component at (0, j, k) and their strides
     int64_t b[DIM], sy[DIM], sz[DIM];
 #pragma unroll
@@ -303,59 +319,85 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
     const double zNeg = (DIM == 3) ? Fd.lneg[2][k] : 0.0, zPos = (DIM == 3) ? Fd.lpos[2][k] : 0.0;
     const double gvyz = (F == 1) ? Fd.ginv[j] : ((F == 2) ? Fd.ginv[k] : 0.0);
 #define PIB_V(ff, di, dj, dk) U[b[ff] + i + (di) + (dj) * sy[ff] + (dk) * sz[ff]]
-    for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i < nx - 1; i += gridDim.x * 256) {
+    for (int i = 1 + bxi * 256 + threadIdx.x; i < nx - 1; i += gx * 256) {
         const int64_t g = b[F] + i;
-        const double dLx = Fd.dl[0][i + 1];
-        // ---- G p
-        const double gv = (F == 0) ? Fd.ginv[i] : gvyz;
+        // Every value the point needs is requested HERE, before the first use, and its three results are stored at the end: written
+        // in the order of the formulae (p, then the convective stencil, a store, conv1, the Laplacian's stencil again, a store,
+        // diff1, a store) the compiler kept five memory round trips one after the other per wave -- the stores between them forbid
+        // moving the loads up, and each wait behind a store waited for the store too -- and the kernel ran at the latency of those
+        // (3 TB/s whatever the L2 hit rate: PMC had 2.9 x the algorithmic bytes fetched without the XCD bands, 1.0 x with them, at
+        // the same 370 us).  Same operations on the same values in the same order: same bits.
         const int64_t pc = pbase + i;
-        double r = 0.0 + (-gv) * p[pc];
-        r = r + gv * p[pc + pstF];
-        r = -1.0 * r;
+        const double p0 = p[pc], p1 = p[pc + pstF];
         const double self = U[g];
+        const double uxm = PIB_V(F, -1, 0, 0), uxp = PIB_V(F, 1, 0, 0), uym = PIB_V(F, 0, -1, 0), uyp = PIB_V(F, 0, 1, 0);
+        const double uzm = (DIM == 3) ? PIB_V(F, 0, 0, -1) : 0.0, uzp = (DIM == 3) ? PIB_V(F, 0, 0, 1) : 0.0;
+        // the other components' values of N(u): a0..a3 the first of them (v for u, u for v and w), c0..c3 the second (w for u and v,
+        // v for w), in the order the formulae below read them
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+        if (T.nconv > 0) {
+            if (F == 0) {
+                a0 = PIB_V(1, 0, -1, 0), a1 = PIB_V(1, 1, -1, 0), a2 = PIB_V(1, 0, 0, 0), a3 = PIB_V(1, 1, 0, 0);
+                if (DIM == 3) c0 = PIB_V(DIM - 1, 0, 0, -1), c1 = PIB_V(DIM - 1, 1, 0, -1), c2 = PIB_V(DIM - 1, 0, 0, 0), c3 = PIB_V(DIM - 1, 1, 0, 0);
+            } else if (F == 1) {
+                a0 = PIB_V(0, -1, 0, 0), a1 = PIB_V(0, -1, 1, 0), a2 = PIB_V(0, 0, 0, 0), a3 = PIB_V(0, 0, 1, 0);
+                if (DIM == 3) c0 = PIB_V(DIM - 1, 0, 0, -1), c1 = PIB_V(DIM - 1, 0, 1, -1), c2 = PIB_V(DIM - 1, 0, 0, 0), c3 = PIB_V(DIM - 1, 0, 1, 0);
+            } else {
+                a0 = PIB_V(0, -1, 0, 0), a1 = PIB_V(0, -1, 0, 1), a2 = PIB_V(0, 0, 0, 0), a3 = PIB_V(0, 0, 0, 1);
+                c0 = PIB_V(1, 0, -1, 0), c1 = PIB_V(1, 0, -1, 1), c2 = PIB_V(1, 0, 0, 0), c3 = PIB_V(1, 0, 0, 1);
+            }
+        }
+        const double cold = (T.nconv > 1) ? conv1[g] : 0.0;
+        const double dold = (T.ndiff > 1) ? diff1[g] : 0.0;
+        const double dLx = Fd.dl[0][i + 1];
+        const double gv = (F == 0) ? Fd.ginv[i] : gvyz;
+        const double xNeg = Fd.lneg[0][i], xPos = Fd.lpos[0][i];
+        // ---- G p
+        double r = 0.0 + (-gv) * p0;
+        r = r + gv * p1;
+        r = -1.0 * r;
         r = r + (1.0 / dt) * self;
         // ---- N(u)  (createconvection.cpp:40-195)
+        double cn = 0.0;
         if (T.nconv > 0) {
-        const double W = (self + PIB_V(F, -1, 0, 0)) / 2.0, E = (self + PIB_V(F, 1, 0, 0)) / 2.0;
-        const double S = (self + PIB_V(F, 0, -1, 0)) / 2.0, N = (self + PIB_V(F, 0, 1, 0)) / 2.0;
-        double B = 0.0, Fw = 0.0;
-        if (DIM == 3) {
-            B = (self + PIB_V(F, 0, 0, -1)) / 2.0;
-            Fw = (self + PIB_V(F, 0, 0, 1)) / 2.0;
-        }
-        double cv;
-        if (F == 0) {
-            const double vS = (PIB_V(1, 0, -1, 0) + PIB_V(1, 1, -1, 0)) / 2.0;
-            const double vN = (PIB_V(1, 0, 0, 0) + PIB_V(1, 1, 0, 0)) / 2.0;
-            cv = (E * E - W * W) / dLx + (vN * N - vS * S) / dLy;
+            const double W = (self + uxm) / 2.0, E = (self + uxp) / 2.0;
+            const double S = (self + uym) / 2.0, N = (self + uyp) / 2.0;
+            double B = 0.0, Fw = 0.0;
             if (DIM == 3) {
-                const double wB = (PIB_V(DIM - 1, 0, 0, -1) + PIB_V(DIM - 1, 1, 0, -1)) / 2.0;
-                const double wF = (PIB_V(DIM - 1, 0, 0, 0) + PIB_V(DIM - 1, 1, 0, 0)) / 2.0;
-                cv = cv + (wF * Fw - wB * B) / dLz;
+                B = (self + uzm) / 2.0;
+                Fw = (self + uzp) / 2.0;
             }
-        } else if (F == 1) {
-            const double uW = (PIB_V(0, -1, 0, 0) + PIB_V(0, -1, 1, 0)) / 2.0;
-            const double uE = (PIB_V(0, 0, 0, 0) + PIB_V(0, 0, 1, 0)) / 2.0;
-            cv = (uE * E - uW * W) / dLx + (N * N - S * S) / dLy;
-            if (DIM == 3) {
-                const double wB = (PIB_V(DIM - 1, 0, 0, -1) + PIB_V(DIM - 1, 0, 1, -1)) / 2.0;
-                const double wF = (PIB_V(DIM - 1, 0, 0, 0) + PIB_V(DIM - 1, 0, 1, 0)) / 2.0;
-                cv = cv + (wF * Fw - wB * B) / dLz;
+            double cv;
+            if (F == 0) {
+                const double vS = (a0 + a1) / 2.0;
+                const double vN = (a2 + a3) / 2.0;
+                cv = (E * E - W * W) / dLx + (vN * N - vS * S) / dLy;
+                if (DIM == 3) {
+                    const double wB = (c0 + c1) / 2.0;
+                    const double wF = (c2 + c3) / 2.0;
+                    cv = cv + (wF * Fw - wB * B) / dLz;
+                }
+            } else if (F == 1) {
+                const double uW = (a0 + a1) / 2.0;
+                const double uE = (a2 + a3) / 2.0;
+                cv = (uE * E - uW * W) / dLx + (N * N - S * S) / dLy;
+                if (DIM == 3) {
+                    const double wB = (c0 + c1) / 2.0;
+                    const double wF = (c2 + c3) / 2.0;
+                    cv = cv + (wF * Fw - wB * B) / dLz;
+                }
+            } else {
+                const double uW = (a0 + a1) / 2.0;
+                const double uE = (a2 + a3) / 2.0;
+                const double vS = (c0 + c1) / 2.0;
+                const double vN = (c2 + c3) / 2.0;
+                cv = (uE * E - uW * W) / dLx + (vN * N - vS * S) / dLy + (Fw * Fw - B * B) / dLz;
             }
-        } else {
-            const double uW = (PIB_V(0, -1, 0, 0) + PIB_V(0, -1, 0, 1)) / 2.0;
-            const double uE = (PIB_V(0, 0, 0, 0) + PIB_V(0, 0, 0, 1)) / 2.0;
-            const double vS = (PIB_V(1, 0, -1, 0) + PIB_V(1, 0, -1, 1)) / 2.0;
-            const double vN = (PIB_V(1, 0, 0, 0) + PIB_V(1, 0, 0, 1)) / 2.0;
-            cv = (uE * E - uW * W) / dLx + (vN * N - vS * S) / dLy + (Fw * Fw - B * B) / dLz;
-        }
-        const double cn = -1.0 * cv;
-        conv0[g] = cn;
-        r = r + T.cc[0] * cn;
-        if (T.nconv > 1) r = r + T.cc[1] * conv1[g];
+            cn = -1.0 * cv;
+            r = r + T.cc[0] * cn;
+            if (T.nconv > 1) r = r + T.cc[1] * cold;
         }
         // ---- L u in the row's column order z-, y-, x-, diag, x+, y+, z+ ; no ghost point: the corrections are zero
-        const double xNeg = Fd.lneg[0][i], xPos = Fd.lpos[0][i];
         double acc = 0.0;
         acc = acc + xNeg;
         acc = acc + xPos;
@@ -367,24 +409,27 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         }
         const double diag = -acc;
         double lu = 0.0;
-        if (DIM == 3) lu = lu + zNeg * PIB_V(F, 0, 0, -1);
-        lu = lu + yNeg * PIB_V(F, 0, -1, 0);
-        lu = lu + xNeg * PIB_V(F, -1, 0, 0);
+        if (DIM == 3) lu = lu + zNeg * uzm;
+        lu = lu + yNeg * uym;
+        lu = lu + xNeg * uxm;
         lu = lu + diag * self;
-        lu = lu + xPos * PIB_V(F, 1, 0, 0);
-        lu = lu + yPos * PIB_V(F, 0, 1, 0);
-        if (DIM == 3) lu = lu + zPos * PIB_V(F, 0, 0, 1);
+        lu = lu + xPos * uxp;
+        lu = lu + yPos * uyp;
+        if (DIM == 3) lu = lu + zPos * uzp;
         const double lc = 0.0, lcn = 0.0;
+        double df = 0.0;
         if (T.ndiff > 0) {
-            double df = lu + lc;
+            df = lu + lc;
             df = nu * df;
-            diff0[g] = df;
             r = r + T.dc[0] * df;
-            if (T.ndiff > 1) r = r + T.dc[1] * diff1[g];
+            if (T.ndiff > 1) r = r + T.dc[1] * dold;
         }
         const double b1 = nu * lcn;
         r = r + T.cimpl * b1;
+        if (T.nconv > 0) conv0[g] = cn;
+        if (T.ndiff > 0) diff0[g] = df;
         rhs1[g] = r;
+    }
     }
 #undef PIB_V
 }
@@ -1440,16 +1485,22 @@ try {
         if (ns->T.ndiff > 1) std::swap(ns->diff0, ns->diff1);
         // bc->updateEqs(solution, dt) (:508) into a1n; the right-hand side needs both generations
         hipLaunchKernelGGL(k_ns_ghosts<1>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);
+        // interior kernel of the explicit terms: rows dealt to the XCDs in bands (PIB_RHS_BANDS=0: row by row, the 3-D grid)
+        static const int rhs_bands = std::getenv("PIB_RHS_BANDS") ? std::atoi(std::getenv("PIB_RHS_BANDS")) : 1;
+        // (planes a workgroup walks: 1 / 2 / 4 / 8 measured 1.09 / 1.02 / 1.03 / 1.06 ms of rhsVelocity per 256^3 step)
+        static const int rhs_kz = std::getenv("PIB_RHS_PLANES") ? std::max(1, std::atoi(std::getenv("PIB_RHS_PLANES"))) : 2;
 #define PIB_RHS(DIM_, F_)                                                                                                   \
     {                                                                                                                       \
         const NsField &Fq = D.f[F_];                                                                                        \
         const bool inner = Fq.n[0] >= 3 && Fq.n[1] >= 3 && (DIM_ == 2 || Fq.n[2] >= 3);                                     \
-        if (inner)                                                                                                          \
-            hipLaunchKernelGGL((k_ns_rhs_velocity<DIM_, F_>),                                                               \
-                               dim3((unsigned)((Fq.n[0] - 2 + 255) / 256), (unsigned)(Fq.n[1] - 2),                           \
-                                    (unsigned)(DIM_ == 3 ? Fq.n[2] - 2 : 1)),                                                 \
-                               dim3(256), 0, ns->stream, D, ns->dt, ns->nu, ns->T, ns->U, ns->p, ns->conv[1],               \
-                               ns->conv[0], ns->rhs1, ns->diff0, ns->diff1);                                                \
+        if (inner) {                                                                                                        \
+            const int gx_ = (int)((Fq.n[0] - 2 + 255) / 256);                                                               \
+            const int band_ = (DIM_ == 3 && rhs_bands && Fq.n[1] - 2 >= 64) ? (int)((Fq.n[1] - 2 + 7) / 8) : 0;              \
+            const dim3 grid_ = band_ ? dim3((unsigned)(gx_ * 8 * band_ * ((Fq.n[2] - 2 + rhs_kz - 1) / rhs_kz)))            \
+                                     : dim3((unsigned)gx_, (unsigned)(Fq.n[1] - 2), (unsigned)(DIM_ == 3 ? Fq.n[2] - 2 : 1)); \
+            hipLaunchKernelGGL((k_ns_rhs_velocity<DIM_, F_>), grid_, dim3(256), 0, ns->stream, D, ns->dt, ns->nu, ns->T,     \
+                               ns->U, ns->p, ns->conv[1], ns->conv[0], ns->rhs1, ns->diff0, ns->diff1, gx_, band_, rhs_kz);  \
+        }                                                                                                                   \
         const int64_t shell = inner ? 2 * (Fq.n[1] * Fq.n[2] + (Fq.n[0] - 2) * Fq.n[2] +                                    \
                                            (DIM_ == 3 ? (Fq.n[0] - 2) * (Fq.n[1] - 2) : 0))                                 \
                                     : Fq.n[0] * Fq.n[1] * Fq.n[2];                                                          \

@@ -18,6 +18,30 @@ def child(cycles):
     from test_gpu_fuzz import _multigrid_mesh
     from test_gpu_parity import gmg_cfg
     forms = ((0, 0, 0), (1, 0, 0), (1, 1024, 0), (1, 1024, 1), (0, 1024, 1), (1, 4096, 1), (1, 200, 1))
+    if os.environ.get("STRESS_THREADS"):
+        # solvers created, run (stream capture in thread-local mode) and destroyed on threads that then EXIT -- what the loopback
+        # tests do with their rank threads -- before the main thread's loop
+        import threading
+
+        def one(seed):
+            dim, n, w, per = _multigrid_mesh(seed)
+            N = int(np.prod(n))
+            b = np.random.default_rng(seed).uniform(-1, 1, N)
+            b -= b.mean()
+            s = LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=1))
+            if any(per):
+                s.setPeriodic(per)
+            s.assemblePoisson(n, w, 0.01, capi.NULLSPACE_CONSTANT)
+            x = np.zeros(N)
+            s.solve(x, b)
+            s.destroy()
+
+        for rnd in range(int(os.environ["STRESS_THREADS"])):
+            th = [threading.Thread(target=one, args=(2 * t,)) for t in range(4)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
     done = 0
     seed = 0
     while done < cycles:
