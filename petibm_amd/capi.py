@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -120,7 +121,10 @@ def load():
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for this backend)")
-    import torch  # noqa: F401  (see module docstring: one HIP runtime per process)
+    if os.environ.get("PIB_TORCH_FIRST", "1") != "0" or "torch" in sys.modules:
+        import torch  # noqa: F401  (see module docstring: one HIP runtime per process)
+    # (PIB_TORCH_FIRST=0 in a process that never imports torch: the library runs on /opt/rocm's own HIP / ROCr -- what a C or C++
+    # application linking libpetibm_amd.so gets -- instead of the older runtime torch bundles; tools/abort_hunt.sh compares the two)
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)

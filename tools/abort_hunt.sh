@@ -5,6 +5,7 @@ TAG=${1:-run}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/abort_hunt; mkdir -p $O
 ulimit -c unlimited
+echo "PIB_TORCH_FIRST=${PIB_TORCH_FIRST:-1}"
 echo "core_pattern: $(cat /proc/sys/kernel/core_pattern)" > $O/$TAG.log
 rm -f /tmp/core* core*
 timeout 800 python -X faulthandler -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_periodic.py tests/test_gpu_multirank_loopback.py -x -q -v -s >> $O/$TAG.log 2>&1
