@@ -623,11 +623,10 @@ __global__ void k_cg_sr_step(Scalars *S, double *hist, double n_global, int lazy
 // ------------------------------------------------------------------ helpers
 // The captured iteration body (hipGraphExec) is destroyed BEFORE any memory its kernel, copy and fill nodes point at is freed,
 // and before a stream it was launched on goes: every release path (pib_destroy, a new matrix, new work vectors, the multigrid's
-// and the redistribution's buffers, the immersed-boundary state behind the Schur hook) calls this first.  Until round 4's end
-// pib_destroy freed the level buffers first and the graph after them; now and then (2 of 16 cold-start runs of the parity /
-// fuzz subset, never in 2800 create-solve-destroy cycles of tools/destroy_stress.py) the process died INSIDE pib_destroy, in the
-// HIP runtime -- once with SIGSEGV, once with std::bad_variant_access ("std::get: wrong index for variant", a string only
-// libamdhip64.so contains) -- the signature of the runtime walking node state that refers to released memory objects.
+// and the redistribution's buffers, the immersed-boundary state behind the Schur hook) calls this first.  (Until round 4's end
+// pib_destroy freed the level buffers first and the graph after them.  The order was turned round while hunting an intermittent
+// crash that surfaced inside pib_destroy; that crash turned out to be the runtime's own -- docs/history/round4.md -- and the
+// order stays because it is the right one.)
 void drop_iteration_graph(pib_solver *s)
 {
     if (s == nullptr || s->graph == nullptr) return;
