@@ -11,9 +11,9 @@ import socket
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+
+# torch is imported where it is used, not at collection: a `-m gpu` run of the suite then never imports it, and the library can run
+# on /opt/rocm's own HIP runtime instead of the one torch bundles (petibm_amd/capi.py: PIB_TORCH_FIRST)
 
 from oracle import clib, mesh as omesh, operators as oops
 import slab_plans as partition
@@ -49,6 +49,8 @@ def _local_csr(A, plan):
 
 def _halo(x_pad, plan):
     """One exchange: [ghost_lo | owned | ghost_hi]; contiguous planes, one send/recv pair per neighbour."""
+    import torch
+    import torch.distributed as dist
     n = plan.n_local
     owned = x_pad[plan.ghost_lo:plan.ghost_lo + n]
     reqs = []
@@ -70,6 +72,8 @@ def _halo(x_pad, plan):
 
 
 def _allreduce(*vals):
+    import torch
+    import torch.distributed as dist
     t = torch.tensor(vals, dtype=torch.float64)
     dist.all_reduce(t)
     return t.tolist()
@@ -78,6 +82,7 @@ def _allreduce(*vals):
 def _worker(rank, world, port, n, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m, A, b = _system(n)
     plan = partition.slab_plan(n, world, rank)
@@ -129,6 +134,7 @@ def _worker(rank, world, port, n, out_dir):
 @pytest.mark.parametrize("world,n", [(2, (12, 10, 8)), (3, (9, 8, 10)), (2, (24, 16))])
 def test_zslab_pcg_over_gloo_matches_single_rank_oracle(tmp_path, world, n):
     port = _free_port()
+    import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
     m, A, b = _system(n)
     ref = clib.cg(A, b, pc="jacobi", nullspace=1, norm="unpreconditioned", rtol=1e-10, atol=0.0, dtol=1e300,
