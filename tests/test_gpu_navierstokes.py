@@ -108,6 +108,28 @@ def test_time_step_matches_oracle(case, pinned):
     s.destroy()
 
 
+@pytest.mark.parametrize("n", [(300, 70, 6), (130, 150, 9)])
+def test_first_step_rhs_on_wide_3d_meshes_is_bit_identical(n):
+    """navierstokes.hip k_ns_rhs_velocity where its launch geometry has something to get wrong: rows dealt to the XCDs in bands (from
+    64 interior rows on), two chunks of a row (more than 256 interior points), two planes per workgroup with an odd plane count --
+    every interior point exactly once, the bits of the oracle's explicit terms (navierstokes.cpp:432-521)."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    cfg = cavity(n, nu=0.02, dt=0.005)
+    m = omesh.create_mesh(cfg)
+    ref = ons.NavierStokes(m, 0.005, 0.02, pinned=False)
+    rng = np.random.default_rng(11)
+    U0 = 0.1 * rng.uniform(-1, 1, m.UN)
+    p0 = 0.1 * rng.uniform(-1, 1, m.pN)
+    ref.set_state(U0, p0)
+    ref.advance(velocity_rhs_only=True)
+    s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=KSP_P)
+    s.setState(U0, p0)
+    s.advance()
+    r1 = s.getState(rhs=True)[2]
+    assert np.array_equal(r1, ref.last_rhs1)
+    s.destroy()
+
+
 def test_unsupported_boundary_conditions_are_errors():
     from petibm_amd.capi import PibError, ERR_SUP, ERR_ARG_WRONG
     from petibm_amd.navierstokes import NavierStokesSolver
