@@ -3,6 +3,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -258,3 +259,17 @@ def test_an_exception_inside_the_library_comes_back_as_an_error_code(capi, monke
     assert e.value.code == capi.ERR_MEM
     monkeypatch.delenv("PIB_TEST_THROW")
     assert capi.config_describe("poisson", AMGX_POISSON)["method"] == "cg"
+
+
+def test_collecting_the_gpu_suite_does_not_import_torch():
+    """tests/conftest.py runs the GPU suite on /opt/rocm's own HIP runtime (PIB_TORCH_FIRST=0): that only holds while no test module
+    imports torch at collection -- afterwards torch would load the copies it bundles beside the ones the library already uses."""
+    code = ("import sys, pytest\n"
+            "class P:\n"
+            "    def pytest_collection_finish(self, session):\n"
+            "        print('TORCH_AT_COLLECTION', 'torch' in sys.modules, len(session.items))\n"
+            "pytest.main(['tests', '-m', 'gpu', '--collect-only', '-q'], plugins=[P()])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300).stdout
+    line = [l for l in out.splitlines() if l.startswith("TORCH_AT_COLLECTION")]
+    assert line and line[0].split()[1] == "False" and int(line[0].split()[2]) > 600, out[-2000:]
