@@ -12,6 +12,7 @@ using namespace pib;
 static int make_solver(pib_solver **out, const char *name, const Config &cfg, const char *cfg_path, int rank,
                        int nranks, const void *uid, int device)
 {
+    install_crash_backtrace();  // (PIB_CRASH_BACKTRACE; once per process)
     if (out == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_create: null output handle");
     *out = nullptr;
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_create: bad rank %d / %d", rank, nranks);
@@ -71,7 +72,6 @@ int pib_version(void) { return 100; }
 int pib_create(pib_solver **s, const char *name, const char *cfg_path, int rank, int nranks, const void *uid_or_null,
                int device)
 try {
-    install_crash_backtrace();
     Config cfg;
     PIB_CHK(parse_config_file(cfg_path, name ? name : "", cfg));
     return make_solver(s, name, cfg, cfg_path, rank, nranks, uid_or_null, device);
@@ -82,7 +82,6 @@ try {
 int pib_create_from_string(pib_solver **s, const char *name, const char *cfg_text, int rank, int nranks,
                            const void *uid_or_null, int device)
 try {
-    install_crash_backtrace();
     Config cfg;
     PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", cfg));
     return make_solver(s, name, cfg, "<string>", rank, nranks, uid_or_null, device);
