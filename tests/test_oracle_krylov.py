@@ -216,3 +216,58 @@ def test_chebyshev_restatement_against_scipy_and_numpy(systems):
     evA = np.linalg.eigvals(S.toarray()).real
     r = clib.chebyshev(Av, b, emin=0.98 * evA.min(), emax=1.02 * evA.max(), pc="none", rtol=1e-12, atol=0.0, maxit=500)
     assert r["reason"] == 2 and np.linalg.norm(r["x"] - us) <= 1e-10 * np.linalg.norm(us)
+
+
+@pytest.mark.parametrize("n,side", [((16, 12, 10), "right"), ((16, 12, 10), "left"), ((24, 20), "right")])
+def test_bcgs_with_the_multigrid_is_the_published_recurrence(n, side):
+    """oracle/csrc/oracle.c:orc_bcgs_gmg (BiCGStab around the V-cycle, the mean removed after every application on the singular
+    system) against a numpy restatement of the published recurrences with `GMG.apply` as M^-1: right-preconditioned with the true
+    residual's L2 norm (AmgX PBICGSTAB, what /root/reference/src/linsolver/linsolveramgx.cpp:62-72 configures from a solver file) and
+    left-preconditioned with the preconditioned residual's norm (KSPBCGS, linsolverksp.cpp:62-66).  The C restatement is what the GPU
+    path is compared with (tests/test_gpu_bicgstab_gmg.py); this pins it on the CPU."""
+    m = omesh.create_mesh(omesh.uniform_config(n))
+    D, Gm, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    dt = 1e-2
+    _, A = oops.create_poisson_operator(D, Gm, L, dt, 0.5e-2)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    g = clib.GMG(n, w, dt, nullspace=1, pre=1, post=1)
+    rng = np.random.default_rng(17)
+    xs = rng.uniform(-1, 1, m.pN)
+    xs -= xs.mean()
+    b = clib.spmv(A, xs)
+
+    def minv(v):
+        z = g.apply(v)
+        return z - z.mean()
+
+    amul = lambda v: clib.spmv(A, v)
+    op = (lambda v: amul(minv(v))) if side == "right" else (lambda v: minv(amul(v)))
+    x = np.zeros(m.pN)
+    r = b.copy() if side == "right" else minv(b)
+    rp = r.copy()
+    p = np.zeros_like(r)
+    v = np.zeros_like(r)
+    rho_old = alpha = omega_old = 1.0
+    hist = [np.linalg.norm(r)]
+    for it in range(12):
+        rho = r @ rp
+        beta = (rho / rho_old) * (alpha / omega_old)
+        p = r - (omega_old * beta) * v + beta * p
+        v = op(p)
+        alpha = rho / (v @ rp)
+        s = r - alpha * v
+        t = op(s)
+        omega = (s @ t) / (t @ t)
+        x = x + alpha * (minv(p) if side == "right" else p) + omega * (minv(s) if side == "right" else s)
+        r = s - omega * t
+        hist.append(np.linalg.norm(r))
+        rho_old, omega_old = rho, omega
+        if hist[-1] <= 1e-10 * hist[0]:
+            break
+    ref = g.bcgs(A, b, norm="unpreconditioned" if side == "right" else "preconditioned", rtol=1e-10, atol=1e-50, dtol=1e300, maxit=50)
+    assert ref["reason"] > 0 and abs(ref["iters"] - (len(hist) - 1)) <= 1
+    k = min(len(hist), len(ref["history"]), 6)
+    assert np.allclose(ref["history"][:k], hist[:k], rtol=1e-8)
+    e = (ref["x"] - ref["x"].mean()) - (x - x.mean())
+    assert np.linalg.norm(e) <= 1e-6 * np.linalg.norm(xs)
+    assert np.linalg.norm(b - clib.spmv(A, ref["x"])) <= (2e-10 if side == "right" else 1e-7) * np.linalg.norm(b)
