@@ -145,3 +145,86 @@ def test_zslab_pcg_over_gloo_matches_single_rank_oracle(tmp_path, world, n):
     assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
     e = (x - x.mean()) - (ref["x"] - ref["x"].mean())
     assert np.linalg.norm(e) <= 1e-8 * np.linalg.norm(ref["x"])
+
+
+SHIFT = 40.0  # A - SHIFT I: the (negative semi-definite) Poisson operator made non-singular, a stand-in for the velocity system
+
+
+def _worker_bcgs(rank, world, port, n, out_dir):
+    """BiCGStab + Jacobi in the lean form of csrc/krylov.hip with the residual update merged (pib_bicgstab_merge_r): per iteration two
+    halo exchanges (the products' inputs) and TWO all-reduces -- v.r~, then the five sums s.t, t.t, s.s, r~.s, r~.t from which omega,
+    |r|^2 and r.r~ follow -- instead of the three of the textbook iteration."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, A, b = _system(n)
+    plan = partition.slab_plan(n, world, rank)
+    rp_, cl, vl = _local_csr(A, plan)
+    nl, g0 = plan.n_local, plan.ghost_lo
+    rows = np.repeat(np.arange(nl), np.diff(rp_))
+    isd = cl == rows + g0
+    vl = vl.copy()
+    vl[isd] -= SHIFT
+    dinv = np.zeros(nl)
+    dinv[rows[isd]] = 1.0 / vl[isd]
+    bl = b[plan.row0:plan.row0 + nl]
+    pad = np.zeros(g0 + nl + plan.ghost_hi)
+    reductions = 0
+
+    def product(vec):  # A M^-1 vec: the sweep applied to the owned entries, the neighbours' planes exchanged
+        pad[g0:g0 + nl] = dinv * vec
+        _halo(pad, plan)
+        return np.bincount(rows, weights=vl * pad[cl], minlength=nl)
+
+    x = np.zeros(nl)
+    r = bl.copy()
+    rt = r.copy()
+    p = np.zeros(nl)
+    v = np.zeros(nl)
+    (rho,) = _allreduce(r @ rt)
+    r0 = np.sqrt(rho)
+    rho_old = alpha = omega_old = 1.0
+    its = 0
+    while its < 500:
+        beta = (rho / rho_old) * (alpha / omega_old)
+        p = r - (omega_old * beta) * v + beta * p
+        v = product(p)
+        (vrt,) = _allreduce(v @ rt)
+        reductions += 1
+        alpha = rho / vrt
+        s = r - alpha * v
+        t = product(s)
+        st, tt, ss, rts, rtt = _allreduce(s @ t, t @ t, s @ s, rt @ s, rt @ t)
+        reductions += 1
+        omega = st / tt
+        x += alpha * (dinv * p) + omega * (dinv * s)
+        r = s - omega * t  # (on the device: formed by the NEXT p-update)
+        r2 = max(ss - omega * (2.0 * st - omega * tt), 0.0)
+        rho_old, omega_old, rho = rho, omega, rts - omega * rtt
+        its += 1
+        if np.sqrt(r2) <= 1e-10 * r0:
+            break
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
+    np.save(os.path.join(out_dir, f"its{rank}.npy"), np.array([its, reductions]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, (12, 10, 8)), (3, (9, 8, 10))])
+def test_zslab_bicgstab_with_two_reductions_over_gloo_matches_single_rank_oracle(tmp_path, world, n):
+    import copy
+    port = _free_port()
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_bcgs, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    m, A, b = _system(n)
+    A2 = copy.copy(A)
+    A2.val = A.val.copy()
+    rows = np.repeat(np.arange(A.n_rows), np.diff(A.rowptr))
+    A2.val[A.col == rows] -= SHIFT
+    ref = clib.bcgs(A2, b, pc="jacobi", norm="unpreconditioned", rtol=1e-10, atol=0.0, dtol=1e300, maxit=500)
+    x = np.concatenate([np.load(tmp_path / f"x{r}.npy") for r in range(world)])
+    rec = [np.load(tmp_path / f"its{r}.npy") for r in range(world)]
+    assert len({int(v[0]) for v in rec}) == 1 and abs(int(rec[0][0]) - ref["iters"]) <= 1
+    assert all(int(v[1]) == 2 * int(v[0]) for v in rec)  # two all-reduces per iteration
+    assert np.linalg.norm(b - clib.spmv(A2, x)) <= 2e-10 * np.linalg.norm(b)
+    assert np.linalg.norm(x - ref["x"]) <= 1e-8 * np.linalg.norm(ref["x"])
