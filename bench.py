@@ -483,6 +483,110 @@ def host_buffer_case(n: int, dt: float, cfg_text: str) -> dict:
             "grid": [n, n, n], "dt": dt, "rhs": "cosine", "staged": "b in, x out (8 n^3 bytes each); x in as well when the solver file keeps the guess"}
 
 
+def pinned_device_case(n: int, dt: float, cfg_text: str, steps: int = 2) -> dict:
+    """The pinned-row convention (MatZeroRowsColumns on row 0: every `type: GPU` run of PetIBM, navierstokes.cpp:414-420) on
+    the device-assembled operator with x and b resident in HBM: the headline's solve under the other null-space convention."""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    s = LinSolverHIP("poisson", config_text=cfg_text)
+    w = np.full(n, 1.0 / n)
+    s.assemblePoisson((n, n, n), [w, w, w], dt, capi.NULLSPACE_PINNED)
+    xs = manufactured_solution(n, 0, n)
+    xs -= xs[0]
+    xs_d, b_d, x_d, r_d = s.deviceVec(), s.deviceVec(), s.deviceVec(), s.deviceVec()
+    xs_d.upload(xs)
+    s.matMult(xs_d, b_d)
+    s.solve(x_d, b_d)
+    s.synchronize()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(steps):
+        s.solve(x_d, b_d)
+        its += s.getIters()
+    s.synchronize()
+    el = time.perf_counter() - t0
+    s.matMult(x_d, r_d)
+    bl = b_d.download()
+    rl = bl - r_d.download()
+    rel = float(np.sqrt((rl @ rl) / (bl @ bl)))
+    fused = int(s.counters()[6])
+    s.destroy()
+    return {"metric": "Poisson DOF/s, pinned pressure row (the reference's type: GPU convention), x and b in HBM", "value": n ** 3 * steps / el,
+            "unit": "DOF/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": 1, "iters_per_solve": its / steps,
+            "true_rel_residual": rel, "grid": [n, n, n], "dt": dt, "rhs": "cosine (x*[0] = 0)", "residual_updates_in_vcycle": fused}
+
+
+def dropin_amgx_route_case(n: int, dt: float, tol: float, register_host: bool = False, steps: int = 2) -> dict:
+    """What an UNCHANGED PetIBM does with a `type: GPU` Poisson solver, end to end (src/linsolver/linsolveramgx.cpp:84,96 behind
+    include/petibm_amd/AmgXSolver.hpp): a host int32 CSR whose row / column 0 MatZeroRowsColumns has replaced by the identity
+    (navierstokes.cpp:414-420; the pattern keeps its explicit zeros) goes through pib_set_csr_i32 ONLY -- no grid hint, no device
+    assembly: the backend recovers the mesh structure from the entries --, the solver file is the reference's own
+    (examples/navierstokes/taylorgreenvortex3dRe1600_GPU/config/poisson_solver.info, with the bench's tolerance), b[0] = 0
+    (navierstokes.cpp:553-558), x and b are pageable host arrays and x is the initial guess (AmgXSolver::solve).  The host CSR is
+    obtained by downloading a device-assembled copy (the bench's way of having an application's matrix at this size within
+    seconds); that solver is destroyed before the timed one is created.
+    register_host: the caller's x / b page-locked with hipHostRegister around the solves (what an application could do once)."""
+    import ctypes
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    w = np.full(n, 1.0 / n)
+    t = LinSolverHIP("scratch", config_text=solver_config("jacobi", tol, 10))
+    t.assemblePoisson((n, n, n), [w, w, w], dt, capi.NULLSPACE_PINNED)
+    rp, cl, vl = t.getCSR()
+    rp32, cl32 = rp.astype(np.int32), cl.astype(np.int32)
+    del rp, cl
+    xs = manufactured_solution(n, 0, n)
+    xs -= xs[0]
+    b = np.empty_like(xs)
+    t.matMult(xs, b)
+    t.destroy()
+    assert b[0] == 0.0 and vl[0] == 1.0
+    text = reference_solver_file(tol, False).replace("pib_initial_guess_nonzero=0\n", "")  # x is the guess, as AmgX takes it
+    s = LinSolverHIP("poisson", config_text=text)
+
+    class Host:  # (setMatrix wants .rowptr / .col / .val)
+        rowptr, col, val = rp32, cl32, vl
+    t0 = time.perf_counter()
+    s.setMatrix(Host)
+    s.synchronize()
+    t_set = time.perf_counter() - t0
+    st = s.gridStructure()
+    x = np.zeros_like(xs)
+    hip = None
+    if register_host:
+        hip = ctypes.CDLL("libamdhip64.so")
+        for a in (x, b):
+            rc = hip.hipHostRegister(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 0)
+            if rc != 0:
+                raise RuntimeError(f"hipHostRegister failed ({rc})")
+    s.solve(x, b)  # warm-up: the staging buffers are allocated here
+    its, el = 0, 0.0
+    for _ in range(steps):
+        x[:] = 0.0
+        t0 = time.perf_counter()
+        s.solve(x, b)  # returns with x back in host memory
+        el += time.perf_counter() - t0
+        its += s.getIters()
+    fused = int(s.counters()[6])
+    r = np.empty_like(xs)
+    s.matMult(x, r)
+    r = b - r
+    rel = float(np.sqrt((r @ r) / (b @ b)))
+    err = float(np.abs(x - xs).max() / np.abs(xs).max())
+    if hip is not None:
+        for a in (x, b):
+            hip.hipHostUnregister(ctypes.c_void_p(a.ctypes.data))
+    s.destroy()
+    return {"metric": "Poisson DOF/s through the reference's AmgX plug point: host int32 CSR with pinned row 0 via pib_set_csr_i32 only, "
+                      "the reference's solver file, pageable host x / b, x as the guess (PCIe inclusive)",
+            "value": n ** 3 * steps / el, "unit": "DOF/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": 1,
+            "iters_per_solve": its / steps, "true_rel_residual": rel, "max_rel_error_vs_manufactured": err, "set_matrix_s": t_set,
+            "structure_recovered": bool(st and st.get("detected")), "nullspace_detected": (st or {}).get("nullspace"),
+            "residual_updates_in_vcycle": fused, "host_buffers": "hipHostRegister'ed" if register_host else "pageable",
+            "staged": "b and the guess in, x out (8 n^3 bytes each)", "grid": [n, n, n], "dt": dt, "rhs": "cosine (x*[0] = 0)",
+            "cycle": "V(1,1) of the file read as fused pairs: V(2,2) (pib_sweep_pairs=1, default)"}
+
+
 def refuse(args, why: str) -> int:
     """A run that cannot start still prints ONE JSON line (value null + the reason) instead of a bare traceback."""
     if int(os.environ.get("RANK", "0")) == 0:
@@ -902,7 +1006,11 @@ def poisson_bench(args) -> int:
                                                                             cycle="V(1,1) literally (pib_sweep_pairs=0)")),
                          ("velocity_256_cubed", lambda: velocity_case(256, 2, 1, args.kernel_reps)),
                          ("velocity_256_cubed_chebyshev", lambda: velocity_chebyshev_pair(256, args.kernel_reps)),
-                         ("host_buffers_512", lambda: host_buffer_case(512, 5e-4, base_cfg))):
+                         ("host_buffers_512", lambda: host_buffer_case(512, 5e-4, base_cfg)),
+                         # the reference's `type: GPU` convention: pressure row 0 pinned -- on the device-assembled operator, and
+                         # end to end the way an unchanged PetIBM hands things over (host CSR through setMatrix only, host x / b)
+                         ("pinned_row_512", lambda: pinned_device_case(512, 5e-4, base_cfg)),
+                         ("dropin_amgx_route_512", lambda: dropin_amgx_route_case(512, 5e-4, args.tol))):
             try:
                 entry = fn()
                 entry["name"] = name

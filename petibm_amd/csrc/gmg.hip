@@ -544,7 +544,12 @@ __global__ __launch_bounds__(256) PIB_WAVES_ATTR(PIB_WAVES_PRESMOOTH) void k_pre
                     }
                 }
             }
-            if (pin_sum != nullptr && kw == 0 && off_c == 0) bv[0] = bv[0] - *pin_sum;  // PINNED: effective b at cell 0
+            if (pin_sum != nullptr && kw == 0) {  // PINNED: effective b at cell 0 (as a tile's own cell, or as the halo cell of
+                                                  // the tiles across a periodic seam)
+                if (off_c == 0) bv[0] = bv[0] - *pin_sum;
+                if (hy_ok && off_hy == 0) hyv = hyv - *pin_sum;
+                if (hx_ok && off_hx == 0) hxv = hxv - *pin_sum;
+            }
             const double rwz = L.rwz[kw], czm = L.cmz[kw], czp = L.cpz[kw];
             bcur = bv;
             if (czm != key_zm || czp != key_zp) {  // (workgroup-uniform)
@@ -1202,7 +1207,8 @@ template <int DOTS>
 __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
                                                          const double *__restrict__ b, const double *__restrict__ xc,
                                                          const double *__restrict__ xi, double *__restrict__ xo, int FZ,
-                                                         double *__restrict__ part, int part_stride, int dlo, int dhi)
+                                                         double *__restrict__ part, int part_stride, int dlo, int dhi,
+                                                         const double *__restrict__ pin_sum = nullptr)
 {
     if (S != nullptr && S->done) return;
     // x + P e on the plane the first step works on, the first step's result on the plane the second works on: two copies each
@@ -1361,6 +1367,14 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
 #pragma unroll
         for (int e = 0; e < 2; ++e) out[e] = (in && which[e]) ? *reinterpret_cast<const v4 *>(pl + goff[e]) : zero;
     };
+    // PINNED (level 0): the effective right-hand side at global cell 0 is b[0] - *pin_sum; cell 0 is the first cell of an aligned
+    // piece -- the tile piece of workgroup (0, 0), a margin piece of its neighbours (across the seam on a periodic level)
+    auto pin_b = [&](int k, v4 bv[2]) {
+        if (pin_sum == nullptr || !inz(k) || zw(k) != 0) return;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (first[e] && goff[e] == 0) bv[e][0] = bv[e][0] - *pin_sum;
+    };
     // x + P e of the thread's pieces on plane k (old: the old iterate there): own coarse cell, then the x neighbour, per
     // z slot and y slot -- the order of k_prolong_rows / k_prolong_smooth
     auto correct = [&](int k, const v4 old[2], v4 out[2]) {
@@ -1461,6 +1475,7 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
     need_stage(l0 - 2);
     fetch(xi, l0 - 2, ok, anext);
     fetch(b, l0 - 3, first, bnext);
+    pin_b(l0 - 3, bnext);
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending on entry either (see the wait inside the march)
     for (int k = l0 - 4; k < lend; ++k) {
@@ -1477,6 +1492,7 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
         if (k + 1 < lend) {
             fetch(xi, k + 3, ok, anext);
             fetch(b, k + 2, first, bnext);
+            pin_b(k + 2, bnext);
         }
         correct(k + 2, a2, xpn);
         const int cur = k & 1, nxt = cur ^ 1;
@@ -1507,9 +1523,12 @@ __global__ __launch_bounds__(UNT) void k_prolong_smooth2(const Scalars *__restri
             const v4 out = step(0, S1[cur], s1c[0], s1m[0], s1n[0], bcur[0], rwz, czm, czp, w2);
             *reinterpret_cast<v4 *>(xo + (int64_t)k * plane + goff[0]) = out;
             if (DOTS && k >= dlo && k < dhi) {
+                // (z.r takes the UNMODIFIED residual, as k_level<8>'s braw: at the pinned cell that is 0 = (0 - sum) + sum exactly)
+                v4 br = bcur[0];
+                if (pin_sum != nullptr && k == 0 && goff[0] == 0) br[0] = br[0] + *pin_sum;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    acc0 += out[c] * bcur[0][c];
+                    acc0 += out[c] * br[c];
                     acc1 += out[c] * out[c];
                     acc2 += out[c];
                 }
@@ -1892,7 +1911,7 @@ constexpr int QSY = RSY + 2;                 // rows of the iterate's tile: the 
 constexpr int QV4 = (RSX / 4) * QSY;         // its aligned 4-cell pieces (680: up to three per thread)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_resid_restrict_march(const Scalars *__restrict__ S, LevelDev F, LevelDev C,
                                                               const double *__restrict__ b, const double *__restrict__ x,
-                                                              double *__restrict__ bc, int CZ)
+                                                              double *__restrict__ bc, int CZ, const double *__restrict__ pin_sum = nullptr)
 {
     if (S != nullptr && S->done) return;
     __shared__ __attribute__((aligned(32))) double xs[QSY][SWR];   // the iterate on the current plane: cols i0-4 .. i0+131, rows j0-2 .. j0+17 (swizzled rows: swz)
@@ -1979,6 +1998,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const double *pf = b + (int64_t)(zwrap(kf) - F.k0) * fplane;
 #pragma unroll
         for (int e = 0; e < 3; ++e) out[e] = (in && res[e]) ? *reinterpret_cast<const v4 *>(pf + goff[e]) : zero;
+        if (pin_sum != nullptr && in && zwrap(kf) == 0) {  // PINNED (level 0): effective b at global cell 0, the first cell of an aligned piece
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (res[e] && goff[e] == 0) out[e][0] = out[e][0] - *pin_sum;
+        }
     };
     auto put_x = [&](const v4 v[3]) {
 #pragma unroll
@@ -2697,7 +2721,7 @@ __device__ __forceinline__ void sm_phase(const LevelDev &F, const SmGeom &G, con
 // way down: b -> the pre-smoothed iterate x (owned cells) and the next level's right-hand side bc = P^T (b - A x)
 __global__ __launch_bounds__(SM_NT) void k_small_down(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega, int pre,
                                                       const double *__restrict__ b, double *__restrict__ x, double *__restrict__ bc, int bcx,
-                                                      int bcy, int bcz)
+                                                      int bcy, int bcz, const double *__restrict__ pin_sum = nullptr)
 {
     __shared__ double A_[SM_MAXR], B_[SM_MAXR];
     __shared__ SmTabs T;
@@ -2721,6 +2745,11 @@ __global__ __launch_bounds__(SM_NT) void k_small_down(const Scalars *__restrict_
     sm_cells(G, cell);
 #pragma unroll
     for (int u = 0; u < SM_NB; ++u) bq[u] = cell[u] >= 0 ? b[sm_global(F, G, cell[u])] : 0.0;
+    if (pin_sum != nullptr && F.k0 == 0) {  // PINNED (level 0): effective b at global cell 0, in every region that holds it
+#pragma unroll
+        for (int u = 0; u < SM_NB; ++u)
+            if (cell[u] >= 0 && sm_global(F, G, cell[u]) == 0) bq[u] = bq[u] - *pin_sum;
+    }
     sm_stage_tabs(F, C, G, T);
     __syncthreads();
     SST();
@@ -2954,6 +2983,7 @@ void gmg_release(pib_solver *s)
         if (L.d) (void)hipFree(L.d);
     }
     s->levels.clear();
+    s->pin_row = PinRow{};
     s->has_grid = false;
 }
 
@@ -3204,6 +3234,28 @@ int grid_register(pib_solver *s, int dim, const int64_t n[3], const double *cons
     for (int d = 0; d < 3 && dt == 0.0; ++d)
         if (nn[d] > 1) dt = hg[d][0] * (0.5 * (hw[d][1] + hw[d][0]));
 
+    // PINNED: row 0 of the singular operator without its diagonal (what MatZeroRowsColumns took out of the matrix): the solver's
+    // recurrence for the residual's sum reads the few entries of p next to cell 0 with these coefficients (krylov.hip cg_s1)
+    s->pin_row = PinRow{};
+    if (nullspace == PIB_NULLSPACE_PINNED) {
+        PinRow &pr = s->pin_row;
+        pr.ready = true;
+        if (k0 == 0) {
+            const double vol = (hw[0][0] * hw[1][0]) * hw[2][0];
+            const int64_t stride[3] = {1, nn[0], plane0};
+            for (int d = 0; d < 3; ++d) {
+                const int64_t nd = nn[d];
+                if (nd <= 1) continue;
+                const double w0 = hw[d][0];
+                pr.off[pr.n] = stride[d];  // towards +d: face 0
+                pr.coef[pr.n++] = (hg[d][0] / w0) * vol;
+                if (pern[d]) {  // towards -d: the wrap face, cell nd - 1 (through the low halo plane on a ring of slabs)
+                    pr.off[pr.n] = (d == 2 && P > 1) ? -plane0 : stride[d] * (nd - 1);
+                    pr.coef[pr.n++] = (hg[d][(size_t)nd - 1] / w0) * vol;
+                }
+            }
+        }
+    }
     std::vector<GridLevel> &lv = s->levels;
     const int max_levels = std::max(1, s->cfg.max_levels);
     bool replicated = (P == 1);
@@ -3575,7 +3627,10 @@ static int coarse_need(const pib_solver *s, int l, int e)
 bool gmg_fused_update_ok(const pib_solver *s)
 {
     if (!s->has_grid || s->levels.empty() || !s->gmg_error.empty()) return false;
-    if (s->cfg.smoother == Smoother::CHEBYSHEV || !s->cfg.fuse_presmooth || s->nullspace == PIB_NULLSPACE_PINNED) return false;
+    if (s->cfg.smoother == Smoother::CHEBYSHEV || !s->cfg.fuse_presmooth) return false;
+    // (a pinned pressure row: the compatible right-hand side needs the NEW residual's sum before the march that forms it --
+    // it comes from the recurrence sum r - alpha sum w, krylov.hip cg_s1, when the row next to cell 0 is known: pin_row)
+    if (s->nullspace == PIB_NULLSPACE_PINNED && (s->cfg.pin_sum_local == 0 || !s->pin_row.ready)) return false;
     if (s->levels.size() < 2) return false;
     const GridLevel &g = s->levels[0];
     const int64_t nk = g.k1 - g.k0;
@@ -3611,7 +3666,10 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     const int pre = std::max(1, s->cfg.presweeps) * deg * pairs, post = std::max(0, s->cfg.postsweeps) * deg * pairs;
     const int nl = (int)s->levels.size();
     const int P = s->comm.nranks, rank = s->comm.rank;
-    const double *pin = (s->nullspace == PIB_NULLSPACE_PINNED) ? &s->d_s->red[5] : nullptr;
+    // PINNED: the sum of the residual that makes the right-hand side compatible -- red[5], summed by the pass that formed the
+    // residual, or pin_sigma when that pass is this cycle's own first march (krylov.hip cg_s1: sum r - alpha sum w, the second sum
+    // from the few entries of p next to cell 0)
+    const double *pin = (s->nullspace == PIB_NULLSPACE_PINNED) ? (s->gmg_pin_local ? &s->d_s->pin_sigma : &s->d_s->red[5]) : nullptr;
     std::vector<double *> cur((size_t)nl, nullptr);  // current iterate buffer per level (owned pointer)
     const double lmax = s->cfg.cheby_lmax, lmin = lmax / s->cfg.cheby_ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
@@ -3882,7 +3940,6 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         const bool slabs = I.dist && li[(size_t)l + 1].dist && !(g.per & 4) && std::min(I.maxd, I.cdepth) >= fin0 + 2 &&
                            coarse_need(s, l, fin0 + 2) <= li[(size_t)l + 1].maxd;
         if (!(whole || slabs) || g.zring) return false;
-        if (l == 0 && pin != nullptr) return false;
         const bool per_ok = g.per == g.tper && (!(g.per & 4) || g.n[2] >= 8);
         if (!g.plain_pair || !per_ok || !fused_run_ok(s, g, 0, I.nk) || g.n[1] % UTY != 0) return false;
         auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
@@ -4039,10 +4096,10 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             int bc3[3];
             unsigned nblk = 0;
             const bool local_pair = !I.dist && !li[(size_t)l + 1].dist && (s->comm.nranks == 1 || (g.replicated && cg1.replicated));
-            // (level 0 too -- a 2-D case's finest level is such a level -- unless its right-hand side needs the pinned row's
-            // correction or PCG's residual update folded in; the way up of level 0 keeps its launches: its last step delivers
-            // the Krylov sums in a fixed order of workgroups)
-            const bool level_ok = l >= 1 || (pin_l == nullptr && s->gmg_upd.w == nullptr);
+            // (level 0 too -- a 2-D case's finest level is such a level, with the pinned row's correction of its right-hand side if
+            // there is one -- unless PCG's residual update is folded in; the way up of level 0 keeps its launches: its last step
+            // delivers the Krylov sums in a fixed order of workgroups)
+            const bool level_ok = l >= 1 || s->gmg_upd.w == nullptr;
             if (level_ok && !cheb && local_pair && small_level_boxes(s, g, cg1, pre, true, bc3, &nblk)) {
                 if (l == 0) {  // no swaps on the way down: the swaps of the way up must end in z (the fused pair of
                                // post-smoothing steps, k_prolong_smooth2, is ONE swap -- the same count as above)
@@ -4050,7 +4107,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                     if (up_swaps % 2 == 0) { a = z; c = xa; } else { a = xa; c = z; }
                 }
                 hipLaunchKernelGGL(k_small_down, dim3(nblk), dim3(SM_NT), 0, q, S, dev_of(g), dev_of(cg1), omega, pre, b, a, cg1.b + cg1.pad, bc3[0],
-                                   bc3[1], bc3[2]);
+                                   bc3[1], bc3[2], pin_l);
                 PIB_HIP(hipGetLastError());
                 set_valid(a, 0);
                 set_valid(cg1.b + cg1.pad, 0);
@@ -4127,11 +4184,11 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 if (!whole && I.dist && li[(size_t)l + 1].dist && !g.zring && !(g.per & 4) && valid(a) >= 2 && valid(b) >= 1 &&
                     std::min(I.maxd, I.cdepth) >= 2)
                     whole = true;
-                if (s->cfg.fuse_residual_restrict && whole && pin_l == nullptr && s->cfg.march_restrict && g.plain_pair && g.per == g.tper &&
+                if (s->cfg.fuse_residual_restrict && whole && s->cfg.march_restrict && g.plain_pair && g.per == g.tper &&
                     g.n[0] % RX == 0 && g.n[1] % RY == 0 && nkc >= 4 && nkc * c1.plane * 8 >= (int64_t)s->cfg.march_min_cells) {
                     const int CZ = nkc * c1.plane >= ((int64_t)1 << 23) ? 32 : 8;  // (as launch_restrict)
                     hipLaunchKernelGGL(k_resid_restrict_march, dim3((unsigned)(g.n[0] / RX), (unsigned)(g.n[1] / RY), (unsigned)((nkc + CZ - 1) / CZ)),
-                                       dim3(256), 0, q, S, dev_of(g), dev_of(c1), b, a, c1.b + c1.pad, CZ);
+                                       dim3(256), 0, q, S, dev_of(g), dev_of(c1), b, a, c1.b + c1.pad, CZ, pin_l);
                     PIB_HIP(hipGetLastError());
                     set_valid(c1.b + c1.pad, 0);
                     cur[(size_t)l] = a;
@@ -4233,14 +4290,14 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 double *part = s->d_gmg_part;
                 const int part_stride = (int)s->gmg_part_cap;
                 hipLaunchKernelGGL(k_prolong_smooth2<1>, mg, dim3(UNT), 0, q, S, dev_of(sub), dev_of(cg), omega, bq, xc, aq, cq, FZ, part, part_stride,
-                                   (int)g.k0, (int)g.k1);
+                                   (int)g.k0, (int)g.k1, pin_l);
                 double *stage = part + 3 * (int64_t)part_stride;
                 hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)needp, stage);
                 hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
                 s->gmg_dots_done = true;
             } else
                 hipLaunchKernelGGL(k_prolong_smooth2<0>, mg, dim3(UNT), 0, q, S, dev_of(sub), dev_of(cg), omega, bq, xc, aq, cq, FZ, (double *)nullptr, 0,
-                                   (int)g.k0, (int)g.k1);
+                                   (int)g.k0, (int)g.k1, pin_l);
             PIB_HIP(hipGetLastError());
             set_valid(c, I.dist ? fin : 0);
             std::swap(a, c);

@@ -521,6 +521,17 @@ __global__ void k_cg_s_init(Scalars *S, double *hist, double n_global, int lazy_
     }
 }
 
+// pr.n > 0 (a pinned pressure row, this rank owns cell 0, the residual's sum is wanted ahead of the pass that forms the
+// residual): sum r_new = sum r - a sum w, and sum w = -sum_f coef[f] p[off[f]] -- the columns of the singular operator sum to
+// zero and p[0] = 0 (PinRow, pib_internal.hpp).  red[5] is the sum the pass that formed r delivered: re-based every iteration,
+// the recurrence is one step long and carries no drift.
+__device__ __forceinline__ void cg_pin_sigma(Scalars *S, const PinRowDev &pr)
+{
+    if (pr.n <= 0) return;
+    double t = 0.0;
+    for (int f = 0; f < pr.n; ++f) t = fma(pr.coef[f], pr.p[pr.off[f]], t);
+    S->pin_sigma = S->red[5] + S->a * t;
+}
 __device__ __forceinline__ void cg_s1(Scalars *S)
 {
     S->xapplied = S->xa_it;  // this iteration's p-update has applied what the previous one owed
@@ -537,10 +548,11 @@ __device__ __forceinline__ void cg_s1(Scalars *S)
     S->betaold = S->beta;
     S->xa_it += 1;  // x += a p is owed
 }
-__global__ void k_cg_s1(Scalars *S)
+__global__ void k_cg_s1(Scalars *S, PinRowDev pr)
 {
     if (S->done) return;
     cg_s1(S);
+    if (!S->done) cg_pin_sigma(S, pr);
 }
 
 // do_norm: evaluate the monitored norm + convergence; do_beta: new beta, b.
@@ -901,7 +913,8 @@ static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guard
 
 // x, b: device pointers, n_local entries.
 template <int POST>
-static int finalize_post(pib_solver *s, int slot0, int nslots, int count, double *hist, int conv_is_its, hipStream_t q);
+static int finalize_post(pib_solver *s, int slot0, int nslots, int count, double *hist, int conv_is_its, hipStream_t q,
+                         const PinRowDev &pr = PinRowDev{nullptr, 0, {}, {}});
 
 int solve_cg(pib_solver *s, double *x, const double *b)
 {
@@ -934,6 +947,11 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     PIB_CHK(init_scalars(s));
     int nb = 0;
     const int pin0 = (lazy == 2 && A.row0 == 0) ? 1 : 0;
+    s->gmg_pin_local = false;  // (the set-up's cycle takes the sum OpInit delivers; the iterations may switch: see pin_local)
+    struct PinLocalReset {
+        pib_solver *s;
+        ~PinLocalReset() { s->gmg_pin_local = false; }
+    } pin_local_reset{s};
 
     // ---- initial residual, z, norms
     if (!guess) {
@@ -963,7 +981,20 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     // first kernel, which reads the residual anyway (gmg.hip k_presmooth2<., 1>: 24 B/row and a launch less per iteration).
     // That kernel recomputes halo cells, so the new residual goes to the OTHER of two buffers, iteration by iteration.
     // (several ranks, round 4: on z-slabs with deep halos too -- w is exchanged instead of the residual, gmg.hip)
-    const bool fused_upd = gmg && s->cfg.fuse_residual_update && lazy == 1 && n > s->cfg.graph_max_rows && gmg_fused_update_ok(s);
+    // (a pinned pressure row, round 5: the compatible right-hand side of the cycle needs the NEW residual's sum before the march
+    // that forms it -- pin_sigma, from cg_s1's one-step recurrence)
+    const bool fused_upd = gmg && s->cfg.fuse_residual_update && (lazy == 1 || (lazy == 2 && s->cfg.pin_sum_local != 0 && s->pin_row.ready)) &&
+                           n > s->cfg.graph_max_rows && gmg_fused_update_ok(s);
+    const bool pin_local = gmg && lazy == 2 && s->pin_row.ready && (s->cfg.pin_sum_local == 1 || (s->cfg.pin_sum_local < 0 && fused_upd));
+    PinRowDev pin_dev{nullptr, 0, {}, {}};
+    if (pin_local && A.row0 == 0 && s->pin_row.n > 0) {
+        pin_dev.p = P;
+        pin_dev.n = s->pin_row.n;
+        for (int f = 0; f < s->pin_row.n; ++f) {
+            pin_dev.off[f] = (long long)s->pin_row.off[f];
+            pin_dev.coef[f] = s->pin_row.coef[f];
+        }
+    }
     struct UpdCtx {
         double *hist;
         double ng;
@@ -1031,11 +1062,12 @@ int solve_cg(pib_solver *s, double *x, const double *b)
             }
             PIB_CHK(matmult(s, P, W, part_pw, true, q));
             if (s->comm.nranks == 1)
-                PIB_CHK(finalize_post<4>(s, SLOT_PW, 1, spmv_blocks, nullptr, 0, q));
+                PIB_CHK(finalize_post<4>(s, SLOT_PW, 1, spmv_blocks, nullptr, 0, q, pin_dev));
             else {
                 PIB_CHK(finalize(s, SLOT_PW, 1, spmv_blocks, q));
-                hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s);
+                hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s, pin_dev);
             }
+            s->gmg_pin_local = pin_local;  // (read by gmg_apply while the body is enqueued or captured; cleared behind the loop)
             if (fused_upd) {
                 s->gmg_upd.w = W;
                 s->gmg_upd.r_old = R;
@@ -1629,7 +1661,7 @@ __global__ void k_b_s_end(Scalars *S, double *hist, int conv_is_its)
 // launches.  POST: 1 BiCGStab alpha, 2 omega, 3 end of iteration, 4 CG alpha, 5 / 6: 1 / 3 with the deferred x update.
 template <int POST>
 __global__ __launch_bounds__(256) void k_finalize_post(Scalars *__restrict__ S, const double *__restrict__ part, int slot0, int nslots,
-                                                       int count, double *hist, int conv_is_its)
+                                                       int count, double *hist, int conv_is_its, PinRowDev pr = PinRowDev{nullptr, 0, {}, {}})
 {
     if (S->done) return;
     __shared__ double sh[4];
@@ -1648,7 +1680,10 @@ __global__ __launch_bounds__(256) void k_finalize_post(Scalars *__restrict__ S, 
         if (POST == 1) b_s_alpha(S);
         if (POST == 2) b_s_omega(S);
         if (POST == 3) b_s_end(S, hist, conv_is_its);
-        if (POST == 4) cg_s1(S);
+        if (POST == 4) {
+            cg_s1(S);
+            if (!S->done) cg_pin_sigma(S, pr);
+        }
         if (POST == 5) {  // matrix-free BiCGStab: this iteration's p-update has applied what the previous one owed
             S->xpend = 0;
             b_s_alpha(S);
@@ -1675,9 +1710,9 @@ __global__ __launch_bounds__(256) void k_finalize_post(Scalars *__restrict__ S, 
     }
 }
 template <int POST>
-static int finalize_post(pib_solver *s, int slot0, int nslots, int count, double *hist, int conv_is_its, hipStream_t q)
+static int finalize_post(pib_solver *s, int slot0, int nslots, int count, double *hist, int conv_is_its, hipStream_t q, const PinRowDev &pr)
 {
-    hipLaunchKernelGGL((k_finalize_post<POST>), dim3(1), dim3(256), 0, q, s->d_s, s->d_part, slot0, nslots, count, hist, conv_is_its);
+    hipLaunchKernelGGL((k_finalize_post<POST>), dim3(1), dim3(256), 0, q, s->d_s, s->d_part, slot0, nslots, count, hist, conv_is_its, pr);
     PIB_HIP(hipGetLastError());
     return 0;
 }

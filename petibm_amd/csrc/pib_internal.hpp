@@ -156,6 +156,7 @@ struct Config {
     int cg_single_reduction = 0;   // CG with PETSc's single-reduction recurrences (-<name>_ksp_cg_single_reduction; solver file: pib_cg_single_reduction=1): ONE all-reduce per iteration, 16 B/row more vector traffic (krylov.hip solve_cg_sr)
     int fuse_residual_update_slabs = 1;  // ... on z-slabs too: w = A p is exchanged to the depth the residual was, the march keeps the residual's ghost planes by recurrence (gmg.hip k_presmooth2<., 1> with wext)
     int fuse_residual_update = 1;  // PCG + multigrid on one rank: r = r - alpha w by the V-cycle's first march instead of a pass of its own
+    int pin_sum_local = -1;  // pinned pressure row + multigrid: the residual's sum that makes the cycle's right-hand side compatible from the recurrence sum r - alpha sum w, sum w = -(row 0 of the singular operator) . p (krylov.hip cg_s1) instead of the update pass's own sum -- what lets the update ride in the cycle's first march; -1: with the fused update only, 1: always, 0: never (no fused update under a pinned row)
     int fuse_bicgstab_dots = 1;  // ... and its two dot-only passes summed by the products themselves (sums grouped by tile: the iterates equal the CSR path's to rounding, no longer bit for bit; 0 keeps the bit-identical route)
     int blocked_direct_solve = 1;   // dense.hip: the explicit inverse of the direct solver by 64-column block elimination (0: one launch per column)
     int accumulate_unscaled_x = 1;  // ... and x summed before the Jacobi sweep, swept once at the end (krylov.hip OpBFUpdateP::y): 8 B/row/iteration less, x to rounding
@@ -214,6 +215,25 @@ struct Scalars {
     // p[kp1] = a0 p[km1] + omega p[k] + cz z, and which of the two rotating vectors holds the current iterate
     double c_km1, c_k, cheb_mu, cheb_omegaprod, cheb_scale, cheb_a0, cheb_cz;
     int sol;
+    // pinned pressure row + multigrid with the residual update inside the cycle: sum r of the residual the first march is about to
+    // form (cg_s1: red[5] - alpha sum w)
+    double pin_sigma;
+};
+
+// Row 0 of the SINGULAR level-0 operator without its diagonal (the entries MatZeroRowsColumns removed from the matrix,
+// navierstokes.cpp:414-420): offsets of the neighbours of cell 0 in a ghost-padded vector and the unscaled coefficients.
+// The columns of the singular operator sum to zero, so for any p with p[0] = 0:  sum_{i >= 1} (A' p)_i = -sum_f coef[f] p[off[f]].
+struct PinRow {
+    bool ready = false;  // the grid is registered with a pinned row (true on every rank; n > 0 on the rank that owns cell 0)
+    int n = 0;
+    int64_t off[6] = {0, 0, 0, 0, 0, 0};
+    double coef[6] = {0, 0, 0, 0, 0, 0};
+};
+struct PinRowDev {  // ... as a kernel argument, with the vector
+    const double *p;
+    int n;
+    long long off[6];
+    double coef[6];
 };
 
 // ------------------------------------------------------------------ who sends how many doubles to whom
@@ -433,6 +453,8 @@ struct pib_solver {
     double *d_gmg_part = nullptr;   // z.r, z.z, sum z partials of the V-cycle's last smoothing kernel (gmg.hip mode 8)
     int64_t gmg_part_cap = 0;
     bool gmg_want_dots = false, gmg_dots_done = false;
+    pib::PinRow pin_row;          // gmg.hip grid_register (PINNED)
+    bool gmg_pin_local = false;   // this cycle's compatible right-hand side takes Scalars::pin_sigma instead of red[5] (set by the solver around gmg_apply)
     // PCG's residual update r = r_old - alpha w left to the preconditioner's first kernel (gmg.hip k_presmooth2<., 1>): set by
     // the solver around gmg_apply; `after` finalizes r.r / sum r from the kernel's partials and runs the convergence step
     struct GmgUpd {

@@ -4,6 +4,7 @@
 #include <petscvec.h>
 typedef struct _p_Mat *Mat;
 typedef const char *MatType;
+typedef struct { PetscInt k, j, i, c; } MatStencil;
 #define MATSEQAIJ "seqaij"
 #define MATMPIAIJ "mpiaij"
 typedef enum { MAT_INITIAL_MATRIX, MAT_REUSE_MATRIX, MAT_IGNORE_MATRIX, MAT_INPLACE_MATRIX } MatReuse;

@@ -10,6 +10,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -31,6 +33,43 @@ def test_amgx_surface_rejects_a_wrong_argument_type():
     r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-I", "tests/stubs/petsc", "-I", "include", "-x", "c++", "-"],
                        cwd=ROOT, input=bad, capture_output=True, text=True)
     assert r.returncode != 0
+
+
+REFERENCE = "/root/reference"
+
+
+def _reference_unit(src, extra_inc=()):
+    """`g++ -fsyntax-only -DHAVE_AMGX` of one of the reference's OWN source files, read where it lies under /root/reference
+    (nothing copied, nothing built), with <AmgXSolver.hpp> resolving to this repository's shim and PETSc / yaml-cpp to the
+    declarations-only stubs."""
+    inc = []
+    for d in list(extra_inc) + ["tests/stubs/petsc", "tests/stubs/yaml", "include/petibm_amd", os.path.join(REFERENCE, "include")]:
+        inc += ["-I", d]
+    return subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-DHAVE_AMGX"] + inc + [os.path.join(REFERENCE, "src", "linsolver", src)],
+                          cwd=ROOT, capture_output=True, text=True)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "src", "linsolver")), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize("src", ["linsolveramgx.cpp", "linsolver.cpp"])
+def test_the_references_own_amgx_plug_file_parses_against_the_shim(src):
+    """INTEGRATION.md B says src/linsolver/linsolveramgx.cpp compiles UNCHANGED against include/petibm_amd/AmgXSolver.hpp.
+    Here the reference's own translation units -- linsolveramgx.cpp (the six AmgXSolver members it calls: initialize, setA,
+    solve, getIters, getResidual, finalize; :37-123) and linsolver.cpp (the factory that makes a LinSolverAmgX for `type: GPU`,
+    :77-83) -- are type-checked IN PLACE against that shim.  A syntax check, not a build: PETSc and yaml-cpp are
+    declarations-only stubs (tests/stubs), nothing is linked or run; skipped where /root/reference does not exist."""
+    r = _reference_unit(src)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "src", "linsolver")), reason="the reference tree exists in the build container only")
+def test_the_reference_plug_file_check_has_teeth(tmp_path):
+    """... and it fails when the shim lacks a member the reference calls (getResidual(iter, res), linsolveramgx.cpp:123)"""
+    shim = open(os.path.join(ROOT, "include", "petibm_amd", "AmgXSolver.hpp")).read()
+    bad = shim.replace("getResidual", "getResidualRenamed")
+    assert bad != shim
+    (tmp_path / "AmgXSolver.hpp").write_text(bad)
+    r = _reference_unit("linsolveramgx.cpp", extra_inc=[str(tmp_path), os.path.join(ROOT, "include", "petibm_amd")])
+    assert r.returncode != 0 and "getResidual" in r.stderr
 
 
 def test_petsc_ksp_driver_parses_against_the_stub_and_bench_builds_it_only_when_petsc_is_found(monkeypatch, tmp_path):

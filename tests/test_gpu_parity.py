@@ -946,6 +946,46 @@ def test_residual_update_inside_the_vcycle_is_bit_identical(lin, flavour, sweeps
     assert out[2][2] == out[1][2] and np.array_equal(out[2][0], out[1][0]) and np.array_equal(out[2][1], out[1][1])
 
 
+@pytest.mark.parametrize("sweeps", [2, 1])
+def test_residual_update_inside_the_vcycle_with_a_pinned_row(lin, sweeps):
+    """The convention every `type: GPU` run of PetIBM uses (MatZeroRowsColumns on row 0, navierstokes.cpp:414-420) with the
+    residual update inside the cycle's first march (round 5).  The cycle's compatible right-hand side needs sum r of the NEW
+    residual before the march that forms it: cg_s1 gives it as sum r_old - alpha sum w, with sum w from the entries of p next
+    to cell 0 (the columns of the singular operator sum to zero).  Against the separate pass fed the same sum
+    (pib_pin_sum_local=1: the same iterates up to the grouping of red[5]'s partial sums, which the recurrence starts from)
+    and against the separate pass with its own direct sum (the round-4 path); all the other fused marches (residual +
+    restriction, prolongation + two steps) run with the pinned cell too."""
+    from petibm_amd import capi
+    n = (256, 128, 136)
+    w = [np.full(n[0], 1.0 / n[0]) * (1.0 + 0.3 * np.sin(np.arange(n[0]) / 17.0)),
+         np.full(n[1], 1.0 / n[1]), np.full(n[2], 1.5 / n[2]) * (1.0 + 0.2 * np.cos(np.arange(n[2]) / 11.0))]
+    dt = 0.01
+    xs = np.random.default_rng(7).uniform(-1, 1, n[0] * n[1] * n[2])
+    xs[0] = 0.0
+    out = []
+    for extra in ("", "pib_fuse_residual_update=0\npib_pin_sum_local=1\n", "pib_fuse_residual_update=0\n", "pib_pin_sum_local=0\n"):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra="pib_march_min_cells=0\n" + extra))
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED)
+        b = np.empty_like(xs)
+        s.matMult(xs, b)
+        assert b[0] == 0.0  # (the identity row)
+        x = np.zeros_like(xs)
+        s.solve(x, b)
+        r = np.empty_like(xs)
+        s.matMult(x, r)
+        out.append((x, np.array(s.getResidualHistory()), s.getIters(), np.linalg.norm(b - r) / np.linalg.norm(b), int(s.counters()[6])))
+        s.destroy()
+    fused, same_sum, direct, off = out
+    assert fused[4] >= fused[2] and same_sum[4] == 0 and direct[4] == 0 and off[4] == 0  # pin_sum_local=0: no fused update under a pinned row
+    assert 5 <= fused[2] <= 40 and fused[2] == same_sum[2] == direct[2] == off[2]
+    assert fused[3] <= 2e-10 and fused[0][0] == 0.0
+    scale = np.abs(direct[0]).max()
+    assert np.abs(fused[0] - same_sum[0]).max() <= 1e-11 * scale and np.allclose(fused[1], same_sum[1], rtol=1e-9)
+    assert np.abs(fused[0] - direct[0]).max() <= 1e-9 * scale and np.allclose(fused[1], direct[1], rtol=1e-7)
+    assert np.array_equal(direct[0], off[0]) and np.array_equal(direct[1], off[1])
+    assert np.abs(fused[0] - xs).max() <= 1e-6 * np.abs(xs).max()
+
+
 def test_one_sweep_of_the_solver_file_is_a_fused_pair_of_steps(lin):
     """`pib_sweep_pairs` (default 1): the reference's files say presweeps = postsweeps = 1 (AmgX's classical AMG); the
     geometric stand-in reads a sweep as one fused pair of damped-Jacobi steps.  The default with V(1,1) in the file is, bit

@@ -569,30 +569,37 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per, pc):
 @pytest.mark.parametrize("n,per,ratios", [((128, 32, 24), (True, True, True), None), ((256, 16, 40), (True, False, True), (1.0, 1.01, 1.0)),
                                           ((128, 16, 34), (False, True, False), (1.002, 1.0, 0.99)),
                                           ((128, 16, 8), (False, False, True), (1.002, 1.01, 1.0))])
-def test_marching_transfers_on_periodic_levels_are_bit_identical(lin, n, per, ratios, key, sweeps):
+@pytest.mark.parametrize("pinned", [False, True])
+def test_marching_transfers_on_periodic_levels_are_bit_identical(lin, n, per, ratios, key, sweeps, pinned):
     """gmg.hip k_restrict_march / k_prolong_smooth where the transfers reach across a periodic seam (the tile's cells
     beyond the domain are the ones at the other end, plane -1 is plane nz - 1, coarse plane -1 is coarse plane nzc - 1):
     the same sums in the same order as the row kernels, so the whole solve is bit-identical with them switched off; the
-    all-periodic case is the Taylor-Green box of examples/navierstokes/taylorgreenvortex3dRe1600_GPU."""
+    all-periodic case is the Taylor-Green box of examples/navierstokes/taylorgreenvortex3dRe1600_GPU -- which, as a
+    `type: GPU` case, pins pressure row 0 (navierstokes.cpp:414-420): pinned = True is that convention, cell 0 being a
+    margin cell of the tiles across the seams."""
     from petibm_amd import capi
     dt = 0.01
     cfg = omesh.periodic_config(n, per, ratios=ratios)
     m = omesh.create_mesh(cfg)
     D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
     _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
-    xs, b = rhs_for(A)
+    if pinned:
+        A = oops.pin_row0(A)
+    xs, b = rhs_for(A, zero_mean=not pinned)
+    if pinned:
+        b[0] = 0.0
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
     for march in (1, 0):
         s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=sweeps, post=sweeps, extra=f"pib_march_min_cells=0\n{key}={march}\n"))
         s.setPeriodic(per)
-        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)
         s.solve(x, b)
         out.append((x, s.getResidualHistory(), s.getIters()))
         s.destroy()
     assert out[0][2] == out[1][2] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
-    g = clib.GMG(n, w, dt, nullspace=1, pre=sweeps, post=sweeps, omega=0.9, coarsest_sweeps=32, periodic=per)
+    g = clib.GMG(n, w, dt, nullspace=2 if pinned else 1, pre=sweeps, post=sweeps, omega=0.9, coarsest_sweeps=32, periodic=per)
     ref = g.pcg(A, b, rtol=1e-10, maxit=200)
     assert iters_close(out[0][2], ref["iters"])
     assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
@@ -600,24 +607,31 @@ def test_marching_transfers_on_periodic_levels_are_bit_identical(lin, n, per, ra
 
 @pytest.mark.parametrize("n,per", [((128, 16, 24), (True, True, True)), ((128, 8, 40), (True, False, True)),
                                    ((256, 16, 18), (False, True, False))])
-def test_blocked_smoothers_on_periodic_levels(lin, n, per):
+@pytest.mark.parametrize("pinned", [False, True])
+def test_blocked_smoothers_on_periodic_levels(lin, n, per, pinned):
     """gmg.hip k_presmooth2 / k_level_march on periodic levels (the tile's halo cells are the ones across the seam,
     plane -1 is plane nz - 1): the fused pre-smoothing pair is bit-identical to the streaming kernels, the blocked level
-    kernel equal to rounding (mode 8 groups its sums by tile), and both follow the oracle's periodic V-cycle."""
+    kernel equal to rounding (mode 8 groups its sums by tile), and both follow the oracle's periodic V-cycle.  pinned: the
+    reference's Taylor-Green `type: GPU` convention -- cell 0, whose right-hand side carries the compatibility term, is then a
+    HALO cell of the tiles across the x and y seams (round 5: their first step had taken its unmodified value)."""
     from petibm_amd import capi
     dt = 0.01
     cfg = omesh.periodic_config(n, per)
     m = omesh.create_mesh(cfg)
     D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
     _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
-    xs, b = rhs_for(A)
+    if pinned:
+        A = oops.pin_row0(A)
+    xs, b = rhs_for(A, zero_mean=not pinned)
+    if pinned:
+        b[0] = 0.0
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = {}
     for name, extra in (("march", "pib_march_min_cells=0\n"), ("nofuse", "pib_march_min_cells=0\npib_fuse_presmooth=0\n"),
                         ("stream", "pib_march_min_cells=0\npib_march_levels=0\npib_fuse_presmooth=0\n")):
         s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=extra))
         s.setPeriodic(per)
-        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)
         s.solve(x, b)
         out[name] = (x, s.getResidualHistory(), s.getIters())
@@ -626,7 +640,7 @@ def test_blocked_smoothers_on_periodic_levels(lin, n, per):
     assert np.array_equal(out["march"][0], out["nofuse"][0])
     assert out["march"][2] == out["stream"][2] and np.allclose(out["march"][1], out["stream"][1], rtol=1e-9)
     assert np.abs(out["march"][0] - out["stream"][0]).max() <= 1e-11 * np.abs(out["stream"][0]).max()
-    g = clib.GMG(n, w, dt, nullspace=1, pre=2, post=2, omega=0.9, coarsest_sweeps=32, periodic=per)
+    g = clib.GMG(n, w, dt, nullspace=2 if pinned else 1, pre=2, post=2, omega=0.9, coarsest_sweeps=32, periodic=per)
     ref = g.pcg(A, b, rtol=1e-10, maxit=200)
     assert iters_close(out["march"][2], ref["iters"])
     ke = min(len(out["march"][1]), len(ref["history"]), 6)
