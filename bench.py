@@ -560,13 +560,15 @@ def dropin_amgx_route_case(n: int, dt: float, tol: float, register_host: bool = 
             if rc != 0:
                 raise RuntimeError(f"hipHostRegister failed ({rc})")
     s.solve(x, b)  # warm-up: the staging buffers are allocated here
-    its, el = 0, 0.0
+    its, el, h2d, d2h = 0, 0.0, 0.0, 0.0
     for _ in range(steps):
         x[:] = 0.0
         t0 = time.perf_counter()
         s.solve(x, b)  # returns with x back in host memory
         el += time.perf_counter() - t0
         its += s.getIters()
+        sm = s.stagingMs()
+        h2d, d2h = h2d + sm[0], d2h + sm[1]
     fused = int(s.counters()[6])
     r = np.empty_like(xs)
     s.matMult(x, r)
@@ -583,6 +585,7 @@ def dropin_amgx_route_case(n: int, dt: float, tol: float, register_host: bool = 
             "iters_per_solve": its / steps, "true_rel_residual": rel, "max_rel_error_vs_manufactured": err, "set_matrix_s": t_set,
             "structure_recovered": bool(st and st.get("detected")), "nullspace_detected": (st or {}).get("nullspace"),
             "residual_updates_in_vcycle": fused, "host_buffers": "hipHostRegister'ed" if register_host else "pageable",
+            "copy_in_ms": h2d / steps, "copy_out_ms": d2h / steps, "device_ms": 1e3 * el / steps - (h2d + d2h) / steps,
             "staged": "b and the guess in, x out (8 n^3 bytes each)", "grid": [n, n, n], "dt": dt, "rhs": "cosine (x*[0] = 0)",
             "cycle": "V(1,1) of the file read as fused pairs: V(2,2) (pib_sweep_pairs=1, default)"}
 

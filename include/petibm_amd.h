@@ -413,6 +413,10 @@ int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_avg);
  * [3]=halo exchanges (all-gathers included), [4]=host syncs, [5]=ranks of the communicator (ncclCommCount),
  * [6]=PCG iterations whose residual update ran inside the V-cycle's first kernel (pib_fuse_residual_update). */
 int pib_get_counters(pib_solver *s, int64_t counters[8]);
+/* Host-vector callers (the Vecs of linsolverksp.cpp:97-116 / AmgXSolver::solve, linsolveramgx.cpp:96-105, live in host memory):
+ * milliseconds the last pib_solve spent staging b (and x, when it is the guess) to HBM and x back over PCIe; 0 / 0 when both
+ * pointers were device pointers. */
+int pib_get_staging_ms(pib_solver *s, double *h2d_ms, double *d2h_ms);
 /* Krylov iterations launched as replays of the captured iteration graph since the solver was created (launch-bound systems:
  * pib_use_graph, pib_graph_max_rows; on several ranks with the device-ordered peer transport only). */
 int pib_get_graph_replays(pib_solver *s, int64_t *replays);

@@ -108,6 +108,7 @@ _PROTOS = {
     "pib_ns_get_ib_operator": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp, _vp, _vp]),
     "pib_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pib_get_counters": (C.c_int, [_vp, _vp]),
+    "pib_get_staging_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

@@ -1,4 +1,5 @@
 // capi.cpp -- the extern "C" surface declared in include/petibm_amd.h.
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -439,6 +440,10 @@ try {
     const double *bdev = b;
     const size_t bytes = sizeof(double) * (size_t)s->A.n;
     if (!xd || !bd) PIB_CHK(ensure_stage(s));
+    // (host vectors: what the copies over PCIe cost is kept for pib_get_staging_ms -- wall time around the enqueue + wait of each
+    // direction; the stream is idle when a solve starts, so that is the copies' own time)
+    s->stage_ms[0] = s->stage_ms[1] = 0.0;
+    const auto t_in = std::chrono::steady_clock::now();
     if (!xd) {
         xdev = s->x_dev;
         if (s->cfg.initial_guess_nonzero) PIB_HIP(hipMemcpyAsync(xdev, x, bytes, hipMemcpyHostToDevice, s->stream));
@@ -446,6 +451,10 @@ try {
     if (!bd) {
         PIB_HIP(hipMemcpyAsync(s->b_dev, b, bytes, hipMemcpyHostToDevice, s->stream));
         bdev = s->b_dev;
+    }
+    if ((!xd || !bd) && bytes >= ((size_t)1 << 20)) {  // (small systems inside a time loop: no extra host round trip, no figure)
+        PIB_HIP(hipStreamSynchronize(s->stream));  // (pageable source: the copy has returned already; a registered one: now)
+        s->stage_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
     }
     int err;
     if (s->redist.active) {
@@ -481,8 +490,10 @@ try {
         err = fail(PIB_ERR_SUP, "solver %s: unsupported Krylov method", s->name.c_str());
     if (err) return err;
     if (!xd) {
+        const auto t_out = std::chrono::steady_clock::now();
         PIB_HIP(hipMemcpyAsync(x, xdev, bytes, hipMemcpyDeviceToHost, s->stream));
         PIB_HIP(hipStreamSynchronize(s->stream));
+        s->stage_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_out).count();
     }
     if (s->reason < 0 && s->cfg.error_if_not_converged)
         return fail(PIB_ERR_CONV_FAILED, "PetIBM exited due to solver %s diverged with reason %d (iterations %d, residual %g).",
@@ -635,6 +646,16 @@ int pib_get_graph_replays(pib_solver *s, int64_t *replays)
 try {
     if (s == nullptr || replays == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
     *replays = s->graph_replays + (s->redist.active ? s->redist.inner->graph_replays : 0);
+    return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
+}
+
+int pib_get_staging_ms(pib_solver *s, double *h2d_ms, double *d2h_ms)
+try {
+    if (s == nullptr || h2d_ms == nullptr || d2h_ms == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
+    *h2d_ms = s->stage_ms[0];
+    *d2h_ms = s->stage_ms[1];
     return 0;
 } catch (...) {
     return pib::fail_exception(__func__);

@@ -443,6 +443,7 @@ struct pib_solver {
     int n_work = 0;
     double *x_dev = nullptr, *b_dev = nullptr;  // staging for host-pointer callers
     int64_t stage_n = 0;
+    double stage_ms[2] = {0.0, 0.0};  // host-vector callers: what the last solve spent copying b (+ the guess) in / x out (pib_get_staging_ms)
     pib::Scalars *d_s = nullptr, *h_s = nullptr;
     double *d_part = nullptr;  // [PIB_NRED][PIB_MAXPART]
     double *d_spmv_part = nullptr;  // one p.Ap partial per SpMV workgroup

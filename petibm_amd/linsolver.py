@@ -278,6 +278,12 @@ class LinSolverBase:
         capi.check(capi.load().pib_get_counters(self._h, c.ctypes.data))
         return c
 
+    def stagingMs(self):
+        """(h2d_ms, d2h_ms) the last solve spent copying host vectors in / out (pib_get_staging_ms); zeros for device vectors"""
+        a, b = C.c_double(), C.c_double()
+        capi.check(capi.load().pib_get_staging_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def deviceVec(self, n: Optional[int] = None) -> DeviceVec:
         return DeviceVec(self, self.n_local if n is None else n)
 
