@@ -763,6 +763,10 @@ def poisson_bench(args) -> int:
         st = {}
         try:
             uid = make_id(transport) if world > 1 else None
+            if transport == "rccl" and os.environ.get("PIB_FORCE_RCCL_FAIL") == "1":
+                # first-contact drill (tests, tools/first_contact.sh): behave as if RCCL's bootstrap had failed on this node -- raised
+                # HERE, where pib_create's error would surface; the library itself carries no test hook
+                raise RuntimeError("ncclCommInitRank: forced failure (PIB_FORCE_RCCL_FAIL=1)")
             sv = LinSolverHIP("poisson", config_text=base_text + extra, rank=rank, nranks=world, uid=uid, device=local)
             st["s"] = sv
             w = np.full(n, 1.0 / n)

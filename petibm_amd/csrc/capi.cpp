@@ -1,4 +1,5 @@
 // capi.cpp -- the extern "C" surface declared in include/petibm_amd.h.
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <new>
@@ -103,11 +104,15 @@ try {
 int pib_config_describe(const char *name, const char *cfg_text, char *buf, int buflen)
 try {
     if (buf == nullptr || buflen < 1) return fail(PIB_ERR_ARG_NULL, "pib_config_describe: null buffer");
-    // (drill of the ABI's catch-all, tests/test_host_logic.py: an exception raised inside the library comes back as a code)
+#ifdef PIB_TEST_HOOKS
+    // (drill of the ABI's catch-all, tests/test_host_logic.py: an exception raised inside the library comes back as a code.
+    // Compiled only into the test variant of this one translation unit -- tests build it with -DPIB_TEST_HOOKS; the product
+    // library carries no hook)
     if (const char *e = std::getenv("PIB_TEST_THROW")) {
         if (e[0] == 'm') throw std::bad_alloc();
         throw std::runtime_error(e);
     }
+#endif
     Config c;
     PIB_CHK(parse_config_text(cfg_text ? cfg_text : "", name ? name : "", c));
     const char *method = c.method == Method::CG ? "cg" : (c.method == Method::BICGSTAB ? "bicgstab" : (c.method == Method::CHEBYSHEV ? "chebyshev" : "preonly"));
@@ -116,13 +121,18 @@ try {
                   "flavor=%s type=\"%s\" method=%s pc=%s norm=%s max_iters=%d rtol=%.17g atol=%.17g dtol=%.17g "
                   "monitor=%d guess_nonzero=%d error_if_not_converged=%d jacobi_relaxation=%.17g presweeps=%d "
                   "postsweeps=%d smoother=%s smoother_relaxation=%.17g coarsest_sweeps=%d max_levels=%d "
-                  "cheby_degree=%d cheby_lmax=%.17g cheby_lmin=%.17g cg_single_reduction=%d sweep_pairs=%d",
+                  "cheby_degree=%d cheby_lmax=%.17g cheby_lmin=%.17g cg_single_reduction=%d sweep_pairs=%d "
+                  "effective_presteps=%d effective_poststeps=%d",
                   c.flavor == Flavor::AMGX ? "amgx" : "ksp", c.flavor == Flavor::AMGX ? "NVIDIA AmgX" : "PETSc KSP",
                   method, pc, c.norm == NormType::PRECONDITIONED ? "preconditioned" : "unpreconditioned", c.max_iters,
                   c.rtol, c.atol, c.dtol, c.monitor_residual ? 1 : 0, c.initial_guess_nonzero ? 1 : 0,
                   c.error_if_not_converged ? 1 : 0, c.jacobi_relaxation, c.presweeps, c.postsweeps,
                   c.smoother == Smoother::JACOBI ? "jacobi" : "chebyshev", c.smoother_relaxation, c.coarsest_sweeps,
-                  c.max_levels, c.cheby_degree, c.cheby_lmax, c.cheby_lmax / c.cheby_ratio, c.cg_single_reduction, c.sweep_pairs);
+                  c.max_levels, c.cheby_degree, c.cheby_lmax, c.cheby_lmax / c.cheby_ratio, c.cg_single_reduction, c.sweep_pairs,
+                  // what the cycle runs (gmg.hip gmg_apply): a sweep of the file is a fused PAIR of damped-Jacobi steps unless
+                  // pib_sweep_pairs=0; a Chebyshev sweep is one polynomial of degree cheby_degree
+                  std::max(1, c.presweeps) * (c.smoother == Smoother::CHEBYSHEV ? std::max(1, c.cheby_degree) : (c.sweep_pairs ? 2 : 1)),
+                  std::max(0, c.postsweeps) * (c.smoother == Smoother::CHEBYSHEV ? std::max(1, c.cheby_degree) : (c.sweep_pairs ? 2 : 1)));
     return 0;
 } catch (...) {
     return pib::fail_exception(__func__);
@@ -253,6 +263,7 @@ int pib_set_csr(pib_solver *s, int64_t n_local, int64_t row0_global, int64_t n_g
                 const int64_t *col_global, const double *val)
 try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr: null solver");
+    PIB_CHK(comm_usable(s));
     return set_csr_any(s, n_local, row0_global, n_global, rowptr, col_global, nullptr, nullptr, val);
 } catch (...) {
     return pib::fail_exception(__func__);
@@ -262,6 +273,7 @@ int pib_set_csr_i32(pib_solver *s, int32_t n_local, int32_t row0_global, int32_t
                     const int32_t *col_global, const double *val)
 try {
     if (s == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_set_csr_i32: null solver");
+    PIB_CHK(comm_usable(s));
     return set_csr_any(s, n_local, row0_global, n_global, nullptr, nullptr, rowptr, col_global, val);
 } catch (...) {
     return pib::fail_exception(__func__);
@@ -434,6 +446,7 @@ int pib_solve(pib_solver *s, double *x, const double *b)
 try {
     if (s == nullptr || x == nullptr || b == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_solve: null argument");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "solver %s: pib_solve called before a matrix was set", s->name.c_str());
+    PIB_CHK(comm_usable(s));  // (a communicator aborted by ANY solver of the sharing group: fail at once, never a null or dangling handle)
     PIB_HIP(hipSetDevice(s->device));
     const bool xd = is_device_ptr(x), bd = is_device_ptr(b);
     double *xdev = x;
@@ -546,6 +559,7 @@ int pib_mat_mult(pib_solver *s, const double *x, double *y)
 try {
     if (s == nullptr || x == nullptr || y == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_mat_mult: null argument");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_mat_mult called before a matrix was set");
+    PIB_CHK(comm_usable(s));
     PIB_HIP(hipSetDevice(s->device));
     PIB_CHK(ensure_work(s, 4));
     const size_t bytes = sizeof(double) * (size_t)s->A.n;

@@ -3620,6 +3620,22 @@ static int coarse_need(const pib_solver *s, int l, int e)
     return std::max(need, 0);
 }
 
+// Several ranks: the fused residual update changes WHICH vector travels (w instead of r) and where the reductions sit, so all
+// ranks must take it or none.  Slabs differ by a plane (512 x 512 x 380 on 8 ranks: 47 or 48 planes, either side of the 12.58 M-cell
+// threshold): the conditions are evaluated for EVERY rank's slab -- plane counts, the cell threshold, the partial-sum slots, the
+// captured-graph limit -- from quantities all ranks hold (gmg_own); what is left to the launch site (pointer alignment, halo depths)
+// is the same on every rank by construction (pads and strides are multiples of the level's plane and of 4 doubles).
+static bool fused_update_slabs_all_ranks(const pib_solver *s, const GridLevel &g)
+{
+    for (int q2 = 0; q2 < s->comm.nranks; ++q2) {
+        const int64_t nk = s->gmg_own[0][(size_t)q2].second - s->gmg_own[0][(size_t)q2].first;
+        if (nk < 8 || nk * g.plane <= s->cfg.graph_max_rows) return false;
+        const int FZ = march_planes(g, nk);
+        if (!fused_run_ok(s, g, 0, nk) || (g.n[0] / FX) * (g.n[1] / FY) * ((nk + FZ - 1) / FZ + 2) > PIB_MAXPART) return false;
+    }
+    return true;
+}
+
 // One V-cycle: z = M^-1 r.   r, z: ghost-padded work vectors of the Krylov solver
 // (their ghost planes double as the level-0 halo planes).
 // PCG may leave its residual update to the level-0 pre-smoothing march (k_presmooth2<., 1>): one rank, the fused march serves
@@ -3640,10 +3656,9 @@ bool gmg_fused_update_ok(const pib_solver *s)
         // (the cycle decides again with its own predicate at the launch site and falls back to the separate pass if it must)
         if (!s->cfg.fuse_residual_update_slabs || !s->cfg.deep_halo || g.replicated || g.zring || (g.per & 4)) return false;
         if (std::max(1, s->cfg.presweeps) * (s->cfg.sweep_pairs ? 2 : 1) < 2) return false;
-        for (int q2 = 0; q2 < s->comm.nranks; ++q2)
-            if (s->gmg_own[0][(size_t)q2].second - s->gmg_own[0][(size_t)q2].first < 8) return false;
-        return fused_run_ok(s, g, 0, nk) && (g.n[0] / FX) * (g.n[1] / FY) * ((nk + FZ - 1) / FZ + 2) <= PIB_MAXPART;
+        return fused_update_slabs_all_ranks(s, g);
     }
+    if (s->A.n <= s->cfg.graph_max_rows) return false;  // (a captured iteration cannot alternate the residual's two buffers)
     if (g.k0 != 0 || nk != g.n[2] || !fused_run_ok(s, g, 0, nk)) return false;
     return (g.n[0] / FX) * (g.n[1] / FY) * ((nk + FZ - 1) / FZ) <= PIB_MAXPART;
 }
@@ -4076,9 +4091,11 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             // predicate of its two launch sites below; if it cannot take the update, the update runs as a pass of its own first
             const int FZ0 = march_planes(g, I.nk);
             auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
-            bool site = s->cfg.fuse_residual_update == 1 && !cheb && s->cfg.fuse_presmooth && fused_run_ok(s, g, 0, I.nk) &&
-                        (g.n[0] / FX) * (g.n[1] / FY) * ((I.nk + FZ0 - 1) / FZ0 + 2) <= PIB_MAXPART && al32(b) &&
-                        (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
+            // (several ranks: the slab-dependent parts for EVERY rank's slab -- fused_update_slabs_all_ranks -- so that all ranks fall
+            // back together or not at all)
+            bool site = s->cfg.fuse_residual_update == 1 && !cheb && s->cfg.fuse_presmooth && al32(b) && (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
+            if (I.dist) site = site && fused_update_slabs_all_ranks(s, g);
+            else site = site && fused_run_ok(s, g, 0, I.nk) && (g.n[0] / FX) * (g.n[1] / FY) * ((I.nk + FZ0 - 1) / FZ0 + 2) <= PIB_MAXPART;
             // z-slabs: the two-step march only, deep halos (the residual's depth is what w is exchanged to), aligned planes
             if (I.dist)
                 site = site && pre >= 2 && !g.zring && down_depth(0) >= 2 && down_depth(0) <= I.maxd && al32(s->gmg_upd.w) && al32(s->gmg_upd.r_old) &&

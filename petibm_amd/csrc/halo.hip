@@ -658,6 +658,7 @@ static int peer_attach(pib_solver *s, int rank, int nranks, const char *name)
     return 0;
 }
 
+static void adopt_nccl(pib_solver *s);
 int comm_init(pib_solver *s, int rank, int nranks, const void *uid)
 {
     s->comm.rank = rank;
@@ -677,16 +678,45 @@ int comm_init(pib_solver *s, int rank, int nranks, const void *uid)
     ncclUniqueId id;
     static_assert(sizeof(ncclUniqueId) <= PIB_UID_BYTES, "unique id does not fit");
     std::memcpy(&id, uid, sizeof(id));
-    // first-contact drill (tests, tools/first_contact.sh): behave as if RCCL's bootstrap had failed on this node
-    if (const char *f = std::getenv("PIB_FORCE_RCCL_FAIL"))
-        if (f[0] == '1') return fail(PIB_ERR_LIB, "ncclCommInitRank: forced failure (PIB_FORCE_RCCL_FAIL=1)");
     PIB_NCCL(ncclCommInitRank(&s->comm.comm, nranks, id, rank));
+    adopt_nccl(s);
+    return 0;
+}
+
+// the communicator just created in s->comm.comm gets its shared holder (destroyed by the last solver that lets go of it)
+static void adopt_nccl(pib_solver *s)
+{
+    s->comm.shared = std::shared_ptr<CommShared>(new CommShared{s->comm.comm, false}, [](CommShared *c) {
+        if (c->comm && !c->aborted) (void)ncclCommDestroy(c->comm);
+        delete c;
+    });
+}
+
+void comm_abort(pib_solver *s)
+{
+    if (s->comm.shared) {
+        if (!s->comm.shared->aborted && s->comm.shared->comm) (void)ncclCommAbort(s->comm.shared->comm);
+        s->comm.shared->aborted = true;
+        s->comm.shared->comm = nullptr;
+    } else if (s->comm.comm)
+        (void)ncclCommAbort(s->comm.comm);
+    s->comm.comm = nullptr;
+}
+
+int comm_usable(pib_solver *s)
+{
+    if (s->comm.shared && s->comm.shared->aborted) {
+        s->comm.comm = nullptr;  // (an alias of the aborted handle)
+        return fail(PIB_ERR_LIB, "solver %s: its RCCL communicator was aborted (a collective did not complete within PIB_RCCL_TIMEOUT_S, in this "
+                                 "solver or in one that shares the communicator): destroy the solvers of the group and create them again",
+                    s->name.c_str());
+    }
     return 0;
 }
 
 void comm_release(pib_solver *s)
 {
-    if (s->comm.comm && !s->comm.borrowed) (void)ncclCommDestroy(s->comm.comm);
+    s->comm.shared.reset();  // (the last holder destroys the communicator, unless it was aborted)
     s->comm.comm = nullptr;
     if (s->comm.loop && s->comm.peer && !s->comm.borrowed) peer_destroy(s->comm.loop);  // this solver attached it
     s->comm.loop = nullptr;  // a loopback group is owned by whoever created it
@@ -763,6 +793,9 @@ int comm_setup_halo(pib_solver *s)
     std::vector<int64_t> all;
     PIB_CHK(allgather_host4(s, mine, all));
     int err = 0;
+    // (the longest message of this plan on ANY rank: what the peer transport chooses its protocol from, group-wide)
+    A.halo_group_longest = 0;
+    for (int q = 0; q < P; ++q) A.halo_group_longest = std::max(A.halo_group_longest, std::max(all[4 * (size_t)q + 1], all[4 * (size_t)q + 2]));
     // the setMatrix route: rank 0 reaching below its first row (or the last rank beyond its last) means the slab axis is
     // periodic -- upload_csr has placed those columns next to the rank's rows
     if (all[4 * 0 + 1] > 0 || all[4 * (size_t)(P - 1) + 2] > 0) s->comm.ring = true;
@@ -800,7 +833,7 @@ int comm_setup_halo(pib_solver *s)
 static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, bool has_pv, bool has_nx,
                                 const std::vector<std::pair<const double *, int64_t>> &to_prev,
                                 const std::vector<std::pair<const double *, int64_t>> &to_next, double *ghost_lo, int64_t lo,
-                                double *ghost_hi, int64_t hi, const char *what)
+                                double *ghost_hi, int64_t hi, const char *what, int64_t group_longest = 0)
 {
     LoopbackGroup *g = s->comm.loop;
     PeerFailGuard guard(g);
@@ -808,7 +841,12 @@ static int peer_window_exchange(pib_solver *s, hipStream_t st, int pv, int nx, b
     int64_t np = 0, nn = 0;
     for (const auto &m : to_prev) np += m.second;
     for (const auto &m : to_next) nn += m.second;
-    const int64_t longest = std::max(std::max(np, nn), std::max(lo, hi));
+    // The two protocols below do not interoperate (puts into the neighbour's window against gets from the own one), so the choice
+    // must be the GROUP's: `group_longest` is the longest message any rank of the group has in this exchange, agreed when the plan
+    // was built (comm_setup_halo: DeviceCsr::halo_group_longest).  The multigrid's plane exchanges pass 0: their messages are
+    // depth x plane on every rank.  (Until round 5 a rank decided from its own messages: two neighbours either side of the
+    // quarter-window bound -- non-uniform ghost ranges -- would have picked different paths and hung.)
+    const int64_t longest = std::max(std::max(std::max(np, nn), std::max(lo, hi)), group_longest);
     // device-ordered: a message per neighbour in one receive half (a quarter window each).  Longer messages -- up to half a
     // send window, the host-ordered limit -- take the host-ordered path below, as the general exchange and the all-gather do
     // (inside a captured iteration that path refuses: begin()).
@@ -897,7 +935,7 @@ static int lb_halo(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, 
 // Generic contiguous-plane exchange on a ghost-padded vector:
 //   [lo ghosts | n_owned | hi ghosts], x_owned points at the owned part.
 int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, int64_t hi, int64_t send_prev,
-                         int64_t send_next, hipStream_t st)
+                         int64_t send_next, hipStream_t st, int64_t group_longest)
 {
     const int P = s->comm.nranks, r = s->comm.rank;
     if (!s->comm.active()) return 0;
@@ -906,7 +944,7 @@ int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_
     if (s->comm.loop && s->comm.loop->shm) {
         const bool ring = s->comm.ring;
         return peer_window_exchange(s, st, (r + P - 1) % P, (r + 1) % P, r > 0 || ring, r < P - 1 || ring, {{x_owned, send_prev}},
-                                    {{x_owned + n_owned - send_next, send_next}}, x_owned - lo, lo, x_owned + n_owned, hi, "halo planes");
+                                    {{x_owned + n_owned - send_next, send_next}}, x_owned - lo, lo, x_owned + n_owned, hi, "halo planes", group_longest);
     }
     if (s->comm.loop) return lb_halo(s, x_owned, n_owned, lo, hi, st);
     if (s->comm.ring) {
@@ -956,7 +994,7 @@ static int halo_exchange_segments(pib_solver *s, double *x_owned, hipStream_t st
         for (int64_t c : A.seg_recv_hi) hi += c;
         const bool ring = s->comm.ring;
         return peer_window_exchange(s, st, (r + P - 1) % P, (r + 1) % P, r > 0 || ring, r < P - 1 || ring, to_prev, to_next,
-                                    x_owned - A.ghost_lo, lo, x_owned + A.n, hi, "halo segments");
+                                    x_owned - A.ghost_lo, lo, x_owned + A.n, hi, "halo segments", A.halo_group_longest);
     }
     if (s->comm.loop) {
         LoopbackGroup *g = s->comm.loop;
@@ -1038,7 +1076,7 @@ int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st)
     if (!s->comm.active()) return 0;
     if (A.general) return halo_exchange_general(s, x_owned, st);
     if (A.segmented) return halo_exchange_segments(s, x_owned, st);
-    return halo_exchange_planes(s, x_owned, A.n, A.ghost_lo, A.ghost_hi, A.send_prev, A.send_next, st);
+    return halo_exchange_planes(s, x_owned, A.n, A.ghost_lo, A.ghost_hi, A.send_prev, A.send_next, st, A.halo_group_longest);
 }
 
 // in-place sum over ranks of `count` (<= PIB_NRED) doubles in device memory
@@ -1381,6 +1419,7 @@ try {
     s->comm.rank = 0;
     s->comm.nranks = 1;
     PIB_NCCL(ncclCommInitRank(&s->comm.comm, 1, id, 0));
+    adopt_nccl(s);
     int cnt = 0;
     PIB_NCCL(ncclCommCount(s->comm.comm, &cnt));
     if (comm_ranks_out) *comm_ranks_out = cnt;
@@ -1499,8 +1538,7 @@ try {
     *max_err_out = err;
     PIB_HIP(hipFree(d));
     PIB_HIP(hipFree(d2));
-    (void)ncclCommDestroy(s->comm.comm);
-    s->comm.comm = nullptr;
+    comm_release(s);
     (void)hipEventDestroy(ev_a);
     (void)hipEventDestroy(ev_b);
     (void)hipStreamDestroy(s->stream);
@@ -1529,6 +1567,8 @@ try {
         ncclUniqueId id;
         PIB_NCCL(ncclGetUniqueId(&id));
         PIB_NCCL(ncclCommInitRank(&s->comm.comm, 1, id, 0));
+        adopt_nccl(s);
+    adopt_nccl(s);
         s->comm.ring = true;
     } else
         PIB_HIP(hipSetDevice(s->device));
@@ -1559,8 +1599,7 @@ try {
     if (s->comm.loop) PIB_CHK(s->comm.loop->barrier());
     PIB_HIP(hipFree(d));
     if (own) {
-        (void)ncclCommDestroy(s->comm.comm);
-        s->comm.comm = nullptr;
+        comm_release(s);
         (void)hipStreamDestroy(s->stream);
         s->stream = nullptr;
     }

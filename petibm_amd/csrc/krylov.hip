@@ -693,8 +693,7 @@ static int poll(pib_solver *s)
             if (++spins > 2000) {  // (the first ~2000 queries spin: a batch takes a millisecond or so; then 50 us naps)
                 std::this_thread::sleep_for(std::chrono::microseconds(50));
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
-                    (void)ncclCommAbort(s->comm.comm);
-                    s->comm.comm = nullptr;
+                    comm_abort(s);  // (once for every solver that shares the communicator: they all see `aborted` from here on)
                     return fail(PIB_ERR_LIB, "solver %s: an RCCL collective did not complete within %.0f s (PIB_RCCL_TIMEOUT_S): communicator aborted",
                                 s->name.c_str(), limit);
                 }
@@ -983,8 +982,10 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     // (several ranks, round 4: on z-slabs with deep halos too -- w is exchanged instead of the residual, gmg.hip)
     // (a pinned pressure row, round 5: the compatible right-hand side of the cycle needs the NEW residual's sum before the march
     // that forms it -- pin_sigma, from cg_s1's one-step recurrence)
+    // (several ranks: gmg_fused_update_ok decides from EVERY rank's slab -- its rows against the captured-graph limit included --,
+    // never from this rank's own: all ranks take the fused form or none does)
     const bool fused_upd = gmg && s->cfg.fuse_residual_update && (lazy == 1 || (lazy == 2 && s->cfg.pin_sum_local != 0 && s->pin_row.ready)) &&
-                           n > s->cfg.graph_max_rows && gmg_fused_update_ok(s);
+                           gmg_fused_update_ok(s);
     const bool pin_local = gmg && lazy == 2 && s->pin_row.ready && (s->cfg.pin_sum_local == 1 || (s->cfg.pin_sum_local < 0 && fused_upd));
     PinRowDev pin_dev{nullptr, 0, {}, {}};
     if (pin_local && A.row0 == 0 && s->pin_row.n > 0) {

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -284,6 +285,7 @@ struct DeviceCsr {
     int64_t first_boundary_lo = 0;  // rows [0, n_lo) touch the low halo
     int64_t n_lo = 0, n_hi = 0;     // rows touching the low / high halo (contiguous at both ends)
     int64_t send_prev = 0, send_next = 0;  // entries the neighbours need from this rank
+    int64_t halo_group_longest = 0;        // ... and the longest such message on any rank of the group (the peer transport's protocol choice)
     int64_t max_chunk_nnz = 1 << 30;       // largest 256-row chunk (selects the SpMV's LDS capacity)
     // Segmented halo plan (packed velocity ordering: a rank's vector is [u-slab | v-slab | w-slab], so what a neighbour
     // needs is one plane out of each block): {offset in the owned vector, count} per message to the previous / next
@@ -340,8 +342,17 @@ struct GridLevel {
 };
 
 struct LoopbackGroup;  // halo.hip: test-only transport (ranks = threads of one process on one GPU)
+// One RCCL communicator, shared by every solver that borrows it (one RCCL id makes one communicator: the Poisson solver of a
+// flow engine, the inner slab solver of the box route).  The LAST holder to let go destroys it -- unless it was aborted
+// (krylov.hip poll(): a collective that never completed): then every holder sees `aborted`, nobody destroys or uses the
+// dangling handle again, and any later solve of the group fails at once with a clear error (halo.hip comm_abort / comm_usable).
+struct CommShared {
+    ncclComm_t comm = nullptr;
+    bool aborted = false;
+};
 struct Comm {
     ncclComm_t comm = nullptr;
+    std::shared_ptr<CommShared> shared;  // set with `comm` (null for the loopback / peer transports and for one rank)
     LoopbackGroup *loop = nullptr;
     int rank = 0, nranks = 1;
     bool borrowed = false;  // the communicator belongs to another solver of the same engine (one RCCL id makes one communicator)
@@ -516,7 +527,7 @@ int comm_init(pib_solver *s, int rank, int nranks, const void *uid);
 int comm_setup_halo(pib_solver *s);
 int halo_exchange(pib_solver *s, double *x_owned, hipStream_t st);
 int halo_exchange_planes(pib_solver *s, double *x_owned, int64_t n_owned, int64_t lo, int64_t hi, int64_t send_prev,
-                         int64_t send_next, hipStream_t st);
+                         int64_t send_next, hipStream_t st, int64_t group_longest = 0);
 int allreduce_slots(pib_solver *s, int first, int count, hipStream_t st);
 int comm_allreduce_sum(pib_solver *s, double *dev, int count, hipStream_t st);
 int comm_allreduce_big(pib_solver *s, double *dev, int64_t count, hipStream_t st);
@@ -526,6 +537,8 @@ int comm_allgatherv(pib_solver *s, const double *send, double *recv_base, const 
 // every rank's messages lie back to back (destination order) at `stream`; the message from rank q lands at recv[q]
 int comm_exchange_v(pib_solver *s, const ExchangePlan &pl, const double *stream, double *const *recv, hipStream_t st);
 void comm_release(pib_solver *s);
+void comm_abort(pib_solver *s);   // ncclCommAbort ONCE for the whole sharing group
+int comm_usable(pib_solver *s);   // PIB_ERR_LIB when the group's communicator was aborted (also clears this solver's alias)
 bool comm_capturable(const pib_solver *s);
 void comm_capture_boundary(pib_solver *s, bool begin);
 // partition.cpp: rows in any partition (DMDA boxes, the per-rank-packed velocity ordering)

@@ -409,7 +409,9 @@ int redist_rows_on_device(pib_solver *s, pib_solver *in, const RedistField &F, c
     A.n_global = n_global;
     A.ghost_lo = (nnz > 0 && cmin < G.row0s) ? G.row0s - cmin : 0;
     A.ghost_hi = (nnz > 0 && cmax > G.row0s + F.n_slab - 1) ? cmax - (G.row0s + F.n_slab - 1) : 0;
-    if (A.ghost_lo + A.n + A.ghost_hi >= (int64_t)INT32_MAX) return fail(PIB_ERR_SUP, "set_csr: local column range does not fit 32-bit indices");
+    // (behind the ranks' vote for the device route: PIB_ERR_SUP is the caller's cue to fall back to the host path, which this one rank
+    // would then walk alone -- a plain error instead; unreachable while n_global < 2^31 is part of the vote)
+    if (A.ghost_lo + A.n + A.ghost_hi >= (int64_t)INT32_MAX) return fail(PIB_ERR_LIB, "set_csr: local column range does not fit 32-bit indices");
     A.rp64 = false;
     PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
     PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));

@@ -454,3 +454,39 @@ def test_residual_update_inside_the_vcycle_on_slabs(P, n, extra):
     assert s1.getIters() == fused[0][1]
     assert np.linalg.norm((x - x.mean()) - (x1 - x1.mean())) <= 1e-9 * np.linalg.norm(x1)
     s1.destroy()
+
+
+@pytest.mark.parametrize("limit", ["cells", "graph_rows"])
+def test_fused_residual_update_is_decided_by_all_ranks_slabs_together(limit):
+    """Slabs differ by a plane: 128 x 16 x 35 on 3 ranks is 12 / 12 / 11 planes.  With the marching kernels' cell threshold
+    (or the captured-graph row limit) BETWEEN the two slab sizes, a decision taken from a rank's own slab would put ranks 0, 1
+    on the fused residual update -- w travels, the reductions sit inside the cycle -- and rank 2 on the separate pass: the
+    collectives would no longer match (a hang, or r received where w was sent).  The conditions are evaluated for every
+    rank's slab (gmg.hip fused_update_slabs_all_ranks): no rank fuses, the solve is the single rank's."""
+    from petibm_amd import capi
+    import slab_plans as partition
+    from petibm_amd.linsolver import LinSolverHIP
+    dt, P, n = 0.01, 3, (128, 16, 35)
+    m, A, xs, b = _system(n, dt)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    plans = partition.all_plans(n, P)
+    planes = sorted({pl.n_local // (n[0] * n[1]) for pl in plans})
+    assert planes == [11, 12]
+    between = 128 * 16 * 11 + 1000  # more than the thin slab has, fewer than the thick ones
+    base = (f"pib_march_min_cells={between}\npib_graph_max_rows=0\n" if limit == "cells" else f"pib_march_min_cells=0\npib_graph_max_rows={between}\n")
+
+    def rank_fn(r, uid):
+        pl = plans[r]
+        s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=base, sweeps=2), rank=r, nranks=P, uid=uid, device=0)
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
+        x = np.zeros(pl.n_local)
+        s.solve(x, np.ascontiguousarray(b[pl.row0:pl.row0 + pl.n_local]))
+        out = (x, s.getIters(), s.counters().copy())
+        s.destroy()
+        return out
+
+    res = _run_ranks(P, rank_fn)
+    assert all(int(r[2][6]) == 0 for r in res) and len({r[1] for r in res}) == 1
+    assert len({(int(r[2][2]), int(r[2][3])) for r in res}) == 1  # the same reductions and exchanges on every rank
+    x = np.concatenate([r[0] for r in res])
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)

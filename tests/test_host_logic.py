@@ -244,21 +244,49 @@ def test_every_solver_file_key_of_the_backend_is_documented():
     assert listed - read == set(), f"documented but not read: {sorted(listed - read)}"
 
 
-def test_an_exception_inside_the_library_comes_back_as_an_error_code(capi, monkeypatch):
+def test_an_exception_inside_the_library_comes_back_as_an_error_code(built_library, tmp_path):
     """Every extern "C" entry point is a function-try-block (csrc/config.cpp: fail_exception): a C++ exception must not unwind
     into the C / ctypes / cgo caller (std::terminate: the host application aborted by its linear solver).  The reference's
-    own boundary behaves like this: PETSc functions return error codes (CHKERRQ, /root/reference/src/linsolver/linsolverksp.cpp:48-60)."""
-    from petibm_amd.capi import PibError
-    monkeypatch.setenv("PIB_TEST_THROW", "drill")
-    with pytest.raises(PibError) as e:
-        capi.config_describe("poisson", AMGX_POISSON)
-    assert e.value.code == capi.ERR_LIB and "C++ exception: drill" in str(e.value)
-    monkeypatch.setenv("PIB_TEST_THROW", "m")
-    with pytest.raises(PibError) as e:
-        capi.config_describe("poisson", AMGX_POISSON)
-    assert e.value.code == capi.ERR_MEM
-    monkeypatch.delenv("PIB_TEST_THROW")
-    assert capi.config_describe("poisson", AMGX_POISSON)["method"] == "cg"
+    own boundary behaves like this: PETSc functions return error codes (CHKERRQ, /root/reference/src/linsolver/linsolverksp.cpp:48-60).
+    The throw is drilled in a TEST VARIANT of the library -- csrc/capi.cpp recompiled with -DPIB_TEST_HOOKS and linked with the
+    product's other objects, loaded in a process of its own; the product library carries no test hook (and ignores the variable)."""
+    from petibm_amd import build as B
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(os.path.dirname(B.library_path()), "obj")
+    hook_o, hook_so = str(tmp_path / "capi_hooks.o"), str(tmp_path / "libpetibm_amd_hooks.so")
+    cflags = [f for f in B.HIPCC_FLAGS if f != "-shared"]
+    subprocess.check_call([hipcc] + cflags + ["-DPIB_TEST_HOOKS", "-x", "hip", "-c", os.path.join(ROOT, "petibm_amd", "csrc", "capi.cpp"), "-o", hook_o])
+    objs = [hook_o] + [os.path.join(objdir, os.path.splitext(f)[0] + ".o") for f in B.SOURCES if f != "capi.cpp"]
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hook_so] + objs + ["-lrccl"])
+    code = ("import ctypes as C, os, sys\n"
+            "lib = C.CDLL(sys.argv[1])\n"
+            "lib.pib_last_error.restype = C.c_char_p\n"
+            "buf = C.create_string_buffer(2048)\n"
+            "for val in ('drill', 'm', None):\n"
+            "    if val is None: os.environ.pop('PIB_TEST_THROW')\n"
+            "    else: os.environ['PIB_TEST_THROW'] = val\n"
+            "    rc = lib.pib_config_describe(b'poisson', sys.argv[2].encode(), buf, 2048)\n"
+            "    print('RC', rc, lib.pib_last_error().decode() if rc else buf.value.decode())\n")
+    out = subprocess.run([sys.executable, "-c", code, hook_so, AMGX_POISSON], capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("RC ")]
+    assert len(lines) == 3, out.stdout + out.stderr
+    assert lines[0].startswith("RC 76 ") and "C++ exception: drill" in lines[0]   # PETSC_ERR_LIB
+    assert lines[1].startswith("RC 55 ")                                          # PETSC_ERR_MEM
+    assert lines[2].startswith("RC 0 ") and "method=cg" in lines[2]
+    # the product library: no hook
+    out = subprocess.run([sys.executable, "-c", code, B.library_path(), AMGX_POISSON], capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("RC ")]
+    assert len(lines) == 3 and all(l.startswith("RC 0 ") for l in lines), out.stdout + out.stderr
+
+
+def test_config_describe_reports_the_steps_the_cycle_runs(capi):
+    """`pib_sweep_pairs` (default 1) reads a sweep of the solver file as a fused pair of damped-Jacobi steps: the description
+    says so next to the file's own counts; Chebyshev smoothing counts its polynomial degree instead."""
+    d = capi.config_describe("poisson", AMGX_POISSON)
+    assert (d["presweeps"], d["postsweeps"], d["sweep_pairs"]) == ("1", "1", "1")
+    assert (d["effective_presteps"], d["effective_poststeps"]) == ("2", "2")
+    d = capi.config_describe("poisson", AMGX_POISSON + "pib_sweep_pairs=0\n")
+    assert (d["effective_presteps"], d["effective_poststeps"]) == ("1", "1")
 
 
 def test_collecting_the_gpu_suite_does_not_import_torch():
