@@ -246,12 +246,13 @@ class GMG:
     def bcgs(self, m, b, x0=None, norm="unpreconditioned", rtol=1e-10, atol=0.0, dtol=1e4, maxit=1000):
         """KSPBCGS / PBICGSTAB preconditioned by the V-cycle (oracle/csrc/oracle.c:orc_bcgs_gmg): left-preconditioned with
         norm="preconditioned" (the KSP flavour), right-preconditioned otherwise (the AmgX flavour); the mean is removed after
-        every application when the multigrid was created with nullspace=1."""
+        every application when the multigrid was created with nullspace=1; nullspace=2 (pinned row 0): the output is shifted
+        by its value at cell 0 and the pinned unknown keeps the input's value."""
         b = np.ascontiguousarray(b, dtype=np.float64)
         x = np.zeros(m.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
         hist = np.full(maxit + 2, np.nan)
         its, rn = C.c_int(0), C.c_double(0)
-        reason = lib().orc_bcgs_gmg(self._h, m.n_rows, m.rowptr, m.col, m.val, 1 if self.nullspace == 1 else 0, NORM[norm],
+        reason = lib().orc_bcgs_gmg(self._h, m.n_rows, m.rowptr, m.col, m.val, self.nullspace if self.nullspace in (1, 2) else 0, NORM[norm],
                                     rtol, atol, dtol, int(maxit), int(x0 is not None), b, x, C.byref(its), C.byref(rn),
                                     hist.ctypes.data)
         return {"x": x, "iters": its.value, "rnorm": rn.value, "reason": int(reason),

@@ -150,7 +150,8 @@ typedef struct {
     const double *val;
     const double *dinv; /* 1/diag for Jacobi, NULL otherwise */
     int pc;
-    int nullspace; /* 1: remove the mean after every PC apply (MatNullSpace const) */
+    int nullspace; /* 1: remove the mean after every PC apply (MatNullSpace const); 2 (PC_GMG only): pinned pressure row --
+                    * z <- z - z[0], z[0] = r[0] behind the cycle, whose right-hand side gmg.c makes compatible (as gmg.c PCAPPLY) */
     void *gmg;     /* PC_GMG: the build's multigrid (gmg.c) */
 } sys_t;
 
@@ -169,6 +170,12 @@ static void pcapply(const sys_t *s, const double *r, double *z)
         copy(n, r, z);
     }
     if (s->nullspace == 1) remove_mean(n, z);
+    if (s->nullspace == 2 && s->pc == PC_GMG) {
+        const double z0 = z[0];
+#pragma omp parallel for schedule(static)
+        for (i64 i = 0; i < n; ++i) z[i] -= z0;
+        z[0] = r[0];
+    }
 }
 
 static int converged_default(double rnorm, double ttol, double rnorm0, double atol, double dtol, int *reason)

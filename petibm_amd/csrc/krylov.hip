@@ -301,6 +301,37 @@ struct OpDotZR {
     }
 };
 
+// Pinned pressure row + multigrid where the shift cannot be lazy (single-reduction CG: the matrix is applied to z itself;
+// BiCGStab: the cycle's output goes straight into a product): z <- z - z[0], z[0] = r[0] in a pass of its own -- what the
+// oracle's PCAPPLY / pcapply do for nullspace 2 (oracle/csrc/gmg.c, oracle.c) -- with the sums z.r, z.z, sum z of the result
+// (DOTS).  red[slot] holds z[0] of the raw cycle output (k_fetch_z0, all-reduced); `owner`: this rank holds row 0.
+template <int DOTS>
+struct OpPinShift {
+    static constexpr int NRED = DOTS ? 3 : 0;
+    double *z;
+    const double *r;
+    int owner, slot;
+    double m;
+    __device__ void prepare(const Scalars *S) { m = S->red[slot]; }
+    template <int W>
+    __device__ void apply(int64_t i, double (&acc)[DOTS ? 3 : 1]) const
+    {
+        Pack<W> vz = ld<W>(z, i), vr = ld<W>(r, i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) vz.v[k] = vz.v[k] - m;
+        if (owner && i == 0) vz.v[0] = vr.v[0];
+        st<W>(z, i, vz);
+        if (DOTS) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                acc[0] += vz.v[k] * vr.v[k];
+                acc[1] += vz.v[k] * vz.v[k];
+                acc[DOTS ? 2 : 0] += vz.v[k];
+            }
+        }
+    }
+};
+
 // x += a p (the update the previous iteration owes, elements [xlo, xhi) of the index space: x has no ghost entries) ;
 // p = (z - mean) + b p      (first iteration: p = z - mean)
 struct OpUpdateP {
@@ -483,10 +514,10 @@ __device__ __forceinline__ void lazy_shift(Scalars *S, double n_global, int lazy
     S->mean = m;
 }
 
-__global__ void k_fetch_z0(Scalars *S, const double *z, int owner)
+__global__ void k_fetch_z0(Scalars *S, const double *z, int owner, int slot = 3)
 {
     if (S->done) return;
-    S->red[3] = owner ? z[0] : 0.0;
+    S->red[slot] = owner ? z[0] : 0.0;
 }
 
 __global__ void k_pin_x0(double *x, const double *b) { x[0] = b[0]; }
@@ -1142,10 +1173,12 @@ int solve_cg_sr(pib_solver *s, double *x, const double *b)
     const bool gmg = (pc == Precond::GMG);
     int lazy = 0;
     if (s->nullspace == PIB_NULLSPACE_CONSTANT) lazy = 1;
-    if (s->nullspace == PIB_NULLSPACE_PINNED && gmg)
-        return fail(PIB_ERR_SUP, "solver %s: single-reduction CG with the multigrid and a pinned pressure row is not supported "
-                                 "(the lazy shift by z[0] does not commute with the product): use the constant null space or the standard recurrence",
-                    s->name.c_str());
+    // A pinned pressure row with the multigrid (round 5): the shift by z[0] does not commute with the product (the pinned matrix
+    // does not annihilate constants), and here the matrix is applied to z itself -- so it is applied for real, in a pass of its
+    // own behind the cycle (OpPinShift, which also forms z.r, z.z, sum z); the cycle's compatible right-hand side needs the
+    // GLOBAL sum of r ahead of it.  Costs one 24 B/row pass and, on several ranks, two small all-reduces more per iteration.
+    const bool pin_gmg = gmg && s->nullspace == PIB_NULLSPACE_PINNED;
+    const int pin0 = (pin_gmg && A.row0 == 0) ? 1 : 0;
     const int monitor = s->cfg.monitor_residual ? 1 : 0;
     const int conv_is_its = monitor ? 0 : 1;
     const bool v2 = aligned16(x) && aligned16(b);
@@ -1173,11 +1206,36 @@ int solve_cg_sr(pib_solver *s, double *x, const double *b)
         return 0;
     };
 
+    // the cycle under a pinned row: sum r made global first, the cycle, z[0] to every rank, the shift with the sums
+    auto pinned_cycle = [&](bool guarded) -> int {
+        PIB_CHK(allreduce_slots(s, 4, 2, q));  // r.r, sum r (nothing on one rank)
+        s->gmg_guarded = guarded;
+        s->gmg_want_dots = false;
+        PIB_CHK(gmg_apply(s, R, Z, q));
+        s->counters[1]++;
+        hipLaunchKernelGGL(k_fetch_z0, dim3(1), dim3(1), 0, q, s->d_s, Z, (A.row0 == 0) ? 1 : 0, 3);
+        PIB_HIP(hipGetLastError());
+        PIB_CHK(allreduce_slots(s, 3, 1, q));
+        int nbz = 0;
+        OpPinShift<1> sh{Z, R, pin0, 3, 0.0};
+        PIB_CHK(launch_vec(s, n, sh, true, 0, &nbz, true, q));  // (reads the shift from the scalars: always given them)
+        hipLaunchKernelGGL(k_finalize, dim3(3), dim3(256), 0, q, s->d_s, s->d_part, 0, nbz);
+        PIB_HIP(hipGetLastError());
+        s->z_halo_depth = 0;  // (the shift ran on the owned entries: the ghost planes the cycle left behind are stale, the product exchanges z)
+        return 0;
+    };
+    // the iteration's one big reduction: slots 0 .. 6; under a pinned row r.r / sum r (4, 5) and z[0] (3) are global already
+    auto reduce_all = [&]() -> int {
+        if (!pin_gmg) return allreduce_slots(s, 0, 7, q);
+        PIB_CHK(allreduce_slots(s, 0, 3, q));
+        return allreduce_slots(s, 6, 1, q);
+    };
     // ---- set-up: r, z, their sums (as solve_cg), then the first product and its sum
     if (!guess) {
         OpFill z0{x, 0.0};
         PIB_CHK(launch_vec(s, n, z0, v2, 0, nullptr, false, q));
     }
+    if (pin0) hipLaunchKernelGGL(k_pin_x0, dim3(1), dim3(1), 0, q, x, b);  // identity row 0: x[0] = b[0], r[0] = 0
     if (guess) {
         OpCopy cp{x, P};
         PIB_CHK(launch_vec(s, n, cp, v2, 0, nullptr, false, q));
@@ -1187,14 +1245,15 @@ int solve_cg_sr(pib_solver *s, double *x, const double *b)
         OpInit<PCM_JACOBI> op{b, W, A.dinv, R, Z, omega, guess ? 1 : 0, 0};
         PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
     } else {
-        OpInit<PCM_NONE> op{b, W, nullptr, R, Z, 1.0, guess ? 1 : 0, 0};
+        OpInit<PCM_NONE> op{b, W, nullptr, R, Z, 1.0, guess ? 1 : 0, pin0};
         PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
     }
     hipLaunchKernelGGL(k_finalize, dim3(6), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);
     PIB_HIP(hipGetLastError());
-    if (gmg) PIB_CHK(gmg_pc_and_dots(s, R, Z, false, q, false));
+    if (pin_gmg) PIB_CHK(pinned_cycle(false));
+    else if (gmg) PIB_CHK(gmg_pc_and_dots(s, R, Z, false, q, false));
     PIB_CHK(product(false));
-    PIB_CHK(allreduce_slots(s, 0, 7, q));
+    PIB_CHK(reduce_all());
     hipLaunchKernelGGL(k_cg_s_init, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, monitor);
     hipLaunchKernelGGL(k_cg_sr_first, dim3(1), dim3(1), 0, q, s->d_s);
     PIB_HIP(hipGetLastError());
@@ -1221,11 +1280,12 @@ int solve_cg_sr(pib_solver *s, double *x, const double *b)
                 OpSRUpdate<PCM_EXTERNAL> op{SV, nullptr, Z, P, W, x, R, 1.0, 0.0, 0.0, 0.0, 0};
                 PIB_CHK(launch_vec(s, n, op, xal, 0, &nb, true, q));
                 hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, q, s->d_s, s->d_part, 4, nb);  // r.r, sum r
-                PIB_CHK(gmg_pc_and_dots(s, R, Z, true, q, false));
+                if (pin_gmg) PIB_CHK(pinned_cycle(true));
+                else PIB_CHK(gmg_pc_and_dots(s, R, Z, true, q, false));
             }
             PIB_HIP(hipGetLastError());
             PIB_CHK(product(true));
-            PIB_CHK(allreduce_slots(s, 0, 7, q));
+            PIB_CHK(reduce_all());
             hipLaunchKernelGGL(k_cg_sr_step, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, conv_is_its);
             PIB_HIP(hipGetLastError());
             return 0;
@@ -1732,9 +1792,6 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
         return fail(PIB_ERR_ORDER,
                     "solver %s: a multigrid (AMG/GMG) preconditioner needs the grid structure: call "
                     "pib_set_grid_hint or pib_assemble_poisson before pib_solve", s->name.c_str());
-    if (gmg && s->nullspace == PIB_NULLSPACE_PINNED)
-        return fail(PIB_ERR_SUP, "solver %s: BiCGStab with the multigrid and a pinned pressure row is not supported "
-                    "(CG takes the pair; or attach the constant null space)", s->name.c_str());
     if (pc == Precond::JACOBI && A.dinv == nullptr) return fail(PIB_ERR_ORDER, "Jacobi preconditioner without a diagonal");
     PIB_CHK(ensure_work(s, 9));
     double *R = s->vec(0), *RP = s->vec(1), *P = s->vec(2), *V = s->vec(3), *S = s->vec(4), *T = s->vec(5),
@@ -1754,11 +1811,28 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     PIB_CHK(init_scalars(s));
     int nb = 0;
     const bool project = gmg && s->nullspace == PIB_NULLSPACE_CONSTANT;
+    // a pinned pressure row (round 5; the oracle's pcapply, nullspace 2): the cycle's right-hand side is made compatible with the
+    // sum of ITS input (slot 5, where gmg_apply reads it), its output is shifted by its value at cell 0, and the pinned unknown
+    // keeps the input's value -- the preconditioner of the pinned system, as the CG path applies it
+    const bool pinned = gmg && s->nullspace == PIB_NULLSPACE_PINNED;
     auto apply_gmg = [&](const double *in, double *out, bool guarded) -> int {
         s->gmg_guarded = guarded;
         s->gmg_want_dots = false;
+        if (pinned) {
+            int nbs = 0;
+            OpSumV sv{in};
+            PIB_CHK(launch_vec(s, n, sv, true, 5, &nbs, guarded, q));
+            PIB_CHK(finalize(s, 5, 1, nbs, q));
+        }
         PIB_CHK(gmg_apply(s, in, out, q));
         s->counters[1]++;
+        if (pinned) {
+            hipLaunchKernelGGL(k_fetch_z0, dim3(1), dim3(1), 0, q, s->d_s, out, (A.row0 == 0) ? 1 : 0, 5);
+            PIB_HIP(hipGetLastError());
+            PIB_CHK(allreduce_slots(s, 5, 1, q));
+            OpPinShift<0> sh{out, in, (A.row0 == 0) ? 1 : 0, 5, 0.0};
+            PIB_CHK(launch_vec(s, n, sh, true, 0, nullptr, true, q));  // (reads the shift from the scalars: always given them)
+        }
         if (project) {
             int nbs = 0;
             OpSumV sv{out};

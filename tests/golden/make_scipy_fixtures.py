@@ -103,6 +103,110 @@ def make(name, w, dt, seed):
     print(f"{path}: {N} cells, nnz(A) = {A.nnz}, {os.path.getsize(path)} bytes")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 5: the velocity operator.  L (createlaplacian.cpp:108-162) and A = I/dt - c nu L (navierstokes.cpp:342-344) with the
+# ghost-point folds of createlaplacian.cpp:232-243, and D with the Neumann fold of createdivergence.cpp:231-242, rebuilt from the
+# definitions:
+#   * staggered points (cartesianmesh.cpp:225-330): component f along its own direction sits on the interior vertices (n - 1
+#     points, control-volume width = mean of the two adjacent cell widths, the two boundary vertices are its ghost points); along
+#     the other directions on the cell centres (n points, width = the cell's, ghost points mirrored half a cell outside);
+#   * second difference of point s along a direction: 1 / (dneg dself) towards s - 1, 1 / (dpos dself) towards s + 1
+#     (createlaplacian.cpp:134-151), the diagonal minus their sum over all directions;
+#   * a ghost value is a0 * (the boundary-adjacent point) + a1, so its coefficient times a0 lands on the row's own diagonal
+#     (misc.cpp:226-260: the target of a ghost is the point next to it);  a0 per face and component
+#     (singleboundarydirichlet.cpp:34-43, singleboundaryneumann.cpp:27-28, singleboundaryconvective.cpp:20-47):
+#     DIRICHLET / CONVECTIVE: 0 for the component normal to the face, -1 for a tangential one;  NEUMANN: 1.
+A0 = {"DIRICHLET": (0.0, -1.0), "CONVECTIVE": (0.0, -1.0), "NEUMANN": (1.0, 1.0)}  # (normal, tangential)
+
+
+def lap1(w, lo, f_is_dir, a0_lo, a0_hi):
+    w = np.asarray(w, dtype=np.float64)
+    n = len(w)
+    vert = lo + np.concatenate([[0.0], np.cumsum(w)])
+    if f_is_dir:
+        full = vert                                   # ghosts = the two boundary vertices
+        dl = 0.5 * (w[:-1] + w[1:])
+    else:
+        cen = vert[:-1] + 0.5 * w
+        full = np.concatenate([[vert[0] - 0.5 * w[0]], cen, [vert[-1] + 0.5 * w[-1]]])
+        dl = w
+    m = len(full) - 2
+    dneg = full[1:-1] - full[:-2]
+    dpos = full[2:] - full[1:-1]
+    am, ap = 1.0 / (dneg * dl), 1.0 / (dpos * dl)
+    T = sp.diags([am[1:], -(am + ap), ap[:-1]], [-1, 0, 1], shape=(m, m), format="lil")
+    T[0, 0] += am[0] * a0_lo
+    T[m - 1, m - 1] += ap[m - 1] * a0_hi
+    return T.tocsr()
+
+
+def velocity_operators(w, lo, bc, dt, cnu):
+    """w: 2 or 3 width arrays; lo: domain start per direction; bc[d] = (type at the minus face, type at the plus face) of direction
+    d, the same type for every component.  Returns L, A = I/dt - cnu L (packed [u | v | w], x fastest in every block) and D with the
+    Neumann fold."""
+    dim = len(w)
+    w3 = [np.asarray(v, dtype=np.float64) for v in w] + [np.ones(1)] * (3 - dim)
+    lo3 = list(lo) + [0.0] * (3 - dim)
+    n = [len(v) for v in w3]
+    blocks, dblocks = [], []
+    for f in range(dim):
+        nf = [n[d] - 1 if d == f else n[d] for d in range(3)]
+        I = [sp.identity(m, format="csr") for m in nf]
+        Lf = None
+        for d in range(dim):
+            a0 = [A0[bc[d][side]][0 if d == f else 1] for side in (0, 1)]
+            T = lap1(w3[d], lo3[d], d == f, a0[0], a0[1])
+            mats = [I[0], I[1], I[2]]
+            mats[d] = T
+            term = kron3(mats[2], mats[1], mats[0])
+            Lf = term if Lf is None else Lf + term
+        blocks.append(Lf.tocsr())
+        # divergence block of component f: +area at a cell's plus face, -area at its minus face; a NEUMANN face of direction f folds
+        # the boundary flux (ghost = 1 * the adjacent interior face + a1) onto that interior face's column
+        d1 = div1(n[f]).tolil()
+        if A0[bc[f][0]][0] != 0.0:
+            d1[0, 0] += -1.0 * A0[bc[f][0]][0]
+        if A0[bc[f][1]][0] != 0.0:
+            d1[n[f] - 1, n[f] - 2] += 1.0 * A0[bc[f][1]][0]
+        Wd = [sp.diags(v, format="csr") for v in w3]
+        mats = [Wd[0], Wd[1], Wd[2]]
+        mats[f] = d1.tocsr()
+        dblocks.append(kron3(mats[2], mats[1], mats[0]))
+    L = sp.block_diag(blocks, format="csr")
+    N = L.shape[0]
+    A = (sp.identity(N, format="csr") / dt - cnu * L).tocsr()
+    D = sp.hstack(dblocks, format="csr")
+    for M in (L, A, D):
+        M.sum_duplicates()
+        M.sort_indices()
+    return L, A, D
+
+
+def make_velocity(name, w, lo, bc, dt, nu, seed):
+    cnu = 0.5 * nu  # Crank-Nicolson (timeintegration.h: implicit coefficient 0.5)
+    L, A, D = velocity_operators(w, lo, bc, dt, cnu)
+    N = A.shape[0]
+    rng = np.random.default_rng(seed)
+    us = rng.uniform(-1.0, 1.0, N)
+    b = A @ us
+    ur = rng.uniform(-1.0, 1.0, N)
+    x_lu = spla.spsolve(A.tocsc(), b)
+    assert np.linalg.norm(x_lu - us) <= 1e-10 * np.linalg.norm(us)
+    out = {"dt": np.float64(dt), "nu": np.float64(nu), "cnu": np.float64(cnu), "dim": np.int64(len(w)), "us": us, "b": b, "ur": ur, "y": A @ ur,
+           "yL": L @ ur, "yD": D @ ur, "x_lu": x_lu, "lo": np.asarray(lo, dtype=np.float64),
+           "bc": np.array([[t for t in bc[d]] for d in range(len(w))])}
+    for d, wd in enumerate(w):
+        out[f"w{d}"] = np.asarray(wd, dtype=np.float64)
+    for tag, M in (("L", L), ("A", A), ("D", D)):
+        out[f"{tag}_rowptr"] = M.indptr.astype(np.int64)
+        out[f"{tag}_col"] = M.indices.astype(np.int64)
+        out[f"{tag}_val"] = M.data.astype(np.float64)
+        out[f"{tag}_shape"] = np.array(M.shape, dtype=np.int64)
+    path = os.path.join(HERE, f"scipy_velocity_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {N} velocity points, nnz(A) = {A.nnz}, {os.path.getsize(path)} bytes")
+
+
 if __name__ == "__main__":
     ref = json.load(open(os.path.join(HERE, "reference_test_vectors.json")))["cartesianmesh2d_dirichlet"]
     w2 = [np.array(ref["dLTrue"][3][0], dtype=np.float64), np.array(ref["dLTrue"][3][1], dtype=np.float64)]
@@ -110,3 +214,10 @@ if __name__ == "__main__":
     make("ref12x11", w2, 0.01, 11)
     make("uniform8", [np.full(8, 1.0 / 8)] * 3, 1e-3, 12)
     make("stretched16", [stretched(16, 1.25), stretched(16, 1.15), stretched(16, 1.3)], 5e-3, 13)
+    # the velocity operator: the reference's 12 x 11 mesh (its own domain start, tests/mesh/cartesianmesh2d_dirichlet.cpp) with a
+    # convective outlet and a Neumann top, and the 16^3 stretched cavity with one face of every kind
+    lo2 = [float(ref["coordTrue"][4][0][0]), float(ref["coordTrue"][4][1][0])] if "coordTrue" in ref else [0.1, 0.05]
+    make_velocity("ref12x11", w2, lo2, [("DIRICHLET", "CONVECTIVE"), ("DIRICHLET", "NEUMANN")], 0.01, 0.01, 21)
+    make_velocity("stretched16", [stretched(16, 1.25), stretched(16, 1.15), stretched(16, 1.3)], [0.0, -0.5, 0.25],
+                  [("DIRICHLET", "CONVECTIVE"), ("NEUMANN", "DIRICHLET"), ("DIRICHLET", "NEUMANN")], 5e-3, 1e-2, 22)
+    make_velocity("dirichlet8", [np.full(8, 1.0 / 8)] * 3, [0.0, 0.0, 0.0], [("DIRICHLET", "DIRICHLET")] * 3, 1e-3, 1e-3, 23)

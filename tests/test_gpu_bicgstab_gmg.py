@@ -85,19 +85,40 @@ def test_bcgs_with_gamg_matches_oracle_ksp_flavour(lin, case):
     s.destroy()
 
 
-def test_bicgstab_with_multigrid_and_a_pinned_row_is_refused(lin):
+@pytest.mark.parametrize("flavour", ["amgx", "ksp"])
+@pytest.mark.parametrize("case,pre,post", [("3d_uniform", 1, 1), ("3d_stretched", 2, 2), ("2d_stretched", 1, 1)])
+def test_bicgstab_with_the_multigrid_and_a_pinned_row_matches_oracle(lin, case, pre, post, flavour):
+    """Round 5 (a PIB_ERR_SUP until then): `solver=PBICGSTAB, preconditioner=AMG` on the system every `type: GPU` run of PetIBM
+    hands over -- row 0 pinned (navierstokes.cpp:414-420).  The preconditioner of the pinned system as the CG path and the
+    oracle apply it (oracle.c pcapply, nullspace 2): the cycle's right-hand side made compatible with the sum of ITS input,
+    the output shifted by its value at cell 0, the pinned unknown keeping the input's value."""
     from petibm_amd import capi
-    from petibm_amd.capi import PibError, ERR_SUP
-    n, dt = [16, 16, 16], 0.01
-    w = [np.full(16, 1.0 / 16)] * 3
-    text = gmg_cfg().replace("solver(solv)=PCG", "solver(solv)=PBICGSTAB")
+    dt = 0.01
+    m, A, _ = poisson_system(CASES[case], dt=dt, pinned=True)
+    xs, b = rhs_for(A, zero_mean=False)
+    b[0] = 0.0
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    if flavour == "amgx":
+        text = gmg_cfg(pre=pre, post=post).replace("solver(solv)=PCG", "solver(solv)=PBICGSTAB") + "pib_initial_guess_nonzero=0\n"
+        norm, tolr = "unpreconditioned", 1.5e-10
+    else:
+        text = ("-poisson_ksp_type bcgs\n-poisson_ksp_rtol 1.0E-10\n-poisson_ksp_atol 1.0E-50\n-poisson_pc_type gamg\n"
+                f"-poisson_pib_smoother jacobi\n-poisson_pib_presweeps {pre}\n-poisson_pib_postsweeps {post}\n-poisson_pib_sweep_pairs 0\n")
+        norm, tolr = "preconditioned", 1e-8
     s = lin.LinSolverHIP("poisson", config_text=text)
     s.assemblePoisson(n, w, dt, capi.NULLSPACE_PINNED)
-    b = np.random.default_rng(3).standard_normal(16 ** 3)
-    x = np.zeros(16 ** 3)
-    with pytest.raises(PibError) as e:
-        s.solve(x, b)
-    assert e.value.code == ERR_SUP
+    x = np.zeros(A.n_rows)
+    s.solve(x, b)
+    g = clib.GMG(n, w, dt, nullspace=2, pre=pre, post=post, omega=0.9, coarsest_sweeps=32)
+    ref = g.bcgs(A, b, norm=norm, rtol=1e-10, atol=1e-50 if flavour == "ksp" else 0.0, dtol=1e300, maxit=200)
+    assert ref["reason"] > 0 and s.getReason() > 0
+    assert iters_close(s.getIters(), ref["iters"])
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= tolr * np.linalg.norm(b)
+    h = s.getResidualHistory()
+    ke = min(len(h), len(ref["history"]), 4)
+    assert np.allclose(h[:ke], ref["history"][:ke], rtol=1e-7)
+    assert np.linalg.norm(x - ref["x"]) <= 1e-7 * np.linalg.norm(ref["x"])
     s.destroy()
 
 
@@ -138,4 +159,50 @@ def test_pbicgstab_with_amg_on_loopback_slabs(lin, P, n, extra):
     k = min(len(res[0][2]), len(s1.getResidualHistory()), 4)
     assert np.allclose(res[0][2][:k], s1.getResidualHistory()[:k], rtol=1e-7)
     assert np.linalg.norm((x - x.mean()) - (x1 - x1.mean())) <= 1e-7 * np.linalg.norm(x1)
+    s1.destroy()
+
+
+@pytest.mark.parametrize("solver", ["PBICGSTAB", "PCG_SR"])
+@pytest.mark.parametrize("P,n", [(2, (16, 16, 32)), (3, (32, 32, 36))])
+def test_pinned_row_pairs_on_loopback_slabs(lin, P, n, solver):
+    """The two pairs that refused a pinned row until round 5 -- BiCGStab + multigrid, single-reduction CG + multigrid -- on
+    z-slabs: rank 0 owns the pinned row, the sum of the cycle's input and the cycle's value at cell 0 travel through
+    all-reduces; every rank stops at the single rank's iteration, the solution is the single rank's."""
+    from petibm_amd import capi
+    import slab_plans as partition
+    from petibm_amd.linsolver import LinSolverHIP
+    from oracle import operators as oops
+    from test_gpu_multirank_loopback import _cfg, _run_ranks, _system
+    dt = 0.01
+    m, A, xs, _ = _system(n, dt)
+    A = oops.pin_row0(A)
+    xs = xs - xs[0]
+    b = clib.spmv(A, xs)
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    plans = partition.all_plans(n, P)
+    text = _cfg("AMG", extra="pib_agglomerate_below=100\n", sweeps=2)
+    text = text.replace("solver(solv)=PCG", "solver(solv)=PBICGSTAB") if solver == "PBICGSTAB" else text + "pib_cg_single_reduction=1\n"
+
+    def rank_fn(r, uid):
+        pl = plans[r]
+        s = LinSolverHIP("poisson", config_text=text, rank=r, nranks=P, uid=uid, device=0)
+        s.assemblePoisson(n, w, dt, capi.NULLSPACE_PINNED)
+        x = np.zeros(pl.n_local)
+        s.solve(x, np.ascontiguousarray(b[pl.row0:pl.row0 + pl.n_local]))
+        out = (x, s.getIters(), s.getResidualHistory())
+        s.destroy()
+        return out
+
+    res = _run_ranks(P, rank_fn)
+    x = np.concatenate([r[0] for r in res])
+    assert len({r[1] for r in res}) == 1 and x[0] == 0.0
+    assert np.linalg.norm(b - clib.spmv(A, x)) <= 1.5e-10 * np.linalg.norm(b)
+    s1 = LinSolverHIP("poisson", config_text=text)
+    s1.assemblePoisson(n, w, dt, capi.NULLSPACE_PINNED)
+    x1 = np.zeros(A.n_rows)
+    s1.solve(x1, b)
+    assert iters_close(res[0][1], s1.getIters())
+    k = min(len(res[0][2]), len(s1.getResidualHistory()), 4)
+    assert np.allclose(res[0][2][:k], s1.getResidualHistory()[:k], rtol=1e-7)
+    assert np.linalg.norm(x - x1) <= 1e-7 * np.linalg.norm(x1)
     s1.destroy()

@@ -218,26 +218,35 @@ def test_chebyshev_restatement_against_scipy_and_numpy(systems):
     assert r["reason"] == 2 and np.linalg.norm(r["x"] - us) <= 1e-10 * np.linalg.norm(us)
 
 
+@pytest.mark.parametrize("pinned", [False, True])
 @pytest.mark.parametrize("n,side", [((16, 12, 10), "right"), ((16, 12, 10), "left"), ((24, 20), "right")])
-def test_bcgs_with_the_multigrid_is_the_published_recurrence(n, side):
+def test_bcgs_with_the_multigrid_is_the_published_recurrence(n, side, pinned):
     """oracle/csrc/oracle.c:orc_bcgs_gmg (BiCGStab around the V-cycle, the mean removed after every application on the singular
     system) against a numpy restatement of the published recurrences with `GMG.apply` as M^-1: right-preconditioned with the true
     residual's L2 norm (AmgX PBICGSTAB, what /root/reference/src/linsolver/linsolveramgx.cpp:62-72 configures from a solver file) and
     left-preconditioned with the preconditioned residual's norm (KSPBCGS, linsolverksp.cpp:62-66).  The C restatement is what the GPU
-    path is compared with (tests/test_gpu_bicgstab_gmg.py); this pins it on the CPU."""
+    path is compared with (tests/test_gpu_bicgstab_gmg.py); this pins it on the CPU.  pinned (round 5): row / column 0 replaced by
+    the identity (navierstokes.cpp:414-420) -- the cycle's right-hand side made compatible inside `GMG.apply` (nullspace 2), its output
+    shifted by its value at cell 0, the pinned unknown keeping the input's value (oracle.c pcapply)."""
     m = omesh.create_mesh(omesh.uniform_config(n))
     D, Gm, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
     dt = 1e-2
     _, A = oops.create_poisson_operator(D, Gm, L, dt, 0.5e-2)
+    if pinned:
+        A = oops.pin_row0(A)
     w = [m.dL[3][d].true for d in range(m.dim)]
-    g = clib.GMG(n, w, dt, nullspace=1, pre=1, post=1)
+    g = clib.GMG(n, w, dt, nullspace=2 if pinned else 1, pre=1, post=1)
     rng = np.random.default_rng(17)
     xs = rng.uniform(-1, 1, m.pN)
-    xs -= xs.mean()
+    xs -= xs[0] if pinned else xs.mean()
     b = clib.spmv(A, xs)
 
     def minv(v):
         z = g.apply(v)
+        if pinned:
+            z = z - z[0]
+            z[0] = v[0]
+            return z
         return z - z.mean()
 
     amul = lambda v: clib.spmv(A, v)
@@ -271,6 +280,8 @@ def test_bcgs_with_the_multigrid_is_the_published_recurrence(n, side):
     e = (ref["x"] - ref["x"].mean()) - (x - x.mean())
     assert np.linalg.norm(e) <= 1e-6 * np.linalg.norm(xs)
     assert np.linalg.norm(b - clib.spmv(A, ref["x"])) <= (2e-10 if side == "right" else 1e-7) * np.linalg.norm(b)
+    if pinned:
+        assert abs(ref["x"][0]) <= 1e-12 * np.abs(xs).max() and np.linalg.norm(ref["x"] - xs) <= 1e-6 * np.linalg.norm(xs)
 
 
 def test_merged_residual_update_identities():
