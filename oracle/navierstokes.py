@@ -279,6 +279,7 @@ class NavierStokes:
         self.A = oops.create_velocity_operator(self.L, dt, self.cimpl * nu)
         self.BNG, DBNG = oops.create_poisson_operator(self.D, self.G, self.L, dt, self.cimpl * nu, bn_order)
         self.DBNG = oops.pin_row0(DBNG) if pinned else DBNG
+        self.nonsymmetric = any(mesh.bc_types.get((f, 2 * f + e), "NOBC") == "NEUMANN" for f in range(mesh.dim) for e in (0, 1))
         self.ghosts = make_ghosts(mesh)
         self.U = np.zeros(mesh.UN)
         self.p = np.zeros(mesh.pN)
@@ -341,7 +342,12 @@ class NavierStokes:
         self.info["vIters"] = r["iters"]
         rhs2 = self.rhs_poisson()
         self.last_rhs2 = rhs2
-        rp = self.gmg.pcg(self.DBNG, rhs2, rtol=0.0, atol=self.ptol, maxit=500)
+        if self.nonsymmetric:
+            # a NEUMANN condition on a normal velocity component folds a0 = 1 into D (createdivergence.cpp:231-242): DBNG is no
+            # longer symmetric at that face -- BiCGStab (Jacobi) instead of CG
+            rp = clib.bcgs(self.DBNG, rhs2, pc="jacobi", norm="unpreconditioned", rtol=0.0, atol=self.ptol, dtol=1e300, maxit=5000)
+        else:
+            rp = self.gmg.pcg(self.DBNG, rhs2, rtol=0.0, atol=self.ptol, maxit=500)
         assert rp["reason"] > 0, rp
         dP = rp["x"]
         if not self.pinned:

@@ -226,6 +226,7 @@ struct GdMesh {
     int64_t pn[3];
     const double *dlff[3];       // dL[f][f], index s+1
     const double *pw[3];         // pressure-cell widths
+    double a0n[3][2];            // a0 of component f's ghost point at its own minus / plus boundary (Neumann: 1; else 0)
 };
 
 // createGradient (creategradient.cpp:64-128, normalize = FALSE): row of velocity point (f; i,j,k) = {-1/dL at its cell,
@@ -261,7 +262,10 @@ __global__ __launch_bounds__(256) void k_bn_gradient(GdMesh M, int64_t UN, int32
 
 // createDivergence (createdivergence.cpp:135-223, normalize = FALSE): row of a pressure cell = -area at the minus face,
 // +area at the plus face of every direction, columns = packed velocity indices in ascending order.  Ghost faces have no
-// column (a0 = 0 for the normal component with Dirichlet / convective boundaries, :231-242).
+// column of their own: their coefficient times a0 is ADDED to the entry of their target -- the interior face next to them, the
+// cell's other face (createdivergence.cpp:231-242; a0 = 0 for the normal component with Dirichlet / convective boundaries,
+// 1 with NEUMANN, singleboundaryneumann.cpp:27-28: the boundary cell's row then loses that direction altogether, the entry
+// staying in the pattern as an explicit zero).
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bn_divergence(GdMesh M, int64_t pN, int32_t *__restrict__ rp, int32_t *__restrict__ col,
                                                        double *__restrict__ val)
@@ -278,12 +282,16 @@ __global__ __launch_bounds__(256) void k_bn_divergence(GdMesh M, int64_t pN, int
             const int64_t base = M.foff[f] + ijk[0] + M.fn[f][0] * (ijk[1] + M.fn[f][1] * ijk[2]);  // the + face (index s)
             const bool has_m = s > 0 || wrap, has_p = s < M.fn[f][f];
             const int64_t cm = (s > 0) ? base - st[f] : base + (M.fn[f][f] - 1) * st[f];
+            // (ghost faces of a wall-bounded direction: the minus face of cell 0 folds onto the plus face's entry, the plus face
+            // of the last cell onto the minus face's)
+            const double fold_p = (!wrap && s == 0) ? (-area[f]) * M.a0n[f][0] : 0.0;
+            const double fold_m = (!wrap && !has_p) ? area[f] * M.a0n[f][1] : 0.0;
             if (has_m && s > 0) {
-                if (FILL) { col[o] = (int32_t)cm; val[o] = -area[f]; }
+                if (FILL) { col[o] = (int32_t)cm; val[o] = (fold_m != 0.0) ? -area[f] + fold_m : -area[f]; }
                 ++o;
             }
             if (has_p) {
-                if (FILL) { col[o] = (int32_t)base; val[o] = area[f]; }
+                if (FILL) { col[o] = (int32_t)base; val[o] = (fold_p != 0.0) ? area[f] + fold_p : area[f]; }
                 ++o;
             }
             if (has_m && s == 0) {  // wrapped minus face: velocity point n-1 sorts after the plus face
@@ -340,9 +348,6 @@ static int build_bn_chain(pib_solver *s, int dim, const int64_t n[3], const doub
                           Csr32 *BNkeep = nullptr)
 {
     hipStream_t q = s->stream;
-    for (int f = 0; f < dim; ++f)
-        if (a0[6 * f + 2 * f] != 0.0 || a0[6 * f + 2 * f + 1] != 0.0)
-            return fail(PIB_ERR_SUP, "BN order > 1: a ghost fold on the normal velocity component (Neumann) changes D; not supported");
     // L = createLaplacian: the velocity assembly with MatScale(1), MatShift(0)
     PIB_CHK(assemble_velocity(s, dim, n, w, mn, mx, a0, std::numeric_limits<double>::infinity(), -1.0));
     if (s->A.rp64) return fail(PIB_ERR_SUP, "BN order > 1: the Laplacian needs 64-bit offsets (too large for the product chain)");
@@ -361,6 +366,8 @@ static int build_bn_chain(pib_solver *s, int dim, const int64_t n[3], const doub
     GdMesh M;
     std::memset(&M, 0, sizeof M);
     M.dim = dim;
+    for (int f = 0; f < dim; ++f)  // the ghost fold of D (round 5): a0 of the NORMAL component at its two boundaries
+        for (int e = 0; e < 2; ++e) M.a0n[f][e] = s->periodic[f] ? 0.0 : a0[6 * f + 2 * f + e];
     velocity_mesh_arrays(dim, n, w, mn, mx, s->periodic, hdl, hco, M.fn, &s->mesh_window);
     std::vector<double *> tofree;
     int64_t UN = 0, pN = 1;

@@ -390,7 +390,9 @@ int pib_assemble_poisson_bn(pib_solver *s, int dim, const int64_t n[3], const do
 try {
     if (s == nullptr || n == nullptr || lo == nullptr || hi == nullptr || a0 == nullptr)
         return fail(PIB_ERR_ARG_NULL, "pib_assemble_poisson_bn: null argument");
-    if (bn_order == 1) return pib_assemble_poisson(s, dim, n, wx, wy, wz, dt, nullspace);
+    bool fold = false;  // a ghost fold on a normal velocity component (NEUMANN): D changes, the symmetric assembly does not apply
+    for (int f = 0; f < dim; ++f) fold = fold || a0[6 * f + 2 * f] != 0.0 || a0[6 * f + 2 * f + 1] != 0.0;
+    if (bn_order == 1 && !fold) return pib_assemble_poisson(s, dim, n, wx, wy, wz, dt, nullspace);
     PIB_HIP(hipSetDevice(s->device));
     s->has_matrix = false;
     s->has_grid = false;

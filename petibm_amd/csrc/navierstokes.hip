@@ -666,9 +666,19 @@ __global__ __launch_bounds__(256) void k_ns_div_sub(NsDev D, int64_t pin_cell, c
                 s = s + area[f] * t[base];
                 continue;
             }
-            // ghost faces carry a0 = 0 for the normal component (Dirichlet / convective): no column
-            if (has_m) s = s + (-area[f]) * t[has_p ? base - st : base];
-            if (has_p) s = s + area[f] * t[base];
+            // ghost faces: a0 = 0 for the normal component with Dirichlet / convective boundaries (no column); NEUMANN folds the
+            // ghost's coefficient onto the cell's other face (the entries of k_ns_rhs_poisson's row)
+            double vm = -area[f], vp = area[f];
+            if (!has_m) {
+                const double tt = (-area[f]) * F.a0[2 * f];
+                if (tt != 0.0) vp = vp + tt;
+            }
+            if (!has_p) {
+                const double tt = area[f] * F.a0[2 * f + 1];
+                if (tt != 0.0) vm = vm + tt;
+            }
+            if (has_m) s = s + vm * t[has_p ? base - st : base];
+            if (has_p) s = s + vp * t[base];
         }
         w[c] = w[c] - s;
     }
@@ -912,13 +922,11 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
                 gdl[6 * f + loc] = 0.0;
             } else if (t == 0 || t == 2) {  // DIRICHLET (singleboundarydirichlet.cpp:35-44), CONVECTIVE (singleboundaryconvective.cpp:20-36)
                 a0[6 * f + loc] = (axis == f) ? 0.0 : -1.0;
-            } else if (t == 1 && axis == f) {
-                // a Neumann condition on the NORMAL component folds a0 = 1 into D (createdivergence.cpp:231-242) and
-                // hence into DBNG; pib_assemble_poisson builds the a0 = 0 operator only
-                return bail(fail(PIB_ERR_SUP, "pib_ns_create: NEUMANN on the normal velocity component (field %d, boundary %d) "
-                                              "is not supported by the on-device Poisson assembly", f, loc));
-            } else if (t == 1) {  // NEUMANN (singleboundaryneumann.cpp:27-28)
+            } else if (t == 1) {  // NEUMANN (singleboundaryneumann.cpp:27-28) -- on the NORMAL component too (round 5): a0 = 1 then
+                // folds into D (createdivergence.cpp:231-242) and hence into DBNG, which loses its symmetry at that face:
+                // the Poisson operator comes from the reference's product chain with the folded D (bn.hip), see below
                 a0[6 * f + loc] = 1.0;
+                if (axis == f) ns->neumann_normal = true;
             } else {
                 return bail(fail(PIB_ERR_SUP, "pib_ns_create: boundary type %d is not supported (0 DIRICHLET, 1 NEUMANN, "
                                               "2 CONVECTIVE, 3 PERIODIC)", t));
@@ -940,9 +948,22 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
     char tbuf[64];
     pib_get_type(ns->psol, tbuf, sizeof tbuf);
     ns->pinned = (std::strcmp(tbuf, "NVIDIA AmgX") == 0) ? 1 : 0;
-    if ((err = pib_assemble_poisson(ns->psol, dim, n, wx, wy, wz, dt, ns->pinned ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT)))
-        return bail(err);
     const double *wg[3] = {wx, wy, wz};
+    if (ns->neumann_normal) {
+        // D carries a ghost fold: DBNG = D (dt I) G through the chain of sparse products with the folded D (bn.hip, order 1; on
+        // slabs the window chain), the multigrid of the unfolded operator registered as preconditioner only.  The matrix is no
+        // longer symmetric at the Neumann face, so a solver file that says CG gets BiCGStab with the same preconditioner -- said
+        // once on stderr, never silently
+        if (ns->psol->cfg.method == Method::CG) {
+            ns->psol->cfg.method = Method::BICGSTAB;
+            std::fprintf(stderr, "[petibm_amd] poisson solver: a NEUMANN condition on a normal velocity component makes DBNG non-symmetric "
+                                 "(createdivergence.cpp:231-242): CG of the solver file replaced by BiCGStab, same preconditioner\n");
+        }
+        if ((err = assemble_poisson_bn(ns->psol, dim, n, wg, lo, hi, a0_global, dt, 0.5 * nu, 1, ns->pinned ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT,
+                                       nullptr, nullptr, nullptr, nullptr)))
+            return bail(err);
+    } else if ((err = pib_assemble_poisson(ns->psol, dim, n, wx, wy, wz, dt, ns->pinned ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT)))
+        return bail(err);
     for (int d = 0; d < dim; ++d) {
         ns->h_n[d] = n[d];
         ns->h_w[d].assign(wg[d], wg[d] + n[d]);
@@ -1216,8 +1237,14 @@ try {
     const int dim = ns->D.dim;
     const double *w[3] = {ns->h_w[0].data(), ns->h_w[1].data(), dim == 3 ? ns->h_w[2].data() : nullptr};
     const int nullspace = ns->pinned ? PIB_NULLSPACE_PINNED : PIB_NULLSPACE_CONSTANT;
-    if (order == 1) {
+    if (order == 1 && !ns->neumann_normal) {
         PIB_CHK(pib_assemble_poisson(ns->psol, dim, ns->h_n, w[0], w[1], w[2], ns->dt, nullspace));
+    } else if (order == 1) {  // (the folded D: the chain, with the matrix-free projection of order 1)
+        ns->psol->has_matrix = false;
+        ns->psol->has_grid = false;
+        gmg_release(ns->psol);
+        PIB_CHK(assemble_poisson_bn(ns->psol, dim, ns->h_n, w, ns->lo, ns->hi, ns->h_a0, ns->dt, ns->T.cimpl * ns->nu, 1, nullspace, nullptr, nullptr,
+                                    nullptr, nullptr));
     } else {
         ns->psol->has_matrix = false;
         ns->psol->has_grid = false;

@@ -108,6 +108,7 @@ struct pib_ns {
     bool ring = false;  // several ranks and a periodic slab axis: both ends of the extended slab are cuts, the plane exchanges wrap
     // parameters.BN > 1 (pib_ns_set_bn_order): the projection multiplies by the assembled BNG
     int bn_order = 1;
+    bool neumann_normal = false;  // a NEUMANN condition on a normal velocity component: D carries a ghost fold, DBNG comes from the product chain (bn.hip)
     int32_t *bng_rowptr = nullptr, *bng_col = nullptr;
     double *bng_val = nullptr;
     int64_t bng_nnz = 0;

@@ -111,6 +111,48 @@ def test_random_mesh_operators_bit_exact(seed):
     s.destroy()
 
 
+@pytest.mark.parametrize("seed", SEEDS[:16])
+def test_random_mesh_divergence_fold_bit_exact(seed):
+    """createDivergence's ghost fold (createdivergence.cpp:231-242; SURVEY 8 a-6, on the device since round 5): on the random
+    meshes, one to three wall-bounded faces get a NEUMANN condition on their NORMAL component (a0 = 1: the boundary cells' rows of
+    D lose that face), and D (BN) G from the device's chain of sparse products -- BN order 1 and 2, pinned or not -- is the
+    oracle's bit for bit; so is its product with a random vector.  (Whether the pinned matrix is then non-singular depends on
+    where the faces are: operators only here, the time step has its own case.)"""
+    from petibm_amd import capi
+    from petibm_amd.linsolver import LinSolverHIP
+    cfg, per, _ = random_config(seed)
+    rng = np.random.default_rng(5000 + seed)
+    dim = len(cfg["mesh"])
+    faces = [(d, side) for d in range(dim) for side in (0, 1) if not per[d]]
+    if not faces:
+        pytest.skip("every direction periodic: no ghost point to fold")
+    for k in rng.choice(len(faces), size=min(len(faces), int(rng.integers(1, 4))), replace=False):
+        d, side = faces[int(k)]
+        cfg["flow"]["boundaryConditions"][2 * d + side]["uvw"[d]] = ["NEUMANN", float(rng.uniform(-0.05, 0.05))]
+    m = omesh.create_mesh(cfg)
+    dt, cnu = cfg["parameters"]["dt"], 0.5 * cfg["flow"]["nu"]
+    n = [int(v) for v in m.n[3][: m.dim]]
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    a0 = _a0_table(m)
+    assert any(a0[f][2 * f + e] == 1.0 for f in range(m.dim) for e in (0, 1))
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    for order in (1, 2):
+        _, A = oops.create_poisson_operator(D, G, L, dt, cnu, bn_order=order)
+        pinned = bool((seed + order) % 2)
+        if pinned:
+            A = oops.pin_row0(A)
+        s = LinSolverHIP("poisson", config_text=amgx_cfg())
+        s.setPeriodic(per)
+        s.assemblePoissonBN(n, w, m.min[: m.dim], m.max[: m.dim], a0, dt, cnu, order, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+        rp, cl, vl = s.getCSR()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(cl, A.col) and np.array_equal(vl, A.val)
+        x = np.random.default_rng(seed).uniform(-1, 1, A.n_rows)
+        y = np.empty_like(x)
+        s.matMult(x, y)
+        assert np.array_equal(y, clib.spmv(A, x))
+        s.destroy()
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_mesh_time_steps_match_oracle(seed):
     from petibm_amd.navierstokes import NavierStokesSolver
