@@ -9,7 +9,7 @@ three steps the fields agree with the single rank to the solver tolerance (the K
 import numpy as np
 import pytest
 
-from test_gpu_navierstokes import cavity, moving_walls_3d, convective_outlet, AMGX_P, KSP_P, VEL
+from test_gpu_navierstokes import cavity, moving_walls_3d, convective_outlet, neumann_outlet, AMGX_P, KSP_P, VEL
 from test_gpu_multirank_loopback import _run_ranks
 
 pytestmark = pytest.mark.gpu
@@ -25,6 +25,10 @@ CASES = {
     "3d_periodic_box": (lambda: _periodic((10, 8, 12), (True, True, True)), False),
     "3d_channel_periodic_z": (lambda: _periodic((8, 7, 16), (False, False, True)), True),
     "2d_periodic_y": (lambda: _periodic((12, 12), (True, True)), False),
+    # round 5: a NEUMANN outlet on the NORMAL component (the divergence's ghost fold; the Poisson operator from the window chain
+    # of sparse products, bn.hip, BiCGStab in place of the file's CG); outlet next to the pinned cell: non-singular system
+    "3d_neumann_outlet": (lambda: neumann_outlet((10, 8, 9), outlet="xMinus"), True),
+    "2d_neumann_outlet": (lambda: neumann_outlet((16, 12), outlet="xMinus"), True),
 }
 
 
@@ -39,7 +43,7 @@ def _periodic(n, per):
 @pytest.mark.parametrize("case,P", [("3d_cavity", 2), ("3d_cavity", 3), ("3d_moving_walls_neumann", 2),
                                     ("3d_convective_outlet", 3), ("2d_convective_outlet", 2), ("2d_cavity", 3),
                                     ("3d_periodic_box", 2), ("3d_periodic_box", 3), ("3d_channel_periodic_z", 4),
-                                    ("2d_periodic_y", 2)])
+                                    ("2d_periodic_y", 2), ("3d_neumann_outlet", 2), ("2d_neumann_outlet", 3)])
 def test_time_step_on_slabs_reproduces_the_single_rank(case, P):
     from petibm_amd.navierstokes import NavierStokesSolver
     make, pinned = CASES[case]
@@ -51,6 +55,8 @@ def test_time_step_on_slabs_reproduces_the_single_rank(case, P):
     p0 = 0.1 * rng.uniform(-1, 1, one.pN)
     if "convective" in case:
         U0[: int(np.prod(one._field_shape(0)))] += 1.0  # perturbed free stream
+    if "neumann_outlet" in case:
+        U0[: int(np.prod(one._field_shape(0)))] -= 1.0  # ... towards xMinus
     one.setState(U0, p0)
     one.advance(1)
     U1, p1, rhs1, rhs2 = one.getState(rhs=True)
