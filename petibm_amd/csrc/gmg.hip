@@ -28,6 +28,7 @@
 //     operator; both keep the preconditioner symmetric.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "pib_internal.hpp"
@@ -3524,7 +3525,34 @@ static bool fused_run_ok(const pib_solver *s, const GridLevel &g, int64_t kb, in
 #ifndef PIB_MARCH_PLANES_BIG
 #define PIB_MARCH_PLANES_BIG 64
 #endif
-static int march_planes(const GridLevel &g, int64_t kc) { return kc * g.plane >= ((int64_t)1 << 26) ? PIB_MARCH_PLANES_BIG : 16; }
+static int march_planes(const GridLevel &g, int64_t kc)
+{
+    // (PIB_MARCH_PLANES_SMALL: planes per workgroup on runs below 2^23 cells -- the 2 M-cell levels under a slab, which the marches
+    // only reach when pib_march_min_cells is lowered; an experiment knob, profiles/r05_slab_mid_levels.txt)
+    static const int small_planes = std::getenv("PIB_MARCH_PLANES_SMALL") ? std::max(2, std::atoi(std::getenv("PIB_MARCH_PLANES_SMALL"))) : 16;
+    if (kc * g.plane >= ((int64_t)1 << 26)) return PIB_MARCH_PLANES_BIG;
+    return kc * g.plane < ((int64_t)1 << 23) ? small_planes : 16;
+}
+
+// The Krylov sums z.r, z.z, sum z a level-0 kernel left as per-workgroup partials: their fixed-order reduction into S->red[0..2].
+// Round 5: when the solver asks for it (gmg_defer_dots) and the partials are few enough for ONE workgroup, the reduction is left
+// to the solver's own closing kernel of the cycle (krylov.hip k_dots_tail: the three sums, z[0] and -- on one rank -- the scalar
+// step of the iteration in a single launch instead of four).
+constexpr int DEFER_DOTS_MAX = 32768;
+static int reduce_dots(pib_solver *s, double *part, int part_stride, int count, hipStream_t q)
+{
+    if (s->gmg_defer_dots && count <= DEFER_DOTS_MAX) {
+        s->gmg_pending_part = part;
+        s->gmg_pending_stride = part_stride;
+        s->gmg_pending_count = count;
+        return 0;
+    }
+    double *stage = part + 3 * (int64_t)part_stride;
+    hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, count, stage);
+    hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
+    PIB_HIP(hipGetLastError());
+    return 0;
+}
 
 // MODE on the planes [kb, kb + kc) relative to the first owned plane (kb < 0 / kb + kc > nk: ghost planes); the vectors
 // point at the first OWNED plane.  dots: mode 8 sums over the owned planes only.
@@ -3584,12 +3612,7 @@ static int launch_level_planes(pib_solver *s, const GridLevel &g, int64_t kb, in
         nparts = (int)(sg.x * sg.y);
     }
     PIB_HIP(hipGetLastError());
-    if (MODE == 8) {
-        double *stage = part + 3 * (int64_t)part_stride;
-        hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, nparts, stage);
-        hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
-        PIB_HIP(hipGetLastError());
-    }
+    if (MODE == 8) PIB_CHK(reduce_dots(s, part, part_stride, nparts, q));
     return 0;
 }
 
@@ -3672,6 +3695,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     const Scalars *S = guarded ? s->d_s : nullptr;
     s->halo_fresh = nullptr;
     s->gmg_dots_done = false;
+    s->gmg_pending_count = 0;
     s->z_halo_depth = 0;
     const double omega = s->cfg.smoother_relaxation;
     const bool cheb = (s->cfg.smoother == Smoother::CHEBYSHEV);
@@ -4308,9 +4332,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 const int part_stride = (int)s->gmg_part_cap;
                 hipLaunchKernelGGL(k_prolong_smooth2<1>, mg, dim3(UNT), 0, q, S, dev_of(sub), dev_of(cg), omega, bq, xc, aq, cq, FZ, part, part_stride,
                                    (int)g.k0, (int)g.k1, pin_l);
-                double *stage = part + 3 * (int64_t)part_stride;
-                hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)needp, stage);
-                hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
+                PIB_CHK(reduce_dots(s, part, part_stride, (int)needp, q));
                 s->gmg_dots_done = true;
             } else
                 hipLaunchKernelGGL(k_prolong_smooth2<0>, mg, dim3(UNT), 0, q, S, dev_of(sub), dev_of(cg), omega, bq, xc, aq, cq, FZ, (double *)nullptr, 0,
@@ -4351,9 +4373,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                     const int part_stride = (int)s->gmg_part_cap;
                     hipLaunchKernelGGL(k_prolong_smooth<1>, mg, dim3(256), 0, q, S, dev_of(sub), dev_of(cg), omega, b + ka * pl, xc,
                                        a + ka * pl, c + ka * pl, pin_l, FZ, part, part_stride, dlo, dhi);
-                    double *stage = part + 3 * (int64_t)part_stride;
-                    hipLaunchKernelGGL(k_reduce_big, dim3(BIG_STAGE, 3), dim3(256), 0, q, s->d_s, part, part_stride, (int)needp, stage);
-                    hipLaunchKernelGGL(k_finalize_big, dim3(3), dim3(64), 0, q, s->d_s, stage);
+                    PIB_CHK(reduce_dots(s, part, part_stride, (int)needp, q));
                     s->gmg_dots_done = true;
                 } else
                     hipLaunchKernelGGL(k_prolong_smooth<0>, mg, dim3(256), 0, q, S, dev_of(sub), dev_of(cg), omega, b + ka * pl, xc,

@@ -627,6 +627,37 @@ __global__ void k_cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean
     cg_s2(S, hist, n_global, lazy_mean, do_norm, do_beta, conv_is_its);
 }
 
+// The closing kernel of a preconditioner application whose Krylov sums the V-cycle left as per-workgroup partials (gmg.hip
+// reduce_dots: at most DEFER_DOTS_MAX of them per sum): z.r, z.z, sum z reduced in a fixed order by ONE workgroup, z[0] fetched
+// (pinned null space), and -- POST, one rank: nothing sits between the sums and their consumer -- the iteration's scalar step.
+// One launch where k_reduce_big, k_finalize_big, k_fetch_z0 and k_cg_s2 were four (round 5).
+template <int POST>
+__global__ __launch_bounds__(1024) void k_dots_tail(Scalars *__restrict__ S, const double *__restrict__ part, int stride, int count,
+                                                    const double *__restrict__ z, int owner, double *hist, double n_global, int lazy_mean,
+                                                    int do_norm, int do_beta, int conv_is_its)
+{
+    if (S->done) return;
+    __shared__ double sh[16];
+    for (int slot = 0; slot < 3; ++slot) {
+        const double *p = part + (int64_t)slot * stride;
+        double v = 0.0;
+        for (int i = threadIdx.x; i < count; i += 1024) v += p[i];
+        v = wsum(v);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 16; ++w) t += sh[w];
+            S->red[slot] = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        S->red[3] = owner ? z[0] : 0.0;
+        if (POST) cg_s2(S, hist, n_global, lazy_mean, do_norm, do_beta, conv_is_its);
+    }
+}
+
 // ---- single-reduction CG (KSPCGUseSingleReduction; oracle/csrc/oracle.c:orc_cg_single_reduction): the matrix is applied to z,
 // s = A z, and the top of an iteration needs no sum of its own --
 //     dpi = p'w = delta - beta^2 dpiold / betaold^2   (delta = z's; the first iteration: p = z, dpi = delta),   a = beta / dpi
@@ -922,20 +953,50 @@ static int fetch_results(pib_solver *s, int enq)
 
 // ------------------------------------------------------------------ CG
 // Apply the multigrid preconditioner z = M^-1 r and finalize z.r, z.z, sum z (+ z[0] when pinned).
-static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guarded, hipStream_t q, bool reduce = true)
+// `post` (guarded applications inside the iteration only): the scalar step that consumes the sums -- cg_s2's arguments.  On one
+// rank, when the cycle deferred its sums' reduction (gmg.hip reduce_dots), that step runs inside the closing kernel and
+// *post_done says so: the caller then skips its own k_cg_s2.
+struct CgS2Args {
+    double *hist;
+    double n_global;
+    int lazy_mean, do_norm, do_beta, conv_is_its;
+};
+static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guarded, hipStream_t q, bool reduce = true,
+                           const CgS2Args *post = nullptr, bool *post_done = nullptr)
 {
     int nb = 0;
+    if (post_done) *post_done = false;
     s->gmg_guarded = guarded;
     s->gmg_want_dots = (s->cfg.fuse_dots != 0);
-    PIB_CHK(gmg_apply(s, R, Z, q));
+    s->gmg_defer_dots = guarded && s->cfg.merge_scalar_kernels != 0;
+    const int err = gmg_apply(s, R, Z, q);
     s->gmg_want_dots = false;
+    s->gmg_defer_dots = false;
+    if (err) return err;
     s->counters[1]++;
+    const int owner = (s->A.row0 == 0) ? 1 : 0;
+    if (s->gmg_dots_done && s->gmg_pending_count > 0) {
+        // the three sums, z[0] and (one rank) the scalar step in one launch
+        const bool with_post = post != nullptr && reduce && s->comm.nranks == 1;
+        const CgS2Args a = post ? *post : CgS2Args{nullptr, 0.0, 0, 0, 0, 0};
+        if (with_post)
+            hipLaunchKernelGGL(k_dots_tail<1>, dim3(1), dim3(1024), 0, q, s->d_s, s->gmg_pending_part, s->gmg_pending_stride, s->gmg_pending_count, Z,
+                               owner, a.hist, a.n_global, a.lazy_mean, a.do_norm, a.do_beta, a.conv_is_its);
+        else
+            hipLaunchKernelGGL(k_dots_tail<0>, dim3(1), dim3(1024), 0, q, s->d_s, s->gmg_pending_part, s->gmg_pending_stride, s->gmg_pending_count, Z,
+                               owner, (double *)nullptr, 0.0, 0, 0, 0, 0);
+        PIB_HIP(hipGetLastError());
+        s->gmg_pending_count = 0;
+        if (with_post && post_done) *post_done = true;
+        if (!reduce) return 0;
+        return allreduce_slots(s, 0, 4, q);
+    }
     if (!s->gmg_dots_done) {  // else: z.r, z.z, sum z came out of the V-cycle's last smoothing kernel
         OpDotZR dz{Z, R};
         PIB_CHK(launch_vec(s, s->A.n, dz, true, 0, &nb, guarded, q));
         hipLaunchKernelGGL(k_finalize, dim3(3), dim3(256), 0, q, s->d_s, s->d_part, 0, nb);
     }
-    hipLaunchKernelGGL(k_fetch_z0, dim3(1), dim3(1), 0, q, s->d_s, Z, (s->A.row0 == 0) ? 1 : 0);
+    hipLaunchKernelGGL(k_fetch_z0, dim3(1), dim3(1), 0, q, s->d_s, Z, owner);
     PIB_HIP(hipGetLastError());
     if (!reduce) return 0;  // (single-reduction CG: these sums travel with the product's)
     return allreduce_slots(s, 0, 4, q);
@@ -1051,6 +1112,8 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     };
     auto after_update = +[](pib_solver *ps, int nblocks, hipStream_t st) -> int {
         // r.r and sum r of the new residual from the march's partials (slots 4, 5), then the convergence step on |r|
+        if (ps->comm.nranks == 1 && upd_ctx.unprec && ps->cfg.merge_scalar_kernels)  // (POST 8: the two sums, then cg_s2's norm step)
+            return finalize_post<8>(ps, 4, 2, nblocks, upd_ctx.hist, upd_ctx.conv_is_its, st);
         hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, st, ps->d_s, ps->d_part, 4, nblocks);
         PIB_HIP(hipGetLastError());
         PIB_CHK(allreduce_slots(ps, 4, 2, st));  // (several ranks; nothing on one)
@@ -1106,13 +1169,15 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 s->gmg_upd.after = after_update;
                 s->gmg_upd.fallback = update_fallback;
                 s->gmg_upd.used = false;
-                const int err = gmg_pc_and_dots(s, R2, Z, true, q);
+                const CgS2Args closing{s->d_hist, ng, lazy, unprec ? 0 : 1, 1, conv_is_its};
+                bool closed = false;
+                const int err = gmg_pc_and_dots(s, R2, Z, true, q, true, &closing, &closed);
                 s->gmg_upd.w = nullptr;
                 if (err) return err;
                 if (!s->gmg_upd.used) return fail(PIB_ERR_LIB, "solver %s: the multigrid did not take the residual update", s->name.c_str());
                 std::swap(R, R2);
                 s->counters[6]++;
-                hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, unprec ? 0 : 1, 1, conv_is_its);
+                if (!closed) hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, unprec ? 0 : 1, 1, conv_is_its);
                 PIB_HIP(hipGetLastError());
                 return 0;
             }
@@ -1123,13 +1188,18 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 OpUpdateXR<PCM_NONE> op{W, nullptr, R, Z, 1.0, 0.0};
                 PIB_CHK(launch_vec(s, n, op, true, 0, &nb, true, q));
             }
-            PIB_CHK(finalize(s, 0, 6, nb, q));
+            const bool merged6 = gmg && unprec && s->comm.nranks == 1 && s->cfg.merge_scalar_kernels;
+            if (merged6) PIB_CHK(finalize_post<8>(s, 0, 6, nb, s->d_hist, conv_is_its, q));
+            else PIB_CHK(finalize(s, 0, 6, nb, q));
             if (gmg) {
-                if (unprec)
+                if (unprec && !merged6)
                     hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, 0, 1, 0, conv_is_its);
-                PIB_CHK(gmg_pc_and_dots(s, R, Z, true, q));
-                hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, unprec ? 0 : 1, 1,
-                                   conv_is_its);
+                const CgS2Args closing{s->d_hist, ng, lazy, unprec ? 0 : 1, 1, conv_is_its};
+                bool closed = false;
+                PIB_CHK(gmg_pc_and_dots(s, R, Z, true, q, true, &closing, &closed));
+                if (!closed)
+                    hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, unprec ? 0 : 1, 1,
+                                       conv_is_its);
             } else {
                 hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, 1, 1, conv_is_its);
             }
@@ -1755,6 +1825,7 @@ __global__ __launch_bounds__(256) void k_finalize_post(Scalars *__restrict__ S, 
             S->xpend = 1;
             b_s_end(S, hist, conv_is_its);
         }
+        if (POST == 8) cg_s2(S, hist, 0.0, 0, 1, 0, conv_is_its);  // CG: the monitored norm |r| and its convergence test (no shift, no beta)
         if (POST == 7) {  // omega and the end of the iteration at once: r = s - omega t is owed too (OpBFUpdateP::t), its sums
             // follow from the second product's five -- red[3..7] = s.t, t.t, s.s, rp.s, rp.t:
             // |r|^2 = s.s - omega (2 s.t - omega t.t), r.rp = rp.s - omega rp.t

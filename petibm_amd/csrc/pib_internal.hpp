@@ -176,6 +176,7 @@ struct Config {
     int fuse_residual_restrict = 1;  // multigrid: residual + restriction of such a level in ONE march (gmg.hip k_resid_restrict_march)
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
+    int merge_scalar_kernels = 1;  // ... and the one-workgroup kernels behind them in one launch: the sums' reduction, z[0] and (one rank) the iteration's scalar step (krylov.hip k_dots_tail); the residual sums + norm test likewise (k_finalize_post<8>)
     int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
     int deep_up = 1;         // ... and the coarse corrections of the way up need no exchange of their own: a distributed level's right-hand side is exchanged as deep as its final iterate is read by the finer level's prolongation (gmg.hip: fin_l[])
@@ -465,6 +466,10 @@ struct pib_solver {
     double *d_gmg_part = nullptr;   // z.r, z.z, sum z partials of the V-cycle's last smoothing kernel (gmg.hip mode 8)
     int64_t gmg_part_cap = 0;
     bool gmg_want_dots = false, gmg_dots_done = false;
+    // ... whose final reduction the cycle may leave to the solver's closing kernel (gmg.hip reduce_dots, krylov.hip k_dots_tail)
+    bool gmg_defer_dots = false;
+    double *gmg_pending_part = nullptr;
+    int gmg_pending_stride = 0, gmg_pending_count = 0;
     pib::PinRow pin_row;          // gmg.hip grid_register (PINNED)
     bool gmg_pin_local = false;   // this cycle's compatible right-hand side takes Scalars::pin_sigma instead of red[5] (set by the solver around gmg_apply)
     // PCG's residual update r = r_old - alpha w left to the preconditioner's first kernel (gmg.hip k_presmooth2<., 1>): set by
