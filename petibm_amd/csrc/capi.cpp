@@ -166,6 +166,9 @@ try {
     if (s->ev_b) (void)hipEventDestroy(s->ev_b);
     if (s->ev_halo) (void)hipEventDestroy(s->ev_halo);
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_side) (void)hipEventDestroy(s->ev_side);
+    if (s->stream_side) (void)hipStreamDestroy(s->stream_side);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->stream_comm) (void)hipStreamDestroy(s->stream_comm);
     delete s;

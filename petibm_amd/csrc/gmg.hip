@@ -3989,6 +3989,11 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         GridLevel &g = s->levels[(size_t)l];
         const LI &I = li[(size_t)l];
         const int64_t pl = g.plane;
+        // (the cycle has left level 0: what the solver wants to run beside the coarse levels is forked here)
+        if (l == 1 && s->gmg_side_hook != nullptr && !s->gmg_side_launched) {
+            PIB_CHK(s->gmg_side_hook(s, q));
+            s->gmg_side_launched = true;
+        }
         if (l == tail0) {
             TailArgs T;
             std::memset(&T, 0, sizeof T);

@@ -176,6 +176,8 @@ struct Config {
     int fuse_residual_restrict = 1;  // multigrid: residual + restriction of such a level in ONE march (gmg.hip k_resid_restrict_march)
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
+    int side_x_update = 0;  // multigrid-PCG beyond the captured-graph size, at most side_x_max_rows local rows (a slab of a multi-GPU run): x += alpha p as a kernel of its own on a second stream beside the V-cycle's coarse levels instead of riding on the p-update (40 -> 24 B/row on the critical path).  OFF: measured SLOWER on the 512 x 512 x 64 slab (0.99 -> 1.03-1.67 ms per iteration, profiles/r05_slab_side_x_update.md) -- launched chip-wide the update takes the CU slots of the 2 M-cell levels' kernels, on a few workgroups it outlasts the cycle
+    int64_t side_x_max_rows = (int64_t)1 << 25;
     int merge_scalar_kernels = 1;  // ... and the one-workgroup kernels behind them in one launch: the sums' reduction, z[0] and (one rank) the iteration's scalar step (krylov.hip k_dots_tail); the residual sums + norm test likewise (k_finalize_post<8>)
     int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
@@ -426,6 +428,13 @@ struct pib_solver {
     int device = 0;
     hipStream_t stream = nullptr, stream_comm = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr, ev_ready = nullptr;
+    // PCG on slab-sized systems: x += alpha p on a stream of its own beside the V-cycle's coarse levels, which leave the HBM idle
+    // (krylov.hip solve_cg, gmg.hip gmg_apply: forked when the cycle leaves level 0, joined ahead of the next p-update)
+    hipStream_t stream_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_side = nullptr;
+    int (*gmg_side_hook)(pib_solver *s, hipStream_t q) = nullptr;  // set by the solver around gmg_apply; called once, below level 0
+    void *gmg_side_ctx = nullptr;
+    bool gmg_side_launched = false;
     pib::DeviceCsr A;
     bool has_matrix = false;
     // grid hint
