@@ -434,13 +434,10 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
 #undef PIB_V
 }
 
-// rhs2 = D u + Dbc (navierstokes.cpp:540-563); D row in packed-column order u(i-1), u(i), v(j-1), v(j), w(k-1), w(k)
-__global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int64_t pin_cell, const double *__restrict__ U,
-                                                        double *__restrict__ rhs2)
+// rhs2 = D u + Dbc (navierstokes.cpp:540-563) at one pressure cell; D row in packed-column order u(i-1), u(i), v(j-1), v(j), w(k-1), w(k)
+__device__ __forceinline__ double rhs_poisson_cell(const NsDev &D, const double *__restrict__ U, int64_t i, int64_t j, int64_t k)
 {
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < D.pN; c += (int64_t)gridDim.x * 256) {
-        int64_t i, j, k;
-        split3(c, D.pn[0], D.pn[1], i, j, k);
+    {
         const int64_t ijk[3] = {i, j, k};
         const double wx = D.pw[0][i], wy = D.pw[1][j], wz = (D.dim == 3) ? D.pw[2][k] : 1.0;
         const double area[3] = {wy * wz, wx * wz, wx * wy};
@@ -482,10 +479,31 @@ __global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int64_t pin_cel
             if (has_p) s = s + vp * U[base];
             if (!has_p) corr = corr + area[f] * D.a1[face_index(F, 2 * f + 1, fi[0], fi[1], fi[2])];
         }
-        double r = s + corr;
+        return s + corr;
+    }
+}
+__global__ __launch_bounds__(256) void k_ns_rhs_poisson(NsDev D, int64_t pin_cell, const double *__restrict__ U,
+                                                        double *__restrict__ rhs2)
+{
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < D.pN; c += (int64_t)gridDim.x * 256) {
+        int64_t i, j, k;
+        split3(c, D.pn[0], D.pn[1], i, j, k);
+        double r = rhs_poisson_cell(D, U, i, j, k);
         if (c == pin_cell) r = 0.0;  // the pinned pressure's row (global cell 0; -1: none on this rank)
         rhs2[c] = r;
     }
+}
+// ... walked by grid line (round 5, as k_ns_project_rows): j, k workgroup-uniform, no index division, the lanes' loads coalesced
+__global__ __launch_bounds__(256) void k_ns_rhs_poisson_rows(NsDev D, int64_t pin_cell, const double *__restrict__ U,
+                                                             double *__restrict__ rhs2)
+{
+    const int j = blockIdx.y, k = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int)D.pn[0]) return;
+    const int64_t c = i + D.pn[0] * (j + D.pn[1] * (int64_t)k);
+    double r = rhs_poisson_cell(D, U, i, j, k);
+    if (c == pin_cell) r = 0.0;
+    rhs2[c] = r;
 }
 
 // Ghost-point state, one ghost point per lane.  MODE 0: setGhostICs (navierstokes.cpp:142), 1: updateEqs into
@@ -578,6 +596,43 @@ __global__ __launch_bounds__(256) void k_ns_project(NsDev D, double dt, const do
             U[g] = U[g] + (-1.0) * r;
         }
         if (g < D.pN) p[g] = p[g] + 1.0 * dP[g];
+    }
+}
+
+// The same projection walked by PRESSURE CELL (round 5): a workgroup takes a piece of a grid line (j, k workgroup-uniform: no
+// index division, the y / z gradient entries through the scalar path, the x one from the 1 / dL table instead of a division per
+// point), a lane its cell -- p += dP there, and the velocity point of every component that carries the cell's own index (its +
+// face): one load of dP[c] serves all four updates, the + neighbours come from the cache.  Every velocity point has such a cell
+// (a component has n - 1 points along its own direction, n when periodic).  Same expressions as k_ns_project: same bits.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_ns_project_rows(NsDev D, double dt, const double *__restrict__ dP, double *__restrict__ U,
+                                                         double *__restrict__ p)
+{
+    const int j = blockIdx.y, k = (DIM == 3) ? blockIdx.z : 0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nx = (int)D.pn[0];
+    if (i >= nx) return;
+    const int64_t sy = D.pn[0], sz = D.pn[0] * D.pn[1];
+    const int64_t c = i + sy * j + sz * (int64_t)k;
+    const double d0 = dP[c];
+    p[c] = p[c] + 1.0 * d0;
+    const int ijk[3] = {i, j, k};
+    const int64_t pst[3] = {1, sy, sz};
+#pragma unroll
+    for (int f = 0; f < DIM; ++f) {
+        const NsField &F = D.f[f];
+        if (i >= (int)F.n[0] || j >= (int)F.n[1] || k >= (int)F.n[2]) continue;
+        const int64_t g = F.off + i + F.n[0] * (j + F.n[1] * (int64_t)k);
+        const double gv = F.ginv[ijk[f]];
+        double r;
+        if (ijk[f] < (int)D.pn[f] - 1) {
+            r = 0.0 + (dt * (-gv)) * d0;
+            r = r + (dt * gv) * dP[c + pst[f]];
+        } else {  // periodic seam: column order of BNG's row
+            r = 0.0 + (dt * gv) * dP[c - (D.pn[f] - 1) * pst[f]];
+            r = r + (dt * (-gv)) * d0;
+        }
+        U[g] = U[g] + (-1.0) * r;
     }
 }
 
@@ -1567,7 +1622,14 @@ try {
             PIB_CHK(ns_halo_velocity(ns, ns->U));  // u += BNH df changed owned points next to the neighbours' planes
         }
         PIB_CHK(mark(3));  // end of rhsForces + solveForces (nothing between the two marks without bodies)
-        hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns_pin_cell(ns), ns->U, ns->rhs2);
+        {
+            static const int by_rows = std::getenv("PIB_RHS_POISSON_ROWS") ? std::atoi(std::getenv("PIB_RHS_POISSON_ROWS")) : 1;
+            const dim3 pg((unsigned)((D.pn[0] + 255) / 256), (unsigned)D.pn[1], (unsigned)(D.dim == 3 ? D.pn[2] : 1));
+            if (by_rows && D.pn[1] <= 65535 && (D.dim == 2 || D.pn[2] <= 65535))
+                hipLaunchKernelGGL(k_ns_rhs_poisson_rows, pg, dim3(256), 0, ns->stream, D, ns_pin_cell(ns), ns->U, ns->rhs2);
+            else
+                hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns_pin_cell(ns), ns->U, ns->rhs2);
+        }
         PIB_HIP(hipGetLastError());
         PIB_CHK(mark(4));  // end of rhsPoisson
         if (coupled) {
@@ -1594,7 +1656,15 @@ try {
             hipLaunchKernelGGL(k_ns_project_csr, dim3(gt), dim3(256), 0, ns->stream, D.UN, D.pN, ns->bng_rowptr, ns->bng_col,
                                ns->bng_val, ns->dP, ns->U, ns->p);
         else
+        {
+            static const int by_rows = std::getenv("PIB_PROJECT_ROWS") ? std::atoi(std::getenv("PIB_PROJECT_ROWS")) : 1;
+            const dim3 pg((unsigned)((D.pn[0] + 255) / 256), (unsigned)D.pn[1], (unsigned)(D.dim == 3 ? D.pn[2] : 1));
+            if (by_rows && D.pn[1] <= 65535 && (D.dim == 2 || D.pn[2] <= 65535)) {
+                if (D.dim == 3) hipLaunchKernelGGL(k_ns_project_rows<3>, pg, dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
+                else hipLaunchKernelGGL(k_ns_project_rows<2>, pg, dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
+            } else
             hipLaunchKernelGGL(k_ns_project, dim3(gt), dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
+        }
         if (ns->ib) PIB_CHK(ib_update_forces(ns));  // f += df  (decoupledibpm.cpp:125)
         PIB_CHK(ns_halo_velocity(ns, ns->U));       // the projected velocity on the neighbours' planes
         hipLaunchKernelGGL(k_ns_ghosts<2>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);  // bc->updateGhostValues (:263)
