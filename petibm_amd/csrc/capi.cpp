@@ -151,7 +151,7 @@ try {
     dense_release(s);
     vel_stencil_release(s);
     s->A.release();
-    if (s->work_base) (void)hipFree(s->work_base);
+    (void)free_work(s);
     if (s->x_dev) (void)hipFree(s->x_dev);
     if (s->b_dev) (void)hipFree(s->b_dev);
     if (s->d_s) (void)hipFree(s->d_s);
@@ -675,6 +675,18 @@ try {
     if (s == nullptr || h2d_ms == nullptr || d2h_ms == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
     *h2d_ms = s->stage_ms[0];
     *d2h_ms = s->stage_ms[1];
+    return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
+}
+
+int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept)
+try {
+    if (s == nullptr || searches == nullptr || candidates == nullptr || ms_had == nullptr || ms_kept == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
+    *searches = s->placements;
+    *candidates = s->place_tried;
+    *ms_had = s->place_ms[0];
+    *ms_kept = s->place_ms[1];
     return 0;
 } catch (...) {
     return pib::fail_exception(__func__);

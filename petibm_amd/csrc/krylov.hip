@@ -709,6 +709,20 @@ void drop_iteration_graph(pib_solver *s)
     s->graph = nullptr;
 }
 
+int free_work(pib_solver *s)
+{
+    if (s->work_base) PIB_HIP(hipFree(s->work_base));
+    s->work_base = nullptr;
+    s->work = nullptr;
+    for (double *&v : s->work_split) {
+        if (v) PIB_HIP(hipFree(v));
+        v = nullptr;
+    }
+    s->placed_against = nullptr;
+    s->n_work = 0;
+    return 0;
+}
+
 int ensure_work(pib_solver *s, int nvec)
 {
     const DeviceCsr &A = s->A;
@@ -717,14 +731,25 @@ int ensure_work(pib_solver *s, int nvec)
     lo = (lo + 3) & ~int64_t(3);  // owned part 32-byte aligned
     int64_t stride = lo + A.n + hi + 4;
     stride = (stride + 3) & ~int64_t(3);
-    if (s->work != nullptr && s->n_work >= nvec && s->work_stride == stride && s->work_lo == lo) return 0;
+    static const int64_t split_rows = [] {
+        const char *e = std::getenv("PIB_SPLIT_WORK_ROWS");
+        return e ? (int64_t)std::atoll(e) : (int64_t)-1;
+    }();
+    const bool split = split_rows >= 0 && A.n >= split_rows && nvec <= pib_solver::MAX_WORK;
+    const bool have = split ? s->work_split[0] != nullptr : s->work != nullptr;
+    if (have && s->n_work >= nvec && s->work_stride == stride && s->work_lo == lo) return 0;
     drop_iteration_graph(s);  // a captured iteration body holds the old vectors' addresses (and goes BEFORE they do)
-    if (s->work_base) PIB_HIP(hipFree(s->work_base));
-    s->work_base = nullptr;
-    s->work = nullptr;
-    PIB_HIP(hipMalloc(&s->work_base, (size_t)(stride * nvec + 4) * sizeof(double)));
-    PIB_HIP(hipMemsetAsync(s->work_base, 0, (size_t)(stride * nvec + 4) * sizeof(double), s->stream));
-    s->work = s->work_base;  // hipMalloc is 256-byte aligned; lo and stride are multiples of 4 doubles
+    PIB_CHK(free_work(s));
+    if (split) {
+        for (int i = 0; i < nvec; ++i) {
+            PIB_HIP(hipMalloc(&s->work_split[i], (size_t)(stride + 4) * sizeof(double)));
+            PIB_HIP(hipMemsetAsync(s->work_split[i], 0, (size_t)(stride + 4) * sizeof(double), s->stream));
+        }
+    } else {
+        PIB_HIP(hipMalloc(&s->work_base, (size_t)(stride * nvec + 4) * sizeof(double)));
+        PIB_HIP(hipMemsetAsync(s->work_base, 0, (size_t)(stride * nvec + 4) * sizeof(double), s->stream));
+        s->work = s->work_base;  // hipMalloc is 256-byte aligned; lo and stride are multiples of 4 doubles
+    }
     s->work_lo = lo;
     s->work_stride = stride;
     s->n_work = nvec;
@@ -1002,6 +1027,161 @@ static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guard
     return allreduce_slots(s, 0, 4, q);
 }
 
+// ---- placing the search direction against the caller's x (cfg.place_update_vector)
+// The p-update's access pattern with NEUTRAL arithmetic: z read, p and x read and written.  p is all zeros and a is -0.0, so
+// x + a p gives every x back bit for bit (x + (-0.0) == x for +0.0 and -0.0 alike) and p stays zero; z only has to be loaded.
+__global__ __launch_bounds__(256) void k_place_probe(int64_t n2, const double2 *__restrict__ z, double2 *__restrict__ p, double2 *__restrict__ x, double a)
+{
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + 256 * u;
+        if (i < n2) {
+            const double2 vz = z[i], vp = p[i];
+            double2 vx = x[i];
+            vx.x += a * vp.x;
+            vx.y += a * vp.y;
+            x[i] = vx;
+            double2 np = {vp.x + a * vp.x, vp.y + a * vp.y};
+            if (vz.x == 1.2345678e300 && vz.y == -1.2345678e300) np.x = a;  // (keeps the load of z; p stays zero or minus zero)
+            p[i] = np;
+        }
+    }
+}
+
+// Best of three launches, in ms (one untimed launch first).
+static int place_probe_ms(pib_solver *s, int64_t n, const double *z, double *p, double *x, hipEvent_t e0, hipEvent_t e1, double *out)
+{
+    const int64_t n2 = n / 2;
+    const unsigned nb = (unsigned)((n2 + 1023) / 1024);
+    double best = 1e30;
+    for (int r = 0; r < 4; ++r) {
+        PIB_HIP(hipEventRecord(e0, s->stream));
+        hipLaunchKernelGGL(k_place_probe, dim3(nb), dim3(256), 0, s->stream, n2, (const double2 *)z, (double2 *)p, (double2 *)x, -0.0);
+        PIB_HIP(hipGetLastError());
+        PIB_HIP(hipEventRecord(e1, s->stream));
+        PIB_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        PIB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (r) best = std::min(best, (double)ms);
+    }
+    *out = best;
+    return 0;
+}
+
+// Work vector `idx` (p: dead between solves) into an allocation of its own that streams well beside x.
+// What the lab found (tools/place_lab.hip pairs / mix / far, profiles/r05_vector_placement_lab.txt): device allocations fall
+// into CLASSES -- runs of 4 to 64 GiB in allocation order -- and a kernel that reads and writes two vectors of one class runs
+// some 12 % under the rate it has on vectors of two classes; which class an allocation is in cannot be read off its address, and
+// the runs differ from box to box and from process to process.  So: time the probe on two NEIGHBOURING fresh allocations (one
+// class, as good as always: the slow reference), then on (p, x); while that is not 5 % under the slowest time seen, walk on
+// through fresh allocations -- 2, 4, 8 ... GiB further each step, the gaps allocated and never touched -- and probe each against
+// x.  Everything allocated stays allocated until the walk ends, so that every step lands on other physical blocks; the walk
+// stops after cfg.place_candidates steps or when only a quarter of the device's memory would be left.  A search costs 10 ms
+// when p is well placed already and some 50 ms when not, and runs when x is a buffer the solver has not seen (three times in a
+// solver's life at most: a caller with a new x every solve keeps the third).
+static int place_update_vector(pib_solver *s, int idx, int zidx, double *x)
+{
+    const DeviceCsr &A = s->A;
+    if (!s->cfg.place_update_vector || A.n < s->cfg.place_min_rows || A.n != A.n_global || x == nullptr || !aligned16(x)) return 0;
+    if (x == s->placed_against || s->placements >= 3 || idx >= pib_solver::MAX_WORK) return 0;
+    const size_t bytes = (size_t)(s->work_stride + 4) * sizeof(double);
+    std::vector<void *> held;  // spacers and rejected candidates
+    struct Held {
+        std::vector<void *> &v;
+        ~Held()
+        {
+            for (void *h : v) (void)hipFree(h);
+        }
+    } held_guard{held};
+    // (the walk's budget: what is free now less a quarter of the device, asked ONCE -- hipMemGetInfo takes 100 ms)
+    size_t budget = 0, used = 0;
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > tot / 4) budget = fr - tot / 4;
+    }
+    auto room = [&](size_t want) { return used + want <= budget; };
+    auto fresh = [&](double **out) -> bool {
+        *out = nullptr;
+        if (!room(bytes) || hipMalloc(out, bytes) != hipSuccess) {
+            (void)hipGetLastError();  // no room: the search ends with what it has
+            *out = nullptr;
+            return false;
+        }
+        if (hipMemsetAsync(*out, 0, bytes, s->stream) != hipSuccess) {
+            (void)hipFree(*out);
+            *out = nullptr;
+            return false;
+        }
+        used += bytes;
+        return true;
+    };
+    if (s->work_split[idx] == nullptr) {
+        if (!fresh(&s->work_split[idx])) return 0;
+    } else
+        PIB_HIP(hipMemsetAsync(s->work_split[idx], 0, bytes, s->stream));
+    hipEvent_t e0, e1;
+    PIB_HIP(hipEventCreate(&e0));
+    PIB_HIP(hipEventCreate(&e1));
+    struct Ev {
+        hipEvent_t a, b;
+        ~Ev() { (void)hipEventDestroy(a), (void)hipEventDestroy(b); }
+    } ev{e0, e1};
+    const double *z = s->vec(zidx);
+    const int64_t lo = s->work_lo;
+    double *cur = s->work_split[idx];
+    int tried = 1;
+    // the slow reference: two neighbouring fresh allocations
+    double *n0 = nullptr, *n1 = nullptr;
+    double tref = 0.0, t0 = 0.0;
+    if (fresh(&n0)) held.push_back(n0);
+    if (fresh(&n1)) held.push_back(n1);
+    if (n0 && n1) PIB_CHK(place_probe_ms(s, A.n, z, n0 + lo, n1 + lo, e0, e1, &tref));
+    PIB_CHK(place_probe_ms(s, A.n, z, cur + lo, x, e0, e1, &t0));
+    double tslow = std::max(tref, t0), tkept = t0;
+    double *kept = cur;
+    static const bool debug = std::getenv("PIB_PLACE_DEBUG") != nullptr;
+    if (debug) std::fprintf(stderr, "[place] neighbours %.3f ms, (p %p, x %p) %.3f ms\n", tref, (void *)cur, (void *)x, t0);
+    auto fast = [&](double t) { return t <= 0.95 * tslow; };
+    if (!fast(t0)) {
+        // (n1 is a candidate already: the first step of the walk)
+        for (int k = 0; k < s->cfg.place_candidates; ++k) {
+            double *c = nullptr;
+            if (k == 0 && n1 != nullptr)
+                c = n1;
+            else {
+                const size_t step = (size_t)1 << (30 + std::min(k, 6));  // 2, 4 ... 64 GiB
+                void *sp = nullptr;
+                if (step > bytes && room(step) && hipMalloc(&sp, step - bytes) == hipSuccess) held.push_back(sp), used += step - bytes;
+                (void)hipGetLastError();
+                if (!fresh(&c)) break;
+                held.push_back(c);
+            }
+            double t = 0.0;
+            PIB_CHK(place_probe_ms(s, A.n, z, c + lo, x, e0, e1, &t));
+            ++tried;
+            if (debug) std::fprintf(stderr, "[place] step %d: %p %.3f ms\n", k, (void *)c, t);
+            tslow = std::max(tslow, t);
+            if (t < tkept) kept = c, tkept = t;
+            if (fast(tkept)) break;
+        }
+        if (!fast(tkept)) kept = cur, tkept = t0;  // nothing in another class within reach: the solver keeps the vector it had
+    }
+    if (kept != cur) {
+        for (void *&h : held)
+            if (h == (void *)kept) h = nullptr;  // (hipFree(nullptr) is a no-op)
+        held.push_back(cur);
+        drop_iteration_graph(s);
+        s->work_split[idx] = kept;
+    }
+    s->placed_against = x;
+    s->placements++;
+    s->place_tried = tried;
+    s->place_ms[0] = t0;
+    s->place_ms[1] = tkept;
+    return 0;
+}
+
 // x, b: device pointers, n_local entries.
 template <int POST>
 static int finalize_post(pib_solver *s, int slot0, int nslots, int count, double *hist, int conv_is_its, hipStream_t q,
@@ -1013,6 +1193,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     const int64_t n = A.n;
     hipStream_t q = s->stream;
     PIB_CHK(ensure_work(s, 5));
+    PIB_CHK(place_update_vector(s, 2, 1, x));
     double *R = s->vec(0), *Z = s->vec(1), *P = s->vec(2), *W = s->vec(3);
     double *R2 = s->vec(4);  // the other residual buffer of the fused update below
     const Precond pc = s->cfg.pc;
@@ -1292,6 +1473,7 @@ int solve_cg_sr(pib_solver *s, double *x, const double *b)
     const int64_t n = A.n;
     hipStream_t q = s->stream;
     PIB_CHK(ensure_work(s, 5));
+    PIB_CHK(place_update_vector(s, 2, 1, x));
     double *R = s->vec(0), *Z = s->vec(1), *P = s->vec(2), *W = s->vec(3), *SV = s->vec(4);
     const Precond pc = s->cfg.pc;
     const bool guess = s->cfg.initial_guess_nonzero;

@@ -178,6 +178,9 @@ struct Config {
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int side_x_update = 0;  // multigrid-PCG beyond the captured-graph size, at most side_x_max_rows local rows (a slab of a multi-GPU run): x += alpha p as a kernel of its own on a second stream beside the V-cycle's coarse levels instead of riding on the p-update (40 -> 24 B/row on the critical path).  OFF: measured SLOWER on the 512 x 512 x 64 slab (0.99 -> 1.03-1.67 ms per iteration, profiles/r05_slab_side_x_update.md) -- launched chip-wide the update takes the CU slots of the 2 M-cell levels' kernels, on a few workgroups it outlasts the cycle
     int64_t side_x_max_rows = (int64_t)1 << 25;
+    int place_update_vector = 1;  // CG on one rank, systems of place_min_rows rows and more: the search direction p gets an allocation of its own, CHOSEN by timing the p-update's access pattern against the caller's x while walking through fresh allocations (krylov.hip, place_update_vector).  The flat update reads and writes both vectors, and its rate has two modes (6.3 against 5.6 TB/s at 512^3: 835 against 960 us, 8 % of the solve) set by which physical blocks the two sit in -- a property of the pair, the same for the life of the process, that no address arithmetic inside one allocation moves (profiles/r05_vector_placement_lab.txt)
+    int64_t place_min_rows = (int64_t)1 << 24;
+    int place_candidates = 8;  // steps the walk takes at most (2, 4, 8 ... GiB apart)
     int merge_scalar_kernels = 1;  // ... and the one-workgroup kernels behind them in one launch: the sums' reduction, z[0] and (one rank) the iteration's scalar step (krylov.hip k_dots_tail); the residual sums + norm test likewise (k_finalize_post<8>)
     int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
@@ -527,7 +530,15 @@ struct pib_solver {
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t work_lo = 0;      // entries before the owned part of a work vector
     Redist redist;            // general row partition + multigrid: the solve happens on z-slabs in the inner solver
-    double *vec(int i) const { return work + (int64_t)i * work_stride + work_lo; }
+    // Work vector i: out of the one pool, or (split_work: large systems) an allocation of its own -- the rate of a flat kernel that
+    // writes two vectors depends on which PHYSICAL blocks the two sit in (profiles/r05_vector_placement_lab.txt), and only
+    // separately allocated vectors can be exchanged for better placed ones.
+    static constexpr int MAX_WORK = 12;
+    double *work_split[MAX_WORK] = {};
+    const double *placed_against = nullptr;  // the x that p was last placed against (place_update_vector)
+    int placements = 0, place_tried = 0;     // searches run (at most 3 in a solver's life), candidates timed by the last one
+    double place_ms[2] = {0.0, 0.0};         // the probe with the vector the solver had / with the one it kept
+    double *vec(int i) const { return (work_split[i] != nullptr ? work_split[i] : work + (int64_t)i * work_stride) + work_lo; }
 };
 
 namespace pib {
@@ -583,6 +594,7 @@ int solve_chebyshev(pib_solver *s, double *x, const double *b);  // KSPCHEBYSHEV
 // Gershgorin interval [lo, hi] of the (Jacobi-)preconditioned matrix, the maximum over the ranks; cached per matrix
 int gershgorin_bounds(pib_solver *s, bool jacobi, double *lo, double *hi);
 int ensure_work(pib_solver *s, int nvec);
+int free_work(pib_solver *s);
 // assemble.hip: take a copy of a CSR that already lives in HBM (single rank, 32-bit offsets) as the solver's matrix
 int adopt_device_csr(pib_solver *s, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col, const double *val);
 int after_set_matrix(pib_solver *s);

@@ -284,6 +284,12 @@ class LinSolverBase:
         capi.check(capi.load().pib_get_staging_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def placement(self):
+        """(searches, candidates, ms_had, ms_kept) of the search direction's placement against x (pib_get_placement); zeros when none ran"""
+        a, b, c, d = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        capi.check(capi.load().pib_get_placement(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
     def deviceVec(self, n: Optional[int] = None) -> DeviceVec:
         return DeviceVec(self, self.n_local if n is None else n)
 

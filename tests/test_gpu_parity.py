@@ -1012,6 +1012,52 @@ def test_x_update_on_a_second_stream_is_bit_identical(lin, pinned):
     assert np.abs(out[0][0] - xs).max() <= 1e-6 * np.abs(xs).max()
 
 
+@pytest.mark.parametrize("sr", [0, 1])
+def test_search_direction_placed_against_x_is_bit_identical(lin, sr):
+    """`pib_place_update_vector` (CG on one rank, 2^24 rows and more; here pushed down to every size): p moves to an allocation of
+    its own, chosen by timing the p-update's access pattern against the caller's x while walking through fresh allocations
+    (krylov.hip, place_update_vector; profiles/r05_vector_placement_lab.txt).  The probe computes x + (-0.0) * 0: a guess in x
+    comes back bit for bit, and the solve is the one without the search.  One search per x the solver has not seen, three in a
+    solver's life."""
+    from petibm_amd import capi
+    n = (64, 48, 40)
+    w = [np.full(n[0], 1.0 / n[0]), np.full(n[1], 1.0 / n[1]) * (1.0 + 0.2 * np.sin(np.arange(n[1]) / 5.0)), np.full(n[2], 1.0 / n[2])]
+    dt = 0.01
+    rng = np.random.default_rng(11)
+    xs = rng.uniform(-1, 1, n[0] * n[1] * n[2])
+    xs -= xs.mean()
+    guess = xs + 1e-3 * rng.uniform(-1, 1, xs.size)
+    guess[::7] = -0.0  # (signed zeros survive the probe too)
+    out = []
+    for place in (1, 0):
+        extra = f"pib_place_update_vector={place}\npib_place_min_rows=1000\npib_place_candidates=2\npib_cg_single_reduction={sr}\n"
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=extra))
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+        xs_d, b_d, x_d, x2_d = s.deviceVec(), s.deviceVec(), s.deviceVec(), s.deviceVec()
+        xs_d.upload(xs)
+        s.matMult(xs_d, b_d)
+        x_d.upload(guess)
+        s.solve(x_d, b_d)
+        first = (x_d.download(), s.getIters(), np.array(s.getResidualHistory()))
+        searches = [s.placement()[0]]
+        x_d.upload(guess)
+        s.solve(x_d, b_d)  # the same x: no second search
+        searches.append(s.placement()[0])
+        x2_d.upload(guess)
+        s.solve(x2_d, b_d)  # another x: one more
+        searches.append(s.placement()[0])
+        again = (x2_d.download(), s.getIters(), np.array(s.getResidualHistory()))
+        out.append((first, again, searches, s.placement()))
+        s.destroy()
+    for k in (0, 1):
+        assert out[0][k][1] == out[1][k][1] and np.array_equal(out[0][k][2], out[1][k][2]) and np.array_equal(out[0][k][0], out[1][k][0])
+    assert np.array_equal(out[0][0][0], out[0][1][0])
+    assert out[0][2] == [1, 1, 2] and out[1][2] == [0, 0, 0]
+    assert out[0][3][1] >= 1 and out[0][3][2] > 0.0 and out[0][3][3] <= out[0][3][2]
+    err = out[0][0][0] - xs
+    assert np.abs(err - err.mean()).max() <= 1e-6 * np.abs(xs).max()  # (up to the constant the guess brought)
+
+
 def test_one_sweep_of_the_solver_file_is_a_fused_pair_of_steps(lin):
     """`pib_sweep_pairs` (default 1): the reference's files say presweeps = postsweeps = 1 (AmgX's classical AMG); the
     geometric stand-in reads a sweep as one fused pair of damped-Jacobi steps.  The default with V(1,1) in the file is, bit
