@@ -315,8 +315,9 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.side_x_max_rows = std::atoll(d.get("default", "pib_side_x_max_rows", "33554432").c_str());
     c.place_update_vector = std::atoi(d.get("default", "pib_place_update_vector", "1").c_str());
     c.place_min_rows = std::atoll(d.get("default", "pib_place_min_rows", "16777216").c_str());
-    c.place_candidates = std::atoi(d.get("default", "pib_place_candidates", "5").c_str());
-    c.place_residuals = std::atoi(d.get("default", "pib_place_residuals", "1").c_str());
+    c.place_candidates = std::atoi(d.get("default", "pib_place_candidates", "6").c_str());
+    c.place_residuals = std::atoi(d.get("default", "pib_place_residuals", "0").c_str());
+    c.place_product = std::atoi(d.get("default", "pib_place_product", "1").c_str());
     c.cg_single_reduction = std::atoi(d.get("default", "pib_cg_single_reduction", "0").c_str());
     c.fuse_residual_update_slabs = std::atoi(d.get("default", "pib_fuse_residual_update_slabs", "1").c_str());
     c.sweep_pairs = std::atoi(d.get("default", "pib_sweep_pairs", "1").c_str());
@@ -464,6 +465,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_place_min_rows", v)) c.place_min_rows = std::atoll(v.c_str());
     if (get("pib_place_candidates", v)) c.place_candidates = std::atoi(v.c_str());
     if (get("pib_place_residuals", v)) c.place_residuals = std::atoi(v.c_str());
+    if (get("pib_place_product", v)) c.place_product = std::atoi(v.c_str());
     if (get("ksp_cg_single_reduction", v)) c.cg_single_reduction = truthy(v) ? 1 : 0;  // PETSc's own option (KSPCGUseSingleReduction)
     if (get("pib_cg_single_reduction", v)) c.cg_single_reduction = std::atoi(v.c_str());
     if (get("pib_fuse_residual_update_slabs", v)) c.fuse_residual_update_slabs = std::atoi(v.c_str());

@@ -1084,9 +1084,10 @@ static int place_probe_ms(pib_solver *s, int64_t n, const double *z, double *p, 
 // most: a caller with a new x every solve keeps the third).
 struct PlaceNeed {
     int idx;               // the work vector to place
-    double *partner[3];    // the vectors it must stream well beside (each comes back bit for bit)
+    double *partner[3];    // kind 0: the vectors it must stream well beside (each comes back bit for bit)
     int np;
-    double t_had = 0.0, t_kept = 0.0;
+    int kind = 0;          // 0: the pair probe beside the partners; 1: the CSR product p -> this vector, timed itself
+    double t_had = 0.0, t_kept = 0.0, tslow = 0.0;
     bool met = false;
 };
 
@@ -1141,9 +1142,23 @@ static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn,
     const double *z = s->vec(zidx);
     const int64_t lo = s->work_lo;
     static const bool debug = std::getenv("PIB_PLACE_DEBUG") != nullptr;
-    // the worst of the candidate's probes beside the need's partners
+    // the worst of the candidate's probes beside the need's partners / the product into the candidate (best of two)
     auto beside = [&](double *c, const PlaceNeed &nd, double *out) -> int {
         double w = 0.0;
+        if (nd.kind == 1) {
+            w = 1e30;
+            for (int r = 0; r < 3; ++r) {
+                PIB_HIP(hipEventRecord(e0, s->stream));
+                PIB_CHK(spmv_rows(s, s->vec(2), c + lo, 0, A.n, nullptr, false, s->stream));
+                PIB_HIP(hipEventRecord(e1, s->stream));
+                PIB_HIP(hipEventSynchronize(e1));
+                float ms = 0.f;
+                PIB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                if (r) w = std::min(w, (double)ms);
+            }
+            *out = w;
+            return 0;
+        }
         for (int k = 0; k < nd.np; ++k) {
             double t = 0.0;
             PIB_CHK(place_probe_ms(s, A.n, z, c + lo, nd.partner[k], e0, e1, &t));
@@ -1155,35 +1170,44 @@ static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn,
     int tried = 0;
     // the slow reference: two neighbouring fresh allocations
     double *n0 = nullptr, *n1 = nullptr;
-    double tslow = 0.0;
+    double tnb = 0.0;
     if (fresh(&n0)) held.push_back(n0);
     if (fresh(&n1)) held.push_back(n1);
-    if (n0 && n1) PIB_CHK(place_probe_ms(s, A.n, z, n0 + lo, n1 + lo, e0, e1, &tslow));
-    if (debug) std::fprintf(stderr, "[place] neighbours %.3f ms\n", tslow);
+    if (n0 && n1) PIB_CHK(place_probe_ms(s, A.n, z, n0 + lo, n1 + lo, e0, e1, &tnb));
+    if (debug) std::fprintf(stderr, "[place] neighbours %.3f ms\n", tnb);
     for (int i = 0; i < nn; ++i) {
         PIB_CHK(beside(s->work_split[needs[i].idx], needs[i], &needs[i].t_had));
         needs[i].t_kept = needs[i].t_had;
-        tslow = std::max(tslow, needs[i].t_had);
+        needs[i].tslow = std::max(needs[i].kind == 0 ? tnb : 0.0, needs[i].t_had);
         ++tried;
         if (debug) std::fprintf(stderr, "[place] work vector %d (%p): %.3f ms\n", needs[i].idx, (void *)s->work_split[needs[i].idx], needs[i].t_had);
     }
-    // (the two modes: 0.87-0.89 against 0.96-1.03 ms at 512^3 -- 0.925 of the slowest time seen separates them whatever the
-    // slow sample was)
-    auto fast = [&](double t) { return t <= 0.925 * tslow; };
+    // Pair probe: two modes, 0.87-0.89 against 0.96-1.03 ms at 512^3 -- 0.925 of the slowest time seen separates them whatever
+    // the slow sample was.  The product: 2.23-2.26 ms at best, 2.45-2.50 at worst and levels in between (the output's class
+    // against the coefficients', the column indices', the input's: tools/spmv_placement_scan.py) -- a candidate is taken when
+    // it is 2 % better than what the solver has, and the search goes on until the product streams 6.15 TB/s of the CSR's
+    // algorithmic bytes (the best level is 6.2 for every matrix far beyond the caches, which is what place_min_rows selects).
+    const double spmv_bytes = (double)A.nnz * 12.0 + (double)A.n * (A.rp64 ? 24.0 : 20.0);
+    auto good_product = [&](double t) { return spmv_bytes / (t * 1e-3) >= 6.15e12; };
+    auto takes = [&](const PlaceNeed &nd, double t) { return nd.kind == 0 ? t <= 0.925 * nd.tslow : t <= 0.98 * nd.t_kept; };
     auto open_needs = [&]() {
         int c = 0;
-        for (int i = 0; i < nn; ++i) needs[i].met = needs[i].met || fast(needs[i].t_kept), c += needs[i].met ? 0 : 1;
+        for (int i = 0; i < nn; ++i) {
+            PlaceNeed &nd = needs[i];
+            nd.met = nd.met || (nd.kind == 0 ? nd.t_kept <= 0.925 * nd.tslow : good_product(nd.t_kept));
+            c += nd.met ? 0 : 1;
+        }
         return c;
     };
     int gap = 0;  // the next candidate comes 2^gap GiB further on (a candidate that was taken: its neighbour is tried next)
     bool first = true;
-    for (int k = 0, misses = 0; misses < s->cfg.place_candidates && open_needs() > 0; ++k) {
+    for (int k = 0, misses = 0; k < 24 && misses < s->cfg.place_candidates && open_needs() > 0; ++k) {
         double *c = nullptr;
         if (first && n1 != nullptr)
             c = n1;
         else {
             if (gap > 0) {
-                const size_t step = (size_t)1 << (30 + std::min(gap, 4));  // 2, 4, 8, 16, 16 ... GiB
+                const size_t step = (size_t)1 << (30 + std::min(gap, 6));  // 2, 4, 8, 16, 32, 64 GiB
                 void *sp = nullptr;
                 if (step > bytes && room(step) && hipMalloc(&sp, step - bytes) == hipSuccess) held.push_back(sp), used += step - bytes;
                 (void)hipGetLastError();
@@ -1199,14 +1223,14 @@ static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn,
             PIB_CHK(beside(c, needs[i], &t));
             ++tried;
             if (debug) std::fprintf(stderr, "[place] step %d (gap %d): %p for work vector %d: %.3f ms\n", k, gap, (void *)c, needs[i].idx, t);
-            tslow = std::max(tslow, t);
-            if (fast(t)) {
+            needs[i].tslow = std::max(needs[i].tslow, t);
+            if (takes(needs[i], t)) {
                 double *&v = s->work_split[needs[i].idx];
                 for (void *&h : held)
                     if (h == (void *)c) h = (void *)v;  // the vector the solver had goes with the rejected ones
                 v = c;
                 needs[i].t_kept = t;
-                needs[i].met = true;
+                needs[i].met = needs[i].kind == 0 || good_product(t);
                 taken = true;
                 drop_iteration_graph(s);
             }
@@ -1225,9 +1249,13 @@ static int place_update_vector(pib_solver *s, int idx, int zidx, double *x)
     const DeviceCsr &A = s->A;
     if (!s->cfg.place_update_vector || A.n < s->cfg.place_min_rows || A.n != A.n_global || x == nullptr || !aligned16(x)) return 0;
     if (x == s->placed_against || s->placements >= 3 || idx >= pib_solver::MAX_WORK) return 0;
-    PlaceNeed needs[3];
+    PlaceNeed needs[4];
     int nn = 0;
     needs[nn++] = PlaceNeed{idx, {x, nullptr, nullptr}, 1};
+    if (s->cfg.place_product && s->A.val != nullptr && s->A.col != nullptr && !stencil_matmult_ok(s)) {  // (the CSR product, not the stencil twin)
+        needs[nn] = PlaceNeed{3, {nullptr, nullptr, nullptr}, 0};
+        needs[nn++].kind = 1;
+    }
     if (s->cfg.place_residuals && s->cfg.fuse_residual_update && s->cfg.pc == Precond::GMG && !s->levels.empty() && s->levels[0].x != nullptr && s->placements == 0) {
         GridLevel &g = s->levels[0];
         if (aligned16(g.x + g.pad) && aligned16(g.x2 + g.pad) && g.nloc == A.n)
@@ -2729,6 +2757,100 @@ try {
     };
     if (which == 1) {
         PIB_HIP(hipMemsetAsync(s->d_s, 0, sizeof(Scalars), q));
+    }
+    if (which == 100) {
+        // measurement only (tools/spmv_placement_scan.py): the CSR product with its INPUT, then its OUTPUT, on each of 14 fresh
+        // allocations 2 GiB apart -- which vector's placement class sets the product's 2.36 / 2.50 ms modes?  Printed to stderr.
+        const size_t bytes = (size_t)(s->work_stride + 4) * sizeof(double);
+        std::vector<void *> held;
+        std::vector<double *> cand;
+        for (int k = 0; k < 14; ++k) {
+            void *sp = nullptr;
+            double *c = nullptr;
+            if (k && bytes < ((size_t)2 << 30) && hipMalloc(&sp, ((size_t)2 << 30) - bytes) == hipSuccess) held.push_back(sp);
+            if (hipMalloc(&c, bytes) != hipSuccess) break;
+            PIB_HIP(hipMemsetAsync(c, 0, bytes, q));
+            held.push_back(c);
+            cand.push_back(c + s->work_lo);
+        }
+        auto time_pw = [&](double *p, double *w, double *out) -> int {
+            double best = 1e30;
+            for (int r = 0; r < 4; ++r) {
+                PIB_HIP(hipEventRecord(s->ev_a, q));
+                PIB_CHK(spmv_rows(s, p, w, 0, n, nullptr, false, q));
+                PIB_HIP(hipEventRecord(s->ev_b, q));
+                PIB_HIP(hipEventSynchronize(s->ev_b));
+                float ms = 0.f;
+                PIB_HIP(hipEventElapsedTime(&ms, s->ev_a, s->ev_b));
+                if (r) best = std::min(best, (double)ms);
+            }
+            *out = best;
+            return 0;
+        };
+        double t = 0.0;
+        PIB_CHK(time_pw(P, W, &t));
+        std::fprintf(stderr, "[spmv scan] the solver's own p %p, w %p: %.3f ms\n", (void *)P, (void *)W, t);
+        for (size_t k = 0; k < cand.size(); ++k) {
+            double tp = 0.0, tw = 0.0, tb = 0.0;
+            PIB_CHK(time_pw(cand[k], W, &tp));
+            PIB_CHK(time_pw(P, cand[k], &tw));
+            PIB_CHK(time_pw(cand[k], cand[(k + 1) % cand.size()], &tb));
+            std::fprintf(stderr, "[spmv scan] candidate %2zu %p: as the input %.3f ms, as the output %.3f ms, input with the next one as output %.3f ms\n", k,
+                         (void *)cand[k], tp, tw, tb);
+        }
+        // ... then, with the best output found, the column indices and after them the coefficients COPIED to fresh allocations
+        // 4 GiB apart (the arrays themselves stay where they are: the pointers are swapped for the timing only)
+        double *wbest = W;
+        double tbest = t;
+        for (size_t k = 0; k < cand.size(); ++k) {
+            double tw = 0.0;
+            PIB_CHK(time_pw(P, cand[k], &tw));
+            if (tw < tbest) tbest = tw, wbest = cand[k];
+        }
+        std::fprintf(stderr, "[spmv scan] best output %p: %.3f ms\n", (void *)wbest, tbest);
+        DeviceCsr &A = s->A;
+        const size_t cb = sizeof(int32_t) * (size_t)(A.nnz + 4), vb = sizeof(double) * (size_t)(A.nnz + 4);
+        int32_t *const col_own = A.col;
+        double *const val_own = A.val;
+        int32_t *col_best = A.col;
+        double *val_best = A.val;
+        int rc = 0;
+        for (int pass = 0; pass < 2 && rc == 0; ++pass) {
+            for (int k = 0; k < 8 && rc == 0; ++k) {
+                void *sp = nullptr, *c = nullptr;
+                const size_t want = pass == 0 ? cb : vb;
+                if (k && hipMalloc(&sp, (size_t)4 << 30) == hipSuccess) held.push_back(sp);
+                if (hipMalloc(&c, want) != hipSuccess) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                held.push_back(c);
+                if (hipMemcpyAsync(c, pass == 0 ? (void *)col_own : (void *)val_own, want, hipMemcpyDeviceToDevice, q) != hipSuccess) break;
+                A.col = pass == 0 ? (int32_t *)c : col_best;
+                A.val = pass == 0 ? val_own : (double *)c;
+                double t1 = 0.0, t2 = 0.0;
+                rc = time_pw(P, wbest, &t1);
+                if (rc == 0) rc = time_pw(P, W, &t2);
+                std::fprintf(stderr, "[spmv scan] %s copied to %p: %.3f ms with the best output, %.3f ms with the solver's own\n", pass == 0 ? "column indices" : "coefficients", c, t1,
+                             t2);
+                if (rc == 0 && t1 < tbest * 0.97) {
+                    tbest = t1;
+                    if (pass == 0) col_best = (int32_t *)c;
+                    else val_best = (double *)c;
+                }
+            }
+        }
+        A.col = col_own;  // the solver's own arrays again, before the copies go
+        A.val = val_own;
+        PIB_HIP(hipStreamSynchronize(q));
+        std::fprintf(stderr, "[spmv scan] best found %.3f ms (columns %s, coefficients %s)\n", tbest, col_best == col_own ? "own" : "moved", val_best == val_own ? "own" : "moved");
+        if (rc != 0) {
+            for (void *h : held) (void)hipFree(h);
+            return rc;
+        }
+        for (void *h : held) (void)hipFree(h);
+        *ms_avg = t;
+        return 0;
     }
     PIB_CHK(run(2));  // warm-up
     PIB_HIP(hipEventRecord(s->ev_a, q));

@@ -180,8 +180,9 @@ struct Config {
     int64_t side_x_max_rows = (int64_t)1 << 25;
     int place_update_vector = 1;  // CG on one rank, systems of place_min_rows rows and more: the search direction p gets an allocation of its own, CHOSEN by timing the p-update's access pattern against the caller's x while walking through fresh allocations (krylov.hip, place_update_vector).  The flat update reads and writes both vectors, and its rate has two modes (6.3 against 5.6 TB/s at 512^3: 835 against 960 us, 8 % of the solve) set by which physical blocks the two sit in -- a property of the pair, the same for the life of the process, that no address arithmetic inside one allocation moves (profiles/r05_vector_placement_lab.txt)
     int64_t place_min_rows = (int64_t)1 << 24;
-    int place_candidates = 5;  // candidates nobody took before the walk gives up (2, 4, 8, 16, 16 GiB apart: 46 GiB)
-    int place_residuals = 1;   // ... and the two residual buffers of the fused residual update beside the level-0 iterate the V-cycle's first march writes with the new residual (k_presmooth2<0, 1>: 0.86 -> 0.80 ms at 512^3 where the process drew one class)
+    int place_candidates = 6;  // candidates nobody took before the walk gives up (2, 4, 8, 16, 32, 64 GiB apart: classes of 72 GiB have been seen)
+    int place_product = 1;     // ... and w, the CSR product's OUTPUT, by timing the product itself into each candidate: 2.24 against 2.48 ms at 512^3 by whether w shares the class of the matrix arrays (profiles/r05_vector_placement_lab.txt, the spmv scan)
+    int place_residuals = 0;   // (off: the first march gained 0.86 -> 0.80 ms on one box and lost 0.815 -> 0.84 on another -- the pair probe does not predict a kernel with three read and two written streams) ... and the two residual buffers of the fused residual update beside the level-0 iterate the V-cycle's first march writes with the new residual (k_presmooth2<0, 1>: 0.86 -> 0.80 ms at 512^3 where the process drew one class)
     int merge_scalar_kernels = 1;  // ... and the one-workgroup kernels behind them in one launch: the sums' reduction, z[0] and (one rank) the iteration's scalar step (krylov.hip k_dots_tail); the residual sums + norm test likewise (k_finalize_post<8>)
     int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)

@@ -1017,7 +1017,7 @@ def test_search_direction_placed_against_x_is_bit_identical(lin, sr):
     """`pib_place_update_vector` (CG on one rank, 2^24 rows and more; here pushed down to every size): p moves to an allocation of
     its own, chosen by timing the p-update's access pattern against the caller's x while walking through fresh allocations
     (krylov.hip, place_update_vector; profiles/r05_vector_placement_lab.txt).  The probe computes x + (-0.0) * 0: a guess in x
-    comes back bit for bit, and the solve is the one without the search.  One search per x the solver has not seen, three in a
+    comes back bit for bit, and the solve is the one without the search (w is placed in the same walk, by the time of the product into each candidate).  One search per x the solver has not seen, three in a
     solver's life."""
     from petibm_amd import capi
     n = (64, 48, 40)
