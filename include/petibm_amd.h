@@ -420,7 +420,7 @@ int pib_get_staging_ms(pib_solver *s, double *h2d_ms, double *d2h_ms);
 /* Krylov iterations launched as replays of the captured iteration graph since the solver was created (launch-bound systems:
  * pib_use_graph, pib_graph_max_rows; on several ranks with the device-ordered peer transport only). */
 int pib_get_graph_replays(pib_solver *s, int64_t *replays);
-/* The placement of the search direction against the caller's x (pib_place_update_vector: CG on one rank, 2^24 rows and more):
+/* The placement of the search direction against the caller's x (pib_place_update_vector: CG on one rank, 2^25 rows and more):
  * searches run since the solver was created, allocations the last search timed, and the probe's time (ms: the p-update's access
  * pattern over both vectors) with the vector the solver had and with the one it kept.  All zero when no search ran. */
 int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept);

@@ -314,7 +314,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.side_x_update = std::atoi(d.get("default", "pib_side_x_update", "0").c_str());
     c.side_x_max_rows = std::atoll(d.get("default", "pib_side_x_max_rows", "33554432").c_str());
     c.place_update_vector = std::atoi(d.get("default", "pib_place_update_vector", "1").c_str());
-    c.place_min_rows = std::atoll(d.get("default", "pib_place_min_rows", "16777216").c_str());
+    c.place_min_rows = std::atoll(d.get("default", "pib_place_min_rows", "33554432").c_str());
     c.place_candidates = std::atoi(d.get("default", "pib_place_candidates", "6").c_str());
     c.place_residuals = std::atoi(d.get("default", "pib_place_residuals", "0").c_str());
     c.place_product = std::atoi(d.get("default", "pib_place_product", "1").c_str());

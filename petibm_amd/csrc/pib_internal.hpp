@@ -179,7 +179,7 @@ struct Config {
     int side_x_update = 0;  // multigrid-PCG beyond the captured-graph size, at most side_x_max_rows local rows (a slab of a multi-GPU run): x += alpha p as a kernel of its own on a second stream beside the V-cycle's coarse levels instead of riding on the p-update (40 -> 24 B/row on the critical path).  OFF: measured SLOWER on the 512 x 512 x 64 slab (0.99 -> 1.03-1.67 ms per iteration, profiles/r05_slab_side_x_update.md) -- launched chip-wide the update takes the CU slots of the 2 M-cell levels' kernels, on a few workgroups it outlasts the cycle
     int64_t side_x_max_rows = (int64_t)1 << 25;
     int place_update_vector = 1;  // CG on one rank, systems of place_min_rows rows and more: the search direction p gets an allocation of its own, CHOSEN by timing the p-update's access pattern against the caller's x while walking through fresh allocations (krylov.hip, place_update_vector).  The flat update reads and writes both vectors, and its rate has two modes (6.3 against 5.6 TB/s at 512^3: 835 against 960 us, 8 % of the solve) set by which physical blocks the two sit in -- a property of the pair, the same for the life of the process, that no address arithmetic inside one allocation moves (profiles/r05_vector_placement_lab.txt)
-    int64_t place_min_rows = (int64_t)1 << 24;
+    int64_t place_min_rows = (int64_t)1 << 25;  // (measured on slabs of the 512^3 system: 2^24 rows no gain, 2^25 1.5 %, 2^26 2.6 %, 2^27 3 %)
     int place_candidates = 6;  // candidates nobody took before the walk gives up (2, 4, 8, 16, 32, 64 GiB apart: classes of 72 GiB have been seen)
     int place_product = 1;     // ... and w, the CSR product's OUTPUT, by timing the product itself into each candidate: 2.24 against 2.48 ms at 512^3 by whether w shares the class of the matrix arrays (profiles/r05_vector_placement_lab.txt, the spmv scan)
     int place_residuals = 0;   // (off: the first march gained 0.86 -> 0.80 ms on one box and lost 0.815 -> 0.84 on another -- the pair probe does not predict a kernel with three read and two written streams) ... and the two residual buffers of the fused residual update beside the level-0 iterate the V-cycle's first march writes with the new residual (k_presmooth2<0, 1>: 0.86 -> 0.80 ms at 512^3 where the process drew one class)

@@ -1014,7 +1014,7 @@ def test_x_update_on_a_second_stream_is_bit_identical(lin, pinned):
 
 @pytest.mark.parametrize("sr", [0, 1])
 def test_search_direction_placed_against_x_is_bit_identical(lin, sr):
-    """`pib_place_update_vector` (CG on one rank, 2^24 rows and more; here pushed down to every size): p moves to an allocation of
+    """`pib_place_update_vector` (CG on one rank, 2^25 rows and more; here pushed down to every size): p moves to an allocation of
     its own, chosen by timing the p-update's access pattern against the caller's x while walking through fresh allocations
     (krylov.hip, place_update_vector; profiles/r05_vector_placement_lab.txt).  The probe computes x + (-0.0) * 0: a guess in x
     comes back bit for bit, and the solve is the one without the search (w is placed in the same walk, by the time of the product into each candidate).  One search per x the solver has not seen, three in a
