@@ -336,7 +336,8 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str 
     ms_free = s.timeKernel(5, kernel_reps)
     ms_spmv = s.timeKernel(0, max(2, kernel_reps // 4))
     rp_bytes = 8 if s.nnz >= 2 ** 31 - 1 else 4
-    alg_csr = 12.0 * s.nnz + rp_bytes * (UN + 1) + 16.0 * UN
+    idx = s.productIndexBytes()
+    alg_csr = spmv_algorithmic_bytes(s.nnz, UN, idx, rp_bytes)
     alg_free = 16.0 * UN  # x read once, y written once; tables are 1-D (reported apart from the CSR figure)
     # velstencil.hip vel_stencil_apply: components of >= 4 M points with lines of >= 127 take the one-launch marching form
     vel_kernel = ("pib::k_vel_product<0> (LDS-tiled march of the three components + their boundary shells in one launch: the product BiCGStab runs)"
@@ -353,7 +354,7 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str 
                      "achieved": alg_free / ms_free / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_free / ms_free / 1e6 / HBM_PEAK_GBS, "ms_per_launch": ms_free, "algorithmic_bytes": alg_free,
                      "traffic": None},
-        "csr_spmv": {"kernel": f"pib::k_spmv_lds<int{8 * rp_bytes}>", "achieved": alg_csr / ms_spmv / 1e6, "unit": "GB/s",
+        "csr_spmv": {"kernel": f"pib::k_spmv_lds{'_coded' if idx == 1 else ''}<int{8 * rp_bytes}>", "index_bytes_per_entry": idx, "achieved": alg_csr / ms_spmv / 1e6, "unit": "GB/s",
                      "frac": alg_csr / ms_spmv / 1e6 / HBM_PEAK_GBS, "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_csr}}
     s.destroy()
     return out
@@ -392,9 +393,15 @@ def random_rhs_solution(n: int, k0: int, k1: int) -> np.ndarray:
 #   prolongation + both post-smoothing steps (+ the Krylov sums) in one march 24 + 1 on the levels the marching kernels serve
 #   (24 + 1 and 24 as two kernels below them, and everywhere until late in round 3) -- 16 + 17 + 25 = 58 on the finest level
 #   (98), the coarser levels a seventh of that.       Sum: 227 B per row and iteration at 512^3 (272 with both detours through HBM).
+def spmv_algorithmic_bytes(nnz: float, n: float, idx_bytes: int = 4, rp_bytes: float = 4.0) -> float:
+    """compulsory bytes of one CSR product in the format the kernel streams: value + index per entry, row offsets, x once, y,
+    and with one-byte column codes the 16-entry dictionary of every 256-row block (kernels_spmv.hip)"""
+    return (8.0 + idx_bytes) * nnz + rp_bytes * (n + 1) + 16.0 * n + (64.0 * ((n + 255) // 256) if idx_bytes == 1 else 0.0)
+
+
 def solve_bytes_per_row_iter(pre: int, post: int, nnz_per_row: float, fused_residual_restrict: bool = True,
-                             fused_post_pair: bool = True, n_rows: float = 134217728.0) -> float:
-    spmv = 12.0 * nnz_per_row + 4.0 + 16.0
+                             fused_post_pair: bool = True, n_rows: float = 134217728.0, idx_bytes: int = 4) -> float:
+    spmv = (8.0 + idx_bytes) * nnz_per_row + 4.0 + 16.0 + (0.25 if idx_bytes == 1 else 0.0)
     down = (16.0 if pre >= 2 else 8.0 + 8.0) + 24.0 * max(pre - 2, 0) + (17.0 if fused_residual_restrict and pre >= 2 else 24.0 + 9.0)
     up = (25.0 if post >= 1 else 17.0) + 24.0 * max(post - 1, 0)
     # the way up, level by level (cells / 8 each): fused on the levels the marching kernels serve (pib_march_min_cells)
@@ -434,6 +441,7 @@ def poisson_case(n: int, dt: float, cfg_text: str, rhs: str, steps: int, warmup:
     out = {"value": n ** 3 * steps / el, "unit": "DOF/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
            "iters_per_solve": its / steps, "true_rel_residual": rel, "grid": [n, n, n], "dt": dt, "rhs": rhs}
     nnz, nl = s.nnz, s.n_local
+    out["index_bytes_per_entry"] = s.productIndexBytes()
     s.destroy()
     return out, ms_k, nnz, nl
 
@@ -441,8 +449,9 @@ def poisson_case(n: int, dt: float, cfg_text: str, rhs: str, steps: int, warmup:
 def secondary_poisson(n, dt, cfg_text, rhs, which_kernel, args) -> dict:
     out, ms_k, nnz, nl = poisson_case(n, dt, cfg_text, rhs, 2, 1, args.kernel_reps, which_kernel)
     if which_kernel == 0:
-        alg = 12.0 * nnz + 4.0 * (nl + 1) + 16.0 * nl
-        kname = "pib::k_spmv_lds<int32> (CSR SpMV)"
+        idx = out["index_bytes_per_entry"]
+        alg = spmv_algorithmic_bytes(nnz, nl, idx)
+        kname = "pib::k_spmv_lds_coded<int32> (CSR SpMV from one-byte column codes)" if idx == 1 else "pib::k_spmv_lds<int32> (CSR SpMV)"
     else:
         alg = 16.0 * nl + 8.0 * 3 * n  # SURVEY.md 8d B_stencil: x read once, y written once, the 1-D width arrays
         kname = "pib::k_level<0,4> (matrix-free stencil twin, reported apart from the CSR figure)"
@@ -913,7 +922,9 @@ def poisson_bench(args) -> int:
 
     # roofline of the dominant kernel: CSR SpMV, HIP events on the solver's stream
     nnz_l, n_l = s.nnz, s.n_local
-    alg_bytes = 12.0 * nnz_l + 4.0 * (n_l + 1) + 16.0 * n_l  # SURVEY.md 8d B_spmv_csr
+    csr_bytes = 12.0 * nnz_l + 4.0 * (n_l + 1) + 16.0 * n_l  # SURVEY.md 8d B_spmv_csr (fp64 values, int32 columns)
+    idx_bytes = s.productIndexBytes()  # 1: the product streams a one-byte column code per entry (pib_compress_columns), 4: the column
+    alg_bytes = spmv_algorithmic_bytes(nnz_l, n_l, idx_bytes)
     try:
         ms_spmv = s.timeKernel(0, args.kernel_reps)
         counters = s.counters()
@@ -950,10 +961,16 @@ def poisson_bench(args) -> int:
             "cg_iters_per_s": iters / elapsed, "iters_per_solve": iters / args.steps,
             "true_rel_residual": true_rel, "setup_s": t_setup,
             "spmv_gdof_per_s": n_l / (ms_spmv * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "pib::k_spmv_lds<int32> (fp64 CSR SpMV K1, local slab)",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("pib::k_spmv_lds_coded<int32> (fp64 CSR SpMV K1 from one-byte column codes, local slab)" if idx_bytes == 1
+                                    else "pib::k_spmv_lds<int32> (fp64 CSR SpMV K1, local slab)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0], "traffic_source": traffic[1],
-                         "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes},
+                         "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes,
+                         # the bytes of the format the kernel streams ((8 + index_bytes) per entry + 4 per row offset + x once + y
+                         # + 64 B of dictionary per 256 rows); SURVEY 8d's plain-CSR figure beside it, against the same launch time
+                         "index_bytes_per_entry": idx_bytes, "csr_algorithmic_bytes": csr_bytes,
+                         "csr_equivalent_frac": csr_bytes / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "reductions": int(counters[2]),
                          "halo_exchanges": int(counters[3]), "host_polls": int(counters[4]),
                          "comm_ranks": int(counters[5]),  # ncclCommCount of the solver's communicator (1: none)
@@ -969,7 +986,7 @@ def poisson_bench(args) -> int:
             # Several ranks: all rows against the ranks' combined peak (the slabs' redundant ghost planes are not counted).
             bpr = solve_bytes_per_row_iter(args.presweeps, args.postsweeps, nnz_l / n_l,
                                            "pib_fuse_residual_restrict=0" not in args.extra_config,
-                                           "pib_fuse_post_pair=0" not in args.extra_config, float(pN))
+                                           "pib_fuse_post_pair=0" not in args.extra_config, float(pN), idx_bytes)
             per_solve = iters / args.steps + 1.0
             gbs = bpr * pN * per_solve / (elapsed / args.steps) / 1e9
             out["roofline_solve"] = {"bound": "hbm", "bytes_per_row_per_iteration": bpr, "iterations_counted": per_solve,

@@ -424,6 +424,10 @@ int pib_get_graph_replays(pib_solver *s, int64_t *replays);
  * searches run since the solver was created, allocations the last search timed, and the probe's time (ms: the p-update's access
  * pattern over both vectors) with the vector the solver had and with the one it kept.  All zero when no search ran. */
 int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept);
+/* What the CSR product (the MatMult inside KSPSolve / AmgXSolver::solve) streams per matrix entry besides the 8-byte value: 4 (the
+ * int32 column) or 1 (pib_compress_columns: a one-byte code into the dictionary of column offsets of the entry's 256-row block,
+ * built at setMatrix when no block has more than 16 distinct offsets -- every stencil matrix).  Same products, same order. */
+int pib_get_product_format(pib_solver *s, int *index_bytes_per_entry);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,7 @@ _PROTOS = {
     "pib_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pib_get_counters": (C.c_int, [_vp, _vp]),
     "pib_get_staging_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pib_get_product_format": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "pib_get_placement": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)

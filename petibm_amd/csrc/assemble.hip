@@ -27,6 +27,11 @@ void DeviceCsr::release()
     if (col) (void)hipFree(col);
     if (val) (void)hipFree(val);
     if (dinv) (void)hipFree(dinv);
+    if (code) (void)hipFree(code);
+    if (dict) (void)hipFree(dict);
+    code = nullptr;
+    dict = nullptr;
+    coded = false;
     rowptr = nullptr;
     col = nullptr;
     val = nullptr;

@@ -680,6 +680,16 @@ try {
     return pib::fail_exception(__func__);
 }
 
+int pib_get_product_format(pib_solver *s, int *index_bytes_per_entry)
+try {
+    if (s == nullptr || index_bytes_per_entry == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
+    if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_get_product_format: no matrix");
+    *index_bytes_per_entry = s->A.coded ? 1 : 4;
+    return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
+}
+
 int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept)
 try {
     if (s == nullptr || searches == nullptr || candidates == nullptr || ms_had == nullptr || ms_kept == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");

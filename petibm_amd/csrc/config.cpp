@@ -313,6 +313,9 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.merge_scalar_kernels = std::atoi(d.get("default", "pib_merge_scalar_kernels", "1").c_str());
     c.side_x_update = std::atoi(d.get("default", "pib_side_x_update", "0").c_str());
     c.side_x_max_rows = std::atoll(d.get("default", "pib_side_x_max_rows", "33554432").c_str());
+    c.compress_columns = std::atoi(d.get("default", "pib_compress_columns", "1").c_str());
+    c.split_work_rows = std::atoll(d.get("default", "pib_split_work_rows", "33554432").c_str());
+    c.split_work_gap_gib = std::atoi(d.get("default", "pib_split_work_gap_gib", "16").c_str());
     c.place_update_vector = std::atoi(d.get("default", "pib_place_update_vector", "1").c_str());
     c.place_min_rows = std::atoll(d.get("default", "pib_place_min_rows", "33554432").c_str());
     c.place_candidates = std::atoi(d.get("default", "pib_place_candidates", "6").c_str());
@@ -461,6 +464,9 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_merge_scalar_kernels", v)) c.merge_scalar_kernels = std::atoi(v.c_str());
     if (get("pib_side_x_update", v)) c.side_x_update = std::atoi(v.c_str());
     if (get("pib_side_x_max_rows", v)) c.side_x_max_rows = std::atoll(v.c_str());
+    if (get("pib_compress_columns", v)) c.compress_columns = std::atoi(v.c_str());
+    if (get("pib_split_work_rows", v)) c.split_work_rows = std::atoll(v.c_str());
+    if (get("pib_split_work_gap_gib", v)) c.split_work_gap_gib = std::atoi(v.c_str());
     if (get("pib_place_update_vector", v)) c.place_update_vector = std::atoi(v.c_str());
     if (get("pib_place_min_rows", v)) c.place_min_rows = std::atoll(v.c_str());
     if (get("pib_place_candidates", v)) c.place_candidates = std::atoi(v.c_str());

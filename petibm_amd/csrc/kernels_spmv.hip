@@ -28,6 +28,7 @@
 //     products (no FMA contraction: the library is built -ffp-contract=off),
 //     which the oracle reproduces -> bit-exact parity.
 #include <algorithm>
+#include <climits>
 
 #include <cstring>
 
@@ -243,6 +244,157 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S,
     }
 }
 
+// The same product from COLUMN CODES (DeviceCsr::code / dict): phase 1 brings the values and one byte per entry into LDS
+// (16 codes per lane and instruction), phase 2 turns a code into the column -- row + dictionary[block of the row][code] -- and
+// gathers x as above.  9 instead of 12 bytes per entry from HBM (104 -> 83 B per 7-point row); the products, their order
+// and the rounding are those of k_spmv_lds: bit-identical.  The dictionaries belong to the 256-row blocks of the MATRIX; a
+// chunk that does not start on a block (a row range of a split product) reads two of them.
+// CAP: a multiple of 16 (the span starts on a multiple of 16 entries).  1296: 5-point rows, 1808: 7-point rows.
+template <typename RP, bool DOT, int CAP>
+__global__ __launch_bounds__(256) void k_spmv_lds_coded(const Scalars *__restrict__ S, int64_t r_begin, int64_t r_end,
+                                                        const RP *__restrict__ rowptr, const uint8_t *__restrict__ code,
+                                                        const int32_t *__restrict__ dict, const double *__restrict__ val,
+                                                        const double *__restrict__ xg, int64_t ghost_lo, double *__restrict__ y,
+                                                        double *__restrict__ part, ChunkOrder ord)
+{
+    if (S != nullptr && S->done) return;
+    constexpr int ND = DeviceCsr::CODE_DICT;
+    __shared__ __attribute__((aligned(16))) double vals[CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t codes[CAP];
+    __shared__ int32_t dl[2 * ND];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t nchunks = (r_end - r_begin + LDS_ROWS - 1) / LDS_ROWS;
+    const int64_t cpx = (nchunks + 7) >> 3;
+    const int64_t sq = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    double dacc = 0.0;
+    if ((int64_t)(blockIdx.x >> 3) < cpx && sq < nchunks) {
+        const int64_t c = chunk_of(ord, sq);
+        const int64_t r0 = r_begin + c * LDS_ROWS;
+        const int nr = (int)((r_end - r0 < LDS_ROWS) ? (r_end - r0) : LDS_ROWS);
+        const RP p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+        RP rs = 0, re = 0;
+        if (tid < nr) {
+            rs = rowptr[r0 + tid];
+            re = rowptr[r0 + tid + 1];
+        }
+        const int64_t blk0 = r0 >> 8;
+        if (tid < 2 * ND) dl[tid] = dict[blk0 * ND + tid];  // (the array has one block of slack at its end)
+        const int boff = (int)(((r0 + tid) >> 8) - blk0) * ND;
+        double sum = 0.0, xd = 0.0;
+        bool have_diag = false;
+        const int32_t dcol = (int32_t)(ghost_lo + r0 + tid);
+        const RP a0 = p0 & ~(RP)15;
+        for (RP t0 = a0; t0 < p1; t0 += CAP) {
+#pragma unroll
+            for (int u = 0; u < (CAP + 511) / 512; ++u) {
+                const RP q = t0 + 2 * (tid + u * 256);
+                if (q < p1 && q - t0 < CAP)
+                    __builtin_amdgcn_global_load_lds((const void *)(val + q), (__attribute__((address_space(3))) void *)&vals[(int)(q - t0)],
+                                                     16, 0, 0);
+            }
+            {
+                const RP q = t0 + 16 * tid;
+                if (q < p1 && q - t0 < CAP)
+                    __builtin_amdgcn_global_load_lds((const void *)(code + q), (__attribute__((address_space(3))) void *)&codes[(int)(q - t0)],
+                                                     16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const RP lo = (rs > t0) ? rs : t0;
+            const RP hi = (re < t0 + CAP) ? re : (t0 + CAP);
+            for (RP p = lo; p < hi; p += 8) {
+                double vv[8], xx[8];
+                int32_t cc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = p + u < hi;
+                    cc[u] = ok ? dcol + dl[boff + codes[(int)(p - t0) + u]] : 0;
+                    vv[u] = ok ? vals[(int)(p - t0) + u] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xx[u] = (p + u < hi) ? xg[cc[u]] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (p + u < hi) {
+                        sum = sum + vv[u] * xx[u];
+                        if (DOT && cc[u] == dcol) {
+                            xd = xx[u];
+                            have_diag = true;
+                        }
+                    }
+            }
+            if (t0 + CAP < p1) __syncthreads();
+        }
+        if (tid < nr) {
+            y[r0 + tid] = sum;
+            if (DOT) {
+                if (!have_diag) xd = xg[dcol];
+                dacc = xd * sum;
+            }
+        }
+    }
+    if (DOT) {
+        const double s = block_sum_256(dacc, red);
+        if (tid == 0) part[blockIdx.x] = s;
+    }
+}
+
+// Set-up of the codes: one workgroup per 256-row block.  The block's distinct offsets col - row go through a 256-slot hash
+// table in LDS (compare-and-swap insertion), the used slots are numbered in slot order (the dictionary), every entry gets
+// its offset's number.  A block with more than CODE_DICT offsets raises *too_many and the matrix keeps its plain columns.
+template <typename RP>
+__global__ __launch_bounds__(256) void k_build_codes(int64_t n, int64_t ghost_lo, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                     uint8_t *__restrict__ code, int32_t *__restrict__ dict, int *__restrict__ too_many)
+{
+    constexpr int ND = DeviceCsr::CODE_DICT;
+    constexpr int EMPTY = INT_MIN;
+    __shared__ int table[256];
+    __shared__ int number[256];
+    __shared__ int count;
+    const int tid = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+    table[tid] = EMPTY;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    RP rs = 0, re = 0;
+    if (r < n) rs = rowptr[r], re = rowptr[r + 1];
+    const int64_t base = ghost_lo + r;
+    auto slot_of = [&](int d, bool insert) {
+        unsigned h = ((unsigned)d * 2654435761u) >> 24;
+        for (int probe = 0; probe < 256; ++probe, h = (h + 1) & 255u) {
+            if (insert) {
+                const int old = atomicCAS(&table[h], EMPTY, d);
+                if (old == EMPTY || old == d) return (int)h;
+            } else if (table[h] == d)
+                return (int)h;
+        }
+        return -1;
+    };
+    bool lost = false;
+    for (RP p = rs; p < re; ++p) {
+        const int64_t d = (int64_t)col[p] - base;
+        if (d == (int64_t)EMPTY || slot_of((int)d, true) < 0) lost = true;
+    }
+    if (lost) atomicAdd(&count, 1000);
+    __syncthreads();
+    if (tid == 0) {
+        int c = count;
+        for (int k = 0; k < 256; ++k) number[k] = (table[k] != EMPTY) ? c++ : -1;
+        count = c;
+    }
+    __syncthreads();
+    const int nd = count;
+    if (nd > ND) {
+        if (tid == 0) atomicMax(too_many, nd);
+        return;
+    }
+    if (tid < ND) dict[(int64_t)blockIdx.x * ND + tid] = 0;
+    __syncthreads();
+    if (number[tid] >= 0) dict[(int64_t)blockIdx.x * ND + number[tid]] = table[tid];
+    for (RP p = rs; p < re; ++p) code[p] = (uint8_t)number[slot_of((int)((int64_t)col[p] - base), false)];
+}
+
 // largest number of entries in a 256-row chunk (chooses the LDS capacity)
 template <typename RP>
 __global__ void k_max_chunk_nnz(int64_t n, const RP *__restrict__ rowptr, unsigned long long *__restrict__ out)
@@ -357,6 +509,33 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
             hipLaunchKernelGGL((k_spmv_lds<RP, false, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, \
                                r_end, (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord); \
     } while (0)
+#define PIB_LAUNCH_CODED(RP, CAP)                                                                                         \
+    do {                                                                                                                  \
+        if (dot_part)                                                                                                     \
+            hipLaunchKernelGGL((k_spmv_lds_coded<RP, true, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, \
+                               (const RP *)A.rowptr, A.code, A.dict, A.val, xg, A.ghost_lo, y, big, ord);                 \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_spmv_lds_coded<RP, false, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, \
+                               (const RP *)A.rowptr, A.code, A.dict, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);   \
+    } while (0)
+        if (A.coded && variant == 0) {
+            const int64_t need16 = A.max_chunk_nnz + 15;  // the span is widened to a start that is a multiple of 16
+            if (need16 <= 1296) {
+                if (A.rp64) PIB_LAUNCH_CODED(int64_t, 1296); else PIB_LAUNCH_CODED(int32_t, 1296);
+            } else if (need16 <= 1808) {
+                if (A.rp64) PIB_LAUNCH_CODED(int64_t, 1808); else PIB_LAUNCH_CODED(int32_t, 1808);
+            } else {
+                if (A.rp64) PIB_LAUNCH_CODED(int64_t, 2064); else PIB_LAUNCH_CODED(int32_t, 2064);
+            }
+            PIB_HIP(hipGetLastError());
+            if (dot_part) {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
+                PIB_HIP(hipGetLastError());
+            }
+            s->counters[0]++;
+            return 0;
+        }
+#undef PIB_LAUNCH_CODED
         // +3: the span is widened to a start that is a multiple of four
         const int64_t need = A.max_chunk_nnz + 3;
         if (need <= 1284) {
@@ -419,6 +598,46 @@ __global__ void k_extract_dinv(int64_t n, int64_t ghost_lo, const RP *__restrict
     }
 }
 
+// DeviceCsr::code / dict of the matrix just set (cfg.compress_columns); a matrix some block of which has more than
+// CODE_DICT distinct offsets keeps its plain columns.
+static int build_column_codes(pib_solver *s)
+{
+    DeviceCsr &A = s->A;
+    if (A.code) PIB_HIP(hipFree(A.code));
+    if (A.dict) PIB_HIP(hipFree(A.dict));
+    A.code = nullptr;
+    A.dict = nullptr;
+    A.coded = false;
+    if (!s->cfg.compress_columns || A.n <= 0 || A.nnz <= 0 || A.col == nullptr) return 0;
+    const int64_t nblk = (A.n + 255) / 256;
+    PIB_HIP(hipMalloc(&A.code, (size_t)A.nnz + 64));
+    PIB_HIP(hipMalloc(&A.dict, sizeof(int32_t) * (size_t)(nblk + 1) * DeviceCsr::CODE_DICT));
+    PIB_HIP(hipMemsetAsync(A.code + A.nnz, 0, 64, s->stream));
+    PIB_HIP(hipMemsetAsync(A.dict + nblk * DeviceCsr::CODE_DICT, 0, sizeof(int32_t) * DeviceCsr::CODE_DICT, s->stream));
+    int *d_many = nullptr, h_many = 0;
+    PIB_HIP(hipMalloc(&d_many, sizeof(int)));
+    PIB_HIP(hipMemsetAsync(d_many, 0, sizeof(int), s->stream));
+    if (A.rp64)
+        hipLaunchKernelGGL(k_build_codes<int64_t>, dim3((unsigned)nblk), dim3(256), 0, s->stream, A.n, A.ghost_lo, (const int64_t *)A.rowptr, A.col, A.code,
+                           A.dict, d_many);
+    else
+        hipLaunchKernelGGL(k_build_codes<int32_t>, dim3((unsigned)nblk), dim3(256), 0, s->stream, A.n, A.ghost_lo, (const int32_t *)A.rowptr, A.col, A.code,
+                           A.dict, d_many);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipMemcpyAsync(&h_many, d_many, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    PIB_HIP(hipFree(d_many));
+    if (h_many > 0) {
+        PIB_HIP(hipFree(A.code));
+        PIB_HIP(hipFree(A.dict));
+        A.code = nullptr;
+        A.dict = nullptr;
+        return 0;
+    }
+    A.coded = true;
+    return 0;
+}
+
 int extract_dinv(pib_solver *s, int *n_missing)
 {
     DeviceCsr &A = s->A;
@@ -456,6 +675,7 @@ int extract_dinv(pib_solver *s, int *n_missing)
     PIB_HIP(hipFree(d_max));
     A.max_chunk_nnz = (int64_t)h_max;
     *n_missing = h;
+    PIB_CHK(build_column_codes(s));
     return 0;
 }
 

@@ -731,20 +731,36 @@ int ensure_work(pib_solver *s, int nvec)
     lo = (lo + 3) & ~int64_t(3);  // owned part 32-byte aligned
     int64_t stride = lo + A.n + hi + 4;
     stride = (stride + 3) & ~int64_t(3);
-    static const int64_t split_rows = [] {
-        const char *e = std::getenv("PIB_SPLIT_WORK_ROWS");
-        return e ? (int64_t)std::atoll(e) : (int64_t)-1;
-    }();
-    const bool split = split_rows >= 0 && A.n >= split_rows && nvec <= pib_solver::MAX_WORK;
+    // Large systems on one rank: every work vector an allocation of its own, some GiB apart (the gaps are allocated, never
+    // touched and freed again once the vectors stand).  One pool puts all the vectors of a Krylov method into ONE placement
+    // class (krylov.hip, place_work_vectors), where the flat kernels that read and write several of them run slowest.
+    const bool split = s->cfg.split_work_rows >= 0 && A.n >= s->cfg.split_work_rows && A.n == A.n_global && nvec <= pib_solver::MAX_WORK;
     const bool have = split ? s->work_split[0] != nullptr : s->work != nullptr;
     if (have && s->n_work >= nvec && s->work_stride == stride && s->work_lo == lo) return 0;
     drop_iteration_graph(s);  // a captured iteration body holds the old vectors' addresses (and goes BEFORE they do)
     PIB_CHK(free_work(s));
     if (split) {
-        for (int i = 0; i < nvec; ++i) {
-            PIB_HIP(hipMalloc(&s->work_split[i], (size_t)(stride + 4) * sizeof(double)));
-            PIB_HIP(hipMemsetAsync(s->work_split[i], 0, (size_t)(stride + 4) * sizeof(double), s->stream));
+        const size_t bytes = (size_t)(stride + 4) * sizeof(double);
+        size_t gap = (size_t)std::max(0, s->cfg.split_work_gap_gib) << 30;
+        if (gap > 0) {  // (never below a quarter of the device's memory, the vectors counted)
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < tot / 4 + (size_t)nvec * (bytes + gap)) gap = 0;
         }
+        std::vector<void *> spacers;
+        for (int i = 0; i < nvec; ++i) {
+            if (i && gap > bytes) {
+                void *sp = nullptr;
+                if (hipMalloc(&sp, gap - bytes) == hipSuccess) spacers.push_back(sp);
+                (void)hipGetLastError();
+            }
+            const hipError_t e = hipMalloc(&s->work_split[i], bytes);
+            if (e != hipSuccess) {
+                for (void *sp : spacers) (void)hipFree(sp);
+                PIB_HIP(e);
+            }
+            PIB_HIP(hipMemsetAsync(s->work_split[i], 0, bytes, s->stream));
+        }
+        for (void *sp : spacers) (void)hipFree(sp);
     } else {
         PIB_HIP(hipMalloc(&s->work_base, (size_t)(stride * nvec + 4) * sizeof(double)));
         PIB_HIP(hipMemsetAsync(s->work_base, 0, (size_t)(stride * nvec + 4) * sizeof(double), s->stream));

@@ -178,6 +178,9 @@ struct Config {
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int side_x_update = 0;  // multigrid-PCG beyond the captured-graph size, at most side_x_max_rows local rows (a slab of a multi-GPU run): x += alpha p as a kernel of its own on a second stream beside the V-cycle's coarse levels instead of riding on the p-update (40 -> 24 B/row on the critical path).  OFF: measured SLOWER on the 512 x 512 x 64 slab (0.99 -> 1.03-1.67 ms per iteration, profiles/r05_slab_side_x_update.md) -- launched chip-wide the update takes the CU slots of the 2 M-cell levels' kernels, on a few workgroups it outlasts the cycle
     int64_t side_x_max_rows = (int64_t)1 << 25;
+    int64_t split_work_rows = (int64_t)1 << 25;  // one rank, systems of at least that many rows: every work vector of the Krylov methods an allocation of its own, split_work_gap_gib apart, instead of one pool (-1: the pool always) -- BiCGStab on the 400^3 velocity system (192 M rows): 88.2 -> 84.2 ms per solve split, 83.2 with 16 GiB gaps (profiles/r05_vector_placement_lab.txt)
+    int split_work_gap_gib = 16;
+    int compress_columns = 1;  // the CSR product reads a 1-byte dictionary code per entry instead of the int32 column where the matrix allows (DeviceCsr::code): 9 instead of 12 B per entry from HBM; same products in the same order, bit for bit
     int place_update_vector = 1;  // CG on one rank, systems of place_min_rows rows and more: the search direction p gets an allocation of its own, CHOSEN by timing the p-update's access pattern against the caller's x while walking through fresh allocations (krylov.hip, place_update_vector).  The flat update reads and writes both vectors, and its rate has two modes (6.3 against 5.6 TB/s at 512^3: 835 against 960 us, 8 % of the solve) set by which physical blocks the two sit in -- a property of the pair, the same for the life of the process, that no address arithmetic inside one allocation moves (profiles/r05_vector_placement_lab.txt)
     int64_t place_min_rows = (int64_t)1 << 25;  // (measured on slabs of the 512^3 system: 2^24 rows no gain, 2^25 1.5 %, 2^26 2.6 %, 2^27 3 %)
     int place_candidates = 6;  // candidates nobody took before the walk gives up (2, 4, 8, 16, 32, 64 GiB apart: classes of 72 GiB have been seen)
@@ -290,6 +293,13 @@ struct DeviceCsr {
     int32_t *col = nullptr;   // local (ghost-shifted) column index
     double *val = nullptr;
     double *dinv = nullptr;   // 1/diag
+    // Column codes (kernels_spmv.hip, build_column_codes): per entry one byte, the index of (col - row) in the dictionary of the
+    // entry's 256-row block (CODE_DICT entries per block) -- what the CSR product streams instead of the 4-byte column whenever
+    // every block of the matrix has at most CODE_DICT distinct offsets (any stencil matrix); col stays for everybody else.
+    static constexpr int CODE_DICT = 16;
+    uint8_t *code = nullptr;   // [nnz + 64]
+    int32_t *dict = nullptr;   // [(n + 255) / 256 + 1][CODE_DICT]
+    bool coded = false;
     int64_t first_boundary_lo = 0;  // rows [0, n_lo) touch the low halo
     int64_t n_lo = 0, n_hi = 0;     // rows touching the low / high halo (contiguous at both ends)
     int64_t send_prev = 0, send_next = 0;  // entries the neighbours need from this rank

@@ -284,6 +284,12 @@ class LinSolverBase:
         capi.check(capi.load().pib_get_staging_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def productIndexBytes(self) -> int:
+        """bytes per matrix entry the CSR product reads besides the value: 4 (int32 column) or 1 (pib_compress_columns)"""
+        v = C.c_int()
+        capi.check(capi.load().pib_get_product_format(self._h, C.byref(v)))
+        return v.value
+
     def placement(self):
         """(searches, candidates, ms_had, ms_kept) of the search direction's placement against x (pib_get_placement); zeros when none ran"""
         a, b, c, d = C.c_int(), C.c_int(), C.c_double(), C.c_double()

@@ -114,6 +114,52 @@ def test_spmv_bit_exact(lin, case, variant):
         s.destroy()
 
 
+def test_spmv_from_column_codes_is_the_csr_product(lin):
+    """`pib_compress_columns` (default): at setMatrix every 256-row block of the matrix gets the dictionary of its distinct
+    offsets col - row, and the CSR product streams one byte per entry (the offset's number) instead of the int32 column
+    (kernels_spmv.hip k_spmv_lds_coded: 9 instead of 12 B per entry) -- the same products in the same order, bit for bit.
+    A matrix some block of which has more than 16 distinct offsets keeps its plain columns."""
+    rng = np.random.default_rng(23)
+    mats = []
+    for cfg in (STRETCHED_2D, stretched_3d(), omesh.uniform_config((40, 24, 20))):
+        m, DBNG, L = poisson_system(cfg)
+        mats += [(DBNG, 1), (oops.create_velocity_operator(L, 0.01, 0.005), 1)]
+    n = 1500
+    rows, cols, vals = [], [], []
+    for r in range(n):
+        c = np.sort(rng.choice(n, size=int(rng.integers(1, 9)), replace=False))
+        rows += [r] * len(c)
+        cols += list(c)
+        vals += list(rng.uniform(-1, 1, len(c)))
+    mats.append((oops.csr_from_coo(n, n, rows, cols, vals), 4))  # scattered columns: hundreds of offsets per block
+    # 17 offsets in the second block only: one too many
+    n = 600
+    offs = list(range(-8, 9))
+    rows, cols, vals = [], [], []
+    for r in range(n):
+        for o in (offs if r == 300 else offs[6:11]):
+            if 0 <= r + o < n:
+                rows.append(r), cols.append(r + o), vals.append(float(rng.uniform(-1, 1)))
+    mats.append((oops.csr_from_coo(n, n, rows, cols, vals), 4))
+    rows, cols, vals = [], [], []
+    for r in range(n):
+        for o in (offs[:16] if r == 300 else offs[6:11]):  # 16: fits
+            if 0 <= r + o < n:
+                rows.append(r), cols.append(r + o), vals.append(float(rng.uniform(-1, 1)))
+    mats.append((oops.csr_from_coo(n, n, rows, cols, vals), 1))
+    for A, index_bytes in mats:
+        x = rng.uniform(-1, 1, A.n_cols)
+        ref = clib.spmv(A, x)
+        for compress in (1, 0):
+            s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(extra=f"pib_compress_columns={compress}\n"))
+            s.setMatrix(A)
+            assert s.productIndexBytes() == (index_bytes if compress else 4)
+            y = np.empty(A.n_rows)
+            s.matMult(x, y)
+            assert np.array_equal(y, ref)
+            s.destroy()
+
+
 @pytest.mark.parametrize("n", [(64, 32, 6), (32, 64, 5), (128, 16, 3), (16, 16, 16)])
 def test_spmv_tiled_chunk_order_bit_exact(lin, n):
     """With a 3-D grid registered the SpMV walks its 256-row chunks in plane-interleaved tile order;
