@@ -354,7 +354,7 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str 
                      "achieved": alg_free / ms_free / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_free / ms_free / 1e6 / HBM_PEAK_GBS, "ms_per_launch": ms_free, "algorithmic_bytes": alg_free,
                      "traffic": None},
-        "csr_spmv": {"kernel": f"pib::k_spmv_lds{'_coded' if idx == 1 else ''}<int{8 * rp_bytes}>", "index_bytes_per_entry": idx, "achieved": alg_csr / ms_spmv / 1e6, "unit": "GB/s",
+        "csr_spmv": {"kernel": f"pib::k_spmv_lds{'_pattern' if idx == 0 else '_coded' if idx == 1 else ''}<int{8 * rp_bytes}>", "index_bytes_per_entry": idx, "achieved": alg_csr / ms_spmv / 1e6, "unit": "GB/s",
                      "frac": alg_csr / ms_spmv / 1e6 / HBM_PEAK_GBS, "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_csr}}
     s.destroy()
     return out
@@ -396,12 +396,15 @@ def random_rhs_solution(n: int, k0: int, k1: int) -> np.ndarray:
 def spmv_algorithmic_bytes(nnz: float, n: float, idx_bytes: int = 4, rp_bytes: float = 4.0) -> float:
     """compulsory bytes of one CSR product in the format the kernel streams: value + index per entry, row offsets, x once, y,
     and with one-byte column codes the 16-entry dictionary of every 256-row block (kernels_spmv.hip)"""
-    return (8.0 + idx_bytes) * nnz + rp_bytes * (n + 1) + 16.0 * n + (64.0 * ((n + 255) // 256) if idx_bytes == 1 else 0.0)
+    blocks = (n + 255) // 256
+    if idx_bytes == 0:  # row patterns: one byte per row; the table's index and two row offsets per 256-row block (the tables are shared)
+        return 8.0 * nnz + 17.0 * n + (4.0 + 2.0 * rp_bytes) * blocks
+    return (8.0 + idx_bytes) * nnz + rp_bytes * (n + 1) + 16.0 * n + (64.0 * blocks if idx_bytes == 1 else 0.0)
 
 
 def solve_bytes_per_row_iter(pre: int, post: int, nnz_per_row: float, fused_residual_restrict: bool = True,
                              fused_post_pair: bool = True, n_rows: float = 134217728.0, idx_bytes: int = 4) -> float:
-    spmv = (8.0 + idx_bytes) * nnz_per_row + 4.0 + 16.0 + (0.25 if idx_bytes == 1 else 0.0)
+    spmv = (8.0 * nnz_per_row + 17.0 + 12.0 / 256.0) if idx_bytes == 0 else ((8.0 + idx_bytes) * nnz_per_row + 4.0 + 16.0 + (0.25 if idx_bytes == 1 else 0.0))
     down = (16.0 if pre >= 2 else 8.0 + 8.0) + 24.0 * max(pre - 2, 0) + (17.0 if fused_residual_restrict and pre >= 2 else 24.0 + 9.0)
     up = (25.0 if post >= 1 else 17.0) + 24.0 * max(post - 1, 0)
     # the way up, level by level (cells / 8 each): fused on the levels the marching kernels serve (pib_march_min_cells)
@@ -451,7 +454,8 @@ def secondary_poisson(n, dt, cfg_text, rhs, which_kernel, args) -> dict:
     if which_kernel == 0:
         idx = out["index_bytes_per_entry"]
         alg = spmv_algorithmic_bytes(nnz, nl, idx)
-        kname = "pib::k_spmv_lds_coded<int32> (CSR SpMV from one-byte column codes)" if idx == 1 else "pib::k_spmv_lds<int32> (CSR SpMV)"
+        kname = ("pib::k_spmv_lds_pattern<int32> (CSR SpMV from one-byte row patterns)" if idx == 0 else
+                 "pib::k_spmv_lds_coded<int32> (CSR SpMV from one-byte column codes)" if idx == 1 else "pib::k_spmv_lds<int32> (CSR SpMV)")
     else:
         alg = 16.0 * nl + 8.0 * 3 * n  # SURVEY.md 8d B_stencil: x read once, y written once, the 1-D width arrays
         kname = "pib::k_level<0,4> (matrix-free stencil twin, reported apart from the CSR figure)"
@@ -962,7 +966,8 @@ def poisson_bench(args) -> int:
             "true_rel_residual": true_rel, "setup_s": t_setup,
             "spmv_gdof_per_s": n_l / (ms_spmv * 1e-3) / 1e9,
             "roofline": {"bound": "hbm",
-                         "kernel": ("pib::k_spmv_lds_coded<int32> (fp64 CSR SpMV K1 from one-byte column codes, local slab)" if idx_bytes == 1
+                         "kernel": ("pib::k_spmv_lds_pattern<int32> (fp64 CSR SpMV K1 from one-byte row patterns, local slab)" if idx_bytes == 0
+                                    else "pib::k_spmv_lds_coded<int32> (fp64 CSR SpMV K1 from one-byte column codes, local slab)" if idx_bytes == 1
                                     else "pib::k_spmv_lds<int32> (fp64 CSR SpMV K1, local slab)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0], "traffic_source": traffic[1],

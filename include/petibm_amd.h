@@ -425,8 +425,10 @@ int pib_get_graph_replays(pib_solver *s, int64_t *replays);
  * pattern over both vectors) with the vector the solver had and with the one it kept.  All zero when no search ran. */
 int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept);
 /* What the CSR product (the MatMult inside KSPSolve / AmgXSolver::solve) streams per matrix entry besides the 8-byte value: 4 (the
- * int32 column) or 1 (pib_compress_columns: a one-byte code into the dictionary of column offsets of the entry's 256-row block,
- * built at setMatrix when no block has more than 16 distinct offsets -- every stencil matrix).  Same products, same order. */
+ * int32 column), 1 (pib_compress_columns=1: a one-byte code into the dictionary of column offsets of the entry's 256-row block,
+ * built at setMatrix when no block has more than 16 distinct offsets) or 0 (pib_compress_columns=2, the default: one byte per
+ * ROW, the number of the row's list of offsets in the block's table of up to 8 patterns of up to 8 entries -- every 5- / 7-point
+ * stencil matrix).  Same products, same order, same bits. */
 int pib_get_product_format(pib_solver *s, int *index_bytes_per_entry);
 
 #ifdef __cplusplus

@@ -32,6 +32,16 @@ void DeviceCsr::release()
     code = nullptr;
     dict = nullptr;
     coded = false;
+    if (pat_id) (void)hipFree(pat_id);
+    if (pat_tab) (void)hipFree(pat_tab);
+    if (pat_len) (void)hipFree(pat_len);
+    if (pat_blk) (void)hipFree(pat_blk);
+    pat_blk = nullptr;
+    pat_tables = 0;
+    pat_id = nullptr;
+    pat_tab = nullptr;
+    pat_len = nullptr;
+    patterned = false;
     rowptr = nullptr;
     col = nullptr;
     val = nullptr;

@@ -684,7 +684,7 @@ int pib_get_product_format(pib_solver *s, int *index_bytes_per_entry)
 try {
     if (s == nullptr || index_bytes_per_entry == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
     if (!s->has_matrix) return fail(PIB_ERR_ORDER, "pib_get_product_format: no matrix");
-    *index_bytes_per_entry = s->A.coded ? 1 : 4;
+    *index_bytes_per_entry = s->A.patterned ? 0 : (s->A.coded ? 1 : 4);
     return 0;
 } catch (...) {
     return pib::fail_exception(__func__);

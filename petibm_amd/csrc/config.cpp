@@ -313,7 +313,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.merge_scalar_kernels = std::atoi(d.get("default", "pib_merge_scalar_kernels", "1").c_str());
     c.side_x_update = std::atoi(d.get("default", "pib_side_x_update", "0").c_str());
     c.side_x_max_rows = std::atoll(d.get("default", "pib_side_x_max_rows", "33554432").c_str());
-    c.compress_columns = std::atoi(d.get("default", "pib_compress_columns", "1").c_str());
+    c.compress_columns = std::atoi(d.get("default", "pib_compress_columns", "2").c_str());
     c.split_work_rows = std::atoll(d.get("default", "pib_split_work_rows", "33554432").c_str());
     c.split_work_gap_gib = std::atoi(d.get("default", "pib_split_work_gap_gib", "16").c_str());
     c.place_update_vector = std::atoi(d.get("default", "pib_place_update_vector", "1").c_str());

@@ -29,6 +29,8 @@
 //     which the oracle reproduces -> bit-exact parity.
 #include <algorithm>
 #include <climits>
+#include <unordered_map>
+#include <vector>
 
 #include <cstring>
 
@@ -340,6 +342,169 @@ __global__ __launch_bounds__(256) void k_spmv_lds_coded(const Scalars *__restric
     }
 }
 
+// The product from ROW PATTERNS (DeviceCsr::pat_id / pat_tab / pat_len): a workgroup takes one 256-row block of the matrix, brings
+// the block's values into LDS (phase 1 as above), its pattern table (PAT_N lists of up to PAT_LEN offsets col - row) and one
+// byte per row; a row's first entry is the exclusive prefix sum of the pattern lengths over the block's rows (wave scans), its
+// columns are row + offset.  Nothing per entry but the value and nothing per row but one byte come from HBM (blocks with the same
+// table share it: the few distinct tables of a stencil matrix stay in the L2): 8 nnz + 17 n + 12 B per block, 73 B per 7-point
+// row against 104.  Products, order and rounding are those of k_spmv_lds.
+template <typename RP, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_lds_pattern(const Scalars *__restrict__ S, int64_t r_begin, int64_t r_end, const RP *__restrict__ rowptr,
+                                                          const uint8_t *__restrict__ pat_id, const int32_t *__restrict__ pat_blk,
+                                                          const int32_t *__restrict__ pat_tab, const uint8_t *__restrict__ pat_len,
+                                                          const double *__restrict__ val,
+                                                          const double *__restrict__ xg, int64_t ghost_lo, double *__restrict__ y,
+                                                          double *__restrict__ part, ChunkOrder ord)
+{
+    if (S != nullptr && S->done) return;
+    constexpr int PN = DeviceCsr::PAT_N, PL = DeviceCsr::PAT_LEN, CAP = 256 * PL + 16;
+    __shared__ __attribute__((aligned(16))) double vals[CAP];
+    __shared__ __attribute__((aligned(16))) int32_t tab[PN * PL];
+    __shared__ int lens[PN];
+    __shared__ int wsum[4];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t nchunks = (r_end - r_begin + LDS_ROWS - 1) / LDS_ROWS;
+    const int64_t cpx = (nchunks + 7) >> 3;
+    const int64_t sq = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    double dacc = 0.0;
+    if ((int64_t)(blockIdx.x >> 3) < cpx && sq < nchunks) {
+        const int64_t c = chunk_of(ord, sq);
+        const int64_t r0 = r_begin + c * LDS_ROWS;  // a multiple of 256 (the launcher sees to it)
+        const int nr = (int)((r_end - r0 < LDS_ROWS) ? (r_end - r0) : LDS_ROWS);
+        const int64_t blk = r0 >> 8;
+        const RP p0 = rowptr[r0], p1 = rowptr[r0 + nr];
+        const RP a0 = p0 & ~(RP)1;
+#pragma unroll
+        for (int u = 0; u < (CAP + 511) / 512; ++u) {
+            const RP q = a0 + 2 * (tid + u * 256);
+            if (q < p1) __builtin_amdgcn_global_load_lds((const void *)(val + q), (__attribute__((address_space(3))) void *)&vals[(int)(q - a0)], 16, 0, 0);
+        }
+        const int id = (tid < nr) ? (int)pat_id[r0 + tid] : 0;
+        const int64_t tix = pat_blk[blk];
+        if (tid < PN * PL) tab[tid] = pat_tab[tix * (PN * PL) + tid];
+        if (tid < PN) lens[tid] = pat_len[tix * PN + tid];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int len = (tid < nr) ? lens[id] : 0;
+        // exclusive prefix sum of len over the block's rows
+        int incl = len;
+        const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < w) before += wsum[k];
+        const int start = (int)(p0 - a0) + before + incl - len;
+        const int32_t dcol = (int32_t)(ghost_lo + r0 + tid);
+        int32_t dd[PL];
+#pragma unroll
+        for (int u = 0; u < PL; ++u) dd[u] = tab[id * PL + u];
+        double vv[PL], xx[PL];
+#pragma unroll
+        for (int u = 0; u < PL; ++u) vv[u] = (u < len) ? vals[start + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < PL; ++u) xx[u] = (u < len) ? xg[dcol + dd[u]] : 0.0;
+        double sum = 0.0, xd = 0.0;
+        bool have_diag = false;
+#pragma unroll
+        for (int u = 0; u < PL; ++u)
+            if (u < len) {
+                sum = sum + vv[u] * xx[u];
+                if (DOT && dd[u] == 0) {
+                    xd = xx[u];
+                    have_diag = true;
+                }
+            }
+        if (tid < nr) {
+            y[r0 + tid] = sum;
+            if (DOT) {
+                if (!have_diag) xd = xg[dcol];
+                dacc = xd * sum;
+            }
+        }
+    }
+    if (DOT) {
+        const double s = block_sum_256(dacc, red);
+        if (tid == 0) part[blockIdx.x] = s;
+    }
+}
+
+// Set-up of the row patterns: one workgroup per 256-row block.  Round after round the first row without a pattern number
+// publishes its list of offsets, every row with the same list takes the round's number; more than PAT_N rounds, or a row of
+// more than PAT_LEN entries, and the matrix keeps its per-entry form.
+template <typename RP>
+__global__ __launch_bounds__(256) void k_build_patterns(int64_t n, int64_t ghost_lo, const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        uint8_t *__restrict__ pat_id, int32_t *__restrict__ pat_tab, uint8_t *__restrict__ pat_len,
+                                                        int *__restrict__ failed)
+{
+    constexpr int PN = DeviceCsr::PAT_N, PL = DeviceCsr::PAT_LEN;
+    __shared__ int leader;
+    __shared__ int cur[PL + 1];
+    const int tid = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+    int len = 0;
+    int d[PL];
+#pragma unroll
+    for (int u = 0; u < PL; ++u) d[u] = 0;
+    bool bad = false;
+    if (r < n) {
+        const RP rs = rowptr[r], re = rowptr[r + 1];
+        if (re - rs > (RP)PL) bad = true;
+        else {
+            len = (int)(re - rs);
+            for (int u = 0; u < len; ++u) {
+                const int64_t v = (int64_t)col[rs + u] - (ghost_lo + r);
+                if (v < -2147483647LL || v > 2147483647LL) bad = true;
+                d[u] = (int)v;
+            }
+        }
+    }
+    if (tid < PN * PL) pat_tab[(int64_t)blockIdx.x * (PN * PL) + tid] = 0;
+    if (tid < PN) pat_len[(int64_t)blockIdx.x * PN + tid] = 0;
+    bool open = (r < n) && !bad;
+    int id = 0;
+    for (int round = 0; round <= PN; ++round) {
+        if (tid == 0) leader = 1 << 30;
+        __syncthreads();
+        if (open) atomicMin(&leader, tid);
+        __syncthreads();
+        const int L = leader;
+        if (L == (1 << 30)) break;  // every row has its number
+        if (round == PN) {
+            bad = true;
+            break;
+        }
+        if (tid == L) {
+            cur[PL] = len;
+#pragma unroll
+            for (int u = 0; u < PL; ++u) cur[u] = d[u];
+            pat_len[(int64_t)blockIdx.x * PN + round] = (uint8_t)len;
+#pragma unroll
+            for (int u = 0; u < PL; ++u) pat_tab[(int64_t)blockIdx.x * (PN * PL) + round * PL + u] = d[u];
+        }
+        __syncthreads();
+        if (open) {
+            bool same = cur[PL] == len;
+#pragma unroll
+            for (int u = 0; u < PL; ++u) same = same && (u >= len || cur[u] == d[u]);
+            if (same) {
+                id = round;
+                open = false;
+            }
+        }
+        __syncthreads();
+    }
+    if (bad) atomicAdd(failed, 1);
+    pat_id[r] = (uint8_t)id;  // (the array covers whole blocks)
+}
+
 // Set-up of the codes: one workgroup per 256-row block.  The block's distinct offsets col - row go through a 256-slot hash
 // table in LDS (compare-and-swap insertion), the used slots are numbered in slot order (the dictionary), every entry gets
 // its offset's number.  A block with more than CODE_DICT offsets raises *too_many and the matrix keeps its plain columns.
@@ -518,6 +683,30 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
             hipLaunchKernelGGL((k_spmv_lds_coded<RP, false, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, \
                                (const RP *)A.rowptr, A.code, A.dict, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);   \
     } while (0)
+        if (A.patterned && variant == 0 && (r_begin & 255) == 0) {
+            if (dot_part) {
+                if (A.rp64)
+                    hipLaunchKernelGGL((k_spmv_lds_pattern<int64_t, true>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const int64_t *)A.rowptr,
+                                       A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, big, ord);
+                else
+                    hipLaunchKernelGGL((k_spmv_lds_pattern<int32_t, true>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const int32_t *)A.rowptr,
+                                       A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, big, ord);
+            } else {
+                if (A.rp64)
+                    hipLaunchKernelGGL((k_spmv_lds_pattern<int64_t, false>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const int64_t *)A.rowptr,
+                                       A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);
+                else
+                    hipLaunchKernelGGL((k_spmv_lds_pattern<int32_t, false>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const int32_t *)A.rowptr,
+                                       A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);
+            }
+            PIB_HIP(hipGetLastError());
+            if (dot_part) {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
+                PIB_HIP(hipGetLastError());
+            }
+            s->counters[0]++;
+            return 0;
+        }
         if (A.coded && variant == 0) {
             const int64_t need16 = A.max_chunk_nnz + 15;  // the span is widened to a start that is a multiple of 16
             if (need16 <= 1296) {
@@ -598,6 +787,127 @@ __global__ void k_extract_dinv(int64_t n, int64_t ghost_lo, const RP *__restrict
     }
 }
 
+// DeviceCsr::pat_* of the matrix just set (cfg.compress_columns >= 2); a matrix with a row of more than PAT_LEN entries or a
+// block of more than PAT_N distinct rows keeps its per-entry codes.
+// 64-bit FNV-1a over a block's table and lengths
+__global__ __launch_bounds__(256) void k_hash_tables(int64_t nblk, const int32_t *__restrict__ tab, const uint8_t *__restrict__ len, unsigned long long *__restrict__ out)
+{
+    constexpr int PN = DeviceCsr::PAT_N, PL = DeviceCsr::PAT_LEN;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk) return;
+    unsigned long long h = 1469598103934665603ull;
+    for (int k = 0; k < PN * PL; ++k) h = (h ^ (unsigned)tab[b * (PN * PL) + k]) * 1099511628211ull;
+    for (int k = 0; k < PN; ++k) h = (h ^ len[b * PN + k]) * 1099511628211ull;
+    out[b] = h;
+}
+// the distinct tables gathered from their first blocks
+__global__ void k_gather_tables(const int32_t *__restrict__ rep, const int32_t *__restrict__ tab, const uint8_t *__restrict__ len, int32_t *__restrict__ otab,
+                                uint8_t *__restrict__ olen)
+{
+    constexpr int PN = DeviceCsr::PAT_N, PL = DeviceCsr::PAT_LEN;
+    const int64_t b = rep[blockIdx.x];
+    for (int k = threadIdx.x; k < PN * PL; k += blockDim.x) otab[(int64_t)blockIdx.x * (PN * PL) + k] = tab[b * (PN * PL) + k];
+    for (int k = threadIdx.x; k < PN; k += blockDim.x) olen[(int64_t)blockIdx.x * PN + k] = len[b * PN + k];
+}
+// ... and every block's own table compared with the shared one it was given (a hash collision would show here)
+__global__ __launch_bounds__(256) void k_check_tables(int64_t nblk, const int32_t *__restrict__ blk, const int32_t *__restrict__ tab, const uint8_t *__restrict__ len,
+                                                      const int32_t *__restrict__ otab, const uint8_t *__restrict__ olen, int *__restrict__ failed)
+{
+    constexpr int PN = DeviceCsr::PAT_N, PL = DeviceCsr::PAT_LEN;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk) return;
+    const int64_t t = blk[b];
+    bool same = true;
+    for (int k = 0; k < PN * PL; ++k) same = same && tab[b * (PN * PL) + k] == otab[t * (PN * PL) + k];
+    for (int k = 0; k < PN; ++k) same = same && len[b * PN + k] == olen[t * PN + k];
+    if (!same) atomicAdd(failed, 1);
+}
+
+static int build_row_patterns(pib_solver *s)
+{
+    DeviceCsr &A = s->A;
+    const int64_t nblk = (A.n + 255) / 256;
+    constexpr int PN = DeviceCsr::PAT_N, PL = DeviceCsr::PAT_LEN;
+    int32_t *t_tab = nullptr, *d_rep = nullptr;
+    uint8_t *t_len = nullptr;
+    unsigned long long *d_hash = nullptr;
+    int *d_failed = nullptr;
+    struct Tmp {
+        int32_t *&a, *&r;
+        uint8_t *&b;
+        unsigned long long *&c;
+        int *&d;
+        ~Tmp()
+        {
+            if (a) (void)hipFree(a);
+            if (r) (void)hipFree(r);
+            if (b) (void)hipFree(b);
+            if (c) (void)hipFree(c);
+            if (d) (void)hipFree(d);
+        }
+    } tmp{t_tab, d_rep, t_len, d_hash, d_failed};
+    auto drop = [&]() {
+        if (A.pat_id) (void)hipFree(A.pat_id);
+        if (A.pat_blk) (void)hipFree(A.pat_blk);
+        if (A.pat_tab) (void)hipFree(A.pat_tab);
+        if (A.pat_len) (void)hipFree(A.pat_len);
+        A.pat_id = nullptr;
+        A.pat_blk = nullptr;
+        A.pat_tab = nullptr;
+        A.pat_len = nullptr;
+        A.pat_tables = 0;
+        return 0;
+    };
+    PIB_HIP(hipMalloc(&A.pat_id, (size_t)nblk * 256));
+    PIB_HIP(hipMalloc(&t_tab, sizeof(int32_t) * (size_t)nblk * PN * PL));
+    PIB_HIP(hipMalloc(&t_len, (size_t)nblk * PN));
+    PIB_HIP(hipMalloc(&d_hash, sizeof(unsigned long long) * (size_t)nblk));
+    PIB_HIP(hipMalloc(&d_failed, sizeof(int)));
+    PIB_HIP(hipMemsetAsync(d_failed, 0, sizeof(int), s->stream));
+    if (A.rp64)
+        hipLaunchKernelGGL(k_build_patterns<int64_t>, dim3((unsigned)nblk), dim3(256), 0, s->stream, A.n, A.ghost_lo, (const int64_t *)A.rowptr, A.col, A.pat_id,
+                           t_tab, t_len, d_failed);
+    else
+        hipLaunchKernelGGL(k_build_patterns<int32_t>, dim3((unsigned)nblk), dim3(256), 0, s->stream, A.n, A.ghost_lo, (const int32_t *)A.rowptr, A.col, A.pat_id,
+                           t_tab, t_len, d_failed);
+    PIB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_hash_tables, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s->stream, nblk, t_tab, t_len, d_hash);
+    PIB_HIP(hipGetLastError());
+    int h_failed = 0;
+    std::vector<unsigned long long> hh((size_t)nblk);
+    PIB_HIP(hipMemcpyAsync(&h_failed, d_failed, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PIB_HIP(hipMemcpyAsync(hh.data(), d_hash, sizeof(unsigned long long) * (size_t)nblk, hipMemcpyDeviceToHost, s->stream));
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    if (h_failed > 0) return drop();
+    // the distinct tables in the order of their first blocks
+    std::unordered_map<unsigned long long, int32_t> seen;
+    std::vector<int32_t> blk((size_t)nblk), rep;
+    for (int64_t b = 0; b < nblk; ++b) {
+        auto it = seen.find(hh[(size_t)b]);
+        if (it == seen.end()) {
+            it = seen.emplace(hh[(size_t)b], (int32_t)rep.size()).first;
+            rep.push_back((int32_t)b);
+        }
+        blk[(size_t)b] = it->second;
+    }
+    A.pat_tables = (int64_t)rep.size();
+    PIB_HIP(hipMalloc(&A.pat_blk, sizeof(int32_t) * (size_t)nblk));
+    PIB_HIP(hipMalloc(&A.pat_tab, sizeof(int32_t) * rep.size() * PN * PL));
+    PIB_HIP(hipMalloc(&A.pat_len, rep.size() * PN));
+    PIB_HIP(hipMalloc(&d_rep, sizeof(int32_t) * rep.size()));
+    PIB_HIP(hipMemcpyAsync(A.pat_blk, blk.data(), sizeof(int32_t) * (size_t)nblk, hipMemcpyHostToDevice, s->stream));
+    PIB_HIP(hipMemcpyAsync(d_rep, rep.data(), sizeof(int32_t) * rep.size(), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_gather_tables, dim3((unsigned)rep.size()), dim3(64), 0, s->stream, d_rep, t_tab, t_len, A.pat_tab, A.pat_len);
+    PIB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_check_tables, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s->stream, nblk, A.pat_blk, t_tab, t_len, A.pat_tab, A.pat_len, d_failed);
+    PIB_HIP(hipGetLastError());
+    PIB_HIP(hipMemcpyAsync(&h_failed, d_failed, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    PIB_HIP(hipStreamSynchronize(s->stream));  // (blk / rep are read by the copies until here)
+    if (h_failed > 0) return drop();
+    A.patterned = true;
+    return 0;
+}
+
 // DeviceCsr::code / dict of the matrix just set (cfg.compress_columns); a matrix some block of which has more than
 // CODE_DICT distinct offsets keeps its plain columns.
 static int build_column_codes(pib_solver *s)
@@ -605,9 +915,19 @@ static int build_column_codes(pib_solver *s)
     DeviceCsr &A = s->A;
     if (A.code) PIB_HIP(hipFree(A.code));
     if (A.dict) PIB_HIP(hipFree(A.dict));
+    if (A.pat_id) PIB_HIP(hipFree(A.pat_id));
+    if (A.pat_tab) PIB_HIP(hipFree(A.pat_tab));
+    if (A.pat_len) PIB_HIP(hipFree(A.pat_len));
+    if (A.pat_blk) PIB_HIP(hipFree(A.pat_blk));
+    A.pat_blk = nullptr;
+    A.pat_tables = 0;
     A.code = nullptr;
     A.dict = nullptr;
     A.coded = false;
+    A.pat_id = nullptr;
+    A.pat_tab = nullptr;
+    A.pat_len = nullptr;
+    A.patterned = false;
     if (!s->cfg.compress_columns || A.n <= 0 || A.nnz <= 0 || A.col == nullptr) return 0;
     const int64_t nblk = (A.n + 255) / 256;
     PIB_HIP(hipMalloc(&A.code, (size_t)A.nnz + 64));
@@ -635,6 +955,7 @@ static int build_column_codes(pib_solver *s)
         return 0;
     }
     A.coded = true;
+    if (s->cfg.compress_columns >= 2) PIB_CHK(build_row_patterns(s));
     return 0;
 }
 

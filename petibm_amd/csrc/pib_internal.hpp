@@ -180,7 +180,7 @@ struct Config {
     int64_t side_x_max_rows = (int64_t)1 << 25;
     int64_t split_work_rows = (int64_t)1 << 25;  // one rank, systems of at least that many rows: every work vector of the Krylov methods an allocation of its own, split_work_gap_gib apart, instead of one pool (-1: the pool always) -- BiCGStab on the 400^3 velocity system (192 M rows): 88.2 -> 84.2 ms per solve split, 83.2 with 16 GiB gaps (profiles/r05_vector_placement_lab.txt)
     int split_work_gap_gib = 16;
-    int compress_columns = 1;  // the CSR product reads a 1-byte dictionary code per entry instead of the int32 column where the matrix allows (DeviceCsr::code): 9 instead of 12 B per entry from HBM; same products in the same order, bit for bit
+    int compress_columns = 2;  // what the CSR product streams besides the values, where the matrix allows: 2 one byte per ROW (the row's pattern of column offsets, DeviceCsr::pat_id: 73 instead of 104 B per 7-point row), 1 one byte per entry (DeviceCsr::code: 83 B), 0 the int32 columns and row offsets.  The same products in the same order, bit for bit
     int place_update_vector = 1;  // CG on one rank, systems of place_min_rows rows and more: the search direction p gets an allocation of its own, CHOSEN by timing the p-update's access pattern against the caller's x while walking through fresh allocations (krylov.hip, place_update_vector).  The flat update reads and writes both vectors, and its rate has two modes (6.3 against 5.6 TB/s at 512^3: 835 against 960 us, 8 % of the solve) set by which physical blocks the two sit in -- a property of the pair, the same for the life of the process, that no address arithmetic inside one allocation moves (profiles/r05_vector_placement_lab.txt)
     int64_t place_min_rows = (int64_t)1 << 25;  // (measured on slabs of the 512^3 system: 2^24 rows no gain, 2^25 1.5 %, 2^26 2.6 %, 2^27 3 %)
     int place_candidates = 6;  // candidates nobody took before the walk gives up (2, 4, 8, 16, 32, 64 GiB apart: classes of 72 GiB have been seen)
@@ -300,6 +300,17 @@ struct DeviceCsr {
     uint8_t *code = nullptr;   // [nnz + 64]
     int32_t *dict = nullptr;   // [(n + 255) / 256 + 1][CODE_DICT]
     bool coded = false;
+    // Row patterns (build_row_patterns): where every row of a 256-row block has at most PAT_LEN entries and the block at most
+    // PAT_N distinct rows-as-offset-lists, a row is one byte -- the number of its pattern in the block's table -- and the product
+    // streams no per-entry index and no per-row offset at all: 8 B per entry + 1 B per row (+ 4 B per block).
+    // Blocks with the same table share it (pat_blk: the block's table), so that the tables stay in the L2.
+    static constexpr int PAT_N = 16, PAT_LEN = 8;
+    uint8_t *pat_id = nullptr;    // [blocks * 256]
+    int32_t *pat_blk = nullptr;   // [blocks] index of the block's table
+    int32_t *pat_tab = nullptr;   // [tables][PAT_N][PAT_LEN] offsets col - row
+    uint8_t *pat_len = nullptr;   // [tables][PAT_N]
+    int64_t pat_tables = 0;
+    bool patterned = false;
     int64_t first_boundary_lo = 0;  // rows [0, n_lo) touch the low halo
     int64_t n_lo = 0, n_hi = 0;     // rows touching the low / high halo (contiguous at both ends)
     int64_t send_prev = 0, send_next = 0;  // entries the neighbours need from this rank

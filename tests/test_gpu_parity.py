@@ -114,16 +114,38 @@ def test_spmv_bit_exact(lin, case, variant):
         s.destroy()
 
 
-def test_spmv_from_column_codes_is_the_csr_product(lin):
-    """`pib_compress_columns` (default): at setMatrix every 256-row block of the matrix gets the dictionary of its distinct
-    offsets col - row, and the CSR product streams one byte per entry (the offset's number) instead of the int32 column
-    (kernels_spmv.hip k_spmv_lds_coded: 9 instead of 12 B per entry) -- the same products in the same order, bit for bit.
-    A matrix some block of which has more than 16 distinct offsets keeps its plain columns."""
+def expected_product_format(A, compress):
+    """the rules of kernels_spmv.hip restated: 0 (row patterns) when every row has at most 8 entries and every 256-row block at
+    most 16 distinct rows-as-lists-of-offsets; else 1 (column codes) when every block has at most 16 distinct offsets; else 4"""
+    if compress == 0:
+        return 4
+    rp, cl = np.asarray(A.rowptr), np.asarray(A.col)
+    pat_ok, code_ok = True, True
+    for b0 in range(0, A.n_rows, 256):
+        pats, offs = set(), set()
+        for r in range(b0, min(b0 + 256, A.n_rows)):
+            d = tuple(int(c) - r for c in cl[rp[r]:rp[r + 1]])
+            pats.add(d)
+            offs.update(d)
+            pat_ok = pat_ok and len(d) <= 8
+        pat_ok = pat_ok and len(pats) <= 16
+        code_ok = code_ok and len(offs) <= 16
+    if not code_ok:
+        return 4
+    return 0 if (compress == 2 and pat_ok) else 1
+
+
+def test_spmv_from_row_patterns_and_column_codes_is_the_csr_product(lin):
+    """`pib_compress_columns`: at setMatrix every 256-row block of the matrix gets the table of its distinct rows-as-lists-of-
+    offsets col - row (2, the default: up to 16 patterns of up to 8 entries, one byte per ROW in the product's stream, blocks
+    with the same table sharing it -- kernels_spmv.hip k_spmv_lds_pattern) or the dictionary of its distinct offsets (1: up to
+    16, one byte per ENTRY -- k_spmv_lds_coded) in place of the int32 columns and row offsets: the same products in the same
+    order, bit for bit.  A matrix that does not fit the one form falls to the next; `pib_get_product_format` says which."""
     rng = np.random.default_rng(23)
     mats = []
-    for cfg in (STRETCHED_2D, stretched_3d(), omesh.uniform_config((40, 24, 20))):
+    for cfg in (STRETCHED_2D, stretched_3d(), omesh.uniform_config((40, 24, 20)), omesh.uniform_config((256, 6, 5)), omesh.uniform_config((130, 9, 4))):
         m, DBNG, L = poisson_system(cfg)
-        mats += [(DBNG, 1), (oops.create_velocity_operator(L, 0.01, 0.005), 1)]
+        mats += [DBNG, oops.create_velocity_operator(L, 0.01, 0.005)]
     n = 1500
     rows, cols, vals = [], [], []
     for r in range(n):
@@ -131,33 +153,37 @@ def test_spmv_from_column_codes_is_the_csr_product(lin):
         rows += [r] * len(c)
         cols += list(c)
         vals += list(rng.uniform(-1, 1, len(c)))
-    mats.append((oops.csr_from_coo(n, n, rows, cols, vals), 4))  # scattered columns: hundreds of offsets per block
-    # 17 offsets in the second block only: one too many
+    mats.append(oops.csr_from_coo(n, n, rows, cols, vals))  # scattered columns: hundreds of offsets per block
     n = 600
     offs = list(range(-8, 9))
-    rows, cols, vals = [], [], []
-    for r in range(n):
-        for o in (offs if r == 300 else offs[6:11]):
-            if 0 <= r + o < n:
-                rows.append(r), cols.append(r + o), vals.append(float(rng.uniform(-1, 1)))
-    mats.append((oops.csr_from_coo(n, n, rows, cols, vals), 4))
-    rows, cols, vals = [], [], []
-    for r in range(n):
-        for o in (offs[:16] if r == 300 else offs[6:11]):  # 16: fits
-            if 0 <= r + o < n:
-                rows.append(r), cols.append(r + o), vals.append(float(rng.uniform(-1, 1)))
-    mats.append((oops.csr_from_coo(n, n, rows, cols, vals), 1))
-    for A, index_bytes in mats:
+    for wide in (offs, offs[:16]):  # 17 offsets in the second block: one too many for the dictionary; 16 fit it, but no pattern holds a row of 16
+        rows, cols, vals = [], [], []
+        for r in range(n):
+            for o in (wide if r == 300 else offs[6:11]):
+                if 0 <= r + o < n:
+                    rows.append(r), cols.append(r + o), vals.append(float(rng.uniform(-1, 1)))
+        mats.append(oops.csr_from_coo(n, n, rows, cols, vals))
+    for distinct in (16, 17):  # that many distinct rows in the second block: the last pattern / one too many
+        rows, cols, vals = [], [], []
+        for r in range(n):
+            for o in ((-1 - (r % distinct) if r % distinct < 14 else -1, 0, 1 + (r % distinct) // 14 + (r % distinct) % 14 * 0) if 256 <= r < 512 else (-1, 0, 1)):
+                if 0 <= r + o < n:
+                    rows.append(r), cols.append(r + o), vals.append(float(rng.uniform(-1, 1)))
+        mats.append(oops.csr_from_coo(n, n, rows, cols, vals))
+    seen = set()
+    for A in mats:
         x = rng.uniform(-1, 1, A.n_cols)
         ref = clib.spmv(A, x)
-        for compress in (1, 0):
+        for compress in (2, 1, 0):
             s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(extra=f"pib_compress_columns={compress}\n"))
             s.setMatrix(A)
-            assert s.productIndexBytes() == (index_bytes if compress else 4)
+            assert s.productIndexBytes() == expected_product_format(A, compress)
+            seen.add((compress, s.productIndexBytes()))
             y = np.empty(A.n_rows)
             s.matMult(x, y)
             assert np.array_equal(y, ref)
             s.destroy()
+    assert {(2, 0), (2, 1), (2, 4), (1, 1), (1, 4), (0, 4)} <= seen  # every form and every fall was exercised
 
 
 @pytest.mark.parametrize("n", [(64, 32, 6), (32, 64, 5), (128, 16, 3), (16, 16, 16)])
