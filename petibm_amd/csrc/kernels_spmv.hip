@@ -29,6 +29,7 @@
 //     which the oracle reproduces -> bit-exact parity.
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <unordered_map>
 #include <vector>
 
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S,
     // sequence range [x*cpx, (x+1)*cpx) in dispatch order
     const int64_t cpx = (nchunks + 7) >> 3;
     const int64_t sq = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    double dacc = 0.0;
+    double dacc = 0.0, ysum = 0.0;
+    int64_t yrow = -1;
     if ((int64_t)(blockIdx.x >> 3) < cpx && sq < nchunks) {
         const int64_t c = chunk_of(ord, sq);
         const int64_t r0 = r_begin + c * LDS_ROWS;
@@ -232,18 +234,18 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const Scalars *__restrict__ S,
             }
             if (t0 + CAP < p1) __syncthreads();
         }
-        if (tid < nr) {
-            y[r0 + tid] = sum;
-            if (DOT) {
-                if (!have_diag) xd = xg[dcol];
-                dacc = xd * sum;
-            }
+        if (DOT && tid < nr) {
+            if (!have_diag) xd = xg[dcol];
+            dacc = xd * sum;
         }
+        ysum = sum;
+        yrow = (tid < nr) ? r0 + tid : -1;
     }
     if (DOT) {
         const double s = block_sum_256(dacc, red);
         if (tid == 0) part[blockIdx.x] = s;
     }
+    if (yrow >= 0) y[yrow] = ysum;  // (the rows' store last: see k_spmv_lds_pattern)
 }
 
 // The same product from COLUMN CODES (DeviceCsr::code / dict): phase 1 brings the values and one byte per entry into LDS
@@ -269,7 +271,8 @@ __global__ __launch_bounds__(256) void k_spmv_lds_coded(const Scalars *__restric
     const int64_t nchunks = (r_end - r_begin + LDS_ROWS - 1) / LDS_ROWS;
     const int64_t cpx = (nchunks + 7) >> 3;
     const int64_t sq = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    double dacc = 0.0;
+    double dacc = 0.0, ysum = 0.0;
+    int64_t yrow = -1;
     if ((int64_t)(blockIdx.x >> 3) < cpx && sq < nchunks) {
         const int64_t c = chunk_of(ord, sq);
         const int64_t r0 = r_begin + c * LDS_ROWS;
@@ -328,18 +331,18 @@ __global__ __launch_bounds__(256) void k_spmv_lds_coded(const Scalars *__restric
             }
             if (t0 + CAP < p1) __syncthreads();
         }
-        if (tid < nr) {
-            y[r0 + tid] = sum;
-            if (DOT) {
-                if (!have_diag) xd = xg[dcol];
-                dacc = xd * sum;
-            }
+        if (DOT && tid < nr) {
+            if (!have_diag) xd = xg[dcol];
+            dacc = xd * sum;
         }
+        ysum = sum;
+        yrow = (tid < nr) ? r0 + tid : -1;
     }
     if (DOT) {
         const double s = block_sum_256(dacc, red);
         if (tid == 0) part[blockIdx.x] = s;
     }
+    if (yrow >= 0) y[yrow] = ysum;  // (the rows' store last: see k_spmv_lds_pattern)
 }
 
 // The product from ROW PATTERNS (DeviceCsr::pat_id / pat_tab / pat_len): a workgroup takes one 256-row block of the matrix, brings
@@ -362,12 +365,12 @@ __global__ __launch_bounds__(256) void k_spmv_lds_pattern(const Scalars *__restr
     __shared__ __attribute__((aligned(16))) int32_t tab[PN * PL];
     __shared__ int lens[PN];
     __shared__ int wsum[4];
-    __shared__ double red[4];
     const int tid = threadIdx.x;
     const int64_t nchunks = (r_end - r_begin + LDS_ROWS - 1) / LDS_ROWS;
     const int64_t cpx = (nchunks + 7) >> 3;
     const int64_t sq = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    double dacc = 0.0;
+    double dacc = 0.0, ysum = 0.0;
+    int64_t yrow = -1;
     if ((int64_t)(blockIdx.x >> 3) < cpx && sq < nchunks) {
         const int64_t c = chunk_of(ord, sq);
         const int64_t r0 = r_begin + c * LDS_ROWS;  // a multiple of 256 (the launcher sees to it)
@@ -413,27 +416,36 @@ __global__ __launch_bounds__(256) void k_spmv_lds_pattern(const Scalars *__restr
         for (int u = 0; u < PL; ++u) xx[u] = (u < len) ? xg[dcol + dd[u]] : 0.0;
         double sum = 0.0, xd = 0.0;
         bool have_diag = false;
+        // (selects, not branches: written as nested ifs the fused-dot form compiled to eight branches behind the gathers and
+        // ran 1.93 against 1.77 ms)
 #pragma unroll
-        for (int u = 0; u < PL; ++u)
-            if (u < len) {
-                sum = sum + vv[u] * xx[u];
-                if (DOT && dd[u] == 0) {
-                    xd = xx[u];
-                    have_diag = true;
-                }
-            }
-        if (tid < nr) {
-            y[r0 + tid] = sum;
+        for (int u = 0; u < PL; ++u) {
+            const double t = sum + vv[u] * xx[u];
+            sum = (u < len) ? t : sum;
             if (DOT) {
-                if (!have_diag) xd = xg[dcol];
-                dacc = xd * sum;
+                const bool dg = (u < len) && dd[u] == 0;
+                xd = dg ? xx[u] : xd;
+                have_diag = have_diag || dg;
             }
         }
+        if (DOT && tid < nr) {
+            if (!have_diag) xd = xg[dcol];
+            dacc = xd * sum;
+        }
+        ysum = sum;
+        yrow = (tid < nr) ? r0 + tid : -1;
     }
     if (DOT) {
-        const double s = block_sum_256(dacc, red);
-        if (tid == 0) part[blockIdx.x] = s;
+        // one partial per WAVE (no barrier behind the rows' work); k_reduce_partials<4> adds a workgroup's four as block_sum_256
+        // did, (w0 + w1) + (w2 + w3): the same sums.  The partial is stored BEFORE the rows' results: as the wave's last
+        // instruction the one-lane store cost 0.23 ms per 512^3 launch (1.98 against 1.75 ms, tools/_dot_probe.py -- a wave that
+        // ends on a small store holds its slot and the workgroup's LDS for that store's round trip)
+        // ... stored XCD by XCD (workgroup b runs on XCD b % 8: the partials of one XCD's workgroups are neighbours, so that the
+        // 128-byte lines fill up inside ONE L2 instead of being written back in eighths by eight of them)
+        const double s = wave_sum(dacc);
+        if ((tid & 63) == 0) part[4 * ((int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) + (tid >> 6)] = s;
     }
+    if (yrow >= 0) y[yrow] = ysum;  // (the rows' store LAST: the wave's small store of its partial is not the one it ends on)
 }
 
 // Set-up of the row patterns: one workgroup per 256-row block.  Round after round the first row without a pattern number
@@ -575,6 +587,9 @@ __global__ void k_max_chunk_nnz(int64_t n, const RP *__restrict__ rowptr, unsign
 }
 
 // stage 1 of the p.Ap reduction: `nin` per-workgroup partials -> <= 1024 partial sums (fixed order)
+// (QUAD = 4: every input is the four per-wave partials of one workgroup, added as block_sum_256 adds them)
+// (... of workgroup i, which the pattern kernel stores XCD by XCD: at (i % 8) * (nin / 8) + i / 8)
+template <int QUAD = 1>
 __global__ __launch_bounds__(256) void k_reduce_partials(const Scalars *__restrict__ S, const double *__restrict__ in,
                                                          int64_t nin, double *__restrict__ out)
 {
@@ -583,7 +598,14 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const Scalars *__restri
     const int64_t per = (nin + gridDim.x - 1) / gridDim.x;
     const int64_t b = (int64_t)blockIdx.x * per, e = (b + per < nin) ? b + per : nin;
     double v = 0.0;
-    for (int64_t i = b + threadIdx.x; i < e; i += 256) v += in[i];
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+        if (QUAD == 4) {
+            const int64_t at = (i & 7) * (nin >> 3) + (i >> 3);
+            const double2 lo = *reinterpret_cast<const double2 *>(in + 4 * at), hi = *reinterpret_cast<const double2 *>(in + 4 * at + 2);
+            v += (lo.x + lo.y) + (hi.x + hi.y);
+        } else
+            v += in[i];
+    }
     const double s = block_sum_256(v, red);
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
@@ -657,11 +679,11 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
         const ChunkOrder ord = make_order(s, r_begin, r_end);
         double *big = nullptr;
         if (dot_part) {
-            if (s->spmv_part_cap < grid) {
+            if (s->spmv_part_cap < 4 * grid) {  // (four per workgroup for the pattern kernel's per-wave partials)
                 if (s->d_spmv_part) PIB_HIP(hipFree(s->d_spmv_part));
                 s->d_spmv_part = nullptr;
-                PIB_HIP(hipMalloc(&s->d_spmv_part, sizeof(double) * (size_t)grid));
-                s->spmv_part_cap = grid;
+                PIB_HIP(hipMalloc(&s->d_spmv_part, sizeof(double) * (size_t)(4 * grid)));
+                s->spmv_part_cap = 4 * grid;
             }
             big = s->d_spmv_part;
         }
@@ -701,7 +723,7 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
             }
             PIB_HIP(hipGetLastError());
             if (dot_part) {
-                hipLaunchKernelGGL(k_reduce_partials, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
+                hipLaunchKernelGGL(k_reduce_partials<4>, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
                 PIB_HIP(hipGetLastError());
             }
             s->counters[0]++;
@@ -718,7 +740,7 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
             }
             PIB_HIP(hipGetLastError());
             if (dot_part) {
-                hipLaunchKernelGGL(k_reduce_partials, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
+                hipLaunchKernelGGL(k_reduce_partials<1>, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
                 PIB_HIP(hipGetLastError());
             }
             s->counters[0]++;
@@ -738,7 +760,7 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
         PIB_HIP(hipGetLastError());
         if (dot_part) {
             // SPMV_GRID partial sums out, like the persistent kernels
-            hipLaunchKernelGGL(k_reduce_partials, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
+            hipLaunchKernelGGL(k_reduce_partials<1>, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
             PIB_HIP(hipGetLastError());
         }
         s->counters[0]++;

@@ -2762,6 +2762,18 @@ try {
                     PIB_CHK(stencil_matmult(s, P, W, nullptr, false, q));
                     break;
                 case 4: PIB_CHK(gmg_apply(s, R, Z, q)); break;
+                case 6: PIB_CHK(spmv_rows(s, P, W, 0, n, s->d_part, false, q)); break;  // the product with the fused p.w partials, as CG launches it
+                case 7: {  // ... behind the p-update, as in a CG iteration (the pair's time is reported)
+                    OpUpdateP up{Z, P, R, 0, n, 0.0, 0.0, 0.0, 0, 0};
+                    PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
+                    PIB_CHK(spmv_rows(s, P, W, 0, n, s->d_part, false, q));
+                    break;
+                }
+                case 8: {  // the p-update alone
+                    OpUpdateP up{Z, P, R, 0, n, 0.0, 0.0, 0.0, 0, 0};
+                    PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
+                    break;
+                }
                 case 5:  // the matrix-free product of the velocity operator (velstencil.hip, 56 B/row)
                     if (!s->vel.valid) return fail(PIB_ERR_ORDER, "pib_time_kernel: no velocity-operator structure");
                     PIB_CHK(vel_stencil_apply(s, P, W, false, q));
@@ -2771,7 +2783,7 @@ try {
         }
         return 0;
     };
-    if (which == 1) {
+    if (which == 1 || which == 7 || which == 8) {
         PIB_HIP(hipMemsetAsync(s->d_s, 0, sizeof(Scalars), q));
     }
     if (which == 100) {
