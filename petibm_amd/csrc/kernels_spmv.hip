@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k_spmv_lds_coded(const Scalars *__restric
 // columns are row + offset.  Nothing per entry but the value and nothing per row but one byte come from HBM (blocks with the same
 // table share it: the few distinct tables of a stencil matrix stay in the L2): 8 nnz + 17 n + 12 B per block, 73 B per 7-point
 // row against 104.  Products, order and rounding are those of k_spmv_lds.
-template <typename RP, bool DOT>
+template <typename RP, bool DOT, int CAP>
 __global__ __launch_bounds__(256) void k_spmv_lds_pattern(const Scalars *__restrict__ S, int64_t r_begin, int64_t r_end, const RP *__restrict__ rowptr,
                                                           const uint8_t *__restrict__ pat_id, const int32_t *__restrict__ pat_blk,
                                                           const int32_t *__restrict__ pat_tab, const uint8_t *__restrict__ pat_len,
@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256) void k_spmv_lds_pattern(const Scalars *__restr
                                                           double *__restrict__ part, ChunkOrder ord)
 {
     if (S != nullptr && S->done) return;
-    constexpr int PN = DeviceCsr::PAT_N, PL = DeviceCsr::PAT_LEN, CAP = 256 * PL + 16;
+    // CAP: the block's entries + 2 (the span starts on an even entry): 1296 for 5-point rows, 1808 for 7-point rows, 2064 for anything
+    // of up to PAT_LEN entries a row (less LDS: one more workgroup per CU)
+    constexpr int PN = DeviceCsr::PAT_N, PL = DeviceCsr::PAT_LEN;
     __shared__ __attribute__((aligned(16))) double vals[CAP];
     __shared__ __attribute__((aligned(16))) int32_t tab[PN * PL];
     __shared__ int lens[PN];
@@ -706,21 +708,24 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
                                (const RP *)A.rowptr, A.code, A.dict, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);   \
     } while (0)
         if (A.patterned && variant == 0 && (r_begin & 255) == 0) {
-            if (dot_part) {
-                if (A.rp64)
-                    hipLaunchKernelGGL((k_spmv_lds_pattern<int64_t, true>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const int64_t *)A.rowptr,
-                                       A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, big, ord);
-                else
-                    hipLaunchKernelGGL((k_spmv_lds_pattern<int32_t, true>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const int32_t *)A.rowptr,
-                                       A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, big, ord);
+#define PIB_LAUNCH_PATTERN(RP, CAP)                                                                                                                  \
+    do {                                                                                                                                             \
+        if (dot_part)                                                                                                                                \
+            hipLaunchKernelGGL((k_spmv_lds_pattern<RP, true, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const RP *)A.rowptr, \
+                               A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, big, ord);                                     \
+        else                                                                                                                                         \
+            hipLaunchKernelGGL((k_spmv_lds_pattern<RP, false, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const RP *)A.rowptr, \
+                               A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);                       \
+    } while (0)
+            const int64_t need2 = A.max_chunk_nnz + 2;
+            if (need2 <= 1296) {
+                if (A.rp64) PIB_LAUNCH_PATTERN(int64_t, 1296); else PIB_LAUNCH_PATTERN(int32_t, 1296);
+            } else if (need2 <= 1808) {
+                if (A.rp64) PIB_LAUNCH_PATTERN(int64_t, 1808); else PIB_LAUNCH_PATTERN(int32_t, 1808);
             } else {
-                if (A.rp64)
-                    hipLaunchKernelGGL((k_spmv_lds_pattern<int64_t, false>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const int64_t *)A.rowptr,
-                                       A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);
-                else
-                    hipLaunchKernelGGL((k_spmv_lds_pattern<int32_t, false>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, (const int32_t *)A.rowptr,
-                                       A.pat_id, A.pat_blk, A.pat_tab, A.pat_len, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);
+                if (A.rp64) PIB_LAUNCH_PATTERN(int64_t, 2064); else PIB_LAUNCH_PATTERN(int32_t, 2064);
             }
+#undef PIB_LAUNCH_PATTERN
             PIB_HIP(hipGetLastError());
             if (dot_part) {
                 hipLaunchKernelGGL(k_reduce_partials<4>, dim3(SPMV_GRID), dim3(256), 0, st, S, big, grid, dot_part);
