@@ -1201,10 +1201,14 @@ static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn,
     // Pair probe: two modes, 0.87-0.89 against 0.96-1.03 ms at 512^3 -- 0.925 of the slowest time seen separates them whatever
     // the slow sample was.  The product: 2.23-2.26 ms at best, 2.45-2.50 at worst and levels in between (the output's class
     // against the coefficients', the column indices', the input's: tools/spmv_placement_scan.py) -- a candidate is taken when
-    // it is 2 % better than what the solver has, and the search goes on until the product streams 6.15 TB/s of the CSR's
-    // algorithmic bytes (the best level is 6.2 for every matrix far beyond the caches, which is what place_min_rows selects).
-    const double spmv_bytes = (double)A.nnz * 12.0 + (double)A.n * (A.rp64 ? 24.0 : 20.0);
-    auto good_product = [&](double t) { return spmv_bytes / (t * 1e-3) >= 6.15e12; };
+    // it is 2 % better than what the solver has, and the search goes on until the product streams 6.15 TB/s of its algorithmic
+    // bytes (the best level is 6.2 for every matrix far beyond the caches, which is what place_min_rows selects; 5.9 with the
+    // compressed forms).
+    // (the bytes of the form the product streams: kernels_spmv.hip -- row patterns 8 nnz + 17 n, column codes 9 nnz + 20 n)
+    const double spmv_bytes = A.patterned ? (double)A.nnz * 8.0 + (double)A.n * 17.0
+                              : (double)A.nnz * (A.coded ? 9.0 : 12.0) + (double)A.n * (A.rp64 ? 24.0 : 20.0);
+    const double good_rate = (A.patterned || A.coded) ? 5.9e12 : 6.15e12;  // (the compressed forms' best level: 5.9-5.95)
+    auto good_product = [&](double t) { return spmv_bytes / (t * 1e-3) >= good_rate; };
     auto takes = [&](const PlaceNeed &nd, double t) { return nd.kind == 0 ? t <= 0.925 * nd.tslow : t <= 0.98 * nd.t_kept; };
     auto open_needs = [&]() {
         int c = 0;
