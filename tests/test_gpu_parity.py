@@ -1130,6 +1130,34 @@ def test_search_direction_placed_against_x_is_bit_identical(lin, sr):
     assert np.abs(err - err.mean()).max() <= 1e-6 * np.abs(xs).max()  # (up to the constant the guess brought)
 
 
+@pytest.mark.parametrize("solver,pc", [("PCG", "BLOCK_JACOBI"), ("PCG", "AMG"), ("PBICGSTAB", "BLOCK_JACOBI"), ("PBICGSTAB", "NOSOLVER")])
+def test_work_vectors_as_separate_allocations_are_bit_identical(lin, solver, pc):
+    """`pib_split_work_rows` (one rank, 2^25 rows and more; here pushed down to every size): every work vector of the Krylov
+    method is an allocation of its own instead of a slice of one pool -- and, with a gap, some GiB from the next while they are
+    being allocated.  Where a vector lives changes no bit of the solve."""
+    from petibm_amd import capi
+    n = (48, 40, 36)
+    w = [np.full(n[0], 1.0 / n[0]) * (1.0 + 0.25 * np.sin(np.arange(n[0]) / 7.0)), np.full(n[1], 1.0 / n[1]), np.full(n[2], 1.2 / n[2])]
+    dt = 0.01
+    xs = np.random.default_rng(31).uniform(-1, 1, n[0] * n[1] * n[2])
+    xs -= xs.mean()
+    out = []
+    for split, gap in ((-1, 0), (1000, 0), (1000, 1)):
+        extra = f"pib_split_work_rows={split}\npib_split_work_gap_gib={gap}\npib_place_update_vector=0\n"
+        text = gmg_cfg(pre=2, post=2, extra=extra) if pc == "AMG" else amgx_cfg(solver=solver, pc=pc, tol=1e-9, extra=extra)
+        s = lin.LinSolverHIP("poisson", config_text=text)
+        s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_CONSTANT)
+        b = np.empty_like(xs)
+        s.matMult(xs, b)
+        x = np.zeros_like(xs)
+        s.solve(x, b)
+        out.append((x, s.getIters(), np.array(s.getResidualHistory())))
+        s.destroy()
+    for k in (1, 2):
+        assert out[k][1] == out[0][1] and np.array_equal(out[k][2], out[0][2]) and np.array_equal(out[k][0], out[0][0])
+    assert out[0][1] > 3
+
+
 def test_one_sweep_of_the_solver_file_is_a_fused_pair_of_steps(lin):
     """`pib_sweep_pairs` (default 1): the reference's files say presweeps = postsweeps = 1 (AmgX's classical AMG); the
     geometric stand-in reads a sweep as one fused pair of damped-Jacobi steps.  The default with V(1,1) in the file is, bit
