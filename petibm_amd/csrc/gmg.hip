@@ -3528,7 +3528,7 @@ static bool fused_run_ok(const pib_solver *s, const GridLevel &g, int64_t kb, in
 static int march_planes(const GridLevel &g, int64_t kc)
 {
     // (PIB_MARCH_PLANES_SMALL: planes per workgroup on runs below 2^23 cells -- the 2 M-cell levels under a slab, which the marches
-    // only reach when pib_march_min_cells is lowered; an experiment knob, profiles/r05_slab_mid_levels.txt)
+    // only reach when pib_march_min_cells is lowered; an experiment knob, profiles/r05_slab8_iteration_timeline.md)
     static const int small_planes = std::getenv("PIB_MARCH_PLANES_SMALL") ? std::max(2, std::atoi(std::getenv("PIB_MARCH_PLANES_SMALL"))) : 16;
     if (kc * g.plane >= ((int64_t)1 << 26)) return PIB_MARCH_PLANES_BIG;
     return kc * g.plane < ((int64_t)1 << 23) ? small_planes : 16;
