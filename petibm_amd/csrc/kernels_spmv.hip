@@ -956,6 +956,10 @@ static int build_column_codes(pib_solver *s)
     A.pat_len = nullptr;
     A.patterned = false;
     if (!s->cfg.compress_columns || A.n <= 0 || A.nnz <= 0 || A.col == nullptr) return 0;
+    if (s->cfg.compress_columns >= 2) {  // the row patterns first: a matrix that takes them needs no per-entry codes (every
+        PIB_CHK(build_row_patterns(s));  // product here covers the rows from 0, i.e. starts on a block)
+        if (A.patterned) return 0;
+    }
     const int64_t nblk = (A.n + 255) / 256;
     PIB_HIP(hipMalloc(&A.code, (size_t)A.nnz + 64));
     PIB_HIP(hipMalloc(&A.dict, sizeof(int32_t) * (size_t)(nblk + 1) * DeviceCsr::CODE_DICT));
@@ -982,7 +986,6 @@ static int build_column_codes(pib_solver *s)
         return 0;
     }
     A.coded = true;
-    if (s->cfg.compress_columns >= 2) PIB_CHK(build_row_patterns(s));
     return 0;
 }
 

@@ -116,7 +116,7 @@ def test_spmv_bit_exact(lin, case, variant):
 
 def expected_product_format(A, compress):
     """the rules of kernels_spmv.hip restated: 0 (row patterns) when every row has at most 8 entries and every 256-row block at
-    most 16 distinct rows-as-lists-of-offsets; else 1 (column codes) when every block has at most 16 distinct offsets; else 4"""
+    most 16 distinct rows-as-lists-of-offsets (tried first); else 1 (column codes) when every block has at most 16 distinct offsets; else 4"""
     if compress == 0:
         return 4
     rp, cl = np.asarray(A.rowptr), np.asarray(A.col)
@@ -130,9 +130,9 @@ def expected_product_format(A, compress):
             pat_ok = pat_ok and len(d) <= 8
         pat_ok = pat_ok and len(pats) <= 16
         code_ok = code_ok and len(offs) <= 16
-    if not code_ok:
-        return 4
-    return 0 if (compress == 2 and pat_ok) else 1
+    if compress == 2 and pat_ok:
+        return 0
+    return 1 if code_ok else 4
 
 
 def test_spmv_from_row_patterns_and_column_codes_is_the_csr_product(lin):
