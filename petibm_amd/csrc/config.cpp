@@ -295,6 +295,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.fuse_presmooth = std::atoi(d.get("default", "pib_fuse_presmooth", "1").c_str());
     c.march_restrict = std::atoi(d.get("default", "pib_march_restrict", "1").c_str());
     c.fuse_residual_restrict = std::atoi(d.get("default", "pib_fuse_residual_restrict", "1").c_str());
+    c.fuse_down_march = std::atoi(d.get("default", "pib_fuse_down_march", "1").c_str());
     c.fuse_post_pair = std::atoi(d.get("default", "pib_fuse_post_pair", "1").c_str());
     c.fuse_prolong = std::atoi(d.get("default", "pib_fuse_prolong", "1").c_str());
     c.march_levels = std::atoi(d.get("default", "pib_march_levels", "1").c_str());
@@ -446,6 +447,7 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_fuse_presmooth", v)) c.fuse_presmooth = std::atoi(v.c_str());
     if (get("pib_march_restrict", v)) c.march_restrict = std::atoi(v.c_str());
     if (get("pib_fuse_residual_restrict", v)) c.fuse_residual_restrict = std::atoi(v.c_str());
+    if (get("pib_fuse_down_march", v)) c.fuse_down_march = std::atoi(v.c_str());
     if (get("pib_fuse_post_pair", v)) c.fuse_post_pair = std::atoi(v.c_str());
     if (get("pib_fuse_prolong", v)) c.fuse_prolong = std::atoi(v.c_str());
     if (get("pib_march_levels", v)) c.march_levels = std::atoi(v.c_str());

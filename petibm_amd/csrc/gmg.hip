@@ -2104,6 +2104,306 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 }
 
+// ---- the way down of a V(2, .) cycle on a large level in ONE march (end of round 5: docs/design/down_march.md).
+// k_presmooth2 (two Jacobi steps from zero; with UPD the Krylov residual's update on the fly) and k_resid_restrict_march
+// (residual of the smoothed iterate, restricted) as one kernel: x1 = omega D^-1 b is pointwise, x2 needs x1 one cell around,
+// the residual x2 one cell around, the restriction the residual one cell around -- all of it a function of the right-hand
+// side within three cells.  A workgroup walks up through the fine planes of its 128 x TY tile; every one of its active threads
+// owns ONE aligned 4-cell piece of the tile + 4 columns / 3 rows around it (34 x (TY + 6) pieces) and keeps that piece's
+// right-hand side, x1 and x2 on three consecutive planes each in registers (the z neighbours); the x / y neighbours come
+// from LDS rows (x1 on TY + 6 rows, x2 on TY + 4, the residual on TY + 2; two slots each for x1 and x2, so that the plane a
+// stage reads was completed an iteration earlier: two barriers per plane).  The tile's own cells of the chunk's own planes
+// are written (the new residual with UPD, x2), nothing else but the coarse right-hand side: with TY = 8 the right-hand side
+// (and w) is read 1.86 x, 17 B per cell written -- 47 instead of 57 B per cell (TY = 16: 40, but one piece per thread then
+// needs 768 threads and their 168 registers do not hold a piece's thirteen plane values without spilling).  Every value by the expression of the kernel it replaces:
+// the same bits (the Krylov sums of UPD in k_presmooth2's grouping: its 128 x 8 tiles, its FZ planes = this kernel's 2 CZ).
+constexpr int DPR = RSX / 4;   // pieces per row: 34
+constexpr int down_threads(int TY) { return ((DPR * (TY + 6) + 63) / 64) * 64; }  // 768 for 16 rows, 512 for 8
+template <int UPD, int TY>
+__global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
+                                                    const double *__restrict__ b, double *__restrict__ xo, double *__restrict__ bc, int CZ,
+                                                    const double *__restrict__ pin_sum, const double *__restrict__ uw, double *__restrict__ unew,
+                                                    double *__restrict__ upart, int upart_stride)
+{
+    if (S != nullptr && S->done) return;
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    constexpr int DNT = down_threads(TY), DRY = TY + 6, DXY = TY + 4, DSY = TY + 2;  // threads; rows of the right-hand side / x1 (j0 - 3 ..), of x2, of the residual
+    constexpr int NRT = 64 * (TY / 2);                                                 // threads of the restriction: a wave per coarse row
+    __shared__ __attribute__((aligned(32))) double x1s[2][DRY][SWR];
+    __shared__ __attribute__((aligned(32))) double xs[2][DXY][SWR];
+    __shared__ __attribute__((aligned(32))) double rs[DSY][SWR];
+    __shared__ __attribute__((aligned(16))) double tcx[4][SWR];  // cm, cp, w, 1 / w of the tile's columns i0 - 4 .. i0 + 131 (swizzled)
+    __shared__ double tcy[4][DRY];                               // ... and of its rows j0 - 3 .. j0 + 18
+    constexpr int ZT = 80;                                       // >= 2 CZ + 7 planes (CZ <= 32)
+    __shared__ double tz[6][ZT];                                 // w, cm, cp, 1 / w, restriction weight up / down of the planes kfs + e
+    const double ua = UPD ? S->a : 0.0;
+    const int tid = threadIdx.x, lane = tid & 63, tw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Tile3 tb = tile_of_block();
+    const int i0 = tb.x * RX, j0 = tb.y * TY;
+    const int I = tb.x * (RX / 2) + lane, J = tb.y * (TY / 2) + (tw % (TY / 2));  // the coarse cell of a thread of the first eight waves
+    const int KA = C.k0 + tb.z * CZ, KB = min(KA + CZ, C.k0 + C.nk);     // coarse planes [KA, KB): fine planes [2 KA, 2 KB) are this chunk's own
+    const bool rthread = tid < NRT;
+    const double4 rw = F.tx.rw[rthread ? I : 0];
+    double wj[4] = {0.0, 0.0, 0.0, 0.0};
+    if (rthread) {
+        int sj[4];
+        rs1d4(F.t[1], J, F.ny, false, wj, sj);
+    }
+    const int64_t fplane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
+    for (int e = tid; e < RSX; e += DNT) {
+        const int gi = i0 - 4 + e;
+        const bool in = gi >= 0 && gi < F.nx;
+        tcx[0][swz(e)] = in ? F.cmx[gi] : 0.0;
+        tcx[1][swz(e)] = in ? F.cpx[gi] : 0.0;
+        tcx[2][swz(e)] = in ? F.wx[gi] : 0.0;
+        tcx[3][swz(e)] = in ? F.rwx[gi] : 0.0;
+    }
+    if (tid < DRY) {
+        const int gj = j0 - 3 + tid;
+        const bool in = gj >= 0 && gj < F.ny;
+        tcy[0][tid] = in ? F.cmy[gj] : 0.0;
+        tcy[1][tid] = in ? F.cpy[gj] : 0.0;
+        tcy[2][tid] = in ? F.wy[gj] : 0.0;
+        tcy[3][tid] = in ? F.rwy[gj] : 0.0;
+    }
+    const int kf0 = 2 * KA - 1, kf1 = 2 * (KB - 1) + 2;  // fine planes whose residual feeds [KA, KB)
+    const int kfs = kf0 - 2;                              // the march starts two planes earlier: x2 of kf0 - 1 and kf0 first
+    for (int e = tid; e < ZT; e += DNT) {
+        const int kf = kfs + e;
+        const bool in = kf >= 0 && kf < F.nzg && kf <= kf1 + 2;
+        const int Kh = (kf & 1) ? (kf + 1) / 2 : kf / 2;
+        tz[0][e] = in ? F.wz[kf] : 0.0;
+        tz[1][e] = in ? F.cmz[kf] : 0.0;
+        tz[2][e] = in ? F.cpz[kf] : 0.0;
+        tz[3][e] = in ? F.rwz[kf] : 0.0;
+        tz[4][e] = in ? rz_weight(F.t[2], kf, Kh) : 0.0;
+        tz[5][e] = in ? rz_weight(F.t[2], kf, Kh - 1) : 0.0;
+    }
+    // this thread's piece: row R of the 22, columns X .. X + 3 of the 136
+    const int R = tid / DPR, X = 4 * (tid - R * DPR);
+    const int gi = i0 - 4 + X, gj = j0 - 3 + R;
+    const bool mine = tid < DPR * DRY;
+    const bool ok = mine && gi >= 0 && gi < F.nx && gj >= 0 && gj < F.ny;
+    const bool has2 = mine && R >= 1 && R <= DXY, hasr = mine && R >= 2 && R <= DSY + 1;   // carries x2 / the residual
+    const bool own = ok && R >= 3 && R < 3 + TY && X >= 4 && X < 4 + RX;                    // a piece of the tile itself
+    const int64_t goff = (int64_t)(ok ? gj : 0) * F.nx + (ok ? gi : 0);
+    __syncthreads();  // the tables
+    // the piece's in-plane coefficients
+    // (the piece's in-plane coefficients come from the LDS tables where they are used: registers are what this kernel is short of)
+    v4 rxy4 = {0, 0, 0, 0};
+    double cym = 0.0, cyp = 0.0;
+    if (mine) {
+        const v4 rwx4 = swz_get4(tcx[3], X);
+        cym = tcy[0][R];
+        cyp = tcy[1][R];
+        const double rwyj = tcy[3][R];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rxy4[c] = rwx4[c] * rwyj;
+    }
+    const v4 zero = {0, 0, 0, 0};
+    const double omc = 1.0 - omega;
+    double ur0 = 0.0, ur1 = 0.0;
+    auto inz = [&](int kf) { return kf >= 0 && kf < F.nzg; };
+    // the right-hand side of the piece on plane kf: requested ...
+    auto request = [&](int kf, v4 &vb, v4 &vw) {
+        vb = zero;
+        vw = zero;
+        if (ok && inz(kf)) {
+            vb = *reinterpret_cast<const v4 *>(b + (int64_t)(kf - F.k0) * fplane + goff);
+            if (UPD) vw = *reinterpret_cast<const v4 *>(uw + (int64_t)(kf - F.k0) * fplane + goff);
+        }
+    };
+    // ... and taken in: the Krylov update, the tile's share of the new residual and of its sums, the pinned cell
+    auto take = [&](int kf, v4 vb, const v4 &vw) -> v4 {
+        if (!(ok && inz(kf))) return zero;
+        if (UPD) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vb[c] = vb[c] - ua * vw[c];
+            if (own && kf >= 2 * KA && kf < 2 * KB) {
+                *reinterpret_cast<v4 *>(unew + (int64_t)(kf - F.k0) * fplane + goff) = vb;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ur0 += vb[c] * vb[c];
+                    ur1 += vb[c];
+                }
+            }
+        }
+        if (pin_sum != nullptr && kf == 0 && goff == 0) vb[0] = vb[0] - *pin_sum;
+        return vb;
+    };
+    // omega / d of the piece's cells on a plane
+    // (divided again only when a plane's z coefficients differ from the previous plane's: workgroup-uniform)
+    double key_zm = __builtin_nan(""), key_zp = __builtin_nan("");
+    v4 wlast = zero;
+    auto weights = [&](int e) -> v4 {
+        const double czm = tz[1][e], czp = tz[2][e];
+        if (czm != key_zm || czp != key_zp) {
+            key_zm = czm, key_zp = czp;
+            wlast = zero;
+            if (ok) {
+                const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wlast[c] = jweight(omega, -(((((cxm4[c] + cxp4[c]) + cym) + cyp) + czm) + czp));
+            }
+        }
+        return wlast;
+    };
+    auto first_step = [&](const v4 &vb, const v4 &w, int e) -> v4 {
+        v4 o = zero;
+        if (ok) {
+            const double rwz = tz[3][e];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = w[c] * ((vb[c] * rxy4[c]) * rwz);
+        }
+        return o;
+    };
+    // registers: the right-hand side on the planes kf, kf + 1, kf + 2; x1 on kf, kf + 1 (kf + 2 is formed in the iteration);
+    // x2 on kf - 1, kf (kf + 1 is formed in the iteration); omega / d of plane kf + 1
+    v4 r0, r1, r2, x1a, x1b, xm = zero, xc = zero, wb, nb, nw;
+    {
+        v4 tb0, tw0, tb1, tw1, tb2, tw2;
+        request(kfs, tb0, tw0);
+        request(kfs + 1, tb1, tw1);
+        request(kfs + 2, tb2, tw2);
+        r0 = take(kfs, tb0, tw0);
+        r1 = take(kfs + 1, tb1, tw1);
+        r2 = take(kfs + 2, tb2, tw2);
+        const v4 w0 = weights(0);
+        wb = weights(1);
+        x1a = first_step(r0, w0, 0);
+        x1b = first_step(r1, wb, 1);
+        if (mine) swz_put4(x1s[(kfs + 1) & 1][R], X, x1b);
+    }
+    __syncthreads();
+    double lo = 0.0, hi = 0.0;
+    for (int kf = kfs; kf <= kf1; ++kf) {
+        const int e = kf - kfs;
+        if (kf + 3 <= kf1 + 2) request(kf + 3, nb, nw);
+        // ---- x1 of plane kf + 2
+        const v4 wa = weights(e + 2);
+        const v4 x1c = first_step(r2, wa, e + 2);
+        if (mine) swz_put4(x1s[kf & 1][R], X, x1c);  // (slot of plane kf + 2)
+        // ---- x2 of plane kf + 1: the second step, from x1 of the planes kf .. kf + 2 and its own plane's x / y neighbours in LDS
+        v4 xp = zero;
+        if (has2 && ok && inz(kf + 1)) {
+            const double rwz = tz[3][e + 1], czm = tz[1][e + 1], czp = tz[2][e + 1];
+            const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X);
+            const double(*pl)[SWR] = x1s[(kf + 1) & 1];
+            const v4 ylo = swz_get4(pl[R - 1], X), yhi = swz_get4(pl[R + 1], X);
+            const double xleft = X > 0 ? pl[R][swz(X - 1)] : 0.0, xright = X + 4 < RSX ? pl[R][swz(X + 4)] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double xcc = x1b[c];
+                const double left = (c == 0) ? xleft : x1b[c > 0 ? c - 1 : 0], right = (c == 3) ? xright : x1b[c < 3 ? c + 1 : 0];
+                double t = (r1[c] * rxy4[c]) * rwz;
+                t = nacc(t, cxm4[c], left);
+                t = nacc(t, cxp4[c], right);
+                t = nacc(t, cym, ylo[c]);
+                t = nacc(t, cyp, yhi[c]);
+                t = nacc(t, czm, x1a[c]);
+                t = nacc(t, czp, x1c[c]);
+                xp[c] = jrelax(xcc, omc, wb[c], t);
+            }
+            if (own && kf + 1 >= 2 * KA && kf + 1 < 2 * KB) *reinterpret_cast<v4 *>(xo + (int64_t)(kf + 1 - F.k0) * fplane + goff) = xp;
+        }
+        if (has2) swz_put4(xs[(kf + 1) & 1][R - 1], X, xp);
+        // ---- the residual of plane kf (x2 of the planes kf - 1, kf, kf + 1; plane kf's x / y neighbours in LDS)
+        if (kf >= kf0 && hasr) {
+            v4 out = zero;
+            if (ok && inz(kf)) {
+                const double wzk = tz[0][e], czm = tz[1][e], czp = tz[2][e];
+                const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X), wx4 = swz_get4(tcx[2], X);
+                const double wyj = tcy[2][R];
+                const double(*pl)[SWR] = xs[kf & 1];
+                const int Q = R - 1;  // the piece's row among x2's
+                const v4 ylo = swz_get4(pl[Q - 1], X), yhi = swz_get4(pl[Q + 1], X);
+                const double xleft = X > 0 ? pl[Q][swz(X - 1)] : 0.0, xright = X + 4 < RSX ? pl[Q][swz(X + 4)] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double xcc = xc[c];
+                    const double left = (c == 0) ? xleft : xc[c > 0 ? c - 1 : 0], right = (c == 3) ? xright : xc[c < 3 ? c + 1 : 0];
+                    double sum = 0.0;
+                    sum = facc(sum, cxm4[c], left, xcc);
+                    sum = facc(sum, cxp4[c], right, xcc);
+                    sum = facc(sum, cym, ylo[c], xcc);
+                    sum = facc(sum, cyp, yhi[c], xcc);
+                    sum = facc(sum, czm, xm[c], xcc);
+                    sum = facc(sum, czp, xp[c], xcc);
+                    out[c] = resid(r0[c], sum * (wx4[c] * wyj), wzk);
+                }
+            }
+            swz_put4(rs[R - 2], X, out);
+        }
+        __syncthreads();
+        // ---- the restriction's share of plane kf
+        const bool odd = kf & 1;
+        const int Khi = odd ? (kf + 1) / 2 : kf / 2, Klo = Khi - 1;
+        if (kf >= kf0 && rthread && inz(kf)) {
+            const bool dohi = Khi >= KA && Khi < KB, dolo = Klo >= KA && Klo < KB;
+            const double wkhi = dohi ? tz[4][e] : 0.0, wklo = dolo ? tz[5][e] : 0.0;
+            const int qc = swz(2 * lane + 4), ql = swz(2 * lane + 3), qr = swz(2 * lane + 6);
+            double t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double *rowp = rs[2 * (tw % (TY / 2)) + r];
+                const double2 cc = *reinterpret_cast<const double2 *>(rowp + qc);
+                t[r] = rsum_x(rw, rowp[ql], cc.x, cc.y, rowp[qr]);
+            }
+            double u = 0.0;
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) u = tacc(u, wj[b2], t[b2]);
+            if (dolo) lo = tacc(lo, wklo, u);
+            if (dohi) hi = tacc(hi, wkhi, u);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the plane requested at the top (placed here: see k_resid_restrict_march)
+        const v4 r3 = (kf + 3 <= kf1 + 2) ? take(kf + 3, nb, nw) : zero;
+        if (kf >= kf0 && !odd) {
+            if (rthread && Klo >= KA && Klo < KB) bc[(int64_t)(Klo - C.k0) * cplane + (int64_t)J * C.nx + I] = lo;
+            lo = hi;
+            hi = 0.0;
+        }
+        __syncthreads();
+        r0 = r1;
+        r1 = r2;
+        r2 = r3;
+        x1a = x1b;
+        x1b = x1c;
+        xm = xc;
+        xc = xp;
+        wb = wa;
+    }
+    if (UPD) {
+        // the sums in k_presmooth2's grouping: its workgroup (x tile, 8-row half of this tile, this z chunk) summed thread (ty, tx) by
+        // thread over the lanes of its four waves, then (w0 + w1) + (w2 + w3)
+        double(*ush)[TY][RX / 4] = reinterpret_cast<double(*)[TY][RX / 4]>(&x1s[0][0][0]);  // (the planes are done with)
+        __shared__ double uw4[2][2][4];
+        if (R >= 3 && R < 3 + TY && X >= 4 && X < 4 + RX && mine) {
+            ush[0][R - 3][(X - 4) / 4] = ur0;
+            ush[1][R - 3][(X - 4) / 4] = ur1;
+        }
+        __syncthreads();
+        if (tid < 32 * TY) {
+            const int half = tid >> 8, t = tid & 255, ty = t >> 5, tx = t & 31;
+            double v0 = ush[0][8 * half + ty][tx], v1 = ush[1][8 * half + ty][tx];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                v0 += __shfl_down(v0, o, 64);
+                v1 += __shfl_down(v1, o, 64);
+            }
+            if ((t & 63) == 0) {
+                uw4[half][0][t >> 6] = v0;
+                uw4[half][1][t >> 6] = v1;
+            }
+        }
+        __syncthreads();
+        if (tid < TY / 4) {
+            const int half = tid >> 1, k2 = tid & 1;
+            const int64_t blk = ((int64_t)tb.z * ((TY / 8) * gridDim.y) + (TY / 8) * tb.y + half) * gridDim.x + tb.x;
+            upart[(int64_t)k2 * upart_stride + blk] = (uw4[half][k2][0] + uw4[half][k2][1]) + (uw4[half][k2][2] + uw4[half][k2][3]);
+        }
+    }
+}
+
 // coarsest level in ONE workgroup: `sweeps` damped-Jacobi sweeps from zero,
 // ping-pong between xa / xb (global, L2-resident), block barrier between sweeps.
 __global__ __launch_bounds__(256) void k_coarsest(const Scalars *__restrict__ S, LevelDev L, double omega, int sweeps,
@@ -4216,6 +4516,47 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         } else {
             // the pre-smoothed iterate is kept as deep as the way up wants it (the corrected iterate starts from it)
             const int want_x = I.dist ? std::max(2, post + final_depth(l)) : 0;
+            // the two steps, the residual and the restriction in ONE march (k_down_march) where both marches below would run on a
+            // level that is whole on this one rank and not periodic
+            {
+                const GridLevel &c1 = s->levels[(size_t)l + 1];
+                const int64_t nkc = c1.k1 - c1.k0;
+                const int FZ = march_planes(g, I.nk);
+                const bool upd = l == 0 && s->gmg_upd.w != nullptr;
+                auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
+                const bool fits = s->cfg.fuse_down_march && pre == 2 && !cheb && s->cfg.fuse_presmooth && s->cfg.fuse_residual_restrict &&
+                                  s->cfg.march_restrict && !I.dist && !li[(size_t)l + 1].dist && s->comm.nranks == 1 && g.k0 == 0 && g.k1 == g.n[2] &&
+                                  c1.k0 == 0 && c1.k1 == c1.n[2] && !g.zring && g.per == 0 && g.tper == 0 && g.plain_pair && !halo_pending &&
+                                  fused_run_ok(s, g, 0, I.nk) && g.n[0] % RX == 0 && g.n[1] % 8 == 0 && (g.n[2] & 1) == 0 && 2 * nkc == g.n[2] && nkc >= 4 &&
+                                  nkc * c1.plane * 8 >= (int64_t)s->cfg.march_min_cells && (FZ & 1) == 0 && FZ / 2 <= 32 && al32(b) && al32(c) &&
+                                  (!upd || (al32(s->gmg_upd.w) && al32(s->gmg_upd.r_old)));
+                if (fits) {
+                    const int CZ = FZ / 2;
+                    // (128 x 8 tiles, 512 threads, 214 registers and no spill: 1.19 ms per 512^3 launch against 0.84 + 0.51; the 128 x 16
+                    // tile -- 40 instead of 47 B per cell -- needs 768 threads, i.e. 168 registers, and spilled 65: 3.4 ms)
+                    constexpr int TY = 8;
+                    const dim3 grid((unsigned)(g.n[0] / RX), (unsigned)(g.n[1] / TY), (unsigned)((nkc + CZ - 1) / CZ));
+                    if (upd) {
+                        const int nblk = (int)((TY / 8) * grid.x * grid.y * grid.z);  // (k_presmooth2's workgroups: one per 8 rows of a tile)
+                        if (nblk > PIB_MAXPART) return fail(PIB_ERR_LIB, "fused residual update: too many workgroups for the partial sums");
+                        hipLaunchKernelGGL((k_down_march<1, TY>), grid, dim3(down_threads(TY)), 0, q, S, dev_of(g), dev_of(c1), omega, s->gmg_upd.r_old, c,
+                                           c1.b + c1.pad, CZ, pin_l, s->gmg_upd.w, const_cast<double *>(b), s->d_part + 4 * (int64_t)PIB_MAXPART, (int)PIB_MAXPART);
+                        PIB_HIP(hipGetLastError());
+                        s->gmg_upd.used = true;
+                        PIB_CHK(s->gmg_upd.after(s, nblk, q));
+                    } else {
+                        hipLaunchKernelGGL((k_down_march<0, TY>), grid, dim3(down_threads(TY)), 0, q, S, dev_of(g), dev_of(c1), omega, b, c, c1.b + c1.pad, CZ, pin_l,
+                                           (const double *)nullptr, (double *)nullptr, (double *)nullptr, 0);
+                        PIB_HIP(hipGetLastError());
+                    }
+                    set_valid(c, 0);
+                    std::swap(a, c);
+                    set_valid(c1.b + c1.pad, 0);
+                    cur[(size_t)l] = a;
+                    s->gmg_spare[(size_t)l] = c;
+                    continue;
+                }
+            }
             PIB_CHK(smooth_seq(l, b, pin_l, a, c, pre, true, want_x));
             // residual and restriction in one march where the marching restriction would run (k_resid_restrict_march): the
             // residual never goes to HBM

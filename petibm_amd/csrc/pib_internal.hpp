@@ -173,6 +173,7 @@ struct Config {
     int fuse_prolong = 1;  // multigrid: prolongation + first post-smoothing step of a fully paired large level in one kernel (gmg.hip k_prolong_smooth)
     int march_restrict = 1;  // multigrid: restriction of a fully paired 3-D level by the z-marching LDS kernel (gmg.hip k_restrict_march)
     int fuse_post_pair = 1;  // multigrid: prolongation + both post-smoothing steps of V(., 2) in ONE march (gmg.hip k_prolong_smooth2)
+    int fuse_down_march = 1;  // multigrid V(2, .), a level whole on one rank and not periodic: the two pre-smoothing steps (with PCG's residual update), the residual and the restriction in ONE march (gmg.hip k_down_march: 40 instead of 57 B per cell); 0: k_presmooth2 + k_resid_restrict_march
     int fuse_residual_restrict = 1;  // multigrid: residual + restriction of such a level in ONE march (gmg.hip k_resid_restrict_march)
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass

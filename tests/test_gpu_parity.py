@@ -936,7 +936,7 @@ def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
     assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
+@pytest.mark.parametrize("key,sweeps", [("pib_fuse_down_march", 2), ("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
 @pytest.mark.parametrize("n,pinned", [((128, 32, 24), False), ((256, 16, 40), True), ((128, 16, 34), False)])
 def test_marching_transfers_are_bit_identical(lin, n, pinned, key, sweeps):
     """gmg.hip k_restrict_march (fully paired 3-D levels with nx % 128 == 0, ny % 16 == 0: a fine plane goes through LDS
@@ -1016,6 +1016,33 @@ def test_residual_update_inside_the_vcycle_is_bit_identical(lin, flavour, sweeps
     assert out[0][3] <= 2e-10
     # the fallback (a refusing launch site no longer fails the solve: the update runs as its own pass, into the other buffer)
     assert out[2][2] == out[1][2] and np.array_equal(out[2][0], out[1][0]) and np.array_equal(out[2][1], out[1][1])
+
+
+def test_way_down_in_one_march_with_the_residual_update_is_bit_identical(lin):
+    """gmg.hip k_down_march<1>: the two pre-smoothing steps with PCG's residual update, the residual and the restriction of
+    level 0 in ONE march against k_presmooth2<0, 1> + k_resid_restrict_march -- the same expressions cell by cell and the Krylov
+    sums in the same grouping: iterates, solution AND the residual history bit for bit."""
+    from petibm_amd import capi
+    n = (256, 128, 136)
+    w = [np.full(n[0], 1.0 / n[0]) * (1.0 + 0.3 * np.sin(np.arange(n[0]) / 17.0)),
+         np.full(n[1], 1.0 / n[1]), np.full(n[2], 1.5 / n[2]) * (1.0 + 0.2 * np.cos(np.arange(n[2]) / 11.0))]
+    dt = 0.01
+    xs = np.random.default_rng(7).uniform(-1, 1, n[0] * n[1] * n[2])
+    out = []
+    for pinned in (False, True):
+        xp = xs - (xs[0] if pinned else xs.mean())
+        for down in (1, 0):
+            s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_fuse_down_march={down}\npib_march_min_cells=0\n"))
+            s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
+            b = np.empty_like(xp)
+            s.matMult(xp, b)
+            x = np.zeros_like(xp)
+            s.solve(x, b)
+            out.append((x, np.array(s.getResidualHistory()), s.getIters(), int(s.counters()[6])))
+            s.destroy()
+        a, c = out[-2], out[-1]
+        assert a[3] >= a[2] > 4 and c[3] >= c[2]  # the residual update ran inside the cycle either way
+        assert a[2] == c[2] and np.array_equal(a[1], c[1]) and np.array_equal(a[0], c[0])
 
 
 @pytest.mark.parametrize("sweeps", [2, 1])
