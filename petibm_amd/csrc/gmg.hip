@@ -2117,18 +2117,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 // (and w) is read 1.86 x, 17 B per cell written -- 47 instead of 57 B per cell (TY = 16: 40, but one piece per thread then
 // needs 768 threads and their 168 registers do not hold a piece's thirteen plane values without spilling).  Every value by the expression of the kernel it replaces:
 // the same bits (the Krylov sums of UPD in k_presmooth2's grouping: its 128 x 8 tiles, its FZ planes = this kernel's 2 CZ).
-constexpr int DPR = RSX / 4;   // pieces per row: 34
-constexpr int down_threads(int TY) { return ((DPR * (TY + 6) + 63) / 64) * 64; }  // 768 for 16 rows, 512 for 8
-template <int UPD, int TY>
-__global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
+constexpr int down_threads(int TX, int TY) { return ((((TX + 8) / 4) * (TY + 6) + 63) / 64) * 64; }  // 128 x 8: 512, 64 x 16: 448
+template <int UPD, int TX, int TY>
+__global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scalars *__restrict__ S, LevelDev F, LevelDev C, double omega,
                                                     const double *__restrict__ b, double *__restrict__ xo, double *__restrict__ bc, int CZ,
                                                     const double *__restrict__ pin_sum, const double *__restrict__ uw, double *__restrict__ unew,
                                                     double *__restrict__ upart, int upart_stride)
 {
     if (S != nullptr && S->done) return;
     typedef double v4 __attribute__((ext_vector_type(4)));
-    constexpr int DNT = down_threads(TY), DRY = TY + 6, DXY = TY + 4, DSY = TY + 2;  // threads; rows of the right-hand side / x1 (j0 - 3 ..), of x2, of the residual
-    constexpr int NRT = 64 * (TY / 2);                                                 // threads of the restriction: a wave per coarse row
+    constexpr int DSX = TX + 8, DPR = DSX / 4;                                          // columns i0 - 4 .. i0 + TX + 3 in 4-cell pieces
+    constexpr int DNT = down_threads(TX, TY), DRY = TY + 6, DXY = TY + 4, DSY = TY + 2;  // threads; rows of the right-hand side / x1 (j0 - 3 ..), of x2, of the residual
+    constexpr int NRT = (TX / 2) * (TY / 2), CL = TX / 2;                                // threads of the restriction: one per coarse cell of the tile, CL a row
     __shared__ __attribute__((aligned(32))) double x1s[2][DRY][SWR];
     __shared__ __attribute__((aligned(32))) double xs[2][DXY][SWR];
     __shared__ __attribute__((aligned(32))) double rs[DSY][SWR];
@@ -2139,8 +2139,9 @@ __global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *
     const double ua = UPD ? S->a : 0.0;
     const int tid = threadIdx.x, lane = tid & 63, tw = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Tile3 tb = tile_of_block();
-    const int i0 = tb.x * RX, j0 = tb.y * TY;
-    const int I = tb.x * (RX / 2) + lane, J = tb.y * (TY / 2) + (tw % (TY / 2));  // the coarse cell of a thread of the first eight waves
+    const int i0 = tb.x * TX, j0 = tb.y * TY;
+    const int ci = tid % CL, cj = (tid / CL) % (TY / 2);               // the coarse cell of a thread of the restriction, within the tile
+    const int I = tb.x * CL + ci, J = tb.y * (TY / 2) + cj;  // the coarse cell of a thread of the first eight waves
     const int KA = C.k0 + tb.z * CZ, KB = min(KA + CZ, C.k0 + C.nk);     // coarse planes [KA, KB): fine planes [2 KA, 2 KB) are this chunk's own
     const bool rthread = tid < NRT;
     const double4 rw = F.tx.rw[rthread ? I : 0];
@@ -2150,7 +2151,7 @@ __global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *
         rs1d4(F.t[1], J, F.ny, false, wj, sj);
     }
     const int64_t fplane = (int64_t)F.nx * F.ny, cplane = (int64_t)C.nx * C.ny;
-    for (int e = tid; e < RSX; e += DNT) {
+    for (int e = tid; e < DSX; e += DNT) {
         const int gi = i0 - 4 + e;
         const bool in = gi >= 0 && gi < F.nx;
         tcx[0][swz(e)] = in ? F.cmx[gi] : 0.0;
@@ -2185,7 +2186,7 @@ __global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *
     const bool mine = tid < DPR * DRY;
     const bool ok = mine && gi >= 0 && gi < F.nx && gj >= 0 && gj < F.ny;
     const bool has2 = mine && R >= 1 && R <= DXY, hasr = mine && R >= 2 && R <= DSY + 1;   // carries x2 / the residual
-    const bool own = ok && R >= 3 && R < 3 + TY && X >= 4 && X < 4 + RX;                    // a piece of the tile itself
+    const bool own = ok && R >= 3 && R < 3 + TY && X >= 4 && X < 4 + TX;                    // a piece of the tile itself
     const int64_t goff = (int64_t)(ok ? gj : 0) * F.nx + (ok ? gi : 0);
     __syncthreads();  // the tables
     // the piece's in-plane coefficients
@@ -2290,7 +2291,7 @@ __global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *
             const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X);
             const double(*pl)[SWR] = x1s[(kf + 1) & 1];
             const v4 ylo = swz_get4(pl[R - 1], X), yhi = swz_get4(pl[R + 1], X);
-            const double xleft = X > 0 ? pl[R][swz(X - 1)] : 0.0, xright = X + 4 < RSX ? pl[R][swz(X + 4)] : 0.0;
+            const double xleft = X > 0 ? pl[R][swz(X - 1)] : 0.0, xright = X + 4 < DSX ? pl[R][swz(X + 4)] : 0.0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const double xcc = x1b[c];
@@ -2317,7 +2318,7 @@ __global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *
                 const double(*pl)[SWR] = xs[kf & 1];
                 const int Q = R - 1;  // the piece's row among x2's
                 const v4 ylo = swz_get4(pl[Q - 1], X), yhi = swz_get4(pl[Q + 1], X);
-                const double xleft = X > 0 ? pl[Q][swz(X - 1)] : 0.0, xright = X + 4 < RSX ? pl[Q][swz(X + 4)] : 0.0;
+                const double xleft = X > 0 ? pl[Q][swz(X - 1)] : 0.0, xright = X + 4 < DSX ? pl[Q][swz(X + 4)] : 0.0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const double xcc = xc[c];
@@ -2341,11 +2342,11 @@ __global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *
         if (kf >= kf0 && rthread && inz(kf)) {
             const bool dohi = Khi >= KA && Khi < KB, dolo = Klo >= KA && Klo < KB;
             const double wkhi = dohi ? tz[4][e] : 0.0, wklo = dolo ? tz[5][e] : 0.0;
-            const int qc = swz(2 * lane + 4), ql = swz(2 * lane + 3), qr = swz(2 * lane + 6);
+            const int qc = swz(2 * ci + 4), ql = swz(2 * ci + 3), qr = swz(2 * ci + 6);
             double t[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double *rowp = rs[2 * (tw % (TY / 2)) + r];
+                const double *rowp = rs[2 * cj + r];
                 const double2 cc = *reinterpret_cast<const double2 *>(rowp + qc);
                 t[r] = rsum_x(rw, rowp[ql], cc.x, cc.y, rowp[qr]);
             }
@@ -2373,33 +2374,34 @@ __global__ __launch_bounds__(down_threads(TY)) void k_down_march(const Scalars *
         wb = wa;
     }
     if (UPD) {
-        // the sums in k_presmooth2's grouping: its workgroup (x tile, 8-row half of this tile, this z chunk) summed thread (ty, tx) by
-        // thread over the lanes of its four waves, then (w0 + w1) + (w2 + w3)
-        double(*ush)[TY][RX / 4] = reinterpret_cast<double(*)[TY][RX / 4]>(&x1s[0][0][0]);  // (the planes are done with)
-        __shared__ double uw4[2][2][4];
-        if (R >= 3 && R < 3 + TY && X >= 4 && X < 4 + RX && mine) {
-            ush[0][R - 3][(X - 4) / 4] = ur0;
-            ush[1][R - 3][(X - 4) / 4] = ur1;
+        // TX = 128, TY = 8: the sums in k_presmooth2's grouping -- its workgroup summed thread (ty, tx) by thread over the lanes of its four
+        // waves, then (w0 + w1) + (w2 + w3): the same bits.  Other tiles: the tile's pieces in rows of TX / 4, summed the same way over
+        // the lanes of up to four waves (equal to rounding: the residual NORMS the solver prints move in their last digits).
+        constexpr int NP = TY * (TX / 4);  // pieces of the tile: 256
+        static_assert(NP == 256, "the sums are formed by four waves");
+        double(*ush)[NP] = reinterpret_cast<double(*)[NP]>(&x1s[0][0][0]);  // (the planes are done with)
+        __shared__ double uw4[2][4];
+        if (R >= 3 && R < 3 + TY && X >= 4 && X < 4 + TX && mine) {
+            ush[0][(R - 3) * (TX / 4) + (X - 4) / 4] = ur0;
+            ush[1][(R - 3) * (TX / 4) + (X - 4) / 4] = ur1;
         }
         __syncthreads();
-        if (tid < 32 * TY) {
-            const int half = tid >> 8, t = tid & 255, ty = t >> 5, tx = t & 31;
-            double v0 = ush[0][8 * half + ty][tx], v1 = ush[1][8 * half + ty][tx];
+        if (tid < NP) {
+            double v0 = ush[0][tid], v1 = ush[1][tid];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 v0 += __shfl_down(v0, o, 64);
                 v1 += __shfl_down(v1, o, 64);
             }
-            if ((t & 63) == 0) {
-                uw4[half][0][t >> 6] = v0;
-                uw4[half][1][t >> 6] = v1;
+            if ((tid & 63) == 0) {
+                uw4[0][tid >> 6] = v0;
+                uw4[1][tid >> 6] = v1;
             }
         }
         __syncthreads();
-        if (tid < TY / 4) {
-            const int half = tid >> 1, k2 = tid & 1;
-            const int64_t blk = ((int64_t)tb.z * ((TY / 8) * gridDim.y) + (TY / 8) * tb.y + half) * gridDim.x + tb.x;
-            upart[(int64_t)k2 * upart_stride + blk] = (uw4[half][k2][0] + uw4[half][k2][1]) + (uw4[half][k2][2] + uw4[half][k2][3]);
+        if (tid < 2) {
+            const int64_t blk = ((int64_t)tb.z * gridDim.y + tb.y) * gridDim.x + tb.x;
+            upart[(int64_t)tid * upart_stride + blk] = (uw4[tid][0] + uw4[tid][1]) + (uw4[tid][2] + uw4[tid][3]);
         }
     }
 }
@@ -4534,19 +4536,21 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                     const int CZ = FZ / 2;
                     // (128 x 8 tiles, 512 threads, 214 registers and no spill: 1.19 ms per 512^3 launch against 0.84 + 0.51; the 128 x 16
                     // tile -- 40 instead of 47 B per cell -- needs 768 threads, i.e. 168 registers, and spilled 65: 3.4 ms)
-                    constexpr int TY = 8;
-                    const dim3 grid((unsigned)(g.n[0] / RX), (unsigned)(g.n[1] / TY), (unsigned)((nkc + CZ - 1) / CZ));
+                    // ... 64 x 16 tiles (42 B per cell, 212 registers): 60.9-61.0 against 61.2-61.4 ms per solve on one box, and the Krylov
+                    // sums no longer in k_presmooth2's grouping: not kept)
+                    constexpr int TX = 128, TY = 8;
+                    const dim3 grid((unsigned)(g.n[0] / TX), (unsigned)(g.n[1] / TY), (unsigned)((nkc + CZ - 1) / CZ));
                     if (upd) {
-                        const int nblk = (int)((TY / 8) * grid.x * grid.y * grid.z);  // (k_presmooth2's workgroups: one per 8 rows of a tile)
+                        const int nblk = (int)(grid.x * grid.y * grid.z);  // (128 x 8 tiles: k_presmooth2's workgroups)
                         if (nblk > PIB_MAXPART) return fail(PIB_ERR_LIB, "fused residual update: too many workgroups for the partial sums");
-                        hipLaunchKernelGGL((k_down_march<1, TY>), grid, dim3(down_threads(TY)), 0, q, S, dev_of(g), dev_of(c1), omega, s->gmg_upd.r_old, c,
+                        hipLaunchKernelGGL((k_down_march<1, TX, TY>), grid, dim3(down_threads(TX, TY)), 0, q, S, dev_of(g), dev_of(c1), omega, s->gmg_upd.r_old, c,
                                            c1.b + c1.pad, CZ, pin_l, s->gmg_upd.w, const_cast<double *>(b), s->d_part + 4 * (int64_t)PIB_MAXPART, (int)PIB_MAXPART);
                         PIB_HIP(hipGetLastError());
                         s->gmg_upd.used = true;
                         PIB_CHK(s->gmg_upd.after(s, nblk, q));
                     } else {
-                        hipLaunchKernelGGL((k_down_march<0, TY>), grid, dim3(down_threads(TY)), 0, q, S, dev_of(g), dev_of(c1), omega, b, c, c1.b + c1.pad, CZ, pin_l,
-                                           (const double *)nullptr, (double *)nullptr, (double *)nullptr, 0);
+                        hipLaunchKernelGGL((k_down_march<0, TX, TY>), grid, dim3(down_threads(TX, TY)), 0, q, S, dev_of(g), dev_of(c1), omega, b, c, c1.b + c1.pad, CZ,
+                                           pin_l, (const double *)nullptr, (double *)nullptr, (double *)nullptr, 0);
                         PIB_HIP(hipGetLastError());
                     }
                     set_valid(c, 0);
