@@ -2137,7 +2137,7 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
     constexpr int ZT = 80;                                       // >= 2 CZ + 7 planes (CZ <= 32)
     __shared__ double tz[6][ZT];                                 // w, cm, cp, 1 / w, restriction weight up / down of the planes kfs + e
     const double ua = UPD ? S->a : 0.0;
-    const int tid = threadIdx.x, lane = tid & 63, tw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x;
     const Tile3 tb = tile_of_block();
     const int i0 = tb.x * TX, j0 = tb.y * TY;
     const int ci = tid % CL, cj = (tid / CL) % (TY / 2);               // the coarse cell of a thread of the restriction, within the tile
