@@ -2277,12 +2277,17 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
     }
     __syncthreads();
     double lo = 0.0, hi = 0.0;
-    for (int kf = kfs; kf <= kf1; ++kf) {
+    // One plane of the march.  The planes a piece keeps rotate through NAMES, not through registers: three calls with the names
+    // rotated make one pass of the loop below (the copies r0 = r1, r1 = r2 ... at the end of a plane were 56 of its ~250 vector
+    // instructions, and the kernel is bound by instruction issue: 2.85e8 of them per 512^3 launch against 1.63e8 in the pair it
+    // replaces).  A0, A1, A2: the right-hand side on kf, kf + 1, kf + 2 (A0 takes plane kf + 3 at the end); X0, X1: x1 on kf, kf + 1
+    // (X0 takes plane kf + 2); M, C: x2 on kf - 1, kf (M takes plane kf + 1).
+    auto plane = [&](int kf, v4 &A0, v4 &A1, v4 &A2, v4 &X0, v4 &X1, v4 &Q0, v4 &Q1) {
         const int e = kf - kfs;
         if (kf + 3 <= kf1 + 2) request(kf + 3, nb, nw);
         // ---- x1 of plane kf + 2
         const v4 wa = weights(e + 2);
-        const v4 x1c = first_step(r2, wa, e + 2);
+        const v4 x1c = first_step(A2, wa, e + 2);
         if (mine) swz_put4(x1s[kf & 1][R], X, x1c);  // (slot of plane kf + 2)
         // ---- x2 of plane kf + 1: the second step, from x1 of the planes kf .. kf + 2 and its own plane's x / y neighbours in LDS
         v4 xp = zero;
@@ -2294,14 +2299,14 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
             const double xleft = X > 0 ? pl[R][swz(X - 1)] : 0.0, xright = X + 4 < DSX ? pl[R][swz(X + 4)] : 0.0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const double xcc = x1b[c];
-                const double left = (c == 0) ? xleft : x1b[c > 0 ? c - 1 : 0], right = (c == 3) ? xright : x1b[c < 3 ? c + 1 : 0];
-                double t = (r1[c] * rxy4[c]) * rwz;
+                const double xcc = X1[c];
+                const double left = (c == 0) ? xleft : X1[c > 0 ? c - 1 : 0], right = (c == 3) ? xright : X1[c < 3 ? c + 1 : 0];
+                double t = (A1[c] * rxy4[c]) * rwz;
                 t = nacc(t, cxm4[c], left);
                 t = nacc(t, cxp4[c], right);
                 t = nacc(t, cym, ylo[c]);
                 t = nacc(t, cyp, yhi[c]);
-                t = nacc(t, czm, x1a[c]);
+                t = nacc(t, czm, X0[c]);
                 t = nacc(t, czp, x1c[c]);
                 xp[c] = jrelax(xcc, omc, wb[c], t);
             }
@@ -2321,16 +2326,16 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
                 const double xleft = X > 0 ? pl[Q][swz(X - 1)] : 0.0, xright = X + 4 < DSX ? pl[Q][swz(X + 4)] : 0.0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const double xcc = xc[c];
-                    const double left = (c == 0) ? xleft : xc[c > 0 ? c - 1 : 0], right = (c == 3) ? xright : xc[c < 3 ? c + 1 : 0];
+                    const double xcc = Q1[c];
+                    const double left = (c == 0) ? xleft : Q1[c > 0 ? c - 1 : 0], right = (c == 3) ? xright : Q1[c < 3 ? c + 1 : 0];
                     double sum = 0.0;
                     sum = facc(sum, cxm4[c], left, xcc);
                     sum = facc(sum, cxp4[c], right, xcc);
                     sum = facc(sum, cym, ylo[c], xcc);
                     sum = facc(sum, cyp, yhi[c], xcc);
-                    sum = facc(sum, czm, xm[c], xcc);
+                    sum = facc(sum, czm, Q0[c], xcc);
                     sum = facc(sum, czp, xp[c], xcc);
-                    out[c] = resid(r0[c], sum * (wx4[c] * wyj), wzk);
+                    out[c] = resid(A0[c], sum * (wx4[c] * wyj), wzk);
                 }
             }
             swz_put4(rs[R - 2], X, out);
@@ -2357,21 +2362,25 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
             if (dohi) hi = tacc(hi, wkhi, u);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the plane requested at the top (placed here: see k_resid_restrict_march)
-        const v4 r3 = (kf + 3 <= kf1 + 2) ? take(kf + 3, nb, nw) : zero;
+        A0 = (kf + 3 <= kf1 + 2) ? take(kf + 3, nb, nw) : zero;
         if (kf >= kf0 && !odd) {
             if (rthread && Klo >= KA && Klo < KB) bc[(int64_t)(Klo - C.k0) * cplane + (int64_t)J * C.nx + I] = lo;
             lo = hi;
             hi = 0.0;
         }
         __syncthreads();
-        r0 = r1;
-        r1 = r2;
-        r2 = r3;
-        x1a = x1b;
-        x1b = x1c;
-        xm = xc;
-        xc = xp;
+        X0 = x1c;
+        Q0 = xp;
         wb = wa;
+    };
+    // (the right-hand side's names come round after three planes, x1's and x2's after two: six planes a pass)
+    for (int kf = kfs; kf <= kf1; kf += 6) {
+        plane(kf, r0, r1, r2, x1a, x1b, xm, xc);
+        if (kf + 1 <= kf1) plane(kf + 1, r1, r2, r0, x1b, x1a, xc, xm);
+        if (kf + 2 <= kf1) plane(kf + 2, r2, r0, r1, x1a, x1b, xm, xc);
+        if (kf + 3 <= kf1) plane(kf + 3, r0, r1, r2, x1b, x1a, xc, xm);
+        if (kf + 4 <= kf1) plane(kf + 4, r1, r2, r0, x1a, x1b, xm, xc);
+        if (kf + 5 <= kf1) plane(kf + 5, r2, r0, r1, x1b, x1a, xc, xm);
     }
     if (UPD) {
         // TX = 128, TY = 8: the sums in k_presmooth2's grouping -- its workgroup summed thread (ty, tx) by thread over the lanes of its four
