@@ -2190,16 +2190,20 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
     const int64_t goff = (int64_t)(ok ? gj : 0) * F.nx + (ok ? gi : 0);
     __syncthreads();  // the tables
     // the piece's in-plane coefficients
-    // (the piece's in-plane coefficients come from the LDS tables where they are used: registers are what this kernel is short of)
-    v4 rxy4 = {0, 0, 0, 0};
+    v4 rxy4 = {0, 0, 0, 0}, cxm4 = {0, 0, 0, 0}, cxp4 = {0, 0, 0, 0}, vxy4 = {0, 0, 0, 0};
     double cym = 0.0, cyp = 0.0;
     if (mine) {
-        const v4 rwx4 = swz_get4(tcx[3], X);
+        const v4 rwx4 = swz_get4(tcx[3], X), wx4 = swz_get4(tcx[2], X);
+        cxm4 = swz_get4(tcx[0], X);
+        cxp4 = swz_get4(tcx[1], X);
         cym = tcy[0][R];
         cyp = tcy[1][R];
-        const double rwyj = tcy[3][R];
+        const double rwyj = tcy[3][R], wyj = tcy[2][R];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) rxy4[c] = rwx4[c] * rwyj;
+        for (int c = 0; c < 4; ++c) {
+            rxy4[c] = rwx4[c] * rwyj;
+            vxy4[c] = wx4[c] * wyj;
+        }
     }
     const v4 zero = {0, 0, 0, 0};
     const double omc = 1.0 - omega;
@@ -2242,7 +2246,6 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
             key_zm = czm, key_zp = czp;
             wlast = zero;
             if (ok) {
-                const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) wlast[c] = jweight(omega, -(((((cxm4[c] + cxp4[c]) + cym) + cyp) + czm) + czp));
             }
@@ -2293,7 +2296,6 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
         v4 xp = zero;
         if (has2 && ok && inz(kf + 1)) {
             const double rwz = tz[3][e + 1], czm = tz[1][e + 1], czp = tz[2][e + 1];
-            const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X);
             const double(*pl)[SWR] = x1s[(kf + 1) & 1];
             const v4 ylo = swz_get4(pl[R - 1], X), yhi = swz_get4(pl[R + 1], X);
             const double xleft = X > 0 ? pl[R][swz(X - 1)] : 0.0, xright = X + 4 < DSX ? pl[R][swz(X + 4)] : 0.0;
@@ -2318,8 +2320,6 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
             v4 out = zero;
             if (ok && inz(kf)) {
                 const double wzk = tz[0][e], czm = tz[1][e], czp = tz[2][e];
-                const v4 cxm4 = swz_get4(tcx[0], X), cxp4 = swz_get4(tcx[1], X), wx4 = swz_get4(tcx[2], X);
-                const double wyj = tcy[2][R];
                 const double(*pl)[SWR] = xs[kf & 1];
                 const int Q = R - 1;  // the piece's row among x2's
                 const v4 ylo = swz_get4(pl[Q - 1], X), yhi = swz_get4(pl[Q + 1], X);
@@ -2335,7 +2335,7 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
                     sum = facc(sum, cyp, yhi[c], xcc);
                     sum = facc(sum, czm, Q0[c], xcc);
                     sum = facc(sum, czp, xp[c], xcc);
-                    out[c] = resid(A0[c], sum * (wx4[c] * wyj), wzk);
+                    out[c] = resid(A0[c], sum * vxy4[c], wzk);
                 }
             }
             swz_put4(rs[R - 2], X, out);
