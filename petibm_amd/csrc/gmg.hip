@@ -383,6 +383,15 @@ __device__ __forceinline__ swv4 swz_get4(const double *row, int X)  // X a multi
     const swv4 v = {a[0], a[1], b[0], b[1]};
     return v;
 }
+// A workgroup barrier that orders LDS only: __syncthreads() is a release / acquire fence over ALL memory, i.e. s_waitcnt vmcnt(0)
+// in front of every s_barrier -- which ends the flight of the global loads a marching kernel has requested for its NEXT plane
+// at the first barrier of the current one.  The LDS hand-over between the stages of a plane needs lgkmcnt(0) only.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 // Register budgets of the LDS-tiled kernels.  A 256-thread workgroup is four waves, one per SIMD, and the compiler sizes
 // its register use for whatever occupancy it happens to reach: k_level_march<8> took 144 VGPRs (three waves per SIMD),
 // k_presmooth2 142 (three), k_prolong_smooth 212 (two).  amdgpu_waves_per_eu(n) asks for n: the march fits 126 without
@@ -2340,7 +2349,7 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
             }
             swz_put4(rs[R - 2], X, out);
         }
-        __syncthreads();
+        lds_barrier();
         // ---- the restriction's share of plane kf
         const bool odd = kf & 1;
         const int Khi = odd ? (kf + 1) / 2 : kf / 2, Klo = Khi - 1;
@@ -2368,7 +2377,7 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
             lo = hi;
             hi = 0.0;
         }
-        __syncthreads();
+        lds_barrier();
         X0 = x1c;
         Q0 = xp;
         wb = wa;
