@@ -2219,12 +2219,14 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
     double ur0 = 0.0, ur1 = 0.0;
     auto inz = [&](int kf) { return kf >= 0 && kf < F.nzg; };
     // the right-hand side of the piece on plane kf: requested ...
+    // (a vector is zeroed on the path that needs the zeros, not ahead of the branch: the kernel is bound by instruction issue)
     auto request = [&](int kf, v4 &vb, v4 &vw) {
-        vb = zero;
-        vw = zero;
         if (ok && inz(kf)) {
             vb = *reinterpret_cast<const v4 *>(b + (int64_t)(kf - F.k0) * fplane + goff);
             if (UPD) vw = *reinterpret_cast<const v4 *>(uw + (int64_t)(kf - F.k0) * fplane + goff);
+        } else {
+            vb = zero;
+            vw = zero;
         }
     };
     // ... and taken in: the Krylov update, the tile's share of the new residual and of its sums, the pinned cell
@@ -2261,13 +2263,12 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
         }
         return wlast;
     };
+    // (a piece outside the domain has w = 0 and a zero right-hand side: its x1 is 0 * 0 without a branch)
     auto first_step = [&](const v4 &vb, const v4 &w, int e) -> v4 {
-        v4 o = zero;
-        if (ok) {
-            const double rwz = tz[3][e];
+        v4 o;
+        const double rwz = tz[3][e];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = w[c] * ((vb[c] * rxy4[c]) * rwz);
-        }
+        for (int c = 0; c < 4; ++c) o[c] = w[c] * ((vb[c] * rxy4[c]) * rwz);
         return o;
     };
     // registers: the right-hand side on the planes kf, kf + 1, kf + 2; x1 on kf, kf + 1 (kf + 2 is formed in the iteration);
@@ -2302,7 +2303,7 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
         const v4 x1c = first_step(A2, wa, e + 2);
         if (mine) swz_put4(x1s[kf & 1][R], X, x1c);  // (slot of plane kf + 2)
         // ---- x2 of plane kf + 1: the second step, from x1 of the planes kf .. kf + 2 and its own plane's x / y neighbours in LDS
-        v4 xp = zero;
+        v4 xp;
         if (has2 && ok && inz(kf + 1)) {
             const double rwz = tz[3][e + 1], czm = tz[1][e + 1], czp = tz[2][e + 1];
             const double(*pl)[SWR] = x1s[(kf + 1) & 1];
@@ -2322,11 +2323,12 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
                 xp[c] = jrelax(xcc, omc, wb[c], t);
             }
             if (own && kf + 1 >= 2 * KA && kf + 1 < 2 * KB) *reinterpret_cast<v4 *>(xo + (int64_t)(kf + 1 - F.k0) * fplane + goff) = xp;
-        }
+        } else
+            xp = zero;
         if (has2) swz_put4(xs[(kf + 1) & 1][R - 1], X, xp);
         // ---- the residual of plane kf (x2 of the planes kf - 1, kf, kf + 1; plane kf's x / y neighbours in LDS)
         if (kf >= kf0 && hasr) {
-            v4 out = zero;
+            v4 out;
             if (ok && inz(kf)) {
                 const double wzk = tz[0][e], czm = tz[1][e], czp = tz[2][e];
                 const double(*pl)[SWR] = xs[kf & 1];
@@ -2346,7 +2348,8 @@ __global__ __launch_bounds__(down_threads(TX, TY)) void k_down_march(const Scala
                     sum = facc(sum, czp, xp[c], xcc);
                     out[c] = resid(A0[c], sum * vxy4[c], wzk);
                 }
-            }
+            } else
+                out = zero;
             swz_put4(rs[R - 2], X, out);
         }
         lds_barrier();
