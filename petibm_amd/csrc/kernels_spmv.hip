@@ -885,10 +885,14 @@ static int build_row_patterns(pib_solver *s)
         A.pat_tables = 0;
         return 0;
     };
-    PIB_HIP(hipMalloc(&A.pat_id, (size_t)nblk * 256));
-    PIB_HIP(hipMalloc(&t_tab, sizeof(int32_t) * (size_t)nblk * PN * PL));
-    PIB_HIP(hipMalloc(&t_len, (size_t)nblk * PN));
-    PIB_HIP(hipMalloc(&d_hash, sizeof(unsigned long long) * (size_t)nblk));
+    // (the compressed forms are optional: a device short of memory keeps the plain columns instead of failing setMatrix)
+    auto opt = [](hipError_t e) {
+        if (e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
+    };
+    if (!opt(hipMalloc(&A.pat_id, (size_t)nblk * 256)) || !opt(hipMalloc(&t_tab, sizeof(int32_t) * (size_t)nblk * PN * PL)) ||
+        !opt(hipMalloc(&t_len, (size_t)nblk * PN)) || !opt(hipMalloc(&d_hash, sizeof(unsigned long long) * (size_t)nblk)))
+        return drop();
     PIB_HIP(hipMalloc(&d_failed, sizeof(int)));
     PIB_HIP(hipMemsetAsync(d_failed, 0, sizeof(int), s->stream));
     if (A.rp64)
@@ -918,10 +922,9 @@ static int build_row_patterns(pib_solver *s)
         blk[(size_t)b] = it->second;
     }
     A.pat_tables = (int64_t)rep.size();
-    PIB_HIP(hipMalloc(&A.pat_blk, sizeof(int32_t) * (size_t)nblk));
-    PIB_HIP(hipMalloc(&A.pat_tab, sizeof(int32_t) * rep.size() * PN * PL));
-    PIB_HIP(hipMalloc(&A.pat_len, rep.size() * PN));
-    PIB_HIP(hipMalloc(&d_rep, sizeof(int32_t) * rep.size()));
+    if (!opt(hipMalloc(&A.pat_blk, sizeof(int32_t) * (size_t)nblk)) || !opt(hipMalloc(&A.pat_tab, sizeof(int32_t) * rep.size() * PN * PL)) ||
+        !opt(hipMalloc(&A.pat_len, rep.size() * PN)) || !opt(hipMalloc(&d_rep, sizeof(int32_t) * rep.size())))
+        return drop();
     PIB_HIP(hipMemcpyAsync(A.pat_blk, blk.data(), sizeof(int32_t) * (size_t)nblk, hipMemcpyHostToDevice, s->stream));
     PIB_HIP(hipMemcpyAsync(d_rep, rep.data(), sizeof(int32_t) * rep.size(), hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(k_gather_tables, dim3((unsigned)rep.size()), dim3(64), 0, s->stream, d_rep, t_tab, t_len, A.pat_tab, A.pat_len);
@@ -961,8 +964,14 @@ static int build_column_codes(pib_solver *s)
         if (A.patterned) return 0;
     }
     const int64_t nblk = (A.n + 255) / 256;
-    PIB_HIP(hipMalloc(&A.code, (size_t)A.nnz + 64));
-    PIB_HIP(hipMalloc(&A.dict, sizeof(int32_t) * (size_t)(nblk + 1) * DeviceCsr::CODE_DICT));
+    if (hipMalloc(&A.code, (size_t)A.nnz + 64) != hipSuccess || hipMalloc(&A.dict, sizeof(int32_t) * (size_t)(nblk + 1) * DeviceCsr::CODE_DICT) != hipSuccess) {
+        (void)hipGetLastError();  // (optional: see build_row_patterns)
+        if (A.code) (void)hipFree(A.code);
+        if (A.dict) (void)hipFree(A.dict);
+        A.code = nullptr;
+        A.dict = nullptr;
+        return 0;
+    }
     PIB_HIP(hipMemsetAsync(A.code + A.nnz, 0, 64, s->stream));
     PIB_HIP(hipMemsetAsync(A.dict + nblk * DeviceCsr::CODE_DICT, 0, sizeof(int32_t) * DeviceCsr::CODE_DICT, s->stream));
     int *d_many = nullptr, h_many = 0;
