@@ -236,14 +236,21 @@ def spmv_only(args) -> int:
     s.assemblePoisson((n, n, n), [w, w, w], 5e-4 if n == 512 else 1e-3, capi.NULLSPACE_CONSTANT)
     s.timeKernel(0, 3)
     s.destroy()
+    # ... and the plain int32-column CSR kernel (SURVEY 8d's 104 B/row, what north_star quotes): k_spmv_lds<...>
+    s = LinSolverHIP("poisson", config_text=solver_config(args.pc, args.tol, args.max_iters, args.omega, args.presweeps, args.postsweeps) +
+                     "pib_compress_columns=0\n")
+    s.assemblePoisson((n, n, n), [w, w, w], 5e-4 if n == 512 else 1e-3, capi.NULLSPACE_CONSTANT)
+    s.timeKernel(0, 3)
+    s.destroy()
     return 0
 
 
 def collect_traffic(n: int, mode: str):
     """`roofline.traffic` measured in THIS run: the SpMV leg once more under `rocprofv3 --pmc FETCH_SIZE` and once under
     `--pmc WRITE_SIZE` (separate passes with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; run from
-    /tmp with TMPDIR=/tmp), in a child process of this script (`--spmv-only`).  KiB per k_spmv_lds dispatch, averaged;
-    FETCH_SIZE doubled (gfx950 tallies 128-byte requests as 64).  (bytes, source) or (None, reason).
+    /tmp with TMPDIR=/tmp), in a child process of this script (`--spmv-only`: the product kernel in use AND the plain
+    int32-column CSR kernel).  KiB per dispatch, averaged per kernel; FETCH_SIZE doubled (gfx950 tallies 128-byte requests as
+    64).  ({"default": bytes, "csr_plain": bytes}, source) or (None, reason).
     mode: "auto" (when rocprofv3 is on PATH and this is not already a profiled child), "on", "off"."""
     import csv
     import glob
@@ -256,29 +263,36 @@ def collect_traffic(n: int, mode: str):
     if tool is None:
         return None, "rocprofv3 not found"
     env = dict(os.environ, TMPDIR="/tmp", PIB_BENCH_CHILD="1")
-    kib = {}
+    kib = {"default": {}, "csr_plain": {}}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix=f"pib_pmc_{counter}_", dir="/tmp")
         try:
             cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--spmv-only", "--grid", str(n)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
-            vals = []
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=360)
+            vals = {"default": [], "csr_plain": []}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "k_spmv_lds" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
+                    name = row.get("Kernel_Name", "")
+                    if "k_spmv_lds" in name and row.get("Counter_Name") == counter:
+                        plain = "k_spmv_lds_pattern" not in name and "k_spmv_lds_coded" not in name
+                        vals["csr_plain" if plain else "default"].append(float(row["Counter_Value"]))
+            if not vals["default"] and vals["csr_plain"]:  # (the default form IS the plain kernel: pib_compress_columns=0 in the config)
+                vals["default"] = vals["csr_plain"]
+            if not vals["default"]:
                 return None, f"rocprofv3 --pmc {counter}: no k_spmv_lds dispatch in the output (rc {r.returncode})"
-            kib[counter] = sum(vals) / len(vals)
+            for k in vals:
+                if vals[k]:
+                    kib[k][counter] = sum(vals[k]) / len(vals[k])
         except Exception as e:  # noqa: BLE001
             return None, f"rocprofv3 --pmc {counter} failed: {e}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    traffic = 2.0 * 1024.0 * kib["FETCH_SIZE"] + 1024.0 * kib["WRITE_SIZE"]
-    return traffic, (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes over `bench.py --spmv-only "
-                     f"--grid {n}`), mean per k_spmv_lds dispatch: FETCH_SIZE {kib['FETCH_SIZE']:.4g} KiB x 2 (gfx950 correction) + "
-                     f"WRITE_SIZE {kib['WRITE_SIZE']:.4g} KiB")
+    traffic = {k: (2.0 * 1024.0 * v["FETCH_SIZE"] + 1024.0 * v["WRITE_SIZE"]) if len(v) == 2 else None for k, v in kib.items()}
+    src = (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes over `bench.py --spmv-only "
+           f"--grid {n}`), mean per dispatch: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE; KiB per dispatch: " +
+           "; ".join(f"{k}: FETCH_SIZE {v.get('FETCH_SIZE', float('nan')):.4g}, WRITE_SIZE {v.get('WRITE_SIZE', float('nan')):.4g}" for k, v in kib.items()))
+    return traffic, src
 
 
 def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str = "", solver: str = "PBICGSTAB", tol: float = 1e-10) -> dict:
@@ -946,12 +960,37 @@ def poisson_bench(args) -> int:
     if rank == 0:
         # HBM traffic of the SpMV: counted in this run where rocprofv3 exists (one GPU), else the committed passes
         traffic = (None, None)
+        traffic_plain = None
         if world == 1:
             traffic = collect_traffic(n, args.pmc)
             if traffic[0] is None:
                 if args.pmc == "on":
                     notes.append(f"--pmc on: {traffic[1]}")
                 traffic = measured_traffic(n, world)
+            else:
+                traffic_plain = traffic[0].get("csr_plain")
+                traffic = (traffic[0].get("default"), traffic[1])
+        # the kernel north_star names, in the same process: the plain int32-column CSR product (104 B per 7-point row,
+        # 13.94 GB per 512^3 launch) -- pib_compress_columns=0, same matrix, HIP events on the solver's stream
+        csr_plain = None
+        if world == 1:
+            try:
+                if idx_bytes == 4:
+                    ms_plain = ms_spmv
+                else:
+                    s2 = LinSolverHIP("poisson", config_text=base_text + "pib_compress_columns=0\n")
+                    w1 = np.full(n, 1.0 / n)
+                    s2.assemblePoisson((n, n, n), [w1, w1, w1], dt, capi.NULLSPACE_CONSTANT)
+                    assert s2.productIndexBytes() == 4
+                    ms_plain = s2.timeKernel(0, args.kernel_reps)
+                    s2.destroy()
+                gbs_plain = csr_bytes / (ms_plain * 1e-3) / 1e9
+                csr_plain = {"kernel": "pib::k_spmv_lds<int32> (fp64 CSR SpMV, int32 columns + int32 row offsets: pib_compress_columns=0)",
+                             "ms_per_launch": ms_plain, "algorithmic_bytes": csr_bytes, "bytes_per_row": csr_bytes / n_l,
+                             "achieved": gbs_plain, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_plain / HBM_PEAK_GBS,
+                             "traffic": traffic_plain}
+            except Exception as e:  # noqa: BLE001
+                notes.append(f"plain-CSR product timing failed: {e}")
         out = {
             "metric": f"Poisson DOF/s (one pressure solve to rel. residual 1e-10), {n}^3 cavity",
             "value": pN * args.steps / elapsed, "unit": "DOF/s", "n_gpus": world, "steps": args.steps,
@@ -974,14 +1013,20 @@ def poisson_bench(args) -> int:
                          "ms_per_launch": ms_spmv, "algorithmic_bytes": alg_bytes,
                          # the bytes of the format the kernel streams ((8 + index_bytes) per entry + 4 per row offset + x once + y
                          # + 64 B of dictionary per 256 rows); SURVEY 8d's plain-CSR figure beside it, against the same launch time
-                         "index_bytes_per_entry": idx_bytes, "csr_algorithmic_bytes": csr_bytes,
-                         "csr_equivalent_frac": csr_bytes / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "index_bytes_per_entry": idx_bytes,
+                         # (a) the plain-CSR launch north_star quotes, timed in this process, its PMC traffic from the same passes
+                         "csr_plain": csr_plain},
             "counters": {"spmv": int(counters[0]), "pc_apply": int(counters[1]), "reductions": int(counters[2]),
                          "halo_exchanges": int(counters[3]), "host_polls": int(counters[4]),
                          "comm_ranks": int(counters[5]),  # ncclCommCount of the solver's communicator (1: none)
                          "residual_updates_in_vcycle": int(counters[6]),  # iterations whose r -= a w ran inside the V-cycle's first march
                          "halo_bytes_sent": int(counters[7])},  # by this rank in the last solve (exchanges + all-gathers)
         }
+        try:  # what runs (pib_describe) and what the bounded placement search did on this box
+            out["runs"] = s.describe().splitlines()
+            out["placement"] = dict(zip(("searches", "candidates", "ms_had", "ms_kept", "held_bytes", "search_ms"), s.placementInfo()))
+        except Exception as e:  # noqa: BLE001
+            notes.append(f"describe failed: {e}")
         if world > 1:  # what every rank communicated in its last solve
             out["per_rank"] = [{"rank": q, "halo_exchanges": int(all_counters[q][3]), "reductions": int(all_counters[q][2]),
                                 "halo_bytes_sent": int(all_counters[q][7]), "spmv": int(all_counters[q][0])} for q in range(world)]
@@ -994,9 +1039,10 @@ def poisson_bench(args) -> int:
                                            "pib_fuse_post_pair=0" not in args.extra_config, float(pN), idx_bytes)
             per_solve = iters / args.steps + 1.0
             gbs = bpr * pN * per_solve / (elapsed / args.steps) / 1e9
-            out["roofline_solve"] = {"bound": "hbm", "bytes_per_row_per_iteration": bpr, "iterations_counted": per_solve,
-                                     "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
-                                     "ms_per_iteration": 1e3 * elapsed / args.steps / per_solve}
+            # (b) inside `roofline`, where the driver's parsed record keeps it
+            out["roofline"]["solve"] = {"bound": "hbm", "bytes_per_row_per_iteration": bpr, "iterations_counted": per_solve,
+                                        "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
+                                        "ms_per_iteration": 1e3 * elapsed / args.steps / per_solve, "ms_per_solve": 1e3 * elapsed / args.steps}
         def finite(o):  # NaN is not JSON
             if isinstance(o, dict):
                 return {k: finite(v) for k, v in o.items()}
@@ -1044,6 +1090,10 @@ def poisson_bench(args) -> int:
                 entry = fn()
                 entry["name"] = name
                 out["secondary"].append(entry)
+                if name == "dropin_amgx_route_512":
+                    # (c) the route an unchanged PetIBM takes, split: device / copy in / copy out per solve, and setMatrix
+                    out["roofline"]["dropin"] = {k: entry[k] for k in ("ms_per_step", "device_ms", "copy_in_ms", "copy_out_ms", "set_matrix_s",
+                                                                      "iters_per_solve", "true_rel_residual", "host_buffers")}
             except Exception as exc:  # noqa: BLE001
                 out.setdefault("notes", []).append(f"secondary line {name} failed: {exc}")
     if rank == 0:

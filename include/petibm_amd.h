@@ -146,6 +146,15 @@ int pib_destroy(pib_solver *s);
  * convention from this string (navierstokes.cpp:402-426). */
 int pib_get_type(pib_solver *s, char *buf, int buflen);
 
+/* What this solver RUNS (pib_config_describe says what its file asks for): first line key=value pairs -- type, method, pc,
+ * product (csr_int32_columns | csr_column_codes | csr_row_patterns | matrix_free_stencil | matrix_free_velocity), partition,
+ * ranks, levels, smoother, presteps / poststeps (smoothing STEPS per level: a sweep of the file is a pair unless
+ * pib_sweep_pairs=0), nullspace, structure, placement_searches --, then one "departure: ..." line for every place where the
+ * backend departs from the file (CG -> BiCGStab for a non-symmetric DBNG, ...).  getType keeps the reference's two strings
+ * (navierstokes.cpp:402-426 compares them); LinSolverBase::printInfo (include/petibm/linsolver.h:103) prints this text under
+ * the reference's banner.  Valid at any time after pib_create; the product is "none" before setMatrix. */
+int pib_describe(pib_solver *s, char *buf, int buflen);
+
 /* ---- setMatrix ------------------------------------------------------------
  * LinSolverBase::setMatrix(const Mat&) / AmgXSolver::setA(A)
  * (src/linsolver/linsolveramgx.cpp:84, src/linsolver/linsolverksp.cpp:78-79).
@@ -364,6 +373,8 @@ int pib_ns_get_stage_times(pib_ns *ns, double ms[6], int64_t *steps);
 const char *pib_ns_stage_name(int stage);
 /* the columns of iterations-<start>.txt (navierstokes.cpp:766-794) for the last step */
 int pib_ns_get_solver_info(pib_ns *ns, int *v_iters, double *v_res, int *p_iters, double *p_res);
+/* writeLinSolversInfo (navierstokes.cpp:780-787): pib_describe of the engine's velocity (0) or Poisson (1) solver */
+int pib_ns_describe_solver(pib_ns *ns, int which, char *buf, int buflen);
 int pib_ns_destroy(pib_ns *ns);
 
 /* ---- immersed bodies: DecoupledIBPMSolver (applications/decoupledibpm/decoupledibpm.cpp) ----------------------
@@ -421,9 +432,12 @@ int pib_get_staging_ms(pib_solver *s, double *h2d_ms, double *d2h_ms);
  * pib_use_graph, pib_graph_max_rows; on several ranks with the device-ordered peer transport only). */
 int pib_get_graph_replays(pib_solver *s, int64_t *replays);
 /* The placement of the search direction against the caller's x (pib_place_update_vector: CG on one rank, 2^25 rows and more):
- * searches run since the solver was created, allocations the last search timed, and the probe's time (ms: the p-update's access
- * pattern over both vectors) with the vector the solver had and with the one it kept.  All zero when no search ran. */
-int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept);
+ * searches run since the solver was created (a device whose memory is more than half taken gets a search that times nothing),
+ * allocations the last search timed, the probe's time (ms: the p-update's access pattern over both vectors) with the vector the
+ * solver had and with the one it kept, the most bytes any search held at one time beyond the solver's own vectors (gaps,
+ * reference vectors, rejected candidates: never more than min(16 GiB, a tenth of the free memory)) and the wall time of all
+ * searches (ms).  All zero when no search ran; held_bytes / search_ms may be NULL. */
+int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept, int64_t *held_bytes, double *search_ms);
 /* What the CSR product (the MatMult inside KSPSolve / AmgXSolver::solve) streams per matrix entry besides the 8-byte value: 4 (the
  * int32 column), 1 (pib_compress_columns=1: a one-byte code into the dictionary of column offsets of the entry's 256-row block,
  * built at setMatrix when no block has more than 16 distinct offsets) or 0 (pib_compress_columns=2, the default: one byte per

@@ -70,9 +70,19 @@ public:
     {
         std::string info = std::string(80, '=') + "\nLinear Solver " + name + ":\n" + std::string(80, '=') + "\n";
         info += "\tType: " + type + "\n\n\tConfig file: " + config + "\n\n";
+        // what actually runs, one "Runs:" line each: the effective solver and every departure from the file (pib_describe)
+        const std::string runs = describeRuns();
+        for (size_t b = 0; b < runs.size();) {
+            size_t e = runs.find('\n', b);
+            if (e == std::string::npos) e = runs.size();
+            info += "\tRuns: " + runs.substr(b, e - b) + "\n";
+            b = e + 1;
+        }
+        if (!runs.empty()) info += "\n";
         std::fputs(info.c_str(), stdout);
         return 0;
     }
+    virtual std::string describeRuns() const { return std::string(); }
     ErrorCode getType(std::string &_type) const
     {
         _type = type;
@@ -153,6 +163,12 @@ public:
     /** periodic directions of the mesh (mesh->periodic[0][d]); before setGridHint / the on-device assembly */
     ErrorCode setPeriodic(const int periodic[3]) { return pib_set_periodic(h_, periodic); }
     pib_solver *handle() { return h_; }
+    std::string describeRuns() const override
+    {
+        char buf[4096];
+        if (h_ == nullptr || pib_describe(h_, buf, (int)sizeof buf) != 0) return std::string();
+        return std::string(buf);
+    }
 
 protected:
     ErrorCode init() override

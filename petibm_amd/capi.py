@@ -54,6 +54,7 @@ _PROTOS = {
     "pib_slab_range": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "pib_destroy": (C.c_int, [_vp]),
     "pib_get_type": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "pib_describe": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "pib_set_csr": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "pib_set_csr_i32": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "pib_set_grid_hint": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
@@ -93,6 +94,7 @@ _PROTOS = {
     "pib_ns_advance": (C.c_int, [_vp, C.c_int]),
     "pib_ns_get_history": (C.c_int, [_vp, _vp, _vp, _vp]),
     "pib_ns_set_history": (C.c_int, [_vp, _vp, _vp]),
+    "pib_ns_describe_solver": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int]),
     "pib_ns_get_solver_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                          C.POINTER(C.c_double)]),
     "pib_ns_stage_timers": (C.c_int, [_vp, C.c_int]),
@@ -110,7 +112,8 @@ _PROTOS = {
     "pib_get_counters": (C.c_int, [_vp, _vp]),
     "pib_get_staging_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pib_get_product_format": (C.c_int, [_vp, C.POINTER(C.c_int)]),
-    "pib_get_placement": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pib_get_placement": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

@@ -166,6 +166,8 @@ try {
     if (s->ev_b) (void)hipEventDestroy(s->ev_b);
     if (s->ev_halo) (void)hipEventDestroy(s->ev_halo);
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    for (hipEvent_t e : s->ev_stage)
+        if (e) (void)hipEventDestroy(e);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_side) (void)hipEventDestroy(s->ev_side);
     if (s->stream_side) (void)hipStreamDestroy(s->stream_side);
@@ -182,6 +184,50 @@ try {
     if (s == nullptr || buf == nullptr || buflen < 1) return fail(PIB_ERR_ARG_NULL, "pib_get_type: null argument");
     std::strncpy(buf, s->type_string.c_str(), (size_t)buflen - 1);
     buf[buflen - 1] = '\0';
+    return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
+}
+
+// What this solver RUNS, as opposed to what its file says (pib_config_describe): one line of key=value pairs, then one line per
+// departure from the file.  LinSolverBase::printInfo (include/petibm/linsolver.h:103) prints it under the reference's banner.
+int pib_describe(pib_solver *s, char *buf, int buflen)
+try {
+    if (s == nullptr || buf == nullptr || buflen < 1) return fail(PIB_ERR_ARG_NULL, "pib_describe: null argument");
+    const Config &c = s->cfg;
+    const char *method = c.method == Method::CG ? (c.cg_single_reduction ? "cg_single_reduction" : "cg")
+                                                : (c.method == Method::BICGSTAB ? "bicgstab" : (c.method == Method::CHEBYSHEV ? "chebyshev" : "preonly"));
+    const char *pc = c.pc == Precond::NONE ? "none" : (c.pc == Precond::JACOBI ? "jacobi" : (c.pc == Precond::LU ? "lu" : "gmg"));
+    const pib_solver *in = s->redist.active ? s->redist.inner : s;  // (rows in boxes + multigrid: the solve happens on the inner slabs)
+    const char *product = "none";
+    if (in->has_matrix) {
+        if (in->vel.valid && c.matrix_free_velocity) product = "matrix_free_velocity";
+        else if (stencil_matmult_ok(in)) product = "matrix_free_stencil";
+        else if (in->A.patterned) product = "csr_row_patterns";
+        else if (in->A.coded) product = "csr_column_codes";
+        else product = in->A.rp64 ? "csr_int32_columns_int64_offsets" : "csr_int32_columns";
+    }
+    const bool cheb = c.smoother == Smoother::CHEBYSHEV;
+    const int per = cheb ? std::max(1, c.cheby_degree) : (c.sweep_pairs ? 2 : 1);
+    std::string out;
+    char line[1024];
+    std::snprintf(line, sizeof line,
+                  "type=\"%s\" method=%s pc=%s product=%s partition=%s ranks=%d levels=%d smoother=%s presteps=%d poststeps=%d "
+                  "nullspace=%s structure=%s placement_searches=%d",
+                  s->type_string.c_str(), method, pc, product,
+                  s->redist.active ? "boxes_to_slabs" : (s->comm.nranks > 1 ? (s->A.general ? "general" : "slabs") : "single"), s->comm.nranks,
+                  (int)in->levels.size(), cheb ? "chebyshev" : "jacobi", c.pc == Precond::GMG ? std::max(1, c.presweeps) * per : 0,
+                  c.pc == Precond::GMG ? std::max(0, c.postsweeps) * per : 0,
+                  in->nullspace == PIB_NULLSPACE_PINNED ? "pinned_row0" : (in->nullspace == PIB_NULLSPACE_CONSTANT ? "constant" : "none"),
+                  in->has_grid ? (in->structure_detected ? "recovered" : "given") : "none", in->placements);
+    out = line;
+    if (c.pc == Precond::GMG && !cheb && c.sweep_pairs && (c.presweeps > 0 || c.postsweeps > 0))
+        out += "\ndeparture: smoother: a sweep of the file runs as a fused pair of damped-Jacobi steps (pib_sweep_pairs=0: one step)";
+    for (const std::string &d : s->departures) out += "\ndeparture: " + d;
+    if (s->redist.active)
+        for (const std::string &d : s->redist.inner->departures) out += "\ndeparture: " + d;
+    if ((int)out.size() >= buflen) return fail(PIB_ERR_ARG_OUTOFRANGE, "pib_describe: %d bytes needed", (int)out.size() + 1);
+    std::memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
 } catch (...) {
     return pib::fail_exception(__func__);
@@ -458,10 +504,16 @@ try {
     const double *bdev = b;
     const size_t bytes = sizeof(double) * (size_t)s->A.n;
     if (!xd || !bd) PIB_CHK(ensure_stage(s));
-    // (host vectors: what the copies over PCIe cost is kept for pib_get_staging_ms -- wall time around the enqueue + wait of each
-    // direction; the stream is idle when a solve starts, so that is the copies' own time)
+    // (host vectors: what the copies over PCIe cost is kept for pib_get_staging_ms -- the way in between two events on the stream,
+    // the way out as wall time around its enqueue + the wait the caller needs anyway)
     s->stage_ms[0] = s->stage_ms[1] = 0.0;
-    const auto t_in = std::chrono::steady_clock::now();
+    if ((!xd && s->cfg.initial_guess_nonzero) || !bd) {
+        if (s->ev_stage[0] == nullptr) {
+            PIB_HIP(hipEventCreate(&s->ev_stage[0]));
+            PIB_HIP(hipEventCreate(&s->ev_stage[1]));
+        }
+        PIB_HIP(hipEventRecord(s->ev_stage[0], s->stream));
+    }
     if (!xd) {
         xdev = s->x_dev;
         if (s->cfg.initial_guess_nonzero) PIB_HIP(hipMemcpyAsync(xdev, x, bytes, hipMemcpyHostToDevice, s->stream));
@@ -470,10 +522,9 @@ try {
         PIB_HIP(hipMemcpyAsync(s->b_dev, b, bytes, hipMemcpyHostToDevice, s->stream));
         bdev = s->b_dev;
     }
-    if ((!xd || !bd) && bytes >= ((size_t)1 << 20)) {  // (small systems inside a time loop: no extra host round trip, no figure)
-        PIB_HIP(hipStreamSynchronize(s->stream));  // (pageable source: the copy has returned already; a registered one: now)
-        s->stage_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
-    }
+    // (no host round trip for the figure: two events bracket the copies on the stream, read once the solve has synchronised)
+    const bool staged_in = (!xd && s->cfg.initial_guess_nonzero) || !bd;
+    if (staged_in) PIB_HIP(hipEventRecord(s->ev_stage[1], s->stream));
     int err;
     if (s->redist.active) {
         // rows in DMDA boxes + multigrid: b (and the guess) go to the z-slabs of the inner solver, x comes back
@@ -507,6 +558,11 @@ try {
     else
         err = fail(PIB_ERR_SUP, "solver %s: unsupported Krylov method", s->name.c_str());
     if (err) return err;
+    if (staged_in) {  // (every method returns behind a synchronisation of the stream: both events have completed)
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->ev_stage[0], s->ev_stage[1]) == hipSuccess) s->stage_ms[0] = (double)ms;
+        else (void)hipGetLastError();
+    }
     if (!xd) {
         const auto t_out = std::chrono::steady_clock::now();
         PIB_HIP(hipMemcpyAsync(x, xdev, bytes, hipMemcpyDeviceToHost, s->stream));
@@ -690,13 +746,15 @@ try {
     return pib::fail_exception(__func__);
 }
 
-int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept)
+int pib_get_placement(pib_solver *s, int *searches, int *candidates, double *ms_had, double *ms_kept, int64_t *held_bytes, double *search_ms)
 try {
     if (s == nullptr || searches == nullptr || candidates == nullptr || ms_had == nullptr || ms_kept == nullptr) return fail(PIB_ERR_ARG_NULL, "null argument");
     *searches = s->placements;
     *candidates = s->place_tried;
     *ms_had = s->place_ms[0];
     *ms_kept = s->place_ms[1];
+    if (held_bytes) *held_bytes = s->place_held_bytes;
+    if (search_ms) *search_ms = s->place_search_ms;
     return 0;
 } catch (...) {
     return pib::fail_exception(__func__);

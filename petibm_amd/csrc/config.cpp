@@ -315,13 +315,8 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.side_x_update = std::atoi(d.get("default", "pib_side_x_update", "0").c_str());
     c.side_x_max_rows = std::atoll(d.get("default", "pib_side_x_max_rows", "33554432").c_str());
     c.compress_columns = std::atoi(d.get("default", "pib_compress_columns", "2").c_str());
-    c.split_work_rows = std::atoll(d.get("default", "pib_split_work_rows", "33554432").c_str());
-    c.split_work_gap_gib = std::atoi(d.get("default", "pib_split_work_gap_gib", "0").c_str());
     c.place_update_vector = std::atoi(d.get("default", "pib_place_update_vector", "1").c_str());
     c.place_min_rows = std::atoll(d.get("default", "pib_place_min_rows", "33554432").c_str());
-    c.place_candidates = std::atoi(d.get("default", "pib_place_candidates", "4").c_str());
-    c.place_residuals = std::atoi(d.get("default", "pib_place_residuals", "0").c_str());
-    c.place_product = std::atoi(d.get("default", "pib_place_product", "0").c_str());
     c.cg_single_reduction = std::atoi(d.get("default", "pib_cg_single_reduction", "0").c_str());
     c.fuse_residual_update_slabs = std::atoi(d.get("default", "pib_fuse_residual_update_slabs", "1").c_str());
     c.sweep_pairs = std::atoi(d.get("default", "pib_sweep_pairs", "1").c_str());
@@ -467,13 +462,8 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_side_x_update", v)) c.side_x_update = std::atoi(v.c_str());
     if (get("pib_side_x_max_rows", v)) c.side_x_max_rows = std::atoll(v.c_str());
     if (get("pib_compress_columns", v)) c.compress_columns = std::atoi(v.c_str());
-    if (get("pib_split_work_rows", v)) c.split_work_rows = std::atoll(v.c_str());
-    if (get("pib_split_work_gap_gib", v)) c.split_work_gap_gib = std::atoi(v.c_str());
     if (get("pib_place_update_vector", v)) c.place_update_vector = std::atoi(v.c_str());
     if (get("pib_place_min_rows", v)) c.place_min_rows = std::atoll(v.c_str());
-    if (get("pib_place_candidates", v)) c.place_candidates = std::atoi(v.c_str());
-    if (get("pib_place_residuals", v)) c.place_residuals = std::atoi(v.c_str());
-    if (get("pib_place_product", v)) c.place_product = std::atoi(v.c_str());
     if (get("ksp_cg_single_reduction", v)) c.cg_single_reduction = truthy(v) ? 1 : 0;  // PETSc's own option (KSPCGUseSingleReduction)
     if (get("pib_cg_single_reduction", v)) c.cg_single_reduction = std::atoi(v.c_str());
     if (get("pib_fuse_residual_update_slabs", v)) c.fuse_residual_update_slabs = std::atoi(v.c_str());

@@ -686,6 +686,10 @@ int comm_init(pib_solver *s, int rank, int nranks, const void *uid)
 // the communicator just created in s->comm.comm gets its shared holder (destroyed by the last solver that lets go of it)
 static void adopt_nccl(pib_solver *s)
 {
+    if (s->comm.shared) {  // a second holder's deleter would destroy the communicator the first one still serves
+        std::fprintf(stderr, "petibm_amd: adopt_nccl called twice for one communicator\n");
+        std::abort();
+    }
     s->comm.shared = std::shared_ptr<CommShared>(new CommShared{s->comm.comm, false}, [](CommShared *c) {
         if (c->comm && !c->aborted) (void)ncclCommDestroy(c->comm);
         delete c;
@@ -1568,7 +1572,6 @@ try {
         PIB_NCCL(ncclGetUniqueId(&id));
         PIB_NCCL(ncclCommInitRank(&s->comm.comm, 1, id, 0));
         adopt_nccl(s);
-    adopt_nccl(s);
         s->comm.ring = true;
     } else
         PIB_HIP(hipSetDevice(s->device));

@@ -731,36 +731,21 @@ int ensure_work(pib_solver *s, int nvec)
     lo = (lo + 3) & ~int64_t(3);  // owned part 32-byte aligned
     int64_t stride = lo + A.n + hi + 4;
     stride = (stride + 3) & ~int64_t(3);
-    // Large systems on one rank: every work vector an allocation of its own, some GiB apart (the gaps are allocated, never
-    // touched and freed again once the vectors stand).  One pool puts all the vectors of a Krylov method into ONE placement
-    // class (krylov.hip, place_work_vectors), where the flat kernels that read and write several of them run slowest.
-    const bool split = s->cfg.split_work_rows >= 0 && A.n >= s->cfg.split_work_rows && A.n == A.n_global && nvec <= pib_solver::MAX_WORK;
+    // Large systems on one rank (pib_place_min_rows rows and more): every work vector an allocation of its own.  One pool puts all
+    // the vectors of a Krylov method into ONE placement class (place_walk below), where the flat kernels that read and write
+    // several of them run slowest (BiCGStab on the 400^3 velocity system: 88.2 -> 84.2 ms per solve), and only separately
+    // allocated vectors can be exchanged for better placed ones.
+    const bool split = s->cfg.place_min_rows >= 0 && A.n >= s->cfg.place_min_rows && A.n == A.n_global && nvec <= pib_solver::MAX_WORK;
     const bool have = split ? s->work_split[0] != nullptr : s->work != nullptr;
     if (have && s->n_work >= nvec && s->work_stride == stride && s->work_lo == lo) return 0;
     drop_iteration_graph(s);  // a captured iteration body holds the old vectors' addresses (and goes BEFORE they do)
     PIB_CHK(free_work(s));
     if (split) {
         const size_t bytes = (size_t)(stride + 4) * sizeof(double);
-        size_t gap = (size_t)std::max(0, s->cfg.split_work_gap_gib) << 30;
-        if (gap > 0) {  // (never below a quarter of the device's memory, the vectors counted)
-            size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < tot / 4 + (size_t)nvec * (bytes + gap)) gap = 0;
-        }
-        std::vector<void *> spacers;
         for (int i = 0; i < nvec; ++i) {
-            if (i && gap > bytes) {
-                void *sp = nullptr;
-                if (hipMalloc(&sp, gap - bytes) == hipSuccess) spacers.push_back(sp);
-                (void)hipGetLastError();
-            }
-            const hipError_t e = hipMalloc(&s->work_split[i], bytes);
-            if (e != hipSuccess) {
-                for (void *sp : spacers) (void)hipFree(sp);
-                PIB_HIP(e);
-            }
+            PIB_HIP(hipMalloc(&s->work_split[i], bytes));
             PIB_HIP(hipMemsetAsync(s->work_split[i], 0, bytes, s->stream));
         }
-        for (void *sp : spacers) (void)hipFree(sp);
     } else {
         PIB_HIP(hipMalloc(&s->work_base, (size_t)(stride * nvec + 4) * sizeof(double)));
         PIB_HIP(hipMemsetAsync(s->work_base, 0, (size_t)(stride * nvec + 4) * sizeof(double), s->stream));
@@ -1090,24 +1075,18 @@ static int place_probe_ms(pib_solver *s, int64_t n, const double *z, double *p, 
 // into CLASSES -- runs of 4 to 64 GiB in allocation order -- and a kernel that reads and writes two vectors of one class runs
 // some 12 % under the rate it has on vectors of two classes; which class an allocation is in cannot be read off its address, and
 // the runs differ from box to box and from process to process.  So: time the probe on two NEIGHBOURING fresh allocations (one
-// class, as good as always: the slow reference), then on every vector to place beside its partners; while one of them is not
-// clearly under the slowest time seen, walk on through fresh allocations -- 2, 4, 8, 16, 16 ... GiB further each step, the gaps
-// allocated and never touched; the neighbour of a candidate that was taken comes next without a gap -- and probe each beside
-// the partners of the vectors still to place.  Everything allocated stays allocated until the walk ends, so that every step
-// lands on other physical blocks; the walk stops after cfg.place_candidates candidates nobody took or when only a quarter of
-// the device's memory would be left.  A search costs 10-20 ms when the vectors are well placed already and 0.1-0.8 s when not
-// (the driver clears what it hands out), and runs when x is a buffer the solver has not seen (three times in a solver's life at
-// most: a caller with a new x every solve keeps the third).
-struct PlaceNeed {
-    int idx;               // the work vector to place
-    double *partner[3];    // kind 0: the vectors it must stream well beside (each comes back bit for bit)
-    int np;
-    int kind = 0;          // 0: the pair probe beside the partners; 1: the CSR product p -> this vector, timed itself
-    double t_had = 0.0, t_kept = 0.0, tslow = 0.0;
-    bool met = false;
-};
+// class, as good as always: the slow reference), then on p beside x; while that is not clearly under the slowest time seen, walk
+// on through fresh allocations -- 2, 4, 8 GiB further each step, the gaps allocated and never touched -- and probe each beside x.
+// BOUNDED (round 6): everything the walk holds at one time -- gaps, the two reference vectors, candidates not taken -- stays
+// under PLACE_HOLD_CAP = min(16 GiB, a tenth of the memory free when the search starts); no search at all on a device whose
+// memory is more than half taken (another solver of the process, other ranks or processes sharing the GPU: the transient
+// allocations would be theirs to miss); an allocation or a probe that fails inside the walk ends the walk with what the solver
+// has -- placement is optional, never a solve's error.  A search costs 10-20 ms when the pair is well placed already and
+// 0.1-0.4 s when not, and runs when x is a buffer the solver has not seen (three times in a solver's life at most).
+// pib_get_placement reports searches, candidates, the probe's two times, the bytes held at the walk's peak and its wall time.
+static constexpr size_t PLACE_HOLD_CAP = (size_t)16 << 30;
 
-static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn, int *tried_out)
+static int place_walk(pib_solver *s, int idx, int zidx, double *x, int *tried_out, double *t_had_out, double *t_kept_out)
 {
     const DeviceCsr &A = s->A;
     const size_t bytes = (size_t)(s->work_stride + 4) * sizeof(double);
@@ -1119,11 +1098,15 @@ static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn,
             for (void *h : v) (void)hipFree(h);
         }
     } held_guard{held};
-    // (the walk's budget: what is free now less a quarter of the device, asked ONCE -- hipMemGetInfo takes 100 ms)
     size_t budget = 0, used = 0;
     {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > tot / 4) budget = fr - tot / 4;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        if (fr < tot / 2) return 0;  // a shared or well-filled device: no search
+        budget = std::min(PLACE_HOLD_CAP, fr / 10);
     }
     auto room = [&](size_t want) { return used + want <= budget; };
     auto fresh = [&](double **out) -> bool {
@@ -1134,20 +1117,21 @@ static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn,
             return false;
         }
         if (hipMemsetAsync(*out, 0, bytes, s->stream) != hipSuccess) {
+            (void)hipGetLastError();
             (void)hipFree(*out);
             *out = nullptr;
             return false;
         }
         used += bytes;
+        s->place_held_bytes = std::max(s->place_held_bytes, (int64_t)used);
         return true;
     };
-    for (int i = 0; i < nn; ++i) {
-        double *&v = s->work_split[needs[i].idx];
-        if (v == nullptr) {
-            if (!fresh(&v)) return 0;
-        } else
-            PIB_HIP(hipMemsetAsync(v, 0, bytes, s->stream));
-    }
+    double *&v = s->work_split[idx];
+    if (v == nullptr) {
+        if (!fresh(&v)) return 0;
+        used -= bytes;  // (the solver's own vector is not a transient)
+    } else
+        PIB_HIP(hipMemsetAsync(v, 0, bytes, s->stream));
     hipEvent_t e0, e1;
     PIB_HIP(hipEventCreate(&e0));
     PIB_HIP(hipEventCreate(&e1));
@@ -1158,31 +1142,6 @@ static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn,
     const double *z = s->vec(zidx);
     const int64_t lo = s->work_lo;
     static const bool debug = std::getenv("PIB_PLACE_DEBUG") != nullptr;
-    // the worst of the candidate's probes beside the need's partners / the product into the candidate (best of two)
-    auto beside = [&](double *c, const PlaceNeed &nd, double *out) -> int {
-        double w = 0.0;
-        if (nd.kind == 1) {
-            w = 1e30;
-            for (int r = 0; r < 3; ++r) {
-                PIB_HIP(hipEventRecord(e0, s->stream));
-                PIB_CHK(spmv_rows(s, s->vec(2), c + lo, 0, A.n, nullptr, false, s->stream));
-                PIB_HIP(hipEventRecord(e1, s->stream));
-                PIB_HIP(hipEventSynchronize(e1));
-                float ms = 0.f;
-                PIB_HIP(hipEventElapsedTime(&ms, e0, e1));
-                if (r) w = std::min(w, (double)ms);
-            }
-            *out = w;
-            return 0;
-        }
-        for (int k = 0; k < nd.np; ++k) {
-            double t = 0.0;
-            PIB_CHK(place_probe_ms(s, A.n, z, c + lo, nd.partner[k], e0, e1, &t));
-            w = std::max(w, t);
-        }
-        *out = w;
-        return 0;
-    };
     int tried = 0;
     // the slow reference: two neighbouring fresh allocations
     double *n0 = nullptr, *n1 = nullptr;
@@ -1191,106 +1150,76 @@ static int place_work_vectors(pib_solver *s, int zidx, PlaceNeed *needs, int nn,
     if (fresh(&n1)) held.push_back(n1);
     if (n0 && n1) PIB_CHK(place_probe_ms(s, A.n, z, n0 + lo, n1 + lo, e0, e1, &tnb));
     if (debug) std::fprintf(stderr, "[place] neighbours %.3f ms\n", tnb);
-    for (int i = 0; i < nn; ++i) {
-        PIB_CHK(beside(s->work_split[needs[i].idx], needs[i], &needs[i].t_had));
-        needs[i].t_kept = needs[i].t_had;
-        needs[i].tslow = std::max(needs[i].kind == 0 ? tnb : 0.0, needs[i].t_had);
-        ++tried;
-        if (debug) std::fprintf(stderr, "[place] work vector %d (%p): %.3f ms\n", needs[i].idx, (void *)s->work_split[needs[i].idx], needs[i].t_had);
-    }
-    // Pair probe: two modes, 0.87-0.89 against 0.96-1.03 ms at 512^3 -- 0.925 of the slowest time seen separates them whatever
-    // the slow sample was.  The product: 2.23-2.26 ms at best, 2.45-2.50 at worst and levels in between (the output's class
-    // against the coefficients', the column indices', the input's: tools/spmv_placement_scan.py) -- a candidate is taken when
-    // it is 2 % better than what the solver has, and the search goes on until the product streams 6.15 TB/s of its algorithmic
-    // bytes (the best level is 6.2 for every matrix far beyond the caches, which is what place_min_rows selects; 5.9 with the
-    // compressed forms).
-    // (the bytes of the form the product streams: kernels_spmv.hip -- row patterns 8 nnz + 17 n, column codes 9 nnz + 20 n)
-    const double spmv_bytes = A.patterned ? (double)A.nnz * 8.0 + (double)A.n * 17.0
-                              : (double)A.nnz * (A.coded ? 9.0 : 12.0) + (double)A.n * (A.rp64 ? 24.0 : 20.0);
-    const double good_rate = (A.patterned || A.coded) ? 5.9e12 : 6.15e12;  // (the compressed forms' best level: 5.9-5.95)
-    auto good_product = [&](double t) { return spmv_bytes / (t * 1e-3) >= good_rate; };
-    auto takes = [&](const PlaceNeed &nd, double t) { return nd.kind == 0 ? t <= 0.925 * nd.tslow : t <= 0.98 * nd.t_kept; };
-    auto open_needs = [&]() {
-        int c = 0;
-        for (int i = 0; i < nn; ++i) {
-            PlaceNeed &nd = needs[i];
-            nd.met = nd.met || (nd.kind == 0 ? nd.t_kept <= 0.925 * nd.tslow : good_product(nd.t_kept));
-            c += nd.met ? 0 : 1;
-        }
-        return c;
-    };
-    int gap = 0;  // the next candidate comes 2^gap GiB further on (a candidate that was taken: its neighbour is tried next)
+    double t_had = 0.0;
+    PIB_CHK(place_probe_ms(s, A.n, z, v + lo, x, e0, e1, &t_had));
+    ++tried;
+    double t_kept = t_had, tslow = std::max(tnb, t_had);
+    *t_had_out = *t_kept_out = t_had;
+    if (debug) std::fprintf(stderr, "[place] work vector %d (%p): %.3f ms\n", idx, (void *)v, t_had);
+    // Two modes, 0.87-0.89 against 0.96-1.03 ms at 512^3 -- 0.925 of the slowest time seen separates them whatever the slow
+    // sample was.
+    int gap = 0;  // the next candidate comes 2^gap GiB further on
     bool first = true;
-    for (int k = 0, misses = 0; k < 24 && misses < s->cfg.place_candidates && open_needs() > 0; ++k) {
+    for (int k = 0; k < 8 && t_kept > 0.925 * tslow; ++k) {
         double *c = nullptr;
         if (first && n1 != nullptr)
             c = n1;
         else {
             if (gap > 0) {
-                const size_t step = (size_t)1 << (30 + std::min(gap, 6));  // 2, 4, 8, 16, 32, 64 GiB
+                size_t step = (size_t)1 << (30 + std::min(gap, 3));  // 2, 4, 8 GiB
+                // (a gap that does not fit any more shrinks to what does, down to the vector's own size: then the walk ends)
+                while (step > bytes && !room(step)) step >>= 1;
                 void *sp = nullptr;
-                if (step > bytes && room(step) && hipMalloc(&sp, step - bytes) == hipSuccess) held.push_back(sp), used += step - bytes;
+                if (step > bytes && hipMalloc(&sp, step - bytes) == hipSuccess) {
+                    held.push_back(sp), used += step - bytes;
+                    s->place_held_bytes = std::max(s->place_held_bytes, (int64_t)used);
+                }
                 (void)hipGetLastError();
             }
             if (!fresh(&c)) break;
             held.push_back(c);
         }
         first = false;
-        bool taken = false;
-        for (int i = 0; i < nn && !taken; ++i) {
-            if (needs[i].met) continue;
-            double t = 0.0;
-            PIB_CHK(beside(c, needs[i], &t));
-            ++tried;
-            if (debug) std::fprintf(stderr, "[place] step %d (gap %d): %p for work vector %d: %.3f ms\n", k, gap, (void *)c, needs[i].idx, t);
-            needs[i].tslow = std::max(needs[i].tslow, t);
-            if (takes(needs[i], t)) {
-                double *&v = s->work_split[needs[i].idx];
-                for (void *&h : held)
-                    if (h == (void *)c) h = (void *)v;  // the vector the solver had goes with the rejected ones
-                v = c;
-                needs[i].t_kept = t;
-                needs[i].met = needs[i].kind == 0 || good_product(t);
-                taken = true;
-                drop_iteration_graph(s);
-            }
+        double t = 0.0;
+        PIB_CHK(place_probe_ms(s, A.n, z, c + lo, x, e0, e1, &t));
+        ++tried;
+        if (debug) std::fprintf(stderr, "[place] step %d (gap %d): %p for work vector %d: %.3f ms\n", k, gap, (void *)c, idx, t);
+        tslow = std::max(tslow, t);
+        if (t <= 0.925 * tslow) {
+            for (void *&h : held)
+                if (h == (void *)c) h = (void *)v;  // the vector the solver had goes with the rejected ones
+            v = c;
+            t_kept = t;
+            drop_iteration_graph(s);
         }
-        gap = taken ? 0 : gap + 1;
-        misses += taken ? 0 : 1;
+        ++gap;
     }
     *tried_out = tried;
+    *t_kept_out = t_kept;
     return 0;
 }
 
-// CG's placements: p beside x (the p-update writes both), and -- with the residual update inside the V-cycle's first march -- the
-// two residual buffers beside the level-0 iterate that march writes with the new residual.
+// CG's placement: p beside x (the p-update reads and writes both).
 static int place_update_vector(pib_solver *s, int idx, int zidx, double *x)
 {
     const DeviceCsr &A = s->A;
     if (!s->cfg.place_update_vector || A.n < s->cfg.place_min_rows || A.n != A.n_global || x == nullptr || !aligned16(x)) return 0;
     if (x == s->placed_against || s->placements >= 3 || idx >= pib_solver::MAX_WORK) return 0;
-    PlaceNeed needs[4];
-    int nn = 0;
-    needs[nn++] = PlaceNeed{idx, {x, nullptr, nullptr}, 1};
-    if (s->cfg.place_product && s->A.val != nullptr && s->A.col != nullptr && !stencil_matmult_ok(s)) {  // (the CSR product, not the stencil twin)
-        needs[nn] = PlaceNeed{3, {nullptr, nullptr, nullptr}, 0};
-        needs[nn++].kind = 1;
-    }
-    if (s->cfg.place_residuals && s->cfg.fuse_residual_update && s->cfg.pc == Precond::GMG && !s->levels.empty() && s->levels[0].x != nullptr && s->placements == 0) {
-        GridLevel &g = s->levels[0];
-        if (aligned16(g.x + g.pad) && aligned16(g.x2 + g.pad) && g.nloc == A.n)
-            for (int r : {0, 4}) {
-                needs[nn] = PlaceNeed{r, {g.x + g.pad, g.x2 + g.pad, nullptr}, 2};
-                ++nn;
-            }
-    }
     int tried = 0;
-    PIB_CHK(place_work_vectors(s, zidx, needs, nn, &tried));
+    double t_had = 0.0, t_kept = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (place_walk(s, idx, zidx, x, &tried, &t_had, &t_kept) != 0) {
+        // optional: a failure inside the walk is not the solve's failure (the vector the solver has stays)
+        (void)hipGetLastError();
+        s->departures.push_back(std::string("placement: a search was abandoned (") + pib_last_error() + ")");
+    }
+    PIB_HIP(hipStreamSynchronize(s->stream));
+    s->place_search_ms += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     s->placed_against = x;
     s->placements++;
     s->place_tried = tried;
-    s->place_ms[0] = needs[0].t_had;
-    s->place_ms[1] = needs[0].t_kept;
+    s->place_ms[0] = t_had;
+    s->place_ms[1] = t_kept;
     return 0;
 }
 
@@ -1371,7 +1300,11 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     // never from this rank's own: all ranks take the fused form or none does)
     const bool fused_upd = gmg && s->cfg.fuse_residual_update && (lazy == 1 || (lazy == 2 && s->cfg.pin_sum_local != 0 && s->pin_row.ready)) &&
                            gmg_fused_update_ok(s);
-    const bool pin_local = gmg && lazy == 2 && s->pin_row.ready && (s->cfg.pin_sum_local == 1 || (s->cfg.pin_sum_local < 0 && fused_upd));
+    // (several ranks: pin_sigma exists on the rank that owns cell 0 only.  With the fused update the slabs are wall-bounded and
+    // thick enough that no other rank recomputes cell 0; without it -- a z-ring, where the last rank sees cell 0 as a halo cell
+    // across the seam, or thin slabs -- every rank takes the all-reduced red[5] instead, whatever pib_pin_sum_local asks for)
+    const bool pin_local = gmg && lazy == 2 && s->pin_row.ready && (s->cfg.pin_sum_local == 1 || (s->cfg.pin_sum_local < 0 && fused_upd)) &&
+                           (s->comm.nranks <= 1 || fused_upd);
     PinRowDev pin_dev{nullptr, 0, {}, {}};
     if (pin_local && A.row0 == 0 && s->pin_row.n > 0) {
         pin_dev.p = P;

@@ -1011,6 +1011,8 @@ static int ns_create_impl(pib_ns **out, int dim, const int64_t n_global[3], cons
         // once on stderr, never silently
         if (ns->psol->cfg.method == Method::CG) {
             ns->psol->cfg.method = Method::BICGSTAB;
+            ns->psol->departures.push_back("method: the file's cg runs as bicgstab (same preconditioner): a NEUMANN condition on a normal velocity "
+                                           "component makes DBNG non-symmetric (createdivergence.cpp:231-242)");
             std::fprintf(stderr, "[petibm_amd] poisson solver: a NEUMANN condition on a normal velocity component makes DBNG non-symmetric "
                                  "(createdivergence.cpp:231-242): CG of the solver file replaced by BiCGStab, same preconditioner\n");
         }
@@ -1719,6 +1721,18 @@ try {
     if (p_iters) *p_iters = ns->p_iters;
     if (p_res) *p_res = ns->p_res;
     return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
+}
+
+/* NavierStokesSolver::writeLinSolversInfo (navierstokes.cpp:780-787 prints both solvers' banners): what each solver of the engine
+ * RUNS -- pib_describe of the velocity (which = 0) or Poisson (1) solver, departures from their files included */
+int pib_ns_describe_solver(pib_ns *ns, int which, char *buf, int buflen)
+try {
+    if (ns == nullptr) return pib::fail(PIB_ERR_ARG_NULL, "null engine");
+    pib_solver *s = which == 0 ? ns->vsol : (which == 1 ? ns->psol : nullptr);
+    if (s == nullptr) return pib::fail(PIB_ERR_ARG_OUTOFRANGE, "pib_ns_describe_solver: no solver %d in this engine", which);
+    return pib_describe(s, buf, buflen);
 } catch (...) {
     return pib::fail_exception(__func__);
 }

@@ -179,14 +179,9 @@ struct Config {
     int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
     int side_x_update = 0;  // multigrid-PCG beyond the captured-graph size, at most side_x_max_rows local rows (a slab of a multi-GPU run): x += alpha p as a kernel of its own on a second stream beside the V-cycle's coarse levels instead of riding on the p-update (40 -> 24 B/row on the critical path).  OFF: measured SLOWER on the 512 x 512 x 64 slab (0.99 -> 1.03-1.67 ms per iteration, profiles/r05_slab_side_x_update.md) -- launched chip-wide the update takes the CU slots of the 2 M-cell levels' kernels, on a few workgroups it outlasts the cycle
     int64_t side_x_max_rows = (int64_t)1 << 25;
-    int64_t split_work_rows = (int64_t)1 << 25;  // one rank, systems of at least that many rows: every work vector of the Krylov methods an allocation of its own, split_work_gap_gib apart, instead of one pool (-1: the pool always) -- BiCGStab on the 400^3 velocity system (192 M rows): 88.2 -> 84.2 ms per solve split, 83.2 with 16 GiB gaps (profiles/r05_vector_placement_lab.txt)
-    int split_work_gap_gib = 0;  // (gaps: 83.2 against 84.2 ms on the 400^3 velocity system, nothing at 512^3 -- and memory the driver has just taken back is slow to hand out again: a first solve of seconds behind 64 GiB of gaps)
     int compress_columns = 2;  // what the CSR product streams besides the values, where the matrix allows: 2 one byte per ROW (the row's pattern of column offsets, DeviceCsr::pat_id: 73 instead of 104 B per 7-point row), 1 one byte per entry (DeviceCsr::code: 83 B), 0 the int32 columns and row offsets.  The same products in the same order, bit for bit
     int place_update_vector = 1;  // CG on one rank, systems of place_min_rows rows and more: the search direction p gets an allocation of its own, CHOSEN by timing the p-update's access pattern against the caller's x while walking through fresh allocations (krylov.hip, place_update_vector).  The flat update reads and writes both vectors, and its rate has two modes (6.3 against 5.6 TB/s at 512^3: 835 against 960 us, 8 % of the solve) set by which physical blocks the two sit in -- a property of the pair, the same for the life of the process, that no address arithmetic inside one allocation moves (profiles/r05_vector_placement_lab.txt)
-    int64_t place_min_rows = (int64_t)1 << 25;  // (measured on slabs of the 512^3 system: 2^24 rows no gain, 2^25 1.5 %, 2^26 2.6 %, 2^27 3 %)
-    int place_candidates = 4;  // candidates nobody took before the walk gives up (2, 4, 8, 16 GiB apart; 6: up to 126 GiB -- classes of 72 GiB have been seen, but a walk that long costs a second or more)
-    int place_product = 0;     // (off since the product streams row patterns: 1.72-1.78 -> 1.71 ms is all a better placed w gives it, and the need is never "met", so the walk runs to its end: 0.3-1.5 s in the first solve) ... and w, the CSR product's OUTPUT, by timing the product itself into each candidate: 2.24 against 2.48 ms at 512^3 by whether w shares the class of the matrix arrays (profiles/r05_vector_placement_lab.txt, the spmv scan)
-    int place_residuals = 0;   // (off: the first march gained 0.86 -> 0.80 ms on one box and lost 0.815 -> 0.84 on another -- the pair probe does not predict a kernel with three read and two written streams) ... and the two residual buffers of the fused residual update beside the level-0 iterate the V-cycle's first march writes with the new residual (k_presmooth2<0, 1>: 0.86 -> 0.80 ms at 512^3 where the process drew one class)
+    int64_t place_min_rows = (int64_t)1 << 25;  // one rank, systems of at least that many rows: every work vector of the Krylov methods an allocation of its own instead of one pool (-1: the pool always), and CG's search (measured on slabs of the 512^3 system: 2^24 rows no gain, 2^25 1.5 %, 2^26 2.6 %, 2^27 3 %)
     int merge_scalar_kernels = 1;  // ... and the one-workgroup kernels behind them in one launch: the sums' reduction, z[0] and (one rank) the iteration's scalar step (krylov.hip k_dots_tail); the residual sums + norm test likewise (k_finalize_post<8>)
     int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
@@ -451,6 +446,9 @@ struct Redist {
 struct pib_solver {
     std::string name, cfg_path, type_string;
     pib::Config cfg;
+    // where the backend departs from the solver file (pib_describe, printInfo): one sentence per departure, in the order they
+    // were decided -- e.g. CG of the file replaced by BiCGStab for a non-symmetric DBNG (navierstokes.hip ns_create)
+    std::vector<std::string> departures;
     pib::Comm comm;
     int device = 0;
     hipStream_t stream = nullptr, stream_comm = nullptr;
@@ -491,6 +489,7 @@ struct pib_solver {
     int n_work = 0;
     double *x_dev = nullptr, *b_dev = nullptr;  // staging for host-pointer callers
     int64_t stage_n = 0;
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};  // bracket the copies of a host-vector caller's b / guess (read after the solve)
     double stage_ms[2] = {0.0, 0.0};  // host-vector callers: what the last solve spent copying b (+ the guess) in / x out (pib_get_staging_ms)
     pib::Scalars *d_s = nullptr, *h_s = nullptr;
     double *d_part = nullptr;  // [PIB_NRED][PIB_MAXPART]
@@ -562,6 +561,8 @@ struct pib_solver {
     const double *placed_against = nullptr;  // the x that p was last placed against (place_update_vector)
     int placements = 0, place_tried = 0;     // searches run (at most 3 in a solver's life), candidates timed by the last one
     double place_ms[2] = {0.0, 0.0};         // the probe with the vector the solver had / with the one it kept
+    int64_t place_held_bytes = 0;            // the most a search held at one time (gaps, reference vectors, rejected candidates)
+    double place_search_ms = 0.0;            // wall time of all searches
     double *vec(int i) const { return (work_split[i] != nullptr ? work_split[i] : work + (int64_t)i * work_stride) + work_lo; }
 };
 

@@ -90,9 +90,19 @@ class LinSolverBase:
     def getType(self) -> str:
         return self.type
 
+    def describe(self) -> str:
+        """pib_describe: what this solver runs -- first line key=value pairs, then one 'departure: ...' line per place where
+        the backend departs from the solver file"""
+        buf = C.create_string_buffer(4096)
+        capi.check(capi.load().pib_describe(self._h, buf, 4096))
+        return buf.value.decode()
+
     def printInfo(self) -> str:
+        """the reference's banner (src/linsolver/linsolver.cpp:29-41) + what actually runs"""
         info = "=" * 80 + f"\nLinear Solver {self.name}:\n" + "=" * 80 + "\n"
         info += f"\tType: {self.type}\n\n\tConfig file: {self.config}\n\n"
+        if self._h:
+            info += "".join(f"\tRuns: {ln}\n" for ln in self.describe().splitlines()) + "\n"
         print(info, end="")
         return info
 
@@ -285,16 +295,22 @@ class LinSolverBase:
         return a.value, b.value
 
     def productIndexBytes(self) -> int:
-        """bytes per matrix entry the CSR product reads besides the value: 4 (int32 column) or 1 (pib_compress_columns)"""
+        """bytes per matrix entry the CSR product reads besides the value: 4 (int32 column), 1 (pib_compress_columns=1: a column
+        code per entry) or 0 (pib_compress_columns=2, the default: one pattern byte per ROW)"""
         v = C.c_int()
         capi.check(capi.load().pib_get_product_format(self._h, C.byref(v)))
         return v.value
 
     def placement(self):
         """(searches, candidates, ms_had, ms_kept) of the search direction's placement against x (pib_get_placement); zeros when none ran"""
-        a, b, c, d = C.c_int(), C.c_int(), C.c_double(), C.c_double()
-        capi.check(capi.load().pib_get_placement(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return a.value, b.value, c.value, d.value
+        return self.placementInfo()[:4]
+
+    def placementInfo(self):
+        """(searches, candidates, ms_had, ms_kept, held_bytes, search_ms): ... plus the most bytes a search held at one time and
+        the wall time of all searches"""
+        a, b, c, d, e, f = C.c_int(), C.c_int(), C.c_double(), C.c_double(), C.c_int64(), C.c_double()
+        capi.check(capi.load().pib_get_placement(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), C.byref(f)))
+        return a.value, b.value, c.value, d.value, e.value, f.value
 
     def deviceVec(self, n: Optional[int] = None) -> DeviceVec:
         return DeviceVec(self, self.n_local if n is None else n)

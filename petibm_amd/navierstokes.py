@@ -367,6 +367,12 @@ class NavierStokesSolver:
         capi.check(capi.load().pib_ns_get_solver_info(self._h, C.byref(vi), C.byref(vr), C.byref(pi), C.byref(pr)))
         return self.ite, vi.value, vr.value, pi.value, pr.value
 
+    def describeSolver(self, which: str) -> str:
+        """what the engine's 'velocity' / 'poisson' solver RUNS (pib_describe), departures from its file included"""
+        buf = C.create_string_buffer(4096)
+        capi.check(capi.load().pib_ns_describe_solver(self._h, {"velocity": 0, "poisson": 1}[which], buf, 4096))
+        return buf.value.decode()
+
     def destroy(self):
         if self._h:
             capi.load().pib_ns_destroy(self._h)

@@ -204,6 +204,11 @@ def test_time_step_with_a_neumann_outlet_on_the_normal_component_matches_oracle(
     ref.set_state(U0, p0)
     s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=AMGX_P)
     assert "replaced by BiCGStab" in capfd.readouterr().err
+    # ... and through the API, not on stderr only (pib_describe): the method that runs, and the departure from the file
+    d = s.describeSolver("poisson")
+    assert "method=bicgstab" in d.splitlines()[0] and 'type="NVIDIA AmgX"' in d.splitlines()[0]
+    assert any(ln.startswith("departure: method: the file's cg runs as bicgstab") for ln in d.splitlines()[1:])
+    assert "method=bicgstab" in s.describeSolver("velocity").splitlines()[0] and "departure: method" not in s.describeSolver("velocity")
     s.setState(U0, p0)
     for step in range(3):
         ref.advance()

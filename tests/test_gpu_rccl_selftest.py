@@ -29,6 +29,18 @@ def test_rccl_entry_points_in_a_one_rank_world(n_owned, ghost):
     assert err.value == 0.0
 
 
+def test_comm_latency_in_its_own_one_rank_world():
+    """pib_comm_latency(NULL, ...) builds its own one-rank RCCL world (tools/comm_latency.py): ONE holder adopts the
+    communicator (a second adoption destroyed it under the exchanges -- round-5 advisor finding); both timings come back
+    positive and a second call in the same process works (the first one's communicator was destroyed exactly once)."""
+    from petibm_amd import capi
+    lib = capi.load()
+    for _ in range(2):
+        us = (C.c_double * 2)(-1.0, -1.0)
+        capi.check(lib.pib_comm_latency(None, 1024, 5, us))
+        assert us[0] > 0.0 and us[1] > 0.0
+
+
 def test_selftest_rejects_a_halo_wider_than_the_slab():
     from petibm_amd import capi
     lib = capi.load()
