@@ -168,9 +168,6 @@ try {
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
     for (hipEvent_t e : s->ev_stage)
         if (e) (void)hipEventDestroy(e);
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->ev_side) (void)hipEventDestroy(s->ev_side);
-    if (s->stream_side) (void)hipStreamDestroy(s->stream_side);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->stream_comm) (void)hipStreamDestroy(s->stream_comm);
     delete s;

@@ -291,7 +291,6 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.graph_max_rows = std::atoll(d.get("default", "pib_graph_max_rows", "4194304").c_str());
     c.spmv_variant = std::atoi(d.get("default", "pib_spmv_variant", "0").c_str());
     c.overlap_halo = std::atoi(d.get("default", "pib_overlap_halo", "1").c_str());
-    c.fuse_dots = std::atoi(d.get("default", "pib_fuse_dots", "1").c_str());
     c.fuse_presmooth = std::atoi(d.get("default", "pib_fuse_presmooth", "1").c_str());
     c.march_restrict = std::atoi(d.get("default", "pib_march_restrict", "1").c_str());
     c.fuse_residual_restrict = std::atoi(d.get("default", "pib_fuse_residual_restrict", "1").c_str());
@@ -303,17 +302,11 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.matrix_free_velocity = std::atoi(d.get("default", "pib_matrix_free_velocity", "1").c_str());
     c.march_velocity = std::atoi(d.get("default", "pib_march_velocity", "1").c_str());
     c.fuse_velocity_product = std::atoi(d.get("default", "pib_fuse_velocity_product", "1").c_str());
-    c.velocity_march_planes = std::atoi(d.get("default", "pib_velocity_march_planes", "16").c_str());
-    c.velocity_tile_edges = std::atoi(d.get("default", "pib_velocity_tile_edges", "1").c_str());
     c.redistribute_velocity = std::atoi(d.get("default", "pib_redistribute_velocity", "1").c_str());
     c.lean_bicgstab = std::atoi(d.get("default", "pib_lean_bicgstab", "1").c_str());
-    c.blocked_reductions = std::atoi(d.get("default", "pib_blocked_reductions", "1").c_str());
     c.fuse_bicgstab_dots = std::atoi(d.get("default", "pib_fuse_bicgstab_dots", "1").c_str());
     c.fuse_residual_update = std::atoi(d.get("default", "pib_fuse_residual_update", "1").c_str());
     c.pin_sum_local = std::atoi(d.get("default", "pib_pin_sum_local", "-1").c_str());
-    c.merge_scalar_kernels = std::atoi(d.get("default", "pib_merge_scalar_kernels", "1").c_str());
-    c.side_x_update = std::atoi(d.get("default", "pib_side_x_update", "0").c_str());
-    c.side_x_max_rows = std::atoll(d.get("default", "pib_side_x_max_rows", "33554432").c_str());
     c.compress_columns = std::atoi(d.get("default", "pib_compress_columns", "2").c_str());
     c.place_update_vector = std::atoi(d.get("default", "pib_place_update_vector", "1").c_str());
     c.place_min_rows = std::atoll(d.get("default", "pib_place_min_rows", "33554432").c_str());
@@ -322,7 +315,6 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.sweep_pairs = std::atoi(d.get("default", "pib_sweep_pairs", "1").c_str());
     c.fuse_chebyshev_update = std::atoi(d.get("default", "pib_fuse_chebyshev_update", "1").c_str());
     c.blocked_direct_solve = std::atoi(d.get("default", "pib_blocked_direct_solve", "1").c_str());
-    c.accumulate_unscaled_x = std::atoi(d.get("default", "pib_accumulate_unscaled_x", "1").c_str());
     c.bicgstab_merge_r = std::atoi(d.get("default", "pib_bicgstab_merge_r", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
@@ -333,8 +325,6 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "-1").c_str());
     c.coarse_tail_lds = std::atoi(d.get("default", "pib_coarse_tail_lds", "1").c_str());
     c.fuse_small_levels = std::atoi(d.get("default", "pib_fuse_small_levels", "1").c_str());
-    c.small_level_cells = std::atoi(d.get("default", "pib_small_level_cells", "300000").c_str());
-    c.small_level_cells_3d = std::atoi(d.get("default", "pib_small_level_cells_3d", "40000").c_str());
     if (d.has("default", "pib_initial_guess_nonzero"))
         c.initial_guess_nonzero = truthy(d.get("default", "pib_initial_guess_nonzero", "1"));
     if (d.has("default", "pib_norm")) {
@@ -438,7 +428,6 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_graph_max_rows", v)) c.graph_max_rows = std::atoll(v.c_str());
     if (get("pib_spmv_variant", v)) c.spmv_variant = std::atoi(v.c_str());
     if (get("pib_overlap_halo", v)) c.overlap_halo = std::atoi(v.c_str());
-    if (get("pib_fuse_dots", v)) c.fuse_dots = std::atoi(v.c_str());
     if (get("pib_fuse_presmooth", v)) c.fuse_presmooth = std::atoi(v.c_str());
     if (get("pib_march_restrict", v)) c.march_restrict = std::atoi(v.c_str());
     if (get("pib_fuse_residual_restrict", v)) c.fuse_residual_restrict = std::atoi(v.c_str());
@@ -450,17 +439,11 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_matrix_free_velocity", v)) c.matrix_free_velocity = std::atoi(v.c_str());
     if (get("pib_march_velocity", v)) c.march_velocity = std::atoi(v.c_str());
     if (get("pib_fuse_velocity_product", v)) c.fuse_velocity_product = std::atoi(v.c_str());
-    if (get("pib_velocity_march_planes", v)) c.velocity_march_planes = std::atoi(v.c_str());
-    if (get("pib_velocity_tile_edges", v)) c.velocity_tile_edges = std::atoi(v.c_str());
     if (get("pib_redistribute_velocity", v)) c.redistribute_velocity = std::atoi(v.c_str());
     if (get("pib_lean_bicgstab", v)) c.lean_bicgstab = std::atoi(v.c_str());
-    if (get("pib_blocked_reductions", v)) c.blocked_reductions = std::atoi(v.c_str());
     if (get("pib_fuse_bicgstab_dots", v)) c.fuse_bicgstab_dots = std::atoi(v.c_str());
     if (get("pib_fuse_residual_update", v)) c.fuse_residual_update = std::atoi(v.c_str());
     if (get("pib_pin_sum_local", v)) c.pin_sum_local = std::atoi(v.c_str());
-    if (get("pib_merge_scalar_kernels", v)) c.merge_scalar_kernels = std::atoi(v.c_str());
-    if (get("pib_side_x_update", v)) c.side_x_update = std::atoi(v.c_str());
-    if (get("pib_side_x_max_rows", v)) c.side_x_max_rows = std::atoll(v.c_str());
     if (get("pib_compress_columns", v)) c.compress_columns = std::atoi(v.c_str());
     if (get("pib_place_update_vector", v)) c.place_update_vector = std::atoi(v.c_str());
     if (get("pib_place_min_rows", v)) c.place_min_rows = std::atoll(v.c_str());
@@ -470,7 +453,6 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_sweep_pairs", v)) c.sweep_pairs = std::atoi(v.c_str());
     if (get("pib_fuse_chebyshev_update", v)) c.fuse_chebyshev_update = std::atoi(v.c_str());
     if (get("pib_blocked_direct_solve", v)) c.blocked_direct_solve = std::atoi(v.c_str());
-    if (get("pib_accumulate_unscaled_x", v)) c.accumulate_unscaled_x = std::atoi(v.c_str());
     if (get("pib_bicgstab_merge_r", v)) c.bicgstab_merge_r = std::atoi(v.c_str());
     if (get("pib_matrix_free_poisson", v)) c.matrix_free_poisson = std::atoi(v.c_str());
     if (get("pib_agglomerate_below", v)) c.agglomerate_below = std::atoi(v.c_str());
@@ -481,8 +463,6 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_coarse_tail", v)) c.coarse_tail = std::atoi(v.c_str());
     if (get("pib_coarse_tail_lds", v)) c.coarse_tail_lds = std::atoi(v.c_str());
     if (get("pib_fuse_small_levels", v)) c.fuse_small_levels = std::atoi(v.c_str());
-    if (get("pib_small_level_cells", v)) c.small_level_cells = std::atoi(v.c_str());
-    if (get("pib_small_level_cells_3d", v)) c.small_level_cells_3d = std::atoi(v.c_str());
     if (get("pib_presweeps", v)) c.presweeps = std::atoi(v.c_str());
     if (get("pib_postsweeps", v)) c.postsweeps = std::atoi(v.c_str());
     if (get("pib_cheby_degree", v)) c.cheby_degree = std::atoi(v.c_str());

@@ -3382,16 +3382,17 @@ static int launch_prolong(const GridLevel &f, const GridLevel &c, const double *
 // `c` carries the coarse planes to produce in k0 / k1 (the owned ones, which may be a part of a replicated level)
 // the small-level kernels' box of coarse cells per workgroup (k_small_down: steps = pre, k_small_up: steps = post); false:
 // the level does not qualify
+constexpr int64_t SMALL_LEVEL_CELLS = 300000, SMALL_LEVEL_CELLS_3D = 40000;  // levels of at most this many cells (3-D: the margins cost more)
 static bool small_level_boxes(const pib_solver *s, const GridLevel &f, const GridLevel &c, int steps, bool down, int bc[3], unsigned *blocks)
 {
     if (!s->cfg.fuse_small_levels || steps < 1 || steps > 2) return false;
-    if (f.nloc > (int64_t)s->cfg.small_level_cells || f.zring || c.zring) return false;
+    if (f.nloc > SMALL_LEVEL_CELLS || f.zring || c.zring) return false;
     if (f.k0 != 0 || f.k1 != f.n[2] || c.k0 != 0 || c.k1 != c.n[2]) return false;  // both levels whole on this rank
     if (f.per != f.tper) return false;
     int nt = 0;
     for (int d = 0; d < 3; ++d) nt += f.n[d] > 1 ? 1 : 0;
     // a 3-D level pays 5-13 x in recomputed margins, all of it instruction issue on the workgroup's one CU
-    if (nt == 3 && f.nloc > (int64_t)s->cfg.small_level_cells_3d) return false;
+    if (nt == 3 && f.nloc > SMALL_LEVEL_CELLS_3D) return false;
     // boxes of 4^3 coarse cells on a 3-D level; 8^2 on a 2-D one while that gives at most one workgroup per CU (the kernels
     // hold one workgroup per CU: a second round of workgroups doubles the launch's time), else 16^2
     for (int side = (nt == 3 ? 4 : 8);; side *= 2) {
@@ -4312,11 +4313,6 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         GridLevel &g = s->levels[(size_t)l];
         const LI &I = li[(size_t)l];
         const int64_t pl = g.plane;
-        // (the cycle has left level 0: what the solver wants to run beside the coarse levels is forked here)
-        if (l == 1 && s->gmg_side_hook != nullptr && !s->gmg_side_launched) {
-            PIB_CHK(s->gmg_side_hook(s, q));
-            s->gmg_side_launched = true;
-        }
         if (l == tail0) {
             TailArgs T;
             std::memset(&T, 0, sizeof T);

@@ -179,7 +179,7 @@ static int launch_vec(pib_solver *s, int64_t n, const Op &op, bool vec2, int slo
         }
     }
     int64_t per = 0;
-    if (s->cfg.blocked_reductions && ng >= ((int64_t)1 << 22)) per = (((ng + nb - 1) / nb + 255) / 256) * 256;
+    if (ng >= ((int64_t)1 << 22)) per = (((ng + nb - 1) / nb + 255) / 256) * 256;
     if (vec2)
         hipLaunchKernelGGL((k_vec<2, Op>), dim3(nb), dim3(256), 0, stq, S, n, op, part, e_begin, e_end, per);
     else
@@ -993,8 +993,8 @@ static int gmg_pc_and_dots(pib_solver *s, const double *R, double *Z, bool guard
     int nb = 0;
     if (post_done) *post_done = false;
     s->gmg_guarded = guarded;
-    s->gmg_want_dots = (s->cfg.fuse_dots != 0);
-    s->gmg_defer_dots = guarded && s->cfg.merge_scalar_kernels != 0;
+    s->gmg_want_dots = true;
+    s->gmg_defer_dots = guarded;
     const int err = gmg_apply(s, R, Z, q);
     s->gmg_want_dots = false;
     s->gmg_defer_dots = false;
@@ -1338,7 +1338,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     };
     auto after_update = +[](pib_solver *ps, int nblocks, hipStream_t st) -> int {
         // r.r and sum r of the new residual from the march's partials (slots 4, 5), then the convergence step on |r|
-        if (ps->comm.nranks == 1 && upd_ctx.unprec && ps->cfg.merge_scalar_kernels)  // (POST 8: the two sums, then cg_s2's norm step)
+        if (ps->comm.nranks == 1 && upd_ctx.unprec)  // (POST 8: the two sums, then cg_s2's norm step)
             return finalize_post<8>(ps, 4, 2, nblocks, upd_ctx.hist, upd_ctx.conv_is_its, st);
         hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, st, ps->d_s, ps->d_part, 4, nblocks);
         PIB_HIP(hipGetLastError());
@@ -1353,46 +1353,8 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     int enq = 0;
     const int maxit = s->cfg.max_iters;
     double *part_pw = s->d_part + (int64_t)SLOT_PW * PIB_MAXPART;
-    // Slab-sized systems (round 5): x += alpha p leaves the p-update -- which then moves 24 instead of 40 B/row on the critical
-    // path -- and runs as the `owed update` kernels below on a stream of its own, forked by the V-cycle when it leaves level 0
-    // (gmg.hip gmg_side_hook) and joined ahead of the next p-update: beside the coarse levels, which leave the HBM idle.  The
-    // owed / applied counters of the scalars keep it exact: a live iteration's update is applied once, an over-enqueued one's never.
-    const bool side_x = gmg && s->cfg.side_x_update && n > s->cfg.graph_max_rows && n <= s->cfg.side_x_max_rows && s->levels.size() >= 2;
-    struct SideCtx {
-        int64_t n;
-        const double *p;
-        double *x;
-    };
-    static thread_local SideCtx side_ctx;
-    side_ctx = SideCtx{n, P, x};
-    bool side_pending = false;
-    auto side_hook = +[](pib_solver *ps, hipStream_t main) -> int {
-        const SideCtx &c = *static_cast<const SideCtx *>(ps->gmg_side_ctx);
-        PIB_HIP(hipEventRecord(ps->ev_fork, main));
-        PIB_HIP(hipStreamWaitEvent(ps->stream_side, ps->ev_fork, 0));
-        // (a FEW workgroups walking the vector: launched chip-wide, the update's workgroups took the CU slots of the 2 M-cell
-        // levels' kernels and stretched those from 13 to 78 us each -- profiles/r05_slab_side_x_update.md)
-        static const int side_blocks = std::getenv("PIB_SIDE_X_BLOCKS") ? std::max(1, std::atoi(std::getenv("PIB_SIDE_X_BLOCKS"))) : 128;
-        hipLaunchKernelGGL(k_flush_x, dim3((unsigned)std::min<int64_t>(side_blocks, std::max<int64_t>(1, (c.n + 255) / 256))), dim3(256), 0, ps->stream_side,
-                           ps->d_s, c.n, c.p, c.x, 0);
-        hipLaunchKernelGGL(k_flush_done, dim3(1), dim3(1), 0, ps->stream_side, ps->d_s, 0);
-        PIB_HIP(hipGetLastError());
-        PIB_HIP(hipEventRecord(ps->ev_side, ps->stream_side));
-        return 0;
-    };
-    if (side_x) {
-        if (s->stream_side == nullptr) PIB_HIP(hipStreamCreateWithFlags(&s->stream_side, hipStreamNonBlocking));
-        if (s->ev_fork == nullptr) PIB_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-        if (s->ev_side == nullptr) PIB_HIP(hipEventCreateWithFlags(&s->ev_side, hipEventDisableTiming));
-    }
-    auto join_side = [&]() -> int {
-        if (side_pending) PIB_HIP(hipStreamWaitEvent(q, s->ev_side, 0));
-        side_pending = false;
-        return 0;
-    };
     // the x update the last iteration owes
     auto flush = [&](int if_done) {
-        (void)join_side();
         hipLaunchKernelGGL(k_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
                            s->d_s, n, P, x, if_done);
         hipLaunchKernelGGL(k_flush_done, dim3(1), dim3(1), 0, q, s->d_s, if_done);
@@ -1407,17 +1369,16 @@ int solve_cg(pib_solver *s, double *x, const double *b)
     while (!s->h_s->done && enq < maxit) {
         const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
         auto body = [&]() -> int {
-            PIB_CHK(join_side());  // (the previous iteration's x += alpha p reads the p this iteration is about to overwrite)
             const int64_t zv = gmg ? (int64_t)s->z_halo_depth * s->levels[0].plane : 0;
             if (s->comm.nranks > 1 && zv > 0 && zv >= A.ghost_lo && zv >= A.ghost_hi) {
                 // the V-cycle left z valid on the ghost planes the matrix reaches: p = z + beta p there too (the ghost
                 // values of p follow the same recurrence as their owners'), and the product needs no exchange
                 const bool ev = (A.ghost_lo & 1) == 0 && (n & 1) == 0 && xal;
-                OpUpdateP up{Z - A.ghost_lo, P - A.ghost_lo, side_x ? nullptr : x - A.ghost_lo, A.ghost_lo, A.ghost_lo + n, 0.0, 0.0, 0.0, 0, 0};
+                OpUpdateP up{Z - A.ghost_lo, P - A.ghost_lo, x - A.ghost_lo, A.ghost_lo, A.ghost_lo + n, 0.0, 0.0, 0.0, 0, 0};
                 PIB_CHK(launch_vec(s, n + A.ghost_lo + A.ghost_hi, up, ev, 0, nullptr, true, q));
                 s->halo_fresh = P;
             } else {
-                OpUpdateP up{Z, P, side_x ? nullptr : x, 0, n, 0.0, 0.0, 0.0, 0, 0};
+                OpUpdateP up{Z, P, x, 0, n, 0.0, 0.0, 0.0, 0, 0};
                 PIB_CHK(update_p_and_exchange(s, n, up, P, q, xal));
             }
             PIB_CHK(matmult(s, P, W, part_pw, true, q));
@@ -1428,23 +1389,6 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 hipLaunchKernelGGL(k_cg_s1, dim3(1), dim3(1), 0, q, s->d_s, pin_dev);
             }
             s->gmg_pin_local = pin_local;  // (read by gmg_apply while the body is enqueued or captured; cleared behind the loop)
-            struct SideGuard {  // the fork's hook for THIS iteration's cycle; if the cycle never got below level 0, the update runs here
-                pib_solver *s;
-                bool on;
-                ~SideGuard() { s->gmg_side_hook = nullptr; }
-            } side_guard{s, side_x};
-            if (side_x) {
-                s->gmg_side_hook = side_hook;
-                s->gmg_side_ctx = &side_ctx;
-                s->gmg_side_launched = false;
-            }
-            auto side_after = [&]() -> int {
-                if (!side_x) return 0;
-                if (!s->gmg_side_launched) PIB_CHK(side_hook(s, q));
-                s->gmg_side_hook = nullptr;
-                side_pending = true;
-                return 0;
-            };
             if (fused_upd) {
                 s->gmg_upd.w = W;
                 s->gmg_upd.r_old = R;
@@ -1461,7 +1405,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 s->counters[6]++;
                 if (!closed) hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, unprec ? 0 : 1, 1, conv_is_its);
                 PIB_HIP(hipGetLastError());
-                return side_after();
+                return 0;
             }
             if (pc == Precond::JACOBI) {
                 OpUpdateXR<PCM_JACOBI> op{W, A.dinv, R, Z, omega, 0.0};
@@ -1470,7 +1414,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 OpUpdateXR<PCM_NONE> op{W, nullptr, R, Z, 1.0, 0.0};
                 PIB_CHK(launch_vec(s, n, op, true, 0, &nb, true, q));
             }
-            const bool merged6 = gmg && unprec && s->comm.nranks == 1 && s->cfg.merge_scalar_kernels;
+            const bool merged6 = gmg && unprec && s->comm.nranks == 1;
             if (merged6) PIB_CHK(finalize_post<8>(s, 0, 6, nb, s->d_hist, conv_is_its, q));
             else PIB_CHK(finalize(s, 0, 6, nb, q));
             if (gmg) {
@@ -1486,7 +1430,7 @@ int solve_cg(pib_solver *s, double *x, const double *b)
                 hipLaunchKernelGGL(k_cg_s2, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, ng, lazy, 1, 1, conv_is_its);
             }
             PIB_HIP(hipGetLastError());
-            return side_after();
+            return 0;
         };
         PIB_CHK(run_iterations(s, todo, enq, graph_key(1, x, b), q, body));
         const bool first = enq == 0;
@@ -2242,7 +2186,7 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
                         reinterpret_cast<uintptr_t>(T)) & 31u) == 0;
     const bool fused_dots = lean && s->cfg.fuse_bicgstab_dots;
     // ... and x accumulated before the Jacobi sweep (OpBFUpdateP::y) in the vector the general path keeps M^-1 p in
-    double *Y = (fused_dots && s->cfg.accumulate_unscaled_x) ? s->vec(7) : nullptr;
+    double *Y = fused_dots ? s->vec(7) : nullptr;
     // ... and the residual update merged into the next p-update, |r|^2 and r.rp out of the second product's sums
     const bool merge_r = Y != nullptr && s->cfg.bicgstab_merge_r;
     if (lean && jac && !one_rank) {

@@ -270,6 +270,93 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity_shell(NsDev D, int f, i
     }
 }
 
+// rhs1, -N(u) and nu (L u) at an INTERIOR point of component F from the values its stencils read (no ghost value, no ghost
+// equation, no periodic wrap: the boundary terms are exact zeros): the operations of rhs_velocity_point in the same order.  Shared
+// by the per-component interior kernel and the three-component march below -- one text, so both give the same bits.
+//   a0..a3: the first of the other components' values of N(u) (v for u; u for v and w), c0..c3 the second (w for u and v; v for w)
+template <int DIM, int F>
+__device__ __forceinline__ void rhs_interior_arith(const NsTime &T, double dt, double nu, double p0, double p1, double self, double uxm, double uxp,
+                                                   double uym, double uyp, double uzm, double uzp, double a0, double a1, double a2, double a3,
+                                                   double c0, double c1, double c2, double c3, double cold, double dold, double dLx, double dLy,
+                                                   double dLz, double gv, double xNeg, double xPos, double yNeg, double yPos, double zNeg,
+                                                   double zPos, double &cn, double &df, double &r)
+{
+    // ---- G p
+    r = 0.0 + (-gv) * p0;
+    r = r + gv * p1;
+    r = -1.0 * r;
+    r = r + (1.0 / dt) * self;
+    // ---- N(u)  (createconvection.cpp:40-195)
+    cn = 0.0;
+    if (T.nconv > 0) {
+        const double W = (self + uxm) / 2.0, E = (self + uxp) / 2.0;
+        const double S = (self + uym) / 2.0, N = (self + uyp) / 2.0;
+        double B = 0.0, Fw = 0.0;
+        if (DIM == 3) {
+            B = (self + uzm) / 2.0;
+            Fw = (self + uzp) / 2.0;
+        }
+        double cv;
+        if (F == 0) {
+            const double vS = (a0 + a1) / 2.0;
+            const double vN = (a2 + a3) / 2.0;
+            cv = (E * E - W * W) / dLx + (vN * N - vS * S) / dLy;
+            if (DIM == 3) {
+                const double wB = (c0 + c1) / 2.0;
+                const double wF = (c2 + c3) / 2.0;
+                cv = cv + (wF * Fw - wB * B) / dLz;
+            }
+        } else if (F == 1) {
+            const double uW = (a0 + a1) / 2.0;
+            const double uE = (a2 + a3) / 2.0;
+            cv = (uE * E - uW * W) / dLx + (N * N - S * S) / dLy;
+            if (DIM == 3) {
+                const double wB = (c0 + c1) / 2.0;
+                const double wF = (c2 + c3) / 2.0;
+                cv = cv + (wF * Fw - wB * B) / dLz;
+            }
+        } else {
+            const double uW = (a0 + a1) / 2.0;
+            const double uE = (a2 + a3) / 2.0;
+            const double vS = (c0 + c1) / 2.0;
+            const double vN = (c2 + c3) / 2.0;
+            cv = (uE * E - uW * W) / dLx + (vN * N - vS * S) / dLy + (Fw * Fw - B * B) / dLz;
+        }
+        cn = -1.0 * cv;
+        r = r + T.cc[0] * cn;
+        if (T.nconv > 1) r = r + T.cc[1] * cold;
+    }
+    // ---- L u in the row's column order z-, y-, x-, diag, x+, y+, z+ ; no ghost point: the corrections are zero
+    double acc = 0.0;
+    acc = acc + xNeg;
+    acc = acc + xPos;
+    acc = acc + yNeg;
+    acc = acc + yPos;
+    if (DIM == 3) {
+        acc = acc + zNeg;
+        acc = acc + zPos;
+    }
+    const double diag = -acc;
+    double lu = 0.0;
+    if (DIM == 3) lu = lu + zNeg * uzm;
+    lu = lu + yNeg * uym;
+    lu = lu + xNeg * uxm;
+    lu = lu + diag * self;
+    lu = lu + xPos * uxp;
+    lu = lu + yPos * uyp;
+    if (DIM == 3) lu = lu + zPos * uzp;
+    const double lc = 0.0, lcn = 0.0;
+    df = 0.0;
+    if (T.ndiff > 0) {
+        df = lu + lc;
+        df = nu * df;
+        r = r + T.dc[0] * df;
+        if (T.ndiff > 1) r = r + T.dc[1] * dold;
+    }
+    const double b1 = nu * lcn;
+    r = r + T.cimpl * b1;
+}
+
 // The interior of component F (every index in [1, n-2]: no ghost value, no ghost equation, no periodic wrap in the
 // stencil): grid (x chunks, j-1, k-1), so j and k are workgroup-uniform (their mesh coefficients come through the scalar
 // path, no per-point division) and a lane walks i; branch-free, direct loads, the operations of rhs_velocity_point in
@@ -352,86 +439,173 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
         const double dLx = Fd.dl[0][i + 1];
         const double gv = (F == 0) ? Fd.ginv[i] : gvyz;
         const double xNeg = Fd.lneg[0][i], xPos = Fd.lpos[0][i];
-        // ---- G p
-        double r = 0.0 + (-gv) * p0;
-        r = r + gv * p1;
-        r = -1.0 * r;
-        r = r + (1.0 / dt) * self;
-        // ---- N(u)  (createconvection.cpp:40-195)
-        double cn = 0.0;
-        if (T.nconv > 0) {
-            const double W = (self + uxm) / 2.0, E = (self + uxp) / 2.0;
-            const double S = (self + uym) / 2.0, N = (self + uyp) / 2.0;
-            double B = 0.0, Fw = 0.0;
-            if (DIM == 3) {
-                B = (self + uzm) / 2.0;
-                Fw = (self + uzp) / 2.0;
-            }
-            double cv;
-            if (F == 0) {
-                const double vS = (a0 + a1) / 2.0;
-                const double vN = (a2 + a3) / 2.0;
-                cv = (E * E - W * W) / dLx + (vN * N - vS * S) / dLy;
-                if (DIM == 3) {
-                    const double wB = (c0 + c1) / 2.0;
-                    const double wF = (c2 + c3) / 2.0;
-                    cv = cv + (wF * Fw - wB * B) / dLz;
-                }
-            } else if (F == 1) {
-                const double uW = (a0 + a1) / 2.0;
-                const double uE = (a2 + a3) / 2.0;
-                cv = (uE * E - uW * W) / dLx + (N * N - S * S) / dLy;
-                if (DIM == 3) {
-                    const double wB = (c0 + c1) / 2.0;
-                    const double wF = (c2 + c3) / 2.0;
-                    cv = cv + (wF * Fw - wB * B) / dLz;
-                }
-            } else {
-                const double uW = (a0 + a1) / 2.0;
-                const double uE = (a2 + a3) / 2.0;
-                const double vS = (c0 + c1) / 2.0;
-                const double vN = (c2 + c3) / 2.0;
-                cv = (uE * E - uW * W) / dLx + (vN * N - vS * S) / dLy + (Fw * Fw - B * B) / dLz;
-            }
-            cn = -1.0 * cv;
-            r = r + T.cc[0] * cn;
-            if (T.nconv > 1) r = r + T.cc[1] * cold;
-        }
-        // ---- L u in the row's column order z-, y-, x-, diag, x+, y+, z+ ; no ghost point: the corrections are zero
-        double acc = 0.0;
-        acc = acc + xNeg;
-        acc = acc + xPos;
-        acc = acc + yNeg;
-        acc = acc + yPos;
-        if (DIM == 3) {
-            acc = acc + zNeg;
-            acc = acc + zPos;
-        }
-        const double diag = -acc;
-        double lu = 0.0;
-        if (DIM == 3) lu = lu + zNeg * uzm;
-        lu = lu + yNeg * uym;
-        lu = lu + xNeg * uxm;
-        lu = lu + diag * self;
-        lu = lu + xPos * uxp;
-        lu = lu + yPos * uyp;
-        if (DIM == 3) lu = lu + zPos * uzp;
-        const double lc = 0.0, lcn = 0.0;
-        double df = 0.0;
-        if (T.ndiff > 0) {
-            df = lu + lc;
-            df = nu * df;
-            r = r + T.dc[0] * df;
-            if (T.ndiff > 1) r = r + T.dc[1] * dold;
-        }
-        const double b1 = nu * lcn;
-        r = r + T.cimpl * b1;
+        double cn, df, r;
+        rhs_interior_arith<DIM, F>(T, dt, nu, p0, p1, self, uxm, uxp, uym, uyp, uzm, uzp, a0, a1, a2, a3, c0, c1, c2, c3, cold, dold, dLx, dLy, dLz,
+                                   gv, xNeg, xPos, yNeg, yPos, zNeg, zPos, cn, df, r);
         if (T.nconv > 0) conv0[g] = cn;
         if (T.ndiff > 0) diff0[g] = df;
         rhs1[g] = r;
     }
     }
 #undef PIB_V
+}
+
+// The interiors of ALL THREE components in one z-march (3-D; round 6).  The per-component kernels above read every value of U
+// three times from HBM / L2 (once as the component's own stencil, twice as the other components' cross terms of N(u)) and p three
+// times: 64 B per velocity point where 42.7 suffice.  Here a workgroup owns a RHS_TX x RHS_TY tile of cells and marches through
+// RHS planes; planes k-1, k, k+1 of u, v and w (tile + one ring of halo points, each component in its own index space: point
+// (i,j,k) of a component sits on the + face of cell (i,j,k)) and planes k, k+1 of p live in LDS, plane k+2 is on its way in
+// registers while plane k is computed, and the three points of a cell are computed by the cell's thread from LDS reads only.
+// Four LDS slots per component (three for p): the plane that arrives replaces the one nobody reads any more, so ONE barrier per
+// plane.  HBM traffic per cell: U 24 B (+ the ring, from L2: tiles next to each other in y share an XCD), p 8, the old N(u) 24,
+// three results x 3 components 72 (48 when the diffusive term is not kept) = 128 (104) instead of 192.
+// Same values through rhs_interior_arith: the bits of k_ns_rhs_velocity.  The boundary layer stays with k_ns_rhs_velocity_shell.
+#ifndef PIB_RHS_WAVES
+#define PIB_RHS_WAVES 4  // waves per SIMD the march is compiled for (128 registers: two workgroups per CU)
+#endif
+constexpr int RHS_TX = 64, RHS_TY = 8, RHS_PX = RHS_TX + 2, RHS_TILE = 664;  // (66 x 10 = 660 points, padded)
+constexpr int RHS_HALO = 2 * RHS_PX + 2 * RHS_TY;                            // 148 ring points
+template <bool STORE_DIFF>
+__global__ __launch_bounds__(RHS_TX * RHS_TY, PIB_RHS_WAVES) void k_ns_rhs_march(NsDev D, double dt, double nu, NsTime T, const double *__restrict__ U,
+                                                               const double *__restrict__ p, const double *__restrict__ conv1,
+                                                               double *__restrict__ conv0, double *__restrict__ rhs1,
+                                                               double *__restrict__ diff0, const double *__restrict__ diff1, int ntx,
+                                                               int nty, int band, int KZ)
+{
+    __shared__ double su[3][4][RHS_TILE];
+    __shared__ double sp[3][RHS_TILE];
+    // workgroups L, L + 8, ... share an XCD: each of the eight classes takes a band of tile rows (tiles that share ring points
+    // run side by side on one L2), x tiles fastest, then the band's rows, then the z chunks
+    const int L = blockIdx.x, xcd = L & 7;
+    int m = L >> 3;
+    const int txi = m % ntx;
+    m /= ntx;
+    const int tyi = xcd * band + m % band;
+    const int zc = m / band;
+    if (tyi >= nty) return;
+    const int t = threadIdx.x, tx = t & (RHS_TX - 1), ty = t / RHS_TX;
+    const int i0 = txi * RHS_TX, j0 = tyi * RHS_TY;
+    // (a wave is one row of the tile: j is wave-uniform, and so is everything looked up by it -- scalar registers)
+    const int i = i0 + tx, j = __builtin_amdgcn_readfirstlane(j0 + ty);
+    const int kmax = (int)D.pn[2] - 2;  // last cell plane on which some component has an interior point
+    const int ka = 1 + zc * KZ, kb = min(ka + KZ, kmax + 1);
+    if (ka >= kb) return;
+    // this thread's second point of a plane: ring point h = t (t < RHS_HALO)
+    int hx = 0, hy = 0;
+    if (t < RHS_PX) hx = t, hy = 0;
+    else if (t < 2 * RHS_PX) hx = t - RHS_PX, hy = RHS_TY + 1;
+    else if (t < 2 * RHS_PX + RHS_TY) hx = 0, hy = t - 2 * RHS_PX + 1;
+    else hx = RHS_PX - 1, hy = t - 2 * RHS_PX - RHS_TY + 1;
+    const bool has_h = t < RHS_HALO;
+    const int lm = (ty + 1) * RHS_PX + tx + 1, lh = hy * RHS_PX + hx;  // LDS positions of the two
+    const int hi_ = i0 - 1 + hx, hj_ = j0 - 1 + hy;                    // ... and the ring point's indices
+    // global offsets (plane 0) and validity of the two points in every component's index space and in the cells'
+    int64_t gm[4], gh[4], pl[4];
+    bool vm[4], vh[4];
+    int nz[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t n0 = c < 3 ? D.f[c].n[0] : D.pn[0], n1 = c < 3 ? D.f[c].n[1] : D.pn[1];
+        nz[c] = (int)(c < 3 ? D.f[c].n[2] : D.pn[2]);
+        const int64_t off = c < 3 ? D.f[c].off : 0;
+        pl[c] = n0 * n1;
+        vm[c] = i < n0 && j < n1;
+        vh[c] = has_h && hi_ >= 0 && hi_ < n0 && hj_ >= 0 && hj_ < n1;
+        gm[c] = off + i + n0 * (int64_t)j;
+        gh[c] = off + hi_ + n0 * (int64_t)hj_;
+    }
+    // interior of every component in x and y, and the k-independent coefficients of the thread's three points
+    bool in_xy[3];
+    double dLx[3], xNeg[3], xPos[3], dLy[3], yNeg[3], yPos[3], gvxy[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const NsField &Fd = D.f[f];
+        const bool in_x = i >= 1 && i <= (int)Fd.n[0] - 2, in_y = j >= 1 && j <= (int)Fd.n[1] - 2;
+        in_xy[f] = in_x && in_y;
+        dLx[f] = xNeg[f] = xPos[f] = dLy[f] = yNeg[f] = yPos[f] = gvxy[f] = 0.0;
+        if (in_y) dLy[f] = Fd.dl[1][j + 1], yNeg[f] = Fd.lneg[1][j], yPos[f] = Fd.lpos[1][j];  // (uniform)
+        if (in_x) dLx[f] = Fd.dl[0][i + 1], xNeg[f] = Fd.lneg[0][i], xPos[f] = Fd.lpos[0][i];
+        if (f == 0 && in_x) gvxy[f] = Fd.ginv[i];
+        if (f == 1 && in_y) gvxy[f] = Fd.ginv[j];
+    }
+    double rm[4], rh[4];  // plane on its way: the thread's tile point and ring point of u, v, w, p
+    auto fetch = [&](int kk) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double *src = c < 3 ? U : p;
+            const bool zin = kk >= 0 && kk < nz[c];
+            rm[c] = (zin && vm[c]) ? src[gm[c] + pl[c] * kk] : 0.0;
+            rh[c] = (zin && vh[c]) ? src[gh[c] + pl[c] * kk] : 0.0;
+        }
+    };
+    auto put = [&](int kk) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            su[c][kk & 3][lm] = rm[c];
+            if (has_h) su[c][kk & 3][lh] = rh[c];
+        }
+        sp[kk % 3][lm] = rm[3];
+        if (has_h) sp[kk % 3][lh] = rh[3];
+    };
+    for (int kk = ka - 1; kk <= ka + 1; ++kk) {
+        fetch(kk);
+        put(kk);
+    }
+    __syncthreads();
+    for (int k = ka; k < kb; ++k) {
+        fetch(k + 2);
+        const int sm = (k - 1) & 3, s0 = k & 3, s1 = (k + 1) & 3;
+        const double *pk = sp[k % 3], *pk1 = sp[(k + 1) % 3];
+#define PIB_L(c, sl, dx, dy) su[c][sl][lm + (dx) + (dy) * RHS_PX]
+        // ---- u
+        if (in_xy[0] && k <= nz[0] - 2) {
+            const NsField &Fd = D.f[0];
+            const int64_t g = gm[0] + pl[0] * k;
+            const double cold = (T.nconv > 1) ? conv1[g] : 0.0, dold = (T.ndiff > 1) ? diff1[g] : 0.0;
+            double cn, df, r;
+            rhs_interior_arith<3, 0>(T, dt, nu, pk[lm], pk[lm + 1], PIB_L(0, s0, 0, 0), PIB_L(0, s0, -1, 0), PIB_L(0, s0, 1, 0), PIB_L(0, s0, 0, -1),
+                                     PIB_L(0, s0, 0, 1), PIB_L(0, sm, 0, 0), PIB_L(0, s1, 0, 0), PIB_L(1, s0, 0, -1), PIB_L(1, s0, 1, -1),
+                                     PIB_L(1, s0, 0, 0), PIB_L(1, s0, 1, 0), PIB_L(2, sm, 0, 0), PIB_L(2, sm, 1, 0), PIB_L(2, s0, 0, 0),
+                                     PIB_L(2, s0, 1, 0), cold, dold, dLx[0], dLy[0], Fd.dl[2][k + 1], gvxy[0], xNeg[0], xPos[0], yNeg[0], yPos[0],
+                                     Fd.lneg[2][k], Fd.lpos[2][k], cn, df, r);
+            if (T.nconv > 0) conv0[g] = cn;
+            if (STORE_DIFF && T.ndiff > 0) diff0[g] = df;
+            rhs1[g] = r;
+        }
+        // ---- v
+        if (in_xy[1] && k <= nz[1] - 2) {
+            const NsField &Fd = D.f[1];
+            const int64_t g = gm[1] + pl[1] * k;
+            const double cold = (T.nconv > 1) ? conv1[g] : 0.0, dold = (T.ndiff > 1) ? diff1[g] : 0.0;
+            double cn, df, r;
+            rhs_interior_arith<3, 1>(T, dt, nu, pk[lm], pk[lm + RHS_PX], PIB_L(1, s0, 0, 0), PIB_L(1, s0, -1, 0), PIB_L(1, s0, 1, 0), PIB_L(1, s0, 0, -1),
+                                     PIB_L(1, s0, 0, 1), PIB_L(1, sm, 0, 0), PIB_L(1, s1, 0, 0), PIB_L(0, s0, -1, 0), PIB_L(0, s0, -1, 1),
+                                     PIB_L(0, s0, 0, 0), PIB_L(0, s0, 0, 1), PIB_L(2, sm, 0, 0), PIB_L(2, sm, 0, 1), PIB_L(2, s0, 0, 0),
+                                     PIB_L(2, s0, 0, 1), cold, dold, dLx[1], dLy[1], Fd.dl[2][k + 1], gvxy[1], xNeg[1], xPos[1], yNeg[1], yPos[1],
+                                     Fd.lneg[2][k], Fd.lpos[2][k], cn, df, r);
+            if (T.nconv > 0) conv0[g] = cn;
+            if (STORE_DIFF && T.ndiff > 0) diff0[g] = df;
+            rhs1[g] = r;
+        }
+        // ---- w
+        if (in_xy[2] && k <= nz[2] - 2) {
+            const NsField &Fd = D.f[2];
+            const int64_t g = gm[2] + pl[2] * k;
+            const double cold = (T.nconv > 1) ? conv1[g] : 0.0, dold = (T.ndiff > 1) ? diff1[g] : 0.0;
+            double cn, df, r;
+            rhs_interior_arith<3, 2>(T, dt, nu, pk[lm], pk1[lm], PIB_L(2, s0, 0, 0), PIB_L(2, s0, -1, 0), PIB_L(2, s0, 1, 0), PIB_L(2, s0, 0, -1),
+                                     PIB_L(2, s0, 0, 1), PIB_L(2, sm, 0, 0), PIB_L(2, s1, 0, 0), PIB_L(0, s0, -1, 0), PIB_L(0, s1, -1, 0),
+                                     PIB_L(0, s0, 0, 0), PIB_L(0, s1, 0, 0), PIB_L(1, s0, 0, -1), PIB_L(1, s1, 0, -1), PIB_L(1, s0, 0, 0),
+                                     PIB_L(1, s1, 0, 0), cold, dold, dLx[2], dLy[2], Fd.dl[2][k + 1], Fd.ginv[k], xNeg[2], xPos[2], yNeg[2], yPos[2],
+                                     Fd.lneg[2][k], Fd.lpos[2][k], cn, df, r);
+            if (T.nconv > 0) conv0[g] = cn;
+            if (STORE_DIFF && T.ndiff > 0) diff0[g] = df;
+            rhs1[g] = r;
+        }
+#undef PIB_L
+        put(k + 2);  // (slot (k + 2) & 3 held plane k - 2, last read before the previous barrier)
+        __syncthreads();
+    }
 }
 
 // rhs2 = D u + Dbc (navierstokes.cpp:540-563) at one pressure cell; D row in packed-column order u(i-1), u(i), v(j-1), v(j), w(k-1), w(k)
@@ -1573,11 +1747,31 @@ try {
         static const int rhs_bands = std::getenv("PIB_RHS_BANDS") ? std::atoi(std::getenv("PIB_RHS_BANDS")) : 1;
         // (planes a workgroup walks: 1 / 2 / 4 / 8 measured 1.09 / 1.02 / 1.03 / 1.06 ms of rhsVelocity per 256^3 step)
         static const int rhs_kz = std::getenv("PIB_RHS_PLANES") ? std::max(1, std::atoi(std::getenv("PIB_RHS_PLANES"))) : 2;
+        // 3-D, every component with an interior: the three interiors in ONE z-march over tiles of cells (k_ns_rhs_march: U and p
+        // from HBM once per step instead of three times); the shells as before.  With a one-term diffusive scheme (Crank-Nicolson,
+        // explicit Euler) nothing reads the stored diffusive term but the restart files (navierstokes.cpp:672-680), which are
+        // written between two calls of advance: it is stored in the last step of a call only.
+        static const int rhs_march = std::getenv("PIB_RHS_MARCH") ? std::atoi(std::getenv("PIB_RHS_MARCH")) : 1;
+        bool all_inner = D.dim == 3;
+        for (int f = 0; f < 3 && all_inner; ++f) all_inner = D.f[f].n[0] >= 3 && D.f[f].n[1] >= 3 && D.f[f].n[2] >= 3;
+        const bool march = rhs_march && all_inner && D.pn[0] >= 32 && D.pn[1] >= 8 && D.pn[2] >= 4;
+        if (march) {
+            const int ntx = (int)((D.pn[0] + RHS_TX - 1) / RHS_TX), nty = (int)((D.pn[1] + RHS_TY - 1) / RHS_TY), band = (nty + 7) / 8;
+            const int KZ = 32, nzc = (int)((D.pn[2] - 2 + KZ - 1) / KZ);
+            const dim3 grid_((unsigned)(8 * ntx * band * nzc));
+            const bool keep_diff = ns->T.ndiff > 1 || it == nsteps - 1;
+            if (keep_diff)
+                hipLaunchKernelGGL(k_ns_rhs_march<true>, grid_, dim3(RHS_TX * RHS_TY), 0, ns->stream, D, ns->dt, ns->nu, ns->T, ns->U, ns->p,
+                                   ns->conv[1], ns->conv[0], ns->rhs1, ns->diff0, ns->diff1, ntx, nty, band, KZ);
+            else
+                hipLaunchKernelGGL(k_ns_rhs_march<false>, grid_, dim3(RHS_TX * RHS_TY), 0, ns->stream, D, ns->dt, ns->nu, ns->T, ns->U, ns->p,
+                                   ns->conv[1], ns->conv[0], ns->rhs1, ns->diff0, ns->diff1, ntx, nty, band, KZ);
+        }
 #define PIB_RHS(DIM_, F_)                                                                                                   \
     {                                                                                                                       \
         const NsField &Fq = D.f[F_];                                                                                        \
         const bool inner = Fq.n[0] >= 3 && Fq.n[1] >= 3 && (DIM_ == 2 || Fq.n[2] >= 3);                                     \
-        if (inner) {                                                                                                        \
+        if (inner && !march) {                                                                                              \
             const int gx_ = (int)((Fq.n[0] - 2 + 255) / 256);                                                               \
             const int band_ = (DIM_ == 3 && rhs_bands && Fq.n[1] - 2 >= 64) ? (int)((Fq.n[1] - 2 + 7) / 8) : 0;              \
             const dim3 grid_ = band_ ? dim3((unsigned)(gx_ * 8 * band_ * ((Fq.n[2] - 2 + rhs_kz - 1) / rhs_kz)))            \

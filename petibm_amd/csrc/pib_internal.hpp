@@ -147,8 +147,6 @@ struct Config {
     int overlap_min_bytes = 1 << 20;  // multigrid on slabs: a right-hand-side exchange of at least this size per neighbour runs on the communication stream behind the interior planes of its first consumer
     int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024; 0: off.
     int fuse_small_levels = 1;  // gmg.hip: a small level's way down / way up in one launch each (k_small_down / k_small_up); 0: per-phase launches
-    int small_level_cells = 300000;  // ... levels of at most this many cells
-    int small_level_cells_3d = 40000;  // ... and of at most this many when the level is 3-D (the margins cost more there)
     int coarse_tail_lds = 1;  // ... with the tail levels' vectors and 1-D tables in LDS when they fit (gmg.hip: 83 -> 44 us per tail of a 448^2 mesh); 0: HBM
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
@@ -160,12 +158,8 @@ struct Config {
     int pin_sum_local = -1;  // pinned pressure row + multigrid: the residual's sum that makes the cycle's right-hand side compatible from the recurrence sum r - alpha sum w, sum w = -(row 0 of the singular operator) . p (krylov.hip cg_s1) instead of the update pass's own sum -- what lets the update ride in the cycle's first march; -1: with the fused update only, 1: always, 0: never (no fused update under a pinned row)
     int fuse_bicgstab_dots = 1;  // ... and its two dot-only passes summed by the products themselves (sums grouped by tile: the iterates equal the CSR path's to rounding, no longer bit for bit; 0 keeps the bit-identical route)
     int blocked_direct_solve = 1;   // dense.hip: the explicit inverse of the direct solver by 64-column block elimination (0: one launch per column)
-    int accumulate_unscaled_x = 1;  // ... and x summed before the Jacobi sweep, swept once at the end (krylov.hip OpBFUpdateP::y): 8 B/row/iteration less, x to rounding
     int bicgstab_merge_r = 1;  // ... and r = s - omega t formed by the next p-update, |r|^2 and r.rp from the second product's five sums (krylov.hip OpBFUpdateP::t): 16 B/row/iteration and one reduction less
-    int blocked_reductions = 1;  // vector kernels with sums on >= 2^22 entries: a contiguous range per workgroup instead of a grid stride
     int lean_bicgstab = 1;  // BiCGStab on the matrix-free velocity operator without stored M^-1 p / M^-1 s and with the x update deferred (krylov.hip OpBFUpdateP)
-    int velocity_tile_edges = 1;  // one-launch velocity product, wall-bounded x and y: the tiles produce their x / y boundary cells, the shell is two planes
-    int velocity_march_planes = 16;  // planes a workgroup of k_vel_march walks through
     int fuse_velocity_product = 1;  // 3-D: the three components' tiles and shells in one launch (velstencil.hip k_vel_product)
     int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR
     int march_min_cells = 12 << 20;  // smallest level / plane run the LDS-tiled marching kernels take: a 256^3 level, the 62 interior planes of a 512 x 512 x 64 slab (tests lower it to reach them on small grids)
@@ -176,13 +170,9 @@ struct Config {
     int fuse_down_march = 1;  // multigrid V(2, .), a level whole on one rank and not periodic: the two pre-smoothing steps (with PCG's residual update), the residual and the restriction in ONE march (gmg.hip k_down_march: 40 instead of 57 B per cell); 0: k_presmooth2 + k_resid_restrict_march
     int fuse_residual_restrict = 1;  // multigrid: residual + restriction of such a level in ONE march (gmg.hip k_resid_restrict_march)
     int fuse_presmooth = 1;  // multigrid: the first two pre-smoothing steps of a level in one LDS-tiled kernel (gmg.hip k_presmooth2)
-    int fuse_dots = 1;       // multigrid-PCG: z.r, z.z, sum z from the V-cycle's last smoothing kernel instead of a separate pass
-    int side_x_update = 0;  // multigrid-PCG beyond the captured-graph size, at most side_x_max_rows local rows (a slab of a multi-GPU run): x += alpha p as a kernel of its own on a second stream beside the V-cycle's coarse levels instead of riding on the p-update (40 -> 24 B/row on the critical path).  OFF: measured SLOWER on the 512 x 512 x 64 slab (0.99 -> 1.03-1.67 ms per iteration, profiles/r05_slab_side_x_update.md) -- launched chip-wide the update takes the CU slots of the 2 M-cell levels' kernels, on a few workgroups it outlasts the cycle
-    int64_t side_x_max_rows = (int64_t)1 << 25;
     int compress_columns = 2;  // what the CSR product streams besides the values, where the matrix allows: 2 one byte per ROW (the row's pattern of column offsets, DeviceCsr::pat_id: 73 instead of 104 B per 7-point row), 1 one byte per entry (DeviceCsr::code: 83 B), 0 the int32 columns and row offsets.  The same products in the same order, bit for bit
     int place_update_vector = 1;  // CG on one rank, systems of place_min_rows rows and more: the search direction p gets an allocation of its own, CHOSEN by timing the p-update's access pattern against the caller's x while walking through fresh allocations (krylov.hip, place_update_vector).  The flat update reads and writes both vectors, and its rate has two modes (6.3 against 5.6 TB/s at 512^3: 835 against 960 us, 8 % of the solve) set by which physical blocks the two sit in -- a property of the pair, the same for the life of the process, that no address arithmetic inside one allocation moves (profiles/r05_vector_placement_lab.txt)
     int64_t place_min_rows = (int64_t)1 << 25;  // one rank, systems of at least that many rows: every work vector of the Krylov methods an allocation of its own instead of one pool (-1: the pool always), and CG's search (measured on slabs of the 512^3 system: 2^24 rows no gain, 2^25 1.5 %, 2^26 2.6 %, 2^27 3 %)
-    int merge_scalar_kernels = 1;  // ... and the one-workgroup kernels behind them in one launch: the sums' reduction, z[0] and (one rank) the iteration's scalar step (krylov.hip k_dots_tail); the residual sums + norm test likewise (k_finalize_post<8>)
     int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
     int deep_up = 1;         // ... and the coarse corrections of the way up need no exchange of their own: a distributed level's right-hand side is exchanged as deep as its final iterate is read by the finer level's prolongation (gmg.hip: fin_l[])
@@ -453,13 +443,6 @@ struct pib_solver {
     int device = 0;
     hipStream_t stream = nullptr, stream_comm = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_halo = nullptr, ev_ready = nullptr;
-    // PCG on slab-sized systems: x += alpha p on a stream of its own beside the V-cycle's coarse levels, which leave the HBM idle
-    // (krylov.hip solve_cg, gmg.hip gmg_apply: forked when the cycle leaves level 0, joined ahead of the next p-update)
-    hipStream_t stream_side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_side = nullptr;
-    int (*gmg_side_hook)(pib_solver *s, hipStream_t q) = nullptr;  // set by the solver around gmg_apply; called once, below level 0
-    void *gmg_side_ctx = nullptr;
-    bool gmg_side_launched = false;
     pib::DeviceCsr A;
     bool has_matrix = false;
     // grid hint

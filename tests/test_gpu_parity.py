@@ -1114,10 +1114,10 @@ def test_residual_update_inside_the_vcycle_with_a_pinned_row(lin, sweeps):
 
 
 @pytest.mark.parametrize("pinned", [False, True])
-def test_x_update_on_a_second_stream_is_bit_identical(lin, pinned):
-    """`pib_side_x_update=1` (off by default: measured slower, profiles/r05_slab_side_x_update.md): x += alpha p leaves the p-update
-    and runs on a stream of its own, forked when the V-cycle leaves level 0 and joined ahead of the next p-update; the owed /
-    applied counters of the device scalars keep it exact -- the same solution bit for bit, over-enqueued iterations included."""
+def test_iterations_enqueued_blind_are_no_ops_behind_done(lin, pinned):
+    """`pib_check_every=64`: 64 iterations go out before the host looks at the device's scalars; the ones behind convergence are
+    no-ops behind the device's `done` flag, and the x update the last live iteration owes is applied exactly once (the owed /
+    applied counters of the scalars) -- the same solution, iteration count and history as with a poll after every iteration."""
     from petibm_amd import capi
     n = (256, 128, 136)
     w = [np.full(n[0], 1.0 / n[0]) * (1.0 + 0.3 * np.sin(np.arange(n[0]) / 17.0)),
@@ -1126,13 +1126,13 @@ def test_x_update_on_a_second_stream_is_bit_identical(lin, pinned):
     xs = np.random.default_rng(7).uniform(-1, 1, n[0] * n[1] * n[2])
     xs -= xs[0] if pinned else xs.mean()
     out = []
-    for side in (1, 0):
-        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_side_x_update={side}\npib_check_every=64\n"))
+    for every in (64, 1):
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_check_every={every}\n"))
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         b = np.empty_like(xs)
         s.matMult(xs, b)
         x = np.zeros_like(xs)
-        s.solve(x, b)  # (64 iterations enqueued blind: most of them no-ops behind the device's `done`)
+        s.solve(x, b)
         out.append((x, s.getIters(), np.array(s.getResidualHistory())))
         s.destroy()
     assert out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][0], out[1][0])
