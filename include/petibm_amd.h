@@ -288,6 +288,8 @@ int pib_mat_mult(pib_solver *s, const double *x, double *y);
 
 /* ---- device-side helpers for callers that keep vectors in HBM (bench.py) ---- */
 int pib_device_alloc(pib_solver *s, int64_t nbytes, void **ptr);
+/* free / total bytes of the solver's device (hipMemGetInfo): what the bounded placement search budgets against */
+int pib_device_mem_info(pib_solver *s, int64_t *free_bytes, int64_t *total_bytes);
 int pib_device_free(pib_solver *s, void *ptr);
 int pib_memcpy_h2d(pib_solver *s, void *dst, const void *src, int64_t nbytes);
 int pib_memcpy_d2h(pib_solver *s, void *dst, const void *src, int64_t nbytes);

@@ -74,6 +74,7 @@ _PROTOS = {
     "pib_get_reason": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "pib_mat_mult": (C.c_int, [_vp, _vp, _vp]),
     "pib_device_alloc": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
+    "pib_device_mem_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pib_device_free": (C.c_int, [_vp, _vp]),
     "pib_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, _i64]),
     "pib_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, _i64]),

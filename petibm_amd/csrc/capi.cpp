@@ -641,6 +641,18 @@ try {
 } catch (...) {
     return pib::fail_exception(__func__);
 }
+int pib_device_mem_info(pib_solver *s, int64_t *free_bytes, int64_t *total_bytes)
+try {
+    if (s == nullptr || free_bytes == nullptr || total_bytes == nullptr) return fail(PIB_ERR_ARG_NULL, "pib_device_mem_info: null argument");
+    PIB_HIP(hipSetDevice(s->device));
+    size_t fr = 0, tot = 0;
+    PIB_HIP(hipMemGetInfo(&fr, &tot));
+    *free_bytes = (int64_t)fr;
+    *total_bytes = (int64_t)tot;
+    return 0;
+} catch (...) {
+    return pib::fail_exception(__func__);
+}
 int pib_device_free(pib_solver *s, void *ptr)
 try {
     if (s != nullptr) PIB_HIP(hipSetDevice(s->device));

@@ -1167,6 +1167,7 @@ static int place_walk(pib_solver *s, int idx, int zidx, double *x, int *tried_ou
         else {
             if (gap > 0) {
                 size_t step = (size_t)1 << (30 + std::min(gap, 3));  // 2, 4, 8 GiB
+                step = std::min(step, 64 * bytes);                   // (... of a vector of a GiB; small systems: in proportion)
                 // (a gap that does not fit any more shrinks to what does, down to the vector's own size: then the walk ends)
                 while (step > bytes && !room(step)) step >>= 1;
                 void *sp = nullptr;
@@ -1203,7 +1204,7 @@ static int place_walk(pib_solver *s, int idx, int zidx, double *x, int *tried_ou
 static int place_update_vector(pib_solver *s, int idx, int zidx, double *x)
 {
     const DeviceCsr &A = s->A;
-    if (!s->cfg.place_update_vector || A.n < s->cfg.place_min_rows || A.n != A.n_global || x == nullptr || !aligned16(x)) return 0;
+    if (!s->cfg.place_update_vector || s->cfg.place_min_rows < 0 || A.n < s->cfg.place_min_rows || A.n != A.n_global || x == nullptr || !aligned16(x)) return 0;
     if (x == s->placed_against || s->placements >= 3 || idx >= pib_solver::MAX_WORK) return 0;
     int tried = 0;
     double t_had = 0.0, t_kept = 0.0;

@@ -312,6 +312,12 @@ class LinSolverBase:
         capi.check(capi.load().pib_get_placement(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), C.byref(f)))
         return a.value, b.value, c.value, d.value, e.value, f.value
 
+    def deviceMemInfo(self):
+        """(free, total) bytes of the solver's device"""
+        a, b = C.c_int64(), C.c_int64()
+        capi.check(capi.load().pib_device_mem_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def deviceVec(self, n: Optional[int] = None) -> DeviceVec:
         return DeviceVec(self, self.n_local if n is None else n)
 

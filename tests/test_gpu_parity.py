@@ -1174,7 +1174,7 @@ def test_search_direction_placed_against_x_is_bit_identical(lin, sr):
         s.solve(x2_d, b_d)  # another x: one more
         searches.append(s.placement()[0])
         again = (x2_d.download(), s.getIters(), np.array(s.getResidualHistory()))
-        out.append((first, again, searches, s.placement(), s.placementInfo()))
+        out.append((first, again, searches, s.placement(), s.placementInfo(), s.deviceMemInfo()))
         s.destroy()
     for k in (0, 1):
         assert out[0][k][1] == out[1][k][1] and np.array_equal(out[0][k][2], out[1][k][2]) and np.array_equal(out[0][k][0], out[1][k][0])
@@ -1182,8 +1182,7 @@ def test_search_direction_placed_against_x_is_bit_identical(lin, sr):
     assert out[0][2] == [1, 1, 2] and out[1][2] == [0, 0, 0]
     assert out[0][3][1] >= 1 and out[0][3][2] > 0.0 and out[0][3][3] <= out[0][3][2]
     # the walk is bounded: what it held at one time stays under min(16 GiB, a tenth of the free memory)
-    import torch
-    free, _ = torch.cuda.mem_get_info()
+    free = out[0][5][0]
     assert 0 <= out[0][4][4] <= min(16 << 30, free // 10 + (64 << 20)) and out[0][4][5] > 0.0
     assert out[1][4][4] == 0 and out[1][4][5] == 0.0
     err = out[0][0][0] - xs
@@ -1193,23 +1192,24 @@ def test_search_direction_placed_against_x_is_bit_identical(lin, sr):
 def test_no_placement_search_on_a_device_whose_memory_is_mostly_taken(lin):
     """The walk allocates transients; on a device that somebody else has filled (another solver of the process, other ranks
     sharing the GPU) they would be the neighbour's to miss.  With 85 % of the HBM taken before the solver is created: no error,
-    no candidate timed, nothing held, and the solve is the plain one bit for bit."""
-    import torch
+    no candidate timed, nothing held, and the solve is the plain one bit for bit.  (The memory is taken through the library's
+    own allocator: the pytest process never loads torch's HIP runtime, tests/conftest.py.)"""
     from petibm_amd import capi
+    from petibm_amd.linsolver import DeviceVec
     n = (48, 40, 32)
     w = [np.full(n[0], 1.0 / n[0]), np.full(n[1], 1.0 / n[1]), np.full(n[2], 1.0 / n[2]) * (1.0 + 0.2 * np.cos(np.arange(n[2]) / 4.0))]
     xs = np.random.default_rng(5).uniform(-1, 1, n[0] * n[1] * n[2])
     xs -= xs.mean()
     out = []
+    scratch = lin.LinSolverHIP("scratch", config_text=amgx_cfg())
     for fill in (False, True):
         hog = None
         if fill:
-            torch.cuda.empty_cache()
-            free, total = torch.cuda.mem_get_info()
+            free, total = scratch.deviceMemInfo()
             want = int(0.85 * total) - (total - free)
             assert want > 0
-            hog = torch.empty(want, dtype=torch.uint8, device="cuda")  # (allocated, never touched)
-            free2, _ = torch.cuda.mem_get_info()
+            hog = DeviceVec(scratch, want // 8)  # (allocated, never touched)
+            free2, _ = scratch.deviceMemInfo()
             assert free2 < total // 2
         s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra="pib_place_update_vector=1\npib_place_min_rows=1000\n"))
         s.assemblePoisson(list(n), w, 0.01, capi.NULLSPACE_CONSTANT)
@@ -1219,9 +1219,12 @@ def test_no_placement_search_on_a_device_whose_memory_is_mostly_taken(lin):
         x_d.upload(np.zeros_like(xs))
         s.solve(x_d, b_d)
         out.append((x_d.download(), s.getIters(), np.array(s.getResidualHistory()), s.placementInfo()))
+        for v in (x_d, b_d, xs_d):
+            v.free()
         s.destroy()
-        del hog
-        torch.cuda.empty_cache()
+        if hog is not None:
+            hog.free()
+    scratch.destroy()
     assert out[0][3][1] >= 1 and out[0][3][4] > 0          # the free device: a search that timed candidates and held something
     assert out[1][3][1] == 0 and out[1][3][4] == 0          # the filled one: nothing timed, nothing held
     assert out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][0], out[1][0])

@@ -301,3 +301,19 @@ def test_collecting_the_gpu_suite_does_not_import_torch():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300).stdout
     line = [l for l in out.splitlines() if l.startswith("TORCH_AT_COLLECTION")]
     assert line and line[0].split()[1] == "False" and int(line[0].split()[2]) > 600, out[-2000:]
+
+
+def test_gpu_tests_never_load_torchs_hip_runtime_into_the_pytest_process():
+    """tests/conftest.py: the GPU suite runs the library on /opt/rocm's own HIP runtime (PIB_TORCH_FIRST=0); a test that imports
+    torch in the pytest process pulls torch's bundled runtime in beside it -- round 6 saw exactly that end in `double free or
+    corruption` at interpreter exit.  GPU tests that need torch (bench.py under the launcher) start it in a child process."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.abspath(__file__))
+    bad = []
+    for f in sorted(glob.glob(os.path.join(root, "test_gpu_*.py"))):
+        for k, line in enumerate(open(f), 1):
+            if re.match(r"\s*(import torch|from torch)", line):
+                bad.append(f"{os.path.basename(f)}:{k}")
+    assert bad == []
