@@ -60,3 +60,36 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-lrccl"])
     return out
+
+
+MPI_PREFIX = os.environ.get("PIB_MPI_PREFIX", "/opt/conda")  # MPICH 3.3.2 in this image
+
+
+def build_mpi_example(verbose: bool = False):
+    """examples/mpi/poisson_boxes_mpi: the PETSc-free `mpiexec -n P` launch through the C ABI.  Returns the
+    binary's path, or None when the image has no MPI.  The MPI runtime's directory also holds an OLD libstdc++, so it must not
+    get onto the binary's search path: the four libraries MPICH needs are reached through symlinks in examples/mpi/lib."""
+    lib = os.path.join(MPI_PREFIX, "lib", "libmpi.so.12")
+    if not (os.path.exists(lib) and os.path.exists(os.path.join(MPI_PREFIX, "include", "mpi.h"))):
+        return None
+    root = os.path.join(_HERE, "..")
+    d = os.path.join(root, "examples", "mpi")
+    priv = os.path.join(d, "lib")
+    os.makedirs(priv, exist_ok=True)
+    for name in ("libmpi.so.12", "libgfortran.so.4", "libgomp.so.1", "libquadmath.so.0"):
+        src, dst = os.path.join(MPI_PREFIX, "lib", name), os.path.join(priv, name)
+        if os.path.exists(src) and not os.path.lexists(dst):
+            os.symlink(src, dst)
+    out = os.path.join(d, "poisson_boxes_mpi")
+    cmd = ["g++", "-std=c++14", "-Wall", "-I", os.path.join(root, "include"), "-I", os.path.join(MPI_PREFIX, "include"),
+           os.path.join(d, "poisson_boxes_mpi.cpp"), "-L", _LIBDIR, "-lpetibm_amd", os.path.join(priv, "libmpi.so.12"),
+           "-Wl,-rpath,$ORIGIN/lib", "-Wl,-rpath,$ORIGIN/../../petibm_amd/lib", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def mpiexec_path():
+    p = os.path.join(MPI_PREFIX, "bin", "mpiexec")
+    return p if os.path.exists(p) else None
