@@ -289,7 +289,6 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.check_every = std::atoi(d.get("default", "pib_check_every", "0").c_str());
     c.use_graph = std::atoi(d.get("default", "pib_use_graph", "1").c_str());
     c.graph_max_rows = std::atoll(d.get("default", "pib_graph_max_rows", "4194304").c_str());
-    c.spmv_variant = std::atoi(d.get("default", "pib_spmv_variant", "0").c_str());
     c.overlap_halo = std::atoi(d.get("default", "pib_overlap_halo", "1").c_str());
     c.fuse_presmooth = std::atoi(d.get("default", "pib_fuse_presmooth", "1").c_str());
     c.march_restrict = std::atoi(d.get("default", "pib_march_restrict", "1").c_str());
@@ -426,7 +425,6 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_check_every", v)) c.check_every = std::atoi(v.c_str());
     if (get("pib_use_graph", v)) c.use_graph = std::atoi(v.c_str());
     if (get("pib_graph_max_rows", v)) c.graph_max_rows = std::atoll(v.c_str());
-    if (get("pib_spmv_variant", v)) c.spmv_variant = std::atoi(v.c_str());
     if (get("pib_overlap_halo", v)) c.overlap_halo = std::atoi(v.c_str());
     if (get("pib_fuse_presmooth", v)) c.fuse_presmooth = std::atoi(v.c_str());
     if (get("pib_march_restrict", v)) c.march_restrict = std::atoi(v.c_str());

@@ -15,7 +15,7 @@
 //     gathers x with the ROW-PER-LANE mapping, so one gather instruction reads
 //     ~64 consecutive x values (4-5 cache lines) instead of 9 rows x 7
 //     diagonals (10+ lines): the vector-L1 tag rate, not HBM, was what capped
-//     the entry-per-lane kernel (k_spmv_stream, kept as variant 1) at 50 %.
+//     the entry-per-lane kernel of round 1 at 50 %.
 //   * one chunk per workgroup, workgroups dispatched in sequence order: the
 //     chip sweeps a moving window of addresses (measured: persistent
 //     grid-stride loops stream 10-15 % slower on MI355X).
@@ -39,10 +39,6 @@
 
 namespace pib {
 
-constexpr int SPMV_BLOCK = 256;
-constexpr int SPMV_ROWS = 256;
-constexpr int SPMV_NPT = 8;
-constexpr int SPMV_TILE = SPMV_BLOCK * SPMV_NPT;  // 2048 products = 16 KiB
 constexpr int SPMV_GRID = 2048;                   // 256 CUs x 8 workgroups
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -64,75 +60,6 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh /* >= 4 */)
     __syncthreads();
     return r;
 }
-
-template <typename RP, bool DOT>
-__global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_stream(const Scalars *__restrict__ S, int64_t r_begin,
-                                                            int64_t r_end, const RP *__restrict__ rowptr,
-                                                            const int32_t *__restrict__ col,
-                                                            const double *__restrict__ val,
-                                                            const double *__restrict__ xg,  // ghosted base
-                                                            int64_t ghost_lo, double *__restrict__ y,
-                                                            double *__restrict__ part)
-{
-    if (S != nullptr && S->done) return;
-    __shared__ double prod[SPMV_TILE];
-    __shared__ RP srow[SPMV_ROWS + 1];
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    const int64_t nchunks = (r_end - r_begin + SPMV_ROWS - 1) / SPMV_ROWS;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int64_t cpx = (nchunks + 7) >> 3;
-    const int64_t c_lo = (int64_t)xcd * cpx;
-    const int64_t c_hi = (c_lo + cpx < nchunks) ? c_lo + cpx : nchunks;
-    double dacc = 0.0;
-
-    for (int64_t c = c_lo + j; c < c_hi; c += bpx) {
-        const int64_t r0 = r_begin + c * SPMV_ROWS;
-        const int nr = (int)((r_end - r0 < SPMV_ROWS) ? (r_end - r0) : SPMV_ROWS);
-        for (int t = tid; t <= nr; t += SPMV_BLOCK) srow[t] = rowptr[r0 + t];
-        __syncthreads();
-        const RP p0 = srow[0], p1 = srow[nr];
-        RP rs = 0, re = 0;
-        if (tid < nr) {
-            rs = srow[tid];
-            re = srow[tid + 1];
-        }
-        double sum = 0.0;
-        for (RP t0 = p0; t0 < p1; t0 += SPMV_TILE) {
-            const int cnt = (int)((p1 - t0 < (RP)SPMV_TILE) ? (p1 - t0) : (RP)SPMV_TILE);
-            int32_t cc[SPMV_NPT];
-            double vv[SPMV_NPT];
-#pragma unroll
-            for (int u = 0; u < SPMV_NPT; ++u) {
-                const int i = tid + u * SPMV_BLOCK;
-                cc[u] = (i < cnt) ? col[t0 + i] : 0;
-                vv[u] = (i < cnt) ? val[t0 + i] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < SPMV_NPT; ++u) {
-                const int i = tid + u * SPMV_BLOCK;
-                if (i < cnt) prod[i] = vv[u] * xg[cc[u]];
-            }
-            __syncthreads();
-            if (tid < nr) {
-                const RP lo = (rs > t0) ? rs : t0;
-                const RP hi = (re < t0 + cnt) ? re : (t0 + cnt);
-                for (RP p = lo; p < hi; ++p) sum = sum + prod[(int)(p - t0)];
-            }
-            __syncthreads();
-        }
-        if (p1 == p0) __syncthreads();  // srow is rewritten by the next chunk
-        if (tid < nr) {
-            y[r0 + tid] = sum;
-            if (DOT) dacc += xg[ghost_lo + r0 + tid] * sum;
-        }
-    }
-    if (DOT) {
-        const double s = block_sum_256(dacc, red);
-        if (tid == 0) part[blockIdx.x] = s;
-    }
-}
-
 
 // ----------------------------------------------------------------------------
 // chunk order (see header): sequence position -> chunk id
@@ -612,38 +539,13 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const Scalars *__restri
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
-// Row-per-thread fallback (variant 2): simplest possible CSR kernel, kept as
-// the A/B baseline for the profile and as the checker of the stream kernel.
-template <typename RP, bool DOT>
-__global__ __launch_bounds__(256) void k_spmv_scalar(const Scalars *__restrict__ S, int64_t r_begin, int64_t r_end,
-                                                     const RP *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                     const double *__restrict__ val, const double *__restrict__ xg,
-                                                     int64_t ghost_lo, double *__restrict__ y,
-                                                     double *__restrict__ part)
-{
-    if (S != nullptr && S->done) return;
-    __shared__ double red[4];
-    double dacc = 0.0;
-    for (int64_t r = r_begin + (int64_t)blockIdx.x * 256 + threadIdx.x; r < r_end; r += (int64_t)gridDim.x * 256) {
-        double sum = 0.0;
-        const RP pe = rowptr[r + 1];
-        for (RP p = rowptr[r]; p < pe; ++p) sum = sum + val[p] * xg[col[p]];
-        y[r] = sum;
-        if (DOT) dacc += xg[ghost_lo + r] * sum;
-    }
-    if (DOT) {
-        const double s = block_sum_256(dacc, red);
-        if (threadIdx.x == 0) part[blockIdx.x] = s;
-    }
-}
-
 int spmv_launch_blocks() { return SPMV_GRID; }
 
 // chunk order for rows [r_begin, r_end) given the registered grid (3-D only; the rows must start on a plane)
 static ChunkOrder make_order(const pib_solver *s, int64_t r_begin, int64_t r_end)
 {
     ChunkOrder o{0, 0, 0, 0};
-    if (!s->has_grid || s->levels.empty() || s->cfg.spmv_variant == 3) return o;
+    if (!s->has_grid || s->levels.empty()) return o;
     const GridLevel &g = s->levels[0];
     const int64_t nx = g.n[0], ny = g.n[1], plane = nx * ny;
     if (ny < 2 || plane % LDS_ROWS != 0 || r_begin % plane != 0 || (r_end - r_begin) % plane != 0) return o;
@@ -674,8 +576,7 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
     }
     const double *xg = x_owned - A.ghost_lo;
     const Scalars *S = guarded ? s->d_s : nullptr;
-    const int variant = s->cfg.spmv_variant;
-    if (variant == 0 || variant == 3) {
+    {
         const int64_t nchunks = (r_end - r_begin + LDS_ROWS - 1) / LDS_ROWS;
         const int64_t grid = ((nchunks + 7) / 8) * 8;
         const ChunkOrder ord = make_order(s, r_begin, r_end);
@@ -707,7 +608,7 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
             hipLaunchKernelGGL((k_spmv_lds_coded<RP, false, CAP>), dim3((unsigned)grid), dim3(256), 0, st, S, r_begin, r_end, \
                                (const RP *)A.rowptr, A.code, A.dict, A.val, xg, A.ghost_lo, y, (double *)nullptr, ord);   \
     } while (0)
-        if (A.patterned && variant == 0 && (r_begin & 255) == 0) {
+        if (A.patterned && (r_begin & 255) == 0) {
 #define PIB_LAUNCH_PATTERN(RP, CAP)                                                                                                                  \
     do {                                                                                                                                             \
         if (dot_part)                                                                                                                                \
@@ -734,7 +635,7 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
             s->counters[0]++;
             return 0;
         }
-        if (A.coded && variant == 0) {
+        if (A.coded) {
             const int64_t need16 = A.max_chunk_nnz + 15;  // the span is widened to a start that is a multiple of 16
             if (need16 <= 1296) {
                 if (A.rp64) PIB_LAUNCH_CODED(int64_t, 1296); else PIB_LAUNCH_CODED(int32_t, 1296);
@@ -771,24 +672,6 @@ int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, 
         s->counters[0]++;
         return 0;
     }
-#define PIB_LAUNCH(KERNEL, RP)                                                                                   \
-    do {                                                                                                         \
-        if (dot_part)                                                                                            \
-            hipLaunchKernelGGL((KERNEL<RP, true>), dim3(SPMV_GRID), dim3(256), 0, st, S, r_begin, r_end,        \
-                               (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, dot_part);                 \
-        else                                                                                                     \
-            hipLaunchKernelGGL((KERNEL<RP, false>), dim3(SPMV_GRID), dim3(256), 0, st, S, r_begin, r_end,       \
-                               (const RP *)A.rowptr, A.col, A.val, xg, A.ghost_lo, y, (double *)nullptr);        \
-    } while (0)
-    if (variant == 2) {
-        if (A.rp64) PIB_LAUNCH(k_spmv_scalar, int64_t); else PIB_LAUNCH(k_spmv_scalar, int32_t);
-    } else {
-        if (A.rp64) PIB_LAUNCH(k_spmv_stream, int64_t); else PIB_LAUNCH(k_spmv_stream, int32_t);
-    }
-#undef PIB_LAUNCH
-    PIB_HIP(hipGetLastError());
-    s->counters[0]++;
-    return 0;
 }
 
 // ---------------------------------------------------------------- 1/diag

@@ -142,7 +142,6 @@ struct Config {
     int check_every = 0;     // iterations enqueued between host convergence polls (0 = auto)
     int use_graph = 1;       // capture the iteration body in a hipGraph
     int64_t graph_max_rows = 1 << 22;  // ... for systems of at most this many local rows (launch-bound ones)
-    int spmv_variant = 0;    // 0 LDS-transpose + tiled chunk order (default), 3 same in natural order, 1 entry-per-lane stream, 2 row-per-thread
     int overlap_halo = 1;
     int overlap_min_bytes = 1 << 20;  // multigrid on slabs: a right-hand-side exchange of at least this size per neighbour runs on the communication stream behind the interior planes of its first consumer
     int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024; 0: off.
