@@ -355,7 +355,7 @@ def velocity_case(n: int, steps: int, warmup: int, kernel_reps: int, extra: str 
     alg_free = 16.0 * UN  # x read once, y written once; tables are 1-D (reported apart from the CSR figure)
     # velstencil.hip vel_stencil_apply: components of >= 4 M points with lines of >= 127 take the one-launch marching form
     vel_kernel = ("pib::k_vel_product<0> (LDS-tiled march of the three components + their boundary shells in one launch: the product BiCGStab runs)"
-                  if n ** 3 >= (1 << 22) and n >= 128 and "pib_fuse_velocity_product=0" not in extra and "pib_march_velocity=0" not in extra
+                  if n ** 3 >= (1 << 22) and n >= 128 and "pib_fuse_velocity_product=0" not in extra and "pib_march=0" not in extra
                   else "pib::k_vel_interior4<3> / k_vel_march + k_vel_shell x 3 components (the products BiCGStab runs)")
     out = {
         "metric": f"velocity-system DOF/s ({'BiCGStab' if solver == 'PBICGSTAB' else 'Chebyshev'}+Jacobi to |r| <= {tol:g})", "value": UN * steps / el,

@@ -288,7 +288,7 @@ static int set_csr_any(pib_solver *s, int64_t n_local, int64_t row0_global, int6
             PIB_CHK(detect_velocity_structure(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val));
             // ... and the velocity system in BOXES ([u box | v box | w box] per rank, PETSC_DECIDE from 4 ranks up): moved to
             // packed slabs inside the backend, like the pressure rows for the multigrid (partition.cpp)
-            if (!s->vel.valid && s->cfg.redistribute_velocity)
+            if (!s->vel.valid)
                 PIB_CHK(redist_velocity_setup(s, n_local, row0_global, n_global, rp64, cl64, rp32, cl32, val, ranges));
         }
         return 0;

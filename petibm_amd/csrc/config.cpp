@@ -287,39 +287,29 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     }
     // library-specific keys (default scope)
     c.check_every = std::atoi(d.get("default", "pib_check_every", "0").c_str());
-    c.use_graph = std::atoi(d.get("default", "pib_use_graph", "1").c_str());
     c.graph_max_rows = std::atoll(d.get("default", "pib_graph_max_rows", "4194304").c_str());
-    c.overlap_halo = std::atoi(d.get("default", "pib_overlap_halo", "1").c_str());
     c.fuse_presmooth = std::atoi(d.get("default", "pib_fuse_presmooth", "1").c_str());
-    c.march_restrict = std::atoi(d.get("default", "pib_march_restrict", "1").c_str());
     c.fuse_residual_restrict = std::atoi(d.get("default", "pib_fuse_residual_restrict", "1").c_str());
     c.fuse_down_march = std::atoi(d.get("default", "pib_fuse_down_march", "1").c_str());
     c.fuse_post_pair = std::atoi(d.get("default", "pib_fuse_post_pair", "1").c_str());
     c.fuse_prolong = std::atoi(d.get("default", "pib_fuse_prolong", "1").c_str());
-    c.march_levels = std::atoi(d.get("default", "pib_march_levels", "1").c_str());
+    c.march = std::atoi(d.get("default", "pib_march", "1").c_str());
     c.march_min_cells = std::atoi(d.get("default", "pib_march_min_cells", "12582912").c_str());
     c.matrix_free_velocity = std::atoi(d.get("default", "pib_matrix_free_velocity", "1").c_str());
-    c.march_velocity = std::atoi(d.get("default", "pib_march_velocity", "1").c_str());
     c.fuse_velocity_product = std::atoi(d.get("default", "pib_fuse_velocity_product", "1").c_str());
-    c.redistribute_velocity = std::atoi(d.get("default", "pib_redistribute_velocity", "1").c_str());
-    c.lean_bicgstab = std::atoi(d.get("default", "pib_lean_bicgstab", "1").c_str());
-    c.fuse_bicgstab_dots = std::atoi(d.get("default", "pib_fuse_bicgstab_dots", "1").c_str());
-    c.fuse_residual_update = std::atoi(d.get("default", "pib_fuse_residual_update", "1").c_str());
+    c.bicgstab_form = std::atoi(d.get("default", "pib_bicgstab_form", "3").c_str());
+    c.fuse_residual_update = std::atoi(d.get("default", "pib_fuse_residual_update", "2").c_str());
     c.pin_sum_local = std::atoi(d.get("default", "pib_pin_sum_local", "-1").c_str());
     c.compress_columns = std::atoi(d.get("default", "pib_compress_columns", "2").c_str());
     c.place_update_vector = std::atoi(d.get("default", "pib_place_update_vector", "1").c_str());
     c.place_min_rows = std::atoll(d.get("default", "pib_place_min_rows", "33554432").c_str());
     c.cg_single_reduction = std::atoi(d.get("default", "pib_cg_single_reduction", "0").c_str());
-    c.fuse_residual_update_slabs = std::atoi(d.get("default", "pib_fuse_residual_update_slabs", "1").c_str());
     c.sweep_pairs = std::atoi(d.get("default", "pib_sweep_pairs", "1").c_str());
     c.fuse_chebyshev_update = std::atoi(d.get("default", "pib_fuse_chebyshev_update", "1").c_str());
-    c.blocked_direct_solve = std::atoi(d.get("default", "pib_blocked_direct_solve", "1").c_str());
-    c.bicgstab_merge_r = std::atoi(d.get("default", "pib_bicgstab_merge_r", "1").c_str());
     c.matrix_free_poisson = std::atoi(d.get("default", "pib_matrix_free_poisson", "-1").c_str());
     c.agglomerate_below = std::atoi(d.get("default", "pib_agglomerate_below", "300000").c_str());
     c.detect_structure = std::atoi(d.get("default", "pib_detect_structure", "1").c_str());
-    c.deep_halo = std::atoi(d.get("default", "pib_deep_halo", "1").c_str());
-    c.deep_up = std::atoi(d.get("default", "pib_deep_up", "1").c_str());
+    c.deep_halo = std::atoi(d.get("default", "pib_deep_halo", "2").c_str());
     c.overlap_min_bytes = std::atoi(d.get("default", "pib_overlap_min_bytes", "1048576").c_str());
     c.coarse_tail = std::atoi(d.get("default", "pib_coarse_tail", "-1").c_str());
     c.coarse_tail_lds = std::atoi(d.get("default", "pib_coarse_tail_lds", "1").c_str());
@@ -423,23 +413,17 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
         return fail(PIB_ERR_SUP, "config: -%sksp_type preonly and -%spc_type lu go together (direct solve)", pre.c_str(),
                     pre.c_str());
     if (get("pib_check_every", v)) c.check_every = std::atoi(v.c_str());
-    if (get("pib_use_graph", v)) c.use_graph = std::atoi(v.c_str());
     if (get("pib_graph_max_rows", v)) c.graph_max_rows = std::atoll(v.c_str());
-    if (get("pib_overlap_halo", v)) c.overlap_halo = std::atoi(v.c_str());
     if (get("pib_fuse_presmooth", v)) c.fuse_presmooth = std::atoi(v.c_str());
-    if (get("pib_march_restrict", v)) c.march_restrict = std::atoi(v.c_str());
     if (get("pib_fuse_residual_restrict", v)) c.fuse_residual_restrict = std::atoi(v.c_str());
     if (get("pib_fuse_down_march", v)) c.fuse_down_march = std::atoi(v.c_str());
     if (get("pib_fuse_post_pair", v)) c.fuse_post_pair = std::atoi(v.c_str());
     if (get("pib_fuse_prolong", v)) c.fuse_prolong = std::atoi(v.c_str());
-    if (get("pib_march_levels", v)) c.march_levels = std::atoi(v.c_str());
+    if (get("pib_march", v)) c.march = std::atoi(v.c_str());
     if (get("pib_march_min_cells", v)) c.march_min_cells = std::atoi(v.c_str());
     if (get("pib_matrix_free_velocity", v)) c.matrix_free_velocity = std::atoi(v.c_str());
-    if (get("pib_march_velocity", v)) c.march_velocity = std::atoi(v.c_str());
     if (get("pib_fuse_velocity_product", v)) c.fuse_velocity_product = std::atoi(v.c_str());
-    if (get("pib_redistribute_velocity", v)) c.redistribute_velocity = std::atoi(v.c_str());
-    if (get("pib_lean_bicgstab", v)) c.lean_bicgstab = std::atoi(v.c_str());
-    if (get("pib_fuse_bicgstab_dots", v)) c.fuse_bicgstab_dots = std::atoi(v.c_str());
+    if (get("pib_bicgstab_form", v)) c.bicgstab_form = std::atoi(v.c_str());
     if (get("pib_fuse_residual_update", v)) c.fuse_residual_update = std::atoi(v.c_str());
     if (get("pib_pin_sum_local", v)) c.pin_sum_local = std::atoi(v.c_str());
     if (get("pib_compress_columns", v)) c.compress_columns = std::atoi(v.c_str());
@@ -447,16 +431,12 @@ static int apply_petsc(const std::string &text, const std::string &name, Config 
     if (get("pib_place_min_rows", v)) c.place_min_rows = std::atoll(v.c_str());
     if (get("ksp_cg_single_reduction", v)) c.cg_single_reduction = truthy(v) ? 1 : 0;  // PETSc's own option (KSPCGUseSingleReduction)
     if (get("pib_cg_single_reduction", v)) c.cg_single_reduction = std::atoi(v.c_str());
-    if (get("pib_fuse_residual_update_slabs", v)) c.fuse_residual_update_slabs = std::atoi(v.c_str());
     if (get("pib_sweep_pairs", v)) c.sweep_pairs = std::atoi(v.c_str());
     if (get("pib_fuse_chebyshev_update", v)) c.fuse_chebyshev_update = std::atoi(v.c_str());
-    if (get("pib_blocked_direct_solve", v)) c.blocked_direct_solve = std::atoi(v.c_str());
-    if (get("pib_bicgstab_merge_r", v)) c.bicgstab_merge_r = std::atoi(v.c_str());
     if (get("pib_matrix_free_poisson", v)) c.matrix_free_poisson = std::atoi(v.c_str());
     if (get("pib_agglomerate_below", v)) c.agglomerate_below = std::atoi(v.c_str());
     if (get("pib_detect_structure", v)) c.detect_structure = std::atoi(v.c_str());
     if (get("pib_deep_halo", v)) c.deep_halo = std::atoi(v.c_str());
-    if (get("pib_deep_up", v)) c.deep_up = std::atoi(v.c_str());
     if (get("pib_overlap_min_bytes", v)) c.overlap_min_bytes = std::atoi(v.c_str());
     if (get("pib_coarse_tail", v)) c.coarse_tail = std::atoi(v.c_str());
     if (get("pib_coarse_tail_lds", v)) c.coarse_tail_lds = std::atoi(v.c_str());

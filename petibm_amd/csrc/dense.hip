@@ -299,7 +299,7 @@ int dense_setup(pib_solver *s)
     hipStream_t q = s->stream;
     const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
     const int64_t np = (n + GB - 1) / GB * GB;
-    const bool blocked = s->cfg.blocked_direct_solve && n >= 2 * GB;
+    const bool blocked = n >= 2 * GB;
     // buffers (and the captured elimination graph) are kept while the size stays the same: a moving body re-factorises
     // a matrix of the same order every time step (rigidkinematics.cpp:135-139)
     if (s->dense_n != n || s->dense_inv == nullptr) {

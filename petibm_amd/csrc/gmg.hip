@@ -241,7 +241,7 @@ static int launch_restrict(const pib_solver *s, const GridLevel &f, const GridLe
     const int64_t nkc = c.k1 - c.k0;
     // transfers across a periodic z seam: the whole fine level is on this rank (the slab axis of a distributed level never wraps)
     const bool z_ok = !(f.tper & 4) || (f.k0 == 0 && f.k1 == f.n[2]);
-    if (s->cfg.march_restrict && f.plain_pair && z_ok && f.n[0] % RX == 0 && f.n[1] % RY == 0 && nkc >= 4 &&
+    if (s->cfg.march && f.plain_pair && z_ok && f.n[0] % RX == 0 && f.n[1] % RY == 0 && nkc >= 4 &&
         nkc * c.plane * 8 >= (int64_t)s->cfg.march_min_cells) {
         // coarse planes per workgroup: 32 on a 512^3 fine level (1024 workgroups), 8 below
         const int CZ = nkc * c.plane >= ((int64_t)1 << 23) ? 32 : 8;
@@ -253,7 +253,7 @@ static int launch_restrict(const pib_solver *s, const GridLevel &f, const GridLe
     const int vec_ok = (f.n[0] % 2 == 0 && (reinterpret_cast<uintptr_t>(rf) & 15u) == 0) ? 1 : 0;
     // any aggregation, the level whole on this rank, no periodic z seam, 3-D, large enough to fill the chip with one wave per coarse
     // row and z-chunk: the z-marching form
-    if (s->cfg.march_restrict && !(f.tper & 4) && f.k0 == 0 && f.k1 == f.n[2] && c.k0 == 0 && c.k1 == c.n[2] && f.n[1] > 1 && c.n[2] >= 4 &&
+    if (s->cfg.march && !(f.tper & 4) && f.k0 == 0 && f.k1 == f.n[2] && c.k0 == 0 && c.k1 == c.n[2] && f.n[1] > 1 && c.n[2] >= 4 &&
         c.n[0] * c.n[1] * c.n[2] >= std::min<int64_t>((int64_t)1 << 17, s->cfg.march_min_cells)) {  // (the tests lower the bound)
         // coarse planes per workgroup: so that there are about four workgroups per CU
         const int64_t wg_plane = ((c.n[1] + 3) / 4) * ((c.n[0] + 63) / 64);
@@ -670,11 +670,8 @@ static bool fused_run_ok(const pib_solver *s, const GridLevel &g, int64_t kb, in
 #endif
 static int march_planes(const GridLevel &g, int64_t kc)
 {
-    // (PIB_MARCH_PLANES_SMALL: planes per workgroup on runs below 2^23 cells -- the 2 M-cell levels under a slab, which the marches
-    // only reach when pib_march_min_cells is lowered; an experiment knob, profiles/r05_slab8_iteration_timeline.md)
-    static const int small_planes = std::getenv("PIB_MARCH_PLANES_SMALL") ? std::max(2, std::atoi(std::getenv("PIB_MARCH_PLANES_SMALL"))) : 16;
     if (kc * g.plane >= ((int64_t)1 << 26)) return PIB_MARCH_PLANES_BIG;
-    return kc * g.plane < ((int64_t)1 << 23) ? small_planes : 16;
+    return 16;
 }
 
 // The Krylov sums z.r, z.z, sum z a level-0 kernel left as per-workgroup partials: their fixed-order reduction into S->red[0..2].
@@ -719,7 +716,7 @@ static int launch_level_planes(pib_solver *s, const GridLevel &g, int64_t kb, in
     int part_stride = 0;
     const int64_t nx = g.n[0], ny = g.n[1];
     const unsigned nk = (unsigned)kc;
-    const bool march = (MODE == 2 || MODE == 3 || MODE == 8) && s->cfg.march_levels && march_run_ok(s, g, kb, kc) &&
+    const bool march = (MODE == 2 || MODE == 3 || MODE == 8) && s->cfg.march && march_run_ok(s, g, kb, kc) &&
                        ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(xi) | reinterpret_cast<uintptr_t>(xo)) & 31u) == 0;
     const int FZ = march_planes(g, kc);
     const dim3 mg((unsigned)(nx / FX), (unsigned)(ny / FY), (unsigned)((nk + FZ - 1) / FZ));
@@ -820,7 +817,7 @@ bool gmg_fused_update_ok(const pib_solver *s)
     if (s->comm.nranks > 1) {
         // z-slabs (round 4): level 0 distributed with deep halos, every rank's slab thick enough for them, the two-step march
         // (the cycle decides again with its own predicate at the launch site and falls back to the separate pass if it must)
-        if (!s->cfg.fuse_residual_update_slabs || !s->cfg.deep_halo || g.replicated || g.zring || (g.per & 4)) return false;
+        if (s->cfg.fuse_residual_update < 2 || !s->cfg.deep_halo || g.replicated || g.zring || (g.per & 4)) return false;
         if (std::max(1, s->cfg.presweeps) * (s->cfg.sweep_pairs ? 2 : 1) < 2) return false;
         return fused_update_slabs_all_ranks(s, g);
     }
@@ -1094,7 +1091,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     // latency-bound levels are relaxed redundantly.  Where the level's slabs are too thin for that depth the exchange stays.
     std::vector<int> fin_l((size_t)nl, 0);
     fin_l[0] = (li[0].dist && li[0].maxd > 1) ? 1 : 0;
-    if (s->cfg.deep_up && !cheb && post >= 1)
+    if (s->cfg.deep_halo >= 2 && !cheb && post >= 1)
         for (int l = 1; l < nl; ++l) {
             if (!li[(size_t)l].dist || !li[(size_t)l - 1].dist) continue;
             const int want = coarse_need(s, l - 1, fin_l[(size_t)l - 1] + post);
@@ -1260,7 +1257,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
             // (several ranks: the slab-dependent parts for EVERY rank's slab -- fused_update_slabs_all_ranks -- so that all ranks fall
             // back together or not at all)
-            bool site = s->cfg.fuse_residual_update == 1 && !cheb && s->cfg.fuse_presmooth && al32(b) && (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
+            bool site = s->cfg.fuse_residual_update >= 1 && !cheb && s->cfg.fuse_presmooth && al32(b) && (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
             if (I.dist) site = site && fused_update_slabs_all_ranks(s, g);
             else site = site && fused_run_ok(s, g, 0, I.nk) && (g.n[0] / FX) * (g.n[1] / FY) * ((I.nk + FZ0 - 1) / FZ0 + 2) <= PIB_MAXPART;
             // z-slabs: the two-step march only, deep halos (the residual's depth is what w is exchanged to), aligned planes
@@ -1307,7 +1304,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
         // march on the same planes, the neighbours' included)
         const double *xv = (l == 0 && I.dist && s->gmg_upd.w != nullptr) ? s->gmg_upd.w : b;
         set_valid(xv, 0);
-        if (I.dist && s->cfg.overlap_halo && I.nk >= 4 && (int64_t)Dd * g.plane * 8 >= (int64_t)s->cfg.overlap_min_bytes)
+        if (I.dist && s->cfg.overlap_min_bytes >= 0 && I.nk >= 4 && (int64_t)Dd * g.plane * 8 >= (int64_t)s->cfg.overlap_min_bytes)
             PIB_CHK(need_async(l, xv, Dd));
         else
             PIB_CHK(need(l, xv, Dd));
@@ -1363,7 +1360,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 const bool upd = l == 0 && s->gmg_upd.w != nullptr;
                 auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
                 const bool fits = s->cfg.fuse_down_march && pre == 2 && !cheb && s->cfg.fuse_presmooth && s->cfg.fuse_residual_restrict &&
-                                  s->cfg.march_restrict && !I.dist && !li[(size_t)l + 1].dist && s->comm.nranks == 1 && g.k0 == 0 && g.k1 == g.n[2] &&
+                                  s->cfg.march && !I.dist && !li[(size_t)l + 1].dist && s->comm.nranks == 1 && g.k0 == 0 && g.k1 == g.n[2] &&
                                   c1.k0 == 0 && c1.k1 == c1.n[2] && !g.zring && g.per == 0 && g.tper == 0 && g.plain_pair && !halo_pending &&
                                   fused_run_ok(s, g, 0, I.nk) && g.n[0] % RX == 0 && g.n[1] % 8 == 0 && (g.n[2] & 1) == 0 && 2 * nkc == g.n[2] && nkc >= 4 &&
                                   nkc * c1.plane * 8 >= (int64_t)s->cfg.march_min_cells && (FZ & 1) == 0 && FZ / 2 <= 32 && al32(b) && al32(c) &&
@@ -1411,7 +1408,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
                 if (!whole && I.dist && li[(size_t)l + 1].dist && !g.zring && !(g.per & 4) && valid(a) >= 2 && valid(b) >= 1 &&
                     std::min(I.maxd, I.cdepth) >= 2)
                     whole = true;
-                if (s->cfg.fuse_residual_restrict && whole && s->cfg.march_restrict && g.plain_pair && g.per == g.tper &&
+                if (s->cfg.fuse_residual_restrict && whole && s->cfg.march && g.plain_pair && g.per == g.tper &&
                     g.n[0] % RX == 0 && g.n[1] % RY == 0 && nkc >= 4 && nkc * c1.plane * 8 >= (int64_t)s->cfg.march_min_cells) {
                     const int CZ = nkc * c1.plane >= ((int64_t)1 << 23) ? 32 : 8;  // (as launch_restrict)
                     hipLaunchKernelGGL(k_resid_restrict_march, dim3((unsigned)(g.n[0] / RX), (unsigned)(g.n[1] / RY), (unsigned)((nkc + CZ - 1) / CZ)),
@@ -1638,7 +1635,7 @@ int stencil_matmult(pib_solver *s, const double *x, double *y, double *dot_part,
     const int64_t nk = g.k1 - g.k0;
     const int FZ = march_planes(g, nk);
     const dim3 mg((unsigned)(g.n[0] / FX), (unsigned)(g.n[1] / FY), (unsigned)((nk + FZ - 1) / FZ));
-    const bool march = s->cfg.march_levels && g.dim == 3 && march_run_ok(s, g, 0, nk) &&
+    const bool march = s->cfg.march && g.dim == 3 && march_run_ok(s, g, 0, nk) &&
                        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 31u) == 0 &&
                        (int64_t)mg.x * mg.y * mg.z <= spmv_launch_blocks();
     if (march) {

@@ -834,7 +834,7 @@ template <class Body>
 static int run_iterations(pib_solver *s, int todo, int first_index, uint64_t key, hipStream_t q, Body body)
 {
     // (several ranks: when the transport's collectives can be captured -- the device-ordered peer transport, halo.hip)
-    const bool use = s->cfg.use_graph && comm_capturable(s) && s->A.n <= s->cfg.graph_max_rows;
+    const bool use = comm_capturable(s) && s->A.n <= s->cfg.graph_max_rows;  // (pib_graph_max_rows=0: never)
     for (int it = 0; it < todo; ++it) {
         if (!use || first_index + it == 0) {
             PIB_CHK(body());
@@ -907,7 +907,7 @@ static int matmult(pib_solver *s, double *p_owned, double *w, double *dot_part, 
     return spmv_rows(s, p_owned, w, 0, s->A.n, dot_part, guarded, stq);
 }
 
-// p = z + beta p with the halo exchange of p overlapped (cfg.overlap_halo): the entries the neighbours need are
+// p = z + beta p with the halo exchange of p overlapped (cfg.overlap_min_bytes >= 0): the entries the neighbours need are
 // updated first, their exchange runs on the communication stream while the rest of p is updated; the SpMV that
 // follows finds the halo fresh.
 template <class Op>
@@ -915,7 +915,7 @@ static int update_p_and_exchange(pib_solver *s, int64_t n, const Op &up, double 
 {
     const DeviceCsr &A = s->A;
     // (a general plan's send entries are scattered over the vector: no leading / trailing part to update first)
-    const bool split = s->comm.nranks > 1 && s->cfg.overlap_halo && !A.general && (A.send_prev % 2 == 0) && (A.send_next % 2 == 0) &&
+    const bool split = s->comm.nranks > 1 && s->cfg.overlap_min_bytes >= 0 && !A.general && (A.send_prev % 2 == 0) && (A.send_next % 2 == 0) &&
                        (n % 2 == 0) && A.send_prev + A.send_next < n;
     if (!split) return launch_vec(s, n, up, vec2, 0, nullptr, true, q);
     PIB_CHK(launch_vec(s, n, up, vec2, 0, nullptr, true, q, 0, A.send_prev));
@@ -2181,15 +2181,15 @@ int solve_bicgstab(pib_solver *s, double *x, const double *b)
     // scalar step; the sweep needs the neighbours' diagonal on the ghost planes: a ghost-padded copy of 1 / a_ii, exchanged
     // once per solve, in the vector the general path keeps M^-1 s in.
     const bool lean = (jac || pc == Precond::NONE) && !left && (one_rank || s->vel.slab_axis >= 0) &&
-                      s->cfg.lean_bicgstab && s->vel.valid && s->cfg.matrix_free_velocity &&
+                      s->cfg.bicgstab_form >= 1 && s->vel.valid && s->cfg.matrix_free_velocity &&
                       s->post_matmult == nullptr && vel_stencil_fused_ok(s) && aligned16(x) &&
                       ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(V) |
                         reinterpret_cast<uintptr_t>(T)) & 31u) == 0;
-    const bool fused_dots = lean && s->cfg.fuse_bicgstab_dots;
+    const bool fused_dots = lean && s->cfg.bicgstab_form >= 2;
     // ... and x accumulated before the Jacobi sweep (OpBFUpdateP::y) in the vector the general path keeps M^-1 p in
     double *Y = fused_dots ? s->vec(7) : nullptr;
     // ... and the residual update merged into the next p-update, |r|^2 and r.rp out of the second product's sums
-    const bool merge_r = Y != nullptr && s->cfg.bicgstab_merge_r;
+    const bool merge_r = Y != nullptr && s->cfg.bicgstab_form >= 3;
     if (lean && jac && !one_rank) {
         double *D = s->vec(8);
         PIB_HIP(hipMemcpyAsync(D, A.dinv, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, q));

@@ -1743,18 +1743,17 @@ try {
         if (ns->T.ndiff > 1) std::swap(ns->diff0, ns->diff1);
         // bc->updateEqs(solution, dt) (:508) into a1n; the right-hand side needs both generations
         hipLaunchKernelGGL(k_ns_ghosts<1>, dim3(gg), dim3(256), 0, ns->stream, D, ns->dt, ns->U);
-        // interior kernel of the explicit terms: rows dealt to the XCDs in bands (PIB_RHS_BANDS=0: row by row, the 3-D grid)
-        static const int rhs_bands = std::getenv("PIB_RHS_BANDS") ? std::atoi(std::getenv("PIB_RHS_BANDS")) : 1;
+        // interior kernel of the explicit terms: rows dealt to the XCDs in bands (a short component: row by row, the 3-D grid)
+        constexpr int rhs_bands = 1;
         // (planes a workgroup walks: 1 / 2 / 4 / 8 measured 1.09 / 1.02 / 1.03 / 1.06 ms of rhsVelocity per 256^3 step)
-        static const int rhs_kz = std::getenv("PIB_RHS_PLANES") ? std::max(1, std::atoi(std::getenv("PIB_RHS_PLANES"))) : 2;
+        constexpr int rhs_kz = 2;
         // 3-D, every component with an interior: the three interiors in ONE z-march over tiles of cells (k_ns_rhs_march: U and p
         // from HBM once per step instead of three times); the shells as before.  With a one-term diffusive scheme (Crank-Nicolson,
         // explicit Euler) nothing reads the stored diffusive term but the restart files (navierstokes.cpp:672-680), which are
         // written between two calls of advance: it is stored in the last step of a call only.
-        static const int rhs_march = std::getenv("PIB_RHS_MARCH") ? std::atoi(std::getenv("PIB_RHS_MARCH")) : 1;
         bool all_inner = D.dim == 3;
         for (int f = 0; f < 3 && all_inner; ++f) all_inner = D.f[f].n[0] >= 3 && D.f[f].n[1] >= 3 && D.f[f].n[2] >= 3;
-        const bool march = rhs_march && all_inner && D.pn[0] >= 32 && D.pn[1] >= 8 && D.pn[2] >= 4;
+        const bool march = all_inner && D.pn[0] >= 32 && D.pn[1] >= 8 && D.pn[2] >= 4;
         if (march) {
             const int ntx = (int)((D.pn[0] + RHS_TX - 1) / RHS_TX), nty = (int)((D.pn[1] + RHS_TY - 1) / RHS_TY), band = (nty + 7) / 8;
             const int KZ = 32, nzc = (int)((D.pn[2] - 2 + KZ - 1) / KZ);
@@ -1819,9 +1818,8 @@ try {
         }
         PIB_CHK(mark(3));  // end of rhsForces + solveForces (nothing between the two marks without bodies)
         {
-            static const int by_rows = std::getenv("PIB_RHS_POISSON_ROWS") ? std::atoi(std::getenv("PIB_RHS_POISSON_ROWS")) : 1;
             const dim3 pg((unsigned)((D.pn[0] + 255) / 256), (unsigned)D.pn[1], (unsigned)(D.dim == 3 ? D.pn[2] : 1));
-            if (by_rows && D.pn[1] <= 65535 && (D.dim == 2 || D.pn[2] <= 65535))
+            if (D.pn[1] <= 65535 && (D.dim == 2 || D.pn[2] <= 65535))
                 hipLaunchKernelGGL(k_ns_rhs_poisson_rows, pg, dim3(256), 0, ns->stream, D, ns_pin_cell(ns), ns->U, ns->rhs2);
             else
                 hipLaunchKernelGGL(k_ns_rhs_poisson, dim3(gp), dim3(256), 0, ns->stream, D, ns_pin_cell(ns), ns->U, ns->rhs2);
@@ -1853,9 +1851,8 @@ try {
                                ns->bng_val, ns->dP, ns->U, ns->p);
         else
         {
-            static const int by_rows = std::getenv("PIB_PROJECT_ROWS") ? std::atoi(std::getenv("PIB_PROJECT_ROWS")) : 1;
             const dim3 pg((unsigned)((D.pn[0] + 255) / 256), (unsigned)D.pn[1], (unsigned)(D.dim == 3 ? D.pn[2] : 1));
-            if (by_rows && D.pn[1] <= 65535 && (D.dim == 2 || D.pn[2] <= 65535)) {
+            if (D.pn[1] <= 65535 && (D.dim == 2 || D.pn[2] <= 65535)) {
                 if (D.dim == 3) hipLaunchKernelGGL(k_ns_project_rows<3>, pg, dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
                 else hipLaunchKernelGGL(k_ns_project_rows<2>, pg, dim3(256), 0, ns->stream, D, ns->dt, ns->dP, ns->U, ns->p);
             } else

@@ -140,9 +140,7 @@ struct Config {
     int coarsest_sweeps = 32;
     // execution
     int check_every = 0;     // iterations enqueued between host convergence polls (0 = auto)
-    int use_graph = 1;       // capture the iteration body in a hipGraph
-    int64_t graph_max_rows = 1 << 22;  // ... for systems of at most this many local rows (launch-bound ones)
-    int overlap_halo = 1;
+    int64_t graph_max_rows = 1 << 22;  // capture the iteration body in a hipGraph for systems of at most this many local rows (launch-bound ones); 0: never
     int overlap_min_bytes = 1 << 20;  // multigrid on slabs: a right-hand-side exchange of at least this size per neighbour runs on the communication stream behind the interior planes of its first consumer
     int coarse_tail = -1;    // > 0: multigrid levels with at most this many cells run in ONE single-workgroup kernel; -1: 1024; 0: off.
     int fuse_small_levels = 1;  // gmg.hip: a small level's way down / way up in one launch each (k_small_down / k_small_up); 0: per-phase launches
@@ -150,21 +148,15 @@ struct Config {
                              // Measured SLOWER than per-level launches at every size on MI355X (512^3: 142.5 ms off, 145 ms at
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
-    int march_velocity = 1;        // matrix-free velocity product: LDS-tiled z-marching form for tile-divisible components (velstencil.hip k_vel_march)
     int cg_single_reduction = 0;   // CG with PETSc's single-reduction recurrences (-<name>_ksp_cg_single_reduction; solver file: pib_cg_single_reduction=1): ONE all-reduce per iteration, 16 B/row more vector traffic (krylov.hip solve_cg_sr)
-    int fuse_residual_update_slabs = 1;  // ... on z-slabs too: w = A p is exchanged to the depth the residual was, the march keeps the residual's ghost planes by recurrence (gmg.hip k_presmooth2<., 1> with wext)
-    int fuse_residual_update = 1;  // PCG + multigrid on one rank: r = r - alpha w by the V-cycle's first march instead of a pass of its own
+    int fuse_residual_update = 2;  // PCG + multigrid: r = r - alpha w by the V-cycle's first march instead of a pass of its own.  1: on one rank only; 2 (default): on z-slabs too -- w = A p is exchanged to the depth the residual was, the march keeps the residual's ghost planes by recurrence; 0: the separate pass
     int pin_sum_local = -1;  // pinned pressure row + multigrid: the residual's sum that makes the cycle's right-hand side compatible from the recurrence sum r - alpha sum w, sum w = -(row 0 of the singular operator) . p (krylov.hip cg_s1) instead of the update pass's own sum -- what lets the update ride in the cycle's first march; -1: with the fused update only, 1: always, 0: never (no fused update under a pinned row)
-    int fuse_bicgstab_dots = 1;  // ... and its two dot-only passes summed by the products themselves (sums grouped by tile: the iterates equal the CSR path's to rounding, no longer bit for bit; 0 keeps the bit-identical route)
-    int blocked_direct_solve = 1;   // dense.hip: the explicit inverse of the direct solver by 64-column block elimination (0: one launch per column)
-    int bicgstab_merge_r = 1;  // ... and r = s - omega t formed by the next p-update, |r|^2 and r.rp from the second product's five sums (krylov.hip OpBFUpdateP::t): 16 B/row/iteration and one reduction less
-    int lean_bicgstab = 1;  // BiCGStab on the matrix-free velocity operator without stored M^-1 p / M^-1 s and with the x update deferred (krylov.hip OpBFUpdateP)
+    int bicgstab_form = 3;  // BiCGStab on the matrix-free velocity operator (krylov.hip OpBFUpdateP): 0 the general path; 1 lean -- no stored M^-1 p / M^-1 s, the x update deferred: the same iterates bit for bit; 2 + the two dot-only passes summed by the products themselves (sums grouped by tile: iterates to rounding); 3 (default) + r = s - omega t formed by the next p-update, |r|^2 and r.rp from the second product's five sums (16 B/row/iteration and one reduction less)
     int fuse_velocity_product = 1;  // 3-D: the three components' tiles and shells in one launch (velstencil.hip k_vel_product)
     int matrix_free_velocity = 1;  // Krylov products with the velocity operator from the mesh tables (velstencil.hip) instead of the CSR
     int march_min_cells = 12 << 20;  // smallest level / plane run the LDS-tiled marching kernels take: a 256^3 level, the 62 interior planes of a 512 x 512 x 64 slab (tests lower it to reach them on small grids)
-    int march_levels = 1;    // multigrid: Jacobi steps / residuals of the large levels by the 2.5-D blocked kernel (gmg.hip k_level_march)
+    int march = 1;           // the LDS-tiled z-marching forms: Jacobi steps / residuals of the large multigrid levels (gmg_level_kernels.hpp k_level_march), the restriction of a fully paired 3-D level (gmg_down_kernels.hpp k_restrict_march), the matrix-free velocity product (velstencil.hip k_vel_march); 0: the flat streaming forms (same bits)
     int fuse_prolong = 1;  // multigrid: prolongation + first post-smoothing step of a fully paired large level in one kernel (gmg.hip k_prolong_smooth)
-    int march_restrict = 1;  // multigrid: restriction of a fully paired 3-D level by the z-marching LDS kernel (gmg.hip k_restrict_march)
     int fuse_post_pair = 1;  // multigrid: prolongation + both post-smoothing steps of V(., 2) in ONE march (gmg.hip k_prolong_smooth2)
     int fuse_down_march = 1;  // multigrid V(2, .), a level whole on one rank and not periodic: the two pre-smoothing steps (with PCG's residual update), the residual and the restriction in ONE march (gmg.hip k_down_march: 40 instead of 57 B per cell); 0: k_presmooth2 + k_resid_restrict_march
     int fuse_residual_restrict = 1;  // multigrid: residual + restriction of such a level in ONE march (gmg.hip k_resid_restrict_march)
@@ -172,10 +164,8 @@ struct Config {
     int compress_columns = 2;  // what the CSR product streams besides the values, where the matrix allows: 2 one byte per ROW (the row's pattern of column offsets, DeviceCsr::pat_id: 73 instead of 104 B per 7-point row), 1 one byte per entry (DeviceCsr::code: 83 B), 0 the int32 columns and row offsets.  The same products in the same order, bit for bit
     int place_update_vector = 1;  // CG on one rank, systems of place_min_rows rows and more: the search direction p gets an allocation of its own, CHOSEN by timing the p-update's access pattern against the caller's x while walking through fresh allocations (krylov.hip, place_update_vector).  The flat update reads and writes both vectors, and its rate has two modes (6.3 against 5.6 TB/s at 512^3: 835 against 960 us, 8 % of the solve) set by which physical blocks the two sit in -- a property of the pair, the same for the life of the process, that no address arithmetic inside one allocation moves (profiles/r05_vector_placement_lab.txt)
     int64_t place_min_rows = (int64_t)1 << 25;  // one rank, systems of at least that many rows: every work vector of the Krylov methods an allocation of its own instead of one pool (-1: the pool always), and CG's search (measured on slabs of the 512^3 system: 2^24 rows no gain, 2^25 1.5 %, 2^26 2.6 %, 2^27 3 %)
-    int redistribute_velocity = 1;  // velocity rows in DMDA boxes (several ranks): move them to packed z-slabs for the matrix-free products (partition.cpp); 0: CSR products on the boxes
     int detect_structure = 1;  // pib_set_csr with a multigrid preconditioner: recover the mesh structure from the matrix (structure.cpp)
-    int deep_up = 1;         // ... and the coarse corrections of the way up need no exchange of their own: a distributed level's right-hand side is exchanged as deep as its final iterate is read by the finer level's prolongation (gmg.hip: fin_l[])
-    int deep_halo = 1;       // multi-GPU multigrid: exchange several ghost planes at once and recompute the ghost cells (gmg.hip); 0: one plane per stencil kernel
+    int deep_halo = 2;       // multi-GPU multigrid: exchange several ghost planes at once and recompute the ghost cells (gmg.hip); 2 (default): ... and the coarse corrections of the way up need no exchange of their own (a level's right-hand side is exchanged as deep as its final iterate is read by the finer level's prolongation: fin_l[]); 1: deep on the way down only; 0: one plane per stencil kernel
     int agglomerate_below = 300000;  // multi-GPU GMG: levels with fewer cells are solved redundantly per GPU
     std::string raw;
 };

@@ -862,7 +862,7 @@ void vel_stencil_release(pib_solver *s)
 bool vel_stencil_fused_ok(const pib_solver *s)
 {
     const VelStencil &h = s->vel;
-    if (!h.valid || h.dim != 3 || !s->cfg.march_velocity || !s->cfg.fuse_velocity_product) return false;
+    if (!h.valid || h.dim != 3 || !s->cfg.march || !s->cfg.fuse_velocity_product) return false;
     for (int f = 0; f < 3; ++f) {
         const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
         if (!(ny >= 3 && nz >= 3 && nx >= VX - 1 && nx * ny * nz >= std::min<int64_t>(s->cfg.march_min_cells, (int64_t)1 << 22))) return false;
@@ -909,7 +909,7 @@ int vel_stencil_apply(pib_solver *s, const double *x, double *y, bool guarded, h
     const int MZ = 16;  // planes a workgroup of the march walks through (8 ... 64 measured flat within 2 %)
     auto marches = [&](int f) {
         const int64_t nx = h.n[f][0], ny = h.n[f][1], nz = h.n[f][2];
-        return h.dim == 3 && s->cfg.march_velocity && ny >= 3 && nz >= 3 && nx >= VX - 1 &&
+        return h.dim == 3 && s->cfg.march && ny >= 3 && nz >= 3 && nx >= VX - 1 &&
                nx * ny * nz >= std::min<int64_t>(s->cfg.march_min_cells, (int64_t)1 << 22);
     };
     if (h.dim == 3 && s->cfg.fuse_velocity_product && marches(0) && marches(1) && marches(2)) {

@@ -151,7 +151,7 @@ SHIFT = 40.0  # A - SHIFT I: the (negative semi-definite) Poisson operator made 
 
 
 def _worker_bcgs(rank, world, port, n, out_dir):
-    """BiCGStab + Jacobi in the lean form of csrc/krylov.hip with the residual update merged (pib_bicgstab_merge_r): per iteration two
+    """BiCGStab + Jacobi in the lean form of csrc/krylov.hip with the residual update merged (pib_bicgstab_form=3): per iteration two
     halo exchanges (the products' inputs) and TWO all-reduces -- v.r~, then the five sums s.t, t.t, s.s, r~.s, r~.t from which omega,
     |r|^2 and r.r~ follow -- instead of the three of the textbook iteration."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"

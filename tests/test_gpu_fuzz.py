@@ -97,7 +97,7 @@ def test_random_mesh_operators_bit_exact(seed):
     b = clib.spmv(V, us)
     for free in (1, 0):  # the products of the solve from the mesh tables, then from the CSR: same iterates
         t = LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc="BLOCK_JACOBI", tol=1e-12, conv="ABSOLUTE", maxit=500)
-                         + f"pib_matrix_free_velocity={free}\npib_lean_bicgstab=0\n")
+                         + f"pib_matrix_free_velocity={free}\npib_bicgstab_form=0\n")
         t.setPeriodic(per)
         t.assembleVelocity(n, w, m.min[: m.dim], m.max[: m.dim], _a0_table(m), dt, cnu)
         xv = np.zeros(V.n_rows)
@@ -473,7 +473,7 @@ def test_random_mesh_general_restriction_march_is_bit_identical(seed):
     b -= b.mean()
     out = []
     for march in (0, 1):
-        s = LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post, extra=f"pib_march_min_cells=0\npib_march_restrict={march}\n"
+        s = LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post, extra=f"pib_march_min_cells=0\npib_march={march}\n"
                                                                                  "pib_fuse_small_levels=0\npib_coarse_tail=0\n"))
         if any(per):
             s.setPeriodic(per)
@@ -508,7 +508,7 @@ def test_random_paired_levels_marching_kernels_are_bit_identical(seed):
     b = rng.uniform(-1, 1, N)
     b -= b.mean()
     out = []
-    off = "pib_march_levels=0\npib_fuse_presmooth=0\npib_march_restrict=0\npib_fuse_prolong=0\n"
+    off = "pib_march=0\npib_fuse_presmooth=0\npib_fuse_prolong=0\n"
     for extra in ("", "pib_fuse_post_pair=0\n", "pib_fuse_residual_restrict=0\n", off):
         s = LinSolverHIP("poisson", config_text=gmg_cfg(pre=pre, post=post, extra="pib_march_min_cells=0\n" + extra))
         if any(per):

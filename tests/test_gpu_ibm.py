@@ -80,22 +80,24 @@ def test_direct_forces_solve_matches_lapack(lin=None):
     """-forces_ksp_type preonly -forces_pc_type lu: the explicit inverse built on the device reproduces a dense LU solve"""
     from petibm_amd.linsolver import LinSolverHIP
     m = omesh.create_mesh(body_mesh())
+    # (180 unknowns: the blocked elimination, 64 columns at a time -- from 128 unknowns on; 60: one launch per column)
+    for bodies in ([circle(60), circle(30, r=0.2)], [circle(30, r=0.2)]):
+        A = ibm.create_ib_operators(m, bodies, 0.01)["EBNH"]
+        b = np.random.default_rng(2).uniform(-1, 1, A.n_rows)
+        want = np.linalg.solve(A.to_dense(), b)
+        kappa = np.linalg.cond(A.to_dense())
+        for text in (FORCES, "config_version=2\nsolver(s)=DENSE_LU_SOLVER\n"):  # (PETSc's spelling, AmgX's)
+            s = LinSolverHIP("forces", config_text=text)
+            s.setMatrix(A)
+            x = np.zeros(A.n_rows)
+            s.solve(x, b)
+            # forward error of a backward-stable solve: a few cond(A) eps (cond = 3.5e5 with both bodies; the backward error is checked below)
+            assert np.linalg.norm(x - want) <= 4.0 * kappa * np.finfo(float).eps * np.linalg.norm(want)
+            # backward error (the two overlapping bodies make this system ill-conditioned: |x| ~ 1e4 |b|)
+            assert np.linalg.norm(b - clib.spmv(A, x)) <= 1e-13 * np.linalg.norm(A.val) * np.linalg.norm(x)
+            assert s.getIters() == 1 and s.getReason() > 0
+            s.destroy()
     A = ibm.create_ib_operators(m, [circle(60), circle(30, r=0.2)], 0.01)["EBNH"]
-    b = np.random.default_rng(2).uniform(-1, 1, A.n_rows)
-    want = np.linalg.solve(A.to_dense(), b)
-    kappa = np.linalg.cond(A.to_dense())
-    # (the blocked elimination -- the default from 128 unknowns on --, the one-launch-per-column form, AmgX's spelling)
-    for text in (FORCES, FORCES + "-forces_pib_blocked_direct_solve 0\n", "config_version=2\nsolver(s)=DENSE_LU_SOLVER\n"):
-        s = LinSolverHIP("forces", config_text=text)
-        s.setMatrix(A)
-        x = np.zeros(A.n_rows)
-        s.solve(x, b)
-        # forward error of a backward-stable solve: a few cond(A) eps (cond = 3.5e5 here; the backward error is checked below)
-        assert np.linalg.norm(x - want) <= 4.0 * kappa * np.finfo(float).eps * np.linalg.norm(want)
-        # backward error (the two overlapping bodies make this system ill-conditioned: |x| ~ 1e4 |b|)
-        assert np.linalg.norm(b - clib.spmv(A, x)) <= 1e-13 * np.linalg.norm(A.val) * np.linalg.norm(x)
-        assert s.getIters() == 1 and s.getReason() > 0
-        s.destroy()
     # a singular matrix is a zero-pivot error (PETSC_ERR_MAT_LU_ZRPVT), not a wrong answer
     from petibm_amd import capi
     Z = A.copy()

@@ -187,7 +187,7 @@ def test_multirank_gmg_on_stretched_mesh_with_ragged_slabs(P, n, extra):
 
 
 def test_halo_overlap_does_not_change_a_single_bit():
-    """pib_overlap_halo: boundary planes first, exchange on the communication stream during the interior part of the
+    """pib_overlap_min_bytes (-1: no overlap): boundary planes first, exchange on the communication stream during the interior part of the
     producing kernel (V-cycle smoothers, residual, prolongation, p = z + beta p).  Same kernels, same values: the
     residual history and the solution are identical with and without it."""
     from petibm_amd import capi
@@ -201,7 +201,7 @@ def test_halo_overlap_does_not_change_a_single_bit():
     for flag in (0, 1):
         def rank_fn(r, uid, flag=flag):
             pl = plans[r]
-            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=f"pib_agglomerate_below=10\npib_overlap_halo={flag}\n"),
+            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=f"pib_agglomerate_below=10\npib_overlap_min_bytes={0 if flag else -1}\n"),
                              rank=r, nranks=P, uid=uid, device=0)
             s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
             x = np.zeros(pl.n_local)
@@ -280,7 +280,7 @@ def test_multirank_velocity_system(P, case):
     csr = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_matrix_free_velocity=0\n"))
     march = case.startswith("3d_march")
     if march:  # the route without the fused sums keeps the bits of the CSR route on slabs as on one rank
-        exact = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_fuse_bicgstab_dots=0\n"))
+        exact = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_bicgstab_form=1\n"))
         for a, c in zip(exact, csr):
             assert a[2] == c[2] and np.array_equal(a[3], c[3]) and np.array_equal(a[1], c[1])
     for a, c in zip(res, csr):
@@ -405,13 +405,13 @@ def test_config3_512_cubed_on_8_slabs(recurrence):
     (2, (128, 16, 64), ""),
     (3, (128, 16, 96), "pib_overlap_min_bytes=0\n"),     # w's exchange on the communication stream behind the interior planes
     (4, (128, 32, 64), "pib_agglomerate_below=100\n"),
-    (2, (128, 16, 64), "pib_cg_single_reduction=0\npib_deep_up=0\n"),
+    (2, (128, 16, 64), "pib_cg_single_reduction=0\npib_deep_halo=1\n"),
 ])
 def test_residual_update_inside_the_vcycle_on_slabs(P, n, extra):
     """Round 4: PCG's r = r - alpha w inside the V-cycle's first march on z-slabs too (krylov.hip / gmg.hip k_presmooth2<., 1>
     with `wext`): w = A p is exchanged to the depth the residual was, every launch updates the planes it loads, the neighbours'
     planes of the new residual are written as well and follow the recurrence from then on.  Same expression per cell: the
-    iterates are those of the separate pass (pib_fuse_residual_update_slabs=0) bit for bit on every rank; the counters say the
+    iterates are those of the separate pass (pib_fuse_residual_update=1: one rank only) bit for bit on every rank; the counters say the
     fused form ran; the solve is the single rank's."""
     from petibm_amd import capi
     import slab_plans as partition
@@ -425,7 +425,7 @@ def test_residual_update_inside_the_vcycle_on_slabs(P, n, extra):
     def run(fuse):
         def rank_fn(r, uid):
             pl = plans[r]
-            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=base + f"pib_fuse_residual_update_slabs={fuse}\n", sweeps=2), rank=r, nranks=P,
+            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=base + f"pib_fuse_residual_update={2 if fuse else 1}\n", sweeps=2), rank=r, nranks=P,
                              uid=uid, device=0)
             s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
             x = np.zeros(pl.n_local)

@@ -108,11 +108,13 @@ def test_time_step_matches_oracle(case, pinned):
     s.destroy()
 
 
-@pytest.mark.parametrize("n", [(300, 70, 6), (130, 150, 9)])
+@pytest.mark.parametrize("n", [(300, 70, 6), (130, 150, 9), (70, 20, 40), (30, 150, 9)])
 def test_first_step_rhs_on_wide_3d_meshes_is_bit_identical(n):
-    """navierstokes.hip k_ns_rhs_velocity where its launch geometry has something to get wrong: rows dealt to the XCDs in bands (from
-    64 interior rows on), two chunks of a row (more than 256 interior points), two planes per workgroup with an odd plane count --
-    every interior point exactly once, the bits of the oracle's explicit terms (navierstokes.cpp:432-521)."""
+    """navierstokes.hip where the launch geometry of the explicit terms has something to get wrong.  The three-component march
+    (k_ns_rhs_march, 32 cells and more along x): partial 64 x 8 tiles in x and y, tile rows dealt to the XCDs in bands, one and two
+    z chunks of 32 planes, the last cell plane on which only u and v have interior points.  The per-component kernel
+    (k_ns_rhs_velocity, the (30, 150, 9) mesh): rows in bands, two planes per workgroup with an odd plane count.  Every interior
+    point exactly once, the bits of the oracle's explicit terms (navierstokes.cpp:432-521)."""
     from petibm_amd.navierstokes import NavierStokesSolver
     cfg = cavity(n, nu=0.02, dt=0.005)
     m = omesh.create_mesh(cfg)

@@ -951,7 +951,7 @@ def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = []
     for march in (1, 0):
-        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_march_levels={march}\n"))
+        s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=f"pib_march_min_cells=0\npib_march={march}\n"))
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)
         x = np.zeros(A.n_rows)
         s.solve(x, b)
@@ -963,7 +963,7 @@ def test_blocked_level_kernel_matches_the_streaming_one(lin, n, pinned):
     assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("key,sweeps", [("pib_fuse_down_march", 2), ("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
+@pytest.mark.parametrize("key,sweeps", [("pib_fuse_down_march", 2), ("pib_march", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
 @pytest.mark.parametrize("n,pinned", [((128, 32, 24), False), ((256, 16, 40), True), ((128, 16, 34), False)])
 def test_marching_transfers_are_bit_identical(lin, n, pinned, key, sweeps):
     """gmg.hip k_restrict_march (fully paired 3-D levels with nx % 128 == 0, ny % 16 == 0: a fine plane goes through LDS

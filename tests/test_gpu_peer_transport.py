@@ -140,7 +140,7 @@ def test_iteration_graph_on_ranks(tmp_path, P, n, pc):
     for g in (0, 1):
         d = os.path.join(str(tmp_path), f"graph{g}")
         os.makedirs(d)
-        job = dict(kind="poisson", n=n, w=w, dt=dt, cfg=_cfg(pc, extra=f"pib_use_graph={g}\npib_agglomerate_below=100\n"), xs=xs, b=b,
+        job = dict(kind="poisson", n=n, w=w, dt=dt, cfg=_cfg(pc, extra=f"pib_graph_max_rows={4194304 if g else 0}\npib_agglomerate_below=100\n"), xs=xs, b=b,
                    periodic=None, timed_solves=3)
         out[g] = run_ranks(d, job, P, order="device")
     for a, c in zip(out[0], out[1]):

@@ -404,7 +404,7 @@ def test_velocity_system_on_a_periodic_slab_axis(P, n, per):
 
     res = _run_ranks(P, rank_fn)
     csr = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_matrix_free_velocity=0\n"))  # matrix-free products on slabs = the CSR's
-    exact = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_fuse_bicgstab_dots=0\n")) if n[0] >= 128 else res
+    exact = _run_ranks(P, lambda r, uid: rank_fn(r, uid, "pib_bicgstab_form=1\n")) if n[0] >= 128 else res
     for a, c in zip(exact, csr):
         assert a[2] == c[2] and np.array_equal(a[3], c[3]) and np.array_equal(a[1], c[1])
     for a, c in zip(res, csr):  # (the marching sizes: sums folded into the products, iterates to rounding)
@@ -539,11 +539,11 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per, pc):
     # one launch for the three components' tiles and shells (k_vel_product), a launch each, the streaming kernels, the CSR
     # (the first also runs BiCGStab without stored M^-1 p / M^-1 s and with the x update deferred: krylov.hip OpBFUpdateP);
     # the last two are the fused routes, whose products also sum v.rp, s.t, t.t (grouped by tile: equal to rounding, not bit for bit)
-    for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_bicgstab_dots=0\n",
-                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_lean_bicgstab=0\n",
+    for extra in ("pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_bicgstab_form=1\n",
+                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_bicgstab_form=0\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_fuse_velocity_product=0\n",
-                  "pib_matrix_free_velocity=1\npib_march_velocity=0\n", "pib_matrix_free_velocity=0\n",
-                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_bicgstab_merge_r=0\n",
+                  "pib_matrix_free_velocity=1\npib_march=0\n", "pib_matrix_free_velocity=0\n",
+                  "pib_matrix_free_velocity=1\npib_march_min_cells=0\npib_bicgstab_form=2\n",
                   "pib_matrix_free_velocity=1\npib_march_min_cells=0\n"):
         s = lin.LinSolverHIP("velocity", config_text=amgx_cfg(solver="PBICGSTAB", pc=pc, tol=1e-13 if pc != "NOSOLVER" else 1e-10,
                                                               conv="ABSOLUTE", maxit=500, extra=extra))
@@ -565,7 +565,7 @@ def test_blocked_velocity_product_is_the_csr_product(lin, n, per, pc):
         assert np.abs(fused[0] - out[0][0]).max() <= (1e-12 if pc != "NOSOLVER" else 1e-10) * max(1.0, np.abs(out[0][0]).max())
 
 
-@pytest.mark.parametrize("key,sweeps", [("pib_march_restrict", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
+@pytest.mark.parametrize("key,sweeps", [("pib_march", 2), ("pib_fuse_residual_restrict", 2), ("pib_fuse_post_pair", 2), ("pib_fuse_prolong", 2), ("pib_fuse_prolong", 1)])
 @pytest.mark.parametrize("n,per,ratios", [((128, 32, 24), (True, True, True), None), ((256, 16, 40), (True, False, True), (1.0, 1.01, 1.0)),
                                           ((128, 16, 34), (False, True, False), (1.002, 1.0, 0.99)),
                                           ((128, 16, 8), (False, False, True), (1.002, 1.01, 1.0))])
@@ -628,7 +628,7 @@ def test_blocked_smoothers_on_periodic_levels(lin, n, per, pinned):
     w = [m.dL[3][d].true for d in range(m.dim)]
     out = {}
     for name, extra in (("march", "pib_march_min_cells=0\n"), ("nofuse", "pib_march_min_cells=0\npib_fuse_presmooth=0\n"),
-                        ("stream", "pib_march_min_cells=0\npib_march_levels=0\npib_fuse_presmooth=0\n")):
+                        ("stream", "pib_march_min_cells=0\npib_march=0\npib_fuse_presmooth=0\n")):
         s = lin.LinSolverHIP("poisson", config_text=gmg_cfg(pre=2, post=2, extra=extra))
         s.setPeriodic(per)
         s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED if pinned else capi.NULLSPACE_CONSTANT)

@@ -289,6 +289,20 @@ def test_config_describe_reports_the_steps_the_cycle_runs(capi):
     assert (d["effective_presteps"], d["effective_poststeps"]) == ("1", "1")
 
 
+def test_norm_and_chebyshev_degree_keys(capi):
+    """`pib_norm` overrides the flavour's monitored norm (AmgX-style files: the L2 norm of the true residual, `norm=L2`; PETSc-options
+    files: KSPCG's preconditioned norm); `pib_cheby_degree` is the degree of one Chebyshev smoothing "sweep" in the PETSc-options
+    flavour, which has no native key for it (AmgX-style files say `chebyshev_polynomial_order`)."""
+    d = capi.config_describe("poisson", AMGX_POISSON)
+    assert d["norm"] == "unpreconditioned"
+    assert capi.config_describe("poisson", AMGX_POISSON + "pib_norm=PRECONDITIONED\n")["norm"] == "preconditioned"
+    p = capi.config_describe("poisson", PETSC_BOTH)
+    assert p["norm"] == "preconditioned"
+    assert capi.config_describe("poisson", PETSC_BOTH + "-poisson_ksp_norm_type unpreconditioned\n")["norm"] == "unpreconditioned"  # (its own spelling there)
+    c = capi.config_describe("poisson", PETSC_BOTH + "-poisson_pib_smoother CHEBYSHEV\n-poisson_pib_cheby_degree 3\n")
+    assert (c["smoother"], c["cheby_degree"], c["effective_presteps"]) == ("chebyshev", "3", "3")
+
+
 def test_collecting_the_gpu_suite_does_not_import_torch():
     """tests/conftest.py runs the GPU suite on /opt/rocm's own HIP runtime (PIB_TORCH_FIRST=0): that only holds while no test module
     imports torch at collection -- afterwards torch would load the copies it bundles beside the ones the library already uses."""
@@ -317,3 +331,21 @@ def test_gpu_tests_never_load_torchs_hip_runtime_into_the_pytest_process():
             if re.match(r"\s*(import torch|from torch)", line):
                 bad.append(f"{os.path.basename(f)}:{k}")
     assert bad == []
+
+
+def test_every_solver_file_key_is_exercised_by_a_test_and_there_are_at_most_35():
+    """The backend's own solver-file keys (csrc/config.cpp) stay a SMALL surface: at most 35, each one used by at least one test
+    of this directory (the `-<prefix>_pib_<key>` spelling of the PETSc-options flavour counts) -- a key nothing tests is a code
+    path nothing tests."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = open(os.path.join(root, "petibm_amd", "csrc", "config.cpp")).read()
+    keys = sorted(set(re.findall(r'get\("(pib_[a-z0-9_]+)"', cfg)) | set(re.findall(r'"default", "(pib_[a-z0-9_]+)"', cfg)))
+    assert len(keys) <= 35, keys
+    me = os.path.abspath(__file__)
+    text = "\n".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "*.py")) if os.path.abspath(f) != me)
+    text += "\n" + "\n".join(line for line in open(me) if "AMGX_" in line or "PETSC_" in line or "config_describe" in line)
+    unused = [k for k in keys if not re.search(k + r"(?![a-z0-9_])", text)]
+    assert unused == [], f"keys no test uses: {unused}"

@@ -285,7 +285,7 @@ def test_bcgs_with_the_multigrid_is_the_published_recurrence(n, side, pinned):
 
 
 def test_merged_residual_update_identities():
-    """csrc/krylov.hip k_finalize_post<7> (pib_bicgstab_merge_r): with omega = s.t / t.t and r = s - omega t, the sums the iteration
+    """csrc/krylov.hip k_finalize_post<7> (pib_bicgstab_form=3): with omega = s.t / t.t and r = s - omega t, the sums the iteration
     needs follow from five sums over s, t, r~ alone -- |r|^2 = s.s - omega (2 s.t - omega t.t), r.r~ = r~.s - omega r~.t -- so the
     pass that formed r only to sum it can go.  The relative error of |r|^2 by that formula is eps |s|^2 / |r|^2: checked here for
     half-steps that cut the residual by 3 x ... 1000 x."""

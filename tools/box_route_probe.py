@@ -115,7 +115,7 @@ def main():
 
 def velocity_part(n, P):
     """vSolver->setMatrix(A): per rank [u box | v box | w box]; moved to packed z-slabs for the matrix-free products
-    (default) against CSR products with the general packed halo plan on the boxes (pib_redistribute_velocity=0)."""
+    (default) against CSR products with the general packed halo plan on the boxes (pib_detect_structure=0: nothing recovered, nothing moved)."""
     from oracle import mesh as omesh
     dt, cnu = 1e-3, 0.5e-3
     t0 = time.perf_counter()
@@ -129,7 +129,7 @@ def velocity_part(n, P):
     print(f"# velocity system {n}^3 ({m.UN} rows) on {P} ranks, process grid {L.grid}; host preparation {time.perf_counter() - t0:.1f} s", flush=True)
     base = ("config_version=2\nsolver(solv)=PBICGSTAB\nsolv:max_iters=1000\nsolv:monitor_residual=1\nsolv:convergence=ABSOLUTE\n"
             "solv:tolerance=1e-10\nsolv:norm=L2\nsolv:preconditioner(prec)=BLOCK_JACOBI\nprec:relaxation_factor=0.9\npib_initial_guess_nonzero=0\n")
-    for extra, label in (("", "boxes -> packed slabs, matrix-free"), ("pib_redistribute_velocity=0\n", "boxes, CSR products")):
+    for extra, label in (("", "boxes -> packed slabs, matrix-free"), ("pib_detect_structure=0\n", "boxes, CSR products (no structure recovery)")):
         def rank_fn(r, uid):
             s = LinSolverHIP("velocity", config_text=base + extra, rank=r, nranks=P, uid=uid, device=0)
             r0, r1 = int(L.packed_offsets[r]), int(L.packed_offsets[r + 1])
