@@ -161,20 +161,25 @@ int upload_csr_general(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_g
     });
     PIB_HIP(hipMalloc(&A.col, sizeof(int32_t) * (size_t)(nnz + 4)));
     PIB_HIP(hipMalloc(&A.val, sizeof(double) * (size_t)(nnz + 4)));
-    PIB_MEMSET(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4));
-    PIB_MEMSET(A.val, 0, sizeof(double) * (size_t)(nnz + 4));
-    PIB_HIP(hipMemcpy(A.col, c32.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
-    PIB_HIP(hipMemcpy(A.val, val + base, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    // (on the solver's own stream: null-stream fills and copies wait for every stream of the process -- the other ranks' set-up,
+    // when the ranks of a process are threads on one device)
+    hipStream_t st = s->stream;
+    PIB_HIP(hipMemsetAsync(A.col, 0, sizeof(int32_t) * (size_t)(nnz + 4), st));
+    PIB_HIP(hipMemsetAsync(A.val, 0, sizeof(double) * (size_t)(nnz + 4), st));
+    PIB_HIP(hipMemcpyAsync(A.col, c32.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, st));
+    PIB_HIP(hipMemcpyAsync(A.val, val + base, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, st));
     if (A.rp64) {
         std::vector<int64_t> rp((size_t)n_local + 1);
         for (int64_t i = 0; i <= n_local; ++i) rp[(size_t)i] = V.RP(i) - base;
         PIB_HIP(hipMalloc(&A.rowptr, sizeof(int64_t) * ((size_t)n_local + 1)));
-        PIB_HIP(hipMemcpy(A.rowptr, rp.data(), sizeof(int64_t) * ((size_t)n_local + 1), hipMemcpyHostToDevice));
+        PIB_HIP(hipMemcpyAsync(A.rowptr, rp.data(), sizeof(int64_t) * ((size_t)n_local + 1), hipMemcpyHostToDevice, st));
+        PIB_HIP(hipStreamSynchronize(st));
     } else {
         std::vector<int32_t> rp((size_t)n_local + 1);
         for (int64_t i = 0; i <= n_local; ++i) rp[(size_t)i] = (int32_t)(V.RP(i) - base);
         PIB_HIP(hipMalloc(&A.rowptr, sizeof(int32_t) * ((size_t)n_local + 1)));
-        PIB_HIP(hipMemcpy(A.rowptr, rp.data(), sizeof(int32_t) * ((size_t)n_local + 1), hipMemcpyHostToDevice));
+        PIB_HIP(hipMemcpyAsync(A.rowptr, rp.data(), sizeof(int32_t) * ((size_t)n_local + 1), hipMemcpyHostToDevice, st));
+        PIB_HIP(hipStreamSynchronize(st));
     }
     // ---- who needs what: every rank's request counts, all-gathered; then the index lists themselves travel to the owners
     std::vector<double> req((size_t)P), reqs;
@@ -217,8 +222,9 @@ int upload_csr_general(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_g
     }
     PIB_HIP(hipMalloc(&A.send_idx, sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1)));
     PIB_HIP(hipMalloc(&A.send_buf, sizeof(double) * (size_t)std::max<int64_t>(ns, 1)));
-    PIB_HIP(hipMemcpy(A.send_idx, idx.data(), sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1), hipMemcpyHostToDevice));
-    PIB_MEMSET(A.send_buf, 0, sizeof(double) * (size_t)std::max<int64_t>(ns, 1));
+    PIB_HIP(hipMemcpyAsync(A.send_idx, idx.data(), sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1), hipMemcpyHostToDevice, s->stream));
+    PIB_HIP(hipMemsetAsync(A.send_buf, 0, sizeof(double) * (size_t)std::max<int64_t>(ns, 1), s->stream));
+    PIB_HIP(hipStreamSynchronize(s->stream));
     return 0;
 }
 

@@ -598,7 +598,11 @@ def test_marching_transfers_on_periodic_levels_are_bit_identical(lin, n, per, ra
         s.solve(x, b)
         out.append((x, s.getResidualHistory(), s.getIters()))
         s.destroy()
-    assert out[0][2] == out[1][2] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    if key == "pib_march":  # (also switches the blocked level kernels, whose Krylov sums are grouped by tile: to rounding)
+        assert out[0][2] == out[1][2] and np.allclose(out[0][1], out[1][1], rtol=1e-9, atol=0.0)
+        assert np.abs(out[0][0] - out[1][0]).max() <= 1e-12 * np.abs(out[1][0]).max()
+    else:
+        assert out[0][2] == out[1][2] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
     g = clib.GMG(n, w, dt, nullspace=2 if pinned else 1, pre=sweeps, post=sweeps, omega=0.9, coarsest_sweeps=32, periodic=per)
     ref = g.pcg(A, b, rtol=1e-10, maxit=200)
     assert iters_close(out[0][2], ref["iters"])
