@@ -5,8 +5,8 @@
 // :84 (`setA`) and :96 (`solve`) is done here with plain MPI calls, i.e. what include/petibm_amd/petsc_adapter.hpp does with
 // PETSc's communicator (broadcastUniqueId, localDevice):
 //   * rank 0 draws the communicator id (RCCL, or the HIP-IPC peer windows with PIB_TRANSPORT=peer), MPI_Bcast hands it round;
-//   * MPI_Comm_split_type(MPI_COMM_TYPE_SHARED) gives the node-local rank = the HIP device (modulo the device count: a test box
-//     with one GPU carries every rank on device 0, which RCCL refuses and the peer transport accepts);
+//   * MPI_Comm_split_type(MPI_COMM_TYPE_SHARED) gives the node-local rank = the HIP device (a test box with one GPU carries every
+//     rank on device 0 -- third argument --, which RCCL refuses and the peer transport accepts);
 //   * the mesh is cut into the (m, n, p) boxes DMDACreate3d picks with PETSC_DECIDE for a cube on a power-of-two communicator
 //     (src/mesh/cartesianmesh.cpp:97,503-519: (1,1,2), (1,2,2), (2,2,2)), rows numbered rank by rank, inside a box x fastest
 //     (the "PETSc ordering" of a DMDA) -- int32 indices as AmgX's mode dDDI, global columns;
@@ -16,7 +16,8 @@
 //
 //   g++ -std=c++14 -I include -I /opt/conda/include examples/mpi/poisson_boxes_mpi.cpp -L petibm_amd/lib -lpetibm_amd
 //       -L /opt/conda/lib -lmpi -Wl,-rpath,/opt/conda/lib -o examples/mpi/poisson_boxes_mpi
-//   PIB_TRANSPORT=peer mpiexec -n 8 examples/mpi/poisson_boxes_mpi 64
+//   mpiexec -n 8 examples/mpi/poisson_boxes_mpi 64                              (8 GPUs, RCCL)
+//   PIB_TRANSPORT=peer mpiexec -n 8 examples/mpi/poisson_boxes_mpi 64 1e-10 1   (8 ranks sharing ONE GPU: the test box)
 #include <mpi.h>
 
 #include <cmath>
@@ -58,6 +59,8 @@ int main(int argc, char **argv)
     MPI_Comm_size(MPI_COMM_WORLD, &size);
     const int N = argc > 1 ? std::atoi(argv[1]) : 48;
     const double tol = argc > 2 ? std::atof(argv[2]) : 1e-10;
+    // (a test box with fewer GPUs than ranks: the node-local rank modulo this many devices -- the peer transport only; 0: one each)
+    const int devices = argc > 3 ? std::atoi(argv[3]) : 0;
 
     // ---- the communicator id: rank 0 draws it, everybody receives it
     char uid[PIB_UID_BYTES];
@@ -168,7 +171,7 @@ int main(int argc, char **argv)
                   "prec:presweeps=1\nprec:postsweeps=1\nprec:smoother=BLOCK_JACOBI\nprec:relaxation_factor=0.9\n",
                   tol);
     pib_solver *s = nullptr;
-    int e = pib_create_from_string(&s, "poisson", cfg, rank, size, size > 1 ? uid : nullptr, lrank);
+    int e = pib_create_from_string(&s, "poisson", cfg, rank, size, size > 1 ? uid : nullptr, devices > 0 ? lrank % devices : lrank);
     if (e) die(rank, "pib_create", e);
     e = pib_set_csr_i32(s, n_local, (int32_t)me.first, (int32_t)n_global, rowptr.data(), col.data(), val.data());
     if (e) die(rank, "pib_set_csr_i32", e);

@@ -298,7 +298,7 @@ static int apply_amgx(const AmgxDoc &d, Config &c)
     c.matrix_free_velocity = std::atoi(d.get("default", "pib_matrix_free_velocity", "1").c_str());
     c.fuse_velocity_product = std::atoi(d.get("default", "pib_fuse_velocity_product", "1").c_str());
     c.bicgstab_form = std::atoi(d.get("default", "pib_bicgstab_form", "3").c_str());
-    c.fuse_residual_update = std::atoi(d.get("default", "pib_fuse_residual_update", "2").c_str());
+    c.fuse_residual_update = std::atoi(d.get("default", "pib_fuse_residual_update", "1").c_str());
     c.pin_sum_local = std::atoi(d.get("default", "pib_pin_sum_local", "-1").c_str());
     c.compress_columns = std::atoi(d.get("default", "pib_compress_columns", "2").c_str());
     c.place_update_vector = std::atoi(d.get("default", "pib_place_update_vector", "1").c_str());

@@ -817,7 +817,7 @@ bool gmg_fused_update_ok(const pib_solver *s)
     if (s->comm.nranks > 1) {
         // z-slabs (round 4): level 0 distributed with deep halos, every rank's slab thick enough for them, the two-step march
         // (the cycle decides again with its own predicate at the launch site and falls back to the separate pass if it must)
-        if (s->cfg.fuse_residual_update < 2 || !s->cfg.deep_halo || g.replicated || g.zring || (g.per & 4)) return false;
+        if (s->cfg.fuse_residual_update < 0 || !s->cfg.deep_halo || g.replicated || g.zring || (g.per & 4)) return false;
         if (std::max(1, s->cfg.presweeps) * (s->cfg.sweep_pairs ? 2 : 1) < 2) return false;
         return fused_update_slabs_all_ranks(s, g);
     }
@@ -1257,7 +1257,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
             auto al32 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 31u) == 0; };
             // (several ranks: the slab-dependent parts for EVERY rank's slab -- fused_update_slabs_all_ranks -- so that all ranks fall
             // back together or not at all)
-            bool site = s->cfg.fuse_residual_update >= 1 && !cheb && s->cfg.fuse_presmooth && al32(b) && (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
+            bool site = (s->cfg.fuse_residual_update == 1 || s->cfg.fuse_residual_update == -1) && !cheb && s->cfg.fuse_presmooth && al32(b) && (pre >= 2 ? al32(c) : (al32(a) && al32(rr)));
             if (I.dist) site = site && fused_update_slabs_all_ranks(s, g);
             else site = site && fused_run_ok(s, g, 0, I.nk) && (g.n[0] / FX) * (g.n[1] / FY) * ((I.nk + FZ0 - 1) / FZ0 + 2) <= PIB_MAXPART;
             // z-slabs: the two-step march only, deep halos (the residual's depth is what w is exchanged to), aligned planes

@@ -149,7 +149,7 @@ struct Config {
                              // 64..4096 cells, 152 ms at 32768): launches pipeline, one CU with block barriers does not. Off.
     int matrix_free_poisson = -1;  // Krylov products of a Poisson solve with the stencil twin: 1 on, 0 off, -1 = on inside the device time step only (>= 2^20 rows)
     int cg_single_reduction = 0;   // CG with PETSc's single-reduction recurrences (-<name>_ksp_cg_single_reduction; solver file: pib_cg_single_reduction=1): ONE all-reduce per iteration, 16 B/row more vector traffic (krylov.hip solve_cg_sr)
-    int fuse_residual_update = 2;  // PCG + multigrid: r = r - alpha w by the V-cycle's first march instead of a pass of its own.  1: on one rank only; 2 (default): on z-slabs too -- w = A p is exchanged to the depth the residual was, the march keeps the residual's ghost planes by recurrence; 0: the separate pass
+    int fuse_residual_update = 1;  // PCG + multigrid: r = r - alpha w by the V-cycle's first march instead of a pass of its own.  1 (default): on one rank and on z-slabs -- there w = A p is exchanged to the depth the residual was and the march keeps the residual's ghost planes by recurrence; -1: on one rank only; 0: the separate pass; 2 (tests): asked for, but the launch site refuses it: the fallback pass
     int pin_sum_local = -1;  // pinned pressure row + multigrid: the residual's sum that makes the cycle's right-hand side compatible from the recurrence sum r - alpha sum w, sum w = -(row 0 of the singular operator) . p (krylov.hip cg_s1) instead of the update pass's own sum -- what lets the update ride in the cycle's first march; -1: with the fused update only, 1: always, 0: never (no fused update under a pinned row)
     int bicgstab_form = 3;  // BiCGStab on the matrix-free velocity operator (krylov.hip OpBFUpdateP): 0 the general path; 1 lean -- no stored M^-1 p / M^-1 s, the x update deferred: the same iterates bit for bit; 2 + the two dot-only passes summed by the products themselves (sums grouped by tile: iterates to rounding); 3 (default) + r = s - omega t formed by the next p-update, |r|^2 and r.rp from the second product's five sums (16 B/row/iteration and one reduction less)
     int fuse_velocity_product = 1;  // 3-D: the three components' tiles and shells in one launch (velstencil.hip k_vel_product)

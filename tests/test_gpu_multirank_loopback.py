@@ -411,7 +411,7 @@ def test_residual_update_inside_the_vcycle_on_slabs(P, n, extra):
     """Round 4: PCG's r = r - alpha w inside the V-cycle's first march on z-slabs too (krylov.hip / gmg.hip k_presmooth2<., 1>
     with `wext`): w = A p is exchanged to the depth the residual was, every launch updates the planes it loads, the neighbours'
     planes of the new residual are written as well and follow the recurrence from then on.  Same expression per cell: the
-    iterates are those of the separate pass (pib_fuse_residual_update=1: one rank only) bit for bit on every rank; the counters say the
+    iterates are those of the separate pass (pib_fuse_residual_update=-1: one rank only) bit for bit on every rank; the counters say the
     fused form ran; the solve is the single rank's."""
     from petibm_amd import capi
     import slab_plans as partition
@@ -425,7 +425,7 @@ def test_residual_update_inside_the_vcycle_on_slabs(P, n, extra):
     def run(fuse):
         def rank_fn(r, uid):
             pl = plans[r]
-            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=base + f"pib_fuse_residual_update={2 if fuse else 1}\n", sweeps=2), rank=r, nranks=P,
+            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=base + f"pib_fuse_residual_update={1 if fuse else -1}\n", sweeps=2), rank=r, nranks=P,
                              uid=uid, device=0)
             s.assemblePoisson(n, w, dt, capi.NULLSPACE_CONSTANT)
             x = np.zeros(pl.n_local)

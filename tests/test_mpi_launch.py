@@ -48,7 +48,7 @@ def test_mpiexec_ranks_on_petsc_decide_boxes(mpi_binary, ranks, n):
     ranks per device; on a node with P GPUs the same line runs over RCCL without the variable)."""
     exe, mpiexec = mpi_binary
     env = dict(os.environ, PIB_TRANSPORT="peer", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([mpiexec, "-n", str(ranks), exe, str(n), "1e-10"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    out = subprocess.run([mpiexec, "-n", str(ranks), exe, str(n), "1e-10", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
