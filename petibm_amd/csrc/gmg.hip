@@ -44,7 +44,7 @@ namespace pib {
 // halo memory / deepest exchange of a distributed level (see "halos of a distributed level" below)
 constexpr int HALO_PAD_PLANES = 8;   // memory per side (the fused kernels read one plane beyond the run they process)
 constexpr int HALO_MAX_DEPTH = 6;    // deepest exchange: V(2,2) needs 4 planes of the residual on level 0; below it 3, or -- when the
-                                     // way up is to run without exchanges of its own (pib_deep_up) -- 5 on level 1 and 6 on level 2
+                                     // way up is to run without exchanges of its own (pib_deep_halo=2) -- 5 on level 1 and 6 on level 2
 
 static LevelDev dev_of(const GridLevel &g)
 {
@@ -1085,7 +1085,7 @@ int gmg_apply(pib_solver *s, const double *r, double *z, hipStream_t q)
     // reach of one plane; level 0 also carries the post-smoothing steps and one plane of the result z, so that neither
     // the corrected iterate nor p = z + beta p (the next Krylov product's input) needs an exchange of its own
     // ... and a coarser distributed level delivers ITS final iterate on as many ghost planes as the prolongation onto the finer
-    // level reads (pib_deep_up, round 4): the exchange of the coarse correction on the way up -- a collective with nothing to
+    // level reads (pib_deep_halo=2, round 4): the exchange of the coarse correction on the way up -- a collective with nothing to
     // hide behind -- goes, the right-hand side of that level is exchanged deeper on the way down instead (the same bytes: at
     // 512^3 / 8 five planes of level 1 instead of 3 + 2, six of level 2 instead of 3 + 3) and a few more ghost planes of two
     // latency-bound levels are relaxed redundantly.  Where the level's slabs are too thin for that depth the exchange stays.

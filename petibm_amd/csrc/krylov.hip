@@ -1812,15 +1812,15 @@ struct OpShiftV {  // v -= red[slot] / n_global
 // product): M^-1 p and M^-1 s are never stored -- the products apply the sweep as they read their input
 // (vel_stencil_apply's dinv / opc) -- and x += alpha M^-1 p + omega M^-1 s is applied by the NEXT iteration's p-update,
 // which reads p anyway.  216 -> 200 B/row/iteration (27 -> 25 vector passes).  Every value is computed by the expression
-// of the general path above: bit-identical iterates -- unless `pib_fuse_bicgstab_dots` (default on) lets the products sum
+// of the general path above: bit-identical iterates -- unless `pib_bicgstab_form` >= 2 (default 3) lets the products sum
 // v.rp and s.t, t.t themselves (two passes less, 184 B/row/iteration): those sums are grouped by tile, so alpha and omega
 // agree with the general path's to rounding only.
 struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*beta) v + beta p
     // y != nullptr: the owed update goes into y += xalpha p + xomega s instead -- the sum of the search directions BEFORE the
     // (stationary) Jacobi sweep, x = x0 + M^-1 y once at the end (k_b_flush_x) -- which takes the dinv and x streams out
     // of this pass: 56 instead of 64 B/row.  x then differs from the general path's by rounding (the residual recurrence
-    // does not see x), so this rides with the fused sums (`pib_fuse_bicgstab_dots`), not with the bit-identical route.
-    // t != nullptr (`pib_bicgstab_merge_r`, with y): the residual update the previous iteration owes, r = s - omega t, is formed
+    // does not see x), so this rides with the fused sums (`pib_bicgstab_form` >= 2), not with the bit-identical route.
+    // t != nullptr (`pib_bicgstab_form` 3, with y): the residual update the previous iteration owes, r = s - omega t, is formed
     // HERE (s is read for y anyway) and stored for the next s = r - alpha v: OpBFUpdateR's pass (s, t, rp in, r out) is gone, its two
     // sums come out of the second product's five (k_finalize_post<7>).  Same expression: r has the bits OpBFUpdateR would store.
     static constexpr int NRED = 0;
