@@ -431,7 +431,7 @@ int pib_get_counters(pib_solver *s, int64_t counters[8]);
  * pointers were device pointers. */
 int pib_get_staging_ms(pib_solver *s, double *h2d_ms, double *d2h_ms);
 /* Krylov iterations launched as replays of the captured iteration graph since the solver was created (launch-bound systems:
- * pib_graph_max_rows (0: never); on several ranks with the device-ordered peer transport only). */
+ * the solver-file key pib_graph_max_rows, 0 = never; on several ranks with the device-ordered peer transport only). */
 int pib_get_graph_replays(pib_solver *s, int64_t *replays);
 /* The placement of the search direction against the caller's x (pib_place_update_vector: CG on one rank, 2^25 rows and more):
  * searches run since the solver was created (a device whose memory is more than half taken gets a search that times nothing),

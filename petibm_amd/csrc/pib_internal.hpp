@@ -631,6 +631,7 @@ int detect_velocity_structure(pib_solver *s, int64_t n_local, int64_t row0, int6
                               const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val);
 int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
                           const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val);
+void grid_detection_rows(const int64_t n[3], int64_t k0, int64_t k1, std::vector<int64_t> &local_rows);  // the local rows it reads
 // gmg.hip
 int gmg_verify(pib_solver *s);
 int stencil_apply(pib_solver *s, double *x_owned, double *y, hipStream_t st);

@@ -303,8 +303,8 @@ struct DevScratchSet {
 };
 
 // The whole move.  In: this rank's rows as the caller handed them over (host), the field's geometry and plans (F), the widest
-// row W.  Out: `in` holds the slab's matrix (device CSR, like upload_csr would have made it); h_rp / h_cl / h_vl: the same rows
-// with natural GLOBAL columns in pinned host memory for the structure recovery (released by the caller: free).
+// row W.  Out: `in` holds the slab's matrix (device CSR, like upload_csr would have made it); h_rp / h_cl / h_vl: the rows the
+// structure recovery reads, natural GLOBAL columns, every other row empty, in host memory (released by the caller: free).
 // Returns PIB_ERR_SUP when the shape does not fit this path (rows wider than 16 entries, 64-bit sizes): the caller's host path.
 int redist_rows_on_device(pib_solver *s, pib_solver *in, const RedistField &F, const int64_t N[3], int64_t n_local, int64_t row0, int64_t n_global,
                           const int64_t *rp64, const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val, int64_t W,
@@ -427,18 +427,44 @@ int redist_rows_on_device(pib_solver *s, pib_solver *in, const RedistField &F, c
     hipLaunchKernelGGL(k_slab_fill<WMAX>, dim3(nbs), dim3(256), 0, st, G, d_recv, (int)W, d_rp64, G.row0s - A.ghost_lo, A.col, d_nat, A.val);
     hipLaunchKernelGGL(k_to_i32, dim3(nbs), dim3(256), 0, st, d_rp64, static_cast<int32_t *>(A.rowptr), F.n_slab + 1);
     PIB_HIP(hipGetLastError());
-    // ---- the same rows for the structure recovery on the host (pinned: the copy runs at PCIe speed)
-    // (plain host memory: pinning 1.5 GB costs more than the staged copy saves)
+    // ---- for the structure recovery on the host: ONLY the rows it reads (structure.cpp grid_detection_rows: the first rows and
+    // three lines through a base cell, a thousand rows), as a CSR whose other rows are empty -- the whole slab was 1.4 GB over
+    // PCIe and 1.5 GB of host memory per rank at 512^3 / 8, and 1.3 of the 3.9 s of a box-route setMatrix on the shared test GPU
     tr.mark("slab CSR built");
-    *h_rp = static_cast<int32_t *>(std::malloc(sizeof(int32_t) * ((size_t)F.n_slab + 1)));
-    *h_cl = static_cast<int32_t *>(std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
-    *h_vl = static_cast<double *>(std::malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
-    if (*h_rp == nullptr || *h_cl == nullptr || *h_vl == nullptr) return fail(PIB_ERR_MEM, "set_csr: out of host memory");
-    PIB_HIP(hipMemcpyAsync(*h_rp, A.rowptr, sizeof(int32_t) * ((size_t)F.n_slab + 1), hipMemcpyDeviceToHost, st));
-    PIB_HIP(hipMemcpyAsync(*h_cl, d_nat, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st));
-    PIB_HIP(hipMemcpyAsync(*h_vl, A.val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st));
+    std::vector<int64_t> need;
+    grid_detection_rows(N, F.k0, F.k1, need);
+    *h_rp = static_cast<int32_t *>(std::calloc((size_t)F.n_slab + 1, sizeof(int32_t)));
+    std::vector<int32_t> drp(2 * need.size() + 2, 0);
+    if (*h_rp == nullptr) return fail(PIB_ERR_MEM, "set_csr: out of host memory");
+    PIB_HIP(hipStreamSynchronize(st));
+    const int32_t *d_rp32 = static_cast<const int32_t *>(A.rowptr);
+    for (size_t t = 0; t < need.size(); ++t)  // (begin, end) of every needed row: adjacent offsets, 8 bytes each
+        PIB_HIP(hipMemcpyAsync(&drp[2 * t], d_rp32 + need[t], 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PIB_HIP(hipStreamSynchronize(st));
+    int64_t keep = 0;
+    for (size_t t = 0; t < need.size(); ++t) keep += drp[2 * t + 1] - drp[2 * t];
+    *h_cl = static_cast<int32_t *>(std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(keep, 1)));
+    *h_vl = static_cast<double *>(std::malloc(sizeof(double) * (size_t)std::max<int64_t>(keep, 1)));
+    if (*h_cl == nullptr || *h_vl == nullptr) return fail(PIB_ERR_MEM, "set_csr: out of host memory");
+    {
+        int64_t at = 0;
+        size_t t = 0;
+        for (int64_t l = 0; l < F.n_slab; ++l) {  // the compact row offsets: empty rows everywhere else
+            (*h_rp)[l] = (int32_t)at;
+            if (t < need.size() && need[t] == l) {
+                const int32_t b0 = drp[2 * t], len = drp[2 * t + 1] - drp[2 * t];
+                if (len > 0) {
+                    PIB_HIP(hipMemcpyAsync(*h_cl + at, d_nat + b0, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, st));
+                    PIB_HIP(hipMemcpyAsync(*h_vl + at, A.val + b0, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, st));
+                }
+                at += len;
+                ++t;
+            }
+        }
+        (*h_rp)[F.n_slab] = (int32_t)at;
+    }
     PIB_HIP(hipStreamSynchronize(st));  // (this stream only: a plain hipMemcpy waits for every stream of the process)
-    tr.mark("slab CSR copied to the host");
+    tr.mark("the rows the structure recovery reads copied to the host");
     *nnz_out = nnz;
     return 0;
 }

@@ -51,6 +51,32 @@ struct HostCsr {
 
 int comm_allgather_host(pib_solver *s, const std::vector<double> &mine, std::vector<double> &all);
 
+// The LOCAL rows detect_grid_structure reads of a rank's natural z-slab (y-slab) [k0, k1) of an n[0] x n[1] x n[2] grid (2-D:
+// n[1] = 1, slab axis = n[2]): the first eight rows, the two in-plane lines through base index 1 on slab plane 1 (its owner only)
+// and the line along the slab axis through the in-plane base cell.  A caller that holds the rows on the device (the box route,
+// redistribute.hip) downloads only these -- a thousand rows instead of the slab's 1.4 GB at 512^3 / 8; every `take` and every
+// RP / CL access below must stay inside this set (a row outside it reads as "entry not stored": no structure, never a wrong one).
+void grid_detection_rows(const int64_t n[3], int64_t k0, int64_t k1, std::vector<int64_t> &local_rows)
+{
+    const bool three = n[1] > 1;
+    const int64_t pl = n[0] * n[1], n_local = (k1 - k0) * pl;
+    std::set<int64_t> rows;
+    for (int64_t l = 0; l < std::min<int64_t>(n_local, 8); ++l) rows.insert(l);
+    auto add = [&](int64_t global) {
+        const int64_t l = global - k0 * pl;
+        if (l >= 0 && l < n_local) rows.insert(l);
+    };
+    if (k0 <= 1 && 1 < k1) {
+        if (three) {
+            for (int64_t i = 0; i < n[0]; ++i) add(pl + n[0] + i);
+            for (int64_t j = 0; j < n[1]; ++j) add(pl + j * n[0] + 1);
+        } else
+            for (int64_t i = 0; i < n[0]; ++i) add(pl + i);
+    }
+    for (int64_t k = k0; k < k1; ++k) add(k * pl + (three ? n[0] + 1 : 1));
+    local_rows.assign(rows.begin(), rows.end());
+}
+
 // returns 0 always unless a collective / HIP call fails; success shows in s->has_grid
 int detect_grid_structure(pib_solver *s, int64_t n_local, int64_t row0, int64_t n_global, const int64_t *rp64,
                           const int64_t *cl64, const int32_t *rp32, const int32_t *cl32, const double *val)
