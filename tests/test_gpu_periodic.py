@@ -365,6 +365,43 @@ def test_periodic_slab_axis_across_ranks(P, n, per, pc, extra):
     s1.destroy()
 
 
+@pytest.mark.parametrize("P,n", [(2, (16, 16, 32)), (3, (16, 16, 36))])
+def test_pinned_row_on_a_periodic_slab_ring_ignores_the_local_sum(P, n):
+    """Round-5 advisor finding: on a z-RING of slabs the last rank recomputes global cell 0 as a halo cell across the seam; with
+    `pib_pin_sum_local=1` it read `Scalars::pin_sigma`, which only the rank that owns cell 0 ever sets.  The local sum is now taken
+    on several ranks only together with the fused residual update (wall-bounded slabs thick enough that nobody else touches cell 0);
+    everywhere else every rank uses the all-reduced sum: =1 and =0 give the same bits here, and the solve meets the contract."""
+    from petibm_amd import capi
+    import slab_plans as partition
+    from petibm_amd.linsolver import LinSolverHIP
+    from test_gpu_multirank_loopback import _cfg, _run_ranks
+    dt, per = 0.01, (True, True, True)
+    m = omesh.create_mesh(omesh.periodic_config(n, per))
+    D, G, L = oops.create_divergence(m), oops.create_gradient(m), oops.create_laplacian(m)
+    _, A = oops.create_poisson_operator(D, G, L, dt, 0.005)
+    A = oops.pin_row0(A)
+    xs, b = rhs_for(A, zero_mean=False)
+    b[0] = 0.0
+    w = [m.dL[3][d].true for d in range(m.dim)]
+    plans = partition.all_plans(n, P)
+    out = []
+    for local in (1, 0):
+        def rank_fn(r, uid, local=local):
+            pl = plans[r]
+            s = LinSolverHIP("poisson", config_text=_cfg("AMG", extra=f"pib_sweep_pairs=1\npib_pin_sum_local={local}\n"), rank=r, nranks=P, uid=uid, device=0)
+            s.setPeriodic(per)
+            s.assemblePoisson(list(n), w, dt, capi.NULLSPACE_PINNED)
+            x = np.zeros(pl.n_local)
+            s.solve(x, np.ascontiguousarray(b[pl.row0:pl.row0 + pl.n_local]))
+            out_r = (x, s.getIters(), np.array(s.getResidualHistory()))
+            s.destroy()
+            return out_r
+        res = _run_ranks(P, rank_fn)
+        out.append((np.concatenate([r[0] for r in res]), res[0][1], res[0][2]))
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][0], out[1][0])
+    assert np.linalg.norm(b - clib.spmv(A, out[0][0])) <= 1.5e-10 * np.linalg.norm(b)
+
+
 @pytest.mark.parametrize("P,n,per", [(2, (10, 9, 12), (True, True, True)), (3, (8, 6, 12), (False, False, True)),
                                      (2, (12, 10), (True, True)), (4, (6, 5, 16), (True, False, True)),
                                      (2, (128, 8, 16), (True, True, True)), (3, (128, 9, 12), (False, True, True))])  # one-launch march on the slabs
