@@ -187,6 +187,45 @@ def test_random_mesh_time_steps_match_oracle(seed):
     s.destroy()
 
 
+@pytest.mark.parametrize("seed", [0, 3, 6, 9, 12, 15, 18, 21])
+def test_random_wide_3d_meshes_first_step_rhs_through_the_march(seed):
+    """The three-component march of the explicit terms (navierstokes.hip k_ns_rhs_march: 3-D meshes of 32 cells and more along x)
+    on the sweep's boundary sets -- walls, sliding walls, zero-gradient components, a convective outlet, periodic directions -- and
+    sub-domain layouts, refined 12 x 3 x 3 so that the march's tiles (partial ones included) cover them: rhs1 of the first step is
+    the oracle's bit for bit (across a periodic seam a shell row sums its wrapped neighbour in another place: 1e-13 there)."""
+    from petibm_amd.navierstokes import NavierStokesSolver
+    cfg, per, stream = random_config(seed)
+    assert len(cfg["mesh"]) == 3
+    for d, factor in enumerate((12, 3, 3)):
+        for sub in cfg["mesh"][d]["subDomains"]:
+            sub["cells"] *= factor
+            sub["stretchRatio"] = float(sub["stretchRatio"] ** (1.0 / factor))
+    m = omesh.create_mesh(cfg)
+    assert m.n[3][0] >= 48
+    dt, nu = cfg["parameters"]["dt"], cfg["flow"]["nu"]
+    pinned = bool(seed % 2) or stream >= 0
+    ref = ons.NavierStokes(m, dt, nu, pinned=pinned)
+    rng = np.random.default_rng(177 + seed)
+    U0, p0 = 0.1 * rng.uniform(-1, 1, m.UN), 0.1 * rng.uniform(-1, 1, m.pN)
+    if stream >= 0:
+        off = sum(int(np.prod(m.n[f])) for f in range(stream))
+        U0[off: off + int(np.prod(m.n[stream]))] += 1.0
+    if pinned:
+        p0[0] = 0.0
+    ref.set_state(U0, p0)
+    ref.advance(velocity_rhs_only=True)
+    s = NavierStokesSolver(cfg, velocity_cfg=VEL, poisson_cfg=AMGX_P if pinned else KSP_P)
+    s.setState(U0, p0)
+    s.advance()
+    r1 = s.getState(rhs=True)[2]
+    if any(per):
+        assert np.abs(r1 - ref.last_rhs1).max() <= 1e-13 * np.abs(ref.last_rhs1).max()
+        assert (r1 != ref.last_rhs1).mean() <= 0.2  # (the seam's shell rows only)
+    else:
+        assert np.array_equal(r1, ref.last_rhs1)
+    s.destroy()
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_mesh_time_steps_on_slabs(seed):
     """The same configurations on 2 or 3 slabs (loopback ranks on the one GPU) against the single-rank engine: rhs1 of the
