@@ -975,8 +975,11 @@ def poisson_bench(args) -> int:
         csr_plain = None
         if world == 1:
             try:
+                free_b, _ = s.deviceMemInfo()
                 if idx_bytes == 4:
                     ms_plain = ms_spmv
+                elif free_b < 2.0 * (12.0 * nnz_l + 64.0 * n_l):  # (a second copy of the system beside the first: 768^3 and up may not have it)
+                    raise RuntimeError(f"{free_b / 1e9:.0f} GB free: no room for a second copy of the matrix")
                 else:
                     s2 = LinSolverHIP("poisson", config_text=base_text + "pib_compress_columns=0\n")
                     w1 = np.full(n, 1.0 / n)
