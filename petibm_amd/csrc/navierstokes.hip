@@ -465,6 +465,8 @@ __global__ __launch_bounds__(256) void k_ns_rhs_velocity(NsDev D, double dt, dou
 #endif
 constexpr int RHS_TX = 64, RHS_TY = 8, RHS_PX = RHS_TX + 2, RHS_TILE = 664;  // (66 x 10 = 660 points, padded)
 constexpr int RHS_HALO = 2 * RHS_PX + 2 * RHS_TY;                            // 148 ring points
+static_assert(RHS_TX == 64, "a wave is one row of the tile: j is wave-uniform (readfirstlane)");
+static_assert(RHS_HALO <= RHS_TX * RHS_TY, "one ring point per thread");
 template <bool STORE_DIFF>
 __global__ __launch_bounds__(RHS_TX * RHS_TY, PIB_RHS_WAVES) void k_ns_rhs_march(NsDev D, double dt, double nu, NsTime T, const double *__restrict__ U,
                                                                const double *__restrict__ p, const double *__restrict__ conv1,
