@@ -32,667 +32,9 @@
 
 #include "pib_internal.hpp"
 
+#include "krylov_ops.hpp"
+
 namespace pib {
-
-int spmv_rows(pib_solver *s, const double *x_owned, double *y, int64_t r_begin, int64_t r_end, double *dot_part,
-              bool guarded, hipStream_t st);
-int spmv_launch_blocks();
-
-#ifndef PIB_VGRID_MAX
-#define PIB_VGRID_MAX 2048
-#endif
-constexpr int VGRID_MAX = PIB_VGRID_MAX;
-
-__device__ __forceinline__ double wsum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-
-template <int W>
-struct Pack {
-    double v[W];
-};
-template <int W>
-__device__ __forceinline__ Pack<W> ld(const double *p, int64_t i)
-{
-    Pack<W> r;
-    if constexpr (W == 2) {
-        const double2 t = *reinterpret_cast<const double2 *>(p + 2 * i);
-        r.v[0] = t.x;
-        r.v[1] = t.y;
-    } else {
-        r.v[0] = p[i];
-    }
-    return r;
-}
-template <int W>
-__device__ __forceinline__ void st(double *p, int64_t i, const Pack<W> &r)
-{
-    if constexpr (W == 2) {
-        *reinterpret_cast<double2 *>(p + 2 * i) = make_double2(r.v[0], r.v[1]);
-    } else {
-        p[i] = r.v[0];
-    }
-}
-
-// Generic fused vector kernel.  Op::NRED partial sums go to
-// part[(k)*PIB_MAXPART + blockIdx.x].
-// [e_begin, e_end): element range (multiples of W; the odd tail element belongs to the range that ends at n)
-template <int W, class Op>
-__global__ __launch_bounds__(256) void k_vec(const Scalars *__restrict__ S, int64_t n, Op op, double *__restrict__ part,
-                                             int64_t e_begin, int64_t e_end, int64_t per = 0)
-{
-    if (S != nullptr && S->done) return;
-    constexpr int NR = Op::NRED > 0 ? Op::NRED : 1;
-    double acc[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) acc[k] = 0.0;
-    op.prepare(S);
-    const int64_t ng = (e_end == n) ? n / W : e_end / W;
-    if (per > 0) {
-        // large vectors: a contiguous range per workgroup (a 24 B/cell stream runs 0.56 instead of 0.60 ms per 512^3 pass
-        // this way: tools/vcycle_lab.hip S) -- the partial sums are then grouped by range instead of by stride
-        const int64_t lo = e_begin / W + (int64_t)blockIdx.x * per, hi = min(lo + per, ng);
-#pragma unroll 2
-        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) op.template apply<W>(i, acc);
-    } else {
-        const int64_t stride = (int64_t)gridDim.x * 256;
-#pragma unroll 2
-        for (int64_t i = e_begin / W + (int64_t)blockIdx.x * 256 + threadIdx.x; i < ng; i += stride) op.template apply<W>(i, acc);
-    }
-    if (W == 2 && (n & 1) && e_end == n && blockIdx.x == 0 && threadIdx.x == 0) op.template apply<1>(n - 1, acc);
-    if (Op::NRED > 0) {
-        __shared__ double sh[NR][4];
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const double v = wsum(acc[k]);
-            if (lane == 0) sh[k][w] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < NR) {
-            const int k = threadIdx.x;
-            part[(int64_t)k * PIB_MAXPART + blockIdx.x] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
-        }
-    }
-}
-
-// The same for operations without sums, one contiguous chunk of 4 x 256 packs per workgroup instead of a grid-stride
-// loop: the dispatcher then sweeps a moving address window (tools/vcycle_lab.hip: 5.5 -> 5.8 TB/s for a 2-read-1-write
-// stream; the SpMV gained 10-15 % from the same change).  Kernels with sums keep the bounded grid (their partials).
-template <int W, class Op>
-__global__ __launch_bounds__(256) void k_vec_chunk(const Scalars *__restrict__ S, int64_t n, Op op, int64_t e_begin, int64_t e_end)
-{
-    if (S != nullptr && S->done) return;
-    double acc[1] = {0.0};
-    op.prepare(S);
-    const int64_t ng = (e_end == n) ? n / W : e_end / W;
-    const int64_t base = e_begin / W + (int64_t)blockIdx.x * 1024 + threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = base + 256 * u;
-        if (i < ng) op.template apply<W>(i, acc);
-    }
-    if (W == 2 && (n & 1) && e_end == n && blockIdx.x == 0 && threadIdx.x == 0) op.template apply<1>(n - 1, acc);
-}
-
-// sum `count` partials of each of `nslots` slots (one block per slot), fixed order.
-__global__ __launch_bounds__(256) void k_finalize(Scalars *__restrict__ S, const double *__restrict__ part, int slot0,
-                                                  int count)
-{
-    if (S->done) return;
-    const int slot = slot0 + blockIdx.x;
-    const double *p = part + (int64_t)slot * PIB_MAXPART;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < count; i += 256) v += p[i];
-    __shared__ double sh[4];
-    v = wsum(v);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) S->red[slot] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
-static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-template <class Op>
-static int launch_vec(pib_solver *s, int64_t n, const Op &op, bool vec2, int slot0, int *nblocks_out, bool guarded,
-                      hipStream_t stq, int64_t e_begin = 0, int64_t e_end = -1)
-{
-    if (e_end < 0) e_end = n;
-    if (e_end <= e_begin) return 0;
-    int64_t ng = vec2 ? (e_end - e_begin + 1) / 2 : (e_end - e_begin);
-    int nb = (int)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (ng + 255) / 256));
-    double *part = s->d_part + (int64_t)slot0 * PIB_MAXPART;
-    const Scalars *S = guarded ? s->d_s : nullptr;
-    if constexpr (Op::NRED == 0) {
-        if (ng >= ((int64_t)1 << 20)) {  // large streaming update: chunked
-            const unsigned nc = (unsigned)((ng + 1023) / 1024);
-            if (vec2)
-                hipLaunchKernelGGL((k_vec_chunk<2, Op>), dim3(nc), dim3(256), 0, stq, S, n, op, e_begin, e_end);
-            else
-                hipLaunchKernelGGL((k_vec_chunk<1, Op>), dim3(nc), dim3(256), 0, stq, S, n, op, e_begin, e_end);
-            PIB_HIP(hipGetLastError());
-            if (nblocks_out) *nblocks_out = (int)nc;
-            return 0;
-        }
-    }
-    int64_t per = 0;
-    if (ng >= ((int64_t)1 << 22)) per = (((ng + nb - 1) / nb + 255) / 256) * 256;
-    if (vec2)
-        hipLaunchKernelGGL((k_vec<2, Op>), dim3(nb), dim3(256), 0, stq, S, n, op, part, e_begin, e_end, per);
-    else
-        hipLaunchKernelGGL((k_vec<1, Op>), dim3(nb), dim3(256), 0, stq, S, n, op, part, e_begin, e_end, per);
-    PIB_HIP(hipGetLastError());
-    if (nblocks_out) *nblocks_out = nb;
-    return 0;
-}
-
-int allreduce_slots(pib_solver *s, int first, int count, hipStream_t stq)
-{
-    return comm_allreduce_sum(s, &s->d_s->red[first], count, stq);
-}
-
-static int finalize(pib_solver *s, int slot0, int nslots, int count, hipStream_t stq)
-{
-    hipLaunchKernelGGL(k_finalize, dim3(nslots), dim3(256), 0, stq, s->d_s, s->d_part, slot0, count);
-    PIB_HIP(hipGetLastError());
-    return allreduce_slots(s, slot0, nslots, stq);
-}
-
-// ------------------------------------------------------------------ ops
-// reduction slot map (CG): 0 z.r  1 z.z  2 sum z  3 z[0] (pinned GMG)  4 r.r  5 sum r  6 p.w
-constexpr int SLOT_PW = 6;
-enum { PCM_NONE = 0, PCM_JACOBI = 1, PCM_EXTERNAL = 2 };
-
-// r = b - w (guess) or r = b ; z = M^-1 r ; partials 0..5
-template <int PCM>
-struct OpInit {
-    static constexpr int NRED = 6;
-    const double *b, *w, *dinv;
-    double *r, *z;
-    double omega;
-    int guess;
-    int pin0;  // this rank owns the pinned row 0: its residual is exactly 0 (x[0] = b[0] was set)
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[6]) const
-    {
-        Pack<W> vb = ld<W>(b, i), vr, vz;
-        if (guess) {
-            Pack<W> vw = ld<W>(w, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vr.v[k] = vb.v[k] - vw.v[k];
-        } else {
-            vr = vb;
-        }
-        if (pin0 && i == 0) vr.v[0] = 0.0;
-        if (PCM == PCM_JACOBI) {
-            Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vz.v[k] = omega * (vd.v[k] * vr.v[k]);
-            st<W>(z, i, vz);
-        } else {
-            vz = vr;
-        }
-        st<W>(r, i, vr);
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            acc[0] += vz.v[k] * vr.v[k];
-            acc[1] += vz.v[k] * vz.v[k];
-            acc[2] += vz.v[k];
-            acc[4] += vr.v[k] * vr.v[k];
-            acc[5] += vr.v[k];
-        }
-    }
-};
-
-// r -= a w ; z = M^-1 r ; partials 0..4.  (x += a p rides on the next p-update, which reads p anyway: OpUpdateP.)
-template <int PCM>
-struct OpUpdateXR {
-    static constexpr int NRED = 6;
-    const double *w, *dinv;
-    double *r, *z;
-    double omega;
-    double a;
-    __device__ void prepare(const Scalars *S) { a = S->a; }
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[6]) const
-    {
-        Pack<W> vw = ld<W>(w, i), vr = ld<W>(r, i), vz;
-#pragma unroll
-        for (int k = 0; k < W; ++k) vr.v[k] = vr.v[k] - a * vw.v[k];
-        st<W>(r, i, vr);
-        if (PCM == PCM_JACOBI) {
-            Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vz.v[k] = omega * (vd.v[k] * vr.v[k]);
-            st<W>(z, i, vz);
-        } else {
-            vz = vr;
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            acc[0] += vz.v[k] * vr.v[k];
-            acc[1] += vz.v[k] * vz.v[k];
-            acc[2] += vz.v[k];
-            acc[4] += vr.v[k] * vr.v[k];
-            acc[5] += vr.v[k];
-        }
-    }
-};
-
-// partials 0 z.r, 1 z.z, 2 sum z -- after an external PC apply
-struct OpDotZR {
-    static constexpr int NRED = 3;
-    const double *z, *r;
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[3]) const
-    {
-        Pack<W> vz = ld<W>(z, i), vr = ld<W>(r, i);
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            acc[0] += vz.v[k] * vr.v[k];
-            acc[1] += vz.v[k] * vz.v[k];
-            acc[2] += vz.v[k];
-        }
-    }
-};
-
-// Pinned pressure row + multigrid where the shift cannot be lazy (single-reduction CG: the matrix is applied to z itself;
-// BiCGStab: the cycle's output goes straight into a product): z <- z - z[0], z[0] = r[0] in a pass of its own -- what the
-// oracle's PCAPPLY / pcapply do for nullspace 2 (oracle/csrc/gmg.c, oracle.c) -- with the sums z.r, z.z, sum z of the result
-// (DOTS).  red[slot] holds z[0] of the raw cycle output (k_fetch_z0, all-reduced); `owner`: this rank holds row 0.
-template <int DOTS>
-struct OpPinShift {
-    static constexpr int NRED = DOTS ? 3 : 0;
-    double *z;
-    const double *r;
-    int owner, slot;
-    double m;
-    __device__ void prepare(const Scalars *S) { m = S->red[slot]; }
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[DOTS ? 3 : 1]) const
-    {
-        Pack<W> vz = ld<W>(z, i), vr = ld<W>(r, i);
-#pragma unroll
-        for (int k = 0; k < W; ++k) vz.v[k] = vz.v[k] - m;
-        if (owner && i == 0) vz.v[0] = vr.v[0];
-        st<W>(z, i, vz);
-        if (DOTS) {
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                acc[0] += vz.v[k] * vr.v[k];
-                acc[1] += vz.v[k] * vz.v[k];
-                acc[DOTS ? 2 : 0] += vz.v[k];
-            }
-        }
-    }
-};
-
-// x += a p (the update the previous iteration owes, elements [xlo, xhi) of the index space: x has no ghost entries) ;
-// p = (z - mean) + b p      (first iteration: p = z - mean)
-struct OpUpdateP {
-    static constexpr int NRED = 0;
-    const double *z;
-    double *p;
-    double *x;          // indexed like p; may be null (no x update)
-    int64_t xlo, xhi;   // both even
-    double bcoef, mean, a;
-    int first, pend;
-    __device__ void prepare(const Scalars *S)
-    {
-        bcoef = S->b;
-        mean = S->mean;
-        first = (S->its == 0);
-        a = S->a;
-        pend = (x != nullptr && S->xa_it != S->xapplied);
-    }
-    template <int W>
-    __device__ void apply(int64_t i, double (&)[1]) const
-    {
-        Pack<W> vz = ld<W>(z, i), vp;
-        if (first) {
-#pragma unroll
-            for (int k = 0; k < W; ++k) vp.v[k] = vz.v[k] - mean;
-        } else {
-            vp = ld<W>(p, i);
-            if (pend && i * W >= xlo && i * W < xhi) {
-                Pack<W> vx = ld<W>(x, i);
-#pragma unroll
-                for (int k = 0; k < W; ++k) vx.v[k] = vx.v[k] + a * vp.v[k];
-                st<W>(x, i, vx);
-            }
-#pragma unroll
-            for (int k = 0; k < W; ++k) vp.v[k] = (vz.v[k] - mean) + bcoef * vp.v[k];
-        }
-        st<W>(p, i, vp);
-    }
-};
-
-// single-reduction CG: the whole vector part of an iteration in one pass --
-//   p = (z - mean) + b p ;  w = s + b w  (= A p) ;  x += a p ;  r -= a w ;  z = M^-1 r (Jacobi / none) ; partials 0, 1, 2, 4, 5
-// (the first iteration: p = z - mean, w = s).  PCM_EXTERNAL (multigrid): z is left alone, only r.r and sum r are summed.
-template <int PCM>
-struct OpSRUpdate {
-    static constexpr int NRED = 6;
-    const double *sv, *dinv;
-    double *z, *p, *w, *x, *r;
-    double omega;
-    double bcoef, a, mean;
-    int first;
-    __device__ void prepare(const Scalars *S)
-    {
-        bcoef = S->b;
-        a = S->a;
-        mean = S->mean;
-        first = (S->its == 0);
-    }
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[6]) const
-    {
-        Pack<W> vz = ld<W>(z, i), vs = ld<W>(sv, i), vp, vw;
-        if (first) {
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                vp.v[k] = vz.v[k] - mean;
-                vw.v[k] = vs.v[k];
-            }
-        } else {
-            vp = ld<W>(p, i);
-            vw = ld<W>(w, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                vp.v[k] = (vz.v[k] - mean) + bcoef * vp.v[k];
-                vw.v[k] = vs.v[k] + bcoef * vw.v[k];
-            }
-        }
-        st<W>(p, i, vp);
-        st<W>(w, i, vw);
-        Pack<W> vx = ld<W>(x, i), vr = ld<W>(r, i);
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            vx.v[k] = vx.v[k] + a * vp.v[k];
-            vr.v[k] = vr.v[k] - a * vw.v[k];
-        }
-        st<W>(x, i, vx);
-        st<W>(r, i, vr);
-        if (PCM == PCM_JACOBI) {
-            Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vz.v[k] = omega * (vd.v[k] * vr.v[k]);
-            st<W>(z, i, vz);
-        } else if (PCM == PCM_NONE) {
-            vz = vr;  // z aliases r
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            if (PCM != PCM_EXTERNAL) {
-                acc[0] += vz.v[k] * vr.v[k];
-                acc[1] += vz.v[k] * vz.v[k];
-                acc[2] += vz.v[k];
-            }
-            acc[4] += vr.v[k] * vr.v[k];
-            acc[5] += vr.v[k];
-        }
-    }
-};
-
-// the x update still owed when the iteration stops: x += a p
-// (if_done: launched speculatively after the first batch of iterations -- acts only if the solve has stopped, see solve_cg)
-__global__ __launch_bounds__(256) void k_flush_x(const Scalars *__restrict__ S, int64_t n, const double *__restrict__ p,
-                                                 double *__restrict__ x, int if_done)
-{
-    if (if_done && !S->done) return;
-    if (S->xa_it == S->xapplied) return;
-    const double a = S->a;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = x[i] + a * p[i];
-}
-__global__ void k_flush_done(Scalars *S, int if_done)
-{
-    if (if_done && !S->done) return;
-    S->xapplied = S->xa_it;
-}
-
-struct OpCopy {
-    static constexpr int NRED = 0;
-    const double *src;
-    double *dst;
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&)[1]) const
-    {
-        st<W>(dst, i, ld<W>(src, i));
-    }
-};
-
-struct OpFill {
-    static constexpr int NRED = 0;
-    double *dst;
-    double value;
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&)[1]) const
-    {
-        Pack<W> v;
-#pragma unroll
-        for (int k = 0; k < W; ++k) v.v[k] = value;
-        st<W>(dst, i, v);
-    }
-};
-
-// ------------------------------------------------------------ scalar kernels
-__device__ __forceinline__ void converged_default(Scalars *S, double dp)
-{
-    if (dp != dp) {
-        S->reason = PIB_DIVERGED_NANORINF;
-        S->done = 1;
-    } else if (dp <= S->ttol) {
-        S->reason = (dp < S->atol) ? PIB_CONVERGED_ATOL : PIB_CONVERGED_RTOL;
-        S->done = 1;
-    } else if (S->dtol > 0.0 && dp >= S->dtol * S->rnorm0) {
-        S->reason = PIB_DIVERGED_DTOL;
-        S->done = 1;
-    }
-}
-
-// lazy: 0 no shift; 1 z <- z - mean(z) (constant null space); 2 z <- z - z[0] (pinned pressure + multigrid).
-// The shift m is applied lazily: p = (z - m) + b p in OpUpdateP, and the dot products are corrected here:
-//   (z-m).r = z.r - m sum(r) ;  |z-m|^2 = z.z - 2 m sum(z) + n m^2
-__device__ __forceinline__ void lazy_shift(Scalars *S, double n_global, int lazy, double &zr, double &zz)
-{
-    double m = 0.0;
-    if (lazy == 1) m = S->red[2] / n_global;
-    if (lazy == 2) m = S->red[3];
-    if (lazy) {
-        zr = zr - m * S->red[5];
-        zz = (zz - 2.0 * m * S->red[2]) + n_global * m * m;
-        if (zz < 0.0) zz = 0.0;
-    }
-    S->mean = m;
-}
-
-__global__ void k_fetch_z0(Scalars *S, const double *z, int owner, int slot = 3)
-{
-    if (S->done) return;
-    S->red[slot] = owner ? z[0] : 0.0;
-}
-
-__global__ void k_pin_x0(double *x, const double *b) { x[0] = b[0]; }
-
-__global__ void k_cg_s_init(Scalars *S, double *hist, double n_global, int lazy_mean, int monitor)
-{
-    double zr = S->red[0], zz = S->red[1], rr = S->red[4];
-    lazy_shift(S, n_global, lazy_mean, zr, zz);
-    const double dp = (S->normtype == 0) ? sqrt(zz) : sqrt(rr);
-    S->dp = dp;
-    S->rnorm0 = dp;
-    S->ttol = monitor ? fmax(S->rtol * dp, S->atol) : -1.0;
-    S->its = 0;
-    S->reason = 0;
-    S->done = 0;
-    S->dpi = 0.0;
-    S->dpiold = 0.0;
-    S->b = 0.0;
-    hist[0] = dp;
-    converged_default(S, dp);
-    S->beta = zr;
-    S->betaold = zr;
-    if (!S->done && S->maxit <= 0) {
-        S->reason = PIB_DIVERGED_ITS;
-        S->done = 1;
-    }
-    if (!S->done && zr == 0.0) {
-        S->reason = PIB_CONVERGED_ATOL;
-        S->its = 1;
-        hist[1] = dp;
-        S->done = 1;
-    }
-}
-
-// pr.n > 0 (a pinned pressure row, this rank owns cell 0, the residual's sum is wanted ahead of the pass that forms the
-// residual): sum r_new = sum r - a sum w, and sum w = -sum_f coef[f] p[off[f]] -- the columns of the singular operator sum to
-// zero and p[0] = 0 (PinRow, pib_internal.hpp).  red[5] is the sum the pass that formed r delivered: re-based every iteration,
-// the recurrence is one step long and carries no drift.
-__device__ __forceinline__ void cg_pin_sigma(Scalars *S, const PinRowDev &pr)
-{
-    if (pr.n <= 0) return;
-    double t = 0.0;
-    for (int f = 0; f < pr.n; ++f) t = fma(pr.coef[f], pr.p[pr.off[f]], t);
-    S->pin_sigma = S->red[5] + S->a * t;
-}
-__device__ __forceinline__ void cg_s1(Scalars *S)
-{
-    S->xapplied = S->xa_it;  // this iteration's p-update has applied what the previous one owed
-    S->dpiold = S->dpi;
-    const double dpi = S->red[6];
-    S->dpi = dpi;
-    if (dpi == 0.0 || dpi != dpi || (S->its > 0 && ((dpi > 0.0) != (S->dpiold > 0.0)))) {
-        S->reason = (dpi != dpi) ? PIB_DIVERGED_NANORINF : PIB_DIVERGED_INDEFINITE_MAT;
-        S->its += 1;
-        S->done = 1;
-        return;
-    }
-    S->a = S->beta / dpi;
-    S->betaold = S->beta;
-    S->xa_it += 1;  // x += a p is owed
-}
-__global__ void k_cg_s1(Scalars *S, PinRowDev pr)
-{
-    if (S->done) return;
-    cg_s1(S);
-    if (!S->done) cg_pin_sigma(S, pr);
-}
-
-// do_norm: evaluate the monitored norm + convergence; do_beta: new beta, b.
-__device__ __forceinline__ void cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean, int do_norm, int do_beta,
-                                      int conv_is_its)
-{
-    double zr = S->red[0], zz = S->red[1], rr = S->red[4];
-    if (do_beta) lazy_shift(S, n_global, lazy_mean, zr, zz);
-    if (do_norm) {
-        const double dp = (S->normtype == 0) ? sqrt(zz) : sqrt(rr);
-        S->dp = dp;
-        S->its += 1;
-        hist[S->its] = dp;
-        converged_default(S, dp);
-        if (!S->done && S->its >= S->maxit) {
-            S->reason = conv_is_its ? PIB_CONVERGED_ITS : PIB_DIVERGED_ITS;
-            S->done = 1;
-        }
-    }
-    if (do_beta && !S->done) {
-        S->beta = zr;
-        if (zr == 0.0) {
-            S->reason = PIB_CONVERGED_ATOL;
-            S->its += 1;
-            hist[S->its] = S->dp;
-            S->done = 1;
-        } else if ((zr > 0.0) != (S->betaold > 0.0)) {
-            S->reason = PIB_DIVERGED_INDEFINITE_PC;
-            S->its += 1;
-            hist[S->its] = S->dp;
-            S->done = 1;
-        } else {
-            S->b = zr / S->betaold;
-        }
-    }
-}
-__global__ void k_cg_s2(Scalars *S, double *hist, double n_global, int lazy_mean, int do_norm, int do_beta,
-                        int conv_is_its)
-{
-    if (S->done) return;
-    cg_s2(S, hist, n_global, lazy_mean, do_norm, do_beta, conv_is_its);
-}
-
-// The closing kernel of a preconditioner application whose Krylov sums the V-cycle left as per-workgroup partials (gmg.hip
-// reduce_dots: at most DEFER_DOTS_MAX of them per sum): z.r, z.z, sum z reduced in a fixed order by ONE workgroup, z[0] fetched
-// (pinned null space), and -- POST, one rank: nothing sits between the sums and their consumer -- the iteration's scalar step.
-// One launch where k_reduce_big, k_finalize_big, k_fetch_z0 and k_cg_s2 were four (round 5).
-template <int POST>
-__global__ __launch_bounds__(1024) void k_dots_tail(Scalars *__restrict__ S, const double *__restrict__ part, int stride, int count,
-                                                    const double *__restrict__ z, int owner, double *hist, double n_global, int lazy_mean,
-                                                    int do_norm, int do_beta, int conv_is_its)
-{
-    if (S->done) return;
-    __shared__ double sh[16];
-    for (int slot = 0; slot < 3; ++slot) {
-        const double *p = part + (int64_t)slot * stride;
-        double v = 0.0;
-        for (int i = threadIdx.x; i < count; i += 1024) v += p[i];
-        v = wsum(v);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-            for (int w = 0; w < 16; ++w) t += sh[w];
-            S->red[slot] = t;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        S->red[3] = owner ? z[0] : 0.0;
-        if (POST) cg_s2(S, hist, n_global, lazy_mean, do_norm, do_beta, conv_is_its);
-    }
-}
-
-// ---- single-reduction CG (KSPCGUseSingleReduction; oracle/csrc/oracle.c:orc_cg_single_reduction): the matrix is applied to z,
-// s = A z, and the top of an iteration needs no sum of its own --
-//     dpi = p'w = delta - beta^2 dpiold / betaold^2   (delta = z's; the first iteration: p = z, dpi = delta),   a = beta / dpi
-// -- so ALL sums of an iteration (z.r, z.z, sum z, z[0], r.r, sum r, z.s) go through ONE all-reduce, behind the product.
-// (z - m).s = z.s - m sum(s), and sum(s) = 1'A z = 0 for the symmetric operator with A 1 = 0 the lazy shift is used with: the
-// term is dropped.
-__device__ __forceinline__ void cg_sr_top(Scalars *S)
-{
-    S->dpiold = S->dpi;
-    const double delta = S->red[6], beta = S->beta, bo = S->betaold;
-    const double dpi = (S->its == 0) ? delta : delta - beta * beta * S->dpiold / (bo * bo);
-    S->dpi = dpi;
-    if (dpi == 0.0 || dpi != dpi || (S->its > 0 && ((dpi > 0.0) != (S->dpiold > 0.0)))) {
-        S->reason = (dpi != dpi) ? PIB_DIVERGED_NANORINF : PIB_DIVERGED_INDEFINITE_MAT;
-        S->its += 1;
-        S->done = 1;
-        return;
-    }
-    S->a = beta / dpi;
-    S->betaold = beta;
-}
-// after the set-up (k_cg_s_init has beta, b = 0) and the first product s = A z
-__global__ void k_cg_sr_first(Scalars *S)
-{
-    if (S->done) return;
-    cg_sr_top(S);
-}
-// end of an iteration (norm, convergence, the new beta and b) and the top of the next one (dpi, a)
-__global__ void k_cg_sr_step(Scalars *S, double *hist, double n_global, int lazy_mean, int conv_is_its)
-{
-    if (S->done) return;
-    cg_s2(S, hist, n_global, lazy_mean, 1, 1, conv_is_its);
-    if (S->done) return;
-    cg_sr_top(S);
-}
 
 // ------------------------------------------------------------------ helpers
 // The captured iteration body (hipGraphExec) is destroyed BEFORE any memory its kernel, copy and fill nodes point at is freed,
@@ -1602,1013 +944,9 @@ int solve_cg_sr(pib_solver *s, double *x, const double *b)
 
 }  // namespace pib
 
-// ------------------------------------------------------------------ BiCGStab (K10)
-// PETSc's KSPBCGS recurrences (oracle/csrc/oracle.c:orc_bcgs):
-//   KSP flavour : left preconditioning, recurrences on the preconditioned residual
-//   AmgX flavour: PBICGSTAB, right preconditioning, true-residual L2 norm
-// used for the velocity system A = I/dt - c nu L (navierstokes.cpp:342-344), which is
-// non-symmetric on stretched meshes (createlaplacian.cpp row scaling).
-// reduction slots: 0 |r|^2  1 r.rp  2 v.rp  3 s.t  4 t.t
-namespace pib {
+#include "krylov_bicgstab.hpp"
+#include "krylov_chebyshev.hpp"
 
-template <int PCM>
-struct OpBInit {  // r = M^-1 (b - w) (left) or b - w (right); rp = r; p = v = 0
-    static constexpr int NRED = 1;
-    const double *b, *w, *dinv;
-    double *r, *rp, *p, *v;
-    double omega_pc;
-    int guess, left;
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[1]) const
-    {
-        Pack<W> vb = ld<W>(b, i), vr, zero;
-        if (guess) {
-            Pack<W> vw = ld<W>(w, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vr.v[k] = vb.v[k] - vw.v[k];
-        } else {
-            vr = vb;
-        }
-        if (PCM == PCM_JACOBI && left) {
-            Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vr.v[k] = omega_pc * (vd.v[k] * vr.v[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            zero.v[k] = 0.0;
-            acc[0] += vr.v[k] * vr.v[k];
-        }
-        st<W>(r, i, vr);
-        st<W>(rp, i, vr);
-        st<W>(p, i, zero);
-        st<W>(v, i, zero);
-    }
-};
-
-template <int PCM>
-struct OpBUpdateP {  // p = r - (omegaold*beta) v + beta p ; right: ph = M^-1 p
-    static constexpr int NRED = 0;
-    const double *r, *v, *dinv;
-    double *p, *ph;
-    double omega_pc;
-    int left;
-    double beta, ob;
-    __device__ void prepare(const Scalars *S)
-    {
-        beta = S->b;
-        ob = S->omegaold * S->b;
-    }
-    template <int W>
-    __device__ void apply(int64_t i, double (&)[1]) const
-    {
-        Pack<W> vr = ld<W>(r, i), vv = ld<W>(v, i), vp = ld<W>(p, i);
-#pragma unroll
-        for (int k = 0; k < W; ++k) vp.v[k] = (vr.v[k] - ob * vv.v[k]) + beta * vp.v[k];
-        st<W>(p, i, vp);
-        if (!left && PCM == PCM_JACOBI) {
-            Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vp.v[k] = omega_pc * (vd.v[k] * vp.v[k]);
-            st<W>(ph, i, vp);
-        }
-    }
-};
-
-template <int PCM>
-struct OpBPcDot {  // left: out = M^-1 in ; partial slot = out . other
-    static constexpr int NRED = 1;
-    const double *in, *dinv, *other;
-    double *out;
-    double omega_pc;
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[1]) const
-    {
-        Pack<W> vi = ld<W>(in, i), vo = ld<W>(other, i);
-        if (PCM == PCM_JACOBI) {
-            Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vi.v[k] = omega_pc * (vd.v[k] * vi.v[k]);
-            st<W>(out, i, vi);
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) acc[0] += vi.v[k] * vo.v[k];
-    }
-};
-
-template <int PCM>
-struct OpBUpdateS {  // s = r - alpha v ; right: sh = M^-1 s
-    static constexpr int NRED = 0;
-    const double *r, *v, *dinv;
-    double *sv, *sh;
-    double omega_pc;
-    int left;
-    double alpha;
-    __device__ void prepare(const Scalars *S) { alpha = S->alpha; }
-    template <int W>
-    __device__ void apply(int64_t i, double (&)[1]) const
-    {
-        Pack<W> vr = ld<W>(r, i), vv = ld<W>(v, i);
-#pragma unroll
-        for (int k = 0; k < W; ++k) vr.v[k] = vr.v[k] - alpha * vv.v[k];
-        st<W>(sv, i, vr);
-        if (!left && PCM == PCM_JACOBI) {
-            Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vr.v[k] = omega_pc * (vd.v[k] * vr.v[k]);
-            st<W>(sh, i, vr);
-        }
-    }
-};
-
-template <int PCM>
-struct OpBPcDot2 {  // left: t = M^-1 in ; partials s.t (slot 3) t.t (slot 4)
-    static constexpr int NRED = 2;
-    const double *in, *dinv, *sv;
-    double *t;
-    double omega_pc;
-    int left;
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[2]) const
-    {
-        Pack<W> vi = ld<W>(in, i), vs = ld<W>(sv, i);
-        if (left && PCM == PCM_JACOBI) {
-            Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vi.v[k] = omega_pc * (vd.v[k] * vi.v[k]);
-            st<W>(t, i, vi);
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            acc[0] += vs.v[k] * vi.v[k];
-            acc[1] += vi.v[k] * vi.v[k];
-        }
-    }
-};
-
-struct OpBUpdateX {  // x += alpha ph + omega sh ; r = s - omega t ; partials |r|^2 (0), r.rp (1)
-    static constexpr int NRED = 2;
-    const double *ph, *sh, *sv, *t, *rp;
-    double *x, *r;
-    double alpha, omega;
-    int only_alpha;  // t == 0 exit of PETSc: x += alpha p, nothing else
-    __device__ void prepare(const Scalars *S)
-    {
-        alpha = S->alpha;
-        omega = S->omega;
-    }
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[2]) const
-    {
-        Pack<W> vp = ld<W>(ph, i), vsh = ld<W>(sh, i), vs = ld<W>(sv, i), vt = ld<W>(t, i), vx = ld<W>(x, i),
-                vrp = ld<W>(rp, i), vr;
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            vx.v[k] = (vx.v[k] + alpha * vp.v[k]) + omega * vsh.v[k];
-            vr.v[k] = vs.v[k] - omega * vt.v[k];
-            acc[0] += vr.v[k] * vr.v[k];
-            acc[1] += vr.v[k] * vrp.v[k];
-        }
-        st<W>(x, i, vx);
-        st<W>(r, i, vr);
-    }
-};
-
-// the multigrid under BiCGStab: z = M^-1 r is one V-cycle, and on a singular system (constant null space) its mean is removed
-// after every application, as KSP_PCApply + KSP_RemoveNullSpace do (oracle: pcapply with PC_GMG)
-struct OpSumV {  // partial: sum v
-    static constexpr int NRED = 1;
-    const double *v;
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[1]) const
-    {
-        const Pack<W> vv = ld<W>(v, i);
-#pragma unroll
-        for (int k = 0; k < W; ++k) acc[0] += vv.v[k];
-    }
-};
-struct OpShiftV {  // v -= red[slot] / n_global
-    static constexpr int NRED = 0;
-    double *v;
-    double inv_n;
-    int slot;
-    double m;
-    __device__ void prepare(const Scalars *S) { m = S->red[slot] * inv_n; }
-    template <int W>
-    __device__ void apply(int64_t i, double (&)[1]) const
-    {
-        Pack<W> vv = ld<W>(v, i);
-#pragma unroll
-        for (int k = 0; k < W; ++k) vv.v[k] = vv.v[k] - m;
-        st<W>(v, i, vv);
-    }
-};
-
-// ---- the same recurrences on the matrix-free velocity operator (right preconditioning, Jacobi, one rank, the one-launch
-// product): M^-1 p and M^-1 s are never stored -- the products apply the sweep as they read their input
-// (vel_stencil_apply's dinv / opc) -- and x += alpha M^-1 p + omega M^-1 s is applied by the NEXT iteration's p-update,
-// which reads p anyway.  216 -> 200 B/row/iteration (27 -> 25 vector passes).  Every value is computed by the expression
-// of the general path above: bit-identical iterates -- unless `pib_bicgstab_form` >= 2 (default 3) lets the products sum
-// v.rp and s.t, t.t themselves (two passes less, 184 B/row/iteration): those sums are grouped by tile, so alpha and omega
-// agree with the general path's to rounding only.
-struct OpBFUpdateP {  // x += xalpha ph + xomega sh (owed) ; p = r - (omegaold*beta) v + beta p
-    // y != nullptr: the owed update goes into y += xalpha p + xomega s instead -- the sum of the search directions BEFORE the
-    // (stationary) Jacobi sweep, x = x0 + M^-1 y once at the end (k_b_flush_x) -- which takes the dinv and x streams out
-    // of this pass: 56 instead of 64 B/row.  x then differs from the general path's by rounding (the residual recurrence
-    // does not see x), so this rides with the fused sums (`pib_bicgstab_form` >= 2), not with the bit-identical route.
-    // t != nullptr (`pib_bicgstab_form` 3, with y): the residual update the previous iteration owes, r = s - omega t, is formed
-    // HERE (s is read for y anyway) and stored for the next s = r - alpha v: OpBFUpdateR's pass (s, t, rp in, r out) is gone, its two
-    // sums come out of the second product's five (k_finalize_post<7>).  Same expression: r has the bits OpBFUpdateR would store.
-    static constexpr int NRED = 0;
-    const double *r, *v, *dinv, *sv;
-    double *p, *x, *y;
-    double omega_pc;
-    double beta, ob, xa, xo;
-    int pend;
-    const double *t = nullptr;
-    double *rw = nullptr;
-    __device__ void prepare(const Scalars *S)
-    {
-        beta = S->b;
-        ob = S->omegaold * S->b;
-        pend = S->xpend;
-        xa = S->xalpha;
-        xo = S->xomega;
-    }
-    template <int W>
-    __device__ void apply(int64_t i, double (&)[1]) const
-    {
-        Pack<W> vr, vv = ld<W>(v, i), vp = ld<W>(p, i);
-        if (!(pend && t != nullptr)) vr = ld<W>(r, i);
-        if (pend && y != nullptr) {
-            Pack<W> vs = ld<W>(sv, i), vy = ld<W>(y, i);
-            if (t != nullptr) {
-                const Pack<W> vt = ld<W>(t, i);
-#pragma unroll
-                for (int k = 0; k < W; ++k) vr.v[k] = vs.v[k] - xo * vt.v[k];
-                st<W>(rw, i, vr);
-            }
-#pragma unroll
-            for (int k = 0; k < W; ++k) vy.v[k] = (vy.v[k] + xa * vp.v[k]) + xo * vs.v[k];
-            st<W>(y, i, vy);
-        } else if (pend && dinv == nullptr) {  // no preconditioner (NOSOLVER): ph = p, sh = s
-            Pack<W> vs = ld<W>(sv, i), vx = ld<W>(x, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vx.v[k] = (vx.v[k] + xa * vp.v[k]) + xo * vs.v[k];
-            st<W>(x, i, vx);
-        } else if (pend) {
-            Pack<W> vd = ld<W>(dinv, i), vs = ld<W>(sv, i), vx = ld<W>(x, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                const double ph = omega_pc * (vd.v[k] * vp.v[k]), sh = omega_pc * (vd.v[k] * vs.v[k]);
-                vx.v[k] = (vx.v[k] + xa * ph) + xo * sh;
-            }
-            st<W>(x, i, vx);
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) vp.v[k] = (vr.v[k] - ob * vv.v[k]) + beta * vp.v[k];
-        st<W>(p, i, vp);
-    }
-};
-struct OpBFUpdateR {  // r = s - omega t ; partials |r|^2 (0), r.rp (1)
-    static constexpr int NRED = 2;
-    const double *sv, *t, *rp;
-    double *r;
-    double omega;
-    __device__ void prepare(const Scalars *S) { omega = S->omega; }
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[2]) const
-    {
-        Pack<W> vs = ld<W>(sv, i), vt = ld<W>(t, i), vrp = ld<W>(rp, i), vr;
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            vr.v[k] = vs.v[k] - omega * vt.v[k];
-            acc[0] += vr.v[k] * vr.v[k];
-            acc[1] += vr.v[k] * vrp.v[k];
-        }
-        st<W>(r, i, vr);
-    }
-};
-// the x update still owed when the iteration stops
-// (y != nullptr: x = x0 + M^-1 (y + what is owed), see OpBFUpdateP)
-__global__ __launch_bounds__(256) void k_b_flush_x(Scalars *__restrict__ S, int64_t n, const double *__restrict__ p,
-                                                   const double *__restrict__ sv, const double *__restrict__ dinv, double omega_pc,
-                                                   double *__restrict__ x, const double *__restrict__ y, int if_done)
-{
-    if (if_done && !S->done) return;
-    const int pend = S->xpend;
-    if (!pend && y == nullptr) return;
-    const double xa = S->xalpha, xo = S->xomega;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        if (y != nullptr) {
-            const double acc = pend ? (y[i] + xa * p[i]) + xo * sv[i] : y[i];
-            x[i] = x[i] + (dinv != nullptr ? omega_pc * (dinv[i] * acc) : acc);
-        } else if (dinv == nullptr) {
-            x[i] = (x[i] + xa * p[i]) + xo * sv[i];
-        } else {
-            const double ph = omega_pc * (dinv[i] * p[i]), sh = omega_pc * (dinv[i] * sv[i]);
-            x[i] = (x[i] + xa * ph) + xo * sh;
-        }
-    }
-}
-__global__ void k_b_flush_done(Scalars *S, int if_done)
-{
-    if (if_done && !S->done) return;
-    S->xpend = 0;
-}
-
-__global__ void k_b_s_init(Scalars *S, double *hist, int monitor)
-{
-    const double dp = sqrt(S->red[0]);
-    S->dp = dp;
-    S->rnorm0 = dp;
-    S->ttol = monitor ? fmax(S->rtol * dp, S->atol) : -1.0;
-    S->its = 0;
-    S->reason = 0;
-    S->done = 0;
-    S->xpend = 0;
-    hist[0] = dp;
-    converged_default(S, dp);
-    S->rho = S->red[0];  // rp = r  ->  <r,rp> = |r|^2
-    S->rhoold = 1.0;
-    S->alpha = 1.0;
-    S->omega = 1.0;
-    S->omegaold = 1.0;
-    if (!S->done && S->maxit <= 0) {
-        S->reason = PIB_DIVERGED_ITS;
-        S->done = 1;
-    }
-    if (!S->done && S->rho == 0.0) {
-        S->reason = PIB_DIVERGED_BREAKDOWN;
-        S->done = 1;
-    }
-    S->b = (S->rho / S->rhoold) * (S->alpha / S->omegaold);  // beta of the first iteration
-}
-
-__device__ __forceinline__ void b_s_alpha(Scalars *S)
-{
-    const double d1 = S->red[2];
-    if (d1 == 0.0 || d1 != d1) {
-        S->reason = (d1 != d1) ? PIB_DIVERGED_NANORINF : PIB_DIVERGED_BREAKDOWN;
-        S->done = 1;
-        return;
-    }
-    S->alpha = S->rho / d1;
-}
-__global__ void k_b_s_alpha(Scalars *S)
-{
-    if (S->done) return;
-    b_s_alpha(S);
-}
-
-__device__ __forceinline__ void b_s_omega(Scalars *S)
-{
-    const double d1 = S->red[3], d2 = S->red[4];
-    if (d2 == 0.0) {
-        // t = 0: PETSc accepts x += alpha p when s = 0 too; s.s is not available separately here, but
-        // t = K s = 0 with a non-singular operator means s = 0.
-        S->omega = 0.0;
-        return;
-    }
-    S->omega = d1 / d2;
-}
-__global__ void k_b_s_omega(Scalars *S)
-{
-    if (S->done) return;
-    b_s_omega(S);
-}
-
-__device__ __forceinline__ void b_s_end(Scalars *S, double *hist, int conv_is_its)
-{
-    const double dp = sqrt(S->red[0]);
-    S->dp = dp;
-    S->rhoold = S->rho;
-    S->omegaold = S->omega;
-    S->its += 1;
-    hist[S->its] = dp;
-    converged_default(S, dp);
-    if (!S->done && S->its >= S->maxit) {
-        S->reason = conv_is_its ? PIB_CONVERGED_ITS : PIB_DIVERGED_ITS;
-        S->done = 1;
-    }
-    if (S->done) return;
-    if (S->rhoold == 0.0 || S->omega == 0.0) {
-        S->reason = PIB_DIVERGED_BREAKDOWN;
-        S->done = 1;
-        return;
-    }
-    S->rho = S->red[1];
-    if (S->rho == 0.0) {
-        S->reason = PIB_DIVERGED_BREAKDOWN;
-        S->done = 1;
-        return;
-    }
-    S->b = (S->rho / S->rhoold) * (S->alpha / S->omegaold);
-}
-__global__ void k_b_s_end(Scalars *S, double *hist, int conv_is_its)
-{
-    if (S->done) return;
-    b_s_end(S, hist, conv_is_its);
-}
-
-// The reduction of k_finalize (same order, slot after slot) followed by the scalar step that consumes it, in one launch:
-// on one rank nothing sits between the two (no all-reduce), and a small problem's Krylov iteration is a chain of ~5 us
-// launches.  POST: 1 BiCGStab alpha, 2 omega, 3 end of iteration, 4 CG alpha, 5 / 6: 1 / 3 with the deferred x update.
-template <int POST>
-__global__ __launch_bounds__(256) void k_finalize_post(Scalars *__restrict__ S, const double *__restrict__ part, int slot0, int nslots,
-                                                       int count, double *hist, int conv_is_its, PinRowDev pr = PinRowDev{nullptr, 0, {}, {}})
-{
-    if (S->done) return;
-    __shared__ double sh[4];
-    for (int q = 0; q < nslots; ++q) {
-        const int slot = slot0 + q;
-        const double *p = part + (int64_t)slot * PIB_MAXPART;
-        double v = 0.0;
-        for (int i = threadIdx.x; i < count; i += 256) v += p[i];
-        v = wsum(v);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) S->red[slot] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (POST == 1) b_s_alpha(S);
-        if (POST == 2) b_s_omega(S);
-        if (POST == 3) b_s_end(S, hist, conv_is_its);
-        if (POST == 4) {
-            cg_s1(S);
-            if (!S->done) cg_pin_sigma(S, pr);
-        }
-        if (POST == 5) {  // matrix-free BiCGStab: this iteration's p-update has applied what the previous one owed
-            S->xpend = 0;
-            b_s_alpha(S);
-        }
-        if (POST == 6) {  // ... and its x update is owed from here on
-            S->xalpha = S->alpha;
-            S->xomega = S->omega;
-            S->xpend = 1;
-            b_s_end(S, hist, conv_is_its);
-        }
-        if (POST == 8) cg_s2(S, hist, 0.0, 0, 1, 0, conv_is_its);  // CG: the monitored norm |r| and its convergence test (no shift, no beta)
-        if (POST == 7) {  // omega and the end of the iteration at once: r = s - omega t is owed too (OpBFUpdateP::t), its sums
-            // follow from the second product's five -- red[3..7] = s.t, t.t, s.s, rp.s, rp.t:
-            // |r|^2 = s.s - omega (2 s.t - omega t.t), r.rp = rp.s - omega rp.t
-            b_s_omega(S);
-            const double om = S->omega;
-            const double r2 = S->red[5] - om * (2.0 * S->red[3] - om * S->red[4]);
-            S->red[0] = r2 > 0.0 ? r2 : (r2 != r2 ? r2 : 0.0);
-            S->red[1] = S->red[6] - om * S->red[7];
-            S->xalpha = S->alpha;
-            S->xomega = S->omega;
-            S->xpend = 1;
-            b_s_end(S, hist, conv_is_its);
-        }
-    }
-}
-template <int POST>
-static int finalize_post(pib_solver *s, int slot0, int nslots, int count, double *hist, int conv_is_its, hipStream_t q, const PinRowDev &pr)
-{
-    hipLaunchKernelGGL((k_finalize_post<POST>), dim3(1), dim3(256), 0, q, s->d_s, s->d_part, slot0, nslots, count, hist, conv_is_its, pr);
-    PIB_HIP(hipGetLastError());
-    return 0;
-}
-
-int solve_bicgstab(pib_solver *s, double *x, const double *b)
-{
-    const DeviceCsr &A = s->A;
-    const int64_t n = A.n;
-    hipStream_t q = s->stream;
-    const Precond pc = s->cfg.pc;
-    // BiCGStab with the multigrid (round 4): AmgX takes any solver x preconditioner pair of a solver file
-    // (/root/reference/src/linsolver/linsolveramgx.cpp:62-72), PETSc any -ksp_type / -pc_type; the V-cycle is applied where the
-    // general path applies the Jacobi sweep, as a call of its own (gmg_apply), followed by the projection on a singular system
-    const bool gmg = (pc == Precond::GMG);
-    if (gmg && !s->has_grid)
-        return fail(PIB_ERR_ORDER,
-                    "solver %s: a multigrid (AMG/GMG) preconditioner needs the grid structure: call "
-                    "pib_set_grid_hint or pib_assemble_poisson before pib_solve", s->name.c_str());
-    if (pc == Precond::JACOBI && A.dinv == nullptr) return fail(PIB_ERR_ORDER, "Jacobi preconditioner without a diagonal");
-    PIB_CHK(ensure_work(s, 9));
-    double *R = s->vec(0), *RP = s->vec(1), *P = s->vec(2), *V = s->vec(3), *S = s->vec(4), *T = s->vec(5),
-           *T2 = s->vec(6), *PH = s->vec(7), *SH = s->vec(8);
-    const bool left = (s->cfg.norm == NormType::PRECONDITIONED);
-    const bool jac = (pc == Precond::JACOBI);
-    const bool guess = s->cfg.initial_guess_nonzero;
-    const double opc = jac ? s->cfg.jacobi_relaxation : 1.0;
-    const int monitor = s->cfg.monitor_residual ? 1 : 0;
-    const int conv_is_its = monitor ? 0 : 1;
-    const bool v2 = aligned16(x) && aligned16(b);
-    if ((!jac && !gmg) || left) {  // no separate preconditioned copies needed
-        PH = P;
-        SH = S;
-    }
-    for (int k = 0; k < 8; ++k) s->counters[k] = 0;
-    PIB_CHK(init_scalars(s));
-    int nb = 0;
-    const bool project = gmg && s->nullspace == PIB_NULLSPACE_CONSTANT;
-    // a pinned pressure row (round 5; the oracle's pcapply, nullspace 2): the cycle's right-hand side is made compatible with the
-    // sum of ITS input (slot 5, where gmg_apply reads it), its output is shifted by its value at cell 0, and the pinned unknown
-    // keeps the input's value -- the preconditioner of the pinned system, as the CG path applies it
-    const bool pinned = gmg && s->nullspace == PIB_NULLSPACE_PINNED;
-    auto apply_gmg = [&](const double *in, double *out, bool guarded) -> int {
-        s->gmg_guarded = guarded;
-        s->gmg_want_dots = false;
-        if (pinned) {
-            int nbs = 0;
-            OpSumV sv{in};
-            PIB_CHK(launch_vec(s, n, sv, true, 5, &nbs, guarded, q));
-            PIB_CHK(finalize(s, 5, 1, nbs, q));
-        }
-        PIB_CHK(gmg_apply(s, in, out, q));
-        s->counters[1]++;
-        if (pinned) {
-            hipLaunchKernelGGL(k_fetch_z0, dim3(1), dim3(1), 0, q, s->d_s, out, (A.row0 == 0) ? 1 : 0, 5);
-            PIB_HIP(hipGetLastError());
-            PIB_CHK(allreduce_slots(s, 5, 1, q));
-            OpPinShift<0> sh{out, in, (A.row0 == 0) ? 1 : 0, 5, 0.0};
-            PIB_CHK(launch_vec(s, n, sh, true, 0, nullptr, true, q));  // (reads the shift from the scalars: always given them)
-        }
-        if (project) {
-            int nbs = 0;
-            OpSumV sv{out};
-            PIB_CHK(launch_vec(s, n, sv, true, 5, &nbs, guarded, q));
-            PIB_CHK(finalize(s, 5, 1, nbs, q));
-            OpShiftV sh{out, 1.0 / (double)A.n_global, 5, 0.0};
-            PIB_CHK(launch_vec(s, n, sh, true, 0, nullptr, true, q));  // (reads the sum from the scalars: always given them)
-        }
-        return 0;
-    };
-    if (guess) {
-        OpCopy cp{x, PH == P ? PH : P};
-        // use T2 as the ghost-padded SpMV input so P stays free
-        OpCopy cp2{x, T2};
-        (void)cp;
-        PIB_CHK(launch_vec(s, n, cp2, v2, 0, nullptr, false, q));
-        PIB_CHK(matmult(s, T2, T, nullptr, false, q));
-    } else {
-        OpFill z0{x, 0.0};
-        PIB_CHK(launch_vec(s, n, z0, v2, 0, nullptr, false, q));
-    }
-    if (jac) {
-        OpBInit<PCM_JACOBI> op{b, T, A.dinv, R, RP, P, V, opc, guess ? 1 : 0, left ? 1 : 0};
-        PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
-    } else if (gmg && left) {  // r = M^-1 (b - w): the raw residual (in T2), the V-cycle, then the pass that sets rp, p, v and |r|^2
-        OpBInit<PCM_NONE> raw{b, T, nullptr, T2, RP, P, V, 1.0, guess ? 1 : 0, 0};
-        PIB_CHK(launch_vec(s, n, raw, v2, 0, &nb, false, q));
-        PIB_CHK(apply_gmg(T2, T, false));
-        OpBInit<PCM_NONE> op{T, T, nullptr, R, RP, P, V, 1.0, 0, 0};
-        PIB_CHK(launch_vec(s, n, op, true, 0, &nb, false, q));
-    } else {
-        OpBInit<PCM_NONE> op{b, T, nullptr, R, RP, P, V, 1.0, guess ? 1 : 0, left ? 1 : 0};
-        PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
-    }
-    PIB_CHK(finalize(s, 0, 1, nb, q));
-    hipLaunchKernelGGL(k_b_s_init, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, monitor);
-    PIB_HIP(hipGetLastError());
-
-    const int batch0 = first_batch(s), batch1 = next_batch(s);
-    const int maxit = s->cfg.max_iters;
-    const bool one_rank = s->comm.nranks == 1;
-    // the matrix-free velocity operator in its one-launch form: no stored M^-1 p / M^-1 s, deferred x update (OpBFUpdateP)
-    // (also without a preconditioner -- NOSOLVER, the velocity solver file of flatplate3dRe100_GPU and multicylinders2dRe100_GPU:
-    // the sweep drops out, dv == nullptr)
-    const double *dv = jac ? A.dinv : nullptr;  // (on slabs: its ghost-padded copy, below)
-    // On slabs the products exchange their input's boundary planes first and the sums go through the all-reduce before their
-    // scalar step; the sweep needs the neighbours' diagonal on the ghost planes: a ghost-padded copy of 1 / a_ii, exchanged
-    // once per solve, in the vector the general path keeps M^-1 s in.
-    const bool lean = (jac || pc == Precond::NONE) && !left && (one_rank || s->vel.slab_axis >= 0) &&
-                      s->cfg.bicgstab_form >= 1 && s->vel.valid && s->cfg.matrix_free_velocity &&
-                      s->post_matmult == nullptr && vel_stencil_fused_ok(s) && aligned16(x) &&
-                      ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(V) |
-                        reinterpret_cast<uintptr_t>(T)) & 31u) == 0;
-    const bool fused_dots = lean && s->cfg.bicgstab_form >= 2;
-    // ... and x accumulated before the Jacobi sweep (OpBFUpdateP::y) in the vector the general path keeps M^-1 p in
-    double *Y = fused_dots ? s->vec(7) : nullptr;
-    // ... and the residual update merged into the next p-update, |r|^2 and r.rp out of the second product's sums
-    const bool merge_r = Y != nullptr && s->cfg.bicgstab_form >= 3;
-    if (lean && jac && !one_rank) {
-        double *D = s->vec(8);
-        PIB_HIP(hipMemcpyAsync(D, A.dinv, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, q));
-        PIB_CHK(halo_exchange(s, D, q));
-        dv = D;
-    }
-    if (Y != nullptr) {
-        OpFill y0{Y, 0.0};
-        PIB_CHK(launch_vec(s, n, y0, v2, 0, nullptr, false, q));
-    }
-    int enq = 0;
-    // the x update the last iteration owes (lean recurrences only)
-    auto flush = [&](int if_done) {
-        if (!lean) return;
-        hipLaunchKernelGGL(k_b_flush_x, dim3((unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256))), dim3(256), 0, q,
-                           s->d_s, n, P, S, dv, opc, x, (const double *)Y, if_done);
-        hipLaunchKernelGGL(k_b_flush_done, dim3(1), dim3(1), 0, q, s->d_s, if_done);
-    };
-    if (!skip_first_poll(s)) {  // (as in solve_cg)
-        flush(1);
-        PIB_CHK(fetch_results(s, 0));
-        if (s->h_s->done) return 0;
-    }
-    while (!s->h_s->done && enq < maxit) {
-        const int todo = std::min(enq == 0 ? batch0 : batch1, maxit - enq);
-        // reduce the partial sums of `nslots` slots and run scalar step POST: one launch on one rank, with the all-reduce
-        // in between on several (k_finalize_post with no slots left to reduce is the scalar step alone)
-        auto reduce_then = [&](auto post_tag, int slot0, int nslots, int count, double *hist, int cis) -> int {
-            constexpr int POST = decltype(post_tag)::value;
-            if (one_rank) return finalize_post<POST>(s, slot0, nslots, count, hist, cis, q);
-            PIB_CHK(finalize(s, slot0, nslots, count, q));
-            return finalize_post<POST>(s, slot0, 0, 0, hist, cis, q);
-        };
-        auto body_lean = [&]() -> int {
-            OpBFUpdateP up{R, V, dv, S, P, x, Y, opc, 0.0, 0.0, 0.0, 0.0, 0};
-            if (merge_r) {
-                up.t = T;
-                up.rw = R;
-            }
-            PIB_CHK(launch_vec(s, n, up, true, 0, nullptr, true, q));
-            if (!one_rank) PIB_CHK(halo_exchange(s, P, q));
-            if (fused_dots) {  // v = K M^-1 p and v.rp by the same kernel
-                PIB_CHK(vel_stencil_apply(s, P, V, true, q, dv, opc, 1, RP, 2));
-                nb = VEL_DOT_PARTIALS;
-            } else {
-                PIB_CHK(vel_stencil_apply(s, P, V, true, q, dv, opc));  // v = K M^-1 p
-                OpBPcDot<PCM_NONE> d1{V, nullptr, RP, V, 1.0};
-                PIB_CHK(launch_vec(s, n, d1, true, 2, &nb, true, q));
-            }
-            PIB_CHK(reduce_then(std::integral_constant<int, 5>(), 2, 1, nb, nullptr, 0));
-            OpBUpdateS<PCM_NONE> us{R, V, nullptr, S, S, 1.0, 0, 0.0};  // s = r - alpha v
-            PIB_CHK(launch_vec(s, n, us, true, 0, nullptr, true, q));
-            if (!one_rank) PIB_CHK(halo_exchange(s, S, q));
-            if (merge_r) {  // t = K M^-1 s with s.t, t.t, s.s, rp.s, rp.t; omega and the end of the iteration in one scalar step
-                PIB_CHK(vel_stencil_apply(s, S, T, true, q, dv, opc, 4, RP, 3));
-                PIB_CHK(reduce_then(std::integral_constant<int, 7>(), 3, 5, VEL_DOT_PARTIALS, s->d_hist, conv_is_its));
-                PIB_HIP(hipGetLastError());
-                return 0;
-            }
-            if (fused_dots) {  // t = K M^-1 s with s.t and t.t
-                PIB_CHK(vel_stencil_apply(s, S, T, true, q, dv, opc, 2, nullptr, 3));
-                nb = VEL_DOT_PARTIALS;
-            } else {
-                PIB_CHK(vel_stencil_apply(s, S, T, true, q, dv, opc));  // t = K M^-1 s
-                OpBPcDot2<PCM_NONE> d2{T, nullptr, S, T, 1.0, 0};
-                PIB_CHK(launch_vec(s, n, d2, true, 3, &nb, true, q));
-            }
-            PIB_CHK(reduce_then(std::integral_constant<int, 2>(), 3, 2, nb, nullptr, 0));
-            OpBFUpdateR ur{S, T, RP, R, 0.0};
-            PIB_CHK(launch_vec(s, n, ur, true, 0, &nb, true, q));
-            PIB_CHK(reduce_then(std::integral_constant<int, 6>(), 0, 2, nb, s->d_hist, conv_is_its));
-            PIB_HIP(hipGetLastError());
-            return 0;
-        };
-        auto body = [&]() -> int {
-            if (lean) return body_lean();
-            // p = r - omegaold*beta*v + beta*p  (+ ph = M^-1 p)
-            if (jac) {
-                OpBUpdateP<PCM_JACOBI> op{R, V, A.dinv, P, PH, opc, left ? 1 : 0, 0.0, 0.0};
-                PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
-            } else {
-                OpBUpdateP<PCM_NONE> op{R, V, nullptr, P, PH, 1.0, left ? 1 : 0, 0.0, 0.0};
-                PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
-                if (gmg && !left) PIB_CHK(apply_gmg(P, PH, true));  // ph = M^-1 p
-            }
-            // v = K p ; d1 = v.rp
-            if (left && gmg) {  // v = M^-1 (K p)
-                PIB_CHK(matmult(s, P, T2, nullptr, true, q));
-                PIB_CHK(apply_gmg(T2, V, true));
-                OpBPcDot<PCM_NONE> op{V, nullptr, RP, V, 1.0};
-                PIB_CHK(launch_vec(s, n, op, true, 2, &nb, true, q));
-            } else if (left && jac) {
-                PIB_CHK(matmult(s, P, T2, nullptr, true, q));
-                OpBPcDot<PCM_JACOBI> op{T2, A.dinv, RP, V, opc};
-                PIB_CHK(launch_vec(s, n, op, true, 2, &nb, true, q));
-            } else {
-                PIB_CHK(matmult(s, PH, V, nullptr, true, q));
-                OpBPcDot<PCM_NONE> op{V, nullptr, RP, V, 1.0};
-                PIB_CHK(launch_vec(s, n, op, true, 2, &nb, true, q));
-            }
-            if (one_rank)
-                PIB_CHK(finalize_post<1>(s, 2, 1, nb, nullptr, 0, q));
-            else {
-                PIB_CHK(finalize(s, 2, 1, nb, q));
-                hipLaunchKernelGGL(k_b_s_alpha, dim3(1), dim3(1), 0, q, s->d_s);
-            }
-            // s = r - alpha v (+ sh = M^-1 s)
-            if (jac) {
-                OpBUpdateS<PCM_JACOBI> op{R, V, A.dinv, S, SH, opc, left ? 1 : 0, 0.0};
-                PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
-            } else {
-                OpBUpdateS<PCM_NONE> op{R, V, nullptr, S, SH, 1.0, left ? 1 : 0, 0.0};
-                PIB_CHK(launch_vec(s, n, op, true, 0, nullptr, true, q));
-                if (gmg && !left) PIB_CHK(apply_gmg(S, SH, true));  // sh = M^-1 s
-            }
-            // t = K s ; s.t, t.t
-            if (left && gmg) {  // t = M^-1 (K s)
-                PIB_CHK(matmult(s, S, T2, nullptr, true, q));
-                PIB_CHK(apply_gmg(T2, T, true));
-                OpBPcDot2<PCM_NONE> op{T, nullptr, S, T, 1.0, 0};
-                PIB_CHK(launch_vec(s, n, op, true, 3, &nb, true, q));
-            } else if (left && jac) {
-                PIB_CHK(matmult(s, S, T2, nullptr, true, q));
-                OpBPcDot2<PCM_JACOBI> op{T2, A.dinv, S, T, opc, 1};
-                PIB_CHK(launch_vec(s, n, op, true, 3, &nb, true, q));
-            } else {
-                PIB_CHK(matmult(s, SH, T, nullptr, true, q));
-                OpBPcDot2<PCM_NONE> op{T, nullptr, S, T, 1.0, 0};
-                PIB_CHK(launch_vec(s, n, op, true, 3, &nb, true, q));
-            }
-            if (one_rank)
-                PIB_CHK(finalize_post<2>(s, 3, 2, nb, nullptr, 0, q));
-            else {
-                PIB_CHK(finalize(s, 3, 2, nb, q));
-                hipLaunchKernelGGL(k_b_s_omega, dim3(1), dim3(1), 0, q, s->d_s);
-            }
-            // x += alpha ph + omega sh ; r = s - omega t ; |r|^2, r.rp
-            OpBUpdateX op{PH, SH, S, T, RP, x, R, 0.0, 0.0, 0};
-            PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, true, q));
-            if (one_rank)
-                PIB_CHK(finalize_post<3>(s, 0, 2, nb, s->d_hist, conv_is_its, q));
-            else {
-                PIB_CHK(finalize(s, 0, 2, nb, q));
-                hipLaunchKernelGGL(k_b_s_end, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, conv_is_its);
-            }
-            PIB_HIP(hipGetLastError());
-            return 0;
-        };
-        PIB_CHK(run_iterations(s, todo, enq, graph_key(2, x, b), q, body));
-        const bool first = enq == 0;
-        enq += todo;
-        if (first) {  // (as in solve_cg: closing kernels behind the first batch, one synchronisation if that was the solve)
-            flush(1);
-            PIB_CHK(fetch_results(s, enq));
-            if (s->h_s->done) return 0;
-        } else
-            PIB_CHK(poll(s));
-    }
-    flush(0);
-    return fetch_results(s, enq);
-}
-
-// ------------------------------------------------------------------ Chebyshev
-// PETSc's KSPCHEBYSHEV (`-<name>_ksp_type chebyshev`, reached like every KSP type through KSPSetFromOptions at
-// /root/reference/src/linsolver/linsolverksp.cpp:62-66; AmgX flavour: solver=CHEBYSHEV) -- oracle/csrc/oracle.c:orc_chebyshev
-// has the recurrences.  The velocity operator I/dt - c nu L is strongly diagonally dominant, and an iteration that needs
-// no inner products moves a third of BiCGStab's bytes per product: one product, one pass
-//     r = b - A p[k] ; z = M^-1 r ; |r|^2, |z|^2 ; p[kp1] = (1 - omega) p[km1] + omega p[k] + omega scale z
-// (p[kp1] overwrites p[km1]: two rotating vectors), one reduction for the monitored norm.  The coefficients of the next
-// update are formed on the device by the scalar step, so a PAIR of iterations (in = P1, then in = P0) is a body that can
-// be captured once and replayed.  The update of an iteration is applied before its norm is known: harmless, the iterate
-// the norm speaks of -- p[k] -- is only read, and S->sol says which vector holds it.
-struct OpChebInit {  // r = b - w (guess) or b ; z = M^-1 r ; |r|^2 (0), |z|^2 (1) ; p1 = p0 + scale z
-    static constexpr int NRED = 2;
-    const double *b, *w, *dinv, *p0;
-    double *p1;
-    double opc, scale;
-    int guess;
-    __device__ void prepare(const Scalars *) {}
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[2]) const
-    {
-        Pack<W> vr = ld<W>(b, i), v0 = ld<W>(p0, i), v1;
-        if (guess) {
-            const Pack<W> vw = ld<W>(w, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vr.v[k] = vr.v[k] - vw.v[k];
-        }
-        Pack<W> vz = vr;
-        if (dinv != nullptr) {
-            const Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vz.v[k] = opc * (vd.v[k] * vr.v[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            acc[0] += vr.v[k] * vr.v[k];
-            acc[1] += vz.v[k] * vz.v[k];
-            v1.v[k] = v0.v[k] + scale * vz.v[k];
-        }
-        st<W>(p1, i, v1);
-    }
-};
-struct OpChebStep {  // r = b - w ; z = M^-1 r ; |r|^2 (0), |z|^2 (1) ; pm = (a0 pm + omega pk) + cz z
-    static constexpr int NRED = 2;
-    const double *b, *w, *dinv, *pk;
-    double *pm;
-    double opc;
-    double a0, om, cz;
-    __device__ void prepare(const Scalars *S)
-    {
-        a0 = S->cheb_a0;
-        om = S->omega;
-        cz = S->cheb_cz;
-    }
-    template <int W>
-    __device__ void apply(int64_t i, double (&acc)[2]) const
-    {
-        Pack<W> vr = ld<W>(b, i), vm = ld<W>(pm, i);
-        const Pack<W> vw = ld<W>(w, i), vk = ld<W>(pk, i);
-#pragma unroll
-        for (int k = 0; k < W; ++k) vr.v[k] = vr.v[k] - vw.v[k];
-        Pack<W> vz = vr;
-        if (dinv != nullptr) {
-            const Pack<W> vd = ld<W>(dinv, i);
-#pragma unroll
-            for (int k = 0; k < W; ++k) vz.v[k] = opc * (vd.v[k] * vr.v[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            acc[0] += vr.v[k] * vr.v[k];
-            acc[1] += vz.v[k] * vz.v[k];
-            vm.v[k] = (a0 * vm.v[k] + om * vk.v[k]) + cz * vz.v[k];
-        }
-        st<W>(pm, i, vm);
-    }
-};
-// c[kp1] = 2 mu c[k] - c[km1] ; omega = omegaprod c[k] / c[kp1]: the coefficients of the update that follows
-__device__ __forceinline__ void cheb_next(Scalars *S)
-{
-    const double ckp1 = 2.0 * S->cheb_mu * S->c_k - S->c_km1;
-    S->omega = S->cheb_omegaprod * S->c_k / ckp1;
-    S->cheb_a0 = 1.0 - S->omega;
-    S->cheb_cz = S->omega * S->cheb_scale;
-    S->c_km1 = S->c_k;
-    S->c_k = ckp1;
-    if (S->c_k > 0x1p900) {  // only the ratio of consecutive c's enters: an exact rescaling keeps a long run from overflowing
-        S->c_km1 *= 0x1p-900;
-        S->c_k *= 0x1p-900;
-    }
-}
-__global__ void k_cheb_s_init(Scalars *S, double *hist, int monitor, double mu, double omegaprod, double scale)
-{
-    const double dp = sqrt(S->normtype == 0 ? S->red[1] : S->red[0]);
-    S->dp = dp;
-    S->rnorm0 = dp;
-    S->ttol = monitor ? fmax(S->rtol * dp, S->atol) : -1.0;
-    S->its = 0;
-    S->reason = 0;
-    S->done = 0;
-    S->sol = 0;
-    hist[0] = dp;
-    converged_default(S, dp);
-    if (!S->done && S->maxit <= 0) {
-        S->reason = PIB_DIVERGED_ITS;
-        S->done = 1;
-    }
-    if (S->done) return;
-    S->its = 1;  // p[k] = p[km1] + scale M^-1 r is the first iteration
-    S->sol = 1;
-    S->cheb_mu = mu;
-    S->cheb_omegaprod = omegaprod;
-    S->cheb_scale = scale;
-    S->c_km1 = 1.0;
-    S->c_k = mu;
-    cheb_next(S);
-}
-// the scalar step of loop pass i = its (KSPSolve_Chebyshev counts the pass before it tests), or -- its == maxit -- the closing
-// residual of the last iterate
-__global__ void k_cheb_s_step(Scalars *S, double *hist, int conv_is_its)
-{
-    if (S->done) return;
-    const double dp = sqrt(S->normtype == 0 ? S->red[1] : S->red[0]);
-    S->dp = dp;
-    const int i = S->its;
-    hist[i] = dp;
-    if (i >= S->maxit) {  // the loop is over: this was the residual of the last iterate
-        converged_default(S, dp);
-        if (!S->done) {
-            S->reason = conv_is_its ? PIB_CONVERGED_ITS : PIB_DIVERGED_ITS;
-            S->done = 1;
-        }
-        return;
-    }
-    S->its = i + 1;
-    converged_default(S, dp);
-    if (S->done) {
-        hist[S->its] = dp;  // (the entry pib_get_residual / getResidual(its) read)
-        return;
-    }
-    S->sol ^= 1;  // the update this pass applied is the new iterate
-    cheb_next(S);
-}
-__global__ __launch_bounds__(256) void k_cheb_flush(const Scalars *__restrict__ S, int64_t n, const double *__restrict__ p0,
-                                                    const double *__restrict__ p1, double *__restrict__ x, int if_done)
-{
-    if (if_done && !S->done) return;
-    const double *src = S->sol ? p1 : p0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = src[i];
-}
-
-int solve_chebyshev(pib_solver *s, double *x, const double *b)
-{
-    const DeviceCsr &A = s->A;
-    const int64_t n = A.n;
-    hipStream_t q = s->stream;
-    const Precond pc = s->cfg.pc;
-    if (pc != Precond::JACOBI && pc != Precond::NONE)
-        return fail(PIB_ERR_SUP, "solver %s: the Chebyshev iteration runs with Jacobi or no preconditioner", s->name.c_str());
-    if (s->nullspace != PIB_NULLSPACE_NONE)
-        return fail(PIB_ERR_SUP, "solver %s: the Chebyshev iteration is for definite systems (the velocity operator), not for a singular one", s->name.c_str());
-    if (s->post_matmult != nullptr)
-        return fail(PIB_ERR_SUP, "solver %s: the Chebyshev iteration needs the operator to be the matrix alone", s->name.c_str());
-    const bool jac = (pc == Precond::JACOBI);
-    if (jac && A.dinv == nullptr) return fail(PIB_ERR_ORDER, "Jacobi preconditioner without a diagonal");
-    const double opc = jac ? s->cfg.jacobi_relaxation : 1.0;
-    double emin = s->cfg.cheb_emin, emax = s->cfg.cheb_emax;
-    if (!(emax > 0.0)) {
-        double lo = 0.0, hi = 0.0;
-        PIB_CHK(gershgorin_bounds(s, jac, &lo, &hi));
-        emin = jac ? opc * lo : lo;
-        emax = jac ? opc * hi : hi;
-        if (!(emin > 0.0) || !(emax >= emin))
-            return fail(PIB_ERR_SUP,
-                        "solver %s: the matrix is not strictly diagonally dominant (Gershgorin interval [%g, %g]): give the Chebyshev "
-                        "iteration its bounds (-%s_ksp_chebyshev_eigenvalues emin,emax / cheby_min_lambda, cheby_max_lambda)",
-                        s->name.c_str(), emin, emax, s->name.c_str());
-    }
-    const double scale = 2.0 / (emax + emin), alpha = 1.0 - scale * emin;
-    if (!(alpha > 0.0)) return fail(PIB_ERR_ARG_OUTOFRANGE, "solver %s: Chebyshev bounds with emin = emax", s->name.c_str());
-    const double mu = 1.0 / alpha, omegaprod = 2.0 / alpha;
-    PIB_CHK(ensure_work(s, 3));
-    double *P0 = s->vec(0), *P1 = s->vec(1), *Wv = s->vec(2);
-    const bool guess = s->cfg.initial_guess_nonzero;
-    const int monitor = s->cfg.monitor_residual ? 1 : 0;
-    const int conv_is_its = monitor ? 0 : 1;
-    const bool v2 = aligned16(x) && aligned16(b);
-    const double *dv = jac ? A.dinv : nullptr;
-    for (int k = 0; k < 8; ++k) s->counters[k] = 0;
-    PIB_CHK(init_scalars(s));
-    int nb = 0;
-    if (guess) {
-        OpCopy cp{x, P0};
-        PIB_CHK(launch_vec(s, n, cp, v2, 0, nullptr, false, q));
-        PIB_CHK(matmult(s, P0, Wv, nullptr, false, q));
-    } else {
-        OpFill z0{P0, 0.0};
-        PIB_CHK(launch_vec(s, n, z0, true, 0, nullptr, false, q));
-    }
-    {
-        OpChebInit op{b, Wv, dv, P0, P1, opc, scale, guess ? 1 : 0};
-        PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, false, q));
-    }
-    PIB_CHK(finalize(s, 0, 2, nb, q));
-    hipLaunchKernelGGL(k_cheb_s_init, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, monitor, mu, omegaprod, scale);
-    PIB_HIP(hipGetLastError());
-    const unsigned fb = (unsigned)std::min<int64_t>(VGRID_MAX, std::max<int64_t>(1, (n + 255) / 256));
-    auto flush = [&](int if_done) { hipLaunchKernelGGL(k_cheb_flush, dim3(fb), dim3(256), 0, q, s->d_s, n, P0, P1, x, if_done); };
-    // one loop pass: the residual of `in` and the update of `ot`
-    // the matrix-free velocity operator in its one-launch form applies the update behind the product (velstencil.hip:
-    // k_vel_product<2>): p[k] read once with its halos, b, 1 / a_ii and p[km1] read once, p[kp1] written -- five vector
-    // passes per iteration where BiCGStab's lean form moves 23 for two products
-    const bool fused = s->cfg.fuse_chebyshev_update && (s->comm.nranks == 1 || s->vel.slab_axis >= 0) && s->vel.valid &&
-                       s->cfg.matrix_free_velocity && vel_stencil_fused_ok(s) &&
-                       ((reinterpret_cast<uintptr_t>(P0) | reinterpret_cast<uintptr_t>(P1)) & 31u) == 0;
-    auto pass = [&](double *in, double *ot) -> int {
-        if (fused) {
-            if (s->comm.nranks > 1) PIB_CHK(halo_exchange(s, in, q));
-            PIB_CHK(vel_stencil_apply_cheb(s, in, ot, b, dv, opc, q, 0));
-            nb = VEL_DOT_PARTIALS;
-        } else {
-            PIB_CHK(matmult(s, in, Wv, nullptr, true, q));
-            OpChebStep op{b, Wv, dv, in, ot, opc, 0.0, 0.0, 0.0};
-            PIB_CHK(launch_vec(s, n, op, v2, 0, &nb, true, q));
-        }
-        PIB_CHK(finalize(s, 0, 2, nb, q));
-        hipLaunchKernelGGL(k_cheb_s_step, dim3(1), dim3(1), 0, q, s->d_s, s->d_hist, conv_is_its);
-        PIB_HIP(hipGetLastError());
-        return 0;
-    };
-    auto body = [&]() -> int {
-        PIB_CHK(pass(P1, P0));
-        return pass(P0, P1);
-    };
-    const int maxit = s->cfg.max_iters;  // passes 1 .. maxit - 1 and the closing residual: maxit of them
-    int enq = 0;
-    if (!skip_first_poll(s)) {
-        flush(1);
-        PIB_CHK(fetch_results(s, 0));
-        if (s->h_s->done) return 0;
-    }
-    const int batch0 = first_batch(s), batch1 = next_batch(s);
-    while (!s->h_s->done && enq < maxit) {
-        const int todo = (std::min(enq == 0 ? batch0 : batch1, maxit - enq) + 1) / 2;  // pairs
-        PIB_CHK(run_iterations(s, todo, enq / 2, graph_key(3, x, b), q, body));
-        const bool first = enq == 0;
-        enq += 2 * todo;
-        if (first) {
-            flush(1);
-            PIB_CHK(fetch_results(s, enq));
-            if (s->h_s->done) return 0;
-        } else
-            PIB_CHK(poll(s));
-    }
-    flush(0);
-    return fetch_results(s, enq);
-}
-
-}  // namespace pib
 
 // ------------------------------------------------------------ instrumentation
 extern "C" int pib_time_kernel(pib_solver *s, int which, int reps, double *ms_avg)
