@@ -179,7 +179,7 @@ int parse_config_file(const char *path, const std::string &name, Config &cfg);
 // return;` so over-enqueued iterations are no-ops.
 constexpr int PIB_MAX_RANKS = 64;  // ranks of one communicator (general halo plans, box <-> slab moves, the peer transport)
 constexpr int PIB_NRED = 8;       // reduction slots
-constexpr int PIB_MAXPART = 4096; // partial sums per slot (>= max blocks of a reduction)
+constexpr int PIB_MAXPART = 32768;  // partial sums per slot (>= the workgroups of any kernel that leaves partials: the fused marches of a 1024^3 level are 16384-18432; 4096 until round 6 sent 768^3 and up to the separate residual-update pass)
 struct Scalars {
     double red[PIB_NRED];  // finalized (and all-reduced) sums
     double beta, betaold, dpi, dpiold, dp, a, b;
