@@ -149,7 +149,8 @@ int pib_get_type(pib_solver *s, char *buf, int buflen);
 /* What this solver RUNS (pib_config_describe says what its file asks for): first line key=value pairs -- type, method, pc,
  * product (csr_int32_columns | csr_column_codes | csr_row_patterns | matrix_free_stencil | matrix_free_velocity), partition,
  * ranks, levels, smoother, presteps / poststeps (smoothing STEPS per level: a sweep of the file is a pair unless
- * pib_sweep_pairs=0), nullspace, structure, placement_searches --, then one "departure: ..." line for every place where the
+ * pib_sweep_pairs=0), nullspace, structure, residual_update (PCG + multigrid: in_vcycle when r -= alpha w rides in the cycle's first
+ * march, separate_pass when the system is too small or not tile-divisible for that), placement_searches --, then one "departure: ..." line for every place where the
  * backend departs from the file (CG -> BiCGStab for a non-symmetric DBNG, ...).  getType keeps the reference's two strings
  * (navierstokes.cpp:402-426 compares them); LinSolverBase::printInfo (include/petibm/linsolver.h:103) prints this text under
  * the reference's banner.  Valid at any time after pib_create; the product is "none" before setMatrix. */

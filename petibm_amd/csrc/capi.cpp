@@ -210,13 +210,19 @@ try {
     char line[1024];
     std::snprintf(line, sizeof line,
                   "type=\"%s\" method=%s pc=%s product=%s partition=%s ranks=%d levels=%d smoother=%s presteps=%d poststeps=%d "
-                  "nullspace=%s structure=%s placement_searches=%d",
+                  "nullspace=%s structure=%s residual_update=%s placement_searches=%d",
                   s->type_string.c_str(), method, pc, product,
                   s->redist.active ? "boxes_to_slabs" : (s->comm.nranks > 1 ? (s->A.general ? "general" : "slabs") : "single"), s->comm.nranks,
                   (int)in->levels.size(), cheb ? "chebyshev" : "jacobi", c.pc == Precond::GMG ? std::max(1, c.presweeps) * per : 0,
                   c.pc == Precond::GMG ? std::max(0, c.postsweeps) * per : 0,
                   in->nullspace == PIB_NULLSPACE_PINNED ? "pinned_row0" : (in->nullspace == PIB_NULLSPACE_CONSTANT ? "constant" : "none"),
-                  in->has_grid ? (in->structure_detected ? "recovered" : "given") : "none", in->placements);
+                  in->has_grid ? (in->structure_detected ? "recovered" : "given") : "none",
+                  // PCG + multigrid: does r -= alpha w ride in the V-cycle's first march (gmg_fused_update_ok: large systems whose level 0
+                  // the fused marches serve), or run as a pass of its own (48 B/row/iteration more)
+                  (c.method == Method::CG && !c.cg_single_reduction && c.pc == Precond::GMG && in->has_matrix)
+                      ? ((c.fuse_residual_update != 0 && c.fuse_residual_update != 2 && gmg_fused_update_ok(in)) ? "in_vcycle" : "separate_pass")
+                      : "n/a",
+                  in->placements);
     out = line;
     if (c.pc == Precond::GMG && !cheb && c.sweep_pairs && (c.presweeps > 0 || c.postsweeps > 0))
         out += "\ndeparture: smoother: a sweep of the file runs as a fused pair of damped-Jacobi steps (pib_sweep_pairs=0: one step)";

@@ -149,6 +149,7 @@ def test_describe_says_what_runs(lin, capsys):
         lines = s.describe().splitlines()
         assert f"product={form}" in lines[0] and "structure=recovered" in lines[0] and "nullspace=constant" in lines[0]
         assert "presteps=2 poststeps=2" in lines[0] and "partition=single ranks=1" in lines[0]
+        assert "residual_update=separate_pass" in lines[0]  # (a system this small runs as a captured graph: no fused update)
         assert any(ln.startswith("departure: smoother: a sweep of the file runs as a fused pair") for ln in lines[1:])
         assert s.getType() == "NVIDIA AmgX"
         info = s.printInfo()
@@ -1042,6 +1043,7 @@ def test_residual_update_inside_the_vcycle_is_bit_identical(lin, flavour, sweeps
         r = np.empty_like(xs)
         s.matMult(x, r)
         out.append((x, np.array(s.getResidualHistory()), s.getIters(), np.linalg.norm(b - r) / np.linalg.norm(b), int(s.counters()[6])))
+        assert ("residual_update=in_vcycle" if fuse == 1 else "residual_update=separate_pass") in s.describe().splitlines()[0]
         s.destroy()
     assert out[0][4] >= out[0][2] and out[1][4] == 0  # every (enqueued) iteration of the first run took the fused form, none of the second
     assert out[0][2] == out[1][2] and 5 <= out[0][2] <= 40
